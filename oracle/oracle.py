@@ -1,0 +1,155 @@
+"""ctypes front-end of the CPU oracle (``oracle/picaso_oracle.c``).  TEST INFRASTRUCTURE.
+
+Exposes the reference's Python signatures (``picaso/fluxes.py``, ``picaso/disco.py``) on top of the
+plain-C restatement so parity tests read like calls into the reference.  Only ``tests/``,
+``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import this module; the
+product package ``picaso_amd`` never does.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+_dp = ctypes.POINTER(ctypes.c_double)
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "libpicaso_oracle.so")
+    src = os.path.join(_HERE, "picaso_oracle.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B"])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = ctypes.CDLL(build())
+    return _LIB
+
+
+def _a(x, shape=None):
+    a = np.ascontiguousarray(x, dtype=np.float64)
+    if shape is not None:
+        a = np.ascontiguousarray(np.broadcast_to(a, shape))
+    return a
+
+
+def _p(a):
+    return a.ctypes.data_as(_dp) if a is not None else None
+
+
+def _per_wave(x, nwno):
+    """Scalar-or-array (reference accepts both) -> (nwno) array."""
+    return _a(np.zeros(nwno) + np.asarray(x, dtype=np.float64))
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise Exception("oracle %s failed with code %d" % (what, rc))
+
+
+def _reflected(variant, nlevel, nwno, numg, numt, planes, surf_reflect, ubar0, ubar1, cos_theta,
+               F0PI, single_phase, multi_phase, frac_a, frac_b, frac_c, constant_back,
+               constant_forward, get_toa_intensity, get_lvl_flux, toon_coefficients, b_top):
+    keep = [_a(p) for p in planes]
+    sr = _per_wave(surf_reflect, nwno)
+    f0 = _per_wave(F0PI, nwno)
+    u0, u1 = _a(ubar0), _a(ubar1)
+    xint = np.zeros((numg, numt, nwno))
+    lvl = [np.zeros((numg, numt, nlevel, nwno)) for _ in range(4)] if variant == 0 else [None] * 4
+    want_lvl = bool(get_lvl_flux) and variant == 0
+    rc = lib().orc_reflected(
+        ctypes.c_int(variant), ctypes.c_int(nlevel), ctypes.c_int(nwno), ctypes.c_int(numg),
+        ctypes.c_int(numt), *[_p(k) for k in keep], _p(sr), _p(u0), _p(u1),
+        ctypes.c_double(cos_theta), _p(f0), ctypes.c_int(single_phase), ctypes.c_int(multi_phase),
+        ctypes.c_double(frac_a), ctypes.c_double(frac_b), ctypes.c_double(frac_c),
+        ctypes.c_double(constant_back), ctypes.c_double(constant_forward),
+        ctypes.c_int(get_toa_intensity), ctypes.c_int(get_lvl_flux),
+        ctypes.c_int(toon_coefficients), ctypes.c_double(b_top), _p(xint),
+        *[_p(l) if want_lvl else None for l in lvl])
+    _check(rc, "reflected")
+    return xint, lvl
+
+
+def get_reflected_1d(nlevel, wno, nwno, numg, numt, dtau, tau, w0, cosb, gcos2, ftau_cld, ftau_ray,
+                     dtau_og, tau_og, w0_og, cosb_og, surf_reflect, ubar0, ubar1, cos_theta, F0PI,
+                     single_phase, multi_phase, frac_a, frac_b, frac_c, constant_back,
+                     constant_forward, get_toa_intensity=1, get_lvl_flux=0, toon_coefficients=0,
+                     b_top=0):
+    """Signature of reference ``fluxes.get_reflected_1d`` (fluxes.py:1010-1015)."""
+    xint, lvl = _reflected(0, nlevel, nwno, numg, numt,
+                           (dtau, tau, w0, cosb, gcos2, ftau_cld, ftau_ray, dtau_og, tau_og, w0_og,
+                            cosb_og), surf_reflect, ubar0, ubar1, cos_theta, F0PI, single_phase,
+                           multi_phase, frac_a, frac_b, frac_c, constant_back, constant_forward,
+                           get_toa_intensity, get_lvl_flux, toon_coefficients, b_top)
+    return xint, tuple(lvl)
+
+
+def get_reflected_3d(nlevel, wno, nwno, numg, numt, dtau_3d, tau_3d, w0_3d, cosb_3d, gcos2_3d,
+                     ftau_cld_3d, ftau_ray_3d, dtau_og_3d, tau_og_3d, w0_og_3d, cosb_og_3d,
+                     surf_reflect, ubar0, ubar1, cos_theta, F0PI, single_phase, multi_phase, frac_a,
+                     frac_b, frac_c, constant_back, constant_forward):
+    """Signature of reference ``fluxes.get_reflected_3d`` (fluxes.py:355-358)."""
+    xint, _ = _reflected(1, nlevel, nwno, numg, numt,
+                         (dtau_3d, tau_3d, w0_3d, cosb_3d, gcos2_3d, ftau_cld_3d, ftau_ray_3d,
+                          dtau_og_3d, tau_og_3d, w0_og_3d, cosb_og_3d), surf_reflect, ubar0, ubar1,
+                         cos_theta, F0PI, single_phase, multi_phase, frac_a, frac_b, frac_c,
+                         constant_back, constant_forward, 1, 0, 0, 0.0)
+    return xint
+
+
+def _thermal(variant, nlevel, wno, nwno, numg, numt, tlevel, dtau, w0, cosb, plevel, ubar1,
+             surf_reflect, hard_surface, dwno, calc_type):
+    wno_, tl, dt, w0_, cb, pl, u1 = (_a(wno), _a(tlevel), _a(dtau), _a(w0), _a(cosb), _a(plevel),
+                                     _a(ubar1))
+    sr = _per_wave(surf_reflect, nwno)
+    dw = _per_wave(dwno, nwno)
+    out = np.zeros((numg, numt, nwno))
+    lvl = [np.zeros((numg, numt, nlevel, nwno)) for _ in range(4)] if variant == 0 else [None] * 4
+    rc = lib().orc_thermal(
+        ctypes.c_int(variant), ctypes.c_int(nlevel), _p(wno_), ctypes.c_int(nwno),
+        ctypes.c_int(numg), ctypes.c_int(numt), _p(tl), _p(dt), _p(w0_), _p(cb), _p(pl), _p(u1),
+        _p(sr), ctypes.c_int(int(hard_surface)), _p(dw), ctypes.c_int(calc_type), _p(out),
+        *[_p(l) for l in lvl])
+    _check(rc, "thermal")
+    return out, lvl
+
+
+def get_thermal_1d(nlevel, wno, nwno, numg, numt, tlevel, dtau, w0, cosb, plevel, ubar1,
+                   surf_reflect, hard_surface, dwno, calc_type):
+    """Signature of reference ``fluxes.get_thermal_1d`` (fluxes.py:1683-1684)."""
+    out, lvl = _thermal(0, nlevel, wno, nwno, numg, numt, tlevel, dtau, w0, cosb, plevel, ubar1,
+                        surf_reflect, hard_surface, dwno, calc_type)
+    return out, tuple(lvl)
+
+
+def get_thermal_3d(nlevel, wno, nwno, numg, numt, tlevel_3d, dtau_3d, w0_3d, cosb_3d, plevel_3d,
+                   ubar1, surf_reflect, hard_surface):
+    """Signature of reference ``fluxes.get_thermal_3d`` (fluxes.py:2148-2149)."""
+    out, _ = _thermal(1, nlevel, wno, nwno, numg, numt, tlevel_3d, dtau_3d, w0_3d, cosb_3d,
+                      plevel_3d, ubar1, surf_reflect, hard_surface, 0.0, 0)
+    return out
+
+
+def compress_disco(nwno, cos_theta, xint_at_top, gweight, tweight, F0PI):
+    """Signature of reference ``disco.compress_disco`` (disco.py:118)."""
+    x, gw, tw = _a(xint_at_top), _a(gweight), _a(tweight)
+    f0 = _per_wave(F0PI, nwno)
+    out = np.zeros(nwno)
+    lib().orc_compress_disco(ctypes.c_int(nwno), ctypes.c_double(cos_theta), _p(x), _p(gw),
+                             ctypes.c_int(len(gw)), _p(tw), ctypes.c_int(len(tw)), _p(f0), _p(out))
+    return out
+
+
+def compress_thermal(nwno, flux_at_top, gweight, tweight):
+    """Signature of reference ``disco.compress_thermal`` (disco.py:152); 3-D or 4-D input."""
+    x, gw, tw = _a(flux_at_top), _a(gweight), _a(tweight)
+    inner = x.shape[2:]
+    out = np.zeros(inner)
+    lib().orc_compress_thermal(ctypes.c_size_t(int(np.prod(inner))), _p(x), _p(gw),
+                               ctypes.c_int(len(gw)), _p(tw), ctypes.c_int(len(tw)), _p(out))
+    return out

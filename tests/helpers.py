@@ -1,0 +1,79 @@
+"""Shared helpers for the parity tests: golden-fixture access and error metrics."""
+import glob
+import os
+
+import numpy as np
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+PLANES = ("dtau", "tau", "w0", "cosb", "gcos2", "ftau_cld", "ftau_ray", "dtau_og", "tau_og",
+          "w0_og", "cosb_og")
+
+
+def golden_files(prefix):
+    return sorted(glob.glob(os.path.join(GOLDEN, prefix + "*.npz")))
+
+
+def scene_id(path):
+    return os.path.basename(path)[:-4]
+
+
+class Golden:
+    def __init__(self, path):
+        self.z = np.load(path)
+        self.keys = list(self.z.keys())
+
+    def __getitem__(self, k):
+        return self.z[k]
+
+    def inp(self, k):
+        return self.z["in/" + k]
+
+    def geo(self, k):
+        v = self.z["geo/" + k]
+        return v if v.ndim else v.item()
+
+    def opt(self, k):
+        return float(self.z["opt/" + k])
+
+    def cases(self, family):
+        """Unique case keys 'family/<case>' present in the file."""
+        out = []
+        for k in self.keys:
+            parts = k.split("/")
+            if parts[0] == family and parts[1] not in out:
+                out.append(parts[1])
+        return out
+
+    def tthg(self):
+        return tuple(self.opt(k) for k in ("frac_a", "frac_b", "frac_c", "constant_back",
+                                           "constant_forward"))
+
+
+def rel_err(got, ref, floor=0.0):
+    """max |got-ref| / max(|ref|, floor); floor lets cancellation-dominated entries be judged
+    against the scale of the field instead of their own tiny magnitude."""
+    got, ref = np.asarray(got), np.asarray(ref)
+    den = np.maximum(np.abs(ref), floor)
+    den = np.where(den == 0, 1.0, den)
+    return float(np.max(np.abs(got - ref) / den))
+
+
+def scale_err(got, ref):
+    """max |got-ref| relative to the per-wavelength scale (max over leading axes)."""
+    got, ref = np.asarray(got), np.asarray(ref)
+    lead = tuple(range(ref.ndim - 1))
+    scale = np.max(np.abs(ref), axis=lead, keepdims=True)
+    scale = np.where(scale == 0, 1.0, scale)
+    return float(np.max(np.abs(got - ref) / scale))
+
+
+def lvl_err(got4, ref4):
+    """Level-flux metric: max |got-ref| over the four (numg,numt,nlevel,nwno) arrays, relative to
+    the per-wavelength scale of the whole flux field (max over the four arrays, angles, levels).
+    The reference's downward-flux expressions cancel catastrophically in optically thin layers
+    (sigma1*(1-e) + sigma2*(mu*e + dtau - mu)), so tiny entries carry no relative precision even
+    between two runs of the reference with different libm."""
+    ref4 = [np.asarray(r) for r in ref4]
+    scale = np.max(np.stack([np.max(np.abs(r), axis=(0, 1, 2)) for r in ref4]), axis=0)
+    scale = np.where(scale == 0, 1.0, scale)
+    return max(float(np.max(np.abs(np.asarray(g) - r) / scale)) for g, r in zip(got4, ref4))

@@ -1,0 +1,88 @@
+"""Pin the CPU oracle (oracle/picaso_oracle.c) against golden vectors produced by the reference's
+own source (tests/golden/make_golden.py).  Tolerance: 1e-11 relative on intensities/fluxes at the
+top of the atmosphere (observed ~1e-13: libm-vs-numpy last-ulp differences only); level fluxes are
+judged against the per-wavelength field scale because the reference's own downward-flux expressions
+cancel catastrophically in thin layers."""
+import numpy as np
+import pytest
+
+from helpers import PLANES, Golden, golden_files, lvl_err, rel_err, scene_id
+
+TOL = 1e-11
+FILES_1D = golden_files("scene1d_")
+FILES_3D = golden_files("scene3d_")
+
+
+@pytest.mark.parametrize("path", FILES_1D, ids=scene_id)
+def test_reflected_1d(path, oracle):
+    g = Golden(path)
+    nlevel, nwno = g.inp("tau").shape
+    planes = [g.inp(k) for k in PLANES]
+    for case in g.cases("refl1d"):
+        sp, mp, tc, lvl = (int(s[-1]) for s in case.split("_"))
+        b_top = float(g["refl1d/%s/b_top" % case])
+        xint, lv = oracle.get_reflected_1d(
+            nlevel, g.inp("wno"), nwno, g.geo("numg"), g.geo("numt"), *planes,
+            g.inp("surf_reflect"), g.geo("ubar0"), g.geo("ubar1"), g.geo("cos_theta"),
+            g.inp("F0PI"), sp, mp, *g.tthg(), get_toa_intensity=1, get_lvl_flux=lvl,
+            toon_coefficients=tc, b_top=b_top)
+        assert rel_err(xint, g["refl1d/%s/xint" % case]) < TOL, case
+        if lvl:
+            ref4 = [g["refl1d/%s/%s" % (case, nm)] for nm in ("fm", "fp", "fmm", "fpm")]
+            assert lvl_err(lv, ref4) < TOL, case
+
+
+@pytest.mark.parametrize("path", FILES_1D, ids=scene_id)
+def test_thermal_1d(path, oracle):
+    g = Golden(path)
+    nlevel, nwno = g.inp("tau").shape
+    for case in g.cases("therm1d"):
+        hs, ct = (int(s[-1]) for s in case.split("_"))
+        rs = np.zeros(nwno) + g.inp("surf_reflect")
+        flux, lv = oracle.get_thermal_1d(nlevel, g.inp("wno"), nwno, g.geo("numg"), g.geo("numt"),
+                                         g.inp("tlevel"), g.inp("dtau_og"), g.inp("w0_no_raman"),
+                                         g.inp("cosb_og"), g.inp("plevel"), g.geo("ubar1"), rs, hs,
+                                         g["dwno"], ct)
+        assert rel_err(flux, g["therm1d/%s/flux" % case]) < TOL, case
+        if "therm1d/%s/fm" % case in g.keys:
+            ref4 = [g["therm1d/%s/%s" % (case, nm)] for nm in ("fm", "fp", "fmm", "fpm")]
+            assert lvl_err(lv, ref4) < TOL, case
+
+
+@pytest.mark.parametrize("path", FILES_1D + FILES_3D, ids=scene_id)
+def test_compress(path, oracle):
+    g = Golden(path)
+    nwno = g.inp("wno").shape[0]
+    fam = "refl1d" if "scene1d" in path else "refl3d"
+    key = "sp3_mp0_tc0_lvl0" if fam == "refl1d" else "sp0_mp0"
+    alb = oracle.compress_disco(nwno, g.geo("cos_theta"), g["%s/%s/xint" % (fam, key)],
+                                g.geo("gweight"), g.geo("tweight"), g.inp("F0PI"))
+    assert rel_err(alb, g["compress_disco/albedo"]) < 1e-13
+    tfam, tkey = ("therm1d", "hs0_ct0") if fam == "refl1d" else ("therm3d", "hs0")
+    fl = oracle.compress_thermal(nwno, g["%s/%s/flux" % (tfam, tkey)], g.geo("gweight"),
+                                 g.geo("tweight"))
+    assert rel_err(fl, g["compress_thermal/flux"]) < 1e-13
+    if fam == "refl1d":
+        fl4 = oracle.compress_thermal(nwno, g["therm1d/hs0_ct0/fp"], g.geo("gweight"),
+                                      g.geo("tweight"))
+        assert rel_err(fl4, g["compress_thermal/lvl_fp"]) < 1e-13
+
+
+@pytest.mark.parametrize("path", FILES_3D, ids=scene_id)
+def test_reflected_thermal_3d(path, oracle):
+    g = Golden(path)
+    nlevel, nwno = g.inp("tau").shape[:2]
+    planes = [g.inp(k) for k in PLANES]
+    for case in g.cases("refl3d"):
+        sp, mp = (int(s[-1]) for s in case.split("_"))
+        xint = oracle.get_reflected_3d(nlevel, g.inp("wno"), nwno, g.geo("numg"), g.geo("numt"),
+                                       *planes, g.inp("surf_reflect"), g.geo("ubar0"),
+                                       g.geo("ubar1"), g.geo("cos_theta"), g.inp("F0PI"), sp, mp,
+                                       *g.tthg())
+        assert rel_err(xint, g["refl3d/%s/xint" % case]) < TOL, case
+    for hs in (0, 1):
+        flux = oracle.get_thermal_3d(nlevel, g.inp("wno"), nwno, g.geo("numg"), g.geo("numt"),
+                                     g.inp("tlevel"), g.inp("dtau_og"), g.inp("w0_no_raman"),
+                                     g.inp("cosb_og"), g.inp("plevel"), g.geo("ubar1"),
+                                     g.inp("surf_reflect"), hs)
+        assert rel_err(flux, g["therm3d/hs%d/flux" % hs]) < TOL, hs
