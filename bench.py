@@ -1,0 +1,173 @@
+#!/usr/bin/env python
+"""Headline benchmark: spectra/s of a 1e5-wavelength x 90-layer Toon reflected-light spectrum
+(BASELINE.json configs[2]; 5 Gauss angles, TTHG_ray + N=2 + delta-Eddington, fused disk
+integration) with all input planes resident in HBM.
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one full spectrum per GPU (get_reflected_1d + compress_disco over the rank's
+wavelength shard).  N > 1 is weak scaling: the wavelength grid is N x 1e5 points, each rank owns
+a contiguous 1e5-point shard, and the albedo shards are collected with one RCCL all-gather
+inside the timed region.  Prints ONE JSON line (rank 0).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from picaso_amd import _lib, device, disco, resident  # noqa: E402
+from picaso_amd import synthetic as syn  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+TTHG = (1.0, -1.0, 2.0, -0.5, 1.0)   # frac_a, frac_b, frac_c, constant_back, constant_forward
+
+
+def algorithmic_bytes(nwno, nlayer, nang, with_albedo=True):
+    """9 layer planes + 2 level planes + F0PI + surf_reflect read once,
+    xint_at_top (+ albedo) written once."""
+    nlevel = nlayer + 1
+    return 8 * nwno * (9 * nlayer + 2 * nlevel + 2 + nang + (1 if with_albedo else 0))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--nwno", type=int, default=100000, help="wavelengths per GPU")
+    ap.add_argument("--nlayer", type=int, default=90)
+    ap.add_argument("--ngauss", type=int, default=5, help="disk Gauss angles (5..8)")
+    ap.add_argument("--cpu-sample", type=int, default=100000,
+                    help="wavelengths of the same workload timed on the CPU oracle (0 = skip)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+
+    dist = torch = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    ctx = _lib.context(local_rank)
+    nwno, nlayer, nlevel = args.nwno, args.nlayer, args.nlayer + 1
+    ng = args.ngauss
+    gang, gw, tang, tw = disco.get_angles_1d(ng)
+    ubar0, ubar1, _, _, _ = disco.compute_disco(ng, 1, gang, tang, 0.0)
+    cos_theta = 1.0     # symmetric 1-D geometry (reference justdoit.py:1532)
+
+    # ---- synthetic shard of the (world*nwno)-point grid, built on the host, uploaded once ----
+    scene = syn.make_scene(nlayer, nwno, seed=3 + 1000 * rank)
+    scene["F0PI"] = np.ones(nwno)
+    scene["surf_reflect"] = np.zeros(nwno)
+    d = resident.upload_scene(scene, resident.REFLECTED_PLANES + ("F0PI", "surf_reflect"), ctx=ctx)
+    xint = device.DeviceArray((ng, 1, nwno), ctx)
+    if world > 1:
+        alb_t = torch.empty(nwno, dtype=torch.float64, device="cuda")
+        full_t = torch.empty(world * nwno, dtype=torch.float64, device="cuda")
+        albedo = alb_t.data_ptr()
+    else:
+        alb_d = device.DeviceArray((nwno,), ctx)
+        albedo = alb_d
+
+    def step():
+        resident.reflected_1d(ctx, nlevel, nwno, ng, 1, d, d["surf_reflect"], ubar0, ubar1,
+                              cos_theta, d["F0PI"], 3, 0, *TTHG, xint, toon_coefficients=0,
+                              b_top=0.0, gweight=gw, tweight=tw, albedo=albedo)
+        if world > 1:
+            device.sync(ctx)                                  # our stream -> RCCL's stream
+            dist.all_gather_into_tensor(full_t, alb_t)        # RCCL over xGMI: the final spectrum
+
+    def barrier():
+        device.sync(ctx)
+        if world > 1:
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    device.timer_start(ctx)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    kernel_ms_total = device.timer_stop(ctx)                  # HIP events on the kernel's stream
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- parity + CPU baseline on rank 0 (outside the timed region) ----
+    out = None
+    if rank == 0:
+        alb_gpu = alb_t.cpu().numpy() if world > 1 else alb_d.to_host()
+        ms_per_step = 1e3 * elapsed / args.steps
+        value = world * args.steps / elapsed
+        nang = ng
+        abytes = algorithmic_bytes(nwno, nlayer, nang)
+        kernel_ms = kernel_ms_total / args.steps
+        achieved = abytes / (kernel_ms * 1e-3) / 1e9
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tfile):
+            try:
+                traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "spectra/sec (1e5 wave x 90 layer reflected)",
+            "value": value, "unit": "spectra/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[2]: Toon two-stream reflected light "
+                                   "(get_reflected_1d + compress_disco), TTHG_ray, N=2, "
+                                   "delta-Eddington, Rayleigh + cloud slab",
+                       "nwno_per_gpu": nwno, "nlayer": nlayer, "gauss_angles": ng,
+                       "sharding": "wavelength blocks, %d x %d" % (world, nwno),
+                       "collective": "rccl all_gather of albedo shards" if world > 1 else "none"},
+            "wavelength_layer_updates_per_s": value * nwno * nlayer,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "k_reflected_toa<%d,false>" % nang,
+                         "kernel_ms": kernel_ms, "algorithmic_bytes": abytes},
+        }
+        if world == 1 and args.cpu_sample > 0:
+            from oracle import oracle as orc
+            ns = min(args.cpu_sample, nwno)
+            sl = slice(0, ns)
+            planes = [np.ascontiguousarray(scene[k][:, sl]) for k in resident.REFLECTED_PLANES]
+            t1 = time.perf_counter()
+            xo, _ = orc.get_reflected_1d(nlevel, scene["wno"][sl], ns, ng, 1, *planes, 0.0, ubar0,
+                                         ubar1, cos_theta, np.ones(ns), 3, 0, *TTHG)
+            alb_cpu = orc.compress_disco(ns, cos_theta, xo, gw, tw, np.ones(ns))
+            cpu_s = time.perf_counter() - t1
+            err = float(np.max(np.abs(alb_gpu[sl] - alb_cpu) / np.abs(alb_cpu)))
+            out["cpu_baseline"] = {
+                "value": (ns / nwno) / cpu_s, "unit": "spectra/s", "cores": 1, "kind": "port",
+                "sample": "%d of %d wavelengths of the same scene, oracle/picaso_oracle.c "
+                          "(single-thread C restatement of the reference's serial numba path), "
+                          "%.1f s" % (ns, nwno, cpu_s),
+                "host_cores_available": len(os.sched_getaffinity(0))}
+            out["max_rel_err_vs_oracle"] = err
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,180 @@
+/*
+ * picaso_hip.h -- C ABI of the MI355X (gfx950) implementation of PICASO's per-wavelength
+ * radiative-transfer hot path.
+ *
+ * The reference (natashabatalha/picaso v4.0.1) is pure Python + numba; it has no FFI.  Its
+ * "operator interface" for this path is the set of Python function signatures that
+ * justdoit.picaso() calls (reference picaso/justdoit.py:243,260,275,337,365,492,510,530,567).
+ * Each entry point below replaces one of those functions and keeps its argument order and
+ * meaning; the ctypes binding that a maintainer adds on the reference side is shown in
+ * INTEGRATION.md and implemented in picaso_amd/_lib.py.
+ *
+ * Conventions
+ *  - All arrays are float64, C-contiguous, in the reference's own layout: planes are
+ *    (nlayer|nlevel, nwno) layer-major / wavelength-contiguous for 1-D and
+ *    (nlayer|nlevel, nwno, numg, numt) for 3-D (reference fluxes.py:1032-1047, :355-358).
+ *  - `surf_reflect` and `F0PI` are always (nwno) arrays (the Python shim broadcasts scalars).
+ *  - Functions without a suffix take HOST pointers, run synchronously (H2D, kernel, D2H) and own
+ *    no caller memory.  Functions ending in `_dev` take DEVICE pointers for every plane /
+ *    per-wavelength vector / output (geometry tables ubar0, ubar1, gweight, tweight, tlevel,
+ *    plevel stay host pointers: they are tiny), enqueue on the context's stream and return
+ *    without synchronising; `plane_pitch` is the element stride between consecutive layers
+ *    (== nwno for a dense plane, larger for a wavelength-shard view of a bigger plane).
+ *  - Return value 0 = ok; non-zero = error, message via picaso_last_error().
+ *  - NaN/inf propagate as in the reference (no clamping beyond the reference's own clips).
+ *  - One context per process and GPU; calls on one context are serialised by the caller.
+ */
+#ifndef PICASO_HIP_H
+#define PICASO_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct picaso_ctx picaso_ctx;
+
+/* ---- context / plumbing ------------------------------------------------------------------ */
+int picaso_device_count(int *count);
+int picaso_ctx_create(int device, picaso_ctx **out);
+void picaso_ctx_destroy(picaso_ctx *ctx);
+const char *picaso_last_error(const picaso_ctx *ctx); /* ctx may be NULL: last global error */
+const char *picaso_version(void);
+
+int picaso_dev_malloc(picaso_ctx *ctx, size_t bytes, void **dptr);
+int picaso_dev_free(picaso_ctx *ctx, void *dptr);
+int picaso_memcpy_h2d(picaso_ctx *ctx, void *dst, const void *src, size_t bytes);
+int picaso_memcpy_d2h(picaso_ctx *ctx, void *dst, const void *src, size_t bytes);
+int picaso_memcpy_d2d(picaso_ctx *ctx, void *dst, const void *src, size_t bytes);
+/* strided row copy: `height` rows of `width_bytes`, used to upload a wavelength shard
+ * [w0, w0+n) of an (nlayer, nwno) host plane */
+int picaso_memcpy_h2d_2d(picaso_ctx *ctx, void *dst, size_t dpitch_bytes, const void *src,
+                         size_t spitch_bytes, size_t width_bytes, size_t height);
+int picaso_memset(picaso_ctx *ctx, void *dst, int value, size_t bytes);
+int picaso_sync(picaso_ctx *ctx);
+/* HIP-event timing on the context's own stream (the stream every kernel here is launched on) */
+int picaso_timer_start(picaso_ctx *ctx);
+int picaso_timer_stop(picaso_ctx *ctx, float *elapsed_ms);
+/* raw hipStream_t of the context (for callers that interleave their own work, e.g. RCCL) */
+void *picaso_stream(picaso_ctx *ctx);
+
+/* ---- Toon89 two-stream reflected light ---------------------------------------------------- */
+/* replaces fluxes.get_reflected_1d (reference picaso/fluxes.py:1009-1413).
+ * Outputs: xint_at_top (numg,numt,nwno); the four level-flux arrays (numg,numt,nlevel,nwno) are
+ * written only when get_lvl_flux != 0 (pass NULL otherwise; the reference returns zeros). */
+int picaso_get_reflected_1d(picaso_ctx *ctx, int nlevel, const double *wno, int nwno, int numg,
+                            int numt, const double *dtau, const double *tau, const double *w0,
+                            const double *cosb, const double *gcos2, const double *ftau_cld,
+                            const double *ftau_ray, const double *dtau_og, const double *tau_og,
+                            const double *w0_og, const double *cosb_og, const double *surf_reflect,
+                            const double *ubar0, const double *ubar1, double cos_theta,
+                            const double *F0PI, int single_phase, int multi_phase, double frac_a,
+                            double frac_b, double frac_c, double constant_back,
+                            double constant_forward, int get_toa_intensity, int get_lvl_flux,
+                            int toon_coefficients, double b_top, double *xint_at_top,
+                            double *flux_minus_all, double *flux_plus_all,
+                            double *flux_minus_midpt_all, double *flux_plus_midpt_all);
+
+/* device-resident form of the above.  Optional fused disk integration
+ * (disco.compress_disco, reference picaso/disco.py:117-149): if `albedo` is non-NULL,
+ * gweight (numg) / tweight (numt) host tables are used to also write albedo (nwno). */
+int picaso_get_reflected_1d_dev(picaso_ctx *ctx, int nlevel, int nwno, long plane_pitch, int numg,
+                                int numt, const double *dtau, const double *tau, const double *w0,
+                                const double *cosb, const double *gcos2, const double *ftau_cld,
+                                const double *ftau_ray, const double *dtau_og,
+                                const double *tau_og, const double *w0_og, const double *cosb_og,
+                                const double *surf_reflect, const double *ubar0,
+                                const double *ubar1, double cos_theta, const double *F0PI,
+                                int single_phase, int multi_phase, double frac_a, double frac_b,
+                                double frac_c, double constant_back, double constant_forward,
+                                int get_toa_intensity, int get_lvl_flux, int toon_coefficients,
+                                double b_top, double *xint_at_top, double *flux_minus_all,
+                                double *flux_plus_all, double *flux_minus_midpt_all,
+                                double *flux_plus_midpt_all, const double *gweight,
+                                const double *tweight, double *albedo);
+
+/* replaces fluxes.get_reflected_3d (reference picaso/fluxes.py:354-660); planes are
+ * (nlayer|nlevel, nwno, numg, numt), output (numg,numt,nwno). */
+int picaso_get_reflected_3d(picaso_ctx *ctx, int nlevel, const double *wno, int nwno, int numg,
+                            int numt, const double *dtau_3d, const double *tau_3d,
+                            const double *w0_3d, const double *cosb_3d, const double *gcos2_3d,
+                            const double *ftau_cld_3d, const double *ftau_ray_3d,
+                            const double *dtau_og_3d, const double *tau_og_3d,
+                            const double *w0_og_3d, const double *cosb_og_3d,
+                            const double *surf_reflect, const double *ubar0, const double *ubar1,
+                            double cos_theta, const double *F0PI, int single_phase, int multi_phase,
+                            double frac_a, double frac_b, double frac_c, double constant_back,
+                            double constant_forward, double *xint_at_top);
+
+int picaso_get_reflected_3d_dev(picaso_ctx *ctx, int nlevel, int nwno, int numg, int numt,
+                                const double *dtau_3d, const double *tau_3d, const double *w0_3d,
+                                const double *cosb_3d, const double *gcos2_3d,
+                                const double *ftau_cld_3d, const double *ftau_ray_3d,
+                                const double *dtau_og_3d, const double *tau_og_3d,
+                                const double *w0_og_3d, const double *cosb_og_3d,
+                                const double *surf_reflect, const double *ubar0,
+                                const double *ubar1, double cos_theta, const double *F0PI,
+                                int single_phase, int multi_phase, double frac_a, double frac_b,
+                                double frac_c, double constant_back, double constant_forward,
+                                double *xint_at_top, const double *gweight, const double *tweight,
+                                double *albedo);
+
+/* ---- Toon89 two-stream thermal emission --------------------------------------------------- */
+/* replaces fluxes.get_thermal_1d (reference picaso/fluxes.py:1682-1912).
+ * Outputs: flux_at_top (numg,numt,nwno); the four (numg,numt,nlevel,nwno) arrays are written when
+ * non-NULL (the reference always fills them; pass NULL for a spectrum-only call). */
+int picaso_get_thermal_1d(picaso_ctx *ctx, int nlevel, const double *wno, int nwno, int numg,
+                          int numt, const double *tlevel, const double *dtau, const double *w0,
+                          const double *cosb, const double *plevel, const double *ubar1,
+                          const double *surf_reflect, int hard_surface, const double *dwno,
+                          int calc_type, double *flux_at_top, double *flux_minus,
+                          double *flux_plus, double *flux_minus_mdpt, double *flux_plus_mdpt);
+
+/* device-resident form; optional fused disco.compress_thermal (reference disco.py:151-181) into
+ * `flux_disk` (nwno) when non-NULL. */
+int picaso_get_thermal_1d_dev(picaso_ctx *ctx, int nlevel, const double *wno, int nwno,
+                              long plane_pitch, int numg, int numt, const double *tlevel,
+                              const double *dtau, const double *w0, const double *cosb,
+                              const double *plevel, const double *ubar1,
+                              const double *surf_reflect, int hard_surface, const double *dwno,
+                              int calc_type, double *flux_at_top, double *flux_minus,
+                              double *flux_plus, double *flux_minus_mdpt, double *flux_plus_mdpt,
+                              const double *gweight, const double *tweight, double *flux_disk);
+
+/* replaces fluxes.get_thermal_3d (reference picaso/fluxes.py:2147-2352); tlevel_3d / plevel_3d are
+ * (nlevel,numg,numt), planes (nlayer,nwno,numg,numt). */
+int picaso_get_thermal_3d(picaso_ctx *ctx, int nlevel, const double *wno, int nwno, int numg,
+                          int numt, const double *tlevel_3d, const double *dtau_3d,
+                          const double *w0_3d, const double *cosb_3d, const double *plevel_3d,
+                          const double *ubar1, const double *surf_reflect, int hard_surface,
+                          double *int_at_top);
+
+int picaso_get_thermal_3d_dev(picaso_ctx *ctx, int nlevel, const double *wno, int nwno, int numg,
+                              int numt, const double *tlevel_3d, const double *dtau_3d,
+                              const double *w0_3d, const double *cosb_3d, const double *plevel_3d,
+                              const double *ubar1, const double *surf_reflect, int hard_surface,
+                              double *int_at_top, const double *gweight, const double *tweight,
+                              double *flux_disk);
+
+/* ---- disk quadrature ----------------------------------------------------------------------- */
+/* replaces disco.compress_disco (reference picaso/disco.py:117-149) */
+int picaso_compress_disco(picaso_ctx *ctx, int nwno, double cos_theta, const double *xint_at_top,
+                          const double *gweight, int ng, const double *tweight, int nt,
+                          const double *F0PI, double *albedo);
+int picaso_compress_disco_dev(picaso_ctx *ctx, int nwno, double cos_theta,
+                              const double *xint_at_top, const double *gweight, int ng,
+                              const double *tweight, int nt, const double *F0PI, double *albedo);
+/* replaces disco.compress_thermal (reference picaso/disco.py:151-181); `ninner` = nwno for a
+ * (ng,nt,nwno) input or nlevel*nwno for a (ng,nt,nlevel,nwno) input */
+int picaso_compress_thermal(picaso_ctx *ctx, size_t ninner, const double *flux_at_top,
+                            const double *gweight, int ng, const double *tweight, int nt,
+                            double *flux);
+int picaso_compress_thermal_dev(picaso_ctx *ctx, size_t ninner, const double *flux_at_top,
+                                const double *gweight, int ng, const double *tweight, int nt,
+                                double *flux);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PICASO_HIP_H */

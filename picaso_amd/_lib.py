@@ -1,0 +1,97 @@
+"""ctypes binding of the C ABI declared in ``include/picaso_hip.h``.
+
+The HIP library is the product: if ``libpicaso_hip.so`` is missing, or no MI355X is visible when
+a compute entry point is called, this module raises -- there is no CPU fallback.
+"""
+import ctypes
+import os
+import re
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpicaso_hip.so")
+HEADER = os.path.join(os.path.dirname(_HERE), "include", "picaso_hip.h")
+
+c_double_p = ctypes.POINTER(ctypes.c_double)
+_lib = None
+_ctx = {}
+
+
+class PicasoHipError(Exception):
+    pass
+
+
+def declared_symbols():
+    """Every function name include/picaso_hip.h declares."""
+    with open(HEADER) as fh:
+        text = fh.read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(picaso_[a-z0-9_]+)\s*\(", text)))
+
+
+def load():
+    """Load the shared library (no GPU needed for this step)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PicasoHipError(
+            "picaso_amd: %s not found -- build it with `python -c 'import __graft_entry__ as g; "
+            "g.build()'` (hipcc, gfx950).  There is no CPU fallback." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.picaso_last_error.restype = ctypes.c_char_p
+    lib.picaso_last_error.argtypes = [ctypes.c_void_p]
+    lib.picaso_version.restype = ctypes.c_char_p
+    lib.picaso_stream.restype = ctypes.c_void_p
+    lib.picaso_stream.argtypes = [ctypes.c_void_p]
+    _lib = lib
+    return lib
+
+
+def check(rc, ctx=None):
+    if rc != 0:
+        msg = load().picaso_last_error(ctx)
+        raise PicasoHipError(msg.decode() if msg else "picaso_hip error %d" % rc)
+
+
+def device_count():
+    n = ctypes.c_int(0)
+    rc = load().picaso_device_count(ctypes.byref(n))
+    return n.value if rc == 0 else 0
+
+
+def context(device=None):
+    """Per-process, per-device context (lazy: safe to import before fork)."""
+    if device is None:
+        device = int(os.environ.get("PICASO_AMD_DEVICE", "0"))
+    key = (os.getpid(), device)
+    if key not in _ctx:
+        lib = load()
+        h = ctypes.c_void_p()
+        rc = lib.picaso_ctx_create(ctypes.c_int(device), ctypes.byref(h))
+        if rc != 0:
+            raise PicasoHipError("picaso_amd needs an MI355X (gfx950) GPU: %s"
+                                 % lib.picaso_last_error(None).decode())
+        _ctx[key] = h
+    return _ctx[key]
+
+
+def f64(x, shape=None):
+    a = np.ascontiguousarray(x, dtype=np.float64)
+    if shape is not None and a.shape != tuple(shape):
+        a = np.ascontiguousarray(np.broadcast_to(a, shape))
+    return a
+
+
+def ptr(a):
+    if a is None:
+        return None
+    if isinstance(a, np.ndarray):
+        return a.ctypes.data_as(c_double_p)
+    return ctypes.cast(ctypes.c_void_p(int(a)), c_double_p)   # raw device address
+
+
+def per_wave(x, nwno):
+    """Scalar-or-(nwno) array -> (nwno) float64 array (the reference accepts both)."""
+    return f64(np.zeros(nwno) + np.asarray(x, dtype=np.float64))

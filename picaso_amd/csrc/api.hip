@@ -1,0 +1,672 @@
+// Host side of the C ABI (include/picaso_hip.h): context, memory plumbing, argument marshalling.
+#include "common.hpp"
+
+#include <algorithm>
+#include <cmath>
+
+namespace pz {
+
+thread_local char g_err[512] = {0};
+
+int fail(picaso_ctx *ctx, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (ctx) snprintf(ctx->err, sizeof(ctx->err), "%s", buf);
+    snprintf(g_err, sizeof(g_err), "%s", buf);
+    return 1;
+}
+
+int arena_reset(picaso_ctx *ctx, size_t need)
+{
+    // host-pointer calls are synchronous: nothing from a previous call may still use the arena
+    PZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (need > ctx->arena_bytes) {
+        if (ctx->arena) PZ_HIP(ctx, hipFree(ctx->arena));
+        ctx->arena = nullptr;
+        ctx->arena_bytes = 0;
+        const size_t want = align_up(need + (need >> 3), 1u << 20);
+        PZ_HIP(ctx, hipMalloc((void **)&ctx->arena, want));
+        ctx->arena_bytes = want;
+    }
+    ctx->arena_used = 0;
+    return 0;
+}
+
+void *arena_take(picaso_ctx *ctx, size_t bytes)
+{
+    const size_t b = align_up(bytes);
+    if (ctx->arena_used + b > ctx->arena_bytes) return nullptr;
+    void *p = ctx->arena + ctx->arena_used;
+    ctx->arena_used += b;
+    return p;
+}
+
+int table_upload(picaso_ctx *ctx, const void *host, size_t bytes, const void **dev)
+{
+    if (bytes > picaso_ctx::SLOT_BYTES)
+        return fail(ctx, "geometry/profile table of %zu bytes exceeds the %zu-byte slot", bytes,
+                    picaso_ctx::SLOT_BYTES);
+    const int s = ctx->ring_next;
+    ctx->ring_next = (s + 1) % picaso_ctx::NSLOT;
+    if (ctx->ring_pending[s]) {
+        PZ_HIP(ctx, hipEventSynchronize(ctx->ring_ev[s]));
+        ctx->ring_pending[s] = false;
+    }
+    char *h = ctx->ring_h + (size_t)s * picaso_ctx::SLOT_BYTES;
+    char *d = ctx->ring_d + (size_t)s * picaso_ctx::SLOT_BYTES;
+    memcpy(h, host, bytes);
+    PZ_HIP(ctx, hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, ctx->stream));
+    PZ_HIP(ctx, hipEventRecord(ctx->ring_ev[s], ctx->stream));
+    ctx->ring_pending[s] = true;
+    *dev = d;
+    return 0;
+}
+
+// split `n` angles into ceil(n/MAX_ANGLES) nearly equal chunks
+static std::vector<int> angle_chunks(int n)
+{
+    const int k = (n + MAX_ANGLES - 1) / MAX_ANGLES;
+    std::vector<int> out;
+    int left = n;
+    for (int i = 0; i < k; ++i) {
+        const int c = (left + (k - i) - 1) / (k - i);
+        out.push_back(c);
+        left -= c;
+    }
+    return out;
+}
+
+static int check_phase_options(picaso_ctx *ctx, int single_phase, int multi_phase, int toon)
+{
+    // the reference raises UnboundLocalError for these; report cleanly instead
+    if (single_phase < 0 || single_phase > 3)
+        return fail(ctx, "single_phase must be 0..3 (cahoy, OTHG, TTHG, TTHG_ray), got %d", single_phase);
+    if (multi_phase < 0 || multi_phase > 1)
+        return fail(ctx, "multi_phase must be 0 (N=2) or 1 (N=1), got %d", multi_phase);
+    if (toon < 0 || toon > 1)
+        return fail(ctx, "toon_coefficients must be 0 (quadrature) or 1 (eddington), got %d", toon);
+    return 0;
+}
+
+}  // namespace pz
+
+using namespace pz;
+
+extern "C" {
+
+const char *picaso_version(void) { return "picaso_amd 0.1.0 (gfx950)"; }
+
+const char *picaso_last_error(const picaso_ctx *ctx) { return ctx ? ctx->err : g_err; }
+
+int picaso_device_count(int *count)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *count = 0;
+        return fail(nullptr, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    }
+    *count = n;
+    return 0;
+}
+
+int picaso_ctx_create(int device, picaso_ctx **out)
+{
+    *out = nullptr;
+    int n = 0;
+    if (picaso_device_count(&n) != 0 || n == 0) return fail(nullptr, "no HIP device visible");
+    if (device < 0 || device >= n) return fail(nullptr, "device %d out of range (%d visible)", device, n);
+    picaso_ctx *ctx = new picaso_ctx();
+    ctx->device = device;
+    PZ_HIP(nullptr, hipSetDevice(device));
+    hipDeviceProp_t prop;
+    PZ_HIP(nullptr, hipGetDeviceProperties(&prop, device));
+    ctx->ncu = prop.multiProcessorCount;
+    PZ_HIP(nullptr, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    PZ_HIP(nullptr, hipEventCreate(&ctx->ev0));
+    PZ_HIP(nullptr, hipEventCreate(&ctx->ev1));
+    const size_t ring = picaso_ctx::SLOT_BYTES * picaso_ctx::NSLOT;
+    PZ_HIP(nullptr, hipHostMalloc((void **)&ctx->ring_h, ring, hipHostMallocDefault));
+    PZ_HIP(nullptr, hipMalloc((void **)&ctx->ring_d, ring));
+    for (int i = 0; i < picaso_ctx::NSLOT; ++i)
+        PZ_HIP(nullptr, hipEventCreateWithFlags(&ctx->ring_ev[i], hipEventDisableTiming));
+    *out = ctx;
+    return 0;
+}
+
+void picaso_ctx_destroy(picaso_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->arena) (void)hipFree(ctx->arena);
+    if (ctx->ring_d) (void)hipFree(ctx->ring_d);
+    if (ctx->ring_h) (void)hipHostFree(ctx->ring_h);
+    for (int i = 0; i < picaso_ctx::NSLOT; ++i)
+        if (ctx->ring_ev[i]) (void)hipEventDestroy(ctx->ring_ev[i]);
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int picaso_dev_malloc(picaso_ctx *ctx, size_t bytes, void **dptr)
+{
+    PZ_HIP(ctx, hipSetDevice(ctx->device));
+    PZ_HIP(ctx, hipMalloc(dptr, bytes ? bytes : 8));
+    return 0;
+}
+int picaso_dev_free(picaso_ctx *ctx, void *dptr)
+{
+    PZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    PZ_HIP(ctx, hipFree(dptr));
+    return 0;
+}
+int picaso_memcpy_h2d(picaso_ctx *ctx, void *dst, const void *src, size_t bytes)
+{
+    PZ_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    PZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+int picaso_memcpy_d2h(picaso_ctx *ctx, void *dst, const void *src, size_t bytes)
+{
+    PZ_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    PZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+int picaso_memcpy_d2d(picaso_ctx *ctx, void *dst, const void *src, size_t bytes)
+{
+    PZ_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    return 0;
+}
+int picaso_memcpy_h2d_2d(picaso_ctx *ctx, void *dst, size_t dpitch, const void *src, size_t spitch,
+                         size_t width, size_t height)
+{
+    PZ_HIP(ctx, hipMemcpy2DAsync(dst, dpitch, src, spitch, width, height, hipMemcpyHostToDevice,
+                                 ctx->stream));
+    PZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+int picaso_memset(picaso_ctx *ctx, void *dst, int value, size_t bytes)
+{
+    PZ_HIP(ctx, hipMemsetAsync(dst, value, bytes, ctx->stream));
+    return 0;
+}
+int picaso_sync(picaso_ctx *ctx)
+{
+    PZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+int picaso_timer_start(picaso_ctx *ctx)
+{
+    PZ_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    return 0;
+}
+int picaso_timer_stop(picaso_ctx *ctx, float *ms)
+{
+    PZ_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    PZ_HIP(ctx, hipEventSynchronize(ctx->ev1));
+    PZ_HIP(ctx, hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
+    return 0;
+}
+void *picaso_stream(picaso_ctx *ctx) { return (void *)ctx->stream; }
+
+/* ============================================================================================
+ * reflected light
+ * ============================================================================================ */
+int picaso_get_reflected_1d_dev(picaso_ctx *ctx, int nlevel, int nwno, long plane_pitch, int numg,
+                                int numt, const double *dtau, const double *tau, const double *w0,
+                                const double *cosb, const double *gcos2, const double *ftau_cld,
+                                const double *ftau_ray, const double *dtau_og,
+                                const double *tau_og, const double *w0_og, const double *cosb_og,
+                                const double *surf_reflect, const double *ubar0,
+                                const double *ubar1, double cos_theta, const double *F0PI,
+                                int single_phase, int multi_phase, double frac_a, double frac_b,
+                                double frac_c, double constant_back, double constant_forward,
+                                int get_toa_intensity, int get_lvl_flux, int toon_coefficients,
+                                double b_top, double *xint_at_top, double *flux_minus_all,
+                                double *flux_plus_all, double *flux_minus_midpt_all,
+                                double *flux_plus_midpt_all, const double *gweight,
+                                const double *tweight, double *albedo)
+{
+    if (!ctx) return fail(nullptr, "null context");
+    if (nlevel < 2 || nwno < 1 || numg < 1 || numt < 1)
+        return fail(ctx, "get_reflected_1d: bad sizes nlevel=%d nwno=%d numg=%d numt=%d", nlevel, nwno, numg, numt);
+    if (plane_pitch < nwno) return fail(ctx, "get_reflected_1d: plane_pitch %ld < nwno %d", plane_pitch, nwno);
+    PZ_TRY(check_phase_options(ctx, single_phase, multi_phase, toon_coefficients));
+    PZ_HIP(ctx, hipSetDevice(ctx->device));
+    const int nang = numg * numt;
+    if (get_lvl_flux) {
+        if (!flux_minus_all || !flux_plus_all || !flux_minus_midpt_all || !flux_plus_midpt_all)
+            return fail(ctx, "get_reflected_1d: get_lvl_flux=1 needs the four level-flux outputs");
+        return fail(ctx, "get_reflected_1d: level fluxes (get_lvl_flux=1) are not built yet");
+    }
+    if (!get_toa_intensity) {   // reference returns zeros (fluxes.py:1113, 1262)
+        PZ_HIP(ctx, hipMemsetAsync(xint_at_top, 0, sizeof(double) * (size_t)nang * nwno, ctx->stream));
+        if (albedo) PZ_HIP(ctx, hipMemsetAsync(albedo, 0, sizeof(double) * nwno, ctx->stream));
+        return 0;
+    }
+    ReflectedArgs a{};
+    a.nlayer = nlevel - 1;
+    a.ncol = nwno;
+    a.pitch = plane_pitch;
+    a.nfac = 1;
+    a.nwno = nwno;
+    a.dtau = dtau; a.tau = tau; a.w0 = w0; a.cosb = cosb; a.gcos2 = gcos2; a.ftau_cld = ftau_cld;
+    a.ftau_ray = ftau_ray; a.dtau_og = dtau_og; a.tau_og = tau_og; a.w0_og = w0_og; a.cosb_og = cosb_og;
+    a.surf_reflect = surf_reflect; a.F0PI = F0PI; a.cos_theta = cos_theta;
+    a.single_phase = single_phase; a.multi_phase = multi_phase; a.toon_coefficients = toon_coefficients;
+    a.frac_a = frac_a; a.frac_b = frac_b; a.frac_c = frac_c; a.constant_back = constant_back;
+    a.constant_forward = constant_forward; a.b_top = b_top;
+    const bool fuse = albedo && gweight && tweight;
+    a.albedo = fuse ? albedo : nullptr;
+    a.albedo_scale = ((numt == 1) ? 2.0 * 3.14159265358979323846 : 1.0) * 0.5;   // disco.py:140-141
+    int done = 0;
+    const auto chunks = angle_chunks(nang);
+    for (size_t c = 0; c < chunks.size(); ++c) {
+        a.na = chunks[c];
+        for (int k = 0; k < a.na; ++k) {
+            const int idx = done + k;
+            a.u0[k] = ubar0[idx];
+            a.u1[k] = ubar1[idx];
+            a.wgt[k] = fuse ? gweight[idx / numt] * tweight[idx % numt] : 0.0;
+        }
+        a.xint = xint_at_top + (size_t)done * nwno;
+        a.albedo_first = (c == 0);
+        a.albedo_last = (c + 1 == chunks.size());
+        PZ_TRY(launch_reflected_toa(ctx, a, false));
+        done += a.na;
+    }
+    return 0;
+}
+
+int picaso_get_reflected_1d(picaso_ctx *ctx, int nlevel, const double *wno, int nwno, int numg,
+                            int numt, const double *dtau, const double *tau, const double *w0,
+                            const double *cosb, const double *gcos2, const double *ftau_cld,
+                            const double *ftau_ray, const double *dtau_og, const double *tau_og,
+                            const double *w0_og, const double *cosb_og, const double *surf_reflect,
+                            const double *ubar0, const double *ubar1, double cos_theta,
+                            const double *F0PI, int single_phase, int multi_phase, double frac_a,
+                            double frac_b, double frac_c, double constant_back,
+                            double constant_forward, int get_toa_intensity, int get_lvl_flux,
+                            int toon_coefficients, double b_top, double *xint_at_top,
+                            double *flux_minus_all, double *flux_plus_all,
+                            double *flux_minus_midpt_all, double *flux_plus_midpt_all)
+{
+    (void)wno;   // accepted but never read, exactly like the reference
+    if (!ctx) return fail(nullptr, "null context");
+    if (nlevel < 2 || nwno < 1 || numg < 1 || numt < 1)
+        return fail(ctx, "get_reflected_1d: bad sizes nlevel=%d nwno=%d numg=%d numt=%d", nlevel, nwno, numg, numt);
+    PZ_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t nl = (size_t)(nlevel - 1) * nwno, nv = (size_t)nlevel * nwno;
+    const size_t nang = (size_t)numg * numt;
+    const size_t lvl_elems = get_lvl_flux ? 4 * nang * nv : 0;
+    const size_t need = sizeof(double) * (9 * nl + 2 * nv + 2 * (size_t)nwno + nang * nwno + lvl_elems) + 64 * 256;
+    PZ_TRY(arena_reset(ctx, need));
+    const double *d_dtau, *d_tau, *d_w0, *d_cosb, *d_gcos2, *d_fc, *d_fr, *d_dto, *d_tauo, *d_w0o, *d_cbo, *d_rs, *d_f0;
+    PZ_TRY(arena_upload(ctx, dtau, nl, &d_dtau));
+    PZ_TRY(arena_upload(ctx, tau, nv, &d_tau));
+    PZ_TRY(arena_upload(ctx, w0, nl, &d_w0));
+    PZ_TRY(arena_upload(ctx, cosb, nl, &d_cosb));
+    PZ_TRY(arena_upload(ctx, gcos2, nl, &d_gcos2));
+    PZ_TRY(arena_upload(ctx, ftau_cld, nl, &d_fc));
+    PZ_TRY(arena_upload(ctx, ftau_ray, nl, &d_fr));
+    PZ_TRY(arena_upload(ctx, dtau_og, nl, &d_dto));
+    PZ_TRY(arena_upload(ctx, tau_og, nv, &d_tauo));
+    PZ_TRY(arena_upload(ctx, w0_og, nl, &d_w0o));
+    PZ_TRY(arena_upload(ctx, cosb_og, nl, &d_cbo));
+    PZ_TRY(arena_upload(ctx, surf_reflect, (size_t)nwno, &d_rs));
+    PZ_TRY(arena_upload(ctx, F0PI, (size_t)nwno, &d_f0));
+    double *d_x = (double *)arena_take(ctx, sizeof(double) * nang * nwno);
+    double *d_lvl[4] = {nullptr, nullptr, nullptr, nullptr};
+    if (get_lvl_flux)
+        for (int j = 0; j < 4; ++j) d_lvl[j] = (double *)arena_take(ctx, sizeof(double) * nang * nv);
+    if (!d_x || (get_lvl_flux && !d_lvl[3])) return fail(ctx, "arena exhausted");
+    PZ_TRY(picaso_get_reflected_1d_dev(ctx, nlevel, nwno, nwno, numg, numt, d_dtau, d_tau, d_w0, d_cosb,
+                                       d_gcos2, d_fc, d_fr, d_dto, d_tauo, d_w0o, d_cbo, d_rs, ubar0, ubar1,
+                                       cos_theta, d_f0, single_phase, multi_phase, frac_a, frac_b, frac_c,
+                                       constant_back, constant_forward, get_toa_intensity, get_lvl_flux,
+                                       toon_coefficients, b_top, d_x, d_lvl[0], d_lvl[1], d_lvl[2], d_lvl[3],
+                                       nullptr, nullptr, nullptr));
+    PZ_HIP(ctx, hipMemcpyAsync(xint_at_top, d_x, sizeof(double) * nang * nwno, hipMemcpyDeviceToHost, ctx->stream));
+    if (get_lvl_flux) {
+        double *h[4] = {flux_minus_all, flux_plus_all, flux_minus_midpt_all, flux_plus_midpt_all};
+        for (int j = 0; j < 4; ++j)
+            PZ_HIP(ctx, hipMemcpyAsync(h[j], d_lvl[j], sizeof(double) * nang * nv, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    PZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int picaso_get_reflected_3d_dev(picaso_ctx *ctx, int nlevel, int nwno, int numg, int numt,
+                                const double *dtau_3d, const double *tau_3d, const double *w0_3d,
+                                const double *cosb_3d, const double *gcos2_3d,
+                                const double *ftau_cld_3d, const double *ftau_ray_3d,
+                                const double *dtau_og_3d, const double *tau_og_3d,
+                                const double *w0_og_3d, const double *cosb_og_3d,
+                                const double *surf_reflect, const double *ubar0,
+                                const double *ubar1, double cos_theta, const double *F0PI,
+                                int single_phase, int multi_phase, double frac_a, double frac_b,
+                                double frac_c, double constant_back, double constant_forward,
+                                double *xint_at_top, const double *gweight, const double *tweight,
+                                double *albedo)
+{
+    if (!ctx) return fail(nullptr, "null context");
+    if (nlevel < 2 || nwno < 1 || numg < 1 || numt < 1)
+        return fail(ctx, "get_reflected_3d: bad sizes nlevel=%d nwno=%d numg=%d numt=%d", nlevel, nwno, numg, numt);
+    PZ_TRY(check_phase_options(ctx, single_phase, multi_phase, 0));
+    PZ_HIP(ctx, hipSetDevice(ctx->device));
+    const int nfac = numg * numt;
+    std::vector<double> tab(2 * (size_t)nfac);
+    for (int i = 0; i < nfac; ++i) { tab[i] = ubar0[i]; tab[nfac + i] = ubar1[i]; }
+    const void *d_tab = nullptr;
+    PZ_TRY(table_upload(ctx, tab.data(), sizeof(double) * tab.size(), &d_tab));
+    ReflectedArgs a{};
+    a.nlayer = nlevel - 1;
+    a.ncol = (long)nwno * nfac;
+    a.pitch = a.ncol;
+    a.nfac = nfac;
+    a.nwno = nwno;
+    a.dtau = dtau_3d; a.tau = tau_3d; a.w0 = w0_3d; a.cosb = cosb_3d; a.gcos2 = gcos2_3d;
+    a.ftau_cld = ftau_cld_3d; a.ftau_ray = ftau_ray_3d; a.dtau_og = dtau_og_3d; a.tau_og = tau_og_3d;
+    a.w0_og = w0_og_3d; a.cosb_og = cosb_og_3d;
+    a.surf_reflect = surf_reflect; a.F0PI = F0PI; a.cos_theta = cos_theta;
+    a.single_phase = single_phase; a.multi_phase = multi_phase; a.toon_coefficients = 0;
+    a.frac_a = frac_a; a.frac_b = frac_b; a.frac_c = frac_c; a.constant_back = constant_back;
+    a.constant_forward = constant_forward; a.b_top = 0.0;
+    a.na = 1;
+    a.u0_tab = (const double *)d_tab;
+    a.u1_tab = (const double *)d_tab + nfac;
+    a.xint = xint_at_top;
+    a.albedo = nullptr;
+    PZ_TRY(launch_reflected_toa(ctx, a, true));
+    if (albedo && gweight && tweight)
+        PZ_TRY(picaso_compress_disco_dev(ctx, nwno, cos_theta, xint_at_top, gweight, numg, tweight, numt, F0PI, albedo));
+    return 0;
+}
+
+int picaso_get_reflected_3d(picaso_ctx *ctx, int nlevel, const double *wno, int nwno, int numg,
+                            int numt, const double *dtau_3d, const double *tau_3d,
+                            const double *w0_3d, const double *cosb_3d, const double *gcos2_3d,
+                            const double *ftau_cld_3d, const double *ftau_ray_3d,
+                            const double *dtau_og_3d, const double *tau_og_3d,
+                            const double *w0_og_3d, const double *cosb_og_3d,
+                            const double *surf_reflect, const double *ubar0, const double *ubar1,
+                            double cos_theta, const double *F0PI, int single_phase, int multi_phase,
+                            double frac_a, double frac_b, double frac_c, double constant_back,
+                            double constant_forward, double *xint_at_top)
+{
+    (void)wno;
+    if (!ctx) return fail(nullptr, "null context");
+    if (nlevel < 2 || nwno < 1 || numg < 1 || numt < 1)
+        return fail(ctx, "get_reflected_3d: bad sizes");
+    PZ_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t nfac = (size_t)numg * numt;
+    const size_t nl = (size_t)(nlevel - 1) * nwno * nfac, nv = (size_t)nlevel * nwno * nfac;
+    const size_t need = sizeof(double) * (9 * nl + 2 * nv + 2 * (size_t)nwno + nfac * nwno) + 64 * 256;
+    PZ_TRY(arena_reset(ctx, need));
+    const double *d[11], *d_rs, *d_f0;
+    const double *h[11] = {dtau_3d, tau_3d, w0_3d, cosb_3d, gcos2_3d, ftau_cld_3d, ftau_ray_3d,
+                           dtau_og_3d, tau_og_3d, w0_og_3d, cosb_og_3d};
+    for (int j = 0; j < 11; ++j) PZ_TRY(arena_upload(ctx, h[j], (j == 1 || j == 8) ? nv : nl, &d[j]));
+    PZ_TRY(arena_upload(ctx, surf_reflect, (size_t)nwno, &d_rs));
+    PZ_TRY(arena_upload(ctx, F0PI, (size_t)nwno, &d_f0));
+    double *d_x = (double *)arena_take(ctx, sizeof(double) * nfac * nwno);
+    if (!d_x) return fail(ctx, "arena exhausted");
+    PZ_TRY(picaso_get_reflected_3d_dev(ctx, nlevel, nwno, numg, numt, d[0], d[1], d[2], d[3], d[4], d[5], d[6],
+                                       d[7], d[8], d[9], d[10], d_rs, ubar0, ubar1, cos_theta, d_f0,
+                                       single_phase, multi_phase, frac_a, frac_b, frac_c, constant_back,
+                                       constant_forward, d_x, nullptr, nullptr, nullptr));
+    PZ_HIP(ctx, hipMemcpyAsync(xint_at_top, d_x, sizeof(double) * nfac * nwno, hipMemcpyDeviceToHost, ctx->stream));
+    PZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+/* ============================================================================================
+ * thermal emission
+ * ============================================================================================ */
+int picaso_get_thermal_1d_dev(picaso_ctx *ctx, int nlevel, const double *wno, int nwno,
+                              long plane_pitch, int numg, int numt, const double *tlevel,
+                              const double *dtau, const double *w0, const double *cosb,
+                              const double *plevel, const double *ubar1,
+                              const double *surf_reflect, int hard_surface, const double *dwno,
+                              int calc_type, double *flux_at_top, double *flux_minus,
+                              double *flux_plus, double *flux_minus_mdpt, double *flux_plus_mdpt,
+                              const double *gweight, const double *tweight, double *flux_disk)
+{
+    if (!ctx) return fail(nullptr, "null context");
+    if (nlevel < 2 || nwno < 1 || numg < 1 || numt < 1)
+        return fail(ctx, "get_thermal_1d: bad sizes nlevel=%d nwno=%d numg=%d numt=%d", nlevel, nwno, numg, numt);
+    if (plane_pitch < nwno) return fail(ctx, "get_thermal_1d: plane_pitch %ld < nwno %d", plane_pitch, nwno);
+    if (calc_type != 0 && calc_type != 1) return fail(ctx, "get_thermal_1d: calc_type must be 0 or 1");
+    if (calc_type == 1 && !dwno) return fail(ctx, "get_thermal_1d: calc_type=1 needs dwno");
+    if (flux_minus || flux_plus || flux_minus_mdpt || flux_plus_mdpt)
+        return fail(ctx, "get_thermal_1d: level fluxes are not built yet (pass NULL for a spectrum-only call)");
+    PZ_HIP(ctx, hipSetDevice(ctx->device));
+    const int nang = numg * numt;
+    std::vector<double> tab(2 * (size_t)nlevel);
+    for (int i = 0; i < nlevel; ++i) { tab[i] = tlevel[i]; tab[nlevel + i] = plevel[i]; }
+    const void *d_tab = nullptr;
+    PZ_TRY(table_upload(ctx, tab.data(), sizeof(double) * tab.size(), &d_tab));
+    ThermalArgs a{};
+    a.nlayer = nlevel - 1;
+    a.ncol = nwno;
+    a.pitch = plane_pitch;
+    a.nfac = 1;
+    a.nwno = nwno;
+    a.wno = wno; a.dwno = dwno;
+    a.tlevel = (const double *)d_tab; a.plevel = (const double *)d_tab + nlevel;
+    a.dtau = dtau; a.w0 = w0; a.cosb = cosb; a.surf_reflect = surf_reflect;
+    a.hard_surface = hard_surface; a.calc_type = calc_type;
+    const bool fuse = flux_disk && gweight && tweight;
+    a.disk = fuse ? flux_disk : nullptr;
+    a.disk_scale = (numt == 1) ? 1.0 : 1.0 / (2.0 * 3.14159265358979323846);   // disco.py:174-175
+    int done = 0;
+    const auto chunks = angle_chunks(nang);
+    for (size_t c = 0; c < chunks.size(); ++c) {
+        a.na = chunks[c];
+        for (int k = 0; k < a.na; ++k) {
+            const int idx = done + k;
+            a.u1[k] = ubar1[idx];
+            a.wgt[k] = fuse ? gweight[idx / numt] * tweight[idx % numt] : 0.0;
+        }
+        a.flux = flux_at_top + (size_t)done * nwno;
+        a.disk_first = (c == 0);
+        a.disk_last = (c + 1 == chunks.size());
+        PZ_TRY(launch_thermal_toa(ctx, a, false));
+        done += a.na;
+    }
+    return 0;
+}
+
+int picaso_get_thermal_1d(picaso_ctx *ctx, int nlevel, const double *wno, int nwno, int numg,
+                          int numt, const double *tlevel, const double *dtau, const double *w0,
+                          const double *cosb, const double *plevel, const double *ubar1,
+                          const double *surf_reflect, int hard_surface, const double *dwno,
+                          int calc_type, double *flux_at_top, double *flux_minus,
+                          double *flux_plus, double *flux_minus_mdpt, double *flux_plus_mdpt)
+{
+    if (!ctx) return fail(nullptr, "null context");
+    if (nlevel < 2 || nwno < 1 || numg < 1 || numt < 1) return fail(ctx, "get_thermal_1d: bad sizes");
+    PZ_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t nl = (size_t)(nlevel - 1) * nwno, nv = (size_t)nlevel * nwno;
+    const size_t nang = (size_t)numg * numt;
+    const bool lvl = flux_minus || flux_plus || flux_minus_mdpt || flux_plus_mdpt;
+    const size_t need = sizeof(double) * (3 * nl + 3 * (size_t)nwno + nang * nwno + (lvl ? 4 * nang * nv : 0)) + 64 * 256;
+    PZ_TRY(arena_reset(ctx, need));
+    const double *d_dtau, *d_w0, *d_cosb, *d_rs, *d_wno, *d_dwno = nullptr;
+    PZ_TRY(arena_upload(ctx, dtau, nl, &d_dtau));
+    PZ_TRY(arena_upload(ctx, w0, nl, &d_w0));
+    PZ_TRY(arena_upload(ctx, cosb, nl, &d_cosb));
+    PZ_TRY(arena_upload(ctx, surf_reflect, (size_t)nwno, &d_rs));
+    PZ_TRY(arena_upload(ctx, wno, (size_t)nwno, &d_wno));
+    if (dwno) PZ_TRY(arena_upload(ctx, dwno, (size_t)nwno, &d_dwno));
+    double *d_f = (double *)arena_take(ctx, sizeof(double) * nang * nwno);
+    double *d_lvl[4] = {nullptr, nullptr, nullptr, nullptr};
+    if (lvl)
+        for (int j = 0; j < 4; ++j) d_lvl[j] = (double *)arena_take(ctx, sizeof(double) * nang * nv);
+    if (!d_f || (lvl && !d_lvl[3])) return fail(ctx, "arena exhausted");
+    PZ_TRY(picaso_get_thermal_1d_dev(ctx, nlevel, d_wno, nwno, nwno, numg, numt, tlevel, d_dtau, d_w0, d_cosb,
+                                     plevel, ubar1, d_rs, hard_surface, d_dwno, calc_type, d_f, d_lvl[0],
+                                     d_lvl[1], d_lvl[2], d_lvl[3], nullptr, nullptr, nullptr));
+    PZ_HIP(ctx, hipMemcpyAsync(flux_at_top, d_f, sizeof(double) * nang * nwno, hipMemcpyDeviceToHost, ctx->stream));
+    if (lvl) {
+        double *h[4] = {flux_minus, flux_plus, flux_minus_mdpt, flux_plus_mdpt};
+        for (int j = 0; j < 4; ++j)
+            if (h[j]) PZ_HIP(ctx, hipMemcpyAsync(h[j], d_lvl[j], sizeof(double) * nang * nv, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    PZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int picaso_get_thermal_3d_dev(picaso_ctx *ctx, int nlevel, const double *wno, int nwno, int numg,
+                              int numt, const double *tlevel_3d, const double *dtau_3d,
+                              const double *w0_3d, const double *cosb_3d, const double *plevel_3d,
+                              const double *ubar1, const double *surf_reflect, int hard_surface,
+                              double *int_at_top, const double *gweight, const double *tweight,
+                              double *flux_disk)
+{
+    if (!ctx) return fail(nullptr, "null context");
+    if (nlevel < 2 || nwno < 1 || numg < 1 || numt < 1) return fail(ctx, "get_thermal_3d: bad sizes");
+    PZ_HIP(ctx, hipSetDevice(ctx->device));
+    const int nfac = numg * numt;
+    std::vector<double> tab((size_t)nfac * (2 * (size_t)nlevel + 1));
+    double *t_u1 = tab.data(), *t_T = t_u1 + nfac, *t_P = t_T + (size_t)nlevel * nfac;
+    for (int i = 0; i < nfac; ++i) t_u1[i] = ubar1[i];
+    for (size_t i = 0; i < (size_t)nlevel * nfac; ++i) { t_T[i] = tlevel_3d[i]; t_P[i] = plevel_3d[i]; }
+    const void *d_tab = nullptr;
+    PZ_TRY(table_upload(ctx, tab.data(), sizeof(double) * tab.size(), &d_tab));
+    ThermalArgs a{};
+    a.nlayer = nlevel - 1;
+    a.ncol = (long)nwno * nfac;
+    a.pitch = a.ncol;
+    a.nfac = nfac;
+    a.nwno = nwno;
+    a.wno = wno; a.dwno = nullptr;
+    a.u1_tab = (const double *)d_tab;
+    a.tlevel = a.u1_tab + nfac;
+    a.plevel = a.tlevel + (size_t)nlevel * nfac;
+    a.dtau = dtau_3d; a.w0 = w0_3d; a.cosb = cosb_3d; a.surf_reflect = surf_reflect;
+    a.hard_surface = hard_surface; a.calc_type = 0;
+    a.na = 1;
+    a.flux = int_at_top;
+    a.disk = nullptr;
+    PZ_TRY(launch_thermal_toa(ctx, a, true));
+    if (flux_disk && gweight && tweight)
+        PZ_TRY(picaso_compress_thermal_dev(ctx, (size_t)nwno, int_at_top, gweight, numg, tweight, numt, flux_disk));
+    return 0;
+}
+
+int picaso_get_thermal_3d(picaso_ctx *ctx, int nlevel, const double *wno, int nwno, int numg,
+                          int numt, const double *tlevel_3d, const double *dtau_3d,
+                          const double *w0_3d, const double *cosb_3d, const double *plevel_3d,
+                          const double *ubar1, const double *surf_reflect, int hard_surface,
+                          double *int_at_top)
+{
+    if (!ctx) return fail(nullptr, "null context");
+    if (nlevel < 2 || nwno < 1 || numg < 1 || numt < 1) return fail(ctx, "get_thermal_3d: bad sizes");
+    PZ_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t nfac = (size_t)numg * numt;
+    const size_t nl = (size_t)(nlevel - 1) * nwno * nfac;
+    const size_t need = sizeof(double) * (3 * nl + 2 * (size_t)nwno + nfac * nwno) + 64 * 256;
+    PZ_TRY(arena_reset(ctx, need));
+    const double *d_dtau, *d_w0, *d_cosb, *d_rs, *d_wno;
+    PZ_TRY(arena_upload(ctx, dtau_3d, nl, &d_dtau));
+    PZ_TRY(arena_upload(ctx, w0_3d, nl, &d_w0));
+    PZ_TRY(arena_upload(ctx, cosb_3d, nl, &d_cosb));
+    PZ_TRY(arena_upload(ctx, surf_reflect, (size_t)nwno, &d_rs));
+    PZ_TRY(arena_upload(ctx, wno, (size_t)nwno, &d_wno));
+    double *d_f = (double *)arena_take(ctx, sizeof(double) * nfac * nwno);
+    if (!d_f) return fail(ctx, "arena exhausted");
+    PZ_TRY(picaso_get_thermal_3d_dev(ctx, nlevel, d_wno, nwno, numg, numt, tlevel_3d, d_dtau, d_w0, d_cosb,
+                                     plevel_3d, ubar1, d_rs, hard_surface, d_f, nullptr, nullptr, nullptr));
+    PZ_HIP(ctx, hipMemcpyAsync(int_at_top, d_f, sizeof(double) * nfac * nwno, hipMemcpyDeviceToHost, ctx->stream));
+    PZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+/* ============================================================================================
+ * disk quadrature
+ * ============================================================================================ */
+static int upload_weights(picaso_ctx *ctx, const double *gweight, int ng, const double *tweight, int nt,
+                          const double **d_w)
+{
+    if (ng < 1 || nt < 1) return fail(ctx, "compress: empty weight table");
+    std::vector<double> wts(2 * (size_t)ng * nt);
+    for (int g = 0; g < ng; ++g)
+        for (int t = 0; t < nt; ++t) {
+            wts[2 * ((size_t)g * nt + t)] = gweight[g];
+            wts[2 * ((size_t)g * nt + t) + 1] = tweight[t];
+        }
+    const void *d = nullptr;
+    PZ_TRY(table_upload(ctx, wts.data(), sizeof(double) * wts.size(), &d));
+    *d_w = (const double *)d;
+    return 0;
+}
+
+int picaso_compress_disco_dev(picaso_ctx *ctx, int nwno, double cos_theta,
+                              const double *xint_at_top, const double *gweight, int ng,
+                              const double *tweight, int nt, const double *F0PI, double *albedo)
+{
+    if (!ctx) return fail(nullptr, "null context");
+    PZ_HIP(ctx, hipSetDevice(ctx->device));
+    const double *d_w = nullptr;
+    PZ_TRY(upload_weights(ctx, gweight, ng, tweight, nt, &d_w));
+    const double sym = (nt == 1) ? 2.0 * 3.14159265358979323846 : 1.0;      // disco.py:140-141
+    return launch_compress_dev(ctx, (size_t)nwno, xint_at_top, d_w, ng * nt, F0PI, sym * 0.5, cos_theta + 1.0, albedo);
+}
+
+int picaso_compress_disco(picaso_ctx *ctx, int nwno, double cos_theta, const double *xint_at_top,
+                          const double *gweight, int ng, const double *tweight, int nt,
+                          const double *F0PI, double *albedo)
+{
+    if (!ctx) return fail(nullptr, "null context");
+    PZ_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t nx = (size_t)ng * nt * nwno;
+    PZ_TRY(arena_reset(ctx, sizeof(double) * (nx + 2 * (size_t)nwno) + 16 * 256));
+    const double *d_x, *d_f0;
+    PZ_TRY(arena_upload(ctx, xint_at_top, nx, &d_x));
+    PZ_TRY(arena_upload(ctx, F0PI, (size_t)nwno, &d_f0));
+    double *d_o = (double *)arena_take(ctx, sizeof(double) * nwno);
+    if (!d_o) return fail(ctx, "arena exhausted");
+    PZ_TRY(picaso_compress_disco_dev(ctx, nwno, cos_theta, d_x, gweight, ng, tweight, nt, d_f0, d_o));
+    PZ_HIP(ctx, hipMemcpyAsync(albedo, d_o, sizeof(double) * nwno, hipMemcpyDeviceToHost, ctx->stream));
+    PZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int picaso_compress_thermal_dev(picaso_ctx *ctx, size_t ninner, const double *flux_at_top,
+                                const double *gweight, int ng, const double *tweight, int nt,
+                                double *flux)
+{
+    if (!ctx) return fail(nullptr, "null context");
+    PZ_HIP(ctx, hipSetDevice(ctx->device));
+    const double *d_w = nullptr;
+    PZ_TRY(upload_weights(ctx, gweight, ng, tweight, nt, &d_w));
+    const double sym = (nt == 1) ? 1.0 : 1.0 / (2.0 * 3.14159265358979323846);   // disco.py:174-175
+    return launch_compress_dev(ctx, ninner, flux_at_top, d_w, ng * nt, nullptr, sym, 0.0, flux);
+}
+
+int picaso_compress_thermal(picaso_ctx *ctx, size_t ninner, const double *flux_at_top,
+                            const double *gweight, int ng, const double *tweight, int nt,
+                            double *flux)
+{
+    if (!ctx) return fail(nullptr, "null context");
+    PZ_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t nx = (size_t)ng * nt * ninner;
+    PZ_TRY(arena_reset(ctx, sizeof(double) * (nx + ninner) + 16 * 256));
+    const double *d_x;
+    PZ_TRY(arena_upload(ctx, flux_at_top, nx, &d_x));
+    double *d_o = (double *)arena_take(ctx, sizeof(double) * ninner);
+    if (!d_o) return fail(ctx, "arena exhausted");
+    PZ_TRY(picaso_compress_thermal_dev(ctx, ninner, d_x, gweight, ng, tweight, nt, d_o));
+    PZ_HIP(ctx, hipMemcpyAsync(flux, d_o, sizeof(double) * ninner, hipMemcpyDeviceToHost, ctx->stream));
+    PZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,123 @@
+// Internal header shared by the gfx950 translation units (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "../../include/picaso_hip.h"
+
+struct picaso_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    char err[512] = {0};
+    int ncu = 256;
+    // staging arena for the host-pointer entry points (grown on demand, reused across calls)
+    char *arena = nullptr;
+    size_t arena_bytes = 0, arena_used = 0;
+    // ring of small pinned-host/device slots for geometry / profile tables handed over as host
+    // pointers by the *_dev entry points (which return before the stream has consumed them)
+    static constexpr int NSLOT = 8;
+    static constexpr size_t SLOT_BYTES = 1u << 20;
+    char *ring_h = nullptr, *ring_d = nullptr;
+    hipEvent_t ring_ev[NSLOT] = {};
+    bool ring_pending[NSLOT] = {};
+    int ring_next = 0;
+};
+
+namespace pz {
+
+extern thread_local char g_err[512];
+
+int fail(picaso_ctx *ctx, const char *fmt, ...);
+
+#define PZ_HIP(ctx, expr)                                                                    \
+    do {                                                                                     \
+        hipError_t e__ = (expr);                                                             \
+        if (e__ != hipSuccess)                                                               \
+            return pz::fail(ctx, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__),     \
+                            __FILE__, __LINE__);                                             \
+    } while (0)
+
+#define PZ_TRY(expr)              \
+    do {                          \
+        int rc__ = (expr);        \
+        if (rc__ != 0) return rc__; \
+    } while (0)
+
+// Bump allocator over the context arena: reset at the start of every host-pointer call.
+int arena_reset(picaso_ctx *ctx, size_t need_bytes);
+void *arena_take(picaso_ctx *ctx, size_t bytes);
+
+template <typename T>
+inline int arena_upload(picaso_ctx *ctx, const T *host, size_t count, const T **dev)
+{
+    T *d = static_cast<T *>(arena_take(ctx, count * sizeof(T)));
+    if (!d) return fail(ctx, "arena exhausted");
+    PZ_HIP(ctx, hipMemcpyAsync(d, host, count * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+    *dev = d;
+    return 0;
+}
+
+inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+
+// ---------------------------------------------------------------------------------------------
+// launchers implemented in the kernel translation units
+// ---------------------------------------------------------------------------------------------
+constexpr int MAX_ANGLES = 8;   // angles fused per launch (per-lane register state)
+
+struct ReflectedArgs {
+    int nlayer;
+    long ncol;          // columns: nwno (1-D) or nwno*nfac (3-D)
+    long pitch;         // elements between consecutive layers of a plane
+    int nfac;           // 1 for 1-D; numg*numt for 3-D (facet index fastest in memory)
+    int nwno;
+    const double *dtau, *tau, *w0, *cosb, *gcos2, *ftau_cld, *ftau_ray, *dtau_og, *tau_og, *w0_og,
+        *cosb_og;
+    const double *surf_reflect, *F0PI;      // (nwno)
+    double cos_theta;
+    int single_phase, multi_phase, toon_coefficients;
+    double frac_a, frac_b, frac_c, constant_back, constant_forward, b_top;
+    // 1-D: angles of this launch (shared planes).  3-D: device tables (nfac) of |ubar|.
+    int na;
+    double u0[MAX_ANGLES], u1[MAX_ANGLES];
+    double wgt[MAX_ANGLES];                 // gweight*tweight per angle (fused disk sum, 1-D)
+    const double *u0_tab, *u1_tab;          // 3-D
+    double *xint;                           // 1-D: this launch's first angle row, (na, nwno); 3-D: (nfac, nwno)
+    double *albedo;                         // nullable; 1-D fused compress_disco accumulator
+    double albedo_scale;                    // sym_fac*0.5*(cos_theta+1)
+    int albedo_first, albedo_last;          // first chunk initialises, last chunk finalises (/F0PI*scale)
+};
+int launch_reflected_toa(picaso_ctx *ctx, const ReflectedArgs &a, bool is3d);
+
+struct ReflectedLvlArgs;   // level-flux (two-sweep) variant, see toon_reflected_lvl.hip
+
+struct ThermalArgs {
+    int nlayer;
+    long ncol, pitch;
+    int nfac, nwno;
+    const double *wno, *dwno;               // (nwno)
+    const double *tlevel, *plevel;          // device: (nlevel) for 1-D, (nlevel,nfac) for 3-D
+    const double *dtau, *w0, *cosb;
+    const double *surf_reflect;
+    int hard_surface, calc_type;
+    int na;
+    double u1[MAX_ANGLES], wgt[MAX_ANGLES];
+    const double *u1_tab;                   // 3-D
+    double *flux;                           // (na,nwno) / (nfac,nwno)
+    double *disk;                           // nullable fused compress_thermal accumulator
+    double disk_scale;
+    int disk_first, disk_last;
+};
+int launch_thermal_toa(picaso_ctx *ctx, const ThermalArgs &a, bool is3d);
+
+int launch_compress_dev(picaso_ctx *ctx, size_t ninner, const double *x, const double *wts_dev,
+                        int nang, const double *F0PI, double c1, double c2, double *out);
+
+// copy a small host table into the next ring slot; *dev is valid for kernels enqueued afterwards
+int table_upload(picaso_ctx *ctx, const void *host, size_t bytes, const void **dev);
+
+}  // namespace pz

@@ -1,0 +1,212 @@
+// Toon89 two-stream thermal emission, top-of-atmosphere flux -- gfx950.
+//
+// Replaces fluxes.get_thermal_1d / get_thermal_3d (reference picaso/fluxes.py:1682-1912,
+// :2147-2352) for the spectrum path: flux_at_top = flux_plus_mdpt[:, :, 0, :] (fluxes.py:1910).
+//
+// Same lane mapping and the same single top-down sweep as toon_reflected.hip: the two-stream
+// system (hemispheric mean, linear-in-tau Planck source) has ONE right-hand side per wavelength,
+// so (rho, delta) are shared by all angles; only the TOA functional (kappa, zeta) is per angle.
+// The Planck function is evaluated on the fly per level (never materialised, fluxes.py:1752).
+// The upward source-function recursion (Toon Table 3, fluxes.py:1897-1907)
+//     F+[i] = F+[i+1] e_i + G_i/(lam mu - 1)(EP e - 1) + H_i/(lam mu + 1)(1 - EM e) + alpha terms,
+//     F+m[0] = F+[1] em_0 + G_0/(lam mu-1)(EP em - EPm) - H_0/(lam mu+1)(EM em - EMm) + alpha terms
+// is a linear functional of (pos_i, neg_i) with weights known top-down
+// (W_0 = 1 with the mid-point form for layer 0, W_i = em_0 * prod_{1<=j<i} e_j below).
+#include "common.hpp"
+#include "device_math.hpp"
+
+namespace pz {
+
+template <int NA, bool IS3D>
+__global__ __launch_bounds__(256) void k_thermal_toa(const ThermalArgs a)
+{
+    const long col = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (col >= a.ncol) return;
+    const int nfac = IS3D ? a.nfac : 1;
+    const long w = IS3D ? col / nfac : col;
+    const int fac = IS3D ? (int)(col - w * nfac) : 0;
+    const int n = a.nlayer;
+    const long pitch = a.pitch;
+    const double mu1 = 0.5;                                   // fluxes.py:1748
+    const double wn = a.wno[w];
+    const double dwn = (!IS3D && a.calc_type == 1) ? a.dwno[w] : 0.0;
+    const double rs = a.surf_reflect[w];
+    const bool integrated = (!IS3D && a.calc_type == 1);
+    const long lstride = IS3D ? nfac : 1;                     // tlevel_3d is (nlevel, ng, nt)
+    const double *tl = a.tlevel + fac, *pl = a.plevel + fac;
+
+    double u1[NA], iu1[NA];
+#pragma unroll
+    for (int k = 0; k < NA; ++k) {
+        u1[k] = IS3D ? a.u1_tab[fac] : a.u1[k];               // 3-D thermal takes ubar1 as is
+        iu1[k] = 1.0 / u1[k];
+    }
+    const double *p_dtau = a.dtau + col, *p_w0 = a.w0 + col, *p_cosb = a.cosb + col;
+
+    auto planck = [&](int l) {
+        const double t = tl[(long)l * lstride];
+        return integrated ? planck_integrated(t, wn, dwn) : planck_lambda(t, wn);
+    };
+
+    double W[NA], kappa[NA], zeta[NA];
+    double rho = 0.0, delta = 0.0, pgam = 0.0, pEM = 0.0, pcpd = 0.0, pcmd = 0.0, b1_last = 0.0;
+    double Bn = planck(0);
+    const double B_top = Bn;
+    double tau_top = 0.0;
+
+    double n_dt = p_dtau[0], n_w0 = p_w0[0], n_cb = p_cosb[0];
+    for (int i = 0; i < n; ++i) {
+        const double dt = n_dt, w0 = n_w0, g = n_cb;
+        if (i + 1 < n) {
+            const long o = (long)(i + 1) * pitch;
+            n_dt = p_dtau[o];
+            n_w0 = p_w0[o];
+            n_cb = p_cosb[o];
+        }
+        const double B0 = Bn;
+        Bn = planck(i + 1);
+        const double b1 = (Bn - B0) / dt;                      // fluxes.py:1757
+        const double g1 = 2.0 - w0 * (1 + g), g2 = w0 * (1 - g);   // fluxes.py:1760
+        const double lam = sqrt(g1 * g1 - g2 * g2);
+        const double gam = (g1 - lam) / g2;
+        const double s = 1.0 / (g1 + g2);                      // fluxes.py:1766
+        const double cpu = 2 * PI * mu1 * (B0 + b1 * s);       // fluxes.py:1772-1779
+        const double cmu = 2 * PI * mu1 * (B0 - b1 * s);
+        const double cpd = 2 * PI * mu1 * (B0 + b1 * dt + b1 * s);
+        const double cmd = 2 * PI * mu1 * (B0 + b1 * dt - b1 * s);
+        const double E = fmin(lam * dt, 35.0);                 // fluxes.py:1784-1786
+        const double EP = exp(E), EM = 1.0 / EP;
+        const double al1 = 2 * PI * (B0 + b1 * (s - mu1));     // fluxes.py:1846-1847
+        const double al2 = 2 * PI * b1;
+        const double gcoef = (1.0 / mu1 - lam);                // G = gcoef*pos   fluxes.py:1842
+        const double hcoef = gam * (lam + 1.0 / mu1);          // H = hcoef*neg   fluxes.py:1843
+
+        double rho_n = gam, delta_n = 0.0, sfac = 0.0, t = 0.0;
+        if (i == 0) {
+            tau_top = dt * pl[0] / (pl[lstride] - pl[0]);      // fluxes.py:1797
+            const double b_top = IS3D ? PI * (1.0 - exp(-tau_top / mu1)) * B_top   // :2253
+                                      : (1.0 - exp(-tau_top / mu1)) * B_top * PI;  // :1800
+            delta_n = b_top - cmu;
+        } else {
+            const double em2 = pEM * pEM;
+            const double a1 = 1.0 - pgam * em2 * rho;
+            const double a2 = pgam - em2 * rho;
+            const double inv = 1.0 / (a1 - gam * a2);
+            const double rP = (cpu - pcpd) - pgam * pEM * delta;
+            const double rM = (cmu - pcmd) - pEM * delta;
+            rho_n = (gam * a1 - a2) * inv;
+            delta_n = (a2 * rP - a1 * rM) * inv;
+            const double ia = pEM / a1;
+            sfac = (1.0 - gam * rho_n) * ia;
+            t = (gam * delta_n + rP) * ia;
+        }
+        const bool last = (i == n - 1);
+        double EPm = 0.0, EMm = 0.0;
+        if (i == 0) {
+            EPm = exp(0.5 * E);                                // fluxes.py:1856-1857
+            EMm = 1.0 / EPm;
+        }
+#pragma unroll
+        for (int k = 0; k < NA; ++k) {
+            const double mu = u1[k];
+            const double lp = gcoef / (lam * mu - 1.0), lm = hcoef / (lam * mu + 1.0);
+            if (i == 0) {
+                const double em = exp(-0.5 * dt * iu1[k]);     // fluxes.py:1878
+                const double vp = lp * (EP * em - EPm);        // fluxes.py:1903-1907
+                const double vn = -lm * (EM * em - EMm);
+                const double c0 = al1 * (1. - em) + al2 * (mu + 0.5 * dt - (dt + mu) * em);
+                kappa[k] = c0 + vn * delta_n;
+                zeta[k] = vp - vn * rho_n;
+                W[k] = em;
+            } else {
+                const double e = exp(-dt * iu1[k]);            // fluxes.py:1877
+                const double vp = W[k] * lp * (EP * e - 1.0);  // fluxes.py:1897-1901
+                const double vn = W[k] * lm * (1.0 - EM * e);
+                const double c0 = W[k] * (al1 * (1. - e) + al2 * (mu - (dt + mu) * e));
+                kappa[k] = kappa[k] + c0 + zeta[k] * t + vn * delta_n;
+                zeta[k] = zeta[k] * sfac + vp - vn * rho_n;
+                W[k] = W[k] * e;
+            }
+            if (last) {                                        // F+[n] boundary intensity
+                double fb;
+                if (!IS3D) {
+                    if (a.hard_surface) fb = (1.0 - rs) * Bn * 2 * PI;       // fluxes.py:1871
+                    else fb = (Bn + b1 * mu) * 2 * PI;                       // fluxes.py:1873
+                } else {
+                    if (a.hard_surface) fb = PI * (PI * Bn);                 // fluxes.py:2256,2310
+                    else fb = PI * (Bn + b1 * mu);                           // fluxes.py:2312
+                }
+                // for a single layer the boundary feeds the mid-point of layer 0 directly
+                kappa[k] += W[k] * fb;
+            }
+        }
+        rho = rho_n;
+        delta = delta_n;
+        pgam = gam;
+        pEM = EM;
+        pcpd = cpd;
+        pcmd = cmd;
+        b1_last = b1;
+    }
+    double b_surface;
+    if (!IS3D) {
+        if (a.hard_surface) b_surface = (1.0 - rs) * Bn * PI;               // fluxes.py:1803-1804
+        else b_surface = (Bn + b1_last * mu1) * PI;                         // fluxes.py:1806
+    } else {
+        if (a.hard_surface) b_surface = PI * Bn;                            // fluxes.py:2256
+        else b_surface = PI * (Bn + b1_last * mu1);                         // fluxes.py:2258
+    }
+    const double em2 = pEM * pEM;
+    const double pos = (pEM * (b_surface - pcpd + rs * pcmd) - em2 * (pgam - rs) * delta) /
+                       ((1.0 - rs * pgam) - em2 * (pgam - rs) * rho);
+    double disk = 0.0;
+#pragma unroll
+    for (int k = 0; k < NA; ++k) {
+        const double x = kappa[k] + zeta[k] * pos;
+        if (IS3D) a.flux[(long)fac * a.nwno + w] = x;
+        else a.flux[(long)k * a.nwno + w] = x;
+        disk = disk + x * a.wgt[k];
+    }
+    if (!IS3D && a.disk) {                                     // fused disco.compress_thermal
+        double acc = a.disk_first ? disk : a.disk[w] + disk;
+        if (a.disk_last) acc = acc * a.disk_scale;
+        a.disk[w] = acc;
+    }
+}
+
+template <int NA>
+static int launch1d(picaso_ctx *ctx, const ThermalArgs &a)
+{
+    const int block = 256;
+    const long grid = (a.ncol + block - 1) / block;
+    hipLaunchKernelGGL((k_thermal_toa<NA, false>), dim3((unsigned)grid), dim3(block), 0,
+                       ctx->stream, a);
+    PZ_HIP(ctx, hipGetLastError());
+    return 0;
+}
+
+int launch_thermal_toa(picaso_ctx *ctx, const ThermalArgs &a, bool is3d)
+{
+    if (a.ncol <= 0 || a.nlayer < 1) return fail(ctx, "thermal: empty problem");
+    if (is3d) {
+        const int block = 256;
+        const long grid = (a.ncol + block - 1) / block;
+        hipLaunchKernelGGL((k_thermal_toa<1, true>), dim3((unsigned)grid), dim3(block), 0,
+                           ctx->stream, a);
+        PZ_HIP(ctx, hipGetLastError());
+        return 0;
+    }
+    switch (a.na) {
+        case 1: return launch1d<1>(ctx, a);
+        case 2: return launch1d<2>(ctx, a);
+        case 3: return launch1d<3>(ctx, a);
+        case 4: return launch1d<4>(ctx, a);
+        case 5: return launch1d<5>(ctx, a);
+        case 6: return launch1d<6>(ctx, a);
+        case 7: return launch1d<7>(ctx, a);
+        case 8: return launch1d<8>(ctx, a);
+    }
+    return fail(ctx, "thermal: unsupported angle chunk %d", a.na);
+}
+
+}  // namespace pz

@@ -1,0 +1,79 @@
+"""Device-resident buffers for callers that keep planes in HBM across calls (bench, sharded runs)."""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+
+
+class DeviceArray:
+    """A float64 array living in HBM, owned by the library's context."""
+
+    def __init__(self, shape, ctx=None):
+        self.ctx = ctx if ctx is not None else _lib.context()
+        self.shape = tuple(int(s) for s in np.atleast_1d(shape))
+        self.size = int(np.prod(self.shape))
+        self.nbytes = self.size * 8
+        p = ctypes.c_void_p()
+        _lib.check(_lib.load().picaso_dev_malloc(self.ctx, ctypes.c_size_t(self.nbytes),
+                                                 ctypes.byref(p)), self.ctx)
+        self.addr = p.value
+
+    @classmethod
+    def from_host(cls, arr, ctx=None):
+        a = _lib.f64(arr)
+        d = cls(a.shape, ctx)
+        _lib.check(_lib.load().picaso_memcpy_h2d(d.ctx, ctypes.c_void_p(d.addr), _lib.ptr(a),
+                                                 ctypes.c_size_t(d.nbytes)), d.ctx)
+        return d
+
+    @classmethod
+    def from_host_columns(cls, arr, w_lo, w_hi, ctx=None):
+        """Upload the wavelength shard ``arr[..., w_lo:w_hi]`` of a (rows, nwno) plane."""
+        a = _lib.f64(arr)
+        rows, nwno = int(np.prod(a.shape[:-1])), a.shape[-1]
+        n = w_hi - w_lo
+        d = cls(a.shape[:-1] + (n,), ctx)
+        src = ctypes.c_void_p(a.ctypes.data + 8 * w_lo)
+        _lib.check(_lib.load().picaso_memcpy_h2d_2d(
+            d.ctx, ctypes.c_void_p(d.addr), ctypes.c_size_t(8 * n), src, ctypes.c_size_t(8 * nwno),
+            ctypes.c_size_t(8 * n), ctypes.c_size_t(rows)), d.ctx)
+        return d
+
+    def to_host(self):
+        out = np.empty(self.shape, dtype=np.float64)
+        _lib.check(_lib.load().picaso_memcpy_d2h(self.ctx, _lib.ptr(out), ctypes.c_void_p(self.addr),
+                                                 ctypes.c_size_t(self.nbytes)), self.ctx)
+        return out
+
+    def zero(self):
+        _lib.check(_lib.load().picaso_memset(self.ctx, ctypes.c_void_p(self.addr), 0,
+                                             ctypes.c_size_t(self.nbytes)), self.ctx)
+
+    def free(self):
+        if self.addr:
+            _lib.load().picaso_dev_free(self.ctx, ctypes.c_void_p(self.addr))
+            self.addr = 0
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def sync(ctx=None):
+    ctx = ctx if ctx is not None else _lib.context()
+    _lib.check(_lib.load().picaso_sync(ctx), ctx)
+
+
+def timer_start(ctx=None):
+    ctx = ctx if ctx is not None else _lib.context()
+    _lib.check(_lib.load().picaso_timer_start(ctx), ctx)
+
+
+def timer_stop(ctx=None):
+    ctx = ctx if ctx is not None else _lib.context()
+    ms = ctypes.c_float(0)
+    _lib.check(_lib.load().picaso_timer_stop(ctx, ctypes.byref(ms)), ctx)
+    return ms.value

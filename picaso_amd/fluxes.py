@@ -1,0 +1,108 @@
+"""Drop-in counterparts of the reference's radiative-transfer functions (``picaso/fluxes.py``).
+
+Same names, positional argument order, dtypes/shapes and return tuples as the reference; the
+arithmetic runs in the hand-written gfx950 kernels behind ``include/picaso_hip.h``.  Inputs may
+be numpy arrays (copied to HBM, result copied back) -- exactly how ``justdoit.picaso()`` calls the
+reference (reference picaso/justdoit.py:275-283, 337-342, 492, 510).  For HBM-resident planes use
+``picaso_amd.resident``.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from ._lib import check, context, f64, load, per_wave, ptr
+
+_ci, _cd = ctypes.c_int, ctypes.c_double
+
+
+def get_reflected_1d(nlevel, wno, nwno, numg, numt, dtau, tau, w0, cosb, gcos2, ftau_cld, ftau_ray,
+                     dtau_og, tau_og, w0_og, cosb_og, surf_reflect, ubar0, ubar1, cos_theta, F0PI,
+                     single_phase, multi_phase, frac_a, frac_b, frac_c, constant_back,
+                     constant_forward, get_toa_intensity=1, get_lvl_flux=0, toon_coefficients=0,
+                     b_top=0):
+    """Toon89 reflected light, 1-D (reference ``fluxes.get_reflected_1d``, fluxes.py:1009-1413).
+
+    Returns ``(xint_at_top (numg,numt,nwno), (flux_minus_all, flux_plus_all, flux_minus_midpt_all,
+    flux_plus_midpt_all))`` with the four ``(numg,numt,nlevel,nwno)`` arrays zero unless
+    ``get_lvl_flux`` (as in the reference).
+    """
+    ctx = context()
+    nlayer = nlevel - 1
+    planes = [f64(p) for p in (dtau, tau, w0, cosb, gcos2, ftau_cld, ftau_ray, dtau_og, tau_og,
+                               w0_og, cosb_og)]
+    for p, rows in zip(planes, (nlayer, nlevel, nlayer, nlayer, nlayer, nlayer, nlayer, nlayer,
+                                nlevel, nlayer, nlayer)):
+        if p.shape != (rows, nwno):
+            raise Exception("get_reflected_1d: plane of shape %s, expected %s" % (p.shape, (rows, nwno)))
+    rs, f0 = per_wave(surf_reflect, nwno), per_wave(F0PI, nwno)
+    u0, u1 = f64(ubar0, (numg, numt)), f64(ubar1, (numg, numt))
+    xint = np.zeros((numg, numt, nwno))
+    lvl = [np.zeros((numg, numt, nlevel, nwno)) for _ in range(4)]
+    check(load().picaso_get_reflected_1d(
+        ctx, _ci(nlevel), None, _ci(nwno), _ci(numg), _ci(numt), *[ptr(p) for p in planes],
+        ptr(rs), ptr(u0), ptr(u1), _cd(cos_theta), ptr(f0), _ci(int(single_phase)),
+        _ci(int(multi_phase)), _cd(frac_a), _cd(frac_b), _cd(frac_c), _cd(constant_back),
+        _cd(constant_forward), _ci(int(get_toa_intensity)), _ci(int(get_lvl_flux)),
+        _ci(int(toon_coefficients)), _cd(b_top), ptr(xint),
+        *[ptr(l) if get_lvl_flux else None for l in lvl]), ctx)
+    return xint, tuple(lvl)
+
+
+def get_reflected_3d(nlevel, wno, nwno, numg, numt, dtau_3d, tau_3d, w0_3d, cosb_3d, gcos2_3d,
+                     ftau_cld_3d, ftau_ray_3d, dtau_og_3d, tau_og_3d, w0_og_3d, cosb_og_3d,
+                     surf_reflect, ubar0, ubar1, cos_theta, F0PI, single_phase, multi_phase, frac_a,
+                     frac_b, frac_c, constant_back, constant_forward):
+    """Toon89 reflected light with per-facet planes ``(nlayer|nlevel, nwno, numg, numt)``
+    (reference ``fluxes.get_reflected_3d``, fluxes.py:354-660).  Returns ``xint_at_top``."""
+    ctx = context()
+    planes = [f64(p) for p in (dtau_3d, tau_3d, w0_3d, cosb_3d, gcos2_3d, ftau_cld_3d, ftau_ray_3d,
+                               dtau_og_3d, tau_og_3d, w0_og_3d, cosb_og_3d)]
+    rs, f0 = per_wave(surf_reflect, nwno), per_wave(F0PI, nwno)
+    u0, u1 = f64(ubar0, (numg, numt)), f64(ubar1, (numg, numt))
+    xint = np.zeros((numg, numt, nwno))
+    check(load().picaso_get_reflected_3d(
+        ctx, _ci(nlevel), None, _ci(nwno), _ci(numg), _ci(numt), *[ptr(p) for p in planes],
+        ptr(rs), ptr(u0), ptr(u1), _cd(cos_theta), ptr(f0), _ci(int(single_phase)),
+        _ci(int(multi_phase)), _cd(frac_a), _cd(frac_b), _cd(frac_c), _cd(constant_back),
+        _cd(constant_forward), ptr(xint)), ctx)
+    return xint
+
+
+def get_thermal_1d(nlevel, wno, nwno, numg, numt, tlevel, dtau, w0, cosb, plevel, ubar1,
+                   surf_reflect, hard_surface, dwno, calc_type, want_lvl=True):
+    """Toon89 thermal emission, 1-D (reference ``fluxes.get_thermal_1d``, fluxes.py:1682-1912).
+
+    Returns ``(flux_at_top, (flux_minus, flux_plus, flux_minus_mdpt, flux_plus_mdpt))``.  The
+    reference always fills the four ``(numg,numt,nlevel,nwno)`` arrays; ``want_lvl=False`` (what
+    this package's own ``picaso()`` passes for a spectrum) skips them and returns zeros there.
+    """
+    ctx = context()
+    wno_, tl, pl = f64(wno), f64(tlevel), f64(plevel)
+    dt, w0_, cb = f64(dtau), f64(w0), f64(cosb)
+    rs, dw = per_wave(surf_reflect, nwno), per_wave(dwno, nwno)
+    u1 = f64(ubar1, (numg, numt))
+    flux = np.zeros((numg, numt, nwno))
+    lvl = [np.zeros((numg, numt, nlevel, nwno)) for _ in range(4)]
+    check(load().picaso_get_thermal_1d(
+        ctx, _ci(nlevel), ptr(wno_), _ci(nwno), _ci(numg), _ci(numt), ptr(tl), ptr(dt), ptr(w0_),
+        ptr(cb), ptr(pl), ptr(u1), ptr(rs), _ci(int(hard_surface)), ptr(dw), _ci(int(calc_type)),
+        ptr(flux), *[ptr(l) if want_lvl else None for l in lvl]), ctx)
+    return flux, tuple(lvl)
+
+
+def get_thermal_3d(nlevel, wno, nwno, numg, numt, tlevel_3d, dtau_3d, w0_3d, cosb_3d, plevel_3d,
+                   ubar1, surf_reflect, hard_surface):
+    """Toon89 thermal emission with per-facet profiles (reference ``fluxes.get_thermal_3d``,
+    fluxes.py:2147-2352).  Returns ``int_at_top (numg,numt,nwno)``."""
+    ctx = context()
+    wno_ = f64(wno)
+    tl, pl = f64(tlevel_3d), f64(plevel_3d)
+    dt, w0_, cb = f64(dtau_3d), f64(w0_3d), f64(cosb_3d)
+    rs = per_wave(surf_reflect, nwno)
+    u1 = f64(ubar1, (numg, numt))
+    out = np.zeros((numg, numt, nwno))
+    check(load().picaso_get_thermal_3d(
+        ctx, _ci(nlevel), ptr(wno_), _ci(nwno), _ci(numg), _ci(numt), ptr(tl), ptr(dt), ptr(w0_),
+        ptr(cb), ptr(pl), ptr(u1), ptr(rs), _ci(int(hard_surface)), ptr(out)), ctx)
+    return out

@@ -1,0 +1,77 @@
+"""HBM-resident form of the hot path: planes stay on the GPU across calls.
+
+Used by ``bench.py``, by wavelength-sharded multi-GPU runs and by any caller that evaluates many
+geometries / options on the same atmosphere.  Thin wrappers over the ``*_dev`` entry points of
+``include/picaso_hip.h``; every plane argument is a ``DeviceArray`` (or a raw device address).
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from ._lib import check, f64, load, ptr
+from .device import DeviceArray
+
+_ci, _cd = ctypes.c_int, ctypes.c_double
+REFLECTED_PLANES = ("dtau", "tau", "w0", "cosb", "gcos2", "ftau_cld", "ftau_ray", "dtau_og",
+                    "tau_og", "w0_og", "cosb_og")
+
+
+def _addr(x):
+    if x is None:
+        return None
+    return ptr(x.addr if isinstance(x, DeviceArray) else x)
+
+
+def upload_scene(scene, keys, w_lo=None, w_hi=None, ctx=None):
+    """Upload the named (rows, nwno) planes / (nwno) vectors of a host scene dict, optionally only
+    the wavelength shard [w_lo, w_hi)."""
+    out = {}
+    for k in keys:
+        a = f64(scene[k])
+        if w_lo is None:
+            out[k] = DeviceArray.from_host(a, ctx)
+        elif a.ndim == 1:
+            out[k] = DeviceArray.from_host(a[w_lo:w_hi], ctx)
+        else:
+            out[k] = DeviceArray.from_host_columns(a, w_lo, w_hi, ctx)
+    return out
+
+
+def reflected_1d(ctx, nlevel, nwno, numg, numt, planes, surf_reflect, ubar0, ubar1, cos_theta,
+                 F0PI, single_phase, multi_phase, frac_a, frac_b, frac_c, constant_back,
+                 constant_forward, xint_at_top, toon_coefficients=0, b_top=0.0, gweight=None,
+                 tweight=None, albedo=None, plane_pitch=None):
+    """Asynchronous ``get_reflected_1d`` on resident planes (+ optional fused ``compress_disco``).
+    ``planes`` maps the 11 reference plane names to DeviceArrays; outputs are DeviceArrays (or raw
+    device addresses, e.g. ``torch_tensor.data_ptr()``)."""
+    u0, u1 = f64(ubar0, (numg, numt)), f64(ubar1, (numg, numt))
+    gw = f64(gweight) if gweight is not None else None
+    tw = f64(tweight) if tweight is not None else None
+    pitch = nwno if plane_pitch is None else plane_pitch
+    check(load().picaso_get_reflected_1d_dev(
+        ctx, _ci(nlevel), _ci(nwno), ctypes.c_long(pitch), _ci(numg), _ci(numt),
+        *[_addr(planes[k]) for k in REFLECTED_PLANES], _addr(surf_reflect), ptr(u0), ptr(u1),
+        _cd(cos_theta), _addr(F0PI), _ci(single_phase), _ci(multi_phase), _cd(frac_a), _cd(frac_b),
+        _cd(frac_c), _cd(constant_back), _cd(constant_forward), _ci(1), _ci(0),
+        _ci(toon_coefficients), _cd(b_top), _addr(xint_at_top), None, None, None, None,
+        ptr(gw) if gw is not None else None, ptr(tw) if tw is not None else None, _addr(albedo)),
+        ctx)
+
+
+def thermal_1d(ctx, nlevel, wno, nwno, numg, numt, tlevel, dtau, w0, cosb, plevel, ubar1,
+               surf_reflect, hard_surface, flux_at_top, dwno=None, calc_type=0, gweight=None,
+               tweight=None, flux_disk=None, plane_pitch=None):
+    """Asynchronous ``get_thermal_1d`` on resident planes (+ optional fused ``compress_thermal``).
+    ``wno``/``dwno``/``surf_reflect`` and the planes are device-resident; tlevel/plevel host."""
+    u1 = f64(ubar1, (numg, numt))
+    tl, pl = f64(tlevel), f64(plevel)
+    gw = f64(gweight) if gweight is not None else None
+    tw = f64(tweight) if tweight is not None else None
+    pitch = nwno if plane_pitch is None else plane_pitch
+    check(load().picaso_get_thermal_1d_dev(
+        ctx, _ci(nlevel), _addr(wno), _ci(nwno), ctypes.c_long(pitch), _ci(numg), _ci(numt),
+        ptr(tl), _addr(dtau), _addr(w0), _addr(cosb), ptr(pl), ptr(u1), _addr(surf_reflect),
+        _ci(int(hard_surface)), _addr(dwno), _ci(calc_type), _addr(flux_at_top), None, None, None,
+        None, ptr(gw) if gw is not None else None, ptr(tw) if tw is not None else None,
+        _addr(flux_disk)), ctx)
