@@ -12,6 +12,9 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-fast-math"
          "-Wall", "-Wno-unused-function"]
 
 
+FLAGS += os.environ.get("PICASO_HIPCC_EXTRA", "").split()
+
+
 def sources():
     return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
 

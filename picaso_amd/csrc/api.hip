@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 
 namespace pz {
 
@@ -69,7 +70,12 @@ int table_upload(picaso_ctx *ctx, const void *host, size_t bytes, const void **d
 // split `n` angles into ceil(n/MAX_ANGLES) nearly equal chunks
 static std::vector<int> angle_chunks(int n)
 {
-    const int k = (n + MAX_ANGLES - 1) / MAX_ANGLES;
+    int maxa = MAX_ANGLES;
+    if (const char *e = getenv("PICASO_AMD_MAX_ANGLES")) {   // tuning knob: angles fused per launch
+        const int v = atoi(e);
+        if (v >= 1 && v <= MAX_ANGLES) maxa = v;
+    }
+    const int k = (n + maxa - 1) / maxa;
     std::vector<int> out;
     int left = n;
     for (int i = 0; i < k; ++i) {

@@ -33,8 +33,14 @@
 
 namespace pz {
 
-template <int NA, bool IS3D>
-__global__ __launch_bounds__(256) void k_reflected_toa(const ReflectedArgs a)
+// ZP ("zero phase"): every angle of the launch has ubar0 == ubar1 (the symmetric 1-D geometry,
+// reference justdoit.py:1513-1532), so exp(-dtau (u0+u1)/(u0 u1)) = exp(-dtau/u1)^2 and the
+// u0-side constants coincide with the u1-side ones.
+#ifndef PZ_REFL_MINWAVES
+#define PZ_REFL_MINWAVES 1
+#endif
+template <int NA, bool IS3D, bool ZP>
+__global__ __launch_bounds__(256, PZ_REFL_MINWAVES) void k_reflected_toa(const ReflectedArgs a)
 {
     const long col = blockIdx.x * (long)blockDim.x + threadIdx.x;
     if (col >= a.ncol) return;
@@ -49,7 +55,7 @@ __global__ __launch_bounds__(256) void k_reflected_toa(const ReflectedArgs a)
     const int mp = a.multi_phase, sp = a.single_phase;
     const double ct = a.cos_theta;
 
-    double u0[NA], u1[NA], iu0[NA], iu1[NA], iu0sq[NA], mus[NA], wq[NA], q2[NA];
+    double u0[NA], u1[NA], iu0[NA], iu1[NA], iu0sq[NA], wq[NA], q2[NA];
 #pragma unroll
     for (int k = 0; k < NA; ++k) {
         if (IS3D) {
@@ -59,11 +65,10 @@ __global__ __launch_bounds__(256) void k_reflected_toa(const ReflectedArgs a)
             u0[k] = a.u0[k];
             u1[k] = a.u1[k];
         }
-        iu0[k] = 1.0 / u0[k];
         iu1[k] = 1.0 / u1[k];
-        iu0sq[k] = 1.0 / (u0[k] * u0[k]);
-        mus[k] = (u0[k] + u1[k]) / (u0[k] * u1[k]);
-        wq[k] = u0[k] / (u0[k] + u1[k]);
+        iu0[k] = ZP ? iu1[k] : 1.0 / u0[k];
+        iu0sq[k] = 1.0 / (u0[k] * u0[k]);              // as the reference forms it (fluxes.py:1155)
+        wq[k] = ZP ? 0.5 : u0[k] / (u0[k] + u1[k]);
         const double ubar2 = 0.767;                     // fluxes.py:1280
         q2[k] = (3.0 * ubar2 * ubar2 * u1[k] * u1[k] - 1.0) / 2.0;
     }
@@ -86,7 +91,7 @@ __global__ __launch_bounds__(256) void k_reflected_toa(const ReflectedArgs a)
             zeta[k] = 0.0;
             delta[k] = 0.0;
             pcpd[k] = pcmd[k] = 0.0;
-            xu[k] = exp(-tau0 * iu0[k]);
+            xu[k] = fexp(-tau0 * iu0[k]);
         }
     }
 
@@ -114,24 +119,17 @@ __global__ __launch_bounds__(256) void k_reflected_toa(const ReflectedArgs a)
         }
         // ---- angle-independent layer quantities (fluxes.py:1132-1141, 1172-1177) ----
         const double fcg = fc * g;
-        double g1, g2;
-        if (tc == 1) {
-            g1 = (7.0 - w0 * (4.0 + 3.0 * fcg)) / 4.0;
-            g2 = -(1.0 - w0 * (4.0 - 3.0 * fcg)) / 4.0;
-        } else {
-            g1 = (SQ3 * 0.5) * (2.0 - w0 * (1.0 + fcg));
-            g2 = (SQ3 * w0 * 0.5) * (1.0 - fcg);
-        }
-        const double lam = sqrt(g1 * g1 - g2 * g2);
-        const double gam = (g1 - lam) / g2;
+        double g1, g2, lam, lam2;
+        toon_gammas(tc, w0, fcg, g1, g2, lam, lam2);
+        const double gam = (g1 - lam) * frcp(g2);
         const double E = fmin(lam * dt, clip);
-        const double EP = exp(E);
-        const double EM = 1.0 / EP;
+        const double EP = fexp(E);
+        const double EM = frcp(EP);
         const double ps = p_single<IS3D>(sp, cbo, gcos2, fc, fr, ct, a.frac_a, a.frac_b, a.frac_c,
                                          a.constant_back, a.constant_forward);
-        const double ssa = (w0o * F / (4.0 * PI)) * ps;    // fluxes.py:1397-1398
+        const double ssa = (w0o * F * (0.25 / PI)) * ps;   // fluxes.py:1397-1398
         const double w2pi = w0 * (0.5 / PI);                // fluxes.py:1290-1296
-        const double lam2 = lam * lam;
+        const double Fw0 = F * w0;
 
         // ---- elimination factors shared by all angles ----
         double inv = 0.0, a1 = 0.0, a2 = 0.0, ia = 0.0, rho_n = gam, sfac = 0.0;
@@ -139,38 +137,58 @@ __global__ __launch_bounds__(256) void k_reflected_toa(const ReflectedArgs a)
             const double em2 = pEM * pEM;
             a1 = 1.0 - pgam * em2 * rho;
             a2 = pgam - em2 * rho;
-            inv = 1.0 / (a1 - gam * a2);
+            const double d1 = a1 - gam * a2;
+const double r12 = frcp(d1 * a1);            // one reciprocal for 1/d1 and 1/a1
+            inv = r12 * a1;
             rho_n = (gam * a1 - a2) * inv;
-            ia = pEM / a1;
+            ia = pEM * (r12 * d1);
             sfac = (1.0 - gam * rho_n) * ia;
         }
         const bool last = (i == n - 1);
+        const double pgEM = pgam * pEM;
 
 #pragma unroll
         for (int k = 0; k < NA; ++k) {
             // direct-beam particular solution (fluxes.py:1146-1169)
             double g3;
-            if (tc == 1) g3 = (2.0 - 3.0 * fcg * u0[k]) / 4.0;
+            if (tc == 1) g3 = (2.0 - 3.0 * fcg * u0[k]) * 0.25;
             else g3 = 0.5 * (1.0 - SQ3 * fcg * u0[k]);
             const double g4 = 1.0 - g3;
-            const double fw_den = F * w0 / (lam2 - iu0sq[k]);
+            const double fw_den = Fw0 * frcp(sub_unfused(lam2, iu0sq[k]));
             const double am = fw_den * (g4 * (g1 + iu0[k]) + g2 * g3);
             const double ap = fw_den * (g3 * (g1 - iu0[k]) + g2 * g4);
-            const double xd = exp(-tau_n * iu0[k]);
+            const double xd = fexp(-tau_n * iu0[k]);
             const double cmu = am * xu[k], cpu = ap * xu[k];
             const double cmd = am * xd, cpd = ap * xd;
             xu[k] = xd;
             // source-function coefficients (fluxes.py:1275-1296, 1395-1406)
-            const double et = exp(-dt * iu1[k]);
+            const double et = fexp(-dt * iu1[k]);
             const double q = (mp == 0) ? gcos2 * q2[k] : 0.0;
             const double h15 = 1.5 * fcg * u1[k];
             const double mpl = 1.0 + h15 + q, mmi = 1.0 - h15 + q;
-            double vp = T[k] * (w2pi * (mpl + gam * mmi) * (EP * et - 1.0) / (lam * u1[k] - 1.0));
-            double vn = T[k] * (w2pi * (gam * mpl + mmi) * (1.0 - EM * et) / (lam * u1[k] + 1.0));
+            const double lu = lam * u1[k];
+            const double Tw = T[k] * w2pi;
+// NB: 1/(lu-1) and 1/(lu+1) are formed separately on purpose.  At lambda*u1 -> 1 (which for
+            // ubar0 == ubar1 coincides with the lambda^2 = 1/u0^2 singularity of the particular solution)
+            // the particular and homogeneous parts cancel with an amplification ~1/|lambda u1 - 1|, so
+            // every factor has to be good to ~1 ulp; (lu-1)/(lu^2-1) loses eps/|lu-1| and was
+            // measured to shift xint by 9e-5 on a near-singular column.
+            double vp = Tw * (mpl + gam * mmi) * (EP * et - 1.0) * frcp(lu - 1.0);
+            double vn = Tw * (gam * mpl + mmi) * (1.0 - EM * et) * frcp(lu + 1.0);
             const double Aq = (mpl * cpu + mmi * cmu) * w2pi;
-            const double S0 = (ssa * exp(-tauo * iu0[k]) * (1.0 - exp(-dto * mus[k])) +
-                               Aq * (1.0 - exp(-dt * mus[k]))) * wq[k];
-            double kap = kappa[k] + T[k] * S0;
+            const double eo = fexp(-tauo * iu0[k]);
+            double t1, t2;                                 // 1 - exp(-dtau_og*mus), 1 - exp(-dtau*mus)
+            if (ZP) {
+                const double e1 = fexp(-dto * iu1[k]);
+                t1 = 1.0 - e1 * e1;
+                t2 = 1.0 - et * et;
+            } else {
+                const double mus = iu0[k] + iu1[k];
+                t1 = 1.0 - fexp(-dto * mus);
+                t2 = 1.0 - fexp(-dt * mus);
+            }
+            const double S0 = (ssa * eo * t1 + Aq * t2) * wq[k];
+            double kap = fma(T[k], S0, kappa[k]);
             const double Tn = T[k] * et;
             if (last) {                                   // xint[n] = flux_zero/pi (fluxes.py:1266-1270)
                 vp += Tn * EP * (1.0 / PI);
@@ -182,7 +200,7 @@ __global__ __launch_bounds__(256) void k_reflected_toa(const ReflectedArgs a)
                 zeta[k] = vp - vn * gam;
                 kap += vn * delta[k];
             } else {
-                const double rP = (cpu - pcpd[k]) - pgam * pEM * delta[k];
+                const double rP = (cpu - pcpd[k]) - pgEM * delta[k];
                 const double rM = (cmu - pcmd[k]) - pEM * delta[k];
                 const double delta_n = (a2 * rP - a1 * rM) * inv;
                 const double t = (gam * delta_n + rP) * ia;
@@ -194,6 +212,9 @@ __global__ __launch_bounds__(256) void k_reflected_toa(const ReflectedArgs a)
             T[k] = Tn;
             pcpd[k] = cpd;
             pcmd[k] = cmd;
+#ifdef PZ_SCHED_BARRIER
+            __builtin_amdgcn_sched_barrier(0);
+#endif
         }
         rho = rho_n;
         pgam = gam;
@@ -226,8 +247,14 @@ static int launch1d(picaso_ctx *ctx, const ReflectedArgs &a)
 {
     const int block = 256;
     const long grid = (a.ncol + block - 1) / block;
-    hipLaunchKernelGGL((k_reflected_toa<NA, false>), dim3((unsigned)grid), dim3(block), 0,
-                       ctx->stream, a);
+    bool zp = true;
+    for (int k = 0; k < a.na; ++k) zp = zp && (a.u0[k] == a.u1[k]);
+    if (zp)
+        hipLaunchKernelGGL((k_reflected_toa<NA, false, true>), dim3((unsigned)grid), dim3(block), 0,
+                           ctx->stream, a);
+    else
+        hipLaunchKernelGGL((k_reflected_toa<NA, false, false>), dim3((unsigned)grid), dim3(block), 0,
+                           ctx->stream, a);
     PZ_HIP(ctx, hipGetLastError());
     return 0;
 }
@@ -238,7 +265,7 @@ int launch_reflected_toa(picaso_ctx *ctx, const ReflectedArgs &a, bool is3d)
     if (is3d) {
         const int block = 256;
         const long grid = (a.ncol + block - 1) / block;
-        hipLaunchKernelGGL((k_reflected_toa<1, true>), dim3((unsigned)grid), dim3(block), 0,
+        hipLaunchKernelGGL((k_reflected_toa<1, true, false>), dim3((unsigned)grid), dim3(block), 0,
                            ctx->stream, a);
         PZ_HIP(ctx, hipGetLastError());
         return 0;
