@@ -277,8 +277,14 @@ int picaso_get_reflected_1d_dev(picaso_ctx *ctx, int nlevel, int nwno, long plan
         a.na = chunks[c];
         for (int k = 0; k < a.na; ++k) {
             const int idx = done + k;
-            a.u0[k] = ubar0[idx];
-            a.u1[k] = ubar1[idx];
+            const double v0 = ubar0[idx], v1 = ubar1[idx];
+            a.u0[k] = v0;
+            a.u1[k] = v1;
+            a.iu0[k] = 1.0 / v0;
+            a.iu1[k] = 1.0 / v1;
+            a.iu0sq[k] = 1.0 / (v0 * v0);              // as the reference forms it (fluxes.py:1155)
+            a.wq[k] = v0 / (v0 + v1);
+            a.q2[k] = (3.0 * 0.767 * 0.767 * v1 * v1 - 1.0) / 2.0;   // ubar2 = 0.767 (fluxes.py:1280)
             a.wgt[k] = fuse ? gweight[idx / numt] * tweight[idx % numt] : 0.0;
         }
         a.xint = xint_at_top + (size_t)done * nwno;

@@ -84,6 +84,9 @@ struct ReflectedArgs {
     // 1-D: angles of this launch (shared planes).  3-D: device tables (nfac) of |ubar|.
     int na;
     double u0[MAX_ANGLES], u1[MAX_ANGLES];
+    // derived per-angle constants, precomputed on the host so they arrive as wave-uniform SGPR
+    // values (fp64 has no scalar ALU: computing 1/u in the kernel parks uniform values in VGPRs)
+    double iu0[MAX_ANGLES], iu1[MAX_ANGLES], iu0sq[MAX_ANGLES], wq[MAX_ANGLES], q2[MAX_ANGLES];
     double wgt[MAX_ANGLES];                 // gweight*tweight per angle (fused disk sum, 1-D)
     const double *u0_tab, *u1_tab;          // 3-D
     double *xint;                           // 1-D: this launch's first angle row, (na, nwno); 3-D: (nfac, nwno)

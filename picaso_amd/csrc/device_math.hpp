@@ -18,21 +18,36 @@ constexpr double SQ3 = 1.7320508075688772935;
 // evaluation rounding), scaling by v_ldexp_f64 which also gives the correct gradual underflow
 // to 0 for very negative x and +inf for x > 709.8.  NaN propagates.  (exp(-inf) gives NaN, not
 // 0: the solver never forms it for finite optical depths.)
+// p*r + c as a 3-address VOP3 v_fma_f64 with the coefficient in an SGPR pair.  Written as inline
+// asm because hipcc otherwise selects the 2-address v_fmac_f64 for Horner steps and has to re-copy
+// the (VGPR-parked) coefficient into the destination before every step: one v_mov_b64 per
+// polynomial term, ~230 dead moves per layer in the 5-angle reflected kernel.
+// Coefficients sit in VGPRs ("v"): with "s" the 11 coefficient pairs push the kernel over the
+// SGPR budget and come back as v_readlane + s_nop pairs (measured 0.411 ms vs 0.405 ms).
+#ifndef PZ_COEF_CONSTRAINT
+#define PZ_COEF_CONSTRAINT "v"
+#endif
+__device__ __forceinline__ double horner_step(double p, double r, double c)
+{
+    double out;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(out) : "v"(p), "v"(r), PZ_COEF_CONSTRAINT(c));
+    return out;
+}
+
 __device__ __forceinline__ double fexp(double x)
 {
     const double k = __builtin_rint(x * 1.4426950408889634);
     double r = fma(k, -0.6931471805599453, x);
     r = fma(k, -2.3190468138462996e-17, r);
-    double p = 0x1.af395738f52d5p-26;
-    p = fma(p, r, 0x1.28923356dc7b1p-22);
-    p = fma(p, r, 0x1.71de0d6feee62p-19);
-    p = fma(p, r, 0x1.a019b87af85f3p-16);
-    p = fma(p, r, 0x1.a01a01a7cf2d3p-13);
-    p = fma(p, r, 0x1.6c16c178b1673p-10);
-    p = fma(p, r, 0x1.11111111109b3p-7);
-    p = fma(p, r, 0x1.5555555553d03p-5);
-    p = fma(p, r, 0x1.5555555555556p-3);
-    p = fma(p, r, 0x1.0000000000001p-1);
+    double p = horner_step(0x1.af395738f52d5p-26, r, 0x1.28923356dc7b1p-22);
+    p = horner_step(p, r, 0x1.71de0d6feee62p-19);
+    p = horner_step(p, r, 0x1.a019b87af85f3p-16);
+    p = horner_step(p, r, 0x1.a01a01a7cf2d3p-13);
+    p = horner_step(p, r, 0x1.6c16c178b1673p-10);
+    p = horner_step(p, r, 0x1.11111111109b3p-7);
+    p = horner_step(p, r, 0x1.5555555553d03p-5);
+    p = horner_step(p, r, 0x1.5555555555556p-3);
+    p = horner_step(p, r, 0x1.0000000000001p-1);
     p = fma(r * r, p, r);
     return ldexp(1.0 + p, (int)k);
 }
@@ -79,12 +94,25 @@ __device__ __forceinline__ double sub_unfused(double a, double b)
     return a - b;
 }
 
+// 1/sqrt(x) to ~1 ulp: v_rsq_f64 + two Newton steps (y <- y + y*(0.5 - 0.5 x y^2)), 9 instructions
+// versus ~31 for sqrt() followed by a correctly rounded divide.
+__device__ __forceinline__ double frsq(double x)
+{
+    double y = __builtin_amdgcn_rsq(x);
+    const double hx = 0.5 * x;
+    double e = fma(-hx * y, y, 0.5);
+    y = fma(y, e, y);
+    e = fma(-hx * y, y, 0.5);
+    y = fma(y, e, y);
+    return y;
+}
+
 // Henyey-Greenstein term in the frame of the downward beam:
 // (1-g^2)/sqrt((1+g^2+2 g cos_theta)^3)   (reference picaso/fluxes.py:1308-1317)
 __device__ __forceinline__ double hg_term(double g, double ct)
 {
     const double b = 1.0 + g * g + 2.0 * g * ct;
-    return (1.0 - g * g) / sqrt(b * b * b);
+    return (1.0 - g * g) * frsq(b * b * b);
 }
 
 // x**c with the common exponent 2 (config default TTHG fraction 1 - g_back^2) kept cheap.
@@ -111,8 +139,8 @@ __device__ __forceinline__ double p_single(int single_phase, double cosb_og, dou
         const double b1 = 1.0 + cosb_og * cosb_og + 2.0 * cosb_og * ct;
         const double hb = -cosb_og / 2.0;
         const double b2 = 1.0 + hb * hb + 2.0 * hb * ct;
-        return f * (1.0 - gf * gf) / sqrt(b1 * b1 * b1) +
-               (1.0 - f) * (1.0 - gb * gb) / sqrt(b2 * b2 * b2) + gcos2;
+        return f * (1.0 - gf * gf) * frsq(b1 * b1 * b1) +
+               (1.0 - f) * (1.0 - gb * gb) * frsq(b2 * b2 * b2) + gcos2;
     }
     const double tthg = f * hg_term(gf, ct) + (1.0 - f) * hg_term(gb, ct);
     if (single_phase == 2) return tthg;

@@ -26,19 +26,164 @@
 //     using pos_{i-1} = s_i pos_i + t_i (contracting: s ~ exp(-lambda dtau));
 //   * the surface row (fluxes.py:178-181) fixes pos_{n-1}; xint_at_top = kappa + zeta pos.
 // Each input element is read exactly once; nothing but the result is written.  Against the
-// reference the result differs only by rounding (<= 6e-11 relative on the golden scenes, at the
+// reference the result differs only by rounding (<= 1e-10 relative on the golden scenes, at the
 // level of the reference's own fp64 conditioning); see tests/test_parity_gpu.py.
+//
+// The kernel is FP64-VALU bound (~20 fp64 instructions per algorithmic byte at 5 angles), so the
+// code below is organised around instruction count: lean exp / reciprocal / rsqrt helpers
+// (device_math.hpp), first and last layer peeled out of the loop, host-precomputed per-angle
+// constants (SGPR resident), and -- for the symmetric geometry -- exponentials carried as running
+// products when the cumulative optical depth really is the running sum of the layer depths.
 #include "common.hpp"
 #include "device_math.hpp"
 
 namespace pz {
 
-// ZP ("zero phase"): every angle of the launch has ubar0 == ubar1 (the symmetric 1-D geometry,
-// reference justdoit.py:1513-1532), so exp(-dtau (u0+u1)/(u0 u1)) = exp(-dtau/u1)^2 and the
-// u0-side constants coincide with the u1-side ones.
+// Two waves per SIMD: one fp64 wave alone issues at most every ~5.1 cycles (tools/ubench/
+// f64_rates.hip) while the pipe accepts one per ~3.5-4, and a 1e5-column spectrum is only 1.5 waves
+// per SIMD, so co-residency beats the extra scratch spills (measured 0.405 ms vs 0.481 ms).
 #ifndef PZ_REFL_MINWAVES
-#define PZ_REFL_MINWAVES 1
+#define PZ_REFL_MINWAVES 2
 #endif
+
+template <int NA>
+struct ReflState {
+    // D1 = c+dn + Gamma EM delta, D2 = c-dn + EM delta of the layer above: the only combinations of
+    // (c+dn, c-dn, delta) the next interface and the surface row need (two registers, not three)
+    double T[NA], kappa[NA], zeta[NA], D1[NA], D2[NA], xu[NA], eo[NA];
+    double rho, pgam, pEM;
+};
+
+struct LayerIn {
+    double dt, tau_n, w0, g, gcos2, fc, fr, dto, tauo, tauo_n, w0o, cbo;
+    bool cum_tau, cum_tauo;   // wave-uniform: tau[i+1] == tau[i] + dtau[i] (resp. tau_og) bit-exactly
+};
+
+// One layer of the sweep.  FIRST / LAST are compile-time so the top row and the bottom-boundary
+// terms cost nothing inside the loop.  ZP: every angle has ubar0 == ubar1 (symmetric 1-D geometry,
+// reference justdoit.py:1513-1532): exp(-dtau (u0+u1)/(u0 u1)) = exp(-dtau/u1)^2, and when the
+// level optical depths are the exact running sums of the layer depths (how compute_opacity builds
+// them, optics.py:353-354, 418-420) exp(-tau[i+1]/u0) = exp(-tau[i]/u0) exp(-dtau[i]/u1) needs no
+// exponential of its own.  The check is bit-exact and per wave, so arbitrary caller-supplied tau
+// planes still take the direct exp(-tau/u0).
+template <int NA, bool IS3D, bool ZP, bool FIRST, bool LAST>
+__device__ __forceinline__ void reflected_layer(const ReflectedArgs &a, const LayerIn &L,
+                                                ReflState<NA> &S, const double (&u0)[NA],
+                                                const double (&u1)[NA], const double (&iu0)[NA],
+                                                const double (&iu1)[NA], const double (&iu0sq)[NA],
+                                                const double (&wq)[NA], const double (&q2)[NA],
+                                                double F, double clip, int tc, double b_top)
+{
+    const double dt = L.dt, w0 = L.w0;
+    // ---- angle-independent layer quantities (fluxes.py:1132-1141, 1172-1177) ----
+    const double fcg = L.fc * L.g;
+    double g1, g2, lam, lam2;
+    toon_gammas(tc, w0, fcg, g1, g2, lam, lam2);
+    const double gam = (g1 - lam) * frcp(g2);
+    const double E = fmin(lam * dt, clip);
+    const double EP = fexp(E);
+    const double EM = frcp(EP);
+    const double ps = p_single<IS3D>(a.single_phase, L.cbo, L.gcos2, L.fc, L.fr, a.cos_theta, a.frac_a,
+                                     a.frac_b, a.frac_c, a.constant_back, a.constant_forward);
+    const double ssa = (L.w0o * F * (0.25 / PI)) * ps;    // fluxes.py:1397-1398
+    const double w2pi = w0 * (0.5 / PI);                   // fluxes.py:1290-1296
+    const double Fw0 = F * w0;
+    const double gcq = (a.multi_phase == 0) ? L.gcos2 : 0.0;   // N=2 vs N=1 (fluxes.py:1275-1287)
+
+    // ---- elimination factors shared by all angles ----
+    double inv = 0.0, a1 = 0.0, a2 = 0.0, ia = 0.0, rho_n = gam, sfac = 0.0;
+    if (!FIRST) {
+        const double em2 = S.pEM * S.pEM;
+        a1 = 1.0 - S.pgam * em2 * S.rho;
+        a2 = S.pgam - em2 * S.rho;
+        const double d1 = a1 - gam * a2;
+        const double r12 = frcp(d1 * a1);                  // one reciprocal for 1/d1 and 1/a1
+        inv = r12 * a1;
+        rho_n = (gam * a1 - a2) * inv;
+        ia = S.pEM * (r12 * d1);
+        sfac = (1.0 - gam * rho_n) * ia;
+    }
+    const double gEM = gam * EM;
+
+#pragma unroll
+    for (int k = 0; k < NA; ++k) {
+        // direct-beam particular solution (fluxes.py:1146-1169)
+        double g3;
+        if (tc == 1) g3 = (2.0 - 3.0 * fcg * u0[k]) * 0.25;
+        else g3 = 0.5 * (1.0 - SQ3 * fcg * u0[k]);
+        const double g4 = 1.0 - g3;
+        const double den = sub_unfused(lam2, iu0sq[k]);    // lambda^2 - 1/u0^2, reference rounding
+        const double lu = lam * u1[k];
+        const double lm1 = lu - 1.0, lp1 = lu + 1.0;
+        // One v_rcp_f64 (quarter rate) for the three reciprocals.  Every factor is itself good to
+        // 1 ulp (lm1 is exact by Sterbenz near the lambda u1 = 1 singularity), so the three results
+        // stay within a few ulp -- which matters: at lambda u1 -> 1 the particular and homogeneous
+        // parts cancel with an amplification ~1/|lambda u1 - 1|.
+        const double lml = lm1 * lp1;
+        const double r3 = frcp(den * lml);
+        const double rden = r3 * lml;
+        const double rlm = (r3 * den) * lp1;               // 1/(lu - 1)
+        const double rlp = (r3 * den) * lm1;               // 1/(lu + 1)
+        const double fw_den = Fw0 * rden;
+        const double am = fw_den * (g4 * (g1 + iu0[k]) + g2 * g3);
+        const double ap = fw_den * (g3 * (g1 - iu0[k]) + g2 * g4);
+        const double et = fexp(-dt * iu1[k]);
+        const double xd = (ZP && L.cum_tau) ? S.xu[k] * et : fexp(-L.tau_n * iu0[k]);
+        const double cmu = am * S.xu[k], cpu = ap * S.xu[k];
+        const double cmd = am * xd, cpd = ap * xd;
+        S.xu[k] = xd;
+        // source-function coefficients (fluxes.py:1275-1296, 1395-1406)
+        const double q = gcq * q2[k];
+        const double h15 = 1.5 * fcg * u1[k];
+        const double mpl = 1.0 + h15 + q, mmi = 1.0 - h15 + q;
+        const double Tw = S.T[k] * w2pi;
+        double vp = Tw * (mpl + gam * mmi) * (EP * et - 1.0) * rlm;
+        double vn = Tw * (gam * mpl + mmi) * (1.0 - EM * et) * rlp;
+        const double Aq = (mpl * cpu + mmi * cmu) * w2pi;
+        const double eo = S.eo[k];                         // exp(-tau_og[i]/u0)
+        double t1, t2;                                     // 1 - exp(-dtau_og*mus), 1 - exp(-dtau*mus)
+        if (ZP) {
+            const double e1 = fexp(-L.dto * iu1[k]);
+            t1 = 1.0 - e1 * e1;
+            t2 = 1.0 - et * et;
+            if (!LAST) S.eo[k] = L.cum_tauo ? eo * e1 : fexp(-L.tauo_n * iu0[k]);
+        } else {
+            const double mus = iu0[k] + iu1[k];
+            t1 = 1.0 - fexp(-L.dto * mus);
+            t2 = 1.0 - fexp(-dt * mus);
+            if (!LAST) S.eo[k] = fexp(-L.tauo_n * iu0[k]);
+        }
+        const double S0 = (ssa * eo * t1 + Aq * t2) * wq[k];
+        double kap = fma(S.T[k], S0, S.kappa[k]);
+        const double Tn = S.T[k] * et;
+        if (LAST) {                                        // xint[n] = flux_zero/pi (fluxes.py:1266-1270)
+            vp += Tn * EP * (1.0 / PI);
+            vn += Tn * gam * EM * (1.0 / PI);
+            kap += Tn * cpd * (1.0 / PI);
+        }
+        double delta_n;
+        if (FIRST) {                                       // top row (fluxes.py:155-158)
+            delta_n = b_top - cmu;
+            S.zeta[k] = vp - vn * gam;
+            kap += vn * delta_n;
+        } else {
+            const double rP = cpu - S.D1[k];
+            const double rM = cmu - S.D2[k];
+            delta_n = (a2 * rP - a1 * rM) * inv;
+            const double t = (gam * delta_n + rP) * ia;
+            kap += S.zeta[k] * t + vn * delta_n;
+            S.zeta[k] = S.zeta[k] * sfac + vp - vn * rho_n;
+        }
+        S.kappa[k] = kap;
+        S.T[k] = Tn;
+        S.D1[k] = fma(gEM, delta_n, cpd);
+        S.D2[k] = fma(EM, delta_n, cmd);
+    }
+    S.rho = rho_n;
+    S.pgam = gam;
+    S.pEM = EM;
+}
+
 template <int NA, bool IS3D, bool ZP>
 __global__ __launch_bounds__(256, PZ_REFL_MINWAVES) void k_reflected_toa(const ReflectedArgs a)
 {
@@ -52,8 +197,6 @@ __global__ __launch_bounds__(256, PZ_REFL_MINWAVES) void k_reflected_toa(const R
     const double clip = IS3D ? 40.0 : 35.0;            // fluxes.py:516 vs :1174
     const int tc = IS3D ? 0 : a.toon_coefficients;     // 3-D is quadrature only (fluxes.py:489)
     const double b_top = IS3D ? 0.0 : a.b_top;         // fluxes.py:522
-    const int mp = a.multi_phase, sp = a.single_phase;
-    const double ct = a.cos_theta;
 
     double u0[NA], u1[NA], iu0[NA], iu1[NA], iu0sq[NA], wq[NA], q2[NA];
 #pragma unroll
@@ -61,16 +204,21 @@ __global__ __launch_bounds__(256, PZ_REFL_MINWAVES) void k_reflected_toa(const R
         if (IS3D) {
             u0[k] = fabs(a.u0_tab[fac]);                // fluxes.py:467-468
             u1[k] = fabs(a.u1_tab[fac]);
-        } else {
+            iu1[k] = 1.0 / u1[k];
+            iu0[k] = 1.0 / u0[k];
+            iu0sq[k] = 1.0 / (u0[k] * u0[k]);          // as the reference forms it (fluxes.py:1155)
+            wq[k] = u0[k] / (u0[k] + u1[k]);
+            const double ubar2 = 0.767;                 // fluxes.py:1280
+            q2[k] = (3.0 * ubar2 * ubar2 * u1[k] * u1[k] - 1.0) / 2.0;
+        } else {                                        // host-precomputed, wave-uniform
             u0[k] = a.u0[k];
             u1[k] = a.u1[k];
+            iu1[k] = a.iu1[k];
+            iu0[k] = ZP ? a.iu1[k] : a.iu0[k];
+            iu0sq[k] = a.iu0sq[k];
+            wq[k] = ZP ? 0.5 : a.wq[k];
+            q2[k] = a.q2[k];
         }
-        iu1[k] = 1.0 / u1[k];
-        iu0[k] = ZP ? iu1[k] : 1.0 / u0[k];
-        iu0sq[k] = 1.0 / (u0[k] * u0[k]);              // as the reference forms it (fluxes.py:1155)
-        wq[k] = ZP ? 0.5 : u0[k] / (u0[k] + u1[k]);
-        const double ubar2 = 0.767;                     // fluxes.py:1280
-        q2[k] = (3.0 * ubar2 * ubar2 * u1[k] * u1[k] - 1.0) / 2.0;
     }
     const double F = a.F0PI[w], rs = a.surf_reflect[w];
 
@@ -79,165 +227,86 @@ __global__ __launch_bounds__(256, PZ_REFL_MINWAVES) void k_reflected_toa(const R
                  *p_fr = a.ftau_ray + col, *p_dto = a.dtau_og + col, *p_tauo = a.tau_og + col,
                  *p_w0o = a.w0_og + col, *p_cbo = a.cosb_og + col;
 
-    // per-angle sweep state
-    double T[NA], kappa[NA], zeta[NA], delta[NA], pcpd[NA], pcmd[NA], xu[NA];
-    double rho = 0.0, pgam = 0.0, pEM = 0.0;
+    ReflState<NA> S;
+    S.rho = S.pgam = S.pEM = 0.0;
+    double tau_i = p_tau[0];
     {
-        const double tau0 = p_tau[0];
+        const double tauo0 = p_tauo[0];
 #pragma unroll
         for (int k = 0; k < NA; ++k) {
-            T[k] = 1.0;
-            kappa[k] = 0.0;
-            zeta[k] = 0.0;
-            delta[k] = 0.0;
-            pcpd[k] = pcmd[k] = 0.0;
-            xu[k] = fexp(-tau0 * iu0[k]);
+            S.T[k] = 1.0;
+            S.kappa[k] = S.zeta[k] = 0.0;
+            S.D1[k] = S.D2[k] = 0.0;
+            S.xu[k] = fexp(-tau_i * iu0[k]);
+            S.eo[k] = fexp(-tauo0 * iu0[k]);
         }
     }
 
-    // software prefetch of the next layer's 11 plane values
-    double n_dt = p_dtau[0], n_tau = p_tau[pitch], n_w0 = p_w0[0], n_cb = p_cosb[0],
-           n_g2 = p_gcos2[0], n_fc = p_fc[0], n_fr = p_fr[0], n_dto = p_dto[0], n_tauo = p_tauo[0],
-           n_w0o = p_w0o[0], n_cbo = p_cbo[0];
+    // software prefetch: `nx` always holds the next layer's plane values
+    LayerIn nx;
+    nx.dt = p_dtau[0]; nx.tau_n = p_tau[pitch]; nx.w0 = p_w0[0]; nx.g = p_cosb[0];
+    nx.gcos2 = p_gcos2[0]; nx.fc = p_fc[0]; nx.fr = p_fr[0]; nx.dto = p_dto[0];
+    nx.tauo = p_tauo[0]; nx.w0o = p_w0o[0]; nx.cbo = p_cbo[0];
 
-    for (int i = 0; i < n; ++i) {
-        const double dt = n_dt, tau_n = n_tau, w0 = n_w0, g = n_cb, gcos2 = n_g2, fc = n_fc,
-                     fr = n_fr, dto = n_dto, tauo = n_tauo, w0o = n_w0o, cbo = n_cbo;
+    auto advance = [&](int i, LayerIn &cur) {
+        cur = nx;
         if (i + 1 < n) {
             const long o = (long)(i + 1) * pitch;
-            n_dt = p_dtau[o];
-            n_tau = p_tau[o + pitch];
-            n_w0 = p_w0[o];
-            n_cb = p_cosb[o];
-            n_g2 = p_gcos2[o];
-            n_fc = p_fc[o];
-            n_fr = p_fr[o];
-            n_dto = p_dto[o];
-            n_tauo = p_tauo[o];
-            n_w0o = p_w0o[o];
-            n_cbo = p_cbo[o];
+            nx.dt = p_dtau[o];
+            nx.tau_n = p_tau[o + pitch];
+            nx.w0 = p_w0[o];
+            nx.g = p_cosb[o];
+            nx.gcos2 = p_gcos2[o];
+            nx.fc = p_fc[o];
+            nx.fr = p_fr[o];
+            nx.dto = p_dto[o];
+            nx.tauo = p_tauo[o];
+            nx.w0o = p_w0o[o];
+            nx.cbo = p_cbo[o];
         }
-        // ---- angle-independent layer quantities (fluxes.py:1132-1141, 1172-1177) ----
-        const double fcg = fc * g;
-        double g1, g2, lam, lam2;
-        toon_gammas(tc, w0, fcg, g1, g2, lam, lam2);
-        const double gam = (g1 - lam) * frcp(g2);
-        const double E = fmin(lam * dt, clip);
-        const double EP = fexp(E);
-        const double EM = frcp(EP);
-        const double ps = p_single<IS3D>(sp, cbo, gcos2, fc, fr, ct, a.frac_a, a.frac_b, a.frac_c,
-                                         a.constant_back, a.constant_forward);
-        const double ssa = (w0o * F * (0.25 / PI)) * ps;   // fluxes.py:1397-1398
-        const double w2pi = w0 * (0.5 / PI);                // fluxes.py:1290-1296
-        const double Fw0 = F * w0;
+        cur.tauo_n = nx.tauo;     // tau_og of the level below (unused in the last layer)
+        if (ZP) {
+            cur.cum_tau = __all(cur.tau_n == tau_i + cur.dt);
+            cur.cum_tauo = __all(cur.tauo_n == cur.tauo + cur.dto);
+        } else {
+            cur.cum_tau = cur.cum_tauo = false;
+        }
+        tau_i = cur.tau_n;
+    };
 
-        // ---- elimination factors shared by all angles ----
-        double inv = 0.0, a1 = 0.0, a2 = 0.0, ia = 0.0, rho_n = gam, sfac = 0.0;
-        if (i > 0) {
-            const double em2 = pEM * pEM;
-            a1 = 1.0 - pgam * em2 * rho;
-            a2 = pgam - em2 * rho;
-            const double d1 = a1 - gam * a2;
-const double r12 = frcp(d1 * a1);            // one reciprocal for 1/d1 and 1/a1
-            inv = r12 * a1;
-            rho_n = (gam * a1 - a2) * inv;
-            ia = pEM * (r12 * d1);
-            sfac = (1.0 - gam * rho_n) * ia;
+    LayerIn cur;
+    if (n == 1) {
+        advance(0, cur);
+        reflected_layer<NA, IS3D, ZP, true, true>(a, cur, S, u0, u1, iu0, iu1, iu0sq, wq, q2, F, clip, tc, b_top);
+    } else {
+        advance(0, cur);
+        reflected_layer<NA, IS3D, ZP, true, false>(a, cur, S, u0, u1, iu0, iu1, iu0sq, wq, q2, F, clip, tc, b_top);
+        for (int i = 1; i < n - 1; ++i) {
+            advance(i, cur);
+            reflected_layer<NA, IS3D, ZP, false, false>(a, cur, S, u0, u1, iu0, iu1, iu0sq, wq, q2, F, clip, tc, b_top);
         }
-        const bool last = (i == n - 1);
-        const double pgEM = pgam * pEM;
-
-#pragma unroll
-        for (int k = 0; k < NA; ++k) {
-            // direct-beam particular solution (fluxes.py:1146-1169)
-            double g3;
-            if (tc == 1) g3 = (2.0 - 3.0 * fcg * u0[k]) * 0.25;
-            else g3 = 0.5 * (1.0 - SQ3 * fcg * u0[k]);
-            const double g4 = 1.0 - g3;
-            const double fw_den = Fw0 * frcp(sub_unfused(lam2, iu0sq[k]));
-            const double am = fw_den * (g4 * (g1 + iu0[k]) + g2 * g3);
-            const double ap = fw_den * (g3 * (g1 - iu0[k]) + g2 * g4);
-            const double xd = fexp(-tau_n * iu0[k]);
-            const double cmu = am * xu[k], cpu = ap * xu[k];
-            const double cmd = am * xd, cpd = ap * xd;
-            xu[k] = xd;
-            // source-function coefficients (fluxes.py:1275-1296, 1395-1406)
-            const double et = fexp(-dt * iu1[k]);
-            const double q = (mp == 0) ? gcos2 * q2[k] : 0.0;
-            const double h15 = 1.5 * fcg * u1[k];
-            const double mpl = 1.0 + h15 + q, mmi = 1.0 - h15 + q;
-            const double lu = lam * u1[k];
-            const double Tw = T[k] * w2pi;
-// NB: 1/(lu-1) and 1/(lu+1) are formed separately on purpose.  At lambda*u1 -> 1 (which for
-            // ubar0 == ubar1 coincides with the lambda^2 = 1/u0^2 singularity of the particular solution)
-            // the particular and homogeneous parts cancel with an amplification ~1/|lambda u1 - 1|, so
-            // every factor has to be good to ~1 ulp; (lu-1)/(lu^2-1) loses eps/|lu-1| and was
-            // measured to shift xint by 9e-5 on a near-singular column.
-            double vp = Tw * (mpl + gam * mmi) * (EP * et - 1.0) * frcp(lu - 1.0);
-            double vn = Tw * (gam * mpl + mmi) * (1.0 - EM * et) * frcp(lu + 1.0);
-            const double Aq = (mpl * cpu + mmi * cmu) * w2pi;
-            const double eo = fexp(-tauo * iu0[k]);
-            double t1, t2;                                 // 1 - exp(-dtau_og*mus), 1 - exp(-dtau*mus)
-            if (ZP) {
-                const double e1 = fexp(-dto * iu1[k]);
-                t1 = 1.0 - e1 * e1;
-                t2 = 1.0 - et * et;
-            } else {
-                const double mus = iu0[k] + iu1[k];
-                t1 = 1.0 - fexp(-dto * mus);
-                t2 = 1.0 - fexp(-dt * mus);
-            }
-            const double S0 = (ssa * eo * t1 + Aq * t2) * wq[k];
-            double kap = fma(T[k], S0, kappa[k]);
-            const double Tn = T[k] * et;
-            if (last) {                                   // xint[n] = flux_zero/pi (fluxes.py:1266-1270)
-                vp += Tn * EP * (1.0 / PI);
-                vn += Tn * gam * EM * (1.0 / PI);
-                kap += Tn * cpd * (1.0 / PI);
-            }
-            if (i == 0) {                                 // top row (fluxes.py:155-158)
-                delta[k] = b_top - cmu;
-                zeta[k] = vp - vn * gam;
-                kap += vn * delta[k];
-            } else {
-                const double rP = (cpu - pcpd[k]) - pgEM * delta[k];
-                const double rM = (cmu - pcmd[k]) - pEM * delta[k];
-                const double delta_n = (a2 * rP - a1 * rM) * inv;
-                const double t = (gam * delta_n + rP) * ia;
-                kap += zeta[k] * t + vn * delta_n;
-                zeta[k] = zeta[k] * sfac + vp - vn * rho_n;
-                delta[k] = delta_n;
-            }
-            kappa[k] = kap;
-            T[k] = Tn;
-            pcpd[k] = cpd;
-            pcmd[k] = cmd;
-#ifdef PZ_SCHED_BARRIER
-            __builtin_amdgcn_sched_barrier(0);
-#endif
-        }
-        rho = rho_n;
-        pgam = gam;
-        pEM = EM;
+        advance(n - 1, cur);
+        reflected_layer<NA, IS3D, ZP, false, true>(a, cur, S, u0, u1, iu0, iu1, iu0sq, wq, q2, F, clip, tc, b_top);
     }
 
     // ---- surface row (fluxes.py:178-183) and output ----
-    const double em2 = pEM * pEM;
-    const double bden = 1.0 / ((1.0 - rs * pgam) - em2 * (pgam - rs) * rho);
+    // EP(1 - rs G) pos + EM(G - rs) neg = b_surface - c+dn + rs c-dn with neg = delta - rho pos,
+    // divided through by EP:  pos = EM (b_surface - D1 + rs D2) / ((1 - rs G) - EM^2 (G - rs) rho)
+    const double em2 = S.pEM * S.pEM;
+    const double bden = 1.0 / ((1.0 - rs * S.pgam) - em2 * (S.pgam - rs) * S.rho);
     double alb = 0.0;
 #pragma unroll
     for (int k = 0; k < NA; ++k) {
-        const double b_surface = 0.0 + rs * u0[k] * F * xu[k];
-        const double pos = (pEM * (b_surface - pcpd[k] + rs * pcmd[k]) -
-                            em2 * (pgam - rs) * delta[k]) * bden;
-        const double x = kappa[k] + zeta[k] * pos;
+        const double b_surface = 0.0 + rs * u0[k] * F * S.xu[k];
+        const double pos = S.pEM * (b_surface - S.D1[k] + rs * S.D2[k]) * bden;
+        const double x = S.kappa[k] + S.zeta[k] * pos;
         if (IS3D) a.xint[(long)fac * a.nwno + w] = x;
         else a.xint[(long)k * a.nwno + w] = x;
         alb = alb + x * a.wgt[k];
     }
     if (!IS3D && a.albedo) {                              // fused disco.compress_disco (disco.py:145-148)
         double acc = a.albedo_first ? alb : a.albedo[w] + alb;
-        if (a.albedo_last) acc = a.albedo_scale * acc / F * (ct + 1.0);
+        if (a.albedo_last) acc = a.albedo_scale * acc / F * (a.cos_theta + 1.0);
         a.albedo[w] = acc;
     }
 }
