@@ -153,7 +153,7 @@ __device__ __forceinline__ double planck_lambda(double t, double wno)
     const double h = 6.62607004e-27, c = 2.99792458e+10, k = 1.38064852e-16;
     const double wcm = 1.0 / wno;
     const double w2 = wcm * wcm;
-    return ((2.0 * h * (c * c)) / (w2 * w2 * wcm)) * (1.0 / (exp((h * c) / (t * (wcm * k))) - 1.0));
+    return ((2.0 * h * (c * c)) / (w2 * w2 * wcm)) * frcp(fexp((h * c) / (t * (wcm * k))) - 1.0);
 }
 
 // 3-point bin mean of the wavenumber Planck function (reference fluxes.py:1608-1658, nbb = 1).
@@ -165,7 +165,7 @@ __device__ __forceinline__ double planck_integrated(double t, double wave, doubl
 #pragma unroll
     for (int kk = -1; kk <= 1; ++kk) {
         const double wn = wave + kk * dwave / 2.0;
-        s += c1 * (wn * wn * wn) / (exp(c2 * wn / t) - 1.0);
+        s += c1 * (wn * wn * wn) * frcp(fexp(c2 * wn / t) - 1.0);
     }
     return s / 3.0;
 }

@@ -65,17 +65,17 @@ __global__ __launch_bounds__(256) void k_thermal_toa(const ThermalArgs a)
         }
         const double B0 = Bn;
         Bn = planck(i + 1);
-        const double b1 = (Bn - B0) / dt;                      // fluxes.py:1757
+        const double b1 = (Bn - B0) * frcp(dt);                // fluxes.py:1757
         const double g1 = 2.0 - w0 * (1 + g), g2 = w0 * (1 - g);   // fluxes.py:1760
         const double lam = sqrt(g1 * g1 - g2 * g2);
-        const double gam = (g1 - lam) / g2;
-        const double s = 1.0 / (g1 + g2);                      // fluxes.py:1766
+        const double gam = (g1 - lam) * frcp(g2);
+        const double s = frcp(g1 + g2);                        // fluxes.py:1766
         const double cpu = 2 * PI * mu1 * (B0 + b1 * s);       // fluxes.py:1772-1779
         const double cmu = 2 * PI * mu1 * (B0 - b1 * s);
         const double cpd = 2 * PI * mu1 * (B0 + b1 * dt + b1 * s);
         const double cmd = 2 * PI * mu1 * (B0 + b1 * dt - b1 * s);
         const double E = fmin(lam * dt, 35.0);                 // fluxes.py:1784-1786
-        const double EP = exp(E), EM = 1.0 / EP;
+        const double EP = fexp(E), EM = frcp(EP);
         const double al1 = 2 * PI * (B0 + b1 * (s - mu1));     // fluxes.py:1846-1847
         const double al2 = 2 * PI * b1;
         const double gcoef = (1.0 / mu1 - lam);                // G = gcoef*pos   fluxes.py:1842
@@ -84,34 +84,40 @@ __global__ __launch_bounds__(256) void k_thermal_toa(const ThermalArgs a)
         double rho_n = gam, delta_n = 0.0, sfac = 0.0, t = 0.0;
         if (i == 0) {
             tau_top = dt * pl[0] / (pl[lstride] - pl[0]);      // fluxes.py:1797
-            const double b_top = IS3D ? PI * (1.0 - exp(-tau_top / mu1)) * B_top   // :2253
-                                      : (1.0 - exp(-tau_top / mu1)) * B_top * PI;  // :1800
+            const double b_top = IS3D ? PI * (1.0 - fexp(-tau_top / mu1)) * B_top   // :2253
+                                      : (1.0 - fexp(-tau_top / mu1)) * B_top * PI;  // :1800
             delta_n = b_top - cmu;
         } else {
             const double em2 = pEM * pEM;
             const double a1 = 1.0 - pgam * em2 * rho;
             const double a2 = pgam - em2 * rho;
-            const double inv = 1.0 / (a1 - gam * a2);
+            const double d1 = a1 - gam * a2;
+            const double r12 = frcp(d1 * a1);                  // one reciprocal for 1/d1 and 1/a1
+            const double inv = r12 * a1;
             const double rP = (cpu - pcpd) - pgam * pEM * delta;
             const double rM = (cmu - pcmd) - pEM * delta;
             rho_n = (gam * a1 - a2) * inv;
             delta_n = (a2 * rP - a1 * rM) * inv;
-            const double ia = pEM / a1;
+            const double ia = pEM * (r12 * d1);
             sfac = (1.0 - gam * rho_n) * ia;
             t = (gam * delta_n + rP) * ia;
         }
         const bool last = (i == n - 1);
         double EPm = 0.0, EMm = 0.0;
         if (i == 0) {
-            EPm = exp(0.5 * E);                                // fluxes.py:1856-1857
-            EMm = 1.0 / EPm;
+            EPm = fexp(0.5 * E);                               // fluxes.py:1856-1857
+            EMm = frcp(EPm);
         }
 #pragma unroll
         for (int k = 0; k < NA; ++k) {
             const double mu = u1[k];
-            const double lp = gcoef / (lam * mu - 1.0), lm = hcoef / (lam * mu + 1.0);
+            // 1/(lam mu - 1) and 1/(lam mu + 1) from one reciprocal of the product of the two
+            // 1-ulp factors (see toon_reflected.hip: no cancellation, lm1 is exact near lam mu = 1)
+            const double lm1 = lam * mu - 1.0, lp1 = lam * mu + 1.0;
+            const double r2 = frcp(lm1 * lp1);
+            const double lp = gcoef * (r2 * lp1), lm = hcoef * (r2 * lm1);
             if (i == 0) {
-                const double em = exp(-0.5 * dt * iu1[k]);     // fluxes.py:1878
+                const double em = fexp(-0.5 * dt * iu1[k]);    // fluxes.py:1878
                 const double vp = lp * (EP * em - EPm);        // fluxes.py:1903-1907
                 const double vn = -lm * (EM * em - EMm);
                 const double c0 = al1 * (1. - em) + al2 * (mu + 0.5 * dt - (dt + mu) * em);
@@ -119,7 +125,7 @@ __global__ __launch_bounds__(256) void k_thermal_toa(const ThermalArgs a)
                 zeta[k] = vp - vn * rho_n;
                 W[k] = em;
             } else {
-                const double e = exp(-dt * iu1[k]);            // fluxes.py:1877
+                const double e = fexp(-dt * iu1[k]);           // fluxes.py:1877
                 const double vp = W[k] * lp * (EP * e - 1.0);  // fluxes.py:1897-1901
                 const double vn = W[k] * lm * (1.0 - EM * e);
                 const double c0 = W[k] * (al1 * (1. - e) + al2 * (mu - (dt + mu) * e));
