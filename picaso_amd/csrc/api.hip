@@ -150,6 +150,7 @@ void picaso_ctx_destroy(picaso_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->arena) (void)hipFree(ctx->arena);
+    if (ctx->lvl_scratch) (void)hipFree(ctx->lvl_scratch);
     if (ctx->ring_d) (void)hipFree(ctx->ring_d);
     if (ctx->ring_h) (void)hipHostFree(ctx->ring_h);
     for (int i = 0; i < picaso_ctx::NSLOT; ++i)
@@ -249,12 +250,11 @@ int picaso_get_reflected_1d_dev(picaso_ctx *ctx, int nlevel, int nwno, long plan
     if (get_lvl_flux) {
         if (!flux_minus_all || !flux_plus_all || !flux_minus_midpt_all || !flux_plus_midpt_all)
             return fail(ctx, "get_reflected_1d: get_lvl_flux=1 needs the four level-flux outputs");
-        return fail(ctx, "get_reflected_1d: level fluxes (get_lvl_flux=1) are not built yet");
     }
     if (!get_toa_intensity) {   // reference returns zeros (fluxes.py:1113, 1262)
         PZ_HIP(ctx, hipMemsetAsync(xint_at_top, 0, sizeof(double) * (size_t)nang * nwno, ctx->stream));
         if (albedo) PZ_HIP(ctx, hipMemsetAsync(albedo, 0, sizeof(double) * nwno, ctx->stream));
-        return 0;
+        if (!get_lvl_flux) return 0;
     }
     ReflectedArgs a{};
     a.nlayer = nlevel - 1;
@@ -271,6 +271,26 @@ int picaso_get_reflected_1d_dev(picaso_ctx *ctx, int nlevel, int nwno, long plan
     const bool fuse = albedo && gweight && tweight;
     a.albedo = fuse ? albedo : nullptr;
     a.albedo_scale = ((numt == 1) ? 2.0 * 3.14159265358979323846 : 1.0) * 0.5;   // disco.py:140-141
+    if (get_lvl_flux) {   // two-sweep kernel, one angle per launch (fluxes.py:1219-1257)
+        const size_t plane = (size_t)(nlevel - 1) * nwno;
+        PZ_TRY(lvl_scratch_reserve(ctx, sizeof(double) * 4 * plane));
+        ReflectedLvlArgs la{};
+        la.base = a;
+        la.base.na = 1;
+        la.base.albedo = nullptr;
+        la.scratch = ctx->lvl_scratch;
+        const size_t lv = (size_t)nlevel * nwno;
+        for (int idx = 0; idx < nang; ++idx) {
+            const double v0 = ubar0[idx], v1 = ubar1[idx];
+            la.base.u0[0] = v0; la.base.u1[0] = v1;
+            la.base.iu0[0] = 1.0 / v0; la.base.iu1[0] = 1.0 / v1;
+            la.base.iu0sq[0] = 1.0 / (v0 * v0);
+            la.fm = flux_minus_all + idx * lv; la.fp = flux_plus_all + idx * lv;
+            la.fmm = flux_minus_midpt_all + idx * lv; la.fpm = flux_plus_midpt_all + idx * lv;
+            PZ_TRY(launch_reflected_lvl(ctx, la));
+        }
+        if (!get_toa_intensity) return 0;
+    }
     int done = 0;
     const auto chunks = angle_chunks(nang);
     for (size_t c = 0; c < chunks.size(); ++c) {
@@ -456,12 +476,14 @@ int picaso_get_thermal_1d_dev(picaso_ctx *ctx, int nlevel, const double *wno, in
     if (plane_pitch < nwno) return fail(ctx, "get_thermal_1d: plane_pitch %ld < nwno %d", plane_pitch, nwno);
     if (calc_type != 0 && calc_type != 1) return fail(ctx, "get_thermal_1d: calc_type must be 0 or 1");
     if (calc_type == 1 && !dwno) return fail(ctx, "get_thermal_1d: calc_type=1 needs dwno");
-    if (flux_minus || flux_plus || flux_minus_mdpt || flux_plus_mdpt)
-        return fail(ctx, "get_thermal_1d: level fluxes are not built yet (pass NULL for a spectrum-only call)");
+    const bool want_lvl = flux_minus || flux_plus || flux_minus_mdpt || flux_plus_mdpt;
+    if (want_lvl && !(flux_minus && flux_plus && flux_minus_mdpt && flux_plus_mdpt))
+        return fail(ctx, "get_thermal_1d: pass all four level-flux outputs or none");
     PZ_HIP(ctx, hipSetDevice(ctx->device));
     const int nang = numg * numt;
-    std::vector<double> tab(2 * (size_t)nlevel);
+    std::vector<double> tab(2 * (size_t)nlevel + (size_t)nang);
     for (int i = 0; i < nlevel; ++i) { tab[i] = tlevel[i]; tab[nlevel + i] = plevel[i]; }
+    for (int i = 0; i < nang; ++i) tab[2 * (size_t)nlevel + i] = ubar1[i];
     const void *d_tab = nullptr;
     PZ_TRY(table_upload(ctx, tab.data(), sizeof(double) * tab.size(), &d_tab));
     ThermalArgs a{};
@@ -477,6 +499,21 @@ int picaso_get_thermal_1d_dev(picaso_ctx *ctx, int nlevel, const double *wno, in
     const bool fuse = flux_disk && gweight && tweight;
     a.disk = fuse ? flux_disk : nullptr;
     a.disk_scale = (numt == 1) ? 1.0 : 1.0 / (2.0 * 3.14159265358979323846);   // disco.py:174-175
+    if (want_lvl) {   // the reference always fills these (fluxes.py:1851-1907): two-sweep kernel
+        const size_t plane = (size_t)(nlevel - 1) * nwno;
+        PZ_TRY(lvl_scratch_reserve(ctx, sizeof(double) * 4 * plane));
+        ThermalLvlArgs la{};
+        la.base = a;
+        la.nang = nang;
+        la.u1_dev = (const double *)d_tab + 2 * (size_t)nlevel;
+        la.flux = flux_at_top;
+        la.fm = flux_minus; la.fp = flux_plus; la.fmm = flux_minus_mdpt; la.fpm = flux_plus_mdpt;
+        la.scratch = ctx->lvl_scratch;
+        PZ_TRY(launch_thermal_lvl(ctx, la));
+        if (fuse)
+            PZ_TRY(picaso_compress_thermal_dev(ctx, (size_t)nwno, flux_at_top, gweight, numg, tweight, numt, flux_disk));
+        return 0;
+    }
     int done = 0;
     const auto chunks = angle_chunks(nang);
     for (size_t c = 0; c < chunks.size(); ++c) {

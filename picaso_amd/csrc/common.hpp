@@ -26,6 +26,9 @@ struct picaso_ctx {
     hipEvent_t ring_ev[NSLOT] = {};
     bool ring_pending[NSLOT] = {};
     int ring_next = 0;
+    // per-layer sweep state of the level-flux (two-sweep) kernels: 4 planes (nlayer, ncol)
+    double *lvl_scratch = nullptr;
+    size_t lvl_scratch_bytes = 0;
 };
 
 namespace pz {
@@ -96,7 +99,6 @@ struct ReflectedArgs {
 };
 int launch_reflected_toa(picaso_ctx *ctx, const ReflectedArgs &a, bool is3d);
 
-struct ReflectedLvlArgs;   // level-flux (two-sweep) variant, see toon_reflected_lvl.hip
 
 struct ThermalArgs {
     int nlayer;
@@ -116,6 +118,27 @@ struct ThermalArgs {
     int disk_first, disk_last;
 };
 int launch_thermal_toa(picaso_ctx *ctx, const ThermalArgs &a, bool is3d);
+
+// level-flux (two-sweep) variants, toon_lvl.hip.  One angle per launch for reflected light
+// (its right-hand side is per angle); all angles inside one launch for thermal (one solve).
+struct ReflectedLvlArgs {
+    ReflectedArgs base;                     // na == 1: u0[0], u1[0]
+    int want_toa;                           // also write base.xint (get_toa_intensity)
+    double *fm, *fp, *fmm, *fpm;            // this angle's (nlevel, nwno) output planes
+    double *scratch;                        // 4 planes (nlayer, nwno): rho, delta, s, t
+};
+int launch_reflected_lvl(picaso_ctx *ctx, const ReflectedLvlArgs &a);
+
+struct ThermalLvlArgs {
+    ThermalArgs base;
+    int nang;
+    const double *u1_dev;                   // (nang) device table
+    double *flux;                           // (nang, nwno)
+    double *fm, *fp, *fmm, *fpm;            // (nang, nlevel, nwno)
+    double *scratch;                        // 4 planes (nlayer, nwno)
+};
+int launch_thermal_lvl(picaso_ctx *ctx, const ThermalLvlArgs &a);
+int lvl_scratch_reserve(picaso_ctx *ctx, size_t bytes);
 
 int launch_compress_dev(picaso_ctx *ctx, size_t ninner, const double *x, const double *wts_dev,
                         int nang, const double *F0PI, double c1, double c2, double *out);

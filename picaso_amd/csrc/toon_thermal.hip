@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void k_thermal_toa(const ThermalArgs a)
     };
 
     double W[NA], kappa[NA], zeta[NA];
-    double rho = 0.0, delta = 0.0, pgam = 0.0, pEM = 0.0, pcpd = 0.0, pcmd = 0.0, b1_last = 0.0;
+    double rho = 0.0, delta = 0.0, pgam = 0.0, pEM = 0.0, pq = 0.0, b1_last = 0.0, s_last = 0.0;
     double Bn = planck(0);
     const double B_top = Bn;
     double tau_top = 0.0;
@@ -70,10 +70,13 @@ __global__ __launch_bounds__(256) void k_thermal_toa(const ThermalArgs a)
         const double lam = sqrt(g1 * g1 - g2 * g2);
         const double gam = (g1 - lam) * frcp(g2);
         const double s = frcp(g1 + g2);                        // fluxes.py:1766
-        const double cpu = 2 * PI * mu1 * (B0 + b1 * s);       // fluxes.py:1772-1779
+        // fluxes.py:1772-1779 with 2 pi mu1 = pi and B0 + b1 dtau = B_{i+1}:
+        //   c+up = pi B_i + q, c-up = pi B_i - q, c+dn = pi B_{i+1} + q, c-dn = pi B_{i+1} - q,
+        // so the interface right-hand sides are +-(q_i - q_{i-1}) with the pi B terms cancelled
+        // analytically (the reference cancels them numerically, at a cost of up to 11 digits in
+        // optically thick, weakly scattering layers).
+        const double q = PI * b1 * s;
         const double cmu = 2 * PI * mu1 * (B0 - b1 * s);
-        const double cpd = 2 * PI * mu1 * (B0 + b1 * dt + b1 * s);
-        const double cmd = 2 * PI * mu1 * (B0 + b1 * dt - b1 * s);
         const double E = fmin(lam * dt, 35.0);                 // fluxes.py:1784-1786
         const double EP = fexp(E), EM = frcp(EP);
         const double al1 = 2 * PI * (B0 + b1 * (s - mu1));     // fluxes.py:1846-1847
@@ -94,8 +97,9 @@ __global__ __launch_bounds__(256) void k_thermal_toa(const ThermalArgs a)
             const double d1 = a1 - gam * a2;
             const double r12 = frcp(d1 * a1);                  // one reciprocal for 1/d1 and 1/a1
             const double inv = r12 * a1;
-            const double rP = (cpu - pcpd) - pgam * pEM * delta;
-            const double rM = (cmu - pcmd) - pEM * delta;
+            const double dq = q - pq;
+            const double rP = dq - pgam * pEM * delta;
+            const double rM = -dq - pEM * delta;
             rho_n = (gam * a1 - a2) * inv;
             delta_n = (a2 * rP - a1 * rM) * inv;
             const double ia = pEM * (r12 * d1);
@@ -150,20 +154,21 @@ __global__ __launch_bounds__(256) void k_thermal_toa(const ThermalArgs a)
         delta = delta_n;
         pgam = gam;
         pEM = EM;
-        pcpd = cpd;
-        pcmd = cmd;
+        pq = q;
         b1_last = b1;
+        s_last = s;
     }
-    double b_surface;
-    if (!IS3D) {
-        if (a.hard_surface) b_surface = (1.0 - rs) * Bn * PI;               // fluxes.py:1803-1804
-        else b_surface = (Bn + b1_last * mu1) * PI;                         // fluxes.py:1806
-    } else {
-        if (a.hard_surface) b_surface = PI * Bn;                            // fluxes.py:2256
-        else b_surface = PI * (Bn + b1_last * mu1);                         // fluxes.py:2258
-    }
+    // surface row b_surface - c+dn + rs c-dn with the pi B_n terms cancelled analytically:
+    //   1-D soft (fluxes.py:1806) : pi [b1 (mu1 - s) + rs (B_n - b1 s)]
+    //   1-D hard (fluxes.py:1803) : -pi b1 s (1 + rs)                (b_surface = (1-rs) pi B_n)
+    //   3-D soft (fluxes.py:2258) : same as 1-D soft
+    //   3-D hard (fluxes.py:2256) : pi [rs B_n - b1 s (1 + rs)]     (b_surface = pi B_n, no emissivity)
+    double bsum;
+    if (!a.hard_surface) bsum = PI * (b1_last * (mu1 - s_last) + rs * (Bn - b1_last * s_last));
+    else if (!IS3D) bsum = -PI * b1_last * s_last * (1.0 + rs);
+    else bsum = PI * (rs * Bn - b1_last * s_last * (1.0 + rs));
     const double em2 = pEM * pEM;
-    const double pos = (pEM * (b_surface - pcpd + rs * pcmd) - em2 * (pgam - rs) * delta) /
+    const double pos = (pEM * bsum - em2 * (pgam - rs) * delta) /
                        ((1.0 - rs * pgam) - em2 * (pgam - rs) * rho);
     double disk = 0.0;
 #pragma unroll

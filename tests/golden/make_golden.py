@@ -99,6 +99,23 @@ def run_reflected_1d(name, sc, geo, rs, f0, store):
                     nwno, geo["cos_theta"], xint, geo["gweight"], geo["tweight"], f0)
 
 
+def _extended(fn, *args, **kw):
+    """Evaluate a reference function in x87 extended precision (np.longdouble): every float64 array
+    argument is widened and the module-level ``zeros`` the reference allocates its work arrays with
+    is made to allocate longdouble.  Used to record how well-conditioned the reference's OWN fp64
+    level fluxes are (deep, optically thick levels cancel catastrophically in the bottom boundary
+    row), so that the parity tests can tell implementation error from the reference's rounding."""
+    L = np.longdouble
+    wide = [a.astype(L) if isinstance(a, np.ndarray) and a.dtype == np.float64 else a for a in args]
+    orig = fl.zeros
+    fl.zeros = lambda *a, **k: np.zeros(*a, dtype=L, **k)
+    try:
+        out = fn(*wide, **kw)
+    finally:
+        fl.zeros = orig
+    return out
+
+
 def run_thermal_1d(name, sc, geo, rs, store):
     nlevel, nwno = sc["nlevel"], sc["nwno"]
     dwno = np.gradient(sc["wno"])
@@ -114,6 +131,12 @@ def run_thermal_1d(name, sc, geo, rs, store):
         if hs == ct:
             for nm, arr in zip(("fm", "fp", "fmm", "fpm"), lv):
                 store[key + "/" + nm] = arr
+            _, lvx = _extended(fl.get_thermal_1d, nlevel, sc["wno"], nwno, geo["numg"],
+                               geo["numt"], sc["tlevel"], sc["dtau_og"].copy(),
+                               sc["w0_no_raman"].copy(), sc["cosb_og"].copy(), sc["plevel"],
+                               geo["ubar1"], rsv, hs, dwno, ct)
+            for nm, arr in zip(("fm", "fp", "fmm", "fpm"), lvx):
+                store[key + "/" + nm + "_x80"] = np.asarray(arr, dtype=np.float64)
         if (hs, ct) == (0, 0):
             store["compress_thermal/flux"] = di.compress_thermal(nwno, flux, geo["gweight"],
                                                                  geo["tweight"])

@@ -77,3 +77,22 @@ def lvl_err(got4, ref4):
     scale = np.max(np.stack([np.max(np.abs(r), axis=(0, 1, 2)) for r in ref4]), axis=0)
     scale = np.where(scale == 0, 1.0, scale)
     return max(float(np.max(np.abs(np.asarray(g) - r) / scale)) for g, r in zip(got4, ref4))
+
+
+def lvl_excess(got4, ref4, x80_4, tol):
+    """Element-wise level-flux check against the reference's fp64 output AND its extended-precision
+    evaluation.  With e_ref = |ref - x80| (how far the reference's own fp64 rounding moved that
+    element) the kernel may differ from the reference by tol*scale + 2 e_ref and from the
+    extended-precision value by tol*scale + e_ref/500 (x87 extended carries 11 more mantissa bits
+    than fp64, so x80 itself is only good to ~e_ref/2048).  Returns the worst excess over the
+    allowance in units of the per-wavelength field scale (<= 0 means pass)."""
+    ref4 = [np.asarray(r) for r in ref4]
+    scale = np.max(np.stack([np.max(np.abs(r), axis=(0, 1, 2)) for r in ref4]), axis=0)
+    scale = np.where(scale == 0, 1.0, scale)
+    worst = -np.inf
+    for g, r, x in zip(got4, ref4, x80_4):
+        e_ref = np.abs(r - x)
+        ex1 = (np.abs(np.asarray(g) - r) - 2.0 * e_ref) / scale - tol
+        ex2 = (np.abs(np.asarray(g) - x) - e_ref / 500.0) / scale - tol
+        worst = max(worst, float(np.max(ex1)), float(np.max(ex2)))
+    return worst

@@ -6,10 +6,11 @@ reference's two-sweep Thomas only by rounding)."""
 import numpy as np
 import pytest
 
-from helpers import PLANES, Golden, golden_files, rel_err, scene_id
+from helpers import PLANES, Golden, golden_files, lvl_err, lvl_excess, rel_err, scene_id
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-8
+LVL_TOL = 1e-7   # level fluxes: noise in one level leaks into its neighbours through the recursion
 FILES_1D = golden_files("scene1d_")
 FILES_3D = golden_files("scene3d_")
 
@@ -59,6 +60,46 @@ def test_thermal_1d_golden(path, hip):
                                             g.inp("w0_no_raman"), g.inp("cosb_og"), g.inp("plevel"),
                                             g.geo("ubar1"), rs, hs, g["dwno"], ct, want_lvl=False)
         assert rel_err(flux, g["therm1d/%s/flux" % case]) < TOL, case
+
+
+@pytest.mark.parametrize("path", FILES_1D, ids=scene_id)
+def test_level_fluxes_golden(path, hip):
+    """get_lvl_flux=1 (reflected) and the always-filled thermal level/mid-point fluxes: the climate
+    caller's outputs.  Judged against the per-wavelength scale of the flux field (helpers.lvl_err)."""
+    g = Golden(path)
+    nlevel, nwno = g.inp("tau").shape
+    planes = [g.inp(k) for k in PLANES]
+    for case in g.cases("refl1d"):
+        sp, mp, tc, lvl = (int(s[-1]) for s in case.split("_"))
+        if not lvl:
+            continue
+        b_top = float(g["refl1d/%s/b_top" % case])
+        xint, lv = hip.fluxes.get_reflected_1d(
+            nlevel, g.inp("wno"), nwno, g.geo("numg"), g.geo("numt"), *planes,
+            g.inp("surf_reflect"), g.geo("ubar0"), g.geo("ubar1"), g.geo("cos_theta"),
+            g.inp("F0PI"), sp, mp, *g.tthg(), get_toa_intensity=1, get_lvl_flux=1,
+            toon_coefficients=tc, b_top=b_top)
+        assert rel_err(xint, g["refl1d/%s/xint" % case]) < TOL, case
+        ref4 = [g["refl1d/%s/%s" % (case, nm)] for nm in ("fm", "fp", "fmm", "fpm")]
+        assert lvl_err(lv, ref4) < TOL, case
+    for case in g.cases("therm1d"):
+        if "therm1d/%s/fm" % case not in g.keys:
+            continue
+        hs, ct = (int(s[-1]) for s in case.split("_"))
+        rs = np.zeros(nwno) + g.inp("surf_reflect")
+        flux, lv = hip.fluxes.get_thermal_1d(nlevel, g.inp("wno"), nwno, g.geo("numg"),
+                                             g.geo("numt"), g.inp("tlevel"), g.inp("dtau_og"),
+                                             g.inp("w0_no_raman"), g.inp("cosb_og"),
+                                             g.inp("plevel"), g.geo("ubar1"), rs, hs, g["dwno"], ct)
+        assert rel_err(flux, g["therm1d/%s/flux" % case]) < TOL, case
+        # The reference's own fp64 downward fluxes at deep, optically thick levels are noise at the
+        # 1e-4..1e-6 level (catastrophic cancellation in its bottom boundary row: b_surface -
+        # c_plus_down, fluxes.py:181): the fixture also holds the reference algorithm evaluated in
+        # x87 extended precision ("_x80").  The kernel must sit on the well-conditioned answer and
+        # may differ from the reference's fp64 output by no more than the reference itself does.
+        ref4 = [g["therm1d/%s/%s" % (case, nm)] for nm in ("fm", "fp", "fmm", "fpm")]
+        x80 = [g["therm1d/%s/%s_x80" % (case, nm)] for nm in ("fm", "fp", "fmm", "fpm")]
+        assert lvl_excess(lv, ref4, x80, LVL_TOL) <= 0.0, case
 
 
 @pytest.mark.parametrize("path", FILES_3D, ids=scene_id)
