@@ -70,7 +70,9 @@ int table_upload(picaso_ctx *ctx, const void *host, size_t bytes, const void **d
 // split `n` angles into ceil(n/MAX_ANGLES) nearly equal chunks
 static std::vector<int> angle_chunks(int n)
 {
-    int maxa = MAX_ANGLES;
+    // 5 angles per launch keeps the LDS-resident sweep state at 70 KB per 256-thread block, i.e. two
+    // blocks (two waves per SIMD) per CU; 6..8 angles are split 3+3 / 4+3 / 4+4
+    int maxa = 5;
     if (const char *e = getenv("PICASO_AMD_MAX_ANGLES")) {   // tuning knob: angles fused per launch
         const int v = atoi(e);
         if (v >= 1 && v <= MAX_ANGLES) maxa = v;

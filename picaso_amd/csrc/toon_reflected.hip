@@ -46,12 +46,39 @@ namespace pz {
 #define PZ_REFL_MINWAVES 2
 #endif
 
-template <int NA>
+// Per-angle sweep state (7 doubles per angle).  D1 = c+dn + Gamma EM delta, D2 = c-dn + EM delta of
+// the layer above: the only combinations of (c+dn, c-dn, delta) the next interface and the surface
+// row need.  For NA >= 4 part of the state lives in LDS ([var][angle][lane], so a wave's
+// ds_read_b64 / ds_write_b64 hit 64 consecutive 8-byte words: conflict free): all in registers the
+// 5-angle kernel needs ~300 VGPRs, i.e. either one wave per SIMD or ~50 registers spilled to
+// scratch, whose reloads share the vmcnt queue with the plane prefetch.
+constexpr int NSTATE = 7;
+enum { S_T = 0, S_XU, S_EO, S_KAPPA, S_ZETA, S_D1, S_D2 };   // late-use variables last
+
+// NLDS = how many of the state variables (counted from the END of the enum order below) live in
+// LDS when LDS is on; the rest stay in registers.
+// Measured on the 5-angle headline case: 0 -> 50 VGPRs spilled to scratch (0.416 ms), 4 -> no
+// spills, 41 KB LDS per block (0.410 ms), 7 -> 72 KB (0.421 ms): the kernel is VALU-issue bound,
+// so 4 is chosen for being spill-free with the smaller LDS footprint.
+#ifndef PZ_REFL_NLDS
+#define PZ_REFL_NLDS 4
+#endif
+template <int NA, bool LDS>
 struct ReflState {
-    // D1 = c+dn + Gamma EM delta, D2 = c-dn + EM delta of the layer above: the only combinations of
-    // (c+dn, c-dn, delta) the next interface and the surface row need (two registers, not three)
-    double T[NA], kappa[NA], zeta[NA], D1[NA], D2[NA], xu[NA], eo[NA];
+    static constexpr int NL = LDS ? PZ_REFL_NLDS : 0;      // variables [NSTATE-NL, NSTATE) in LDS
+    static constexpr int NR = NSTATE - NL;
+    double reg[NR > 0 ? NR : 1][NA];
+    double *lds;                                   // this lane's column of the block's LDS tile
     double rho, pgam, pEM;
+    __device__ __forceinline__ double get(int var, int k) const
+    {
+        return (var >= NR) ? lds[((var - NR) * NA + k) * 256] : reg[var < NR ? var : 0][k];
+    }
+    __device__ __forceinline__ void set(int var, int k, double v)
+    {
+        if (var >= NR) lds[((var - NR) * NA + k) * 256] = v;
+        else reg[var < NR ? var : 0][k] = v;
+    }
 };
 
 struct LayerIn {
@@ -66,9 +93,9 @@ struct LayerIn {
 // them, optics.py:353-354, 418-420) exp(-tau[i+1]/u0) = exp(-tau[i]/u0) exp(-dtau[i]/u1) needs no
 // exponential of its own.  The check is bit-exact and per wave, so arbitrary caller-supplied tau
 // planes still take the direct exp(-tau/u0).
-template <int NA, bool IS3D, bool ZP, bool FIRST, bool LAST>
+template <int NA, bool IS3D, bool ZP, bool FIRST, bool LAST, bool LDS>
 __device__ __forceinline__ void reflected_layer(const ReflectedArgs &a, const LayerIn &L,
-                                                ReflState<NA> &S, const double (&u0)[NA],
+                                                ReflState<NA, LDS> &S, const double (&u0)[NA],
                                                 const double (&u1)[NA], const double (&iu0)[NA],
                                                 const double (&iu1)[NA], const double (&iu0sq)[NA],
                                                 const double (&wq)[NA], const double (&q2)[NA],
@@ -128,34 +155,35 @@ __device__ __forceinline__ void reflected_layer(const ReflectedArgs &a, const La
         const double am = fw_den * (g4 * (g1 + iu0[k]) + g2 * g3);
         const double ap = fw_den * (g3 * (g1 - iu0[k]) + g2 * g4);
         const double et = fexp(-dt * iu1[k]);
-        const double xd = (ZP && L.cum_tau) ? S.xu[k] * et : fexp(-L.tau_n * iu0[k]);
-        const double cmu = am * S.xu[k], cpu = ap * S.xu[k];
+        const double xu = S.get(S_XU, k), Tk = S.get(S_T, k);
+        const double xd = (ZP && L.cum_tau) ? xu * et : fexp(-L.tau_n * iu0[k]);
+        const double cmu = am * xu, cpu = ap * xu;
         const double cmd = am * xd, cpd = ap * xd;
-        S.xu[k] = xd;
+        S.set(S_XU, k, xd);
         // source-function coefficients (fluxes.py:1275-1296, 1395-1406)
         const double q = gcq * q2[k];
         const double h15 = 1.5 * fcg * u1[k];
         const double mpl = 1.0 + h15 + q, mmi = 1.0 - h15 + q;
-        const double Tw = S.T[k] * w2pi;
+        const double Tw = Tk * w2pi;
         double vp = Tw * (mpl + gam * mmi) * (EP * et - 1.0) * rlm;
         double vn = Tw * (gam * mpl + mmi) * (1.0 - EM * et) * rlp;
         const double Aq = (mpl * cpu + mmi * cmu) * w2pi;
-        const double eo = S.eo[k];                         // exp(-tau_og[i]/u0)
+        const double eo = S.get(S_EO, k);                  // exp(-tau_og[i]/u0)
         double t1, t2;                                     // 1 - exp(-dtau_og*mus), 1 - exp(-dtau*mus)
         if (ZP) {
             const double e1 = fexp(-L.dto * iu1[k]);
             t1 = 1.0 - e1 * e1;
             t2 = 1.0 - et * et;
-            if (!LAST) S.eo[k] = L.cum_tauo ? eo * e1 : fexp(-L.tauo_n * iu0[k]);
+            if (!LAST) S.set(S_EO, k, L.cum_tauo ? eo * e1 : fexp(-L.tauo_n * iu0[k]));
         } else {
             const double mus = iu0[k] + iu1[k];
             t1 = 1.0 - fexp(-L.dto * mus);
             t2 = 1.0 - fexp(-dt * mus);
-            if (!LAST) S.eo[k] = fexp(-L.tauo_n * iu0[k]);
+            if (!LAST) S.set(S_EO, k, fexp(-L.tauo_n * iu0[k]));
         }
         const double S0 = (ssa * eo * t1 + Aq * t2) * wq[k];
-        double kap = fma(S.T[k], S0, S.kappa[k]);
-        const double Tn = S.T[k] * et;
+        double kap = fma(Tk, S0, S.get(S_KAPPA, k));
+        const double Tn = Tk * et;
         if (LAST) {                                        // xint[n] = flux_zero/pi (fluxes.py:1266-1270)
             vp += Tn * EP * (1.0 / PI);
             vn += Tn * gam * EM * (1.0 / PI);
@@ -164,20 +192,21 @@ __device__ __forceinline__ void reflected_layer(const ReflectedArgs &a, const La
         double delta_n;
         if (FIRST) {                                       // top row (fluxes.py:155-158)
             delta_n = b_top - cmu;
-            S.zeta[k] = vp - vn * gam;
+            S.set(S_ZETA, k, vp - vn * gam);
             kap += vn * delta_n;
         } else {
-            const double rP = cpu - S.D1[k];
-            const double rM = cmu - S.D2[k];
+            const double rP = cpu - S.get(S_D1, k);
+            const double rM = cmu - S.get(S_D2, k);
+            const double zeta = S.get(S_ZETA, k);
             delta_n = (a2 * rP - a1 * rM) * inv;
             const double t = (gam * delta_n + rP) * ia;
-            kap += S.zeta[k] * t + vn * delta_n;
-            S.zeta[k] = S.zeta[k] * sfac + vp - vn * rho_n;
+            kap += zeta * t + vn * delta_n;
+            S.set(S_ZETA, k, zeta * sfac + vp - vn * rho_n);
         }
-        S.kappa[k] = kap;
-        S.T[k] = Tn;
-        S.D1[k] = fma(gEM, delta_n, cpd);
-        S.D2[k] = fma(EM, delta_n, cmd);
+        S.set(S_KAPPA, k, kap);
+        S.set(S_T, k, Tn);
+        S.set(S_D1, k, fma(gEM, delta_n, cpd));
+        S.set(S_D2, k, fma(EM, delta_n, cmd));
     }
     S.rho = rho_n;
     S.pgam = gam;
@@ -227,18 +256,23 @@ __global__ __launch_bounds__(256, PZ_REFL_MINWAVES) void k_reflected_toa(const R
                  *p_fr = a.ftau_ray + col, *p_dto = a.dtau_og + col, *p_tauo = a.tau_og + col,
                  *p_w0o = a.w0_og + col, *p_cbo = a.cosb_og + col;
 
-    ReflState<NA> S;
+    constexpr bool LDS = (NA >= 4) && !IS3D;
+    __shared__ double lds_state[LDS ? (PZ_REFL_NLDS > 0 ? PZ_REFL_NLDS : 1) * NA * 256 : 1];
+    ReflState<NA, LDS> S;
+    S.lds = lds_state + threadIdx.x;
     S.rho = S.pgam = S.pEM = 0.0;
     double tau_i = p_tau[0];
     {
         const double tauo0 = p_tauo[0];
 #pragma unroll
         for (int k = 0; k < NA; ++k) {
-            S.T[k] = 1.0;
-            S.kappa[k] = S.zeta[k] = 0.0;
-            S.D1[k] = S.D2[k] = 0.0;
-            S.xu[k] = fexp(-tau_i * iu0[k]);
-            S.eo[k] = fexp(-tauo0 * iu0[k]);
+            S.set(S_T, k, 1.0);
+            S.set(S_KAPPA, k, 0.0);
+            S.set(S_ZETA, k, 0.0);
+            S.set(S_D1, k, 0.0);
+            S.set(S_D2, k, 0.0);
+            S.set(S_XU, k, fexp(-tau_i * iu0[k]));
+            S.set(S_EO, k, fexp(-tauo0 * iu0[k]));
         }
     }
 
@@ -277,16 +311,16 @@ __global__ __launch_bounds__(256, PZ_REFL_MINWAVES) void k_reflected_toa(const R
     LayerIn cur;
     if (n == 1) {
         advance(0, cur);
-        reflected_layer<NA, IS3D, ZP, true, true>(a, cur, S, u0, u1, iu0, iu1, iu0sq, wq, q2, F, clip, tc, b_top);
+        reflected_layer<NA, IS3D, ZP, true, true, LDS>(a, cur, S, u0, u1, iu0, iu1, iu0sq, wq, q2, F, clip, tc, b_top);
     } else {
         advance(0, cur);
-        reflected_layer<NA, IS3D, ZP, true, false>(a, cur, S, u0, u1, iu0, iu1, iu0sq, wq, q2, F, clip, tc, b_top);
+        reflected_layer<NA, IS3D, ZP, true, false, LDS>(a, cur, S, u0, u1, iu0, iu1, iu0sq, wq, q2, F, clip, tc, b_top);
         for (int i = 1; i < n - 1; ++i) {
             advance(i, cur);
-            reflected_layer<NA, IS3D, ZP, false, false>(a, cur, S, u0, u1, iu0, iu1, iu0sq, wq, q2, F, clip, tc, b_top);
+            reflected_layer<NA, IS3D, ZP, false, false, LDS>(a, cur, S, u0, u1, iu0, iu1, iu0sq, wq, q2, F, clip, tc, b_top);
         }
         advance(n - 1, cur);
-        reflected_layer<NA, IS3D, ZP, false, true>(a, cur, S, u0, u1, iu0, iu1, iu0sq, wq, q2, F, clip, tc, b_top);
+        reflected_layer<NA, IS3D, ZP, false, true, LDS>(a, cur, S, u0, u1, iu0, iu1, iu0sq, wq, q2, F, clip, tc, b_top);
     }
 
     // ---- surface row (fluxes.py:178-183) and output ----
@@ -297,9 +331,9 @@ __global__ __launch_bounds__(256, PZ_REFL_MINWAVES) void k_reflected_toa(const R
     double alb = 0.0;
 #pragma unroll
     for (int k = 0; k < NA; ++k) {
-        const double b_surface = 0.0 + rs * u0[k] * F * S.xu[k];
-        const double pos = S.pEM * (b_surface - S.D1[k] + rs * S.D2[k]) * bden;
-        const double x = S.kappa[k] + S.zeta[k] * pos;
+        const double b_surface = 0.0 + rs * u0[k] * F * S.get(S_XU, k);
+        const double pos = S.pEM * (b_surface - S.get(S_D1, k) + rs * S.get(S_D2, k)) * bden;
+        const double x = S.get(S_KAPPA, k) + S.get(S_ZETA, k) * pos;
         if (IS3D) a.xint[(long)fac * a.nwno + w] = x;
         else a.xint[(long)k * a.nwno + w] = x;
         alb = alb + x * a.wgt[k];
