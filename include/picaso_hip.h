@@ -174,6 +174,45 @@ int picaso_compress_thermal_dev(picaso_ctx *ctx, size_t ninner, const double *fl
                                 const double *gweight, int ng, const double *tweight, int nt,
                                 double *flux);
 
+/* ---- opacity pre-stage --------------------------------------------------------------------- */
+/* Gas + Rayleigh optical depth per (layer, wavelength) from HBM-resident opacity tables.
+ * Replaces the arithmetic of RetrieveOpacities.get_opacities / get_opacities_nearest (reference
+ * picaso/optics.py:2241-2368: per layer, bilinear interpolation of log10(kappa) in (1/T, log10 P)
+ * between the four bracketing table rows -- or the nearest row -- times Avogadro's number) and of
+ * the TAUGAS / TAURAY sums of compute_opacity (optics.py:144-277).  The table rows themselves
+ * (read from the sqlite DB by host Python) live on the device:
+ *   mol_tables[m]  : (n_pt_rows, nwno)  kappa (nearest) or log10(kappa, zero -> 1e-50) (linear)
+ *   cont_tables[c] : (n_cia_temps, nwno) continuum opacity
+ *   ray_tables[r]  : (nwno)             Rayleigh cross section
+ * Small per-layer host tables select and weight them:
+ *   mol_rows  [nmol][nlayer][4] row indices   mol_wts [nmol][nlayer][4] interpolation weights
+ *   mol_fac   [nmol][nlayer]    colden*x/mmw (times exclude_mol factor)
+ *   cont_rows [ncont][nlayer]   nearest-temperature row, cont_fac [ncont][nlayer] layer coefficient
+ *   ray_fac   [nray][nlayer]    colden*x/mmw
+ * Outputs taugas, tauray: device planes (nlayer, nwno).  `linear` = 1 for query_method='linear'. */
+int picaso_opacity_gas_dev(picaso_ctx *ctx, int nlayer, int nwno, int linear, int nmol,
+                           const double *const *mol_tables, const int *mol_rows,
+                           const double *mol_wts, const double *mol_fac, int ncont,
+                           const double *const *cont_tables, const int *cont_rows,
+                           const double *cont_fac, int nray, const double *const *ray_tables,
+                           const double *ray_fac, double *taugas, double *tauray);
+
+/* replaces the mixing half of optics.compute_opacity (reference picaso/optics.py:327-431):
+ * DTAU, TAU, W0, COSB, ftau_cld, ftau_ray, GCOS2, W0_no_raman, f_deltaM and the delta-Eddington
+ * scaled set from the gas / Rayleigh / cloud optical depths.  All arrays are device planes
+ * (nlayer, nwno) except tau, tau_og (nlevel, nwno).  `raman_factor` may be NULL (then
+ * `raman_const`, 0.99999 for raman='none', is used).  test_mode: 0 off, 1 'rayleigh',
+ * 2 constant-tau (optics.py:372-399).  Output order = the reference's return tuple
+ * (optics.py:423-431). */
+int picaso_compute_opacity_dev(picaso_ctx *ctx, int nlayer, int nwno, const double *taugas,
+                               const double *tauray, const double *taucld, const double *w0_cld,
+                               const double *g0_cld, const double *raman_factor,
+                               double raman_const, int test_mode, int delta_eddington, int stream,
+                               double *dtau, double *tau, double *w0, double *cosb,
+                               double *ftau_cld, double *ftau_ray, double *gcos2, double *dtau_og,
+                               double *tau_og, double *w0_og, double *cosb_og, double *w0_no_raman,
+                               double *f_deltaM);
+
 #ifdef __cplusplus
 }
 #endif

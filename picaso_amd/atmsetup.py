@@ -1,0 +1,153 @@
+"""Minimal atmosphere state for the accelerated path (counterpart of the reference ``ATMSETUP``,
+picaso/atmsetup.py:17-876, restricted to what ``picaso()`` needs to feed the opacity and solver
+kernels).  Host-side numpy only; everything is cgs (no astropy units).
+
+Kept from the reference: level -> layer averaging (atmsetup.py:219-229), mean molecular weight
+(:345-361), constant-gravity column density (:549-556), the cloud-free default and the
+``(nlayer, nwno)`` reshape of cloud tables (:558-627), ``get_needed_continuum`` (:248-283).
+Out of scope: altitude integration, chemistry, 3-D regridding, virga clouds.
+"""
+import numpy as np
+
+# atomic masses (g/mol) for the species the synthetic / test configurations use
+_ATOMIC = {"H": 1.00794, "He": 4.002602, "C": 12.0107, "N": 14.0067, "O": 15.9994, "Na": 22.98977,
+           "K": 39.0983, "S": 32.065, "P": 30.97376, "Ti": 47.867, "V": 50.9415, "Fe": 55.845,
+           "Si": 28.0855, "Mg": 24.305, "Al": 26.98154, "Ca": 40.078, "Cr": 51.9961, "Li": 6.941,
+           "Rb": 85.4678, "Cs": 132.90545, "Cl": 35.453, "F": 18.9984}
+
+
+def molecular_weight(name):
+    """Molecular weight from a formula such as 'H2O', 'CH4', 'TiO' (case-sensitive elements)."""
+    import re
+    if name in ("e-", "H-"):
+        return _ATOMIC["H"] if name == "H-" else 5.4858e-4
+    name = name.rstrip("+-")
+    total, pos = 0.0, 0
+    for m in re.finditer(r"([A-Z][a-z]?)(\d*)", name):
+        if m.start() != pos or m.group(1) not in _ATOMIC:
+            raise KeyError(name)
+        total += _ATOMIC[m.group(1)] * (int(m.group(2)) if m.group(2) else 1)
+        pos = m.end()
+    if pos != len(name) or total == 0:
+        raise KeyError(name)
+    return total
+
+
+class _Consts:
+    pconv = 1e6                 # bar -> dyn/cm2 (atmsetup.py:50)
+    k_b = 1.380649e-16          # erg/K
+    G = 6.6743e-8
+    amu = 1.66053906660e-24     # g
+    rgas = 8.31446261815324     # J/K/mol, as the reference's c.R.value (atmsetup.py:56)
+    pi = np.pi
+
+
+class _Obj:
+    pass
+
+
+class ATMSETUP:
+    def __init__(self, config):
+        self.input = config
+        self.warnings = []
+        self.c = _Consts()
+        self.planet = _Obj()
+        self.layer, self.level = {}, {}
+        self.dimension = "1d"
+
+    def add_warnings(self, w):
+        self.warnings += [w]
+
+    def get_profile(self):
+        read = self.input["atmosphere"]["profile"]           # dict-like / DataFrame of level columns
+        cols = list(read.keys())
+        weights, molecules = {}, []
+        for k in cols:
+            if k in ("pressure", "temperature"):
+                continue
+            if k == "e-":
+                self.level["electrons"] = np.asarray(read["e-"], dtype=float)
+                self.layer["electrons"] = 0.5 * (self.level["electrons"][1:] + self.level["electrons"][:-1])
+                continue
+            try:
+                weights[k] = molecular_weight(k)
+                molecules.append(k)
+            except KeyError:
+                self.add_warnings("Ignoring %s in input file, not recognized molecule" % k)
+        self.weights = weights
+        self.molecules = np.array(molecules, dtype=str)
+        self.level["mixingratios"] = {m: np.asarray(read[m], dtype=float) for m in molecules}
+        self.layer["mixingratios"] = {m: 0.5 * (v[1:] + v[:-1])
+                                      for m, v in self.level["mixingratios"].items()}
+        self.level["temperature"] = np.asarray(read["temperature"], dtype=float)
+        self.level["pressure_bar"] = np.asarray(read["pressure"], dtype=float)
+        self.level["pressure"] = self.level["pressure_bar"] * self.c.pconv
+        self.layer["temperature"] = 0.5 * (self.level["temperature"][1:] + self.level["temperature"][:-1])
+        self.layer["pressure"] = np.sqrt(self.level["pressure"][1:] * self.level["pressure"][:-1])
+        self.c.nlevel = len(self.level["temperature"])
+        self.c.nlayer = self.c.nlevel - 1
+
+    def get_mmw(self):
+        w = np.zeros(self.c.nlevel)
+        for m in self.molecules:
+            w = w + self.level["mixingratios"][m] * self.weights[m]
+        self.level["mmw"] = w
+        self.layer["mmw"] = 0.5 * (w[:-1] + w[1:])
+
+    def get_density(self):
+        self.level["den"] = self.level["pressure"] / (self.c.k_b * self.level["temperature"])
+
+    def get_altitude(self, p_reference=1, constant_gravity=True):
+        """Constant gravity only (the reference falls back to it when no radius is given,
+        atmsetup.py:396-398)."""
+        self.layer["gravity"] = np.zeros(self.c.nlayer) + self.planet.gravity
+        self.level["gravity"] = np.zeros(self.c.nlevel) + self.planet.gravity
+
+    def get_column_density(self):
+        self.layer["colden"] = (self.level["pressure"][1:] - self.level["pressure"][:-1]) / self.layer["gravity"]
+
+    def get_needed_continuum(self, available_ray_mol, available_continuum):
+        """Continuum pairs and Rayleigh species present in both the profile and the opacity data
+        (reference atmsetup.py:248-283; isotopologue name simplification is not needed here)."""
+        names = list(self.molecules)
+        self.continuum_molecules = []
+        for m1 in names:
+            for m2 in names:
+                if m1 + m2 in available_continuum:
+                    self.continuum_molecules += [[m1, m2]]
+        if "H-" in names and "H-bf" in available_continuum:
+            self.continuum_molecules += [["H-", "bf"]]
+        if "H" in names and "electrons" in self.level.keys() and "H-ff" in available_continuum:
+            self.continuum_molecules += [["H-", "ff"]]
+        if "H2" in names and "electrons" in self.level.keys() and "H2-" in available_continuum:
+            self.continuum_molecules += [["H2-", ""]]
+        self.rayleigh_molecules = [m for m in names if m in available_ray_mol]
+
+    def get_clouds(self, wno):
+        nwno = np.size(wno)
+        prof = self.input["clouds"]["profile"]
+        if prof is None:
+            z = np.zeros((self.c.nlayer, nwno))
+            self.layer["cloud"] = {"w0": z, "g0": z.copy(), "opd": z.copy()}
+            return
+        in_wno = self.input["clouds"]["wavenumber"]
+        cld = {}
+        for k in ("opd", "g0", "w0"):
+            v = np.asarray(prof[k], dtype=np.float64)
+            if v.ndim == 0:
+                v = np.zeros((self.c.nlayer, nwno)) + v
+            elif v.size == self.c.nlayer:
+                v = np.repeat(v.reshape(self.c.nlayer, 1), nwno, axis=1)
+            else:
+                nin = v.size // self.c.nlayer
+                v = v.reshape(self.c.nlayer, nin)
+                if nin != nwno:
+                    if in_wno is None:
+                        raise Exception("cloud table has %d wavelengths, opacities %d: give "
+                                        "clouds(wavenumber=...) to regrid" % (nin, nwno))
+                    v = np.stack([np.interp(wno, in_wno, row) for row in v])   # wavelength.regrid
+            cld[k] = np.ascontiguousarray(v)
+        self.layer["cloud"] = cld
+
+    def as_dict(self):
+        return dict(level=self.level, layer=self.layer, warnings=self.warnings)

@@ -1,0 +1,298 @@
+"""API surface of the accelerated path: ``inputs`` / ``picaso()`` / ``inputs.spectrum()``
+(counterpart of the reference ``picaso/justdoit.py``: ``picaso`` :65-621, ``class inputs`` :1421,
+``phase_angle`` :1453, ``approx`` :4635, ``spectrum`` :4779).
+
+What is kept: the call sequence, keyword surface and option tables for the 1-D reflected / thermal
+spectrum with Toon two-stream radiative transfer, the routing of the 13 ``compute_opacity`` planes
+into the solvers (reflected: delta-scaled + ``_OG``; thermal: ``DTAU_OG, W0_no_raman, COSB_OG``),
+the return-dict keys and the post-processing formulas.  Quantities are plain cgs floats (the
+reference's astropy-unit arguments are not reproduced) and everything between ``get_opacities`` and
+``compress_disco`` stays in HBM.
+
+Out of scope here: chemistry, virga clouds, stellar grids (``star()`` takes a
+relative flux vector), xarray I/O, climate, retrievals, phase curves, 3-D regridding.
+"""
+import copy
+
+import numpy as np
+
+from . import _lib, disco, optics, resident
+from .atmsetup import ATMSETUP
+from .device import DeviceArray
+
+# option tables (reference justdoit.py:5512-5534, 5647-5658)
+def single_phase_options(printout=True):
+    return ["cahoy", "OTHG", "TTHG", "TTHG_ray"]
+
+
+def multi_phase_options(printout=True):
+    return ["N=2", "N=1", "isotropic"]
+
+
+def raman_options():
+    return ["oklopcic", "pollack", "none"]
+
+
+def toon_phase_coefficients(printout=True):
+    return ["quadrature", "eddington"]
+
+
+_DEFAULTS = {   # reference/config.json
+    "phase_angle": 0, "test_mode": None,
+    "planet": {"gravity": None, "radius": np.nan, "mass": np.nan},
+    "star": {"database": "nostar", "radius": "nostar", "semi_major": np.nan, "relative_flux": None},
+    "atmosphere": {"profile": None, "exclude_mol": 1},
+    "clouds": {"profile": None, "wavenumber": None, "do_holes": False},
+    "approx": {"p_reference": 1, "rt_method": "toon", "get_lvl_flux": False,
+               "rt_params": {"toon": {"toon_coefficients": 0, "multi_phase": 0, "single_phase": 3},
+                             "common": {"stream": 2, "delta_eddington": True, "raman": 2,
+                                        "TTHG_params": {"fraction": [1, -1, 2], "constant_back": -0.5,
+                                                        "constant_forward": 1}}}},
+}
+
+
+def opannection(filename_db, wave_range=None, resample=1, query_method="nearest",
+                rayleigh_opa=None):
+    """Open a monochromatic opacity DB (reference schema) as HBM-resident tables
+    (reference ``opannection``, justdoit.py:1296-1419, monochromatic branch)."""
+    return optics.RetrieveOpacities.from_sqlite(filename_db, wave_range=wave_range, resample=resample,
+                                                query_method=query_method, rayleigh_opa=rayleigh_opa)
+
+
+class inputs:
+    """Builder of the run configuration (reference ``class inputs``, justdoit.py:1421)."""
+
+    def __init__(self):
+        self.inputs = copy.deepcopy(_DEFAULTS)
+        self.phase_angle(0)
+
+    def phase_angle(self, phase=0, num_gangle=10, num_tangle=1, symmetry=False):
+        """Geometry (reference justdoit.py:1453-1605, without the symmetry reduction)."""
+        if (phase > 2 * np.pi) or (phase < 0):
+            raise Exception("Oops! you input a phase angle greater than 2*pi or less than 0. Please "
+                            "make sure your inputs are in radian units: 0<phase<2pi")
+        if (num_tangle == 1) or (num_gangle == 1):
+            if phase != 0:
+                raise Exception("The default PICASO disk integration is to use num_tangle=1 and "
+                                "num_gangle>1 ... please resubmit phase_angle with num_tange>10 and "
+                                "num_gangle>10.")
+            if num_gangle == 1:
+                raise Exception("num_gangle cannot be 1. Please resubmit your run with num_tangle=1, "
+                                "and increase number of Gauss points")
+            num_gangle = int(num_gangle / 2)
+            possible = np.array([5, 6, 7, 8])
+            num_gangle = int(possible[(np.abs(possible - num_gangle)).argmin()])
+            gangle, gweight, tangle, tweight = disco.get_angles_1d(num_gangle)
+            ng, nt = len(gangle), len(tangle)
+            ubar0, ubar1, cos_theta, lat, lon = disco.compute_disco(ng, nt, gangle, tangle, phase)
+            cos_theta = 1.0                                   # justdoit.py:1532
+        else:
+            if symmetry:
+                raise Exception("symmetry reduction is not built; use the full disk")
+            ng, nt = int(num_gangle), int(num_tangle)
+            gangle, gweight, tangle, tweight = disco.get_angles_3d(ng, nt)
+            ubar0, ubar1, cos_theta, lat, lon = disco.compute_disco(ng, nt, gangle, tangle, phase)
+        self.inputs["phase_angle"] = phase
+        self.inputs["disco"] = dict(num_gangle=ng, num_tangle=nt, gangle=gangle, gweight=gweight,
+                                    tangle=tangle, tweight=tweight, latitude=lat, longitude=lon,
+                                    cos_theta=cos_theta, ubar0=ubar0, ubar1=ubar1)
+
+    def gravity(self, gravity=None, radius=np.nan, mass=np.nan):
+        """Surface gravity in cm/s^2 (cgs; the reference takes astropy units, justdoit.py:1663)."""
+        if gravity is None:
+            if np.isnan(radius) or np.isnan(mass):
+                raise Exception("Need to specify gravity or radius and mass")
+            gravity = 6.6743e-8 * mass / radius ** 2
+        self.inputs["planet"].update(gravity=float(gravity), radius=radius, mass=mass)
+
+    def star(self, opannection=None, relative_flux=None, radius=np.nan, semi_major=np.nan):
+        """Stellar flux per wavelength bin on the opacity grid (``F0PI``).  ``None`` = 'nostar'
+        (F0PI = 1, reference justdoit.py:174-177).  Stellar-grid interpolation is out of scope."""
+        if relative_flux is None:
+            self.inputs["star"].update(database="nostar", radius="nostar", relative_flux=None)
+        else:
+            self.inputs["star"].update(database="user", radius=radius, semi_major=semi_major,
+                                       relative_flux=np.asarray(relative_flux, dtype=float))
+
+    def atmosphere(self, df=None, exclude_mol=1):
+        """Level profile: columns pressure (bar), temperature (K) and volume mixing ratios
+        (reference justdoit.py:1915)."""
+        if df is None or "pressure" not in df.keys() or "temperature" not in df.keys():
+            raise Exception("atmosphere(df=...) needs 'pressure' and 'temperature' columns")
+        self.inputs["atmosphere"]["profile"] = df
+        self.inputs["atmosphere"]["exclude_mol"] = exclude_mol
+        self.nlevel = len(df["pressure"])
+
+    def clouds(self, df=None, wavenumber=None, do_holes=False, fhole=None, fthin_cld=None):
+        """Cloud opd / w0 / g0 per (layer, wavelength) (reference justdoit.py:4126)."""
+        self.inputs["clouds"].update(profile=df, wavenumber=wavenumber, do_holes=do_holes,
+                                     fhole=fhole, fthin_cld=fthin_cld)
+
+    def surface_reflect(self, albedo, wavenumber=None, old_wavenumber=None):
+        """Surface reflectivity, scalar or per wavelength (reference justdoit.py:4092)."""
+        self.inputs["surface_reflect"] = albedo
+        self.inputs["hard_surface"] = 1
+
+    def approx(self, single_phase="TTHG_ray", multi_phase="N=2", delta_eddington=True,
+               raman="none", tthg_frac=[1, -1, 2], tthg_back=-0.5, tthg_forward=1, p_reference=1,
+               rt_method="toon", stream=2, toon_coefficients="quadrature", get_lvl_flux=False):
+        """String options -> the integers the solvers take (reference justdoit.py:4635-4738)."""
+        if rt_method != "toon":
+            raise Exception("rt_method='SH' is not built in this round; use 'toon'")
+        a = self.inputs["approx"]
+        a["get_lvl_flux"] = get_lvl_flux
+        a["rt_method"] = rt_method
+        a["p_reference"] = p_reference
+        c = a["rt_params"]["common"]
+        c["stream"] = 2
+        c["delta_eddington"] = delta_eddington
+        c["raman"] = raman_options().index(raman)
+        if not isinstance(tthg_frac, (list, np.ndarray)):
+            raise Exception("tthg_frac should be a list or ndarray of length=3")
+        if len(tthg_frac) != 3:
+            raise Exception("tthg_frac should be of length=3 so that : tthg_frac[0] + "
+                            "tthg_frac[1]*g_b^tthg_frac[2]")
+        c["TTHG_params"].update(fraction=list(tthg_frac), constant_back=tthg_back,
+                                constant_forward=tthg_forward)
+        t = a["rt_params"]["toon"]
+        t["toon_coefficients"] = toon_phase_coefficients(False).index(toon_coefficients)
+        t["multi_phase"] = multi_phase_options(False).index(multi_phase)
+        t["single_phase"] = single_phase_options(False).index(single_phase)
+
+    def spectrum(self, opacityclass, calculation="reflected", dimension="1d", full_output=False,
+                 plot_opacity=False, as_dict=True):
+        """Run the spectrum (reference justdoit.py:4779-4840)."""
+        if self.inputs["atmosphere"]["profile"] is None:
+            raise Exception("Need to set atmosphere profile with the atmosphere() function")
+        if self.inputs["planet"]["gravity"] is None:
+            raise Exception("Need to set gravity with the gravity() function")
+        if dimension != "1d":
+            raise Exception("dimension='3d' orchestration is not built; call "
+                            "picaso_amd.fluxes.get_reflected_3d / get_thermal_3d directly")
+        return picaso(self, opacityclass, dimension=dimension, calculation=calculation,
+                      full_output=full_output, plot_opacity=plot_opacity, as_dict=as_dict)
+
+
+def picaso(bundle, opacityclass, dimension="1d", calculation="reflected", full_output=False,
+           plot_opacity=False, as_dict=True):
+    """Spectrum driver (reference ``picaso()``, justdoit.py:65-621, 1-D Toon branch)."""
+    inp = bundle.inputs
+    opa = opacityclass
+    ctx = opa.ctx
+    wno, nwno = opa.wno, opa.nwno
+    ngauss = opa.ngauss
+    common = inp["approx"]["rt_params"]["common"]
+    toon = inp["approx"]["rt_params"]["toon"]
+    frac_a, frac_b, frac_c = common["TTHG_params"]["fraction"]
+    constant_back = common["TTHG_params"]["constant_back"]
+    constant_forward = common["TTHG_params"]["constant_forward"]
+    geom = inp["disco"]
+    ng, nt = geom["num_gangle"], geom["num_tangle"]
+    gweight, tweight = geom["gweight"], geom["tweight"]
+    cos_theta, ubar0, ubar1 = geom["cos_theta"], geom["ubar0"], geom["ubar1"]
+    if inp["star"]["database"] == "nostar":
+        F0PI = np.zeros(nwno) + 1.0                           # justdoit.py:174-175
+    else:
+        F0PI = inp["star"]["relative_flux"]
+    stellar = getattr(opa, "unshifted_stellar_spec", None)
+    if stellar is None:
+        stellar = F0PI
+    b_top = 0.0
+    sa = inp["star"]["semi_major"]
+    radius_star = inp["star"]["radius"]
+
+    atm = ATMSETUP(inp)
+    atm.surf_reflect = inp.get("surface_reflect", 0)
+    atm.hard_surface = inp.get("hard_surface", 0)
+    atm.wavenumber = wno
+    atm.planet.gravity = inp["planet"]["gravity"]
+    atm.planet.radius = inp["planet"]["radius"]
+    atm.planet.mass = inp["planet"]["mass"]
+    atm.get_lvl_flux = inp["approx"].get("get_lvl_flux", False)
+    atm.get_profile()
+    atm.get_mmw()
+    atm.get_density()
+    atm.get_altitude(p_reference=inp["approx"]["p_reference"])
+    atm.get_column_density()
+    atm.get_needed_continuum(opa.rayleigh_molecules, opa.avail_continuum)
+    atm.get_clouds(wno)
+    no_opa = [m for m in atm.molecules if m not in opa.molecules]
+    if no_opa:
+        atm.add_warnings("I found chemistry for these but I do not have computed individual line "
+                         "opacities (not including continuum) for: " + ",".join(no_opa))
+    atm.molecules = np.array([m for m in atm.molecules if m not in no_opa])
+    nlevel, nlayer = atm.c.nlevel, atm.c.nlayer
+
+    opa.get_opacities(atm, exclude_mol=inp["atmosphere"]["exclude_mol"])
+    planes = optics.compute_opacity_resident(
+        atm, opa, ngauss=ngauss, stream=common["stream"], delta_eddington=common["delta_eddington"],
+        test_mode=inp["test_mode"], raman=common["raman"], full_output=full_output)
+
+    rs = DeviceArray.from_host(np.zeros(nwno) + np.asarray(atm.surf_reflect, dtype=float), ctx)
+    d_f0 = DeviceArray.from_host(np.asarray(F0PI, dtype=float), ctx)
+    returns = {"wavenumber": wno}
+    if "reflected" in calculation:
+        xint = DeviceArray((ng, nt, nwno), ctx)
+        alb = DeviceArray((nwno,), ctx)
+        lvl = [DeviceArray((ng, nt, nlevel, nwno), ctx) for _ in range(4)] if atm.get_lvl_flux else None
+        _reflected(ctx, nlevel, nwno, ng, nt, planes, rs, ubar0, ubar1, cos_theta, d_f0,
+                   toon["single_phase"], toon["multi_phase"], frac_a, frac_b, frac_c, constant_back,
+                   constant_forward, toon["toon_coefficients"], b_top, xint, lvl, gweight, tweight, alb)
+        albedo = alb.to_host()
+        returns["albedo"] = albedo
+        if full_output:
+            atm.xint_at_top = xint.to_host()
+        if lvl is not None:
+            atm.lvl_output_reflected = dict(zip(("flux_minus", "flux_plus", "flux_minus_mdpt",
+                                                 "flux_plus_mdpt"), [a.to_host() for a in lvl]))
+        # Batalha+2019 eq. 18 (justdoit.py:552-553)
+        returns["bond_albedo"] = (np.trapezoid(x=1 / wno, y=albedo * stellar) /
+                                  np.trapezoid(x=1 / wno, y=stellar))
+        if (not np.isnan(sa)) and (not np.isnan(atm.planet.radius)):
+            returns["fpfs_reflected"] = albedo * (atm.planet.radius / sa) ** 2.0
+        else:
+            returns["fpfs_reflected"] = []
+    if "thermal" in calculation:
+        d_wno = DeviceArray.from_host(wno, ctx)
+        flux = DeviceArray((ng, nt, nwno), ctx)
+        disk = DeviceArray((nwno,), ctx)
+        resident.thermal_1d(ctx, nlevel, d_wno, nwno, ng, nt, atm.level["temperature"],
+                            planes["dtau_og"], planes["w0_no_raman"], planes["cosb_og"],
+                            atm.level["pressure"], ubar1, rs, atm.hard_surface, flux,
+                            gweight=gweight, tweight=tweight, flux_disk=disk)
+        thermal = disk.to_host()
+        returns["thermal"] = thermal
+        returns["thermal_unit"] = "erg/s/(cm^2)/(cm)"
+        returns["effective_temperature"] = (np.trapezoid(x=1 / wno[::-1], y=thermal[::-1]) / 5.67e-5) ** 0.25
+        if full_output:
+            atm.flux_at_top = flux.to_host()
+        if radius_star == "nostar":
+            returns["fpfs_thermal"] = ["No star mode for Brown Dwarfs was used"]
+        elif (not np.isnan(atm.planet.radius)) and (not np.isnan(radius_star)):
+            returns["fpfs_thermal"] = thermal / stellar * (atm.planet.radius / radius_star) ** 2.0
+        else:
+            returns["fpfs_thermal"] = []
+    if ("fpfs_reflected" in returns) and ("fpfs_thermal" in returns):
+        if (not isinstance(returns["fpfs_reflected"], list)) and (not isinstance(returns["fpfs_thermal"], list)):
+            returns["fpfs_total"] = returns["fpfs_thermal"] + returns["fpfs_reflected"]
+    if full_output:
+        returns["full_output"] = atm.as_dict() if as_dict else atm
+    return returns
+
+
+def _reflected(ctx, nlevel, nwno, ng, nt, planes, rs, ubar0, ubar1, cos_theta, F0PI, single_phase,
+               multi_phase, frac_a, frac_b, frac_c, constant_back, constant_forward,
+               toon_coefficients, b_top, xint, lvl, gweight, tweight, albedo):
+    import ctypes
+    from ._lib import check, f64, load, ptr
+    u0, u1 = f64(ubar0, (ng, nt)), f64(ubar1, (ng, nt))
+    gw, tw = f64(gweight), f64(tweight)
+    ci, cd = ctypes.c_int, ctypes.c_double
+    check(load().picaso_get_reflected_1d_dev(
+        ctx, ci(nlevel), ci(nwno), ctypes.c_long(nwno), ci(ng), ci(nt),
+        *[ptr(planes[k].addr) for k in resident.REFLECTED_PLANES], ptr(rs.addr), ptr(u0), ptr(u1),
+        cd(cos_theta), ptr(F0PI.addr), ci(single_phase), ci(multi_phase), cd(frac_a), cd(frac_b),
+        cd(frac_c), cd(constant_back), cd(constant_forward), ci(1), ci(1 if lvl else 0),
+        ci(toon_coefficients), cd(b_top), ptr(xint.addr),
+        *[ptr(l.addr) if lvl else None for l in (lvl or [None] * 4)], ptr(gw), ptr(tw),
+        ptr(albedo.addr)), ctx)

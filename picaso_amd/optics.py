@@ -1,0 +1,448 @@
+"""Opacity retrieval + mixing on the GPU (counterpart of the reference ``picaso/optics.py``).
+
+* ``RetrieveOpacities`` keeps the reference class's surface (``get_opacities(atm)``, ``wno``,
+  ``nwno``, ``molecules``, ``rayleigh_molecules``, ``gauss_wts`` ...; reference optics.py:1877-2402)
+  but loads the sqlite rows ONCE into HBM-resident tables (288 GB is room for a full
+  1060-point x R~15000 monochromatic DB); ``get_opacities`` only bracket-searches the (P,T) grid on
+  the host (a few hundred scalars) -- the per-(layer, wavelength) interpolation
+  ``10**(sum w log10 kappa) * N_A`` runs in ``k_opacity_gas``.
+* ``compute_opacity`` keeps the reference signature and 13-array return tuple (optics.py:26-431);
+  the gas / Rayleigh sums and the mixing / delta-Eddington algebra run in ``k_opacity_gas`` and
+  ``k_compute_opacity``.  ``compute_opacity_resident`` returns the planes as ``DeviceArray``s so that
+  ``picaso()`` can hand them straight to the solvers without a PCIe round trip.
+
+Database I/O (sqlite, ``np.load`` of blobs) and the Rayleigh cross sections are host-side data
+preparation, out of the accelerated path: Rayleigh ``sigma(nu)`` per species is
+supplied by the caller (``rayleigh_opa``) or read from an optional ``rayleigh`` table of the DB.
+"""
+import ctypes
+import io
+import math
+import sqlite3
+
+import numpy as np
+
+from . import _lib
+from ._lib import check, f64, load, ptr
+from .device import DeviceArray
+
+_ci, _cd = ctypes.c_int, ctypes.c_double
+AVOGADRO = 6.02214086e+23
+OUT_NAMES = ("dtau", "tau", "w0", "cosb", "ftau_cld", "ftau_ray", "gcos2", "dtau_og", "tau_og",
+             "w0_og", "cosb_og", "w0_no_raman", "f_deltaM")
+
+
+def _convert_array(text):
+    out = io.BytesIO(text)
+    out.seek(0)
+    return np.load(out).copy()
+
+
+def find_nearest(array, value):
+    return int((np.abs(np.asarray(array) - value)).argmin())
+
+
+class RetrieveOpacities:
+    """Monochromatic opacity tables resident in HBM (reference ``RetrieveOpacities``,
+    optics.py:1877-2402).  Build with ``from_sqlite`` (reference DB schema: tables ``header``,
+    ``molecular``, ``continuum``) or ``from_arrays``."""
+
+    def __init__(self, wno, pt_pairs, molecular, continuum, cia_temps, rayleigh_opa=None,
+                 query_method="nearest", relative_flux=None, ctx=None):
+        self.ctx = ctx if ctx is not None else _lib.context()
+        self.ngauss = 1                                     # optics.py:1946-1947
+        self.gauss_wts = np.array([1])
+        self.wno = f64(wno)
+        self.wave = 1e4 / self.wno
+        self.nwno = int(self.wno.size)
+        self.pt_pairs = sorted(set((int(i), float(p), float(t)) for i, p, t in pt_pairs),
+                               key=lambda x: x[0])          # optics.py:2019
+        temps = []
+        for _, _, t in self.pt_pairs:
+            if t not in temps:
+                temps.append(t)
+        self.temps = np.array(temps)
+        self.nc_p = np.array([sum(1 for x in self.pt_pairs if x[2] == t) for t in temps])
+        pres = []
+        for _, p, _ in self.pt_pairs:
+            if p not in pres:
+                pres.append(p)
+        self.pressures = np.array(pres)
+        self.p_log_grid = np.log10(self.pressures)          # optics.py:2023-2025
+        self.t_inv_grid = 1 / self.temps
+        self.molecules = np.array(sorted(molecular.keys()))
+        self.avail_continuum = sorted(continuum.keys())
+        self.cia_temps = np.unique(np.asarray(cia_temps, dtype=float))
+        if query_method not in ("nearest", "linear"):
+            raise Exception("Do not recognize query method for opacities: %s. Options are nearest "
+                            "or linear" % query_method)
+        self.query_method = query_method
+        self.relative_flux = relative_flux
+        self.raman_stellar_shifts = None
+        # ---- HBM-resident tables ----
+        ptid = [x[0] for x in self.pt_pairs]
+        self._row_of_ptid = {pid: r for r, pid in enumerate(ptid)}
+        self._mol_raw, self._mol_log = {}, {}
+        for m in self.molecules:
+            tab = np.stack([f64(molecular[m][pid]) for pid in ptid])          # (npt, nwno)
+            self._mol_raw[m] = DeviceArray.from_host(tab, self.ctx)
+            if query_method == "linear":                    # optics.py:2281-2288 done once
+                self._mol_log[m] = DeviceArray.from_host(
+                    np.log10(np.where(tab != 0, tab, 1e-50)), self.ctx)
+        self._cia = {}
+        for pair in self.avail_continuum:
+            tab = np.stack([f64(continuum[pair][t]) for t in self.cia_temps])
+            self._cia[pair] = DeviceArray.from_host(tab, self.ctx)
+        self.rayleigh_opa = {k: f64(v) for k, v in (rayleigh_opa or {}).items()}
+        self.rayleigh_molecules = list(self.rayleigh_opa.keys())
+        self._ray = {k: DeviceArray.from_host(v, self.ctx) for k, v in self.rayleigh_opa.items()}
+        self.molecular_opa, self.continuum_opa = {}, {}
+        self._plan = None
+
+    # ------------------------------------------------------------------------------------------
+    @classmethod
+    def from_sqlite(cls, db_filename, wave_range=None, resample=1, query_method="nearest",
+                    rayleigh_opa=None, ctx=None):
+        """Read a monochromatic opacity DB in the reference schema (optics.py:1998-2039, 2159-2239)."""
+        conn = sqlite3.connect(db_filename)
+        cur = conn.cursor()
+        cur.execute("SELECT wavenumber_grid FROM header")
+        wno = _convert_array(cur.fetchone()[0])[::resample]
+        wave = 1e4 / wno
+        loc = slice(None) if wave_range is None else np.where(
+            (wave > min(wave_range)) & (wave < max(wave_range)))
+        cur.execute("SELECT ptid, pressure, temperature FROM molecular")
+        pt_pairs = sorted(set(cur.fetchall()), key=lambda x: x[0])
+        molecular = {}
+        cur.execute("SELECT molecule, ptid, opacity FROM molecular")
+        for mol, pid, blob in cur.fetchall():
+            molecular.setdefault(mol, {})[int(pid)] = _convert_array(blob)[::resample][loc]
+        continuum, cia_temps = {}, set()
+        cur.execute("SELECT molecule, temperature, opacity FROM continuum")
+        for mol, t, blob in cur.fetchall():
+            continuum.setdefault(mol, {})[float(t)] = _convert_array(blob)[::resample][loc]
+            cia_temps.add(float(t))
+        if rayleigh_opa is None:
+            try:
+                cur.execute("SELECT molecule, opacity FROM rayleigh")
+                rayleigh_opa = {m: _convert_array(b)[::resample][loc] for m, b in cur.fetchall()}
+            except sqlite3.OperationalError:
+                rayleigh_opa = {}
+        conn.close()
+        return cls(wno[loc], pt_pairs, molecular, continuum, sorted(cia_temps), rayleigh_opa,
+                   query_method, ctx=ctx)
+
+    # ------------------------------------------------------------------------------------------
+    def find_needed_pts(self, tlayer, player):
+        """Bracketing (1/T, log10 P) table rows and weights per layer; restates the index logic
+        of reference optics.py:2048-2123 (ragged grid: ``nc_p`` pressures per temperature, row
+        index = sum(nc_p[:it]) + ip, pressure index clamped to ``nc_p[it_hi] - 3``)."""
+        t_inv = 1 / np.asarray(tlayer, dtype=float)
+        p_log = np.log10(np.asarray(player, dtype=float))
+        t_inv_grid, p_log_grid, nc_p = self.t_inv_grid, self.p_log_grid, self.nc_p
+        t_low_ind = []
+        for i in t_inv:
+            find = np.where(t_inv_grid > i)[0]
+            t_low_ind += [0] if len(find) == 0 else [find[-1]]
+        t_low_ind = np.array(t_low_ind)
+        t_low_ind[t_low_ind == (len(t_inv_grid) - 1)] = len(t_inv_grid) - 2
+        t_hi_ind = t_low_ind + 1
+        t_inv_low, t_inv_hi = t_inv_grid[t_low_ind], t_inv_grid[t_hi_ind]
+        p_low_ind = []
+        for i in p_log:
+            find = np.where(p_log_grid <= i)[0]
+            p_low_ind += [0] if len(find) == 0 else [find[-1]]
+        p_low_ind = np.array(p_low_ind)
+        for i in range(len(p_low_ind)):
+            p_low_ind[i] = min(p_low_ind[i], nc_p[t_hi_ind[i]] - 3)
+        p_log_low = p_log_grid[p_low_ind]
+        p_hi_ind = p_low_ind + 1
+        p_log_hi = p_log_grid[p_hi_ind]
+        t_low_10XX = np.array([sum(nc_p[0:i]) for i in t_low_ind])
+        t_hi_10XX = np.array([sum(nc_p[0:i]) for i in t_hi_ind])
+        t_interp = ((t_inv - t_inv_low) / (t_inv_hi - t_inv_low))[:, np.newaxis]
+        p_interp = ((p_log - p_log_low) / (p_log_hi - p_log_low))[:, np.newaxis]
+        return (t_interp, p_interp, t_low_10XX + p_low_ind, t_hi_10XX + p_low_ind,
+                t_low_10XX + p_hi_ind, t_hi_10XX + p_hi_ind)
+
+    def get_opacities(self, atmosphere, exclude_mol=1):
+        """Select table rows / weights for this atmosphere (reference optics.py:2241-2368).  The
+        per-wavelength arithmetic is deferred to the GPU (``compute_opacity``)."""
+        nlayer = atmosphere.c.nlayer
+        tlayer = np.asarray(atmosphere.layer["temperature"], dtype=float)
+        player = np.asarray(atmosphere.layer["pressure"], dtype=float) / atmosphere.c.pconv
+        molecules = [m for m in atmosphere.molecules]
+        cia_pairs = [k[0] + k[1] for k in atmosphere.continuum_molecules]
+        rows = np.zeros((len(molecules), nlayer, 4), dtype=np.int32)
+        wts = np.zeros((len(molecules), nlayer, 4))
+        if self.query_method == "linear":
+            t_i, p_i, i_ll, i_hl, i_lh, i_hh = self.find_needed_pts(tlayer, player)
+            t_i, p_i = t_i[:, 0], p_i[:, 0]
+            # order of the reference's four terms (optics.py:2290-2293)
+            r4 = np.stack([i_ll, i_hl, i_hh, i_lh], axis=1)
+            w4 = np.stack([(1 - t_i) * (1 - p_i), t_i * (1 - p_i), t_i * p_i, (1 - t_i) * p_i], axis=1)
+            # the reference addresses rows by ptid = 1 + index; tables are stored in ptid order
+            rows[:] = np.array([[self._row_of_ptid[1 + int(x)] for x in r] for r in r4])[None]
+            wts[:] = w4[None]
+            atmosphere.layer["pt_opa_index"] = 1 + np.unique(r4)
+        else:                                               # optics.py:2330-2332
+            ind_pt = [min(self.pt_pairs, key=lambda c: math.hypot(
+                np.log(c[1]) - np.log(coordinate[0]), c[2] - coordinate[1]))[0]
+                for coordinate in zip(player, tlayer)]
+            rows[:, :, 0] = np.array([self._row_of_ptid[i] for i in ind_pt])[None]
+            wts[:, :, 0] = 1.0
+            atmosphere.layer["pt_opa_index"] = ind_pt
+        fac = np.ones(len(molecules))
+        if exclude_mol != 1:
+            fac = np.array([exclude_mol[m] for m in molecules], dtype=float)
+        temps = np.unique(self.cia_temps)
+        cia_rows = np.array([find_nearest(temps, t) for t in tlayer], dtype=np.int32)   # :2298
+        self._plan = dict(molecules=molecules, rows=rows, wts=wts, fac=fac, cia_pairs=cia_pairs,
+                          cia_rows=cia_rows, nlayer=nlayer)
+        self.molecular_opa = _LazyPlanes(self, "mol")
+        self.continuum_opa = _LazyPlanes(self, "cia")
+
+    get_opacities_nearest = get_opacities
+
+    # materialise one (nlayer, nwno) opacity plane on request (debugging / drop-in access)
+    def _materialise(self, kind, key):
+        pl = self._plan
+        nlayer = pl["nlayer"]
+        one = np.ones((1, nlayer))
+        zero_g = DeviceArray((nlayer, self.nwno), self.ctx)
+        zero_r = DeviceArray((nlayer, self.nwno), self.ctx)
+        if kind == "mol":
+            m = pl["molecules"].index(key)
+            fac = one * pl["fac"][m] / AVOGADRO             # kernel multiplies by N_A * fac
+            tabs = [self._mol_log[key] if self.query_method == "linear" else self._mol_raw[key]]
+            _gas_call(self, nlayer, tabs, pl["rows"][m:m + 1], pl["wts"][m:m + 1], fac * AVOGADRO,
+                      [], None, None, [], None, zero_g, zero_r)
+        else:
+            _gas_call(self, nlayer, [], None, None, None, [self._cia[key]],
+                      pl["cia_rows"][None], one, [], None, zero_g, zero_r)
+        return zero_g.to_host()
+
+
+class _LazyPlanes(dict):
+    """``molecular_opa`` / ``continuum_opa`` dictionaries whose planes are computed on first access."""
+
+    def __init__(self, opa, kind):
+        super().__init__()
+        self._opa, self._kind = opa, kind
+        names = opa._plan["molecules"] if kind == "mol" else opa._plan["cia_pairs"]
+        self._names = list(names)
+
+    def keys(self):
+        return self._names
+
+    def __iter__(self):
+        return iter(self._names)
+
+    def __len__(self):
+        return len(self._names)
+
+    def __contains__(self, k):
+        return k in self._names
+
+    def __getitem__(self, k):
+        if not dict.__contains__(self, k):
+            if k not in self._names:
+                raise KeyError(k)
+            dict.__setitem__(self, k, self._opa._materialise(self._kind, k))
+        return dict.__getitem__(self, k)
+
+
+def _ptr_array(devs):
+    arr = (ctypes.c_void_p * max(1, len(devs)))()
+    for i, d in enumerate(devs):
+        arr[i] = d.addr
+    return ctypes.cast(arr, ctypes.POINTER(ctypes.POINTER(ctypes.c_double)))
+
+
+def _gas_call(opa, nlayer, mol_tabs, mol_rows, mol_wts, mol_fac, cont_tabs, cont_rows, cont_fac,
+              ray_tabs, ray_fac, taugas, tauray):
+    ip = ctypes.POINTER(ctypes.c_int)
+
+    def iarr(x):
+        return None if x is None else np.ascontiguousarray(x, dtype=np.int32)
+
+    mr, cr = iarr(mol_rows), iarr(cont_rows)
+    mw = f64(mol_wts) if mol_wts is not None else None
+    mf = f64(mol_fac) if mol_fac is not None else None
+    cf = f64(cont_fac) if cont_fac is not None else None
+    rf = f64(ray_fac) if ray_fac is not None else None
+    check(load().picaso_opacity_gas_dev(
+        opa.ctx, _ci(nlayer), _ci(opa.nwno), _ci(1 if opa.query_method == "linear" else 0),
+        _ci(len(mol_tabs)), _ptr_array(mol_tabs), mr.ctypes.data_as(ip) if mr is not None else None,
+        ptr(mw), ptr(mf), _ci(len(cont_tabs)), _ptr_array(cont_tabs),
+        cr.ctypes.data_as(ip) if cr is not None else None, ptr(cf), _ci(len(ray_tabs)),
+        _ptr_array(ray_tabs), ptr(rf), ptr(taugas.addr), ptr(tauray.addr)), opa.ctx)
+
+
+def _layer_factors(atm, opacityclass):
+    """Per-layer scalar coefficients of the TAUGAS / TAURAY sums (reference optics.py:144-277)."""
+    pl = opacityclass._plan
+    nlayer = atm.c.nlayer
+    tlevel = np.asarray(atm.level["temperature"], dtype=float)
+    plevel = np.asarray(atm.level["pressure"], dtype=float) / atm.c.pconv
+    tlayer = np.asarray(atm.layer["temperature"], dtype=float)
+    player_cgs = np.asarray(atm.layer["pressure"], dtype=float)
+    gravity = atm.planet.gravity / 100.0
+    mmw = np.asarray(atm.layer["mmw"], dtype=float)
+    colden = np.asarray(atm.layer["colden"], dtype=float)
+    mix = atm.layer["mixingratios"]
+
+    def x(m):
+        return np.asarray(mix[m].values if hasattr(mix[m], "values") else mix[m], dtype=float)
+
+    ACOEF = (tlayer / (tlevel[:-1] * tlevel[1:])) * (
+        tlevel[1:] * plevel[1:] - tlevel[:-1] * plevel[:-1]) / (plevel[1:] - plevel[:-1])
+    BCOEF = (tlayer / (tlevel[:-1] * tlevel[1:])) * (
+        tlevel[:-1] - tlevel[1:]) / (plevel[1:] - plevel[:-1])
+    COEF1 = atm.c.rgas * 273.15 ** 2 * .5E5 * (
+        ACOEF * (plevel[1:] ** 2 - plevel[:-1] ** 2) + BCOEF * (
+            2. / 3.) * (plevel[1:] ** 3 - plevel[:-1] ** 3)) / (
+        1.01325 ** 2 * gravity * tlayer * mmw)
+    cont_fac = []
+    for m in atm.continuum_molecules:
+        if m[0] == "H-" and m[1] == "bf":                  # optics.py:175-179
+            cont_fac.append(x(m[0]) * colden / (mmw * atm.c.amu))
+        elif m[0] == "H-" and m[1] == "ff":                # optics.py:187-193
+            cont_fac.append(player_cgs * x("H") * np.asarray(atm.layer["electrons"]) * colden /
+                            (tlayer * mmw * atm.c.amu * atm.c.k_b))
+        elif m[0] == "H2-" and m[1] == "":                 # optics.py:203-213
+            cont_fac.append(player_cgs * x("H2") * np.asarray(atm.layer["electrons"]) * colden /
+                            (mmw * atm.c.amu))
+        else:                                               # optics.py:224-227
+            cont_fac.append(COEF1 * x(m[0]) * x(m[1]))
+    mol_fac = [pl["fac"][i] * (colden * x(m) / mmw) for i, m in enumerate(pl["molecules"])]   # :246-249
+    ray_names = [m for m in atm.rayleigh_molecules if m in opacityclass._ray]
+    ray_fac = [colden * x(m) / mmw for m in ray_names]     # optics.py:265-271
+    shape = (0, nlayer)
+    return (np.array(mol_fac).reshape((-1, nlayer)) if mol_fac else np.zeros(shape),
+            np.array(cont_fac).reshape((-1, nlayer)) if cont_fac else np.zeros(shape),
+            ray_names, np.array(ray_fac).reshape((-1, nlayer)) if ray_fac else np.zeros(shape))
+
+
+def compute_opacity_resident(atmosphere, opacityclass, ngauss=1, stream=2, delta_eddington=True,
+                             test_mode=False, raman=0, fthin_cld=None, do_holes=False,
+                             full_output=False):
+    """GPU ``compute_opacity`` returning a dict of the 13 planes as DeviceArrays (no ngauss axis)."""
+    if ngauss != 1:
+        raise Exception("picaso_amd.compute_opacity: only monochromatic opacities (ngauss=1) "
+                        "are built; correlated-k is the next scope row (SURVEY.md 8f)")
+    atm, opa = atmosphere, opacityclass
+    ctx = opa.ctx
+    nlayer, nwno = atm.c.nlayer, opa.nwno
+    if opa._plan is None or opa._plan["nlayer"] != nlayer:
+        raise Exception("call opacityclass.get_opacities(atmosphere) first")
+    pl = opa._plan
+    mol_fac, cont_fac, ray_names, ray_fac = _layer_factors(atm, opa)
+    taugas, tauray = DeviceArray((nlayer, nwno), ctx), DeviceArray((nlayer, nwno), ctx)
+    mol_tabs = [(opa._mol_log if opa.query_method == "linear" else opa._mol_raw)[m]
+                for m in pl["molecules"]]
+    cont_tabs = [opa._cia[p] for p in pl["cia_pairs"]]
+    cont_rows = np.repeat(pl["cia_rows"][None], len(cont_tabs), axis=0) if cont_tabs else None
+    _gas_call(opa, nlayer, mol_tabs, pl["rows"] if mol_tabs else None,
+              pl["wts"] if mol_tabs else None, mol_fac if mol_tabs else None, cont_tabs, cont_rows,
+              cont_fac if cont_tabs else None, [opa._ray[m] for m in ray_names],
+              ray_fac if ray_names else None, taugas, tauray)
+    # ---- Raman factor (host: once per atmosphere, optics.py:285-306) ----
+    raman_plane, raman_const = None, 0.99999
+    if raman == 0:
+        rf = compute_raman(nwno, nlayer, opa.wno, opa.raman_stellar_shifts,
+                           np.asarray(atm.layer["temperature"], dtype=float), opa.raman_db["c"],
+                           opa.raman_db["ji"], opa.raman_db["deltanu"])
+        raman_plane = DeviceArray.from_host(np.minimum(rf, 0.99999), ctx)
+    elif raman == 1:
+        raise Exception("raman='pollack' needs the reference's raman_fortran.txt table; use "
+                        "'oklopcic' or 'none'")
+    cld = atm.layer["cloud"]
+    taucld = np.zeros((nlayer, nwno)) + np.asarray(cld["opd"], dtype=float)
+    if do_holes:
+        taucld = fthin_cld * taucld                         # optics.py:314-315
+    d_cld = DeviceArray.from_host(taucld, ctx)
+    d_w0 = DeviceArray.from_host(np.zeros((nlayer, nwno)) + np.asarray(cld["w0"], dtype=float), ctx)
+    d_g0 = DeviceArray.from_host(np.zeros((nlayer, nwno)) + np.asarray(cld["g0"], dtype=float), ctx)
+    tm = 0
+    if test_mode not in (None, False):                      # optics.py:372 (`test_mode != None`)
+        tm = 1 if test_mode == "rayleigh" else 2
+    out = {}
+    for k in OUT_NAMES:
+        rows = nlayer + 1 if k in ("tau", "tau_og") else nlayer
+        out[k] = DeviceArray((rows, nwno), ctx)
+    check(load().picaso_compute_opacity_dev(
+        ctx, _ci(nlayer), _ci(nwno), ptr(taugas.addr), ptr(tauray.addr), ptr(d_cld.addr),
+        ptr(d_w0.addr), ptr(d_g0.addr), ptr(raman_plane.addr) if raman_plane else None,
+        _cd(raman_const), _ci(tm), _ci(1 if delta_eddington else 0), _ci(stream),
+        *[ptr(out[k].addr) for k in OUT_NAMES]), ctx)
+    if full_output:
+        atmosphere.taugas = taugas.to_host()[:, :, None]
+        atmosphere.tauray = tauray.to_host()[:, :, None]
+        atmosphere.taucld = taucld[:, :, None]
+    return out
+
+
+def compute_opacity(atmosphere, opacityclass, ngauss=1, stream=2, delta_eddington=True,
+                    test_mode=False, raman=0, plot_opacity=False, full_output=False,
+                    return_mode=False, fthin_cld=None, do_holes=False):
+    """Reference signature and return tuple (optics.py:26-27, 423-431): 13 numpy arrays
+    ``(nlayer|nlevel, nwno, ngauss)``."""
+    if plot_opacity or return_mode:
+        raise Exception("plot_opacity / return_mode are plotting aids of the reference and are "
+                        "not part of the accelerated path")
+    d = compute_opacity_resident(atmosphere, opacityclass, ngauss=ngauss, stream=stream,
+                                 delta_eddington=delta_eddington, test_mode=test_mode, raman=raman,
+                                 fthin_cld=fthin_cld, do_holes=do_holes, full_output=full_output)
+    return tuple(d[k].to_host()[:, :, None] for k in OUT_NAMES)
+
+
+# ------------------------------------------------------------------------------------------------
+# Raman factor (host side, once per atmosphere): reference optics.py:434-581
+# ------------------------------------------------------------------------------------------------
+def partition_function(j, T):
+    """Statistical weight x Boltzmann factor of H2 rotational level J, restating reference
+    optics.py:524-549 as written there (including its j(j+1) factor appearing in both ``b_energy``
+    and the exponent, and the ortho/para weight 3 for odd J)."""
+    k = 1.38064852e-16
+    b = 60.853
+    c = 29979245800
+    h = 6.62607004e-27
+    b_energy = (b * (h) * (c) * j * (j + 1) / k)
+    if j % 2 == 0:
+        return (2.0 * j + 1.0) * np.exp(-0.5 * b_energy * j * (j + 1) / T)
+    return 3.0 * (2.0 * j + 1.0) * np.exp(-0.5 * b_energy * j * (j + 1) / T)
+
+
+def partition_sum(T):
+    """Partition sum truncated at J = 19 (reference optics.py:551-567)."""
+    Z = np.zeros(np.size(T))
+    for j in range(0, 20):
+        Z += partition_function(j, T)
+    return Z
+
+
+def j_fraction(j, T):
+    """Fraction of H2 in rotational state J at temperature T (reference optics.py:524-545)."""
+    return partition_function(j, T) / partition_sum(T)
+
+
+def compute_raman(nwno, nlayer, wno, stellar_shifts, tlayer, cross_sections, j_initial, deltanu):
+    """Oklopcic Raman factor (reference optics.py:434-494)."""
+    cross_sections = np.asarray(cross_sections, dtype=float)
+    j_initial = np.asarray(j_initial, dtype=int)
+    deltanu = np.asarray(deltanu, dtype=float)
+    w_shift = np.zeros((nlayer, nwno))
+    wo_shift = np.zeros((nlayer, nwno))
+    ray = np.zeros((nlayer, nwno))
+    j_at_temp = np.zeros((10, nlayer))
+    for i in range(10):
+        j_at_temp[i, :] = j_fraction(i, tlayer)
+    for i in range(cross_sections.shape[0]):
+        Q = cross_sections[i] / wno ** 3.0 / (wno + deltanu[i])
+        if deltanu[i] == 0:
+            ray += np.outer(j_at_temp[j_initial[i], :], Q)
+        else:
+            w_shift += np.outer(j_at_temp[j_initial[i], :], Q * stellar_shifts[:, i])
+            wo_shift += np.outer(j_at_temp[j_initial[i], :], Q)
+    return (ray + w_shift) / (ray + wo_shift)

@@ -250,3 +250,147 @@ if __name__ == "__main__":
         make_3d()
     if "geometry" in which:
         make_geometry()
+
+
+# ------------------------------------------------------------------------------------------------
+# opacity pre-stage: RetrieveOpacities.get_opacities[_nearest] + compute_opacity
+# ------------------------------------------------------------------------------------------------
+def make_optics():
+    """Synthetic monochromatic sqlite DB in the reference schema (committed next to the fixtures),
+    driven through the reference's own RetrieveOpacities + compute_opacity with a duck-typed
+    atmosphere."""
+    import sqlite3
+    import types
+    import pandas as pd
+    optics = ref_shim.load("optics")
+    rayleigh = ref_shim.load("rayleigh")
+    rng = np.random.default_rng(4242)
+    nwno = 40
+    wno = np.linspace(4000.0, 25000.0, nwno)
+    temps = [100.0, 300.0, 700.0, 1500.0, 3000.0]
+    press = [1e-6, 1e-4, 1e-2, 1.0, 100.0, 500.0]
+    mols = ["H2O", "CH4", "H2"]
+    cont_pairs = ["H2H2", "H2He", "H2CH4"]
+    cia_temps = [75.0, 200.0, 500.0, 1000.0, 2000.0, 4000.0]
+    db = os.path.join(HERE, "synthetic_opacities.db")
+    if os.path.exists(db):
+        os.remove(db)
+
+    def adapt(arr):
+        out = io.BytesIO()
+        np.save(out, arr)
+        out.seek(0)
+        return sqlite3.Binary(out.read())
+    import io
+    sqlite3.register_adapter(np.ndarray, adapt)
+    sqlite3.register_adapter(np.int64, int)
+    conn = sqlite3.connect(db)
+    cur = conn.cursor()
+    cur.execute("CREATE TABLE header (id INTEGER PRIMARY KEY, pressure_unit VARCHAR, temperature_unit "
+                "VARCHAR, wavenumber_grid array, continuum_unit VARCHAR, molecular_unit VARCHAR)")
+    cur.execute("CREATE TABLE molecular (id INTEGER PRIMARY KEY, ptid INTEGER, molecule VARCHAR, "
+                "pressure FLOAT, temperature FLOAT, opacity array)")
+    cur.execute("CREATE TABLE continuum (id INTEGER PRIMARY KEY, molecule VARCHAR, temperature FLOAT, "
+                "opacity array)")
+    cur.execute("CREATE TABLE rayleigh (id INTEGER PRIMARY KEY, molecule VARCHAR, opacity array)")
+    cur.execute("INSERT INTO header (pressure_unit, temperature_unit, wavenumber_grid, continuum_unit, "
+                "molecular_unit) VALUES (?,?,?,?,?)", ("bar", "kelvin", wno, "cm-1 amagat-2", "cm2/molecule"))
+    ptid = 0
+    for t in temps:
+        for p in press:
+            ptid += 1
+            for m in mols:
+                lg = (-24.0 + 2.0 * np.sin(wno / 2500.0 + mols.index(m)) + 0.4 * np.log10(p)
+                      + 0.8 * np.log10(t / 300.0) + 0.2 * rng.standard_normal(nwno))
+                k = 10.0 ** lg
+                if m == "CH4":
+                    k[::7] = 0.0            # exercise the zero -> 1e-50 floor (optics.py:2282)
+                cur.execute("INSERT INTO molecular (ptid, molecule, pressure, temperature, opacity) "
+                            "VALUES (?,?,?,?,?)", (ptid, m, p, t, k))
+    for pair in cont_pairs:
+        for t in cia_temps:
+            k = 10.0 ** (-7.0 + np.cos(wno / 4000.0 + cont_pairs.index(pair)) + 0.3 * np.log10(t / 300.0))
+            cur.execute("INSERT INTO continuum (molecule, temperature, opacity) VALUES (?,?,?)",
+                        (pair, t, k))
+    ray = rayleigh.Rayleigh(wno)
+    ray_opa = {m: ray.compute_sigma(m) for m in ("H2", "He", "CH4", "H2O")}
+    for m, v in ray_opa.items():
+        cur.execute("INSERT INTO rayleigh (molecule, opacity) VALUES (?,?)", (m, v))
+    conn.commit()
+    conn.close()
+
+    nlevel = 31
+    nlayer = nlevel - 1
+    plevel_bar = np.logspace(-5.5, 1.8, nlevel)
+    tlevel = 150.0 + 1200.0 * ((np.log10(plevel_bar) + 5.5) / 7.3) ** 2
+    mix = {"H2": np.full(nlevel, 0.84), "He": np.full(nlevel, 0.155),
+           "H2O": np.linspace(1e-4, 3e-3, nlevel), "CH4": np.linspace(4e-4, 1e-3, nlevel)}
+    gravity = 2500.0
+    weights = {"H2": 2.01588, "He": 4.002602, "H2O": 18.01528, "CH4": 16.04246}
+    cld_opd = np.zeros((nlayer, nwno))
+    cld_opd[14:20] = 0.3 * (1.0 + 0.2 * np.sin(wno / 3000.0))
+    cld_w0 = np.zeros((nlayer, nwno))
+    cld_w0[14:20] = 0.93
+    cld_g0 = np.zeros((nlayer, nwno))
+    cld_g0[14:20] = 0.65
+    shifts_n = None
+
+    def make_atm():
+        atm = types.SimpleNamespace()
+        c = types.SimpleNamespace(nlayer=nlayer, nlevel=nlevel, pconv=1e6, k_b=1.380649e-16,
+                                  amu=1.66053906660e-24, rgas=8.31446261815324)
+        atm.c = c
+        atm.planet = types.SimpleNamespace(gravity=gravity)
+        p = plevel_bar * 1e6
+        atm.level = {"pressure": p, "temperature": tlevel}
+        lay_mix = pd.DataFrame({k: 0.5 * (v[1:] + v[:-1]) for k, v in mix.items()})
+        mmw_lvl = sum(mix[k] * weights[k] for k in mix)
+        atm.layer = {"pressure": np.sqrt(p[1:] * p[:-1]), "temperature": 0.5 * (tlevel[1:] + tlevel[:-1]),
+                     "mmw": 0.5 * (mmw_lvl[1:] + mmw_lvl[:-1]), "colden": (p[1:] - p[:-1]) / gravity,
+                     "electrons": np.zeros(nlayer), "mixingratios": lay_mix,
+                     "cloud": {"opd": cld_opd.copy(), "w0": cld_w0.copy(), "g0": cld_g0.copy()}}
+        atm.molecules = np.array(["H2O", "CH4", "H2"])
+        atm.continuum_molecules = [["H2", "H2"], ["H2", "He"], ["H2", "CH4"]]
+        atm.rayleigh_molecules = ["H2", "He", "CH4", "H2O"]
+        return atm
+
+    store = {"in/plevel_bar": plevel_bar, "in/tlevel": tlevel, "in/gravity": np.array(gravity),
+             "in/cld_opd": cld_opd, "in/cld_w0": cld_w0, "in/cld_g0": cld_g0, "in/wno": wno}
+    for k, v in mix.items():
+        store["in/mix/" + k] = v
+    names = ("dtau", "tau", "w0", "cosb", "ftau_cld", "ftau_ray", "gcos2", "dtau_og", "tau_og",
+             "w0_og", "cosb_og", "w0_no_raman", "f_deltaM")
+    raman_file = os.path.join(ref_shim.REF_ROOT, "reference", "opacities", "raman.txt")
+    for qm in ("nearest", "linear"):
+        opa = optics.RetrieveOpacities(db, raman_file, query_method=qm)
+        if shifts_n is None:
+            shifts_n = 1.0 + 0.05 * rng.standard_normal((nwno, len(opa.raman_db)))
+            store["in/raman_shifts"] = shifts_n
+            store["in/raman_c"] = opa.raman_db["c"].values
+            store["in/raman_ji"] = opa.raman_db["ji"].values
+            store["in/raman_deltanu"] = opa.raman_db["deltanu"].values
+        opa.raman_stellar_shifts = shifts_n
+        atm = make_atm()
+        opa.get_opacities(atm)
+        for m in atm.molecules:
+            store["%s/molecular_opa/%s" % (qm, m)] = opa.molecular_opa[m]
+        for pr in ("H2H2", "H2He", "H2CH4"):
+            store["%s/continuum_opa/%s" % (qm, pr)] = opa.continuum_opa[pr]
+        store["%s/pt_opa_index" % qm] = np.asarray(atm.layer["pt_opa_index"])
+        for de, stream, raman, tm in ((True, 2, 2, None), (False, 2, 2, None), (True, 4, 0, None),
+                                      (True, 2, 2, "rayleigh"), (False, 2, 2, "constant_tau")):
+            atm = make_atm()
+            opa.get_opacities(atm)
+            out = optics.compute_opacity(atm, opa, ngauss=1, stream=stream, delta_eddington=de,
+                                         test_mode=tm, raman=raman)
+            key = "%s/de%d_s%d_r%d_tm%s" % (qm, int(de), stream, raman, tm or "none")
+            for nm, arr in zip(names, out):
+                store[key + "/" + nm] = np.asarray(arr)[:, :, 0]
+    path = os.path.join(HERE, "optics.npz")
+    np.savez_compressed(path, **store)
+    print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024), "and", db,
+          "%.1f KB" % (os.path.getsize(db) / 1024))
+
+
+if __name__ == "__main__" and (("optics" in sys.argv[1:]) or not sys.argv[1:]):
+    make_optics()

@@ -1,0 +1,89 @@
+"""Known-answer check owned by the reference: Dlugach & Yanovitskij (1974) Table XXI geometric
+albedos (tests/golden/DLUGACH_TEST.csv is the reference's own data file,
+reference/base_cases/testing/DLUGACH_TEST.csv), driven as the reference's
+model_compare.dlugach_test does (model_compare.py:109-207): 60 levels, constant-tau test mode
+(opd 0.2 per layer), OTHG single scattering, N=1 multiple scattering, no delta-Eddington, zero
+phase, 5 Gauss angles, albedo at the last wavelength.
+
+Toon89 two-stream is a few-% method (the reference's notebook
+docs/notebooks/H_radiativetransfer/1_AnalyzingApproximationsReflectedLightToon.py expects that):
+the table pins the physics, the oracle pins the arithmetic.
+  * CPU: the oracle reproduces the table to <= 0.06 absolute (observed max 0.046) for
+    w0 <= 0.95.  The table is for SEMI-INFINITE atmospheres; the reference's set-up has a total
+    optical depth of only 59 x 0.2 = 11.8, which for w0 -> 1 and forward-peaked phase functions is
+    far from semi-infinite (oracle 0.31 vs table 0.64 at w0 = 0.999999, g = 0.9 -- the reference's
+    own code gives the same), so those columns are only used for the GPU-vs-oracle comparison.
+  * GPU: inputs.spectrum() through the opacity tables and kernels equals the oracle to 1e-8 on
+    the whole 6 x 9 grid.
+"""
+import csv
+import os
+
+import numpy as np
+import pytest
+
+from helpers import GOLDEN
+
+NLEVEL = 60
+G0S = ("0", "0.50", "0.75", "0.80", "0.85", "0.90")
+
+
+def table():
+    with open(os.path.join(GOLDEN, "DLUGACH_TEST.csv")) as fh:
+        rows = list(csv.reader(fh))
+    w0s = rows[0][1:]
+    return w0s, {r[0]: [float(x) for x in r[1:]] for r in rows[1:]}
+
+
+def oracle_albedo(oracle, w0, g0, nwno=4, opd=0.2):
+    from picaso_amd import disco
+    from picaso_amd import synthetic as syn
+    nlayer = NLEVEL - 1
+    sc = syn.delta_scale(syn.constant_scene(nlayer, nwno, opd, w0, g0), delta_eddington=False)
+    g, gw, t, tw = disco.get_angles_1d(5)
+    u0, u1, ct, _, _ = disco.compute_disco(5, 1, g, t, 0.0)
+    x, _ = oracle.get_reflected_1d(NLEVEL, None, nwno, 5, 1, sc["dtau"], sc["tau"], sc["w0"], sc["cosb"],
+                                   sc["gcos2"], sc["ftau_cld"], sc["ftau_ray"], sc["dtau_og"],
+                                   sc["tau_og"], sc["w0_og"], sc["cosb_og"], 0.0, u0, u1, 1.0,
+                                   np.ones(nwno), 1, 1, 1.0, -1.0, 2.0, -0.5, 1.0)
+    return oracle.compress_disco(nwno, 1.0, x, gw, tw, np.ones(nwno))
+
+
+def test_oracle_reproduces_table(oracle):
+    w0s, tab = table()
+    worst = 0.0
+    for g0 in G0S:
+        for j, w in enumerate(w0s):
+            w0 = 0.999999 if float(w) == 1.0 else float(w)
+            if w0 > 0.95:
+                continue
+            alb = oracle_albedo(oracle, w0, float(g0))[-1]
+            worst = max(worst, abs(alb - tab[g0][j]))
+    assert worst < 0.06, worst
+
+
+@pytest.mark.gpu
+def test_gpu_spectrum_matches_oracle_and_table(oracle):
+    from picaso_amd import justdoit as jdi
+    opa = jdi.opannection(os.path.join(GOLDEN, "synthetic_opacities.db"))
+    w0s, tab = table()
+    case = jdi.inputs()
+    case.phase_angle(0)
+    case.gravity(gravity=2500.0)
+    p = np.logspace(-6, 3, NLEVEL)
+    case.atmosphere(df={"pressure": p, "temperature": p * 0 + 1000, "H2": p * 0 + 0.99,
+                        "H2O": p * 0 + 0.01})
+    case.approx(raman="none", single_phase="OTHG", multi_phase="N=1", delta_eddington=False)
+    case.inputs["test_mode"] = "constant_tau"
+    worst_o, worst_t = 0.0, 0.0
+    for g0 in G0S:
+        for j, w in enumerate(w0s):
+            w0 = 0.999999 if float(w) == 1.0 else float(w)
+            case.clouds(df={"opd": 0.2, "w0": w0, "g0": float(g0)})
+            alb = case.spectrum(opa, calculation="reflected")["albedo"]
+            ref = oracle_albedo(oracle, w0, float(g0), nwno=opa.nwno)
+            worst_o = max(worst_o, float(np.max(np.abs(alb - ref) / ref)))
+            if w0 <= 0.95:
+                worst_t = max(worst_t, abs(alb[-1] - tab[g0][j]))
+    assert worst_o < 1e-8, worst_o
+    assert worst_t < 0.06, worst_t

@@ -1,0 +1,164 @@
+"""Opacity pre-stage: (i) CPU -- oracle/optics_oracle.py against the reference-generated
+tests/golden/optics.npz; (ii) GPU -- picaso_amd.optics (HBM-resident tables read from the
+synthetic sqlite DB in the reference schema, k_opacity_gas + k_compute_opacity) against the same
+fixture, and an end-to-end inputs.spectrum() run against the oracle chain."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import GOLDEN, rel_err
+
+NAMES = ("dtau", "tau", "w0", "cosb", "ftau_cld", "ftau_ray", "gcos2", "dtau_og", "tau_og", "w0_og",
+         "cosb_og", "w0_no_raman", "f_deltaM")
+DB = os.path.join(GOLDEN, "synthetic_opacities.db")
+WEIGHTS = {"H2": 2.01588, "He": 4.002602, "H2O": 18.01528, "CH4": 16.04246}
+CASES = ("de1_s2_r2_tmnone", "de0_s2_r2_tmnone", "de1_s4_r0_tmnone", "de1_s2_r2_tmrayleigh",
+         "de0_s2_r2_tmconstant_tau")
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return np.load(os.path.join(GOLDEN, "optics.npz"))
+
+
+def _close(a, b, tol=1e-12):
+    a, b = np.asarray(a), np.asarray(b)
+    both_nan = np.isnan(a) & np.isnan(b)
+    den = np.where(np.abs(b) > 0, np.abs(b), 1.0)
+    err = np.where(both_nan, 0.0, np.abs(a - b) / den)
+    return float(np.nanmax(err)) < tol and np.array_equal(np.isnan(a), np.isnan(b))
+
+
+def _case_args(key):
+    de, s, r, tm = key.split("_", 3)
+    return bool(int(de[2])), int(s[1]), int(r[1]), (None if tm == "tmnone" else tm[2:])
+
+
+def test_oracle_compute_opacity(gold):
+    """oracle mixing algebra vs the reference: rebuild TAUGAS/TAURAY from the reference's own
+    molecular/continuum planes, then compare all 13 outputs."""
+    from oracle import optics_oracle as oo
+    from picaso_amd import optics as px
+    wno = gold["in/wno"]
+    nlevel = len(gold["in/tlevel"])
+    p = gold["in/plevel_bar"] * 1e6
+    t = gold["in/tlevel"]
+    mix = {k: 0.5 * (gold["in/mix/" + k][1:] + gold["in/mix/" + k][:-1]) for k in WEIGHTS}
+    mmw_l = sum(gold["in/mix/" + k] * WEIGHTS[k] for k in WEIGHTS)
+    mmw = 0.5 * (mmw_l[1:] + mmw_l[:-1])
+    g = float(gold["in/gravity"])
+    colden = (p[1:] - p[:-1]) / g
+    tlayer = 0.5 * (t[1:] + t[:-1])
+    plev = p / 1e6
+    A = (tlayer / (t[:-1] * t[1:])) * (t[1:] * plev[1:] - t[:-1] * plev[:-1]) / (plev[1:] - plev[:-1])
+    B = (tlayer / (t[:-1] * t[1:])) * (t[:-1] - t[1:]) / (plev[1:] - plev[:-1])
+    COEF1 = 8.31446261815324 * 273.15 ** 2 * .5E5 * (A * (plev[1:] ** 2 - plev[:-1] ** 2) + B * (2. / 3.) * (
+        plev[1:] ** 3 - plev[:-1] ** 3)) / (1.01325 ** 2 * (g / 100.0) * tlayer * mmw)
+    import sqlite3
+    conn = sqlite3.connect(DB)
+    ray = {m: px._convert_array(b) for m, b in conn.execute("SELECT molecule, opacity FROM rayleigh")}
+    conn.close()
+    for qm in ("nearest", "linear"):
+        taugas = np.zeros((nlevel - 1, len(wno)))
+        for a, b in (("H2", "H2"), ("H2", "He"), ("H2", "CH4")):
+            taugas += gold["%s/continuum_opa/%s" % (qm, a + b)] * (COEF1 * mix[a] * mix[b])[:, None]
+        for m in ("H2O", "CH4", "H2"):
+            taugas += gold["%s/molecular_opa/%s" % (qm, m)] * (colden * mix[m] / mmw)[:, None]
+        tauray = np.zeros_like(taugas)
+        for m in ("H2", "He", "CH4", "H2O"):
+            tauray += ray[m][None, :] * (colden * mix[m] / mmw)[:, None]
+        for key in CASES:
+            de, s, r, tm = _case_args(key)
+            if r == 0:
+                rf = px.compute_raman(len(wno), nlevel - 1, wno, gold["in/raman_shifts"], tlayer,
+                                      gold["in/raman_c"], gold["in/raman_ji"], gold["in/raman_deltanu"])
+                rf = np.minimum(rf, 0.99999)
+            else:
+                rf = 0.99999
+            out = oo.compute_opacity(taugas, tauray, gold["in/cld_opd"], gold["in/cld_w0"],
+                                     gold["in/cld_g0"], rf, stream=s, delta_eddington=de, test_mode=tm)
+            for nm, arr in zip(NAMES, out):
+                assert _close(arr, gold["%s/%s/%s" % (qm, key, nm)], 1e-11), (qm, key, nm)
+
+
+# ------------------------------------------------------------------------------------------------
+def _bundle(gold, px_just, tm, de, stream_unused, raman):
+    case = px_just.inputs()
+    case.phase_angle(0)
+    case.gravity(gravity=float(gold["in/gravity"]))
+    prof = {"pressure": gold["in/plevel_bar"], "temperature": gold["in/tlevel"]}
+    for k in ("H2", "He", "H2O", "CH4"):
+        prof[k] = gold["in/mix/" + k]
+    case.atmosphere(df=prof)
+    case.clouds(df={"opd": gold["in/cld_opd"], "w0": gold["in/cld_w0"], "g0": gold["in/cld_g0"]})
+    case.approx(raman=["oklopcic", "pollack", "none"][raman], delta_eddington=de)
+    case.inputs["test_mode"] = tm
+    return case
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("qm", ["nearest", "linear"])
+def test_gpu_compute_opacity(gold, qm):
+    from picaso_amd import justdoit as jdi
+    from picaso_amd import optics as px
+    from picaso_amd.atmsetup import ATMSETUP
+    opa = jdi.opannection(DB, query_method=qm)
+    assert opa.nwno == len(gold["in/wno"])
+    opa.raman_stellar_shifts = gold["in/raman_shifts"]
+    opa.raman_db = {"c": gold["in/raman_c"], "ji": gold["in/raman_ji"], "deltanu": gold["in/raman_deltanu"]}
+    for key in CASES:
+        de, s, r, tm = _case_args(key)
+        case = _bundle(gold, jdi, tm, de, s, r)
+        atm = ATMSETUP(case.inputs)
+        atm.planet.gravity = case.inputs["planet"]["gravity"]
+        atm.get_profile(); atm.get_mmw(); atm.get_altitude(); atm.get_column_density()
+        atm.get_needed_continuum(opa.rayleigh_molecules, opa.avail_continuum)
+        atm.get_clouds(opa.wno)
+        atm.molecules = np.array([m for m in atm.molecules if m in opa.molecules])
+        opa.get_opacities(atm)
+        if key == CASES[0]:
+            for m in ("H2O", "CH4", "H2"):
+                assert _close(opa.molecular_opa[m], gold["%s/molecular_opa/%s" % (qm, m)], 1e-11), m
+            for pr in ("H2H2", "H2He", "H2CH4"):
+                assert _close(opa.continuum_opa[pr], gold["%s/continuum_opa/%s" % (qm, pr)], 1e-13), pr
+        out = px.compute_opacity(atm, opa, ngauss=1, stream=s, delta_eddington=de, test_mode=tm, raman=r)
+        assert len(out) == 13
+        for nm, arr in zip(NAMES, out):
+            assert arr.shape[2] == 1
+            assert _close(arr[:, :, 0], gold["%s/%s/%s" % (qm, key, nm)], 1e-10), (qm, key, nm)
+
+
+@pytest.mark.gpu
+def test_gpu_spectrum_end_to_end(gold, oracle):
+    """inputs.spectrum(): opacity tables -> compute_opacity -> Toon reflected + thermal -> disk
+    integration entirely on the GPU, against the chain [reference compute_opacity planes from the
+    fixture -> CPU oracle solvers]."""
+    from picaso_amd import disco
+    from picaso_amd import justdoit as jdi
+    opa = jdi.opannection(DB, query_method="linear")
+    case = _bundle(gold, jdi, None, True, 2, 2)
+    case.surface_reflect(0.2)
+    out = case.spectrum(opa, calculation="reflected+thermal", full_output=True)
+    key = "linear/de1_s2_r2_tmnone"
+    P = {nm: gold["%s/%s" % (key, nm)] for nm in NAMES}
+    nlevel, nwno = P["tau"].shape
+    g, gw, t, tw = disco.get_angles_1d(5)
+    u0, u1, ct, _, _ = disco.compute_disco(5, 1, g, t, 0.0)
+    x, _ = oracle.get_reflected_1d(nlevel, opa.wno, nwno, 5, 1, P["dtau"], P["tau"], P["w0"], P["cosb"],
+                                   P["gcos2"], P["ftau_cld"], P["ftau_ray"], P["dtau_og"], P["tau_og"],
+                                   P["w0_og"], P["cosb_og"], 0.2, u0, u1, 1.0, np.ones(nwno), 3, 0,
+                                   1.0, -1.0, 2.0, -0.5, 1.0)
+    alb = oracle.compress_disco(nwno, 1.0, x, gw, tw, np.ones(nwno))
+    assert rel_err(out["albedo"], alb) < 1e-8
+    f, _ = oracle.get_thermal_1d(nlevel, opa.wno, nwno, 5, 1, gold["in/tlevel"], P["dtau_og"],
+                                 P["w0_no_raman"], P["cosb_og"], gold["in/plevel_bar"] * 1e6, u1,
+                                 np.full(nwno, 0.2), 1, opa.wno * 0, 0)
+    th = oracle.compress_thermal(nwno, f, gw, tw)
+    assert rel_err(out["thermal"], th) < 1e-8
+    wno = opa.wno
+    assert np.isclose(out["bond_albedo"], np.trapezoid(x=1 / wno, y=alb) / np.trapezoid(x=1 / wno, y=alb * 0 + 1))
+    assert np.isclose(out["effective_temperature"],
+                      (np.trapezoid(x=1 / wno[::-1], y=th[::-1]) / 5.67e-5) ** 0.25)
+    assert set(("wavenumber", "albedo", "bond_albedo", "fpfs_reflected", "thermal", "thermal_unit",
+                "effective_temperature", "fpfs_thermal", "full_output")) <= set(out.keys())
