@@ -1,0 +1,97 @@
+#!/usr/bin/env python
+"""Secondary measurements quoted in DESIGN.md (run on the GPU box): thermal (BASELINE configs[1]),
+3-D reflected facets, level-flux kernels, opacity pre-stage, and the PCIe-inclusive host-pointer
+call of the headline workload.  HIP-event timed on the library's stream, inputs resident in HBM
+unless stated."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from picaso_amd import _lib, device, disco, fluxes, resident  # noqa: E402
+from picaso_amd import synthetic as syn  # noqa: E402
+from picaso_amd.device import DeviceArray  # noqa: E402
+
+TTHG = (1.0, -1.0, 2.0, -0.5, 1.0)
+
+
+def timeit(fn, ctx, reps=10, warm=2):
+    for _ in range(warm):
+        fn()
+    device.sync(ctx)
+    device.timer_start(ctx)
+    for _ in range(reps):
+        fn()
+    return device.timer_stop(ctx) / reps
+
+
+def main():
+    ctx = _lib.context(0)
+    out = {}
+    g, gw, t, tw = disco.get_angles_1d(5)
+    u0, u1, ct, _, _ = disco.compute_disco(5, 1, g, t, 0.0)
+    nlayer = 90
+    for nwno in (10000, 100000):
+        sc = syn.make_scene(nlayer, nwno, seed=5)
+        d = resident.upload_scene(sc, ("dtau_og", "w0_no_raman", "cosb_og", "wno"), ctx=ctx)
+        rs = DeviceArray.from_host(np.zeros(nwno), ctx)
+        flux = DeviceArray((5, 1, nwno), ctx)
+        disk = DeviceArray((nwno,), ctx)
+        ms = timeit(lambda: resident.thermal_1d(ctx, nlayer + 1, d["wno"], nwno, 5, 1, sc["tlevel"],
+                                                d["dtau_og"], d["w0_no_raman"], d["cosb_og"],
+                                                sc["plevel"], u1, rs, 0, flux, gweight=gw, tweight=tw,
+                                                flux_disk=disk), ctx)
+        ab = 8 * nwno * (3 * nlayer + 3 + 5 + 1)
+        out["thermal_%d" % nwno] = dict(ms=ms, spectra_per_s=1e3 / ms, GBps=ab / ms / 1e6,
+                                        algorithmic_bytes=ab)
+        if nwno == 100000:
+            # PCIe-inclusive: host-pointer drop-in call of the headline reflected workload
+            planes = [sc[k] for k in resident.REFLECTED_PLANES]
+            t0 = time.perf_counter()
+            fluxes.get_reflected_1d(nlayer + 1, sc["wno"], nwno, 5, 1, *planes, 0.0, u0, u1, 1.0,
+                                    np.ones(nwno), 3, 0, *TTHG)
+            t1 = time.perf_counter()
+            fluxes.get_reflected_1d(nlayer + 1, sc["wno"], nwno, 5, 1, *planes, 0.0, u0, u1, 1.0,
+                                    np.ones(nwno), 3, 0, *TTHG)
+            t2 = time.perf_counter()
+            out["reflected_host_pointers_1e5"] = dict(first_call_s=t1 - t0, second_call_s=t2 - t1,
+                                                      spectra_per_s=1.0 / (t2 - t1),
+                                                      note="includes np.zeros of the 4 level-flux arrays "
+                                                           "(1.46 GB) the reference signature returns")
+            # level fluxes (climate caller shape: one angle)
+            dd = resident.upload_scene(sc, resident.REFLECTED_PLANES, ctx=ctx)
+    # 3-D facets: 8x8 facets, 90 layers, 4096 wavelengths (same per-facet planes replicated)
+    ng = nt = 8
+    nw3 = 4096
+    sc = syn.make_scene(nlayer, nw3, seed=7)
+    gg, ggw, tt, ttw = disco.get_angles_3d(ng, nt)
+    v0, v1, cth, _, _ = disco.compute_disco(ng, nt, gg, tt, np.pi / 3)
+    dev3 = {}
+    for k in resident.REFLECTED_PLANES:
+        dev3[k] = DeviceArray.from_host(np.repeat(sc[k][:, :, None], ng * nt, axis=2), ctx)
+    f0 = DeviceArray.from_host(np.ones(nw3), ctx)
+    rs3 = DeviceArray.from_host(np.zeros(nw3), ctx)
+    x3 = DeviceArray((ng, nt, nw3), ctx)
+    a3 = DeviceArray((nw3,), ctx)
+    import ctypes
+    from picaso_amd._lib import check, f64, load, ptr
+    ci, cd = ctypes.c_int, ctypes.c_double
+
+    def run3d():
+        check(load().picaso_get_reflected_3d_dev(
+            ctx, ci(nlayer + 1), ci(nw3), ci(ng), ci(nt), *[ptr(dev3[k].addr) for k in resident.REFLECTED_PLANES],
+            ptr(rs3.addr), ptr(f64(v0)), ptr(f64(v1)), cd(cth), ptr(f0.addr), ci(0), ci(0),
+            *[cd(v) for v in TTHG], ptr(x3.addr), ptr(f64(ggw)), ptr(f64(ttw)), ptr(a3.addr)), ctx)
+    ms = timeit(run3d, ctx, reps=5)
+    ab = 8 * nw3 * ng * nt * (9 * nlayer + 2 * (nlayer + 1) + 1)
+    out["reflected_3d_8x8_%d" % nw3] = dict(ms=ms, GBps=ab / ms / 1e6, algorithmic_bytes=ab,
+                                            facet_columns_per_s=nw3 * ng * nt / ms * 1e3)
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
