@@ -18,8 +18,8 @@ _dp = ctypes.POINTER(ctypes.c_double)
 
 def build(force=False):
     so = os.path.join(_HERE, "libpicaso_oracle.so")
-    src = os.path.join(_HERE, "picaso_oracle.c")
-    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("picaso_oracle.c", "sh_oracle.c", "Makefile")]
+    if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s", "-B"])
     return so
 
@@ -153,3 +153,49 @@ def compress_thermal(nwno, flux_at_top, gweight, tweight):
     lib().orc_compress_thermal(ctypes.c_size_t(int(np.prod(inner))), _p(x), _p(gw),
                                ctypes.c_int(len(gw)), _p(tw), ctypes.c_int(len(tw)), _p(out))
     return out
+
+
+def get_reflected_SH(nlevel, nwno, numg, numt, dtau, tau, w0, cosb, ftau_cld, ftau_ray, f_deltaM,
+                     dtau_og, tau_og, w0_og, cosb_og, surf_reflect, ubar0, ubar1, cos_theta, F0PI,
+                     w_single_form, w_multi_form, psingle_form, w_single_rayleigh, w_multi_rayleigh,
+                     psingle_rayleigh, frac_a, frac_b, frac_c, constant_back, constant_forward,
+                     stream, b_top=0, flx=0, single_form=0):
+    """Signature of reference ``fluxes.get_reflected_SH`` (fluxes.py:2675-2679).  Like the
+    reference, the TTHG branch multiplies ``f_deltaM`` IN PLACE once per angle (fluxes.py:2823-2824)
+    -- the caller's array is modified when it is a float64 C-contiguous array."""
+    if flx:
+        raise Exception("oracle: flx=1 (layer fluxes) is not restated")
+    keep = [_a(p) for p in (dtau, tau, w0, cosb, ftau_cld, ftau_ray)]
+    fd = f_deltaM if (isinstance(f_deltaM, np.ndarray) and f_deltaM.dtype == np.float64
+                      and f_deltaM.flags.c_contiguous) else _a(f_deltaM).copy()
+    og = [_a(p) for p in (dtau_og, tau_og, w0_og, cosb_og)]
+    sr, f0 = _per_wave(surf_reflect, nwno), _per_wave(F0PI, nwno)
+    u0, u1 = _a(ubar0), _a(ubar1)
+    xint = np.zeros((numg, numt, nwno))
+    ci, cd = ctypes.c_int, ctypes.c_double
+    rc = lib().orc_reflected_SH(
+        ci(nlevel), ci(nwno), ci(numg), ci(numt), *[_p(k) for k in keep], _p(fd), *[_p(k) for k in og],
+        _p(sr), _p(u0), _p(u1), cd(cos_theta), _p(f0), ci(w_single_form), ci(w_multi_form),
+        ci(psingle_form), ci(w_single_rayleigh), ci(w_multi_rayleigh), ci(psingle_rayleigh),
+        cd(frac_a), cd(frac_b), cd(frac_c), cd(constant_back), cd(constant_forward), ci(stream),
+        cd(b_top), ci(single_form), _p(xint))
+    _check(rc, "reflected_SH")
+    return xint, np.zeros((numg, numt, stream * nlevel, nwno))
+
+
+def get_thermal_SH(nlevel, wno, nwno, numg, numt, tlevel, dtau, tau, w0, cosb, dtau_og, tau_og,
+                   w0_og, w0_no_raman, cosb_og, plevel, ubar1, surf_reflect, stream, hard_surface,
+                   flx=0):
+    """Signature of reference ``fluxes.get_thermal_SH`` (fluxes.py:2979-2981)."""
+    if flx:
+        raise Exception("oracle: flx=1 is broken in the reference (fluxes.py:3102) and not restated")
+    arrs = [_a(p) for p in (wno, tlevel, dtau, tau, w0, cosb, cosb_og, plevel, ubar1)]
+    sr = _per_wave(surf_reflect, nwno)
+    xint = np.zeros((numg, numt, nwno))
+    ci = ctypes.c_int
+    wno_, tl, dt, ta, w0_, cb, cbo, pl, u1 = arrs
+    rc = lib().orc_thermal_SH(ci(nlevel), _p(wno_), ci(nwno), ci(numg), ci(numt), _p(tl), _p(dt),
+                              _p(ta), _p(w0_), _p(cb), _p(cbo), _p(pl), _p(u1), _p(sr), ci(stream),
+                              ci(int(hard_surface)), _p(xint))
+    _check(rc, "thermal_SH")
+    return xint, np.zeros((numg, numt, stream * nlevel, nwno))

@@ -1,0 +1,699 @@
+// Spherical-harmonics (SH2 / SH4) reflected light and thermal emission -- gfx950.
+//
+// Replaces fluxes.get_reflected_SH / get_thermal_SH with setup_2_stream_fluxes,
+// setup_4_stream_fluxes and solve_4_stream_banded (reference picaso/fluxes.py:2675-3628).  The
+// reference assembles a banded matrix (5 diagonals for SH2, 11 for SH4: 3.2 GB at 1e5 x 90) per
+// angle and calls LAPACK dgbsv per wavelength.  Here nothing is assembled: per layer the stream
+// coefficients split into NB = stream/2 decaying-mode unknowns d and NB growing-mode unknowns
+// u = E v (E = diag exp(-lambda_m dtau), so v is the bounded value at the layer bottom); with the
+// NB x NB blocks Mn, Pl of the reference's boundary rows the moment fluxes are
+//     top :  Fmn = Mn d + Pl E v + zmn_dn      Fpl = Pl d + Mn E v + zpl_dn
+//     bot :  Fmn = Mn E d + Pl v + zmn_up      Fpl = Pl E d + Mn v + zpl_up
+// (SH4: Mn = [[p1mn,p2mn],[q1mn,q2mn]], Pl = [[p1pl,p2pl],[q1pl,q2pl]], fluxes.py:3427-3543;
+//  SH2: Mn = Q1, Pl = Q2, fluxes.py:3251-3301).  One top-down sweep carries the relation
+// d_i = delta_i - R_i v_i that everything above imposes on layer i and the TOA functional
+// J = kappa + zeta.v_i of the source-function integrals (fluxes.py:2898-2970, 3105-3182); the
+// surface rows fix v_{n-1}.  Only decaying exponentials appear, the blocks are the physical
+// reflection operators, and no pivoting across layers is needed: tools/sh_sweep_numpy.py agrees
+// with the reference's pivoted LAPACK solve to 2e-13 on thin, thick (35-clipped) and conservative
+// columns (tests/test_single_sweep_numpy.py).  One lane per wavelength, every plane read once per
+// angle, coalesced in the reference's (nlayer, nwno) layout.
+//
+// Reference quirk kept: in the TTHG branch f_deltaM is multiplied in place once per angle
+// (fluxes.py:2823-2824), so angle k (in (g,t) order) sees f_deltaM * fac^(k+1).
+#include "common.hpp"
+#include "device_math.hpp"
+
+namespace pz {
+
+struct SHArgs {
+    int nlayer, nwno, stream;
+    long pitch;
+    const double *dtau, *tau, *w0, *ftau_cld, *ftau_ray, *f_deltaM, *dtau_og, *tau_og, *w0_og, *cosb_og;
+    const double *surf_reflect, *F0PI;
+    double u0, u1, cos_theta;
+    int w_single_form, w_multi_form, psingle_form, w_single_rayleigh, w_multi_rayleigh,
+        psingle_rayleigh, single_form;
+    double frac_a, frac_b, frac_c, constant_back, constant_forward, b_top;
+    int fd_power;            // angle index + 1 (compounded f_deltaM), 1 when compounding is off
+    // thermal
+    const double *wno, *tlevel, *plevel;     // device (nwno) / (nlevel) / (nlevel)
+    int hard_surface, use_ff;                // use_ff: cosb != cosb_og somewhere (fluxes.py:3072-3075)
+    double *xint;                            // (nwno) for this angle
+};
+
+__device__ __forceinline__ double clip35(double x) { return fmin(fmax(x, -35.0), 35.0); }   // slice_rav
+
+template <int NB>
+struct Blk {
+    double m[NB][NB];
+};
+
+template <int NB>
+__device__ __forceinline__ Blk<NB> mm(const Blk<NB> &A, const Blk<NB> &B)
+{
+    Blk<NB> C;
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            double s = 0.0;
+#pragma unroll
+            for (int k = 0; k < NB; ++k) s += A.m[i][k] * B.m[k][j];
+            C.m[i][j] = s;
+        }
+    return C;
+}
+
+template <int NB>
+__device__ __forceinline__ void mv(const Blk<NB> &A, const double (&x)[NB], double (&y)[NB])
+{
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < NB; ++k) s += A.m[i][k] * x[k];
+        y[i] = s;
+    }
+}
+
+template <int NB>
+__device__ __forceinline__ void mtv(const Blk<NB> &A, const double (&x)[NB], double (&y)[NB])   // A^T x
+{
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < NB; ++k) s += A.m[k][i] * x[k];
+        y[i] = s;
+    }
+}
+
+template <int NB>
+__device__ __forceinline__ Blk<NB> inv(const Blk<NB> &A)
+{
+    Blk<NB> R;
+    if (NB == 1) {
+        R.m[0][0] = 1.0 / A.m[0][0];
+    } else {
+        const double idet = 1.0 / (A.m[0][0] * A.m[NB - 1][NB - 1] - A.m[0][NB - 1] * A.m[NB - 1][0]);
+        R.m[0][0] = A.m[NB - 1][NB - 1] * idet;
+        R.m[NB - 1][NB - 1] = A.m[0][0] * idet;
+        R.m[0][NB - 1] = -A.m[0][NB - 1] * idet;
+        R.m[NB - 1][0] = -A.m[NB - 1][0] * idet;
+    }
+    return R;
+}
+
+template <int NB>
+__device__ __forceinline__ Blk<NB> scale_cols(const Blk<NB> &A, const double (&e)[NB])   // A diag(e)
+{
+    Blk<NB> R;
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) R.m[i][j] = A.m[i][j] * e[j];
+    return R;
+}
+
+template <int NB>
+__device__ __forceinline__ double dot(const double (&a)[NB], const double (&b)[NB])
+{
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) s += a[i] * b[i];
+    return s;
+}
+
+__device__ __forceinline__ void legP4(double mu, double (&P)[4])   // fluxes.py:3639-3646, l = 0..3
+{
+    P[0] = 1;
+    P[1] = mu;
+    P[2] = (3 * mu * mu - 1) / 2;
+    P[3] = (5 * mu * mu * mu - 3 * mu) / 2;
+}
+
+// Per-layer mode structure from the a_l coefficients.
+template <int NB>
+struct Modes {
+    double lam[NB], E[NB];
+    Blk<NB> Mn, Pl;
+    double cA[2 * NB][2 * NB];   // A[j][m] of fluxes.py:3601-3605 (SH4); unused for SH2
+    double q;                    // SH2: lam/a1
+    double beta, gama;           // SH4 quartic coefficients (particular solution)
+};
+
+__device__ __forceinline__ void modes_sh4(const double (&a)[4], double dt, Modes<2> &M)
+{
+    const double a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3];
+    M.beta = a0 * a1 + 4 * a0 * a3 / 9 + a2 * a3 / 9;                 // fluxes.py:3388-3391
+    M.gama = a0 * a1 * a2 * a3 / 9;
+    const double disc = sqrt(M.beta * M.beta - 4 * M.gama);
+    const double l1 = sqrt((M.beta + disc) / 2), l2 = sqrt((M.beta - disc) / 2);
+    M.lam[0] = l1;
+    M.lam[1] = l2;
+    const double R1 = -a0 / l1, R2 = -a0 / l2;                        // :3423-3425
+    const double Q1 = 0.5 * (a0 * a1 / (l1 * l1) - 1), Q2 = 0.5 * (a0 * a1 / (l2 * l2) - 1);
+    const double S1 = -3 / (2 * a3) * (a0 * a1 / l1 - l1), S2 = -3 / (2 * a3) * (a0 * a1 / l2 - l2);
+    const double tp = 2 * PI;
+    M.Pl.m[0][0] = (0.5 + R1 + 5 * Q1 / 8) * tp;                      // p1pl  :3427-3434
+    M.Pl.m[0][1] = (0.5 + R2 + 5 * Q2 / 8) * tp;                      // p2pl
+    M.Pl.m[1][0] = (-0.125 + 5 * Q1 / 8 + S1) * tp;                   // q1pl
+    M.Pl.m[1][1] = (-0.125 + 5 * Q2 / 8 + S2) * tp;                   // q2pl
+    M.Mn.m[0][0] = (0.5 - R1 + 5 * Q1 / 8) * tp;                      // p1mn
+    M.Mn.m[0][1] = (0.5 - R2 + 5 * Q2 / 8) * tp;                      // p2mn
+    M.Mn.m[1][0] = (-0.125 + 5 * Q1 / 8 - S1) * tp;                   // q1mn
+    M.Mn.m[1][1] = (-0.125 + 5 * Q2 / 8 - S2) * tp;                   // q2mn
+    M.E[0] = fexp(-clip35(l1 * dt));                                  // :3418-3421
+    M.E[1] = fexp(-clip35(l2 * dt));
+    // A[j][m], m = (d0, u0, d1, u1)
+    const double Aj[4][4] = {{1, 1, 1, 1}, {R1, -R1, R2, -R2}, {Q1, Q1, Q2, Q2}, {S1, -S1, S2, -S2}};
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) M.cA[j][m] = Aj[j][m];
+}
+
+__device__ __forceinline__ void modes_sh2(const double (&a)[2], double dt, Modes<1> &M)
+{
+    const double lam = sqrt(a[0] * a[1]);                             // fluxes.py:3245
+    M.lam[0] = lam;
+    M.q = lam / a[1];                                                 // :3251
+    M.Mn.m[0][0] = (0.5 + M.q) * 2 * PI;                              // Q1
+    M.Pl.m[0][0] = (0.5 - M.q) * 2 * PI;                              // Q2
+    M.E[0] = fexp(-clip35(lam * dt));                                 // :3246-3248
+}
+
+// One kernel for stream 2 / 4 (NB = 1 / 2), reflected / thermal.
+template <int NB, bool THERMAL>
+__global__ __launch_bounds__(256) void k_sh(const SHArgs a)
+{
+    constexpr int NS = 2 * NB;      // stream
+    const long w = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (w >= a.nwno) return;
+    const int n = a.nlayer;
+    const long pitch = a.pitch;
+    const double u0 = a.u0, u1 = a.u1, ct = a.cos_theta;
+    const double F = THERMAL ? 0.0 : a.F0PI[w], rs = a.surf_reflect[w];
+    double Pu0[4], Pu1[4];
+    legP4(-u0, Pu0);
+    legP4(u1, Pu1);
+    const double mus = THERMAL ? 0.0 : (u1 + u0) / (u1 * u0);
+    const double iu1 = 1.0 / u1;
+
+    // thermal: Planck at the levels (fluxes.py:3058-3060)
+    const double wn = THERMAL ? a.wno[w] : 0.0;
+    double Bn = THERMAL ? planck_lambda(a.tlevel[0], wn) : 0.0;
+    const double B_top = Bn;
+    double b1_last = 0.0;
+
+    double T = 1.0, kappa = 0.0;
+    double zeta[NB], delta[NB];
+    Blk<NB> R;
+    // previous layer
+    Blk<NB> pMn, pPl, pME, pPE;
+    double p_zmn_up[NB], p_zpl_up[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) { zeta[i] = delta[i] = p_zmn_up[i] = p_zpl_up[i] = 0.0; }
+
+    for (int i = 0; i < n; ++i) {
+        const long o = (long)i * pitch + w;
+        const double dt = a.dtau[o], w0 = a.w0[o], cbo = a.cosb_og[o];
+        // ---- Legendre weights of the phase function ----
+        double wsg[NS], wmu[NS];
+#pragma unroll
+        for (int l = 0; l < NS; ++l) { wsg[l] = 1.0; wmu[l] = 1.0; }
+        double psing = 0.0;
+        if (!THERMAL) {
+            const double fc = a.ftau_cld[o], fr = a.ftau_ray[o];
+            // f_deltaM as angle k of the reference sees it: its TTHG branch multiplies the array in
+            // place by `fac` once per angle (:2823-2824), so the OTHG branch of angle k reads
+            // f_deltaM fac^k (the aliasing is live when one form is OTHG and the other TTHG) and
+            // the TTHG branch f_deltaM fac^(k+1).
+            double fd_prev = a.f_deltaM[o], fd = fd_prev, f = 0.0, gf = 0.0, gb = 0.0;
+            const bool tthg = (a.w_single_form == 0 || a.w_multi_form == 0);
+            if (tthg) {
+                gf = a.constant_forward * cbo;
+                gb = a.constant_back * cbo;
+                f = a.frac_a + a.frac_b * pow_frac(gb, a.frac_c);
+                double cfs = 1.0, cbs = 1.0;
+#pragma unroll
+                for (int l = 0; l < NS; ++l) { cfs *= a.constant_forward; cbs *= a.constant_back; }
+                const double fac = (f * cfs + (1 - f) * cbs);
+                for (int p = 1; p < a.fd_power; ++p) fd_prev *= fac;
+                fd = fd_prev * fac;
+            }
+            if (a.w_single_form == 1 || a.w_multi_form == 1) {               // OTHG :2811-2817
+                double cl = 1.0;
+#pragma unroll
+                for (int l = 1; l < NS; ++l) {
+                    cl *= cbo;
+                    const double ww = ((2 * l + 1) * cl - (2 * l + 1) * fd_prev) / (1 - fd_prev);
+                    if (a.w_single_form == 1) wsg[l] = ww;
+                    if (a.w_multi_form == 1) wmu[l] = ww;
+                }
+            }
+            if (tthg) {                                                      // TTHG :2819-2831
+                double gfl = 1.0, gbl = 1.0;
+#pragma unroll
+                for (int l = 1; l < NS; ++l) {
+                    gfl *= gf;
+                    gbl *= gb;
+                    const double ww = ((2 * l + 1) * (f * gfl + (1 - f) * gbl) - (2 * l + 1) * fd) / (1 - fd);
+                    if (a.w_single_form == 0) wsg[l] = ww;
+                    if (a.w_multi_form == 0) wmu[l] = ww;
+                }
+            }
+            if (a.w_single_rayleigh == 1) {                                  // :2833-2836
+#pragma unroll
+                for (int l = 1; l < NS; ++l) wsg[l] *= fc;
+                if (NS == 4) wsg[2] += 0.5 * fr;
+            }
+            if (a.w_multi_rayleigh == 1) {                                   // :2837-2840
+#pragma unroll
+                for (int l = 1; l < NS; ++l) wmu[l] *= fc;
+                if (NS == 4) wmu[2] += 0.5 * fr;
+            }
+            if (a.single_form == 0) {                                        // :2843-2855
+                if (a.psingle_form == 1) psing = hg_term(cbo, ct);
+                else if (a.psingle_form == 0) {
+                    const double gf = a.constant_forward * cbo, gb = a.constant_back * cbo;
+                    const double f = a.frac_a + a.frac_b * pow_frac(gb, a.frac_c);
+                    psing = f * hg_term(gf, ct) + (1 - f) * hg_term(gb, ct);
+                }
+                if (a.psingle_rayleigh == 1) psing = fc * psing + fr * (0.75 * (1 + ct * ct));
+            } else {                                                         // legendre form :2954-2957
+#pragma unroll
+                for (int l = 0; l < NS; ++l) psing += wsg[l] * Pu0[l] * Pu1[l];
+            }
+        } else {                                                             // thermal :3072-3083
+            const double ff = a.use_ff ? ((NS == 4) ? cbo * cbo * cbo * cbo : cbo * cbo) : 0.0;
+            double cl = 1.0;
+#pragma unroll
+            for (int l = 0; l < NS; ++l) {
+                wmu[l] = (2 * l + 1) * (cl - ff) / (1 - ff);
+                cl *= cbo;
+            }
+        }
+        double al[NS], bl[NS];
+#pragma unroll
+        for (int l = 0; l < NS; ++l) {                                       // :2858-2860, :3083
+            al[l] = (2 * l + 1) - w0 * wmu[l];
+            bl[l] = THERMAL ? 0.0 : (F * (w0 * wsg[l])) * Pu0[l] / (4 * PI);
+        }
+        // ---- modes ----
+        Modes<NB> M;
+        if constexpr (NB == 2) modes_sh4(al, dt, M);
+        else modes_sh2(al, dt, M);
+        // ---- particular solution at the layer top / bottom ----
+        double eta[NS];
+        double zmn_dn[NB], zpl_dn[NB], zmn_up[NB], zpl_up[NB];
+        double B0 = 0.0, b1 = 0.0;
+        if (!THERMAL) {
+            double zpl[NB], zmn[NB];
+            const double tau_t = a.tau[o], tau_b = a.tau[o + pitch];
+            double ed, eu;
+            if constexpr (NB == 2) {                                         // :3397-3416, :3441-3450
+                const double x = 1 / u0, x2 = x * x;
+                const double iDel = 1.0 / (9 * (x2 * x2 - M.beta * x2 + M.gama));
+                const double a0 = al[0], a1 = al[1], a2 = al[2], a3 = al[3];
+                const double b0 = bl[0], b1_ = bl[1], b2 = bl[2], b3 = bl[3];
+                eta[0] = ((a1 * b0 - b1_ * x) * (a2 * a3 - 9 * x2) + 2 * (a3 * b2 - 2 * a3 * b0 - 3 * b3 * x) * x2) * iDel;
+                eta[1] = ((a0 * b1_ - b0 * x) * (a2 * a3 - 9 * x2) - 2 * a0 * (a3 * b2 - 3 * b3 * x) * x) * iDel;
+                eta[2] = ((a3 * b2 - 3 * b3 * x) * (a0 * a1 - x2) - 2 * a3 * (a0 * b1_ - b0 * x) * x) * iDel;
+                eta[3] = ((a2 * b3 - 3 * b2 * x) * (a0 * a1 - x2) + 2 * (3 * a0 * b1_ - 2 * a0 * b3 - 3 * b0 * x) * x2) * iDel;
+                zpl[0] = (eta[0] / 2 + eta[1] + 5 * eta[2] / 8) * 2 * PI;
+                zmn[0] = (eta[0] / 2 - eta[1] + 5 * eta[2] / 8) * 2 * PI;
+                zpl[1] = (-eta[0] / 8 + 5 * eta[2] / 8 + eta[3]) * 2 * PI;
+                zmn[1] = (-eta[0] / 8 + 5 * eta[2] / 8 - eta[3]) * 2 * PI;
+                ed = fexp(-clip35(tau_t / u0));
+                eu = fexp(-clip35(tau_b / u0));
+            } else {                                                         // :3240-3265
+                const double x = 1 / u0;
+                const double iDel = 1.0 / (x * x - al[0] * al[1]);
+                eta[0] = (bl[1] * x - al[1] * bl[0]) * iDel;
+                eta[1] = (bl[0] * x - al[0] * bl[1]) * iDel;
+                zmn[0] = (0.5 * eta[0] - eta[1]) * 2 * PI;
+                zpl[0] = (0.5 * eta[0] + eta[1]) * 2 * PI;
+                ed = fexp(-tau_t / u0);
+                eu = fexp(-tau_b / u0);
+            }
+#pragma unroll
+            for (int r = 0; r < NB; ++r) {
+                zmn_dn[r] = zmn[r] * ed; zpl_dn[r] = zpl[r] * ed;
+                zmn_up[r] = zmn[r] * eu; zpl_up[r] = zpl[r] * eu;
+            }
+        } else {                                                             // :3451-3459 / :3266-3270
+            B0 = Bn;
+            Bn = planck_lambda(a.tlevel[i + 1], wn);
+            b1 = (Bn - B0) / dt;
+            b1_last = b1;
+            const double om = 1 - w0;
+            zmn_dn[0] = om / al[0] * (B0 / 2 - b1 / al[1]) * 2 * PI;
+            zpl_dn[0] = om / al[0] * (B0 / 2 + b1 / al[1]) * 2 * PI;
+            zmn_up[0] = om / al[0] * (B0 / 2 - b1 / al[1] + b1 * dt / 2) * 2 * PI;
+            zpl_up[0] = om / al[0] * (B0 / 2 + b1 / al[1] + b1 * dt / 2) * 2 * PI;
+            if constexpr (NB == 2) {
+                zmn_dn[1] = zpl_dn[1] = -0.5 * om / (4 * al[0]) * (B0) * 2 * PI;
+                zmn_up[1] = zpl_up[1] = -0.5 * om / (4 * al[0]) * (B0 + b1 * dt) * 2 * PI;
+            }
+#pragma unroll
+            for (int l = 0; l < NS; ++l) eta[l] = 0.0;
+        }
+        const Blk<NB> ME = scale_cols(M.Mn, M.E), PE = scale_cols(M.Pl, M.E);
+
+        // ---- functional weights (source-function integrals) ----
+        double gd[NB], gv[NB], c;
+        {
+            const double e_u1 = THERMAL ? 0.0 : 0.0;
+            (void)e_u1;
+            double cm[NS];
+            if constexpr (NB == 2) {
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    double s = 0.0;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) s = s + wmu[j] * Pu1[j] * M.cA[j][m];
+                    cm[m] = s;
+                }
+            } else {                                                         // :2916-2917, :3124-3125
+                cm[0] = (wmu[0] - wmu[1] * Pu1[1] * M.q);
+                cm[1] = (wmu[0] + wmu[1] * Pu1[1] * M.q);
+            }
+            const double scale = THERMAL ? 2 * PI : 1.0;                     // :3167 vs :2961
+            const double tw = T * iu1 * w0 * scale;
+#pragma unroll
+            for (int r = 0; r < NB; ++r) {
+                const double alpha = iu1 + M.lam[r], beta = iu1 - M.lam[r];
+                const double ha = (1 - fexp(-clip35(alpha * dt))) / alpha;   // :2929-2937
+                const double hb = (1 - fexp(-clip35(beta * dt))) / beta;
+                gd[r] = tw * cm[2 * r] * ha;
+                gv[r] = tw * cm[2 * r + 1] * hb * M.E[r];
+            }
+            if (!THERMAL) {
+                const double exptrm_mus = (1 - fexp(-clip35(mus * dt))) / mus;            // :2901-2905
+                const double tau_mu = a.tau[o] * 1 / u0;
+                const double expon1 = exptrm_mus * fexp(-clip35(tau_mu));
+                double Nsum = 0.0;
+#pragma unroll
+                for (int l = 0; l < NS; ++l) Nsum += wmu[l] * Pu1[l] * eta[l] * expon1;   // :2919-2920, 2945-2948
+                const double single = a.w0_og[o] * F / (4 * PI) * psing *
+                                      (1 - fexp(-clip35(mus * a.dtau_og[o]))) * fexp(-a.tau_og[o] / u0) / mus;   // :2959-2965
+                c = T * iu1 * (w0 * Nsum + single);
+            } else {
+                const double edc = (NB == 2) ? fexp(-clip35(dt * iu1)) : fexp(-dt * iu1);  // :3154 vs :3127
+                const double core = (1 - w0) * u1 / al[0];
+                const double N0 = wmu[0] * (core * (B0 * (1 - edc) + b1 * (u1 - (dt + u1) * edc)));     // :3128, :3155
+                const double N1 = wmu[1] * Pu1[1] * (core * (b1 * (1 - edc) / al[1]));                  // :3129, :3156
+                const double ed2 = fexp(-dt * iu1);                                                      // :3163-3165
+                c = T * iu1 * (w0 * (N0 + N1) * 2 * PI +
+                               2 * PI * (1 - w0) * u1 * (B0 * (1 - ed2) + b1 * (u1 - (dt + u1) * ed2)));
+            }
+        }
+        const double Tn = T * fexp(-dt * iu1);
+        if (i == n - 1) {
+            if (!THERMAL) {       // xint[n] = flux_bot/pi = (Pl E d + Mn v + zpl_up)[0]/pi  (:2891, :2967)
+#pragma unroll
+                for (int r = 0; r < NB; ++r) {
+                    gd[r] += Tn * (1.0 / PI) * PE.m[0][r];
+                    gv[r] += Tn * (1.0 / PI) * M.Mn.m[0][r];
+                }
+                c += Tn * (1.0 / PI) * zpl_up[0];
+            } else {              // :3173-3176
+                c += Tn * (a.hard_surface ? Bn * 2 * PI : (Bn + b1 * u1) * 2 * PI);
+            }
+        }
+        // ---- elimination ----
+        if (i == 0) {
+            double bt[NB];
+            double b_top;
+            if (!THERMAL) b_top = a.b_top;
+            else {
+                const double tau_top = dt * a.plevel[0] / (a.plevel[1] - a.plevel[0]);   // :3062-3063
+                b_top = PI * (1.0 - fexp(-tau_top / 0.5)) * B_top;
+            }
+            bt[0] = b_top - zmn_dn[0];                                       // :3479-3480 / :3283
+            if constexpr (NB == 2) bt[1] = -b_top / 4 - zmn_dn[1];
+            const Blk<NB> Mni = inv(M.Mn);
+            R = mm(Mni, PE);
+            mv(Mni, bt, delta);
+            double tmp[NB];
+            mtv(R, gd, tmp);
+            kappa = c + dot(gd, delta);
+#pragma unroll
+            for (int r = 0; r < NB; ++r) zeta[r] = gv[r] - tmp[r];
+        } else {
+            Blk<NB> A1 = mm(pME, R), A2 = mm(pPE, R);
+#pragma unroll
+            for (int r = 0; r < NB; ++r)
+#pragma unroll
+                for (int s = 0; s < NB; ++s) {
+                    A1.m[r][s] = pPl.m[r][s] - A1.m[r][s];
+                    A2.m[r][s] = pMn.m[r][s] - A2.m[r][s];
+                }
+            const Blk<NB> A2i = inv(A2);
+            const Blk<NB> G = mm(A1, A2i);
+            double cP[NB], cM[NB], t1[NB], t2[NB];
+            mv(pPE, delta, t1);
+            mv(pME, delta, t2);
+#pragma unroll
+            for (int r = 0; r < NB; ++r) {
+                cP[r] = zpl_dn[r] - p_zpl_up[r] - t1[r];
+                cM[r] = t2[r] + p_zmn_up[r] - zmn_dn[r];
+            }
+            Blk<NB> K = mm(G, M.Pl), GM = mm(G, ME);
+#pragma unroll
+            for (int r = 0; r < NB; ++r)
+#pragma unroll
+                for (int s = 0; s < NB; ++s) {
+                    K.m[r][s] = M.Mn.m[r][s] - K.m[r][s];
+                    GM.m[r][s] = PE.m[r][s] - GM.m[r][s];        // -(G Mn E - Pl E)
+                }
+            K = inv(K);
+            const Blk<NB> Rn = mm(K, GM);
+            double deltan[NB], rhs[NB];
+            mv(G, cP, rhs);
+#pragma unroll
+            for (int r = 0; r < NB; ++r) rhs[r] += cM[r];
+            mv(K, rhs, deltan);
+            Blk<NB> Sm = mm(M.Pl, Rn);
+#pragma unroll
+            for (int r = 0; r < NB; ++r)
+#pragma unroll
+                for (int s = 0; s < NB; ++s) Sm.m[r][s] = ME.m[r][s] - Sm.m[r][s];
+            Sm = mm(A2i, Sm);
+            double tv[NB], t[NB];
+            mv(M.Pl, deltan, tv);
+#pragma unroll
+            for (int r = 0; r < NB; ++r) tv[r] += cP[r];
+            mv(A2i, tv, t);
+            kappa = kappa + dot(zeta, t) + dot(gd, deltan) + c;
+            double z1[NB], z2[NB];
+            mtv(Sm, zeta, z1);
+            mtv(Rn, gd, z2);
+#pragma unroll
+            for (int r = 0; r < NB; ++r) {
+                zeta[r] = z1[r] + gv[r] - z2[r];
+                delta[r] = deltan[r];
+            }
+            R = Rn;
+        }
+        pMn = M.Mn; pPl = M.Pl; pME = ME; pPE = PE;
+#pragma unroll
+        for (int r = 0; r < NB; ++r) { p_zmn_up[r] = zmn_up[r]; p_zpl_up[r] = zpl_up[r]; }
+        T = Tn;
+    }
+    // ---- surface rows (:3484-3494 / :3287-3289) ----
+    double bs[NB];
+    if (!THERMAL) {
+        const double bsf = (0. + rs * u0 * F * fexp(-a.tau[(long)n * pitch + w] / u0));   // :2863-2864
+        bs[0] = bsf;
+        if constexpr (NB == 2) bs[1] = -bsf / 4;
+    } else {
+        bs[0] = a.hard_surface ? PI * Bn : PI * (Bn + b1_last * 0.5);                       // :3065-3068
+        if constexpr (NB == 2) bs[1] = (-PI * Bn / 4);                                       // :3070
+    }
+    Blk<NB> L, W;
+#pragma unroll
+    for (int r = 0; r < NB; ++r)
+#pragma unroll
+        for (int s = 0; s < NB; ++s) {
+            W.m[r][s] = pPE.m[r][s] - rs * pME.m[r][s];
+            L.m[r][s] = pMn.m[r][s] - rs * pPl.m[r][s];
+        }
+    const Blk<NB> WR = mm(W, R);
+#pragma unroll
+    for (int r = 0; r < NB; ++r)
+#pragma unroll
+        for (int s = 0; s < NB; ++s) L.m[r][s] -= WR.m[r][s];
+    double wd[NB], rhs[NB], v[NB];
+    mv(W, delta, wd);
+#pragma unroll
+    for (int r = 0; r < NB; ++r) rhs[r] = bs[r] - p_zpl_up[r] + rs * p_zmn_up[r] - wd[r];
+    mv(inv(L), rhs, v);
+    a.xint[w] = kappa + dot(zeta, v);
+}
+
+int launch_sh(picaso_ctx *ctx, const SHArgs &a, bool thermal)
+{
+    const int block = 256;
+    const dim3 grid((unsigned)((a.nwno + block - 1) / block));
+    if (a.stream == 4) {
+        if (thermal) hipLaunchKernelGGL((k_sh<2, true>), grid, dim3(block), 0, ctx->stream, a);
+        else hipLaunchKernelGGL((k_sh<2, false>), grid, dim3(block), 0, ctx->stream, a);
+    } else {
+        if (thermal) hipLaunchKernelGGL((k_sh<1, true>), grid, dim3(block), 0, ctx->stream, a);
+        else hipLaunchKernelGGL((k_sh<1, false>), grid, dim3(block), 0, ctx->stream, a);
+    }
+    PZ_HIP(ctx, hipGetLastError());
+    return 0;
+}
+
+}  // namespace pz
+
+using namespace pz;
+
+extern "C" {
+
+int picaso_get_reflected_SH_dev(picaso_ctx *ctx, int nlevel, int nwno, long plane_pitch, int numg, int numt,
+                                const double *dtau, const double *tau, const double *w0,
+                                const double *cosb, const double *ftau_cld, const double *ftau_ray,
+                                const double *f_deltaM, const double *dtau_og, const double *tau_og,
+                                const double *w0_og, const double *cosb_og, const double *surf_reflect,
+                                const double *ubar0, const double *ubar1, double cos_theta,
+                                const double *F0PI, int w_single_form, int w_multi_form,
+                                int psingle_form, int w_single_rayleigh, int w_multi_rayleigh,
+                                int psingle_rayleigh, double frac_a, double frac_b, double frac_c,
+                                double constant_back, double constant_forward, int stream,
+                                double b_top, int flx, int single_form, int compound_f_deltaM,
+                                double *xint_at_top, const double *gweight, const double *tweight,
+                                double *albedo)
+{
+    (void)cosb;
+    if (!ctx) return fail(nullptr, "null context");
+    if (nlevel < 2 || nwno < 1 || numg < 1 || numt < 1) return fail(ctx, "get_reflected_SH: bad sizes");
+    if (stream != 2 && stream != 4) return fail(ctx, "get_reflected_SH: stream must be 2 or 4, got %d", stream);
+    if (flx) return fail(ctx, "get_reflected_SH: flx=1 (layer fluxes) is not built");
+    if (plane_pitch < nwno) return fail(ctx, "get_reflected_SH: plane_pitch < nwno");
+    PZ_HIP(ctx, hipSetDevice(ctx->device));
+    SHArgs a{};
+    a.nlayer = nlevel - 1; a.nwno = nwno; a.stream = stream; a.pitch = plane_pitch;
+    a.dtau = dtau; a.tau = tau; a.w0 = w0; a.ftau_cld = ftau_cld; a.ftau_ray = ftau_ray;
+    a.f_deltaM = f_deltaM; a.dtau_og = dtau_og; a.tau_og = tau_og; a.w0_og = w0_og; a.cosb_og = cosb_og;
+    a.surf_reflect = surf_reflect; a.F0PI = F0PI; a.cos_theta = cos_theta;
+    a.w_single_form = w_single_form; a.w_multi_form = w_multi_form; a.psingle_form = psingle_form;
+    a.w_single_rayleigh = w_single_rayleigh; a.w_multi_rayleigh = w_multi_rayleigh;
+    a.psingle_rayleigh = psingle_rayleigh; a.single_form = single_form;
+    a.frac_a = frac_a; a.frac_b = frac_b; a.frac_c = frac_c; a.constant_back = constant_back;
+    a.constant_forward = constant_forward; a.b_top = b_top;
+    const int nang = numg * numt;
+    for (int k = 0; k < nang; ++k) {
+        a.u0 = ubar0[k];
+        a.u1 = ubar1[k];
+        a.fd_power = compound_f_deltaM ? k + 1 : 1;
+        a.xint = xint_at_top + (size_t)k * nwno;
+        PZ_TRY(launch_sh(ctx, a, false));
+    }
+    if (albedo && gweight && tweight)
+        PZ_TRY(picaso_compress_disco_dev(ctx, nwno, cos_theta, xint_at_top, gweight, numg, tweight, numt, F0PI, albedo));
+    return 0;
+}
+
+int picaso_get_reflected_SH(picaso_ctx *ctx, int nlevel, int nwno, int numg, int numt, const double *dtau,
+                            const double *tau, const double *w0, const double *cosb,
+                            const double *ftau_cld, const double *ftau_ray, const double *f_deltaM,
+                            const double *dtau_og, const double *tau_og, const double *w0_og,
+                            const double *cosb_og, const double *surf_reflect, const double *ubar0,
+                            const double *ubar1, double cos_theta, const double *F0PI,
+                            int w_single_form, int w_multi_form, int psingle_form,
+                            int w_single_rayleigh, int w_multi_rayleigh, int psingle_rayleigh,
+                            double frac_a, double frac_b, double frac_c, double constant_back,
+                            double constant_forward, int stream, double b_top, int flx,
+                            int single_form, int compound_f_deltaM, double *xint_at_top)
+{
+    if (!ctx) return fail(nullptr, "null context");
+    if (nlevel < 2 || nwno < 1 || numg < 1 || numt < 1) return fail(ctx, "get_reflected_SH: bad sizes");
+    PZ_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t nl = (size_t)(nlevel - 1) * nwno, nv = (size_t)nlevel * nwno, nang = (size_t)numg * numt;
+    PZ_TRY(arena_reset(ctx, sizeof(double) * (9 * nl + 2 * nv + 2 * (size_t)nwno + nang * nwno) + 64 * 256));
+    const double *d[10], *d_rs, *d_f0;
+    const double *h[10] = {dtau, tau, w0, ftau_cld, ftau_ray, f_deltaM, dtau_og, tau_og, w0_og, cosb_og};
+    for (int j = 0; j < 10; ++j) PZ_TRY(arena_upload(ctx, h[j], (j == 1 || j == 7) ? nv : nl, &d[j]));
+    PZ_TRY(arena_upload(ctx, surf_reflect, (size_t)nwno, &d_rs));
+    PZ_TRY(arena_upload(ctx, F0PI, (size_t)nwno, &d_f0));
+    double *d_x = (double *)arena_take(ctx, sizeof(double) * nang * nwno);
+    if (!d_x) return fail(ctx, "arena exhausted");
+    PZ_TRY(picaso_get_reflected_SH_dev(ctx, nlevel, nwno, nwno, numg, numt, d[0], d[1], d[2], cosb, d[3], d[4], d[5],
+                                       d[6], d[7], d[8], d[9], d_rs, ubar0, ubar1, cos_theta, d_f0, w_single_form,
+                                       w_multi_form, psingle_form, w_single_rayleigh, w_multi_rayleigh,
+                                       psingle_rayleigh, frac_a, frac_b, frac_c, constant_back, constant_forward,
+                                       stream, b_top, flx, single_form, compound_f_deltaM, d_x, nullptr, nullptr,
+                                       nullptr));
+    PZ_HIP(ctx, hipMemcpyAsync(xint_at_top, d_x, sizeof(double) * nang * nwno, hipMemcpyDeviceToHost, ctx->stream));
+    PZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int picaso_get_thermal_SH_dev(picaso_ctx *ctx, int nlevel, const double *wno, int nwno, long plane_pitch,
+                              int numg, int numt, const double *tlevel, const double *dtau,
+                              const double *tau, const double *w0, const double *cosb_og,
+                              const double *plevel, const double *ubar1, const double *surf_reflect,
+                              int stream, int hard_surface, int cosb_differs_from_cosb_og, int flx,
+                              double *xint_at_top, const double *gweight, const double *tweight,
+                              double *flux_disk)
+{
+    (void)tau;
+    if (!ctx) return fail(nullptr, "null context");
+    if (nlevel < 2 || nwno < 1 || numg < 1 || numt < 1) return fail(ctx, "get_thermal_SH: bad sizes");
+    if (stream != 2 && stream != 4) return fail(ctx, "get_thermal_SH: stream must be 2 or 4, got %d", stream);
+    if (flx) return fail(ctx, "get_thermal_SH: flx=1 is broken in the reference (fluxes.py:3102) and not built");
+    PZ_HIP(ctx, hipSetDevice(ctx->device));
+    std::vector<double> tab(2 * (size_t)nlevel);
+    for (int i = 0; i < nlevel; ++i) { tab[i] = tlevel[i]; tab[nlevel + i] = plevel[i]; }
+    const void *d_tab = nullptr;
+    PZ_TRY(table_upload(ctx, tab.data(), sizeof(double) * tab.size(), &d_tab));
+    SHArgs a{};
+    a.nlayer = nlevel - 1; a.nwno = nwno; a.stream = stream; a.pitch = plane_pitch;
+    a.dtau = dtau; a.w0 = w0; a.cosb_og = cosb_og; a.surf_reflect = surf_reflect;
+    a.wno = wno; a.tlevel = (const double *)d_tab; a.plevel = a.tlevel + nlevel;
+    a.hard_surface = hard_surface; a.use_ff = cosb_differs_from_cosb_og;
+    const int nang = numg * numt;
+    for (int k = 0; k < nang; ++k) {
+        a.u0 = 0.0;
+        a.u1 = ubar1[k];
+        a.xint = xint_at_top + (size_t)k * nwno;
+        PZ_TRY(launch_sh(ctx, a, true));
+    }
+    if (flux_disk && gweight && tweight)
+        PZ_TRY(picaso_compress_thermal_dev(ctx, (size_t)nwno, xint_at_top, gweight, numg, tweight, numt, flux_disk));
+    return 0;
+}
+
+int picaso_get_thermal_SH(picaso_ctx *ctx, int nlevel, const double *wno, int nwno, int numg, int numt,
+                          const double *tlevel, const double *dtau, const double *tau, const double *w0,
+                          const double *cosb_og, const double *plevel, const double *ubar1,
+                          const double *surf_reflect, int stream, int hard_surface,
+                          int cosb_differs_from_cosb_og, int flx, double *xint_at_top)
+{
+    if (!ctx) return fail(nullptr, "null context");
+    if (nlevel < 2 || nwno < 1 || numg < 1 || numt < 1) return fail(ctx, "get_thermal_SH: bad sizes");
+    PZ_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t nl = (size_t)(nlevel - 1) * nwno, nang = (size_t)numg * numt;
+    PZ_TRY(arena_reset(ctx, sizeof(double) * (3 * nl + 2 * (size_t)nwno + nang * nwno) + 32 * 256));
+    const double *d_dtau, *d_w0, *d_cbo, *d_rs, *d_wno;
+    PZ_TRY(arena_upload(ctx, dtau, nl, &d_dtau));
+    PZ_TRY(arena_upload(ctx, w0, nl, &d_w0));
+    PZ_TRY(arena_upload(ctx, cosb_og, nl, &d_cbo));
+    PZ_TRY(arena_upload(ctx, surf_reflect, (size_t)nwno, &d_rs));
+    PZ_TRY(arena_upload(ctx, wno, (size_t)nwno, &d_wno));
+    double *d_x = (double *)arena_take(ctx, sizeof(double) * nang * nwno);
+    if (!d_x) return fail(ctx, "arena exhausted");
+    PZ_TRY(picaso_get_thermal_SH_dev(ctx, nlevel, d_wno, nwno, nwno, numg, numt, tlevel, d_dtau, tau, d_w0, d_cbo,
+                                     plevel, ubar1, d_rs, stream, hard_surface, cosb_differs_from_cosb_og, flx, d_x,
+                                     nullptr, nullptr, nullptr));
+    PZ_HIP(ctx, hipMemcpyAsync(xint_at_top, d_x, sizeof(double) * nang * nwno, hipMemcpyDeviceToHost, ctx->stream));
+    PZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+}  // extern "C"

@@ -106,3 +106,59 @@ def get_thermal_3d(nlevel, wno, nwno, numg, numt, tlevel_3d, dtau_3d, w0_3d, cos
         ctx, _ci(nlevel), ptr(wno_), _ci(nwno), _ci(numg), _ci(numt), ptr(tl), ptr(dt), ptr(w0_),
         ptr(cb), ptr(pl), ptr(u1), ptr(rs), _ci(int(hard_surface)), ptr(out)), ctx)
     return out
+
+
+def get_reflected_SH(nlevel, nwno, numg, numt, dtau, tau, w0, cosb, ftau_cld, ftau_ray, f_deltaM,
+                     dtau_og, tau_og, w0_og, cosb_og, surf_reflect, ubar0, ubar1, cos_theta, F0PI,
+                     w_single_form, w_multi_form, psingle_form, w_single_rayleigh, w_multi_rayleigh,
+                     psingle_rayleigh, frac_a, frac_b, frac_c, constant_back, constant_forward,
+                     stream, b_top=0, flx=0, single_form=0, compound_f_deltaM=True):
+    """Spherical-harmonics reflected light, stream = 2 or 4 (reference ``fluxes.get_reflected_SH``,
+    fluxes.py:2675-2976).  Returns ``(xint_at_top, flux)`` with ``flux`` zeros
+    ``(numg, numt, stream*nlevel, nwno)`` as in the reference for ``flx=0`` (``flx=1`` raises).
+
+    ``compound_f_deltaM=True`` (default) reproduces the reference: its TTHG branch multiplies
+    ``f_deltaM`` in place once per angle (fluxes.py:2823-2824), so angle k sees
+    ``f_deltaM * fac**(k+1)`` and the caller's array is left multiplied by ``fac**(numg*numt)``
+    (done here too when ``f_deltaM`` is a writable float64 array).  ``False`` gives the
+    non-compounding variant (every angle sees ``f_deltaM * fac``; the caller's array is untouched).
+    """
+    ctx = context()
+    arrs = [f64(p) for p in (dtau, tau, w0, cosb, ftau_cld, ftau_ray, f_deltaM, dtau_og, tau_og,
+                             w0_og, cosb_og)]
+    rs, f0 = per_wave(surf_reflect, nwno), per_wave(F0PI, nwno)
+    u0, u1 = f64(ubar0, (numg, numt)), f64(ubar1, (numg, numt))
+    xint = np.zeros((numg, numt, nwno))
+    check(load().picaso_get_reflected_SH(
+        ctx, _ci(nlevel), _ci(nwno), _ci(numg), _ci(numt), *[ptr(p) for p in arrs], ptr(rs), ptr(u0),
+        ptr(u1), _cd(cos_theta), ptr(f0), _ci(int(w_single_form)), _ci(int(w_multi_form)),
+        _ci(int(psingle_form)), _ci(int(w_single_rayleigh)), _ci(int(w_multi_rayleigh)),
+        _ci(int(psingle_rayleigh)), _cd(frac_a), _cd(frac_b), _cd(frac_c), _cd(constant_back),
+        _cd(constant_forward), _ci(int(stream)), _cd(b_top), _ci(int(flx)), _ci(int(single_form)),
+        _ci(1 if compound_f_deltaM else 0), ptr(xint)), ctx)
+    if compound_f_deltaM and (w_single_form == 0 or w_multi_form == 0) and \
+            isinstance(f_deltaM, np.ndarray) and f_deltaM.dtype == np.float64 and f_deltaM.flags.writeable:
+        gb = constant_back * np.asarray(cosb_og, dtype=float)
+        f = frac_a + frac_b * gb ** frac_c
+        f_deltaM *= (f * constant_forward ** stream + (1 - f) * constant_back ** stream) ** (numg * numt)
+    return xint, np.zeros((numg, numt, stream * nlevel, nwno))
+
+
+def get_thermal_SH(nlevel, wno, nwno, numg, numt, tlevel, dtau, tau, w0, cosb, dtau_og, tau_og,
+                   w0_og, w0_no_raman, cosb_og, plevel, ubar1, surf_reflect, stream, hard_surface,
+                   flx=0):
+    """Spherical-harmonics thermal emission (reference ``fluxes.get_thermal_SH``,
+    fluxes.py:2979-3186; ``flx=1`` is broken in the reference and raises here).
+    Returns ``(xint_at_top, flux)``."""
+    ctx = context()
+    wno_, tl, pl = f64(wno), f64(tlevel), f64(plevel)
+    dt, ta, w0_, cbo = f64(dtau), f64(tau), f64(w0), f64(cosb_og)
+    differs = 0 if np.array_equal(np.asarray(cosb), np.asarray(cosb_og)) else 1   # fluxes.py:3072
+    rs = per_wave(surf_reflect, nwno)
+    u1 = f64(ubar1, (numg, numt))
+    xint = np.zeros((numg, numt, nwno))
+    check(load().picaso_get_thermal_SH(
+        ctx, _ci(nlevel), ptr(wno_), _ci(nwno), _ci(numg), _ci(numt), ptr(tl), ptr(dt), ptr(ta),
+        ptr(w0_), ptr(cbo), ptr(pl), ptr(u1), ptr(rs), _ci(int(stream)), _ci(int(hard_surface)),
+        _ci(differs), _ci(int(flx)), ptr(xint)), ctx)
+    return xint, np.zeros((numg, numt, stream * nlevel, nwno))

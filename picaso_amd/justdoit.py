@@ -37,6 +37,18 @@ def toon_phase_coefficients(printout=True):
     return ["quadrature", "eddington"]
 
 
+def SH_psingle_form_options(printout=True):
+    return ["explicit", "legendre"]
+
+
+def SH_scattering_options(printout=True):
+    return ["TTHG", "OTHG", "isotropic"]
+
+
+def SH_rayleigh_options(printout=True):
+    return ["off", "on"]
+
+
 _DEFAULTS = {   # reference/config.json
     "phase_angle": 0, "test_mode": None,
     "planet": {"gravity": None, "radius": np.nan, "mass": np.nan},
@@ -45,6 +57,9 @@ _DEFAULTS = {   # reference/config.json
     "clouds": {"profile": None, "wavenumber": None, "do_holes": False},
     "approx": {"p_reference": 1, "rt_method": "toon", "get_lvl_flux": False,
                "rt_params": {"toon": {"toon_coefficients": 0, "multi_phase": 0, "single_phase": 3},
+                             "SH": {"single_form": 0, "w_single_form": 0, "w_multi_form": 0,
+                                    "psingle_form": 0, "w_single_rayleigh": 1, "w_multi_rayleigh": 1,
+                                    "psingle_rayleigh": 1, "calculate_fluxes": 0},
                              "common": {"stream": 2, "delta_eddington": True, "raman": 2,
                                         "TTHG_params": {"fraction": [1, -1, 2], "constant_back": -0.5,
                                                         "constant_forward": 1}}}},
@@ -135,17 +150,35 @@ class inputs:
 
     def approx(self, single_phase="TTHG_ray", multi_phase="N=2", delta_eddington=True,
                raman="none", tthg_frac=[1, -1, 2], tthg_back=-0.5, tthg_forward=1, p_reference=1,
-               rt_method="toon", stream=2, toon_coefficients="quadrature", get_lvl_flux=False):
+               rt_method="toon", stream=2, toon_coefficients="quadrature", single_form="explicit",
+               calculate_fluxes="off", w_single_form="TTHG", w_multi_form="TTHG", psingle_form="TTHG",
+               w_single_rayleigh="on", w_multi_rayleigh="on", psingle_rayleigh="on",
+               get_lvl_flux=False):
         """String options -> the integers the solvers take (reference justdoit.py:4635-4738)."""
-        if rt_method != "toon":
-            raise Exception("rt_method='SH' is not built in this round; use 'toon'")
+        if rt_method not in ("toon", "SH"):
+            raise Exception("rt_method must be 'toon' or 'SH'")
+        if calculate_fluxes != "off":
+            raise Exception("SH calculate_fluxes='on' (layer fluxes) is not built")
+        for opt in (w_single_form, w_multi_form, psingle_form):
+            if opt == "isotropic":      # accepted but not handled by the reference (SURVEY App. C)
+                raise Exception("SH form 'isotropic' is not handled by the reference solver either")
         a = self.inputs["approx"]
         a["get_lvl_flux"] = get_lvl_flux
         a["rt_method"] = rt_method
         a["p_reference"] = p_reference
         c = a["rt_params"]["common"]
-        c["stream"] = 2
+        c["stream"] = 2 if rt_method == "toon" else int(stream)      # justdoit.py:4702-4705
+        if c["stream"] not in (2, 4):
+            raise Exception("stream must be 2 or 4")
         c["delta_eddington"] = delta_eddington
+        sh = a["rt_params"]["SH"]
+        sh["single_form"] = SH_psingle_form_options(False).index(single_form)
+        sh["w_single_form"] = SH_scattering_options(False).index(w_single_form)
+        sh["w_multi_form"] = SH_scattering_options(False).index(w_multi_form)
+        sh["psingle_form"] = SH_scattering_options(False).index(psingle_form)
+        sh["w_single_rayleigh"] = SH_rayleigh_options(False).index(w_single_rayleigh)
+        sh["w_multi_rayleigh"] = SH_rayleigh_options(False).index(w_multi_rayleigh)
+        sh["psingle_rayleigh"] = SH_rayleigh_options(False).index(psingle_rayleigh)
         c["raman"] = raman_options().index(raman)
         if not isinstance(tthg_frac, (list, np.ndarray)):
             raise Exception("tthg_frac should be a list or ndarray of length=3")
@@ -234,10 +267,16 @@ def picaso(bundle, opacityclass, dimension="1d", calculation="reflected", full_o
     if "reflected" in calculation:
         xint = DeviceArray((ng, nt, nwno), ctx)
         alb = DeviceArray((nwno,), ctx)
-        lvl = [DeviceArray((ng, nt, nlevel, nwno), ctx) for _ in range(4)] if atm.get_lvl_flux else None
-        _reflected(ctx, nlevel, nwno, ng, nt, planes, rs, ubar0, ubar1, cos_theta, d_f0,
-                   toon["single_phase"], toon["multi_phase"], frac_a, frac_b, frac_c, constant_back,
-                   constant_forward, toon["toon_coefficients"], b_top, xint, lvl, gweight, tweight, alb)
+        lvl = None
+        if inp["approx"]["rt_method"] == "SH":                # justdoit.py:259-269
+            _reflected_sh(ctx, nlevel, nwno, ng, nt, planes, rs, ubar0, ubar1, cos_theta, d_f0,
+                          inp["approx"]["rt_params"]["SH"], frac_a, frac_b, frac_c, constant_back,
+                          constant_forward, common["stream"], b_top, xint, gweight, tweight, alb)
+        else:
+            lvl = [DeviceArray((ng, nt, nlevel, nwno), ctx) for _ in range(4)] if atm.get_lvl_flux else None
+            _reflected(ctx, nlevel, nwno, ng, nt, planes, rs, ubar0, ubar1, cos_theta, d_f0,
+                       toon["single_phase"], toon["multi_phase"], frac_a, frac_b, frac_c, constant_back,
+                       constant_forward, toon["toon_coefficients"], b_top, xint, lvl, gweight, tweight, alb)
         albedo = alb.to_host()
         returns["albedo"] = albedo
         if full_output:
@@ -256,10 +295,15 @@ def picaso(bundle, opacityclass, dimension="1d", calculation="reflected", full_o
         d_wno = DeviceArray.from_host(wno, ctx)
         flux = DeviceArray((ng, nt, nwno), ctx)
         disk = DeviceArray((nwno,), ctx)
-        resident.thermal_1d(ctx, nlevel, d_wno, nwno, ng, nt, atm.level["temperature"],
-                            planes["dtau_og"], planes["w0_no_raman"], planes["cosb_og"],
-                            atm.level["pressure"], ubar1, rs, atm.hard_surface, flux,
-                            gweight=gweight, tweight=tweight, flux_disk=disk)
+        if inp["approx"]["rt_method"] == "SH":                # justdoit.py:364-370
+            _thermal_sh(ctx, nlevel, d_wno, nwno, ng, nt, atm.level["temperature"], planes,
+                        atm.level["pressure"], ubar1, rs, common["stream"], atm.hard_surface,
+                        common["delta_eddington"], flux, gweight, tweight, disk)
+        else:
+            resident.thermal_1d(ctx, nlevel, d_wno, nwno, ng, nt, atm.level["temperature"],
+                                planes["dtau_og"], planes["w0_no_raman"], planes["cosb_og"],
+                                atm.level["pressure"], ubar1, rs, atm.hard_surface, flux,
+                                gweight=gweight, tweight=tweight, flux_disk=disk)
         thermal = disk.to_host()
         returns["thermal"] = thermal
         returns["thermal_unit"] = "erg/s/(cm^2)/(cm)"
@@ -296,3 +340,43 @@ def _reflected(ctx, nlevel, nwno, ng, nt, planes, rs, ubar0, ubar1, cos_theta, F
         ci(toon_coefficients), cd(b_top), ptr(xint.addr),
         *[ptr(l.addr) if lvl else None for l in (lvl or [None] * 4)], ptr(gw), ptr(tw),
         ptr(albedo.addr)), ctx)
+
+
+def _reflected_sh(ctx, nlevel, nwno, ng, nt, planes, rs, ubar0, ubar1, cos_theta, F0PI, sh, frac_a,
+                  frac_b, frac_c, constant_back, constant_forward, stream, b_top, xint, gweight,
+                  tweight, albedo):
+    import ctypes
+    from ._lib import check, f64, load, ptr
+    u0, u1 = f64(ubar0, (ng, nt)), f64(ubar1, (ng, nt))
+    gw, tw = f64(gweight), f64(tweight)
+    ci, cd = ctypes.c_int, ctypes.c_double
+    names = ("dtau", "tau", "w0", "cosb", "ftau_cld", "ftau_ray", "f_deltaM", "dtau_og", "tau_og",
+             "w0_og", "cosb_og")
+    check(load().picaso_get_reflected_SH_dev(
+        ctx, ci(nlevel), ci(nwno), ctypes.c_long(nwno), ci(ng), ci(nt),
+        *[ptr(planes[k].addr) for k in names], ptr(rs.addr), ptr(u0), ptr(u1), cd(cos_theta),
+        ptr(F0PI.addr), ci(sh["w_single_form"]), ci(sh["w_multi_form"]), ci(sh["psingle_form"]),
+        ci(sh["w_single_rayleigh"]), ci(sh["w_multi_rayleigh"]), ci(sh["psingle_rayleigh"]),
+        cd(frac_a), cd(frac_b), cd(frac_c), cd(constant_back), cd(constant_forward), ci(stream),
+        cd(b_top), ci(0), ci(sh["single_form"]), ci(1), ptr(xint.addr), ptr(gw), ptr(tw),
+        ptr(albedo.addr)), ctx)
+
+
+def _thermal_sh(ctx, nlevel, d_wno, nwno, ng, nt, tlevel, planes, plevel, ubar1, rs, stream,
+                hard_surface, delta_eddington, flux, gweight, tweight, disk):
+    import ctypes
+    from ._lib import check, f64, load, ptr
+    u1 = f64(ubar1, (ng, nt))
+    gw, tw = f64(gweight), f64(tweight)
+    tl, pl = f64(tlevel), f64(plevel)
+    ci = ctypes.c_int
+    # np.array_equal(cosb, cosb_og) (fluxes.py:3072): the planes differ exactly when the
+    # delta-Eddington scaling was applied with a non-zero asymmetry somewhere
+    differs = 0
+    if delta_eddington:
+        differs = int(np.any(planes["f_deltaM"].to_host() != 0))
+    check(load().picaso_get_thermal_SH_dev(
+        ctx, ci(nlevel), ptr(d_wno.addr), ci(nwno), ctypes.c_long(nwno), ci(ng), ci(nt), ptr(tl),
+        ptr(planes["dtau"].addr), ptr(planes["tau"].addr), ptr(planes["w0"].addr),
+        ptr(planes["cosb_og"].addr), ptr(pl), ptr(u1), ptr(rs.addr), ci(stream), ci(int(hard_surface)),
+        ci(differs), ci(0), ptr(flux.addr), ptr(gw), ptr(tw), ptr(disk.addr)), ctx)

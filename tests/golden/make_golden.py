@@ -392,5 +392,54 @@ def make_optics():
           "%.1f KB" % (os.path.getsize(db) / 1024))
 
 
+def make_sh():
+    """get_reflected_SH / get_thermal_SH (stream 2 and 4) on three of the 1-D scenes.  f_deltaM is
+    handed over as a fresh copy each call (the reference compounds it in place per angle)."""
+    sc_all = scenes_1d()
+    for name in ("cfg3like", "phase60", "thick", "conservative"):
+        sc, geo, rs, f0 = sc_all[name]
+        nlevel, nwno = sc["nlevel"], sc["nwno"]
+        store = {}
+        for k in PLANES + ("wno", "tlevel", "plevel", "w0_no_raman", "f_deltaM"):
+            store["in/" + k] = sc[k]
+        store["in/surf_reflect"] = np.asarray(rs, dtype=float)
+        store["in/F0PI"] = f0
+        for k, v in geo.items():
+            store["geo/" + k] = np.asarray(v)
+        for k, v in TTHG.items():
+            store["opt/" + k] = np.array(v)
+        combos = [(0, 0, 0, 1, 1, 1, 0), (1, 1, 1, 1, 1, 1, 0), (0, 0, 0, 0, 0, 0, 0),
+                  (1, 0, 0, 1, 1, 1, 1), (1, 1, 1, 0, 1, 0, 1)]
+        for stream in (2, 4):
+            for (wsf, wmf, psf, wsr, wmr, psr, sf) in combos:
+                fd = sc["f_deltaM"].copy()
+                if stream == 4:      # f_deltaM = cosb**stream for the delta-M scaled scenes
+                    fd = sc["cosb_og"] ** 4 if np.any(sc["f_deltaM"]) else fd
+                store["in/f_deltaM_s%d" % stream] = fd.copy()
+                xint, _ = fl.get_reflected_SH(
+                    nlevel, nwno, geo["numg"], geo["numt"], sc["dtau"].copy(), sc["tau"].copy(),
+                    sc["w0"].copy(), sc["cosb"].copy(), sc["ftau_cld"].copy(), sc["ftau_ray"].copy(),
+                    fd, sc["dtau_og"].copy(), sc["tau_og"].copy(), sc["w0_og"].copy(),
+                    sc["cosb_og"].copy(), rs, geo["ubar0"], geo["ubar1"], geo["cos_theta"], f0, wsf,
+                    wmf, psf, wsr, wmr, psr, TTHG["frac_a"], TTHG["frac_b"], TTHG["frac_c"],
+                    TTHG["constant_back"], TTHG["constant_forward"], stream, b_top=0.0, flx=0,
+                    single_form=sf)
+                store["reflsh/s%d_f%d%d%d_r%d%d%d_sf%d/xint" % (stream, wsf, wmf, psf, wsr, wmr, psr, sf)] = xint
+            for hs in (0, 1):
+                rsv = np.zeros(nwno) + rs
+                xint, _ = fl.get_thermal_SH(nlevel, sc["wno"], nwno, geo["numg"], geo["numt"],
+                                            sc["tlevel"], sc["dtau"].copy(), sc["tau"].copy(),
+                                            sc["w0"].copy(), sc["cosb"].copy(), sc["dtau_og"].copy(),
+                                            sc["tau_og"].copy(), sc["w0_og"].copy(),
+                                            sc["w0_no_raman"].copy(), sc["cosb_og"].copy(),
+                                            sc["plevel"], geo["ubar1"], rsv, stream, hs)
+                store["thermsh/s%d_hs%d/xint" % (stream, hs)] = xint
+        path = os.path.join(HERE, "scene_sh_%s.npz" % name)
+        np.savez_compressed(path, **store)
+        print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024))
+
+
 if __name__ == "__main__" and (("optics" in sys.argv[1:]) or not sys.argv[1:]):
     make_optics()
+if __name__ == "__main__" and (("sh" in sys.argv[1:]) or not sys.argv[1:]):
+    make_sh()

@@ -86,3 +86,38 @@ def test_reflected_thermal_3d(path, oracle):
                                      g.inp("cosb_og"), g.inp("plevel"), g.geo("ubar1"),
                                      g.inp("surf_reflect"), hs)
         assert rel_err(flux, g["therm3d/hs%d/flux" % hs]) < TOL, hs
+
+
+FILES_SH = golden_files("scene_sh_")
+
+
+def _sh_case(case):
+    s, f, r, sf = case.split("_")
+    return int(s[1]), [int(c) for c in f[1:]], [int(c) for c in r[1:]], int(sf[2])
+
+
+@pytest.mark.parametrize("path", FILES_SH, ids=scene_id)
+def test_spherical_harmonics(path, oracle):
+    """SH2 / SH4 reflected + thermal (banded LU with partial pivoting restated from LAPACK dgbsv)
+    against the reference (scipy.linalg.solve_banded).  Agreement is limited by the conditioning
+    of the reference's 11-diagonal system (entries spanning e^-35 .. e^+35), not by the port."""
+    g = Golden(path)
+    nlevel, nwno = g.inp("tau").shape
+    for case in g.cases("reflsh"):
+        stream, (wsf, wmf, psf), (wsr, wmr, psr), sf = _sh_case(case)
+        xint, _ = oracle.get_reflected_SH(
+            nlevel, nwno, g.geo("numg"), g.geo("numt"), g.inp("dtau"), g.inp("tau"), g.inp("w0"),
+            g.inp("cosb"), g.inp("ftau_cld"), g.inp("ftau_ray"), g.inp("f_deltaM_s%d" % stream).copy(),
+            g.inp("dtau_og"), g.inp("tau_og"), g.inp("w0_og"), g.inp("cosb_og"), g.inp("surf_reflect"),
+            g.geo("ubar0"), g.geo("ubar1"), g.geo("cos_theta"), g.inp("F0PI"), wsf, wmf, psf, wsr, wmr,
+            psr, *g.tthg(), stream, b_top=0.0, flx=0, single_form=sf)
+        assert rel_err(xint, g["reflsh/%s/xint" % case]) < 1e-8, case
+    for case in g.cases("thermsh"):
+        stream, hs = int(case[1]), int(case[-1])
+        rs = np.zeros(nwno) + g.inp("surf_reflect")
+        xint, _ = oracle.get_thermal_SH(nlevel, g.inp("wno"), nwno, g.geo("numg"), g.geo("numt"),
+                                        g.inp("tlevel"), g.inp("dtau"), g.inp("tau"), g.inp("w0"),
+                                        g.inp("cosb"), g.inp("dtau_og"), g.inp("tau_og"), g.inp("w0_og"),
+                                        g.inp("w0_no_raman"), g.inp("cosb_og"), g.inp("plevel"),
+                                        g.geo("ubar1"), rs, stream, hs)
+        assert rel_err(xint, g["thermsh/%s/xint" % case]) < 1e-8, case

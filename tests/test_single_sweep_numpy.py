@@ -39,3 +39,27 @@ def test_thermal_sweep(path):
                            g.inp("w0_no_raman"), g.inp("cosb_og"), g.inp("plevel"),
                            g.geo("ubar1").ravel(), rs, hs)
         assert rel_err(x, g["therm1d/hs%d_ct0/flux" % hs].reshape(x.shape)) < 1e-8, hs
+
+
+@pytest.mark.parametrize("path", golden_files("scene_sh_"), ids=scene_id)
+def test_sh4_block_sweep(path):
+    """The 2x2-block single sweep (tools/sh_sweep_numpy.py) against the reference's SH4 results
+    (LAPACK dgbsv with partial pivoting on the 11-diagonal system): no banded matrix, no pivoting
+    across layers, same answer to ~1e-13 -- including thick (35-clipped) and conservative columns
+    and the reference's per-angle f_deltaM compounding."""
+    import sh_sweep_numpy as sh
+    g = Golden(path)
+    nlevel, nwno = g.inp("tau").shape
+    rs = np.zeros(nwno) + g.inp("surf_reflect")
+    for case in g.cases("reflsh"):
+        s, f, r, sf = case.split("_")
+        if s != "s4":
+            continue
+        wsf, wmf, psf = (int(c) for c in f[1:])
+        wsr, wmr, psr = (int(c) for c in r[1:])
+        x = sh.reflected_sh4(nlevel, nwno, g.inp("dtau"), g.inp("tau"), g.inp("w0"), g.inp("ftau_cld"),
+                             g.inp("ftau_ray"), g.inp("f_deltaM_s4"), g.inp("dtau_og"), g.inp("tau_og"),
+                             g.inp("w0_og"), g.inp("cosb_og"), rs, g.geo("ubar0").ravel(),
+                             g.geo("ubar1").ravel(), g.geo("cos_theta"), g.inp("F0PI"), wsf, wmf, psf,
+                             wsr, wmr, psr, *g.tthg(), 0.0, int(sf[2]))
+        assert rel_err(x, g["reflsh/%s/xint" % case].reshape(x.shape)) < 1e-10, case
