@@ -44,6 +44,9 @@ def main():
     ap.add_argument("--nwno", type=int, default=100000, help="wavelengths per GPU")
     ap.add_argument("--nlayer", type=int, default=90)
     ap.add_argument("--ngauss", type=int, default=5, help="disk Gauss angles (5..8)")
+    ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"),
+                    help="collective backend for N > 1 (nccl = RCCL over xGMI; gloo only for smoke "
+                         "tests of the sharded path on a box with fewer GPUs than ranks)")
     ap.add_argument("--cpu-sample", type=int, default=100000,
                     help="wavelengths of the same workload timed on the CPU oracle (0 = skip)")
     args = ap.parse_args()
@@ -55,13 +58,20 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
 
     dist = torch = None
+    ndev = _lib.device_count()
+    if ndev < 1:
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible")
+    dev = local_rank if args.backend == "nccl" else local_rank % ndev
     if world > 1:
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            torch.cuda.set_device(dev)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+        else:
+            dist.init_process_group("gloo")
 
-    ctx = _lib.context(local_rank)
+    ctx = _lib.context(dev)
     nwno, nlayer, nlevel = args.nwno, args.nlayer, args.nlayer + 1
     ng = args.ngauss
     gang, gw, tang, tw = disco.get_angles_1d(ng)
@@ -74,28 +84,35 @@ def main():
     scene["surf_reflect"] = np.zeros(nwno)
     d = resident.upload_scene(scene, resident.REFLECTED_PLANES + ("F0PI", "surf_reflect"), ctx=ctx)
     xint = device.DeviceArray((ng, 1, nwno), ctx)
-    if world > 1:
+    use_nccl = world > 1 and args.backend == "nccl"
+    if use_nccl:
         alb_t = torch.empty(nwno, dtype=torch.float64, device="cuda")
         full_t = torch.empty(world * nwno, dtype=torch.float64, device="cuda")
         albedo = alb_t.data_ptr()
     else:
         alb_d = device.DeviceArray((nwno,), ctx)
         albedo = alb_d
+        if world > 1:
+            full_t = torch.empty(world * nwno, dtype=torch.float64)
 
     def step():
         resident.reflected_1d(ctx, nlevel, nwno, ng, 1, d, d["surf_reflect"], ubar0, ubar1,
                               cos_theta, d["F0PI"], 3, 0, *TTHG, xint, toon_coefficients=0,
                               b_top=0.0, gweight=gw, tweight=tw, albedo=albedo)
-        if world > 1:
+        if use_nccl:
             device.sync(ctx)                                  # our stream -> RCCL's stream
             dist.all_gather_into_tensor(full_t, alb_t)        # RCCL over xGMI: the final spectrum
+        elif world > 1:                                       # gloo smoke path: gather on the host
+            dist.all_gather_into_tensor(full_t, torch.from_numpy(alb_d.to_host()))
 
     def barrier():
         device.sync(ctx)
         if world > 1:
-            torch.cuda.synchronize()
+            if use_nccl:
+                torch.cuda.synchronize()
             dist.barrier()
-            torch.cuda.synchronize()
+            if use_nccl:
+                torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         step()
@@ -108,14 +125,16 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if use_nccl else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
     # ---- parity + CPU baseline on rank 0 (outside the timed region) ----
     out = None
     if rank == 0:
-        alb_gpu = alb_t.cpu().numpy() if world > 1 else alb_d.to_host()
+        alb_gpu = alb_t.cpu().numpy() if use_nccl else alb_d.to_host()
+        if world > 1:   # the gathered spectrum must contain this rank's shard bit-exactly
+            assert np.array_equal(full_t[:nwno].cpu().numpy(), alb_gpu), "all-gather mismatch"
         ms_per_step = 1e3 * elapsed / args.steps
         value = world * args.steps / elapsed
         nang = ng
@@ -139,7 +158,8 @@ def main():
                                    "delta-Eddington, Rayleigh + cloud slab",
                        "nwno_per_gpu": nwno, "nlayer": nlayer, "gauss_angles": ng,
                        "sharding": "wavelength blocks, %d x %d" % (world, nwno),
-                       "collective": "rccl all_gather of albedo shards" if world > 1 else "none"},
+                       "collective": ("rccl all_gather of albedo shards" if use_nccl else
+                                      "gloo all_gather (smoke)") if world > 1 else "none"},
             "wavelength_layer_updates_per_s": value * nwno * nlayer,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

@@ -94,9 +94,9 @@ __device__ __forceinline__ Blk<NB> inv(const Blk<NB> &A)
 {
     Blk<NB> R;
     if (NB == 1) {
-        R.m[0][0] = 1.0 / A.m[0][0];
+        R.m[0][0] = frcp(A.m[0][0]);
     } else {
-        const double idet = 1.0 / (A.m[0][0] * A.m[NB - 1][NB - 1] - A.m[0][NB - 1] * A.m[NB - 1][0]);
+        const double idet = frcp(A.m[0][0] * A.m[NB - 1][NB - 1] - A.m[0][NB - 1] * A.m[NB - 1][0]);
         R.m[0][0] = A.m[NB - 1][NB - 1] * idet;
         R.m[NB - 1][NB - 1] = A.m[0][0] * idet;
         R.m[0][NB - 1] = -A.m[0][NB - 1] * idet;
@@ -152,9 +152,10 @@ __device__ __forceinline__ void modes_sh4(const double (&a)[4], double dt, Modes
     const double l1 = sqrt((M.beta + disc) / 2), l2 = sqrt((M.beta - disc) / 2);
     M.lam[0] = l1;
     M.lam[1] = l2;
-    const double R1 = -a0 / l1, R2 = -a0 / l2;                        // :3423-3425
-    const double Q1 = 0.5 * (a0 * a1 / (l1 * l1) - 1), Q2 = 0.5 * (a0 * a1 / (l2 * l2) - 1);
-    const double S1 = -3 / (2 * a3) * (a0 * a1 / l1 - l1), S2 = -3 / (2 * a3) * (a0 * a1 / l2 - l2);
+    const double il1 = frcp(l1), il2 = frcp(l2), a01 = a0 * a1, s3 = -1.5 * frcp(a3);
+    const double R1 = -a0 * il1, R2 = -a0 * il2;                      // :3423-3425
+    const double Q1 = 0.5 * (a01 * il1 * il1 - 1), Q2 = 0.5 * (a01 * il2 * il2 - 1);
+    const double S1 = s3 * (a01 * il1 - l1), S2 = s3 * (a01 * il2 - l2);
     const double tp = 2 * PI;
     M.Pl.m[0][0] = (0.5 + R1 + 5 * Q1 / 8) * tp;                      // p1pl  :3427-3434
     M.Pl.m[0][1] = (0.5 + R2 + 5 * Q2 / 8) * tp;                      // p2pl
@@ -178,7 +179,7 @@ __device__ __forceinline__ void modes_sh2(const double (&a)[2], double dt, Modes
 {
     const double lam = sqrt(a[0] * a[1]);                             // fluxes.py:3245
     M.lam[0] = lam;
-    M.q = lam / a[1];                                                 // :3251
+    M.q = lam * frcp(a[1]);                                           // :3251
     M.Mn.m[0][0] = (0.5 + M.q) * 2 * PI;                              // Q1
     M.Pl.m[0][0] = (0.5 - M.q) * 2 * PI;                              // Q2
     M.E[0] = fexp(-clip35(lam * dt));                                 // :3246-3248
@@ -199,7 +200,7 @@ __global__ __launch_bounds__(256) void k_sh(const SHArgs a)
     legP4(-u0, Pu0);
     legP4(u1, Pu1);
     const double mus = THERMAL ? 0.0 : (u1 + u0) / (u1 * u0);
-    const double iu1 = 1.0 / u1;
+    const double iu1 = 1.0 / u1, iu0 = THERMAL ? 0.0 : 1.0 / u0, imus = THERMAL ? 0.0 : 1.0 / ((u1 + u0) / (u1 * u0));
 
     // thermal: Planck at the levels (fluxes.py:3058-3060)
     const double wn = THERMAL ? a.wno[w] : 0.0;
@@ -245,21 +246,23 @@ __global__ __launch_bounds__(256) void k_sh(const SHArgs a)
             }
             if (a.w_single_form == 1 || a.w_multi_form == 1) {               // OTHG :2811-2817
                 double cl = 1.0;
+                const double ifp = frcp(1 - fd_prev);
 #pragma unroll
                 for (int l = 1; l < NS; ++l) {
                     cl *= cbo;
-                    const double ww = ((2 * l + 1) * cl - (2 * l + 1) * fd_prev) / (1 - fd_prev);
+                    const double ww = ((2 * l + 1) * cl - (2 * l + 1) * fd_prev) * ifp;
                     if (a.w_single_form == 1) wsg[l] = ww;
                     if (a.w_multi_form == 1) wmu[l] = ww;
                 }
             }
             if (tthg) {                                                      // TTHG :2819-2831
                 double gfl = 1.0, gbl = 1.0;
+                const double ifd = frcp(1 - fd);
 #pragma unroll
                 for (int l = 1; l < NS; ++l) {
                     gfl *= gf;
                     gbl *= gb;
-                    const double ww = ((2 * l + 1) * (f * gfl + (1 - f) * gbl) - (2 * l + 1) * fd) / (1 - fd);
+                    const double ww = ((2 * l + 1) * (f * gfl + (1 - f) * gbl) - (2 * l + 1) * fd) * ifd;
                     if (a.w_single_form == 0) wsg[l] = ww;
                     if (a.w_multi_form == 0) wmu[l] = ww;
                 }
@@ -289,9 +292,10 @@ __global__ __launch_bounds__(256) void k_sh(const SHArgs a)
         } else {                                                             // thermal :3072-3083
             const double ff = a.use_ff ? ((NS == 4) ? cbo * cbo * cbo * cbo : cbo * cbo) : 0.0;
             double cl = 1.0;
+            const double iff = frcp(1 - ff);
 #pragma unroll
             for (int l = 0; l < NS; ++l) {
-                wmu[l] = (2 * l + 1) * (cl - ff) / (1 - ff);
+                wmu[l] = (2 * l + 1) * (cl - ff) * iff;
                 cl *= cbo;
             }
         }
@@ -299,7 +303,7 @@ __global__ __launch_bounds__(256) void k_sh(const SHArgs a)
 #pragma unroll
         for (int l = 0; l < NS; ++l) {                                       // :2858-2860, :3083
             al[l] = (2 * l + 1) - w0 * wmu[l];
-            bl[l] = THERMAL ? 0.0 : (F * (w0 * wsg[l])) * Pu0[l] / (4 * PI);
+            bl[l] = THERMAL ? 0.0 : (F * (w0 * wsg[l])) * Pu0[l] * (0.25 / PI);
         }
         // ---- modes ----
         Modes<NB> M;
@@ -314,8 +318,8 @@ __global__ __launch_bounds__(256) void k_sh(const SHArgs a)
             const double tau_t = a.tau[o], tau_b = a.tau[o + pitch];
             double ed, eu;
             if constexpr (NB == 2) {                                         // :3397-3416, :3441-3450
-                const double x = 1 / u0, x2 = x * x;
-                const double iDel = 1.0 / (9 * (x2 * x2 - M.beta * x2 + M.gama));
+                const double x = iu0, x2 = x * x;
+                const double iDel = frcp(9 * (x2 * x2 - M.beta * x2 + M.gama));
                 const double a0 = al[0], a1 = al[1], a2 = al[2], a3 = al[3];
                 const double b0 = bl[0], b1_ = bl[1], b2 = bl[2], b3 = bl[3];
                 eta[0] = ((a1 * b0 - b1_ * x) * (a2 * a3 - 9 * x2) + 2 * (a3 * b2 - 2 * a3 * b0 - 3 * b3 * x) * x2) * iDel;
@@ -326,17 +330,17 @@ __global__ __launch_bounds__(256) void k_sh(const SHArgs a)
                 zmn[0] = (eta[0] / 2 - eta[1] + 5 * eta[2] / 8) * 2 * PI;
                 zpl[1] = (-eta[0] / 8 + 5 * eta[2] / 8 + eta[3]) * 2 * PI;
                 zmn[1] = (-eta[0] / 8 + 5 * eta[2] / 8 - eta[3]) * 2 * PI;
-                ed = fexp(-clip35(tau_t / u0));
-                eu = fexp(-clip35(tau_b / u0));
+                ed = fexp(-clip35(tau_t * iu0));
+                eu = fexp(-clip35(tau_b * iu0));
             } else {                                                         // :3240-3265
-                const double x = 1 / u0;
-                const double iDel = 1.0 / (x * x - al[0] * al[1]);
+                const double x = iu0;
+                const double iDel = frcp(x * x - al[0] * al[1]);
                 eta[0] = (bl[1] * x - al[1] * bl[0]) * iDel;
                 eta[1] = (bl[0] * x - al[0] * bl[1]) * iDel;
                 zmn[0] = (0.5 * eta[0] - eta[1]) * 2 * PI;
                 zpl[0] = (0.5 * eta[0] + eta[1]) * 2 * PI;
-                ed = fexp(-tau_t / u0);
-                eu = fexp(-tau_b / u0);
+                ed = fexp(-tau_t * iu0);
+                eu = fexp(-tau_b * iu0);
             }
 #pragma unroll
             for (int r = 0; r < NB; ++r) {
@@ -346,16 +350,16 @@ __global__ __launch_bounds__(256) void k_sh(const SHArgs a)
         } else {                                                             // :3451-3459 / :3266-3270
             B0 = Bn;
             Bn = planck_lambda(a.tlevel[i + 1], wn);
-            b1 = (Bn - B0) / dt;
+            b1 = (Bn - B0) * frcp(dt);
             b1_last = b1;
-            const double om = 1 - w0;
-            zmn_dn[0] = om / al[0] * (B0 / 2 - b1 / al[1]) * 2 * PI;
-            zpl_dn[0] = om / al[0] * (B0 / 2 + b1 / al[1]) * 2 * PI;
-            zmn_up[0] = om / al[0] * (B0 / 2 - b1 / al[1] + b1 * dt / 2) * 2 * PI;
-            zpl_up[0] = om / al[0] * (B0 / 2 + b1 / al[1] + b1 * dt / 2) * 2 * PI;
+            const double oma = (1 - w0) * frcp(al[0]), b1a = b1 * frcp(al[1]);
+            zmn_dn[0] = oma * (B0 / 2 - b1a) * 2 * PI;
+            zpl_dn[0] = oma * (B0 / 2 + b1a) * 2 * PI;
+            zmn_up[0] = oma * (B0 / 2 - b1a + b1 * dt / 2) * 2 * PI;
+            zpl_up[0] = oma * (B0 / 2 + b1a + b1 * dt / 2) * 2 * PI;
             if constexpr (NB == 2) {
-                zmn_dn[1] = zpl_dn[1] = -0.5 * om / (4 * al[0]) * (B0) * 2 * PI;
-                zmn_up[1] = zpl_up[1] = -0.5 * om / (4 * al[0]) * (B0 + b1 * dt) * 2 * PI;
+                zmn_dn[1] = zpl_dn[1] = -0.125 * oma * (B0) * 2 * PI;
+                zmn_up[1] = zpl_up[1] = -0.125 * oma * (B0 + b1 * dt) * 2 * PI;
             }
 #pragma unroll
             for (int l = 0; l < NS; ++l) eta[l] = 0.0;
@@ -385,26 +389,27 @@ __global__ __launch_bounds__(256) void k_sh(const SHArgs a)
 #pragma unroll
             for (int r = 0; r < NB; ++r) {
                 const double alpha = iu1 + M.lam[r], beta = iu1 - M.lam[r];
-                const double ha = (1 - fexp(-clip35(alpha * dt))) / alpha;   // :2929-2937
-                const double hb = (1 - fexp(-clip35(beta * dt))) / beta;
+                const double rab = frcp(alpha * beta);                        // one reciprocal for both
+                const double ha = (1 - fexp(-clip35(alpha * dt))) * (rab * beta);    // :2929-2937
+                const double hb = (1 - fexp(-clip35(beta * dt))) * (rab * alpha);
                 gd[r] = tw * cm[2 * r] * ha;
                 gv[r] = tw * cm[2 * r + 1] * hb * M.E[r];
             }
             if (!THERMAL) {
-                const double exptrm_mus = (1 - fexp(-clip35(mus * dt))) / mus;            // :2901-2905
-                const double tau_mu = a.tau[o] * 1 / u0;
+                const double exptrm_mus = (1 - fexp(-clip35(mus * dt))) * imus;           // :2901-2905
+                const double tau_mu = a.tau[o] * iu0;
                 const double expon1 = exptrm_mus * fexp(-clip35(tau_mu));
                 double Nsum = 0.0;
 #pragma unroll
                 for (int l = 0; l < NS; ++l) Nsum += wmu[l] * Pu1[l] * eta[l] * expon1;   // :2919-2920, 2945-2948
                 const double single = a.w0_og[o] * F / (4 * PI) * psing *
-                                      (1 - fexp(-clip35(mus * a.dtau_og[o]))) * fexp(-a.tau_og[o] / u0) / mus;   // :2959-2965
+                                      (1 - fexp(-clip35(mus * a.dtau_og[o]))) * fexp(-a.tau_og[o] * iu0) * imus;   // :2959-2965
                 c = T * iu1 * (w0 * Nsum + single);
             } else {
                 const double edc = (NB == 2) ? fexp(-clip35(dt * iu1)) : fexp(-dt * iu1);  // :3154 vs :3127
-                const double core = (1 - w0) * u1 / al[0];
+                const double core = (1 - w0) * u1 * frcp(al[0]);
                 const double N0 = wmu[0] * (core * (B0 * (1 - edc) + b1 * (u1 - (dt + u1) * edc)));     // :3128, :3155
-                const double N1 = wmu[1] * Pu1[1] * (core * (b1 * (1 - edc) / al[1]));                  // :3129, :3156
+                const double N1 = wmu[1] * Pu1[1] * (core * (b1 * (1 - edc) * frcp(al[1])));            // :3129, :3156
                 const double ed2 = fexp(-dt * iu1);                                                      // :3163-3165
                 c = T * iu1 * (w0 * (N0 + N1) * 2 * PI +
                                2 * PI * (1 - w0) * u1 * (B0 * (1 - ed2) + b1 * (u1 - (dt + u1) * ed2)));

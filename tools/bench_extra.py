@@ -90,6 +90,26 @@ def main():
     ab = 8 * nw3 * ng * nt * (9 * nlayer + 2 * (nlayer + 1) + 1)
     out["reflected_3d_8x8_%d" % nw3] = dict(ms=ms, GBps=ab / ms / 1e6, algorithmic_bytes=ab,
                                             facet_columns_per_s=nw3 * ng * nt / ms * 1e3)
+    # SH4 reflected (BASELINE configs[3] per-GPU shard sizes): 12 500 and 100 000 wavelengths
+    for nwno in (12500, 100000):
+        sc = syn.make_scene(nlayer, nwno, seed=9, stream=4)
+        names = ("dtau", "tau", "w0", "cosb", "ftau_cld", "ftau_ray", "f_deltaM", "dtau_og", "tau_og",
+                 "w0_og", "cosb_og")
+        dd = resident.upload_scene(sc, names, ctx=ctx)
+        f0 = DeviceArray.from_host(np.ones(nwno), ctx)
+        rs = DeviceArray.from_host(np.zeros(nwno), ctx)
+        x = DeviceArray((5, 1, nwno), ctx)
+        alb = DeviceArray((nwno,), ctx)
+
+        def runsh():
+            check(load().picaso_get_reflected_SH_dev(
+                ctx, ci(nlayer + 1), ci(nwno), ctypes.c_long(nwno), ci(5), ci(1),
+                *[ptr(dd[k].addr) for k in names], ptr(rs.addr), ptr(f64(u0)), ptr(f64(u1)), cd(1.0),
+                ptr(f0.addr), ci(0), ci(0), ci(0), ci(1), ci(1), ci(1), *[cd(v) for v in TTHG], ci(4),
+                cd(0.0), ci(0), ci(0), ci(1), ptr(x.addr), ptr(f64(gw)), ptr(f64(tw)), ptr(alb.addr)), ctx)
+        ms = timeit(runsh, ctx, reps=5)
+        ab = 8 * nwno * (9 * nlayer + 2 * (nlayer + 1) + 2 + 5 + 1)
+        out["reflected_SH4_%d" % nwno] = dict(ms=ms, spectra_per_s=1e3 / ms, GBps_algorithmic=ab / ms / 1e6)
     print(json.dumps(out, indent=1))
 
 
