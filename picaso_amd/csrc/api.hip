@@ -227,6 +227,21 @@ void *picaso_stream(picaso_ctx *ctx) { return (void *)ctx->stream; }
 /* ============================================================================================
  * reflected light
  * ============================================================================================ */
+static ReflectedArgs::Angle make_refl_angle(double v0, double v1, double wgt)
+{
+    const double NL2E = -1.4426950408889634074;
+    ReflectedArgs::Angle g;
+    g.u0 = v0; g.u1 = v1;
+    g.iu0 = 1.0 / v0;
+    g.iu0sq = 1.0 / (v0 * v0);                  // as the reference forms it (fluxes.py:1155)
+    g.nl0 = NL2E / v0; g.nl1 = NL2E / v1;
+    g.nlm = NL2E * (1.0 / v0 + 1.0 / v1);
+    g.wq2 = 2.0 * (v0 / (v0 + v1));
+    g.q2 = (3.0 * 0.767 * 0.767 * v1 * v1 - 1.0) / 2.0;   // ubar2 = 0.767 (fluxes.py:1280)
+    g.wgt = wgt;
+    return g;
+}
+
 int picaso_get_reflected_1d_dev(picaso_ctx *ctx, int nlevel, int nwno, long plane_pitch, int numg,
                                 int numt, const double *dtau, const double *tau, const double *w0,
                                 const double *cosb, const double *gcos2, const double *ftau_cld,
@@ -284,9 +299,7 @@ int picaso_get_reflected_1d_dev(picaso_ctx *ctx, int nlevel, int nwno, long plan
         const size_t lv = (size_t)nlevel * nwno;
         for (int idx = 0; idx < nang; ++idx) {
             const double v0 = ubar0[idx], v1 = ubar1[idx];
-            la.base.u0[0] = v0; la.base.u1[0] = v1;
-            la.base.iu0[0] = 1.0 / v0; la.base.iu1[0] = 1.0 / v1;
-            la.base.iu0sq[0] = 1.0 / (v0 * v0);
+            la.base.ang[0] = make_refl_angle(v0, v1, 0.0);
             la.fm = flux_minus_all + idx * lv; la.fp = flux_plus_all + idx * lv;
             la.fmm = flux_minus_midpt_all + idx * lv; la.fpm = flux_plus_midpt_all + idx * lv;
             PZ_TRY(launch_reflected_lvl(ctx, la));
@@ -300,14 +313,7 @@ int picaso_get_reflected_1d_dev(picaso_ctx *ctx, int nlevel, int nwno, long plan
         for (int k = 0; k < a.na; ++k) {
             const int idx = done + k;
             const double v0 = ubar0[idx], v1 = ubar1[idx];
-            a.u0[k] = v0;
-            a.u1[k] = v1;
-            a.iu0[k] = 1.0 / v0;
-            a.iu1[k] = 1.0 / v1;
-            a.iu0sq[k] = 1.0 / (v0 * v0);              // as the reference forms it (fluxes.py:1155)
-            a.wq[k] = v0 / (v0 + v1);
-            a.q2[k] = (3.0 * 0.767 * 0.767 * v1 * v1 - 1.0) / 2.0;   // ubar2 = 0.767 (fluxes.py:1280)
-            a.wgt[k] = fuse ? gweight[idx / numt] * tweight[idx % numt] : 0.0;
+            a.ang[k] = make_refl_angle(v0, v1, fuse ? gweight[idx / numt] * tweight[idx % numt] : 0.0);
         }
         a.xint = xint_at_top + (size_t)done * nwno;
         a.albedo_first = (c == 0);

@@ -85,12 +85,17 @@ struct ReflectedArgs {
     int single_phase, multi_phase, toon_coefficients;
     double frac_a, frac_b, frac_c, constant_back, constant_forward, b_top;
     // 1-D: angles of this launch (shared planes).  3-D: device tables (nfac) of |ubar|.
+    // Per-angle constants are derived on the host so they arrive as wave-uniform SGPR values (fp64
+    // has no scalar ALU: computing 1/u in the kernel parks uniform values in VGPRs), and are kept
+    // together per angle so that one s_load_dwordx16 fetches everything an angle block needs.
     int na;
-    double u0[MAX_ANGLES], u1[MAX_ANGLES];
-    // derived per-angle constants, precomputed on the host so they arrive as wave-uniform SGPR
-    // values (fp64 has no scalar ALU: computing 1/u in the kernel parks uniform values in VGPRs)
-    double iu0[MAX_ANGLES], iu1[MAX_ANGLES], iu0sq[MAX_ANGLES], wq[MAX_ANGLES], q2[MAX_ANGLES];
-    double wgt[MAX_ANGLES];                 // gweight*tweight per angle (fused disk sum, 1-D)
+    struct Angle {
+        double u1, iu0, iu0sq, nl1, q2;     // used by the symmetric-geometry (ubar0 == ubar1) kernel
+        double u0, nl0, nlm, wq2, wgt;
+        // iu0sq = 1/(u0 u0) as the reference forms it (fluxes.py:1155); nl0/nl1/nlm = -log2(e)/u0,
+        // -log2(e)/u1, -log2(e)(1/u0 + 1/u1): exp(-x/u) = 2^(x nl); wq2 = 2 u0/(u0+u1);
+        // q2 = (3 ubar2^2 u1^2 - 1)/2, ubar2 = 0.767 (fluxes.py:1280); wgt = gweight*tweight
+    } ang[MAX_ANGLES];
     const double *u0_tab, *u1_tab;          // 3-D
     double *xint;                           // 1-D: this launch's first angle row, (na, nwno); 3-D: (nfac, nwno)
     double *albedo;                         // nullable; 1-D fused compress_disco accumulator

@@ -52,6 +52,61 @@ __device__ __forceinline__ double fexp(double x)
     return ldexp(1.0 + p, (int)k);
 }
 
+// 2^t, <= 1 ulp, 15 VALU instructions: t = n + f with f = t - rint(t) exact, degree-11 polynomial
+// 1 + f (c0 + c1 f + ... + c10 f^10) (Chebyshev-node interpolant of (2^f - 1)/f on |f| <= 1/2,
+// max rel. error 1.14e-16 including evaluation rounding).  The kernels call it as
+// fexp2(dtau * (-log2(e)/u)) with the per-angle constant formed on the host, which saves the
+// argument multiply and the two-term ln2 reduction of fexp: exp(-dtau/u) then carries
+// ~2 eps |dtau/u| of argument error instead of the reference's 1 eps |dtau/u| (np.exp(-dtau/u)).
+// Saturating v_cvt_i32_f64 + v_ldexp_f64 give 0 / inf at the extremes; NaN propagates.
+constexpr double NEG_LOG2E = -1.4426950408889634074;
+__device__ __forceinline__ double fexp2(double t)
+{
+    const double n = __builtin_rint(t);
+    const double f = t - n;
+    double p = horner_step(0x1.e9d3fe3952179p-32, f, 0x1.e6063f7217bc6p-28);
+    p = horner_step(p, f, 0x1.b524fae627834p-24);
+    p = horner_step(p, f, 0x1.62bfd47773353p-20);
+    p = horner_step(p, f, 0x1.ffcbfc670dcd4p-17);
+    p = horner_step(p, f, 0x1.430913096fd9fp-13);
+    p = horner_step(p, f, 0x1.5d87fe78a5276p-10);
+    p = horner_step(p, f, 0x1.3b2ab6fba1ddap-7);
+    p = horner_step(p, f, 0x1.c6b08d704a0c2p-5);
+    p = horner_step(p, f, 0x1.ebfbdff82c598p-3);
+    p = horner_step(p, f, 0x1.62e42fefa39efp-1);
+    return ldexp(fma(f, p, 1.0), (int)n);
+}
+
+// The same polynomial with its coefficients held in VGPRs as ordinary (opaque) values: the compiler
+// then selects the 3-address v_fma_f64 by itself (the coefficient is live across the loop, so the
+// 2-address v_fmac_f64 is not an option) and, unlike around inline asm, it knows the instruction:
+// no conservative s_nop after every Horner step (128 per layer in the 5-angle reflected kernel,
+// ~3.7 cycles each when a wave runs alone on its SIMD; tools/ubench/f64_rates.hip).
+struct Exp2Coef {
+    double c[11];
+    __device__ __forceinline__ void load()
+    {
+        const double k[11] = {0x1.62e42fefa39efp-1, 0x1.ebfbdff82c598p-3, 0x1.c6b08d704a0c2p-5,
+                              0x1.3b2ab6fba1ddap-7, 0x1.5d87fe78a5276p-10, 0x1.430913096fd9fp-13,
+                              0x1.ffcbfc670dcd4p-17, 0x1.62bfd47773353p-20, 0x1.b524fae627834p-24,
+                              0x1.e6063f7217bc6p-28, 0x1.e9d3fe3952179p-32};
+#pragma unroll
+        for (int i = 0; i < 11; ++i) {
+            c[i] = k[i];
+            asm volatile("" : "+v"(c[i]));      // opaque: not rematerialisable as a literal
+        }
+    }
+};
+__device__ __forceinline__ double fexp2(double t, const Exp2Coef &K)
+{
+    const double n = __builtin_rint(t);
+    const double f = t - n;
+    double p = fma(K.c[10], f, K.c[9]);
+#pragma unroll
+    for (int i = 8; i >= 0; --i) p = fma(p, f, K.c[i]);
+    return ldexp(fma(f, p, 1.0), (int)n);
+}
+
 // 1/b to ~1 ulp: v_rcp_f64 (2^-23 relative) + two Newton steps, 5 instructions
 // (a correctly rounded a/b costs 11 with div_scale/div_fmas/div_fixup).
 __device__ __forceinline__ double frcp(double b)

@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void k_reflected_lvl(const ReflectedLvlArgs A)
     if (w >= a.ncol) return;
     const int n = a.nlayer;
     const long pitch = a.pitch, nw = a.nwno;
-    const double u0 = a.u0[0], iu0 = a.iu0[0], iu0sq = a.iu0sq[0];
+    const double u0 = a.ang[0].u0, iu0 = a.ang[0].iu0, iu0sq = a.ang[0].iu0sq;
     const double F = a.F0PI[w], rs = a.surf_reflect[w];
     double *s_rho = A.scratch + w, *s_del = s_rho + (long)n * nw, *s_s = s_del + (long)n * nw,
            *s_t = s_s + (long)n * nw;

@@ -84,6 +84,7 @@ struct ReflState {
 struct LayerIn {
     double dt, tau_n, w0, g, gcos2, fc, fr, dto, tauo, tauo_n, w0o, cbo;
     bool cum_tau, cum_tauo;   // wave-uniform: tau[i+1] == tau[i] + dtau[i] (resp. tau_og) bit-exactly
+    bool same_dt;             // wave-uniform: dtau_og == dtau (no delta-scaling in this layer)
 };
 
 // One layer of the sweep.  FIRST / LAST are compile-time so the top row and the bottom-boundary
@@ -95,11 +96,10 @@ struct LayerIn {
 // planes still take the direct exp(-tau/u0).
 template <int NA, bool IS3D, bool ZP, bool FIRST, bool LAST, bool LDS>
 __device__ __forceinline__ void reflected_layer(const ReflectedArgs &a, const LayerIn &L,
-                                                ReflState<NA, LDS> &S, const double (&u0)[NA],
-                                                const double (&u1)[NA], const double (&iu0)[NA],
-                                                const double (&iu1)[NA], const double (&iu0sq)[NA],
-                                                const double (&wq)[NA], const double (&q2)[NA],
-                                                double F, double clip, int tc, double b_top)
+                                                ReflState<NA, LDS> &S,
+                                                const ReflectedArgs::Angle (&g)[NA],
+                                                const Exp2Coef &K, double F, double clip, int tc,
+                                                double b_top)
 {
     const double dt = L.dt, w0 = L.w0;
     // ---- angle-independent layer quantities (fluxes.py:1132-1141, 1172-1177) ----
@@ -108,25 +108,39 @@ __device__ __forceinline__ void reflected_layer(const ReflectedArgs &a, const La
     toon_gammas(tc, w0, fcg, g1, g2, lam, lam2);
     const double gam = (g1 - lam) * frcp(g2);
     const double E = fmin(lam * dt, clip);
-    const double EP = fexp(E);
+    const double EP = fexp2(E * -NEG_LOG2E, K);
     const double EM = frcp(EP);
     const double ps = p_single<IS3D>(a.single_phase, L.cbo, L.gcos2, L.fc, L.fr, a.cos_theta, a.frac_a,
                                      a.frac_b, a.frac_c, a.constant_back, a.constant_forward);
-    const double ssa = (L.w0o * F * (0.25 / PI)) * ps;    // fluxes.py:1397-1398
+    const double ssa_h = (L.w0o * F * (0.125 / PI)) * ps;  // (w0_og F0PI/4pi) p_single / 2, fluxes.py:1397-1398
     const double w2pi = w0 * (0.5 / PI);                   // fluxes.py:1290-1296
-    const double Fw0 = F * w0;
+    const double Fw0h = (0.5 * F) * w0;
     const double gcq = (a.multi_phase == 0) ? L.gcos2 : 0.0;   // N=2 vs N=1 (fluxes.py:1275-1287)
+    // The direct-beam coefficients (fluxes.py:1146-1169) with g3 = 1/2 - c u0, g4 = 1/2 + c u0
+    // (c = sqrt(3) fcg/2 quadrature, 3 fcg/4 Eddington) and u0 (1/u0) = 1 collapse to
+    //   2 (g4 (g1 + 1/u0) + g2 g3) = A0 + hz,   2 (g3 (g1 - 1/u0) + g2 g4) = A0 - hz,
+    //   A0 = g1 + g2 + 2c,  hz = 1/u0 + 2c (g1 - g2) u0,
+    // and the multiple-scattering brackets (fluxes.py:1275-1296) with B0 = 1 + gcos2 q2 to
+    //   (1 + 1.5 fcg u1 + q) + Gamma (1 - 1.5 fcg u1 + q) = (1 + Gamma) B0 + (1 - Gamma) 1.5 fcg u1  etc.
+    const double c2 = (tc == 1) ? 1.5 * fcg : SQ3 * fcg;
+    const double A0 = (g1 + g2) + c2;
+    const double A1 = c2 * (g1 - g2);
+    const double c15 = 1.5 * fcg;
+    const double gp = 1.0 + gam;
+    const double gmc = (1.0 - gam) * c15;
 
     // ---- elimination factors shared by all angles ----
-    double inv = 0.0, a1 = 0.0, a2 = 0.0, ia = 0.0, rho_n = gam, sfac = 0.0;
+    double a1i = 0.0, a2i = 0.0, ia = 0.0, rho_n = gam, sfac = 0.0;
     if (!FIRST) {
         const double em2 = S.pEM * S.pEM;
-        a1 = 1.0 - S.pgam * em2 * S.rho;
-        a2 = S.pgam - em2 * S.rho;
+        const double a1 = 1.0 - S.pgam * em2 * S.rho;
+        const double a2 = S.pgam - em2 * S.rho;
         const double d1 = a1 - gam * a2;
         const double r12 = frcp(d1 * a1);                  // one reciprocal for 1/d1 and 1/a1
-        inv = r12 * a1;
-        rho_n = (gam * a1 - a2) * inv;
+        const double inv = r12 * a1;
+        a1i = a1 * inv;
+        a2i = a2 * inv;
+        rho_n = gam * a1i - a2i;
         ia = S.pEM * (r12 * d1);
         sfac = (1.0 - gam * rho_n) * ia;
     }
@@ -134,54 +148,58 @@ __device__ __forceinline__ void reflected_layer(const ReflectedArgs &a, const La
 
 #pragma unroll
     for (int k = 0; k < NA; ++k) {
-        // direct-beam particular solution (fluxes.py:1146-1169)
-        double g3;
-        if (tc == 1) g3 = (2.0 - 3.0 * fcg * u0[k]) * 0.25;
-        else g3 = 0.5 * (1.0 - SQ3 * fcg * u0[k]);
-        const double g4 = 1.0 - g3;
-        const double den = sub_unfused(lam2, iu0sq[k]);    // lambda^2 - 1/u0^2, reference rounding
-        const double lu = lam * u1[k];
+        const double u1_k = g[k].u1, u0_k = ZP ? g[k].u1 : g[k].u0, iu0_k = g[k].iu0, iu0sq_k = g[k].iu0sq;
+        const double nl1_k = g[k].nl1, nl0_k = ZP ? g[k].nl1 : g[k].nl0, q2_k = g[k].q2;
+        const double wq2_k = ZP ? 1.0 : g[k].wq2;
+        const double den = sub_unfused(lam2, iu0sq_k);    // lambda^2 - 1/u0^2, reference rounding
+        const double lu = lam * u1_k;
         const double lm1 = lu - 1.0, lp1 = lu + 1.0;
-        // One v_rcp_f64 (quarter rate) for the three reciprocals.  Every factor is itself good to
-        // 1 ulp (lm1 is exact by Sterbenz near the lambda u1 = 1 singularity), so the three results
+        // One v_rcp_f64 (quarter rate) for 1/den, 1/(lu-1) and 1/(lu+1).  Every factor is itself good
+        // to 1 ulp (lm1 is exact by Sterbenz near the lambda u1 = 1 singularity), so the results
         // stay within a few ulp -- which matters: at lambda u1 -> 1 the particular and homogeneous
         // parts cancel with an amplification ~1/|lambda u1 - 1|.
         const double lml = lm1 * lp1;
         const double r3 = frcp(den * lml);
-        const double rden = r3 * lml;
-        const double rlm = (r3 * den) * lp1;               // 1/(lu - 1)
-        const double rlp = (r3 * den) * lm1;               // 1/(lu + 1)
-        const double fw_den = Fw0 * rden;
-        const double am = fw_den * (g4 * (g1 + iu0[k]) + g2 * g3);
-        const double ap = fw_den * (g3 * (g1 - iu0[k]) + g2 * g4);
-        const double et = fexp(-dt * iu1[k]);
+        const double rden = r3 * lml;                      // 1/den
+        const double rd = r3 * den;                        // 1/((lu-1)(lu+1))
+        const double hz = fma(A1, u0_k, iu0_k);
+        const double am2 = A0 + hz, ap2 = A0 - hz;
+        const double et = fexp2(dt * nl1_k, K);              // exp(-dtau/u1)
         const double xu = S.get(S_XU, k), Tk = S.get(S_T, k);
-        const double xd = (ZP && L.cum_tau) ? xu * et : fexp(-L.tau_n * iu0[k]);
-        const double cmu = am * xu, cpu = ap * xu;
-        const double cmd = am * xd, cpd = ap * xd;
+        const double xd = (ZP && L.cum_tau) ? xu * et : fexp2(L.tau_n * nl0_k, K);
+        const double fw = Fw0h * rden;
+        const double fx = fw * xu, fxd = fw * xd;
+        const double cmu = am2 * fx, cpu = ap2 * fx;       // c-/c+ at the top of the layer
+        const double cmd = am2 * fxd, cpd = ap2 * fxd;     // ... and at the bottom
         S.set(S_XU, k, xd);
         // source-function coefficients (fluxes.py:1275-1296, 1395-1406)
-        const double q = gcq * q2[k];
-        const double h15 = 1.5 * fcg * u1[k];
-        const double mpl = 1.0 + h15 + q, mmi = 1.0 - h15 + q;
-        const double Tw = Tk * w2pi;
-        double vp = Tw * (mpl + gam * mmi) * (EP * et - 1.0) * rlm;
-        double vn = Tw * (gam * mpl + mmi) * (1.0 - EM * et) * rlp;
-        const double Aq = (mpl * cpu + mmi * cmu) * w2pi;
+        const double B0 = fma(gcq, q2_k, 1.0);
+        const double h15 = c15 * u1_k;
+        const double Aqq = fma(B0, A0, -(h15 * hz));       // (mpl c+ + mmi c-) / (2 fx)
+        const double X = gp * B0, Y = gmc * u1_k;
+        const double Tw = Tk * w2pi, Trd = Tw * rd;
+        const double ee = fma(EP, et, -1.0), ff = fma(-EM, et, 1.0);
+        double vp = (Trd * lp1) * ((X + Y) * ee);
+        double vn = (Trd * lm1) * ((X - Y) * ff);
         const double eo = S.get(S_EO, k);                  // exp(-tau_og[i]/u0)
         double t1, t2;                                     // 1 - exp(-dtau_og*mus), 1 - exp(-dtau*mus)
         if (ZP) {
-            const double e1 = fexp(-L.dto * iu1[k]);
-            t1 = 1.0 - e1 * e1;
-            t2 = 1.0 - et * et;
-            if (!LAST) S.set(S_EO, k, L.cum_tauo ? eo * e1 : fexp(-L.tauo_n * iu0[k]));
+            t2 = fma(-et, et, 1.0);
+            double e1 = et;
+            t1 = t2;
+            if (!L.same_dt) {                              // delta-scaled layer: dtau_og != dtau
+                e1 = fexp2(L.dto * nl1_k, K);
+                t1 = fma(-e1, e1, 1.0);
+            }
+            if (!LAST) S.set(S_EO, k, L.cum_tauo ? eo * e1 : fexp2(L.tauo_n * nl0_k, K));
         } else {
-            const double mus = iu0[k] + iu1[k];
-            t1 = 1.0 - fexp(-L.dto * mus);
-            t2 = 1.0 - fexp(-dt * mus);
-            if (!LAST) S.set(S_EO, k, fexp(-L.tauo_n * iu0[k]));
+            t1 = 1.0 - fexp2(L.dto * g[k].nlm, K);
+            t2 = 1.0 - fexp2(dt * g[k].nlm, K);
+            if (!LAST) S.set(S_EO, k, fexp2(L.tauo_n * nl0_k, K));
         }
-        const double S0 = (ssa * eo * t1 + Aq * t2) * wq[k];
+        // S0 = (ssa eo t1 + Aq t2) u0/(u0+u1) with Aq = 2 w2pi fx Aqq; wq2 = 2 u0/(u0+u1) (1 if ZP)
+        const double s1 = (ssa_h * wq2_k) * (eo * t1);
+        const double S0 = fma((w2pi * wq2_k) * fx, Aqq * t2, s1);
         double kap = fma(Tk, S0, S.get(S_KAPPA, k));
         const double Tn = Tk * et;
         if (LAST) {                                        // xint[n] = flux_zero/pi (fluxes.py:1266-1270)
@@ -198,7 +216,7 @@ __device__ __forceinline__ void reflected_layer(const ReflectedArgs &a, const La
             const double rP = cpu - S.get(S_D1, k);
             const double rM = cmu - S.get(S_D2, k);
             const double zeta = S.get(S_ZETA, k);
-            delta_n = (a2 * rP - a1 * rM) * inv;
+            delta_n = a2i * rP - a1i * rM;
             const double t = (gam * delta_n + rP) * ia;
             kap += zeta * t + vn * delta_n;
             S.set(S_ZETA, k, zeta * sfac + vp - vn * rho_n);
@@ -227,26 +245,26 @@ __global__ __launch_bounds__(256, PZ_REFL_MINWAVES) void k_reflected_toa(const R
     const int tc = IS3D ? 0 : a.toon_coefficients;     // 3-D is quadrature only (fluxes.py:489)
     const double b_top = IS3D ? 0.0 : a.b_top;         // fluxes.py:522
 
-    double u0[NA], u1[NA], iu0[NA], iu1[NA], iu0sq[NA], wq[NA], q2[NA];
+    Exp2Coef K;
+    K.load();
+    ReflectedArgs::Angle g[NA];
 #pragma unroll
     for (int k = 0; k < NA; ++k) {
         if (IS3D) {
-            u0[k] = fabs(a.u0_tab[fac]);                // fluxes.py:467-468
-            u1[k] = fabs(a.u1_tab[fac]);
-            iu1[k] = 1.0 / u1[k];
-            iu0[k] = 1.0 / u0[k];
-            iu0sq[k] = 1.0 / (u0[k] * u0[k]);          // as the reference forms it (fluxes.py:1155)
-            wq[k] = u0[k] / (u0[k] + u1[k]);
+            const double v0 = fabs(a.u0_tab[fac]), v1 = fabs(a.u1_tab[fac]);   // fluxes.py:467-468
+            g[k].u0 = v0;
+            g[k].u1 = v1;
+            g[k].iu0 = 1.0 / v0;
+            g[k].iu0sq = 1.0 / (v0 * v0);              // as the reference forms it (fluxes.py:1155)
+            g[k].nl0 = NEG_LOG2E / v0;
+            g[k].nl1 = NEG_LOG2E / v1;
+            g[k].nlm = NEG_LOG2E * (1.0 / v0 + 1.0 / v1);
+            g[k].wq2 = 2.0 * (v0 / (v0 + v1));
             const double ubar2 = 0.767;                 // fluxes.py:1280
-            q2[k] = (3.0 * ubar2 * ubar2 * u1[k] * u1[k] - 1.0) / 2.0;
+            g[k].q2 = (3.0 * ubar2 * ubar2 * v1 * v1 - 1.0) / 2.0;
+            g[k].wgt = 0.0;
         } else {                                        // host-precomputed, wave-uniform
-            u0[k] = a.u0[k];
-            u1[k] = a.u1[k];
-            iu1[k] = a.iu1[k];
-            iu0[k] = ZP ? a.iu1[k] : a.iu0[k];
-            iu0sq[k] = a.iu0sq[k];
-            wq[k] = ZP ? 0.5 : a.wq[k];
-            q2[k] = a.q2[k];
+            g[k] = a.ang[k];
         }
     }
     const double F = a.F0PI[w], rs = a.surf_reflect[w];
@@ -271,8 +289,9 @@ __global__ __launch_bounds__(256, PZ_REFL_MINWAVES) void k_reflected_toa(const R
             S.set(S_ZETA, k, 0.0);
             S.set(S_D1, k, 0.0);
             S.set(S_D2, k, 0.0);
-            S.set(S_XU, k, fexp(-tau_i * iu0[k]));
-            S.set(S_EO, k, fexp(-tauo0 * iu0[k]));
+            const double nl0_k = ZP ? g[k].nl1 : g[k].nl0;
+            S.set(S_XU, k, fexp2(tau_i * nl0_k, K));
+            S.set(S_EO, k, fexp2(tauo0 * nl0_k, K));
         }
     }
 
@@ -286,6 +305,12 @@ __global__ __launch_bounds__(256, PZ_REFL_MINWAVES) void k_reflected_toa(const R
         cur = nx;
         if (i + 1 < n) {
             const long o = (long)(i + 1) * pitch;
+#ifdef PZ_EXP_NOLOAD   // experiment: no plane traffic inside the loop (results are wrong)
+            asm volatile("" : "+v"(nx.dt), "+v"(nx.tau_n), "+v"(nx.w0), "+v"(nx.g), "+v"(nx.gcos2), "+v"(nx.fc));
+            asm volatile("" : "+v"(nx.fr), "+v"(nx.dto), "+v"(nx.tauo), "+v"(nx.w0o), "+v"(nx.cbo));
+            if (o < 0)
+#endif
+            {
             nx.dt = p_dtau[o];
             nx.tau_n = p_tau[o + pitch];
             nx.w0 = p_w0[o];
@@ -297,13 +322,15 @@ __global__ __launch_bounds__(256, PZ_REFL_MINWAVES) void k_reflected_toa(const R
             nx.tauo = p_tauo[o];
             nx.w0o = p_w0o[o];
             nx.cbo = p_cbo[o];
+            }
         }
         cur.tauo_n = nx.tauo;     // tau_og of the level below (unused in the last layer)
         if (ZP) {
             cur.cum_tau = __all(cur.tau_n == tau_i + cur.dt);
             cur.cum_tauo = __all(cur.tauo_n == cur.tauo + cur.dto);
+            cur.same_dt = __all(cur.dto == cur.dt);
         } else {
-            cur.cum_tau = cur.cum_tauo = false;
+            cur.cum_tau = cur.cum_tauo = cur.same_dt = false;
         }
         tau_i = cur.tau_n;
     };
@@ -311,16 +338,16 @@ __global__ __launch_bounds__(256, PZ_REFL_MINWAVES) void k_reflected_toa(const R
     LayerIn cur;
     if (n == 1) {
         advance(0, cur);
-        reflected_layer<NA, IS3D, ZP, true, true, LDS>(a, cur, S, u0, u1, iu0, iu1, iu0sq, wq, q2, F, clip, tc, b_top);
+        reflected_layer<NA, IS3D, ZP, true, true, LDS>(a, cur, S, g, K, F, clip, tc, b_top);
     } else {
         advance(0, cur);
-        reflected_layer<NA, IS3D, ZP, true, false, LDS>(a, cur, S, u0, u1, iu0, iu1, iu0sq, wq, q2, F, clip, tc, b_top);
+        reflected_layer<NA, IS3D, ZP, true, false, LDS>(a, cur, S, g, K, F, clip, tc, b_top);
         for (int i = 1; i < n - 1; ++i) {
             advance(i, cur);
-            reflected_layer<NA, IS3D, ZP, false, false, LDS>(a, cur, S, u0, u1, iu0, iu1, iu0sq, wq, q2, F, clip, tc, b_top);
+            reflected_layer<NA, IS3D, ZP, false, false, LDS>(a, cur, S, g, K, F, clip, tc, b_top);
         }
         advance(n - 1, cur);
-        reflected_layer<NA, IS3D, ZP, false, true, LDS>(a, cur, S, u0, u1, iu0, iu1, iu0sq, wq, q2, F, clip, tc, b_top);
+        reflected_layer<NA, IS3D, ZP, false, true, LDS>(a, cur, S, g, K, F, clip, tc, b_top);
     }
 
     // ---- surface row (fluxes.py:178-183) and output ----
@@ -331,12 +358,12 @@ __global__ __launch_bounds__(256, PZ_REFL_MINWAVES) void k_reflected_toa(const R
     double alb = 0.0;
 #pragma unroll
     for (int k = 0; k < NA; ++k) {
-        const double b_surface = 0.0 + rs * u0[k] * F * S.get(S_XU, k);
+        const double b_surface = 0.0 + rs * (ZP ? g[k].u1 : g[k].u0) * F * S.get(S_XU, k);
         const double pos = S.pEM * (b_surface - S.get(S_D1, k) + rs * S.get(S_D2, k)) * bden;
         const double x = S.get(S_KAPPA, k) + S.get(S_ZETA, k) * pos;
         if (IS3D) a.xint[(long)fac * a.nwno + w] = x;
         else a.xint[(long)k * a.nwno + w] = x;
-        alb = alb + x * a.wgt[k];
+        alb = alb + x * g[k].wgt;
     }
     if (!IS3D && a.albedo) {                              // fused disco.compress_disco (disco.py:145-148)
         double acc = a.albedo_first ? alb : a.albedo[w] + alb;
@@ -351,7 +378,7 @@ static int launch1d(picaso_ctx *ctx, const ReflectedArgs &a)
     const int block = 256;
     const long grid = (a.ncol + block - 1) / block;
     bool zp = true;
-    for (int k = 0; k < a.na; ++k) zp = zp && (a.u0[k] == a.u1[k]);
+    for (int k = 0; k < a.na; ++k) zp = zp && (a.ang[k].u0 == a.ang[k].u1);
     if (zp)
         hipLaunchKernelGGL((k_reflected_toa<NA, false, true>), dim3((unsigned)grid), dim3(block), 0,
                            ctx->stream, a);

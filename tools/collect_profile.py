@@ -1,0 +1,42 @@
+#!/usr/bin/env python
+"""Condense a tools/profile.sh output directory (gpurun_out/prof_<tag>) into the small summaries kept
+under profiles/: <name>_kernel_stats.csv, <name>_pmc_summary.csv and traffic.json.
+
+    python tools/collect_profile.py gpurun_out/prof_r01v3 r01_v3
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+src, name = sys.argv[1], sys.argv[2]
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+dst = os.path.join(root, "profiles")
+stats = glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True)
+if stats:
+    shutil.copy(stats[0], os.path.join(dst, name + "_kernel_stats.csv"))
+agg = collections.defaultdict(lambda: [0, 0.0])
+for f in sorted(glob.glob(os.path.join(src, "pmc_*", "**", "*counter_collection.csv"), recursive=True)):
+    for row in csv.DictReader(open(f)):
+        k = (row.get("Kernel_Name", ""), row.get("Counter_Name"))
+        agg[k][0] += 1
+        agg[k][1] += float(row.get("Counter_Value", 0))
+with open(os.path.join(dst, name + "_pmc_summary.csv"), "w") as fh:
+    w = csv.writer(fh)
+    w.writerow(["kernel", "counter", "dispatches", "mean_per_dispatch"])
+    for (kern, ctr), (n, v) in sorted(agg.items()):
+        w.writerow([kern, ctr, n, "%.6g" % (v / n)])
+# HBM traffic of the headline kernel: FETCH_SIZE / WRITE_SIZE are in KB; FETCH_SIZE under-counts by
+# 2x on gfx950 (MI355X_MICROARCH.md, HBM / rocprofv3 section), collected in separate passes.
+fetch = [v / n for (k, c), (n, v) in agg.items() if c == "FETCH_SIZE" and "k_reflected_toa<5" in k]
+write = [v / n for (k, c), (n, v) in agg.items() if c == "WRITE_SIZE" and "k_reflected_toa<5" in k]
+if fetch and write:
+    json.dump({"hbm_bytes_per_launch": (2.0 * fetch[0] + write[0]) * 1024.0,
+               "source": "profiles/%s_pmc_summary.csv" % name,
+               "note": "(2*FETCH_SIZE + WRITE_SIZE) KB per dispatch of k_reflected_toa<5,false,true>; "
+                       "FETCH_SIZE doubled per the gfx950 correction in MI355X_MICROARCH.md"},
+              open(os.path.join(dst, "traffic.json"), "w"), indent=1)
+print(open(os.path.join(dst, name + "_pmc_summary.csv")).read())

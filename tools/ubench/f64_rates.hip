@@ -29,6 +29,11 @@ __global__ __launch_bounds__(256) void k(double* out, long long* cyc, double see
             if (OP == 9) { asm volatile("v_mov_b64 %0, %1\n v_mov_b64 %1, %2\n v_mov_b64 %2, %3\n v_mov_b64 %3, %4\n v_mov_b64 %4, %5\n v_mov_b64 %5, %6\n v_mov_b64 %6, %7\n v_mov_b64 %7, %0" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)); }
             if (OP == 10) { asm volatile("v_cndmask_b32 %0, %0, %1, vcc\n v_cndmask_b32 %1, %1, %0, vcc\n v_cndmask_b32 %0, %0, %1, vcc\n v_cndmask_b32 %1, %1, %0, vcc\n v_cndmask_b32 %0, %0, %1, vcc\n v_cndmask_b32 %1, %1, %0, vcc\n v_cndmask_b32 %0, %0, %1, vcc\n v_cndmask_b32 %1, %1, %0, vcc" : "+v"(e0), "+v"(e1) : : "vcc"); }
             if (OP == 11) { asm volatile("v_lshl_add_u32 %0, %0, 1, %1\n v_lshl_add_u32 %1, %1, 1, %0\n v_lshl_add_u32 %0, %0, 1, %1\n v_lshl_add_u32 %1, %1, 1, %0\n v_lshl_add_u32 %0, %0, 1, %1\n v_lshl_add_u32 %1, %1, 1, %0\n v_lshl_add_u32 %0, %0, 1, %1\n v_lshl_add_u32 %1, %1, 1, %0" : "+v"(e0), "+v"(e1)); }
+            if (OP == 15) { int f0=e0,f1=e1,f2=e0+1,f3=e1+1; asm volatile("v_cndmask_b32 %0, %0, %4, vcc\n v_cndmask_b32 %1, %1, %4, vcc\n v_cndmask_b32 %2, %2, %4, vcc\n v_cndmask_b32 %3, %3, %4, vcc\n v_cndmask_b32 %0, %0, %5, vcc\n v_cndmask_b32 %1, %1, %5, vcc\n v_cndmask_b32 %2, %2, %5, vcc\n v_cndmask_b32 %3, %3, %5, vcc" : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3) : "v"(e0), "v"(e1) : "vcc"); e0 += f0+f1+f2+f3; }
+            if (OP == 16) { int f0=e0,f1=e1,f2=e0+1,f3=e1+1; asm volatile("v_cndmask_b32_e64 %0, %0, %4, s[20:21]\n v_cndmask_b32_e64 %1, %1, %4, s[20:21]\n v_cndmask_b32_e64 %2, %2, %4, s[20:21]\n v_cndmask_b32_e64 %3, %3, %4, s[20:21]\n v_cndmask_b32_e64 %0, %0, %5, s[20:21]\n v_cndmask_b32_e64 %1, %1, %5, s[20:21]\n v_cndmask_b32_e64 %2, %2, %5, s[20:21]\n v_cndmask_b32_e64 %3, %3, %5, s[20:21]" : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3) : "v"(e0), "v"(e1) : "s20", "s21"); e0 += f0+f1+f2+f3; }
+            if (OP == 17) { asm volatile("v_fma_f64 %0, %0, %8, %9\n s_nop 0\n v_fma_f64 %0, %0, %8, %9\n s_nop 0\n v_fma_f64 %0, %0, %8, %9\n s_nop 0\n v_fma_f64 %0, %0, %8, %9\n s_nop 0\n v_fma_f64 %0, %0, %8, %9\n s_nop 0\n v_fma_f64 %0, %0, %8, %9\n s_nop 0\n v_fma_f64 %0, %0, %8, %9\n s_nop 0\n v_fma_f64 %0, %0, %8, %9\n s_nop 0" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c), "v"(d)); }
+            if (OP == 18) { asm volatile("v_cmp_gt_f64 vcc, %0, %8\n v_cmp_gt_f64 vcc, %1, %8\n v_cmp_gt_f64 vcc, %2, %8\n v_cmp_gt_f64 vcc, %3, %8\n v_cmp_gt_f64 vcc, %4, %8\n v_cmp_gt_f64 vcc, %5, %8\n v_cmp_gt_f64 vcc, %6, %8\n v_cmp_gt_f64 vcc, %7, %8" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(d) : "vcc"); }
+            if (OP == 19) { asm volatile("v_readlane_b32 s20, %0, 0\n v_readlane_b32 s21, %0, 1\n v_readlane_b32 s20, %1, 0\n v_readlane_b32 s21, %1, 1\n v_readlane_b32 s20, %0, 2\n v_readlane_b32 s21, %0, 3\n v_readlane_b32 s20, %1, 2\n v_readlane_b32 s21, %1, 3" : "+v"(e0), "+v"(e1) : : "s20", "s21"); }
             if (OP == 12) { asm volatile("v_fma_f64 %0, %0, %8, %9\n v_fma_f64 %0, %0, %8, %9\n v_fma_f64 %0, %0, %8, %9\n v_fma_f64 %0, %0, %8, %9\n v_fma_f64 %0, %0, %8, %9\n v_fma_f64 %0, %0, %8, %9\n v_fma_f64 %0, %0, %8, %9\n v_fma_f64 %0, %0, %8, %9" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c), "v"(d)); }
             if (OP == 13) { asm volatile("v_sqrt_f64 %0, %0\n v_sqrt_f64 %1, %1\n v_sqrt_f64 %2, %2\n v_sqrt_f64 %3, %3\n v_sqrt_f64 %4, %4\n v_sqrt_f64 %5, %5\n v_sqrt_f64 %6, %6\n v_sqrt_f64 %7, %7" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)); }
             if (OP == 14) { asm volatile("v_fma_f64 %0, %0, %8, %9\n v_fma_f64 %1, %1, %8, %9\n v_fma_f64 %2, %2, %8, %9\n v_fma_f64 %3, %3, %8, %9\n v_fma_f64 %4, %4, %8, %9\n v_fma_f64 %5, %5, %8, %9\n v_fma_f64 %6, %6, %8, %9\n v_fma_f64 %7, %7, %8, %9" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "s"(c), "v"(d)); }
@@ -66,6 +71,7 @@ int main()
     for (int w = 1; w <= 2; ++w) {
         run<0>("v_fma_f64", w); run<14>("v_fma_f64(sgpr)", w); run<12>("v_fma_f64 dep", w); run<1>("v_mul_f64", w); run<2>("v_add_f64", w); run<8>("v_max_f64", w);
         run<3>("v_rcp_f64", w); run<7>("v_rsq_f64", w); run<13>("v_sqrt_f64", w); run<4>("v_rndne_f64", w); run<5>("v_ldexp_f64", w); run<6>("v_cvt_i32_f64", w);
-        run<9>("v_mov_b64", w); run<10>("v_cndmask_b32", w); run<11>("v_lshl_add_u32", w);
+        run<9>("v_mov_b64", w); run<10>("v_cndmask_b32 dep", w); run<15>("v_cndmask vcc ind", w); run<16>("v_cndmask sgpr ind", w); run<11>("v_lshl_add_u32", w);
+        run<17>("v_fma dep + s_nop", w); run<18>("v_cmp_gt_f64", w); run<19>("v_readlane_b32", w);
     }
 }
