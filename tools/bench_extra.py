@@ -64,6 +64,30 @@ def main():
                                                            "(1.46 GB) the reference signature returns")
             # level fluxes (climate caller shape: one angle)
             dd = resident.upload_scene(sc, resident.REFLECTED_PLANES, ctx=ctx)
+    # Headline workload variants: (a) as bench.py (cloud slab in 10 of 90 layers: the other layers
+    # are not delta-scaled and skip the second exponential), (b) cloud in every layer (every layer
+    # delta-scaled: no shortcut), (c) phase angle 60 deg (ubar0 != ubar1: general kernel)
+    nwno = 100000
+    base = syn.make_scene(nlayer, nwno, seed=3)
+    comps = [base[k].copy() for k in ("taugas", "tauray", "taucld", "w0_cld", "g0_cld")]
+    rng = np.random.default_rng(11)
+    comps[2] = comps[2] + 0.01 * comps[0].mean() * (1.0 + 0.2 * rng.random((nlayer, 1)))
+    comps[3] = np.where(comps[3] > 0, comps[3], 0.9)
+    comps[4] = np.where(comps[4] > 0, comps[4], 0.6)
+    everywhere = syn.mix_planes(*comps)
+    u0p, u1p, ctp, _, _ = disco.compute_disco(5, 1, g, t, np.pi / 3)
+    for tag, planes, a0, a1, cth in (("slab", base, u0, u1, 1.0), ("cloud_everywhere", everywhere, u0, u1, 1.0),
+                                     ("phase60", base, u0p, u1p, float(ctp))):
+        pl = dict(planes)
+        pl["F0PI"] = np.ones(nwno)
+        pl["surf_reflect"] = np.zeros(nwno)
+        dd = resident.upload_scene(pl, resident.REFLECTED_PLANES + ("F0PI", "surf_reflect"), ctx=ctx)
+        xi = DeviceArray((5, 1, nwno), ctx)
+        al = DeviceArray((nwno,), ctx)
+        ms = timeit(lambda: resident.reflected_1d(ctx, nlayer + 1, nwno, 5, 1, dd, dd["surf_reflect"], a0, a1,
+                                                  cth, dd["F0PI"], 3, 0, *TTHG, xi, toon_coefficients=0,
+                                                  b_top=0.0, gweight=gw, tweight=tw, albedo=al), ctx, reps=20)
+        out["reflected_1e5_%s" % tag] = dict(ms=ms, spectra_per_s=1e3 / ms, frac_of_8TBs=0.8 / ms / 8.0)
     # 3-D facets: 8x8 facets, 90 layers, 4096 wavelengths (same per-facet planes replicated)
     ng = nt = 8
     nw3 = 4096
