@@ -26,23 +26,35 @@
 
 namespace pz {
 
+constexpr int SH_MAX_ANG = 16;
+
 struct SHArgs {
     int nlayer, nwno, stream;
     long pitch;
     const double *dtau, *tau, *w0, *ftau_cld, *ftau_ray, *f_deltaM, *dtau_og, *tau_og, *w0_og, *cosb_og;
     const double *surf_reflect, *F0PI;
-    double u0, u1, cos_theta;
+    // blockIdx.y = angle of this launch chunk; constants derived on the host (uniform -> SGPR)
+    struct Angle {
+        double u0, u1, iu0, iu1, mus, imus, nl0, nl1, nlm;   // nl* = -log2(e) {1/u0, 1/u1, mus}
+    } ang[SH_MAX_ANG];
+    int first_angle, compound;                               // reference angle index of ang[0]
+    double cos_theta;
     int w_single_form, w_multi_form, psingle_form, w_single_rayleigh, w_multi_rayleigh,
         psingle_rayleigh, single_form;
     double frac_a, frac_b, frac_c, constant_back, constant_forward, b_top;
-    int fd_power;            // angle index + 1 (compounded f_deltaM), 1 when compounding is off
     // thermal
     const double *wno, *tlevel, *plevel;     // device (nwno) / (nlevel) / (nlevel)
     int hard_surface, use_ff;                // use_ff: cosb != cosb_og somewhere (fluxes.py:3072-3075)
-    double *xint;                            // (nwno) for this angle
+    double *xint;                            // (angles of this launch, nwno)
 };
 
 __device__ __forceinline__ double clip35(double x) { return fmin(fmax(x, -35.0), 35.0); }   // slice_rav
+constexpr double LOG2E = 1.4426950408889634074;
+constexpr double EXP_M35 = 6.305116760146989e-16;        // exp(-35)
+// exp(x) through the base-2 polynomial (device_math.hpp)
+__device__ __forceinline__ double fexpk(double x, const Exp2Coef &K) { return fexp2(x * LOG2E, K); }
+// exp(-clip35(y/u)) for y >= 0 given t = y * (-log2(e)/u): only the lower clip can bind
+__device__ __forceinline__ double fexp2_clip(double t, const Exp2Coef &K) { return fexp2(fmax(t, -35.0 * LOG2E), K); }
 
 template <int NB>
 struct Blk {
@@ -143,16 +155,20 @@ struct Modes {
     double beta, gama;           // SH4 quartic coefficients (particular solution)
 };
 
-__device__ __forceinline__ void modes_sh4(const double (&a)[4], double dt, Modes<2> &M)
+__device__ __forceinline__ void modes_sh4(const double (&a)[4], double dt, Modes<2> &M, const Exp2Coef &K)
 {
     const double a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3];
     M.beta = a0 * a1 + 4 * a0 * a3 / 9 + a2 * a3 / 9;                 // fluxes.py:3388-3391
     M.gama = a0 * a1 * a2 * a3 / 9;
     const double disc = sqrt(M.beta * M.beta - 4 * M.gama);
-    const double l1 = sqrt((M.beta + disc) / 2), l2 = sqrt((M.beta - disc) / 2);
+    // lam = x rsqrt(x) and 1/lam = rsqrt(x) from one v_rsq_f64 + Newton (frsq, ~1 ulp) instead of a
+    // correctly rounded sqrt followed by a reciprocal (fluxes.py:3393-3394, 3423-3425)
+    const double x1 = (M.beta + disc) / 2, x2 = (M.beta - disc) / 2;
+    const double il1 = frsq(x1), il2 = frsq(x2);
+    const double l1 = x1 * il1, l2 = x2 * il2;
     M.lam[0] = l1;
     M.lam[1] = l2;
-    const double il1 = frcp(l1), il2 = frcp(l2), a01 = a0 * a1, s3 = -1.5 * frcp(a3);
+    const double a01 = a0 * a1, s3 = -1.5 * frcp(a3);
     const double R1 = -a0 * il1, R2 = -a0 * il2;                      // :3423-3425
     const double Q1 = 0.5 * (a01 * il1 * il1 - 1), Q2 = 0.5 * (a01 * il2 * il2 - 1);
     const double S1 = s3 * (a01 * il1 - l1), S2 = s3 * (a01 * il2 - l2);
@@ -165,8 +181,8 @@ __device__ __forceinline__ void modes_sh4(const double (&a)[4], double dt, Modes
     M.Mn.m[0][1] = (0.5 - R2 + 5 * Q2 / 8) * tp;                      // p2mn
     M.Mn.m[1][0] = (-0.125 + 5 * Q1 / 8 - S1) * tp;                   // q1mn
     M.Mn.m[1][1] = (-0.125 + 5 * Q2 / 8 - S2) * tp;                   // q2mn
-    M.E[0] = fexp(-clip35(l1 * dt));                                  // :3418-3421
-    M.E[1] = fexp(-clip35(l2 * dt));
+    M.E[0] = fexpk(-clip35(l1 * dt), K);                              // :3418-3421
+    M.E[1] = fexpk(-clip35(l2 * dt), K);
     // A[j][m], m = (d0, u0, d1, u1)
     const double Aj[4][4] = {{1, 1, 1, 1}, {R1, -R1, R2, -R2}, {Q1, Q1, Q2, Q2}, {S1, -S1, S2, -S2}};
 #pragma unroll
@@ -175,32 +191,40 @@ __device__ __forceinline__ void modes_sh4(const double (&a)[4], double dt, Modes
         for (int m = 0; m < 4; ++m) M.cA[j][m] = Aj[j][m];
 }
 
-__device__ __forceinline__ void modes_sh2(const double (&a)[2], double dt, Modes<1> &M)
+__device__ __forceinline__ void modes_sh2(const double (&a)[2], double dt, Modes<1> &M, const Exp2Coef &K)
 {
     const double lam = sqrt(a[0] * a[1]);                             // fluxes.py:3245
     M.lam[0] = lam;
     M.q = lam * frcp(a[1]);                                           // :3251
     M.Mn.m[0][0] = (0.5 + M.q) * 2 * PI;                              // Q1
     M.Pl.m[0][0] = (0.5 - M.q) * 2 * PI;                              // Q2
-    M.E[0] = fexp(-clip35(lam * dt));                                 // :3246-3248
+    M.E[0] = fexpk(-clip35(lam * dt), K);                             // :3246-3248
 }
 
 // One kernel for stream 2 / 4 (NB = 1 / 2), reflected / thermal.
 template <int NB, bool THERMAL>
-__global__ __launch_bounds__(256) void k_sh(const SHArgs a)
+#ifndef PZ_SH_MINWAVES
+#define PZ_SH_MINWAVES 2
+#endif
+__global__ __launch_bounds__(256, PZ_SH_MINWAVES) void k_sh(const SHArgs a)
 {
     constexpr int NS = 2 * NB;      // stream
     const long w = blockIdx.x * (long)blockDim.x + threadIdx.x;
     if (w >= a.nwno) return;
     const int n = a.nlayer;
     const long pitch = a.pitch;
-    const double u0 = a.u0, u1 = a.u1, ct = a.cos_theta;
+    const SHArgs::Angle &g = a.ang[blockIdx.y];
+    const double u0 = g.u0, u1 = g.u1, ct = a.cos_theta;
+    const int fd_power = a.compound ? a.first_angle + (int)blockIdx.y + 1 : 1;   // compounded f_deltaM
+    double *const xint = a.xint + (long)blockIdx.y * a.nwno;
     const double F = THERMAL ? 0.0 : a.F0PI[w], rs = a.surf_reflect[w];
     double Pu0[4], Pu1[4];
     legP4(-u0, Pu0);
     legP4(u1, Pu1);
-    const double mus = THERMAL ? 0.0 : (u1 + u0) / (u1 * u0);
-    const double iu1 = 1.0 / u1, iu0 = THERMAL ? 0.0 : 1.0 / u0, imus = THERMAL ? 0.0 : 1.0 / ((u1 + u0) / (u1 * u0));
+    const double mus = g.mus, iu1 = g.iu1, iu0 = g.iu0, imus = g.imus;
+    const bool sym = (u0 == u1);                                     // mus = 2/u1
+    Exp2Coef K;
+    K.load();
 
     // thermal: Planck at the levels (fluxes.py:3058-3060)
     const double wn = THERMAL ? a.wno[w] : 0.0;
@@ -209,6 +233,7 @@ __global__ __launch_bounds__(256) void k_sh(const SHArgs a)
     double b1_last = 0.0;
 
     double T = 1.0, kappa = 0.0;
+    double e_top = 0.0;              // exp(-tau/u0) at the top of the current layer (carried)
     double zeta[NB], delta[NB];
     Blk<NB> R;
     // previous layer
@@ -241,7 +266,7 @@ __global__ __launch_bounds__(256) void k_sh(const SHArgs a)
 #pragma unroll
                 for (int l = 0; l < NS; ++l) { cfs *= a.constant_forward; cbs *= a.constant_back; }
                 const double fac = (f * cfs + (1 - f) * cbs);
-                for (int p = 1; p < a.fd_power; ++p) fd_prev *= fac;
+                for (int p = 1; p < fd_power; ++p) fd_prev *= fac;
                 fd = fd_prev * fac;
             }
             if (a.w_single_form == 1 || a.w_multi_form == 1) {               // OTHG :2811-2817
@@ -307,12 +332,12 @@ __global__ __launch_bounds__(256) void k_sh(const SHArgs a)
         }
         // ---- modes ----
         Modes<NB> M;
-        if constexpr (NB == 2) modes_sh4(al, dt, M);
-        else modes_sh2(al, dt, M);
+        if constexpr (NB == 2) modes_sh4(al, dt, M, K);
+        else modes_sh2(al, dt, M, K);
         // ---- particular solution at the layer top / bottom ----
         double eta[NS];
         double zmn_dn[NB], zpl_dn[NB], zmn_up[NB], zpl_up[NB];
-        double B0 = 0.0, b1 = 0.0;
+        double B0 = 0.0, b1 = 0.0, ed_layer = 0.0;
         if (!THERMAL) {
             double zpl[NB], zmn[NB];
             const double tau_t = a.tau[o], tau_b = a.tau[o + pitch];
@@ -330,8 +355,8 @@ __global__ __launch_bounds__(256) void k_sh(const SHArgs a)
                 zmn[0] = (eta[0] / 2 - eta[1] + 5 * eta[2] / 8) * 2 * PI;
                 zpl[1] = (-eta[0] / 8 + 5 * eta[2] / 8 + eta[3]) * 2 * PI;
                 zmn[1] = (-eta[0] / 8 + 5 * eta[2] / 8 - eta[3]) * 2 * PI;
-                ed = fexp(-clip35(tau_t * iu0));
-                eu = fexp(-clip35(tau_b * iu0));
+                ed = (i == 0) ? fexp2_clip(tau_t * g.nl0, K) : e_top;    // = last layer's eu (same element)
+                eu = fexp2_clip(tau_b * g.nl0, K);
             } else {                                                         // :3240-3265
                 const double x = iu0;
                 const double iDel = frcp(x * x - al[0] * al[1]);
@@ -339,9 +364,11 @@ __global__ __launch_bounds__(256) void k_sh(const SHArgs a)
                 eta[1] = (bl[0] * x - al[0] * bl[1]) * iDel;
                 zmn[0] = (0.5 * eta[0] - eta[1]) * 2 * PI;
                 zpl[0] = (0.5 * eta[0] + eta[1]) * 2 * PI;
-                ed = fexp(-tau_t * iu0);
-                eu = fexp(-tau_b * iu0);
+                ed = (i == 0) ? fexp2(tau_t * g.nl0, K) : e_top;
+                eu = fexp2(tau_b * g.nl0, K);
             }
+            e_top = eu;
+            ed_layer = ed;
 #pragma unroll
             for (int r = 0; r < NB; ++r) {
                 zmn_dn[r] = zmn[r] * ed; zpl_dn[r] = zpl[r] * ed;
@@ -367,7 +394,7 @@ __global__ __launch_bounds__(256) void k_sh(const SHArgs a)
         const Blk<NB> ME = scale_cols(M.Mn, M.E), PE = scale_cols(M.Pl, M.E);
 
         // ---- functional weights (source-function integrals) ----
-        double gd[NB], gv[NB], c;
+        double gd[NB], gv[NB], c, Tn;
         {
             const double e_u1 = THERMAL ? 0.0 : 0.0;
             (void)e_u1;
@@ -386,36 +413,54 @@ __global__ __launch_bounds__(256) void k_sh(const SHArgs a)
             }
             const double scale = THERMAL ? 2 * PI : 1.0;                     // :3167 vs :2961
             const double tw = T * iu1 * w0 * scale;
+            const double edt = fexp2(dt * g.nl1, K);                         // exp(-dtau/u1)
+            // exp(-(1/u1 +- lam) dtau) = exp(-dtau/u1) E^{+-1} when no 35-clip binds anywhere in the
+            // wave ((1/u1 + lam_max) dtau <= 35 covers all four arguments); otherwise the reference's
+            // clipped exponentials are formed directly (:2929-2937).
+            const bool noclip = __all((iu1 + M.lam[0]) * dt <= 35.0);
 #pragma unroll
             for (int r = 0; r < NB; ++r) {
                 const double alpha = iu1 + M.lam[r], beta = iu1 - M.lam[r];
                 const double rab = frcp(alpha * beta);                        // one reciprocal for both
-                const double ha = (1 - fexp(-clip35(alpha * dt))) * (rab * beta);    // :2929-2937
-                const double hb = (1 - fexp(-clip35(beta * dt))) * (rab * alpha);
+                double ea, eb;
+                if (noclip) {
+                    ea = edt * M.E[r];
+                    eb = edt * frcp(M.E[r]);
+                } else {
+                    ea = fexpk(-clip35(alpha * dt), K);
+                    eb = fexpk(-clip35(beta * dt), K);
+                }
+                const double ha = (1 - ea) * (rab * beta);
+                const double hb = (1 - eb) * (rab * alpha);
                 gd[r] = tw * cm[2 * r] * ha;
                 gv[r] = tw * cm[2 * r + 1] * hb * M.E[r];
             }
             if (!THERMAL) {
-                const double exptrm_mus = (1 - fexp(-clip35(mus * dt))) * imus;           // :2901-2905
-                const double tau_mu = a.tau[o] * iu0;
-                const double expon1 = exptrm_mus * fexp(-clip35(tau_mu));
+                // (1 - exp(-clip35(mus dtau)))/mus (:2901-2905); mus = 2/u1 in the symmetric geometry
+                const bool sq = sym && __all(mus * dt <= 35.0);
+                const double e_mus = sq ? edt * edt : fexp2_clip(dt * g.nlm, K);
+                const double exptrm_mus = (1 - e_mus) * imus;
+                // exp(-clip35(tau/u0)): the layer-top exponential above (SH4 clips it too; SH2 does not)
+                const double expon1 = exptrm_mus * ((NB == 2) ? ed_layer : fmax(ed_layer, EXP_M35));
                 double Nsum = 0.0;
 #pragma unroll
                 for (int l = 0; l < NS; ++l) Nsum += wmu[l] * Pu1[l] * eta[l] * expon1;   // :2919-2920, 2945-2948
+                const double dto = a.dtau_og[o];
+                const double e_muso = __all(dto == dt) ? e_mus : fexp2_clip(dto * g.nlm, K);
                 const double single = a.w0_og[o] * F / (4 * PI) * psing *
-                                      (1 - fexp(-clip35(mus * a.dtau_og[o]))) * fexp(-a.tau_og[o] * iu0) * imus;   // :2959-2965
+                                      (1 - e_muso) * fexp2(a.tau_og[o] * g.nl0, K) * imus;   // :2959-2965
                 c = T * iu1 * (w0 * Nsum + single);
             } else {
-                const double edc = (NB == 2) ? fexp(-clip35(dt * iu1)) : fexp(-dt * iu1);  // :3154 vs :3127
+                const double ed2 = edt;                                                                  // :3163-3165
+                const double edc = (NB == 2) ? fmax(edt, EXP_M35) : edt;   // exp(-clip35(dtau/u1)) :3154 vs :3127
                 const double core = (1 - w0) * u1 * frcp(al[0]);
                 const double N0 = wmu[0] * (core * (B0 * (1 - edc) + b1 * (u1 - (dt + u1) * edc)));     // :3128, :3155
                 const double N1 = wmu[1] * Pu1[1] * (core * (b1 * (1 - edc) * frcp(al[1])));            // :3129, :3156
-                const double ed2 = fexp(-dt * iu1);                                                      // :3163-3165
                 c = T * iu1 * (w0 * (N0 + N1) * 2 * PI +
                                2 * PI * (1 - w0) * u1 * (B0 * (1 - ed2) + b1 * (u1 - (dt + u1) * ed2)));
             }
+            Tn = T * edt;
         }
-        const double Tn = T * fexp(-dt * iu1);
         if (i == n - 1) {
             if (!THERMAL) {       // xint[n] = flux_bot/pi = (Pl E d + Mn v + zpl_up)[0]/pi  (:2891, :2967)
 #pragma unroll
@@ -435,7 +480,7 @@ __global__ __launch_bounds__(256) void k_sh(const SHArgs a)
             if (!THERMAL) b_top = a.b_top;
             else {
                 const double tau_top = dt * a.plevel[0] / (a.plevel[1] - a.plevel[0]);   // :3062-3063
-                b_top = PI * (1.0 - fexp(-tau_top / 0.5)) * B_top;
+                b_top = PI * (1.0 - fexpk(-tau_top / 0.5, K)) * B_top;
             }
             bt[0] = b_top - zmn_dn[0];                                       // :3479-3480 / :3283
             if constexpr (NB == 2) bt[1] = -b_top / 4 - zmn_dn[1];
@@ -511,7 +556,7 @@ __global__ __launch_bounds__(256) void k_sh(const SHArgs a)
     // ---- surface rows (:3484-3494 / :3287-3289) ----
     double bs[NB];
     if (!THERMAL) {
-        const double bsf = (0. + rs * u0 * F * fexp(-a.tau[(long)n * pitch + w] / u0));   // :2863-2864
+        const double bsf = (0. + rs * u0 * F * fexpk(-a.tau[(long)n * pitch + w] / u0, K));   // :2863-2864
         bs[0] = bsf;
         if constexpr (NB == 2) bs[1] = -bsf / 4;
     } else {
@@ -536,13 +581,13 @@ __global__ __launch_bounds__(256) void k_sh(const SHArgs a)
 #pragma unroll
     for (int r = 0; r < NB; ++r) rhs[r] = bs[r] - p_zpl_up[r] + rs * p_zmn_up[r] - wd[r];
     mv(inv(L), rhs, v);
-    a.xint[w] = kappa + dot(zeta, v);
+    xint[w] = kappa + dot(zeta, v);
 }
 
-int launch_sh(picaso_ctx *ctx, const SHArgs &a, bool thermal)
+static int launch_sh(picaso_ctx *ctx, const SHArgs &a, int nang, bool thermal)
 {
     const int block = 256;
-    const dim3 grid((unsigned)((a.nwno + block - 1) / block));
+    const dim3 grid((unsigned)((a.nwno + block - 1) / block), (unsigned)nang);
     if (a.stream == 4) {
         if (thermal) hipLaunchKernelGGL((k_sh<2, true>), grid, dim3(block), 0, ctx->stream, a);
         else hipLaunchKernelGGL((k_sh<2, false>), grid, dim3(block), 0, ctx->stream, a);
@@ -551,6 +596,36 @@ int launch_sh(picaso_ctx *ctx, const SHArgs &a, bool thermal)
         else hipLaunchKernelGGL((k_sh<1, false>), grid, dim3(block), 0, ctx->stream, a);
     }
     PZ_HIP(ctx, hipGetLastError());
+    return 0;
+}
+
+// All angles of a call go into one launch (grid.y = angle, SH_MAX_ANG per launch): a 1e5-column
+// spectrum is only 1.5 waves per SIMD per angle, five angles together fill the chip evenly.
+static int launch_sh_angles(picaso_ctx *ctx, SHArgs &a, int nang, const double *ubar0, const double *ubar1,
+                            double *xint_at_top, bool thermal)
+{
+    for (int done = 0; done < nang; done += SH_MAX_ANG) {
+        const int m = (nang - done < SH_MAX_ANG) ? nang - done : SH_MAX_ANG;
+        for (int k = 0; k < m; ++k) {
+            SHArgs::Angle &g = a.ang[k];
+            g.u1 = ubar1[done + k];
+            g.iu1 = 1.0 / g.u1;
+            g.nl1 = -LOG2E * g.iu1;
+            if (thermal) {
+                g.u0 = g.iu0 = g.mus = g.imus = g.nl0 = g.nlm = 0.0;
+            } else {
+                g.u0 = ubar0[done + k];
+                g.iu0 = 1.0 / g.u0;
+                g.mus = (g.u1 + g.u0) / (g.u1 * g.u0);                       // fluxes.py:2899
+                g.imus = 1.0 / g.mus;
+                g.nl0 = -LOG2E * g.iu0;
+                g.nlm = -LOG2E * g.mus;
+            }
+        }
+        a.first_angle = done;
+        a.xint = xint_at_top + (size_t)done * a.nwno;
+        PZ_TRY(launch_sh(ctx, a, m, thermal));
+    }
     return 0;
 }
 
@@ -591,14 +666,8 @@ int picaso_get_reflected_SH_dev(picaso_ctx *ctx, int nlevel, int nwno, long plan
     a.psingle_rayleigh = psingle_rayleigh; a.single_form = single_form;
     a.frac_a = frac_a; a.frac_b = frac_b; a.frac_c = frac_c; a.constant_back = constant_back;
     a.constant_forward = constant_forward; a.b_top = b_top;
-    const int nang = numg * numt;
-    for (int k = 0; k < nang; ++k) {
-        a.u0 = ubar0[k];
-        a.u1 = ubar1[k];
-        a.fd_power = compound_f_deltaM ? k + 1 : 1;
-        a.xint = xint_at_top + (size_t)k * nwno;
-        PZ_TRY(launch_sh(ctx, a, false));
-    }
+    a.compound = compound_f_deltaM ? 1 : 0;
+    PZ_TRY(launch_sh_angles(ctx, a, numg * numt, ubar0, ubar1, xint_at_top, false));
     if (albedo && gweight && tweight)
         PZ_TRY(picaso_compress_disco_dev(ctx, nwno, cos_theta, xint_at_top, gweight, numg, tweight, numt, F0PI, albedo));
     return 0;
@@ -662,13 +731,7 @@ int picaso_get_thermal_SH_dev(picaso_ctx *ctx, int nlevel, const double *wno, in
     a.dtau = dtau; a.w0 = w0; a.cosb_og = cosb_og; a.surf_reflect = surf_reflect;
     a.wno = wno; a.tlevel = (const double *)d_tab; a.plevel = a.tlevel + nlevel;
     a.hard_surface = hard_surface; a.use_ff = cosb_differs_from_cosb_og;
-    const int nang = numg * numt;
-    for (int k = 0; k < nang; ++k) {
-        a.u0 = 0.0;
-        a.u1 = ubar1[k];
-        a.xint = xint_at_top + (size_t)k * nwno;
-        PZ_TRY(launch_sh(ctx, a, true));
-    }
+    PZ_TRY(launch_sh_angles(ctx, a, numg * numt, nullptr, ubar1, xint_at_top, true));
     if (flux_disk && gweight && tweight)
         PZ_TRY(picaso_compress_thermal_dev(ctx, (size_t)nwno, xint_at_top, gweight, numg, tweight, numt, flux_disk));
     return 0;

@@ -35,105 +35,110 @@ def main():
     g, gw, t, tw = disco.get_angles_1d(5)
     u0, u1, ct, _, _ = disco.compute_disco(5, 1, g, t, 0.0)
     nlayer = 90
-    for nwno in (10000, 100000):
-        sc = syn.make_scene(nlayer, nwno, seed=5)
-        d = resident.upload_scene(sc, ("dtau_og", "w0_no_raman", "cosb_og", "wno"), ctx=ctx)
-        rs = DeviceArray.from_host(np.zeros(nwno), ctx)
-        flux = DeviceArray((5, 1, nwno), ctx)
-        disk = DeviceArray((nwno,), ctx)
-        ms = timeit(lambda: resident.thermal_1d(ctx, nlayer + 1, d["wno"], nwno, 5, 1, sc["tlevel"],
-                                                d["dtau_og"], d["w0_no_raman"], d["cosb_og"],
-                                                sc["plevel"], u1, rs, 0, flux, gweight=gw, tweight=tw,
-                                                flux_disk=disk), ctx)
-        ab = 8 * nwno * (3 * nlayer + 3 + 5 + 1)
-        out["thermal_%d" % nwno] = dict(ms=ms, spectra_per_s=1e3 / ms, GBps=ab / ms / 1e6,
-                                        algorithmic_bytes=ab)
-        if nwno == 100000:
-            # PCIe-inclusive: host-pointer drop-in call of the headline reflected workload
-            planes = [sc[k] for k in resident.REFLECTED_PLANES]
-            t0 = time.perf_counter()
-            fluxes.get_reflected_1d(nlayer + 1, sc["wno"], nwno, 5, 1, *planes, 0.0, u0, u1, 1.0,
-                                    np.ones(nwno), 3, 0, *TTHG)
-            t1 = time.perf_counter()
-            fluxes.get_reflected_1d(nlayer + 1, sc["wno"], nwno, 5, 1, *planes, 0.0, u0, u1, 1.0,
-                                    np.ones(nwno), 3, 0, *TTHG)
-            t2 = time.perf_counter()
-            out["reflected_host_pointers_1e5"] = dict(first_call_s=t1 - t0, second_call_s=t2 - t1,
-                                                      spectra_per_s=1.0 / (t2 - t1),
-                                                      note="includes np.zeros of the 4 level-flux arrays "
-                                                           "(1.46 GB) the reference signature returns")
-            # level fluxes (climate caller shape: one angle)
-            dd = resident.upload_scene(sc, resident.REFLECTED_PLANES, ctx=ctx)
-    # Headline workload variants: (a) as bench.py (cloud slab in 10 of 90 layers: the other layers
-    # are not delta-scaled and skip the second exponential), (b) cloud in every layer (every layer
-    # delta-scaled: no shortcut), (c) phase angle 60 deg (ubar0 != ubar1: general kernel)
-    nwno = 100000
-    base = syn.make_scene(nlayer, nwno, seed=3)
-    comps = [base[k].copy() for k in ("taugas", "tauray", "taucld", "w0_cld", "g0_cld")]
-    rng = np.random.default_rng(11)
-    comps[2] = comps[2] + 0.01 * comps[0].mean() * (1.0 + 0.2 * rng.random((nlayer, 1)))
-    comps[3] = np.where(comps[3] > 0, comps[3], 0.9)
-    comps[4] = np.where(comps[4] > 0, comps[4], 0.6)
-    everywhere = syn.mix_planes(*comps)
-    u0p, u1p, ctp, _, _ = disco.compute_disco(5, 1, g, t, np.pi / 3)
-    for tag, planes, a0, a1, cth in (("slab", base, u0, u1, 1.0), ("cloud_everywhere", everywhere, u0, u1, 1.0),
-                                     ("phase60", base, u0p, u1p, float(ctp))):
-        pl = dict(planes)
-        pl["F0PI"] = np.ones(nwno)
-        pl["surf_reflect"] = np.zeros(nwno)
-        dd = resident.upload_scene(pl, resident.REFLECTED_PLANES + ("F0PI", "surf_reflect"), ctx=ctx)
-        xi = DeviceArray((5, 1, nwno), ctx)
-        al = DeviceArray((nwno,), ctx)
-        ms = timeit(lambda: resident.reflected_1d(ctx, nlayer + 1, nwno, 5, 1, dd, dd["surf_reflect"], a0, a1,
-                                                  cth, dd["F0PI"], 3, 0, *TTHG, xi, toon_coefficients=0,
-                                                  b_top=0.0, gweight=gw, tweight=tw, albedo=al), ctx, reps=20)
-        out["reflected_1e5_%s" % tag] = dict(ms=ms, spectra_per_s=1e3 / ms, frac_of_8TBs=0.8 / ms / 8.0)
-    # 3-D facets: 8x8 facets, 90 layers, 4096 wavelengths (same per-facet planes replicated)
-    ng = nt = 8
-    nw3 = 4096
-    sc = syn.make_scene(nlayer, nw3, seed=7)
-    gg, ggw, tt, ttw = disco.get_angles_3d(ng, nt)
-    v0, v1, cth, _, _ = disco.compute_disco(ng, nt, gg, tt, np.pi / 3)
-    dev3 = {}
-    for k in resident.REFLECTED_PLANES:
-        dev3[k] = DeviceArray.from_host(np.repeat(sc[k][:, :, None], ng * nt, axis=2), ctx)
-    f0 = DeviceArray.from_host(np.ones(nw3), ctx)
-    rs3 = DeviceArray.from_host(np.zeros(nw3), ctx)
-    x3 = DeviceArray((ng, nt, nw3), ctx)
-    a3 = DeviceArray((nw3,), ctx)
+    only = os.environ.get("BENCH_ONLY")        # thermal | variants | 3d | sh (default: all)
+    if only in (None, "thermal"):
+        for nwno in (10000, 100000):
+            sc = syn.make_scene(nlayer, nwno, seed=5)
+            d = resident.upload_scene(sc, ("dtau_og", "w0_no_raman", "cosb_og", "wno"), ctx=ctx)
+            rs = DeviceArray.from_host(np.zeros(nwno), ctx)
+            flux = DeviceArray((5, 1, nwno), ctx)
+            disk = DeviceArray((nwno,), ctx)
+            ms = timeit(lambda: resident.thermal_1d(ctx, nlayer + 1, d["wno"], nwno, 5, 1, sc["tlevel"],
+                                                    d["dtau_og"], d["w0_no_raman"], d["cosb_og"],
+                                                    sc["plevel"], u1, rs, 0, flux, gweight=gw, tweight=tw,
+                                                    flux_disk=disk), ctx)
+            ab = 8 * nwno * (3 * nlayer + 3 + 5 + 1)
+            out["thermal_%d" % nwno] = dict(ms=ms, spectra_per_s=1e3 / ms, GBps=ab / ms / 1e6,
+                                            algorithmic_bytes=ab)
+            if nwno == 100000:
+                # PCIe-inclusive: host-pointer drop-in call of the headline reflected workload
+                planes = [sc[k] for k in resident.REFLECTED_PLANES]
+                t0 = time.perf_counter()
+                fluxes.get_reflected_1d(nlayer + 1, sc["wno"], nwno, 5, 1, *planes, 0.0, u0, u1, 1.0,
+                                        np.ones(nwno), 3, 0, *TTHG)
+                t1 = time.perf_counter()
+                fluxes.get_reflected_1d(nlayer + 1, sc["wno"], nwno, 5, 1, *planes, 0.0, u0, u1, 1.0,
+                                        np.ones(nwno), 3, 0, *TTHG)
+                t2 = time.perf_counter()
+                out["reflected_host_pointers_1e5"] = dict(first_call_s=t1 - t0, second_call_s=t2 - t1,
+                                                          spectra_per_s=1.0 / (t2 - t1),
+                                                          note="includes np.zeros of the 4 level-flux arrays "
+                                                               "(1.46 GB) the reference signature returns")
+                # level fluxes (climate caller shape: one angle)
+                dd = resident.upload_scene(sc, resident.REFLECTED_PLANES, ctx=ctx)
+    if only in (None, "variants"):
+        # Headline workload variants: (a) as bench.py (cloud slab in 10 of 90 layers: the other layers
+        # are not delta-scaled and skip the second exponential), (b) cloud in every layer (every layer
+        # delta-scaled: no shortcut), (c) phase angle 60 deg (ubar0 != ubar1: general kernel)
+        nwno = 100000
+        base = syn.make_scene(nlayer, nwno, seed=3)
+        comps = [base[k].copy() for k in ("taugas", "tauray", "taucld", "w0_cld", "g0_cld")]
+        rng = np.random.default_rng(11)
+        comps[2] = comps[2] + 0.01 * comps[0].mean() * (1.0 + 0.2 * rng.random((nlayer, 1)))
+        comps[3] = np.where(comps[3] > 0, comps[3], 0.9)
+        comps[4] = np.where(comps[4] > 0, comps[4], 0.6)
+        everywhere = syn.mix_planes(*comps)
+        u0p, u1p, ctp, _, _ = disco.compute_disco(5, 1, g, t, np.pi / 3)
+        for tag, planes, a0, a1, cth in (("slab", base, u0, u1, 1.0), ("cloud_everywhere", everywhere, u0, u1, 1.0),
+                                         ("phase60", base, u0p, u1p, float(ctp))):
+            pl = dict(planes)
+            pl["F0PI"] = np.ones(nwno)
+            pl["surf_reflect"] = np.zeros(nwno)
+            dd = resident.upload_scene(pl, resident.REFLECTED_PLANES + ("F0PI", "surf_reflect"), ctx=ctx)
+            xi = DeviceArray((5, 1, nwno), ctx)
+            al = DeviceArray((nwno,), ctx)
+            ms = timeit(lambda: resident.reflected_1d(ctx, nlayer + 1, nwno, 5, 1, dd, dd["surf_reflect"], a0, a1,
+                                                      cth, dd["F0PI"], 3, 0, *TTHG, xi, toon_coefficients=0,
+                                                      b_top=0.0, gweight=gw, tweight=tw, albedo=al), ctx, reps=20)
+            out["reflected_1e5_%s" % tag] = dict(ms=ms, spectra_per_s=1e3 / ms, frac_of_8TBs=0.8 / ms / 8.0)
     import ctypes
     from picaso_amd._lib import check, f64, load, ptr
     ci, cd = ctypes.c_int, ctypes.c_double
+    if only in (None, "3d"):
+        # 3-D facets: 8x8 facets, 90 layers, 4096 wavelengths (same per-facet planes replicated)
+        ng = nt = 8
+        nw3 = 4096
+        sc = syn.make_scene(nlayer, nw3, seed=7)
+        gg, ggw, tt, ttw = disco.get_angles_3d(ng, nt)
+        v0, v1, cth, _, _ = disco.compute_disco(ng, nt, gg, tt, np.pi / 3)
+        dev3 = {}
+        for k in resident.REFLECTED_PLANES:
+            dev3[k] = DeviceArray.from_host(np.repeat(sc[k][:, :, None], ng * nt, axis=2), ctx)
+        f0 = DeviceArray.from_host(np.ones(nw3), ctx)
+        rs3 = DeviceArray.from_host(np.zeros(nw3), ctx)
+        x3 = DeviceArray((ng, nt, nw3), ctx)
+        a3 = DeviceArray((nw3,), ctx)
 
-    def run3d():
-        check(load().picaso_get_reflected_3d_dev(
-            ctx, ci(nlayer + 1), ci(nw3), ci(ng), ci(nt), *[ptr(dev3[k].addr) for k in resident.REFLECTED_PLANES],
-            ptr(rs3.addr), ptr(f64(v0)), ptr(f64(v1)), cd(cth), ptr(f0.addr), ci(0), ci(0),
-            *[cd(v) for v in TTHG], ptr(x3.addr), ptr(f64(ggw)), ptr(f64(ttw)), ptr(a3.addr)), ctx)
-    ms = timeit(run3d, ctx, reps=5)
-    ab = 8 * nw3 * ng * nt * (9 * nlayer + 2 * (nlayer + 1) + 1)
-    out["reflected_3d_8x8_%d" % nw3] = dict(ms=ms, GBps=ab / ms / 1e6, algorithmic_bytes=ab,
-                                            facet_columns_per_s=nw3 * ng * nt / ms * 1e3)
-    # SH4 reflected (BASELINE configs[3] per-GPU shard sizes): 12 500 and 100 000 wavelengths
-    for nwno in (12500, 100000):
-        sc = syn.make_scene(nlayer, nwno, seed=9, stream=4)
-        names = ("dtau", "tau", "w0", "cosb", "ftau_cld", "ftau_ray", "f_deltaM", "dtau_og", "tau_og",
-                 "w0_og", "cosb_og")
-        dd = resident.upload_scene(sc, names, ctx=ctx)
-        f0 = DeviceArray.from_host(np.ones(nwno), ctx)
-        rs = DeviceArray.from_host(np.zeros(nwno), ctx)
-        x = DeviceArray((5, 1, nwno), ctx)
-        alb = DeviceArray((nwno,), ctx)
+        def run3d():
+            check(load().picaso_get_reflected_3d_dev(
+                ctx, ci(nlayer + 1), ci(nw3), ci(ng), ci(nt), *[ptr(dev3[k].addr) for k in resident.REFLECTED_PLANES],
+                ptr(rs3.addr), ptr(f64(v0)), ptr(f64(v1)), cd(cth), ptr(f0.addr), ci(0), ci(0),
+                *[cd(v) for v in TTHG], ptr(x3.addr), ptr(f64(ggw)), ptr(f64(ttw)), ptr(a3.addr)), ctx)
+        ms = timeit(run3d, ctx, reps=5)
+        ab = 8 * nw3 * ng * nt * (9 * nlayer + 2 * (nlayer + 1) + 1)
+        out["reflected_3d_8x8_%d" % nw3] = dict(ms=ms, GBps=ab / ms / 1e6, algorithmic_bytes=ab,
+                                                facet_columns_per_s=nw3 * ng * nt / ms * 1e3)
+    if only in (None, "sh"):
+        # SH4 reflected (BASELINE configs[3] per-GPU shard sizes): 12 500 and 100 000 wavelengths
+        for nwno in (12500, 100000):
+            sc = syn.make_scene(nlayer, nwno, seed=9, stream=4)
+            names = ("dtau", "tau", "w0", "cosb", "ftau_cld", "ftau_ray", "f_deltaM", "dtau_og", "tau_og",
+                     "w0_og", "cosb_og")
+            dd = resident.upload_scene(sc, names, ctx=ctx)
+            f0 = DeviceArray.from_host(np.ones(nwno), ctx)
+            rs = DeviceArray.from_host(np.zeros(nwno), ctx)
+            x = DeviceArray((5, 1, nwno), ctx)
+            alb = DeviceArray((nwno,), ctx)
 
-        def runsh():
-            check(load().picaso_get_reflected_SH_dev(
-                ctx, ci(nlayer + 1), ci(nwno), ctypes.c_long(nwno), ci(5), ci(1),
-                *[ptr(dd[k].addr) for k in names], ptr(rs.addr), ptr(f64(u0)), ptr(f64(u1)), cd(1.0),
-                ptr(f0.addr), ci(0), ci(0), ci(0), ci(1), ci(1), ci(1), *[cd(v) for v in TTHG], ci(4),
-                cd(0.0), ci(0), ci(0), ci(1), ptr(x.addr), ptr(f64(gw)), ptr(f64(tw)), ptr(alb.addr)), ctx)
-        ms = timeit(runsh, ctx, reps=5)
-        ab = 8 * nwno * (9 * nlayer + 2 * (nlayer + 1) + 2 + 5 + 1)
-        out["reflected_SH4_%d" % nwno] = dict(ms=ms, spectra_per_s=1e3 / ms, GBps_algorithmic=ab / ms / 1e6)
+            def runsh():
+                check(load().picaso_get_reflected_SH_dev(
+                    ctx, ci(nlayer + 1), ci(nwno), ctypes.c_long(nwno), ci(5), ci(1),
+                    *[ptr(dd[k].addr) for k in names], ptr(rs.addr), ptr(f64(u0)), ptr(f64(u1)), cd(1.0),
+                    ptr(f0.addr), ci(0), ci(0), ci(0), ci(1), ci(1), ci(1), *[cd(v) for v in TTHG], ci(4),
+                    cd(0.0), ci(0), ci(0), ci(1), ptr(x.addr), ptr(f64(gw)), ptr(f64(tw)), ptr(alb.addr)), ctx)
+            ms = timeit(runsh, ctx, reps=5)
+            ab = 8 * nwno * (9 * nlayer + 2 * (nlayer + 1) + 2 + 5 + 1)
+            out["reflected_SH4_%d" % nwno] = dict(ms=ms, spectra_per_s=1e3 / ms, GBps_algorithmic=ab / ms / 1e6)
     print(json.dumps(out, indent=1))
 
 
