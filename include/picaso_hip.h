@@ -224,6 +224,38 @@ int picaso_compress_thermal_dev(picaso_ctx *ctx, size_t ninner, const double *fl
                                 const double *gweight, int ng, const double *tweight, int nt,
                                 double *flux);
 
+/* ---- correlated-k Gauss-point batch and patchy-cloud blend -------------------------------- */
+/* The reference loops the solver over the `ngauss` correlated-k points of every wavelength bin and
+ * accumulates `xint_at_top += xint * gauss_wts[ig]` (reference picaso/justdoit.py:256-307 reflected,
+ * :328-380 thermal), slicing `DTAU[:,:,ig]` out of the (nlayer|nlevel, nwno, ngauss) arrays that
+ * compute_opacity returns (optics.py:423-431).  These entry points take those arrays as they are
+ * (Gauss index fastest), solve all nwno*ngauss columns in one launch and return the Gauss-weighted
+ * (numg,numt,nwno) intensities; `gauss_wts` is a host array of length ngauss (<= 32).  Optional
+ * fused disk quadrature as in the _dev forms above.  Level fluxes: call the ngauss = 1 forms. */
+int picaso_get_reflected_1d_ck_dev(picaso_ctx *ctx, int nlevel, int nwno, int ngauss, int numg, int numt,
+                                   const double *dtau, const double *tau, const double *w0,
+                                   const double *cosb, const double *gcos2, const double *ftau_cld,
+                                   const double *ftau_ray, const double *dtau_og, const double *tau_og,
+                                   const double *w0_og, const double *cosb_og,
+                                   const double *surf_reflect, const double *ubar0,
+                                   const double *ubar1, double cos_theta, const double *F0PI,
+                                   int single_phase, int multi_phase, double frac_a, double frac_b,
+                                   double frac_c, double constant_back, double constant_forward,
+                                   int toon_coefficients, double b_top, const double *gauss_wts,
+                                   double *xint_at_top, const double *gweight, const double *tweight,
+                                   double *albedo);
+int picaso_get_thermal_1d_ck_dev(picaso_ctx *ctx, int nlevel, const double *wno, int nwno, int ngauss,
+                                 int numg, int numt, const double *tlevel, const double *dtau,
+                                 const double *w0, const double *cosb, const double *plevel,
+                                 const double *ubar1, const double *surf_reflect, int hard_surface,
+                                 const double *dwno, int calc_type, const double *gauss_wts,
+                                 double *flux_at_top, const double *gweight, const double *tweight,
+                                 double *flux_disk);
+/* out = a*x + b*y on device arrays: the patchy-cloud blend (1-fhole)*cloudy + fhole*clear
+ * (reference picaso/justdoit.py:300-305, 356-361) */
+int picaso_axpby_dev(picaso_ctx *ctx, size_t n, double a, const double *x, double b, const double *y,
+                     double *out);
+
 /* ---- opacity pre-stage --------------------------------------------------------------------- */
 /* Gas + Rayleigh optical depth per (layer, wavelength) from HBM-resident opacity tables.
  * Replaces the arithmetic of RetrieveOpacities.get_opacities / get_opacities_nearest (reference

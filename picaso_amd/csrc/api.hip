@@ -242,7 +242,7 @@ static ReflectedArgs::Angle make_refl_angle(double v0, double v1, double wgt)
     return g;
 }
 
-int picaso_get_reflected_1d_dev(picaso_ctx *ctx, int nlevel, int nwno, long plane_pitch, int numg,
+static int reflected_1d_core(picaso_ctx *ctx, int nlevel, int nwno, int ncolper, long plane_pitch, int numg,
                                 int numt, const double *dtau, const double *tau, const double *w0,
                                 const double *cosb, const double *gcos2, const double *ftau_cld,
                                 const double *ftau_ray, const double *dtau_og,
@@ -260,7 +260,10 @@ int picaso_get_reflected_1d_dev(picaso_ctx *ctx, int nlevel, int nwno, long plan
     if (!ctx) return fail(nullptr, "null context");
     if (nlevel < 2 || nwno < 1 || numg < 1 || numt < 1)
         return fail(ctx, "get_reflected_1d: bad sizes nlevel=%d nwno=%d numg=%d numt=%d", nlevel, nwno, numg, numt);
-    if (plane_pitch < nwno) return fail(ctx, "get_reflected_1d: plane_pitch %ld < nwno %d", plane_pitch, nwno);
+    const long ncol = (long)nwno * ncolper;
+    if (plane_pitch < ncol) return fail(ctx, "get_reflected_1d: plane_pitch %ld < %ld columns", plane_pitch, ncol);
+    if (ncolper > 1 && (get_lvl_flux || albedo))
+        return fail(ctx, "get_reflected_1d: level fluxes / fused disk sum are per-wavelength outputs (ngauss = 1)");
     PZ_TRY(check_phase_options(ctx, single_phase, multi_phase, toon_coefficients));
     PZ_HIP(ctx, hipSetDevice(ctx->device));
     const int nang = numg * numt;
@@ -269,13 +272,14 @@ int picaso_get_reflected_1d_dev(picaso_ctx *ctx, int nlevel, int nwno, long plan
             return fail(ctx, "get_reflected_1d: get_lvl_flux=1 needs the four level-flux outputs");
     }
     if (!get_toa_intensity) {   // reference returns zeros (fluxes.py:1113, 1262)
-        PZ_HIP(ctx, hipMemsetAsync(xint_at_top, 0, sizeof(double) * (size_t)nang * nwno, ctx->stream));
+        PZ_HIP(ctx, hipMemsetAsync(xint_at_top, 0, sizeof(double) * (size_t)nang * ncol, ctx->stream));
         if (albedo) PZ_HIP(ctx, hipMemsetAsync(albedo, 0, sizeof(double) * nwno, ctx->stream));
         if (!get_lvl_flux) return 0;
     }
     ReflectedArgs a{};
     a.nlayer = nlevel - 1;
-    a.ncol = nwno;
+    a.ncol = ncol;
+    a.ncolper = ncolper;
     a.pitch = plane_pitch;
     a.nfac = 1;
     a.nwno = nwno;
@@ -315,12 +319,67 @@ int picaso_get_reflected_1d_dev(picaso_ctx *ctx, int nlevel, int nwno, long plan
             const double v0 = ubar0[idx], v1 = ubar1[idx];
             a.ang[k] = make_refl_angle(v0, v1, fuse ? gweight[idx / numt] * tweight[idx % numt] : 0.0);
         }
-        a.xint = xint_at_top + (size_t)done * nwno;
+        a.xint = xint_at_top + (size_t)done * ncol;
         a.albedo_first = (c == 0);
         a.albedo_last = (c + 1 == chunks.size());
         PZ_TRY(launch_reflected_toa(ctx, a, false));
         done += a.na;
     }
+    return 0;
+}
+
+int picaso_get_reflected_1d_dev(picaso_ctx *ctx, int nlevel, int nwno, long plane_pitch, int numg,
+                                int numt, const double *dtau, const double *tau, const double *w0,
+                                const double *cosb, const double *gcos2, const double *ftau_cld,
+                                const double *ftau_ray, const double *dtau_og,
+                                const double *tau_og, const double *w0_og, const double *cosb_og,
+                                const double *surf_reflect, const double *ubar0,
+                                const double *ubar1, double cos_theta, const double *F0PI,
+                                int single_phase, int multi_phase, double frac_a, double frac_b,
+                                double frac_c, double constant_back, double constant_forward,
+                                int get_toa_intensity, int get_lvl_flux, int toon_coefficients,
+                                double b_top, double *xint_at_top, double *flux_minus_all,
+                                double *flux_plus_all, double *flux_minus_midpt_all,
+                                double *flux_plus_midpt_all, const double *gweight,
+                                const double *tweight, double *albedo)
+{
+    return reflected_1d_core(ctx, nlevel, nwno, 1, plane_pitch, numg, numt, dtau, tau, w0, cosb, gcos2,
+                             ftau_cld, ftau_ray, dtau_og, tau_og, w0_og, cosb_og, surf_reflect, ubar0,
+                             ubar1, cos_theta, F0PI, single_phase, multi_phase, frac_a, frac_b, frac_c,
+                             constant_back, constant_forward, get_toa_intensity, get_lvl_flux,
+                             toon_coefficients, b_top, xint_at_top, flux_minus_all, flux_plus_all,
+                             flux_minus_midpt_all, flux_plus_midpt_all, gweight, tweight, albedo);
+}
+
+int picaso_get_reflected_1d_ck_dev(picaso_ctx *ctx, int nlevel, int nwno, int ngauss, int numg, int numt,
+                                   const double *dtau, const double *tau, const double *w0,
+                                   const double *cosb, const double *gcos2, const double *ftau_cld,
+                                   const double *ftau_ray, const double *dtau_og, const double *tau_og,
+                                   const double *w0_og, const double *cosb_og,
+                                   const double *surf_reflect, const double *ubar0,
+                                   const double *ubar1, double cos_theta, const double *F0PI,
+                                   int single_phase, int multi_phase, double frac_a, double frac_b,
+                                   double frac_c, double constant_back, double constant_forward,
+                                   int toon_coefficients, double b_top, const double *gauss_wts,
+                                   double *xint_at_top, const double *gweight, const double *tweight,
+                                   double *albedo)
+{
+    if (!ctx) return fail(nullptr, "null context");
+    if (ngauss < 1 || ngauss > MAX_CK_GAUSS) return fail(ctx, "get_reflected_1d_ck: ngauss must be 1..%d", MAX_CK_GAUSS);
+    if (!gauss_wts) return fail(ctx, "get_reflected_1d_ck: gauss_wts is null");
+    if (nwno < 1 || numg < 1 || numt < 1) return fail(ctx, "get_reflected_1d_ck: bad sizes");
+    const int nang = numg * numt;
+    const long ncol = (long)nwno * ngauss;
+    PZ_TRY(lvl_scratch_reserve(ctx, sizeof(double) * (size_t)nang * ncol));
+    double *xcol = (double *)ctx->lvl_scratch;
+    PZ_TRY(reflected_1d_core(ctx, nlevel, nwno, ngauss, ncol, numg, numt, dtau, tau, w0, cosb, gcos2, ftau_cld,
+                             ftau_ray, dtau_og, tau_og, w0_og, cosb_og, surf_reflect, ubar0, ubar1,
+                             cos_theta, F0PI, single_phase, multi_phase, frac_a, frac_b, frac_c,
+                             constant_back, constant_forward, 1, 0, toon_coefficients, b_top, xcol, nullptr,
+                             nullptr, nullptr, nullptr, nullptr, nullptr, nullptr));
+    PZ_TRY(launch_weighted_colsum(ctx, nang, nwno, ngauss, gauss_wts, xcol, xint_at_top));
+    if (albedo && gweight && tweight)
+        PZ_TRY(picaso_compress_disco_dev(ctx, nwno, cos_theta, xint_at_top, gweight, numg, tweight, numt, F0PI, albedo));
     return 0;
 }
 
@@ -469,7 +528,7 @@ int picaso_get_reflected_3d(picaso_ctx *ctx, int nlevel, const double *wno, int 
 /* ============================================================================================
  * thermal emission
  * ============================================================================================ */
-int picaso_get_thermal_1d_dev(picaso_ctx *ctx, int nlevel, const double *wno, int nwno,
+static int thermal_1d_core(picaso_ctx *ctx, int nlevel, const double *wno, int nwno, int ncolper,
                               long plane_pitch, int numg, int numt, const double *tlevel,
                               const double *dtau, const double *w0, const double *cosb,
                               const double *plevel, const double *ubar1,
@@ -481,12 +540,15 @@ int picaso_get_thermal_1d_dev(picaso_ctx *ctx, int nlevel, const double *wno, in
     if (!ctx) return fail(nullptr, "null context");
     if (nlevel < 2 || nwno < 1 || numg < 1 || numt < 1)
         return fail(ctx, "get_thermal_1d: bad sizes nlevel=%d nwno=%d numg=%d numt=%d", nlevel, nwno, numg, numt);
-    if (plane_pitch < nwno) return fail(ctx, "get_thermal_1d: plane_pitch %ld < nwno %d", plane_pitch, nwno);
+    const long ncol = (long)nwno * ncolper;
+    if (plane_pitch < ncol) return fail(ctx, "get_thermal_1d: plane_pitch %ld < %ld columns", plane_pitch, ncol);
     if (calc_type != 0 && calc_type != 1) return fail(ctx, "get_thermal_1d: calc_type must be 0 or 1");
     if (calc_type == 1 && !dwno) return fail(ctx, "get_thermal_1d: calc_type=1 needs dwno");
     const bool want_lvl = flux_minus || flux_plus || flux_minus_mdpt || flux_plus_mdpt;
     if (want_lvl && !(flux_minus && flux_plus && flux_minus_mdpt && flux_plus_mdpt))
         return fail(ctx, "get_thermal_1d: pass all four level-flux outputs or none");
+    if (ncolper > 1 && (want_lvl || flux_disk))
+        return fail(ctx, "get_thermal_1d: level fluxes / fused disk sum are per-wavelength outputs (ngauss = 1)");
     PZ_HIP(ctx, hipSetDevice(ctx->device));
     const int nang = numg * numt;
     std::vector<double> tab(2 * (size_t)nlevel + (size_t)nang);
@@ -496,7 +558,8 @@ int picaso_get_thermal_1d_dev(picaso_ctx *ctx, int nlevel, const double *wno, in
     PZ_TRY(table_upload(ctx, tab.data(), sizeof(double) * tab.size(), &d_tab));
     ThermalArgs a{};
     a.nlayer = nlevel - 1;
-    a.ncol = nwno;
+    a.ncol = ncol;
+    a.ncolper = ncolper;
     a.pitch = plane_pitch;
     a.nfac = 1;
     a.nwno = nwno;
@@ -531,13 +594,60 @@ int picaso_get_thermal_1d_dev(picaso_ctx *ctx, int nlevel, const double *wno, in
             a.u1[k] = ubar1[idx];
             a.wgt[k] = fuse ? gweight[idx / numt] * tweight[idx % numt] : 0.0;
         }
-        a.flux = flux_at_top + (size_t)done * nwno;
+        a.flux = flux_at_top + (size_t)done * ncol;
         a.disk_first = (c == 0);
         a.disk_last = (c + 1 == chunks.size());
         PZ_TRY(launch_thermal_toa(ctx, a, false));
         done += a.na;
     }
     return 0;
+}
+
+int picaso_get_thermal_1d_dev(picaso_ctx *ctx, int nlevel, const double *wno, int nwno,
+                              long plane_pitch, int numg, int numt, const double *tlevel,
+                              const double *dtau, const double *w0, const double *cosb,
+                              const double *plevel, const double *ubar1,
+                              const double *surf_reflect, int hard_surface, const double *dwno,
+                              int calc_type, double *flux_at_top, double *flux_minus,
+                              double *flux_plus, double *flux_minus_mdpt, double *flux_plus_mdpt,
+                              const double *gweight, const double *tweight, double *flux_disk)
+{
+    return thermal_1d_core(ctx, nlevel, wno, nwno, 1, plane_pitch, numg, numt, tlevel, dtau, w0, cosb, plevel,
+                           ubar1, surf_reflect, hard_surface, dwno, calc_type, flux_at_top, flux_minus,
+                           flux_plus, flux_minus_mdpt, flux_plus_mdpt, gweight, tweight, flux_disk);
+}
+
+int picaso_get_thermal_1d_ck_dev(picaso_ctx *ctx, int nlevel, const double *wno, int nwno, int ngauss,
+                                 int numg, int numt, const double *tlevel, const double *dtau,
+                                 const double *w0, const double *cosb, const double *plevel,
+                                 const double *ubar1, const double *surf_reflect, int hard_surface,
+                                 const double *dwno, int calc_type, const double *gauss_wts,
+                                 double *flux_at_top, const double *gweight, const double *tweight,
+                                 double *flux_disk)
+{
+    if (!ctx) return fail(nullptr, "null context");
+    if (ngauss < 1 || ngauss > MAX_CK_GAUSS) return fail(ctx, "get_thermal_1d_ck: ngauss must be 1..%d", MAX_CK_GAUSS);
+    if (!gauss_wts) return fail(ctx, "get_thermal_1d_ck: gauss_wts is null");
+    if (nwno < 1 || numg < 1 || numt < 1) return fail(ctx, "get_thermal_1d_ck: bad sizes");
+    const int nang = numg * numt;
+    const long ncol = (long)nwno * ngauss;
+    PZ_TRY(lvl_scratch_reserve(ctx, sizeof(double) * (size_t)nang * ncol));
+    double *xcol = (double *)ctx->lvl_scratch;
+    PZ_TRY(thermal_1d_core(ctx, nlevel, wno, nwno, ngauss, ncol, numg, numt, tlevel, dtau, w0, cosb, plevel, ubar1,
+                           surf_reflect, hard_surface, dwno, calc_type, xcol, nullptr, nullptr, nullptr,
+                           nullptr, nullptr, nullptr, nullptr));
+    PZ_TRY(launch_weighted_colsum(ctx, nang, nwno, ngauss, gauss_wts, xcol, flux_at_top));
+    if (flux_disk && gweight && tweight)
+        PZ_TRY(picaso_compress_thermal_dev(ctx, (size_t)nwno, flux_at_top, gweight, numg, tweight, numt, flux_disk));
+    return 0;
+}
+
+int picaso_axpby_dev(picaso_ctx *ctx, size_t n, double a, const double *x, double b, const double *y,
+                     double *out)
+{
+    if (!ctx) return fail(nullptr, "null context");
+    PZ_HIP(ctx, hipSetDevice(ctx->device));
+    return launch_axpby(ctx, n, a, x, b, y, out);
 }
 
 int picaso_get_thermal_1d(picaso_ctx *ctx, int nlevel, const double *wno, int nwno, int numg,

@@ -72,9 +72,12 @@ inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 // ---------------------------------------------------------------------------------------------
 constexpr int MAX_ANGLES = 8;   // angles fused per launch (per-lane register state)
 
+constexpr int MAX_CK_GAUSS = 32;   // Gauss points of a correlated-k table (reference tables use 8 or 20)
+
 struct ReflectedArgs {
     int nlayer;
-    long ncol;          // columns: nwno (1-D) or nwno*nfac (3-D)
+    long ncol;          // columns: nwno*ncolper (1-D) or nwno*nfac (3-D)
+    int ncolper;        // 1-D only: columns per wavelength (correlated-k Gauss points, fastest axis)
     long pitch;         // elements between consecutive layers of a plane
     int nfac;           // 1 for 1-D; numg*numt for 3-D (facet index fastest in memory)
     int nwno;
@@ -103,12 +106,18 @@ struct ReflectedArgs {
     int albedo_first, albedo_last;          // first chunk initialises, last chunk finalises (/F0PI*scale)
 };
 int launch_reflected_toa(picaso_ctx *ctx, const ReflectedArgs &a, bool is3d);
+// out[r][w] = sum_j wts[j] in[r][w*n + j]  (correlated-k Gauss-point sum, justdoit.py:307, 380)
+int launch_weighted_colsum(picaso_ctx *ctx, int nrows, long nwno, int n, const double *wts_host,
+                           const double *in, double *out);
+// out = a x + b y (patchy-cloud blend, justdoit.py:300-305)
+int launch_axpby(picaso_ctx *ctx, size_t n, double a, const double *x, double b, const double *y, double *out);
 
 
 struct ThermalArgs {
     int nlayer;
     long ncol, pitch;
     int nfac, nwno;
+    int ncolper;                            // 1-D only: columns per wavelength (correlated-k Gauss points)
     const double *wno, *dwno;               // (nwno)
     const double *tlevel, *plevel;          // device: (nlevel) for 1-D, (nlevel,nfac) for 3-D
     const double *dtau, *w0, *cosb;

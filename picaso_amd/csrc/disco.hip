@@ -34,4 +34,58 @@ int launch_compress_dev(picaso_ctx *ctx, size_t ninner, const double *x, const d
     return 0;
 }
 
+
+// Correlated-k Gauss-point sum (reference justdoit.py:307, 380: `xint_at_top += xint*gauss_wts[ig]`,
+// in ig order): in is (nrows, nwno, n) with the Gauss index fastest, out (nrows, nwno).
+struct ColsumArgs {
+    long nwno;
+    int n;
+    double wts[MAX_CK_GAUSS];
+    const double *in;
+    double *out;
+};
+
+__global__ __launch_bounds__(256) void k_weighted_colsum(const ColsumArgs a)
+{
+    const long w = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (w >= a.nwno) return;
+    const double *src = a.in + ((long)blockIdx.y * a.nwno + w) * a.n;
+    double acc = 0.0;
+    for (int j = 0; j < a.n; ++j) acc = acc + src[j] * a.wts[j];
+    a.out[(long)blockIdx.y * a.nwno + w] = acc;
+}
+
+int launch_weighted_colsum(picaso_ctx *ctx, int nrows, long nwno, int n, const double *wts_host,
+                           const double *in, double *out)
+{
+    if (n < 1 || n > MAX_CK_GAUSS) return fail(ctx, "gauss sum: ngauss must be 1..%d, got %d", MAX_CK_GAUSS, n);
+    if (nrows < 1 || nwno < 1) return 0;
+    ColsumArgs a{};
+    a.nwno = nwno; a.n = n; a.in = in; a.out = out;
+    for (int j = 0; j < n; ++j) a.wts[j] = wts_host[j];
+    const int block = 256;
+    hipLaunchKernelGGL(k_weighted_colsum, dim3((unsigned)((nwno + block - 1) / block), (unsigned)nrows),
+                       dim3(block), 0, ctx->stream, a);
+    PZ_HIP(ctx, hipGetLastError());
+    return 0;
+}
+
+__global__ __launch_bounds__(256) void k_axpby(size_t n, double a, const double *__restrict__ x, double b,
+                                               const double *__restrict__ y, double *__restrict__ out)
+{
+#pragma clang fp contract(off)      // two products and a sum, as numpy evaluates the blend
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i < n) out[i] = a * x[i] + b * y[i];
+}
+
+int launch_axpby(picaso_ctx *ctx, size_t n, double a, const double *x, double b, const double *y, double *out)
+{
+    if (n == 0) return 0;
+    const int block = 256;
+    hipLaunchKernelGGL(k_axpby, dim3((unsigned)((n + block - 1) / block)), dim3(block), 0, ctx->stream, n, a,
+                       x, b, y, out);
+    PZ_HIP(ctx, hipGetLastError());
+    return 0;
+}
+
 }  // namespace pz

@@ -237,7 +237,7 @@ __global__ __launch_bounds__(256, PZ_REFL_MINWAVES) void k_reflected_toa(const R
     const long col = blockIdx.x * (long)blockDim.x + threadIdx.x;
     if (col >= a.ncol) return;
     const int nfac = IS3D ? a.nfac : 1;
-    const long w = IS3D ? col / nfac : col;
+    const long w = IS3D ? col / nfac : (a.ncolper > 1 ? col / a.ncolper : col);
     const int fac = IS3D ? (int)(col - w * nfac) : 0;
     const int n = a.nlayer;
     const long pitch = a.pitch;
@@ -362,7 +362,7 @@ __global__ __launch_bounds__(256, PZ_REFL_MINWAVES) void k_reflected_toa(const R
         const double pos = S.pEM * (b_surface - S.get(S_D1, k) + rs * S.get(S_D2, k)) * bden;
         const double x = S.get(S_KAPPA, k) + S.get(S_ZETA, k) * pos;
         if (IS3D) a.xint[(long)fac * a.nwno + w] = x;
-        else a.xint[(long)k * a.nwno + w] = x;
+        else a.xint[(long)k * a.ncol + col] = x;
         alb = alb + x * g[k].wgt;
     }
     if (!IS3D && a.albedo) {                              // fused disco.compress_disco (disco.py:145-148)

@@ -23,7 +23,7 @@ __global__ __launch_bounds__(256) void k_thermal_toa(const ThermalArgs a)
     const long col = blockIdx.x * (long)blockDim.x + threadIdx.x;
     if (col >= a.ncol) return;
     const int nfac = IS3D ? a.nfac : 1;
-    const long w = IS3D ? col / nfac : col;
+    const long w = IS3D ? col / nfac : (a.ncolper > 1 ? col / a.ncolper : col);
     const int fac = IS3D ? (int)(col - w * nfac) : 0;
     const int n = a.nlayer;
     const long pitch = a.pitch;
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256) void k_thermal_toa(const ThermalArgs a)
     for (int k = 0; k < NA; ++k) {
         const double x = kappa[k] + zeta[k] * pos;
         if (IS3D) a.flux[(long)fac * a.nwno + w] = x;
-        else a.flux[(long)k * a.nwno + w] = x;
+        else a.flux[(long)k * a.ncol + col] = x;
         disk = disk + x * a.wgt[k];
     }
     if (!IS3D && a.disk) {                                     // fused disco.compress_thermal

@@ -1,0 +1,94 @@
+"""Correlated-k Gauss-point batch and patchy-cloud blend on the GPU vs the reference's loop
+(justdoit.py:256-307, 328-380) restated with the CPU oracle: one solve per Gauss point on the
+strided slice ``plane[:, :, ig]``, accumulated with ``gauss_wts`` in ig order."""
+import numpy as np
+import pytest
+
+from helpers import PLANES, rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-8
+TTHG = (1.0, -1.0, 2.0, -0.5, 1.0)
+
+
+def _ck_scene(nlayer, nwno, ngauss, seed):
+    """Planes (nlayer|nlevel, nwno, ngauss): the gas optical depth differs per Gauss point, Rayleigh
+    and cloud are shared (reference optics.py:234-262, 309-315)."""
+    from picaso_amd import synthetic as syn
+    base = syn.make_scene(nlayer, nwno, seed=seed)
+    scale = 10.0 ** np.linspace(-1.5, 1.0, ngauss)           # k-distribution: weak -> strong
+    per_g = [syn.mix_planes(base["taugas"] * s, base["tauray"], base["taucld"], base["w0_cld"],
+                            base["g0_cld"]) for s in scale]
+    planes = {k: np.ascontiguousarray(np.stack([p[k] for p in per_g], axis=2)) for k in per_g[0]}
+    return base, planes
+
+
+def test_reflected_and_thermal_ck_batch(oracle):
+    from picaso_amd import _lib, disco, resident
+    from picaso_amd.device import DeviceArray
+    ctx = _lib.context()
+    nlayer, nwno, ngauss, ng = 33, 515, 4, 5
+    base, planes = _ck_scene(nlayer, nwno, ngauss, seed=77)
+    wts = np.array([0.35, 0.3, 0.25, 0.1])
+    gang, gw, tang, tw = disco.get_angles_1d(ng)
+    u0, u1, ct, _, _ = disco.compute_disco(ng, 1, gang, tang, 0.0)
+    f0 = np.linspace(0.8, 1.3, nwno)
+    rs = np.full(nwno, 0.2)
+    # ---- reference-style loop with the oracle ----
+    xo = 0.0
+    fo = 0.0
+    for ig in range(ngauss):
+        sl = [np.ascontiguousarray(planes[k][:, :, ig]) for k in PLANES]
+        x, _ = oracle.get_reflected_1d(nlayer + 1, base["wno"], nwno, ng, 1, *sl, rs, u0, u1, 1.0, f0,
+                                       3, 0, *TTHG)
+        xo = xo + x * wts[ig]
+        f, _ = oracle.get_thermal_1d(nlayer + 1, base["wno"], nwno, ng, 1, base["tlevel"],
+                                     np.ascontiguousarray(planes["dtau_og"][:, :, ig]),
+                                     np.ascontiguousarray(planes["w0_no_raman"][:, :, ig]),
+                                     np.ascontiguousarray(planes["cosb_og"][:, :, ig]), base["plevel"],
+                                     u1, rs, 0, base["wno"] * 0, 0)
+        fo = fo + f * wts[ig]
+    alb_o = oracle.compress_disco(nwno, 1.0, xo, gw, tw, f0)
+    # ---- one batched launch each ----
+    d = {k: DeviceArray.from_host(planes[k], ctx) for k in PLANES + ("w0_no_raman",)}
+    d_rs, d_f0 = DeviceArray.from_host(rs, ctx), DeviceArray.from_host(f0, ctx)
+    d_wno = DeviceArray.from_host(base["wno"], ctx)
+    xint, alb = DeviceArray((ng, 1, nwno), ctx), DeviceArray((nwno,), ctx)
+    resident.reflected_1d_ck(ctx, nlayer + 1, nwno, ngauss, ng, 1, d, d_rs, u0, u1, 1.0, d_f0, 3, 0,
+                             *TTHG, wts, xint, gweight=gw, tweight=tw, albedo=alb)
+    assert rel_err(xint.to_host(), xo) < TOL
+    assert rel_err(alb.to_host(), alb_o) < TOL
+    flux = DeviceArray((ng, 1, nwno), ctx)
+    resident.thermal_1d_ck(ctx, nlayer + 1, d_wno, nwno, ngauss, ng, 1, base["tlevel"], d["dtau_og"],
+                           d["w0_no_raman"], d["cosb_og"], base["plevel"], u1, d_rs, 0, wts, flux)
+    assert rel_err(flux.to_host(), fo) < TOL
+    # ngauss = 1 through the batch entry point == the plain one
+    d1 = {k: DeviceArray.from_host(planes[k][:, :, :1], ctx) for k in PLANES}
+    x1 = DeviceArray((ng, 1, nwno), ctx)
+    resident.reflected_1d_ck(ctx, nlayer + 1, nwno, 1, ng, 1, d1, d_rs, u0, u1, 1.0, d_f0, 3, 0, *TTHG,
+                             np.ones(1), x1)
+    x2 = DeviceArray((ng, 1, nwno), ctx)
+    resident.reflected_1d(ctx, nlayer + 1, nwno, ng, 1, d1, d_rs, u0, u1, 1.0, d_f0, 3, 0, *TTHG, x2)
+    assert np.array_equal(x1.to_host(), x2.to_host())
+
+
+def test_ck_argument_errors():
+    from picaso_amd import _lib, resident
+    from picaso_amd.device import DeviceArray
+    ctx = _lib.context()
+    z = DeviceArray((4,), ctx)
+    d = {k: z for k in PLANES}
+    with pytest.raises(Exception, match="ngauss"):
+        resident.reflected_1d_ck(ctx, 2, 1, 33, 1, 1, d, z, [[0.5]], [[0.5]], 1.0, z, 3, 0, *TTHG,
+                                 np.ones(33), z)
+
+
+def test_axpby_blend():
+    from picaso_amd import _lib, resident
+    from picaso_amd.device import DeviceArray
+    ctx = _lib.context()
+    rng = np.random.default_rng(5)
+    x, y = rng.random(1001), rng.random(1001)
+    dx, dy, do = DeviceArray.from_host(x, ctx), DeviceArray.from_host(y, ctx), DeviceArray((1001,), ctx)
+    resident.axpby(ctx, 0.7, dx, 0.3, dy, do)
+    assert np.array_equal(do.to_host(), 0.7 * x + 0.3 * y)
