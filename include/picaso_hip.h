@@ -295,6 +295,31 @@ int picaso_compute_opacity_dev(picaso_ctx *ctx, int nlayer, int nwno, const doub
                                double *tau_og, double *w0_og, double *cosb_og, double *w0_no_raman,
                                double *f_deltaM);
 
+/* Correlated-k forms of the two calls above (reference RetrieveCKs.get_pre_mix_ck,
+ * picaso/optics.py:1081-1161; RetrieveCKs.get_continuum, :1398-1498; compute_opacity with
+ * ngauss > 1, :234-262).  Molecular tables have nwno*ngauss columns per row (Gauss index fastest,
+ * the reference's kappa[p,t,wno,gauss] layout) and taugas / all 13 outputs are
+ * (nlayer|nlevel, nwno, ngauss); Rayleigh, cloud and Raman planes have no Gauss axis.
+ *   mol_mode : 0 nearest row, 1 10**(sum_4 w log10 kappa), 2 exp(sum_4 w ln kappa) (premixed CK)
+ *   cont_mode: 0 nearest-temperature row (cont_rows [ncont][nlayer], cont_wts NULL),
+ *              1 exp(w0 ln k[row0] + w1 ln k[row1]) (cont_rows, cont_wts [ncont][nlayer][2];
+ *                tables hold ln kappa) */
+int picaso_opacity_gas_ck_dev(picaso_ctx *ctx, int nlayer, int nwno, int ngauss, int mol_mode, int nmol,
+                              const double *const *mol_tables, const int *mol_rows,
+                              const double *mol_wts, const double *mol_fac, int cont_mode, int ncont,
+                              const double *const *cont_tables, const int *cont_rows,
+                              const double *cont_wts, const double *cont_fac, int nray,
+                              const double *const *ray_tables, const double *ray_fac, double *taugas,
+                              double *tauray);
+int picaso_compute_opacity_ck_dev(picaso_ctx *ctx, int nlayer, int nwno, int ngauss, const double *taugas,
+                                  const double *tauray, const double *taucld, const double *w0_cld,
+                                  const double *g0_cld, const double *raman_factor,
+                                  double raman_const, int test_mode, int delta_eddington, int stream,
+                                  double *dtau, double *tau, double *w0, double *cosb,
+                                  double *ftau_cld, double *ftau_ray, double *gcos2, double *dtau_og,
+                                  double *tau_og, double *w0_og, double *cosb_og, double *w0_no_raman,
+                                  double *f_deltaM);
+
 #ifdef __cplusplus
 }
 #endif

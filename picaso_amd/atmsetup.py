@@ -150,4 +150,34 @@ class ATMSETUP:
         self.layer["cloud"] = cld
 
     def as_dict(self):
-        return dict(level=self.level, layer=self.layer, warnings=self.warnings)
+        """Picklable ``full_output`` dictionary with the reference's key names
+        (reference atmsetup.py:704-790)."""
+        bars = self.c.pconv
+        out = {"weights": getattr(self, "weights", None),
+               "layer": {"pressure_unit": "bars", "mixingratio_unit": "volume/volume",
+                         "temperature_unit": "K", "pressure": self.layer["pressure"] / bars,
+                         "mixingratios": self.layer["mixingratios"],
+                         "temperature": self.layer["temperature"],
+                         "column_density": self.layer.get("colden"), "mmw": self.layer.get("mmw"),
+                         "cloud": {k: self.layer["cloud"][k] for k in ("w0", "g0", "opd")}},
+               "wavenumber": getattr(self, "wavenumber", None), "wavenumber_unit": "cm-1",
+               "level": {"pressure": self.level["pressure"] / bars,
+                         "temperature": self.level["temperature"]},
+               "latitude": getattr(self, "latitude", None), "longitude": getattr(self, "longitude", None),
+               "star": {"flux_unit": "erg/cm2/s/cm"}, "warnings": self.warnings}
+        for k in ("taugas", "tauray", "taucld"):
+            out[k] = getattr(self, k, None)
+        if getattr(self, "get_lvl_flux", False):
+            for key, attr in (("thermal_fluxes", "lvl_output_thermal"), ("reflected_fluxes", "lvl_output_reflected")):
+                if getattr(self, attr, None) is not None:
+                    out["level"][key] = getattr(self, attr)
+        for k in ("dz", "z"):
+            if k in self.level:
+                out["level"][k] = self.level[k]
+        if hasattr(self, "xint_at_top"):
+            out["albedo_3d"] = self.xint_at_top
+            out["reflected_unit"] = "albedo"
+        if hasattr(self, "flux_at_top"):
+            out["thermal_3d"] = self.flux_at_top
+            out["thermal_unit"] = "erg/cm2/s/cm"
+        return out

@@ -11,48 +11,65 @@
 namespace pz {
 
 struct GasArgs {
-    int nlayer, nwno, linear, nmol, ncont, nray;
+    int nlayer, nwno, nmol, ncont, nray;
+    int ncolper;      // columns per wavelength of the molecular tables / taugas (correlated-k Gauss points)
+    int mol_mode;     // 0 nearest row; 1 10**(sum_4 w log10 kappa) (optics.py:2290-2293);
+                      // 2 exp(sum_4 w ln kappa), premixed correlated-k (optics.py:1152-1157)
+    int cont_mode;    // 0 nearest-temperature row (optics.py:2298-2306);
+                      // 1 exp((1-t) ln k_lo + t ln k_hi), correlated-k continuum (optics.py:1486-1489)
     const double *const *mol_tables, *const *cont_tables, *const *ray_tables;   // device arrays of device ptrs
     const int *mol_rows, *cont_rows;          // device
-    const double *mol_wts, *mol_fac, *cont_fac, *ray_fac;
+    const double *mol_wts, *mol_fac, *cont_wts, *cont_fac, *ray_fac;
     double *taugas, *tauray;
 };
 
 __global__ __launch_bounds__(256) void k_opacity_gas(const GasArgs a)
 {
-    const long w = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    const long col = blockIdx.x * (long)blockDim.x + threadIdx.x;
     const int lay = blockIdx.y;
-    if (w >= a.nwno) return;
-    const long nw = a.nwno;
+    const long nw = a.nwno, ncol = nw * a.ncolper;
+    if (col >= ncol) return;
+    const long w = (a.ncolper > 1) ? col / a.ncolper : col;
     double tg = 0.0;
     // continuum first, then molecules: the reference's accumulation order (optics.py:172-255)
     for (int c = 0; c < a.ncont; ++c) {
-        const long row = a.cont_rows[c * a.nlayer + lay];
-        tg += a.cont_tables[c][row * nw + w] * a.cont_fac[c * a.nlayer + lay];
+        double k;
+        if (a.cont_mode == 1) {
+            const int b = (c * a.nlayer + lay) * 2;
+            const double *tab = a.cont_tables[c];
+            k = fexp(a.cont_wts[b] * tab[(long)a.cont_rows[b] * nw + w] +
+                     a.cont_wts[b + 1] * tab[(long)a.cont_rows[b + 1] * nw + w]);
+        } else {
+            k = a.cont_tables[c][(long)a.cont_rows[c * a.nlayer + lay] * nw + w];
+        }
+        tg += k * a.cont_fac[c * a.nlayer + lay];
     }
     for (int m = 0; m < a.nmol; ++m) {
         const int base = (m * a.nlayer + lay) * 4;
         const double *tab = a.mol_tables[m];
         double cx;
-        if (a.linear) {          // 10**(sum_k w_k log10 kappa_k)   (optics.py:2290-2293)
-            double lg = a.mol_wts[base] * tab[(long)a.mol_rows[base] * nw + w];
-            lg = lg + a.mol_wts[base + 1] * tab[(long)a.mol_rows[base + 1] * nw + w];
-            lg = lg + a.mol_wts[base + 2] * tab[(long)a.mol_rows[base + 2] * nw + w];
-            lg = lg + a.mol_wts[base + 3] * tab[(long)a.mol_rows[base + 3] * nw + w];
-            cx = fexp(lg * 2.302585092994046);
+        if (a.mol_mode) {
+            double lg = a.mol_wts[base] * tab[(long)a.mol_rows[base] * ncol + col];
+            lg = lg + a.mol_wts[base + 1] * tab[(long)a.mol_rows[base + 1] * ncol + col];
+            lg = lg + a.mol_wts[base + 2] * tab[(long)a.mol_rows[base + 2] * ncol + col];
+            lg = lg + a.mol_wts[base + 3] * tab[(long)a.mol_rows[base + 3] * ncol + col];
+            cx = fexp(a.mol_mode == 1 ? lg * 2.302585092994046 : lg);
         } else {                 // nearest (p,T) row (optics.py:2351)
-            cx = tab[(long)a.mol_rows[base] * nw + w];
+            cx = tab[(long)a.mol_rows[base] * ncol + col];
         }
-        tg += (cx * 6.02214086e+23) * a.mol_fac[m * a.nlayer + lay];    // optics.py:2294, :246-250
+        tg += (cx * 6.02214086e+23) * a.mol_fac[m * a.nlayer + lay];    // optics.py:2294, :246-250, :1159
     }
-    double tr = 0.0;
-    for (int r = 0; r < a.nray; ++r) tr += a.ray_tables[r][w] * a.ray_fac[r * a.nlayer + lay];   // :265-271
-    a.taugas[(long)lay * nw + w] = tg;
-    a.tauray[(long)lay * nw + w] = tr;
+    a.taugas[(long)lay * ncol + col] = tg;
+    if (col == w * a.ncolper) {      // Rayleigh has no Gauss-point axis (optics.py:265-277)
+        double tr = 0.0;
+        for (int r = 0; r < a.nray; ++r) tr += a.ray_tables[r][w] * a.ray_fac[r * a.nlayer + lay];   // :265-271
+        a.tauray[(long)lay * nw + w] = tr;
+    }
 }
 
 struct MixArgs {
     int nlayer, nwno, test_mode, delta_eddington, stream;
+    int ncolper;      // columns per wavelength of taugas and of every output (tauray, cloud, raman have none)
     const double *taugas, *tauray, *taucld, *w0c, *g0c, *raman;
     double raman_const;
     double *dtau, *tau, *w0, *cosb, *ftau_cld, *ftau_ray, *gcos2, *dtau_og, *tau_og, *w0_og,
@@ -68,16 +85,17 @@ __device__ __forceinline__ double ipow(double x, int n)
 
 __global__ __launch_bounds__(256) void k_compute_opacity(const MixArgs a)
 {
-    const long w = blockIdx.x * (long)blockDim.x + threadIdx.x;
-    if (w >= a.nwno) return;
-    const long nw = a.nwno;
+    const long col = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    const long nw = a.nwno, ncol = nw * a.ncolper;
+    if (col >= ncol) return;
+    const long w = (a.ncolper > 1) ? col / a.ncolper : col;
     double tau_run = 0.0, taud_run = 0.0;
-    a.tau_og[w] = 0.0;
-    a.tau[w] = 0.0;
+    a.tau_og[col] = 0.0;
+    a.tau[col] = 0.0;
     for (int i = 0; i < a.nlayer; ++i) {
-        const long o = (long)i * nw + w;
-        const double tg = a.taugas[o], tr = a.tauray[o], tc = a.taucld[o], wc = a.w0c[o], gc = a.g0c[o];
-        const double rf = a.raman ? a.raman[o] : a.raman_const;
+        const long o = (long)i * ncol + col, ow = (long)i * nw + w;
+        const double tg = a.taugas[o], tr = a.tauray[ow], tc = a.taucld[ow], wc = a.w0c[ow], gc = a.g0c[ow];
+        const double rf = a.raman ? a.raman[ow] : a.raman_const;
         double dtau = tg + tr + tc;                                     // optics.py:329
         double fcld = (wc * tc) / (wc * tc + tr);                       // :335
         double cosb = gc;                                               // :338
@@ -97,7 +115,7 @@ __global__ __launch_bounds__(256) void k_compute_opacity(const MixArgs a)
             w0nr = w0;
         }
         tau_run += dtau;                                                // numba_cumsum (:353-354)
-        a.dtau_og[o] = dtau; a.tau_og[o + nw] = tau_run; a.w0_og[o] = w0; a.cosb_og[o] = cosb;
+        a.dtau_og[o] = dtau; a.tau_og[o + ncol] = tau_run; a.w0_og[o] = w0; a.cosb_og[o] = cosb;
         a.ftau_cld[o] = fcld; a.ftau_ray[o] = fray; a.gcos2[o] = gcos2; a.w0_no_raman[o] = w0nr;
         if (a.delta_eddington) {                                        // :401-420
             const double f = ipow(cosb, a.stream);
@@ -105,9 +123,9 @@ __global__ __launch_bounds__(256) void k_compute_opacity(const MixArgs a)
             const double cbd = (cosb - f) / (1. - f);
             const double dtd = dtau * (1. - w0 * f);
             taud_run += dtd;
-            a.f_deltaM[o] = f; a.w0[o] = w0d; a.cosb[o] = cbd; a.dtau[o] = dtd; a.tau[o + nw] = taud_run;
+            a.f_deltaM[o] = f; a.w0[o] = w0d; a.cosb[o] = cbd; a.dtau[o] = dtd; a.tau[o + ncol] = taud_run;
         } else {                                                        // :428-431
-            a.f_deltaM[o] = 0 * cosb; a.w0[o] = w0; a.cosb[o] = cosb; a.dtau[o] = dtau; a.tau[o + nw] = tau_run;
+            a.f_deltaM[o] = 0 * cosb; a.w0[o] = w0; a.cosb[o] = cosb; a.dtau[o] = dtau; a.tau[o + ncol] = tau_run;
         }
     }
 }
@@ -118,26 +136,32 @@ using namespace pz;
 
 extern "C" {
 
-int picaso_opacity_gas_dev(picaso_ctx *ctx, int nlayer, int nwno, int linear, int nmol,
-                           const double *const *mol_tables, const int *mol_rows,
-                           const double *mol_wts, const double *mol_fac, int ncont,
-                           const double *const *cont_tables, const int *cont_rows,
-                           const double *cont_fac, int nray, const double *const *ray_tables,
-                           const double *ray_fac, double *taugas, double *tauray)
+int picaso_opacity_gas_ck_dev(picaso_ctx *ctx, int nlayer, int nwno, int ngauss, int mol_mode, int nmol,
+                              const double *const *mol_tables, const int *mol_rows,
+                              const double *mol_wts, const double *mol_fac, int cont_mode, int ncont,
+                              const double *const *cont_tables, const int *cont_rows,
+                              const double *cont_wts, const double *cont_fac, int nray,
+                              const double *const *ray_tables, const double *ray_fac, double *taugas,
+                              double *tauray)
 {
     if (!ctx) return fail(nullptr, "null context");
     if (nlayer < 1 || nwno < 1 || nmol < 0 || ncont < 0 || nray < 0) return fail(ctx, "opacity_gas: bad sizes");
+    if (ngauss < 1 || ngauss > MAX_CK_GAUSS) return fail(ctx, "opacity_gas: ngauss must be 1..%d", MAX_CK_GAUSS);
+    if (mol_mode < 0 || mol_mode > 2 || cont_mode < 0 || cont_mode > 1) return fail(ctx, "opacity_gas: bad mode");
+    if (cont_mode == 1 && ncont > 0 && !cont_wts) return fail(ctx, "opacity_gas: cont_mode=1 needs cont_wts");
     PZ_HIP(ctx, hipSetDevice(ctx->device));
     // pack the small per-layer host tables into one ring slot
+    const int crow = (cont_mode == 1) ? 2 : 1;
     const size_t n_ptr = (size_t)nmol + ncont + nray;
     const size_t b_ptr = align_up(n_ptr * sizeof(double *), 8);
     const size_t b_mrow = align_up((size_t)nmol * nlayer * 4 * sizeof(int), 8);
-    const size_t b_crow = align_up((size_t)ncont * nlayer * sizeof(int), 8);
+    const size_t b_crow = align_up((size_t)ncont * nlayer * crow * sizeof(int), 8);
     const size_t b_mw = (size_t)nmol * nlayer * 4 * sizeof(double);
     const size_t b_mf = (size_t)nmol * nlayer * sizeof(double);
+    const size_t b_cw = (cont_mode == 1) ? (size_t)ncont * nlayer * 2 * sizeof(double) : 0;
     const size_t b_cf = (size_t)ncont * nlayer * sizeof(double);
     const size_t b_rf = (size_t)nray * nlayer * sizeof(double);
-    std::vector<char> buf(b_ptr + b_mrow + b_crow + b_mw + b_mf + b_cf + b_rf + 64);
+    std::vector<char> buf(b_ptr + b_mrow + b_crow + b_mw + b_mf + b_cw + b_cf + b_rf + 64);
     char *p = buf.data();
     const double **h_ptr = (const double **)p;
     for (int m = 0; m < nmol; ++m) h_ptr[m] = mol_tables[m];
@@ -145,16 +169,18 @@ int picaso_opacity_gas_dev(picaso_ctx *ctx, int nlayer, int nwno, int linear, in
     for (int r = 0; r < nray; ++r) h_ptr[nmol + ncont + r] = ray_tables[r];
     size_t off = b_ptr;
     const size_t o_mrow = off; if (nmol) memcpy(p + off, mol_rows, (size_t)nmol * nlayer * 4 * sizeof(int)); off += b_mrow;
-    const size_t o_crow = off; if (ncont) memcpy(p + off, cont_rows, (size_t)ncont * nlayer * sizeof(int)); off += b_crow;
+    const size_t o_crow = off; if (ncont) memcpy(p + off, cont_rows, (size_t)ncont * nlayer * crow * sizeof(int)); off += b_crow;
     const size_t o_mw = off; if (nmol) memcpy(p + off, mol_wts, b_mw); off += b_mw;
     const size_t o_mf = off; if (nmol) memcpy(p + off, mol_fac, b_mf); off += b_mf;
+    const size_t o_cw = off; if (ncont && b_cw) memcpy(p + off, cont_wts, b_cw); off += b_cw;
     const size_t o_cf = off; if (ncont) memcpy(p + off, cont_fac, b_cf); off += b_cf;
     const size_t o_rf = off; if (nray) memcpy(p + off, ray_fac, b_rf); off += b_rf;
     const void *d = nullptr;
     PZ_TRY(table_upload(ctx, p, off, &d));
     const char *dc = (const char *)d;
     GasArgs a{};
-    a.nlayer = nlayer; a.nwno = nwno; a.linear = linear; a.nmol = nmol; a.ncont = ncont; a.nray = nray;
+    a.nlayer = nlayer; a.nwno = nwno; a.nmol = nmol; a.ncont = ncont; a.nray = nray;
+    a.ncolper = ngauss; a.mol_mode = mol_mode; a.cont_mode = cont_mode;
     a.mol_tables = (const double *const *)dc;
     a.cont_tables = a.mol_tables + nmol;
     a.ray_tables = a.cont_tables + ncont;
@@ -162,12 +188,57 @@ int picaso_opacity_gas_dev(picaso_ctx *ctx, int nlayer, int nwno, int linear, in
     a.cont_rows = (const int *)(dc + o_crow);
     a.mol_wts = (const double *)(dc + o_mw);
     a.mol_fac = (const double *)(dc + o_mf);
+    a.cont_wts = (const double *)(dc + o_cw);
     a.cont_fac = (const double *)(dc + o_cf);
     a.ray_fac = (const double *)(dc + o_rf);
     a.taugas = taugas; a.tauray = tauray;
     const int block = 256;
-    dim3 grid((unsigned)((nwno + block - 1) / block), (unsigned)nlayer);
+    const long ncol = (long)nwno * ngauss;
+    dim3 grid((unsigned)((ncol + block - 1) / block), (unsigned)nlayer);
     hipLaunchKernelGGL(k_opacity_gas, grid, dim3(block), 0, ctx->stream, a);
+    PZ_HIP(ctx, hipGetLastError());
+    return 0;
+}
+
+int picaso_opacity_gas_dev(picaso_ctx *ctx, int nlayer, int nwno, int linear, int nmol,
+                           const double *const *mol_tables, const int *mol_rows,
+                           const double *mol_wts, const double *mol_fac, int ncont,
+                           const double *const *cont_tables, const int *cont_rows,
+                           const double *cont_fac, int nray, const double *const *ray_tables,
+                           const double *ray_fac, double *taugas, double *tauray)
+{
+    return picaso_opacity_gas_ck_dev(ctx, nlayer, nwno, 1, linear ? 1 : 0, nmol, mol_tables, mol_rows, mol_wts,
+                                     mol_fac, 0, ncont, cont_tables, cont_rows, nullptr, cont_fac, nray,
+                                     ray_tables, ray_fac, taugas, tauray);
+}
+
+int picaso_compute_opacity_ck_dev(picaso_ctx *ctx, int nlayer, int nwno, int ngauss, const double *taugas,
+                                  const double *tauray, const double *taucld, const double *w0_cld,
+                                  const double *g0_cld, const double *raman_factor,
+                                  double raman_const, int test_mode, int delta_eddington, int stream,
+                                  double *dtau, double *tau, double *w0, double *cosb,
+                                  double *ftau_cld, double *ftau_ray, double *gcos2, double *dtau_og,
+                                  double *tau_og, double *w0_og, double *cosb_og, double *w0_no_raman,
+                                  double *f_deltaM)
+{
+    if (!ctx) return fail(nullptr, "null context");
+    if (nlayer < 1 || nwno < 1) return fail(ctx, "compute_opacity: bad sizes");
+    if (ngauss < 1 || ngauss > MAX_CK_GAUSS) return fail(ctx, "compute_opacity: ngauss must be 1..%d", MAX_CK_GAUSS);
+    if (test_mode < 0 || test_mode > 2) return fail(ctx, "compute_opacity: test_mode must be 0, 1 or 2");
+    if (stream != 2 && stream != 4) return fail(ctx, "compute_opacity: stream must be 2 or 4");
+    PZ_HIP(ctx, hipSetDevice(ctx->device));
+    MixArgs a{};
+    a.nlayer = nlayer; a.nwno = nwno; a.ncolper = ngauss; a.test_mode = test_mode;
+    a.delta_eddington = delta_eddington;
+    a.stream = stream; a.taugas = taugas; a.tauray = tauray; a.taucld = taucld; a.w0c = w0_cld;
+    a.g0c = g0_cld; a.raman = raman_factor; a.raman_const = raman_const;
+    a.dtau = dtau; a.tau = tau; a.w0 = w0; a.cosb = cosb; a.ftau_cld = ftau_cld; a.ftau_ray = ftau_ray;
+    a.gcos2 = gcos2; a.dtau_og = dtau_og; a.tau_og = tau_og; a.w0_og = w0_og; a.cosb_og = cosb_og;
+    a.w0_no_raman = w0_no_raman; a.f_deltaM = f_deltaM;
+    const int block = 256;
+    const long ncol = (long)nwno * ngauss;
+    hipLaunchKernelGGL(k_compute_opacity, dim3((unsigned)((ncol + block - 1) / block)), dim3(block), 0,
+                       ctx->stream, a);
     PZ_HIP(ctx, hipGetLastError());
     return 0;
 }
@@ -181,23 +252,10 @@ int picaso_compute_opacity_dev(picaso_ctx *ctx, int nlayer, int nwno, const doub
                                double *tau_og, double *w0_og, double *cosb_og, double *w0_no_raman,
                                double *f_deltaM)
 {
-    if (!ctx) return fail(nullptr, "null context");
-    if (nlayer < 1 || nwno < 1) return fail(ctx, "compute_opacity: bad sizes");
-    if (test_mode < 0 || test_mode > 2) return fail(ctx, "compute_opacity: test_mode must be 0, 1 or 2");
-    if (stream != 2 && stream != 4) return fail(ctx, "compute_opacity: stream must be 2 or 4");
-    PZ_HIP(ctx, hipSetDevice(ctx->device));
-    MixArgs a{};
-    a.nlayer = nlayer; a.nwno = nwno; a.test_mode = test_mode; a.delta_eddington = delta_eddington;
-    a.stream = stream; a.taugas = taugas; a.tauray = tauray; a.taucld = taucld; a.w0c = w0_cld;
-    a.g0c = g0_cld; a.raman = raman_factor; a.raman_const = raman_const;
-    a.dtau = dtau; a.tau = tau; a.w0 = w0; a.cosb = cosb; a.ftau_cld = ftau_cld; a.ftau_ray = ftau_ray;
-    a.gcos2 = gcos2; a.dtau_og = dtau_og; a.tau_og = tau_og; a.w0_og = w0_og; a.cosb_og = cosb_og;
-    a.w0_no_raman = w0_no_raman; a.f_deltaM = f_deltaM;
-    const int block = 256;
-    hipLaunchKernelGGL(k_compute_opacity, dim3((unsigned)((nwno + block - 1) / block)), dim3(block), 0,
-                       ctx->stream, a);
-    PZ_HIP(ctx, hipGetLastError());
-    return 0;
+    return picaso_compute_opacity_ck_dev(ctx, nlayer, nwno, 1, taugas, tauray, taucld, w0_cld, g0_cld,
+                                         raman_factor, raman_const, test_mode, delta_eddington, stream, dtau,
+                                         tau, w0, cosb, ftau_cld, ftau_ray, gcos2, dtau_og, tau_og, w0_og,
+                                         cosb_og, w0_no_raman, f_deltaM);
 }
 
 }  // extern "C"

@@ -257,9 +257,22 @@ def picaso(bundle, opacityclass, dimension="1d", calculation="reflected", full_o
     nlevel, nlayer = atm.c.nlevel, atm.c.nlayer
 
     opa.get_opacities(atm, exclude_mol=inp["atmosphere"]["exclude_mol"])
-    planes = optics.compute_opacity_resident(
-        atm, opa, ngauss=ngauss, stream=common["stream"], delta_eddington=common["delta_eddington"],
-        test_mode=inp["test_mode"], raman=common["raman"], full_output=full_output)
+    co_kw = dict(ngauss=ngauss, stream=common["stream"], delta_eddington=common["delta_eddington"],
+                 test_mode=inp["test_mode"], raman=common["raman"], full_output=full_output)
+    planes = optics.compute_opacity_resident(atm, opa, **co_kw)
+    # patchy clouds (justdoit.py:139-142, 248-252): a second, thinned-cloud column set
+    do_holes = bool(inp["clouds"].get("do_holes", False))
+    fhole = planes_clear = None
+    if do_holes:
+        fhole = float(inp["clouds"]["fhole"])
+        planes_clear = optics.compute_opacity_resident(atm, opa, fthin_cld=inp["clouds"]["fthin_cld"],
+                                                       do_holes=True, **co_kw)
+    gauss_wts = np.asarray(opa.gauss_wts, dtype=float)
+    is_sh = inp["approx"]["rt_method"] == "SH"
+    if is_sh and (ngauss > 1 or do_holes):
+        raise Exception("rt_method='SH' with correlated-k tables or patchy clouds is not built; use 'toon'")
+    if atm.get_lvl_flux and ngauss > 1:
+        raise Exception("get_lvl_flux with correlated-k tables is not built")
 
     rs = DeviceArray.from_host(np.zeros(nwno) + np.asarray(atm.surf_reflect, dtype=float), ctx)
     d_f0 = DeviceArray.from_host(np.asarray(F0PI, dtype=float), ctx)
@@ -268,15 +281,37 @@ def picaso(bundle, opacityclass, dimension="1d", calculation="reflected", full_o
         xint = DeviceArray((ng, nt, nwno), ctx)
         alb = DeviceArray((nwno,), ctx)
         lvl = None
-        if inp["approx"]["rt_method"] == "SH":                # justdoit.py:259-269
+        if is_sh:                                             # justdoit.py:259-269
             _reflected_sh(ctx, nlevel, nwno, ng, nt, planes, rs, ubar0, ubar1, cos_theta, d_f0,
                           inp["approx"]["rt_params"]["SH"], frac_a, frac_b, frac_c, constant_back,
                           constant_forward, common["stream"], b_top, xint, gweight, tweight, alb)
         else:
             lvl = [DeviceArray((ng, nt, nlevel, nwno), ctx) for _ in range(4)] if atm.get_lvl_flux else None
-            _reflected(ctx, nlevel, nwno, ng, nt, planes, rs, ubar0, ubar1, cos_theta, d_f0,
-                       toon["single_phase"], toon["multi_phase"], frac_a, frac_b, frac_c, constant_back,
-                       constant_forward, toon["toon_coefficients"], b_top, xint, lvl, gweight, tweight, alb)
+            tt = (toon["single_phase"], toon["multi_phase"], frac_a, frac_b, frac_c, constant_back,
+                  constant_forward)
+
+            def run(pl, x, lv, fuse):                         # the ngauss loop of justdoit.py:256-307
+                if ngauss > 1:
+                    resident.reflected_1d_ck(ctx, nlevel, nwno, ngauss, ng, nt, pl, rs, ubar0, ubar1,
+                                             cos_theta, d_f0, *tt, gauss_wts, x,
+                                             toon_coefficients=toon["toon_coefficients"], b_top=b_top,
+                                             gweight=gweight if fuse else None,
+                                             tweight=tweight if fuse else None, albedo=alb if fuse else None)
+                else:
+                    _reflected(ctx, nlevel, nwno, ng, nt, pl, rs, ubar0, ubar1, cos_theta, d_f0, *tt,
+                               toon["toon_coefficients"], b_top, x, lv, gweight, tweight,
+                               alb if fuse else None)
+            if not do_holes:
+                run(planes, xint, lvl, True)
+            else:                                             # justdoit.py:287-305
+                xc = DeviceArray((ng, nt, nwno), ctx)
+                lvc = [DeviceArray((ng, nt, nlevel, nwno), ctx) for _ in range(4)] if lvl else None
+                run(planes, xint, lvl, False)
+                run(planes_clear, xc, lvc, False)
+                resident.axpby(ctx, 1.0 - fhole, xint, fhole, xc, xint)
+                for a_, b_ in zip(lvl or [], lvc or []):
+                    resident.axpby(ctx, 1.0 - fhole, a_, fhole, b_, a_)
+                resident.compress_disco(ctx, nwno, cos_theta, xint, gweight, tweight, d_f0, alb)
         albedo = alb.to_host()
         returns["albedo"] = albedo
         if full_output:
@@ -295,15 +330,30 @@ def picaso(bundle, opacityclass, dimension="1d", calculation="reflected", full_o
         d_wno = DeviceArray.from_host(wno, ctx)
         flux = DeviceArray((ng, nt, nwno), ctx)
         disk = DeviceArray((nwno,), ctx)
-        if inp["approx"]["rt_method"] == "SH":                # justdoit.py:364-370
+        if is_sh:                                             # justdoit.py:364-370
             _thermal_sh(ctx, nlevel, d_wno, nwno, ng, nt, atm.level["temperature"], planes,
                         atm.level["pressure"], ubar1, rs, common["stream"], atm.hard_surface,
                         common["delta_eddington"], flux, gweight, tweight, disk)
         else:
-            resident.thermal_1d(ctx, nlevel, d_wno, nwno, ng, nt, atm.level["temperature"],
-                                planes["dtau_og"], planes["w0_no_raman"], planes["cosb_og"],
-                                atm.level["pressure"], ubar1, rs, atm.hard_surface, flux,
-                                gweight=gweight, tweight=tweight, flux_disk=disk)
+            def runt(pl, fx, fuse):                           # the ngauss loop of justdoit.py:328-380
+                kw = dict(gweight=gweight, tweight=tweight, flux_disk=disk) if fuse else {}
+                if ngauss > 1:
+                    resident.thermal_1d_ck(ctx, nlevel, d_wno, nwno, ngauss, ng, nt, atm.level["temperature"],
+                                           pl["dtau_og"], pl["w0_no_raman"], pl["cosb_og"],
+                                           atm.level["pressure"], ubar1, rs, atm.hard_surface, gauss_wts,
+                                           fx, **kw)
+                else:
+                    resident.thermal_1d(ctx, nlevel, d_wno, nwno, ng, nt, atm.level["temperature"],
+                                        pl["dtau_og"], pl["w0_no_raman"], pl["cosb_og"],
+                                        atm.level["pressure"], ubar1, rs, atm.hard_surface, fx, **kw)
+            if not do_holes:
+                runt(planes, flux, True)
+            else:                                             # justdoit.py:346-361
+                fc = DeviceArray((ng, nt, nwno), ctx)
+                runt(planes, flux, False)
+                runt(planes_clear, fc, False)
+                resident.axpby(ctx, 1.0 - fhole, flux, fhole, fc, flux)
+                resident.compress_thermal(ctx, nwno, flux, gweight, tweight, disk)
         thermal = disk.to_host()
         returns["thermal"] = thermal
         returns["thermal_unit"] = "erg/s/(cm^2)/(cm)"
@@ -339,7 +389,7 @@ def _reflected(ctx, nlevel, nwno, ng, nt, planes, rs, ubar0, ubar1, cos_theta, F
         cd(frac_c), cd(constant_back), cd(constant_forward), ci(1), ci(1 if lvl else 0),
         ci(toon_coefficients), cd(b_top), ptr(xint.addr),
         *[ptr(l.addr) if lvl else None for l in (lvl or [None] * 4)], ptr(gw), ptr(tw),
-        ptr(albedo.addr)), ctx)
+        ptr(albedo.addr) if albedo is not None else None), ctx)
 
 
 def _reflected_sh(ctx, nlevel, nwno, ng, nt, planes, rs, ubar0, ubar1, cos_theta, F0PI, sh, frac_a,

@@ -223,6 +223,123 @@ class RetrieveOpacities:
         return zero_g.to_host()
 
 
+class RetrieveCKs:
+    """Pre-mixed correlated-k tables resident in HBM (reference ``RetrieveCKs`` with
+    ``method='preweighted'``, optics.py:655-1547): ``ln kappa[p, t, wno, gauss]`` on a ragged
+    (P,T) grid (``nc_p`` pressures per temperature) plus the CIA continuum.  ``get_opacities``
+    restates the host index search of ``get_pre_mix_ck`` (:1081-1150) and ``get_continuum``
+    (:1411-1428, 1474-1478); the exponentials of the interpolated logs run in ``k_opacity_gas``.
+
+    Built from arrays (the reference's legacy ascii / HDF5 table readers are file-format code
+    outside the accelerated path); ``continuum`` maps 'H2H2'-style keys to {temperature: kappa(wno)}.
+    """
+
+    def __init__(self, wno, gauss_wts, pressures, temps, nc_p, ln_kappa, continuum=None, cia_temps=(),
+                 rayleigh_opa=None, relative_flux=None, ctx=None):
+        self.ctx = ctx if ctx is not None else _lib.context()
+        self.wno = f64(wno)
+        self.wave = 1e4 / self.wno
+        self.nwno = int(self.wno.size)
+        self.gauss_wts = f64(gauss_wts)
+        self.ngauss = int(self.gauss_wts.size)
+        self.pressures = np.unique(np.asarray(pressures, dtype=float))     # optics.py:1095
+        self.temps = np.unique(np.asarray(temps, dtype=float))             # optics.py:1097
+        self.nc_p = np.asarray(nc_p, dtype=int)
+        k = f64(ln_kappa)
+        if k.shape != (self.pressures.size, self.temps.size, self.nwno, self.ngauss):
+            raise Exception("RetrieveCKs: ln_kappa must be (npres, ntemp, nwno, ngauss) = %s, got %s"
+                            % ((self.pressures.size, self.temps.size, self.nwno, self.ngauss), k.shape))
+        self._kappa = DeviceArray.from_host(k.reshape((-1, self.nwno * self.ngauss)), self.ctx)
+        continuum = continuum or {}
+        self.avail_continuum = sorted(continuum.keys())
+        self.cia_temps = np.sort(np.unique(np.asarray(cia_temps, dtype=float)))
+        self._cia = {}
+        for pair in self.avail_continuum:                   # ln(kappa) rows in sorted-temperature order
+            tab = np.stack([f64(continuum[pair][t]) for t in self.cia_temps])
+            self._cia[pair] = DeviceArray.from_host(np.log(tab), self.ctx)
+        self.rayleigh_opa = {m: f64(v) for m, v in (rayleigh_opa or {}).items()}
+        self.rayleigh_molecules = list(self.rayleigh_opa.keys())
+        self._ray = {m: DeviceArray.from_host(v, self.ctx) for m, v in self.rayleigh_opa.items()}
+        self.molecules = np.array([])                       # premixed: no per-molecule tables
+        self.query_method = "premixed"
+        self.relative_flux = relative_flux
+        self.raman_stellar_shifts = None
+        self.molecular_opa, self.continuum_opa = None, {}
+        self._plan = None
+
+    def get_opacities(self, atmosphere, exclude_mol=1):
+        """Table rows / weights for this atmosphere (``get_opacities_preweighted``: continuum +
+        ``get_pre_mix_ck``, reference optics.py:1500-1538)."""
+        if exclude_mol != 1:
+            raise Exception("premixed correlated-k tables cannot exclude molecules")
+        nlayer = atmosphere.c.nlayer
+        tlayer = np.asarray(atmosphere.layer["temperature"], dtype=float)
+        player = np.asarray(atmosphere.layer["pressure"], dtype=float) / atmosphere.c.pconv
+        t_inv, p_log = 1 / tlayer, np.log10(player)
+        p_log_grid = np.log10(self.pressures[self.pressures > 0])
+        t_inv_grid = 1 / self.temps
+        t_low = np.zeros(nlayer, dtype=int)
+        for i, v in enumerate(t_inv):                       # optics.py:1101-1113
+            find = np.where(t_inv_grid > v)[0]
+            t_low[i] = 0 if len(find) == 0 else find[-1]
+        t_low[t_low == (len(t_inv_grid) - 1)] = len(t_inv_grid) - 2
+        t_hi = t_low + 1
+        p_low = np.zeros(nlayer, dtype=int)
+        for i, v in enumerate(p_log):                       # optics.py:1124-1141
+            find = np.where(p_log_grid <= v)[0]
+            p_low[i] = 0 if len(find) == 0 else find[-1]
+            p_low[i] = min(p_low[i], self.nc_p[t_hi[i]] - 3)
+        p_hi = p_low + 1
+        t_i = (t_inv - t_inv_grid[t_low]) / (t_inv_grid[t_hi] - t_inv_grid[t_low])
+        p_i = (p_log - p_log_grid[p_low]) / (p_log_grid[p_hi] - p_log_grid[p_low])
+        nt = self.temps.size
+        # the reference's four terms in order (optics.py:1153-1156); row = ip * ntemp + it
+        rows = np.stack([p_low * nt + t_low, p_low * nt + t_hi, p_hi * nt + t_hi, p_hi * nt + t_low],
+                        axis=1).astype(np.int32)[None]
+        wts = np.stack([(1 - t_i) * (1 - p_i), t_i * (1 - p_i), t_i * p_i, (1 - t_i) * p_i], axis=1)[None]
+        # continuum: bracketing CIA temperatures and the 1/T weight (optics.py:1411-1428, 1474-1478)
+        st = self.cia_temps
+        cia_pairs = [k[0] + k[1] for k in atmosphere.continuum_molecules]
+        cia_rows = np.zeros((nlayer, 2), dtype=np.int32)
+        cia_wts = np.zeros((nlayer, 2))
+        if cia_pairs:
+            for i, t in enumerate(tlayer):
+                if t <= st[0]:
+                    lo = 0
+                elif t >= st[-1]:
+                    lo = len(st) - 2
+                else:
+                    lo = int(np.where(st - t <= 0)[0][-1])
+                ti = (1 / t - 1 / st[lo]) / (1 / st[lo + 1] - 1 / st[lo])
+                cia_rows[i] = (lo, lo + 1)
+                cia_wts[i] = (1 - ti, ti)
+        self._plan = dict(premixed=True, molecules=["premixed"], rows=rows, wts=wts, fac=np.ones(1),
+                          cia_pairs=cia_pairs, cia_rows=cia_rows, cia_wts=cia_wts, nlayer=nlayer)
+        self.continuum_opa = _LazyPlanes(self, "cia")
+        self.molecular_opa = None
+
+    get_opacities_preweighted = get_opacities
+
+    def get_molecular_opa(self):
+        """``molecular_opa`` (nlayer, nwno, ngauss) as the reference stores it (optics.py:1159)."""
+        pl = self._plan
+        nlayer = pl["nlayer"]
+        tg = DeviceArray((nlayer, self.nwno, self.ngauss), self.ctx)
+        tr = DeviceArray((nlayer, self.nwno), self.ctx)
+        _gas_call(self, nlayer, [self._kappa], pl["rows"], pl["wts"], np.ones((1, nlayer)), [], None,
+                  None, [], None, tg, tr, mol_mode=2, ngauss=self.ngauss)
+        return tg.to_host()
+
+    def _materialise(self, kind, key):
+        pl = self._plan
+        nlayer = pl["nlayer"]
+        tg = DeviceArray((nlayer, self.nwno), self.ctx)
+        tr = DeviceArray((nlayer, self.nwno), self.ctx)
+        _gas_call(self, nlayer, [], None, None, None, [self._cia[key]], pl["cia_rows"][None],
+                  np.ones((1, nlayer)), [], None, tg, tr, mol_mode=0, cont_wts=pl["cia_wts"][None], ngauss=1)
+        return tg.to_host()
+
+
 class _LazyPlanes(dict):
     """``molecular_opa`` / ``continuum_opa`` dictionaries whose planes are computed on first access."""
 
@@ -260,22 +377,28 @@ def _ptr_array(devs):
 
 
 def _gas_call(opa, nlayer, mol_tabs, mol_rows, mol_wts, mol_fac, cont_tabs, cont_rows, cont_fac,
-              ray_tabs, ray_fac, taugas, tauray):
+              ray_tabs, ray_fac, taugas, tauray, mol_mode=None, cont_wts=None, ngauss=1):
+    """``picaso_opacity_gas_ck_dev``: gather + interpolate table rows into TAUGAS / TAURAY.
+    ``mol_mode`` 0 nearest, 1 log10-bilinear (monochromatic 'linear'), 2 ln-bilinear (premixed CK);
+    ``cont_wts`` given -> log-linear continuum between two rows per layer (CK)."""
     ip = ctypes.POINTER(ctypes.c_int)
 
     def iarr(x):
         return None if x is None else np.ascontiguousarray(x, dtype=np.int32)
 
+    if mol_mode is None:
+        mol_mode = 1 if opa.query_method == "linear" else 0
     mr, cr = iarr(mol_rows), iarr(cont_rows)
     mw = f64(mol_wts) if mol_wts is not None else None
     mf = f64(mol_fac) if mol_fac is not None else None
+    cw = f64(cont_wts) if cont_wts is not None else None
     cf = f64(cont_fac) if cont_fac is not None else None
     rf = f64(ray_fac) if ray_fac is not None else None
-    check(load().picaso_opacity_gas_dev(
-        opa.ctx, _ci(nlayer), _ci(opa.nwno), _ci(1 if opa.query_method == "linear" else 0),
+    check(load().picaso_opacity_gas_ck_dev(
+        opa.ctx, _ci(nlayer), _ci(opa.nwno), _ci(ngauss), _ci(mol_mode),
         _ci(len(mol_tabs)), _ptr_array(mol_tabs), mr.ctypes.data_as(ip) if mr is not None else None,
-        ptr(mw), ptr(mf), _ci(len(cont_tabs)), _ptr_array(cont_tabs),
-        cr.ctypes.data_as(ip) if cr is not None else None, ptr(cf), _ci(len(ray_tabs)),
+        ptr(mw), ptr(mf), _ci(1 if cw is not None else 0), _ci(len(cont_tabs)), _ptr_array(cont_tabs),
+        cr.ctypes.data_as(ip) if cr is not None else None, ptr(cw), ptr(cf), _ci(len(ray_tabs)),
         _ptr_array(ray_tabs), ptr(rf), ptr(taugas.addr), ptr(tauray.addr)), opa.ctx)
 
 
@@ -315,7 +438,10 @@ def _layer_factors(atm, opacityclass):
                             (mmw * atm.c.amu))
         else:                                               # optics.py:224-227
             cont_fac.append(COEF1 * x(m[0]) * x(m[1]))
-    mol_fac = [pl["fac"][i] * (colden * x(m) / mmw) for i, m in enumerate(pl["molecules"])]   # :246-249
+    if pl.get("premixed"):                                # optics.py:256-262
+        mol_fac = [colden / mmw]
+    else:
+        mol_fac = [pl["fac"][i] * (colden * x(m) / mmw) for i, m in enumerate(pl["molecules"])]   # :246-249
     ray_names = [m for m in atm.rayleigh_molecules if m in opacityclass._ray]
     ray_fac = [colden * x(m) / mmw for m in ray_names]     # optics.py:265-271
     shape = (0, nlayer)
@@ -325,28 +451,39 @@ def _layer_factors(atm, opacityclass):
 
 
 def compute_opacity_resident(atmosphere, opacityclass, ngauss=1, stream=2, delta_eddington=True,
-                             test_mode=False, raman=0, fthin_cld=None, do_holes=False,
+                             test_mode=None, raman=0, fthin_cld=None, do_holes=False,
                              full_output=False):
-    """GPU ``compute_opacity`` returning a dict of the 13 planes as DeviceArrays (no ngauss axis)."""
-    if ngauss != 1:
-        raise Exception("picaso_amd.compute_opacity: only monochromatic opacities (ngauss=1) "
-                        "are built; correlated-k is the next scope row (SURVEY.md 8f)")
+    """GPU ``compute_opacity`` returning a dict of the 13 planes as DeviceArrays: ``(rows, nwno)``
+    for monochromatic opacities, ``(rows, nwno, ngauss)`` (reference layout, optics.py:423-431)
+    for correlated-k tables."""
     atm, opa = atmosphere, opacityclass
+    if ngauss != opa.ngauss:
+        raise Exception("compute_opacity: ngauss=%d but the opacity tables have %d Gauss points"
+                        % (ngauss, opa.ngauss))
     ctx = opa.ctx
     nlayer, nwno = atm.c.nlayer, opa.nwno
     if opa._plan is None or opa._plan["nlayer"] != nlayer:
         raise Exception("call opacityclass.get_opacities(atmosphere) first")
     pl = opa._plan
+    gshape = (nwno,) if ngauss == 1 else (nwno, ngauss)
     mol_fac, cont_fac, ray_names, ray_fac = _layer_factors(atm, opa)
-    taugas, tauray = DeviceArray((nlayer, nwno), ctx), DeviceArray((nlayer, nwno), ctx)
-    mol_tabs = [(opa._mol_log if opa.query_method == "linear" else opa._mol_raw)[m]
-                for m in pl["molecules"]]
+    taugas, tauray = DeviceArray((nlayer,) + gshape, ctx), DeviceArray((nlayer, nwno), ctx)
     cont_tabs = [opa._cia[p] for p in pl["cia_pairs"]]
-    cont_rows = np.repeat(pl["cia_rows"][None], len(cont_tabs), axis=0) if cont_tabs else None
+    if pl.get("premixed"):
+        mol_tabs, mol_mode = [opa._kappa], 2
+        cont_rows = np.repeat(pl["cia_rows"][None], len(cont_tabs), axis=0) if cont_tabs else None
+        cont_wts = np.repeat(pl["cia_wts"][None], len(cont_tabs), axis=0) if cont_tabs else None
+    else:
+        mol_tabs = [(opa._mol_log if opa.query_method == "linear" else opa._mol_raw)[m]
+                    for m in pl["molecules"]]
+        mol_mode = 1 if opa.query_method == "linear" else 0
+        cont_rows = np.repeat(pl["cia_rows"][None], len(cont_tabs), axis=0) if cont_tabs else None
+        cont_wts = None
     _gas_call(opa, nlayer, mol_tabs, pl["rows"] if mol_tabs else None,
               pl["wts"] if mol_tabs else None, mol_fac if mol_tabs else None, cont_tabs, cont_rows,
               cont_fac if cont_tabs else None, [opa._ray[m] for m in ray_names],
-              ray_fac if ray_names else None, taugas, tauray)
+              ray_fac if ray_names else None, taugas, tauray, mol_mode=mol_mode, cont_wts=cont_wts,
+              ngauss=ngauss)
     # ---- Raman factor (host: once per atmosphere, optics.py:285-306) ----
     raman_plane, raman_const = None, 0.99999
     if raman == 0:
@@ -365,21 +502,21 @@ def compute_opacity_resident(atmosphere, opacityclass, ngauss=1, stream=2, delta
     d_w0 = DeviceArray.from_host(np.zeros((nlayer, nwno)) + np.asarray(cld["w0"], dtype=float), ctx)
     d_g0 = DeviceArray.from_host(np.zeros((nlayer, nwno)) + np.asarray(cld["g0"], dtype=float), ctx)
     tm = 0
-    if test_mode not in (None, False):                      # optics.py:372 (`test_mode != None`)
-        tm = 1 if test_mode == "rayleigh" else 2
+    if test_mode is not None:      # optics.py:372 `test_mode != None`: anything but None, including the
+        tm = 1 if test_mode == "rayleigh" else 2            # signature default False, is a test mode
     out = {}
     for k in OUT_NAMES:
         rows = nlayer + 1 if k in ("tau", "tau_og") else nlayer
-        out[k] = DeviceArray((rows, nwno), ctx)
-    check(load().picaso_compute_opacity_dev(
-        ctx, _ci(nlayer), _ci(nwno), ptr(taugas.addr), ptr(tauray.addr), ptr(d_cld.addr),
+        out[k] = DeviceArray((rows,) + gshape, ctx)
+    check(load().picaso_compute_opacity_ck_dev(
+        ctx, _ci(nlayer), _ci(nwno), _ci(ngauss), ptr(taugas.addr), ptr(tauray.addr), ptr(d_cld.addr),
         ptr(d_w0.addr), ptr(d_g0.addr), ptr(raman_plane.addr) if raman_plane else None,
         _cd(raman_const), _ci(tm), _ci(1 if delta_eddington else 0), _ci(stream),
         *[ptr(out[k].addr) for k in OUT_NAMES]), ctx)
     if full_output:
-        atmosphere.taugas = taugas.to_host()[:, :, None]
-        atmosphere.tauray = tauray.to_host()[:, :, None]
-        atmosphere.taucld = taucld[:, :, None]
+        atmosphere.taugas = taugas.to_host().reshape((nlayer, nwno, ngauss))
+        atmosphere.tauray = np.repeat(tauray.to_host()[:, :, None], ngauss, axis=2)
+        atmosphere.taucld = np.repeat(taucld[:, :, None], ngauss, axis=2)
     return out
 
 
@@ -387,14 +524,16 @@ def compute_opacity(atmosphere, opacityclass, ngauss=1, stream=2, delta_eddingto
                     test_mode=False, raman=0, plot_opacity=False, full_output=False,
                     return_mode=False, fthin_cld=None, do_holes=False):
     """Reference signature and return tuple (optics.py:26-27, 423-431): 13 numpy arrays
-    ``(nlayer|nlevel, nwno, ngauss)``."""
+    ``(nlayer|nlevel, nwno, ngauss)``.  As in the reference, any ``test_mode`` other than ``None`` --
+    including the signature default ``False`` -- selects a Dlugach test mode (optics.py:372);
+    ``picaso()`` passes ``inputs['test_mode']``, which defaults to ``None``."""
     if plot_opacity or return_mode:
         raise Exception("plot_opacity / return_mode are plotting aids of the reference and are "
                         "not part of the accelerated path")
     d = compute_opacity_resident(atmosphere, opacityclass, ngauss=ngauss, stream=stream,
                                  delta_eddington=delta_eddington, test_mode=test_mode, raman=raman,
                                  fthin_cld=fthin_cld, do_holes=do_holes, full_output=full_output)
-    return tuple(d[k].to_host()[:, :, None] for k in OUT_NAMES)
+    return tuple(d[k].to_host().reshape(d[k].shape[:2] + (ngauss,)) for k in OUT_NAMES)
 
 
 # ------------------------------------------------------------------------------------------------

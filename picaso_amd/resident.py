@@ -121,3 +121,18 @@ def axpby(ctx, a, x, b, y, out):
     n = int(np.prod(x.shape))
     check(load().picaso_axpby_dev(ctx, ctypes.c_size_t(n), _cd(a), _addr(x), _cd(b), _addr(y),
                                   _addr(out)), ctx)
+
+
+def compress_disco(ctx, nwno, cos_theta, xint_at_top, gweight, tweight, F0PI, albedo):
+    """``disco.compress_disco`` on DeviceArrays (reference disco.py:117-149)."""
+    gw, tw = f64(gweight), f64(tweight)
+    check(load().picaso_compress_disco_dev(ctx, _ci(nwno), _cd(cos_theta), _addr(xint_at_top), ptr(gw),
+                                           _ci(gw.size), ptr(tw), _ci(tw.size), _addr(F0PI),
+                                           _addr(albedo)), ctx)
+
+
+def compress_thermal(ctx, ninner, flux_at_top, gweight, tweight, flux):
+    """``disco.compress_thermal`` on DeviceArrays (reference disco.py:151-181)."""
+    gw, tw = f64(gweight), f64(tweight)
+    check(load().picaso_compress_thermal_dev(ctx, ctypes.c_size_t(ninner), _addr(flux_at_top), ptr(gw),
+                                             _ci(gw.size), ptr(tw), _ci(tw.size), _addr(flux)), ctx)

@@ -392,6 +392,93 @@ def make_optics():
           "%.1f KB" % (os.path.getsize(db) / 1024))
 
 
+def make_ck():
+    """Premixed correlated-k path: a synthetic ln(kappa) table (ragged pressure grid per temperature,
+    4 Gauss points) driven through the reference's own RetrieveCKs.get_pre_mix_ck / get_continuum
+    (bound to a bare instance: the constructor only parses file formats that are not available
+    here) and compute_opacity(ngauss=4); continuum rows come from synthetic_opacities.db."""
+    import types
+    import pandas as pd
+    optics = ref_shim.load("optics")
+    db = os.path.join(HERE, "synthetic_opacities.db")
+    assert os.path.exists(db), "run `make_golden.py optics` first"
+    rng = np.random.default_rng(777)
+    og = np.load(os.path.join(HERE, "optics.npz"))
+    wno = og["in/wno"]
+    nwno = wno.size
+    ngauss = 4
+    gauss_wts = np.array([0.4, 0.3, 0.2, 0.1])
+    temps = np.array([100.0, 250.0, 600.0, 1200.0, 2600.0])
+    press = np.array([1e-6, 1e-4, 1e-2, 1.0, 30.0, 300.0])
+    nc_p = np.array([6, 6, 6, 5, 4])                      # hot temperatures lack the highest pressures
+    # the reference keeps one entry per (P,T) pair (optics.py:1556-1575 style lists)
+    pressures = np.concatenate([press[:n] for n in nc_p])
+    temps_flat = np.concatenate([[t] * n for t, n in zip(temps, nc_p)])
+    kappa = np.zeros((press.size, temps.size, nwno, ngauss))
+    for ip, p_ in enumerate(press):
+        for it, t_ in enumerate(temps):
+            base = (-26.0 + 2.0 * np.sin(wno / 2500.0) + 0.5 * np.log10(p_) + 0.9 * np.log10(t_ / 300.0))
+            for ig in range(ngauss):
+                kappa[ip, it, :, ig] = np.log(10.0) * (base + 0.9 * ig + 0.1 * rng.standard_normal(nwno))
+    cia_temps = np.array([75.0, 200.0, 500.0, 1000.0, 2000.0, 4000.0])
+
+    nlevel = 31
+    nlayer = nlevel - 1
+    plevel_bar = og["in/plevel_bar"]
+    tlevel = og["in/tlevel"].copy()
+    mixkeys = ("H2", "He", "H2O", "CH4")
+    mix = {k: og["in/mix/" + k] for k in mixkeys}
+    gravity = float(og["in/gravity"])
+    weights = {"H2": 2.01588, "He": 4.002602, "H2O": 18.01528, "CH4": 16.04246}
+
+    def make_atm():
+        atm = types.SimpleNamespace()
+        atm.c = types.SimpleNamespace(nlayer=nlayer, nlevel=nlevel, pconv=1e6, k_b=1.380649e-16,
+                                      amu=1.66053906660e-24, rgas=8.31446261815324)
+        atm.planet = types.SimpleNamespace(gravity=gravity)
+        p = plevel_bar * 1e6
+        atm.level = {"pressure": p, "temperature": tlevel}
+        lay_mix = pd.DataFrame({k: 0.5 * (v[1:] + v[:-1]) for k, v in mix.items()})
+        mmw_lvl = sum(mix[k] * weights[k] for k in mix)
+        atm.layer = {"pressure": np.sqrt(p[1:] * p[:-1]), "temperature": 0.5 * (tlevel[1:] + tlevel[:-1]),
+                     "mmw": 0.5 * (mmw_lvl[1:] + mmw_lvl[:-1]), "colden": (p[1:] - p[:-1]) / gravity,
+                     "electrons": np.zeros(nlayer), "mixingratios": lay_mix,
+                     "cloud": {"opd": og["in/cld_opd"].copy(), "w0": og["in/cld_w0"].copy(),
+                               "g0": og["in/cld_g0"].copy()}}
+        atm.molecules = np.array(["H2O", "CH4", "H2"])
+        atm.continuum_molecules = [["H2", "H2"], ["H2", "He"], ["H2", "CH4"]]
+        atm.rayleigh_molecules = ["H2", "He", "CH4", "H2O"]
+        return atm
+
+    opa = object.__new__(optics.RetrieveCKs)
+    opa.pressures, opa.temps, opa.nc_p, opa.kappa = pressures, temps_flat, nc_p, kappa
+    opa.continuum_db, opa.cia_temps = db, cia_temps
+    opa.wno, opa.nwno, opa.ngauss, opa.gauss_wts = wno, nwno, ngauss, gauss_wts
+    rayleigh = ref_shim.load("rayleigh")
+    ray = rayleigh.Rayleigh(wno)
+    opa.rayleigh_opa = {m: ray.compute_sigma(m) for m in ("H2", "He", "CH4", "H2O")}
+    atm = make_atm()
+    opa.get_pre_mix_ck(atm)
+    opa.get_continuum(atm)
+    store = {"in/press": press, "in/temps": temps, "in/nc_p": nc_p, "in/kappa": kappa,
+             "in/gauss_wts": gauss_wts, "in/cia_temps": cia_temps, "molecular_opa": opa.molecular_opa}
+    for pr in ("H2H2", "H2He", "H2CH4"):
+        store["continuum_opa/" + pr] = opa.continuum_opa[pr]
+    names = ("dtau", "tau", "w0", "cosb", "ftau_cld", "ftau_ray", "gcos2", "dtau_og", "tau_og",
+             "w0_og", "cosb_og", "w0_no_raman", "f_deltaM")
+    for de, stream in ((True, 2), (False, 2), (True, 4)):
+        atm = make_atm()
+        opa.get_pre_mix_ck(atm)
+        opa.get_continuum(atm)
+        out = optics.compute_opacity(atm, opa, ngauss=ngauss, stream=stream, delta_eddington=de, raman=2,
+                                     test_mode=None)
+        for nm, arr in zip(names, out):
+            store["de%d_s%d/%s" % (int(de), stream, nm)] = np.asarray(arr)
+    path = os.path.join(HERE, "ck.npz")
+    np.savez_compressed(path, **store)
+    print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024))
+
+
 def make_sh():
     """get_reflected_SH / get_thermal_SH (stream 2 and 4) on three of the 1-D scenes.  f_deltaM is
     handed over as a fresh copy each call (the reference compounds it in place per angle)."""
@@ -441,5 +528,7 @@ def make_sh():
 
 if __name__ == "__main__" and (("optics" in sys.argv[1:]) or not sys.argv[1:]):
     make_optics()
+if __name__ == "__main__" and (("ck" in sys.argv[1:]) or not sys.argv[1:]):
+    make_ck()
 if __name__ == "__main__" and (("sh" in sys.argv[1:]) or not sys.argv[1:]):
     make_sh()
