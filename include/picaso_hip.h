@@ -224,6 +224,21 @@ int picaso_compress_thermal_dev(picaso_ctx *ctx, size_t ninner, const double *fl
                                 const double *gweight, int ng, const double *tweight, int nt,
                                 double *flux);
 
+/* ---- transmission ------------------------------------------------------------------------- */
+/* replaces fluxes.get_transit_1d (reference picaso/fluxes.py:2581-2663): (Rp/Rs)^2 per wavelength
+ * from the chord-integrated slant optical depth (Brown 2001, eq. 11).  z, dz, player, tlayer are
+ * host arrays of length nlevel indexed exactly as the reference indexes them (its caller passes
+ * the level pressure / temperature, justdoit.py:390-394); mmw, colden host arrays of length
+ * nlevel-1; dtau (nlevel-1, nwno) = DTAU_OG.  Output rprs2 (nwno). */
+int picaso_get_transit_1d(picaso_ctx *ctx, const double *z, const double *dz, int nlevel, int nwno,
+                          double rstar, const double *mmw, double k_b, double amu, const double *player,
+                          const double *tlayer, const double *colden, const double *dtau, double *rprs2);
+/* device-resident dtau / rprs2 (row pitch `plane_pitch` elements) */
+int picaso_get_transit_1d_dev(picaso_ctx *ctx, const double *z, const double *dz, int nlevel, int nwno,
+                              long plane_pitch, double rstar, const double *mmw, double k_b, double amu,
+                              const double *player, const double *tlayer, const double *colden,
+                              const double *dtau, double *rprs2);
+
 /* ---- correlated-k Gauss-point batch and patchy-cloud blend -------------------------------- */
 /* The reference loops the solver over the `ngauss` correlated-k points of every wavelength bin and
  * accumulates `xint_at_top += xint * gauss_wts[ig]` (reference picaso/justdoit.py:256-307 reflected,

@@ -199,3 +199,13 @@ def get_thermal_SH(nlevel, wno, nwno, numg, numt, tlevel, dtau, tau, w0, cosb, d
                               ci(int(hard_surface)), _p(xint))
     _check(rc, "thermal_SH")
     return xint, np.zeros((numg, numt, stream * nlevel, nwno))
+
+
+def get_transit_1d(z, dz, nlevel, nwno, rstar, mmw, k_b, amu, player, tlayer, colden, DTAU):
+    """Signature of reference ``fluxes.get_transit_1d`` (fluxes.py:2582-2583)."""
+    out = np.zeros(nwno)
+    lib().orc_get_transit_1d(_p(_a(z)), _p(_a(dz)), ctypes.c_int(nlevel), ctypes.c_int(nwno),
+                             ctypes.c_double(rstar), _p(_a(mmw)), ctypes.c_double(k_b),
+                             ctypes.c_double(amu), _p(_a(player)), _p(_a(tlayer)), _p(_a(colden)),
+                             _p(_a(DTAU)), _p(out))
+    return out

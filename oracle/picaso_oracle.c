@@ -481,3 +481,42 @@ int orc_compress_thermal(size_t ninner, const double *flux_at_top, const double 
     }
     return 0;
 }
+
+/* get_transit_1d -- reference picaso/fluxes.py:2581-2663 (Brown 2001 eq. 11).  Loop structure and
+ * operation order of the reference: delta_length[i][j] (:2625-2644), TAU = DTAU/colden*mmw
+ * (:2648-2650), TAUALL accumulated in j order (:2653-2656), F (:2660-2661).  player/tlayer are
+ * indexed exactly as the reference indexes them (arrays of length >= nlevel-1). */
+int orc_get_transit_1d(const double *z, const double *dz, int nlevel, int nwno, double rstar,
+                       const double *mmw, double k_b, double amu, const double *player,
+                       const double *tlayer, const double *colden, const double *DTAU, double *F)
+{
+    const int n = nlevel, nl = nlevel - 1;
+    double *dlen = (double *)calloc((size_t)n * n, sizeof(double));
+    double *tau = (double *)malloc(sizeof(double) * nl);
+    if (!dlen || !tau) { free(dlen); free(tau); return 1; }
+    double seg = 0.0;
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < i; ++j) {
+            const double ref = z[i], inner = z[i - j], outer = z[i - j - 1];
+            if (inner != ref && outer != ref)
+                seg = sqrt(outer * outer - ref * ref) - sqrt(inner * inner - ref * ref);
+            else if (inner == ref)
+                seg = sqrt(outer * outer - ref * ref);
+            dlen[(size_t)i * n + j] = seg * player[i - j - 1] / tlayer[i - j - 1] / k_b;
+        }
+    double zmin = z[0];
+    for (int i = 1; i < n; ++i) zmin = z[i] < zmin ? z[i] : zmin;
+    for (int w = 0; w < nwno; ++w) {
+        for (int l = 0; l < nl; ++l) tau[l] = DTAU[(size_t)l * nwno + w] / colden[l] * (mmw[l] * amu);
+        double acc = 0.0;
+        for (int i = 0; i < n; ++i) {
+            double t = 0.0;
+            for (int j = 0; j < i; ++j) t = t + 2 * tau[i - j - 1] * dlen[(size_t)i * n + j];
+            acc = acc + (1.0 - exp(-t)) * (z[i] * dz[i]);
+        }
+        F[w] = (zmin / rstar) * (zmin / rstar) + 2. / (rstar * rstar) * acc;
+    }
+    free(dlen);
+    free(tau);
+    return 0;
+}

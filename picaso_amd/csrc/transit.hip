@@ -1,0 +1,124 @@
+// Transmission spectrum (Rp/Rs)^2 -- gfx950.
+// Replaces fluxes.get_transit_1d (reference picaso/fluxes.py:2581-2663; Brown 2001 eq. 11).
+//
+// Per wavelength: slant optical depth along the chord tangent at every level i,
+//     TAUALL_i = sum_{j<i} 2 TAU[i-j-1] delta_length[i][j],   TAU[l] = DTAU[l]/colden[l]*mmw[l],
+// then F = (min z / Rs)^2 + 2/Rs^2 sum_i (1 - exp(-TAUALL_i)) z_i dz_i.  The chord geometry
+// delta_length (nlevel x nlevel, wavelength independent; fluxes.py:2625-2644) is formed on the host
+// in the reference's arithmetic and read as wave-uniform scalars; the kernel is the O(nlevel^2)
+// per-wavelength part.  One lane per wavelength, 64 lanes per block: the block's slice of the scaled
+// optical-depth plane is staged once in LDS ([layer][lane], conflict free), so HBM sees each DTAU
+// element exactly once (algorithmic bytes 8 nwno (nlayer + 1)).
+#include "common.hpp"
+#include "device_math.hpp"
+
+namespace pz {
+
+struct TransitArgs {
+    int nlevel, nwno;
+    long pitch;
+    const double *dtau;        // (nlayer, nwno) device
+    const double *tab;         // device table: delta_length[nlevel*nlevel], zdz[nlevel], colden[nlayer], mmw_g[nlayer]
+    double zmin_term, two_over_rs2;
+    double *out;               // (nwno)
+};
+
+constexpr int TRANSIT_BLOCK = 64;
+
+__global__ __launch_bounds__(TRANSIT_BLOCK) void k_transit(const TransitArgs a)
+{
+    extern __shared__ double tau_lds[];                 // [nlayer][64]
+    const long w = blockIdx.x * (long)TRANSIT_BLOCK + threadIdx.x;
+    const int n = a.nlevel, nl = n - 1;
+    const double *dl = a.tab, *zdz = dl + (long)n * n, *colden = zdz + n, *mmw = colden + nl;
+    const bool live = w < a.nwno;
+    for (int l = 0; l < nl; ++l) {                      // TAU = DTAU / colden * mmw   (fluxes.py:2648-2650)
+        const double d = live ? a.dtau[(long)l * a.pitch + w] : 0.0;
+        tau_lds[l * TRANSIT_BLOCK + threadIdx.x] = d / colden[l] * mmw[l];
+    }
+    if (!live) return;
+    double acc = 0.0;
+    for (int i = 0; i < n; ++i) {
+        double t = 0.0;
+        const double *row = dl + (long)i * n;
+        for (int j = 0; j < i; ++j)                     // two because of the sphere's symmetry (:2655-2656)
+            t = t + (2.0 * tau_lds[(i - j - 1) * TRANSIT_BLOCK + threadIdx.x]) * row[j];
+        acc = acc + (1.0 - fexp(-t)) * zdz[i];          // (1 - transmitted) . (z dz)     (:2660-2661)
+    }
+    a.out[w] = a.zmin_term + a.two_over_rs2 * acc;
+}
+
+int launch_transit(picaso_ctx *ctx, const TransitArgs &a)
+{
+    const size_t lds = sizeof(double) * (size_t)(a.nlevel - 1) * TRANSIT_BLOCK;
+    if (lds > 160 * 1024) return fail(ctx, "get_transit_1d: %d levels exceed the LDS tile", a.nlevel);
+    const long grid = (a.nwno + TRANSIT_BLOCK - 1) / TRANSIT_BLOCK;
+    if (lds > 64 * 1024)
+        PZ_HIP(ctx, hipFuncSetAttribute((const void *)k_transit, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_transit, dim3((unsigned)grid), dim3(TRANSIT_BLOCK), lds, ctx->stream, a);
+    PZ_HIP(ctx, hipGetLastError());
+    return 0;
+}
+
+}  // namespace pz
+
+using namespace pz;
+
+extern "C" {
+
+int picaso_get_transit_1d_dev(picaso_ctx *ctx, const double *z, const double *dz, int nlevel, int nwno,
+                              long plane_pitch, double rstar, const double *mmw, double k_b, double amu,
+                              const double *player, const double *tlayer, const double *colden,
+                              const double *dtau, double *rprs2)
+{
+    if (!ctx) return fail(nullptr, "null context");
+    if (nlevel < 2 || nwno < 1) return fail(ctx, "get_transit_1d: bad sizes nlevel=%d nwno=%d", nlevel, nwno);
+    if (plane_pitch < nwno) return fail(ctx, "get_transit_1d: plane_pitch %ld < nwno %d", plane_pitch, nwno);
+    PZ_HIP(ctx, hipSetDevice(ctx->device));
+    const int n = nlevel, nl = nlevel - 1;
+    std::vector<double> tab((size_t)n * n + n + 2 * (size_t)nl, 0.0);
+    double *dlen = tab.data(), *zdz = dlen + (size_t)n * n, *cd = zdz + n, *mg = cd + nl;
+    // chord segments between shells (fluxes.py:2625-2644); `player`/`tlayer` are indexed exactly as
+    // the reference indexes them (its caller passes the LEVEL pressure/temperature, justdoit.py:391-393)
+    double seg = 0.0;
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < i; ++j) {
+            const double ref = z[i], inner = z[i - j], outer = z[i - j - 1];
+            if (inner != ref && outer != ref) seg = sqrt(outer * outer - ref * ref) - sqrt(inner * inner - ref * ref);
+            else if (inner == ref) seg = sqrt(outer * outer - ref * ref);
+            dlen[(size_t)i * n + j] = seg * player[i - j - 1] / tlayer[i - j - 1] / k_b;
+        }
+    double zmin = z[0];
+    for (int i = 0; i < n; ++i) { zdz[i] = z[i] * dz[i]; zmin = z[i] < zmin ? z[i] : zmin; }
+    for (int l = 0; l < nl; ++l) { cd[l] = colden[l]; mg[l] = mmw[l] * amu; }   // mmw in grams (:2623)
+    const void *d_tab = nullptr;
+    PZ_TRY(table_upload(ctx, tab.data(), sizeof(double) * tab.size(), &d_tab));
+    TransitArgs a{};
+    a.nlevel = nlevel; a.nwno = nwno; a.pitch = plane_pitch; a.dtau = dtau; a.tab = (const double *)d_tab;
+    a.zmin_term = (zmin / rstar) * (zmin / rstar);
+    a.two_over_rs2 = 2.0 / (rstar * rstar);
+    a.out = rprs2;
+    return launch_transit(ctx, a);
+}
+
+int picaso_get_transit_1d(picaso_ctx *ctx, const double *z, const double *dz, int nlevel, int nwno,
+                          double rstar, const double *mmw, double k_b, double amu, const double *player,
+                          const double *tlayer, const double *colden, const double *dtau, double *rprs2)
+{
+    if (!ctx) return fail(nullptr, "null context");
+    if (nlevel < 2 || nwno < 1) return fail(ctx, "get_transit_1d: bad sizes nlevel=%d nwno=%d", nlevel, nwno);
+    PZ_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t nl = (size_t)(nlevel - 1) * nwno;
+    PZ_TRY(arena_reset(ctx, sizeof(double) * (nl + (size_t)nwno) + 8 * 256));
+    const double *d_dtau;
+    PZ_TRY(arena_upload(ctx, dtau, nl, &d_dtau));
+    double *d_out = (double *)arena_take(ctx, sizeof(double) * (size_t)nwno);
+    if (!d_out) return fail(ctx, "arena exhausted");
+    PZ_TRY(picaso_get_transit_1d_dev(ctx, z, dz, nlevel, nwno, nwno, rstar, mmw, k_b, amu, player, tlayer, colden,
+                                     d_dtau, d_out));
+    PZ_HIP(ctx, hipMemcpyAsync(rprs2, d_out, sizeof(double) * (size_t)nwno, hipMemcpyDeviceToHost, ctx->stream));
+    PZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+}  // extern "C"

@@ -162,3 +162,18 @@ def get_thermal_SH(nlevel, wno, nwno, numg, numt, tlevel, dtau, tau, w0, cosb, d
         ptr(w0_), ptr(cbo), ptr(pl), ptr(u1), ptr(rs), _ci(int(stream)), _ci(int(hard_surface)),
         _ci(differs), _ci(int(flx)), ptr(xint)), ctx)
     return xint, np.zeros((numg, numt, stream * nlevel, nwno))
+
+
+def get_transit_1d(z, dz, nlevel, nwno, rstar, mmw, k_b, amu, player, tlayer, colden, DTAU):
+    """Transmission spectrum ``(Rp/Rs)**2`` (reference ``fluxes.get_transit_1d``, fluxes.py:2581-2663).
+    Same positional arguments; ``DTAU`` is ``(nlayer, nwno)``.  Returns ``(nwno,)``."""
+    ctx = context()
+    d = f64(DTAU)
+    if d.shape != (nlevel - 1, nwno):
+        raise Exception("get_transit_1d: DTAU of shape %s, expected %s" % (d.shape, (nlevel - 1, nwno)))
+    out = np.zeros(nwno)
+    check(load().picaso_get_transit_1d(
+        ctx, ptr(f64(z, (nlevel,))), ptr(f64(dz, (nlevel,))), _ci(nlevel), _ci(nwno), _cd(rstar),
+        ptr(f64(mmw, (nlevel - 1,))), _cd(k_b), _cd(amu), ptr(f64(player)), ptr(f64(tlayer)),
+        ptr(f64(colden, (nlevel - 1,))), ptr(d), ptr(out)), ctx)
+    return out

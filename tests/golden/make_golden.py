@@ -479,6 +479,40 @@ def make_ck():
     print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024))
 
 
+
+def make_transit():
+    """get_transit_1d of the reference on a hydrostatic isothermal-ish column (z decreasing from the
+    top), called as justdoit.py:390-394 calls it: LEVEL pressure / temperature in the player / tlayer
+    slots."""
+    fluxes = ref_shim.load("fluxes")
+    rng = np.random.default_rng(99)
+    store = {}
+    for name, nlevel, nwno in (("a", 31, 24), ("b", 61, 16), ("two", 3, 8)):
+        nl = nlevel - 1
+        k_b, amu, G = 1.380649e-16, 1.66053906660e-24, 6.67430e-8
+        plevel = np.logspace(-6, 1.5, nlevel) * 1e6
+        tlevel = 600.0 + 500.0 * np.linspace(0, 1, nlevel) ** 2
+        mmw = 2.3 + 0.2 * rng.random(nl)
+        radius, gravity = 7.0e9, 2500.0
+        # hydrostatic altitude above the deepest level, decreasing with index
+        H = k_b * 0.5 * (tlevel[1:] + tlevel[:-1]) / (mmw * amu * gravity)
+        dzl = H * np.log(plevel[1:] / plevel[:-1])
+        z = radius + np.concatenate([np.cumsum(dzl[::-1])[::-1], [0.0]])
+        dz = np.concatenate([dzl, [dzl[-1]]])
+        colden = (plevel[1:] - plevel[:-1]) / gravity
+        wl = np.linspace(0, 1, nwno)
+        dtau = (10 ** (-6 + 7 * np.linspace(0, 1, nl))[:, None]) * (1 + 5 * np.sin(6 * wl)[None, :] ** 2) \
+            * (1 + 0.1 * rng.random((nl, nwno)))
+        rstar = 6.96e10
+        F = fluxes.get_transit_1d(z, dz, nlevel, nwno, rstar, mmw, k_b, amu, plevel, tlevel, colden, dtau)
+        for k, v in dict(z=z, dz=dz, mmw=mmw, plevel=plevel, tlevel=tlevel, colden=colden, dtau=dtau,
+                         rstar=np.array(rstar), k_b=np.array(k_b), amu=np.array(amu), F=F).items():
+            store["%s/%s" % (name, k)] = v
+    path = os.path.join(HERE, "transit.npz")
+    np.savez_compressed(path, **store)
+    print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024))
+
+
 def make_sh():
     """get_reflected_SH / get_thermal_SH (stream 2 and 4) on three of the 1-D scenes.  f_deltaM is
     handed over as a fresh copy each call (the reference compounds it in place per angle)."""
@@ -530,5 +564,7 @@ if __name__ == "__main__" and (("optics" in sys.argv[1:]) or not sys.argv[1:]):
     make_optics()
 if __name__ == "__main__" and (("ck" in sys.argv[1:]) or not sys.argv[1:]):
     make_ck()
+if __name__ == "__main__" and (("transit" in sys.argv[1:]) or not sys.argv[1:]):
+    make_transit()
 if __name__ == "__main__" and (("sh" in sys.argv[1:]) or not sys.argv[1:]):
     make_sh()
