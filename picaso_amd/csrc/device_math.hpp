@@ -107,6 +107,15 @@ __device__ __forceinline__ double fexp2(double t, const Exp2Coef &K)
     return ldexp(fma(f, p, 1.0), (int)n);
 }
 
+// fexp2 for the rarely taken side of a wave-uniform choice (direct exponential instead of a running
+// product): the empty volatile asm keeps the compiler from if-converting the branch into a select
+// that evaluates the polynomial on every layer.
+__device__ __forceinline__ double fexp2_cold(double t, const Exp2Coef &K)
+{
+    asm volatile("" : "+v"(t));
+    return fexp2(t, K);
+}
+
 // 1/b to ~1 ulp: v_rcp_f64 (2^-23 relative) + two Newton steps, 5 instructions
 // (a correctly rounded a/b costs 11 with div_scale/div_fmas/div_fixup).
 __device__ __forceinline__ double frcp(double b)

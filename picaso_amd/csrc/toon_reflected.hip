@@ -82,9 +82,11 @@ struct ReflState {
 };
 
 struct LayerIn {
-    double dt, tau_n, w0, g, gcos2, fc, fr, dto, tauo, tauo_n, w0o, cbo;
-    bool cum_tau, cum_tauo;   // wave-uniform: tau[i+1] == tau[i] + dtau[i] (resp. tau_og) bit-exactly
-    bool same_dt;             // wave-uniform: dtau_og == dtau (no delta-scaling in this layer)
+    double dt, tau_n, w0, g, gcos2, fc, fr, dto, tauo, w0o, cbo;
+    // wave-uniform flags, set when the layer is consumed:
+    bool cum_tau;    // tau[i+1] == tau[i] + dtau[i] bit-exactly: exp(-tau[i+1]/u) = exp(-tau[i]/u) exp(-dtau/u)
+    bool eo_ok;      // tau_og[i] == tau_og[i-1] + dtau_og[i-1]: the carried product is exp(-tau_og[i]/u)
+    bool same_dt;    // dtau_og == dtau (no delta-scaling in this layer)
 };
 
 // One layer of the sweep.  FIRST / LAST are compile-time so the top row and the bottom-boundary
@@ -165,8 +167,9 @@ __device__ __forceinline__ void reflected_layer(const ReflectedArgs &a, const La
         const double hz = fma(A1, u0_k, iu0_k);
         const double am2 = A0 + hz, ap2 = A0 - hz;
         const double et = fexp2(dt * nl1_k, K);              // exp(-dtau/u1)
+        const double e0 = ZP ? et : fexp2(dt * nl0_k, K);    // exp(-dtau/u0)
         const double xu = S.get(S_XU, k), Tk = S.get(S_T, k);
-        const double xd = (ZP && L.cum_tau) ? xu * et : fexp2(L.tau_n * nl0_k, K);
+        const double xd = L.cum_tau ? xu * e0 : fexp2_cold(L.tau_n * nl0_k, K);
         const double fw = Fw0h * rden;
         const double fx = fw * xu, fxd = fw * xd;
         const double cmu = am2 * fx, cpu = ap2 * fx;       // c-/c+ at the top of the layer
@@ -181,22 +184,19 @@ __device__ __forceinline__ void reflected_layer(const ReflectedArgs &a, const La
         const double ee = fma(EP, et, -1.0), ff = fma(-EM, et, 1.0);
         double vp = (Trd * lp1) * ((X + Y) * ee);
         double vn = (Trd * lm1) * ((X - Y) * ff);
-        const double eo = S.get(S_EO, k);                  // exp(-tau_og[i]/u0)
-        double t1, t2;                                     // 1 - exp(-dtau_og*mus), 1 - exp(-dtau*mus)
-        if (ZP) {
-            t2 = fma(-et, et, 1.0);
-            double e1 = et;
-            t1 = t2;
-            if (!L.same_dt) {                              // delta-scaled layer: dtau_og != dtau
-                e1 = fexp2(L.dto * nl1_k, K);
-                t1 = fma(-e1, e1, 1.0);
-            }
-            if (!LAST) S.set(S_EO, k, L.cum_tauo ? eo * e1 : fexp2(L.tauo_n * nl0_k, K));
-        } else {
-            t1 = 1.0 - fexp2(L.dto * g[k].nlm, K);
-            t2 = 1.0 - fexp2(dt * g[k].nlm, K);
-            if (!LAST) S.set(S_EO, k, fexp2(L.tauo_n * nl0_k, K));
+        // exp(-tau_og[i]/u0): the running product of the layers above when tau_og really is the
+        // running sum of dtau_og, else formed directly
+        const double eo = (!FIRST && L.eo_ok) ? S.get(S_EO, k) : fexp2_cold(L.tauo * nl0_k, K);
+        // 1 - exp(-dtau (1/u0 + 1/u1)) and the same for dtau_og (fluxes.py:1395-1406) from the two
+        // single-angle exponentials; a layer that is not delta-scaled (dtau_og == dtau) shares them
+        const double t2 = fma(-e0, et, 1.0);
+        double t1 = t2, e0o = e0;
+        if (!L.same_dt) {
+            const double e1o = fexp2_cold(L.dto * nl1_k, K);
+            e0o = ZP ? e1o : fexp2_cold(L.dto * nl0_k, K);
+            t1 = fma(-e0o, e1o, 1.0);
         }
+        if (!LAST) S.set(S_EO, k, eo * e0o);
         // S0 = (ssa eo t1 + Aq t2) u0/(u0+u1) with Aq = 2 w2pi fx Aqq; wq2 = 2 u0/(u0+u1) (1 if ZP)
         const double s1 = (ssa_h * wq2_k) * (eo * t1);
         const double S0 = fma((w2pi * wq2_k) * fx, Aqq * t2, s1);
@@ -231,8 +231,13 @@ __device__ __forceinline__ void reflected_layer(const ReflectedArgs &a, const La
     S.pEM = EM;
 }
 
+// One or two angles per lane (the 3-D facet kernel, angle tails) need far fewer registers: ask for
+// more waves per SIMD there, the HBM-bound case lives on memory-level parallelism.
+#ifndef PZ_REFL_MINWAVES_FEW
+#define PZ_REFL_MINWAVES_FEW 2
+#endif
 template <int NA, bool IS3D, bool ZP>
-__global__ __launch_bounds__(256, PZ_REFL_MINWAVES) void k_reflected_toa(const ReflectedArgs a)
+__global__ __launch_bounds__(256, (NA <= 2 ? PZ_REFL_MINWAVES_FEW : PZ_REFL_MINWAVES)) void k_reflected_toa(const ReflectedArgs a)
 {
     const long col = blockIdx.x * (long)blockDim.x + threadIdx.x;
     if (col >= a.ncol) return;
@@ -280,75 +285,86 @@ __global__ __launch_bounds__(256, PZ_REFL_MINWAVES) void k_reflected_toa(const R
     S.lds = lds_state + threadIdx.x;
     S.rho = S.pgam = S.pEM = 0.0;
     double tau_i = p_tau[0];
-    {
-        const double tauo0 = p_tauo[0];
+    double tauo_pred = 0.0;          // tau_og[i-1] + dtau_og[i-1] of the layer above
 #pragma unroll
-        for (int k = 0; k < NA; ++k) {
-            S.set(S_T, k, 1.0);
-            S.set(S_KAPPA, k, 0.0);
-            S.set(S_ZETA, k, 0.0);
-            S.set(S_D1, k, 0.0);
-            S.set(S_D2, k, 0.0);
-            const double nl0_k = ZP ? g[k].nl1 : g[k].nl0;
-            S.set(S_XU, k, fexp2(tau_i * nl0_k, K));
-            S.set(S_EO, k, fexp2(tauo0 * nl0_k, K));
-        }
+    for (int k = 0; k < NA; ++k) {
+        S.set(S_T, k, 1.0);
+        S.set(S_KAPPA, k, 0.0);
+        S.set(S_ZETA, k, 0.0);
+        S.set(S_D1, k, 0.0);
+        S.set(S_D2, k, 0.0);
+        S.set(S_EO, k, 0.0);
+        S.set(S_XU, k, fexp2(tau_i * (ZP ? g[k].nl1 : g[k].nl0), K));
     }
 
-    // software prefetch: `nx` always holds the next layer's plane values
-    LayerIn nx;
-    nx.dt = p_dtau[0]; nx.tau_n = p_tau[pitch]; nx.w0 = p_w0[0]; nx.g = p_cosb[0];
-    nx.gcos2 = p_gcos2[0]; nx.fc = p_fc[0]; nx.fr = p_fr[0]; nx.dto = p_dto[0];
-    nx.tauo = p_tauo[0]; nx.w0o = p_w0o[0]; nx.cbo = p_cbo[0];
-
-    auto advance = [&](int i, LayerIn &cur) {
-        cur = nx;
-        if (i + 1 < n) {
-            const long o = (long)(i + 1) * pitch;
-#ifdef PZ_EXP_NOLOAD   // experiment: no plane traffic inside the loop (results are wrong)
-            asm volatile("" : "+v"(nx.dt), "+v"(nx.tau_n), "+v"(nx.w0), "+v"(nx.g), "+v"(nx.gcos2), "+v"(nx.fc));
-            asm volatile("" : "+v"(nx.fr), "+v"(nx.dto), "+v"(nx.tauo), "+v"(nx.w0o), "+v"(nx.cbo));
-            if (o < 0)
-#endif
-            {
-            nx.dt = p_dtau[o];
-            nx.tau_n = p_tau[o + pitch];
-            nx.w0 = p_w0[o];
-            nx.g = p_cosb[o];
-            nx.gcos2 = p_gcos2[o];
-            nx.fc = p_fc[o];
-            nx.fr = p_fr[o];
-            nx.dto = p_dto[o];
-            nx.tauo = p_tauo[o];
-            nx.w0o = p_w0o[o];
-            nx.cbo = p_cbo[o];
-            }
-        }
-        cur.tauo_n = nx.tauo;     // tau_og of the level below (unused in the last layer)
-        if (ZP) {
-            cur.cum_tau = __all(cur.tau_n == tau_i + cur.dt);
-            cur.cum_tauo = __all(cur.tauo_n == cur.tauo + cur.dto);
-            cur.same_dt = __all(cur.dto == cur.dt);
-        } else {
-            cur.cum_tau = cur.cum_tauo = cur.same_dt = false;
-        }
-        tau_i = cur.tau_n;
+    // Software prefetch with two register sets used alternately (loop unrolled by two): the eleven
+    // plane loads of layer i+1 are issued before layer i is computed and nothing has to be copied
+    // between the sets, so they stay in flight for a whole layer (a copy would force the wave to
+    // drain vmcnt at the end of every layer, which costs the HBM-bound facet kernel ~25 %).
+    auto load = [&](LayerIn &L, int i) {
+        const long o = (long)i * pitch;
+        L.dt = p_dtau[o];
+        L.tau_n = p_tau[o + pitch];
+        L.w0 = p_w0[o];
+        L.g = p_cosb[o];
+        L.gcos2 = p_gcos2[o];
+        L.fc = p_fc[o];
+        L.fr = p_fr[o];
+        L.dto = p_dto[o];
+        L.tauo = p_tauo[o];
+        L.w0o = p_w0o[o];
+        L.cbo = p_cbo[o];
     };
+    auto prep = [&](LayerIn &L) {
+        L.cum_tau = __all(L.tau_n == tau_i + L.dt);
+        L.eo_ok = __all(L.tauo == tauo_pred);
+        L.same_dt = __all(L.dto == L.dt);
+        tau_i = L.tau_n;
+        tauo_pred = L.tauo + L.dto;
+    };
+#define PZ_LAYER(FIRST_, LAST_, L_)                                                                      \
+    do {                                                                                                 \
+        prep(L_);                                                                                        \
+        reflected_layer<NA, IS3D, ZP, FIRST_, LAST_, LDS>(a, L_, S, g, K, F, clip, tc, b_top);           \
+    } while (0)
 
-    LayerIn cur;
+    // Few angles per lane (the HBM-bound 3-D facet kernel): two register sets.  Many angles: the
+    // kernel is at its register limit and FP64-bound, one prefetch set copied per layer is cheaper
+    // than the spills the second set would cause (measured: 0.98 ms vs 0.36 ms at five angles).
+    constexpr bool TWO_SETS = (NA <= 2);
+    LayerIn A, B;
+    load(A, 0);
     if (n == 1) {
-        advance(0, cur);
-        reflected_layer<NA, IS3D, ZP, true, true, LDS>(a, cur, S, g, K, F, clip, tc, b_top);
-    } else {
-        advance(0, cur);
-        reflected_layer<NA, IS3D, ZP, true, false, LDS>(a, cur, S, g, K, F, clip, tc, b_top);
-        for (int i = 1; i < n - 1; ++i) {
-            advance(i, cur);
-            reflected_layer<NA, IS3D, ZP, false, false, LDS>(a, cur, S, g, K, F, clip, tc, b_top);
+        PZ_LAYER(true, true, A);
+    } else if constexpr (TWO_SETS) {
+        load(B, 1);
+        PZ_LAYER(true, false, A);
+        int i = 1;                               // B holds layer i
+        for (; i + 2 <= n - 1; i += 2) {         // layers i and i+1 are interior, layer i+2 exists
+            load(A, i + 1);
+            PZ_LAYER(false, false, B);
+            load(B, i + 2);
+            PZ_LAYER(false, false, A);
         }
-        advance(n - 1, cur);
-        reflected_layer<NA, IS3D, ZP, false, true, LDS>(a, cur, S, g, K, F, clip, tc, b_top);
+        if (i == n - 1) {
+            PZ_LAYER(false, true, B);
+        } else {                                 // i == n - 2
+            load(A, i + 1);
+            PZ_LAYER(false, false, B);
+            PZ_LAYER(false, true, A);
+        }
+    } else {
+        load(B, 1);                              // B: prefetch set, A: the layer being computed
+        PZ_LAYER(true, false, A);
+        for (int i = 1; i < n - 1; ++i) {
+            A = B;
+            load(B, i + 1);
+            PZ_LAYER(false, false, A);
+        }
+        A = B;
+        PZ_LAYER(false, true, A);
     }
+#undef PZ_LAYER
 
     // ---- surface row (fluxes.py:178-183) and output ----
     // EP(1 - rs G) pos + EM(G - rs) neg = b_surface - c+dn + rs c-dn with neg = delta - rho pos,
