@@ -88,6 +88,16 @@ static std::vector<int> angle_chunks(int n)
     return out;
 }
 
+// Run each angle as its own wave (grid.y) instead of carrying them in one lane?  Worth it while all
+// angle-waves together still fit about one wave per SIMD (1024 SIMDs): measured on the reflected
+// kernel with 5 angles, 10 000 columns 0.093 ms vs 0.183 ms fused, 30 000 columns 0.217 vs 0.188 ms.
+static bool spread_angles(long ncol, int nang)
+{
+    long limit = 1280L * 64;                       // angle-columns
+    if (const char *e = getenv("PICASO_AMD_SPREAD_COLS")) limit = atol(e);
+    return nang > 1 && ncol * nang <= limit;
+}
+
 static int check_phase_options(picaso_ctx *ctx, int single_phase, int multi_phase, int toon)
 {
     // the reference raises UnboundLocalError for these; report cleanly instead
@@ -311,6 +321,24 @@ static int reflected_1d_core(picaso_ctx *ctx, int nlevel, int nwno, int ncolper,
         if (!get_toa_intensity) return 0;
     }
     int done = 0;
+    if (spread_angles(ncol, nang)) {
+        // Few columns: the chip is far from full and a lane's serial instruction stream sets the
+        // latency, so every angle runs as its own wave (grid.y) and the disk sum is a separate pass.
+        a.na = 1;
+        a.albedo = nullptr;
+        while (done < nang) {
+            const int m = (nang - done < MAX_ANGLES) ? nang - done : MAX_ANGLES;
+            for (int k = 0; k < m; ++k) a.ang[k] = make_refl_angle(ubar0[done + k], ubar1[done + k], 0.0);
+            a.ny = m;
+            a.xint = xint_at_top + (size_t)done * ncol;
+            PZ_TRY(launch_reflected_toa(ctx, a, false));
+            done += m;
+        }
+        if (fuse)
+            PZ_TRY(picaso_compress_disco_dev(ctx, nwno, cos_theta, xint_at_top, gweight, numg, tweight, numt, F0PI, albedo));
+        return 0;
+    }
+    a.ny = 1;
     const auto chunks = angle_chunks(nang);
     for (size_t c = 0; c < chunks.size(); ++c) {
         a.na = chunks[c];
@@ -586,6 +614,22 @@ static int thermal_1d_core(picaso_ctx *ctx, int nlevel, const double *wno, int n
         return 0;
     }
     int done = 0;
+    if (spread_angles(ncol, nang)) {             // see reflected_1d_core
+        a.na = 1;
+        a.disk = nullptr;
+        while (done < nang) {
+            const int m = (nang - done < MAX_ANGLES) ? nang - done : MAX_ANGLES;
+            for (int k = 0; k < m; ++k) { a.u1[k] = ubar1[done + k]; a.wgt[k] = 0.0; }
+            a.ny = m;
+            a.flux = flux_at_top + (size_t)done * ncol;
+            PZ_TRY(launch_thermal_toa(ctx, a, false));
+            done += m;
+        }
+        if (fuse)
+            PZ_TRY(picaso_compress_thermal_dev(ctx, (size_t)nwno, flux_at_top, gweight, numg, tweight, numt, flux_disk));
+        return 0;
+    }
+    a.ny = 1;
     const auto chunks = angle_chunks(nang);
     for (size_t c = 0; c < chunks.size(); ++c) {
         a.na = chunks[c];

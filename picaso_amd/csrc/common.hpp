@@ -91,7 +91,8 @@ struct ReflectedArgs {
     // Per-angle constants are derived on the host so they arrive as wave-uniform SGPR values (fp64
     // has no scalar ALU: computing 1/u in the kernel parks uniform values in VGPRs), and are kept
     // together per angle so that one s_load_dwordx16 fetches everything an angle block needs.
-    int na;
+    int na;            // angles carried per lane (template NA of the launch)
+    int ny;            // grid.y: angle groups of `na` running as separate waves (small problems)
     struct Angle {
         double u1, iu0, iu0sq, nl1, q2;     // used by the symmetric-geometry (ubar0 == ubar1) kernel
         double u0, nl0, nlm, wq2, wgt;
@@ -123,7 +124,7 @@ struct ThermalArgs {
     const double *dtau, *w0, *cosb;
     const double *surf_reflect;
     int hard_surface, calc_type;
-    int na;
+    int na, ny;                             // angles per lane, angle groups in grid.y (see ReflectedArgs)
     double u1[MAX_ANGLES], wgt[MAX_ANGLES];
     const double *u1_tab;                   // 3-D
     double *flux;                           // (na,nwno) / (nfac,nwno)

@@ -269,7 +269,7 @@ __global__ __launch_bounds__(256, (NA <= 2 ? PZ_REFL_MINWAVES_FEW : PZ_REFL_MINW
             g[k].q2 = (3.0 * ubar2 * ubar2 * v1 * v1 - 1.0) / 2.0;
             g[k].wgt = 0.0;
         } else {                                        // host-precomputed, wave-uniform
-            g[k] = a.ang[k];
+            g[k] = a.ang[blockIdx.y * NA + k];          // blockIdx.y: angle group (0 unless ny > 1)
         }
     }
     const double F = a.F0PI[w], rs = a.surf_reflect[w];
@@ -378,7 +378,7 @@ __global__ __launch_bounds__(256, (NA <= 2 ? PZ_REFL_MINWAVES_FEW : PZ_REFL_MINW
         const double pos = S.pEM * (b_surface - S.get(S_D1, k) + rs * S.get(S_D2, k)) * bden;
         const double x = S.get(S_KAPPA, k) + S.get(S_ZETA, k) * pos;
         if (IS3D) a.xint[(long)fac * a.nwno + w] = x;
-        else a.xint[(long)k * a.ncol + col] = x;
+        else a.xint[(long)(blockIdx.y * NA + k) * a.ncol + col] = x;
         alb = alb + x * g[k].wgt;
     }
     if (!IS3D && a.albedo) {                              // fused disco.compress_disco (disco.py:145-148)
@@ -392,15 +392,13 @@ template <int NA>
 static int launch1d(picaso_ctx *ctx, const ReflectedArgs &a)
 {
     const int block = 256;
-    const long grid = (a.ncol + block - 1) / block;
+    const dim3 grid((unsigned)((a.ncol + block - 1) / block), (unsigned)(a.ny > 1 ? a.ny : 1));
     bool zp = true;
-    for (int k = 0; k < a.na; ++k) zp = zp && (a.ang[k].u0 == a.ang[k].u1);
+    for (int k = 0; k < a.na * (int)grid.y; ++k) zp = zp && (a.ang[k].u0 == a.ang[k].u1);
     if (zp)
-        hipLaunchKernelGGL((k_reflected_toa<NA, false, true>), dim3((unsigned)grid), dim3(block), 0,
-                           ctx->stream, a);
+        hipLaunchKernelGGL((k_reflected_toa<NA, false, true>), grid, dim3(block), 0, ctx->stream, a);
     else
-        hipLaunchKernelGGL((k_reflected_toa<NA, false, false>), dim3((unsigned)grid), dim3(block), 0,
-                           ctx->stream, a);
+        hipLaunchKernelGGL((k_reflected_toa<NA, false, false>), grid, dim3(block), 0, ctx->stream, a);
     PZ_HIP(ctx, hipGetLastError());
     return 0;
 }

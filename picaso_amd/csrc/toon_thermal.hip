@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256) void k_thermal_toa(const ThermalArgs a)
     double u1[NA], iu1[NA];
 #pragma unroll
     for (int k = 0; k < NA; ++k) {
-        u1[k] = IS3D ? a.u1_tab[fac] : a.u1[k];               // 3-D thermal takes ubar1 as is
+        u1[k] = IS3D ? a.u1_tab[fac] : a.u1[blockIdx.y * NA + k];   // 3-D thermal takes ubar1 as is
         iu1[k] = 1.0 / u1[k];
     }
     const double *p_dtau = a.dtau + col, *p_w0 = a.w0 + col, *p_cosb = a.cosb + col;
@@ -175,8 +175,8 @@ __global__ __launch_bounds__(256) void k_thermal_toa(const ThermalArgs a)
     for (int k = 0; k < NA; ++k) {
         const double x = kappa[k] + zeta[k] * pos;
         if (IS3D) a.flux[(long)fac * a.nwno + w] = x;
-        else a.flux[(long)k * a.ncol + col] = x;
-        disk = disk + x * a.wgt[k];
+        else a.flux[(long)(blockIdx.y * NA + k) * a.ncol + col] = x;
+        disk = disk + x * a.wgt[IS3D ? 0 : blockIdx.y * NA + k];
     }
     if (!IS3D && a.disk) {                                     // fused disco.compress_thermal
         double acc = a.disk_first ? disk : a.disk[w] + disk;
@@ -189,9 +189,8 @@ template <int NA>
 static int launch1d(picaso_ctx *ctx, const ThermalArgs &a)
 {
     const int block = 256;
-    const long grid = (a.ncol + block - 1) / block;
-    hipLaunchKernelGGL((k_thermal_toa<NA, false>), dim3((unsigned)grid), dim3(block), 0,
-                       ctx->stream, a);
+    const dim3 grid((unsigned)((a.ncol + block - 1) / block), (unsigned)(a.ny > 1 ? a.ny : 1));
+    hipLaunchKernelGGL((k_thermal_toa<NA, false>), grid, dim3(block), 0, ctx->stream, a);
     PZ_HIP(ctx, hipGetLastError());
     return 0;
 }
