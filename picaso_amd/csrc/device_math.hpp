@@ -211,6 +211,10 @@ __device__ __forceinline__ double p_single(int single_phase, double cosb_og, dou
     return ftau_cld * tthg + ftau_ray * (0.75 * (1.0 + ct * ct));
 }
 
+constexpr double LOG2E_D = 1.4426950408889634074;
+// exp(x) through the base-2 polynomial with resident coefficients
+__device__ __forceinline__ double fexpk(double x, const Exp2Coef &K) { return fexp2(x * LOG2E_D, K); }
+
 // Planck function per unit wavelength, cgs, at wavelength 1/wno (reference fluxes.py:1660-1680).
 __device__ __forceinline__ double planck_lambda(double t, double wno)
 {
@@ -218,6 +222,13 @@ __device__ __forceinline__ double planck_lambda(double t, double wno)
     const double wcm = 1.0 / wno;
     const double w2 = wcm * wcm;
     return ((2.0 * h * (c * c)) / (w2 * w2 * wcm)) * frcp(fexp((h * c) / (t * (wcm * k))) - 1.0);
+}
+__device__ __forceinline__ double planck_lambda(double t, double wno, const Exp2Coef &K)
+{
+    const double h = 6.62607004e-27, c = 2.99792458e+10, k = 1.38064852e-16;
+    const double wcm = 1.0 / wno;
+    const double w2 = wcm * wcm;
+    return ((2.0 * h * (c * c)) / (w2 * w2 * wcm)) * frcp(fexpk((h * c) / (t * (wcm * k)), K) - 1.0);
 }
 
 // 3-point bin mean of the wavenumber Planck function (reference fluxes.py:1608-1658, nbb = 1).

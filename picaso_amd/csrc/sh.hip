@@ -49,10 +49,8 @@ struct SHArgs {
 };
 
 __device__ __forceinline__ double clip35(double x) { return fmin(fmax(x, -35.0), 35.0); }   // slice_rav
-constexpr double LOG2E = 1.4426950408889634074;
+constexpr double LOG2E = LOG2E_D;
 constexpr double EXP_M35 = 6.305116760146989e-16;        // exp(-35)
-// exp(x) through the base-2 polynomial (device_math.hpp)
-__device__ __forceinline__ double fexpk(double x, const Exp2Coef &K) { return fexp2(x * LOG2E, K); }
 // exp(-clip35(y/u)) for y >= 0 given t = y * (-log2(e)/u): only the lower clip can bind
 __device__ __forceinline__ double fexp2_clip(double t, const Exp2Coef &K) { return fexp2(fmax(t, -35.0 * LOG2E), K); }
 
@@ -228,7 +226,7 @@ __global__ __launch_bounds__(256, PZ_SH_MINWAVES) void k_sh(const SHArgs a)
 
     // thermal: Planck at the levels (fluxes.py:3058-3060)
     const double wn = THERMAL ? a.wno[w] : 0.0;
-    double Bn = THERMAL ? planck_lambda(a.tlevel[0], wn) : 0.0;
+    double Bn = THERMAL ? planck_lambda(a.tlevel[0], wn, K) : 0.0;
     const double B_top = Bn;
     double b1_last = 0.0;
 
@@ -376,7 +374,7 @@ __global__ __launch_bounds__(256, PZ_SH_MINWAVES) void k_sh(const SHArgs a)
             }
         } else {                                                             // :3451-3459 / :3266-3270
             B0 = Bn;
-            Bn = planck_lambda(a.tlevel[i + 1], wn);
+            Bn = planck_lambda(a.tlevel[i + 1], wn, K);
             b1 = (Bn - B0) * frcp(dt);
             b1_last = b1;
             const double oma = (1 - w0) * frcp(al[0]), b1a = b1 * frcp(al[1]);

@@ -35,17 +35,19 @@ __global__ __launch_bounds__(256) void k_thermal_toa(const ThermalArgs a)
     const long lstride = IS3D ? nfac : 1;                     // tlevel_3d is (nlevel, ng, nt)
     const double *tl = a.tlevel + fac, *pl = a.plevel + fac;
 
-    double u1[NA], iu1[NA];
+    Exp2Coef K;
+    K.load();
+    double u1[NA], nl1[NA];                                    // nl1 = -log2(e)/u1: exp(-x/u1) = 2^(x nl1)
 #pragma unroll
     for (int k = 0; k < NA; ++k) {
         u1[k] = IS3D ? a.u1_tab[fac] : a.u1[blockIdx.y * NA + k];   // 3-D thermal takes ubar1 as is
-        iu1[k] = 1.0 / u1[k];
+        nl1[k] = NEG_LOG2E / u1[k];
     }
     const double *p_dtau = a.dtau + col, *p_w0 = a.w0 + col, *p_cosb = a.cosb + col;
 
     auto planck = [&](int l) {
         const double t = tl[(long)l * lstride];
-        return integrated ? planck_integrated(t, wn, dwn) : planck_lambda(t, wn);
+        return integrated ? planck_integrated(t, wn, dwn) : planck_lambda(t, wn, K);
     };
 
     double W[NA], kappa[NA], zeta[NA];
@@ -78,7 +80,7 @@ __global__ __launch_bounds__(256) void k_thermal_toa(const ThermalArgs a)
         const double q = PI * b1 * s;
         const double cmu = 2 * PI * mu1 * (B0 - b1 * s);
         const double E = fmin(lam * dt, 35.0);                 // fluxes.py:1784-1786
-        const double EP = fexp(E), EM = frcp(EP);
+        const double EP = fexpk(E, K), EM = frcp(EP);
         const double al1 = 2 * PI * (B0 + b1 * (s - mu1));     // fluxes.py:1846-1847
         const double al2 = 2 * PI * b1;
         const double gcoef = (1.0 / mu1 - lam);                // G = gcoef*pos   fluxes.py:1842
@@ -87,8 +89,8 @@ __global__ __launch_bounds__(256) void k_thermal_toa(const ThermalArgs a)
         double rho_n = gam, delta_n = 0.0, sfac = 0.0, t = 0.0;
         if (i == 0) {
             tau_top = dt * pl[0] / (pl[lstride] - pl[0]);      // fluxes.py:1797
-            const double b_top = IS3D ? PI * (1.0 - fexp(-tau_top / mu1)) * B_top   // :2253
-                                      : (1.0 - fexp(-tau_top / mu1)) * B_top * PI;  // :1800
+            const double b_top = IS3D ? PI * (1.0 - fexpk(-tau_top / mu1, K)) * B_top   // :2253
+                                      : (1.0 - fexpk(-tau_top / mu1, K)) * B_top * PI;  // :1800
             delta_n = b_top - cmu;
         } else {
             const double em2 = pEM * pEM;
@@ -109,7 +111,7 @@ __global__ __launch_bounds__(256) void k_thermal_toa(const ThermalArgs a)
         const bool last = (i == n - 1);
         double EPm = 0.0, EMm = 0.0;
         if (i == 0) {
-            EPm = fexp(0.5 * E);                               // fluxes.py:1856-1857
+            EPm = fexpk(0.5 * E, K);                           // fluxes.py:1856-1857
             EMm = frcp(EPm);
         }
 #pragma unroll
@@ -121,7 +123,7 @@ __global__ __launch_bounds__(256) void k_thermal_toa(const ThermalArgs a)
             const double r2 = frcp(lm1 * lp1);
             const double lp = gcoef * (r2 * lp1), lm = hcoef * (r2 * lm1);
             if (i == 0) {
-                const double em = fexp(-0.5 * dt * iu1[k]);    // fluxes.py:1878
+                const double em = fexp2(0.5 * dt * nl1[k], K); // fluxes.py:1878
                 const double vp = lp * (EP * em - EPm);        // fluxes.py:1903-1907
                 const double vn = -lm * (EM * em - EMm);
                 const double c0 = al1 * (1. - em) + al2 * (mu + 0.5 * dt - (dt + mu) * em);
@@ -129,7 +131,7 @@ __global__ __launch_bounds__(256) void k_thermal_toa(const ThermalArgs a)
                 zeta[k] = vp - vn * rho_n;
                 W[k] = em;
             } else {
-                const double e = fexp(-dt * iu1[k]);           // fluxes.py:1877
+                const double e = fexp2(dt * nl1[k], K);        // fluxes.py:1877
                 const double vp = W[k] * lp * (EP * e - 1.0);  // fluxes.py:1897-1901
                 const double vn = W[k] * lm * (1.0 - EM * e);
                 const double c0 = W[k] * (al1 * (1. - e) + al2 * (mu - (dt + mu) * e));
