@@ -234,3 +234,55 @@ def test_sh_vs_oracle_fresh_scene(hip, oracle):
     assert rel_err(xg, xo) < TOL
     xg2, _ = hip.fluxes.get_reflected_SH(*common, sc["f_deltaM"].copy(), *tail, compound_f_deltaM=False)
     assert rel_err(xg2[0], xo[0]) < TOL and rel_err(xg2[-1], xo[-1]) > 1e-6   # only angle 0 coincides
+
+
+def test_edge_sizes_and_many_angles(hip, oracle):
+    """One wavelength x one layer; 3 x 4 = 12 angles in 1-D (angle chunking 4+4+4, numt > 1 disk
+    weights); 20 angles on a single column."""
+    from picaso_amd import synthetic as syn
+    rng = np.random.default_rng(3)
+    for nlayer, nwno, ng, nt in ((1, 1, 5, 1), (7, 3, 3, 4), (12, 1, 20, 1), (90, 70, 8, 8)):
+        sc = syn.make_scene(nlayer, nwno, seed=100 + nlayer)
+        u0 = rng.uniform(0.05, 1.0, (ng, nt))
+        u1 = rng.uniform(0.05, 1.0, (ng, nt))
+        planes = [sc[k] for k in PLANES]
+        args = (nlayer + 1, sc["wno"], nwno, ng, nt, *planes, 0.3, u0, u1, 0.4, np.ones(nwno), 3, 0, 1.0,
+                -1.0, 2.0, -0.5, 1.0)
+        xg, _ = hip.fluxes.get_reflected_1d(*args)
+        xo, _ = oracle.get_reflected_1d(*args)
+        assert xg.shape == (ng, nt, nwno)
+        assert rel_err(xg, xo) < TOL, (nlayer, nwno, ng, nt)
+        targs = (nlayer + 1, sc["wno"], nwno, ng, nt, sc["tlevel"], sc["dtau_og"], sc["w0_no_raman"],
+                 sc["cosb_og"], sc["plevel"], u1, np.zeros(nwno), 0, sc["wno"] * 0, 0)
+        fg, _ = hip.fluxes.get_thermal_1d(*targs, want_lvl=False)
+        fo, _ = oracle.get_thermal_1d(*targs)
+        assert rel_err(fg, fo) < TOL, (nlayer, nwno, ng, nt)
+
+
+def test_extreme_optical_depths_and_nan_isolation(hip, oracle):
+    """Layers from dtau = 1e-12 to 1e3 in one column set (exponent clips at 35, underflowing direct
+    beam), and a NaN planted in one column: it must come out as NaN in that column only (the
+    reference propagates NaN silently)."""
+    from picaso_amd import synthetic as syn
+    nlayer, nwno = 40, 130
+    sc = syn.make_scene(nlayer, nwno, seed=55)
+    scale = 10.0 ** np.linspace(-9, 3.5, nlayer)[:, None]
+    comps = [sc["taugas"] * scale, sc["tauray"] * scale, sc["taucld"], sc["w0_cld"], sc["g0_cld"]]
+    P = syn.mix_planes(*comps)
+    gang, gw, tang, tw = hip.disco.get_angles_1d(5)
+    u0, u1, ct, _, _ = hip.disco.compute_disco(5, 1, gang, tang, 0.0)
+    planes = [P[k] for k in PLANES]
+    args = (nlayer + 1, sc["wno"], nwno, 5, 1, *planes, 0.0, u0, u1, 1.0, np.ones(nwno), 3, 0, 1.0, -1.0,
+            2.0, -0.5, 1.0)
+    xg, _ = hip.fluxes.get_reflected_1d(*args)
+    xo, _ = oracle.get_reflected_1d(*args)
+    assert np.all(np.isfinite(xg))
+    assert rel_err(xg, xo) < TOL
+    bad = [p.copy() for p in planes]
+    bad[2][17, 64] = np.nan                                  # w0 of one (layer, wavelength)
+    args_bad = (nlayer + 1, sc["wno"], nwno, 5, 1, *bad, 0.0, u0, u1, 1.0, np.ones(nwno), 3, 0, 1.0, -1.0,
+                2.0, -0.5, 1.0)
+    xb, _ = hip.fluxes.get_reflected_1d(*args_bad)
+    assert np.all(np.isnan(xb[:, :, 64]))
+    keep = np.arange(nwno) != 64
+    assert np.array_equal(xb[:, :, keep], xg[:, :, keep])
