@@ -246,7 +246,9 @@ int picaso_get_transit_1d_dev(picaso_ctx *ctx, const double *z, const double *dz
  * compute_opacity returns (optics.py:423-431).  These entry points take those arrays as they are
  * (Gauss index fastest), solve all nwno*ngauss columns in one launch and return the Gauss-weighted
  * (numg,numt,nwno) intensities; `gauss_wts` is a host array of length ngauss (<= 32).  Optional
- * fused disk quadrature as in the _dev forms above.  Level fluxes: call the ngauss = 1 forms. */
+ * fused disk quadrature as in the _dev forms above.  The four level-flux outputs
+ * (numg,numt,nlevel,nwno) are Gauss-weighted the same way (justdoit.py:309-313, 372-376: the climate
+ * caller's inputs) and are written when get_lvl_flux = 1 / when non-NULL. */
 int picaso_get_reflected_1d_ck_dev(picaso_ctx *ctx, int nlevel, int nwno, int ngauss, int numg, int numt,
                                    const double *dtau, const double *tau, const double *w0,
                                    const double *cosb, const double *gcos2, const double *ftau_cld,
@@ -256,16 +258,19 @@ int picaso_get_reflected_1d_ck_dev(picaso_ctx *ctx, int nlevel, int nwno, int ng
                                    const double *ubar1, double cos_theta, const double *F0PI,
                                    int single_phase, int multi_phase, double frac_a, double frac_b,
                                    double frac_c, double constant_back, double constant_forward,
-                                   int toon_coefficients, double b_top, const double *gauss_wts,
-                                   double *xint_at_top, const double *gweight, const double *tweight,
-                                   double *albedo);
+                                   int get_toa_intensity, int get_lvl_flux, int toon_coefficients,
+                                   double b_top, const double *gauss_wts, double *xint_at_top,
+                                   double *flux_minus_all, double *flux_plus_all,
+                                   double *flux_minus_midpt_all, double *flux_plus_midpt_all,
+                                   const double *gweight, const double *tweight, double *albedo);
 int picaso_get_thermal_1d_ck_dev(picaso_ctx *ctx, int nlevel, const double *wno, int nwno, int ngauss,
                                  int numg, int numt, const double *tlevel, const double *dtau,
                                  const double *w0, const double *cosb, const double *plevel,
                                  const double *ubar1, const double *surf_reflect, int hard_surface,
                                  const double *dwno, int calc_type, const double *gauss_wts,
-                                 double *flux_at_top, const double *gweight, const double *tweight,
-                                 double *flux_disk);
+                                 double *flux_at_top, double *flux_minus, double *flux_plus,
+                                 double *flux_minus_mdpt, double *flux_plus_mdpt, const double *gweight,
+                                 const double *tweight, double *flux_disk);
 /* out = a*x + b*y on device arrays: the patchy-cloud blend (1-fhole)*cloudy + fhole*clear
  * (reference picaso/justdoit.py:300-305, 356-361) */
 int picaso_axpby_dev(picaso_ctx *ctx, size_t n, double a, const double *x, double b, const double *y,

@@ -163,6 +163,7 @@ void picaso_ctx_destroy(picaso_ctx *ctx)
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->arena) (void)hipFree(ctx->arena);
     if (ctx->lvl_scratch) (void)hipFree(ctx->lvl_scratch);
+    if (ctx->ck_scratch) (void)hipFree(ctx->ck_scratch);
     if (ctx->ring_d) (void)hipFree(ctx->ring_d);
     if (ctx->ring_h) (void)hipHostFree(ctx->ring_h);
     for (int i = 0; i < picaso_ctx::NSLOT; ++i)
@@ -272,8 +273,8 @@ static int reflected_1d_core(picaso_ctx *ctx, int nlevel, int nwno, int ncolper,
         return fail(ctx, "get_reflected_1d: bad sizes nlevel=%d nwno=%d numg=%d numt=%d", nlevel, nwno, numg, numt);
     const long ncol = (long)nwno * ncolper;
     if (plane_pitch < ncol) return fail(ctx, "get_reflected_1d: plane_pitch %ld < %ld columns", plane_pitch, ncol);
-    if (ncolper > 1 && (get_lvl_flux || albedo))
-        return fail(ctx, "get_reflected_1d: level fluxes / fused disk sum are per-wavelength outputs (ngauss = 1)");
+    if (ncolper > 1 && albedo)
+        return fail(ctx, "get_reflected_1d: the fused disk sum is a per-wavelength output (ngauss = 1)");
     PZ_TRY(check_phase_options(ctx, single_phase, multi_phase, toon_coefficients));
     PZ_HIP(ctx, hipSetDevice(ctx->device));
     const int nang = numg * numt;
@@ -303,14 +304,14 @@ static int reflected_1d_core(picaso_ctx *ctx, int nlevel, int nwno, int ncolper,
     a.albedo = fuse ? albedo : nullptr;
     a.albedo_scale = ((numt == 1) ? 2.0 * 3.14159265358979323846 : 1.0) * 0.5;   // disco.py:140-141
     if (get_lvl_flux) {   // two-sweep kernel, one angle per launch (fluxes.py:1219-1257)
-        const size_t plane = (size_t)(nlevel - 1) * nwno;
+        const size_t plane = (size_t)(nlevel - 1) * ncol;
         PZ_TRY(lvl_scratch_reserve(ctx, sizeof(double) * 4 * plane));
         ReflectedLvlArgs la{};
         la.base = a;
         la.base.na = 1;
         la.base.albedo = nullptr;
         la.scratch = ctx->lvl_scratch;
-        const size_t lv = (size_t)nlevel * nwno;
+        const size_t lv = (size_t)nlevel * ncol;
         for (int idx = 0; idx < nang; ++idx) {
             const double v0 = ubar0[idx], v1 = ubar1[idx];
             la.base.ang[0] = make_refl_angle(v0, v1, 0.0);
@@ -388,24 +389,37 @@ int picaso_get_reflected_1d_ck_dev(picaso_ctx *ctx, int nlevel, int nwno, int ng
                                    const double *ubar1, double cos_theta, const double *F0PI,
                                    int single_phase, int multi_phase, double frac_a, double frac_b,
                                    double frac_c, double constant_back, double constant_forward,
-                                   int toon_coefficients, double b_top, const double *gauss_wts,
-                                   double *xint_at_top, const double *gweight, const double *tweight,
-                                   double *albedo)
+                                   int get_toa_intensity, int get_lvl_flux, int toon_coefficients,
+                                   double b_top, const double *gauss_wts, double *xint_at_top,
+                                   double *flux_minus_all, double *flux_plus_all,
+                                   double *flux_minus_midpt_all, double *flux_plus_midpt_all,
+                                   const double *gweight, const double *tweight, double *albedo)
 {
     if (!ctx) return fail(nullptr, "null context");
     if (ngauss < 1 || ngauss > MAX_CK_GAUSS) return fail(ctx, "get_reflected_1d_ck: ngauss must be 1..%d", MAX_CK_GAUSS);
     if (!gauss_wts) return fail(ctx, "get_reflected_1d_ck: gauss_wts is null");
-    if (nwno < 1 || numg < 1 || numt < 1) return fail(ctx, "get_reflected_1d_ck: bad sizes");
+    if (nlevel < 2 || nwno < 1 || numg < 1 || numt < 1) return fail(ctx, "get_reflected_1d_ck: bad sizes");
+    if (get_lvl_flux && !(flux_minus_all && flux_plus_all && flux_minus_midpt_all && flux_plus_midpt_all))
+        return fail(ctx, "get_reflected_1d_ck: get_lvl_flux=1 needs the four level-flux outputs");
     const int nang = numg * numt;
     const long ncol = (long)nwno * ngauss;
-    PZ_TRY(lvl_scratch_reserve(ctx, sizeof(double) * (size_t)nang * ncol));
-    double *xcol = (double *)ctx->lvl_scratch;
+    const size_t nx = (size_t)nang * ncol, nl = get_lvl_flux ? (size_t)nang * nlevel * ncol : 0;
+    PZ_TRY(ck_scratch_reserve(ctx, sizeof(double) * (nx + 4 * nl)));
+    double *xcol = ctx->ck_scratch, *l0 = xcol + nx;
     PZ_TRY(reflected_1d_core(ctx, nlevel, nwno, ngauss, ncol, numg, numt, dtau, tau, w0, cosb, gcos2, ftau_cld,
                              ftau_ray, dtau_og, tau_og, w0_og, cosb_og, surf_reflect, ubar0, ubar1,
                              cos_theta, F0PI, single_phase, multi_phase, frac_a, frac_b, frac_c,
-                             constant_back, constant_forward, 1, 0, toon_coefficients, b_top, xcol, nullptr,
-                             nullptr, nullptr, nullptr, nullptr, nullptr, nullptr));
+                             constant_back, constant_forward, get_toa_intensity, get_lvl_flux,
+                             toon_coefficients, b_top, xcol, nl ? l0 : nullptr, nl ? l0 + nl : nullptr,
+                             nl ? l0 + 2 * nl : nullptr, nl ? l0 + 3 * nl : nullptr, nullptr, nullptr,
+                             nullptr));
+    // Gauss-point sums in ig order (justdoit.py:307-313)
     PZ_TRY(launch_weighted_colsum(ctx, nang, nwno, ngauss, gauss_wts, xcol, xint_at_top));
+    if (nl) {
+        double *outs[4] = {flux_minus_all, flux_plus_all, flux_minus_midpt_all, flux_plus_midpt_all};
+        for (int j = 0; j < 4; ++j)
+            PZ_TRY(launch_weighted_colsum(ctx, nang * nlevel, nwno, ngauss, gauss_wts, l0 + j * nl, outs[j]));
+    }
     if (albedo && gweight && tweight)
         PZ_TRY(picaso_compress_disco_dev(ctx, nwno, cos_theta, xint_at_top, gweight, numg, tweight, numt, F0PI, albedo));
     return 0;
@@ -575,8 +589,8 @@ static int thermal_1d_core(picaso_ctx *ctx, int nlevel, const double *wno, int n
     const bool want_lvl = flux_minus || flux_plus || flux_minus_mdpt || flux_plus_mdpt;
     if (want_lvl && !(flux_minus && flux_plus && flux_minus_mdpt && flux_plus_mdpt))
         return fail(ctx, "get_thermal_1d: pass all four level-flux outputs or none");
-    if (ncolper > 1 && (want_lvl || flux_disk))
-        return fail(ctx, "get_thermal_1d: level fluxes / fused disk sum are per-wavelength outputs (ngauss = 1)");
+    if (ncolper > 1 && flux_disk)
+        return fail(ctx, "get_thermal_1d: the fused disk sum is a per-wavelength output (ngauss = 1)");
     PZ_HIP(ctx, hipSetDevice(ctx->device));
     const int nang = numg * numt;
     std::vector<double> tab(2 * (size_t)nlevel + (size_t)nang);
@@ -599,7 +613,7 @@ static int thermal_1d_core(picaso_ctx *ctx, int nlevel, const double *wno, int n
     a.disk = fuse ? flux_disk : nullptr;
     a.disk_scale = (numt == 1) ? 1.0 : 1.0 / (2.0 * 3.14159265358979323846);   // disco.py:174-175
     if (want_lvl) {   // the reference always fills these (fluxes.py:1851-1907): two-sweep kernel
-        const size_t plane = (size_t)(nlevel - 1) * nwno;
+        const size_t plane = (size_t)(nlevel - 1) * ncol;
         PZ_TRY(lvl_scratch_reserve(ctx, sizeof(double) * 4 * plane));
         ThermalLvlArgs la{};
         la.base = a;
@@ -666,21 +680,32 @@ int picaso_get_thermal_1d_ck_dev(picaso_ctx *ctx, int nlevel, const double *wno,
                                  const double *w0, const double *cosb, const double *plevel,
                                  const double *ubar1, const double *surf_reflect, int hard_surface,
                                  const double *dwno, int calc_type, const double *gauss_wts,
-                                 double *flux_at_top, const double *gweight, const double *tweight,
-                                 double *flux_disk)
+                                 double *flux_at_top, double *flux_minus, double *flux_plus,
+                                 double *flux_minus_mdpt, double *flux_plus_mdpt, const double *gweight,
+                                 const double *tweight, double *flux_disk)
 {
     if (!ctx) return fail(nullptr, "null context");
     if (ngauss < 1 || ngauss > MAX_CK_GAUSS) return fail(ctx, "get_thermal_1d_ck: ngauss must be 1..%d", MAX_CK_GAUSS);
     if (!gauss_wts) return fail(ctx, "get_thermal_1d_ck: gauss_wts is null");
-    if (nwno < 1 || numg < 1 || numt < 1) return fail(ctx, "get_thermal_1d_ck: bad sizes");
+    if (nlevel < 2 || nwno < 1 || numg < 1 || numt < 1) return fail(ctx, "get_thermal_1d_ck: bad sizes");
+    const bool want_lvl = flux_minus || flux_plus || flux_minus_mdpt || flux_plus_mdpt;
+    if (want_lvl && !(flux_minus && flux_plus && flux_minus_mdpt && flux_plus_mdpt))
+        return fail(ctx, "get_thermal_1d_ck: pass all four level-flux outputs or none");
     const int nang = numg * numt;
     const long ncol = (long)nwno * ngauss;
-    PZ_TRY(lvl_scratch_reserve(ctx, sizeof(double) * (size_t)nang * ncol));
-    double *xcol = (double *)ctx->lvl_scratch;
+    const size_t nx = (size_t)nang * ncol, nl = want_lvl ? (size_t)nang * nlevel * ncol : 0;
+    PZ_TRY(ck_scratch_reserve(ctx, sizeof(double) * (nx + 4 * nl)));
+    double *xcol = ctx->ck_scratch, *l0 = xcol + nx;
     PZ_TRY(thermal_1d_core(ctx, nlevel, wno, nwno, ngauss, ncol, numg, numt, tlevel, dtau, w0, cosb, plevel, ubar1,
-                           surf_reflect, hard_surface, dwno, calc_type, xcol, nullptr, nullptr, nullptr,
-                           nullptr, nullptr, nullptr, nullptr));
-    PZ_TRY(launch_weighted_colsum(ctx, nang, nwno, ngauss, gauss_wts, xcol, flux_at_top));
+                           surf_reflect, hard_surface, dwno, calc_type, xcol, nl ? l0 : nullptr,
+                           nl ? l0 + nl : nullptr, nl ? l0 + 2 * nl : nullptr, nl ? l0 + 3 * nl : nullptr,
+                           nullptr, nullptr, nullptr));
+    PZ_TRY(launch_weighted_colsum(ctx, nang, nwno, ngauss, gauss_wts, xcol, flux_at_top));   // justdoit.py:380
+    if (nl) {
+        double *outs[4] = {flux_minus, flux_plus, flux_minus_mdpt, flux_plus_mdpt};
+        for (int j = 0; j < 4; ++j)
+            PZ_TRY(launch_weighted_colsum(ctx, nang * nlevel, nwno, ngauss, gauss_wts, l0 + j * nl, outs[j]));
+    }
     if (flux_disk && gweight && tweight)
         PZ_TRY(picaso_compress_thermal_dev(ctx, (size_t)nwno, flux_at_top, gweight, numg, tweight, numt, flux_disk));
     return 0;

@@ -29,6 +29,8 @@ struct picaso_ctx {
     // per-layer sweep state of the level-flux (two-sweep) kernels: 4 planes (nlayer, ncol)
     double *lvl_scratch = nullptr;
     size_t lvl_scratch_bytes = 0;
+    double *ck_scratch = nullptr;          // per-column results of a correlated-k batch before the Gauss sum
+    size_t ck_scratch_bytes = 0;
 };
 
 namespace pz {
@@ -154,6 +156,7 @@ struct ThermalLvlArgs {
 };
 int launch_thermal_lvl(picaso_ctx *ctx, const ThermalLvlArgs &a);
 int lvl_scratch_reserve(picaso_ctx *ctx, size_t bytes);
+int ck_scratch_reserve(picaso_ctx *ctx, size_t bytes);
 
 int launch_compress_dev(picaso_ctx *ctx, size_t ninner, const double *x, const double *wts_dev,
                         int nang, const double *F0PI, double c1, double c2, double *out);

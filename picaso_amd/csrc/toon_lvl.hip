@@ -27,6 +27,18 @@ int lvl_scratch_reserve(picaso_ctx *ctx, size_t bytes)
     return 0;
 }
 
+int ck_scratch_reserve(picaso_ctx *ctx, size_t bytes)
+{
+    if (bytes <= ctx->ck_scratch_bytes) return 0;
+    PZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->ck_scratch) PZ_HIP(ctx, hipFree(ctx->ck_scratch));
+    ctx->ck_scratch = nullptr;
+    ctx->ck_scratch_bytes = 0;
+    PZ_HIP(ctx, hipMalloc((void **)&ctx->ck_scratch, bytes));
+    ctx->ck_scratch_bytes = bytes;
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------------
 // reflected light, one angle
 // ------------------------------------------------------------------------------------------------
@@ -58,12 +70,13 @@ __device__ __forceinline__ ReflLayer refl_layer_coeffs(const ReflectedArgs &a, l
 __global__ __launch_bounds__(256) void k_reflected_lvl(const ReflectedLvlArgs A)
 {
     const ReflectedArgs &a = A.base;
-    const long w = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    const long w = blockIdx.x * (long)blockDim.x + threadIdx.x;     // column (wavelength x Gauss point)
     if (w >= a.ncol) return;
+    const long wv = (a.ncolper > 1) ? w / a.ncolper : w;             // wavelength of this column
     const int n = a.nlayer;
-    const long pitch = a.pitch, nw = a.nwno;
+    const long pitch = a.pitch, nw = a.ncol;
     const double u0 = a.ang[0].u0, iu0 = a.ang[0].iu0, iu0sq = a.ang[0].iu0sq;
-    const double F = a.F0PI[w], rs = a.surf_reflect[w];
+    const double F = a.F0PI[wv], rs = a.surf_reflect[wv];
     double *s_rho = A.scratch + w, *s_del = s_rho + (long)n * nw, *s_s = s_del + (long)n * nw,
            *s_t = s_s + (long)n * nw;
 
@@ -176,14 +189,15 @@ __device__ __forceinline__ ThermLayer therm_layer_coeffs(const ThermalArgs &a, l
 __global__ __launch_bounds__(256) void k_thermal_lvl(const ThermalLvlArgs A)
 {
     const ThermalArgs &a = A.base;
-    const long w = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    const long w = blockIdx.x * (long)blockDim.x + threadIdx.x;     // column (wavelength x Gauss point)
     if (w >= a.ncol) return;
+    const long wv = (a.ncolper > 1) ? w / a.ncolper : w;
     const int n = a.nlayer, nlevel = n + 1;
-    const long pitch = a.pitch, nw = a.nwno;
+    const long pitch = a.pitch, nw = a.ncol;
     const double mu1 = 0.5;
-    const double wn = a.wno[w], rs = a.surf_reflect[w];
+    const double wn = a.wno[wv], rs = a.surf_reflect[wv];
     const bool integrated = (a.calc_type == 1);
-    const double dwn = integrated ? a.dwno[w] : 0.0;
+    const double dwn = integrated ? a.dwno[wv] : 0.0;
     auto planck = [&](int l) {
         const double t = a.tlevel[l];
         return integrated ? planck_integrated(t, wn, dwn) : planck_lambda(t, wn);

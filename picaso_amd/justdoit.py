@@ -271,8 +271,6 @@ def picaso(bundle, opacityclass, dimension="1d", calculation="reflected", full_o
     is_sh = inp["approx"]["rt_method"] == "SH"
     if is_sh and (ngauss > 1 or do_holes):
         raise Exception("rt_method='SH' with correlated-k tables or patchy clouds is not built; use 'toon'")
-    if atm.get_lvl_flux and ngauss > 1:
-        raise Exception("get_lvl_flux with correlated-k tables is not built")
 
     rs = DeviceArray.from_host(np.zeros(nwno) + np.asarray(atm.surf_reflect, dtype=float), ctx)
     d_f0 = DeviceArray.from_host(np.asarray(F0PI, dtype=float), ctx)
@@ -296,7 +294,8 @@ def picaso(bundle, opacityclass, dimension="1d", calculation="reflected", full_o
                                              cos_theta, d_f0, *tt, gauss_wts, x,
                                              toon_coefficients=toon["toon_coefficients"], b_top=b_top,
                                              gweight=gweight if fuse else None,
-                                             tweight=tweight if fuse else None, albedo=alb if fuse else None)
+                                             tweight=tweight if fuse else None, albedo=alb if fuse else None,
+                                             lvl_fluxes=lv)
                 else:
                     _reflected(ctx, nlevel, nwno, ng, nt, pl, rs, ubar0, ubar1, cos_theta, d_f0, *tt,
                                toon["toon_coefficients"], b_top, x, lv, gweight, tweight,

@@ -80,40 +80,46 @@ def thermal_1d(ctx, nlevel, wno, nwno, numg, numt, tlevel, dtau, w0, cosb, pleve
 def reflected_1d_ck(ctx, nlevel, nwno, ngauss, numg, numt, planes, surf_reflect, ubar0, ubar1,
                     cos_theta, F0PI, single_phase, multi_phase, frac_a, frac_b, frac_c,
                     constant_back, constant_forward, gauss_wts, xint_at_top, toon_coefficients=0,
-                    b_top=0.0, gweight=None, tweight=None, albedo=None):
+                    b_top=0.0, gweight=None, tweight=None, albedo=None, get_toa_intensity=1,
+                    lvl_fluxes=None):
     """The reference's ``for ig in range(ngauss)`` loop around ``get_reflected_1d``
-    (justdoit.py:256-307) as one launch: planes are ``(nlayer|nlevel, nwno, ngauss)`` DeviceArrays
+    (justdoit.py:256-313) as one launch: planes are ``(nlayer|nlevel, nwno, ngauss)`` DeviceArrays
     exactly as ``compute_opacity`` lays them out, ``xint_at_top`` is the Gauss-weighted
-    ``(numg,numt,nwno)`` result."""
+    ``(numg,numt,nwno)`` result; ``lvl_fluxes`` = four ``(numg,numt,nlevel,nwno)`` DeviceArrays
+    (flux_minus, flux_plus, flux_minus_mdpt, flux_plus_mdpt) turns ``get_lvl_flux`` on."""
     u0, u1 = f64(ubar0, (numg, numt)), f64(ubar1, (numg, numt))
     gw = f64(gweight) if gweight is not None else None
     tw = f64(tweight) if tweight is not None else None
     wts = f64(gauss_wts, (ngauss,))
+    lv = list(lvl_fluxes) if lvl_fluxes is not None else [None] * 4
     check(load().picaso_get_reflected_1d_ck_dev(
         ctx, _ci(nlevel), _ci(nwno), _ci(ngauss), _ci(numg), _ci(numt),
         *[_addr(planes[k]) for k in REFLECTED_PLANES], _addr(surf_reflect), ptr(u0), ptr(u1),
         _cd(cos_theta), _addr(F0PI), _ci(single_phase), _ci(multi_phase), _cd(frac_a), _cd(frac_b),
-        _cd(frac_c), _cd(constant_back), _cd(constant_forward), _ci(toon_coefficients), _cd(b_top),
-        ptr(wts), _addr(xint_at_top), ptr(gw) if gw is not None else None,
+        _cd(frac_c), _cd(constant_back), _cd(constant_forward), _ci(int(get_toa_intensity)),
+        _ci(1 if lvl_fluxes is not None else 0), _ci(toon_coefficients), _cd(b_top), ptr(wts),
+        _addr(xint_at_top), *[_addr(x) for x in lv], ptr(gw) if gw is not None else None,
         ptr(tw) if tw is not None else None, _addr(albedo)), ctx)
 
 
 def thermal_1d_ck(ctx, nlevel, wno, nwno, ngauss, numg, numt, tlevel, dtau, w0, cosb, plevel, ubar1,
                   surf_reflect, hard_surface, gauss_wts, flux_at_top, dwno=None, calc_type=0,
-                  gweight=None, tweight=None, flux_disk=None):
+                  gweight=None, tweight=None, flux_disk=None, lvl_fluxes=None):
     """The ``ngauss`` loop around ``get_thermal_1d`` (justdoit.py:328-380) as one launch; planes
-    ``(nlayer, nwno, ngauss)``, result Gauss-weighted ``(numg,numt,nwno)``."""
+    ``(nlayer, nwno, ngauss)``, result Gauss-weighted ``(numg,numt,nwno)``; optional Gauss-weighted
+    level fluxes as in ``reflected_1d_ck``."""
     u1 = f64(ubar1, (numg, numt))
     tl, pl = f64(tlevel), f64(plevel)
     gw = f64(gweight) if gweight is not None else None
     tw = f64(tweight) if tweight is not None else None
     wts = f64(gauss_wts, (ngauss,))
+    lv = list(lvl_fluxes) if lvl_fluxes is not None else [None] * 4
     check(load().picaso_get_thermal_1d_ck_dev(
         ctx, _ci(nlevel), _addr(wno), _ci(nwno), _ci(ngauss), _ci(numg), _ci(numt), ptr(tl),
         _addr(dtau), _addr(w0), _addr(cosb), ptr(pl), ptr(u1), _addr(surf_reflect),
         _ci(int(hard_surface)), _addr(dwno), _ci(calc_type), ptr(wts), _addr(flux_at_top),
-        ptr(gw) if gw is not None else None, ptr(tw) if tw is not None else None,
-        _addr(flux_disk)), ctx)
+        *[_addr(x) for x in lv], ptr(gw) if gw is not None else None,
+        ptr(tw) if tw is not None else None, _addr(flux_disk)), ctx)
 
 
 def axpby(ctx, a, x, b, y, out):

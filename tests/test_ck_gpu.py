@@ -72,6 +72,65 @@ def test_reflected_and_thermal_ck_batch(oracle):
     assert np.array_equal(x1.to_host(), x2.to_host())
 
 
+def test_ck_level_fluxes(oracle):
+    """Climate-caller shape (one angle, ubar = 0.5, level fluxes on, justdoit/climate callers):
+    Gauss-weighted level fluxes of the batch == the reference loop with the oracle."""
+    from helpers import lvl_err
+    from picaso_amd import _lib, resident
+    from picaso_amd.device import DeviceArray
+    ctx = _lib.context()
+    nlayer, nwno, ngauss = 21, 130, 3
+    base, planes = _ck_scene(nlayer, nwno, ngauss, seed=78)
+    wts = np.array([0.5, 0.3, 0.2])
+    u = np.array([[0.5]])
+    f0, rs = np.ones(nwno), np.full(nwno, 0.1)
+    dwno = np.full(nwno, 20.0)
+    lo = [0.0] * 4
+    lt = [0.0] * 4
+    for ig in range(ngauss):
+        sl = [np.ascontiguousarray(planes[k][:, :, ig]) for k in PLANES]
+        _, lv = oracle.get_reflected_1d(nlayer + 1, base["wno"], nwno, 1, 1, *sl, rs, u, u, 1.0, f0, 3, 0,
+                                        *TTHG, get_toa_intensity=0, get_lvl_flux=1)
+        _, lvt = oracle.get_thermal_1d(nlayer + 1, base["wno"], nwno, 1, 1, base["tlevel"],
+                                       np.ascontiguousarray(planes["dtau_og"][:, :, ig]),
+                                       np.ascontiguousarray(planes["w0_no_raman"][:, :, ig]),
+                                       np.ascontiguousarray(planes["cosb_og"][:, :, ig]), base["plevel"],
+                                       u, rs, 0, dwno, 1)
+        for j in range(4):
+            lo[j] = lo[j] + lv[j] * wts[ig]
+            lt[j] = lt[j] + lvt[j] * wts[ig]
+    d = {k: DeviceArray.from_host(planes[k], ctx) for k in PLANES + ("w0_no_raman",)}
+    d_rs, d_f0 = DeviceArray.from_host(rs, ctx), DeviceArray.from_host(f0, ctx)
+    d_wno, d_dw = DeviceArray.from_host(base["wno"], ctx), DeviceArray.from_host(dwno, ctx)
+    x = DeviceArray((1, 1, nwno), ctx)
+    lv = [DeviceArray((1, 1, nlayer + 1, nwno), ctx) for _ in range(4)]
+    resident.reflected_1d_ck(ctx, nlayer + 1, nwno, ngauss, 1, 1, d, d_rs, u, u, 1.0, d_f0, 3, 0, *TTHG, wts,
+                             x, get_toa_intensity=0, lvl_fluxes=lv)
+    assert not np.any(x.to_host())
+    assert lvl_err([a.to_host() for a in lv], lo) < 1e-7
+    fx = DeviceArray((1, 1, nwno), ctx)
+    lvt_d = [DeviceArray((1, 1, nlayer + 1, nwno), ctx) for _ in range(4)]
+    resident.thermal_1d_ck(ctx, nlayer + 1, d_wno, nwno, ngauss, 1, 1, base["tlevel"], d["dtau_og"],
+                           d["w0_no_raman"], d["cosb_og"], base["plevel"], u, d_rs, 0, wts, fx, dwno=d_dw,
+                           calc_type=1, lvl_fluxes=lvt_d)
+    got = [a.to_host() for a in lvt_d]
+    # vs the oracle: bounded by the reference formula's own conditioning in optically thick layers
+    # (b_surface - c_plus_down cancellation, see tests/helpers.py:lvl_excess and DESIGN.md section 3)
+    assert lvl_err(got, lt) < 2e-4
+    # the batch plumbing itself: identical to looping the ngauss = 1 entry point over the slices
+    from picaso_amd import fluxes
+    lg = [0.0] * 4
+    for ig in range(ngauss):
+        _, l1 = fluxes.get_thermal_1d(nlayer + 1, base["wno"], nwno, 1, 1, base["tlevel"],
+                                      np.ascontiguousarray(planes["dtau_og"][:, :, ig]),
+                                      np.ascontiguousarray(planes["w0_no_raman"][:, :, ig]),
+                                      np.ascontiguousarray(planes["cosb_og"][:, :, ig]), base["plevel"], u,
+                                      rs, 0, dwno, 1)
+        for j in range(4):
+            lg[j] = lg[j] + l1[j] * wts[ig]
+    assert lvl_err(got, lg) < 1e-14
+
+
 def test_ck_argument_errors():
     from picaso_amd import _lib, resident
     from picaso_amd.device import DeviceArray
