@@ -58,18 +58,21 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
 
     dist = torch = None
+    launched = "RANK" in os.environ          # under torch.distributed.run (also with one rank)
+    if launched:
+        # torch first: PyTorch-ROCm bundles its own HIP runtime and the process must hold exactly one
+        # (picaso_amd/_lib.py then binds libpicaso_hip.so to the copy torch has mapped)
+        import torch
+        import torch.distributed as dist
+        if args.backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
     ndev = _lib.device_count()
     if ndev < 1:
         raise SystemExit("bench.py needs an MI355X: no HIP device visible")
     dev = local_rank if args.backend == "nccl" else local_rank % ndev
-    if world > 1:
-        import torch
-        import torch.distributed as dist
-        if args.backend == "nccl":
-            torch.cuda.set_device(dev)
-            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
-        else:
-            dist.init_process_group("gloo")
 
     ctx = _lib.context(dev)
     nwno, nlayer, nlevel = args.nwno, args.nlayer, args.nlayer + 1
@@ -84,7 +87,7 @@ def main():
     scene["surf_reflect"] = np.zeros(nwno)
     d = resident.upload_scene(scene, resident.REFLECTED_PLANES + ("F0PI", "surf_reflect"), ctx=ctx)
     xint = device.DeviceArray((ng, 1, nwno), ctx)
-    use_nccl = world > 1 and args.backend == "nccl"
+    use_nccl = launched and args.backend == "nccl"
     if use_nccl:
         alb_t = torch.empty(nwno, dtype=torch.float64, device="cuda")
         full_t = torch.empty(world * nwno, dtype=torch.float64, device="cuda")
@@ -92,7 +95,7 @@ def main():
     else:
         alb_d = device.DeviceArray((nwno,), ctx)
         albedo = alb_d
-        if world > 1:
+        if launched:
             full_t = torch.empty(world * nwno, dtype=torch.float64)
 
     def step():
@@ -102,12 +105,13 @@ def main():
         if use_nccl:
             device.sync(ctx)                                  # our stream -> RCCL's stream
             dist.all_gather_into_tensor(full_t, alb_t)        # RCCL over xGMI: the final spectrum
-        elif world > 1:                                       # gloo smoke path: gather on the host
+            torch.cuda.synchronize()                          # the shard buffer is rewritten next step
+        elif launched:                                        # gloo smoke path: gather on the host
             dist.all_gather_into_tensor(full_t, torch.from_numpy(alb_d.to_host()))
 
     def barrier():
         device.sync(ctx)
-        if world > 1:
+        if launched:
             if use_nccl:
                 torch.cuda.synchronize()
             dist.barrier()
@@ -124,7 +128,7 @@ def main():
     kernel_ms_total = device.timer_stop(ctx)                  # HIP events on the kernel's stream
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if launched:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if use_nccl else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -133,7 +137,7 @@ def main():
     out = None
     if rank == 0:
         alb_gpu = alb_t.cpu().numpy() if use_nccl else alb_d.to_host()
-        if world > 1:   # the gathered spectrum must contain this rank's shard bit-exactly
+        if launched:    # the gathered spectrum must contain this rank's shard bit-exactly
             assert np.array_equal(full_t[:nwno].cpu().numpy(), alb_gpu), "all-gather mismatch"
         ms_per_step = 1e3 * elapsed / args.steps
         value = world * args.steps / elapsed
@@ -159,7 +163,7 @@ def main():
                        "nwno_per_gpu": nwno, "nlayer": nlayer, "gauss_angles": ng,
                        "sharding": "wavelength blocks, %d x %d" % (world, nwno),
                        "collective": ("rccl all_gather of albedo shards" if use_nccl else
-                                      "gloo all_gather (smoke)") if world > 1 else "none"},
+                                      "gloo all_gather (smoke)") if launched else "none"},
             "wavelength_layer_updates_per_s": value * nwno * nlayer,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
@@ -185,7 +189,7 @@ def main():
                 "host_cores_available": len(os.sched_getaffinity(0))}
             out["max_rel_err_vs_oracle"] = err
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if launched:
         dist.destroy_process_group()
 
 

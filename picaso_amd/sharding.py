@@ -4,6 +4,10 @@ Every function on the hot path is pointwise in wavelength, so t
 into contiguous blocks, one per rank, with no exchange inside the solve; the only collective is
 the all-gather of the final spectrum shards (RCCL over xGMI when the backend is "nccl", gloo in
 the CPU tests).  Pure host logic: usable without a GPU.
+
+One HIP runtime per process: PyTorch-ROCm wheels bundle their own ``libamdhip64``; import torch (and
+select the device) BEFORE the first ``picaso_amd`` call in a process that uses both, as ``bench.py``
+does -- ``picaso_amd._lib`` then binds ``libpicaso_hip.so`` to the runtime torch has mapped.
 """
 import numpy as np
 
