@@ -206,7 +206,17 @@ __device__ __forceinline__ double p_single(int single_phase, double cosb_og, dou
         return f * (1.0 - gf * gf) * frsq(b1 * b1 * b1) +
                (1.0 - f) * (1.0 - gb * gb) * frsq(b2 * b2 * b2) + gcos2;
     }
-    const double tthg = f * hg_term(gf, ct) + (1.0 - f) * hg_term(gb, ct);
+    double tthg;
+    if (!IS3D && ct == 1.0) {
+        // zero phase angle (cos_theta = 1, the symmetric 1-D geometry): 1 + g^2 + 2g = (1+g)^2, so
+        // (1-g^2)/((1+g)^2)^1.5 = (1-g)/(1+g)^2 -- one reciprocal for both terms instead of two rsqrt
+        const double pf = 1.0 + gf, pb = 1.0 + gb;
+        const double qf = pf * pf, qb = pb * pb;
+        const double r = frcp(qf * qb);
+        tthg = (f * (1.0 - gf) * qb + (1.0 - f) * (1.0 - gb) * qf) * r;
+    } else {
+        tthg = f * hg_term(gf, ct) + (1.0 - f) * hg_term(gb, ct);
+    }
     if (single_phase == 2) return tthg;
     return ftau_cld * tthg + ftau_ray * (0.75 * (1.0 + ct * ct));
 }
