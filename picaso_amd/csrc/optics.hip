@@ -70,6 +70,8 @@ __global__ __launch_bounds__(256) void k_opacity_gas(const GasArgs a)
 struct MixArgs {
     int nlayer, nwno, test_mode, delta_eddington, stream;
     int ncolper;      // columns per wavelength of taugas and of every output (tauray, cloud, raman have none)
+    long ostride, ooff;   // outputs are written at element index*ostride + ooff: facet `ooff` of the
+                          // (rows, nwno, nfacets) planes get_reflected_3d takes (1, 0 otherwise)
     const double *taugas, *tauray, *taucld, *w0c, *g0c, *raman;
     double raman_const;
     double *dtau, *tau, *w0, *cosb, *ftau_cld, *ftau_ray, *gcos2, *dtau_og, *tau_og, *w0_og,
@@ -90,8 +92,8 @@ __global__ __launch_bounds__(256) void k_compute_opacity(const MixArgs a)
     if (col >= ncol) return;
     const long w = (a.ncolper > 1) ? col / a.ncolper : col;
     double tau_run = 0.0, taud_run = 0.0;
-    a.tau_og[col] = 0.0;
-    a.tau[col] = 0.0;
+    a.tau_og[col * a.ostride + a.ooff] = 0.0;
+    a.tau[col * a.ostride + a.ooff] = 0.0;
     for (int i = 0; i < a.nlayer; ++i) {
         const long o = (long)i * ncol + col, ow = (long)i * nw + w;
         const double tg = a.taugas[o], tr = a.tauray[ow], tc = a.taucld[ow], wc = a.w0c[ow], gc = a.g0c[ow];
@@ -115,17 +117,18 @@ __global__ __launch_bounds__(256) void k_compute_opacity(const MixArgs a)
             w0nr = w0;
         }
         tau_run += dtau;                                                // numba_cumsum (:353-354)
-        a.dtau_og[o] = dtau; a.tau_og[o + ncol] = tau_run; a.w0_og[o] = w0; a.cosb_og[o] = cosb;
-        a.ftau_cld[o] = fcld; a.ftau_ray[o] = fray; a.gcos2[o] = gcos2; a.w0_no_raman[o] = w0nr;
+        const long q = o * a.ostride + a.ooff, qn = (o + ncol) * a.ostride + a.ooff;
+        a.dtau_og[q] = dtau; a.tau_og[qn] = tau_run; a.w0_og[q] = w0; a.cosb_og[q] = cosb;
+        a.ftau_cld[q] = fcld; a.ftau_ray[q] = fray; a.gcos2[q] = gcos2; a.w0_no_raman[q] = w0nr;
         if (a.delta_eddington) {                                        // :401-420
             const double f = ipow(cosb, a.stream);
             const double w0d = w0 * (1. - f) / (1.0 - w0 * f);
             const double cbd = (cosb - f) / (1. - f);
             const double dtd = dtau * (1. - w0 * f);
             taud_run += dtd;
-            a.f_deltaM[o] = f; a.w0[o] = w0d; a.cosb[o] = cbd; a.dtau[o] = dtd; a.tau[o + ncol] = taud_run;
+            a.f_deltaM[q] = f; a.w0[q] = w0d; a.cosb[q] = cbd; a.dtau[q] = dtd; a.tau[qn] = taud_run;
         } else {                                                        // :428-431
-            a.f_deltaM[o] = 0 * cosb; a.w0[o] = w0; a.cosb[o] = cosb; a.dtau[o] = dtau; a.tau[o + ncol] = tau_run;
+            a.f_deltaM[q] = 0 * cosb; a.w0[q] = w0; a.cosb[q] = cosb; a.dtau[q] = dtau; a.tau[qn] = tau_run;
         }
     }
 }
@@ -228,7 +231,7 @@ int picaso_compute_opacity_ck_dev(picaso_ctx *ctx, int nlayer, int nwno, int nga
     if (stream != 2 && stream != 4) return fail(ctx, "compute_opacity: stream must be 2 or 4");
     PZ_HIP(ctx, hipSetDevice(ctx->device));
     MixArgs a{};
-    a.nlayer = nlayer; a.nwno = nwno; a.ncolper = ngauss; a.test_mode = test_mode;
+    a.nlayer = nlayer; a.nwno = nwno; a.ncolper = ngauss; a.ostride = 1; a.ooff = 0; a.test_mode = test_mode;
     a.delta_eddington = delta_eddington;
     a.stream = stream; a.taugas = taugas; a.tauray = tauray; a.taucld = taucld; a.w0c = w0_cld;
     a.g0c = g0_cld; a.raman = raman_factor; a.raman_const = raman_const;
@@ -238,6 +241,36 @@ int picaso_compute_opacity_ck_dev(picaso_ctx *ctx, int nlayer, int nwno, int nga
     const int block = 256;
     const long ncol = (long)nwno * ngauss;
     hipLaunchKernelGGL(k_compute_opacity, dim3((unsigned)((ncol + block - 1) / block)), dim3(block), 0,
+                       ctx->stream, a);
+    PZ_HIP(ctx, hipGetLastError());
+    return 0;
+}
+
+int picaso_compute_opacity_facet_dev(picaso_ctx *ctx, int nlayer, int nwno, int nfacets, int facet,
+                                     const double *taugas, const double *tauray, const double *taucld,
+                                     const double *w0_cld, const double *g0_cld, const double *raman_factor,
+                                     double raman_const, int test_mode, int delta_eddington, int stream,
+                                     double *dtau, double *tau, double *w0, double *cosb,
+                                     double *ftau_cld, double *ftau_ray, double *gcos2, double *dtau_og,
+                                     double *tau_og, double *w0_og, double *cosb_og, double *w0_no_raman,
+                                     double *f_deltaM)
+{
+    if (!ctx) return fail(nullptr, "null context");
+    if (nlayer < 1 || nwno < 1) return fail(ctx, "compute_opacity: bad sizes");
+    if (nfacets < 1 || facet < 0 || facet >= nfacets) return fail(ctx, "compute_opacity: facet %d of %d", facet, nfacets);
+    if (test_mode < 0 || test_mode > 2) return fail(ctx, "compute_opacity: test_mode must be 0, 1 or 2");
+    if (stream != 2 && stream != 4) return fail(ctx, "compute_opacity: stream must be 2 or 4");
+    PZ_HIP(ctx, hipSetDevice(ctx->device));
+    MixArgs a{};
+    a.nlayer = nlayer; a.nwno = nwno; a.ncolper = 1; a.ostride = nfacets; a.ooff = facet;
+    a.test_mode = test_mode; a.delta_eddington = delta_eddington;
+    a.stream = stream; a.taugas = taugas; a.tauray = tauray; a.taucld = taucld; a.w0c = w0_cld;
+    a.g0c = g0_cld; a.raman = raman_factor; a.raman_const = raman_const;
+    a.dtau = dtau; a.tau = tau; a.w0 = w0; a.cosb = cosb; a.ftau_cld = ftau_cld; a.ftau_ray = ftau_ray;
+    a.gcos2 = gcos2; a.dtau_og = dtau_og; a.tau_og = tau_og; a.w0_og = w0_og; a.cosb_og = cosb_og;
+    a.w0_no_raman = w0_no_raman; a.f_deltaM = f_deltaM;
+    const int block = 256;
+    hipLaunchKernelGGL(k_compute_opacity, dim3((unsigned)((nwno + block - 1) / block)), dim3(block), 0,
                        ctx->stream, a);
     PZ_HIP(ctx, hipGetLastError());
     return 0;

@@ -143,6 +143,22 @@ class inputs:
         self.inputs["clouds"].update(profile=df, wavenumber=wavenumber, do_holes=do_holes,
                                      fhole=fhole, fthin_cld=fthin_cld)
 
+    def atmosphere_3d(self, profiles, exclude_mol=1):
+        """Per-facet level profiles for ``spectrum(dimension='3d')``: ``pressure`` (nlevel,) in bar,
+        ``temperature`` and every mixing ratio ``(nlevel, num_gangle, num_tangle)`` (or ``(nlevel,)``,
+        shared by all facets), already on the Gauss/Chebyshev facets of ``phase_angle()`` (the
+        reference regrids an xarray lon/lat dataset first, justdoit.py:2389-2560; that regridding is
+        data preparation outside the path)."""
+        if "pressure" not in profiles or "temperature" not in profiles:
+            raise Exception("atmosphere_3d(profiles) needs 'pressure' and 'temperature'")
+        self.inputs["atmosphere"]["profile_3d"] = {k: np.asarray(v, dtype=float) for k, v in profiles.items()}
+        self.inputs["atmosphere"]["exclude_mol"] = exclude_mol
+        self.nlevel = len(profiles["pressure"])
+
+    def clouds_3d(self, df=None):
+        """Cloud ``opd``/``w0``/``g0`` as ``(nlayer, nwno, num_gangle, num_tangle)`` arrays."""
+        self.inputs["clouds"]["profile_3d"] = df
+
     def surface_reflect(self, albedo, wavenumber=None, old_wavenumber=None):
         """Surface reflectivity, scalar or per wavelength (reference justdoit.py:4092)."""
         self.inputs["surface_reflect"] = albedo
@@ -195,15 +211,47 @@ class inputs:
     def spectrum(self, opacityclass, calculation="reflected", dimension="1d", full_output=False,
                  plot_opacity=False, as_dict=True):
         """Run the spectrum (reference justdoit.py:4779-4840)."""
-        if self.inputs["atmosphere"]["profile"] is None:
-            raise Exception("Need to set atmosphere profile with the atmosphere() function")
+        if dimension not in ("1d", "3d"):
+            raise Exception("dimension must be '1d' or '3d'")
+        have = self.inputs["atmosphere"].get("profile" if dimension == "1d" else "profile_3d")
+        if have is None:
+            raise Exception("Need to set atmosphere profile with the atmosphere%s() function"
+                            % ("" if dimension == "1d" else "_3d"))
         if self.inputs["planet"]["gravity"] is None:
             raise Exception("Need to set gravity with the gravity() function")
-        if dimension != "1d":
-            raise Exception("dimension='3d' orchestration is not built; call "
-                            "picaso_amd.fluxes.get_reflected_3d / get_thermal_3d directly")
         return picaso(self, opacityclass, dimension=dimension, calculation=calculation,
                       full_output=full_output, plot_opacity=plot_opacity, as_dict=as_dict)
+
+
+def _setup_atmosphere(inp, opa, wno, profile=None, cloud_profile=None):
+    """ATMSETUP sequence of the reference's ``picaso()`` (justdoit.py:180-243) for the 1-D profile
+    or, in the 3-D path, for one facet's profile (``atm_1d.disect(g,t)``, justdoit.py:446-449)."""
+    cfg = inp
+    if profile is not None:
+        cfg = dict(inp)
+        cfg["atmosphere"] = dict(inp["atmosphere"], profile=profile)
+        cfg["clouds"] = dict(inp["clouds"], profile=cloud_profile)
+    atm = ATMSETUP(cfg)
+    atm.surf_reflect = inp.get("surface_reflect", 0)
+    atm.hard_surface = inp.get("hard_surface", 0)
+    atm.wavenumber = wno
+    atm.planet.gravity = inp["planet"]["gravity"]
+    atm.planet.radius = inp["planet"]["radius"]
+    atm.planet.mass = inp["planet"]["mass"]
+    atm.get_lvl_flux = inp["approx"].get("get_lvl_flux", False)
+    atm.get_profile()
+    atm.get_mmw()
+    atm.get_density()
+    atm.get_altitude(p_reference=inp["approx"]["p_reference"])
+    atm.get_column_density()
+    atm.get_needed_continuum(opa.rayleigh_molecules, opa.avail_continuum)
+    atm.get_clouds(wno)
+    no_opa = [m for m in atm.molecules if m not in opa.molecules]
+    if no_opa:
+        atm.add_warnings("I found chemistry for these but I do not have computed individual line "
+                         "opacities (not including continuum) for: " + ",".join(no_opa))
+    atm.molecules = np.array([m for m in atm.molecules if m not in no_opa])
+    return atm
 
 
 def picaso(bundle, opacityclass, dimension="1d", calculation="reflected", full_output=False,
@@ -234,43 +282,52 @@ def picaso(bundle, opacityclass, dimension="1d", calculation="reflected", full_o
     sa = inp["star"]["semi_major"]
     radius_star = inp["star"]["radius"]
 
-    atm = ATMSETUP(inp)
-    atm.surf_reflect = inp.get("surface_reflect", 0)
-    atm.hard_surface = inp.get("hard_surface", 0)
-    atm.wavenumber = wno
-    atm.planet.gravity = inp["planet"]["gravity"]
-    atm.planet.radius = inp["planet"]["radius"]
-    atm.planet.mass = inp["planet"]["mass"]
-    atm.get_lvl_flux = inp["approx"].get("get_lvl_flux", False)
-    atm.get_profile()
-    atm.get_mmw()
-    atm.get_density()
-    atm.get_altitude(p_reference=inp["approx"]["p_reference"])
-    atm.get_column_density()
-    atm.get_needed_continuum(opa.rayleigh_molecules, opa.avail_continuum)
-    atm.get_clouds(wno)
-    no_opa = [m for m in atm.molecules if m not in opa.molecules]
-    if no_opa:
-        atm.add_warnings("I found chemistry for these but I do not have computed individual line "
-                         "opacities (not including continuum) for: " + ",".join(no_opa))
-    atm.molecules = np.array([m for m in atm.molecules if m not in no_opa])
+    do_holes = bool(inp["clouds"].get("do_holes", False))
+    is_sh = inp["approx"]["rt_method"] == "SH"
+    planes3d = tlev3 = plev3 = None
+    if dimension == "3d":                                      # justdoit.py:407-471
+        if is_sh or ngauss > 1 or do_holes or inp["approx"].get("get_lvl_flux", False):
+            raise Exception("dimension='3d' is built for rt_method='toon', monochromatic opacities, "
+                            "no patchy clouds and no level fluxes")
+        prof3 = inp["atmosphere"]["profile_3d"]
+        cld3 = inp["clouds"].get("profile_3d")
+        atm = None
+        for g in range(ng):
+            for t in range(nt):
+                prof = {k: (v if v.ndim == 1 else v[:, g, t]) for k, v in prof3.items()}
+                cld = None if cld3 is None else {k: np.asarray(cld3[k])[:, :, g, t] for k in ("opd", "w0", "g0")}
+                atm_f = _setup_atmosphere(inp, opa, wno, prof, cld)
+                if atm is None:
+                    atm = atm_f
+                    nl3 = atm.c.nlayer
+                    planes3d = {k: DeviceArray(((nl3 + 1 if k in ("tau", "tau_og") else nl3), nwno, ng, nt), ctx)
+                                for k in optics.OUT_NAMES}
+                    tlev3, plev3 = np.zeros((nl3 + 1, ng, nt)), np.zeros((nl3 + 1, ng, nt))
+                opa.get_opacities(atm_f, exclude_mol=inp["atmosphere"]["exclude_mol"])
+                optics.compute_opacity_resident(
+                    atm_f, opa, ngauss=1, stream=common["stream"], delta_eddington=common["delta_eddington"],
+                    test_mode=inp["test_mode"], raman=common["raman"], facet=(g * nt + t, ng * nt),
+                    out=planes3d)
+                tlev3[:, g, t] = atm_f.level["temperature"]
+                plev3[:, g, t] = atm_f.level["pressure"]
+    else:
+        atm = _setup_atmosphere(inp, opa, wno)
     nlevel, nlayer = atm.c.nlevel, atm.c.nlayer
 
-    opa.get_opacities(atm, exclude_mol=inp["atmosphere"]["exclude_mol"])
-    co_kw = dict(ngauss=ngauss, stream=common["stream"], delta_eddington=common["delta_eddington"],
-                 test_mode=inp["test_mode"], raman=common["raman"], full_output=full_output)
-    planes = optics.compute_opacity_resident(atm, opa, **co_kw)
-    # patchy clouds (justdoit.py:139-142, 248-252): a second, thinned-cloud column set
-    do_holes = bool(inp["clouds"].get("do_holes", False))
-    fhole = planes_clear = None
-    if do_holes:
-        fhole = float(inp["clouds"]["fhole"])
-        planes_clear = optics.compute_opacity_resident(atm, opa, fthin_cld=inp["clouds"]["fthin_cld"],
-                                                       do_holes=True, **co_kw)
+    fhole = planes = planes_clear = None
     gauss_wts = np.asarray(opa.gauss_wts, dtype=float)
-    is_sh = inp["approx"]["rt_method"] == "SH"
-    if is_sh and (ngauss > 1 or do_holes):
-        raise Exception("rt_method='SH' with correlated-k tables or patchy clouds is not built; use 'toon'")
+    if dimension == "1d":
+        opa.get_opacities(atm, exclude_mol=inp["atmosphere"]["exclude_mol"])
+        co_kw = dict(ngauss=ngauss, stream=common["stream"], delta_eddington=common["delta_eddington"],
+                     test_mode=inp["test_mode"], raman=common["raman"], full_output=full_output)
+        planes = optics.compute_opacity_resident(atm, opa, **co_kw)
+        # patchy clouds (justdoit.py:139-142, 248-252): a second, thinned-cloud column set
+        if do_holes:
+            fhole = float(inp["clouds"]["fhole"])
+            planes_clear = optics.compute_opacity_resident(atm, opa, fthin_cld=inp["clouds"]["fthin_cld"],
+                                                           do_holes=True, **co_kw)
+        if is_sh and (ngauss > 1 or do_holes):
+            raise Exception("rt_method='SH' with correlated-k tables or patchy clouds is not built; use 'toon'")
 
     rs = DeviceArray.from_host(np.zeros(nwno) + np.asarray(atm.surf_reflect, dtype=float), ctx)
     d_f0 = DeviceArray.from_host(np.asarray(F0PI, dtype=float), ctx)
@@ -279,7 +336,11 @@ def picaso(bundle, opacityclass, dimension="1d", calculation="reflected", full_o
         xint = DeviceArray((ng, nt, nwno), ctx)
         alb = DeviceArray((nwno,), ctx)
         lvl = None
-        if is_sh:                                             # justdoit.py:259-269
+        if dimension == "3d":                                 # justdoit.py:488-500
+            resident.reflected_3d(ctx, nlevel, nwno, ng, nt, planes3d, rs, ubar0, ubar1, cos_theta, d_f0,
+                                  toon["single_phase"], toon["multi_phase"], frac_a, frac_b, frac_c,
+                                  constant_back, constant_forward, xint, gweight, tweight, alb)
+        elif is_sh:                                           # justdoit.py:259-269
             _reflected_sh(ctx, nlevel, nwno, ng, nt, planes, rs, ubar0, ubar1, cos_theta, d_f0,
                           inp["approx"]["rt_params"]["SH"], frac_a, frac_b, frac_c, constant_back,
                           constant_forward, common["stream"], b_top, xint, gweight, tweight, alb)
@@ -329,7 +390,11 @@ def picaso(bundle, opacityclass, dimension="1d", calculation="reflected", full_o
         d_wno = DeviceArray.from_host(wno, ctx)
         flux = DeviceArray((ng, nt, nwno), ctx)
         disk = DeviceArray((nwno,), ctx)
-        if is_sh:                                             # justdoit.py:364-370
+        if dimension == "3d":                                 # justdoit.py:502-514
+            resident.thermal_3d(ctx, nlevel, d_wno, nwno, ng, nt, tlev3, planes3d["dtau_og"],
+                                planes3d["w0_no_raman"], planes3d["cosb_og"], plev3, ubar1, rs,
+                                atm.hard_surface, flux, gweight, tweight, disk)
+        elif is_sh:                                           # justdoit.py:364-370
             _thermal_sh(ctx, nlevel, d_wno, nwno, ng, nt, atm.level["temperature"], planes,
                         atm.level["pressure"], ubar1, rs, common["stream"], atm.hard_surface,
                         common["delta_eddington"], flux, gweight, tweight, disk)

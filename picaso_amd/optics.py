@@ -452,10 +452,12 @@ def _layer_factors(atm, opacityclass):
 
 def compute_opacity_resident(atmosphere, opacityclass, ngauss=1, stream=2, delta_eddington=True,
                              test_mode=None, raman=0, fthin_cld=None, do_holes=False,
-                             full_output=False):
+                             full_output=False, facet=None, out=None):
     """GPU ``compute_opacity`` returning a dict of the 13 planes as DeviceArrays: ``(rows, nwno)``
     for monochromatic opacities, ``(rows, nwno, ngauss)`` (reference layout, optics.py:423-431)
-    for correlated-k tables."""
+    for correlated-k tables.  3-D path: ``facet=(index, nfacets)`` and ``out`` = dict of
+    ``(rows, nwno, numg, numt)`` DeviceArrays fills that facet of the planes ``get_reflected_3d``
+    takes (reference justdoit.py:444-471)."""
     atm, opa = atmosphere, opacityclass
     if ngauss != opa.ngauss:
         raise Exception("compute_opacity: ngauss=%d but the opacity tables have %d Gauss points"
@@ -504,6 +506,15 @@ def compute_opacity_resident(atmosphere, opacityclass, ngauss=1, stream=2, delta
     tm = 0
     if test_mode is not None:      # optics.py:372 `test_mode != None`: anything but None, including the
         tm = 1 if test_mode == "rayleigh" else 2            # signature default False, is a test mode
+    if facet is not None:
+        if ngauss != 1:
+            raise Exception("compute_opacity: the 3-D facet form takes monochromatic opacities")
+        check(load().picaso_compute_opacity_facet_dev(
+            ctx, _ci(nlayer), _ci(nwno), _ci(facet[1]), _ci(facet[0]), ptr(taugas.addr), ptr(tauray.addr),
+            ptr(d_cld.addr), ptr(d_w0.addr), ptr(d_g0.addr), ptr(raman_plane.addr) if raman_plane else None,
+            _cd(raman_const), _ci(tm), _ci(1 if delta_eddington else 0), _ci(stream),
+            *[ptr(out[k].addr) for k in OUT_NAMES]), ctx)
+        return out
     out = {}
     for k in OUT_NAMES:
         rows = nlayer + 1 if k in ("tau", "tau_og") else nlayer

@@ -142,3 +142,34 @@ def compress_thermal(ctx, ninner, flux_at_top, gweight, tweight, flux):
     gw, tw = f64(gweight), f64(tweight)
     check(load().picaso_compress_thermal_dev(ctx, ctypes.c_size_t(ninner), _addr(flux_at_top), ptr(gw),
                                              _ci(gw.size), ptr(tw), _ci(tw.size), _addr(flux)), ctx)
+
+
+def reflected_3d(ctx, nlevel, nwno, numg, numt, planes, surf_reflect, ubar0, ubar1, cos_theta, F0PI,
+                 single_phase, multi_phase, frac_a, frac_b, frac_c, constant_back, constant_forward,
+                 xint_at_top, gweight=None, tweight=None, albedo=None):
+    """``get_reflected_3d`` on resident ``(nlayer|nlevel, nwno, numg, numt)`` planes (+ optional fused
+    ``compress_disco``)."""
+    u0, u1 = f64(ubar0, (numg, numt)), f64(ubar1, (numg, numt))
+    gw = f64(gweight) if gweight is not None else None
+    tw = f64(tweight) if tweight is not None else None
+    check(load().picaso_get_reflected_3d_dev(
+        ctx, _ci(nlevel), _ci(nwno), _ci(numg), _ci(numt), *[_addr(planes[k]) for k in REFLECTED_PLANES],
+        _addr(surf_reflect), ptr(u0), ptr(u1), _cd(cos_theta), _addr(F0PI), _ci(single_phase),
+        _ci(multi_phase), _cd(frac_a), _cd(frac_b), _cd(frac_c), _cd(constant_back),
+        _cd(constant_forward), _addr(xint_at_top), ptr(gw) if gw is not None else None,
+        ptr(tw) if tw is not None else None, _addr(albedo)), ctx)
+
+
+def thermal_3d(ctx, nlevel, wno, nwno, numg, numt, tlevel_3d, dtau_3d, w0_3d, cosb_3d, plevel_3d, ubar1,
+               surf_reflect, hard_surface, int_at_top, gweight=None, tweight=None, flux_disk=None):
+    """``get_thermal_3d`` on resident ``(nlayer, nwno, numg, numt)`` planes; ``tlevel_3d`` /
+    ``plevel_3d`` host ``(nlevel, numg, numt)``."""
+    u1 = f64(ubar1, (numg, numt))
+    tl, pl = f64(tlevel_3d, (nlevel, numg, numt)), f64(plevel_3d, (nlevel, numg, numt))
+    gw = f64(gweight) if gweight is not None else None
+    tw = f64(tweight) if tweight is not None else None
+    check(load().picaso_get_thermal_3d_dev(
+        ctx, _ci(nlevel), _addr(wno), _ci(nwno), _ci(numg), _ci(numt), ptr(tl), _addr(dtau_3d),
+        _addr(w0_3d), _addr(cosb_3d), ptr(pl), ptr(u1), _addr(surf_reflect), _ci(int(hard_surface)),
+        _addr(int_at_top), ptr(gw) if gw is not None else None, ptr(tw) if tw is not None else None,
+        _addr(flux_disk)), ctx)

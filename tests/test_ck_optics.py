@@ -219,3 +219,59 @@ def test_gpu_patchy_clouds_end_to_end(og, oracle):
     assert rel_err(out["full_output"]["albedo_3d"], x) < 1e-7
     assert rel_err(out["albedo"], oracle.compress_disco(nwno, 1.0, x, gw, tw, np.ones(nwno))) < 1e-7
     assert rel_err(out["thermal"], oracle.compress_thermal(nwno, f, gw, tw)) < 1e-7
+
+
+@pytest.mark.gpu
+def test_gpu_3d_spectrum_end_to_end(og, oracle):
+    """spectrum(dimension='3d'): per-facet opacities -> facet-strided planes on the device ->
+    get_reflected_3d / get_thermal_3d -> disk integration, against the oracle chain.  Facets share
+    the gas column and differ in cloud optical depth (x facet factor)."""
+    from oracle import optics_oracle as oo
+    from picaso_amd import disco
+    from picaso_amd import justdoit as jdi
+    ng, nt = 2, 3
+    fac = 0.25 + np.arange(ng * nt).reshape(ng, nt) / 4.0
+    opa = jdi.opannection(DB, query_method="linear")
+    case = jdi.inputs()
+    case.phase_angle(np.pi / 3, num_gangle=ng, num_tangle=nt)
+    case.gravity(gravity=float(og["in/gravity"]))
+    nlevel = len(og["in/tlevel"])
+    prof = {"pressure": og["in/plevel_bar"], "temperature": np.repeat(og["in/tlevel"][:, None, None], ng, 1).repeat(nt, 2)}
+    for k in ("H2", "He", "H2O", "CH4"):
+        prof[k] = og["in/mix/" + k]
+    case.atmosphere_3d(prof)
+    cld = {k: np.repeat(og["in/cld_" + k][:, :, None, None], ng, 2).repeat(nt, 3) for k in ("opd", "w0", "g0")}
+    cld["opd"] = cld["opd"] * fac[None, None]
+    case.clouds_3d(cld)
+    case.approx(raman="none", delta_eddington=True)
+    case.surface_reflect(0.2)
+    out = case.spectrum(opa, calculation="reflected+thermal", dimension="3d", full_output=True)
+    # oracle chain
+    key = "linear/de0_s2_r2_tmnone"
+    dtau, taucld = og[key + "/dtau_og"], og["in/cld_opd"]
+    fray = og[key + "/ftau_ray"]
+    with np.errstate(invalid="ignore", divide="ignore"):
+        tauray = np.where(fray > 0, fray * og["in/cld_w0"] * taucld / np.where(fray < 1, 1 - fray, 1.0), 0.0)
+    tauray = np.where(taucld > 0, tauray, og[key + "/w0_no_raman"] * dtau / 0.99999)
+    taugas = dtau - tauray - taucld
+    nwno = dtau.shape[1]
+    P3 = {nm: [] for nm in NAMES}
+    for g in range(ng):
+        for t in range(nt):
+            P = dict(zip(NAMES, oo.compute_opacity(taugas, tauray, fac[g, t] * taucld, og["in/cld_w0"],
+                                                   og["in/cld_g0"], 0.99999, stream=2, delta_eddington=True)))
+            for nm in NAMES:
+                P3[nm].append(P[nm])
+    P3 = {nm: np.ascontiguousarray(np.stack(v, axis=2).reshape(v[0].shape + (ng, nt))) for nm, v in P3.items()}
+    gg, gw, tt, tw = disco.get_angles_3d(ng, nt)
+    u0, u1, ct, _, _ = disco.compute_disco(ng, nt, gg, tt, np.pi / 3)
+    x = oracle.get_reflected_3d(nlevel, opa.wno, nwno, ng, nt, *[P3[k] for k in PLANES], 0.2, u0, u1, ct,
+                                np.ones(nwno), 3, 0, *TTHG)
+    assert rel_err(out["full_output"]["albedo_3d"], x) < 1e-7
+    assert rel_err(out["albedo"], oracle.compress_disco(nwno, ct, x, gw, tw, np.ones(nwno))) < 1e-7
+    tl3 = np.repeat(og["in/tlevel"][:, None, None], ng, 1).repeat(nt, 2)
+    pl3 = np.repeat((og["in/plevel_bar"] * 1e6)[:, None, None], ng, 1).repeat(nt, 2)
+    f = oracle.get_thermal_3d(nlevel, opa.wno, nwno, ng, nt, tl3, P3["dtau_og"], P3["w0_no_raman"],
+                              P3["cosb_og"], pl3, u1, np.full(nwno, 0.2), 1)
+    assert rel_err(out["full_output"]["thermal_3d"], f) < 1e-7
+    assert rel_err(out["thermal"], oracle.compress_thermal(nwno, f, gw, tw)) < 1e-7
