@@ -103,9 +103,10 @@ def main():
                               cos_theta, d["F0PI"], 3, 0, *TTHG, xint, toon_coefficients=0,
                               b_top=0.0, gweight=gw, tweight=tw, albedo=albedo)
         if use_nccl:
-            device.sync(ctx)                                  # our stream -> RCCL's stream
+            # The library's stream is torch's current stream (ExternalStream below), so RCCL orders the
+            # gather after the kernel and the next step's kernel after the gather on the device: no
+            # host synchronisation inside the timed loop.
             dist.all_gather_into_tensor(full_t, alb_t)        # RCCL over xGMI: the final spectrum
-            torch.cuda.synchronize()                          # the shard buffer is rewritten next step
         elif launched:                                        # gloo smoke path: gather on the host
             dist.all_gather_into_tensor(full_t, torch.from_numpy(alb_d.to_host()))
 
@@ -118,16 +119,21 @@ def main():
             if use_nccl:
                 torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    device.timer_start(ctx)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    kernel_ms_total = device.timer_stop(ctx)                  # HIP events on the kernel's stream
-    barrier()
-    elapsed = time.perf_counter() - t0
+    import contextlib
+    on_lib_stream = contextlib.nullcontext()
+    if use_nccl:
+        on_lib_stream = torch.cuda.stream(torch.cuda.ExternalStream(_lib.stream_ptr(ctx)))
+    with on_lib_stream:
+        for _ in range(args.warmup):
+            step()
+        barrier()
+        device.timer_start(ctx)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        kernel_ms_total = device.timer_stop(ctx)              # HIP events on the kernel's stream
+        barrier()
+        elapsed = time.perf_counter() - t0
     if launched:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if use_nccl else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -72,6 +72,12 @@ def check(rc, ctx=None):
         raise PicasoHipError(msg.decode() if msg else "picaso_hip error %d" % rc)
 
 
+def stream_ptr(ctx):
+    """The hipStream_t all of this context's kernels run on, as an integer (e.g. for
+    ``torch.cuda.ExternalStream``)."""
+    return int(load().picaso_stream(ctx))
+
+
 def device_count():
     n = ctypes.c_int(0)
     rc = load().picaso_device_count(ctypes.byref(n))
