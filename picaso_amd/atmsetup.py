@@ -126,6 +126,7 @@ class ATMSETUP:
     def get_clouds(self, wno):
         nwno = np.size(wno)
         prof = self.input["clouds"]["profile"]
+        self.cloud_free = prof is None
         if prof is None:
             z = np.zeros((self.c.nlayer, nwno))
             self.layer["cloud"] = {"w0": z, "g0": z.copy(), "opd": z.copy()}

@@ -46,6 +46,12 @@ class DeviceArray:
                                                  ctypes.c_size_t(self.nbytes)), self.ctx)
         return out
 
+    @classmethod
+    def zeros(cls, shape, ctx=None):
+        d = cls(shape, ctx)
+        d.zero()
+        return d
+
     def zero(self):
         _lib.check(_lib.load().picaso_memset(self.ctx, ctypes.c_void_p(self.addr), 0,
                                              ctypes.c_size_t(self.nbytes)), self.ctx)

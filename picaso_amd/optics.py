@@ -497,12 +497,19 @@ def compute_opacity_resident(atmosphere, opacityclass, ngauss=1, stream=2, delta
         raise Exception("raman='pollack' needs the reference's raman_fortran.txt table; use "
                         "'oklopcic' or 'none'")
     cld = atm.layer["cloud"]
-    taucld = np.zeros((nlayer, nwno)) + np.asarray(cld["opd"], dtype=float)
+
+    def plane(x):       # (nlayer, nwno) float64 without a copy when the caller already has one
+        a = np.asarray(x, dtype=float)
+        return a if a.shape == (nlayer, nwno) else np.ascontiguousarray(np.broadcast_to(a, (nlayer, nwno)))
+    taucld = plane(cld["opd"])
     if do_holes:
         taucld = fthin_cld * taucld                         # optics.py:314-315
-    d_cld = DeviceArray.from_host(taucld, ctx)
-    d_w0 = DeviceArray.from_host(np.zeros((nlayer, nwno)) + np.asarray(cld["w0"], dtype=float), ctx)
-    d_g0 = DeviceArray.from_host(np.zeros((nlayer, nwno)) + np.asarray(cld["g0"], dtype=float), ctx)
+    if getattr(atm, "cloud_free", False):                   # no cloud profile: zero planes, no PCIe
+        d_cld, d_w0, d_g0 = (DeviceArray.zeros((nlayer, nwno), ctx) for _ in range(3))
+    else:
+        d_cld = DeviceArray.from_host(taucld, ctx)
+        d_w0 = DeviceArray.from_host(plane(cld["w0"]), ctx)
+        d_g0 = DeviceArray.from_host(plane(cld["g0"]), ctx)
     tm = 0
     if test_mode is not None:      # optics.py:372 `test_mode != None`: anything but None, including the
         tm = 1 if test_mode == "rayleigh" else 2            # signature default False, is a test mode
@@ -527,7 +534,7 @@ def compute_opacity_resident(atmosphere, opacityclass, ngauss=1, stream=2, delta
     if full_output:
         atmosphere.taugas = taugas.to_host().reshape((nlayer, nwno, ngauss))
         atmosphere.tauray = np.repeat(tauray.to_host()[:, :, None], ngauss, axis=2)
-        atmosphere.taucld = np.repeat(taucld[:, :, None], ngauss, axis=2)
+        atmosphere.taucld = np.repeat(np.asarray(taucld)[:, :, None], ngauss, axis=2)
     return out
 
 

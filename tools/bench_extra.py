@@ -139,6 +139,54 @@ def main():
             ms = timeit(runsh, ctx, reps=5)
             ab = 8 * nwno * (9 * nlayer + 2 * (nlayer + 1) + 2 + 5 + 1)
             out["reflected_SH4_%d" % nwno] = dict(ms=ms, spectra_per_s=1e3 / ms, GBps_algorithmic=ab / ms / 1e6)
+    if only in (None, "e2e"):
+        # inputs.spectrum() end to end at 1e5 wavelengths x 90 layers: HBM-resident synthetic opacity
+        # tables (5 molecules x 40 (P,T) points, 2 CIA pairs), linear interpolation, cloud slab
+        from picaso_amd import justdoit as jdi
+        from picaso_amd import optics as px
+        nwno = 100000
+        wno = np.linspace(2000.0, 33333.0, nwno)
+        rng = np.random.default_rng(1)
+        temps = [100.0, 300.0, 700.0, 1500.0, 3000.0]
+        press = [1e-6, 1e-4, 1e-2, 1e-1, 1.0, 10.0, 100.0, 500.0]
+        pt, pid = [], 0
+        for t_ in temps:
+            for p_ in press:
+                pid += 1
+                pt.append((pid, p_, t_))
+        mols = ["H2O", "CH4", "CO", "NH3", "H2"]
+        molecular = {m: {i: 10.0 ** (-24.0 + 2.0 * np.sin(wno / 2500.0 + k) + 0.4 * np.log10(p_) + 0.8 * np.log10(t_ / 300.0))
+                         for (i, p_, t_) in pt} for k, m in enumerate(mols)}
+        cia_t = [75.0, 200.0, 500.0, 1000.0, 2000.0, 4000.0]
+        continuum = {pr: {t_: 10.0 ** (-7.0 + np.cos(wno / 4000.0 + k) + 0.3 * np.log10(t_ / 300.0)) for t_ in cia_t}
+                     for k, pr in enumerate(("H2H2", "H2He"))}
+        ray = {m: 1e-27 * (wno / 1e4) ** 4 for m in ("H2", "He")}
+        t0 = time.perf_counter()
+        opa = px.RetrieveOpacities(wno, pt, molecular, continuum, cia_t, rayleigh_opa=ray, query_method="linear", ctx=ctx)
+        t_tables = time.perf_counter() - t0
+        nlevel = 91
+        plev = np.logspace(-6, 2, nlevel)
+        prof = {"pressure": plev, "temperature": 150.0 + 1200.0 * ((np.log10(plev) + 6) / 8) ** 2,
+                "H2": np.full(nlevel, 0.84), "He": np.full(nlevel, 0.155), "H2O": np.full(nlevel, 1e-3),
+                "CH4": np.full(nlevel, 5e-4), "CO": np.full(nlevel, 1e-4), "NH3": np.full(nlevel, 1e-5)}
+        opd = np.zeros((nlevel - 1, nwno)); opd[50:60] = 0.3
+        w0c = np.zeros_like(opd); w0c[50:60] = 0.9
+        g0c = np.zeros_like(opd); g0c[50:60] = 0.6
+        case = jdi.inputs()
+        case.phase_angle(0)
+        case.gravity(gravity=2500.0)
+        case.atmosphere(df=prof)
+        case.clouds(df={"opd": opd, "w0": w0c, "g0": g0c})
+        case.approx(raman="none")
+        case.spectrum(opa, calculation="reflected+thermal")
+        ts = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            case.spectrum(opa, calculation="reflected+thermal")
+            ts.append(time.perf_counter() - t0)
+        out["spectrum_e2e_1e5"] = dict(table_upload_s=t_tables, spectrum_s=min(ts),
+                                       note="inputs.spectrum(reflected+thermal): host set-up, cloud planes H2D "
+                                            "(3 x 72 MB), opacity interpolation + mixing + both solvers on the GPU")
     print(json.dumps(out, indent=1))
 
 
