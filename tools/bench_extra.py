@@ -139,6 +139,17 @@ def main():
             ms = timeit(runsh, ctx, reps=5)
             ab = 8 * nwno * (9 * nlayer + 2 * (nlayer + 1) + 2 + 5 + 1)
             out["reflected_SH4_%d" % nwno] = dict(ms=ms, spectra_per_s=1e3 / ms, GBps_algorithmic=ab / ms / 1e6)
+    if only in (None, "copy"):
+        # measured HBM ceiling on this box: device-to-device copy of 2 GiB (read + write = 4 GiB of traffic)
+        import ctypes as _ct
+        from picaso_amd._lib import check as _check, load as _load
+        nbytes = 2 << 30
+        src, dst = DeviceArray((nbytes // 8,), ctx), DeviceArray((nbytes // 8,), ctx)
+        src.zero()
+        ms = timeit(lambda: _check(_load().picaso_memcpy_d2d(ctx, _ct.c_void_p(dst.addr), _ct.c_void_p(src.addr),
+                                                              _ct.c_size_t(nbytes)), ctx), ctx, reps=10)
+        out["hbm_copy_d2d_2GiB"] = dict(ms=ms, GBps_read_plus_write=2 * nbytes / ms / 1e6)
+        src.free(); dst.free()
     if only in (None, "e2e"):
         # inputs.spectrum() end to end at 1e5 wavelengths x 90 layers: HBM-resident synthetic opacity
         # tables (5 molecules x 40 (P,T) points, 2 CIA pairs), linear interpolation, cloud slab
