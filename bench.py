@@ -151,13 +151,14 @@ def main():
         abytes = algorithmic_bytes(nwno, nlayer, nang)
         kernel_ms = kernel_ms_total / args.steps
         achieved = abytes / (kernel_ms * 1e-3) / 1e9
-        traffic = None
+        traffic = valu = None
         tfile = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tfile):
             try:
-                traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
+                prof = json.load(open(tfile))
+                traffic, valu = prof.get("hbm_bytes_per_launch"), prof.get("valu_wave_insts_per_launch")
             except Exception:
-                traffic = None
+                traffic = valu = None
         out = {
             "metric": "spectra/sec (1e5 wave x 90 layer reflected)",
             "value": value, "unit": "spectra/s", "n_gpus": world, "steps": args.steps,
@@ -176,6 +177,14 @@ def main():
                          "kernel": "k_reflected_toa<%d,false>" % nang,
                          "kernel_ms": kernel_ms, "algorithmic_bytes": abytes},
         }
+        if valu and nwno == 100000 and nlayer == 90 and ng == 5:
+            # second ceiling: the kernel is FP64-VALU bound.  PMC instruction count of this launch shape
+            # (profiles/) over the live kernel time, against the fp64 issue rate measured on an MI355X
+            # with tools/ubench/f64_rates.hip (2.47 ns per wave64 instruction per SIMD, 1024 SIMDs)
+            rate = valu * 64 / (kernel_ms * 1e-3) / 1e12
+            peak = 1024 * 64 / 2.47e-9 / 1e12
+            out["fp64_issue"] = {"achieved": rate, "peak_measured": peak, "unit": "T lane-instr/s",
+                                 "frac": rate / peak, "valu_wave_insts_per_launch": valu}
         if world == 1 and args.cpu_sample > 0:
             from oracle import oracle as orc
             ns = min(args.cpu_sample, nwno)

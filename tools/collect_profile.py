@@ -33,8 +33,10 @@ with open(os.path.join(dst, name + "_pmc_summary.csv"), "w") as fh:
 # 2x on gfx950 (MI355X_MICROARCH.md, HBM / rocprofv3 section), collected in separate passes.
 fetch = [v / n for (k, c), (n, v) in agg.items() if c == "FETCH_SIZE" and "k_reflected_toa<5" in k]
 write = [v / n for (k, c), (n, v) in agg.items() if c == "WRITE_SIZE" and "k_reflected_toa<5" in k]
+valu = [v / n for (k, c), (n, v) in agg.items() if c == "SQ_INSTS_VALU" and "k_reflected_toa<5" in k]
 if fetch and write:
     json.dump({"hbm_bytes_per_launch": (2.0 * fetch[0] + write[0]) * 1024.0,
+               "valu_wave_insts_per_launch": valu[0] if valu else None,
                "source": "profiles/%s_pmc_summary.csv" % name,
                "note": "(2*FETCH_SIZE + WRITE_SIZE) KB per dispatch of k_reflected_toa<5,false,true>; "
                        "FETCH_SIZE doubled per the gfx950 correction in MI355X_MICROARCH.md"},
