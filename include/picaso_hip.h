@@ -44,6 +44,9 @@ const char *picaso_version(void);
 
 int picaso_dev_malloc(picaso_ctx *ctx, size_t bytes, void **dptr);
 int picaso_dev_free(picaso_ctx *ctx, void *dptr);
+/* picaso_dev_free keeps blocks for reuse by later picaso_dev_malloc calls of the same size (reuse is
+ * ordered on the context's stream); this returns all cached blocks to the driver. */
+int picaso_pool_trim(picaso_ctx *ctx);
 int picaso_memcpy_h2d(picaso_ctx *ctx, void *dst, const void *src, size_t bytes);
 int picaso_memcpy_d2h(picaso_ctx *ctx, void *dst, const void *src, size_t bytes);
 int picaso_memcpy_d2d(picaso_ctx *ctx, void *dst, const void *src, size_t bytes);

@@ -127,9 +127,9 @@ class ATMSETUP:
         nwno = np.size(wno)
         prof = self.input["clouds"]["profile"]
         self.cloud_free = prof is None
-        if prof is None:
-            z = np.zeros((self.c.nlayer, nwno))
-            self.layer["cloud"] = {"w0": z, "g0": z.copy(), "opd": z.copy()}
+        if prof is None:       # (nlayer, nwno) zeros as read-only broadcast views: no 3 x 72 MB host arrays
+            z = np.broadcast_to(np.zeros((self.c.nlayer, 1)), (self.c.nlayer, nwno))
+            self.layer["cloud"] = {"w0": z, "g0": z, "opd": z}
             return
         in_wno = self.input["clouds"]["wavenumber"]
         cld = {}

@@ -161,6 +161,8 @@ void picaso_ctx_destroy(picaso_ctx *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    for (auto &kv : ctx->pool) (void)hipFree(kv.second);
+    for (auto &kv : ctx->live) (void)hipFree(kv.first);
     if (ctx->arena) (void)hipFree(ctx->arena);
     if (ctx->lvl_scratch) (void)hipFree(ctx->lvl_scratch);
     if (ctx->ck_scratch) (void)hipFree(ctx->ck_scratch);
@@ -174,17 +176,57 @@ void picaso_ctx_destroy(picaso_ctx *ctx)
     delete ctx;
 }
 
+static int pool_release_all(picaso_ctx *ctx)
+{
+    if (ctx->pool.empty()) return 0;
+    PZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (auto &kv : ctx->pool) (void)hipFree(kv.second);
+    ctx->pool.clear();
+    ctx->pool_bytes = 0;
+    return 0;
+}
+
 int picaso_dev_malloc(picaso_ctx *ctx, size_t bytes, void **dptr)
 {
     PZ_HIP(ctx, hipSetDevice(ctx->device));
-    PZ_HIP(ctx, hipMalloc(dptr, bytes ? bytes : 8));
+    const size_t size = align_up(bytes ? bytes : 8, 256);
+    auto it = ctx->pool.find(size);
+    if (it != ctx->pool.end()) {
+        *dptr = it->second;
+        ctx->pool.erase(it);
+        ctx->pool_bytes -= size;
+    } else {
+        hipError_t e = hipMalloc(dptr, size);
+        if (e != hipSuccess) {                       // out of memory: give the cached blocks back, retry
+            (void)hipGetLastError();
+            PZ_TRY(pool_release_all(ctx));
+            PZ_HIP(ctx, hipMalloc(dptr, size));
+        }
+    }
+    ctx->live[*dptr] = size;
     return 0;
 }
 int picaso_dev_free(picaso_ctx *ctx, void *dptr)
 {
-    PZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    PZ_HIP(ctx, hipFree(dptr));
+    if (!dptr) return 0;
+    auto it = ctx->live.find(dptr);
+    if (it == ctx->live.end()) return fail(ctx, "picaso_dev_free: %p was not allocated by picaso_dev_malloc", dptr);
+    const size_t size = it->second;
+    ctx->live.erase(it);
+    if (ctx->pool_bytes + size > picaso_ctx::POOL_CAP) {
+        PZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        PZ_HIP(ctx, hipFree(dptr));
+        return 0;
+    }
+    ctx->pool.emplace(size, dptr);
+    ctx->pool_bytes += size;
     return 0;
+}
+int picaso_pool_trim(picaso_ctx *ctx)
+{
+    if (!ctx) return fail(nullptr, "null context");
+    PZ_HIP(ctx, hipSetDevice(ctx->device));
+    return pool_release_all(ctx);
 }
 int picaso_memcpy_h2d(picaso_ctx *ctx, void *dst, const void *src, size_t bytes)
 {

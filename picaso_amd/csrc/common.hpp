@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <unordered_map>
+
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -31,6 +33,13 @@ struct picaso_ctx {
     size_t lvl_scratch_bytes = 0;
     double *ck_scratch = nullptr;          // per-column results of a correlated-k batch before the Gauss sum
     size_t ck_scratch_bytes = 0;
+    // picaso_dev_malloc / picaso_dev_free keep released blocks for reuse (hipFree synchronises the
+    // device and costs ~0.5 ms; a spectrum() call releases a few dozen planes).  Reuse is safe
+    // without a synchronisation because every access to library-owned memory is ordered on `stream`.
+    std::unordered_multimap<size_t, void *> pool;      // size -> free block
+    std::unordered_map<void *, size_t> live;           // block -> size
+    size_t pool_bytes = 0;
+    static constexpr size_t POOL_CAP = 64ull << 30;    // cached (free) bytes kept at most
 };
 
 namespace pz {

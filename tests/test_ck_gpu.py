@@ -151,3 +151,20 @@ def test_axpby_blend():
     dx, dy, do = DeviceArray.from_host(x, ctx), DeviceArray.from_host(y, ctx), DeviceArray((1001,), ctx)
     resident.axpby(ctx, 0.7, dx, 0.3, dy, do)
     assert np.array_equal(do.to_host(), 0.7 * x + 0.3 * y)
+
+
+def test_device_block_reuse():
+    """Released device blocks are reused (no hipFree / hipMalloc per call) and can be trimmed."""
+    import ctypes
+    from picaso_amd import _lib
+    from picaso_amd.device import DeviceArray
+    ctx = _lib.context()
+    a = DeviceArray((12345,), ctx)
+    addr = a.addr
+    a.free()
+    b = DeviceArray((12345,), ctx)
+    assert b.addr == addr
+    b.free()
+    _lib.check(_lib.load().picaso_pool_trim(ctx), ctx)
+    with pytest.raises(_lib.PicasoHipError):
+        _lib.check(_lib.load().picaso_dev_free(ctx, ctypes.c_void_p(0x1000)), ctx)

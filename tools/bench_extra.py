@@ -195,6 +195,18 @@ def main():
             t0 = time.perf_counter()
             case.spectrum(opa, calculation="reflected+thermal")
             ts.append(time.perf_counter() - t0)
+        clear = jdi.inputs()
+        clear.phase_angle(0)
+        clear.gravity(gravity=2500.0)
+        clear.atmosphere(df=prof)
+        clear.approx(raman="none")
+        clear.spectrum(opa, calculation="reflected+thermal")
+        tc = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            clear.spectrum(opa, calculation="reflected+thermal")
+            tc.append(time.perf_counter() - t0)
+        out["spectrum_e2e_1e5_cloud_free"] = dict(spectrum_s=min(tc))
         out["spectrum_e2e_1e5"] = dict(table_upload_s=t_tables, spectrum_s=min(ts),
                                        note="inputs.spectrum(reflected+thermal): host set-up, cloud planes H2D "
                                             "(3 x 72 MB), opacity interpolation + mixing + both solvers on the GPU")
