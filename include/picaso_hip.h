@@ -343,18 +343,19 @@ int picaso_compute_opacity_ck_dev(picaso_ctx *ctx, int nlayer, int nwno, int nga
                                   double *tau_og, double *w0_og, double *cosb_og, double *w0_no_raman,
                                   double *f_deltaM);
 
-/* Facet form for the 3-D path (reference picaso/justdoit.py:444-471: `DTAU_3d[:,:,g,t,:] = dtau` per
- * facet): inputs are one facet's (nlayer, nwno) optical depths, the 13 outputs are the
- * (nlayer|nlevel, nwno, nfacets) planes picaso_get_reflected_3d / _thermal_3d take (facet index
- * fastest); this call fills facet `facet` of them. */
-int picaso_compute_opacity_facet_dev(picaso_ctx *ctx, int nlayer, int nwno, int nfacets, int facet,
-                                     const double *taugas, const double *tauray, const double *taucld,
-                                     const double *w0_cld, const double *g0_cld, const double *raman_factor,
-                                     double raman_const, int test_mode, int delta_eddington, int stream,
-                                     double *dtau, double *tau, double *w0, double *cosb,
-                                     double *ftau_cld, double *ftau_ray, double *gcos2, double *dtau_og,
-                                     double *tau_og, double *w0_og, double *cosb_og, double *w0_no_raman,
-                                     double *f_deltaM);
+/* 3-D path (reference picaso/justdoit.py:444-471 fills `DTAU_3d[:,:,g,t,:] = dtau` facet by facet):
+ * one launch mixes all facets.  taugas, tauray (and raman_factor when non-NULL) are facet-major
+ * (nfacets, nlayer, nwno) -- picaso_opacity_gas_dev is called once per facet on its slice -- the cloud
+ * inputs are (nlayer, nwno, nfacets) as the caller holds them (NULL = no cloud), and the 13 outputs are
+ * the (nlayer|nlevel, nwno, nfacets) planes picaso_get_reflected_3d / _thermal_3d take. */
+int picaso_compute_opacity_facets_dev(picaso_ctx *ctx, int nlayer, int nwno, int nfacets,
+                                      const double *taugas, const double *tauray, const double *taucld,
+                                      const double *w0_cld, const double *g0_cld, const double *raman_factor,
+                                      double raman_const, int test_mode, int delta_eddington, int stream,
+                                      double *dtau, double *tau, double *w0, double *cosb,
+                                      double *ftau_cld, double *ftau_ray, double *gcos2, double *dtau_og,
+                                      double *tau_og, double *w0_og, double *cosb_og, double *w0_no_raman,
+                                      double *f_deltaM);
 
 #ifdef __cplusplus
 }

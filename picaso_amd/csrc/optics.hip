@@ -70,8 +70,10 @@ __global__ __launch_bounds__(256) void k_opacity_gas(const GasArgs a)
 struct MixArgs {
     int nlayer, nwno, test_mode, delta_eddington, stream;
     int ncolper;      // columns per wavelength of taugas and of every output (tauray, cloud, raman have none)
-    long ostride, ooff;   // outputs are written at element index*ostride + ooff: facet `ooff` of the
-                          // (rows, nwno, nfacets) planes get_reflected_3d takes (1, 0 otherwise)
+    int nfac;         // > 1: 3-D facet mode.  Columns are (wavelength, facet) with the facet fastest -- the
+                      // layout of the (rows, nwno, ng, nt) planes get_reflected_3d takes and of the cloud
+                      // inputs; taugas / tauray / raman are facet-major (nfac, nlayer, nwno), as the per-facet
+                      // gas launches write them (ncolper must be 1)
     const double *taugas, *tauray, *taucld, *w0c, *g0c, *raman;
     double raman_const;
     double *dtau, *tau, *w0, *cosb, *ftau_cld, *ftau_ray, *gcos2, *dtau_og, *tau_og, *w0_og,
@@ -85,18 +87,26 @@ __device__ __forceinline__ double ipow(double x, int n)
     return r;
 }
 
-__global__ __launch_bounds__(256) void k_compute_opacity(const MixArgs a)
+__global__ __launch_bounds__(1024) void k_compute_opacity(const MixArgs a)
 {
     const long col = blockIdx.x * (long)blockDim.x + threadIdx.x;
-    const long nw = a.nwno, ncol = nw * a.ncolper;
+    const bool facets = a.nfac > 1;
+    const long nw = a.nwno, ncol = nw * (facets ? a.nfac : a.ncolper);
     if (col >= ncol) return;
-    const long w = (a.ncolper > 1) ? col / a.ncolper : col;
+    const long w = facets ? col / a.nfac : ((a.ncolper > 1) ? col / a.ncolper : col);
+    const long fbase = facets ? (col - w * a.nfac) * a.nlayer : 0;     // facet-major row block of this column
     double tau_run = 0.0, taud_run = 0.0;
-    a.tau_og[col * a.ostride + a.ooff] = 0.0;
-    a.tau[col * a.ostride + a.ooff] = 0.0;
+    a.tau_og[col] = 0.0;
+    a.tau[col] = 0.0;
     for (int i = 0; i < a.nlayer; ++i) {
-        const long o = (long)i * ncol + col, ow = (long)i * nw + w;
-        const double tg = a.taugas[o], tr = a.tauray[ow], tc = a.taucld[ow], wc = a.w0c[ow], gc = a.g0c[ow];
+        const long o = (long)i * ncol + col;
+        // gas / Rayleigh / Raman: per wavelength (monochromatic), per column (correlated-k) or per
+        // (facet, layer) row; cloud: per wavelength, or per column in facet mode (NULL = no cloud)
+        const long og = facets ? (fbase + i) * nw + w : o;
+        const long ow = facets ? og : (long)i * nw + w;
+        const long oc = facets ? o : (long)i * nw + w;
+        const double tg = a.taugas[og], tr = a.tauray[ow];
+        const double tc = a.taucld ? a.taucld[oc] : 0.0, wc = a.w0c ? a.w0c[oc] : 0.0, gc = a.g0c ? a.g0c[oc] : 0.0;
         const double rf = a.raman ? a.raman[ow] : a.raman_const;
         double dtau = tg + tr + tc;                                     // optics.py:329
         double fcld = (wc * tc) / (wc * tc + tr);                       // :335
@@ -117,7 +127,7 @@ __global__ __launch_bounds__(256) void k_compute_opacity(const MixArgs a)
             w0nr = w0;
         }
         tau_run += dtau;                                                // numba_cumsum (:353-354)
-        const long q = o * a.ostride + a.ooff, qn = (o + ncol) * a.ostride + a.ooff;
+        const long q = o, qn = o + ncol;
         a.dtau_og[q] = dtau; a.tau_og[qn] = tau_run; a.w0_og[q] = w0; a.cosb_og[q] = cosb;
         a.ftau_cld[q] = fcld; a.ftau_ray[q] = fray; a.gcos2[q] = gcos2; a.w0_no_raman[q] = w0nr;
         if (a.delta_eddington) {                                        // :401-420
@@ -231,7 +241,7 @@ int picaso_compute_opacity_ck_dev(picaso_ctx *ctx, int nlayer, int nwno, int nga
     if (stream != 2 && stream != 4) return fail(ctx, "compute_opacity: stream must be 2 or 4");
     PZ_HIP(ctx, hipSetDevice(ctx->device));
     MixArgs a{};
-    a.nlayer = nlayer; a.nwno = nwno; a.ncolper = ngauss; a.ostride = 1; a.ooff = 0; a.test_mode = test_mode;
+    a.nlayer = nlayer; a.nwno = nwno; a.ncolper = ngauss; a.nfac = 0; a.test_mode = test_mode;
     a.delta_eddington = delta_eddington;
     a.stream = stream; a.taugas = taugas; a.tauray = tauray; a.taucld = taucld; a.w0c = w0_cld;
     a.g0c = g0_cld; a.raman = raman_factor; a.raman_const = raman_const;
@@ -246,31 +256,33 @@ int picaso_compute_opacity_ck_dev(picaso_ctx *ctx, int nlayer, int nwno, int nga
     return 0;
 }
 
-int picaso_compute_opacity_facet_dev(picaso_ctx *ctx, int nlayer, int nwno, int nfacets, int facet,
-                                     const double *taugas, const double *tauray, const double *taucld,
-                                     const double *w0_cld, const double *g0_cld, const double *raman_factor,
-                                     double raman_const, int test_mode, int delta_eddington, int stream,
-                                     double *dtau, double *tau, double *w0, double *cosb,
-                                     double *ftau_cld, double *ftau_ray, double *gcos2, double *dtau_og,
-                                     double *tau_og, double *w0_og, double *cosb_og, double *w0_no_raman,
-                                     double *f_deltaM)
+int picaso_compute_opacity_facets_dev(picaso_ctx *ctx, int nlayer, int nwno, int nfacets,
+                                      const double *taugas, const double *tauray, const double *taucld,
+                                      const double *w0_cld, const double *g0_cld, const double *raman_factor,
+                                      double raman_const, int test_mode, int delta_eddington, int stream,
+                                      double *dtau, double *tau, double *w0, double *cosb,
+                                      double *ftau_cld, double *ftau_ray, double *gcos2, double *dtau_og,
+                                      double *tau_og, double *w0_og, double *cosb_og, double *w0_no_raman,
+                                      double *f_deltaM)
 {
     if (!ctx) return fail(nullptr, "null context");
-    if (nlayer < 1 || nwno < 1) return fail(ctx, "compute_opacity: bad sizes");
-    if (nfacets < 1 || facet < 0 || facet >= nfacets) return fail(ctx, "compute_opacity: facet %d of %d", facet, nfacets);
+    if (nlayer < 1 || nwno < 1 || nfacets < 1) return fail(ctx, "compute_opacity: bad sizes");
     if (test_mode < 0 || test_mode > 2) return fail(ctx, "compute_opacity: test_mode must be 0, 1 or 2");
     if (stream != 2 && stream != 4) return fail(ctx, "compute_opacity: stream must be 2 or 4");
     PZ_HIP(ctx, hipSetDevice(ctx->device));
     MixArgs a{};
-    a.nlayer = nlayer; a.nwno = nwno; a.ncolper = 1; a.ostride = nfacets; a.ooff = facet;
+    a.nlayer = nlayer; a.nwno = nwno; a.ncolper = 1; a.nfac = nfacets > 1 ? nfacets : 0;
     a.test_mode = test_mode; a.delta_eddington = delta_eddington;
     a.stream = stream; a.taugas = taugas; a.tauray = tauray; a.taucld = taucld; a.w0c = w0_cld;
     a.g0c = g0_cld; a.raman = raman_factor; a.raman_const = raman_const;
     a.dtau = dtau; a.tau = tau; a.w0 = w0; a.cosb = cosb; a.ftau_cld = ftau_cld; a.ftau_ray = ftau_ray;
     a.gcos2 = gcos2; a.dtau_og = dtau_og; a.tau_og = tau_og; a.w0_og = w0_og; a.cosb_og = cosb_og;
     a.w0_no_raman = w0_no_raman; a.f_deltaM = f_deltaM;
-    const int block = 256;
-    hipLaunchKernelGGL(k_compute_opacity, dim3((unsigned)((nwno + block - 1) / block)), dim3(block), 0,
+    // 1024-thread blocks = 16 wavelengths x 64 facets: the facet-major gas rows are read 8 bytes per
+    // lane, and the 16 waves of a block consume each 128-byte line they touch
+    const int block = 1024;
+    const long ncol = (long)nwno * nfacets;
+    hipLaunchKernelGGL(k_compute_opacity, dim3((unsigned)((ncol + block - 1) / block)), dim3(block), 0,
                        ctx->stream, a);
     PZ_HIP(ctx, hipGetLastError());
     return 0;

@@ -56,10 +56,20 @@ class DeviceArray:
         _lib.check(_lib.load().picaso_memset(self.ctx, ctypes.c_void_p(self.addr), 0,
                                              ctypes.c_size_t(self.nbytes)), self.ctx)
 
+    def row_block(self, index):
+        """Non-owning view of ``self[index]`` (leading axis) -- e.g. one facet of a facet-major stack."""
+        v = DeviceArray.__new__(DeviceArray)
+        v.ctx, v.shape = self.ctx, self.shape[1:]
+        v.size = int(np.prod(v.shape))
+        v.nbytes = v.size * 8
+        v.addr = self.addr + int(index) * v.nbytes
+        v._owner = self            # keeps the parent alive; views are never freed
+        return v
+
     def free(self):
-        if self.addr:
+        if self.addr and not hasattr(self, "_owner"):
             _lib.load().picaso_dev_free(self.ctx, ctypes.c_void_p(self.addr))
-            self.addr = 0
+        self.addr = 0
 
     def __del__(self):
         try:

@@ -291,25 +291,20 @@ def picaso(bundle, opacityclass, dimension="1d", calculation="reflected", full_o
                             "no patchy clouds and no level fluxes")
         prof3 = inp["atmosphere"]["profile_3d"]
         cld3 = inp["clouds"].get("profile_3d")
-        atm = None
+        atms = []
         for g in range(ng):
+            row = []
             for t in range(nt):
                 prof = {k: (v if v.ndim == 1 else v[:, g, t]) for k, v in prof3.items()}
-                cld = None if cld3 is None else {k: np.asarray(cld3[k])[:, :, g, t] for k in ("opd", "w0", "g0")}
-                atm_f = _setup_atmosphere(inp, opa, wno, prof, cld)
-                if atm is None:
-                    atm = atm_f
-                    nl3 = atm.c.nlayer
-                    planes3d = {k: DeviceArray(((nl3 + 1 if k in ("tau", "tau_og") else nl3), nwno, ng, nt), ctx)
-                                for k in optics.OUT_NAMES}
-                    tlev3, plev3 = np.zeros((nl3 + 1, ng, nt)), np.zeros((nl3 + 1, ng, nt))
-                opa.get_opacities(atm_f, exclude_mol=inp["atmosphere"]["exclude_mol"])
-                optics.compute_opacity_resident(
-                    atm_f, opa, ngauss=1, stream=common["stream"], delta_eddington=common["delta_eddington"],
-                    test_mode=inp["test_mode"], raman=common["raman"], facet=(g * nt + t, ng * nt),
-                    out=planes3d)
-                tlev3[:, g, t] = atm_f.level["temperature"]
-                plev3[:, g, t] = atm_f.level["pressure"]
+                row.append(_setup_atmosphere(inp, opa, wno, prof, None))
+            atms.append(row)
+        atm = atms[0][0]
+        planes3d = optics.compute_opacity_facets(
+            atms, opa, ng, nt, stream=common["stream"], delta_eddington=common["delta_eddington"],
+            test_mode=inp["test_mode"], raman=common["raman"], clouds_3d=cld3,
+            exclude_mol=inp["atmosphere"]["exclude_mol"])
+        tlev3 = np.stack([np.stack([a_.level["temperature"] for a_ in row], axis=1) for row in atms], axis=1)
+        plev3 = np.stack([np.stack([a_.level["pressure"] for a_ in row], axis=1) for row in atms], axis=1)
     else:
         atm = _setup_atmosphere(inp, opa, wno)
     nlevel, nlayer = atm.c.nlevel, atm.c.nlayer

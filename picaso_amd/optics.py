@@ -450,26 +450,12 @@ def _layer_factors(atm, opacityclass):
             ray_names, np.array(ray_fac).reshape((-1, nlayer)) if ray_fac else np.zeros(shape))
 
 
-def compute_opacity_resident(atmosphere, opacityclass, ngauss=1, stream=2, delta_eddington=True,
-                             test_mode=None, raman=0, fthin_cld=None, do_holes=False,
-                             full_output=False, facet=None, out=None):
-    """GPU ``compute_opacity`` returning a dict of the 13 planes as DeviceArrays: ``(rows, nwno)``
-    for monochromatic opacities, ``(rows, nwno, ngauss)`` (reference layout, optics.py:423-431)
-    for correlated-k tables.  3-D path: ``facet=(index, nfacets)`` and ``out`` = dict of
-    ``(rows, nwno, numg, numt)`` DeviceArrays fills that facet of the planes ``get_reflected_3d``
-    takes (reference justdoit.py:444-471)."""
-    atm, opa = atmosphere, opacityclass
-    if ngauss != opa.ngauss:
-        raise Exception("compute_opacity: ngauss=%d but the opacity tables have %d Gauss points"
-                        % (ngauss, opa.ngauss))
-    ctx = opa.ctx
-    nlayer, nwno = atm.c.nlayer, opa.nwno
-    if opa._plan is None or opa._plan["nlayer"] != nlayer:
-        raise Exception("call opacityclass.get_opacities(atmosphere) first")
+def gas_stage(atm, opa, taugas, tauray):
+    """TAUGAS / TAURAY of one atmosphere into the given device planes (``k_opacity_gas``): table rows
+    and weights from ``opa.get_opacities(atm)``, per-layer coefficients of reference optics.py:144-277."""
     pl = opa._plan
-    gshape = (nwno,) if ngauss == 1 else (nwno, ngauss)
+    nlayer, ngauss = atm.c.nlayer, opa.ngauss
     mol_fac, cont_fac, ray_names, ray_fac = _layer_factors(atm, opa)
-    taugas, tauray = DeviceArray((nlayer,) + gshape, ctx), DeviceArray((nlayer, nwno), ctx)
     cont_tabs = [opa._cia[p] for p in pl["cia_pairs"]]
     if pl.get("premixed"):
         mol_tabs, mol_mode = [opa._kappa], 2
@@ -486,16 +472,82 @@ def compute_opacity_resident(atmosphere, opacityclass, ngauss=1, stream=2, delta
               cont_fac if cont_tabs else None, [opa._ray[m] for m in ray_names],
               ray_fac if ray_names else None, taugas, tauray, mol_mode=mol_mode, cont_wts=cont_wts,
               ngauss=ngauss)
-    # ---- Raman factor (host: once per atmosphere, optics.py:285-306) ----
-    raman_plane, raman_const = None, 0.99999
+
+
+def raman_plane_host(atm, opa, raman):
+    """Raman factor plane on the host (once per atmosphere, reference optics.py:285-306) or None."""
     if raman == 0:
-        rf = compute_raman(nwno, nlayer, opa.wno, opa.raman_stellar_shifts,
+        rf = compute_raman(opa.nwno, atm.c.nlayer, opa.wno, opa.raman_stellar_shifts,
                            np.asarray(atm.layer["temperature"], dtype=float), opa.raman_db["c"],
                            opa.raman_db["ji"], opa.raman_db["deltanu"])
-        raman_plane = DeviceArray.from_host(np.minimum(rf, 0.99999), ctx)
-    elif raman == 1:
+        return np.minimum(rf, 0.99999)
+    if raman == 1:
         raise Exception("raman='pollack' needs the reference's raman_fortran.txt table; use "
                         "'oklopcic' or 'none'")
+    return None
+
+
+def compute_opacity_facets(atms, opacityclass, numg, numt, stream=2, delta_eddington=True, test_mode=None,
+                           raman=0, clouds_3d=None, exclude_mol=1):
+    """3-D path: the 13 ``(nlayer|nlevel, nwno, numg, numt)`` planes ``get_reflected_3d`` /
+    ``get_thermal_3d`` take, from one atmosphere per facet (``atms[g][t]``; reference
+    justdoit.py:444-471).  Gas + Rayleigh optical depths are gathered facet by facet into a
+    facet-major stack; one launch then mixes all facets (cloud inputs ``(nlayer, nwno, numg, numt)``
+    arrays ``opd``/``w0``/``g0`` or None) and writes the planes with the facet index fastest."""
+    opa = opacityclass
+    ctx = opa.ctx
+    nfac = numg * numt
+    nlayer, nwno = atms[0][0].c.nlayer, opa.nwno
+    if opa.ngauss != 1:
+        raise Exception("compute_opacity_facets takes monochromatic opacities")
+    tg3, tr3 = DeviceArray((nfac, nlayer, nwno), ctx), DeviceArray((nfac, nlayer, nwno), ctx)
+    rf3 = [] if raman == 0 else None
+    for g in range(numg):
+        for t in range(numt):
+            f = g * numt + t
+            opa.get_opacities(atms[g][t], exclude_mol=exclude_mol)
+            gas_stage(atms[g][t], opa, tg3.row_block(f), tr3.row_block(f))
+            if rf3 is not None:
+                rf3.append(raman_plane_host(atms[g][t], opa, raman))
+    if raman == 1:
+        raman_plane_host(atms[0][0], opa, raman)
+    d_rf = DeviceArray.from_host(np.stack(rf3), ctx) if rf3 else None
+    d_c = [None, None, None]
+    if clouds_3d is not None:
+        d_c = [DeviceArray.from_host(np.asarray(clouds_3d[k], dtype=float).reshape(nlayer, nwno, nfac), ctx)
+               for k in ("opd", "w0", "g0")]
+    tm = 0
+    if test_mode is not None:
+        tm = 1 if test_mode == "rayleigh" else 2
+    out = {k: DeviceArray(((nlayer + 1 if k in ("tau", "tau_og") else nlayer), nwno, numg, numt), ctx)
+           for k in OUT_NAMES}
+    check(load().picaso_compute_opacity_facets_dev(
+        ctx, _ci(nlayer), _ci(nwno), _ci(nfac), ptr(tg3.addr), ptr(tr3.addr),
+        *[ptr(d.addr) if d is not None else None for d in d_c], ptr(d_rf.addr) if d_rf is not None else None,
+        _cd(0.99999), _ci(tm), _ci(1 if delta_eddington else 0), _ci(stream),
+        *[ptr(out[k].addr) for k in OUT_NAMES]), ctx)
+    return out
+
+
+def compute_opacity_resident(atmosphere, opacityclass, ngauss=1, stream=2, delta_eddington=True,
+                             test_mode=None, raman=0, fthin_cld=None, do_holes=False,
+                             full_output=False):
+    """GPU ``compute_opacity`` returning a dict of the 13 planes as DeviceArrays: ``(rows, nwno)``
+    for monochromatic opacities, ``(rows, nwno, ngauss)`` (reference layout, optics.py:423-431)
+    for correlated-k tables.  (3-D path: ``compute_opacity_facets``.)"""
+    atm, opa = atmosphere, opacityclass
+    if ngauss != opa.ngauss:
+        raise Exception("compute_opacity: ngauss=%d but the opacity tables have %d Gauss points"
+                        % (ngauss, opa.ngauss))
+    ctx = opa.ctx
+    nlayer, nwno = atm.c.nlayer, opa.nwno
+    if opa._plan is None or opa._plan["nlayer"] != nlayer:
+        raise Exception("call opacityclass.get_opacities(atmosphere) first")
+    gshape = (nwno,) if ngauss == 1 else (nwno, ngauss)
+    taugas, tauray = DeviceArray((nlayer,) + gshape, ctx), DeviceArray((nlayer, nwno), ctx)
+    gas_stage(atm, opa, taugas, tauray)
+    rf_host = raman_plane_host(atm, opa, raman)
+    raman_plane, raman_const = (DeviceArray.from_host(rf_host, ctx) if rf_host is not None else None), 0.99999
     cld = atm.layer["cloud"]
 
     def plane(x):       # (nlayer, nwno) float64 without a copy when the caller already has one
@@ -513,15 +565,6 @@ def compute_opacity_resident(atmosphere, opacityclass, ngauss=1, stream=2, delta
     tm = 0
     if test_mode is not None:      # optics.py:372 `test_mode != None`: anything but None, including the
         tm = 1 if test_mode == "rayleigh" else 2            # signature default False, is a test mode
-    if facet is not None:
-        if ngauss != 1:
-            raise Exception("compute_opacity: the 3-D facet form takes monochromatic opacities")
-        check(load().picaso_compute_opacity_facet_dev(
-            ctx, _ci(nlayer), _ci(nwno), _ci(facet[1]), _ci(facet[0]), ptr(taugas.addr), ptr(tauray.addr),
-            ptr(d_cld.addr), ptr(d_w0.addr), ptr(d_g0.addr), ptr(raman_plane.addr) if raman_plane else None,
-            _cd(raman_const), _ci(tm), _ci(1 if delta_eddington else 0), _ci(stream),
-            *[ptr(out[k].addr) for k in OUT_NAMES]), ctx)
-        return out
     out = {}
     for k in OUT_NAMES:
         rows = nlayer + 1 if k in ("tau", "tau_og") else nlayer
