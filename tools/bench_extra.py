@@ -207,6 +207,27 @@ def main():
             clear.spectrum(opa, calculation="reflected+thermal")
             tc.append(time.perf_counter() - t0)
         out["spectrum_e2e_1e5_cloud_free"] = dict(spectrum_s=min(tc))
+        # BASELINE configs[4] per-GPU shard: 8 x 8 facets x 12 500 wavelengths x 90 layers, per-facet T
+        nw3 = 12500
+        opa3 = px.RetrieveOpacities(wno[::8], pt, {m: {i: v[::8] for i, v in d_.items()} for m, d_ in molecular.items()},
+                                    {p_: {t_: v[::8] for t_, v in d_.items()} for p_, d_ in continuum.items()}, cia_t,
+                                    rayleigh_opa={m: v[::8] for m, v in ray.items()}, query_method="linear", ctx=ctx)
+        ng3 = nt3 = 8
+        prof3 = {k: v for k, v in prof.items()}
+        pert = 1.0 + 0.1 * np.cos(np.arange(64).reshape(8, 8))
+        prof3["temperature"] = prof["temperature"][:, None, None] * pert[None]
+        c3 = jdi.inputs()
+        c3.phase_angle(np.pi / 3, num_gangle=ng3, num_tangle=nt3)
+        c3.gravity(gravity=2500.0)
+        c3.atmosphere_3d(prof3)
+        c3.approx(raman="none")
+        c3.spectrum(opa3, calculation="reflected+thermal", dimension="3d")
+        t3 = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            c3.spectrum(opa3, calculation="reflected+thermal", dimension="3d")
+            t3.append(time.perf_counter() - t0)
+        out["spectrum_3d_e2e_8x8x%d" % opa3.nwno] = dict(spectrum_s=min(t3))
         out["spectrum_e2e_1e5"] = dict(table_upload_s=t_tables, spectrum_s=min(ts),
                                        note="inputs.spectrum(reflected+thermal): host set-up, cloud planes H2D "
                                             "(3 x 72 MB), opacity interpolation + mixing + both solvers on the GPU")
