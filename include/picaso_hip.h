@@ -163,8 +163,10 @@ int picaso_get_thermal_3d_dev(picaso_ctx *ctx, int nlevel, const double *wno, in
 /* ---- spherical harmonics (SH2 / SH4) ------------------------------------------------------- */
 /* replaces fluxes.get_reflected_SH with setup_2/4_stream_fluxes + solve_4_stream_banded (reference
  * picaso/fluxes.py:2675-2976, :3189-3628).  stream = 2 or 4.  Output xint_at_top (numg,numt,nwno);
- * the reference's second return value `flux` is zeros unless flx=1, which is not built (flx must
- * be 0).  `compound_f_deltaM` = 1 reproduces the reference's in-place multiplication of f_deltaM
+ * with flx=1 also the reference's second return value `flux` (numg,numt,stream*nlevel,nwno), the
+ * layer moment fluxes F.X + G of calculate_flux (fluxes.py:3631-3635): per level the downward
+ * moments then the upward ones, at the top of layer 0 and the bottom of every layer (pass NULL with
+ * flx=0).  `compound_f_deltaM` = 1 reproduces the reference's in-place multiplication of f_deltaM
  * once per angle in the TTHG branch (fluxes.py:2823-2824; angle k sees f_deltaM*fac^(k+1));
  * 0 gives the non-compounding variant.  The library never writes to f_deltaM. */
 int picaso_get_reflected_SH(picaso_ctx *ctx, int nlevel, int nwno, int numg, int numt,
@@ -177,7 +179,8 @@ int picaso_get_reflected_SH(picaso_ctx *ctx, int nlevel, int nwno, int numg, int
                             int psingle_form, int w_single_rayleigh, int w_multi_rayleigh,
                             int psingle_rayleigh, double frac_a, double frac_b, double frac_c,
                             double constant_back, double constant_forward, int stream, double b_top,
-                            int flx, int single_form, int compound_f_deltaM, double *xint_at_top);
+                            int flx, int single_form, int compound_f_deltaM, double *xint_at_top,
+                            double *flux);
 int picaso_get_reflected_SH_dev(picaso_ctx *ctx, int nlevel, int nwno, long plane_pitch, int numg,
                                 int numt, const double *dtau, const double *tau, const double *w0,
                                 const double *cosb, const double *ftau_cld, const double *ftau_ray,
@@ -190,7 +193,8 @@ int picaso_get_reflected_SH_dev(picaso_ctx *ctx, int nlevel, int nwno, long plan
                                 double frac_a, double frac_b, double frac_c, double constant_back,
                                 double constant_forward, int stream, double b_top, int flx,
                                 int single_form, int compound_f_deltaM, double *xint_at_top,
-                                const double *gweight, const double *tweight, double *albedo);
+                                double *flux, const double *gweight, const double *tweight,
+                                double *albedo);
 
 /* replaces fluxes.get_thermal_SH (reference picaso/fluxes.py:2979-3186), flx = 0.  Of the
  * reference's arguments only tlevel, dtau, w0, cosb_og, plevel, ubar1, surf_reflect are read by

@@ -163,8 +163,6 @@ def get_reflected_SH(nlevel, nwno, numg, numt, dtau, tau, w0, cosb, ftau_cld, ft
     """Signature of reference ``fluxes.get_reflected_SH`` (fluxes.py:2675-2679).  Like the
     reference, the TTHG branch multiplies ``f_deltaM`` IN PLACE once per angle (fluxes.py:2823-2824)
     -- the caller's array is modified when it is a float64 C-contiguous array."""
-    if flx:
-        raise Exception("oracle: flx=1 (layer fluxes) is not restated")
     keep = [_a(p) for p in (dtau, tau, w0, cosb, ftau_cld, ftau_ray)]
     fd = f_deltaM if (isinstance(f_deltaM, np.ndarray) and f_deltaM.dtype == np.float64
                       and f_deltaM.flags.c_contiguous) else _a(f_deltaM).copy()
@@ -172,15 +170,16 @@ def get_reflected_SH(nlevel, nwno, numg, numt, dtau, tau, w0, cosb, ftau_cld, ft
     sr, f0 = _per_wave(surf_reflect, nwno), _per_wave(F0PI, nwno)
     u0, u1 = _a(ubar0), _a(ubar1)
     xint = np.zeros((numg, numt, nwno))
+    flux = np.zeros((numg, numt, stream * nlevel, nwno))
     ci, cd = ctypes.c_int, ctypes.c_double
     rc = lib().orc_reflected_SH(
         ci(nlevel), ci(nwno), ci(numg), ci(numt), *[_p(k) for k in keep], _p(fd), *[_p(k) for k in og],
         _p(sr), _p(u0), _p(u1), cd(cos_theta), _p(f0), ci(w_single_form), ci(w_multi_form),
         ci(psingle_form), ci(w_single_rayleigh), ci(w_multi_rayleigh), ci(psingle_rayleigh),
         cd(frac_a), cd(frac_b), cd(frac_c), cd(constant_back), cd(constant_forward), ci(stream),
-        cd(b_top), ci(single_form), _p(xint))
+        cd(b_top), ci(single_form), _p(xint), _p(flux) if flx else None)
     _check(rc, "reflected_SH")
-    return xint, np.zeros((numg, numt, stream * nlevel, nwno))
+    return xint, flux
 
 
 def get_thermal_SH(nlevel, wno, nwno, numg, numt, tlevel, dtau, tau, w0, cosb, dtau_og, tau_og,

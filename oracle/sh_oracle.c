@@ -105,6 +105,7 @@ typedef struct {
     int n;
     double *lam1, *lam2, *eta /*4n*/, *A /*16n: A[j][m][i]*/, *X /*4n*/;
     double flux_bot;
+    double *flux;       /* nullable: 4(n+1) moment fluxes F.X + G (fluxes=1, :3552-3599) */
 } sh4_out;
 
 static int sh4_column(int n, const double *w0, const double *dtau, const double *tau /*n+1*/, const double *a /*4n*/,
@@ -228,6 +229,21 @@ static int sh4_column(int n, const double *w0, const double *dtau, const double 
     int info = gb_solve(N, kl, ku, ab, ldab, rhs, ipiv);
     memcpy(o->X, rhs, sizeof(double) * N);
     o->flux_bot = fb0 * rhs[N - 4] + fb1 * rhs[N - 3] + fb2 * rhs[N - 2] + fb3 * rhs[N - 1] + gbot;   /* :2891 */
+    if (o->flux) {                                  /* calculate_flux: F.dot(X) + G (:3552-3599, :3631-3635) */
+        const double *x = rhs;
+        double *fl = o->flux;
+        fl[0] = p1mn[0] * x[0] + p1pl[0] * x[1] + p2mn[0] * x[2] + p2pl[0] * x[3] + z1mn_dn[0];
+        fl[1] = q1mn[0] * x[0] + q1pl[0] * x[1] + q2mn[0] * x[2] + q2pl[0] * x[3] + z2mn_dn[0];
+        fl[2] = p1pl[0] * x[0] + p1mn[0] * x[1] + p2pl[0] * x[2] + p2mn[0] * x[3] + z1pl_dn[0];
+        fl[3] = q1pl[0] * x[0] + q1mn[0] * x[1] + q2pl[0] * x[2] + q2mn[0] * x[3] + z2pl_dn[0];
+        for (int k = 0; k < n; ++k) {
+            const double *xk = x + 4 * k;
+            const double g4[4] = {z1mn_up[k], z2mn_up[k], z1pl_up[k], z2pl_up[k]};
+            for (int r = 0; r < 4; ++r)
+                fl[4 * (k + 1) + r] = FF(r, 0, k) * xk[0] + FF(r, 1, k) * xk[1] + FF(r, 2, k) * xk[2] +
+                                      FF(r, 3, k) * xk[3] + g4[r];
+        }
+    }
     free(p1pl);
     return info;
 #undef FF
@@ -237,6 +253,7 @@ static int sh4_column(int n, const double *w0, const double *dtau, const double 
 typedef struct {
     double *lam, *q, *eta /*2n*/, *X /*2n*/;
     double flux_bot;
+    double *flux;       /* nullable: 2(n+1) moment fluxes F.X + G (fluxes=1, :3311-3331) */
 } sh2_out;
 
 static int sh2_column(int n, const double *w0, const double *dtau, const double *tau, const double *a /*2n*/,
@@ -304,6 +321,16 @@ static int sh2_column(int n, const double *w0, const double *dtau, const double 
     int info = gb_solve(N, kl, ku, ab, ldab, rhs, ipiv);
     memcpy(o->X, rhs, sizeof(double) * N);
     o->flux_bot = fb0 * rhs[N - 2] + fb1 * rhs[N - 1] + gbot;
+    if (o->flux) {                                  /* F.dot(X) + G (:3311-3331) */
+        const double *x = rhs;
+        double *fl = o->flux;
+        fl[0] = Q1[0] * x[0] + Q2[0] * x[1] + zmn_dn[0];
+        fl[1] = Q2[0] * x[0] + Q1[0] * x[1] + zpl_dn[0];
+        for (int k = 0; k < n; ++k) {
+            fl[2 * (k + 1)] = Q1mn[k] * x[2 * k] + Q2pl[k] * x[2 * k + 1] + zmn_up[k];
+            fl[2 * (k + 1) + 1] = Q2mn[k] * x[2 * k] + Q1pl[k] * x[2 * k + 1] + zpl_up[k];
+        }
+    }
     free(Q1);
     return info;
 }
@@ -321,11 +348,12 @@ int orc_reflected_SH(int nlevel, int nwno, int numg, int numt, const double *dta
                      int w_multi_form, int psingle_form, int w_single_rayleigh, int w_multi_rayleigh,
                      int psingle_rayleigh, double frac_a, double frac_b, double frac_c,
                      double constant_back, double constant_forward, int stream, double b_top,
-                     int single_form, double *xint_at_top)
+                     int single_form, double *xint_at_top, double *flux_out /* nullable (numg,numt,stream*nlevel,nwno) */)
 {
     const int n = nlevel - 1;
     if (stream != 2 && stream != 4) return 2;
     (void)cosb;
+    double *fcol = flux_out ? (double *)malloc(sizeof(double) * stream * (size_t)nlevel) : 0;
     const int N = stream * n, kl = (stream == 4) ? 5 : 2, ldab = 3 * kl + 1;
     double *ab = (double *)malloc(sizeof(double) * ((size_t)ldab * N + 2 * N + 64 * (size_t)n + 64));
     double *rhs = ab + (size_t)ldab * N, *X = rhs + N;
@@ -400,17 +428,20 @@ int orc_reflected_SH(int nlevel, int nwno, int numg, int numt, const double *dta
                 for (int i = 0; i <= n; ++i) taucol[i] = P(tau, i, w);
                 double flux_bot;
                 if (stream == 2) {
-                    sh2_out o = {lam1, qq, eta, X, 0};
+                    sh2_out o = {lam1, qq, eta, X, 0, fcol};
                     rc = sh2_column(n, w0col, dcol, taucol, a, bb, b_top, b_surface, rs, u0, 0, 0, 0, ab, ipiv, rhs, &o);
                     flux_bot = o.flux_bot;
                 } else {
-                    sh4_out o = {n, lam1, lam2, eta, A, X, 0};
+                    sh4_out o = {n, lam1, lam2, eta, A, X, 0, fcol};
                     rc = sh4_column(n, w0col, dcol, taucol, a, bb, b_top, b_surface, b_surface_SH4, rs, u0, 0, 0, 0,
                                     ab, ipiv, rhs, &o);
                     flux_bot = o.flux_bot;
                 }
                 free(dcol);
                 if (rc) break;
+                if (fcol)
+                    for (int r = 0; r < stream * nlevel; ++r)
+                        flux_out[((size_t)fac * stream * nlevel + r) * nwno + w] = fcol[r];
                 const double mus = (u1 + u0) / (u1 * u0);                                    /* :2900 */
                 double xint = flux_bot / PI;                                                /* :2967 */
                 /* the recursion runs bottom-up; integrals are per layer */
@@ -461,6 +492,7 @@ int orc_reflected_SH(int nlevel, int nwno, int numg, int numt, const double *dta
         }
     free(ab);
     free(ipiv);
+    free(fcol);
     return rc;
 }
 

@@ -178,6 +178,8 @@ class ATMSETUP:
         if hasattr(self, "xint_at_top"):
             out["albedo_3d"] = self.xint_at_top
             out["reflected_unit"] = "albedo"
+        if hasattr(self, "flux_layers"):       # SH layer moment fluxes (calculate_fluxes='on')
+            out["flux_layers"] = self.flux_layers
         if hasattr(self, "flux_at_top"):
             out["thermal_3d"] = self.flux_at_top
             out["thermal_unit"] = "erg/cm2/s/cm"

@@ -46,6 +46,9 @@ struct SHArgs {
     const double *wno, *tlevel, *plevel;     // device (nwno) / (nlevel) / (nlevel)
     int hard_surface, use_ff;                // use_ff: cosb != cosb_og somewhere (fluxes.py:3072-3075)
     double *xint;                            // (angles of this launch, nwno)
+    // flx = 1 (reflected): layer moment fluxes F.X + G (calculate_flux, fluxes.py:3631-3635)
+    double *flux;                            // (angles of this launch, stream*nlevel, nwno)
+    double *scratch;                         // (angles, 4 NB^2 + 5 NB, nlayer, nwno) sweep-1 state
 };
 
 __device__ __forceinline__ double clip35(double x) { return fmin(fmax(x, -35.0), 35.0); }   // slice_rav
@@ -200,7 +203,7 @@ __device__ __forceinline__ void modes_sh2(const double (&a)[2], double dt, Modes
 }
 
 // One kernel for stream 2 / 4 (NB = 1 / 2), reflected / thermal.
-template <int NB, bool THERMAL>
+template <int NB, bool THERMAL, bool FLX>
 #ifndef PZ_SH_MINWAVES
 #define PZ_SH_MINWAVES 2
 #endif
@@ -239,6 +242,14 @@ __global__ __launch_bounds__(256, PZ_SH_MINWAVES) void k_sh(const SHArgs a)
     double p_zmn_up[NB], p_zpl_up[NB];
 #pragma unroll
     for (int i = 0; i < NB; ++i) { zeta[i] = delta[i] = p_zmn_up[i] = p_zpl_up[i] = 0.0; }
+
+    // flx = 1: sweep-1 state of every layer for the back-substitution ([slot][layer][wavelength])
+    constexpr int NSLOT = 4 * NB * NB + 5 * NB;
+    double *const scr = FLX ? a.scratch + (long)blockIdx.y * NSLOT * n * a.nwno + w : nullptr;
+    auto slot = [&](int sl, int i) -> double & { return scr[((long)sl * n + i) * a.nwno]; };
+    double top_zmn[NB], top_zpl[NB];
+#pragma unroll
+    for (int r = 0; r < NB; ++r) top_zmn[r] = top_zpl[r] = 0.0;
 
     for (int i = 0; i < n; ++i) {
         const long o = (long)i * pitch + w;
@@ -535,6 +546,15 @@ __global__ __launch_bounds__(256, PZ_SH_MINWAVES) void k_sh(const SHArgs a)
 #pragma unroll
             for (int r = 0; r < NB; ++r) tv[r] += cP[r];
             mv(A2i, tv, t);
+            if constexpr (FLX) {                       // v_{i-1} = Sm v_i + t
+                int sl = 3 * NB * NB + 4 * NB;
+#pragma unroll
+                for (int r = 0; r < NB; ++r)
+#pragma unroll
+                    for (int c2 = 0; c2 < NB; ++c2) slot(sl++, i) = Sm.m[r][c2];
+#pragma unroll
+                for (int r = 0; r < NB; ++r) slot(sl++, i) = t[r];
+            }
             kappa = kappa + dot(zeta, t) + dot(gd, deltan) + c;
             double z1[NB], z2[NB];
             mtv(Sm, zeta, z1);
@@ -545,6 +565,33 @@ __global__ __launch_bounds__(256, PZ_SH_MINWAVES) void k_sh(const SHArgs a)
                 delta[r] = deltan[r];
             }
             R = Rn;
+        }
+        if constexpr (FLX) {
+            int sl = 0;
+#pragma unroll
+            for (int r = 0; r < NB; ++r) slot(sl++, i) = delta[r];
+#pragma unroll
+            for (int r = 0; r < NB; ++r)
+#pragma unroll
+                for (int c = 0; c < NB; ++c) slot(sl++, i) = R.m[r][c];
+#pragma unroll
+            for (int r = 0; r < NB; ++r)
+#pragma unroll
+                for (int c = 0; c < NB; ++c) slot(sl++, i) = M.Mn.m[r][c];
+#pragma unroll
+            for (int r = 0; r < NB; ++r)
+#pragma unroll
+                for (int c = 0; c < NB; ++c) slot(sl++, i) = M.Pl.m[r][c];
+#pragma unroll
+            for (int r = 0; r < NB; ++r) slot(sl++, i) = M.E[r];
+#pragma unroll
+            for (int r = 0; r < NB; ++r) slot(sl++, i) = zmn_up[r];
+#pragma unroll
+            for (int r = 0; r < NB; ++r) slot(sl++, i) = zpl_up[r];
+            if (i == 0) {
+#pragma unroll
+                for (int r = 0; r < NB; ++r) { top_zmn[r] = zmn_dn[r]; top_zpl[r] = zpl_dn[r]; }
+            }
         }
         pMn = M.Mn; pPl = M.Pl; pME = ME; pPE = PE;
 #pragma unroll
@@ -580,18 +627,90 @@ __global__ __launch_bounds__(256, PZ_SH_MINWAVES) void k_sh(const SHArgs a)
     for (int r = 0; r < NB; ++r) rhs[r] = bs[r] - p_zpl_up[r] + rs * p_zmn_up[r] - wd[r];
     mv(inv(L), rhs, v);
     xint[w] = kappa + dot(zeta, v);
+    if constexpr (FLX) {
+        // ---- sweep 2: back-substitute v_i, d_i = delta_i - R_i v_i and write the moment fluxes at the
+        // bottom of every layer (and the top of layer 0) in the row order of the reference's F.X + G:
+        // (Fmn[0..NB), Fpl[0..NB)) per level (fluxes.py:3311-3331, 3552-3599)
+        double *fl = a.flux + (long)blockIdx.y * NS * (n + 1) * a.nwno + w;
+        double vv[NB];
+#pragma unroll
+        for (int r = 0; r < NB; ++r) vv[r] = v[r];
+        for (int i = n - 1; i >= 0; --i) {
+            int sl = 0;
+            double dl[NB], E[NB], zmu[NB], zpu[NB], d[NB], Rv[NB];
+            Blk<NB> Ri, Mn, Pl;
+#pragma unroll
+            for (int r = 0; r < NB; ++r) dl[r] = slot(sl++, i);
+#pragma unroll
+            for (int r = 0; r < NB; ++r)
+#pragma unroll
+                for (int c2 = 0; c2 < NB; ++c2) Ri.m[r][c2] = slot(sl++, i);
+#pragma unroll
+            for (int r = 0; r < NB; ++r)
+#pragma unroll
+                for (int c2 = 0; c2 < NB; ++c2) Mn.m[r][c2] = slot(sl++, i);
+#pragma unroll
+            for (int r = 0; r < NB; ++r)
+#pragma unroll
+                for (int c2 = 0; c2 < NB; ++c2) Pl.m[r][c2] = slot(sl++, i);
+#pragma unroll
+            for (int r = 0; r < NB; ++r) E[r] = slot(sl++, i);
+#pragma unroll
+            for (int r = 0; r < NB; ++r) zmu[r] = slot(sl++, i);
+#pragma unroll
+            for (int r = 0; r < NB; ++r) zpu[r] = slot(sl++, i);
+            mv(Ri, vv, Rv);
+#pragma unroll
+            for (int r = 0; r < NB; ++r) d[r] = dl[r] - Rv[r];
+            const Blk<NB> MEi = scale_cols(Mn, E), PEi = scale_cols(Pl, E);
+            double x1[NB], x2[NB];
+            mv(MEi, d, x1);
+            mv(Pl, vv, x2);
+#pragma unroll
+            for (int r = 0; r < NB; ++r) fl[(long)(NS * (i + 1) + r) * a.nwno] = x1[r] + x2[r] + zmu[r];
+            mv(PEi, d, x1);
+            mv(Mn, vv, x2);
+#pragma unroll
+            for (int r = 0; r < NB; ++r) fl[(long)(NS * (i + 1) + NB + r) * a.nwno] = x1[r] + x2[r] + zpu[r];
+            if (i == 0) {
+                mv(Mn, d, x1);
+                mv(PEi, vv, x2);
+#pragma unroll
+                for (int r = 0; r < NB; ++r) fl[(long)r * a.nwno] = x1[r] + x2[r] + top_zmn[r];
+                mv(Pl, d, x1);
+                mv(MEi, vv, x2);
+#pragma unroll
+                for (int r = 0; r < NB; ++r) fl[(long)(NB + r) * a.nwno] = x1[r] + x2[r] + top_zpl[r];
+            } else {
+                Blk<NB> Smi;
+                double ti[NB], nv[NB];
+#pragma unroll
+                for (int r = 0; r < NB; ++r)
+#pragma unroll
+                    for (int c2 = 0; c2 < NB; ++c2) Smi.m[r][c2] = slot(sl++, i);
+#pragma unroll
+                for (int r = 0; r < NB; ++r) ti[r] = slot(sl++, i);
+                mv(Smi, vv, nv);
+#pragma unroll
+                for (int r = 0; r < NB; ++r) vv[r] = nv[r] + ti[r];
+            }
+        }
+    }
 }
 
 static int launch_sh(picaso_ctx *ctx, const SHArgs &a, int nang, bool thermal)
 {
     const int block = 256;
     const dim3 grid((unsigned)((a.nwno + block - 1) / block), (unsigned)nang);
+    const bool flx = a.flux != nullptr;
     if (a.stream == 4) {
-        if (thermal) hipLaunchKernelGGL((k_sh<2, true>), grid, dim3(block), 0, ctx->stream, a);
-        else hipLaunchKernelGGL((k_sh<2, false>), grid, dim3(block), 0, ctx->stream, a);
+        if (thermal) hipLaunchKernelGGL((k_sh<2, true, false>), grid, dim3(block), 0, ctx->stream, a);
+        else if (flx) hipLaunchKernelGGL((k_sh<2, false, true>), grid, dim3(block), 0, ctx->stream, a);
+        else hipLaunchKernelGGL((k_sh<2, false, false>), grid, dim3(block), 0, ctx->stream, a);
     } else {
-        if (thermal) hipLaunchKernelGGL((k_sh<1, true>), grid, dim3(block), 0, ctx->stream, a);
-        else hipLaunchKernelGGL((k_sh<1, false>), grid, dim3(block), 0, ctx->stream, a);
+        if (thermal) hipLaunchKernelGGL((k_sh<1, true, false>), grid, dim3(block), 0, ctx->stream, a);
+        else if (flx) hipLaunchKernelGGL((k_sh<1, false, true>), grid, dim3(block), 0, ctx->stream, a);
+        else hipLaunchKernelGGL((k_sh<1, false, false>), grid, dim3(block), 0, ctx->stream, a);
     }
     PZ_HIP(ctx, hipGetLastError());
     return 0;
@@ -600,10 +719,23 @@ static int launch_sh(picaso_ctx *ctx, const SHArgs &a, int nang, bool thermal)
 // All angles of a call go into one launch (grid.y = angle, SH_MAX_ANG per launch): a 1e5-column
 // spectrum is only 1.5 waves per SIMD per angle, five angles together fill the chip evenly.
 static int launch_sh_angles(picaso_ctx *ctx, SHArgs &a, int nang, const double *ubar0, const double *ubar1,
-                            double *xint_at_top, bool thermal)
+                            double *xint_at_top, double *flux, bool thermal)
 {
-    for (int done = 0; done < nang; done += SH_MAX_ANG) {
-        const int m = (nang - done < SH_MAX_ANG) ? nang - done : SH_MAX_ANG;
+    const int nb = a.stream / 2, nslot = 4 * nb * nb + 5 * nb;
+    const size_t per_angle = (size_t)nslot * a.nlayer * a.nwno;
+    // flx = 1 keeps the sweep state of every layer: limit the angles per launch to ~8 GB of scratch
+    int max_ang = SH_MAX_ANG;
+    if (flux) {
+        const size_t cap = (size_t)8 << 30;
+        max_ang = (int)(cap / (per_angle * sizeof(double)));
+        if (max_ang < 1) max_ang = 1;
+        if (max_ang > SH_MAX_ANG) max_ang = SH_MAX_ANG;
+        PZ_TRY(ck_scratch_reserve(ctx, sizeof(double) * per_angle * (size_t)(nang < max_ang ? nang : max_ang)));
+    }
+    for (int done = 0; done < nang; done += max_ang) {
+        const int m = (nang - done < max_ang) ? nang - done : max_ang;
+        a.flux = flux ? flux + (size_t)done * a.stream * (a.nlayer + 1) * a.nwno : nullptr;
+        a.scratch = flux ? ctx->ck_scratch : nullptr;
         for (int k = 0; k < m; ++k) {
             SHArgs::Angle &g = a.ang[k];
             g.u1 = ubar1[done + k];
@@ -644,14 +776,15 @@ int picaso_get_reflected_SH_dev(picaso_ctx *ctx, int nlevel, int nwno, long plan
                                 int psingle_rayleigh, double frac_a, double frac_b, double frac_c,
                                 double constant_back, double constant_forward, int stream,
                                 double b_top, int flx, int single_form, int compound_f_deltaM,
-                                double *xint_at_top, const double *gweight, const double *tweight,
-                                double *albedo)
+                                double *xint_at_top, double *flux, const double *gweight,
+                                const double *tweight, double *albedo)
 {
     (void)cosb;
     if (!ctx) return fail(nullptr, "null context");
     if (nlevel < 2 || nwno < 1 || numg < 1 || numt < 1) return fail(ctx, "get_reflected_SH: bad sizes");
     if (stream != 2 && stream != 4) return fail(ctx, "get_reflected_SH: stream must be 2 or 4, got %d", stream);
-    if (flx) return fail(ctx, "get_reflected_SH: flx=1 (layer fluxes) is not built");
+    if (flx && !flux) return fail(ctx, "get_reflected_SH: flx=1 needs the flux output (numg,numt,stream*nlevel,nwno)");
+    if (flx && plane_pitch != nwno) return fail(ctx, "get_reflected_SH: flx=1 needs contiguous planes");
     if (plane_pitch < nwno) return fail(ctx, "get_reflected_SH: plane_pitch < nwno");
     PZ_HIP(ctx, hipSetDevice(ctx->device));
     SHArgs a{};
@@ -665,7 +798,7 @@ int picaso_get_reflected_SH_dev(picaso_ctx *ctx, int nlevel, int nwno, long plan
     a.frac_a = frac_a; a.frac_b = frac_b; a.frac_c = frac_c; a.constant_back = constant_back;
     a.constant_forward = constant_forward; a.b_top = b_top;
     a.compound = compound_f_deltaM ? 1 : 0;
-    PZ_TRY(launch_sh_angles(ctx, a, numg * numt, ubar0, ubar1, xint_at_top, false));
+    PZ_TRY(launch_sh_angles(ctx, a, numg * numt, ubar0, ubar1, xint_at_top, flx ? flux : nullptr, false));
     if (albedo && gweight && tweight)
         PZ_TRY(picaso_compress_disco_dev(ctx, nwno, cos_theta, xint_at_top, gweight, numg, tweight, numt, F0PI, albedo));
     return 0;
@@ -681,27 +814,32 @@ int picaso_get_reflected_SH(picaso_ctx *ctx, int nlevel, int nwno, int numg, int
                             int w_single_rayleigh, int w_multi_rayleigh, int psingle_rayleigh,
                             double frac_a, double frac_b, double frac_c, double constant_back,
                             double constant_forward, int stream, double b_top, int flx,
-                            int single_form, int compound_f_deltaM, double *xint_at_top)
+                            int single_form, int compound_f_deltaM, double *xint_at_top, double *flux)
 {
     if (!ctx) return fail(nullptr, "null context");
     if (nlevel < 2 || nwno < 1 || numg < 1 || numt < 1) return fail(ctx, "get_reflected_SH: bad sizes");
+    if (stream != 2 && stream != 4) return fail(ctx, "get_reflected_SH: stream must be 2 or 4, got %d", stream);
+    if (flx && !flux) return fail(ctx, "get_reflected_SH: flx=1 needs the flux output (numg,numt,stream*nlevel,nwno)");
     PZ_HIP(ctx, hipSetDevice(ctx->device));
     const size_t nl = (size_t)(nlevel - 1) * nwno, nv = (size_t)nlevel * nwno, nang = (size_t)numg * numt;
-    PZ_TRY(arena_reset(ctx, sizeof(double) * (9 * nl + 2 * nv + 2 * (size_t)nwno + nang * nwno) + 64 * 256));
+    const size_t nflux = flx ? nang * stream * nlevel * nwno : 0;
+    PZ_TRY(arena_reset(ctx, sizeof(double) * (9 * nl + 2 * nv + 2 * (size_t)nwno + nang * nwno + nflux) + 64 * 256));
     const double *d[10], *d_rs, *d_f0;
     const double *h[10] = {dtau, tau, w0, ftau_cld, ftau_ray, f_deltaM, dtau_og, tau_og, w0_og, cosb_og};
     for (int j = 0; j < 10; ++j) PZ_TRY(arena_upload(ctx, h[j], (j == 1 || j == 7) ? nv : nl, &d[j]));
     PZ_TRY(arena_upload(ctx, surf_reflect, (size_t)nwno, &d_rs));
     PZ_TRY(arena_upload(ctx, F0PI, (size_t)nwno, &d_f0));
     double *d_x = (double *)arena_take(ctx, sizeof(double) * nang * nwno);
-    if (!d_x) return fail(ctx, "arena exhausted");
+    double *d_fl = nflux ? (double *)arena_take(ctx, sizeof(double) * nflux) : nullptr;
+    if (!d_x || (nflux && !d_fl)) return fail(ctx, "arena exhausted");
     PZ_TRY(picaso_get_reflected_SH_dev(ctx, nlevel, nwno, nwno, numg, numt, d[0], d[1], d[2], cosb, d[3], d[4], d[5],
                                        d[6], d[7], d[8], d[9], d_rs, ubar0, ubar1, cos_theta, d_f0, w_single_form,
                                        w_multi_form, psingle_form, w_single_rayleigh, w_multi_rayleigh,
                                        psingle_rayleigh, frac_a, frac_b, frac_c, constant_back, constant_forward,
-                                       stream, b_top, flx, single_form, compound_f_deltaM, d_x, nullptr, nullptr,
-                                       nullptr));
+                                       stream, b_top, flx, single_form, compound_f_deltaM, d_x, d_fl, nullptr,
+                                       nullptr, nullptr));
     PZ_HIP(ctx, hipMemcpyAsync(xint_at_top, d_x, sizeof(double) * nang * nwno, hipMemcpyDeviceToHost, ctx->stream));
+    if (nflux) PZ_HIP(ctx, hipMemcpyAsync(flux, d_fl, sizeof(double) * nflux, hipMemcpyDeviceToHost, ctx->stream));
     PZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return 0;
 }
@@ -729,7 +867,7 @@ int picaso_get_thermal_SH_dev(picaso_ctx *ctx, int nlevel, const double *wno, in
     a.dtau = dtau; a.w0 = w0; a.cosb_og = cosb_og; a.surf_reflect = surf_reflect;
     a.wno = wno; a.tlevel = (const double *)d_tab; a.plevel = a.tlevel + nlevel;
     a.hard_surface = hard_surface; a.use_ff = cosb_differs_from_cosb_og;
-    PZ_TRY(launch_sh_angles(ctx, a, numg * numt, nullptr, ubar1, xint_at_top, true));
+    PZ_TRY(launch_sh_angles(ctx, a, numg * numt, nullptr, ubar1, xint_at_top, nullptr, true));
     if (flux_disk && gweight && tweight)
         PZ_TRY(picaso_compress_thermal_dev(ctx, (size_t)nwno, xint_at_top, gweight, numg, tweight, numt, flux_disk));
     return 0;

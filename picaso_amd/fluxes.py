@@ -114,8 +114,9 @@ def get_reflected_SH(nlevel, nwno, numg, numt, dtau, tau, w0, cosb, ftau_cld, ft
                      psingle_rayleigh, frac_a, frac_b, frac_c, constant_back, constant_forward,
                      stream, b_top=0, flx=0, single_form=0, compound_f_deltaM=True):
     """Spherical-harmonics reflected light, stream = 2 or 4 (reference ``fluxes.get_reflected_SH``,
-    fluxes.py:2675-2976).  Returns ``(xint_at_top, flux)`` with ``flux`` zeros
-    ``(numg, numt, stream*nlevel, nwno)`` as in the reference for ``flx=0`` (``flx=1`` raises).
+    fluxes.py:2675-2976).  Returns ``(xint_at_top, flux)``; ``flux`` is
+    ``(numg, numt, stream*nlevel, nwno)``, zeros for ``flx=0`` as in the reference and the layer moment
+    fluxes ``F.X + G`` of ``calculate_flux`` (fluxes.py:3631-3635) for ``flx=1``.
 
     ``compound_f_deltaM=True`` (default) reproduces the reference: its TTHG branch multiplies
     ``f_deltaM`` in place once per angle (fluxes.py:2823-2824), so angle k sees
@@ -129,19 +130,20 @@ def get_reflected_SH(nlevel, nwno, numg, numt, dtau, tau, w0, cosb, ftau_cld, ft
     rs, f0 = per_wave(surf_reflect, nwno), per_wave(F0PI, nwno)
     u0, u1 = f64(ubar0, (numg, numt)), f64(ubar1, (numg, numt))
     xint = np.zeros((numg, numt, nwno))
+    flux = np.zeros((numg, numt, stream * nlevel, nwno))
     check(load().picaso_get_reflected_SH(
         ctx, _ci(nlevel), _ci(nwno), _ci(numg), _ci(numt), *[ptr(p) for p in arrs], ptr(rs), ptr(u0),
         ptr(u1), _cd(cos_theta), ptr(f0), _ci(int(w_single_form)), _ci(int(w_multi_form)),
         _ci(int(psingle_form)), _ci(int(w_single_rayleigh)), _ci(int(w_multi_rayleigh)),
         _ci(int(psingle_rayleigh)), _cd(frac_a), _cd(frac_b), _cd(frac_c), _cd(constant_back),
         _cd(constant_forward), _ci(int(stream)), _cd(b_top), _ci(int(flx)), _ci(int(single_form)),
-        _ci(1 if compound_f_deltaM else 0), ptr(xint)), ctx)
+        _ci(1 if compound_f_deltaM else 0), ptr(xint), ptr(flux) if flx else None), ctx)
     if compound_f_deltaM and (w_single_form == 0 or w_multi_form == 0) and \
             isinstance(f_deltaM, np.ndarray) and f_deltaM.dtype == np.float64 and f_deltaM.flags.writeable:
         gb = constant_back * np.asarray(cosb_og, dtype=float)
         f = frac_a + frac_b * gb ** frac_c
         f_deltaM *= (f * constant_forward ** stream + (1 - f) * constant_back ** stream) ** (numg * numt)
-    return xint, np.zeros((numg, numt, stream * nlevel, nwno))
+    return xint, flux
 
 
 def get_thermal_SH(nlevel, wno, nwno, numg, numt, tlevel, dtau, tau, w0, cosb, dtau_og, tau_og,

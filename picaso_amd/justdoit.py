@@ -173,8 +173,8 @@ class inputs:
         """String options -> the integers the solvers take (reference justdoit.py:4635-4738)."""
         if rt_method not in ("toon", "SH"):
             raise Exception("rt_method must be 'toon' or 'SH'")
-        if calculate_fluxes != "off":
-            raise Exception("SH calculate_fluxes='on' (layer fluxes) is not built")
+        if calculate_fluxes not in ("off", "on"):
+            raise Exception("calculate_fluxes must be 'off' or 'on'")
         for opt in (w_single_form, w_multi_form, psingle_form):
             if opt == "isotropic":      # accepted but not handled by the reference (SURVEY App. C)
                 raise Exception("SH form 'isotropic' is not handled by the reference solver either")
@@ -195,6 +195,7 @@ class inputs:
         sh["w_single_rayleigh"] = SH_rayleigh_options(False).index(w_single_rayleigh)
         sh["w_multi_rayleigh"] = SH_rayleigh_options(False).index(w_multi_rayleigh)
         sh["psingle_rayleigh"] = SH_rayleigh_options(False).index(psingle_rayleigh)
+        sh["calculate_fluxes"] = ["off", "on"].index(calculate_fluxes)       # justdoit.py:4736
         c["raman"] = raman_options().index(raman)
         if not isinstance(tthg_frac, (list, np.ndarray)):
             raise Exception("tthg_frac should be a list or ndarray of length=3")
@@ -336,9 +337,15 @@ def picaso(bundle, opacityclass, dimension="1d", calculation="reflected", full_o
                                   toon["single_phase"], toon["multi_phase"], frac_a, frac_b, frac_c,
                                   constant_back, constant_forward, xint, gweight, tweight, alb)
         elif is_sh:                                           # justdoit.py:259-269
+            sh_opt = inp["approx"]["rt_params"]["SH"]
+            sh_flux = None                                    # layer moment fluxes, flx = calculate_fluxes
+            if sh_opt["calculate_fluxes"]:
+                sh_flux = DeviceArray((ng, nt, common["stream"] * nlevel, nwno), ctx)
             _reflected_sh(ctx, nlevel, nwno, ng, nt, planes, rs, ubar0, ubar1, cos_theta, d_f0,
-                          inp["approx"]["rt_params"]["SH"], frac_a, frac_b, frac_c, constant_back,
-                          constant_forward, common["stream"], b_top, xint, gweight, tweight, alb)
+                          sh_opt, frac_a, frac_b, frac_c, constant_back, constant_forward,
+                          common["stream"], b_top, xint, gweight, tweight, alb, sh_flux)
+            if sh_flux is not None:
+                atm.flux_layers = sh_flux.to_host()
         else:
             lvl = [DeviceArray((ng, nt, nlevel, nwno), ctx) for _ in range(4)] if atm.get_lvl_flux else None
             tt = (toon["single_phase"], toon["multi_phase"], frac_a, frac_b, frac_c, constant_back,
@@ -453,7 +460,7 @@ def _reflected(ctx, nlevel, nwno, ng, nt, planes, rs, ubar0, ubar1, cos_theta, F
 
 def _reflected_sh(ctx, nlevel, nwno, ng, nt, planes, rs, ubar0, ubar1, cos_theta, F0PI, sh, frac_a,
                   frac_b, frac_c, constant_back, constant_forward, stream, b_top, xint, gweight,
-                  tweight, albedo):
+                  tweight, albedo, flux=None):
     import ctypes
     from ._lib import check, f64, load, ptr
     u0, u1 = f64(ubar0, (ng, nt)), f64(ubar1, (ng, nt))
@@ -467,7 +474,8 @@ def _reflected_sh(ctx, nlevel, nwno, ng, nt, planes, rs, ubar0, ubar1, cos_theta
         ptr(F0PI.addr), ci(sh["w_single_form"]), ci(sh["w_multi_form"]), ci(sh["psingle_form"]),
         ci(sh["w_single_rayleigh"]), ci(sh["w_multi_rayleigh"]), ci(sh["psingle_rayleigh"]),
         cd(frac_a), cd(frac_b), cd(frac_c), cd(constant_back), cd(constant_forward), ci(stream),
-        cd(b_top), ci(0), ci(sh["single_form"]), ci(1), ptr(xint.addr), ptr(gw), ptr(tw),
+        cd(b_top), ci(1 if flux is not None else 0), ci(sh["single_form"]), ci(1), ptr(xint.addr),
+        ptr(flux.addr) if flux is not None else None, ptr(gw), ptr(tw),
         ptr(albedo.addr)), ctx)
 
 

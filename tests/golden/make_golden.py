@@ -537,15 +537,18 @@ def make_sh():
                 if stream == 4:      # f_deltaM = cosb**stream for the delta-M scaled scenes
                     fd = sc["cosb_og"] ** 4 if np.any(sc["f_deltaM"]) else fd
                 store["in/f_deltaM_s%d" % stream] = fd.copy()
-                xint, _ = fl.get_reflected_SH(
+                want_flux = (wsf, wmf, psf, wsr, wmr, psr, sf) == combos[0]
+                xint, flux = fl.get_reflected_SH(
                     nlevel, nwno, geo["numg"], geo["numt"], sc["dtau"].copy(), sc["tau"].copy(),
                     sc["w0"].copy(), sc["cosb"].copy(), sc["ftau_cld"].copy(), sc["ftau_ray"].copy(),
                     fd, sc["dtau_og"].copy(), sc["tau_og"].copy(), sc["w0_og"].copy(),
                     sc["cosb_og"].copy(), rs, geo["ubar0"], geo["ubar1"], geo["cos_theta"], f0, wsf,
                     wmf, psf, wsr, wmr, psr, TTHG["frac_a"], TTHG["frac_b"], TTHG["frac_c"],
-                    TTHG["constant_back"], TTHG["constant_forward"], stream, b_top=0.0, flx=0,
-                    single_form=sf)
+                    TTHG["constant_back"], TTHG["constant_forward"], stream, b_top=0.0,
+                    flx=1 if want_flux else 0, single_form=sf)
                 store["reflsh/s%d_f%d%d%d_r%d%d%d_sf%d/xint" % (stream, wsf, wmf, psf, wsr, wmr, psr, sf)] = xint
+                if want_flux:       # layer moment fluxes F.X + G (calculate_flux, fluxes.py:3631-3635)
+                    store["reflsh/s%d_f%d%d%d_r%d%d%d_sf%d/flux" % (stream, wsf, wmf, psf, wsr, wmr, psr, sf)] = flux
             for hs in (0, 1):
                 rsv = np.zeros(nwno) + rs
                 xint, _ = fl.get_thermal_SH(nlevel, sc["wno"], nwno, geo["numg"], geo["numt"],

@@ -175,19 +175,21 @@ def test_gpu_spectrum_sh4_end_to_end(gold, oracle):
     opa.raman_stellar_shifts = gold["in/raman_shifts"]
     opa.raman_db = {"c": gold["in/raman_c"], "ji": gold["in/raman_ji"], "deltanu": gold["in/raman_deltanu"]}
     case = _bundle(gold, jdi, None, True, 4, 0)
-    case.approx(raman="oklopcic", rt_method="SH", stream=4, delta_eddington=True)
-    out = case.spectrum(opa, calculation="reflected+thermal")
+    case.approx(raman="oklopcic", rt_method="SH", stream=4, delta_eddington=True, calculate_fluxes="on")
+    out = case.spectrum(opa, calculation="reflected+thermal", full_output=True)
     key = "linear/de1_s4_r0_tmnone"
     P = {nm: gold["%s/%s" % (key, nm)] for nm in NAMES}
     nlevel, nwno = P["tau"].shape
     g, gw, t, tw = disco.get_angles_1d(5)
     u0, u1, ct, _, _ = disco.compute_disco(5, 1, g, t, 0.0)
-    x, _ = oracle.get_reflected_SH(nlevel, nwno, 5, 1, P["dtau"], P["tau"], P["w0"], P["cosb"],
-                                   P["ftau_cld"], P["ftau_ray"], P["f_deltaM"].copy(), P["dtau_og"],
-                                   P["tau_og"], P["w0_og"], P["cosb_og"], 0.0, u0, u1, 1.0,
-                                   np.ones(nwno), 0, 0, 0, 1, 1, 1, 1.0, -1.0, 2.0, -0.5, 1.0, 4)
+    x, fl = oracle.get_reflected_SH(nlevel, nwno, 5, 1, P["dtau"], P["tau"], P["w0"], P["cosb"],
+                                    P["ftau_cld"], P["ftau_ray"], P["f_deltaM"].copy(), P["dtau_og"],
+                                    P["tau_og"], P["w0_og"], P["cosb_og"], 0.0, u0, u1, 1.0,
+                                    np.ones(nwno), 0, 0, 0, 1, 1, 1, 1.0, -1.0, 2.0, -0.5, 1.0, 4, flx=1)
     alb = oracle.compress_disco(nwno, 1.0, x, gw, tw, np.ones(nwno))
     assert rel_err(out["albedo"], alb) < 1e-8
+    from helpers import scale_err
+    assert scale_err(out["full_output"]["flux_layers"], fl) < 1e-8    # calculate_fluxes='on' 
     f, _ = oracle.get_thermal_SH(nlevel, opa.wno, nwno, 5, 1, gold["in/tlevel"], P["dtau"], P["tau"],
                                  P["w0"], P["cosb"], P["dtau_og"], P["tau_og"], P["w0_og"],
                                  P["w0_no_raman"], P["cosb_og"], gold["in/plevel_bar"] * 1e6, u1,

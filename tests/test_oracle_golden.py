@@ -6,7 +6,7 @@ cancel catastrophically in thin layers."""
 import numpy as np
 import pytest
 
-from helpers import PLANES, Golden, golden_files, lvl_err, rel_err, scene_id
+from helpers import PLANES, Golden, golden_files, lvl_err, rel_err, scale_err, scene_id
 
 TOL = 1e-11
 FILES_1D = golden_files("scene1d_")
@@ -105,13 +105,16 @@ def test_spherical_harmonics(path, oracle):
     nlevel, nwno = g.inp("tau").shape
     for case in g.cases("reflsh"):
         stream, (wsf, wmf, psf), (wsr, wmr, psr), sf = _sh_case(case)
-        xint, _ = oracle.get_reflected_SH(
+        has_flux = ("reflsh/%s/flux" % case) in g.z.files
+        xint, flux = oracle.get_reflected_SH(
             nlevel, nwno, g.geo("numg"), g.geo("numt"), g.inp("dtau"), g.inp("tau"), g.inp("w0"),
             g.inp("cosb"), g.inp("ftau_cld"), g.inp("ftau_ray"), g.inp("f_deltaM_s%d" % stream).copy(),
             g.inp("dtau_og"), g.inp("tau_og"), g.inp("w0_og"), g.inp("cosb_og"), g.inp("surf_reflect"),
             g.geo("ubar0"), g.geo("ubar1"), g.geo("cos_theta"), g.inp("F0PI"), wsf, wmf, psf, wsr, wmr,
-            psr, *g.tthg(), stream, b_top=0.0, flx=0, single_form=sf)
+            psr, *g.tthg(), stream, b_top=0.0, flx=1 if has_flux else 0, single_form=sf)
         assert rel_err(xint, g["reflsh/%s/xint" % case]) < 1e-8, case
+        if has_flux:        # layer moment fluxes (flx=1): field-scale metric, entries span many decades
+            assert scale_err(flux, g["reflsh/%s/flux" % case]) < 1e-8, case
     for case in g.cases("thermsh"):
         stream, hs = int(case[1]), int(case[-1])
         rs = np.zeros(nwno) + g.inp("surf_reflect")

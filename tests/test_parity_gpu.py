@@ -6,7 +6,7 @@ reference's two-sweep Thomas only by rounding)."""
 import numpy as np
 import pytest
 
-from helpers import PLANES, Golden, golden_files, lvl_err, lvl_excess, rel_err, scene_id
+from helpers import PLANES, Golden, golden_files, lvl_err, lvl_excess, rel_err, scale_err, scene_id
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-8
@@ -196,14 +196,19 @@ def test_spherical_harmonics_golden(path, hip):
         stream, (wsf, wmf, psf), (wsr, wmr, psr), sf = _sh_case(case)
         fd = g.inp("f_deltaM_s%d" % stream).copy()
         fd0 = fd.copy()
+        has_flux = ("reflsh/%s/flux" % case) in g.z.files
         xint, flux = hip.fluxes.get_reflected_SH(
             nlevel, nwno, g.geo("numg"), g.geo("numt"), g.inp("dtau"), g.inp("tau"), g.inp("w0"),
             g.inp("cosb"), g.inp("ftau_cld"), g.inp("ftau_ray"), fd, g.inp("dtau_og"), g.inp("tau_og"),
             g.inp("w0_og"), g.inp("cosb_og"), g.inp("surf_reflect"), g.geo("ubar0"), g.geo("ubar1"),
             g.geo("cos_theta"), g.inp("F0PI"), wsf, wmf, psf, wsr, wmr, psr, *g.tthg(), stream,
-            b_top=0.0, flx=0, single_form=sf)
+            b_top=0.0, flx=1 if has_flux else 0, single_form=sf)
         assert flux.shape == (g.geo("numg"), g.geo("numt"), stream * nlevel, nwno)
         assert rel_err(xint, g["reflsh/%s/xint" % case]) < TOL, case
+        if has_flux:      # layer moment fluxes (flx=1), two-sweep variant of the block elimination
+            assert scale_err(flux, g["reflsh/%s/flux" % case]) < TOL, case
+        else:
+            assert not np.any(flux)
         if wsf == 0 or wmf == 0:      # the reference leaves the caller's f_deltaM compounded
             assert not np.array_equal(fd, fd0) or not np.any(fd0)
         else:

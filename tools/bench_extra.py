@@ -135,7 +135,7 @@ def main():
                     ctx, ci(nlayer + 1), ci(nwno), ctypes.c_long(nwno), ci(5), ci(1),
                     *[ptr(dd[k].addr) for k in names], ptr(rs.addr), ptr(f64(u0)), ptr(f64(u1)), cd(1.0),
                     ptr(f0.addr), ci(0), ci(0), ci(0), ci(1), ci(1), ci(1), *[cd(v) for v in TTHG], ci(4),
-                    cd(0.0), ci(0), ci(0), ci(1), ptr(x.addr), ptr(f64(gw)), ptr(f64(tw)), ptr(alb.addr)), ctx)
+                    cd(0.0), ci(0), ci(0), ci(1), ptr(x.addr), None, ptr(f64(gw)), ptr(f64(tw)), ptr(alb.addr)), ctx)
             ms = timeit(runsh, ctx, reps=5)
             ab = 8 * nwno * (9 * nlayer + 2 * (nlayer + 1) + 2 + 5 + 1)
             out["reflected_SH4_%d" % nwno] = dict(ms=ms, spectra_per_s=1e3 / ms, GBps_algorithmic=ab / ms / 1e6)
