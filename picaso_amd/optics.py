@@ -140,26 +140,20 @@ class RetrieveOpacities:
         t_inv = 1 / np.asarray(tlayer, dtype=float)
         p_log = np.log10(np.asarray(player, dtype=float))
         t_inv_grid, p_log_grid, nc_p = self.t_inv_grid, self.p_log_grid, self.nc_p
-        t_low_ind = []
-        for i in t_inv:
-            find = np.where(t_inv_grid > i)[0]
-            t_low_ind += [0] if len(find) == 0 else [find[-1]]
-        t_low_ind = np.array(t_low_ind)
+        # last grid index satisfying the condition (0 when none does), all layers at once
+        def last_true(mask):
+            return np.where(mask, np.arange(mask.shape[1])[None, :], -1).max(axis=1).clip(min=0)
+        t_low_ind = last_true(t_inv_grid[None, :] > t_inv[:, None])
         t_low_ind[t_low_ind == (len(t_inv_grid) - 1)] = len(t_inv_grid) - 2
         t_hi_ind = t_low_ind + 1
         t_inv_low, t_inv_hi = t_inv_grid[t_low_ind], t_inv_grid[t_hi_ind]
-        p_low_ind = []
-        for i in p_log:
-            find = np.where(p_log_grid <= i)[0]
-            p_low_ind += [0] if len(find) == 0 else [find[-1]]
-        p_low_ind = np.array(p_low_ind)
-        for i in range(len(p_low_ind)):
-            p_low_ind[i] = min(p_low_ind[i], nc_p[t_hi_ind[i]] - 3)
+        p_low_ind = last_true(p_log_grid[None, :] <= p_log[:, None])
+        p_low_ind = np.minimum(p_low_ind, nc_p[t_hi_ind] - 3)
         p_log_low = p_log_grid[p_low_ind]
         p_hi_ind = p_low_ind + 1
         p_log_hi = p_log_grid[p_hi_ind]
-        t_low_10XX = np.array([sum(nc_p[0:i]) for i in t_low_ind])
-        t_hi_10XX = np.array([sum(nc_p[0:i]) for i in t_hi_ind])
+        csum = np.concatenate([[0], np.cumsum(nc_p)])
+        t_low_10XX, t_hi_10XX = csum[t_low_ind], csum[t_hi_ind]
         t_interp = ((t_inv - t_inv_low) / (t_inv_hi - t_inv_low))[:, np.newaxis]
         p_interp = ((p_log - p_log_low) / (p_log_hi - p_log_low))[:, np.newaxis]
         return (t_interp, p_interp, t_low_10XX + p_low_ind, t_hi_10XX + p_low_ind,
@@ -196,7 +190,7 @@ class RetrieveOpacities:
         if exclude_mol != 1:
             fac = np.array([exclude_mol[m] for m in molecules], dtype=float)
         temps = np.unique(self.cia_temps)
-        cia_rows = np.array([find_nearest(temps, t) for t in tlayer], dtype=np.int32)   # :2298
+        cia_rows = np.abs(temps[None, :] - tlayer[:, None]).argmin(axis=1).astype(np.int32)   # :2298
         self._plan = dict(molecules=molecules, rows=rows, wts=wts, fac=fac, cia_pairs=cia_pairs,
                           cia_rows=cia_rows, nlayer=nlayer)
         self.molecular_opa = _LazyPlanes(self, "mol")
