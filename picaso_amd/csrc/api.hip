@@ -656,7 +656,7 @@ static int thermal_1d_core(picaso_ctx *ctx, int nlevel, const double *wno, int n
     a.disk_scale = (numt == 1) ? 1.0 : 1.0 / (2.0 * 3.14159265358979323846);   // disco.py:174-175
     if (want_lvl) {   // the reference always fills these (fluxes.py:1851-1907): two-sweep kernel
         const size_t plane = (size_t)(nlevel - 1) * ncol;
-        PZ_TRY(lvl_scratch_reserve(ctx, sizeof(double) * 4 * plane));
+        PZ_TRY(lvl_scratch_reserve(ctx, sizeof(double) * (4 * plane + (size_t)nlevel * ncol)));
         ThermalLvlArgs la{};
         la.base = a;
         la.nang = nang;

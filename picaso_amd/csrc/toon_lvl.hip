@@ -161,11 +161,11 @@ int launch_reflected_lvl(picaso_ctx *ctx, const ReflectedLvlArgs &a)
 // thermal emission, all angles (one solve per wavelength, fluxes.py:1812-1831)
 // ------------------------------------------------------------------------------------------------
 struct ThermLayer {
-    double B0, b1, lam, gam, s, E, EP, EM, cmu, q;   // q = pi b1/(g1+g2): c+- = pi B +- q
+    double B0, b1, lam, gam, s, E, EP, EM, EPm, EMm, cmu, q;   // q = pi b1/(g1+g2): c+- = pi B +- q; EPm = exp(E/2)
 };
 
 __device__ __forceinline__ ThermLayer therm_layer_coeffs(const ThermalArgs &a, long off, double B0,
-                                                         double Bn)
+                                                         double Bn, const Exp2Coef &K)
 {
     ThermLayer r;
     const double mu1 = 0.5;
@@ -181,8 +181,10 @@ __device__ __forceinline__ ThermLayer therm_layer_coeffs(const ThermalArgs &a, l
     r.q = PI * r.b1 * r.s;
     r.cmu = 2 * PI * mu1 * (B0 - r.b1 * r.s);
     r.E = fmin(r.lam * dt, 35.0);
-    r.EP = fexp(r.E);
-    r.EM = frcp(r.EP);
+    r.EPm = fexpk(0.5 * r.E, K);                            // exp(E/2) (fluxes.py:1856-1857) ...
+    r.EMm = frcp(r.EPm);
+    r.EP = r.EPm * r.EPm;                                   // ... and exp(E), exp(-E) from it
+    r.EM = r.EMm * r.EMm;
     return r;
 }
 
@@ -198,26 +200,30 @@ __global__ __launch_bounds__(256) void k_thermal_lvl(const ThermalLvlArgs A)
     const double wn = a.wno[wv], rs = a.surf_reflect[wv];
     const bool integrated = (a.calc_type == 1);
     const double dwn = integrated ? a.dwno[wv] : 0.0;
+    Exp2Coef K;
+    K.load();
     auto planck = [&](int l) {
         const double t = a.tlevel[l];
-        return integrated ? planck_integrated(t, wn, dwn) : planck_lambda(t, wn);
+        return integrated ? planck_integrated(t, wn, dwn) : planck_lambda(t, wn, K);
     };
     double *s_rho = A.scratch + w, *s_del = s_rho + (long)n * nw, *s_s = s_del + (long)n * nw,
-           *s_t = s_s + (long)n * nw;
+           *s_t = s_s + (long)n * nw, *s_B = s_t + (long)n * nw;   // s_B: Planck function at the nlevel levels
 
     // ---- sweep 1 ----
     double rho = 0.0, delta = 0.0, pgam = 0.0, pEM = 0.0, pq = 0.0, b1_last = 0.0, s_last = 0.0;
     double Bn = planck(0);
+    s_B[0] = Bn;
     const double B_top = Bn;
     const double tau_top = a.dtau[w] * a.plevel[0] / (a.plevel[1] - a.plevel[0]);   // fluxes.py:1797
     for (int i = 0; i < n; ++i) {
         const double B0 = Bn;
         Bn = planck(i + 1);
-        const ThermLayer r = therm_layer_coeffs(a, (long)i * pitch + w, B0, Bn);
+        s_B[(long)(i + 1) * nw] = Bn;      // the per-angle passes below read it back (3 exp per level when integrated)
+        const ThermLayer r = therm_layer_coeffs(a, (long)i * pitch + w, B0, Bn, K);
         double rho_n, delta_n, sfac = 0.0, t = 0.0;
         if (i == 0) {
             rho_n = r.gam;
-            delta_n = (1.0 - fexp(-tau_top / mu1)) * B_top * PI - r.cmu;            // fluxes.py:1800
+            delta_n = (1.0 - fexpk(-tau_top / mu1, K)) * B_top * PI - r.cmu;        // fluxes.py:1800
         } else {
             const double em2 = pEM * pEM;
             const double a1 = 1.0 - pgam * em2 * rho, a2 = pgam - em2 * rho;
@@ -261,28 +267,29 @@ __global__ __launch_bounds__(256) void k_thermal_lvl(const ThermalLvlArgs A)
 
     // ---- per angle: Toon Table-3 source-function sweeps (fluxes.py:1864-1910) ----
     for (int k = 0; k < A.nang; ++k) {
-        const double mu = A.u1_dev[k], imu = 1.0 / mu;
+        const double mu = A.u1_dev[k], imu = 1.0 / mu, nlh = 0.5 * NEG_LOG2E * imu;   // exp(-x/(2 mu)) = 2^(x nlh)
         double *fm = A.fm + ((long)k * nlevel) * nw + w, *fp = A.fp + ((long)k * nlevel) * nw + w,
                *fmm = A.fmm + ((long)k * nlevel) * nw + w, *fpm = A.fpm + ((long)k * nlevel) * nw + w;
         // downward
-        double Bcur = planck(0);
-        double Fm = (1 - fexp(-tau_top * imu)) * B_top * 2 * PI;                     // :1875
+        double Bcur = s_B[0];
+        double Fm = (1 - fexpk(-tau_top * imu, K)) * B_top * 2 * PI;                 // :1875
         fm[0] = Fm;
         for (int i = 0; i < n; ++i) {
             const double B0 = Bcur;
-            Bcur = planck(i + 1);
+            Bcur = s_B[(long)(i + 1) * nw];
             const long off = (long)i * pitch + w;
-            const ThermLayer r = therm_layer_coeffs(a, off, B0, Bcur);
+            const ThermLayer r = therm_layer_coeffs(a, off, B0, Bcur, K);
             const double dt = a.dtau[off];
             const double P = s_rho[(long)i * nw], N = s_del[(long)i * nw];
-            const double J = r.gam * (r.lam + 1.0 / mu1) * P, K = (1.0 / mu1 - r.lam) * N;   // :1844-1845
+            const double J = r.gam * (r.lam + 1.0 / mu1) * P, Kc = (1.0 / mu1 - r.lam) * N;  // :1844-1845
             const double si1 = 2 * PI * (r.B0 - r.b1 * (r.s - mu1)), si2 = 2 * PI * r.b1;     // :1848-1849
-            const double ea = fexp(-dt * imu), eam = fexp(-0.5 * dt * imu);
-            const double EPm = fexp(0.5 * r.E), EMm = frcp(EPm);
-            const double lup = frcp(r.lam * mu + 1.0), lum = frcp(r.lam * mu - 1.0);
-            fmm[(long)i * nw] = (Fm * eam + (J * lup) * (EPm - eam) + (K * frcp(-r.lam * mu + 1.0)) * (EMm - eam) +
+            const double eam = fexp2(dt * nlh, K), ea = eam * eam;        // exp(-dtau/(2 mu)), exp(-dtau/mu)
+            const double EPm = r.EPm, EMm = r.EMm;
+            const double lp1 = r.lam * mu + 1.0, lm1 = r.lam * mu - 1.0, r2 = frcp(lp1 * lm1);
+            const double lup = r2 * lm1, lum = r2 * lp1;                  // 1/(lam mu + 1), 1/(lam mu - 1)
+            fmm[(long)i * nw] = (Fm * eam + (J * lup) * (EPm - eam) - (Kc * lum) * (EMm - eam) +
                                  si1 * (1. - eam) + si2 * (mu * eam + 0.5 * dt - mu));         // :1889-1893
-            Fm = (Fm * ea + (J * lup) * (r.EP - ea) + (K * lum) * (ea - r.EM) + si1 * (1. - ea) +
+            Fm = (Fm * ea + (J * lup) * (r.EP - ea) + (Kc * lum) * (ea - r.EM) + si1 * (1. - ea) +
                   si2 * (mu * ea + dt - mu));                                                  // :1883-1887
             fm[(long)(i + 1) * nw] = Fm;
         }
@@ -294,17 +301,18 @@ __global__ __launch_bounds__(256) void k_thermal_lvl(const ThermalLvlArgs A)
         fpm[(long)n * nw] = 0.0;
         double Bnext = Bb;
         for (int i = n - 1; i >= 0; --i) {
-            const double B0 = planck(i);
+            const double B0 = s_B[(long)i * nw];
             const long off = (long)i * pitch + w;
-            const ThermLayer r = therm_layer_coeffs(a, off, B0, Bnext);
+            const ThermLayer r = therm_layer_coeffs(a, off, B0, Bnext, K);
             Bnext = B0;
             const double dt = a.dtau[off];
             const double P = s_rho[(long)i * nw], N = s_del[(long)i * nw];
             const double G = (1.0 / mu1 - r.lam) * P, H = r.gam * (r.lam + 1.0 / mu1) * N;    // :1842-1843
             const double al1 = 2 * PI * (r.B0 + r.b1 * (r.s - mu1)), al2 = 2 * PI * r.b1;     // :1846-1847
-            const double ea = fexp(-dt * imu), eam = fexp(-0.5 * dt * imu);
-            const double EPm = fexp(0.5 * r.E), EMm = frcp(EPm);
-            const double lup = frcp(r.lam * mu + 1.0), lum = frcp(r.lam * mu - 1.0);
+            const double eam = fexp2(dt * nlh, K), ea = eam * eam;
+            const double EPm = r.EPm, EMm = r.EMm;
+            const double lp1 = r.lam * mu + 1.0, lm1 = r.lam * mu - 1.0, r2 = frcp(lp1 * lm1);
+            const double lup = r2 * lm1, lum = r2 * lp1;
             fpm[(long)i * nw] = (Fp * eam + (G * lum) * (r.EP * eam - EPm) - (H * lup) * (r.EM * eam - EMm) +
                                  al1 * (1. - eam) + al2 * (mu + 0.5 * dt - (dt + mu) * eam)); // :1903-1907
             Fp = (Fp * ea + (G * lum) * (r.EP * ea - 1.0) + (H * lup) * (1.0 - r.EM * ea) + al1 * (1. - ea) +

@@ -64,8 +64,25 @@ def main():
                                                           spectra_per_s=1.0 / (t2 - t1),
                                                           note="includes np.zeros of the 4 level-flux arrays "
                                                                "(1.46 GB) the reference signature returns")
-                # level fluxes (climate caller shape: one angle)
-                dd = resident.upload_scene(sc, resident.REFLECTED_PLANES, ctx=ctx)
+                # level fluxes (climate caller shape: one angle, ubar = 0.5): the two-sweep kernels
+                dd = resident.upload_scene(sc, resident.REFLECTED_PLANES + ("w0_no_raman",), ctx=ctx)
+                f0d = DeviceArray.from_host(np.ones(nwno), ctx)
+                dwd = DeviceArray.from_host(np.full(nwno, 0.3), ctx)
+                xl = DeviceArray((1, 1, nwno), ctx)
+                lv4 = [DeviceArray((1, 1, nlayer + 1, nwno), ctx) for _ in range(4)]
+                half = np.array([[0.5]])
+                ms = timeit(lambda: resident.reflected_1d_ck(
+                    ctx, nlayer + 1, nwno, 1, 1, 1, dd, rs, half, half, 1.0, f0d, 3, 0, *TTHG, np.ones(1), xl,
+                    get_toa_intensity=0, lvl_fluxes=lv4), ctx)
+                lb = 8 * nwno * (9 * nlayer + 2 * (nlayer + 1) + 2 + 4 * (nlayer + 1) + 8 * nlayer)
+                out["reflected_lvl_1e5"] = dict(ms=ms, GBps=lb / ms / 1e6,
+                                                note="bytes: planes + 4 level outputs + 4-plane sweep scratch written and read")
+                ms = timeit(lambda: resident.thermal_1d_ck(
+                    ctx, nlayer + 1, d["wno"], nwno, 1, 1, 1, sc["tlevel"], dd["dtau_og"], dd["w0_no_raman"],
+                    dd["cosb_og"], sc["plevel"], half, rs, 0, np.ones(1), xl, dwno=dwd, calc_type=1,
+                    lvl_fluxes=lv4), ctx)
+                lb = 8 * nwno * (3 * nlayer + 3 + 4 * (nlayer + 1) + 8 * nlayer)
+                out["thermal_lvl_1e5"] = dict(ms=ms, GBps=lb / ms / 1e6)
     if only in (None, "variants"):
         # Headline workload variants: (a) as bench.py (cloud slab in 10 of 90 layers: the other layers
         # are not delta-scaled and skip the second exponential), (b) cloud in every layer (every layer
