@@ -7,7 +7,7 @@
  * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it.
  *
  * Pinning: every function here is checked against golden vectors produced by importing the
- * reference's own source in the build container (tests/golden/make_golden.py -> tests/golden/*.npz;
+ * reference's own source in the build container (tests/golden/make_golden.py -> the .npz fixtures under tests/golden;
  * tests/test_oracle_golden.py) and against the reference-owned Dlugach & Yanovitskij table
  * (reference/base_cases/testing/DLUGACH_TEST.csv via tests/test_dlugach.py).
  *
