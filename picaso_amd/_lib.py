@@ -100,6 +100,18 @@ def context(device=None):
     return _ctx[key]
 
 
+def new_context(device=None):
+    """An additional context (its own HIP stream, arenas and block cache) on the device, e.g. to keep
+    two independent spectra in flight.  Device memory may be read from any context's stream."""
+    if device is None:
+        device = int(os.environ.get("PICASO_AMD_DEVICE", "0"))
+    h = ctypes.c_void_p()
+    rc = load().picaso_ctx_create(ctypes.c_int(device), ctypes.byref(h))
+    if rc != 0:
+        raise PicasoHipError(load().picaso_last_error(None).decode())
+    return h
+
+
 def f64(x, shape=None):
     a = np.ascontiguousarray(x, dtype=np.float64)
     if shape is not None and a.shape != tuple(shape):

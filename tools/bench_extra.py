@@ -108,6 +108,47 @@ def main():
                                                       cth, dd["F0PI"], 3, 0, *TTHG, xi, toon_coefficients=0,
                                                       b_top=0.0, gweight=gw, tweight=tw, albedo=al), ctx, reps=20)
             out["reflected_1e5_%s" % tag] = dict(ms=ms, spectra_per_s=1e3 / ms, frac_of_8TBs=0.8 / ms / 8.0)
+    if only in (None, "pipeline"):
+        # Independent spectra kept in flight on two streams (two contexts): a 1e5-column spectrum is
+        # 1.5 waves per SIMD, so the tail of one launch (half the SIMDs idle) overlaps the head of
+        # the next.  Throughput over 40 spectra, same workload as bench.py.
+        nwno = 100000
+        sc = syn.make_scene(nlayer, nwno, seed=3)
+        sc["F0PI"] = np.ones(nwno)
+        sc["surf_reflect"] = np.zeros(nwno)
+        ctxs = [ctx, _lib.new_context(0), _lib.new_context(0), _lib.new_context(0)]
+        dd = resident.upload_scene(sc, resident.REFLECTED_PLANES + ("F0PI", "surf_reflect"), ctx=ctx)
+        outs = [(DeviceArray((5, 1, nwno), c), DeviceArray((nwno,), c)) for c in ctxs]
+        device.sync(ctx)
+
+        def spectrum(j):
+            c = ctxs[j % len(ctxs)]
+            xi, al = outs[j % len(ctxs)]
+            resident.reflected_1d(c, nlayer + 1, nwno, 5, 1, dd, dd["surf_reflect"], u0, u1, 1.0, dd["F0PI"], 3, 0,
+                                  *TTHG, xi, toon_coefficients=0, b_top=0.0, gweight=gw, tweight=tw, albedo=al)
+        for nstream in (1, 2, 3, 4):
+            use = ctxs[:nstream]
+            ctxs_run = use
+            for j in range(4):
+                c = use[j % nstream]
+                resident.reflected_1d(c, nlayer + 1, nwno, 5, 1, dd, dd["surf_reflect"], u0, u1, 1.0, dd["F0PI"],
+                                      3, 0, *TTHG, outs[j % nstream][0], gweight=gw, tweight=tw,
+                                      albedo=outs[j % nstream][1])
+            for c in use:
+                device.sync(c)
+            t0 = time.perf_counter()
+            K = 120
+            for j in range(K):
+                c = use[j % nstream]
+                resident.reflected_1d(c, nlayer + 1, nwno, 5, 1, dd, dd["surf_reflect"], u0, u1, 1.0, dd["F0PI"],
+                                      3, 0, *TTHG, outs[j % nstream][0], gweight=gw, tweight=tw,
+                                      albedo=outs[j % nstream][1])
+            for c in use:
+                device.sync(c)
+            dt_ = time.perf_counter() - t0
+            out["reflected_1e5_throughput_%dstream" % nstream] = dict(ms_per_spectrum=1e3 * dt_ / K,
+                                                                      spectra_per_s=K / dt_)
+        assert all(np.array_equal(outs[0][1].to_host(), o[1].to_host()) for o in outs[1:])
     import ctypes
     from picaso_amd._lib import check, f64, load, ptr
     ci, cd = ctypes.c_int, ctypes.c_double
