@@ -87,6 +87,7 @@ struct LayerIn {
     bool cum_tau;    // tau[i+1] == tau[i] + dtau[i] bit-exactly: exp(-tau[i+1]/u) = exp(-tau[i]/u) exp(-dtau/u)
     bool eo_ok;      // tau_og[i] == tau_og[i-1] + dtau_og[i-1]: the carried product is exp(-tau_og[i]/u)
     bool same_dt;    // dtau_og == dtau (no delta-scaling in this layer)
+    bool nocld;      // ftau_cld == 0 (no cloud in this layer)
 };
 
 // One layer of the sweep.  FIRST / LAST are compile-time so the top row and the bottom-boundary
@@ -112,8 +113,15 @@ __device__ __forceinline__ void reflected_layer(const ReflectedArgs &a, const La
     const double E = fmin(lam * dt, clip);
     const double EP = fexp2(E * -NEG_LOG2E, K);
     const double EM = frcp(EP);
-    const double ps = p_single<IS3D>(a.single_phase, L.cbo, L.gcos2, L.fc, L.fr, a.cos_theta, a.frac_a,
-                                     a.frac_b, a.frac_c, a.constant_back, a.constant_forward);
+    // No cloud anywhere in this layer of the wave (ftau_cld == 0 in every lane, checked per wave):
+    // TTHG_ray's p_single = ftau_cld tthg + ftau_ray 3/4 (1 + cos^2) is its Rayleigh part alone
+    // (bit-identical: 0 * tthg + x = x), without the two Henyey-Greenstein terms.
+    double ps;
+    if (L.nocld && a.single_phase == 3)
+        ps = L.fr * (0.75 * (1.0 + a.cos_theta * a.cos_theta));
+    else
+        ps = p_single<IS3D>(a.single_phase, L.cbo, L.gcos2, L.fc, L.fr, a.cos_theta, a.frac_a, a.frac_b,
+                            a.frac_c, a.constant_back, a.constant_forward);
     const double ssa_h = (L.w0o * F * (0.125 / PI)) * ps;  // (w0_og F0PI/4pi) p_single / 2, fluxes.py:1397-1398
     const double w2pi = w0 * (0.5 / PI);                   // fluxes.py:1290-1296
     const double Fw0h = (0.5 * F) * w0;
@@ -319,6 +327,7 @@ __global__ __launch_bounds__(256, (NA <= 2 ? PZ_REFL_MINWAVES_FEW : PZ_REFL_MINW
         L.cum_tau = __all(L.tau_n == tau_i + L.dt);
         L.eo_ok = __all(L.tauo == tauo_pred);
         L.same_dt = __all(L.dto == L.dt);
+        L.nocld = __all(L.fc == 0.0);
         tau_i = L.tau_n;
         tauo_pred = L.tauo + L.dto;
     };
