@@ -47,6 +47,10 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"),
                     help="collective backend for N > 1 (nccl = RCCL over xGMI; gloo only for smoke "
                          "tests of the sharded path on a box with fewer GPUs than ranks)")
+    ap.add_argument("--pipelined", action="store_true",
+                    help="also time the same K spectra issued round-robin on two streams (extra JSON object; "
+                         "off by default so that a rocprofv3 trace of the default run holds only the "
+                         "single-stream launches the roofline refers to)")
     ap.add_argument("--cpu-sample", type=int, default=100000,
                     help="wavelengths of the same workload timed on the CPU oracle (0 = skip)")
     args = ap.parse_args()
@@ -185,7 +189,7 @@ def main():
             peak = 1024 * 64 / 2.47e-9 / 1e12
             out["fp64_issue"] = {"achieved": rate, "peak_measured": peak, "unit": "T lane-instr/s",
                                  "frac": rate / peak, "valu_wave_insts_per_launch": valu}
-        if world == 1 and not launched:
+        if world == 1 and not launched and args.pipelined:
             # Not the headline: the same K spectra issued round-robin on two streams (two library
             # contexts).  A 1e5-column spectrum is 1.5 waves per SIMD, so on one stream half the SIMDs
             # idle through the tail of every launch; with a second spectrum in flight they do not.
