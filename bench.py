@@ -233,6 +233,28 @@ def main():
                           "%.1f s" % (ns, nwno, cpu_s),
                 "host_cores_available": len(os.sched_getaffinity(0))}
             out["max_rel_err_vs_oracle"] = err
+            # the same C restatement on many host cores: wavelength blocks on a thread pool (the
+            # ctypes calls release the GIL; the reference itself is serial, so this is an upper bound on
+            # what its algorithm could do on this host, not a measurement of the reference)
+            from concurrent.futures import ThreadPoolExecutor
+            nthr = min(64, len(os.sched_getaffinity(0)))
+            if nthr > 1:
+                edges = np.linspace(0, ns, nthr + 1).astype(int)
+
+                def work(j):
+                    a_, b_ = edges[j], edges[j + 1]
+                    pl = [np.ascontiguousarray(scene[k][:, a_:b_]) for k in resident.REFLECTED_PLANES]
+                    x_, _ = orc.get_reflected_1d(nlevel, scene["wno"][a_:b_], b_ - a_, ng, 1, *pl, 0.0, ubar0,
+                                                 ubar1, cos_theta, np.ones(b_ - a_), 3, 0, *TTHG)
+                    return orc.compress_disco(b_ - a_, cos_theta, x_, gw, tw, np.ones(b_ - a_))
+                t1 = time.perf_counter()
+                with ThreadPoolExecutor(nthr) as ex:
+                    parts = list(ex.map(work, range(nthr)))
+                thr_s = time.perf_counter() - t1
+                assert np.array_equal(np.concatenate(parts), alb_cpu)
+                out["cpu_baseline_threads"] = {"value": (ns / nwno) / thr_s, "unit": "spectra/s", "cores": nthr,
+                                               "kind": "port", "sample": "same sample, %d wavelength blocks on "
+                                               "%d threads, %.2f s" % (nthr, nthr, thr_s)}
         print(json.dumps(out), flush=True)
     if launched:
         dist.destroy_process_group()
