@@ -246,6 +246,15 @@ int picaso_get_transit_1d_dev(picaso_ctx *ctx, const double *z, const double *dz
                               const double *player, const double *tlayer, const double *colden,
                               const double *dtau, double *rprs2);
 
+/* The correlated-k loop of the transmission branch (reference picaso/justdoit.py:388-405):
+ * dtau is (nlevel-1, nwno*ngauss) with the Gauss index fastest (= DTAU_OG[:, :, ig] for every ig),
+ * rprs2 (nwno) = sum_ig get_transit_1d(DTAU_OG[:,:,ig]) * gauss_wts[ig], summed in ig order.
+ * gauss_wts is a host array of ngauss (<= 32) weights. */
+int picaso_get_transit_1d_ck_dev(picaso_ctx *ctx, const double *z, const double *dz, int nlevel, int nwno,
+                                 int ngauss, double rstar, const double *mmw, double k_b, double amu,
+                                 const double *player, const double *tlayer, const double *colden,
+                                 const double *dtau, const double *gauss_wts, double *rprs2);
+
 /* ---- correlated-k Gauss-point batch and patchy-cloud blend -------------------------------- */
 /* The reference loops the solver over the `ngauss` correlated-k points of every wavelength bin and
  * accumulates `xint_at_top += xint * gauss_wts[ig]` (reference picaso/justdoit.py:256-307 reflected,

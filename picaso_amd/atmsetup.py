@@ -52,6 +52,7 @@ class ATMSETUP:
         self.warnings = []
         self.c = _Consts()
         self.planet = _Obj()
+        self.planet.radius = self.planet.mass = np.nan       # gravity-only planet unless the caller sets them
         self.layer, self.level = {}, {}
         self.dimension = "1d"
 
@@ -97,11 +98,44 @@ class ATMSETUP:
     def get_density(self):
         self.level["den"] = self.level["pressure"] / (self.c.k_b * self.level["temperature"])
 
-    def get_altitude(self, p_reference=1, constant_gravity=True):
-        """Constant gravity only (the reference falls back to it when no radius is given,
-        atmsetup.py:396-398)."""
-        self.layer["gravity"] = np.zeros(self.c.nlayer) + self.planet.gravity
-        self.level["gravity"] = np.zeros(self.c.nlevel) + self.planet.gravity
+    def get_altitude(self, p_reference=1, constant_gravity=False):
+        """Level altitude ``z``, thickness ``dz`` and gravity by hydrostatic integration outwards
+        from the reference pressure (reference atmsetup.py:384-461).  Without a planet radius the
+        gravity is constant (``:398``) and ``z`` is NaN, as in the reference.  The layer gravity is
+        the mean of the level values *before* the two end levels are filled in (``:453``), so the
+        top and bottom layers carry half the gravity -- kept, it sets ``colden`` and every opacity."""
+        c, planet = self.c, self.planet
+        p_reference = p_reference * c.pconv
+        if np.isnan(planet.radius):
+            constant_gravity = True
+        mmw = self.level["mmw"] * c.amu
+        tlevel, plevel = self.level["temperature"], self.level["pressure"]
+        if p_reference >= np.max(plevel):
+            p_reference = np.max(plevel)
+        else:
+            p_reference = plevel[plevel >= p_reference][0]    # snap to the pressure grid (:414)
+        z = np.zeros(np.shape(tlevel)) + planet.radius
+        dz = np.zeros(np.shape(tlevel))
+        gravity = np.zeros(np.shape(tlevel))
+
+        def g_at(i):
+            return planet.gravity if constant_gravity else c.G * planet.mass / z[i] ** 2
+
+        below = np.unique(np.where(plevel > p_reference)[0])
+        for i in below - 1:                                   # inwards from the reference level
+            gravity[i] = g_at(i)
+            dz[i] = c.k_b * tlevel[i] / (mmw[i] * gravity[i]) * np.log(plevel[i + 1] / plevel[i])
+            z[i + 1] = z[i] - dz[i]
+        for i in np.unique(np.where(plevel <= p_reference)[0])[::-1][:-1]:     # outwards
+            gravity[i] = g_at(i)
+            dz[i] = c.k_b * tlevel[i] / (mmw[i] * gravity[i]) * np.log(plevel[i] / plevel[i - 1])
+            z[i - 1] = z[i] + dz[i]
+        dz[0] = dz[1]
+        dz[-1] = dz[-2]
+        self.level["z"], self.level["dz"] = z, dz
+        self.layer["gravity"] = 0.5 * (gravity[:-1] + gravity[1:])
+        gravity[-1], gravity[0] = g_at(-1), g_at(0)
+        self.level["scale_height"] = c.k_b * tlevel / (mmw * gravity)
 
     def get_column_density(self):
         self.layer["colden"] = (self.level["pressure"][1:] - self.level["pressure"][:-1]) / self.layer["gravity"]

@@ -121,4 +121,22 @@ int picaso_get_transit_1d(picaso_ctx *ctx, const double *z, const double *dz, in
     return 0;
 }
 
+int picaso_get_transit_1d_ck_dev(picaso_ctx *ctx, const double *z, const double *dz, int nlevel, int nwno,
+                                 int ngauss, double rstar, const double *mmw, double k_b, double amu,
+                                 const double *player, const double *tlayer, const double *colden,
+                                 const double *dtau, const double *gauss_wts, double *rprs2)
+{
+    if (!ctx) return fail(nullptr, "null context");
+    if (ngauss < 1 || ngauss > MAX_CK_GAUSS) return fail(ctx, "get_transit_1d_ck: ngauss must be 1..%d", MAX_CK_GAUSS);
+    if (!gauss_wts) return fail(ctx, "get_transit_1d_ck: gauss_wts is null");
+    if (nlevel < 2 || nwno < 1) return fail(ctx, "get_transit_1d_ck: bad sizes nlevel=%d nwno=%d", nlevel, nwno);
+    const long ncol = (long)nwno * ngauss;
+    if (ncol > 0x7fffffffL) return fail(ctx, "get_transit_1d_ck: nwno*ngauss exceeds 2^31-1");
+    PZ_TRY(ck_scratch_reserve(ctx, sizeof(double) * (size_t)ncol));
+    PZ_TRY(picaso_get_transit_1d_dev(ctx, z, dz, nlevel, (int)ncol, ncol, rstar, mmw, k_b, amu, player, tlayer,
+                                     colden, dtau, ctx->ck_scratch));
+    // rprs2 += rprs2_g * gauss_wts[ig] in ig order (justdoit.py:388-405)
+    return launch_weighted_colsum(ctx, 1, nwno, ngauss, gauss_wts, ctx->ck_scratch, rprs2);
+}
+
 }  // extern "C"

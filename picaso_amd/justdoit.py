@@ -432,6 +432,24 @@ def picaso(bundle, opacityclass, dimension="1d", calculation="reflected", full_o
             returns["fpfs_thermal"] = thermal / stellar * (atm.planet.radius / radius_star) ** 2.0
         else:
             returns["fpfs_thermal"] = []
+    if "transmission" in calculation:                         # justdoit.py:388-405, :522-523
+        if dimension != "1d":
+            raise Exception("transmission is a 1-D calculation (the reference has no 3-D branch for it)")
+        if radius_star == "nostar" or np.isnan(radius_star) or np.isnan(atm.planet.radius):
+            raise Exception("transmission needs the stellar radius (star()) and the planet radius and "
+                            "mass (gravity())")
+        tr = DeviceArray((nwno,), ctx)
+
+        def runtr(pl, out):
+            resident.transit_1d_ck(ctx, atm.level["z"], atm.level["dz"], nlevel, nwno, ngauss, radius_star,
+                                   atm.layer["mmw"], atm.c.k_b, atm.c.amu, atm.level["pressure"],
+                                   atm.level["temperature"], atm.layer["colden"], pl["dtau_og"], gauss_wts, out)
+        runtr(planes, tr)
+        if do_holes:                                          # blend per Gauss point == blend of the sums
+            trc = DeviceArray((nwno,), ctx)
+            runtr(planes_clear, trc)
+            resident.axpby(ctx, 1.0 - fhole, tr, fhole, trc, tr)
+        returns["transit_depth"] = tr.to_host()
     if ("fpfs_reflected" in returns) and ("fpfs_thermal" in returns):
         if (not isinstance(returns["fpfs_reflected"], list)) and (not isinstance(returns["fpfs_thermal"], list)):
             returns["fpfs_total"] = returns["fpfs_thermal"] + returns["fpfs_reflected"]

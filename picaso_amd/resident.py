@@ -122,6 +122,17 @@ def thermal_1d_ck(ctx, nlevel, wno, nwno, ngauss, numg, numt, tlevel, dtau, w0, 
         ptr(tw) if tw is not None else None, _addr(flux_disk)), ctx)
 
 
+def transit_1d_ck(ctx, z, dz, nlevel, nwno, ngauss, rstar, mmw, k_b, amu, player, tlayer, colden, dtau,
+                  gauss_wts, rprs2):
+    """The transmission branch's correlated-k loop (reference justdoit.py:388-405) on a resident
+    ``DTAU_OG`` plane ``(nlevel-1, nwno*ngauss)``, Gauss index fastest; ``rprs2`` (nwno) DeviceArray."""
+    wts = f64(gauss_wts, (ngauss,))
+    check(load().picaso_get_transit_1d_ck_dev(
+        ctx, ptr(f64(z, (nlevel,))), ptr(f64(dz, (nlevel,))), _ci(nlevel), _ci(nwno), _ci(ngauss),
+        _cd(rstar), ptr(f64(mmw, (nlevel - 1,))), _cd(k_b), _cd(amu), ptr(f64(player)), ptr(f64(tlayer)),
+        ptr(f64(colden, (nlevel - 1,))), _addr(dtau), ptr(wts), _addr(rprs2)), ctx)
+
+
 def axpby(ctx, a, x, b, y, out):
     """``out = a*x + b*y`` on DeviceArrays of equal size (patchy-cloud blend, justdoit.py:300-305)."""
     n = int(np.prod(x.shape))

@@ -255,6 +255,23 @@ if __name__ == "__main__":
 # ------------------------------------------------------------------------------------------------
 # opacity pre-stage: RetrieveOpacities.get_opacities[_nearest] + compute_opacity
 # ------------------------------------------------------------------------------------------------
+def _ref_colden(p_dyn, tlevel, mmw_lvl, gravity, p_reference=1):
+    """Layer column density exactly as the reference's ATMSETUP produces it for a gravity-only planet
+    (get_altitude + get_column_density, atmsetup.py:384-461, :549-555; justdoit.py:204-206)."""
+    am = ref_shim.load("atmsetup")
+
+    class Bare:
+        pass
+    s = Bare()
+    s.c, s.planet, s.level, s.layer = Bare(), Bare(), {}, {}
+    s.c.pconv, s.c.k_b, s.c.amu, s.c.G, s.c.nlevel = 1e6, 1.380649e-16, 1.66053906660e-24, 6.6743e-8, len(p_dyn)
+    s.planet.radius, s.planet.mass, s.planet.gravity = np.nan, np.nan, gravity
+    s.level.update(mmw=mmw_lvl, temperature=tlevel, pressure=p_dyn)
+    am.ATMSETUP.get_altitude(s, p_reference=p_reference)
+    am.ATMSETUP.get_column_density(s)
+    return s.layer["colden"]
+
+
 def make_optics():
     """Synthetic monochromatic sqlite DB in the reference schema (committed next to the fixtures),
     driven through the reference's own RetrieveOpacities + compute_opacity with a duck-typed
@@ -346,7 +363,7 @@ def make_optics():
         lay_mix = pd.DataFrame({k: 0.5 * (v[1:] + v[:-1]) for k, v in mix.items()})
         mmw_lvl = sum(mix[k] * weights[k] for k in mix)
         atm.layer = {"pressure": np.sqrt(p[1:] * p[:-1]), "temperature": 0.5 * (tlevel[1:] + tlevel[:-1]),
-                     "mmw": 0.5 * (mmw_lvl[1:] + mmw_lvl[:-1]), "colden": (p[1:] - p[:-1]) / gravity,
+                     "mmw": 0.5 * (mmw_lvl[1:] + mmw_lvl[:-1]), "colden": _ref_colden(p, tlevel, mmw_lvl, gravity),
                      "electrons": np.zeros(nlayer), "mixingratios": lay_mix,
                      "cloud": {"opd": cld_opd.copy(), "w0": cld_w0.copy(), "g0": cld_g0.copy()}}
         atm.molecules = np.array(["H2O", "CH4", "H2"])
@@ -355,6 +372,7 @@ def make_optics():
         return atm
 
     store = {"in/plevel_bar": plevel_bar, "in/tlevel": tlevel, "in/gravity": np.array(gravity),
+             "in/colden": make_atm().layer["colden"],
              "in/cld_opd": cld_opd, "in/cld_w0": cld_w0, "in/cld_g0": cld_g0, "in/wno": wno}
     for k, v in mix.items():
         store["in/mix/" + k] = v
@@ -441,7 +459,7 @@ def make_ck():
         lay_mix = pd.DataFrame({k: 0.5 * (v[1:] + v[:-1]) for k, v in mix.items()})
         mmw_lvl = sum(mix[k] * weights[k] for k in mix)
         atm.layer = {"pressure": np.sqrt(p[1:] * p[:-1]), "temperature": 0.5 * (tlevel[1:] + tlevel[:-1]),
-                     "mmw": 0.5 * (mmw_lvl[1:] + mmw_lvl[:-1]), "colden": (p[1:] - p[:-1]) / gravity,
+                     "mmw": 0.5 * (mmw_lvl[1:] + mmw_lvl[:-1]), "colden": _ref_colden(p, tlevel, mmw_lvl, gravity),
                      "electrons": np.zeros(nlayer), "mixingratios": lay_mix,
                      "cloud": {"opd": og["in/cld_opd"].copy(), "w0": og["in/cld_w0"].copy(),
                                "g0": og["in/cld_g0"].copy()}}
@@ -571,3 +589,45 @@ if __name__ == "__main__" and (("transit" in sys.argv[1:]) or not sys.argv[1:]):
     make_transit()
 if __name__ == "__main__" and (("sh" in sys.argv[1:]) or not sys.argv[1:]):
     make_sh()
+
+
+def make_altitude():
+    """ATMSETUP.get_altitude + get_column_density of the reference (atmsetup.py:384-461, :549-555),
+    called unbound on a bare object carrying the fields they read (astropy is absent here, so the
+    constants are given in cgs as astropy would)."""
+    am = ref_shim.load("atmsetup")
+
+    class Bare:
+        pass
+    store = {}
+    cases = dict(
+        const_g=dict(nlevel=12, radius=np.nan, mass=np.nan, gravity=2500.0, p_reference=1.0, plo=-5, phi=2),
+        r_and_m=dict(nlevel=31, radius=7.1e9, mass=1.9e30, gravity=2516.0, p_reference=10.0, plo=-6, phi=2),
+        pref_deep=dict(nlevel=9, radius=6.4e8, mass=6.0e27, gravity=978.0, p_reference=1e4, plo=-4, phi=1),
+        pref_top=dict(nlevel=7, radius=2.5e9, mass=1.0e29, gravity=1068.0, p_reference=1e-9, plo=-3, phi=1),
+    )
+    rng = np.random.default_rng(5)
+    for name, cs in cases.items():
+        n = cs["nlevel"]
+        s = Bare()
+        s.c, s.planet, s.level, s.layer = Bare(), Bare(), {}, {}
+        s.c.pconv, s.c.k_b, s.c.amu, s.c.G, s.c.nlevel = 1e6, 1.380649e-16, 1.66053906660e-24, 6.6743e-8, n
+        s.planet.radius, s.planet.mass, s.planet.gravity = cs["radius"], cs["mass"], cs["gravity"]
+        s.level["mmw"] = 2.2 + 0.3 * rng.random(n)
+        s.level["temperature"] = 150.0 + 1200.0 * np.linspace(0, 1, n) ** 1.5
+        s.level["pressure"] = np.logspace(cs["plo"], cs["phi"], n) * 1e6
+        am.ATMSETUP.get_altitude(s, p_reference=cs["p_reference"])
+        am.ATMSETUP.get_column_density(s)
+        for k in ("radius", "mass", "gravity", "p_reference"):
+            store["%s/%s" % (name, k)] = np.array(cs[k])
+        for k in ("mmw", "temperature", "pressure", "z", "dz", "scale_height"):
+            store["%s/%s" % (name, k)] = s.level[k]
+        store["%s/layer_gravity" % name] = s.layer["gravity"]
+        store["%s/colden" % name] = s.layer["colden"]
+    path = os.path.join(HERE, "altitude.npz")
+    np.savez_compressed(path, **store)
+    print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024))
+
+
+if __name__ == "__main__" and (("altitude" in sys.argv[1:]) or not sys.argv[1:]):
+    make_altitude()

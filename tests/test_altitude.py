@@ -1,0 +1,35 @@
+"""Host-side hydrostatic altitude / column density against vectors produced by the reference's own
+``ATMSETUP.get_altitude`` / ``get_column_density`` (tests/golden/make_golden.py altitude)."""
+import os
+
+import numpy as np
+import pytest
+
+from picaso_amd.atmsetup import ATMSETUP
+
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "altitude.npz"))
+CASES = sorted({k.split("/")[0] for k in G.files})
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_altitude_matches_reference(case):
+    g = {k.split("/", 1)[1]: G[k] for k in G.files if k.startswith(case + "/")}
+    atm = ATMSETUP({})
+    atm.planet.radius, atm.planet.mass = float(g["radius"]), float(g["mass"])
+    atm.planet.gravity = float(g["gravity"])
+    atm.level.update(mmw=g["mmw"], temperature=g["temperature"], pressure=g["pressure"])
+    atm.c.nlevel, atm.c.nlayer = len(g["mmw"]), len(g["mmw"]) - 1
+    atm.get_altitude(p_reference=float(g["p_reference"]))
+    atm.get_column_density()
+    for key, got in (("z", atm.level["z"]), ("dz", atm.level["dz"]),
+                     ("scale_height", atm.level["scale_height"]),
+                     ("layer_gravity", atm.layer["gravity"]), ("colden", atm.layer["colden"])):
+        np.testing.assert_allclose(got, g[key], rtol=1e-14, atol=0, equal_nan=True, err_msg=key)
+
+
+def test_end_layers_carry_half_gravity():
+    # the reference averages the level gravity before filling its two end levels (atmsetup.py:453)
+    g = {k.split("/", 1)[1]: G[k] for k in G.files if k.startswith("const_g/")}
+    lg = g["layer_gravity"]
+    assert lg[0] == 0.5 * g["gravity"] and lg[-1] == 0.5 * g["gravity"]
+    assert np.all(lg[1:-1] == g["gravity"])

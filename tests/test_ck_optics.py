@@ -47,7 +47,7 @@ def _layers(og):
     mmw_l = sum(og["in/mix/" + k] * WEIGHTS[k] for k in WEIGHTS)
     mmw = 0.5 * (mmw_l[1:] + mmw_l[:-1])
     g = float(og["in/gravity"])
-    colden = (p[1:] - p[:-1]) / g
+    colden = og["in/colden"]                 # as the reference's ATMSETUP gives it (half-gravity end layers)
     tlayer = 0.5 * (t[1:] + t[:-1])
     player = np.sqrt(p[1:] * p[:-1]) / 1e6
     plev = p / 1e6

@@ -67,7 +67,7 @@ def test_atmsetup_layer_quantities():
     c.atmosphere(df={"pressure": p, "temperature": np.linspace(200, 900, nlevel), "H2": np.full(nlevel, 0.85),
                      "He": np.full(nlevel, 0.15)})
     atm = ATMSETUP(c.inputs)
-    atm.planet.gravity = 2500.0
+    atm.planet.gravity, atm.planet.radius, atm.planet.mass = 2500.0, np.nan, np.nan
     atm.get_profile()
     atm.get_mmw()
     atm.get_altitude()
@@ -75,7 +75,9 @@ def test_atmsetup_layer_quantities():
     assert atm.c.nlevel == nlevel and atm.c.nlayer == nlevel - 1
     assert np.allclose(atm.layer["pressure"], np.sqrt(p[1:] * p[:-1]) * 1e6)      # bars -> dyn/cm2, log mean
     assert np.allclose(atm.layer["mmw"], 0.85 * 2.01588 + 0.15 * 4.002602)
-    assert np.allclose(atm.layer["colden"], (p[1:] - p[:-1]) * 1e6 / 2500.0)
+    g_layer = np.full(nlevel - 1, 2500.0)
+    g_layer[[0, -1]] = 1250.0                 # the reference's end layers (atmsetup.py:453)
+    assert np.allclose(atm.layer["colden"], (p[1:] - p[:-1]) * 1e6 / g_layer)
     atm.get_clouds(np.linspace(1000, 2000, 7))
     assert atm.cloud_free and atm.layer["cloud"]["opd"].shape == (nlevel - 1, 7) and not atm.layer["cloud"]["opd"].any()
 

@@ -48,7 +48,7 @@ def test_oracle_compute_opacity(gold):
     mmw_l = sum(gold["in/mix/" + k] * WEIGHTS[k] for k in WEIGHTS)
     mmw = 0.5 * (mmw_l[1:] + mmw_l[:-1])
     g = float(gold["in/gravity"])
-    colden = (p[1:] - p[:-1]) / g
+    colden = gold["in/colden"]               # as the reference's ATMSETUP gives it (half-gravity end layers)
     tlayer = 0.5 * (t[1:] + t[:-1])
     plev = p / 1e6
     A = (tlayer / (t[:-1] * t[1:])) * (t[1:] * plev[1:] - t[:-1] * plev[:-1]) / (plev[1:] - plev[:-1])

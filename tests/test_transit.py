@@ -69,3 +69,71 @@ def test_gpu_transit_vs_oracle_large(oracle):
         ptr(f64(t)), ptr(f64(colden)), ptr(d.addr), ptr(out.addr)), ctx)
     base = (z.min() / 6.96e10) ** 2
     assert rel_err(out.to_host() - base, Fo - base) < 1e-9
+
+
+def _transit_case(og, jdi, **cloud_kw):
+    case = jdi.inputs()
+    case.phase_angle(0)
+    case.gravity(radius=7.1e9, mass=1.9e30)
+    case.star(relative_flux=np.ones(len(og["in/wno"])), radius=6.96e10, semi_major=7.5e11)
+    prof = {"pressure": og["in/plevel_bar"], "temperature": og["in/tlevel"]}
+    for k in ("H2", "He", "H2O", "CH4"):
+        prof[k] = og["in/mix/" + k]
+    case.atmosphere(df=prof)
+    case.clouds(df={"opd": og["in/cld_opd"], "w0": og["in/cld_w0"], "g0": og["in/cld_g0"]}, **cloud_kw)
+    case.approx(raman="none", p_reference=10)
+    return case
+
+
+def _oracle_depth(oracle, fo, dtau_og, wts, rstar=6.96e10):
+    """The Gauss-point loop of justdoit.py:388-405 with the CPU oracle."""
+    lv, ly = fo["level"], fo["layer"]
+    nlevel, nwno = len(lv["z"]), dtau_og.shape[1]
+    out = 0.0
+    for ig, w in enumerate(wts):
+        out = out + w * oracle.get_transit_1d(lv["z"], lv["dz"], nlevel, nwno, rstar, ly["mmw"], 1.380649e-16,
+                                              1.66053906660e-24, lv["pressure"] * 1e6, lv["temperature"],
+                                              ly["column_density"], np.ascontiguousarray(dtau_og[:, :, ig]))
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["mono", "ck", "holes"])
+def test_gpu_transmission_end_to_end(oracle, kind):
+    """inputs.spectrum(calculation='transmission'): hydrostatic z/dz from ATMSETUP.get_altitude
+    (pinned to the reference in test_altitude.py), DTAU_OG resident, correlated-k sum and
+    patchy-cloud blend on the device; against the oracle on the run's own optical depths."""
+    import test_ck_optics as tck
+    from picaso_amd import justdoit as jdi
+    og = np.load(os.path.join(os.path.dirname(__file__), "golden", "optics.npz"))
+    if kind == "ck":
+        ck = np.load(os.path.join(os.path.dirname(__file__), "golden", "ck.npz"))
+        opa, wts = tck._ck_class(ck), ck["in/gauss_wts"]
+    else:
+        opa, wts = jdi.opannection(tck.DB, query_method="linear"), np.array([1.0])
+    fhole, fthin = 0.35, 0.2
+    case = _transit_case(og, jdi, **(dict(do_holes=True, fhole=fhole, fthin_cld=fthin) if kind == "holes" else {}))
+    out = case.spectrum(opa, calculation="transmission", full_output=True)
+    fo = out["full_output"]
+    nlayer, nwno = fo["taucld"].shape[:2]
+    gas = fo["taugas"].reshape(nlayer, nwno, -1) + fo["tauray"].reshape(nlayer, nwno, -1)
+    cld = og["in/cld_opd"][:, :, None]      # (full_output keeps the thinned deck when do_holes)
+    assert np.all(np.diff(fo["level"]["z"]) < 0) and np.isfinite(out["transit_depth"]).all()
+    want = _oracle_depth(oracle, fo, gas + cld, wts)
+    if kind == "holes":
+        want = (1.0 - fhole) * want + fhole * _oracle_depth(oracle, fo, gas + fthin * cld, wts)
+    base = (fo["level"]["z"].min() / 6.96e10) ** 2
+    assert rel_err(out["transit_depth"] - base, want - base) < 1e-9
+    # the cloud deck and the molecular bands both show: depth varies with wavelength
+    assert np.ptp(out["transit_depth"]) > 0
+
+
+@pytest.mark.gpu
+def test_gpu_transmission_needs_radii():
+    import test_ck_optics as tck
+    from picaso_amd import justdoit as jdi
+    og = np.load(os.path.join(os.path.dirname(__file__), "golden", "optics.npz"))
+    case = _transit_case(og, jdi)
+    case.gravity(gravity=2500.0)
+    with pytest.raises(Exception, match="radius"):
+        case.spectrum(jdi.opannection(tck.DB, query_method="linear"), calculation="transmission")

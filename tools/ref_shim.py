@@ -44,7 +44,7 @@ def install_shims():
         nb.__graft_shim__ = True
         sys.modules["numba"] = nb
     for name in ("bokeh", "bokeh.plotting", "bokeh.palettes", "bokeh.io", "bokeh.models",
-                 "astropy", "astropy.io", "astropy.io.fits", "h5py"):
+                 "astropy", "astropy.io", "astropy.io.fits", "astropy.units", "astropy.constants", "h5py"):
         if name not in sys.modules:
             sys.modules[name] = _Dummy(name)
     os.environ.setdefault("picaso_refdata", os.path.join(REF_ROOT, "reference"))
@@ -65,7 +65,7 @@ _cache = {}
 
 
 def load(name):
-    """name in {'fluxes','disco','rayleigh','optics'} -> reference module object."""
+    """name in {'fluxes','disco','rayleigh','optics','atmsetup'} -> reference module object."""
     if name in _cache:
         return _cache[name]
     if not available():
@@ -73,12 +73,12 @@ def load(name):
     install_shims()
     if name in ("fluxes", "disco", "rayleigh"):
         mod = _load_by_path("_picaso_ref_" + name, name + ".py")
-    elif name == "optics":
+    elif name in ("optics", "atmsetup"):
         if "picaso" not in sys.modules:
             pkg = types.ModuleType("picaso")
             pkg.__path__ = [os.path.join(REF_ROOT, "picaso")]
             sys.modules["picaso"] = pkg
-        mod = importlib.import_module("picaso.optics")
+        mod = importlib.import_module("picaso." + name)
     else:
         raise KeyError(name)
     _cache[name] = mod
