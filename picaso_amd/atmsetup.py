@@ -2,34 +2,61 @@
 picaso/atmsetup.py:17-876, restricted to what ``picaso()`` needs to feed the opacity and solver
 kernels).  Host-side numpy only; everything is cgs (no astropy units).
 
-Kept from the reference: level -> layer averaging (atmsetup.py:219-229), mean molecular weight
-(:345-361), constant-gravity column density (:549-556), the cloud-free default and the
-``(nlayer, nwno)`` reshape of cloud tables (:558-627), ``get_needed_continuum`` (:248-283).
-Out of scope: altitude integration, chemistry, 3-D regridding, virga clouds.
+Kept from the reference: level -> layer averaging (atmsetup.py:219-229), molecular weights from
+main-isotope masses (``get_weights`` :285-342) and mean molecular weight (:345-361), hydrostatic
+altitude and the column density with its half-gravity end layers (:384-461, :549-556), the
+cloud-free default and the ``(nlayer, nwno)`` reshape of cloud tables (:558-627),
+``get_needed_continuum`` (:248-283).  Pinned to the reference by tests/golden/altitude.npz.
+Out of scope: chemistry, 3-D regridding, virga clouds.
 """
 import numpy as np
 
-# atomic masses (g/mol) for the species the synthetic / test configurations use
-_ATOMIC = {"H": 1.00794, "He": 4.002602, "C": 12.0107, "N": 14.0067, "O": 15.9994, "Na": 22.98977,
-           "K": 39.0983, "S": 32.065, "P": 30.97376, "Ti": 47.867, "V": 50.9415, "Fe": 55.845,
-           "Si": 28.0855, "Mg": 24.305, "Al": 26.98154, "Ca": 40.078, "Cr": 51.9961, "Li": 6.941,
-           "Rb": 85.4678, "Cs": 132.90545, "Cl": 35.453, "F": 18.9984}
+# Mass (u) of the most abundant isotope of every element: the reference weighs a molecule with these,
+# not with standard atomic weights (``get_weights``, atmsetup.py:285-342: argmax of the isotope
+# abundances), so H2 is 2.01565 rather than 2.01588 -- it enters every opacity through colden/mmw.
+_MAIN_ISOTOPE = {
+    "H": 1.0078250321, "D": 2.014101778, "He": 4.0026032497, "Li": 7.016004, "Be": 9.0121821,
+    "B": 11.0093055, "C": 12.0, "N": 14.0030740052, "O": 15.9949146221, "F": 18.9984032,
+    "Ne": 19.9924401759, "Na": 22.98976967, "Mg": 23.9850419, "Al": 26.98153844, "Si": 27.9769265327,
+    "P": 30.97376151, "S": 31.97207069, "Cl": 34.96885271, "Ar": 39.962383123, "K": 38.9637069,
+    "Ca": 39.9625912, "Sc": 44.9559102, "Ti": 47.9479471, "V": 50.9439637, "Cr": 51.9405119,
+    "Mn": 54.9380496, "Fe": 55.9349421, "Co": 58.9332002, "Ni": 57.9353479, "Cu": 62.9296011,
+    "Zn": 63.9291466, "Ga": 68.925581, "Ge": 73.9211782, "As": 74.9215964, "Se": 79.9165218,
+    "Br": 78.9183376, "Kr": 83.911507, "Rb": 84.9117893, "Sr": 87.9056143, "Y": 88.9058479,
+    "Zr": 89.9047037, "Nb": 92.9063775, "Mo": 97.9054078, "Tc": 97.907216, "Ru": 101.9043495,
+    "Rh": 102.905504, "Pd": 105.903483, "Ag": 106.905093, "Cd": 113.9033581, "In": 114.903878,
+    "Sn": 119.9021966, "Sb": 120.903818, "Te": 129.9062228, "I": 126.904468, "Xe": 131.9041545,
+    "Cs": 132.905447, "Ba": 137.905241, "La": 138.906348, "Ce": 139.905434, "Pr": 140.907648,
+    "Nd": 141.907719, "Pm": 144.912744, "Sm": 151.919728, "Eu": 152.921226, "Gd": 157.924101,
+    "Tb": 158.925343, "Dy": 163.929171, "Ho": 164.930319, "Er": 165.93029, "Tm": 168.934211,
+    "Yb": 173.9388581, "Lu": 174.9407679, "Hf": 179.9465488, "Ta": 180.947996, "W": 183.9509326,
+    "Re": 186.9557508, "Os": 191.961479, "Ir": 192.962924, "Pt": 194.964774, "Au": 196.966552,
+    "Hg": 201.970626, "Tl": 204.974412, "Pb": 207.976636, "Bi": 208.980383, "Po": 208.982416,
+    "At": 209.987131, "Rn": 222.0175705, "Fr": 223.0197307, "Ra": 226.0254026, "Ac": 227.027747,
+    "Th": 232.0380504, "Pa": 231.0358789, "U": 238.0507826, "Np": 237.0481673, "Pu": 244.064198,
+    "Am": 243.0613727, "Cm": 247.070347, "Bk": 247.070299, "Cf": 251.07958, "Es": 252.08297,
+    "Fm": 257.095099, "Md": 258.098425, "No": 259.10102, "Lr": 262.10969, "Rf": 261.10875,
+    "Db": 262.11415, "Sg": 266.12193, "Bh": 264.12473, "Hs": 269.13411, "Mt": 268.13882}
 
 
 def molecular_weight(name):
-    """Molecular weight from a formula such as 'H2O', 'CH4', 'TiO' (case-sensitive elements)."""
+    """Molecular weight from a formula such as 'H2O', 'CH4', 'TiO', 'CH3D' (case-sensitive elements),
+    tokenised as the reference does (``separate_molecule_name`` / ``separate_string_number``,
+    atmsetup.py:807-820): charges are ignored ('H3+' weighs 3 H).  Raises ``KeyError`` for anything
+    that is not a formula; the reference's '_'-separated isotopologue names are not built."""
     import re
-    if name in ("e-", "H-"):
-        return _ATOMIC["H"] if name == "H-" else 5.4858e-4
-    name = name.rstrip("+-")
-    total, pos = 0.0, 0
-    for m in re.finditer(r"([A-Z][a-z]?)(\d*)", name):
-        if m.start() != pos or m.group(1) not in _ATOMIC:
-            raise KeyError(name)
-        total += _ATOMIC[m.group(1)] * (int(m.group(2)) if m.group(2) else 1)
-        pos = m.end()
-    if pos != len(name) or total == 0:
+    if name == "e-":
+        return 0.0                                            # no element token: weight 0 (:309, :340)
+    if "_" in name:
         raise KeyError(name)
+    total = 0.0
+    tokens = re.findall(r"[A-Z][a-z]?\d*|\d+", name)
+    if not tokens:
+        raise KeyError(name)
+    for tok in tokens:
+        sep = re.findall(r"[A-Za-z]+|\d+", tok)
+        el, num = (sep[0], 1) if len(sep) == 1 else sep
+        total += _MAIN_ISOTOPE[el] * float(num)
     return total
 
 

@@ -272,6 +272,12 @@ def _ref_colden(p_dyn, tlevel, mmw_lvl, gravity, p_reference=1):
     return s.layer["colden"]
 
 
+def _ref_weights(names):
+    """Molecular weights from the reference's ATMSETUP.get_weights (main-isotope masses)."""
+    am = ref_shim.load("atmsetup")
+    return {k: float(am.ATMSETUP.get_weights(object(), [k])[k]) for k in names}
+
+
 def make_optics():
     """Synthetic monochromatic sqlite DB in the reference schema (committed next to the fixtures),
     driven through the reference's own RetrieveOpacities + compute_opacity with a duck-typed
@@ -343,7 +349,7 @@ def make_optics():
     mix = {"H2": np.full(nlevel, 0.84), "He": np.full(nlevel, 0.155),
            "H2O": np.linspace(1e-4, 3e-3, nlevel), "CH4": np.linspace(4e-4, 1e-3, nlevel)}
     gravity = 2500.0
-    weights = {"H2": 2.01588, "He": 4.002602, "H2O": 18.01528, "CH4": 16.04246}
+    weights = _ref_weights(("H2", "He", "H2O", "CH4"))
     cld_opd = np.zeros((nlayer, nwno))
     cld_opd[14:20] = 0.3 * (1.0 + 0.2 * np.sin(wno / 3000.0))
     cld_w0 = np.zeros((nlayer, nwno))
@@ -376,6 +382,7 @@ def make_optics():
              "in/cld_opd": cld_opd, "in/cld_w0": cld_w0, "in/cld_g0": cld_g0, "in/wno": wno}
     for k, v in mix.items():
         store["in/mix/" + k] = v
+        store["in/weight/" + k] = np.array(weights[k])
     names = ("dtau", "tau", "w0", "cosb", "ftau_cld", "ftau_ray", "gcos2", "dtau_og", "tau_og",
              "w0_og", "cosb_og", "w0_no_raman", "f_deltaM")
     raman_file = os.path.join(ref_shim.REF_ROOT, "reference", "opacities", "raman.txt")
@@ -447,7 +454,7 @@ def make_ck():
     mixkeys = ("H2", "He", "H2O", "CH4")
     mix = {k: og["in/mix/" + k] for k in mixkeys}
     gravity = float(og["in/gravity"])
-    weights = {"H2": 2.01588, "He": 4.002602, "H2O": 18.01528, "CH4": 16.04246}
+    weights = _ref_weights(("H2", "He", "H2O", "CH4"))
 
     def make_atm():
         atm = types.SimpleNamespace()
@@ -624,6 +631,15 @@ def make_altitude():
             store["%s/%s" % (name, k)] = s.level[k]
         store["%s/layer_gravity" % name] = s.layer["gravity"]
         store["%s/colden" % name] = s.layer["colden"]
+    # molecular weights of the species PICASO's opacity databases and chemistry tables name
+    mols = ["H2", "He", "H2O", "CH4", "CO", "CO2", "NH3", "N2", "Na", "K", "TiO", "VO", "FeH", "H2S", "PH3", "HCN",
+            "C2H2", "C2H4", "C2H6", "O2", "O3", "SO2", "Fe", "H", "Li", "Rb", "Cs", "CrH", "MgH", "SiO", "OCS",
+            "LiCl", "LiH", "LiF", "H-", "H+", "H3+", "NO", "NO2", "N2O", "CaH", "AlH", "OH", "CH3D", "HDO", "Ar",
+            "Ne", "Kr", "Xe", "SiH4", "GeH4", "AsH3", "HCl", "HF", "NaH", "KCl", "Mg", "Ca", "Al", "Ti", "V", "Cr",
+            "Mn", "Ni", "Zn", "C", "N", "O", "S", "P", "Si", "graphite"]
+    wts = _ref_weights(mols)
+    store["weights/names"] = np.array(mols)
+    store["weights/values"] = np.array([wts[m] for m in mols])
     path = os.path.join(HERE, "altitude.npz")
     np.savez_compressed(path, **store)
     print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024))

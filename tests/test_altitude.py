@@ -5,10 +5,10 @@ import os
 import numpy as np
 import pytest
 
-from picaso_amd.atmsetup import ATMSETUP
+from picaso_amd.atmsetup import ATMSETUP, molecular_weight
 
 G = np.load(os.path.join(os.path.dirname(__file__), "golden", "altitude.npz"))
-CASES = sorted({k.split("/")[0] for k in G.files})
+CASES = sorted({k.split("/")[0] for k in G.files} - {"weights"})
 
 
 @pytest.mark.parametrize("case", CASES)
@@ -33,3 +33,15 @@ def test_end_layers_carry_half_gravity():
     lg = g["layer_gravity"]
     assert lg[0] == 0.5 * g["gravity"] and lg[-1] == 0.5 * g["gravity"]
     assert np.all(lg[1:-1] == g["gravity"])
+
+
+def test_molecular_weights_match_reference():
+    """Main-isotope masses (reference ATMSETUP.get_weights, atmsetup.py:285-342), not standard
+    atomic weights: H2 = 2.01565."""
+    for name, want in zip(G["weights/names"], G["weights/values"]):
+        if want == 0.0:                       # no element token: the reference carries it at weight 0
+            with pytest.raises(KeyError):
+                molecular_weight(str(name))
+        else:
+            assert molecular_weight(str(name)) == pytest.approx(float(want), rel=1e-15), name
+    assert molecular_weight("H2") == pytest.approx(2.0156500642, rel=1e-15)

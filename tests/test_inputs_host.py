@@ -74,7 +74,7 @@ def test_atmsetup_layer_quantities():
     atm.get_column_density()
     assert atm.c.nlevel == nlevel and atm.c.nlayer == nlevel - 1
     assert np.allclose(atm.layer["pressure"], np.sqrt(p[1:] * p[:-1]) * 1e6)      # bars -> dyn/cm2, log mean
-    assert np.allclose(atm.layer["mmw"], 0.85 * 2.01588 + 0.15 * 4.002602)
+    assert np.allclose(atm.layer["mmw"], 0.85 * 2.0156500642 + 0.15 * 4.0026032497, rtol=1e-14)   # main-isotope masses
     g_layer = np.full(nlevel - 1, 2500.0)
     g_layer[[0, -1]] = 1250.0                 # the reference's end layers (atmsetup.py:453)
     assert np.allclose(atm.layer["colden"], (p[1:] - p[:-1]) * 1e6 / g_layer)

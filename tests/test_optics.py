@@ -12,7 +12,9 @@ from helpers import GOLDEN, rel_err
 NAMES = ("dtau", "tau", "w0", "cosb", "ftau_cld", "ftau_ray", "gcos2", "dtau_og", "tau_og", "w0_og",
          "cosb_og", "w0_no_raman", "f_deltaM")
 DB = os.path.join(GOLDEN, "synthetic_opacities.db")
-WEIGHTS = {"H2": 2.01588, "He": 4.002602, "H2O": 18.01528, "CH4": 16.04246}
+# molecular weights as the reference's ATMSETUP.get_weights gives them (main-isotope masses), from the fixture
+_G = np.load(os.path.join(GOLDEN, "optics.npz"))
+WEIGHTS = {k: float(_G["in/weight/" + k]) for k in ("H2", "He", "H2O", "CH4")}
 CASES = ("de1_s2_r2_tmnone", "de0_s2_r2_tmnone", "de1_s4_r0_tmnone", "de1_s2_r2_tmrayleigh",
          "de0_s2_r2_tmconstant_tau")
 
