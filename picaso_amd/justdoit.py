@@ -82,7 +82,7 @@ class inputs:
         self.phase_angle(0)
 
     def phase_angle(self, phase=0, num_gangle=10, num_tangle=1, symmetry=False):
-        """Geometry (reference justdoit.py:1453-1605, without the symmetry reduction)."""
+        """Geometry (reference justdoit.py:1453-1605), including the quadrant ``symmetry`` reduction."""
         if (phase > 2 * np.pi) or (phase < 0):
             raise Exception("Oops! you input a phase angle greater than 2*pi or less than 0. Please "
                             "make sure your inputs are in radian units: 0<phase<2pi")
@@ -102,15 +102,37 @@ class inputs:
             ubar0, ubar1, cos_theta, lat, lon = disco.compute_disco(ng, nt, gangle, tangle, phase)
             cos_theta = 1.0                                   # justdoit.py:1532
         else:
-            if symmetry:
-                raise Exception("symmetry reduction is not built; use the full disk")
             ng, nt = int(num_gangle), int(num_tangle)
             gangle, gweight, tangle, tweight = disco.get_angles_3d(ng, nt)
             ubar0, ubar1, cos_theta, lat, lon = disco.compute_disco(ng, nt, gangle, tangle, phase)
+            if symmetry:                                      # justdoit.py:1562-1602: one quadrant
+                if phase != 0:
+                    raise Exception("If phase is non zero then you cannot utilize symmetry to reduce "
+                                    "computation speed.")
+                for n, nm in ((num_tangle, "num_tangle"), (num_gangle, "num_gangle")):
+                    if n == 2 or (n % 2 != 0 and n != 1):
+                        raise Exception("Youve selected %s=%d however for symmetry to be utilized we need "
+                                        "at LEAST two points on either side of the symmetric axis (e.g. "
+                                        "num angles >=4 or 1)." % (nm, n))
+                full = dict(num_gangle=ng, num_tangle=nt, gangle=gangle, gweight=gweight, tangle=tangle,
+                            tweight=tweight, latitude=lat, longitude=lon, cos_theta=cos_theta, ubar0=ubar0,
+                            ubar1=ubar1)
+                nt_uni = len(np.unique((tweight * 1e6).astype(int)))          # unique to 1 ppm
+                ng_uni = len(np.unique((gweight * 1e6).astype(int)))
+                self.inputs["phase_angle"] = phase
+                self.inputs["disco"] = dict(
+                    symmetry="true", num_tangle=nt_uni, num_gangle=ng_uni, ubar1=ubar1[0:ng_uni, 0:nt_uni],
+                    ubar0=ubar0[0:ng_uni, 0:nt_uni], latitude=lat[0:nt_uni], longitude=lon[0:ng_uni],
+                    gangle=gangle[0:ng_uni], gweight=(num_tangle / nt_uni) * gweight[0:ng_uni],   # sic (:1595-1598)
+                    tangle=tangle[0:nt_uni], tweight=(num_gangle / ng_uni) * tweight[0:nt_uni],
+                    cos_theta=cos_theta, full_geometry=full)
+                return
         self.inputs["phase_angle"] = phase
         self.inputs["disco"] = dict(num_gangle=ng, num_tangle=nt, gangle=gangle, gweight=gweight,
                                     tangle=tangle, tweight=tweight, latitude=lat, longitude=lon,
                                     cos_theta=cos_theta, ubar0=ubar0, ubar1=ubar1)
+        if nt > 1:
+            self.inputs["disco"]["symmetry"] = "false"
 
     def gravity(self, gravity=None, radius=np.nan, mass=np.nan):
         """Surface gravity in cm/s^2 (cgs; the reference takes astropy units, justdoit.py:1663)."""

@@ -18,6 +18,7 @@ supplied by the caller (``rayleigh_opa``) or read from an optional ``rayleigh`` 
 import ctypes
 import io
 import math
+import os
 import sqlite3
 
 import numpy as np
@@ -476,9 +477,29 @@ def raman_plane_host(atm, opa, raman):
                            opa.raman_db["ji"], opa.raman_db["deltanu"])
         return np.minimum(rf, 0.99999)
     if raman == 1:
-        raise Exception("raman='pollack' needs the reference's raman_fortran.txt table; use "
-                        "'oklopcic' or 'none'")
+        return np.minimum(raman_pollack(atm.c.nlayer, 1e4 / opa.wno), 0.99999)      # optics.py:296-298
     return None
+
+
+def raman_pollack(nlayer, wave, table=None):
+    """Pollack+1986 Raman factor: the reference's tabulated ``raman_fortran.txt`` (two whitespace
+    columns, wavelength in micron and factor) interpolated linearly onto ``wave`` and tiled over the
+    layers (reference optics.py:584-652).  ``table`` = path or ``(w, f)`` arrays; by default the
+    file is looked up where the reference looks, ``$picaso_refdata/opacities/raman_fortran.txt``."""
+    if table is None:
+        ref = os.environ.get("picaso_refdata")
+        if ref is None:
+            raise Exception("raman='pollack' reads $picaso_refdata/opacities/raman_fortran.txt: set the "
+                            "picaso_refdata environment variable or use raman='oklopcic' / 'none'")
+        table = os.path.join(ref, "opacities", "raman_fortran.txt")
+    if isinstance(table, (str, bytes, os.PathLike)):
+        if not os.path.isfile(table):
+            raise Exception("raman='pollack': table %s not found" % table)
+        w, f = np.loadtxt(table, unpack=True)
+    else:
+        w, f = (np.asarray(x, dtype=float) for x in table)
+    row = np.interp(np.asarray(wave, dtype=float), w, f)
+    return np.repeat(row[None, :], nlayer, axis=0)
 
 
 def compute_opacity_facets(atms, opacityclass, numg, numt, stream=2, delta_eddington=True, test_mode=None,
@@ -495,7 +516,7 @@ def compute_opacity_facets(atms, opacityclass, numg, numt, stream=2, delta_eddin
     if opa.ngauss != 1:
         raise Exception("compute_opacity_facets takes monochromatic opacities")
     tg3, tr3 = DeviceArray((nfac, nlayer, nwno), ctx), DeviceArray((nfac, nlayer, nwno), ctx)
-    rf3 = [] if raman == 0 else None
+    rf3 = [] if raman in (0, 1) else None
     for g in range(numg):
         for t in range(numt):
             f = g * numt + t
@@ -503,8 +524,6 @@ def compute_opacity_facets(atms, opacityclass, numg, numt, stream=2, delta_eddin
             gas_stage(atms[g][t], opa, tg3.row_block(f), tr3.row_block(f))
             if rf3 is not None:
                 rf3.append(raman_plane_host(atms[g][t], opa, raman))
-    if raman == 1:
-        raman_plane_host(atms[0][0], opa, raman)
     d_rf = DeviceArray.from_host(np.stack(rf3), ctx) if rf3 else None
     d_c = [None, None, None]
     if clouds_3d is not None:

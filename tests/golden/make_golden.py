@@ -403,7 +403,8 @@ def make_optics():
             store["%s/continuum_opa/%s" % (qm, pr)] = opa.continuum_opa[pr]
         store["%s/pt_opa_index" % qm] = np.asarray(atm.layer["pt_opa_index"])
         for de, stream, raman, tm in ((True, 2, 2, None), (False, 2, 2, None), (True, 4, 0, None),
-                                      (True, 2, 2, "rayleigh"), (False, 2, 2, "constant_tau")):
+                                      (True, 2, 2, "rayleigh"), (False, 2, 2, "constant_tau"),
+                                      (True, 2, 1, None)):
             atm = make_atm()
             opa.get_opacities(atm)
             out = optics.compute_opacity(atm, opa, ngauss=1, stream=stream, delta_eddington=de,
@@ -647,3 +648,21 @@ def make_altitude():
 
 if __name__ == "__main__" and (("altitude" in sys.argv[1:]) or not sys.argv[1:]):
     make_altitude()
+
+
+def make_raman_pollack():
+    """optics.raman_pollack of the reference on its own table (reference/opacities/raman_fortran.txt).
+    The fixture carries the table (data), the wavelength grids and the reference's outputs."""
+    op = ref_shim.load("optics")
+    tab = np.loadtxt(os.path.join(ref_shim.REF_ROOT, "reference", "opacities", "raman_fortran.txt"))
+    store = {"table/w": tab[:, 0], "table/f": tab[:, 1]}
+    for name, wave in (("vis", np.linspace(0.3, 1.0, 57)), ("wide", 1e4 / np.linspace(500.0, 40000.0, 41))):
+        store[name + "/wave"] = wave
+        store[name + "/factor"] = op.raman_pollack(4, wave)
+    path = os.path.join(HERE, "raman_pollack.npz")
+    np.savez_compressed(path, **store)
+    print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024))
+
+
+if __name__ == "__main__" and (("raman_pollack" in sys.argv[1:]) or not sys.argv[1:]):
+    make_raman_pollack()

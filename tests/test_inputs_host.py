@@ -91,3 +91,32 @@ def test_spectrum_requires_inputs():
         c.spectrum(None)
     with pytest.raises(Exception, match="dimension"):
         c.spectrum(None, dimension="2d")
+
+
+def test_phase_angle_symmetry_quadrant():
+    """symmetry=True keeps one quadrant with doubled weights (reference justdoit.py:1562-1602)."""
+    c = jdi.inputs()
+    c.phase_angle(0, num_gangle=6, num_tangle=4, symmetry=True)
+    d = c.inputs["disco"]
+    f = d["full_geometry"]
+    assert (d["num_gangle"], d["num_tangle"], d["symmetry"]) == (3, 2, "true")
+    assert d["ubar0"].shape == d["ubar1"].shape == (3, 2)
+    assert np.array_equal(d["ubar0"], f["ubar0"][:3, :2]) and np.array_equal(d["gangle"], f["gangle"][:3])
+    # the reference scales gweight by num_tangle/nt_uni and tweight by num_gangle/ng_uni (both 2 here)
+    assert np.array_equal(d["gweight"], (4 / 2) * f["gweight"][:3])
+    assert np.array_equal(d["tweight"], (6 / 3) * f["tweight"][:2])
+    full = np.sum(np.outer(f["gweight"], f["tweight"]) * f["ubar0"])
+    quad = np.sum(np.outer(d["gweight"], d["tweight"]) * d["ubar0"])
+    assert np.isclose(full, quad, rtol=1e-14)
+    c.phase_angle(0, num_gangle=6, num_tangle=4)
+    assert c.inputs["disco"]["symmetry"] == "false" and "full_geometry" not in c.inputs["disco"]
+
+
+@pytest.mark.parametrize("kw,msg", [(dict(phase=0.3, num_gangle=6, num_tangle=4), "non zero"),
+                                    (dict(num_gangle=2, num_tangle=4), "num_gangle=2"),
+                                    (dict(num_gangle=6, num_tangle=3), "num_tangle=3"),
+                                    (dict(num_gangle=5, num_tangle=4), "num_gangle=5")])
+def test_phase_angle_symmetry_errors(kw, msg):
+    c = jdi.inputs()
+    with pytest.raises(Exception, match=msg):
+        c.phase_angle(symmetry=True, **kw)

@@ -16,7 +16,45 @@ DB = os.path.join(GOLDEN, "synthetic_opacities.db")
 _G = np.load(os.path.join(GOLDEN, "optics.npz"))
 WEIGHTS = {k: float(_G["in/weight/" + k]) for k in ("H2", "He", "H2O", "CH4")}
 CASES = ("de1_s2_r2_tmnone", "de0_s2_r2_tmnone", "de1_s4_r0_tmnone", "de1_s2_r2_tmrayleigh",
-         "de0_s2_r2_tmconstant_tau")
+         "de0_s2_r2_tmconstant_tau", "de1_s2_r1_tmnone")
+
+
+@pytest.fixture(scope="module")
+def pollack_table(tmp_path_factory):
+    """The reference's raman_fortran.txt (carried as data in raman_pollack.npz) laid out where the
+    reference looks for it: $picaso_refdata/opacities/raman_fortran.txt."""
+    g = np.load(os.path.join(GOLDEN, "raman_pollack.npz"))
+    root = tmp_path_factory.mktemp("refdata")
+    os.makedirs(root / "opacities")
+    np.savetxt(root / "opacities" / "raman_fortran.txt", np.column_stack([g["table/w"], g["table/f"]]),
+               fmt="%.17g")
+    old = os.environ.get("picaso_refdata")
+    os.environ["picaso_refdata"] = str(root)
+    yield g
+    if old is None:
+        del os.environ["picaso_refdata"]
+    else:
+        os.environ["picaso_refdata"] = old
+
+
+def test_raman_pollack_matches_reference(pollack_table):
+    from picaso_amd import optics as px
+    g = pollack_table
+    for name in ("vis", "wide"):
+        # (pandas' fast float parser, which the reference reads the table with, is 1 ulp off here and there)
+        np.testing.assert_allclose(px.raman_pollack(4, g[name + "/wave"]), g[name + "/factor"], rtol=1e-15)
+    tab = (g["table/w"], g["table/f"])
+    np.testing.assert_allclose(px.raman_pollack(2, g["vis/wave"], table=tab), g["vis/factor"][:2], rtol=1e-15)
+
+
+def test_raman_pollack_without_table(monkeypatch):
+    from picaso_amd import optics as px
+    monkeypatch.delenv("picaso_refdata", raising=False)
+    with pytest.raises(Exception, match="picaso_refdata"):
+        px.raman_pollack(3, np.linspace(0.3, 1, 5))
+    monkeypatch.setenv("picaso_refdata", "/nonexistent")
+    with pytest.raises(Exception, match="not found"):
+        px.raman_pollack(3, np.linspace(0.3, 1, 5))
 
 
 @pytest.fixture(scope="module")
@@ -37,7 +75,7 @@ def _case_args(key):
     return bool(int(de[2])), int(s[1]), int(r[1]), (None if tm == "tmnone" else tm[2:])
 
 
-def test_oracle_compute_opacity(gold):
+def test_oracle_compute_opacity(gold, pollack_table):
     """oracle mixing algebra vs the reference: rebuild TAUGAS/TAURAY from the reference's own
     molecular/continuum planes, then compare all 13 outputs."""
     from oracle import optics_oracle as oo
@@ -76,6 +114,8 @@ def test_oracle_compute_opacity(gold):
                 rf = px.compute_raman(len(wno), nlevel - 1, wno, gold["in/raman_shifts"], tlayer,
                                       gold["in/raman_c"], gold["in/raman_ji"], gold["in/raman_deltanu"])
                 rf = np.minimum(rf, 0.99999)
+            elif r == 1:
+                rf = np.minimum(px.raman_pollack(nlevel - 1, 1e4 / wno), 0.99999)
             else:
                 rf = 0.99999
             out = oo.compute_opacity(taugas, tauray, gold["in/cld_opd"], gold["in/cld_w0"],
@@ -101,7 +141,7 @@ def _bundle(gold, px_just, tm, de, stream_unused, raman):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("qm", ["nearest", "linear"])
-def test_gpu_compute_opacity(gold, qm):
+def test_gpu_compute_opacity(gold, qm, pollack_table):
     from picaso_amd import justdoit as jdi
     from picaso_amd import optics as px
     from picaso_amd.atmsetup import ATMSETUP
@@ -198,3 +238,39 @@ def test_gpu_spectrum_sh4_end_to_end(gold, oracle):
                                  np.zeros(nwno), 4, 0)
     th = oracle.compress_thermal(nwno, f, gw, tw)
     assert rel_err(out["thermal"], th) < 1e-8
+
+
+@pytest.mark.gpu
+def test_gpu_symmetry_quadrant_equals_full_disk(gold):
+    """phase_angle(symmetry=True): the 3x2 quadrant with the reference's doubled weights gives the
+    full 6x4 disk's albedo and thermal flux for a horizontally uniform planet at full phase."""
+    from picaso_amd import justdoit as jdi
+    opa = jdi.opannection(DB, query_method="linear")
+    outs = []
+    for sym in (False, True):
+        case = _bundle(gold, jdi, None, True, 2, 2)
+        case.phase_angle(0, num_gangle=6, num_tangle=4, symmetry=sym)
+        case.surface_reflect(0.1)
+        outs.append(case.spectrum(opa, calculation="reflected+thermal", full_output=True))
+    assert outs[1]["full_output"]["albedo_3d"].shape[:2] == (3, 2)
+    assert rel_err(outs[1]["albedo"], outs[0]["albedo"]) < 1e-12
+    assert rel_err(outs[1]["thermal"], outs[0]["thermal"]) < 1e-12
+
+
+@pytest.mark.gpu
+def test_gpu_spectrum_pollack_raman(gold, oracle, pollack_table):
+    """approx(raman='pollack') end to end against the reference's compute_opacity(raman=1) planes."""
+    from picaso_amd import disco
+    from picaso_amd import justdoit as jdi
+    opa = jdi.opannection(DB, query_method="linear")
+    case = _bundle(gold, jdi, None, True, 2, 1)
+    out = case.spectrum(opa, calculation="reflected")
+    P = {nm: gold["linear/de1_s2_r1_tmnone/" + nm] for nm in NAMES}
+    nlevel, nwno = P["tau"].shape
+    g, gw, t, tw = disco.get_angles_1d(5)
+    u0, u1, ct, _, _ = disco.compute_disco(5, 1, g, t, 0.0)
+    x, _ = oracle.get_reflected_1d(nlevel, opa.wno, nwno, 5, 1, P["dtau"], P["tau"], P["w0"], P["cosb"],
+                                   P["gcos2"], P["ftau_cld"], P["ftau_ray"], P["dtau_og"], P["tau_og"],
+                                   P["w0_og"], P["cosb_og"], 0.0, u0, u1, 1.0, np.ones(nwno), 3, 0,
+                                   1.0, -1.0, 2.0, -0.5, 1.0)
+    assert rel_err(out["albedo"], oracle.compress_disco(nwno, 1.0, x, gw, tw, np.ones(nwno))) < 1e-8
