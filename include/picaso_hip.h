@@ -231,6 +231,23 @@ int picaso_compress_thermal_dev(picaso_ctx *ctx, size_t ninner, const double *fl
                                 const double *gweight, int ng, const double *tweight, int nt,
                                 double *flux);
 
+/* ---- on-the-fly correlated-k gas mixing (resort-rebin) ---------------------------------------- */
+/* replaces deq_chem.mix_all_gases_gasesfly (reference picaso/deq_chem.py:333-384, with
+ * do_mixing_mono_gasesfly :387-477 and mix_2_gases :537-597), the loop nest of
+ * RetrieveCKs.mix_my_opacities_gasesfly (picaso/optics.py:1164-1198).
+ * kappas: host array of `ngas` DEVICE pointers, each ln(kappa) of one gas laid out
+ * (npres, ntemp, nwno, ngauss) as the reference's self.kappas[mol]; mixes: host (ngas, nlayer) layer
+ * volume mixing ratios; gauss_pts / gauss_wts: host (ngauss), ngauss <= 8; indices: host (4, nlayer)
+ * int32 = [p_low, p_hi, t_low, t_hi] of get_mixing_indices (optics.py:1200-1278).
+ * Output (device): ln of the mixed coefficients laid out (nlayer, 4, nwno, ngauss), neighbour index
+ * ct = 0 (p_low,t_low), 1 (p_low,t_hi), 2 (p_hi,t_low), 3 (p_hi,t_hi) -- the reference's
+ * (nlayer, nwno, ngauss, 4) array with the neighbour axis moved forward, so that each neighbour is a
+ * (nwno*ngauss) table row for the ln-bilinear interpolation of picaso_opacity_gas_ck_dev. */
+int picaso_mix_all_gases_gasesfly_dev(picaso_ctx *ctx, int ngas, const double *const *kappas, int npres,
+                                      int ntemp, int nwno, int ngauss, const double *mixes,
+                                      const double *gauss_pts, const double *gauss_wts, const int *indices,
+                                      int nlayer, double *kappa_mixed);
+
 /* ---- transmission ------------------------------------------------------------------------- */
 /* replaces fluxes.get_transit_1d (reference picaso/fluxes.py:2581-2663): (Rp/Rs)^2 per wavelength
  * from the chord-integrated slant optical depth (Brown 2001, eq. 11).  z, dz, player, tlayer are

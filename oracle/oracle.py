@@ -18,7 +18,7 @@ _dp = ctypes.POINTER(ctypes.c_double)
 
 def build(force=False):
     so = os.path.join(_HERE, "libpicaso_oracle.so")
-    srcs = [os.path.join(_HERE, f) for f in ("picaso_oracle.c", "sh_oracle.c", "Makefile")]
+    srcs = [os.path.join(_HERE, f) for f in ("picaso_oracle.c", "sh_oracle.c", "mix_oracle.c", "Makefile")]
     if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s", "-B"])
     return so
@@ -207,4 +207,22 @@ def get_transit_1d(z, dz, nlevel, nwno, rstar, mmw, k_b, amu, player, tlayer, co
                              ctypes.c_double(rstar), _p(_a(mmw)), ctypes.c_double(k_b),
                              ctypes.c_double(amu), _p(_a(player)), _p(_a(tlayer)), _p(_a(colden)),
                              _p(_a(DTAU)), _p(out))
+    return out
+
+
+def mix_all_gases_gasesfly(kappas, mixes, gauss_pts, gauss_wts, indices):
+    """Signature of reference ``deq_chem.mix_all_gases_gasesfly`` (deq_chem.py:333-384): ``kappas`` a list
+    of ``(npres, ntemp, nwno, nk)`` ln(kappa) tables, ``mixes`` a list of per-layer mixing ratios,
+    ``indices`` = [p_low, p_hi, t_low, t_hi] per layer.  Returns ``(nlayer, nwno, nk, 4)``."""
+    ks = [_a(k) for k in kappas]
+    npres, ntemp, nwno, nk = ks[0].shape
+    mx = _a(np.stack([np.asarray(m, dtype=float) for m in mixes]))
+    idx = np.ascontiguousarray(indices, dtype=np.int32)
+    nlayer = idx.shape[1]
+    ptrs = (_dp * len(ks))(*[_p(k) for k in ks])
+    out = np.zeros((nlayer, nwno, nk, 4))
+    _check(lib().orc_mix_all_gases_gasesfly(
+        ctypes.c_int(len(ks)), ptrs, ctypes.c_int(npres), ctypes.c_int(ntemp), ctypes.c_int(nwno),
+        ctypes.c_int(nk), _p(mx), _p(_a(gauss_pts)), _p(_a(gauss_wts)),
+        idx.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), ctypes.c_int(nlayer), _p(out)), "mix_all_gases_gasesfly")
     return out

@@ -1,0 +1,178 @@
+// On-the-fly correlated-k gas mixing ("resort-rebin", Amundsen et al. 2017) -- gfx950.
+// Replaces deq_chem.mix_all_gases_gasesfly / do_mixing_mono_gasesfly / mix_2_gases
+// (reference picaso/deq_chem.py:333-384, :387-477, :537-597), the inner loops of
+// RetrieveCKs.mix_my_opacities_gasesfly (picaso/optics.py:1164-1198).
+//
+// One wavefront per (layer, P-T neighbour, wavenumber bin): with Nk <= 8 Gauss points the Nk^2 <= 64
+// random-overlap products of two gases are exactly one lane each (lane = i*Nk + j).  Per gas added:
+//   key   = (mix1*k1[i] + mix2*k2[j]) / (mix1+mix2)                      (:571, unfused)
+//   stable rank sort across the wave (v_readlane broadcast, ties by lane = np.argsort 'mergesort'),
+//   keys and weights moved to their sorted lanes with ds_permute,
+//   sequential prefix sum of the sorted weights (np.cumsum order), x = cum / cum[last],
+//   np.interp(gauss_pts, x, log10(key)) -> 10** -> the Nk coefficients of the mixture (:586-590),
+// everything in registers; no LDS tile, no scratch.  HBM traffic is the table rows read
+// (ngas * Nk doubles per bin) and Nk doubles written: the kernel is VALU/cross-lane bound.
+#include "common.hpp"
+#include "device_math.hpp"
+
+namespace pz {
+
+constexpr int MIX_MAX_GAUSS = 8;
+
+struct CKMixArgs {
+    int ngas, nk, nwno, nlayer, ntemp;
+    const double *const *tabs;      // device: ngas pointers to ln(kappa) (npres, ntemp, nwno, nk)
+    const double *mixes;            // device (ngas, nlayer)
+    const int *indices;             // device (4, nlayer): p_low, p_hi, t_low, t_hi
+    double gpts[MIX_MAX_GAUSS], gwts[MIX_MAX_GAUSS];
+    double *out;                    // (nlayer, 4, nwno, nk) ln of the mixed coefficients
+};
+
+__device__ __forceinline__ double readlane_d(double v, int lane)
+{
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)b, lane);
+    const int hi = __builtin_amdgcn_readlane((int)(b >> 32), lane);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+// value of `v` moves from this lane to lane `dst`
+__device__ __forceinline__ double permute_to_d(double v, int dst)
+{
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_ds_permute(dst << 2, (int)b);
+    const int hi = __builtin_amdgcn_ds_permute(dst << 2, (int)(b >> 32));
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+__global__ __launch_bounds__(256) void k_ckmix(const CKMixArgs a)
+{
+#pragma clang fp contract(off)
+    const int lane = threadIdx.x & 63;
+    const long iw = blockIdx.x * 4L + (threadIdx.x >> 6);
+    if (iw >= a.nwno) return;                          // whole wave
+    const int il = blockIdx.y >> 2, ct = blockIdx.y & 3;
+    const int nk = a.nk, n2 = nk * nk;
+    const bool valid = lane < n2;
+    const int i = valid ? lane / nk : 0, j = valid ? lane - i * nk : 0;
+    // neighbour ct = 2*ip + it of the reference's nested loops (deq_chem.py:371-372)
+    const int p_ind = a.indices[(ct >> 1) * a.nlayer + il];
+    const int t_ind = a.indices[(2 + (ct & 1)) * a.nlayer + il];
+    const size_t off = (((size_t)p_ind * a.ntemp + t_ind) * a.nwno + iw) * nk;
+    double wi = 0.0, wj = 0.0;
+    for (int n = 0; n < nk; ++n) {                     // by-value tables: uniform index only
+        wi = (i == n) ? a.gwts[n] : wi;
+        wj = (j == n) ? a.gwts[n] : wj;
+    }
+    const double w_own = valid ? wi * wj : 0.0;        // eq. 10 Amundsen 2017 (:572)
+
+    double k1 = exp(a.tabs[0][off + i]);               // (:428) coefficient i of the running mixture
+    double mix_t = a.mixes[il];
+    for (int g = 1; g < a.ngas; ++g) {
+        const double k2 = exp(a.tabs[g][off + j]);
+        const double mix2 = a.mixes[(size_t)g * a.nlayer + il];
+        const double mt = mix_t + mix2;
+        const double key = valid ? (mix_t * k1 + mix2 * k2) / mt : __builtin_inf();
+        // stable rank: number of elements that sort before this one
+        int rank = 0;
+        for (int t = 0; t < n2; ++t) {
+            const double kt = readlane_d(key, t);
+            rank += ((kt < key) || (kt == key && t < lane)) ? 1 : 0;
+        }
+        const bool bad = __any(valid && (key != key));  // NaN in -> NaN out
+        const int dst = valid ? rank : lane;
+        const double ks = permute_to_d(key, dst);
+        const double ws = permute_to_d(w_own, dst);
+        // np.cumsum: c[0] = w[0], c[n] = c[n-1] + w[n]
+        double cum = 0.0;
+        for (int t = 0; t < n2; ++t) {
+            const double wt = readlane_d(ws, t);
+            cum = (lane >= t) ? cum + wt : cum;
+        }
+        const double x = cum / readlane_d(cum, n2 - 1);       // np.max of an increasing sum (:582)
+        const double f = log10(ks);
+        const double x_last = readlane_d(x, n2 - 1), f_first = readlane_d(f, 0), f_last = readlane_d(f, n2 - 1);
+        double rsel = 0.0;
+        for (int n = 0; n < nk; ++n) {                 // np.interp(gauss_pts, x, f)   (:586)
+            const double gp = a.gpts[n];
+            const int cnt = __popcll(__ballot(valid && x <= gp));
+            double r;
+            if (gp > x_last) r = f_last;
+            else if (cnt == 0) r = f_first;
+            else if (cnt == n2) r = f_last;
+            else {
+                const int jj = cnt - 1;
+                const double xj = readlane_d(x, jj), xj1 = readlane_d(x, jj + 1);
+                const double fj = readlane_d(f, jj), fj1 = readlane_d(f, jj + 1);
+                if (xj == gp) r = fj;
+                else {
+                    const double slope = (fj1 - fj) / (xj1 - xj);
+                    r = slope * (gp - xj) + fj;
+                    if (r != r) {
+                        r = slope * (gp - xj1) + fj1;
+                        if (r != r && fj == fj1) r = fj;
+                    }
+                }
+            }
+            rsel = (i == n) ? r : rsel;
+        }
+        k1 = bad ? __builtin_nan("") : pow(10.0, rsel);
+        mix_t = mt;
+    }
+    if (valid && j == 0)
+        a.out[(((size_t)il * 4 + ct) * a.nwno + iw) * nk + i] = log(k1);
+}
+
+}  // namespace pz
+
+using namespace pz;
+
+extern "C" {
+
+int picaso_mix_all_gases_gasesfly_dev(picaso_ctx *ctx, int ngas, const double *const *kappas, int npres,
+                                      int ntemp, int nwno, int ngauss, const double *mixes,
+                                      const double *gauss_pts, const double *gauss_wts, const int *indices,
+                                      int nlayer, double *kappa_mixed)
+{
+    if (!ctx) return fail(nullptr, "null context");
+    if (ngas < 1 || ngas > 256) return fail(ctx, "mix_all_gases_gasesfly: ngas must be 1..256, got %d", ngas);
+    if (ngauss < 1 || ngauss > MIX_MAX_GAUSS)
+        return fail(ctx, "mix_all_gases_gasesfly: ngauss must be 1..%d (one wavefront holds the ngauss^2 "
+                         "overlap products), got %d", MIX_MAX_GAUSS, ngauss);
+    if (npres < 1 || ntemp < 1 || nwno < 1 || nlayer < 1)
+        return fail(ctx, "mix_all_gases_gasesfly: bad sizes npres=%d ntemp=%d nwno=%d nlayer=%d", npres, ntemp,
+                    nwno, nlayer);
+    if (!kappas || !mixes || !gauss_pts || !gauss_wts || !indices || !kappa_mixed)
+        return fail(ctx, "mix_all_gases_gasesfly: null argument");
+    for (int l = 0; l < nlayer; ++l)
+        for (int q = 0; q < 4; ++q) {
+            const int v = indices[q * nlayer + l], lim = q < 2 ? npres : ntemp;
+            if (v < 0 || v >= lim)
+                return fail(ctx, "mix_all_gases_gasesfly: index %d of layer %d outside the %s grid (%d)", v, l,
+                            q < 2 ? "pressure" : "temperature", lim);
+        }
+    PZ_HIP(ctx, hipSetDevice(ctx->device));
+    // one ring slot: [gas table pointers | mixes | indices]
+    const size_t b_ptr = sizeof(double *) * (size_t)ngas, b_mix = sizeof(double) * (size_t)ngas * nlayer,
+                 b_idx = sizeof(int) * 4 * (size_t)nlayer;
+    std::vector<char> host(b_ptr + b_mix + b_idx);
+    memcpy(host.data(), kappas, b_ptr);
+    memcpy(host.data() + b_ptr, mixes, b_mix);
+    memcpy(host.data() + b_ptr + b_mix, indices, b_idx);
+    const void *d = nullptr;
+    PZ_TRY(table_upload(ctx, host.data(), host.size(), &d));
+    CKMixArgs a{};
+    a.ngas = ngas; a.nk = ngauss; a.nwno = nwno; a.nlayer = nlayer; a.ntemp = ntemp;
+    a.tabs = (const double *const *)d;
+    a.mixes = (const double *)((const char *)d + b_ptr);
+    a.indices = (const int *)((const char *)d + b_ptr + b_mix);
+    for (int n = 0; n < ngauss; ++n) { a.gpts[n] = gauss_pts[n]; a.gwts[n] = gauss_wts[n]; }
+    a.out = kappa_mixed;
+    const dim3 grid((unsigned)((nwno + 3) / 4), (unsigned)nlayer * 4u);
+    if ((long)nlayer * 4 > 65535) return fail(ctx, "mix_all_gases_gasesfly: nlayer %d exceeds the launch grid", nlayer);
+    hipLaunchKernelGGL(k_ckmix, grid, dim3(256), 0, ctx->stream, a);
+    PZ_HIP(ctx, hipGetLastError());
+    return 0;
+}
+
+}  // extern "C"

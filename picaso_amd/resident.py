@@ -133,6 +133,31 @@ def transit_1d_ck(ctx, z, dz, nlevel, nwno, ngauss, rstar, mmw, k_b, amu, player
         ptr(f64(colden, (nlevel - 1,))), _addr(dtau), ptr(wts), _addr(rprs2)), ctx)
 
 
+def mix_all_gases_gasesfly(ctx, kappas, mixes, gauss_pts, gauss_wts, indices, out=None):
+    """On-the-fly correlated-k gas mixing, reference ``deq_chem.mix_all_gases_gasesfly``
+    (deq_chem.py:333-384).  ``kappas``: list of DeviceArrays ``(npres, ntemp, nwno, ngauss)`` of
+    ln(kappa), one per gas; ``mixes``: list of per-layer mixing ratios; ``indices`` =
+    [p_low, p_hi, t_low, t_hi].  Returns a DeviceArray ``(nlayer, 4, nwno, ngauss)``: the reference's
+    ``(nlayer, nwno, ngauss, 4)`` array with the neighbour axis moved forward."""
+    npres, ntemp, nwno, nk = kappas[0].shape
+    for k in kappas:
+        if tuple(k.shape) != (npres, ntemp, nwno, nk):
+            raise Exception("mix_all_gases_gasesfly: all gas tables must share one (npres, ntemp, nwno, ngauss)")
+    mx = f64(np.stack([np.asarray(m, dtype=float) for m in mixes]))
+    idx = np.ascontiguousarray(indices, dtype=np.int32)
+    nlayer = idx.shape[1]
+    if idx.shape[0] != 4 or mx.shape != (len(kappas), nlayer):
+        raise Exception("mix_all_gases_gasesfly: indices must be (4, nlayer) and mixes (ngas, nlayer)")
+    if out is None:
+        out = DeviceArray((nlayer, 4, nwno, nk), ctx)
+    ptrs = (ctypes.c_void_p * len(kappas))(*[k.addr for k in kappas])
+    check(load().picaso_mix_all_gases_gasesfly_dev(
+        ctx, _ci(len(kappas)), ctypes.cast(ptrs, ctypes.POINTER(ctypes.POINTER(ctypes.c_double))), _ci(npres),
+        _ci(ntemp), _ci(nwno), _ci(nk), ptr(mx), ptr(f64(gauss_pts, (nk,))), ptr(f64(gauss_wts, (nk,))),
+        idx.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), _ci(nlayer), _addr(out)), ctx)
+    return out
+
+
 def axpby(ctx, a, x, b, y, out):
     """``out = a*x + b*y`` on DeviceArrays of equal size (patchy-cloud blend, justdoit.py:300-305)."""
     n = int(np.prod(x.shape))

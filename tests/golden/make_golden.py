@@ -666,3 +666,56 @@ def make_raman_pollack():
 
 if __name__ == "__main__" and (("raman_pollack" in sys.argv[1:]) or not sys.argv[1:]):
     make_raman_pollack()
+
+
+def _double_gauss(n_half=4):
+    """8-point double-Gauss abscissae/weights on (0,1) in the style of the k-tables: two Gauss-Legendre
+    sets on [0, 0.95] and [0.95, 1]."""
+    xg, wg = np.polynomial.legendre.leggauss(n_half)
+    pts = np.concatenate([0.95 * 0.5 * (xg + 1), 0.95 + 0.05 * 0.5 * (xg + 1)])
+    wts = np.concatenate([0.95 * 0.5 * wg, 0.05 * 0.5 * wg])
+    return pts, wts
+
+
+def make_mixing():
+    """deq_chem.mix_2_gases / mix_all_gases_gasesfly of the reference on synthetic per-gas ln(kappa)
+    tables (monotonic in g, as k-coefficients are), 8 and 4 Gauss points, 2..6 gases."""
+    dq = ref_shim.load("deq_chem")
+    rng = np.random.default_rng(2024)
+    store = {}
+    for name, nk, ngas, npres, ntemp, nwno, nlayer in (("g8", 8, 5, 4, 3, 6, 5), ("g4", 4, 3, 3, 3, 5, 4),
+                                                        ("two", 8, 2, 3, 2, 4, 3), ("g8many", 8, 9, 3, 3, 3, 3)):
+        if nk == 8:
+            pts, wts = _double_gauss(4)
+        else:
+            xg, wg = np.polynomial.legendre.leggauss(nk)
+            pts, wts = 0.5 * (xg + 1), 0.5 * wg
+        kappas = []
+        for g in range(ngas):
+            base = -50.0 + 8.0 * rng.random((npres, ntemp, nwno, 1))
+            steps = np.cumsum(rng.random((npres, ntemp, nwno, nk)) * rng.choice([0.2, 2.0, 6.0]), axis=3)
+            kappas.append(base + steps)
+        # one gas with exactly equal coefficients in a bin: ties in the sort
+        kappas[-1][0, 0, 0, :] = kappas[-1][0, 0, 0, 0]
+        mixes = [10.0 ** (-1.0 - 6.0 * rng.random(nlayer)) for _ in range(ngas)]
+        mixes[0] = 0.8 + 0.1 * rng.random(nlayer)
+        p_low = rng.integers(0, npres - 1, nlayer)
+        t_low = rng.integers(0, ntemp - 1, nlayer)
+        p_low[0], t_low[0] = 0, 0
+        indices = np.array([p_low, p_low + 1, t_low, t_low + 1])
+        out = dq.mix_all_gases_gasesfly(kappas, mixes, pts, wts, indices)
+        store[name + "/gauss_pts"], store[name + "/gauss_wts"] = pts, wts
+        store[name + "/kappas"] = np.stack(kappas)
+        store[name + "/mixes"] = np.stack(mixes)
+        store[name + "/indices"] = indices
+        store[name + "/kappa_mixed"] = out
+        k1, k2 = np.exp(kappas[0][0, 0, 0]), np.exp(kappas[1][0, 0, 0])
+        kb, mt = dq.mix_2_gases(k1, k2, mixes[0][0], mixes[1][0], pts, wts)
+        store[name + "/pair_kmix"], store[name + "/pair_mix_t"] = kb, np.array(mt)
+    path = os.path.join(HERE, "mixing.npz")
+    np.savez_compressed(path, **store)
+    print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024))
+
+
+if __name__ == "__main__" and (("mixing" in sys.argv[1:]) or not sys.argv[1:]):
+    make_mixing()

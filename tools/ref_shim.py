@@ -65,13 +65,13 @@ _cache = {}
 
 
 def load(name):
-    """name in {'fluxes','disco','rayleigh','optics','atmsetup'} -> reference module object."""
+    """name in {'fluxes','disco','rayleigh','deq_chem','optics','atmsetup'} -> reference module object."""
     if name in _cache:
         return _cache[name]
     if not available():
         raise RuntimeError("reference tree not present (expected only in the build container)")
     install_shims()
-    if name in ("fluxes", "disco", "rayleigh"):
+    if name in ("fluxes", "disco", "rayleigh", "deq_chem"):
         mod = _load_by_path("_picaso_ref_" + name, name + ".py")
     elif name in ("optics", "atmsetup"):
         if "picaso" not in sys.modules:
