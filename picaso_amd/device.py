@@ -66,6 +66,16 @@ class DeviceArray:
         v._owner = self            # keeps the parent alive; views are never freed
         return v
 
+    def reshape(self, shape):
+        """Non-owning view of the same buffer under another shape of equal size."""
+        shape = tuple(int(x) for x in shape)
+        if int(np.prod(shape)) != self.size:
+            raise ValueError("cannot reshape %s into %s" % (self.shape, shape))
+        v = DeviceArray.__new__(DeviceArray)
+        v.ctx, v.shape, v.size, v.nbytes, v.addr = self.ctx, shape, self.size, self.nbytes, self.addr
+        v._owner = self
+        return v
+
     def free(self):
         if self.addr and not hasattr(self, "_owner"):
             _lib.load().picaso_dev_free(self.ctx, ctypes.c_void_p(self.addr))

@@ -229,8 +229,8 @@ class RetrieveCKs:
     outside the accelerated path); ``continuum`` maps 'H2H2'-style keys to {temperature: kappa(wno)}.
     """
 
-    def __init__(self, wno, gauss_wts, pressures, temps, nc_p, ln_kappa, continuum=None, cia_temps=(),
-                 rayleigh_opa=None, relative_flux=None, ctx=None):
+    def __init__(self, wno, gauss_wts, pressures, temps, nc_p, ln_kappa=None, continuum=None, cia_temps=(),
+                 rayleigh_opa=None, relative_flux=None, ctx=None, kappas=None, gauss_pts=None, on_fly=None):
         self.ctx = ctx if ctx is not None else _lib.context()
         self.wno = f64(wno)
         self.wave = 1e4 / self.wno
@@ -240,11 +240,26 @@ class RetrieveCKs:
         self.pressures = np.unique(np.asarray(pressures, dtype=float))     # optics.py:1095
         self.temps = np.unique(np.asarray(temps, dtype=float))             # optics.py:1097
         self.nc_p = np.asarray(nc_p, dtype=int)
-        k = f64(ln_kappa)
-        if k.shape != (self.pressures.size, self.temps.size, self.nwno, self.ngauss):
-            raise Exception("RetrieveCKs: ln_kappa must be (npres, ntemp, nwno, ngauss) = %s, got %s"
-                            % ((self.pressures.size, self.temps.size, self.nwno, self.ngauss), k.shape))
-        self._kappa = DeviceArray.from_host(k.reshape((-1, self.nwno * self.ngauss)), self.ctx)
+        shape = (self.pressures.size, self.temps.size, self.nwno, self.ngauss)
+        if ln_kappa is None and not kappas:
+            raise Exception("RetrieveCKs: give the premixed ln_kappa table and/or per-gas kappas")
+        self._kappa = None
+        if ln_kappa is not None:
+            k = f64(ln_kappa)
+            if k.shape != shape:
+                raise Exception("RetrieveCKs: ln_kappa must be (npres, ntemp, nwno, ngauss) = %s, got %s"
+                                % (shape, k.shape))
+            self._kappa = DeviceArray.from_host(k.reshape((-1, self.nwno * self.ngauss)), self.ctx)
+        # per-gas ln(kappa) tables for on-the-fly mixing (the reference's self.kappas, optics.py:1315)
+        self._kappas = {}
+        for m, tab in (kappas or {}).items():
+            t = f64(tab)
+            if t.shape != shape:
+                raise Exception("RetrieveCKs: kappas[%r] must be %s, got %s" % (m, shape, t.shape))
+            self._kappas[m] = DeviceArray.from_host(t, self.ctx)
+        self.gauss_pts = f64(gauss_pts) if gauss_pts is not None else None
+        if self._kappas and (self.gauss_pts is None or self.gauss_pts.size != self.ngauss):
+            raise Exception("RetrieveCKs: on-the-fly mixing needs gauss_pts (ngauss abscissae)")
         continuum = continuum or {}
         self.avail_continuum = sorted(continuum.keys())
         self.cia_temps = np.sort(np.unique(np.asarray(cia_temps, dtype=float)))
@@ -255,18 +270,42 @@ class RetrieveCKs:
         self.rayleigh_opa = {m: f64(v) for m, v in (rayleigh_opa or {}).items()}
         self.rayleigh_molecules = list(self.rayleigh_opa.keys())
         self._ray = {m: DeviceArray.from_host(v, self.ctx) for m, v in self.rayleigh_opa.items()}
-        self.molecules = np.array([])                       # premixed: no per-molecule tables
+        self.molecules = np.array(list(self._kappas.keys()))  # premixed only: no per-molecule tables
         self.query_method = "premixed"
         self.relative_flux = relative_flux
         self.raman_stellar_shifts = None
         self.molecular_opa, self.continuum_opa = None, {}
         self._plan = None
+        # the reference binds get_opacities to the on-the-fly or the preweighted variant at
+        # construction (optics.py:688, :713); default: on the fly when only per-gas tables are given
+        self.on_fly = bool(on_fly) if on_fly is not None else (self._kappa is None)
+        if self.on_fly:
+            if not self._kappas:
+                raise Exception("RetrieveCKs: on_fly=True needs per-gas kappas")
+            self.get_opacities = self.get_opacities_deq_onfly
 
     def get_opacities(self, atmosphere, exclude_mol=1):
         """Table rows / weights for this atmosphere (``get_opacities_preweighted``: continuum +
         ``get_pre_mix_ck``, reference optics.py:1500-1538)."""
         if exclude_mol != 1:
             raise Exception("premixed correlated-k tables cannot exclude molecules")
+        nlayer = atmosphere.c.nlayer
+        if self._kappa is None:
+            raise Exception("no premixed table loaded: use get_opacities_deq_onfly")
+        (p_low, p_hi, t_low, t_hi), t_i, p_i = self.get_mixing_indices(atmosphere)
+        nt = self.temps.size
+        # the reference's four terms in order (optics.py:1153-1156); row = ip * ntemp + it
+        rows = np.stack([p_low * nt + t_low, p_low * nt + t_hi, p_hi * nt + t_hi, p_hi * nt + t_low],
+                        axis=1).astype(np.int32)[None]
+        wts = np.stack([(1 - t_i) * (1 - p_i), t_i * (1 - p_i), t_i * p_i, (1 - t_i) * p_i], axis=1)[None]
+        self._plan = dict(premixed=True, molecules=["premixed"], rows=rows, wts=wts, fac=np.ones(1), nlayer=nlayer)
+        self._plan_continuum(atmosphere)
+        self.molecular_opa = None
+
+    def get_mixing_indices(self, atmosphere):
+        """Bracketing pressure / temperature grid indices and the 1/T, log10 P interpolation weights
+        of every layer (reference ``get_mixing_indices``, optics.py:1200-1278; the same search opens
+        ``get_pre_mix_ck``, :1081-1150).  Returns ``[p_low, p_hi, t_low, t_hi], t_interp, p_interp``."""
         nlayer = atmosphere.c.nlayer
         tlayer = np.asarray(atmosphere.layer["temperature"], dtype=float)
         player = np.asarray(atmosphere.layer["pressure"], dtype=float) / atmosphere.c.pconv
@@ -287,12 +326,44 @@ class RetrieveCKs:
         p_hi = p_low + 1
         t_i = (t_inv - t_inv_grid[t_low]) / (t_inv_grid[t_hi] - t_inv_grid[t_low])
         p_i = (p_log - p_log_grid[p_low]) / (p_log_grid[p_hi] - p_log_grid[p_low])
-        nt = self.temps.size
-        # the reference's four terms in order (optics.py:1153-1156); row = ip * ntemp + it
-        rows = np.stack([p_low * nt + t_low, p_low * nt + t_hi, p_hi * nt + t_hi, p_hi * nt + t_low],
-                        axis=1).astype(np.int32)[None]
+        return np.array([p_low, p_hi, t_low, t_hi]), t_i, p_i
+
+    def mix_my_opacities_gasesfly(self, atmosphere, exclude_mol=1):
+        """On-the-fly mixing of the per-gas k-tables at the four P-T neighbours of every layer
+        (reference optics.py:1164-1198): ``k_ckmix`` leaves ln of the mixed coefficients in HBM as
+        ``4*nlayer`` table rows; the ln-bilinear interpolation and exp (:1191-1197) then run in
+        ``k_opacity_gas`` exactly as for a premixed table."""
+        from . import resident
+        nlayer = atmosphere.c.nlayer
+        mols = [m for m in atmosphere.molecules if (exclude_mol == 1) or (exclude_mol[m] == 1)]
+        if not mols:
+            raise Exception("mix_my_opacities_gasesfly: no molecules to mix")
+        for m in mols:
+            if m not in self._kappas:
+                raise KeyError("no k-table for %s" % m)
+        mix = atmosphere.layer["mixingratios"]
+        mixes = [np.asarray(mix[m].values if hasattr(mix[m], "values") else mix[m], dtype=float) for m in mols]
+        indices, t_i, p_i = self.get_mixing_indices(atmosphere)
+        self._mixed = resident.mix_all_gases_gasesfly(self.ctx, [self._kappas[m] for m in mols], mixes,
+                                                      self.gauss_pts, self.gauss_wts, indices)
+        base = 4 * np.arange(nlayer)
+        # (1-t)(1-p) k[0] + t(1-p) k[1] + t p k[3] + (1-t) p k[2]       (optics.py:1193-1196)
+        rows = np.stack([base, base + 1, base + 3, base + 2], axis=1).astype(np.int32)[None]
         wts = np.stack([(1 - t_i) * (1 - p_i), t_i * (1 - p_i), t_i * p_i, (1 - t_i) * p_i], axis=1)[None]
+        keep = {k: self._plan[k] for k in ("cia_pairs", "cia_rows", "cia_wts")} if self._plan else {}
+        self._plan = dict(premixed=True, molecules=["premixed"], rows=rows, wts=wts, fac=np.ones(1), nlayer=nlayer,
+                          table=self._mixed.reshape((4 * nlayer, self.nwno * self.ngauss)), **keep)
+        self.molecular_opa = None
+
+    def get_opacities_deq_onfly(self, atmosphere, exclude_mol=1):
+        """Continuum + on-the-fly mixed molecular opacity (reference optics.py:1512-1525)."""
+        self.mix_my_opacities_gasesfly(atmosphere, exclude_mol=exclude_mol)
+        self._plan_continuum(atmosphere)
+
+    def _plan_continuum(self, atmosphere):
         # continuum: bracketing CIA temperatures and the 1/T weight (optics.py:1411-1428, 1474-1478)
+        nlayer = atmosphere.c.nlayer
+        tlayer = np.asarray(atmosphere.layer["temperature"], dtype=float)
         st = self.cia_temps
         cia_pairs = [k[0] + k[1] for k in atmosphere.continuum_molecules]
         cia_rows = np.zeros((nlayer, 2), dtype=np.int32)
@@ -308,12 +379,11 @@ class RetrieveCKs:
                 ti = (1 / t - 1 / st[lo]) / (1 / st[lo + 1] - 1 / st[lo])
                 cia_rows[i] = (lo, lo + 1)
                 cia_wts[i] = (1 - ti, ti)
-        self._plan = dict(premixed=True, molecules=["premixed"], rows=rows, wts=wts, fac=np.ones(1),
-                          cia_pairs=cia_pairs, cia_rows=cia_rows, cia_wts=cia_wts, nlayer=nlayer)
+        self._plan.update(cia_pairs=cia_pairs, cia_rows=cia_rows, cia_wts=cia_wts)
         self.continuum_opa = _LazyPlanes(self, "cia")
-        self.molecular_opa = None
 
-    get_opacities_preweighted = get_opacities
+    def get_opacities_preweighted(self, atmosphere, exclude_mol=1):
+        return RetrieveCKs.get_opacities(self, atmosphere, exclude_mol)
 
     def get_molecular_opa(self):
         """``molecular_opa`` (nlayer, nwno, ngauss) as the reference stores it (optics.py:1159)."""
@@ -321,7 +391,7 @@ class RetrieveCKs:
         nlayer = pl["nlayer"]
         tg = DeviceArray((nlayer, self.nwno, self.ngauss), self.ctx)
         tr = DeviceArray((nlayer, self.nwno), self.ctx)
-        _gas_call(self, nlayer, [self._kappa], pl["rows"], pl["wts"], np.ones((1, nlayer)), [], None,
+        _gas_call(self, nlayer, [pl.get("table", self._kappa)], pl["rows"], pl["wts"], np.ones((1, nlayer)), [], None,
                   None, [], None, tg, tr, mol_mode=2, ngauss=self.ngauss)
         return tg.to_host()
 
@@ -453,7 +523,7 @@ def gas_stage(atm, opa, taugas, tauray):
     mol_fac, cont_fac, ray_names, ray_fac = _layer_factors(atm, opa)
     cont_tabs = [opa._cia[p] for p in pl["cia_pairs"]]
     if pl.get("premixed"):
-        mol_tabs, mol_mode = [opa._kappa], 2
+        mol_tabs, mol_mode = [pl.get("table", opa._kappa)], 2
         cont_rows = np.repeat(pl["cia_rows"][None], len(cont_tabs), axis=0) if cont_tabs else None
         cont_wts = np.repeat(pl["cia_wts"][None], len(cont_tabs), axis=0) if cont_tabs else None
     else:

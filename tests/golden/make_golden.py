@@ -500,6 +500,32 @@ def make_ck():
                                      test_mode=None)
         for nm, arr in zip(names, out):
             store["de%d_s%d/%s" % (int(de), stream, nm)] = np.asarray(arr)
+    # on-the-fly mixing of per-gas tables through the reference's own methods
+    # (RetrieveCKs.get_mixing_indices / mix_my_opacities_gasesfly, optics.py:1164-1278)
+    rng = np.random.default_rng(31)
+    xg, wg = np.polynomial.legendre.leggauss(ngauss)
+    opa.gauss_pts = list(0.5 * (xg + 1))
+    opa.kappas = {}
+    for m in ("H2O", "CH4", "H2"):
+        base = kappa[:, :, :, :1] - 3.0 * rng.random((kappa.shape[0], kappa.shape[1], kappa.shape[2], 1))
+        opa.kappas[m] = base + np.cumsum(rng.random(kappa.shape) * 1.5, axis=3)
+        store["fly/kappas/" + m] = opa.kappas[m]
+    store["fly/gauss_pts"] = np.array(opa.gauss_pts)
+    opa.temps = temps            # the per-gas table loader keeps the unique temperatures (get_ck_tables)
+    atm = make_atm()
+    idx, t_i, p_i = opa.get_mixing_indices(atm)
+    store["fly/indices"], store["fly/t_interp"], store["fly/p_interp"] = idx, t_i, p_i
+    opa.mix_my_opacities_gasesfly(atm)
+    store["fly/molecular_opa"] = opa.molecular_opa
+    atm = make_atm()
+    opa.mix_my_opacities_gasesfly(atm, exclude_mol={"H2O": 1, "CH4": 0, "H2": 1})
+    store["fly/molecular_opa_noCH4"] = opa.molecular_opa
+    atm = make_atm()
+    opa.get_continuum(atm)
+    opa.mix_my_opacities_gasesfly(atm)
+    out = optics.compute_opacity(atm, opa, ngauss=ngauss, stream=2, delta_eddington=True, raman=2, test_mode=None)
+    for nm, arr in zip(names, out):
+        store["fly/de1_s2/" + nm] = np.asarray(arr)
     path = os.path.join(HERE, "ck.npz")
     np.savez_compressed(path, **store)
     print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024))

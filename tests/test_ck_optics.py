@@ -87,24 +87,28 @@ def test_oracle_ck_against_reference(ck, og):
             assert _close(np.broadcast_to(arr, ref.shape), ref, 1e-11), (key, nm)
 
 
-def _ck_class(ck, ctx=None):
+def _ck_class(ck, ctx=None, fly=False):
     from picaso_amd import optics as px
     ray, cont = _db_tables()
     wno = np.load(os.path.join(GOLDEN, "optics.npz"))["in/wno"]
     press, temps, nc_p = ck["in/press"], ck["in/temps"], ck["in/nc_p"]
     pressures = np.concatenate([press[:n] for n in nc_p])
     temps_flat = np.concatenate([[t] * n for t, n in zip(temps, nc_p)])
+    extra = {}
+    if fly:
+        extra = dict(kappas={m: ck["fly/kappas/" + m] for m in ("H2O", "CH4", "H2")},
+                     gauss_pts=ck["fly/gauss_pts"], on_fly=True)
     return px.RetrieveCKs(wno, ck["in/gauss_wts"], pressures, temps_flat, nc_p, ck["in/kappa"],
                           continuum={a + b: cont[a + b] for a, b in PAIRS}, cia_temps=ck["in/cia_temps"],
-                          rayleigh_opa=ray)
+                          rayleigh_opa=ray, **extra)
 
 
-def _case(og, jdi, de=True):
+def _case(og, jdi, de=True, order=("H2", "He", "H2O", "CH4")):
     case = jdi.inputs()
     case.phase_angle(0)
     case.gravity(gravity=float(og["in/gravity"]))
     prof = {"pressure": og["in/plevel_bar"], "temperature": og["in/tlevel"]}
-    for k in ("H2", "He", "H2O", "CH4"):
+    for k in order:
         prof[k] = og["in/mix/" + k]
     case.atmosphere(df=prof)
     case.clouds(df={"opd": og["in/cld_opd"], "w0": og["in/cld_w0"], "g0": og["in/cld_g0"]})
@@ -275,3 +279,76 @@ def test_gpu_3d_spectrum_end_to_end(og, oracle):
                               P3["cosb_og"], pl3, u1, np.full(nwno, 0.2), 1)
     assert rel_err(out["full_output"]["thermal_3d"], f) < 1e-7
     assert rel_err(out["thermal"], oracle.compress_thermal(nwno, f, gw, tw)) < 1e-7
+
+
+# ---- on-the-fly gas mixing through the class (reference optics.py:1164-1278) ----------------------
+def _fly_atm(og):
+    import types
+    L = _layers(og)
+    atm = types.SimpleNamespace()
+    atm.c = types.SimpleNamespace(nlayer=len(L["tlayer"]), pconv=1e6)
+    atm.layer = {"temperature": L["tlayer"], "pressure": L["player"] * 1e6, "mixingratios": L["mix"]}
+    atm.molecules = np.array(["H2O", "CH4", "H2"])
+    return atm
+
+
+def test_mixing_indices_against_reference(ck, og):
+    """get_mixing_indices (host search) on a bare object: indices and weights of the reference."""
+    import types
+    from picaso_amd import optics as px
+    press, temps, nc_p = ck["in/press"], ck["in/temps"], ck["in/nc_p"]
+    bare = types.SimpleNamespace(pressures=np.unique(np.concatenate([press[:n] for n in nc_p])),
+                                 temps=np.unique(temps), nc_p=nc_p)
+    idx, t_i, p_i = px.RetrieveCKs.get_mixing_indices(bare, _fly_atm(og))
+    assert np.array_equal(idx, ck["fly/indices"])
+    assert _close(t_i, ck["fly/t_interp"], 1e-14) and _close(p_i, ck["fly/p_interp"], 1e-14)
+
+
+def test_oracle_gasesfly_molecular_opa(ck, og, oracle):
+    """Oracle mixing + the reference's bilinear step (optics.py:1191-1197) = its molecular_opa."""
+    atm = _fly_atm(og)
+    kappas = [ck["fly/kappas/" + m] for m in atm.molecules]
+    mixes = [atm.layer["mixingratios"][m] for m in atm.molecules]
+    xg, wg = ck["fly/gauss_pts"], ck["in/gauss_wts"]
+    km = oracle.mix_all_gases_gasesfly(kappas, mixes, xg, wg, ck["fly/indices"])
+    t, p = ck["fly/t_interp"][:, None, None], ck["fly/p_interp"][:, None, None]
+    kap = (1 - t) * (1 - p) * km[..., 0] + t * (1 - p) * km[..., 1] + t * p * km[..., 3] + (1 - t) * p * km[..., 2]
+    assert _close(np.exp(kap) * 6.02214086e+23, ck["fly/molecular_opa"], 1e-11)
+
+
+@pytest.mark.gpu
+def test_gpu_gasesfly_opacities_and_mixing(ck, og):
+    """RetrieveCKs with per-gas tables: k_ckmix + ln-bilinear interpolation against the reference's
+    mix_my_opacities_gasesfly (incl. exclude_mol) and compute_opacity on the mixed table."""
+    from picaso_amd import justdoit as jdi
+    from picaso_amd import optics as px
+    opa = _ck_class(ck, fly=True)
+    assert list(opa.molecules) == ["H2O", "CH4", "H2"]
+    # gases are mixed in the order of the profile columns (atmosphere.molecules); the fixture's is
+    # H2O, CH4, H2 and sequential resort-rebin is not commutative
+    case = _case(og, jdi, True, order=("H2O", "CH4", "H2", "He"))
+    atm = jdi._setup_atmosphere(case.inputs, opa, opa.wno)
+    assert list(atm.molecules) == ["H2O", "CH4", "H2"]
+    opa.get_opacities(atm)                                    # bound to get_opacities_deq_onfly
+    assert _close(opa.get_molecular_opa(), ck["fly/molecular_opa"], 1e-10)
+    for pr in ("H2H2", "H2He", "H2CH4"):
+        assert _close(opa.continuum_opa[pr], ck["continuum_opa/" + pr], 1e-12), pr
+    out = px.compute_opacity(atm, opa, ngauss=4, stream=2, delta_eddington=True, raman=2, test_mode=None)
+    for nm, arr in zip(NAMES, out):
+        ref = ck["fly/de1_s2/" + nm]
+        assert _close(np.broadcast_to(arr, ref.shape), ref, 1e-9), nm
+    opa.get_opacities(atm, exclude_mol={"H2O": 1, "CH4": 0, "H2": 1})
+    assert _close(opa.get_molecular_opa(), ck["fly/molecular_opa_noCH4"], 1e-10)
+    # the premixed table is still reachable
+    opa.get_opacities_preweighted(atm)
+    assert _close(opa.get_molecular_opa(), ck["molecular_opa"], 1e-10)
+
+
+@pytest.mark.gpu
+def test_gpu_gasesfly_spectrum_runs_through_picaso(ck, og):
+    from picaso_amd import justdoit as jdi
+    opa = _ck_class(ck, fly=True)
+    out = _case(og, jdi, True).spectrum(opa, calculation="reflected+thermal")
+    pre = _case(og, jdi, True).spectrum(_ck_class(ck), calculation="reflected+thermal")
+    assert np.isfinite(out["albedo"]).all() and np.isfinite(out["thermal"]).all()
+    assert not np.allclose(out["albedo"], pre["albedo"])      # different (synthetic) gas tables
