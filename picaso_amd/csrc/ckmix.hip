@@ -6,12 +6,13 @@
 // One wavefront per (layer, P-T neighbour, wavenumber bin): with Nk <= 8 Gauss points the Nk^2 <= 64
 // random-overlap products of two gases are exactly one lane each (lane = i*Nk + j).  Per gas added:
 //   key   = (mix1*k1[i] + mix2*k2[j]) / (mix1+mix2)                      (:571, unfused)
-//   stable rank sort across the wave (v_readlane broadcast, ties by lane = np.argsort 'mergesort'),
+//   stable rank sort across the wave (LDS broadcast of the keys, ties by lane = np.argsort 'mergesort'),
 //   keys and weights moved to their sorted lanes with ds_permute,
-//   sequential prefix sum of the sorted weights (np.cumsum order), x = cum / cum[last],
+//   prefix sum of the sorted weights (wave scan), x = cum / cum[last],
 //   np.interp(gauss_pts, x, log10(key)) -> 10** -> the Nk coefficients of the mixture (:586-590),
-// everything in registers; no LDS tile, no scratch.  HBM traffic is the table rows read
-// (ngas * Nk doubles per bin) and Nk doubles written: the kernel is VALU/cross-lane bound.
+// everything in registers apart from the 512-byte key row each wave broadcasts from LDS.  HBM traffic
+// is the table rows read (ngas * Nk doubles per bin) and Nk doubles written: the kernel is
+// VALU/cross-lane bound.
 #include "common.hpp"
 #include "device_math.hpp"
 
@@ -45,12 +46,31 @@ __device__ __forceinline__ double permute_to_d(double v, int dst)
     return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 
+// 10^r as 2^(r log2 10) with the product carried in two terms (hi + lo), so the result keeps the
+// ~1 ulp of fexp2 for |r| up to the ~50 of log10(kappa)
+__device__ __forceinline__ double fexp10(double r)
+{
+    constexpr double L_HI = 0x1.a934f0979a371p+1, L_LO = 0x1.7f2495fb7fa6dp-53;   // log2(10)
+    const double th = r * L_HI;
+    const double tl = fma(r, L_HI, -th) + r * L_LO;
+    return fexp2(th) * fma(tl, 0x1.62e42fefa39efp-1, 1.0);
+}
+
+__device__ __forceinline__ double shfl_d(double v, int src_lane)
+{
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_ds_bpermute(src_lane << 2, (int)b);
+    const int hi = __builtin_amdgcn_ds_bpermute(src_lane << 2, (int)(b >> 32));
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
 __global__ __launch_bounds__(256) void k_ckmix(const CKMixArgs a)
 {
 #pragma clang fp contract(off)
-    const int lane = threadIdx.x & 63;
-    const long iw = blockIdx.x * 4L + (threadIdx.x >> 6);
-    if (iw >= a.nwno) return;                          // whole wave
+    __shared__ __attribute__((aligned(16))) double s_key[4][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const long iw = blockIdx.x * 4L + wv;
+    if (iw >= a.nwno) return;                          // whole wave; no block-level barrier below
     const int il = blockIdx.y >> 2, ct = blockIdx.y & 3;
     const int nk = a.nk, n2 = nk * nk;
     const bool valid = lane < n2;
@@ -65,58 +85,66 @@ __global__ __launch_bounds__(256) void k_ckmix(const CKMixArgs a)
         wj = (j == n) ? a.gwts[n] : wj;
     }
     const double w_own = valid ? wi * wj : 0.0;        // eq. 10 Amundsen 2017 (:572)
+    double *row = s_key[wv];
+    const int n2e = (n2 + 1) & ~1;
 
-    double k1 = exp(a.tabs[0][off + i]);               // (:428) coefficient i of the running mixture
+    double k1 = fexp(a.tabs[0][off + i]);              // (:428) coefficient i of the running mixture
     double mix_t = a.mixes[il];
     for (int g = 1; g < a.ngas; ++g) {
-        const double k2 = exp(a.tabs[g][off + j]);
+        const double k2 = fexp(a.tabs[g][off + j]);
         const double mix2 = a.mixes[(size_t)g * a.nlayer + il];
         const double mt = mix_t + mix2;
         const double key = valid ? (mix_t * k1 + mix2 * k2) / mt : __builtin_inf();
-        // stable rank: number of elements that sort before this one
+        // stable rank = number of elements sorting before this one (ties by original index, as
+        // np.argsort(kind='mergesort')); the keys are broadcast from LDS two per ds_read_b128
+        row[lane] = key;
+        __builtin_amdgcn_wave_barrier();
         int rank = 0;
-        for (int t = 0; t < n2; ++t) {
-            const double kt = readlane_d(key, t);
-            rank += ((kt < key) || (kt == key && t < lane)) ? 1 : 0;
+        for (int t = 0; t < n2e; t += 2) {
+            const double2 kk = *reinterpret_cast<const double2 *>(row + t);
+            rank += ((kk.x < key) || (kk.x == key && t < lane)) ? 1 : 0;
+            rank += ((kk.y < key) || (kk.y == key && t + 1 < lane)) ? 1 : 0;
         }
+        __builtin_amdgcn_wave_barrier();
         const bool bad = __any(valid && (key != key));  // NaN in -> NaN out
         const int dst = valid ? rank : lane;
         const double ks = permute_to_d(key, dst);
         const double ws = permute_to_d(w_own, dst);
-        // np.cumsum: c[0] = w[0], c[n] = c[n-1] + w[n]
-        double cum = 0.0;
-        for (int t = 0; t < n2; ++t) {
-            const double wt = readlane_d(ws, t);
-            cum = (lane >= t) ? cum + wt : cum;
+        // cumulative weight (np.cumsum; a log-step wave scan: sums of <= 64 positive weights, the
+        // summation order differs from numpy's in the last bit only)
+        double cum = ws;
+        for (int o = 1; o < 64; o <<= 1) {
+            const double up = shfl_d(cum, lane - o);
+            cum = (lane >= o) ? cum + up : cum;
         }
         const double x = cum / readlane_d(cum, n2 - 1);       // np.max of an increasing sum (:582)
         const double f = log10(ks);
+        // np.interp(gauss_pts, x, f) (:586): slope of the segment [lane, lane+1] once per lane
+        const int nb = lane + 1 < n2 ? lane + 1 : lane;
+        const double x1 = shfl_d(x, nb), f1 = shfl_d(f, nb);
+        const double slope = (f1 - f) / (x1 - x);
         const double x_last = readlane_d(x, n2 - 1), f_first = readlane_d(f, 0), f_last = readlane_d(f, n2 - 1);
         double rsel = 0.0;
-        for (int n = 0; n < nk; ++n) {                 // np.interp(gauss_pts, x, f)   (:586)
+        for (int n = 0; n < nk; ++n) {
             const double gp = a.gpts[n];
             const int cnt = __popcll(__ballot(valid && x <= gp));
             double r;
-            if (gp > x_last) r = f_last;
+            if (gp > x_last || cnt >= n2) r = f_last;
             else if (cnt == 0) r = f_first;
-            else if (cnt == n2) r = f_last;
             else {
                 const int jj = cnt - 1;
-                const double xj = readlane_d(x, jj), xj1 = readlane_d(x, jj + 1);
-                const double fj = readlane_d(f, jj), fj1 = readlane_d(f, jj + 1);
+                const double xj = readlane_d(x, jj), fj = readlane_d(f, jj), sj = readlane_d(slope, jj);
+                r = sj * (gp - xj) + fj;
                 if (xj == gp) r = fj;
-                else {
-                    const double slope = (fj1 - fj) / (xj1 - xj);
-                    r = slope * (gp - xj) + fj;
-                    if (r != r) {
-                        r = slope * (gp - xj1) + fj1;
-                        if (r != r && fj == fj1) r = fj;
-                    }
+                else if (r != r) {                     // numpy's fallbacks for a non-finite slope
+                    const double xj1 = readlane_d(x, jj + 1), fj1 = readlane_d(f, jj + 1);
+                    r = sj * (gp - xj1) + fj1;
+                    if (r != r && fj == fj1) r = fj;
                 }
             }
             rsel = (i == n) ? r : rsel;
         }
-        k1 = bad ? __builtin_nan("") : pow(10.0, rsel);
+        k1 = bad ? __builtin_nan("") : fexp10(rsel);
         mix_t = mt;
     }
     if (valid && j == 0)

@@ -35,7 +35,7 @@ def main():
     g, gw, t, tw = disco.get_angles_1d(5)
     u0, u1, ct, _, _ = disco.compute_disco(5, 1, g, t, 0.0)
     nlayer = 90
-    only = os.environ.get("BENCH_ONLY")        # thermal | variants | 3d | sh (default: all)
+    only = os.environ.get("BENCH_ONLY")        # thermal | variants | pipeline | 3d | sh | copy | mix | e2e (default: all)
     if only in (None, "thermal"):
         for nwno in (10000, 100000):
             sc = syn.make_scene(nlayer, nwno, seed=5)
@@ -208,6 +208,34 @@ def main():
                                                               _ct.c_size_t(nbytes)), ctx), ctx, reps=10)
         out["hbm_copy_d2d_2GiB"] = dict(ms=ms, GBps_read_plus_write=2 * nbytes / ms / 1e6)
         src.free(); dst.free()
+    if only in (None, "mix"):
+        # on-the-fly correlated-k mixing at the climate tables' shape: 661 bins x 8 Gauss points,
+        # 90 layers x 4 P-T neighbours, 17 gases; CPU oracle on a 3-layer sample of the same job
+        from oracle import oracle as orc
+        rng = np.random.default_rng(11)
+        nk, ngas, npres, ntemp, nw, nl = 8, 17, 20, 15, 661, 90
+        xg, wg = np.polynomial.legendre.leggauss(4)
+        pts = np.concatenate([0.95 * 0.5 * (xg + 1), 0.95 + 0.05 * 0.5 * (xg + 1)])
+        wts = np.concatenate([0.95 * 0.5 * wg, 0.05 * 0.5 * wg])
+        kap = [-55.0 + 10.0 * rng.random((npres, ntemp, nw, 1))
+               + np.cumsum(rng.random((npres, ntemp, nw, nk)) * rng.choice([0.1, 1.0, 5.0]), axis=3)
+               for _ in range(ngas)]
+        mixes = [10.0 ** (-1.0 - 7.0 * rng.random(nl)) for _ in range(ngas)]
+        p_low, t_low = rng.integers(0, npres - 1, nl), rng.integers(0, ntemp - 1, nl)
+        idx = np.array([p_low, p_low + 1, t_low, t_low + 1])
+        dk = [DeviceArray.from_host(k, ctx) for k in kap]
+        outm = DeviceArray((nl, 4, nw, nk), ctx)
+        ms = timeit(lambda: resident.mix_all_gases_gasesfly(ctx, dk, mixes, pts, wts, idx, out=outm), ctx, reps=5)
+        t0 = time.perf_counter()
+        ref = orc.mix_all_gases_gasesfly(kap, [m[:3] for m in mixes], pts, wts, idx[:, :3])
+        cpu_s = (time.perf_counter() - t0) * nl / 3
+        err = float(np.max(np.abs(np.moveaxis(outm.to_host()[:3], 1, 3) - ref)))
+        pair_mixes = nl * 4 * nw * (ngas - 1)
+        out["ckmix_661x8_90layers_17gases"] = dict(ms=ms, pair_mixes_per_s=pair_mixes / ms * 1e3,
+                                                   cpu_oracle_1core_s=cpu_s, speedup=cpu_s * 1e3 / ms,
+                                                   max_abs_err_lnk_vs_oracle=err)
+        for d_ in dk:
+            d_.free()
     if only in (None, "e2e"):
         # inputs.spectrum() end to end at 1e5 wavelengths x 90 layers: HBM-resident synthetic opacity
         # tables (5 molecules x 40 (P,T) points, 2 CIA pairs), linear interpolation, cloud slab
