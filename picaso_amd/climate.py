@@ -1,0 +1,122 @@
+"""Radiative-transfer call of the climate solver on the GPU: ``get_fluxes``.
+
+Drop-in for the reference's ``climate.get_fluxes`` (picaso/climate.py:1687-1952), the function its
+T(P) iteration evaluates on every Newton step: Toon reflected light at the two-stream angle
+``ubar = 0.5`` and Toon thermal emission with bin-integrated Planck functions (``calc_type=1``),
+both returning level and layer-midpoint fluxes for every correlated-k Gauss point, then the
+Gauss-weight, patchy-cloud, disk and wavenumber sums.  Same positional arguments (the reference's
+namedtuples or anything with the same attribute names) and the same eight arrays back.
+
+Here the ``ngauss`` loop is one launch over ``nwno*ngauss`` columns per solver
+(``picaso_get_reflected_1d_ck_dev`` / ``picaso_get_thermal_1d_ck_dev``, level-flux kernels of
+``toon_lvl.hip``), the cloudy/clear blend and the disk quadrature run on the device, and only the
+``(nlevel, nwno)`` results come back for the final wavenumber sums.
+"""
+from collections import namedtuple
+
+import numpy as np
+
+from . import _lib, resident
+from ._lib import f64
+from .device import DeviceArray
+
+# the reference's containers (climate.py:1962-1966)
+Atmosphere_Tuple = namedtuple("Atmosphere_Tuple", ["dtdp", "mmw_layer", "nlevel", "t_level", "p_level", "condensables",
+                                                   "condensable_abundances", "condensable_weights", "scale_height"])
+OpacityWEd_Tuple = namedtuple("OpacityWEd_Tuple", ["DTAU", "TAU", "W0", "COSB", "ftau_cld", "ftau_ray", "GCOS2",
+                                                   "W0_no_raman", "f_deltaM"])
+OpacityNoEd_Tuple = namedtuple("OpacityNoEd_Tuple", ["DTAU", "TAU", "W0", "COSB"])
+ScatteringPhase_Tuple = namedtuple("ScatteringPhase_Tuple", ["surf_reflect", "single_phase", "multi_phase", "frac_a",
+                                                             "frac_b", "frac_c", "constant_back", "constant_forward"])
+Disco_Tuple = namedtuple("Disco_Tuple", ["ng", "nt", "gweight", "tweight", "ubar0", "ubar1", "cos_theta"])
+Opagrid_Tuple = namedtuple("Opagrid_Tuple", ["nwno", "delta_wno", "wno", "ngauss", "gauss_wts"])
+
+
+def _planes(wed, noed, ctx, thermal_only=False):
+    """Upload the (rows, nwno, ngauss) arrays of one opacity set (DeviceArrays pass through)."""
+    def up(x):
+        return x if isinstance(x, DeviceArray) else DeviceArray.from_host(f64(x), ctx)
+    pl = {"dtau_og": up(noed.DTAU), "w0_no_raman": up(wed.W0_no_raman), "cosb_og": up(noed.COSB)}
+    if not thermal_only:
+        pl.update(dtau=up(wed.DTAU), tau=up(wed.TAU), w0=up(wed.W0), cosb=up(wed.COSB), gcos2=up(wed.GCOS2),
+                  ftau_cld=up(wed.ftau_cld), ftau_ray=up(wed.ftau_ray), tau_og=up(noed.TAU), w0_og=up(noed.W0))
+    return pl
+
+
+def get_fluxes(Atmosphere, OpacityWEd, OpacityNoEd, ScatteringPhase, Disco, Opagrid, F0PI, reflected, thermal,
+               do_holes=False, fhole=0.0, hole_OpacityWEd=None, hole_OpacityNoEd=None, ctx=None):
+    """Visible and IR net (layer and level), upward and downward fluxes (reference
+    ``climate.get_fluxes``, climate.py:1687-1952).  Returns ``flux_net_v_layer, flux_net_v, flux_plus_v,
+    flux_minus_v, flux_net_ir_layer, flux_net_ir, flux_plus_ir, flux_minus_ir``."""
+    ctx = ctx if ctx is not None else _lib.context()
+    pressure, temperature, nlevel = Atmosphere.p_level, Atmosphere.t_level, int(Atmosphere.nlevel)
+    sp = ScatteringPhase
+    ng, nt = int(Disco.ng), int(Disco.nt)
+    nwno, ngauss = int(Opagrid.nwno), int(Opagrid.ngauss)
+    dwni, wno, gauss_wts = f64(Opagrid.delta_wno), f64(Opagrid.wno), f64(Opagrid.gauss_wts)
+    if do_holes and (hole_OpacityWEd is None or hole_OpacityNoEd is None):
+        raise Exception("get_fluxes: do_holes=True needs hole_OpacityWEd and hole_OpacityNoEd")
+
+    flux_net_v = np.zeros((ng, nt, nlevel))
+    flux_net_v_layer = np.zeros((ng, nt, nlevel))
+    flux_plus_v = np.zeros((ng, nt, nlevel, nwno))
+    flux_minus_v = np.zeros((ng, nt, nlevel, nwno))
+    flux_net_ir = np.zeros(nlevel)
+    flux_net_ir_layer = np.zeros(nlevel)
+    flux_plus_ir = np.zeros((nlevel, nwno))
+    flux_minus_ir = np.zeros((nlevel, nwno))
+
+    rs = DeviceArray.from_host(np.zeros(nwno) + f64(sp.surf_reflect), ctx)
+    sets = [_planes(OpacityWEd, OpacityNoEd, ctx, thermal_only=not reflected)]
+    if do_holes:
+        sets.append(_planes(hole_OpacityWEd, hole_OpacityNoEd, ctx, thermal_only=not reflected))
+
+    def blend(results):                                   # (1-fhole)*cloudy + fhole*clear, climate.py:1838-1842
+        if len(results) == 1:
+            return results[0]
+        for a, b in zip(*results):
+            resident.axpby(ctx, 1.0 - fhole, a, fhole, b, a)
+        return results[0]
+
+    if reflected:                                         # climate.py:1796-1874
+        d_f0 = DeviceArray.from_host(np.zeros(nwno) + f64(F0PI), ctx)
+        half = np.full((1, 1), 0.5)                       # ubar0_clima = ubar1_clima = 0.5, one angle
+        xdummy = DeviceArray((1, 1, nwno), ctx)
+        res = []
+        for pl in sets:
+            lv = [DeviceArray((1, 1, nlevel, nwno), ctx) for _ in range(4)]
+            resident.reflected_1d_ck(ctx, nlevel, nwno, ngauss, 1, 1, pl, rs, half, half, float(Disco.cos_theta),
+                                     d_f0, int(sp.single_phase), int(sp.multi_phase), float(sp.frac_a),
+                                     float(sp.frac_b), float(sp.frac_c), float(sp.constant_back),
+                                     float(sp.constant_forward), gauss_wts, xdummy, get_toa_intensity=0,
+                                     lvl_fluxes=lv)
+            res.append(lv)
+        fm, fp, fmm, fpm = [x.to_host() for x in blend(res)]        # Gauss-weighted (1,1,nlevel,nwno)
+        flux_net_v_layer += np.sum(fpm, axis=3) - np.sum(fmm, axis=3)
+        flux_net_v += np.sum(fp, axis=3) - np.sum(fm, axis=3)
+        flux_plus_v += fp
+        flux_minus_v += fm
+
+    if thermal:                                           # climate.py:1879-1941
+        d_wno, d_dw = DeviceArray.from_host(wno, ctx), DeviceArray.from_host(dwni, ctx)
+        xdummy = DeviceArray((ng, nt, nwno), ctx)
+        res = []
+        for pl in sets:
+            lv = [DeviceArray((ng, nt, nlevel, nwno), ctx) for _ in range(4)]
+            resident.thermal_1d_ck(ctx, nlevel, d_wno, nwno, ngauss, ng, nt, temperature, pl["dtau_og"],
+                                   pl["w0_no_raman"], pl["cosb_og"], pressure, Disco.ubar1, rs, 0, gauss_wts,
+                                   xdummy, dwno=d_dw, calc_type=1, lvl_fluxes=lv)
+            res.append(lv)
+        disk = []
+        for x in blend(res):                              # compress_thermal over the disk angles (:1925-1928)
+            d = DeviceArray((nlevel, nwno), ctx)
+            resident.compress_thermal(ctx, nlevel * nwno, x, Disco.gweight, Disco.tweight, d)
+            disk.append(d.to_host())
+        fm, fp, fmm, fpm = disk
+        flux_net_ir_layer = ((fpm - fmm) * dwni).sum(axis=1)                  # (:1931-1936)
+        flux_net_ir = ((fp - fm) * dwni).sum(axis=1)
+        flux_plus_ir = fp * dwni
+        flux_minus_ir = fm * dwni
+
+    return (flux_net_v_layer, flux_net_v, flux_plus_v, flux_minus_v, flux_net_ir_layer, flux_net_ir,
+            flux_plus_ir, flux_minus_ir)

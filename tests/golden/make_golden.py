@@ -745,3 +745,67 @@ def make_mixing():
 
 if __name__ == "__main__" and (("mixing" in sys.argv[1:]) or not sys.argv[1:]):
     make_mixing()
+
+
+def _climate_inputs(nlevel=21, nwno=12, ngauss=3, seed=40, cloud_scale=1.0):
+    """Per-Gauss-point synthetic planes stacked into the reference's (rows, nwno, ngauss) arrays."""
+    nlayer = nlevel - 1
+    scs = [syn.make_scene(nlayer, nwno, seed=seed + ig, gas_scale=10.0 ** (ig - 1), cloud_opd=2.0 * cloud_scale)
+           for ig in range(ngauss)]
+    st = {k: np.ascontiguousarray(np.stack([sc[k] for sc in scs], axis=2))
+          for k in PLANES + ("w0_no_raman",)}
+    return scs[0], st
+
+
+def make_climate_fluxes():
+    """climate.get_fluxes of the reference (climate.py:1687-1952) with its own namedtuples: the
+    correlated-k / level-flux / wavenumber-sum wrapper the climate solver calls every iteration."""
+    cl = ref_shim.load("climate")
+    store = {}
+    for name, nlevel, nwno, ngauss, holes in (("a", 21, 12, 3, False), ("holes", 16, 9, 2, True),
+                                              ("g1", 11, 7, 1, False)):
+        sc0, st = _climate_inputs(nlevel, nwno, ngauss)
+        geo = geometry_1d(5)
+        wno = sc0["wno"]
+        dwni = np.abs(np.gradient(wno))
+        rng = np.random.default_rng(3)
+        f0pi = 0.5 + rng.random(nwno)
+        atm = cl.Atmosphere_Tuple(None, None, nlevel, sc0["tlevel"], sc0["plevel"], None, None, None, None)
+        wed = cl.OpacityWEd_Tuple(st["dtau"], st["tau"], st["w0"], st["cosb"], st["ftau_cld"], st["ftau_ray"],
+                                  st["gcos2"], st["w0_no_raman"], None)
+        noed = cl.OpacityNoEd_Tuple(st["dtau_og"], st["tau_og"], st["w0_og"], st["cosb_og"])
+        sp = cl.ScatteringPhase_Tuple(np.full(nwno, 0.1), 3, 0, 1.0, -1.0, 2.0, -0.5, 1.0)
+        dis = cl.Disco_Tuple(5, 1, geo["gweight"], geo["tweight"], geo["ubar0"], geo["ubar1"], 1.0)
+        import collections
+        Opagrid = collections.namedtuple("Opagrid", ["nwno", "delta_wno", "wno", "ngauss", "gauss_wts"])
+        gw = np.array([0.5, 0.3, 0.2][:ngauss])
+        gw = gw / gw.sum()
+        og = Opagrid(nwno, dwni, wno, ngauss, gw)
+        kw = {}
+        if holes:
+            _, stc = _climate_inputs(nlevel, nwno, ngauss, cloud_scale=0.05)
+            kw = dict(do_holes=True, fhole=0.3,
+                      hole_OpacityWEd=cl.OpacityWEd_Tuple(stc["dtau"], stc["tau"], stc["w0"], stc["cosb"],
+                                                          stc["ftau_cld"], stc["ftau_ray"], stc["gcos2"],
+                                                          stc["w0_no_raman"], None),
+                      hole_OpacityNoEd=cl.OpacityNoEd_Tuple(stc["dtau_og"], stc["tau_og"], stc["w0_og"],
+                                                            stc["cosb_og"]))
+            for k, v in stc.items():
+                store["%s/clear/%s" % (name, k)] = v
+        out = cl.get_fluxes(atm, wed, noed, sp, dis, og, f0pi, True, True, **kw)
+        for k, v in st.items():
+            store["%s/%s" % (name, k)] = v
+        for k, v in dict(tlevel=sc0["tlevel"], plevel=sc0["plevel"], wno=wno, dwni=dwni, f0pi=f0pi, gauss_wts=gw,
+                         gweight=geo["gweight"], tweight=geo["tweight"], ubar0=geo["ubar0"],
+                         ubar1=geo["ubar1"]).items():
+            store["%s/%s" % (name, k)] = v
+        for k, v in zip(("flux_net_v_layer", "flux_net_v", "flux_plus_v", "flux_minus_v", "flux_net_ir_layer",
+                         "flux_net_ir", "flux_plus_ir", "flux_minus_ir"), out):
+            store["%s/out/%s" % (name, k)] = np.asarray(v)
+    path = os.path.join(HERE, "climate_fluxes.npz")
+    np.savez_compressed(path, **store)
+    print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024))
+
+
+if __name__ == "__main__" and (("climate" in sys.argv[1:]) or not sys.argv[1:]):
+    make_climate_fluxes()

@@ -1,0 +1,91 @@
+"""The climate solver's RT call, get_fluxes (level fluxes + dwni-weighted sums):
+oracle/climate_oracle.py and picaso_amd.climate.get_fluxes against tests/golden/climate_fluxes.npz,
+outputs of the reference's own climate.get_fluxes with its namedtuples."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import GOLDEN, rel_err
+
+CASES = ("a", "holes", "g1")
+OUT = ("flux_net_v_layer", "flux_net_v", "flux_plus_v", "flux_minus_v", "flux_net_ir_layer", "flux_net_ir",
+       "flux_plus_ir", "flux_minus_ir")
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return np.load(os.path.join(GOLDEN, "climate_fluxes.npz"))
+
+
+def _args(g, c, mod):
+    """The reference's positional arguments, built with `mod`'s namedtuples."""
+    def tup(prefix):
+        p = {k: g["%s/%s%s" % (c, prefix, k)] for k in ("dtau", "tau", "w0", "cosb", "ftau_cld", "ftau_ray", "gcos2",
+                                                       "w0_no_raman", "dtau_og", "tau_og", "w0_og", "cosb_og")}
+        return (mod.OpacityWEd_Tuple(p["dtau"], p["tau"], p["w0"], p["cosb"], p["ftau_cld"], p["ftau_ray"],
+                                     p["gcos2"], p["w0_no_raman"], None),
+                mod.OpacityNoEd_Tuple(p["dtau_og"], p["tau_og"], p["w0_og"], p["cosb_og"]))
+    nlevel, nwno, ngauss = g[c + "/tau"].shape
+    atm = mod.Atmosphere_Tuple(None, None, nlevel, g[c + "/tlevel"], g[c + "/plevel"], None, None, None, None)
+    wed, noed = tup("")
+    sp = mod.ScatteringPhase_Tuple(np.full(nwno, 0.1), 3, 0, 1.0, -1.0, 2.0, -0.5, 1.0)
+    dis = mod.Disco_Tuple(5, 1, g[c + "/gweight"], g[c + "/tweight"], g[c + "/ubar0"], g[c + "/ubar1"], 1.0)
+    og = mod.Opagrid_Tuple(nwno, g[c + "/dwni"], g[c + "/wno"], ngauss, g[c + "/gauss_wts"])
+    kw = {}
+    if c == "holes":
+        hw, hn = tup("clear/")
+        kw = dict(do_holes=True, fhole=0.3, hole_OpacityWEd=hw, hole_OpacityNoEd=hn)
+    return (atm, wed, noed, sp, dis, og, g[c + "/f0pi"], True, True), kw
+
+
+def _check(out, g, c, tol, tol_ir_lvl=None):
+    """Net fluxes: relative to the field maximum.  Level fluxes per wavenumber: tests/helpers.lvl_err's
+    metric, |got - ref| over the per-wavenumber scale of the (plus, minus) pair -- entries that all
+    but vanish are differences of nearly equal terms in the reference's formulation.  The thermal
+    level fluxes of optically thick Gauss points carry the reference's own b_surface - c_plus_down
+    cancellation (tests/test_ck_gpu.py): `tol_ir_lvl`."""
+    assert len(out) == 8
+    got = dict(zip(OUT, out))
+    for name in OUT:
+        want = g["%s/out/%s" % (c, name)]
+        assert np.shape(got[name]) == want.shape, name
+    for name in ("flux_net_v_layer", "flux_net_v", "flux_net_ir_layer", "flux_net_ir"):
+        want = g["%s/out/%s" % (c, name)]
+        assert rel_err(got[name], want, 1e-4 * np.abs(want).max()) < tol, (c, name)
+    for leg, t_ in (("v", tol), ("ir", tol_ir_lvl or tol)):
+        wp, wm = g["%s/out/flux_plus_%s" % (c, leg)], g["%s/out/flux_minus_%s" % (c, leg)]
+        ax = tuple(range(wp.ndim - 1))
+        scale = np.maximum(np.abs(wp).max(axis=ax), np.abs(wm).max(axis=ax))
+        scale = np.where(scale == 0, 1.0, scale)
+        for nm, w in (("plus", wp), ("minus", wm)):
+            assert np.max(np.abs(got["flux_%s_%s" % (nm, leg)] - w) / scale) < t_, (c, leg, nm)
+
+
+@pytest.mark.parametrize("c", CASES)
+def test_oracle_get_fluxes(gold, c):
+    from oracle import climate_oracle as co
+    from picaso_amd import climate as pc          # namedtuple definitions only (no device call)
+    args, kw = _args(gold, c, pc)
+    _check(co.get_fluxes(*args, **kw), gold, c, 1e-9)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("c", CASES)
+def test_gpu_get_fluxes(gold, c):
+    from picaso_amd import climate as pc
+    args, kw = _args(gold, c, pc)
+    _check(pc.get_fluxes(*args, **kw), gold, c, 2e-8, tol_ir_lvl=2e-4)
+
+
+@pytest.mark.gpu
+def test_gpu_get_fluxes_single_legs(gold):
+    """reflected-only / thermal-only calls leave the other leg's outputs at zero, as the reference."""
+    from picaso_amd import climate as pc
+    args, kw = _args(gold, "a", pc)
+    full = pc.get_fluxes(*args, **kw)
+    r = pc.get_fluxes(*args[:7], True, False)
+    t = pc.get_fluxes(*args[:7], False, True)
+    for k in range(4):
+        assert np.array_equal(r[k], full[k]) and not np.any(t[k])
+        assert np.array_equal(t[4 + k], full[4 + k]) and not np.any(r[4 + k])

@@ -24,6 +24,9 @@ class _Dummy(types.ModuleType):
             raise AttributeError(name)
         return _noop
 
+    def __getitem__(self, key):          # numba type specs such as float64[:]
+        return self
+
 
 def _noop(*a, **k):
     return None
@@ -41,10 +44,16 @@ def install_shims():
         nb.jit = nb.njit = nb.vectorize = nb.guvectorize = _jit
         nb.prange = range
         nb.objmode = _noop
+        nb.float32 = nb.float64 = nb.int32 = nb.int64 = _Dummy("numba.types")
+        exp = types.ModuleType("numba.experimental")
+        exp.jitclass = _jit
+        nb.experimental = exp
+        sys.modules["numba.experimental"] = exp
         nb.__graft_shim__ = True
         sys.modules["numba"] = nb
     for name in ("bokeh", "bokeh.plotting", "bokeh.palettes", "bokeh.io", "bokeh.models",
-                 "astropy", "astropy.io", "astropy.io.fits", "astropy.units", "astropy.constants", "h5py"):
+                 "astropy", "astropy.io", "astropy.io.fits", "astropy.units", "astropy.constants", "h5py",
+                 "virga", "virga.justdoit"):
         if name not in sys.modules:
             sys.modules[name] = _Dummy(name)
     os.environ.setdefault("picaso_refdata", os.path.join(REF_ROOT, "reference"))
@@ -65,7 +74,7 @@ _cache = {}
 
 
 def load(name):
-    """name in {'fluxes','disco','rayleigh','deq_chem','optics','atmsetup'} -> reference module object."""
+    """name in {'fluxes','disco','rayleigh','deq_chem','optics','atmsetup','climate'} -> reference module object."""
     if name in _cache:
         return _cache[name]
     if not available():
@@ -73,7 +82,7 @@ def load(name):
     install_shims()
     if name in ("fluxes", "disco", "rayleigh", "deq_chem"):
         mod = _load_by_path("_picaso_ref_" + name, name + ".py")
-    elif name in ("optics", "atmsetup"):
+    elif name in ("optics", "atmsetup", "climate"):
         if "picaso" not in sys.modules:
             pkg = types.ModuleType("picaso")
             pkg.__path__ = [os.path.join(REF_ROOT, "picaso")]
