@@ -59,8 +59,7 @@ def get_fluxes(Atmosphere, OpacityWEd, OpacityNoEd, ScatteringPhase, Disco, Opag
 
     flux_net_v = np.zeros((ng, nt, nlevel))
     flux_net_v_layer = np.zeros((ng, nt, nlevel))
-    flux_plus_v = np.zeros((ng, nt, nlevel, nwno))
-    flux_minus_v = np.zeros((ng, nt, nlevel, nwno))
+    flux_plus_v = flux_minus_v = None
     flux_net_ir = np.zeros(nlevel)
     flux_net_ir_layer = np.zeros(nlevel)
     flux_plus_ir = np.zeros((nlevel, nwno))
@@ -84,18 +83,20 @@ def get_fluxes(Atmosphere, OpacityWEd, OpacityNoEd, ScatteringPhase, Disco, Opag
         xdummy = DeviceArray((1, 1, nwno), ctx)
         res = []
         for pl in sets:
-            lv = [DeviceArray((1, 1, nlevel, nwno), ctx) for _ in range(4)]
+            stack = DeviceArray((4, 1, 1, nlevel, nwno), ctx)       # one buffer, one copy back
+            lv = [stack.row_block(k) for k in range(4)]
             resident.reflected_1d_ck(ctx, nlevel, nwno, ngauss, 1, 1, pl, rs, half, half, float(Disco.cos_theta),
                                      d_f0, int(sp.single_phase), int(sp.multi_phase), float(sp.frac_a),
                                      float(sp.frac_b), float(sp.frac_c), float(sp.constant_back),
                                      float(sp.constant_forward), gauss_wts, xdummy, get_toa_intensity=0,
                                      lvl_fluxes=lv)
             res.append(lv)
-        fm, fp, fmm, fpm = [x.to_host() for x in blend(res)]        # Gauss-weighted (1,1,nlevel,nwno)
+        fm, fp, fmm, fpm = blend(res)[0]._owner.to_host()           # Gauss-weighted (1,1,nlevel,nwno) each
         flux_net_v_layer += np.sum(fpm, axis=3) - np.sum(fmm, axis=3)
         flux_net_v += np.sum(fp, axis=3) - np.sum(fm, axis=3)
-        flux_plus_v += fp
-        flux_minus_v += fm
+        # the single two-stream angle stands for every disk angle (climate.py:1803-1805, :1868-1869)
+        flux_plus_v = np.broadcast_to(fp, (ng, nt, nlevel, nwno)).copy()
+        flux_minus_v = np.broadcast_to(fm, (ng, nt, nlevel, nwno)).copy()
 
     if thermal:                                           # climate.py:1879-1941
         d_wno, d_dw = DeviceArray.from_host(wno, ctx), DeviceArray.from_host(dwni, ctx)
@@ -107,16 +108,16 @@ def get_fluxes(Atmosphere, OpacityWEd, OpacityNoEd, ScatteringPhase, Disco, Opag
                                    pl["w0_no_raman"], pl["cosb_og"], pressure, Disco.ubar1, rs, 0, gauss_wts,
                                    xdummy, dwno=d_dw, calc_type=1, lvl_fluxes=lv)
             res.append(lv)
-        disk = []
-        for x in blend(res):                              # compress_thermal over the disk angles (:1925-1928)
-            d = DeviceArray((nlevel, nwno), ctx)
-            resident.compress_thermal(ctx, nlevel * nwno, x, Disco.gweight, Disco.tweight, d)
-            disk.append(d.to_host())
-        fm, fp, fmm, fpm = disk
+        disk = DeviceArray((4, nlevel, nwno), ctx)
+        for k, x in enumerate(blend(res)):                # compress_thermal over the disk angles (:1925-1928)
+            resident.compress_thermal(ctx, nlevel * nwno, x, Disco.gweight, Disco.tweight, disk.row_block(k))
+        fm, fp, fmm, fpm = disk.to_host()
         flux_net_ir_layer = ((fpm - fmm) * dwni).sum(axis=1)                  # (:1931-1936)
         flux_net_ir = ((fp - fm) * dwni).sum(axis=1)
         flux_plus_ir = fp * dwni
         flux_minus_ir = fm * dwni
 
+    if flux_plus_v is None:
+        flux_plus_v, flux_minus_v = np.zeros((ng, nt, nlevel, nwno)), np.zeros((ng, nt, nlevel, nwno))
     return (flux_net_v_layer, flux_net_v, flux_plus_v, flux_minus_v, flux_net_ir_layer, flux_net_ir,
             flux_plus_ir, flux_minus_ir)

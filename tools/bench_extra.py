@@ -35,7 +35,7 @@ def main():
     g, gw, t, tw = disco.get_angles_1d(5)
     u0, u1, ct, _, _ = disco.compute_disco(5, 1, g, t, 0.0)
     nlayer = 90
-    only = os.environ.get("BENCH_ONLY")        # thermal | variants | pipeline | 3d | sh | copy | mix | e2e (default: all)
+    only = os.environ.get("BENCH_ONLY")        # thermal | variants | pipeline | 3d | sh | copy | mix | climate | e2e (default: all)
     if only in (None, "thermal"):
         for nwno in (10000, 100000):
             sc = syn.make_scene(nlayer, nwno, seed=5)
@@ -236,6 +236,41 @@ def main():
                                                    max_abs_err_lnk_vs_oracle=err)
         for d_ in dk:
             d_.free()
+    if only in (None, "climate"):
+        # climate.get_fluxes at the climate tables' shape: 91 levels, 661 bins x 8 Gauss points, 5 disk
+        # angles for the thermal leg; host-array call (PCIe inclusive), planes already resident, CPU oracle
+        from oracle import climate_oracle as co
+        from picaso_amd import climate as pc
+        nlev, nw, ngq = 91, 661, 8
+        scs = [syn.make_scene(nlev - 1, nw, seed=70 + ig, gas_scale=10.0 ** (0.5 * ig - 2)) for ig in range(ngq)]
+        keys = resident.REFLECTED_PLANES + ("w0_no_raman",)
+        st = {k: np.ascontiguousarray(np.stack([sc[k] for sc in scs], axis=2)) for k in keys}
+        xg, wg = np.polynomial.legendre.leggauss(ngq)
+        wno_c = scs[0]["wno"]
+        atm_t = pc.Atmosphere_Tuple(None, None, nlev, scs[0]["tlevel"], scs[0]["plevel"], None, None, None, None)
+        sp_t = pc.ScatteringPhase_Tuple(np.zeros(nw), 3, 0, 1.0, -1.0, 2.0, -0.5, 1.0)
+        dis_t = pc.Disco_Tuple(5, 1, gw, tw, u0, u1, 1.0)
+        og_t = pc.Opagrid_Tuple(nw, np.abs(np.gradient(wno_c)), wno_c, ngq, 0.5 * wg)
+
+        def tuples(conv):
+            return (pc.OpacityWEd_Tuple(*[conv(st[k]) for k in ("dtau", "tau", "w0", "cosb", "ftau_cld", "ftau_ray",
+                                                                 "gcos2", "w0_no_raman")], None),
+                    pc.OpacityNoEd_Tuple(*[conv(st[k]) for k in ("dtau_og", "tau_og", "w0_og", "cosb_og")]))
+        wh, nh = tuples(lambda a: a)
+        wd, nd = tuples(lambda a: DeviceArray.from_host(a, ctx))
+        res = {}
+        for tag, (w_, n_) in (("host_arrays", (wh, nh)), ("resident_planes", (wd, nd))):
+            pc.get_fluxes(atm_t, w_, n_, sp_t, dis_t, og_t, np.ones(nw), True, True)
+            ts = []
+            for _ in range(5):
+                t0 = time.perf_counter()
+                pc.get_fluxes(atm_t, w_, n_, sp_t, dis_t, og_t, np.ones(nw), True, True)
+                ts.append(time.perf_counter() - t0)
+            res[tag + "_ms"] = 1e3 * min(ts)
+        t0 = time.perf_counter()
+        co.get_fluxes(atm_t, wh, nh, sp_t, dis_t, og_t, np.ones(nw), True, True)
+        res["cpu_oracle_1core_ms"] = 1e3 * (time.perf_counter() - t0)
+        out["climate_get_fluxes_91x661x8"] = res
     if only in (None, "e2e"):
         # inputs.spectrum() end to end at 1e5 wavelengths x 90 layers: HBM-resident synthetic opacity
         # tables (5 molecules x 40 (P,T) points, 2 CIA pairs), linear interpolation, cloud slab
