@@ -170,6 +170,9 @@ void picaso_ctx_destroy(picaso_ctx *ctx)
     if (ctx->ring_h) (void)hipHostFree(ctx->ring_h);
     for (int i = 0; i < picaso_ctx::NSLOT; ++i)
         if (ctx->ring_ev[i]) (void)hipEventDestroy(ctx->ring_ev[i]);
+    if (ctx->stage) (void)hipHostFree(ctx->stage);
+    for (int i = 0; i < 2; ++i)
+        if (ctx->stage_ev[i]) (void)hipEventDestroy(ctx->stage_ev[i]);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -228,16 +231,71 @@ int picaso_pool_trim(picaso_ctx *ctx)
     PZ_HIP(ctx, hipSetDevice(ctx->device));
     return pool_release_all(ctx);
 }
+// Host <-> device copies of up to STAGE_MAX_COPY bytes go through the context's pinned bounce buffer
+// in two alternating halves (the DMA of one half overlaps the host memcpy of the other).  Handing
+// pageable memory straight to hipMemcpyAsync makes the runtime pin the caller's pages for transfers
+// above ~1 MB; when the caller then frees that memory (numpy returns large arrays to the OS) the
+// next HIP call pays for the teardown -- measured 26-29 ms per climate.get_fluxes call on the
+// MI355X box against 0.3 ms for the staged copy of the same 1.9 MB.
+static int stage_reserve(picaso_ctx *ctx)
+{
+    if (ctx->stage) return 0;
+    PZ_HIP(ctx, hipHostMalloc((void **)&ctx->stage, picaso_ctx::STAGE_BYTES, hipHostMallocDefault));
+    for (int i = 0; i < 2; ++i) PZ_HIP(ctx, hipEventCreateWithFlags(&ctx->stage_ev[i], hipEventDisableTiming));
+    return 0;
+}
+
 int picaso_memcpy_h2d(picaso_ctx *ctx, void *dst, const void *src, size_t bytes)
 {
-    PZ_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    if (!ctx) return fail(nullptr, "null context");
+    if (bytes == 0) return 0;
+    PZ_HIP(ctx, hipSetDevice(ctx->device));
+    if (bytes > picaso_ctx::STAGE_MAX_COPY) {
+        PZ_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+        PZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        return 0;
+    }
+    PZ_TRY(stage_reserve(ctx));
+    const size_t half = picaso_ctx::STAGE_BYTES / 2;
+    size_t c = 0;
+    for (size_t off = 0; off < bytes; off += half, ++c) {
+        const size_t len = bytes - off < half ? bytes - off : half;
+        char *h = ctx->stage + (c & 1) * half;
+        if (c >= 2) PZ_HIP(ctx, hipEventSynchronize(ctx->stage_ev[c & 1]));   // this half's previous DMA is done
+        memcpy(h, (const char *)src + off, len);
+        PZ_HIP(ctx, hipMemcpyAsync((char *)dst + off, h, len, hipMemcpyHostToDevice, ctx->stream));
+        PZ_HIP(ctx, hipEventRecord(ctx->stage_ev[c & 1], ctx->stream));
+    }
     PZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return 0;
 }
 int picaso_memcpy_d2h(picaso_ctx *ctx, void *dst, const void *src, size_t bytes)
 {
-    PZ_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
-    PZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (!ctx) return fail(nullptr, "null context");
+    if (bytes == 0) return 0;
+    PZ_HIP(ctx, hipSetDevice(ctx->device));
+    if (bytes > picaso_ctx::STAGE_MAX_COPY) {
+        PZ_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        PZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        return 0;
+    }
+    PZ_TRY(stage_reserve(ctx));
+    const size_t half = picaso_ctx::STAGE_BYTES / 2;
+    const size_t n = (bytes + half - 1) / half;
+    auto issue = [&](size_t c) -> int {
+        const size_t off = c * half, len = bytes - off < half ? bytes - off : half;
+        PZ_HIP(ctx, hipMemcpyAsync(ctx->stage + (c & 1) * half, (const char *)src + off, len, hipMemcpyDeviceToHost,
+                                   ctx->stream));
+        PZ_HIP(ctx, hipEventRecord(ctx->stage_ev[c & 1], ctx->stream));
+        return 0;
+    };
+    PZ_TRY(issue(0));
+    for (size_t c = 0; c < n; ++c) {
+        if (c + 1 < n) PZ_TRY(issue(c + 1));               // the other half, already drained
+        PZ_HIP(ctx, hipEventSynchronize(ctx->stage_ev[c & 1]));
+        const size_t off = c * half, len = bytes - off < half ? bytes - off : half;
+        memcpy((char *)dst + off, ctx->stage + (c & 1) * half, len);
+    }
     return 0;
 }
 int picaso_memcpy_d2d(picaso_ctx *ctx, void *dst, const void *src, size_t bytes)

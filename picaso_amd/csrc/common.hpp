@@ -28,6 +28,12 @@ struct picaso_ctx {
     hipEvent_t ring_ev[NSLOT] = {};
     bool ring_pending[NSLOT] = {};
     int ring_next = 0;
+    // pinned bounce buffer (two halves) for host<->device copies of small and medium arrays, so the
+    // caller's pageable memory is never pinned by the runtime (see picaso_memcpy_h2d)
+    static constexpr size_t STAGE_BYTES = 8u << 20;
+    static constexpr size_t STAGE_MAX_COPY = 64u << 20;
+    char *stage = nullptr;
+    hipEvent_t stage_ev[2] = {};
     // per-layer sweep state of the level-flux (two-sweep) kernels: 4 planes (nlayer, ncol)
     double *lvl_scratch = nullptr;
     size_t lvl_scratch_bytes = 0;

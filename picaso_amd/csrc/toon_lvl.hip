@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256) void k_reflected_lvl(const ReflectedLvlArgs A)
 
 int launch_reflected_lvl(picaso_ctx *ctx, const ReflectedLvlArgs &a)
 {
-    const int block = 256;
+    const int block = a.base.ncol <= 64L * 256 ? 64 : 256;   // see launch_thermal_lvl
     const long grid = (a.base.ncol + block - 1) / block;
     hipLaunchKernelGGL(k_reflected_lvl, dim3((unsigned)grid), dim3(block), 0, ctx->stream, a);
     PZ_HIP(ctx, hipGetLastError());
@@ -188,7 +188,7 @@ __device__ __forceinline__ ThermLayer therm_layer_coeffs(const ThermalArgs &a, l
     return r;
 }
 
-__global__ __launch_bounds__(256) void k_thermal_lvl(const ThermalLvlArgs A)
+__global__ __launch_bounds__(256) void k_thermal_lvl_solve(const ThermalLvlArgs A)
 {
     const ThermalArgs &a = A.base;
     const long w = blockIdx.x * (long)blockDim.x + threadIdx.x;     // column (wavelength x Gauss point)
@@ -264,14 +264,34 @@ __global__ __launch_bounds__(256) void k_thermal_lvl(const ThermalLvlArgs A)
         s_del[(long)i * nw] = neg;
         pos = pos_up;
     }
+}
 
-    // ---- per angle: Toon Table-3 source-function sweeps (fluxes.py:1864-1910) ----
-    for (int k = 0; k < A.nang; ++k) {
-        const double mu = A.u1_dev[k], imu = 1.0 / mu, nlh = 0.5 * NEG_LOG2E * imu;   // exp(-x/(2 mu)) = 2^(x nlh)
-        double *fm = A.fm + ((long)k * nlevel) * nw + w, *fp = A.fp + ((long)k * nlevel) * nw + w,
-               *fmm = A.fmm + ((long)k * nlevel) * nw + w, *fpm = A.fpm + ((long)k * nlevel) * nw + w;
-        // downward
-        double Bcur = s_B[0];
+// Per angle and direction (blockIdx.y = angle, blockIdx.z = 0 downward / 1 upward): Toon Table-3
+// source-function sweeps (fluxes.py:1864-1910) on the two-stream solution k_thermal_lvl_solve left
+// in the scratch planes (pos, neg per layer; Planck function per level).  Angles and directions are
+// independent, so a correlated-k climate grid of a few thousand columns still fills the chip.
+__global__ __launch_bounds__(256) void k_thermal_lvl_angle(const ThermalLvlArgs A)
+{
+    const ThermalArgs &a = A.base;
+    const long w = blockIdx.x * (long)blockDim.x + threadIdx.x;     // column (wavelength x Gauss point)
+    if (w >= a.ncol) return;
+    const long wv = (a.ncolper > 1) ? w / a.ncolper : w;
+    const int n = a.nlayer, nlevel = n + 1;
+    const long pitch = a.pitch, nw = a.ncol;
+    const double mu1 = 0.5;
+    const double rs = a.surf_reflect[wv];
+    Exp2Coef K;
+    K.load();
+    const double *s_rho = A.scratch + w, *s_del = s_rho + (long)n * nw, *s_B = s_del + 3 * (long)n * nw;
+    const int k = blockIdx.y;
+    const bool upward = blockIdx.z == 1;
+    const double mu = A.u1_dev[k], imu = 1.0 / mu, nlh = 0.5 * NEG_LOG2E * imu;   // exp(-x/(2 mu)) = 2^(x nlh)
+    double *fm = A.fm + ((long)k * nlevel) * nw + w, *fp = A.fp + ((long)k * nlevel) * nw + w,
+           *fmm = A.fmm + ((long)k * nlevel) * nw + w, *fpm = A.fpm + ((long)k * nlevel) * nw + w;
+    if (!upward) {
+        const double B_top = s_B[0];
+        const double tau_top = a.dtau[w] * a.plevel[0] / (a.plevel[1] - a.plevel[0]);   // fluxes.py:1797
+        double Bcur = B_top;
         double Fm = (1 - fexpk(-tau_top * imu, K)) * B_top * 2 * PI;                 // :1875
         fm[0] = Fm;
         for (int i = 0; i < n; ++i) {
@@ -294,40 +314,46 @@ __global__ __launch_bounds__(256) void k_thermal_lvl(const ThermalLvlArgs A)
             fm[(long)(i + 1) * nw] = Fm;
         }
         fmm[(long)n * nw] = 0.0;
-        // upward
-        const double Bb = Bcur;
-        double Fp = a.hard_surface ? (1.0 - rs) * Bb * 2 * PI : (Bb + b1_last * mu) * 2 * PI;  // :1871-1873
-        fp[(long)n * nw] = Fp;
-        fpm[(long)n * nw] = 0.0;
-        double Bnext = Bb;
-        for (int i = n - 1; i >= 0; --i) {
-            const double B0 = s_B[(long)i * nw];
-            const long off = (long)i * pitch + w;
-            const ThermLayer r = therm_layer_coeffs(a, off, B0, Bnext, K);
-            Bnext = B0;
-            const double dt = a.dtau[off];
-            const double P = s_rho[(long)i * nw], N = s_del[(long)i * nw];
-            const double G = (1.0 / mu1 - r.lam) * P, H = r.gam * (r.lam + 1.0 / mu1) * N;    // :1842-1843
-            const double al1 = 2 * PI * (r.B0 + r.b1 * (r.s - mu1)), al2 = 2 * PI * r.b1;     // :1846-1847
-            const double eam = fexp2(dt * nlh, K), ea = eam * eam;
-            const double EPm = r.EPm, EMm = r.EMm;
-            const double lp1 = r.lam * mu + 1.0, lm1 = r.lam * mu - 1.0, r2 = frcp(lp1 * lm1);
-            const double lup = r2 * lm1, lum = r2 * lp1;
-            fpm[(long)i * nw] = (Fp * eam + (G * lum) * (r.EP * eam - EPm) - (H * lup) * (r.EM * eam - EMm) +
-                                 al1 * (1. - eam) + al2 * (mu + 0.5 * dt - (dt + mu) * eam)); // :1903-1907
-            Fp = (Fp * ea + (G * lum) * (r.EP * ea - 1.0) + (H * lup) * (1.0 - r.EM * ea) + al1 * (1. - ea) +
-                  al2 * (mu - (dt + mu) * ea));                                                // :1897-1901
-            fp[(long)i * nw] = Fp;
-        }
-        A.flux[(long)k * nw + w] = fpm[0];                                                     // :1910
+        return;
     }
+    const double Bb = s_B[(long)n * nw];
+    // b1 of the bottom layer, formed as therm_layer_coeffs forms it
+    const double b1_last = (Bb - s_B[(long)(n - 1) * nw]) * frcp(a.dtau[(long)(n - 1) * pitch + w]);
+    double Fp = a.hard_surface ? (1.0 - rs) * Bb * 2 * PI : (Bb + b1_last * mu) * 2 * PI;  // :1871-1873
+    fp[(long)n * nw] = Fp;
+    fpm[(long)n * nw] = 0.0;
+    double Bnext = Bb;
+    for (int i = n - 1; i >= 0; --i) {
+        const double B0 = s_B[(long)i * nw];
+        const long off = (long)i * pitch + w;
+        const ThermLayer r = therm_layer_coeffs(a, off, B0, Bnext, K);
+        Bnext = B0;
+        const double dt = a.dtau[off];
+        const double P = s_rho[(long)i * nw], N = s_del[(long)i * nw];
+        const double G = (1.0 / mu1 - r.lam) * P, H = r.gam * (r.lam + 1.0 / mu1) * N;    // :1842-1843
+        const double al1 = 2 * PI * (r.B0 + r.b1 * (r.s - mu1)), al2 = 2 * PI * r.b1;     // :1846-1847
+        const double eam = fexp2(dt * nlh, K), ea = eam * eam;
+        const double EPm = r.EPm, EMm = r.EMm;
+        const double lp1 = r.lam * mu + 1.0, lm1 = r.lam * mu - 1.0, r2 = frcp(lp1 * lm1);
+        const double lup = r2 * lm1, lum = r2 * lp1;
+        fpm[(long)i * nw] = (Fp * eam + (G * lum) * (r.EP * eam - EPm) - (H * lup) * (r.EM * eam - EMm) +
+                             al1 * (1. - eam) + al2 * (mu + 0.5 * dt - (dt + mu) * eam)); // :1903-1907
+        Fp = (Fp * ea + (G * lum) * (r.EP * ea - 1.0) + (H * lup) * (1.0 - r.EM * ea) + al1 * (1. - ea) +
+              al2 * (mu - (dt + mu) * ea));                                                // :1897-1901
+        fp[(long)i * nw] = Fp;
+    }
+    A.flux[(long)k * nw + w] = fpm[0];                                                     // :1910
 }
 
 int launch_thermal_lvl(picaso_ctx *ctx, const ThermalLvlArgs &a)
 {
-    const int block = 256;
+    // one wave per block while the column count is small: the sweeps are latency bound and a
+    // correlated-k climate grid (a few thousand columns) then spreads over as many CUs as it has waves
+    const int block = a.base.ncol <= 64L * 256 ? 64 : 256;
     const long grid = (a.base.ncol + block - 1) / block;
-    hipLaunchKernelGGL(k_thermal_lvl, dim3((unsigned)grid), dim3(block), 0, ctx->stream, a);
+    hipLaunchKernelGGL(k_thermal_lvl_solve, dim3((unsigned)grid), dim3(block), 0, ctx->stream, a);
+    PZ_HIP(ctx, hipGetLastError());
+    hipLaunchKernelGGL(k_thermal_lvl_angle, dim3((unsigned)grid, (unsigned)a.nang, 2u), dim3(block), 0, ctx->stream, a);
     PZ_HIP(ctx, hipGetLastError());
     return 0;
 }
