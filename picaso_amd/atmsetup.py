@@ -144,6 +144,22 @@ class ATMSETUP:
         z = np.zeros(np.shape(tlevel)) + planet.radius
         dz = np.zeros(np.shape(tlevel))
         gravity = np.zeros(np.shape(tlevel))
+        n = len(plevel)
+        if constant_gravity and n > 1 and np.all(np.diff(plevel) > 0):
+            # same arithmetic as the level loops below, element-wise (gravity does not depend on z;
+            # the running sums are sequential like the loops): 64 facets x 91 levels per 3-D spectrum
+            g = planet.gravity
+            iref = int(np.argmax(plevel >= p_reference))
+            scale_h = c.k_b * tlevel / (mmw * g)
+            if iref < n - 1:                                  # inwards from the reference level
+                gravity[iref:n - 1] = g
+                dz[iref:n - 1] = scale_h[iref:n - 1] * np.log(plevel[iref + 1:] / plevel[iref:n - 1])
+                z[iref:] = np.cumsum(np.concatenate(([z[iref]], -dz[iref:n - 1])))
+            if iref >= 1:                                     # outwards
+                gravity[1:iref + 1] = g
+                dz[1:iref + 1] = scale_h[1:iref + 1] * np.log(plevel[1:iref + 1] / plevel[0:iref])
+                z[iref::-1] = np.cumsum(np.concatenate(([z[iref]], dz[iref:0:-1])))
+            return self._finish_altitude(z, dz, gravity, lambda i: g, tlevel, mmw)
 
         def g_at(i):
             return planet.gravity if constant_gravity else c.G * planet.mass / z[i] ** 2
@@ -157,12 +173,15 @@ class ATMSETUP:
             gravity[i] = g_at(i)
             dz[i] = c.k_b * tlevel[i] / (mmw[i] * gravity[i]) * np.log(plevel[i] / plevel[i - 1])
             z[i - 1] = z[i] + dz[i]
+        return self._finish_altitude(z, dz, gravity, g_at, tlevel, mmw)
+
+    def _finish_altitude(self, z, dz, gravity, g_at, tlevel, mmw):
         dz[0] = dz[1]
         dz[-1] = dz[-2]
         self.level["z"], self.level["dz"] = z, dz
         self.layer["gravity"] = 0.5 * (gravity[:-1] + gravity[1:])
         gravity[-1], gravity[0] = g_at(-1), g_at(0)
-        self.level["scale_height"] = c.k_b * tlevel / (mmw * gravity)
+        self.level["scale_height"] = self.c.k_b * tlevel / (mmw * gravity)
 
     def get_column_density(self):
         self.layer["colden"] = (self.level["pressure"][1:] - self.level["pressure"][:-1]) / self.layer["gravity"]

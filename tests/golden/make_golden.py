@@ -639,6 +639,9 @@ def make_altitude():
         r_and_m=dict(nlevel=31, radius=7.1e9, mass=1.9e30, gravity=2516.0, p_reference=10.0, plo=-6, phi=2),
         pref_deep=dict(nlevel=9, radius=6.4e8, mass=6.0e27, gravity=978.0, p_reference=1e4, plo=-4, phi=1),
         pref_top=dict(nlevel=7, radius=2.5e9, mass=1.0e29, gravity=1068.0, p_reference=1e-9, plo=-3, phi=1),
+        const_g_deep=dict(nlevel=10, radius=np.nan, mass=np.nan, gravity=1500.0, p_reference=1e4, plo=-4, phi=1),
+        const_g_top=dict(nlevel=6, radius=np.nan, mass=np.nan, gravity=900.0, p_reference=1e-9, plo=-3, phi=1),
+        const_g_two=dict(nlevel=2, radius=np.nan, mass=np.nan, gravity=900.0, p_reference=1.0, plo=-1, phi=1),
     )
     rng = np.random.default_rng(5)
     for name, cs in cases.items():

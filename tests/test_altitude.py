@@ -45,3 +45,32 @@ def test_molecular_weights_match_reference():
         else:
             assert molecular_weight(str(name)) == pytest.approx(float(want), rel=1e-15), name
     assert molecular_weight("H2") == pytest.approx(2.0156500642, rel=1e-15)
+
+
+def test_constant_gravity_with_radius_matches_level_loop():
+    """The element-wise constant-gravity path against the level-by-level recurrence it replaces
+    (z stays finite when a radius is given and constant_gravity=True is asked for)."""
+    rng = np.random.default_rng(0)
+    n = 23
+    p = np.logspace(-5, 2, n) * 1e6
+    t = 200.0 + 900.0 * rng.random(n)
+    w = 2.2 + 0.2 * rng.random(n)
+    g, k_b, amu, r0 = 1234.0, 1.380649e-16, 1.66053906660e-24, 7.0e9
+    for pref_bar in (1e-9, 1.0, 1e4):
+        atm = ATMSETUP({})
+        atm.planet.radius, atm.planet.mass, atm.planet.gravity = r0, 1.9e30, g
+        atm.level.update(mmw=w, temperature=t, pressure=p)
+        atm.c.nlevel, atm.c.nlayer = n, n - 1
+        atm.get_altitude(p_reference=pref_bar, constant_gravity=True)
+        pref = min(pref_bar * 1e6, p.max())
+        iref = int(np.argmax(p >= pref))
+        z, dz = np.zeros(n) + r0, np.zeros(n)
+        for i in range(iref, n - 1):
+            dz[i] = k_b * t[i] / (w[i] * amu * g) * np.log(p[i + 1] / p[i])
+            z[i + 1] = z[i] - dz[i]
+        for i in range(iref, 0, -1):
+            dz[i] = k_b * t[i] / (w[i] * amu * g) * np.log(p[i] / p[i - 1])
+            z[i - 1] = z[i] + dz[i]
+        dz[0], dz[-1] = dz[1], dz[-2]
+        assert np.array_equal(atm.level["z"], z) and np.array_equal(atm.level["dz"], dz), pref_bar
+        assert np.all(np.diff(atm.level["z"]) < 0)
