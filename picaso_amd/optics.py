@@ -83,6 +83,8 @@ class RetrieveOpacities:
         # ---- HBM-resident tables ----
         ptid = [x[0] for x in self.pt_pairs]
         self._row_of_ptid = {pid: r for r, pid in enumerate(ptid)}
+        self._row_lut = np.full(int(max(ptid)) + 1, -1, dtype=np.int64)      # ptid -> table row
+        self._row_lut[np.asarray(ptid, dtype=np.int64)] = np.arange(len(ptid))
         self._mol_raw, self._mol_log = {}, {}
         for m in self.molecules:
             tab = np.stack([f64(molecular[m][pid]) for pid in ptid])          # (npt, nwno)
@@ -177,7 +179,12 @@ class RetrieveOpacities:
             r4 = np.stack([i_ll, i_hl, i_hh, i_lh], axis=1)
             w4 = np.stack([(1 - t_i) * (1 - p_i), t_i * (1 - p_i), t_i * p_i, (1 - t_i) * p_i], axis=1)
             # the reference addresses rows by ptid = 1 + index; tables are stored in ptid order
-            rows[:] = np.array([[self._row_of_ptid[1 + int(x)] for x in r] for r in r4])[None]
+            ids = 1 + r4
+            lut = self._row_lut[np.minimum(ids, len(self._row_lut) - 1)]
+            missing = (ids >= len(self._row_lut)) | (lut < 0)
+            if missing.any():
+                raise KeyError("opacity table has no row for ptid %d" % int(ids[missing][0]))
+            rows[:] = lut[None]
             wts[:] = w4[None]
             atmosphere.layer["pt_opa_index"] = 1 + np.unique(r4)
         else:                                               # optics.py:2330-2332
