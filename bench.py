@@ -93,8 +93,11 @@ def main():
     xint = device.DeviceArray((ng, 1, nwno), ctx)
     use_nccl = launched and args.backend == "nccl"
     if use_nccl:
-        alb_t = torch.empty(nwno, dtype=torch.float64, device="cuda")
-        full_t = torch.empty(world * nwno, dtype=torch.float64, device="cuda")
+        # two result buffers: the gather of one spectrum overlaps the solve of the next
+        alb_tt = [torch.empty(nwno, dtype=torch.float64, device="cuda") for _ in range(2)]
+        full_tt = [torch.empty(world * nwno, dtype=torch.float64, device="cuda") for _ in range(2)]
+        pending = [None, None]
+        alb_t, full_t = alb_tt[0], full_tt[0]
         albedo = alb_t.data_ptr()
     else:
         alb_d = device.DeviceArray((nwno,), ctx)
@@ -102,17 +105,36 @@ def main():
         if launched:
             full_t = torch.empty(world * nwno, dtype=torch.float64)
 
+    nstep = [0]
+
     def step():
+        if use_nccl:
+            # The library's stream is torch's current stream (ExternalStream below).  The gather of
+            # spectrum i runs on RCCL's own stream after the kernel that produced it (async_op: the
+            # compute stream does not wait for it), so it overlaps the solve of spectrum i+1, which
+            # writes the other result buffer; a buffer is reused only after its previous gather has
+            # finished -- a device-side wait, no host synchronisation inside the timed loop.
+            b = nstep[0] & 1
+            nstep[0] += 1
+            if pending[b] is not None:
+                pending[b].wait()
+            resident.reflected_1d(ctx, nlevel, nwno, ng, 1, d, d["surf_reflect"], ubar0, ubar1,
+                                  cos_theta, d["F0PI"], 3, 0, *TTHG, xint, toon_coefficients=0,
+                                  b_top=0.0, gweight=gw, tweight=tw, albedo=alb_tt[b].data_ptr())
+            pending[b] = dist.all_gather_into_tensor(full_tt[b], alb_tt[b], async_op=True)   # RCCL over xGMI
+            return
         resident.reflected_1d(ctx, nlevel, nwno, ng, 1, d, d["surf_reflect"], ubar0, ubar1,
                               cos_theta, d["F0PI"], 3, 0, *TTHG, xint, toon_coefficients=0,
                               b_top=0.0, gweight=gw, tweight=tw, albedo=albedo)
-        if use_nccl:
-            # The library's stream is torch's current stream (ExternalStream below), so RCCL orders the
-            # gather after the kernel and the next step's kernel after the gather on the device: no
-            # host synchronisation inside the timed loop.
-            dist.all_gather_into_tensor(full_t, alb_t)        # RCCL over xGMI: the final spectrum
-        elif launched:                                        # gloo smoke path: gather on the host
+        if launched:                                          # gloo smoke path: gather on the host
             dist.all_gather_into_tensor(full_t, torch.from_numpy(alb_d.to_host()))
+
+    def drain():
+        if use_nccl:
+            for k in range(2):
+                if pending[k] is not None:
+                    pending[k].wait()
+                    pending[k] = None
 
     def barrier():
         device.sync(ctx)
@@ -130,13 +152,15 @@ def main():
     with on_lib_stream:
         for _ in range(args.warmup):
             step()
+        drain()
         barrier()
         device.timer_start(ctx)
         t0 = time.perf_counter()
         for _ in range(args.steps):
             step()
         kernel_ms_total = device.timer_stop(ctx)              # HIP events on the kernel's stream
-        barrier()
+        drain()                                               # every spectrum gathered ...
+        barrier()                                             # ... and every rank done
         elapsed = time.perf_counter() - t0
     if launched:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if use_nccl else "cpu")
@@ -146,6 +170,9 @@ def main():
     # ---- parity + CPU baseline on rank 0 (outside the timed region) ----
     out = None
     if rank == 0:
+        if use_nccl:
+            last = (nstep[0] - 1) & 1
+            alb_t, full_t = alb_tt[last], full_tt[last]
         alb_gpu = alb_t.cpu().numpy() if use_nccl else alb_d.to_host()
         if launched:    # the gathered spectrum must contain this rank's shard bit-exactly
             assert np.array_equal(full_t[:nwno].cpu().numpy(), alb_gpu), "all-gather mismatch"
