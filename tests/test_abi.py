@@ -63,3 +63,40 @@ def test_loads_after_torch_import():
             "assert all(hasattr(h, n) for n in _lib.declared_symbols()); print('ok')" % ROOT)
     p = subprocess.run([sys.executable, "-c", code], capture_output=True, timeout=600)
     assert p.returncode == 0 and b"ok" in p.stdout, p.stderr.decode()[-2000:]
+
+
+def _no_gpu_here():
+    from picaso_amd import _lib
+    return _lib.device_count() == 0
+
+
+def test_product_path_fails_loudly_without_a_gpu():
+    """No CPU fallback: on a machine without a HIP device every product entry point raises."""
+    import numpy as np
+    import pytest
+    if not _no_gpu_here():
+        pytest.skip("a GPU is visible here")
+    from picaso_amd import climate, fluxes, synthetic as syn
+    from picaso_amd._lib import PicasoHipError
+    sc = syn.make_scene(5, 8, seed=1)
+    with pytest.raises(PicasoHipError, match="no HIP device|GPU"):
+        fluxes.get_thermal_1d(6, sc["wno"], 8, 5, 1, sc["tlevel"], sc["dtau_og"], sc["w0_no_raman"], sc["cosb_og"],
+                              sc["plevel"], np.full((5, 1), 0.5), 0.0, 0, sc["wno"] * 0, 0)
+    with pytest.raises(PicasoHipError):
+        fluxes.get_transit_1d(np.linspace(2, 1, 6), np.ones(6), 6, 8, 1.0, np.ones(5), 1.0, 1.0, np.ones(6), np.ones(6),
+                              np.ones(5), sc["dtau_og"])
+    atm = climate.Atmosphere_Tuple(None, None, 6, sc["tlevel"], sc["plevel"], None, None, None, None)
+    with pytest.raises(PicasoHipError):
+        climate.get_fluxes(atm, None, None, climate.ScatteringPhase_Tuple(0.0, 3, 0, 1, -1, 2, -.5, 1),
+                           climate.Disco_Tuple(5, 1, np.ones(5), np.ones(1), None, None, 1.0),
+                           climate.Opagrid_Tuple(8, np.ones(8), sc["wno"], 1, np.ones(1)), 1.0, True, True)
+
+
+def test_missing_library_is_a_clear_error(monkeypatch):
+    """Without libpicaso_hip.so the loader says how to build it and that nothing else will run."""
+    import pytest
+    from picaso_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libpicaso_hip.so")
+    with pytest.raises(_lib.PicasoHipError, match="no CPU fallback"):
+        _lib.load()
