@@ -9,7 +9,8 @@
 //   stable rank sort across the wave (LDS broadcast of the keys, ties by lane = np.argsort 'mergesort'),
 //   keys and weights moved to their sorted lanes with ds_permute,
 //   prefix sum of the sorted weights (wave scan), x = cum / cum[last],
-//   np.interp(gauss_pts, x, log10(key)) -> 10** -> the Nk coefficients of the mixture (:586-590),
+//   np.interp(gauss_pts, x, log k) -> k (base 2 here, base 10 in the reference: the base cancels in a
+//   linear interpolation) -> the Nk coefficients of the mixture (:586-590),
 // everything in registers apart from the 512-byte key row each wave broadcasts from LDS.  HBM traffic
 // is the table rows read (ngas * Nk doubles per bin) and Nk doubles written: the kernel is
 // VALU/cross-lane bound.
@@ -46,14 +47,35 @@ __device__ __forceinline__ double permute_to_d(double v, int dst)
     return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 
-// 10^r as 2^(r log2 10) with the product carried in two terms (hi + lo), so the result keeps the
-// ~1 ulp of fexp2 for |r| up to the ~50 of log10(kappa)
-__device__ __forceinline__ double fexp10(double r)
+// log2(x) for x > 0, ~1 ulp of the result, ~37 instructions (ocml's log10 takes 118): x = m 2^e with
+// m in [sqrt(1/2), sqrt(2)), log2 m = (2/ln 2) atanh(s), s = (m - 1)/(m + 1), |s| <= 0.172, odd series
+// to s^21 (next term < 3e-18 relative).  The rebinning interpolates linearly in log k, so the base of
+// the logarithm cancels: interpolating log2 k and returning 2^r is the reference's
+// 10**np.interp(., ., log10 k) up to the rounding of the logarithms themselves.
+__device__ __forceinline__ double flog2(double x)
 {
-    constexpr double L_HI = 0x1.a934f0979a371p+1, L_LO = 0x1.7f2495fb7fa6dp-53;   // log2(10)
-    const double th = r * L_HI;
-    const double tl = fma(r, L_HI, -th) + r * L_LO;
-    return fexp2(th) * fma(tl, 0x1.62e42fefa39efp-1, 1.0);
+    int e;
+    double m = frexp(x, &e);                                   // m in [1/2, 1)
+    const bool low = m < 0x1.6a09e667f3bcdp-1;
+    m = low ? m + m : m;
+    e = low ? e - 1 : e;
+    const double s = (m - 1.0) * frcp(m + 1.0);
+    const double t = s * s;
+    double q = fma(t, 1.0 / 21.0, 1.0 / 19.0);
+    q = fma(q, t, 1.0 / 17.0);
+    q = fma(q, t, 1.0 / 15.0);
+    q = fma(q, t, 1.0 / 13.0);
+    q = fma(q, t, 1.0 / 11.0);
+    q = fma(q, t, 1.0 / 9.0);
+    q = fma(q, t, 1.0 / 7.0);
+    q = fma(q, t, 1.0 / 5.0);
+    q = fma(q, t, 1.0 / 3.0);
+    constexpr double C_HI = 0x1.71547652b82fep+1, C_LO = 0x1.777d0ffda0d24p-55;   // 2/ln 2
+    const double cs = C_HI * s;
+    const double lo = fma(C_HI, s, -cs) + C_LO * s;
+    const double l = cs + fma(cs * t, q, lo);
+    const double r = (double)e + l;
+    return x == 0.0 ? -__builtin_inf() : (x == __builtin_inf() ? x : r);
 }
 
 __device__ __forceinline__ double shfl_d(double v, int src_lane)
@@ -79,10 +101,11 @@ __global__ __launch_bounds__(256) void k_ckmix(const CKMixArgs a)
     const int p_ind = a.indices[(ct >> 1) * a.nlayer + il];
     const int t_ind = a.indices[(2 + (ct & 1)) * a.nlayer + il];
     const size_t off = (((size_t)p_ind * a.ntemp + t_ind) * a.nwno + iw) * nk;
-    double wi = 0.0, wj = 0.0;
+    double wi = 0.0, wj = 0.0, gp_own = 0.0;
     for (int n = 0; n < nk; ++n) {                     // by-value tables: uniform index only
         wi = (i == n) ? a.gwts[n] : wi;
         wj = (j == n) ? a.gwts[n] : wj;
+        gp_own = (i == n) ? a.gpts[n] : gp_own;
     }
     const double w_own = valid ? wi * wj : 0.0;        // eq. 10 Amundsen 2017 (:572)
     double *row = s_key[wv];
@@ -118,33 +141,35 @@ __global__ __launch_bounds__(256) void k_ckmix(const CKMixArgs a)
             cum = (lane >= o) ? cum + up : cum;
         }
         const double x = cum / readlane_d(cum, n2 - 1);       // np.max of an increasing sum (:582)
-        const double f = log10(ks);
+        const double f = flog2(ks);
         // np.interp(gauss_pts, x, f) (:586): slope of the segment [lane, lane+1] once per lane
         const int nb = lane + 1 < n2 ? lane + 1 : lane;
         const double x1 = shfl_d(x, nb), f1 = shfl_d(f, nb);
         const double slope = (f1 - f) / (x1 - x);
-        const double x_last = readlane_d(x, n2 - 1), f_first = readlane_d(f, 0), f_last = readlane_d(f, n2 - 1);
-        double rsel = 0.0;
-        for (int n = 0; n < nk; ++n) {
-            const double gp = a.gpts[n];
-            const int cnt = __popcll(__ballot(valid && x <= gp));
-            double r;
-            if (gp > x_last || cnt >= n2) r = f_last;
-            else if (cnt == 0) r = f_first;
-            else {
-                const int jj = cnt - 1;
-                const double xj = readlane_d(x, jj), fj = readlane_d(f, jj), sj = readlane_d(slope, jj);
-                r = sj * (gp - xj) + fj;
-                if (xj == gp) r = fj;
-                else if (r != r) {                     // numpy's fallbacks for a non-finite slope
-                    const double xj1 = readlane_d(x, jj + 1), fj1 = readlane_d(f, jj + 1);
-                    r = sj * (gp - xj1) + fj1;
-                    if (r != r && fj == fj1) r = fj;
-                }
-            }
-            rsel = (i == n) ? r : rsel;
+        // every lane looks up the segment of its own Gauss point gauss_pts[i] (the lanes of one i
+        // agree): binary search for the last x <= gp over the sorted lanes, 6 ds_bpermute rounds
+        const double x_first = readlane_d(x, 0), x_last = readlane_d(x, n2 - 1);
+        const double f_first = readlane_d(f, 0), f_last = readlane_d(f, n2 - 1);
+        int pos = 0;
+#pragma unroll
+        for (int st = 32; st >= 1; st >>= 1) {
+            const int cand = pos + st;
+            const double xc = shfl_d(x, cand & 63);
+            pos = (cand < n2 && xc <= gp_own) ? cand : pos;
         }
-        k1 = bad ? __builtin_nan("") : fexp10(rsel);
+        const int pos1 = pos + 1 < n2 ? pos + 1 : pos;
+        const double xj = shfl_d(x, pos), fj = shfl_d(f, pos), sj = shfl_d(slope, pos);
+        const double xj1 = shfl_d(x, pos1), fj1 = shfl_d(f, pos1);
+        double rsel = sj * (gp_own - xj) + fj;
+        if (rsel != rsel) {                            // numpy's fallbacks for a non-finite slope
+            rsel = sj * (gp_own - xj1) + fj1;
+            if (rsel != rsel && fj == fj1) rsel = fj;
+        }
+        rsel = (xj == gp_own) ? fj : rsel;
+        rsel = (pos == n2 - 1) ? f_last : rsel;
+        rsel = (gp_own < x_first) ? f_first : rsel;
+        rsel = (gp_own > x_last) ? f_last : rsel;
+        k1 = bad ? __builtin_nan("") : fexp2(rsel);
         mix_t = mt;
     }
     if (valid && j == 0)
