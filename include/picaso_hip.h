@@ -336,7 +336,8 @@ int picaso_opacity_gas_dev(picaso_ctx *ctx, int nlayer, int nwno, int linear, in
  * DTAU, TAU, W0, COSB, ftau_cld, ftau_ray, GCOS2, W0_no_raman, f_deltaM and the delta-Eddington
  * scaled set from the gas / Rayleigh / cloud optical depths.  All arrays are device planes
  * (nlayer, nwno) except tau, tau_og (nlevel, nwno).  `raman_factor` may be NULL (then
- * `raman_const`, 0.99999 for raman='none', is used).  test_mode: 0 off, 1 'rayleigh',
+ * `raman_const`, 0.99999 for raman='none', is used); `taucld`, `w0_cld`, `g0_cld` may be NULL
+ * (cloud-free atmosphere: read as zero planes).  test_mode: 0 off, 1 'rayleigh',
  * 2 constant-tau (optics.py:372-399).  Output order = the reference's return tuple
  * (optics.py:423-431). */
 int picaso_compute_opacity_dev(picaso_ctx *ctx, int nlayer, int nwno, const double *taugas,

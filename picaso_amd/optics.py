@@ -646,8 +646,8 @@ def compute_opacity_resident(atmosphere, opacityclass, ngauss=1, stream=2, delta
     taucld = plane(cld["opd"])
     if do_holes:
         taucld = fthin_cld * taucld                         # optics.py:314-315
-    if getattr(atm, "cloud_free", False):                   # no cloud profile: zero planes, no PCIe
-        d_cld, d_w0, d_g0 = (DeviceArray.zeros((nlayer, nwno), ctx) for _ in range(3))
+    if getattr(atm, "cloud_free", False) and not do_holes:  # no cloud profile: NULL planes read as zero
+        d_cld = d_w0 = d_g0 = None
     else:
         d_cld = DeviceArray.from_host(taucld, ctx)
         d_w0 = DeviceArray.from_host(plane(cld["w0"]), ctx)
@@ -660,8 +660,9 @@ def compute_opacity_resident(atmosphere, opacityclass, ngauss=1, stream=2, delta
         rows = nlayer + 1 if k in ("tau", "tau_og") else nlayer
         out[k] = DeviceArray((rows,) + gshape, ctx)
     check(load().picaso_compute_opacity_ck_dev(
-        ctx, _ci(nlayer), _ci(nwno), _ci(ngauss), ptr(taugas.addr), ptr(tauray.addr), ptr(d_cld.addr),
-        ptr(d_w0.addr), ptr(d_g0.addr), ptr(raman_plane.addr) if raman_plane else None,
+        ctx, _ci(nlayer), _ci(nwno), _ci(ngauss), ptr(taugas.addr), ptr(tauray.addr),
+        *[ptr(x.addr) if x is not None else None for x in (d_cld, d_w0, d_g0)],
+        ptr(raman_plane.addr) if raman_plane else None,
         _cd(raman_const), _ci(tm), _ci(1 if delta_eddington else 0), _ci(stream),
         *[ptr(out[k].addr) for k in OUT_NAMES]), ctx)
     if full_output:
