@@ -83,3 +83,22 @@ def test_gpu_mixing_rejects_bad_arguments():
     with pytest.raises(Exception, match="outside"):
         resident.mix_all_gases_gasesfly(ctx, k, [np.ones(1)] * 2, np.linspace(0.1, 0.9, 4), np.ones(4) / 4,
                                         np.array([[0], [2], [0], [1]]))
+
+
+@pytest.mark.gpu
+def test_gpu_mixing_reference_signature(gold):
+    """picaso_amd.deq_chem.mix_all_gases_gasesfly: numpy in, the reference's array layout out; the
+    device copies of the tables are reused until their content changes."""
+    from picaso_amd import deq_chem
+    deq_chem.clear_table_cache()
+    args = _case(gold, "g8")
+    out = deq_chem.mix_all_gases_gasesfly(*args)
+    want = gold["g8/kappa_mixed"]
+    assert out.shape == want.shape and np.max(np.abs(out - want)) < 1e-11
+    n_cached = len(deq_chem._tables)
+    assert n_cached == len(args[0])
+    out2 = deq_chem.mix_all_gases_gasesfly(*args)
+    assert np.array_equal(out, out2) and len(deq_chem._tables) == n_cached
+    args[0][1][...] = args[0][1] + 0.5               # same buffer, new content: re-uploaded
+    out3 = deq_chem.mix_all_gases_gasesfly(*args)
+    assert not np.array_equal(out, out3)
