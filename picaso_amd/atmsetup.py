@@ -125,6 +125,11 @@ class ATMSETUP:
     def get_density(self):
         self.level["den"] = self.level["pressure"] / (self.c.k_b * self.level["temperature"])
 
+    def get_dtdp(self):
+        """d ln T / d ln P per layer (reference atmsetup.py:371-383)."""
+        self.layer["dtdp"] = (np.diff(np.log(self.level["temperature"])) /
+                              np.diff(np.log(self.level["pressure"])))
+
     def get_altitude(self, p_reference=1, constant_gravity=False):
         """Level altitude ``z``, thickness ``dz`` and gravity by hydrostatic integration outwards
         from the reference pressure (reference atmsetup.py:384-461).  Without a planet radius the

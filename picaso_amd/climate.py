@@ -32,6 +32,52 @@ Disco_Tuple = namedtuple("Disco_Tuple", ["ng", "nt", "gweight", "tweight", "ubar
 Opagrid_Tuple = namedtuple("Opagrid_Tuple", ["nwno", "delta_wno", "wno", "ngauss", "gauss_wts"])
 
 
+def calculate_atm(bundle, opacityclass, only_atmosphere=False):
+    """Atmosphere set-up and opacities of one climate iteration (reference ``climate.calculate_atm``,
+    climate.py:1969-2135): returns ``OpacityWEd, OpacityNoEd, ScatteringPhase, Disco, Atmosphere,
+    (OpacityWEd_hole, OpacityNoEd_hole)`` with the reference's namedtuples.  The opacity planes are
+    HBM-resident ``DeviceArray`` objects ``(nlayer|nlevel, nwno, ngauss)`` -- ``get_fluxes`` takes them as
+    they are (``.to_host()`` gives the reference's numpy arrays)."""
+    from . import justdoit, optics
+    inputs = bundle.inputs
+    opa = opacityclass
+    common = inputs["approx"]["rt_params"]["common"]
+    toon = inputs["approx"]["rt_params"]["toon"]
+    frac_a, frac_b, frac_c = common["TTHG_params"]["fraction"]
+    geom = inputs["disco"]
+    do_holes = bool(inputs["clouds"].get("do_holes", False))
+    atm = justdoit._setup_atmosphere(inputs, opa, opa.wno)
+    atm.surf_reflect = 0                                   # climate.py:2052
+    atm.get_dtdp()
+    prof = inputs["atmosphere"]["profile"]
+    ours = [m for m in ("H2O", "CH4", "NH3", "Fe") if m in prof.keys()]                  # :2090-2093
+    Atmosphere = Atmosphere_Tuple(atm.layer["dtdp"], atm.layer["mmw"], atm.c.nlevel,
+                                  np.ascontiguousarray(atm.level["temperature"]).copy(),
+                                  np.ascontiguousarray(atm.level["pressure_bar"]).copy(), ours,
+                                  np.array([np.asarray(prof[m], dtype=float) for m in ours]),
+                                  [atm.weights[m] for m in ours], atm.level["scale_height"])
+    if only_atmosphere:
+        return Atmosphere
+    opa.get_opacities(atm)
+    kw = dict(ngauss=opa.ngauss, stream=common["stream"], delta_eddington=common["delta_eddington"],
+              test_mode=inputs["test_mode"], raman=common["raman"])
+
+    def tuples(pl):
+        return (OpacityWEd_Tuple(pl["dtau"], pl["tau"], pl["w0"], pl["cosb"], pl["ftau_cld"], pl["ftau_ray"],
+                                 pl["gcos2"], pl["w0_no_raman"], pl["f_deltaM"]),
+                OpacityNoEd_Tuple(pl["dtau_og"], pl["tau_og"], pl["w0_og"], pl["cosb_og"]))
+    holes = (None, None)
+    if do_holes:                                           # :2104-2112
+        holes = tuples(optics.compute_opacity_resident(atm, opa, fthin_cld=inputs["clouds"]["fthin_cld"],
+                                                       do_holes=True, **kw))
+    wed, noed = tuples(optics.compute_opacity_resident(atm, opa, **kw))
+    sp = ScatteringPhase_Tuple(atm.surf_reflect, toon["single_phase"], toon["multi_phase"], frac_a, frac_b, frac_c,
+                               common["TTHG_params"]["constant_back"], common["TTHG_params"]["constant_forward"])
+    dis = Disco_Tuple(geom["num_gangle"], geom["num_tangle"], geom["gweight"], geom["tweight"], geom["ubar0"],
+                      geom["ubar1"], geom["cos_theta"])
+    return wed, noed, sp, dis, Atmosphere, holes
+
+
 def _planes(wed, noed, ctx, thermal_only=False):
     """Upload the (rows, nwno, ngauss) arrays of one opacity set (DeviceArrays pass through)."""
     def up(x):

@@ -89,3 +89,39 @@ def test_gpu_get_fluxes_single_legs(gold):
     for k in range(4):
         assert np.array_equal(r[k], full[k]) and not np.any(t[k])
         assert np.array_equal(t[4 + k], full[4 + k]) and not np.any(r[4 + k])
+
+
+@pytest.mark.gpu
+def test_gpu_calculate_atm_feeds_get_fluxes(oracle):
+    """climate.calculate_atm (resident planes) -> climate.get_fluxes, on a 4-point correlated-k table:
+    planes against the reference's compute_opacity(ngauss=4) fixture, fluxes against the oracle's
+    get_fluxes on those reference planes."""
+    import test_ck_optics as tck
+    from oracle import climate_oracle as co
+    from picaso_amd import climate as pc
+    from picaso_amd import justdoit as jdi
+    ck = np.load(os.path.join(GOLDEN, "ck.npz"))
+    og = np.load(os.path.join(GOLDEN, "optics.npz"))
+    opa = tck._ck_class(ck)
+    case = tck._case(og, jdi, True)
+    wed, noed, sp, dis, atm_t, holes = pc.calculate_atm(case, opa)
+    assert holes == (None, None) and sp.surf_reflect == 0 and atm_t.nlevel == len(og["in/tlevel"])
+    ref = {nm: ck["de1_s2/" + nm] for nm in tck.NAMES}
+    for got, nm in ((wed.DTAU, "dtau"), (wed.TAU, "tau"), (wed.W0, "w0"), (wed.COSB, "cosb"), (wed.GCOS2, "gcos2"),
+                    (wed.W0_no_raman, "w0_no_raman"), (noed.DTAU, "dtau_og"), (noed.TAU, "tau_og")):
+        assert tck._close(got.to_host(), ref[nm], 1e-9), nm
+    assert np.allclose(atm_t.dtdp, np.diff(np.log(og["in/tlevel"])) / np.diff(np.log(og["in/plevel_bar"])))
+    only = pc.calculate_atm(case, opa, only_atmosphere=True)
+    assert np.array_equal(only.t_level, atm_t.t_level) and only.condensables == ["H2O", "CH4"]
+    nwno, ngauss = opa.nwno, opa.ngauss
+    grid = pc.Opagrid_Tuple(nwno, np.abs(np.gradient(opa.wno)), opa.wno, ngauss, ck["in/gauss_wts"])
+    out = pc.get_fluxes(atm_t, wed, noed, sp, dis, grid, np.ones(nwno), True, True)
+    wed_h = pc.OpacityWEd_Tuple(ref["dtau"], ref["tau"], ref["w0"], ref["cosb"], ref["ftau_cld"], ref["ftau_ray"],
+                                ref["gcos2"], ref["w0_no_raman"], None)
+    noed_h = pc.OpacityNoEd_Tuple(ref["dtau_og"], ref["tau_og"], ref["w0_og"], ref["cosb_og"])
+    want = co.get_fluxes(atm_t, wed_h, noed_h, sp, dis, grid, np.ones(nwno), True, True)
+    # visible nets tight; the thermal nets of this scene's optically thick Gauss points carry the
+    # reference formulation's own cancellation noise at the deep levels (tests/test_ck_gpu.py, DESIGN.md 3)
+    for name, a, b in zip(OUT, out, want):
+        if name.startswith("flux_net"):
+            assert rel_err(a, b, 1e-4 * np.abs(b).max()) < (1e-4 if name.endswith("_ir") or "ir_" in name else 1e-7), name
