@@ -1,0 +1,113 @@
+"""Randomised differential test: the HIP library against the CPU oracle over seeded random
+combinations of sizes (including ragged last blocks and one or two layers), geometry (1-D Gauss
+tables, ng x nt grids at a phase angle), phase-function / coefficient options, delta-Eddington,
+surface reflectivity, stellar flux and cloud structure.  Small scenes, so the oracle takes
+milliseconds; the point is coverage of option combinations and wave-uniform fast paths
+(cloud-free layers, cumulative-tau planes, symmetric geometry) that the fixtures hit only singly.
+Entries below 1e-4 of a field's maximum (limb facets, where exp(-tau/mu) all but vanishes) are judged
+against that scale: they carry the rounding of O(max) terms in the reference as well."""
+import numpy as np
+import pytest
+
+from helpers import PLANES, lvl_err, rel_err
+
+TTHG = (1.0, -1.0, 2.0, -0.5, 1.0)
+
+
+def _geometry(rng):
+    from picaso_amd import disco
+    if rng.random() < 0.5:
+        ng = int(rng.choice([5, 6, 7, 8]))
+        g, gw, t, tw = disco.get_angles_1d(ng)
+        u0, u1, ct, _, _ = disco.compute_disco(ng, 1, g, t, 0.0)
+        return ng, 1, gw, tw, u0, u1, 1.0
+    ng, nt = int(rng.integers(2, 6)), int(rng.integers(2, 5))
+    g, gw, t, tw = disco.get_angles_3d(ng, nt)
+    u0, u1, ct, _, _ = disco.compute_disco(ng, nt, g, t, float(rng.choice([0.0, 0.4, 1.1, 2.0])))
+    return ng, nt, gw, tw, u0, u1, ct
+
+
+def _scene(rng, seed):
+    from picaso_amd import synthetic as syn
+    nlayer = int(rng.choice([1, 2, 3, 7, 19, 40]))
+    nwno = int(rng.choice([1, 5, 63, 64, 65, 130, 257]))
+    kind = rng.integers(0, 4)
+    kw = dict(seed=int(seed), delta_eddington=bool(rng.integers(0, 2)))
+    if kind == 0:
+        kw.update(cloud=False)
+    elif kind == 1:
+        kw.update(cloud_opd=float(10.0 ** rng.uniform(-2, 1.5)))
+    elif kind == 2:
+        kw.update(gas_scale=float(10.0 ** rng.uniform(-3, 2)), ray_scale=float(10.0 ** rng.uniform(-1, 1)))
+    return syn.make_scene(nlayer, nwno, **kw), nlayer, nwno
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("block", range(6))
+def test_fuzz_reflected(oracle, block):
+    from picaso_amd import fluxes
+    rng = np.random.default_rng(1000 + block)
+    for it in range(20):
+        sc, nlayer, nwno = _scene(rng, 50 * block + it)
+        ng, nt, gw, tw, u0, u1, ct = _geometry(rng)
+        sp, mp, tc = int(rng.integers(0, 4)), int(rng.integers(0, 2)), int(rng.integers(0, 2))
+        lvl = int(rng.integers(0, 2))
+        rs = float(rng.choice([0.0, 0.3, 1.0])) if rng.random() < 0.7 else rng.random(nwno)
+        f0 = np.ones(nwno) if rng.random() < 0.5 else 0.2 + rng.random(nwno)
+        b_top = float(rng.choice([0.0, 0.0, 0.5]))
+        args = (nlayer + 1, sc["wno"], nwno, ng, nt, *[sc[k] for k in PLANES], rs, u0, u1, ct, f0, sp, mp, *TTHG)
+        kw = dict(get_toa_intensity=1, get_lvl_flux=lvl, toon_coefficients=tc, b_top=b_top)
+        xg, lg = fluxes.get_reflected_1d(*args, **kw)
+        xo, lo = oracle.get_reflected_1d(*args, **kw)
+        tag = (block, it, nlayer, nwno, ng, nt, sp, mp, tc, lvl)
+        assert rel_err(xg, xo, 1e-4 * np.abs(xo).max()) < 1e-8, tag
+        if lvl:
+            # contract tolerance: with single layers of optical depth 50-2000 (these random scenes have
+            # them) the reference's level-flux expressions combine exp(+35)-sized terms and the upward
+            # flux differs by up to 2e-7 of the field scale between formulations (median 8e-11)
+            assert lvl_err(lg, lo) < 1e-6, tag
+        ag = oracle.compress_disco(nwno, ct, xo, gw, tw, f0)
+        from picaso_amd import disco
+        assert rel_err(disco.compress_disco(nwno, ct, xg, gw, tw, f0), ag, 1e-4 * np.abs(ag).max()) < 1e-8, tag
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("block", range(4))
+def test_fuzz_thermal(oracle, block):
+    from picaso_amd import fluxes
+    rng = np.random.default_rng(2000 + block)
+    for it in range(20):
+        sc, nlayer, nwno = _scene(rng, 900 + 50 * block + it)
+        ng, nt, gw, tw, u0, u1, ct = _geometry(rng)
+        hard = int(rng.integers(0, 2))
+        calc = int(rng.integers(0, 2))
+        rs = float(rng.choice([0.0, 0.2])) if rng.random() < 0.7 else 0.5 * rng.random(nwno)
+        dw = np.abs(np.gradient(sc["wno"])) if nwno > 1 else np.array([10.0])
+        args = (nlayer + 1, sc["wno"], nwno, ng, nt, sc["tlevel"], sc["dtau_og"], sc["w0_no_raman"], sc["cosb_og"],
+                sc["plevel"], u1, rs, hard, dw, calc)
+        fg, _ = fluxes.get_thermal_1d(*args)
+        fo, _ = oracle.get_thermal_1d(*args)
+        assert rel_err(fg, fo, 1e-4 * np.abs(fo).max()) < 1e-8, (block, it, nlayer, nwno, ng, nt, hard, calc)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("block", range(3))
+def test_fuzz_spherical_harmonics(oracle, block):
+    from picaso_amd import fluxes
+    rng = np.random.default_rng(3000 + block)
+    for it in range(12):
+        sc, nlayer, nwno = _scene(rng, 1800 + 50 * block + it)
+        stream = int(rng.choice([2, 4]))
+        # the SH planes carry their own delta-M factor: rebuild the scene with the matching stream
+        from picaso_amd import synthetic as syn
+        sc = syn.make_scene(nlayer, nwno, seed=1800 + 50 * block + it, stream=stream)
+        ng, nt, gw, tw, u0, u1, ct = _geometry(rng)
+        opts = [int(rng.integers(0, 2)) for _ in range(3)] + [int(rng.integers(0, 2)) for _ in range(3)]
+        sform = int(rng.integers(0, 2))
+        rs = float(rng.choice([0.0, 0.3]))
+        args = lambda fd: (nlayer + 1, nwno, ng, nt, sc["dtau"], sc["tau"], sc["w0"], sc["cosb"], sc["ftau_cld"],
+                           sc["ftau_ray"], fd, sc["dtau_og"], sc["tau_og"], sc["w0_og"], sc["cosb_og"], rs, u0, u1,
+                           ct, np.ones(nwno), *opts, *TTHG, stream)
+        xg, _ = fluxes.get_reflected_SH(*args(sc["f_deltaM"].copy()), b_top=0.0, flx=0, single_form=sform)
+        xo, _ = oracle.get_reflected_SH(*args(sc["f_deltaM"].copy()), b_top=0.0, flx=0, single_form=sform)
+        assert rel_err(xg, xo, 1e-4 * np.abs(xo).max()) < 1e-7, (block, it, nlayer, nwno, ng, nt, stream, opts, sform)
