@@ -111,3 +111,84 @@ def test_fuzz_spherical_harmonics(oracle, block):
         xg, _ = fluxes.get_reflected_SH(*args(sc["f_deltaM"].copy()), b_top=0.0, flx=0, single_form=sform)
         xo, _ = oracle.get_reflected_SH(*args(sc["f_deltaM"].copy()), b_top=0.0, flx=0, single_form=sform)
         assert rel_err(xg, xo, 1e-4 * np.abs(xo).max()) < 1e-7, (block, it, nlayer, nwno, ng, nt, stream, opts, sform)
+
+
+def _facet_planes(rng, nlayer, nwno, ng, nt, seed):
+    """Per-facet planes (rows, nwno, ng, nt): every facet its own random scene."""
+    from picaso_amd import synthetic as syn
+    scs = [[syn.make_scene(nlayer, nwno, seed=seed + 31 * (g * nt + t), cloud=bool((g + t) % 2),
+                           gas_scale=float(10.0 ** rng.uniform(-2, 1))) for t in range(nt)] for g in range(ng)]
+    keys = PLANES + ("w0_no_raman",)
+    st = {k: np.ascontiguousarray(np.stack([np.stack([scs[g][t][k] for t in range(nt)], axis=2)
+                                            for g in range(ng)], axis=2)) for k in keys}
+    tl = np.stack([np.stack([scs[g][t]["tlevel"] * (1 + 0.05 * g - 0.03 * t) for t in range(nt)], axis=1)
+                   for g in range(ng)], axis=1)
+    pl = np.stack([np.stack([scs[g][t]["plevel"] for t in range(nt)], axis=1) for g in range(ng)], axis=1)
+    return scs[0][0], st, tl, pl
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("block", range(3))
+def test_fuzz_facets_3d(oracle, block):
+    from picaso_amd import disco, fluxes
+    rng = np.random.default_rng(4000 + block)
+    for it in range(6):
+        nlayer = int(rng.choice([1, 4, 17]))
+        nwno = int(rng.choice([3, 33, 70]))
+        ng, nt = int(rng.integers(2, 6)), int(rng.integers(2, 5))
+        g, gw, t, tw = disco.get_angles_3d(ng, nt)
+        u0, u1, ct, _, _ = disco.compute_disco(ng, nt, g, t, float(rng.choice([0.0, 0.7, 1.6])))
+        sc0, st, tl, pl = _facet_planes(rng, nlayer, nwno, ng, nt, 7000 + 100 * block + it)
+        sp, mp = int(rng.integers(0, 4)), int(rng.integers(0, 2))
+        rs = float(rng.choice([0.0, 0.4]))
+        a = (nlayer + 1, sc0["wno"], nwno, ng, nt, *[st[k] for k in PLANES], rs, u0, u1, ct, np.ones(nwno), sp, mp,
+             *TTHG)
+        xg, xo = fluxes.get_reflected_3d(*a), oracle.get_reflected_3d(*a)
+        assert rel_err(xg, xo, 1e-4 * np.abs(xo).max()) < 1e-8, (block, it, nlayer, nwno, ng, nt, sp, mp)
+        hs = int(rng.integers(0, 2))
+        b = (nlayer + 1, sc0["wno"], nwno, ng, nt, tl, st["dtau_og"], st["w0_no_raman"], st["cosb_og"], pl, u1, rs, hs)
+        fg, fo = fluxes.get_thermal_3d(*b), oracle.get_thermal_3d(*b)
+        assert rel_err(fg, fo, 1e-4 * np.abs(fo).max()) < 1e-8, (block, it, nlayer, nwno, ng, nt, hs)
+
+
+@pytest.mark.gpu
+def test_fuzz_compute_opacity(oracle):
+    """Mixing + delta-Eddington kernel against the numpy restatement on random optical depths,
+    all test modes / streams, with and without a Raman plane and clouds."""
+    from oracle import optics_oracle as oo
+    from picaso_amd import _lib
+    from picaso_amd._lib import check, load, ptr
+    from picaso_amd.device import DeviceArray
+    import ctypes
+    names = ("dtau", "tau", "w0", "cosb", "ftau_cld", "ftau_ray", "gcos2", "dtau_og", "tau_og", "w0_og", "cosb_og",
+             "w0_no_raman", "f_deltaM")
+    ctx = _lib.context()
+    rng = np.random.default_rng(55)
+    for it in range(24):
+        nlayer, nwno = int(rng.choice([1, 2, 9, 31])), int(rng.choice([1, 17, 64, 300]))
+        tg = 10.0 ** rng.uniform(-6, 2, (nlayer, nwno))
+        tr = 10.0 ** rng.uniform(-6, 1, (nlayer, nwno))
+        cloudy = it % 3 != 0
+        tc = np.where(rng.random((nlayer, nwno)) < 0.4, 10.0 ** rng.uniform(-3, 1, (nlayer, nwno)), 0.0) * cloudy
+        wc, gc = 0.2 + 0.79 * rng.random((nlayer, nwno)), 0.95 * rng.random((nlayer, nwno))
+        null_cloud = (not cloudy) and it % 2 == 0            # NULL cloud planes = zero planes
+        if null_cloud:
+            wc, gc = np.zeros_like(wc), np.zeros_like(gc)
+        raman = rng.random((nlayer, nwno)) * 0.99999 if it % 2 else None
+        tm = [None, "rayleigh", "constant_tau"][it % 3] if it % 4 == 0 else None
+        de, stream = bool(rng.integers(0, 2)), int(rng.choice([2, 4]))
+        want = oo.compute_opacity(tg, tr, tc, wc, gc, raman if raman is not None else 0.99999, stream=stream,
+                                  delta_eddington=de, test_mode=tm)
+        d = {k: DeviceArray.from_host(v, ctx) for k, v in dict(tg=tg, tr=tr, tc=tc, wc=wc, gc=gc).items()}
+        d_r = DeviceArray.from_host(raman, ctx) if raman is not None else None
+        outs = [DeviceArray((nlayer + 1 if k in ("tau", "tau_og") else nlayer, nwno), ctx) for k in names]
+        check(load().picaso_compute_opacity_dev(
+            ctx, ctypes.c_int(nlayer), ctypes.c_int(nwno), ptr(d["tg"].addr), ptr(d["tr"].addr),
+            None if null_cloud else ptr(d["tc"].addr), None if null_cloud else ptr(d["wc"].addr),
+            None if null_cloud else ptr(d["gc"].addr), ptr(d_r.addr) if d_r else None, ctypes.c_double(0.99999),
+            ctypes.c_int({None: 0, "rayleigh": 1, "constant_tau": 2}[tm]), ctypes.c_int(int(de)),
+            ctypes.c_int(stream), *[ptr(o.addr) for o in outs]), ctx)
+        for k, o, w in zip(names, outs, want):
+            got = o.to_host()
+            w = np.broadcast_to(w, got.shape)
+            assert rel_err(got, w, 1e-300) < 1e-12, (it, k, nlayer, nwno, tm, de, stream)
