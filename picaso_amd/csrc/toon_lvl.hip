@@ -120,31 +120,51 @@ __global__ __launch_bounds__(256) void k_reflected_lvl(const ReflectedLvlArgs A)
                  ((1.0 - rs * pgam) - em2b * (pgam - rs) * rho);
     (void)tau_bot;
 
-    // ---- sweep 2: bottom-up substitution + fluxes (fluxes.py:1219-1257) ----
-    const double uF = u0 * F;
+    // ---- sweep 2: bottom-up substitution; pos_i replaces the sweep factor in the scratch ----
     for (int i = n - 1; i >= 0; --i) {
-        const long off = (long)i * pitch + w;
-        const ReflLayer r = refl_layer_coeffs(a, off, F, u0, iu0, iu0sq);
-        const double neg = s_del[(long)i * nw] - s_rho[(long)i * nw] * pos;
-        const double tau_i = a.tau[off], dt = a.dtau[off];
-        const double xu_i = fexp(-tau_i * iu0);
-        const double cmu = r.am * xu_i, cpu = r.ap * xu_i;
-        const long o = (long)i * nw + w;
-        A.fm[o] = (pos * r.gam + neg + cmu) + uF * xu_i;                     // :1227, :1236
-        A.fp[o] = pos + r.gam * neg + cpu;                                    // :1228
-        const double EPm = fexp(0.5 * r.E), EMm = frcp(EPm);                  // :1239-1240
-        const double xm = fexp(-(tau_i + 0.5 * dt) * iu0);                    // :1243-1244
-        A.fmm[o] = (r.gam * pos * EPm + neg * EMm + r.am * xm) + uF * xm;     // :1248, :1251
-        A.fpm[o] = pos * EPm + r.gam * neg * EMm + r.ap * xm;                 // :1249
-        if (i == n - 1) {                                                     // level n (:1230-1233)
-            const double xd = fexp(-a.tau[off + pitch] * iu0);
-            const long ob = (long)n * nw + w;
-            A.fm[ob] = (r.gam * pos * r.EP + neg * r.EM + r.am * xd) + uF * xd;
-            A.fp[ob] = pos * r.EP + r.gam * neg * r.EM + r.ap * xd;
-            A.fmm[ob] = 0.0;
-            A.fpm[ob] = 0.0;
-        }
-        pos = s_s[(long)i * nw] * pos + s_t[(long)i * nw];                    // pos_{i-1}
+        const double pos_up = s_s[(long)i * nw] * pos + s_t[(long)i * nw];    // pos_{i-1}
+        s_s[(long)i * nw] = pos;
+        pos = pos_up;
+    }
+}
+
+// Level and mid-layer fluxes from the two-stream solution (fluxes.py:1219-1257): one thread per
+// (layer, column) -- the layers are independent once pos/neg are known, so this part of the work
+// does not sit on the sequential sweep (it is most of the arithmetic: the coefficients and four
+// exponentials per layer).
+__global__ __launch_bounds__(256) void k_reflected_lvl_fluxes(const ReflectedLvlArgs A)
+{
+    const ReflectedArgs &a = A.base;
+    const long w = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (w >= a.ncol) return;
+    const long wv = (a.ncolper > 1) ? w / a.ncolper : w;
+    const int n = a.nlayer, i = blockIdx.y;
+    const long pitch = a.pitch, nw = a.ncol;
+    const double u0 = a.ang[0].u0, iu0 = a.ang[0].iu0, iu0sq = a.ang[0].iu0sq;
+    const double F = a.F0PI[wv];
+    const double *s_rho = A.scratch + w, *s_del = s_rho + (long)n * nw, *s_pos = s_del + (long)n * nw;
+    const double uF = u0 * F;
+    const long off = (long)i * pitch + w;
+    const ReflLayer r = refl_layer_coeffs(a, off, F, u0, iu0, iu0sq);
+    const double pos = s_pos[(long)i * nw];
+    const double neg = s_del[(long)i * nw] - s_rho[(long)i * nw] * pos;
+    const double tau_i = a.tau[off], dt = a.dtau[off];
+    const double xu_i = fexp(-tau_i * iu0);
+    const double cmu = r.am * xu_i, cpu = r.ap * xu_i;
+    const long o = (long)i * nw + w;
+    A.fm[o] = (pos * r.gam + neg + cmu) + uF * xu_i;                     // :1227, :1236
+    A.fp[o] = pos + r.gam * neg + cpu;                                    // :1228
+    const double EPm = fexp(0.5 * r.E), EMm = frcp(EPm);                  // :1239-1240
+    const double xm = fexp(-(tau_i + 0.5 * dt) * iu0);                    // :1243-1244
+    A.fmm[o] = (r.gam * pos * EPm + neg * EMm + r.am * xm) + uF * xm;     // :1248, :1251
+    A.fpm[o] = pos * EPm + r.gam * neg * EMm + r.ap * xm;                 // :1249
+    if (i == n - 1) {                                                     // level n (:1230-1233)
+        const double xd = fexp(-a.tau[off + pitch] * iu0);
+        const long ob = (long)n * nw + w;
+        A.fm[ob] = (r.gam * pos * r.EP + neg * r.EM + r.am * xd) + uF * xd;
+        A.fp[ob] = pos * r.EP + r.gam * neg * r.EM + r.ap * xd;
+        A.fmm[ob] = 0.0;
+        A.fpm[ob] = 0.0;
     }
 }
 
@@ -153,6 +173,10 @@ int launch_reflected_lvl(picaso_ctx *ctx, const ReflectedLvlArgs &a)
     const int block = a.base.ncol <= 64L * 256 ? 64 : 256;   // see launch_thermal_lvl
     const long grid = (a.base.ncol + block - 1) / block;
     hipLaunchKernelGGL(k_reflected_lvl, dim3((unsigned)grid), dim3(block), 0, ctx->stream, a);
+    PZ_HIP(ctx, hipGetLastError());
+    const long grid256 = (a.base.ncol + 255) / 256;
+    hipLaunchKernelGGL(k_reflected_lvl_fluxes, dim3((unsigned)grid256, (unsigned)a.base.nlayer), dim3(256), 0,
+                       ctx->stream, a);
     PZ_HIP(ctx, hipGetLastError());
     return 0;
 }
