@@ -412,6 +412,13 @@ def make_optics():
             key = "%s/de%d_s%d_r%d_tm%s" % (qm, int(de), stream, raman, tm or "none")
             for nm, arr in zip(names, out):
                 store[key + "/" + nm] = np.asarray(arr)[:, :, 0]
+        # patchy clouds: the thinned-cloud column set (optics.py:314-315, justdoit.py:248-252)
+        atm = make_atm()
+        opa.get_opacities(atm)
+        out = optics.compute_opacity(atm, opa, ngauss=1, stream=2, delta_eddington=True, test_mode=None, raman=2,
+                                     fthin_cld=0.1, do_holes=True)
+        for nm, arr in zip(names, out):
+            store["%s/holes_fthin0.1/%s" % (qm, nm)] = np.asarray(arr)[:, :, 0]
     path = os.path.join(HERE, "optics.npz")
     np.savez_compressed(path, **store)
     print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024), "and", db,

@@ -274,3 +274,35 @@ def test_gpu_spectrum_pollack_raman(gold, oracle, pollack_table):
                                    P["w0_og"], P["cosb_og"], 0.0, u0, u1, 1.0, np.ones(nwno), 3, 0,
                                    1.0, -1.0, 2.0, -0.5, 1.0)
     assert rel_err(out["albedo"], oracle.compress_disco(nwno, 1.0, x, gw, tw, np.ones(nwno))) < 1e-8
+
+
+def test_oracle_thinned_cloud_planes(gold):
+    """compute_opacity(do_holes=True, fthin_cld=0.1) of the reference = the mixing with 0.1 x cloud opd."""
+    from oracle import optics_oracle as oo
+    key = "linear/de1_s2_r2_tmnone"
+    dtau, taucld = gold[key + "/dtau_og"], gold["in/cld_opd"]
+    # TAUGAS + TAURAY from the un-thinned reference planes: dtau_og - taucld; Rayleigh from ftau_ray / w0
+    fray, w0c = gold[key + "/ftau_ray"], gold["in/cld_w0"]
+    with np.errstate(invalid="ignore", divide="ignore"):
+        tauray = np.where(fray < 1, fray * w0c * taucld / np.where(fray < 1, 1 - fray, 1.0), 0.0)
+    tauray = np.where(taucld > 0, tauray, gold[key + "/w0_no_raman"] * dtau / 0.99999)
+    taugas = dtau - tauray - taucld
+    out = oo.compute_opacity(taugas, tauray, 0.1 * taucld, w0c, gold["in/cld_g0"], 0.99999, stream=2,
+                             delta_eddington=True)
+    for nm, arr in zip(NAMES, out):
+        assert _close(arr, gold["linear/holes_fthin0.1/" + nm], 1e-9), nm
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("qm", ["nearest", "linear"])
+def test_gpu_thinned_cloud_planes(gold, qm):
+    from picaso_amd import justdoit as jdi
+    from picaso_amd import optics as px
+    opa = jdi.opannection(DB, query_method=qm)
+    case = _bundle(gold, jdi, None, True, 2, 2)
+    atm = jdi._setup_atmosphere(case.inputs, opa, opa.wno)
+    opa.get_opacities(atm)
+    out = px.compute_opacity(atm, opa, ngauss=1, stream=2, delta_eddington=True, test_mode=None, raman=2,
+                             fthin_cld=0.1, do_holes=True)
+    for nm, arr in zip(NAMES, out):
+        assert _close(arr[:, :, 0], gold["%s/holes_fthin0.1/%s" % (qm, nm)], 1e-10), (qm, nm)
