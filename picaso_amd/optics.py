@@ -319,17 +319,14 @@ class RetrieveCKs:
         t_inv, p_log = 1 / tlayer, np.log10(player)
         p_log_grid = np.log10(self.pressures[self.pressures > 0])
         t_inv_grid = 1 / self.temps
-        t_low = np.zeros(nlayer, dtype=int)
-        for i, v in enumerate(t_inv):                       # optics.py:1101-1113
-            find = np.where(t_inv_grid > v)[0]
-            t_low[i] = 0 if len(find) == 0 else find[-1]
+
+        def last_true(mask):        # last grid index satisfying the condition, 0 when none does
+            return np.where(mask, np.arange(mask.shape[1])[None, :], -1).max(axis=1).clip(min=0)
+        t_low = last_true(t_inv_grid[None, :] > t_inv[:, None])                  # optics.py:1101-1113
         t_low[t_low == (len(t_inv_grid) - 1)] = len(t_inv_grid) - 2
         t_hi = t_low + 1
-        p_low = np.zeros(nlayer, dtype=int)
-        for i, v in enumerate(p_log):                       # optics.py:1124-1141
-            find = np.where(p_log_grid <= v)[0]
-            p_low[i] = 0 if len(find) == 0 else find[-1]
-            p_low[i] = min(p_low[i], self.nc_p[t_hi[i]] - 3)
+        p_low = last_true(p_log_grid[None, :] <= p_log[:, None])                 # optics.py:1124-1141
+        p_low = np.minimum(p_low, self.nc_p[t_hi] - 3)
         p_hi = p_low + 1
         t_i = (t_inv - t_inv_grid[t_low]) / (t_inv_grid[t_hi] - t_inv_grid[t_low])
         p_i = (p_log - p_log_grid[p_low]) / (p_log_grid[p_hi] - p_log_grid[p_low])
@@ -376,16 +373,11 @@ class RetrieveCKs:
         cia_rows = np.zeros((nlayer, 2), dtype=np.int32)
         cia_wts = np.zeros((nlayer, 2))
         if cia_pairs:
-            for i, t in enumerate(tlayer):
-                if t <= st[0]:
-                    lo = 0
-                elif t >= st[-1]:
-                    lo = len(st) - 2
-                else:
-                    lo = int(np.where(st - t <= 0)[0][-1])
-                ti = (1 / t - 1 / st[lo]) / (1 / st[lo + 1] - 1 / st[lo])
-                cia_rows[i] = (lo, lo + 1)
-                cia_wts[i] = (1 - ti, ti)
+            lo = np.where(st[None, :] <= tlayer[:, None], np.arange(len(st))[None, :], -1).max(axis=1)
+            lo = np.clip(lo, 0, len(st) - 2)              # below the grid: first pair; at/above its top: last pair
+            ti = (1 / tlayer - 1 / st[lo]) / (1 / st[lo + 1] - 1 / st[lo])
+            cia_rows = np.stack([lo, lo + 1], axis=1).astype(np.int32)
+            cia_wts = np.stack([1 - ti, ti], axis=1)
         self._plan.update(cia_pairs=cia_pairs, cia_rows=cia_rows, cia_wts=cia_wts)
         self.continuum_opa = _LazyPlanes(self, "cia")
 
