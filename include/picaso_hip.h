@@ -337,7 +337,8 @@ int picaso_opacity_gas_dev(picaso_ctx *ctx, int nlayer, int nwno, int linear, in
  * scaled set from the gas / Rayleigh / cloud optical depths.  All arrays are device planes
  * (nlayer, nwno) except tau, tau_og (nlevel, nwno).  `raman_factor` may be NULL (then
  * `raman_const`, 0.99999 for raman='none', is used); `taucld`, `w0_cld`, `g0_cld` may be NULL
- * (cloud-free atmosphere: read as zero planes).  test_mode: 0 off, 1 'rayleigh',
+ * (cloud-free atmosphere: read as zero planes).  Any of the 13 output planes may be NULL: it is then
+ * not written (a thermal-only caller needs dtau_og, w0_no_raman and cosb_og only).  test_mode: 0 off, 1 'rayleigh',
  * 2 constant-tau (optics.py:372-399).  Output order = the reference's return tuple
  * (optics.py:423-431). */
 int picaso_compute_opacity_dev(picaso_ctx *ctx, int nlayer, int nwno, const double *taugas,

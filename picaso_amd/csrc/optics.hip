@@ -143,8 +143,10 @@ __global__ __launch_bounds__(1024) void k_compute_opacity(const MixArgs a)
     const long w = facets ? col / a.nfac : ((a.ncolper > 1) ? col / a.ncolper : col);
     const long fbase = facets ? (col - w * a.nfac) * a.nlayer : 0;     // facet-major row block of this column
     double tau_run = 0.0, taud_run = 0.0;
-    a.tau_og[col] = 0.0;
-    a.tau[col] = 0.0;
+    // every output plane is optional: a caller that runs only the thermal (or only the transmission)
+    // leg asks for 3 (1) of the 13 planes and the kernel does not write the rest
+    if (a.tau_og) a.tau_og[col] = 0.0;
+    if (a.tau) a.tau[col] = 0.0;
     for (int i = 0; i < a.nlayer; ++i) {
         const long o = (long)i * ncol + col;
         // gas / Rayleigh / Raman: per wavelength (monochromatic), per column (correlated-k) or per
@@ -175,17 +177,31 @@ __global__ __launch_bounds__(1024) void k_compute_opacity(const MixArgs a)
         }
         tau_run += dtau;                                                // numba_cumsum (:353-354)
         const long q = o, qn = o + ncol;
-        a.dtau_og[q] = dtau; a.tau_og[qn] = tau_run; a.w0_og[q] = w0; a.cosb_og[q] = cosb;
-        a.ftau_cld[q] = fcld; a.ftau_ray[q] = fray; a.gcos2[q] = gcos2; a.w0_no_raman[q] = w0nr;
+        if (a.dtau_og) a.dtau_og[q] = dtau;
+        if (a.tau_og) a.tau_og[qn] = tau_run;
+        if (a.w0_og) a.w0_og[q] = w0;
+        if (a.cosb_og) a.cosb_og[q] = cosb;
+        if (a.ftau_cld) a.ftau_cld[q] = fcld;
+        if (a.ftau_ray) a.ftau_ray[q] = fray;
+        if (a.gcos2) a.gcos2[q] = gcos2;
+        if (a.w0_no_raman) a.w0_no_raman[q] = w0nr;
         if (a.delta_eddington) {                                        // :401-420
             const double f = ipow(cosb, a.stream);
             const double w0d = w0 * (1. - f) / (1.0 - w0 * f);
             const double cbd = (cosb - f) / (1. - f);
             const double dtd = dtau * (1. - w0 * f);
             taud_run += dtd;
-            a.f_deltaM[q] = f; a.w0[q] = w0d; a.cosb[q] = cbd; a.dtau[q] = dtd; a.tau[qn] = taud_run;
+            if (a.f_deltaM) a.f_deltaM[q] = f;
+            if (a.w0) a.w0[q] = w0d;
+            if (a.cosb) a.cosb[q] = cbd;
+            if (a.dtau) a.dtau[q] = dtd;
+            if (a.tau) a.tau[qn] = taud_run;
         } else {                                                        // :428-431
-            a.f_deltaM[q] = 0 * cosb; a.w0[q] = w0; a.cosb[q] = cosb; a.dtau[q] = dtau; a.tau[qn] = tau_run;
+            if (a.f_deltaM) a.f_deltaM[q] = 0 * cosb;
+            if (a.w0) a.w0[q] = w0;
+            if (a.cosb) a.cosb[q] = cosb;
+            if (a.dtau) a.dtau[q] = dtau;
+            if (a.tau) a.tau[qn] = tau_run;
         }
     }
 }

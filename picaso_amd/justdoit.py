@@ -350,8 +350,19 @@ def picaso(bundle, opacityclass, dimension="1d", calculation="reflected", full_o
     gauss_wts = np.asarray(opa.gauss_wts, dtype=float)
     if dimension == "1d":
         opa.get_opacities(atm, exclude_mol=inp["atmosphere"]["exclude_mol"])
+        # only the planes the requested legs read are written (toon: 11 for reflected light, 3 for
+        # thermal emission, 1 for transmission; the SH solvers take the whole set)
+        want = None
+        if not is_sh:
+            want = set()
+            if "reflected" in calculation:
+                want |= set(resident.REFLECTED_PLANES)
+            if "thermal" in calculation:
+                want |= {"dtau_og", "w0_no_raman", "cosb_og"}
+            if "transmission" in calculation:
+                want |= {"dtau_og"}
         co_kw = dict(ngauss=ngauss, stream=common["stream"], delta_eddington=common["delta_eddington"],
-                     test_mode=inp["test_mode"], raman=common["raman"], full_output=full_output)
+                     test_mode=inp["test_mode"], raman=common["raman"], full_output=full_output, want=want)
         planes = optics.compute_opacity_resident(atm, opa, **co_kw)
         # patchy clouds (justdoit.py:139-142, 248-252): a second, thinned-cloud column set
         if do_holes:

@@ -613,10 +613,11 @@ def compute_opacity_facets(atms, opacityclass, numg, numt, stream=2, delta_eddin
 
 def compute_opacity_resident(atmosphere, opacityclass, ngauss=1, stream=2, delta_eddington=True,
                              test_mode=None, raman=0, fthin_cld=None, do_holes=False,
-                             full_output=False):
+                             full_output=False, want=None):
     """GPU ``compute_opacity`` returning a dict of the 13 planes as DeviceArrays: ``(rows, nwno)``
     for monochromatic opacities, ``(rows, nwno, ngauss)`` (reference layout, optics.py:423-431)
-    for correlated-k tables.  (3-D path: ``compute_opacity_facets``.)"""
+    for correlated-k tables.  (3-D path: ``compute_opacity_facets``.)  ``want``: names of the planes
+    the caller will read (default all 13); the others are neither allocated nor written."""
     atm, opa = atmosphere, opacityclass
     if ngauss != opa.ngauss:
         raise Exception("compute_opacity: ngauss=%d but the opacity tables have %d Gauss points"
@@ -650,13 +651,14 @@ def compute_opacity_resident(atmosphere, opacityclass, ngauss=1, stream=2, delta
     out = {}
     for k in OUT_NAMES:
         rows = nlayer + 1 if k in ("tau", "tau_og") else nlayer
-        out[k] = DeviceArray((rows,) + gshape, ctx)
+        out[k] = DeviceArray((rows,) + gshape, ctx) if (want is None or k in want) else None
     check(load().picaso_compute_opacity_ck_dev(
         ctx, _ci(nlayer), _ci(nwno), _ci(ngauss), ptr(taugas.addr), ptr(tauray.addr),
         *[ptr(x.addr) if x is not None else None for x in (d_cld, d_w0, d_g0)],
         ptr(raman_plane.addr) if raman_plane else None,
         _cd(raman_const), _ci(tm), _ci(1 if delta_eddington else 0), _ci(stream),
-        *[ptr(out[k].addr) for k in OUT_NAMES]), ctx)
+        *[ptr(out[k].addr) if out[k] is not None else None for k in OUT_NAMES]), ctx)
+    out = {k: v for k, v in out.items() if v is not None}
     if full_output:
         atmosphere.taugas = taugas.to_host().reshape((nlayer, nwno, ngauss))
         atmosphere.tauray = np.repeat(tauray.to_host()[:, :, None], ngauss, axis=2)

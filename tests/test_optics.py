@@ -306,3 +306,16 @@ def test_gpu_thinned_cloud_planes(gold, qm):
                              fthin_cld=0.1, do_holes=True)
     for nm, arr in zip(NAMES, out):
         assert _close(arr[:, :, 0], gold["%s/holes_fthin0.1/%s" % (qm, nm)], 1e-10), (qm, nm)
+
+
+@pytest.mark.gpu
+def test_gpu_single_leg_spectra_equal_the_combined_run(gold):
+    """A thermal-only (reflected-only) spectrum asks the mixing kernel for 3 (11) of its 13 planes;
+    the results are those of the combined run bit for bit."""
+    from picaso_amd import justdoit as jdi
+    opa = jdi.opannection(DB, query_method="linear")
+    both = _bundle(gold, jdi, None, True, 2, 2).spectrum(opa, calculation="reflected+thermal")
+    th = _bundle(gold, jdi, None, True, 2, 2).spectrum(opa, calculation="thermal")
+    rf = _bundle(gold, jdi, None, True, 2, 2).spectrum(opa, calculation="reflected")
+    assert np.array_equal(th["thermal"], both["thermal"]) and "albedo" not in th
+    assert np.array_equal(rf["albedo"], both["albedo"]) and "thermal" not in rf
