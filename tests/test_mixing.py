@@ -102,3 +102,37 @@ def test_gpu_mixing_reference_signature(gold):
     args[0][1][...] = args[0][1] + 0.5               # same buffer, new content: re-uploaded
     out3 = deq_chem.mix_all_gases_gasesfly(*args)
     assert not np.array_equal(out, out3)
+
+
+@pytest.mark.gpu
+def test_gpu_mixing_fuzz_vs_oracle(oracle):
+    """Random Gauss-point counts 1..8 (odd squares leave a ragged last key pair), 1..10 gases, flat
+    gases (8-way ties in every sort), tiny and huge abundances, sizes that leave partial blocks."""
+    rng = np.random.default_rng(31337 + int(os.environ.get("PICASO_FUZZ_OFFSET", "0")))
+    for it in range(30):
+        nk = int(rng.integers(1, 9))
+        ngas = int(rng.integers(1, 11))
+        npres, ntemp = int(rng.integers(2, 5)), int(rng.integers(2, 5))
+        nwno, nlayer = int(rng.choice([1, 3, 4, 5, 33])), int(rng.integers(1, 6))
+        xg, wg = np.polynomial.legendre.leggauss(nk)
+        pts, wts = 0.5 * (xg + 1), 0.5 * wg
+        kappas = []
+        for g in range(ngas):
+            base = -60.0 + 20.0 * rng.random((npres, ntemp, nwno, 1))
+            kind = rng.integers(0, 3)
+            if kind == 0:                                   # flat: every coefficient of a bin equal
+                k = np.repeat(base, nk, axis=3)
+            elif kind == 1:                                 # steep
+                k = base + np.cumsum(rng.random((npres, ntemp, nwno, nk)) * 8.0, axis=3)
+            else:                                           # gentle, with repeated values
+                k = base + np.cumsum(np.round(rng.random((npres, ntemp, nwno, nk)) * 2.0) * 0.25, axis=3)
+            kappas.append(np.ascontiguousarray(k))
+        mixes = [10.0 ** rng.uniform(-12, 0, nlayer) for _ in range(ngas)]
+        p_low, t_low = rng.integers(0, npres - 1, nlayer), rng.integers(0, ntemp - 1, nlayer)
+        idx = np.array([p_low, p_low + 1, t_low, t_low + 1])
+        want = oracle.mix_all_gases_gasesfly(kappas, mixes, pts, wts, idx)
+        g = {"x/kappas": np.stack(kappas), "x/mixes": np.stack(mixes), "x/gauss_pts": pts, "x/gauss_wts": wts,
+             "x/indices": idx}
+        out = _gpu_mix(g, "x")
+        assert out.shape == want.shape
+        assert np.max(np.abs(out - want)) < 1e-10, (it, nk, ngas, nwno, nlayer)
