@@ -168,3 +168,61 @@ def test_device_block_reuse():
     _lib.check(_lib.load().picaso_pool_trim(ctx), ctx)
     with pytest.raises(_lib.PicasoHipError):
         _lib.check(_lib.load().picaso_dev_free(ctx, ctypes.c_void_p(0x1000)), ctx)
+
+
+def test_ck_batch_fuzz(oracle):
+    """Random Gauss-point counts (1..8), wavelength counts around the block edges, angle counts and
+    level-flux requests: the batched launch over nwno*ngauss columns against the reference's
+    per-Gauss-point loop with the oracle (GPU against GPU for the level fluxes: bit-exact plumbing)."""
+    import os
+    from helpers import lvl_err
+    from picaso_amd import _lib, disco, resident
+    from picaso_amd.device import DeviceArray
+    ctx = _lib.context()
+    rng = np.random.default_rng(4242 + int(os.environ.get("PICASO_FUZZ_OFFSET", "0")))
+    for it in range(12):
+        nlayer = int(rng.choice([1, 2, 9, 23]))
+        nwno = int(rng.choice([1, 7, 31, 32, 33, 65, 200]))
+        ngauss = int(rng.integers(1, 9))
+        ng = int(rng.choice([5, 6, 8]))
+        base, planes = _ck_scene(nlayer, nwno, ngauss, seed=300 + it)
+        wts = rng.random(ngauss)
+        wts /= wts.sum()
+        gang, gw, tang, tw = disco.get_angles_1d(ng)
+        u0, u1, ct, _, _ = disco.compute_disco(ng, 1, gang, tang, 0.0)
+        f0 = 0.5 + rng.random(nwno)
+        rs = rng.random(nwno) * 0.5
+        lvl = bool(rng.integers(0, 2))
+        xo = fo = 0.0
+        for ig in range(ngauss):
+            sl = [np.ascontiguousarray(planes[k][:, :, ig]) for k in PLANES]
+            x, _ = oracle.get_reflected_1d(nlayer + 1, base["wno"], nwno, ng, 1, *sl, rs, u0, u1, 1.0, f0, 3, 0, *TTHG)
+            f, _ = oracle.get_thermal_1d(nlayer + 1, base["wno"], nwno, ng, 1, base["tlevel"],
+                                         np.ascontiguousarray(planes["dtau_og"][:, :, ig]),
+                                         np.ascontiguousarray(planes["w0_no_raman"][:, :, ig]),
+                                         np.ascontiguousarray(planes["cosb_og"][:, :, ig]), base["plevel"], u1, rs,
+                                         0, base["wno"] * 0, 0)
+            xo, fo = xo + x * wts[ig], fo + f * wts[ig]
+        d = {k: DeviceArray.from_host(planes[k], ctx) for k in PLANES + ("w0_no_raman",)}
+        d_rs, d_f0 = DeviceArray.from_host(rs, ctx), DeviceArray.from_host(f0, ctx)
+        d_wno = DeviceArray.from_host(base["wno"], ctx)
+        xint, flux = DeviceArray((ng, 1, nwno), ctx), DeviceArray((ng, 1, nwno), ctx)
+        lv = [DeviceArray((ng, 1, nlayer + 1, nwno), ctx) for _ in range(4)] if lvl else None
+        resident.reflected_1d_ck(ctx, nlayer + 1, nwno, ngauss, ng, 1, d, d_rs, u0, u1, 1.0, d_f0, 3, 0, *TTHG, wts,
+                                 xint, lvl_fluxes=lv)
+        resident.thermal_1d_ck(ctx, nlayer + 1, d_wno, nwno, ngauss, ng, 1, base["tlevel"], d["dtau_og"],
+                               d["w0_no_raman"], d["cosb_og"], base["plevel"], u1, d_rs, 0, wts, flux)
+        tag = (it, nlayer, nwno, ngauss, ng, lvl)
+        tol = float(np.clip(2e-15 * np.exp(min(2.0 * planes["dtau_og"].max(), 35.0)), 1e-8, 1e-6))
+        assert rel_err(xint.to_host(), xo, max(1e-4 * np.abs(xo).max(), 1e-6 * f0.max())) < tol, tag
+        assert rel_err(flux.to_host(), fo, 1e-4 * np.abs(fo).max()) < tol, tag
+        if lvl:                       # Gauss-weighted level fluxes == the weighted sum of single-point launches
+            acc = [0.0] * 4
+            for ig in range(ngauss):
+                d1 = {k: DeviceArray.from_host(planes[k][:, :, ig:ig + 1], ctx) for k in PLANES}
+                l1 = [DeviceArray((ng, 1, nlayer + 1, nwno), ctx) for _ in range(4)]
+                x1 = DeviceArray((ng, 1, nwno), ctx)
+                resident.reflected_1d_ck(ctx, nlayer + 1, nwno, 1, ng, 1, d1, d_rs, u0, u1, 1.0, d_f0, 3, 0, *TTHG,
+                                         np.ones(1), x1, lvl_fluxes=l1)
+                acc = [a + b.to_host() * wts[ig] for a, b in zip(acc, l1)]
+            assert lvl_err([a.to_host() for a in lv], acc) < 1e-13, tag
