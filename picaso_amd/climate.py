@@ -90,10 +90,16 @@ def _planes(wed, noed, ctx, thermal_only=False):
 
 
 def get_fluxes(Atmosphere, OpacityWEd, OpacityNoEd, ScatteringPhase, Disco, Opagrid, F0PI, reflected, thermal,
-               do_holes=False, fhole=0.0, hole_OpacityWEd=None, hole_OpacityNoEd=None, ctx=None):
+               do_holes=False, fhole=0.0, hole_OpacityWEd=None, hole_OpacityNoEd=None, ctx=None,
+               copy_outputs=False):
     """Visible and IR net (layer and level), upward and downward fluxes (reference
     ``climate.get_fluxes``, climate.py:1687-1952).  Returns ``flux_net_v_layer, flux_net_v, flux_plus_v,
-    flux_minus_v, flux_net_ir_layer, flux_net_ir, flux_plus_ir, flux_minus_ir``."""
+    flux_minus_v, flux_net_ir_layer, flux_net_ir, flux_plus_ir, flux_minus_ir``.
+
+    ``flux_plus_v`` / ``flux_minus_v`` are ``(ng, nt, nlevel, nwno)`` as in the reference, where every
+    disk angle holds the same two-stream result (climate.py:1803-1805, :1868-1869); here they are
+    read-only broadcast views of that one ``(nlevel, nwno)`` array (the climate solver reads
+    ``[0, 0, :, :]``, climate.py:946-947) unless ``copy_outputs=True`` asks for writable copies."""
     ctx = ctx if ctx is not None else _lib.context()
     pressure, temperature, nlevel = Atmosphere.p_level, Atmosphere.t_level, int(Atmosphere.nlevel)
     sp = ScatteringPhase
@@ -141,8 +147,10 @@ def get_fluxes(Atmosphere, OpacityWEd, OpacityNoEd, ScatteringPhase, Disco, Opag
         flux_net_v_layer += np.sum(fpm, axis=3) - np.sum(fmm, axis=3)
         flux_net_v += np.sum(fp, axis=3) - np.sum(fm, axis=3)
         # the single two-stream angle stands for every disk angle (climate.py:1803-1805, :1868-1869)
-        flux_plus_v = np.broadcast_to(fp, (ng, nt, nlevel, nwno)).copy()
-        flux_minus_v = np.broadcast_to(fm, (ng, nt, nlevel, nwno)).copy()
+        flux_plus_v = np.broadcast_to(fp, (ng, nt, nlevel, nwno))
+        flux_minus_v = np.broadcast_to(fm, (ng, nt, nlevel, nwno))
+        if copy_outputs:
+            flux_plus_v, flux_minus_v = flux_plus_v.copy(), flux_minus_v.copy()
 
     if thermal:                                           # climate.py:1879-1941
         d_wno, d_dw = DeviceArray.from_host(wno, ctx), DeviceArray.from_host(dwni, ctx)

@@ -86,6 +86,10 @@ def test_gpu_get_fluxes_single_legs(gold):
     full = pc.get_fluxes(*args, **kw)
     r = pc.get_fluxes(*args[:7], True, False)
     t = pc.get_fluxes(*args[:7], False, True)
+    # the (ng, nt, ...) visible fluxes are broadcast views of the single two-stream result by default
+    assert not full[2].flags.writeable and full[2].strides[:2] == (0, 0)
+    cp = pc.get_fluxes(*args, copy_outputs=True, **kw)
+    assert cp[2].flags.writeable and np.array_equal(cp[2], full[2]) and np.array_equal(cp[3], full[3])
     for k in range(4):
         assert np.array_equal(r[k], full[k]) and not np.any(t[k])
         assert np.array_equal(t[4 + k], full[4 + k]) and not np.any(r[4 + k])
