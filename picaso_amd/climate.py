@@ -143,14 +143,7 @@ def get_fluxes(Atmosphere, OpacityWEd, OpacityNoEd, ScatteringPhase, Disco, Opag
                                      float(sp.constant_forward), gauss_wts, xdummy, get_toa_intensity=0,
                                      lvl_fluxes=lv)
             res.append(lv)
-        fm, fp, fmm, fpm = blend(res)[0]._owner.to_host()           # Gauss-weighted (1,1,nlevel,nwno) each
-        flux_net_v_layer += np.sum(fpm, axis=3) - np.sum(fmm, axis=3)
-        flux_net_v += np.sum(fp, axis=3) - np.sum(fm, axis=3)
-        # the single two-stream angle stands for every disk angle (climate.py:1803-1805, :1868-1869)
-        flux_plus_v = np.broadcast_to(fp, (ng, nt, nlevel, nwno))
-        flux_minus_v = np.broadcast_to(fm, (ng, nt, nlevel, nwno))
-        if copy_outputs:
-            flux_plus_v, flux_minus_v = flux_plus_v.copy(), flux_minus_v.copy()
+        refl_stack = blend(res)[0]._owner                 # read back after the thermal leg is enqueued
 
     if thermal:                                           # climate.py:1879-1941
         d_wno, d_dw = DeviceArray.from_host(wno, ctx), DeviceArray.from_host(dwni, ctx)
@@ -165,7 +158,20 @@ def get_fluxes(Atmosphere, OpacityWEd, OpacityNoEd, ScatteringPhase, Disco, Opag
         disk = DeviceArray((4, nlevel, nwno), ctx)
         for k, x in enumerate(blend(res)):                # compress_thermal over the disk angles (:1925-1928)
             resident.compress_thermal(ctx, nlevel * nwno, x, Disco.gweight, Disco.tweight, disk.row_block(k))
-        fm, fp, fmm, fpm = disk.to_host()
+        therm_disk = disk
+
+    # both legs are on the stream before the first copy back (each copy is a synchronisation)
+    if reflected:
+        fm, fp, fmm, fpm = refl_stack.to_host()           # Gauss-weighted (1,1,nlevel,nwno) each
+        flux_net_v_layer += np.sum(fpm, axis=3) - np.sum(fmm, axis=3)
+        flux_net_v += np.sum(fp, axis=3) - np.sum(fm, axis=3)
+        # the single two-stream angle stands for every disk angle (climate.py:1803-1805, :1868-1869)
+        flux_plus_v = np.broadcast_to(fp, (ng, nt, nlevel, nwno))
+        flux_minus_v = np.broadcast_to(fm, (ng, nt, nlevel, nwno))
+        if copy_outputs:
+            flux_plus_v, flux_minus_v = flux_plus_v.copy(), flux_minus_v.copy()
+    if thermal:
+        fm, fp, fmm, fpm = therm_disk.to_host()
         flux_net_ir_layer = ((fpm - fmm) * dwni).sum(axis=1)                  # (:1931-1936)
         flux_net_ir = ((fp - fm) * dwni).sum(axis=1)
         flux_plus_ir = fp * dwni
