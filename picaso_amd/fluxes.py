@@ -10,7 +10,6 @@ import ctypes
 
 import numpy as np
 
-from . import _lib
 from ._lib import check, context, f64, load, per_wave, ptr
 
 _ci, _cd = ctypes.c_int, ctypes.c_double

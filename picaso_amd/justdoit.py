@@ -16,7 +16,7 @@ import copy
 
 import numpy as np
 
-from . import _lib, disco, optics, resident
+from . import disco, optics, resident
 from .atmsetup import ATMSETUP
 from .device import DeviceArray
 

@@ -8,7 +8,6 @@ import ctypes
 
 import numpy as np
 
-from . import _lib
 from ._lib import check, f64, load, ptr
 from .device import DeviceArray
 
