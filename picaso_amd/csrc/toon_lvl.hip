@@ -218,7 +218,7 @@ __global__ __launch_bounds__(256) void k_thermal_lvl_solve(const ThermalLvlArgs 
     const long w = blockIdx.x * (long)blockDim.x + threadIdx.x;     // column (wavelength x Gauss point)
     if (w >= a.ncol) return;
     const long wv = (a.ncolper > 1) ? w / a.ncolper : w;
-    const int n = a.nlayer, nlevel = n + 1;
+    const int n = a.nlayer;
     const long pitch = a.pitch, nw = a.ncol;
     const double mu1 = 0.5;
     const double wn = a.wno[wv], rs = a.surf_reflect[wv];
