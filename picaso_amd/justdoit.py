@@ -177,6 +177,74 @@ class inputs:
         self.inputs["atmosphere"]["exclude_mol"] = exclude_mol
         self.nlevel = len(profiles["pressure"])
 
+    def phase_curve_geometry(self, calculation, phase_grid, num_gangle=10, num_tangle=10):
+        """Facet geometry of every phase of a phase curve (reference justdoit.py:1606-1660): reflected
+        light takes the illumination geometry of each phase, thermal emission the full-disk geometry
+        of phase 0 for all of them (the planet emits in every direction; the phase enters through
+        the rotated temperature map)."""
+        phase_grid = [float(p) for p in phase_grid]
+        if min(phase_grid) < 0:
+            raise Exception("Input minimum of phase grid less than 0. Input phase_grid such that there are "
+                            "only values between 0-2pi")
+        if max(phase_grid) > np.pi * 2:
+            raise Exception("Input maximum of phase grid is greater than 2pi. Input phase_grid such that "
+                            "there are only values between 0-2pi")
+        if calculation not in ("thermal", "reflected"):
+            raise Exception("Phase curve setup only works for calculation=thermal or reflected")
+        ng, nt = int(num_gangle), int(num_tangle)
+        gangle, gweight, tangle, tweight = disco.get_angles_3d(ng, nt)
+
+        def compute_angles(phase):
+            ubar0, ubar1, cos_theta, lat, lon = disco.compute_disco(ng, nt, gangle, tangle, phase)
+            return dict(num_gangle=ng, num_tangle=nt, gangle=gangle, gweight=gweight, tangle=tangle,
+                        tweight=tweight, latitude=lat, longitude=lon, cos_theta=cos_theta, ubar0=ubar0,
+                        ubar1=ubar1, symmetry="false")
+        self.inputs["phase_angle"] = phase_grid
+        self.inputs["disco"] = {p: compute_angles(0.0 if calculation == "thermal" else p) for p in phase_grid}
+        self.inputs["disco"]["calculation"] = calculation
+
+    def atmosphere_4d(self, profiles_by_phase, exclude_mol=1):
+        """One ``atmosphere_3d``-style profile dictionary per phase of ``phase_curve_geometry`` (the
+        reference rotates and regrids an xarray lon/lat map per phase, justdoit.py:3666-3790 -- data
+        preparation; here the per-phase facet profiles come in as arrays)."""
+        profs = list(profiles_by_phase)
+        for pr in profs:
+            if "pressure" not in pr or "temperature" not in pr:
+                raise Exception("atmosphere_4d: every phase needs 'pressure' and 'temperature'")
+        self.inputs["atmosphere"]["profile_4d"] = [{k: np.asarray(v, dtype=float) for k, v in pr.items()}
+                                                   for pr in profs]
+        self.inputs["atmosphere"]["exclude_mol"] = exclude_mol
+        self.nlevel = len(profs[0]["pressure"])
+
+    def phase_curve(self, opacityclass, full_output=False, plot_opacity=False, n_cpu=1, verbose=False,
+                    clouds_by_phase=None):
+        """Spectrum at every phase of ``phase_curve_geometry`` (reference justdoit.py:4741-4777; its
+        ``n_cpu`` joblib fan-out is a loop here: the phases share the resident opacity tables and one
+        GPU).  Returns ``{phase: spectrum output}``."""
+        phases = self.inputs["phase_angle"]
+        all_geom = self.inputs["disco"]
+        if not isinstance(all_geom, dict) or "calculation" not in all_geom:
+            raise Exception("run phase_curve_geometry() first")
+        profs = self.inputs["atmosphere"].get("profile_4d")
+        if profs is None or len(profs) != len(phases):
+            raise Exception("atmosphere_4d() needs one profile per phase (%d)" % len(phases))
+        calculation = all_geom["calculation"]
+        results = {}
+        try:
+            for i, ph in enumerate(phases):
+                if verbose:
+                    print("Currently computing Phase", (i, ph))
+                self.inputs["phase_angle"] = ph
+                self.inputs["disco"] = all_geom[ph]
+                self.inputs["atmosphere"]["profile_3d"] = profs[i]
+                if clouds_by_phase is not None:
+                    self.inputs["clouds"]["profile_3d"] = clouds_by_phase[i]
+                results[ph] = self.spectrum(opacityclass, calculation=calculation, dimension="3d",
+                                            full_output=full_output, plot_opacity=plot_opacity)
+        finally:
+            self.inputs["phase_angle"], self.inputs["disco"] = phases, all_geom
+        return results
+
     def clouds_3d(self, df=None):
         """Cloud ``opd``/``w0``/``g0`` as ``(nlayer, nwno, num_gangle, num_tangle)`` arrays."""
         self.inputs["clouds"]["profile_3d"] = df

@@ -352,3 +352,41 @@ def test_gpu_gasesfly_spectrum_runs_through_picaso(ck, og):
     pre = _case(og, jdi, True).spectrum(_ck_class(ck), calculation="reflected+thermal")
     assert np.isfinite(out["albedo"]).all() and np.isfinite(out["thermal"]).all()
     assert not np.allclose(out["albedo"], pre["albedo"])      # different (synthetic) gas tables
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("calc", ["reflected", "thermal"])
+def test_gpu_phase_curve_equals_single_phase_runs(og, calc):
+    """phase_curve(): every phase of phase_curve_geometry with its own facet profiles, against the
+    same phases run one at a time through phase_angle() + atmosphere_3d() + spectrum(dimension='3d')
+    (thermal phase curves integrate over the phase-0 geometry, justdoit.py:1648-1653)."""
+    from picaso_amd import justdoit as jdi
+    opa = jdi.opannection(DB, query_method="linear")
+    ng, nt = 3, 2
+    phases = [0.0, 0.9, 2.0]
+    nlevel = len(og["in/tlevel"])
+
+    def profile(k):
+        dT = 40.0 * k * np.cos(np.arange(ng))[None, :, None] * np.ones((1, 1, nt))
+        pr = {"pressure": og["in/plevel_bar"], "temperature": og["in/tlevel"][:, None, None] + dT}
+        for m in ("H2", "He", "H2O", "CH4"):
+            pr[m] = og["in/mix/" + m]
+        return pr
+
+    case = jdi.inputs()
+    case.gravity(gravity=float(og["in/gravity"]))
+    case.approx(raman="none")
+    case.phase_curve_geometry(calc, phases, num_gangle=ng, num_tangle=nt)
+    case.atmosphere_4d([profile(k) for k in range(len(phases))])
+    curve = case.phase_curve(opa)
+    assert list(curve.keys()) == phases and case.inputs["phase_angle"] == phases
+    key = "albedo" if calc == "reflected" else "thermal"
+    for k, ph in enumerate(phases):
+        one = jdi.inputs()
+        one.gravity(gravity=float(og["in/gravity"]))
+        one.approx(raman="none")
+        one.phase_angle(ph if calc == "reflected" else 0.0, num_gangle=ng, num_tangle=nt)
+        one.atmosphere_3d(profile(k))
+        want = one.spectrum(opa, calculation=calc, dimension="3d")
+        assert np.array_equal(curve[ph][key], want[key]), (calc, ph)
+    assert not np.array_equal(curve[phases[0]][key], curve[phases[2]][key])

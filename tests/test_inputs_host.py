@@ -120,3 +120,30 @@ def test_phase_angle_symmetry_errors(kw, msg):
     c = jdi.inputs()
     with pytest.raises(Exception, match=msg):
         c.phase_angle(symmetry=True, **kw)
+
+
+def test_phase_curve_geometry():
+    """Reflected light: the geometry of every phase; thermal: the phase-0 geometry for all phases
+    (reference justdoit.py:1606-1660)."""
+    from picaso_amd import disco
+    phases = [0.0, 0.8, 2.1]
+    c = jdi.inputs()
+    c.phase_curve_geometry("reflected", phases, num_gangle=4, num_tangle=3)
+    d = c.inputs["disco"]
+    assert c.inputs["phase_angle"] == phases and d["calculation"] == "reflected"
+    g, gw, t, tw = disco.get_angles_3d(4, 3)
+    for p in phases:
+        u0, u1, ct, lat, lon = disco.compute_disco(4, 3, g, t, p)
+        assert np.array_equal(d[p]["ubar0"], u0) and np.array_equal(d[p]["ubar1"], u1) and d[p]["cos_theta"] == ct
+        assert d[p]["symmetry"] == "false"
+    c.phase_curve_geometry("thermal", phases, num_gangle=4, num_tangle=3)
+    d = c.inputs["disco"]
+    u0, u1, ct, lat, lon = disco.compute_disco(4, 3, g, t, 0.0)
+    for p in phases:
+        assert np.array_equal(d[p]["ubar0"], u0) and d[p]["cos_theta"] == ct
+    with pytest.raises(Exception, match="thermal or reflected"):
+        c.phase_curve_geometry("transmission", phases)
+    with pytest.raises(Exception, match="greater than 2pi"):
+        c.phase_curve_geometry("thermal", [0.0, 7.0])
+    with pytest.raises(Exception, match="one profile per phase"):
+        c.phase_curve(None)
