@@ -35,7 +35,9 @@ extern "C" {
 
 typedef struct picaso_ctx picaso_ctx;
 
-/* ---- context / plumbing ------------------------------------------------------------------ */
+/* ---- context / plumbing ------------------------------------------------------------------
+ * No counterpart in the reference (it has no device, no FFI and no explicit memory): contexts,
+ * device buffers, copies and stream timing for callers that keep planes resident in HBM. */
 int picaso_device_count(int *count);
 int picaso_ctx_create(int device, picaso_ctx **out);
 void picaso_ctx_destroy(picaso_ctx *ctx);
