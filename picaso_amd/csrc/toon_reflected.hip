@@ -45,6 +45,10 @@ namespace pz {
 #ifndef PZ_REFL_MINWAVES
 #define PZ_REFL_MINWAVES 2
 #endif
+// threads per block (a tuning knob of tools/sweep.sh; the LDS state tile is [var][angle][PZ_REFL_BLOCK])
+#ifndef PZ_REFL_BLOCK
+#define PZ_REFL_BLOCK 256
+#endif
 
 // Per-angle sweep state (7 doubles per angle).  D1 = c+dn + Gamma EM delta, D2 = c-dn + EM delta of
 // the layer above: the only combinations of (c+dn, c-dn, delta) the next interface and the surface
@@ -72,11 +76,11 @@ struct ReflState {
     double rho, pgam, pEM;
     __device__ __forceinline__ double get(int var, int k) const
     {
-        return (var >= NR) ? lds[((var - NR) * NA + k) * 256] : reg[var < NR ? var : 0][k];
+        return (var >= NR) ? lds[((var - NR) * NA + k) * PZ_REFL_BLOCK] : reg[var < NR ? var : 0][k];
     }
     __device__ __forceinline__ void set(int var, int k, double v)
     {
-        if (var >= NR) lds[((var - NR) * NA + k) * 256] = v;
+        if (var >= NR) lds[((var - NR) * NA + k) * PZ_REFL_BLOCK] = v;
         else reg[var < NR ? var : 0][k] = v;
     }
 };
@@ -245,7 +249,7 @@ __device__ __forceinline__ void reflected_layer(const ReflectedArgs &a, const La
 #define PZ_REFL_MINWAVES_FEW 2
 #endif
 template <int NA, bool IS3D, bool ZP>
-__global__ __launch_bounds__(256, (NA <= 2 ? PZ_REFL_MINWAVES_FEW : PZ_REFL_MINWAVES)) void k_reflected_toa(const ReflectedArgs a)
+__global__ __launch_bounds__(PZ_REFL_BLOCK, (NA <= 2 ? PZ_REFL_MINWAVES_FEW : PZ_REFL_MINWAVES)) void k_reflected_toa(const ReflectedArgs a)
 {
     const long col = blockIdx.x * (long)blockDim.x + threadIdx.x;
     if (col >= a.ncol) return;
@@ -288,7 +292,7 @@ __global__ __launch_bounds__(256, (NA <= 2 ? PZ_REFL_MINWAVES_FEW : PZ_REFL_MINW
                  *p_w0o = a.w0_og + col, *p_cbo = a.cosb_og + col;
 
     constexpr bool LDS = (NA >= 4) && !IS3D;
-    __shared__ double lds_state[LDS ? (PZ_REFL_NLDS > 0 ? PZ_REFL_NLDS : 1) * NA * 256 : 1];
+    __shared__ double lds_state[LDS ? (PZ_REFL_NLDS > 0 ? PZ_REFL_NLDS : 1) * NA * PZ_REFL_BLOCK : 1];
     ReflState<NA, LDS> S;
     S.lds = lds_state + threadIdx.x;
     S.rho = S.pgam = S.pEM = 0.0;
@@ -400,7 +404,7 @@ __global__ __launch_bounds__(256, (NA <= 2 ? PZ_REFL_MINWAVES_FEW : PZ_REFL_MINW
 template <int NA>
 static int launch1d(picaso_ctx *ctx, const ReflectedArgs &a)
 {
-    const int block = 256;
+    const int block = PZ_REFL_BLOCK;
     const dim3 grid((unsigned)((a.ncol + block - 1) / block), (unsigned)(a.ny > 1 ? a.ny : 1));
     bool zp = true;
     for (int k = 0; k < a.na * (int)grid.y; ++k) zp = zp && (a.ang[k].u0 == a.ang[k].u1);
@@ -416,7 +420,7 @@ int launch_reflected_toa(picaso_ctx *ctx, const ReflectedArgs &a, bool is3d)
 {
     if (a.ncol <= 0 || a.nlayer < 1) return fail(ctx, "reflected: empty problem");
     if (is3d) {
-        const int block = 256;
+        const int block = PZ_REFL_BLOCK;
         const long grid = (a.ncol + block - 1) / block;
         hipLaunchKernelGGL((k_reflected_toa<1, true, false>), dim3((unsigned)grid), dim3(block), 0,
                            ctx->stream, a);
