@@ -58,6 +58,13 @@ int picaso_memcpy_h2d_2d(picaso_ctx *ctx, void *dst, size_t dpitch_bytes, const 
                          size_t spitch_bytes, size_t width_bytes, size_t height);
 int picaso_memset(picaso_ctx *ctx, void *dst, int value, size_t bytes);
 int picaso_sync(picaso_ctx *ctx);
+/* work enqueued on `waiter` after this call starts only when everything enqueued on `signaller` so
+ * far has finished (device-side; the host does not block).  Two contexts on one device: e.g. the
+ * thermal leg of a spectrum on a second stream next to the reflected leg, both reading planes the
+ * first stream produced. */
+int picaso_ctx_wait(picaso_ctx *waiter, picaso_ctx *signaller);
+/* HIP device ordinal the context was created on */
+int picaso_ctx_device(picaso_ctx *ctx, int *device);
 /* HIP-event timing on the context's own stream (the stream every kernel here is launched on) */
 int picaso_timer_start(picaso_ctx *ctx);
 int picaso_timer_stop(picaso_ctx *ctx, float *elapsed_ms);

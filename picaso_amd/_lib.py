@@ -112,6 +112,18 @@ def new_context(device=None):
     return h
 
 
+def device_of(ctx):
+    d = ctypes.c_int(0)
+    check(load().picaso_ctx_device(ctx, ctypes.byref(d)), ctx)
+    return d.value
+
+
+def ctx_wait(waiter, signaller):
+    """Work enqueued on ``waiter`` from now on starts after everything enqueued on ``signaller`` so far
+    (device-side ordering between two contexts' streams; the host does not block)."""
+    check(load().picaso_ctx_wait(waiter, signaller), waiter)
+
+
 def f64(x, shape=None):
     a = np.ascontiguousarray(x, dtype=np.float64)
     if shape is not None and a.shape != tuple(shape):

@@ -170,6 +170,7 @@ void picaso_ctx_destroy(picaso_ctx *ctx)
     if (ctx->ring_h) (void)hipHostFree(ctx->ring_h);
     for (int i = 0; i < picaso_ctx::NSLOT; ++i)
         if (ctx->ring_ev[i]) (void)hipEventDestroy(ctx->ring_ev[i]);
+    if (ctx->wait_ev) (void)hipEventDestroy(ctx->wait_ev);
     if (ctx->stage) (void)hipHostFree(ctx->stage);
     for (int i = 0; i < 2; ++i)
         if (ctx->stage_ev[i]) (void)hipEventDestroy(ctx->stage_ev[i]);
@@ -319,6 +320,25 @@ int picaso_memset(picaso_ctx *ctx, void *dst, int value, size_t bytes)
 int picaso_sync(picaso_ctx *ctx)
 {
     PZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+int picaso_ctx_device(picaso_ctx *ctx, int *device)
+{
+    if (!ctx || !device) return fail(ctx, "picaso_ctx_device: null argument");
+    *device = ctx->device;
+    return 0;
+}
+int picaso_ctx_wait(picaso_ctx *waiter, picaso_ctx *signaller)
+{
+    if (!waiter || !signaller) return fail(nullptr, "null context");
+    if (waiter == signaller) return 0;
+    if (waiter->device != signaller->device) return fail(waiter, "picaso_ctx_wait: contexts on different devices");
+    PZ_HIP(waiter, hipSetDevice(waiter->device));
+    // ev1 of the signaller is only used between timer_start / timer_stop pairs on the host side;
+    // a dedicated event keeps the two uses apart
+    if (!signaller->wait_ev) PZ_HIP(waiter, hipEventCreateWithFlags(&signaller->wait_ev, hipEventDisableTiming));
+    PZ_HIP(waiter, hipEventRecord(signaller->wait_ev, signaller->stream));
+    PZ_HIP(waiter, hipStreamWaitEvent(waiter->stream, signaller->wait_ev, 0));
     return 0;
 }
 int picaso_timer_start(picaso_ctx *ctx)

@@ -15,6 +15,7 @@ struct picaso_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t wait_ev = nullptr;          // recorded on this stream for picaso_ctx_wait
     char err[512] = {0};
     int ncu = 256;
     // staging arena for the host-pointer entry points (grown on demand, reused across calls)

@@ -14,9 +14,11 @@ relative flux vector), xarray I/O, climate, retrievals, phase curves, 3-D regrid
 """
 import copy
 
+import os
+
 import numpy as np
 
-from . import disco, optics, resident
+from . import _lib, disco, optics, resident
 from .atmsetup import ATMSETUP
 from .device import DeviceArray
 
@@ -442,6 +444,16 @@ def picaso(bundle, opacityclass, dimension="1d", calculation="reflected", full_o
 
     rs = _resident_vector(opa, "surf_reflect", atm.surf_reflect, nwno)
     d_f0 = _resident_vector(opa, "F0PI", F0PI, nwno)
+    # 1-D Toon spectra with both legs: the thermal kernels go to a second stream that waits for the
+    # opacity planes only, so they run next to the reflected-light kernel (each of the two alone
+    # leaves SIMDs idle through its tail) instead of behind it
+    tctx = ctx
+    if (dimension == "1d" and not is_sh and "reflected" in calculation and "thermal" in calculation
+            and os.environ.get("PICASO_AMD_OVERLAP_LEGS", "1") != "0"):
+        if "_ctx2" not in opa.__dict__:
+            opa._ctx2 = _lib.new_context(_lib.device_of(ctx))
+        tctx = opa._ctx2
+        _lib.ctx_wait(tctx, ctx)
     returns = {"wavenumber": wno}
     # every leg first enqueues its kernels; the copies back (each a stream synchronisation) and the
     # host-side integrals run afterwards, so the GPU goes through reflected + thermal (+ transit)
@@ -512,8 +524,8 @@ def picaso(bundle, opacityclass, dimension="1d", calculation="reflected", full_o
         collect.append(collect_reflected)
     if "thermal" in calculation:
         d_wno = _resident_vector(opa, "wno", wno, nwno)
-        flux = DeviceArray((ng, nt, nwno), ctx)
-        disk = DeviceArray((nwno,), ctx)
+        flux = DeviceArray((ng, nt, nwno), tctx)
+        disk = DeviceArray((nwno,), tctx)
         if dimension == "3d":                                 # justdoit.py:502-514
             resident.thermal_3d(ctx, nlevel, d_wno, nwno, ng, nt, tlev3, planes3d["dtau_og"],
                                 planes3d["w0_no_raman"], planes3d["cosb_og"], plev3, ubar1, rs,
@@ -526,22 +538,22 @@ def picaso(bundle, opacityclass, dimension="1d", calculation="reflected", full_o
             def runt(pl, fx, fuse):                           # the ngauss loop of justdoit.py:328-380
                 kw = dict(gweight=gweight, tweight=tweight, flux_disk=disk) if fuse else {}
                 if ngauss > 1:
-                    resident.thermal_1d_ck(ctx, nlevel, d_wno, nwno, ngauss, ng, nt, atm.level["temperature"],
+                    resident.thermal_1d_ck(tctx, nlevel, d_wno, nwno, ngauss, ng, nt, atm.level["temperature"],
                                            pl["dtau_og"], pl["w0_no_raman"], pl["cosb_og"],
                                            atm.level["pressure"], ubar1, rs, atm.hard_surface, gauss_wts,
                                            fx, **kw)
                 else:
-                    resident.thermal_1d(ctx, nlevel, d_wno, nwno, ng, nt, atm.level["temperature"],
+                    resident.thermal_1d(tctx, nlevel, d_wno, nwno, ng, nt, atm.level["temperature"],
                                         pl["dtau_og"], pl["w0_no_raman"], pl["cosb_og"],
                                         atm.level["pressure"], ubar1, rs, atm.hard_surface, fx, **kw)
             if not do_holes:
                 runt(planes, flux, True)
             else:                                             # justdoit.py:346-361
-                fc = DeviceArray((ng, nt, nwno), ctx)
+                fc = DeviceArray((ng, nt, nwno), tctx)
                 runt(planes, flux, False)
                 runt(planes_clear, fc, False)
-                resident.axpby(ctx, 1.0 - fhole, flux, fhole, fc, flux)
-                resident.compress_thermal(ctx, nwno, flux, gweight, tweight, disk)
+                resident.axpby(tctx, 1.0 - fhole, flux, fhole, fc, flux)
+                resident.compress_thermal(tctx, nwno, flux, gweight, tweight, disk)
 
         def collect_thermal():
             thermal = disk.to_host()
