@@ -319,3 +319,25 @@ def test_gpu_single_leg_spectra_equal_the_combined_run(gold):
     rf = _bundle(gold, jdi, None, True, 2, 2).spectrum(opa, calculation="reflected")
     assert np.array_equal(th["thermal"], both["thermal"]) and "albedo" not in th
     assert np.array_equal(rf["albedo"], both["albedo"]) and "thermal" not in rf
+
+
+@pytest.mark.gpu
+def test_gpu_overlapped_legs_stress(gold):
+    """The thermal leg runs on a second stream next to the reflected leg; 150 back-to-back spectra of
+    two alternating atmospheres must each reproduce their single-leg results bit for bit (a missing
+    stream dependency would let one call's thermal kernel read the next call's planes)."""
+    from picaso_amd import justdoit as jdi
+    opa = jdi.opannection(DB, query_method="linear")
+    cases, want = [], []
+    for k in range(2):
+        c = _bundle(gold, jdi, None, True, 2, 2)
+        prof = dict(c.inputs["atmosphere"]["profile"])
+        prof["temperature"] = np.asarray(prof["temperature"]) * (1.0 + 0.2 * k)
+        prof["H2O"] = np.asarray(prof["H2O"]) * (1.0 + 3.0 * k)
+        c.atmosphere(df=prof)
+        cases.append(c)
+        want.append((c.spectrum(opa, calculation="reflected")["albedo"], c.spectrum(opa, calculation="thermal")["thermal"]))
+    assert not np.array_equal(want[0][1], want[1][1])
+    for i in range(150):
+        out = cases[i % 2].spectrum(opa, calculation="reflected+thermal")
+        assert np.array_equal(out["albedo"], want[i % 2][0]) and np.array_equal(out["thermal"], want[i % 2][1]), i
