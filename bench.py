@@ -1,17 +1,30 @@
 #!/usr/bin/env python
-"""Headline benchmark: spectra/s of a 1e5-wavelength x 90-layer Toon reflected-light spectrum
+"""Headline benchmark: spectra/s of ONE 1e5-wavelength x 90-layer Toon reflected-light spectrum
 (BASELINE.json configs[2]; 5 Gauss angles, TTHG_ray + N=2 + delta-Eddington, fused disk
 integration) with all input planes resident in HBM.
 
-    python bench.py [--gpus N --steps K --warmup W]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py [--gpus N --steps K --warmup W] [--config 1|2|3|4] [--scaling strong|weak]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
 
-One "step" = one full spectrum per GPU (get_reflected_1d + compress_disco over the rank's
-wavelength shard).  N > 1 is weak scaling: the wavelength grid is N x 1e5 points, each rank owns
-a contiguous 1e5-point shard, and the albedo shards are collected with one RCCL all-gather
-inside the timed region.  Prints ONE JSON line (rank 0).
+One process per GPU (the launcher only provides RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*; nothing
+here imports PyTorch).  One "step" = one full spectrum: every rank solves its contiguous wavelength
+block of the SAME 1e5-point grid (strong scaling, BASELINE's metric) and the albedo shards are
+all-gathered inside the timed region by RCCL inside libpicaso_hip.so (picaso_all_gather_dev, on the
+kernel's own stream).  `--scaling weak` gives every rank its own 1e5-point block of an N x 1e5 grid
+instead.  Prints ONE JSON line (rank 0).
+
+--config selects the other BASELINE workloads (not the headline): 1 thermal emission 1e4 x 90,
+3 SH4 reflected 1e5 x 90, 4 3-D 8x8 facets x 90 x nwno (default 12 500 per GPU: 1e5 over 8 GPUs).
+
+Clock ramp: an idle MI355X takes ~100 launches (30 ms) of this kernel to reach its steady clock
+state (tools/refl_time.py --ramp: 0.53, 0.35, 0.32, 0.30, 0.29 ... 0.25 ms per launch in groups of
+ten from cold) and falls back within milliseconds of idling, so the W warm-up steps are preceded by
+--prewarm-ms of the same launches, untimed; the timed region is exactly K steps between two
+barrier + synchronise pairs.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -21,19 +34,169 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+if os.environ.get("NCCL_DEBUG", "").upper() == "VERSION":
+    # the image exports NCCL_DEBUG=VERSION: librccl would print a version banner on stdout next to
+    # the one JSON line this script owes its caller
+    del os.environ["NCCL_DEBUG"]
 
-from picaso_amd import _lib, device, disco, resident  # noqa: E402
+from picaso_amd import _lib, device, disco, resident, sharding  # noqa: E402
 from picaso_amd import synthetic as syn  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 TTHG = (1.0, -1.0, 2.0, -0.5, 1.0)   # frac_a, frac_b, frac_c, constant_back, constant_forward
 
 
-def algorithmic_bytes(nwno, nlayer, nang, with_albedo=True):
-    """9 layer planes + 2 level planes + F0PI + surf_reflect read once,
-    xint_at_top (+ albedo) written once."""
-    nlevel = nlayer + 1
-    return 8 * nwno * (9 * nlayer + 2 * nlevel + 2 + nang + (1 if with_albedo else 0))
+def kernel_source_hash():
+    """Hash of the kernel sources the committed PMC numbers (profiles/traffic.json) refer to."""
+    h = hashlib.sha1()
+    for f in ("toon_reflected.hip", "device_math.hpp", "common.hpp"):
+        with open(os.path.join(ROOT, "picaso_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+# ---------------------------------------------------------------------------------------------
+# workloads: each returns a dict with solve(), the local result DeviceArray, algorithmic bytes of
+# the local launch, and how to check the result against the CPU oracle
+# ---------------------------------------------------------------------------------------------
+def workload_reflected(ctx, args, lo, hi, seed, nwno_total):
+    """configs[2]: get_reflected_1d + compress_disco (9 layer planes + 2 level planes +
+    F0PI + surf_reflect read once, xint_at_top and albedo written once)."""
+    nlayer, nlevel, ng = args.nlayer, args.nlayer + 1, args.ngauss
+    n = hi - lo
+    gang, gw, tang, tw = disco.get_angles_1d(ng)
+    ubar0, ubar1, _, _, _ = disco.compute_disco(ng, 1, gang, tang, 0.0)
+    scene = syn.make_scene(nlayer, nwno_total, seed=seed)
+    scene["F0PI"] = np.ones(nwno_total)
+    scene["surf_reflect"] = np.zeros(nwno_total)
+    keys = resident.REFLECTED_PLANES + ("F0PI", "surf_reflect")
+    d = resident.upload_scene(scene, keys, lo, hi, ctx=ctx)
+    xint = device.DeviceArray((ng, 1, n), ctx)
+
+    def solve(albedo):
+        resident.reflected_1d(ctx, nlevel, n, ng, 1, d, d["surf_reflect"], ubar0, ubar1, 1.0, d["F0PI"], 3, 0,
+                              *TTHG, xint, toon_coefficients=0, b_top=0.0, gweight=gw, tweight=tw, albedo=albedo)
+
+    def oracle(sl):
+        from oracle import oracle as orc
+        ns = sl.stop - sl.start
+        planes = [np.ascontiguousarray(scene[k][:, sl]) for k in resident.REFLECTED_PLANES]
+        xo, _ = orc.get_reflected_1d(nlevel, scene["wno"][sl], ns, ng, 1, *planes, 0.0, ubar0, ubar1, 1.0,
+                                     np.ones(ns), 3, 0, *TTHG)
+        return orc.compress_disco(ns, 1.0, xo, gw, tw, np.ones(ns))
+
+    return dict(solve=solve, oracle=oracle, nloc=n,
+                abytes=8 * n * (9 * nlayer + 2 * nlevel + 2 + ng + 1),
+                kernel="k_reflected_toa<%d, false, true, true>" % ng,
+                workload="BASELINE configs[2]: Toon two-stream reflected light (get_reflected_1d + "
+                         "compress_disco), TTHG_ray, N=2, delta-Eddington, Rayleigh + cloud slab",
+                metric="spectra/sec (1e5 wave x 90 layer reflected)")
+
+
+def workload_thermal(ctx, args, lo, hi, seed, nwno_total):
+    """configs[1]: get_thermal_1d + compress_thermal (3 layer planes + wno + surf_reflect in, flux +
+    disk flux out)."""
+    nlayer, nlevel, ng = args.nlayer, args.nlayer + 1, args.ngauss
+    n = hi - lo
+    gang, gw, tang, tw = disco.get_angles_1d(ng)
+    _, ubar1, _, _, _ = disco.compute_disco(ng, 1, gang, tang, 0.0)
+    scene = syn.make_scene(nlayer, nwno_total, seed=seed)
+    scene["surf_reflect"] = np.zeros(nwno_total)
+    scene["dwno"] = scene["wno"] * 0
+    d = resident.upload_scene(scene, ("dtau_og", "w0_no_raman", "cosb_og", "wno", "dwno", "surf_reflect"), lo, hi,
+                              ctx=ctx)
+    flux = device.DeviceArray((ng, 1, n), ctx)
+
+    def solve(disk):
+        resident.thermal_1d(ctx, nlevel, d["wno"], n, ng, 1, scene["tlevel"], d["dtau_og"], d["w0_no_raman"],
+                            d["cosb_og"], scene["plevel"], ubar1, d["surf_reflect"], 0, flux, dwno=d["dwno"],
+                            calc_type=0, gweight=gw, tweight=tw, flux_disk=disk)
+
+    def oracle(sl):
+        from oracle import oracle as orc
+        ns = sl.stop - sl.start
+        fo, _ = orc.get_thermal_1d(nlevel, scene["wno"][sl], ns, ng, 1, scene["tlevel"],
+                                   np.ascontiguousarray(scene["dtau_og"][:, sl]),
+                                   np.ascontiguousarray(scene["w0_no_raman"][:, sl]),
+                                   np.ascontiguousarray(scene["cosb_og"][:, sl]), scene["plevel"], ubar1,
+                                   np.zeros(ns), 0, scene["wno"][sl] * 0, 0)
+        return orc.compress_thermal(ns, fo, gw, tw)
+
+    return dict(solve=solve, oracle=oracle, nloc=n, abytes=8 * n * (3 * nlayer + 3 + ng + 1),
+                kernel="k_thermal_toa<%d, false>" % ng,
+                workload="BASELINE configs[1]: thermal emission (get_thermal_1d + compress_thermal), "
+                         "Planck per level, 5 Gauss angles",
+                metric="spectra/sec (%d wave x %d layer thermal)" % (nwno_total, nlayer))
+
+
+def workload_sh4(ctx, args, lo, hi, seed, nwno_total):
+    """configs[3]: get_reflected_SH, stream = 4, + compress_disco."""
+    nlayer, nlevel, ng = args.nlayer, args.nlayer + 1, args.ngauss
+    n = hi - lo
+    gang, gw, tang, tw = disco.get_angles_1d(ng)
+    ubar0, ubar1, _, _, _ = disco.compute_disco(ng, 1, gang, tang, 0.0)
+    scene = syn.make_scene(nlayer, nwno_total, seed=seed, stream=4)
+    scene["F0PI"] = np.ones(nwno_total)
+    scene["surf_reflect"] = np.zeros(nwno_total)
+    d = resident.upload_scene(scene, resident.SH_PLANES + ("F0PI", "surf_reflect"), lo, hi, ctx=ctx)
+    xint = device.DeviceArray((ng, 1, n), ctx)
+    opts = (0, 0, 0, 1, 1, 1)        # w_single_form, w_multi_form, psingle_form, *_rayleigh (config.json defaults)
+
+    def solve(albedo):
+        resident.reflected_SH(ctx, nlevel, n, ng, 1, d, d["surf_reflect"], ubar0, ubar1, 1.0, d["F0PI"], *opts,
+                              *TTHG, 4, xint, gweight=gw, tweight=tw, albedo=albedo)
+
+    def oracle(sl):
+        from oracle import oracle as orc
+        ns = sl.stop - sl.start
+        planes = [np.ascontiguousarray(scene[k][:, sl]) for k in resident.SH_PLANES]
+        xo, _ = orc.get_reflected_SH(nlevel, ns, ng, 1, *planes, np.zeros(ns), ubar0, ubar1, 1.0, np.ones(ns),
+                                     *opts, *TTHG, 4)
+        return orc.compress_disco(ns, 1.0, xo, gw, tw, np.ones(ns))
+
+    return dict(solve=solve, oracle=oracle, nloc=n,
+                abytes=8 * n * (9 * nlayer + 2 * nlevel + 2 + ng + 1),
+                kernel="k_sh<2, false, false>",
+                workload="BASELINE configs[3]: spherical-harmonics SH4 reflected light (get_reflected_SH + "
+                         "compress_disco), TTHG, delta-M, Rayleigh + cloud slab",
+                metric="spectra/sec (%d wave x %d layer SH4 reflected)" % (nwno_total, nlayer))
+
+
+def workload_3d(ctx, args, lo, hi, seed, nwno_total):
+    """configs[4]: get_reflected_3d on 8x8 facets + compress_disco; facet index fastest in memory."""
+    nlayer, nlevel = args.nlayer, args.nlayer + 1
+    ng = nt = 8
+    n = hi - lo
+    gang, gw, tang, tw = disco.get_angles_3d(ng, nt)
+    ubar0, ubar1, ct, _, _ = disco.compute_disco(ng, nt, gang, tang, 0.0)
+    base = syn.make_scene(nlayer, n, seed=seed + 7 * lo)
+    rng = np.random.default_rng(seed)
+    fac = 1.0 + 0.05 * rng.standard_normal(ng * nt)          # facet-to-facet variation of the optical depths
+    d = {}
+    for k in resident.REFLECTED_PLANES:
+        a = base[k]
+        if k in ("dtau", "tau", "dtau_og", "tau_og"):
+            a3 = a[:, :, None] * fac[None, None, :]
+        else:
+            a3 = np.repeat(a[:, :, None], ng * nt, axis=2)
+        d[k] = device.DeviceArray.from_host(np.ascontiguousarray(a3), ctx)
+    f0 = device.DeviceArray.from_host(np.ones(n), ctx)
+    rs = device.DeviceArray.from_host(np.zeros(n), ctx)
+    xint = device.DeviceArray((ng, nt, n), ctx)
+
+    def solve(albedo):
+        resident.reflected_3d(ctx, nlevel, n, ng, nt, d, rs, ubar0, ubar1, float(ct), f0, 0, 0, *TTHG, xint,
+                              gweight=gw, tweight=tw, albedo=albedo)
+
+    return dict(solve=solve, oracle=None, nloc=n,
+                abytes=8 * n * (ng * nt * (9 * nlayer + 2 * nlevel + 1) + 2 + 1),
+                kernel="k_reflected_toa<1, true, false>",
+                workload="BASELINE configs[4]: 3-D reflected light, 8x8 facets (get_reflected_3d + compress_disco)",
+                metric="spectra/sec (%d wave x %d layer x 64 facet 3-D reflected)" % (nwno_total, nlayer))
+
+
+WORKLOADS = {1: (workload_thermal, 10000), 2: (workload_reflected, 100000), 3: (workload_sh4, 100000),
+             4: (workload_3d, 12500)}
 
 
 def main():
@@ -41,174 +204,157 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--nwno", type=int, default=100000, help="wavelengths per GPU")
+    ap.add_argument("--config", type=int, default=2, choices=(1, 2, 3, 4))
+    ap.add_argument("--scaling", default="strong", choices=("strong", "weak"))
+    ap.add_argument("--nwno", type=int, default=0, help="wavelengths of the whole spectrum (0 = the config's)")
     ap.add_argument("--nlayer", type=int, default=90)
     ap.add_argument("--ngauss", type=int, default=5, help="disk Gauss angles (5..8)")
-    ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"),
-                    help="collective backend for N > 1 (nccl = RCCL over xGMI; gloo only for smoke "
-                         "tests of the sharded path on a box with fewer GPUs than ranks)")
-    ap.add_argument("--pipelined", action="store_true",
-                    help="also time the same K spectra issued round-robin on two streams (extra JSON object; "
-                         "off by default so that a rocprofv3 trace of the default run holds only the "
-                         "single-stream launches the roofline refers to)")
+    ap.add_argument("--prewarm-ms", type=float, default=400.0,
+                    help="untimed launches of the same step before the W warm-up steps (clock ramp)")
     ap.add_argument("--cpu-sample", type=int, default=100000,
                     help="wavelengths of the same workload timed on the CPU oracle (0 = skip)")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    rank, world, local_rank, addr, port = sharding.launcher_env()
+    launched = "RANK" in os.environ
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-
-    dist = torch = None
-    launched = "RANK" in os.environ          # under torch.distributed.run (also with one rank)
-    if launched:
-        # torch first: PyTorch-ROCm bundles its own HIP runtime and the process must hold exactly one
-        # (picaso_amd/_lib.py then binds libpicaso_hip.so to the copy torch has mapped)
-        import torch
-        import torch.distributed as dist
-        if args.backend == "nccl":
-            torch.cuda.set_device(local_rank)
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group("gloo")
     ndev = _lib.device_count()
     if ndev < 1:
         raise SystemExit("bench.py needs an MI355X: no HIP device visible")
-    dev = local_rank if args.backend == "nccl" else local_rank % ndev
+    ctx = _lib.context(local_rank % ndev)
+    group = comm = None
+    if launched:
+        group = sharding.HostGroup(rank, world, addr, port)
+        comm = sharding.Comm.from_launcher(ctx, group)     # RCCL inside the library
 
-    ctx = _lib.context(dev)
-    nwno, nlayer, nlevel = args.nwno, args.nlayer, args.nlayer + 1
-    ng = args.ngauss
-    gang, gw, tang, tw = disco.get_angles_1d(ng)
-    ubar0, ubar1, _, _, _ = disco.compute_disco(ng, 1, gang, tang, 0.0)
-    cos_theta = 1.0     # symmetric 1-D geometry (reference justdoit.py:1532)
-
-    # ---- synthetic shard of the (world*nwno)-point grid, built on the host, uploaded once ----
-    scene = syn.make_scene(nlayer, nwno, seed=3 + 1000 * rank)
-    scene["F0PI"] = np.ones(nwno)
-    scene["surf_reflect"] = np.zeros(nwno)
-    d = resident.upload_scene(scene, resident.REFLECTED_PLANES + ("F0PI", "surf_reflect"), ctx=ctx)
-    xint = device.DeviceArray((ng, 1, nwno), ctx)
-    use_nccl = launched and args.backend == "nccl"
-    if use_nccl:
-        # two result buffers: the gather of one spectrum overlaps the solve of the next
-        alb_tt = [torch.empty(nwno, dtype=torch.float64, device="cuda") for _ in range(2)]
-        full_tt = [torch.empty(world * nwno, dtype=torch.float64, device="cuda") for _ in range(2)]
-        pending = [None, None]
-        alb_t, full_t = alb_tt[0], full_tt[0]
-        albedo = alb_t.data_ptr()
+    build, nwno_cfg = WORKLOADS[args.config]
+    nwno = args.nwno or nwno_cfg
+    if args.scaling == "strong":
+        nwno_total = nwno
+        lo, hi = sharding.shard_of(nwno_total, world, rank)
+        seed = 3
     else:
-        alb_d = device.DeviceArray((nwno,), ctx)
-        albedo = alb_d
-        if launched:
-            full_t = torch.empty(world * nwno, dtype=torch.float64)
-
+        nwno_total = nwno * world
+        lo, hi = rank * nwno, (rank + 1) * nwno
+        seed = 3
+    wl = build(ctx, args, lo, hi, seed, nwno_total)
+    nloc = hi - lo
+    # two result buffers: with N > 1 the gather of spectrum i may still be in flight on the stream when
+    # spectrum i+1 is solved (everything is ordered on the one stream; two buffers keep the last
+    # gathered spectrum intact for the checks below)
+    loc = [device.DeviceArray((nloc,), ctx) for _ in range(2)]
+    full = [device.DeviceArray((nwno_total,), ctx) for _ in range(2)] if comm else None
     nstep = [0]
 
-    def step():
-        if use_nccl:
-            # The library's stream is torch's current stream (ExternalStream below).  The gather of
-            # spectrum i runs on RCCL's own stream after the kernel that produced it (async_op: the
-            # compute stream does not wait for it), so it overlaps the solve of spectrum i+1, which
-            # writes the other result buffer; a buffer is reused only after its previous gather has
-            # finished -- a device-side wait, no host synchronisation inside the timed loop.
-            b = nstep[0] & 1
-            nstep[0] += 1
-            if pending[b] is not None:
-                pending[b].wait()
-            resident.reflected_1d(ctx, nlevel, nwno, ng, 1, d, d["surf_reflect"], ubar0, ubar1,
-                                  cos_theta, d["F0PI"], 3, 0, *TTHG, xint, toon_coefficients=0,
-                                  b_top=0.0, gweight=gw, tweight=tw, albedo=alb_tt[b].data_ptr())
-            pending[b] = dist.all_gather_into_tensor(full_tt[b], alb_tt[b], async_op=True)   # RCCL over xGMI
-            return
-        resident.reflected_1d(ctx, nlevel, nwno, ng, 1, d, d["surf_reflect"], ubar0, ubar1,
-                              cos_theta, d["F0PI"], 3, 0, *TTHG, xint, toon_coefficients=0,
-                              b_top=0.0, gweight=gw, tweight=tw, albedo=albedo)
-        if launched:                                          # gloo smoke path: gather on the host
-            dist.all_gather_into_tensor(full_t, torch.from_numpy(alb_d.to_host()))
-
-    def drain():
-        if use_nccl:
-            for k in range(2):
-                if pending[k] is not None:
-                    pending[k].wait()
-                    pending[k] = None
+    def step(gather=True):
+        b = nstep[0] & 1
+        nstep[0] += 1
+        wl["solve"](loc[b])
+        if comm and gather:
+            comm.all_gather_spectrum(loc[b], full[b], nwno_total)
 
     def barrier():
         device.sync(ctx)
-        if launched:
-            if use_nccl:
-                torch.cuda.synchronize()
-            dist.barrier()
-            if use_nccl:
-                torch.cuda.synchronize()
+        if comm:
+            comm.barrier()
 
-    import contextlib
-    on_lib_stream = contextlib.nullcontext()
-    if use_nccl:
-        on_lib_stream = torch.cuda.stream(torch.cuda.ExternalStream(_lib.stream_ptr(ctx)))
-    with on_lib_stream:
-        for _ in range(args.warmup):
-            step()
-        drain()
-        barrier()
+    def timed(nsteps, gather=True):
         device.timer_start(ctx)
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        kernel_ms_total = device.timer_stop(ctx)              # HIP events on the kernel's stream
-        drain()                                               # every spectrum gathered ...
-        barrier()                                             # ... and every rank done
-        elapsed = time.perf_counter() - t0
-    if launched:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if use_nccl else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        for _ in range(nsteps):
+            step(gather)
+        return device.timer_stop(ctx) / nsteps
 
-    # ---- parity + CPU baseline on rank 0 (outside the timed region) ----
+    # ---- clock ramp (untimed), warm-up, timed region ----
+    t0 = time.perf_counter()
+    nprewarm = 0
+    while (time.perf_counter() - t0) * 1e3 < args.prewarm_ms:
+        for _ in range(20):
+            step()
+        nprewarm += 20
+        device.sync(ctx)
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    device.timer_start(ctx)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    stream_ms = device.timer_stop(ctx) / args.steps       # HIP events on the kernel's stream (solve + gather)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if comm:
+        elapsed = comm.max(elapsed)
+    last = (nstep[0] - 1) & 1
+    res_local = loc[last].to_host()
+    res_full = full[last].to_host() if comm else res_local
+
+    # ---- untimed: per-rank split of the step into solve and gather ----
+    kernel_ms = stream_ms
+    per_rank = None
+    if comm:
+        for _ in range(200):                # the copies above idled the GPU: back to steady clocks first
+            step()
+        kernel_ms = timed(args.steps, gather=False)
+        both_ms = timed(args.steps, gather=True)
+        info = json.dumps({"rank": rank, "nwno": nloc, "kernel_ms": kernel_ms,
+                           "gather_ms": max(both_ms - kernel_ms, 0.0)}).encode()
+        per_rank = [json.loads(b.decode()) for b in group.all_gather_bytes(info)]
+
     out = None
     if rank == 0:
-        if use_nccl:
-            last = (nstep[0] - 1) & 1
-            alb_t, full_t = alb_tt[last], full_tt[last]
-        alb_gpu = alb_t.cpu().numpy() if use_nccl else alb_d.to_host()
-        if launched:    # the gathered spectrum must contain this rank's shard bit-exactly
-            assert np.array_equal(full_t[:nwno].cpu().numpy(), alb_gpu), "all-gather mismatch"
+        # ---- parity: the gathered spectrum holds this rank's shard bit-exactly, and (strong scaling)
+        # equals the spectrum solved unsharded on this GPU bit for bit (SURVEY 7 test (v)) ----
+        checks = {}
+        if comm:
+            assert np.array_equal(res_full[lo:hi], res_local), "all-gather mismatch"
+            checks["gathered_contains_local_shard"] = True
+            if args.scaling == "strong" and args.config != 4:
+                wl1 = build(ctx, args, 0, nwno_total, seed, nwno_total)
+                one = device.DeviceArray((nwno_total,), ctx)
+                wl1["solve"](one)
+                device.sync(ctx)
+                same = bool(np.array_equal(one.to_host(), res_full))
+                assert same, "sharded spectrum differs from the unsharded one"
+                checks["bit_identical_to_unsharded"] = same
         ms_per_step = 1e3 * elapsed / args.steps
-        value = world * args.steps / elapsed
-        nang = ng
-        abytes = algorithmic_bytes(nwno, nlayer, nang)
-        kernel_ms = kernel_ms_total / args.steps
+        spectra_per_step = 1 if args.scaling == "strong" else world
+        value = spectra_per_step * args.steps / elapsed
+        abytes = wl["abytes"]
         achieved = abytes / (kernel_ms * 1e-3) / 1e9
         traffic = valu = None
         tfile = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tfile):
+        src_hash = kernel_source_hash()
+        if args.config == 2 and world == 1 and nwno == 100000 and args.nlayer == 90 and args.ngauss == 5 \
+                and os.path.exists(tfile):
             try:
                 prof = json.load(open(tfile))
-                traffic, valu = prof.get("hbm_bytes_per_launch"), prof.get("valu_wave_insts_per_launch")
+                if prof.get("kernel_source_hash") == src_hash:     # counters of THESE kernel sources only
+                    traffic, valu = prof.get("hbm_bytes_per_launch"), prof.get("valu_wave_insts_per_launch")
             except Exception:
                 traffic = valu = None
         out = {
-            "metric": "spectra/sec (1e5 wave x 90 layer reflected)",
+            "metric": wl["metric"] if args.config != 2 else "spectra/sec (1e5 wave x 90 layer reflected)",
             "value": value, "unit": "spectra/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[2]: Toon two-stream reflected light "
-                                   "(get_reflected_1d + compress_disco), TTHG_ray, N=2, "
-                                   "delta-Eddington, Rayleigh + cloud slab",
-                       "nwno_per_gpu": nwno, "nlayer": nlayer, "gauss_angles": ng,
-                       "sharding": "wavelength blocks, %d x %d" % (world, nwno),
-                       "collective": ("rccl all_gather of albedo shards" if use_nccl else
-                                      "gloo all_gather (smoke)") if launched else "none"},
-            "wavelength_layer_updates_per_s": value * nwno * nlayer,
+            "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": wl["workload"], "nwno": nwno_total, "nlayer": args.nlayer,
+                       "gauss_angles": args.ngauss if args.config != 4 else 64,
+                       "sharding": "%d contiguous wavelength block(s) of %s" % (
+                           world, "%d..%d" % (nwno_total // world, -(-nwno_total // world))),
+                       "collective": "RCCL all-gather of the albedo shards inside libpicaso_hip.so "
+                                     "(picaso_all_gather_dev), in the timed region" if comm else "none"},
+            "prewarm": {"ms": args.prewarm_ms, "launches": nprewarm, "why": "GPU clock ramp, untimed"},
+            "wavelength_layer_updates_per_s": value * nwno_total / spectra_per_step * args.nlayer,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "k_reflected_toa<%d,false>" % nang,
-                         "kernel_ms": kernel_ms, "algorithmic_bytes": abytes},
+                         "kernel": wl["kernel"], "kernel_ms": kernel_ms, "algorithmic_bytes": abytes,
+                         "kernel_source_hash": src_hash},
         }
-        if valu and nwno == 100000 and nlayer == 90 and ng == 5:
+        if per_rank:
+            out["per_rank"] = per_rank
+            out["checks"] = checks
+        if valu:
             # second ceiling: the kernel is FP64-VALU bound.  PMC instruction count of this launch shape
             # (profiles/) over the live kernel time, against the fp64 issue rate measured on an MI355X
             # with tools/ubench/f64_rates.hip (2.47 ns per wave64 instruction per SIMD, 1024 SIMDs)
@@ -216,75 +362,41 @@ def main():
             peak = 1024 * 64 / 2.47e-9 / 1e12
             out["fp64_issue"] = {"achieved": rate, "peak_measured": peak, "unit": "T lane-instr/s",
                                  "frac": rate / peak, "valu_wave_insts_per_launch": valu}
-        if world == 1 and not launched and args.pipelined:
-            # Not the headline: the same K spectra issued round-robin on two streams (two library
-            # contexts).  A 1e5-column spectrum is 1.5 waves per SIMD, so on one stream half the SIMDs
-            # idle through the tail of every launch; with a second spectrum in flight they do not.
-            # Per-kernel durations (what rocprofv3 reports) get longer, spectra per second go up.
-            ctx2 = _lib.new_context(dev)
-            x2, a2 = device.DeviceArray((ng, 1, nwno), ctx2), device.DeviceArray((nwno,), ctx2)
-            lanes = [(ctx, xint, alb_d), (ctx2, x2, a2)]
-
-            def step2(j):
-                c, xo, ao = lanes[j % 2]
-                resident.reflected_1d(c, nlevel, nwno, ng, 1, d, d["surf_reflect"], ubar0, ubar1, cos_theta,
-                                      d["F0PI"], 3, 0, *TTHG, xo, toon_coefficients=0, b_top=0.0, gweight=gw,
-                                      tweight=tw, albedo=ao)
-            for j in range(4):
-                step2(j)
-            device.sync(ctx); device.sync(ctx2)
-            t2 = time.perf_counter()
-            for j in range(args.steps):
-                step2(j)
-            device.sync(ctx); device.sync(ctx2)
-            e2 = time.perf_counter() - t2
-            assert np.array_equal(a2.to_host(), alb_gpu)
-            out["pipelined_2streams"] = {"value": args.steps / e2, "unit": "spectra/s",
-                                         "ms_per_step": 1e3 * e2 / args.steps,
-                                         "hbm_frac_throughput": abytes * args.steps / e2 / 1e9 / HBM_PEAK_GBS}
-        if world == 1 and args.cpu_sample > 0:
-            from oracle import oracle as orc
-            ns = min(args.cpu_sample, nwno)
-            sl = slice(0, ns)
-            planes = [np.ascontiguousarray(scene[k][:, sl]) for k in resident.REFLECTED_PLANES]
+        if world == 1 and args.cpu_sample > 0 and wl["oracle"] is not None:
+            ns = min(args.cpu_sample, nloc)
             t1 = time.perf_counter()
-            xo, _ = orc.get_reflected_1d(nlevel, scene["wno"][sl], ns, ng, 1, *planes, 0.0, ubar0,
-                                         ubar1, cos_theta, np.ones(ns), 3, 0, *TTHG)
-            alb_cpu = orc.compress_disco(ns, cos_theta, xo, gw, tw, np.ones(ns))
+            cpu = wl["oracle"](slice(0, ns))
             cpu_s = time.perf_counter() - t1
-            err = float(np.max(np.abs(alb_gpu[sl] - alb_cpu) / np.abs(alb_cpu)))
+            err = float(np.max(np.abs(res_local[:ns] - cpu) / np.abs(cpu)))
+            ncores = len(os.sched_getaffinity(0))
             out["cpu_baseline"] = {
-                "value": (ns / nwno) / cpu_s, "unit": "spectra/s", "cores": 1, "kind": "port",
-                "sample": "%d of %d wavelengths of the same scene, oracle/picaso_oracle.c "
-                          "(single-thread C restatement of the reference's serial numba path), "
-                          "%.1f s" % (ns, nwno, cpu_s),
-                "host_cores_available": len(os.sched_getaffinity(0))}
+                "value": (ns / nwno_total) / cpu_s, "unit": "spectra/s", "cores": 1, "kind": "port",
+                "sample": "%d of %d wavelengths of the same scene, oracle/ C restatement of the reference's "
+                          "serial numba path on one core, %.1f s" % (ns, nwno_total, cpu_s),
+                "host_cores_available": ncores}
             out["max_rel_err_vs_oracle"] = err
-            # the same C restatement on many host cores: wavelength blocks on a thread pool (the
-            # ctypes calls release the GIL; the reference itself is serial, so this is an upper bound on
-            # what its algorithm could do on this host, not a measurement of the reference)
+            # the same C restatement on ALL host cores: wavelength blocks on a thread pool (the ctypes
+            # calls release the GIL; the reference itself is serial, so this is an upper bound on what
+            # its algorithm could do on this host, not a measurement of the reference)
             from concurrent.futures import ThreadPoolExecutor
-            nthr = min(64, len(os.sched_getaffinity(0)))
+            nthr = max(1, ncores)
             if nthr > 1:
                 edges = np.linspace(0, ns, nthr + 1).astype(int)
-
-                def work(j):
-                    a_, b_ = edges[j], edges[j + 1]
-                    pl = [np.ascontiguousarray(scene[k][:, a_:b_]) for k in resident.REFLECTED_PLANES]
-                    x_, _ = orc.get_reflected_1d(nlevel, scene["wno"][a_:b_], b_ - a_, ng, 1, *pl, 0.0, ubar0,
-                                                 ubar1, cos_theta, np.ones(b_ - a_), 3, 0, *TTHG)
-                    return orc.compress_disco(b_ - a_, cos_theta, x_, gw, tw, np.ones(b_ - a_))
                 t1 = time.perf_counter()
                 with ThreadPoolExecutor(nthr) as ex:
-                    parts = list(ex.map(work, range(nthr)))
+                    parts = list(ex.map(lambda j: wl["oracle"](slice(int(edges[j]), int(edges[j + 1]))),
+                                        [j for j in range(nthr) if edges[j + 1] > edges[j]]))
                 thr_s = time.perf_counter() - t1
-                assert np.array_equal(np.concatenate(parts), alb_cpu)
-                out["cpu_baseline_threads"] = {"value": (ns / nwno) / thr_s, "unit": "spectra/s", "cores": nthr,
-                                               "kind": "port", "sample": "same sample, %d wavelength blocks on "
-                                               "%d threads, %.2f s" % (nthr, nthr, thr_s)}
+                assert np.array_equal(np.concatenate(parts), cpu)
+                out["cpu_baseline_threads"] = {
+                    "value": (ns / nwno_total) / thr_s, "unit": "spectra/s", "cores": nthr, "kind": "port",
+                    "sample": "same sample, %d wavelength blocks on %d threads (all host cores), %.2f s"
+                              % (nthr, nthr, thr_s)}
         print(json.dumps(out), flush=True)
-    if launched:
-        dist.destroy_process_group()
+    if comm:
+        comm.barrier()
+        comm.destroy()
+        group.close()
 
 
 if __name__ == "__main__":

@@ -68,8 +68,35 @@ int picaso_ctx_device(picaso_ctx *ctx, int *device);
 /* HIP-event timing on the context's own stream (the stream every kernel here is launched on) */
 int picaso_timer_start(picaso_ctx *ctx);
 int picaso_timer_stop(picaso_ctx *ctx, float *elapsed_ms);
-/* raw hipStream_t of the context (for callers that interleave their own work, e.g. RCCL) */
+/* raw hipStream_t of the context (for callers that interleave their own work on it) */
 void *picaso_stream(picaso_ctx *ctx);
+
+/* ---- multi-GPU: wavelength shards gathered with RCCL over xGMI -------------------------------
+ * Replaces the reference's process fan-out (joblib.Parallel over independent spectra, reference
+ * picaso/justdoit.py:4774): here ONE spectrum is cut into contiguous wavelength blocks, one per GPU;
+ * the solve needs no exchange and the only collective is the all-gather of the result shards.
+ *  - one process per GPU: rank 0 calls picaso_comm_unique_id and hands the 128 bytes to the other
+ *    ranks through any side channel (picaso_amd/sharding.py: a TCP socket), every rank then calls
+ *    picaso_comm_init_rank with its own context;
+ *  - one process, several GPUs: picaso_comm_init_all(ndev, ctxs, comms) (ncclCommInitAll).
+ * Collectives take DEVICE pointers and are enqueued on the context's stream behind the kernels that
+ * produced their input (no host synchronisation); picaso_comm_max / _sum / _barrier move one host
+ * double and synchronise (timing reductions of a launcher). */
+#define PICASO_COMM_ID_BYTES 128
+typedef struct picaso_comm picaso_comm;
+int picaso_comm_unique_id(void *id128);
+int picaso_comm_init_rank(picaso_ctx *ctx, int nranks, int rank, const void *id128, picaso_comm **out);
+int picaso_comm_init_all(int ndev, picaso_ctx *const *ctxs, picaso_comm **out);
+void picaso_comm_destroy(picaso_comm *comm);
+int picaso_comm_rank(const picaso_comm *comm, int *rank, int *nranks);
+/* recv[r*count + i] = rank r's send[i] */
+int picaso_all_gather_dev(picaso_comm *comm, const double *send, double *recv, size_t count);
+/* ragged shards: rank r's counts[r] elements land at recv + displs[r] on every rank */
+int picaso_all_gatherv_dev(picaso_comm *comm, const double *send, double *recv, const size_t *counts,
+                           const size_t *displs);
+int picaso_comm_max(picaso_comm *comm, double *value);
+int picaso_comm_sum(picaso_comm *comm, double *value);
+int picaso_comm_barrier(picaso_comm *comm);
 
 /* ---- Toon89 two-stream reflected light ---------------------------------------------------- */
 /* replaces fluxes.get_reflected_1d (reference picaso/fluxes.py:1009-1413).

@@ -30,22 +30,6 @@ def declared_symbols():
     return sorted(set(re.findall(r"\b(picaso_[A-Za-z0-9_]+)\s*\(", text)))
 
 
-def _share_hip_runtime_with_torch():
-    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own ``libamdhip64.so``
-    (SONAME libamdhip64.so.7, the SONAME this library links against); two copies of the runtime in
-    one process cannot both own the GPUs (the second reports "No HIP GPUs are available").  When
-    torch is already imported -- the multi-GPU launcher uses ``torch.distributed`` for RCCL -- make
-    sure its runtime is the one mapped first, so that the dynamic loader resolves our dependency to
-    that same copy.  Processes that never import torch use the system ROCm runtime."""
-    import sys
-    torch = sys.modules.get("torch")
-    if torch is None or getattr(getattr(torch, "version", None), "hip", None) is None:
-        return
-    bundled = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
-    if os.path.exists(bundled):
-        ctypes.CDLL(bundled, mode=ctypes.RTLD_GLOBAL)
-
-
 def load():
     """Load the shared library (no GPU needed for this step)."""
     global _lib
@@ -55,7 +39,6 @@ def load():
         raise PicasoHipError(
             "picaso_amd: %s not found -- build it with `python -c 'import __graft_entry__ as g; "
             "g.build()'` (hipcc, gfx950).  There is no CPU fallback." % LIB_PATH)
-    _share_hip_runtime_with_torch()
     lib = ctypes.CDLL(LIB_PATH)
     lib.picaso_last_error.restype = ctypes.c_char_p
     lib.picaso_last_error.argtypes = [ctypes.c_void_p]
@@ -73,8 +56,7 @@ def check(rc, ctx=None):
 
 
 def stream_ptr(ctx):
-    """The hipStream_t all of this context's kernels run on, as an integer (e.g. for
-    ``torch.cuda.ExternalStream``)."""
+    """The hipStream_t all of this context's kernels run on, as an integer."""
     return int(load().picaso_stream(ctx))
 
 

@@ -49,7 +49,9 @@ def build(force=False, verbose=False):
             raise RuntimeError("hipcc failed on %s" % src)
         if verbose and out:
             print(out.decode())
-    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
+    # librccl.so: the multi-GPU layer (csrc/comm.hip) calls RCCL directly
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs +
+                          ["-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"])
     return LIB
 
 

@@ -358,7 +358,7 @@ void *picaso_stream(picaso_ctx *ctx) { return (void *)ctx->stream; }
 /* ============================================================================================
  * reflected light
  * ============================================================================================ */
-static ReflectedArgs::Angle make_refl_angle(double v0, double v1, double wgt)
+static ReflectedArgs::Angle make_refl_angle(double v0, double v1, double gw, double tw = 0.0)
 {
     const double NL2E = -1.4426950408889634074;
     ReflectedArgs::Angle g;
@@ -369,7 +369,8 @@ static ReflectedArgs::Angle make_refl_angle(double v0, double v1, double wgt)
     g.nlm = NL2E * (1.0 / v0 + 1.0 / v1);
     g.wq2 = 2.0 * (v0 / (v0 + v1));
     g.q2 = (3.0 * 0.767 * 0.767 * v1 * v1 - 1.0) / 2.0;   // ubar2 = 0.767 (fluxes.py:1280)
-    g.wgt = wgt;
+    g.wgt = gw;
+    g.wgt2 = tw;
     return g;
 }
 
@@ -466,7 +467,7 @@ static int reflected_1d_core(picaso_ctx *ctx, int nlevel, int nwno, int ncolper,
         for (int k = 0; k < a.na; ++k) {
             const int idx = done + k;
             const double v0 = ubar0[idx], v1 = ubar1[idx];
-            a.ang[k] = make_refl_angle(v0, v1, fuse ? gweight[idx / numt] * tweight[idx % numt] : 0.0);
+            a.ang[k] = make_refl_angle(v0, v1, fuse ? gweight[idx / numt] : 0.0, fuse ? tweight[idx % numt] : 0.0);
         }
         a.xint = xint_at_top + (size_t)done * ncol;
         a.albedo_first = (c == 0);
@@ -753,7 +754,7 @@ static int thermal_1d_core(picaso_ctx *ctx, int nlevel, const double *wno, int n
         a.disk = nullptr;
         while (done < nang) {
             const int m = (nang - done < MAX_ANGLES) ? nang - done : MAX_ANGLES;
-            for (int k = 0; k < m; ++k) { a.u1[k] = ubar1[done + k]; a.wgt[k] = 0.0; }
+            for (int k = 0; k < m; ++k) { a.u1[k] = ubar1[done + k]; a.wgt[k] = a.wgt2[k] = 0.0; }
             a.ny = m;
             a.flux = flux_at_top + (size_t)done * ncol;
             PZ_TRY(launch_thermal_toa(ctx, a, false));
@@ -770,7 +771,8 @@ static int thermal_1d_core(picaso_ctx *ctx, int nlevel, const double *wno, int n
         for (int k = 0; k < a.na; ++k) {
             const int idx = done + k;
             a.u1[k] = ubar1[idx];
-            a.wgt[k] = fuse ? gweight[idx / numt] * tweight[idx % numt] : 0.0;
+            a.wgt[k] = fuse ? gweight[idx / numt] : 0.0;
+            a.wgt2[k] = fuse ? tweight[idx % numt] : 0.0;
         }
         a.flux = flux_at_top + (size_t)done * ncol;
         a.disk_first = (c == 0);

@@ -113,10 +113,10 @@ struct ReflectedArgs {
     int ny;            // grid.y: angle groups of `na` running as separate waves (small problems)
     struct Angle {
         double u1, iu0, iu0sq, nl1, q2;     // used by the symmetric-geometry (ubar0 == ubar1) kernel
-        double u0, nl0, nlm, wq2, wgt;
+        double u0, nl0, nlm, wq2, wgt, wgt2;
         // iu0sq = 1/(u0 u0) as the reference forms it (fluxes.py:1155); nl0/nl1/nlm = -log2(e)/u0,
         // -log2(e)/u1, -log2(e)(1/u0 + 1/u1): exp(-x/u) = 2^(x nl); wq2 = 2 u0/(u0+u1);
-        // q2 = (3 ubar2^2 u1^2 - 1)/2, ubar2 = 0.767 (fluxes.py:1280); wgt = gweight*tweight
+        // q2 = (3 ubar2^2 u1^2 - 1)/2, ubar2 = 0.767 (fluxes.py:1280); wgt, wgt2 = gweight[g], tweight[t]
     } ang[MAX_ANGLES];
     const double *u0_tab, *u1_tab;          // 3-D
     double *xint;                           // 1-D: this launch's first angle row, (na, nwno); 3-D: (nfac, nwno)
@@ -143,7 +143,7 @@ struct ThermalArgs {
     const double *surf_reflect;
     int hard_surface, calc_type;
     int na, ny;                             // angles per lane, angle groups in grid.y (see ReflectedArgs)
-    double u1[MAX_ANGLES], wgt[MAX_ANGLES];
+    double u1[MAX_ANGLES], wgt[MAX_ANGLES], wgt2[MAX_ANGLES];   // wgt = gweight[g], wgt2 = tweight[t]
     const double *u1_tab;                   // 3-D
     double *flux;                           // (na,nwno) / (nfac,nwno)
     double *disk;                           // nullable fused compress_thermal accumulator

@@ -99,6 +99,7 @@ struct Exp2Coef {
 };
 __device__ __forceinline__ double fexp2(double t, const Exp2Coef &K)
 {
+#pragma clang fp contract(off)
     const double n = __builtin_rint(t);
     const double f = t - n;
     double p = fma(K.c[10], f, K.c[9]);
@@ -120,6 +121,7 @@ __device__ __forceinline__ double fexp2_cold(double t, const Exp2Coef &K)
 // (a correctly rounded a/b costs 11 with div_scale/div_fmas/div_fixup).
 __device__ __forceinline__ double frcp(double b)
 {
+#pragma clang fp contract(off)
     double y = __builtin_amdgcn_rcp(b);
     double e = fma(-b, y, 1.0);
     y = fma(y, e, y);
@@ -152,21 +154,46 @@ __device__ __forceinline__ void toon_gammas(int toon_coefficients, double w0, do
     lam2 = lam * lam;
 }
 
+// toon_gammas with ftau_cld*cosb = +0 folded by hand: 1 + 0 = 1, w0 * 1 = w0, 4 + 0 = 4 exactly, so
+// the values are bit-identical to toon_gammas(.., fcg = 0, ..)
+__device__ __forceinline__ void toon_gammas_nocld(int toon_coefficients, double w0, double &g1, double &g2,
+                                                  double &lam, double &lam2)
+{
+#pragma clang fp contract(off)
+    if (toon_coefficients == 1) {
+        g1 = (7.0 - w0 * 4.0) / 4.0;
+        g2 = -(1.0 - w0 * 4.0) / 4.0;
+    } else {
+        g1 = (SQ3 * 0.5) * (2.0 - w0);
+        g2 = SQ3 * w0 * 0.5;
+    }
+    const double a = g1 * g1;
+    const double b = g2 * g2;
+    lam = sqrt(a - b);
+    lam2 = lam * lam;
+}
+
 __device__ __forceinline__ double sub_unfused(double a, double b)
 {
 #pragma clang fp contract(off)
     return a - b;
+}
+__device__ __forceinline__ double mul_unfused(double a, double b)
+{
+#pragma clang fp contract(off)
+    return a * b;
 }
 
 // 1/sqrt(x) to ~1 ulp: v_rsq_f64 + two Newton steps (y <- y + y*(0.5 - 0.5 x y^2)), 9 instructions
 // versus ~31 for sqrt() followed by a correctly rounded divide.
 __device__ __forceinline__ double frsq(double x)
 {
+#pragma clang fp contract(off)
     double y = __builtin_amdgcn_rsq(x);
     const double hx = 0.5 * x;
-    double e = fma(-hx * y, y, 0.5);
+    double e = fma(-(hx * y), y, 0.5);
     y = fma(y, e, y);
-    e = fma(-hx * y, y, 0.5);
+    e = fma(-(hx * y), y, 0.5);
     y = fma(y, e, y);
     return y;
 }
@@ -175,13 +202,15 @@ __device__ __forceinline__ double frsq(double x)
 // (1-g^2)/sqrt((1+g^2+2 g cos_theta)^3)   (reference picaso/fluxes.py:1308-1317)
 __device__ __forceinline__ double hg_term(double g, double ct)
 {
-    const double b = 1.0 + g * g + 2.0 * g * ct;
-    return (1.0 - g * g) * frsq(b * b * b);
+#pragma clang fp contract(off)
+    const double b = fma(2.0 * g, ct, fma(g, g, 1.0));
+    return fma(-g, g, 1.0) * frsq((b * b) * b);
 }
 
 // x**c with the common exponent 2 (config default TTHG fraction 1 - g_back^2) kept cheap.
 __device__ __forceinline__ double pow_frac(double x, double c)
 {
+#pragma clang fp contract(off)
     return (c == 2.0) ? x * x : pow(x, c);
 }
 
@@ -194,17 +223,19 @@ __device__ __forceinline__ double p_single(int single_phase, double cosb_og, dou
                                            double frac_a, double frac_b, double frac_c,
                                            double constant_back, double constant_forward)
 {
+    // operations written out (explicit fma, no contraction): see reflected_layer
+#pragma clang fp contract(off)
     if (single_phase == 1) return hg_term(cosb_og, ct);
     const double gf = constant_forward * cosb_og;
     const double gb = constant_back * cosb_og;
-    const double f = frac_a + frac_b * pow_frac(gb, frac_c);
+    const double f = fma(frac_b, pow_frac(gb, frac_c), frac_a);
     if (single_phase == 0) {
-        if (!IS3D) return f * hg_term(gf, ct) + (1.0 - f) * hg_term(gb, ct) + gcos2;
-        const double b1 = 1.0 + cosb_og * cosb_og + 2.0 * cosb_og * ct;
+        if (!IS3D) return fma(1.0 - f, hg_term(gb, ct), fma(f, hg_term(gf, ct), gcos2));
+        const double b1 = fma(2.0 * cosb_og, ct, fma(cosb_og, cosb_og, 1.0));
         const double hb = -cosb_og / 2.0;
-        const double b2 = 1.0 + hb * hb + 2.0 * hb * ct;
-        return f * (1.0 - gf * gf) * frsq(b1 * b1 * b1) +
-               (1.0 - f) * (1.0 - gb * gb) * frsq(b2 * b2 * b2) + gcos2;
+        const double b2 = fma(2.0 * hb, ct, fma(hb, hb, 1.0));
+        return fma((1.0 - f) * fma(-gb, gb, 1.0), frsq((b2 * b2) * b2),
+                   fma(f * fma(-gf, gf, 1.0), frsq((b1 * b1) * b1), gcos2));
     }
     double tthg;
     if (!IS3D && ct == 1.0) {
@@ -213,12 +244,12 @@ __device__ __forceinline__ double p_single(int single_phase, double cosb_og, dou
         const double pf = 1.0 + gf, pb = 1.0 + gb;
         const double qf = pf * pf, qb = pb * pb;
         const double r = frcp(qf * qb);
-        tthg = (f * (1.0 - gf) * qb + (1.0 - f) * (1.0 - gb) * qf) * r;
+        tthg = fma((1.0 - f) * (1.0 - gb), qf, (f * (1.0 - gf)) * qb) * r;
     } else {
-        tthg = f * hg_term(gf, ct) + (1.0 - f) * hg_term(gb, ct);
+        tthg = fma(1.0 - f, hg_term(gb, ct), f * hg_term(gf, ct));
     }
     if (single_phase == 2) return tthg;
-    return ftau_cld * tthg + ftau_ray * (0.75 * (1.0 + ct * ct));
+    return fma(ftau_cld, tthg, ftau_ray * (0.75 * fma(ct, ct, 1.0)));
 }
 
 constexpr double LOG2E_D = 1.4426950408889634074;

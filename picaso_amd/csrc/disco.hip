@@ -15,7 +15,10 @@ __global__ __launch_bounds__(256) void k_compress(size_t ninner, const double *_
     const size_t w = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (w >= ninner) return;
     double acc = 0.0;
-    for (int k = 0; k < nang; ++k) acc = acc + x[(size_t)k * ninner + w] * wts[2 * k] * wts[2 * k + 1];
+    {
+#pragma clang fp contract(off)
+        for (int k = 0; k < nang; ++k) acc = acc + x[(size_t)k * ninner + w] * wts[2 * k] * wts[2 * k + 1];
+    }
     // compress_disco: sym_fac*0.5*albedo/F0PI*(cos_theta+1)   (disco.py:148)
     // compress_thermal: flux*sym_fac                          (disco.py:181)
     out[w] = F0PI ? c1 * acc / F0PI[w] * c2 : acc * c1;

@@ -178,7 +178,11 @@ __global__ __launch_bounds__(256) void k_thermal_toa(const ThermalArgs a)
         const double x = kappa[k] + zeta[k] * pos;
         if (IS3D) a.flux[(long)fac * a.nwno + w] = x;
         else a.flux[(long)(blockIdx.y * NA + k) * a.ncol + col] = x;
-        disk = disk + x * a.wgt[IS3D ? 0 : blockIdx.y * NA + k];
+        {   // flux + x*gweight*tweight in the reference's order, unfused (disco.py:174-176), as k_compress
+#pragma clang fp contract(off)
+            const int ia = IS3D ? 0 : blockIdx.y * NA + k;
+            disk = disk + x * a.wgt[ia] * a.wgt2[ia];
+        }
     }
     if (!IS3D && a.disk) {                                     // fused disco.compress_thermal
         double acc = a.disk_first ? disk : a.disk[w] + disk;

@@ -43,7 +43,7 @@ def reflected_1d(ctx, nlevel, nwno, numg, numt, planes, surf_reflect, ubar0, uba
                  tweight=None, albedo=None, plane_pitch=None):
     """Asynchronous ``get_reflected_1d`` on resident planes (+ optional fused ``compress_disco``).
     ``planes`` maps the 11 reference plane names to DeviceArrays; outputs are DeviceArrays (or raw
-    device addresses, e.g. ``torch_tensor.data_ptr()``)."""
+    device addresses)."""
     u0, u1 = f64(ubar0, (numg, numt)), f64(ubar1, (numg, numt))
     gw = f64(gweight) if gweight is not None else None
     tw = f64(tweight) if tweight is not None else None
@@ -177,6 +177,31 @@ def compress_thermal(ctx, ninner, flux_at_top, gweight, tweight, flux):
     gw, tw = f64(gweight), f64(tweight)
     check(load().picaso_compress_thermal_dev(ctx, ctypes.c_size_t(ninner), _addr(flux_at_top), ptr(gw),
                                              _ci(gw.size), ptr(tw), _ci(tw.size), _addr(flux)), ctx)
+
+
+SH_PLANES = ("dtau", "tau", "w0", "cosb", "ftau_cld", "ftau_ray", "f_deltaM", "dtau_og", "tau_og", "w0_og",
+             "cosb_og")
+
+
+def reflected_SH(ctx, nlevel, nwno, numg, numt, planes, surf_reflect, ubar0, ubar1, cos_theta, F0PI,
+                 w_single_form, w_multi_form, psingle_form, w_single_rayleigh, w_multi_rayleigh,
+                 psingle_rayleigh, frac_a, frac_b, frac_c, constant_back, constant_forward, stream,
+                 xint_at_top, b_top=0.0, single_form=0, compound_f_deltaM=True, gweight=None, tweight=None,
+                 albedo=None, plane_pitch=None):
+    """Asynchronous ``get_reflected_SH`` (``flx=0``) on resident planes (+ optional fused
+    ``compress_disco``); ``planes`` maps ``SH_PLANES`` to DeviceArrays."""
+    u0, u1 = f64(ubar0, (numg, numt)), f64(ubar1, (numg, numt))
+    gw = f64(gweight) if gweight is not None else None
+    tw = f64(tweight) if tweight is not None else None
+    pitch = nwno if plane_pitch is None else plane_pitch
+    check(load().picaso_get_reflected_SH_dev(
+        ctx, _ci(nlevel), _ci(nwno), ctypes.c_long(pitch), _ci(numg), _ci(numt),
+        *[_addr(planes[k]) for k in SH_PLANES], _addr(surf_reflect), ptr(u0), ptr(u1), _cd(cos_theta),
+        _addr(F0PI), _ci(int(w_single_form)), _ci(int(w_multi_form)), _ci(int(psingle_form)),
+        _ci(int(w_single_rayleigh)), _ci(int(w_multi_rayleigh)), _ci(int(psingle_rayleigh)), _cd(frac_a),
+        _cd(frac_b), _cd(frac_c), _cd(constant_back), _cd(constant_forward), _ci(int(stream)), _cd(b_top),
+        _ci(0), _ci(int(single_form)), _ci(1 if compound_f_deltaM else 0), _addr(xint_at_top), None,
+        ptr(gw) if gw is not None else None, ptr(tw) if tw is not None else None, _addr(albedo)), ctx)
 
 
 def reflected_3d(ctx, nlevel, nwno, numg, numt, planes, surf_reflect, ubar0, ubar1, cos_theta, F0PI,

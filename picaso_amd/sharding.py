@@ -1,15 +1,29 @@
-"""Wavelength sharding across the GPUs of one node (one process per GPU).
+"""Wavelength sharding across the GPUs of one node (one process per GPU, or one process driving
+several GPUs).
 
-Every function on the hot path is pointwise in wavelength, so the grid is cut
-into contiguous blocks, one per rank, with no exchange inside the solve; the only collective is
-the all-gather of the final spectrum shards (RCCL over xGMI when the backend is "nccl", gloo in
-the CPU tests).  Pure host logic: usable without a GPU.
+Every function on the hot path is pointwise in wavelength, so the grid of ONE
+spectrum is cut into contiguous blocks, one per rank, with no exchange inside the solve; the only
+collective is the all-gather of the final spectrum shards, which runs inside ``libpicaso_hip.so``
+(RCCL over xGMI, ``csrc/comm.hip``) on the context's own stream.  Replaces the reference's joblib
+fan-out of independent spectra (reference ``justdoit.py:4774``).
 
-One HIP runtime per process: PyTorch-ROCm wheels bundle their own ``libamdhip64``; import torch (and
-select the device) BEFORE the first ``picaso_amd`` call in a process that uses both, as ``bench.py``
-does -- ``picaso_amd._lib`` then binds ``libpicaso_hip.so`` to the runtime torch has mapped.
+No PyTorch, no MPI: the 128-byte RCCL id travels from rank 0 to the other ranks over a plain TCP
+socket (``HostGroup``), using the ``RANK`` / ``WORLD_SIZE`` / ``MASTER_ADDR`` / ``MASTER_PORT``
+environment the one-process-per-GPU launcher provides.  ``HostGroup`` also
+carries small host-side collectives (bytes broadcast, array all-gather), which is what the CPU tests
+of the sharded path use.
 """
+import ctypes
+import os
+import socket
+import struct
+import time
+
 import numpy as np
+
+from . import _lib
+
+COMM_ID_BYTES = 128
 
 
 def shard_bounds(nwno, world):
@@ -27,23 +41,209 @@ def shard_of(nwno, world, rank):
     return shard_bounds(nwno, world)[rank]
 
 
-def all_gather_spectrum(local, nwno, dist=None, group=None):
-    """Gather per-rank spectrum shards (last axis = wavelength) into the full spectrum on every
-    rank.  `local` is a numpy array (gloo / single process) or a torch tensor on the rank's GPU
-    (nccl).  Ragged shards are padded to the largest shard for the collective and trimmed after."""
-    if dist is None or not dist.is_initialized() or dist.get_world_size(group) == 1:
-        return local
-    import torch
-    world = dist.get_world_size(group)
-    bounds = shard_bounds(nwno, world)
-    nmax = max(hi - lo for lo, hi in bounds)
-    is_np = isinstance(local, np.ndarray)
-    t = torch.from_numpy(np.ascontiguousarray(local)) if is_np else local
-    lead = tuple(t.shape[:-1])
-    pad = torch.zeros(lead + (nmax,), dtype=t.dtype, device=t.device)
-    pad[..., : t.shape[-1]] = t
-    out = [torch.empty_like(pad) for _ in range(world)]
-    dist.all_gather(out, pad.contiguous(), group=group)
-    pieces = [out[r][..., : hi - lo] for r, (lo, hi) in enumerate(bounds)]
-    full = torch.cat(pieces, dim=-1)
-    return full.numpy() if is_np else full
+def launcher_env():
+    """(rank, world, local_rank, addr, port) from the launcher's environment (1 process: 0, 1, 0)."""
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", str(rank)))
+    addr = os.environ.get("MASTER_ADDR", "127.0.0.1")
+    # the launcher's own store listens on MASTER_PORT: take a fixed offset from it
+    port = int(os.environ.get("PICASO_AMD_RDZV_PORT", str(int(os.environ.get("MASTER_PORT", "29500")) + 37)))
+    return rank, world, local, addr, port
+
+
+# ---------------------------------------------------------------------------------------------
+# host side channel: a star over TCP with rank 0 in the middle
+# ---------------------------------------------------------------------------------------------
+def _send_msg(sock, payload):
+    sock.sendall(struct.pack("<Q", len(payload)) + payload)
+
+
+def _recv_exact(sock, n):
+    buf = bytearray()
+    while len(buf) < n:
+        chunk = sock.recv(n - len(buf))
+        if not chunk:
+            raise ConnectionError("picaso_amd.sharding: peer closed the rendezvous socket")
+        buf.extend(chunk)
+    return bytes(buf)
+
+
+def _recv_msg(sock):
+    (n,) = struct.unpack("<Q", _recv_exact(sock, 8))
+    return _recv_exact(sock, n)
+
+
+class HostGroup:
+    """Rank 0 listens on (addr, port); ranks 1..world-1 connect and identify themselves.  Small
+    host-side collectives only: the spectra themselves never travel through here on a GPU run."""
+
+    def __init__(self, rank, world, addr="127.0.0.1", port=29537, timeout=120.0):
+        self.rank, self.world = int(rank), int(world)
+        self.peers = {}          # rank 0: rank -> socket
+        self.sock = None         # other ranks: socket to rank 0
+        if self.world == 1:
+            return
+        if self.rank == 0:
+            srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+            srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+            srv.bind((addr, port))
+            srv.listen(self.world)
+            srv.settimeout(timeout)
+            while len(self.peers) < self.world - 1:
+                conn, _ = srv.accept()
+                conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                (r,) = struct.unpack("<i", _recv_exact(conn, 4))
+                if r <= 0 or r >= self.world or r in self.peers:
+                    raise RuntimeError("picaso_amd.sharding: unexpected rank %d at the rendezvous" % r)
+                self.peers[r] = conn
+            srv.close()
+        else:
+            t0 = time.time()
+            while True:
+                try:
+                    s = socket.create_connection((addr, port), timeout=5.0)
+                    break
+                except OSError:
+                    if time.time() - t0 > timeout:
+                        raise
+                    time.sleep(0.05)
+            s.settimeout(timeout)
+            s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+            s.sendall(struct.pack("<i", self.rank))
+            self.sock = s
+
+    def broadcast(self, payload=None):
+        """bytes of rank 0 on every rank"""
+        if self.world == 1:
+            return payload
+        if self.rank == 0:
+            for r in sorted(self.peers):
+                _send_msg(self.peers[r], payload)
+            return payload
+        return _recv_msg(self.sock)
+
+    def gather(self, payload):
+        """list of every rank's bytes on rank 0 (None elsewhere)"""
+        if self.world == 1:
+            return [payload]
+        if self.rank == 0:
+            out = [payload] + [None] * (self.world - 1)
+            for r in sorted(self.peers):
+                out[r] = _recv_msg(self.peers[r])
+            return out
+        _send_msg(self.sock, payload)
+        return None
+
+    def all_gather_bytes(self, payload):
+        parts = self.gather(payload)
+        blob = None
+        if self.rank == 0:
+            blob = b"".join(struct.pack("<Q", len(p)) + p for p in parts)
+        blob = self.broadcast(blob)
+        out, o = [], 0
+        for _ in range(self.world):
+            (n,) = struct.unpack_from("<Q", blob, o)
+            out.append(blob[o + 8:o + 8 + n])
+            o += 8 + n
+        return out
+
+    def barrier(self):
+        self.all_gather_bytes(b"")
+
+    def max(self, value):
+        vals = [struct.unpack("<d", b)[0] for b in self.all_gather_bytes(struct.pack("<d", float(value)))]
+        return max(vals)
+
+    def all_gather_spectrum(self, local, nwno):
+        """Host arrays: per-rank shards (last axis = this rank's wavelength block) -> full spectrum."""
+        local = np.ascontiguousarray(local, dtype=np.float64)
+        bounds = shard_bounds(nwno, self.world)
+        lo, hi = bounds[self.rank]
+        if local.shape[-1] != hi - lo:
+            raise ValueError("rank %d holds %d wavelengths, its block is [%d, %d)" % (self.rank, local.shape[-1], lo, hi))
+        parts = self.all_gather_bytes(local.tobytes())
+        lead = local.shape[:-1]
+        pieces = [np.frombuffer(p, dtype=np.float64).reshape(lead + (b[1] - b[0],)) for p, b in zip(parts, bounds)]
+        return np.concatenate(pieces, axis=-1)
+
+    def close(self):
+        for s in self.peers.values():
+            s.close()
+        if self.sock is not None:
+            self.sock.close()
+        self.peers, self.sock = {}, None
+
+
+# ---------------------------------------------------------------------------------------------
+# device collectives: RCCL inside the library
+# ---------------------------------------------------------------------------------------------
+def _addr(x):
+    return ctypes.c_void_p(int(x.addr if hasattr(x, "addr") else x))
+
+
+class Comm:
+    """RCCL communicator of the library bound to one context (one GPU).  ``Comm.from_launcher`` is the
+    one-process-per-GPU form; ``Comm.init_all`` the single-process form."""
+
+    def __init__(self, handle, ctx, rank, world, group=None):
+        self.handle, self.ctx, self.rank, self.world, self.group = handle, ctx, rank, world, group
+
+    @classmethod
+    def from_launcher(cls, ctx, group):
+        """Every rank calls this with its context and the HostGroup it shares with the others."""
+        lib = _lib.load()
+        uid = None
+        if group.rank == 0:
+            buf = ctypes.create_string_buffer(COMM_ID_BYTES)
+            _lib.check(lib.picaso_comm_unique_id(buf), None)
+            uid = buf.raw
+        uid = group.broadcast(uid)
+        if uid is None or len(uid) != COMM_ID_BYTES:
+            raise _lib.PicasoHipError("picaso_amd.sharding: bad RCCL id at the rendezvous")
+        h = ctypes.c_void_p()
+        _lib.check(lib.picaso_comm_init_rank(ctx, ctypes.c_int(group.world), ctypes.c_int(group.rank),
+                                             ctypes.c_char_p(uid), ctypes.byref(h)), ctx)
+        return cls(h, ctx, group.rank, group.world, group)
+
+    @classmethod
+    def init_all(cls, ctxs):
+        lib = _lib.load()
+        n = len(ctxs)
+        arr = (ctypes.c_void_p * n)(*[c.value if hasattr(c, "value") else c for c in ctxs])
+        out = (ctypes.c_void_p * n)()
+        _lib.check(lib.picaso_comm_init_all(ctypes.c_int(n), arr, out), ctxs[0])
+        return [cls(ctypes.c_void_p(out[i]), ctxs[i], i, n) for i in range(n)]
+
+    def all_gather(self, send, recv, count):
+        """recv[r*count + i] = rank r's send[i] (device buffers; asynchronous on the context's stream)"""
+        _lib.check(_lib.load().picaso_all_gather_dev(self.handle, _addr(send), _addr(recv),
+                                                     ctypes.c_size_t(int(count))), self.ctx)
+
+    def all_gatherv(self, send, recv, counts, displs):
+        c = (ctypes.c_size_t * self.world)(*[int(x) for x in counts])
+        d = (ctypes.c_size_t * self.world)(*[int(x) for x in displs])
+        _lib.check(_lib.load().picaso_all_gatherv_dev(self.handle, _addr(send), _addr(recv), c, d), self.ctx)
+
+    def all_gather_spectrum(self, local, full, nwno):
+        """Per-rank shard (this rank's block of ``shard_bounds(nwno, world)``, device) -> ``full`` (nwno,
+        device) on every rank.  Equal blocks use ncclAllGather, ragged ones the grouped-broadcast form."""
+        bounds = shard_bounds(nwno, self.world)
+        counts = [hi - lo for lo, hi in bounds]
+        if len(set(counts)) == 1:
+            self.all_gather(local, full, counts[0])
+        else:
+            self.all_gatherv(local, full, counts, [lo for lo, _ in bounds])
+
+    def max(self, value):
+        v = ctypes.c_double(float(value))
+        _lib.check(_lib.load().picaso_comm_max(self.handle, ctypes.byref(v)), self.ctx)
+        return v.value
+
+    def barrier(self):
+        _lib.check(_lib.load().picaso_comm_barrier(self.handle), self.ctx)
+
+    def destroy(self):
+        if self.handle:
+            _lib.load().picaso_comm_destroy(self.handle)
+            self.handle = None

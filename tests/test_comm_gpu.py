@@ -1,0 +1,95 @@
+"""The library's RCCL layer (csrc/comm.hip) on the GPU box: a one-rank communicator built from a
+library-generated id runs every collective entry point (librccl.so gets mapped and called), and the
+sharded solve -- two contexts (streams) of one GPU each solving its wavelength block of one spectrum
+into its slice of a shared result -- is bit-identical to the unsharded launch.  (More than one rank
+needs more than one GPU: RCCL refuses two ranks on one device; bench.py --gpus N covers that on the
+multi-GPU node.)"""
+import ctypes
+
+import numpy as np
+import pytest
+
+from picaso_amd import _lib, device, disco, resident, sharding
+from picaso_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+TTHG = (1.0, -1.0, 2.0, -0.5, 1.0)
+
+
+def test_one_rank_rccl_collectives():
+    ctx = _lib.context(0)
+    group = sharding.HostGroup(0, 1)
+    comm = sharding.Comm.from_launcher(ctx, group)
+    try:
+        n = 4099
+        host = np.linspace(-1.0, 1.0, n)
+        send = device.DeviceArray.from_host(host, ctx)
+        recv = device.DeviceArray.zeros((n,), ctx)
+        comm.all_gather(send, recv, n)
+        device.sync(ctx)
+        assert np.array_equal(recv.to_host(), host)
+        recv.zero()
+        comm.all_gather_spectrum(send, recv, n)
+        device.sync(ctx)
+        assert np.array_equal(recv.to_host(), host)
+        recv.zero()
+        comm.all_gatherv(send, recv, [n], [0])
+        device.sync(ctx)
+        assert np.array_equal(recv.to_host(), host)
+        assert comm.max(3.25) == 3.25
+        comm.barrier()
+        r, w = ctypes.c_int(-1), ctypes.c_int(-1)
+        _lib.check(_lib.load().picaso_comm_rank(comm.handle, ctypes.byref(r), ctypes.byref(w)), ctx)
+        assert (r.value, w.value) == (0, 1)
+    finally:
+        comm.destroy()
+    maps = open("/proc/self/maps").read()
+    assert "librccl" in maps
+
+
+def test_unique_ids_differ():
+    lib = _lib.load()
+    a, b = ctypes.create_string_buffer(128), ctypes.create_string_buffer(128)
+    _lib.check(lib.picaso_comm_unique_id(a), None)
+    _lib.check(lib.picaso_comm_unique_id(b), None)
+    assert a.raw != b.raw
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_product_sharded_over_contexts_bit_identical(world):
+    nlayer, nwno, ng = 40, 30011, 5
+    nlevel = nlayer + 1
+    gang, gw, tang, tw = disco.get_angles_1d(ng)
+    u0, u1, _, _, _ = disco.compute_disco(ng, 1, gang, tang, 0.0)
+    sc = syn.make_scene(nlayer, nwno, seed=21)
+    sc["F0PI"] = np.linspace(0.5, 1.5, nwno)
+    sc["surf_reflect"] = np.full(nwno, 0.2)
+    keys = resident.REFLECTED_PLANES + ("F0PI", "surf_reflect")
+    ctx0 = _lib.context(0)
+    d = resident.upload_scene(sc, keys, ctx=ctx0)
+    x = device.DeviceArray((ng, 1, nwno), ctx0)
+    alb = device.DeviceArray((nwno,), ctx0)
+    resident.reflected_1d(ctx0, nlevel, nwno, ng, 1, d, d["surf_reflect"], u0, u1, 1.0, d["F0PI"], 3, 0, *TTHG, x,
+                          gweight=gw, tweight=tw, albedo=alb)
+    device.sync(ctx0)
+    want = alb.to_host()
+    full = device.DeviceArray.zeros((nwno,), ctx0)
+    ctxs = [ctx0] + [_lib.new_context(0) for _ in range(world - 1)]
+    keep = []
+    for r, (lo, hi) in enumerate(sharding.shard_bounds(nwno, world)):
+        c = ctxs[r]
+        dr = resident.upload_scene(sc, keys, lo, hi, ctx=c)
+        xr = device.DeviceArray((ng, 1, hi - lo), c)
+        resident.reflected_1d(c, nlevel, hi - lo, ng, 1, dr, dr["surf_reflect"], u0, u1, 1.0, dr["F0PI"], 3, 0,
+                              *TTHG, xr, gweight=gw, tweight=tw, albedo=full.addr + 8 * lo)
+        keep.append((dr, xr))
+    for c in ctxs:
+        device.sync(c)
+    got = full.to_host()
+    for dr, xr in keep:                      # arrays belong to their context: release them before it goes
+        for v in dr.values():
+            v.free()
+        xr.free()
+    for c in ctxs[1:]:
+        _lib.load().picaso_ctx_destroy(c)
+    assert np.array_equal(got, want)

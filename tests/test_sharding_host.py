@@ -1,0 +1,145 @@
+"""Wavelength sharding, N > 1, on CPU: world sizes 2 and 3 (ragged blocks) as real processes.
+
+The ranks find each other the way bench.py's do (picaso_amd.sharding.HostGroup: a TCP star on
+127.0.0.1, no PyTorch, no MPI), rank 0's 128-byte communicator id reaches every rank intact, every
+rank solves only its block of the grid, and the gathered spectrum is bit-identical to the unsharded
+one (sharding changes no arithmetic: every column is independent).  The per-rank solve is the CPU
+oracle here -- this covers the sharding / rendezvous / gather logic of the multi-GPU path; the
+device collectives (RCCL inside libpicaso_hip.so) are exercised by tests/test_comm_gpu.py.
+A second test runs the same shards through torch.distributed's gloo backend (test-side adapter only:
+the product does not import torch) as an independent check of the block layout.
+"""
+import multiprocessing as mp
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+NAMES = ("dtau", "tau", "w0", "cosb", "gcos2", "ftau_cld", "ftau_ray", "dtau_og", "tau_og", "w0_og", "cosb_og")
+
+
+def _solve_block(nwno, lo, hi):
+    from oracle import oracle as orc
+    from picaso_amd import disco
+    from picaso_amd import synthetic as syn
+    nlayer = 20
+    sc = syn.make_scene(nlayer, nwno, seed=12)
+    g, gw, t, tw = disco.get_angles_1d(5)
+    u0, u1, ct, _, _ = disco.compute_disco(5, 1, g, t, 0.0)
+    planes = [np.ascontiguousarray(sc[k][:, lo:hi]) for k in NAMES]
+    f0 = np.linspace(0.8, 1.2, nwno)
+    x, _ = orc.get_reflected_1d(nlayer + 1, sc["wno"][lo:hi], hi - lo, 5, 1, *planes, 0.1, u0, u1, 1.0, f0[lo:hi],
+                                3, 0, 1.0, -1.0, 2.0, -0.5, 1.0)
+    return x, orc.compress_disco(hi - lo, 1.0, x, gw, tw, f0[lo:hi])
+
+
+def _worker(rank, world, port, nwno, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    os.environ.pop("PICASO_AMD_RDZV_PORT", None)
+    from picaso_amd import sharding
+    r, w, local, addr, rport = sharding.launcher_env()
+    assert (r, w, local, addr, rport) == (rank, world, rank, "127.0.0.1", port + 37)
+    group = sharding.HostGroup(r, w, addr, rport)
+    uid = bytes((7 * i + 3) % 256 for i in range(sharding.COMM_ID_BYTES)) if rank == 0 else None
+    uid = group.broadcast(uid)                       # the RCCL id's path (rank 0 -> all)
+    lo, hi = sharding.shard_of(nwno, world, rank)
+    x, alb = _solve_block(nwno, lo, hi)
+    full_alb = group.all_gather_spectrum(alb, nwno)
+    full_x = group.all_gather_spectrum(x, nwno)
+    slowest = group.max(float(rank))
+    group.barrier()
+    q.put((rank, uid, full_alb, full_x, slowest))
+    group.barrier()
+    group.close()
+
+
+@pytest.mark.parametrize("world,nwno", [(2, 64), (3, 50)])
+def test_sharded_equals_unsharded_host_group(world, nwno, oracle):
+    from picaso_amd import sharding
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 23000 + (os.getpid() % 2000) + 40 * world
+    procs = [ctx.Process(target=_worker, args=(r, world, port, nwno, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    x, alb = _solve_block(nwno, 0, nwno)
+    want_uid = bytes((7 * i + 3) % 256 for i in range(sharding.COMM_ID_BYTES))
+    assert sorted(g[0] for g in got) == list(range(world))
+    for rank, uid, full_alb, full_x, slowest in got:
+        assert uid == want_uid and len(uid) == 128
+        assert full_alb.shape == (nwno,) and full_x.shape == x.shape
+        assert np.array_equal(full_alb, alb)
+        assert np.array_equal(full_x, x)
+        assert slowest == float(world - 1)
+
+
+def _gloo_worker(rank, world, port, nwno, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch
+    import torch.distributed as dist
+    from picaso_amd import sharding
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    bounds = sharding.shard_bounds(nwno, world)
+    lo, hi = bounds[rank]
+    _, alb = _solve_block(nwno, lo, hi)
+    nmax = max(b[1] - b[0] for b in bounds)
+    pad = torch.zeros(nmax, dtype=torch.float64)
+    pad[: hi - lo] = torch.from_numpy(alb)
+    out = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(out, pad)
+    full = np.concatenate([out[r][: b[1] - b[0]].numpy() for r, b in enumerate(bounds)])
+    if rank == 0:
+        q.put(full)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_equals_unsharded_gloo(oracle):
+    world, nwno = 2, 33
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 25500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_gloo_worker, args=(r, world, port, nwno, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    full = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    _, alb = _solve_block(nwno, 0, nwno)
+    assert np.array_equal(full, alb)
+
+
+def test_shard_bounds():
+    from picaso_amd.sharding import shard_bounds
+    for n, w in ((100000, 8), (10, 3), (5, 8), (1, 1)):
+        b = shard_bounds(n, w)
+        assert b[0][0] == 0 and b[-1][1] == n
+        assert all(b[i][1] == b[i + 1][0] for i in range(w - 1))
+        sizes = [hi - lo for lo, hi in b]
+        assert max(sizes) - min(sizes) <= 1
+
+
+def test_product_does_not_import_torch():
+    """north_star: host code calls the kernels through ctypes, no PyTorch anywhere in the product."""
+    import re
+    offenders = []
+    for base, _, files in os.walk(os.path.join(ROOT, "picaso_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                text = open(os.path.join(base, f)).read()
+                if re.search(r"^\s*(import|from)\s+torch\b", text, re.M):
+                    offenders.append(f)
+    text = open(os.path.join(ROOT, "bench.py")).read()
+    if re.search(r"^\s*(import|from)\s+torch\b", text, re.M):
+        offenders.append("bench.py")
+    assert not offenders, offenders
