@@ -33,11 +33,13 @@ struct SHArgs {
     long pitch;
     const double *dtau, *tau, *w0, *ftau_cld, *ftau_ray, *f_deltaM, *dtau_og, *tau_og, *w0_og, *cosb_og;
     const double *surf_reflect, *F0PI;
-    // blockIdx.y = angle of this launch chunk; constants derived on the host (uniform -> SGPR)
+    // angles of this launch chunk; constants derived on the host (wave-uniform -> SGPR)
     struct Angle {
         double u0, u1, iu0, iu1, mus, imus, nl0, nl1, nlm;   // nl* = -log2(e) {1/u0, 1/u1, mus}
     } ang[SH_MAX_ANG];
-    int first_angle, compound;                               // reference angle index of ang[0]
+    int first_angle, compound, nang;                         // reference angle index of ang[0]; angles of this launch
+    int xcd_order;                                           // block order, see k_sh
+    unsigned ncg;                                            // column groups (blocks per angle)
     double cos_theta;
     int w_single_form, w_multi_form, psingle_form, w_single_rayleigh, w_multi_rayleigh,
         psingle_rayleigh, single_form;
@@ -210,14 +212,32 @@ template <int NB, bool THERMAL, bool FLX>
 __global__ __launch_bounds__(256, PZ_SH_MINWAVES) void k_sh(const SHArgs a)
 {
     constexpr int NS = 2 * NB;      // stream
-    const long w = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    // 1-D grid, XCD-aware order.  Consecutive workgroups go to consecutive XCDs (8 of them, each with
+    // its own L2), and every angle re-reads the same 13 planes: block b = (chunk of 8 column groups,
+    // angle, column group within the chunk), so the nang blocks of one column group are dispatched
+    // within 8*nang blocks of each other, all on XCD (column group % 8): the first one's plane rows are
+    // L2 hits for the others (HBM fetch 3.6 GB -> ~1.2 GB per 1e5 x 90 x 5 spectrum, PMC).
+    // Small launches (about one block per CU or less) keep the plain angle-major order: there the XCD
+    // grouping would put five blocks of a column group on one XCD while others stay short of work.
+    const int nang = a.nang;
+    const unsigned b = blockIdx.x;
+    int ang;
+    long w;
+    if (a.xcd_order) {
+        const unsigned chunk = b / (8u * nang), rem = b - chunk * (8u * nang);
+        ang = (int)(rem >> 3);
+        w = ((long)chunk * 8 + (rem & 7u)) * blockDim.x + threadIdx.x;
+    } else {
+        ang = (int)(b / a.ncg);
+        w = (long)(b - (unsigned)ang * a.ncg) * blockDim.x + threadIdx.x;
+    }
     if (w >= a.nwno) return;
     const int n = a.nlayer;
     const long pitch = a.pitch;
-    const SHArgs::Angle &g = a.ang[blockIdx.y];
+    const SHArgs::Angle &g = a.ang[ang];
     const double u0 = g.u0, u1 = g.u1, ct = a.cos_theta;
-    const int fd_power = a.compound ? a.first_angle + (int)blockIdx.y + 1 : 1;   // compounded f_deltaM
-    double *const xint = a.xint + (long)blockIdx.y * a.nwno;
+    const int fd_power = a.compound ? a.first_angle + ang + 1 : 1;   // compounded f_deltaM
+    double *const xint = a.xint + (long)ang * a.nwno;
     const double F = THERMAL ? 0.0 : a.F0PI[w], rs = a.surf_reflect[w];
     double Pu0[4], Pu1[4];
     legP4(-u0, Pu0);
@@ -245,7 +265,7 @@ __global__ __launch_bounds__(256, PZ_SH_MINWAVES) void k_sh(const SHArgs a)
 
     // flx = 1: sweep-1 state of every layer for the back-substitution ([slot][layer][wavelength])
     constexpr int NSLOT = 4 * NB * NB + 5 * NB;
-    double *const scr = FLX ? a.scratch + (long)blockIdx.y * NSLOT * n * a.nwno + w : nullptr;
+    double *const scr = FLX ? a.scratch + (long)ang * NSLOT * n * a.nwno + w : nullptr;
     auto slot = [&](int sl, int i) -> double & { return scr[((long)sl * n + i) * a.nwno]; };
     double top_zmn[NB], top_zpl[NB];
 #pragma unroll
@@ -631,7 +651,7 @@ __global__ __launch_bounds__(256, PZ_SH_MINWAVES) void k_sh(const SHArgs a)
         // ---- sweep 2: back-substitute v_i, d_i = delta_i - R_i v_i and write the moment fluxes at the
         // bottom of every layer (and the top of layer 0) in the row order of the reference's F.X + G:
         // (Fmn[0..NB), Fpl[0..NB)) per level (fluxes.py:3311-3331, 3552-3599)
-        double *fl = a.flux + (long)blockIdx.y * NS * (n + 1) * a.nwno + w;
+        double *fl = a.flux + (long)ang * NS * (n + 1) * a.nwno + w;
         double vv[NB];
 #pragma unroll
         for (int r = 0; r < NB; ++r) vv[r] = v[r];
@@ -698,10 +718,13 @@ __global__ __launch_bounds__(256, PZ_SH_MINWAVES) void k_sh(const SHArgs a)
     }
 }
 
-static int launch_sh(picaso_ctx *ctx, const SHArgs &a, int nang, bool thermal)
+static int launch_sh(picaso_ctx *ctx, SHArgs &a, int nang, bool thermal)
 {
     const int block = 256;
-    const dim3 grid((unsigned)((a.nwno + block - 1) / block), (unsigned)nang);
+    const unsigned ncg = (unsigned)((a.nwno + block - 1) / block);          // column groups
+    a.ncg = ncg;
+    a.xcd_order = (ncg * (unsigned)nang >= 4u * (unsigned)ctx->ncu) && !getenv("PICASO_AMD_SH_ANGLE_MAJOR");
+    const dim3 grid(a.xcd_order ? ((ncg + 7u) / 8u) * 8u * (unsigned)nang : ncg * (unsigned)nang);
     const bool flx = a.flux != nullptr;
     if (a.stream == 4) {
         if (thermal) hipLaunchKernelGGL((k_sh<2, true, false>), grid, dim3(block), 0, ctx->stream, a);
@@ -753,6 +776,7 @@ static int launch_sh_angles(picaso_ctx *ctx, SHArgs &a, int nang, const double *
             }
         }
         a.first_angle = done;
+        a.nang = m;
         a.xint = xint_at_top + (size_t)done * a.nwno;
         PZ_TRY(launch_sh(ctx, a, m, thermal));
     }

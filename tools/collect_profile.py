@@ -13,6 +13,7 @@ import shutil
 import sys
 
 src, name = sys.argv[1], sys.argv[2]
+kernel_tag = sys.argv[3] if len(sys.argv) > 3 else "k_reflected_toa<5"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 dst = os.path.join(root, "profiles")
 stats = glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True)
@@ -31,14 +32,18 @@ with open(os.path.join(dst, name + "_pmc_summary.csv"), "w") as fh:
         w.writerow([kern, ctr, n, "%.6g" % (v / n)])
 # HBM traffic of the headline kernel: FETCH_SIZE / WRITE_SIZE are in KB; FETCH_SIZE under-counts by
 # 2x on gfx950 (MI355X_MICROARCH.md, HBM / rocprofv3 section), collected in separate passes.
-fetch = [v / n for (k, c), (n, v) in agg.items() if c == "FETCH_SIZE" and "k_reflected_toa<5" in k]
-write = [v / n for (k, c), (n, v) in agg.items() if c == "WRITE_SIZE" and "k_reflected_toa<5" in k]
-valu = [v / n for (k, c), (n, v) in agg.items() if c == "SQ_INSTS_VALU" and "k_reflected_toa<5" in k]
-if fetch and write:
+fetch = [v / n for (k, c), (n, v) in agg.items() if c == "FETCH_SIZE" and kernel_tag in k]
+write = [v / n for (k, c), (n, v) in agg.items() if c == "WRITE_SIZE" and kernel_tag in k]
+valu = [v / n for (k, c), (n, v) in agg.items() if c == "SQ_INSTS_VALU" and kernel_tag in k]
+if fetch and write and kernel_tag == "k_reflected_toa<5":
+    sys.path.insert(0, root)
+    import bench
     json.dump({"hbm_bytes_per_launch": (2.0 * fetch[0] + write[0]) * 1024.0,
                "valu_wave_insts_per_launch": valu[0] if valu else None,
+               "kernel_source_hash": bench.kernel_source_hash(),
                "source": "profiles/%s_pmc_summary.csv" % name,
-               "note": "(2*FETCH_SIZE + WRITE_SIZE) KB per dispatch of k_reflected_toa<5,false,true>; "
-                       "FETCH_SIZE doubled per the gfx950 correction in MI355X_MICROARCH.md"},
+               "note": "(2*FETCH_SIZE + WRITE_SIZE) KB per dispatch of the headline k_reflected_toa launch; "
+                       "FETCH_SIZE doubled per the gfx950 correction in MI355X_MICROARCH.md; bench.py only "
+                       "quotes these numbers while kernel_source_hash matches the sources it runs"},
               open(os.path.join(dst, "traffic.json"), "w"), indent=1)
 print(open(os.path.join(dst, name + "_pmc_summary.csv")).read())
