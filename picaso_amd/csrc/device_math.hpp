@@ -256,20 +256,30 @@ constexpr double LOG2E_D = 1.4426950408889634074;
 // exp(x) through the base-2 polynomial with resident coefficients
 __device__ __forceinline__ double fexpk(double x, const Exp2Coef &K) { return fexp2(x * LOG2E_D, K); }
 
+// 1/(e - 1) of the Planck function.  Cold levels at short wavelengths overflow the exponential
+// (hc wno/kT > 709.8: below ~68 K at 0.3 um): numpy forms 1/(inf - 1) = 0 there, while frcp(inf) is
+// NaN (v_rcp gives 0 and the Newton step fma(-inf, 0, 1) is NaN), which would poison the disk sum,
+// effective_temperature and fpfs_thermal of an otherwise finite spectrum.
+__device__ __forceinline__ double planck_rcp(double e)
+{
+    const double y = frcp(e - 1.0);
+    return (e == __builtin_inf()) ? 0.0 : y;
+}
+
 // Planck function per unit wavelength, cgs, at wavelength 1/wno (reference fluxes.py:1660-1680).
 __device__ __forceinline__ double planck_lambda(double t, double wno)
 {
     const double h = 6.62607004e-27, c = 2.99792458e+10, k = 1.38064852e-16;
     const double wcm = 1.0 / wno;
     const double w2 = wcm * wcm;
-    return ((2.0 * h * (c * c)) / (w2 * w2 * wcm)) * frcp(fexp((h * c) / (t * (wcm * k))) - 1.0);
+    return ((2.0 * h * (c * c)) / (w2 * w2 * wcm)) * planck_rcp(fexp((h * c) / (t * (wcm * k))));
 }
 __device__ __forceinline__ double planck_lambda(double t, double wno, const Exp2Coef &K)
 {
     const double h = 6.62607004e-27, c = 2.99792458e+10, k = 1.38064852e-16;
     const double wcm = 1.0 / wno;
     const double w2 = wcm * wcm;
-    return ((2.0 * h * (c * c)) / (w2 * w2 * wcm)) * frcp(fexpk((h * c) / (t * (wcm * k)), K) - 1.0);
+    return ((2.0 * h * (c * c)) / (w2 * w2 * wcm)) * planck_rcp(fexpk((h * c) / (t * (wcm * k)), K));
 }
 
 // 3-point bin mean of the wavenumber Planck function (reference fluxes.py:1608-1658, nbb = 1).
@@ -281,7 +291,7 @@ __device__ __forceinline__ double planck_integrated(double t, double wave, doubl
 #pragma unroll
     for (int kk = -1; kk <= 1; ++kk) {
         const double wn = wave + kk * dwave / 2.0;
-        s += c1 * (wn * wn * wn) * frcp(fexp(c2 * wn / t) - 1.0);
+        s += c1 * (wn * wn * wn) * planck_rcp(fexp(c2 * wn / t));
     }
     return s / 3.0;
 }

@@ -41,7 +41,7 @@ int launch_compress_dev(picaso_ctx *ctx, size_t ninner, const double *x, const d
 // Correlated-k Gauss-point sum (reference justdoit.py:307, 380: `xint_at_top += xint*gauss_wts[ig]`,
 // in ig order): in is (nrows, nwno, n) with the Gauss index fastest, out (nrows, nwno).
 struct ColsumArgs {
-    long nwno;
+    long nwno, nrows;
     int n;
     double wts[MAX_CK_GAUSS];
     const double *in;
@@ -50,12 +50,16 @@ struct ColsumArgs {
 
 __global__ __launch_bounds__(256) void k_weighted_colsum(const ColsumArgs a)
 {
+#pragma clang fp contract(off)      // `xint_at_top += xint*gauss_wts[ig]`: a product and a sum, as numpy
     const long w = blockIdx.x * (long)blockDim.x + threadIdx.x;
     if (w >= a.nwno) return;
-    const double *src = a.in + ((long)blockIdx.y * a.nwno + w) * a.n;
-    double acc = 0.0;
-    for (int j = 0; j < a.n; ++j) acc = acc + src[j] * a.wts[j];
-    a.out[(long)blockIdx.y * a.nwno + w] = acc;
+    // rows (angle x level of a level-flux batch) can exceed the 65 535 limit of grid.y: stride over them
+    for (long row = blockIdx.y; row < a.nrows; row += gridDim.y) {
+        const double *src = a.in + (row * a.nwno + w) * a.n;
+        double acc = 0.0;
+        for (int j = 0; j < a.n; ++j) acc = acc + src[j] * a.wts[j];
+        a.out[row * a.nwno + w] = acc;
+    }
 }
 
 int launch_weighted_colsum(picaso_ctx *ctx, int nrows, long nwno, int n, const double *wts_host,
@@ -67,14 +71,16 @@ int launch_weighted_colsum(picaso_ctx *ctx, int nrows, long nwno, int n, const d
     a.nwno = nwno; a.n = n; a.in = in; a.out = out;
     for (int j = 0; j < n; ++j) a.wts[j] = wts_host[j];
     const int block = 256;
-    hipLaunchKernelGGL(k_weighted_colsum, dim3((unsigned)((nwno + block - 1) / block), (unsigned)nrows),
+    a.nrows = nrows;
+    hipLaunchKernelGGL(k_weighted_colsum, dim3((unsigned)((nwno + block - 1) / block), (unsigned)(nrows < 65535 ? nrows : 65535)),
                        dim3(block), 0, ctx->stream, a);
     PZ_HIP(ctx, hipGetLastError());
     return 0;
 }
 
-__global__ __launch_bounds__(256) void k_axpby(size_t n, double a, const double *__restrict__ x, double b,
-                                               const double *__restrict__ y, double *__restrict__ out)
+// out may alias x or y (the patchy-cloud blends are in place): no __restrict__ here
+__global__ __launch_bounds__(256) void k_axpby(size_t n, double a, const double *x, double b, const double *y,
+                                               double *out)
 {
 #pragma clang fp contract(off)      // two products and a sum, as numpy evaluates the blend
     const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;

@@ -63,3 +63,170 @@ def test_sampled_columns_vs_oracle(full, oracle):
     assert rel_err(full["x"][:, :, idx], xo) < 1e-8
     alb_o = oracle.compress_disco(idx.size, 1.0, xo, full["gw"], full["tw"], sc["F0PI"][idx])
     assert rel_err(full["alb"][idx], alb_o) < 1e-8
+
+
+def test_eight_shards_as_on_an_8_gpu_node(full):
+    """12 500-wavelength shards take the one-angle-per-wave path (small launch); the headline launch
+    fuses five angles per lane: the results agree bit for bit (explicit-fma arithmetic)."""
+    from picaso_amd.sharding import shard_bounds
+    parts = [full["run"](full["sc"], lo, hi) for lo, hi in shard_bounds(NWNO, 8)]
+    assert np.array_equal(np.concatenate([p[0] for p in parts], axis=2), full["x"])
+    assert np.array_equal(np.concatenate([p[1] for p in parts]), full["alb"])
+
+
+# ---------------------------------------------------------------------------------------------
+# the other BASELINE.json configurations at their stated sizes
+# ---------------------------------------------------------------------------------------------
+def _thermal(nwno, lo=None, hi=None, seed=5):
+    from picaso_amd import _lib, disco, resident
+    from picaso_amd import synthetic as syn
+    from picaso_amd.device import DeviceArray
+    ctx = _lib.context()
+    sc = syn.make_scene(NLAYER, nwno, seed=seed)
+    sc["surf_reflect"] = np.zeros(nwno)
+    sc["dwno"] = np.full(nwno, 2.0)
+    g, gw, t, tw = disco.get_angles_1d(NG)
+    _, u1, _, _, _ = disco.compute_disco(NG, 1, g, t, 0.0)
+
+    def run(lo, hi, calc_type):
+        n = hi - lo
+        d = resident.upload_scene(sc, ("dtau_og", "w0_no_raman", "cosb_og", "wno", "dwno", "surf_reflect"), lo, hi,
+                                  ctx=ctx)
+        f, disk = DeviceArray((NG, 1, n), ctx), DeviceArray((n,), ctx)
+        resident.thermal_1d(ctx, NLAYER + 1, d["wno"], n, NG, 1, sc["tlevel"], d["dtau_og"], d["w0_no_raman"],
+                            d["cosb_og"], sc["plevel"], u1, d["surf_reflect"], 0, f, dwno=d["dwno"],
+                            calc_type=calc_type, gweight=gw, tweight=tw, flux_disk=disk)
+        return f.to_host(), disk.to_host()
+    return sc, u1, gw, tw, run
+
+
+@pytest.mark.parametrize("nwno,calc_type", [(10000, 0), (100000, 0), (10000, 1)])
+def test_thermal_fullsize(nwno, calc_type, oracle):
+    """configs[1]: get_thermal_1d, 90 layers, 1e4 (and 1e5) wavelengths: sampled columns against the
+    oracle, shard concatenation bit-identical."""
+    from picaso_amd.sharding import shard_bounds
+    sc, u1, gw, tw, run = _thermal(nwno)
+    f, disk = run(0, nwno, calc_type)
+    assert np.all(np.isfinite(f)) and np.all(disk > 0)
+    idx = np.sort(np.random.default_rng(4).choice(nwno, 1500, replace=False))
+    fo, _ = oracle.get_thermal_1d(NLAYER + 1, sc["wno"][idx], idx.size, NG, 1, sc["tlevel"],
+                                  np.ascontiguousarray(sc["dtau_og"][:, idx]),
+                                  np.ascontiguousarray(sc["w0_no_raman"][:, idx]),
+                                  np.ascontiguousarray(sc["cosb_og"][:, idx]), sc["plevel"], u1, np.zeros(idx.size), 0,
+                                  sc["dwno"][idx], calc_type)
+    assert rel_err(f[:, :, idx], fo) < 1e-8
+    assert rel_err(disk[idx], oracle.compress_thermal(idx.size, fo, gw, tw)) < 1e-8
+    parts = [run(lo, hi, calc_type) for lo, hi in shard_bounds(nwno, 3)]
+    assert np.array_equal(np.concatenate([p[0] for p in parts], axis=2), f)
+    assert np.array_equal(np.concatenate([p[1] for p in parts]), disk)
+
+
+def test_sh4_fullsize_eight_shards(oracle):
+    """configs[3]: SH4 reflected light, 1e5 wavelengths x 90 layers x 5 angles in 8 shards of 12 500 (the
+    8-GPU split): shard concatenation bit-identical to the unsharded launch, sampled columns against
+    the oracle (the reference's banded LAPACK solve restated)."""
+    from picaso_amd import _lib, disco, resident
+    from picaso_amd import synthetic as syn
+    from picaso_amd.device import DeviceArray
+    from picaso_amd.sharding import shard_bounds
+    ctx = _lib.context()
+    nwno = NWNO
+    sc = syn.make_scene(NLAYER, nwno, seed=9, stream=4)
+    sc["F0PI"] = np.linspace(0.5, 2.0, nwno)
+    sc["surf_reflect"] = np.full(nwno, 0.05)
+    g, gw, t, tw = disco.get_angles_1d(NG)
+    u0, u1, _, _, _ = disco.compute_disco(NG, 1, g, t, 0.0)
+    opts = (0, 0, 0, 1, 1, 1)
+
+    def run(lo, hi):
+        n = hi - lo
+        d = resident.upload_scene(sc, resident.SH_PLANES + ("F0PI", "surf_reflect"), lo, hi, ctx=ctx)
+        x, alb = DeviceArray((NG, 1, n), ctx), DeviceArray((n,), ctx)
+        resident.reflected_SH(ctx, NLAYER + 1, n, NG, 1, d, d["surf_reflect"], u0, u1, 1.0, d["F0PI"], *opts, *TTHG,
+                              4, x, gweight=gw, tweight=tw, albedo=alb)
+        return x.to_host(), alb.to_host()
+    x, alb = run(0, nwno)
+    assert np.all(np.isfinite(x))
+    parts = [run(lo, hi) for lo, hi in shard_bounds(nwno, 8)]
+    assert np.array_equal(np.concatenate([p[0] for p in parts], axis=2), x)
+    assert np.array_equal(np.concatenate([p[1] for p in parts]), alb)
+    idx = np.sort(np.random.default_rng(6).choice(nwno, 600, replace=False))
+    planes = [np.ascontiguousarray(sc[k][:, idx]) for k in resident.SH_PLANES]
+    xo, _ = oracle.get_reflected_SH(NLAYER + 1, idx.size, NG, 1, *planes, sc["surf_reflect"][idx], u0, u1, 1.0,
+                                    sc["F0PI"][idx], *opts, *TTHG, 4)
+    assert rel_err(x[:, :, idx], xo) < 1e-8
+    assert rel_err(alb[idx], oracle.compress_disco(idx.size, 1.0, xo, gw, tw, sc["F0PI"][idx])) < 1e-8
+
+
+def test_3d_64_facets_90_layers(oracle):
+    """configs[4] shape: 8 x 8 = 64 facets (one wavefront per wavelength) x 90 layers x 4 096 wavelengths
+    with facet-dependent optical depths and angles: sampled (wavelength, facet) columns against the
+    oracle's get_reflected_3d, compress_disco against the oracle, wavelength shards bit-identical."""
+    from picaso_amd import _lib, disco, resident
+    from picaso_amd import synthetic as syn
+    from picaso_amd.device import DeviceArray
+    ctx = _lib.context()
+    ng = nt = 8
+    nwno = 4096
+    gang, gw, tang, tw = disco.get_angles_3d(ng, nt)
+    u0, u1, ct, _, _ = disco.compute_disco(ng, nt, gang, tang, 0.6)
+    base = syn.make_scene(NLAYER, nwno, seed=17)
+    fac = 1.0 + 0.1 * np.random.default_rng(3).standard_normal(ng * nt)
+    sc3 = {}
+    for k in PLANES:
+        a = base[k]
+        a3 = a[:, :, None] * fac[None, None, :] if k in ("dtau", "dtau_og") else np.repeat(a[:, :, None], ng * nt, 2)
+        sc3[k] = np.ascontiguousarray(a3)
+    for name, dname in (("tau", "dtau"), ("tau_og", "dtau_og")):       # level planes consistent with the layers
+        tau = np.zeros((NLAYER + 1, nwno, ng * nt))
+        tau[1:] = np.cumsum(sc3[dname], axis=0)
+        sc3[name] = tau
+    f0 = np.linspace(0.7, 1.3, nwno)
+    rs = np.full(nwno, 0.1)
+
+    def run(lo, hi):
+        n = hi - lo
+        d = {k: DeviceArray.from_host(np.ascontiguousarray(sc3[k][:, lo:hi]), ctx) for k in PLANES}
+        F, R = DeviceArray.from_host(f0[lo:hi], ctx), DeviceArray.from_host(rs[lo:hi], ctx)
+        x, alb = DeviceArray((ng, nt, n), ctx), DeviceArray((n,), ctx)
+        resident.reflected_3d(ctx, NLAYER + 1, n, ng, nt, d, R, u0, u1, float(ct), F, 0, 0, *TTHG, x, gweight=gw,
+                              tweight=tw, albedo=alb)
+        return x.to_host(), alb.to_host()
+    x, alb = run(0, nwno)
+    assert np.all(np.isfinite(x))
+    p1, p2 = run(0, 1500), run(1500, nwno)
+    assert np.array_equal(np.concatenate([p1[0], p2[0]], axis=2), x)
+    assert np.array_equal(np.concatenate([p1[1], p2[1]]), alb)
+    idx = np.sort(np.random.default_rng(5).choice(nwno, 40, replace=False))
+    planes = [np.ascontiguousarray(sc3[k][:, idx].reshape(sc3[k].shape[0], idx.size, ng, nt)) for k in PLANES]
+    xo = oracle.get_reflected_3d(NLAYER + 1, base["wno"][idx], idx.size, ng, nt, *planes, rs[idx], u0, u1, float(ct),
+                                 f0[idx], 0, 0, *TTHG)
+    xo = xo[0] if isinstance(xo, tuple) else xo
+    assert rel_err(x[:, :, idx], xo) < 1e-8
+    assert rel_err(alb[idx], oracle.compress_disco(idx.size, float(ct), xo, gw, tw, f0[idx])) < 1e-8
+
+
+@pytest.mark.parametrize("calc_type", [0, 1])
+def test_cold_levels_planck_overflow(calc_type, oracle):
+    """A 40 K level at 0.3 um: hc wno/kT = 1200 overflows exp(); the reference forms 1/(inf-1) = 0.  The
+    spectrum stays finite and equals the oracle's (the Newton reciprocal of inf would be NaN)."""
+    from picaso_amd import disco, fluxes
+    from picaso_amd import synthetic as syn
+    nlayer, nwno = 30, 257
+    sc = syn.make_scene(nlayer, nwno, seed=4)
+    wno = np.linspace(20000.0, 33333.0, nwno)
+    tlevel = np.linspace(40.0, 160.0, nlayer + 1)
+    g, gw, t, tw = disco.get_angles_1d(NG)
+    _, u1, _, _, _ = disco.compute_disco(NG, 1, g, t, 0.0)
+    args = (nlayer + 1, wno, nwno, NG, 1, tlevel, sc["dtau_og"], sc["w0_no_raman"], sc["cosb_og"], sc["plevel"], u1,
+            np.zeros(nwno), 0, np.full(nwno, 50.0), calc_type)
+    fg, lg = fluxes.get_thermal_1d(*args)
+    fo, lo = oracle.get_thermal_1d(*args)
+    assert np.all(np.isfinite(fg)) and np.all(np.isfinite(fo))
+    assert 1.4387769 * wno.max() / tlevel.min() > 709.8            # exp() of the top level really overflows
+    scale = np.max(np.abs(fo))
+    assert np.max(np.abs(fg - fo)) <= 1e-8 * scale
+    nz = np.abs(fo) > 1e-250
+    assert rel_err(fg[nz], fo[nz]) < 1e-8
+    for a, b in zip(lg, lo):
+        assert np.all(np.isfinite(a))
