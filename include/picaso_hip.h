@@ -255,6 +255,8 @@ int picaso_get_thermal_SH_dev(picaso_ctx *ctx, int nlevel, const double *wno, in
 int picaso_compress_disco(picaso_ctx *ctx, int nwno, double cos_theta, const double *xint_at_top,
                           const double *gweight, int ng, const double *tweight, int nt,
                           const double *F0PI, double *albedo);
+/* device form; F0PI == NULL means F0PI = 1 (how the reference disk-integrates its level fluxes,
+ * justdoit.py:536-548: pass nwno = nlevel*nwno columns) */
 int picaso_compress_disco_dev(picaso_ctx *ctx, int nwno, double cos_theta,
                               const double *xint_at_top, const double *gweight, int ng,
                               const double *tweight, int nt, const double *F0PI, double *albedo);

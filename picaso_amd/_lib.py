@@ -94,6 +94,20 @@ def new_context(device=None):
     return h
 
 
+_aux = {}
+
+
+def aux_context(device=None):
+    """The process's second context on the device (its own stream): the thermal leg of a spectrum runs
+    there next to the reflected leg.  Created once per (process, device) and kept, like ``context()``."""
+    if device is None:
+        device = int(os.environ.get("PICASO_AMD_DEVICE", "0"))
+    key = (os.getpid(), device)
+    if key not in _aux:
+        _aux[key] = new_context(device)
+    return _aux[key]
+
+
 def device_of(ctx):
     d = ctypes.c_int(0)
     check(load().picaso_ctx_device(ctx, ctypes.byref(d)), ctx)

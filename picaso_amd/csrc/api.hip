@@ -1006,7 +1006,7 @@ int picaso_compress_thermal_dev(picaso_ctx *ctx, size_t ninner, const double *fl
     const double *d_w = nullptr;
     PZ_TRY(upload_weights(ctx, gweight, ng, tweight, nt, &d_w));
     const double sym = (nt == 1) ? 1.0 : 1.0 / (2.0 * 3.14159265358979323846);   // disco.py:174-175
-    return launch_compress_dev(ctx, ninner, flux_at_top, d_w, ng * nt, nullptr, sym, 0.0, flux);
+    return launch_compress_dev(ctx, ninner, flux_at_top, d_w, ng * nt, nullptr, sym, -1.0, flux);
 }
 
 int picaso_compress_thermal(picaso_ctx *ctx, size_t ninner, const double *flux_at_top,

@@ -21,7 +21,8 @@ __global__ __launch_bounds__(256) void k_compress(size_t ninner, const double *_
     }
     // compress_disco: sym_fac*0.5*albedo/F0PI*(cos_theta+1)   (disco.py:148)
     // compress_thermal: flux*sym_fac                          (disco.py:181)
-    out[w] = F0PI ? c1 * acc / F0PI[w] * c2 : acc * c1;
+    // c2 < 0 marks the thermal form (cos_theta + 1 is never negative); F0PI == NULL: F0PI = 1
+    out[w] = (c2 >= 0.0) ? c1 * acc / (F0PI ? F0PI[w] : 1.0) * c2 : acc * c1;
 }
 
 // wts_dev: device table of nang (gweight[g], tweight[t]) pairs in (g,t) loop order

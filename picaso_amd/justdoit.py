@@ -18,7 +18,7 @@ import os
 
 import numpy as np
 
-from . import _lib, disco, optics, resident
+from . import _lib, device, disco, optics, resident
 from .atmsetup import ATMSETUP
 from .device import DeviceArray
 
@@ -450,145 +450,183 @@ def picaso(bundle, opacityclass, dimension="1d", calculation="reflected", full_o
     tctx = ctx
     if (dimension == "1d" and not is_sh and "reflected" in calculation and "thermal" in calculation
             and os.environ.get("PICASO_AMD_OVERLAP_LEGS", "1") != "0"):
-        if "_ctx2" not in opa.__dict__:
-            opa._ctx2 = _lib.new_context(_lib.device_of(ctx))
-        tctx = opa._ctx2
+        tctx = _lib.aux_context(_lib.device_of(ctx))     # one per process and device, shared by every caller
         _lib.ctx_wait(tctx, ctx)
     returns = {"wavenumber": wno}
-    # every leg first enqueues its kernels; the copies back (each a stream synchronisation) and the
-    # host-side integrals run afterwards, so the GPU goes through reflected + thermal (+ transit)
-    # back to back while the host is still preparing the next launch
-    collect = []
-    if "reflected" in calculation:
-        xint = DeviceArray((ng, nt, nwno), ctx)
-        alb = DeviceArray((nwno,), ctx)
-        lvl = None
-        if dimension == "3d":                                 # justdoit.py:488-500
-            resident.reflected_3d(ctx, nlevel, nwno, ng, nt, planes3d, rs, ubar0, ubar1, cos_theta, d_f0,
-                                  toon["single_phase"], toon["multi_phase"], frac_a, frac_b, frac_c,
-                                  constant_back, constant_forward, xint, gweight, tweight, alb)
-        elif is_sh:                                           # justdoit.py:259-269
-            sh_opt = inp["approx"]["rt_params"]["SH"]
-            sh_flux = None                                    # layer moment fluxes, flx = calculate_fluxes
-            if sh_opt["calculate_fluxes"]:
-                sh_flux = DeviceArray((ng, nt, common["stream"] * nlevel, nwno), ctx)
-            _reflected_sh(ctx, nlevel, nwno, ng, nt, planes, rs, ubar0, ubar1, cos_theta, d_f0,
-                          sh_opt, frac_a, frac_b, frac_c, constant_back, constant_forward,
-                          common["stream"], b_top, xint, gweight, tweight, alb, sh_flux)
-            if sh_flux is not None:
-                atm.flux_layers = sh_flux.to_host()
-        else:
-            lvl = [DeviceArray((ng, nt, nlevel, nwno), ctx) for _ in range(4)] if atm.get_lvl_flux else None
-            tt = (toon["single_phase"], toon["multi_phase"], frac_a, frac_b, frac_c, constant_back,
-                  constant_forward)
-
-            def run(pl, x, lv, fuse):                         # the ngauss loop of justdoit.py:256-307
-                if ngauss > 1:
-                    resident.reflected_1d_ck(ctx, nlevel, nwno, ngauss, ng, nt, pl, rs, ubar0, ubar1,
-                                             cos_theta, d_f0, *tt, gauss_wts, x,
-                                             toon_coefficients=toon["toon_coefficients"], b_top=b_top,
-                                             gweight=gweight if fuse else None,
-                                             tweight=tweight if fuse else None, albedo=alb if fuse else None,
-                                             lvl_fluxes=lv)
-                else:
-                    _reflected(ctx, nlevel, nwno, ng, nt, pl, rs, ubar0, ubar1, cos_theta, d_f0, *tt,
-                               toon["toon_coefficients"], b_top, x, lv, gweight, tweight,
-                               alb if fuse else None)
-            if not do_holes:
-                run(planes, xint, lvl, True)
-            else:                                             # justdoit.py:287-305
-                xc = DeviceArray((ng, nt, nwno), ctx)
-                lvc = [DeviceArray((ng, nt, nlevel, nwno), ctx) for _ in range(4)] if lvl else None
-                run(planes, xint, lvl, False)
-                run(planes_clear, xc, lvc, False)
-                resident.axpby(ctx, 1.0 - fhole, xint, fhole, xc, xint)
-                for a_, b_ in zip(lvl or [], lvc or []):
-                    resident.axpby(ctx, 1.0 - fhole, a_, fhole, b_, a_)
-                resident.compress_disco(ctx, nwno, cos_theta, xint, gweight, tweight, d_f0, alb)
-
-        def collect_reflected():          # read back after every leg has been enqueued (see `collect`)
-            albedo = alb.to_host()
-            returns["albedo"] = albedo
-            if full_output:
-                atm.xint_at_top = xint.to_host()
-            if lvl is not None:
-                atm.lvl_output_reflected = dict(zip(("flux_minus", "flux_plus", "flux_minus_mdpt",
-                                                     "flux_plus_mdpt"), [a.to_host() for a in lvl]))
-            # Batalha+2019 eq. 18 (justdoit.py:552-553)
-            returns["bond_albedo"] = (np.trapezoid(x=1 / wno, y=albedo * stellar) /
-                                      np.trapezoid(x=1 / wno, y=stellar))
-            if (not np.isnan(sa)) and (not np.isnan(atm.planet.radius)):
-                returns["fpfs_reflected"] = albedo * (atm.planet.radius / sa) ** 2.0
+    try:
+        # every leg first enqueues its kernels; the copies back (each a stream synchronisation) and the
+        # host-side integrals run afterwards, so the GPU goes through reflected + thermal (+ transit)
+        # back to back while the host is still preparing the next launch
+        collect = []
+        if "reflected" in calculation:
+            xint = DeviceArray((ng, nt, nwno), ctx)
+            alb = DeviceArray((nwno,), ctx)
+            lvl = None
+            if dimension == "3d":                                 # justdoit.py:488-500
+                resident.reflected_3d(ctx, nlevel, nwno, ng, nt, planes3d, rs, ubar0, ubar1, cos_theta, d_f0,
+                                      toon["single_phase"], toon["multi_phase"], frac_a, frac_b, frac_c,
+                                      constant_back, constant_forward, xint, gweight, tweight, alb)
+            elif is_sh:                                           # justdoit.py:259-269
+                sh_opt = inp["approx"]["rt_params"]["SH"]
+                sh_flux = None                                    # layer moment fluxes, flx = calculate_fluxes
+                if sh_opt["calculate_fluxes"]:
+                    sh_flux = DeviceArray((ng, nt, common["stream"] * nlevel, nwno), ctx)
+                _reflected_sh(ctx, nlevel, nwno, ng, nt, planes, rs, ubar0, ubar1, cos_theta, d_f0,
+                              sh_opt, frac_a, frac_b, frac_c, constant_back, constant_forward,
+                              common["stream"], b_top, xint, gweight, tweight, alb, sh_flux)
+                if sh_flux is not None:
+                    atm.flux_layers = sh_flux.to_host()
             else:
-                returns["fpfs_reflected"] = []
-        collect.append(collect_reflected)
-    if "thermal" in calculation:
-        d_wno = _resident_vector(opa, "wno", wno, nwno)
-        flux = DeviceArray((ng, nt, nwno), tctx)
-        disk = DeviceArray((nwno,), tctx)
-        if dimension == "3d":                                 # justdoit.py:502-514
-            resident.thermal_3d(ctx, nlevel, d_wno, nwno, ng, nt, tlev3, planes3d["dtau_og"],
-                                planes3d["w0_no_raman"], planes3d["cosb_og"], plev3, ubar1, rs,
-                                atm.hard_surface, flux, gweight, tweight, disk)
-        elif is_sh:                                           # justdoit.py:364-370
-            _thermal_sh(ctx, nlevel, d_wno, nwno, ng, nt, atm.level["temperature"], planes,
-                        atm.level["pressure"], ubar1, rs, common["stream"], atm.hard_surface,
-                        common["delta_eddington"], flux, gweight, tweight, disk)
-        else:
-            def runt(pl, fx, fuse):                           # the ngauss loop of justdoit.py:328-380
-                kw = dict(gweight=gweight, tweight=tweight, flux_disk=disk) if fuse else {}
-                if ngauss > 1:
-                    resident.thermal_1d_ck(tctx, nlevel, d_wno, nwno, ngauss, ng, nt, atm.level["temperature"],
-                                           pl["dtau_og"], pl["w0_no_raman"], pl["cosb_og"],
-                                           atm.level["pressure"], ubar1, rs, atm.hard_surface, gauss_wts,
-                                           fx, **kw)
+                lvl = [DeviceArray((ng, nt, nlevel, nwno), ctx) for _ in range(4)] if atm.get_lvl_flux else None
+                tt = (toon["single_phase"], toon["multi_phase"], frac_a, frac_b, frac_c, constant_back,
+                      constant_forward)
+
+                def run(pl, x, lv, fuse):                         # the ngauss loop of justdoit.py:256-307
+                    if ngauss > 1:
+                        resident.reflected_1d_ck(ctx, nlevel, nwno, ngauss, ng, nt, pl, rs, ubar0, ubar1,
+                                                 cos_theta, d_f0, *tt, gauss_wts, x,
+                                                 toon_coefficients=toon["toon_coefficients"], b_top=b_top,
+                                                 gweight=gweight if fuse else None,
+                                                 tweight=tweight if fuse else None, albedo=alb if fuse else None,
+                                                 lvl_fluxes=lv)
+                    else:
+                        _reflected(ctx, nlevel, nwno, ng, nt, pl, rs, ubar0, ubar1, cos_theta, d_f0, *tt,
+                                   toon["toon_coefficients"], b_top, x, lv, gweight, tweight,
+                                   alb if fuse else None)
+                if not do_holes:
+                    run(planes, xint, lvl, True)
+                else:                                             # justdoit.py:287-305
+                    xc = DeviceArray((ng, nt, nwno), ctx)
+                    lvc = [DeviceArray((ng, nt, nlevel, nwno), ctx) for _ in range(4)] if lvl else None
+                    run(planes, xint, lvl, False)
+                    run(planes_clear, xc, lvc, False)
+                    resident.axpby(ctx, 1.0 - fhole, xint, fhole, xc, xint)
+                    for a_, b_ in zip(lvl or [], lvc or []):
+                        resident.axpby(ctx, 1.0 - fhole, a_, fhole, b_, a_)
+                    resident.compress_disco(ctx, nwno, cos_theta, xint, gweight, tweight, d_f0, alb)
+
+            def collect_reflected():          # read back after every leg has been enqueued (see `collect`)
+                albedo = alb.to_host()
+                returns["albedo"] = albedo
+                if full_output:
+                    atm.xint_at_top = xint.to_host()
+                if lvl is not None:
+                    # justdoit.py:536-548: every level disk-integrated with compress_disco(..., F0PI = 1):
+                    # (nlevel, nwno) arrays; on the device over nlevel*nwno columns (F0PI = None means 1)
+                    atm.lvl_output_reflected = {}
+                    for key, a_ in zip(("flux_minus", "flux_plus", "flux_minus_mdpt", "flux_plus_mdpt"), lvl):
+                        dsum = DeviceArray((nlevel, nwno), ctx)
+                        resident.compress_disco(ctx, nlevel * nwno, cos_theta, a_, gweight, tweight, None, dsum)
+                        atm.lvl_output_reflected[key] = dsum.to_host()
+                # Batalha+2019 eq. 18 (justdoit.py:552-553)
+                returns["bond_albedo"] = (np.trapezoid(x=1 / wno, y=albedo * stellar) /
+                                          np.trapezoid(x=1 / wno, y=stellar))
+                if (not np.isnan(sa)) and (not np.isnan(atm.planet.radius)):
+                    returns["fpfs_reflected"] = albedo * (atm.planet.radius / sa) ** 2.0
                 else:
-                    resident.thermal_1d(tctx, nlevel, d_wno, nwno, ng, nt, atm.level["temperature"],
-                                        pl["dtau_og"], pl["w0_no_raman"], pl["cosb_og"],
-                                        atm.level["pressure"], ubar1, rs, atm.hard_surface, fx, **kw)
-            if not do_holes:
-                runt(planes, flux, True)
-            else:                                             # justdoit.py:346-361
-                fc = DeviceArray((ng, nt, nwno), tctx)
-                runt(planes, flux, False)
-                runt(planes_clear, fc, False)
-                resident.axpby(tctx, 1.0 - fhole, flux, fhole, fc, flux)
-                resident.compress_thermal(tctx, nwno, flux, gweight, tweight, disk)
-
-        def collect_thermal():
-            thermal = disk.to_host()
-            returns["thermal"] = thermal
-            returns["thermal_unit"] = "erg/s/(cm^2)/(cm)"
-            returns["effective_temperature"] = (np.trapezoid(x=1 / wno[::-1], y=thermal[::-1]) / 5.67e-5) ** 0.25
-            if full_output:
-                atm.flux_at_top = flux.to_host()
-            if radius_star == "nostar":
-                returns["fpfs_thermal"] = ["No star mode for Brown Dwarfs was used"]
-            elif (not np.isnan(atm.planet.radius)) and (not np.isnan(radius_star)):
-                returns["fpfs_thermal"] = thermal / stellar * (atm.planet.radius / radius_star) ** 2.0
+                    returns["fpfs_reflected"] = []
+            collect.append(collect_reflected)
+        if "thermal" in calculation:
+            d_wno = _resident_vector(opa, "wno", wno, nwno)
+            flux = DeviceArray((ng, nt, nwno), tctx)
+            disk = DeviceArray((nwno,), tctx)
+            if dimension == "3d":                                 # justdoit.py:502-514
+                resident.thermal_3d(ctx, nlevel, d_wno, nwno, ng, nt, tlev3, planes3d["dtau_og"],
+                                    planes3d["w0_no_raman"], planes3d["cosb_og"], plev3, ubar1, rs,
+                                    atm.hard_surface, flux, gweight, tweight, disk)
+            elif is_sh:                                           # justdoit.py:364-370
+                _thermal_sh(ctx, nlevel, d_wno, nwno, ng, nt, atm.level["temperature"], planes,
+                            atm.level["pressure"], ubar1, rs, common["stream"], atm.hard_surface,
+                            common["delta_eddington"], flux, gweight, tweight, disk)
             else:
-                returns["fpfs_thermal"] = []
-        collect.append(collect_thermal)
-    if "transmission" in calculation:                         # justdoit.py:388-405, :522-523
-        if dimension != "1d":
-            raise Exception("transmission is a 1-D calculation (the reference has no 3-D branch for it)")
-        if radius_star == "nostar" or np.isnan(radius_star) or np.isnan(atm.planet.radius):
-            raise Exception("transmission needs the stellar radius (star()) and the planet radius and "
-                            "mass (gravity())")
-        tr = DeviceArray((nwno,), ctx)
+                # get_lvl_flux switches the thermal leg to calc_type = 1 with dwno = wno*0 (justdoit.py:322-327,
+                # :342): the bin-mean Planck function in wavenumber units, also for the top-of-atmosphere flux
+                tlvl = [DeviceArray((ng, nt, nlevel, nwno), tctx) for _ in range(4)] if atm.get_lvl_flux else None
+                tkw = {}
+                if tlvl is not None:
+                    tkw = dict(dwno=DeviceArray.zeros((nwno,), tctx), calc_type=1)
 
-        def runtr(pl, out):
-            resident.transit_1d_ck(ctx, atm.level["z"], atm.level["dz"], nlevel, nwno, ngauss, radius_star,
-                                   atm.layer["mmw"], atm.c.k_b, atm.c.amu, atm.level["pressure"],
-                                   atm.level["temperature"], atm.layer["colden"], pl["dtau_og"], gauss_wts, out)
-        runtr(planes, tr)
-        if do_holes:                                          # blend per Gauss point == blend of the sums
-            trc = DeviceArray((nwno,), ctx)
-            runtr(planes_clear, trc)
-            resident.axpby(ctx, 1.0 - fhole, tr, fhole, trc, tr)
-        returns["transit_depth"] = tr.to_host()
-    for fin in collect:
-        fin()
+                def runt(pl, fx, lv, fuse):                       # the ngauss loop of justdoit.py:328-380
+                    kw = dict(gweight=gweight, tweight=tweight, flux_disk=disk) if fuse else {}
+                    kw.update(tkw)
+                    if ngauss > 1:
+                        resident.thermal_1d_ck(tctx, nlevel, d_wno, nwno, ngauss, ng, nt, atm.level["temperature"],
+                                               pl["dtau_og"], pl["w0_no_raman"], pl["cosb_og"],
+                                               atm.level["pressure"], ubar1, rs, atm.hard_surface, gauss_wts,
+                                               fx, lvl_fluxes=lv, **kw)
+                    else:
+                        resident.thermal_1d(tctx, nlevel, d_wno, nwno, ng, nt, atm.level["temperature"],
+                                            pl["dtau_og"], pl["w0_no_raman"], pl["cosb_og"],
+                                            atm.level["pressure"], ubar1, rs, atm.hard_surface, fx, lvl_fluxes=lv, **kw)
+                if not do_holes:
+                    runt(planes, flux, tlvl, True)
+                else:                                             # justdoit.py:346-361
+                    fc = DeviceArray((ng, nt, nwno), tctx)
+                    tlvc = [DeviceArray((ng, nt, nlevel, nwno), tctx) for _ in range(4)] if tlvl else None
+                    runt(planes, flux, tlvl, False)
+                    runt(planes_clear, fc, tlvc, False)
+                    resident.axpby(tctx, 1.0 - fhole, flux, fhole, fc, flux)
+                    for a_, b_ in zip(tlvl or [], tlvc or []):
+                        resident.axpby(tctx, 1.0 - fhole, a_, fhole, b_, a_)
+                    resident.compress_thermal(tctx, nwno, flux, gweight, tweight, disk)
+                tlvl_disk = None
+                if tlvl is not None:                              # justdoit.py:575-580, disk sums on the device
+                    tlvl_disk = []
+                    for a_ in tlvl:
+                        dsum = DeviceArray((nlevel, nwno), tctx)
+                        resident.compress_thermal(tctx, nlevel * nwno, a_, gweight, tweight, dsum)
+                        tlvl_disk.append(dsum)
+
+            def collect_thermal():
+                thermal = disk.to_host()
+                returns["thermal"] = thermal
+                returns["thermal_unit"] = "erg/s/(cm^2)/(cm)"
+                returns["effective_temperature"] = (np.trapezoid(x=1 / wno[::-1], y=thermal[::-1]) / 5.67e-5) ** 0.25
+                if full_output:
+                    atm.flux_at_top = flux.to_host()
+                if dimension != "3d" and not is_sh and tlvl_disk is not None:
+                    # energy per wavenumber bin: disk-integrated level flux * delta_wno (justdoit.py:575-580)
+                    delta_wno = getattr(opa, "delta_wno", None)
+                    if delta_wno is None:
+                        delta_wno = np.concatenate((np.diff(wno), [np.diff(wno)[-1]]))
+                    atm.lvl_output_thermal = {
+                        key: a_.to_host() * delta_wno
+                        for key, a_ in zip(("flux_minus", "flux_plus", "flux_minus_mdpt", "flux_plus_mdpt"), tlvl_disk)}
+                if radius_star == "nostar":
+                    returns["fpfs_thermal"] = ["No star mode for Brown Dwarfs was used"]
+                elif (not np.isnan(atm.planet.radius)) and (not np.isnan(radius_star)):
+                    returns["fpfs_thermal"] = thermal / stellar * (atm.planet.radius / radius_star) ** 2.0
+                else:
+                    returns["fpfs_thermal"] = []
+            collect.append(collect_thermal)
+        if "transmission" in calculation:                         # justdoit.py:388-405, :522-523
+            if dimension != "1d":
+                raise Exception("transmission is a 1-D calculation (the reference has no 3-D branch for it)")
+            if radius_star == "nostar" or np.isnan(radius_star) or np.isnan(atm.planet.radius):
+                raise Exception("transmission needs the stellar radius (star()) and the planet radius and "
+                                "mass (gravity())")
+            tr = DeviceArray((nwno,), ctx)
+
+            def runtr(pl, out):
+                resident.transit_1d_ck(ctx, atm.level["z"], atm.level["dz"], nlevel, nwno, ngauss, radius_star,
+                                       atm.layer["mmw"], atm.c.k_b, atm.c.amu, atm.level["pressure"],
+                                       atm.level["temperature"], atm.layer["colden"], pl["dtau_og"], gauss_wts, out)
+            runtr(planes, tr)
+            if do_holes:                                          # blend per Gauss point == blend of the sums
+                trc = DeviceArray((nwno,), ctx)
+                runtr(planes_clear, trc)
+                resident.axpby(ctx, 1.0 - fhole, tr, fhole, trc, tr)
+            returns["transit_depth"] = tr.to_host()
+        for fin in collect:
+            fin()
+    finally:
+        # an exception between enqueueing the thermal leg on the second stream and its copy back must
+        # not let the plane blocks return to the pool while that stream may still read them
+        if tctx is not ctx:
+            try:
+                device.sync(tctx)
+            except Exception:
+                pass
     if ("fpfs_reflected" in returns) and ("fpfs_thermal" in returns):
         if (not isinstance(returns["fpfs_reflected"], list)) and (not isinstance(returns["fpfs_thermal"], list)):
             returns["fpfs_total"] = returns["fpfs_thermal"] + returns["fpfs_reflected"]

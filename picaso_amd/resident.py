@@ -60,7 +60,7 @@ def reflected_1d(ctx, nlevel, nwno, numg, numt, planes, surf_reflect, ubar0, uba
 
 def thermal_1d(ctx, nlevel, wno, nwno, numg, numt, tlevel, dtau, w0, cosb, plevel, ubar1,
                surf_reflect, hard_surface, flux_at_top, dwno=None, calc_type=0, gweight=None,
-               tweight=None, flux_disk=None, plane_pitch=None):
+               tweight=None, flux_disk=None, plane_pitch=None, lvl_fluxes=None):
     """Asynchronous ``get_thermal_1d`` on resident planes (+ optional fused ``compress_thermal``).
     ``wno``/``dwno``/``surf_reflect`` and the planes are device-resident; tlevel/plevel host."""
     u1 = f64(ubar1, (numg, numt))
@@ -71,8 +71,9 @@ def thermal_1d(ctx, nlevel, wno, nwno, numg, numt, tlevel, dtau, w0, cosb, pleve
     check(load().picaso_get_thermal_1d_dev(
         ctx, _ci(nlevel), _addr(wno), _ci(nwno), ctypes.c_long(pitch), _ci(numg), _ci(numt),
         ptr(tl), _addr(dtau), _addr(w0), _addr(cosb), ptr(pl), ptr(u1), _addr(surf_reflect),
-        _ci(int(hard_surface)), _addr(dwno), _ci(calc_type), _addr(flux_at_top), None, None, None,
-        None, ptr(gw) if gw is not None else None, ptr(tw) if tw is not None else None,
+        _ci(int(hard_surface)), _addr(dwno), _ci(calc_type), _addr(flux_at_top),
+        *[_addr(x) for x in (lvl_fluxes if lvl_fluxes is not None else [None] * 4)],
+        ptr(gw) if gw is not None else None, ptr(tw) if tw is not None else None,
         _addr(flux_disk)), ctx)
 
 

@@ -341,3 +341,55 @@ def test_gpu_overlapped_legs_stress(gold):
     for i in range(150):
         out = cases[i % 2].spectrum(opa, calculation="reflected+thermal")
         assert np.array_equal(out["albedo"], want[i % 2][0]) and np.array_equal(out["thermal"], want[i % 2][1]), i
+
+
+@pytest.mark.gpu
+def test_gpu_spectrum_level_fluxes_output_contract(gold, oracle):
+    """approx(get_lvl_flux=True): picaso() returns disk-integrated level fluxes, not the raw
+    (ng, nt, nlevel, nwno) arrays -- reflected: compress_disco(..., F0PI = 1) of every level
+    (reference justdoit.py:536-548), thermal: the calc_type = 1 solve with dwno = wno*0
+    (justdoit.py:322-327, 342), compress_thermal of every level times delta_wno (justdoit.py:575-580).
+    Expected values: [reference compute_opacity planes from the fixture -> CPU oracle solvers with
+    get_lvl_flux -> those reference lines restated with the oracle's compress_*]."""
+    from picaso_amd import disco
+    from picaso_amd import justdoit as jdi
+    opa = jdi.opannection(DB, query_method="linear")
+    case = _bundle(gold, jdi, None, True, 2, 2)
+    case.surface_reflect(0.2)
+    case.approx(raman="none", delta_eddington=True, get_lvl_flux=True)
+    out = case.spectrum(opa, calculation="reflected+thermal", full_output=True)
+    lev = out["full_output"]["level"]
+    key = "linear/de1_s2_r2_tmnone"
+    P = {nm: gold["%s/%s" % (key, nm)] for nm in NAMES}
+    nlevel, nwno = P["tau"].shape
+    g, gw, t, tw = disco.get_angles_1d(5)
+    u0, u1, ct, _, _ = disco.compute_disco(5, 1, g, t, 0.0)
+    x, lv = oracle.get_reflected_1d(nlevel, opa.wno, nwno, 5, 1, P["dtau"], P["tau"], P["w0"], P["cosb"],
+                                    P["gcos2"], P["ftau_cld"], P["ftau_ray"], P["dtau_og"], P["tau_og"],
+                                    P["w0_og"], P["cosb_og"], 0.2, u0, u1, 1.0, np.ones(nwno), 3, 0,
+                                    1.0, -1.0, 2.0, -0.5, 1.0, get_toa_intensity=1, get_lvl_flux=1)
+    names = ("flux_minus", "flux_plus", "flux_minus_mdpt", "flux_plus_mdpt")
+    assert set(lev["reflected_fluxes"]) == set(names) and set(lev["thermal_fluxes"]) == set(names)
+    for nm, data in zip(names, lv):
+        want = np.array([oracle.compress_disco(nwno, 1.0, data[:, :, i, :], gw, tw, np.ones(nwno))
+                         for i in range(nlevel)])
+        got = lev["reflected_fluxes"][nm]
+        assert got.shape == (nlevel, nwno)
+        assert scale_err_rows(got, want) < 1e-8, nm
+    f, tl = oracle.get_thermal_1d(nlevel, opa.wno, nwno, 5, 1, gold["in/tlevel"], P["dtau_og"],
+                                  P["w0_no_raman"], P["cosb_og"], gold["in/plevel_bar"] * 1e6, u1,
+                                  np.full(nwno, 0.2), 1, opa.wno * 0, 1)
+    delta_wno = np.concatenate((np.diff(opa.wno), [np.diff(opa.wno)[-1]]))
+    for nm, data in zip(names, tl):
+        want = oracle.compress_thermal(nwno, data, gw, tw) * delta_wno
+        got = lev["thermal_fluxes"][nm]
+        assert got.shape == (nlevel, nwno)
+        assert scale_err_rows(got, want) < 2e-7, nm          # thick-layer level fluxes: see helpers.lvl_excess
+    assert rel_err(out["thermal"], oracle.compress_thermal(nwno, f, gw, tw)) < 1e-8
+
+
+def scale_err_rows(got, want):
+    """max |got - want| over the per-wavelength scale of the field"""
+    scale = np.max(np.abs(want), axis=0, keepdims=True)
+    scale = np.where(scale == 0, 1.0, scale)
+    return float(np.max(np.abs(got - want) / scale))
