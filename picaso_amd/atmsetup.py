@@ -87,6 +87,10 @@ class ATMSETUP:
         self.warnings += [w]
 
     def get_profile(self):
+        """Level columns -> level / layer state.  Columns are ``(nlevel,)`` arrays, or -- the facet form
+        the 3-D path uses -- ``(nlevel, nfacets)`` for the facet-dependent ones and ``(nlevel, 1)`` for
+        the shared ones: every method below slices along axis 0 only, so one ATMSETUP then carries all
+        facets at once (64 facet set-ups per 3-D spectrum become one)."""
         read = self.input["atmosphere"]["profile"]           # dict-like / DataFrame of level columns
         cols = list(read.keys())
         weights, molecules = {}, []
@@ -116,7 +120,7 @@ class ATMSETUP:
         self.c.nlayer = self.c.nlevel - 1
 
     def get_mmw(self):
-        w = np.zeros(self.c.nlevel)
+        w = 0.0                                               # 0 + x = x exactly: as np.zeros(nlevel) + ...
         for m in self.molecules:
             w = w + self.level["mixingratios"][m] * self.weights[m]
         self.level["mmw"] = w
@@ -146,11 +150,12 @@ class ATMSETUP:
             p_reference = np.max(plevel)
         else:
             p_reference = plevel[plevel >= p_reference][0]    # snap to the pressure grid (:414)
-        z = np.zeros(np.shape(tlevel)) + planet.radius
-        dz = np.zeros(np.shape(tlevel))
-        gravity = np.zeros(np.shape(tlevel))
+        shape = np.broadcast(tlevel, mmw, plevel).shape       # (nlevel,) or, facet form, (nlevel, nfacets)
+        z = np.zeros(shape) + planet.radius
+        dz = np.zeros(shape)
+        gravity = np.zeros(shape)
         n = len(plevel)
-        if constant_gravity and n > 1 and np.all(np.diff(plevel) > 0):
+        if constant_gravity and n > 1 and np.ndim(tlevel) == 1 and np.all(np.diff(plevel) > 0):
             # same arithmetic as the level loops below, element-wise (gravity does not depend on z;
             # the running sums are sequential like the loops): 64 facets x 91 levels per 3-D spectrum
             g = planet.gravity
@@ -167,7 +172,15 @@ class ATMSETUP:
             return self._finish_altitude(z, dz, gravity, lambda i: g, tlevel, mmw)
 
         def g_at(i):
-            return planet.gravity if constant_gravity else c.G * planet.mass / z[i] ** 2
+            if constant_gravity:
+                return planet.gravity
+            zi = z[i]
+            if np.ndim(zi):
+                # facet form: libm pow() per element, which is what `z[i] ** 2` is for the numpy scalar of
+                # the 1-D path (and of the reference); numpy squares ARRAYS as x*x, one ulp off now and then
+                import math
+                return c.G * planet.mass / np.array([math.pow(v, 2.0) for v in zi])
+            return c.G * planet.mass / zi ** 2
 
         below = np.unique(np.where(plevel > p_reference)[0])
         for i in below - 1:                                   # inwards from the reference level

@@ -19,17 +19,35 @@ def sources():
     return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
 
 
-def stale():
-    if not os.path.exists(LIB):
-        return True
-    t = os.path.getmtime(LIB)
-    deps = sources() + glob.glob(os.path.join(CSRC, "*.hpp")) + \
+STAMP = LIB + ".srchash"
+
+
+def source_hash():
+    """sha256 over every input of the build: csrc/*.hip, csrc/*.hpp, the C header and the flags."""
+    import hashlib
+    h = hashlib.sha256()
+    deps = sources() + sorted(glob.glob(os.path.join(CSRC, "*.hpp"))) + \
         [os.path.join(os.path.dirname(HERE), "include", "picaso_hip.h")]
-    return any(os.path.getmtime(d) > t for d in deps)
+    for d in deps:
+        h.update(os.path.basename(d).encode())
+        with open(d, "rb") as fh:
+            h.update(fh.read())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()
+
+
+def stale():
+    """The library is current when the hash stored beside it equals the hash of the sources (file
+    times say nothing after a checkout or a copy to another box)."""
+    if not (os.path.exists(LIB) and os.path.exists(STAMP)):
+        return True
+    with open(STAMP) as fh:
+        return fh.read().strip() != source_hash()
 
 
 def build(force=False, verbose=False):
     if not force and not stale():
+        print("picaso_amd.build: libpicaso_hip.so reused (source hash %s matches)" % source_hash()[:12])
         return LIB
     objs = []
     procs = []
@@ -52,6 +70,9 @@ def build(force=False, verbose=False):
     # librccl.so: the multi-GPU layer (csrc/comm.hip) calls RCCL directly
     subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs +
                           ["-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"])
+    with open(STAMP, "w") as fh:
+        fh.write(source_hash() + "\n")
+    print("picaso_amd.build: libpicaso_hip.so compiled for gfx950 (source hash %s)" % source_hash()[:12])
     return LIB
 
 

@@ -231,7 +231,13 @@ class inputs:
         if profs is None or len(profs) != len(phases):
             raise Exception("atmosphere_4d() needs one profile per phase (%d)" % len(phases))
         calculation = all_geom["calculation"]
-        results = {}
+        # Every phase is enqueued before the first result is copied back: the GPU runs the phases back to
+        # back while the host sets up the next one (one facet-form ATMSETUP and one batched gas stage per
+        # phase), and the copies back (each a stream synchronisation) come at the end.  The input planes
+        # of a phase return to the context's block cache as soon as its kernels are enqueued (reuse is
+        # ordered on the stream); at most `in_flight` phases keep their small result buffers pending.
+        in_flight = int(os.environ.get("PICASO_AMD_PHASES_IN_FLIGHT", "16"))
+        results, pending = {}, []
         try:
             for i, ph in enumerate(phases):
                 if verbose:
@@ -241,8 +247,13 @@ class inputs:
                 self.inputs["atmosphere"]["profile_3d"] = profs[i]
                 if clouds_by_phase is not None:
                     self.inputs["clouds"]["profile_3d"] = clouds_by_phase[i]
-                results[ph] = self.spectrum(opacityclass, calculation=calculation, dimension="3d",
-                                            full_output=full_output, plot_opacity=plot_opacity)
+                pending.append((ph, picaso(self, opacityclass, dimension="3d", calculation=calculation,
+                                           full_output=full_output, plot_opacity=plot_opacity, defer=True)))
+                if len(pending) >= in_flight:
+                    p0, fin = pending.pop(0)
+                    results[p0] = fin()
+            for p0, fin in pending:
+                results[p0] = fin()
         finally:
             self.inputs["phase_angle"], self.inputs["disco"] = phases, all_geom
         return results
@@ -362,8 +373,12 @@ def _setup_atmosphere(inp, opa, wno, profile=None, cloud_profile=None):
 
 
 def picaso(bundle, opacityclass, dimension="1d", calculation="reflected", full_output=False,
-           plot_opacity=False, as_dict=True):
-    """Spectrum driver (reference ``picaso()``, justdoit.py:65-621, 1-D Toon branch)."""
+           plot_opacity=False, as_dict=True, defer=False):
+    """Spectrum driver (reference ``picaso()``, justdoit.py:65-621, 1-D Toon branch).
+
+    ``defer=True`` (used by ``phase_curve``): every kernel of the spectrum is enqueued and a function is
+    returned that copies the results back and finishes the output dictionary -- the caller can enqueue
+    the next spectrum while the GPU is still working on this one."""
     inp = bundle.inputs
     opa = opacityclass
     ctx = opa.ctx
@@ -398,20 +413,36 @@ def picaso(bundle, opacityclass, dimension="1d", calculation="reflected", full_o
                             "no patchy clouds and no level fluxes")
         prof3 = inp["atmosphere"]["profile_3d"]
         cld3 = inp["clouds"].get("profile_3d")
-        atms = []
-        for g in range(ng):
-            row = []
-            for t in range(nt):
-                prof = {k: (v if v.ndim == 1 else v[:, g, t]) for k, v in prof3.items()}
-                row.append(_setup_atmosphere(inp, opa, wno, prof, None))
-            atms.append(row)
-        atm = atms[0][0]
-        planes3d = optics.compute_opacity_facets(
-            atms, opa, ng, nt, stream=common["stream"], delta_eddington=common["delta_eddington"],
-            test_mode=inp["test_mode"], raman=common["raman"], clouds_3d=cld3,
-            exclude_mol=inp["atmosphere"]["exclude_mol"])
-        tlev3 = np.stack([np.stack([a_.level["temperature"] for a_ in row], axis=1) for row in atms], axis=1)
-        plev3 = np.stack([np.stack([a_.level["pressure"] for a_ in row], axis=1) for row in atms], axis=1)
+        co3 = dict(stream=common["stream"], delta_eddington=common["delta_eddington"], test_mode=inp["test_mode"],
+                   raman=common["raman"], clouds_3d=cld3, exclude_mol=inp["atmosphere"]["exclude_mol"])
+        if os.environ.get("PICASO_AMD_FACET_LOOP"):           # A/B: one ATMSETUP + one gas launch per facet
+            atms = []
+            for g in range(ng):
+                row = []
+                for t in range(nt):
+                    prof = {k: (v if v.ndim == 1 else v[:, g, t]) for k, v in prof3.items()}
+                    row.append(_setup_atmosphere(inp, opa, wno, prof, None))
+                atms.append(row)
+            atm = atms[0][0]
+            planes3d = optics.compute_opacity_facets(atms, opa, ng, nt, **co3)
+            tlev3 = np.stack([np.stack([a_.level["temperature"] for a_ in row], axis=1) for row in atms], axis=1)
+            plev3 = np.stack([np.stack([a_.level["pressure"] for a_ in row], axis=1) for row in atms], axis=1)
+        else:
+            # all facets in ONE facet-form ATMSETUP ((nlevel, nfacets) columns; the reference builds one
+            # per facet, justdoit.py:437-449) and one batched gas stage
+            nfac, nlv = ng * nt, len(prof3["pressure"])
+            prof_f = {}
+            for k, v in prof3.items():
+                if k == "temperature":
+                    prof_f[k] = np.ascontiguousarray(np.broadcast_to(v.reshape(nlv, -1), (nlv, nfac)))
+                else:
+                    prof_f[k] = v.reshape(nlv, -1)            # (nlevel, 1) shared or (nlevel, nfacets)
+            atm_f = _setup_atmosphere(inp, opa, wno, prof_f, None)
+            atm = _setup_atmosphere(inp, opa, wno, {k: (v if v.ndim == 1 else v[:, 0, 0]) for k, v in prof3.items()},
+                                    None)                     # facet (0, 0): sizes, surface, full_output
+            planes3d = optics.compute_opacity_facets(atm_f, opa, ng, nt, **co3)
+            tlev3 = atm_f.level["temperature"].reshape(nlv, ng, nt)
+            plev3 = np.ascontiguousarray(np.broadcast_to(atm_f.level["pressure"].reshape(nlv, 1, 1), (nlv, ng, nt)))
     else:
         atm = _setup_atmosphere(inp, opa, wno)
     nlevel, nlayer = atm.c.nlevel, atm.c.nlayer
@@ -616,9 +647,10 @@ def picaso(bundle, opacityclass, dimension="1d", calculation="reflected", full_o
                 trc = DeviceArray((nwno,), ctx)
                 runtr(planes_clear, trc)
                 resident.axpby(ctx, 1.0 - fhole, tr, fhole, trc, tr)
-            returns["transit_depth"] = tr.to_host()
-        for fin in collect:
-            fin()
+            collect.append(lambda: returns.__setitem__("transit_depth", tr.to_host()))
+        if not defer:
+            for fin in collect:
+                fin()
     finally:
         # an exception between enqueueing the thermal leg on the second stream and its copy back must
         # not let the plane blocks return to the pool while that stream may still read them
@@ -627,12 +659,17 @@ def picaso(bundle, opacityclass, dimension="1d", calculation="reflected", full_o
                 device.sync(tctx)
             except Exception:
                 pass
-    if ("fpfs_reflected" in returns) and ("fpfs_thermal" in returns):
-        if (not isinstance(returns["fpfs_reflected"], list)) and (not isinstance(returns["fpfs_thermal"], list)):
-            returns["fpfs_total"] = returns["fpfs_thermal"] + returns["fpfs_reflected"]
-    if full_output:
-        returns["full_output"] = atm.as_dict() if as_dict else atm
-    return returns
+    def finish():
+        if defer:
+            for fin in collect:
+                fin()
+        if ("fpfs_reflected" in returns) and ("fpfs_thermal" in returns):
+            if (not isinstance(returns["fpfs_reflected"], list)) and (not isinstance(returns["fpfs_thermal"], list)):
+                returns["fpfs_total"] = returns["fpfs_thermal"] + returns["fpfs_reflected"]
+        if full_output:
+            returns["full_output"] = atm.as_dict() if as_dict else atm
+        return returns
+    return finish if defer else finish()
 
 
 def _reflected(ctx, nlevel, nwno, ng, nt, planes, rs, ubar0, ubar1, cos_theta, F0PI, single_phase,

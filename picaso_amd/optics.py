@@ -508,10 +508,17 @@ def _layer_factors(atm, opacityclass):
         mol_fac = [pl["fac"][i] * (colden * x(m) / mmw) for i, m in enumerate(pl["molecules"])]   # :246-249
     ray_names = [m for m in atm.rayleigh_molecules if m in opacityclass._ray]
     ray_fac = [colden * x(m) / mmw for m in ray_names]     # optics.py:265-271
-    shape = (0, nlayer)
-    return (np.array(mol_fac).reshape((-1, nlayer)) if mol_fac else np.zeros(shape),
-            np.array(cont_fac).reshape((-1, nlayer)) if cont_fac else np.zeros(shape),
-            ray_names, np.array(ray_fac).reshape((-1, nlayer)) if ray_fac else np.zeros(shape))
+    nfac = tlayer.shape[1] if tlayer.ndim == 2 else 0         # facet form of ATMSETUP: (nlayer, nfacets)
+
+    def table(rows):
+        """(nspecies, nlayer) -- or facet-major (nspecies, nfacets*nlayer) for a facet atmosphere"""
+        if not rows:
+            return np.zeros((0, nlayer * max(nfac, 1)))
+        if nfac == 0:
+            return np.array(rows).reshape((-1, nlayer))
+        full = np.stack([np.broadcast_to(r, (nlayer, nfac)) for r in rows])       # (n, nlayer, nfac)
+        return np.ascontiguousarray(full.transpose(0, 2, 1)).reshape(len(rows), nfac * nlayer)
+    return table(mol_fac), table(cont_fac), ray_names, table(ray_fac)
 
 
 def gas_stage(atm, opa, taugas, tauray):
@@ -536,6 +543,12 @@ def gas_stage(atm, opa, taugas, tauray):
               cont_fac if cont_tabs else None, [opa._ray[m] for m in ray_names],
               ray_fac if ray_names else None, taugas, tauray, mol_mode=mol_mode, cont_wts=cont_wts,
               ngauss=ngauss)
+
+
+def types_namespace_layer(atm_f, tlayer):
+    """One facet's view of a facet-form atmosphere: what raman_plane_host reads."""
+    import types
+    return types.SimpleNamespace(c=atm_f.c, layer={"temperature": tlayer})
 
 
 def raman_plane_host(atm, opa, raman):
@@ -571,6 +584,44 @@ def raman_pollack(nlayer, wave, table=None):
     return np.repeat(row[None, :], nlayer, axis=0)
 
 
+def gas_stage_facets(atm_f, opa, nfac, tg3, tr3, exclude_mol=1):
+    """TAUGAS / TAURAY of every facet from ONE facet-form atmosphere (``ATMSETUP`` with
+    ``(nlevel, nfacets)`` columns): the facet stack ``(nfacets, nlayer, nwno)`` is a tall atmosphere of
+    ``nfacets*nlayer`` layers for ``k_opacity_gas``, so the bracket search, the layer coefficients and the
+    launch run once over all facets (chunked only so the per-layer tables fit one upload slot) instead
+    of once per facet (reference loop: justdoit.py:437-471).  Same arithmetic per element as the
+    per-facet path: the results are bit-identical (tests/test_ck_optics.py)."""
+    import types
+    nlayer = atm_f.c.nlayer
+    ntot = nfac * nlayer
+
+    def flat(a):                      # (nlayer, nfacets | 1) -> facet-major (nfacets*nlayer,)
+        return np.ascontiguousarray(np.broadcast_to(np.asarray(a, dtype=float), (nlayer, nfac)).T).ravel()
+    tall = types.SimpleNamespace(
+        c=types.SimpleNamespace(nlayer=ntot, pconv=atm_f.c.pconv),
+        layer={"temperature": flat(atm_f.layer["temperature"]), "pressure": flat(atm_f.layer["pressure"])},
+        molecules=atm_f.molecules, continuum_molecules=atm_f.continuum_molecules)
+    opa.get_opacities(tall, exclude_mol=exclude_mol)
+    pl = opa._plan
+    if pl.get("premixed"):
+        raise Exception("the 3-D path takes monochromatic opacities")
+    mol_fac, cont_fac, ray_names, ray_fac = _layer_factors(atm_f, opa)
+    mol_tabs = [(opa._mol_log if opa.query_method == "linear" else opa._mol_raw)[m] for m in pl["molecules"]]
+    mol_mode = 1 if opa.query_method == "linear" else 0
+    cont_tabs = [opa._cia[p] for p in pl["cia_pairs"]]
+    ray_tabs = [opa._ray[m] for m in ray_names]
+    per_layer = len(mol_tabs) * (16 + 32 + 8) + len(cont_tabs) * (4 + 8) + len(ray_tabs) * 8 + 8
+    fchunk = max(1, int((900 * 1024) // (per_layer * nlayer)))          # one 1 MB upload slot per launch
+    for f0 in range(0, nfac, fchunk):
+        f1 = min(nfac, f0 + fchunk)
+        sl = slice(f0 * nlayer, f1 * nlayer)
+        cont_rows = np.repeat(pl["cia_rows"][None, sl], len(cont_tabs), axis=0) if cont_tabs else None
+        _gas_call(opa, (f1 - f0) * nlayer, mol_tabs, pl["rows"][:, sl] if mol_tabs else None,
+                  pl["wts"][:, sl] if mol_tabs else None, mol_fac[:, sl] if mol_tabs else None, cont_tabs,
+                  cont_rows, cont_fac[:, sl] if cont_tabs else None, ray_tabs, ray_fac[:, sl] if ray_tabs else None,
+                  tg3.row_block(f0), tr3.row_block(f0), mol_mode=mol_mode, ngauss=1)
+
+
 def compute_opacity_facets(atms, opacityclass, numg, numt, stream=2, delta_eddington=True, test_mode=None,
                            raman=0, clouds_3d=None, exclude_mol=1):
     """3-D path: the 13 ``(nlayer|nlevel, nwno, numg, numt)`` planes ``get_reflected_3d`` /
@@ -581,12 +632,21 @@ def compute_opacity_facets(atms, opacityclass, numg, numt, stream=2, delta_eddin
     opa = opacityclass
     ctx = opa.ctx
     nfac = numg * numt
-    nlayer, nwno = atms[0][0].c.nlayer, opa.nwno
+    nlayer, nwno = (atms[0][0] if isinstance(atms, list) else atms).c.nlayer, opa.nwno
     if opa.ngauss != 1:
         raise Exception("compute_opacity_facets takes monochromatic opacities")
     tg3, tr3 = DeviceArray((nfac, nlayer, nwno), ctx), DeviceArray((nfac, nlayer, nwno), ctx)
     rf3 = [] if raman in (0, 1) else None
-    for g in range(numg):
+    if not isinstance(atms, list):                            # one facet-form atmosphere: batched gas stage
+        atm_f = atms
+        gas_stage_facets(atm_f, opa, nfac, tg3, tr3, exclude_mol=exclude_mol)
+        if rf3 is not None:
+            tl = np.broadcast_to(np.asarray(atm_f.layer["temperature"], dtype=float), (nlayer, nfac))
+            for f in range(nfac):
+                one = types_namespace_layer(atm_f, tl[:, f])
+                rf3.append(raman_plane_host(one, opa, raman))
+        atms = None
+    for g in range(numg if atms is not None else 0):
         for t in range(numt):
             f = g * numt + t
             opa.get_opacities(atms[g][t], exclude_mol=exclude_mol)

@@ -281,6 +281,48 @@ def test_gpu_3d_spectrum_end_to_end(og, oracle):
     assert rel_err(out["thermal"], oracle.compress_thermal(nwno, f, gw, tw)) < 1e-7
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("raman,radius", [("none", False), ("oklopcic", False), ("none", True), ("oklopcic", True)])
+def test_gpu_3d_batched_facets_equal_per_facet_loop(og, raman, radius, monkeypatch):
+    """The 3-D path sets all facets up in ONE facet-form ATMSETUP and gathers their gas optical depths in
+    one batched launch; the per-facet loop (one ATMSETUP, bracket search and launch per facet, the
+    reference's structure justdoit.py:437-471) gives bit-identical spectra -- facets with their own
+    temperature and water profiles, constant and altitude-dependent gravity, with and without the
+    per-facet Raman plane."""
+    from picaso_amd import justdoit as jdi
+    ng, nt = 4, 3
+    opa = jdi.opannection(DB, query_method="linear")
+    if raman == "oklopcic":
+        gold = np.load(os.path.join(GOLDEN, "optics.npz"))
+        opa.raman_stellar_shifts = gold["in/raman_shifts"]
+        opa.raman_db = {"c": gold["in/raman_c"], "ji": gold["in/raman_ji"], "deltanu": gold["in/raman_deltanu"]}
+    pert = 1.0 + 0.15 * np.cos(np.arange(ng * nt).reshape(ng, nt))
+
+    def run():
+        case = jdi.inputs()
+        case.phase_angle(np.pi / 4, num_gangle=ng, num_tangle=nt)
+        if radius:
+            case.gravity(radius=7.0e9, mass=1.9e30)
+        else:
+            case.gravity(gravity=float(og["in/gravity"]))
+        prof = {"pressure": og["in/plevel_bar"], "temperature": og["in/tlevel"][:, None, None] * pert[None]}
+        for k in ("H2", "He", "CH4"):
+            prof[k] = og["in/mix/" + k]
+        prof["H2O"] = og["in/mix/H2O"][:, None, None] * (2.0 - pert)[None]
+        case.atmosphere_3d(prof)
+        case.approx(raman=raman, delta_eddington=True)
+        case.surface_reflect(0.1)
+        return case.spectrum(opa, calculation="reflected+thermal", dimension="3d", full_output=True)
+    a = run()
+    monkeypatch.setenv("PICASO_AMD_FACET_LOOP", "1")
+    b = run()
+    for k in ("albedo", "thermal"):
+        assert np.all(np.isfinite(a[k]))
+        assert np.array_equal(a[k], b[k]), k
+    assert np.array_equal(a["full_output"]["albedo_3d"], b["full_output"]["albedo_3d"])
+    assert np.array_equal(a["full_output"]["thermal_3d"], b["full_output"]["thermal_3d"])
+
+
 # ---- on-the-fly gas mixing through the class (reference optics.py:1164-1278) ----------------------
 def _fly_atm(og):
     import types
@@ -390,3 +432,56 @@ def test_gpu_phase_curve_equals_single_phase_runs(og, calc):
         want = one.spectrum(opa, calculation=calc, dimension="3d")
         assert np.array_equal(curve[ph][key], want[key]), (calc, ph)
     assert not np.array_equal(curve[phases[0]][key], curve[phases[2]][key])
+
+
+@pytest.mark.gpu
+def test_gpu_phase_curve_against_oracle_solver(og, oracle):
+    """phase_curve() with every phase enqueued before the first copy back: per phase, the planes of the
+    product's own opacity stage (facet-form ATMSETUP + batched gas stage, pinned to the reference by
+    the tests above) go through the CPU oracle's get_reflected_3d / compress_disco (and get_thermal_3d /
+    compress_thermal for a thermal curve) -- an independent check of the solver and disk integration of
+    every phase, next to the self-consistency test above."""
+    from picaso_amd import disco, optics
+    from picaso_amd import justdoit as jdi
+    opa = jdi.opannection(DB, query_method="linear")
+    ng, nt = 4, 3
+    phases = [0.0, 0.7, 1.9, 3.0, 4.4]
+    nlevel = len(og["in/tlevel"])
+
+    def profile(k):
+        dT = 30.0 * (k + 1) * np.cos(np.arange(ng * nt).reshape(ng, nt) + k)[None]
+        pr = {"pressure": og["in/plevel_bar"], "temperature": og["in/tlevel"][:, None, None] + dT}
+        for m in ("H2", "He", "H2O", "CH4"):
+            pr[m] = og["in/mix/" + m]
+        return pr
+    for calc in ("reflected", "thermal"):
+        case = jdi.inputs()
+        case.gravity(gravity=float(og["in/gravity"]))
+        case.approx(raman="none")
+        case.surface_reflect(0.15)
+        case.phase_curve_geometry(calc, phases, num_gangle=ng, num_tangle=nt)
+        case.atmosphere_4d([profile(k) for k in range(len(phases))])
+        curve = case.phase_curve(opa, full_output=True)
+        gg, gw, tt, tw = disco.get_angles_3d(ng, nt)
+        for k, ph in enumerate(phases):
+            prof3 = {kk: np.asarray(v, dtype=float) for kk, v in profile(k).items()}
+            prof_f = {kk: (np.ascontiguousarray(np.broadcast_to(v.reshape(nlevel, -1), (nlevel, ng * nt)))
+                           if kk == "temperature" else v.reshape(nlevel, -1)) for kk, v in prof3.items()}
+            atm_f = jdi._setup_atmosphere(case.inputs, opa, opa.wno, prof_f, None)
+            P = optics.compute_opacity_facets(atm_f, opa, ng, nt, stream=2, delta_eddington=True, test_mode=None,
+                                              raman=2, clouds_3d=None, exclude_mol=1)
+            P = {kk: v.to_host() for kk, v in P.items()}
+            nwno = opa.nwno
+            u0, u1, ct, _, _ = disco.compute_disco(ng, nt, gg, tt, ph if calc == "reflected" else 0.0)
+            if calc == "reflected":
+                x = oracle.get_reflected_3d(nlevel, opa.wno, nwno, ng, nt, *[P[kk] for kk in PLANES], 0.15, u0, u1,
+                                            ct, np.ones(nwno), 3, 0, *TTHG)
+                assert rel_err(curve[ph]["full_output"]["albedo_3d"], x) < 1e-8, ph
+                assert rel_err(curve[ph]["albedo"], oracle.compress_disco(nwno, ct, x, gw, tw, np.ones(nwno))) < 1e-8
+            else:
+                tl3 = prof3["temperature"]
+                pl3 = np.repeat((og["in/plevel_bar"] * 1e6)[:, None, None], ng, 1).repeat(nt, 2)
+                f = oracle.get_thermal_3d(nlevel, opa.wno, nwno, ng, nt, tl3, P["dtau_og"], P["w0_no_raman"],
+                                          P["cosb_og"], pl3, u1, np.full(nwno, 0.15), 1)
+                assert rel_err(curve[ph]["full_output"]["thermal_3d"], f) < 1e-8, ph
+                assert rel_err(curve[ph]["thermal"], oracle.compress_thermal(nwno, f, gw, tw)) < 1e-8
