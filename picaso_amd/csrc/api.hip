@@ -91,9 +91,10 @@ static std::vector<int> angle_chunks(int n)
 // Run each angle as its own wave (grid.y) instead of carrying them in one lane?  Worth it while all
 // angle-waves together still fit about one wave per SIMD (1024 SIMDs): measured on the reflected
 // kernel with 5 angles, 10 000 columns 0.093 ms vs 0.183 ms fused, 30 000 columns 0.217 vs 0.188 ms.
-static bool spread_angles(long ncol, int nang)
+// Steady-state clocks, reflected kernel, 5 angles (tools/refl_time.py, one box): 12 500 columns 0.079 ms
+// spread vs 0.157 fused, 25 000 0.147 vs 0.158, 32 768 0.137 vs 0.157, 40 000 0.258 vs 0.159.
+static bool spread_angles(long ncol, int nang, long limit = 1280L * 64)
 {
-    long limit = 1280L * 64;                       // angle-columns
     if (const char *e = getenv("PICASO_AMD_SPREAD_COLS")) limit = atol(e);
     return nang > 1 && ncol * nang <= limit;
 }
@@ -443,7 +444,7 @@ static int reflected_1d_core(picaso_ctx *ctx, int nlevel, int nwno, int ncolper,
         if (!get_toa_intensity) return 0;
     }
     int done = 0;
-    if (spread_angles(ncol, nang)) {
+    if (spread_angles(ncol, nang, 2560L * 64)) {
         // Few columns: the chip is far from full and a lane's serial instruction stream sets the
         // latency, so every angle runs as its own wave (grid.y) and the disk sum is a separate pass.
         a.na = 1;

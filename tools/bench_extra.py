@@ -19,10 +19,17 @@ from picaso_amd.device import DeviceArray  # noqa: E402
 TTHG = (1.0, -1.0, 2.0, -0.5, 1.0)
 
 
-def timeit(fn, ctx, reps=10, warm=2):
-    for _ in range(warm):
+def timeit(fn, ctx, reps=10, warm=2, prewarm_s=0.25):
+    """Mean HIP-event time per call in the GPU's steady clock state: an idle MI355X needs a few hundred
+    launches (tens of ms) to ramp its clocks up and drops back within ms of idling, so the timed calls
+    follow `prewarm_s` of the same calls without a gap."""
+    t0 = time.perf_counter()
+    n = 0
+    while time.perf_counter() - t0 < prewarm_s or n < warm:
         fn()
-    device.sync(ctx)
+        n += 1
+        if n % 16 == 0:
+            device.sync(ctx)
     device.timer_start(ctx)
     for _ in range(reps):
         fn()
@@ -137,7 +144,7 @@ def main():
             for c in use:
                 device.sync(c)
             t0 = time.perf_counter()
-            K = 120
+            K = 600
             for j in range(K):
                 c = use[j % nstream]
                 resident.reflected_1d(c, nlayer + 1, nwno, 5, 1, dd, dd["surf_reflect"], u0, u1, 1.0, dd["F0PI"],
