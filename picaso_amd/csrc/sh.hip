@@ -27,6 +27,19 @@
 namespace pz {
 
 constexpr int SH_MAX_ANG = 16;
+// A/B switches of the round-2 instruction-count work, both measured slower and left off
+// (AB_CMD="python tools/sh_time.py" tools/ab.sh, SH4 1e5 x 90 x 5, steady state, one box: 1.131 ms with
+// both off):
+//   PZ_SH_OPT_EXP  exp(-tau[i+1]/u0) and exp(-tau_og/u0) as products of exponentials already at hand
+//                  when the wave's planes allow it (two of five exponentials per layer): 1.305 ms --
+//                  the wave-uniform tests and branches cost more than the polynomials they skip;
+//   PZ_SH_OPT_NC   odd-moment terms of eta / cm / Nsum skipped on cloud-free layers: 1.165 ms.
+#ifndef PZ_SH_OPT_EXP
+#define PZ_SH_OPT_EXP 0
+#endif
+#ifndef PZ_SH_OPT_NC
+#define PZ_SH_OPT_NC 0
+#endif
 
 struct SHArgs {
     int nlayer, nwno, stream;
@@ -205,7 +218,10 @@ __device__ __forceinline__ void modes_sh2(const double (&a)[2], double dt, Modes
 }
 
 // One kernel for stream 2 / 4 (NB = 1 / 2), reflected / thermal.
-template <int NB, bool THERMAL, bool FLX>
+// FAST: the reference's default SH options (config.json: TTHG weights for single and multiple
+// scattering, TTHG single-scattering phase function, Rayleigh in all three, explicit single form,
+// frac_c = 2) fixed at compile time: the nine option words are branches inside the layer loop otherwise.
+template <int NB, bool THERMAL, bool FLX, bool FAST = false>
 #ifndef PZ_SH_MINWAVES
 #define PZ_SH_MINWAVES 2
 #endif
@@ -234,6 +250,11 @@ __global__ __launch_bounds__(256, PZ_SH_MINWAVES) void k_sh(const SHArgs a)
     if (w >= a.nwno) return;
     const int n = a.nlayer;
     const long pitch = a.pitch;
+    const int w_single_form = FAST ? 0 : a.w_single_form, w_multi_form = FAST ? 0 : a.w_multi_form;
+    const int psingle_form = FAST ? 0 : a.psingle_form, single_form = FAST ? 0 : a.single_form;
+    const int w_single_rayleigh = FAST ? 1 : a.w_single_rayleigh, w_multi_rayleigh = FAST ? 1 : a.w_multi_rayleigh;
+    const int psingle_rayleigh = FAST ? 1 : a.psingle_rayleigh;
+    const double frac_c = FAST ? 2.0 : a.frac_c;
     const SHArgs::Angle &g = a.ang[ang];
     const double u0 = g.u0, u1 = g.u1, ct = a.cos_theta;
     const int fd_power = a.compound ? a.first_angle + ang + 1 : 1;   // compounded f_deltaM
@@ -279,6 +300,7 @@ __global__ __launch_bounds__(256, PZ_SH_MINWAVES) void k_sh(const SHArgs a)
 #pragma unroll
         for (int l = 0; l < NS; ++l) { wsg[l] = 1.0; wmu[l] = 1.0; }
         double psing = 0.0;
+        bool nocld = false;          // reflected: no cloud in this layer anywhere in the wave (see below)
         if (!THERMAL) {
             const double fc = a.ftau_cld[o], fr = a.ftau_ray[o];
             // f_deltaM as angle k of the reference sees it: its TTHG branch multiplies the array in
@@ -286,11 +308,22 @@ __global__ __launch_bounds__(256, PZ_SH_MINWAVES) void k_sh(const SHArgs a)
             // f_deltaM fac^k (the aliasing is live when one form is OTHG and the other TTHG) and
             // the TTHG branch f_deltaM fac^(k+1).
             double fd_prev = a.f_deltaM[o], fd = fd_prev, f = 0.0, gf = 0.0, gb = 0.0;
-            const bool tthg = (a.w_single_form == 0 || a.w_multi_form == 0);
+            // No cloud in this layer anywhere in the wave and Rayleigh-weighted moments (w_*_rayleigh = 1):
+            // every l >= 1 moment is multiplied by ftau_cld = 0, so the weights are (1, 0, ftau_ray/2, 0)
+            // whatever the phase-function form and f_deltaM -- the TTHG / OTHG blocks (a pow, two
+            // reciprocals, the compounding loop) are skipped.  Same values as the general path gives on
+            // such a layer (there the moments come out as +-0).
+            nocld = (w_single_rayleigh == 1) && (w_multi_rayleigh == 1) && __all(fc == 0.0);
+            const bool tthg = !nocld && (w_single_form == 0 || w_multi_form == 0);
+            if (nocld) {
+#pragma unroll
+                for (int l = 1; l < NS; ++l) { wsg[l] = 0.0; wmu[l] = 0.0; }
+                if (NS == 4) { wsg[2] = 0.5 * fr; wmu[2] = 0.5 * fr; }
+            }
             if (tthg) {
                 gf = a.constant_forward * cbo;
                 gb = a.constant_back * cbo;
-                f = a.frac_a + a.frac_b * pow_frac(gb, a.frac_c);
+                f = a.frac_a + a.frac_b * pow_frac(gb, frac_c);
                 double cfs = 1.0, cbs = 1.0;
 #pragma unroll
                 for (int l = 0; l < NS; ++l) { cfs *= a.constant_forward; cbs *= a.constant_back; }
@@ -298,15 +331,15 @@ __global__ __launch_bounds__(256, PZ_SH_MINWAVES) void k_sh(const SHArgs a)
                 for (int p = 1; p < fd_power; ++p) fd_prev *= fac;
                 fd = fd_prev * fac;
             }
-            if (a.w_single_form == 1 || a.w_multi_form == 1) {               // OTHG :2811-2817
+            if (!nocld && (w_single_form == 1 || w_multi_form == 1)) {   // OTHG :2811-2817
                 double cl = 1.0;
                 const double ifp = frcp(1 - fd_prev);
 #pragma unroll
                 for (int l = 1; l < NS; ++l) {
                     cl *= cbo;
                     const double ww = ((2 * l + 1) * cl - (2 * l + 1) * fd_prev) * ifp;
-                    if (a.w_single_form == 1) wsg[l] = ww;
-                    if (a.w_multi_form == 1) wmu[l] = ww;
+                    if (w_single_form == 1) wsg[l] = ww;
+                    if (w_multi_form == 1) wmu[l] = ww;
                 }
             }
             if (tthg) {                                                      // TTHG :2819-2831
@@ -317,28 +350,30 @@ __global__ __launch_bounds__(256, PZ_SH_MINWAVES) void k_sh(const SHArgs a)
                     gfl *= gf;
                     gbl *= gb;
                     const double ww = ((2 * l + 1) * (f * gfl + (1 - f) * gbl) - (2 * l + 1) * fd) * ifd;
-                    if (a.w_single_form == 0) wsg[l] = ww;
-                    if (a.w_multi_form == 0) wmu[l] = ww;
+                    if (w_single_form == 0) wsg[l] = ww;
+                    if (w_multi_form == 0) wmu[l] = ww;
                 }
             }
-            if (a.w_single_rayleigh == 1) {                                  // :2833-2836
+            if (!nocld && w_single_rayleigh == 1) {                        // :2833-2836
 #pragma unroll
                 for (int l = 1; l < NS; ++l) wsg[l] *= fc;
                 if (NS == 4) wsg[2] += 0.5 * fr;
             }
-            if (a.w_multi_rayleigh == 1) {                                   // :2837-2840
+            if (!nocld && w_multi_rayleigh == 1) {                         // :2837-2840
 #pragma unroll
                 for (int l = 1; l < NS; ++l) wmu[l] *= fc;
                 if (NS == 4) wmu[2] += 0.5 * fr;
             }
-            if (a.single_form == 0) {                                        // :2843-2855
-                if (a.psingle_form == 1) psing = hg_term(cbo, ct);
-                else if (a.psingle_form == 0) {
+            if (single_form == 0 && nocld && psingle_rayleigh == 1) {       // ftau_cld (..) + Rayleigh = Rayleigh
+                psing = fr * (0.75 * (1 + ct * ct));
+            } else if (single_form == 0) {                                 // :2843-2855
+                if (psingle_form == 1) psing = hg_term(cbo, ct);
+                else if (psingle_form == 0) {
                     const double gf = a.constant_forward * cbo, gb = a.constant_back * cbo;
-                    const double f = a.frac_a + a.frac_b * pow_frac(gb, a.frac_c);
+                    const double f = a.frac_a + a.frac_b * pow_frac(gb, frac_c);
                     psing = f * hg_term(gf, ct) + (1 - f) * hg_term(gb, ct);
                 }
-                if (a.psingle_rayleigh == 1) psing = fc * psing + fr * (0.75 * (1 + ct * ct));
+                if (psingle_rayleigh == 1) psing = fc * psing + fr * (0.75 * (1 + ct * ct));
             } else {                                                         // legendre form :2954-2957
 #pragma unroll
                 for (int l = 0; l < NS; ++l) psing += wsg[l] * Pu0[l] * Pu1[l];
@@ -359,6 +394,7 @@ __global__ __launch_bounds__(256, PZ_SH_MINWAVES) void k_sh(const SHArgs a)
             al[l] = (2 * l + 1) - w0 * wmu[l];
             bl[l] = THERMAL ? 0.0 : (F * (w0 * wsg[l])) * Pu0[l] * (0.25 / PI);
         }
+        const double edt_layer = fexp2(dt * g.nl1, K);                   // exp(-dtau/u1)
         // ---- modes ----
         Modes<NB> M;
         if constexpr (NB == 2) modes_sh4(al, dt, M, K);
@@ -376,16 +412,49 @@ __global__ __launch_bounds__(256, PZ_SH_MINWAVES) void k_sh(const SHArgs a)
                 const double iDel = frcp(9 * (x2 * x2 - M.beta * x2 + M.gama));
                 const double a0 = al[0], a1 = al[1], a2 = al[2], a3 = al[3];
                 const double b0 = bl[0], b1_ = bl[1], b2 = bl[2], b3 = bl[3];
-                eta[0] = ((a1 * b0 - b1_ * x) * (a2 * a3 - 9 * x2) + 2 * (a3 * b2 - 2 * a3 * b0 - 3 * b3 * x) * x2) * iDel;
-                eta[1] = ((a0 * b1_ - b0 * x) * (a2 * a3 - 9 * x2) - 2 * a0 * (a3 * b2 - 3 * b3 * x) * x) * iDel;
-                eta[2] = ((a3 * b2 - 3 * b3 * x) * (a0 * a1 - x2) - 2 * a3 * (a0 * b1_ - b0 * x) * x) * iDel;
-                eta[3] = ((a2 * b3 - 3 * b2 * x) * (a0 * a1 - x2) + 2 * (3 * a0 * b1_ - 2 * a0 * b3 - 3 * b0 * x) * x2) * iDel;
-                zpl[0] = (eta[0] / 2 + eta[1] + 5 * eta[2] / 8) * 2 * PI;
-                zmn[0] = (eta[0] / 2 - eta[1] + 5 * eta[2] / 8) * 2 * PI;
-                zpl[1] = (-eta[0] / 8 + 5 * eta[2] / 8 + eta[3]) * 2 * PI;
-                zmn[1] = (-eta[0] / 8 + 5 * eta[2] / 8 - eta[3]) * 2 * PI;
+                {
+                    // eta_l = Delta_l / Delta (:3398-3411), operations written out (no contraction) so that
+                    // the cloud-free form below -- the same expressions with the terms that carry
+                    // b1 = b3 = 0 (odd moments times ftau_cld = 0) dropped, each dropped term an exact
+                    // zero -- gives bit-identical values on such a layer
+#pragma clang fp contract(off)
+                    const double P = fma(a2, a3, -(9 * x2)), Q = fma(a0, a1, -x2);
+                    const double a3b2 = a3 * b2, b0x = b0 * x;
+                    double A, B, C, D, E_, F_;
+                    if (PZ_SH_OPT_NC && nocld) {
+                        A = a1 * b0;
+                        B = a3b2 - 2 * (a3 * b0);
+                        C = -b0x;
+                        D = a3b2;
+                        E_ = -(3 * (b2 * x));
+                        F_ = -(3 * b0x);
+                    } else {
+                        const double a0b1 = a0 * b1_, b3x3 = 3 * (b3 * x);
+                        A = a1 * b0 - b1_ * x;
+                        B = (a3b2 - 2 * (a3 * b0)) - b3x3;
+                        C = a0b1 - b0x;
+                        D = a3b2 - b3x3;
+                        E_ = a2 * b3 - 3 * (b2 * x);
+                        F_ = (3 * a0b1 - 2 * (a0 * b3)) - 3 * b0x;
+                    }
+                    eta[0] = fma(A, P, 2 * (B * x2)) * iDel;
+                    eta[1] = fma(C, P, -((2 * a0) * (D * x))) * iDel;
+                    eta[2] = fma(D, Q, -((2 * a3) * (C * x))) * iDel;
+                    eta[3] = fma(E_, Q, 2 * (F_ * x2)) * iDel;
+                    const double h0 = 0.5 * eta[0], e58 = 0.625 * eta[2], m0 = -0.125 * eta[0];
+                    zpl[0] = ((h0 + eta[1]) + e58) * (2 * PI);
+                    zmn[0] = ((h0 - eta[1]) + e58) * (2 * PI);
+                    zpl[1] = ((m0 + e58) + eta[3]) * (2 * PI);
+                    zmn[1] = ((m0 + e58) - eta[3]) * (2 * PI);
+                }
                 ed = (i == 0) ? fexp2_clip(tau_t * g.nl0, K) : e_top;    // = last layer's eu (same element)
-                eu = fexp2_clip(tau_b * g.nl0, K);
+                // exp(-tau[i+1]/u0) = exp(-tau[i]/u0) exp(-dtau/u1) in the symmetric geometry when the level
+                // depths are the running sums of the layer depths (bit-exact, whole wave) and the 35-clip
+                // does not bind at the bottom: one exponential less per layer
+                if (PZ_SH_OPT_EXP && sym && __all(tau_b == tau_t + dt) && __all(tau_b * g.nl0 >= -35.0 * LOG2E))
+                    eu = ed * edt_layer;
+                else
+                    eu = fexp2_clip(tau_b * g.nl0, K);
             } else {                                                         // :3240-3265
                 const double x = iu0;
                 const double iDel = frcp(x * x - al[0] * al[1]);
@@ -429,12 +498,23 @@ __global__ __launch_bounds__(256, PZ_SH_MINWAVES) void k_sh(const SHArgs a)
             (void)e_u1;
             double cm[NS];
             if constexpr (NB == 2) {
-#pragma unroll
-                for (int m = 0; m < 4; ++m) {
-                    double s = 0.0;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) s = s + wmu[j] * Pu1[j] * M.cA[j][m];
-                    cm[m] = s;
+                // sum_j w_multi_j P_j(u1) A[j][m] (:3601-3605): A's columns come in +- pairs (rows 1 and 3
+                // change sign between the decaying and the growing mode), so the four sums are two even and
+                // two odd parts; the odd parts vanish exactly on a cloud-free layer (w_multi_1 = w_multi_3 = 0)
+#pragma clang fp contract(off)
+                const double wP0 = wmu[0] * Pu1[0], wP2 = wmu[2] * Pu1[2];
+                const double e01 = fma(wP2, M.cA[2][0], wP0), e23 = fma(wP2, M.cA[2][2], wP0);
+                if (PZ_SH_OPT_NC && !THERMAL && nocld) {
+                    cm[0] = cm[1] = e01;
+                    cm[2] = cm[3] = e23;
+                } else {
+                    const double wP1 = wmu[1] * Pu1[1], wP3 = wmu[3] * Pu1[3];
+                    const double o01 = fma(wP3, M.cA[3][0], wP1 * M.cA[1][0]);
+                    const double o23 = fma(wP3, M.cA[3][2], wP1 * M.cA[1][2]);
+                    cm[0] = e01 + o01;
+                    cm[1] = e01 - o01;
+                    cm[2] = e23 + o23;
+                    cm[3] = e23 - o23;
                 }
             } else {                                                         // :2916-2917, :3124-3125
                 cm[0] = (wmu[0] - wmu[1] * Pu1[1] * M.q);
@@ -442,7 +522,7 @@ __global__ __launch_bounds__(256, PZ_SH_MINWAVES) void k_sh(const SHArgs a)
             }
             const double scale = THERMAL ? 2 * PI : 1.0;                     // :3167 vs :2961
             const double tw = T * iu1 * w0 * scale;
-            const double edt = fexp2(dt * g.nl1, K);                         // exp(-dtau/u1)
+            const double edt = edt_layer;                                    // exp(-dtau/u1)
             // exp(-(1/u1 +- lam) dtau) = exp(-dtau/u1) E^{+-1} when no 35-clip binds anywhere in the
             // wave ((1/u1 + lam_max) dtau <= 35 covers all four arguments); otherwise the reference's
             // clipped exponentials are formed directly (:2929-2937).
@@ -471,13 +551,26 @@ __global__ __launch_bounds__(256, PZ_SH_MINWAVES) void k_sh(const SHArgs a)
                 const double exptrm_mus = (1 - e_mus) * imus;
                 // exp(-clip35(tau/u0)): the layer-top exponential above (SH4 clips it too; SH2 does not)
                 const double expon1 = exptrm_mus * ((NB == 2) ? ed_layer : fmax(ed_layer, EXP_M35));
-                double Nsum = 0.0;
-#pragma unroll
-                for (int l = 0; l < NS; ++l) Nsum += wmu[l] * Pu1[l] * eta[l] * expon1;   // :2919-2920, 2945-2948
+                double Nsum;
+                {                                                            // :2919-2920, 2945-2948
+#pragma clang fp contract(off)
+                    double sN = (wmu[0] * Pu1[0]) * eta[0];
+                    if (NS == 4) sN = fma(wmu[2] * Pu1[2], eta[2], sN);
+                    if (!(PZ_SH_OPT_NC && nocld)) {                          // odd moments: zero without cloud
+                        sN = fma(wmu[1] * Pu1[1], eta[1], sN);
+                        if (NS == 4) sN = fma(wmu[3] * Pu1[3], eta[3], sN);
+                    }
+                    Nsum = sN * expon1;
+                }
                 const double dto = a.dtau_og[o];
                 const double e_muso = __all(dto == dt) ? e_mus : fexp2_clip(dto * g.nlm, K);
+                // exp(-tau_og/u0) at the layer top: the (unclipped) exponential of tau already at hand when
+                // nothing above has been delta-scaled (tau_og == tau in the whole wave)
+                const double tauo = a.tau_og[o];
+                const double e_tauo = (PZ_SH_OPT_EXP && __all(tauo == a.tau[o]) && __all(tauo * g.nl0 >= -35.0 * LOG2E))
+                                          ? ed_layer : fexp2(tauo * g.nl0, K);
                 const double single = a.w0_og[o] * F / (4 * PI) * psing *
-                                      (1 - e_muso) * fexp2(a.tau_og[o] * g.nl0, K) * imus;   // :2959-2965
+                                      (1 - e_muso) * e_tauo * imus;          // :2959-2965
                 c = T * iu1 * (w0 * Nsum + single);
             } else {
                 const double ed2 = edt;                                                                  // :3163-3165
@@ -726,13 +819,18 @@ static int launch_sh(picaso_ctx *ctx, SHArgs &a, int nang, bool thermal)
     a.xcd_order = (ncg * (unsigned)nang >= 4u * (unsigned)ctx->ncu) && !getenv("PICASO_AMD_SH_ANGLE_MAJOR");
     const dim3 grid(a.xcd_order ? ((ncg + 7u) / 8u) * 8u * (unsigned)nang : ncg * (unsigned)nang);
     const bool flx = a.flux != nullptr;
+    const bool fast = !thermal && !flx && !getenv("PICASO_AMD_SH_GENERIC") && a.w_single_form == 0 &&
+                      a.w_multi_form == 0 && a.psingle_form == 0 && a.single_form == 0 && a.w_single_rayleigh == 1 &&
+                      a.w_multi_rayleigh == 1 && a.psingle_rayleigh == 1 && a.frac_c == 2.0;   // config.json defaults
     if (a.stream == 4) {
         if (thermal) hipLaunchKernelGGL((k_sh<2, true, false>), grid, dim3(block), 0, ctx->stream, a);
         else if (flx) hipLaunchKernelGGL((k_sh<2, false, true>), grid, dim3(block), 0, ctx->stream, a);
+        else if (fast) hipLaunchKernelGGL((k_sh<2, false, false, true>), grid, dim3(block), 0, ctx->stream, a);
         else hipLaunchKernelGGL((k_sh<2, false, false>), grid, dim3(block), 0, ctx->stream, a);
     } else {
         if (thermal) hipLaunchKernelGGL((k_sh<1, true, false>), grid, dim3(block), 0, ctx->stream, a);
         else if (flx) hipLaunchKernelGGL((k_sh<1, false, true>), grid, dim3(block), 0, ctx->stream, a);
+        else if (fast) hipLaunchKernelGGL((k_sh<1, false, false, true>), grid, dim3(block), 0, ctx->stream, a);
         else hipLaunchKernelGGL((k_sh<1, false, false>), grid, dim3(block), 0, ctx->stream, a);
     }
     PZ_HIP(ctx, hipGetLastError());
