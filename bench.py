@@ -156,7 +156,7 @@ def workload_sh4(ctx, args, lo, hi, seed, nwno_total):
 
     return dict(solve=solve, oracle=oracle, nloc=n,
                 abytes=8 * n * (9 * nlayer + 2 * nlevel + 2 + ng + 1),
-                kernel="k_sh<2, false, false>",
+                kernel="k_sh<2, false, false, true>",
                 workload="BASELINE configs[3]: spherical-harmonics SH4 reflected light (get_reflected_SH + "
                          "compress_disco), TTHG, delta-M, Rayleigh + cloud slab",
                 metric="spectra/sec (%d wave x %d layer SH4 reflected)" % (nwno_total, nlayer))

@@ -36,6 +36,7 @@ __device__ __forceinline__ double horner_step(double p, double r, double c)
 
 __device__ __forceinline__ double fexp(double x)
 {
+#pragma clang fp contract(off)
     const double k = __builtin_rint(x * 1.4426950408889634);
     double r = fma(k, -0.6931471805599453, x);
     r = fma(k, -2.3190468138462996e-17, r);
@@ -262,6 +263,7 @@ __device__ __forceinline__ double fexpk(double x, const Exp2Coef &K) { return fe
 // effective_temperature and fpfs_thermal of an otherwise finite spectrum.
 __device__ __forceinline__ double planck_rcp(double e)
 {
+#pragma clang fp contract(off)
     const double y = frcp(e - 1.0);
     return (e == __builtin_inf()) ? 0.0 : y;
 }
@@ -269,6 +271,7 @@ __device__ __forceinline__ double planck_rcp(double e)
 // Planck function per unit wavelength, cgs, at wavelength 1/wno (reference fluxes.py:1660-1680).
 __device__ __forceinline__ double planck_lambda(double t, double wno)
 {
+#pragma clang fp contract(off)
     const double h = 6.62607004e-27, c = 2.99792458e+10, k = 1.38064852e-16;
     const double wcm = 1.0 / wno;
     const double w2 = wcm * wcm;
@@ -276,6 +279,7 @@ __device__ __forceinline__ double planck_lambda(double t, double wno)
 }
 __device__ __forceinline__ double planck_lambda(double t, double wno, const Exp2Coef &K)
 {
+#pragma clang fp contract(off)
     const double h = 6.62607004e-27, c = 2.99792458e+10, k = 1.38064852e-16;
     const double wcm = 1.0 / wno;
     const double w2 = wcm * wcm;
@@ -285,6 +289,7 @@ __device__ __forceinline__ double planck_lambda(double t, double wno, const Exp2
 // 3-point bin mean of the wavenumber Planck function (reference fluxes.py:1608-1658, nbb = 1).
 __device__ __forceinline__ double planck_integrated(double t, double wave, double dwave)
 {
+#pragma clang fp contract(off)
     const double h = 6.62607004e-27, c = 2.99792458e+10, k = 1.38064852e-16;
     const double c1 = 2 * h * (c * c), c2 = h * c / k;
     double s = 0.0;

@@ -20,6 +20,10 @@ namespace pz {
 template <int NA, bool IS3D>
 __global__ __launch_bounds__(256) void k_thermal_toa(const ThermalArgs a)
 {
+    // Operations written out (no contraction, explicit fma), as in toon_reflected.hip: the one-angle
+    // launch of a small wavelength shard and the five-angle launch of the whole grid round identically,
+    // so a column's flux does not depend on how the grid is cut.
+#pragma clang fp contract(off)
     const long col = blockIdx.x * (long)blockDim.x + threadIdx.x;
     if (col >= a.ncol) return;
     const int nfac = IS3D ? a.nfac : 1;
@@ -69,7 +73,7 @@ __global__ __launch_bounds__(256) void k_thermal_toa(const ThermalArgs a)
         Bn = planck(i + 1);
         const double b1 = (Bn - B0) * frcp(dt);                // fluxes.py:1757
         const double g1 = 2.0 - w0 * (1 + g), g2 = w0 * (1 - g);   // fluxes.py:1760
-        const double lam = sqrt(g1 * g1 - g2 * g2);
+        const double lam = sqrt(g1 * g1 - g2 * g2);                // unfused, as numpy
         const double gam = (g1 - lam) * frcp(g2);
         const double s = frcp(g1 + g2);                        // fluxes.py:1766
         // fluxes.py:1772-1779 with 2 pi mu1 = pi and B0 + b1 dtau = B_{i+1}:
@@ -77,11 +81,11 @@ __global__ __launch_bounds__(256) void k_thermal_toa(const ThermalArgs a)
         // so the interface right-hand sides are +-(q_i - q_{i-1}) with the pi B terms cancelled
         // analytically (the reference cancels them numerically, at a cost of up to 11 digits in
         // optically thick, weakly scattering layers).
-        const double q = PI * b1 * s;
-        const double cmu = 2 * PI * mu1 * (B0 - b1 * s);
+        const double q = (PI * b1) * s;
+        const double cmu = (2 * PI * mu1) * fma(-b1, s, B0);
         const double E = fmin(lam * dt, 35.0);                 // fluxes.py:1784-1786
         const double EP = fexpk(E, K), EM = frcp(EP);
-        const double al1 = 2 * PI * (B0 + b1 * (s - mu1));     // fluxes.py:1846-1847
+        const double al1 = (2 * PI) * fma(b1, s - mu1, B0);    // fluxes.py:1846-1847
         const double al2 = 2 * PI * b1;
         const double gcoef = (1.0 / mu1 - lam);                // G = gcoef*pos   fluxes.py:1842
         const double hcoef = gam * (lam + 1.0 / mu1);          // H = hcoef*neg   fluxes.py:1843
@@ -94,19 +98,19 @@ __global__ __launch_bounds__(256) void k_thermal_toa(const ThermalArgs a)
             delta_n = b_top - cmu;
         } else {
             const double em2 = pEM * pEM;
-            const double a1 = 1.0 - pgam * em2 * rho;
-            const double a2 = pgam - em2 * rho;
-            const double d1 = a1 - gam * a2;
+            const double a1 = fma(-(pgam * em2), rho, 1.0);
+            const double a2 = fma(-em2, rho, pgam);
+            const double d1 = fma(-gam, a2, a1);
             const double r12 = frcp(d1 * a1);                  // one reciprocal for 1/d1 and 1/a1
             const double inv = r12 * a1;
             const double dq = q - pq;
-            const double rP = dq - pgam * pEM * delta;
-            const double rM = -dq - pEM * delta;
-            rho_n = (gam * a1 - a2) * inv;
-            delta_n = (a2 * rP - a1 * rM) * inv;
+            const double rP = fma(-(pgam * pEM), delta, dq);
+            const double rM = fma(-pEM, delta, -dq);
+            rho_n = fma(gam, a1, -a2) * inv;
+            delta_n = fma(a2, rP, -(a1 * rM)) * inv;
             const double ia = pEM * (r12 * d1);
-            sfac = (1.0 - gam * rho_n) * ia;
-            t = (gam * delta_n + rP) * ia;
+            sfac = fma(-gam, rho_n, 1.0) * ia;
+            t = fma(gam, delta_n, rP) * ia;
         }
         const bool last = (i == n - 1);
         double EPm = 0.0, EMm = 0.0;
@@ -119,37 +123,38 @@ __global__ __launch_bounds__(256) void k_thermal_toa(const ThermalArgs a)
             const double mu = u1[k];
             // 1/(lam mu - 1) and 1/(lam mu + 1) from one reciprocal of the product of the two
             // 1-ulp factors (see toon_reflected.hip: no cancellation, lm1 is exact near lam mu = 1)
-            const double lm1 = lam * mu - 1.0, lp1 = lam * mu + 1.0;
+            const double lmu = lam * mu;
+            const double lm1 = lmu - 1.0, lp1 = lmu + 1.0;
             const double r2 = frcp(lm1 * lp1);
             const double lp = gcoef * (r2 * lp1), lm = hcoef * (r2 * lm1);
             if (i == 0) {
-                const double em = fexp2(0.5 * dt * nl1[k], K); // fluxes.py:1878
-                const double vp = lp * (EP * em - EPm);        // fluxes.py:1903-1907
-                const double vn = -lm * (EM * em - EMm);
-                const double c0 = al1 * (1. - em) + al2 * (mu + 0.5 * dt - (dt + mu) * em);
-                kappa[k] = c0 + vn * delta_n;
-                zeta[k] = vp - vn * rho_n;
+                const double em = fexp2((0.5 * dt) * nl1[k], K); // fluxes.py:1878
+                const double vp = lp * fma(EP, em, -EPm);      // fluxes.py:1903-1907
+                const double vn = -lm * fma(EM, em, -EMm);
+                const double c0 = fma(al2, fma(-(dt + mu), em, mu + 0.5 * dt), al1 * (1. - em));
+                kappa[k] = fma(vn, delta_n, c0);
+                zeta[k] = fma(-vn, rho_n, vp);
                 W[k] = em;
             } else {
                 const double e = fexp2(dt * nl1[k], K);        // fluxes.py:1877
-                const double vp = W[k] * lp * (EP * e - 1.0);  // fluxes.py:1897-1901
-                const double vn = W[k] * lm * (1.0 - EM * e);
-                const double c0 = W[k] * (al1 * (1. - e) + al2 * (mu - (dt + mu) * e));
-                kappa[k] = kappa[k] + c0 + zeta[k] * t + vn * delta_n;
-                zeta[k] = zeta[k] * sfac + vp - vn * rho_n;
+                const double vp = (W[k] * lp) * fma(EP, e, -1.0);  // fluxes.py:1897-1901
+                const double vn = (W[k] * lm) * fma(-EM, e, 1.0);
+                const double c0 = W[k] * fma(al2, fma(-(dt + mu), e, mu), al1 * (1. - e));
+                kappa[k] = fma(vn, delta_n, fma(zeta[k], t, kappa[k] + c0));
+                zeta[k] = fma(-vn, rho_n, fma(zeta[k], sfac, vp));
                 W[k] = W[k] * e;
             }
             if (last) {                                        // F+[n] boundary intensity
                 double fb;
                 if (!IS3D) {
-                    if (a.hard_surface) fb = (1.0 - rs) * Bn * 2 * PI;       // fluxes.py:1871
-                    else fb = (Bn + b1 * mu) * 2 * PI;                       // fluxes.py:1873
+                    if (a.hard_surface) fb = ((1.0 - rs) * Bn) * (2 * PI);   // fluxes.py:1871
+                    else fb = fma(b1, mu, Bn) * (2 * PI);                    // fluxes.py:1873
                 } else {
                     if (a.hard_surface) fb = PI * (PI * Bn);                 // fluxes.py:2256,2310
-                    else fb = PI * (Bn + b1 * mu);                           // fluxes.py:2312
+                    else fb = PI * fma(b1, mu, Bn);                          // fluxes.py:2312
                 }
                 // for a single layer the boundary feeds the mid-point of layer 0 directly
-                kappa[k] += W[k] * fb;
+                kappa[k] = fma(W[k], fb, kappa[k]);
             }
         }
         rho = rho_n;
@@ -166,16 +171,17 @@ __global__ __launch_bounds__(256) void k_thermal_toa(const ThermalArgs a)
     //   3-D soft (fluxes.py:2258) : same as 1-D soft
     //   3-D hard (fluxes.py:2256) : pi [rs B_n - b1 s (1 + rs)]     (b_surface = pi B_n, no emissivity)
     double bsum;
-    if (!a.hard_surface) bsum = PI * (b1_last * (mu1 - s_last) + rs * (Bn - b1_last * s_last));
-    else if (!IS3D) bsum = -PI * b1_last * s_last * (1.0 + rs);
-    else bsum = PI * (rs * Bn - b1_last * s_last * (1.0 + rs));
+    const double bs_l = b1_last * s_last;
+    if (!a.hard_surface) bsum = PI * fma(rs, Bn - bs_l, b1_last * (mu1 - s_last));
+    else if (!IS3D) bsum = -PI * (bs_l * (1.0 + rs));
+    else bsum = PI * fma(rs, Bn, -(bs_l * (1.0 + rs)));
     const double em2 = pEM * pEM;
-    const double pos = (pEM * bsum - em2 * (pgam - rs) * delta) /
-                       ((1.0 - rs * pgam) - em2 * (pgam - rs) * rho);
+    const double egr = em2 * (pgam - rs);
+    const double pos = fma(pEM, bsum, -(egr * delta)) / fma(-egr, rho, fma(-rs, pgam, 1.0));
     double disk = 0.0;
 #pragma unroll
     for (int k = 0; k < NA; ++k) {
-        const double x = kappa[k] + zeta[k] * pos;
+        const double x = fma(zeta[k], pos, kappa[k]);
         if (IS3D) a.flux[(long)fac * a.nwno + w] = x;
         else a.flux[(long)(blockIdx.y * NA + k) * a.ncol + col] = x;
         {   // flux + x*gweight*tweight in the reference's order, unfused (disco.py:174-176), as k_compress

@@ -116,9 +116,10 @@ def test_thermal_fullsize(nwno, calc_type, oracle):
                                   sc["dwno"][idx], calc_type)
     assert rel_err(f[:, :, idx], fo) < 1e-8
     assert rel_err(disk[idx], oracle.compress_thermal(idx.size, fo, gw, tw)) < 1e-8
-    parts = [run(lo, hi, calc_type) for lo, hi in shard_bounds(nwno, 3)]
-    assert np.array_equal(np.concatenate([p[0] for p in parts], axis=2), f)
-    assert np.array_equal(np.concatenate([p[1] for p in parts]), disk)
+    for world in (3, 8):       # 8 shards of a 1e5 grid take the one-angle-per-wave launch, the whole grid the fused one
+        parts = [run(lo, hi, calc_type) for lo, hi in shard_bounds(nwno, world)]
+        assert np.array_equal(np.concatenate([p[0] for p in parts], axis=2), f)
+        assert np.array_equal(np.concatenate([p[1] for p in parts]), disk)
 
 
 def test_sh4_fullsize_eight_shards(oracle):
