@@ -278,24 +278,25 @@ def _ref_weights(names):
     return {k: float(am.ATMSETUP.get_weights(object(), [k])[k]) for k in names}
 
 
-def make_optics():
+def make_optics(nwno=40, nlevel=31, tag="", full=True):
     """Synthetic monochromatic sqlite DB in the reference schema (committed next to the fixtures),
     driven through the reference's own RetrieveOpacities + compute_opacity with a duck-typed
-    atmosphere."""
+    atmosphere (SURVEY.md Appendix B).  Defaults: the 40-point x 30-layer fixture of round 1;
+    ``make_optics(196, 61, "_196x60", full=False)`` is BASELINE configs[0]'s shape (196-point opacity
+    grid, 60 layers) with the planes of the default options only."""
     import sqlite3
     import types
     import pandas as pd
     optics = ref_shim.load("optics")
     rayleigh = ref_shim.load("rayleigh")
     rng = np.random.default_rng(4242)
-    nwno = 40
     wno = np.linspace(4000.0, 25000.0, nwno)
     temps = [100.0, 300.0, 700.0, 1500.0, 3000.0]
     press = [1e-6, 1e-4, 1e-2, 1.0, 100.0, 500.0]
     mols = ["H2O", "CH4", "H2"]
     cont_pairs = ["H2H2", "H2He", "H2CH4"]
     cia_temps = [75.0, 200.0, 500.0, 1000.0, 2000.0, 4000.0]
-    db = os.path.join(HERE, "synthetic_opacities.db")
+    db = os.path.join(HERE, "synthetic_opacities%s.db" % tag)
     if os.path.exists(db):
         os.remove(db)
 
@@ -342,7 +343,6 @@ def make_optics():
     conn.commit()
     conn.close()
 
-    nlevel = 31
     nlayer = nlevel - 1
     plevel_bar = np.logspace(-5.5, 1.8, nlevel)
     tlevel = 150.0 + 1200.0 * ((np.log10(plevel_bar) + 5.5) / 7.3) ** 2
@@ -350,12 +350,13 @@ def make_optics():
            "H2O": np.linspace(1e-4, 3e-3, nlevel), "CH4": np.linspace(4e-4, 1e-3, nlevel)}
     gravity = 2500.0
     weights = _ref_weights(("H2", "He", "H2O", "CH4"))
+    c0, c1 = (14 * nlayer) // 30, (20 * nlayer) // 30         # cloud slab (layers 14..19 of 30)
     cld_opd = np.zeros((nlayer, nwno))
-    cld_opd[14:20] = 0.3 * (1.0 + 0.2 * np.sin(wno / 3000.0))
+    cld_opd[c0:c1] = 0.3 * (1.0 + 0.2 * np.sin(wno / 3000.0))
     cld_w0 = np.zeros((nlayer, nwno))
-    cld_w0[14:20] = 0.93
+    cld_w0[c0:c1] = 0.93
     cld_g0 = np.zeros((nlayer, nwno))
-    cld_g0[14:20] = 0.65
+    cld_g0[c0:c1] = 0.65
     shifts_n = None
 
     def make_atm():
@@ -386,7 +387,7 @@ def make_optics():
     names = ("dtau", "tau", "w0", "cosb", "ftau_cld", "ftau_ray", "gcos2", "dtau_og", "tau_og",
              "w0_og", "cosb_og", "w0_no_raman", "f_deltaM")
     raman_file = os.path.join(ref_shim.REF_ROOT, "reference", "opacities", "raman.txt")
-    for qm in ("nearest", "linear"):
+    for qm in (("nearest", "linear") if full else ("linear",)):
         opa = optics.RetrieveOpacities(db, raman_file, query_method=qm)
         if shifts_n is None:
             shifts_n = 1.0 + 0.05 * rng.standard_normal((nwno, len(opa.raman_db)))
@@ -402,9 +403,9 @@ def make_optics():
         for pr in ("H2H2", "H2He", "H2CH4"):
             store["%s/continuum_opa/%s" % (qm, pr)] = opa.continuum_opa[pr]
         store["%s/pt_opa_index" % qm] = np.asarray(atm.layer["pt_opa_index"])
-        for de, stream, raman, tm in ((True, 2, 2, None), (False, 2, 2, None), (True, 4, 0, None),
-                                      (True, 2, 2, "rayleigh"), (False, 2, 2, "constant_tau"),
-                                      (True, 2, 1, None)):
+        for de, stream, raman, tm in (((True, 2, 2, None), (False, 2, 2, None), (True, 4, 0, None),
+                                       (True, 2, 2, "rayleigh"), (False, 2, 2, "constant_tau"),
+                                       (True, 2, 1, None)) if full else ((True, 2, 2, None),)):
             atm = make_atm()
             opa.get_opacities(atm)
             out = optics.compute_opacity(atm, opa, ngauss=1, stream=stream, delta_eddington=de,
@@ -412,6 +413,8 @@ def make_optics():
             key = "%s/de%d_s%d_r%d_tm%s" % (qm, int(de), stream, raman, tm or "none")
             for nm, arr in zip(names, out):
                 store[key + "/" + nm] = np.asarray(arr)[:, :, 0]
+        if not full:
+            continue
         # patchy clouds: the thinned-cloud column set (optics.py:314-315, justdoit.py:248-252)
         atm = make_atm()
         opa.get_opacities(atm)
@@ -419,7 +422,7 @@ def make_optics():
                                      fthin_cld=0.1, do_holes=True)
         for nm, arr in zip(names, out):
             store["%s/holes_fthin0.1/%s" % (qm, nm)] = np.asarray(arr)[:, :, 0]
-    path = os.path.join(HERE, "optics.npz")
+    path = os.path.join(HERE, "optics%s.npz" % tag)
     np.savez_compressed(path, **store)
     print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024), "and", db,
           "%.1f KB" % (os.path.getsize(db) / 1024))
@@ -624,6 +627,8 @@ def make_sh():
 
 if __name__ == "__main__" and (("optics" in sys.argv[1:]) or not sys.argv[1:]):
     make_optics()
+if __name__ == "__main__" and (("optics196" in sys.argv[1:]) or not sys.argv[1:]):
+    make_optics(196, 61, "_196x60", full=False)
 if __name__ == "__main__" and (("ck" in sys.argv[1:]) or not sys.argv[1:]):
     make_ck()
 if __name__ == "__main__" and (("transit" in sys.argv[1:]) or not sys.argv[1:]):

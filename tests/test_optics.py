@@ -393,3 +393,33 @@ def scale_err_rows(got, want):
     scale = np.max(np.abs(want), axis=0, keepdims=True)
     scale = np.where(scale == 0, 1.0, scale)
     return float(np.max(np.abs(got - want) / scale))
+
+
+@pytest.mark.gpu
+def test_gpu_spectrum_config0_196_points_60_layers(oracle):
+    """BASELINE configs[0] at its stated shape: reflected-light spectrum on a 196-point opacity grid x 60
+    layers through inputs.spectrum() (sqlite DB -> HBM tables -> gas stage -> mixing -> Toon solver ->
+    disk integration), against [the reference's own compute_opacity planes for this DB and profile
+    (tests/golden/optics_196x60.npz, generated by make_golden.py optics196) -> CPU oracle solver]."""
+    from picaso_amd import disco
+    from picaso_amd import justdoit as jdi
+    g196 = np.load(os.path.join(GOLDEN, "optics_196x60.npz"))
+    opa = jdi.opannection(os.path.join(GOLDEN, "synthetic_opacities_196x60.db"), query_method="linear")
+    assert opa.nwno == 196 and len(g196["in/tlevel"]) == 61
+    case = _bundle(g196, jdi, None, True, 2, 2)
+    case.surface_reflect(0.1)
+    out = case.spectrum(opa, calculation="reflected+thermal", full_output=True)
+    key = "linear/de1_s2_r2_tmnone"
+    P = {nm: g196["%s/%s" % (key, nm)] for nm in NAMES}
+    nlevel, nwno = P["tau"].shape
+    assert (nlevel, nwno) == (61, 196)
+    g, gw, t, tw = disco.get_angles_1d(5)
+    u0, u1, ct, _, _ = disco.compute_disco(5, 1, g, t, 0.0)
+    x, _ = oracle.get_reflected_1d(nlevel, opa.wno, nwno, 5, 1, P["dtau"], P["tau"], P["w0"], P["cosb"],
+                                   P["gcos2"], P["ftau_cld"], P["ftau_ray"], P["dtau_og"], P["tau_og"],
+                                   P["w0_og"], P["cosb_og"], 0.1, u0, u1, 1.0, np.ones(nwno), 3, 0,
+                                   1.0, -1.0, 2.0, -0.5, 1.0)
+    assert rel_err(out["albedo"], oracle.compress_disco(nwno, 1.0, x, gw, tw, np.ones(nwno))) < 1e-8
+    f, _ = oracle.get_thermal_1d(nlevel, opa.wno, nwno, 5, 1, g196["in/tlevel"], P["dtau_og"], P["w0_no_raman"],
+                                 P["cosb_og"], g196["in/plevel_bar"] * 1e6, u1, np.full(nwno, 0.1), 1, opa.wno * 0, 0)
+    assert rel_err(out["thermal"], oracle.compress_thermal(nwno, f, gw, tw)) < 1e-8
