@@ -413,8 +413,13 @@ def picaso(bundle, opacityclass, dimension="1d", calculation="reflected", full_o
                             "no patchy clouds and no level fluxes")
         prof3 = inp["atmosphere"]["profile_3d"]
         cld3 = inp["clouds"].get("profile_3d")
+        want3 = set()
+        if "reflected" in calculation:
+            want3 |= set(resident.REFLECTED_PLANES)
+        if "thermal" in calculation:
+            want3 |= {"dtau_og", "w0_no_raman", "cosb_og"}
         co3 = dict(stream=common["stream"], delta_eddington=common["delta_eddington"], test_mode=inp["test_mode"],
-                   raman=common["raman"], clouds_3d=cld3, exclude_mol=inp["atmosphere"]["exclude_mol"])
+                   raman=common["raman"], clouds_3d=cld3, exclude_mol=inp["atmosphere"]["exclude_mol"], want=want3)
         if os.environ.get("PICASO_AMD_FACET_LOOP"):           # A/B: one ATMSETUP + one gas launch per facet
             atms = []
             for g in range(ng):

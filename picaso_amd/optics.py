@@ -623,7 +623,7 @@ def gas_stage_facets(atm_f, opa, nfac, tg3, tr3, exclude_mol=1):
 
 
 def compute_opacity_facets(atms, opacityclass, numg, numt, stream=2, delta_eddington=True, test_mode=None,
-                           raman=0, clouds_3d=None, exclude_mol=1):
+                           raman=0, clouds_3d=None, exclude_mol=1, want=None):
     """3-D path: the 13 ``(nlayer|nlevel, nwno, numg, numt)`` planes ``get_reflected_3d`` /
     ``get_thermal_3d`` take, from one atmosphere per facet (``atms[g][t]``; reference
     justdoit.py:444-471).  Gas + Rayleigh optical depths are gathered facet by facet into a
@@ -661,14 +661,16 @@ def compute_opacity_facets(atms, opacityclass, numg, numt, stream=2, delta_eddin
     tm = 0
     if test_mode is not None:
         tm = 1 if test_mode == "rayleigh" else 2
-    out = {k: DeviceArray(((nlayer + 1 if k in ("tau", "tau_og") else nlayer), nwno, numg, numt), ctx)
-           for k in OUT_NAMES}
+    # only the planes the requested legs read are allocated and written (each is nfacets x 72 MB at
+    # 1e5 wavelengths x 90 layers): 11 for reflected light, 3 for thermal emission
+    out = {k: (DeviceArray(((nlayer + 1 if k in ("tau", "tau_og") else nlayer), nwno, numg, numt), ctx)
+               if (want is None or k in want) else None) for k in OUT_NAMES}
     check(load().picaso_compute_opacity_facets_dev(
         ctx, _ci(nlayer), _ci(nwno), _ci(nfac), ptr(tg3.addr), ptr(tr3.addr),
         *[ptr(d.addr) if d is not None else None for d in d_c], ptr(d_rf.addr) if d_rf is not None else None,
         _cd(0.99999), _ci(tm), _ci(1 if delta_eddington else 0), _ci(stream),
-        *[ptr(out[k].addr) for k in OUT_NAMES]), ctx)
-    return out
+        *[ptr(out[k].addr) if out[k] is not None else None for k in OUT_NAMES]), ctx)
+    return {k: v for k, v in out.items() if v is not None}
 
 
 def compute_opacity_resident(atmosphere, opacityclass, ngauss=1, stream=2, delta_eddington=True,

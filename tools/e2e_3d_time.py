@@ -56,6 +56,14 @@ for tag, env in (("batched", None), ("per_facet_loop", "1")):
     out["spectrum_3d_8x8x%d_%s_ms" % (nwno, tag)] = round(1e3 * min(ts), 3)
     out["albedo_sum_" + tag] = float(np.sum(r["albedo"]))
 os.environ.pop("PICASO_AMD_FACET_LOOP", None)
+for calc in ("reflected", "thermal"):
+    c3.spectrum(opa, calculation=calc, dimension="3d")
+    ts = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        c3.spectrum(opa, calculation=calc, dimension="3d")
+        ts.append(time.perf_counter() - t0)
+    out["spectrum_3d_%s_only_ms" % calc] = round(1e3 * min(ts), 3)
 # phase curve: P phases of the same map
 P = 8
 phases = list(np.linspace(0.0, 2 * np.pi * (P - 1) / P, P))
@@ -67,5 +75,14 @@ pc.approx(raman="none")
 pc.phase_curve(opa)
 t0 = time.perf_counter()
 res = pc.phase_curve(opa)
-out["phase_curve_%d_phases_ms" % P] = round(1e3 * (time.perf_counter() - t0), 3)
+out["phase_curve_reflected_%d_phases_ms" % P] = round(1e3 * (time.perf_counter() - t0), 3)
+pt = jdi.inputs()
+pt.phase_curve_geometry("thermal", phases, num_gangle=ng, num_tangle=nt)
+pt.gravity(gravity=2500.0)
+pt.atmosphere_4d([prof3 for _ in phases])
+pt.approx(raman="none")
+pt.phase_curve(opa)
+t0 = time.perf_counter()
+res = pt.phase_curve(opa)
+out["phase_curve_thermal_%d_phases_ms" % P] = round(1e3 * (time.perf_counter() - t0), 3)
 print(json.dumps(out))
