@@ -266,13 +266,19 @@ def main():
         return device.timer_stop(ctx) / nsteps
 
     # ---- clock ramp (untimed), warm-up, timed region ----
+    # The time-based part launches the solve only (no collective: the ranks may run different numbers
+    # of iterations); a fixed number of complete steps follows so that the gather is warm as well.
     t0 = time.perf_counter()
     nprewarm = 0
     while (time.perf_counter() - t0) * 1e3 < args.prewarm_ms:
         for _ in range(20):
-            step()
+            step(gather=False)
         nprewarm += 20
         device.sync(ctx)
+    if args.prewarm_ms > 0:
+        for _ in range(20):
+            step()
+        nprewarm += 20
     for _ in range(args.warmup):
         step()
     barrier()

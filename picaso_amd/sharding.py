@@ -87,7 +87,15 @@ class HostGroup:
         if self.rank == 0:
             srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
             srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
-            srv.bind((addr, port))
+            t0 = time.time()
+            while True:                      # a previous run's listener may still be closing
+                try:
+                    srv.bind((addr, port))
+                    break
+                except OSError:
+                    if time.time() - t0 > 30.0:
+                        raise
+                    time.sleep(0.2)
             srv.listen(self.world)
             srv.settimeout(timeout)
             while len(self.peers) < self.world - 1:
