@@ -102,3 +102,15 @@ def test_missing_library_is_a_clear_error(monkeypatch):
     monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libpicaso_hip.so")
     with pytest.raises(_lib.PicasoHipError, match="no CPU fallback"):
         _lib.load()
+
+
+def test_committed_pmc_numbers_belong_to_the_committed_kernel_sources():
+    """profiles/traffic.json (HBM bytes and VALU instructions per launch, quoted by bench.py as
+    roofline.traffic / fp64_issue) carries the hash of the kernel sources it was measured on; bench.py
+    drops the numbers when the hash differs.  Committed state: they match."""
+    import json
+    sys.path.insert(0, ROOT)
+    import bench
+    prof = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+    assert prof["kernel_source_hash"] == bench.kernel_source_hash()
+    assert 0.95 < prof["hbm_bytes_per_launch"] / 8.0e8 < 1.2
