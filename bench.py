@@ -313,16 +313,21 @@ def main():
         # equals the spectrum solved unsharded on this GPU bit for bit (SURVEY 7 test (v)) ----
         checks = {}
         if comm:
-            assert np.array_equal(res_full[lo:hi], res_local), "all-gather mismatch"
-            checks["gathered_contains_local_shard"] = True
+            # recorded in the JSON line (and on stderr when false) rather than asserted: a failed check must
+            # not cost the run its measurement
+            checks["gathered_contains_local_shard"] = bool(np.array_equal(res_full[lo:hi], res_local))
             if args.scaling == "strong" and args.config != 4:
                 wl1 = build(ctx, args, 0, nwno_total, seed, nwno_total)
                 one = device.DeviceArray((nwno_total,), ctx)
                 wl1["solve"](one)
                 device.sync(ctx)
-                same = bool(np.array_equal(one.to_host(), res_full))
-                assert same, "sharded spectrum differs from the unsharded one"
-                checks["bit_identical_to_unsharded"] = same
+                ref_full = one.to_host()
+                checks["bit_identical_to_unsharded"] = bool(np.array_equal(ref_full, res_full))
+                checks["max_rel_diff_vs_unsharded"] = float(np.max(np.abs(ref_full - res_full) /
+                                                                   np.maximum(np.abs(ref_full), 1e-300)))
+            for k, v in checks.items():
+                if v is False:
+                    print("bench.py: CHECK FAILED: %s" % k, file=sys.stderr, flush=True)
         ms_per_step = 1e3 * elapsed / args.steps
         spectra_per_step = 1 if args.scaling == "strong" else world
         value = spectra_per_step * args.steps / elapsed
