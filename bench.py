@@ -123,7 +123,7 @@ def workload_thermal(ctx, args, lo, hi, seed, nwno_total):
         return orc.compress_thermal(ns, fo, gw, tw)
 
     return dict(solve=solve, oracle=oracle, nloc=n, abytes=8 * n * (3 * nlayer + 3 + ng + 1),
-                kernel="k_thermal_toa<%d, false>" % ng,
+                kernel=("k_thermal_coop<%d>" if n <= 32768 else "k_thermal_toa<%d, false>") % ng,
                 workload="BASELINE configs[1]: thermal emission (get_thermal_1d + compress_thermal), "
                          "Planck per level, 5 Gauss angles",
                 metric="spectra/sec (%d wave x %d layer thermal)" % (nwno_total, nlayer))

@@ -715,11 +715,6 @@ static int thermal_1d_core(picaso_ctx *ctx, int nlevel, const double *wno, int n
         return fail(ctx, "get_thermal_1d: the fused disk sum is a per-wavelength output (ngauss = 1)");
     PZ_HIP(ctx, hipSetDevice(ctx->device));
     const int nang = numg * numt;
-    std::vector<double> tab(2 * (size_t)nlevel + (size_t)nang);
-    for (int i = 0; i < nlevel; ++i) { tab[i] = tlevel[i]; tab[nlevel + i] = plevel[i]; }
-    for (int i = 0; i < nang; ++i) tab[2 * (size_t)nlevel + i] = ubar1[i];
-    const void *d_tab = nullptr;
-    PZ_TRY(table_upload(ctx, tab.data(), sizeof(double) * tab.size(), &d_tab));
     ThermalArgs a{};
     a.nlayer = nlevel - 1;
     a.ncol = ncol;
@@ -728,12 +723,37 @@ static int thermal_1d_core(picaso_ctx *ctx, int nlevel, const double *wno, int n
     a.nfac = 1;
     a.nwno = nwno;
     a.wno = wno; a.dwno = dwno;
-    a.tlevel = (const double *)d_tab; a.plevel = (const double *)d_tab + nlevel;
     a.dtau = dtau; a.w0 = w0; a.cosb = cosb; a.surf_reflect = surf_reflect;
     a.hard_surface = hard_surface; a.calc_type = calc_type;
     const bool fuse = flux_disk && gweight && tweight;
     a.disk = fuse ? flux_disk : nullptr;
     a.disk_scale = (numt == 1) ? 1.0 : 1.0 / (2.0 * 3.14159265358979323846);   // disco.py:174-175
+    // Small launches: the cooperative kernel (helper waves compute the layer quantities into LDS, one
+    // sweeper wave per 64 columns runs the recurrence for all angles; the level temperatures travel as
+    // kernel arguments).  Step time of get_thermal_1d + compress_thermal at 1e4 x 90 x 5 (BASELINE
+    // configs[1]) and where it stops paying: DESIGN.md section 4.
+    if (!want_lvl) {
+        long coop_cols = 32768;
+        if (const char *e = getenv("PICASO_AMD_THERMAL_COOP_COLS")) coop_cols = atol(e);
+        a.na = nang;
+        a.ny = 1;
+        if (nang <= 5 && ncol <= coop_cols && thermal_coop_ok(a)) {
+            for (int k = 0; k < nang; ++k) {
+                a.u1[k] = ubar1[k];
+                a.wgt[k] = fuse ? gweight[k / numt] : 0.0;
+                a.wgt2[k] = fuse ? tweight[k % numt] : 0.0;
+            }
+            a.flux = flux_at_top;
+            a.disk_first = a.disk_last = 1;
+            return launch_thermal_coop(ctx, a, tlevel, plevel);
+        }
+    }
+    std::vector<double> tab(2 * (size_t)nlevel + (size_t)nang);
+    for (int i = 0; i < nlevel; ++i) { tab[i] = tlevel[i]; tab[nlevel + i] = plevel[i]; }
+    for (int i = 0; i < nang; ++i) tab[2 * (size_t)nlevel + i] = ubar1[i];
+    const void *d_tab = nullptr;
+    PZ_TRY(table_upload(ctx, tab.data(), sizeof(double) * tab.size(), &d_tab));
+    a.tlevel = (const double *)d_tab; a.plevel = (const double *)d_tab + nlevel;
     if (want_lvl) {   // the reference always fills these (fluxes.py:1851-1907): two-sweep kernel
         const size_t plane = (size_t)(nlevel - 1) * ncol;
         PZ_TRY(lvl_scratch_reserve(ctx, sizeof(double) * (4 * plane + (size_t)nlevel * ncol)));
@@ -951,8 +971,10 @@ int picaso_get_thermal_3d(picaso_ctx *ctx, int nlevel, const double *wno, int nw
 /* ============================================================================================
  * disk quadrature
  * ============================================================================================ */
-static int upload_weights(picaso_ctx *ctx, const double *gweight, int ng, const double *tweight, int nt,
-                          const double **d_w)
+// (gweight[g], tweight[t]) pairs in (g,t) loop order; small tables go with the kernel arguments
+static int compress_with_weights(picaso_ctx *ctx, size_t ninner, const double *x, const double *gweight, int ng,
+                                 const double *tweight, int nt, const double *F0PI, double c1, double c2,
+                                 double *out)
 {
     if (ng < 1 || nt < 1) return fail(ctx, "compress: empty weight table");
     std::vector<double> wts(2 * (size_t)ng * nt);
@@ -961,10 +983,10 @@ static int upload_weights(picaso_ctx *ctx, const double *gweight, int ng, const 
             wts[2 * ((size_t)g * nt + t)] = gweight[g];
             wts[2 * ((size_t)g * nt + t) + 1] = tweight[t];
         }
+    if (ng * nt <= 128) return launch_compress_hostw(ctx, ninner, x, wts.data(), ng * nt, F0PI, c1, c2, out);
     const void *d = nullptr;
     PZ_TRY(table_upload(ctx, wts.data(), sizeof(double) * wts.size(), &d));
-    *d_w = (const double *)d;
-    return 0;
+    return launch_compress_dev(ctx, ninner, x, (const double *)d, ng * nt, F0PI, c1, c2, out);
 }
 
 int picaso_compress_disco_dev(picaso_ctx *ctx, int nwno, double cos_theta,
@@ -973,10 +995,9 @@ int picaso_compress_disco_dev(picaso_ctx *ctx, int nwno, double cos_theta,
 {
     if (!ctx) return fail(nullptr, "null context");
     PZ_HIP(ctx, hipSetDevice(ctx->device));
-    const double *d_w = nullptr;
-    PZ_TRY(upload_weights(ctx, gweight, ng, tweight, nt, &d_w));
     const double sym = (nt == 1) ? 2.0 * 3.14159265358979323846 : 1.0;      // disco.py:140-141
-    return launch_compress_dev(ctx, (size_t)nwno, xint_at_top, d_w, ng * nt, F0PI, sym * 0.5, cos_theta + 1.0, albedo);
+    return compress_with_weights(ctx, (size_t)nwno, xint_at_top, gweight, ng, tweight, nt, F0PI, sym * 0.5,
+                                 cos_theta + 1.0, albedo);
 }
 
 int picaso_compress_disco(picaso_ctx *ctx, int nwno, double cos_theta, const double *xint_at_top,
@@ -1004,10 +1025,8 @@ int picaso_compress_thermal_dev(picaso_ctx *ctx, size_t ninner, const double *fl
 {
     if (!ctx) return fail(nullptr, "null context");
     PZ_HIP(ctx, hipSetDevice(ctx->device));
-    const double *d_w = nullptr;
-    PZ_TRY(upload_weights(ctx, gweight, ng, tweight, nt, &d_w));
     const double sym = (nt == 1) ? 1.0 : 1.0 / (2.0 * 3.14159265358979323846);   // disco.py:174-175
-    return launch_compress_dev(ctx, ninner, flux_at_top, d_w, ng * nt, nullptr, sym, -1.0, flux);
+    return compress_with_weights(ctx, ninner, flux_at_top, gweight, ng, tweight, nt, nullptr, sym, -1.0, flux);
 }
 
 int picaso_compress_thermal(picaso_ctx *ctx, size_t ninner, const double *flux_at_top,

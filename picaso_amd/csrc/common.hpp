@@ -151,6 +151,9 @@ struct ThermalArgs {
     int disk_first, disk_last;
 };
 int launch_thermal_toa(picaso_ctx *ctx, const ThermalArgs &a, bool is3d);
+// cooperative kernel for small 1-D launches (toon_thermal.hip): helper waves + a sweeper wave per 64 columns
+bool thermal_coop_ok(const ThermalArgs &a);
+int launch_thermal_coop(picaso_ctx *ctx, const ThermalArgs &a, const double *tlevel_host, const double *plevel_host);
 
 // level-flux (two-sweep) variants, toon_lvl.hip.  One angle per launch for reflected light
 // (its right-hand side is per angle); all angles inside one launch for thermal (one solve).
@@ -174,6 +177,9 @@ int launch_thermal_lvl(picaso_ctx *ctx, const ThermalLvlArgs &a);
 int lvl_scratch_reserve(picaso_ctx *ctx, size_t bytes);
 int ck_scratch_reserve(picaso_ctx *ctx, size_t bytes);
 
+// the same with up to 128 host weight pairs carried in the kernel arguments (no table upload)
+int launch_compress_hostw(picaso_ctx *ctx, size_t ninner, const double *x, const double *wts_host, int nang,
+                          const double *F0PI, double c1, double c2, double *out);
 int launch_compress_dev(picaso_ctx *ctx, size_t ninner, const double *x, const double *wts_dev,
                         int nang, const double *F0PI, double c1, double c2, double *out);
 

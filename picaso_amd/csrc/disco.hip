@@ -25,6 +25,43 @@ __global__ __launch_bounds__(256) void k_compress(size_t ninner, const double *_
     out[w] = (c2 >= 0.0) ? c1 * acc / (F0PI ? F0PI[w] : 1.0) * c2 : acc * c1;
 }
 
+// Up to COMPRESS_ARG_ANGLES (g,t) weight pairs travel as kernel arguments: no table upload (a host-to-
+// device copy on the stream ahead of the launch) for a kernel that lasts a few microseconds.
+constexpr int COMPRESS_ARG_ANGLES = 128;
+struct CompressArgs {
+    size_t ninner;
+    const double *x, *F0PI;
+    double *out;
+    int nang;
+    double c1, c2;
+    double wts[2 * COMPRESS_ARG_ANGLES];
+};
+__global__ __launch_bounds__(256) void k_compress_args(const CompressArgs a)
+{
+    const size_t w = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (w >= a.ninner) return;
+    double acc = 0.0;
+    {
+#pragma clang fp contract(off)
+        for (int k = 0; k < a.nang; ++k) acc = acc + a.x[(size_t)k * a.ninner + w] * a.wts[2 * k] * a.wts[2 * k + 1];
+    }
+    a.out[w] = (a.c2 >= 0.0) ? a.c1 * acc / (a.F0PI ? a.F0PI[w] : 1.0) * a.c2 : acc * a.c1;   // as k_compress
+}
+
+// host weight pairs (nang <= COMPRESS_ARG_ANGLES)
+int launch_compress_hostw(picaso_ctx *ctx, size_t ninner, const double *x, const double *wts_host, int nang,
+                          const double *F0PI, double c1, double c2, double *out)
+{
+    if (ninner == 0) return 0;
+    CompressArgs a{};
+    a.ninner = ninner; a.x = x; a.F0PI = F0PI; a.out = out; a.nang = nang; a.c1 = c1; a.c2 = c2;
+    for (int k = 0; k < 2 * nang; ++k) a.wts[k] = wts_host[k];
+    const int block = 256;
+    hipLaunchKernelGGL(k_compress_args, dim3((unsigned)((ninner + block - 1) / block)), dim3(block), 0, ctx->stream, a);
+    PZ_HIP(ctx, hipGetLastError());
+    return 0;
+}
+
 // wts_dev: device table of nang (gweight[g], tweight[t]) pairs in (g,t) loop order
 int launch_compress_dev(picaso_ctx *ctx, size_t ninner, const double *x, const double *wts_dev,
                         int nang, const double *F0PI, double c1, double c2, double *out)
