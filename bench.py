@@ -10,8 +10,9 @@ integration) with all input planes resident in HBM.
 One process per GPU (the launcher only provides RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*; nothing
 here imports PyTorch).  One "step" = one full spectrum: every rank solves its contiguous wavelength
 block of the SAME 1e5-point grid (strong scaling, BASELINE's metric) and the albedo shards are
-all-gathered inside the timed region by RCCL inside libpicaso_hip.so (picaso_all_gather_dev, on the
-kernel's own stream).  `--scaling weak` gives every rank its own 1e5-point block of an N x 1e5 grid
+all-gathered inside the timed region by RCCL inside libpicaso_hip.so (picaso_all_gather_async_dev: the
+gather of spectrum i runs on the communicator's own stream behind the kernel that produced it and
+overlaps the solve of spectrum i+1; every gather has finished when the timed region ends).  `--scaling weak` gives every rank its own 1e5-point block of an N x 1e5 grid
 instead.  Prints ONE JSON line (rank 0).
 
 --config selects the other BASELINE workloads (not the headline): 1 thermal emission 1e4 x 90,
@@ -240,21 +241,27 @@ def main():
         seed = 3
     wl = build(ctx, args, lo, hi, seed, nwno_total)
     nloc = hi - lo
-    # two result buffers: with N > 1 the gather of spectrum i may still be in flight on the stream when
-    # spectrum i+1 is solved (everything is ordered on the one stream; two buffers keep the last
-    # gathered spectrum intact for the checks below)
+    # two result buffers: with N > 1 the gather of spectrum i is still in flight on the communicator's
+    # stream while spectrum i+1 is solved into the other buffer
     loc = [device.DeviceArray((nloc,), ctx) for _ in range(2)]
     full = [device.DeviceArray((nwno_total,), ctx) for _ in range(2)] if comm else None
     nstep = [0]
 
     def step(gather=True):
+        # spectrum i is solved into buffer i & 1; its gather runs on the communicator's stream and overlaps
+        # the solve of spectrum i+1 (other buffer); a buffer is reused only after its previous gather
+        # (device-side wait, no host synchronisation)
         b = nstep[0] & 1
         nstep[0] += 1
+        if comm:
+            comm.wait_slot(b)
         wl["solve"](loc[b])
         if comm and gather:
-            comm.all_gather_spectrum(loc[b], full[b], nwno_total)
+            comm.all_gather_spectrum_async(loc[b], full[b], nwno_total, b)
 
     def barrier():
+        if comm:
+            comm.wait_slot(-1)       # every gather has finished before the stream is drained
         device.sync(ctx)
         if comm:
             comm.barrier()
@@ -286,7 +293,9 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    stream_ms = device.timer_stop(ctx) / args.steps       # HIP events on the kernel's stream (solve + gather)
+    if comm:
+        comm.wait_slot(-1)
+    stream_ms = device.timer_stop(ctx) / args.steps       # HIP events on the kernel's stream (solve [+ last gathers])
     barrier()
     elapsed = time.perf_counter() - t0
     if comm:
@@ -302,7 +311,11 @@ def main():
         for _ in range(200):                # the copies above idled the GPU: back to steady clocks first
             step()
         kernel_ms = timed(args.steps, gather=False)
-        both_ms = timed(args.steps, gather=True)
+        device.timer_start(ctx)                               # the gather alone, serialised behind each solve
+        for _ in range(args.steps):
+            step(gather=True)
+            comm.wait_slot(-1)
+        both_ms = device.timer_stop(ctx) / args.steps
         info = json.dumps({"rank": rank, "nwno": nloc, "kernel_ms": kernel_ms,
                            "gather_ms": max(both_ms - kernel_ms, 0.0)}).encode()
         per_rank = [json.loads(b.decode()) for b in group.all_gather_bytes(info)]
@@ -354,7 +367,8 @@ def main():
                        "sharding": "%d contiguous wavelength block(s) of %s" % (
                            world, "%d..%d" % (nwno_total // world, -(-nwno_total // world))),
                        "collective": "RCCL all-gather of the albedo shards inside libpicaso_hip.so "
-                                     "(picaso_all_gather_dev), in the timed region" if comm else "none"},
+                                     "(picaso_all_gather_async_dev: overlaps the next solve), in the timed region"
+                       if comm else "none"},
             "prewarm": {"ms": args.prewarm_ms, "launches": nprewarm, "why": "GPU clock ramp, untimed"},
             "wavelength_layer_updates_per_s": value * nwno_total / spectra_per_step * args.nlayer,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -94,6 +94,14 @@ int picaso_all_gather_dev(picaso_comm *comm, const double *send, double *recv, s
 /* ragged shards: rank r's counts[r] elements land at recv + displs[r] on every rank */
 int picaso_all_gatherv_dev(picaso_comm *comm, const double *send, double *recv, const size_t *counts,
                            const size_t *displs);
+/* overlapped form: the gather starts when everything enqueued on the context's stream so far is done and
+ * runs on the communicator's own stream; `slot` (0..3) names the result buffer.  counts == NULL: equal
+ * blocks of `count` elements; else the ragged form.  picaso_comm_wait_slot(comm, slot) orders later work
+ * of the context's stream behind the last gather of that slot (slot < 0: of all slots); the synchronous
+ * collectives and picaso_comm_max / _sum / _barrier wait for all slots first. */
+int picaso_all_gather_async_dev(picaso_comm *comm, const double *send, double *recv, size_t count,
+                                const size_t *counts, const size_t *displs, int slot);
+int picaso_comm_wait_slot(picaso_comm *comm, int slot);
 int picaso_comm_max(picaso_comm *comm, double *value);
 int picaso_comm_sum(picaso_comm *comm, double *value);
 int picaso_comm_barrier(picaso_comm *comm);

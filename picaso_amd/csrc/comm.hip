@@ -16,6 +16,13 @@ struct picaso_comm {
     picaso_ctx *ctx = nullptr;
     int nranks = 1, rank = 0;
     double *scratch = nullptr;       // device scratch of the small host-value collectives
+    // overlapped gathers (picaso_all_gather_async_dev): the collective runs on the communicator's own
+    // stream behind an event of the compute stream, one completion event per result slot
+    static constexpr int NSLOT = 4;
+    hipStream_t stream = nullptr;
+    hipEvent_t ready = nullptr;
+    hipEvent_t done[NSLOT] = {};
+    bool pending[NSLOT] = {};
 };
 
 using namespace pz;
@@ -48,9 +55,13 @@ static int comm_finish(picaso_ctx *ctx, ncclComm_t c, int nranks, int rank, pica
     pc->nranks = nranks;
     pc->rank = rank;
     hipError_t e = hipMalloc((void **)&pc->scratch, sizeof(double) * (size_t)(nranks + 1));
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&pc->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&pc->ready, hipEventDisableTiming);
+    for (int i = 0; i < picaso_comm::NSLOT && e == hipSuccess; ++i)
+        e = hipEventCreateWithFlags(&pc->done[i], hipEventDisableTiming);
     if (e != hipSuccess) {
         delete pc;
-        return fail(ctx, "picaso_comm: hipMalloc failed: %s", hipGetErrorString(e));
+        return fail(ctx, "picaso_comm: set-up failed: %s", hipGetErrorString(e));
     }
     *out = pc;
     return 0;
@@ -91,8 +102,13 @@ void picaso_comm_destroy(picaso_comm *c)
     if (!c) return;
     (void)hipSetDevice(c->ctx->device);
     (void)hipStreamSynchronize(c->ctx->stream);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->comm) (void)ncclCommDestroy(c->comm);
     if (c->scratch) (void)hipFree(c->scratch);
+    for (int i = 0; i < picaso_comm::NSLOT; ++i)
+        if (c->done[i]) (void)hipEventDestroy(c->done[i]);
+    if (c->ready) (void)hipEventDestroy(c->ready);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
 
@@ -110,7 +126,54 @@ int picaso_all_gather_dev(picaso_comm *c, const double *send, double *recv, size
     if (!c) return fail(nullptr, "picaso_all_gather_dev: null communicator");
     picaso_ctx *ctx = c->ctx;
     PZ_HIP(ctx, hipSetDevice(ctx->device));
+    PZ_TRY(picaso_comm_wait_slot(c, -1));
     PZ_NCCL(ctx, ncclAllGather(send, recv, count, ncclDouble, c->comm, ctx->stream));
+    return 0;
+}
+
+// The same gather off the compute stream: it starts when everything enqueued on the context's stream so
+// far has finished (device-side event) and runs on the communicator's own stream, so the context's
+// stream can go on with the next spectrum while the shards of this one travel.  `slot` (0..3) names
+// the result buffer: picaso_comm_wait_slot makes the context's stream wait for the last gather of that
+// slot before the buffer is written or read again.  counts == NULL: equal blocks of `count`.
+int picaso_all_gather_async_dev(picaso_comm *c, const double *send, double *recv, size_t count,
+                                const size_t *counts, const size_t *displs, int slot)
+{
+    if (!c) return fail(nullptr, "picaso_all_gather_async_dev: null communicator");
+    picaso_ctx *ctx = c->ctx;
+    if (slot < 0 || slot >= picaso_comm::NSLOT) return fail(ctx, "picaso_all_gather_async_dev: slot must be 0..3");
+    PZ_HIP(ctx, hipSetDevice(ctx->device));
+    PZ_HIP(ctx, hipEventRecord(c->ready, ctx->stream));
+    PZ_HIP(ctx, hipStreamWaitEvent(c->stream, c->ready, 0));
+    if (!counts) {
+        PZ_NCCL(ctx, ncclAllGather(send, recv, count, ncclDouble, c->comm, c->stream));
+    } else {
+        if (!displs) return fail(ctx, "picaso_all_gather_async_dev: counts without displs");
+        PZ_NCCL(ctx, ncclGroupStart());
+        for (int r = 0; r < c->nranks; ++r) {
+            const double *src = (r == c->rank) ? send : recv + displs[r];
+            PZ_NCCL(ctx, ncclBroadcast(src, recv + displs[r], counts[r], ncclDouble, r, c->comm, c->stream));
+        }
+        PZ_NCCL(ctx, ncclGroupEnd());
+    }
+    PZ_HIP(ctx, hipEventRecord(c->done[slot], c->stream));
+    c->pending[slot] = true;
+    return 0;
+}
+
+// work enqueued on the context's stream from now on starts after the last asynchronous gather of `slot`
+// (slot < 0: of every slot) has finished; device-side, the host does not block
+int picaso_comm_wait_slot(picaso_comm *c, int slot)
+{
+    if (!c) return fail(nullptr, "picaso_comm_wait_slot: null communicator");
+    picaso_ctx *ctx = c->ctx;
+    if (slot >= picaso_comm::NSLOT) return fail(ctx, "picaso_comm_wait_slot: slot must be < 4");
+    PZ_HIP(ctx, hipSetDevice(ctx->device));
+    for (int i = 0; i < picaso_comm::NSLOT; ++i) {
+        if ((slot >= 0 && i != slot) || !c->pending[i]) continue;
+        PZ_HIP(ctx, hipStreamWaitEvent(ctx->stream, c->done[i], 0));
+        c->pending[i] = false;
+    }
     return 0;
 }
 
@@ -122,6 +185,7 @@ int picaso_all_gatherv_dev(picaso_comm *c, const double *send, double *recv, con
     if (!c || !counts || !displs) return fail(nullptr, "picaso_all_gatherv_dev: null argument");
     picaso_ctx *ctx = c->ctx;
     PZ_HIP(ctx, hipSetDevice(ctx->device));
+    PZ_TRY(picaso_comm_wait_slot(c, -1));
     PZ_NCCL(ctx, ncclGroupStart());
     for (int r = 0; r < c->nranks; ++r) {
         const double *src = (r == c->rank) ? send : recv + displs[r];
@@ -137,6 +201,7 @@ static int allreduce_host(picaso_comm *c, double *value, ncclRedOp_t op)
     if (!c || !value) return fail(nullptr, "picaso_comm reduce: null argument");
     picaso_ctx *ctx = c->ctx;
     PZ_HIP(ctx, hipSetDevice(ctx->device));
+    PZ_TRY(picaso_comm_wait_slot(c, -1));       // collectives of one communicator never overlap each other
     PZ_HIP(ctx, hipMemcpyAsync(c->scratch, value, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     PZ_NCCL(ctx, ncclAllReduce(c->scratch, c->scratch, 1, ncclDouble, op, c->comm, ctx->stream));
     PZ_HIP(ctx, hipMemcpyAsync(value, c->scratch, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));

@@ -243,6 +243,24 @@ class Comm:
         else:
             self.all_gatherv(local, full, counts, [lo for lo, _ in bounds])
 
+    def all_gather_spectrum_async(self, local, full, nwno, slot):
+        """As ``all_gather_spectrum`` but on the communicator's own stream, behind everything enqueued on
+        the context's stream so far: the next solve overlaps the gather.  ``wait_slot(slot)`` before the
+        buffers of that slot are written or read again."""
+        bounds = shard_bounds(nwno, self.world)
+        counts = [hi - lo for lo, hi in bounds]
+        if len(set(counts)) == 1:
+            c = d = None
+        else:
+            c = (ctypes.c_size_t * self.world)(*counts)
+            d = (ctypes.c_size_t * self.world)(*[lo for lo, _ in bounds])
+        _lib.check(_lib.load().picaso_all_gather_async_dev(self.handle, _addr(local), _addr(full),
+                                                           ctypes.c_size_t(counts[0]), c, d, ctypes.c_int(slot)),
+                   self.ctx)
+
+    def wait_slot(self, slot=-1):
+        _lib.check(_lib.load().picaso_comm_wait_slot(self.handle, ctypes.c_int(slot)), self.ctx)
+
     def max(self, value):
         v = ctypes.c_double(float(value))
         _lib.check(_lib.load().picaso_comm_max(self.handle, ctypes.byref(v)), self.ctx)

@@ -36,6 +36,19 @@ def test_one_rank_rccl_collectives():
         comm.all_gatherv(send, recv, [n], [0])
         device.sync(ctx)
         assert np.array_equal(recv.to_host(), host)
+        # overlapped form: the gather is ordered behind the producer on the context's stream, later work of
+        # that stream behind the gather (wait_slot); the producer of the next result may overlap it
+        recv2 = device.DeviceArray.zeros((n,), ctx)
+        sends = [device.DeviceArray.from_host(host * (it + 1), ctx) for it in range(6)]
+        for it in range(6):
+            slot = it & 1
+            comm.wait_slot(slot)
+            comm.all_gather_spectrum_async(sends[it], recv if slot == 0 else recv2, n, slot)
+        comm.wait_slot(-1)
+        device.sync(ctx)
+        assert np.array_equal(recv.to_host(), host * 5) and np.array_equal(recv2.to_host(), host * 6)
+        with pytest.raises(RuntimeError):
+            comm.all_gather_spectrum_async(send, recv, n, 7)
         assert comm.max(3.25) == 3.25
         comm.barrier()
         r, w = ctypes.c_int(-1), ctypes.c_int(-1)
