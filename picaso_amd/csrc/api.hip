@@ -89,14 +89,45 @@ static std::vector<int> angle_chunks(int n)
 }
 
 // Run each angle as its own wave (grid.y) instead of carrying them in one lane?  Worth it while all
-// angle-waves together still fit about one wave per SIMD (1024 SIMDs): measured on the reflected
-// kernel with 5 angles, 10 000 columns 0.093 ms vs 0.183 ms fused, 30 000 columns 0.217 vs 0.188 ms.
-// Steady-state clocks, reflected kernel, 5 angles (tools/refl_time.py, one box): 12 500 columns 0.079 ms
-// spread vs 0.157 fused, 25 000 0.147 vs 0.158, 32 768 0.137 vs 0.157, 40 000 0.258 vs 0.159.
+// angle-waves together still fit about one wave per SIMD (1024 SIMDs).  The thermal kernels and reflected
+// launches of more than MAX_ANGLES angles decide with this product rule; the reflected kernel with few
+// angles chooses among group sizes (reflected_angle_group below).
 static bool spread_angles(long ncol, int nang, long limit = 1280L * 64)
 {
     if (const char *e = getenv("PICASO_AMD_SPREAD_COLS")) limit = atol(e);
     return nang > 1 && ncol * nang <= limit;
+}
+
+// Reflected kernel: how many angles a wave carries (0 = all of them fused in one lane, the launch of the
+// large grids).  A sweep is one long dependent chain, so below ~1 wave per SIMD (1024 SIMDs) the time of a
+// launch is the time of ONE wave, which grows with the angles it carries -- measured alone on a SIMD
+// (steady clocks, 90 layers, disk sum included): 1 angle 0.049 ms, 2: 0.068, 3: 0.097, 5: 0.160 -- and with
+// two waves per SIMD 2 angles take 0.137, 3: 0.155, 5: 0.235.  So mid-size grids run groups of g angles as
+// separate waves (grid.y) and the cheapest shape that still fits is taken; measured with 5 angles
+// (tools/experiments/angle_group_sweep.sh): 10 000 columns g=1 0.050 ms (fused 0.158), 12 500 g=2 0.069
+// (g=1 0.071: 980 waves no longer place one per SIMD), 20 000 g=2 0.074, 25 000 g=3 0.098 (g=1 0.141),
+// 32 768 g=3 0.099, 40 000 g=2 0.141 (fused 0.160), 50 000 g=3 0.163 = fused, 60 000 fused 0.162 (g=3 0.186).
+// The result does not depend on the shape (explicit-fma arithmetic, disk sum in the reference's order).
+static int reflected_angle_group(long ncol, int nang)
+{
+    if (const char *e = getenv("PICASO_AMD_ANGLE_GROUP")) return atoi(e);
+    if (nang <= 1) return 0;
+    if (nang > MAX_ANGLES) return spread_angles(ncol, nang, 2560L * 64) ? 1 : 0;
+    const long colwaves = (ncol + 63) / 64;
+    if (colwaves > 1024) return 0;
+    static const double alone[MAX_ANGLES + 1] = {0, 0.049, 0.068, 0.097, 0.128, 0.160, 0.192, 0.224, 0.256};
+    static const double paired[4] = {0, 0, 0.137, 0.155};
+    static const long fits_alone[4] = {0, 820, 1024, 1024}, fits_paired[4] = {0, 0, 1900, 1600};
+    double best = alone[nang];
+    int group = 0;
+    for (int g = 1; g <= 3 && g < nang; ++g) {
+        const int ngroups = (nang + g - 1) / g;
+        if (ngroups * g > MAX_ANGLES) continue;
+        const long waves = colwaves * ngroups;
+        const double t = waves <= fits_alone[g] ? alone[g] : waves <= fits_paired[g] ? paired[g] : 1e9;
+        if (t < best) { best = t; group = g; }
+    }
+    return group;
 }
 
 static int check_phase_options(picaso_ctx *ctx, int single_phase, int multi_phase, int toon)
@@ -444,7 +475,25 @@ static int reflected_1d_core(picaso_ctx *ctx, int nlevel, int nwno, int ncolper,
         if (!get_toa_intensity) return 0;
     }
     int done = 0;
-    if (spread_angles(ncol, nang, 2560L * 64)) {
+    const int group = reflected_angle_group(ncol, nang);
+    if (group > 1 && group < nang && ((nang + group - 1) / group) * group <= MAX_ANGLES) {
+        // Mid-size grids: groups of `group` angles per wave (grid.y), the last group padded with a copy of
+        // the last angle (its extra results are not stored); disk sum as a separate pass, like below.
+        a.na = group;
+        a.ny = (nang + group - 1) / group;
+        a.nvalid = nang;
+        a.albedo = nullptr;
+        for (int k = 0; k < a.ny * group; ++k) {
+            const int idx = k < nang ? k : nang - 1;
+            a.ang[k] = make_refl_angle(ubar0[idx], ubar1[idx], 0.0);
+        }
+        a.xint = xint_at_top;
+        PZ_TRY(launch_reflected_toa(ctx, a, false));
+        if (fuse)
+            PZ_TRY(picaso_compress_disco_dev(ctx, nwno, cos_theta, xint_at_top, gweight, numg, tweight, numt, F0PI, albedo));
+        return 0;
+    }
+    if (group == 1) {
         // Few columns: the chip is far from full and a lane's serial instruction stream sets the
         // latency, so every angle runs as its own wave (grid.y) and the disk sum is a separate pass.
         a.na = 1;
@@ -453,6 +502,7 @@ static int reflected_1d_core(picaso_ctx *ctx, int nlevel, int nwno, int ncolper,
             const int m = (nang - done < MAX_ANGLES) ? nang - done : MAX_ANGLES;
             for (int k = 0; k < m; ++k) a.ang[k] = make_refl_angle(ubar0[done + k], ubar1[done + k], 0.0);
             a.ny = m;
+            a.nvalid = m;
             a.xint = xint_at_top + (size_t)done * ncol;
             PZ_TRY(launch_reflected_toa(ctx, a, false));
             done += m;

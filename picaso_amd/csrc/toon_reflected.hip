@@ -486,7 +486,9 @@ __global__ __launch_bounds__(PZ_REFL_BLOCK, (NA <= 2 ? PZ_REFL_MINWAVES_FEW : PZ
     // ---- surface row (fluxes.py:178-183) and output ----
     // EP(1 - rs G) pos + EM(G - rs) neg = b_surface - c+dn + rs c-dn with neg = delta - rho pos,
     // divided through by EP:  pos = EM (b_surface - D1 + rs D2) / ((1 - rs G) - EM^2 (G - rs) rho)
-    double alb = 0.0;
+    // disk sum in the reference's order (one running sum over all angles): a later chunk of a launch
+    // split over angles continues from the stored partial sum
+    double alb = (!IS3D && a.albedo && !a.albedo_first) ? a.albedo[w] : 0.0;
     double xout[NA];
     {
 #pragma clang fp contract(off)
@@ -503,11 +505,11 @@ __global__ __launch_bounds__(PZ_REFL_BLOCK, (NA <= 2 ? PZ_REFL_MINWAVES_FEW : PZ
     for (int k = 0; k < NA; ++k) {
         const double x = xout[k];
         if (IS3D) a.xint[(long)fac * a.nwno + w] = x;
-        else a.xint[(long)(blockIdx.y * NA + k) * a.ncol + col] = x;
+        else if (NA == 1 || (int)blockIdx.y * NA + k < a.nvalid) a.xint[(long)(blockIdx.y * NA + k) * a.ncol + col] = x;
         alb = disk_accumulate(alb, x, g[k].wgt, g[k].wgt2);
     }
     if (!IS3D && a.albedo) {                              // fused disco.compress_disco (disco.py:145-148)
-        double acc = a.albedo_first ? alb : a.albedo[w] + alb;
+        double acc = alb;
         if (a.albedo_last) acc = disk_finish(a.albedo_scale, acc, F, a.cos_theta);
         a.albedo[w] = acc;
     }
@@ -523,8 +525,10 @@ static bool fast_options(const ReflectedArgs &a)
 }
 
 template <int NA>
-static int launch1d(picaso_ctx *ctx, const ReflectedArgs &a)
+static int launch1d(picaso_ctx *ctx, const ReflectedArgs &a_in)
 {
+    ReflectedArgs a = a_in;
+    if (a.nvalid <= 0) a.nvalid = NA * (a.ny > 1 ? a.ny : 1);     // no padded angle slots
     const int block = PZ_REFL_BLOCK;
     const dim3 grid((unsigned)((a.ncol + block - 1) / block), (unsigned)(a.ny > 1 ? a.ny : 1));
     bool zp = true;

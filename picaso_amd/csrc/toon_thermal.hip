@@ -249,7 +249,8 @@ __global__ __launch_bounds__(256) void k_thermal_toa(const ThermalArgs a)
         s_last = L.s;
     }
     const double pos = thermal_surface_pos<IS3D>(S, Bn, b1_last, s_last, rs, a.hard_surface);
-    double disk = 0.0;
+    // one running disk sum over all angles (disco.py:174-176): a later angle chunk continues from the stored one
+    double disk = (!IS3D && a.disk && !a.disk_first) ? a.disk[w] : 0.0;
 #pragma unroll
     for (int k = 0; k < NA; ++k) {
         const double x = fma(zeta[k], pos, kappa[k]);
@@ -261,7 +262,7 @@ __global__ __launch_bounds__(256) void k_thermal_toa(const ThermalArgs a)
         }
     }
     if (!IS3D && a.disk) {                                     // fused disco.compress_thermal
-        double acc = a.disk_first ? disk : a.disk[w] + disk;
+        double acc = disk;
         if (a.disk_last) acc = acc * a.disk_scale;
         a.disk[w] = acc;
     }
@@ -469,7 +470,7 @@ __global__ __launch_bounds__(64 * (COOP_HELPERS + 2)) void k_thermal_coop(const 
     for (int k = 0; k < NA; ++k)                               // F+[n] boundary intensity
         kappa[k] = fma(W[k], thermal_bottom<false>(Bn, b1_last, u1[k], rs, a.hard_surface), kappa[k]);
     const double pos = thermal_surface_pos<false>(S, Bn, b1_last, s_last, rs, a.hard_surface);
-    double disk = 0.0;
+    double disk = (a.disk && active && !a.disk_first) ? a.disk[w] : 0.0;
 #pragma unroll
     for (int k = 0; k < NA; ++k) {
         const double x = fma(zeta[k], pos, kappa[k]);
@@ -477,7 +478,7 @@ __global__ __launch_bounds__(64 * (COOP_HELPERS + 2)) void k_thermal_coop(const 
         disk = disk + x * a.wgt[k] * a.wgt2[k];                // reference order, unfused (disco.py:174-176)
     }
     if (a.disk && active) {                                    // fused disco.compress_thermal
-        double acc = a.disk_first ? disk : a.disk[w] + disk;
+        double acc = disk;
         if (a.disk_last) acc = acc * a.disk_scale;
         a.disk[w] = acc;
     }

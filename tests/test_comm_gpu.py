@@ -47,7 +47,7 @@ def test_one_rank_rccl_collectives():
         comm.wait_slot(-1)
         device.sync(ctx)
         assert np.array_equal(recv.to_host(), host * 5) and np.array_equal(recv2.to_host(), host * 6)
-        with pytest.raises(RuntimeError):
+        with pytest.raises(_lib.PicasoHipError):
             comm.all_gather_spectrum_async(send, recv, n, 7)
         assert comm.max(3.25) == 3.25
         comm.barrier()

@@ -74,6 +74,35 @@ def test_eight_shards_as_on_an_8_gpu_node(full):
     assert np.array_equal(np.concatenate([p[1] for p in parts]), full["alb"])
 
 
+@pytest.mark.parametrize("ng,nwno", [(5, 25000), (5, 12500), (6, 9000), (7, 4000)])
+def test_angle_grouping_does_not_change_a_bit(ng, nwno, monkeypatch):
+    """Mid-size grids run groups of 1, 2 or 3 angles per wave (api.hip:reflected_angle_group; the last group
+    padded): intensities and albedo are bit-identical to the all-fused launch, whatever the grouping."""
+    from picaso_amd import _lib, disco, resident
+    from picaso_amd import synthetic as syn
+    from picaso_amd.device import DeviceArray
+    ctx = _lib.context()
+    sc = syn.make_scene(40, nwno, seed=21)
+    sc["F0PI"] = np.linspace(0.5, 2.0, nwno)
+    sc["surf_reflect"] = np.full(nwno, 0.2)
+    g, gw, t, tw = disco.get_angles_1d(ng)
+    u0, u1, _, _, _ = disco.compute_disco(ng, 1, g, t, 0.0)
+    d = resident.upload_scene(sc, resident.REFLECTED_PLANES + ("F0PI", "surf_reflect"), ctx=ctx)
+    res = {}
+    for group in ("0", "1", "2", "3", "4", None):
+        if group is None:
+            monkeypatch.delenv("PICASO_AMD_ANGLE_GROUP", raising=False)
+        else:
+            monkeypatch.setenv("PICASO_AMD_ANGLE_GROUP", group)
+        x, alb = DeviceArray.zeros((ng, 1, nwno), ctx), DeviceArray.zeros((nwno,), ctx)
+        resident.reflected_1d(ctx, 41, nwno, ng, 1, d, d["surf_reflect"], u0, u1, 1.0, d["F0PI"], 3, 0,
+                              *TTHG, x, gweight=gw, tweight=tw, albedo=alb)
+        res[group] = (x.to_host(), alb.to_host())
+    assert np.all(res["0"][0] > 0) and np.all(res["0"][1] > 0)
+    for group, (x, alb) in res.items():
+        assert np.array_equal(x, res["0"][0]) and np.array_equal(alb, res["0"][1]), group
+
+
 # ---------------------------------------------------------------------------------------------
 # the other BASELINE.json configurations at their stated sizes
 # ---------------------------------------------------------------------------------------------
@@ -98,6 +127,38 @@ def _thermal(nwno, lo=None, hi=None, seed=5):
                             calc_type=calc_type, gweight=gw, tweight=tw, flux_disk=disk)
         return f.to_host(), disk.to_host()
     return sc, u1, gw, tw, run
+
+
+@pytest.mark.parametrize("ng", [5, 7])
+def test_thermal_launch_shape_does_not_change_a_bit(ng, monkeypatch):
+    """Thermal kernel: all angles fused in a lane (7 angles: two launches of 4 + 3 continuing one disk sum),
+    one angle per wave, or the cooperative kernel -- fluxes and disk average agree bit for bit."""
+    from picaso_amd import _lib, disco, resident
+    from picaso_amd import synthetic as syn
+    from picaso_amd.device import DeviceArray
+    ctx = _lib.context()
+    nwno, nlayer = 3000, 40
+    sc = syn.make_scene(nlayer, nwno, seed=6)
+    sc["surf_reflect"] = np.zeros(nwno)
+    sc["dwno"] = np.full(nwno, 2.0)
+    g, gw, t, tw = disco.get_angles_1d(ng)
+    _, u1, _, _, _ = disco.compute_disco(ng, 1, g, t, 0.0)
+    d = resident.upload_scene(sc, ("dtau_og", "w0_no_raman", "cosb_og", "wno", "dwno", "surf_reflect"), ctx=ctx)
+    res = []
+    for env in ({"PICASO_AMD_THERMAL_NO_COOP": "1", "PICASO_AMD_SPREAD_COLS": "0"},
+                {"PICASO_AMD_THERMAL_NO_COOP": "1", "PICASO_AMD_SPREAD_COLS": "100000000"}, {}):
+        for k in ("PICASO_AMD_THERMAL_NO_COOP", "PICASO_AMD_SPREAD_COLS"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        f, disk = DeviceArray.zeros((ng, 1, nwno), ctx), DeviceArray.zeros((nwno,), ctx)
+        resident.thermal_1d(ctx, nlayer + 1, d["wno"], nwno, ng, 1, sc["tlevel"], d["dtau_og"], d["w0_no_raman"],
+                            d["cosb_og"], sc["plevel"], u1, d["surf_reflect"], 0, f, dwno=d["dwno"],
+                            calc_type=0, gweight=gw, tweight=tw, flux_disk=disk)
+        res.append((f.to_host(), disk.to_host()))
+    assert np.all(res[0][1] > 0)
+    for f, disk in res[1:]:
+        assert np.array_equal(f, res[0][0]) and np.array_equal(disk, res[0][1])
 
 
 @pytest.mark.parametrize("nwno,calc_type", [(10000, 0), (100000, 0), (10000, 1)])
