@@ -154,6 +154,16 @@ int picaso_get_reflected_3d(picaso_ctx *ctx, int nlevel, const double *wno, int 
                             double frac_a, double frac_b, double frac_c, double constant_back,
                             double constant_forward, double *xint_at_top);
 
+/* device-resident form (+ optional fused compress_disco into `albedo`).  Planes that compute_opacity
+ * derives exactly from other planes may be passed as NULL; the kernel then re-derives them with the same
+ * operations instead of reading them from HBM (picaso() does this for the whole 3-D path):
+ *   tau_3d / tau_og_3d : running sums of dtau_3d / dtau_og_3d from 0 at the top (optics.py:353-354, 418-420)
+ *   gcos2_3d           : 0.5 ftau_ray (optics.py:342)
+ *   cosb_3d, ftau_cld_3d, ftau_ray_3d, cosb_og_3d (all four, and gcos2_3d): no cloud in any column:
+ *                        0, 0, 1, 0 (and 0.5), what optics.py:335-342 gives for TAUCLD = 0 and TAURAY > 0
+ *   dtau_og_3d, w0_og_3d (both; then tau_og_3d too): no delta-scaling, equal to dtau_3d / w0_3d -- the case
+ *                        of cosb = 0 (optics.py:412-420 with f = 0) and of delta_eddington = False
+ * dtau_3d and w0_3d are always required. */
 int picaso_get_reflected_3d_dev(picaso_ctx *ctx, int nlevel, int nwno, int numg, int numt,
                                 const double *dtau_3d, const double *tau_3d, const double *w0_3d,
                                 const double *cosb_3d, const double *gcos2_3d,
@@ -197,6 +207,8 @@ int picaso_get_thermal_3d(picaso_ctx *ctx, int nlevel, const double *wno, int nw
                           const double *ubar1, const double *surf_reflect, int hard_surface,
                           double *int_at_top);
 
+/* device-resident form (+ optional fused compress_thermal into `flux_disk`); cosb_3d NULL = no cloud in any
+ * column (cosb_og = 0, optics.py:338): the plane is not read */
 int picaso_get_thermal_3d_dev(picaso_ctx *ctx, int nlevel, const double *wno, int nwno, int numg,
                               int numt, const double *tlevel_3d, const double *dtau_3d,
                               const double *w0_3d, const double *cosb_3d, const double *plevel_3d,

@@ -424,6 +424,8 @@ static int reflected_1d_core(picaso_ctx *ctx, int nlevel, int nwno, int ncolper,
     if (!ctx) return fail(nullptr, "null context");
     if (nlevel < 2 || nwno < 1 || numg < 1 || numt < 1)
         return fail(ctx, "get_reflected_1d: bad sizes nlevel=%d nwno=%d numg=%d numt=%d", nlevel, nwno, numg, numt);
+    if (!dtau || !tau || !w0 || !cosb || !gcos2 || !ftau_cld || !ftau_ray || !dtau_og || !tau_og || !w0_og || !cosb_og)
+        return fail(ctx, "get_reflected_1d: all eleven planes are required");
     const long ncol = (long)nwno * ncolper;
     if (plane_pitch < ncol) return fail(ctx, "get_reflected_1d: plane_pitch %ld < %ld columns", plane_pitch, ncol);
     if (ncolper > 1 && albedo)
@@ -673,6 +675,15 @@ int picaso_get_reflected_3d_dev(picaso_ctx *ctx, int nlevel, int nwno, int numg,
         return fail(ctx, "get_reflected_3d: bad sizes nlevel=%d nwno=%d numg=%d numt=%d", nlevel, nwno, numg, numt);
     PZ_TRY(check_phase_options(ctx, single_phase, multi_phase, 0));
     PZ_HIP(ctx, hipSetDevice(ctx->device));
+    // planes compute_opacity derives exactly from others may be NULL (re-derived in the kernel, see picaso_hip.h)
+    if (!dtau_3d || !w0_3d) return fail(ctx, "get_reflected_3d: dtau and w0 are required");
+    const int ncld = (cosb_3d != nullptr) + (ftau_cld_3d != nullptr) + (ftau_ray_3d != nullptr) + (cosb_og_3d != nullptr);
+    if (ncld != 0 && ncld != 4)
+        return fail(ctx, "get_reflected_3d: cosb, ftau_cld, ftau_ray and cosb_og are given together or all NULL (no cloud)");
+    if (ncld == 0 && gcos2_3d) return fail(ctx, "get_reflected_3d: gcos2 without ftau_ray");
+    if ((dtau_og_3d != nullptr) != (w0_og_3d != nullptr))
+        return fail(ctx, "get_reflected_3d: dtau_og and w0_og are given together or both NULL (no delta-scaling)");
+    if (!dtau_og_3d && tau_og_3d) return fail(ctx, "get_reflected_3d: tau_og without dtau_og");
     const int nfac = numg * numt;
     std::vector<double> tab(2 * (size_t)nfac);
     for (int i = 0; i < nfac; ++i) { tab[i] = ubar0[i]; tab[nfac + i] = ubar1[i]; }
@@ -754,6 +765,7 @@ static int thermal_1d_core(picaso_ctx *ctx, int nlevel, const double *wno, int n
     if (!ctx) return fail(nullptr, "null context");
     if (nlevel < 2 || nwno < 1 || numg < 1 || numt < 1)
         return fail(ctx, "get_thermal_1d: bad sizes nlevel=%d nwno=%d numg=%d numt=%d", nlevel, nwno, numg, numt);
+    if (!dtau || !w0 || !cosb) return fail(ctx, "get_thermal_1d: dtau, w0 and cosb are required");
     const long ncol = (long)nwno * ncolper;
     if (plane_pitch < ncol) return fail(ctx, "get_thermal_1d: plane_pitch %ld < %ld columns", plane_pitch, ncol);
     if (calc_type != 0 && calc_type != 1) return fail(ctx, "get_thermal_1d: calc_type must be 0 or 1");
@@ -961,6 +973,7 @@ int picaso_get_thermal_3d_dev(picaso_ctx *ctx, int nlevel, const double *wno, in
 {
     if (!ctx) return fail(nullptr, "null context");
     if (nlevel < 2 || nwno < 1 || numg < 1 || numt < 1) return fail(ctx, "get_thermal_3d: bad sizes");
+    if (!dtau_3d || !w0_3d) return fail(ctx, "get_thermal_3d: dtau and w0 are required (cosb NULL = no cloud)");
     PZ_HIP(ctx, hipSetDevice(ctx->device));
     const int nfac = numg * numt;
     std::vector<double> tab((size_t)nfac * (2 * (size_t)nlevel + 1));

@@ -134,6 +134,62 @@ __device__ __forceinline__ double ipow(double x, int n)
     return r;
 }
 
+// One layer of one column: mixing + delta-Eddington (optics.py:327-431), running level sums in tau_run /
+// taud_run.  Shared by the plane kernel and the facet kernel; operations as written (no contraction), so
+// both give the same bits -- and planes that coincide analytically (w0 and w0_no_raman for a constant Raman
+// factor of 0.99999, the delta-scaled and the unscaled set for cosb = 0) coincide bit for bit, which the
+// 3-D path relies on when it leaves the duplicates out.
+__device__ __forceinline__ void mix_layer(const MixArgs &a, long q, long qn, double tg, double tr, double tc,
+                                          double wc, double gc, double rf, double &tau_run, double &taud_run)
+{
+#pragma clang fp contract(off)
+    double dtau = tg + tr + tc;                                     // optics.py:329
+    double fcld = (wc * tc) / (wc * tc + tr);                       // :335
+    double cosb = gc;                                               // :338
+    double fray = tr / (tr + wc * tc);                              // :341
+    double gcos2 = 0.5 * fray;                                      // :342
+    double w0 = (tr * rf + tc * wc) / (tg + tr + tc);               // :346
+    double w0nr = (tr * 0.99999 + tc * wc) / (tg + tr + tc);        // :350
+    if (a.test_mode) {                                              // :372-399
+        if (a.test_mode == 1) {          // 'rayleigh'
+            dtau = tr; gcos2 = 0.5; fray = 1.0; fcld = 0.0;
+        } else {                         // constant tau from the cloud opd
+            dtau = tc; gcos2 = 0.0; fray = 0.0; fcld = 1.0;
+        }
+        if (dtau <= 0) dtau = 1e-10;
+        cosb = gc;
+        w0 = (wc <= 0) ? 1e-10 : wc;
+        w0nr = w0;
+    }
+    tau_run += dtau;                                                // numba_cumsum (:353-354)
+    if (a.dtau_og) a.dtau_og[q] = dtau;
+    if (a.tau_og) a.tau_og[qn] = tau_run;
+    if (a.w0_og) a.w0_og[q] = w0;
+    if (a.cosb_og) a.cosb_og[q] = cosb;
+    if (a.ftau_cld) a.ftau_cld[q] = fcld;
+    if (a.ftau_ray) a.ftau_ray[q] = fray;
+    if (a.gcos2) a.gcos2[q] = gcos2;
+    if (a.w0_no_raman) a.w0_no_raman[q] = w0nr;
+    if (a.delta_eddington) {                                        // :401-420
+        const double f = ipow(cosb, a.stream);
+        const double w0d = w0 * (1. - f) / (1.0 - w0 * f);
+        const double cbd = (cosb - f) / (1. - f);
+        const double dtd = dtau * (1. - w0 * f);
+        taud_run += dtd;
+        if (a.f_deltaM) a.f_deltaM[q] = f;
+        if (a.w0) a.w0[q] = w0d;
+        if (a.cosb) a.cosb[q] = cbd;
+        if (a.dtau) a.dtau[q] = dtd;
+        if (a.tau) a.tau[qn] = taud_run;
+    } else {                                                        // :428-431
+        if (a.f_deltaM) a.f_deltaM[q] = 0 * cosb;
+        if (a.w0) a.w0[q] = w0;
+        if (a.cosb) a.cosb[q] = cosb;
+        if (a.dtau) a.dtau[q] = dtau;
+        if (a.tau) a.tau[qn] = tau_run;
+    }
+}
+
 __global__ __launch_bounds__(1024) void k_compute_opacity(const MixArgs a)
 {
     const long col = blockIdx.x * (long)blockDim.x + threadIdx.x;
@@ -157,51 +213,81 @@ __global__ __launch_bounds__(1024) void k_compute_opacity(const MixArgs a)
         const double tg = a.taugas[og], tr = a.tauray[ow];
         const double tc = a.taucld ? a.taucld[oc] : 0.0, wc = a.w0c ? a.w0c[oc] : 0.0, gc = a.g0c ? a.g0c[oc] : 0.0;
         const double rf = a.raman ? a.raman[ow] : a.raman_const;
-        double dtau = tg + tr + tc;                                     // optics.py:329
-        double fcld = (wc * tc) / (wc * tc + tr);                       // :335
-        double cosb = gc;                                               // :338
-        double fray = tr / (tr + wc * tc);                              // :341
-        double gcos2 = 0.5 * fray;                                      // :342
-        double w0 = (tr * rf + tc * wc) / (tg + tr + tc);               // :346
-        double w0nr = (tr * 0.99999 + tc * wc) / (tg + tr + tc);        // :350
-        if (a.test_mode) {                                              // :372-399
-            if (a.test_mode == 1) {          // 'rayleigh'
-                dtau = tr; gcos2 = 0.5; fray = 1.0; fcld = 0.0;
-            } else {                         // constant tau from the cloud opd
-                dtau = tc; gcos2 = 0.0; fray = 0.0; fcld = 1.0;
+        mix_layer(a, o, o + ncol, tg, tr, tc, wc, gc, rf, tau_run, taud_run);
+    }
+}
+
+// Facet mode with the transposition staged through LDS.  The gas / Rayleigh / Raman rows arrive facet-major
+// (nfac, nlayer, nwno) -- what the batched gas launch writes, one coalesced row per (facet, layer) -- and the
+// planes leave with the facet index fastest, (rows, nwno, nfac), what get_reflected_3d reads.  A block owns
+// 1024 consecutive output columns = all facets of 1024/nfac (+ partial) wavelengths; per layer its threads
+// first copy the [facet][wavelength] tile of each input row set into LDS along the rows (16 consecutive
+// wavelengths per 128-byte line at 64 facets), then every thread picks its own (wavelength, facet) element.
+// Reading the rows directly, 8 bytes per lane from 64 different lines, relied on the 16 waves of a block
+// finding each other's lines in L1 and ran at 1.4 TB/s; the loads of layer i+1 are in flight while layer i
+// is mixed.
+constexpr int MIXF_BLOCK = 1024, MIXF_TILE = 2048;
+__global__ __launch_bounds__(MIXF_BLOCK) void k_compute_opacity_facets(const MixArgs a)
+{
+    __shared__ double tile[3][MIXF_TILE];
+    const long nw = a.nwno;
+    const int nfac = a.nfac, n = a.nlayer;
+    const long ncol = nw * nfac;
+    const long c0 = blockIdx.x * (long)MIXF_BLOCK;
+    const long col = c0 + threadIdx.x;
+    const bool active = col < ncol;
+    const long w_first = c0 / nfac;
+    const long c_last = (c0 + MIXF_BLOCK - 1 < ncol) ? c0 + MIXF_BLOCK - 1 : ncol - 1;
+    const int nwl = (int)(c_last / nfac - w_first) + 1;          // wavelengths this block touches
+    const int ldp = nwl | 1;                                       // odd row pitch of the LDS tile
+    const int nel = nfac * nwl;                                    // <= MIXF_TILE (launcher)
+    // staging assignment: element e = (facet e / nwl, wavelength e % nwl), at most two per thread
+    long src[2];
+    int dst[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int e = threadIdx.x + r * MIXF_BLOCK;
+        const int fe = e / nwl, j = e - fe * nwl;
+        src[r] = (e < nel) ? ((long)fe * n) * nw + w_first + j : -1;
+        dst[r] = fe * ldp + j;
+    }
+    const long w = active ? col / nfac : 0;
+    const int my = active ? (int)(col - w * nfac) * ldp + (int)(w - w_first) : 0;
+    const bool has_rf = a.raman != nullptr;
+    double pg[2], pr[2], pf[2];
+    auto fetch = [&](int i) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+            if (src[r] >= 0) {
+                const long o = src[r] + (long)i * nw;
+                pg[r] = a.taugas[o];
+                pr[r] = a.tauray[o];
+                if (has_rf) pf[r] = a.raman[o];
             }
-            if (dtau <= 0) dtau = 1e-10;
-            cosb = gc;
-            w0 = (wc <= 0) ? 1e-10 : wc;
-            w0nr = w0;
-        }
-        tau_run += dtau;                                                // numba_cumsum (:353-354)
-        const long q = o, qn = o + ncol;
-        if (a.dtau_og) a.dtau_og[q] = dtau;
-        if (a.tau_og) a.tau_og[qn] = tau_run;
-        if (a.w0_og) a.w0_og[q] = w0;
-        if (a.cosb_og) a.cosb_og[q] = cosb;
-        if (a.ftau_cld) a.ftau_cld[q] = fcld;
-        if (a.ftau_ray) a.ftau_ray[q] = fray;
-        if (a.gcos2) a.gcos2[q] = gcos2;
-        if (a.w0_no_raman) a.w0_no_raman[q] = w0nr;
-        if (a.delta_eddington) {                                        // :401-420
-            const double f = ipow(cosb, a.stream);
-            const double w0d = w0 * (1. - f) / (1.0 - w0 * f);
-            const double cbd = (cosb - f) / (1. - f);
-            const double dtd = dtau * (1. - w0 * f);
-            taud_run += dtd;
-            if (a.f_deltaM) a.f_deltaM[q] = f;
-            if (a.w0) a.w0[q] = w0d;
-            if (a.cosb) a.cosb[q] = cbd;
-            if (a.dtau) a.dtau[q] = dtd;
-            if (a.tau) a.tau[qn] = taud_run;
-        } else {                                                        // :428-431
-            if (a.f_deltaM) a.f_deltaM[q] = 0 * cosb;
-            if (a.w0) a.w0[q] = w0;
-            if (a.cosb) a.cosb[q] = cosb;
-            if (a.dtau) a.dtau[q] = dtau;
-            if (a.tau) a.tau[qn] = tau_run;
+    };
+    double tau_run = 0.0, taud_run = 0.0;
+    if (active) {
+        if (a.tau_og) a.tau_og[col] = 0.0;
+        if (a.tau) a.tau[col] = 0.0;
+    }
+    fetch(0);
+    for (int i = 0; i < n; ++i) {
+        __syncthreads();                       // the tile of the layer above has been consumed
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+            if (src[r] >= 0) {
+                tile[0][dst[r]] = pg[r];
+                tile[1][dst[r]] = pr[r];
+                if (has_rf) tile[2][dst[r]] = pf[r];
+            }
+        __syncthreads();
+        if (i + 1 < n) fetch(i + 1);
+        if (active) {
+            const long o = (long)i * ncol + col;
+            const double tg = tile[0][my], tr = tile[1][my];
+            const double rf = has_rf ? tile[2][my] : a.raman_const;
+            const double tc = a.taucld ? a.taucld[o] : 0.0, wc = a.w0c ? a.w0c[o] : 0.0, gc = a.g0c ? a.g0c[o] : 0.0;
+            mix_layer(a, o, o + ncol, tg, tr, tc, wc, gc, rf, tau_run, taud_run);
         }
     }
 }
@@ -341,12 +427,17 @@ int picaso_compute_opacity_facets_dev(picaso_ctx *ctx, int nlayer, int nwno, int
     a.dtau = dtau; a.tau = tau; a.w0 = w0; a.cosb = cosb; a.ftau_cld = ftau_cld; a.ftau_ray = ftau_ray;
     a.gcos2 = gcos2; a.dtau_og = dtau_og; a.tau_og = tau_og; a.w0_og = w0_og; a.cosb_og = cosb_og;
     a.w0_no_raman = w0_no_raman; a.f_deltaM = f_deltaM;
-    // 1024-thread blocks = 16 wavelengths x 64 facets: the facet-major gas rows are read 8 bytes per
-    // lane, and the 16 waves of a block consume each 128-byte line they touch
-    const int block = 1024;
+    const int block = MIXF_BLOCK;
     const long ncol = (long)nwno * nfacets;
-    hipLaunchKernelGGL(k_compute_opacity, dim3((unsigned)((ncol + block - 1) / block)), dim3(block), 0,
-                       ctx->stream, a);
+    const dim3 grid((unsigned)((ncol + block - 1) / block));
+    // LDS-staged transposition while a block's [facet][wavelength] tile fits (<= 341 facets); else (and for a
+    // single facet, where there is nothing to transpose) the direct kernel
+    const bool staged = nfacets > 1 && (long)nfacets * ((block / nfacets + 2) | 1) <= MIXF_TILE &&
+                        !getenv("PICASO_AMD_MIX_DIRECT");
+    if (staged)
+        hipLaunchKernelGGL(k_compute_opacity_facets, grid, dim3(block), 0, ctx->stream, a);
+    else
+        hipLaunchKernelGGL(k_compute_opacity, grid, dim3(block), 0, ctx->stream, a);
     PZ_HIP(ctx, hipGetLastError());
     return 0;
 }

@@ -375,7 +375,18 @@ __global__ __launch_bounds__(PZ_REFL_BLOCK, (NA <= 2 ? PZ_REFL_MINWAVES_FEW : PZ
     ReflState<NA, LDS> S;
     S.lds = lds_state + threadIdx.x;
     S.rho = S.pgam = S.pEM = 0.0;
-    double tau_i = p_tau[0];
+    // 3-D entry point: planes that compute_opacity derives exactly from others may be left out (NULL) and
+    // are re-derived here with the same operations instead of being written to and read from HBM --
+    //   tau / tau_og   : running sums of dtau / dtau_og from 0 at the top (optics.py:353-354, 418-420)
+    //   gcos2          : 0.5 ftau_ray (optics.py:342)
+    //   ftau_cld (with cosb, cosb_og, ftau_ray, gcos2): column without cloud: 0, 0, 0, 1, 0.5 (optics.py:335-342
+    //                    with TAUCLD = 0)
+    //   dtau_og / w0_og: no delta-scaling (cosb = 0: f = 0, optics.py:412-420 reduce to x*1): dtau / w0
+    // all wave-uniform (kernel arguments); the 1-D launches always pass every plane
+    const bool derive_tau = IS3D && a.tau == nullptr, derive_tauo = IS3D && a.tau_og == nullptr;
+    const bool derive_g2 = IS3D && a.gcos2 == nullptr, clear = IS3D && a.ftau_cld == nullptr;
+    const bool alias_og = IS3D && a.dtau_og == nullptr;
+    double tau_i = derive_tau ? 0.0 : p_tau[0];
     double tauo_pred = 0.0;          // tau_og[i-1] + dtau_og[i-1] of the layer above
 #pragma unroll
     for (int k = 0; k < NA; ++k) {
@@ -417,8 +428,24 @@ __global__ __launch_bounds__(PZ_REFL_BLOCK, (NA <= 2 ? PZ_REFL_MINWAVES_FEW : PZ
         }
         const long o = (long)i * pitch;
         L.dt = p_dtau[o];
-        L.tau_n = p_tau[o + pitch];
         L.w0 = p_w0[o];
+        if constexpr (IS3D) {                      // only the loads are issued here; derived values in prep
+            if (!derive_tau) L.tau_n = p_tau[o + pitch];
+            if (!clear) {
+                L.g = p_cosb[o];
+                L.fc = p_fc[o];
+                L.fr = p_fr[o];
+                L.cbo = p_cbo[o];
+                if (!derive_g2) L.gcos2 = p_gcos2[o];
+            }
+            if (!alias_og) {
+                L.dto = p_dto[o];
+                L.w0o = p_w0o[o];
+            }
+            if (!derive_tauo) L.tauo = p_tauo[o];
+            return;
+        }
+        L.tau_n = p_tau[o + pitch];
         L.g = p_cosb[o];
         L.gcos2 = p_gcos2[o];
         L.fc = p_fc[o];
@@ -429,6 +456,13 @@ __global__ __launch_bounds__(PZ_REFL_BLOCK, (NA <= 2 ? PZ_REFL_MINWAVES_FEW : PZ
         L.cbo = p_cbo[o];
     };
     auto prep = [&](LayerIn &L) {
+        if constexpr (IS3D) {
+            if (clear) { L.g = 0.0; L.fc = 0.0; L.fr = 1.0; L.gcos2 = 0.5; L.cbo = 0.0; }
+            else if (derive_g2) L.gcos2 = 0.5 * L.fr;
+            if (alias_og) { L.dto = L.dt; L.w0o = L.w0; }
+            if (derive_tau) L.tau_n = tau_i + L.dt;
+            if (derive_tauo) L.tauo = tauo_pred;
+        }
         L.cum_tau = __all(L.tau_n == tau_i + L.dt);
         L.eo_ok = __all(L.tauo == tauo_pred);
         L.same_dt = __all(L.dto == L.dt);

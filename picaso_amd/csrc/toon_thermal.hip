@@ -199,14 +199,16 @@ __global__ __launch_bounds__(256) void k_thermal_toa(const ThermalArgs a)
     double Bn = planck(0);
     const double B_top = Bn;
 
-    double n_dt = p_dtau[0], n_w0 = p_w0[0], n_cb = p_cosb[0];
+    // 3-D entry point: cosb NULL = column without cloud (cosb_og = 0 everywhere, optics.py:338): not read
+    const bool has_g = !IS3D || a.cosb != nullptr;
+    double n_dt = p_dtau[0], n_w0 = p_w0[0], n_cb = has_g ? p_cosb[0] : 0.0;
     for (int i = 0; i < n; ++i) {
         const double dt = n_dt, w0 = n_w0, g = n_cb;
         if (i + 1 < n) {
             const long o = (long)(i + 1) * pitch;
             n_dt = p_dtau[o];
             n_w0 = p_w0[o];
-            n_cb = p_cosb[o];
+            if (has_g) n_cb = p_cosb[o];
         }
         const double B0 = Bn;
         Bn = planck(i + 1);

@@ -413,11 +413,27 @@ def picaso(bundle, opacityclass, dimension="1d", calculation="reflected", full_o
                             "no patchy clouds and no level fluxes")
         prof3 = inp["atmosphere"]["profile_3d"]
         cld3 = inp["clouds"].get("profile_3d")
+        # Only planes that cannot be re-derived exactly inside the solvers are written (each is nfacets x 9 MB
+        # at 12 500 wavelengths x 90 layers): the level optical depths are running sums and gcos2 is
+        # 0.5 ftau_ray, so the reflected kernel takes 8 planes instead of 11; without cloud (and outside the
+        # test modes) cosb = cosb_og = ftau_cld = 0, ftau_ray = 1 and the delta-scaling is the identity, which
+        # leaves dtau and w0 -- and w0_no_raman equals w0 when the Raman factor is the constant 0.99999
+        # (raman='none').  PICASO_AMD_ALL_PLANES=1 writes and reads the full set (A/B, tests).
+        clear3 = cld3 is None and inp["test_mode"] is None and not os.environ.get("PICASO_AMD_ALL_PLANES")
+        lean3 = not os.environ.get("PICASO_AMD_ALL_PLANES")
         want3 = set()
+        th3 = ("dtau_og", "w0_no_raman", "cosb_og")
         if "reflected" in calculation:
-            want3 |= set(resident.REFLECTED_PLANES)
+            if clear3:
+                want3 |= {"dtau", "w0"}
+            elif lean3:
+                want3 |= set(resident.REFLECTED_PLANES) - {"tau", "tau_og", "gcos2"}
+            else:
+                want3 |= set(resident.REFLECTED_PLANES)
         if "thermal" in calculation:
-            want3 |= {"dtau_og", "w0_no_raman", "cosb_og"}
+            if clear3:
+                th3 = ("dtau", "w0" if (common["raman"] == 2 and "reflected" in calculation) else "w0_no_raman", None)
+            want3 |= {k for k in th3 if k is not None}
         co3 = dict(stream=common["stream"], delta_eddington=common["delta_eddington"], test_mode=inp["test_mode"],
                    raman=common["raman"], clouds_3d=cld3, exclude_mol=inp["atmosphere"]["exclude_mol"], want=want3)
         if os.environ.get("PICASO_AMD_FACET_LOOP"):           # A/B: one ATMSETUP + one gas launch per facet
@@ -567,8 +583,8 @@ def picaso(bundle, opacityclass, dimension="1d", calculation="reflected", full_o
             flux = DeviceArray((ng, nt, nwno), tctx)
             disk = DeviceArray((nwno,), tctx)
             if dimension == "3d":                                 # justdoit.py:502-514
-                resident.thermal_3d(ctx, nlevel, d_wno, nwno, ng, nt, tlev3, planes3d["dtau_og"],
-                                    planes3d["w0_no_raman"], planes3d["cosb_og"], plev3, ubar1, rs,
+                resident.thermal_3d(ctx, nlevel, d_wno, nwno, ng, nt, tlev3, planes3d[th3[0]],
+                                    planes3d[th3[1]], planes3d[th3[2]] if th3[2] else None, plev3, ubar1, rs,
                                     atm.hard_surface, flux, gweight, tweight, disk)
             elif is_sh:                                           # justdoit.py:364-370
                 _thermal_sh(ctx, nlevel, d_wno, nwno, ng, nt, atm.level["temperature"], planes,

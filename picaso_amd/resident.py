@@ -209,12 +209,13 @@ def reflected_3d(ctx, nlevel, nwno, numg, numt, planes, surf_reflect, ubar0, uba
                  single_phase, multi_phase, frac_a, frac_b, frac_c, constant_back, constant_forward,
                  xint_at_top, gweight=None, tweight=None, albedo=None):
     """``get_reflected_3d`` on resident ``(nlayer|nlevel, nwno, numg, numt)`` planes (+ optional fused
-    ``compress_disco``)."""
+    ``compress_disco``).  Planes missing from ``planes`` are passed as NULL: the kernel re-derives them
+    (picaso_hip.h: tau / tau_og / gcos2; no-cloud constants; no delta-scaling)."""
     u0, u1 = f64(ubar0, (numg, numt)), f64(ubar1, (numg, numt))
     gw = f64(gweight) if gweight is not None else None
     tw = f64(tweight) if tweight is not None else None
     check(load().picaso_get_reflected_3d_dev(
-        ctx, _ci(nlevel), _ci(nwno), _ci(numg), _ci(numt), *[_addr(planes[k]) for k in REFLECTED_PLANES],
+        ctx, _ci(nlevel), _ci(nwno), _ci(numg), _ci(numt), *[_addr(planes.get(k)) for k in REFLECTED_PLANES],
         _addr(surf_reflect), ptr(u0), ptr(u1), _cd(cos_theta), _addr(F0PI), _ci(single_phase),
         _ci(multi_phase), _cd(frac_a), _cd(frac_b), _cd(frac_c), _cd(constant_back),
         _cd(constant_forward), _addr(xint_at_top), ptr(gw) if gw is not None else None,

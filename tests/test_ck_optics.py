@@ -323,6 +323,49 @@ def test_gpu_3d_batched_facets_equal_per_facet_loop(og, raman, radius, monkeypat
     assert np.array_equal(a["full_output"]["thermal_3d"], b["full_output"]["thermal_3d"])
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("cloudy,raman,delta", [(False, "none", True), (False, "oklopcic", True), (True, "none", True),
+                                                (True, "oklopcic", False), (False, "none", False)])
+def test_gpu_3d_planes_rederived_in_the_solvers_bit_identical(og, cloudy, raman, delta, monkeypatch):
+    """The 3-D path does not write the planes the solvers can re-derive exactly (level optical depths, gcos2;
+    without cloud also cosb, ftau_cld, ftau_ray, the *_og twins and -- raman='none' -- w0_no_raman): the
+    spectra are bit-identical to those from the full set of 13 planes (PICASO_AMD_ALL_PLANES=1)."""
+    from picaso_amd import justdoit as jdi
+    ng, nt = 3, 2
+    opa = jdi.opannection(DB, query_method="linear")
+    if raman == "oklopcic":
+        gold = np.load(os.path.join(GOLDEN, "optics.npz"))
+        opa.raman_stellar_shifts = gold["in/raman_shifts"]
+        opa.raman_db = {"c": gold["in/raman_c"], "ji": gold["in/raman_ji"], "deltanu": gold["in/raman_deltanu"]}
+    pert = 1.0 + 0.1 * np.cos(np.arange(ng * nt).reshape(ng, nt))
+
+    def run(calc):
+        case = jdi.inputs()
+        case.phase_angle(np.pi / 3, num_gangle=ng, num_tangle=nt)
+        case.gravity(gravity=float(og["in/gravity"]))
+        prof = {"pressure": og["in/plevel_bar"], "temperature": og["in/tlevel"][:, None, None] * pert[None]}
+        for k in ("H2", "He", "H2O", "CH4"):
+            prof[k] = og["in/mix/" + k]
+        case.atmosphere_3d(prof)
+        if cloudy:
+            cld = {k: np.repeat(og["in/cld_" + k][:, :, None, None], ng, 2).repeat(nt, 3) for k in ("opd", "w0", "g0")}
+            cld["opd"] = cld["opd"] * pert[None, None]
+            case.clouds_3d(cld)
+        case.approx(raman=raman, delta_eddington=delta)
+        case.surface_reflect(0.15)
+        return case.spectrum(opa, calculation=calc, dimension="3d", full_output=True)
+    for calc in ("reflected+thermal", "thermal", "reflected"):
+        monkeypatch.delenv("PICASO_AMD_ALL_PLANES", raising=False)
+        a = run(calc)
+        monkeypatch.setenv("PICASO_AMD_ALL_PLANES", "1")
+        b = run(calc)
+        for k, k3 in (("albedo", "albedo_3d"), ("thermal", "thermal_3d")):
+            if k in a:
+                assert np.all(np.isfinite(a[k])) and np.any(a[k] > 0)
+                assert np.array_equal(a[k], b[k]), (calc, k)
+                assert np.array_equal(a["full_output"][k3], b["full_output"][k3]), (calc, k3)
+
+
 # ---- on-the-fly gas mixing through the class (reference optics.py:1164-1278) ----------------------
 def _fly_atm(og):
     import types

@@ -41,6 +41,17 @@ c3.phase_angle(np.pi / 3, num_gangle=ng, num_tangle=nt)
 c3.gravity(gravity=2500.0)
 c3.atmosphere_3d(prof3)
 c3.approx(raman="none")
+if os.environ.get("PROFILE_3D"):      # PROFILE_3D=1: cProfile + wall time of the batched call alone (for rocprofv3 too)
+    import cProfile, pstats
+    for _ in range(30):
+        c3.spectrum(opa, calculation="reflected+thermal", dimension="3d")
+    pr = cProfile.Profile()
+    pr.enable()
+    for _ in range(20):
+        c3.spectrum(opa, calculation="reflected+thermal", dimension="3d")
+    pr.disable()
+    pstats.Stats(pr).sort_stats("cumulative").print_stats(45)
+    sys.exit(0)
 out = {}
 for tag, env in (("batched", None), ("per_facet_loop", "1")):
     if env:
