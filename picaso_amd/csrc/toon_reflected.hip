@@ -326,8 +326,12 @@ __device__ __forceinline__ double disk_finish(double c1, double acc, double F, d
     return c1 * acc / F * (cos_theta + 1.0);
 }
 
-template <int NA, bool IS3D, bool ZP, bool FAST = false>
-__global__ __launch_bounds__(PZ_REFL_BLOCK, (NA <= 2 ? PZ_REFL_MINWAVES_FEW : PZ_REFL_MINWAVES)) void k_reflected_toa(const ReflectedArgs a)
+// BIG: one wave per SIMD (grids of up to 1 024 column-waves, five angles): the whole 512-entry register file
+// belongs to the wave, so the sweep state stays in registers instead of LDS -- 50 000 columns 0.1365 ms against
+// 0.1636 (tools/experiments/big_sweep.sh), same bits.  Of no use to the 1e5-column launch: its 1 563 waves need
+// two per SIMD.
+template <int NA, bool IS3D, bool ZP, bool FAST = false, bool BIG = false>
+__global__ __launch_bounds__(PZ_REFL_BLOCK, (BIG ? 1 : NA <= 2 ? PZ_REFL_MINWAVES_FEW : PZ_REFL_MINWAVES)) void k_reflected_toa(const ReflectedArgs a)
 {
 #pragma clang fp contract(off)      // operations as written, see reflected_layer
     const long col = blockIdx.x * (long)blockDim.x + threadIdx.x;
@@ -370,7 +374,7 @@ __global__ __launch_bounds__(PZ_REFL_BLOCK, (NA <= 2 ? PZ_REFL_MINWAVES_FEW : PZ
                  *p_fr = a.ftau_ray + col, *p_dto = a.dtau_og + col, *p_tauo = a.tau_og + col,
                  *p_w0o = a.w0_og + col, *p_cbo = a.cosb_og + col;
 
-    constexpr bool LDS = (NA >= 4) && !IS3D;
+    constexpr bool LDS = (NA >= 4) && !IS3D && !BIG;
     __shared__ double lds_state[LDS ? (PZ_REFL_NLDS > 0 ? PZ_REFL_NLDS : 1) * NA * PZ_REFL_BLOCK : 1];
     ReflState<NA, LDS> S;
     S.lds = lds_state + threadIdx.x;
@@ -567,7 +571,12 @@ static int launch1d(picaso_ctx *ctx, const ReflectedArgs &a_in)
     const dim3 grid((unsigned)((a.ncol + block - 1) / block), (unsigned)(a.ny > 1 ? a.ny : 1));
     bool zp = true;
     for (int k = 0; k < a.na * (int)grid.y; ++k) zp = zp && (a.ang[k].u0 == a.ang[k].u1);
-    if (zp && fast_options(a))
+    bool big = false;
+    if constexpr (NA == 5) big = a.ny <= 1 && (a.ncol + 63) / 64 <= 1024 && getenv("PICASO_AMD_REFL_NO_BIG") == nullptr;
+    if (zp && fast_options(a) && big) {
+        if constexpr (NA == 5)
+            hipLaunchKernelGGL((k_reflected_toa<NA, false, true, true, true>), grid, dim3(block), 0, ctx->stream, a);
+    } else if (zp && fast_options(a))
         hipLaunchKernelGGL((k_reflected_toa<NA, false, true, true>), grid, dim3(block), 0, ctx->stream, a);
     else if (zp)
         hipLaunchKernelGGL((k_reflected_toa<NA, false, true>), grid, dim3(block), 0, ctx->stream, a);

@@ -98,6 +98,13 @@ def test_angle_grouping_does_not_change_a_bit(ng, nwno, monkeypatch):
         resident.reflected_1d(ctx, 41, nwno, ng, 1, d, d["surf_reflect"], u0, u1, 1.0, d["F0PI"], 3, 0,
                               *TTHG, x, gweight=gw, tweight=tw, albedo=alb)
         res[group] = (x.to_host(), alb.to_host())
+    # the fused launch with its state in LDS (what grids of more than 1 024 column-waves run) instead of registers
+    monkeypatch.setenv("PICASO_AMD_ANGLE_GROUP", "0")
+    monkeypatch.setenv("PICASO_AMD_REFL_NO_BIG", "1")
+    x, alb = DeviceArray.zeros((ng, 1, nwno), ctx), DeviceArray.zeros((nwno,), ctx)
+    resident.reflected_1d(ctx, 41, nwno, ng, 1, d, d["surf_reflect"], u0, u1, 1.0, d["F0PI"], 3, 0,
+                          *TTHG, x, gweight=gw, tweight=tw, albedo=alb)
+    res["lds"] = (x.to_host(), alb.to_host())
     assert np.all(res["0"][0] > 0) and np.all(res["0"][1] > 0)
     for group, (x, alb) in res.items():
         assert np.array_equal(x, res["0"][0]) and np.array_equal(alb, res["0"][1]), group
