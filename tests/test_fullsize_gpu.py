@@ -74,8 +74,10 @@ def test_eight_shards_as_on_an_8_gpu_node(full):
     assert np.array_equal(np.concatenate([p[1] for p in parts]), full["alb"])
 
 
-@pytest.mark.parametrize("ng,nwno", [(5, 25000), (5, 12500), (6, 9000), (7, 4000)])
-def test_angle_grouping_does_not_change_a_bit(ng, nwno, monkeypatch):
+@pytest.mark.parametrize("ng,nwno,phase,sp,tc", [(5, 25000, 0.0, 3, 0), (5, 12500, 0.0, 3, 0), (6, 9000, 0.0, 3, 0),
+                                                 (7, 4000, 0.0, 3, 0), (5, 6000, 0.7, 3, 0), (5, 6000, 0.0, 1, 1),
+                                                 (6, 3000, 1.1, 2, 0)])
+def test_angle_grouping_does_not_change_a_bit(ng, nwno, phase, sp, tc, monkeypatch):
     """Mid-size grids run groups of 1, 2 or 3 angles per wave (api.hip:reflected_angle_group; the last group
     padded): intensities and albedo are bit-identical to the all-fused launch, whatever the grouping."""
     from picaso_amd import _lib, disco, resident
@@ -86,7 +88,7 @@ def test_angle_grouping_does_not_change_a_bit(ng, nwno, monkeypatch):
     sc["F0PI"] = np.linspace(0.5, 2.0, nwno)
     sc["surf_reflect"] = np.full(nwno, 0.2)
     g, gw, t, tw = disco.get_angles_1d(ng)
-    u0, u1, _, _, _ = disco.compute_disco(ng, 1, g, t, 0.0)
+    u0, u1, cos_theta, _, _ = disco.compute_disco(ng, 1, g, t, phase)       # phase > 0: ubar0 != ubar1, generic kernel
     d = resident.upload_scene(sc, resident.REFLECTED_PLANES + ("F0PI", "surf_reflect"), ctx=ctx)
     res = {}
     for group in ("0", "1", "2", "3", "4", None):
@@ -95,15 +97,15 @@ def test_angle_grouping_does_not_change_a_bit(ng, nwno, monkeypatch):
         else:
             monkeypatch.setenv("PICASO_AMD_ANGLE_GROUP", group)
         x, alb = DeviceArray.zeros((ng, 1, nwno), ctx), DeviceArray.zeros((nwno,), ctx)
-        resident.reflected_1d(ctx, 41, nwno, ng, 1, d, d["surf_reflect"], u0, u1, 1.0, d["F0PI"], 3, 0,
-                              *TTHG, x, gweight=gw, tweight=tw, albedo=alb)
+        resident.reflected_1d(ctx, 41, nwno, ng, 1, d, d["surf_reflect"], u0, u1, cos_theta, d["F0PI"], sp, 0,
+                              *TTHG, x, toon_coefficients=tc, gweight=gw, tweight=tw, albedo=alb)
         res[group] = (x.to_host(), alb.to_host())
     # the fused launch with its state in LDS (what grids of more than 1 024 column-waves run) instead of registers
     monkeypatch.setenv("PICASO_AMD_ANGLE_GROUP", "0")
     monkeypatch.setenv("PICASO_AMD_REFL_NO_BIG", "1")
     x, alb = DeviceArray.zeros((ng, 1, nwno), ctx), DeviceArray.zeros((nwno,), ctx)
-    resident.reflected_1d(ctx, 41, nwno, ng, 1, d, d["surf_reflect"], u0, u1, 1.0, d["F0PI"], 3, 0,
-                          *TTHG, x, gweight=gw, tweight=tw, albedo=alb)
+    resident.reflected_1d(ctx, 41, nwno, ng, 1, d, d["surf_reflect"], u0, u1, cos_theta, d["F0PI"], sp, 0,
+                          *TTHG, x, toon_coefficients=tc, gweight=gw, tweight=tw, albedo=alb)
     res["lds"] = (x.to_host(), alb.to_host())
     assert np.all(res["0"][0] > 0) and np.all(res["0"][1] > 0)
     for group, (x, alb) in res.items():
