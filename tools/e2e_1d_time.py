@@ -1,0 +1,53 @@
+#!/usr/bin/env python
+"""End-to-end time of the cloud-free 1-D spectrum(reflected+thermal) at 1e5 wavelengths x 90 layers (resident
+synthetic opacity tables) -- run on the GPU box.  PROFILE_1D=1: many calls and nothing else (for rocprofv3
+--kernel-trace --stats) plus a cProfile of the host side."""
+import json, os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from picaso_amd import _lib
+from picaso_amd import justdoit as jdi
+from picaso_amd import optics as px
+
+nwno, nlevel = int(os.environ.get("NWNO", "100000")), 91
+ctx = _lib.context(0)
+wno = np.linspace(2000.0, 33333.0, nwno)
+temps, press = [100.0, 300.0, 700.0, 1500.0, 3000.0], [1e-6, 1e-4, 1e-2, 1e-1, 1.0, 10.0, 100.0, 500.0]
+pt = [(i + 1, p, t) for i, (t, p) in enumerate((t, p) for t in temps for p in press)]
+mols = ["H2O", "CH4", "CO", "NH3", "H2"]
+molecular = {m: {i: 10.0 ** (-24.0 + 2.0 * np.sin(wno / 2500.0 + k) + 0.4 * np.log10(p) + 0.8 * np.log10(t / 300.0))
+                 for (i, p, t) in pt} for k, m in enumerate(mols)}
+cia_t = [75.0, 200.0, 500.0, 1000.0, 2000.0, 4000.0]
+continuum = {pr: {t: 10.0 ** (-7.0 + np.cos(wno / 4000.0 + k) + 0.3 * np.log10(t / 300.0)) for t in cia_t}
+             for k, pr in enumerate(("H2H2", "H2He"))}
+ray = {m: 1e-27 * (wno / 1e4) ** 4 for m in ("H2", "He")}
+opa = px.RetrieveOpacities(wno, pt, molecular, continuum, cia_t, rayleigh_opa=ray, query_method="linear", ctx=ctx)
+plev = np.logspace(-6, 2, nlevel)
+prof = {"pressure": plev, "temperature": 150.0 + 1200.0 * ((np.log10(plev) + 6) / 8) ** 2, "H2": np.full(nlevel, 0.84),
+        "He": np.full(nlevel, 0.155), "H2O": np.full(nlevel, 1e-3), "CH4": np.full(nlevel, 5e-4),
+        "CO": np.full(nlevel, 1e-4), "NH3": np.full(nlevel, 1e-5)}
+case = jdi.inputs()
+case.phase_angle(0)
+case.gravity(gravity=2500.0)
+case.atmosphere(df=prof)
+case.approx(raman="none")
+calc = os.environ.get("CALC", "reflected+thermal")
+for _ in range(30):
+    r = case.spectrum(opa, calculation=calc)
+if os.environ.get("PROFILE_1D"):
+    import cProfile, pstats
+    pr = cProfile.Profile()
+    pr.enable()
+    for _ in range(50):
+        case.spectrum(opa, calculation=calc)
+    pr.disable()
+    pstats.Stats(pr).sort_stats("cumulative").print_stats(35)
+    sys.exit(0)
+ts = []
+for _ in range(20):
+    t0 = time.perf_counter()
+    r = case.spectrum(opa, calculation=calc)
+    ts.append(time.perf_counter() - t0)
+print(json.dumps({"spectrum_1d_%d_%s_ms" % (nwno, calc): round(1e3 * min(ts), 3), "median_ms": round(1e3 * float(np.median(ts)), 3),
+                  "albedo_sum": float(np.sum(r.get("albedo", 0.0)))}))
