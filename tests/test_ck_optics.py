@@ -356,8 +356,10 @@ def test_gpu_3d_planes_rederived_in_the_solvers_bit_identical(og, cloudy, raman,
         return case.spectrum(opa, calculation=calc, dimension="3d", full_output=True)
     for calc in ("reflected+thermal", "thermal", "reflected"):
         monkeypatch.delenv("PICASO_AMD_ALL_PLANES", raising=False)
+        monkeypatch.delenv("PICASO_AMD_MIX_DIRECT", raising=False)
         a = run(calc)
         monkeypatch.setenv("PICASO_AMD_ALL_PLANES", "1")
+        monkeypatch.setenv("PICASO_AMD_MIX_DIRECT", "1")      # and the mixing kernel without the LDS-staged transposition
         b = run(calc)
         for k, k3 in (("albedo", "albedo_3d"), ("thermal", "thermal_3d")):
             if k in a:
