@@ -104,8 +104,8 @@ static bool spread_angles(long ncol, int nang, long limit = 1280L * 64)
 // (steady clocks, 90 layers, disk sum included): 1 angle 0.049 ms, 2: 0.068, 3: 0.097, 5: 0.160 -- and with
 // two waves per SIMD 2 angles take 0.137, 3: 0.155, 5: 0.235.  So mid-size grids run groups of g angles as
 // separate waves (grid.y) and the cheapest shape that still fits is taken; measured with 5 angles
-// (tools/experiments/angle_group_sweep.sh): 10 000 columns g=1 0.050 ms (fused 0.158), 12 500 g=2 0.069
-// (g=1 0.071: 980 waves no longer place one per SIMD), 20 000 g=2 0.074, 25 000 g=3 0.098 (g=1 0.141),
+// (tools/experiments/angle_group_sweep.sh): 10 000 columns g=1 0.050 ms (fused 0.158), 12 500 g=1 0.050 (0.071
+// before the group launches went out in XCD-aware order, see k_reflected_toa), 20 000 g=2 0.070, 25 000 g=3 0.098 (g=1 0.141),
 // 32 768 g=3 0.099, 40 000 g=2 0.141 (fused 0.160), 50 000 g=3 0.163 = fused, 60 000 fused 0.162 (g=3 0.186);
 // since then the fused launch of up to 1 024 column-waves keeps its state in registers (one wave per SIMD owns
 // the register file): 40 000 0.136, 50 000 0.137, 65 536 0.148.
@@ -120,7 +120,7 @@ static int reflected_angle_group(long ncol, int nang)
     // (five angles alone: the all-register variant of the kernel, 0.136; with the state in LDS 0.160)
     static const double alone[MAX_ANGLES + 1] = {0, 0.049, 0.068, 0.097, 0.128, 0.136, 0.192, 0.224, 0.256};
     static const double paired[4] = {0, 0, 0.137, 0.155};
-    static const long fits_alone[4] = {0, 820, 1024, 1024}, fits_paired[4] = {0, 0, 1900, 1600};
+    static const long fits_alone[4] = {0, 1024, 1024, 1024}, fits_paired[4] = {0, 0, 1900, 1600};
     double best = alone[nang];
     int group = 0;
     for (int g = 1; g <= 3 && g < nang; ++g) {

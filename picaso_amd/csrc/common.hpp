@@ -112,6 +112,7 @@ struct ReflectedArgs {
     int na;            // angles carried per lane (template NA of the launch)
     int ny;            // grid.y: angle groups of `na` running as separate waves (small problems)
     int nvalid;        // ny > 1: angles [0, nvalid) of the ny*na slots are real, the rest pad the last group
+    int ncg;           // ny > 1: column groups (workgroups along the wavelength axis); set by the launcher
     struct Angle {
         double u1, iu0, iu0sq, nl1, q2;     // used by the symmetric-geometry (ubar0 == ubar1) kernel
         double u0, nl0, nlm, wq2, wgt, wgt2;

@@ -334,7 +334,30 @@ template <int NA, bool IS3D, bool ZP, bool FAST = false, bool BIG = false>
 __global__ __launch_bounds__(PZ_REFL_BLOCK, (BIG ? 1 : NA <= 2 ? PZ_REFL_MINWAVES_FEW : PZ_REFL_MINWAVES)) void k_reflected_toa(const ReflectedArgs a)
 {
 #pragma clang fp contract(off)      // operations as written, see reflected_layer
-    const long col = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    // Angle groups as separate workgroups (ny > 1): every group re-reads the eleven planes of its columns.
+    // Consecutive workgroups go to consecutive XCDs (8, each with its own L2), so the launch is 1-D and, for
+    // the column groups that fill whole chunks of 8, block b = (chunk, angle group, column group within the
+    // chunk): the ny workgroups of one column group are dispatched 8 apart, all to XCD (column group % 8),
+    // and all but the first find the planes in that L2.  The last ncg % 8 column groups go out in plain
+    // (angle group, column group) order, which spreads their workgroups over the XCDs -- sending them after
+    // their chunk would put up to 8 x ny more workgroups on the first XCDs than on the others (12 500
+    // columns, one angle per wave: 35 on XCD 0 of 32 CUs, 0.078 ms instead of 0.050).  A 2-D (x, y) grid
+    // shares L2 only when the column-group count happens to be a multiple of 8 (12 250 columns 0.050 ms,
+    // 12 000 0.069, 12 500 0.072: tools/experiments/knee.sh).
+    unsigned bx = blockIdx.x, by = 0;
+    if (!IS3D && a.ny > 1) {
+        const unsigned ny = (unsigned)a.ny, ncg = (unsigned)a.ncg, nfull = ncg & ~7u;
+        if (bx < nfull * ny) {
+            const unsigned per = 8u * ny, chunk = bx / per, rem = bx - chunk * per;
+            by = rem >> 3;
+            bx = chunk * 8u + (rem & 7u);
+        } else {
+            const unsigned idx = bx - nfull * ny, left = ncg - nfull;
+            by = idx / left;
+            bx = nfull + (idx - by * left);
+        }
+    }
+    const long col = bx * (long)blockDim.x + threadIdx.x;
     if (col >= a.ncol) return;
     const int nfac = IS3D ? a.nfac : 1;
     const long w = IS3D ? col / nfac : (a.ncolper > 1 ? col / a.ncolper : col);
@@ -364,7 +387,7 @@ __global__ __launch_bounds__(PZ_REFL_BLOCK, (BIG ? 1 : NA <= 2 ? PZ_REFL_MINWAVE
             g[k].q2 = (3.0 * ubar2 * ubar2 * v1 * v1 - 1.0) / 2.0;
             g[k].wgt = g[k].wgt2 = 0.0;
         } else {                                        // host-precomputed, wave-uniform
-            g[k] = a.ang[blockIdx.y * NA + k];          // blockIdx.y: angle group (0 unless ny > 1)
+            g[k] = a.ang[by * NA + k];                  // by: angle group (0 unless ny > 1)
         }
     }
     const double F = a.F0PI[w], rs = a.surf_reflect[w];
@@ -543,7 +566,7 @@ __global__ __launch_bounds__(PZ_REFL_BLOCK, (BIG ? 1 : NA <= 2 ? PZ_REFL_MINWAVE
     for (int k = 0; k < NA; ++k) {
         const double x = xout[k];
         if (IS3D) a.xint[(long)fac * a.nwno + w] = x;
-        else if (NA == 1 || (int)blockIdx.y * NA + k < a.nvalid) a.xint[(long)(blockIdx.y * NA + k) * a.ncol + col] = x;
+        else if (NA == 1 || (int)by * NA + k < a.nvalid) a.xint[(long)(by * NA + k) * a.ncol + col] = x;
         alb = disk_accumulate(alb, x, g[k].wgt, g[k].wgt2);
     }
     if (!IS3D && a.albedo) {                              // fused disco.compress_disco (disco.py:145-148)
@@ -568,9 +591,11 @@ static int launch1d(picaso_ctx *ctx, const ReflectedArgs &a_in)
     ReflectedArgs a = a_in;
     if (a.nvalid <= 0) a.nvalid = NA * (a.ny > 1 ? a.ny : 1);     // no padded angle slots
     const int block = PZ_REFL_BLOCK;
-    const dim3 grid((unsigned)((a.ncol + block - 1) / block), (unsigned)(a.ny > 1 ? a.ny : 1));
+    const unsigned ncg = (unsigned)((a.ncol + block - 1) / block), ny = (unsigned)(a.ny > 1 ? a.ny : 1);
+    a.ncg = (int)ncg;
+    const dim3 grid(ncg * ny);                      // ny > 1: 1-D, in the XCD-aware order of the kernel
     bool zp = true;
-    for (int k = 0; k < a.na * (int)grid.y; ++k) zp = zp && (a.ang[k].u0 == a.ang[k].u1);
+    for (int k = 0; k < a.na * (int)ny; ++k) zp = zp && (a.ang[k].u0 == a.ang[k].u1);
     bool big = false;
     if constexpr (NA == 5) big = a.ny <= 1 && (a.ncol + 63) / 64 <= 1024 && getenv("PICASO_AMD_REFL_NO_BIG") == nullptr;
     if (zp && fast_options(a) && big) {
