@@ -100,34 +100,33 @@ static bool spread_angles(long ncol, int nang, long limit = 1280L * 64)
 
 // Reflected kernel: how many angles a wave carries (0 = all of them fused in one lane, the launch of the
 // large grids).  A sweep is one long dependent chain, so below ~1 wave per SIMD (1024 SIMDs) the time of a
-// launch is the time of ONE wave, which grows with the angles it carries -- measured alone on a SIMD
-// (steady clocks, 90 layers, disk sum included): 1 angle 0.049 ms, 2: 0.068, 3: 0.097, 5: 0.160 -- and with
-// two waves per SIMD 2 angles take 0.137, 3: 0.155, 5: 0.235.  So mid-size grids run groups of g angles as
-// separate waves (grid.y) and the cheapest shape that still fits is taken; measured with 5 angles
-// (tools/experiments/angle_group_sweep.sh): 10 000 columns g=1 0.050 ms (fused 0.158), 12 500 g=1 0.050 (0.071
-// before the group launches went out in XCD-aware order, see k_reflected_toa), 20 000 g=2 0.070, 25 000 g=3 0.098 (g=1 0.141),
-// 32 768 g=3 0.099, 40 000 g=2 0.141 (fused 0.160), 50 000 g=3 0.163 = fused, 60 000 fused 0.162 (g=3 0.186);
-// since then the fused launch of up to 1 024 column-waves keeps its state in registers (one wave per SIMD owns
-// the register file): 40 000 0.136, 50 000 0.137, 65 536 0.148.
-// The result does not depend on the shape (explicit-fma arithmetic, disk sum in the reference's order).
-static int reflected_angle_group(long ncol, int nang)
+// launch is the time of ONE wave, which grows with the angles it carries.  Mid-size grids therefore run groups
+// of g angles as separate workgroups (XCD-aware order, see k_reflected_toa) and the disk sum as a separate pass;
+// measured per shape (steady clocks, 90 layers, 5 angles, disk sum included; tools/experiments/
+// angle_group_sweep.sh, knee.sh) -- while the launch has at most one 256-thread workgroup per CU (one wave per
+// SIMD): g=1 0.050 ms, g=2 0.070, g=3 0.098; at most two per CU: g=1 0.084-0.086, g=2 0.111-0.130, g=3 0.153;
+// all five fused with the state in registers (one wave per SIMD, up to 65 536 columns) 0.136, with two waves
+// per SIMD 0.235.  One workgroup more than that and the time jumps (26 200 columns g=1: 0.119).  The cheapest
+// shape that fits is taken: up to 13 056 columns g=1, to 21 760 g=2, to 25 600 g=1 (two per CU), to 32 768 g=3,
+// to 42 000 g=2 (two per CU), then fused.  The result does not depend on the shape (explicit-fma arithmetic,
+// disk sum in the reference's order).
+static int reflected_angle_group(picaso_ctx *ctx, long ncol, int nang)
 {
     if (const char *e = getenv("PICASO_AMD_ANGLE_GROUP")) return atoi(e);
     if (nang <= 1) return 0;
     if (nang > MAX_ANGLES) return spread_angles(ncol, nang, 2560L * 64) ? 1 : 0;
-    const long colwaves = (ncol + 63) / 64;
-    if (colwaves > 1024) return 0;
+    const long colwaves = (ncol + 63) / 64, ncg = (ncol + 255) / 256, ncu = ctx->ncu;
+    if (colwaves > 4L * ncu) return 0;
     // (five angles alone: the all-register variant of the kernel, 0.136; with the state in LDS 0.160)
-    static const double alone[MAX_ANGLES + 1] = {0, 0.049, 0.068, 0.097, 0.128, 0.136, 0.192, 0.224, 0.256};
-    static const double paired[4] = {0, 0, 0.137, 0.155};
-    static const long fits_alone[4] = {0, 1024, 1024, 1024}, fits_paired[4] = {0, 0, 1900, 1600};
+    static const double alone[MAX_ANGLES + 1] = {0, 0.050, 0.070, 0.098, 0.128, 0.136, 0.192, 0.224, 0.256};
+    static const double paired[4] = {0, 0.086, 0.126, 0.153};
     double best = alone[nang];
     int group = 0;
     for (int g = 1; g <= 3 && g < nang; ++g) {
         const int ngroups = (nang + g - 1) / g;
         if (ngroups * g > MAX_ANGLES) continue;
-        const long waves = colwaves * ngroups;
-        const double t = waves <= fits_alone[g] ? alone[g] : waves <= fits_paired[g] ? paired[g] : 1e9;
+        const long blocks = ncg * ngroups;
+        const double t = blocks <= ncu ? alone[g] : blocks <= 2 * ncu ? paired[g] : 1e9;
         if (t < best) { best = t; group = g; }
     }
     return group;
@@ -480,7 +479,7 @@ static int reflected_1d_core(picaso_ctx *ctx, int nlevel, int nwno, int ncolper,
         if (!get_toa_intensity) return 0;
     }
     int done = 0;
-    const int group = reflected_angle_group(ncol, nang);
+    const int group = reflected_angle_group(ctx, ncol, nang);
     if (group > 1 && group < nang && ((nang + group - 1) / group) * group <= MAX_ANGLES) {
         // Mid-size grids: groups of `group` angles per wave (grid.y), the last group padded with a copy of
         // the last angle (its extra results are not stored); disk sum as a separate pass, like below.
