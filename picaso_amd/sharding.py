@@ -74,52 +74,88 @@ def _recv_msg(sock):
     return _recv_exact(sock, n)
 
 
+_HELLO, _ACK = b"PZRV", b"PZOK"
+PORT_STEPS = (0, 1000, 2000)          # fall-back ports (offsets) when the first one is taken by someone else
+
+
 class HostGroup:
-    """Rank 0 listens on (addr, port); ranks 1..world-1 connect and identify themselves.  Small
-    host-side collectives only: the spectra themselves never travel through here on a GPU run."""
+    """Rank 0 listens on ``port`` (all interfaces); ranks 1..world-1 connect to ``addr`` and identify
+    themselves.  Small host-side collectives only: the spectra themselves never travel through here on a GPU
+    run.  If the port is in use by something else, rank 0 moves on to ``port + 1000`` and ``port + 2000``;
+    the other ranks try the candidates in turn until one answers with the rendezvous handshake.  Connections
+    that do not start with the handshake are dropped."""
 
     def __init__(self, rank, world, addr="127.0.0.1", port=29537, timeout=120.0):
         self.rank, self.world = int(rank), int(world)
         self.peers = {}          # rank 0: rank -> socket
         self.sock = None         # other ranks: socket to rank 0
+        self.port = None
         if self.world == 1:
             return
+        ports = [port + d for d in PORT_STEPS if port + d < 65536]
         if self.rank == 0:
             srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
             srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
             t0 = time.time()
-            while True:                      # a previous run's listener may still be closing
-                try:
-                    srv.bind((addr, port))
-                    break
-                except OSError:
+            while self.port is None:         # a previous run's listener may still be closing
+                for p in ports:
+                    try:
+                        srv.bind(("", p))
+                        self.port = p
+                        break
+                    except OSError:
+                        continue
+                if self.port is None:
                     if time.time() - t0 > 30.0:
-                        raise
+                        raise OSError("picaso_amd.sharding: none of the rendezvous ports %s can be bound" % ports)
                     time.sleep(0.2)
-            srv.listen(self.world)
+            srv.listen(self.world + 8)
             srv.settimeout(timeout)
             while len(self.peers) < self.world - 1:
                 conn, _ = srv.accept()
+                try:
+                    conn.settimeout(5.0)
+                    hello = _recv_exact(conn, 8)
+                    (r,) = struct.unpack("<i", hello[4:])
+                    if hello[:4] != _HELLO or r <= 0 or r >= self.world or r in self.peers:
+                        raise ConnectionError("not a rank of this job")
+                    conn.sendall(_ACK)
+                except (OSError, ConnectionError, struct.error):
+                    conn.close()             # a stray connection: not ours
+                    continue
+                conn.settimeout(timeout)
                 conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
-                (r,) = struct.unpack("<i", _recv_exact(conn, 4))
-                if r <= 0 or r >= self.world or r in self.peers:
-                    raise RuntimeError("picaso_amd.sharding: unexpected rank %d at the rendezvous" % r)
                 self.peers[r] = conn
             srv.close()
         else:
             t0 = time.time()
-            while True:
-                try:
-                    s = socket.create_connection((addr, port), timeout=5.0)
-                    break
-                except OSError:
+            hosts = [addr] if addr in ("127.0.0.1", "localhost") else [addr, "127.0.0.1"]   # one node: loopback works too
+            while self.sock is None:
+                for host in hosts:
+                    for p in ports:
+                        try:
+                            s = socket.create_connection((host, p), timeout=2.0)
+                            s.sendall(_HELLO + struct.pack("<i", self.rank))
+                            s.settimeout(5.0)
+                            if _recv_exact(s, 4) != _ACK:
+                                raise ConnectionError("no handshake")
+                        except (OSError, ConnectionError):
+                            try:
+                                s.close()
+                            except Exception:
+                                pass
+                            continue
+                        self.sock, self.port = s, p
+                        break
+                    if self.sock is not None:
+                        break
+                if self.sock is None:
                     if time.time() - t0 > timeout:
-                        raise
+                        raise ConnectionError("picaso_amd.sharding: rank %d found no rendezvous at %s ports %s"
+                                              % (self.rank, hosts, ports))
                     time.sleep(0.05)
-            s.settimeout(timeout)
-            s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
-            s.sendall(struct.pack("<i", self.rank))
-            self.sock = s
+            self.sock.settimeout(timeout)
+            self.sock.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
 
     def broadcast(self, payload=None):
         """bytes of rank 0 on every rank"""

@@ -81,6 +81,61 @@ def test_sharded_equals_unsharded_host_group(world, nwno, oracle):
         assert slowest == float(world - 1)
 
 
+def _rdzv_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    from picaso_amd import sharding
+    group = sharding.HostGroup(rank, world, "127.0.0.1", port, timeout=60.0)
+    got = group.broadcast(b"id-of-rank-0" if rank == 0 else None)
+    vals = group.all_gather_bytes(bytes([rank]))
+    q.put((rank, group.port, got, vals))
+    group.barrier()
+    group.close()
+
+
+def test_rendezvous_survives_a_taken_port_and_stray_connections():
+    """The first rendezvous port is held by a foreign listener (which answers nothing): rank 0 moves to the
+    next candidate and the other ranks find it there; a connection that does not speak the handshake is
+    dropped without disturbing the group."""
+    import socket
+    import threading
+    import time
+    world = 3
+    port = 27000 + (os.getpid() % 2000)
+    squatter = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+    squatter.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+    squatter.bind(("127.0.0.1", port))
+    squatter.listen(8)
+    stop = []
+
+    def stray():                       # pokes the fall-back port with garbage while the group forms
+        while not stop:
+            try:
+                s = socket.create_connection(("127.0.0.1", port + 1000), timeout=0.5)
+                s.sendall(b"GET / HTTP/1.0\r\n\r\n")
+                s.close()
+            except OSError:
+                pass
+            time.sleep(0.05)
+    t = threading.Thread(target=stray, daemon=True)
+    t.start()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rdzv_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    stop.append(1)
+    squatter.close()
+    assert sorted(g[0] for g in got) == [0, 1, 2]
+    for rank, used, bid, vals in got:
+        assert used == port + 1000
+        assert bid == b"id-of-rank-0"
+        assert vals == [bytes([r]) for r in range(world)]
+
+
 def _gloo_worker(rank, world, port, nwno, q):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
