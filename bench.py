@@ -88,7 +88,7 @@ def workload_reflected(ctx, args, lo, hi, seed, nwno_total):
 
     return dict(solve=solve, oracle=oracle, nloc=n,
                 abytes=8 * n * (9 * nlayer + 2 * nlevel + 2 + ng + 1),
-                kernel="k_reflected_toa<%d, false, true, true>" % ng,
+                kernel="k_reflected_toa<%d, false, true, true, false, false>" % ng,
                 workload="BASELINE configs[2]: Toon two-stream reflected light (get_reflected_1d + "
                          "compress_disco), TTHG_ray, N=2, delta-Eddington, Rayleigh + cloud slab",
                 metric="spectra/sec (1e5 wave x 90 layer reflected)")
@@ -191,7 +191,7 @@ def workload_3d(ctx, args, lo, hi, seed, nwno_total):
 
     return dict(solve=solve, oracle=None, nloc=n,
                 abytes=8 * n * (ng * nt * (9 * nlayer + 2 * nlevel + 1) + 2 + 1),
-                kernel="k_reflected_toa<1, true, false>",
+                kernel="k_reflected_toa<1, true, false, false, false, false>",
                 workload="BASELINE configs[4]: 3-D reflected light, 8x8 facets (get_reflected_3d + compress_disco)",
                 metric="spectra/sec (%d wave x %d layer x 64 facet 3-D reflected)" % (nwno_total, nlayer))
 

@@ -330,7 +330,9 @@ __device__ __forceinline__ double disk_finish(double c1, double acc, double F, d
 // belongs to the wave, so the sweep state stays in registers instead of LDS -- 50 000 columns 0.1365 ms against
 // 0.1636 (tools/experiments/big_sweep.sh), same bits.  Of no use to the 1e5-column launch: its 1 563 waves need
 // two per SIMD.
-template <int NA, bool IS3D, bool ZP, bool FAST = false, bool BIG = false>
+// DRV (3-D only): some planes are NULL and re-derived in the kernel (see below); the full-plane 3-D launch keeps
+// the branch-free load sequence (the conditional loads cost the HBM-bound facet kernel 7 %)
+template <int NA, bool IS3D, bool ZP, bool FAST = false, bool BIG = false, bool DRV = false>
 __global__ __launch_bounds__(PZ_REFL_BLOCK, (BIG ? 1 : NA <= 2 ? PZ_REFL_MINWAVES_FEW : PZ_REFL_MINWAVES)) void k_reflected_toa(const ReflectedArgs a)
 {
 #pragma clang fp contract(off)      // operations as written, see reflected_layer
@@ -397,7 +399,10 @@ __global__ __launch_bounds__(PZ_REFL_BLOCK, (BIG ? 1 : NA <= 2 ? PZ_REFL_MINWAVE
                  *p_fr = a.ftau_ray + col, *p_dto = a.dtau_og + col, *p_tauo = a.tau_og + col,
                  *p_w0o = a.w0_og + col, *p_cbo = a.cosb_og + col;
 
-    constexpr bool LDS = (NA >= 4) && !IS3D && !BIG;
+#ifndef PZ_REFL_LDS_MIN
+#define PZ_REFL_LDS_MIN 4
+#endif
+    constexpr bool LDS = (NA >= PZ_REFL_LDS_MIN) && !IS3D && !BIG;
     __shared__ double lds_state[LDS ? (PZ_REFL_NLDS > 0 ? PZ_REFL_NLDS : 1) * NA * PZ_REFL_BLOCK : 1];
     ReflState<NA, LDS> S;
     S.lds = lds_state + threadIdx.x;
@@ -410,9 +415,9 @@ __global__ __launch_bounds__(PZ_REFL_BLOCK, (BIG ? 1 : NA <= 2 ? PZ_REFL_MINWAVE
     //                    with TAUCLD = 0)
     //   dtau_og / w0_og: no delta-scaling (cosb = 0: f = 0, optics.py:412-420 reduce to x*1): dtau / w0
     // all wave-uniform (kernel arguments); the 1-D launches always pass every plane
-    const bool derive_tau = IS3D && a.tau == nullptr, derive_tauo = IS3D && a.tau_og == nullptr;
-    const bool derive_g2 = IS3D && a.gcos2 == nullptr, clear = IS3D && a.ftau_cld == nullptr;
-    const bool alias_og = IS3D && a.dtau_og == nullptr;
+    const bool derive_tau = DRV && a.tau == nullptr, derive_tauo = DRV && a.tau_og == nullptr;
+    const bool derive_g2 = DRV && a.gcos2 == nullptr, clear = DRV && a.ftau_cld == nullptr;
+    const bool alias_og = DRV && a.dtau_og == nullptr;
     double tau_i = derive_tau ? 0.0 : p_tau[0];
     double tauo_pred = 0.0;          // tau_og[i-1] + dtau_og[i-1] of the layer above
 #pragma unroll
@@ -456,7 +461,7 @@ __global__ __launch_bounds__(PZ_REFL_BLOCK, (BIG ? 1 : NA <= 2 ? PZ_REFL_MINWAVE
         const long o = (long)i * pitch;
         L.dt = p_dtau[o];
         L.w0 = p_w0[o];
-        if constexpr (IS3D) {                      // only the loads are issued here; derived values in prep
+        if constexpr (DRV) {                       // only the loads are issued here; derived values in prep
             if (!derive_tau) L.tau_n = p_tau[o + pitch];
             if (!clear) {
                 L.g = p_cosb[o];
@@ -483,7 +488,7 @@ __global__ __launch_bounds__(PZ_REFL_BLOCK, (BIG ? 1 : NA <= 2 ? PZ_REFL_MINWAVE
         L.cbo = p_cbo[o];
     };
     auto prep = [&](LayerIn &L) {
-        if constexpr (IS3D) {
+        if constexpr (DRV) {
             if (clear) { L.g = 0.0; L.fc = 0.0; L.fr = 1.0; L.gcos2 = 0.5; L.cbo = 0.0; }
             else if (derive_g2) L.gcos2 = 0.5 * L.fr;
             if (alias_og) { L.dto = L.dt; L.w0o = L.w0; }
@@ -506,10 +511,15 @@ __global__ __launch_bounds__(PZ_REFL_BLOCK, (BIG ? 1 : NA <= 2 ? PZ_REFL_MINWAVE
             reflected_layer<NA, IS3D, ZP, FIRST_, LAST_, LDS, FAST>(a, L_, S, g, K, F, clip, tc, b_top); \
     } while (0)
 
-    // Few angles per lane (the HBM-bound 3-D facet kernel): two register sets.  Many angles: the
-    // kernel is at its register limit and FP64-bound, one prefetch set copied per layer is cheaper
-    // than the spills the second set would cause (measured: 0.98 ms vs 0.36 ms at five angles).
-    constexpr bool TWO_SETS = (NA <= 2);
+    // Two register sets used alternately (no copy) for one or two angles per lane -- the HBM-bound 3-D facet
+    // kernel -- and for five: there the eleven v_mov_b64 of the copy are 2.3 % of the launch (0.2357 ->
+    // 0.2302 ms, same box, no spills at 254 VGPRs).  Three angles spill with a second set (14 VGPRs), four
+    // and six to eight (chunked launches, rarely used) are left on the copying form.  (Early in round 1 the
+    // second set made the five-angle kernel spill: 0.98 ms vs 0.36 ms; the state has since moved to LDS.)
+#ifndef PZ_REFL_TWOSETS_5
+#define PZ_REFL_TWOSETS_5 1
+#endif
+    constexpr bool TWO_SETS = (NA <= 2) || (PZ_REFL_TWOSETS_5 && NA == 5);
     LayerIn A, B;
     load(A, 0);
     if (n == 1) {
@@ -617,8 +627,12 @@ int launch_reflected_toa(picaso_ctx *ctx, const ReflectedArgs &a, bool is3d)
     if (is3d) {
         const int block = PZ_REFL_BLOCK;
         const long grid = (a.ncol + block - 1) / block;
-        hipLaunchKernelGGL((k_reflected_toa<1, true, false>), dim3((unsigned)grid), dim3(block), 0,
-                           ctx->stream, a);
+        const bool all = a.tau && a.tau_og && a.gcos2 && a.ftau_cld && a.dtau_og;
+        if (all)
+            hipLaunchKernelGGL((k_reflected_toa<1, true, false>), dim3((unsigned)grid), dim3(block), 0, ctx->stream, a);
+        else
+            hipLaunchKernelGGL((k_reflected_toa<1, true, false, false, false, true>), dim3((unsigned)grid), dim3(block),
+                               0, ctx->stream, a);
         PZ_HIP(ctx, hipGetLastError());
         return 0;
     }
