@@ -10,9 +10,10 @@ integration) with all input planes resident in HBM.
 One process per GPU (the launcher only provides RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*; nothing
 here imports PyTorch).  One "step" = one full spectrum: every rank solves its contiguous wavelength
 block of the SAME 1e5-point grid (strong scaling, BASELINE's metric) and the albedo shards are
-all-gathered inside the timed region by RCCL inside libpicaso_hip.so (picaso_all_gather_async_dev: the
-gather of spectrum i runs on the communicator's own stream behind the kernel that produced it and
-overlaps the solve of spectrum i+1; every gather has finished when the timed region ends).  `--scaling weak` gives every rank its own 1e5-point block of an N x 1e5 grid
+all-gathered inside the timed region by RCCL inside libpicaso_hip.so (picaso_all_gather_multi_async_dev: spectra
+are handed to RCCL in batches of --gather-every, one collective launch per batch on the communicator's own stream
+behind the kernels that produced them, overlapping the solves of the next batch; each spectrum lands contiguous in
+its own buffer and every gather has finished when the timed region ends).  `--scaling weak` gives every rank its own 1e5-point block of an N x 1e5 grid
 instead.  Prints ONE JSON line (rank 0).
 
 --config selects the other BASELINE workloads (not the headline): 1 thermal emission 1e4 x 90,
@@ -207,6 +208,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", type=int, default=2, choices=(1, 2, 3, 4))
     ap.add_argument("--scaling", default="strong", choices=("strong", "weak"))
+    ap.add_argument("--gather-every", type=int, default=4,
+                    help="N > 1: spectra per collective launch (a group of that many all-gathers; each spectrum is "
+                         "still gathered into its own contiguous buffer inside the timed region)")
     ap.add_argument("--nwno", type=int, default=0, help="wavelengths of the whole spectrum (0 = the config's)")
     ap.add_argument("--nlayer", type=int, default=90)
     ap.add_argument("--ngauss", type=int, default=5, help="disk Gauss angles (5..8)")
@@ -243,24 +247,40 @@ def main():
     nloc = hi - lo
     # two result buffers: with N > 1 the gather of spectrum i is still in flight on the communicator's
     # stream while spectrum i+1 is solved into the other buffer
-    loc = [device.DeviceArray((nloc,), ctx) for _ in range(2)]
-    full = [device.DeviceArray((nwno_total,), ctx) for _ in range(2)] if comm else None
+    # N > 1: spectra are gathered in batches of G (one collective launch per batch: the two stream events and
+    # the RCCL launch of a collective cost ~10 us, a fifth of a 12 500-column solve); two batches of buffers, so
+    # the gather of one batch runs on the communicator's stream while the next batch is being solved
+    G = max(1, args.gather_every) if comm else 1
+    loc = [device.DeviceArray((nloc,), ctx) for _ in range(2 * G)]
+    full = [device.DeviceArray((nwno_total,), ctx) for _ in range(2 * G)] if comm else None
     nstep = [0]
+    pending = []                 # buffer indices solved but not yet handed to a collective
+
+    def flush():
+        if comm and pending:
+            slot = (pending[0] // G) & 1
+            if len(pending) == 1:
+                comm.all_gather_spectrum_async(loc[pending[0]], full[pending[0]], nwno_total, slot)
+            else:
+                comm.all_gather_spectra_async([loc[j] for j in pending], [full[j] for j in pending], nwno_total, slot)
+            del pending[:]
 
     def step(gather=True):
-        # spectrum i is solved into buffer i & 1; its gather runs on the communicator's stream and overlaps
-        # the solve of spectrum i+1 (other buffer); a buffer is reused only after its previous gather
-        # (device-side wait, no host synchronisation)
-        b = nstep[0] & 1
+        # spectrum i is solved into buffer i % 2G; a batch's buffers are reused only after the batch's previous
+        # gather (device-side wait at the start of the batch, no host synchronisation)
+        j = nstep[0] % (2 * G)
         nstep[0] += 1
-        if comm:
-            comm.wait_slot(b)
-        wl["solve"](loc[b])
+        if comm and j % G == 0:
+            comm.wait_slot((j // G) & 1)
+        wl["solve"](loc[j])
         if comm and gather:
-            comm.all_gather_spectrum_async(loc[b], full[b], nwno_total, b)
+            pending.append(j)
+            if j % G == G - 1:
+                flush()
 
     def barrier():
         if comm:
+            flush()                  # a partial last batch
             comm.wait_slot(-1)       # every gather has finished before the stream is drained
         device.sync(ctx)
         if comm:
@@ -282,6 +302,7 @@ def main():
             step(gather=False)
         nprewarm += 20
         device.sync(ctx)
+    nstep[0] = 0                     # the ranks ran different numbers of ramp launches: same batch phase from here on
     if args.prewarm_ms > 0:
         for _ in range(20):
             step()
@@ -294,13 +315,14 @@ def main():
     for _ in range(args.steps):
         step()
     if comm:
+        flush()
         comm.wait_slot(-1)
     stream_ms = device.timer_stop(ctx) / args.steps       # HIP events on the kernel's stream (solve [+ last gathers])
     barrier()
     elapsed = time.perf_counter() - t0
     if comm:
         elapsed = comm.max(elapsed)
-    last = (nstep[0] - 1) & 1
+    last = (nstep[0] - 1) % (2 * G)
     res_local = loc[last].to_host()
     res_full = full[last].to_host() if comm else res_local
 
@@ -314,6 +336,7 @@ def main():
         device.timer_start(ctx)                               # the gather alone, serialised behind each solve
         for _ in range(args.steps):
             step(gather=True)
+            flush()
             comm.wait_slot(-1)
         both_ms = device.timer_stop(ctx) / args.steps
         info = json.dumps({"rank": rank, "nwno": nloc, "kernel_ms": kernel_ms,
@@ -367,7 +390,8 @@ def main():
                        "sharding": "%d contiguous wavelength block(s) of %s" % (
                            world, "%d..%d" % (nwno_total // world, -(-nwno_total // world))),
                        "collective": "RCCL all-gather of the albedo shards inside libpicaso_hip.so "
-                                     "(picaso_all_gather_async_dev: overlaps the next solve), in the timed region"
+                                     "(picaso_all_gather_multi_async_dev: batches of %d spectra per collective launch, overlapping the next solves), "
+                                     "in the timed region" % G
                        if comm else "none"},
             "prewarm": {"ms": args.prewarm_ms, "launches": nprewarm, "why": "GPU clock ramp, untimed"},
             "wavelength_layer_updates_per_s": value * nwno_total / spectra_per_step * args.nlayer,

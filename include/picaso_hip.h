@@ -101,6 +101,9 @@ int picaso_all_gatherv_dev(picaso_comm *comm, const double *send, double *recv, 
  * collectives and picaso_comm_max / _sum / _barrier wait for all slots first. */
 int picaso_all_gather_async_dev(picaso_comm *comm, const double *send, double *recv, size_t count,
                                 const size_t *counts, const size_t *displs, int slot);
+/* n spectra in one collective launch (a group of n all-gathers): send[i] / recv[i] as above for each */
+int picaso_all_gather_multi_async_dev(picaso_comm *comm, int n, const double *const *send, double *const *recv,
+                                      size_t count, const size_t *counts, const size_t *displs, int slot);
 int picaso_comm_wait_slot(picaso_comm *comm, int slot);
 int picaso_comm_max(picaso_comm *comm, double *value);
 int picaso_comm_sum(picaso_comm *comm, double *value);

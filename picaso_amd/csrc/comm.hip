@@ -161,6 +161,37 @@ int picaso_all_gather_async_dev(picaso_comm *c, const double *send, double *recv
     return 0;
 }
 
+// n spectra in ONE collective launch (ncclGroupStart / End around n all-gathers): each spectrum still lands
+// contiguous in its own receive buffer, and the per-collective cost (two stream events, one RCCL launch) is paid
+// once per n spectra.  Same ordering rules and slots as picaso_all_gather_async_dev.
+int picaso_all_gather_multi_async_dev(picaso_comm *c, int n, const double *const *send, double *const *recv,
+                                      size_t count, const size_t *counts, const size_t *displs, int slot)
+{
+    if (!c) return fail(nullptr, "picaso_all_gather_multi_async_dev: null communicator");
+    picaso_ctx *ctx = c->ctx;
+    if (slot < 0 || slot >= picaso_comm::NSLOT) return fail(ctx, "picaso_all_gather_multi_async_dev: slot must be 0..3");
+    if (n < 1 || !send || !recv) return fail(ctx, "picaso_all_gather_multi_async_dev: bad arguments");
+    if (counts && !displs) return fail(ctx, "picaso_all_gather_multi_async_dev: counts without displs");
+    PZ_HIP(ctx, hipSetDevice(ctx->device));
+    PZ_HIP(ctx, hipEventRecord(c->ready, ctx->stream));
+    PZ_HIP(ctx, hipStreamWaitEvent(c->stream, c->ready, 0));
+    PZ_NCCL(ctx, ncclGroupStart());
+    for (int i = 0; i < n; ++i) {
+        if (!counts) {
+            PZ_NCCL(ctx, ncclAllGather(send[i], recv[i], count, ncclDouble, c->comm, c->stream));
+        } else {
+            for (int r = 0; r < c->nranks; ++r) {
+                const double *src = (r == c->rank) ? send[i] : recv[i] + displs[r];
+                PZ_NCCL(ctx, ncclBroadcast(src, recv[i] + displs[r], counts[r], ncclDouble, r, c->comm, c->stream));
+            }
+        }
+    }
+    PZ_NCCL(ctx, ncclGroupEnd());
+    PZ_HIP(ctx, hipEventRecord(c->done[slot], c->stream));
+    c->pending[slot] = true;
+    return 0;
+}
+
 // work enqueued on the context's stream from now on starts after the last asynchronous gather of `slot`
 // (slot < 0: of every slot) has finished; device-side, the host does not block
 int picaso_comm_wait_slot(picaso_comm *c, int slot)

@@ -294,6 +294,22 @@ class Comm:
                                                            ctypes.c_size_t(counts[0]), c, d, ctypes.c_int(slot)),
                    self.ctx)
 
+    def all_gather_spectra_async(self, locals_, fulls, nwno, slot):
+        """Several spectra in one collective launch: ``locals_[i]`` (this rank's block) -> ``fulls[i]``."""
+        bounds = shard_bounds(nwno, self.world)
+        counts = [hi - lo for lo, hi in bounds]
+        if len(set(counts)) == 1:
+            c = d = None
+        else:
+            c = (ctypes.c_size_t * self.world)(*counts)
+            d = (ctypes.c_size_t * self.world)(*[lo for lo, _ in bounds])
+        n = len(locals_)
+        snd = (ctypes.c_void_p * n)(*[int(x.addr) for x in locals_])
+        rcv = (ctypes.c_void_p * n)(*[int(x.addr) for x in fulls])
+        _lib.check(_lib.load().picaso_all_gather_multi_async_dev(self.handle, ctypes.c_int(n), snd, rcv,
+                                                                 ctypes.c_size_t(counts[0]), c, d, ctypes.c_int(slot)),
+                   self.ctx)
+
     def wait_slot(self, slot=-1):
         _lib.check(_lib.load().picaso_comm_wait_slot(self.handle, ctypes.c_int(slot)), self.ctx)
 

@@ -60,7 +60,7 @@ def test_no_cpu_fallback_without_gpu(lib):
 def test_comm_symbols_and_rccl_linked(lib):
     """The multi-GPU layer lives in the library: comm entry points exported, librccl a direct dependency."""
     for n in ("picaso_comm_unique_id", "picaso_comm_init_rank", "picaso_comm_init_all", "picaso_all_gather_dev",
-              "picaso_all_gatherv_dev", "picaso_all_gather_async_dev", "picaso_comm_wait_slot", "picaso_comm_max", "picaso_comm_barrier", "picaso_comm_destroy"):
+              "picaso_all_gatherv_dev", "picaso_all_gather_async_dev", "picaso_all_gather_multi_async_dev", "picaso_comm_wait_slot", "picaso_comm_max", "picaso_comm_barrier", "picaso_comm_destroy"):
         assert hasattr(lib, n), n
     from picaso_amd import _lib
     out = subprocess.run(["readelf", "-d", _lib.LIB_PATH], capture_output=True).stdout.decode()

@@ -49,6 +49,13 @@ def test_one_rank_rccl_collectives():
         assert np.array_equal(recv.to_host(), host * 5) and np.array_equal(recv2.to_host(), host * 6)
         with pytest.raises(_lib.PicasoHipError):
             comm.all_gather_spectrum_async(send, recv, n, 7)
+        # several spectra in one collective launch
+        outs = [device.DeviceArray.zeros((n,), ctx) for _ in range(3)]
+        comm.all_gather_spectra_async(sends[:3], outs, n, 2)
+        comm.wait_slot(2)
+        device.sync(ctx)
+        for k in range(3):
+            assert np.array_equal(outs[k].to_host(), host * (k + 1))
         assert comm.max(3.25) == 3.25
         comm.barrier()
         r, w = ctypes.c_int(-1), ctypes.c_int(-1)
