@@ -190,7 +190,7 @@ __device__ __forceinline__ void modes_sh4(const double (&a)[4], double dt, Modes
     const double a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3];
     M.beta = a0 * a1 + div_const(4 * a0 * a3, 9.0, R9) + div_const(a2 * a3, 9.0, R9);   // fluxes.py:3388-3391
     M.gama = div_const(a0 * a1 * a2 * a3, 9.0, R9);
-    const double disc = sqrt(M.beta * M.beta - 4 * M.gama);
+    const double disc = fsqrt(M.beta * M.beta - 4 * M.gama);
     // lam = x rsqrt(x) and 1/lam = rsqrt(x) from one v_rsq_f64 + Newton (frsq, ~1 ulp) instead of a
     // correctly rounded sqrt followed by a reciprocal (fluxes.py:3393-3394, 3423-3425)
     const double x1 = (M.beta + disc) / 2, x2 = (M.beta - disc) / 2;

@@ -197,7 +197,7 @@ __device__ __forceinline__ ThermLayer therm_layer_coeffs(const ThermalArgs &a, l
     r.B0 = B0;
     r.b1 = (Bn - B0) * frcp(dt);                            // fluxes.py:1757
     const double g1 = 2.0 - w0 * (1 + g), g2 = w0 * (1 - g);
-    r.lam = sqrt(g1 * g1 - g2 * g2);
+    r.lam = fsqrt(g1 * g1 - g2 * g2);
     r.gam = (g1 - r.lam) * frcp(g2);
     r.s = frcp(g1 + g2);
     // fluxes.py:1772-1779 with 2 pi mu1 = pi and B0 + b1 dtau = B_{i+1}:

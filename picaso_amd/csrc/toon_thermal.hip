@@ -37,7 +37,7 @@ __device__ __forceinline__ void thermal_shared(double B0, double Bn, double dt, 
     const double mu1 = 0.5;                                    // fluxes.py:1748
     L.b1 = (Bn - B0) * frcp(dt);                               // fluxes.py:1757
     const double g1 = 2.0 - w0 * (1 + g), g2 = w0 * (1 - g);   // fluxes.py:1760
-    L.lam = sqrt(g1 * g1 - g2 * g2);                           // unfused, as numpy
+    L.lam = fsqrt(g1 * g1 - g2 * g2);                          // unfused, as numpy
     L.gam = (g1 - L.lam) * frcp(g2);
     L.s = frcp(g1 + g2);                                       // fluxes.py:1766
     // fluxes.py:1772-1779 with 2 pi mu1 = pi and B0 + b1 dtau = B_{i+1}:
