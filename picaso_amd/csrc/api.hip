@@ -104,11 +104,11 @@ static bool spread_angles(long ncol, int nang, long limit = 1280L * 64)
 // of g angles as separate workgroups (XCD-aware order, see k_reflected_toa) and the disk sum as a separate pass;
 // measured per shape (steady clocks, 90 layers, 5 angles, disk sum included; tools/experiments/
 // angle_group_sweep.sh, knee.sh) -- while the launch has at most one 256-thread workgroup per CU (one wave per
-// SIMD): g=1 0.050 ms, g=2 0.070, g=3 0.098; at most two per CU: g=1 0.084-0.086, g=2 0.111-0.130, g=3 0.153;
-// all five fused with the state in registers (one wave per SIMD, up to 65 536 columns) 0.136, with two waves
-// per SIMD 0.235.  One workgroup more than that and the time jumps (26 200 columns g=1: 0.119).  The cheapest
-// shape that fits is taken: up to 13 056 columns g=1, to 21 760 g=2, to 25 600 g=1 (two per CU), to 32 768 g=3,
-// to 42 000 g=2 (two per CU), then fused.  The result does not depend on the shape (explicit-fma arithmetic,
+// SIMD): g=1 0.050 ms, g=2 0.063, g=3 0.084; at most two per CU: g=1 0.084, g=2 0.100-0.117, g=3 0.140;
+// all five fused with the state in registers (one wave per SIMD, up to 65 536 columns) 0.105-0.130, with two
+// waves per SIMD 0.225.  One workgroup more than that and the time jumps (26 200 columns g=1: 0.119).  The
+// cheapest shape that fits is taken: up to 13 056 columns g=1, to 21 760 g=2, to 32 768 g=3, then fused.
+// (Before the branch-free layer body the numbers were 0.050 / 0.070 / 0.098 alone, 0.136 fused.)  The result does not depend on the shape (explicit-fma arithmetic,
 // disk sum in the reference's order).
 static int reflected_angle_group(picaso_ctx *ctx, long ncol, int nang)
 {
@@ -118,8 +118,8 @@ static int reflected_angle_group(picaso_ctx *ctx, long ncol, int nang)
     const long colwaves = (ncol + 63) / 64, ncg = (ncol + 255) / 256, ncu = ctx->ncu;
     if (colwaves > 4L * ncu) return 0;
     // (five angles alone: the all-register variant of the kernel, 0.136; with the state in LDS 0.160)
-    static const double alone[MAX_ANGLES + 1] = {0, 0.050, 0.070, 0.098, 0.128, 0.136, 0.192, 0.224, 0.256};
-    static const double paired[4] = {0, 0.086, 0.126, 0.153};
+    static const double alone[MAX_ANGLES + 1] = {0, 0.050, 0.063, 0.084, 0.128, 0.105, 0.192, 0.224, 0.256};
+    static const double paired[4] = {0, 0.085, 0.110, 0.140};
     double best = alone[nang];
     int group = 0;
     for (int g = 1; g <= 3 && g < nang; ++g) {
