@@ -74,6 +74,9 @@ enum { S_T = 0, S_XU, S_EO, S_KAPPA, S_ZETA, S_D1, S_D2 };   // late-use variabl
 #define PZ_REFL_SADDR 1
 #endif
 // second copy of the interior layer body for layers without cloud (FAST kernels only)
+#ifndef PZ_REFL_CLOUD_BODY
+#define PZ_REFL_CLOUD_BODY 1
+#endif
 #ifndef PZ_REFL_NOCLD_BODY
 #define PZ_REFL_NOCLD_BODY 1
 #endif
@@ -111,6 +114,7 @@ struct LayerIn {
     bool same_dt;    // dtau_og == dtau (no delta-scaling in this layer)
     bool nocld;      // ftau_cld == 0 (no cloud in this layer)
     bool allf;       // cum_tau && eo_ok && same_dt
+    bool af_cloud;   // cum_tau && eo_ok && !same_dt on a layer with cloud
 };
 
 // One layer of the sweep.  FIRST / LAST are compile-time so the top row and the bottom-boundary
@@ -134,8 +138,10 @@ struct LayerIn {
 // the five-angle launch ran 14 % faster and a one-wave-per-SIMD launch 20-27 % (branch bubbles with nothing to
 // hide them, basic blocks too small to schedule across).  Same operations as the general body takes when
 // the flags are true, so the bits do not change.
+// SDT (with AF): 1 = same_dt holds as well (the cloud-free copy), 2 = it does not (the usual cloud layer: delta-
+// scaled, so dtau_og != dtau and the two extra exponentials are always formed) -- both straight-line.
 template <int NA, bool IS3D, bool ZP, bool FIRST, bool LAST, bool LDS, bool FAST = false, bool NC = false,
-          bool AF = false>
+          bool AF = false, int SDT = 1>
 __device__ __forceinline__ void reflected_layer(const ReflectedArgs &a, const LayerIn &L,
                                                 ReflState<NA, LDS> &S,
                                                 const ReflectedArgs::Angle (&g)[NA],
@@ -274,7 +280,7 @@ __device__ __forceinline__ void reflected_layer(const ReflectedArgs &a, const La
         // single-angle exponentials; a layer that is not delta-scaled (dtau_og == dtau) shares them
         const double t2 = fma(-e0, et, 1.0);
         double t1 = t2, e0o = e0;
-        if (!AF && !L.same_dt) {
+        if (AF ? (SDT == 2) : !L.same_dt) {
             const double e1o = fexp2_cold(L.dto * nl1_k, K);
             e0o = ZP ? e1o : fexp2_cold(L.dto * nl0_k, K);
             t1 = fma(-e0o, e1o, 1.0);
@@ -508,6 +514,7 @@ __global__ __launch_bounds__(PZ_REFL_BLOCK, (BIG ? 1 : NA <= 2 ? PZ_REFL_MINWAVE
         L.same_dt = __all(L.dto == L.dt);
         L.nocld = __all(L.fc == 0.0);
         L.allf = L.cum_tau && L.eo_ok && L.same_dt;
+        L.af_cloud = L.cum_tau && L.eo_ok && !L.same_dt && !L.nocld;
         tau_i = L.tau_n;
         tauo_pred = L.tauo + L.dto;
     };
@@ -516,6 +523,8 @@ __global__ __launch_bounds__(PZ_REFL_BLOCK, (BIG ? 1 : NA <= 2 ? PZ_REFL_MINWAVE
         prep(L_);                                                                                        \
         if (PZ_REFL_NOCLD_BODY && FAST && !(FIRST_) && !(LAST_) && L_.nocld && L_.allf)                  \
             reflected_layer<NA, IS3D, ZP, FIRST_, LAST_, LDS, FAST, true, true>(a, L_, S, g, K, F, clip, tc, b_top); \
+        else if (PZ_REFL_CLOUD_BODY && FAST && !(FIRST_) && !(LAST_) && L_.af_cloud)                      \
+            reflected_layer<NA, IS3D, ZP, FIRST_, LAST_, LDS, FAST, false, true, 2>(a, L_, S, g, K, F, clip, tc, b_top); \
         else                                                                                             \
             reflected_layer<NA, IS3D, ZP, FIRST_, LAST_, LDS, FAST>(a, L_, S, g, K, F, clip, tc, b_top); \
     } while (0)
