@@ -537,7 +537,7 @@ __global__ __launch_bounds__(PZ_REFL_BLOCK, (BIG ? 1 : NA <= 2 ? PZ_REFL_MINWAVE
 #ifndef PZ_REFL_TWOSETS_5
 #define PZ_REFL_TWOSETS_5 1
 #endif
-    constexpr bool TWO_SETS = (NA <= 2) || (PZ_REFL_TWOSETS_5 && NA == 5);
+    constexpr bool TWO_SETS = (NA <= 2) || (PZ_REFL_TWOSETS_5 && NA == 5 && FAST);   // generic five-angle kernel: 30 VGPRs spilled with it
     LayerIn A, B;
     load(A, 0);
     if (n == 1) {
