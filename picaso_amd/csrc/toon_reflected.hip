@@ -74,6 +74,9 @@ enum { S_T = 0, S_XU, S_EO, S_KAPPA, S_ZETA, S_D1, S_D2 };   // late-use variabl
 #define PZ_REFL_SADDR 1
 #endif
 // second copy of the interior layer body for layers without cloud (FAST kernels only)
+#ifndef PZ_REFL_FAST_NONZP
+#define PZ_REFL_FAST_NONZP 1
+#endif
 #ifndef PZ_REFL_CLOUD_BODY
 #define PZ_REFL_CLOUD_BODY 1
 #endif
@@ -157,7 +160,7 @@ __device__ __forceinline__ void reflected_layer(const ReflectedArgs &a, const La
     const int tc = FAST ? 0 : tc_;
     const int single_phase = FAST ? 3 : a.single_phase;
     const int multi_phase = FAST ? 0 : a.multi_phase;
-    const double cos_theta = FAST ? 1.0 : a.cos_theta;
+    const double cos_theta = (FAST && ZP) ? 1.0 : a.cos_theta;   // zero phase: cos_theta = 1 (what ZP geometry means)
     const double frac_c = FAST ? 2.0 : a.frac_c;
     const double dt = L.dt, w0 = L.w0;
     // ---- angle-independent layer quantities (fluxes.py:1132-1141, 1172-1177) ----
@@ -537,7 +540,10 @@ __global__ __launch_bounds__(PZ_REFL_BLOCK, (BIG ? 1 : NA <= 2 ? PZ_REFL_MINWAVE
 #ifndef PZ_REFL_TWOSETS_5
 #define PZ_REFL_TWOSETS_5 1
 #endif
-    constexpr bool TWO_SETS = (NA <= 2) || (PZ_REFL_TWOSETS_5 && NA == 5 && FAST);   // generic five-angle kernel: 30 VGPRs spilled with it
+#ifndef PZ_REFL_TWOSETS_NONZP
+#define PZ_REFL_TWOSETS_NONZP 0
+#endif
+    constexpr bool TWO_SETS = (NA <= 2) || (PZ_REFL_TWOSETS_5 && NA == 5 && FAST && (ZP || PZ_REFL_TWOSETS_NONZP));   // generic five-angle kernel: 30 VGPRs spilled with it
     LayerIn A, B;
     load(A, 0);
     if (n == 1) {
@@ -604,12 +610,13 @@ __global__ __launch_bounds__(PZ_REFL_BLOCK, (BIG ? 1 : NA <= 2 ? PZ_REFL_MINWAVE
     }
 }
 
-// the reference's default options in the symmetric zero-phase geometry (see reflected_layer)
-static bool fast_options(const ReflectedArgs &a)
+// the reference's default options (see reflected_layer); zp: the symmetric zero-phase geometry, where the
+// compile-time variant also fixes cos_theta = 1 -- at other phase angles (ubar0 != ubar1) cos_theta stays an argument
+static bool fast_options(const ReflectedArgs &a, bool zp)
 {
     if (getenv("PICASO_AMD_REFL_GENERIC")) return false;      // A/B switch for tools/
     if ((double)a.pitch * (a.nlayer + 1) * 8.0 >= 4294967296.0) return false;   // 32-bit plane offsets
-    return a.toon_coefficients == 0 && a.single_phase == 3 && a.multi_phase == 0 && a.cos_theta == 1.0 &&
+    return a.toon_coefficients == 0 && a.single_phase == 3 && a.multi_phase == 0 && (!zp || a.cos_theta == 1.0) &&
            a.frac_c == 2.0;
 }
 
@@ -626,11 +633,14 @@ static int launch1d(picaso_ctx *ctx, const ReflectedArgs &a_in)
     for (int k = 0; k < a.na * (int)ny; ++k) zp = zp && (a.ang[k].u0 == a.ang[k].u1);
     bool big = false;
     if constexpr (NA == 5) big = a.ny <= 1 && (a.ncol + 63) / 64 <= 1024 && getenv("PICASO_AMD_REFL_NO_BIG") == nullptr;
-    if (zp && fast_options(a) && big) {
+    const bool fast = fast_options(a, zp);
+    if (zp && fast && big) {
         if constexpr (NA == 5)
             hipLaunchKernelGGL((k_reflected_toa<NA, false, true, true, true>), grid, dim3(block), 0, ctx->stream, a);
-    } else if (zp && fast_options(a))
+    } else if (zp && fast)
         hipLaunchKernelGGL((k_reflected_toa<NA, false, true, true>), grid, dim3(block), 0, ctx->stream, a);
+    else if (fast && PZ_REFL_FAST_NONZP)        // default options at a non-zero phase angle
+        hipLaunchKernelGGL((k_reflected_toa<NA, false, false, true>), grid, dim3(block), 0, ctx->stream, a);
     else if (zp)
         hipLaunchKernelGGL((k_reflected_toa<NA, false, true>), grid, dim3(block), 0, ctx->stream, a);
     else

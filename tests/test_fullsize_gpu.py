@@ -107,6 +107,13 @@ def test_angle_grouping_does_not_change_a_bit(ng, nwno, phase, sp, tc, monkeypat
     resident.reflected_1d(ctx, 41, nwno, ng, 1, d, d["surf_reflect"], u0, u1, cos_theta, d["F0PI"], sp, 0,
                           *TTHG, x, toon_coefficients=tc, gweight=gw, tweight=tw, albedo=alb)
     res["lds"] = (x.to_host(), alb.to_host())
+    # and the generic kernel (options as run-time arguments) instead of the compile-time default-options variants
+    monkeypatch.delenv("PICASO_AMD_REFL_NO_BIG", raising=False)
+    monkeypatch.setenv("PICASO_AMD_REFL_GENERIC", "1")
+    x, alb = DeviceArray.zeros((ng, 1, nwno), ctx), DeviceArray.zeros((nwno,), ctx)
+    resident.reflected_1d(ctx, 41, nwno, ng, 1, d, d["surf_reflect"], u0, u1, cos_theta, d["F0PI"], sp, 0,
+                          *TTHG, x, toon_coefficients=tc, gweight=gw, tweight=tw, albedo=alb)
+    res["generic"] = (x.to_host(), alb.to_host())
     assert np.all(res["0"][0] > 0) and np.all(res["0"][1] > 0)
     for group, (x, alb) in res.items():
         assert np.array_equal(x, res["0"][0]) and np.array_equal(alb, res["0"][1]), group
