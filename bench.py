@@ -4,11 +4,13 @@
 integration) with all input planes resident in HBM.
 
     python bench.py [--gpus N --steps K --warmup W] [--config 1|2|3|4] [--scaling strong|weak]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
 
-One process per GPU (the launcher only provides RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*; nothing
-here imports PyTorch).  One "step" = one full spectrum: every rank solves its contiguous wavelength
+One process per GPU.  `python bench.py --gpus N` starts its own N ranks (spawn_ranks below: plain
+subprocesses, each with RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR / MASTER_PORT and a random job token in its
+environment; rank 0's stdout is this process's stdout) and exits non-zero, saying so, when fewer than N GPUs are
+visible.  Any other one-process-per-GPU launcher that sets the same variables works as well (the driver's
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py
+--gpus N ...`: only its environment is used; nothing here imports PyTorch).  One "step" = one full spectrum: every rank solves its contiguous wavelength
 block of the SAME 1e5-point grid (strong scaling, BASELINE's metric) and the albedo shards are
 all-gathered inside the timed region by RCCL inside libpicaso_hip.so (picaso_all_gather_multi_async_dev: spectra
 are handed to RCCL in batches of --gather-every, one collective launch per batch on the communicator's own stream
@@ -29,6 +31,9 @@ import argparse
 import hashlib
 import json
 import os
+import secrets
+import socket
+import subprocess
 import sys
 import time
 
@@ -201,6 +206,42 @@ WORKLOADS = {1: (workload_thermal, 10000), 2: (workload_reflected, 100000), 3: (
              4: (workload_3d, 12500)}
 
 
+def spawn_ranks(ngpus):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves, one process per GPU, with the
+    environment a one-process-per-GPU launcher would give them, and wait.  The parent never touches HIP (the GPUs
+    belong to the ranks); rank 0 inherits stdout, so its one JSON line is this process's one JSON line.  The first
+    rank that fails takes the job down: the others are terminated (by PID: they are our own children) and the exit
+    status is non-zero."""
+    probe = socket.socket(socket.AF_INET, socket.SOCK_STREAM)      # a free loopback port for the rendezvous
+    probe.bind(("127.0.0.1", 0))
+    port = probe.getsockname()[1]
+    probe.close()
+    base = dict(os.environ, WORLD_SIZE=str(ngpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                PICASO_AMD_RDZV_PORT=str(port), PICASO_AMD_JOB_TOKEN=secrets.token_hex(16),
+                PICASO_AMD_BENCH_SPAWNED="1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    procs = []
+    for r in range(ngpus):
+        env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    alive = list(procs)
+    while alive:
+        for p in list(alive):
+            code = p.poll()
+            if code is None:
+                continue
+            alive.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+                for q in alive:                  # a rank died: the others would wait at the rendezvous for ever
+                    q.terminate()
+        time.sleep(0.02)
+    if rc != 0:
+        print("bench.py: a rank of the %d-GPU job failed (exit status %d)" % (ngpus, rc), file=sys.stderr, flush=True)
+    return rc if rc >= 0 else 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -218,16 +259,33 @@ def main():
                     help="untimed launches of the same step before the W warm-up steps (clock ramp)")
     ap.add_argument("--cpu-sample", type=int, default=100000,
                     help="wavelengths of the same workload timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--rendezvous-only", action="store_true",
+                    help="start the ranks, let them find each other (HostGroup) and exit: checks the launch path "
+                         "of a node without touching a GPU")
     args = ap.parse_args()
 
-    rank, world, local_rank, addr, port = sharding.launcher_env()
     launched = "RANK" in os.environ
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if args.gpus > 1 and not launched:
+        raise SystemExit(spawn_ranks(args.gpus))
+    rank, world, local_rank, addr, port = sharding.launcher_env()
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
+    if args.rendezvous_only:
+        group = sharding.HostGroup(rank, world, addr, port, timeout=60.0)
+        seen = [int(b.decode()) for b in group.all_gather_bytes(str(rank).encode())]
+        group.barrier()
+        if rank == 0:
+            print(json.dumps({"rendezvous": seen, "world": world, "port": group.port,
+                              "spawned_by_bench": bool(os.environ.get("PICASO_AMD_BENCH_SPAWNED"))}), flush=True)
+        group.close()
+        return
     ndev = _lib.device_count()
-    if ndev < 1:
-        raise SystemExit("bench.py needs an MI355X: no HIP device visible")
-    ctx = _lib.context(local_rank % ndev)
+    if ndev < max(world, 1):
+        # one GPU per rank, never two ranks on one device and never fewer ranks than asked for
+        raise SystemExit("bench.py [rank %d]: --gpus %d needs %d GPUs, %d visible" % (rank, args.gpus, world, ndev))
+    if local_rank >= ndev:
+        raise SystemExit("bench.py [rank %d]: LOCAL_RANK %d but %d GPUs visible" % (rank, local_rank, ndev))
+    ctx = _lib.context(local_rank)
     group = comm = None
     if launched:
         group = sharding.HostGroup(rank, world, addr, port)

@@ -14,6 +14,7 @@ carries small host-side collectives (bytes broadcast, array all-gather), which i
 of the sharded path use.
 """
 import ctypes
+import hashlib
 import os
 import socket
 import struct
@@ -76,34 +77,61 @@ def _recv_msg(sock):
 
 _HELLO, _ACK = b"PZRV", b"PZOK"
 PORT_STEPS = (0, 1000, 2000)          # fall-back ports (offsets) when the first one is taken by someone else
+TOKEN_BYTES = 16
+_LOOPBACK = ("127.0.0.1", "localhost", "::1")
+
+
+def job_token():
+    """16 bytes that identify THIS job at the rendezvous: two jobs on one node (or a stale listener of an
+    earlier one) must not be able to complete each other's handshake.  ``PICASO_AMD_JOB_TOKEN`` (hex; bench.py's
+    own launcher hands every rank a random one) wins; otherwise a hash of what the launcher gives every rank of
+    one job and no rank of another: the store address, the world size and the launcher's run id."""
+    tok = os.environ.get("PICASO_AMD_JOB_TOKEN")
+    if tok:
+        try:
+            raw = bytes.fromhex(tok)
+        except ValueError:
+            raw = tok.encode()
+        return hashlib.sha256(raw).digest()[:TOKEN_BYTES]
+    ident = ":".join(os.environ.get(k, "") for k in ("MASTER_ADDR", "MASTER_PORT", "WORLD_SIZE", "TORCHELASTIC_RUN_ID",
+                                                     "SLURM_JOB_ID", "SLURM_STEP_ID"))
+    return hashlib.sha256(ident.encode()).digest()[:TOKEN_BYTES]
 
 
 class HostGroup:
-    """Rank 0 listens on ``port`` (all interfaces); ranks 1..world-1 connect to ``addr`` and identify
-    themselves.  Small host-side collectives only: the spectra themselves never travel through here on a GPU
-    run.  If the port is in use by something else, rank 0 moves on to ``port + 1000`` and ``port + 2000``;
-    the other ranks try the candidates in turn until one answers with the rendezvous handshake.  Connections
-    that do not start with the handshake are dropped."""
+    """Rank 0 listens on ``port`` of ``addr`` (loopback for a single-node job; all interfaces only when
+    ``addr`` is not an address of this host); ranks 1..world-1 connect to ``addr`` and identify themselves with
+    their rank and the job token (``job_token()``), which rank 0 checks and echoes, so a rank of another job or a
+    stale listener is refused on both sides.  Small host-side collectives only: the spectra themselves never
+    travel through here on a GPU run.  If the port is in use by something else, rank 0 moves on to
+    ``port + 1000`` and ``port + 2000``; the other ranks try the candidates in turn until one answers with the
+    rendezvous handshake of THIS job.  Connections that do not start with the handshake are dropped."""
 
-    def __init__(self, rank, world, addr="127.0.0.1", port=29537, timeout=120.0):
+    def __init__(self, rank, world, addr="127.0.0.1", port=29537, timeout=120.0, token=None):
         self.rank, self.world = int(rank), int(world)
         self.peers = {}          # rank 0: rank -> socket
         self.sock = None         # other ranks: socket to rank 0
         self.port = None
         if self.world == 1:
             return
+        token = job_token() if token is None else hashlib.sha256(bytes(token)).digest()[:TOKEN_BYTES]
         ports = [port + d for d in PORT_STEPS if port + d < 65536]
         if self.rank == 0:
             srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
             srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+            bind_host = "127.0.0.1" if addr in _LOOPBACK else addr
             t0 = time.time()
             while self.port is None:         # a previous run's listener may still be closing
                 for p in ports:
                     try:
-                        srv.bind(("", p))
+                        srv.bind((bind_host, p))
                         self.port = p
                         break
-                    except OSError:
+                    except socket.gaierror:
+                        bind_host = ""       # MASTER_ADDR does not resolve here: all interfaces (the token guards)
+                    except OSError as e:
+                        if e.errno == 99:    # EADDRNOTAVAIL: MASTER_ADDR is not an address of this host
+                            bind_host = ""
                         continue
                 if self.port is None:
                     if time.time() - t0 > 30.0:
@@ -115,11 +143,12 @@ class HostGroup:
                 conn, _ = srv.accept()
                 try:
                     conn.settimeout(5.0)
-                    hello = _recv_exact(conn, 8)
-                    (r,) = struct.unpack("<i", hello[4:])
-                    if hello[:4] != _HELLO or r <= 0 or r >= self.world or r in self.peers:
+                    hello = _recv_exact(conn, 8 + TOKEN_BYTES)
+                    (r,) = struct.unpack("<i", hello[4:8])
+                    if (hello[:4] != _HELLO or hello[8:] != token or r <= 0 or r >= self.world
+                            or r in self.peers):
                         raise ConnectionError("not a rank of this job")
-                    conn.sendall(_ACK)
+                    conn.sendall(_ACK + token)
                 except (OSError, ConnectionError, struct.error):
                     conn.close()             # a stray connection: not ours
                     continue
@@ -129,16 +158,16 @@ class HostGroup:
             srv.close()
         else:
             t0 = time.time()
-            hosts = [addr] if addr in ("127.0.0.1", "localhost") else [addr, "127.0.0.1"]   # one node: loopback works too
+            hosts = ["127.0.0.1"] if addr in _LOOPBACK else [addr]      # no blind loopback try for a remote rank 0
             while self.sock is None:
                 for host in hosts:
                     for p in ports:
                         try:
                             s = socket.create_connection((host, p), timeout=2.0)
-                            s.sendall(_HELLO + struct.pack("<i", self.rank))
+                            s.sendall(_HELLO + struct.pack("<i", self.rank) + token)
                             s.settimeout(5.0)
-                            if _recv_exact(s, 4) != _ACK:
-                                raise ConnectionError("no handshake")
+                            if _recv_exact(s, 4 + TOKEN_BYTES) != _ACK + token:
+                                raise ConnectionError("no handshake of this job")
                         except (OSError, ConnectionError):
                             try:
                                 s.close()

@@ -198,3 +198,75 @@ def test_product_does_not_import_torch():
     if re.search(r"^\s*(import|from)\s+torch\b", text, re.M):
         offenders.append("bench.py")
     assert not offenders, offenders
+
+
+def _run_bench(*argv, timeout=180):
+    import subprocess
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "PICASO_AMD_RDZV_PORT",
+                        "PICASO_AMD_JOB_TOKEN")}
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(argv), env=env,
+                          capture_output=True, text=True, timeout=timeout)
+
+
+def test_bench_spawns_its_own_ranks_and_fails_loudly_without_the_gpus():
+    """`python bench.py --gpus 2` with no launcher environment starts two ranks itself; on a box with fewer
+    than two GPUs every rank says so and the job exits non-zero -- it never runs one rank and calls it two."""
+    import ctypes
+    from picaso_amd import _lib
+    r = _run_bench("--gpus", "2", "--steps", "2", "--warmup", "1")
+    ndev = _lib.device_count()
+    if ndev >= 2:
+        pytest.skip("two GPUs visible: the job would run")
+    assert r.returncode != 0
+    for rank in (0, 1):
+        assert "bench.py [rank %d]: --gpus 2 needs 2 GPUs, %d visible" % (rank, ndev) in r.stderr
+    assert r.stdout.strip() == ""          # no JSON line of a job that did not run
+
+
+def test_bench_ranks_find_each_other_through_the_spawned_environment():
+    import json
+    r = _run_bench("--gpus", "3", "--rendezvous-only")
+    assert r.returncode == 0, r.stderr
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["rendezvous"] == [0, 1, 2] and line["world"] == 3 and line["spawned_by_bench"] is True
+
+
+def test_bench_refuses_a_launcher_world_that_is_not_gpus():
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29431")
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env,
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "--gpus 2 but the launcher started WORLD_SIZE=1" in r.stderr
+
+
+def _token_worker(rank, world, port, token, q):
+    sys.path.insert(0, ROOT)
+    from picaso_amd import sharding
+    try:
+        g = sharding.HostGroup(rank, world, "127.0.0.1", port, timeout=6.0, token=token)
+        q.put((rank, "joined", g.all_gather_bytes(bytes([rank]))))
+        g.close()
+    except Exception as e:                       # noqa: BLE001
+        q.put((rank, "refused", type(e).__name__))
+
+
+def test_rendezvous_refuses_a_rank_of_another_job():
+    """Two jobs share a node and a port: a rank carrying job B's token cannot complete job A's handshake (it is
+    dropped by rank 0 and gives up), and job A still forms with its own ranks."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 21000 + (os.getpid() % 2000)
+    a0 = ctx.Process(target=_token_worker, args=(0, 2, port, b"job-A", q))
+    intruder = ctx.Process(target=_token_worker, args=(1, 2, port, b"job-B", q))
+    a0.start()
+    intruder.start()
+    first = q.get(timeout=60)
+    assert first[0] == 1 and first[1] == "refused"            # the foreign rank never got in
+    a1 = ctx.Process(target=_token_worker, args=(1, 2, port, b"job-A", q))
+    a1.start()
+    got = sorted([q.get(timeout=60), q.get(timeout=60)])
+    for p in (a0, intruder, a1):
+        p.join(timeout=30)
+    assert [g[:2] for g in got] == [(0, "joined"), (1, "joined")]
+    assert got[0][2] == [b"\x00", b"\x01"]
