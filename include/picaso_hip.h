@@ -108,6 +108,16 @@ int picaso_comm_wait_slot(picaso_comm *comm, int slot);
 int picaso_comm_max(picaso_comm *comm, double *value);
 int picaso_comm_sum(picaso_comm *comm, double *value);
 int picaso_comm_barrier(picaso_comm *comm);
+/* One thread driving ALL communicators of picaso_comm_init_all (rank order): the per-device calls of one
+ * collective sit inside one ncclGroupStart / End and nothing is waited for before every rank is posted.
+ * (picaso_all_gather_dev, picaso_comm_max / _sum / _barrier issue one rank's call and are for one thread -- or
+ * process -- per communicator.)  recv[i], on device i, receives every device's block; counts == NULL: equal
+ * blocks of `count` elements, else counts[r] elements of rank r at displs[r].  Replaces the gather step of the
+ * reference's joblib fan-out (justdoit.py:4774) for the single-process form, SURVEY 8(e). */
+int picaso_all_gather_group_dev(int n, picaso_comm *const *comms, const double *const *send, double *const *recv,
+                                size_t count, const size_t *counts, const size_t *displs);
+int picaso_comm_group_max(int n, picaso_comm *const *comms, double *values /* [n], in and out */);
+int picaso_comm_group_barrier(int n, picaso_comm *const *comms);
 
 /* ---- Toon89 two-stream reflected light ---------------------------------------------------- */
 /* replaces fluxes.get_reflected_1d (reference picaso/fluxes.py:1009-1413).

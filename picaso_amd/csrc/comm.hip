@@ -47,6 +47,21 @@ int picaso_comm_unique_id(void *id128)
     return 0;
 }
 
+// releases whatever of a communicator exists (also the clean-up of a failed set-up); no synchronisation
+static void comm_release(picaso_comm *c)
+{
+    if (!c) return;
+    if (c->ctx) (void)hipSetDevice(c->ctx->device);
+    if (c->comm) (void)ncclCommDestroy(c->comm);
+    if (c->scratch) (void)hipFree(c->scratch);
+    for (int i = 0; i < picaso_comm::NSLOT; ++i)
+        if (c->done[i]) (void)hipEventDestroy(c->done[i]);
+    if (c->ready) (void)hipEventDestroy(c->ready);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+// takes ownership of `c` (destroyed with everything else when the set-up fails)
 static int comm_finish(picaso_ctx *ctx, ncclComm_t c, int nranks, int rank, picaso_comm **out)
 {
     picaso_comm *pc = new picaso_comm();
@@ -60,12 +75,24 @@ static int comm_finish(picaso_ctx *ctx, ncclComm_t c, int nranks, int rank, pica
     for (int i = 0; i < picaso_comm::NSLOT && e == hipSuccess; ++i)
         e = hipEventCreateWithFlags(&pc->done[i], hipEventDisableTiming);
     if (e != hipSuccess) {
-        delete pc;
+        comm_release(pc);
         return fail(ctx, "picaso_comm: set-up failed: %s", hipGetErrorString(e));
     }
     *out = pc;
     return 0;
 }
+
+// an error inside an open ncclGroupStart / End must close the group before returning: every later collective of
+// this thread would otherwise join a group that never ends
+#define PZ_NCCL_IN_GROUP(ctx, expr)                                                               \
+    do {                                                                                          \
+        ncclResult_t r__ = (expr);                                                                \
+        if (r__ != ncclSuccess) {                                                                 \
+            (void)ncclGroupEnd();                                                                 \
+            return pz::fail(ctx, "%s failed: %s (%s:%d)", #expr, ncclGetErrorString(r__), __FILE__, \
+                            __LINE__);                                                            \
+        }                                                                                         \
+    } while (0)
 
 int picaso_comm_init_rank(picaso_ctx *ctx, int nranks, int rank, const void *id128, picaso_comm **out)
 {
@@ -88,11 +115,24 @@ int picaso_comm_init_all(int ndev, picaso_ctx *const *ctxs, picaso_comm **out)
         if (!ctxs[i]) return fail(nullptr, "picaso_comm_init_all: null context %d", i);
         devs[i] = ctxs[i]->device;
     }
+    for (int i = 0; i < ndev; ++i)
+        for (int j = 0; j < i; ++j)
+            if (devs[i] == devs[j])
+                return fail(ctxs[0], "picaso_comm_init_all: device %d listed twice (RCCL takes one rank per device)", devs[i]);
     std::vector<ncclComm_t> cs(ndev);
     PZ_NCCL(ctxs[0], ncclCommInitAll(cs.data(), ndev, devs.data()));
+    for (int i = 0; i < ndev; ++i) out[i] = nullptr;
     for (int i = 0; i < ndev; ++i) {
-        PZ_HIP(ctxs[i], hipSetDevice(devs[i]));
-        PZ_TRY(comm_finish(ctxs[i], cs[i], ndev, i, &out[i]));
+        int rc = (hipSetDevice(devs[i]) == hipSuccess) ? comm_finish(ctxs[i], cs[i], ndev, i, &out[i])
+                                                       : fail(ctxs[i], "picaso_comm_init_all: hipSetDevice(%d) failed", devs[i]);
+        if (rc != 0) {                       // nothing half-built is left behind
+            for (int j = 0; j < ndev; ++j) {
+                if (out[j]) comm_release(out[j]);
+                else if (j > i) (void)ncclCommDestroy(cs[j]);
+                out[j] = nullptr;
+            }
+            return rc;
+        }
     }
     return 0;
 }
@@ -103,13 +143,7 @@ void picaso_comm_destroy(picaso_comm *c)
     (void)hipSetDevice(c->ctx->device);
     (void)hipStreamSynchronize(c->ctx->stream);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    if (c->comm) (void)ncclCommDestroy(c->comm);
-    if (c->scratch) (void)hipFree(c->scratch);
-    for (int i = 0; i < picaso_comm::NSLOT; ++i)
-        if (c->done[i]) (void)hipEventDestroy(c->done[i]);
-    if (c->ready) (void)hipEventDestroy(c->ready);
-    if (c->stream) (void)hipStreamDestroy(c->stream);
-    delete c;
+    comm_release(c);
 }
 
 int picaso_comm_rank(const picaso_comm *c, int *rank, int *nranks)
@@ -142,17 +176,18 @@ int picaso_all_gather_async_dev(picaso_comm *c, const double *send, double *recv
     if (!c) return fail(nullptr, "picaso_all_gather_async_dev: null communicator");
     picaso_ctx *ctx = c->ctx;
     if (slot < 0 || slot >= picaso_comm::NSLOT) return fail(ctx, "picaso_all_gather_async_dev: slot must be 0..3");
+    if (!send || !recv) return fail(ctx, "picaso_all_gather_async_dev: null buffer");
+    if (counts && !displs) return fail(ctx, "picaso_all_gather_async_dev: counts without displs");
     PZ_HIP(ctx, hipSetDevice(ctx->device));
     PZ_HIP(ctx, hipEventRecord(c->ready, ctx->stream));
     PZ_HIP(ctx, hipStreamWaitEvent(c->stream, c->ready, 0));
     if (!counts) {
         PZ_NCCL(ctx, ncclAllGather(send, recv, count, ncclDouble, c->comm, c->stream));
     } else {
-        if (!displs) return fail(ctx, "picaso_all_gather_async_dev: counts without displs");
         PZ_NCCL(ctx, ncclGroupStart());
         for (int r = 0; r < c->nranks; ++r) {
             const double *src = (r == c->rank) ? send : recv + displs[r];
-            PZ_NCCL(ctx, ncclBroadcast(src, recv + displs[r], counts[r], ncclDouble, r, c->comm, c->stream));
+            PZ_NCCL_IN_GROUP(ctx, ncclBroadcast(src, recv + displs[r], counts[r], ncclDouble, r, c->comm, c->stream));
         }
         PZ_NCCL(ctx, ncclGroupEnd());
     }
@@ -178,11 +213,11 @@ int picaso_all_gather_multi_async_dev(picaso_comm *c, int n, const double *const
     PZ_NCCL(ctx, ncclGroupStart());
     for (int i = 0; i < n; ++i) {
         if (!counts) {
-            PZ_NCCL(ctx, ncclAllGather(send[i], recv[i], count, ncclDouble, c->comm, c->stream));
+            PZ_NCCL_IN_GROUP(ctx, ncclAllGather(send[i], recv[i], count, ncclDouble, c->comm, c->stream));
         } else {
             for (int r = 0; r < c->nranks; ++r) {
                 const double *src = (r == c->rank) ? send[i] : recv[i] + displs[r];
-                PZ_NCCL(ctx, ncclBroadcast(src, recv[i] + displs[r], counts[r], ncclDouble, r, c->comm, c->stream));
+                PZ_NCCL_IN_GROUP(ctx, ncclBroadcast(src, recv[i] + displs[r], counts[r], ncclDouble, r, c->comm, c->stream));
             }
         }
     }
@@ -220,13 +255,109 @@ int picaso_all_gatherv_dev(picaso_comm *c, const double *send, double *recv, con
     PZ_NCCL(ctx, ncclGroupStart());
     for (int r = 0; r < c->nranks; ++r) {
         const double *src = (r == c->rank) ? send : recv + displs[r];
-        PZ_NCCL(ctx, ncclBroadcast(src, recv + displs[r], counts[r], ncclDouble, r, c->comm, ctx->stream));
+        PZ_NCCL_IN_GROUP(ctx, ncclBroadcast(src, recv + displs[r], counts[r], ncclDouble, r, c->comm, ctx->stream));
     }
     PZ_NCCL(ctx, ncclGroupEnd());
     return 0;
 }
 
+/* --------------------------------------------------------------------------------------------------------
+ * One thread driving several communicators (picaso_comm_init_all): RCCL requires the per-device calls of ONE
+ * collective to sit inside one ncclGroupStart / End -- issued one communicator after the other, the first call
+ * waits for peers that the same thread has not posted yet.  These entry points take all communicators of the
+ * process at once; nothing is synchronised before every rank has been posted.
+ * -------------------------------------------------------------------------------------------------------- */
+static int group_check(int n, picaso_comm *const *cs, const char *what)
+{
+    if (n < 1 || !cs) return fail(nullptr, "%s: bad arguments", what);
+    for (int i = 0; i < n; ++i) {
+        if (!cs[i]) return fail(nullptr, "%s: null communicator %d", what, i);
+        if (cs[i]->nranks != n || cs[i]->rank != i)
+            return fail(cs[i]->ctx, "%s: communicator %d is rank %d of %d; pass all %d communicators of "
+                        "picaso_comm_init_all in rank order", what, i, cs[i]->rank, cs[i]->nranks, n);
+    }
+    return 0;
+}
+
+// recv[i] (on device i) <- the blocks send[0..n-1] of all devices; counts == NULL: equal blocks of `count`.
+// Enqueued on every context's own stream behind the kernels that produced its block.
+int picaso_all_gather_group_dev(int n, picaso_comm *const *cs, const double *const *send, double *const *recv,
+                                size_t count, const size_t *counts, const size_t *displs)
+{
+    PZ_TRY(group_check(n, cs, "picaso_all_gather_group_dev"));
+    if (!send || !recv) return fail(cs[0]->ctx, "picaso_all_gather_group_dev: null buffer list");
+    if (counts && !displs) return fail(cs[0]->ctx, "picaso_all_gather_group_dev: counts without displs");
+    for (int i = 0; i < n; ++i) {
+        if (!send[i] || !recv[i]) return fail(cs[i]->ctx, "picaso_all_gather_group_dev: null buffer of rank %d", i);
+        PZ_TRY(picaso_comm_wait_slot(cs[i], -1));
+    }
+    picaso_ctx *ctx0 = cs[0]->ctx;
+    PZ_NCCL(ctx0, ncclGroupStart());
+    for (int i = 0; i < n; ++i) {
+        picaso_ctx *ctx = cs[i]->ctx;
+        if (hipSetDevice(ctx->device) != hipSuccess) {
+            (void)ncclGroupEnd();
+            return fail(ctx, "picaso_all_gather_group_dev: hipSetDevice(%d) failed", ctx->device);
+        }
+        if (!counts) {
+            PZ_NCCL_IN_GROUP(ctx, ncclAllGather(send[i], recv[i], count, ncclDouble, cs[i]->comm, ctx->stream));
+        } else {
+            for (int r = 0; r < n; ++r) {
+                const double *src = (r == i) ? send[i] : recv[i] + displs[r];
+                PZ_NCCL_IN_GROUP(ctx, ncclBroadcast(src, recv[i] + displs[r], counts[r], ncclDouble, r, cs[i]->comm,
+                                                    ctx->stream));
+            }
+        }
+    }
+    PZ_NCCL(ctx0, ncclGroupEnd());
+    return 0;
+}
+
+// every device's stream has drained and every rank's reduction has arrived; values[i] <- reduction over ranks
+static int group_allreduce_host(int n, picaso_comm *const *cs, double *values, ncclRedOp_t op, const char *what)
+{
+    PZ_TRY(group_check(n, cs, what));
+    if (!values) return fail(cs[0]->ctx, "%s: null values", what);
+    for (int i = 0; i < n; ++i) {
+        picaso_ctx *ctx = cs[i]->ctx;
+        PZ_HIP(ctx, hipSetDevice(ctx->device));
+        PZ_TRY(picaso_comm_wait_slot(cs[i], -1));
+        PZ_HIP(ctx, hipMemcpyAsync(cs[i]->scratch, values + i, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    }
+    PZ_NCCL(cs[0]->ctx, ncclGroupStart());
+    for (int i = 0; i < n; ++i) {
+        if (hipSetDevice(cs[i]->ctx->device) != hipSuccess) {
+            (void)ncclGroupEnd();
+            return fail(cs[i]->ctx, "%s: hipSetDevice(%d) failed", what, cs[i]->ctx->device);
+        }
+        PZ_NCCL_IN_GROUP(cs[i]->ctx, ncclAllReduce(cs[i]->scratch, cs[i]->scratch, 1, ncclDouble, op, cs[i]->comm,
+                                                   cs[i]->ctx->stream));
+    }
+    PZ_NCCL(cs[0]->ctx, ncclGroupEnd());
+    for (int i = 0; i < n; ++i) {            // only now, with every rank posted, is anything waited for
+        picaso_ctx *ctx = cs[i]->ctx;
+        PZ_HIP(ctx, hipSetDevice(ctx->device));
+        PZ_HIP(ctx, hipMemcpyAsync(values + i, cs[i]->scratch, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    }
+    for (int i = 0; i < n; ++i) {
+        PZ_HIP(cs[i]->ctx, hipSetDevice(cs[i]->ctx->device));
+        PZ_HIP(cs[i]->ctx, hipStreamSynchronize(cs[i]->ctx->stream));
+    }
+    return 0;
+}
+int picaso_comm_group_max(int n, picaso_comm *const *cs, double *values)
+{
+    return group_allreduce_host(n, cs, values, ncclMax, "picaso_comm_group_max");
+}
+int picaso_comm_group_barrier(int n, picaso_comm *const *cs)
+{
+    std::vector<double> ones((size_t)(n > 0 ? n : 1), 1.0);
+    return group_allreduce_host(n, cs, ones.data(), ncclSum, "picaso_comm_group_barrier");
+}
+
 // max / sum of one host double over the ranks (timing reductions of the launcher); synchronises.
+// ONE THREAD PER COMMUNICATOR: with several communicators in one thread (picaso_comm_init_all) use
+// picaso_comm_group_max / picaso_comm_group_barrier, which post every rank before anything is waited for.
 static int allreduce_host(picaso_comm *c, double *value, ncclRedOp_t op)
 {
     if (!c || !value) return fail(nullptr, "picaso_comm reduce: null argument");

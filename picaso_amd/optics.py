@@ -291,6 +291,44 @@ class RetrieveCKs:
                 raise Exception("RetrieveCKs: on_fly=True needs per-gas kappas")
             self.get_opacities = self.get_opacities_deq_onfly
 
+    @classmethod
+    def from_files(cls, ck_db, continuum_db, method="preweighted", preload_gases="all", rayleigh_opa=None,
+                   ctx=None, refdata=None):
+        """The reference's constructor ``RetrieveCKs(ck_dir, continuum_db, method, preload_gases)``
+        (optics.py:676-722): ``method='preweighted'`` reads ONE premixed HDF5 table, ``'resortrebin'`` a directory
+        of per-gas tables for on-the-fly mixing (``read_ck_tables``); the continuum comes from the sqlite database
+        the reference ships (``read_continuum_db``).  The legacy ``ascii_data`` / ``full_abunds`` directory form
+        (optics.py:772-1058; deprecated there) is not read.  Rayleigh cross sections are data supplied by the
+        caller, as for the monochromatic tables."""
+        if method not in ("preweighted", "resortrebin"):
+            raise Exception("Only resortrebin and preweighted are options for Correlated-Ks")
+        if method == "preweighted" and os.path.isdir(ck_db):
+            raise Exception("method='preweighted' reads the premixed HDF5 file; the legacy ascii_data / full_abunds "
+                            "directory of the reference (deprecated there) is not supported: %s" % ck_db)
+        t = read_ck_tables(ck_db, preload_gases=preload_gases if method == "resortrebin" else None, refdata=refdata)
+        cwno, continuum, cia_temps = read_continuum_db(continuum_db)
+        if cwno.shape != np.shape(t["wno"]) or not np.allclose(cwno, t["wno"], rtol=1e-6):
+            raise Exception("the continuum database %s is on a different wavenumber grid (%d points) than the "
+                            "k-tables (%d)" % (continuum_db, cwno.size, np.size(t["wno"])))
+        # ragged grid: pressure / temperature of every table point, temperature-major (optics.py:1095-1141)
+        temps, nc_p = np.asarray(t["temps"], dtype=float), np.asarray(t["nc_p"], dtype=int)
+        press = np.asarray(t["pressures"], dtype=float)
+        pressures = np.concatenate([press[:n] for n in nc_p])
+        temps_flat = np.concatenate([[tt] * n for tt, n in zip(np.unique(temps), nc_p)])
+        kw = dict(continuum=continuum, cia_temps=cia_temps, rayleigh_opa=rayleigh_opa, ctx=ctx)
+        if method == "preweighted":
+            if "kappa" not in t:
+                raise Exception("method='preweighted' needs the premixed HDF5 file, got a directory: %s" % ck_db)
+            obj = cls(t["wno"], t["gauss_wts"], pressures, temps_flat, nc_p, ln_kappa=t["kappa"],
+                      gauss_pts=t["gauss_pts"], **kw)
+            obj.full_abunds = {k: t["abunds"][:, i] for i, k in enumerate(t["abunds_map"])}
+        else:
+            obj = cls(t["wno"], t["gauss_wts"], pressures, temps_flat, nc_p, kappas=t["kappas"],
+                      gauss_pts=t["gauss_pts"], on_fly=True, **kw)
+        obj.delta_wno = np.asarray(t["delta_wno"], dtype=float)
+        obj.ck_filename, obj.continuum_db, obj.preload_gases = ck_db, continuum_db, t["molecules"]
+        return obj
+
     def get_opacities(self, atmosphere, exclude_mol=1):
         """Table rows / weights for this atmosphere (``get_opacities_preweighted``: continuum +
         ``get_pre_mix_ck``, reference optics.py:1500-1538)."""
@@ -402,6 +440,173 @@ class RetrieveCKs:
         _gas_call(self, nlayer, [], None, None, None, [self._cia[key]], pl["cia_rows"][None],
                   np.ones((1, nlayer)), [], None, tg, tr, mol_mode=0, cont_wts=pl["cia_wts"][None], ngauss=1)
         return tg.to_host()
+
+
+# ------------------------------------------------------------------------------------------------
+# correlated-k table files -> arrays (the readers in front of the device-resident tables)
+# ------------------------------------------------------------------------------------------------
+def g_w_2gauss(order=4, gfrac=0.95):
+    """Abscissae and weights of the two-part Gauss quadrature of the k-tables (reference
+    opacity_factory.py:1474-1503): ``order`` Gauss-Legendre points on [0, gfrac] and on [gfrac, 1]."""
+    g, w = np.polynomial.legendre.leggauss(order)
+    return (np.concatenate((gfrac * 0.5 * (g + 1.0), gfrac + (1.0 - gfrac) * 0.5 * (g + 1.0))),
+            np.concatenate((gfrac * w * 0.5, (1.0 - gfrac) * w * 0.5)))
+
+
+def _h5py():
+    try:
+        import h5py
+    except ImportError as e:       # not a dependency of the solver path: only these readers need it
+        raise Exception("reading HDF5 correlated-k tables needs the h5py package (pip install h5py); the "
+                        "tables can also be handed to RetrieveCKs as arrays") from e
+    return h5py
+
+
+def read_continuum_db(continuum_db):
+    """``(wno, {pair: {T: kappa(wno)}}, cia_temps)`` from the sqlite continuum database the reference ships
+    for its k-tables (tables ``header`` / ``continuum``; reference optics.py:1067-1079, 1398-1498)."""
+    if not os.path.isfile(continuum_db):
+        raise Exception("The continuum opacity file does not exist: %s" % continuum_db)
+    conn = sqlite3.connect(continuum_db)
+    cur = conn.cursor()
+    cur.execute("SELECT wavenumber_grid FROM header")
+    wno = _convert_array(cur.fetchone()[0])
+    continuum, cia_temps = {}, set()
+    cur.execute("SELECT molecule, temperature, opacity FROM continuum")
+    for mol, t, blob in cur.fetchall():
+        continuum.setdefault(mol, {})[float(t)] = _convert_array(blob)
+        cia_temps.add(float(t))
+    conn.close()
+    return wno, continuum, np.array(sorted(cia_temps))
+
+
+def read_ck_tables(path, preload_gases=None, refdata=None):
+    """The reference's ``get_ck_tables`` (opacity_factory.py:2221-2327, the successor of
+    ``RetrieveCKs.get_h5_data``, optics.py:725-770, and ``load_kcoeff_arrays_first``): either ONE premixed HDF5
+    file (datasets ``ck_molecules, wno, delta_wno, pressures, temperatures, gauss_pts, gauss_wts, kcoeffs
+    [npres, ntemp, nwno, ngauss] = ln kappa, abunds, abunds_map``; ``nc_p`` = table points per temperature) or
+    a DIRECTORY of per-gas tables for on-the-fly mixing (``<gas>_1460.hdf5`` with the same datasets plus ``nc_p``,
+    or ``<gas>_1460.npy`` arrays on the 661-bin grid, whose axes come from ``$picaso_refdata``:
+    ``climate_INPUTS/wvno_661`` and ``opacities/grid1460.csv``, with the 2 x 4-point Gauss set).  Returns plain
+    numpy arrays: ``wno, delta_wno, pressures, temps, nc_p, gauss_pts, gauss_wts, molecules`` and ``kappa``
+    (premixed) or ``kappas`` {gas: table}."""
+    out = {}
+    if os.path.isfile(path) and ((".hdf5" in path) or (".h5" in path)):
+        h5py = _h5py()
+        with h5py.File(path, "r") as f:
+            out["molecules"] = [x.decode("utf-8") for x in f["ck_molecules"][:]]
+            out["wno"], out["delta_wno"] = f["wno"][:], f["delta_wno"][:]
+            pres, temp = np.asarray(f["pressures"][:], dtype=float), np.asarray(f["temperatures"][:], dtype=float)
+            out["gauss_pts"], out["gauss_wts"] = f["gauss_pts"][:], f["gauss_wts"][:]
+            out["kappa"] = f["kcoeffs"][:]
+            out["abunds"] = np.asarray(f["abunds"][:])
+            out["abunds_map"] = [x.decode("utf-8") for x in f["abunds_map"][:]]
+        # table points per temperature, temperatures in increasing order (pandas groupby('temperature').size())
+        ut = np.unique(temp)
+        out["nc_p"] = np.array([int(np.sum(temp == t)) for t in ut])
+        out["temps"], out["pressures"] = ut, np.unique(pres)
+        return out
+    if not os.path.isdir(path):
+        raise Exception("The CK filename that you have selected does not exist. Please make sure you have "
+                        "downloaded and unpacked the right CK file.")
+    import glob
+    if preload_gases is None or (isinstance(preload_gases, str) and preload_gases == "all"):
+        found = sorted(glob.glob(os.path.join(path, "*.hdf5"))) or sorted(glob.glob(os.path.join(path, "*.npy")))
+        if not found:
+            raise Exception("No .npy or .hdf5 molecule files were found in %s" % path)
+        preload_gases = [os.path.basename(f).split("_")[0] for f in found]       # justdoit.py:1397-1407
+    elif isinstance(preload_gases, str):
+        preload_gases = [preload_gases]
+    out["kappas"] = {}
+    for mol in preload_gases:
+        f5, fn = os.path.join(path, "%s_1460.hdf5" % mol), os.path.join(path, "%s_1460.npy" % mol)
+        if os.path.isfile(f5):
+            h5py = _h5py()
+            with h5py.File(f5, "r") as f:
+                out["wno"], out["delta_wno"] = f["wno"][:], f["delta_wno"][:]
+                out["pressures"], out["temps"] = np.unique(f["pressures"][:]), np.unique(f["temperatures"][:])
+                out["gauss_pts"], out["gauss_wts"] = f["gauss_pts"][:], f["gauss_wts"][:]
+                out["nc_p"] = np.array([int(i) for i in f["nc_p"][:]])
+                out["kappas"][mol] = f["kcoeffs"][:]
+        elif os.path.isfile(fn):
+            ref = refdata or os.environ.get("picaso_refdata")
+            if ref is None:
+                raise Exception("the .npy k-tables take their axes from $picaso_refdata (climate_INPUTS/wvno_661, "
+                                "opacities/grid1460.csv): set the picaso_refdata environment variable")
+            out["wno"], out["delta_wno"] = np.loadtxt(os.path.join(ref, "climate_INPUTS", "wvno_661"),
+                                                      usecols=[0, 1], unpack=True)
+            grid = np.genfromtxt(os.path.join(ref, "opacities", "grid1460.csv"), delimiter=",", names=True)
+            t_all, p_all = np.asarray(grid["temperature_K"], dtype=float), np.asarray(grid["pressure_bar"], dtype=float)
+            # pandas .unique(): order of first appearance; groupby().size(): increasing temperature
+            _, ip = np.unique(p_all, return_index=True)
+            _, it = np.unique(t_all, return_index=True)
+            out["pressures"], out["temps"] = p_all[np.sort(ip)], t_all[np.sort(it)]
+            out["nc_p"] = np.array([int(np.sum(t_all == t)) for t in np.unique(t_all)])
+            out["gauss_pts"], out["gauss_wts"] = g_w_2gauss(order=4, gfrac=0.95)
+            out["kappas"][mol] = np.load(fn)
+    if not out["kappas"]:
+        raise Exception("Uh oh. No molecules are left to mix. Its likely you have not downloaded the correct files.")
+    out["molecules"] = list(out["kappas"].keys())
+    return out
+
+
+def shard_opacity(opa, lo, hi, ctx):
+    """The wavelength block ``[lo, hi)`` of an opacity object (``RetrieveOpacities`` or ``RetrieveCKs``) with
+    its tables resident on ANOTHER context / GPU: the multi-GPU form of ``picaso()`` (``devices=N``) cuts the
+    grid of one spectrum into contiguous blocks and keeps each block's tables on its own device.
+    Every function on the path is pointwise in wavelength, so a shard is a complete opacity object of ``hi - lo``
+    wavelengths; per-wavelength host vectors are sliced, tables are sliced along their wavelength axis (Gauss
+    index fastest inside a wavelength for correlated-k tables) and uploaded once.  ``[0, nwno)`` on the object's
+    own context is the object itself."""
+    import copy
+    lo, hi = int(lo), int(hi)
+    if not (0 <= lo < hi <= opa.nwno):
+        raise Exception("shard_opacity: block [%d, %d) outside the %d-point grid" % (lo, hi, opa.nwno))
+    same_ctx = getattr(ctx, "value", ctx) == getattr(opa.ctx, "value", opa.ctx)
+    if lo == 0 and hi == opa.nwno and same_ctx:
+        return opa
+    nwno, ng = opa.nwno, opa.ngauss
+    s = copy.copy(opa)
+    s.ctx = ctx
+    s.nwno = hi - lo
+    s.wno = np.ascontiguousarray(opa.wno[lo:hi])
+    s.wave = 1e4 / s.wno
+    s._plan = None
+    s.__dict__.pop("_resident_vectors", None)
+    s.__dict__.pop("_shards", None)
+    s.__dict__.pop("_replicas", None)
+    s.molecular_opa, s.continuum_opa = ({} if isinstance(opa.molecular_opa, dict) else None), {}
+
+    def cols(d, per=1):
+        """device table (..., nwno*per) -> its columns of the block, on ctx"""
+        if d is None:
+            return None
+        shape = tuple(d.shape)
+        h = d.to_host().reshape((-1, nwno * per))
+        out = DeviceArray.from_host(np.ascontiguousarray(h[:, lo * per:hi * per]), ctx)
+        if len(shape) == 1:
+            return out.reshape(((hi - lo) * per,))
+        return out
+    for name in ("_mol_raw", "_mol_log", "_cia"):
+        if hasattr(opa, name):
+            setattr(s, name, {k: cols(v) for k, v in getattr(opa, name).items()})
+    if getattr(opa, "_kappa", None) is not None:
+        s._kappa = cols(opa._kappa, ng)
+    if hasattr(opa, "_kappas"):
+        s._kappas = {}
+        for m, tab in opa._kappas.items():
+            npres, ntemp = tab.shape[0], tab.shape[1]
+            s._kappas[m] = cols(tab, ng).reshape((npres, ntemp, hi - lo, ng))
+    s.rayleigh_opa = {k: np.ascontiguousarray(v[lo:hi]) for k, v in opa.rayleigh_opa.items()}
+    s._ray = {k: DeviceArray.from_host(v, ctx) for k, v in s.rayleigh_opa.items()}
+    # per-wavelength host attributes callers hang on the opacity object (stellar spectrum, Raman shifts, bin widths)
+    for name in ("relative_flux", "unshifted_stellar_spec", "delta_wno", "raman_stellar_shifts"):
+        v = getattr(opa, name, None)
+        if isinstance(v, np.ndarray) and v.shape[:1] == (nwno,):
+            setattr(s, name, np.ascontiguousarray(v[lo:hi]))
+    if hasattr(opa, "get_opacities") and getattr(opa, "on_fly", False):
+        s.get_opacities = s.get_opacities_deq_onfly          # bound method of the shard, not of the parent
+    return s
 
 
 class _LazyPlanes(dict):

@@ -354,3 +354,68 @@ class Comm:
         if self.handle:
             _lib.load().picaso_comm_destroy(self.handle)
             self.handle = None
+
+
+class DeviceGroup:
+    """One process driving several GPUs: one context per device, the communicators of ``picaso_comm_init_all``,
+    and collectives that post every device's call inside one RCCL group (``picaso_all_gather_group_dev``) --
+    a thread that issued them one communicator after the other would wait in the first call for peers it has
+    not posted yet.  ``devices``: device indices, each at most once (RCCL takes one rank per device)."""
+
+    def __init__(self, devices):
+        self.devices = [int(d) for d in devices]
+        if len(set(self.devices)) != len(self.devices):
+            raise _lib.PicasoHipError("DeviceGroup: every device at most once, got %s" % self.devices)
+        ndev = _lib.device_count()
+        if not self.devices or max(self.devices) >= ndev or min(self.devices) < 0:
+            raise _lib.PicasoHipError("DeviceGroup: devices %s but %d GPU(s) visible" % (self.devices, ndev))
+        self.ctxs = [_lib.context(d) for d in self.devices]
+        lib = _lib.load()
+        n = len(self.ctxs)
+        arr = (ctypes.c_void_p * n)(*[c.value for c in self.ctxs])
+        out = (ctypes.c_void_p * n)()
+        _lib.check(lib.picaso_comm_init_all(ctypes.c_int(n), arr, out), self.ctxs[0])
+        self._handles = (ctypes.c_void_p * n)(*[out[i] for i in range(n)])
+        self.world = n
+
+    def all_gather_spectrum(self, locals_, fulls, nwno):
+        """``locals_[i]`` (device i's block of ``shard_bounds(nwno, n)``) -> ``fulls[i]`` (nwno) on every device."""
+        n = self.world
+        bounds = shard_bounds(nwno, n)
+        counts = [hi - lo for lo, hi in bounds]
+        if len(set(counts)) == 1:
+            c = d = None
+        else:
+            c = (ctypes.c_size_t * n)(*counts)
+            d = (ctypes.c_size_t * n)(*[lo for lo, _ in bounds])
+        snd = (ctypes.c_void_p * n)(*[int(x.addr) for x in locals_])
+        rcv = (ctypes.c_void_p * n)(*[int(x.addr) for x in fulls])
+        _lib.check(_lib.load().picaso_all_gather_group_dev(ctypes.c_int(n), self._handles, snd, rcv,
+                                                           ctypes.c_size_t(counts[0]), c, d), self.ctxs[0])
+
+    def max(self, values):
+        n = self.world
+        v = (ctypes.c_double * n)(*[float(x) for x in values])
+        _lib.check(_lib.load().picaso_comm_group_max(ctypes.c_int(n), self._handles, v), self.ctxs[0])
+        return [v[i] for i in range(n)]
+
+    def barrier(self):
+        _lib.check(_lib.load().picaso_comm_group_barrier(ctypes.c_int(self.world), self._handles), self.ctxs[0])
+
+    def destroy(self):
+        if self._handles is not None:
+            for h in self._handles:
+                if h:
+                    _lib.load().picaso_comm_destroy(ctypes.c_void_p(h))
+            self._handles = None
+
+
+_device_groups = {}
+
+
+def device_group(devices):
+    """The process's DeviceGroup for this device list (communicators are created once and kept)."""
+    key = (os.getpid(), tuple(int(d) for d in devices))
+    if key not in _device_groups:
+        _device_groups[key] = DeviceGroup(devices)
+    return _device_groups[key]

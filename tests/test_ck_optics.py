@@ -188,7 +188,7 @@ def test_gpu_patchy_clouds_end_to_end(og, oracle):
     from picaso_amd import disco
     from picaso_amd import justdoit as jdi
     fhole, fthin = 0.3, 0.1
-    opa = jdi.opannection(DB, query_method="linear")
+    opa = jdi.opannection(filename_db=DB, query_method="linear")
     case = _case(og, jdi, True)
     case.clouds(df={"opd": og["in/cld_opd"], "w0": og["in/cld_w0"], "g0": og["in/cld_g0"]}, do_holes=True,
                 fhole=fhole, fthin_cld=fthin)
@@ -235,7 +235,7 @@ def test_gpu_3d_spectrum_end_to_end(og, oracle):
     from picaso_amd import justdoit as jdi
     ng, nt = 2, 3
     fac = 0.25 + np.arange(ng * nt).reshape(ng, nt) / 4.0
-    opa = jdi.opannection(DB, query_method="linear")
+    opa = jdi.opannection(filename_db=DB, query_method="linear")
     case = jdi.inputs()
     case.phase_angle(np.pi / 3, num_gangle=ng, num_tangle=nt)
     case.gravity(gravity=float(og["in/gravity"]))
@@ -291,7 +291,7 @@ def test_gpu_3d_batched_facets_equal_per_facet_loop(og, raman, radius, monkeypat
     per-facet Raman plane."""
     from picaso_amd import justdoit as jdi
     ng, nt = 4, 3
-    opa = jdi.opannection(DB, query_method="linear")
+    opa = jdi.opannection(filename_db=DB, query_method="linear")
     if raman == "oklopcic":
         gold = np.load(os.path.join(GOLDEN, "optics.npz"))
         opa.raman_stellar_shifts = gold["in/raman_shifts"]
@@ -332,7 +332,7 @@ def test_gpu_3d_planes_rederived_in_the_solvers_bit_identical(og, cloudy, raman,
     spectra are bit-identical to those from the full set of 13 planes (PICASO_AMD_ALL_PLANES=1)."""
     from picaso_amd import justdoit as jdi
     ng, nt = 3, 2
-    opa = jdi.opannection(DB, query_method="linear")
+    opa = jdi.opannection(filename_db=DB, query_method="linear")
     if raman == "oklopcic":
         gold = np.load(os.path.join(GOLDEN, "optics.npz"))
         opa.raman_stellar_shifts = gold["in/raman_shifts"]
@@ -448,7 +448,7 @@ def test_gpu_phase_curve_equals_single_phase_runs(og, calc):
     same phases run one at a time through phase_angle() + atmosphere_3d() + spectrum(dimension='3d')
     (thermal phase curves integrate over the phase-0 geometry, justdoit.py:1648-1653)."""
     from picaso_amd import justdoit as jdi
-    opa = jdi.opannection(DB, query_method="linear")
+    opa = jdi.opannection(filename_db=DB, query_method="linear")
     ng, nt = 3, 2
     phases = [0.0, 0.9, 2.0]
     nlevel = len(og["in/tlevel"])
@@ -488,7 +488,7 @@ def test_gpu_phase_curve_against_oracle_solver(og, oracle):
     every phase, next to the self-consistency test above."""
     from picaso_amd import disco, optics
     from picaso_amd import justdoit as jdi
-    opa = jdi.opannection(DB, query_method="linear")
+    opa = jdi.opannection(filename_db=DB, query_method="linear")
     ng, nt = 4, 3
     phases = [0.0, 0.7, 1.9, 3.0, 4.4]
     nlevel = len(og["in/tlevel"])

@@ -65,7 +65,7 @@ def test_oracle_reproduces_table(oracle):
 @pytest.mark.gpu
 def test_gpu_spectrum_matches_oracle_and_table(oracle):
     from picaso_amd import justdoit as jdi
-    opa = jdi.opannection(os.path.join(GOLDEN, "synthetic_opacities.db"))
+    opa = jdi.opannection(filename_db=os.path.join(GOLDEN, "synthetic_opacities.db"))
     w0s, tab = table()
     case = jdi.inputs()
     case.phase_angle(0)

@@ -145,7 +145,7 @@ def test_gpu_compute_opacity(gold, qm, pollack_table):
     from picaso_amd import justdoit as jdi
     from picaso_amd import optics as px
     from picaso_amd.atmsetup import ATMSETUP
-    opa = jdi.opannection(DB, query_method=qm)
+    opa = jdi.opannection(filename_db=DB, query_method=qm)
     assert opa.nwno == len(gold["in/wno"])
     opa.raman_stellar_shifts = gold["in/raman_shifts"]
     opa.raman_db = {"c": gold["in/raman_c"], "ji": gold["in/raman_ji"], "deltanu": gold["in/raman_deltanu"]}
@@ -178,7 +178,7 @@ def test_gpu_spectrum_end_to_end(gold, oracle):
     fixture -> CPU oracle solvers]."""
     from picaso_amd import disco
     from picaso_amd import justdoit as jdi
-    opa = jdi.opannection(DB, query_method="linear")
+    opa = jdi.opannection(filename_db=DB, query_method="linear")
     case = _bundle(gold, jdi, None, True, 2, 2)
     case.surface_reflect(0.2)
     out = case.spectrum(opa, calculation="reflected+thermal", full_output=True)
@@ -213,7 +213,7 @@ def test_gpu_spectrum_sh4_end_to_end(gold, oracle):
     planes from the fixture -> CPU oracle SH solvers (LAPACK-style banded LU)]."""
     from picaso_amd import disco
     from picaso_amd import justdoit as jdi
-    opa = jdi.opannection(DB, query_method="linear")
+    opa = jdi.opannection(filename_db=DB, query_method="linear")
     opa.raman_stellar_shifts = gold["in/raman_shifts"]
     opa.raman_db = {"c": gold["in/raman_c"], "ji": gold["in/raman_ji"], "deltanu": gold["in/raman_deltanu"]}
     case = _bundle(gold, jdi, None, True, 4, 0)
@@ -245,7 +245,7 @@ def test_gpu_symmetry_quadrant_equals_full_disk(gold):
     """phase_angle(symmetry=True): the 3x2 quadrant with the reference's doubled weights gives the
     full 6x4 disk's albedo and thermal flux for a horizontally uniform planet at full phase."""
     from picaso_amd import justdoit as jdi
-    opa = jdi.opannection(DB, query_method="linear")
+    opa = jdi.opannection(filename_db=DB, query_method="linear")
     outs = []
     for sym in (False, True):
         case = _bundle(gold, jdi, None, True, 2, 2)
@@ -262,7 +262,7 @@ def test_gpu_spectrum_pollack_raman(gold, oracle, pollack_table):
     """approx(raman='pollack') end to end against the reference's compute_opacity(raman=1) planes."""
     from picaso_amd import disco
     from picaso_amd import justdoit as jdi
-    opa = jdi.opannection(DB, query_method="linear")
+    opa = jdi.opannection(filename_db=DB, query_method="linear")
     case = _bundle(gold, jdi, None, True, 2, 1)
     out = case.spectrum(opa, calculation="reflected")
     P = {nm: gold["linear/de1_s2_r1_tmnone/" + nm] for nm in NAMES}
@@ -298,7 +298,7 @@ def test_oracle_thinned_cloud_planes(gold):
 def test_gpu_thinned_cloud_planes(gold, qm):
     from picaso_amd import justdoit as jdi
     from picaso_amd import optics as px
-    opa = jdi.opannection(DB, query_method=qm)
+    opa = jdi.opannection(filename_db=DB, query_method=qm)
     case = _bundle(gold, jdi, None, True, 2, 2)
     atm = jdi._setup_atmosphere(case.inputs, opa, opa.wno)
     opa.get_opacities(atm)
@@ -313,7 +313,7 @@ def test_gpu_single_leg_spectra_equal_the_combined_run(gold):
     """A thermal-only (reflected-only) spectrum asks the mixing kernel for 3 (11) of its 13 planes;
     the results are those of the combined run bit for bit."""
     from picaso_amd import justdoit as jdi
-    opa = jdi.opannection(DB, query_method="linear")
+    opa = jdi.opannection(filename_db=DB, query_method="linear")
     both = _bundle(gold, jdi, None, True, 2, 2).spectrum(opa, calculation="reflected+thermal")
     th = _bundle(gold, jdi, None, True, 2, 2).spectrum(opa, calculation="thermal")
     rf = _bundle(gold, jdi, None, True, 2, 2).spectrum(opa, calculation="reflected")
@@ -327,7 +327,7 @@ def test_gpu_overlapped_legs_stress(gold):
     two alternating atmospheres must each reproduce their single-leg results bit for bit (a missing
     stream dependency would let one call's thermal kernel read the next call's planes)."""
     from picaso_amd import justdoit as jdi
-    opa = jdi.opannection(DB, query_method="linear")
+    opa = jdi.opannection(filename_db=DB, query_method="linear")
     cases, want = [], []
     for k in range(2):
         c = _bundle(gold, jdi, None, True, 2, 2)
@@ -353,7 +353,7 @@ def test_gpu_spectrum_level_fluxes_output_contract(gold, oracle):
     get_lvl_flux -> those reference lines restated with the oracle's compress_*]."""
     from picaso_amd import disco
     from picaso_amd import justdoit as jdi
-    opa = jdi.opannection(DB, query_method="linear")
+    opa = jdi.opannection(filename_db=DB, query_method="linear")
     case = _bundle(gold, jdi, None, True, 2, 2)
     case.surface_reflect(0.2)
     case.approx(raman="none", delta_eddington=True, get_lvl_flux=True)
@@ -404,7 +404,7 @@ def test_gpu_spectrum_config0_196_points_60_layers(oracle):
     from picaso_amd import disco
     from picaso_amd import justdoit as jdi
     g196 = np.load(os.path.join(GOLDEN, "optics_196x60.npz"))
-    opa = jdi.opannection(os.path.join(GOLDEN, "synthetic_opacities_196x60.db"), query_method="linear")
+    opa = jdi.opannection(filename_db=os.path.join(GOLDEN, "synthetic_opacities_196x60.db"), query_method="linear")
     assert opa.nwno == 196 and len(g196["in/tlevel"]) == 61
     case = _bundle(g196, jdi, None, True, 2, 2)
     case.surface_reflect(0.1)

@@ -110,7 +110,7 @@ def test_gpu_transmission_end_to_end(oracle, kind):
         ck = np.load(os.path.join(os.path.dirname(__file__), "golden", "ck.npz"))
         opa, wts = tck._ck_class(ck), ck["in/gauss_wts"]
     else:
-        opa, wts = jdi.opannection(tck.DB, query_method="linear"), np.array([1.0])
+        opa, wts = jdi.opannection(filename_db=tck.DB, query_method="linear"), np.array([1.0])
     fhole, fthin = 0.35, 0.2
     case = _transit_case(og, jdi, **(dict(do_holes=True, fhole=fhole, fthin_cld=fthin) if kind == "holes" else {}))
     out = case.spectrum(opa, calculation="transmission", full_output=True)
@@ -136,4 +136,4 @@ def test_gpu_transmission_needs_radii():
     case = _transit_case(og, jdi)
     case.gravity(gravity=2500.0)
     with pytest.raises(Exception, match="radius"):
-        case.spectrum(jdi.opannection(tck.DB, query_method="linear"), calculation="transmission")
+        case.spectrum(jdi.opannection(filename_db=tck.DB, query_method="linear"), calculation="transmission")
