@@ -68,12 +68,116 @@ _DEFAULTS = {   # reference/config.json
 }
 
 
-def opannection(filename_db, wave_range=None, resample=1, query_method="nearest",
-                rayleigh_opa=None):
-    """Open a monochromatic opacity DB (reference schema) as HBM-resident tables
-    (reference ``opannection``, justdoit.py:1296-1419, monochromatic branch)."""
-    return optics.RetrieveOpacities.from_sqlite(filename_db, wave_range=wave_range, resample=resample,
-                                                query_method=query_method, rayleigh_opa=rayleigh_opa)
+def _refdata():
+    ref = os.environ.get("picaso_refdata")
+    if ref is None:
+        raise Exception("no file was given and the picaso_refdata environment variable is not set: the default "
+                        "opacity files are looked up under $picaso_refdata/opacities, as in the reference")
+    return ref
+
+
+def opannection(wave_range=None, filename_db=None, resample=1, method="resampled", ck_db=None, raman_db=None,
+                preload_gases="all", verbose=False, query_method="nearest", rayleigh_opa=None):
+    """Opacity connection with the reference's keywords in the reference's order (``opannection``,
+    justdoit.py:1296-1419): the tables are read once and stay resident in HBM.
+
+    ``method='resampled'`` (default): monochromatic sqlite database ``filename_db`` (default, as in the
+    reference, the first ``$picaso_refdata/opacities/opacities*.db``) -> ``RetrieveOpacities``;
+    ``'preweighted'``: premixed correlated-k HDF5 file ``ck_db`` + continuum database ``filename_db`` (default
+    ``$picaso_refdata/opacities/ck_cx_cont_opacities.db``) -> ``RetrieveCKs``; ``'resortrebin'``: directory
+    ``ck_db`` of per-gas k-tables (``preload_gases``) mixed on the fly.  ``query_method`` ('nearest' |
+    'linear': how (P,T) table points are combined, an attribute the reference sets on the class afterwards) and
+    ``rayleigh_opa`` (Rayleigh cross sections as data) are additions after the reference's keywords."""
+    import glob
+    if isinstance(wave_range, (str, bytes, os.PathLike)):
+        raise Exception("opannection(wave_range=None, filename_db=None, ...): the first positional argument is "
+                        "wave_range, as in the reference; pass the database as filename_db=%r" % (wave_range,))
+    if method == "resampled" and ck_db is None:
+        if filename_db is None:
+            found = sorted(glob.glob(os.path.join(_refdata(), "opacities", "opacities*.db")))
+            if not found:
+                raise Exception("Could not find anything with the naming scheme opacities*.db in the opacities "
+                                "folder. Please use the get_data function to download an opacity file.")
+            if len(found) > 1 and verbose:
+                print("Found more than one opacity database. Choosing the first one.")
+            filename_db = found[0]
+        elif not os.path.isfile(filename_db):
+            raise Exception("The opacity file you have entered does not exist: " + str(filename_db))
+        if resample != 1 and verbose:
+            print("YOU ARE REQUESTING RESAMPLING!! This could degrade the precision of your spectral calculations "
+                  "so should be used with caution.")
+        opa = optics.RetrieveOpacities.from_sqlite(filename_db, wave_range=wave_range, resample=resample,
+                                                   query_method=query_method, rayleigh_opa=rayleigh_opa)
+        if verbose:
+            print("verbose=True; Molecule set=", opa.molecules)
+        return opa
+    if method == "resampled":
+        raise Exception("ck_db was supplied but method is set to resampled. Change kwarg method='preweighted' to "
+                        "use the preweighted ck tables")
+    if method == "preweighted":
+        if filename_db is None:
+            filename_db = os.path.join(_refdata(), "opacities", "ck_cx_cont_opacities.db")
+        if ck_db is None or not os.path.exists(ck_db):
+            if ck_db is not None and os.path.isfile(str(ck_db).rstrip("/") + ".tar.gz"):
+                raise Exception("The CK filename that you have selected appears still be .tar.gz. Please unpack "
+                                "and rerun")
+            raise Exception("The CK filename that you have selected does not exist. Please make sure you have "
+                            "downloaded and unpacked the right CK file.")
+        return optics.RetrieveCKs.from_files(ck_db, filename_db, method="preweighted", rayleigh_opa=rayleigh_opa)
+    if method == "resortrebin":
+        if filename_db is None:
+            filename_db = os.path.join(_refdata(), "climate_INPUTS", "ck_cx_cont_opacities_661.db")
+        if ck_db is None:
+            ck_db = os.path.join(_refdata(), "opacities", "resortrebin")
+        return optics.RetrieveCKs.from_files(ck_db, filename_db, method="resortrebin", preload_gases=preload_gases,
+                                             rayleigh_opa=rayleigh_opa)
+    raise Exception("The only available opacity methods are: resortrebin, preweighted, and resampled")
+
+
+_UNIT_CGS = {   # plain-string stand-ins for the astropy units of the reference's tutorials -> cgs factors
+    "cm/s**2": 1.0, "cm/(s**2)": 1.0, "cm/s2": 1.0, "m/s**2": 100.0, "m/(s**2)": 100.0, "m/s2": 100.0,
+    "cm": 1.0, "m": 100.0, "km": 1e5, "rjup": 7.1492e9, "r_jup": 7.1492e9, "jupiterrad": 7.1492e9,
+    "rearth": 6.3781e8, "r_earth": 6.3781e8, "earthrad": 6.3781e8, "rsun": 6.957e10, "r_sun": 6.957e10,
+    "g": 1.0, "kg": 1e3, "mjup": 1.8981246e30, "m_jup": 1.8981246e30, "jupitermass": 1.8981246e30,
+    "mearth": 5.9721679e27, "m_earth": 5.9721679e27, "earthmass": 5.9721679e27, "msun": 1.98840987e33,
+    "m_sun": 1.98840987e33, "au": 1.495978707e13,
+}
+
+
+def _to_cgs(value, unit, what):
+    """``value * unit`` in cgs.  ``unit``: None (already cgs), a number (the cgs value of one unit), a unit
+    string of ``_UNIT_CGS``, or an astropy unit / quantity when astropy is installed (duck-typed: ``.to``)."""
+    if unit is None:
+        return float(value)
+    if isinstance(unit, (int, float, np.floating, np.integer)):
+        return float(value) * float(unit)
+    if isinstance(unit, str):
+        key = unit.strip().lower().replace(" ", "")
+        if key not in _UNIT_CGS:
+            raise Exception("%s: unit %r not known; give a cgs value (unit=None), a factor, or one of %s"
+                            % (what, unit, sorted(_UNIT_CGS)))
+        return float(value) * _UNIT_CGS[key]
+    if hasattr(unit, "to") or hasattr(value * unit, "to"):            # astropy
+        target = {"gravity": "cm/s2", "radius": "cm", "mass": "g"}[what]
+        return float((value * unit).to(target).value)
+    raise Exception("%s: cannot interpret unit %r" % (what, unit))
+
+
+def get_cld_input_grid(filename_or_grid="wave_EGP.dat"):
+    """Wavenumbers (increasing) of the 196-point grid cloud tables come on (reference wavelength.py:9-40):
+    ``$picaso_refdata/opacities/wave_EGP.dat`` (whitespace table with a 'wavenumber' column) or an array."""
+    if isinstance(filename_or_grid, np.ndarray):
+        return np.sort(filename_or_grid)
+    path = filename_or_grid
+    if not os.path.isabs(path):
+        path = os.path.join(_refdata(), "opacities", filename_or_grid)
+    if not os.path.isfile(path):
+        raise Exception("cloud wavenumber grid %s not found" % path)
+    with open(path) as fh:
+        header = fh.readline().split()
+        col = header.index("wavenumber")
+        vals = [float(line.split()[col]) for line in fh if line.strip()]
+    return np.sort(np.array(vals))
 
 
 class inputs:
@@ -136,13 +240,26 @@ class inputs:
         if nt > 1:
             self.inputs["disco"]["symmetry"] = "false"
 
-    def gravity(self, gravity=None, radius=np.nan, mass=np.nan):
-        """Surface gravity in cm/s^2 (cgs; the reference takes astropy units, justdoit.py:1663)."""
-        if gravity is None:
-            if np.isnan(radius) or np.isnan(mass):
-                raise Exception("Need to specify gravity or radius and mass")
-            gravity = 6.6743e-8 * mass / radius ** 2
-        self.inputs["planet"].update(gravity=float(gravity), radius=radius, mass=mass)
+    def gravity(self, gravity=None, gravity_unit=None, radius=None, radius_unit=None, mass=None, mass_unit=None):
+        """Surface gravity from ``gravity`` or from ``radius`` and ``mass``, with the reference's keywords in the
+        reference's order (justdoit.py:1663-1702).  A ``*_unit`` of ``None`` means the value is already cgs
+        (cm/s^2, cm, g); otherwise a unit string ('m/s**2', 'rjup', 'mjup', 'rearth', ...), a cgs factor, or an
+        astropy unit when astropy is installed."""
+        if radius is not None and isinstance(radius, float) and np.isnan(radius):
+            radius = None
+        if mass is not None and isinstance(mass, float) and np.isnan(mass):
+            mass = None
+        planet = self.inputs["planet"]
+        if (mass is not None) and (radius is not None):
+            m, r = _to_cgs(mass, mass_unit, "mass"), _to_cgs(radius, radius_unit, "radius")
+            g = 6.6743e-8 * m / r ** 2              # as the reference: mass and radius win over `gravity`
+            planet.update(radius=r, radius_unit="cm", mass=m, mass_unit="g", gravity=g, gravity_unit="cm/(s**2)")
+        elif gravity is not None:
+            planet.update(gravity=_to_cgs(gravity, gravity_unit, "gravity"), gravity_unit="cm/(s**2)",
+                          radius=np.nan, radius_unit="Radius not specified", mass=np.nan,
+                          mass_unit="Mass not specified")
+        else:
+            raise Exception("Need to specify gravity or radius and mass + additional units")
 
     def star(self, opannection=None, relative_flux=None, radius=np.nan, semi_major=np.nan):
         """Stellar flux per wavelength bin on the opacity grid (``F0PI``).  ``None`` = 'nostar'
@@ -162,10 +279,54 @@ class inputs:
         self.inputs["atmosphere"]["exclude_mol"] = exclude_mol
         self.nlevel = len(df["pressure"])
 
-    def clouds(self, df=None, wavenumber=None, do_holes=False, fhole=None, fthin_cld=None):
-        """Cloud opd / w0 / g0 per (layer, wavelength) (reference justdoit.py:4126)."""
-        self.inputs["clouds"].update(profile=df, wavenumber=wavenumber, do_holes=do_holes,
-                                     fhole=fhole, fthin_cld=fthin_cld)
+    def clouds(self, filename=None, g0=None, w0=None, opd=None, p=None, dp=None, df=None, do_holes=False,
+               fhole=None, fthin_cld=None, wavenumber=None, **pd_kwargs):
+        """Cloud ``opd`` / ``w0`` / ``g0`` per (layer, wavelength) with the reference's keywords in the reference's
+        order (justdoit.py:4126-4268): a table (``df`` dict / DataFrame, or ``filename`` read with pandas), or box
+        clouds -- lists ``g0, w0, opd`` with bottom pressures ``p`` and thicknesses ``dp`` (log10 bar), laid on the
+        196-point cloud wavenumber grid of ``$picaso_refdata/opacities/wave_EGP.dat`` exactly as the reference does.
+        ``wavenumber`` (an addition): the table's own grid when it has no 'wavenumber' column and is not on the
+        opacity grid."""
+        if not hasattr(self, "nlevel"):
+            raise Exception("Please make sure to run `atmosphere` before adding clouds")
+        nlayer = self.nlevel - 1
+        if (filename is not None) != (df is not None):
+            if filename is not None:
+                import pandas as pd
+                df = pd.read_csv(filename, **pd_kwargs)
+            cols = list(df.keys())
+            for k in ("g0", "w0", "opd"):
+                if k not in cols:
+                    raise Exception("Please make sure %s is a named column in cld file" % k)
+            if ("pressure" in cols) and ("wavenumber" in cols):      # sort by (pressure, wavenumber), :4211-4216
+                pr, wn = np.asarray(df["pressure"], dtype=float), np.asarray(df["wavenumber"], dtype=float)
+                order = np.lexsort((wn, pr))
+                grid = np.unique(wn)
+                if pr.size != nlayer * grid.size:
+                    raise Exception("There are %d rows in the df, which does not equal %d layers previously "
+                                    "specified x %d wave pts" % (pr.size, nlayer, grid.size))
+                df = {k: np.asarray(df[k], dtype=float)[order] for k in ("opd", "w0", "g0")}
+                wavenumber = grid
+            self.inputs["clouds"].update(profile=df, wavenumber=wavenumber)
+        elif filename is not None:
+            raise Exception("give either filename or df, not both")
+        elif None in [g0, w0, opd, p, dp]:
+            raise Exception("Must either give dataframe/dict, OR a complete set of g0, w0, opd,p,dp to compute cloud "
+                            "profile")
+        else:                                                       # box clouds, justdoit.py:4235-4266
+            plev = np.asarray(self.inputs["atmosphere"]["profile"]["pressure"], dtype=float)
+            player = np.sqrt(plev[1:] * plev[:-1])
+            wgrid = get_cld_input_grid("wave_EGP.dat")
+            prof = {k: np.zeros((nlayer, wgrid.size)) for k in ("g0", "w0", "opd")}
+            for ig, iw, io, ip, idp in zip(*[np.atleast_1d(x) for x in (g0, w0, opd, p, dp)]):
+                inside = (player >= 10 ** (ip - idp)) & (player <= 10 ** ip)
+                prof["g0"][inside], prof["w0"][inside], prof["opd"][inside] = ig, iw, io
+            self.inputs["clouds"].update(profile=prof, wavenumber=wgrid)
+        self.inputs["clouds"]["do_holes"] = do_holes
+        if do_holes:
+            if fhole is None:
+                raise Exception("fhole must be float 0-1 if do_holes = True")
+            self.inputs["clouds"].update(fhole=fhole, fthin_cld=fthin_cld)
 
     def atmosphere_3d(self, profiles, exclude_mol=1):
         """Per-facet level profiles for ``spectrum(dimension='3d')``: ``pressure`` (nlevel,) in bar,

@@ -147,3 +147,133 @@ def test_phase_curve_geometry():
         c.phase_curve_geometry("thermal", [0.0, 7.0])
     with pytest.raises(Exception, match="one profile per phase"):
         c.phase_curve(None)
+
+
+# ------------------------------------------------------------------------------------------------
+# keyword surface of the top-level builders: the reference's names in the reference's order
+# (justdoit.py:1296 opannection, :1663 gravity, :4126 clouds, :4779 spectrum) -- written out here, the
+# reference source is not on the GPU box
+# ------------------------------------------------------------------------------------------------
+def _names(f):
+    import inspect
+    return [p for p in inspect.signature(f).parameters if p != "self"]
+
+
+def test_builder_signatures_start_with_the_reference_keywords():
+    assert _names(jdi.opannection)[:8] == ["wave_range", "filename_db", "resample", "method", "ck_db", "raman_db",
+                                           "preload_gases", "verbose"]
+    assert _names(jdi.inputs.gravity) == ["gravity", "gravity_unit", "radius", "radius_unit", "mass", "mass_unit"]
+    assert _names(jdi.inputs.clouds)[:10] == ["filename", "g0", "w0", "opd", "p", "dp", "df", "do_holes", "fhole",
+                                              "fthin_cld"]
+    assert _names(jdi.inputs.spectrum)[:6] == ["opacityclass", "calculation", "dimension", "full_output",
+                                               "plot_opacity", "as_dict"]
+    assert _names(jdi.picaso)[:7] == ["bundle", "opacityclass", "dimension", "calculation", "full_output",
+                                      "plot_opacity", "as_dict"]
+
+
+def test_gravity_with_the_tutorial_keyword_sets():
+    c = jdi.inputs()
+    c.gravity(gravity=25, gravity_unit="m/s**2")                       # tutorial: u.Unit('m/(s**2)')
+    assert c.inputs["planet"]["gravity"] == 2500.0 and np.isnan(c.inputs["planet"]["radius"])
+    c.gravity(gravity=2479.0)                                           # plain cgs float, unit None
+    assert c.inputs["planet"]["gravity"] == 2479.0
+    c.gravity(radius=1.0, radius_unit="rjup", mass=1.0, mass_unit="mjup")
+    pl = c.inputs["planet"]
+    assert pl["radius"] == 7.1492e9 and pl["mass"] == 1.8981246e30
+    assert np.isclose(pl["gravity"], 6.6743e-8 * 1.8981246e30 / 7.1492e9 ** 2)
+    assert 2400 < pl["gravity"] < 2600
+    c.gravity(radius=7.0e9, mass=1.9e30)                                # cgs floats
+    assert np.isclose(c.inputs["planet"]["gravity"], 6.6743e-8 * 1.9e30 / 49e18)
+    with pytest.raises(Exception, match="Need to specify gravity or radius and mass"):
+        c.gravity()
+    with pytest.raises(Exception, match="unit"):
+        c.gravity(gravity=1, gravity_unit="furlong/fortnight**2")
+
+
+def _write_cloud_grid(tmp_path, monkeypatch, n=196):
+    d = tmp_path / "opacities"
+    d.mkdir()
+    wn = np.round(np.linspace(40.0, 33000.0, n)[::-1], 2)              # decreasing, as the shipped table
+    with open(d / "wave_EGP.dat", "w") as fh:
+        fh.write("   i   micron.    wavenumber idum     idum1    idum2     idum3\n")
+        for i, w in enumerate(wn):
+            fh.write("%4d %9.3f %9.2f %8.2f- %7.2f %9.3f %9.3f\n" % (i + 1, 1e4 / w, w, w - 1, w + 1, 2.0, w))
+    monkeypatch.setenv("picaso_refdata", str(tmp_path))
+    return np.sort(wn)
+
+
+def test_box_clouds_with_the_tutorial_keyword_set(tmp_path, monkeypatch):
+    wgrid = _write_cloud_grid(tmp_path, monkeypatch)
+    c = jdi.inputs()
+    with pytest.raises(Exception, match="atmosphere"):
+        c.clouds(g0=[0.9], w0=[0.99], opd=[0.5], p=[0.0], dp=[1.0])
+    nlevel = 31
+    plev = np.logspace(-5, 2, nlevel)
+    c.atmosphere(df={"pressure": plev, "temperature": np.linspace(150, 1200, nlevel), "H2": np.ones(nlevel)})
+    c.clouds(g0=[0.9, 0.5], w0=[0.99, 0.8], opd=[0.5, 2.0], p=[0.0, -2.0], dp=[1.0, 0.5])   # two decks
+    cl = c.inputs["clouds"]
+    assert np.array_equal(cl["wavenumber"], wgrid) and cl["do_holes"] is False
+    player = np.sqrt(plev[1:] * plev[:-1])
+    in1 = (player >= 10 ** -1.0) & (player <= 10 ** 0.0)
+    in2 = (player >= 10 ** -2.5) & (player <= 10 ** -2.0)
+    assert in1.any() and in2.any()
+    for k, v1, v2 in (("g0", 0.9, 0.5), ("w0", 0.99, 0.8), ("opd", 0.5, 2.0)):
+        a = cl["profile"][k]
+        assert a.shape == (nlevel - 1, 196)
+        assert np.all(a[in1] == v1) and np.all(a[in2] == v2) and np.all(a[~(in1 | in2)] == 0)
+    # ATMSETUP puts the 196-point table onto the opacity grid
+    c.gravity(gravity=2500.0)
+    atm = ATMSETUP(c.inputs)
+    atm.get_profile()
+    wno = np.linspace(3000.0, 20000.0, 57)
+    atm.get_clouds(wno)
+    assert atm.layer["cloud"]["opd"].shape == (nlevel - 1, 57)
+    assert np.all(atm.layer["cloud"]["opd"][in1] == 0.5) and np.all(atm.layer["cloud"]["w0"][in2] == 0.8)
+    with pytest.raises(Exception, match="complete set"):
+        c.clouds(g0=[0.9], w0=[0.9], opd=[1.0], p=[0.0])
+    with pytest.raises(Exception, match="fhole"):
+        c.clouds(g0=[0.9], w0=[0.9], opd=[1.0], p=[0.0], dp=[1.0], do_holes=True)
+    c.clouds(g0=[0.9], w0=[0.9], opd=[1.0], p=[0.0], dp=[1.0], do_holes=True, fhole=0.3, fthin_cld=0.1)
+    assert cl["do_holes"] is True and cl["fhole"] == 0.3 and cl["fthin_cld"] == 0.1
+
+
+def test_cloud_table_with_pressure_and_wavenumber_columns_is_sorted_like_the_reference():
+    c = jdi.inputs()
+    nlevel = 4
+    plev = np.logspace(-3, 0, nlevel)
+    c.atmosphere(df={"pressure": plev, "temperature": np.full(nlevel, 500.0), "H2": np.ones(nlevel)})
+    pl = np.sqrt(plev[1:] * plev[:-1])
+    wn = np.array([100.0, 200.0, 300.0, 400.0, 500.0])
+    pp, ww = np.meshgrid(pl, wn, indexing="ij")
+    opd = pp * 1000 + ww
+    rng = np.random.default_rng(5)
+    perm = rng.permutation(opd.size)                                    # rows in any order
+    df = {"pressure": pp.ravel()[perm], "wavenumber": ww.ravel()[perm], "opd": opd.ravel()[perm],
+          "w0": np.full(opd.size, 0.9), "g0": np.full(opd.size, 0.1)}
+    c.clouds(df=df)
+    assert np.array_equal(c.inputs["clouds"]["wavenumber"], wn)
+    assert np.array_equal(np.asarray(c.inputs["clouds"]["profile"]["opd"]).reshape(3, 5), opd)
+    with pytest.raises(Exception, match="rows in the df"):
+        c.clouds(df={k: v[:-1] for k, v in df.items()})
+    with pytest.raises(Exception, match="opd is a named column"):
+        c.clouds(df={"w0": 1, "g0": 1})
+
+
+def test_opannection_reference_keywords_and_errors(tmp_path, monkeypatch):
+    monkeypatch.delenv("picaso_refdata", raising=False)
+    with pytest.raises(Exception, match="first positional argument is wave_range"):
+        jdi.opannection("opacities.db")
+    with pytest.raises(Exception, match="picaso_refdata"):
+        jdi.opannection()
+    with pytest.raises(Exception, match="does not exist"):
+        jdi.opannection(filename_db=str(tmp_path / "nope.db"))
+    with pytest.raises(Exception, match="ck_db was supplied but method is set to resampled"):
+        jdi.opannection(ck_db="somewhere")
+    with pytest.raises(Exception, match="CK filename that you have selected does not exist"):
+        jdi.opannection(method="preweighted", ck_db=str(tmp_path / "nope.hdf5"), filename_db="x.db")
+    with pytest.raises(Exception, match="only available opacity methods"):
+        jdi.opannection(method="linebyline")
+    (tmp_path / "opacities").mkdir()
+    monkeypatch.setenv("picaso_refdata", str(tmp_path))
+    with pytest.raises(Exception, match="naming scheme opacities"):
+        jdi.opannection()
