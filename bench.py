@@ -170,23 +170,25 @@ def workload_sh4(ctx, args, lo, hi, seed, nwno_total):
 
 
 def workload_3d(ctx, args, lo, hi, seed, nwno_total):
-    """configs[4]: get_reflected_3d on 8x8 facets + compress_disco; facet index fastest in memory."""
+    """configs[4]: get_reflected_3d on 8x8 facets + compress_disco; facet index fastest in memory.  The 64 facet
+    plane sets are generated ON THE DEVICE: every (nlayer, n) base plane is uploaded once and tiled
+    over the facets by picaso_broadcast_facets_dev, the optical-depth planes times a per-facet factor -- at the
+    stated size (--nwno 100000 on one GPU) that is 51 GB of planes from 0.8 GB of host arrays."""
     nlayer, nlevel = args.nlayer, args.nlayer + 1
     ng = nt = 8
     n = hi - lo
+    phase = np.pi / 3                                            # SURVEY 8(d): ubar0 != ubar1, cos_theta = 0.5
     gang, gw, tang, tw = disco.get_angles_3d(ng, nt)
-    ubar0, ubar1, ct, _, _ = disco.compute_disco(ng, nt, gang, tang, 0.0)
+    ubar0, ubar1, ct, _, _ = disco.compute_disco(ng, nt, gang, tang, phase)
     base = syn.make_scene(nlayer, n, seed=seed + 7 * lo)
     rng = np.random.default_rng(seed)
     fac = 1.0 + 0.05 * rng.standard_normal(ng * nt)          # facet-to-facet variation of the optical depths
+    scaled = ("dtau", "tau", "dtau_og", "tau_og")
     d = {}
     for k in resident.REFLECTED_PLANES:
-        a = base[k]
-        if k in ("dtau", "tau", "dtau_og", "tau_og"):
-            a3 = a[:, :, None] * fac[None, None, :]
-        else:
-            a3 = np.repeat(a[:, :, None], ng * nt, axis=2)
-        d[k] = device.DeviceArray.from_host(np.ascontiguousarray(a3), ctx)
+        src = device.DeviceArray.from_host(base[k], ctx)
+        d[k] = device.broadcast_facets(src, ng * nt, fac if k in scaled else None, ctx)
+        src.free()
     f0 = device.DeviceArray.from_host(np.ones(n), ctx)
     rs = device.DeviceArray.from_host(np.zeros(n), ctx)
     xint = device.DeviceArray((ng, nt, n), ctx)
@@ -195,10 +197,24 @@ def workload_3d(ctx, args, lo, hi, seed, nwno_total):
         resident.reflected_3d(ctx, nlevel, n, ng, nt, d, rs, ubar0, ubar1, float(ct), f0, 0, 0, *TTHG, xint,
                               gweight=gw, tweight=tw, albedo=albedo)
 
-    return dict(solve=solve, oracle=None, nloc=n,
+    def oracle(sl):
+        from oracle import oracle as orc
+        ns = sl.stop - sl.start
+        planes = []
+        for k in resident.REFLECTED_PLANES:
+            a = np.ascontiguousarray(base[k][:, sl])
+            a3 = a[:, :, None] * fac[None, None, :] if k in scaled else np.repeat(a[:, :, None], ng * nt, axis=2)
+            planes.append(np.ascontiguousarray(a3).reshape(a.shape[0], ns, ng, nt))
+        xo = orc.get_reflected_3d(nlevel, base["wno"][sl], ns, ng, nt, *planes, np.zeros(ns), ubar0, ubar1,
+                                  float(ct), np.ones(ns), 0, 0, *TTHG)
+        xo = xo[0] if isinstance(xo, tuple) else xo
+        return orc.compress_disco(ns, float(ct), xo, gw, tw, np.ones(ns))
+
+    return dict(solve=solve, oracle=oracle, nloc=n, oracle_sample=256,
                 abytes=8 * n * (ng * nt * (9 * nlayer + 2 * nlevel + 1) + 2 + 1),
                 kernel="k_reflected_toa<1, true, false, false, false, false>",
-                workload="BASELINE configs[4]: 3-D reflected light, 8x8 facets (get_reflected_3d + compress_disco)",
+                workload="BASELINE configs[4]: 3-D reflected light, 8x8 facets at phase pi/3 (get_reflected_3d + "
+                         "compress_disco), facet planes generated on the device",
                 metric="spectra/sec (%d wave x %d layer x 64 facet 3-D reflected)" % (nwno_total, nlayer))
 
 
@@ -259,6 +275,8 @@ def main():
                     help="untimed launches of the same step before the W warm-up steps (clock ramp)")
     ap.add_argument("--cpu-sample", type=int, default=100000,
                     help="wavelengths of the same workload timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--steady-steps", type=int, default=2000,
+                    help="N = 1: steps of an extra untimed run after the timed region, reported as steady_state")
     ap.add_argument("--rendezvous-only", action="store_true",
                     help="start the ranks, let them find each other (HostGroup) and exit: checks the launch path "
                          "of a node without touching a GPU")
@@ -350,6 +368,10 @@ def main():
             step(gather)
         return device.timer_stop(ctx) / nsteps
 
+    # ---- the first launches of a cold process (reported, not the metric): what ONE interactive call sees ----
+    device.sync(ctx)
+    cold_ms = timed(20, gather=False)
+    nstep[0] = 0
     # ---- clock ramp (untimed), warm-up, timed region ----
     # The time-based part launches the solve only (no collective: the ranks may run different numbers
     # of iterations); a fixed number of complete steps follows so that the gather is warm as well.
@@ -452,15 +474,26 @@ def main():
                                      "in the timed region" % G
                        if comm else "none"},
             "prewarm": {"ms": args.prewarm_ms, "launches": nprewarm, "why": "GPU clock ramp, untimed"},
+            "cold_ms_first_20": cold_ms,
             "wavelength_layer_updates_per_s": value * nwno_total / spectra_per_step * args.nlayer,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_source": ("profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                                            "these kernel sources, committed; not measured in this run)"
+                                            if traffic is not None else None),
                          "kernel": wl["kernel"], "kernel_ms": kernel_ms, "algorithmic_bytes": abytes,
                          "kernel_source_hash": src_hash},
         }
         if per_rank:
             out["per_rank"] = per_rank
             out["checks"] = checks
+        if world == 1 and args.steady_steps > 0:
+            # a long companion run (untimed by the driver): long enough for a utilisation sampler to see the
+            # GPU busy, and the check that the K timed steps above sit in the steady state
+            nst = max(50, min(args.steady_steps, int(1000.0 / max(ms_per_step, 1e-3))))     # about a second at most
+            for _ in range(50):
+                step()
+            out["steady_state"] = {"steps": nst, "ms_per_step": timed(nst)}
         if valu:
             # second ceiling: the kernel is FP64-VALU bound.  PMC instruction count of this launch shape
             # (profiles/) over the live kernel time, against the fp64 issue rate measured on an MI355X
@@ -470,7 +503,7 @@ def main():
             out["fp64_issue"] = {"achieved": rate, "peak_measured": peak, "unit": "T lane-instr/s",
                                  "frac": rate / peak, "valu_wave_insts_per_launch": valu}
         if world == 1 and args.cpu_sample > 0 and wl["oracle"] is not None:
-            ns = min(args.cpu_sample, nloc)
+            ns = min(args.cpu_sample, nloc, wl.get("oracle_sample", nloc))
             t1 = time.perf_counter()
             cpu = wl["oracle"](slice(0, ns))
             cpu_s = time.perf_counter() - t1

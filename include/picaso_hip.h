@@ -56,6 +56,9 @@ int picaso_memcpy_d2d(picaso_ctx *ctx, void *dst, const void *src, size_t bytes)
  * [w0, w0+n) of an (nlayer, nwno) host plane */
 int picaso_memcpy_h2d_2d(picaso_ctx *ctx, void *dst, size_t dpitch_bytes, const void *src,
                          size_t spitch_bytes, size_t width_bytes, size_t height);
+/* the reverse: read a wavelength block of a resident (rows, nwno[, nfacets]) plane back */
+int picaso_memcpy_d2h_2d(picaso_ctx *ctx, void *dst, size_t dpitch_bytes, const void *src,
+                         size_t spitch_bytes, size_t width_bytes, size_t height);
 int picaso_memset(picaso_ctx *ctx, void *dst, int value, size_t bytes);
 int picaso_sync(picaso_ctx *ctx);
 /* work enqueued on `waiter` after this call starts only when everything enqueued on `signaller` so
@@ -459,6 +462,13 @@ int picaso_compute_opacity_facets_dev(picaso_ctx *ctx, int nlayer, int nwno, int
                                       double *ftau_cld, double *ftau_ray, double *gcos2, double *dtau_og,
                                       double *tau_og, double *w0_og, double *cosb_og, double *w0_no_raman,
                                       double *f_deltaM);
+
+/* A (nrows, nwno) plane shared by all facets -> (nrows, nwno, nfacets), facet index fastest, optionally times
+ * facet_scale[f] (host array of nfacets, or NULL): cloud tables that do not vary over the disk, and the synthetic
+ * facet planes of bench.py --config 4, without building nfacets copies on the host (the reference tiles
+ * `DTAU_3d[:,:,g,t] = dtau` facet by facet on the CPU, justdoit.py:444-471). */
+int picaso_broadcast_facets_dev(picaso_ctx *ctx, size_t nrows, int nwno, int nfacets, const double *src,
+                                const double *facet_scale, double *dst);
 
 #ifdef __cplusplus
 }

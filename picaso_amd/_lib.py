@@ -30,6 +30,22 @@ def declared_symbols():
     return sorted(set(re.findall(r"\b(picaso_[A-Za-z0-9_]+)\s*\(", text)))
 
 
+def _share_hip_runtime_with_torch():
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own ``libamdhip64.so`` (the SONAME this
+    library links against); two copies of the runtime in one process cannot both own the GPUs (the second
+    reports "No HIP GPUs are available").  The product never imports PyTorch -- but when the CALLER's process
+    already has (``torch`` in ``sys.modules``), its runtime is mapped first so that the dynamic loader resolves
+    our dependency to that same copy.  Nothing happens in a process without torch.  (A caller that imports torch
+    AFTER this library gets two runtimes: import torch first; INTEGRATION.md.)"""
+    import sys
+    torch = sys.modules.get("torch")
+    if torch is None or getattr(getattr(torch, "version", None), "hip", None) is None:
+        return
+    bundled = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+    if os.path.exists(bundled):
+        ctypes.CDLL(bundled, mode=ctypes.RTLD_GLOBAL)
+
+
 def load():
     """Load the shared library (no GPU needed for this step)."""
     global _lib
@@ -39,6 +55,7 @@ def load():
         raise PicasoHipError(
             "picaso_amd: %s not found -- build it with `python -c 'import __graft_entry__ as g; "
             "g.build()'` (hipcc, gfx950).  There is no CPU fallback." % LIB_PATH)
+    _share_hip_runtime_with_torch()
     lib = ctypes.CDLL(LIB_PATH)
     lib.picaso_last_error.restype = ctypes.c_char_p
     lib.picaso_last_error.argtypes = [ctypes.c_void_p]

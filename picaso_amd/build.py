@@ -7,7 +7,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libpicaso_hip.so")
-HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+ROCM = os.environ.get("ROCM_PATH") or os.environ.get("ROCM_HOME") or "/opt/rocm"
+HIPCC = os.environ.get("HIPCC", os.path.join(ROCM, "bin", "hipcc"))
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-fast-math",
          "-Wall", "-Wno-unused-function"]
 
@@ -47,7 +48,9 @@ def stale():
 
 def build(force=False, verbose=False):
     if not force and not stale():
-        print("picaso_amd.build: libpicaso_hip.so reused (source hash %s matches)" % source_hash()[:12])
+        # progress goes to stderr: stdout belongs to the caller (bench.py owes its caller ONE JSON line)
+        print("picaso_amd.build: libpicaso_hip.so reused (source hash %s matches)" % source_hash()[:12],
+              file=sys.stderr)
         return LIB
     objs = []
     procs = []
@@ -58,7 +61,7 @@ def build(force=False, verbose=False):
         objs.append(obj)
         cmd = [HIPCC] + FLAGS + ["-c", src, "-o", obj]
         if verbose:
-            print(" ".join(cmd))
+            print(" ".join(cmd), file=sys.stderr)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
     for src, p in procs:
         out, _ = p.communicate()
@@ -66,13 +69,15 @@ def build(force=False, verbose=False):
             sys.stderr.write(out.decode())
             raise RuntimeError("hipcc failed on %s" % src)
         if verbose and out:
-            print(out.decode())
+            print(out.decode(), file=sys.stderr)
     # librccl.so: the multi-GPU layer (csrc/comm.hip) calls RCCL directly
+    rocm_lib = os.path.join(ROCM, "lib")
     subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs +
-                          ["-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"])
+                          ["-L" + rocm_lib, "-lrccl", "-Wl,-rpath," + rocm_lib])
     with open(STAMP, "w") as fh:
         fh.write(source_hash() + "\n")
-    print("picaso_amd.build: libpicaso_hip.so compiled for gfx950 (source hash %s)" % source_hash()[:12])
+    print("picaso_amd.build: libpicaso_hip.so compiled for gfx950 (source hash %s)" % source_hash()[:12],
+          file=sys.stderr)
     return LIB
 
 

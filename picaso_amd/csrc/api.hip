@@ -346,6 +346,16 @@ int picaso_memcpy_h2d_2d(picaso_ctx *ctx, void *dst, size_t dpitch, const void *
     PZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return 0;
 }
+int picaso_memcpy_d2h_2d(picaso_ctx *ctx, void *dst, size_t dpitch, const void *src, size_t spitch,
+                         size_t width, size_t height)
+{
+    if (!ctx) return fail(nullptr, "null context");
+    PZ_HIP(ctx, hipSetDevice(ctx->device));
+    PZ_HIP(ctx, hipMemcpy2DAsync(dst, dpitch, src, spitch, width, height, hipMemcpyDeviceToHost,
+                                 ctx->stream));
+    PZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
 int picaso_memset(picaso_ctx *ctx, void *dst, int value, size_t bytes)
 {
     PZ_HIP(ctx, hipMemsetAsync(dst, value, bytes, ctx->stream));
@@ -1038,8 +1048,8 @@ int picaso_get_thermal_3d(picaso_ctx *ctx, int nlevel, const double *wno, int nw
  * ============================================================================================ */
 // (gweight[g], tweight[t]) pairs in (g,t) loop order; small tables go with the kernel arguments
 static int compress_with_weights(picaso_ctx *ctx, size_t ninner, const double *x, const double *gweight, int ng,
-                                 const double *tweight, int nt, const double *F0PI, double c1, double c2,
-                                 double *out)
+                                 const double *tweight, int nt, const double *F0PI, int mode, double c1,
+                                 double c2, double *out)
 {
     if (ng < 1 || nt < 1) return fail(ctx, "compress: empty weight table");
     std::vector<double> wts(2 * (size_t)ng * nt);
@@ -1048,10 +1058,10 @@ static int compress_with_weights(picaso_ctx *ctx, size_t ninner, const double *x
             wts[2 * ((size_t)g * nt + t)] = gweight[g];
             wts[2 * ((size_t)g * nt + t) + 1] = tweight[t];
         }
-    if (ng * nt <= 128) return launch_compress_hostw(ctx, ninner, x, wts.data(), ng * nt, F0PI, c1, c2, out);
+    if (ng * nt <= 128) return launch_compress_hostw(ctx, ninner, x, wts.data(), ng * nt, F0PI, mode, c1, c2, out);
     const void *d = nullptr;
     PZ_TRY(table_upload(ctx, wts.data(), sizeof(double) * wts.size(), &d));
-    return launch_compress_dev(ctx, ninner, x, (const double *)d, ng * nt, F0PI, c1, c2, out);
+    return launch_compress_dev(ctx, ninner, x, (const double *)d, ng * nt, F0PI, mode, c1, c2, out);
 }
 
 int picaso_compress_disco_dev(picaso_ctx *ctx, int nwno, double cos_theta,
@@ -1061,8 +1071,8 @@ int picaso_compress_disco_dev(picaso_ctx *ctx, int nwno, double cos_theta,
     if (!ctx) return fail(nullptr, "null context");
     PZ_HIP(ctx, hipSetDevice(ctx->device));
     const double sym = (nt == 1) ? 2.0 * 3.14159265358979323846 : 1.0;      // disco.py:140-141
-    return compress_with_weights(ctx, (size_t)nwno, xint_at_top, gweight, ng, tweight, nt, F0PI, sym * 0.5,
-                                 cos_theta + 1.0, albedo);
+    return compress_with_weights(ctx, (size_t)nwno, xint_at_top, gweight, ng, tweight, nt, F0PI, COMPRESS_DISCO,
+                                 sym * 0.5, cos_theta + 1.0, albedo);
 }
 
 int picaso_compress_disco(picaso_ctx *ctx, int nwno, double cos_theta, const double *xint_at_top,
@@ -1091,7 +1101,8 @@ int picaso_compress_thermal_dev(picaso_ctx *ctx, size_t ninner, const double *fl
     if (!ctx) return fail(nullptr, "null context");
     PZ_HIP(ctx, hipSetDevice(ctx->device));
     const double sym = (nt == 1) ? 1.0 : 1.0 / (2.0 * 3.14159265358979323846);   // disco.py:174-175
-    return compress_with_weights(ctx, ninner, flux_at_top, gweight, ng, tweight, nt, nullptr, sym, -1.0, flux);
+    return compress_with_weights(ctx, ninner, flux_at_top, gweight, ng, tweight, nt, nullptr, COMPRESS_THERMAL, sym,
+                                 0.0, flux);
 }
 
 int picaso_compress_thermal(picaso_ctx *ctx, size_t ninner, const double *flux_at_top,

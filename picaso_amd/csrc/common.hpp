@@ -179,11 +179,13 @@ int launch_thermal_lvl(picaso_ctx *ctx, const ThermalLvlArgs &a);
 int lvl_scratch_reserve(picaso_ctx *ctx, size_t bytes);
 int ck_scratch_reserve(picaso_ctx *ctx, size_t bytes);
 
+// disk integration (disco.hip): `mode` says how the (g,t) sum is finished
+enum { COMPRESS_DISCO = 0, COMPRESS_THERMAL = 1 };
 // the same with up to 128 host weight pairs carried in the kernel arguments (no table upload)
 int launch_compress_hostw(picaso_ctx *ctx, size_t ninner, const double *x, const double *wts_host, int nang,
-                          const double *F0PI, double c1, double c2, double *out);
+                          const double *F0PI, int mode, double c1, double c2, double *out);
 int launch_compress_dev(picaso_ctx *ctx, size_t ninner, const double *x, const double *wts_dev,
-                        int nang, const double *F0PI, double c1, double c2, double *out);
+                        int nang, const double *F0PI, int mode, double c1, double c2, double *out);
 
 // copy a small host table into the next ring slot; *dev is valid for kernels enqueued afterwards
 int table_upload(picaso_ctx *ctx, const void *host, size_t bytes, const void **dev);

@@ -7,9 +7,19 @@
 namespace pz {
 
 
+// The two disk integrals differ only in how the (g,t) sum is finished:
+//   COMPRESS_DISCO   : sym_fac*0.5*albedo/F0PI*(cos_theta+1)   (disco.py:148)   c1 = sym_fac*0.5, c2 = cos_theta+1
+//   COMPRESS_THERMAL : flux*sym_fac                           (disco.py:181)   c1 = sym_fac
+__device__ __forceinline__ double compress_finish(int mode, double acc, double c1, double c2, const double *F0PI,
+                                                  size_t w)
+{
+#pragma clang fp contract(off)
+    return (mode == COMPRESS_DISCO) ? c1 * acc / (F0PI ? F0PI[w] : 1.0) * c2 : acc * c1;   // F0PI == NULL: F0PI = 1
+}
+
 __global__ __launch_bounds__(256) void k_compress(size_t ninner, const double *__restrict__ x,
                                                   const double *__restrict__ wts, int nang,
-                                                  const double *__restrict__ F0PI, double c1,
+                                                  const double *__restrict__ F0PI, int mode, double c1,
                                                   double c2, double *__restrict__ out)
 {
     const size_t w = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
@@ -19,10 +29,7 @@ __global__ __launch_bounds__(256) void k_compress(size_t ninner, const double *_
 #pragma clang fp contract(off)
         for (int k = 0; k < nang; ++k) acc = acc + x[(size_t)k * ninner + w] * wts[2 * k] * wts[2 * k + 1];
     }
-    // compress_disco: sym_fac*0.5*albedo/F0PI*(cos_theta+1)   (disco.py:148)
-    // compress_thermal: flux*sym_fac                          (disco.py:181)
-    // c2 < 0 marks the thermal form (cos_theta + 1 is never negative); F0PI == NULL: F0PI = 1
-    out[w] = (c2 >= 0.0) ? c1 * acc / (F0PI ? F0PI[w] : 1.0) * c2 : acc * c1;
+    out[w] = compress_finish(mode, acc, c1, c2, F0PI, w);
 }
 
 // Up to COMPRESS_ARG_ANGLES (g,t) weight pairs travel as kernel arguments: no table upload (a host-to-
@@ -32,7 +39,7 @@ struct CompressArgs {
     size_t ninner;
     const double *x, *F0PI;
     double *out;
-    int nang;
+    int nang, mode;
     double c1, c2;
     double wts[2 * COMPRESS_ARG_ANGLES];
 };
@@ -45,16 +52,19 @@ __global__ __launch_bounds__(256) void k_compress_args(const CompressArgs a)
 #pragma clang fp contract(off)
         for (int k = 0; k < a.nang; ++k) acc = acc + a.x[(size_t)k * a.ninner + w] * a.wts[2 * k] * a.wts[2 * k + 1];
     }
-    a.out[w] = (a.c2 >= 0.0) ? a.c1 * acc / (a.F0PI ? a.F0PI[w] : 1.0) * a.c2 : acc * a.c1;   // as k_compress
+    a.out[w] = compress_finish(a.mode, acc, a.c1, a.c2, a.F0PI, w);
 }
 
 // host weight pairs (nang <= COMPRESS_ARG_ANGLES)
 int launch_compress_hostw(picaso_ctx *ctx, size_t ninner, const double *x, const double *wts_host, int nang,
-                          const double *F0PI, double c1, double c2, double *out)
+                          const double *F0PI, int mode, double c1, double c2, double *out)
 {
     if (ninner == 0) return 0;
+    if (nang < 1 || nang > COMPRESS_ARG_ANGLES)
+        return fail(ctx, "disk integration: %d (g,t) weight pairs do not fit the %d carried as kernel arguments",
+                    nang, COMPRESS_ARG_ANGLES);
     CompressArgs a{};
-    a.ninner = ninner; a.x = x; a.F0PI = F0PI; a.out = out; a.nang = nang; a.c1 = c1; a.c2 = c2;
+    a.ninner = ninner; a.x = x; a.F0PI = F0PI; a.out = out; a.nang = nang; a.mode = mode; a.c1 = c1; a.c2 = c2;
     for (int k = 0; k < 2 * nang; ++k) a.wts[k] = wts_host[k];
     const int block = 256;
     hipLaunchKernelGGL(k_compress_args, dim3((unsigned)((ninner + block - 1) / block)), dim3(block), 0, ctx->stream, a);
@@ -64,13 +74,13 @@ int launch_compress_hostw(picaso_ctx *ctx, size_t ninner, const double *x, const
 
 // wts_dev: device table of nang (gweight[g], tweight[t]) pairs in (g,t) loop order
 int launch_compress_dev(picaso_ctx *ctx, size_t ninner, const double *x, const double *wts_dev,
-                        int nang, const double *F0PI, double c1, double c2, double *out)
+                        int nang, const double *F0PI, int mode, double c1, double c2, double *out)
 {
     if (ninner == 0) return 0;
     const int block = 256;
     const size_t grid = (ninner + block - 1) / block;
     hipLaunchKernelGGL(k_compress, dim3((unsigned)grid), dim3(block), 0, ctx->stream, ninner, x,
-                       wts_dev, nang, F0PI, c1, c2, out);
+                       wts_dev, nang, F0PI, mode, c1, c2, out);
     PZ_HIP(ctx, hipGetLastError());
     return 0;
 }

@@ -292,11 +292,53 @@ __global__ __launch_bounds__(MIXF_BLOCK) void k_compute_opacity_facets(const Mix
     }
 }
 
+// dst[(r, w, f)] = src[(r, w)] * scale[f]: a (rows, nwno) plane shared by all facets laid out with the facet
+// index fastest (what the 3-D solvers and the facet mixing kernel read), optionally scaled per facet.  64-bit
+// element indices: a 64-facet plane at 1e5 wavelengths x 91 levels is 4.7 GB.
+constexpr int BCAST_MAX_FACETS = 256;
+struct BcastArgs {
+    long nin;                       // rows * nwno
+    int nfac;
+    const double *src;
+    double *dst;
+    int has_scale;
+    double scale[BCAST_MAX_FACETS];
+};
+__global__ __launch_bounds__(256) void k_broadcast_facets(const BcastArgs a)
+{
+    const long e = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (e >= a.nin * a.nfac) return;
+    const long q = e / a.nfac;
+    const int f = (int)(e - q * a.nfac);
+    const double v = a.src[q];
+    a.dst[e] = a.has_scale ? v * a.scale[f] : v;
+}
+
 }  // namespace pz
 
 using namespace pz;
 
 extern "C" {
+
+int picaso_broadcast_facets_dev(picaso_ctx *ctx, size_t nrows, int nwno, int nfacets, const double *src,
+                                const double *facet_scale, double *dst)
+{
+    if (!ctx) return fail(nullptr, "null context");
+    if (nrows < 1 || nwno < 1 || nfacets < 1 || !src || !dst) return fail(ctx, "broadcast_facets: bad arguments");
+    if (nfacets > BCAST_MAX_FACETS) return fail(ctx, "broadcast_facets: at most %d facets", BCAST_MAX_FACETS);
+    PZ_HIP(ctx, hipSetDevice(ctx->device));
+    BcastArgs a{};
+    a.nin = (long)nrows * nwno;
+    a.nfac = nfacets;
+    a.src = src;
+    a.dst = dst;
+    a.has_scale = facet_scale != nullptr;
+    for (int f = 0; f < nfacets; ++f) a.scale[f] = facet_scale ? facet_scale[f] : 1.0;
+    const long total = a.nin * nfacets;
+    hipLaunchKernelGGL(k_broadcast_facets, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, a);
+    PZ_HIP(ctx, hipGetLastError());
+    return 0;
+}
 
 int picaso_opacity_gas_ck_dev(picaso_ctx *ctx, int nlayer, int nwno, int ngauss, int mol_mode, int nmol,
                               const double *const *mol_tables, const int *mol_rows,

@@ -40,6 +40,20 @@ class DeviceArray:
             ctypes.c_size_t(8 * n), ctypes.c_size_t(rows)), d.ctx)
         return d
 
+    def columns_to_host(self, w_lo, w_hi):
+        """Host copy of the wavelength block ``self[:, w_lo:w_hi, ...]`` of a resident
+        ``(rows, nwno[, inner...])`` plane (strided rows; 64-bit offsets: a 64-facet plane at 1e5 wavelengths is
+        4.7 GB)."""
+        rows, nwno = self.shape[0], self.shape[1]
+        inner = int(np.prod(self.shape[2:])) if len(self.shape) > 2 else 1
+        n = int(w_hi) - int(w_lo)
+        out = np.empty((rows, n) + tuple(self.shape[2:]), dtype=np.float64)
+        src = ctypes.c_void_p(self.addr + 8 * int(w_lo) * inner)
+        _lib.check(_lib.load().picaso_memcpy_d2h_2d(
+            self.ctx, _lib.ptr(out), ctypes.c_size_t(8 * n * inner), src, ctypes.c_size_t(8 * nwno * inner),
+            ctypes.c_size_t(8 * n * inner), ctypes.c_size_t(rows)), self.ctx)
+        return out
+
     def to_host(self):
         out = np.empty(self.shape, dtype=np.float64)
         _lib.check(_lib.load().picaso_memcpy_d2h(self.ctx, _lib.ptr(out), ctypes.c_void_p(self.addr),
@@ -86,6 +100,19 @@ class DeviceArray:
             self.free()
         except Exception:
             pass
+
+
+def broadcast_facets(src, nfacets, facet_scale=None, ctx=None):
+    """``(rows, nwno)`` DeviceArray -> ``(rows, nwno, nfacets)`` with the facet index fastest, times
+    ``facet_scale[f]`` when given (``picaso_broadcast_facets_dev``)."""
+    ctx = ctx if ctx is not None else src.ctx
+    rows, nwno = src.shape
+    out = DeviceArray((rows, nwno, int(nfacets)), ctx)
+    sc = _lib.f64(facet_scale, (int(nfacets),)) if facet_scale is not None else None
+    _lib.check(_lib.load().picaso_broadcast_facets_dev(ctx, ctypes.c_size_t(rows), ctypes.c_int(nwno),
+                                                      ctypes.c_int(int(nfacets)), ctypes.c_void_p(src.addr),
+                                                      _lib.ptr(sc), ctypes.c_void_p(out.addr)), ctx)
+    return out
 
 
 def sync(ctx=None):

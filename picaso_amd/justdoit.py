@@ -432,7 +432,8 @@ class inputs:
         return results
 
     def clouds_3d(self, df=None):
-        """Cloud ``opd``/``w0``/``g0`` as ``(nlayer, nwno, num_gangle, num_tangle)`` arrays."""
+        """Cloud ``opd``/``w0``/``g0`` as ``(nlayer, nwno, num_gangle, num_tangle)`` arrays, or ``(nlayer, nwno)``
+        for a cloud that is the same on every facet (tiled over the facets on the device)."""
         self.inputs["clouds"]["profile_3d"] = df
 
     def surface_reflect(self, albedo, wavenumber=None, old_wavenumber=None):
@@ -949,7 +950,8 @@ def _slice_inputs(inp, lo, hi, nwno, nlayer):
         cl["profile"] = new
     p3 = cl.get("profile_3d")
     if p3 is not None:
-        cl["profile_3d"] = {k: np.ascontiguousarray(np.asarray(v, dtype=float)[:, lo:hi]) for k, v in p3.items()}
+        cl["profile_3d"] = {k: np.ascontiguousarray(np.asarray(v, dtype=float).reshape((nlayer, nwno, -1))[:, lo:hi])
+                            for k, v in p3.items()}
     out["clouds"] = cl
     return out
 

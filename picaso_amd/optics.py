@@ -861,8 +861,14 @@ def compute_opacity_facets(atms, opacityclass, numg, numt, stream=2, delta_eddin
     d_rf = DeviceArray.from_host(np.stack(rf3), ctx) if rf3 else None
     d_c = [None, None, None]
     if clouds_3d is not None:
-        d_c = [DeviceArray.from_host(np.asarray(clouds_3d[k], dtype=float).reshape(nlayer, nwno, nfac), ctx)
-               for k in ("opd", "w0", "g0")]
+        from .device import broadcast_facets
+        d_c = []
+        for k in ("opd", "w0", "g0"):
+            a = np.asarray(clouds_3d[k], dtype=float)
+            if a.size == nlayer * nwno:          # one table for the whole disk: tiled over the facets on the device
+                d_c.append(broadcast_facets(DeviceArray.from_host(a.reshape(nlayer, nwno), ctx), nfac))
+            else:
+                d_c.append(DeviceArray.from_host(a.reshape(nlayer, nwno, nfac), ctx))
     tm = 0
     if test_mode is not None:
         tm = 1 if test_mode == "rayleigh" else 2

@@ -152,3 +152,49 @@ def delta_scale(sc, delta_eddington=True, stream=2):
         out.update(w0=sc["w0_og"].copy(), cosb=sc["cosb_og"].copy(), dtau=sc["dtau_og"].copy(),
                    tau=sc["tau_og"].copy(), f_deltaM=0.0 * sc["cosb_og"])
     return out
+
+
+def opacity_tables(nwno, mols=("H2O", "CH4"), wno=None):
+    """Arguments of ``optics.RetrieveOpacities(...)`` for a smooth synthetic monochromatic database on ``nwno``
+    wavelengths: a 5 x 6 (T, P) grid of molecular cross sections, two CIA pairs on 6 temperatures, Rayleigh
+    cross sections of H2 / He / CH4 -- the inputs of the 3-D / end-to-end workloads (BASELINE configs[4]: 64
+    facet plane sets generated on the device from per-facet profiles)."""
+    wno = np.linspace(3000.0, 30000.0, nwno) if wno is None else np.asarray(wno, dtype=float)
+    temps, press = [100.0, 300.0, 700.0, 1500.0, 3000.0], [1e-6, 1e-4, 1e-2, 1.0, 100.0, 500.0]
+    pt, molecular, pid = [], {m: {} for m in mols}, 0
+    for t in temps:
+        for p in press:
+            pid += 1
+            pt.append((pid, p, t))
+            for i, m in enumerate(mols):
+                molecular[m][pid] = 10.0 ** (-24 + 2 * np.sin(wno / 2500.0 + i) + 0.4 * np.log10(p)
+                                             + 0.8 * np.log10(t / 300.0))
+    cia_t = [75.0, 200.0, 500.0, 1000.0, 2000.0, 4000.0]
+    continuum = {pr: {t: 10.0 ** (-7 + np.cos(wno / 4000.0 + j) + 0.3 * np.log10(t / 300.0)) for t in cia_t}
+                 for j, pr in enumerate(("H2H2", "H2He"))}
+    ray = {m: 1e-27 * (wno / 1e4) ** 4 * (1 + 0.1 * k) for k, m in enumerate(("H2", "He", "CH4"))}
+    return dict(wno=wno, pt_pairs=pt, molecular=molecular, continuum=continuum, cia_temps=cia_t, rayleigh_opa=ray)
+
+
+def facet_profiles(nlevel, ng, nt, mols=("H2O", "CH4"), amplitude=0.1):
+    """Level profile with per-facet temperatures perturbed by ``amplitude`` (SURVEY 8(d), configs[4])."""
+    plev = np.logspace(-6, 2, nlevel)
+    t = 150.0 + 1200.0 * ((np.log10(plev) + 6) / 8) ** 2
+    pert = 1.0 + amplitude * np.cos(np.arange(ng * nt).reshape(ng, nt))
+    prof = {"pressure": plev, "temperature": t[:, None, None] * pert[None], "H2": np.full(nlevel, 0.84),
+            "He": np.full(nlevel, 0.155)}
+    for i, m in enumerate(mols):
+        prof[m] = np.full(nlevel, 1e-3 / (2 ** i))
+    return prof
+
+
+def cloud_slab(nlayer, nwno, opd=0.4, w0=0.95, g0=0.7, top=0.55, thickness=10):
+    """One ``(nlayer, nwno)`` cloud table (the same on every facet): a slab of ``thickness`` layers."""
+    a = int(top * nlayer)
+    sl = slice(a, min(nlayer, a + thickness))
+    out = {k: np.zeros((nlayer, nwno)) for k in ("opd", "w0", "g0")}
+    ramp = np.linspace(0.8, 1.2, nwno)[None, :]
+    out["opd"][sl] = opd * ramp
+    out["w0"][sl] = w0
+    out["g0"][sl] = g0
+    return out

@@ -284,6 +284,74 @@ def test_3d_64_facets_90_layers(oracle):
     assert rel_err(alb[idx], oracle.compress_disco(idx.size, float(ct), xo, gw, tw, f0[idx])) < 1e-8
 
 
+def test_config4_full_size_on_one_gpu(oracle, monkeypatch):
+    """BASELINE configs[4] at its STATED size on one GPU: 64 facets x 90 layers x 1e5 wavelengths through the
+    product's 3-D path -- per-facet temperatures -> one batched gas stage -> ``compute_opacity_facets`` writes
+    all eleven ``(nlayer|nlevel, nwno, 8, 8)`` planes on the device (4.6-4.7 GB each, 51 GB: the first planes
+    beyond 32-bit byte offsets) -> ``get_reflected_3d`` -> ``compress_disco``.  Wavelength blocks of the resident
+    planes at the start, across the 4 GiB boundary of a plane's first layers, and at the very end (byte offsets
+    > 4.6 GB) are read back and solved by the oracle's ``get_reflected_3d``; the same spectrum computed as two
+    wavelength halves (``devices=[0, 0]``: two opacity shards, two plane sets) is bit-identical to the whole."""
+    import time
+    from picaso_amd import device, disco
+    from picaso_amd import justdoit as jdi
+    from picaso_amd import optics as px
+    from picaso_amd import synthetic as syn
+    t_start = time.time()
+    nwno, nlevel, ng, nt = 100000, NLAYER + 1, 8, 8
+    nfac = ng * nt
+    opa = px.RetrieveOpacities(query_method="linear", **syn.opacity_tables(nwno))
+    case = jdi.inputs()
+    case.phase_angle(np.pi / 3, num_gangle=ng, num_tangle=nt)
+    case.gravity(gravity=2500.0)
+    case.atmosphere_3d(syn.facet_profiles(nlevel, ng, nt))
+    case.clouds_3d(syn.cloud_slab(NLAYER, nwno))               # one table for the disk, tiled on the device
+    case.approx(raman="none")
+    case.surface_reflect(0.1)
+    monkeypatch.setenv("PICASO_AMD_ALL_PLANES", "1")           # write and read every plane, none re-derived
+    kept = {}
+    real = px.compute_opacity_facets
+
+    def spy(*a, **k):
+        out = real(*a, **k)
+        kept.update(out)                                         # keep the resident planes of this call alive
+        return out
+    monkeypatch.setattr(px, "compute_opacity_facets", spy)
+    out = case.spectrum(opa, calculation="reflected", dimension="3d", full_output=True)
+    monkeypatch.setattr(px, "compute_opacity_facets", real)
+    x = out["full_output"]["albedo_3d"]
+    assert x.shape == (ng, nt, nwno) and np.all(np.isfinite(x)) and np.all(np.isfinite(out["albedo"]))
+    assert set(PLANES) <= set(kept)
+    plane_bytes = kept["dtau"].nbytes
+    assert plane_bytes == 8 * NLAYER * nwno * nfac and plane_bytes > 2 ** 32     # 4.6 GB: beyond 32-bit offsets
+    assert kept["tau"].nbytes == 8 * nlevel * nwno * nfac
+    # wavelength blocks read back from the resident planes: [0, 8), [49 996, 50 004), [99 992, 1e5)
+    g, gw, t, tw = disco.get_angles_3d(ng, nt)
+    u0, u1, ct, _, _ = disco.compute_disco(ng, nt, g, t, np.pi / 3)
+    for lo, hi in ((0, 8), (nwno // 2 - 4, nwno // 2 + 4), (nwno - 8, nwno)):
+        n = hi - lo
+        sub = [kept[k].columns_to_host(lo, hi) for k in PLANES]            # (rows, n, 8, 8)
+        assert 8 * ((sub[0].shape[0] - 1) * nwno + lo) * nfac > 2 ** 32    # the last layers lie beyond 4 GiB
+        xo = oracle.get_reflected_3d(nlevel, opa.wno[lo:hi], n, ng, nt, *sub, np.full(n, 0.1), u0, u1, float(ct),
+                                     np.ones(n), 3, 0, *TTHG)
+        xo = xo[0] if isinstance(xo, tuple) else xo
+        assert rel_err(x[:, :, lo:hi], xo) < 1e-8, (lo, hi)
+        assert rel_err(out["albedo"][lo:hi], oracle.compress_disco(n, float(ct), xo, gw, tw, np.ones(n))) < 1e-8
+    # the level planes are the running sums of the layer planes also beyond 4 GiB
+    tail = kept["tau"].columns_to_host(nwno - 4, nwno)
+    dt_tail = kept["dtau"].columns_to_host(nwno - 4, nwno)
+    assert np.array_equal(tail[0], np.zeros_like(tail[0])) and np.all(tail[-1] > 0)
+    assert np.allclose(tail[1:], np.cumsum(dt_tail, axis=0), rtol=1e-13)
+    kept.clear()
+    # two wavelength halves, each with its own opacity shard and plane set: bit-identical to the whole
+    halves = case.spectrum(opa, calculation="reflected", dimension="3d", full_output=True, devices=[0, 0])
+    assert np.array_equal(halves["full_output"]["albedo_3d"], x)
+    assert np.array_equal(halves["albedo"], out["albedo"])
+    assert halves["bond_albedo"] == out["bond_albedo"]
+    device.sync(opa.ctx)
+    assert time.time() - t_start < 90.0
+
+
 @pytest.mark.parametrize("calc_type", [0, 1])
 def test_cold_levels_planck_overflow(calc_type, oracle):
     """A 40 K level at 0.3 um: hc wno/kT = 1200 overflows exp(); the reference forms 1/(inf-1) = 0.  The

@@ -112,9 +112,11 @@ def test_spherical_harmonics(path, oracle):
             g.inp("dtau_og"), g.inp("tau_og"), g.inp("w0_og"), g.inp("cosb_og"), g.inp("surf_reflect"),
             g.geo("ubar0"), g.geo("ubar1"), g.geo("cos_theta"), g.inp("F0PI"), wsf, wmf, psf, wsr, wmr,
             psr, *g.tthg(), stream, b_top=0.0, flx=1 if has_flux else 0, single_form=sf)
-        assert rel_err(xint, g["reflsh/%s/xint" % case]) < 1e-8, case
+        # the restatement follows LAPACK's arithmetic: it sits at <= 3.1e-12 on the committed fixtures, so 1e-10
+        # (not the 1e-8 the conditioning argument alone would allow) catches a regression in sh_oracle.c
+        assert rel_err(xint, g["reflsh/%s/xint" % case]) < 1e-10, case
         if has_flux:        # layer moment fluxes (flx=1): field-scale metric, entries span many decades
-            assert scale_err(flux, g["reflsh/%s/flux" % case]) < 1e-8, case
+            assert scale_err(flux, g["reflsh/%s/flux" % case]) < 1e-10, case
     for case in g.cases("thermsh"):
         stream, hs = int(case[1]), int(case[-1])
         rs = np.zeros(nwno) + g.inp("surf_reflect")
@@ -123,4 +125,4 @@ def test_spherical_harmonics(path, oracle):
                                         g.inp("cosb"), g.inp("dtau_og"), g.inp("tau_og"), g.inp("w0_og"),
                                         g.inp("w0_no_raman"), g.inp("cosb_og"), g.inp("plevel"),
                                         g.geo("ubar1"), rs, stream, hs)
-        assert rel_err(xint, g["thermsh/%s/xint" % case]) < 1e-8, case
+        assert rel_err(xint, g["thermsh/%s/xint" % case]) < 1e-10, case
