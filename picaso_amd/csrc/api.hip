@@ -488,6 +488,23 @@ static int reflected_1d_core(picaso_ctx *ctx, int nlevel, int nwno, int ncolper,
         }
         if (!get_toa_intensity) return 0;
     }
+    // Small launches with the reference's default options: the cooperative kernel (one workgroup per 64 columns:
+    // a wave for the angle-independent layer quantities, one wave per disk angle, fused disk sum), bit-identical
+    // to the fused launch.  Where it stops paying: DESIGN.md section 6.
+    if (nang <= MAX_ANGLES) {
+        long coop_cols = 64L * ctx->ncu;                   // one workgroup (64 columns) per CU
+        if (const char *e = getenv("PICASO_AMD_REFL_COOP_COLS")) coop_cols = atol(e);
+        a.na = nang;
+        a.ny = 1;
+        if (ncol <= coop_cols && reflected_coop_ok(a)) {
+            for (int k = 0; k < nang; ++k)
+                a.ang[k] = make_refl_angle(ubar0[k], ubar1[k], fuse ? gweight[k / numt] : 0.0,
+                                           fuse ? tweight[k % numt] : 0.0);
+            a.xint = xint_at_top;
+            a.albedo_first = a.albedo_last = 1;
+            return launch_reflected_coop(ctx, a);
+        }
+    }
     int done = 0;
     const int group = reflected_angle_group(ctx, ncol, nang);
     if (group > 1 && group < nang && ((nang + group - 1) / group) * group <= MAX_ANGLES) {

@@ -1,0 +1,645 @@
+// Toon89 two-stream reflected light for SMALL launches: one workgroup per 64 wavelength columns -- gfx950.
+//
+// Replaces fluxes.get_reflected_1d (reference picaso/fluxes.py:1009-1413, get_toa_intensity=1, get_lvl_flux=0,
+// the reference's default options) where a launch has at most one 64-column block per CU (<= 16 384 columns on
+// the MI355X): a wavelength shard of a multi-GPU run (12 500 columns per GPU on eight), a climate grid, a coarse
+// spectrum.
+//
+// k_reflected_toa (toon_reflected.hip) carries all disk angles of a column in one lane: the right shape when
+// every SIMD has two such waves, but a launch of <= 1 workgroup per CU lasts as long as ONE lane's serial
+// instruction stream (~480 fp64 instructions per layer at five angles), and spreading the angles over separate
+// workgroups (api.hip:reflected_angle_group) repeats the angle-independent part of the work in every one of
+// them.  Here the waves of ONE workgroup share a column block instead:
+//   * wave L ("loader") streams the eleven plane values of every layer from HBM into an LDS ring, two rounds of
+//     RC_R layers ahead of their use (a round's loads stay in flight across a whole step), and evaluates the
+//     wave-uniform shortcut tests of k_reflected_toa's `prep` on the values it holds;
+//   * wave S ("shared") walks down the layers a round behind L and computes everything that does not depend on
+//     the disk angle -- the two-stream gammas, lambda, Gamma, exp(+-lambda dtau), the single-scattering phase
+//     function, the elimination factors (the only sequential part of it: the recurrence rho) -- into a second ring
+//     ([layer][variable][lane]: conflict-free 8-byte accesses);
+//   * waves A_k, one per disk angle, run the per-angle part of the sweep a round behind S (the direct-beam terms,
+//     the source-function integrals, the TOA functional: `reflected_layer`'s angle loop body, one iteration each)
+//     with their seven state variables in registers;
+//   * one workgroup barrier per round; the disk sum (disco.compress_disco) is fused: the angle waves leave their
+//     result in LDS and wave S adds them in the reference's (g, t) order.
+// Every floating-point operation is the one reflected_layer<.., FAST = true> performs for that (column, angle), in
+// the same order (contraction off, explicit fma): the results are BIT-IDENTICAL to the fused five-angle launch,
+// so a spectrum does not depend on how many GPUs it was cut across (tests/test_parity_gpu.py,
+// test_fullsize_gpu.py, test_fuzz_gpu.py all run through this kernel at their sizes).
+//
+// What it buys, measured: 0.047-0.048 ms for any launch up to 16 384 columns x 90 layers x 5
+// angles, against 0.048-0.050 (one angle per workgroup, <= 13 056 columns) and 0.061 (angle pairs, to 16 384) of the
+// grid.y shapes.  Why not more: a wave alone on its SIMD issues one fp64 instruction per ~7.5 cycles here (2.38 GHz
+// in these light launches), two waves sharing a SIMD one per ~5.8 between them, against the pipe's 4.2 -- the
+// kernel's 556 fp64 instructions per column-block-layer on 7 waves last ~1 200 cycles where 4 saturated SIMDs would
+// need 584.  Getting there takes >= 3 balanced waves per SIMD (PZ_RCOOP_APW = 2, two angles interleaved statement by
+// statement in one wave, measured slower: 0.051 ms).
+#include <type_traits>
+
+#include "common.hpp"
+#include "device_math.hpp"
+
+namespace pz {
+
+#ifndef PZ_RCOOP_ROUND
+#define PZ_RCOOP_ROUND 4
+#endif
+constexpr int RC_R = PZ_RCOOP_ROUND;          // layers per round
+// Hardware wave index of wave S and of the loader wave L: the waves of a workgroup go to the CU's four SIMDs
+// round-robin, so with seven waves (five angles) SIMD 2 holds waves 2 and 6, SIMD 3 only wave 3.  S is the
+// longest role and shares its SIMD with L, which only moves data.
+#ifndef PZ_RCOOP_SWAVE
+#define PZ_RCOOP_SWAVE 2
+#endif
+// the eleven plane values of a layer, as wave L leaves them in LDS
+enum { RW_DT = 0, RW_TAUN, RW_W0, RW_G, RW_GCOS2, RW_FC, RW_FR, RW_DTO, RW_TAUO, RW_W0O, RW_CBO, RW_NV };
+// what wave S leaves for the angle waves
+enum {
+    RC_LAM = 0, RC_EP, RC_EM, RC_GAM, RC_FW0H, RC_A0, RC_W2PI, RC_SSAH,
+    RC_A1I, RC_A2I, RC_IA, RC_SFAC, RC_RHON,         // read for every layer
+    RC_A1, RC_C15, RC_GMC,                           // layers with cloud in some lane
+    RC_NV
+};
+enum { RCF_CUM_TAU = 1, RCF_EO_OK = 2, RCF_SAME_DT = 4, RCF_NOCLD = 8, RCF_ALL = 15 };
+#ifndef PZ_RCOOP_APW
+#define PZ_RCOOP_APW 1
+#endif
+constexpr int RC_APW = PZ_RCOOP_APW;                 // angles per angle wave (1 or 2; measured: 1)
+constexpr int RC_MAX_ANGLES = 6 * RC_APW;            // at most 6 angle waves + S + L = 8 waves (two per SIMD)
+
+struct RcState {
+    double T, XU, EO, KAPPA, ZETA, D1, D2;      // the seven sweep variables of reflected_layer, for one angle
+    double l_gam, l_EM, l_rho;                  // of the last layer, for the surface row
+};
+
+// NA-wide forms of the math helpers: the same operations as fexp2 / frcp (device_math.hpp) for NA independent
+// arguments, written statement by statement over the NA of them.  hipcc keeps long dependent chains together when it
+// schedules a basic block; a wave that is alone on its SIMD then issues one fp64 instruction per ~8.7 cycles (each
+// waits for its predecessor) where the pipe takes one per ~4.2.  Interleaved in the source, the chains of the NA
+// angles fill each other's latency.
+#define RC_FOR_K _Pragma("unroll") for (int kk = 0; kk < NA; ++kk)
+template <int NA>
+__device__ __forceinline__ void fexp2_n(const double (&t)[NA], const Exp2Coef &K, double (&out)[NA])
+{
+#pragma clang fp contract(off)
+    double nn[NA], f[NA], p[NA];
+    RC_FOR_K nn[kk] = __builtin_rint(t[kk]);
+    RC_FOR_K f[kk] = t[kk] - nn[kk];
+    RC_FOR_K p[kk] = fma(K.c[10], f[kk], K.c[9]);
+#pragma unroll
+    for (int i = 8; i >= 0; --i) RC_FOR_K p[kk] = fma(p[kk], f[kk], K.c[i]);
+    RC_FOR_K out[kk] = ldexp(fma(f[kk], p[kk], 1.0), (int)nn[kk]);
+}
+template <int NA>
+__device__ __forceinline__ void frcp_n(const double (&b)[NA], double (&y)[NA])
+{
+#pragma clang fp contract(off)
+    double e[NA];
+    RC_FOR_K y[kk] = __builtin_amdgcn_rcp(b[kk]);
+    RC_FOR_K e[kk] = fma(-b[kk], y[kk], 1.0);
+    RC_FOR_K y[kk] = fma(y[kk], e[kk], y[kk]);
+    RC_FOR_K e[kk] = fma(-b[kk], y[kk], 1.0);
+    RC_FOR_K y[kk] = fma(y[kk], e[kk], y[kk]);
+}
+
+// One layer of NA angles: NA iterations of reflected_layer's angle loop, every statement written over the NA angles
+// (see above).  `in`: the layer's plane values (wave L), `slot`: the angle-independent quantities (wave S), read
+// from LDS once for all NA; `fl`: the wave-uniform shortcut flags of the layer.  PLAIN: all four flags are set,
+// known at compile time (no cloud terms, no fall-back exponentials, no branches).
+template <bool ZP, bool FIRST, bool LAST, bool PLAIN, int NA>
+__device__ __forceinline__ void rc_angle(const double (*in)[64], const double (*slot)[64], int fl, int lane,
+                                         const ReflectedArgs::Angle (&g)[NA], const Exp2Coef &K, double b_top,
+                                         RcState (&st)[NA])
+{
+#pragma clang fp contract(off)
+#ifdef PZ_RCOOP_STUB_A                                 // timing build (wrong results): the angle waves only read
+    st[0].KAPPA += slot[RC_LAM][lane];
+    return;
+#endif
+    constexpr bool first = FIRST, last = LAST;
+    const bool cum_tau = PLAIN || (fl & RCF_CUM_TAU), eo_ok = PLAIN || (fl & RCF_EO_OK),
+               same_dt = PLAIN || (fl & RCF_SAME_DT), nocld = PLAIN || (fl & RCF_NOCLD);
+    const double lam = slot[RC_LAM][lane], EP = slot[RC_EP][lane], EM = slot[RC_EM][lane];
+    const double gam = slot[RC_GAM][lane], dt = in[RW_DT][lane], Fw0h = slot[RC_FW0H][lane];
+    const double A0 = slot[RC_A0][lane], w2pi = slot[RC_W2PI][lane], ssa_h = slot[RC_SSAH][lane];
+    const double gcq = in[RW_GCOS2][lane], a1i = slot[RC_A1I][lane], a2i = slot[RC_A2I][lane];
+    const double ia = slot[RC_IA][lane], sfac = slot[RC_SFAC][lane], rho_n = slot[RC_RHON][lane];
+    double A1 = 0.0, c15 = 0.0, gmc = 0.0;
+    if (!nocld) {
+        A1 = slot[RC_A1][lane];
+        c15 = slot[RC_C15][lane];
+        gmc = slot[RC_GMC][lane];
+    }
+    double tau_n = 0.0, tauo = 0.0, dto = 0.0;
+    if (!PLAIN) {
+        if (!cum_tau) tau_n = in[RW_TAUN][lane];
+        if (first || !eo_ok) tauo = in[RW_TAUO][lane];
+        if (!same_dt) dto = in[RW_DTO][lane];
+    }
+    const double lam2 = lam * lam;                 // toon_gammas forms it the same way
+    const double gp = 1.0 + gam;
+    const double gEM = gam * EM;
+    // ---- the two long chains of a layer: exp(-dtau/u1) and the one reciprocal for 1/den, 1/(lu-1), 1/(lu+1) ----
+    double targ[NA], et[NA], e0[NA], den[NA], lu[NA], lm1[NA], lp1[NA], lml[NA], q3[NA], r3[NA];
+    RC_FOR_K targ[kk] = dt * g[kk].nl1;
+    RC_FOR_K den[kk] = sub_unfused(lam2, g[kk].iu0sq);
+    RC_FOR_K lu[kk] = lam * g[kk].u1;
+    RC_FOR_K lm1[kk] = lu[kk] - 1.0;
+    RC_FOR_K lp1[kk] = lu[kk] + 1.0;
+    RC_FOR_K lml[kk] = lm1[kk] * lp1[kk];
+    RC_FOR_K q3[kk] = den[kk] * lml[kk];
+    fexp2_n<NA>(targ, K, et);
+    frcp_n<NA>(q3, r3);
+    if (ZP) {
+        RC_FOR_K e0[kk] = et[kk];
+    } else {
+        double t0[NA];
+        RC_FOR_K t0[kk] = dt * g[kk].nl0;
+        fexp2_n<NA>(t0, K, e0);
+    }
+    double rden[NA], rd[NA], hz[NA], am2[NA], ap2[NA], xd[NA], fw[NA], fx[NA], fxd[NA];
+    RC_FOR_K rden[kk] = r3[kk] * lml[kk];
+    RC_FOR_K rd[kk] = r3[kk] * den[kk];
+    // PLAIN: the cloud terms folded by hand (fma(0, y, z) = z, x + 0 = x: exact), as reflected_layer's NC copy
+    RC_FOR_K hz[kk] = PLAIN ? g[kk].iu0 : fma(A1, ZP ? g[kk].u1 : g[kk].u0, g[kk].iu0);
+    RC_FOR_K am2[kk] = A0 + hz[kk];
+    RC_FOR_K ap2[kk] = A0 - hz[kk];
+    if (cum_tau) {
+        RC_FOR_K xd[kk] = st[kk].XU * e0[kk];
+    } else {
+        RC_FOR_K xd[kk] = fexp2_cold(tau_n * (ZP ? g[kk].nl1 : g[kk].nl0), K);
+    }
+    RC_FOR_K fw[kk] = Fw0h * rden[kk];
+    RC_FOR_K fx[kk] = fw[kk] * st[kk].XU;
+    RC_FOR_K fxd[kk] = fw[kk] * xd[kk];
+    double cmu[NA], cpu[NA], cmd[NA], cpd[NA], B0[NA], Aqq[NA], X[NA], Y[NA], Tw[NA], Trd[NA], ee[NA], ff[NA];
+    RC_FOR_K cmu[kk] = am2[kk] * fx[kk];
+    RC_FOR_K cpu[kk] = ap2[kk] * fx[kk];
+    RC_FOR_K cmd[kk] = am2[kk] * fxd[kk];
+    RC_FOR_K cpd[kk] = ap2[kk] * fxd[kk];
+    RC_FOR_K B0[kk] = fma(gcq, g[kk].q2, 1.0);
+    if (PLAIN) {
+        RC_FOR_K Aqq[kk] = B0[kk] * A0;
+        RC_FOR_K Y[kk] = 0.0;
+    } else {
+        RC_FOR_K Aqq[kk] = fma(B0[kk], A0, -((c15 * g[kk].u1) * hz[kk]));
+        RC_FOR_K Y[kk] = gmc * g[kk].u1;
+    }
+    RC_FOR_K X[kk] = gp * B0[kk];
+    RC_FOR_K Tw[kk] = st[kk].T * w2pi;
+    RC_FOR_K Trd[kk] = Tw[kk] * rd[kk];
+    RC_FOR_K ee[kk] = fma(EP, et[kk], -1.0);
+    RC_FOR_K ff[kk] = fma(-EM, et[kk], 1.0);
+    double vp[NA], vn[NA], eo[NA], t2[NA], t1[NA], e0o[NA];
+    RC_FOR_K vp[kk] = (Trd[kk] * lp1[kk]) * ((PLAIN ? X[kk] : X[kk] + Y[kk]) * ee[kk]);
+    RC_FOR_K vn[kk] = (Trd[kk] * lm1[kk]) * ((PLAIN ? X[kk] : X[kk] - Y[kk]) * ff[kk]);
+    if (!first && eo_ok) {
+        RC_FOR_K eo[kk] = st[kk].EO;
+    } else {
+        RC_FOR_K eo[kk] = fexp2_cold(tauo * (ZP ? g[kk].nl1 : g[kk].nl0), K);
+    }
+    RC_FOR_K t2[kk] = fma(-e0[kk], et[kk], 1.0);
+    if (same_dt) {
+        RC_FOR_K t1[kk] = t2[kk];
+        RC_FOR_K e0o[kk] = e0[kk];
+    } else {
+        RC_FOR_K {
+            const double e1o = fexp2_cold(dto * g[kk].nl1, K);
+            e0o[kk] = ZP ? e1o : fexp2_cold(dto * g[kk].nl0, K);
+            t1[kk] = fma(-e0o[kk], e1o, 1.0);
+        }
+    }
+    if (!last) RC_FOR_K st[kk].EO = eo[kk] * e0o[kk];
+    double s1[NA], S0[NA], kap[NA], Tn[NA], delta_n[NA];
+    RC_FOR_K s1[kk] = (ssa_h * (ZP ? 1.0 : g[kk].wq2)) * (eo[kk] * t1[kk]);
+    RC_FOR_K S0[kk] = fma((w2pi * (ZP ? 1.0 : g[kk].wq2)) * fx[kk], Aqq[kk] * t2[kk], s1[kk]);
+    RC_FOR_K kap[kk] = fma(st[kk].T, S0[kk], st[kk].KAPPA);
+    RC_FOR_K Tn[kk] = st[kk].T * et[kk];
+    if (last) {                                            // xint[n] = flux_zero/pi (fluxes.py:1266-1270)
+        RC_FOR_K vp[kk] = fma(Tn[kk] * EP, 1.0 / PI, vp[kk]);
+        RC_FOR_K vn[kk] = fma((Tn[kk] * gam) * EM, 1.0 / PI, vn[kk]);
+        RC_FOR_K kap[kk] = fma(Tn[kk] * cpd[kk], 1.0 / PI, kap[kk]);
+    }
+    if (first) {                                           // top row (fluxes.py:155-158)
+        RC_FOR_K delta_n[kk] = b_top - cmu[kk];
+        RC_FOR_K st[kk].ZETA = fma(-vn[kk], gam, vp[kk]);
+        RC_FOR_K kap[kk] = fma(vn[kk], delta_n[kk], kap[kk]);
+    } else {
+        double rP[NA], rM[NA], tt[NA];
+        RC_FOR_K rP[kk] = cpu[kk] - st[kk].D1;
+        RC_FOR_K rM[kk] = cmu[kk] - st[kk].D2;
+        RC_FOR_K delta_n[kk] = fma(a2i, rP[kk], -(a1i * rM[kk]));
+        RC_FOR_K tt[kk] = fma(gam, delta_n[kk], rP[kk]) * ia;
+        RC_FOR_K kap[kk] = fma(st[kk].ZETA, tt[kk], fma(vn[kk], delta_n[kk], kap[kk]));
+        RC_FOR_K st[kk].ZETA = fma(-vn[kk], rho_n, fma(st[kk].ZETA, sfac, vp[kk]));
+    }
+    RC_FOR_K st[kk].XU = xd[kk];
+    RC_FOR_K st[kk].KAPPA = kap[kk];
+    RC_FOR_K st[kk].T = Tn[kk];
+    RC_FOR_K st[kk].D1 = fma(gEM, delta_n[kk], cpd[kk]);
+    RC_FOR_K st[kk].D2 = fma(EM, delta_n[kk], cmd[kk]);
+    if (last) {
+        RC_FOR_K {
+            st[kk].l_gam = gam;
+            st[kk].l_EM = EM;
+            st[kk].l_rho = rho_n;
+        }
+    }
+}
+
+#ifdef PZ_RCOOP_TIMING
+// timing build: per wave of workgroup 0, cycles from kernel start to end and cycles parked at the barriers
+__device__ long long rc_dbg[16][2];
+#define RC_SYNC()                                                          \
+    do {                                                                   \
+        const long long t0__ = __builtin_readcyclecounter();                \
+        __syncthreads();                                                   \
+        dbg_wait += __builtin_readcyclecounter() - t0__;                    \
+    } while (0)
+#else
+#define RC_SYNC() __syncthreads()
+#endif
+
+struct RcShared {
+    double rho, pgam, pEM;                      // the elimination recurrence of reflected_layer (S.rho, S.pgam, S.pEM)
+};
+
+// One layer of wave S: the angle-independent part of reflected_layer<.., FAST = true> (fluxes.py:1132-1141,
+// 1172-1177) and the elimination factors shared by all angles.  PLAIN as in rc_angle (then the layer is an interior
+// one as well): reflected_layer's NC copy, the cloud terms folded by hand.
+template <bool PLAIN>
+__device__ __forceinline__ void rc_shared(const ReflectedArgs &a, const double (*in)[64], double (*slot)[64], int fl,
+                                          bool not_first, int lane, double F, double cos_theta, const Exp2Coef &K,
+                                          RcShared &sh)
+{
+#pragma clang fp contract(off)
+#ifdef PZ_RCOOP_STUB_S                                 // timing build (wrong results): wave S only copies
+    for (int v = 0; v < RC_NV; ++v) slot[v][lane] = in[v % RW_NV][lane] + 0.5;
+    return;
+#endif
+    const double clip = 35.0;                         // fluxes.py:1174
+    const double dt = in[RW_DT][lane], w0 = in[RW_W0][lane], fr = in[RW_FR][lane], w0o = in[RW_W0O][lane];
+    const bool nocld = PLAIN || (fl & RCF_NOCLD);
+    double g1, g2, lam, lam2, fcg = 0.0, ps;
+    if (PLAIN) {
+        toon_gammas_nocld(0, w0, g1, g2, lam, lam2);
+        ps = fr * (0.75 * fma(cos_theta, cos_theta, 1.0));
+    } else {
+        const double cg = in[RW_G][lane], fc = in[RW_FC][lane];
+        fcg = fc * cg;
+        toon_gammas(0, w0, fcg, g1, g2, lam, lam2);
+        if (nocld)
+            ps = fr * (0.75 * fma(cos_theta, cos_theta, 1.0));
+        else
+            ps = p_single<false>(3, in[RW_CBO][lane], in[RW_GCOS2][lane], fc, fr, cos_theta, a.frac_a, a.frac_b, 2.0,
+                                 a.constant_back, a.constant_forward);
+    }
+    const double gam = (g1 - lam) * frcp(g2);
+    const double E = fmin(lam * dt, clip);
+    const double EP = fexp2(E * -NEG_LOG2E, K);
+    const double EM = frcp(EP);
+    const double ssa_h = (w0o * F * (0.125 / PI)) * ps;
+    const double w2pi = w0 * (0.5 / PI);
+    const double Fw0h = (0.5 * F) * w0;
+    const double c2 = PLAIN ? 0.0 : SQ3 * fcg;
+    const double A0 = PLAIN ? (g1 + g2) : (g1 + g2) + c2;
+    double a1i = 0.0, a2i = 0.0, ia = 0.0, rho_n = gam, sfac = 0.0;
+    if (PLAIN || not_first) {
+        const double em2 = sh.pEM * sh.pEM;
+        const double a1 = fma(-(sh.pgam * em2), sh.rho, 1.0);
+        const double a2 = fma(-em2, sh.rho, sh.pgam);
+        const double d1 = fma(-gam, a2, a1);
+        const double r12 = frcp(d1 * a1);
+        const double inv = r12 * a1;
+        a1i = a1 * inv;
+        a2i = a2 * inv;
+        rho_n = fma(gam, a1i, -a2i);
+        ia = sh.pEM * (r12 * d1);
+        sfac = fma(-gam, rho_n, 1.0) * ia;
+    }
+    sh.rho = rho_n;
+    sh.pgam = gam;
+    sh.pEM = EM;
+    slot[RC_LAM][lane] = lam;
+    slot[RC_EP][lane] = EP;
+    slot[RC_EM][lane] = EM;
+    slot[RC_GAM][lane] = gam;
+    slot[RC_FW0H][lane] = Fw0h;
+    slot[RC_A0][lane] = A0;
+    slot[RC_W2PI][lane] = w2pi;
+    slot[RC_SSAH][lane] = ssa_h;
+    slot[RC_A1I][lane] = a1i;
+    slot[RC_A2I][lane] = a2i;
+    slot[RC_IA][lane] = ia;
+    slot[RC_SFAC][lane] = sfac;
+    slot[RC_RHON][lane] = rho_n;
+    if (!PLAIN && !nocld) {
+        slot[RC_A1][lane] = c2 * (g1 - g2);
+        const double c15 = 1.5 * fcg;
+        slot[RC_C15][lane] = c15;
+        slot[RC_GMC][lane] = (1.0 - gam) * c15;
+    }
+}
+
+// ZP: every angle has ubar0 == ubar1 (zero phase angle), as in k_reflected_toa
+template <bool ZP>
+__global__ __launch_bounds__(64 * (RC_MAX_ANGLES / RC_APW + 2)) void k_reflected_coop(const ReflectedArgs a)
+{
+#pragma clang fp contract(off)      // operations as written: the same ones reflected_layer performs
+    __shared__ double raw[3][RC_R][RW_NV][64];        // plane values, two rounds ahead of the angle waves
+    __shared__ double ring[2][RC_R][RC_NV][64];       // wave S's results, one round ahead
+    __shared__ int lflag[3][RC_R];                    // wave-uniform shortcut flags of a layer (wave L)
+    __shared__ int rplain[3];                         // 1: every layer of the round is interior with all flags set
+    __shared__ double xs[RC_MAX_ANGLES][64];
+#ifdef PZ_RCOOP_TIMING
+    long long dbg_wait = 0;
+    const long long dbg_t0 = __builtin_readcyclecounter();
+#define RC_DONE()                                                                              \
+    do {                                                                                       \
+        if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) {                                      \
+            rc_dbg[threadIdx.x >> 6][0] = __builtin_readcyclecounter() - dbg_t0;               \
+            rc_dbg[threadIdx.x >> 6][1] = dbg_wait;                                            \
+        }                                                                                      \
+    } while (0)
+#else
+#define RC_DONE() do {} while (0)
+#endif
+    const int lane = threadIdx.x & 63;
+    const int hw_wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int nang = a.na;
+    const int nawaves = (nang + RC_APW - 1) / RC_APW; // angle waves; the workgroup has nawaves + 2 waves
+    const int lwave = nawaves + 1;                    // the last wave loads
+    const int swave = (PZ_RCOOP_SWAVE < lwave) ? PZ_RCOOP_SWAVE : 0;
+    const bool is_l = hw_wave == lwave, is_s = hw_wave == swave;
+    const int aw = (is_s || is_l) ? 0 : (hw_wave < swave ? hw_wave : hw_wave - 1);    // index of an angle wave
+    const int k0 = aw * RC_APW;                       // its first angle
+    long col = (long)blockIdx.x * 64 + lane;
+    const bool active = col < a.ncol;
+    if (!active) col = a.ncol - 1;                    // padding lanes shadow the last column, never store
+    const long w = a.ncolper > 1 ? col / a.ncolper : col;
+    const int n = a.nlayer;
+    const long pitch = a.pitch;
+    const int nrounds = (n + RC_R - 1) / RC_R;
+    // Schedule (steps separated by one workgroup barrier): in step t wave L loads the planes of round t + 2, wave S
+    // turns the planes of round t + 1 into the shared layer quantities, the angle waves consume round t.
+
+    if (is_l) {
+        // ------------------------------------------------------------------------------------------------
+        // wave L: HBM -> LDS, every plane value read exactly once, and the wave-uniform shortcut tests of
+        // k_reflected_toa's `prep` (bit-exact comparisons, see reflected_layer) on the values it holds
+        // ------------------------------------------------------------------------------------------------
+        const double *pl[RW_NV] = {a.dtau + col, a.tau + col + pitch, a.w0 + col, a.cosb + col, a.gcos2 + col,
+                                   a.ftau_cld + col, a.ftau_ray + col, a.dtau_og + col, a.tau_og + col,
+                                   a.w0_og + col, a.cosb_og + col};
+        double tau_i = a.tau[col];
+        double tauo_pred = 0.0;                       // tau_og[i-1] + dtau_og[i-1] of the layer above
+        // the loads of round q + 1 are issued BEFORE round q's values (loaded a step earlier) are written to LDS and
+        // the step's barrier is reached: a round's loads stay in flight for a whole step instead of holding it up
+        double v[2][RC_R][RW_NV];
+        auto issue = [&](int q, double (&dst)[RC_R][RW_NV]) {
+#pragma unroll
+            for (int j = 0; j < RC_R; ++j) {
+                const int i = q * RC_R + j;
+                if (i < n) {
+                    const long o = (long)i * pitch;
+#pragma unroll
+                    for (int p = 0; p < RW_NV; ++p) dst[j][p] = pl[p][o];
+                }
+            }
+        };
+        auto layer_flags = [&](const double (&x)[RW_NV]) {
+            const bool cum_tau = __all(x[RW_TAUN] == tau_i + x[RW_DT]);
+            const bool eo_ok = __all(x[RW_TAUO] == tauo_pred);
+            const bool same_dt = __all(x[RW_DTO] == x[RW_DT]);
+            const bool nocld = __all(x[RW_FC] == 0.0);
+            tau_i = x[RW_TAUN];
+            tauo_pred = x[RW_TAUO] + x[RW_DTO];
+            return (cum_tau ? RCF_CUM_TAU : 0) | (eo_ok ? RCF_EO_OK : 0) | (same_dt ? RCF_SAME_DT : 0) |
+                   (nocld ? RCF_NOCLD : 0);
+        };
+        auto store = [&](int q, const double (&src)[RC_R][RW_NV]) {
+            int all = RCF_ALL;
+#pragma unroll
+            for (int j = 0; j < RC_R; ++j) {
+                const int i = q * RC_R + j;
+                if (i < n) {
+#pragma unroll
+                    for (int p = 0; p < RW_NV; ++p) raw[q % 3][j][p][lane] = src[j][p];
+                    const int fl = layer_flags(src[j]);
+                    if (lane == 0) lflag[q % 3][j] = fl;
+                    all &= (i > 0 && i < n - 1) ? fl : 0;
+                } else {
+                    all = 0;
+                }
+            }
+            if (lane == 0) rplain[q % 3] = (all == RCF_ALL);
+        };
+        // Steady state without a branch around the loads: a conditional issue makes the compiler's wait-count
+        // bookkeeping give up at the join (s_waitcnt vmcnt(0) before every reissue: the loads of a step then no
+        // longer stay in flight across its barrier), so full rounds run in a loop of their own.
+        auto issue_full = [&](int q, double (&dst)[RC_R][RW_NV]) {
+#pragma unroll
+            for (int j = 0; j < RC_R; ++j) {
+                const long o = (long)(q * RC_R + j) * pitch;
+#pragma unroll
+                for (int p = 0; p < RW_NV; ++p) dst[j][p] = pl[p][o];
+            }
+        };
+        auto store_full = [&](int q, const double (&src)[RC_R][RW_NV]) {     // 0 < layers < n - 1
+            int all = RCF_ALL;
+#pragma unroll
+            for (int j = 0; j < RC_R; ++j) {
+#pragma unroll
+                for (int p = 0; p < RW_NV; ++p) raw[q % 3][j][p][lane] = src[j][p];
+                const int fl = layer_flags(src[j]);
+                if (lane == 0) lflag[q % 3][j] = fl;
+                all &= fl;
+            }
+            if (lane == 0) rplain[q % 3] = (all == RCF_ALL);
+        };
+        const int nfull = n / RC_R;                   // rounds with all RC_R layers
+        const int nsteps = nrounds + 2;
+        // step s (s = 0, 1: the two prologue steps; then the nrounds main steps) stores round s, issues round s + 1
+        issue(0, v[0]);
+        int s2 = 0;
+        if (nfull > 3) {                              // round 0 holds the first layer: general form
+            issue_full(1, v[1]);
+            store(0, v[0]);
+            RC_SYNC();
+            issue_full(2, v[0]);
+            store_full(1, v[1]);
+            RC_SYNC();
+            s2 = 2;
+            for (; s2 + 3 < nfull; s2 += 2) {         // rounds s2 .. s2 + 2 are full and end before the last layer
+                issue_full(s2 + 1, v[1]);             // unrolled by two: the register sets alternate without copies
+                store_full(s2, v[0]);
+                RC_SYNC();
+                issue_full(s2 + 2, v[0]);
+                store_full(s2 + 1, v[1]);
+                RC_SYNC();
+            }
+        }
+        for (; s2 < nsteps; s2 += 2) {
+            if (s2 + 1 < nrounds) issue(s2 + 1, v[1]);
+            if (s2 < nrounds) store(s2, v[0]);
+            RC_SYNC();
+            if (s2 + 1 < nsteps) {
+                if (s2 + 2 < nrounds) issue(s2 + 2, v[0]);
+                if (s2 + 1 < nrounds) store(s2 + 1, v[1]);
+                RC_SYNC();
+            }
+        }
+        RC_SYNC();
+        RC_DONE();
+        return;
+    }
+
+    const double b_top = a.b_top;
+    const double cos_theta = ZP ? 1.0 : a.cos_theta;
+    const double F = a.F0PI[w], rs = a.surf_reflect[w];
+    Exp2Coef K;
+    K.load();
+
+    if (is_s) {
+        // ------------------------------------------------------------------------------------------------
+        // wave S: one round ahead of the angle waves
+        // ------------------------------------------------------------------------------------------------
+        RcShared sh{0.0, 0.0, 0.0};
+        auto produce_round = [&](int q) {
+            const int plain = __builtin_amdgcn_readfirstlane(rplain[q % 3]);
+            if (plain) {                              // straight-line: the layers of the round interleave
+#pragma unroll
+                for (int j = 0; j < RC_R; ++j)
+                    rc_shared<true>(a, raw[q % 3][j], ring[q & 1][j], RCF_ALL, true, lane, F, cos_theta, K, sh);
+            } else {
+#pragma unroll
+                for (int j = 0; j < RC_R; ++j) {
+                    const int i = q * RC_R + j;
+                    if (i < n) {
+                        const int fl = __builtin_amdgcn_readfirstlane(lflag[q % 3][j]);
+                        rc_shared<false>(a, raw[q % 3][j], ring[q & 1][j], fl, i > 0, lane, F, cos_theta, K, sh);
+                    }
+                }
+            }
+        };
+        RC_SYNC();                              // round 0 of the planes is in LDS
+        produce_round(0);
+        RC_SYNC();
+        for (int t = 0; t < nrounds; ++t) {
+            if (t + 1 < nrounds) produce_round(t + 1);
+            RC_SYNC();
+        }
+        // fused disco.compress_disco (disco.py:145-148): one running sum over the angles in (g, t) order
+        RC_SYNC();
+        if (a.albedo && active) {
+            double alb = a.albedo_first ? 0.0 : a.albedo[w];
+            for (int j = 0; j < nang; ++j) alb = alb + xs[j][lane] * a.ang[j].wgt * a.ang[j].wgt2;
+            if (a.albedo_last) alb = a.albedo_scale * alb / F * (a.cos_theta + 1.0);
+            a.albedo[w] = alb;
+        }
+        RC_DONE();
+        return;
+    }
+
+    // ----------------------------------------------------------------------------------------------------
+    // wave A_k: the per-angle part of the sweep (reflected_layer's angle loop body, iteration k)
+    // ----------------------------------------------------------------------------------------------------
+    auto angle_wave = [&](auto na_c) {
+        constexpr int NA = decltype(na_c)::value;
+        ReflectedArgs::Angle g[NA];
+        RcState st[NA];
+#pragma unroll
+        for (int kk = 0; kk < NA; ++kk) {
+            g[kk] = a.ang[k0 + kk];
+            st[kk].T = 1.0;
+            st[kk].XU = fexp2(mul_unfused(a.tau[col], ZP ? g[kk].nl1 : g[kk].nl0), K);
+            st[kk].EO = st[kk].KAPPA = st[kk].ZETA = st[kk].D1 = st[kk].D2 = 0.0;
+            st[kk].l_gam = st[kk].l_EM = st[kk].l_rho = 0.0;
+        }
+        auto consume_round = [&](int q, int plain) {
+            if (plain) {                              // interior layers, all shortcuts, no cloud: straight-line
+#pragma unroll
+                for (int j = 0; j < RC_R; ++j)
+                    rc_angle<ZP, false, false, true, NA>(raw[q % 3][j], ring[q & 1][j], RCF_ALL, lane, g, K, b_top, st);
+                return;
+            }
+#pragma unroll
+            for (int j = 0; j < RC_R; ++j) {
+                const int i = q * RC_R + j;
+                if (i >= n) break;
+                const double(*in)[64] = raw[q % 3][j];
+                const double(*slot)[64] = ring[q & 1][j];
+                const int fl = __builtin_amdgcn_readfirstlane(lflag[q % 3][j]);
+                if (i == 0) {
+                    if (n == 1) rc_angle<ZP, true, true, false, NA>(in, slot, fl, lane, g, K, b_top, st);
+                    else rc_angle<ZP, true, false, false, NA>(in, slot, fl, lane, g, K, b_top, st);
+                } else if (i == n - 1) {
+                    rc_angle<ZP, false, true, false, NA>(in, slot, fl, lane, g, K, b_top, st);
+                } else {
+                    rc_angle<ZP, false, false, false, NA>(in, slot, fl, lane, g, K, b_top, st);
+                }
+            }
+        };
+        RC_SYNC();                                    // planes of round 0 (and its flags)
+        int plain = __builtin_amdgcn_readfirstlane(rplain[0]);
+        RC_SYNC();                                    // wave S's round 0; planes of round 1
+        for (int t = 0; t < nrounds; ++t) {
+            // the flags of the next round are in LDS already (wave L is two rounds ahead): read them before this
+            // round's arithmetic, so that the step does not begin with an exposed LDS round trip
+            const int plain_next = (t + 1 < nrounds) ? __builtin_amdgcn_readfirstlane(rplain[(t + 1) % 3]) : 0;
+            consume_round(t, plain);
+            plain = plain_next;
+            RC_SYNC();
+        }
+        // ---- surface row (fluxes.py:178-183) and output: the epilogue of k_reflected_toa for these angles ----
+#pragma unroll
+        for (int kk = 0; kk < NA; ++kk) {
+            const double em2 = st[kk].l_EM * st[kk].l_EM;
+            const double bden = 1.0 / fma(-(em2 * (st[kk].l_gam - rs)), st[kk].l_rho, fma(-rs, st[kk].l_gam, 1.0));
+            const double b_surface = ((rs * (ZP ? g[kk].u1 : g[kk].u0)) * F) * st[kk].XU;
+            const double pos = (st[kk].l_EM * fma(rs, st[kk].D2, b_surface - st[kk].D1)) * bden;
+            const double x = fma(st[kk].ZETA, pos, st[kk].KAPPA);
+            if (active) a.xint[(long)(k0 + kk) * a.ncol + col] = x;
+            xs[k0 + kk][lane] = x;
+        }
+        RC_SYNC();
+        RC_DONE();
+    };
+    static_assert(RC_APW == 1 || RC_APW == 2, "angle waves carry one or two angles");
+    if (RC_APW == 2 && nang - k0 >= 2) angle_wave(std::integral_constant<int, RC_APW>{});
+    else angle_wave(std::integral_constant<int, 1>{});
+}
+
+bool reflected_coop_ok(const ReflectedArgs &a)
+{
+    if (getenv("PICASO_AMD_REFL_NO_COOP")) return false;
+    if (a.na < 1 || a.na > RC_MAX_ANGLES || a.ny > 1 || a.nlayer < 1) return false;
+    // the reference's default options (what reflected_layer<.., FAST = true> fixes at compile time)
+    return a.toon_coefficients == 0 && a.single_phase == 3 && a.multi_phase == 0 && a.frac_c == 2.0;
+}
+
+#ifdef PZ_RCOOP_TIMING
+}  // namespace pz
+extern "C" int picaso_debug_rcoop(long long *out32)
+{
+    return hipMemcpyFromSymbol(out32, HIP_SYMBOL(pz::rc_dbg), sizeof(long long) * 32) == hipSuccess ? 0 : 1;
+}
+namespace pz {
+#endif
+
+int launch_reflected_coop(picaso_ctx *ctx, const ReflectedArgs &a)
+{
+    if (a.ncol <= 0) return fail(ctx, "reflected: empty problem");
+    bool zp = true;
+    for (int k = 0; k < a.na; ++k) zp = zp && (a.ang[k].u0 == a.ang[k].u1);
+    if (zp && a.cos_theta != 1.0) zp = false;          // as fast_options: the ZP variant fixes cos_theta = 1
+    const dim3 grid((unsigned)((a.ncol + 63) / 64)), block(64 * ((a.na + RC_APW - 1) / RC_APW + 2));
+    if (zp)
+        hipLaunchKernelGGL((k_reflected_coop<true>), grid, block, 0, ctx->stream, a);
+    else
+        hipLaunchKernelGGL((k_reflected_coop<false>), grid, block, 0, ctx->stream, a);
+    PZ_HIP(ctx, hipGetLastError());
+    return 0;
+}
+
+}  // namespace pz
