@@ -242,6 +242,7 @@ def spawn_ranks(ngpus):
                                       stdout=None if r == 0 else subprocess.DEVNULL))
     rc = 0
     alive = list(procs)
+    kill_at = None
     while alive:
         for p in list(alive):
             code = p.poll()
@@ -250,8 +251,11 @@ def spawn_ranks(ngpus):
             alive.remove(p)
             if code != 0 and rc == 0:
                 rc = code
-                for q in alive:                  # a rank died: the others would wait at the rendezvous for ever
-                    q.terminate()
+                kill_at = time.time() + 5.0      # the others usually fail for the same reason and say so themselves
+        if kill_at is not None and time.time() > kill_at:
+            for q in alive:                      # ... or they would wait at the rendezvous for ever
+                q.terminate()
+            kill_at = float("inf")
         time.sleep(0.02)
     if rc != 0:
         print("bench.py: a rank of the %d-GPU job failed (exit status %d)" % (ngpus, rc), file=sys.stderr, flush=True)
