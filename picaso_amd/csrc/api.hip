@@ -99,34 +99,39 @@ static bool spread_angles(long ncol, int nang, long limit = 1280L * 64)
 }
 
 // Reflected kernel: how many angles a wave carries (0 = all of them fused in one lane, the launch of the
-// large grids).  A sweep is one long dependent chain, so below ~1 wave per SIMD (1024 SIMDs) the time of a
-// launch is the time of ONE wave, which grows with the angles it carries.  Mid-size grids therefore run groups
-// of g angles as separate workgroups (XCD-aware order, see k_reflected_toa) and the disk sum as a separate pass;
-// measured per shape (steady clocks, 90 layers, 5 angles, disk sum included; tools/experiments/
-// angle_group_sweep.sh, knee.sh) -- while the launch has at most one 256-thread workgroup per CU (one wave per
-// SIMD): g=1 0.050 ms, g=2 0.063, g=3 0.084; at most two per CU: g=1 0.084, g=2 0.100-0.117, g=3 0.140;
-// all five fused with the state in registers (one wave per SIMD, up to 65 536 columns) 0.105-0.130, with two
-// waves per SIMD 0.225.  One workgroup more than that and the time jumps (26 200 columns g=1: 0.119).  The
-// cheapest shape that fits is taken: up to 13 056 columns g=1, to 21 760 g=2, to 32 768 g=3, then fused.
-// (Before the branch-free layer body the numbers were 0.050 / 0.070 / 0.098 alone, 0.136 fused.)  The result does not depend on the shape (explicit-fma arithmetic,
-// disk sum in the reference's order).
+// large grids).  A sweep is one long dependent chain, so below ~1 wave per SIMD the time of a launch is the time of
+// ONE wave, which grows with the angles it carries.  Mid-size grids therefore run groups of g angles as separate
+// workgroups (XCD-aware order, see k_reflected_toa) and the disk sum as a separate pass.  (Launches of up to one
+// 64-column block per CU with the reference's default options take k_reflected_coop instead, reflected_1d_core.)
+//
+// The choice is made from a two-constant model of a wave's time per layer, fitted to steady-state measurements on
+// the MI355X at 90 layers and 5 angles (tools/experiments/angle_group_sweep.sh, knee.sh):
+//     a wave that carries g angles and has its SIMD to itself:   t1(g) = T_SHARED + g * T_ANGLE        per layer
+//     ... and shares the SIMD with a second wave of the launch:  t2(g) = PAIRED * t1(g)
+// (g = 1, 2, 3 alone: 0.050 / 0.063 / 0.084 ms at 90 layers -> 0.37 + 0.19 g us per layer; paired 0.085 / 0.110 /
+// 0.140 -> x 1.7; five angles fused with the state in registers 0.105-0.130.)  Every shape scales with the layer
+// count alike, so only the RATIOS matter for the choice; what depends on the device is how many 256-thread
+// workgroups a shape may have before it doubles up: one per CU (ctx->ncu) for t1, two per CU for t2, and the
+// fused launch keeps one wave per SIMD up to 4 * ncu column-waves.  The result does not depend on the shape
+// (explicit-fma arithmetic, disk sum in the reference's order).
 static int reflected_angle_group(picaso_ctx *ctx, long ncol, int nang)
 {
     if (const char *e = getenv("PICASO_AMD_ANGLE_GROUP")) return atoi(e);
     if (nang <= 1) return 0;
     if (nang > MAX_ANGLES) return spread_angles(ncol, nang, 2560L * 64) ? 1 : 0;
     const long colwaves = (ncol + 63) / 64, ncg = (ncol + 255) / 256, ncu = ctx->ncu;
-    if (colwaves > 4L * ncu) return 0;
-    // (five angles alone: the all-register variant of the kernel, 0.136; with the state in LDS 0.160)
-    static const double alone[MAX_ANGLES + 1] = {0, 0.050, 0.063, 0.084, 0.128, 0.105, 0.192, 0.224, 0.256};
-    static const double paired[4] = {0, 0.085, 0.110, 0.140};
-    double best = alone[nang];
+    if (colwaves > 4L * ncu) return 0;                 // more than one fused wave per SIMD: throughput regime
+    constexpr double T_SHARED = 0.37, T_ANGLE = 0.19, PAIRED = 1.7;       // us per layer, see above
+    auto t1 = [&](int g) { return T_SHARED + g * T_ANGLE; };
+    // all angles in one lane, one wave per SIMD: the state is in registers up to three angles and for five (the BIG
+    // instantiation) and runs at the model's rate; four and six to eight keep part of it in LDS (~25 % slower)
+    double best = t1(nang) * ((nang <= 3 || nang == 5) ? 1.0 : 1.25);
     int group = 0;
     for (int g = 1; g <= 3 && g < nang; ++g) {
         const int ngroups = (nang + g - 1) / g;
         if (ngroups * g > MAX_ANGLES) continue;
         const long blocks = ncg * ngroups;
-        const double t = blocks <= ncu ? alone[g] : blocks <= 2 * ncu ? paired[g] : 1e9;
+        const double t = blocks <= ncu ? t1(g) : blocks <= 2 * ncu ? PAIRED * t1(g) : 1e9;
         if (t < best) { best = t; group = g; }
     }
     return group;
