@@ -549,7 +549,7 @@ def _setup_atmosphere(inp, opa, wno, profile=None, cloud_profile=None):
 
 
 def picaso(bundle, opacityclass, dimension="1d", calculation="reflected", full_output=False,
-           plot_opacity=False, as_dict=True, defer=False, devices=None, gather="host", _raw=False):
+           plot_opacity=False, as_dict=True, defer=False, devices=None, gather="host", _raw=False, _shared=None):
     """Spectrum driver (reference ``picaso()``, justdoit.py:65-621, 1-D Toon branch).
 
     ``defer=True`` (used by ``phase_curve``): every kernel of the spectrum is enqueued and a function is
@@ -647,6 +647,8 @@ def picaso(bundle, opacityclass, dimension="1d", calculation="reflected", full_o
             planes3d = optics.compute_opacity_facets(atm_f, opa, ng, nt, **co3)
             tlev3 = atm_f.level["temperature"].reshape(nlv, ng, nt)
             plev3 = np.ascontiguousarray(np.broadcast_to(atm_f.level["pressure"].reshape(nlv, 1, 1), (nlv, ng, nt)))
+    elif _shared is not None:
+        atm = _atmosphere_block(_shared["atm"], _shared["lo"], _shared["hi"], wno)
     else:
         atm = _setup_atmosphere(inp, opa, wno)
     nlevel, nlayer = atm.c.nlevel, atm.c.nlayer
@@ -654,7 +656,10 @@ def picaso(bundle, opacityclass, dimension="1d", calculation="reflected", full_o
     fhole = planes = planes_clear = None
     gauss_wts = np.asarray(opa.gauss_wts, dtype=float)
     if dimension == "1d":
-        opa.get_opacities(atm, exclude_mol=inp["atmosphere"]["exclude_mol"])
+        if _shared is not None and _shared.get("plan") is not None:
+            opa._plan = _shared["plan"]         # table rows / weights per layer: the same for every wavelength block
+        else:
+            opa.get_opacities(atm, exclude_mol=inp["atmosphere"]["exclude_mol"])
         # only the planes the requested legs read are written (toon: 11 for reflected light, 3 for
         # thermal emission, 1 for transmission; the SH solvers take the whole set)
         want = None
@@ -689,6 +694,7 @@ def picaso(bundle, opacityclass, dimension="1d", calculation="reflected", full_o
         _lib.ctx_wait(tctx, ctx)
     returns = {"wavenumber": wno}
     dev_results = {}          # per-wavelength results still in HBM (the multi-GPU form gathers them with RCCL)
+    enqueued = False
     try:
         # every leg first enqueues its kernels; the copies back (each a stream synchronisation) and the
         # host-side integrals run afterwards, so the GPU goes through reflected + thermal (+ transit)
@@ -845,18 +851,29 @@ def picaso(bundle, opacityclass, dimension="1d", calculation="reflected", full_o
         if not defer:
             for fin in collect:
                 fin()
+        enqueued = True
     finally:
-        # an exception between enqueueing the thermal leg on the second stream and its copy back must
-        # not let the plane blocks return to the pool while that stream may still read them
-        if tctx is not ctx:
+        # The thermal leg may run on a second stream (tctx) that reads the opacity planes of `ctx`.  The planes must
+        # not return to ctx's block cache while that stream may still read them: in the normal case the copies back
+        # (each a synchronisation of the stream that produced the result) have run by the time they are released --
+        # at the end of this call, or, with defer=True, when `finish` (which keeps them alive) is done.  Only an
+        # exception in between needs the explicit wait.  (A wait here on every call would also make the blocks of
+        # a multi-GPU spectrum, each enqueued with defer=True, take turns instead of running side by side.)
+        if tctx is not ctx and not enqueued:
             try:
                 device.sync(tctx)
             except Exception:
                 pass
+    # planes read from the second stream stay alive until the results are in; everything else returns to the
+    # context's block cache as soon as its kernels are enqueued (reuse is ordered on the stream: the phases of a
+    # phase curve recycle one set of plane blocks)
+    keep_alive = [planes, planes_clear] if tctx is not ctx else []
+
     def finish():
         if defer:
             for fin in collect:
                 fin()
+        del keep_alive[:]
         if _raw:          # one wavelength block of a multi-GPU spectrum: the integrals need the whole grid
             if full_output:
                 returns["full_output"] = atm.as_dict() if as_dict else atm
@@ -919,6 +936,19 @@ def _opacity_shards(opa, devs):
             raise Exception("devices=%d but the grid has only %d wavelengths" % (len(devs), opa.nwno))
         cache[key] = [(lo, hi, optics.shard_opacity(opa, lo, hi, c)) for (lo, hi), c in zip(bounds, ctxs)]
     return cache[key]
+
+
+def _atmosphere_block(atm0, lo, hi, wno):
+    """One wavelength block's view of an ATMSETUP that was set up once for the whole grid: everything but the
+    cloud tables and the wavenumbers is per layer / level and shared; the cloud arrays are column slices (views)."""
+    atm = copy.copy(atm0)
+    atm.wavenumber = wno
+    atm.layer = dict(atm0.layer)
+    atm.layer["cloud"] = {k: v[:, lo:hi] for k, v in atm0.layer["cloud"].items()}
+    sr = atm0.surf_reflect
+    if np.ndim(sr) > 0 and np.size(sr) == np.shape(atm0.layer["cloud"]["opd"])[1]:
+        atm.surf_reflect = np.ascontiguousarray(np.asarray(sr, dtype=float)[lo:hi])
+    return atm
 
 
 class _Bundle:
@@ -997,11 +1027,23 @@ def _picaso_devices(bundle, opa, devices, gather, dimension, calculation, full_o
     nwno = opa.nwno
     nlevel = getattr(bundle, "nlevel", None)
     nlayer = (nlevel - 1) if nlevel else 0
+    # The atmosphere set-up (hydrostatic altitude, column densities, cloud tables on the opacity grid) and the table
+    # rows / weights of every layer do not depend on the wavelength block: done once for the whole grid, not once
+    # per device (0.5 ms of host time per block otherwise, which on eight GPUs is more than the spectrum itself)
+    shared = None
+    if dimension == "1d" and len(shards) > 1:
+        atm0 = _setup_atmosphere(inp, opa, opa.wno)
+        plan = None
+        if not getattr(opa, "on_fly", False):       # on-the-fly mixing leaves a per-block table on each device
+            opa.get_opacities(atm0, exclude_mol=inp["atmosphere"]["exclude_mol"])
+            plan = opa._plan
+        shared = dict(atm=atm0, plan=plan)
     fins = []
     for lo, hi, sub in shards:
         b = _Bundle(_slice_inputs(inp, lo, hi, nwno, nlayer), nlevel)
+        sh = dict(shared, lo=lo, hi=hi) if shared is not None else None
         fins.append(picaso(b, sub, dimension=dimension, calculation=calculation, full_output=full_output,
-                           plot_opacity=plot_opacity, as_dict=True, defer=True, _raw=True))
+                           plot_opacity=plot_opacity, as_dict=True, defer=True, _raw=True, _shared=sh))
     gathered = {}
     if gather == "rccl" and len(devs) > 1:
         if len(set(devs)) != len(devs):

@@ -731,7 +731,12 @@ def gas_stage(atm, opa, taugas, tauray):
     and weights from ``opa.get_opacities(atm)``, per-layer coefficients of reference optics.py:144-277."""
     pl = opa._plan
     nlayer, ngauss = atm.c.nlayer, opa.ngauss
-    mol_fac, cont_fac, ray_names, ray_fac = _layer_factors(atm, opa)
+    # per-layer coefficients: a plan shared by the wavelength blocks of one spectrum (picaso(devices=N)) computes them once
+    fac = pl.get("_factors")
+    if fac is None or fac[0] is not atm.layer["mixingratios"]:
+        fac = (atm.layer["mixingratios"], _layer_factors(atm, opa))
+        pl["_factors"] = fac
+    mol_fac, cont_fac, ray_names, ray_fac = fac[1]
     cont_tabs = [opa._cia[p] for p in pl["cia_pairs"]]
     if pl.get("premixed"):
         mol_tabs, mol_mode = [pl.get("table", opa._kappa)], 2

@@ -44,10 +44,17 @@ if os.environ.get("PROFILE_1D"):
     pr.disable()
     pstats.Stats(pr).sort_stats("cumulative").print_stats(35)
     sys.exit(0)
-ts = []
-for _ in range(20):
-    t0 = time.perf_counter()
-    r = case.spectrum(opa, calculation=calc)
-    ts.append(time.perf_counter() - t0)
-print(json.dumps({"spectrum_1d_%d_%s_ms" % (nwno, calc): round(1e3 * min(ts), 3), "median_ms": round(1e3 * float(np.median(ts)), 3),
-                  "albedo_sum": float(np.sum(r.get("albedo", 0.0)))}))
+out = {}
+# DEVICES="0,0,0,0": the same spectrum in wavelength blocks (on one GPU: one context per entry), host cost of the cut
+devsets = [None] + [[int(x) for x in d.split(",")] for d in os.environ.get("DEVICES", "").split(";") if d]
+for devs in devsets:
+    for _ in range(10):
+        r = case.spectrum(opa, calculation=calc, devices=devs)
+    ts = []
+    for _ in range(20):
+        t0 = time.perf_counter()
+        r = case.spectrum(opa, calculation=calc, devices=devs)
+        ts.append(time.perf_counter() - t0)
+    out["spectrum_1d_%d_%s_devices_%s_ms" % (nwno, calc, "none" if devs is None else len(devs))] = round(1e3 * min(ts), 3)
+out["albedo_sum"] = float(np.sum(r.get("albedo", 0.0)))
+print(json.dumps(out))
