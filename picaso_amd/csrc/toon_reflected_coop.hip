@@ -148,8 +148,16 @@ __device__ __forceinline__ void rc_angle(const double (*in)[64], const double (*
     RC_FOR_K lp1[kk] = lu[kk] + 1.0;
     RC_FOR_K lml[kk] = lm1[kk] * lp1[kk];
     RC_FOR_K q3[kk] = den[kk] * lml[kk];
+#ifdef PZ_RCOOP_STUB_EXP                               // timing build (wrong results): what an exp helper could save
+    RC_FOR_K et[kk] = targ[kk] + 1.0;
+#else
     fexp2_n<NA>(targ, K, et);
+#endif
+#ifdef PZ_RCOOP_STUB_RCP
+    RC_FOR_K r3[kk] = q3[kk] + 1.0;
+#else
     frcp_n<NA>(q3, r3);
+#endif
     if (ZP) {
         RC_FOR_K e0[kk] = et[kk];
     } else {
