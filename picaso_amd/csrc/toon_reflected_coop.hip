@@ -349,6 +349,97 @@ __device__ __forceinline__ void rc_shared(const ReflectedArgs &a, const double (
     }
 }
 
+// NL-wide fsqrt (device_math.hpp), as fexp2_n / frcp_n above
+template <int NL>
+__device__ __forceinline__ void fsqrt_n(const double (&x)[NL], double (&out)[NL])
+{
+#pragma clang fp contract(off)
+    double y[NL], g[NL], h[NL], r[NL], d[NL];
+#define RC_FOR_J _Pragma("unroll") for (int j = 0; j < NL; ++j)
+    RC_FOR_J y[j] = __builtin_amdgcn_rsq(x[j]);
+    RC_FOR_J g[j] = x[j] * y[j];
+    RC_FOR_J h[j] = 0.5 * y[j];
+    RC_FOR_J r[j] = fma(-h[j], g[j], 0.5);
+    RC_FOR_J g[j] = fma(g[j], r[j], g[j]);
+    RC_FOR_J h[j] = fma(h[j], r[j], h[j]);
+    RC_FOR_J r[j] = fma(-h[j], g[j], 0.5);
+    RC_FOR_J g[j] = fma(g[j], r[j], g[j]);
+    RC_FOR_J h[j] = fma(h[j], r[j], h[j]);
+    RC_FOR_J d[j] = fma(-g[j], g[j], x[j]);
+    RC_FOR_J g[j] = fma(d[j], h[j], g[j]);
+    RC_FOR_J out[j] = (x[j] == 0.0) ? x[j] : g[j];
+}
+
+// A whole PLAIN round of wave S (NL interior layers without cloud, all shortcuts): rc_shared<true> for each of
+// them, with the layer-local chains (gammas -> square root -> Gamma; lambda dtau -> exp -> reciprocal) written over
+// the NL layers so that they fill each other's latency -- alone they are ~45 dependent instructions per layer, which
+// made wave S the slowest wave of the workgroup -- and only the rho recurrence left sequential.
+template <int NL>
+__device__ __forceinline__ void rc_shared_plain_round(const double (*in)[RW_NV][64], double (*slot)[RC_NV][64],
+                                                      int lane, double F, double cos_theta, const Exp2Coef &K,
+                                                      RcShared &sh)
+{
+#pragma clang fp contract(off)
+    double dt[NL], w0[NL], fr[NL], w0o[NL];
+    RC_FOR_J {
+        dt[j] = in[j][RW_DT][lane];
+        w0[j] = in[j][RW_W0][lane];
+        fr[j] = in[j][RW_FR][lane];
+        w0o[j] = in[j][RW_W0O][lane];
+    }
+    double g1[NL], g2[NL], aa[NL], bb[NL], dd[NL], lam[NL], ig2[NL], gam[NL], E[NL], targ[NL], EP[NL], EM[NL];
+    RC_FOR_J g1[j] = (SQ3 * 0.5) * (2.0 - w0[j]);               // toon_gammas_nocld, quadrature
+    RC_FOR_J g2[j] = SQ3 * w0[j] * 0.5;
+    RC_FOR_J aa[j] = g1[j] * g1[j];
+    RC_FOR_J bb[j] = g2[j] * g2[j];
+    RC_FOR_J dd[j] = aa[j] - bb[j];
+    fsqrt_n<NL>(dd, lam);
+    frcp_n<NL>(g2, ig2);
+    RC_FOR_J gam[j] = (g1[j] - lam[j]) * ig2[j];
+    RC_FOR_J E[j] = fmin(lam[j] * dt[j], 35.0);                 // fluxes.py:1174
+    RC_FOR_J targ[j] = E[j] * -NEG_LOG2E;
+    fexp2_n<NL>(targ, K, EP);
+    frcp_n<NL>(EP, EM);
+    double ps[NL], ssa_h[NL], w2pi[NL], Fw0h[NL], A0[NL];
+    RC_FOR_J ps[j] = fr[j] * (0.75 * fma(cos_theta, cos_theta, 1.0));
+    RC_FOR_J ssa_h[j] = (w0o[j] * F * (0.125 / PI)) * ps[j];
+    RC_FOR_J w2pi[j] = w0[j] * (0.5 / PI);
+    RC_FOR_J Fw0h[j] = (0.5 * F) * w0[j];
+    RC_FOR_J A0[j] = g1[j] + g2[j];
+    RC_FOR_J {
+        slot[j][RC_LAM][lane] = lam[j];
+        slot[j][RC_EP][lane] = EP[j];
+        slot[j][RC_EM][lane] = EM[j];
+        slot[j][RC_GAM][lane] = gam[j];
+        slot[j][RC_FW0H][lane] = Fw0h[j];
+        slot[j][RC_A0][lane] = A0[j];
+        slot[j][RC_W2PI][lane] = w2pi[j];
+        slot[j][RC_SSAH][lane] = ssa_h[j];
+    }
+    RC_FOR_J {                                                  // the one sequential part: the recurrence rho
+        const double em2 = sh.pEM * sh.pEM;
+        const double a1 = fma(-(sh.pgam * em2), sh.rho, 1.0);
+        const double a2 = fma(-em2, sh.rho, sh.pgam);
+        const double d1 = fma(-gam[j], a2, a1);
+        const double r12 = frcp(d1 * a1);
+        const double inv = r12 * a1;
+        const double a1i = a1 * inv;
+        const double a2i = a2 * inv;
+        const double rho_n = fma(gam[j], a1i, -a2i);
+        const double ia = sh.pEM * (r12 * d1);
+        const double sfac = fma(-gam[j], rho_n, 1.0) * ia;
+        sh.rho = rho_n;
+        sh.pgam = gam[j];
+        sh.pEM = EM[j];
+        slot[j][RC_A1I][lane] = a1i;
+        slot[j][RC_A2I][lane] = a2i;
+        slot[j][RC_IA][lane] = ia;
+        slot[j][RC_SFAC][lane] = sfac;
+        slot[j][RC_RHON][lane] = rho_n;
+    }
+#undef RC_FOR_J
+}
+
 // ZP: every angle has ubar0 == ubar1 (zero phase angle), as in k_reflected_toa
 template <bool ZP>
 __global__ __launch_bounds__(64 * (RC_MAX_ANGLES / RC_APW + 2)) void k_reflected_coop(const ReflectedArgs a)
@@ -515,10 +606,14 @@ __global__ __launch_bounds__(64 * (RC_MAX_ANGLES / RC_APW + 2)) void k_reflected
         RcShared sh{0.0, 0.0, 0.0};
         auto produce_round = [&](int q) {
             const int plain = __builtin_amdgcn_readfirstlane(rplain[q % 3]);
-            if (plain) {                              // straight-line: the layers of the round interleave
+            if (plain) {                              // straight-line, the layers of the round interleaved
+#ifdef PZ_RCOOP_STUB_S
 #pragma unroll
                 for (int j = 0; j < RC_R; ++j)
                     rc_shared<true>(a, raw[q % 3][j], ring[q & 1][j], RCF_ALL, true, lane, F, cos_theta, K, sh);
+#else
+                rc_shared_plain_round<RC_R>(raw[q % 3], ring[q & 1], lane, F, cos_theta, K, sh);
+#endif
             } else {
 #pragma unroll
                 for (int j = 0; j < RC_R; ++j) {
