@@ -119,11 +119,17 @@ __device__ __forceinline__ void rc_angle(const double (*in)[64], const double (*
     constexpr bool first = FIRST, last = LAST;
     const bool cum_tau = PLAIN || (fl & RCF_CUM_TAU), eo_ok = PLAIN || (fl & RCF_EO_OK),
                same_dt = PLAIN || (fl & RCF_SAME_DT), nocld = PLAIN || (fl & RCF_NOCLD);
+#ifdef PZ_RCOOP_STUB_LDS                               // timing build (wrong results): 3 LDS reads per layer instead of 15
+    const double lam = slot[RC_LAM][lane], EP = slot[RC_EP][lane], dt = in[RW_DT][lane];
+    const double EM = lam * 0.9, gam = EP * 0.5, Fw0h = lam * 0.1, A0 = EP * 0.2, w2pi = dt * 0.3, ssa_h = lam * 0.05;
+    const double gcq = EP * 0.01, a1i = lam * 1.1, a2i = EP * 0.3, ia = dt * 0.7, sfac = lam * 0.6, rho_n = EP * 0.4;
+#else
     const double lam = slot[RC_LAM][lane], EP = slot[RC_EP][lane], EM = slot[RC_EM][lane];
     const double gam = slot[RC_GAM][lane], dt = in[RW_DT][lane], Fw0h = slot[RC_FW0H][lane];
     const double A0 = slot[RC_A0][lane], w2pi = slot[RC_W2PI][lane], ssa_h = slot[RC_SSAH][lane];
     const double gcq = in[RW_GCOS2][lane], a1i = slot[RC_A1I][lane], a2i = slot[RC_A2I][lane];
     const double ia = slot[RC_IA][lane], sfac = slot[RC_SFAC][lane], rho_n = slot[RC_RHON][lane];
+#endif
     double A1 = 0.0, c15 = 0.0, gmc = 0.0;
     if (!nocld) {
         A1 = slot[RC_A1][lane];
