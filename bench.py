@@ -281,13 +281,16 @@ def main():
                     help="wavelengths of the same workload timed on the CPU oracle (0 = skip)")
     ap.add_argument("--steady-steps", type=int, default=2000,
                     help="N = 1: steps of an extra untimed run after the timed region, reported as steady_state")
+    ap.add_argument("--spawn", action="store_true",
+                    help="start the ranks as subprocesses also for --gpus 1 (the N > 1 code path -- rendezvous, RCCL "
+                         "communicator, gather in the timed region, checks -- with one rank, on a 1-GPU box)")
     ap.add_argument("--rendezvous-only", action="store_true",
                     help="start the ranks, let them find each other (HostGroup) and exit: checks the launch path "
                          "of a node without touching a GPU")
     args = ap.parse_args()
 
     launched = "RANK" in os.environ
-    if args.gpus > 1 and not launched:
+    if (args.gpus > 1 or args.spawn) and not launched:
         raise SystemExit(spawn_ranks(args.gpus))
     rank, world, local_rank, addr, port = sharding.launcher_env()
     if world != args.gpus:

@@ -5,6 +5,7 @@ into its slice of a shared result -- is bit-identical to the unsharded launch.  
 needs more than one GPU: RCCL refuses two ranks on one device; bench.py --gpus N covers that on the
 multi-GPU node.)"""
 import ctypes
+import os
 
 import numpy as np
 import pytest
@@ -113,3 +114,26 @@ def test_product_sharded_over_contexts_bit_identical(world):
     for c in ctxs[1:]:
         _lib.load().picaso_ctx_destroy(c)
     assert np.array_equal(got, want)
+
+
+def test_bench_self_spawned_rank_runs_the_sharded_path():
+    """`python bench.py --gpus 1 --spawn`: bench.py's own launcher starts the rank as a subprocess with the
+    environment it gives every rank of an N-GPU job; the rank rendezvous, builds the RCCL communicator inside the
+    library, gathers in the timed region and prints the one JSON line with `per_rank` and the bit-identity checks --
+    everything the driver's `bench.py --gpus N` does, with the one rank a 1-GPU box allows."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--spawn", "--steps", "4",
+                        "--warmup", "2", "--nwno", "20000", "--prewarm-ms", "20", "--cpu-sample", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1                                    # ONE JSON line on stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 1 and out["steps"] == 4 and len(out["per_rank"]) == 1
+    assert out["checks"]["gathered_contains_local_shard"] is True
+    assert out["checks"]["bit_identical_to_unsharded"] is True
+    assert out["config"]["collective"].startswith("RCCL all-gather")
