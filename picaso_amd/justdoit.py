@@ -967,9 +967,11 @@ class _Bundle:
         self.inputs, self.nlevel = inputs_dict, nlevel
 
 
-def _slice_inputs(inp, lo, hi, nwno, nlayer):
+def _slice_inputs(inp, lo, hi, nwno, nlayer, clouds=True):
     """The run configuration as one wavelength block sees it: per-wavelength inputs (stellar flux, surface
-    reflectivity, cloud tables already on the opacity grid) cut to ``[lo, hi)``; everything else shared."""
+    reflectivity, cloud tables already on the opacity grid) cut to ``[lo, hi)``; everything else shared.
+    ``clouds=False``: the block takes its cloud columns from an atmosphere that was set up once for the whole grid
+    (``_atmosphere_block``: views, no copies of the (nlayer, nwno) tables)."""
     out = dict(inp)
     star = dict(inp["star"])
     rf = star.get("relative_flux")
@@ -980,7 +982,7 @@ def _slice_inputs(inp, lo, hi, nwno, nlayer):
     if sr is not None and np.size(sr) == nwno and nwno > 1:
         out["surface_reflect"] = np.ascontiguousarray(np.asarray(sr, dtype=float).reshape(nwno)[lo:hi])
     cl = dict(inp["clouds"])
-    prof = cl.get("profile")
+    prof = cl.get("profile") if clouds else None
     if prof is not None:
         new = {}
         for k in ("opd", "g0", "w0"):
@@ -1051,7 +1053,7 @@ def _picaso_devices(bundle, opa, devices, gather, dimension, calculation, full_o
         shared = dict(atm=atm0, plan=plan)
     fins = []
     for lo, hi, sub in shards:
-        b = _Bundle(_slice_inputs(inp, lo, hi, nwno, nlayer), nlevel)
+        b = _Bundle(_slice_inputs(inp, lo, hi, nwno, nlayer, clouds=shared is None), nlevel)
         sh = dict(shared, lo=lo, hi=hi) if shared is not None else None
         fins.append(picaso(b, sub, dimension=dimension, calculation=calculation, full_output=full_output,
                            plot_opacity=plot_opacity, as_dict=True, defer=True, _raw=True, _shared=sh))
