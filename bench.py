@@ -156,7 +156,8 @@ def workload_sh4(ctx, args, lo, hi, seed, nwno_total):
     def oracle(sl):
         from oracle import oracle as orc
         ns = sl.stop - sl.start
-        planes = [np.ascontiguousarray(scene[k][:, sl]) for k in resident.SH_PLANES]
+        # copies: the reference multiplies f_deltaM in place once per angle (and so does its restatement)
+        planes = [np.array(scene[k][:, sl], order="C") for k in resident.SH_PLANES]
         xo, _ = orc.get_reflected_SH(nlevel, ns, ng, 1, *planes, np.zeros(ns), ubar0, ubar1, 1.0, np.ones(ns),
                                      *opts, *TTHG, 4)
         return orc.compress_disco(ns, 1.0, xo, gw, tw, np.ones(ns))
