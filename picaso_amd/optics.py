@@ -575,6 +575,8 @@ def shard_opacity(opa, lo, hi, ctx):
     s.__dict__.pop("_resident_vectors", None)
     s.__dict__.pop("_shards", None)
     s.__dict__.pop("_replicas", None)
+    s.__dict__.pop("_const_planes", None)
+    s.__dict__.pop("_trapz", None)
     s.molecular_opa, s.continuum_opa = ({} if isinstance(opa.molecular_opa, dict) else None), {}
 
     def cols(d, per=1):
