@@ -470,6 +470,13 @@ int picaso_compute_opacity_facets_dev(picaso_ctx *ctx, int nlayer, int nwno, int
 int picaso_broadcast_facets_dev(picaso_ctx *ctx, size_t nrows, int nwno, int nfacets, const double *src,
                                 const double *facet_scale, double *dst);
 
+/* Rows of a (nrows, nin) device table on the increasing grid xp (device, nin >= 2) -> out (nrows, nwno) on the grid
+ * x (device): numpy.interp per row with numpy's own arithmetic, i.e. the reference's wavelength.regrid
+ * (wavelength.py:46-70) as atmsetup.get_clouds applies it to the cloud opd / w0 / g0 tables (atmsetup.py:609-622).
+ * scale (host pointer or NULL): out = *scale * interp, the thinned-cloud multiply of optics.py:314-315. */
+int picaso_regrid_rows_dev(picaso_ctx *ctx, int nrows, int nin, long nwno, const double *xp, const double *fp,
+                           const double *x, const double *scale, double *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -11,6 +11,52 @@ Out of scope: chemistry, 3-D regridding, virga clouds.
 """
 import numpy as np
 
+
+class CloudTables(dict):
+    """``layer['cloud']`` for cloud tables that come on their own wavenumber grid (the 196-point grid of virga and of
+    the box clouds, justdoit.py:4235-4266): ``opd`` / ``w0`` / ``g0`` as ``(nlayer, nwno)`` arrays on the opacity
+    grid, formed with the reference's row-by-row ``numpy.interp`` (wavelength.py:46-70 from atmsetup.py:609-622) only
+    when somebody reads them on the host (``full_output``).  ``compute_opacity`` does not: it takes ``compact`` /
+    ``in_wno`` / ``wno`` and regrids on the device (``picaso_regrid_rows_dev``, same bits) -- the host regrid costs
+    0.5 s per table at 1e5 wavelengths, and the three (nlayer, nwno) tables another 216 MB of host-to-device copy."""
+
+    def __init__(self, compact, in_wno, wno):
+        super().__init__()
+        self.compact = compact                        # name -> (nlayer, nin) float64
+        self.in_wno = np.ascontiguousarray(in_wno, dtype=np.float64)
+        self.wno = wno
+
+    def __missing__(self, k):
+        if k not in self.compact:
+            raise KeyError(k)
+        x = np.asarray(self.wno, dtype=np.float64)
+        v = np.ascontiguousarray(np.stack([np.interp(x, self.in_wno, row) for row in self.compact[k]]))
+        self[k] = v
+        return v
+
+    def __iter__(self):
+        return iter(self.compact)
+
+    def __len__(self):
+        return len(self.compact)
+
+    def __contains__(self, k):
+        return k in self.compact
+
+    def keys(self):
+        return self.compact.keys()
+
+    def values(self):
+        return [self[k] for k in self.compact]
+
+    def items(self):
+        return [(k, self[k]) for k in self.compact]
+
+    def columns(self, lo, hi):
+        """The tables of the wavelength block ``[lo, hi)`` (interpolation is pointwise in the output grid)."""
+        return CloudTables(self.compact, self.in_wno, self.wno[lo:hi])
+
+
 # Mass (u) of the most abundant isotope of every element: the reference weighs a molecule with these,
 # not with standard atomic weights (``get_weights``, atmsetup.py:285-342: argmax of the isotope
 # abundances), so H2 is 2.01565 rather than 2.01588 -- it enters every opacity through colden/mmw.
@@ -230,6 +276,15 @@ class ATMSETUP:
             self.layer["cloud"] = {"w0": z, "g0": z, "opd": z}
             return
         in_wno = self.input["clouds"]["wavenumber"]
+        sizes = {np.size(prof[k]) for k in ("opd", "g0", "w0")}
+        if in_wno is not None and len(sizes) == 1:          # all three on their own grid: regridded where they are read
+            nin = sizes.pop() // self.c.nlayer
+            if nin == np.size(in_wno) and nin >= 2 and nin * self.c.nlayer == np.size(prof["opd"]) \
+                    and not (nin == nwno and np.array_equal(in_wno, wno)):
+                self.layer["cloud"] = CloudTables(
+                    {k: np.ascontiguousarray(np.asarray(prof[k], dtype=np.float64).reshape(self.c.nlayer, nin))
+                     for k in ("opd", "g0", "w0")}, in_wno, wno)
+                return
         cld = {}
         for k in ("opd", "g0", "w0"):
             v = np.asarray(prof[k], dtype=np.float64)

@@ -314,11 +314,97 @@ __global__ __launch_bounds__(256) void k_broadcast_facets(const BcastArgs a)
     a.dst[e] = a.has_scale ? v * a.scale[f] : v;
 }
 
+// Rows of a (nrows, nin) table on the increasing grid xp -> (nrows, nwno) on x, piecewise linear with the end
+// values held outside the grid: numpy.interp per row, which is what the reference's wavelength.regrid does for the
+// cloud tables (wavelength.py:46-70 from atmsetup.py:609-622) -- on the host, 0.5 s per table at 1e5 wavelengths.
+// Bit for bit numpy's arithmetic (numpy/_core/src/multiarray/compiled_base.c:arr_interp): j with
+// xp[j] <= x < xp[j+1]; a knot hit returns fp[j]; otherwise slope = (fp[j+1]-fp[j])/(xp[j+1]-xp[j]) (a correctly
+// rounded division), slope*(x-xp[j]) + fp[j] as a separate multiply and add, and the NaN retry from the other side.
+// One thread per output column: the bracket search is done once for all rows; writes are coalesced.
+constexpr int REGRID_LDS = 4096;
+struct RegridArgs {
+    int nrows, nin;
+    long nwno;
+    const double *xp, *fp, *x;
+    double scale;
+    int has_scale;
+    double *out;
+};
+__global__ __launch_bounds__(256) void k_regrid_rows(const RegridArgs a)
+{
+#pragma clang fp contract(off)
+    __shared__ double sxp[REGRID_LDS];
+    const bool in_lds = a.nin <= REGRID_LDS;
+    if (in_lds) {
+        for (int i = threadIdx.x; i < a.nin; i += blockDim.x) sxp[i] = a.xp[i];
+        __syncthreads();
+    }
+    const double *xp = in_lds ? sxp : a.xp;
+    const long w = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (w >= a.nwno) return;
+    const double xv = a.x[w];
+    const int last = a.nin - 1;
+    int j;                       // -1: left of the grid, nin: right of it, else xp[j] <= x (< xp[j+1])
+    if (xv != xv) j = -2;
+    else if (xv > xp[last]) j = a.nin;
+    else if (xv < xp[0]) j = -1;
+    else {
+        int lo = 0, hi = last;   // xp[lo] <= x <= xp[hi]
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (xv >= xp[mid]) lo = mid;
+            else hi = mid;
+        }
+        j = (xv >= xp[hi]) ? hi : lo;
+    }
+    const bool edge = (j < 0) || (j >= last);
+    const int j0 = j < 0 ? 0 : (j >= last ? last : j), j1 = edge ? j0 : j0 + 1;
+    const double x0 = xp[j0], x1 = xp[j1];
+    const bool knot = edge || (x0 == xv);
+    for (int r = 0; r < a.nrows; ++r) {
+        const double *row = a.fp + (long)r * a.nin;
+        const double y0 = row[j0], y1 = row[j1];
+        double v;
+        if (j == -2) v = xv;
+        else if (knot) v = y0;
+        else {
+            const double slope = (y1 - y0) / (x1 - x0);
+            v = slope * (xv - x0) + y0;
+            if (v != v) {
+                v = slope * (xv - x1) + y1;
+                if (v != v && y0 == y1) v = y0;
+            }
+        }
+        a.out[(long)r * a.nwno + w] = a.has_scale ? a.scale * v : v;
+    }
+}
+
 }  // namespace pz
 
 using namespace pz;
 
 extern "C" {
+
+int picaso_regrid_rows_dev(picaso_ctx *ctx, int nrows, int nin, long nwno, const double *xp, const double *fp,
+                           const double *x, const double *scale, double *out)
+{
+    if (!ctx) return fail(nullptr, "null context");
+    if (nrows < 1 || nin < 2 || nwno < 1 || !xp || !fp || !x || !out) return fail(ctx, "regrid_rows: bad arguments");
+    PZ_HIP(ctx, hipSetDevice(ctx->device));
+    RegridArgs a{};
+    a.nrows = nrows;
+    a.nin = nin;
+    a.nwno = nwno;
+    a.xp = xp;
+    a.fp = fp;
+    a.x = x;
+    a.has_scale = scale != nullptr;
+    a.scale = scale ? *scale : 1.0;
+    a.out = out;
+    hipLaunchKernelGGL(k_regrid_rows, dim3((unsigned)((nwno + 255) / 256)), dim3(256), 0, ctx->stream, a);
+    PZ_HIP(ctx, hipGetLastError());
+    return 0;
+}
 
 int picaso_broadcast_facets_dev(picaso_ctx *ctx, size_t nrows, int nwno, int nfacets, const double *src,
                                 const double *facet_scale, double *dst)

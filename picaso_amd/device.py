@@ -115,6 +115,24 @@ def broadcast_facets(src, nfacets, facet_scale=None, ctx=None):
     return out
 
 
+def regrid_rows(xp, fp, d_x, ctx, scale=None):
+    """``numpy.interp(x, xp, row)`` for every row of the host table ``fp`` ``(nrows, nin)``, on the device grid
+    ``d_x`` (a DeviceArray of ``nwno`` wavenumbers): a ``(nrows, nwno)`` DeviceArray, bit for bit what the
+    reference's ``wavelength.regrid`` returns (``picaso_regrid_rows_dev``).  ``scale``: result times a scalar."""
+    fp = np.ascontiguousarray(fp, dtype=np.float64)
+    nrows, nin = fp.shape
+    nwno = int(d_x.shape[0])
+    d_xp = DeviceArray.from_host(np.ascontiguousarray(xp, dtype=np.float64).reshape(nin), ctx)
+    d_fp = DeviceArray.from_host(fp, ctx)
+    out = DeviceArray((nrows, nwno), ctx)
+    sc = ctypes.byref(ctypes.c_double(float(scale))) if scale is not None else None
+    _lib.check(_lib.load().picaso_regrid_rows_dev(ctx, ctypes.c_int(nrows), ctypes.c_int(nin), ctypes.c_long(nwno),
+                                                  ctypes.c_void_p(d_xp.addr), ctypes.c_void_p(d_fp.addr),
+                                                  ctypes.c_void_p(d_x.addr), sc, ctypes.c_void_p(out.addr)), ctx)
+    out._inputs = (d_xp, d_fp)          # the launch is asynchronous: its inputs live as long as its output
+    return out
+
+
 def sync(ctx=None):
     ctx = ctx if ctx is not None else _lib.context()
     _lib.check(_lib.load().picaso_sync(ctx), ctx)

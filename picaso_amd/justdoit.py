@@ -19,7 +19,7 @@ import os
 import numpy as np
 
 from . import _lib, device, disco, optics, resident
-from .atmsetup import ATMSETUP
+from .atmsetup import ATMSETUP, CloudTables
 from .device import DeviceArray
 
 # option tables (reference justdoit.py:5512-5534, 5647-5658)
@@ -993,9 +993,14 @@ def _atmosphere_block(atm0, lo, hi, wno):
     atm = copy.copy(atm0)
     atm.wavenumber = wno
     atm.layer = dict(atm0.layer)
-    atm.layer["cloud"] = {k: v[:, lo:hi] for k, v in atm0.layer["cloud"].items()}
+    cld = atm0.layer["cloud"]
+    if isinstance(cld, CloudTables):          # tables on their own grid: the block regrids its own columns
+        atm.layer["cloud"] = cld.columns(lo, hi)
+        atm.layer["cloud"].wno = wno
+    else:
+        atm.layer["cloud"] = {k: v[:, lo:hi] for k, v in cld.items()}
     sr = atm0.surf_reflect
-    if np.ndim(sr) > 0 and np.size(sr) == np.shape(atm0.layer["cloud"]["opd"])[1]:
+    if np.ndim(sr) > 0 and np.size(sr) == np.size(atm0.wavenumber):
         atm.surf_reflect = np.ascontiguousarray(np.asarray(sr, dtype=float)[lo:hi])
     return atm
 

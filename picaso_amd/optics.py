@@ -25,7 +25,8 @@ import numpy as np
 
 from . import _lib
 from ._lib import check, f64, load, ptr
-from .device import DeviceArray
+from .atmsetup import CloudTables
+from .device import DeviceArray, regrid_rows
 
 _ci, _cd = ctypes.c_int, ctypes.c_double
 AVOGADRO = 6.02214086e+23
@@ -576,6 +577,7 @@ def shard_opacity(opa, lo, hi, ctx):
     s.__dict__.pop("_shards", None)
     s.__dict__.pop("_replicas", None)
     s.__dict__.pop("_const_planes", None)
+    s.__dict__.pop("_d_wno", None)
     s.__dict__.pop("_trapz", None)
     s.molecular_opa, s.continuum_opa = ({} if isinstance(opa.molecular_opa, dict) else None), {}
 
@@ -891,6 +893,16 @@ def compute_opacity_facets(atms, opacityclass, numg, numt, stream=2, delta_eddin
     return {k: v for k, v in out.items() if v is not None}
 
 
+def _wno_device(opa, wno):
+    """The wavenumber grid as a device vector; the opacity object's own grid is uploaded once."""
+    if wno is opa.wno:
+        hit = opa.__dict__.get("_d_wno")
+        if hit is None:
+            hit = opa.__dict__["_d_wno"] = DeviceArray.from_host(np.ascontiguousarray(wno, dtype=np.float64), opa.ctx)
+        return hit
+    return DeviceArray.from_host(np.ascontiguousarray(wno, dtype=np.float64), opa.ctx)
+
+
 def compute_opacity_resident(atmosphere, opacityclass, ngauss=1, stream=2, delta_eddington=True,
                              test_mode=None, raman=0, fthin_cld=None, do_holes=False,
                              full_output=False, want=None):
@@ -916,13 +928,20 @@ def compute_opacity_resident(atmosphere, opacityclass, ngauss=1, stream=2, delta
     def plane(x):       # (nlayer, nwno) float64 without a copy when the caller already has one
         a = np.asarray(x, dtype=float)
         return a if a.shape == (nlayer, nwno) else np.ascontiguousarray(np.broadcast_to(a, (nlayer, nwno)))
-    taucld = plane(cld["opd"])
-    if do_holes:
-        taucld = fthin_cld * taucld                         # optics.py:314-315
+
+    def taucld_host():
+        t = plane(cld["opd"])
+        return fthin_cld * t if do_holes else t             # optics.py:314-315
+    on_device = isinstance(cld, CloudTables) and np.size(cld.wno) == nwno and not os.environ.get("PICASO_AMD_HOST_REGRID")
     if getattr(atm, "cloud_free", False) and not do_holes:  # no cloud profile: NULL planes read as zero
         d_cld = d_w0 = d_g0 = None
+    elif on_device:     # tables on their own wavenumber grid: interpolated where they are used (same bits)
+        d_x = _wno_device(opa, cld.wno)
+        d_cld = regrid_rows(cld.in_wno, cld.compact["opd"], d_x, ctx, scale=fthin_cld if do_holes else None)
+        d_w0 = regrid_rows(cld.in_wno, cld.compact["w0"], d_x, ctx)
+        d_g0 = regrid_rows(cld.in_wno, cld.compact["g0"], d_x, ctx)
     else:
-        d_cld = DeviceArray.from_host(taucld, ctx)
+        d_cld = DeviceArray.from_host(taucld_host(), ctx)
         d_w0 = DeviceArray.from_host(plane(cld["w0"]), ctx)
         d_g0 = DeviceArray.from_host(plane(cld["g0"]), ctx)
     tm = 0
@@ -942,7 +961,7 @@ def compute_opacity_resident(atmosphere, opacityclass, ngauss=1, stream=2, delta
     if full_output:
         atmosphere.taugas = taugas.to_host().reshape((nlayer, nwno, ngauss))
         atmosphere.tauray = np.repeat(tauray.to_host()[:, :, None], ngauss, axis=2)
-        atmosphere.taucld = np.repeat(np.asarray(taucld)[:, :, None], ngauss, axis=2)
+        atmosphere.taucld = np.repeat(np.asarray(taucld_host())[:, :, None], ngauss, axis=2)
     return out
 
 

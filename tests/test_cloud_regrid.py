@@ -1,0 +1,162 @@
+"""Cloud tables on their own wavenumber grid (virga's and the box clouds' 196 points): the reference regrids them
+row by row with numpy.interp on the host (wavelength.py:46-70 from atmsetup.py:609-622); here ``layer['cloud']``
+keeps the compact tables (``atmsetup.CloudTables``) and ``compute_opacity`` regrids on the device
+(``picaso_regrid_rows_dev``) -- bit for bit the same numbers."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import GOLDEN
+from picaso_amd import justdoit as jdi
+from picaso_amd.atmsetup import CloudTables
+
+DB = os.path.join(GOLDEN, "synthetic_opacities.db")
+
+
+def _rows_interp(x, xp, fp):
+    return np.stack([np.interp(x, xp, row) for row in fp])
+
+
+def test_cloud_tables_form_the_reference_arrays_when_read():
+    rng = np.random.default_rng(5)
+    xp = np.sort(rng.uniform(40.0, 33000.0, 196))
+    wno = np.linspace(30.0, 34000.0, 1500)                      # reaches past both ends of the table's grid
+    compact = {k: rng.random((12, 196)) for k in ("opd", "w0", "g0")}
+    t = CloudTables(compact, xp, wno)
+    assert len(t) == 3 and "w0" in t and "tau" not in t and sorted(t.keys()) == ["g0", "opd", "w0"]
+    assert not dict.__len__(t)                                   # nothing formed yet
+    assert np.array_equal(t["opd"], _rows_interp(wno, xp, compact["opd"])) and t["opd"].flags.c_contiguous
+    assert dict.__len__(t) == 1
+    blk = t.columns(100, 900)
+    for k, v in blk.items():
+        assert np.array_equal(v, _rows_interp(wno, xp, compact[k])[:, 100:900])
+    with pytest.raises(KeyError):
+        t["tau"]
+    assert {k: v.shape for k, v in t.items()} == {k: (12, 1500) for k in ("opd", "w0", "g0")}
+
+
+def _case(og, wgrid=None, holes=False, nwno=None):
+    case = jdi.inputs()
+    case.phase_angle(0)
+    case.gravity(radius=7.1e9, mass=1.9e30)
+    prof = {"pressure": og["in/plevel_bar"], "temperature": og["in/tlevel"]}
+    for k in ("H2", "He", "H2O", "CH4"):
+        prof[k] = og["in/mix/" + k]
+    case.atmosphere(df=prof)
+    nw = len(og["in/wno"])
+    case.star(relative_flux=1.0 + 0.2 * np.cos(np.arange(nw) / 5.0), radius=6.9e10, semi_major=7.5e12)
+    return case
+
+
+def _grid(tmp_path, monkeypatch, lo, hi):
+    d = tmp_path / "opacities"
+    d.mkdir()
+    wn = np.round(np.linspace(lo, hi, 196)[::-1], 2)
+    with open(d / "wave_EGP.dat", "w") as fh:
+        fh.write("   i   micron.    wavenumber idum     idum1    idum2     idum3\n")
+        for i, w in enumerate(wn):
+            fh.write("%4d %9.3f %9.2f %8.2f- %7.2f %9.3f %9.3f\n" % (i + 1, 1e4 / w, w, w - 1, w + 1, 2.0, w))
+    monkeypatch.setenv("picaso_refdata", str(tmp_path))
+
+
+def test_atmosphere_keeps_tables_on_their_own_grid_compact(tmp_path, monkeypatch):
+    og = np.load(os.path.join(GOLDEN, "optics.npz"))
+    wno = og["in/wno"]
+    _grid(tmp_path, monkeypatch, wno.min() * 1.02, wno.max() * 0.97)         # the opacity grid reaches past it
+    case = _case(og)
+    case.clouds(g0=[0.8], w0=[0.95], opd=[1.5], p=[0.0], dp=[1.5])
+    from picaso_amd.atmsetup import ATMSETUP
+    atm = ATMSETUP(case.inputs)
+    atm.get_profile()
+    atm.get_clouds(wno)
+    cld = atm.layer["cloud"]
+    assert isinstance(cld, CloudTables) and cld.compact["opd"].shape == (atm.c.nlayer, 196) and not atm.cloud_free
+    prof = case.inputs["clouds"]["profile"]
+    assert np.array_equal(cld["opd"], _rows_interp(wno, case.inputs["clouds"]["wavenumber"], prof["opd"]))
+    assert cld["opd"].max() == 1.5 and cld["opd"].min() == 0.0
+    # a table already on the opacity grid stays a plain dict of (nlayer, nwno) arrays
+    full = {k: np.array(cld[k]) for k in ("opd", "w0", "g0")}
+    case.clouds(df=full)
+    atm.input = case.inputs
+    atm.get_clouds(wno)
+    assert type(atm.layer["cloud"]) is dict and np.array_equal(atm.layer["cloud"]["w0"], full["w0"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nin,nwno,nrows", [(196, 5000, 9), (2, 777, 3), (5000, 3001, 2), (196, 100000, 4)])
+def test_gpu_regrid_rows_is_numpy_interp(nin, nwno, nrows):
+    from picaso_amd import _lib, device
+    rng = np.random.default_rng(nin + nwno)
+    xp = np.sort(rng.uniform(50.0, 30000.0, nin))
+    x = np.sort(rng.uniform(10.0, 31000.0, nwno))                # some columns left and right of the table's grid
+    x[rng.integers(0, nwno, 40)] = xp[rng.integers(0, nin, 40)]  # exact knots, first and last among them
+    x[:2] = xp[0], xp[-1]
+    fp = rng.random((nrows, nin)) * 10.0 ** rng.integers(-8, 3, (nrows, nin))
+    fp[0] = 0.3                                                  # a box cloud: constant along the row
+    fp[-1, nin // 2:] = 0.0
+    ctx = _lib.context()
+    d_x = device.DeviceArray.from_host(x, ctx)
+    got = device.regrid_rows(xp, fp, d_x, ctx).to_host()
+    assert np.array_equal(got, _rows_interp(x, xp, fp))
+    got = device.regrid_rows(xp, fp, d_x, ctx, scale=0.37).to_host()
+    assert np.array_equal(got, 0.37 * _rows_interp(x, xp, fp))
+
+
+@pytest.mark.gpu
+def test_gpu_regrid_rows_nan_and_inf_follow_numpy():
+    from picaso_amd import _lib, device
+    xp = np.array([1.0, 2.0, 3.0, 4.0, 5.0])
+    fp = np.array([[1.0, np.inf, 3.0, np.nan, np.nan], [2.0, 2.0, np.inf, np.inf, 1.0]])
+    x = np.array([0.5, 1.0, 1.5, 2.0, 2.5, 3.0, 3.5, 4.0, 4.5, 5.0, 6.0, np.nan])
+    ctx = _lib.context()
+    with np.errstate(invalid="ignore"):
+        want = _rows_interp(x, xp, fp)
+    got = device.regrid_rows(xp, fp, device.DeviceArray.from_host(x, ctx), ctx).to_host()
+    assert np.array_equal(got, want, equal_nan=True)
+
+
+def _same(a, b, path=""):
+    if isinstance(a, dict):
+        assert sorted(a.keys()) == sorted(b.keys()), path
+        for k in a:
+            _same(a[k], b[k], path + "/" + str(k))
+    elif isinstance(a, np.ndarray):
+        assert a.shape == b.shape and np.array_equal(a, b, equal_nan=True), path
+    elif isinstance(a, (list, tuple)):
+        assert len(a) == len(b), path
+        for x, y in zip(a, b):
+            _same(x, y, path)
+    else:
+        assert a == b or (a != a and b != b), (path, a, b)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("holes,devices", [(False, None), (True, None), (False, [0, 0, 0])])
+def test_gpu_box_cloud_spectrum_regridded_on_the_device(tmp_path, monkeypatch, holes, devices):
+    og = np.load(os.path.join(GOLDEN, "optics.npz"))
+    wno = og["in/wno"]
+    _grid(tmp_path, monkeypatch, wno.min() * 1.02, wno.max() * 0.97)
+    opa = jdi.opannection(filename_db=DB)
+
+    def run():
+        case = _case(og)
+        case.clouds(g0=[0.8, 0.3], w0=[0.95, 0.7], opd=[1.5, 0.2], p=[0.0, -2.0], dp=[1.5, 1.0],
+                    do_holes=holes, fhole=0.3 if holes else None, fthin_cld=0.25 if holes else None)
+        return case.spectrum(opa, calculation="reflected+thermal+transmission", full_output=True, devices=devices)
+    monkeypatch.delenv("PICASO_AMD_HOST_REGRID", raising=False)
+    dev = run()
+    monkeypatch.setenv("PICASO_AMD_HOST_REGRID", "1")
+    host = run()
+    _same(host, dev)
+    assert np.isfinite(dev["albedo"]).all() and dev["full_output"]["taucld"].max() > 0
+    # and against the table expanded by hand on the host, passed in on the opacity grid
+    case = _case(og)
+    case.clouds(g0=[0.8, 0.3], w0=[0.95, 0.7], opd=[1.5, 0.2], p=[0.0, -2.0], dp=[1.5, 1.0])
+    prof, wg = case.inputs["clouds"]["profile"], case.inputs["clouds"]["wavenumber"]
+    case.clouds(df={k: _rows_interp(wno, wg, prof[k]) for k in ("opd", "w0", "g0")}, do_holes=holes,
+                fhole=0.3 if holes else None, fthin_cld=0.25 if holes else None)
+    monkeypatch.delenv("PICASO_AMD_HOST_REGRID", raising=False)
+    byhand = case.spectrum(opa, calculation="reflected+thermal+transmission", devices=devices)
+    for k in ("albedo", "thermal", "transit_depth"):
+        assert np.array_equal(byhand[k], dev[k]), k

@@ -32,8 +32,26 @@ case.phase_angle(0)
 case.gravity(gravity=2500.0)
 case.atmosphere(df=prof)
 case.approx(raman="none")
+# CLOUD=box: a box cloud on a 196-point grid of its own (what virga and clouds(g0=..., p=..., dp=...) hand over),
+# regridded per call -- on the device, or with PICASO_AMD_HOST_REGRID=1 by the reference's numpy.interp rows;
+# CLOUD=table: the same cloud handed over as three (nlayer, nwno) host tables.
+if os.environ.get("CLOUD"):
+    import tempfile
+    d = tempfile.mkdtemp()
+    os.makedirs(os.path.join(d, "opacities"))
+    wn = np.round(np.linspace(1900.0, 34000.0, 196)[::-1], 2)
+    with open(os.path.join(d, "opacities", "wave_EGP.dat"), "w") as fh:
+        fh.write("   i   micron.    wavenumber idum     idum1    idum2     idum3\n")
+        for i, w in enumerate(wn):
+            fh.write("%4d %9.3f %9.2f %8.2f- %7.2f %9.3f %9.3f\n" % (i + 1, 1e4 / w, w, w - 1, w + 1, 2.0, w))
+    os.environ["picaso_refdata"] = d
+    case.clouds(g0=[0.8], w0=[0.95], opd=[1.5], p=[0.0], dp=[1.5])
+    if os.environ["CLOUD"] == "table":
+        cl = case.inputs["clouds"]
+        case.clouds(df={k: np.stack([np.interp(wno, cl["wavenumber"], row) for row in cl["profile"][k]])
+                        for k in ("opd", "w0", "g0")})
 calc = os.environ.get("CALC", "reflected+thermal")
-for _ in range(30):
+for _ in range(int(os.environ.get("WARM", "30"))):
     r = case.spectrum(opa, calculation=calc)
 if os.environ.get("PROFILE_1D"):
     import cProfile, pstats
