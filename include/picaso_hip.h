@@ -432,7 +432,11 @@ int picaso_compute_opacity_dev(picaso_ctx *ctx, int nlayer, int nwno, const doub
  *   mol_mode : 0 nearest row, 1 10**(sum_4 w log10 kappa), 2 exp(sum_4 w ln kappa) (premixed CK)
  *   cont_mode: 0 nearest-temperature row (cont_rows [ncont][nlayer], cont_wts NULL),
  *              1 exp(w0 ln k[row0] + w1 ln k[row1]) (cont_rows, cont_wts [ncont][nlayer][2];
- *                tables hold ln kappa) */
+ *                tables hold ln kappa)
+ *   raman_rows: nlayer -- raman_factor is a (nlayer, nwno) plane (one per facet, facet-major, in the 3-D form), or
+ *               0 -- ONE row of nwno values used for every layer and facet: the Pollack table, which the reference
+ *               tiles over the layers with np.repeat (optics.py:296-298, 584-652).  picaso_compute_opacity_dev
+ *               takes planes. */
 int picaso_opacity_gas_ck_dev(picaso_ctx *ctx, int nlayer, int nwno, int ngauss, int mol_mode, int nmol,
                               const double *const *mol_tables, const int *mol_rows,
                               const double *mol_wts, const double *mol_fac, int cont_mode, int ncont,
@@ -442,7 +446,7 @@ int picaso_opacity_gas_ck_dev(picaso_ctx *ctx, int nlayer, int nwno, int ngauss,
                               double *tauray);
 int picaso_compute_opacity_ck_dev(picaso_ctx *ctx, int nlayer, int nwno, int ngauss, const double *taugas,
                                   const double *tauray, const double *taucld, const double *w0_cld,
-                                  const double *g0_cld, const double *raman_factor,
+                                  const double *g0_cld, const double *raman_factor, int raman_rows,
                                   double raman_const, int test_mode, int delta_eddington, int stream,
                                   double *dtau, double *tau, double *w0, double *cosb,
                                   double *ftau_cld, double *ftau_ray, double *gcos2, double *dtau_og,
@@ -456,7 +460,7 @@ int picaso_compute_opacity_ck_dev(picaso_ctx *ctx, int nlayer, int nwno, int nga
  * the (nlayer|nlevel, nwno, nfacets) planes picaso_get_reflected_3d / _thermal_3d take. */
 int picaso_compute_opacity_facets_dev(picaso_ctx *ctx, int nlayer, int nwno, int nfacets,
                                       const double *taugas, const double *tauray, const double *taucld,
-                                      const double *w0_cld, const double *g0_cld, const double *raman_factor,
+                                      const double *w0_cld, const double *g0_cld, const double *raman_factor, int raman_rows,
                                       double raman_const, int test_mode, int delta_eddington, int stream,
                                       double *dtau, double *tau, double *w0, double *cosb,
                                       double *ftau_cld, double *ftau_ray, double *gcos2, double *dtau_og,

@@ -123,6 +123,7 @@ struct MixArgs {
                       // gas launches write them (ncolper must be 1)
     const double *taugas, *tauray, *taucld, *w0c, *g0c, *raman;
     double raman_const;
+    int raman_row;    // raman is one row (nwno) for every layer and facet (the Pollack table) instead of a plane
     double *dtau, *tau, *w0, *cosb, *ftau_cld, *ftau_ray, *gcos2, *dtau_og, *tau_og, *w0_og,
         *cosb_og, *w0_no_raman, *f_deltaM;
 };
@@ -199,6 +200,8 @@ __global__ __launch_bounds__(1024) void k_compute_opacity(const MixArgs a)
     const long w = facets ? col / a.nfac : ((a.ncolper > 1) ? col / a.ncolper : col);
     const long fbase = facets ? (col - w * a.nfac) * a.nlayer : 0;     // facet-major row block of this column
     double tau_run = 0.0, taud_run = 0.0;
+    const bool rf_plane = a.raman && !a.raman_row;
+    const double rf_row = (a.raman && a.raman_row) ? a.raman[w] : a.raman_const;
     // every output plane is optional: a caller that runs only the thermal (or only the transmission)
     // leg asks for 3 (1) of the 13 planes and the kernel does not write the rest
     if (a.tau_og) a.tau_og[col] = 0.0;
@@ -212,7 +215,7 @@ __global__ __launch_bounds__(1024) void k_compute_opacity(const MixArgs a)
         const long oc = facets ? o : (long)i * nw + w;
         const double tg = a.taugas[og], tr = a.tauray[ow];
         const double tc = a.taucld ? a.taucld[oc] : 0.0, wc = a.w0c ? a.w0c[oc] : 0.0, gc = a.g0c ? a.g0c[oc] : 0.0;
-        const double rf = a.raman ? a.raman[ow] : a.raman_const;
+        const double rf = rf_plane ? a.raman[ow] : rf_row;
         mix_layer(a, o, o + ncol, tg, tr, tc, wc, gc, rf, tau_run, taud_run);
     }
 }
@@ -253,7 +256,8 @@ __global__ __launch_bounds__(MIXF_BLOCK) void k_compute_opacity_facets(const Mix
     }
     const long w = active ? col / nfac : 0;
     const int my = active ? (int)(col - w * nfac) * ldp + (int)(w - w_first) : 0;
-    const bool has_rf = a.raman != nullptr;
+    const bool has_rf = a.raman != nullptr && !a.raman_row;
+    const double rf_row = (active && a.raman && a.raman_row) ? a.raman[w] : a.raman_const;
     double pg[2], pr[2], pf[2];
     auto fetch = [&](int i) {
 #pragma unroll
@@ -285,7 +289,7 @@ __global__ __launch_bounds__(MIXF_BLOCK) void k_compute_opacity_facets(const Mix
         if (active) {
             const long o = (long)i * ncol + col;
             const double tg = tile[0][my], tr = tile[1][my];
-            const double rf = has_rf ? tile[2][my] : a.raman_const;
+            const double rf = has_rf ? tile[2][my] : rf_row;
             const double tc = a.taucld ? a.taucld[o] : 0.0, wc = a.w0c ? a.w0c[o] : 0.0, gc = a.g0c ? a.g0c[o] : 0.0;
             mix_layer(a, o, o + ncol, tg, tr, tc, wc, gc, rf, tau_run, taud_run);
         }
@@ -504,7 +508,7 @@ int picaso_opacity_gas_dev(picaso_ctx *ctx, int nlayer, int nwno, int linear, in
 
 int picaso_compute_opacity_ck_dev(picaso_ctx *ctx, int nlayer, int nwno, int ngauss, const double *taugas,
                                   const double *tauray, const double *taucld, const double *w0_cld,
-                                  const double *g0_cld, const double *raman_factor,
+                                  const double *g0_cld, const double *raman_factor, int raman_rows,
                                   double raman_const, int test_mode, int delta_eddington, int stream,
                                   double *dtau, double *tau, double *w0, double *cosb,
                                   double *ftau_cld, double *ftau_ray, double *gcos2, double *dtau_og,
@@ -522,6 +526,9 @@ int picaso_compute_opacity_ck_dev(picaso_ctx *ctx, int nlayer, int nwno, int nga
     a.delta_eddington = delta_eddington;
     a.stream = stream; a.taugas = taugas; a.tauray = tauray; a.taucld = taucld; a.w0c = w0_cld;
     a.g0c = g0_cld; a.raman = raman_factor; a.raman_const = raman_const;
+    if (raman_factor && raman_rows != 0 && raman_rows != nlayer)
+        return fail(ctx, "compute_opacity: raman_rows must be nlayer (planes) or 0 (one row for all layers)");
+    a.raman_row = raman_factor && raman_rows == 0;
     a.dtau = dtau; a.tau = tau; a.w0 = w0; a.cosb = cosb; a.ftau_cld = ftau_cld; a.ftau_ray = ftau_ray;
     a.gcos2 = gcos2; a.dtau_og = dtau_og; a.tau_og = tau_og; a.w0_og = w0_og; a.cosb_og = cosb_og;
     a.w0_no_raman = w0_no_raman; a.f_deltaM = f_deltaM;
@@ -535,7 +542,7 @@ int picaso_compute_opacity_ck_dev(picaso_ctx *ctx, int nlayer, int nwno, int nga
 
 int picaso_compute_opacity_facets_dev(picaso_ctx *ctx, int nlayer, int nwno, int nfacets,
                                       const double *taugas, const double *tauray, const double *taucld,
-                                      const double *w0_cld, const double *g0_cld, const double *raman_factor,
+                                      const double *w0_cld, const double *g0_cld, const double *raman_factor, int raman_rows,
                                       double raman_const, int test_mode, int delta_eddington, int stream,
                                       double *dtau, double *tau, double *w0, double *cosb,
                                       double *ftau_cld, double *ftau_ray, double *gcos2, double *dtau_og,
@@ -552,6 +559,9 @@ int picaso_compute_opacity_facets_dev(picaso_ctx *ctx, int nlayer, int nwno, int
     a.test_mode = test_mode; a.delta_eddington = delta_eddington;
     a.stream = stream; a.taugas = taugas; a.tauray = tauray; a.taucld = taucld; a.w0c = w0_cld;
     a.g0c = g0_cld; a.raman = raman_factor; a.raman_const = raman_const;
+    if (raman_factor && raman_rows != 0 && raman_rows != nlayer)
+        return fail(ctx, "compute_opacity: raman_rows must be nlayer (planes) or 0 (one row for all layers)");
+    a.raman_row = raman_factor && raman_rows == 0;
     a.dtau = dtau; a.tau = tau; a.w0 = w0; a.cosb = cosb; a.ftau_cld = ftau_cld; a.ftau_ray = ftau_ray;
     a.gcos2 = gcos2; a.dtau_og = dtau_og; a.tau_og = tau_og; a.w0_og = w0_og; a.cosb_og = cosb_og;
     a.w0_no_raman = w0_no_raman; a.f_deltaM = f_deltaM;
@@ -580,7 +590,7 @@ int picaso_compute_opacity_dev(picaso_ctx *ctx, int nlayer, int nwno, const doub
                                double *f_deltaM)
 {
     return picaso_compute_opacity_ck_dev(ctx, nlayer, nwno, 1, taugas, tauray, taucld, w0_cld, g0_cld,
-                                         raman_factor, raman_const, test_mode, delta_eddington, stream, dtau,
+                                         raman_factor, nlayer, raman_const, test_mode, delta_eddington, stream, dtau,
                                          tau, w0, cosb, ftau_cld, ftau_ray, gcos2, dtau_og, tau_og, w0_og,
                                          cosb_og, w0_no_raman, f_deltaM);
 }

@@ -62,7 +62,7 @@ _DEFAULTS = {   # reference/config.json
                              "SH": {"single_form": 0, "w_single_form": 0, "w_multi_form": 0,
                                     "psingle_form": 0, "w_single_rayleigh": 1, "w_multi_rayleigh": 1,
                                     "psingle_rayleigh": 1, "calculate_fluxes": 0},
-                             "common": {"stream": 2, "delta_eddington": True, "raman": 2,
+                             "common": {"stream": 2, "delta_eddington": True, "raman": 1,
                                         "TTHG_params": {"fraction": [1, -1, 2], "constant_back": -0.5,
                                                         "constant_forward": 1}}}},
 }
@@ -442,7 +442,7 @@ class inputs:
         self.inputs["hard_surface"] = 1
 
     def approx(self, single_phase="TTHG_ray", multi_phase="N=2", delta_eddington=True,
-               raman="none", tthg_frac=[1, -1, 2], tthg_back=-0.5, tthg_forward=1, p_reference=1,
+               raman="pollack", tthg_frac=[1, -1, 2], tthg_back=-0.5, tthg_forward=1, p_reference=1,
                rt_method="toon", stream=2, toon_coefficients="quadrature", single_form="explicit",
                calculate_fluxes="off", w_single_form="TTHG", w_multi_form="TTHG", psingle_form="TTHG",
                w_single_rayleigh="on", w_multi_rayleigh="on", psingle_rayleigh="on",

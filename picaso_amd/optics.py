@@ -578,6 +578,7 @@ def shard_opacity(opa, lo, hi, ctx):
     s.__dict__.pop("_replicas", None)
     s.__dict__.pop("_const_planes", None)
     s.__dict__.pop("_d_wno", None)
+    s.__dict__.pop("_raman_pollack", None)
     s.__dict__.pop("_trapz", None)
     s.molecular_opa, s.continuum_opa = ({} if isinstance(opa.molecular_opa, dict) else None), {}
 
@@ -765,6 +766,25 @@ def types_namespace_layer(atm_f, tlayer):
     return types.SimpleNamespace(c=atm_f.c, layer={"temperature": tlayer})
 
 
+def raman_device(atm, opa, raman):
+    """The Raman factor on the device as ``(DeviceArray or None, raman_rows)``: a ``(nlayer, nwno)`` plane
+    (Oklopcic: depends on the layer temperatures, computed per call on the host) or one row of ``nwno`` values for
+    every layer (Pollack: the table on the opacity grid, kept on the opacity object once formed)."""
+    nlayer = atm.c.nlayer
+    if raman == 1 and not os.environ.get("PICASO_AMD_RAMAN_PLANES"):
+        ref = os.environ.get("picaso_refdata")
+        path = os.path.join(ref, "opacities", "raman_fortran.txt") if ref is not None else None
+        st = os.stat(path) if path is not None and os.path.isfile(path) else None
+        key = (path, st.st_mtime_ns, st.st_size) if st is not None else None
+        hit = opa.__dict__.get("_raman_pollack")
+        if hit is None or key is None or hit[0] != key:
+            row = np.minimum(raman_pollack(1, 1e4 / opa.wno)[0], 0.99999)
+            hit = opa.__dict__["_raman_pollack"] = (key, DeviceArray.from_host(np.ascontiguousarray(row), opa.ctx))
+        return hit[1], 0
+    rf = raman_plane_host(atm, opa, raman)
+    return (DeviceArray.from_host(rf, opa.ctx), nlayer) if rf is not None else (None, nlayer)
+
+
 def raman_plane_host(atm, opa, raman):
     """Raman factor plane on the host (once per atmosphere, reference optics.py:285-306) or None."""
     if raman == 0:
@@ -850,7 +870,8 @@ def compute_opacity_facets(atms, opacityclass, numg, numt, stream=2, delta_eddin
     if opa.ngauss != 1:
         raise Exception("compute_opacity_facets takes monochromatic opacities")
     tg3, tr3 = DeviceArray((nfac, nlayer, nwno), ctx), DeviceArray((nfac, nlayer, nwno), ctx)
-    rf3 = [] if raman in (0, 1) else None
+    row_mode = raman == 1 and not os.environ.get("PICASO_AMD_RAMAN_PLANES")
+    rf3 = [] if raman in (0, 1) and not row_mode else None    # Oklopcic: one plane per facet (layer temperatures)
     if not isinstance(atms, list):                            # one facet-form atmosphere: batched gas stage
         atm_f = atms
         gas_stage_facets(atm_f, opa, nfac, tg3, tr3, exclude_mol=exclude_mol)
@@ -867,7 +888,9 @@ def compute_opacity_facets(atms, opacityclass, numg, numt, stream=2, delta_eddin
             gas_stage(atms[g][t], opa, tg3.row_block(f), tr3.row_block(f))
             if rf3 is not None:
                 rf3.append(raman_plane_host(atms[g][t], opa, raman))
-    d_rf = DeviceArray.from_host(np.stack(rf3), ctx) if rf3 else None
+    d_rf, rf_rows = (DeviceArray.from_host(np.stack(rf3), ctx) if rf3 else None), nlayer
+    if row_mode:                                              # Pollack: one row for every layer and facet
+        d_rf, rf_rows = raman_device(atms[0][0] if isinstance(atms, list) else atm_f, opa, raman)
     d_c = [None, None, None]
     if clouds_3d is not None:
         from .device import broadcast_facets
@@ -888,7 +911,7 @@ def compute_opacity_facets(atms, opacityclass, numg, numt, stream=2, delta_eddin
     check(load().picaso_compute_opacity_facets_dev(
         ctx, _ci(nlayer), _ci(nwno), _ci(nfac), ptr(tg3.addr), ptr(tr3.addr),
         *[ptr(d.addr) if d is not None else None for d in d_c], ptr(d_rf.addr) if d_rf is not None else None,
-        _cd(0.99999), _ci(tm), _ci(1 if delta_eddington else 0), _ci(stream),
+        _ci(rf_rows), _cd(0.99999), _ci(tm), _ci(1 if delta_eddington else 0), _ci(stream),
         *[ptr(out[k].addr) if out[k] is not None else None for k in OUT_NAMES]), ctx)
     return {k: v for k, v in out.items() if v is not None}
 
@@ -921,8 +944,7 @@ def compute_opacity_resident(atmosphere, opacityclass, ngauss=1, stream=2, delta
     gshape = (nwno,) if ngauss == 1 else (nwno, ngauss)
     taugas, tauray = DeviceArray((nlayer,) + gshape, ctx), DeviceArray((nlayer, nwno), ctx)
     gas_stage(atm, opa, taugas, tauray)
-    rf_host = raman_plane_host(atm, opa, raman)
-    raman_plane, raman_const = (DeviceArray.from_host(rf_host, ctx) if rf_host is not None else None), 0.99999
+    (raman_plane, raman_rows), raman_const = raman_device(atm, opa, raman), 0.99999
     cld = atm.layer["cloud"]
 
     def plane(x):       # (nlayer, nwno) float64 without a copy when the caller already has one
@@ -954,7 +976,7 @@ def compute_opacity_resident(atmosphere, opacityclass, ngauss=1, stream=2, delta
     check(load().picaso_compute_opacity_ck_dev(
         ctx, _ci(nlayer), _ci(nwno), _ci(ngauss), ptr(taugas.addr), ptr(tauray.addr),
         *[ptr(x.addr) if x is not None else None for x in (d_cld, d_w0, d_g0)],
-        ptr(raman_plane.addr) if raman_plane else None,
+        ptr(raman_plane.addr) if raman_plane else None, _ci(raman_rows),
         _cd(raman_const), _ci(tm), _ci(1 if delta_eddington else 0), _ci(stream),
         *[ptr(out[k].addr) if out[k] is not None else None for k in OUT_NAMES]), ctx)
     out = {k: v for k, v in out.items() if v is not None}

@@ -324,6 +324,70 @@ def test_gpu_3d_batched_facets_equal_per_facet_loop(og, raman, radius, monkeypat
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("dimension", ["1d", "3d"])
+def test_gpu_pollack_raman_row_equals_tiled_planes(og, dimension, monkeypatch, tmp_path):
+    """raman='pollack' (the reference's default, justdoit.py:4636): the factor depends on the wavelength only. The
+    reference tiles the table over the layers (optics.py:296-298, np.repeat) and, in 3-D, does so once per facet;
+    here ONE row of nwno values stays on the opacity object and the mixing kernels read it for every layer and facet
+    (`raman_rows = 0`).  Bit-identical to the tiled planes (PICASO_AMD_RAMAN_PLANES=1), also through the per-facet
+    loop and in wavelength blocks."""
+    from picaso_amd import justdoit as jdi
+    ng, nt = 3, 2
+    g = np.load(os.path.join(GOLDEN, "raman_pollack.npz"))
+    (tmp_path / "opacities").mkdir()
+    np.savetxt(tmp_path / "opacities" / "raman_fortran.txt", np.column_stack([g["table/w"], g["table/f"]]), fmt="%.17g")
+    monkeypatch.setenv("picaso_refdata", str(tmp_path))
+    opa = jdi.opannection(filename_db=DB, query_method="linear")
+    pert = 1.0 + 0.1 * np.cos(np.arange(ng * nt).reshape(ng, nt))
+
+    def run(devices=None):
+        case = jdi.inputs()                                    # no approx(): Raman is Pollack's table by default
+        case.gravity(gravity=float(og["in/gravity"]))
+        case.surface_reflect(0.1)
+        if dimension == "1d":
+            case.phase_angle(0)
+            prof = {"pressure": og["in/plevel_bar"], "temperature": og["in/tlevel"]}
+            for k in ("H2", "He", "CH4", "H2O"):
+                prof[k] = og["in/mix/" + k]
+            case.atmosphere(df=prof)
+            case.clouds(df={"opd": og["in/cld_opd"], "w0": og["in/cld_w0"], "g0": og["in/cld_g0"]})
+        else:
+            case.phase_angle(np.pi / 3, num_gangle=ng, num_tangle=nt)
+            prof = {"pressure": og["in/plevel_bar"], "temperature": og["in/tlevel"][:, None, None] * pert[None]}
+            for k in ("H2", "He", "CH4", "H2O"):
+                prof[k] = og["in/mix/" + k]
+            case.atmosphere_3d(prof)
+        return case.spectrum(opa, calculation="reflected+thermal", dimension=dimension, devices=devices)
+    row = run()
+    blocks = run(devices=[0, 0])
+    monkeypatch.setenv("PICASO_AMD_RAMAN_PLANES", "1")
+    planes = run()
+    if dimension == "3d":
+        monkeypatch.setenv("PICASO_AMD_FACET_LOOP", "1")
+        loop = run()
+    monkeypatch.delenv("PICASO_AMD_RAMAN_PLANES")
+    case = jdi.inputs()
+    for k in ("albedo", "thermal"):
+        assert np.isfinite(row[k]).all()
+        assert np.array_equal(row[k], planes[k]) and np.array_equal(row[k], blocks[k]), k
+        if dimension == "3d":
+            assert np.array_equal(row[k], loop[k]), k
+    # and it is not the Raman-less spectrum
+    monkeypatch.delenv("PICASO_AMD_FACET_LOOP", raising=False)
+    if dimension == "1d":
+        case.phase_angle(0)
+        case.gravity(gravity=float(og["in/gravity"]))
+        case.surface_reflect(0.1)
+        prof = {"pressure": og["in/plevel_bar"], "temperature": og["in/tlevel"]}
+        for k in ("H2", "He", "CH4", "H2O"):
+            prof[k] = og["in/mix/" + k]
+        case.atmosphere(df=prof)
+        case.clouds(df={"opd": og["in/cld_opd"], "w0": og["in/cld_w0"], "g0": og["in/cld_g0"]})
+        case.approx(raman="none")
+        assert not np.array_equal(case.spectrum(opa, calculation="reflected")["albedo"], row["albedo"])
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("cloudy,raman,delta", [(False, "none", True), (False, "oklopcic", True), (True, "none", True),
                                                 (True, "oklopcic", False), (False, "none", False)])
 def test_gpu_3d_planes_rederived_in_the_solvers_bit_identical(og, cloudy, raman, delta, monkeypatch):

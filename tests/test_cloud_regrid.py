@@ -46,6 +46,7 @@ def _case(og, wgrid=None, holes=False, nwno=None):
     case.atmosphere(df=prof)
     nw = len(og["in/wno"])
     case.star(relative_flux=1.0 + 0.2 * np.cos(np.arange(nw) / 5.0), radius=6.9e10, semi_major=7.5e12)
+    case.approx(raman="none")
     return case
 
 

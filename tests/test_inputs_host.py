@@ -20,6 +20,26 @@ def test_option_tables_match_reference_order():
     assert jdi.SH_rayleigh_options(False) == ["off", "on"]
 
 
+def test_approx_defaults_are_the_reference_defaults():
+    """justdoit.py:4635-4641 and reference/config.json: Raman scattering is Pollack's table unless asked otherwise --
+    both in a fresh ``inputs()`` and after a bare ``approx()``."""
+    import inspect
+    want = dict(single_phase="TTHG_ray", multi_phase="N=2", delta_eddington=True, raman="pollack", tthg_frac=[1, -1, 2],
+                tthg_back=-0.5, tthg_forward=1, p_reference=1, rt_method="toon", stream=2,
+                toon_coefficients="quadrature", single_form="explicit", calculate_fluxes="off", w_single_form="TTHG",
+                w_multi_form="TTHG", psingle_form="TTHG", w_single_rayleigh="on", w_multi_rayleigh="on",
+                psingle_rayleigh="on", get_lvl_flux=False)
+    sig = inspect.signature(jdi.inputs.approx)
+    assert [p for p in sig.parameters][1:] == list(want)
+    assert {k: v.default for k, v in sig.parameters.items() if k != "self"} == want
+    c = jdi.inputs()
+    fresh = {k: (dict(v) if isinstance(v, dict) else v) for k, v in c.inputs["approx"]["rt_params"]["common"].items()}
+    assert fresh["raman"] == 1 and fresh["stream"] == 2 and fresh["delta_eddington"] is True
+    c.approx()
+    assert c.inputs["approx"]["rt_params"]["common"]["raman"] == 1
+    assert c.inputs["approx"]["rt_params"]["toon"] == {"toon_coefficients": 0, "multi_phase": 0, "single_phase": 3}
+
+
 def test_approx_maps_strings_to_solver_integers():
     c = jdi.inputs()
     c.approx(single_phase="OTHG", multi_phase="N=1", delta_eddington=False, raman="none", tthg_frac=[1, -1, 2],

@@ -31,14 +31,32 @@ case = jdi.inputs()
 case.phase_angle(0)
 case.gravity(gravity=2500.0)
 case.atmosphere(df=prof)
-case.approx(raman="none")
+# RAMAN=none|pollack|oklopcic, RT=toon|SH, LVL=1 (level fluxes), STAR=1 (a stellar spectrum on the grid: fpfs and Raman need one)
+akw = dict(raman=os.environ.get("RAMAN", "none"), get_lvl_flux=bool(os.environ.get("LVL")))
+if os.environ.get("RT", "toon") == "SH":
+    akw.update(rt_method="SH", stream=4)
+case.approx(**akw)
+if os.environ.get("STAR") or akw["raman"] != "none":
+    case.star(relative_flux=1.0 + 0.2 * np.cos(wno / 900.0), radius=6.9e10, semi_major=7.5e12)
+    case.gravity(radius=7.1e9, mass=1.9e30)
+if akw["raman"] == "pollack":
+    import tempfile
+    d0 = tempfile.mkdtemp()
+    os.makedirs(os.path.join(d0, "opacities"))
+    wl = np.linspace(0.2, 6.0, 400)
+    np.savetxt(os.path.join(d0, "opacities", "raman_fortran.txt"), np.column_stack([wl, 0.9 + 0.05 * np.cos(wl)]))
+    os.environ["picaso_refdata"] = d0
+if akw["raman"] == "oklopcic":
+    g = np.load(os.path.join(ROOT, "tests", "golden", "optics.npz"))
+    opa.raman_stellar_shifts = None
+    opa.raman_db = {"c": g["in/raman_c"], "ji": g["in/raman_ji"], "deltanu": g["in/raman_deltanu"]}
 # CLOUD=box: a box cloud on a 196-point grid of its own (what virga and clouds(g0=..., p=..., dp=...) hand over),
 # regridded per call -- on the device, or with PICASO_AMD_HOST_REGRID=1 by the reference's numpy.interp rows;
 # CLOUD=table: the same cloud handed over as three (nlayer, nwno) host tables.
 if os.environ.get("CLOUD"):
     import tempfile
-    d = tempfile.mkdtemp()
-    os.makedirs(os.path.join(d, "opacities"))
+    d = os.environ.get("picaso_refdata") or tempfile.mkdtemp()
+    os.makedirs(os.path.join(d, "opacities"), exist_ok=True)
     wn = np.round(np.linspace(1900.0, 34000.0, 196)[::-1], 2)
     with open(os.path.join(d, "opacities", "wave_EGP.dat"), "w") as fh:
         fh.write("   i   micron.    wavenumber idum     idum1    idum2     idum3\n")
