@@ -481,6 +481,16 @@ int picaso_broadcast_facets_dev(picaso_ctx *ctx, size_t nrows, int nwno, int nfa
 int picaso_regrid_rows_dev(picaso_ctx *ctx, int nrows, int nin, long nwno, const double *xp, const double *fp,
                            const double *x, const double *scale, double *out);
 
+/* Oklopcic (2016) Raman factor plane, replaces optics.compute_raman (reference picaso/optics.py:434-494) as
+ * compute_opacity calls it (optics.py:285-294): out (nlayer, nwno) = min((ray + w_shift)/(ray + wo_shift), cap).
+ * Q, QS: device tables (ntrans, nwno) of c_i / wno**3 / (wno + deltanu_i) and of that times the stellar shift ratio
+ * of transition i (formed once per opacity grid / star by the caller; QS rows of Rayleigh transitions are not read);
+ * j_initial, is_rayleigh (deltanu_i == 0): host, ntrans ints; j_at_temp: host (10, nlayer) rotational populations
+ * j_fraction(j, T_layer) (optics.py:524-545). */
+int picaso_raman_oklopcic_dev(picaso_ctx *ctx, int nlayer, long nwno, int ntrans, const double *Q, const double *QS,
+                              const int *j_initial, const int *is_rayleigh, const double *j_at_temp, double cap,
+                              double *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -579,6 +579,7 @@ def shard_opacity(opa, lo, hi, ctx):
     s.__dict__.pop("_const_planes", None)
     s.__dict__.pop("_d_wno", None)
     s.__dict__.pop("_raman_pollack", None)
+    s.__dict__.pop("_raman_oklopcic", None)
     s.__dict__.pop("_trapz", None)
     s.molecular_opa, s.continuum_opa = ({} if isinstance(opa.molecular_opa, dict) else None), {}
 
@@ -781,8 +782,48 @@ def raman_device(atm, opa, raman):
             row = np.minimum(raman_pollack(1, 1e4 / opa.wno)[0], 0.99999)
             hit = opa.__dict__["_raman_pollack"] = (key, DeviceArray.from_host(np.ascontiguousarray(row), opa.ctx))
         return hit[1], 0
+    if raman == 0 and not os.environ.get("PICASO_AMD_RAMAN_PLANES"):
+        out = DeviceArray((nlayer, opa.nwno), opa.ctx)
+        raman_oklopcic_device(opa, np.asarray(atm.layer["temperature"], dtype=float), out)
+        return out, nlayer
     rf = raman_plane_host(atm, opa, raman)
     return (DeviceArray.from_host(rf, opa.ctx), nlayer) if rf is not None else (None, nlayer)
+
+
+def raman_oklopcic_device(opa, tlayer, out):
+    """``min(compute_raman(...), 0.99999)`` (reference optics.py:285-294, 434-494) written into the device plane
+    ``out`` ``(nlayer, nwno)`` by ``picaso_raman_oklopcic_dev``.  Everything that depends on the wavelength only --
+    ``Q_i = c_i / wno**3 / (wno + deltanu_i)`` and ``Q_i * stellar_shifts[:, i]`` -- is formed once with the reference's
+    numpy expressions and kept on the device with the opacity object (until ``raman_db`` or the
+    ``raman_stellar_shifts`` array is replaced); per call only the 10 rotational populations of every layer
+    (``j_fraction``) are computed on the host.  Same bits as the host function, which takes ~1 s per call at 1e5
+    wavelengths."""
+    db, shifts = opa.raman_db, opa.raman_stellar_shifts
+    if db is None or shifts is None:
+        raise Exception("raman='oklopcic' needs opa.raman_db (c, ji, deltanu) and opa.raman_stellar_shifts (nwno, "
+                        "transitions): the ratio of the shifted to the unshifted stellar spectrum on the opacity grid")
+    c, ji, dnu = (np.asarray(db[k], dtype=t) for k, t in (("c", float), ("ji", np.int32), ("deltanu", float)))
+    hit = opa.__dict__.get("_raman_oklopcic")
+    if hit is None or hit["shifts"] is not shifts or not (np.array_equal(hit["c"], c) and np.array_equal(hit["ji"], ji)
+                                                          and np.array_equal(hit["dnu"], dnu)):
+        wno, sh = np.asarray(opa.wno, dtype=float), np.asarray(shifts, dtype=float)
+        Q = np.empty((c.size, wno.size))
+        QS = np.zeros((c.size, wno.size))
+        for i in range(c.size):
+            Q[i] = c[i] / wno ** 3.0 / (wno + dnu[i])
+            if dnu[i] != 0:
+                QS[i] = Q[i] * sh[:, i]
+        hit = opa.__dict__["_raman_oklopcic"] = dict(
+            shifts=shifts, c=c.copy(), ji=np.ascontiguousarray(ji), dnu=dnu.copy(),
+            isray=np.ascontiguousarray((dnu == 0).astype(np.int32)),
+            Q=DeviceArray.from_host(Q, opa.ctx), QS=DeviceArray.from_host(QS, opa.ctx))
+    tlayer = np.asarray(tlayer, dtype=float)
+    nlayer = tlayer.size
+    jat = np.ascontiguousarray(np.stack([j_fraction(j, tlayer) for j in range(10)]), dtype=np.float64)
+    check(load().picaso_raman_oklopcic_dev(
+        opa.ctx, _ci(nlayer), ctypes.c_long(opa.nwno), _ci(c.size), ptr(hit["Q"].addr), ptr(hit["QS"].addr),
+        hit["ji"].ctypes.data_as(ctypes.c_void_p), hit["isray"].ctypes.data_as(ctypes.c_void_p), ptr(jat), _cd(0.99999),
+        ptr(out.addr)), opa.ctx)
 
 
 def raman_plane_host(atm, opa, raman):
@@ -870,8 +911,10 @@ def compute_opacity_facets(atms, opacityclass, numg, numt, stream=2, delta_eddin
     if opa.ngauss != 1:
         raise Exception("compute_opacity_facets takes monochromatic opacities")
     tg3, tr3 = DeviceArray((nfac, nlayer, nwno), ctx), DeviceArray((nfac, nlayer, nwno), ctx)
-    row_mode = raman == 1 and not os.environ.get("PICASO_AMD_RAMAN_PLANES")
-    rf3 = [] if raman in (0, 1) and not row_mode else None    # Oklopcic: one plane per facet (layer temperatures)
+    on_dev = not os.environ.get("PICASO_AMD_RAMAN_PLANES")
+    row_mode = raman == 1 and on_dev
+    rf3 = [] if raman in (0, 1) and not on_dev else None      # host planes, one per facet
+    d_rf3 = DeviceArray((nfac, nlayer, nwno), ctx) if raman == 0 and on_dev else None   # Oklopcic: layer temperatures
     if not isinstance(atms, list):                            # one facet-form atmosphere: batched gas stage
         atm_f = atms
         gas_stage_facets(atm_f, opa, nfac, tg3, tr3, exclude_mol=exclude_mol)
@@ -880,6 +923,10 @@ def compute_opacity_facets(atms, opacityclass, numg, numt, stream=2, delta_eddin
             for f in range(nfac):
                 one = types_namespace_layer(atm_f, tl[:, f])
                 rf3.append(raman_plane_host(one, opa, raman))
+        if d_rf3 is not None:
+            tl = np.broadcast_to(np.asarray(atm_f.layer["temperature"], dtype=float), (nlayer, nfac))
+            for f in range(nfac):
+                raman_oklopcic_device(opa, tl[:, f], d_rf3.row_block(f))
         atms = None
     for g in range(numg if atms is not None else 0):
         for t in range(numt):
@@ -888,7 +935,9 @@ def compute_opacity_facets(atms, opacityclass, numg, numt, stream=2, delta_eddin
             gas_stage(atms[g][t], opa, tg3.row_block(f), tr3.row_block(f))
             if rf3 is not None:
                 rf3.append(raman_plane_host(atms[g][t], opa, raman))
-    d_rf, rf_rows = (DeviceArray.from_host(np.stack(rf3), ctx) if rf3 else None), nlayer
+            if d_rf3 is not None:
+                raman_oklopcic_device(opa, atms[g][t].layer["temperature"], d_rf3.row_block(f))
+    d_rf, rf_rows = (DeviceArray.from_host(np.stack(rf3), ctx) if rf3 else d_rf3), nlayer
     if row_mode:                                              # Pollack: one row for every layer and facet
         d_rf, rf_rows = raman_device(atms[0][0] if isinstance(atms, list) else atm_f, opa, raman)
     d_c = [None, None, None]

@@ -324,13 +324,16 @@ def test_gpu_3d_batched_facets_equal_per_facet_loop(og, raman, radius, monkeypat
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("raman", ["pollack", "oklopcic"])
 @pytest.mark.parametrize("dimension", ["1d", "3d"])
-def test_gpu_pollack_raman_row_equals_tiled_planes(og, dimension, monkeypatch, tmp_path):
+def test_gpu_raman_on_the_device_equals_host_planes(og, dimension, raman, monkeypatch, tmp_path):
     """raman='pollack' (the reference's default, justdoit.py:4636): the factor depends on the wavelength only. The
     reference tiles the table over the layers (optics.py:296-298, np.repeat) and, in 3-D, does so once per facet;
     here ONE row of nwno values stays on the opacity object and the mixing kernels read it for every layer and facet
-    (`raman_rows = 0`).  Bit-identical to the tiled planes (PICASO_AMD_RAMAN_PLANES=1), also through the per-facet
-    loop and in wavelength blocks."""
+    (`raman_rows = 0`).  raman='oklopcic': the factor plane of compute_raman (optics.py:434-494) is formed by
+    `picaso_raman_oklopcic_dev` from resident per-transition tables instead of ~1 s of numpy per call.  Both
+    bit-identical to the host planes (PICASO_AMD_RAMAN_PLANES=1), also through the per-facet loop and in wavelength
+    blocks."""
     from picaso_amd import justdoit as jdi
     ng, nt = 3, 2
     g = np.load(os.path.join(GOLDEN, "raman_pollack.npz"))
@@ -338,10 +341,15 @@ def test_gpu_pollack_raman_row_equals_tiled_planes(og, dimension, monkeypatch, t
     np.savetxt(tmp_path / "opacities" / "raman_fortran.txt", np.column_stack([g["table/w"], g["table/f"]]), fmt="%.17g")
     monkeypatch.setenv("picaso_refdata", str(tmp_path))
     opa = jdi.opannection(filename_db=DB, query_method="linear")
+    if raman == "oklopcic":
+        opa.raman_stellar_shifts = og["in/raman_shifts"]
+        opa.raman_db = {"c": og["in/raman_c"], "ji": og["in/raman_ji"], "deltanu": og["in/raman_deltanu"]}
     pert = 1.0 + 0.1 * np.cos(np.arange(ng * nt).reshape(ng, nt))
 
     def run(devices=None):
         case = jdi.inputs()                                    # no approx(): Raman is Pollack's table by default
+        if raman != "pollack":
+            case.approx(raman=raman)
         case.gravity(gravity=float(og["in/gravity"]))
         case.surface_reflect(0.1)
         if dimension == "1d":
@@ -594,3 +602,30 @@ def test_gpu_phase_curve_against_oracle_solver(og, oracle):
                                           P["cosb_og"], pl3, u1, np.full(nwno, 0.15), 1)
                 assert rel_err(curve[ph]["full_output"]["thermal_3d"], f) < 1e-8, ph
                 assert rel_err(curve[ph]["thermal"], oracle.compress_thermal(nwno, f, gw, tw)) < 1e-8
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nlayer", [1, 29, 30, 31, 90])
+def test_gpu_raman_oklopcic_plane_is_compute_raman(og, nlayer):
+    """picaso_raman_oklopcic_dev against optics.compute_raman (the restatement of reference optics.py:434-494 that the
+    golden planes pin) on fresh temperatures and shift ratios: every element the same bits, for layer counts around the
+    kernel's 30-layer passes; replacing the shift array or the table rebuilds the resident tables."""
+    from picaso_amd import justdoit as jdi
+    from picaso_amd import optics as px
+    from picaso_amd.device import DeviceArray
+    rng = np.random.default_rng(nlayer)
+    opa = jdi.opannection(filename_db=DB)
+    c, ji, dnu = og["in/raman_c"], og["in/raman_ji"], og["in/raman_deltanu"]
+    opa.raman_db = {"c": c, "ji": ji, "deltanu": dnu}
+    for trial in range(2):
+        shifts = 1.0 + 0.3 * rng.standard_normal((opa.nwno, c.size))
+        opa.raman_stellar_shifts = shifts
+        tlayer = rng.uniform(40.0, 3000.0, nlayer)
+        out = DeviceArray((nlayer, opa.nwno), opa.ctx)
+        px.raman_oklopcic_device(opa, tlayer, out)
+        want = np.minimum(px.compute_raman(opa.nwno, nlayer, opa.wno, shifts, tlayer, c, ji, dnu), 0.99999)
+        assert np.array_equal(out.to_host(), want)
+    opa.raman_db = {"c": c * 2.0, "ji": ji, "deltanu": dnu + 1.0}      # no Rayleigh transition left: all shifted
+    px.raman_oklopcic_device(opa, tlayer, out)
+    want = np.minimum(px.compute_raman(opa.nwno, nlayer, opa.wno, shifts, tlayer, c * 2.0, ji, dnu + 1.0), 0.99999)
+    assert np.array_equal(out.to_host(), want, equal_nan=True)

@@ -36,7 +36,7 @@ akw = dict(raman=os.environ.get("RAMAN", "none"), get_lvl_flux=bool(os.environ.g
 if os.environ.get("RT", "toon") == "SH":
     akw.update(rt_method="SH", stream=4)
 case.approx(**akw)
-if os.environ.get("STAR") or akw["raman"] != "none":
+if os.environ.get("STAR") or akw["raman"] != "none" or "transmission" in os.environ.get("CALC", ""):
     case.star(relative_flux=1.0 + 0.2 * np.cos(wno / 900.0), radius=6.9e10, semi_major=7.5e12)
     case.gravity(radius=7.1e9, mass=1.9e30)
 if akw["raman"] == "pollack":
@@ -48,7 +48,7 @@ if akw["raman"] == "pollack":
     os.environ["picaso_refdata"] = d0
 if akw["raman"] == "oklopcic":
     g = np.load(os.path.join(ROOT, "tests", "golden", "optics.npz"))
-    opa.raman_stellar_shifts = None
+    opa.raman_stellar_shifts = 1.0 + 0.02 * np.cos(np.outer(wno / 700.0, 1.0 + np.arange(len(g["in/raman_deltanu"]))))
     opa.raman_db = {"c": g["in/raman_c"], "ji": g["in/raman_ji"], "deltanu": g["in/raman_deltanu"]}
 # CLOUD=box: a box cloud on a 196-point grid of its own (what virga and clouds(g0=..., p=..., dp=...) hand over),
 # regridded per call -- on the device, or with PICASO_AMD_HOST_REGRID=1 by the reference's numpy.interp rows;
@@ -70,7 +70,7 @@ if os.environ.get("CLOUD"):
                         for k in ("opd", "w0", "g0")})
 calc = os.environ.get("CALC", "reflected+thermal")
 for _ in range(int(os.environ.get("WARM", "30"))):
-    r = case.spectrum(opa, calculation=calc)
+    r = case.spectrum(opa, calculation=calc, full_output=bool(os.environ.get("FULL")))
 if os.environ.get("PROFILE_1D"):
     import cProfile, pstats
     pr = cProfile.Profile()
@@ -89,7 +89,7 @@ for devs in devsets:
     ts = []
     for _ in range(20):
         t0 = time.perf_counter()
-        r = case.spectrum(opa, calculation=calc, devices=devs)
+        r = case.spectrum(opa, calculation=calc, devices=devs, full_output=bool(os.environ.get("FULL")))
         ts.append(time.perf_counter() - t0)
     out["spectrum_1d_%d_%s_devices_%s_ms" % (nwno, calc, "none" if devs is None else len(devs))] = round(1e3 * min(ts), 3)
 out["albedo_sum"] = float(np.sum(r.get("albedo", 0.0)))
