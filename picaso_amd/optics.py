@@ -1030,9 +1030,14 @@ def compute_opacity_resident(atmosphere, opacityclass, ngauss=1, stream=2, delta
         *[ptr(out[k].addr) if out[k] is not None else None for k in OUT_NAMES]), ctx)
     out = {k: v for k, v in out.items() if v is not None}
     if full_output:
+        def over_gauss(x):      # (nlayer, nwno) -> (nlayer, nwno, ngauss) as the reference stores it; a view for ngauss = 1
+            return x[:, :, None] if ngauss == 1 else np.repeat(x[:, :, None], ngauss, axis=2)
         atmosphere.taugas = taugas.to_host().reshape((nlayer, nwno, ngauss))
-        atmosphere.tauray = np.repeat(tauray.to_host()[:, :, None], ngauss, axis=2)
-        atmosphere.taucld = np.repeat(np.asarray(taucld_host())[:, :, None], ngauss, axis=2)
+        atmosphere.tauray = over_gauss(tauray.to_host())
+        if getattr(atm, "cloud_free", False):                 # zeros, as the (read-only) cloud tables themselves
+            atmosphere.taucld = np.broadcast_to(np.zeros((1, 1, 1)), (nlayer, nwno, ngauss))
+        else:
+            atmosphere.taucld = over_gauss(np.asarray(taucld_host()))
     return out
 
 

@@ -76,7 +76,7 @@ if os.environ.get("PROFILE_1D"):
     pr = cProfile.Profile()
     pr.enable()
     for _ in range(50):
-        case.spectrum(opa, calculation=calc)
+        case.spectrum(opa, calculation=calc, full_output=bool(os.environ.get("FULL")))
     pr.disable()
     pstats.Stats(pr).sort_stats("cumulative").print_stats(35)
     sys.exit(0)
