@@ -31,6 +31,48 @@ def lib():
     return _LIB
 
 
+_LIB_X80 = None
+
+
+def lib_x80():
+    """The Toon reflected / thermal restatement built with ``real = long double`` (x87 extended precision)."""
+    global _LIB_X80
+    if _LIB_X80 is None:
+        build()
+        _LIB_X80 = ctypes.CDLL(os.path.join(_HERE, "libpicaso_oracle_x80.so"))
+    return _LIB_X80
+
+
+class _Prec:
+    """Array / scalar marshalling of one build of the restatement."""
+
+    def __init__(self, dtype, cscalar, getlib):
+        self.dtype, self.cs, self.lib = dtype, cscalar, getlib
+        self.ptr = ctypes.POINTER(cscalar)
+
+    def a(self, x, shape=None):
+        a = np.ascontiguousarray(x, dtype=self.dtype)
+        if shape is not None:
+            a = np.ascontiguousarray(np.broadcast_to(a, shape))
+        return a
+
+    def p(self, a):
+        return a.ctypes.data_as(self.ptr) if a is not None else None
+
+    def per_wave(self, x, nwno):
+        return self.a(np.zeros(nwno, dtype=self.dtype) + np.asarray(x, dtype=self.dtype))
+
+    def zeros(self, shape):
+        return np.zeros(shape, dtype=self.dtype)
+
+    def out(self, a):
+        return a if self.dtype is np.float64 else np.asarray(a, dtype=np.float64)
+
+
+_F64 = _Prec(np.float64, ctypes.c_double, lib)
+_X80 = _Prec(np.longdouble, ctypes.c_longdouble, lib_x80)
+
+
 def _a(x, shape=None):
     a = np.ascontiguousarray(x, dtype=np.float64)
     if shape is not None:
@@ -54,38 +96,40 @@ def _check(rc, what):
 
 def _reflected(variant, nlevel, nwno, numg, numt, planes, surf_reflect, ubar0, ubar1, cos_theta,
                F0PI, single_phase, multi_phase, frac_a, frac_b, frac_c, constant_back,
-               constant_forward, get_toa_intensity, get_lvl_flux, toon_coefficients, b_top):
-    keep = [_a(p) for p in planes]
-    sr = _per_wave(surf_reflect, nwno)
-    f0 = _per_wave(F0PI, nwno)
-    u0, u1 = _a(ubar0), _a(ubar1)
-    xint = np.zeros((numg, numt, nwno))
-    lvl = [np.zeros((numg, numt, nlevel, nwno)) for _ in range(4)] if variant == 0 else [None] * 4
+               constant_forward, get_toa_intensity, get_lvl_flux, toon_coefficients, b_top, P=_F64):
+    keep = [P.a(p) for p in planes]
+    sr = P.per_wave(surf_reflect, nwno)
+    f0 = P.per_wave(F0PI, nwno)
+    u0, u1 = P.a(ubar0), P.a(ubar1)
+    xint = P.zeros((numg, numt, nwno))
+    lvl = [P.zeros((numg, numt, nlevel, nwno)) for _ in range(4)] if variant == 0 else [None] * 4
     want_lvl = bool(get_lvl_flux) and variant == 0
-    rc = lib().orc_reflected(
+    cd = P.cs
+    rc = P.lib().orc_reflected(
         ctypes.c_int(variant), ctypes.c_int(nlevel), ctypes.c_int(nwno), ctypes.c_int(numg),
-        ctypes.c_int(numt), *[_p(k) for k in keep], _p(sr), _p(u0), _p(u1),
-        ctypes.c_double(cos_theta), _p(f0), ctypes.c_int(single_phase), ctypes.c_int(multi_phase),
-        ctypes.c_double(frac_a), ctypes.c_double(frac_b), ctypes.c_double(frac_c),
-        ctypes.c_double(constant_back), ctypes.c_double(constant_forward),
+        ctypes.c_int(numt), *[P.p(k) for k in keep], P.p(sr), P.p(u0), P.p(u1),
+        cd(cos_theta), P.p(f0), ctypes.c_int(single_phase), ctypes.c_int(multi_phase),
+        cd(frac_a), cd(frac_b), cd(frac_c), cd(constant_back), cd(constant_forward),
         ctypes.c_int(get_toa_intensity), ctypes.c_int(get_lvl_flux),
-        ctypes.c_int(toon_coefficients), ctypes.c_double(b_top), _p(xint),
-        *[_p(l) if want_lvl else None for l in lvl])
+        ctypes.c_int(toon_coefficients), cd(b_top), P.p(xint),
+        *[P.p(l) if want_lvl else None for l in lvl])
     _check(rc, "reflected")
-    return xint, lvl
+    return P.out(xint), [P.out(l) if l is not None else None for l in lvl]
 
 
 def get_reflected_1d(nlevel, wno, nwno, numg, numt, dtau, tau, w0, cosb, gcos2, ftau_cld, ftau_ray,
                      dtau_og, tau_og, w0_og, cosb_og, surf_reflect, ubar0, ubar1, cos_theta, F0PI,
                      single_phase, multi_phase, frac_a, frac_b, frac_c, constant_back,
                      constant_forward, get_toa_intensity=1, get_lvl_flux=0, toon_coefficients=0,
-                     b_top=0):
-    """Signature of reference ``fluxes.get_reflected_1d`` (fluxes.py:1010-1015)."""
+                     b_top=0, x80=False):
+    """Signature of reference ``fluxes.get_reflected_1d`` (fluxes.py:1010-1015).  ``x80=True``: the same expressions
+    evaluated in x87 extended precision (results rounded to float64): how far the reference's own fp64 rounding
+    moves an element is ``|get_reflected_1d(...) - get_reflected_1d(..., x80=True)|``."""
     xint, lvl = _reflected(0, nlevel, nwno, numg, numt,
                            (dtau, tau, w0, cosb, gcos2, ftau_cld, ftau_ray, dtau_og, tau_og, w0_og,
                             cosb_og), surf_reflect, ubar0, ubar1, cos_theta, F0PI, single_phase,
                            multi_phase, frac_a, frac_b, frac_c, constant_back, constant_forward,
-                           get_toa_intensity, get_lvl_flux, toon_coefficients, b_top)
+                           get_toa_intensity, get_lvl_flux, toon_coefficients, b_top, P=_X80 if x80 else _F64)
     return xint, tuple(lvl)
 
 
@@ -103,27 +147,27 @@ def get_reflected_3d(nlevel, wno, nwno, numg, numt, dtau_3d, tau_3d, w0_3d, cosb
 
 
 def _thermal(variant, nlevel, wno, nwno, numg, numt, tlevel, dtau, w0, cosb, plevel, ubar1,
-             surf_reflect, hard_surface, dwno, calc_type):
-    wno_, tl, dt, w0_, cb, pl, u1 = (_a(wno), _a(tlevel), _a(dtau), _a(w0), _a(cosb), _a(plevel),
-                                     _a(ubar1))
-    sr = _per_wave(surf_reflect, nwno)
-    dw = _per_wave(dwno, nwno)
-    out = np.zeros((numg, numt, nwno))
-    lvl = [np.zeros((numg, numt, nlevel, nwno)) for _ in range(4)] if variant == 0 else [None] * 4
-    rc = lib().orc_thermal(
-        ctypes.c_int(variant), ctypes.c_int(nlevel), _p(wno_), ctypes.c_int(nwno),
-        ctypes.c_int(numg), ctypes.c_int(numt), _p(tl), _p(dt), _p(w0_), _p(cb), _p(pl), _p(u1),
-        _p(sr), ctypes.c_int(int(hard_surface)), _p(dw), ctypes.c_int(calc_type), _p(out),
-        *[_p(l) for l in lvl])
+             surf_reflect, hard_surface, dwno, calc_type, P=_F64):
+    wno_, tl, dt, w0_, cb, pl, u1 = (P.a(wno), P.a(tlevel), P.a(dtau), P.a(w0), P.a(cosb), P.a(plevel),
+                                     P.a(ubar1))
+    sr = P.per_wave(surf_reflect, nwno)
+    dw = P.per_wave(dwno, nwno)
+    out = P.zeros((numg, numt, nwno))
+    lvl = [P.zeros((numg, numt, nlevel, nwno)) for _ in range(4)] if variant == 0 else [None] * 4
+    rc = P.lib().orc_thermal(
+        ctypes.c_int(variant), ctypes.c_int(nlevel), P.p(wno_), ctypes.c_int(nwno),
+        ctypes.c_int(numg), ctypes.c_int(numt), P.p(tl), P.p(dt), P.p(w0_), P.p(cb), P.p(pl), P.p(u1),
+        P.p(sr), ctypes.c_int(int(hard_surface)), P.p(dw), ctypes.c_int(calc_type), P.p(out),
+        *[P.p(l) for l in lvl])
     _check(rc, "thermal")
-    return out, lvl
+    return P.out(out), [P.out(l) if l is not None else None for l in lvl]
 
 
 def get_thermal_1d(nlevel, wno, nwno, numg, numt, tlevel, dtau, w0, cosb, plevel, ubar1,
-                   surf_reflect, hard_surface, dwno, calc_type):
-    """Signature of reference ``fluxes.get_thermal_1d`` (fluxes.py:1683-1684)."""
+                   surf_reflect, hard_surface, dwno, calc_type, x80=False):
+    """Signature of reference ``fluxes.get_thermal_1d`` (fluxes.py:1683-1684); ``x80`` as in ``get_reflected_1d``."""
     out, lvl = _thermal(0, nlevel, wno, nwno, numg, numt, tlevel, dtau, w0, cosb, plevel, ubar1,
-                        surf_reflect, hard_surface, dwno, calc_type)
+                        surf_reflect, hard_surface, dwno, calc_type, P=_X80 if x80 else _F64)
     return out, tuple(lvl)
 
 

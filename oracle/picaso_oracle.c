@@ -18,8 +18,19 @@
  * Each function cites the reference file:line it restates.
  */
 #include <math.h>
+#include <tgmath.h>
 #include <stdlib.h>
 #include <string.h>
+
+/* The arithmetic type: double, or -- `make libpicaso_oracle_x80.so`, -DORC_REAL="long double" -- x87 extended
+ * precision with the same expressions (<tgmath.h> picks expl / sqrtl / ...).  The extended build is how the tests
+ * tell the reference's OWN fp64 rounding from an implementation error where its formulas are ill-conditioned
+ * (thick layers: exp(+lambda dtau) terms up to the 35 clip): tests/helpers.py:lvl_excess, tests/test_fuzz_gpu.py.
+ * Constants keep their fp64 values in both builds (the reference's `pi` is a Python float). */
+#ifndef ORC_REAL
+#define ORC_REAL double
+#endif
+typedef ORC_REAL real;
 
 #define PI 3.141592653589793
 
@@ -29,13 +40,13 @@
  * downwards (this direction is what the reference does; kept for identical rounding).
  * as_, ds_ are caller-provided scratch of length l.
  * ------------------------------------------------------------------------------------------ */
-static void tri_diag_solve(int l, const double *a, const double *b, const double *c,
-                           const double *d, double *as_, double *ds_, double *xk)
+static void tri_diag_solve(int l, const real *a, const real *b, const real *c,
+                           const real *d, real *as_, real *ds_, real *xk)
 {
     as_[l - 1] = a[l - 1] / b[l - 1];
     ds_[l - 1] = d[l - 1] / b[l - 1];
     for (int i = l - 2; i >= 0; --i) {
-        double x = 1.0 / (b[i] - c[i] * as_[i + 1]);
+        real x = 1.0 / (b[i] - c[i] * as_[i + 1]);
         as_[i] = a[i] * x;
         ds_[i] = (d[i] - c[i] * ds_[i + 1]) * x;
     }
@@ -47,11 +58,11 @@ static void tri_diag_solve(int l, const double *a, const double *b, const double
  * setup_tri_diag for ONE wavelength column -- reference picaso/fluxes.py:88-183.
  * Inputs are per-layer columns (length nlayer); outputs A,B,C,D of length 2*nlayer.
  * ------------------------------------------------------------------------------------------ */
-static void setup_tri_diag_col(int nlayer, const double *c_plus_up, const double *c_minus_up,
-                               const double *c_plus_down, const double *c_minus_down,
-                               double b_top, double b_surface, double surf_reflect,
-                               const double *gama, const double *ep, const double *em,
-                               double *A, double *B, double *C, double *D)
+static void setup_tri_diag_col(int nlayer, const real *c_plus_up, const real *c_minus_up,
+                               const real *c_plus_down, const real *c_minus_down,
+                               real b_top, real b_surface, real surf_reflect,
+                               const real *gama, const real *ep, const real *em,
+                               real *A, real *B, real *C, real *D)
 {
     int L = 2 * nlayer;
     /* fluxes.py:143-146 */
@@ -92,10 +103,10 @@ static void setup_tri_diag_col(int nlayer, const double *c_plus_up, const double
 #undef E4
 }
 
-static double hg_term(double g, double cos_theta)
+static real hg_term(real g, real cos_theta)
 {
     /* (1-g**2)/sqrt((1+g**2+2*g*cos_theta)**3)   fluxes.py:1316-1317 */
-    double base = 1.0 + g * g + 2.0 * g * cos_theta;
+    real base = 1.0 + g * g + 2.0 * g * cos_theta;
     return (1.0 - g * g) / sqrt(base * base * base);
 }
 
@@ -111,49 +122,49 @@ static double hg_term(double g, double cos_theta)
  * flux_plus_midpt (only for variant 0 with get_lvl_flux).
  * ------------------------------------------------------------------------------------------ */
 int orc_reflected(int variant, int nlevel, int nwno, int numg, int numt,
-                  const double *dtau, const double *tau, const double *w0, const double *cosb,
-                  const double *gcos2, const double *ftau_cld, const double *ftau_ray,
-                  const double *dtau_og, const double *tau_og, const double *w0_og,
-                  const double *cosb_og, const double *surf_reflect, const double *ubar0,
-                  const double *ubar1, double cos_theta, const double *F0PI, int single_phase,
-                  int multi_phase, double frac_a, double frac_b, double frac_c,
-                  double constant_back, double constant_forward, int get_toa_intensity,
-                  int get_lvl_flux, int toon_coefficients, double b_top_in, double *xint_at_top,
-                  double *lvl_fm, double *lvl_fp, double *lvl_fmm, double *lvl_fpm)
+                  const real *dtau, const real *tau, const real *w0, const real *cosb,
+                  const real *gcos2, const real *ftau_cld, const real *ftau_ray,
+                  const real *dtau_og, const real *tau_og, const real *w0_og,
+                  const real *cosb_og, const real *surf_reflect, const real *ubar0,
+                  const real *ubar1, real cos_theta, const real *F0PI, int single_phase,
+                  int multi_phase, real frac_a, real frac_b, real frac_c,
+                  real constant_back, real constant_forward, int get_toa_intensity,
+                  int get_lvl_flux, int toon_coefficients, real b_top_in, real *xint_at_top,
+                  real *lvl_fm, real *lvl_fp, real *lvl_fmm, real *lvl_fpm)
 {
     const int nlayer = nlevel - 1, L = 2 * nlayer;
     if (nlayer < 1 || nwno < 1) return 1;
     if (multi_phase != 0 && multi_phase != 1) return 2;      /* reference: UnboundLocalError */
     if (single_phase < 0 || single_phase > 3) return 2;
     if (toon_coefficients != 0 && toon_coefficients != 1) return 2;
-    const double sq3 = sqrt(3.0);
+    const real sq3 = sqrt(3.0);
     const int is3d = (variant == 1);
     const int nfac = numg * numt;
-    const double clip = is3d ? 40.0 : 35.0;                   /* fluxes.py:1174 vs :516 */
-    const double b_top = is3d ? 0.0 : b_top_in;               /* fluxes.py:522 */
+    const real clip = is3d ? 40.0 : 35.0;                   /* fluxes.py:1174 vs :516 */
+    const real b_top = is3d ? 0.0 : b_top_in;               /* fluxes.py:522 */
     if (is3d) toon_coefficients = 0;                          /* fluxes.py:489-493 */
 
     size_t nl = (size_t)nlayer;
-    double *buf = (double *)malloc(sizeof(double) * (nl * 22 + (size_t)L * 7 + 8));
+    real *buf = (real *)malloc(sizeof(real) * (nl * 22 + (size_t)L * 7 + 8));
     if (!buf) return 3;
-    double *g1 = buf, *g2 = g1 + nl, *lam = g2 + nl, *gam = lam + nl, *cpu = gam + nl,
+    real *g1 = buf, *g2 = g1 + nl, *lam = g2 + nl, *gam = lam + nl, *cpu = gam + nl,
            *cmu = cpu + nl, *cpd = cmu + nl, *cmd = cpd + nl, *expt = cmd + nl, *ep = expt + nl,
            *em = ep + nl, *pos = em + nl, *neg = pos + nl, *apl = neg + nl, *ami = apl + nl,
            *Gq = ami + nl, *Hq = Gq + nl, *Aq = Hq + nl, *psing = Aq + nl;
-    double *A = psing + nl * 4, *B = A + L, *C = B + L, *D = C + L, *AS = D + L, *DS = AS + L,
+    real *A = psing + nl * 4, *B = A + L, *C = B + L, *D = C + L, *AS = D + L, *DS = AS + L,
            *X = DS + L;
 
     for (int ig = 0; ig < numg; ++ig)
         for (int it = 0; it < numt; ++it) {
             const int fac = ig * numt + it;
-            double u1 = ubar1[fac], u0 = ubar0[fac];
+            real u1 = ubar1[fac], u0 = ubar0[fac];
             if (is3d) { u1 = fabs(u1); u0 = fabs(u0); }        /* fluxes.py:467-468 */
             const size_t fs = is3d ? (size_t)nfac : 1, fo = is3d ? (size_t)fac : 0;
 #define P(arr, i, w) arr[((size_t)(i) * nwno + (w)) * fs + fo]
             for (int w = 0; w < nwno; ++w) {
-                const double F = F0PI[w], rs = surf_reflect[w];
+                const real F = F0PI[w], rs = surf_reflect[w];
                 for (int i = 0; i < nlayer; ++i) {
-                    const double w0_ = P(w0, i, w), cb = P(cosb, i, w), fc = P(ftau_cld, i, w);
+                    const real w0_ = P(w0, i, w), cb = P(cosb, i, w), fc = P(ftau_cld, i, w);
                     if (toon_coefficients == 1) {              /* fluxes.py:1134-1135 */
                         g1[i] = (7.0 - w0_ * (4.0 + 3.0 * fc * cb)) / 4.0;
                         g2[i] = -(1.0 - w0_ * (4.0 - 3.0 * fc * cb)) / 4.0;
@@ -163,26 +174,26 @@ int orc_reflected(int variant, int nlevel, int nwno, int numg, int numt,
                     }
                     lam[i] = sqrt(g1[i] * g1[i] - g2[i] * g2[i]);   /* :1140 */
                     gam[i] = (g1[i] - lam[i]) / g2[i];               /* :1141 */
-                    double g3;
+                    real g3;
                     if (toon_coefficients == 1) g3 = (2.0 - 3.0 * fc * cb * u0) / 4.0;  /* :1149 */
                     else g3 = 0.5 * (1.0 - sq3 * fc * cb * u0);                         /* :1151 */
-                    const double g4 = 1.0 - g3;
-                    const double den = lam[i] * lam[i] - 1.0 / (u0 * u0);               /* :1155 */
+                    const real g4 = 1.0 - g3;
+                    const real den = lam[i] * lam[i] - 1.0 / (u0 * u0);               /* :1155 */
                     ami[i] = F * w0_ * (g4 * (g1[i] + 1.0 / u0) + g2[i] * g3) / den;    /* :1158 */
                     apl[i] = F * w0_ * (g3 * (g1[i] - 1.0 / u0) + g2[i] * g4) / den;    /* :1159 */
-                    double x = exp(-P(tau, i, w) / u0);                                  /* :1164 */
+                    real x = exp(-P(tau, i, w) / u0);                                  /* :1164 */
                     cmu[i] = ami[i] * x;
                     cpu[i] = apl[i] * x;
                     x = exp(-P(tau, i + 1, w) / u0);                                     /* :1167 */
                     cmd[i] = ami[i] * x;
                     cpd[i] = apl[i] * x;
-                    double e = lam[i] * P(dtau, i, w);                                   /* :1172 */
+                    real e = lam[i] * P(dtau, i, w);                                   /* :1172 */
                     if (e > clip) e = clip;                                              /* :1174 */
                     expt[i] = e;
                     ep[i] = exp(e);                                                      /* :1176 */
                     em[i] = 1.0 / ep[i];                                                 /* :1177 */
                 }
-                const double b_surface = 0.0 + rs * u0 * F * exp(-P(tau, nlayer, w) / u0); /* :1183 */
+                const real b_surface = 0.0 + rs * u0 * F * exp(-P(tau, nlayer, w) / u0); /* :1183 */
                 setup_tri_diag_col(nlayer, cpu, cmu, cpd, cmd, b_top, b_surface, rs, gam, ep, em,
                                    A, B, C, D);
                 tri_diag_solve(L, A, B, C, D, AS, DS, X);                                /* :1205 */
@@ -194,24 +205,24 @@ int orc_reflected(int variant, int nlevel, int nwno, int numg, int numt,
                 if (get_lvl_flux && !is3d && lvl_fm) {                                   /* :1219-1257 */
                     size_t base = ((size_t)fac * nlevel) * nwno + w;
                     for (int i = 0; i < nlayer; ++i) {
-                        double fm = pos[i] * gam[i] + neg[i] + cmu[i];
-                        double fp = pos[i] + gam[i] * neg[i] + cpu[i];
+                        real fm = pos[i] * gam[i] + neg[i] + cmu[i];
+                        real fp = pos[i] + gam[i] * neg[i] + cpu[i];
                         fm = fm + u0 * F * exp(-P(tau, i, w) / u0);                      /* :1236 */
-                        double epm = exp(0.5 * expt[i]);
-                        double emm = 1.0 / epm;
-                        double taumid = P(tau, i, w) + 0.5 * P(dtau, i, w);
-                        double x = exp(-taumid / u0);
-                        double cpm = apl[i] * x, cmm = ami[i] * x;
-                        double fmm = gam[i] * pos[i] * epm + neg[i] * emm + cmm;
-                        double fpm = pos[i] * epm + gam[i] * neg[i] * emm + cpm;
+                        real epm = exp(0.5 * expt[i]);
+                        real emm = 1.0 / epm;
+                        real taumid = P(tau, i, w) + 0.5 * P(dtau, i, w);
+                        real x = exp(-taumid / u0);
+                        real cpm = apl[i] * x, cmm = ami[i] * x;
+                        real fmm = gam[i] * pos[i] * epm + neg[i] * emm + cmm;
+                        real fpm = pos[i] * epm + gam[i] * neg[i] * emm + cpm;
                         fmm = fmm + u0 * F * exp(-taumid / u0);                          /* :1251 */
                         lvl_fm[base + (size_t)i * nwno] = fm;
                         lvl_fp[base + (size_t)i * nwno] = fp;
                         lvl_fmm[base + (size_t)i * nwno] = fmm;
                         lvl_fpm[base + (size_t)i * nwno] = fpm;
                     }
-                    double fzm = gam[n] * pos[n] * ep[n] + neg[n] * em[n] + cmd[n];      /* :1230 */
-                    double fzp = pos[n] * ep[n] + gam[n] * neg[n] * em[n] + cpd[n];      /* :1231 */
+                    real fzm = gam[n] * pos[n] * ep[n] + neg[n] * em[n] + cmd[n];      /* :1230 */
+                    real fzp = pos[n] * ep[n] + gam[n] * neg[n] * em[n] + cpd[n];      /* :1231 */
                     fzm = fzm + u0 * F * exp(-P(tau, nlayer, w) / u0);
                     lvl_fm[base + (size_t)nlayer * nwno] = fzm;
                     lvl_fp[base + (size_t)nlayer * nwno] = fzp;
@@ -219,14 +230,14 @@ int orc_reflected(int variant, int nlevel, int nwno, int numg, int numt,
                     lvl_fpm[base + (size_t)nlayer * nwno] = 0.0;
                 }
                 if (!get_toa_intensity && !is3d) continue;
-                const double flux_zero = pos[n] * ep[n] + gam[n] * neg[n] * em[n] + cpd[n]; /* :1266 */
-                double xint = flux_zero / PI;                                            /* :1270 */
+                const real flux_zero = pos[n] * ep[n] + gam[n] * neg[n] * em[n] + cpd[n]; /* :1266 */
+                real xint = flux_zero / PI;                                            /* :1270 */
                 for (int i = 0; i < nlayer; ++i) {
-                    const double w0_ = P(w0, i, w), cb = P(cosb, i, w), fc = P(ftau_cld, i, w);
-                    double mp, mm;
+                    const real w0_ = P(w0, i, w), cb = P(cosb, i, w), fc = P(ftau_cld, i, w);
+                    real mp, mm;
                     if (multi_phase == 0) {                                              /* :1275-1284 */
-                        const double ubar2 = 0.767;
-                        const double q = P(gcos2, i, w) * (3.0 * ubar2 * ubar2 * u1 * u1 - 1.0) / 2.0;
+                        const real ubar2 = 0.767;
+                        const real q = P(gcos2, i, w) * (3.0 * ubar2 * ubar2 * u1 * u1 - 1.0) / 2.0;
                         mp = (1.0 + 1.5 * fc * cb * u1 + q);
                         mm = (1.0 - 1.5 * fc * cb * u1 + q);
                     } else {                                                             /* :1285-1287 */
@@ -237,22 +248,22 @@ int orc_reflected(int variant, int nlevel, int nwno, int numg, int numt,
                     Gq[i] = pos[i] * (mp + gam[i] * mm) * w0_ * 0.5 / PI;
                     Hq[i] = neg[i] * (gam[i] * mp + mm) * w0_ * 0.5 / PI;
                     Aq[i] = (mp * cpu[i] + mm * cmu[i]) * w0_ * 0.5 / PI;
-                    const double cbo = P(cosb_og, i, w);
-                    double gf = 0, gb = 0, f = 0;
+                    const real cbo = P(cosb_og, i, w);
+                    real gf = 0, gb = 0, f = 0;
                     if (single_phase != 1) {                                             /* :1303-1306 */
                         gf = constant_forward * cbo;
                         gb = constant_back * cbo;
                         f = frac_a + frac_b * pow(gb, frac_c);
                     }
-                    double p;
+                    real p;
                     if (single_phase == 0) {
                         if (!is3d)                                                       /* :1315-1321 */
                             p = f * hg_term(gf, cos_theta) + (1.0 - f) * hg_term(gb, cos_theta) +
                                 P(gcos2, i, w);
                         else {                                                           /* :605-615 */
-                            double b1 = 1.0 + cbo * cbo + 2.0 * cbo * cos_theta;
-                            double hb = -cbo / 2.0;
-                            double b2 = 1.0 + hb * hb + 2.0 * hb * cos_theta;
+                            real b1 = 1.0 + cbo * cbo + 2.0 * cbo * cos_theta;
+                            real hb = -cbo / 2.0;
+                            real b2 = 1.0 + hb * hb + 2.0 * hb * cos_theta;
                             p = f * (1.0 - gf * gf) / sqrt(b1 * b1 * b1) +
                                 (1.0 - f) * (1.0 - gb * gb) / sqrt(b2 * b2 * b2) + P(gcos2, i, w);
                         }
@@ -267,7 +278,7 @@ int orc_reflected(int variant, int nlevel, int nwno, int numg, int numt,
                     psing[i] = p;
                 }
                 for (int i = nlayer - 1; i >= 0; --i) {                                  /* :1381-1407 */
-                    const double dt = P(dtau, i, w);
+                    const real dt = P(dtau, i, w);
                     xint = (xint * exp(-dt / u1) +
                             (P(w0_og, i, w) * F / (4.0 * PI)) * psing[i] * exp(-P(tau_og, i, w) / u0) *
                                 (1.0 - exp(-P(dtau_og, i, w) * (u0 + u1) / (u0 * u1))) *
@@ -285,21 +296,21 @@ int orc_reflected(int variant, int nlevel, int nwno, int numg, int numt,
 }
 
 /* blackbody -- reference picaso/fluxes.py:1660-1680 (cgs, per unit wavelength, w in cm) */
-static double planck_lambda(double t, double wcm)
+static real planck_lambda(real t, real wcm)
 {
-    const double h = 6.62607004e-27, c = 2.99792458e+10, k = 1.38064852e-16;
+    const real h = 6.62607004e-27, c = 2.99792458e+10, k = 1.38064852e-16;
     return ((2.0 * h * (c * c)) / pow(wcm, 5.0)) * (1.0 / (exp((h * c) / (t * (wcm * k))) - 1.0));
 }
 
 /* blackbody_integrated -- reference picaso/fluxes.py:1608-1658 (3-point bin mean in wavenumber) */
-static double planck_integrated(double t, double wave, double dwave)
+static real planck_integrated(real t, real wave, real dwave)
 {
-    const double h = 6.62607004e-27, c = 2.99792458e+10, k = 1.38064852e-16;
-    const double c1 = 2 * h * (c * c), c2 = h * c / k;
+    const real h = 6.62607004e-27, c = 2.99792458e+10, k = 1.38064852e-16;
+    const real c1 = 2 * h * (c * c), c2 = h * c / k;
     const int nbb = 1;
-    double s = 0.0;
+    real s = 0.0;
     for (int kk = -nbb; kk <= nbb; ++kk) {
-        double wn = wave + kk * dwave / (2.0 * nbb);
+        real wn = wave + kk * dwave / (2.0 * nbb);
         s += c1 * (wn * wn * wn) / (exp(c2 * wn / t) - 1.0);
     }
     return s / (2 * nbb + 1.0);
@@ -313,28 +324,28 @@ static double planck_integrated(double t, double wave, double dwave)
  * (nlevel,ng,nt), planes (nlayer,nwno,ng,nt).  lvl_* (nullable, 1-D only): 4 arrays
  * (numg,numt,nlevel,nwno) always filled by the reference.
  * ------------------------------------------------------------------------------------------ */
-int orc_thermal(int variant, int nlevel, const double *wno, int nwno, int numg, int numt,
-                const double *tlevel, const double *dtau, const double *w0, const double *cosb,
-                const double *plevel, const double *ubar1, const double *surf_reflect,
-                int hard_surface, const double *dwno, int calc_type, double *flux_at_top,
-                double *lvl_fm, double *lvl_fp, double *lvl_fmm, double *lvl_fpm)
+int orc_thermal(int variant, int nlevel, const real *wno, int nwno, int numg, int numt,
+                const real *tlevel, const real *dtau, const real *w0, const real *cosb,
+                const real *plevel, const real *ubar1, const real *surf_reflect,
+                int hard_surface, const real *dwno, int calc_type, real *flux_at_top,
+                real *lvl_fm, real *lvl_fp, real *lvl_fmm, real *lvl_fpm)
 {
     const int nlayer = nlevel - 1, L = 2 * nlayer;
     if (nlayer < 1 || nwno < 1) return 1;
     const int is3d = (variant == 1);
     const int nfac = numg * numt;
-    const double mu1 = 0.5;                                                      /* :1748 */
+    const real mu1 = 0.5;                                                      /* :1748 */
     size_t nl = (size_t)nlayer;
-    double *buf = (double *)malloc(sizeof(double) * (nl * 30 + (size_t)nlevel * 6 + (size_t)L * 7 + 8));
+    real *buf = (real *)malloc(sizeof(real) * (nl * 30 + (size_t)nlevel * 6 + (size_t)L * 7 + 8));
     if (!buf) return 3;
-    double *allb = buf, *b0 = allb + nlevel, *b1 = b0 + nl, *g1 = b1 + nl, *g2 = g1 + nl,
+    real *allb = buf, *b0 = allb + nlevel, *b1 = b0 + nl, *g1 = b1 + nl, *g2 = g1 + nl,
            *lam = g2 + nl, *gam = lam + nl, *gpg = gam + nl, *cpu = gpg + nl, *cmu = cpu + nl,
            *cpd = cmu + nl, *cmd = cpd + nl, *expt = cmd + nl, *ep = expt + nl, *em = ep + nl,
            *pos = em + nl, *neg = pos + nl, *Gq = neg + nl, *Hq = Gq + nl, *Jq = Hq + nl,
            *Kq = Jq + nl, *al1 = Kq + nl, *al2 = al1 + nl, *si1 = al2 + nl, *si2 = si1 + nl,
            *epm = si2 + nl, *emm = epm + nl;
-    double *fmn = emm + nl, *fpl = fmn + nlevel, *fmm = fpl + nlevel, *fpm = fmm + nlevel;
-    double *A = fpm + nlevel + nl, *B = A + L, *C = B + L, *D = C + L, *AS = D + L, *DS = AS + L,
+    real *fmn = emm + nl, *fpl = fmn + nlevel, *fmm = fpl + nlevel, *fpm = fmm + nlevel;
+    real *A = fpm + nlevel + nl, *B = A + L, *C = B + L, *D = C + L, *AS = D + L, *DS = AS + L,
            *X = DS + L;
 
     const int nouter = is3d ? nfac : 1;     /* 3-D redoes the solve per facet (:2213-2214) */
@@ -343,13 +354,13 @@ int orc_thermal(int variant, int nlevel, const double *wno, int nwno, int numg, 
 #define P(arr, i, w) arr[((size_t)(i) * nwno + (w)) * fs + fo]
 #define LV(arr, i) arr[(size_t)(i) * fs + fo]
         for (int w = 0; w < nwno; ++w) {
-            const double rs = surf_reflect[w];
+            const real rs = surf_reflect[w];
             for (int l = 0; l < nlevel; ++l) {
                 if (calc_type == 0 || is3d) allb[l] = planck_lambda(LV(tlevel, l), 1.0 / wno[w]); /* :1752 */
                 else allb[l] = planck_integrated(LV(tlevel, l), wno[w], dwno[w]);                /* :1754 */
             }
             for (int i = 0; i < nlayer; ++i) {
-                const double dt = P(dtau, i, w), w0_ = P(w0, i, w), cb = P(cosb, i, w);
+                const real dt = P(dtau, i, w), w0_ = P(w0, i, w), cb = P(cosb, i, w);
                 b0[i] = allb[i];                                                  /* :1756 */
                 b1[i] = (allb[i + 1] - b0[i]) / dt;                               /* :1757 */
                 g1[i] = 2.0 - w0_ * (1 + cb);                                     /* :1760 */
@@ -361,14 +372,14 @@ int orc_thermal(int variant, int nlevel, const double *wno, int nwno, int numg, 
                 cmu[i] = 2 * PI * mu1 * (b0[i] - b1[i] * gpg[i]);                 /* :1773 */
                 cpd[i] = 2 * PI * mu1 * (b0[i] + b1[i] * dt + b1[i] * gpg[i]);    /* :1778 */
                 cmd[i] = 2 * PI * mu1 * (b0[i] + b1[i] * dt - b1[i] * gpg[i]);    /* :1779 */
-                double e = lam[i] * dt;                                           /* :1784 */
+                real e = lam[i] * dt;                                           /* :1784 */
                 if (e > 35.0) e = 35.0;                                           /* :1786 */
                 expt[i] = e;
                 ep[i] = exp(e);
                 em[i] = 1.0 / ep[i];
             }
-            const double tau_top = P(dtau, 0, w) * LV(plevel, 0) / (LV(plevel, 1) - LV(plevel, 0)); /* :1797 */
-            double b_top, b_surface;
+            const real tau_top = P(dtau, 0, w) * LV(plevel, 0) / (LV(plevel, 1) - LV(plevel, 0)); /* :1797 */
+            real b_top, b_surface;
             if (!is3d) {
                 b_top = (1.0 - exp(-tau_top / mu1)) * allb[0] * PI;                /* :1800 */
                 if (hard_surface) b_surface = (1.0 - rs) * allb[nlevel - 1] * PI;  /* :1803-1804 */
@@ -397,8 +408,8 @@ int orc_thermal(int variant, int nlevel, const double *wno, int nwno, int numg, 
             }
             const int a_lo = is3d ? fo_ : 0, a_hi = is3d ? fo_ + 1 : nfac;
             for (int fac = a_lo; fac < a_hi; ++fac) {
-                const double iu = ubar1[fac];
-                memset(fmn, 0, sizeof(double) * 4 * (size_t)nlevel);
+                const real iu = ubar1[fac];
+                memset(fmn, 0, sizeof(real) * 4 * (size_t)nlevel);
                 if (!is3d) {
                     if (hard_surface) fpl[nlevel - 1] = (1.0 - rs) * allb[nlevel - 1] * 2 * PI;   /* :1871 */
                     else fpl[nlevel - 1] = (allb[nlevel - 1] + b1[nlayer - 1] * iu) * 2 * PI;      /* :1873 */
@@ -411,8 +422,8 @@ int orc_thermal(int variant, int nlevel, const double *wno, int nwno, int numg, 
                 for (int itop = 0; itop < nlayer; ++itop) {                                        /* :1880-1907 */
                     {
                         const int i = itop;
-                        const double dt = P(dtau, i, w);
-                        const double ea = exp(-dt / iu), eam = exp(-0.5 * dt / iu);
+                        const real dt = P(dtau, i, w);
+                        const real ea = exp(-dt / iu), eam = exp(-0.5 * dt / iu);
                         fmn[i + 1] = (fmn[i] * ea + (Jq[i] / (lam[i] * iu + 1.0)) * (ep[i] - ea) +
                                       (Kq[i] / (lam[i] * iu - 1.0)) * (ea - em[i]) + si1[i] * (1. - ea) +
                                       si2[i] * (iu * ea + dt - iu));
@@ -422,8 +433,8 @@ int orc_thermal(int variant, int nlevel, const double *wno, int nwno, int numg, 
                     }
                     {
                         const int i = nlayer - 1 - itop;
-                        const double dt = P(dtau, i, w);
-                        const double ea = exp(-dt / iu), eam = exp(-0.5 * dt / iu);
+                        const real dt = P(dtau, i, w);
+                        const real ea = exp(-dt / iu), eam = exp(-0.5 * dt / iu);
                         fpl[i] = (fpl[i + 1] * ea + (Gq[i] / (lam[i] * iu - 1.0)) * (ep[i] * ea - 1.0) +
                                   (Hq[i] / (lam[i] * iu + 1.0)) * (1.0 - em[i] * ea) + al1[i] * (1. - ea) +
                                   al2[i] * (iu - (dt + iu) * ea));
@@ -452,12 +463,12 @@ int orc_thermal(int variant, int nlevel, const double *wno, int nwno, int numg, 
 }
 
 /* compress_disco -- reference picaso/disco.py:117-149 */
-int orc_compress_disco(int nwno, double cos_theta, const double *xint_at_top, const double *gweight,
-                       int ng, const double *tweight, int nt, const double *F0PI, double *albedo)
+int orc_compress_disco(int nwno, real cos_theta, const real *xint_at_top, const real *gweight,
+                       int ng, const real *tweight, int nt, const real *F0PI, real *albedo)
 {
-    const double sym_fac = (nt == 1) ? 2 * PI : 1.0;
+    const real sym_fac = (nt == 1) ? 2 * PI : 1.0;
     for (int w = 0; w < nwno; ++w) {
-        double a = 0.0;
+        real a = 0.0;
         for (int ig = 0; ig < ng; ++ig)
             for (int it = 0; it < nt; ++it)
                 a = a + xint_at_top[((size_t)ig * nt + it) * nwno + w] * gweight[ig] * tweight[it];
@@ -468,12 +479,12 @@ int orc_compress_disco(int nwno, double cos_theta, const double *xint_at_top, co
 
 /* compress_thermal -- reference picaso/disco.py:151-181; ninner = nwno (3-D input) or
  * nlevel*nwno (4-D input) */
-int orc_compress_thermal(size_t ninner, const double *flux_at_top, const double *gweight, int ng,
-                         const double *tweight, int nt, double *flux)
+int orc_compress_thermal(size_t ninner, const real *flux_at_top, const real *gweight, int ng,
+                         const real *tweight, int nt, real *flux)
 {
-    const double sym_fac = (nt == 1) ? 1.0 : 1.0 / (2 * PI);
+    const real sym_fac = (nt == 1) ? 1.0 : 1.0 / (2 * PI);
     for (size_t w = 0; w < ninner; ++w) {
-        double a = 0.0;
+        real a = 0.0;
         for (int ig = 0; ig < ng; ++ig)
             for (int it = 0; it < nt; ++it)
                 a = a + flux_at_top[((size_t)ig * nt + it) * ninner + w] * gweight[ig] * tweight[it];
@@ -486,31 +497,31 @@ int orc_compress_thermal(size_t ninner, const double *flux_at_top, const double 
  * operation order of the reference: delta_length[i][j] (:2625-2644), TAU = DTAU/colden*mmw
  * (:2648-2650), TAUALL accumulated in j order (:2653-2656), F (:2660-2661).  player/tlayer are
  * indexed exactly as the reference indexes them (arrays of length >= nlevel-1). */
-int orc_get_transit_1d(const double *z, const double *dz, int nlevel, int nwno, double rstar,
-                       const double *mmw, double k_b, double amu, const double *player,
-                       const double *tlayer, const double *colden, const double *DTAU, double *F)
+int orc_get_transit_1d(const real *z, const real *dz, int nlevel, int nwno, real rstar,
+                       const real *mmw, real k_b, real amu, const real *player,
+                       const real *tlayer, const real *colden, const real *DTAU, real *F)
 {
     const int n = nlevel, nl = nlevel - 1;
-    double *dlen = (double *)calloc((size_t)n * n, sizeof(double));
-    double *tau = (double *)malloc(sizeof(double) * nl);
+    real *dlen = (real *)calloc((size_t)n * n, sizeof(real));
+    real *tau = (real *)malloc(sizeof(real) * nl);
     if (!dlen || !tau) { free(dlen); free(tau); return 1; }
-    double seg = 0.0;
+    real seg = 0.0;
     for (int i = 0; i < n; ++i)
         for (int j = 0; j < i; ++j) {
-            const double ref = z[i], inner = z[i - j], outer = z[i - j - 1];
+            const real ref = z[i], inner = z[i - j], outer = z[i - j - 1];
             if (inner != ref && outer != ref)
                 seg = sqrt(outer * outer - ref * ref) - sqrt(inner * inner - ref * ref);
             else if (inner == ref)
                 seg = sqrt(outer * outer - ref * ref);
             dlen[(size_t)i * n + j] = seg * player[i - j - 1] / tlayer[i - j - 1] / k_b;
         }
-    double zmin = z[0];
+    real zmin = z[0];
     for (int i = 1; i < n; ++i) zmin = z[i] < zmin ? z[i] : zmin;
     for (int w = 0; w < nwno; ++w) {
         for (int l = 0; l < nl; ++l) tau[l] = DTAU[(size_t)l * nwno + w] / colden[l] * (mmw[l] * amu);
-        double acc = 0.0;
+        real acc = 0.0;
         for (int i = 0; i < n; ++i) {
-            double t = 0.0;
+            real t = 0.0;
             for (int j = 0; j < i; ++j) t = t + 2 * tau[i - j - 1] * dlen[(size_t)i * n + j];
             acc = acc + (1.0 - exp(-t)) * (z[i] * dz[i]);
         }

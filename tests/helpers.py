@@ -96,3 +96,15 @@ def lvl_excess(got4, ref4, x80_4, tol):
         ex2 = (np.abs(np.asarray(g) - x) - e_ref / 500.0) / scale - tol
         worst = max(worst, float(np.max(ex1)), float(np.max(ex2)))
     return worst
+
+
+def excess(got, ref, x80, tol, floor):
+    """``lvl_excess`` for one array judged relative to ``max(|ref|, floor)``: with e_ref = |ref - x80| (the reference's
+    own fp64 rounding of that element, from its extended-precision evaluation) the result may differ from the
+    reference by tol*scale + 2 e_ref and from the extended-precision value by tol*scale + e_ref/500.  <= 0 passes."""
+    got, ref, x80 = (np.asarray(a, dtype=np.float64) for a in (got, ref, x80))
+    scale = np.maximum(np.abs(ref), floor)
+    e_ref = np.abs(ref - x80)
+    ex1 = (np.abs(got - ref) - 2.0 * e_ref) / scale - tol
+    ex2 = (np.abs(got - x80) - e_ref / 500.0) / scale - tol
+    return max(float(np.max(ex1)), float(np.max(ex2)))

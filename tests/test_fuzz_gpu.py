@@ -6,10 +6,12 @@ milliseconds; the point is coverage of option combinations and wave-uniform fast
 (cloud-free layers, cumulative-tau planes, symmetric geometry) that the fixtures hit only singly.
 Entries below 1e-4 of a field's maximum (limb facets, where exp(-tau/mu) all but vanishes) are judged
 against that scale: they carry the rounding of O(max) terms in the reference as well."""
+import os
+
 import numpy as np
 import pytest
 
-from helpers import PLANES, lvl_err, rel_err
+from helpers import PLANES, excess, lvl_err, lvl_excess, rel_err
 
 TTHG = (1.0, -1.0, 2.0, -0.5, 1.0)
 # PICASO_FUZZ_OFFSET=<int> shifts every seed: a soak run walks through fresh combinations
@@ -24,6 +26,16 @@ def _tol(sc, tight, loose):
     `loose` contract tolerance (1e-6) once a layer reaches the clip."""
     worst = float(np.max(sc["dtau_og"]))
     return float(np.clip(2e-15 * np.exp(min(2.0 * worst, 35.0)), tight, loose))
+
+
+def _dump(name, tag, **arrays):
+    """PICASO_FUZZ_DUMP=dir: inputs and both results of a case, for a look at it off the GPU box
+    (tools/experiments/fuzz_case_x80.py evaluates the reference in extended precision on them)."""
+    d = os.environ.get("PICASO_FUZZ_DUMP")
+    if d:
+        os.makedirs(d, exist_ok=True)
+        np.savez(os.path.join(d, "%s_off%d_%s.npz" % (name, OFFSET, "_".join(str(int(t)) for t in tag[:2]))),
+                 tag=np.array([float(np.sum(t)) if np.ndim(t) else float(t) for t in tag]), **arrays)
 
 
 def _geometry(rng):
@@ -75,16 +87,33 @@ def test_fuzz_reflected(oracle, block):
         # intensities far below the incident flux (albedo < 1e-6: a nearly black layer) are what is left of
         # O(F0PI) terms cancelling; they are judged against 1e-6 of the incident flux
         floor = max(1e-4 * np.abs(xo).max(), 1e-6 * float(np.max(f0)))
-        assert rel_err(xg, xo, floor) < _tol(sc, 1e-8, 1e-6), tag
+        x80 = None
+        if not rel_err(xg, xo, floor) < _tol(sc, 1e-8, 1e-6):
+            # beyond the tolerance: is it the reference's own fp64 rounding?  (see the level fluxes below)
+            x80 = oracle.get_reflected_1d(*args, x80=True, **kw)
+            assert excess(xg, xo, x80[0], _tol(sc, 1e-8, 1e-6), floor) <= 0.0, tag
         if lvl:
             # contract tolerance: with single layers of optical depth 50-2000 (these random scenes have
             # them) the reference's level-flux expressions combine exp(+35)-sized terms and the upward
-            # flux differs by up to 2e-7 of the field scale between formulations (median 8e-11)
-            assert lvl_err(lg, lo) < _tol(sc, 1e-6, 1e-5), tag
+            # flux differs by up to 2e-7 of the field scale between formulations (median 8e-11).  In about one
+            # scene in 400 the difference is larger (up to 1e-4 seen): every time it is the reference's fp64
+            # rounding -- its formulas evaluated in x87 extended precision (the oracle's `x80=True` build of the
+            # same source) move by exactly that much, and the kernel sits 100-1000 x closer to the extended
+            # value than the fp64 reference does (tools/experiments/fuzz_case_x80.py on the reference itself).
+            # Such a scene is held to helpers.lvl_excess: within tol + 2 e_ref of the reference, within
+            # tol + e_ref/500 of the extended-precision value, element by element.
+            if not lvl_err(lg, lo) < _tol(sc, 1e-6, 1e-5):
+                _dump("reflected_lvl", tag, u0=u0, u1=u1, ct=ct, rs=rs, f0=f0, b_top=b_top, opts=np.array([sp, mp, tc]),
+                      wno=sc["wno"], lg=np.stack(lg), lo=np.stack(lo), xg=xg, xo=xo, **{k: sc[k] for k in PLANES})
+                x80 = x80 if x80 is not None else oracle.get_reflected_1d(*args, x80=True, **kw)
+                assert lvl_excess(lg, lo, x80[1], _tol(sc, 1e-6, 1e-5)) <= 0.0, tag
         ag = oracle.compress_disco(nwno, ct, xo, gw, tw, f0)
         from picaso_amd import disco
-        assert rel_err(disco.compress_disco(nwno, ct, xg, gw, tw, f0), ag,
-                       max(1e-4 * np.abs(ag).max(), 1e-6)) < _tol(sc, 1e-8, 1e-6), tag
+        alb, afloor = disco.compress_disco(nwno, ct, xg, gw, tw, f0), max(1e-4 * np.abs(ag).max(), 1e-6)
+        if not rel_err(alb, ag, afloor) < _tol(sc, 1e-8, 1e-6):
+            x80 = x80 if x80 is not None else oracle.get_reflected_1d(*args, x80=True, **kw)
+            assert excess(alb, ag, oracle.compress_disco(nwno, ct, x80[0], gw, tw, f0), _tol(sc, 1e-8, 1e-6),
+                          afloor) <= 0.0, tag
 
 
 @pytest.mark.gpu
@@ -103,8 +132,12 @@ def test_fuzz_thermal(oracle, block):
                 sc["plevel"], u1, rs, hard, dw, calc)
         fg, _ = fluxes.get_thermal_1d(*args)
         fo, _ = oracle.get_thermal_1d(*args)
-        assert rel_err(fg, fo, 1e-4 * np.abs(fo).max()) < _tol(sc, 1e-8, 1e-6), (block, it, nlayer, nwno, ng, nt,
-                                                                                 hard, calc)
+        if not rel_err(fg, fo, 1e-4 * np.abs(fo).max()) < _tol(sc, 1e-8, 1e-6):
+            _dump("thermal", (block, it), u1=u1, rs=rs, hard=hard, dw=dw, calc=calc, fg=fg, fo=fo,
+                  **{k: sc[k] for k in ("wno", "tlevel", "plevel", "dtau_og", "w0_no_raman", "cosb_og")})
+            f80, _ = oracle.get_thermal_1d(*args, x80=True)      # the reference's own fp64 rounding? (see above)
+            assert excess(fg, fo, f80, _tol(sc, 1e-8, 1e-6), 1e-4 * np.abs(fo).max()) <= 0.0, (block, it, nlayer, nwno,
+                                                                                                ng, nt, hard, calc)
 
 
 @pytest.mark.gpu

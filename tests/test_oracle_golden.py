@@ -49,6 +49,27 @@ def test_thermal_1d(path, oracle):
             assert lvl_err(lv, ref4) < TOL, case
 
 
+@pytest.mark.parametrize("path", FILES_1D, ids=scene_id)
+def test_thermal_1d_extended_precision_build(path, oracle):
+    """The `x80=True` build of the restatement (same source, real = long double) against the reference's own
+    level fluxes evaluated in numpy longdouble (the `_x80` arrays of the fixtures, tests/golden/make_golden.py
+    `_extended`): both are x87 extended evaluations of the same expressions, stored rounded to float64 -- they
+    agree to fp64 rounding of the field scale, on scenes where the reference's fp64 level fluxes are off by up to 1.5e-4
+    of the field scale (thick layers: 7.4e-6 on cfg3like, 1.5e-4 on jupiterlike)."""
+    g = Golden(path)
+    nlevel, nwno = g.inp("tau").shape
+    for case in g.cases("therm1d"):
+        if "therm1d/%s/fm_x80" % case not in g.keys:
+            continue
+        hs, ct = (int(s[-1]) for s in case.split("_"))
+        rs = np.zeros(nwno) + g.inp("surf_reflect")
+        args = (nlevel, g.inp("wno"), nwno, g.geo("numg"), g.geo("numt"), g.inp("tlevel"), g.inp("dtau_og"),
+                g.inp("w0_no_raman"), g.inp("cosb_og"), g.inp("plevel"), g.geo("ubar1"), rs, hs, g["dwno"], ct)
+        _, lv80 = oracle.get_thermal_1d(*args, x80=True)
+        want = [g["therm1d/%s/%s_x80" % (case, nm)] for nm in ("fm", "fp", "fmm", "fpm")]
+        assert lvl_err(lv80, want) < 1e-14, case
+
+
 @pytest.mark.parametrize("path", FILES_1D + FILES_3D, ids=scene_id)
 def test_compress(path, oracle):
     g = Golden(path)
