@@ -393,6 +393,7 @@ __global__ __launch_bounds__(256) void k_regrid_rows(const RegridArgs a)
 // so the plane is bit for bit the host's -- which takes 0.97 s per call at 1e5 wavelengths x 90 layers.
 // One thread per wavelength and RAMAN_LCH layers: 3 x RAMAN_LCH accumulators in registers, the tables read once per pass.
 constexpr int RAMAN_LCH = 30;
+constexpr int RAMAN_MAX_TRANS = 1024;
 struct RamanArgs {
     int nlayer, ntrans;
     long nwno;
@@ -404,24 +405,37 @@ struct RamanArgs {
 __global__ __launch_bounds__(256) void k_raman_oklopcic(const RamanArgs a)
 {
 #pragma clang fp contract(off)
-    const long w = blockIdx.x * (long)blockDim.x + threadIdx.x;
-    if (w >= a.nwno) return;
+    // the populations of this pass's layers and the transition table in LDS: every lane reads the same element
+    // (a broadcast ds_read) instead of a dependent global load per (transition, layer)
+    __shared__ double sJ[10][RAMAN_LCH];
+    __shared__ int sji[RAMAN_MAX_TRANS], sray[RAMAN_MAX_TRANS];
     const int l0 = blockIdx.y * RAMAN_LCH, n = a.nlayer;
     const double *meta = a.tab + 10 * (long)n;
+    for (int e = threadIdx.x; e < 10 * RAMAN_LCH; e += blockDim.x) {
+        const int j = e / RAMAN_LCH, l = e - j * RAMAN_LCH;
+        sJ[j][l] = a.tab[(long)j * n + min(l0 + l, n - 1)];
+    }
+    for (int i = threadIdx.x; i < a.ntrans; i += blockDim.x) {
+        sji[i] = (int)meta[2 * i];
+        sray[i] = meta[2 * i + 1] != 0.0;
+    }
+    __syncthreads();
+    const long w = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (w >= a.nwno) return;
     double ray[RAMAN_LCH], ws[RAMAN_LCH], wo[RAMAN_LCH];
 #pragma unroll
     for (int l = 0; l < RAMAN_LCH; ++l) ray[l] = ws[l] = wo[l] = 0.0;
     for (int i = 0; i < a.ntrans; ++i) {
-        const double *J = a.tab + (long)meta[2 * i] * n;
+        const double *J = sJ[sji[i]];
         const double q = a.Q[(long)i * a.nwno + w];
-        if (meta[2 * i + 1] != 0.0) {
+        if (sray[i]) {
 #pragma unroll
-            for (int l = 0; l < RAMAN_LCH; ++l) ray[l] = ray[l] + J[min(l0 + l, n - 1)] * q;
+            for (int l = 0; l < RAMAN_LCH; ++l) ray[l] = ray[l] + J[l] * q;
         } else {
             const double qs = a.QS[(long)i * a.nwno + w];
 #pragma unroll
             for (int l = 0; l < RAMAN_LCH; ++l) {
-                const double j = J[min(l0 + l, n - 1)];
+                const double j = J[l];
                 ws[l] = ws[l] + j * qs;
                 wo[l] = wo[l] + j * q;
             }
@@ -448,6 +462,7 @@ int picaso_raman_oklopcic_dev(picaso_ctx *ctx, int nlayer, long nwno, int ntrans
     if (!ctx) return fail(nullptr, "null context");
     if (nlayer < 1 || nwno < 1 || ntrans < 1 || !Q || !QS || !j_initial || !is_rayleigh || !j_at_temp || !out)
         return fail(ctx, "raman_oklopcic: bad arguments");
+    if (ntrans > RAMAN_MAX_TRANS) return fail(ctx, "raman_oklopcic: at most %d transitions", RAMAN_MAX_TRANS);
     PZ_HIP(ctx, hipSetDevice(ctx->device));
     std::vector<double> tab((size_t)10 * nlayer + 2 * (size_t)ntrans);
     memcpy(tab.data(), j_at_temp, sizeof(double) * 10 * nlayer);
