@@ -21,6 +21,8 @@
 //
 // Reference quirk kept: in the TTHG branch f_deltaM is multiplied in place once per angle
 // (fluxes.py:2823-2824), so angle k (in (g,t) order) sees f_deltaM * fac^(k+1).
+#include <type_traits>
+
 #include "common.hpp"
 #include "device_math.hpp"
 
@@ -540,18 +542,20 @@ __global__ __launch_bounds__(256, PZ_SH_MINWAVES) void k_sh(const SHArgs a)
             // exp(-(1/u1 +- lam) dtau) = exp(-dtau/u1) E^{+-1} when no 35-clip binds anywhere in the
             // wave ((1/u1 + lam_max) dtau <= 35 covers all four arguments); otherwise the reference's
             // clipped exponentials are formed directly (:2929-2937).
-            const bool noclip = __all((iu1 + M.lam[0]) * dt <= 35.0);
+            // The choice is made per LANE (a wavelength's bits must not depend on which other wavelengths share
+            // its wave: blocks of a sharded spectrum cut the waves differently); only the work is wave-uniform --
+            // the direct exponentials are formed when some lane of the wave needs them.
+            const bool noclip_lane = (iu1 + M.lam[0]) * dt <= 35.0;
+            const bool noclip = __all(noclip_lane);
 #pragma unroll
             for (int r = 0; r < NB; ++r) {
                 const double alpha = iu1 + M.lam[r], beta = iu1 - M.lam[r];
                 const double rab = frcp(alpha * beta);                        // one reciprocal for both
-                double ea, eb;
-                if (noclip) {
-                    ea = edt * M.E[r];
-                    eb = edt * frcp(M.E[r]);
-                } else {
-                    ea = fexpk(-clip35(alpha * dt), K);
-                    eb = fexpk(-clip35(beta * dt), K);
+                double ea = edt * M.E[r], eb = edt * frcp(M.E[r]);
+                if (!noclip) {
+                    const double ead = fexpk(-clip35(alpha * dt), K), ebd = fexpk(-clip35(beta * dt), K);
+                    ea = noclip_lane ? ea : ead;
+                    eb = noclip_lane ? eb : ebd;
                 }
                 const double ha = (1 - ea) * (rab * beta);
                 const double hb = (1 - eb) * (rab * alpha);
@@ -560,8 +564,12 @@ __global__ __launch_bounds__(256, PZ_SH_MINWAVES) void k_sh(const SHArgs a)
             }
             if (!THERMAL) {
                 // (1 - exp(-clip35(mus dtau)))/mus (:2901-2905); mus = 2/u1 in the symmetric geometry
-                const bool sq = sym && __all(mus * dt <= 35.0);
-                const double e_mus = sq ? edt * edt : fexp2_clip(dt * g.nlm, K);
+                const bool sq_lane = sym && (mus * dt <= 35.0);                 // per lane, as above
+                double e_mus = edt * edt;
+                if (!__all(sq_lane)) {
+                    const double d = fexp2_clip(dt * g.nlm, K);
+                    e_mus = sq_lane ? e_mus : d;
+                }
                 const double exptrm_mus = (1 - e_mus) * imus;
                 // exp(-clip35(tau/u0)): the layer-top exponential above (SH4 clips it too; SH2 does not)
                 const double expon1 = exptrm_mus * ((NB == 2) ? ed_layer : fmax(ed_layer, EXP_M35));
@@ -577,7 +585,11 @@ __global__ __launch_bounds__(256, PZ_SH_MINWAVES) void k_sh(const SHArgs a)
                     Nsum = sN * expon1;
                 }
                 const double dto = a.dtau_og[o];
-                const double e_muso = __all(dto == dt) ? e_mus : fexp2_clip(dto * g.nlm, K);
+                double e_muso = e_mus;
+                if (!__all(dto == dt)) {
+                    const double d = fexp2_clip(dto * g.nlm, K);
+                    e_muso = (dto == dt) ? e_mus : d;
+                }
                 // exp(-tau_og/u0) at the layer top: the (unclipped) exponential of tau already at hand when
                 // nothing above has been delta-scaled (tau_og == tau in the whole wave)
                 const double tauo = a.tau_og[o];
@@ -825,6 +837,434 @@ __global__ __launch_bounds__(256, PZ_SH_MINWAVES) void k_sh(const SHArgs a)
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Thermal emission: the angle-independent block algebra shared between the disk angles of a lane.
+//
+// In get_thermal_SH (fluxes.py:2979-3182) the angle enters only through the source-function integration along ubar1
+// (:3105-3182): the Legendre weights, the stream matrices, the particular solution and therefore the whole sweep
+// relation d_i = delta_i - R_i v_i are the same for every (g, t).  k_sh<NB, true> nevertheless redid them per angle
+// (one wave per angle: 5 x 560 fp64 instructions per wavelength-layer at five angles).  Here one lane carries NA
+// angles: per layer the modes, the Planck terms and the elimination once (~400 instructions), and per angle only
+// exp(-dtau/ubar1), the integration weights (gd, gv, c) and the update of its TOA functional (kappa, zeta, T):
+// ~110 instructions each.  Small launches keep fewer angles per lane (down to one) so that every SIMD has a wave;
+// the arithmetic below is written out (contraction off, explicit fma) so that an angle's result does not depend on
+// how many angles share its lane.
+// ---------------------------------------------------------------------------------------------------------------
+#pragma clang fp contract(off)
+
+struct SHTArgs {
+    int nlayer, nwno;
+    long pitch;
+    const double *dtau, *w0, *cosb_og, *surf_reflect, *wno, *tlevel, *plevel;
+    int hard_surface, use_ff;
+    int na;                                         // angles of this launch: blockIdx.y = chunk of NA of them
+    struct Angle { double u1, iu1, nl1, p1, p2, p3; } ang[SH_MAX_ANG];
+    double *xint;                                   // first angle of this launch, (na, nwno)
+};
+
+template <int NB>
+__device__ __forceinline__ Blk<NB> mmx(const Blk<NB> &A, const Blk<NB> &B)
+{
+    Blk<NB> C;
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            double s = A.m[i][0] * B.m[0][j];
+#pragma unroll
+            for (int k = 1; k < NB; ++k) s = fma(A.m[i][k], B.m[k][j], s);
+            C.m[i][j] = s;
+        }
+    return C;
+}
+template <int NB>
+__device__ __forceinline__ void mvx(const Blk<NB> &A, const double (&x)[NB], double (&y)[NB])
+{
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        double s = A.m[i][0] * x[0];
+#pragma unroll
+        for (int k = 1; k < NB; ++k) s = fma(A.m[i][k], x[k], s);
+        y[i] = s;
+    }
+}
+template <int NB>
+__device__ __forceinline__ void mtvx(const Blk<NB> &A, const double (&x)[NB], double (&y)[NB])   // A^T x
+{
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        double s = A.m[0][i] * x[0];
+#pragma unroll
+        for (int k = 1; k < NB; ++k) s = fma(A.m[k][i], x[k], s);
+        y[i] = s;
+    }
+}
+template <int NB>
+__device__ __forceinline__ double dotx(const double (&a)[NB], const double (&b)[NB])
+{
+    double s = a[0] * b[0];
+#pragma unroll
+    for (int i = 1; i < NB; ++i) s = fma(a[i], b[i], s);
+    return s;
+}
+template <int NB>
+__device__ __forceinline__ Blk<NB> invx(const Blk<NB> &A)
+{
+    Blk<NB> R;
+    if (NB == 1) {
+        R.m[0][0] = frcp(A.m[0][0]);
+    } else {
+        const double idet = frcp(fma(A.m[0][0], A.m[NB - 1][NB - 1], -(A.m[0][NB - 1] * A.m[NB - 1][0])));
+        R.m[0][0] = A.m[NB - 1][NB - 1] * idet;
+        R.m[NB - 1][NB - 1] = A.m[0][0] * idet;
+        R.m[0][NB - 1] = -(A.m[0][NB - 1] * idet);
+        R.m[NB - 1][0] = -(A.m[NB - 1][0] * idet);
+    }
+    return R;
+}
+template <int NB>
+__device__ __forceinline__ Blk<NB> subx(const Blk<NB> &A, const Blk<NB> &B)
+{
+    Blk<NB> C;
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) C.m[i][j] = A.m[i][j] - B.m[i][j];
+    return C;
+}
+
+// modes_sh4 / modes_sh2 with the arithmetic written out (fluxes.py:3388-3434, 3245-3251)
+struct ModesT4 { double lam[2], E[2], iE[2], R[2], Q[2], S[2]; Blk<2> Mn, Pl; };
+__device__ __forceinline__ void modes_sh4x(const double (&a)[4], double dt, ModesT4 &M, const Exp2Coef &K)
+{
+    const double a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3];
+    const double a01 = a0 * a1;
+    const double beta = (a01 + div_const(4 * (a0 * a3), 9.0, R9)) + div_const(a2 * a3, 9.0, R9);
+    const double gama = div_const((a01 * a2) * a3, 9.0, R9);
+    const double disc = fsqrt(fma(beta, beta, -(4 * gama)));
+    const double x1 = 0.5 * (beta + disc), x2 = 0.5 * (beta - disc);
+    const double il1 = frsq(x1), il2 = frsq(x2);
+    const double l1 = x1 * il1, l2 = x2 * il2;
+    M.lam[0] = l1;
+    M.lam[1] = l2;
+    const double s3 = -1.5 * frcp(a3);
+    const double R1 = -(a0 * il1), R2 = -(a0 * il2);
+    const double Q1 = 0.5 * fma(a01 * il1, il1, -1.0), Q2 = 0.5 * fma(a01 * il2, il2, -1.0);
+    const double S1 = s3 * fma(a01, il1, -l1), S2 = s3 * fma(a01, il2, -l2);
+    M.R[0] = R1; M.R[1] = R2; M.Q[0] = Q1; M.Q[1] = Q2; M.S[0] = S1; M.S[1] = S2;
+    const double tp = 2 * PI, q1 = 0.625 * Q1, q2 = 0.625 * Q2;
+    M.Pl.m[0][0] = ((0.5 + R1) + q1) * tp;
+    M.Pl.m[0][1] = ((0.5 + R2) + q2) * tp;
+    M.Pl.m[1][0] = ((-0.125 + q1) + S1) * tp;
+    M.Pl.m[1][1] = ((-0.125 + q2) + S2) * tp;
+    M.Mn.m[0][0] = ((0.5 - R1) + q1) * tp;
+    M.Mn.m[0][1] = ((0.5 - R2) + q2) * tp;
+    M.Mn.m[1][0] = ((-0.125 + q1) - S1) * tp;
+    M.Mn.m[1][1] = ((-0.125 + q2) - S2) * tp;
+    M.E[0] = fexpk(-clip35(l1 * dt), K);
+    M.E[1] = fexpk(-clip35(l2 * dt), K);
+    M.iE[0] = frcp(M.E[0]);
+    M.iE[1] = frcp(M.E[1]);
+}
+struct ModesT2 { double lam[1], E[1], iE[1], q; Blk<1> Mn, Pl; };
+__device__ __forceinline__ void modes_sh2x(const double (&a)[2], double dt, ModesT2 &M, const Exp2Coef &K)
+{
+    const double lam = fsqrt(a[0] * a[1]);
+    M.lam[0] = lam;
+    M.q = lam * frcp(a[1]);
+    M.Mn.m[0][0] = (0.5 + M.q) * (2 * PI);
+    M.Pl.m[0][0] = (0.5 - M.q) * (2 * PI);
+    M.E[0] = fexpk(-clip35(lam * dt), K);
+    M.iE[0] = frcp(M.E[0]);
+}
+
+template <int NB, int NA>
+__global__ __launch_bounds__(256, 2) void k_sh_thermal(const SHTArgs a)
+{
+    constexpr int NS = 2 * NB;
+    using ModesT = typename std::conditional<NB == 2, ModesT4, ModesT2>::type;
+    const long w = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= a.nwno) return;
+    const int n = a.nlayer;
+    const long pitch = a.pitch;
+    const int k0 = blockIdx.y * NA;                 // this lane's angles: k0 .. k0 + na - 1 (the last chunk may be short)
+    const int na = min(NA, a.na - k0);
+    const SHTArgs::Angle *const ang = a.ang + k0;
+    Exp2Coef K;
+    K.load();
+    const double rs = a.surf_reflect[w], wn = a.wno[w];
+    // Planck function at the levels (fluxes.py:3058-3060): planck_lambda with its level-independent factors hoisted
+    const double hP = 6.62607004e-27, cP_ = 2.99792458e+10, kP = 1.38064852e-16;
+    const double wcm = 1.0 / wn, w2 = wcm * wcm;
+    const double pf = (2.0 * hP * (cP_ * cP_)) / (w2 * w2 * wcm), wk = wcm * kP, hc = hP * cP_;
+    auto planck = [&](double t) { return pf * planck_rcp(fexpk(fdiv(hc, t * wk), K)); };
+    double Bn = planck(a.tlevel[0]);
+    const double B_top = Bn;
+    double b1 = 0.0;
+    // per angle: transmission to the top, TOA functional J = kappa + zeta . v
+    double T[NA], kappa[NA], zeta[NA][NB];
+#pragma unroll
+    for (int k = 0; k < NA; ++k) {
+        T[k] = 1.0;
+        kappa[k] = 0.0;
+#pragma unroll
+        for (int r = 0; r < NB; ++r) zeta[k][r] = 0.0;
+    }
+    double delta[NB];
+    Blk<NB> R, pMn, pPl, pME, pPE;
+    double p_zmn_up[NB], p_zpl_up[NB];
+#pragma unroll
+    for (int r = 0; r < NB; ++r) delta[r] = p_zmn_up[r] = p_zpl_up[r] = 0.0;
+
+    for (int i = 0; i < n; ++i) {
+        const long o = (long)i * pitch + w;
+        const double dt = a.dtau[o], w0 = a.w0[o], cbo = a.cosb_og[o];
+        // ---- Legendre weights and stream coefficients (:3072-3083) ----
+        double wmu[NS], al[NS];
+        {
+            const double c2 = cbo * cbo;
+            const double ff = a.use_ff ? ((NS == 4) ? c2 * c2 : c2) : 0.0;
+            const double iff = frcp(1 - ff);
+            double cl = 1.0;
+#pragma unroll
+            for (int l = 0; l < NS; ++l) {
+                wmu[l] = ((2 * l + 1) * (cl - ff)) * iff;
+                al[l] = fma(-w0, wmu[l], (double)(2 * l + 1));
+                cl *= cbo;
+            }
+        }
+        ModesT M;
+        if constexpr (NB == 2) modes_sh4x(al, dt, M, K);
+        else modes_sh2x(al, dt, M, K);
+        // ---- particular solution (:3451-3459 / :3266-3270) ----
+        const double B0 = Bn;
+        Bn = planck(a.tlevel[i + 1]);
+        b1 = (Bn - B0) * frcp(dt);
+        const double omw = 1 - w0;
+        const double ia0 = frcp(al[0]), ia1 = frcp(al[1]);
+        const double oma = omw * ia0, b1a = b1 * ia1, hB = 0.5 * B0, hbd = 0.5 * (b1 * dt);
+        double zmn_dn[NB], zpl_dn[NB], zmn_up[NB], zpl_up[NB];
+        zmn_dn[0] = (oma * (hB - b1a)) * (2 * PI);
+        zpl_dn[0] = (oma * (hB + b1a)) * (2 * PI);
+        zmn_up[0] = (oma * ((hB - b1a) + hbd)) * (2 * PI);
+        zpl_up[0] = (oma * ((hB + b1a) + hbd)) * (2 * PI);
+        if constexpr (NB == 2) {
+            zmn_dn[1] = zpl_dn[1] = ((-0.125 * oma) * B0) * (2 * PI);
+            zmn_up[1] = zpl_up[1] = ((-0.125 * oma) * fma(b1, dt, B0)) * (2 * PI);
+        }
+        const Blk<NB> ME = scale_cols(M.Mn, M.E), PE = scale_cols(M.Pl, M.E);
+
+        // ---- elimination (angle independent) ----
+        Blk<NB> Rn, Sm;
+        double deltan[NB], t[NB];
+        if (i == 0) {
+            const double tau_top = dt * a.plevel[0] / (a.plevel[1] - a.plevel[0]);   // :3062-3063
+            const double b_top = PI * (1.0 - fexpk(-tau_top / 0.5, K)) * B_top;
+            double bt[NB];
+            bt[0] = b_top - zmn_dn[0];                                               // :3479-3480 / :3283
+            if constexpr (NB == 2) bt[1] = -b_top / 4 - zmn_dn[1];
+            const Blk<NB> Mni = invx(M.Mn);
+            Rn = mmx(Mni, PE);
+            mvx(Mni, bt, deltan);
+#pragma unroll
+            for (int r = 0; r < NB; ++r) t[r] = 0.0;
+            Sm = Rn;                                       // not used for i == 0
+        } else {
+            const Blk<NB> A1 = subx(pPl, mmx(pME, R)), A2 = subx(pMn, mmx(pPE, R));
+            const Blk<NB> A2i = invx(A2);
+            const Blk<NB> G = mmx(A1, A2i);
+            double cP[NB], cM[NB], t1[NB], t2[NB];
+            mvx(pPE, delta, t1);
+            mvx(pME, delta, t2);
+#pragma unroll
+            for (int r = 0; r < NB; ++r) {
+                cP[r] = (zpl_dn[r] - p_zpl_up[r]) - t1[r];
+                cM[r] = (t2[r] + p_zmn_up[r]) - zmn_dn[r];
+            }
+            const Blk<NB> Ki = invx(subx(M.Mn, mmx(G, M.Pl)));
+            const Blk<NB> GM = subx(PE, mmx(G, ME));
+            Rn = mmx(Ki, GM);
+            double rhs[NB];
+            mvx(G, cP, rhs);
+#pragma unroll
+            for (int r = 0; r < NB; ++r) rhs[r] += cM[r];
+            mvx(Ki, rhs, deltan);
+            Sm = mmx(A2i, subx(ME, mmx(M.Pl, Rn)));
+            double tv[NB];
+            mvx(M.Pl, deltan, tv);
+#pragma unroll
+            for (int r = 0; r < NB; ++r) tv[r] += cP[r];
+            mvx(A2i, tv, t);
+        }
+
+        // ---- per angle: source-function integrals of this layer and the update of the TOA functional ----
+#pragma unroll
+        for (int k = 0; k < NA; ++k) {
+            if (k >= na) break;
+            const double u1 = ang[k].u1, iu1 = ang[k].iu1;
+            const double edt = fexp2(dt * ang[k].nl1, K);                         // exp(-dtau/u1)
+            double cm[NS];
+            if constexpr (NB == 2) {                                                 // :3601-3605
+                const double wP2 = wmu[2] * ang[k].p2, wP1 = wmu[1] * ang[k].p1, wP3 = wmu[3] * ang[k].p3;
+                const double e01 = fma(wP2, M.Q[0], wmu[0]), e23 = fma(wP2, M.Q[1], wmu[0]);
+                const double o01 = fma(wP3, M.S[0], wP1 * M.R[0]), o23 = fma(wP3, M.S[1], wP1 * M.R[1]);
+                cm[0] = e01 + o01;
+                cm[1] = e01 - o01;
+                cm[2] = e23 + o23;
+                cm[3] = e23 - o23;
+            } else {                                                                 // :3124-3125
+                const double wq = (wmu[1] * ang[k].p1) * M.q;
+                cm[0] = wmu[0] - wq;
+                cm[1] = wmu[0] + wq;
+            }
+            const double Tk = T[k];
+            const double tw = ((Tk * iu1) * w0) * (2 * PI);                          // :3167
+            const bool noclip_lane = (iu1 + M.lam[0]) * dt <= 35.0;      // per lane; the work is wave-uniform (see k_sh)
+            const bool noclip = __all(noclip_lane);
+            double gd[NB], gv[NB];
+#pragma unroll
+            for (int r = 0; r < NB; ++r) {
+                const double alpha = iu1 + M.lam[r], beta = iu1 - M.lam[r];
+                const double rab = frcp(alpha * beta);
+                double ea = edt * M.E[r], eb = edt * M.iE[r];
+                if (!noclip) {
+                    const double ead = fexpk(-clip35(alpha * dt), K), ebd = fexpk(-clip35(beta * dt), K);
+                    ea = noclip_lane ? ea : ead;
+                    eb = noclip_lane ? eb : ebd;
+                }
+                const double ha = (1 - ea) * (rab * beta), hb = (1 - eb) * (rab * alpha);
+                gd[r] = (tw * cm[2 * r]) * ha;
+                gv[r] = ((tw * cm[2 * r + 1]) * hb) * M.E[r];
+            }
+            const double edc = (NB == 2) ? fmax(edt, EXP_M35) : edt;               // exp(-clip35(dtau/u1)) :3154 vs :3127
+            const double core = oma * u1;
+            const double dtu = dt + u1;
+            const double N0 = wmu[0] * (core * fma(B0, 1 - edc, b1 * fma(-dtu, edc, u1)));     // :3128, :3155
+            const double N1 = (wmu[1] * ang[k].p1) * (core * ((b1 * (1 - edc)) * ia1));      // :3129, :3156
+            const double direct = ((2 * PI) * omw) * (u1 * fma(B0, 1 - edt, b1 * fma(-dtu, edt, u1)));   // :3163-3165
+            double c = (Tk * iu1) * fma(w0 * (N0 + N1), 2 * PI, direct);
+            const double Tn = Tk * edt;
+            if (i == n - 1)                                                          // :3173-3176
+                c = fma(Tn, a.hard_surface ? Bn * (2 * PI) : fma(b1, u1, Bn) * (2 * PI), c);
+            double z2[NB];
+            mtvx(Rn, gd, z2);
+            if (i == 0) {
+                kappa[k] = c + dotx(gd, deltan);
+#pragma unroll
+                for (int r = 0; r < NB; ++r) zeta[k][r] = gv[r] - z2[r];
+            } else {
+                kappa[k] = ((kappa[k] + dotx(zeta[k], t)) + dotx(gd, deltan)) + c;
+                double z1[NB];
+                mtvx(Sm, zeta[k], z1);
+#pragma unroll
+                for (int r = 0; r < NB; ++r) zeta[k][r] = (z1[r] + gv[r]) - z2[r];
+            }
+            T[k] = Tn;
+        }
+        R = Rn;
+#pragma unroll
+        for (int r = 0; r < NB; ++r) {
+            delta[r] = deltan[r];
+            p_zmn_up[r] = zmn_up[r];
+            p_zpl_up[r] = zpl_up[r];
+        }
+        pMn = M.Mn; pPl = M.Pl; pME = ME; pPE = PE;
+    }
+    // ---- surface rows (:3484-3494 / :3287-3289) ----
+    double bs[NB];
+    bs[0] = a.hard_surface ? PI * Bn : PI * fma(b1, 0.5, Bn);                        // :3065-3068
+    if constexpr (NB == 2) bs[1] = -(PI * Bn) / 4;                                   // :3070
+    Blk<NB> W, L;
+#pragma unroll
+    for (int r = 0; r < NB; ++r)
+#pragma unroll
+        for (int s_ = 0; s_ < NB; ++s_) {
+            W.m[r][s_] = fma(-rs, pME.m[r][s_], pPE.m[r][s_]);
+            L.m[r][s_] = fma(-rs, pPl.m[r][s_], pMn.m[r][s_]);
+        }
+    L = subx(L, mmx(W, R));
+    double wd[NB], rhs[NB], v[NB];
+    mvx(W, delta, wd);
+#pragma unroll
+    for (int r = 0; r < NB; ++r) rhs[r] = ((bs[r] - p_zpl_up[r]) + rs * p_zmn_up[r]) - wd[r];
+    mvx(invx(L), rhs, v);
+#pragma unroll
+    for (int k = 0; k < NA; ++k)
+        if (k < na) a.xint[(long)(k0 + k) * a.nwno + w] = kappa[k] + dotx(zeta[k], v);
+}
+#pragma clang fp contract(fast)
+
+template <int NB>
+static void launch_sht_na(picaso_ctx *ctx, const SHTArgs &a, int na, int nchunk)
+{
+    const dim3 grid((unsigned)((a.nwno + 255) / 256), (unsigned)nchunk), block(256);
+    switch (na) {
+    case 1: hipLaunchKernelGGL((k_sh_thermal<NB, 1>), grid, block, 0, ctx->stream, a); break;
+    case 2: hipLaunchKernelGGL((k_sh_thermal<NB, 2>), grid, block, 0, ctx->stream, a); break;
+    case 3: hipLaunchKernelGGL((k_sh_thermal<NB, 3>), grid, block, 0, ctx->stream, a); break;
+    case 4: hipLaunchKernelGGL((k_sh_thermal<NB, 4>), grid, block, 0, ctx->stream, a); break;
+    default: hipLaunchKernelGGL((k_sh_thermal<NB, 5>), grid, block, 0, ctx->stream, a); break;
+    }
+}
+
+// Angles per lane for a launch of `ncol` columns and `nang` angles: the split into ceil(nang / m) nearly equal
+// chunks with the smallest modelled time.  Per wave and layer: S shared + m A per-angle instructions (400 / 110,
+// counted from the source for SH4); one wave alone on its SIMD issues an fp64 instruction every ~5.5 cycles, two
+// or more share the 4 cycles of the pipe, and a launch whose waves are not a multiple of the 2 x SIMD slots pays
+// for the partly filled last round.
+static int sh_thermal_angles_per_lane(const picaso_ctx *ctx, long ncol, int nang)
+{
+    if (const char *e = getenv("PICASO_AMD_SHT_ANGLES")) {
+        const int m = atoi(e);
+        if (m >= 1 && m <= 5) return m;
+    }
+    const double S = 400.0, A = 110.0;
+    const long simds = 4L * ctx->ncu, groups = (ncol + 63) / 64;
+    int best = 1;
+    double best_t = 1e300;
+    for (int m = 1; m <= 5; ++m) {
+        const int nchunk = (nang + m - 1) / m;
+        const long waves = groups * nchunk;
+        const double per_wave = S + A * ((double)nang / nchunk);      // mean chunk
+        const double longest = S + A * ((nang + nchunk - 1) / nchunk);
+        const long full = waves / (2 * simds), rem = waves - full * 2 * simds;
+        const double t = full * 8.0 * per_wave + (rem == 0 ? 0.0 : rem <= simds ? 5.5 * (full ? per_wave : longest)
+                                                                                    : 8.0 * per_wave);
+        if (t < best_t) { best_t = t; best = m; }
+    }
+    return best;
+}
+
+static int launch_sh_thermal(picaso_ctx *ctx, SHTArgs &a, int stream, int nang, const double *ubar1, double *xint)
+{
+    const int m = sh_thermal_angles_per_lane(ctx, a.nwno, nang);
+    const int nchunk = (nang + m - 1) / m;
+    const int per_lane = (nang + nchunk - 1) / nchunk;                           // nearly equal chunks, last one short
+    const int per_launch = (SH_MAX_ANG / per_lane) * per_lane;                   // whole chunks per launch
+    for (int done = 0; done < nang; done += per_launch) {
+        const int na = (nang - done < per_launch) ? nang - done : per_launch;
+        for (int k = 0; k < na; ++k) {
+#pragma clang fp contract(off)
+            SHTArgs::Angle &g = a.ang[k];
+            const double mu = ubar1[done + k];
+            g.u1 = mu;
+            g.iu1 = 1.0 / mu;
+            g.nl1 = -LOG2E * g.iu1;
+            g.p1 = mu;                                                             // legP (fluxes.py:3639-3646)
+            g.p2 = (3 * mu * mu - 1) / 2;
+            g.p3 = (5 * mu * mu * mu - 3 * mu) / 2;
+        }
+        a.na = na;
+        a.xint = xint + (size_t)done * a.nwno;
+        const int chunks = (na + per_lane - 1) / per_lane;
+        if (stream == 4) launch_sht_na<2>(ctx, a, per_lane, chunks);
+        else launch_sht_na<1>(ctx, a, per_lane, chunks);
+        PZ_HIP(ctx, hipGetLastError());
+    }
+    return 0;
+}
+
 static int launch_sh(picaso_ctx *ctx, SHArgs &a, int nang, bool thermal)
 {
     const int block = 256;
@@ -1003,7 +1443,15 @@ int picaso_get_thermal_SH_dev(picaso_ctx *ctx, int nlevel, const double *wno, in
     a.dtau = dtau; a.w0 = w0; a.cosb_og = cosb_og; a.surf_reflect = surf_reflect;
     a.wno = wno; a.tlevel = (const double *)d_tab; a.plevel = a.tlevel + nlevel;
     a.hard_surface = hard_surface; a.use_ff = cosb_differs_from_cosb_og;
-    PZ_TRY(launch_sh_angles(ctx, a, numg * numt, nullptr, ubar1, xint_at_top, nullptr, true));
+    if (getenv("PICASO_AMD_SH_THERMAL_PER_ANGLE")) {            // the round-2 kernel: one wave per angle, nothing shared
+        PZ_TRY(launch_sh_angles(ctx, a, numg * numt, nullptr, ubar1, xint_at_top, nullptr, true));
+    } else {
+        SHTArgs t{};
+        t.nlayer = nlevel - 1; t.nwno = nwno; t.pitch = plane_pitch;
+        t.dtau = dtau; t.w0 = w0; t.cosb_og = cosb_og; t.surf_reflect = surf_reflect; t.wno = wno;
+        t.tlevel = a.tlevel; t.plevel = a.plevel; t.hard_surface = hard_surface; t.use_ff = cosb_differs_from_cosb_og;
+        PZ_TRY(launch_sh_thermal(ctx, t, stream, numg * numt, ubar1, xint_at_top));
+    }
     if (flux_disk && gweight && tweight)
         PZ_TRY(picaso_compress_thermal_dev(ctx, (size_t)nwno, xint_at_top, gweight, numg, tweight, numt, flux_disk));
     return 0;
