@@ -496,6 +496,33 @@ def main():
             out["per_rank"] = per_rank
             out["checks"] = checks
         if world == 1 and args.steady_steps > 0:
+            # the HBM ceiling this box reaches with a plain copy ("peak = vendor 8 TB/s and a measured
+            # hipMemcpyDtoD ceiling on the same box, both stated"): 1 GiB device-to-device, read + write counted
+            try:
+                import ctypes as _ct
+                from picaso_amd._lib import check as _check, load as _load
+                nb = 1 << 30
+                src_c, dst_c = device.DeviceArray((nb // 8,), ctx), device.DeviceArray((nb // 8,), ctx)
+                src_c.zero()
+
+                def _copy():
+                    _check(_load().picaso_memcpy_d2d(ctx, _ct.c_void_p(dst_c.addr), _ct.c_void_p(src_c.addr),
+                                                     _ct.c_size_t(nb)), ctx)
+                for _ in range(3):
+                    _copy()
+                device.sync(ctx)
+                device.timer_start(ctx)
+                for _ in range(10):
+                    _copy()
+                cms = device.timer_stop(ctx) / 10
+                out["roofline"]["measured_copy_peak"] = {"GBps_read_plus_write": 2 * nb / (cms * 1e-3) / 1e9,
+                                                         "what": "picaso_memcpy_d2d of 1 GiB on this box, after the run"}
+                out["roofline"]["frac_of_measured_copy_peak"] = achieved / out["roofline"]["measured_copy_peak"][
+                    "GBps_read_plus_write"]
+                src_c.free()
+                dst_c.free()
+            except Exception as exc:      # a reported extra, never worth the measurement above
+                out["roofline"]["measured_copy_peak"] = {"error": str(exc)}
             # a long companion run (untimed by the driver): long enough for a utilisation sampler to see the
             # GPU busy, and the check that the K timed steps above sit in the steady state
             nst = max(50, min(args.steady_steps, int(1000.0 / max(ms_per_step, 1e-3))))     # about a second at most

@@ -280,7 +280,8 @@ class ATMSETUP:
         if in_wno is not None and len(sizes) == 1:          # all three on their own grid: regridded where they are read
             nin = sizes.pop() // self.c.nlayer
             if nin == np.size(in_wno) and nin >= 2 and nin * self.c.nlayer == np.size(prof["opd"]) \
-                    and not (nin == nwno and np.array_equal(in_wno, wno)):
+                    and not (nin == nwno and np.array_equal(in_wno, wno)) \
+                    and bool(np.all(np.diff(np.asarray(in_wno, dtype=np.float64)) > 0)):   # else: numpy's own answer
                 self.layer["cloud"] = CloudTables(
                     {k: np.ascontiguousarray(np.asarray(prof[k], dtype=np.float64).reshape(self.c.nlayer, nin))
                      for k in ("opd", "g0", "w0")}, in_wno, wno)
