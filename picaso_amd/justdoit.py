@@ -163,6 +163,101 @@ def _to_cgs(value, unit, what):
     raise Exception("%s: cannot interpret unit %r" % (what, unit))
 
 
+_WAVE_UM = {"um": 1.0, "micron": 1.0, "microns": 1.0, "nm": 1e-3, "angs": 1e-4, "angstrom": 1e-4, "aa": 1e-4, "a": 1e-4,
+            "cm": 1e4, "m": 1e6, "mm": 1e3}
+# flux density per unit wavelength -> erg s^-1 cm^-2 per cm of wavelength (the reference's 'erg*cm^(-3)*s^(-1)')
+_FLAM_CGS = {"erg/cm2/s/cm": 1.0, "erg/cm3/s": 1.0, "erg*cm^(-3)*s^(-1)": 1.0, "erg/s/cm3": 1.0,
+             "flam": 1e8, "erg/cm2/s/angs": 1e8, "erg/cm2/s/aa": 1e8, "erg/cm2/s/a": 1e8, "erg/cm2/s/angstrom": 1e8,
+             "erg/s/cm2/aa": 1e8, "erg/s/cm2/angs": 1e8, "erg/cm2/s/um": 1e4, "erg/s/cm2/um": 1e4, "erg/cm2/s/nm": 1e7,
+             "w/m2/um": 1e7, "w/m2/nm": 1e10, "w/m2/m": 1e1, "w/m3": 1e1}
+
+
+def _stellar_cgs(wave, flux, w_unit, f_unit):
+    """A stellar spectrum per unit wavelength -> ``(wavenumber [cm^-1] increasing, flux [erg s^-1 cm^-3])``, what the
+    reference takes from synphot (justdoit.py:1817-1824).  Unit strings of the tables above, or astropy units when
+    astropy is installed."""
+    wave, flux = np.asarray(wave, dtype=float), np.asarray(flux, dtype=float)
+    if isinstance(w_unit, str) and isinstance(f_unit, str):
+        wk, fk = w_unit.strip().lower().replace(" ", ""), f_unit.strip().lower().replace(" ", "")
+        if wk not in _WAVE_UM:
+            raise Exception("star: w_unit %r not known; one of %s" % (w_unit, sorted(_WAVE_UM)))
+        if fk not in _FLAM_CGS:
+            raise Exception("star: f_unit %r not known (flux per unit wavelength); one of %s" % (f_unit, sorted(_FLAM_CGS)))
+        um, f = wave * _WAVE_UM[wk], flux * _FLAM_CGS[fk]
+    else:
+        try:
+            import astropy.units as u
+            um = (wave * u.Unit(w_unit)).to(u.um).value
+            f = (flux * u.Unit(f_unit)).to(u.Unit("erg*cm^(-3)*s^(-1)"),
+                                            equivalencies=u.spectral_density(um * u.um)).value
+        except ImportError:
+            raise Exception("star: give w_unit / f_unit as strings (astropy is not installed)")
+    wno = 1e4 / um
+    order = np.argsort(wno, kind="stable")
+    return wno[order], f[order]
+
+
+def _interp_extrapolate(x, xp, fp):
+    """Piecewise-linear through ``(xp, fp)``, the end segments continued outside (scipy ``interp1d(kind='linear',
+    fill_value='extrapolate')``)."""
+    j = np.clip(np.searchsorted(xp, x, side="right") - 1, 0, len(xp) - 2)
+    slope = (fp[j + 1] - fp[j]) / (xp[j + 1] - xp[j])
+    return fp[j] + slope * (x - xp[j])
+
+
+def bin_star(wno_new, wno_old, Fp):
+    """Mean of the points of ``Fp`` (on the increasing grid ``wno_old``) in the top-hat bins around ``wno_new``
+    (reference optics.py:497-521: half a grid step to either side, the lower edge closed except for the first bin);
+    NaN where a bin catches none.  Searches instead of one mask per bin."""
+    wno_new, wno_old, Fp = (np.asarray(a, dtype=float) for a in (wno_new, wno_old, Fp))
+    n = wno_new.size
+    delta = np.empty(n)
+    delta[:-1] = wno_new[1:] - wno_new[:-1]
+    delta[-1] = delta[-2]
+    lo_edge = wno_new - 0.5 * np.concatenate(([delta[0]], delta[:-1]))
+    hi_edge = wno_new + 0.5 * delta
+    lo = np.searchsorted(wno_old, lo_edge, side="left")           # wno_old >= edge
+    lo[0] = np.searchsorted(wno_old, lo_edge[0], side="right")    # first bin: wno_old > edge
+    hi = np.searchsorted(wno_old, hi_edge, side="left")           # wno_old < edge
+    cs = np.concatenate(([0.0], np.cumsum(Fp)))
+    cnt = hi - lo
+    with np.errstate(invalid="ignore", divide="ignore"):
+        return np.where(cnt > 0, (cs[hi] - cs[lo]) / cnt, np.nan)
+
+
+def create_grid(min_wavelength, max_wavelength, constant_R):
+    """Wavenumbers (increasing) of the constant-resolution wavelength grid from ``min_wavelength`` to at least
+    ``max_wavelength`` micron: neighbours in the ratio (2R+1)/(2R-1) (reference opacity_factory.py:712-739)."""
+    spacing = (2.0 * constant_R + 1.0) / (2.0 * constant_R - 1.0)
+    npts = int(np.ceil(np.log(max_wavelength / min_wavelength) / np.log(spacing))) + 1
+    wl = np.cumprod(np.concatenate(([min_wavelength], np.full(npts - 1, spacing))))
+    return 1e4 / wl[::-1]
+
+
+def mean_regrid(x, y, newx=None, R=None):
+    """Bin ``y(x)`` to the grid ``newx`` (bin edges half way between its points) or to constant resolution ``R``: the
+    mean of the points in every bin, NaN where there is none (reference justplotit.py:31-63, which uses
+    ``scipy.stats.binned_statistic``; the same counting here with numpy).  Returns ``(bin centres, means)``."""
+    x, y = np.asarray(x, dtype=float), np.asarray(y, dtype=float)
+    if newx is None and R is not None:
+        edges = create_grid(1e4 / np.max(x), 1e4 / np.min(x), R)
+    elif newx is not None and R is None:
+        newx = np.asarray(newx, dtype=float)
+        d = np.diff(newx)
+        edges = np.concatenate(([newx[0] - d[0] / 2], newx[:-1] + d / 2.0, [newx[-1] + d[-1] / 2]))
+    else:
+        raise Exception("Please either enter a newx or a R")
+    nb = edges.size - 1
+    idx = np.searchsorted(edges, x, side="right") - 1
+    idx[x == edges[-1]] = nb - 1                                  # the last bin includes its right edge
+    ok = (idx >= 0) & (idx < nb)
+    sums = np.bincount(idx[ok], weights=y[ok], minlength=nb)
+    cnt = np.bincount(idx[ok], minlength=nb)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        means = np.where(cnt > 0, sums / cnt, np.nan)
+    return (edges[:-1] + edges[1:]) / 2.0, means
+
+
 def get_cld_input_grid(filename_or_grid="wave_EGP.dat"):
     """Wavenumbers (increasing) of the 196-point grid cloud tables come on (reference wavelength.py:9-40):
     ``$picaso_refdata/opacities/wave_EGP.dat`` (whitespace table with a 'wavenumber' column) or an array."""
@@ -261,14 +356,88 @@ class inputs:
         else:
             raise Exception("Need to specify gravity or radius and mass + additional units")
 
-    def star(self, opannection=None, relative_flux=None, radius=np.nan, semi_major=np.nan):
-        """Stellar flux per wavelength bin on the opacity grid (``F0PI``).  ``None`` = 'nostar'
-        (F0PI = 1, reference justdoit.py:174-177).  Stellar-grid interpolation is out of scope."""
-        if relative_flux is None:
-            self.inputs["star"].update(database="nostar", radius="nostar", relative_flux=None)
-        else:
-            self.inputs["star"].update(database="user", radius=radius, semi_major=semi_major,
-                                       relative_flux=np.asarray(relative_flux, dtype=float))
+    def star(self, opannection=None, temp=None, metal=None, logg=None, radius=None, radius_unit=None, semi_major=None,
+             semi_major_unit=None, database="ck04models", filename=None, w_unit=None, f_unit=None, relative_flux=None):
+        """The star, with the reference's keywords in the reference's order (justdoit.py:1756-1906).
+
+        ``filename`` (two whitespace columns: wavelength, flux; ``w_unit`` / ``f_unit`` name their units) is binned onto
+        the opacity grid of ``opannection`` the way the reference does it: mean of the stellar points in every bin with
+        interpolated values where a bin catches none (:1880-1888); with ``approx(raman='oklopcic')`` the shifted /
+        unshifted ratios of ``compute_stellar_shits`` on a 5x finer grid (:1833-1842); with ``get_lvl_flux`` the
+        bin-integrated form (:1843-1879).  ``relative_flux`` (an addition): the flux already on the opacity grid
+        (times ``(radius/semi_major)**2`` when both are given it is what the solvers take as F0PI).  Stellar model
+        grids (``temp, metal, logg`` through stsynphot) are outside this package: the call says so.  Nothing given:
+        no star (F0PI = 1, justdoit.py:174-177).  Units: ``None`` = cgs, a unit string (``'R_sun'``, ``'au'``, ...), a cgs
+        factor, or an astropy unit when astropy is installed."""
+        st = self.inputs["star"]
+        r = _to_cgs(radius, radius_unit, "radius") if radius is not None else np.nan
+        sm = _to_cgs(semi_major, semi_major_unit, "radius") if semi_major is not None else np.nan
+        if relative_flux is not None:
+            st.update(database="user", radius=r, semi_major=sm, relative_flux=np.asarray(relative_flux, dtype=float))
+            return
+        if filename is None:
+            if temp is not None or metal is not None or logg is not None:
+                raise Exception("star(temp=, metal=, logg=) looks a model up in the stsynphot grids, which are outside this "
+                                "package: give the spectrum as filename= (with w_unit, f_unit) or relative_flux=")
+            st.update(database="nostar", radius="nostar", relative_flux=None)
+            return
+        if opannection is None:
+            raise Exception("star(filename=...) needs the opacity object: its wavenumber grid is what the star is binned to")
+        if w_unit is None or f_unit is None:
+            raise Exception("Must enter 1) filename,w_unit & f_unit OR 2)temp, metal & logg ")
+        tab = np.loadtxt(filename, usecols=(0, 1), ndmin=2)
+        wno_star, flux_star = _stellar_cgs(tab[:, 0], tab[:, 1], w_unit, f_unit)
+        wno = np.asarray(opannection.wno, dtype=float)
+        lvl = bool(self.inputs["approx"].get("get_lvl_flux", False))
+        if self.inputs["approx"]["rt_params"]["common"]["raman"] == 0:           # :1833-1842
+            if getattr(opannection, "raman_db", None) is None:
+                raise Exception("raman='oklopcic' needs the Raman cross-section table: opannection(raman_db=...)")
+            fine = np.linspace(wno.min() - 2000.0, wno.max() + 6000.0, wno.size * 5)
+            fine_flux = np.interp(fine, wno_star, flux_star)
+            dnu = np.asarray(opannection.raman_db["deltanu"], dtype=float)
+            shifts = np.zeros((wno.size, dnu.size))
+            opannection.unshifted_stellar_spec = bin_star(wno, fine, fine_flux)
+            first = None
+            for i in range(dnu.size):                                             # optics.py:2394-2400
+                sh = bin_star(wno + dnu[i], fine, fine_flux)
+                if first is None:
+                    first = sh * 0 + sh
+                shifts[:, i] = sh / first
+            opannection.raman_stellar_shifts = shifts
+            binned, unit = opannection.unshifted_stellar_spec, "ergs cm^{-2} s^{-1} cm^{-1}"
+        elif lvl:                                                                 # :1843-1879
+            if np.isnan(r) or np.isnan(sm):
+                raise Exception("semi_major and r parameters are not provided but are needed to compute relative fluxes "
+                                "for climate calculation or when get_lvl_flux is True")
+            ok = flux_star > 1e-30
+            lw, lf = np.log10(wno_star[ok]), np.log10(flux_star[ok])
+            fine = 10 ** _interp_extrapolate(np.log10(wno), lw, lf)
+            x = -1.0 / wno
+            binned = np.zeros(wno.size)
+            binned[:-1] = np.diff(x) * (fine[1:] + fine[:-1]) / 2.0               # the two grid points of a bin, :1858-1862
+            if wno.size > 2:
+                slope = (binned[-2] - binned[-3]) / (wno[-2] - wno[-3])
+                binned[-1] = binned[-2] + slope * (wno[-1] - wno[-2])
+            bad = np.isnan(binned) | (binned == 0)
+            if bad.sum() > 20:
+                good = np.where(~bad)[0]
+                binned[bad] = np.interp(wno[bad], wno[good], binned[good])
+            opannection.unshifted_stellar_spec = binned
+            unit = "ergs cm^{-2} s^{-1}"
+        else:                                                                     # :1880-1888
+            interp = np.interp(wno, wno_star, flux_star)
+            _, binned = mean_regrid(wno_star, flux_star, newx=wno)
+            empty = np.isnan(binned)
+            binned[empty] = interp[empty]
+            opannection.unshifted_stellar_spec = binned
+            unit = "ergs cm^{-2} s^{-1} cm^{-1}"
+        have = not (np.isnan(r) or np.isnan(sm))
+        opannection.relative_flux = binned * (r / sm) ** 2 if have else binned * 0 + 1
+        st.update(database=database, temp=temp, logg=logg, metal=metal, radius=r, radius_unit="cm" if radius is not None
+                  else "Radius not supplied", flux=binned, flux_unit=unit, relative_flux=opannection.relative_flux,
+                  relative_flux_unit="(Rs/Sa)^2 * " + unit, semi_major=sm,
+                  semi_major_unit="cm" if semi_major is not None else "Semi Major axis not supplied", filename=filename,
+                  w_unit=w_unit, f_unit=f_unit)
 
     def atmosphere(self, df=None, exclude_mol=1):
         """Level profile: columns pressure (bar), temperature (K) and volume mixing ratios

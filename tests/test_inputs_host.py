@@ -297,3 +297,126 @@ def test_opannection_reference_keywords_and_errors(tmp_path, monkeypatch):
     monkeypatch.setenv("picaso_refdata", str(tmp_path))
     with pytest.raises(Exception, match="naming scheme opacities"):
         jdi.opannection()
+
+
+def test_star_takes_the_reference_keywords(tmp_path):
+    """justdoit.py:1756-1758: star(opannection, temp, metal, logg, radius, radius_unit, semi_major, semi_major_unit,
+    database, filename, w_unit, f_unit) -- plus `relative_flux` at the end."""
+    import inspect
+    names = list(inspect.signature(jdi.inputs.star).parameters)[1:]
+    assert names == ["opannection", "temp", "metal", "logg", "radius", "radius_unit", "semi_major", "semi_major_unit",
+                     "database", "filename", "w_unit", "f_unit", "relative_flux"]
+    c = jdi.inputs()
+    with pytest.raises(Exception, match="stsynphot"):
+        c.star(None, temp=5000, metal=0.0122, logg=4.437, radius=1, radius_unit="R_sun")
+    c.star(relative_flux=np.ones(7), radius=1.0, radius_unit="R_sun", semi_major=0.05, semi_major_unit="au")
+    st = c.inputs["star"]
+    assert st["database"] == "user" and np.isclose(st["radius"], 6.957e10) and np.isclose(st["semi_major"], 0.05 * 1.495978707e13)
+    c.star()
+    assert c.inputs["star"]["database"] == "nostar"
+
+
+def _opa_stub(wno, raman_db=None):
+    import types
+    return types.SimpleNamespace(wno=np.asarray(wno, dtype=float), raman_db=raman_db)
+
+
+def test_star_from_a_file_is_binned_like_the_reference(tmp_path):
+    """filename / w_unit / f_unit: mean of the stellar points in every opacity bin, interpolated where a bin catches
+    none (justdoit.py:1880-1888), relative flux = binned * (R*/a)^2 (:1892-1895)."""
+    from scipy.stats import binned_statistic
+    rng = np.random.default_rng(3)
+    wave_aa = np.sort(rng.uniform(2500.0, 60000.0, 40000))                      # Angstrom, increasing
+    flam = 1e5 * (1.0 + 0.3 * np.sin(wave_aa / 900.0))                           # erg/cm2/s/Angstrom
+    f = tmp_path / "star.txt"
+    np.savetxt(f, np.column_stack([wave_aa, flam]))
+    wno = np.linspace(2000.0, 33000.0, 900)
+    wno[400:420] = np.linspace(wno[400], wno[400] + 0.01, 20)                    # bins too narrow to catch a stellar point
+    wno = np.sort(wno)
+    opa = _opa_stub(wno)
+    c = jdi.inputs()
+    c.approx(raman="none")
+    c.star(opa, filename=str(f), w_unit="Angs", f_unit="FLAM", radius=1, radius_unit="R_sun", semi_major=0.05,
+           semi_major_unit="au")
+    wno_star = (1e4 / (wave_aa * 1e-4))[::-1]
+    flux_star = (flam * 1e8)[::-1]
+    d = np.diff(wno)
+    edges = np.array([wno[0] - d[0] / 2] + list(wno[0:-1] + d / 2.0) + [wno[-1] + d[-1] / 2])
+    want, _, _ = binned_statistic(wno_star, flux_star, bins=edges)
+    hole = np.isnan(want)
+    assert hole.any()
+    want[hole] = np.interp(wno, wno_star, flux_star)[hole]
+    assert np.allclose(opa.unshifted_stellar_spec, want, rtol=1e-13, atol=0)
+    fac = (6.957e10 / (0.05 * 1.495978707e13)) ** 2
+    assert np.allclose(opa.relative_flux, want * fac, rtol=1e-13) and c.inputs["star"]["relative_flux"] is opa.relative_flux
+    assert c.inputs["star"]["flux_unit"] == "ergs cm^{-2} s^{-1} cm^{-1}" and c.inputs["star"]["database"] == "ck04models"
+    c.star(opa, filename=str(f), w_unit="Angs", f_unit="FLAM")                   # no radius / distance: F0PI = 1
+    assert np.array_equal(opa.relative_flux, np.ones(wno.size))
+    with pytest.raises(Exception, match="w_unit"):
+        c.star(opa, filename=str(f), w_unit="furlong", f_unit="FLAM")
+    with pytest.raises(Exception, match="Must enter"):
+        c.star(opa, filename=str(f))
+
+
+def test_star_oklopcic_shifts_and_level_flux_forms(tmp_path):
+    """raman='oklopcic': compute_stellar_shits (optics.py:2370-2402) on the 5x finer grid of justdoit.py:1834-1840;
+    get_lvl_flux: the bin-integrated stellar flux of :1843-1879 (two grid points per bin)."""
+    wave_um = np.linspace(0.2, 6.0, 30000)
+    f_um = 3e6 * np.exp(-((wave_um - 0.6) / 1.5) ** 2) + 1e4                      # erg/cm2/s/um
+    f = tmp_path / "star.txt"
+    np.savetxt(f, np.column_stack([wave_um, f_um]))
+    wno = np.linspace(9000.0, 30000.0, 400)
+    db = {"c": np.ones(3), "ji": np.array([0, 0, 1]), "deltanu": np.array([0.0, 4161.0, 587.0])}
+    opa = _opa_stub(wno, db)
+    c = jdi.inputs()
+    c.approx(raman="oklopcic")
+    c.star(opa, filename=str(f), w_unit="um", f_unit="erg/cm2/s/um")
+    wno_star, flux_star = (1e4 / wave_um)[::-1], (f_um * 1e4)[::-1]
+    fine = np.linspace(wno.min() - 2000, wno.max() + 6000, wno.size * 5)
+    ff = np.interp(fine, wno_star, flux_star)
+
+    def tophat(centres):                      # optics.py:497-521, one mask per bin
+        n = centres.size
+        delta = np.zeros(n)
+        delta[:-1] = centres[1:] - centres[:-1]
+        delta[-1] = delta[-2]
+        out = np.zeros(n)
+        for i in range(1, n):
+            out[i] = np.mean(ff[(fine >= centres[i] - 0.5 * delta[i - 1]) & (fine < centres[i] + 0.5 * delta[i])])
+        out[0] = np.mean(ff[(fine > centres[0] - 0.5 * delta[0]) & (fine < centres[0] + 0.5 * delta[0])])
+        return out
+    base = tophat(wno)
+    assert np.allclose(opa.unshifted_stellar_spec, base, rtol=1e-12)
+    assert opa.raman_stellar_shifts.shape == (wno.size, 3) and np.array_equal(opa.raman_stellar_shifts[:, 0], np.ones(wno.size))
+    assert np.allclose(opa.raman_stellar_shifts[:, 1], tophat(wno + 4161.0) / base, rtol=1e-12)
+    c.approx(raman="none", get_lvl_flux=True)
+    with pytest.raises(Exception, match="semi_major"):
+        c.star(opa, filename=str(f), w_unit="um", f_unit="erg/cm2/s/um")
+    c.star(opa, filename=str(f), w_unit="um", f_unit="erg/cm2/s/um", radius=7e10, semi_major=7e11)
+    fine_p = 10 ** np.interp(np.log10(wno), np.log10(wno_star), np.log10(flux_star))
+    want = np.array([np.trapezoid(fine_p[i:i + 2], x=-1 / wno[i:i + 2]) if i < wno.size - 1 else 0.0 for i in range(wno.size)])
+    slope = (want[-2] - want[-3]) / (wno[-2] - wno[-3])
+    want[-1] = want[-2] + slope * (wno[-1] - wno[-2])
+    assert np.allclose(opa.unshifted_stellar_spec, want, rtol=1e-12)
+    assert c.inputs["star"]["flux_unit"] == "ergs cm^{-2} s^{-1}"
+    assert np.allclose(opa.relative_flux, want * 0.01, rtol=1e-12)
+
+
+def test_mean_regrid_and_create_grid():
+    """mean_regrid (justplotit.py:31-63, scipy binned_statistic) and create_grid (opacity_factory.py:712-739), as the
+    reference's own test uses them: `jdi.mean_regrid(wno, albedo, R=150)` (tests/test_notebooks.py:88)."""
+    from scipy.stats import binned_statistic
+    rng = np.random.default_rng(1)
+    x = np.sort(rng.uniform(10000.0, 33000.0, 5000))
+    y = rng.random(5000)
+    edges = jdi.create_grid(1e4 / x.max(), 1e4 / x.min(), 150)
+    sp = (2.0 * 150 + 1.0) / (2.0 * 150 - 1.0)
+    assert np.allclose((1e4 / edges)[:-1] / (1e4 / edges)[1:], sp) and edges[0] <= x.min() and np.isclose(edges[-1], x.max())
+    cx, m = jdi.mean_regrid(x, y, R=150)
+    want, _, _ = binned_statistic(x, y, bins=edges)
+    assert np.array_equal(m, want, equal_nan=True) and np.array_equal(cx, (edges[:-1] + edges[1:]) / 2)
+    newx = np.linspace(11000.0, 32000.0, 77)
+    cx, m = jdi.mean_regrid(x, y, newx=newx)
+    assert np.allclose(cx, newx) and np.isfinite(m).all()
+    with pytest.raises(Exception, match="newx or a R"):
+        jdi.mean_regrid(x, y)

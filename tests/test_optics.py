@@ -423,3 +423,37 @@ def test_gpu_spectrum_config0_196_points_60_layers(oracle):
     f, _ = oracle.get_thermal_1d(nlevel, opa.wno, nwno, 5, 1, g196["in/tlevel"], P["dtau_og"], P["w0_no_raman"],
                                  P["cosb_og"], g196["in/plevel_bar"] * 1e6, u1, np.full(nwno, 0.1), 1, opa.wno * 0, 0)
     assert rel_err(out["thermal"], oracle.compress_thermal(nwno, f, gw, tw)) < 1e-8
+
+
+@pytest.mark.gpu
+def test_gpu_spectrum_with_a_star_file_and_oklopcic_raman(gold, tmp_path):
+    """The reference's call sequence for Raman scattering after Oklopcic+2016: approx(raman='oklopcic'), then
+    star(opa, filename=..., w_unit=..., f_unit=...) -- which bins the star and leaves the shifted / unshifted ratios
+    on the opacity object (justdoit.py:1833-1842) -- then spectrum(): compute_raman on the device from those ratios."""
+    from picaso_amd import justdoit as jdi
+    from picaso_amd import optics as px
+    opa = jdi.opannection(filename_db=DB, query_method="linear")
+    opa.raman_db = {"c": gold["in/raman_c"], "ji": gold["in/raman_ji"], "deltanu": gold["in/raman_deltanu"]}
+    wave_um = np.linspace(0.05, 300.0, 200000)
+    flux = 2e6 * np.exp(-((np.log(wave_um) - np.log(0.5)) / 1.2) ** 2) * (1.0 + 0.2 * np.sin(wave_um * 40.0)) + 1.0
+    star_file = tmp_path / "star.txt"
+    np.savetxt(star_file, np.column_stack([wave_um, flux]))
+    outs = {}
+    for raman in ("oklopcic", "none"):
+        case = _bundle(gold, jdi, None, True, 2, 2)
+        case.approx(raman=raman)
+        case.gravity(radius=7.0e9, mass=1.9e30)
+        case.star(opa, filename=str(star_file), w_unit="um", f_unit="erg/cm2/s/um", radius=1, radius_unit="R_sun",
+                  semi_major=0.05, semi_major_unit="au")
+        assert opa.relative_flux.shape == (opa.nwno,) and np.all(opa.relative_flux > 0)
+        outs[raman] = case.spectrum(opa, calculation="reflected", full_output=True)
+    assert opa.raman_stellar_shifts.shape == (opa.nwno, len(gold["in/raman_c"]))
+    a, b = outs["oklopcic"], outs["none"]
+    assert np.isfinite(a["albedo"]).all() and np.isfinite(a["fpfs_reflected"]).all()
+    assert not np.array_equal(a["albedo"], b["albedo"])
+    # the plane the mixing saw = min(compute_raman(host restatement), 0.99999): through w0 of the full output
+    from picaso_amd.atmsetup import ATMSETUP
+    rf = np.minimum(px.compute_raman(opa.nwno, len(gold["in/tlevel"]) - 1, opa.wno, opa.raman_stellar_shifts,
+                                     0.5 * (gold["in/tlevel"][1:] + gold["in/tlevel"][:-1]), gold["in/raman_c"],
+                                     gold["in/raman_ji"], gold["in/raman_deltanu"]), 0.99999)
+    assert np.isfinite(rf).all() and rf.min() > 0
