@@ -258,6 +258,50 @@ def mean_regrid(x, y, newx=None, R=None):
     return (edges[:-1] + edges[1:]) / 2.0, means
 
 
+class _UnitNames:
+    """``jdi.u.Unit('m/(s**2)')`` of the reference's tutorials without astropy: the name itself, which ``gravity``,
+    ``star`` and the other builders take (``_UNIT_CGS``)."""
+
+    @staticmethod
+    def Unit(name):
+        return name
+
+
+try:                                    # the reference exposes astropy.units as `justdoit.u`
+    import astropy.units as u           # noqa: F401
+except ImportError:
+    u = _UnitNames()
+
+
+def _base_case(name):
+    return os.path.join(_refdata(), "base_cases", name)
+
+
+def jupiter_pt():
+    """Path of the reference's Jupiter P-T-composition profile (``$picaso_refdata/base_cases``, justdoit.py:5415)."""
+    return _base_case("jupiter.pt")
+
+
+def jupiter_cld():
+    return _base_case("jupiterf3.cld")
+
+
+def HJ_pt():
+    return _base_case("HJ.pt")
+
+
+def HJ_cld():
+    return _base_case("HJ.cld")
+
+
+def brown_dwarf_pt():
+    return _base_case("t1270g200f1_m0.0_co1.0.cmp")
+
+
+def brown_dwarf_cld():
+    return _base_case("t1270g200f1_m0.0_co1.0.cld")
+
+
 def get_cld_input_grid(filename_or_grid="wave_EGP.dat"):
     """Wavenumbers (increasing) of the 196-point grid cloud tables come on (reference wavelength.py:9-40):
     ``$picaso_refdata/opacities/wave_EGP.dat`` (whitespace table with a 'wavenumber' column) or an array."""
@@ -439,14 +483,59 @@ class inputs:
                   semi_major_unit="cm" if semi_major is not None else "Semi Major axis not supplied", filename=filename,
                   w_unit=w_unit, f_unit=f_unit)
 
-    def atmosphere(self, df=None, exclude_mol=1):
-        """Level profile: columns pressure (bar), temperature (K) and volume mixing ratios
-        (reference justdoit.py:1915)."""
-        if df is None or "pressure" not in df.keys() or "temperature" not in df.keys():
-            raise Exception("atmosphere(df=...) needs 'pressure' and 'temperature' columns")
+    def atmosphere(self, df=None, filename=None, exclude_mol=None, mh=None, cto_absolute=None, cto_relative=None,
+                   chem_method=None, quench=False, no_ph3=False, cold_trap=False, vol_rainout=False,
+                   photochem_init_args=None, add_visscher_abunds=True, **pd_kwargs):
+        """Level profile with the reference's keywords (justdoit.py:1915-2075): ``df`` (DataFrame or dict) or
+        ``filename`` (read with ``pandas.read_csv(filename, **pd_kwargs)``) with columns pressure [bar], temperature [K]
+        and volume mixing ratios.  As in the reference: levels are sorted by pressure; ``exclude_mol`` (a name or a list
+        of names) switches molecules off in the opacities only; and Raman scattering is switched off
+        (``raman='none'``) for an atmosphere without H2 or with less than 70 % of it anywhere (:2033-2040).
+        The chemistry keywords (``mh``, ``cto_*``, ``chem_method``, photochemistry, the climate hacks) belong to
+        subsystems outside this package and raise."""
+        if any(x is not None for x in (mh, cto_absolute, cto_relative, chem_method, photochem_init_args)):
+            raise Exception("atmosphere(mh=, cto_*=, chem_method=, photochem_init_args=): chemistry is outside this package; "
+                            "give the mixing ratios as columns of df / filename")
+        if any((quench, no_ph3, cold_trap, vol_rainout)):
+            raise Exception("'quench','no_ph3','cold_trap','vol_rainout' are a climate kwargs and climate calculation is "
+                            "not specified so this will not do anything")
+        if df is not None:
+            if not (isinstance(df, dict) or (hasattr(df, "keys") and hasattr(df, "sort_values"))):
+                raise Exception("df must be pandas DataFrame or dictionary")
+        elif filename is not None:
+            import pandas as pd
+            df = pd.read_csv(filename, **pd_kwargs)
+        elif self.inputs["atmosphere"]["profile"] is not None:
+            df = self.inputs["atmosphere"]["profile"]
+        else:
+            raise Exception("Could not find a starting dataframe in inputs['atmosphere']['profile'] and no df or filename "
+                            "were specified")
+        if "pressure" not in df.keys():
+            raise Exception("Check column names. `pressure` must be included.")
+        if "temperature" not in df.keys():
+            raise Exception("`temperature` not specified as a column/key name")
+        if exclude_mol is None or (isinstance(exclude_mol, (int, float)) and exclude_mol == 1):
+            self.inputs["atmosphere"]["exclude_mol"] = 1
+        elif isinstance(exclude_mol, dict):
+            self.inputs["atmosphere"]["exclude_mol"] = exclude_mol
+        else:
+            names = [exclude_mol] if isinstance(exclude_mol, str) else list(exclude_mol)
+            flags = {k: 1 for k in df.keys()}
+            flags.update({m: 0 for m in names})
+            self.inputs["atmosphere"]["exclude_mol"] = flags
+        if hasattr(df, "sort_values"):
+            df = df.sort_values("pressure").reset_index(drop=True)
+        else:
+            pres = np.asarray(df["pressure"], dtype=float)
+            if np.any(np.diff(pres) < 0):
+                order = np.argsort(pres, kind="stable")
+                df = {k: np.asarray(v)[order] for k, v in df.items()}
         self.inputs["atmosphere"]["profile"] = df
-        self.inputs["atmosphere"]["exclude_mol"] = exclude_mol
         self.nlevel = len(df["pressure"])
+        common = self.inputs["approx"]["rt_params"]["common"]
+        if len(df.keys()) > 2 and common["raman"] != 2:
+            if "H2" not in df.keys() or float(np.min(np.asarray(df["H2"], dtype=float))) < 0.7:
+                common["raman"] = 2
 
     def clouds(self, filename=None, g0=None, w0=None, opd=None, p=None, dp=None, df=None, do_holes=False,
                fhole=None, fthin_cld=None, wavenumber=None, **pd_kwargs):

@@ -2,6 +2,8 @@
 integers the solvers take in the order of the reference's option tables (reference
 justdoit.py:5512-5534, 5655-5658), geometry set-up follows phase_angle() (justdoit.py:1453-1605),
 and the minimal ATMSETUP reproduces the layer quantities the opacity stage consumes."""
+import os
+
 import numpy as np
 import pytest
 
@@ -420,3 +422,57 @@ def test_mean_regrid_and_create_grid():
     assert np.allclose(cx, newx) and np.isfinite(m).all()
     with pytest.raises(Exception, match="newx or a R"):
         jdi.mean_regrid(x, y)
+
+
+def test_atmosphere_takes_the_reference_keywords(tmp_path, monkeypatch):
+    """justdoit.py:1915-2075: df or filename (+ pandas kwargs), exclude_mol by name, levels sorted by pressure, Raman
+    scattering switched off for atmospheres that are not H2-dominated; `jdi.u.Unit(...)` and the base-case paths of the
+    reference's tutorials (tests/test_notebooks.py:55-143)."""
+    import inspect
+    names = list(inspect.signature(jdi.inputs.atmosphere).parameters)[1:]
+    assert names == ["df", "filename", "exclude_mol", "mh", "cto_absolute", "cto_relative", "chem_method", "quench",
+                     "no_ph3", "cold_trap", "vol_rainout", "photochem_init_args", "add_visscher_abunds", "pd_kwargs"]
+    nlevel = 12
+    p = np.logspace(-5, 1, nlevel)
+    f = tmp_path / "planet.pt"
+    with open(f, "w") as fh:
+        fh.write("pressure temperature H2 He CH4\n")
+        for i in reversed(range(nlevel)):                                  # bottom of the atmosphere first
+            fh.write("%.6e %.2f 0.837 0.162 0.001\n" % (p[i], 100.0 + 10 * i))
+    c = jdi.inputs()
+    assert c.inputs["approx"]["rt_params"]["common"]["raman"] == 1
+    c.atmosphere(filename=str(f), sep=r"\s+")
+    prof = c.inputs["atmosphere"]["profile"]
+    assert c.nlevel == nlevel and np.allclose(np.asarray(prof["pressure"]), p) and np.asarray(prof["temperature"])[0] == 100.0
+    assert c.inputs["atmosphere"]["exclude_mol"] == 1 and c.inputs["approx"]["rt_params"]["common"]["raman"] == 1
+    c.atmosphere(filename=str(f), exclude_mol="CH4", sep=r"\s+")
+    ex = c.inputs["atmosphere"]["exclude_mol"]
+    assert ex["CH4"] == 0 and ex["H2"] == 1 and ex["He"] == 1
+    c.atmosphere(df={"pressure": p[::-1], "temperature": np.linspace(900, 100, nlevel), "H2": np.full(nlevel, 0.9),
+                     "He": np.full(nlevel, 0.1)}, exclude_mol=["He"])
+    assert np.array_equal(c.inputs["atmosphere"]["profile"]["pressure"], p)
+    assert np.array_equal(c.inputs["atmosphere"]["profile"]["temperature"], np.linspace(900, 100, nlevel)[::-1])
+    c.atmosphere()                                                         # keeps the profile that is there
+    assert c.nlevel == nlevel
+    # not H2-dominated: Raman scattering off (justdoit.py:2033-2040)
+    c.atmosphere(df={"pressure": p, "temperature": p * 0 + 300, "CO2": p * 0 + 0.96, "N2": p * 0 + 0.04})
+    assert c.inputs["approx"]["rt_params"]["common"]["raman"] == 2
+    c2 = jdi.inputs()
+    c2.atmosphere(df={"pressure": p, "temperature": p * 0 + 300, "H2": p * 0 + 0.5, "H2O": p * 0 + 0.5})
+    assert c2.inputs["approx"]["rt_params"]["common"]["raman"] == 2
+    with pytest.raises(Exception, match="chemistry"):
+        c.atmosphere(df={"pressure": p, "temperature": p}, mh=1, cto_relative=1)
+    with pytest.raises(Exception, match="temperature"):
+        c.atmosphere(df={"pressure": p, "H2": p})
+    with pytest.raises(Exception, match="DataFrame or dictionary"):
+        c.atmosphere(df=[1, 2, 3])
+    with pytest.raises(Exception, match="no df or filename"):
+        jdi.inputs().atmosphere()
+    # units by name and the base cases, as the reference's own test spells them
+    c.gravity(gravity=25, gravity_unit=jdi.u.Unit("m/(s**2)"))
+    assert np.isclose(c.inputs["planet"]["gravity"], 2500.0)
+    c.gravity(radius=1, radius_unit=jdi.u.Unit("R_jup"), mass=1, mass_unit=jdi.u.Unit("M_jup"))
+    assert np.isclose(c.inputs["planet"]["radius"], 7.1492e9)
+    monkeypatch.setenv("picaso_refdata", str(tmp_path))
+    assert jdi.jupiter_pt() == os.path.join(str(tmp_path), "base_cases", "jupiter.pt")
+    assert jdi.brown_dwarf_cld().endswith("t1270g200f1_m0.0_co1.0.cld") and jdi.HJ_pt().endswith("HJ.pt")
