@@ -322,12 +322,41 @@ def get_cld_input_grid(filename_or_grid="wave_EGP.dat"):
 class inputs:
     """Builder of the run configuration (reference ``class inputs``, justdoit.py:1421)."""
 
-    def __init__(self):
+    def __init__(self, calculation="planet", climate=False):
+        """``calculation='browndwarf'``: no star and no Raman scattering (``setup_nostar``), as in the reference
+        (justdoit.py:1446-1451).  ``climate=True`` would start the T(P) iteration, which is outside this package
+        (its radiative-transfer call is ``picaso_amd.climate.get_fluxes``)."""
+        if climate:
+            raise Exception("inputs(climate=True): the climate solver's T(P) iteration is outside this package; its "
+                            "radiative-transfer call is picaso_amd.climate.calculate_atm / get_fluxes")
         self.inputs = copy.deepcopy(_DEFAULTS)
+        self.inputs["calculation"] = calculation
+        if "brown" in calculation:
+            self.setup_nostar()
         self.phase_angle(0)
 
-    def phase_angle(self, phase=0, num_gangle=10, num_tangle=1, symmetry=False):
-        """Geometry (reference justdoit.py:1453-1605), including the quadrant ``symmetry`` reduction."""
+    def setup_nostar(self):
+        """Turns off the planet-specific things (reference justdoit.py:1740-1754): no star, no Raman scattering."""
+        self.inputs["approx"]["rt_params"]["common"]["raman"] = 2
+        self.inputs["star"].update(database="nostar", temp="nostar", logg="nostar", metal="nostar", radius="nostar",
+                                   radius_unit="nostar", flux="nostar", wno="nostar", relative_flux=None)
+
+    def clouds_reset(self):
+        """Cloud tables back to zeros (reference justdoit.py:4115-4124)."""
+        prof = self.inputs["clouds"]["profile"]
+        if prof is not None:
+            self.inputs["clouds"]["profile"] = {k: (np.zeros_like(np.asarray(v, dtype=float)) if k in ("g0", "w0", "opd") else v)
+                                                for k, v in dict(prof).items()}
+
+    def phase_angle(self, phase=0, num_gangle=10, num_tangle=1, symmetry=False, phase_grid=None, calculation=None):
+        """Geometry (reference justdoit.py:1453-1605), including the quadrant ``symmetry`` reduction; with
+        ``phase_grid`` the geometry of every phase of a phase curve (``phase_curve_geometry``, :1492-1497)."""
+        if phase_grid is not None:
+            if calculation is None:
+                raise Exception("Phase curve calculation activated because phase_grid is supplied. However, 'calculation' "
+                                "needs to be specified to either 'thermal' or 'reflected'")
+            self.phase_curve_geometry(calculation, phase_grid, num_gangle=num_gangle, num_tangle=num_tangle)
+            return
         if (phase > 2 * np.pi) or (phase < 0):
             raise Exception("Oops! you input a phase angle greater than 2*pi or less than 0. Please "
                             "make sure your inputs are in radian units: 0<phase<2pi")

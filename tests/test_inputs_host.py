@@ -476,3 +476,30 @@ def test_atmosphere_takes_the_reference_keywords(tmp_path, monkeypatch):
     monkeypatch.setenv("picaso_refdata", str(tmp_path))
     assert jdi.jupiter_pt() == os.path.join(str(tmp_path), "base_cases", "jupiter.pt")
     assert jdi.brown_dwarf_cld().endswith("t1270g200f1_m0.0_co1.0.cld") and jdi.HJ_pt().endswith("HJ.pt")
+
+
+def test_inputs_calculation_browndwarf_and_small_builders():
+    """inputs(calculation='browndwarf') = setup_nostar (justdoit.py:1446-1451, 1740-1754): no star, Raman off;
+    clouds_reset (:4115-4124); phase_angle(phase_grid=, calculation=) hands over to phase_curve_geometry (:1492-1497)."""
+    import inspect
+    assert list(inspect.signature(jdi.inputs.__init__).parameters)[1:] == ["calculation", "climate"]
+    assert list(inspect.signature(jdi.inputs.phase_angle).parameters)[1:] == ["phase", "num_gangle", "num_tangle", "symmetry",
+                                                                               "phase_grid", "calculation"]
+    bd = jdi.inputs(calculation="browndwarf")
+    assert bd.inputs["approx"]["rt_params"]["common"]["raman"] == 2 and bd.inputs["star"]["database"] == "nostar"
+    pl = jdi.inputs()
+    assert pl.inputs["approx"]["rt_params"]["common"]["raman"] == 1 and pl.inputs["calculation"] == "planet"
+    with pytest.raises(Exception, match="climate"):
+        jdi.inputs(climate=True)
+    n = 9
+    p = np.logspace(-4, 1, n)
+    pl.atmosphere(df={"pressure": p, "temperature": p * 0 + 500, "H2": p * 0 + 1})
+    pl.clouds(df={"opd": np.ones((n - 1, 5)), "w0": np.ones((n - 1, 5)) * 0.9, "g0": np.ones((n - 1, 5)) * 0.5},
+              wavenumber=np.linspace(1000, 2000, 5))
+    pl.clouds_reset()
+    prof = pl.inputs["clouds"]["profile"]
+    assert all(not np.any(prof[k]) and prof[k].shape == (n - 1, 5) for k in ("opd", "w0", "g0"))
+    with pytest.raises(Exception, match="'calculation' needs to be specified"):
+        pl.phase_angle(phase_grid=[0.0, 1.0])
+    pl.phase_angle(phase_grid=[0.0, 1.0, 2.0], calculation="reflected", num_gangle=4, num_tangle=4)
+    assert pl.inputs["disco"]["calculation"] == "reflected"
