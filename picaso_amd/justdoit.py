@@ -302,9 +302,12 @@ def brown_dwarf_cld():
     return _base_case("t1270g200f1_m0.0_co1.0.cld")
 
 
-def get_cld_input_grid(filename_or_grid="wave_EGP.dat"):
+def get_cld_input_grid(filename_or_grid="wave_EGP.dat", grid661=False):
     """Wavenumbers (increasing) of the 196-point grid cloud tables come on (reference wavelength.py:9-40):
-    ``$picaso_refdata/opacities/wave_EGP.dat`` (whitespace table with a 'wavenumber' column) or an array."""
+    ``$picaso_refdata/opacities/wave_EGP.dat`` (whitespace table with a 'wavenumber' column) or an array;
+    ``grid661``: the 661-point grid of the climate tables, ``$picaso_refdata/climate_INPUTS/wvno_661``."""
+    if grid661:
+        return np.loadtxt(os.path.join(_refdata(), "climate_INPUTS", "wvno_661"), usecols=[0, 1], unpack=True)[0]
     if isinstance(filename_or_grid, np.ndarray):
         return np.sort(filename_or_grid)
     path = filename_or_grid
@@ -594,6 +597,17 @@ class inputs:
                                     "specified x %d wave pts" % (pr.size, nlayer, grid.size))
                 df = {k: np.asarray(df[k], dtype=float)[order] for k in ("opd", "w0", "g0")}
                 wavenumber = grid
+            elif wavenumber is None:
+                # a table without its own grid (eddysed / virga output): the 196-point grid of wave_EGP.dat, or the
+                # 661-point grid of the climate tables, told by its length (justdoit.py:4212-4219); this package also
+                # takes tables that are already on the opacity grid (told apart in get_clouds)
+                rows = np.size(df["opd"])
+                if rows == nlayer * 196 and os.environ.get("picaso_refdata") is not None \
+                        and os.path.isfile(os.path.join(_refdata(), "opacities", "wave_EGP.dat")):
+                    wavenumber = get_cld_input_grid("wave_EGP.dat")
+                elif rows == nlayer * 661 and os.environ.get("picaso_refdata") is not None \
+                        and os.path.isfile(os.path.join(_refdata(), "climate_INPUTS", "wvno_661")):
+                    wavenumber = get_cld_input_grid(grid661=True)
             self.inputs["clouds"].update(profile=df, wavenumber=wavenumber)
         elif filename is not None:
             raise Exception("give either filename or df, not both")

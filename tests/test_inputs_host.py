@@ -503,3 +503,28 @@ def test_inputs_calculation_browndwarf_and_small_builders():
         pl.phase_angle(phase_grid=[0.0, 1.0])
     pl.phase_angle(phase_grid=[0.0, 1.0, 2.0], calculation="reflected", num_gangle=4, num_tangle=4)
     assert pl.inputs["disco"]["calculation"] == "reflected"
+
+
+def test_cloud_table_without_its_own_grid_gets_the_196_point_grid(tmp_path, monkeypatch):
+    """An eddysed / virga table (columns lvl wv opd g0 w0, (nlevel-1) x 196 rows, no wavenumber column) is on the grid
+    of wave_EGP.dat (justdoit.py:4212-4219), the way the reference's jupiterf3.cld base case comes."""
+    wgrid = _write_cloud_grid(tmp_path, monkeypatch)
+    nlevel = 7
+    p = np.logspace(-4, 1, nlevel)
+    c = jdi.inputs()
+    c.atmosphere(df={"pressure": p, "temperature": p * 0 + 400, "H2": p * 0 + 1})
+    f = tmp_path / "planet.cld"
+    rng = np.random.default_rng(2)
+    with open(f, "w") as fh:
+        fh.write("lvl wv opd g0 w0 sigma\n")
+        for l in range(nlevel - 1):
+            for w in range(196):
+                fh.write("%d %d %.5e %.4f %.4f 0.0\n" % (l + 1, w + 1, rng.random(), rng.random(), rng.random()))
+    c.clouds(filename=str(f), sep=r"\s+")
+    cl = c.inputs["clouds"]
+    assert np.array_equal(cl["wavenumber"], wgrid) and np.size(cl["profile"]["opd"]) == (nlevel - 1) * 196
+    from picaso_amd.atmsetup import ATMSETUP, CloudTables
+    atm = ATMSETUP(c.inputs)
+    atm.get_profile()
+    atm.get_clouds(np.linspace(3000.0, 30000.0, 333))
+    assert isinstance(atm.layer["cloud"], CloudTables) and atm.layer["cloud"]["w0"].shape == (nlevel - 1, 333)
