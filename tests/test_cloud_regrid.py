@@ -161,3 +161,37 @@ def test_gpu_box_cloud_spectrum_regridded_on_the_device(tmp_path, monkeypatch, h
     byhand = case.spectrum(opa, calculation="reflected+thermal+transmission", devices=devices)
     for k in ("albedo", "thermal", "transit_depth"):
         assert np.array_equal(byhand[k], dev[k]), k
+
+
+@pytest.mark.gpu
+def test_gpu_new_entry_points_refuse_bad_arguments():
+    """picaso_regrid_rows_dev / picaso_raman_oklopcic_dev / raman_rows of picaso_compute_opacity_ck_dev: clean error
+    codes with a message, nothing launched."""
+    import ctypes
+    from picaso_amd import _lib, device
+    from picaso_amd._lib import PicasoHipError, check, load
+    ctx = _lib.context()
+    d = device.DeviceArray.from_host(np.arange(8.0), ctx)
+    out = device.DeviceArray((2, 8), ctx)
+    ci, cl, vp = ctypes.c_int, ctypes.c_long, ctypes.c_void_p
+    with pytest.raises(PicasoHipError, match="regrid_rows"):          # a one-point table has no bracket
+        check(load().picaso_regrid_rows_dev(ctx, ci(2), ci(1), cl(8), vp(d.addr), vp(d.addr), vp(d.addr), None, vp(out.addr)), ctx)
+    with pytest.raises(PicasoHipError, match="regrid_rows"):
+        check(load().picaso_regrid_rows_dev(ctx, ci(2), ci(4), cl(8), None, vp(d.addr), vp(d.addr), None, vp(out.addr)), ctx)
+    ji = np.array([0, 12], dtype=np.int32)
+    isr = np.array([1, 0], dtype=np.int32)
+    jat = np.zeros((10, 2))
+    with pytest.raises(PicasoHipError, match="j_initial"):
+        check(load().picaso_raman_oklopcic_dev(ctx, ci(2), cl(8), ci(2), vp(out.addr), vp(out.addr),
+                                               ji.ctypes.data_as(vp), isr.ctypes.data_as(vp), jat.ctypes.data_as(vp),
+                                               ctypes.c_double(0.99999), vp(out.addr)), ctx)
+    with pytest.raises(PicasoHipError, match="at most"):
+        check(load().picaso_raman_oklopcic_dev(ctx, ci(2), cl(8), ci(5000), vp(out.addr), vp(out.addr),
+                                               ji.ctypes.data_as(vp), isr.ctypes.data_as(vp), jat.ctypes.data_as(vp),
+                                               ctypes.c_double(0.99999), vp(out.addr)), ctx)
+    planes = [device.DeviceArray((2, 8), ctx) for _ in range(2)]
+    outs = [vp(device.DeviceArray((3 if k in (1, 8) else 2, 8), ctx).addr) for k in range(13)]
+    with pytest.raises(PicasoHipError, match="raman_rows"):
+        check(load().picaso_compute_opacity_ck_dev(ctx, ci(2), ci(8), ci(1), vp(planes[0].addr), vp(planes[1].addr), None,
+                                                   None, None, vp(d.addr), ci(7), ctypes.c_double(0.99999), ci(0), ci(1),
+                                                   ci(2), *outs), ctx)
