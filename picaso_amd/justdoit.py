@@ -108,6 +108,15 @@ def opannection(wave_range=None, filename_db=None, resample=1, method="resampled
                   "so should be used with caution.")
         opa = optics.RetrieveOpacities.from_sqlite(filename_db, wave_range=wave_range, resample=resample,
                                                    query_method=query_method, rayleigh_opa=rayleigh_opa)
+        # Raman cross sections of H2 (Oklopcic+2016): the reference reads `raman_db`, by default
+        # $picaso_refdata/opacities/raman.txt, with every opacity object (optics.py:1956-1961).  Here a missing default
+        # file is not an error until raman='oklopcic' asks for it.
+        path = raman_db
+        if path is None and os.environ.get("picaso_refdata") is not None:
+            cand = os.path.join(_refdata(), "opacities", "raman.txt")
+            path = cand if os.path.isfile(cand) else None
+        if path is not None:
+            opa.raman_db = read_raman_db(path)
         if verbose:
             print("verbose=True; Molecule set=", opa.molecules)
         return opa
@@ -258,6 +267,23 @@ def mean_regrid(x, y, newx=None, R=None):
     return (edges[:-1] + edges[1:]) / 2.0, means
 
 
+def read_raman_db(path):
+    """The reference's ``raman.txt`` (Oklopcic, Hirata & Heng 2016, table of H2 Raman cross sections): 16 header lines,
+    then whitespace columns ji, jf, vf, c, deltanu (reference optics.py:1956-1961) -> ``{'ji', 'jf', 'vf', 'c',
+    'deltanu'}`` arrays, what ``compute_raman`` and ``star()`` take."""
+    if not os.path.isfile(path):
+        raise Exception("raman_db %s not found" % path)
+    try:                                # pandas' float parser, as the reference: its last bit can differ from strtod's
+        import pandas as pd
+        tab = pd.read_csv(path, sep=r"\s+", skiprows=16, header=None, names=["ji", "jf", "vf", "c", "deltanu"]).values
+    except ImportError:
+        tab = np.loadtxt(path, skiprows=16, ndmin=2)
+    if tab.ndim != 2 or tab.shape[1] < 5:
+        raise Exception("raman_db %s: expected the columns ji, jf, vf, c, deltanu after 16 header lines" % path)
+    return {"ji": tab[:, 0].astype(int), "jf": tab[:, 1].astype(int), "vf": tab[:, 2].astype(int), "c": tab[:, 3].copy(),
+            "deltanu": tab[:, 4].copy()}
+
+
 class _UnitNames:
     """``jdi.u.Unit('m/(s**2)')`` of the reference's tutorials without astropy: the name itself, which ``gravity``,
     ``star`` and the other builders take (``_UNIT_CGS``)."""
@@ -315,6 +341,14 @@ def get_cld_input_grid(filename_or_grid="wave_EGP.dat", grid661=False):
         path = os.path.join(_refdata(), "opacities", filename_or_grid)
     if not os.path.isfile(path):
         raise Exception("cloud wavenumber grid %s not found" % path)
+    try:                                # the reference's reader (pandas' float parser), wavelength.py:31-32
+        import pandas as pd
+        grid = pd.read_csv(path, sep=r"\s+")
+        if "wavenumber" not in grid.keys():
+            raise Exception('Please make sure there is a column named "wavenumber" in your cloud wavegrid file')
+        return np.sort(np.asarray(grid["wavenumber"].values, dtype=float))
+    except ImportError:
+        pass
     with open(path) as fh:
         header = fh.readline().split()
         col = header.index("wavenumber")

@@ -852,7 +852,12 @@ def raman_pollack(nlayer, wave, table=None):
     if isinstance(table, (str, bytes, os.PathLike)):
         if not os.path.isfile(table):
             raise Exception("raman='pollack': table %s not found" % table)
-        w, f = np.loadtxt(table, unpack=True)
+        try:                            # pandas' float parser, as the reference (optics.py:645): last bits differ from strtod's
+            import pandas as pd
+            dat = pd.read_csv(table, sep=r"\s+", header=None, names=["w", "f"])
+            w, f = dat["w"].values, dat["f"].values
+        except ImportError:
+            w, f = np.loadtxt(table, unpack=True)
     else:
         w, f = (np.asarray(x, dtype=float) for x in table)
     row = np.interp(np.asarray(wave, dtype=float), w, f)

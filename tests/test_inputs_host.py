@@ -528,3 +528,35 @@ def test_cloud_table_without_its_own_grid_gets_the_196_point_grid(tmp_path, monk
     atm.get_profile()
     atm.get_clouds(np.linspace(3000.0, 30000.0, 333))
     assert isinstance(atm.layer["cloud"], CloudTables) and atm.layer["cloud"]["w0"].shape == (nlevel - 1, 333)
+
+
+def test_opannection_reads_the_raman_table(tmp_path, monkeypatch):
+    """opannection(raman_db=None): $picaso_refdata/opacities/raman.txt (16 header lines, then ji jf vf c deltanu) is read
+    with every opacity object, as the reference does (optics.py:1956-1961); a path can be given instead."""
+    golden = os.path.join(os.path.dirname(__file__), "golden")
+    db = os.path.join(golden, "synthetic_opacities.db")
+    g = np.load(os.path.join(golden, "optics.npz"))
+    (tmp_path / "opacities").mkdir()
+    f = tmp_path / "opacities" / "raman.txt"
+    with open(f, "w") as fh:
+        fh.write("\n".join("header line %d" % i for i in range(16)) + "\n")
+        for ji, c, dn in zip(g["in/raman_ji"], g["in/raman_c"], g["in/raman_deltanu"]):
+            fh.write("%d %d %d %.17g %.17g\n" % (ji, ji, 0, c, dn))
+    d = jdi.read_raman_db(str(f))
+    assert np.array_equal(d["ji"], g["in/raman_ji"]) and np.allclose(d["c"], g["in/raman_c"], rtol=1e-15) \
+        and np.allclose(d["deltanu"], g["in/raman_deltanu"], rtol=1e-15) and d["jf"].dtype.kind == "i"
+    monkeypatch.delenv("picaso_refdata", raising=False)
+    try:
+        opa = jdi.opannection(filename_db=db)
+    except Exception as exc:                    # no GPU in this container: the table reader is what is under test
+        pytest.skip("opannection needs the device library: %s" % exc)
+    assert getattr(opa, "raman_db", None) is None
+    monkeypatch.setenv("picaso_refdata", str(tmp_path))
+    opa = jdi.opannection(filename_db=db)
+    assert np.array_equal(opa.raman_db["ji"], g["in/raman_ji"]) and np.allclose(opa.raman_db["c"], g["in/raman_c"], rtol=1e-15)
+    other = tmp_path / "mine.txt"
+    other.write_text(f.read_text())
+    opa = jdi.opannection(filename_db=db, raman_db=str(other))
+    assert np.allclose(opa.raman_db["deltanu"], g["in/raman_deltanu"], rtol=1e-15)
+    with pytest.raises(Exception, match="not found"):
+        jdi.opannection(filename_db=db, raman_db=str(tmp_path / "nope.txt"))
