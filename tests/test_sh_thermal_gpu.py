@@ -48,6 +48,8 @@ def _args(sc, nlayer, nwno, ng, nt, u1, rs, stream, hard, delta=True):
 def test_against_oracle_and_per_angle_kernel(hip, oracle, monkeypatch, stream, ng, nt):
     nlayer, nwno = 33, 517
     rng = np.random.default_rng(100 * ng + 10 * nt + stream)
+    monkeypatch.delenv("PICASO_AMD_SH_THERMAL_PER_ANGLE", raising=False)
+    monkeypatch.delenv("PICASO_AMD_SHT_ANGLES", raising=False)
     for trial, (cloud, hard, delta) in enumerate([(True, 0, True), (False, 1, True), (True, 1, False)]):
         sc = _scene(nlayer, nwno, 400 + 7 * trial + ng, stream, cloud=cloud)
         u1 = _geom(hip, ng, nt, 0.0 if nt == 1 else 0.7)
