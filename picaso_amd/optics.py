@@ -1013,9 +1013,17 @@ def compute_opacity_resident(atmosphere, opacityclass, ngauss=1, stream=2, delta
         d_cld = d_w0 = d_g0 = None
     elif on_device:     # tables on their own wavenumber grid: interpolated where they are used (same bits)
         d_x = _wno_device(opa, cld.wno)
-        d_cld = regrid_rows(cld.in_wno, cld.compact["opd"], d_x, ctx, scale=fthin_cld if do_holes else None)
-        d_w0 = regrid_rows(cld.in_wno, cld.compact["w0"], d_x, ctx)
-        d_g0 = regrid_rows(cld.in_wno, cld.compact["g0"], d_x, ctx)
+        if do_holes:    # the thinned optical depth has its own factor (optics.py:314-315)
+            d_cld = regrid_rows(cld.in_wno, cld.compact["opd"], d_x, ctx, scale=fthin_cld)
+            both = regrid_rows(cld.in_wno, np.concatenate([cld.compact["w0"], cld.compact["g0"]]), d_x, ctx)
+            both3 = both.reshape((2, nlayer, nwno))
+            d_w0, d_g0 = both3.row_block(0), both3.row_block(1)
+        else:           # the three tables in one launch: one bracket search per wavelength for all 3 x nlayer rows
+            stack = cld.__dict__.get("_stack")
+            if stack is None:
+                stack = cld.__dict__["_stack"] = np.concatenate([cld.compact[k] for k in ("opd", "w0", "g0")])
+            all3 = regrid_rows(cld.in_wno, stack, d_x, ctx).reshape((3, nlayer, nwno))
+            d_cld, d_w0, d_g0 = all3.row_block(0), all3.row_block(1), all3.row_block(2)
     else:
         d_cld = DeviceArray.from_host(taucld_host(), ctx)
         d_w0 = DeviceArray.from_host(plane(cld["w0"]), ctx)
