@@ -157,6 +157,32 @@ int picaso_get_reflected_1d_dev(picaso_ctx *ctx, int nlevel, int nwno, long plan
                                 double *flux_plus_midpt_all, const double *gweight,
                                 const double *tweight, double *albedo);
 
+/* `nspec` spectra of one shape and one option set in ONE launch (the reference runs the
+ * spectra of a retrieval or the phases of a curve as separate processes -- driver.py:405-426,
+ * justdoit.py:4741-4777 -- each calling get_reflected_1d, fluxes.py:1009-1413).  Every pointer argument of
+ * picaso_get_reflected_1d_dev becomes a HOST array of nspec device pointers (spectrum s: dtau[s], ...,
+ * xint_at_top[s] (numg,numt,nwno), albedo[s] (nwno) when the fused disk sum is asked for); entries may
+ * repeat (one atmosphere under several geometries: the launch then orders its workgroups so that the
+ * spectra share the planes in L2).  Geometry: ngeom = 1 -- ubar0 / ubar1 (numg,numt) and cos_theta[0] for all
+ * spectra -- or ngeom = nspec -- ubar0 / ubar1 (nspec,numg,numt), cos_theta[nspec].  get_toa_intensity = 1,
+ * get_lvl_flux = 0 (level fluxes stay per-spectrum calls); at most 8 disk angles.  Spectrum s of the result
+ * is bit-identical to picaso_get_reflected_1d_dev on its own arguments: a spectrum keeps whole workgroups
+ * in the batched grid and no arithmetic depends on the launch shape.  What it buys: a 1e5-column spectrum
+ * alone fills 1.5 of the 2 wave slots per SIMD (the launch lasts as long as a doubled SIMD), four of them in
+ * one grid run at the kernel's steady rate; small spectra (1e3-1e4 columns) share one launch latency. */
+int picaso_get_reflected_1d_batch_dev(picaso_ctx *ctx, int nspec, int nlevel, int nwno, long plane_pitch, int numg,
+                                      int numt, const double *const *dtau, const double *const *tau,
+                                      const double *const *w0, const double *const *cosb,
+                                      const double *const *gcos2, const double *const *ftau_cld,
+                                      const double *const *ftau_ray, const double *const *dtau_og,
+                                      const double *const *tau_og, const double *const *w0_og,
+                                      const double *const *cosb_og, const double *const *surf_reflect, int ngeom,
+                                      const double *ubar0, const double *ubar1, const double *cos_theta,
+                                      const double *const *F0PI, int single_phase, int multi_phase, double frac_a,
+                                      double frac_b, double frac_c, double constant_back, double constant_forward,
+                                      int toon_coefficients, double b_top, double *const *xint_at_top,
+                                      const double *gweight, const double *tweight, double *const *albedo);
+
 /* replaces fluxes.get_reflected_3d (reference picaso/fluxes.py:354-660); planes are
  * (nlayer|nlevel, nwno, numg, numt), output (numg,numt,nwno). */
 int picaso_get_reflected_3d(picaso_ctx *ctx, int nlevel, const double *wno, int nwno, int numg,
@@ -214,6 +240,18 @@ int picaso_get_thermal_1d_dev(picaso_ctx *ctx, int nlevel, const double *wno, in
                               int calc_type, double *flux_at_top, double *flux_minus,
                               double *flux_plus, double *flux_minus_mdpt, double *flux_plus_mdpt,
                               const double *gweight, const double *tweight, double *flux_disk);
+
+/* `nspec` thermal spectra in one launch, see picaso_get_reflected_1d_batch_dev: tlevel / plevel are HOST tables
+ * (nspec, nlevel), dtau / w0 / cosb / surf_reflect / flux_at_top / flux_disk host arrays of nspec device
+ * pointers, wno / dwno shared; ubar1 (numg,numt) for ngeom = 1 or (nspec,numg,numt).  Spectrum-only form
+ * (no level fluxes).  Bit-identical per spectrum to picaso_get_thermal_1d_dev (fluxes.py:1682-1912). */
+int picaso_get_thermal_1d_batch_dev(picaso_ctx *ctx, int nspec, int nlevel, const double *wno, int nwno,
+                                    long plane_pitch, int numg, int numt, const double *tlevel,
+                                    const double *const *dtau, const double *const *w0, const double *const *cosb,
+                                    const double *plevel, int ngeom, const double *ubar1,
+                                    const double *const *surf_reflect, int hard_surface, const double *dwno,
+                                    int calc_type, double *const *flux_at_top, const double *gweight,
+                                    const double *tweight, double *const *flux_disk);
 
 /* replaces fluxes.get_thermal_3d (reference picaso/fluxes.py:2147-2352); tlevel_3d / plevel_3d are
  * (nlevel,numg,numt), planes (nlayer,nwno,numg,numt). */

@@ -114,13 +114,14 @@ static bool spread_angles(long ncol, int nang, long limit = 1280L * 64)
 // workgroups a shape may have before it doubles up: one per CU (ctx->ncu) for t1, two per CU for t2, and the
 // fused launch keeps one wave per SIMD up to 4 * ncu column-waves.  The result does not depend on the shape
 // (explicit-fma arithmetic, disk sum in the reference's order).
-static int reflected_angle_group(picaso_ctx *ctx, long ncol, int nang)
+static int reflected_angle_group(picaso_ctx *ctx, long ncol, int nang, int nspec = 1)
 {
     if (const char *e = getenv("PICASO_AMD_ANGLE_GROUP")) return atoi(e);
     if (nang <= 1) return 0;
-    if (nang > MAX_ANGLES) return spread_angles(ncol, nang, 2560L * 64) ? 1 : 0;
-    const long colwaves = (ncol + 63) / 64, ncg = (ncol + 255) / 256, ncu = ctx->ncu;
-    if (colwaves > 4L * ncu) return 0;                 // more than one fused wave per SIMD: throughput regime
+    // a batched launch: every spectrum keeps whole workgroups, so the counts are per spectrum x nspec
+    const long colwaves = ((ncol + 255) / 256) * 4 * nspec, ncg = ((ncol + 255) / 256) * nspec, ncu = ctx->ncu;
+    if (nang > MAX_ANGLES) return spread_angles(ncol * nspec, nang, 2560L * 64) ? 1 : 0;
+    if (nspec == 1 ? (ncol + 63) / 64 > 4L * ncu : colwaves > 4L * ncu) return 0;   // more than one fused wave per SIMD: throughput regime
     constexpr double T_SHARED = 0.37, T_ANGLE = 0.19, PAIRED = 1.7;       // us per layer, see above
     auto t1 = [&](int g) { return T_SHARED + g * T_ANGLE; };
     // all angles in one lane, one wave per SIMD: the state is in registers up to three angles and for five (the BIG
@@ -423,6 +424,16 @@ static ReflectedArgs::Angle make_refl_angle(double v0, double v1, double gw, dou
     return g;
 }
 
+// A batched call (picaso_get_reflected_1d_batch_dev): host arrays of nspec device pointers and the geometries
+struct ReflBatchHost {
+    int nspec;
+    const double *const *plane[11];     // dtau, tau, w0, cosb, gcos2, ftau_cld, ftau_ray, dtau_og, tau_og, w0_og, cosb_og
+    const double *const *surf_reflect, *const *F0PI;
+    double *const *xint, *const *albedo;
+    int ngeom;                          // 1: ubar0/ubar1 (numg,numt) and cos_theta[0] for every spectrum; nspec: one each
+    const double *cos_theta;
+};
+
 static int reflected_1d_core(picaso_ctx *ctx, int nlevel, int nwno, int ncolper, long plane_pitch, int numg,
                                 int numt, const double *dtau, const double *tau, const double *w0,
                                 const double *cosb, const double *gcos2, const double *ftau_cld,
@@ -436,13 +447,14 @@ static int reflected_1d_core(picaso_ctx *ctx, int nlevel, int nwno, int ncolper,
                                 double b_top, double *xint_at_top, double *flux_minus_all,
                                 double *flux_plus_all, double *flux_minus_midpt_all,
                                 double *flux_plus_midpt_all, const double *gweight,
-                                const double *tweight, double *albedo)
+                                const double *tweight, double *albedo, const ReflBatchHost *bt = nullptr)
 {
     if (!ctx) return fail(nullptr, "null context");
     if (nlevel < 2 || nwno < 1 || numg < 1 || numt < 1)
         return fail(ctx, "get_reflected_1d: bad sizes nlevel=%d nwno=%d numg=%d numt=%d", nlevel, nwno, numg, numt);
     if (!dtau || !tau || !w0 || !cosb || !gcos2 || !ftau_cld || !ftau_ray || !dtau_og || !tau_og || !w0_og || !cosb_og)
         return fail(ctx, "get_reflected_1d: all eleven planes are required");
+    const int nspec = bt ? bt->nspec : 1;
     const long ncol = (long)nwno * ncolper;
     if (plane_pitch < ncol) return fail(ctx, "get_reflected_1d: plane_pitch %ld < %ld columns", plane_pitch, ncol);
     if (ncolper > 1 && albedo)
@@ -475,6 +487,56 @@ static int reflected_1d_core(picaso_ctx *ctx, int nlevel, int nwno, int ncolper,
     const bool fuse = albedo && gweight && tweight;
     a.albedo = fuse ? albedo : nullptr;
     a.albedo_scale = ((numt == 1) ? 2.0 * 3.14159265358979323846 : 1.0) * 0.5;   // disco.py:140-141
+    // Batched launch: one table entry per spectrum with the angles [first, first + count) of this launch chunk
+    // (slot k of the chunk = reference angle first + k, or a copy of the last angle when the chunk is padded);
+    // xint rows are offset like the single launch's.  The table goes through the ring of pinned slots.
+    std::vector<ReflBatchItem> items;
+    auto upload_batch = [&](int first, int count, bool weights) -> int {
+        items.resize((size_t)nspec);
+        bool zp = true, ct1 = true;
+        for (int s = 0; s < nspec; ++s) {
+            ReflBatchItem &it = items[(size_t)s];
+            const double *const *P[11];
+            for (int j = 0; j < 11; ++j) P[j] = bt->plane[j];
+            it.dtau = P[0][s]; it.tau = P[1][s]; it.w0 = P[2][s]; it.cosb = P[3][s]; it.gcos2 = P[4][s];
+            it.ftau_cld = P[5][s]; it.ftau_ray = P[6][s]; it.dtau_og = P[7][s]; it.tau_og = P[8][s];
+            it.w0_og = P[9][s]; it.cosb_og = P[10][s];
+            it.surf_reflect = bt->surf_reflect[s]; it.F0PI = bt->F0PI[s];
+            it.xint = bt->xint[s] + (size_t)first * ncol;
+            it.albedo = (fuse && weights) ? bt->albedo[s] : nullptr;
+            it.cos_theta = bt->cos_theta[bt->ngeom > 1 ? s : 0];
+            it.u0_tab = it.u1_tab = nullptr;
+            ct1 = ct1 && it.cos_theta == 1.0;
+            const double *u0 = ubar0 + (bt->ngeom > 1 ? (size_t)s * nang : 0), *u1 = ubar1 + (bt->ngeom > 1 ? (size_t)s * nang : 0);
+            for (int k = 0; k < count; ++k) {
+                const int idx = first + k < nang ? first + k : nang - 1;
+                it.ang[k] = make_refl_angle(u0[idx], u1[idx], weights ? gweight[idx / numt] : 0.0,
+                                            weights ? tweight[idx % numt] : 0.0);
+                zp = zp && u0[idx] == u1[idx];
+            }
+        }
+        const void *d = nullptr;
+        PZ_TRY(table_upload(ctx, items.data(), sizeof(ReflBatchItem) * items.size(), &d));
+        a.batch = (const ReflBatchItem *)d;
+        a.nspec = nspec;
+        a.batch_zp = zp ? 1 : 0;
+        // the compile-time default-options kernel of the symmetric geometry fixes cos_theta = 1: only when every
+        // spectrum's is (fast_options looks at a.cos_theta)
+        a.cos_theta = ct1 ? 1.0 : bt->cos_theta[0] == 1.0 ? 2.0 : bt->cos_theta[0];
+        // every spectrum reads the same planes (one atmosphere under several geometries): XCD-sharing order
+        bool shared = nspec > 1;
+        for (int s = 1; s < nspec && shared; ++s)
+            for (int j = 0; j < 11; ++j) shared = shared && bt->plane[j][s] == bt->plane[j][0];
+        a.batch_interleave = shared ? 1 : 0;
+        return 0;
+    };
+    if (bt) {
+        if (get_lvl_flux || !get_toa_intensity)
+            return fail(ctx, "get_reflected_1d_batch: level fluxes are a per-spectrum call (get_toa_intensity=1, get_lvl_flux=0)");
+        if (sizeof(ReflBatchItem) * (size_t)nspec > picaso_ctx::SLOT_BYTES)
+            return fail(ctx, "get_reflected_1d_batch: at most %zu spectra per call", picaso_ctx::SLOT_BYTES / sizeof(ReflBatchItem));
+        if (nang > MAX_ANGLES) return fail(ctx, "get_reflected_1d_batch: at most %d disk angles", MAX_ANGLES);
+    }
     if (get_lvl_flux) {   // two-sweep kernel, one angle per launch (fluxes.py:1219-1257)
         const size_t plane = (size_t)(nlevel - 1) * ncol;
         PZ_TRY(lvl_scratch_reserve(ctx, sizeof(double) * 4 * plane));
@@ -496,7 +558,7 @@ static int reflected_1d_core(picaso_ctx *ctx, int nlevel, int nwno, int ncolper,
     // Small launches with the reference's default options: the cooperative kernel (one workgroup per 64 columns:
     // a wave for the angle-independent layer quantities, one wave per disk angle, fused disk sum), bit-identical
     // to the fused launch.  Where it stops paying: DESIGN.md section 6.
-    if (nang <= MAX_ANGLES) {
+    if (nang <= MAX_ANGLES && !bt) {
         long coop_cols = 64L * ctx->ncu;                   // one workgroup (64 columns) per CU
         if (const char *e = getenv("PICASO_AMD_REFL_COOP_COLS")) coop_cols = atol(e);
         a.na = nang;
@@ -511,7 +573,15 @@ static int reflected_1d_core(picaso_ctx *ctx, int nlevel, int nwno, int ncolper,
         }
     }
     int done = 0;
-    const int group = reflected_angle_group(ctx, ncol, nang);
+    const int group = reflected_angle_group(ctx, ncol, nang, nspec);
+    auto disk_pass = [&]() -> int {                        // separate disk sum of the angle-group shapes
+        if (!fuse) return 0;
+        if (!bt) return picaso_compress_disco_dev(ctx, nwno, cos_theta, xint_at_top, gweight, numg, tweight, numt, F0PI, albedo);
+        for (int s = 0; s < nspec; ++s)
+            PZ_TRY(picaso_compress_disco_dev(ctx, nwno, bt->cos_theta[bt->ngeom > 1 ? s : 0], bt->xint[s], gweight, numg,
+                                             tweight, numt, bt->F0PI[s], bt->albedo[s]));
+        return 0;
+    };
     if (group > 1 && group < nang && ((nang + group - 1) / group) * group <= MAX_ANGLES) {
         // Mid-size grids: groups of `group` angles per wave (grid.y), the last group padded with a copy of
         // the last angle (its extra results are not stored); disk sum as a separate pass, like below.
@@ -524,10 +594,9 @@ static int reflected_1d_core(picaso_ctx *ctx, int nlevel, int nwno, int ncolper,
             a.ang[k] = make_refl_angle(ubar0[idx], ubar1[idx], 0.0);
         }
         a.xint = xint_at_top;
+        if (bt) PZ_TRY(upload_batch(0, a.ny * group, false));
         PZ_TRY(launch_reflected_toa(ctx, a, false));
-        if (fuse)
-            PZ_TRY(picaso_compress_disco_dev(ctx, nwno, cos_theta, xint_at_top, gweight, numg, tweight, numt, F0PI, albedo));
-        return 0;
+        return disk_pass();
     }
     if (group == 1) {
         // Few columns: the chip is far from full and a lane's serial instruction stream sets the
@@ -540,12 +609,11 @@ static int reflected_1d_core(picaso_ctx *ctx, int nlevel, int nwno, int ncolper,
             a.ny = m;
             a.nvalid = m;
             a.xint = xint_at_top + (size_t)done * ncol;
+            if (bt) PZ_TRY(upload_batch(done, m, false));
             PZ_TRY(launch_reflected_toa(ctx, a, false));
             done += m;
         }
-        if (fuse)
-            PZ_TRY(picaso_compress_disco_dev(ctx, nwno, cos_theta, xint_at_top, gweight, numg, tweight, numt, F0PI, albedo));
-        return 0;
+        return disk_pass();
     }
     a.ny = 1;
     const auto chunks = angle_chunks(nang);
@@ -559,10 +627,52 @@ static int reflected_1d_core(picaso_ctx *ctx, int nlevel, int nwno, int ncolper,
         a.xint = xint_at_top + (size_t)done * ncol;
         a.albedo_first = (c == 0);
         a.albedo_last = (c + 1 == chunks.size());
+        if (bt) PZ_TRY(upload_batch(done, a.na, true));
         PZ_TRY(launch_reflected_toa(ctx, a, false));
         done += a.na;
     }
     return 0;
+}
+
+int picaso_get_reflected_1d_batch_dev(picaso_ctx *ctx, int nspec, int nlevel, int nwno, long plane_pitch, int numg,
+                                      int numt, const double *const *dtau, const double *const *tau,
+                                      const double *const *w0, const double *const *cosb,
+                                      const double *const *gcos2, const double *const *ftau_cld,
+                                      const double *const *ftau_ray, const double *const *dtau_og,
+                                      const double *const *tau_og, const double *const *w0_og,
+                                      const double *const *cosb_og, const double *const *surf_reflect, int ngeom,
+                                      const double *ubar0, const double *ubar1, const double *cos_theta,
+                                      const double *const *F0PI, int single_phase, int multi_phase, double frac_a,
+                                      double frac_b, double frac_c, double constant_back, double constant_forward,
+                                      int toon_coefficients, double b_top, double *const *xint_at_top,
+                                      const double *gweight, const double *tweight, double *const *albedo)
+{
+    if (!ctx) return fail(nullptr, "null context");
+    if (nspec < 1) return fail(ctx, "get_reflected_1d_batch: nspec must be >= 1, got %d", nspec);
+    if (ngeom != 1 && ngeom != nspec)
+        return fail(ctx, "get_reflected_1d_batch: ngeom must be 1 (one geometry for all) or nspec, got %d", ngeom);
+    const double *const *pl[11] = {dtau, tau, w0, cosb, gcos2, ftau_cld, ftau_ray, dtau_og, tau_og, w0_og, cosb_og};
+    for (int j = 0; j < 11; ++j) {
+        if (!pl[j]) return fail(ctx, "get_reflected_1d_batch: all eleven plane pointer arrays are required");
+        for (int s = 0; s < nspec; ++s)
+            if (!pl[j][s]) return fail(ctx, "get_reflected_1d_batch: plane %d of spectrum %d is NULL", j, s);
+    }
+    if (!surf_reflect || !F0PI || !xint_at_top || !ubar0 || !ubar1 || !cos_theta)
+        return fail(ctx, "get_reflected_1d_batch: null argument");
+    const bool fuse = albedo && gweight && tweight;
+    for (int s = 0; s < nspec; ++s)
+        if (!surf_reflect[s] || !F0PI[s] || !xint_at_top[s] || (fuse && !albedo[s]))
+            return fail(ctx, "get_reflected_1d_batch: null per-spectrum pointer (spectrum %d)", s);
+    ReflBatchHost bt{};
+    bt.nspec = nspec;
+    for (int j = 0; j < 11; ++j) bt.plane[j] = pl[j];
+    bt.surf_reflect = surf_reflect; bt.F0PI = F0PI; bt.xint = xint_at_top; bt.albedo = albedo;
+    bt.ngeom = ngeom; bt.cos_theta = cos_theta;
+    return reflected_1d_core(ctx, nlevel, nwno, 1, plane_pitch, numg, numt, dtau[0], tau[0], w0[0], cosb[0], gcos2[0],
+                             ftau_cld[0], ftau_ray[0], dtau_og[0], tau_og[0], w0_og[0], cosb_og[0], surf_reflect[0],
+                             ubar0, ubar1, cos_theta[0], F0PI[0], single_phase, multi_phase, frac_a, frac_b, frac_c,
+                             constant_back, constant_forward, 1, 0, toon_coefficients, b_top, xint_at_top[0], nullptr,
+                             nullptr, nullptr, nullptr, gweight, tweight, fuse ? albedo[0] : nullptr, &bt);
 }
 
 int picaso_get_reflected_1d_dev(picaso_ctx *ctx, int nlevel, int nwno, long plane_pitch, int numg,
@@ -787,6 +897,15 @@ int picaso_get_reflected_3d(picaso_ctx *ctx, int nlevel, const double *wno, int 
 /* ============================================================================================
  * thermal emission
  * ============================================================================================ */
+// A batched call (picaso_get_thermal_1d_batch_dev): host arrays of nspec device pointers; tlevel / plevel of the
+// core are then (nspec, nlevel) host tables and ubar1 (ngeom, numg, numt)
+struct ThermalBatchHost {
+    int nspec;
+    const double *const *dtau, *const *w0, *const *cosb, *const *surf_reflect;
+    double *const *flux, *const *disk;
+    int ngeom;
+};
+
 static int thermal_1d_core(picaso_ctx *ctx, int nlevel, const double *wno, int nwno, int ncolper,
                               long plane_pitch, int numg, int numt, const double *tlevel,
                               const double *dtau, const double *w0, const double *cosb,
@@ -794,12 +913,14 @@ static int thermal_1d_core(picaso_ctx *ctx, int nlevel, const double *wno, int n
                               const double *surf_reflect, int hard_surface, const double *dwno,
                               int calc_type, double *flux_at_top, double *flux_minus,
                               double *flux_plus, double *flux_minus_mdpt, double *flux_plus_mdpt,
-                              const double *gweight, const double *tweight, double *flux_disk)
+                              const double *gweight, const double *tweight, double *flux_disk,
+                              const ThermalBatchHost *bt = nullptr)
 {
     if (!ctx) return fail(nullptr, "null context");
     if (nlevel < 2 || nwno < 1 || numg < 1 || numt < 1)
         return fail(ctx, "get_thermal_1d: bad sizes nlevel=%d nwno=%d numg=%d numt=%d", nlevel, nwno, numg, numt);
     if (!dtau || !w0 || !cosb) return fail(ctx, "get_thermal_1d: dtau, w0 and cosb are required");
+    const int nspec = bt ? bt->nspec : 1;
     const long ncol = (long)nwno * ncolper;
     if (plane_pitch < ncol) return fail(ctx, "get_thermal_1d: plane_pitch %ld < %ld columns", plane_pitch, ncol);
     if (calc_type != 0 && calc_type != 1) return fail(ctx, "get_thermal_1d: calc_type must be 0 or 1");
@@ -828,7 +949,45 @@ static int thermal_1d_core(picaso_ctx *ctx, int nlevel, const double *wno, int n
     // sweeper wave per 64 columns runs the recurrence for all angles; the level temperatures travel as
     // kernel arguments).  Step time of get_thermal_1d + compress_thermal at 1e4 x 90 x 5 (BASELINE
     // configs[1]) and where it stops paying: DESIGN.md section 4.
-    if (!want_lvl) {
+    // Batched launch: the table = nspec entries followed by every spectrum's level temperatures and pressures;
+    // entry s carries the angles [first, first + count) of this launch chunk
+    std::vector<char> btab;
+    auto upload_batch = [&](int first, int count, bool weights) -> int {
+        const size_t head = align_up(sizeof(ThermalBatchItem) * (size_t)nspec, 256);
+        btab.resize(head + sizeof(double) * 2 * (size_t)nlevel * nspec);
+        if (btab.size() > picaso_ctx::SLOT_BYTES) return fail(ctx, "get_thermal_1d_batch: too many spectra for one call");
+        ThermalBatchItem *items = (ThermalBatchItem *)btab.data();
+        double *lv = (double *)(btab.data() + head);
+        for (int s = 0; s < nspec; ++s) {
+            memcpy(lv + (size_t)2 * s * nlevel, tlevel + (size_t)s * nlevel, sizeof(double) * nlevel);
+            memcpy(lv + (size_t)(2 * s + 1) * nlevel, plevel + (size_t)s * nlevel, sizeof(double) * nlevel);
+        }
+        const void *d = nullptr;
+        // device addresses of the level tables are known only after the slot is chosen: fill, then upload once
+        const int slot = ctx->ring_next;
+        const char *dbase = ctx->ring_d + (size_t)slot * picaso_ctx::SLOT_BYTES;
+        for (int s = 0; s < nspec; ++s) {
+            ThermalBatchItem &it = items[s];
+            it.dtau = bt->dtau[s]; it.w0 = bt->w0[s]; it.cosb = bt->cosb[s]; it.surf_reflect = bt->surf_reflect[s];
+            it.tlevel = (const double *)(dbase + head) + (size_t)2 * s * nlevel;
+            it.plevel = it.tlevel + nlevel;
+            it.flux = bt->flux[s] + (size_t)first * ncol;
+            it.disk = (weights && bt->disk) ? bt->disk[s] : nullptr;
+            it.u1_tab = nullptr;
+            const double *u1 = ubar1 + (bt->ngeom > 1 ? (size_t)s * nang : 0);
+            for (int k = 0; k < count; ++k) it.u1[k] = u1[first + k];
+        }
+        PZ_TRY(table_upload(ctx, btab.data(), btab.size(), &d));
+        if ((const char *)d != dbase) return fail(ctx, "get_thermal_1d_batch: table slot moved");
+        a.batch = (const ThermalBatchItem *)d;
+        a.nspec = nspec;
+        return 0;
+    };
+    if (bt) {
+        if (want_lvl) return fail(ctx, "get_thermal_1d_batch: level fluxes are a per-spectrum call");
+        if (nang > MAX_ANGLES) return fail(ctx, "get_thermal_1d_batch: at most %d disk angles", MAX_ANGLES);
+    }
+    if (!want_lvl && !bt) {
         long coop_cols = 32768;
         if (const char *e = getenv("PICASO_AMD_THERMAL_COOP_COLS")) coop_cols = atol(e);
         a.na = nang;
@@ -848,7 +1007,7 @@ static int thermal_1d_core(picaso_ctx *ctx, int nlevel, const double *wno, int n
     for (int i = 0; i < nlevel; ++i) { tab[i] = tlevel[i]; tab[nlevel + i] = plevel[i]; }
     for (int i = 0; i < nang; ++i) tab[2 * (size_t)nlevel + i] = ubar1[i];
     const void *d_tab = nullptr;
-    PZ_TRY(table_upload(ctx, tab.data(), sizeof(double) * tab.size(), &d_tab));
+    if (!bt) PZ_TRY(table_upload(ctx, tab.data(), sizeof(double) * tab.size(), &d_tab));
     a.tlevel = (const double *)d_tab; a.plevel = (const double *)d_tab + nlevel;
     if (want_lvl) {   // the reference always fills these (fluxes.py:1851-1907): two-sweep kernel
         const size_t plane = (size_t)(nlevel - 1) * ncol;
@@ -866,7 +1025,7 @@ static int thermal_1d_core(picaso_ctx *ctx, int nlevel, const double *wno, int n
         return 0;
     }
     int done = 0;
-    if (spread_angles(ncol, nang)) {             // see reflected_1d_core
+    if (spread_angles(ncol * nspec, nang)) {     // see reflected_1d_core
         a.na = 1;
         a.disk = nullptr;
         while (done < nang) {
@@ -874,11 +1033,15 @@ static int thermal_1d_core(picaso_ctx *ctx, int nlevel, const double *wno, int n
             for (int k = 0; k < m; ++k) { a.u1[k] = ubar1[done + k]; a.wgt[k] = a.wgt2[k] = 0.0; }
             a.ny = m;
             a.flux = flux_at_top + (size_t)done * ncol;
+            if (bt) PZ_TRY(upload_batch(done, m, false));
             PZ_TRY(launch_thermal_toa(ctx, a, false));
             done += m;
         }
-        if (fuse)
+        if (fuse && !bt)
             PZ_TRY(picaso_compress_thermal_dev(ctx, (size_t)nwno, flux_at_top, gweight, numg, tweight, numt, flux_disk));
+        if (fuse && bt)
+            for (int s = 0; s < nspec; ++s)
+                PZ_TRY(picaso_compress_thermal_dev(ctx, (size_t)nwno, bt->flux[s], gweight, numg, tweight, numt, bt->disk[s]));
         return 0;
     }
     a.ny = 1;
@@ -894,10 +1057,38 @@ static int thermal_1d_core(picaso_ctx *ctx, int nlevel, const double *wno, int n
         a.flux = flux_at_top + (size_t)done * ncol;
         a.disk_first = (c == 0);
         a.disk_last = (c + 1 == chunks.size());
+        if (bt) PZ_TRY(upload_batch(done, a.na, true));
         PZ_TRY(launch_thermal_toa(ctx, a, false));
         done += a.na;
     }
     return 0;
+}
+
+int picaso_get_thermal_1d_batch_dev(picaso_ctx *ctx, int nspec, int nlevel, const double *wno, int nwno,
+                                    long plane_pitch, int numg, int numt, const double *tlevel,
+                                    const double *const *dtau, const double *const *w0, const double *const *cosb,
+                                    const double *plevel, int ngeom, const double *ubar1,
+                                    const double *const *surf_reflect, int hard_surface, const double *dwno,
+                                    int calc_type, double *const *flux_at_top, const double *gweight,
+                                    const double *tweight, double *const *flux_disk)
+{
+    if (!ctx) return fail(nullptr, "null context");
+    if (nspec < 1) return fail(ctx, "get_thermal_1d_batch: nspec must be >= 1, got %d", nspec);
+    if (ngeom != 1 && ngeom != nspec)
+        return fail(ctx, "get_thermal_1d_batch: ngeom must be 1 (one geometry for all) or nspec, got %d", ngeom);
+    if (!dtau || !w0 || !cosb || !surf_reflect || !flux_at_top || !tlevel || !plevel || !ubar1)
+        return fail(ctx, "get_thermal_1d_batch: null argument");
+    const bool fuse = flux_disk && gweight && tweight;
+    for (int s = 0; s < nspec; ++s)
+        if (!dtau[s] || !w0[s] || !cosb[s] || !surf_reflect[s] || !flux_at_top[s] || (fuse && !flux_disk[s]))
+            return fail(ctx, "get_thermal_1d_batch: null per-spectrum pointer (spectrum %d)", s);
+    ThermalBatchHost bt{};
+    bt.nspec = nspec;
+    bt.dtau = dtau; bt.w0 = w0; bt.cosb = cosb; bt.surf_reflect = surf_reflect;
+    bt.flux = flux_at_top; bt.disk = fuse ? flux_disk : nullptr; bt.ngeom = ngeom;
+    return thermal_1d_core(ctx, nlevel, wno, nwno, 1, plane_pitch, numg, numt, tlevel, dtau[0], w0[0], cosb[0], plevel,
+                           ubar1, surf_reflect[0], hard_surface, dwno, calc_type, flux_at_top[0], nullptr, nullptr,
+                           nullptr, nullptr, gweight, tweight, fuse ? flux_disk[0] : nullptr, &bt);
 }
 
 int picaso_get_thermal_1d_dev(picaso_ctx *ctx, int nlevel, const double *wno, int nwno,

@@ -125,6 +125,24 @@ struct ReflectedArgs {
     double *albedo;                         // nullable; 1-D fused compress_disco accumulator
     double albedo_scale;                    // sym_fac*0.5*(cos_theta+1)
     int albedo_first, albedo_last;          // first chunk initialises, last chunk finalises (/F0PI*scale)
+    // Batched launch (picaso_get_reflected_1d_batch_dev): `nspec` spectra of the same shape and options in ONE
+    // grid.  `batch` is a device table with one entry per spectrum (its planes, outputs and geometry); the
+    // members above that the entry also holds are ignored.  Every spectrum keeps whole workgroups (bps blocks
+    // each), so a column meets the same wave-mates as in a single launch.
+    const struct ReflBatchItem *batch;      // nullptr: single spectrum
+    int nspec;
+    unsigned bps;                           // workgroups per spectrum (set by the launcher)
+    int batch_zp;                           // every angle of every spectrum has ubar0 == ubar1 (the table is on the device)
+    int batch_interleave;                   // all spectra read the SAME planes (geometries differ): the workgroups
+                                            // of one column group go to one XCD, like angle groups (ny)
+};
+struct ReflBatchItem {
+    const double *dtau, *tau, *w0, *cosb, *gcos2, *ftau_cld, *ftau_ray, *dtau_og, *tau_og, *w0_og, *cosb_og;
+    const double *surf_reflect, *F0PI;
+    double *xint, *albedo;
+    double cos_theta;
+    const double *u0_tab, *u1_tab;          // 3-D: this spectrum's (nfac) tables of ubar0, ubar1
+    ReflectedArgs::Angle ang[MAX_ANGLES];   // 1-D: this launch chunk's angles of this spectrum
 };
 int launch_reflected_toa(picaso_ctx *ctx, const ReflectedArgs &a, bool is3d);
 // cooperative kernel for small 1-D launches (toon_reflected_coop.hip): one workgroup per 64 columns, a wave for the
@@ -155,6 +173,15 @@ struct ThermalArgs {
     double *disk;                           // nullable fused compress_thermal accumulator
     double disk_scale;
     int disk_first, disk_last;
+    // batched launch (picaso_get_thermal_1d_batch_dev): grid.z = spectrum, see ReflectedArgs::batch
+    const struct ThermalBatchItem *batch;
+    int nspec;
+};
+struct ThermalBatchItem {
+    const double *dtau, *w0, *cosb, *surf_reflect, *tlevel, *plevel;
+    double *flux, *disk;
+    const double *u1_tab;                   // 3-D: (nfac) table of ubar1
+    double u1[MAX_ANGLES];                  // 1-D: this launch chunk's angles of this spectrum
 };
 int launch_thermal_toa(picaso_ctx *ctx, const ThermalArgs &a, bool is3d);
 // cooperative kernel for small 1-D launches (toon_thermal.hip): helper waves + a sweeper wave per 64 columns

@@ -349,33 +349,14 @@ __device__ __forceinline__ double disk_finish(double c1, double acc, double F, d
 // two per SIMD.
 // DRV (3-D only): some planes are NULL and re-derived in the kernel (see below); the full-plane 3-D launch keeps
 // the branch-free load sequence (the conditional loads cost the HBM-bound facet kernel 7 %)
-template <int NA, bool IS3D, bool ZP, bool FAST = false, bool BIG = false, bool DRV = false>
-__global__ __launch_bounds__(PZ_REFL_BLOCK, (BIG ? 1 : NA <= 2 ? PZ_REFL_MINWAVES_FEW : PZ_REFL_MINWAVES)) void k_reflected_toa(const ReflectedArgs a)
+// The kernel body.  `bx_in` = this workgroup's column group within its spectrum, `by_in` = its angle group,
+// `angp` = the angle table (the kernel argument's, or the batch entry's).
+template <int NA, bool IS3D, bool ZP, bool FAST, bool BIG, bool DRV, typename AnglePtr>
+__device__ __forceinline__ void reflected_toa_body(const ReflectedArgs &a, const unsigned bx_in, const unsigned by_in,
+                                                   AnglePtr angp)
 {
 #pragma clang fp contract(off)      // operations as written, see reflected_layer
-    // Angle groups as separate workgroups (ny > 1): every group re-reads the eleven planes of its columns.
-    // Consecutive workgroups go to consecutive XCDs (8, each with its own L2), so the launch is 1-D and, for
-    // the column groups that fill whole chunks of 8, block b = (chunk, angle group, column group within the
-    // chunk): the ny workgroups of one column group are dispatched 8 apart, all to XCD (column group % 8),
-    // and all but the first find the planes in that L2.  The last ncg % 8 column groups go out in plain
-    // (angle group, column group) order, which spreads their workgroups over the XCDs -- sending them after
-    // their chunk would put up to 8 x ny more workgroups on the first XCDs than on the others (12 500
-    // columns, one angle per wave: 35 on XCD 0 of 32 CUs, 0.078 ms instead of 0.050).  A 2-D (x, y) grid
-    // shares L2 only when the column-group count happens to be a multiple of 8 (12 250 columns 0.050 ms,
-    // 12 000 0.069, 12 500 0.072: tools/experiments/knee.sh).
-    unsigned bx = blockIdx.x, by = 0;
-    if (!IS3D && a.ny > 1) {
-        const unsigned ny = (unsigned)a.ny, ncg = (unsigned)a.ncg, nfull = ncg & ~7u;
-        if (bx < nfull * ny) {
-            const unsigned per = 8u * ny, chunk = bx / per, rem = bx - chunk * per;
-            by = rem >> 3;
-            bx = chunk * 8u + (rem & 7u);
-        } else {
-            const unsigned idx = bx - nfull * ny, left = ncg - nfull;
-            by = idx / left;
-            bx = nfull + (idx - by * left);
-        }
-    }
+    const unsigned bx = bx_in, by = by_in;
     const long col = bx * (long)blockDim.x + threadIdx.x;
     if (col >= a.ncol) return;
     const int nfac = IS3D ? a.nfac : 1;
@@ -406,7 +387,10 @@ __global__ __launch_bounds__(PZ_REFL_BLOCK, (BIG ? 1 : NA <= 2 ? PZ_REFL_MINWAVE
             g[k].q2 = (3.0 * ubar2 * ubar2 * v1 * v1 - 1.0) / 2.0;
             g[k].wgt = g[k].wgt2 = 0.0;
         } else {                                        // host-precomputed, wave-uniform
-            g[k] = a.ang[by * NA + k];                  // by: angle group (0 unless ny > 1)
+            const auto &src = angp[by * NA + k];        // by: angle group (0 unless ny > 1)
+            g[k].u1 = src.u1; g[k].iu0 = src.iu0; g[k].iu0sq = src.iu0sq; g[k].nl1 = src.nl1; g[k].q2 = src.q2;
+            g[k].u0 = src.u0; g[k].nl0 = src.nl0; g[k].nlm = src.nlm; g[k].wq2 = src.wq2; g[k].wgt = src.wgt;
+            g[k].wgt2 = src.wgt2;
         }
     }
     const double F = a.F0PI[w], rs = a.surf_reflect[w];
@@ -610,12 +594,79 @@ __global__ __launch_bounds__(PZ_REFL_BLOCK, (BIG ? 1 : NA <= 2 ? PZ_REFL_MINWAVE
     }
 }
 
+// Workgroup b of a 1-D grid of `nrep` replicas (angle groups, or spectra that share their planes) of `ncg` column
+// groups -> (replica, column group) in XCD-aware order, see the comment in k_reflected_toa.
+__device__ __forceinline__ void xcd_decode(unsigned b, unsigned nrep, unsigned ncg, unsigned &rep, unsigned &cg)
+{
+    const unsigned nfull = ncg & ~7u;
+    if (b < nfull * nrep) {
+        const unsigned per = 8u * nrep, chunk = b / per, rem = b - chunk * per;
+        rep = rem >> 3;
+        cg = chunk * 8u + (rem & 7u);
+    } else {
+        const unsigned idx = b - nfull * nrep, left = ncg - nfull;
+        rep = idx / left;
+        cg = nfull + (idx - rep * left);
+    }
+}
+
+template <int NA, bool IS3D, bool ZP, bool FAST = false, bool BIG = false, bool DRV = false>
+__global__ __launch_bounds__(PZ_REFL_BLOCK, (BIG ? 1 : NA <= 2 ? PZ_REFL_MINWAVES_FEW : PZ_REFL_MINWAVES)) void k_reflected_toa(const ReflectedArgs a)
+{
+    // Angle groups as separate workgroups (ny > 1): every group re-reads the eleven planes of its columns.
+    // Consecutive workgroups go to consecutive XCDs (8, each with its own L2), so the launch is 1-D and, for
+    // the column groups that fill whole chunks of 8, block b = (chunk, angle group, column group within the
+    // chunk): the ny workgroups of one column group are dispatched 8 apart, all to XCD (column group % 8),
+    // and all but the first find the planes in that L2.  The last ncg % 8 column groups go out in plain
+    // (angle group, column group) order, which spreads their workgroups over the XCDs -- sending them after
+    // their chunk would put up to 8 x ny more workgroups on the first XCDs than on the others (12 500
+    // columns, one angle per wave: 35 on XCD 0 of 32 CUs, 0.078 ms instead of 0.050).  A 2-D (x, y) grid
+    // shares L2 only when the column-group count happens to be a multiple of 8 (12 250 columns 0.050 ms,
+    // 12 000 0.069, 12 500 0.072: tools/experiments/knee.sh).
+    unsigned bx = blockIdx.x, by = 0;
+    if (!IS3D && a.ny > 1) xcd_decode(blockIdx.x, (unsigned)a.ny, (unsigned)a.ncg, by, bx);
+    reflected_toa_body<NA, IS3D, ZP, FAST, BIG, DRV>(a, bx, by, a.ang);
+}
+
+// The same body for `nspec` spectra in one grid (picaso_get_reflected_1d_batch_dev): the workgroup finds its
+// spectrum's planes, outputs and angle table in the device table a.batch.  A separate instantiation so that the
+// single-spectrum kernels keep their register allocation; same operations, same bits.
+template <int NA, bool IS3D, bool ZP, bool FAST = false, bool BIG = false, bool DRV = false>
+__global__ __launch_bounds__(PZ_REFL_BLOCK, (BIG ? 1 : NA <= 2 ? PZ_REFL_MINWAVES_FEW : PZ_REFL_MINWAVES)) void k_reflected_toa_batch(const ReflectedArgs a)
+{
+    unsigned spec, bx, by = 0;
+    const unsigned ny = a.ny > 1 ? (unsigned)a.ny : 1u;
+    if (!IS3D && a.batch_interleave) {          // shared planes: (spectrum, angle group) replicas of a column group on one XCD
+        unsigned rep;
+        xcd_decode(blockIdx.x, ny * (unsigned)a.nspec, (unsigned)a.ncg, rep, bx);
+        spec = rep / ny;
+        by = rep - spec * ny;
+    } else {
+        spec = blockIdx.x / a.bps;
+        bx = blockIdx.x - spec * a.bps;
+        if (!IS3D && ny > 1) xcd_decode(bx, ny, (unsigned)a.ncg, by, bx);
+    }
+    // The table is read through the constant address space (it is written before the launch and never by it):
+    // its entries then behave like kernel arguments -- scalar loads the compiler may repeat instead of keeping
+    // ~60 angle constants alive through the layer loop (as plain global loads they ended up in VGPRs: 98 spilled).
+    typedef const __attribute__((address_space(4))) ReflBatchItem *ItemPtr;
+    const auto &it = *((ItemPtr)(unsigned long)a.batch + spec);
+    ReflectedArgs b = a;
+    b.dtau = it.dtau; b.tau = it.tau; b.w0 = it.w0; b.cosb = it.cosb; b.gcos2 = it.gcos2; b.ftau_cld = it.ftau_cld;
+    b.ftau_ray = it.ftau_ray; b.dtau_og = it.dtau_og; b.tau_og = it.tau_og; b.w0_og = it.w0_og; b.cosb_og = it.cosb_og;
+    b.surf_reflect = it.surf_reflect; b.F0PI = it.F0PI; b.xint = it.xint; b.albedo = it.albedo;
+    b.cos_theta = it.cos_theta;
+    b.u0_tab = it.u0_tab; b.u1_tab = it.u1_tab;
+    reflected_toa_body<NA, IS3D, ZP, FAST, BIG, DRV>(b, bx, by, it.ang);
+}
+
 // the reference's default options (see reflected_layer); zp: the symmetric zero-phase geometry, where the
 // compile-time variant also fixes cos_theta = 1 -- at other phase angles (ubar0 != ubar1) cos_theta stays an argument
 static bool fast_options(const ReflectedArgs &a, bool zp)
 {
     if (getenv("PICASO_AMD_REFL_GENERIC")) return false;      // A/B switch for tools/
     if ((double)a.pitch * (a.nlayer + 1) * 8.0 >= 4294967296.0) return false;   // 32-bit plane offsets
+    // (a batched launch: a.cos_theta = 1 only if every spectrum's is)
     return a.toon_coefficients == 0 && a.single_phase == 3 && a.multi_phase == 0 && (!zp || a.cos_theta == 1.0) &&
            a.frac_c == 2.0;
 }
@@ -627,24 +678,36 @@ static int launch1d(picaso_ctx *ctx, const ReflectedArgs &a_in)
     if (a.nvalid <= 0) a.nvalid = NA * (a.ny > 1 ? a.ny : 1);     // no padded angle slots
     const int block = PZ_REFL_BLOCK;
     const unsigned ncg = (unsigned)((a.ncol + block - 1) / block), ny = (unsigned)(a.ny > 1 ? a.ny : 1);
+    const unsigned nspec = a.batch ? (unsigned)a.nspec : 1u;
     a.ncg = (int)ncg;
-    const dim3 grid(ncg * ny);                      // ny > 1: 1-D, in the XCD-aware order of the kernel
-    bool zp = true;
-    for (int k = 0; k < a.na * (int)ny; ++k) zp = zp && (a.ang[k].u0 == a.ang[k].u1);
+    a.bps = ncg * ny;
+    const dim3 grid(ncg * ny * nspec);              // ny > 1: 1-D, in the XCD-aware order of the kernel
+    bool zp = a.batch ? a.batch_zp != 0 : true;     // batch: the angle tables are on the device; the caller looked
+    if (!a.batch)
+        for (int k = 0; k < a.na * (int)ny; ++k) zp = zp && (a.ang[k].u0 == a.ang[k].u1);
     bool big = false;
-    if constexpr (NA == 5) big = a.ny <= 1 && (a.ncol + 63) / 64 <= 1024 && getenv("PICASO_AMD_REFL_NO_BIG") == nullptr;
+    if constexpr (NA == 5)
+        big = a.ny <= 1 && (long)nspec * ncg * (block / 64) <= 1024 && getenv("PICASO_AMD_REFL_NO_BIG") == nullptr;
     const bool fast = fast_options(a, zp);
-    if (zp && fast && big) {
-        if constexpr (NA == 5)
-            hipLaunchKernelGGL((k_reflected_toa<NA, false, true, true, true>), grid, dim3(block), 0, ctx->stream, a);
+#define PZ_GO(KERNEL) hipLaunchKernelGGL(KERNEL, grid, dim3(block), 0, ctx->stream, a)
+    if (a.batch) {
+        if (zp && fast && big) {
+            if constexpr (NA == 5) PZ_GO((k_reflected_toa_batch<NA, false, true, true, true>));
+        } else if (zp && fast) PZ_GO((k_reflected_toa_batch<NA, false, true, true>));
+        else if (fast && PZ_REFL_FAST_NONZP) PZ_GO((k_reflected_toa_batch<NA, false, false, true>));
+        else if (zp) PZ_GO((k_reflected_toa_batch<NA, false, true>));
+        else PZ_GO((k_reflected_toa_batch<NA, false, false>));
+    } else if (zp && fast && big) {
+        if constexpr (NA == 5) PZ_GO((k_reflected_toa<NA, false, true, true, true>));
     } else if (zp && fast)
-        hipLaunchKernelGGL((k_reflected_toa<NA, false, true, true>), grid, dim3(block), 0, ctx->stream, a);
+        PZ_GO((k_reflected_toa<NA, false, true, true>));
     else if (fast && PZ_REFL_FAST_NONZP)        // default options at a non-zero phase angle
-        hipLaunchKernelGGL((k_reflected_toa<NA, false, false, true>), grid, dim3(block), 0, ctx->stream, a);
+        PZ_GO((k_reflected_toa<NA, false, false, true>));
     else if (zp)
-        hipLaunchKernelGGL((k_reflected_toa<NA, false, true>), grid, dim3(block), 0, ctx->stream, a);
+        PZ_GO((k_reflected_toa<NA, false, true>));
     else
-        hipLaunchKernelGGL((k_reflected_toa<NA, false, false>), grid, dim3(block), 0, ctx->stream, a);
+        PZ_GO((k_reflected_toa<NA, false, false>));
+#undef PZ_GO
     PZ_HIP(ctx, hipGetLastError());
     return 0;
 }
@@ -652,6 +715,21 @@ static int launch1d(picaso_ctx *ctx, const ReflectedArgs &a_in)
 int launch_reflected_toa(picaso_ctx *ctx, const ReflectedArgs &a, bool is3d)
 {
     if (a.ncol <= 0 || a.nlayer < 1) return fail(ctx, "reflected: empty problem");
+    if (is3d && a.batch) {                         // a.tau etc.: the presence pattern of EVERY spectrum's planes
+        const int block = PZ_REFL_BLOCK;
+        ReflectedArgs b = a;
+        b.bps = (unsigned)((a.ncol + block - 1) / block);
+        b.batch_interleave = 0;
+        const dim3 grid(b.bps * (unsigned)a.nspec);
+        const bool all = a.tau && a.tau_og && a.gcos2 && a.ftau_cld && a.dtau_og;
+        if (all)
+            hipLaunchKernelGGL((k_reflected_toa_batch<1, true, false>), grid, dim3(block), 0, ctx->stream, b);
+        else
+            hipLaunchKernelGGL((k_reflected_toa_batch<1, true, false, false, false, true>), grid, dim3(block), 0,
+                               ctx->stream, b);
+        PZ_HIP(ctx, hipGetLastError());
+        return 0;
+    }
     if (is3d) {
         const int block = PZ_REFL_BLOCK;
         const long grid = (a.ncol + block - 1) / block;

@@ -220,8 +220,10 @@ __device__ __forceinline__ double thermal_surface_pos(const ThSweep &S, double B
     return fma(S.pEM, bsum, -(egr * S.delta)) / fma(-egr, S.rho, fma(-rs, S.pgam, 1.0));
 }
 
-template <int NA, bool IS3D>
-__global__ __launch_bounds__(256) void k_thermal_toa(const ThermalArgs a)
+// `u1p`: the angle table (the kernel argument's or the batch entry's); `wgt`, `wgt2`: the disk weights, always the
+// kernel argument's (indexed by the angle group, so they must not travel in a patched copy of the arguments)
+template <int NA, bool IS3D, typename U1Ptr>
+__device__ __forceinline__ void thermal_toa_body(const ThermalArgs &a, U1Ptr u1p, const double *wgt, const double *wgt2)
 {
 #pragma clang fp contract(off)
     const long col = blockIdx.x * (long)blockDim.x + threadIdx.x;
@@ -244,7 +246,7 @@ __global__ __launch_bounds__(256) void k_thermal_toa(const ThermalArgs a)
     double u1[NA], nl1[NA];                                    // nl1 = -log2(e)/u1: exp(-x/u1) = 2^(x nl1)
 #pragma unroll
     for (int k = 0; k < NA; ++k) {
-        u1[k] = IS3D ? a.u1_tab[fac] : a.u1[blockIdx.y * NA + k];   // 3-D thermal takes ubar1 as is
+        u1[k] = IS3D ? a.u1_tab[fac] : u1p[blockIdx.y * NA + k];    // 3-D thermal takes ubar1 as is
         nl1[k] = NEG_LOG2E / u1[k];
     }
     const double *p_dtau = a.dtau + col, *p_w0 = a.w0 + col, *p_cosb = a.cosb + col;
@@ -321,7 +323,7 @@ __global__ __launch_bounds__(256) void k_thermal_toa(const ThermalArgs a)
         else a.flux[(long)(blockIdx.y * NA + k) * a.ncol + col] = x;
         {   // flux + x*gweight*tweight in the reference's order, unfused (disco.py:174-176), as k_compress
             const int ia = IS3D ? 0 : blockIdx.y * NA + k;
-            disk = disk + x * a.wgt[ia] * a.wgt2[ia];
+            disk = disk + x * wgt[ia] * wgt2[ia];
         }
     }
     if (!IS3D && a.disk) {                                     // fused disco.compress_thermal
@@ -329,6 +331,27 @@ __global__ __launch_bounds__(256) void k_thermal_toa(const ThermalArgs a)
         if (a.disk_last) acc = acc * a.disk_scale;
         a.disk[w] = acc;
     }
+}
+
+template <int NA, bool IS3D>
+__global__ __launch_bounds__(256) void k_thermal_toa(const ThermalArgs a)
+{
+    thermal_toa_body<NA, IS3D>(a, a.u1, a.wgt, a.wgt2);
+}
+
+// `nspec` spectra of one shape in one grid (picaso_get_thermal_1d_batch_dev): grid.z = spectrum, whose planes,
+// level tables, outputs and angles come from the device table a.batch (read through the constant address
+// space like kernel arguments, see k_reflected_toa_batch).  Same body, same bits.
+template <int NA, bool IS3D>
+__global__ __launch_bounds__(256) void k_thermal_toa_batch(const ThermalArgs a)
+{
+    typedef const __attribute__((address_space(4))) ThermalBatchItem *ItemPtr;
+    const auto &it = *((ItemPtr)(unsigned long)a.batch + blockIdx.z);
+    ThermalArgs b = a;
+    b.dtau = it.dtau; b.w0 = it.w0; b.cosb = it.cosb; b.surf_reflect = it.surf_reflect;
+    b.tlevel = it.tlevel; b.plevel = it.plevel; b.flux = it.flux; b.disk = it.disk;
+    b.u1_tab = it.u1_tab;
+    thermal_toa_body<NA, IS3D>(b, it.u1, a.wgt, a.wgt2);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -595,8 +618,10 @@ template <int NA>
 static int launch1d(picaso_ctx *ctx, const ThermalArgs &a)
 {
     const int block = 256;
-    const dim3 grid((unsigned)((a.ncol + block - 1) / block), (unsigned)(a.ny > 1 ? a.ny : 1));
-    hipLaunchKernelGGL((k_thermal_toa<NA, false>), grid, dim3(block), 0, ctx->stream, a);
+    const dim3 grid((unsigned)((a.ncol + block - 1) / block), (unsigned)(a.ny > 1 ? a.ny : 1),
+                    a.batch ? (unsigned)a.nspec : 1u);
+    if (a.batch) hipLaunchKernelGGL((k_thermal_toa_batch<NA, false>), grid, dim3(block), 0, ctx->stream, a);
+    else hipLaunchKernelGGL((k_thermal_toa<NA, false>), grid, dim3(block), 0, ctx->stream, a);
     PZ_HIP(ctx, hipGetLastError());
     return 0;
 }
@@ -607,7 +632,11 @@ int launch_thermal_toa(picaso_ctx *ctx, const ThermalArgs &a, bool is3d)
     if (is3d) {
         const int block = 256;
         const long grid = (a.ncol + block - 1) / block;
-        hipLaunchKernelGGL((k_thermal_toa<1, true>), dim3((unsigned)grid), dim3(block), 0,
+        if (a.batch)
+            hipLaunchKernelGGL((k_thermal_toa_batch<1, true>), dim3((unsigned)grid, 1u, (unsigned)a.nspec), dim3(block),
+                               0, ctx->stream, a);
+        else
+            hipLaunchKernelGGL((k_thermal_toa<1, true>), dim3((unsigned)grid), dim3(block), 0,
                            ctx->stream, a);
         PZ_HIP(ctx, hipGetLastError());
         return 0;

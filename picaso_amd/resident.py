@@ -77,6 +77,85 @@ def thermal_1d(ctx, nlevel, wno, nwno, numg, numt, tlevel, dtau, w0, cosb, pleve
         _addr(flux_disk)), ctx)
 
 
+def _ptr_array(items):
+    """Host array of device addresses (``const double *const *`` of the batched entry points)."""
+    arr = (ctypes.c_void_p * len(items))(*[(x.addr if isinstance(x, DeviceArray) else x) for x in items])
+    return arr, ctypes.cast(arr, ctypes.POINTER(ctypes.POINTER(ctypes.c_double)))
+
+
+def _per_spectrum(x, nspec):
+    """One entry for all spectra or a list of ``nspec``."""
+    if isinstance(x, (list, tuple)):
+        if len(x) != nspec:
+            raise Exception("batched call: expected %d per-spectrum entries, got %d" % (nspec, len(x)))
+        return list(x)
+    return [x] * nspec
+
+
+def reflected_1d_batch(ctx, nlevel, nwno, numg, numt, planes, surf_reflect, ubar0, ubar1, cos_theta, F0PI,
+                       single_phase, multi_phase, frac_a, frac_b, frac_c, constant_back, constant_forward,
+                       xint_at_top, toon_coefficients=0, b_top=0.0, gweight=None, tweight=None, albedo=None,
+                       plane_pitch=None):
+    """``len(planes)`` spectra of one shape and option set in ONE launch (``picaso_get_reflected_1d_batch_dev``):
+    ``planes`` is a list of plane dictionaries as ``reflected_1d`` takes them (entries may be the same
+    dictionary: one atmosphere under several geometries), ``xint_at_top`` / ``albedo`` lists of DeviceArrays,
+    ``surf_reflect`` / ``F0PI`` one DeviceArray for all or a list.  Geometry: ``ubar0`` / ``ubar1`` ``(numg, numt)``
+    and a scalar ``cos_theta`` for all spectra, or ``(nspec, numg, numt)`` and ``nspec`` values.  Spectrum ``s``
+    of the result is bit-identical to ``reflected_1d`` on its own arguments."""
+    nspec = len(planes)
+    u0, u1 = np.asarray(ubar0, dtype=np.float64), np.asarray(ubar1, dtype=np.float64)
+    ngeom = nspec if u0.ndim == 3 else 1
+    shape = (nspec, numg, numt) if ngeom > 1 else (numg, numt)
+    u0, u1 = f64(u0, shape), f64(u1, shape)
+    ct = f64(np.zeros(ngeom) + np.asarray(cos_theta, dtype=np.float64), (ngeom,))
+    gw = f64(gweight) if gweight is not None else None
+    tw = f64(tweight) if tweight is not None else None
+    pitch = nwno if plane_pitch is None else plane_pitch
+    keep, cols = [], []
+    for k in REFLECTED_PLANES:
+        a, p = _ptr_array([pl[k] for pl in planes])
+        keep.append(a)
+        cols.append(p)
+    a_rs, p_rs = _ptr_array(_per_spectrum(surf_reflect, nspec))
+    a_f0, p_f0 = _ptr_array(_per_spectrum(F0PI, nspec))
+    a_x, p_x = _ptr_array(_per_spectrum(xint_at_top, nspec))
+    fuse = albedo is not None and gw is not None and tw is not None
+    a_al, p_al = _ptr_array(_per_spectrum(albedo, nspec)) if fuse else (None, None)
+    check(load().picaso_get_reflected_1d_batch_dev(
+        ctx, _ci(nspec), _ci(nlevel), _ci(nwno), ctypes.c_long(pitch), _ci(numg), _ci(numt), *cols, p_rs,
+        _ci(ngeom), ptr(u0), ptr(u1), ptr(ct), p_f0, _ci(single_phase), _ci(multi_phase), _cd(frac_a), _cd(frac_b),
+        _cd(frac_c), _cd(constant_back), _cd(constant_forward), _ci(toon_coefficients), _cd(b_top), p_x,
+        ptr(gw) if fuse else None, ptr(tw) if fuse else None, p_al), ctx)
+
+
+def thermal_1d_batch(ctx, nlevel, wno, nwno, numg, numt, tlevel, dtau, w0, cosb, plevel, ubar1, surf_reflect,
+                     hard_surface, flux_at_top, dwno=None, calc_type=0, gweight=None, tweight=None, flux_disk=None,
+                     plane_pitch=None):
+    """``len(dtau)`` thermal spectra in ONE launch (``picaso_get_thermal_1d_batch_dev``): ``tlevel`` / ``plevel``
+    host ``(nspec, nlevel)`` (or ``(nlevel,)`` for all), ``dtau`` / ``w0`` / ``cosb`` / ``flux_at_top`` /
+    ``flux_disk`` lists of DeviceArrays, ``surf_reflect`` one DeviceArray or a list, ``wno`` / ``dwno`` shared;
+    ``ubar1`` ``(numg, numt)`` or ``(nspec, numg, numt)``.  Bit-identical per spectrum to ``thermal_1d``."""
+    nspec = len(dtau)
+    u1 = np.asarray(ubar1, dtype=np.float64)
+    ngeom = nspec if u1.ndim == 3 else 1
+    u1 = f64(u1, (nspec, numg, numt) if ngeom > 1 else (numg, numt))
+    tl, pl = f64(tlevel, (nspec, nlevel)), f64(plevel, (nspec, nlevel))
+    gw = f64(gweight) if gweight is not None else None
+    tw = f64(tweight) if tweight is not None else None
+    pitch = nwno if plane_pitch is None else plane_pitch
+    a_dt, p_dt = _ptr_array(list(dtau))
+    a_w0, p_w0 = _ptr_array(_per_spectrum(w0, nspec))
+    a_cb, p_cb = _ptr_array(_per_spectrum(cosb, nspec))
+    a_rs, p_rs = _ptr_array(_per_spectrum(surf_reflect, nspec))
+    a_fx, p_fx = _ptr_array(_per_spectrum(flux_at_top, nspec))
+    fuse = flux_disk is not None and gw is not None and tw is not None
+    a_fd, p_fd = _ptr_array(_per_spectrum(flux_disk, nspec)) if fuse else (None, None)
+    check(load().picaso_get_thermal_1d_batch_dev(
+        ctx, _ci(nspec), _ci(nlevel), _addr(wno), _ci(nwno), ctypes.c_long(pitch), _ci(numg), _ci(numt), ptr(tl),
+        p_dt, p_w0, p_cb, ptr(pl), _ci(ngeom), ptr(u1), p_rs, _ci(int(hard_surface)), _addr(dwno), _ci(calc_type),
+        p_fx, ptr(gw) if fuse else None, ptr(tw) if fuse else None, p_fd), ctx)
+
+
 def reflected_1d_ck(ctx, nlevel, nwno, ngauss, numg, numt, planes, surf_reflect, ubar0, ubar1,
                     cos_theta, F0PI, single_phase, multi_phase, frac_a, frac_b, frac_c,
                     constant_back, constant_forward, gauss_wts, xint_at_top, toon_coefficients=0,

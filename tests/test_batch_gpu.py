@@ -1,0 +1,218 @@
+"""Batched launches (picaso_get_reflected_1d_batch_dev / picaso_get_thermal_1d_batch_dev: B spectra of one
+shape in ONE grid, SURVEY 8(f) rank 4 -- the reference runs them as separate processes, driver.py:405-426,
+justdoit.py:4741-4777, each through get_reflected_1d / get_thermal_1d, fluxes.py:1009-1413 / 1682-1912).
+
+The contract: spectrum s of a batch is bit-identical (np.array_equal) to the single call on its own arguments, for
+every launch shape the batch may take (fused five-angle waves, one wave per SIMD, angle groups, non-zero phase,
+generic options), for B distinct atmospheres, for one atmosphere under B geometries, and for mixtures; plus a
+sample of every batch against the CPU oracle."""
+import numpy as np
+import pytest
+
+from helpers import PLANES, rel_err
+
+pytestmark = pytest.mark.gpu
+TTHG = (1.0, -1.0, 2.0, -0.5, 1.0)
+
+
+def _geom(ng, phase):
+    from picaso_amd import disco
+    if phase == 0.0:
+        g, gw, t, tw = disco.get_angles_1d(ng)
+        nt = 1
+    else:
+        g, gw, t, tw = disco.get_angles_3d(ng, 2)
+        nt = 2
+    u0, u1, ct, _, _ = disco.compute_disco(len(g), nt, g, t, phase)
+    return len(g), nt, u0, u1, (1.0 if phase == 0.0 else float(ct)), gw, tw
+
+
+def _scenes(B, nlayer, nwno, seed0, **kw):
+    from picaso_amd import _lib, resident
+    from picaso_amd import synthetic as syn
+    ctx = _lib.context()
+    host, dev = [], []
+    for s in range(B):
+        sc = syn.make_scene(nlayer, nwno, seed=seed0 + s, **kw)
+        sc["F0PI"] = np.linspace(0.8 + 0.05 * s, 1.3, nwno)
+        sc["surf_reflect"] = np.full(nwno, 0.1 * (s % 3))
+        host.append(sc)
+        dev.append(resident.upload_scene(sc, resident.REFLECTED_PLANES + ("F0PI", "surf_reflect", "w0_no_raman"), ctx=ctx))
+    return ctx, host, dev
+
+
+def _single_reflected(ctx, d, nlayer, nwno, geom, opts, fuse=True):
+    from picaso_amd import device, resident
+    ng, nt, u0, u1, ct, gw, tw = geom
+    x, alb = device.DeviceArray((ng, nt, nwno), ctx), device.DeviceArray((nwno,), ctx)
+    resident.reflected_1d(ctx, nlayer + 1, nwno, ng, nt, d, d["surf_reflect"], u0, u1, ct, d["F0PI"], *opts, x,
+                          gweight=gw if fuse else None, tweight=tw if fuse else None, albedo=alb if fuse else None)
+    return x.to_host(), (alb.to_host() if fuse else None)
+
+
+def _batch_reflected(ctx, devs, nlayer, nwno, geoms, opts, fuse=True):
+    from picaso_amd import device, resident
+    B = len(devs)
+    ng, nt = geoms[0][0], geoms[0][1]
+    xs = [device.DeviceArray((ng, nt, nwno), ctx) for _ in range(B)]
+    als = [device.DeviceArray((nwno,), ctx) for _ in range(B)]
+    same = all(g is geoms[0] for g in geoms)
+    u0 = geoms[0][2] if same else np.stack([g[2] for g in geoms])
+    u1 = geoms[0][3] if same else np.stack([g[3] for g in geoms])
+    ct = geoms[0][4] if same else np.array([g[4] for g in geoms])
+    resident.reflected_1d_batch(ctx, nlayer + 1, nwno, ng, nt, devs, [d["surf_reflect"] for d in devs], u0, u1, ct,
+                                [d["F0PI"] for d in devs], *opts, xs, gweight=geoms[0][5] if fuse else None,
+                                tweight=geoms[0][6] if fuse else None, albedo=als if fuse else None)
+    return [x.to_host() for x in xs], [a.to_host() for a in als] if fuse else None
+
+
+@pytest.mark.parametrize("B", [2, 4, 7])
+@pytest.mark.parametrize("nwno", [300, 12500, 33000])
+def test_reflected_batch_equals_single_calls(B, nwno, oracle):
+    """B distinct atmospheres, default options, zero phase: 300 columns run as angle groups, 12 500 x B crosses from
+    one wave per SIMD (B = 2: the all-register kernel) to two, 33 000 x B is the throughput regime."""
+    nlayer = 90 if nwno > 1000 else 37
+    ctx, host, devs = _scenes(B, nlayer, nwno, 100 + B)
+    geom = _geom(5, 0.0)
+    opts = (3, 0, *TTHG)
+    xb, ab = _batch_reflected(ctx, devs, nlayer, nwno, [geom] * B, opts)
+    for s in range(B):
+        x1, a1 = _single_reflected(ctx, devs[s], nlayer, nwno, geom, opts)
+        assert np.array_equal(xb[s], x1), "spectrum %d of %d differs from its single call" % (s, B)
+        assert np.array_equal(ab[s], a1)
+    # oracle on a column sample of the last spectrum
+    sc = host[-1]
+    idx = np.linspace(0, nwno - 1, min(nwno, 160)).astype(int)
+    args = (nlayer + 1, sc["wno"][idx], idx.size, 5, 1, *[np.ascontiguousarray(sc[k][:, idx]) for k in PLANES],
+            sc["surf_reflect"][idx], geom[2], geom[3], 1.0, sc["F0PI"][idx], 3, 0, *TTHG)
+    xo, _ = oracle.get_reflected_1d(*args)
+    assert rel_err(xb[-1][:, :, idx], xo) < 1e-9
+
+
+@pytest.mark.parametrize("opts", [(3, 0, *TTHG), (0, 1, 0.9, -0.8, 2.0, -0.4, 0.9), (2, 0, *TTHG)])
+def test_reflected_batch_one_atmosphere_several_geometries(opts, oracle):
+    """The phase-curve form: ONE plane set, B geometries (ubar0 != ubar1, cos_theta per spectrum): the shared-plane
+    workgroup order, the non-zero-phase kernels, generic options."""
+    nlayer, nwno, B = 41, 2100, 4
+    ctx, host, devs = _scenes(1, nlayer, nwno, 7)
+    geoms = [_geom(3, ph) for ph in (0.3, 0.9, 1.6, 2.2)]
+    xb, ab = _batch_reflected(ctx, [devs[0]] * B, nlayer, nwno, geoms, opts)
+    for s in range(B):
+        x1, a1 = _single_reflected(ctx, devs[0], nlayer, nwno, geoms[s], opts)
+        assert np.array_equal(xb[s], x1)
+        assert np.array_equal(ab[s], a1)
+    sc, g = host[0], geoms[2]
+    args = (nlayer + 1, sc["wno"], nwno, g[0], g[1], *[sc[k] for k in PLANES], sc["surf_reflect"], g[2], g[3], g[4],
+            sc["F0PI"], opts[0], opts[1], *opts[2:])
+    xo, _ = oracle.get_reflected_1d(*args)
+    assert rel_err(xb[2], xo) < 1e-8
+
+
+def test_reflected_batch_mixed_zero_and_nonzero_phase():
+    """A batch whose geometries are not all symmetric runs the general-geometry kernel for every spectrum; the
+    zero-phase member must still equal its single call (which takes the symmetric-geometry kernel)."""
+    nlayer, nwno = 30, 5000
+    ctx, host, devs = _scenes(3, nlayer, nwno, 21)
+    geoms = [_geom(3, 0.7), _geom(3, 0.7), _geom(3, 0.7)]
+    # make spectrum 1 symmetric: ubar0 := ubar1, cos_theta stays what it is (not 1: the generic-cos_theta path)
+    g1 = list(geoms[1])
+    g1[2] = g1[3].copy()
+    geoms[1] = tuple(g1)
+    opts = (3, 0, *TTHG)
+    xb, ab = _batch_reflected(ctx, devs, nlayer, nwno, geoms, opts)
+    for s in range(3):
+        x1, a1 = _single_reflected(ctx, devs[s], nlayer, nwno, geoms[s], opts)
+        assert np.array_equal(xb[s], x1), s
+        assert np.array_equal(ab[s], a1), s
+
+
+@pytest.mark.parametrize("ng", [6, 8])
+def test_reflected_batch_more_than_five_angles(ng):
+    """6 and 8 disk angles: two launch chunks per batch, the disk sum continued across them per spectrum."""
+    nlayer, nwno, B = 25, 40000, 2
+    ctx, host, devs = _scenes(B, nlayer, nwno, 33)
+    geom = _geom(ng, 0.0)
+    opts = (3, 0, *TTHG)
+    xb, ab = _batch_reflected(ctx, devs, nlayer, nwno, [geom] * B, opts)
+    for s in range(B):
+        x1, a1 = _single_reflected(ctx, devs[s], nlayer, nwno, geom, opts)
+        assert np.array_equal(xb[s], x1) and np.array_equal(ab[s], a1)
+
+
+def test_reflected_batch_without_the_fused_disk_sum_and_bad_arguments():
+    from picaso_amd import _lib, device, resident
+    nlayer, nwno = 12, 700
+    ctx, host, devs = _scenes(2, nlayer, nwno, 3)
+    geom = _geom(5, 0.0)
+    opts = (3, 0, *TTHG)
+    xb, _ = _batch_reflected(ctx, devs, nlayer, nwno, [geom] * 2, opts, fuse=False)
+    for s in range(2):
+        x1, _ = _single_reflected(ctx, devs[s], nlayer, nwno, geom, opts, fuse=False)
+        assert np.array_equal(xb[s], x1)
+    with pytest.raises(_lib.PicasoHipError, match="single_phase"):
+        _batch_reflected(ctx, devs, nlayer, nwno, [geom] * 2, (9, 0, *TTHG))
+    with pytest.raises(Exception, match="per-spectrum"):
+        x = [device.DeviceArray((5, 1, nwno), ctx)]
+        resident.reflected_1d_batch(ctx, nlayer + 1, nwno, 5, 1, devs, devs[0]["surf_reflect"], geom[2], geom[3], 1.0,
+                                    devs[0]["F0PI"], *opts, x)
+
+
+def _single_thermal(ctx, sc, d, wno_d, nlayer, nwno, geom, hard):
+    from picaso_amd import device, resident
+    ng, nt, u0, u1, ct, gw, tw = geom
+    f, disk = device.DeviceArray((ng, nt, nwno), ctx), device.DeviceArray((nwno,), ctx)
+    resident.thermal_1d(ctx, nlayer + 1, wno_d, nwno, ng, nt, sc["tlevel"], d["dtau_og"], d["w0_no_raman"], d["cosb_og"],
+                        sc["plevel"], u1, d["surf_reflect"], hard, f, gweight=gw, tweight=tw, flux_disk=disk)
+    return f.to_host(), disk.to_host()
+
+
+@pytest.mark.parametrize("B", [2, 4, 7])
+@pytest.mark.parametrize("nwno", [400, 10000, 30000])
+def test_thermal_batch_equals_single_calls(B, nwno, oracle):
+    """B atmospheres with their own level temperatures; 1e4 columns is BASELINE configs[1]'s size (the single call
+    takes the cooperative kernel there, the batch the lane-per-column one: same bits)."""
+    from picaso_amd import device, resident
+    nlayer = 90 if nwno > 1000 else 33
+    ctx, host, devs = _scenes(B, nlayer, nwno, 50 + B)
+    for s, sc in enumerate(host):
+        sc["tlevel"] = sc["tlevel"] * (1.0 + 0.03 * s)
+    geom = _geom(5, 0.0)
+    ng, nt, u0, u1, ct, gw, tw = geom
+    wno_d = device.DeviceArray.from_host(host[0]["wno"], ctx)
+    fs = [device.DeviceArray((ng, nt, nwno), ctx) for _ in range(B)]
+    ds = [device.DeviceArray((nwno,), ctx) for _ in range(B)]
+    resident.thermal_1d_batch(ctx, nlayer + 1, wno_d, nwno, ng, nt, np.stack([sc["tlevel"] for sc in host]),
+                              [d["dtau_og"] for d in devs], [d["w0_no_raman"] for d in devs],
+                              [d["cosb_og"] for d in devs], np.stack([sc["plevel"] for sc in host]), u1,
+                              [d["surf_reflect"] for d in devs], 0, fs, gweight=gw, tweight=tw, flux_disk=ds)
+    for s in range(B):
+        f1, d1 = _single_thermal(ctx, host[s], devs[s], wno_d, nlayer, nwno, geom, 0)
+        assert np.array_equal(fs[s].to_host(), f1), s
+        assert np.array_equal(ds[s].to_host(), d1), s
+    sc = host[-1]
+    idx = np.linspace(0, nwno - 1, min(nwno, 128)).astype(int)
+    targs = (nlayer + 1, sc["wno"][idx], idx.size, 5, 1, sc["tlevel"], np.ascontiguousarray(sc["dtau_og"][:, idx]),
+             np.ascontiguousarray(sc["w0_no_raman"][:, idx]), np.ascontiguousarray(sc["cosb_og"][:, idx]), sc["plevel"],
+             u1, sc["surf_reflect"][idx], 0, sc["wno"][idx] * 0, 0)
+    fo, _ = oracle.get_thermal_1d(*targs)
+    assert rel_err(fs[-1].to_host()[:, :, idx], fo) < 1e-9
+
+
+def test_thermal_batch_several_geometries_hard_surface():
+    from picaso_amd import device, resident
+    nlayer, nwno, B = 20, 3000, 3
+    ctx, host, devs = _scenes(B, nlayer, nwno, 77)
+    geoms = [_geom(3, ph) for ph in (0.2, 1.0, 1.9)]
+    ng, nt = geoms[0][0], geoms[0][1]
+    wno_d = device.DeviceArray.from_host(host[0]["wno"], ctx)
+    fs = [device.DeviceArray((ng, nt, nwno), ctx) for _ in range(B)]
+    ds = [device.DeviceArray((nwno,), ctx) for _ in range(B)]
+    resident.thermal_1d_batch(ctx, nlayer + 1, wno_d, nwno, ng, nt, np.stack([sc["tlevel"] for sc in host]),
+                              [d["dtau_og"] for d in devs], [d["w0_no_raman"] for d in devs],
+                              [d["cosb_og"] for d in devs], np.stack([sc["plevel"] for sc in host]),
+                              np.stack([g[3] for g in geoms]), [d["surf_reflect"] for d in devs], 1, fs,
+                              gweight=geoms[0][5], tweight=geoms[0][6], flux_disk=ds)
+    for s in range(B):
+        f1, d1 = _single_thermal(ctx, host[s], devs[s], wno_d, nlayer, nwno, geoms[s], 1)
+        assert np.array_equal(fs[s].to_host(), f1), s
+        assert np.array_equal(ds[s].to_host(), d1), s
