@@ -66,14 +66,15 @@ def kernel_source_hash():
 # workloads: each returns a dict with solve(), the local result DeviceArray, algorithmic bytes of
 # the local launch, and how to check the result against the CPU oracle
 # ---------------------------------------------------------------------------------------------
-def workload_reflected(ctx, args, lo, hi, seed, nwno_total):
+def workload_reflected(ctx, args, lo, hi, seed, nwno_total, scene=None):
     """configs[2]: get_reflected_1d + compress_disco (9 layer planes + 2 level planes +
     F0PI + surf_reflect read once, xint_at_top and albedo written once)."""
     nlayer, nlevel, ng = args.nlayer, args.nlayer + 1, args.ngauss
     n = hi - lo
     gang, gw, tang, tw = disco.get_angles_1d(ng)
     ubar0, ubar1, _, _, _ = disco.compute_disco(ng, 1, gang, tang, 0.0)
-    scene = syn.make_scene(nlayer, nwno_total, seed=seed)
+    if scene is None:
+        scene = syn.make_scene(nlayer, nwno_total, seed=seed)
     scene["F0PI"] = np.ones(nwno_total)
     scene["surf_reflect"] = np.zeros(nwno_total)
     keys = resident.REFLECTED_PLANES + ("F0PI", "surf_reflect")
@@ -92,7 +93,28 @@ def workload_reflected(ctx, args, lo, hi, seed, nwno_total):
                                      np.ones(ns), 3, 0, *TTHG)
         return orc.compress_disco(ns, 1.0, xo, gw, tw, np.ones(ns))
 
-    return dict(solve=solve, oracle=oracle, nloc=n,
+    def solve_batch(B):
+        """B plane sets in ONE launch (picaso_get_reflected_1d_batch_dev): set 0 is the headline's, sets 1..B-1 are
+        copies of it in their own HBM allocations (B x 0.8 GB read per launch; generating B distinct 1e5 x 90
+        scenes on the host would take the bench tens of seconds).  Returns (launch, per-spectrum albedo arrays)."""
+        import ctypes as _ct
+        sets = [d]
+        for _ in range(1, B):
+            c = {}
+            for k in keys:
+                c[k] = device.DeviceArray(d[k].shape, ctx)
+                _lib.check(_lib.load().picaso_memcpy_d2d(ctx, _ct.c_void_p(c[k].addr), _ct.c_void_p(d[k].addr),
+                                                         _ct.c_size_t(d[k].nbytes)), ctx)
+            sets.append(c)
+        xs = [device.DeviceArray((ng, 1, n), ctx) for _ in range(B)]
+        albs = [device.DeviceArray((n,), ctx) for _ in range(B)]
+
+        def launch():
+            resident.reflected_1d_batch(ctx, nlevel, n, ng, 1, sets, [x["surf_reflect"] for x in sets], ubar0, ubar1, 1.0,
+                                        [x["F0PI"] for x in sets], 3, 0, *TTHG, xs, gweight=gw, tweight=tw, albedo=albs)
+        return launch, albs
+
+    return dict(solve=solve, oracle=oracle, nloc=n, scene=scene, solve_batch=solve_batch,
                 abytes=8 * n * (9 * nlayer + 2 * nlevel + 2 + ng + 1),
                 # launches of at most one 64-column block per CU (256 CUs) run the cooperative kernel (api.hip)
                 kernel=("k_reflected_coop<true>" if n <= 16384 and ng <= 5 and not os.environ.get("PICASO_AMD_REFL_NO_COOP")
@@ -102,14 +124,15 @@ def workload_reflected(ctx, args, lo, hi, seed, nwno_total):
                 metric="spectra/sec (1e5 wave x 90 layer reflected)")
 
 
-def workload_thermal(ctx, args, lo, hi, seed, nwno_total):
+def workload_thermal(ctx, args, lo, hi, seed, nwno_total, scene=None):
     """configs[1]: get_thermal_1d + compress_thermal (3 layer planes + wno + surf_reflect in, flux +
     disk flux out)."""
     nlayer, nlevel, ng = args.nlayer, args.nlayer + 1, args.ngauss
     n = hi - lo
     gang, gw, tang, tw = disco.get_angles_1d(ng)
     _, ubar1, _, _, _ = disco.compute_disco(ng, 1, gang, tang, 0.0)
-    scene = syn.make_scene(nlayer, nwno_total, seed=seed)
+    if scene is None:
+        scene = syn.make_scene(nlayer, nwno_total, seed=seed)
     scene["surf_reflect"] = np.zeros(nwno_total)
     scene["dwno"] = scene["wno"] * 0
     d = resident.upload_scene(scene, ("dtau_og", "w0_no_raman", "cosb_og", "wno", "dwno", "surf_reflect"), lo, hi,
@@ -131,20 +154,35 @@ def workload_thermal(ctx, args, lo, hi, seed, nwno_total):
                                    np.zeros(ns), 0, scene["wno"][sl] * 0, 0)
         return orc.compress_thermal(ns, fo, gw, tw)
 
-    return dict(solve=solve, oracle=oracle, nloc=n, abytes=8 * n * (3 * nlayer + 3 + ng + 1),
+    def solve_batch(B):
+        """B thermal spectra in ONE launch (picaso_get_thermal_1d_batch_dev): the planes of the one scene under B
+        level-temperature profiles (T scaled by 1 + 0.01 s), each with its own outputs."""
+        fl = [device.DeviceArray((ng, 1, n), ctx) for _ in range(B)]
+        dk = [device.DeviceArray((n,), ctx) for _ in range(B)]
+        tl = np.stack([scene["tlevel"] * (1.0 + 0.01 * s) for s in range(B)])
+        pl = np.stack([scene["plevel"]] * B)
+
+        def launch():
+            resident.thermal_1d_batch(ctx, nlevel, d["wno"], n, ng, 1, tl, [d["dtau_og"]] * B, d["w0_no_raman"],
+                                      d["cosb_og"], pl, ubar1, d["surf_reflect"], 0, fl, dwno=d["dwno"], calc_type=0,
+                                      gweight=gw, tweight=tw, flux_disk=dk)
+        return launch, dk
+
+    return dict(solve=solve, oracle=oracle, nloc=n, abytes=8 * n * (3 * nlayer + 3 + ng + 1), solve_batch=solve_batch,
                 kernel=("k_thermal_coop<%d>" if n <= 32768 else "k_thermal_toa<%d, false>") % ng,
                 workload="BASELINE configs[1]: thermal emission (get_thermal_1d + compress_thermal), "
                          "Planck per level, 5 Gauss angles",
                 metric="spectra/sec (%d wave x %d layer thermal)" % (nwno_total, nlayer))
 
 
-def workload_sh4(ctx, args, lo, hi, seed, nwno_total):
+def workload_sh4(ctx, args, lo, hi, seed, nwno_total, scene=None):
     """configs[3]: get_reflected_SH, stream = 4, + compress_disco."""
     nlayer, nlevel, ng = args.nlayer, args.nlayer + 1, args.ngauss
     n = hi - lo
     gang, gw, tang, tw = disco.get_angles_1d(ng)
     ubar0, ubar1, _, _, _ = disco.compute_disco(ng, 1, gang, tang, 0.0)
-    scene = syn.make_scene(nlayer, nwno_total, seed=seed, stream=4)
+    if scene is None:
+        scene = syn.make_scene(nlayer, nwno_total, seed=seed, stream=4)
     scene["F0PI"] = np.ones(nwno_total)
     scene["surf_reflect"] = np.zeros(nwno_total)
     d = resident.upload_scene(scene, resident.SH_PLANES + ("F0PI", "surf_reflect"), lo, hi, ctx=ctx)
@@ -172,7 +210,7 @@ def workload_sh4(ctx, args, lo, hi, seed, nwno_total):
                 metric="spectra/sec (%d wave x %d layer SH4 reflected)" % (nwno_total, nlayer))
 
 
-def workload_3d(ctx, args, lo, hi, seed, nwno_total):
+def workload_3d(ctx, args, lo, hi, seed, nwno_total, scene=None):
     """configs[4]: get_reflected_3d on 8x8 facets + compress_disco; facet index fastest in memory.  The 64 facet
     plane sets are generated ON THE DEVICE: every (nlayer, n) base plane is uploaded once and tiled
     over the facets by picaso_broadcast_facets_dev, the optical-depth planes times a per-facet factor -- at the
@@ -265,6 +303,115 @@ def spawn_ranks(ngpus):
     return rc if rc >= 0 else 1
 
 
+def steady_ms(ctx, launch, steps, prewarm_ms=60.0):
+    """HIP-event time per launch in the steady clock state: `prewarm_ms` of the same launches first, no idle gap."""
+    t0 = time.perf_counter()
+    while (time.perf_counter() - t0) * 1e3 < prewarm_ms:
+        for _ in range(10):
+            launch()
+        device.sync(ctx)
+    for _ in range(10):
+        launch()
+    device.timer_start(ctx)
+    for _ in range(steps):
+        launch()
+    return device.timer_stop(ctx) / steps
+
+
+def companions(ctx, args, wl, res_single, nwno_total):
+    """Untimed by the driver, after the timed region of the default line (N = 1, BASELINE configs[2]):
+
+    throughput_batched -- the SAME workload, `--batch` plane sets per launch (picaso_get_reflected_1d_batch_dev),
+        every member checked bit for bit against the single-spectrum result of the timed region;
+    secondary -- the other BASELINE configurations on this box's clock: configs[1] (thermal 1e4 x 90), its batched
+        form, configs[3] (SH4 1e5 x 90), the 12 500-column per-GPU shards of configs[2] and configs[4]; each with its
+        kernel, algorithmic bytes, HBM fraction and the error against the CPU oracle on <= 256 columns.
+    profiles/ holds the rocprofv3 kernel stats of the same command."""
+    extra = {}
+    t_all = time.perf_counter()
+    B = max(2, args.batch)
+    launch, albs = wl["solve_batch"](B)
+    ms = steady_ms(ctx, launch, max(10, 200 // B), prewarm_ms=150.0)
+    same = all(bool(np.array_equal(a.to_host(), res_single)) for a in albs)
+    per = ms / B
+    extra["throughput_batched"] = {
+        "value": 1e3 / per, "unit": "spectra/s", "batch": B, "ms_per_launch": ms, "ms_per_spectrum": per,
+        "roofline_frac": wl["abytes"] / (per * 1e-3) / 1e9 / HBM_PEAK_GBS,
+        "bit_identical_to_single_launch": same,
+        "what": "%d plane sets of the headline workload (set 0 + %d copies in their own HBM allocations) in one "
+                "launch of k_reflected_toa_batch; HIP events, steady clocks, after the timed region" % (B, B - 1)}
+    if not same:
+        print("bench.py: CHECK FAILED: a member of the batched launch differs from the single launch", file=sys.stderr)
+    del launch, albs
+    # The launch is 391 workgroups per spectrum on 512 resident slots: B = 4 is 3.05 generations (the last one 28
+    # workgroups), B = 8 is 6.1 -- the same kernel at a batch size whose tail weighs half as much
+    B2 = 2 * B
+    launch, albs = wl["solve_batch"](B2)
+    ms = steady_ms(ctx, launch, max(10, 200 // B2), prewarm_ms=100.0)
+    extra["throughput_batched"]["batch_%d" % B2] = {
+        "value": 1e3 * B2 / ms, "ms_per_spectrum": ms / B2,
+        "roofline_frac": wl["abytes"] / (ms / B2 * 1e-3) / 1e9 / HBM_PEAK_GBS,
+        "bit_identical_to_single_launch": all(bool(np.array_equal(a.to_host(), res_single)) for a in albs)}
+    del launch, albs
+
+    def entry(w, ms_, n_oracle=256, res=None):
+        e = {"ms": ms_, "kernel": w["kernel"], "algorithmic_bytes": w["abytes"],
+             "frac": w["abytes"] / (ms_ * 1e-3) / 1e9 / HBM_PEAK_GBS, "workload": w["workload"]}
+        if w.get("oracle") is not None and res is not None:
+            ns = min(n_oracle, w["nloc"], w.get("oracle_sample", n_oracle))
+            cpu = w["oracle"](slice(0, ns))
+            e["max_rel_err_vs_oracle"] = float(np.max(np.abs(res[:ns] - cpu) / np.abs(cpu)))
+            e["oracle_columns"] = ns
+        return e
+
+    sec = {}
+    scene = wl["scene"]
+    # configs[1]: thermal emission, 1e4 x 90 (single launch: the cooperative kernel) and 16 spectra per launch
+    a1 = argparse.Namespace(**vars(args))
+    w1 = workload_thermal(ctx, a1, 0, 10000, 3, 10000)
+    out1 = device.DeviceArray((10000,), ctx)
+    ms1 = steady_ms(ctx, lambda: w1["solve"](out1), 300)
+    sec["configs[1]"] = entry(w1, ms1, res=out1.to_host())
+    launch1, dk = w1["solve_batch"](16)
+    msb = steady_ms(ctx, launch1, 60) / 16
+    first = dk[0].to_host()
+    sec["configs[1] x16 batched"] = {
+        "ms": msb, "kernel": "k_thermal_toa_batch<5, false>", "algorithmic_bytes": w1["abytes"],
+        "frac": w1["abytes"] / (msb * 1e-3) / 1e9 / HBM_PEAK_GBS,
+        "bit_identical_to_single_launch": bool(np.array_equal(first, out1.to_host())),
+        "workload": "configs[1], 16 level-temperature profiles per launch (picaso_get_thermal_1d_batch_dev); ms per spectrum"}
+    del launch1, dk, w1
+    # configs[2], the 12 500-column block one of 8 GPUs solves
+    w2 = workload_reflected(ctx, args, 0, 12500, 3, nwno_total, scene=scene)
+    out2 = device.DeviceArray((12500,), ctx)
+    ms2 = steady_ms(ctx, lambda: w2["solve"](out2), 300)
+    sec["configs[2] 12500-column shard"] = entry(w2, ms2, res=out2.to_host())
+    sec["configs[2] 12500-column shard"]["bit_identical_to_unsharded"] = bool(np.array_equal(out2.to_host(), res_single[:12500]))
+    del w2
+    # configs[3]: SH4 reflected, 1e5 x 90: the same optical-depth components mixed for stream = 4
+    sc4 = syn.mix_planes(scene["taugas"], scene["tauray"], scene["taucld"], scene["w0_cld"], scene["g0_cld"], stream=4)
+    sc4["wno"] = scene["wno"]
+    w3 = workload_sh4(ctx, args, 0, nwno_total, 3, nwno_total, scene=sc4)
+    out3 = device.DeviceArray((nwno_total,), ctx)
+    ms3 = steady_ms(ctx, lambda: w3["solve"](out3), 40, prewarm_ms=100.0)
+    sec["configs[3]"] = entry(w3, ms3, n_oracle=128, res=out3.to_host())
+    w3s = workload_sh4(ctx, args, 0, 12500, 3, nwno_total, scene=sc4)
+    out3s = device.DeviceArray((12500,), ctx)
+    ms3s = steady_ms(ctx, lambda: w3s["solve"](out3s), 150)
+    sec["configs[3] 12500-column shard"] = entry(w3s, ms3s)
+    sec["configs[3] 12500-column shard"]["bit_identical_to_unsharded"] = bool(np.array_equal(out3s.to_host(), out3.to_host()[:12500]))
+    del w3, w3s, sc4
+    # configs[4]: 64 facets x 90 layers, the 12 500-wavelength block one of 8 GPUs holds
+    w4 = workload_3d(ctx, args, 0, 12500, 3, 12500)
+    out4 = device.DeviceArray((12500,), ctx)
+    ms4 = steady_ms(ctx, lambda: w4["solve"](out4), 40, prewarm_ms=100.0)
+    sec["configs[4] 12500-column shard"] = entry(w4, ms4, n_oracle=64, res=out4.to_host())
+    del w4
+    extra["secondary"] = sec
+    extra["secondary_seconds"] = time.perf_counter() - t_all
+    return extra
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -284,6 +431,10 @@ def main():
                     help="wavelengths of the same workload timed on the CPU oracle (0 = skip)")
     ap.add_argument("--steady-steps", type=int, default=2000,
                     help="N = 1: steps of an extra untimed run after the timed region, reported as steady_state")
+    ap.add_argument("--secondary", type=int, default=1,
+                    help="N = 1, default workload: after the timed region also time the batched launch of the same "
+                         "workload (throughput_batched) and the other BASELINE configurations (secondary); 0 = skip")
+    ap.add_argument("--batch", type=int, default=4, help="spectra per launch of the throughput_batched companion")
     ap.add_argument("--spawn", action="store_true",
                     help="start the ranks as subprocesses also for --gpus 1 (the N > 1 code path -- rendezvous, RCCL "
                          "communicator, gather in the timed region, checks -- with one rank, on a 1-GPU box)")
@@ -531,6 +682,8 @@ def main():
             for _ in range(50):
                 step()
             out["steady_state"] = {"steps": nst, "ms_per_step": timed(nst)}
+        if world == 1 and args.config == 2 and args.secondary and args.scaling == "strong":
+            out.update(companions(ctx, args, wl, res_local, nwno_total))
         if valu:
             # second ceiling: the kernel is FP64-VALU bound.  PMC instruction count of this launch shape
             # (profiles/) over the live kernel time, against the fp64 issue rate measured on an MI355X

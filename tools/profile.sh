@@ -8,7 +8,7 @@ export TMPDIR=/tmp
 ROOT=$PWD
 # the trace run is the bench line as the driver runs it; PMC passes serialise kernels and need no ramp
 CMD="python $ROOT/bench.py --steps 20 --warmup 5 --cpu-sample 0 $*"
-PMC="python $ROOT/bench.py --steps 6 --warmup 2 --prewarm-ms 0 --cpu-sample 0 --steady-steps 0 $*"
+PMC="python $ROOT/bench.py --steps 6 --warmup 2 --prewarm-ms 0 --cpu-sample 0 --steady-steps 0 --secondary 0 $*"
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- $CMD > $OUT/trace.log 2>&1
 for pass in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES" \
