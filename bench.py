@@ -303,6 +303,14 @@ def spawn_ranks(ngpus):
     return rc if rc >= 0 else 1
 
 
+def orc_flags():
+    try:
+        from oracle import oracle as orc
+        return orc.build_flags()
+    except Exception as exc:
+        return "unknown (%s)" % exc
+
+
 def steady_ms(ctx, launch, steps, prewarm_ms=60.0):
     """HIP-event time per launch in the steady clock state: `prewarm_ms` of the same launches first, no idle gap."""
     t0 = time.perf_counter()
@@ -703,7 +711,7 @@ def main():
                 "value": (ns / nwno_total) / cpu_s, "unit": "spectra/s", "cores": 1, "kind": "port",
                 "sample": "%d of %d wavelengths of the same scene, oracle/ C restatement of the reference's "
                           "serial numba path on one core, %.1f s" % (ns, nwno_total, cpu_s),
-                "host_cores_available": ncores}
+                "host_cores_available": ncores, "flags": orc_flags()}
             out["max_rel_err_vs_oracle"] = err
             # the same C restatement on ALL host cores: wavelength blocks on a thread pool (the ctypes
             # calls release the GIL; the reference itself is serial, so this is an upper bound on what

@@ -16,12 +16,39 @@ _LIB = None
 _dp = ctypes.POINTER(ctypes.c_double)
 
 
+def _host_stamp():
+    """What -march=native resolved to depends on the CPU: model name + ISA flags of this host."""
+    import hashlib
+    try:
+        with open("/proc/cpuinfo") as fh:
+            lines = [ln for ln in fh.read().splitlines() if ln.startswith(("model name", "flags"))][:2]
+    except OSError:
+        lines = []
+    import platform
+    return hashlib.sha1(("\n".join(lines) + platform.machine()).encode()).hexdigest()[:16]
+
+
 def build(force=False):
     so = os.path.join(_HERE, "libpicaso_oracle.so")
+    stamp = so + ".host"
     srcs = [os.path.join(_HERE, f) for f in ("picaso_oracle.c", "sh_oracle.c", "mix_oracle.c", "Makefile")]
-    if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in srcs):
-        subprocess.check_call(["make", "-C", _HERE, "-s", "-B"])
+    here = _host_stamp()
+    try:
+        with open(stamp) as fh:
+            built_on = fh.read().strip()
+    except OSError:
+        built_on = ""
+    if force or not os.path.exists(so) or built_on != here or \
+            os.path.getmtime(so) < max(os.path.getmtime(f) for f in srcs):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "all"])
+        with open(stamp, "w") as fh:
+            fh.write(here + "\n")
     return so
+
+
+def build_flags():
+    """The compiler command line of the CPU baseline (``make flags``), for bench.py's cpu_baseline entry."""
+    return subprocess.check_output(["make", "-C", _HERE, "-s", "flags"]).decode().strip()
 
 
 def lib():

@@ -228,10 +228,17 @@ def bin_star(wno_new, wno_old, Fp):
     lo = np.searchsorted(wno_old, lo_edge, side="left")           # wno_old >= edge
     lo[0] = np.searchsorted(wno_old, lo_edge[0], side="right")    # first bin: wno_old > edge
     hi = np.searchsorted(wno_old, hi_edge, side="left")           # wno_old < edge
-    cs = np.concatenate(([0.0], np.cumsum(Fp)))
+    # The bin means with the reference's own rounding: np.mean of the bin's points.  Bins are grouped by their
+    # point count c and every group is one (nbins_c, c) gather reduced along its contiguous axis -- numpy sums each
+    # row exactly as it sums the 1-D slice the reference hands to np.mean.  (A difference of running sums, as used
+    # until round 3, loses relative precision in the faint bins of a steep spectrum; np.add.reduceat rounds
+    # differently from np.mean from three points on.)
     cnt = hi - lo
-    with np.errstate(invalid="ignore", divide="ignore"):
-        return np.where(cnt > 0, (cs[hi] - cs[lo]) / cnt, np.nan)
+    out = np.full(n, np.nan)
+    for c in np.unique(cnt[cnt > 0]):
+        sel = np.nonzero(cnt == c)[0]
+        out[sel] = np.mean(Fp[lo[sel][:, None] + np.arange(c)[None, :]], axis=1)
+    return out
 
 
 def create_grid(min_wavelength, max_wavelength, constant_R):
@@ -738,6 +745,8 @@ class inputs:
                 cache[tuple(devs)] = [optics.shard_opacity(opacityclass, 0, opacityclass.nwno, c)
                                       for c in _device_contexts(devs, opacityclass.ctx)]
             replicas = cache[tuple(devs)]
+            for rep in replicas:               # star() / query_method / raman_db may have changed since the copy
+                optics.resync_shard(rep, opacityclass, 0, opacityclass.nwno)
         # Every phase is enqueued before the first result is copied back: the GPU runs the phases back to
         # back while the host sets up the next one (one facet-form ATMSETUP and one batched gas stage per
         # phase), and the copies back (each a stream synchronisation) come at the end.  The input planes
@@ -846,12 +855,13 @@ def _resident_vector(opa, name, value, nwno):
     hit = cache.get(name)
     if np.ndim(value) == 0:                        # a scalar: compared as one (no 1e5-element array per call)
         key = float(value)
-        if hit is not None and hit[2] == ("scalar", key, nwno):
+        # (the tag of an array entry is the ndarray itself: compare tuples only)
+        if hit is not None and isinstance(hit[2], tuple) and hit[2] == ("scalar", key, nwno):
             return hit[1]
         a = np.full(nwno, key)
         tag = ("scalar", key, nwno)
     else:
-        if name == "wno" and hit is not None and hit[2] is value:    # the opacity object's own grid: never edited
+        if name == "wno" and hit is not None and not isinstance(hit[2], tuple) and hit[2] is value:    # the opacity object's own grid: never edited
             return hit[1]
         a = np.ascontiguousarray(np.zeros(nwno) + np.asarray(value, dtype=float))
         if hit is not None and hit[0] is not None and hit[0].shape == a.shape and np.array_equal(hit[0], a):
@@ -1319,6 +1329,8 @@ def _opacity_shards(opa, devs):
         if bounds[-1][1] - bounds[-1][0] < 1:
             raise Exception("devices=%d but the grid has only %d wavelengths" % (len(devs), opa.nwno))
         cache[key] = [(lo, hi, optics.shard_opacity(opa, lo, hi, c)) for (lo, hi), c in zip(bounds, ctxs)]
+    for lo, hi, sh in cache[key]:          # star() / query_method / raman_db may have changed since the cut
+        optics.resync_shard(sh, opa, lo, hi)
     return cache[key]
 
 
@@ -1440,9 +1452,13 @@ def _picaso_devices(bundle, opa, devices, gather, dimension, calculation, full_o
         if len(set(devs)) != len(devs):
             raise Exception("gather='rccl' takes every device at most once (RCCL: one rank per device)")
         group = sharding.device_group(devs)
-        for f in fins:                                   # a leg that ran on the block's second stream
-            if f.tctx is not f.ctx:
+        for f, gctx in zip(fins, group.ctxs):
+            if f.tctx is not f.ctx:                      # a leg that ran on the block's second stream
                 _lib.ctx_wait(f.ctx, f.tctx)
+            # the group posts device i's collective on the process's default context of that device; a block that
+            # ran on another context (an opacity object built on new_context()) is ordered in front of it
+            if getattr(gctx, "value", gctx) != getattr(f.ctx, "value", f.ctx):
+                _lib.ctx_wait(gctx, f.ctx)
         for key in fins[0].dev:
             fulls = [DeviceArray((nwno,), f.ctx) for f in fins]
             group.all_gather_spectrum([f.dev[key] for f in fins], fulls, nwno)

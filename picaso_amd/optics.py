@@ -545,6 +545,10 @@ def read_ck_tables(path, preload_gases=None, refdata=None):
             out["nc_p"] = np.array([int(np.sum(t_all == t)) for t in np.unique(t_all)])
             out["gauss_pts"], out["gauss_wts"] = g_w_2gauss(order=4, gfrac=0.95)
             out["kappas"][mol] = np.load(fn)
+        else:                                       # the reference says so and goes on (opacity_factory.py:2286-2290)
+            import warnings
+            warnings.warn("no k-table for %s in %s (neither %s_1460.hdf5 nor %s_1460.npy): it is left out of the "
+                          "mixing" % (mol, path, mol, mol), UserWarning)
     if not out["kappas"]:
         raise Exception("Uh oh. No molecules are left to mix. Its likely you have not downloaded the correct files.")
     out["molecules"] = list(out["kappas"].keys())
@@ -605,13 +609,47 @@ def shard_opacity(opa, lo, hi, ctx):
             s._kappas[m] = cols(tab, ng).reshape((npres, ntemp, hi - lo, ng))
     s.rayleigh_opa = {k: np.ascontiguousarray(v[lo:hi]) for k, v in opa.rayleigh_opa.items()}
     s._ray = {k: DeviceArray.from_host(v, ctx) for k, v in s.rayleigh_opa.items()}
-    # per-wavelength host attributes callers hang on the opacity object (stellar spectrum, Raman shifts, bin widths)
-    for name in ("relative_flux", "unshifted_stellar_spec", "delta_wno", "raman_stellar_shifts"):
-        v = getattr(opa, name, None)
-        if isinstance(v, np.ndarray) and v.shape[:1] == (nwno,):
-            setattr(s, name, np.ascontiguousarray(v[lo:hi]))
+    s._parent_stamp = None
+    resync_shard(s, opa, lo, hi)
     if hasattr(opa, "get_opacities") and getattr(opa, "on_fly", False):
         s.get_opacities = s.get_opacities_deq_onfly          # bound method of the shard, not of the parent
+    return s
+
+
+# host attributes callers (re)assign on the opacity object AFTER a shard of it may exist: star() hangs the stellar
+# spectrum and the Raman shift ratios there, opannection's docstring lets query_method / raman_db be set later
+_SHARD_VECTORS = ("relative_flux", "unshifted_stellar_spec", "delta_wno", "raman_stellar_shifts")
+_SHARD_SCALARS = ("raman_db", "query_method")
+
+
+def resync_shard(s, opa, lo, hi):
+    """Bring a shard's copies of the parent's mutable host attributes up to date (called on every use of a cached
+    shard or replica: ``picaso(devices=...)``, ``phase_curve(devices=...)``).  Cheap when nothing changed: the
+    parent's attribute objects are compared by identity."""
+    if s is opa:
+        return s
+    stamp = tuple(id(getattr(opa, n, None)) for n in _SHARD_VECTORS) + tuple(
+        (id(v) if isinstance(v, np.ndarray) or not isinstance(v, (str, int, float, type(None))) else v)
+        for v in (getattr(opa, n, None) for n in _SHARD_SCALARS))
+    if getattr(s, "_parent_stamp", None) == stamp:
+        return s
+    nwno = opa.nwno
+    for name in _SHARD_VECTORS:
+        v = getattr(opa, name, None)
+        if isinstance(v, np.ndarray) and v.shape[:1] == (nwno,):
+            setattr(s, name, np.ascontiguousarray(v[int(lo):int(hi)]))
+        elif hasattr(opa, name):
+            setattr(s, name, v)
+        else:
+            s.__dict__.pop(name, None)
+    for name in _SHARD_SCALARS:
+        if hasattr(opa, name):
+            setattr(s, name, getattr(opa, name))
+    # device tables derived from them on the shard
+    s.__dict__.pop("_raman_oklopcic", None)
+    s.__dict__.pop("_resident_vectors", None)
+    s._plan = None                         # the (P, T) plan is rebuilt by the next get_opacities call
+    s._parent_stamp = stamp
     return s
 
 

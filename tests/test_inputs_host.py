@@ -560,3 +560,88 @@ def test_opannection_reads_the_raman_table(tmp_path, monkeypatch):
     assert np.allclose(opa.raman_db["deltanu"], g["in/raman_deltanu"], rtol=1e-15)
     with pytest.raises(Exception, match="not found"):
         jdi.opannection(filename_db=db, raman_db=str(tmp_path / "nope.txt"))
+
+
+class _FakeDev:
+    """Stand-in for DeviceArray in host tests of the caches (no GPU): remembers what was uploaded."""
+    uploads = 0
+
+    def __init__(self, arr):
+        self.host = np.array(arr)
+        self.shape = self.host.shape
+        type(self).uploads += 1
+
+    @classmethod
+    def from_host(cls, arr, ctx=None):
+        return cls(arr)
+
+    def to_host(self):
+        return self.host
+
+
+def test_resident_vector_alternating_arrays_and_scalars(monkeypatch):
+    """A spectrum with a star (F0PI an array) followed by a brown-dwarf one on the same opacity object (F0PI = 1.0),
+    surf_reflect array then the default scalar 0: the cache must tell the two kinds apart (round-3 review: the
+    array entry's tag IS the ndarray, and comparing it with a tuple raised)."""
+    from picaso_amd import justdoit as jdi
+    monkeypatch.setattr(jdi, "DeviceArray", _FakeDev)
+
+    class Opa:
+        ctx = None
+    opa, n = Opa(), 7
+    f_arr = np.linspace(1.0, 2.0, n)
+    d1 = jdi._resident_vector(opa, "F0PI", f_arr, n)
+    assert np.array_equal(d1.host, f_arr)
+    d2 = jdi._resident_vector(opa, "F0PI", 1.0, n)                 # scalar after array: used to raise
+    assert np.array_equal(d2.host, np.ones(n))
+    assert jdi._resident_vector(opa, "F0PI", 1.0, n) is d2         # same scalar: cached
+    d3 = jdi._resident_vector(opa, "F0PI", f_arr, n)               # and back
+    assert np.array_equal(d3.host, f_arr)
+    assert jdi._resident_vector(opa, "F0PI", f_arr.copy(), n) is d3     # equal content: cached
+    for v in (np.full(n, 0.3), 0, np.full(n, 0.3), 0.0, 0.5):
+        d = jdi._resident_vector(opa, "surf_reflect", v, n)
+        assert np.array_equal(d.host, np.zeros(n) + v)
+    w = np.linspace(1.0, 2.0, n)
+    dw = jdi._resident_vector(opa, "wno", w, n)
+    assert jdi._resident_vector(opa, "wno", w, n) is dw
+    jdi._resident_vector(opa, "wno", 3.0, n)                       # (never happens; must not raise either)
+    assert np.array_equal(jdi._resident_vector(opa, "wno", w, n).host, w)
+
+
+def test_shards_follow_the_parent_after_star_and_option_changes(monkeypatch):
+    """`devices=N` caches one shard of the opacity object per wavelength block.  star() called again (new stellar
+    spectrum and Raman shift ratios), raman_db / query_method set afterwards: the cached shards must see the new
+    values on their next use (round-3 review: they kept the first ones)."""
+    from picaso_amd import optics
+
+    class Opa:
+        pass
+    opa = Opa()
+    opa.nwno, opa.ngauss, opa.ctx = 10, 1, object()
+    opa.wno = np.linspace(1.0, 2.0, 10)
+    opa.molecular_opa, opa.continuum_opa, opa.rayleigh_opa = {}, {}, {}
+    opa.relative_flux = np.arange(10.0)
+    opa.raman_stellar_shifts = np.arange(20.0).reshape(10, 2)
+    opa.query_method = "nearest"
+    opa.raman_db = None
+    monkeypatch.setattr(optics, "DeviceArray", _FakeDev)
+    sh = optics.shard_opacity(opa, 3, 7, object())
+    assert np.array_equal(sh.relative_flux, np.arange(3.0, 7.0)) and sh.query_method == "nearest"
+    sh._raman_oklopcic = "device tables of the old star"
+    optics.resync_shard(sh, opa, 3, 7)                             # nothing changed: derived tables stay
+    assert sh._raman_oklopcic == "device tables of the old star"
+    opa.relative_flux = np.arange(10.0) * 2                        # star() again
+    opa.raman_stellar_shifts = np.arange(20.0).reshape(10, 2) + 5
+    opa.unshifted_stellar_spec = np.arange(10.0) + 100
+    opa.query_method = "linear"
+    opa.raman_db = {"c": np.ones(3)}
+    optics.resync_shard(sh, opa, 3, 7)
+    assert np.array_equal(sh.relative_flux, 2 * np.arange(3.0, 7.0))
+    assert np.array_equal(sh.raman_stellar_shifts, opa.raman_stellar_shifts[3:7])
+    assert np.array_equal(sh.unshifted_stellar_spec, np.arange(3.0, 7.0) + 100)
+    assert sh.query_method == "linear" and sh.raman_db is opa.raman_db
+    assert not hasattr(sh, "_raman_oklopcic")
+    del opa.unshifted_stellar_spec                                 # inputs.star() of a brown dwarf case: gone again
+    opa.relative_flux = np.ones(10)
+    optics.resync_shard(sh, opa, 3, 7)
+    assert not hasattr(sh, "unshifted_stellar_spec") and np.array_equal(sh.relative_flux, np.ones(4))

@@ -1,15 +1,15 @@
 """GPU parity: the HIP library (through the C ABI / reference call surface in picaso_amd.fluxes,
 picaso_amd.disco) against (a) golden vectors from the reference's own source and (b) the CPU
 oracle on fresh seeded scenes.  Contract from BASELINE.json: <= 1e-6 relative flux error; the
-tests hold the kernels to 1e-8 (observed <= 1e-10: the single-sweep elimination differs from the
-reference's two-sweep Thomas only by rounding)."""
+tests hold the kernels to 1e-9 (observed <= 1e-10: the single-sweep elimination differs from the
+reference's two-sweep Thomas only by rounding; until round 3 the bound was 1e-8, 100 x the evidence)."""
 import numpy as np
 import pytest
 
 from helpers import PLANES, Golden, golden_files, lvl_err, lvl_excess, rel_err, scale_err, scene_id
 
 pytestmark = pytest.mark.gpu
-TOL = 1e-8
+TOL = 1e-9
 LVL_TOL = 1e-7   # level fluxes: noise in one level leaks into its neighbours through the recursion
 FILES_1D = golden_files("scene1d_")
 FILES_3D = golden_files("scene3d_")
