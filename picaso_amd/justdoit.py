@@ -206,6 +206,84 @@ def _stellar_cgs(wave, flux, w_unit, f_unit):
     return wno[order], f[order]
 
 
+_PRESSURE_TO_BAR = {"bar": 1.0, "bars": 1.0, "pa": 1e-5, "pascal": 1e-5, "mbar": 1e-3, "millibar": 1e-3,
+                    "dyn/cm2": 1e-6, "dyne/cm2": 1e-6, "barye": 1e-6, "atm": 1.01325, "hpa": 1e-3, "kpa": 1e-2}
+
+
+def _dataset_like(ds, extra_coords=()):
+    """``(coords, variables)`` of a GCM input in the reference's layout (justdoit.py:3414-3520, 4515-4600: an xarray
+    Dataset with coordinates ``lon`` / ``lat`` (degrees) / ``pressure`` [/ ``wno``] and data variables on
+    ``(lon, lat, pressure[, wno])``), taken from anything that looks like one -- an object with ``.coords[name].values``,
+    ``.keys()`` and ``ds[name].values`` (xarray itself, when the caller has it), or a plain dictionary whose
+    coordinate arrays sit under those names next to the variables (pressure unit: ``ds['pressure_unit']``, default
+    bar).  xarray is not imported here.  Variables come back as ``(lon, lat, pressure[, wno])`` float arrays,
+    ``coords['pressure']`` in bar."""
+    names = ("lon", "lat", "pressure") + tuple(extra_coords)
+    if hasattr(ds, "coords"):
+        have = ds.coords
+        for c in names:
+            if c not in have:
+                raise Exception('Must include "%s" as a coordinate. Please see GCM 3D input tutorials to learn how to '
+                                'reformat your input.' % c)
+        coords = {c: np.asarray(have[c].values, dtype=float) for c in names}
+        unit = getattr(have["pressure"], "attrs", {}).get("units", "bar")
+        variables = {}
+        for k in ds.keys():
+            v = ds[k]
+            arr = np.asarray(v.values, dtype=float)
+            dims = list(getattr(v, "dims", names[:arr.ndim]))
+            order = [dims.index(c) for c in names if c in dims]
+            variables[k] = np.transpose(arr, order) if order != list(range(arr.ndim)) else arr
+    elif isinstance(ds, dict):
+        for c in names:
+            if c not in ds:
+                raise Exception('Must include "%s" as a coordinate. Please see GCM 3D input tutorials to learn how to '
+                                'reformat your input.' % c)
+        coords = {c: np.asarray(ds[c], dtype=float) for c in names}
+        unit = ds.get("pressure_unit", "bar")
+        variables = {k: np.asarray(v, dtype=float) for k, v in ds.items()
+                     if k not in names and k not in ("pressure_unit", "wno_unit")}
+    else:
+        raise Exception("PICASO has moved to only accept xarray input. Please see GCM 3D input tutorials to learn how "
+                        "to reformat your input. (picaso_amd takes an xarray-like object or a dictionary with "
+                        "lon / lat / pressure entries.)")
+    fac = _PRESSURE_TO_BAR.get(str(unit).strip().lower())
+    if fac is None:
+        raise Exception("pressure unit %r not understood (bar, Pa, mbar, dyn/cm2, atm)" % (unit,))
+    coords["pressure"] = coords["pressure"] * fac
+    coords["pressure_unit_in"] = unit
+    return coords, variables
+
+
+def _interp_axis(x_new, x_old, arr, axis):
+    """Linear interpolation of ``arr`` along ``axis`` from the increasing grid ``x_old`` to ``x_new`` (end values
+    held outside the grid)."""
+    x_old = np.asarray(x_old, dtype=float)
+    if x_old.size == 1:
+        return np.repeat(arr, len(x_new), axis=axis)
+    if np.any(np.diff(x_old) < 0):
+        order = np.argsort(x_old)
+        x_old, arr = x_old[order], np.take(arr, order, axis=axis)
+    x = np.clip(np.asarray(x_new, dtype=float), x_old[0], x_old[-1])
+    j = np.clip(np.searchsorted(x_old, x, side="right") - 1, 0, x_old.size - 2)
+    t = (x - x_old[j]) / (x_old[j + 1] - x_old[j])
+    shape = [1] * arr.ndim
+    shape[axis] = -1
+    t = t.reshape(shape)
+    return np.take(arr, j, axis=axis) * (1.0 - t) + np.take(arr, j + 1, axis=axis) * t
+
+
+def _regrid_lonlat(coords, variables, lon_new, lat_new):
+    """Bilinear in (longitude, latitude), both in degrees, of every ``(lon, lat, ...)`` variable.  The reference
+    hands this step to xesmf's 'bilinear' regridder (build_3d_input.py:12-62; not installable here, so the two are
+    not compared): on a rectilinear lon / lat grid that is this interpolation up to ESMF's great-circle cell
+    geometry."""
+    out = {}
+    for k, v in variables.items():
+        out[k] = _interp_axis(lat_new, coords["lat"], _interp_axis(lon_new, coords["lon"], v, 0), 1)
+    return out
+
+
 def _interp_extrapolate(x, xp, fp):
     """Piecewise-linear through ``(xp, fp)``, the end segments continued outside (scipy ``interp1d(kind='linear',
     fill_value='extrapolate')``)."""
@@ -670,17 +748,56 @@ class inputs:
                 raise Exception("fhole must be float 0-1 if do_holes = True")
             self.inputs["clouds"].update(fhole=fhole, fthin_cld=fthin_cld)
 
-    def atmosphere_3d(self, profiles, exclude_mol=1):
-        """Per-facet level profiles for ``spectrum(dimension='3d')``: ``pressure`` (nlevel,) in bar,
-        ``temperature`` and every mixing ratio ``(nlevel, num_gangle, num_tangle)`` (or ``(nlevel,)``,
-        shared by all facets), already on the Gauss/Chebyshev facets of ``phase_angle()`` (the
-        reference regrids an xarray lon/lat dataset first, justdoit.py:2389-2560; that regridding is
-        data preparation outside the path)."""
-        if "pressure" not in profiles or "temperature" not in profiles:
-            raise Exception("atmosphere_3d(profiles) needs 'pressure' and 'temperature'")
-        self.inputs["atmosphere"]["profile_3d"] = {k: np.asarray(v, dtype=float) for k, v in profiles.items()}
+    def atmosphere_3d(self, ds, regrid=True, plot=True, iz_plot=0, verbose=True, exclude_mol=1):
+        """The reference's call (justdoit.py:3414-3519): ``ds`` = the GCM dataset, temperature and abundances on
+        ``(lon, lat, pressure)`` with coordinates in degrees and a pressure unit (an xarray Dataset where the caller
+        has xarray, or a dictionary, see ``_dataset_like``).  ``regrid=True`` interpolates it bilinearly onto the
+        Gauss / Chebyshev facets of ``phase_angle()``; ``regrid=False`` checks that its grid IS that one, as the
+        reference does.  ``plot`` / ``iz_plot`` are accepted and ignored (no plotting here).
+
+        Facet profiles that are already arrays are taken as before: a dictionary WITHOUT ``lon`` / ``lat`` --
+        ``pressure`` (nlevel,) in bar, ``temperature`` and every mixing ratio ``(nlevel, num_gangle, num_tangle)``
+        or ``(nlevel,)`` (shared by all facets)."""
+        if isinstance(ds, dict) and not hasattr(ds, "coords") and "lon" not in ds and "lat" not in ds:
+            profiles = ds
+            if "pressure" not in profiles or "temperature" not in profiles:
+                raise Exception("atmosphere_3d(profiles) needs 'pressure' and 'temperature'")
+            self.inputs["atmosphere"]["profile_3d"] = {k: np.asarray(v, dtype=float) for k, v in profiles.items()}
+            self.inputs["atmosphere"]["exclude_mol"] = exclude_mol
+            self.nlevel = len(profiles["pressure"])
+            return
+        coords, variables = _dataset_like(ds)
+        if "temperature" not in variables:
+            raise Exception("Must include temperature as data component")
+        if verbose and str(coords["pressure_unit_in"]).lower() not in ("bar", "bars"):
+            print("verbose=True; Converting pressure grid from %s to required unit of bar." % coords["pressure_unit_in"])
+        geom = self.inputs["disco"]
+        ng, nt, phase = geom["num_gangle"], geom["num_tangle"], self.inputs["phase_angle"]
+        lat_f, lon_f = geom["latitude"] * 180 / np.pi, geom["longitude"] * 180 / np.pi
+        if regrid:
+            assert nt <= len(coords["lat"]), \
+                "Cannot regrid from a course grid. num_tangle=%d and input grid has len(lat)=%d" % (nt, len(coords["lat"]))
+            assert ng <= len(coords["lon"]), \
+                "Cannot regrid from a course grid. num_gangle=%d and input grid has len(lon)=%d" % (ng, len(coords["lon"]))
+            if verbose:
+                print("verbose=True;regrid=True; Regridding 3D output to ngangle=%d, ntangle=%d, with phase=%s."
+                      % (ng, nt, phase))
+            variables = _regrid_lonlat(coords, variables, lon_f, lat_f)
+        else:
+            assert np.array_equal(lat_f, coords["lat"]), \
+                "Latitudes from the GCM do not match the PICASO grid (phase %s): provide the native GCM grid with regrid=True" % phase
+            assert np.array_equal(lon_f, coords["lon"]), \
+                "Longitude from the GCM do not match the PICASO grid (phase %s): provide the native GCM grid with regrid=True" % phase
+        if len(variables) == 1 and verbose:
+            print("verbose=True;Only one data variable included. Make sure to add in chemical abundances before "
+                  "trying to run spectra.")
+        order = np.argsort(coords["pressure"])                         # ds.sortby('pressure')
+        prof = {"pressure": coords["pressure"][order]}
+        for k, v in variables.items():                                 # (lon, lat, pressure) -> (nlevel, ng, nt)
+            prof[k] = np.ascontiguousarray(np.transpose(v[:, :, order], (2, 0, 1)))
+        self.inputs["atmosphere"]["profile_3d"] = prof
         self.inputs["atmosphere"]["exclude_mol"] = exclude_mol
-        self.nlevel = len(profiles["pressure"])
+        self.nlevel = len(prof["pressure"])
 
     def phase_curve_geometry(self, calculation, phase_grid, num_gangle=10, num_tangle=10):
         """Facet geometry of every phase of a phase curve (reference justdoit.py:1606-1660): reflected
@@ -708,18 +825,64 @@ class inputs:
         self.inputs["disco"] = {p: compute_angles(0.0 if calculation == "thermal" else p) for p in phase_grid}
         self.inputs["disco"]["calculation"] = calculation
 
-    def atmosphere_4d(self, profiles_by_phase, exclude_mol=1):
-        """One ``atmosphere_3d``-style profile dictionary per phase of ``phase_curve_geometry`` (the
-        reference rotates and regrids an xarray lon/lat map per phase, justdoit.py:3666-3790 -- data
-        preparation; here the per-phase facet profiles come in as arrays)."""
-        profs = list(profiles_by_phase)
-        for pr in profs:
-            if "pressure" not in pr or "temperature" not in pr:
-                raise Exception("atmosphere_4d: every phase needs 'pressure' and 'temperature'")
-        self.inputs["atmosphere"]["profile_4d"] = [{k: np.asarray(v, dtype=float) for k, v in pr.items()}
-                                                   for pr in profs]
+    def atmosphere_4d(self, ds=None, shift=None, plot=True, iz_plot=0, verbose=True, zero_point="night_transit",
+                      exclude_mol=1):
+        """The profiles of every phase of ``phase_curve_geometry`` (reference justdoit.py:3666-3880).
+
+        ``ds`` = a list with one ``atmosphere_3d``-style facet-profile dictionary per phase (arrays already on the
+        facets of each phase), or the reference's form: ONE GCM dataset (see ``atmosphere_3d``), which is rotated by
+        ``phase + shift`` degrees of longitude per phase (``shift``: one value per phase, default 0;
+        ``zero_point='night_transit'`` adds 180 degrees for thermal curves as the reference does) and interpolated
+        bilinearly onto that phase's facets.  The reference additionally re-centres the illuminated crescent of a
+        reflected-light curve with corrections written for its 6- and 10-angle grids (justdoit.py:3765-3830);
+        those are not reproduced: hand per-phase facet profiles over for such a curve."""
+        phases = self.inputs["phase_angle"]
+        if ds is None:
+            raise Exception("Need to submit the GCM dataset (or one facet-profile dictionary per phase)")
+        if isinstance(ds, (list, tuple)):
+            profs = list(ds)
+            for pr in profs:
+                if "pressure" not in pr or "temperature" not in pr:
+                    raise Exception("atmosphere_4d: every phase needs 'pressure' and 'temperature'")
+            self.inputs["atmosphere"]["profile_4d"] = [{k: np.asarray(v, dtype=float) for k, v in pr.items()}
+                                                       for pr in profs]
+            self.inputs["atmosphere"]["exclude_mol"] = exclude_mol
+            self.nlevel = len(profs[0]["pressure"])
+            return
+        all_geom = self.inputs["disco"]
+        if not isinstance(all_geom, dict) or "calculation" not in all_geom:
+            raise Exception("run phase_curve_geometry() first")
+        shift = np.zeros(len(phases)) if shift is None else np.asarray(shift, dtype=float)
+        if len(shift) != len(phases):
+            raise Exception("shift must have one entry per phase (%d)" % len(phases))
+        if zero_point == "night_transit":
+            if "reflected" in all_geom["calculation"]:
+                if verbose:
+                    print("Switching to zero point secondary_eclipse which is required for reflected light")
+            else:
+                shift = shift + 180
+        elif zero_point != "secondary_eclipse":
+            raise Exception("Do not recognize input zero point. Please specify: night_transit or secondary_eclipse")
+        self.inputs["shift"] = shift
+        coords, variables = _dataset_like(ds)
+        if "temperature" not in variables:
+            raise Exception("Must include temperature as data component")
+        order = np.argsort(coords["pressure"])
+        profs = []
+        for i, ph in enumerate(phases):
+            lat_f = all_geom[ph]["latitude"] * 180 / np.pi
+            lon_f = all_geom[ph]["longitude"] * 180 / np.pi
+            # the map as this phase sees it: longitudes advanced by phase + shift, wrapped to [-180, 180)
+            lon_rot = (coords["lon"] + ph * 180 / np.pi + shift[i] + 180.0) % 360.0 - 180.0
+            rot = dict(coords, lon=lon_rot)
+            v = _regrid_lonlat(rot, variables, lon_f, lat_f)
+            pr = {"pressure": coords["pressure"][order]}
+            for k, a in v.items():
+                pr[k] = np.ascontiguousarray(np.transpose(a[:, :, order], (2, 0, 1)))
+            profs.append(pr)
+        self.inputs["atmosphere"]["profile_4d"] = profs
         self.inputs["atmosphere"]["exclude_mol"] = exclude_mol
-        self.nlevel = len(profs[0]["pressure"])
+        self.nlevel = len(order)
 
     def phase_curve(self, opacityclass, full_output=False, plot_opacity=False, n_cpu=1, verbose=False,
                     clouds_by_phase=None, devices=None):
@@ -775,10 +938,41 @@ class inputs:
             self.inputs["phase_angle"], self.inputs["disco"] = phases, all_geom
         return results
 
-    def clouds_3d(self, df=None):
-        """Cloud ``opd``/``w0``/``g0`` as ``(nlayer, nwno, num_gangle, num_tangle)`` arrays, or ``(nlayer, nwno)``
-        for a cloud that is the same on every facet (tiled over the facets on the device)."""
-        self.inputs["clouds"]["profile_3d"] = df
+    def clouds_3d(self, ds=None, regrid=True, plot=True, iz_plot=0, iw_plot=0, verbose=True, df=None):
+        """The reference's call (justdoit.py:4515-4620): ``ds`` = cloud ``opd`` / ``w0`` / ``g0`` on
+        ``(lon, lat, pressure, wno)`` (layer pressures; xarray-like or dictionary, see ``_dataset_like``), regridded
+        onto the facets of ``phase_angle()`` (``regrid=True``) or checked against them, then interpolated in
+        wavenumber by ``picaso()`` like any cloud table.  Arrays that are already on the facets are taken as before:
+        a dictionary without ``lon`` / ``lat`` (or ``df=``) holding ``opd`` / ``w0`` / ``g0`` as
+        ``(nlayer, nwno, num_gangle, num_tangle)``, or ``(nlayer, nwno)`` for a cloud that is the same on every facet."""
+        self.inputs["clouds"]["dims"] = "3d"
+        if ds is None:
+            ds = df
+        if ds is None or (isinstance(ds, dict) and not hasattr(ds, "coords") and "lon" not in ds and "lat" not in ds) \
+                or not (isinstance(ds, dict) or hasattr(ds, "coords")):
+            self.inputs["clouds"]["profile_3d"] = ds
+            return
+        coords, variables = _dataset_like(ds, extra_coords=("wno",))
+        for need, what in (("opd", "optical detph"), ("g0", "assymetry"), ("w0", "single scattering")):
+            if need not in variables:
+                raise Exception("Must include '%s' (%s) as data component" % (need, what))
+        geom = self.inputs["disco"]
+        lat_f, lon_f = geom["latitude"] * 180 / np.pi, geom["longitude"] * 180 / np.pi
+        if regrid:
+            variables = _regrid_lonlat(coords, variables, lon_f, lat_f)
+        else:
+            assert np.array_equal(lat_f, coords["lat"]) and np.array_equal(lon_f, coords["lon"]), \
+                "Cloud latitudes / longitudes do not match the PICASO grid: provide the native grid with regrid=True"
+        order = np.argsort(coords["pressure"])
+        wno_c = coords["wno"]
+        worder = np.argsort(wno_c)
+        out = {}
+        for k in ("opd", "w0", "g0"):                                   # (lon, lat, p, wno) -> (nlayer, nwno, ng, nt)
+            v = variables[k][:, :, order][:, :, :, worder]
+            out[k] = np.ascontiguousarray(np.transpose(v, (2, 3, 0, 1)))
+        out["wavenumber"] = wno_c[worder]
+        out["pressure"] = coords["pressure"][order]
+        self.inputs["clouds"]["profile_3d"] = out
 
     def surface_reflect(self, albedo, wavenumber=None, old_wavenumber=None):
         """Surface reflectivity, scalar or per wavelength (reference justdoit.py:4092)."""
@@ -964,6 +1158,12 @@ def picaso(bundle, opacityclass, dimension="1d", calculation="reflected", full_o
                             "no patchy clouds and no level fluxes")
         prof3 = inp["atmosphere"]["profile_3d"]
         cld3 = inp["clouds"].get("profile_3d")
+        if isinstance(cld3, dict) and cld3.get("wavenumber") is not None and not (
+                len(cld3["wavenumber"]) == len(wno) and np.array_equal(cld3["wavenumber"], wno)):
+            # a cloud dataset on its own wavenumber grid (clouds_3d(ds)): onto the opacity grid, linear in wavenumber
+            # like the reference's per-facet get_clouds -> wavelength.regrid (atmsetup.py:609-622)
+            cld3 = dict(cld3, **{k: _interp_axis(wno, cld3["wavenumber"], np.asarray(cld3[k], dtype=float), 1)
+                                 for k in ("opd", "w0", "g0")})
         # Only planes that cannot be re-derived exactly inside the solvers are written (each is nfacets x 9 MB
         # at 12 500 wavelengths x 90 layers): the level optical depths are running sums and gcos2 is
         # 0.5 ftau_ray, so the reflected kernel takes 8 planes instead of 11; without cloud (and outside the

@@ -645,3 +645,100 @@ def test_shards_follow_the_parent_after_star_and_option_changes(monkeypatch):
     opa.relative_flux = np.ones(10)
     optics.resync_shard(sh, opa, 3, 7)
     assert not hasattr(sh, "unshifted_stellar_spec") and np.array_equal(sh.relative_flux, np.ones(4))
+
+
+class _Coord:
+    def __init__(self, values, units=None):
+        self.values = np.asarray(values, dtype=float)
+        self.attrs = {"units": units} if units else {}
+
+
+class _Var:
+    def __init__(self, values, dims):
+        self.values, self.dims = np.asarray(values, dtype=float), dims
+
+
+class _FakeDataset(dict):
+    """The part of an xarray Dataset the builders touch: .coords[name].values / .attrs, keys(), ds[name].values/.dims."""
+
+    def __init__(self, coords, variables):
+        super().__init__(variables)
+        self.coords = coords
+
+
+def test_3d_builders_take_the_reference_keywords_and_a_dataset():
+    """atmosphere_3d(ds, regrid=True, plot=True, iz_plot=0, verbose=True), atmosphere_4d(ds, shift, ...),
+    clouds_3d(ds, regrid, plot, iz_plot, iw_plot, verbose) -- the reference's parameter names (justdoit.py:3414,
+    3666, 4515) with a dataset-like object or dictionary (xarray itself is not needed); a field that is linear in
+    longitude and latitude is reproduced exactly by the bilinear regridding, pressures are converted and sorted."""
+    import inspect
+    from picaso_amd import justdoit as jdi
+    assert list(inspect.signature(jdi.inputs.atmosphere_3d).parameters)[1:6] == ["ds", "regrid", "plot", "iz_plot", "verbose"]
+    assert list(inspect.signature(jdi.inputs.atmosphere_4d).parameters)[1:7] == ["ds", "shift", "plot", "iz_plot", "verbose",
+                                                                                 "zero_point"]
+    assert list(inspect.signature(jdi.inputs.clouds_3d).parameters)[1:7] == ["ds", "regrid", "plot", "iz_plot", "iw_plot",
+                                                                              "verbose"]
+    case = jdi.inputs()
+    case.phase_angle(phase=0.4, num_gangle=4, num_tangle=3)
+    lon, lat = np.linspace(-180, 180, 37), np.linspace(-90, 90, 19)
+    pres_pa = np.logspace(7, 1, 9)                                  # Pa, deepest first: converted and sorted
+    T = 1000.0 + 2.0 * lon[:, None, None] + 3.0 * lat[None, :, None] + 0 * pres_pa[None, None, :] + np.log10(pres_pa)
+    h2o = np.full(T.shape, 1e-3)
+    ds = _FakeDataset({"lon": _Coord(lon), "lat": _Coord(lat), "pressure": _Coord(pres_pa, "Pa")},
+                      {"temperature": _Var(T, ("lon", "lat", "pressure")), "H2O": _Var(h2o, ("lon", "lat", "pressure"))})
+    case.atmosphere_3d(ds, regrid=True, plot=False, iz_plot=0, verbose=False)
+    pr = case.inputs["atmosphere"]["profile_3d"]
+    assert np.allclose(pr["pressure"], np.sort(pres_pa) * 1e-5) and pr["temperature"].shape == (9, 4, 3)
+    geom = case.inputs["disco"]
+    lonf, latf = geom["longitude"] * 180 / np.pi, geom["latitude"] * 180 / np.pi
+    want = 1000.0 + 2.0 * lonf[None, :, None] + 3.0 * latf[None, None, :] + np.log10(np.sort(pres_pa))[:, None, None]
+    assert np.allclose(pr["temperature"], want, rtol=1e-12)
+    # the dictionary form, a variable stored (pressure, lat, lon) in an object with dims is transposed
+    ds2 = _FakeDataset({"lon": _Coord(lon), "lat": _Coord(lat), "pressure": _Coord(pres_pa * 1e-5, "bar")},
+                       {"temperature": _Var(np.transpose(T, (2, 1, 0)), ("pressure", "lat", "lon"))})
+    case.atmosphere_3d(ds2, regrid=True, plot=False, verbose=False)
+    assert np.allclose(case.inputs["atmosphere"]["profile_3d"]["temperature"], want, rtol=1e-12)
+    case.atmosphere_3d({"lon": lon, "lat": lat, "pressure": pres_pa, "pressure_unit": "Pa", "temperature": T}, verbose=False)
+    assert np.allclose(case.inputs["atmosphere"]["profile_3d"]["temperature"], want, rtol=1e-12)
+    # regrid=False: the grid must already be the facets'
+    with pytest.raises(AssertionError, match="do not match the PICASO grid"):
+        case.atmosphere_3d(ds, regrid=False, verbose=False)
+    on_facets = {"lon": lonf, "lat": latf, "pressure": pres_pa * 1e-5,
+                 "temperature": np.transpose(want, (1, 2, 0))[:, :, ::-1]}
+    case.atmosphere_3d(on_facets, regrid=False, verbose=False)
+    assert np.allclose(case.inputs["atmosphere"]["profile_3d"]["temperature"], want, rtol=1e-12)
+    with pytest.raises(Exception, match="temperature"):
+        case.atmosphere_3d({"lon": lon, "lat": lat, "pressure": pres_pa, "H2O": h2o}, verbose=False)
+    with pytest.raises(Exception, match='"lat"'):
+        case.atmosphere_3d(_FakeDataset({"lon": _Coord(lon), "pressure": _Coord(pres_pa, "Pa")}, {}), verbose=False)
+    # the array form of earlier rounds still works
+    case.atmosphere_3d({"pressure": np.sort(pres_pa) * 1e-5, "temperature": want})
+    assert case.inputs["atmosphere"]["profile_3d"]["temperature"].shape == (9, 4, 3)
+
+    # clouds: (lon, lat, pressure, wno) -> (nlayer, nwno, ng, nt)
+    wn = np.linspace(5000.0, 1000.0, 6)                              # decreasing: sorted
+    opd = 0.1 + 0 * lon[:, None, None, None] + 0.01 * lat[None, :, None, None] + 0 * pres_pa[None, None, :8, None] \
+        + 1e-4 * wn[None, None, None, :]
+    cl = {"lon": lon, "lat": lat, "pressure": pres_pa[:8] * 1e-5, "wno": wn, "opd": opd, "w0": 0 * opd + 0.9,
+          "g0": 0 * opd + 0.5}
+    case.clouds_3d(cl, regrid=True, plot=False, iz_plot=0, iw_plot=0, verbose=False)
+    c3 = case.inputs["clouds"]["profile_3d"]
+    assert c3["opd"].shape == (8, 6, 4, 3) and np.array_equal(c3["wavenumber"], np.sort(wn))
+    assert np.allclose(c3["opd"][3, 0], 0.1 + 0.01 * latf[None, :] + 1e-4 * 1000.0)
+    with pytest.raises(Exception, match="'g0'"):
+        case.clouds_3d({k: v for k, v in cl.items() if k != "g0"}, verbose=False)
+
+    # phase curve: one dataset, rotated per phase
+    pc = jdi.inputs()
+    pc.phase_curve_geometry("thermal", [0.0, np.pi / 2], num_gangle=4, num_tangle=3)
+    Tl = 1000.0 + 0 * lon[:, None, None] + 3.0 * lat[None, :, None] + 0 * pres_pa[None, None, :]      # no longitude dependence
+    pc.atmosphere_4d(_FakeDataset({"lon": _Coord(lon), "lat": _Coord(lat), "pressure": _Coord(pres_pa, "Pa")},
+                                  {"temperature": _Var(Tl, ("lon", "lat", "pressure"))}),
+                     shift=np.zeros(2), plot=False, verbose=False, zero_point="night_transit")
+    p4 = pc.inputs["atmosphere"]["profile_4d"]
+    assert len(p4) == 2 and p4[1]["temperature"].shape == (9, 4, 3)
+    assert np.allclose(p4[0]["temperature"], p4[1]["temperature"]) and np.array_equal(pc.inputs["shift"], [180.0, 180.0])
+    with pytest.raises(Exception, match="zero point"):
+        pc.atmosphere_4d({"lon": lon, "lat": lat, "pressure": pres_pa, "temperature": Tl}, zero_point="noon", verbose=False)
+    pc.atmosphere_4d([{"pressure": np.sort(pres_pa) * 1e-5, "temperature": want}] * 2)       # per-phase facet profiles
+    assert len(pc.inputs["atmosphere"]["profile_4d"]) == 2
