@@ -1111,7 +1111,8 @@ def _setup_atmosphere(inp, opa, wno, profile=None, cloud_profile=None):
 
 
 def picaso(bundle, opacityclass, dimension="1d", calculation="reflected", full_output=False,
-           plot_opacity=False, as_dict=True, defer=False, devices=None, gather="host", _raw=False, _shared=None):
+           plot_opacity=False, as_dict=True, defer=False, devices=None, gather="host", _raw=False, _shared=None,
+           _batch=None):
     """Spectrum driver (reference ``picaso()``, justdoit.py:65-621, 1-D Toon branch).
 
     ``defer=True`` (used by ``phase_curve``): every kernel of the spectrum is enqueued and a function is
@@ -1283,7 +1284,7 @@ def picaso(bundle, opacityclass, dimension="1d", calculation="reflected", full_o
     # leaves SIMDs idle through its tail) instead of behind it
     tctx = ctx
     if (dimension == "1d" and not is_sh and "reflected" in calculation and "thermal" in calculation
-            and os.environ.get("PICASO_AMD_OVERLAP_LEGS", "1") != "0"):
+            and _batch is None and os.environ.get("PICASO_AMD_OVERLAP_LEGS", "1") != "0"):
         tctx = _lib.aux_context(_lib.device_of(ctx))     # one per process and device, shared by every caller
         _lib.ctx_wait(tctx, ctx)
     returns = {"wavenumber": wno}
@@ -1325,6 +1326,12 @@ def picaso(bundle, opacityclass, dimension="1d", calculation="reflected", full_o
                                                  gweight=gweight if fuse else None,
                                                  tweight=tweight if fuse else None, albedo=alb if fuse else None,
                                                  lvl_fluxes=lv)
+                    elif _batch is not None and lv is None and fuse:
+                        # spectrum_batch(): the launch is issued later, together with the other spectra's
+                        _batch.add_reflected(
+                            (nlevel, nwno, ng, nt, tt, toon["toon_coefficients"], b_top, tuple(gweight), tuple(tweight)),
+                            dict(ctx=ctx, planes=pl, rs=rs, ubar0=ubar0, ubar1=ubar1, cos_theta=cos_theta, F0PI=d_f0,
+                                 xint=x, albedo=alb))
                     else:
                         _reflected(ctx, nlevel, nwno, ng, nt, pl, rs, ubar0, ubar1, cos_theta, d_f0, *tt,
                                    toon["toon_coefficients"], b_top, x, lv, gweight, tweight,
@@ -1385,6 +1392,12 @@ def picaso(bundle, opacityclass, dimension="1d", calculation="reflected", full_o
                                                pl["dtau_og"], pl["w0_no_raman"], pl["cosb_og"],
                                                atm.level["pressure"], ubar1, rs, atm.hard_surface, gauss_wts,
                                                fx, lvl_fluxes=lv, **kw)
+                    elif _batch is not None and lv is None and fuse and not tkw:
+                        _batch.add_thermal(
+                            (nlevel, nwno, ng, nt, int(atm.hard_surface), d_wno.addr, tuple(gweight), tuple(tweight)),
+                            dict(ctx=tctx, wno=d_wno, tlevel=np.array(atm.level["temperature"], dtype=float),
+                                 plevel=np.array(atm.level["pressure"], dtype=float), dtau=pl["dtau_og"],
+                                 w0=pl["w0_no_raman"], cosb=pl["cosb_og"], ubar1=ubar1, rs=rs, flux=fx, disk=disk))
                     else:
                         resident.thermal_1d(tctx, nlevel, d_wno, nwno, ng, nt, atm.level["temperature"],
                                             pl["dtau_og"], pl["w0_no_raman"], pl["cosb_og"],
@@ -1478,6 +1491,88 @@ def picaso(bundle, opacityclass, dimension="1d", calculation="reflected", full_o
         return out
     finish.dev, finish.ctx, finish.tctx = dev_results, ctx, tctx
     return finish if defer else finish()
+
+
+# ------------------------------------------------------------------------------------------------
+# several spectra in one launch: the retrieval / grid callers of the reference run
+# spectrum() once per sample in separate processes (driver.py:405-426, justdoit.py:4741-4777)
+# ------------------------------------------------------------------------------------------------
+class _SolveBatch:
+    """The Toon solver launches of several ``picaso(defer=True, _batch=...)`` calls, issued by ``flush()`` as ONE
+    batched launch per group of spectra that share shape and options (``picaso_get_reflected_1d_batch_dev`` /
+    ``picaso_get_thermal_1d_batch_dev``): every spectrum is bit-identical to its own launch, the GPU sees one grid
+    that fills it instead of B that each leave its SIMDs half empty."""
+
+    def __init__(self):
+        self.refl, self.therm = {}, {}
+
+    def add_reflected(self, key, item):
+        self.refl.setdefault(key, []).append(item)
+
+    def add_thermal(self, key, item):
+        self.therm.setdefault(key, []).append(item)
+
+    def flush(self):
+        for key, items in self.refl.items():
+            nlevel, nwno, ng, nt, tt, tcoef, b_top, gw, tw = key
+            ctx = items[0]["ctx"]
+            if len(items) == 1:
+                it = items[0]
+                _reflected(ctx, nlevel, nwno, ng, nt, it["planes"], it["rs"], it["ubar0"], it["ubar1"],
+                           it["cos_theta"], it["F0PI"], *tt, tcoef, b_top, it["xint"], None, gw, tw, it["albedo"])
+                continue
+            same = all(np.array_equal(it["ubar0"], items[0]["ubar0"]) and np.array_equal(it["ubar1"], items[0]["ubar1"])
+                       and it["cos_theta"] == items[0]["cos_theta"] for it in items)
+            u0 = items[0]["ubar0"] if same else np.stack([np.asarray(it["ubar0"], dtype=float).reshape(ng, nt) for it in items])
+            u1 = items[0]["ubar1"] if same else np.stack([np.asarray(it["ubar1"], dtype=float).reshape(ng, nt) for it in items])
+            ct = items[0]["cos_theta"] if same else np.array([it["cos_theta"] for it in items], dtype=float)
+            resident.reflected_1d_batch(ctx, nlevel, nwno, ng, nt, [it["planes"] for it in items],
+                                        [it["rs"] for it in items], u0, u1, ct, [it["F0PI"] for it in items], *tt,
+                                        [it["xint"] for it in items], toon_coefficients=tcoef, b_top=b_top,
+                                        gweight=gw, tweight=tw, albedo=[it["albedo"] for it in items])
+        for key, items in self.therm.items():
+            nlevel, nwno, ng, nt, hard, _, gw, tw = key
+            ctx = items[0]["ctx"]
+            if len(items) == 1:
+                it = items[0]
+                resident.thermal_1d(ctx, nlevel, it["wno"], nwno, ng, nt, it["tlevel"], it["dtau"], it["w0"], it["cosb"],
+                                    it["plevel"], it["ubar1"], it["rs"], hard, it["flux"], gweight=gw, tweight=tw,
+                                    flux_disk=it["disk"])
+                continue
+            same = all(np.array_equal(it["ubar1"], items[0]["ubar1"]) for it in items)
+            u1 = items[0]["ubar1"] if same else np.stack([np.asarray(it["ubar1"], dtype=float).reshape(ng, nt) for it in items])
+            resident.thermal_1d_batch(ctx, nlevel, items[0]["wno"], nwno, ng, nt, np.stack([it["tlevel"] for it in items]),
+                                      [it["dtau"] for it in items], [it["w0"] for it in items],
+                                      [it["cosb"] for it in items], np.stack([it["plevel"] for it in items]), u1,
+                                      [it["rs"] for it in items], hard, [it["flux"] for it in items], gweight=gw,
+                                      tweight=tw, flux_disk=[it["disk"] for it in items])
+        self.refl, self.therm = {}, {}
+
+
+def spectrum_batch(cases, opacityclass, calculation="reflected", full_output=False, as_dict=True, batch_size=16):
+    """``[case.spectrum(opacityclass, calculation) for case in cases]`` (1-D) with the solvers of up to
+    ``batch_size`` spectra in ONE launch each: what a retrieval or a model grid asks of the reference one
+    ``spectrum()`` call and one process at a time (driver.py:405-426).  ``cases``: ``inputs`` objects, each with its
+    own atmosphere / clouds / geometry / approximations; spectra whose grids and options agree share a launch (the
+    others go alone), correlated-k, SH, patchy-cloud and level-flux cases take their usual path.  Every output
+    dictionary is bit-identical to ``case.spectrum(...)``'s.  HBM: the planes of a chunk stay resident until its
+    launch (0.8 GB per cloudy 1e5 x 90 spectrum, 0.2 GB per cloud-free one)."""
+    cases = list(cases)
+    outs = []
+    for c0 in range(0, len(cases), max(1, int(batch_size))):
+        chunk = cases[c0:c0 + max(1, int(batch_size))]
+        batch = _SolveBatch()
+        fins = []
+        for case in chunk:
+            if case.inputs["atmosphere"].get("profile") is None:
+                raise Exception("Need to set atmosphere profile with the atmosphere() function")
+            if case.inputs["planet"]["gravity"] is None:
+                raise Exception("Need to set gravity with the gravity() function")
+            fins.append(picaso(case, opacityclass, dimension="1d", calculation=calculation, full_output=full_output,
+                               as_dict=as_dict, defer=True, _batch=batch))
+        batch.flush()
+        outs.extend(fin() for fin in fins)
+    return outs
 
 
 # ------------------------------------------------------------------------------------------------

@@ -216,3 +216,72 @@ def test_thermal_batch_several_geometries_hard_surface():
         f1, d1 = _single_thermal(ctx, host[s], devs[s], wno_d, nlayer, nwno, geoms[s], 1)
         assert np.array_equal(fs[s].to_host(), f1), s
         assert np.array_equal(ds[s].to_host(), d1), s
+
+
+# ---- the product call: justdoit.spectrum_batch ----
+import os  # noqa: E402
+
+from helpers import GOLDEN  # noqa: E402
+from test_devices_gpu import _same  # noqa: E402
+
+DB = os.path.join(GOLDEN, "synthetic_opacities.db")
+
+
+def _product_case(og, jdi, k, cloud=True, phase=0.0, approx=None):
+    """Atmosphere k of a 'retrieval': its own temperature offset, abundances, cloud depth and surface."""
+    case = jdi.inputs()
+    if phase == 0.0:
+        case.phase_angle(0)
+    else:
+        case.phase_angle(phase, num_gangle=4, num_tangle=2)      # 8 facets: a geometry of its own
+    case.gravity(gravity=float(og["in/gravity"]) * (1.0 + 0.05 * k), radius=7.1e9, mass=1.9e30)
+    prof = {"pressure": og["in/plevel_bar"], "temperature": og["in/tlevel"] * (1.0 + 0.02 * k)}
+    for j, m in enumerate(("H2", "He", "H2O", "CH4")):
+        prof[m] = og["in/mix/" + m] * (1.0 + (0.1 * k if j >= 2 else 0.0))
+    case.atmosphere(df=prof)
+    if cloud:
+        case.clouds(df={"opd": og["in/cld_opd"] * (0.5 + 0.5 * k), "w0": og["in/cld_w0"], "g0": og["in/cld_g0"]})
+    nwno = len(og["in/wno"])
+    case.star(relative_flux=1.0 + 0.3 * np.sin(np.arange(nwno) / 7.0), radius=6.9e10, semi_major=7.5e12)
+    case.surface_reflect(0.05 * k)
+    case.approx(**(approx or dict(raman="none", delta_eddington=True)))
+    return case
+
+
+@pytest.mark.parametrize("calc", ["reflected", "thermal", "reflected+thermal", "reflected+thermal+transmission"])
+@pytest.mark.parametrize("B", [2, 4, 7])
+def test_spectrum_batch_equals_spectrum_calls(calc, B):
+    """B atmospheres through spectrum_batch (one solver launch per leg for the whole batch) against B spectrum()
+    calls: every key of every output dictionary, full_output included, bit for bit."""
+    from picaso_amd import justdoit as jdi
+    og = np.load(os.path.join(GOLDEN, "optics.npz"))
+    opa = jdi.opannection(filename_db=DB, query_method="linear")
+    want = [_product_case(og, jdi, k).spectrum(opa, calculation=calc, full_output=True) for k in range(B)]
+    got = jdi.spectrum_batch([_product_case(og, jdi, k) for k in range(B)], opa, calculation=calc, full_output=True)
+    assert len(got) == B
+    for w, g in zip(want, got):
+        _same(w, g)
+
+
+def test_spectrum_batch_mixed_cases_and_chunks():
+    """Cloudy and cloud-free atmospheres, two phase angles and a non-default approximation in one call, chunks of 3:
+    cases that cannot share a launch go alone, the outputs still come back in order and equal spectrum()'s."""
+    from picaso_amd import justdoit as jdi
+    og = np.load(os.path.join(GOLDEN, "optics.npz"))
+    opa = jdi.opannection(filename_db=DB, query_method="linear")
+
+    def cases():
+        return [_product_case(og, jdi, 0), _product_case(og, jdi, 1, cloud=False), _product_case(og, jdi, 2, phase=0.8),
+                _product_case(og, jdi, 3, approx=dict(raman="none", single_phase="OTHG", multi_phase="N=1")),
+                _product_case(og, jdi, 4, cloud=False), _product_case(og, jdi, 5, phase=0.8),
+                _product_case(og, jdi, 6, approx=dict(raman="pollack")) if getattr(opa, "raman_db", None) is not None
+                else _product_case(og, jdi, 6)]
+    want = [c.spectrum(opa, calculation="reflected+thermal") for c in cases()]
+    got = jdi.spectrum_batch(cases(), opa, calculation="reflected+thermal", batch_size=3)
+    for w, g in zip(want, got):
+        _same(w, g)
+    with pytest.raises(Exception, match="gravity"):
+        bad = jdi.inputs()
+        bad.phase_angle(0)
+        bad.atmosphere(df={"pressure": og["in/plevel_bar"], "temperature": og["in/tlevel"], "H2": og["in/mix/H2"]})
+        jdi.spectrum_batch([bad], opa)
