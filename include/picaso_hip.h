@@ -219,6 +219,23 @@ int picaso_get_reflected_3d_dev(picaso_ctx *ctx, int nlevel, int nwno, int numg,
                                 double *xint_at_top, const double *gweight, const double *tweight,
                                 double *albedo);
 
+/* `nspec` 3-D spectra (the phases of a phase curve, justdoit.py:4741-4777) in one launch: host arrays of nspec device
+ * pointers; a plane family that picaso_get_reflected_3d_dev accepts as NULL is left out for ALL spectra by passing
+ * a NULL array; ubar0 / ubar1 (nspec, numg, numt) and cos_theta (nspec) on the host.  Bit-identical per spectrum to
+ * picaso_get_reflected_3d_dev (fluxes.py:354-660). */
+int picaso_get_reflected_3d_batch_dev(picaso_ctx *ctx, int nspec, int nlevel, int nwno, int numg, int numt,
+                                      const double *const *dtau_3d, const double *const *tau_3d,
+                                      const double *const *w0_3d, const double *const *cosb_3d,
+                                      const double *const *gcos2_3d, const double *const *ftau_cld_3d,
+                                      const double *const *ftau_ray_3d, const double *const *dtau_og_3d,
+                                      const double *const *tau_og_3d, const double *const *w0_og_3d,
+                                      const double *const *cosb_og_3d, const double *const *surf_reflect,
+                                      const double *ubar0, const double *ubar1, const double *cos_theta,
+                                      const double *const *F0PI, int single_phase, int multi_phase, double frac_a,
+                                      double frac_b, double frac_c, double constant_back, double constant_forward,
+                                      double *const *xint_at_top, const double *gweight, const double *tweight,
+                                      double *const *albedo);
+
 /* ---- Toon89 two-stream thermal emission --------------------------------------------------- */
 /* replaces fluxes.get_thermal_1d (reference picaso/fluxes.py:1682-1912).
  * Outputs: flux_at_top (numg,numt,nwno); the four (numg,numt,nlevel,nwno) arrays are written when
@@ -270,6 +287,16 @@ int picaso_get_thermal_3d_dev(picaso_ctx *ctx, int nlevel, const double *wno, in
                               double *int_at_top, const double *gweight, const double *tweight,
                               double *flux_disk);
 
+/* `nspec` 3-D thermal spectra in one launch: tlevel_3d / plevel_3d (nspec, nlevel, numg, numt) and ubar1
+ * (nspec, numg, numt) on the host, the rest host arrays of nspec device pointers (cosb_3d == NULL: no cloud in any
+ * spectrum).  Bit-identical per spectrum to picaso_get_thermal_3d_dev (fluxes.py:2147-2352). */
+int picaso_get_thermal_3d_batch_dev(picaso_ctx *ctx, int nspec, int nlevel, const double *wno, int nwno, int numg,
+                                    int numt, const double *tlevel_3d, const double *const *dtau_3d,
+                                    const double *const *w0_3d, const double *const *cosb_3d,
+                                    const double *plevel_3d, const double *ubar1,
+                                    const double *const *surf_reflect, int hard_surface, double *const *int_at_top,
+                                    const double *gweight, const double *tweight, double *const *flux_disk);
+
 /* ---- spherical harmonics (SH2 / SH4) ------------------------------------------------------- */
 /* replaces fluxes.get_reflected_SH with setup_2/4_stream_fluxes + solve_4_stream_banded (reference
  * picaso/fluxes.py:2675-2976, :3189-3628).  stream = 2 or 4.  Output xint_at_top (numg,numt,nwno);
@@ -305,6 +332,25 @@ int picaso_get_reflected_SH_dev(picaso_ctx *ctx, int nlevel, int nwno, long plan
                                 int single_form, int compound_f_deltaM, double *xint_at_top,
                                 double *flux, const double *gweight, const double *tweight,
                                 double *albedo);
+
+/* `nspec` SH spectra (flx = 0) of one shape and option set in one launch, see picaso_get_reflected_1d_batch_dev:
+ * host arrays of nspec device pointers, ngeom = 1 or nspec geometries (at most 16 disk angles), bit-identical per
+ * spectrum to picaso_get_reflected_SH_dev (fluxes.py:2675-2976).  Planes are read, never modified (the reference's
+ * in-place f_deltaM compounding is reproduced per angle inside the kernel). */
+int picaso_get_reflected_SH_batch_dev(picaso_ctx *ctx, int nspec, int nlevel, int nwno, long plane_pitch, int numg,
+                                      int numt, const double *const *dtau, const double *const *tau,
+                                      const double *const *w0, const double *const *cosb,
+                                      const double *const *ftau_cld, const double *const *ftau_ray,
+                                      const double *const *f_deltaM, const double *const *dtau_og,
+                                      const double *const *tau_og, const double *const *w0_og,
+                                      const double *const *cosb_og, const double *const *surf_reflect, int ngeom,
+                                      const double *ubar0, const double *ubar1, const double *cos_theta,
+                                      const double *const *F0PI, int w_single_form, int w_multi_form,
+                                      int psingle_form, int w_single_rayleigh, int w_multi_rayleigh,
+                                      int psingle_rayleigh, double frac_a, double frac_b, double frac_c,
+                                      double constant_back, double constant_forward, int stream, double b_top,
+                                      int single_form, int compound_f_deltaM, double *const *xint_at_top,
+                                      const double *gweight, const double *tweight, double *const *albedo);
 
 /* replaces fluxes.get_thermal_SH (reference picaso/fluxes.py:2979-3186), flx = 0.  Of the
  * reference's arguments only tlevel, dtau, w0, cosb_og, plevel, ubar1, surf_reflect are read by

@@ -857,6 +857,95 @@ int picaso_get_reflected_3d_dev(picaso_ctx *ctx, int nlevel, int nwno, int numg,
     return 0;
 }
 
+int picaso_get_reflected_3d_batch_dev(picaso_ctx *ctx, int nspec, int nlevel, int nwno, int numg, int numt,
+                                      const double *const *dtau_3d, const double *const *tau_3d,
+                                      const double *const *w0_3d, const double *const *cosb_3d,
+                                      const double *const *gcos2_3d, const double *const *ftau_cld_3d,
+                                      const double *const *ftau_ray_3d, const double *const *dtau_og_3d,
+                                      const double *const *tau_og_3d, const double *const *w0_og_3d,
+                                      const double *const *cosb_og_3d, const double *const *surf_reflect,
+                                      const double *ubar0, const double *ubar1, const double *cos_theta,
+                                      const double *const *F0PI, int single_phase, int multi_phase, double frac_a,
+                                      double frac_b, double frac_c, double constant_back, double constant_forward,
+                                      double *const *xint_at_top, const double *gweight, const double *tweight,
+                                      double *const *albedo)
+{
+    if (!ctx) return fail(nullptr, "null context");
+    if (nspec < 1) return fail(ctx, "get_reflected_3d_batch: nspec must be >= 1, got %d", nspec);
+    if (nlevel < 2 || nwno < 1 || numg < 1 || numt < 1) return fail(ctx, "get_reflected_3d_batch: bad sizes");
+    PZ_TRY(check_phase_options(ctx, single_phase, multi_phase, 0));
+    if (!dtau_3d || !w0_3d || !surf_reflect || !F0PI || !xint_at_top || !ubar0 || !ubar1 || !cos_theta)
+        return fail(ctx, "get_reflected_3d_batch: null argument");
+    // a plane family is given for every spectrum or (NULL array) for none: the launch has ONE presence pattern
+    const double *const *pl[11] = {dtau_3d, tau_3d, w0_3d, cosb_3d, gcos2_3d, ftau_cld_3d, ftau_ray_3d, dtau_og_3d,
+                                   tau_og_3d, w0_og_3d, cosb_og_3d};
+    for (int j = 0; j < 11; ++j)
+        for (int s = 0; pl[j] && s < nspec; ++s)
+            if (!pl[j][s]) return fail(ctx, "get_reflected_3d_batch: plane %d of spectrum %d is NULL (a plane family is "
+                                           "given for every spectrum or left out as a whole)", j, s);
+    const int ncld = (cosb_3d != nullptr) + (ftau_cld_3d != nullptr) + (ftau_ray_3d != nullptr) + (cosb_og_3d != nullptr);
+    if (ncld != 0 && ncld != 4)
+        return fail(ctx, "get_reflected_3d_batch: cosb, ftau_cld, ftau_ray and cosb_og are given together or all NULL");
+    if (ncld == 0 && gcos2_3d) return fail(ctx, "get_reflected_3d_batch: gcos2 without ftau_ray");
+    if ((dtau_og_3d != nullptr) != (w0_og_3d != nullptr))
+        return fail(ctx, "get_reflected_3d_batch: dtau_og and w0_og are given together or both NULL");
+    if (!dtau_og_3d && tau_og_3d) return fail(ctx, "get_reflected_3d_batch: tau_og without dtau_og");
+    const bool fuse = albedo && gweight && tweight;
+    for (int s = 0; s < nspec; ++s)
+        if (!surf_reflect[s] || !F0PI[s] || !xint_at_top[s] || (fuse && !albedo[s]))
+            return fail(ctx, "get_reflected_3d_batch: null per-spectrum pointer (spectrum %d)", s);
+    PZ_HIP(ctx, hipSetDevice(ctx->device));
+    const int nfac = numg * numt;
+    // table: nspec entries, then every spectrum's |ubar0|, |ubar1| facet tables
+    const size_t head = align_up(sizeof(ReflBatchItem) * (size_t)nspec, 256);
+    std::vector<char> tab(head + sizeof(double) * 2 * (size_t)nfac * nspec);
+    if (tab.size() > picaso_ctx::SLOT_BYTES) return fail(ctx, "get_reflected_3d_batch: too many spectra for one call");
+    ReflBatchItem *items = (ReflBatchItem *)tab.data();
+    double *geo = (double *)(tab.data() + head);
+    const char *dbase = ctx->ring_d + (size_t)ctx->ring_next * picaso_ctx::SLOT_BYTES;
+    for (int s = 0; s < nspec; ++s) {
+        ReflBatchItem &it = items[s];
+        memset(&it, 0, sizeof(it));
+        auto at = [&](int j) { return pl[j] ? pl[j][s] : nullptr; };
+        it.dtau = at(0); it.tau = at(1); it.w0 = at(2); it.cosb = at(3); it.gcos2 = at(4); it.ftau_cld = at(5);
+        it.ftau_ray = at(6); it.dtau_og = at(7); it.tau_og = at(8); it.w0_og = at(9); it.cosb_og = at(10);
+        it.surf_reflect = surf_reflect[s]; it.F0PI = F0PI[s]; it.xint = xint_at_top[s]; it.albedo = nullptr;
+        it.cos_theta = cos_theta[s];
+        for (int i = 0; i < nfac; ++i) {
+            geo[(size_t)2 * s * nfac + i] = ubar0[(size_t)s * nfac + i];
+            geo[(size_t)(2 * s + 1) * nfac + i] = ubar1[(size_t)s * nfac + i];
+        }
+        it.u0_tab = (const double *)(dbase + head) + (size_t)2 * s * nfac;
+        it.u1_tab = it.u0_tab + nfac;
+    }
+    const void *d = nullptr;
+    PZ_TRY(table_upload(ctx, tab.data(), tab.size(), &d));
+    if ((const char *)d != dbase) return fail(ctx, "get_reflected_3d_batch: table slot moved");
+    ReflectedArgs a{};
+    a.nlayer = nlevel - 1;
+    a.ncol = (long)nwno * nfac;
+    a.pitch = a.ncol;
+    a.nfac = nfac;
+    a.nwno = nwno;
+    a.dtau = dtau_3d[0]; a.tau = tau_3d ? tau_3d[0] : nullptr; a.w0 = w0_3d[0]; a.cosb = cosb_3d ? cosb_3d[0] : nullptr;
+    a.gcos2 = gcos2_3d ? gcos2_3d[0] : nullptr; a.ftau_cld = ftau_cld_3d ? ftau_cld_3d[0] : nullptr;
+    a.ftau_ray = ftau_ray_3d ? ftau_ray_3d[0] : nullptr; a.dtau_og = dtau_og_3d ? dtau_og_3d[0] : nullptr;
+    a.tau_og = tau_og_3d ? tau_og_3d[0] : nullptr; a.w0_og = w0_og_3d ? w0_og_3d[0] : nullptr;
+    a.cosb_og = cosb_og_3d ? cosb_og_3d[0] : nullptr;
+    a.single_phase = single_phase; a.multi_phase = multi_phase; a.toon_coefficients = 0;
+    a.frac_a = frac_a; a.frac_b = frac_b; a.frac_c = frac_c; a.constant_back = constant_back;
+    a.constant_forward = constant_forward; a.b_top = 0.0;
+    a.na = 1;
+    a.batch = (const ReflBatchItem *)d;
+    a.nspec = nspec;
+    PZ_TRY(launch_reflected_toa(ctx, a, true));
+    if (fuse)
+        for (int s = 0; s < nspec; ++s)
+            PZ_TRY(picaso_compress_disco_dev(ctx, nwno, cos_theta[s], xint_at_top[s], gweight, numg, tweight, numt,
+                                             F0PI[s], albedo[s]));
+    return 0;
+}
+
 int picaso_get_reflected_3d(picaso_ctx *ctx, int nlevel, const double *wno, int nwno, int numg,
                             int numt, const double *dtau_3d, const double *tau_3d,
                             const double *w0_3d, const double *cosb_3d, const double *gcos2_3d,
@@ -1225,6 +1314,73 @@ int picaso_get_thermal_3d_dev(picaso_ctx *ctx, int nlevel, const double *wno, in
     PZ_TRY(launch_thermal_toa(ctx, a, true));
     if (flux_disk && gweight && tweight)
         PZ_TRY(picaso_compress_thermal_dev(ctx, (size_t)nwno, int_at_top, gweight, numg, tweight, numt, flux_disk));
+    return 0;
+}
+
+int picaso_get_thermal_3d_batch_dev(picaso_ctx *ctx, int nspec, int nlevel, const double *wno, int nwno, int numg,
+                                    int numt, const double *tlevel_3d, const double *const *dtau_3d,
+                                    const double *const *w0_3d, const double *const *cosb_3d,
+                                    const double *plevel_3d, const double *ubar1,
+                                    const double *const *surf_reflect, int hard_surface, double *const *int_at_top,
+                                    const double *gweight, const double *tweight, double *const *flux_disk)
+{
+    if (!ctx) return fail(nullptr, "null context");
+    if (nspec < 1) return fail(ctx, "get_thermal_3d_batch: nspec must be >= 1, got %d", nspec);
+    if (nlevel < 2 || nwno < 1 || numg < 1 || numt < 1) return fail(ctx, "get_thermal_3d_batch: bad sizes");
+    if (!dtau_3d || !w0_3d || !surf_reflect || !int_at_top || !tlevel_3d || !plevel_3d || !ubar1)
+        return fail(ctx, "get_thermal_3d_batch: null argument");
+    const bool fuse = flux_disk && gweight && tweight;
+    for (int s = 0; s < nspec; ++s)
+        if (!dtau_3d[s] || !w0_3d[s] || (cosb_3d && !cosb_3d[s]) || !surf_reflect[s] || !int_at_top[s] ||
+            (fuse && !flux_disk[s]))
+            return fail(ctx, "get_thermal_3d_batch: null per-spectrum pointer (spectrum %d)", s);
+    PZ_HIP(ctx, hipSetDevice(ctx->device));
+    const int nfac = numg * numt;
+    const size_t per = (size_t)nfac * (2 * (size_t)nlevel + 1);           // u1, T, P of one spectrum
+    const size_t head = align_up(sizeof(ThermalBatchItem) * (size_t)nspec, 256);
+    std::vector<char> tab(head + sizeof(double) * per * nspec);
+    if (tab.size() > picaso_ctx::SLOT_BYTES)
+        return fail(ctx, "get_thermal_3d_batch: at most %zu spectra of this size per call",
+                    (picaso_ctx::SLOT_BYTES - 4096) / (sizeof(double) * per + sizeof(ThermalBatchItem)));
+    ThermalBatchItem *items = (ThermalBatchItem *)tab.data();
+    double *lv = (double *)(tab.data() + head);
+    const char *dbase = ctx->ring_d + (size_t)ctx->ring_next * picaso_ctx::SLOT_BYTES;
+    for (int s = 0; s < nspec; ++s) {
+        double *t_u1 = lv + per * s, *t_T = t_u1 + nfac, *t_P = t_T + (size_t)nlevel * nfac;
+        for (int i = 0; i < nfac; ++i) t_u1[i] = ubar1[(size_t)s * nfac + i];
+        memcpy(t_T, tlevel_3d + (size_t)s * nlevel * nfac, sizeof(double) * (size_t)nlevel * nfac);
+        memcpy(t_P, plevel_3d + (size_t)s * nlevel * nfac, sizeof(double) * (size_t)nlevel * nfac);
+        ThermalBatchItem &it = items[s];
+        memset(&it, 0, sizeof(it));
+        it.dtau = dtau_3d[s]; it.w0 = w0_3d[s]; it.cosb = cosb_3d ? cosb_3d[s] : nullptr;
+        it.surf_reflect = surf_reflect[s];
+        it.u1_tab = (const double *)(dbase + head) + per * s;
+        it.tlevel = it.u1_tab + nfac;
+        it.plevel = it.tlevel + (size_t)nlevel * nfac;
+        it.flux = int_at_top[s];
+        it.disk = nullptr;
+    }
+    const void *d = nullptr;
+    PZ_TRY(table_upload(ctx, tab.data(), tab.size(), &d));
+    if ((const char *)d != dbase) return fail(ctx, "get_thermal_3d_batch: table slot moved");
+    ThermalArgs a{};
+    a.nlayer = nlevel - 1;
+    a.ncol = (long)nwno * nfac;
+    a.pitch = a.ncol;
+    a.nfac = nfac;
+    a.nwno = nwno;
+    a.wno = wno; a.dwno = nullptr;
+    a.dtau = dtau_3d[0]; a.w0 = w0_3d[0]; a.cosb = cosb_3d ? cosb_3d[0] : nullptr;    // cosb: the presence pattern
+    a.surf_reflect = surf_reflect[0];
+    a.hard_surface = hard_surface; a.calc_type = 0;
+    a.na = 1;
+    a.disk = nullptr;
+    a.batch = (const ThermalBatchItem *)d;
+    a.nspec = nspec;
+    PZ_TRY(launch_thermal_toa(ctx, a, true));
+    if (fuse)
+        for (int s = 0; s < nspec; ++s)
+            PZ_TRY(picaso_compress_thermal_dev(ctx, (size_t)nwno, int_at_top[s], gweight, numg, tweight, numt, flux_disk[s]));
     return 0;
 }
 

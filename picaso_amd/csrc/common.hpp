@@ -24,7 +24,7 @@ struct picaso_ctx {
     // ring of small pinned-host/device slots for geometry / profile tables handed over as host
     // pointers by the *_dev entry points (which return before the stream has consumed them)
     static constexpr int NSLOT = 8;
-    static constexpr size_t SLOT_BYTES = 1u << 20;
+    static constexpr size_t SLOT_BYTES = 4u << 20;      // a batched 3-D launch carries every spectrum's level tables
     char *ring_h = nullptr, *ring_d = nullptr;
     hipEvent_t ring_ev[NSLOT] = {};
     bool ring_pending[NSLOT] = {};

@@ -66,6 +66,16 @@ struct SHArgs {
     // flx = 1 (reflected): layer moment fluxes F.X + G (calculate_flux, fluxes.py:3631-3635)
     double *flux;                            // (angles of this launch, stream*nlevel, nwno)
     double *scratch;                         // (angles, 4 NB^2 + 5 NB, nlayer, nwno) sweep-1 state
+    // batched launch (picaso_get_reflected_SH_batch_dev): blockIdx.y = spectrum, see ReflectedArgs::batch
+    const struct SHBatchItem *batch;
+    int nspec_;
+};
+struct SHBatchItem {
+    const double *dtau, *tau, *w0, *ftau_cld, *ftau_ray, *f_deltaM, *dtau_og, *tau_og, *w0_og, *cosb_og;
+    const double *surf_reflect, *F0PI;
+    double *xint;
+    double cos_theta;
+    SHArgs::Angle ang[SH_MAX_ANG];
 };
 
 __device__ __forceinline__ double clip35(double x) { return fmin(fmax(x, -35.0), 35.0); }   // slice_rav
@@ -297,11 +307,11 @@ __device__ __forceinline__ void modes_sh2(const double (&a)[2], double dt, Modes
 // FAST: the reference's default SH options (config.json: TTHG weights for single and multiple
 // scattering, TTHG single-scattering phase function, Rayleigh in all three, explicit single form,
 // frac_c = 2) fixed at compile time: the nine option words are branches inside the layer loop otherwise.
-template <int NB, bool THERMAL, bool FLX, bool FAST = false>
 #ifndef PZ_SH_MINWAVES
 #define PZ_SH_MINWAVES 2
 #endif
-__global__ __launch_bounds__(256, PZ_SH_MINWAVES) void k_sh(const SHArgs a)
+template <int NB, bool THERMAL, bool FLX, bool FAST, typename AnglePtr>
+__device__ __forceinline__ void sh_body(const SHArgs &a, AnglePtr angp)
 {
     constexpr int NS = 2 * NB;      // stream
     // 1-D grid, XCD-aware order.  Consecutive workgroups go to consecutive XCDs (8 of them, each with
@@ -331,7 +341,7 @@ __global__ __launch_bounds__(256, PZ_SH_MINWAVES) void k_sh(const SHArgs a)
     const int w_single_rayleigh = FAST ? 1 : a.w_single_rayleigh, w_multi_rayleigh = FAST ? 1 : a.w_multi_rayleigh;
     const int psingle_rayleigh = FAST ? 1 : a.psingle_rayleigh;
     const double frac_c = FAST ? 2.0 : a.frac_c;
-    const SHArgs::Angle &g = a.ang[ang];
+    const auto &g = angp[ang];
     const double u0 = g.u0, u1 = g.u1, ct = a.cos_theta;
     const int fd_power = a.compound ? a.first_angle + ang + 1 : 1;   // compounded f_deltaM
     double *const xint = a.xint + (long)ang * a.nwno;
@@ -900,6 +910,27 @@ __global__ __launch_bounds__(256, PZ_SH_MINWAVES) void k_sh(const SHArgs a)
     }
 }
 
+template <int NB, bool THERMAL, bool FLX, bool FAST = false>
+__global__ __launch_bounds__(256, PZ_SH_MINWAVES) void k_sh(const SHArgs a)
+{
+    sh_body<NB, THERMAL, FLX, FAST>(a, a.ang);
+}
+
+// `nspec` spectra of one shape and option set in one grid (picaso_get_reflected_SH_batch_dev): blockIdx.y = spectrum,
+// whose planes, output and angle table come from the device table a.batch, read through the constant address
+// space like kernel arguments (see k_reflected_toa_batch).  Same body, same bits.
+template <int NB, bool FAST>
+__global__ __launch_bounds__(256, PZ_SH_MINWAVES) void k_sh_batch(const SHArgs a)
+{
+    typedef const __attribute__((address_space(4))) SHBatchItem *ItemPtr;
+    const auto &it = *((ItemPtr)(unsigned long)a.batch + blockIdx.y);
+    SHArgs b = a;
+    b.dtau = it.dtau; b.tau = it.tau; b.w0 = it.w0; b.ftau_cld = it.ftau_cld; b.ftau_ray = it.ftau_ray;
+    b.f_deltaM = it.f_deltaM; b.dtau_og = it.dtau_og; b.tau_og = it.tau_og; b.w0_og = it.w0_og; b.cosb_og = it.cosb_og;
+    b.surf_reflect = it.surf_reflect; b.F0PI = it.F0PI; b.xint = it.xint; b.cos_theta = it.cos_theta;
+    sh_body<NB, false, false, FAST>(b, it.ang);
+}
+
 
 // ---------------------------------------------------------------------------------------------------------------
 // Thermal emission: the angle-independent block algebra shared between the disk angles of a lane.
@@ -1334,11 +1365,25 @@ static int launch_sh(picaso_ctx *ctx, SHArgs &a, int nang, bool thermal)
     const unsigned ncg = (unsigned)((a.nwno + block - 1) / block);          // column groups
     a.ncg = ncg;
     a.xcd_order = (ncg * (unsigned)nang >= 4u * (unsigned)ctx->ncu) && !getenv("PICASO_AMD_SH_ANGLE_MAJOR");
-    const dim3 grid(a.xcd_order ? ((ncg + 7u) / 8u) * 8u * (unsigned)nang : ncg * (unsigned)nang);
+    const unsigned nspec = a.batch ? (unsigned)a.nspec_ : 1u;
+    if (nspec > 1) a.xcd_order = (ncg * (unsigned)nang * nspec >= 4u * (unsigned)ctx->ncu) && !getenv("PICASO_AMD_SH_ANGLE_MAJOR");
+    const dim3 grid(a.xcd_order ? ((ncg + 7u) / 8u) * 8u * (unsigned)nang : ncg * (unsigned)nang, a.batch ? nspec : 1u);
     const bool flx = a.flux != nullptr;
     const bool fast = !thermal && !flx && !getenv("PICASO_AMD_SH_GENERIC") && a.w_single_form == 0 &&
                       a.w_multi_form == 0 && a.psingle_form == 0 && a.single_form == 0 && a.w_single_rayleigh == 1 &&
                       a.w_multi_rayleigh == 1 && a.psingle_rayleigh == 1 && a.frac_c == 2.0;   // config.json defaults
+    if (a.batch) {
+        if (thermal || flx) return fail(ctx, "SH batch: reflected light without layer fluxes only");
+        if (a.stream == 4) {
+            if (fast) hipLaunchKernelGGL((k_sh_batch<2, true>), grid, dim3(block), 0, ctx->stream, a);
+            else hipLaunchKernelGGL((k_sh_batch<2, false>), grid, dim3(block), 0, ctx->stream, a);
+        } else {
+            if (fast) hipLaunchKernelGGL((k_sh_batch<1, true>), grid, dim3(block), 0, ctx->stream, a);
+            else hipLaunchKernelGGL((k_sh_batch<1, false>), grid, dim3(block), 0, ctx->stream, a);
+        }
+        PZ_HIP(ctx, hipGetLastError());
+        return 0;
+    }
     if (a.stream == 4) {
         if (thermal) hipLaunchKernelGGL((k_sh<2, true, false>), grid, dim3(block), 0, ctx->stream, a);
         else if (flx) hipLaunchKernelGGL((k_sh<2, false, true>), grid, dim3(block), 0, ctx->stream, a);
@@ -1356,6 +1401,25 @@ static int launch_sh(picaso_ctx *ctx, SHArgs &a, int nang, bool thermal)
 
 // All angles of a call go into one launch (grid.y = angle, SH_MAX_ANG per launch): a 1e5-column
 // spectrum is only 1.5 waves per SIMD per angle, five angles together fill the chip evenly.
+static SHArgs::Angle make_sh_angle(double u0, double u1, bool thermal)
+{
+    SHArgs::Angle g;
+    g.u1 = u1;
+    g.iu1 = 1.0 / g.u1;
+    g.nl1 = -LOG2E * g.iu1;
+    if (thermal) {
+        g.u0 = g.iu0 = g.mus = g.imus = g.nl0 = g.nlm = 0.0;
+    } else {
+        g.u0 = u0;
+        g.iu0 = 1.0 / g.u0;
+        g.mus = (g.u1 + g.u0) / (g.u1 * g.u0);                       // fluxes.py:2899
+        g.imus = 1.0 / g.mus;
+        g.nl0 = -LOG2E * g.iu0;
+        g.nlm = -LOG2E * g.mus;
+    }
+    return g;
+}
+
 static int launch_sh_angles(picaso_ctx *ctx, SHArgs &a, int nang, const double *ubar0, const double *ubar1,
                             double *xint_at_top, double *flux, bool thermal)
 {
@@ -1374,22 +1438,7 @@ static int launch_sh_angles(picaso_ctx *ctx, SHArgs &a, int nang, const double *
         const int m = (nang - done < max_ang) ? nang - done : max_ang;
         a.flux = flux ? flux + (size_t)done * a.stream * (a.nlayer + 1) * a.nwno : nullptr;
         a.scratch = flux ? ctx->ck_scratch : nullptr;
-        for (int k = 0; k < m; ++k) {
-            SHArgs::Angle &g = a.ang[k];
-            g.u1 = ubar1[done + k];
-            g.iu1 = 1.0 / g.u1;
-            g.nl1 = -LOG2E * g.iu1;
-            if (thermal) {
-                g.u0 = g.iu0 = g.mus = g.imus = g.nl0 = g.nlm = 0.0;
-            } else {
-                g.u0 = ubar0[done + k];
-                g.iu0 = 1.0 / g.u0;
-                g.mus = (g.u1 + g.u0) / (g.u1 * g.u0);                       // fluxes.py:2899
-                g.imus = 1.0 / g.mus;
-                g.nl0 = -LOG2E * g.iu0;
-                g.nlm = -LOG2E * g.mus;
-            }
-        }
+        for (int k = 0; k < m; ++k) a.ang[k] = make_sh_angle(thermal ? 0.0 : ubar0[done + k], ubar1[done + k], thermal);
         a.first_angle = done;
         a.nang = m;
         a.xint = xint_at_top + (size_t)done * a.nwno;
@@ -1440,6 +1489,84 @@ int picaso_get_reflected_SH_dev(picaso_ctx *ctx, int nlevel, int nwno, long plan
     PZ_TRY(launch_sh_angles(ctx, a, numg * numt, ubar0, ubar1, xint_at_top, flx ? flux : nullptr, false));
     if (albedo && gweight && tweight)
         PZ_TRY(picaso_compress_disco_dev(ctx, nwno, cos_theta, xint_at_top, gweight, numg, tweight, numt, F0PI, albedo));
+    return 0;
+}
+
+int picaso_get_reflected_SH_batch_dev(picaso_ctx *ctx, int nspec, int nlevel, int nwno, long plane_pitch, int numg,
+                                      int numt, const double *const *dtau, const double *const *tau,
+                                      const double *const *w0, const double *const *cosb,
+                                      const double *const *ftau_cld, const double *const *ftau_ray,
+                                      const double *const *f_deltaM, const double *const *dtau_og,
+                                      const double *const *tau_og, const double *const *w0_og,
+                                      const double *const *cosb_og, const double *const *surf_reflect, int ngeom,
+                                      const double *ubar0, const double *ubar1, const double *cos_theta,
+                                      const double *const *F0PI, int w_single_form, int w_multi_form,
+                                      int psingle_form, int w_single_rayleigh, int w_multi_rayleigh,
+                                      int psingle_rayleigh, double frac_a, double frac_b, double frac_c,
+                                      double constant_back, double constant_forward, int stream, double b_top,
+                                      int single_form, int compound_f_deltaM, double *const *xint_at_top,
+                                      const double *gweight, const double *tweight, double *const *albedo)
+{
+    (void)cosb;
+    if (!ctx) return fail(nullptr, "null context");
+    if (nspec < 1) return fail(ctx, "get_reflected_SH_batch: nspec must be >= 1, got %d", nspec);
+    if (nlevel < 2 || nwno < 1 || numg < 1 || numt < 1) return fail(ctx, "get_reflected_SH_batch: bad sizes");
+    if (stream != 2 && stream != 4) return fail(ctx, "get_reflected_SH_batch: stream must be 2 or 4, got %d", stream);
+    if (plane_pitch < nwno) return fail(ctx, "get_reflected_SH_batch: plane_pitch < nwno");
+    if (ngeom != 1 && ngeom != nspec)
+        return fail(ctx, "get_reflected_SH_batch: ngeom must be 1 (one geometry for all) or nspec, got %d", ngeom);
+    const int nang = numg * numt;
+    if (nang > SH_MAX_ANG) return fail(ctx, "get_reflected_SH_batch: at most %d disk angles", SH_MAX_ANG);
+    const double *const *pl[10] = {dtau, tau, w0, ftau_cld, ftau_ray, f_deltaM, dtau_og, tau_og, w0_og, cosb_og};
+    for (int j = 0; j < 10; ++j) {
+        if (!pl[j]) return fail(ctx, "get_reflected_SH_batch: null plane pointer array");
+        for (int s = 0; s < nspec; ++s)
+            if (!pl[j][s]) return fail(ctx, "get_reflected_SH_batch: plane %d of spectrum %d is NULL", j, s);
+    }
+    if (!surf_reflect || !F0PI || !xint_at_top || !ubar0 || !ubar1 || !cos_theta)
+        return fail(ctx, "get_reflected_SH_batch: null argument");
+    const bool fuse = albedo && gweight && tweight;
+    for (int s = 0; s < nspec; ++s)
+        if (!surf_reflect[s] || !F0PI[s] || !xint_at_top[s] || (fuse && !albedo[s]))
+            return fail(ctx, "get_reflected_SH_batch: null per-spectrum pointer (spectrum %d)", s);
+    if (sizeof(SHBatchItem) * (size_t)nspec > picaso_ctx::SLOT_BYTES)
+        return fail(ctx, "get_reflected_SH_batch: at most %zu spectra per call", picaso_ctx::SLOT_BYTES / sizeof(SHBatchItem));
+    PZ_HIP(ctx, hipSetDevice(ctx->device));
+    std::vector<SHBatchItem> items((size_t)nspec);
+    for (int s = 0; s < nspec; ++s) {
+        SHBatchItem &it = items[(size_t)s];
+        it.dtau = dtau[s]; it.tau = tau[s]; it.w0 = w0[s]; it.ftau_cld = ftau_cld[s]; it.ftau_ray = ftau_ray[s];
+        it.f_deltaM = f_deltaM[s]; it.dtau_og = dtau_og[s]; it.tau_og = tau_og[s]; it.w0_og = w0_og[s];
+        it.cosb_og = cosb_og[s]; it.surf_reflect = surf_reflect[s]; it.F0PI = F0PI[s]; it.xint = xint_at_top[s];
+        it.cos_theta = cos_theta[ngeom > 1 ? s : 0];
+        const double *u0 = ubar0 + (ngeom > 1 ? (size_t)s * nang : 0), *u1 = ubar1 + (ngeom > 1 ? (size_t)s * nang : 0);
+        for (int k = 0; k < nang; ++k) it.ang[k] = make_sh_angle(u0[k], u1[k], false);
+    }
+    const void *d = nullptr;
+    PZ_TRY(table_upload(ctx, items.data(), sizeof(SHBatchItem) * items.size(), &d));
+    SHArgs a{};
+    a.nlayer = nlevel - 1; a.nwno = nwno; a.stream = stream; a.pitch = plane_pitch;
+    a.dtau = dtau[0]; a.tau = tau[0]; a.w0 = w0[0]; a.ftau_cld = ftau_cld[0]; a.ftau_ray = ftau_ray[0];
+    a.f_deltaM = f_deltaM[0]; a.dtau_og = dtau_og[0]; a.tau_og = tau_og[0]; a.w0_og = w0_og[0]; a.cosb_og = cosb_og[0];
+    a.surf_reflect = surf_reflect[0]; a.F0PI = F0PI[0]; a.cos_theta = cos_theta[0];
+    a.w_single_form = w_single_form; a.w_multi_form = w_multi_form; a.psingle_form = psingle_form;
+    a.w_single_rayleigh = w_single_rayleigh; a.w_multi_rayleigh = w_multi_rayleigh;
+    a.psingle_rayleigh = psingle_rayleigh; a.single_form = single_form;
+    a.frac_a = frac_a; a.frac_b = frac_b; a.frac_c = frac_c; a.constant_back = constant_back;
+    a.constant_forward = constant_forward; a.b_top = b_top;
+    a.compound = compound_f_deltaM ? 1 : 0;
+    a.batch = (const SHBatchItem *)d;
+    a.nspec_ = nspec;
+    a.first_angle = 0;
+    a.nang = nang;
+    a.xint = xint_at_top[0];
+    a.flux = nullptr;
+    a.scratch = nullptr;
+    PZ_TRY(launch_sh(ctx, a, nang, false));
+    if (fuse)
+        for (int s = 0; s < nspec; ++s)
+            PZ_TRY(picaso_compress_disco_dev(ctx, nwno, cos_theta[ngeom > 1 ? s : 0], xint_at_top[s], gweight, numg,
+                                             tweight, numt, F0PI[s], albedo[s]));
     return 0;
 }
 

@@ -916,6 +916,14 @@ class inputs:
         # of a phase return to the context's block cache as soon as its kernels are enqueued (reuse is
         # ordered on the stream); at most `in_flight` phases keep their small result buffers pending.
         in_flight = int(os.environ.get("PICASO_AMD_PHASES_IN_FLIGHT", "16"))
+        # One solver launch per leg for a CHUNK of phases (picaso_get_reflected_3d_batch_dev / _thermal_3d_batch_dev;
+        # "all phases as one batched launch instead of joblib processes"): the phases' planes
+        # stay resident until the chunk's launch, so the chunk is sized to ~48 GB of planes (PICASO_AMD_PHASE_CHUNK
+        # overrides; 1 = one launch per phase, the round-3 form).  One batch per replica with devices=N.
+        nfac_pc = all_geom[phases[0]]["num_gangle"] * all_geom[phases[0]]["num_tangle"]
+        per_phase = 11 * 8.0 * max(self.nlevel - 1, 1) * opacityclass.nwno * nfac_pc
+        chunk = int(os.environ.get("PICASO_AMD_PHASE_CHUNK", str(max(1, min(in_flight, int(48e9 // max(per_phase, 1.0)))))))
+        batches = [_SolveBatch() if chunk > 1 else None for _ in replicas]
         results, pending = {}, []
         try:
             for i, ph in enumerate(phases):
@@ -926,12 +934,21 @@ class inputs:
                 self.inputs["atmosphere"]["profile_3d"] = profs[i]
                 if clouds_by_phase is not None:
                     self.inputs["clouds"]["profile_3d"] = clouds_by_phase[i]
+                bt = batches[i % len(replicas)]
                 pending.append((ph, picaso(self, replicas[i % len(replicas)], dimension="3d",
                                            calculation=calculation, full_output=full_output,
-                                           plot_opacity=plot_opacity, defer=True)))
+                                           plot_opacity=plot_opacity, defer=True, _batch=bt)))
+                if bt is not None and bt.pending() >= chunk * (2 if "+" in calculation else 1):
+                    bt.flush()
                 if len(pending) >= in_flight:
+                    for b_ in batches:
+                        if b_ is not None:
+                            b_.flush()
                     p0, fin = pending.pop(0)
                     results[p0] = fin()
+            for b_ in batches:
+                if b_ is not None:
+                    b_.flush()
             for p0, fin in pending:
                 results[p0] = fin()
         finally:
@@ -1299,7 +1316,13 @@ def picaso(bundle, opacityclass, dimension="1d", calculation="reflected", full_o
             xint = DeviceArray((ng, nt, nwno), ctx)
             alb = DeviceArray((nwno,), ctx)
             lvl = None
-            if dimension == "3d":                                 # justdoit.py:488-500
+            if dimension == "3d" and _batch is not None:          # phase_curve(): one launch for a chunk of phases
+                tt3 = (toon["single_phase"], toon["multi_phase"], frac_a, frac_b, frac_c, constant_back, constant_forward)
+                present = tuple(k for k in resident.REFLECTED_PLANES if planes3d.get(k) is not None)
+                _batch.add_reflected_3d((nlevel, nwno, ng, nt, tt3, present, tuple(gweight), tuple(tweight)),
+                                        dict(ctx=ctx, planes=planes3d, rs=rs, ubar0=ubar0, ubar1=ubar1,
+                                             cos_theta=cos_theta, F0PI=d_f0, xint=xint, albedo=alb))
+            elif dimension == "3d":                               # justdoit.py:488-500
                 resident.reflected_3d(ctx, nlevel, nwno, ng, nt, planes3d, rs, ubar0, ubar1, cos_theta, d_f0,
                                       toon["single_phase"], toon["multi_phase"], frac_a, frac_b, frac_c,
                                       constant_back, constant_forward, xint, gweight, tweight, alb)
@@ -1368,7 +1391,14 @@ def picaso(bundle, opacityclass, dimension="1d", calculation="reflected", full_o
             d_wno = _resident_vector(opa, "wno", wno, nwno)
             flux = DeviceArray((ng, nt, nwno), tctx)
             disk = DeviceArray((nwno,), tctx)
-            if dimension == "3d":                                 # justdoit.py:502-514
+            if dimension == "3d" and _batch is not None:
+                _batch.add_thermal_3d((nlevel, nwno, ng, nt, int(atm.hard_surface), d_wno.addr, th3[2] is not None,
+                                       tuple(gweight), tuple(tweight)),
+                                      dict(ctx=ctx, wno=d_wno, tlevel=np.array(tlev3, dtype=float),
+                                           plevel=np.array(plev3, dtype=float), dtau=planes3d[th3[0]],
+                                           w0=planes3d[th3[1]], cosb=planes3d[th3[2]] if th3[2] else None,
+                                           ubar1=ubar1, rs=rs, flux=flux, disk=disk, keep=planes3d))
+            elif dimension == "3d":                               # justdoit.py:502-514
                 resident.thermal_3d(ctx, nlevel, d_wno, nwno, ng, nt, tlev3, planes3d[th3[0]],
                                     planes3d[th3[1]], planes3d[th3[2]] if th3[2] else None, plev3, ubar1, rs,
                                     atm.hard_surface, flux, gweight, tweight, disk)
@@ -1504,7 +1534,7 @@ class _SolveBatch:
     that fills it instead of B that each leave its SIMDs half empty."""
 
     def __init__(self):
-        self.refl, self.therm = {}, {}
+        self.refl, self.therm, self.refl3, self.therm3 = {}, {}, {}, {}
 
     def add_reflected(self, key, item):
         self.refl.setdefault(key, []).append(item)
@@ -1512,7 +1542,35 @@ class _SolveBatch:
     def add_thermal(self, key, item):
         self.therm.setdefault(key, []).append(item)
 
+    def add_reflected_3d(self, key, item):
+        self.refl3.setdefault(key, []).append(item)
+
+    def add_thermal_3d(self, key, item):
+        self.therm3.setdefault(key, []).append(item)
+
+    def pending(self):
+        return sum(len(v) for d in (self.refl, self.therm, self.refl3, self.therm3) for v in d.values())
+
     def flush(self):
+        for key, items in self.refl3.items():
+            nlevel, nwno, ng, nt, tt, _, gw, tw = key
+            resident.reflected_3d_batch(items[0]["ctx"], nlevel, nwno, ng, nt, [it["planes"] for it in items],
+                                        [it["rs"] for it in items],
+                                        np.stack([np.asarray(it["ubar0"], dtype=float).reshape(ng, nt) for it in items]),
+                                        np.stack([np.asarray(it["ubar1"], dtype=float).reshape(ng, nt) for it in items]),
+                                        np.array([it["cos_theta"] for it in items], dtype=float),
+                                        [it["F0PI"] for it in items], *tt, [it["xint"] for it in items], gweight=gw,
+                                        tweight=tw, albedo=[it["albedo"] for it in items])
+        for key, items in self.therm3.items():
+            nlevel, nwno, ng, nt, hard, _, has_g, gw, tw = key
+            resident.thermal_3d_batch(items[0]["ctx"], nlevel, items[0]["wno"], nwno, ng, nt,
+                                      np.stack([it["tlevel"] for it in items]), [it["dtau"] for it in items],
+                                      [it["w0"] for it in items], [it["cosb"] for it in items] if has_g else None,
+                                      np.stack([it["plevel"] for it in items]),
+                                      np.stack([np.asarray(it["ubar1"], dtype=float).reshape(ng, nt) for it in items]),
+                                      [it["rs"] for it in items], hard, [it["flux"] for it in items], gweight=gw,
+                                      tweight=tw, flux_disk=[it["disk"] for it in items])
+        self.refl3, self.therm3 = {}, {}
         for key, items in self.refl.items():
             nlevel, nwno, ng, nt, tt, tcoef, b_top, gw, tw = key
             ctx = items[0]["ctx"]

@@ -284,6 +284,41 @@ def reflected_SH(ctx, nlevel, nwno, numg, numt, planes, surf_reflect, ubar0, uba
         ptr(gw) if gw is not None else None, ptr(tw) if tw is not None else None, _addr(albedo)), ctx)
 
 
+def reflected_SH_batch(ctx, nlevel, nwno, numg, numt, planes, surf_reflect, ubar0, ubar1, cos_theta, F0PI,
+                       w_single_form, w_multi_form, psingle_form, w_single_rayleigh, w_multi_rayleigh,
+                       psingle_rayleigh, frac_a, frac_b, frac_c, constant_back, constant_forward, stream,
+                       xint_at_top, b_top=0.0, single_form=0, compound_f_deltaM=True, gweight=None, tweight=None,
+                       albedo=None, plane_pitch=None):
+    """``len(planes)`` SH spectra (``flx=0``) in ONE launch (``picaso_get_reflected_SH_batch_dev``); arguments as
+    ``reflected_1d_batch`` with ``planes`` a list of ``SH_PLANES`` dictionaries.  Bit-identical per spectrum to
+    ``reflected_SH``."""
+    nspec = len(planes)
+    u0, u1 = np.asarray(ubar0, dtype=np.float64), np.asarray(ubar1, dtype=np.float64)
+    ngeom = nspec if u0.ndim == 3 else 1
+    shape = (nspec, numg, numt) if ngeom > 1 else (numg, numt)
+    u0, u1 = f64(u0, shape), f64(u1, shape)
+    ct = f64(np.zeros(ngeom) + np.asarray(cos_theta, dtype=np.float64), (ngeom,))
+    gw = f64(gweight) if gweight is not None else None
+    tw = f64(tweight) if tweight is not None else None
+    pitch = nwno if plane_pitch is None else plane_pitch
+    keep, cols = [], []
+    for k in SH_PLANES:
+        a, p = _ptr_array([pl[k] for pl in planes])
+        keep.append(a)
+        cols.append(p)
+    a_rs, p_rs = _ptr_array(_per_spectrum(surf_reflect, nspec))
+    a_f0, p_f0 = _ptr_array(_per_spectrum(F0PI, nspec))
+    a_x, p_x = _ptr_array(_per_spectrum(xint_at_top, nspec))
+    fuse = albedo is not None and gw is not None and tw is not None
+    a_al, p_al = _ptr_array(_per_spectrum(albedo, nspec)) if fuse else (None, None)
+    check(load().picaso_get_reflected_SH_batch_dev(
+        ctx, _ci(nspec), _ci(nlevel), _ci(nwno), ctypes.c_long(pitch), _ci(numg), _ci(numt), *cols, p_rs, _ci(ngeom),
+        ptr(u0), ptr(u1), ptr(ct), p_f0, _ci(int(w_single_form)), _ci(int(w_multi_form)), _ci(int(psingle_form)),
+        _ci(int(w_single_rayleigh)), _ci(int(w_multi_rayleigh)), _ci(int(psingle_rayleigh)), _cd(frac_a), _cd(frac_b),
+        _cd(frac_c), _cd(constant_back), _cd(constant_forward), _ci(int(stream)), _cd(b_top), _ci(int(single_form)),
+        _ci(1 if compound_f_deltaM else 0), p_x, ptr(gw) if fuse else None, ptr(tw) if fuse else None, p_al), ctx)
+
+
 def reflected_3d(ctx, nlevel, nwno, numg, numt, planes, surf_reflect, ubar0, ubar1, cos_theta, F0PI,
                  single_phase, multi_phase, frac_a, frac_b, frac_c, constant_back, constant_forward,
                  xint_at_top, gweight=None, tweight=None, albedo=None):
@@ -314,3 +349,60 @@ def thermal_3d(ctx, nlevel, wno, nwno, numg, numt, tlevel_3d, dtau_3d, w0_3d, co
         _addr(w0_3d), _addr(cosb_3d), ptr(pl), ptr(u1), _addr(surf_reflect), _ci(int(hard_surface)),
         _addr(int_at_top), ptr(gw) if gw is not None else None, ptr(tw) if tw is not None else None,
         _addr(flux_disk)), ctx)
+
+
+def reflected_3d_batch(ctx, nlevel, nwno, numg, numt, planes, surf_reflect, ubar0, ubar1, cos_theta, F0PI,
+                       single_phase, multi_phase, frac_a, frac_b, frac_c, constant_back, constant_forward,
+                       xint_at_top, gweight=None, tweight=None, albedo=None):
+    """``len(planes)`` 3-D spectra (the phases of a phase curve) in ONE launch
+    (``picaso_get_reflected_3d_batch_dev``): ``planes`` a list of plane dictionaries as ``reflected_3d`` takes them,
+    all with the same keys (a plane family the kernel re-derives is left out of every one of them); ``ubar0`` /
+    ``ubar1`` ``(nspec, numg, numt)``, ``cos_theta`` ``(nspec,)``.  Bit-identical per spectrum to ``reflected_3d``."""
+    nspec = len(planes)
+    keys = set(planes[0].keys())
+    if any(set(pl.keys()) != keys for pl in planes):
+        raise Exception("reflected_3d_batch: every spectrum must hand over the same set of planes")
+    u0, u1 = f64(ubar0, (nspec, numg, numt)), f64(ubar1, (nspec, numg, numt))
+    ct = f64(np.zeros(nspec) + np.asarray(cos_theta, dtype=np.float64), (nspec,))
+    gw = f64(gweight) if gweight is not None else None
+    tw = f64(tweight) if tweight is not None else None
+    keep, cols = [], []
+    for k in REFLECTED_PLANES:
+        if planes[0].get(k) is None:
+            cols.append(None)
+            continue
+        a, p = _ptr_array([pl[k] for pl in planes])
+        keep.append(a)
+        cols.append(p)
+    a_rs, p_rs = _ptr_array(_per_spectrum(surf_reflect, nspec))
+    a_f0, p_f0 = _ptr_array(_per_spectrum(F0PI, nspec))
+    a_x, p_x = _ptr_array(_per_spectrum(xint_at_top, nspec))
+    fuse = albedo is not None and gw is not None and tw is not None
+    a_al, p_al = _ptr_array(_per_spectrum(albedo, nspec)) if fuse else (None, None)
+    check(load().picaso_get_reflected_3d_batch_dev(
+        ctx, _ci(nspec), _ci(nlevel), _ci(nwno), _ci(numg), _ci(numt), *cols, p_rs, ptr(u0), ptr(u1), ptr(ct), p_f0,
+        _ci(single_phase), _ci(multi_phase), _cd(frac_a), _cd(frac_b), _cd(frac_c), _cd(constant_back),
+        _cd(constant_forward), p_x, ptr(gw) if fuse else None, ptr(tw) if fuse else None, p_al), ctx)
+
+
+def thermal_3d_batch(ctx, nlevel, wno, nwno, numg, numt, tlevel_3d, dtau_3d, w0_3d, cosb_3d, plevel_3d, ubar1,
+                     surf_reflect, hard_surface, int_at_top, gweight=None, tweight=None, flux_disk=None):
+    """``len(dtau_3d)`` 3-D thermal spectra in ONE launch (``picaso_get_thermal_3d_batch_dev``): ``tlevel_3d`` /
+    ``plevel_3d`` host ``(nspec, nlevel, numg, numt)``, ``ubar1`` ``(nspec, numg, numt)`` or ``(numg, numt)``; the
+    planes lists of DeviceArrays (``cosb_3d=None``: no cloud in any spectrum).  Bit-identical per spectrum to
+    ``thermal_3d``."""
+    nspec = len(dtau_3d)
+    u1 = f64(ubar1, (nspec, numg, numt))
+    tl, pl = f64(tlevel_3d, (nspec, nlevel, numg, numt)), f64(plevel_3d, (nspec, nlevel, numg, numt))
+    gw = f64(gweight) if gweight is not None else None
+    tw = f64(tweight) if tweight is not None else None
+    a_dt, p_dt = _ptr_array(list(dtau_3d))
+    a_w0, p_w0 = _ptr_array(list(w0_3d))
+    a_cb, p_cb = _ptr_array(list(cosb_3d)) if cosb_3d is not None else (None, None)
+    a_rs, p_rs = _ptr_array(_per_spectrum(surf_reflect, nspec))
+    a_fx, p_fx = _ptr_array(_per_spectrum(int_at_top, nspec))
+    fuse = flux_disk is not None and gw is not None and tw is not None
+    a_fd, p_fd = _ptr_array(_per_spectrum(flux_disk, nspec)) if fuse else (None, None)
+    check(load().picaso_get_thermal_3d_batch_dev(
+        ctx, _ci(nspec), _ci(nlevel), _addr(wno), _ci(nwno), _ci(numg), _ci(numt), ptr(tl), p_dt, p_w0, p_cb, ptr(pl),
+        ptr(u1), p_rs, _ci(int(hard_surface)), p_fx, ptr(gw) if fuse else None, ptr(tw) if fuse else None, p_fd), ctx)

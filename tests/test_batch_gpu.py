@@ -285,3 +285,64 @@ def test_spectrum_batch_mixed_cases_and_chunks():
         bad.phase_angle(0)
         bad.atmosphere(df={"pressure": og["in/plevel_bar"], "temperature": og["in/tlevel"], "H2": og["in/mix/H2"]})
         jdi.spectrum_batch([bad], opa)
+
+
+# ---- spherical harmonics ----
+@pytest.mark.parametrize("stream", [2, 4])
+@pytest.mark.parametrize("B,nwno", [(2, 500), (4, 12500), (7, 3000)])
+def test_reflected_SH_batch_equals_single_calls(stream, B, nwno, oracle):
+    """picaso_get_reflected_SH_batch_dev (fluxes.py:2675-2976 per spectrum): B atmospheres, default SH options; 4 x
+    12 500 columns is the configs[3] shard size and crosses into the XCD-ordered grid."""
+    from picaso_amd import _lib, device, resident
+    from picaso_amd import synthetic as syn
+    ctx = _lib.context()
+    nlayer = 90 if nwno > 5000 else 31
+    geom = _geom(5, 0.0)
+    ng, nt, u0, u1, ct, gw, tw = geom
+    opts = (0, 0, 0, 1, 1, 1)
+    host, devs = [], []
+    for s in range(B):
+        sc = syn.make_scene(nlayer, nwno, seed=300 + 10 * stream + s, stream=stream)
+        sc["F0PI"] = np.linspace(0.9, 1.2 + 0.1 * s, nwno)
+        sc["surf_reflect"] = np.full(nwno, 0.05 * s)
+        host.append(sc)
+        devs.append(resident.upload_scene(sc, resident.SH_PLANES + ("F0PI", "surf_reflect"), ctx=ctx))
+    xs = [device.DeviceArray((ng, nt, nwno), ctx) for _ in range(B)]
+    als = [device.DeviceArray((nwno,), ctx) for _ in range(B)]
+    resident.reflected_SH_batch(ctx, nlayer + 1, nwno, ng, nt, devs, [d["surf_reflect"] for d in devs], u0, u1, ct,
+                                [d["F0PI"] for d in devs], *opts, *TTHG, stream, xs, gweight=gw, tweight=tw, albedo=als)
+    for s in range(B):
+        x1, a1 = device.DeviceArray((ng, nt, nwno), ctx), device.DeviceArray((nwno,), ctx)
+        resident.reflected_SH(ctx, nlayer + 1, nwno, ng, nt, devs[s], devs[s]["surf_reflect"], u0, u1, ct,
+                              devs[s]["F0PI"], *opts, *TTHG, stream, x1, gweight=gw, tweight=tw, albedo=a1)
+        assert np.array_equal(xs[s].to_host(), x1.to_host()), s
+        assert np.array_equal(als[s].to_host(), a1.to_host()), s
+    sc = host[-1]
+    idx = np.linspace(0, nwno - 1, 96).astype(int)
+    planes = [np.array(sc[k][:, idx], order="C") for k in resident.SH_PLANES]
+    xo, _ = oracle.get_reflected_SH(nlayer + 1, idx.size, ng, nt, *planes, sc["surf_reflect"][idx], u0, u1, ct,
+                                    sc["F0PI"][idx], *opts, *TTHG, stream)
+    assert rel_err(xs[-1].to_host()[:, :, idx], xo) < 1e-9
+
+
+def test_reflected_SH_batch_geometries_and_generic_options():
+    """One plane set under three geometries (ubar0 != ubar1), OTHG weights: the generic kernel, per-spectrum angles."""
+    from picaso_amd import _lib, device, resident
+    from picaso_amd import synthetic as syn
+    ctx = _lib.context()
+    nlayer, nwno, B = 27, 1500, 3
+    sc = syn.make_scene(nlayer, nwno, seed=77, stream=4)
+    sc["F0PI"], sc["surf_reflect"] = np.ones(nwno), np.full(nwno, 0.2)
+    d = resident.upload_scene(sc, resident.SH_PLANES + ("F0PI", "surf_reflect"), ctx=ctx)
+    geoms = [_geom(3, ph) for ph in (0.4, 1.1, 2.0)]
+    ng, nt = geoms[0][0], geoms[0][1]
+    opts = (1, 1, 1, 1, 0, 1)
+    xs = [device.DeviceArray((ng, nt, nwno), ctx) for _ in range(B)]
+    resident.reflected_SH_batch(ctx, nlayer + 1, nwno, ng, nt, [d] * B, d["surf_reflect"], np.stack([g[2] for g in geoms]),
+                                np.stack([g[3] for g in geoms]), np.array([g[4] for g in geoms]), d["F0PI"], *opts,
+                                *TTHG, 4, xs)
+    for s, g in enumerate(geoms):
+        x1 = device.DeviceArray((ng, nt, nwno), ctx)
+        resident.reflected_SH(ctx, nlayer + 1, nwno, ng, nt, d, d["surf_reflect"], g[2], g[3], g[4], d["F0PI"], *opts,
+                              *TTHG, 4, x1)
+        assert np.array_equal(xs[s].to_host(), x1.to_host()), s

@@ -19,6 +19,22 @@ dst = os.path.join(root, "profiles")
 stats = glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True)
 if stats:
     shutil.copy(stats[0], os.path.join(dst, name + "_kernel_stats.csv"))
+# the same trace split by launch shape: bench.py's companions run one kernel at several sizes (k_sh at 1e5 and at
+# 12 500 columns, the batched launch at B = 4 and 8), which the per-kernel stats average together
+trace = glob.glob(os.path.join(src, "trace", "**", "*kernel_trace.csv"), recursive=True)
+if trace:
+    by = collections.defaultdict(list)
+    for row in csv.DictReader(open(trace[0])):
+        grid = "x".join(row[k] for k in ("Grid_Size_X", "Grid_Size_Y", "Grid_Size_Z"))
+        by[(row["Kernel_Name"], grid)].append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
+    with open(os.path.join(dst, name + "_kernel_stats_by_grid.csv"), "w") as fh:
+        w = csv.writer(fh)
+        w.writerow(["kernel", "grid_threads", "calls", "average_ns", "median_ns", "min_ns", "max_ns"])
+        for (kern, grid), d in sorted(by.items(), key=lambda kv: -sum(kv[1])):
+            if "pz::" not in kern:
+                continue
+            d = sorted(d)
+            w.writerow([kern, grid, len(d), "%.0f" % (sum(d) / len(d)), d[len(d) // 2], d[0], d[-1]])
 agg = collections.defaultdict(lambda: [0, 0.0])
 for f in sorted(glob.glob(os.path.join(src, "pmc_*", "**", "*counter_collection.csv"), recursive=True)):
     for row in csv.DictReader(open(f)):

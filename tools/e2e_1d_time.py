@@ -92,5 +92,30 @@ for devs in devsets:
         r = case.spectrum(opa, calculation=calc, devices=devs, full_output=bool(os.environ.get("FULL")))
         ts.append(time.perf_counter() - t0)
     out["spectrum_1d_%d_%s_devices_%s_ms" % (nwno, calc, "none" if devs is None else len(devs))] = round(1e3 * min(ts), 3)
+# BATCH="4,16": spectrum_batch() over that many copies of the case (each with its own temperature offset), per spectrum
+import copy
+for B in [int(x) for x in os.environ.get("BATCH", "").split(",") if x]:
+    cases = []
+    for k in range(B):
+        c = copy.deepcopy(case)
+        pk = dict(prof, temperature=prof["temperature"] * (1.0 + 0.01 * k))
+        c.atmosphere(df=pk)
+        cases.append(c)
+    for _ in range(3):
+        rb = jdi.spectrum_batch(cases, opa, calculation=calc, batch_size=B)
+    ts = []
+    for _ in range(8):
+        t0 = time.perf_counter()
+        rb = jdi.spectrum_batch(cases, opa, calculation=calc, batch_size=B)
+        ts.append(time.perf_counter() - t0)
+    tl = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        rl = [c.spectrum(opa, calculation=calc) for c in cases]
+        tl.append(time.perf_counter() - t0)
+    same = all(np.array_equal(a[k], b[k]) for a, b in zip(rb, rl) for k in a if isinstance(a[k], np.ndarray))
+    out["spectrum_batch_%d_ms_per_spectrum" % B] = round(1e3 * min(ts) / B, 3)
+    out["spectrum_loop_%d_ms_per_spectrum" % B] = round(1e3 * min(tl) / B, 3)
+    out["spectrum_batch_%d_equals_loop" % B] = bool(same)
 out["albedo_sum"] = float(np.sum(r.get("albedo", 0.0)))
 print(json.dumps(out))
