@@ -1485,9 +1485,6 @@ def picaso(bundle, opacityclass, dimension="1d", calculation="reflected", full_o
                 resident.axpby(ctx, 1.0 - fhole, tr, fhole, trc, tr)
             dev_results["transit_depth"] = tr
             collect.append(lambda: returns.__setitem__("transit_depth", tr.to_host()))
-        if not defer:
-            for fin in collect:
-                fin()
         enqueued = True
     finally:
         # The thermal leg may run on a second stream (tctx) that reads the opacity planes of `ctx`.  The planes must
@@ -1507,15 +1504,24 @@ def picaso(bundle, opacityclass, dimension="1d", calculation="reflected", full_o
     keep_alive = [planes, planes_clear] if tctx is not ctx else []
 
     def finish():
-        if defer:
-            for fin in collect:
-                fin()
+        # Results are read back leg by leg (each copy waits for the stream that produced it) and a leg's spectrum-wide
+        # integrals run as soon as it has arrived: the Bond-albedo integral overlaps the thermal kernels still running
+        # on the second stream.  Same stages, same order of keys as _postprocess.
+        out = {"wavenumber": wno}
+        for fin in collect:
+            fin()
+            if _raw:
+                continue
+            if "albedo" in returns and "albedo" not in out:
+                _post_reflected(out, returns, wno, stellar, sa, atm.planet.radius, opa)
+            if "thermal" in returns and "thermal" not in out:
+                _post_thermal(out, returns, wno, stellar, radius_star, atm.planet.radius, opa)
         del keep_alive[:]
         if _raw:          # one wavelength block of a multi-GPU spectrum: the integrals need the whole grid
             if full_output:
                 returns["full_output"] = atm.as_dict() if as_dict else atm
             return returns
-        out = _postprocess(returns, wno, stellar, sa, radius_star, atm.planet.radius, opa)
+        out = _post_final(out, returns)
         if full_output:
             out["full_output"] = atm.as_dict() if as_dict else atm
         return out
@@ -1856,50 +1862,84 @@ def _trapz_weights(opa, wno):
     return hit[1], hit[2]
 
 
-def _trapz(d, y):
-    """``np.trapezoid(y, x)`` with ``d = diff(x)`` given: numpy's own expression, so the same bits."""
-    return (d * (y[1:] + y[:-1]) / 2.0).sum(-1)
+def _trapz(d, y, buf=None):
+    """``np.trapezoid(y, x)`` with ``d = diff(x)`` given: numpy's own expression, so the same bits.  ``buf``: a scratch
+    array of ``d``'s shape for the intermediate results (three fresh 0.8 MB arrays per integral at 1e5 wavelengths
+    cost more than the arithmetic)."""
+    if buf is None or buf.shape != d.shape:
+        return (d * (y[1:] + y[:-1]) / 2.0).sum(-1)
+    np.add(y[1:], y[:-1], out=buf)
+    np.multiply(d, buf, out=buf)
+    np.divide(buf, 2.0, out=buf)
+    return buf.sum(-1)
 
 
-def _postprocess(raw, wno, stellar, sa, radius_star, planet_radius, opa=None):
-    """The spectrum-wide quantities of the reference's return dictionary (justdoit.py:552-599) from the
-    per-wavelength results: Bond albedo (Batalha+2019 eq. 18), planet-to-star flux ratios, effective
-    temperature.  Separate from the solve so that a spectrum computed in wavelength blocks on several GPUs
-    goes through exactly the same arithmetic on the gathered arrays as a single-GPU one."""
-    out = {"wavenumber": wno}
-    if "albedo" in raw:
-        albedo = raw["albedo"]
-        out["albedo"] = albedo
-        if opa is not None:
-            d, _ = _trapz_weights(opa, wno)
-            out["bond_albedo"] = _trapz(d, albedo * stellar) / _trapz(d, stellar)
-        else:
-            out["bond_albedo"] = (np.trapezoid(x=1 / wno, y=albedo * stellar) / np.trapezoid(x=1 / wno, y=stellar))
-        if (not np.isnan(sa)) and (not np.isnan(planet_radius)):
-            out["fpfs_reflected"] = albedo * (planet_radius / sa) ** 2.0
-        else:
-            out["fpfs_reflected"] = []
-    if "thermal" in raw:
-        thermal = raw["thermal"]
-        out["thermal"] = thermal
-        out["thermal_unit"] = "erg/s/(cm^2)/(cm)"
-        if opa is not None:
-            _, dr = _trapz_weights(opa, wno)
-            out["effective_temperature"] = (_trapz(dr, thermal[::-1]) / 5.67e-5) ** 0.25
-        else:
-            out["effective_temperature"] = (np.trapezoid(x=1 / wno[::-1], y=thermal[::-1]) / 5.67e-5) ** 0.25
-        if radius_star == "nostar":
-            out["fpfs_thermal"] = ["No star mode for Brown Dwarfs was used"]
-        elif (not np.isnan(planet_radius)) and (not np.isnan(radius_star)):
-            out["fpfs_thermal"] = thermal / stellar * (planet_radius / radius_star) ** 2.0
-        else:
-            out["fpfs_thermal"] = []
+def _trapz_scratch(opa, n):
+    """Two scratch vectors kept on the opacity object for the spectrum-wide integrals."""
+    hit = opa.__dict__.get("_trapz_buf")
+    if hit is None or hit[0].shape != (n - 1,):
+        hit = (np.empty(n - 1), np.empty(n))
+        opa.__dict__["_trapz_buf"] = hit
+    return hit
+
+
+def _post_reflected(out, raw, wno, stellar, sa, planet_radius, opa=None):
+    """Bond albedo (Batalha+2019 eq. 18) and the reflected planet-to-star flux ratio (justdoit.py:552-566)."""
+    albedo = raw["albedo"]
+    out["albedo"] = albedo
+    if opa is not None:
+        d, _ = _trapz_weights(opa, wno)
+        b1, b2 = _trapz_scratch(opa, len(wno))
+        denom = _trapz(d, stellar, b1)
+        np.multiply(albedo, stellar, out=b2)
+        out["bond_albedo"] = _trapz(d, b2, b1) / denom
+    else:
+        out["bond_albedo"] = (np.trapezoid(x=1 / wno, y=albedo * stellar) / np.trapezoid(x=1 / wno, y=stellar))
+    if (not np.isnan(sa)) and (not np.isnan(planet_radius)):
+        out["fpfs_reflected"] = albedo * (planet_radius / sa) ** 2.0
+    else:
+        out["fpfs_reflected"] = []
+
+
+def _post_thermal(out, raw, wno, stellar, radius_star, planet_radius, opa=None):
+    """Effective temperature and the thermal planet-to-star flux ratio (justdoit.py:567-599)."""
+    thermal = raw["thermal"]
+    out["thermal"] = thermal
+    out["thermal_unit"] = "erg/s/(cm^2)/(cm)"
+    if opa is not None:
+        _, dr = _trapz_weights(opa, wno)
+        b1, _ = _trapz_scratch(opa, len(wno))
+        out["effective_temperature"] = (_trapz(dr, thermal[::-1], b1) / 5.67e-5) ** 0.25
+    else:
+        out["effective_temperature"] = (np.trapezoid(x=1 / wno[::-1], y=thermal[::-1]) / 5.67e-5) ** 0.25
+    if radius_star == "nostar":
+        out["fpfs_thermal"] = ["No star mode for Brown Dwarfs was used"]
+    elif (not np.isnan(planet_radius)) and (not np.isnan(radius_star)):
+        out["fpfs_thermal"] = thermal / stellar * (planet_radius / radius_star) ** 2.0
+    else:
+        out["fpfs_thermal"] = []
+
+
+def _post_final(out, raw):
     if "transit_depth" in raw:
         out["transit_depth"] = raw["transit_depth"]
     if ("fpfs_reflected" in out) and ("fpfs_thermal" in out):
         if (not isinstance(out["fpfs_reflected"], list)) and (not isinstance(out["fpfs_thermal"], list)):
             out["fpfs_total"] = out["fpfs_thermal"] + out["fpfs_reflected"]
     return out
+
+
+def _postprocess(raw, wno, stellar, sa, radius_star, planet_radius, opa=None):
+    """The spectrum-wide quantities of the reference's return dictionary (justdoit.py:552-599) from the
+    per-wavelength results: Bond albedo, planet-to-star flux ratios, effective temperature.  Separate from the
+    solve so that a spectrum computed in wavelength blocks on several GPUs goes through exactly the same arithmetic
+    on the gathered arrays as a single-GPU one (which runs the three stages as its results arrive, see ``picaso``)."""
+    out = {"wavenumber": wno}
+    if "albedo" in raw:
+        _post_reflected(out, raw, wno, stellar, sa, planet_radius, opa)
+    if "thermal" in raw:
+        _post_thermal(out, raw, wno, stellar, radius_star, planet_radius, opa)
+    return _post_final(out, raw)
 
 
 def _reflected(ctx, nlevel, nwno, ng, nt, planes, rs, ubar0, ubar1, cos_theta, F0PI, single_phase,

@@ -78,7 +78,7 @@ if os.environ.get("PROFILE_1D"):
     for _ in range(50):
         case.spectrum(opa, calculation=calc, full_output=bool(os.environ.get("FULL")))
     pr.disable()
-    pstats.Stats(pr).sort_stats("cumulative").print_stats(35)
+    pstats.Stats(pr).sort_stats(os.environ.get("SORT", "cumulative")).print_stats(int(os.environ.get("TOP", "35")))
     sys.exit(0)
 out = {}
 # DEVICES="0,0,0,0": the same spectrum in wavelength blocks (on one GPU: one context per entry), host cost of the cut
