@@ -112,24 +112,14 @@ __device__ __forceinline__ void rc_angle(const double (*in)[64], const double (*
                                          RcState (&st)[NA])
 {
 #pragma clang fp contract(off)
-#ifdef PZ_RCOOP_STUB_A                                 // timing build (wrong results): the angle waves only read
-    st[0].KAPPA += slot[RC_LAM][lane];
-    return;
-#endif
     constexpr bool first = FIRST, last = LAST;
     const bool cum_tau = PLAIN || (fl & RCF_CUM_TAU), eo_ok = PLAIN || (fl & RCF_EO_OK),
                same_dt = PLAIN || (fl & RCF_SAME_DT), nocld = PLAIN || (fl & RCF_NOCLD);
-#ifdef PZ_RCOOP_STUB_LDS                               // timing build (wrong results): 3 LDS reads per layer instead of 15
-    const double lam = slot[RC_LAM][lane], EP = slot[RC_EP][lane], dt = in[RW_DT][lane];
-    const double EM = lam * 0.9, gam = EP * 0.5, Fw0h = lam * 0.1, A0 = EP * 0.2, w2pi = dt * 0.3, ssa_h = lam * 0.05;
-    const double gcq = EP * 0.01, a1i = lam * 1.1, a2i = EP * 0.3, ia = dt * 0.7, sfac = lam * 0.6, rho_n = EP * 0.4;
-#else
     const double lam = slot[RC_LAM][lane], EP = slot[RC_EP][lane], EM = slot[RC_EM][lane];
     const double gam = slot[RC_GAM][lane], dt = in[RW_DT][lane], Fw0h = slot[RC_FW0H][lane];
     const double A0 = slot[RC_A0][lane], w2pi = slot[RC_W2PI][lane], ssa_h = slot[RC_SSAH][lane];
     const double gcq = in[RW_GCOS2][lane], a1i = slot[RC_A1I][lane], a2i = slot[RC_A2I][lane];
     const double ia = slot[RC_IA][lane], sfac = slot[RC_SFAC][lane], rho_n = slot[RC_RHON][lane];
-#endif
     double A1 = 0.0, c15 = 0.0, gmc = 0.0;
     if (!nocld) {
         A1 = slot[RC_A1][lane];
@@ -154,16 +144,8 @@ __device__ __forceinline__ void rc_angle(const double (*in)[64], const double (*
     RC_FOR_K lp1[kk] = lu[kk] + 1.0;
     RC_FOR_K lml[kk] = lm1[kk] * lp1[kk];
     RC_FOR_K q3[kk] = den[kk] * lml[kk];
-#ifdef PZ_RCOOP_STUB_EXP                               // timing build (wrong results): what an exp helper could save
-    RC_FOR_K et[kk] = targ[kk] + 1.0;
-#else
     fexp2_n<NA>(targ, K, et);
-#endif
-#ifdef PZ_RCOOP_STUB_RCP
-    RC_FOR_K r3[kk] = q3[kk] + 1.0;
-#else
     frcp_n<NA>(q3, r3);
-#endif
     if (ZP) {
         RC_FOR_K e0[kk] = et[kk];
     } else {
@@ -261,18 +243,7 @@ __device__ __forceinline__ void rc_angle(const double (*in)[64], const double (*
     }
 }
 
-#ifdef PZ_RCOOP_TIMING
-// timing build: per wave of workgroup 0, cycles from kernel start to end and cycles parked at the barriers
-__device__ long long rc_dbg[16][2];
-#define RC_SYNC()                                                          \
-    do {                                                                   \
-        const long long t0__ = __builtin_readcyclecounter();                \
-        __syncthreads();                                                   \
-        dbg_wait += __builtin_readcyclecounter() - t0__;                    \
-    } while (0)
-#else
 #define RC_SYNC() __syncthreads()
-#endif
 
 struct RcShared {
     double rho, pgam, pEM;                      // the elimination recurrence of reflected_layer (S.rho, S.pgam, S.pEM)
@@ -287,10 +258,6 @@ __device__ __forceinline__ void rc_shared(const ReflectedArgs &a, const double (
                                           RcShared &sh)
 {
 #pragma clang fp contract(off)
-#ifdef PZ_RCOOP_STUB_S                                 // timing build (wrong results): wave S only copies
-    for (int v = 0; v < RC_NV; ++v) slot[v][lane] = in[v % RW_NV][lane] + 0.5;
-    return;
-#endif
     const double clip = 35.0;                         // fluxes.py:1174
     const double dt = in[RW_DT][lane], w0 = in[RW_W0][lane], fr = in[RW_FR][lane], w0o = in[RW_W0O][lane];
     const bool nocld = PLAIN || (fl & RCF_NOCLD);
@@ -456,19 +423,6 @@ __global__ __launch_bounds__(64 * (RC_MAX_ANGLES / RC_APW + 2)) void k_reflected
     __shared__ int lflag[3][RC_R];                    // wave-uniform shortcut flags of a layer (wave L)
     __shared__ int rplain[3];                         // 1: every layer of the round is interior with all flags set
     __shared__ double xs[RC_MAX_ANGLES][64];
-#ifdef PZ_RCOOP_TIMING
-    long long dbg_wait = 0;
-    const long long dbg_t0 = __builtin_readcyclecounter();
-#define RC_DONE()                                                                              \
-    do {                                                                                       \
-        if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) {                                      \
-            rc_dbg[threadIdx.x >> 6][0] = __builtin_readcyclecounter() - dbg_t0;               \
-            rc_dbg[threadIdx.x >> 6][1] = dbg_wait;                                            \
-        }                                                                                      \
-    } while (0)
-#else
-#define RC_DONE() do {} while (0)
-#endif
     const int lane = threadIdx.x & 63;
     const int hw_wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int nang = a.na;
@@ -595,7 +549,6 @@ __global__ __launch_bounds__(64 * (RC_MAX_ANGLES / RC_APW + 2)) void k_reflected
             }
         }
         RC_SYNC();
-        RC_DONE();
         return;
     }
 
@@ -613,13 +566,7 @@ __global__ __launch_bounds__(64 * (RC_MAX_ANGLES / RC_APW + 2)) void k_reflected
         auto produce_round = [&](int q) {
             const int plain = __builtin_amdgcn_readfirstlane(rplain[q % 3]);
             if (plain) {                              // straight-line, the layers of the round interleaved
-#ifdef PZ_RCOOP_STUB_S
-#pragma unroll
-                for (int j = 0; j < RC_R; ++j)
-                    rc_shared<true>(a, raw[q % 3][j], ring[q & 1][j], RCF_ALL, true, lane, F, cos_theta, K, sh);
-#else
                 rc_shared_plain_round<RC_R>(raw[q % 3], ring[q & 1], lane, F, cos_theta, K, sh);
-#endif
             } else {
 #pragma unroll
                 for (int j = 0; j < RC_R; ++j) {
@@ -646,7 +593,6 @@ __global__ __launch_bounds__(64 * (RC_MAX_ANGLES / RC_APW + 2)) void k_reflected
             if (a.albedo_last) alb = a.albedo_scale * alb / F * (a.cos_theta + 1.0);
             a.albedo[w] = alb;
         }
-        RC_DONE();
         return;
     }
 
@@ -712,7 +658,6 @@ __global__ __launch_bounds__(64 * (RC_MAX_ANGLES / RC_APW + 2)) void k_reflected
             xs[k0 + kk][lane] = x;
         }
         RC_SYNC();
-        RC_DONE();
     };
     static_assert(RC_APW == 1 || RC_APW == 2, "angle waves carry one or two angles");
     if (RC_APW == 2 && nang - k0 >= 2) angle_wave(std::integral_constant<int, RC_APW>{});
@@ -727,14 +672,6 @@ bool reflected_coop_ok(const ReflectedArgs &a)
     return a.toon_coefficients == 0 && a.single_phase == 3 && a.multi_phase == 0 && a.frac_c == 2.0;
 }
 
-#ifdef PZ_RCOOP_TIMING
-}  // namespace pz
-extern "C" int picaso_debug_rcoop(long long *out32)
-{
-    return hipMemcpyFromSymbol(out32, HIP_SYMBOL(pz::rc_dbg), sizeof(long long) * 32) == hipSuccess ? 0 : 1;
-}
-namespace pz {
-#endif
 
 int launch_reflected_coop(picaso_ctx *ctx, const ReflectedArgs &a)
 {

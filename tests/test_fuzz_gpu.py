@@ -30,7 +30,7 @@ def _tol(sc, tight, loose):
 
 def _dump(name, tag, **arrays):
     """PICASO_FUZZ_DUMP=dir: inputs and both results of a case, for a look at it off the GPU box
-    (tools/experiments/fuzz_case_x80.py evaluates the reference in extended precision on them)."""
+    (tools/fuzz_case_x80.py evaluates the reference in extended precision on them)."""
     d = os.environ.get("PICASO_FUZZ_DUMP")
     if d:
         os.makedirs(d, exist_ok=True)
@@ -99,7 +99,7 @@ def test_fuzz_reflected(oracle, block):
             # scene in 400 the difference is larger (up to 1e-4 seen): every time it is the reference's fp64
             # rounding -- its formulas evaluated in x87 extended precision (the oracle's `x80=True` build of the
             # same source) move by exactly that much, and the kernel sits 100-1000 x closer to the extended
-            # value than the fp64 reference does (tools/experiments/fuzz_case_x80.py on the reference itself).
+            # value than the fp64 reference does (tools/fuzz_case_x80.py on the reference itself).
             # Such a scene is held to helpers.lvl_excess: within tol + 2 e_ref of the reference, within
             # tol + e_ref/500 of the extended-precision value, element by element.
             if not lvl_err(lg, lo) < _tol(sc, 1e-6, 1e-5):

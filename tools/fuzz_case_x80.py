@@ -3,7 +3,7 @@
 results): where do the HIP result and the C oracle sit relative to the reference evaluated in fp64 and in x87
 extended precision?  Run in the build container (imports the reference under tools/ref_shim.py).
 
-    python tools/experiments/fuzz_case_x80.py gpurun_out/fuzz/dump/*.npz
+    python tools/fuzz_case_x80.py gpurun_out/fuzz/dump/*.npz
 """
 import os
 import sys

@@ -7,7 +7,7 @@ angle GROUPS (PICASO_AMD_ANGLE_GROUP=g: ceil(5/g) workgroups per column block, e
 stream at the same time, so that the chip holds ~512 workgroups of unequal size.  Prints ms per spectrum for a
 sweep of N1 (in 256-column blocks) and g.
 
-    python tools/experiments/hetero_split.py [--steps 200]
+    python tools/hetero_split.py [--steps 200]
 """
 import argparse
 import json
