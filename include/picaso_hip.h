@@ -575,6 +575,59 @@ int picaso_raman_oklopcic_dev(picaso_ctx *ctx, int nlayer, long nwno, int ntrans
                               const int *j_initial, const int *is_rayleigh, const double *j_at_temp, double cap,
                               double *out);
 
+/* ---- one call per spectrum: every launch of picaso()'s 1-D Toon path, for every wavelength block -------------
+ * (reference picaso/justdoit.py:236-385 is the per-spectrum sequence; its fan-out over processes :4774).  The
+ * caller keeps one picaso_block per wavelength block (pointers into that block's resident tables and a workspace it
+ * allocated once) and fills one picaso_spectrum_job per call with the per-layer tables all blocks share; the
+ * function enqueues gas stage -> compute_opacity -> reflected || thermal (+ fused disk sums) on every block's
+ * context(s) and returns; picaso_toon_spectrum_collect copies a leg's results into the caller's full-grid host
+ * arrays at [col0, col0 + nwno).  They only chain the entry points above: same results as calling them one by one. */
+typedef struct picaso_block {
+    picaso_ctx *ctx, *tctx;                /* tctx: the thermal leg's context (its own stream), NULL = ctx */
+    int nwno;                              /* columns of this block */
+    long col0;                             /* first column of the block in the full grid (host arrays below) */
+    const double *const *mol_tabs, *const *cont_tabs, *const *ray_tabs;   /* this block's resident tables (device) */
+    const double *cld_opd, *cld_w0, *cld_g0;           /* device cloud planes (nlayer, nwno) or NULL: no cloud */
+    const double *cld_host_opd, *cld_host_w0, *cld_host_g0;   /* OR full-grid HOST planes (nlayer, cld_host_pitch) ... */
+    long cld_host_pitch;
+    double *cld_work_opd, *cld_work_w0, *cld_work_g0;  /* ... copied, this block's columns, into these (nlayer, nwno) */
+    const double *raman;                   /* device Raman factor: plane, one row (job.raman_rows = 0) or NULL */
+    const double *surf_reflect, *F0PI, *wno;           /* device (nwno) */
+    double *taugas, *tauray;               /* workspace (nlayer, nwno) */
+    double *planes[13];                    /* compute_opacity outputs in the order of picaso_compute_opacity_ck_dev;
+                                              NULL = not written */
+    const double *refl_planes[11];         /* what get_reflected_1d reads, its argument order (may alias planes[]
+                                              or constant planes: a cloud-free atmosphere writes three) */
+    const double *th_dtau, *th_w0, *th_cosb;           /* what get_thermal_1d reads */
+    double *xint, *albedo, *flux, *disk;   /* device results: (numg,numt,nwno), (nwno), (numg,numt,nwno), (nwno) */
+    double *albedo_host, *thermal_host;    /* full-grid host results (or NULL: leave them on the device) */
+} picaso_block;
+typedef struct picaso_spectrum_job {
+    int nlayer;
+    int mol_mode, nmol, cont_interp, ncont, nray;      /* as picaso_opacity_gas_ck_dev */
+    const int *mol_rows;
+    const double *mol_wts, *mol_fac;
+    const int *cont_rows;
+    const double *cont_wts, *cont_fac, *ray_fac;
+    int raman_rows;
+    double raman_const;
+    int test_mode, delta_eddington, stream;            /* as picaso_compute_opacity_ck_dev */
+    int do_reflected, do_thermal;
+    int numg, numt;
+    const double *ubar0, *ubar1;           /* host (numg, numt) */
+    double cos_theta;
+    const double *gweight, *tweight;       /* host: the fused disk sums */
+    int single_phase, multi_phase, toon_coefficients;
+    double frac_a, frac_b, frac_c, constant_back, constant_forward, b_top;
+    const double *tlevel, *plevel;         /* host (nlevel) */
+    int hard_surface;
+} picaso_spectrum_job;
+int picaso_toon_spectrum_blocks(int nblocks, const picaso_block *blocks, const picaso_spectrum_job *job);
+/* copy one leg's results (which = 1: albedo, 2: thermal flux) of every block into albedo_host / thermal_host */
+int picaso_toon_spectrum_collect(int nblocks, const picaso_block *blocks, int which);
+/* sizeof(picaso_block), sizeof(picaso_spectrum_job) and two member offsets as compiled (layout check of a binding) */
+int picaso_driver_abi(size_t *block_bytes, size_t *job_bytes, size_t *off_albedo_host, size_t *off_hard_surface);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,105 @@
+// One C call per spectrum: the launches of picaso()'s 1-D Toon path for every wavelength block of the spectrum.
+//
+// The reference's driver (justdoit.py:236-385) calls get_opacities -> compute_opacity -> get_reflected_1d /
+// get_thermal_1d -> compress_disco / compress_thermal once per spectrum; its multi-process fan-out (justdoit.py:4774)
+// runs whole spectra side by side.  Here ONE spectrum may be cut into wavelength blocks, one per GPU,
+// and the Python mirror paid ~0.2 ms of interpreter time per block for a dozen ctypes calls whose arguments differ
+// only in pointers -- more than the 0.1 ms of GPU work of a 12 500-column block.  picaso_toon_spectrum_blocks takes the
+// per-block pointers once (a table the caller builds per opacity object and keeps) and the per-layer tables of THIS
+// call (table rows and weights, mixing coefficients, level temperatures: shared by all blocks) and enqueues, per block,
+//     picaso_opacity_gas_ck_dev -> picaso_compute_opacity_ck_dev -> picaso_get_reflected_1d_dev (+ fused disk sum)
+//                                                                 || picaso_get_thermal_1d_dev  (+ fused disk sum)
+// on the block's own context(s); picaso_toon_spectrum_collect then copies one leg's results of every block into the
+// caller's full-grid host arrays.  Nothing here computes: it is the same entry points in the same order, so the
+// results are the Python path's, bit for bit (tests/test_devices_gpu.py, tests/test_driver_gpu.py).
+#include "common.hpp"
+
+#include <cstddef>
+
+using namespace pz;
+
+extern "C" int picaso_toon_spectrum_blocks(int nblocks, const picaso_block *blocks, const picaso_spectrum_job *job)
+{
+    if (nblocks < 1 || !blocks || !job) return fail(nullptr, "toon_spectrum_blocks: null argument");
+    const picaso_spectrum_job &j = *job;
+    if (j.nlayer < 1 || j.numg < 1 || j.numt < 1) return fail(blocks[0].ctx, "toon_spectrum_blocks: bad sizes");
+    const int nlevel = j.nlayer + 1;
+    for (int b = 0; b < nblocks; ++b) {
+        const picaso_block &k = blocks[b];
+        if (!k.ctx || k.nwno < 1) return fail(k.ctx, "toon_spectrum_blocks: block %d has no context or no columns", b);
+        picaso_ctx *tctx = k.tctx ? k.tctx : k.ctx;
+        // cloud tables handed over as full-grid host planes: this block's columns, strided copy (the reference slices
+        // nothing: it has one grid; justdoit.py:4774 fans out whole spectra)
+        const double *cld[3] = {k.cld_opd, k.cld_w0, k.cld_g0};
+        if (k.cld_host_opd) {
+            const double *src[3] = {k.cld_host_opd, k.cld_host_w0, k.cld_host_g0};
+            double *dst[3] = {k.cld_work_opd, k.cld_work_w0, k.cld_work_g0};
+            for (int c = 0; c < 3; ++c) {
+                if (!src[c] || !dst[c]) return fail(k.ctx, "toon_spectrum_blocks: block %d: incomplete host cloud planes", b);
+                PZ_TRY(picaso_memcpy_h2d_2d(k.ctx, dst[c], sizeof(double) * (size_t)k.nwno, src[c] + k.col0,
+                                            sizeof(double) * (size_t)k.cld_host_pitch, sizeof(double) * (size_t)k.nwno,
+                                            (size_t)j.nlayer));
+                cld[c] = dst[c];
+            }
+        }
+        PZ_TRY(picaso_opacity_gas_ck_dev(k.ctx, j.nlayer, k.nwno, 1, j.mol_mode, j.nmol, k.mol_tabs, j.mol_rows, j.mol_wts,
+                                         j.mol_fac, j.cont_interp, j.ncont, k.cont_tabs, j.cont_rows, j.cont_wts, j.cont_fac,
+                                         j.nray, k.ray_tabs, j.ray_fac, k.taugas, k.tauray));
+        double *const *o = k.planes;
+        PZ_TRY(picaso_compute_opacity_ck_dev(k.ctx, j.nlayer, k.nwno, 1, k.taugas, k.tauray, cld[0], cld[1], cld[2], k.raman,
+                                             j.raman_rows, j.raman_const, j.test_mode, j.delta_eddington, j.stream, o[0],
+                                             o[1], o[2], o[3], o[4], o[5], o[6], o[7], o[8], o[9], o[10], o[11], o[12]));
+        if (tctx != k.ctx && j.do_thermal) PZ_TRY(picaso_ctx_wait(tctx, k.ctx));
+        if (j.do_reflected) {
+            const double *const *r = k.refl_planes;
+            PZ_TRY(picaso_get_reflected_1d_dev(k.ctx, nlevel, k.nwno, k.nwno, j.numg, j.numt, r[0], r[1], r[2], r[3], r[4],
+                                               r[5], r[6], r[7], r[8], r[9], r[10], k.surf_reflect, j.ubar0, j.ubar1,
+                                               j.cos_theta, k.F0PI, j.single_phase, j.multi_phase, j.frac_a, j.frac_b,
+                                               j.frac_c, j.constant_back, j.constant_forward, 1, 0, j.toon_coefficients,
+                                               j.b_top, k.xint, nullptr, nullptr, nullptr, nullptr, j.gweight, j.tweight,
+                                               k.albedo));
+        }
+        if (j.do_thermal) {
+            PZ_TRY(picaso_get_thermal_1d_dev(tctx, nlevel, k.wno, k.nwno, k.nwno, j.numg, j.numt, j.tlevel, k.th_dtau,
+                                             k.th_w0, k.th_cosb, j.plevel, j.ubar1, k.surf_reflect, j.hard_surface,
+                                             nullptr, 0, k.flux, nullptr, nullptr, nullptr, nullptr, j.gweight, j.tweight,
+                                             k.disk));
+        }
+    }
+    return 0;
+}
+
+// Copy one leg's results (which = 1: albedo, 2: thermal flux) of every block into the caller's full-grid host arrays
+// at [col0, col0 + nwno).  Each copy waits for its own stream only; the other blocks and the other leg keep running --
+// the caller integrates the albedo while the thermal kernels finish.
+extern "C" int picaso_toon_spectrum_collect(int nblocks, const picaso_block *blocks, int which)
+{
+    if (nblocks < 1 || !blocks) return fail(nullptr, "toon_spectrum_collect: null argument");
+    for (int b = 0; b < nblocks; ++b) {
+        const picaso_block &k = blocks[b];
+        picaso_ctx *tctx = k.tctx ? k.tctx : k.ctx;
+        if (which == 1) {
+            if (!k.albedo_host) return fail(k.ctx, "toon_spectrum_collect: block %d has no host albedo array", b);
+            PZ_TRY(picaso_memcpy_d2h(k.ctx, k.albedo_host + k.col0, k.albedo, sizeof(double) * (size_t)k.nwno));
+        } else if (which == 2) {
+            if (!k.thermal_host) return fail(k.ctx, "toon_spectrum_collect: block %d has no host thermal array", b);
+            PZ_TRY(picaso_memcpy_d2h(tctx, k.thermal_host + k.col0, k.disk, sizeof(double) * (size_t)k.nwno));
+            // a second stream read the planes of ctx: ctx's next call (which overwrites them) starts behind it
+            if (tctx != k.ctx) PZ_TRY(picaso_ctx_wait(k.ctx, tctx));
+        } else {
+            return fail(k.ctx, "toon_spectrum_collect: which must be 1 (albedo) or 2 (thermal)");
+        }
+    }
+    return 0;
+}
+
+// sizeof / offsets of the two structs above as this library was compiled, so that a binding (picaso_amd/driver.py's
+// ctypes.Structure definitions) can check its layout without a GPU
+extern "C" int picaso_driver_abi(size_t *block_bytes, size_t *job_bytes, size_t *off_albedo_host, size_t *off_hard_surface)
+{
+    if (block_bytes) *block_bytes = sizeof(picaso_block);
+    if (job_bytes) *job_bytes = sizeof(picaso_spectrum_job);
+    if (off_albedo_host) *off_albedo_host = offsetof(picaso_block, albedo_host);
+    if (off_hard_surface) *off_hard_surface = offsetof(picaso_spectrum_job, hard_surface);
+    return 0;
+}

@@ -1142,6 +1142,10 @@ def picaso(bundle, opacityclass, dimension="1d", calculation="reflected", full_o
     if devices is not None:
         return _picaso_devices(bundle, opacityclass, devices, gather, dimension=dimension, calculation=calculation,
                                full_output=full_output, plot_opacity=plot_opacity, as_dict=as_dict, defer=defer)
+    if dimension == "1d" and not (full_output or defer or _raw or plot_opacity) and _shared is None and _batch is None:
+        fast = _picaso_driver(bundle, opacityclass, [(0, opacityclass.nwno, opacityclass)], calculation)
+        if fast is not None:
+            return fast
     inp = bundle.inputs
     opa = opacityclass
     ctx = opa.ctx
@@ -1530,6 +1534,136 @@ def picaso(bundle, opacityclass, dimension="1d", calculation="reflected", full_o
 
 
 # ------------------------------------------------------------------------------------------------
+# one C call per spectrum (csrc/driver.hip): the launch sequence of the 1-D Toon path for every wavelength block
+# ------------------------------------------------------------------------------------------------
+def _picaso_driver(bundle, opa, subs, calculation):
+    """The 1-D Toon spectrum (reference justdoit.py:236-385, 552-599) through ``picaso_toon_spectrum_blocks``: ONE C
+    call enqueues gas stage -> ``compute_opacity`` -> reflected || thermal (+ fused disk sums) on every wavelength block
+    of ``subs`` (``[(lo, hi, opacity object of the block)]``; the whole grid on one GPU is one block), a second and third
+    copy the legs back.  Returns the output dictionary, or None when the call is outside what the driver covers
+    (correlated-k tables, SH, patchy clouds, level fluxes, full_output, transmission, Oklopcic Raman, cloud tables
+    on their own grid, test modes) -- the caller then takes the call-by-call path, whose results these are bit for bit:
+    the C function chains the same entry points in the same order."""
+    from . import driver as drv
+    if os.environ.get("PICASO_AMD_NO_DRIVER") or os.environ.get("PICASO_AMD_RAMAN_PLANES"):
+        return None
+    inp = bundle.inputs
+    legs = set(calculation.split("+"))
+    if not legs or not legs <= {"reflected", "thermal"}:
+        return None
+    if (inp["approx"]["rt_method"] == "SH" or opa.ngauss != 1 or getattr(opa, "on_fly", False)
+            or inp["clouds"].get("do_holes", False) or inp["approx"].get("get_lvl_flux", False)
+            or inp["test_mode"] is not None or not hasattr(opa, "_cia") or not hasattr(opa, "_ray")):
+        return None
+    common = inp["approx"]["rt_params"]["common"]
+    toon = inp["approx"]["rt_params"]["toon"]
+    raman = common["raman"]
+    if raman == 0:
+        return None
+    wno, nwno = opa.wno, opa.nwno
+    atm = _setup_atmosphere(inp, opa, wno)
+    cld = atm.layer["cloud"]
+    cloud_free = bool(getattr(atm, "cloud_free", False))
+    if not cloud_free and isinstance(cld, CloudTables):
+        return None
+    nlevel, nlayer = atm.c.nlevel, atm.c.nlayer
+    opa.get_opacities(atm, exclude_mol=inp["atmosphere"]["exclude_mol"])
+    plan = opa._plan
+    if plan.get("premixed"):
+        return None
+    factors = optics._layer_factors(atm, opa)
+    plan["_factors"] = (atm.layer["mixingratios"], factors)
+    linear = opa.query_method == "linear"
+    do_r, do_t = "reflected" in legs, "thermal" in legs
+    # which planes compute_opacity writes: exactly picaso()'s choice (see there for the cloud-free form)
+    want = set()
+    if do_r:
+        want |= set(resident.REFLECTED_PLANES)
+    if do_t:
+        want |= {"dtau_og", "w0_no_raman", "cosb_og"}
+    lean = (cloud_free and len(getattr(atm, "rayleigh_molecules", [])) > 0 and not os.environ.get("PICASO_AMD_ALL_PLANES"))
+    if lean:
+        want = set()
+        if do_r:
+            want |= {"dtau", "tau", "w0"}
+        if do_t:
+            want |= {"dtau", "w0" if (raman == 2 and do_r) else "w0_no_raman"}
+    geom = inp["disco"]
+    ng, nt = geom["num_gangle"], geom["num_tangle"]
+    frac_a, frac_b, frac_c = common["TTHG_params"]["fraction"]
+    key = (tuple((lo, hi, id(sub)) for lo, hi, sub in subs), nlayer, ng, nt, tuple(plan["molecules"]),
+           tuple(plan["cia_pairs"]), tuple(factors[2]), linear, tuple(sorted(want)), lean, not cloud_free, do_r, do_t)
+    cache = opa.__dict__.setdefault("_driver_tables", {})
+    table = cache.get(key)
+    if table is None:
+        if len(cache) > 8:
+            cache.clear()
+        table = cache[key] = drv.BlockTable(subs, nlayer, ng, nt, plan["molecules"], plan["cia_pairs"], factors[2], linear,
+                                            want, lean, not cloud_free, do_r, do_t, _constant_planes)
+    nostar = inp["star"]["database"] == "nostar"
+    F0PI = (np.zeros(nwno) + 1.0) if nostar else inp["star"]["relative_flux"]
+    stellar = getattr(opa, "unshifted_stellar_spec", None)
+    if stellar is None:
+        stellar = F0PI
+    sr = atm.surf_reflect
+    sr_full = np.ndim(sr) > 0 and np.size(sr) == nwno and nwno > 1
+    overlap = do_r and do_t and os.environ.get("PICASO_AMD_OVERLAP_LEGS", "1") != "0"
+    returns, hold = {}, []
+    if do_r:
+        returns["albedo"] = np.empty(nwno)
+    if do_t:
+        returns["thermal"] = np.empty(nwno)
+    if not cloud_free:
+        def plane(x):
+            a = np.asarray(x, dtype=float)
+            return a if (a.shape == (nlayer, nwno) and a.flags.c_contiguous) else \
+                np.ascontiguousarray(np.broadcast_to(a, (nlayer, nwno)))
+        hcld = [plane(cld[k]) for k in ("opd", "w0", "g0")]
+        hold.append(hcld)
+    for b, (lo, hi, sub) in enumerate(subs):
+        k = table.blocks[b]
+        nw = hi - lo
+        rs = _resident_vector(sub, "surf_reflect", np.asarray(sr, dtype=float).reshape(nwno)[lo:hi] if sr_full else sr, nw)
+        f0 = _resident_vector(sub, "F0PI", 1.0 if nostar else (F0PI if len(subs) == 1 else F0PI[lo:hi]), nw)
+        k.surf_reflect, k.F0PI = drv._dev(rs), drv._dev(f0)
+        if raman == 1:
+            row, _ = optics.raman_device(atm, sub, 1)
+            k.raman = drv._dev(row)
+        else:
+            k.raman = None
+        if not cloud_free:
+            k.cld_host_opd, k.cld_host_w0, k.cld_host_g0 = (drv._host(h) for h in hcld)
+            k.cld_host_pitch = nwno
+        tctx = sub.ctx
+        if do_t:
+            if overlap:
+                tctx = _lib.aux_context(_lib.device_of(sub.ctx))
+            k.tctx = tctx.value if hasattr(tctx, "value") else tctx
+            fl, dk = table.thermal_workspace(b, tctx, ng, nt)
+            k.flux, k.disk = drv._dev(fl), drv._dev(dk)
+            k.wno = drv._dev(_resident_vector(sub, "wno", sub.wno, nw))
+            k.thermal_host = drv._host(returns["thermal"])
+        if do_r:
+            k.albedo_host = drv._host(returns["albedo"])
+    job, keep = drv.make_job(nlayer, plan, factors, linear, 0 if raman == 1 else nlayer, common["stream"],
+                             common["delta_eddington"], do_r, do_t, ng, nt, geom["ubar0"], geom["ubar1"], geom["cos_theta"],
+                             geom["gweight"], geom["tweight"], toon["single_phase"], toon["multi_phase"],
+                             toon["toon_coefficients"], frac_a, frac_b, frac_c, common["TTHG_params"]["constant_back"],
+                             common["TTHG_params"]["constant_forward"], 0.0, atm.level["temperature"], atm.level["pressure"],
+                             atm.hard_surface)
+    drv.enqueue(table, job)
+    out = {"wavenumber": wno}
+    if do_r:
+        drv.collect(table, 1)
+        _post_reflected(out, returns, wno, stellar, inp["star"]["semi_major"], atm.planet.radius, opa)
+    if do_t:
+        drv.collect(table, 2)
+        _post_thermal(out, returns, wno, stellar, inp["star"]["radius"], atm.planet.radius, opa)
+    del keep, hold
+    return _post_final(out, returns)
+
+
+# ------------------------------------------------------------------------------------------------
 # several spectra in one launch (SURVEY 8(f) rank 4): the retrieval / grid callers of the reference run
 # spectrum() once per sample in separate processes (driver.py:405-426, justdoit.py:4741-4777)
 # ------------------------------------------------------------------------------------------------
@@ -1787,6 +1921,10 @@ def _picaso_devices(bundle, opa, devices, gather, dimension, calculation, full_o
     devs = _device_list(devices)
     shards = _opacity_shards(opa, devs)
     nwno = opa.nwno
+    if dimension == "1d" and gather == "host" and not (full_output or defer or plot_opacity):
+        fast = _picaso_driver(bundle, opa, shards, calculation)       # every block in one C call (csrc/driver.hip)
+        if fast is not None:
+            return fast
     nlevel = getattr(bundle, "nlevel", None)
     nlayer = (nlevel - 1) if nlevel else 0
     # The atmosphere set-up (hydrostatic altitude, column densities, cloud tables on the opacity grid) and the table

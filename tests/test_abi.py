@@ -114,3 +114,17 @@ def test_committed_pmc_numbers_belong_to_the_committed_kernel_sources():
     prof = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
     assert prof["kernel_source_hash"] == bench.kernel_source_hash()
     assert 0.95 < prof["hbm_bytes_per_launch"] / 8.0e8 < 1.2
+
+
+def test_driver_structs_match_the_library_layout():
+    """picaso_amd/driver.py restates picaso_block / picaso_spectrum_job (include/picaso_hip.h) as ctypes Structures:
+    same size and member offsets as the compiled library (no GPU needed)."""
+    import ctypes
+    from picaso_amd import _lib, driver
+    lib = _lib.load()
+    vals = [ctypes.c_size_t(0) for _ in range(4)]
+    assert lib.picaso_driver_abi(*[ctypes.byref(v) for v in vals]) == 0
+    assert vals[0].value == ctypes.sizeof(driver.Block)
+    assert vals[1].value == ctypes.sizeof(driver.Job)
+    assert vals[2].value == driver.Block.albedo_host.offset
+    assert vals[3].value == driver.Job.hard_surface.offset

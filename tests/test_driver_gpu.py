@@ -1,0 +1,84 @@
+"""picaso_toon_spectrum_blocks (csrc/driver.hip): one C call enqueues gas stage -> compute_opacity -> reflected ||
+thermal for every wavelength block of a 1-D Toon spectrum (reference sequence justdoit.py:236-385; fan-out
+justdoit.py:4774).  It only chains the library's entry points, so every output must equal the call-by-call path of
+``justdoit.picaso`` (``PICASO_AMD_NO_DRIVER=1``) bit for bit -- single GPU and wavelength blocks, cloud-free (three planes
++ aliases) and cloudy (host cloud planes cut per block inside the C call), Raman off / Pollack, one or both legs, with
+and without a star -- and calls it does not cover must fall through unchanged."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import GOLDEN
+from test_devices_gpu import _same
+
+pytestmark = pytest.mark.gpu
+DB = os.path.join(GOLDEN, "synthetic_opacities.db")
+
+
+def _case(og, jdi, cloud, star, raman, surf_array, k=0):
+    case = jdi.inputs(calculation="planet" if star else "browndwarf")
+    case.phase_angle(0)
+    case.gravity(gravity=float(og["in/gravity"]), radius=7.1e9, mass=1.9e30)
+    prof = {"pressure": og["in/plevel_bar"], "temperature": og["in/tlevel"] * (1.0 + 0.01 * k)}
+    for m in ("H2", "He", "H2O", "CH4"):
+        prof[m] = og["in/mix/" + m]
+    case.atmosphere(df=prof)
+    if cloud:
+        case.clouds(df={"opd": og["in/cld_opd"], "w0": og["in/cld_w0"], "g0": og["in/cld_g0"]})
+    nwno = len(og["in/wno"])
+    if star:
+        case.star(relative_flux=1.0 + 0.3 * np.sin(np.arange(nwno) / 7.0), radius=6.9e10, semi_major=7.5e12)
+    case.surface_reflect(0.1 + 0.2 * np.cos(np.arange(nwno) / 11.0) ** 2 if surf_array else 0.15)
+    case.approx(raman=raman, delta_eddington=True)
+    return case
+
+
+@pytest.fixture
+def pollack_table(tmp_path, monkeypatch):
+    d = tmp_path / "opacities"
+    d.mkdir()
+    wl = np.linspace(0.2, 6.0, 300)
+    np.savetxt(d / "raman_fortran.txt", np.column_stack([wl, 0.9 + 0.05 * np.cos(3 * wl)]))
+    monkeypatch.setenv("picaso_refdata", str(tmp_path))
+
+
+@pytest.mark.parametrize("devices", [None, [0, 0, 0]])
+@pytest.mark.parametrize("calc", ["reflected", "thermal", "reflected+thermal"])
+@pytest.mark.parametrize("cloud,star,raman,surf_array", [(False, True, "none", False), (True, True, "none", True),
+                                                         (False, False, "none", True), (True, True, "pollack", False),
+                                                         (False, True, "pollack", True)])
+def test_driver_equals_call_by_call_path(monkeypatch, pollack_table, devices, calc, cloud, star, raman, surf_array):
+    from picaso_amd import justdoit as jdi
+    og = np.load(os.path.join(GOLDEN, "optics.npz"))
+    opa = jdi.opannection(filename_db=DB, query_method="linear")
+    monkeypatch.setenv("PICASO_AMD_NO_DRIVER", "1")
+    want = [_case(og, jdi, cloud, star, raman, surf_array, k).spectrum(opa, calculation=calc, devices=devices) for k in range(2)]
+    assert "_driver_tables" not in opa.__dict__
+    monkeypatch.delenv("PICASO_AMD_NO_DRIVER")
+    got = [_case(og, jdi, cloud, star, raman, surf_array, k).spectrum(opa, calculation=calc, devices=devices) for k in range(2)]
+    assert len(opa.__dict__["_driver_tables"]) == 1          # the second spectrum reused the first one's block table
+    for w, g in zip(want, got):
+        _same(w, g)
+
+
+def test_driver_nearest_query_and_falls_through_where_it_does_not_apply(monkeypatch):
+    from picaso_amd import justdoit as jdi
+    og = np.load(os.path.join(GOLDEN, "optics.npz"))
+    opa = jdi.opannection(filename_db=DB, query_method="nearest")
+    got = _case(og, jdi, True, True, "none", True).spectrum(opa, calculation="reflected+thermal")
+    assert len(opa.__dict__["_driver_tables"]) == 1
+    monkeypatch.setenv("PICASO_AMD_NO_DRIVER", "1")
+    _same(_case(og, jdi, True, True, "none", True).spectrum(opa, calculation="reflected+thermal"), got)
+    monkeypatch.delenv("PICASO_AMD_NO_DRIVER")
+    n = len(opa.__dict__["_driver_tables"])
+    # outside the driver: full_output, transmission, SH, level fluxes -- the usual path, no new block table
+    _case(og, jdi, True, True, "none", True).spectrum(opa, calculation="reflected", full_output=True)
+    _case(og, jdi, False, True, "none", False).spectrum(opa, calculation="reflected+transmission")
+    sh = _case(og, jdi, True, True, "none", False)
+    sh.approx(raman="none", rt_method="SH", stream=4)
+    sh.spectrum(opa, calculation="reflected")
+    lv = _case(og, jdi, False, True, "none", False)
+    lv.approx(raman="none", get_lvl_flux=True)
+    lv.spectrum(opa, calculation="reflected+thermal")
+    assert len(opa.__dict__["_driver_tables"]) == n

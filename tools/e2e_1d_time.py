@@ -75,8 +75,13 @@ if os.environ.get("PROFILE_1D"):
     import cProfile, pstats
     pr = cProfile.Profile()
     pr.enable()
+    pdev = [int(x) for x in os.environ["DEVICES"].split(";")[0].split(",")] if os.environ.get("DEVICES") else None
+    for _ in range(5):
+        case.spectrum(opa, calculation=calc, devices=pdev)
+    pr = cProfile.Profile()
+    pr.enable()
     for _ in range(50):
-        case.spectrum(opa, calculation=calc, full_output=bool(os.environ.get("FULL")))
+        case.spectrum(opa, calculation=calc, full_output=bool(os.environ.get("FULL")), devices=pdev)
     pr.disable()
     pstats.Stats(pr).sort_stats(os.environ.get("SORT", "cumulative")).print_stats(int(os.environ.get("TOP", "35")))
     sys.exit(0)
