@@ -729,7 +729,11 @@ def main():
                 step()
             out["steady_state"] = {"steps": nst, "ms_per_step": timed(nst)}
         if world == 1 and args.config == 2 and args.secondary and args.scaling == "strong":
-            out.update(companions(ctx, args, wl, res_local, nwno_total))
+            try:      # reported extras: never worth the measurement above
+                out.update(companions(ctx, args, wl, res_local, nwno_total))
+            except Exception as exc:
+                out["companions_error"] = "%s: %s" % (type(exc).__name__, exc)
+                print("bench.py: the companion measurements failed: %s" % exc, file=sys.stderr, flush=True)
         if valu:
             # second ceiling: the kernel is FP64-VALU bound.  PMC instruction count of this launch shape
             # (profiles/) over the live kernel time, against the fp64 issue rate measured on an MI355X

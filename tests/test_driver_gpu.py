@@ -82,3 +82,23 @@ def test_driver_nearest_query_and_falls_through_where_it_does_not_apply(monkeypa
     lv.approx(raman="none", get_lvl_flux=True)
     lv.spectrum(opa, calculation="reflected+thermal")
     assert len(opa.__dict__["_driver_tables"]) == n
+
+
+def test_driver_lean_planes(monkeypatch):
+    """Through the driver as well a cloud-free atmosphere writes three planes (dtau, tau, w0) and hands the solvers
+    aliases and constants for the rest, a cloudy one all eleven; PICASO_AMD_ALL_PLANES=1 writes the full set -- same bits."""
+    from picaso_amd import justdoit as jdi
+    og = np.load(os.path.join(GOLDEN, "optics.npz"))
+    opa = jdi.opannection(filename_db=DB, query_method="linear")
+    lean = _case(og, jdi, False, True, "none", True).spectrum(opa, calculation="reflected+thermal")
+    (t_lean,) = opa.__dict__["_driver_tables"].values()
+    assert set(t_lean.want) == {"dtau", "tau", "w0"}
+    monkeypatch.setenv("PICASO_AMD_ALL_PLANES", "1")
+    full = _case(og, jdi, False, True, "none", True).spectrum(opa, calculation="reflected+thermal")
+    t_full = [t for t in opa.__dict__["_driver_tables"].values() if t is not t_lean][0]
+    assert len(t_full.want) == 12                          # the eleven reflected-light planes + w0_no_raman
+    _same(full, lean)
+    monkeypatch.delenv("PICASO_AMD_ALL_PLANES")
+    _case(og, jdi, True, True, "none", True).spectrum(opa, calculation="reflected")
+    t_cld = [t for t in opa.__dict__["_driver_tables"].values() if t is not t_lean and t is not t_full][0]
+    assert len(t_cld.want) == 11

@@ -81,7 +81,8 @@ def test_lean_planes_not_used_with_clouds_or_test_mode(monkeypatch):
     from picaso_amd import optics as px
     og = np.load(os.path.join(GOLDEN, "optics.npz"))
     opa = jdi.opannection(filename_db=DB)
-    wants = []
+    monkeypatch.setenv("PICASO_AMD_NO_DRIVER", "1")       # the call-by-call path (the C driver makes the same choice:
+    wants = []                                            # tests/test_driver_gpu.py::test_driver_lean_planes)
     real = px.compute_opacity_resident
     monkeypatch.setattr(px, "compute_opacity_resident", lambda *a, **k: (wants.append(k.get("want")), real(*a, **k))[1])
     case = _case(jdi, og, "none", True, False)
