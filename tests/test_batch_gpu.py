@@ -346,3 +346,69 @@ def test_reflected_SH_batch_geometries_and_generic_options():
         resident.reflected_SH(ctx, nlayer + 1, nwno, ng, nt, d, d["surf_reflect"], g[2], g[3], g[4], d["F0PI"], *opts,
                               *TTHG, 4, x1)
         assert np.array_equal(xs[s].to_host(), x1.to_host()), s
+
+
+def test_batch_randomised_shapes_and_options():
+    """Seeded random draws of batch size, grid size (ragged last workgroups), layer count, option set, angle count and
+    geometry sharing: every member of every batch equals its single call, reflected and thermal
+    (PICASO_FUZZ_OFFSET shifts the seed, as in tests/test_fuzz_gpu.py)."""
+    from picaso_amd import _lib, device, resident
+    from picaso_amd import synthetic as syn
+    ctx = _lib.context()
+    rng = np.random.default_rng(4242 + int(os.environ.get("PICASO_FUZZ_OFFSET", "0")))
+    for it in range(14):
+        B = int(rng.integers(2, 10))
+        nwno = int(rng.choice([1, 63, 64, 65, 255, 257, 1000, 4097, 9000, 20011]))
+        nlayer = int(rng.choice([1, 2, 3, 17, 60, 90]))
+        ng = int(rng.choice([5, 5, 6, 8])) if rng.random() < 0.6 else 3
+        phase = 0.0 if ng >= 5 else float(rng.uniform(0.2, 2.5))
+        per_geom = bool(rng.random() < 0.4) and phase != 0.0
+        opts = [(3, 0, *TTHG), (3, 0, *TTHG), (0, 0, 0.9, -0.8, 2.0, -0.4, 0.9), (1, 1, *TTHG), (2, 0, 1.0, -1.0, 2.0, -0.3, 0.8)][
+            int(rng.integers(0, 5))]
+        tc = int(rng.integers(0, 2))
+        shared_planes = bool(rng.random() < 0.25)
+        ctx_, host, devs = _scenes(1 if shared_planes else B, nlayer, nwno, 500 + 20 * it, cloud=bool(rng.random() < 0.7))
+        if shared_planes:
+            host, devs = host * B, devs * B
+        geoms = [_geom(ng, phase + (0.1 * s if per_geom else 0.0)) for s in range(B)]
+        if not per_geom:
+            geoms = [geoms[0]] * B
+        tag = (it, B, nwno, nlayer, ng, phase, per_geom, opts[:2], tc, shared_planes)
+        ngg, nt = geoms[0][0], geoms[0][1]
+        xs = [device.DeviceArray((ngg, nt, nwno), ctx) for _ in range(B)]
+        als = [device.DeviceArray((nwno,), ctx) for _ in range(B)]
+        same = all(g is geoms[0] for g in geoms)
+        resident.reflected_1d_batch(ctx, nlayer + 1, nwno, ngg, nt, devs, [d["surf_reflect"] for d in devs],
+                                    geoms[0][2] if same else np.stack([g[2] for g in geoms]),
+                                    geoms[0][3] if same else np.stack([g[3] for g in geoms]),
+                                    geoms[0][4] if same else np.array([g[4] for g in geoms]),
+                                    [d["F0PI"] for d in devs], *opts, xs, toon_coefficients=tc, b_top=0.01 * it,
+                                    gweight=geoms[0][5], tweight=geoms[0][6], albedo=als)
+        for s in range(B):
+            g = geoms[s]
+            x1, a1 = device.DeviceArray((ngg, nt, nwno), ctx), device.DeviceArray((nwno,), ctx)
+            resident.reflected_1d(ctx, nlayer + 1, nwno, ngg, nt, devs[s], devs[s]["surf_reflect"], g[2], g[3], g[4],
+                                  devs[s]["F0PI"], *opts, x1, toon_coefficients=tc, b_top=0.01 * it, gweight=g[5],
+                                  tweight=g[6], albedo=a1)
+            assert np.array_equal(xs[s].to_host(), x1.to_host(), equal_nan=True), tag + (s,)
+            assert np.array_equal(als[s].to_host(), a1.to_host(), equal_nan=True), tag + (s,)
+        # thermal emission on the same scenes
+        wno_d = device.DeviceArray.from_host(host[0]["wno"], ctx)
+        hard = int(rng.integers(0, 2))
+        fs = [device.DeviceArray((ngg, nt, nwno), ctx) for _ in range(B)]
+        ds = [device.DeviceArray((nwno,), ctx) for _ in range(B)]
+        tl = np.stack([sc["tlevel"] * (1.0 + 0.02 * s) for s, sc in enumerate(host)])
+        resident.thermal_1d_batch(ctx, nlayer + 1, wno_d, nwno, ngg, nt, tl, [d["dtau_og"] for d in devs],
+                                  [d["w0_no_raman"] for d in devs], [d["cosb_og"] for d in devs],
+                                  np.stack([sc["plevel"] for sc in host]),
+                                  geoms[0][3] if same else np.stack([g[3] for g in geoms]),
+                                  [d["surf_reflect"] for d in devs], hard, fs, gweight=geoms[0][5], tweight=geoms[0][6],
+                                  flux_disk=ds)
+        for s in range(B):
+            g = geoms[s]
+            f1, d1 = device.DeviceArray((ngg, nt, nwno), ctx), device.DeviceArray((nwno,), ctx)
+            resident.thermal_1d(ctx, nlayer + 1, wno_d, nwno, ngg, nt, tl[s], devs[s]["dtau_og"], devs[s]["w0_no_raman"],
+                                devs[s]["cosb_og"], host[s]["plevel"], g[3], devs[s]["surf_reflect"], hard, f1,
+                                gweight=g[5], tweight=g[6], flux_disk=d1)
+            assert np.array_equal(fs[s].to_host(), f1.to_host(), equal_nan=True), tag + (s, "thermal")
+            assert np.array_equal(ds[s].to_host(), d1.to_host(), equal_nan=True), tag + (s, "thermal")
