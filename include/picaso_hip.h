@@ -462,6 +462,25 @@ int picaso_get_thermal_1d_ck_dev(picaso_ctx *ctx, int nlevel, const double *wno,
                                  double *flux_at_top, double *flux_minus, double *flux_plus,
                                  double *flux_minus_mdpt, double *flux_plus_mdpt, const double *gweight,
                                  const double *tweight, double *flux_disk);
+
+/* The thermal leg of climate.get_fluxes (reference picaso/climate.py:1879-1941) for `nitem` level-temperature profiles
+ * over ONE set of opacity planes in one launch sequence: the climate solver's Jacobian perturbs one level temperature at
+ * a time and calls get_fluxes with unchanged opacities (climate.py:1105-1180), ~nlevel calls per Newton step.  Planes
+ * dtau / w0 / cosb (nlayer, nwno*ngauss) as picaso_get_thermal_1d_ck_dev takes them; tlevel HOST (nitem, nlevel), plevel
+ * HOST (nlevel).  Output disk4 (4, nlevel, nitem*nwno): flux_minus, flux_plus, flux_minus_mdpt, flux_plus_mdpt, Gauss-
+ * weighted and disk-integrated (compress_thermal), column = profile * nwno + wavelength.  Every profile's numbers are
+ * bit-identical to picaso_get_thermal_1d_ck_dev + picaso_compress_thermal_dev on that profile. */
+int picaso_get_thermal_1d_ck_tbatch_dev(picaso_ctx *ctx, int nitem, int nlevel, const double *wno, int nwno, int ngauss,
+                                        int numg, int numt, const double *tlevel, const double *dtau, const double *w0,
+                                        const double *cosb, const double *plevel, const double *ubar1,
+                                        const double *surf_reflect, int hard_surface, const double *dwno, int calc_type,
+                                        const double *gauss_wts, const double *gweight, const double *tweight,
+                                        double *disk4);
+/* the wavenumber sums of climate.get_fluxes (climate.py:1931-1936) on picaso_get_thermal_1d_ck_tbatch_dev's output:
+ * net_layer[profile][level] = sum_w (plus_mdpt - minus_mdpt) dwno, net[profile][level] = sum_w (plus - minus) dwno
+ * (device (nitem, nlevel) each).  Deterministic tree sums, not numpy's order: ~1e-16 of sum|terms| from get_fluxes' own. */
+int picaso_flux_net_sums_dev(picaso_ctx *ctx, int nlevel, int nitem, int nwno, const double *disk4,
+                             const double *dwno, double *net_layer, double *net);
 /* out = a*x + b*y on device arrays: the patchy-cloud blend (1-fhole)*cloudy + fhole*clear
  * (reference picaso/justdoit.py:300-305, 356-361) */
 int picaso_axpby_dev(picaso_ctx *ctx, size_t n, double a, const double *x, double b, const double *y,

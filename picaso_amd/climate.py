@@ -181,3 +181,65 @@ def get_fluxes(Atmosphere, OpacityWEd, OpacityNoEd, ScatteringPhase, Disco, Opag
         flux_plus_v, flux_minus_v = np.zeros((ng, nt, nlevel, nwno)), np.zeros((ng, nt, nlevel, nwno))
     return (flux_net_v_layer, flux_net_v, flux_plus_v, flux_minus_v, flux_net_ir_layer, flux_net_ir,
             flux_plus_ir, flux_minus_ir)
+
+
+def get_fluxes_tbatch(temperatures, Atmosphere, OpacityWEd, OpacityNoEd, ScatteringPhase, Disco, Opagrid, ctx=None,
+                      chunk=32, nets_only=False):
+    """The IR half of ``get_fluxes`` (``reflected=False, thermal=True``) for every level-temperature profile in
+    ``temperatures`` ``(nitem, nlevel)`` over ONE set of opacities: ``flux_net_ir_layer, flux_net_ir`` ``(nitem, nlevel)``
+    and ``flux_plus_ir, flux_minus_ir`` ``(nitem, nlevel, nwno)``.
+
+    What it is for: the Jacobian of the reference's T(P) iteration perturbs one level temperature at a time, rebuilds
+    the profile and calls ``get_fluxes`` with the SAME opacities (climate.py:1105-1180: ~nlevel calls per Newton step,
+    each a Planck evaluation + two-stream solve + source-function sweeps).  Here the profiles are extra columns of one
+    launch sequence (``picaso_get_thermal_1d_ck_tbatch_dev``: a column reads the shared planes and its own profile's
+    level temperatures); ``chunk`` profiles at a time bound the scratch (91 levels x 661 bins x 8 Gauss points x 5 angles:
+    77 MB per profile).  Row ``k`` of every result equals ``get_fluxes(Atmosphere._replace(t_level=temperatures[k]), ...)``
+    bit for bit (same kernels per column, same numpy sums).  Patchy clouds (``do_holes``) blend the cloudy and the clear
+    column sets before the disk sum: call ``get_fluxes`` per profile for those.
+
+    ``nets_only=True`` (what the Jacobian reads, climate.py:1182-1185): only ``flux_net_ir_layer, flux_net_ir`` come back,
+    summed over wavenumber ON THE DEVICE (``picaso_flux_net_sums_dev``: a fixed tree per row instead of numpy's order, so
+    they agree with ``get_fluxes`` to ~1e-15 relative instead of bit for bit) -- 2 x nlevel doubles per profile cross
+    PCIe instead of 4 x nlevel x nwno."""
+    import ctypes
+    ctx = ctx if ctx is not None else _lib.context()
+    temps = f64(temperatures)
+    nlevel = int(Atmosphere.nlevel)
+    if temps.ndim != 2 or temps.shape[1] != nlevel:
+        raise Exception("get_fluxes_tbatch: temperatures must be (nitem, nlevel=%d)" % nlevel)
+    nitem = temps.shape[0]
+    sp = ScatteringPhase
+    ng, nt = int(Disco.ng), int(Disco.nt)
+    nwno, ngauss = int(Opagrid.nwno), int(Opagrid.ngauss)
+    dwni, wno, gauss_wts = f64(Opagrid.delta_wno), f64(Opagrid.wno), f64(Opagrid.gauss_wts)
+    rs = DeviceArray.from_host(np.zeros(nwno) + f64(sp.surf_reflect), ctx)
+    pl = _planes(OpacityWEd, OpacityNoEd, ctx, thermal_only=True)
+    d_wno, d_dw = DeviceArray.from_host(wno, ctx), DeviceArray.from_host(dwni, ctx)
+    net_layer, net = np.empty((nitem, nlevel)), np.empty((nitem, nlevel))
+    plus = minus = None
+    if not nets_only:
+        plus, minus = np.empty((nitem, nlevel, nwno)), np.empty((nitem, nlevel, nwno))
+    for c0 in range(0, nitem, max(1, int(chunk))):
+        tl = temps[c0:c0 + max(1, int(chunk))]
+        m = tl.shape[0]
+        disk4 = DeviceArray((4, nlevel, m * nwno), ctx)
+        resident.thermal_1d_ck_tbatch(ctx, nlevel, d_wno, nwno, ngauss, ng, nt, tl, pl["dtau_og"], pl["w0_no_raman"],
+                                      pl["cosb_og"], Atmosphere.p_level, Disco.ubar1, rs, 0, gauss_wts, Disco.gweight,
+                                      Disco.tweight, disk4, dwno=d_dw, calc_type=1)
+        if nets_only:
+            d_nl, d_n = DeviceArray((m, nlevel), ctx), DeviceArray((m, nlevel), ctx)
+            _lib.check(_lib.load().picaso_flux_net_sums_dev(ctx, ctypes.c_int(nlevel), ctypes.c_int(m), ctypes.c_int(nwno),
+                                                            ctypes.c_void_p(disk4.addr), ctypes.c_void_p(d_dw.addr),
+                                                            ctypes.c_void_p(d_nl.addr), ctypes.c_void_p(d_n.addr)), ctx)
+            net_layer[c0:c0 + m], net[c0:c0 + m] = d_nl.to_host(), d_n.to_host()
+            continue
+        fm, fp, fmm, fpm = disk4.to_host().reshape(4, nlevel, m, nwno)
+        for k in range(m):                                     # get_fluxes' own expressions (climate.py:1931-1936)
+            net_layer[c0 + k] = ((fpm[:, k] - fmm[:, k]) * dwni).sum(axis=1)
+            net[c0 + k] = ((fp[:, k] - fm[:, k]) * dwni).sum(axis=1)
+            plus[c0 + k] = fp[:, k] * dwni
+            minus[c0 + k] = fm[:, k] * dwni
+    if nets_only:
+        return net_layer, net
+    return net_layer, net, plus, minus

@@ -1230,6 +1230,66 @@ int picaso_get_thermal_1d_ck_dev(picaso_ctx *ctx, int nlevel, const double *wno,
     return 0;
 }
 
+int picaso_get_thermal_1d_ck_tbatch_dev(picaso_ctx *ctx, int nitem, int nlevel, const double *wno, int nwno, int ngauss,
+                                        int numg, int numt, const double *tlevel, const double *dtau, const double *w0,
+                                        const double *cosb, const double *plevel, const double *ubar1,
+                                        const double *surf_reflect, int hard_surface, const double *dwno, int calc_type,
+                                        const double *gauss_wts, const double *gweight, const double *tweight,
+                                        double *disk4)
+{
+    if (!ctx) return fail(nullptr, "null context");
+    if (nitem < 1 || nlevel < 2 || nwno < 1 || numg < 1 || numt < 1) return fail(ctx, "get_thermal_1d_ck_tbatch: bad sizes");
+    if (ngauss < 1 || ngauss > MAX_CK_GAUSS) return fail(ctx, "get_thermal_1d_ck_tbatch: ngauss must be 1..%d", MAX_CK_GAUSS);
+    if (!wno || !tlevel || !dtau || !w0 || !cosb || !plevel || !ubar1 || !surf_reflect || !gauss_wts || !gweight ||
+        !tweight || !disk4)
+        return fail(ctx, "get_thermal_1d_ck_tbatch: null argument");
+    if (calc_type != 0 && calc_type != 1) return fail(ctx, "get_thermal_1d_ck_tbatch: calc_type must be 0 or 1");
+    if (calc_type == 1 && !dwno) return fail(ctx, "get_thermal_1d_ck_tbatch: calc_type=1 needs dwno");
+    PZ_HIP(ctx, hipSetDevice(ctx->device));
+    const int nang = numg * numt, nlayer = nlevel - 1;
+    const long per = (long)nwno * ngauss, ncol = per * nitem, nout = (long)nwno * nitem;
+    std::vector<double> tab((size_t)nitem * nlevel + (size_t)nlevel + (size_t)nang);
+    memcpy(tab.data(), tlevel, sizeof(double) * (size_t)nitem * nlevel);
+    memcpy(tab.data() + (size_t)nitem * nlevel, plevel, sizeof(double) * nlevel);
+    memcpy(tab.data() + (size_t)nitem * nlevel + nlevel, ubar1, sizeof(double) * nang);
+    const void *d_tab = nullptr;
+    PZ_TRY(table_upload(ctx, tab.data(), sizeof(double) * tab.size(), &d_tab));
+    // per-column results before the Gauss sum: flux (nang, ncol) + four (nang, nlevel, ncol); then the Gauss-summed
+    // four (nang, nlevel, nitem*nwno)
+    const size_t nx = (size_t)nang * ncol, nl = (size_t)nang * nlevel * ncol, ng4 = (size_t)nang * nlevel * nout;
+    PZ_TRY(lvl_scratch_reserve(ctx, sizeof(double) * ((size_t)4 * nlayer + nlevel) * ncol));
+    PZ_TRY(ck_scratch_reserve(ctx, sizeof(double) * (nx + 4 * nl + 4 * ng4)));
+    double *xcol = ctx->ck_scratch, *l0 = xcol + nx, *g0 = l0 + 4 * nl;
+    ThermalLvlArgs la{};
+    ThermalArgs &a = la.base;
+    a.nlayer = nlayer;
+    a.ncol = ncol;
+    a.ncolper = ngauss;
+    a.pitch = per;                                   // the planes hold ONE profile's columns
+    a.per_item = per;
+    a.nfac = 1;
+    a.nwno = nwno;
+    a.wno = wno; a.dwno = dwno;
+    a.tlevel = (const double *)d_tab;
+    a.plevel = a.tlevel + (size_t)nitem * nlevel;
+    a.dtau = dtau; a.w0 = w0; a.cosb = cosb; a.surf_reflect = surf_reflect;
+    a.hard_surface = hard_surface; a.calc_type = calc_type;
+    la.nang = nang;
+    la.u1_dev = a.plevel + nlevel;
+    la.flux = xcol;
+    la.fm = l0; la.fp = l0 + nl; la.fmm = l0 + 2 * nl; la.fpm = l0 + 3 * nl;
+    la.scratch = ctx->lvl_scratch;
+    PZ_TRY(launch_thermal_lvl(ctx, la));
+    for (int j = 0; j < 4; ++j) {
+        // Gauss-point sums (justdoit.py:380; the columns of a row are (profile, wavelength, Gauss point)), then the
+        // disk sum over the angles (climate.py:1925-1928)
+        PZ_TRY(launch_weighted_colsum(ctx, nang * nlevel, nout, ngauss, gauss_wts, l0 + j * nl, g0 + j * ng4));
+        PZ_TRY(picaso_compress_thermal_dev(ctx, (size_t)nlevel * nout, g0 + j * ng4, gweight, numg, tweight, numt,
+                                           disk4 + (size_t)j * nlevel * nout));
+    }
+    return 0;
+}
+
 int picaso_axpby_dev(picaso_ctx *ctx, size_t n, double a, const double *x, double b, const double *y,
                      double *out)
 {

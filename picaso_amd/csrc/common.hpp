@@ -176,6 +176,10 @@ struct ThermalArgs {
     // batched launch (picaso_get_thermal_1d_batch_dev): grid.z = spectrum, see ReflectedArgs::batch
     const struct ThermalBatchItem *batch;
     int nspec;
+    // level-flux kernels only (picaso_get_thermal_1d_ck_tbatch_dev): ONE set of planes under `ncol / per_item`
+    // temperature profiles -- the columns are (profile, wavelength, Gauss point), a column reads the planes at
+    // column % per_item and the level temperatures of profile column / per_item (tlevel: (nprofile, nlevel)).  0: off
+    long per_item;
 };
 struct ThermalBatchItem {
     const double *dtau, *w0, *cosb, *surf_reflect, *tlevel, *plevel;

@@ -145,4 +145,44 @@ int launch_axpby(picaso_ctx *ctx, size_t n, double a, const double *x, double b,
     return 0;
 }
 
+// Wavenumber sums of the climate caller (climate.get_fluxes, reference picaso/climate.py:1931-1936): for every (level,
+// profile) row  net = sum_w (plus - minus)[w] dwni[w].  One workgroup per row: 256 strided partial sums, then a fixed
+// LDS tree -- deterministic, but not numpy's summation order (differences ~1e-16 relative to sum |terms|).
+__global__ __launch_bounds__(256) void k_flux_net_sums(int nlevel, int nitem, int nwno, const double *__restrict__ plus,
+                                                       const double *__restrict__ minus, const double *__restrict__ dw,
+                                                       double *__restrict__ out)
+{
+#pragma clang fp contract(off)
+    __shared__ double part[256];
+    const int lev = blockIdx.x, item = blockIdx.y;
+    const size_t row = ((size_t)lev * nitem + item) * nwno;          // rows are (level, profile * nwno + w)
+    double acc = 0.0;
+    for (int w = threadIdx.x; w < nwno; w += 256) acc = acc + (plus[row + w] - minus[row + w]) * dw[w];
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) part[threadIdx.x] = part[threadIdx.x] + part[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[(size_t)item * nlevel + lev] = part[0];
+}
+
 }  // namespace pz
+
+extern "C" int picaso_flux_net_sums_dev(picaso_ctx *ctx, int nlevel, int nitem, int nwno, const double *disk4,
+                                        const double *dwno, double *net_layer, double *net)
+{
+    using namespace pz;
+    if (!ctx) return fail(nullptr, "null context");
+    if (nlevel < 1 || nitem < 1 || nwno < 1 || !disk4 || !dwno || !net_layer || !net)
+        return fail(ctx, "flux_net_sums: bad argument");
+    PZ_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t plane = (size_t)nlevel * nitem * nwno;              // disk4: minus, plus, minus_mdpt, plus_mdpt
+    const dim3 grid((unsigned)nlevel, (unsigned)nitem);
+    hipLaunchKernelGGL(k_flux_net_sums, grid, dim3(256), 0, ctx->stream, nlevel, nitem, nwno, disk4 + 3 * plane,
+                       disk4 + 2 * plane, dwno, net_layer);
+    hipLaunchKernelGGL(k_flux_net_sums, grid, dim3(256), 0, ctx->stream, nlevel, nitem, nwno, disk4 + plane, disk4, dwno,
+                       net);
+    PZ_HIP(ctx, hipGetLastError());
+    return 0;
+}

@@ -215,9 +215,11 @@ __device__ __forceinline__ ThermLayer therm_layer_coeffs(const ThermalArgs &a, l
 __global__ __launch_bounds__(256) void k_thermal_lvl_solve(const ThermalLvlArgs A)
 {
     const ThermalArgs &a = A.base;
-    const long w = blockIdx.x * (long)blockDim.x + threadIdx.x;     // column (wavelength x Gauss point)
+    const long w = blockIdx.x * (long)blockDim.x + threadIdx.x;     // column ([profile,] wavelength, Gauss point)
     if (w >= a.ncol) return;
-    const long wv = (a.ncolper > 1) ? w / a.ncolper : w;
+    // several temperature profiles over one set of planes: wp = the column of the planes, item = the profile
+    const long item = a.per_item ? w / a.per_item : 0, wp = a.per_item ? w - item * a.per_item : w;
+    const long wv = (a.ncolper > 1) ? wp / a.ncolper : wp;
     const int n = a.nlayer;
     const long pitch = a.pitch, nw = a.ncol;
     const double mu1 = 0.5;
@@ -226,8 +228,9 @@ __global__ __launch_bounds__(256) void k_thermal_lvl_solve(const ThermalLvlArgs 
     const double dwn = integrated ? a.dwno[wv] : 0.0;
     Exp2Coef K;
     K.load();
+    const double *tl = a.tlevel + item * (n + 1);
     auto planck = [&](int l) {
-        const double t = a.tlevel[l];
+        const double t = tl[l];
         return integrated ? planck_integrated(t, wn, dwn) : planck_lambda(t, wn, K);
     };
     double *s_rho = A.scratch + w, *s_del = s_rho + (long)n * nw, *s_s = s_del + (long)n * nw,
@@ -238,12 +241,12 @@ __global__ __launch_bounds__(256) void k_thermal_lvl_solve(const ThermalLvlArgs 
     double Bn = planck(0);
     s_B[0] = Bn;
     const double B_top = Bn;
-    const double tau_top = a.dtau[w] * a.plevel[0] / (a.plevel[1] - a.plevel[0]);   // fluxes.py:1797
+    const double tau_top = a.dtau[wp] * a.plevel[0] / (a.plevel[1] - a.plevel[0]);   // fluxes.py:1797
     for (int i = 0; i < n; ++i) {
         const double B0 = Bn;
         Bn = planck(i + 1);
         s_B[(long)(i + 1) * nw] = Bn;      // the per-angle passes below read it back (3 exp per level when integrated)
-        const ThermLayer r = therm_layer_coeffs(a, (long)i * pitch + w, B0, Bn, K);
+        const ThermLayer r = therm_layer_coeffs(a, (long)i * pitch + wp, B0, Bn, K);
         double rho_n, delta_n, sfac = 0.0, t = 0.0;
         if (i == 0) {
             rho_n = r.gam;
@@ -297,9 +300,10 @@ __global__ __launch_bounds__(256) void k_thermal_lvl_solve(const ThermalLvlArgs 
 __global__ __launch_bounds__(256) void k_thermal_lvl_angle(const ThermalLvlArgs A)
 {
     const ThermalArgs &a = A.base;
-    const long w = blockIdx.x * (long)blockDim.x + threadIdx.x;     // column (wavelength x Gauss point)
+    const long w = blockIdx.x * (long)blockDim.x + threadIdx.x;     // column ([profile,] wavelength, Gauss point)
     if (w >= a.ncol) return;
-    const long wv = (a.ncolper > 1) ? w / a.ncolper : w;
+    const long wp = a.per_item ? w % a.per_item : w;                // the column of the (shared) planes
+    const long wv = (a.ncolper > 1) ? wp / a.ncolper : wp;
     const int n = a.nlayer, nlevel = n + 1;
     const long pitch = a.pitch, nw = a.ncol;
     const double mu1 = 0.5;
@@ -314,14 +318,14 @@ __global__ __launch_bounds__(256) void k_thermal_lvl_angle(const ThermalLvlArgs 
            *fmm = A.fmm + ((long)k * nlevel) * nw + w, *fpm = A.fpm + ((long)k * nlevel) * nw + w;
     if (!upward) {
         const double B_top = s_B[0];
-        const double tau_top = a.dtau[w] * a.plevel[0] / (a.plevel[1] - a.plevel[0]);   // fluxes.py:1797
+        const double tau_top = a.dtau[wp] * a.plevel[0] / (a.plevel[1] - a.plevel[0]);   // fluxes.py:1797
         double Bcur = B_top;
         double Fm = (1 - fexpk(-tau_top * imu, K)) * B_top * 2 * PI;                 // :1875
         fm[0] = Fm;
         for (int i = 0; i < n; ++i) {
             const double B0 = Bcur;
             Bcur = s_B[(long)(i + 1) * nw];
-            const long off = (long)i * pitch + w;
+            const long off = (long)i * pitch + wp;
             const ThermLayer r = therm_layer_coeffs(a, off, B0, Bcur, K);
             const double dt = a.dtau[off];
             const double P = s_rho[(long)i * nw], N = s_del[(long)i * nw];
@@ -342,14 +346,14 @@ __global__ __launch_bounds__(256) void k_thermal_lvl_angle(const ThermalLvlArgs 
     }
     const double Bb = s_B[(long)n * nw];
     // b1 of the bottom layer, formed as therm_layer_coeffs forms it
-    const double b1_last = (Bb - s_B[(long)(n - 1) * nw]) * frcp(a.dtau[(long)(n - 1) * pitch + w]);
+    const double b1_last = (Bb - s_B[(long)(n - 1) * nw]) * frcp(a.dtau[(long)(n - 1) * pitch + wp]);
     double Fp = a.hard_surface ? (1.0 - rs) * Bb * 2 * PI : (Bb + b1_last * mu) * 2 * PI;  // :1871-1873
     fp[(long)n * nw] = Fp;
     fpm[(long)n * nw] = 0.0;
     double Bnext = Bb;
     for (int i = n - 1; i >= 0; --i) {
         const double B0 = s_B[(long)i * nw];
-        const long off = (long)i * pitch + w;
+        const long off = (long)i * pitch + wp;
         const ThermLayer r = therm_layer_coeffs(a, off, B0, Bnext, K);
         Bnext = B0;
         const double dt = a.dtau[off];

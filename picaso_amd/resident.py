@@ -201,6 +201,22 @@ def thermal_1d_ck(ctx, nlevel, wno, nwno, ngauss, numg, numt, tlevel, dtau, w0, 
         ptr(tw) if tw is not None else None, _addr(flux_disk)), ctx)
 
 
+def thermal_1d_ck_tbatch(ctx, nlevel, wno, nwno, ngauss, numg, numt, tlevels, dtau, w0, cosb, plevel, ubar1, surf_reflect,
+                         hard_surface, gauss_wts, gweight, tweight, disk4, dwno=None, calc_type=0):
+    """The level fluxes of ``thermal_1d_ck`` + ``compress_thermal`` for every row of ``tlevels`` ``(nitem, nlevel)``
+    over ONE set of planes, in one launch sequence (``picaso_get_thermal_1d_ck_tbatch_dev``): ``disk4`` is a
+    DeviceArray ``(4, nlevel, nitem*nwno)`` -- flux_minus, flux_plus, flux_minus_mdpt, flux_plus_mdpt, Gauss-weighted and
+    disk-integrated, column = profile * nwno + wavelength."""
+    tl = f64(tlevels)
+    nitem = tl.shape[0]
+    tl = f64(tl, (nitem, nlevel))
+    check(load().picaso_get_thermal_1d_ck_tbatch_dev(
+        ctx, _ci(nitem), _ci(nlevel), _addr(wno), _ci(nwno), _ci(ngauss), _ci(numg), _ci(numt), ptr(tl), _addr(dtau),
+        _addr(w0), _addr(cosb), ptr(f64(plevel, (nlevel,))), ptr(f64(ubar1, (numg, numt))), _addr(surf_reflect),
+        _ci(int(hard_surface)), _addr(dwno), _ci(calc_type), ptr(f64(gauss_wts, (ngauss,))), ptr(f64(gweight)),
+        ptr(f64(tweight)), _addr(disk4)), ctx)
+
+
 def transit_1d_ck(ctx, z, dz, nlevel, nwno, ngauss, rstar, mmw, k_b, amu, player, tlayer, colden, dtau,
                   gauss_wts, rprs2):
     """The transmission branch's correlated-k loop (reference justdoit.py:388-405) on a resident

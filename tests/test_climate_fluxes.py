@@ -129,3 +129,40 @@ def test_gpu_calculate_atm_feeds_get_fluxes(oracle):
     for name, a, b in zip(OUT, out, want):
         if name.startswith("flux_net"):
             assert rel_err(a, b, 1e-4 * np.abs(b).max()) < (1e-4 if name.endswith("_ir") or "ir_" in name else 1e-7), name
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("c", ["a", "g1"])
+def test_gpu_get_fluxes_tbatch_is_the_jacobian_loop(gold, c):
+    """climate.get_fluxes_tbatch: the thermal leg for many level-temperature profiles over ONE set of opacities -- what
+    the reference's Jacobian asks of get_fluxes one perturbed profile at a time (climate.py:1105-1180).  Profiles as
+    the solver makes them (one level raised by max(1e-4 T, 3 K), the rest unchanged) plus two globally different
+    ones; every row equals get_fluxes on that profile bit for bit, in one chunk and in ragged chunks."""
+    from picaso_amd import climate as clim
+    (atm, wed, noed, sp, dis, og, f0, _, _), kw = _args(gold, c, clim)
+    t0 = np.asarray(atm.t_level, dtype=float)
+    nlevel = len(t0)
+    profiles = [t0]
+    for jm in range(0, nlevel, max(1, nlevel // 7)):
+        t = t0.copy()
+        t[jm] += max(1e-4 * t0[jm], 3.0)
+        profiles.append(t)
+    profiles += [t0 * 1.05, t0[::-1].copy()]
+    temps = np.stack(profiles)
+    ctx = clim._lib.context()
+    # resident planes, as calculate_atm hands them over
+    wed_d = clim.OpacityWEd_Tuple(*[clim.DeviceArray.from_host(x, ctx) if x is not None else None for x in wed])
+    noed_d = clim.OpacityNoEd_Tuple(*[clim.DeviceArray.from_host(x, ctx) for x in noed])
+    want = [clim.get_fluxes(atm._replace(t_level=t), wed_d, noed_d, sp, dis, og, f0, False, True, ctx=ctx)[4:] for t in temps]
+    for chunk in (64, 3):
+        got = clim.get_fluxes_tbatch(temps, atm, wed_d, noed_d, sp, dis, og, ctx=ctx, chunk=chunk)
+        for k in range(len(temps)):
+            for j, name in enumerate(("flux_net_ir_layer", "flux_net_ir", "flux_plus_ir", "flux_minus_ir")):
+                assert np.array_equal(got[j][k], want[k][j]), (c, chunk, k, name)
+    nl, nn = clim.get_fluxes_tbatch(temps, atm, wed_d, noed_d, sp, dis, og, ctx=ctx, chunk=5, nets_only=True)
+    for k in range(len(temps)):                       # sums on the device: a fixed tree instead of numpy's order
+        for got_, j in ((nl, 0), (nn, 1)):
+            w_ = want[k][j]
+            assert np.max(np.abs(got_[k] - w_)) <= 1e-13 * np.abs(w_).max(), (c, k, j)
+    with pytest.raises(Exception, match="nlevel"):
+        clim.get_fluxes_tbatch(temps[:, :-1], atm, wed_d, noed_d, sp, dis, og, ctx=ctx)

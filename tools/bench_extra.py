@@ -277,6 +277,28 @@ def main():
         t0 = time.perf_counter()
         co.get_fluxes(atm_t, wh, nh, sp_t, dis_t, og_t, np.ones(nw), True, True)
         res["cpu_oracle_1core_ms"] = 1e3 * (time.perf_counter() - t0)
+        # the Jacobian of the T(P) iteration (reference climate.py:1105-1180): one thermal get_fluxes per perturbed level
+        # -- as a loop of calls and as ONE get_fluxes_tbatch call
+        tl0 = np.asarray(scs[0]["tlevel"], dtype=float)
+        temps = np.stack([tl0 + (np.arange(nlev) == jm) * max(1e-4 * tl0[jm], 3.0) for jm in range(nlev)])
+        pc.get_fluxes_tbatch(temps[:4], atm_t, wd, nd, sp_t, dis_t, og_t, ctx=ctx)
+        ts = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            jb = pc.get_fluxes_tbatch(temps, atm_t, wd, nd, sp_t, dis_t, og_t, ctx=ctx)
+            ts.append(time.perf_counter() - t0)
+        res["jacobian_%d_profiles_tbatch_ms" % nlev] = 1e3 * min(ts)
+        ts = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            jn = pc.get_fluxes_tbatch(temps, atm_t, wd, nd, sp_t, dis_t, og_t, ctx=ctx, chunk=nlev, nets_only=True)
+            ts.append(time.perf_counter() - t0)
+        res["jacobian_%d_profiles_tbatch_nets_only_ms" % nlev] = 1e3 * min(ts)
+        res["jacobian_nets_only_max_rel_diff"] = float(max(np.max(np.abs(jn[j] - jb[j]) / np.abs(jb[j]).max()) for j in range(2)))
+        t0 = time.perf_counter()
+        jl = [pc.get_fluxes(atm_t._replace(t_level=t), wd, nd, sp_t, dis_t, og_t, np.ones(nw), False, True, ctx=ctx)[4:] for t in temps]
+        res["jacobian_%d_profiles_loop_ms" % nlev] = 1e3 * (time.perf_counter() - t0)
+        res["jacobian_tbatch_equals_loop"] = bool(all(np.array_equal(jb[j][k], jl[k][j]) for k in range(nlev) for j in range(4)))
         out["climate_get_fluxes_91x661x8"] = res
     if only in (None, "e2e"):
         # inputs.spectrum() end to end at 1e5 wavelengths x 90 layers: HBM-resident synthetic opacity
