@@ -18,12 +18,18 @@ TTHG = (1.0, -1.0, 2.0, -0.5, 1.0)
 OFFSET = int(__import__("os").environ.get("PICASO_FUZZ_OFFSET", "0"))
 
 
+LOOSE = float(__import__("os").environ.get("PICASO_FUZZ_LOOSE", "3e-7"))
+
+
 def _tol(sc, tight, loose):
     """The reference's formulas carry exp(+lambda*dtau) terms (clipped at 35) and lose about
     exp(lambda*dtau) * eps of relative precision in a layer of optical depth dtau; two evaluations of
     them in different operation order differ by that much.  Scenes are therefore held to
-    `tight` (1e-8) while every layer is thin, to 2e-15 * exp(2 dtau_max) in between, and to the
-    `loose` contract tolerance (1e-6) once a layer reaches the clip."""
+    `tight` (1e-8) while every layer is thin, to 2e-15 * exp(2 dtau_max) in between, and to `loose` once a layer
+    reaches the clip.  `loose` for the top-of-atmosphere results is LOOSE = 3e-7 (PICASO_FUZZ_LOOSE overrides): 1.5 x the
+    largest distance from the extended-precision answer seen in ~260 000 combinations (round 3 soak, single layers of
+    optical depth 44-102), a third of BASELINE's 1e-6 contract -- until round 3 it WAS the contract, so a 1e-7
+    regression on thick layers could pass."""
     worst = float(np.max(sc["dtau_og"]))
     return float(np.clip(2e-15 * np.exp(min(2.0 * worst, 35.0)), tight, loose))
 
@@ -88,10 +94,10 @@ def test_fuzz_reflected(oracle, block):
         # O(F0PI) terms cancelling; they are judged against 1e-6 of the incident flux
         floor = max(1e-4 * np.abs(xo).max(), 1e-6 * float(np.max(f0)))
         x80 = None
-        if not rel_err(xg, xo, floor) < _tol(sc, 1e-8, 1e-6):
+        if not rel_err(xg, xo, floor) < _tol(sc, 1e-8, LOOSE):
             # beyond the tolerance: is it the reference's own fp64 rounding?  (see the level fluxes below)
             x80 = oracle.get_reflected_1d(*args, x80=True, **kw)
-            assert excess(xg, xo, x80[0], _tol(sc, 1e-8, 1e-6), floor) <= 0.0, tag
+            assert excess(xg, xo, x80[0], _tol(sc, 1e-8, LOOSE), floor) <= 0.0, tag
         if lvl:
             # contract tolerance: with single layers of optical depth 50-2000 (these random scenes have
             # them) the reference's level-flux expressions combine exp(+35)-sized terms and the upward
@@ -110,9 +116,9 @@ def test_fuzz_reflected(oracle, block):
         ag = oracle.compress_disco(nwno, ct, xo, gw, tw, f0)
         from picaso_amd import disco
         alb, afloor = disco.compress_disco(nwno, ct, xg, gw, tw, f0), max(1e-4 * np.abs(ag).max(), 1e-6)
-        if not rel_err(alb, ag, afloor) < _tol(sc, 1e-8, 1e-6):
+        if not rel_err(alb, ag, afloor) < _tol(sc, 1e-8, LOOSE):
             x80 = x80 if x80 is not None else oracle.get_reflected_1d(*args, x80=True, **kw)
-            assert excess(alb, ag, oracle.compress_disco(nwno, ct, x80[0], gw, tw, f0), _tol(sc, 1e-8, 1e-6),
+            assert excess(alb, ag, oracle.compress_disco(nwno, ct, x80[0], gw, tw, f0), _tol(sc, 1e-8, LOOSE),
                           afloor) <= 0.0, tag
 
 
@@ -132,11 +138,11 @@ def test_fuzz_thermal(oracle, block):
                 sc["plevel"], u1, rs, hard, dw, calc)
         fg, _ = fluxes.get_thermal_1d(*args)
         fo, _ = oracle.get_thermal_1d(*args)
-        if not rel_err(fg, fo, 1e-4 * np.abs(fo).max()) < _tol(sc, 1e-8, 1e-6):
+        if not rel_err(fg, fo, 1e-4 * np.abs(fo).max()) < _tol(sc, 1e-8, LOOSE):
             _dump("thermal", (block, it), u1=u1, rs=rs, hard=hard, dw=dw, calc=calc, fg=fg, fo=fo,
                   **{k: sc[k] for k in ("wno", "tlevel", "plevel", "dtau_og", "w0_no_raman", "cosb_og")})
             f80, _ = oracle.get_thermal_1d(*args, x80=True)      # the reference's own fp64 rounding? (see above)
-            assert excess(fg, fo, f80, _tol(sc, 1e-8, 1e-6), 1e-4 * np.abs(fo).max()) <= 0.0, (block, it, nlayer, nwno,
+            assert excess(fg, fo, f80, _tol(sc, 1e-8, LOOSE), 1e-4 * np.abs(fo).max()) <= 0.0, (block, it, nlayer, nwno,
                                                                                                 ng, nt, hard, calc)
 
 
@@ -194,11 +200,11 @@ def test_fuzz_facets_3d(oracle, block):
         a = (nlayer + 1, sc0["wno"], nwno, ng, nt, *[st[k] for k in PLANES], rs, u0, u1, ct, np.ones(nwno), sp, mp,
              *TTHG)
         xg, xo = fluxes.get_reflected_3d(*a), oracle.get_reflected_3d(*a)
-        assert rel_err(xg, xo, 1e-4 * np.abs(xo).max()) < _tol(st, 1e-8, 1e-6), (block, it, nlayer, nwno, ng, nt, sp, mp)
+        assert rel_err(xg, xo, 1e-4 * np.abs(xo).max()) < _tol(st, 1e-8, LOOSE), (block, it, nlayer, nwno, ng, nt, sp, mp)
         hs = int(rng.integers(0, 2))
         b = (nlayer + 1, sc0["wno"], nwno, ng, nt, tl, st["dtau_og"], st["w0_no_raman"], st["cosb_og"], pl, u1, rs, hs)
         fg, fo = fluxes.get_thermal_3d(*b), oracle.get_thermal_3d(*b)
-        assert rel_err(fg, fo, 1e-4 * np.abs(fo).max()) < _tol(st, 1e-8, 1e-6), (block, it, nlayer, nwno, ng, nt, hs)
+        assert rel_err(fg, fo, 1e-4 * np.abs(fo).max()) < _tol(st, 1e-8, LOOSE), (block, it, nlayer, nwno, ng, nt, hs)
 
 
 @pytest.mark.gpu
