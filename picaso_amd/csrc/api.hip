@@ -557,7 +557,7 @@ static int reflected_1d_core(picaso_ctx *ctx, int nlevel, int nwno, int ncolper,
     }
     // Small launches with the reference's default options: the cooperative kernel (one workgroup per 64 columns:
     // a wave for the angle-independent layer quantities, one wave per disk angle, fused disk sum), bit-identical
-    // to the fused launch.  Where it stops paying: DESIGN.md section 6.
+    // to the fused launch.  Where it stops paying: DESIGN.md section 7.
     if (nang <= MAX_ANGLES && !bt) {
         long coop_cols = 64L * ctx->ncu;                   // one workgroup (64 columns) per CU
         if (const char *e = getenv("PICASO_AMD_REFL_COOP_COLS")) coop_cols = atol(e);
@@ -1037,7 +1037,7 @@ static int thermal_1d_core(picaso_ctx *ctx, int nlevel, const double *wno, int n
     // Small launches: the cooperative kernel (helper waves compute the layer quantities into LDS, one
     // sweeper wave per 64 columns runs the recurrence for all angles; the level temperatures travel as
     // kernel arguments).  Step time of get_thermal_1d + compress_thermal at 1e4 x 90 x 5 (BASELINE
-    // configs[1]) and where it stops paying: DESIGN.md section 4.
+    // configs[1]) and where it stops paying: DESIGN.md section 7 (DESIGN_HISTORY.md section 4).
     // Batched launch: the table = nspec entries followed by every spectrum's level temperatures and pressures;
     // entry s carries the angles [first, first + count) of this launch chunk
     std::vector<char> btab;

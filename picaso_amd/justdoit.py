@@ -1302,7 +1302,7 @@ def picaso(bundle, opacityclass, dimension="1d", calculation="reflected", full_o
     d_f0 = _resident_vector(opa, "F0PI", 1.0 if inp["star"]["database"] == "nostar" else F0PI, nwno)
     # 1-D Toon spectra with both legs: the thermal kernels go to a second stream that waits for the
     # opacity planes only, so they run next to the reflected-light kernel (each of the two alone
-    # leaves SIMDs idle through its tail, DESIGN.md section 4) instead of behind it
+    # leaves SIMDs idle through its tail, DESIGN.md section 6) instead of behind it
     tctx = ctx
     if (dimension == "1d" and not is_sh and "reflected" in calculation and "thermal" in calculation
             and _batch is None and os.environ.get("PICASO_AMD_OVERLAP_LEGS", "1") != "0"):
@@ -1671,7 +1671,7 @@ class _SolveBatch:
     """The Toon solver launches of several ``picaso(defer=True, _batch=...)`` calls, issued by ``flush()`` as ONE
     batched launch per group of spectra that share shape and options (``picaso_get_reflected_1d_batch_dev`` /
     ``picaso_get_thermal_1d_batch_dev``): every spectrum is bit-identical to its own launch, the GPU sees one grid
-    that fills it instead of B that each leave its SIMDs half empty."""
+    that fills it instead of B that each leave its SIMDs half empty (DESIGN.md sections 5 and 6)."""
 
     def __init__(self):
         self.refl, self.therm, self.refl3, self.therm3 = {}, {}, {}, {}
