@@ -87,9 +87,9 @@ class BlockTable:
             k.tctx = None
             k.nwno, k.col0 = nw, lo
             tabs = [(sub._mol_log if linear else sub._mol_raw)[m] for m in mol_names]
-            mt, ct, rt = _table_ptrs(tabs), _table_ptrs([sub._cia[p] for p in cia_pairs]), \
-                _table_ptrs([sub._ray[m] for m in ray_names])
-            self.keep += [mt, ct, rt]
+            ctabs, rtabs = [sub._cia[p] for p in cia_pairs], [sub._ray[m] for m in ray_names]
+            mt, ct, rt = _table_ptrs(tabs), _table_ptrs(ctabs), _table_ptrs(rtabs)
+            self.keep += [mt, ct, rt, tabs, ctabs, rtabs]    # the tables themselves too: the structs hold raw addresses
             k.mol_tabs, k.cont_tabs, k.ray_tabs = ctypes.cast(mt, _dpp), ctypes.cast(ct, _dpp), ctypes.cast(rt, _dpp)
             tg, tr = DeviceArray((nlayer, nw), ctx), DeviceArray((nlayer, nw), ctx)
             self.keep += [tg, tr]

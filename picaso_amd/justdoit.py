@@ -1591,7 +1591,10 @@ def _picaso_driver(bundle, opa, subs, calculation):
     geom = inp["disco"]
     ng, nt = geom["num_gangle"], geom["num_tangle"]
     frac_a, frac_b, frac_c = common["TTHG_params"]["fraction"]
-    key = (tuple((lo, hi, id(sub)) for lo, hi, sub in subs), nlayer, ng, nt, tuple(plan["molecules"]),
+    def table_ids(sub):          # a block table holds raw table addresses: replaced tables are a new signature
+        mt = sub._mol_log if linear else sub._mol_raw
+        return tuple(id(mt[m]) for m in plan["molecules"]) + tuple(id(sub._cia[p]) for p in plan["cia_pairs"])
+    key = (tuple((lo, hi, id(sub)) + table_ids(sub) for lo, hi, sub in subs), nlayer, ng, nt, tuple(plan["molecules"]),
            tuple(plan["cia_pairs"]), tuple(factors[2]), linear, tuple(sorted(want)), lean, not cloud_free, do_r, do_t)
     cache = opa.__dict__.setdefault("_driver_tables", {})
     table = cache.get(key)
