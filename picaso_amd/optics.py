@@ -585,6 +585,8 @@ def shard_opacity(opa, lo, hi, ctx):
     s.__dict__.pop("_raman_pollack", None)
     s.__dict__.pop("_raman_oklopcic", None)
     s.__dict__.pop("_trapz", None)
+    s.__dict__.pop("_trapz_buf", None)
+    s.__dict__.pop("_driver_tables", None)
     s.molecular_opa, s.continuum_opa = ({} if isinstance(opa.molecular_opa, dict) else None), {}
 
     def cols(d, per=1):
