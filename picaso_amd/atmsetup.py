@@ -85,7 +85,20 @@ _MAIN_ISOTOPE = {
     "Db": 262.11415, "Sg": 266.12193, "Bh": 264.12473, "Hs": 269.13411, "Mt": 268.13882}
 
 
+_WEIGHT_CACHE = {}
+
+
 def molecular_weight(name):
+    """Cached ``_molecular_weight`` (a pure function of the name; a retrieval asks for the same half-dozen molecules
+    in every spectrum)."""
+    try:
+        return _WEIGHT_CACHE[name]
+    except KeyError:
+        w = _WEIGHT_CACHE[name] = _molecular_weight(name)
+        return w
+
+
+def _molecular_weight(name):
     """Molecular weight from a formula such as 'H2O', 'CH4', 'TiO', 'CH3D' (case-sensitive elements),
     tokenised as the reference does (``separate_molecule_name`` / ``separate_string_number``,
     atmsetup.py:807-820): charges are ignored ('H3+' weighs 3 H).  Raises ``KeyError`` for anything
