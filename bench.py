@@ -160,17 +160,29 @@ def workload_thermal(ctx, args, lo, hi, seed, nwno_total, scene=None):
         return orc.compress_thermal(ns, fo, gw, tw)
 
     def solve_batch(B):
-        """B thermal spectra in ONE launch (picaso_get_thermal_1d_batch_dev): the planes of the one scene under B
-        level-temperature profiles (T scaled by 1 + 0.01 s), each with its own outputs."""
+        """B thermal spectra in ONE launch (picaso_get_thermal_1d_batch_dev): B copies of the scene's three planes in
+        their own HBM allocations (shared planes would be read from HBM once and from L2 fifteen times: not what B
+        atmospheres of a retrieval do) under B level-temperature profiles (T scaled by 1 + 0.01 s; member 0 is the
+        single launch's), each with its own outputs."""
+        import ctypes as _ct
+        sets = [{k: d[k] for k in ("dtau_og", "w0_no_raman", "cosb_og")}]
+        for _ in range(1, B):
+            c = {}
+            for k in sets[0]:
+                c[k] = device.DeviceArray(d[k].shape, ctx)
+                _lib.check(_lib.load().picaso_memcpy_d2d(ctx, _ct.c_void_p(c[k].addr), _ct.c_void_p(d[k].addr),
+                                                         _ct.c_size_t(d[k].nbytes)), ctx)
+            sets.append(c)
         fl = [device.DeviceArray((ng, 1, n), ctx) for _ in range(B)]
         dk = [device.DeviceArray((n,), ctx) for _ in range(B)]
         tl = np.stack([scene["tlevel"] * (1.0 + 0.01 * s) for s in range(B)])
         pl = np.stack([scene["plevel"]] * B)
 
         def launch():
-            resident.thermal_1d_batch(ctx, nlevel, d["wno"], n, ng, 1, tl, [d["dtau_og"]] * B, d["w0_no_raman"],
-                                      d["cosb_og"], pl, ubar1, d["surf_reflect"], 0, fl, dwno=d["dwno"], calc_type=0,
-                                      gweight=gw, tweight=tw, flux_disk=dk)
+            resident.thermal_1d_batch(ctx, nlevel, d["wno"], n, ng, 1, tl, [x["dtau_og"] for x in sets],
+                                      [x["w0_no_raman"] for x in sets], [x["cosb_og"] for x in sets], pl, ubar1,
+                                      d["surf_reflect"], 0, fl, dwno=d["dwno"], calc_type=0, gweight=gw, tweight=tw,
+                                      flux_disk=dk)
         return launch, dk
 
     return dict(solve=solve, oracle=oracle, nloc=n, abytes=8 * n * (3 * nlayer + 3 + ng + 1), solve_batch=solve_batch,
@@ -425,7 +437,8 @@ def companions(ctx, args, wl, res_single, nwno_total):
         "ms": msb, "kernel": "k_thermal_toa_batch<5, false>", "algorithmic_bytes": w1["abytes"],
         "frac": w1["abytes"] / (msb * 1e-3) / 1e9 / HBM_PEAK_GBS,
         "bit_identical_to_single_launch": bool(np.array_equal(first, out1.to_host())),
-        "workload": "configs[1], 16 level-temperature profiles per launch (picaso_get_thermal_1d_batch_dev); ms per spectrum"}
+        "workload": "configs[1], 16 atmospheres per launch (picaso_get_thermal_1d_batch_dev): 16 plane sets in their own HBM "
+                    "allocations, 16 level-temperature profiles; ms per spectrum"}
     del launch1, dk, w1
     # configs[2], the 12 500-column block one of 8 GPUs solves
     w2 = workload_reflected(ctx, args, 0, 12500, 3, nwno_total, scene=scene)

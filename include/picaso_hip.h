@@ -52,6 +52,15 @@ int picaso_pool_trim(picaso_ctx *ctx);
 int picaso_memcpy_h2d(picaso_ctx *ctx, void *dst, const void *src, size_t bytes);
 int picaso_memcpy_d2h(picaso_ctx *ctx, void *dst, const void *src, size_t bytes);
 int picaso_memcpy_d2d(picaso_ctx *ctx, void *dst, const void *src, size_t bytes);
+/* Result copies that do not wait (the retrieval loop of driver.py:405-426 pipelined: the host sets up the next
+ * spectra while the GPU solves the last ones).  picaso_host_alloc: a pinned host block, kept for reuse after
+ * picaso_host_free.  picaso_memcpy_d2h_async: the copy is enqueued behind the kernels already on the context's
+ * stream and *mark identifies it; picaso_mark_wait blocks until that copy has landed -- work enqueued on the stream
+ * after it does not delay the wait -- and consumes the mark (wait for every mark exactly once). */
+int picaso_host_alloc(picaso_ctx *ctx, size_t bytes, void **hptr);
+int picaso_host_free(picaso_ctx *ctx, void *hptr);
+int picaso_memcpy_d2h_async(picaso_ctx *ctx, void *pinned_dst, const void *src, size_t bytes, void **mark);
+int picaso_mark_wait(picaso_ctx *ctx, void *mark);
 /* strided row copy: `height` rows of `width_bytes`, used to upload a wavelength shard
  * [w0, w0+n) of an (nlayer, nwno) host plane */
 int picaso_memcpy_h2d_2d(picaso_ctx *ctx, void *dst, size_t dpitch_bytes, const void *src,
@@ -481,6 +490,12 @@ int picaso_get_thermal_1d_ck_tbatch_dev(picaso_ctx *ctx, int nitem, int nlevel, 
  * (device (nitem, nlevel) each).  Deterministic tree sums, not numpy's order: ~1e-16 of sum|terms| from get_fluxes' own. */
 int picaso_flux_net_sums_dev(picaso_ctx *ctx, int nlevel, int nitem, int nwno, const double *disk4,
                              const double *dwno, double *net_layer, double *net);
+/* np.trapezoid(y', x) with d = diff(x) resident: sum_j (d[j] * (y'[j + 1] + y'[j])) / 2.0 over the n - 1 intervals, summed
+ * in numpy's own pairwise order (blocks of <= 128 terms with eight partial sums), so the same bits as the reference's
+ * spectrum-wide integrals (justdoit.py:552-599: Bond albedo, effective temperature).  y'[k] = y[k] * mult[k] (mult may be
+ * NULL), with reverse != 0 y'[k] = y[n - 1 - k] (* mult[n - 1 - k]).  out: one double in device memory. */
+int picaso_trapz_dev(picaso_ctx *ctx, long n, const double *d, const double *y, const double *mult, int reverse,
+                     double *out);
 /* out = a*x + b*y on device arrays: the patchy-cloud blend (1-fhole)*cloudy + fhole*clear
  * (reference picaso/justdoit.py:300-305, 356-361) */
 int picaso_axpby_dev(picaso_ctx *ctx, size_t n, double a, const double *x, double b, const double *y,

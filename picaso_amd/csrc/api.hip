@@ -212,6 +212,10 @@ void picaso_ctx_destroy(picaso_ctx *ctx)
         if (ctx->ring_ev[i]) (void)hipEventDestroy(ctx->ring_ev[i]);
     if (ctx->wait_ev) (void)hipEventDestroy(ctx->wait_ev);
     if (ctx->stage) (void)hipHostFree(ctx->stage);
+    free_pairwise_plans(ctx);
+    for (auto &kv : ctx->host_pool) (void)hipHostFree(kv.second);
+    for (auto &kv : ctx->host_live) (void)hipHostFree(kv.first);
+    for (hipEvent_t e : ctx->marks_free) (void)hipEventDestroy(e);
     for (int i = 0; i < 2; ++i)
         if (ctx->stage_ev[i]) (void)hipEventDestroy(ctx->stage_ev[i]);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -337,6 +341,59 @@ int picaso_memcpy_d2h(picaso_ctx *ctx, void *dst, const void *src, size_t bytes)
         const size_t off = c * half, len = bytes - off < half ? bytes - off : half;
         memcpy((char *)dst + off, ctx->stage + (c & 1) * half, len);
     }
+    return 0;
+}
+// Result copies that do not wait.  A retrieval enqueues the next spectra while the GPU is still solving the last ones:
+// the copy of a result is put on the stream behind its kernel, lands in a pinned block, and the host waits for the
+// mark of THAT copy only -- not for the stream, which by then holds the next spectra's launches.
+int picaso_host_alloc(picaso_ctx *ctx, size_t bytes, void **hptr)
+{
+    if (!ctx || !hptr) return fail(ctx, "picaso_host_alloc: null argument");
+    PZ_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t size = align_up(bytes ? bytes : 8, 4096);
+    auto it = ctx->host_pool.find(size);
+    if (it != ctx->host_pool.end()) {
+        *hptr = it->second;
+        ctx->host_pool.erase(it);
+    } else {
+        PZ_HIP(ctx, hipHostMalloc(hptr, size, hipHostMallocDefault));
+    }
+    ctx->host_live[*hptr] = size;
+    return 0;
+}
+int picaso_host_free(picaso_ctx *ctx, void *hptr)
+{
+    if (!hptr) return 0;
+    if (!ctx) return fail(nullptr, "null context");
+    auto it = ctx->host_live.find(hptr);
+    if (it == ctx->host_live.end()) return fail(ctx, "picaso_host_free: %p was not allocated by picaso_host_alloc", hptr);
+    ctx->host_pool.emplace(it->second, hptr);          // reuse is ordered by the caller: it frees after picaso_mark_wait
+    ctx->host_live.erase(it);
+    return 0;
+}
+int picaso_memcpy_d2h_async(picaso_ctx *ctx, void *pinned_dst, const void *src, size_t bytes, void **mark)
+{
+    if (!ctx || !pinned_dst || !src || !mark) return fail(ctx, "picaso_memcpy_d2h_async: null argument");
+    PZ_HIP(ctx, hipSetDevice(ctx->device));
+    hipEvent_t ev;
+    if (!ctx->marks_free.empty()) {
+        ev = ctx->marks_free.back();
+        ctx->marks_free.pop_back();
+    } else {
+        PZ_HIP(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    }
+    if (bytes) PZ_HIP(ctx, hipMemcpyAsync(pinned_dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    PZ_HIP(ctx, hipEventRecord(ev, ctx->stream));
+    *mark = (void *)ev;
+    return 0;
+}
+int picaso_mark_wait(picaso_ctx *ctx, void *mark)
+{
+    if (!ctx || !mark) return fail(ctx, "picaso_mark_wait: null argument");
+    hipEvent_t ev = (hipEvent_t)mark;
+    hipError_t e = hipEventSynchronize(ev);
+    ctx->marks_free.push_back(ev);                     // a mark is waited for once
+    if (e != hipSuccess) return fail(ctx, "hipEventSynchronize failed: %s", hipGetErrorString(e));
     return 0;
 }
 int picaso_memcpy_d2d(picaso_ctx *ctx, void *dst, const void *src, size_t bytes)

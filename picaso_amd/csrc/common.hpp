@@ -11,6 +11,8 @@
 
 #include "../../include/picaso_hip.h"
 
+namespace pz { struct PairwisePlan; }        // integrals.hip: the summation tree of one array length
+
 struct picaso_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -47,6 +49,12 @@ struct picaso_ctx {
     std::unordered_map<void *, size_t> live;           // block -> size
     size_t pool_bytes = 0;
     static constexpr size_t POOL_CAP = 64ull << 30;    // cached (free) bytes kept at most
+    // pinned host blocks for result copies that do not wait (picaso_host_alloc / picaso_memcpy_d2h_async), kept for
+    // reuse like the device blocks, and the events that mark those copies (picaso_mark_wait)
+    std::unordered_multimap<size_t, void *> host_pool;
+    std::unordered_map<void *, size_t> host_live;
+    std::vector<hipEvent_t> marks_free;
+    std::unordered_map<long, pz::PairwisePlan *> pairwise_plans;      // picaso_trapz_dev, by number of summands
 };
 
 namespace pz {
@@ -54,6 +62,7 @@ namespace pz {
 extern thread_local char g_err[512];
 
 int fail(picaso_ctx *ctx, const char *fmt, ...);
+void free_pairwise_plans(picaso_ctx *ctx);
 
 #define PZ_HIP(ctx, expr)                                                                    \
     do {                                                                                     \

@@ -60,6 +60,17 @@ class DeviceArray:
                                                  ctypes.c_size_t(self.nbytes)), self.ctx)
         return out
 
+    def to_host_async(self, pinned):
+        """Enqueue the copy into ``pinned`` (a ``PinnedArray`` of this size) behind the kernels already on the stream
+        and return at once; ``pinned.wait()`` blocks until the copy -- not the stream -- is done."""
+        if pinned.nbytes != self.nbytes:
+            raise ValueError("pinned block of %d bytes for a result of %d" % (pinned.nbytes, self.nbytes))
+        mark = ctypes.c_void_p()
+        _lib.check(_lib.load().picaso_memcpy_d2h_async(self.ctx, ctypes.c_void_p(pinned.addr), ctypes.c_void_p(self.addr),
+                                                       ctypes.c_size_t(self.nbytes), ctypes.byref(mark)), self.ctx)
+        pinned._mark, pinned._mark_ctx = mark, self.ctx
+        return pinned
+
     @classmethod
     def zeros(cls, shape, ctx=None):
         d = cls(shape, ctx)
@@ -80,6 +91,16 @@ class DeviceArray:
         v._owner = self            # keeps the parent alive; views are never freed
         return v
 
+    def head(self, n):
+        """Non-owning view of the first ``n`` elements of a 1-D buffer (a result vector allocated with room for a
+        spectrum-wide integral behind it)."""
+        if len(self.shape) != 1 or not 0 < int(n) <= self.size:
+            raise ValueError("head(%r) of a buffer of shape %s" % (n, self.shape))
+        v = DeviceArray.__new__(DeviceArray)
+        v.ctx, v.shape, v.size, v.nbytes, v.addr = self.ctx, (int(n),), int(n), int(n) * 8, self.addr
+        v._owner = self
+        return v
+
     def reshape(self, shape):
         """Non-owning view of the same buffer under another shape of equal size."""
         shape = tuple(int(x) for x in shape)
@@ -93,6 +114,46 @@ class DeviceArray:
     def free(self):
         if self.addr and not hasattr(self, "_owner"):
             _lib.load().picaso_dev_free(self.ctx, ctypes.c_void_p(self.addr))
+        self.addr = 0
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class PinnedArray:
+    """A float64 block of pinned host memory owned by the library's context (``picaso_host_alloc``): the target of
+    ``DeviceArray.to_host_async``.  ``array`` is a numpy view of it, valid until ``free()`` / collection."""
+
+    def __init__(self, shape, ctx=None):
+        self.ctx = ctx if ctx is not None else _lib.context()
+        self.shape = tuple(int(s) for s in np.atleast_1d(shape))
+        self.nbytes = int(np.prod(self.shape)) * 8
+        p = ctypes.c_void_p()
+        _lib.check(_lib.load().picaso_host_alloc(self.ctx, ctypes.c_size_t(self.nbytes), ctypes.byref(p)), self.ctx)
+        self.addr = p.value
+        self._mark = None
+        buf = (ctypes.c_double * (self.nbytes // 8)).from_address(self.addr)
+        self.array = np.frombuffer(buf, dtype=np.float64).reshape(self.shape)
+
+    def wait(self):
+        """Block until the copy enqueued by ``to_host_async`` has landed; returns the numpy view."""
+        if self._mark is not None:
+            mark, self._mark = self._mark, None
+            _lib.check(_lib.load().picaso_mark_wait(self._mark_ctx, mark), self._mark_ctx)
+        return self.array
+
+    def free(self):
+        if self.addr:
+            if self._mark is not None:          # never hand a block back while a copy into it may be in flight
+                try:
+                    self.wait()
+                except Exception:
+                    pass
+            self.array = None
+            _lib.load().picaso_host_free(self.ctx, ctypes.c_void_p(self.addr))
         self.addr = 0
 
     def __del__(self):

@@ -1310,6 +1310,7 @@ def picaso(bundle, opacityclass, dimension="1d", calculation="reflected", full_o
         _lib.ctx_wait(tctx, ctx)
     returns = {"wavenumber": wno}
     dev_results = {}          # per-wavelength results still in HBM (the multi-GPU form gathers them with RCCL)
+    prefetched = {}           # result copies already on the stream (finish.prefetch)
     enqueued = False
     try:
         # every leg first enqueues its kernels; the copies back (each a stream synchronisation) and the
@@ -1378,7 +1379,7 @@ def picaso(bundle, opacityclass, dimension="1d", calculation="reflected", full_o
             dev_results["albedo"] = alb
 
             def collect_reflected():          # read back after every leg has been enqueued (see `collect`)
-                albedo = alb.to_host()
+                albedo = _fetch(prefetched, "albedo", alb)
                 returns["albedo"] = albedo
                 if full_output:
                     atm.xint_at_top = xint.to_host()
@@ -1458,7 +1459,7 @@ def picaso(bundle, opacityclass, dimension="1d", calculation="reflected", full_o
             dev_results["thermal"] = disk
 
             def collect_thermal():
-                returns["thermal"] = disk.to_host()
+                returns["thermal"] = _fetch(prefetched, "thermal", disk)
                 if full_output:
                     atm.flux_at_top = flux.to_host()
                 if dimension != "3d" and not is_sh and tlvl_disk is not None:
@@ -1529,13 +1530,32 @@ def picaso(bundle, opacityclass, dimension="1d", calculation="reflected", full_o
         if full_output:
             out["full_output"] = atm.as_dict() if as_dict else atm
         return out
-    finish.dev, finish.ctx, finish.tctx = dev_results, ctx, tctx
+    def prefetch():
+        # spectrum_batch(): the copies of the per-wavelength results go on the stream NOW, behind this spectrum's solver
+        # launches, into pinned blocks; finish() then waits for these copies only, while the stream already holds the
+        # next spectra's launches
+        for key in ("albedo", "thermal"):
+            if key in dev_results and key not in prefetched:
+                d = dev_results[key]
+                prefetched[key] = d.to_host_async(device.PinnedArray(d.shape, d.ctx))
+    finish.dev, finish.ctx, finish.tctx, finish.prefetch = dev_results, ctx, tctx, prefetch
     return finish if defer else finish()
 
 
 # ------------------------------------------------------------------------------------------------
 # one C call per spectrum (csrc/driver.hip): the launch sequence of the 1-D Toon path for every wavelength block
 # ------------------------------------------------------------------------------------------------
+def _fetch(prefetched, key, dev):
+    """Host copy of the resident result ``dev``: the pinned block ``finish.prefetch`` put on the stream when there is
+    one (wait for that copy only), a synchronous copy otherwise."""
+    p = prefetched.pop(key, None)
+    if p is None:
+        return dev.to_host()
+    out = p.wait().copy()
+    p.free()
+    return out
+
+
 def _picaso_driver(bundle, opa, subs, calculation):
     """The 1-D Toon spectrum (reference justdoit.py:236-385, 552-599) through ``picaso_toon_spectrum_blocks``: ONE C
     call enqueues gas stage -> ``compute_opacity`` -> reflected || thermal (+ fused disk sums) on every wavelength block
@@ -1750,16 +1770,19 @@ class _SolveBatch:
         self.refl, self.therm = {}, {}
 
 
-def spectrum_batch(cases, opacityclass, calculation="reflected", full_output=False, as_dict=True, batch_size=16):
+def spectrum_batch(cases, opacityclass, calculation="reflected", full_output=False, as_dict=True, batch_size=4):
     """``[case.spectrum(opacityclass, calculation) for case in cases]`` (1-D) with the solvers of up to
     ``batch_size`` spectra in ONE launch each: what a retrieval or a model grid asks of the reference one
     ``spectrum()`` call and one process at a time (driver.py:405-426).  ``cases``: ``inputs`` objects, each with its
     own atmosphere / clouds / geometry / approximations; spectra whose grids and options agree share a launch (the
     others go alone), correlated-k, SH, patchy-cloud and level-flux cases take their usual path.  Every output
-    dictionary is bit-identical to ``case.spectrum(...)``'s.  HBM: the planes of a chunk stay resident until its
-    launch (0.8 GB per cloudy 1e5 x 90 spectrum, 0.2 GB per cloud-free one)."""
+    dictionary is bit-identical to ``case.spectrum(...)``'s.  The chunks are pipelined: while the GPU solves chunk k the
+    host sets up and enqueues chunk k + 1, and only then waits for k's result copies (``picaso_memcpy_d2h_async`` into
+    pinned blocks, ``picaso_mark_wait``) and runs its integrals.  HBM: the planes of a chunk stay resident until its
+    launch (0.8 GB per cloudy 1e5 x 90 spectrum, 0.2 GB per cloud-free one), two chunks at a time."""
     cases = list(cases)
     outs = []
+    in_flight = []                 # chunks whose launches and result copies are on the stream
     for c0 in range(0, len(cases), max(1, int(batch_size))):
         chunk = cases[c0:c0 + max(1, int(batch_size))]
         batch = _SolveBatch()
@@ -1772,6 +1795,14 @@ def spectrum_batch(cases, opacityclass, calculation="reflected", full_output=Fal
             fins.append(picaso(case, opacityclass, dimension="1d", calculation=calculation, full_output=full_output,
                                as_dict=as_dict, defer=True, _batch=batch))
         batch.flush()
+        for fin in fins:
+            fin.prefetch()
+        # the host finishes chunk k (waits for its copies, integrals, ratios) only after chunk k + 1 has been set up and
+        # enqueued: the GPU solves k + 1 meanwhile, and set-up of k + 1 ran while it solved k
+        in_flight.append(fins)
+        if len(in_flight) > 1:
+            outs.extend(fin() for fin in in_flight.pop(0))
+    for fins in in_flight:
         outs.extend(fin() for fin in fins)
     return outs
 

@@ -260,6 +260,14 @@ def axpby(ctx, a, x, b, y, out):
                                   _addr(out)), ctx)
 
 
+def trapz(ctx, n, d, y, out, mult=None, reverse=False):
+    """``np.trapezoid(y * mult, x)`` with ``d = diff(x)`` resident, summed in numpy's own pairwise order (same bits);
+    ``reverse``: over ``y[::-1]`` (and ``mult[::-1]``).  ``out``: a DeviceArray / address of one double
+    (``picaso_trapz_dev``; the Bond-albedo and effective-temperature integrals of justdoit.py:552-599)."""
+    check(load().picaso_trapz_dev(ctx, ctypes.c_long(int(n)), _addr(d), _addr(y), _addr(mult), _ci(1 if reverse else 0),
+                                  _addr(out)), ctx)
+
+
 def compress_disco(ctx, nwno, cos_theta, xint_at_top, gweight, tweight, F0PI, albedo):
     """``disco.compress_disco`` on DeviceArrays (reference disco.py:117-149)."""
     gw, tw = f64(gweight), f64(tweight)

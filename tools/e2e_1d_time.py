@@ -97,7 +97,8 @@ for devs in devsets:
         r = case.spectrum(opa, calculation=calc, devices=devs, full_output=bool(os.environ.get("FULL")))
         ts.append(time.perf_counter() - t0)
     out["spectrum_1d_%d_%s_devices_%s_ms" % (nwno, calc, "none" if devs is None else len(devs))] = round(1e3 * min(ts), 3)
-# BATCH="4,16": spectrum_batch() over that many copies of the case (each with its own temperature offset), per spectrum
+# BATCH="16,64": spectrum_batch() over that many copies of the case (each with its own temperature offset), BSIZE per
+# launch (default 4), per spectrum
 import copy
 for B in [int(x) for x in os.environ.get("BATCH", "").split(",") if x]:
     cases = []
@@ -107,11 +108,11 @@ for B in [int(x) for x in os.environ.get("BATCH", "").split(",") if x]:
         c.atmosphere(df=pk)
         cases.append(c)
     for _ in range(3):
-        rb = jdi.spectrum_batch(cases, opa, calculation=calc, batch_size=B)
+        rb = jdi.spectrum_batch(cases, opa, calculation=calc, batch_size=int(os.environ.get("BSIZE", "4")))
     ts = []
     for _ in range(8):
         t0 = time.perf_counter()
-        rb = jdi.spectrum_batch(cases, opa, calculation=calc, batch_size=B)
+        rb = jdi.spectrum_batch(cases, opa, calculation=calc, batch_size=int(os.environ.get("BSIZE", "4")))
         ts.append(time.perf_counter() - t0)
     tl = []
     for _ in range(3):
