@@ -571,6 +571,27 @@ int picaso_compute_opacity_ck_dev(picaso_ctx *ctx, int nlayer, int nwno, int nga
                                   double *tau_og, double *w0_og, double *cosb_og, double *w0_no_raman,
                                   double *f_deltaM);
 
+/* Gas stage and compute_opacity as ONE launch for monochromatic tables (ngauss = 1): picaso_opacity_gas_ck_dev followed
+ * by picaso_compute_opacity_ck_dev, bit for bit, without the TAUGAS / TAURAY planes travelling to HBM and back (2 x 72 MB
+ * written and read at 1e5 x 90; the two launches 0.22 ms, this one ~0.12).  The mixing is element-wise except for the
+ * level planes tau / tau_og (running sums down a column, optics.py:353-354, 418-420): those are a second, small launch --
+ * level_sums = 1: issued here; 0: left to the caller (picaso_level_sums_dev), who may first let another stream start
+ * on the layer planes (the thermal leg reads no level plane).  Output planes may be NULL as for compute_opacity; tau
+ * needs dtau, tau_og needs dtau_og. */
+int picaso_gas_compute_opacity_dev(picaso_ctx *ctx, int nlayer, int nwno, int mol_mode, int nmol,
+                                   const double *const *mol_tables, const int *mol_rows, const double *mol_wts,
+                                   const double *mol_fac, int cont_mode, int ncont, const double *const *cont_tables,
+                                   const int *cont_rows, const double *cont_wts, const double *cont_fac, int nray,
+                                   const double *const *ray_tables, const double *ray_fac, const double *taucld,
+                                   const double *w0_cld, const double *g0_cld, const double *raman_factor,
+                                   int raman_rows, double raman_const, int test_mode, int delta_eddington, int stream,
+                                   double *dtau, double *tau, double *w0, double *cosb, double *ftau_cld,
+                                   double *ftau_ray, double *gcos2, double *dtau_og, double *tau_og, double *w0_og,
+                                   double *cosb_og, double *w0_no_raman, double *f_deltaM, int level_sums);
+/* tau[0] = 0, tau[i + 1] = tau[i] + dtau[i] for (nlayer, ncol) layer planes -> (nlayer + 1, ncol) level planes; either
+ * pair may be NULL */
+int picaso_level_sums_dev(picaso_ctx *ctx, int nlayer, long ncol, const double *dtau, double *tau, const double *dtau_og,
+                          double *tau_og);
 /* 3-D path (reference picaso/justdoit.py:444-471 fills `DTAU_3d[:,:,g,t,:] = dtau` facet by facet):
  * one launch mixes all facets.  taugas, tauray (and raman_factor when non-NULL) are facet-major
  * (nfacets, nlayer, nwno) -- picaso_opacity_gas_dev is called once per facet on its slice -- the cloud
@@ -635,6 +656,18 @@ typedef struct picaso_block {
     const double *th_dtau, *th_w0, *th_cosb;           /* what get_thermal_1d reads */
     double *xint, *albedo, *flux, *disk;   /* device results: (numg,numt,nwno), (nwno), (numg,numt,nwno), (nwno) */
     double *albedo_host, *thermal_host;    /* full-grid host results (or NULL: leave them on the device) */
+    /* The spectrum-wide integrals of justdoit.py:552-599 on the device (picaso_trapz_dev), for ONE block that covers the
+     * grid: trapz_d = diff(1/wno), trapz_dr = diff(1/wno[::-1]) (nwno - 1 each), stellar (nwno), all device, or NULL.
+     * With trapz_d set, albedo holds nwno + 1 doubles and [nwno] = np.trapz(x=1/wno, y=albedo*stellar); with trapz_dr,
+     * disk[nwno] = np.trapz(x=1/wno[::-1], y=thermal[::-1]); collect then copies nwno + 1 doubles into the host array. */
+    const double *trapz_d, *trapz_dr, *stellar;
+    /* Pinned staging blocks of the caller (picaso_host_alloc, nwno + 1 doubles each) or NULL.  With them the copies of
+     * a leg's results are put on its stream by picaso_toon_spectrum_blocks itself, right behind its last kernel
+     * (picaso_memcpy_d2h_async; the marks below are written by that call), and picaso_toon_spectrum_collect only
+     * waits for the mark and moves the block into the host array: a leg that finishes early is on the host early,
+     * whatever order the legs are collected in.  Without them collect issues a synchronous copy. */
+    double *albedo_pin, *thermal_pin;
+    void *albedo_mark, *thermal_mark;
 } picaso_block;
 typedef struct picaso_spectrum_job {
     int nlayer;
@@ -656,9 +689,11 @@ typedef struct picaso_spectrum_job {
     const double *tlevel, *plevel;         /* host (nlevel) */
     int hard_surface;
 } picaso_spectrum_job;
-int picaso_toon_spectrum_blocks(int nblocks, const picaso_block *blocks, const picaso_spectrum_job *job);
+int picaso_toon_spectrum_blocks(int nblocks, picaso_block *blocks, const picaso_spectrum_job *job);
 /* copy one leg's results (which = 1: albedo, 2: thermal flux) of every block into albedo_host / thermal_host */
-int picaso_toon_spectrum_collect(int nblocks, const picaso_block *blocks, int which);
+int picaso_toon_spectrum_collect(int nblocks, picaso_block *blocks, int which);
+/* wait for and drop result copies that will not be collected (the caller failed in between) */
+int picaso_toon_spectrum_abandon(int nblocks, picaso_block *blocks);
 /* sizeof(picaso_block), sizeof(picaso_spectrum_job) and two member offsets as compiled (layout check of a binding) */
 int picaso_driver_abi(size_t *block_bytes, size_t *job_bytes, size_t *off_albedo_host, size_t *off_hard_surface);
 

@@ -15,18 +15,22 @@
 #include "common.hpp"
 
 #include <cstddef>
+#include <cstdlib>
+#include <cstring>
 
 using namespace pz;
 
-extern "C" int picaso_toon_spectrum_blocks(int nblocks, const picaso_block *blocks, const picaso_spectrum_job *job)
+extern "C" int picaso_toon_spectrum_blocks(int nblocks, picaso_block *blocks, const picaso_spectrum_job *job)
 {
     if (nblocks < 1 || !blocks || !job) return fail(nullptr, "toon_spectrum_blocks: null argument");
     const picaso_spectrum_job &j = *job;
     if (j.nlayer < 1 || j.numg < 1 || j.numt < 1) return fail(blocks[0].ctx, "toon_spectrum_blocks: bad sizes");
     const int nlevel = j.nlayer + 1;
     for (int b = 0; b < nblocks; ++b) {
-        const picaso_block &k = blocks[b];
+        picaso_block &k = blocks[b];
         if (!k.ctx || k.nwno < 1) return fail(k.ctx, "toon_spectrum_blocks: block %d has no context or no columns", b);
+        if (k.albedo_mark || k.thermal_mark)
+            return fail(k.ctx, "toon_spectrum_blocks: block %d still has uncollected results", b);
         picaso_ctx *tctx = k.tctx ? k.tctx : k.ctx;
         // cloud tables handed over as full-grid host planes: this block's columns, strided copy (the reference slices
         // nothing: it has one grid; justdoit.py:4774 fans out whole spectra)
@@ -42,14 +46,29 @@ extern "C" int picaso_toon_spectrum_blocks(int nblocks, const picaso_block *bloc
                 cld[c] = dst[c];
             }
         }
-        PZ_TRY(picaso_opacity_gas_ck_dev(k.ctx, j.nlayer, k.nwno, 1, j.mol_mode, j.nmol, k.mol_tabs, j.mol_rows, j.mol_wts,
-                                         j.mol_fac, j.cont_interp, j.ncont, k.cont_tabs, j.cont_rows, j.cont_wts, j.cont_fac,
-                                         j.nray, k.ray_tabs, j.ray_fac, k.taugas, k.tauray));
         double *const *o = k.planes;
-        PZ_TRY(picaso_compute_opacity_ck_dev(k.ctx, j.nlayer, k.nwno, 1, k.taugas, k.tauray, cld[0], cld[1], cld[2], k.raman,
-                                             j.raman_rows, j.raman_const, j.test_mode, j.delta_eddington, j.stream, o[0],
-                                             o[1], o[2], o[3], o[4], o[5], o[6], o[7], o[8], o[9], o[10], o[11], o[12]));
-        if (tctx != k.ctx && j.do_thermal) PZ_TRY(picaso_ctx_wait(tctx, k.ctx));
+        // gas stage + mixing as one launch, the level planes as a second one that the thermal leg does not wait for
+        // (it reads layer planes only); PICASO_AMD_UNFUSED_OPACITY=1: the two launches with TAUGAS / TAURAY in HBM (A/B)
+        const bool fused = (!o[1] || o[0]) && (!o[8] || o[7]) && !getenv("PICASO_AMD_UNFUSED_OPACITY");
+        if (fused) {
+            PZ_TRY(picaso_gas_compute_opacity_dev(k.ctx, j.nlayer, k.nwno, j.mol_mode, j.nmol, k.mol_tabs, j.mol_rows,
+                                                  j.mol_wts, j.mol_fac, j.cont_interp, j.ncont, k.cont_tabs, j.cont_rows,
+                                                  j.cont_wts, j.cont_fac, j.nray, k.ray_tabs, j.ray_fac, cld[0], cld[1],
+                                                  cld[2], k.raman, j.raman_rows, j.raman_const, j.test_mode,
+                                                  j.delta_eddington, j.stream, o[0], o[1], o[2], o[3], o[4], o[5], o[6],
+                                                  o[7], o[8], o[9], o[10], o[11], o[12], 0));
+            if (tctx != k.ctx && j.do_thermal) PZ_TRY(picaso_ctx_wait(tctx, k.ctx));
+            PZ_TRY(picaso_level_sums_dev(k.ctx, j.nlayer, k.nwno, o[0], o[1], o[7], o[8]));
+        } else {
+            PZ_TRY(picaso_opacity_gas_ck_dev(k.ctx, j.nlayer, k.nwno, 1, j.mol_mode, j.nmol, k.mol_tabs, j.mol_rows,
+                                             j.mol_wts, j.mol_fac, j.cont_interp, j.ncont, k.cont_tabs, j.cont_rows,
+                                             j.cont_wts, j.cont_fac, j.nray, k.ray_tabs, j.ray_fac, k.taugas, k.tauray));
+            PZ_TRY(picaso_compute_opacity_ck_dev(k.ctx, j.nlayer, k.nwno, 1, k.taugas, k.tauray, cld[0], cld[1], cld[2],
+                                                 k.raman, j.raman_rows, j.raman_const, j.test_mode, j.delta_eddington,
+                                                 j.stream, o[0], o[1], o[2], o[3], o[4], o[5], o[6], o[7], o[8], o[9], o[10],
+                                                 o[11], o[12]));
+            if (tctx != k.ctx && j.do_thermal) PZ_TRY(picaso_ctx_wait(tctx, k.ctx));
+        }
         if (j.do_reflected) {
             const double *const *r = k.refl_planes;
             PZ_TRY(picaso_get_reflected_1d_dev(k.ctx, nlevel, k.nwno, k.nwno, j.numg, j.numt, r[0], r[1], r[2], r[3], r[4],
@@ -58,12 +77,26 @@ extern "C" int picaso_toon_spectrum_blocks(int nblocks, const picaso_block *bloc
                                                j.frac_c, j.constant_back, j.constant_forward, 1, 0, j.toon_coefficients,
                                                j.b_top, k.xint, nullptr, nullptr, nullptr, nullptr, j.gweight, j.tweight,
                                                k.albedo));
+            if (k.trapz_d) {
+                if (nblocks != 1) return fail(k.ctx, "toon_spectrum_blocks: device integrals need ONE block over the grid");
+                PZ_TRY(picaso_trapz_dev(k.ctx, k.nwno, k.trapz_d, k.albedo, k.stellar, 0, k.albedo + k.nwno));
+            }
+            if (k.albedo_pin && k.albedo_host)
+                PZ_TRY(picaso_memcpy_d2h_async(k.ctx, k.albedo_pin, k.albedo,
+                                               sizeof(double) * (size_t)(k.nwno + (k.trapz_d ? 1 : 0)), &k.albedo_mark));
         }
         if (j.do_thermal) {
             PZ_TRY(picaso_get_thermal_1d_dev(tctx, nlevel, k.wno, k.nwno, k.nwno, j.numg, j.numt, j.tlevel, k.th_dtau,
                                              k.th_w0, k.th_cosb, j.plevel, j.ubar1, k.surf_reflect, j.hard_surface,
                                              nullptr, 0, k.flux, nullptr, nullptr, nullptr, nullptr, j.gweight, j.tweight,
                                              k.disk));
+            if (k.trapz_dr) {
+                if (nblocks != 1) return fail(k.ctx, "toon_spectrum_blocks: device integrals need ONE block over the grid");
+                PZ_TRY(picaso_trapz_dev(tctx, k.nwno, k.trapz_dr, k.disk, nullptr, 1, k.disk + k.nwno));
+            }
+            if (k.thermal_pin && k.thermal_host)
+                PZ_TRY(picaso_memcpy_d2h_async(tctx, k.thermal_pin, k.disk,
+                                               sizeof(double) * (size_t)(k.nwno + (k.trapz_dr ? 1 : 0)), &k.thermal_mark));
         }
     }
     return 0;
@@ -72,18 +105,34 @@ extern "C" int picaso_toon_spectrum_blocks(int nblocks, const picaso_block *bloc
 // Copy one leg's results (which = 1: albedo, 2: thermal flux) of every block into the caller's full-grid host arrays
 // at [col0, col0 + nwno).  Each copy waits for its own stream only; the other blocks and the other leg keep running --
 // the caller integrates the albedo while the thermal kernels finish.
-extern "C" int picaso_toon_spectrum_collect(int nblocks, const picaso_block *blocks, int which)
+extern "C" int picaso_toon_spectrum_collect(int nblocks, picaso_block *blocks, int which)
 {
     if (nblocks < 1 || !blocks) return fail(nullptr, "toon_spectrum_collect: null argument");
     for (int b = 0; b < nblocks; ++b) {
-        const picaso_block &k = blocks[b];
+        picaso_block &k = blocks[b];
         picaso_ctx *tctx = k.tctx ? k.tctx : k.ctx;
         if (which == 1) {
             if (!k.albedo_host) return fail(k.ctx, "toon_spectrum_collect: block %d has no host albedo array", b);
-            PZ_TRY(picaso_memcpy_d2h(k.ctx, k.albedo_host + k.col0, k.albedo, sizeof(double) * (size_t)k.nwno));
+            const size_t bytes = sizeof(double) * (size_t)(k.nwno + (k.trapz_d ? 1 : 0));
+            if (k.albedo_mark) {
+                void *mark = k.albedo_mark;
+                k.albedo_mark = nullptr;
+                PZ_TRY(picaso_mark_wait(k.ctx, mark));
+                memcpy(k.albedo_host + k.col0, k.albedo_pin, bytes);
+            } else {
+                PZ_TRY(picaso_memcpy_d2h(k.ctx, k.albedo_host + k.col0, k.albedo, bytes));
+            }
         } else if (which == 2) {
             if (!k.thermal_host) return fail(k.ctx, "toon_spectrum_collect: block %d has no host thermal array", b);
-            PZ_TRY(picaso_memcpy_d2h(tctx, k.thermal_host + k.col0, k.disk, sizeof(double) * (size_t)k.nwno));
+            const size_t bytes = sizeof(double) * (size_t)(k.nwno + (k.trapz_dr ? 1 : 0));
+            if (k.thermal_mark) {
+                void *mark = k.thermal_mark;
+                k.thermal_mark = nullptr;
+                PZ_TRY(picaso_mark_wait(tctx, mark));
+                memcpy(k.thermal_host + k.col0, k.thermal_pin, bytes);
+            } else {
+                PZ_TRY(picaso_memcpy_d2h(tctx, k.thermal_host + k.col0, k.disk, bytes));
+            }
             // a second stream read the planes of ctx: ctx's next call (which overwrites them) starts behind it
             if (tctx != k.ctx) PZ_TRY(picaso_ctx_wait(k.ctx, tctx));
         } else {
@@ -91,6 +140,21 @@ extern "C" int picaso_toon_spectrum_collect(int nblocks, const picaso_block *blo
         }
     }
     return 0;
+}
+
+// Results nobody will collect (the caller failed between the two calls): wait for the copies in flight and clear their
+// marks, so that the blocks can take the next spectrum.
+extern "C" int picaso_toon_spectrum_abandon(int nblocks, picaso_block *blocks)
+{
+    if (nblocks < 1 || !blocks) return fail(nullptr, "toon_spectrum_abandon: null argument");
+    int rc = 0;
+    for (int b = 0; b < nblocks; ++b) {
+        picaso_block &k = blocks[b];
+        picaso_ctx *tctx = k.tctx ? k.tctx : k.ctx;
+        if (k.albedo_mark) { if (picaso_mark_wait(k.ctx, k.albedo_mark)) rc = 1; k.albedo_mark = nullptr; }
+        if (k.thermal_mark) { if (picaso_mark_wait(tctx, k.thermal_mark)) rc = 1; k.thermal_mark = nullptr; }
+    }
+    return rc;
 }
 
 // sizeof / offsets of the two structs above as this library was compiled, so that a binding (picaso_amd/driver.py's

@@ -23,7 +23,7 @@ namespace pz {
 
 struct PairwisePlan {
     long m = 0;                 // number of summands
-    int nleaf = 0, nlevel = 0, root = 0;
+    int nleaf = 0, nlevel = 0, root = 0, nvals = 0;
     int *d_leaf = nullptr;      // nleaf + 1 offsets
     int *d_ops = nullptr;       // [level offsets (nlevel + 1)] then (dst, a, b) triples, level by level from the leaves up
     double *d_vals = nullptr;   // nleaf leaf sums, then one value per inner node
@@ -88,8 +88,14 @@ __global__ __launch_bounds__(256) void k_trapz_leaves(const TrapzArgs a)
             for (long i = 0; i < len; ++i) res = res + trapz_elem(a, start + i);
     } else {
         const long body = len - len % 8;
-        double r = trapz_elem(a, start + j);
-        for (long i = 8; i < body; i += 8) r = r + trapz_elem(a, start + i + j);
+        // a leaf has at most 128 terms = 16 per lane: all loads first (they do not depend on each other; the sum does)
+        double e[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) e[i] = trapz_elem(a, start + ((i * 8 < body) ? i * 8 : 0) + j);   // no branch around a load
+        double r = e[0];
+#pragma unroll
+        for (int i = 1; i < 16; ++i)
+            if (i * 8 < body) r = r + e[i];
         r = r + __shfl_xor(r, 1);                   // r0 + r1 | r2 + r3 | r4 + r5 | r6 + r7
         r = r + __shfl_xor(r, 2);                   // (r0 + r1) + (r2 + r3) | (r4 + r5) + (r6 + r7)
         r = r + __shfl_xor(r, 4);
@@ -101,14 +107,22 @@ __global__ __launch_bounds__(256) void k_trapz_leaves(const TrapzArgs a)
 }
 
 // the inner nodes, one level per barrier; a single workgroup (a 1e5-term sum: 13 chunks, 1 023 nodes, 19 levels)
-__global__ __launch_bounds__(1024) void k_pairwise_combine(const int *__restrict__ ops, int nlevel, int root,
-                                                           double *vals, double *__restrict__ out)
+constexpr int COMBINE_LDS = 4096;          // values (leaves + inner nodes) combined in LDS: sums of up to ~2e5 terms
+template <bool IN_LDS>
+__global__ __launch_bounds__(1024) void k_pairwise_combine(const int *__restrict__ ops, int nlevel, int root, int nvals,
+                                                           int nleaf, double *gvals, double *__restrict__ out)
 {
+    __shared__ double lvals[IN_LDS ? COMBINE_LDS : 1];
+    double *vals = IN_LDS ? lvals : gvals;
+    if (IN_LDS) {
+        for (int i = threadIdx.x; i < nleaf; i += blockDim.x) lvals[i] = gvals[i];
+        __syncthreads();
+    }
     const int *trip = ops + nlevel + 1;
     for (int lev = 0; lev < nlevel; ++lev) {
         for (int o = ops[lev] + (int)threadIdx.x; o < ops[lev + 1]; o += (int)blockDim.x)
             vals[trip[3 * o]] = vals[trip[3 * o + 1]] + vals[trip[3 * o + 2]];
-        __threadfence_block();
+        if (!IN_LDS) __threadfence_block();
         __syncthreads();
     }
     if (threadIdx.x == 0) out[0] = vals[root];
@@ -160,6 +174,7 @@ static int get_plan(picaso_ctx *ctx, long m, PairwisePlan **out)
         for (int id : lv) ops.push_back(slot(id));
     PairwisePlan *p = new PairwisePlan;
     p->m = m; p->nleaf = nleaf; p->nlevel = (int)levels.size(); p->root = slot(top.id);
+    p->nvals = nleaf + ninner;
     auto bail = [&](hipError_t e, const char *what) {
         if (p->d_leaf) (void)hipFree(p->d_leaf);
         if (p->d_ops) (void)hipFree(p->d_ops);
@@ -195,7 +210,12 @@ extern "C" int picaso_trapz_dev(picaso_ctx *ctx, long n, const double *d, const 
     TrapzArgs a{n, d, y, mult, reverse, p->d_leaf, p->nleaf, p->d_vals};
     const long threads = (long)p->nleaf * 8;
     hipLaunchKernelGGL(k_trapz_leaves, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx->stream, a);
-    hipLaunchKernelGGL(k_pairwise_combine, dim3(1), dim3(1024), 0, ctx->stream, p->d_ops, p->nlevel, p->root, p->d_vals, out);
+    if (p->nvals <= COMBINE_LDS)
+        hipLaunchKernelGGL(k_pairwise_combine<true>, dim3(1), dim3(1024), 0, ctx->stream, p->d_ops, p->nlevel, p->root,
+                           p->nvals, p->nleaf, p->d_vals, out);
+    else
+        hipLaunchKernelGGL(k_pairwise_combine<false>, dim3(1), dim3(1024), 0, ctx->stream, p->d_ops, p->nlevel, p->root,
+                           p->nvals, p->nleaf, p->d_vals, out);
     PZ_HIP(ctx, hipGetLastError());
     return 0;
 }

@@ -10,6 +10,85 @@
 
 namespace pz {
 
+struct MixArgs {
+    int nlayer, nwno, test_mode, delta_eddington, stream;
+    int ncolper;      // columns per wavelength of taugas and of every output (tauray, cloud, raman have none)
+    int nfac;         // > 1: 3-D facet mode.  Columns are (wavelength, facet) with the facet fastest -- the
+                      // layout of the (rows, nwno, ng, nt) planes get_reflected_3d takes and of the cloud
+                      // inputs; taugas / tauray / raman are facet-major (nfac, nlayer, nwno), as the per-facet
+                      // gas launches write them (ncolper must be 1)
+    const double *taugas, *tauray, *taucld, *w0c, *g0c, *raman;
+    double raman_const;
+    int raman_row;    // raman is one row (nwno) for every layer and facet (the Pollack table) instead of a plane
+    double *dtau, *tau, *w0, *cosb, *ftau_cld, *ftau_ray, *gcos2, *dtau_og, *tau_og, *w0_og,
+        *cosb_og, *w0_no_raman, *f_deltaM;
+};
+
+__device__ __forceinline__ double ipow(double x, int n)
+{
+    double r = 1.0;
+    for (int i = 0; i < n; ++i) r *= x;      // COSB**stream, stream = 2 or 4 (optics.py:412)
+    return r;
+}
+
+// One layer of one column: mixing + delta-Eddington (optics.py:327-431), running level sums in tau_run /
+// taud_run.  Shared by the plane kernel and the facet kernel; operations as written (no contraction), so
+// both give the same bits -- and planes that coincide analytically (w0 and w0_no_raman for a constant Raman
+// factor of 0.99999, the delta-scaled and the unscaled set for cosb = 0) coincide bit for bit, which the
+// 3-D path relies on when it leaves the duplicates out.
+__device__ __forceinline__ void mix_layer(const MixArgs &a, long q, long qn, double tg, double tr, double tc,
+                                          double wc, double gc, double rf, double &tau_run, double &taud_run)
+{
+#pragma clang fp contract(off)
+    // every output is optional (kernel arguments: the tests are scalar); a quotient nobody stores is not formed --
+    // a cloud-free spectrum asks for dtau, w0 (and tau): two of the six divisions
+    const bool want_fc = a.ftau_cld != nullptr, want_fr = a.ftau_ray != nullptr || a.gcos2 != nullptr;
+    const bool want_nr = a.w0_no_raman != nullptr;
+    double dtau = tg + tr + tc;                                     // optics.py:329
+    double fcld = want_fc ? (wc * tc) / (wc * tc + tr) : 0.0;       // :335
+    double cosb = gc;                                               // :338
+    double fray = want_fr ? tr / (tr + wc * tc) : 0.0;              // :341
+    double gcos2 = 0.5 * fray;                                      // :342
+    double w0 = (tr * rf + tc * wc) / (tg + tr + tc);               // :346
+    double w0nr = want_nr ? (tr * 0.99999 + tc * wc) / (tg + tr + tc) : 0.0;   // :350
+    if (a.test_mode) {                                              // :372-399
+        if (a.test_mode == 1) {          // 'rayleigh'
+            dtau = tr; gcos2 = 0.5; fray = 1.0; fcld = 0.0;
+        } else {                         // constant tau from the cloud opd
+            dtau = tc; gcos2 = 0.0; fray = 0.0; fcld = 1.0;
+        }
+        if (dtau <= 0) dtau = 1e-10;
+        cosb = gc;
+        w0 = (wc <= 0) ? 1e-10 : wc;
+        w0nr = w0;
+    }
+    tau_run += dtau;                                                // numba_cumsum (:353-354)
+    if (a.dtau_og) a.dtau_og[q] = dtau;
+    if (a.tau_og) a.tau_og[qn] = tau_run;
+    if (a.w0_og) a.w0_og[q] = w0;
+    if (a.cosb_og) a.cosb_og[q] = cosb;
+    if (a.ftau_cld) a.ftau_cld[q] = fcld;
+    if (a.ftau_ray) a.ftau_ray[q] = fray;
+    if (a.gcos2) a.gcos2[q] = gcos2;
+    if (a.w0_no_raman) a.w0_no_raman[q] = w0nr;
+    if (a.delta_eddington) {                                        // :401-420
+        const double f = ipow(cosb, a.stream);
+        const double dtd = dtau * (1. - w0 * f);
+        taud_run += dtd;
+        if (a.f_deltaM) a.f_deltaM[q] = f;
+        if (a.w0) a.w0[q] = w0 * (1. - f) / (1.0 - w0 * f);
+        if (a.cosb) a.cosb[q] = (cosb - f) / (1. - f);
+        if (a.dtau) a.dtau[q] = dtd;
+        if (a.tau) a.tau[qn] = taud_run;
+    } else {                                                        // :428-431
+        if (a.f_deltaM) a.f_deltaM[q] = 0 * cosb;
+        if (a.w0) a.w0[q] = w0;
+        if (a.cosb) a.cosb[q] = cosb;
+        if (a.dtau) a.dtau[q] = dtau;
+        if (a.tau) a.tau[qn] = tau_run;
+    }
+}
+
 struct GasArgs {
     int nlayer, nwno, nmol, ncont, nray;
     int ncolper;      // columns per wavelength of the molecular tables / taugas (correlated-k Gauss points)
@@ -20,7 +99,9 @@ struct GasArgs {
     const double *const *mol_tables, *const *cont_tables, *const *ray_tables;   // device arrays of device ptrs
     const int *mol_rows, *cont_rows;          // device
     const double *mol_wts, *mol_fac, *cont_wts, *cont_fac, *ray_fac;
-    double *taugas, *tauray;
+    double *taugas, *tauray;  // not written with fuse
+    int fuse;                 // 1: mix_layer on every element straight from the sums (picaso_gas_compute_opacity_dev):
+    MixArgs mix;              //    TAUGAS / TAURAY never travel through HBM; mix.tau / mix.tau_og must be NULL (k_level_sums)
 };
 
 // One lane per column, GAS_LT consecutive layers per thread: neighbouring layers mostly bracket the
@@ -30,6 +111,7 @@ struct GasArgs {
 // (continuum pairs, then molecules; optics.py:172-255), so the tiling does not change a bit.
 constexpr int GAS_LT = 10;
 
+template <int FUSE>      // 0: TAUGAS / TAURAY out; 1: mixing fused in; 2: the cloud-free form of 1
 __global__ __launch_bounds__(256) void k_opacity_gas(const GasArgs a)
 {
     const long col = blockIdx.x * (long)blockDim.x + threadIdx.x;
@@ -95,9 +177,11 @@ __global__ __launch_bounds__(256) void k_opacity_gas(const GasArgs a)
             }
         }
     }
+    if constexpr (FUSE == 0) {
 #pragma unroll
-    for (int l = 0; l < GAS_LT; ++l)
-        if (l < nl) a.taugas[(long)(l0 + l) * ncol + col] = tg[l];
+        for (int l = 0; l < GAS_LT; ++l)
+            if (l < nl) a.taugas[(long)(l0 + l) * ncol + col] = tg[l];
+    }
     if (col == w * a.ncolper) {      // Rayleigh has no Gauss-point axis (optics.py:265-277)
         double tr[GAS_LT];
 #pragma unroll
@@ -108,86 +192,81 @@ __global__ __launch_bounds__(256) void k_opacity_gas(const GasArgs a)
             for (int l = 0; l < GAS_LT; ++l)
                 if (l < nl) tr[l] += rv * a.ray_fac[q * a.nlayer + l0 + l];   // :265-271
         }
+        if constexpr (FUSE == 0) {
 #pragma unroll
-        for (int l = 0; l < GAS_LT; ++l)
-            if (l < nl) a.tauray[(long)(l0 + l) * nw + w] = tr[l];
+            for (int l = 0; l < GAS_LT; ++l)
+                if (l < nl) a.tauray[(long)(l0 + l) * nw + w] = tr[l];
+        }
+        if constexpr (FUSE != 0) {
+            // (ncolper = 1: col == w.)  The mixing of compute_opacity on the values just formed -- the same function
+            // on the same operands as k_compute_opacity reads back from HBM, so the same bits; the level sums, the one
+            // thing that runs down a column, are k_level_sums' (tau / tau_og are NULL here).
+            const bool rf_plane = a.mix.raman && !a.mix.raman_row;
+            const double rf_row = (a.mix.raman && a.mix.raman_row) ? a.mix.raman[w] : a.mix.raman_const;
+            double run0 = 0.0, run1 = 0.0;
+            if constexpr (FUSE == 2) {
+                // The cloud-free spectrum (the host checked: no cloud planes, no test mode, only dtau / w0 /
+                // w0_no_raman wanted): the same mix_layer on a copy of the arguments whose other pointers are literal
+                // NULLs, so the compiler drops the eleven stores it cannot reach and the quotients only they need --
+                // a specialisation by constant propagation, not a second formula.
+                MixArgs m{};
+                m.nlayer = a.mix.nlayer; m.nwno = a.mix.nwno; m.ncolper = 1;
+                m.delta_eddington = a.mix.delta_eddington; m.stream = a.mix.stream;
+                m.dtau = a.mix.dtau; m.w0 = a.mix.w0; m.w0_no_raman = a.mix.w0_no_raman;
+#pragma unroll
+                for (int l = 0; l < GAS_LT; ++l) {
+                    if (l < nl) {
+                        const long o = (long)(l0 + l) * nw + w;
+                        mix_layer(m, o, o, tg[l], tr[l], 0.0, 0.0, 0.0, rf_plane ? a.mix.raman[o] : rf_row, run0, run1);
+                    }
+                }
+            } else {
+                const MixArgs &m = a.mix;
+#pragma unroll
+                for (int l = 0; l < GAS_LT; ++l) {
+                    if (l < nl) {
+                        const long o = (long)(l0 + l) * nw + w;
+                        const double tc = m.taucld ? m.taucld[o] : 0.0, wc = m.w0c ? m.w0c[o] : 0.0,
+                                     gc = m.g0c ? m.g0c[o] : 0.0;
+                        const double rf = rf_plane ? m.raman[o] : rf_row;
+                        mix_layer(m, o, o, tg[l], tr[l], tc, wc, gc, rf, run0, run1);
+                    }
+                }
+            }
+        }
     }
 }
 
-struct MixArgs {
-    int nlayer, nwno, test_mode, delta_eddington, stream;
-    int ncolper;      // columns per wavelength of taugas and of every output (tauray, cloud, raman have none)
-    int nfac;         // > 1: 3-D facet mode.  Columns are (wavelength, facet) with the facet fastest -- the
-                      // layout of the (rows, nwno, ng, nt) planes get_reflected_3d takes and of the cloud
-                      // inputs; taugas / tauray / raman are facet-major (nfac, nlayer, nwno), as the per-facet
-                      // gas launches write them (ncolper must be 1)
-    const double *taugas, *tauray, *taucld, *w0c, *g0c, *raman;
-    double raman_const;
-    int raman_row;    // raman is one row (nwno) for every layer and facet (the Pollack table) instead of a plane
-    double *dtau, *tau, *w0, *cosb, *ftau_cld, *ftau_ray, *gcos2, *dtau_og, *tau_og, *w0_og,
-        *cosb_og, *w0_no_raman, *f_deltaM;
-};
-
-__device__ __forceinline__ double ipow(double x, int n)
-{
-    double r = 1.0;
-    for (int i = 0; i < n; ++i) r *= x;      // COSB**stream, stream = 2 or 4 (optics.py:412)
-    return r;
-}
-
-// One layer of one column: mixing + delta-Eddington (optics.py:327-431), running level sums in tau_run /
-// taud_run.  Shared by the plane kernel and the facet kernel; operations as written (no contraction), so
-// both give the same bits -- and planes that coincide analytically (w0 and w0_no_raman for a constant Raman
-// factor of 0.99999, the delta-scaled and the unscaled set for cosb = 0) coincide bit for bit, which the
-// 3-D path relies on when it leaves the duplicates out.
-__device__ __forceinline__ void mix_layer(const MixArgs &a, long q, long qn, double tg, double tr, double tc,
-                                          double wc, double gc, double rf, double &tau_run, double &taud_run)
+// tau[0] = 0, tau[i + 1] = tau[i] + dtau[i] down every column (numba_cumsum, optics.py:353-354, 418-420): the level
+// planes of the fused gas + mixing launch, whose elements are formed layer tile by layer tile.  Two planes per launch
+// (the delta-scaled and the unscaled set); either pair may be NULL.
+__global__ __launch_bounds__(256) void k_level_sums(int nlayer, long ncol, const double *__restrict__ d0,
+                                                    double *__restrict__ t0, const double *__restrict__ d1,
+                                                    double *__restrict__ t1)
 {
 #pragma clang fp contract(off)
-    double dtau = tg + tr + tc;                                     // optics.py:329
-    double fcld = (wc * tc) / (wc * tc + tr);                       // :335
-    double cosb = gc;                                               // :338
-    double fray = tr / (tr + wc * tc);                              // :341
-    double gcos2 = 0.5 * fray;                                      // :342
-    double w0 = (tr * rf + tc * wc) / (tg + tr + tc);               // :346
-    double w0nr = (tr * 0.99999 + tc * wc) / (tg + tr + tc);        // :350
-    if (a.test_mode) {                                              // :372-399
-        if (a.test_mode == 1) {          // 'rayleigh'
-            dtau = tr; gcos2 = 0.5; fray = 1.0; fcld = 0.0;
-        } else {                         // constant tau from the cloud opd
-            dtau = tc; gcos2 = 0.0; fray = 0.0; fcld = 1.0;
+    const long col = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (col >= ncol) return;
+    const double *d = blockIdx.y == 0 ? d0 : d1;
+    double *t = blockIdx.y == 0 ? t0 : t1;
+    if (!t) return;
+    double run = 0.0;
+    t[col] = 0.0;
+    // eight loads in flight per lane: a column is a chain of dependent adds, the loads are not
+    int i = 0;
+    for (; i + 8 <= nlayer; i += 8) {
+        double v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = d[(long)(i + k) * ncol + col];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            run += v[k];
+            t[(long)(i + k + 1) * ncol + col] = run;
         }
-        if (dtau <= 0) dtau = 1e-10;
-        cosb = gc;
-        w0 = (wc <= 0) ? 1e-10 : wc;
-        w0nr = w0;
     }
-    tau_run += dtau;                                                // numba_cumsum (:353-354)
-    if (a.dtau_og) a.dtau_og[q] = dtau;
-    if (a.tau_og) a.tau_og[qn] = tau_run;
-    if (a.w0_og) a.w0_og[q] = w0;
-    if (a.cosb_og) a.cosb_og[q] = cosb;
-    if (a.ftau_cld) a.ftau_cld[q] = fcld;
-    if (a.ftau_ray) a.ftau_ray[q] = fray;
-    if (a.gcos2) a.gcos2[q] = gcos2;
-    if (a.w0_no_raman) a.w0_no_raman[q] = w0nr;
-    if (a.delta_eddington) {                                        // :401-420
-        const double f = ipow(cosb, a.stream);
-        const double w0d = w0 * (1. - f) / (1.0 - w0 * f);
-        const double cbd = (cosb - f) / (1. - f);
-        const double dtd = dtau * (1. - w0 * f);
-        taud_run += dtd;
-        if (a.f_deltaM) a.f_deltaM[q] = f;
-        if (a.w0) a.w0[q] = w0d;
-        if (a.cosb) a.cosb[q] = cbd;
-        if (a.dtau) a.dtau[q] = dtd;
-        if (a.tau) a.tau[qn] = taud_run;
-    } else {                                                        // :428-431
-        if (a.f_deltaM) a.f_deltaM[q] = 0 * cosb;
-        if (a.w0) a.w0[q] = w0;
-        if (a.cosb) a.cosb[q] = cosb;
-        if (a.dtau) a.dtau[q] = dtau;
-        if (a.tau) a.tau[qn] = tau_run;
+    for (; i < nlayer; ++i) {
+        run += d[(long)i * ncol + col];
+        t[(long)(i + 1) * ncol + col] = run;
     }
 }
 
@@ -529,13 +608,14 @@ int picaso_broadcast_facets_dev(picaso_ctx *ctx, size_t nrows, int nwno, int nfa
     return 0;
 }
 
-int picaso_opacity_gas_ck_dev(picaso_ctx *ctx, int nlayer, int nwno, int ngauss, int mol_mode, int nmol,
-                              const double *const *mol_tables, const int *mol_rows,
-                              const double *mol_wts, const double *mol_fac, int cont_mode, int ncont,
-                              const double *const *cont_tables, const int *cont_rows,
-                              const double *cont_wts, const double *cont_fac, int nray,
-                              const double *const *ray_tables, const double *ray_fac, double *taugas,
-                              double *tauray)
+// the gas stage; `mix` != NULL: with the mixing fused in (taugas / tauray may then be NULL)
+static int gas_launch(picaso_ctx *ctx, int nlayer, int nwno, int ngauss, int mol_mode, int nmol,
+                      const double *const *mol_tables, const int *mol_rows,
+                      const double *mol_wts, const double *mol_fac, int cont_mode, int ncont,
+                      const double *const *cont_tables, const int *cont_rows,
+                      const double *cont_wts, const double *cont_fac, int nray,
+                      const double *const *ray_tables, const double *ray_fac, double *taugas,
+                      double *tauray, const MixArgs *mix)
 {
     if (!ctx) return fail(nullptr, "null context");
     if (nlayer < 1 || nwno < 1 || nmol < 0 || ncont < 0 || nray < 0) return fail(ctx, "opacity_gas: bad sizes");
@@ -585,11 +665,84 @@ int picaso_opacity_gas_ck_dev(picaso_ctx *ctx, int nlayer, int nwno, int ngauss,
     a.cont_fac = (const double *)(dc + o_cf);
     a.ray_fac = (const double *)(dc + o_rf);
     a.taugas = taugas; a.tauray = tauray;
+    if (mix) {
+        const MixArgs &m = *mix;
+        const bool lean = !m.taucld && !m.w0c && !m.g0c && !m.test_mode && !m.cosb && !m.ftau_cld && !m.ftau_ray &&
+                          !m.gcos2 && !m.dtau_og && !m.w0_og && !m.cosb_og && !m.f_deltaM;
+        a.fuse = lean ? 2 : 1;
+        a.mix = m;
+    } else if (!taugas || !tauray) {
+        return fail(ctx, "opacity_gas: null output");
+    }
     const int block = 256;
     const long ncol = (long)nwno * ngauss;
     dim3 grid((unsigned)((ncol + block - 1) / block), (unsigned)((nlayer + GAS_LT - 1) / GAS_LT));
-    hipLaunchKernelGGL(k_opacity_gas, grid, dim3(block), 0, ctx->stream, a);
+    if (a.fuse == 2) hipLaunchKernelGGL(k_opacity_gas<2>, grid, dim3(block), 0, ctx->stream, a);
+    else if (a.fuse == 1) hipLaunchKernelGGL(k_opacity_gas<1>, grid, dim3(block), 0, ctx->stream, a);
+    else hipLaunchKernelGGL(k_opacity_gas<0>, grid, dim3(block), 0, ctx->stream, a);
     PZ_HIP(ctx, hipGetLastError());
+    return 0;
+}
+
+int picaso_opacity_gas_ck_dev(picaso_ctx *ctx, int nlayer, int nwno, int ngauss, int mol_mode, int nmol,
+                              const double *const *mol_tables, const int *mol_rows,
+                              const double *mol_wts, const double *mol_fac, int cont_mode, int ncont,
+                              const double *const *cont_tables, const int *cont_rows,
+                              const double *cont_wts, const double *cont_fac, int nray,
+                              const double *const *ray_tables, const double *ray_fac, double *taugas,
+                              double *tauray)
+{
+    return gas_launch(ctx, nlayer, nwno, ngauss, mol_mode, nmol, mol_tables, mol_rows, mol_wts, mol_fac, cont_mode, ncont,
+                      cont_tables, cont_rows, cont_wts, cont_fac, nray, ray_tables, ray_fac, taugas, tauray, nullptr);
+}
+
+int picaso_level_sums_dev(picaso_ctx *ctx, int nlayer, long ncol, const double *dtau, double *tau, const double *dtau_og,
+                          double *tau_og)
+{
+    if (!ctx) return fail(nullptr, "null context");
+    if (nlayer < 1 || ncol < 1) return fail(ctx, "level_sums: bad sizes");
+    if ((tau && !dtau) || (tau_og && !dtau_og)) return fail(ctx, "level_sums: a level plane without its layer plane");
+    if (!tau && !tau_og) return 0;
+    PZ_HIP(ctx, hipSetDevice(ctx->device));
+    const dim3 grid((unsigned)((ncol + 255) / 256), (tau && tau_og) ? 2u : 1u);
+    if (tau)
+        hipLaunchKernelGGL(k_level_sums, grid, dim3(256), 0, ctx->stream, nlayer, ncol, dtau, tau, dtau_og, tau_og);
+    else
+        hipLaunchKernelGGL(k_level_sums, grid, dim3(256), 0, ctx->stream, nlayer, ncol, dtau_og, tau_og, dtau_og, tau_og);
+    PZ_HIP(ctx, hipGetLastError());
+    return 0;
+}
+
+int picaso_gas_compute_opacity_dev(picaso_ctx *ctx, int nlayer, int nwno, int mol_mode, int nmol,
+                                   const double *const *mol_tables, const int *mol_rows, const double *mol_wts,
+                                   const double *mol_fac, int cont_mode, int ncont, const double *const *cont_tables,
+                                   const int *cont_rows, const double *cont_wts, const double *cont_fac, int nray,
+                                   const double *const *ray_tables, const double *ray_fac, const double *taucld,
+                                   const double *w0_cld, const double *g0_cld, const double *raman_factor,
+                                   int raman_rows, double raman_const, int test_mode, int delta_eddington, int stream,
+                                   double *dtau, double *tau, double *w0, double *cosb, double *ftau_cld,
+                                   double *ftau_ray, double *gcos2, double *dtau_og, double *tau_og, double *w0_og,
+                                   double *cosb_og, double *w0_no_raman, double *f_deltaM, int level_sums)
+{
+    if (!ctx) return fail(nullptr, "null context");
+    if (nlayer < 1 || nwno < 1) return fail(ctx, "gas_compute_opacity: bad sizes");
+    if (test_mode < 0 || test_mode > 2) return fail(ctx, "gas_compute_opacity: test_mode must be 0, 1 or 2");
+    if (stream != 2 && stream != 4) return fail(ctx, "gas_compute_opacity: stream must be 2 or 4");
+    if (raman_factor && raman_rows != 0 && raman_rows != nlayer)
+        return fail(ctx, "gas_compute_opacity: raman_rows must be nlayer (planes) or 0 (one row for all layers)");
+    if ((tau && !dtau) || (tau_og && !dtau_og))
+        return fail(ctx, "gas_compute_opacity: tau / tau_og are the running sums of the dtau / dtau_og planes: ask for those too");
+    MixArgs m{};
+    m.nlayer = nlayer; m.nwno = nwno; m.ncolper = 1; m.nfac = 0; m.test_mode = test_mode;
+    m.delta_eddington = delta_eddington; m.stream = stream;
+    m.taucld = taucld; m.w0c = w0_cld; m.g0c = g0_cld; m.raman = raman_factor; m.raman_const = raman_const;
+    m.raman_row = raman_factor && raman_rows == 0;
+    m.dtau = dtau; m.tau = nullptr; m.w0 = w0; m.cosb = cosb; m.ftau_cld = ftau_cld; m.ftau_ray = ftau_ray;
+    m.gcos2 = gcos2; m.dtau_og = dtau_og; m.tau_og = nullptr; m.w0_og = w0_og; m.cosb_og = cosb_og;
+    m.w0_no_raman = w0_no_raman; m.f_deltaM = f_deltaM;
+    PZ_TRY(gas_launch(ctx, nlayer, nwno, 1, mol_mode, nmol, mol_tables, mol_rows, mol_wts, mol_fac, cont_mode, ncont,
+                      cont_tables, cont_rows, cont_wts, cont_fac, nray, ray_tables, ray_fac, nullptr, nullptr, &m));
+    if (level_sums) PZ_TRY(picaso_level_sums_dev(ctx, nlayer, nwno, dtau, tau, dtau_og, tau_og));
     return 0;
 }
 

@@ -12,7 +12,7 @@ import ctypes
 import numpy as np
 
 from . import _lib
-from .device import DeviceArray
+from .device import DeviceArray, PinnedArray
 
 _dp = ctypes.POINTER(ctypes.c_double)
 _dpp = ctypes.POINTER(_dp)
@@ -33,7 +33,8 @@ class Block(ctypes.Structure):
                 ("taugas", _dp), ("tauray", _dp), ("planes", _dp * 13), ("refl_planes", _dp * 11),
                 ("th_dtau", _dp), ("th_w0", _dp), ("th_cosb", _dp),
                 ("xint", _dp), ("albedo", _dp), ("flux", _dp), ("disk", _dp),
-                ("albedo_host", _dp), ("thermal_host", _dp)]
+                ("albedo_host", _dp), ("thermal_host", _dp), ("trapz_d", _dp), ("trapz_dr", _dp), ("stellar", _dp),
+                ("albedo_pin", _dp), ("thermal_pin", _dp), ("albedo_mark", ctypes.c_void_p), ("thermal_mark", ctypes.c_void_p)]
 
 
 class Job(ctypes.Structure):
@@ -110,9 +111,10 @@ class BlockTable:
             if do_reflected:
                 for i, name in enumerate(REFL_NAMES):
                     k.refl_planes[i] = _dev(pl[name])
-                x, a = DeviceArray((ng, nt, nw), ctx), DeviceArray((nw,), ctx)
-                self.keep += [x, a]
-                k.xint, k.albedo = _dev(x), _dev(a)
+                x, a = DeviceArray((ng, nt, nw), ctx), DeviceArray((nw + 1,), ctx)     # [nw]: the Bond-albedo integral
+                pin = PinnedArray((nw + 1,), ctx)           # the result copy is enqueued with the launches
+                self.keep += [x, a, pin]
+                k.xint, k.albedo, k.albedo_pin = _dev(x), _dev(a), ctypes.cast(ctypes.c_void_p(pin.addr), _dp)
             if do_thermal:
                 k.th_dtau, k.th_w0, k.th_cosb = _dev(pl["dtau_og"]), _dev(pl["w0_no_raman"]), _dev(pl["cosb_og"])
             if host_cloud:
@@ -127,7 +129,8 @@ class BlockTable:
         ws = self.thermal_ws.get(key)
         if ws is None:
             nw = self.blocks[b].nwno
-            ws = self.thermal_ws[key] = (DeviceArray((ng, nt, nw), tctx), DeviceArray((nw,), tctx))
+            ws = self.thermal_ws[key] = (DeviceArray((ng, nt, nw), tctx), DeviceArray((nw + 1,), tctx),    # [nw]: T_eff integral
+                                         PinnedArray((nw + 1,), tctx))
         return ws
 
 
@@ -170,3 +173,8 @@ def enqueue(table, job):
 def collect(table, which):
     _lib.check(_lib.load().picaso_toon_spectrum_collect(ctypes.c_int(table.n), table.blocks, ctypes.c_int(which)),
                table.subs[0][2].ctx)
+
+
+def abandon(table):
+    """Drop result copies nobody will collect (an exception between ``enqueue`` and ``collect``)."""
+    _lib.load().picaso_toon_spectrum_abandon(ctypes.c_int(table.n), table.blocks)

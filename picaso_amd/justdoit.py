@@ -13,6 +13,7 @@ Out of scope here: chemistry, virga clouds, stellar grids 
 relative flux vector), xarray I/O, climate, retrievals, phase curves, 3-D regridding.
 """
 import copy
+import ctypes
 
 import os
 
@@ -1084,6 +1085,17 @@ def _resident_vector(opa, name, value, nwno):
     return d
 
 
+def _ones(opa, nwno):
+    """``np.zeros(nwno) + 1.0`` (the reference's F0PI without a star, justdoit.py:174-175), kept on the opacity object
+    and read-only: nothing on the path writes to F0PI."""
+    hit = opa.__dict__.get("_ones")
+    if hit is None or hit.shape != (nwno,):
+        hit = np.zeros(nwno) + 1.0
+        hit.flags.writeable = False
+        opa.__dict__["_ones"] = hit
+    return hit
+
+
 def _constant_planes(opa, nlayer, nwno):
     """Resident ``(nlayer, nwno)`` planes of 0, 1 and 0.5, kept on the opacity object: what ``compute_opacity``
     writes into cosb / cosb_og / ftau_cld, ftau_ray and gcos2 for an atmosphere without cloud."""
@@ -1319,7 +1331,8 @@ def picaso(bundle, opacityclass, dimension="1d", calculation="reflected", full_o
         collect = []
         if "reflected" in calculation:
             xint = DeviceArray((ng, nt, nwno), ctx)
-            alb = DeviceArray((nwno,), ctx)
+            alb_x = DeviceArray((nwno + 1,), ctx)         # [nwno]: the Bond-albedo integral (finish.prefetch)
+            alb = alb_x.head(nwno)
             lvl = None
             if dimension == "3d" and _batch is not None:          # phase_curve(): one launch for a chunk of phases
                 tt3 = (toon["single_phase"], toon["multi_phase"], frac_a, frac_b, frac_c, constant_back, constant_forward)
@@ -1379,7 +1392,7 @@ def picaso(bundle, opacityclass, dimension="1d", calculation="reflected", full_o
             dev_results["albedo"] = alb
 
             def collect_reflected():          # read back after every leg has been enqueued (see `collect`)
-                albedo = _fetch(prefetched, "albedo", alb)
+                albedo = _fetch(prefetched, "albedo", alb, returns, "bond_integral")
                 returns["albedo"] = albedo
                 if full_output:
                     atm.xint_at_top = xint.to_host()
@@ -1395,7 +1408,8 @@ def picaso(bundle, opacityclass, dimension="1d", calculation="reflected", full_o
         if "thermal" in calculation:
             d_wno = _resident_vector(opa, "wno", wno, nwno)
             flux = DeviceArray((ng, nt, nwno), tctx)
-            disk = DeviceArray((nwno,), tctx)
+            disk_x = DeviceArray((nwno + 1,), tctx)       # [nwno]: the effective-temperature integral
+            disk = disk_x.head(nwno)
             if dimension == "3d" and _batch is not None:
                 _batch.add_thermal_3d((nlevel, nwno, ng, nt, int(atm.hard_surface), d_wno.addr, th3[2] is not None,
                                        tuple(gweight), tuple(tweight)),
@@ -1459,7 +1473,7 @@ def picaso(bundle, opacityclass, dimension="1d", calculation="reflected", full_o
             dev_results["thermal"] = disk
 
             def collect_thermal():
-                returns["thermal"] = _fetch(prefetched, "thermal", disk)
+                returns["thermal"] = _fetch(prefetched, "thermal", disk, returns, "teff_integral")
                 if full_output:
                     atm.flux_at_top = flux.to_host()
                 if dimension != "3d" and not is_sh and tlvl_disk is not None:
@@ -1534,10 +1548,25 @@ def picaso(bundle, opacityclass, dimension="1d", calculation="reflected", full_o
         # spectrum_batch(): the copies of the per-wavelength results go on the stream NOW, behind this spectrum's solver
         # launches, into pinned blocks; finish() then waits for these copies only, while the stream already holds the
         # next spectra's launches
-        for key in ("albedo", "thermal"):
-            if key in dev_results and key not in prefetched:
-                d = dev_results[key]
-                prefetched[key] = d.to_host_async(device.PinnedArray(d.shape, d.ctx))
+        # ... preceded by the spectrum-wide integrals of the two results (numpy's bits: csrc/integrals.hip), each
+        # stored behind its vector so that one copy brings both
+        whole = not _raw and nwno > 1 and _shared is None and not os.environ.get("PICASO_AMD_HOST_INTEGRALS")
+        if "albedo" in dev_results and "albedo" not in prefetched:
+            src, denom = alb, None
+            if whole:
+                d_w, _ = _trapz_resident(opa, wno)
+                d_st = d_f0 if stellar is F0PI else _resident_vector(opa, "stellar", stellar, nwno)
+                denom = _bond_denominator(opa, wno, stellar, d_st)
+                resident.trapz(ctx, nwno, d_w, alb, alb_x.addr + 8 * nwno, mult=d_st)
+                src = alb_x
+            prefetched["albedo"] = (src.to_host_async(device.PinnedArray(src.shape, src.ctx)), denom)
+        if "thermal" in dev_results and "thermal" not in prefetched:
+            src = disk
+            if whole:
+                _, d_wr = _trapz_resident(opa, wno)
+                resident.trapz(tctx, nwno, d_wr, disk, disk_x.addr + 8 * nwno, reverse=True)
+                src = disk_x
+            prefetched["thermal"] = (src.to_host_async(device.PinnedArray(src.shape, src.ctx)), None)
     finish.dev, finish.ctx, finish.tctx, finish.prefetch = dev_results, ctx, tctx, prefetch
     return finish if defer else finish()
 
@@ -1545,13 +1574,18 @@ def picaso(bundle, opacityclass, dimension="1d", calculation="reflected", full_o
 # ------------------------------------------------------------------------------------------------
 # one C call per spectrum (csrc/driver.hip): the launch sequence of the 1-D Toon path for every wavelength block
 # ------------------------------------------------------------------------------------------------
-def _fetch(prefetched, key, dev):
+def _fetch(prefetched, key, dev, returns=None, integral=None):
     """Host copy of the resident result ``dev``: the pinned block ``finish.prefetch`` put on the stream when there is
-    one (wait for that copy only), a synchronous copy otherwise."""
-    p = prefetched.pop(key, None)
-    if p is None:
+    one (wait for that copy only), a synchronous copy otherwise.  A prefetched block one longer than the result carries
+    the result's spectrum-wide integral in its last element: stored as ``returns[integral]``."""
+    hit = prefetched.pop(key, None)
+    if hit is None:
         return dev.to_host()
-    out = p.wait().copy()
+    p, denom = hit
+    a = p.wait()
+    out = a[:dev.size].copy()
+    if a.size > dev.size:
+        returns[integral] = a[dev.size] if denom is None else (a[dev.size], denom)
     p.free()
     return out
 
@@ -1624,18 +1658,22 @@ def _picaso_driver(bundle, opa, subs, calculation):
         table = cache[key] = drv.BlockTable(subs, nlayer, ng, nt, plan["molecules"], plan["cia_pairs"], factors[2], linear,
                                             want, lean, not cloud_free, do_r, do_t, _constant_planes)
     nostar = inp["star"]["database"] == "nostar"
-    F0PI = (np.zeros(nwno) + 1.0) if nostar else inp["star"]["relative_flux"]
+    F0PI = _ones(opa, nwno) if nostar else inp["star"]["relative_flux"]
     stellar = getattr(opa, "unshifted_stellar_spec", None)
     if stellar is None:
         stellar = F0PI
     sr = atm.surf_reflect
     sr_full = np.ndim(sr) > 0 and np.size(sr) == nwno and nwno > 1
     overlap = do_r and do_t and os.environ.get("PICASO_AMD_OVERLAP_LEGS", "1") != "0"
+    # one block over the grid: the spectrum-wide integrals are formed on the device behind each result vector and
+    # arrive with it (host arrays one element longer; the dictionary gets views of the first nwno)
+    integrals = len(subs) == 1 and nwno > 1 and not os.environ.get("PICASO_AMD_HOST_INTEGRALS")
     returns, hold = {}, []
+    full = {}
     if do_r:
-        returns["albedo"] = np.empty(nwno)
+        full["albedo"] = np.empty(nwno + 1 if integrals else nwno)
     if do_t:
-        returns["thermal"] = np.empty(nwno)
+        full["thermal"] = np.empty(nwno + 1 if integrals else nwno)
     if not cloud_free:
         def plane(x):
             a = np.asarray(x, dtype=float)
@@ -1662,27 +1700,56 @@ def _picaso_driver(bundle, opa, subs, calculation):
             if overlap:
                 tctx = _lib.aux_context(_lib.device_of(sub.ctx))
             k.tctx = tctx.value if hasattr(tctx, "value") else tctx
-            fl, dk = table.thermal_workspace(b, tctx, ng, nt)
+            fl, dk, pin = table.thermal_workspace(b, tctx, ng, nt)
             k.flux, k.disk = drv._dev(fl), drv._dev(dk)
+            k.thermal_pin = ctypes.cast(ctypes.c_void_p(pin.addr), drv._dp)
             k.wno = drv._dev(_resident_vector(sub, "wno", sub.wno, nw))
-            k.thermal_host = drv._host(returns["thermal"])
+            k.thermal_host = drv._host(full["thermal"])
         if do_r:
-            k.albedo_host = drv._host(returns["albedo"])
+            k.albedo_host = drv._host(full["albedo"])
+        k.trapz_d = k.trapz_dr = k.stellar = None
+        if integrals:
+            d_w, d_wr = _trapz_resident(sub, wno)
+            if do_r:
+                d_st = f0 if stellar is F0PI else _resident_vector(sub, "stellar", stellar, nw)
+                k.trapz_d, k.stellar = drv._dev(d_w), drv._dev(d_st)
+                denom = _bond_denominator(sub, wno, stellar, d_st)
+            if do_t:
+                k.trapz_dr = drv._dev(d_wr)
     job, keep = drv.make_job(nlayer, plan, factors, linear, 0 if raman == 1 else nlayer, common["stream"],
                              common["delta_eddington"], do_r, do_t, ng, nt, geom["ubar0"], geom["ubar1"], geom["cos_theta"],
                              geom["gweight"], geom["tweight"], toon["single_phase"], toon["multi_phase"],
                              toon["toon_coefficients"], frac_a, frac_b, frac_c, common["TTHG_params"]["constant_back"],
                              common["TTHG_params"]["constant_forward"], 0.0, atm.level["temperature"], atm.level["pressure"],
                              atm.hard_surface)
-    drv.enqueue(table, job)
+    try:
+        drv.enqueue(table, job)
+        return _driver_finish(table, do_r, do_t, full, nwno, integrals, denom if (integrals and do_r) else None, wno, stellar,
+                              inp, atm, opa)
+    except BaseException:
+        drv.abandon(table)
+        raise
+    finally:
+        del keep, hold
+
+
+def _driver_finish(table, do_r, do_t, full, nwno, integrals, denom, wno, stellar, inp, atm, opa):
+    """Second half of ``_picaso_driver``: the results as they arrive (their copies were enqueued with the launches)."""
+    from . import driver as drv
+    returns = {}
     out = {"wavenumber": wno}
     if do_r:
         drv.collect(table, 1)
+        returns["albedo"] = full["albedo"][:nwno]
+        if integrals:
+            returns["bond_integral"] = (full["albedo"][nwno], denom)
         _post_reflected(out, returns, wno, stellar, inp["star"]["semi_major"], atm.planet.radius, opa)
     if do_t:
         drv.collect(table, 2)
+        returns["thermal"] = full["thermal"][:nwno]
+        if integrals:
+            returns["teff_integral"] = full["thermal"][nwno]
         _post_thermal(out, returns, wno, stellar, inp["star"]["radius"], atm.planet.radius, opa)
-    del keep, hold
     return _post_final(out, returns)
 
 
@@ -2055,11 +2122,36 @@ def _trapz_scratch(opa, n):
     return hit
 
 
+def _trapz_resident(opa, wno):
+    """``_trapz_weights`` in HBM (``picaso_trapz_dev``), uploaded once per grid."""
+    d, dr = _trapz_weights(opa, wno)
+    hit = opa.__dict__.get("_trapz_dev")
+    if hit is None or hit[0] is not d:
+        hit = (d, DeviceArray.from_host(d, opa.ctx), DeviceArray.from_host(dr, opa.ctx))
+        opa.__dict__["_trapz_dev"] = hit
+    return hit[1], hit[2]
+
+
+def _bond_denominator(opa, wno, stellar, d_stellar):
+    """``np.trapz(x=1/wno, y=stellar)``, kept while the resident copy of the stellar spectrum is the same object
+    (``_resident_vector`` replaces it when the content changes)."""
+    hit = opa.__dict__.get("_bond_denom")
+    if hit is None or hit[0] is not d_stellar or hit[1] is not wno:
+        d, _ = _trapz_weights(opa, wno)
+        hit = (d_stellar, wno, _trapz(d, np.zeros(len(wno)) + np.asarray(stellar, dtype=float)))
+        opa.__dict__["_bond_denom"] = hit
+    return hit[2]
+
+
 def _post_reflected(out, raw, wno, stellar, sa, planet_radius, opa=None):
-    """Bond albedo (Batalha+2019 eq. 18) and the reflected planet-to-star flux ratio (justdoit.py:552-566)."""
+    """Bond albedo (Batalha+2019 eq. 18) and the reflected planet-to-star flux ratio (justdoit.py:552-566).
+    ``raw["bond_integral"]`` = (numerator integrated on the device, denominator) when the caller had them."""
     albedo = raw["albedo"]
     out["albedo"] = albedo
-    if opa is not None:
+    if raw.get("bond_integral") is not None:
+        num, denom = raw["bond_integral"]
+        out["bond_albedo"] = num / denom
+    elif opa is not None:
         d, _ = _trapz_weights(opa, wno)
         b1, b2 = _trapz_scratch(opa, len(wno))
         denom = _trapz(d, stellar, b1)
@@ -2078,7 +2170,9 @@ def _post_thermal(out, raw, wno, stellar, radius_star, planet_radius, opa=None):
     thermal = raw["thermal"]
     out["thermal"] = thermal
     out["thermal_unit"] = "erg/s/(cm^2)/(cm)"
-    if opa is not None:
+    if raw.get("teff_integral") is not None:
+        out["effective_temperature"] = (raw["teff_integral"] / 5.67e-5) ** 0.25
+    elif opa is not None:
         _, dr = _trapz_weights(opa, wno)
         b1, _ = _trapz_scratch(opa, len(wno))
         out["effective_temperature"] = (_trapz(dr, thermal[::-1], b1) / 5.67e-5) ** 0.25

@@ -587,6 +587,8 @@ def shard_opacity(opa, lo, hi, ctx):
     s.__dict__.pop("_trapz", None)
     s.__dict__.pop("_trapz_buf", None)
     s.__dict__.pop("_driver_tables", None)
+    for k in ("_trapz_dev", "_bond_denom", "_ones"):
+        s.__dict__.pop(k, None)
     s.molecular_opa, s.continuum_opa = ({} if isinstance(opa.molecular_opa, dict) else None), {}
 
     def cols(d, per=1):
@@ -692,7 +694,7 @@ def _ptr_array(devs):
 
 
 def _gas_call(opa, nlayer, mol_tabs, mol_rows, mol_wts, mol_fac, cont_tabs, cont_rows, cont_fac,
-              ray_tabs, ray_fac, taugas, tauray, mol_mode=None, cont_wts=None, ngauss=1):
+              ray_tabs, ray_fac, taugas, tauray, mol_mode=None, cont_wts=None, ngauss=1, mix=None):
     """``picaso_opacity_gas_ck_dev``: gather + interpolate table rows into TAUGAS / TAURAY.
     ``mol_mode`` 0 nearest, 1 log10-bilinear (monochromatic 'linear'), 2 ln-bilinear (premixed CK);
     ``cont_wts`` given -> log-linear continuum between two rows per layer (CK)."""
@@ -709,12 +711,16 @@ def _gas_call(opa, nlayer, mol_tabs, mol_rows, mol_wts, mol_fac, cont_tabs, cont
     cw = f64(cont_wts) if cont_wts is not None else None
     cf = f64(cont_fac) if cont_fac is not None else None
     rf = f64(ray_fac) if ray_fac is not None else None
+    gas_args = (_ci(mol_mode),
+                _ci(len(mol_tabs)), _ptr_array(mol_tabs), mr.ctypes.data_as(ip) if mr is not None else None,
+                ptr(mw), ptr(mf), _ci(1 if cw is not None else 0), _ci(len(cont_tabs)), _ptr_array(cont_tabs),
+                cr.ctypes.data_as(ip) if cr is not None else None, ptr(cw), ptr(cf), _ci(len(ray_tabs)),
+                _ptr_array(ray_tabs), ptr(rf))
+    if mix is not None:       # gas stage + compute_opacity in one launch (ngauss = 1): `mix` = the mixing's arguments
+        check(load().picaso_gas_compute_opacity_dev(opa.ctx, _ci(nlayer), _ci(opa.nwno), *gas_args, *mix), opa.ctx)
+        return
     check(load().picaso_opacity_gas_ck_dev(
-        opa.ctx, _ci(nlayer), _ci(opa.nwno), _ci(ngauss), _ci(mol_mode),
-        _ci(len(mol_tabs)), _ptr_array(mol_tabs), mr.ctypes.data_as(ip) if mr is not None else None,
-        ptr(mw), ptr(mf), _ci(1 if cw is not None else 0), _ci(len(cont_tabs)), _ptr_array(cont_tabs),
-        cr.ctypes.data_as(ip) if cr is not None else None, ptr(cw), ptr(cf), _ci(len(ray_tabs)),
-        _ptr_array(ray_tabs), ptr(rf), ptr(taugas.addr), ptr(tauray.addr)), opa.ctx)
+        opa.ctx, _ci(nlayer), _ci(opa.nwno), _ci(ngauss), *gas_args, ptr(taugas.addr), ptr(tauray.addr)), opa.ctx)
 
 
 def _layer_factors(atm, opacityclass):
@@ -772,9 +778,11 @@ def _layer_factors(atm, opacityclass):
     return table(mol_fac), table(cont_fac), ray_names, table(ray_fac)
 
 
-def gas_stage(atm, opa, taugas, tauray):
+def gas_stage(atm, opa, taugas, tauray, mix=None):
     """TAUGAS / TAURAY of one atmosphere into the given device planes (``k_opacity_gas``): table rows
-    and weights from ``opa.get_opacities(atm)``, per-layer coefficients of reference optics.py:144-277."""
+    and weights from ``opa.get_opacities(atm)``, per-layer coefficients of reference optics.py:144-277.
+    ``mix``: the argument tuple of the mixing (``compute_opacity_resident``) -- both stages then run as ONE launch
+    and TAUGAS / TAURAY are not written."""
     pl = opa._plan
     nlayer, ngauss = atm.c.nlayer, opa.ngauss
     # per-layer coefficients: a plan shared by the wavelength blocks of one spectrum (picaso(devices=N)) computes them once
@@ -798,7 +806,7 @@ def gas_stage(atm, opa, taugas, tauray):
               pl["wts"] if mol_tabs else None, mol_fac if mol_tabs else None, cont_tabs, cont_rows,
               cont_fac if cont_tabs else None, [opa._ray[m] for m in ray_names],
               ray_fac if ray_names else None, taugas, tauray, mol_mode=mol_mode, cont_wts=cont_wts,
-              ngauss=ngauss)
+              ngauss=ngauss, mix=mix)
 
 
 def types_namespace_layer(atm_f, tlayer):
@@ -1036,8 +1044,14 @@ def compute_opacity_resident(atmosphere, opacityclass, ngauss=1, stream=2, delta
     if opa._plan is None or opa._plan["nlayer"] != nlayer:
         raise Exception("call opacityclass.get_opacities(atmosphere) first")
     gshape = (nwno,) if ngauss == 1 else (nwno, ngauss)
-    taugas, tauray = DeviceArray((nlayer,) + gshape, ctx), DeviceArray((nlayer, nwno), ctx)
-    gas_stage(atm, opa, taugas, tauray)
+    # Monochromatic tables: gas stage and mixing as ONE launch (picaso_gas_compute_opacity_dev; TAUGAS / TAURAY stay in
+    # registers) unless the caller wants those two planes back (full_output) or a level plane without its layer plane.
+    # PICASO_AMD_UNFUSED_OPACITY=1: the two launches (A/B, tests) -- same bits either way.
+    fused = (ngauss == 1 and not full_output and not os.environ.get("PICASO_AMD_UNFUSED_OPACITY")
+             and (want is None or (("tau" not in want or "dtau" in want) and ("tau_og" not in want or "dtau_og" in want))))
+    if not fused:
+        taugas, tauray = DeviceArray((nlayer,) + gshape, ctx), DeviceArray((nlayer, nwno), ctx)
+        gas_stage(atm, opa, taugas, tauray)
     (raman_plane, raman_rows), raman_const = raman_device(atm, opa, raman), 0.99999
     cld = atm.layer["cloud"]
 
@@ -1075,12 +1089,15 @@ def compute_opacity_resident(atmosphere, opacityclass, ngauss=1, stream=2, delta
     for k in OUT_NAMES:
         rows = nlayer + 1 if k in ("tau", "tau_og") else nlayer
         out[k] = DeviceArray((rows,) + gshape, ctx) if (want is None or k in want) else None
-    check(load().picaso_compute_opacity_ck_dev(
-        ctx, _ci(nlayer), _ci(nwno), _ci(ngauss), ptr(taugas.addr), ptr(tauray.addr),
-        *[ptr(x.addr) if x is not None else None for x in (d_cld, d_w0, d_g0)],
-        ptr(raman_plane.addr) if raman_plane else None, _ci(raman_rows),
-        _cd(raman_const), _ci(tm), _ci(1 if delta_eddington else 0), _ci(stream),
-        *[ptr(out[k].addr) if out[k] is not None else None for k in OUT_NAMES]), ctx)
+    mix_args = (*[ptr(x.addr) if x is not None else None for x in (d_cld, d_w0, d_g0)],
+                ptr(raman_plane.addr) if raman_plane else None, _ci(raman_rows),
+                _cd(raman_const), _ci(tm), _ci(1 if delta_eddington else 0), _ci(stream),
+                *[ptr(out[k].addr) if out[k] is not None else None for k in OUT_NAMES])
+    if fused:
+        gas_stage(atm, opa, None, None, mix=mix_args + (_ci(1),))
+    else:
+        check(load().picaso_compute_opacity_ck_dev(ctx, _ci(nlayer), _ci(nwno), _ci(ngauss), ptr(taugas.addr),
+                                                   ptr(tauray.addr), *mix_args), ctx)
     out = {k: v for k, v in out.items() if v is not None}
     if full_output:
         def over_gauss(x):      # (nlayer, nwno) -> (nlayer, nwno, ngauss) as the reference stores it; a view for ngauss = 1

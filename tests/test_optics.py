@@ -169,6 +169,15 @@ def test_gpu_compute_opacity(gold, qm, pollack_table):
         for nm, arr in zip(NAMES, out):
             assert arr.shape[2] == 1
             assert _close(arr[:, :, 0], gold["%s/%s/%s" % (qm, key, nm)], 1e-10), (qm, key, nm)
+        # the default is ONE launch for gas stage + mixing (picaso_gas_compute_opacity_dev); the two launches with
+        # TAUGAS / TAURAY through HBM give the same bits in all 13 planes
+        os.environ["PICASO_AMD_UNFUSED_OPACITY"] = "1"
+        try:
+            two = px.compute_opacity(atm, opa, ngauss=1, stream=s, delta_eddington=de, test_mode=tm, raman=r)
+        finally:
+            del os.environ["PICASO_AMD_UNFUSED_OPACITY"]
+        for nm, a1, a2 in zip(NAMES, out, two):
+            assert np.array_equal(a1, a2), (qm, key, nm)
 
 
 @pytest.mark.gpu
