@@ -114,12 +114,14 @@ def new_context(device=None):
 _aux = {}
 
 
-def aux_context(device=None):
+def aux_context(device=None, index=0):
     """The process's second context on the device (its own stream): the thermal leg of a spectrum runs
-    there next to the reflected leg.  Created once per (process, device) and kept, like ``context()``."""
+    there next to the reflected leg.  Created once per (process, device) and kept, like ``context()``.
+    ``index``: a further one per wavelength block when one device carries several blocks of a spectrum
+    (``devices=[0, 0, ...]``) -- with one stream for all of them their thermal legs would run one after the other."""
     if device is None:
         device = int(os.environ.get("PICASO_AMD_DEVICE", "0"))
-    key = (os.getpid(), device)
+    key = (os.getpid(), device, int(index))
     if key not in _aux:
         _aux[key] = new_context(device)
     return _aux[key]

@@ -1681,6 +1681,7 @@ def _picaso_driver(bundle, opa, subs, calculation):
                 np.ascontiguousarray(np.broadcast_to(a, (nlayer, nwno)))
         hcld = [plane(cld[k]) for k in ("opd", "w0", "g0")]
         hold.append(hcld)
+    seen_dev = {}
     for b, (lo, hi, sub) in enumerate(subs):
         k = table.blocks[b]
         nw = hi - lo
@@ -1698,7 +1699,9 @@ def _picaso_driver(bundle, opa, subs, calculation):
         tctx = sub.ctx
         if do_t:
             if overlap:
-                tctx = _lib.aux_context(_lib.device_of(sub.ctx))
+                dev = _lib.device_of(sub.ctx)
+                tctx = _lib.aux_context(dev, seen_dev.get(dev, 0))       # blocks that share a device: a stream each
+                seen_dev[dev] = seen_dev.get(dev, 0) + 1
             k.tctx = tctx.value if hasattr(tctx, "value") else tctx
             fl, dk, pin = table.thermal_workspace(b, tctx, ng, nt)
             k.flux, k.disk = drv._dev(fl), drv._dev(dk)
@@ -2154,7 +2157,17 @@ def _post_reflected(out, raw, wno, stellar, sa, planet_radius, opa=None):
     elif opa is not None:
         d, _ = _trapz_weights(opa, wno)
         b1, b2 = _trapz_scratch(opa, len(wno))
-        denom = _trapz(d, stellar, b1)
+        # the denominator does not change while the stellar spectrum does not: kept with a copy it is compared against
+        # (one pass instead of the integral's four; a read-only array -- the no-star ones -- is known by identity)
+        hit = opa.__dict__.get("_bond_denom_host")
+        if (hit is not None and hit[0] is stellar and hit[1] is wno and isinstance(stellar, np.ndarray)
+                and (not stellar.flags.writeable or np.array_equal(stellar, hit[2]))):
+            denom = hit[3]
+        else:
+            denom = _trapz(d, stellar, b1)
+            if isinstance(stellar, np.ndarray):
+                opa.__dict__["_bond_denom_host"] = (stellar, wno, None if not stellar.flags.writeable else stellar.copy(),
+                                                    denom)
         np.multiply(albedo, stellar, out=b2)
         out["bond_albedo"] = _trapz(d, b2, b1) / denom
     else:

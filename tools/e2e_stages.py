@@ -35,6 +35,9 @@ wrap(jdi, "_post_thermal")
 wrap(jdi, "_resident_vector")
 wrap(jdi, "_picaso_driver")
 wrap(jdi, "picaso")
+wrap(jdi, "_opacity_shards")
+wrap(jdi, "_driver_finish")
+devs = [int(x) for x in os.environ["DEVICES"].split(",")] if os.environ.get("DEVICES") else None
 
 # the scene of tools/e2e_1d_time.py
 from picaso_amd import _lib
@@ -64,12 +67,12 @@ if os.environ.get("STAR"):
     case.star(relative_flux=1.0 + 0.2 * np.cos(wno / 900.0), radius=6.9e10, semi_major=7.5e12)
     case.gravity(radius=7.1e9, mass=1.9e30)
 for _ in range(30):
-    case.spectrum(opa, calculation="reflected+thermal")
+    case.spectrum(opa, calculation="reflected+thermal", devices=devs)
 acc.clear()
 tot = []
 for _ in range(200):
     t0 = time.perf_counter()
-    case.spectrum(opa, calculation="reflected+thermal")
+    case.spectrum(opa, calculation="reflected+thermal", devices=devs)
     tot.append(time.perf_counter() - t0)
 n = len(tot)
 print("spectrum() median %.3f ms, min %.3f" % (1e3 * np.median(tot), 1e3 * min(tot)))
