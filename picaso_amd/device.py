@@ -60,15 +60,17 @@ class DeviceArray:
                                                  ctypes.c_size_t(self.nbytes)), self.ctx)
         return out
 
-    def to_host_async(self, pinned):
+    def to_host_async(self, pinned, ctx=None):
         """Enqueue the copy into ``pinned`` (a ``PinnedArray`` of this size) behind the kernels already on the stream
-        and return at once; ``pinned.wait()`` blocks until the copy -- not the stream -- is done."""
+        (of ``ctx``: another context of the same device, ordered behind this buffer's producer by the caller; default the
+        buffer's own) and return at once; ``pinned.wait()`` blocks until the copy -- not the stream -- is done."""
         if pinned.nbytes != self.nbytes:
             raise ValueError("pinned block of %d bytes for a result of %d" % (pinned.nbytes, self.nbytes))
+        ctx = ctx if ctx is not None else self.ctx
         mark = ctypes.c_void_p()
-        _lib.check(_lib.load().picaso_memcpy_d2h_async(self.ctx, ctypes.c_void_p(pinned.addr), ctypes.c_void_p(self.addr),
-                                                       ctypes.c_size_t(self.nbytes), ctypes.byref(mark)), self.ctx)
-        pinned._mark, pinned._mark_ctx = mark, self.ctx
+        _lib.check(_lib.load().picaso_memcpy_d2h_async(ctx, ctypes.c_void_p(pinned.addr), ctypes.c_void_p(self.addr),
+                                                       ctypes.c_size_t(self.nbytes), ctypes.byref(mark)), ctx)
+        pinned._mark, pinned._mark_ctx = mark, ctx
         return pinned
 
     @classmethod

@@ -1317,9 +1317,9 @@ def picaso(bundle, opacityclass, dimension="1d", calculation="reflected", full_o
     # leaves SIMDs idle through its tail) instead of behind it
     tctx = ctx
     if (dimension == "1d" and not is_sh and "reflected" in calculation and "thermal" in calculation
-            and _batch is None and os.environ.get("PICASO_AMD_OVERLAP_LEGS", "1") != "0"):
+            and os.environ.get("PICASO_AMD_OVERLAP_LEGS", "1") != "0"):
         tctx = _lib.aux_context(_lib.device_of(ctx))     # one per process and device, shared by every caller
-        _lib.ctx_wait(tctx, ctx)
+        _lib.ctx_wait(tctx, ctx)                         # (in a batch: every member's, so the last one covers the launch)
     returns = {"wavenumber": wno}
     dev_results = {}          # per-wavelength results still in HBM (the multi-GPU form gathers them with RCCL)
     prefetched = {}           # result copies already on the stream (finish.prefetch)
@@ -1544,10 +1544,12 @@ def picaso(bundle, opacityclass, dimension="1d", calculation="reflected", full_o
         if full_output:
             out["full_output"] = atm.as_dict() if as_dict else atm
         return out
-    def prefetch():
+    def prefetch(post_ctx=None):
         # spectrum_batch(): the copies of the per-wavelength results go on the stream NOW, behind this spectrum's solver
         # launches, into pinned blocks; finish() then waits for these copies only, while the stream already holds the
-        # next spectra's launches
+        # next spectra's launches.  ``post_ctx``: a context whose stream the caller has ordered behind the solvers
+        # (``ctx_wait``) -- the integrals (four launches that leave the chip empty) and the PCIe copies then run next to
+        # the following spectra's opacity kernels instead of in front of them
         # ... preceded by the spectrum-wide integrals of the two results (numpy's bits: csrc/integrals.hip), each
         # stored behind its vector so that one copy brings both
         whole = not _raw and nwno > 1 and _shared is None and not os.environ.get("PICASO_AMD_HOST_INTEGRALS")
@@ -1557,16 +1559,18 @@ def picaso(bundle, opacityclass, dimension="1d", calculation="reflected", full_o
                 d_w, _ = _trapz_resident(opa, wno)
                 d_st = d_f0 if stellar is F0PI else _resident_vector(opa, "stellar", stellar, nwno)
                 denom = _bond_denominator(opa, wno, stellar, d_st)
-                resident.trapz(ctx, nwno, d_w, alb, alb_x.addr + 8 * nwno, mult=d_st)
+                resident.trapz(post_ctx or ctx, nwno, d_w, alb, alb_x.addr + 8 * nwno, mult=d_st)
                 src = alb_x
-            prefetched["albedo"] = (src.to_host_async(device.PinnedArray(src.shape, src.ctx)), denom)
+            pc = post_ctx or src.ctx
+            prefetched["albedo"] = (src.to_host_async(device.PinnedArray(src.shape, pc), pc), denom)
         if "thermal" in dev_results and "thermal" not in prefetched:
             src = disk
             if whole:
                 _, d_wr = _trapz_resident(opa, wno)
-                resident.trapz(tctx, nwno, d_wr, disk, disk_x.addr + 8 * nwno, reverse=True)
+                resident.trapz(post_ctx or tctx, nwno, d_wr, disk, disk_x.addr + 8 * nwno, reverse=True)
                 src = disk_x
-            prefetched["thermal"] = (src.to_host_async(device.PinnedArray(src.shape, src.ctx)), None)
+            pc = post_ctx or src.ctx
+            prefetched["thermal"] = (src.to_host_async(device.PinnedArray(src.shape, pc), pc), None)
     finish.dev, finish.ctx, finish.tctx, finish.prefetch = dev_results, ctx, tctx, prefetch
     return finish if defer else finish()
 
@@ -1865,8 +1869,17 @@ def spectrum_batch(cases, opacityclass, calculation="reflected", full_output=Fal
             fins.append(picaso(case, opacityclass, dimension="1d", calculation=calculation, full_output=full_output,
                                as_dict=as_dict, defer=True, _batch=batch))
         batch.flush()
+        # integrals and result copies on a stream of their own, behind this chunk's solvers
+        post = {}
         for fin in fins:
-            fin.prefetch()
+            key = getattr(fin.ctx, "value", fin.ctx)
+            if key not in post and not os.environ.get("PICASO_AMD_NO_POST_STREAM"):
+                pc = _lib.aux_context(_lib.device_of(fin.ctx), 1 << 20)
+                _lib.ctx_wait(pc, fin.ctx)
+                if fin.tctx is not fin.ctx:
+                    _lib.ctx_wait(pc, fin.tctx)
+                post[key] = pc
+            fin.prefetch(post.get(key))
         # the host finishes chunk k (waits for its copies, integrals, ratios) only after chunk k + 1 has been set up and
         # enqueued: the GPU solves k + 1 meanwhile, and set-up of k + 1 ran while it solved k
         in_flight.append(fins)
