@@ -471,6 +471,74 @@ def companions(ctx, args, wl, res_single, nwno_total):
     return extra
 
 
+def product_companion(ctx, nwno=100000, nlevel=91, ncalls=30, nbatch=32):
+    """The product call on this box's clock (untimed by the driver, after everything else): `inputs.spectrum(opa,
+    "reflected+thermal")` end to end -- ATMSETUP, table-row search, opacity mixing from resident tables (5 molecules,
+    2 CIA pairs, 2 Rayleigh species), both Toon solves, disk sums, integrals, results on the host -- and the same as a
+    retrieval would run it, `spectrum_batch` over `nbatch` atmospheres (checked key by key against the single calls)."""
+    from picaso_amd import justdoit as jdi
+    from picaso_amd import optics as px
+    t_all = time.perf_counter()
+    wno = np.linspace(2000.0, 33333.0, nwno)
+    temps, press = [100.0, 300.0, 700.0, 1500.0, 3000.0], [1e-6, 1e-4, 1e-2, 1e-1, 1.0, 10.0, 100.0, 500.0]
+    pt = [(i + 1, p, t) for i, (t, p) in enumerate((t, p) for t in temps for p in press)]
+    mols = ["H2O", "CH4", "CO", "NH3", "H2"]
+    molecular = {m: {i: 10.0 ** (-24.0 + 2.0 * np.sin(wno / 2500.0 + k) + 0.4 * np.log10(p) + 0.8 * np.log10(t / 300.0))
+                     for (i, p, t) in pt} for k, m in enumerate(mols)}
+    cia_t = [75.0, 200.0, 500.0, 1000.0, 2000.0, 4000.0]
+    continuum = {pr: {t: 10.0 ** (-7.0 + np.cos(wno / 4000.0 + k) + 0.3 * np.log10(t / 300.0)) for t in cia_t}
+                 for k, pr in enumerate(("H2H2", "H2He"))}
+    ray = {m: 1e-27 * (wno / 1e4) ** 4 for m in ("H2", "He")}
+    opa = px.RetrieveOpacities(wno, pt, molecular, continuum, cia_t, rayleigh_opa=ray, query_method="linear", ctx=ctx)
+    plev = np.logspace(-6, 2, nlevel)
+    prof = {"pressure": plev, "temperature": 150.0 + 1200.0 * ((np.log10(plev) + 6) / 8) ** 2,
+            "H2": np.full(nlevel, 0.84), "He": np.full(nlevel, 0.155), "H2O": np.full(nlevel, 1e-3),
+            "CH4": np.full(nlevel, 5e-4), "CO": np.full(nlevel, 1e-4), "NH3": np.full(nlevel, 1e-5)}
+
+    def make(k):
+        case = jdi.inputs()
+        case.phase_angle(0, num_gangle=5)
+        case.gravity(gravity=2500.0)
+        case.atmosphere(df=dict(prof, temperature=prof["temperature"] * (1.0 + 0.01 * k)))
+        case.approx(raman="none")
+        return case
+    calc = "reflected+thermal"
+    case = make(0)
+    for _ in range(15):
+        r = case.spectrum(opa, calculation=calc)
+    ts = []
+    for _ in range(ncalls):
+        t0 = time.perf_counter()
+        r = case.spectrum(opa, calculation=calc)
+        ts.append(time.perf_counter() - t0)
+    idle = []                          # what one interactive call sees: the GPU has dropped its clocks meanwhile
+    for _ in range(5):
+        time.sleep(0.3)
+        t0 = time.perf_counter()
+        r = case.spectrum(opa, calculation=calc)
+        idle.append(time.perf_counter() - t0)
+    cases = [make(k) for k in range(nbatch)]
+    for _ in range(2):
+        rb = jdi.spectrum_batch(cases, opa, calculation=calc)
+    tb = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        rb = jdi.spectrum_batch(cases, opa, calculation=calc)
+        tb.append(time.perf_counter() - t0)
+    rl = [c.spectrum(opa, calculation=calc) for c in cases[:4]]
+    same = all(np.array_equal(a[k], b[k]) for a, b in zip(rb[:4], rl) for k in a if isinstance(a[k], np.ndarray))
+    return {"product": {
+        "workload": "inputs.spectrum(opa, 'reflected+thermal'), %d wavelengths x %d layers, 5 Gauss angles, cloud-free, "
+                    "resident opacity tables (5 molecules, 2 CIA pairs, 2 Rayleigh species): set-up, opacity mixing, "
+                    "both Toon solves, disk sums, integrals, results on the host" % (nwno, nlevel - 1),
+        "spectrum_ms": 1e3 * float(np.median(ts)), "spectrum_ms_min": 1e3 * min(ts),
+        "spectrum_ms_after_300ms_idle": 1e3 * float(np.median(idle)),
+        "spectrum_batch_ms_per_spectrum": 1e3 * min(tb) / nbatch, "batch_of": nbatch,
+        "spectrum_batch_equals_single_calls": bool(same),
+        "finite": bool(np.all(np.isfinite(r["albedo"])) and np.all(np.isfinite(r["thermal"]))),
+        "seconds": time.perf_counter() - t_all}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -494,6 +562,8 @@ def main():
                     help="N = 1, default workload: after the timed region also time the batched launch of the same "
                          "workload (throughput_batched) and the other BASELINE configurations (secondary); 0 = skip")
     ap.add_argument("--batch", type=int, default=4, help="spectra per launch of the throughput_batched companion")
+    ap.add_argument("--product", type=int, default=1,
+                    help="with --secondary: also time inputs.spectrum() and spectrum_batch() end to end (product); 0 = skip")
     ap.add_argument("--spawn", action="store_true",
                     help="start the ranks as subprocesses also for --gpus 1 (the N > 1 code path -- rendezvous, RCCL "
                          "communicator, gather in the timed region, checks -- with one rank, on a 1-GPU box)")
@@ -747,6 +817,12 @@ def main():
             except Exception as exc:
                 out["companions_error"] = "%s: %s" % (type(exc).__name__, exc)
                 print("bench.py: the companion measurements failed: %s" % exc, file=sys.stderr, flush=True)
+            if args.product:
+                try:
+                    out.update(product_companion(ctx))
+                except Exception as exc:
+                    out["product_error"] = "%s: %s" % (type(exc).__name__, exc)
+                    print("bench.py: the product companion failed: %s" % exc, file=sys.stderr, flush=True)
         if valu:
             # second ceiling: the kernel is FP64-VALU bound.  PMC instruction count of this launch shape
             # (profiles/) over the live kernel time, against the fp64 issue rate measured on an MI355X
