@@ -104,16 +104,25 @@ struct GasArgs {
     MixArgs mix;              //    TAUGAS / TAURAY never travel through HBM; mix.tau / mix.tau_og must be NULL (k_level_sums)
 };
 
-// One lane per column, GAS_LT consecutive layers per thread: neighbouring layers mostly bracket the
+// One lane per column, LT consecutive layers per thread: neighbouring layers mostly bracket the
 // same (P,T) table rows, so a row value is fetched once per tile instead of once per layer (the
 // tables are re-read nlayer/npt times otherwise: 1.4 GB of L2/MALL traffic for 5 molecules at
 // 1e5 x 90, against 144 MB written).  Per element the sums run in the reference's order
 // (continuum pairs, then molecules; optics.py:172-255), so the tiling does not change a bit.
-constexpr int GAS_LT = 10;
+// (round 1, TAUGAS / TAURAY out: 10 layers per tile.  The fused forms carry the mixing per element and ran fastest with 5 or
+// 6: 113 us against 125 at 10, 129 at 3, 145 at 18 for 1e5 x 90 -- tools/gas_time.sh.)
+#ifndef PZ_GAS_LT
+#define PZ_GAS_LT 10
+#endif
+#ifndef PZ_GAS_LT_FUSED
+#define PZ_GAS_LT_FUSED 6
+#endif
+template <int FUSE> struct GasTile { static constexpr int LT = FUSE ? PZ_GAS_LT_FUSED : PZ_GAS_LT; };
 
 template <int FUSE>      // 0: TAUGAS / TAURAY out; 1: mixing fused in; 2: the cloud-free form of 1
 __global__ __launch_bounds__(256) void k_opacity_gas(const GasArgs a)
 {
+    constexpr int GAS_LT = GasTile<FUSE>::LT;
     const long col = blockIdx.x * (long)blockDim.x + threadIdx.x;
     const int l0 = blockIdx.y * GAS_LT;
     const int nl = a.nlayer - l0 < GAS_LT ? a.nlayer - l0 : GAS_LT;
@@ -676,7 +685,8 @@ static int gas_launch(picaso_ctx *ctx, int nlayer, int nwno, int ngauss, int mol
     }
     const int block = 256;
     const long ncol = (long)nwno * ngauss;
-    dim3 grid((unsigned)((ncol + block - 1) / block), (unsigned)((nlayer + GAS_LT - 1) / GAS_LT));
+    const int lt = a.fuse ? GasTile<1>::LT : GasTile<0>::LT;
+    dim3 grid((unsigned)((ncol + block - 1) / block), (unsigned)((nlayer + lt - 1) / lt));
     if (a.fuse == 2) hipLaunchKernelGGL(k_opacity_gas<2>, grid, dim3(block), 0, ctx->stream, a);
     else if (a.fuse == 1) hipLaunchKernelGGL(k_opacity_gas<1>, grid, dim3(block), 0, ctx->stream, a);
     else hipLaunchKernelGGL(k_opacity_gas<0>, grid, dim3(block), 0, ctx->stream, a);
