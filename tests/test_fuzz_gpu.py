@@ -248,3 +248,79 @@ def test_fuzz_compute_opacity(oracle):
             got = o.to_host()
             w = np.broadcast_to(w, got.shape)
             assert rel_err(got, w, 1e-300) < 1e-12, (it, k, nlayer, nwno, tm, de, stream)
+
+
+@pytest.mark.gpu
+def test_fuzz_fused_opacity_equals_two_launches():
+    """picaso_gas_compute_opacity_dev (gas stage + mixing in ONE launch, level sums apart) against
+    picaso_opacity_gas_ck_dev -> picaso_compute_opacity_ck_dev on random tables, table rows, weights and coefficients,
+    with and without cloud / Raman planes, every test mode, and random subsets of the thirteen outputs (the
+    cloud-free subset takes the specialised flavour of the kernel): np.array_equal plane by plane."""
+    import ctypes
+    from picaso_amd import _lib
+    from picaso_amd._lib import check, load, ptr
+    from picaso_amd.device import DeviceArray
+    names = ("dtau", "tau", "w0", "cosb", "ftau_cld", "ftau_ray", "gcos2", "dtau_og", "tau_og", "w0_og", "cosb_og",
+             "w0_no_raman", "f_deltaM")
+    ci, cd = ctypes.c_int, ctypes.c_double
+    ip = ctypes.POINTER(ctypes.c_int)
+    dpp = ctypes.POINTER(ctypes.POINTER(ctypes.c_double))
+    ctx = _lib.context()
+    rng = np.random.default_rng(901 + 7919 * OFFSET)
+    for it in range(30):
+        nlayer, nwno = int(rng.choice([1, 5, 6, 7, 13, 31])), int(rng.choice([1, 17, 256, 300]))
+        nmol, ncont, nray, nrows = int(rng.integers(0, 4)), int(rng.integers(0, 3)), int(rng.integers(1, 3)), 7
+        mol_mode = int(rng.integers(0, 2))
+        tabs = [DeviceArray.from_host(rng.uniform(-26, -20, (nrows, nwno)) if mol_mode else
+                                      10.0 ** rng.uniform(-26, -20, (nrows, nwno)), ctx) for _ in range(nmol)]
+        ctabs = [DeviceArray.from_host(10.0 ** rng.uniform(-8, -5, (nrows, nwno)), ctx) for _ in range(ncont)]
+        rtabs = [DeviceArray.from_host(10.0 ** rng.uniform(-28, -25, (nwno,)), ctx) for _ in range(nray)]
+
+        def parr(xs):
+            a = (ctypes.c_void_p * max(1, len(xs)))(*[x.addr for x in xs])
+            return a, ctypes.cast(a, dpp)
+        k1, p1 = parr(tabs)
+        k2, p2 = parr(ctabs)
+        k3, p3 = parr(rtabs)
+        rows = np.ascontiguousarray(rng.integers(0, nrows, (max(nmol, 1), nlayer, 4)), dtype=np.int32)
+        wts = np.ascontiguousarray(rng.random((max(nmol, 1), nlayer, 4)))
+        mfac = np.ascontiguousarray(10.0 ** rng.uniform(-3, 1, (max(nmol, 1), nlayer)))
+        crows = np.ascontiguousarray(rng.integers(0, nrows, (max(ncont, 1), nlayer)), dtype=np.int32)
+        cfac = np.ascontiguousarray(10.0 ** rng.uniform(2, 6, (max(ncont, 1), nlayer)))
+        rfac = np.ascontiguousarray(10.0 ** rng.uniform(22, 26, (nray, nlayer)))
+        gas = (ci(mol_mode), ci(nmol), p1, rows.ctypes.data_as(ip), ptr(wts), ptr(mfac), ci(0), ci(ncont), p2,
+               crows.ctypes.data_as(ip), None, ptr(cfac), ci(nray), p3, ptr(rfac))
+        cloudy = it % 3 != 0
+        cl = [DeviceArray.from_host(x, ctx) for x in (
+            np.where(rng.random((nlayer, nwno)) < 0.4, 10.0 ** rng.uniform(-3, 1, (nlayer, nwno)), 0.0),
+            0.2 + 0.79 * rng.random((nlayer, nwno)), 0.95 * rng.random((nlayer, nwno)))] if cloudy else [None] * 3
+        rmode = it % 3                                   # Raman: none, a plane, one row
+        raman = None if rmode == 0 else DeviceArray.from_host(
+            rng.random((nlayer, nwno) if rmode == 1 else (nwno,)) * 0.99999, ctx)
+        tm = int(rng.integers(0, 3)) if (cloudy and it % 4 == 0) else 0
+        de, stream = int(rng.integers(0, 2)), int(rng.choice([2, 4]))
+        if it % 5 == 0:
+            want = set(names)
+        elif not cloudy and tm == 0:
+            want = {"dtau", "w0"} | ({"tau"} if it % 2 else set()) | ({"w0_no_raman"} if it % 4 == 1 else set())
+        else:
+            want = {k for k in names if rng.random() < 0.6} | {"dtau", "dtau_og"}
+        mix = (*[ptr(x.addr) if x is not None else None for x in cl], ptr(raman.addr) if raman is not None else None,
+               ci(nlayer if rmode == 1 else 0), cd(0.99999), ci(tm), ci(de), ci(stream))
+
+        def outs():
+            return [DeviceArray.zeros((nlayer + 1 if k in ("tau", "tau_og") else nlayer, nwno), ctx) if k in want else None
+                    for k in names]
+        o1, o2 = outs(), outs()
+        tg, tr = DeviceArray((nlayer, nwno), ctx), DeviceArray((nlayer, nwno), ctx)
+        check(load().picaso_opacity_gas_ck_dev(ctx, ci(nlayer), ci(nwno), ci(1), *gas, ptr(tg.addr), ptr(tr.addr)), ctx)
+        check(load().picaso_compute_opacity_ck_dev(ctx, ci(nlayer), ci(nwno), ci(1), ptr(tg.addr), ptr(tr.addr), *mix,
+                                                   *[ptr(o.addr) if o is not None else None for o in o1]), ctx)
+        check(load().picaso_gas_compute_opacity_dev(ctx, ci(nlayer), ci(nwno), *gas, *mix,
+                                                    *[ptr(o.addr) if o is not None else None for o in o2],
+                                                    ci(1)), ctx)
+        for k, a, b in zip(names, o1, o2):
+            if a is not None:
+                ha, hb = a.to_host(), b.to_host()
+                assert np.all(np.isfinite(ha)) or tm, (it, k)
+                assert np.array_equal(ha, hb, equal_nan=True), (it, k, nlayer, nwno, nmol, ncont, cloudy, rmode, tm, de, sorted(want))
