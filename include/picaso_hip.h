@@ -697,6 +697,46 @@ int picaso_toon_spectrum_abandon(int nblocks, picaso_block *blocks);
 /* sizeof(picaso_block), sizeof(picaso_spectrum_job) and two member offsets as compiled (layout check of a binding) */
 int picaso_driver_abi(size_t *block_bytes, size_t *job_bytes, size_t *off_albedo_host, size_t *off_hard_surface);
 
+/* ---- host-side set-up of one 1-D spectrum in one call (no GPU work) ------------------------------------------------
+ * ATMSETUP's level / layer state (reference atmsetup.py:74-461), the table rows and weights of
+ * RetrieveOpacities.get_opacities (optics.py:2048-2123, 2241-2306) and the per-layer coefficients of the TAUGAS / TAURAY
+ * sums (optics.py:144-277), bit for bit what the Python mirror computes with ~150 numpy calls.  Scope: gravity constant
+ * with height, strictly increasing pressures, 'linear' interpolation, molecule-pair continua.  Returns 0, or > 0 when the
+ * profile is outside that scope (the caller then takes the mirror), < 0 never.  Every pointer is host memory. */
+typedef struct picaso_setup_args {
+    int nlevel, nmol;                      /* nmol: the recognised molecules of the profile, column order */
+    const double *pressure_bar, *temperature;          /* (nlevel) */
+    const double *const *mix;              /* nmol x (nlevel) level mixing ratios */
+    const double *weights;                 /* (nmol) molecular weights */
+    double gravity, radius, p_reference_bar;           /* planet.gravity (cgs), planet.radius (NaN), approx p_reference */
+    double pconv, k_b, amu;
+    double coef1_scale, coef1_den;         /* rgas * 273.15**2 * .5E5 and 1.01325**2 * gravity/100, as Python forms them */
+    /* functions of the pressure grid only, from numpy (kept by the caller while the grid is unchanged) */
+    const double *log_pratio;              /* (nlevel - 1) np.log(P[k+1] / P[k]), P = pressure_bar * pconv */
+    const double *log10_player;            /* (nlayer) np.log10(sqrt(P[k+1] P[k]) / pconv) */
+    const double *pbar_cubed_hi, *pbar_cubed_lo;       /* (nlayer) (P / pconv)[1:] ** 3 and (P / pconv)[:-1] ** 3 */
+    /* the opacity object's (P, T) grid */
+    int nt, npg;
+    const double *t_inv_grid, *p_log_grid;
+    const long *nc_p, *row_lut;
+    int nlut, ncia_t;
+    const double *cia_temps;               /* np.unique(cia_temps) */
+    int nopa, ncont, nray;
+    const int *opa_idx, *cont_a, *cont_b, *ray_idx;    /* indices into the nmol list */
+    /* outputs */
+    double *level_pressure, *level_mmw, *level_den, *z, *dz, *scale_height;               /* (nlevel) */
+    double *layer_temperature, *layer_pressure, *layer_mmw, *layer_gravity, *colden;       /* (nlayer) */
+    double *layer_mix;                     /* (nmol, nlayer) */
+    int *rows;                             /* (nopa, nlayer, 4) */
+    double *wts;                           /* (nopa, nlayer, 4) */
+    int *cia_rows;                         /* (max(ncont, 1), nlayer) */
+    double *mol_fac, *cont_fac, *ray_fac;  /* (nopa | ncont | nray, nlayer) */
+    int *pt_opa_index, *n_pt_opa_index;    /* (4 nlayer) sorted unique ptids used, and how many */
+    double *scratch;                       /* (3 nlevel) */
+} picaso_setup_args;
+int picaso_host_setup(const picaso_setup_args *args);
+size_t picaso_host_setup_abi(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,180 @@
+// Host-side set-up of one 1-D spectrum in ONE call: what ATMSETUP (reference atmsetup.py:74-461: get_profile, get_mmw,
+// get_density, get_altitude, get_column_density), RetrieveOpacities.find_needed_pts / get_opacities (optics.py:2048-2123,
+// 2241-2306) and the per-layer coefficients of compute_opacity's TAUGAS / TAURAY sums (optics.py:144-277) compute per call
+// -- a few hundred scalars per layer, which the Python mirror (picaso_amd/atmsetup.py, optics.py) forms with ~150 numpy
+// calls: 0.17 ms of interpreter time in front of the first launch of a 0.86 ms spectrum, and most of what a retrieval's
+// host thread does per 1e4-wavelength spectrum.  No GPU work here.
+//
+// Same bits as the Python mirror (tests/test_fast_setup.py: np.array_equal on every array, random profiles): every
+// operation below is an IEEE +, -, *, / or sqrt in the order numpy evaluates the mirror's expressions, and the three
+// transcendental arrays -- log(P[k+1]/P[k]), log10(layer pressure), P**3 (as the two slices the mirror raises) -- depend on the pressure grid only and come from
+// numpy itself (the caller keeps them while the grid does not change), so no libm-versus-numpy difference can enter.
+// Scope: one-dimensional columns, gravity constant with height (no planet radius), strictly increasing pressures,
+// bilinear ('linear') table interpolation, molecule-pair continua; everything else stays with the Python mirror.
+#include "common.hpp"
+
+#include <algorithm>
+#include <cmath>
+
+using namespace pz;
+
+namespace {
+#pragma clang fp contract(off)
+
+inline long last_gt(const double *g, int n, double x)       // last j with g[j] > x, 0 when none
+{
+    long r = -1;
+    for (int j = 0; j < n; ++j)
+        if (g[j] > x) r = j;
+    return r < 0 ? 0 : r;
+}
+inline long last_le(const double *g, int n, double x)       // last j with g[j] <= x, 0 when none
+{
+    long r = -1;
+    for (int j = 0; j < n; ++j)
+        if (g[j] <= x) r = j;
+    return r < 0 ? 0 : r;
+}
+
+}  // namespace
+
+extern "C" int picaso_host_setup(const picaso_setup_args *a)
+{
+#pragma clang fp contract(off)
+    if (!a) return fail(nullptr, "picaso_host_setup: null argument");
+    const int n = a->nlevel, nl = n - 1, nmol = a->nmol;
+    if (n < 2 || nmol < 1) return fail(nullptr, "picaso_host_setup: bad sizes");
+    const double *pb_in = a->pressure_bar, *T = a->temperature;
+    double *P = a->level_pressure;
+    // ---- get_profile (atmsetup.py:100-246 as mirrored in picaso_amd/atmsetup.py:get_profile) ----
+    for (int i = 0; i < n; ++i) P[i] = pb_in[i] * a->pconv;
+    for (int i = 0; i < nl; ++i)
+        if (!(P[i + 1] > P[i])) return 2;                                  // not strictly increasing: the mirror's loops
+    for (int i = 0; i < nl; ++i) {
+        a->layer_temperature[i] = 0.5 * (T[i + 1] + T[i]);
+        a->layer_pressure[i] = sqrt(P[i + 1] * P[i]);
+    }
+    for (int m = 0; m < nmol; ++m) {
+        const double *v = a->mix[m];
+        double *o = a->layer_mix + (size_t)m * nl;
+        for (int i = 0; i < nl; ++i) o[i] = 0.5 * (v[i + 1] + v[i]);
+    }
+    // ---- get_mmw: w = 0.0 + x_0 W_0 + x_1 W_1 + ... in column order ----
+    for (int i = 0; i < n; ++i) {
+        double w = 0.0;
+        for (int m = 0; m < nmol; ++m) w = w + a->mix[m][i] * a->weights[m];
+        a->level_mmw[i] = w;
+    }
+    for (int i = 0; i < nl; ++i) a->layer_mmw[i] = 0.5 * (a->level_mmw[i] + a->level_mmw[i + 1]);
+    // ---- get_density ----
+    for (int i = 0; i < n; ++i) a->level_den[i] = P[i] / (a->k_b * T[i]);
+    // ---- get_altitude, constant gravity (atmsetup.py:384-461; the vector form of the mirror) ----
+    {
+        double p_ref = a->p_reference_bar * a->pconv;
+        double pmax = P[0];
+        for (int i = 1; i < n; ++i) pmax = std::max(pmax, P[i]);
+        int iref = 0;
+        if (p_ref >= pmax) p_ref = pmax;
+        for (int i = 0; i < n; ++i)
+            if (P[i] >= p_ref) { iref = i; break; }                          // (also the snap to the grid: P[iref])
+        const double g = a->gravity;
+        double *z = a->z, *dz = a->dz, *grav = a->scratch, *sh = a->scale_height;
+        for (int i = 0; i < n; ++i) {
+            z[i] = 0.0 + a->radius;
+            dz[i] = 0.0;
+            grav[i] = 0.0;
+            sh[i] = (a->k_b * T[i]) / ((a->level_mmw[i] * a->amu) * g);
+        }
+        if (iref < n - 1) {                                                  // inwards from the reference level
+            double acc = z[iref];
+            for (int i = iref; i < n - 1; ++i) {
+                grav[i] = g;
+                dz[i] = sh[i] * a->log_pratio[i];
+                acc = acc + (-dz[i]);
+                z[i + 1] = acc;
+            }
+        }
+        if (iref >= 1) {                                                     // outwards
+            for (int i = 1; i <= iref; ++i) {
+                grav[i] = g;
+                dz[i] = sh[i] * a->log_pratio[i - 1];
+            }
+            double acc = z[iref];
+            for (int i = iref; i >= 1; --i) {
+                acc = acc + dz[i];
+                z[i - 1] = acc;
+            }
+        }
+        dz[0] = dz[1];
+        dz[n - 1] = dz[n - 2];
+        for (int i = 0; i < nl; ++i) a->layer_gravity[i] = 0.5 * (grav[i] + grav[i + 1]);
+        // (scale_height with the end levels' gravity filled in is the same expression as sh: g everywhere)
+    }
+    // ---- get_column_density ----
+    for (int i = 0; i < nl; ++i) a->colden[i] = (P[i + 1] - P[i]) / a->layer_gravity[i];
+
+    // ---- find_needed_pts + get_opacities, 'linear' (optics.py:2048-2123, 2277-2306) ----
+    std::vector<long> csum((size_t)a->nt + 1, 0);
+    for (int t = 0; t < a->nt; ++t) csum[(size_t)t + 1] = csum[(size_t)t] + a->nc_p[t];
+    int *uniq = a->pt_opa_index;
+    int nuniq = 0;
+    for (int i = 0; i < nl; ++i) {
+        const double t_inv = 1 / a->layer_temperature[i], p_log = a->log10_player[i];
+        long t_lo = last_gt(a->t_inv_grid, a->nt, t_inv);
+        if (t_lo == a->nt - 1) t_lo = a->nt - 2;
+        const long t_hi = t_lo + 1;
+        long p_lo = last_le(a->p_log_grid, a->npg, p_log);
+        p_lo = std::min(p_lo, a->nc_p[t_hi] - 3);
+        if (p_lo < 0 || p_lo + 1 >= a->npg) return 3;                        // numpy would wrap a negative index: the mirror's case
+        const long p_hi = p_lo + 1;
+        const double ti = (t_inv - a->t_inv_grid[t_lo]) / (a->t_inv_grid[t_hi] - a->t_inv_grid[t_lo]);
+        const double pi = (p_log - a->p_log_grid[p_lo]) / (a->p_log_grid[p_hi] - a->p_log_grid[p_lo]);
+        const long r4[4] = {csum[t_lo] + p_lo, csum[t_hi] + p_lo, csum[t_hi] + p_hi, csum[t_lo] + p_hi};   // ll, hl, hh, lh
+        const double w4[4] = {(1 - ti) * (1 - pi), ti * (1 - pi), ti * pi, (1 - ti) * pi};
+        for (int q = 0; q < 4; ++q) {
+            const long id = 1 + r4[q];
+            if (id >= a->nlut || a->row_lut[id] < 0) return 4;                // no table row for this ptid: the mirror raises
+            for (int m = 0; m < a->nopa; ++m) {
+                a->rows[((size_t)m * nl + i) * 4 + q] = (int)a->row_lut[id];
+                a->wts[((size_t)m * nl + i) * 4 + q] = w4[q];
+            }
+            uniq[nuniq++] = (int)id;                                         // pt_opa_index = 1 + unique(r4)
+        }
+        // nearest continuum temperature (optics.py:2298): first minimum of |temps - T_layer|
+        int best = 0;
+        double bd = fabs(a->cia_temps[0] - a->layer_temperature[i]);
+        for (int j = 1; j < a->ncia_t; ++j) {
+            const double d = fabs(a->cia_temps[j] - a->layer_temperature[i]);
+            if (d < bd) { bd = d; best = j; }
+        }
+        for (int c = 0; c < std::max(a->ncont, 1); ++c) a->cia_rows[(size_t)c * nl + i] = best;
+    }
+    std::sort(uniq, uniq + nuniq);
+    *a->n_pt_opa_index = (int)(std::unique(uniq, uniq + nuniq) - uniq);
+
+    // ---- per-layer coefficients (optics.py:144-277) ----
+    double *pb = a->scratch + n, *pb2 = pb + n;
+    for (int i = 0; i < n; ++i) {
+        pb[i] = P[i] / a->pconv;                                             // (P_bar pconv) / pconv, as the mirror forms it
+        pb2[i] = pb[i] * pb[i];
+    }
+    for (int i = 0; i < nl; ++i) {
+        const double tl = a->layer_temperature[i], t0 = T[i], t1 = T[i + 1];
+        const double dP = pb[i + 1] - pb[i], pre = tl / (t0 * t1);
+        const double ACOEF = pre * (t1 * pb[i + 1] - t0 * pb[i]) / dP;
+        const double BCOEF = pre * (t0 - t1) / dP;
+        const double inner = ACOEF * (pb2[i + 1] - pb2[i]) + BCOEF * (2. / 3.) * (a->pbar_cubed_hi[i] - a->pbar_cubed_lo[i]);
+        const double COEF1 = a->coef1_scale * inner / (a->coef1_den * tl * a->layer_mmw[i]);
+        for (int c = 0; c < a->ncont; ++c)
+            a->cont_fac[(size_t)c * nl + i] = COEF1 * a->layer_mix[(size_t)a->cont_a[c] * nl + i] *
+                                              a->layer_mix[(size_t)a->cont_b[c] * nl + i];
+        for (int m = 0; m < a->nopa; ++m)
+            a->mol_fac[(size_t)m * nl + i] = 1.0 * (a->colden[i] * a->layer_mix[(size_t)a->opa_idx[m] * nl + i] / a->layer_mmw[i]);
+        for (int r = 0; r < a->nray; ++r)
+            a->ray_fac[(size_t)r * nl + i] = a->colden[i] * a->layer_mix[(size_t)a->ray_idx[r] * nl + i] / a->layer_mmw[i];
+    }
+    return 0;
+}
+
+// sizeof(picaso_setup_args) as compiled (layout check of a binding)
+extern "C" size_t picaso_host_setup_abi(void) { return sizeof(picaso_setup_args); }

@@ -1,0 +1,197 @@
+"""One C call for the host-side set-up of a 1-D spectrum (``picaso_host_setup``, ``csrc/setup.hip``): the level / layer
+state of ``ATMSETUP`` (reference atmsetup.py:74-461), the table rows and weights of ``get_opacities`` (optics.py:2048-2123,
+2241-2306) and the per-layer coefficients of the TAUGAS / TAURAY sums (optics.py:144-277).
+
+``setup(inp, opa, wno)`` returns an ``ATMSETUP`` filled exactly as ``justdoit._setup_atmosphere`` + ``opa.get_opacities``
++ ``optics._layer_factors`` would fill it (``tests/test_fast_setup.py``: every array ``np.array_equal``), or ``None`` when
+the call is outside the C function's scope -- a planet radius (gravity varies with height), an ``e-`` column, ``H-`` / ``H2-``
+continua, nearest-neighbour or correlated-k tables, ``exclude_mol``, facet-form profiles -- and the caller takes the numpy
+mirror.  ``PICASO_AMD_PY_SETUP=1`` forces the mirror (A/B)."""
+import ctypes
+import os
+
+import numpy as np
+
+from . import _lib
+from .atmsetup import ATMSETUP, molecular_weight
+
+_vp, _ci, _cd = ctypes.c_void_p, ctypes.c_int, ctypes.c_double
+
+
+class SetupArgs(ctypes.Structure):
+    _fields_ = [("nlevel", _ci), ("nmol", _ci), ("pressure_bar", _vp), ("temperature", _vp), ("mix", _vp), ("weights", _vp),
+                ("gravity", _cd), ("radius", _cd), ("p_reference_bar", _cd), ("pconv", _cd), ("k_b", _cd), ("amu", _cd),
+                ("coef1_scale", _cd), ("coef1_den", _cd), ("log_pratio", _vp), ("log10_player", _vp), ("pbar_cubed_hi", _vp), ("pbar_cubed_lo", _vp),
+                ("nt", _ci), ("npg", _ci), ("t_inv_grid", _vp), ("p_log_grid", _vp), ("nc_p", _vp), ("row_lut", _vp),
+                ("nlut", _ci), ("ncia_t", _ci), ("cia_temps", _vp), ("nopa", _ci), ("ncont", _ci), ("nray", _ci),
+                ("opa_idx", _vp), ("cont_a", _vp), ("cont_b", _vp), ("ray_idx", _vp),
+                ("level_pressure", _vp), ("level_mmw", _vp), ("level_den", _vp), ("z", _vp), ("dz", _vp),
+                ("scale_height", _vp), ("layer_temperature", _vp), ("layer_pressure", _vp), ("layer_mmw", _vp),
+                ("layer_gravity", _vp), ("colden", _vp), ("layer_mix", _vp), ("rows", _vp), ("wts", _vp), ("cia_rows", _vp),
+                ("mol_fac", _vp), ("cont_fac", _vp), ("ray_fac", _vp), ("pt_opa_index", _vp), ("n_pt_opa_index", _vp),
+                ("scratch", _vp)]
+
+
+def _addr(a):
+    return a.__array_interface__["data"][0]
+
+
+class _Signature:
+    """What depends on the profile's column names and the opacity object only: molecule lists, index tables, the
+    constant half of the argument struct."""
+
+    def __init__(self, cols, opa):
+        self.ok = False
+        weights, molecules = {}, []
+        for k in cols:
+            if k in ("pressure", "temperature"):
+                continue
+            if k == "e-":
+                return                                   # electrons: H- / H2- continua, the mirror's case
+            try:
+                weights[k] = molecular_weight(k)
+            except KeyError:
+                return                                   # unrecognised column: the mirror warns and skips it
+            molecules.append(k)
+        if not molecules or "pressure" not in cols or "temperature" not in cols:
+            return
+        self.all_molecules, self.weights_dict = molecules, weights
+        self.weights = np.array([weights[m] for m in molecules], dtype=np.float64)
+        # get_needed_continuum (atmsetup.py:248-283) on the full list, then the molecules without line opacities dropped
+        avail = opa.avail_continuum
+        self.continuum_molecules = [[m1, m2] for m1 in molecules for m2 in molecules if m1 + m2 in avail]
+        if ("H-" in molecules and "H-bf" in avail):
+            return
+        self.rayleigh_molecules = [m for m in molecules if m in opa.rayleigh_molecules]
+        opam = set(opa.molecules)
+        self.no_opa = [m for m in molecules if m not in opam]
+        self.molecules = [m for m in molecules if m in opam]
+        self.cia_pairs = [a + b for a, b in self.continuum_molecules]
+        self.ray_names = [m for m in self.rayleigh_molecules if m in opa._ray]
+        ix = {m: i for i, m in enumerate(molecules)}
+        i32 = lambda xs: np.ascontiguousarray(xs, dtype=np.int32)
+        self.opa_idx, self.ray_idx = i32([ix[m] for m in self.molecules]), i32([ix[m] for m in self.ray_names])
+        self.cont_a, self.cont_b = i32([ix[a] for a, _ in self.continuum_molecules]), i32([ix[b] for _, b in self.continuum_molecules])
+        self.t_inv_grid = np.ascontiguousarray(opa.t_inv_grid, dtype=np.float64)
+        self.p_log_grid = np.ascontiguousarray(opa.p_log_grid, dtype=np.float64)
+        self.nc_p = np.ascontiguousarray(opa.nc_p, dtype=np.int64)
+        self.row_lut = np.ascontiguousarray(opa._row_lut, dtype=np.int64)
+        self.cia_temps = np.ascontiguousarray(np.unique(opa.cia_temps), dtype=np.float64)
+        if self.cia_temps.size < 1 or self.t_inv_grid.size < 2:
+            return
+        self.ok = True
+
+
+class _PressureGrid:
+    """The three transcendental arrays, from numpy, for one pressure grid."""
+
+    def __init__(self, pbar, pconv):
+        self.pbar = pbar.copy()
+        P = pbar * pconv
+        self.log_pratio = np.ascontiguousarray(np.log(P[1:] / P[:-1]))
+        self.log10_player = np.ascontiguousarray(np.log10(np.sqrt(P[1:] * P[:-1]) / pconv))
+        pb = P / pconv
+        self.cube_hi, self.cube_lo = np.ascontiguousarray(pb[1:] ** 3), np.ascontiguousarray(pb[:-1] ** 3)
+
+
+def setup(inp, opa, wno):
+    if os.environ.get("PICASO_AMD_PY_SETUP"):
+        return None
+    if (getattr(opa, "query_method", None) != "linear" or getattr(opa, "ngauss", 1) != 1 or not hasattr(opa, "_row_lut")
+            or getattr(opa, "on_fly", False)):
+        return None
+    at = inp["atmosphere"]
+    if at.get("exclude_mol", 1) != 1:
+        return None
+    radius = inp["planet"]["radius"]
+    if not (isinstance(radius, float) and radius != radius):            # a planet radius: gravity varies with height
+        return None
+    read = at["profile"]
+    if read is None or not hasattr(read, "keys"):
+        return None
+    cols = tuple(read.keys())
+    cache = opa.__dict__.setdefault("_fast_setup", {})
+    sig = cache.get(cols)
+    if sig is None:
+        if len(cache) > 16:
+            cache.clear()
+        sig = cache[cols] = _Signature(cols, opa)
+    if not sig.ok:
+        return None
+    pbar = np.ascontiguousarray(read["pressure"], dtype=np.float64)
+    T = np.ascontiguousarray(read["temperature"], dtype=np.float64)
+    if pbar.ndim != 1 or T.shape != pbar.shape or pbar.size < 2:
+        return None
+    n = pbar.size
+    nl = n - 1
+    mixcols = [np.ascontiguousarray(read[m], dtype=np.float64) for m in sig.all_molecules]
+    for c in mixcols:
+        if c.shape != pbar.shape:
+            return None
+    atm = ATMSETUP(inp)
+    c = atm.c
+    pg = cache.get("pressure")
+    if pg is None or pg.pbar.shape != pbar.shape or not np.array_equal(pg.pbar, pbar):
+        pg = cache["pressure"] = _PressureGrid(pbar, c.pconv)
+    nmol, nopa, ncont, nray = len(mixcols), len(sig.molecules), len(sig.continuum_molecules), len(sig.ray_names)
+    # one buffer per dtype, carved into the outputs (offsets in elements)
+    sizes = [n] * 6 + [nl] * 5 + [nmol * nl, nopa * nl * 4, nopa * nl, ncont * nl, nray * nl, 3 * n]
+    fbuf = np.empty(sum(sizes))
+    offs = np.concatenate(([0], np.cumsum(sizes)))[:-1].tolist()
+    ibuf = np.empty(nopa * nl * 4 + max(ncont, 1) * nl + 4 * nl + 1, dtype=np.int32)
+    fb, ib = _addr(fbuf), _addr(ibuf)
+    mixp = (_vp * nmol)(*[_addr(x) for x in mixcols])
+    gravity = inp["planet"]["gravity"]
+    a = SetupArgs()
+    a.nlevel, a.nmol = n, nmol
+    a.pressure_bar, a.temperature, a.mix, a.weights = _addr(pbar), _addr(T), ctypes.addressof(mixp), _addr(sig.weights)
+    a.gravity, a.radius, a.p_reference_bar = float(gravity), radius, float(inp["approx"]["p_reference"])
+    a.pconv, a.k_b, a.amu = c.pconv, c.k_b, c.amu
+    a.coef1_scale, a.coef1_den = c.rgas * 273.15 ** 2 * .5E5, 1.01325 ** 2 * (gravity / 100.0)
+    a.log_pratio, a.log10_player = _addr(pg.log_pratio), _addr(pg.log10_player)
+    a.pbar_cubed_hi, a.pbar_cubed_lo = _addr(pg.cube_hi), _addr(pg.cube_lo)
+    a.nt, a.npg = sig.t_inv_grid.size, sig.p_log_grid.size
+    a.t_inv_grid, a.p_log_grid, a.nc_p, a.row_lut = _addr(sig.t_inv_grid), _addr(sig.p_log_grid), _addr(sig.nc_p), _addr(sig.row_lut)
+    a.nlut, a.ncia_t, a.cia_temps = sig.row_lut.size, sig.cia_temps.size, _addr(sig.cia_temps)
+    a.nopa, a.ncont, a.nray = nopa, ncont, nray
+    a.opa_idx, a.cont_a, a.cont_b, a.ray_idx = _addr(sig.opa_idx), _addr(sig.cont_a), _addr(sig.cont_b), _addr(sig.ray_idx)
+    (a.level_pressure, a.level_mmw, a.level_den, a.z, a.dz, a.scale_height, a.layer_temperature, a.layer_pressure,
+     a.layer_mmw, a.layer_gravity, a.colden, a.layer_mix, a.wts, a.mol_fac, a.cont_fac, a.ray_fac, a.scratch) = \
+        [fb + 8 * o for o in offs]
+    o_rows, o_cia, o_pt = 0, nopa * nl * 4, nopa * nl * 4 + max(ncont, 1) * nl
+    a.rows, a.cia_rows, a.pt_opa_index, a.n_pt_opa_index = ib, ib + 4 * o_cia, ib + 4 * o_pt, ib + 4 * (o_pt + 4 * nl)
+    rc = _lib.load().picaso_host_setup(ctypes.byref(a))
+    if rc != 0:
+        return None
+
+    def f(k, shape):
+        return fbuf[offs[k]:offs[k] + sizes[k]].reshape(shape)
+    # ---- the ATMSETUP the mirror would have built (justdoit._setup_atmosphere) ----
+    atm.surf_reflect = inp.get("surface_reflect", 0)
+    atm.hard_surface = inp.get("hard_surface", 0)
+    atm.wavenumber = wno
+    atm.planet.gravity, atm.planet.radius, atm.planet.mass = gravity, radius, inp["planet"]["mass"]
+    atm.get_lvl_flux = inp["approx"].get("get_lvl_flux", False)
+    atm.weights = sig.weights_dict
+    lmix = f(11, (nmol, nl))
+    atm.level.update(mixingratios=dict(zip(sig.all_molecules, mixcols)), temperature=T, pressure_bar=pbar,
+                     pressure=f(0, (n,)), mmw=f(1, (n,)), den=f(2, (n,)), z=f(3, (n,)), dz=f(4, (n,)), scale_height=f(5, (n,)))
+    atm.layer.update(mixingratios={m: lmix[i] for i, m in enumerate(sig.all_molecules)}, temperature=f(6, (nl,)),
+                     pressure=f(7, (nl,)), mmw=f(8, (nl,)), gravity=f(9, (nl,)), colden=f(10, (nl,)))
+    npt = int(ibuf[o_pt + 4 * nl])
+    atm.layer["pt_opa_index"] = ibuf[o_pt:o_pt + npt].astype(np.int64)
+    c.nlevel, c.nlayer = n, nl
+    atm.continuum_molecules = [list(p) for p in sig.continuum_molecules]
+    atm.rayleigh_molecules = list(sig.rayleigh_molecules)
+    atm.get_clouds(wno)
+    if sig.no_opa:
+        atm.add_warnings("I found chemistry for these but I do not have computed individual line "
+                         "opacities (not including continuum) for: " + ",".join(sig.no_opa))
+    atm.molecules = np.array(sig.molecules)
+    cia_rows = ibuf[o_cia:o_cia + nl]
+    plan = dict(molecules=list(sig.molecules), rows=ibuf[:nopa * nl * 4].reshape(nopa, nl, 4), wts=f(12, (nopa, nl, 4)),
+                fac=np.ones(nopa), cia_pairs=list(sig.cia_pairs), cia_rows=cia_rows, nlayer=nl)
+    factors = (f(13, (nopa, nl)), f(14, (ncont, nl)), list(sig.ray_names), f(15, (nray, nl)))
+    plan["_factors"] = (atm.layer["mixingratios"], factors)
+    atm._fast = (plan, factors, opa, (fbuf, ibuf, mixp))
+    return atm

@@ -19,7 +19,7 @@ import os
 
 import numpy as np
 
-from . import _lib, device, disco, optics, resident
+from . import _lib, device, disco, fastsetup, optics, resident
 from .atmsetup import ATMSETUP, CloudTables
 from .device import DeviceArray
 
@@ -1111,6 +1111,10 @@ def _constant_planes(opa, nlayer, nwno):
 def _setup_atmosphere(inp, opa, wno, profile=None, cloud_profile=None):
     """ATMSETUP sequence of the reference's ``picaso()`` (justdoit.py:180-243) for the 1-D profile
     or, in the 3-D path, for one facet's profile (``atm_1d.disect(g,t)``, justdoit.py:446-449)."""
+    if profile is None:                    # the whole set-up in one C call where it applies (fastsetup.py)
+        fast = fastsetup.setup(inp, opa, wno)
+        if fast is not None:
+            return fast
     cfg = inp
     if profile is not None:
         cfg = dict(inp)

@@ -166,6 +166,12 @@ class RetrieveOpacities:
     def get_opacities(self, atmosphere, exclude_mol=1):
         """Select table rows / weights for this atmosphere (reference optics.py:2241-2368).  The
         per-wavelength arithmetic is deferred to the GPU (``compute_opacity``)."""
+        fast = getattr(atmosphere, "_fast", None)
+        if fast is not None and fast[2] is self and exclude_mol == 1:       # formed with the atmosphere (fastsetup.py)
+            self._plan = fast[0]
+            self.molecular_opa = _LazyPlanes(self, "mol")
+            self.continuum_opa = _LazyPlanes(self, "cia")
+            return
         nlayer = atmosphere.c.nlayer
         tlayer = np.asarray(atmosphere.layer["temperature"], dtype=float)
         player = np.asarray(atmosphere.layer["pressure"], dtype=float) / atmosphere.c.pconv
@@ -725,6 +731,9 @@ def _gas_call(opa, nlayer, mol_tabs, mol_rows, mol_wts, mol_fac, cont_tabs, cont
 
 def _layer_factors(atm, opacityclass):
     """Per-layer scalar coefficients of the TAUGAS / TAURAY sums (reference optics.py:144-277)."""
+    fast = getattr(atm, "_fast", None)
+    if fast is not None and fast[2] is opacityclass and opacityclass._plan is fast[0]:
+        return fast[1]
     pl = opacityclass._plan
     nlayer = atm.c.nlayer
     tlevel = np.asarray(atm.level["temperature"], dtype=float)
