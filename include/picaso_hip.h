@@ -700,15 +700,16 @@ int picaso_driver_abi(size_t *block_bytes, size_t *job_bytes, size_t *off_albedo
 /* ---- host-side set-up of one 1-D spectrum in one call (no GPU work) ------------------------------------------------
  * ATMSETUP's level / layer state (reference atmsetup.py:74-461), the table rows and weights of
  * RetrieveOpacities.get_opacities (optics.py:2048-2123, 2241-2306) and the per-layer coefficients of the TAUGAS / TAURAY
- * sums (optics.py:144-277), bit for bit what the Python mirror computes with ~150 numpy calls.  Scope: gravity constant
- * with height, strictly increasing pressures, 'linear' interpolation, molecule-pair continua.  Returns 0, or > 0 when the
+ * sums (optics.py:144-277), bit for bit what the Python mirror computes with ~150 numpy calls.  Scope: strictly
+ * increasing pressures, 'linear' interpolation, molecule-pair continua.  Returns 0, or > 0 when the
  * profile is outside that scope (the caller then takes the mirror), < 0 never.  Every pointer is host memory. */
 typedef struct picaso_setup_args {
     int nlevel, nmol;                      /* nmol: the recognised molecules of the profile, column order */
     const double *pressure_bar, *temperature;          /* (nlevel) */
     const double *const *mix;              /* nmol x (nlevel) level mixing ratios */
     const double *weights;                 /* (nmol) molecular weights */
-    double gravity, radius, p_reference_bar;           /* planet.gravity (cgs), planet.radius (NaN), approx p_reference */
+    double gravity, radius, GM, p_reference_bar;       /* planet.gravity (cgs); planet.radius (NaN: gravity constant with height,
+                                                          else G M / z^2 with GM = G * planet.mass); approx p_reference */
     double pconv, k_b, amu;
     double coef1_scale, coef1_den;         /* rgas * 273.15**2 * .5E5 and 1.01325**2 * gravity/100, as Python forms them */
     /* functions of the pressure grid only, from numpy (kept by the caller while the grid is unchanged) */

@@ -9,7 +9,7 @@
 // operation below is an IEEE +, -, *, / or sqrt in the order numpy evaluates the mirror's expressions, and the three
 // transcendental arrays -- log(P[k+1]/P[k]), log10(layer pressure), P**3 (as the two slices the mirror raises) -- depend on the pressure grid only and come from
 // numpy itself (the caller keeps them while the grid does not change), so no libm-versus-numpy difference can enter.
-// Scope: one-dimensional columns, gravity constant with height (no planet radius), strictly increasing pressures,
+// Scope: one-dimensional columns, strictly increasing pressures,
 // bilinear ('linear') table interpolation, molecule-pair continua; everything else stays with the Python mirror.
 #include "common.hpp"
 
@@ -85,6 +85,28 @@ extern "C" int picaso_host_setup(const picaso_setup_args *a)
             grav[i] = 0.0;
             sh[i] = (a->k_b * T[i]) / ((a->level_mmw[i] * a->amu) * g);
         }
+        if (a->radius == a->radius) {
+            // a planet radius: gravity G M / z^2 level by level (the mirror's loops, atmsetup.py:430-452).  z ** 2 of
+            // a numpy scalar is libm's pow, which is NOT always z * z (0.08 % of arguments differ in the last bit):
+            // called through a volatile pointer so that the compiler cannot fold it into a product.
+            static double (*volatile pow_libm)(double, double) = pow;
+            for (int i = iref; i < n - 1; ++i) {                             // inwards from the reference level
+                grav[i] = a->GM / pow_libm(z[i], 2.0);
+                dz[i] = (a->k_b * T[i]) / ((a->level_mmw[i] * a->amu) * grav[i]) * a->log_pratio[i];
+                z[i + 1] = z[i] - dz[i];
+            }
+            for (int i = iref; i >= 1; --i) {                                // outwards
+                grav[i] = a->GM / pow_libm(z[i], 2.0);
+                dz[i] = (a->k_b * T[i]) / ((a->level_mmw[i] * a->amu) * grav[i]) * a->log_pratio[i - 1];
+                z[i - 1] = z[i] + dz[i];
+            }
+            dz[0] = dz[1];
+            dz[n - 1] = dz[n - 2];
+            for (int i = 0; i < nl; ++i) a->layer_gravity[i] = 0.5 * (grav[i] + grav[i + 1]);
+            grav[n - 1] = a->GM / pow_libm(z[n - 1], 2.0);
+            grav[0] = a->GM / pow_libm(z[0], 2.0);
+            for (int i = 0; i < n; ++i) sh[i] = (a->k_b * T[i]) / ((a->level_mmw[i] * a->amu) * grav[i]);
+        } else {
         if (iref < n - 1) {                                                  // inwards from the reference level
             double acc = z[iref];
             for (int i = iref; i < n - 1; ++i) {
@@ -109,6 +131,7 @@ extern "C" int picaso_host_setup(const picaso_setup_args *a)
         dz[n - 1] = dz[n - 2];
         for (int i = 0; i < nl; ++i) a->layer_gravity[i] = 0.5 * (grav[i] + grav[i + 1]);
         // (scale_height with the end levels' gravity filled in is the same expression as sh: g everywhere)
+        }
     }
     // ---- get_column_density ----
     for (int i = 0; i < nl; ++i) a->colden[i] = (P[i + 1] - P[i]) / a->layer_gravity[i];

@@ -4,7 +4,7 @@ state of ``ATMSETUP`` (reference atmsetup.py:74-461), the table rows and weights
 
 ``setup(inp, opa, wno)`` returns an ``ATMSETUP`` filled exactly as ``justdoit._setup_atmosphere`` + ``opa.get_opacities``
 + ``optics._layer_factors`` would fill it (``tests/test_fast_setup.py``: every array ``np.array_equal``), or ``None`` when
-the call is outside the C function's scope -- a planet radius (gravity varies with height), an ``e-`` column, ``H-`` / ``H2-``
+the call is outside the C function's scope -- an ``e-`` column, ``H-`` / ``H2-``
 continua, nearest-neighbour or correlated-k tables, ``exclude_mol``, facet-form profiles -- and the caller takes the numpy
 mirror.  ``PICASO_AMD_PY_SETUP=1`` forces the mirror (A/B)."""
 import ctypes
@@ -20,7 +20,7 @@ _vp, _ci, _cd = ctypes.c_void_p, ctypes.c_int, ctypes.c_double
 
 class SetupArgs(ctypes.Structure):
     _fields_ = [("nlevel", _ci), ("nmol", _ci), ("pressure_bar", _vp), ("temperature", _vp), ("mix", _vp), ("weights", _vp),
-                ("gravity", _cd), ("radius", _cd), ("p_reference_bar", _cd), ("pconv", _cd), ("k_b", _cd), ("amu", _cd),
+                ("gravity", _cd), ("radius", _cd), ("GM", _cd), ("p_reference_bar", _cd), ("pconv", _cd), ("k_b", _cd), ("amu", _cd),
                 ("coef1_scale", _cd), ("coef1_den", _cd), ("log_pratio", _vp), ("log10_player", _vp), ("pbar_cubed_hi", _vp), ("pbar_cubed_lo", _vp),
                 ("nt", _ci), ("npg", _ci), ("t_inv_grid", _vp), ("p_log_grid", _vp), ("nc_p", _vp), ("row_lut", _vp),
                 ("nlut", _ci), ("ncia_t", _ci), ("cia_temps", _vp), ("nopa", _ci), ("ncont", _ci), ("nray", _ci),
@@ -103,8 +103,8 @@ def setup(inp, opa, wno):
     at = inp["atmosphere"]
     if at.get("exclude_mol", 1) != 1:
         return None
-    radius = inp["planet"]["radius"]
-    if not (isinstance(radius, float) and radius != radius):            # a planet radius: gravity varies with height
+    radius, mass = inp["planet"]["radius"], inp["planet"]["mass"]
+    if not isinstance(radius, float) or (radius == radius and not isinstance(mass, float)):
         return None
     read = at["profile"]
     if read is None or not hasattr(read, "keys"):
@@ -146,6 +146,7 @@ def setup(inp, opa, wno):
     a.nlevel, a.nmol = n, nmol
     a.pressure_bar, a.temperature, a.mix, a.weights = _addr(pbar), _addr(T), ctypes.addressof(mixp), _addr(sig.weights)
     a.gravity, a.radius, a.p_reference_bar = float(gravity), radius, float(inp["approx"]["p_reference"])
+    a.GM = c.G * mass if radius == radius else 0.0
     a.pconv, a.k_b, a.amu = c.pconv, c.k_b, c.amu
     a.coef1_scale, a.coef1_den = c.rgas * 273.15 ** 2 * .5E5, 1.01325 ** 2 * (gravity / 100.0)
     a.log_pratio, a.log10_player = _addr(pg.log_pratio), _addr(pg.log10_player)
