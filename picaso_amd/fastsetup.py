@@ -79,11 +79,45 @@ class _Signature:
         self.cia_temps = np.ascontiguousarray(np.unique(opa.cia_temps), dtype=np.float64)
         if self.cia_temps.size < 1 or self.t_inv_grid.size < 2:
             return
+        self.layouts = {}
         self.ok = True
+
+
+class _Layout:
+    """Output buffers of one (signature, level count): sizes and offsets of the carved arrays, and the argument struct
+    with everything that does not change between calls filled in."""
+    F_NAMES = ("level_pressure", "level_mmw", "level_den", "z", "dz", "scale_height", "layer_temperature", "layer_pressure",
+               "layer_mmw", "layer_gravity", "colden", "layer_mix", "wts", "mol_fac", "cont_fac", "ray_fac", "scratch")
+
+    def __init__(self, sig, n, c):
+        nl = n - 1
+        nmol = len(sig.all_molecules)
+        self.nopa, self.ncont, self.nray = len(sig.molecules), len(sig.continuum_molecules), len(sig.ray_names)
+        nopa, ncont, nray = self.nopa, self.ncont, self.nray
+        self.sizes = [n] * 6 + [nl] * 5 + [nmol * nl, nopa * nl * 4, nopa * nl, ncont * nl, nray * nl, 3 * n]
+        self.offs = np.concatenate(([0], np.cumsum(self.sizes)))[:-1].tolist()
+        self.nf = sum(self.sizes)
+        self.o_cia, self.o_pt = nopa * nl * 4, nopa * nl * 4 + max(ncont, 1) * nl
+        self.ni = self.o_pt + 4 * nl + 1
+        self.f_fields = [(k, 8 * o) for k, o in zip(self.F_NAMES, self.offs)]
+        self.i_fields = [("rows", 0), ("cia_rows", 4 * self.o_cia), ("pt_opa_index", 4 * self.o_pt),
+                         ("n_pt_opa_index", 4 * (self.o_pt + 4 * nl))]
+        a = SetupArgs()
+        a.nlevel, a.nmol, a.weights = n, nmol, _addr(sig.weights)
+        a.pconv, a.k_b, a.amu = c.pconv, c.k_b, c.amu
+        a.coef1_scale = c.rgas * 273.15 ** 2 * .5E5
+        a.nt, a.npg = sig.t_inv_grid.size, sig.p_log_grid.size
+        a.t_inv_grid, a.p_log_grid, a.nc_p, a.row_lut = (_addr(sig.t_inv_grid), _addr(sig.p_log_grid), _addr(sig.nc_p),
+                                                         _addr(sig.row_lut))
+        a.nlut, a.ncia_t, a.cia_temps = sig.row_lut.size, sig.cia_temps.size, _addr(sig.cia_temps)
+        a.nopa, a.ncont, a.nray = nopa, ncont, nray
+        a.opa_idx, a.cont_a, a.cont_b, a.ray_idx = _addr(sig.opa_idx), _addr(sig.cont_a), _addr(sig.cont_b), _addr(sig.ray_idx)
+        self.template = bytes(a)
 
 
 class _PressureGrid:
     """The three transcendental arrays, from numpy, for one pressure grid."""
+    addr = None
 
     def __init__(self, pbar, pconv):
         self.pbar = pbar.copy()
@@ -133,34 +167,28 @@ def setup(inp, opa, wno):
     pg = cache.get("pressure")
     if pg is None or pg.pbar.shape != pbar.shape or not np.array_equal(pg.pbar, pbar):
         pg = cache["pressure"] = _PressureGrid(pbar, c.pconv)
-    nmol, nopa, ncont, nray = len(mixcols), len(sig.molecules), len(sig.continuum_molecules), len(sig.ray_names)
-    # one buffer per dtype, carved into the outputs (offsets in elements)
-    sizes = [n] * 6 + [nl] * 5 + [nmol * nl, nopa * nl * 4, nopa * nl, ncont * nl, nray * nl, 3 * n]
-    fbuf = np.empty(sum(sizes))
-    offs = np.concatenate(([0], np.cumsum(sizes)))[:-1].tolist()
-    ibuf = np.empty(nopa * nl * 4 + max(ncont, 1) * nl + 4 * nl + 1, dtype=np.int32)
+    nmol = len(mixcols)
+    lay = sig.layouts.get(n)
+    if lay is None:
+        lay = sig.layouts[n] = _Layout(sig, n, c)
+    nopa, ncont, nray, sizes, offs, o_cia, o_pt = lay.nopa, lay.ncont, lay.nray, lay.sizes, lay.offs, lay.o_cia, lay.o_pt
+    fbuf = np.empty(lay.nf)
+    ibuf = np.empty(lay.ni, dtype=np.int32)
     fb, ib = _addr(fbuf), _addr(ibuf)
     mixp = (_vp * nmol)(*[_addr(x) for x in mixcols])
     gravity = inp["planet"]["gravity"]
-    a = SetupArgs()
-    a.nlevel, a.nmol = n, nmol
-    a.pressure_bar, a.temperature, a.mix, a.weights = _addr(pbar), _addr(T), ctypes.addressof(mixp), _addr(sig.weights)
+    a = SetupArgs.from_buffer_copy(lay.template)            # the grid / index half is the same for every call
+    a.pressure_bar, a.temperature, a.mix = _addr(pbar), _addr(T), ctypes.addressof(mixp)
     a.gravity, a.radius, a.p_reference_bar = float(gravity), radius, float(inp["approx"]["p_reference"])
     a.GM = c.G * mass if radius == radius else 0.0
-    a.pconv, a.k_b, a.amu = c.pconv, c.k_b, c.amu
-    a.coef1_scale, a.coef1_den = c.rgas * 273.15 ** 2 * .5E5, 1.01325 ** 2 * (gravity / 100.0)
-    a.log_pratio, a.log10_player = _addr(pg.log_pratio), _addr(pg.log10_player)
-    a.pbar_cubed_hi, a.pbar_cubed_lo = _addr(pg.cube_hi), _addr(pg.cube_lo)
-    a.nt, a.npg = sig.t_inv_grid.size, sig.p_log_grid.size
-    a.t_inv_grid, a.p_log_grid, a.nc_p, a.row_lut = _addr(sig.t_inv_grid), _addr(sig.p_log_grid), _addr(sig.nc_p), _addr(sig.row_lut)
-    a.nlut, a.ncia_t, a.cia_temps = sig.row_lut.size, sig.cia_temps.size, _addr(sig.cia_temps)
-    a.nopa, a.ncont, a.nray = nopa, ncont, nray
-    a.opa_idx, a.cont_a, a.cont_b, a.ray_idx = _addr(sig.opa_idx), _addr(sig.cont_a), _addr(sig.cont_b), _addr(sig.ray_idx)
-    (a.level_pressure, a.level_mmw, a.level_den, a.z, a.dz, a.scale_height, a.layer_temperature, a.layer_pressure,
-     a.layer_mmw, a.layer_gravity, a.colden, a.layer_mix, a.wts, a.mol_fac, a.cont_fac, a.ray_fac, a.scratch) = \
-        [fb + 8 * o for o in offs]
-    o_rows, o_cia, o_pt = 0, nopa * nl * 4, nopa * nl * 4 + max(ncont, 1) * nl
-    a.rows, a.cia_rows, a.pt_opa_index, a.n_pt_opa_index = ib, ib + 4 * o_cia, ib + 4 * o_pt, ib + 4 * (o_pt + 4 * nl)
+    a.coef1_den = 1.01325 ** 2 * (gravity / 100.0)
+    if pg.addr is None:
+        pg.addr = (_addr(pg.log_pratio), _addr(pg.log10_player), _addr(pg.cube_hi), _addr(pg.cube_lo))
+    a.log_pratio, a.log10_player, a.pbar_cubed_hi, a.pbar_cubed_lo = pg.addr
+    for name, off in lay.f_fields:
+        setattr(a, name, fb + off)
+    for name, off in lay.i_fields:
+        setattr(a, name, ib + off)
     rc = _lib.load().picaso_host_setup(ctypes.byref(a))
     if rc != 0:
         return None
