@@ -736,6 +736,9 @@ typedef struct picaso_setup_args {
     double *scratch;                       /* (3 nlevel) */
 } picaso_setup_args;
 int picaso_host_setup(const picaso_setup_args *args);
+/* the facets of a 3-D spectrum in one call: facet f reads temperature + f t_stride and mix[m] + f mix_stride[m] (0: one
+ * column for all facets) and writes behind facet f - 1 in every output array (facet-major) */
+int picaso_host_setup_facets(const picaso_setup_args *args, int nfacets, long t_stride, const long *mix_stride);
 size_t picaso_host_setup_abi(void);
 
 #ifdef __cplusplus

@@ -199,5 +199,37 @@ extern "C" int picaso_host_setup(const picaso_setup_args *a)
     return 0;
 }
 
+// The same for the facets of a 3-D spectrum (reference justdoit.py:437-471 sets up one ATMSETUP per facet; the mirror one
+// facet-form ATMSETUP with (nlevel, nfacets) columns): facet f reads its temperature at temperature + f t_stride and
+// molecule m at mix[m] + f mix_stride[m] (0 = one column for all facets; the pressure grid is shared) and writes its outputs
+// behind facet f - 1's -- every output array is facet-major, (nfacets, <the 1-D shape>).  Per element the operations are the
+// 1-D ones, which is what the facet-form mirror evaluates row by row.
+extern "C" int picaso_host_setup_facets(const picaso_setup_args *a, int nfac, long t_stride, const long *mix_stride)
+{
+    if (!a || nfac < 1 || !mix_stride) return fail(nullptr, "picaso_host_setup_facets: null argument");
+    const size_t n = (size_t)a->nlevel, nl = n - 1, nmol = (size_t)a->nmol;
+    const size_t nopa = (size_t)a->nopa, ncont = (size_t)a->ncont, nray = (size_t)a->nray, nc1 = ncont ? ncont : 1;
+    std::vector<const double *> mix(nmol);
+    for (int f = 0; f < nfac; ++f) {
+        picaso_setup_args b = *a;
+        const size_t F = (size_t)f;
+        b.temperature = a->temperature + F * (size_t)t_stride;
+        for (size_t m = 0; m < nmol; ++m) mix[m] = a->mix[m] + F * (size_t)mix_stride[m];
+        b.mix = mix.data();
+        b.level_pressure += F * n; b.level_mmw += F * n; b.level_den += F * n; b.z += F * n; b.dz += F * n;
+        b.scale_height += F * n;
+        b.layer_temperature += F * nl; b.layer_pressure += F * nl; b.layer_mmw += F * nl; b.layer_gravity += F * nl;
+        b.colden += F * nl;
+        b.layer_mix += F * nmol * nl;
+        b.rows += F * nopa * nl * 4; b.wts += F * nopa * nl * 4;
+        b.cia_rows += F * nc1 * nl;
+        b.mol_fac += F * nopa * nl; b.cont_fac += F * ncont * nl; b.ray_fac += F * nray * nl;
+        b.pt_opa_index += F * 4 * nl; b.n_pt_opa_index += F;
+        const int rc = picaso_host_setup(&b);
+        if (rc != 0) return rc;
+    }
+    return 0;
+}
+
 // sizeof(picaso_setup_args) as compiled (layout check of a binding)
 extern "C" size_t picaso_host_setup_abi(void) { return sizeof(picaso_setup_args); }

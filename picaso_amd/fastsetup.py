@@ -224,3 +224,124 @@ def setup(inp, opa, wno):
     plan["_factors"] = (atm.layer["mixingratios"], factors)
     atm._fast = (plan, factors, opa, (fbuf, ibuf, mixp))
     return atm
+
+
+def setup_facets(inp, opa, wno, prof_f):
+    """The facet-form ATMSETUP of the 3-D path (``justdoit.picaso``: columns ``(nlevel, nfacets)`` for what depends on the
+    facet, ``(nlevel, 1)`` for what does not; the pressure grid is shared) from ``picaso_host_setup_facets``, with the tall
+    plan and per-layer coefficients ``optics.gas_stage_facets`` would form (facet-major ``nfacets * nlayer`` layers) attached
+    as ``atm._fast_tall``.  ``None`` outside the C function's scope."""
+    if os.environ.get("PICASO_AMD_PY_SETUP"):
+        return None
+    if (getattr(opa, "query_method", None) != "linear" or getattr(opa, "ngauss", 1) != 1 or not hasattr(opa, "_row_lut")
+            or getattr(opa, "on_fly", False) or inp["atmosphere"].get("exclude_mol", 1) != 1):
+        return None
+    radius, mass = inp["planet"]["radius"], inp["planet"]["mass"]
+    if not isinstance(radius, float) or radius == radius:          # facet form with a planet radius: the mirror (pow per element)
+        return None
+    cols = tuple(prof_f.keys())
+    cache = opa.__dict__.setdefault("_fast_setup", {})
+    sig = cache.get(cols)
+    if sig is None:
+        if len(cache) > 16:
+            cache.clear()
+        sig = cache[cols] = _Signature(cols, opa)
+    if not sig.ok:
+        return None
+    pcol = np.asarray(prof_f["pressure"], dtype=np.float64)
+    tcol = np.asarray(prof_f["temperature"], dtype=np.float64)
+    if pcol.ndim != 2 or pcol.shape[1] != 1 or tcol.ndim != 2 or tcol.shape[0] != pcol.shape[0]:
+        return None
+    n, nfac = tcol.shape
+    nl = n - 1
+    if n < 2 or nfac < 1:
+        return None
+    pbar = np.ascontiguousarray(pcol[:, 0])
+    T = np.ascontiguousarray(tcol.T)                                  # (nfacets, nlevel)
+    mixcols, strides, shared = [], [], []
+    for m in sig.all_molecules:
+        v = np.asarray(prof_f[m], dtype=np.float64)
+        if v.ndim != 2 or v.shape[0] != n or v.shape[1] not in (1, nfac):
+            return None
+        mixcols.append(np.ascontiguousarray(v.T if v.shape[1] > 1 else v[:, 0]))
+        strides.append(0 if v.shape[1] == 1 else n)
+        shared.append(v.shape[1] == 1)
+    atm = ATMSETUP(dict(inp, atmosphere=dict(inp["atmosphere"], profile=prof_f), clouds=dict(inp["clouds"], profile=None)))
+    c = atm.c
+    pg = cache.get("pressure")
+    if pg is None or pg.pbar.shape != pbar.shape or not np.array_equal(pg.pbar, pbar):
+        pg = cache["pressure"] = _PressureGrid(pbar, c.pconv)
+    nmol = len(mixcols)
+    lay = sig.layouts.get(n)
+    if lay is None:
+        lay = sig.layouts[n] = _Layout(sig, n, c)
+    nopa, ncont, nray, sizes = lay.nopa, lay.ncont, lay.nray, lay.sizes
+    nc1 = max(ncont, 1)
+    fsz = sizes[:-1]                                                  # per-facet float outputs (scratch is shared)
+    foff = np.concatenate(([0], np.cumsum([x * nfac for x in fsz]))).tolist()
+    fbuf = np.empty(foff[-1] + sizes[-1])
+    isz = [nopa * nl * 4, nc1 * nl, 4 * nl, 1]
+    ioff = np.concatenate(([0], np.cumsum([x * nfac for x in isz]))).tolist()
+    ibuf = np.empty(ioff[-1], dtype=np.int32)
+    fb, ib = _addr(fbuf), _addr(ibuf)
+    mixp = (_vp * nmol)(*[_addr(x) for x in mixcols])
+    mstr = (ctypes.c_long * nmol)(*strides)
+    gravity = inp["planet"]["gravity"]
+    a = SetupArgs.from_buffer_copy(lay.template)
+    a.pressure_bar, a.temperature, a.mix = _addr(pbar), _addr(T), ctypes.addressof(mixp)
+    a.gravity, a.radius, a.p_reference_bar = float(gravity), radius, float(inp["approx"]["p_reference"])
+    a.GM = 0.0
+    a.coef1_den = 1.01325 ** 2 * (gravity / 100.0)
+    if pg.addr is None:
+        pg.addr = (_addr(pg.log_pratio), _addr(pg.log10_player), _addr(pg.cube_hi), _addr(pg.cube_lo))
+    a.log_pratio, a.log10_player, a.pbar_cubed_hi, a.pbar_cubed_lo = pg.addr
+    for k, name in enumerate(_Layout.F_NAMES):
+        setattr(a, name, fb + 8 * foff[k])
+    for name, o in zip(("rows", "cia_rows", "pt_opa_index", "n_pt_opa_index"), ioff):
+        setattr(a, name, ib + 4 * o)
+    rc = _lib.load().picaso_host_setup_facets(ctypes.byref(a), _ci(nfac), ctypes.c_long(n), mstr)
+    if rc != 0:
+        return None
+
+    def f(k, shape):                                                  # facet-major output k as (nfacets,) + shape
+        return fbuf[foff[k]:foff[k + 1]].reshape((nfac,) + shape)
+
+    def facet_form(x, is_shared):                                     # (nfacets, rows) -> (rows, nfacets | 1) as the mirror holds it
+        return np.ascontiguousarray(x[:1].T) if is_shared else np.ascontiguousarray(x.T)
+    all_shared = all(shared)
+    atm.surf_reflect = inp.get("surface_reflect", 0)
+    atm.hard_surface = inp.get("hard_surface", 0)
+    atm.wavenumber = wno
+    atm.planet.gravity, atm.planet.radius, atm.planet.mass = gravity, radius, mass
+    atm.get_lvl_flux = inp["approx"].get("get_lvl_flux", False)
+    atm.weights = sig.weights_dict
+    lmix = f(11, (nmol, nl))
+    atm.level.update(
+        mixingratios={m: np.asarray(prof_f[m], dtype=np.float64) for m in sig.all_molecules}, temperature=tcol,
+        pressure_bar=pcol, pressure=facet_form(f(0, (n,)), True), mmw=facet_form(f(1, (n,)), all_shared),
+        den=facet_form(f(2, (n,)), False), z=facet_form(f(3, (n,)), False), dz=facet_form(f(4, (n,)), False),
+        scale_height=facet_form(f(5, (n,)), False))
+    atm.layer.update(
+        mixingratios={m: facet_form(lmix[:, i], shared[i]) for i, m in enumerate(sig.all_molecules)},
+        temperature=facet_form(f(6, (nl,)), False), pressure=facet_form(f(7, (nl,)), True),
+        mmw=facet_form(f(8, (nl,)), all_shared), gravity=facet_form(f(9, (nl,)), False), colden=facet_form(f(10, (nl,)), False))
+    c.nlevel, c.nlayer = n, nl
+    atm.continuum_molecules = [list(p) for p in sig.continuum_molecules]
+    atm.rayleigh_molecules = list(sig.rayleigh_molecules)
+    atm.get_clouds(wno)
+    if sig.no_opa:
+        atm.add_warnings("I found chemistry for these but I do not have computed individual line "
+                         "opacities (not including continuum) for: " + ",".join(sig.no_opa))
+    atm.molecules = np.array(sig.molecules)
+    ntot = nfac * nl
+    rows = np.ascontiguousarray(ibuf[ioff[0]:ioff[1]].reshape(nfac, nopa, nl, 4).transpose(1, 0, 2, 3)).reshape(nopa, ntot, 4)
+    wts = np.ascontiguousarray(f(12, (nopa, nl, 4)).transpose(1, 0, 2, 3)).reshape(nopa, ntot, 4)
+    cia_rows = np.ascontiguousarray(ibuf[ioff[1]:ioff[2]].reshape(nfac, nc1, nl)[:, 0, :]).reshape(ntot)
+
+    def tall(k, nsp):
+        return np.ascontiguousarray(f(k, (nsp, nl)).transpose(1, 0, 2)).reshape(nsp, ntot)
+    plan = dict(molecules=list(sig.molecules), rows=rows, wts=wts, fac=np.ones(nopa), cia_pairs=list(sig.cia_pairs),
+                cia_rows=cia_rows, nlayer=ntot)
+    factors = (tall(13, nopa), tall(14, ncont), list(sig.ray_names), tall(15, nray))
+    atm._fast_tall = (plan, factors, opa)
+    return atm

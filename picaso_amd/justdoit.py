@@ -1115,6 +1115,10 @@ def _setup_atmosphere(inp, opa, wno, profile=None, cloud_profile=None):
         fast = fastsetup.setup(inp, opa, wno)
         if fast is not None:
             return fast
+    elif cloud_profile is None and all(getattr(v, "ndim", 0) == 2 for v in profile.values()):      # facet form (3-D path)
+        fast = fastsetup.setup_facets(inp, opa, wno, profile)
+        if fast is not None:
+            return fast
     cfg = inp
     if profile is not None:
         cfg = dict(inp)

@@ -938,11 +938,17 @@ def gas_stage_facets(atm_f, opa, nfac, tg3, tr3, exclude_mol=1):
         c=types.SimpleNamespace(nlayer=ntot, pconv=atm_f.c.pconv),
         layer={"temperature": flat(atm_f.layer["temperature"]), "pressure": flat(atm_f.layer["pressure"])},
         molecules=atm_f.molecules, continuum_molecules=atm_f.continuum_molecules)
-    opa.get_opacities(tall, exclude_mol=exclude_mol)
-    pl = opa._plan
-    if pl.get("premixed"):
-        raise Exception("the 3-D path takes monochromatic opacities")
-    mol_fac, cont_fac, ray_names, ray_fac = _layer_factors(atm_f, opa)
+    fast = getattr(atm_f, "_fast_tall", None)
+    if fast is not None and fast[2] is opa and exclude_mol == 1:       # formed with the atmosphere (fastsetup.setup_facets)
+        opa._plan = pl = fast[0]
+        opa.molecular_opa, opa.continuum_opa = _LazyPlanes(opa, "mol"), _LazyPlanes(opa, "cia")
+        mol_fac, cont_fac, ray_names, ray_fac = fast[1]
+    else:
+        opa.get_opacities(tall, exclude_mol=exclude_mol)
+        pl = opa._plan
+        if pl.get("premixed"):
+            raise Exception("the 3-D path takes monochromatic opacities")
+        mol_fac, cont_fac, ray_names, ray_fac = _layer_factors(atm_f, opa)
     mol_tabs = [(opa._mol_log if opa.query_method == "linear" else opa._mol_raw)[m] for m in pl["molecules"]]
     mol_mode = 1 if opa.query_method == "linear" else 0
     cont_tabs = [opa._cia[p] for p in pl["cia_pairs"]]

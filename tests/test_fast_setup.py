@@ -135,3 +135,55 @@ def test_setup_struct_layout():
     lib = _lib.load()
     lib.picaso_host_setup_abi.restype = ctypes.c_size_t
     assert lib.picaso_host_setup_abi() == ctypes.sizeof(fastsetup.SetupArgs)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_fast_setup_facets_bits_of_the_mirror(opa, monkeypatch, seed):
+    """The facet form of the 3-D path: (nlevel, nfacets) temperature columns, mixing ratios shared or per facet -- the
+    facet-form ATMSETUP and the tall plan / coefficients of optics.gas_stage_facets, array by array."""
+    import types
+    rng = np.random.default_rng(300 + seed)
+    wno = opa._wno_test
+    nlevel, nfac = int(rng.choice([3, 10, 31])), int(rng.choice([1, 4, 9]))
+    cols = ["H2", "He", "H2O", "CH4", "Na"][:int(rng.integers(3, 6))]
+    case = _case(rng, nlevel, float(rng.choice([1.0, 1e-9, 1e5, 0.03])), cols)
+    inp = case.inputs
+    base = inp["atmosphere"]["profile"]
+    prof_f = {"pressure": np.asarray(base["pressure"]).reshape(nlevel, 1),
+              "temperature": np.ascontiguousarray(np.asarray(base["temperature"])[:, None] * (1.0 + 0.1 * rng.random((1, nfac))))}
+    for k in cols:
+        v = np.asarray(base[k]).reshape(nlevel, 1)
+        prof_f[k] = v * (1.0 + 0.2 * rng.random((1, nfac))) if (seed % 2 and k != "H2") else v
+    fast = jdi._setup_atmosphere(inp, opa, wno, prof_f, None)
+    assert getattr(fast, "_fast_tall", None) is not None
+    monkeypatch.setenv("PICASO_AMD_PY_SETUP", "1")
+    ref = jdi._setup_atmosphere(inp, opa, wno, prof_f, None)
+    assert getattr(ref, "_fast_tall", None) is None
+    nl = nlevel - 1
+
+    def flat(a):
+        return np.ascontiguousarray(np.broadcast_to(np.asarray(a, dtype=float), (nl, nfac)).T).ravel()
+    tall = types.SimpleNamespace(c=types.SimpleNamespace(nlayer=nfac * nl, pconv=ref.c.pconv),
+                                 layer={"temperature": flat(ref.layer["temperature"]), "pressure": flat(ref.layer["pressure"])},
+                                 molecules=ref.molecules, continuum_molecules=ref.continuum_molecules)
+    opa.get_opacities(tall, exclude_mol=1)
+    pr, fr = opa._plan, px._layer_factors(ref, opa)
+    monkeypatch.delenv("PICASO_AMD_PY_SETUP")
+    pf, ff = fast._fast_tall[0], fast._fast_tall[1]
+    for d in ("level", "layer"):
+        fd, rd = getattr(fast, d), getattr(ref, d)
+        assert set(fd) == set(rd), (d, set(fd) ^ set(rd))
+        for k in rd:
+            if k == "mixingratios":
+                for m in rd[k]:
+                    _same(fd[k][m], rd[k][m], (d, k, m))
+            elif k != "cloud":
+                _same(fd[k], rd[k], (d, k))
+    assert list(fast.molecules) == list(ref.molecules) and fast.continuum_molecules == ref.continuum_molecules
+    assert fast.rayleigh_molecules == ref.rayleigh_molecules and fast.warnings == ref.warnings
+    assert pf["molecules"] == pr["molecules"] and pf["cia_pairs"] == pr["cia_pairs"] and pf["nlayer"] == pr["nlayer"]
+    for k in ("rows", "wts", "fac", "cia_rows"):
+        _same(pf[k], pr[k], ("plan", k))
+    assert ff[2] == fr[2]
+    for i in (0, 1, 3):
+        _same(ff[i], fr[i], ("factors", i))
