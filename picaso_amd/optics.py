@@ -954,7 +954,7 @@ def gas_stage_facets(atm_f, opa, nfac, tg3, tr3, exclude_mol=1):
     cont_tabs = [opa._cia[p] for p in pl["cia_pairs"]]
     ray_tabs = [opa._ray[m] for m in ray_names]
     per_layer = len(mol_tabs) * (16 + 32 + 8) + len(cont_tabs) * (4 + 8) + len(ray_tabs) * 8 + 8
-    fchunk = max(1, int((900 * 1024) // (per_layer * nlayer)))          # one 1 MB upload slot per launch
+    fchunk = max(1, int((3600 * 1024) // (per_layer * nlayer)))         # one 4 MB upload slot per launch (common.hpp SLOT_BYTES)
     for f0 in range(0, nfac, fchunk):
         f1 = min(nfac, f0 + fchunk)
         sl = slice(f0 * nlayer, f1 * nlayer)
