@@ -1580,7 +1580,13 @@ def picaso(bundle, opacityclass, dimension="1d", calculation="reflected", full_o
             pc = post_ctx or src.ctx
             prefetched["thermal"] = (src.to_host_async(device.PinnedArray(src.shape, pc), pc), None)
     finish.dev, finish.ctx, finish.tctx, finish.prefetch = dev_results, ctx, tctx, prefetch
-    return finish if defer else finish()
+    if defer:
+        return finish
+    if not _raw and not os.environ.get("PICASO_AMD_SYNC_COPIES"):
+        # the call-by-call path (cloud tables on their own grid, Oklopcic Raman, SH, correlated-k, 3-D): integrals and
+        # result copies go on the streams behind each leg's kernels, as the C driver does for the plain Toon call
+        prefetch()
+    return finish()
 
 
 # ------------------------------------------------------------------------------------------------
