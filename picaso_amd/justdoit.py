@@ -1614,7 +1614,7 @@ def _picaso_driver(bundle, opa, subs, calculation):
     of ``subs`` (``[(lo, hi, opacity object of the block)]``; the whole grid on one GPU is one block), a second and third
     copy the legs back.  Returns the output dictionary, or None when the call is outside what the driver covers
     (correlated-k tables, SH, patchy clouds, level fluxes, full_output, transmission, Oklopcic Raman, cloud tables
-    on their own grid, test modes) -- the caller then takes the call-by-call path, whose results these are bit for bit:
+    on their own grid in a multi-block call, test modes) -- the caller then takes the call-by-call path, whose results these are bit for bit:
     the C function chains the same entry points in the same order."""
     from . import driver as drv
     if os.environ.get("PICASO_AMD_NO_DRIVER") or os.environ.get("PICASO_AMD_RAMAN_PLANES"):
@@ -1636,7 +1636,10 @@ def _picaso_driver(bundle, opa, subs, calculation):
     atm = _setup_atmosphere(inp, opa, wno)
     cld = atm.layer["cloud"]
     cloud_free = bool(getattr(atm, "cloud_free", False))
-    if not cloud_free and isinstance(cld, CloudTables):
+    # cloud tables on their own wavenumber grid (what virga and the box-cloud form of clouds() hand over): regridded on the
+    # device as in compute_opacity_resident, for ONE block over the grid
+    tables = not cloud_free and isinstance(cld, CloudTables)
+    if tables and (len(subs) != 1 or np.size(cld.wno) != nwno or os.environ.get("PICASO_AMD_HOST_REGRID")):
         return None
     nlevel, nlayer = atm.c.nlevel, atm.c.nlayer
     opa.get_opacities(atm, exclude_mol=inp["atmosphere"]["exclude_mol"])
@@ -1667,14 +1670,14 @@ def _picaso_driver(bundle, opa, subs, calculation):
         mt = sub._mol_log if linear else sub._mol_raw
         return tuple(id(mt[m]) for m in plan["molecules"]) + tuple(id(sub._cia[p]) for p in plan["cia_pairs"])
     key = (tuple((lo, hi, id(sub)) + table_ids(sub) for lo, hi, sub in subs), nlayer, ng, nt, tuple(plan["molecules"]),
-           tuple(plan["cia_pairs"]), tuple(factors[2]), linear, tuple(sorted(want)), lean, not cloud_free, do_r, do_t)
+           tuple(plan["cia_pairs"]), tuple(factors[2]), linear, tuple(sorted(want)), lean, not cloud_free and not tables, do_r, do_t)
     cache = opa.__dict__.setdefault("_driver_tables", {})
     table = cache.get(key)
     if table is None:
         if len(cache) > 8:
             cache.clear()
         table = cache[key] = drv.BlockTable(subs, nlayer, ng, nt, plan["molecules"], plan["cia_pairs"], factors[2], linear,
-                                            want, lean, not cloud_free, do_r, do_t, _constant_planes)
+                                            want, lean, not cloud_free and not tables, do_r, do_t, _constant_planes)
     nostar = inp["star"]["database"] == "nostar"
     F0PI = _ones(opa, nwno) if nostar else inp["star"]["relative_flux"]
     stellar = getattr(opa, "unshifted_stellar_spec", None)
@@ -1692,7 +1695,15 @@ def _picaso_driver(bundle, opa, subs, calculation):
         full["albedo"] = np.empty(nwno + 1 if integrals else nwno)
     if do_t:
         full["thermal"] = np.empty(nwno + 1 if integrals else nwno)
-    if not cloud_free:
+    dcld = None
+    if tables:
+        stack = cld.__dict__.get("_stack")
+        if stack is None:
+            stack = cld.__dict__["_stack"] = np.concatenate([cld.compact[k] for k in ("opd", "w0", "g0")])
+        all3 = device.regrid_rows(cld.in_wno, stack, optics._wno_device(opa, cld.wno), opa.ctx).reshape((3, nlayer, nwno))
+        dcld = [all3.row_block(0), all3.row_block(1), all3.row_block(2)]
+        hold.append((all3, dcld))
+    elif not cloud_free:
         def plane(x):
             a = np.asarray(x, dtype=float)
             return a if (a.shape == (nlayer, nwno) and a.flags.c_contiguous) else \
@@ -1711,9 +1722,16 @@ def _picaso_driver(bundle, opa, subs, calculation):
             k.raman = drv._dev(row)
         else:
             k.raman = None
-        if not cloud_free:
+        if dcld is not None:
+            k.cld_opd, k.cld_w0, k.cld_g0 = (drv._dev(x) for x in dcld)
+            k.cld_host_opd = k.cld_host_w0 = k.cld_host_g0 = None
+        elif not cloud_free:
+            k.cld_opd = k.cld_w0 = k.cld_g0 = None
             k.cld_host_opd, k.cld_host_w0, k.cld_host_g0 = (drv._host(h) for h in hcld)
             k.cld_host_pitch = nwno
+        else:
+            k.cld_opd = k.cld_w0 = k.cld_g0 = None
+            k.cld_host_opd = k.cld_host_w0 = k.cld_host_g0 = None
         tctx = sub.ctx
         if do_t:
             if overlap:

@@ -102,3 +102,31 @@ def test_driver_lean_planes(monkeypatch):
     _case(og, jdi, True, True, "none", True).spectrum(opa, calculation="reflected")
     t_cld = [t for t in opa.__dict__["_driver_tables"].values() if t is not t_lean and t is not t_full][0]
     assert len(t_cld.want) == 11
+
+
+def test_driver_cloud_tables_on_their_own_grid(monkeypatch):
+    """Cloud tables on a wavenumber grid of their own (virga; the box-cloud form of clouds()): regridded on the device and
+    handed to the driver as device planes -- same bits as the call-by-call path and as the host regrid."""
+    from picaso_amd import justdoit as jdi
+    og = np.load(os.path.join(GOLDEN, "optics.npz"))
+    opa = jdi.opannection(filename_db=DB, query_method="linear")
+    nlayer = len(og["in/tlevel"]) - 1
+    rng = np.random.default_rng(3)
+    cw = np.sort(rng.uniform(opa.wno.min() * 0.9, opa.wno.max() * 1.1, 37))
+
+    def make():
+        case = _case(og, jdi, False, True, "none", True)
+        case.clouds(df={"opd": 0.3 * rng.random((nlayer, 37)), "w0": 0.5 + 0.49 * rng.random((nlayer, 37)),
+                        "g0": 0.9 * rng.random((nlayer, 37))}, wavenumber=cw)
+        return case
+    case = make()
+    from picaso_amd.atmsetup import CloudTables
+    atm = jdi._setup_atmosphere(case.inputs, opa, opa.wno)
+    if not isinstance(atm.layer["cloud"], CloudTables):
+        pytest.skip("clouds(df=) with a wavenumber column does not produce tables on their own grid here")
+    got = case.spectrum(opa, calculation="reflected+thermal")
+    assert len(opa.__dict__.get("_driver_tables", {})) == 1
+    monkeypatch.setenv("PICASO_AMD_NO_DRIVER", "1")
+    _same(case.spectrum(opa, calculation="reflected+thermal"), got)
+    monkeypatch.setenv("PICASO_AMD_HOST_REGRID", "1")
+    _same(case.spectrum(opa, calculation="reflected+thermal"), got)
