@@ -577,7 +577,9 @@ int picaso_compute_opacity_ck_dev(picaso_ctx *ctx, int nlayer, int nwno, int nga
  * level planes tau / tau_og (running sums down a column, optics.py:353-354, 418-420): those are a second, small launch --
  * level_sums = 1: issued here; 0: left to the caller (picaso_level_sums_dev), who may first let another stream start
  * on the layer planes (the thermal leg reads no level plane).  Output planes may be NULL as for compute_opacity; tau
- * needs dtau, tau_og needs dtau_og. */
+ * needs dtau, tau_og needs dtau_og.  Cloud: three (nlayer, nwno) planes, or -- cld_nin >= 2 -- tables on their own grid
+ * cld_xp (cld_nin, increasing), cld_fp (3 nlayer, cld_nin: opd rows, w0 rows, g0 rows), interpolated to the wavenumbers
+ * cld_x (nwno) inside the launch with numpy.interp's bits (picaso_regrid_rows_dev's), no regridded planes in HBM. */
 int picaso_gas_compute_opacity_dev(picaso_ctx *ctx, int nlayer, int nwno, int mol_mode, int nmol,
                                    const double *const *mol_tables, const int *mol_rows, const double *mol_wts,
                                    const double *mol_fac, int cont_mode, int ncont, const double *const *cont_tables,
@@ -587,7 +589,8 @@ int picaso_gas_compute_opacity_dev(picaso_ctx *ctx, int nlayer, int nwno, int mo
                                    int raman_rows, double raman_const, int test_mode, int delta_eddington, int stream,
                                    double *dtau, double *tau, double *w0, double *cosb, double *ftau_cld,
                                    double *ftau_ray, double *gcos2, double *dtau_og, double *tau_og, double *w0_og,
-                                   double *cosb_og, double *w0_no_raman, double *f_deltaM, int level_sums);
+                                   double *cosb_og, double *w0_no_raman, double *f_deltaM, int level_sums, int cld_nin,
+                                   const double *cld_xp, const double *cld_fp, const double *cld_x);
 /* tau[0] = 0, tau[i + 1] = tau[i] + dtau[i] for (nlayer, ncol) layer planes -> (nlayer + 1, ncol) level planes; either
  * pair may be NULL */
 int picaso_level_sums_dev(picaso_ctx *ctx, int nlayer, long ncol, const double *dtau, double *tau, const double *dtau_og,
@@ -668,6 +671,10 @@ typedef struct picaso_block {
      * whatever order the legs are collected in.  Without them collect issues a synchronous copy. */
     double *albedo_pin, *thermal_pin;
     void *albedo_mark, *thermal_mark;
+    /* cloud tables on their own grid (device): cld_tab_nin points cld_tab_xp, rows cld_tab_fp (3 nlayer, cld_tab_nin);
+     * interpolated to `wno` inside the fused opacity launch (picaso_gas_compute_opacity_dev); 0 = none */
+    int cld_tab_nin;
+    const double *cld_tab_xp, *cld_tab_fp;
 } picaso_block;
 typedef struct picaso_spectrum_job {
     int nlayer;

@@ -56,10 +56,12 @@ extern "C" int picaso_toon_spectrum_blocks(int nblocks, picaso_block *blocks, co
                                                   j.cont_wts, j.cont_fac, j.nray, k.ray_tabs, j.ray_fac, cld[0], cld[1],
                                                   cld[2], k.raman, j.raman_rows, j.raman_const, j.test_mode,
                                                   j.delta_eddington, j.stream, o[0], o[1], o[2], o[3], o[4], o[5], o[6],
-                                                  o[7], o[8], o[9], o[10], o[11], o[12], 0));
+                                                  o[7], o[8], o[9], o[10], o[11], o[12], 0, k.cld_tab_nin, k.cld_tab_xp,
+                                                  k.cld_tab_fp, k.cld_tab_nin ? k.wno : nullptr));
             if (tctx != k.ctx && j.do_thermal) PZ_TRY(picaso_ctx_wait(tctx, k.ctx));
             PZ_TRY(picaso_level_sums_dev(k.ctx, j.nlayer, k.nwno, o[0], o[1], o[7], o[8]));
         } else {
+            if (k.cld_tab_nin) return fail(k.ctx, "toon_spectrum_blocks: cloud tables need the fused opacity launch");
             PZ_TRY(picaso_opacity_gas_ck_dev(k.ctx, j.nlayer, k.nwno, 1, j.mol_mode, j.nmol, k.mol_tabs, j.mol_rows,
                                              j.mol_wts, j.mol_fac, j.cont_interp, j.ncont, k.cont_tabs, j.cont_rows,
                                              j.cont_wts, j.cont_fac, j.nray, k.ray_tabs, j.ray_fac, k.taugas, k.tauray));

@@ -18,6 +18,10 @@ struct MixArgs {
                       // inputs; taugas / tauray / raman are facet-major (nfac, nlayer, nwno), as the per-facet
                       // gas launches write them (ncolper must be 1)
     const double *taugas, *tauray, *taucld, *w0c, *g0c, *raman;
+    // fused launch only: cloud tables on their own grid, interpolated where they are used (regrid_value: numpy.interp's
+    // bits) instead of three regridded planes -- cld_fp = (3 nlayer, cld_nin): the opd rows, the w0 rows, the g0 rows
+    int cld_nin;
+    const double *cld_xp, *cld_fp, *cld_x;
     double raman_const;
     int raman_row;    // raman is one row (nwno) for every layer and facet (the Pollack table) instead of a plane
     double *dtau, *tau, *w0, *cosb, *ftau_cld, *ftau_ray, *gcos2, *dtau_og, *tau_og, *w0_og,
@@ -87,6 +91,56 @@ __device__ __forceinline__ void mix_layer(const MixArgs &a, long q, long qn, dou
         if (a.dtau) a.dtau[q] = dtau;
         if (a.tau) a.tau[qn] = tau_run;
     }
+}
+
+// numpy.interp(x, xp, row) for one x against many rows (reference wavelength.regrid, wavelength.py:46-70): the bracket of x
+// in xp once, then per row the slope form numpy evaluates -- shared by k_regrid_rows and the fused gas + mixing launch, so
+// a cloud table interpolated where it is used carries the bits of the regridded plane.
+struct RegridBracket {
+    int j, j0, j1;
+    bool knot;
+    double xv, x0, x1;
+};
+__device__ __forceinline__ RegridBracket regrid_bracket(const double *xp, int nin, double xv)
+{
+    RegridBracket b;
+    const int last = nin - 1;
+    int j;                       // -1: left of the grid, nin: right of it, else xp[j] <= x (< xp[j+1])
+    if (xv != xv) j = -2;
+    else if (xv > xp[last]) j = nin;
+    else if (xv < xp[0]) j = -1;
+    else {
+        int lo = 0, hi = last;   // xp[lo] <= x <= xp[hi]
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (xv >= xp[mid]) lo = mid;
+            else hi = mid;
+        }
+        j = (xv >= xp[hi]) ? hi : lo;
+    }
+    const bool edge = (j < 0) || (j >= last);
+    b.j = j;
+    b.j0 = j < 0 ? 0 : (j >= last ? last : j);
+    b.j1 = edge ? b.j0 : b.j0 + 1;
+    b.xv = xv;
+    b.x0 = xp[b.j0];
+    b.x1 = xp[b.j1];
+    b.knot = edge || (b.x0 == xv);
+    return b;
+}
+__device__ __forceinline__ double regrid_value(const double *row, const RegridBracket &b)
+{
+#pragma clang fp contract(off)
+    const double y0 = row[b.j0], y1 = row[b.j1];
+    if (b.j == -2) return b.xv;
+    if (b.knot) return y0;
+    const double slope = (y1 - y0) / (b.x1 - b.x0);
+    double v = slope * (b.xv - b.x0) + y0;
+    if (v != v) {
+        v = slope * (b.xv - b.x1) + y1;
+        if (v != v && y0 == y1) v = y0;
+    }
+    return v;
 }
 
 struct GasArgs {
@@ -231,12 +285,23 @@ __global__ __launch_bounds__(256) void k_opacity_gas(const GasArgs a)
                 }
             } else {
                 const MixArgs &m = a.mix;
+                RegridBracket cb{};
+                if (m.cld_nin) cb = regrid_bracket(m.cld_xp, m.cld_nin, m.cld_x[w]);
 #pragma unroll
                 for (int l = 0; l < GAS_LT; ++l) {
                     if (l < nl) {
                         const long o = (long)(l0 + l) * nw + w;
-                        const double tc = m.taucld ? m.taucld[o] : 0.0, wc = m.w0c ? m.w0c[o] : 0.0,
-                                     gc = m.g0c ? m.g0c[o] : 0.0;
+                        double tc, wc, gc;
+                        if (m.cld_nin) {
+                            const double *row = m.cld_fp + (long)(l0 + l) * m.cld_nin;
+                            tc = regrid_value(row, cb);
+                            wc = regrid_value(row + (long)m.nlayer * m.cld_nin, cb);
+                            gc = regrid_value(row + 2L * m.nlayer * m.cld_nin, cb);
+                        } else {
+                            tc = m.taucld ? m.taucld[o] : 0.0;
+                            wc = m.w0c ? m.w0c[o] : 0.0;
+                            gc = m.g0c ? m.g0c[o] : 0.0;
+                        }
                         const double rf = rf_plane ? m.raman[o] : rf_row;
                         mix_layer(m, o, o, tg[l], tr[l], tc, wc, gc, rf, run0, run1);
                     }
@@ -434,39 +499,9 @@ __global__ __launch_bounds__(256) void k_regrid_rows(const RegridArgs a)
     const double *xp = in_lds ? sxp : a.xp;
     const long w = blockIdx.x * (long)blockDim.x + threadIdx.x;
     if (w >= a.nwno) return;
-    const double xv = a.x[w];
-    const int last = a.nin - 1;
-    int j;                       // -1: left of the grid, nin: right of it, else xp[j] <= x (< xp[j+1])
-    if (xv != xv) j = -2;
-    else if (xv > xp[last]) j = a.nin;
-    else if (xv < xp[0]) j = -1;
-    else {
-        int lo = 0, hi = last;   // xp[lo] <= x <= xp[hi]
-        while (hi - lo > 1) {
-            const int mid = (lo + hi) >> 1;
-            if (xv >= xp[mid]) lo = mid;
-            else hi = mid;
-        }
-        j = (xv >= xp[hi]) ? hi : lo;
-    }
-    const bool edge = (j < 0) || (j >= last);
-    const int j0 = j < 0 ? 0 : (j >= last ? last : j), j1 = edge ? j0 : j0 + 1;
-    const double x0 = xp[j0], x1 = xp[j1];
-    const bool knot = edge || (x0 == xv);
+    const RegridBracket b = regrid_bracket(xp, a.nin, a.x[w]);
     for (int r = 0; r < a.nrows; ++r) {
-        const double *row = a.fp + (long)r * a.nin;
-        const double y0 = row[j0], y1 = row[j1];
-        double v;
-        if (j == -2) v = xv;
-        else if (knot) v = y0;
-        else {
-            const double slope = (y1 - y0) / (x1 - x0);
-            v = slope * (xv - x0) + y0;
-            if (v != v) {
-                v = slope * (xv - x1) + y1;
-                if (v != v && y0 == y1) v = y0;
-            }
-        }
+        const double v = regrid_value(a.fp + (long)r * a.nin, b);
         a.out[(long)r * a.nwno + w] = a.has_scale ? a.scale * v : v;
     }
 }
@@ -676,7 +711,7 @@ static int gas_launch(picaso_ctx *ctx, int nlayer, int nwno, int ngauss, int mol
     a.taugas = taugas; a.tauray = tauray;
     if (mix) {
         const MixArgs &m = *mix;
-        const bool lean = !m.taucld && !m.w0c && !m.g0c && !m.test_mode && !m.cosb && !m.ftau_cld && !m.ftau_ray &&
+        const bool lean = !m.taucld && !m.w0c && !m.g0c && !m.cld_nin && !m.test_mode && !m.cosb && !m.ftau_cld && !m.ftau_ray &&
                           !m.gcos2 && !m.dtau_og && !m.w0_og && !m.cosb_og && !m.f_deltaM;
         a.fuse = lean ? 2 : 1;
         a.mix = m;
@@ -732,10 +767,14 @@ int picaso_gas_compute_opacity_dev(picaso_ctx *ctx, int nlayer, int nwno, int mo
                                    int raman_rows, double raman_const, int test_mode, int delta_eddington, int stream,
                                    double *dtau, double *tau, double *w0, double *cosb, double *ftau_cld,
                                    double *ftau_ray, double *gcos2, double *dtau_og, double *tau_og, double *w0_og,
-                                   double *cosb_og, double *w0_no_raman, double *f_deltaM, int level_sums)
+                                   double *cosb_og, double *w0_no_raman, double *f_deltaM, int level_sums, int cld_nin,
+                                   const double *cld_xp, const double *cld_fp, const double *cld_x)
 {
     if (!ctx) return fail(nullptr, "null context");
     if (nlayer < 1 || nwno < 1) return fail(ctx, "gas_compute_opacity: bad sizes");
+    if (cld_nin < 0 || (cld_nin > 0 && (cld_nin < 2 || !cld_xp || !cld_fp || !cld_x || taucld || w0_cld || g0_cld)))
+        return fail(ctx, "gas_compute_opacity: cloud tables need cld_nin >= 2, their grid, their rows and the wavenumbers, "
+                         "and exclude cloud planes");
     if (test_mode < 0 || test_mode > 2) return fail(ctx, "gas_compute_opacity: test_mode must be 0, 1 or 2");
     if (stream != 2 && stream != 4) return fail(ctx, "gas_compute_opacity: stream must be 2 or 4");
     if (raman_factor && raman_rows != 0 && raman_rows != nlayer)
@@ -747,6 +786,7 @@ int picaso_gas_compute_opacity_dev(picaso_ctx *ctx, int nlayer, int nwno, int mo
     m.delta_eddington = delta_eddington; m.stream = stream;
     m.taucld = taucld; m.w0c = w0_cld; m.g0c = g0_cld; m.raman = raman_factor; m.raman_const = raman_const;
     m.raman_row = raman_factor && raman_rows == 0;
+    m.cld_nin = cld_nin; m.cld_xp = cld_xp; m.cld_fp = cld_fp; m.cld_x = cld_x;
     m.dtau = dtau; m.tau = nullptr; m.w0 = w0; m.cosb = cosb; m.ftau_cld = ftau_cld; m.ftau_ray = ftau_ray;
     m.gcos2 = gcos2; m.dtau_og = dtau_og; m.tau_og = nullptr; m.w0_og = w0_og; m.cosb_og = cosb_og;
     m.w0_no_raman = w0_no_raman; m.f_deltaM = f_deltaM;

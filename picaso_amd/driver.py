@@ -34,7 +34,8 @@ class Block(ctypes.Structure):
                 ("th_dtau", _dp), ("th_w0", _dp), ("th_cosb", _dp),
                 ("xint", _dp), ("albedo", _dp), ("flux", _dp), ("disk", _dp),
                 ("albedo_host", _dp), ("thermal_host", _dp), ("trapz_d", _dp), ("trapz_dr", _dp), ("stellar", _dp),
-                ("albedo_pin", _dp), ("thermal_pin", _dp), ("albedo_mark", ctypes.c_void_p), ("thermal_mark", ctypes.c_void_p)]
+                ("albedo_pin", _dp), ("thermal_pin", _dp), ("albedo_mark", ctypes.c_void_p), ("thermal_mark", ctypes.c_void_p),
+                ("cld_tab_nin", ctypes.c_int), ("cld_tab_xp", _dp), ("cld_tab_fp", _dp)]
 
 
 class Job(ctypes.Structure):

@@ -1695,14 +1695,20 @@ def _picaso_driver(bundle, opa, subs, calculation):
         full["albedo"] = np.empty(nwno + 1 if integrals else nwno)
     if do_t:
         full["thermal"] = np.empty(nwno + 1 if integrals else nwno)
-    dcld = None
+    dcld = dtab = None
     if tables:
         stack = cld.__dict__.get("_stack")
         if stack is None:
             stack = cld.__dict__["_stack"] = np.concatenate([cld.compact[k] for k in ("opd", "w0", "g0")])
-        all3 = device.regrid_rows(cld.in_wno, stack, optics._wno_device(opa, cld.wno), opa.ctx).reshape((3, nlayer, nwno))
-        dcld = [all3.row_block(0), all3.row_block(1), all3.row_block(2)]
-        hold.append((all3, dcld))
+        if os.environ.get("PICASO_AMD_UNFUSED_OPACITY") or os.environ.get("PICASO_AMD_REGRID_PLANES"):
+            all3 = device.regrid_rows(cld.in_wno, stack, optics._wno_device(opa, cld.wno), opa.ctx).reshape((3, nlayer, nwno))
+            dcld = [all3.row_block(0), all3.row_block(1), all3.row_block(2)]
+            hold.append((all3, dcld))
+        else:           # interpolated inside the opacity launch: no regridded planes in HBM (same bits)
+            dtab = (int(np.size(cld.in_wno)),
+                    DeviceArray.from_host(np.ascontiguousarray(cld.in_wno, dtype=np.float64), opa.ctx),
+                    DeviceArray.from_host(np.ascontiguousarray(stack, dtype=np.float64), opa.ctx))
+            hold.append(dtab)
     elif not cloud_free:
         def plane(x):
             a = np.asarray(x, dtype=float)
@@ -1722,7 +1728,13 @@ def _picaso_driver(bundle, opa, subs, calculation):
             k.raman = drv._dev(row)
         else:
             k.raman = None
-        if dcld is not None:
+        k.cld_tab_nin, k.cld_tab_xp, k.cld_tab_fp = 0, None, None
+        if dtab is not None:
+            k.cld_opd = k.cld_w0 = k.cld_g0 = None
+            k.cld_host_opd = k.cld_host_w0 = k.cld_host_g0 = None
+            k.cld_tab_nin, k.cld_tab_xp, k.cld_tab_fp = dtab[0], drv._dev(dtab[1]), drv._dev(dtab[2])
+            k.wno = drv._dev(_resident_vector(sub, "wno", sub.wno, nw))
+        elif dcld is not None:
             k.cld_opd, k.cld_w0, k.cld_g0 = (drv._dev(x) for x in dcld)
             k.cld_host_opd = k.cld_host_w0 = k.cld_host_g0 = None
         elif not cloud_free:

@@ -1078,7 +1078,19 @@ def compute_opacity_resident(atmosphere, opacityclass, ngauss=1, stream=2, delta
         t = plane(cld["opd"])
         return fthin_cld * t if do_holes else t             # optics.py:314-315
     on_device = isinstance(cld, CloudTables) and np.size(cld.wno) == nwno and not os.environ.get("PICASO_AMD_HOST_REGRID")
+    cld_tab = (_ci(0), None, None, None)
+    tab_keep = None
     if getattr(atm, "cloud_free", False) and not do_holes:  # no cloud profile: NULL planes read as zero
+        d_cld = d_w0 = d_g0 = None
+    elif on_device and fused and not do_holes and not os.environ.get("PICASO_AMD_REGRID_PLANES"):
+        # tables on their own wavenumber grid, interpolated INSIDE the fused opacity launch (numpy.interp's bits, as
+        # picaso_regrid_rows_dev): no regridded planes in HBM
+        stack = cld.__dict__.get("_stack")
+        if stack is None:
+            stack = cld.__dict__["_stack"] = np.concatenate([cld.compact[k] for k in ("opd", "w0", "g0")])
+        tab_keep = (DeviceArray.from_host(np.ascontiguousarray(cld.in_wno, dtype=np.float64), ctx),
+                    DeviceArray.from_host(np.ascontiguousarray(stack, dtype=np.float64), ctx), _wno_device(opa, cld.wno))
+        cld_tab = (_ci(int(np.size(cld.in_wno))), ptr(tab_keep[0].addr), ptr(tab_keep[1].addr), ptr(tab_keep[2].addr))
         d_cld = d_w0 = d_g0 = None
     elif on_device:     # tables on their own wavenumber grid: interpolated where they are used (same bits)
         d_x = _wno_device(opa, cld.wno)
@@ -1109,7 +1121,9 @@ def compute_opacity_resident(atmosphere, opacityclass, ngauss=1, stream=2, delta
                 _cd(raman_const), _ci(tm), _ci(1 if delta_eddington else 0), _ci(stream),
                 *[ptr(out[k].addr) if out[k] is not None else None for k in OUT_NAMES])
     if fused:
-        gas_stage(atm, opa, None, None, mix=mix_args + (_ci(1),))
+        gas_stage(atm, opa, None, None, mix=mix_args + (_ci(1),) + cld_tab)
+        if tab_keep is not None:
+            out["_cloud_tables"] = tab_keep          # the launch is asynchronous: its inputs live as long as its outputs
     else:
         check(load().picaso_compute_opacity_ck_dev(ctx, _ci(nlayer), _ci(nwno), _ci(ngauss), ptr(taugas.addr),
                                                    ptr(tauray.addr), *mix_args), ctx)

@@ -294,6 +294,24 @@ def test_fuzz_fused_opacity_equals_two_launches():
         cl = [DeviceArray.from_host(x, ctx) for x in (
             np.where(rng.random((nlayer, nwno)) < 0.4, 10.0 ** rng.uniform(-3, 1, (nlayer, nwno)), 0.0),
             0.2 + 0.79 * rng.random((nlayer, nwno)), 0.95 * rng.random((nlayer, nwno)))] if cloudy else [None] * 3
+        # every other cloudy case: the cloud as tables on a grid of their own -- regridded planes (picaso_regrid_rows_dev)
+        # for the two launches, the tables themselves for the fused one
+        tab = (0, None, None, None)
+        if cloudy and it % 2:
+            from picaso_amd import device as pdev
+            nin = int(rng.integers(2, 40))
+            xg = np.sort(rng.uniform(900.0, 36000.0, nin))
+            xw = np.sort(rng.uniform(1000.0, 35000.0, nwno))
+            if nwno > 2:
+                xw[1] = xg[min(1, nin - 1)]                          # a knot, and points outside the table's grid
+                xw[0], xw[-1] = xg[0] - 5.0, xg[-1] + 5.0
+            fp = np.concatenate([10.0 ** rng.uniform(-3, 1, (nlayer, nin)) * (rng.random((nlayer, nin)) < 0.6),
+                                 0.2 + 0.79 * rng.random((nlayer, nin)), 0.95 * rng.random((nlayer, nin))])
+            d_x = DeviceArray.from_host(xw, ctx)
+            planes = pdev.regrid_rows(xg, fp, d_x, ctx).reshape((3, nlayer, nwno))
+            cl = [planes.row_block(0), planes.row_block(1), planes.row_block(2)]
+            d_xg, d_fp = DeviceArray.from_host(xg, ctx), DeviceArray.from_host(fp, ctx)
+            tab = (nin, d_xg, d_fp, d_x)
         rmode = it % 3                                   # Raman: none, a plane, one row
         raman = None if rmode == 0 else DeviceArray.from_host(
             rng.random((nlayer, nwno) if rmode == 1 else (nwno,)) * 0.99999, ctx)
@@ -316,9 +334,11 @@ def test_fuzz_fused_opacity_equals_two_launches():
         check(load().picaso_opacity_gas_ck_dev(ctx, ci(nlayer), ci(nwno), ci(1), *gas, ptr(tg.addr), ptr(tr.addr)), ctx)
         check(load().picaso_compute_opacity_ck_dev(ctx, ci(nlayer), ci(nwno), ci(1), ptr(tg.addr), ptr(tr.addr), *mix,
                                                    *[ptr(o.addr) if o is not None else None for o in o1]), ctx)
-        check(load().picaso_gas_compute_opacity_dev(ctx, ci(nlayer), ci(nwno), *gas, *mix,
+        mix2 = mix if not tab[0] else (None, None, None) + mix[3:]
+        check(load().picaso_gas_compute_opacity_dev(ctx, ci(nlayer), ci(nwno), *gas, *mix2,
                                                     *[ptr(o.addr) if o is not None else None for o in o2],
-                                                    ci(1)), ctx)
+                                                    ci(1), ci(tab[0]), *[ptr(x.addr) if x is not None else None for x in tab[1:]]),
+              ctx)
         for k, a, b in zip(names, o1, o2):
             if a is not None:
                 ha, hb = a.to_host(), b.to_host()
