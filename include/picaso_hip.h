@@ -166,6 +166,16 @@ int picaso_get_reflected_1d_dev(picaso_ctx *ctx, int nlevel, int nwno, long plan
                                 double *flux_plus_midpt_all, const double *gweight,
                                 const double *tweight, double *albedo);
 
+/* Planes of picaso_get_reflected_1d_dev / _batch_dev that compute_opacity derives exactly from others may be NULL when
+ * the launch runs the default-options kernels: tau / tau_og (running sums of dtau / dtau_og from 0 at the top,
+ * optics.py:353-354, 418-420), gcos2 (0.5 ftau_ray, optics.py:342), and for a column without cloud cosb, cosb_og,
+ * ftau_cld, ftau_ray (0, 0, 0, 1) together with dtau_og, w0_og (cosb = 0: no delta-scaling) -- re-derived in the kernel
+ * with the same operations, so the same bits, and 3 to 9 of the 11 planes never travel through HBM.  Returns 1 when a
+ * call with these arguments may leave them out (the reference's default options: quadrature coefficients, TTHG_ray,
+ * N = 2, frac_c = 2; cos_theta = 1 in the symmetric geometry; no level fluxes), 0 when it needs all eleven. */
+int picaso_reflected_1d_can_derive(int nlevel, long plane_pitch, int numg, int numt, const double *ubar0,
+                                   const double *ubar1, double cos_theta, int single_phase, int multi_phase, double frac_c,
+                                   int toon_coefficients, int get_lvl_flux);
 /* `nspec` spectra of one shape and one option set in ONE launch (the reference runs the
  * spectra of a retrieval or the phases of a curve as separate processes -- driver.py:405-426,
  * justdoit.py:4741-4777 -- each calling get_reflected_1d, fluxes.py:1009-1413).  Every pointer argument of

@@ -509,8 +509,19 @@ static int reflected_1d_core(picaso_ctx *ctx, int nlevel, int nwno, int ncolper,
     if (!ctx) return fail(nullptr, "null context");
     if (nlevel < 2 || nwno < 1 || numg < 1 || numt < 1)
         return fail(ctx, "get_reflected_1d: bad sizes nlevel=%d nwno=%d numg=%d numt=%d", nlevel, nwno, numg, numt);
-    if (!dtau || !tau || !w0 || !cosb || !gcos2 || !ftau_cld || !ftau_ray || !dtau_og || !tau_og || !w0_og || !cosb_og)
-        return fail(ctx, "get_reflected_1d: all eleven planes are required");
+    // Planes the kernels can re-derive exactly may be NULL (picaso_reflected_1d_can_derive says when): tau / tau_og
+    // (running sums of dtau / dtau_og), gcos2 (0.5 ftau_ray), and -- a column without cloud -- cosb, cosb_og, ftau_cld,
+    // ftau_ray (0, 0, 0, 1) with dtau_og, w0_og (no delta-scaling: dtau, w0).  The cloud set goes together.
+    if (!dtau || !w0) return fail(ctx, "get_reflected_1d: dtau and w0 are required");
+    const bool clear_set = !ftau_cld;
+    if (clear_set ? (cosb || cosb_og || ftau_ray || gcos2) : (!cosb || !cosb_og || !ftau_ray))
+        return fail(ctx, "get_reflected_1d: cosb, cosb_og, ftau_cld, ftau_ray are given together or all left out (gcos2 "
+                         "too in the second case)");
+    if ((dtau_og == nullptr) != (w0_og == nullptr))
+        return fail(ctx, "get_reflected_1d: dtau_og and w0_og are given together or both left out");
+    const bool derived = !tau || !tau_og || !gcos2 || !ftau_cld || !dtau_og;
+    if (derived && (get_lvl_flux || !get_toa_intensity))
+        return fail(ctx, "get_reflected_1d: level fluxes need all eleven planes");
     const int nspec = bt ? bt->nspec : 1;
     const long ncol = (long)nwno * ncolper;
     if (plane_pitch < ncol) return fail(ctx, "get_reflected_1d: plane_pitch %ld < %ld columns", plane_pitch, ncol);
@@ -620,7 +631,7 @@ static int reflected_1d_core(picaso_ctx *ctx, int nlevel, int nwno, int ncolper,
         if (const char *e = getenv("PICASO_AMD_REFL_COOP_COLS")) coop_cols = atol(e);
         a.na = nang;
         a.ny = 1;
-        if (ncol <= coop_cols && reflected_coop_ok(a)) {
+        if (ncol <= coop_cols && !derived && reflected_coop_ok(a)) {
             for (int k = 0; k < nang; ++k)
                 a.ang[k] = make_refl_angle(ubar0[k], ubar1[k], fuse ? gweight[k / numt] : 0.0,
                                            fuse ? tweight[k % numt] : 0.0);
@@ -691,6 +702,19 @@ static int reflected_1d_core(picaso_ctx *ctx, int nlevel, int nwno, int ncolper,
     return 0;
 }
 
+int picaso_reflected_1d_can_derive(int nlevel, long plane_pitch, int numg, int numt, const double *ubar0,
+                                   const double *ubar1, double cos_theta, int single_phase, int multi_phase, double frac_c,
+                                   int toon_coefficients, int get_lvl_flux)
+{
+    if (!ubar0 || !ubar1 || nlevel < 2 || numg < 1 || numt < 1 || get_lvl_flux) return 0;
+    if (getenv("PICASO_AMD_REFL_GENERIC") || getenv("PICASO_AMD_REFL_ALL_PLANES")) return 0;
+    if ((double)plane_pitch * nlevel * 8.0 >= 4294967296.0) return 0;
+    bool zp = true;
+    for (int k = 0; k < numg * numt; ++k) zp = zp && (ubar0[k] == ubar1[k]);
+    return (toon_coefficients == 0 && single_phase == 3 && multi_phase == 0 && frac_c == 2.0 && (!zp || cos_theta == 1.0))
+               ? 1 : 0;
+}
+
 int picaso_get_reflected_1d_batch_dev(picaso_ctx *ctx, int nspec, int nlevel, int nwno, long plane_pitch, int numg,
                                       int numt, const double *const *dtau, const double *const *tau,
                                       const double *const *w0, const double *const *cosb,
@@ -711,8 +735,9 @@ int picaso_get_reflected_1d_batch_dev(picaso_ctx *ctx, int nspec, int nlevel, in
     const double *const *pl[11] = {dtau, tau, w0, cosb, gcos2, ftau_cld, ftau_ray, dtau_og, tau_og, w0_og, cosb_og};
     for (int j = 0; j < 11; ++j) {
         if (!pl[j]) return fail(ctx, "get_reflected_1d_batch: all eleven plane pointer arrays are required");
-        for (int s = 0; s < nspec; ++s)
-            if (!pl[j][s]) return fail(ctx, "get_reflected_1d_batch: plane %d of spectrum %d is NULL", j, s);
+        for (int s = 0; s < nspec; ++s)                  // planes left out (see reflected_1d_core): by every spectrum or by none
+            if ((pl[j][s] == nullptr) != (pl[j][0] == nullptr))
+                return fail(ctx, "get_reflected_1d_batch: plane %d is given for some spectra and left out for others", j);
     }
     if (!surf_reflect || !F0PI || !xint_at_top || !ubar0 || !ubar1 || !cos_theta)
         return fail(ctx, "get_reflected_1d_batch: null argument");

@@ -415,7 +415,9 @@ __device__ __forceinline__ void reflected_toa_body(const ReflectedArgs &a, const
     //   ftau_cld (with cosb, cosb_og, ftau_ray, gcos2): column without cloud: 0, 0, 0, 1, 0.5 (optics.py:335-342
     //                    with TAUCLD = 0)
     //   dtau_og / w0_og: no delta-scaling (cosb = 0: f = 0, optics.py:412-420 reduce to x*1): dtau / w0
-    // all wave-uniform (kernel arguments); the 1-D launches always pass every plane
+    // all wave-uniform (kernel arguments).  The 1-D default-options launches take the same patterns (round 4: the product
+    // leaves tau / tau_og / gcos2 -- and for a cloud-free atmosphere everything but dtau and w0 -- out of HBM; the caller
+    // asks picaso_reflected_1d_can_derive first); every other 1-D launch is handed all eleven planes
     const bool derive_tau = DRV && a.tau == nullptr, derive_tauo = DRV && a.tau_og == nullptr;
     const bool derive_g2 = DRV && a.gcos2 == nullptr, clear = DRV && a.ftau_cld == nullptr;
     const bool alias_og = DRV && a.dtau_og == nullptr;
@@ -444,6 +446,25 @@ __device__ __forceinline__ void reflected_toa_body(const ReflectedArgs &a, const
         return *(const double *)((const char *)base + off);
     };
     auto load = [&](LayerIn &L, int i) {
+        if constexpr (FAST && PZ_REFL_SADDR && DRV) {      // 1-D with planes left out: only what exists is loaded
+            const unsigned o = voff0 + (unsigned)i * pitch8;
+            L.dt = ld(a.dtau, o);
+            L.w0 = ld(a.w0, o);
+            if (!derive_tau) L.tau_n = ld(a.tau + pitch, o);
+            if (!clear) {
+                L.g = ld(a.cosb, o);
+                L.fc = ld(a.ftau_cld, o);
+                L.fr = ld(a.ftau_ray, o);
+                L.cbo = ld(a.cosb_og, o);
+                if (!derive_g2) L.gcos2 = ld(a.gcos2, o);
+            }
+            if (!alias_og) {
+                L.dto = ld(a.dtau_og, o);
+                L.w0o = ld(a.w0_og, o);
+            }
+            if (!derive_tauo) L.tauo = ld(a.tau_og, o);
+            return;
+        }
         if constexpr (FAST && PZ_REFL_SADDR) {
             const unsigned o = voff0 + (unsigned)i * pitch8;
             L.dt = ld(a.dtau, o);
@@ -690,6 +711,21 @@ static int launch1d(picaso_ctx *ctx, const ReflectedArgs &a_in)
         big = a.ny <= 1 && (long)nspec * ncg * (block / 64) <= 1024 && getenv("PICASO_AMD_REFL_NO_BIG") == nullptr;
     const bool fast = fast_options(a, zp);
 #define PZ_GO(KERNEL) hipLaunchKernelGGL(KERNEL, grid, dim3(block), 0, ctx->stream, a)
+    // planes left out (re-derived in the kernel): the default-options kernels only -- reflected_1d_can_derive() is the
+    // caller's way to know
+    const bool drv = !(a.tau && a.tau_og && a.gcos2 && a.ftau_cld && a.dtau_og);
+    if (drv) {
+        if (!fast) return fail(ctx, "reflected: planes may be left out only with the reference's default options");
+        if (a.batch) {
+            if (zp && big) { if constexpr (NA == 5) PZ_GO((k_reflected_toa_batch<NA, false, true, true, true, true>)); }
+            else if (zp) PZ_GO((k_reflected_toa_batch<NA, false, true, true, false, true>));
+            else PZ_GO((k_reflected_toa_batch<NA, false, false, true, false, true>));
+        } else if (zp && big) { if constexpr (NA == 5) PZ_GO((k_reflected_toa<NA, false, true, true, true, true>)); }
+        else if (zp) PZ_GO((k_reflected_toa<NA, false, true, true, false, true>));
+        else PZ_GO((k_reflected_toa<NA, false, false, true, false, true>));
+        PZ_HIP(ctx, hipGetLastError());
+        return 0;
+    }
     if (a.batch) {
         if (zp && fast && big) {
             if constexpr (NA == 5) PZ_GO((k_reflected_toa_batch<NA, false, true, true, true>));

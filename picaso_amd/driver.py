@@ -77,7 +77,7 @@ class BlockTable:
     of the same signature: every access is ordered on the blocks' streams."""
 
     def __init__(self, subs, nlayer, ng, nt, mol_names, cia_pairs, ray_names, linear, want, lean, host_cloud,
-                 do_reflected, do_thermal, const_planes):
+                 do_reflected, do_thermal, const_planes, derive=False):
         self.subs, self.n = subs, len(subs)
         self.blocks = (Block * self.n)()
         self.keep = []                                   # DeviceArrays and pointer tables the structs point into
@@ -102,7 +102,14 @@ class BlockTable:
                     pl[name] = DeviceArray((nlayer + 1 if name in ("tau", "tau_og") else nlayer, nw), ctx)
                     self.keep.append(pl[name])
                     k.planes[i] = _dev(pl[name])
-            if lean:                                     # justdoit.picaso: aliases and constants of a cloud-free atmosphere
+            rpl = pl
+            if lean and derive:                          # the reflected kernel re-derives all but dtau and w0
+                zero, one, half = const_planes(sub, nlayer, nw)
+                rpl = {"dtau": pl["dtau"], "w0": pl.get("w0")}
+                pl.update(dtau_og=pl["dtau"], cosb_og=zero)
+                if "w0_no_raman" not in pl and "w0" in pl:
+                    pl["w0_no_raman"] = pl["w0"]
+            elif lean:                                   # justdoit.picaso: aliases and constants of a cloud-free atmosphere
                 zero, one, half = const_planes(sub, nlayer, nw)
                 pl.update(dtau_og=pl["dtau"], cosb=zero, cosb_og=zero, ftau_cld=zero, ftau_ray=one, gcos2=half)
                 if "tau" in pl:
@@ -111,7 +118,7 @@ class BlockTable:
                     pl["w0_no_raman"] = pl["w0"]
             if do_reflected:
                 for i, name in enumerate(REFL_NAMES):
-                    k.refl_planes[i] = _dev(pl[name])
+                    k.refl_planes[i] = _dev(rpl.get(name))       # None: left out, re-derived in the kernel
                 x, a = DeviceArray((ng, nt, nw), ctx), DeviceArray((nw + 1,), ctx)     # [nw]: the Bond-albedo integral
                 pin = PinnedArray((nw + 1,), ctx)           # the result copy is enqueued with the launches
                 self.keep += [x, a, pin]

@@ -1263,7 +1263,7 @@ def picaso(bundle, opacityclass, dimension="1d", calculation="reflected", full_o
         atm = _setup_atmosphere(inp, opa, wno)
     nlevel, nlayer = atm.c.nlevel, atm.c.nlayer
 
-    fhole = planes = planes_clear = None
+    fhole = planes = planes_clear = rplanes = None
     gauss_wts = np.asarray(opa.gauss_wts, dtype=float)
     if dimension == "1d":
         if _shared is not None and _shared.get("plan") is not None:
@@ -1273,10 +1273,19 @@ def picaso(bundle, opacityclass, dimension="1d", calculation="reflected", full_o
         # only the planes the requested legs read are written (toon: 11 for reflected light, 3 for
         # thermal emission, 1 for transmission; the SH solvers take the whole set)
         want = None
+        # planes the reflected kernels re-derive exactly are not written at all where the launch can do so (default
+        # options; resident.reflected_can_derive): tau, tau_og (running sums), gcos2 (0.5 ftau_ray)
+        derive = (not is_sh and ngauss == 1 and "reflected" in calculation and not do_holes and inp["test_mode"] is None
+                  and not full_output and not os.environ.get("PICASO_AMD_ALL_PLANES")
+                  and resident.reflected_can_derive(nlevel, nwno, ng, nt, ubar0, ubar1, cos_theta, toon["single_phase"],
+                                                    toon["multi_phase"], frac_c, toon["toon_coefficients"],
+                                                    atm.get_lvl_flux))
         if not is_sh:
             want = set()
             if "reflected" in calculation:
                 want |= set(resident.REFLECTED_PLANES)
+                if derive:
+                    want -= {"tau", "tau_og", "gcos2"}
             if "thermal" in calculation:
                 want |= {"dtau_og", "w0_no_raman", "cosb_og"}
             if "transmission" in calculation:
@@ -1294,7 +1303,7 @@ def picaso(bundle, opacityclass, dimension="1d", calculation="reflected", full_o
         if lean:
             want = set()
             if "reflected" in calculation:
-                want |= {"dtau", "tau", "w0"}
+                want |= {"dtau", "w0"} if derive else {"dtau", "tau", "w0"}
             if "thermal" in calculation:
                 th_w0 = "w0" if (common["raman"] == 2 and "reflected" in calculation) else "w0_no_raman"
                 want |= {"dtau", th_w0}
@@ -1303,7 +1312,14 @@ def picaso(bundle, opacityclass, dimension="1d", calculation="reflected", full_o
         co_kw = dict(ngauss=ngauss, stream=common["stream"], delta_eddington=common["delta_eddington"],
                      test_mode=inp["test_mode"], raman=common["raman"], full_output=full_output, want=want)
         planes = optics.compute_opacity_resident(atm, opa, **co_kw)
-        if lean:
+        if lean and derive:
+            # the reflected kernel gets dtau and w0 only (everything else re-derived); the thermal one its three names
+            zero, _, _ = _constant_planes(opa, nlayer, nwno)
+            rplanes = {"dtau": planes["dtau"], "w0": planes["w0"]}
+            planes.update(dtau_og=planes["dtau"], cosb_og=zero)
+            if th_w0 == "w0":
+                planes["w0_no_raman"] = planes["w0"]
+        elif lean:
             zero, one, half = _constant_planes(opa, nlayer, nwno)
             planes.update(dtau_og=planes["dtau"], cosb=zero, cosb_og=zero, ftau_cld=zero, ftau_ray=one, gcos2=half)
             if "tau" in planes:
@@ -1378,7 +1394,8 @@ def picaso(bundle, opacityclass, dimension="1d", calculation="reflected", full_o
                     elif _batch is not None and lv is None and fuse:
                         # spectrum_batch(): the launch is issued later, together with the other spectra's
                         _batch.add_reflected(
-                            (nlevel, nwno, ng, nt, tt, toon["toon_coefficients"], b_top, tuple(gweight), tuple(tweight)),
+                            (nlevel, nwno, ng, nt, tt, toon["toon_coefficients"], b_top, tuple(gweight), tuple(tweight),
+                             tuple(k_ for k_ in resident.REFLECTED_PLANES if pl.get(k_) is not None)),
                             dict(ctx=ctx, planes=pl, rs=rs, ubar0=ubar0, ubar1=ubar1, cos_theta=cos_theta, F0PI=d_f0,
                                  xint=x, albedo=alb))
                     else:
@@ -1386,7 +1403,7 @@ def picaso(bundle, opacityclass, dimension="1d", calculation="reflected", full_o
                                    toon["toon_coefficients"], b_top, x, lv, gweight, tweight,
                                    alb if fuse else None)
                 if not do_holes:
-                    run(planes, xint, lvl, True)
+                    run(rplanes if rplanes is not None else planes, xint, lvl, True)
                 else:                                             # justdoit.py:287-305
                     xc = DeviceArray((ng, nt, nwno), ctx)
                     lvc = [DeviceArray((ng, nt, nlevel, nwno), ctx) for _ in range(4)] if lvl else None
@@ -1650,34 +1667,42 @@ def _picaso_driver(bundle, opa, subs, calculation):
     plan["_factors"] = (atm.layer["mixingratios"], factors)
     linear = opa.query_method == "linear"
     do_r, do_t = "reflected" in legs, "thermal" in legs
-    # which planes compute_opacity writes: exactly picaso()'s choice (see there for the cloud-free form)
+    geom = inp["disco"]
+    ng, nt = geom["num_gangle"], geom["num_tangle"]
+    frac_a, frac_b, frac_c = common["TTHG_params"]["fraction"]
+    # which planes compute_opacity writes: exactly picaso()'s choice (see there for the cloud-free form and for the
+    # planes the reflected kernels re-derive)
+    derive = (do_r and not os.environ.get("PICASO_AMD_ALL_PLANES")
+              and resident.reflected_can_derive(nlevel, nwno, ng, nt, geom["ubar0"], geom["ubar1"], geom["cos_theta"],
+                                                toon["single_phase"], toon["multi_phase"], frac_c,
+                                                toon["toon_coefficients"], False))
     want = set()
     if do_r:
         want |= set(resident.REFLECTED_PLANES)
+        if derive:
+            want -= {"tau", "tau_og", "gcos2"}
     if do_t:
         want |= {"dtau_og", "w0_no_raman", "cosb_og"}
     lean = (cloud_free and len(getattr(atm, "rayleigh_molecules", [])) > 0 and not os.environ.get("PICASO_AMD_ALL_PLANES"))
     if lean:
         want = set()
         if do_r:
-            want |= {"dtau", "tau", "w0"}
+            want |= {"dtau", "w0"} if derive else {"dtau", "tau", "w0"}
         if do_t:
             want |= {"dtau", "w0" if (raman == 2 and do_r) else "w0_no_raman"}
-    geom = inp["disco"]
-    ng, nt = geom["num_gangle"], geom["num_tangle"]
-    frac_a, frac_b, frac_c = common["TTHG_params"]["fraction"]
     def table_ids(sub):          # a block table holds raw table addresses: replaced tables are a new signature
         mt = sub._mol_log if linear else sub._mol_raw
         return tuple(id(mt[m]) for m in plan["molecules"]) + tuple(id(sub._cia[p]) for p in plan["cia_pairs"])
     key = (tuple((lo, hi, id(sub)) + table_ids(sub) for lo, hi, sub in subs), nlayer, ng, nt, tuple(plan["molecules"]),
-           tuple(plan["cia_pairs"]), tuple(factors[2]), linear, tuple(sorted(want)), lean, not cloud_free and not tables, do_r, do_t)
+           tuple(plan["cia_pairs"]), tuple(factors[2]), linear, tuple(sorted(want)), lean, not cloud_free and not tables, do_r, do_t,
+           derive)
     cache = opa.__dict__.setdefault("_driver_tables", {})
     table = cache.get(key)
     if table is None:
         if len(cache) > 8:
             cache.clear()
         table = cache[key] = drv.BlockTable(subs, nlayer, ng, nt, plan["molecules"], plan["cia_pairs"], factors[2], linear,
-                                            want, lean, not cloud_free and not tables, do_r, do_t, _constant_planes)
+                                            want, lean, not cloud_free and not tables, do_r, do_t, _constant_planes, derive)
     nostar = inp["star"]["database"] == "nostar"
     F0PI = _ones(opa, nwno) if nostar else inp["star"]["relative_flux"]
     stellar = getattr(opa, "unshifted_stellar_spec", None)
@@ -1853,7 +1878,7 @@ class _SolveBatch:
                                       tweight=tw, flux_disk=[it["disk"] for it in items])
         self.refl3, self.therm3 = {}, {}
         for key, items in self.refl.items():
-            nlevel, nwno, ng, nt, tt, tcoef, b_top, gw, tw = key
+            nlevel, nwno, ng, nt, tt, tcoef, b_top, gw, tw, _ = key
             ctx = items[0]["ctx"]
             if len(items) == 1:
                 it = items[0]
@@ -2288,7 +2313,8 @@ def _reflected(ctx, nlevel, nwno, ng, nt, planes, rs, ubar0, ubar1, cos_theta, F
     ci, cd = ctypes.c_int, ctypes.c_double
     check(load().picaso_get_reflected_1d_dev(
         ctx, ci(nlevel), ci(nwno), ctypes.c_long(nwno), ci(ng), ci(nt),
-        *[ptr(planes[k].addr) for k in resident.REFLECTED_PLANES], ptr(rs.addr), ptr(u0), ptr(u1),
+        *[ptr(planes[k].addr) if planes.get(k) is not None else None for k in resident.REFLECTED_PLANES],
+        ptr(rs.addr), ptr(u0), ptr(u1),
         cd(cos_theta), ptr(F0PI.addr), ci(single_phase), ci(multi_phase), cd(frac_a), cd(frac_b),
         cd(frac_c), cd(constant_back), cd(constant_forward), ci(1), ci(1 if lvl else 0),
         ci(toon_coefficients), cd(b_top), ptr(xint.addr),

@@ -37,6 +37,17 @@ def upload_scene(scene, keys, w_lo=None, w_hi=None, ctx=None):
     return out
 
 
+def reflected_can_derive(nlevel, nwno, numg, numt, ubar0, ubar1, cos_theta, single_phase, multi_phase, frac_c,
+                         toon_coefficients=0, get_lvl_flux=False):
+    """True when ``reflected_1d`` / ``reflected_1d_batch`` with these arguments may be handed ``None`` for the planes the
+    kernels re-derive (``tau``, ``tau_og``, ``gcos2``; for an atmosphere without cloud everything but ``dtau`` and
+    ``w0``): ``picaso_reflected_1d_can_derive``."""
+    u0, u1 = f64(ubar0, (numg, numt)), f64(ubar1, (numg, numt))
+    return bool(load().picaso_reflected_1d_can_derive(
+        _ci(nlevel), ctypes.c_long(nwno), _ci(numg), _ci(numt), ptr(u0), ptr(u1), _cd(cos_theta), _ci(single_phase),
+        _ci(multi_phase), _cd(frac_c), _ci(toon_coefficients), _ci(1 if get_lvl_flux else 0)))
+
+
 def reflected_1d(ctx, nlevel, nwno, numg, numt, planes, surf_reflect, ubar0, ubar1, cos_theta,
                  F0PI, single_phase, multi_phase, frac_a, frac_b, frac_c, constant_back,
                  constant_forward, xint_at_top, toon_coefficients=0, b_top=0.0, gweight=None,
@@ -50,7 +61,7 @@ def reflected_1d(ctx, nlevel, nwno, numg, numt, planes, surf_reflect, ubar0, uba
     pitch = nwno if plane_pitch is None else plane_pitch
     check(load().picaso_get_reflected_1d_dev(
         ctx, _ci(nlevel), _ci(nwno), ctypes.c_long(pitch), _ci(numg), _ci(numt),
-        *[_addr(planes[k]) for k in REFLECTED_PLANES], _addr(surf_reflect), ptr(u0), ptr(u1),
+        *[_addr(planes.get(k)) for k in REFLECTED_PLANES], _addr(surf_reflect), ptr(u0), ptr(u1),
         _cd(cos_theta), _addr(F0PI), _ci(single_phase), _ci(multi_phase), _cd(frac_a), _cd(frac_b),
         _cd(frac_c), _cd(constant_back), _cd(constant_forward), _ci(1), _ci(0),
         _ci(toon_coefficients), _cd(b_top), _addr(xint_at_top), None, None, None, None,
@@ -79,7 +90,7 @@ def thermal_1d(ctx, nlevel, wno, nwno, numg, numt, tlevel, dtau, w0, cosb, pleve
 
 def _ptr_array(items):
     """Host array of device addresses (``const double *const *`` of the batched entry points)."""
-    arr = (ctypes.c_void_p * len(items))(*[(x.addr if isinstance(x, DeviceArray) else x) for x in items])
+    arr = (ctypes.c_void_p * len(items))(*[(x.addr if isinstance(x, DeviceArray) else x) for x in items])   # None: NULL
     return arr, ctypes.cast(arr, ctypes.POINTER(ctypes.POINTER(ctypes.c_double)))
 
 
@@ -113,7 +124,7 @@ def reflected_1d_batch(ctx, nlevel, nwno, numg, numt, planes, surf_reflect, ubar
     pitch = nwno if plane_pitch is None else plane_pitch
     keep, cols = [], []
     for k in REFLECTED_PLANES:
-        a, p = _ptr_array([pl[k] for pl in planes])
+        a, p = _ptr_array([pl.get(k) for pl in planes])
         keep.append(a)
         cols.append(p)
     a_rs, p_rs = _ptr_array(_per_spectrum(surf_reflect, nspec))

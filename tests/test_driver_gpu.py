@@ -85,14 +85,16 @@ def test_driver_nearest_query_and_falls_through_where_it_does_not_apply(monkeypa
 
 
 def test_driver_lean_planes(monkeypatch):
-    """Through the driver as well a cloud-free atmosphere writes three planes (dtau, tau, w0) and hands the solvers
-    aliases and constants for the rest, a cloudy one all eleven; PICASO_AMD_ALL_PLANES=1 writes the full set -- same bits."""
+    from picaso_amd import resident
+    """Through the driver as well a cloud-free atmosphere writes two planes (dtau, w0: the reflected kernel re-derives the
+    rest, the thermal one gets aliases and a constant), a cloudy one eight of the eleven (tau, tau_og and gcos2 are
+    re-derived); PICASO_AMD_ALL_PLANES=1 writes the full set -- same bits."""
     from picaso_amd import justdoit as jdi
     og = np.load(os.path.join(GOLDEN, "optics.npz"))
     opa = jdi.opannection(filename_db=DB, query_method="linear")
     lean = _case(og, jdi, False, True, "none", True).spectrum(opa, calculation="reflected+thermal")
     (t_lean,) = opa.__dict__["_driver_tables"].values()
-    assert set(t_lean.want) == {"dtau", "tau", "w0"}
+    assert set(t_lean.want) == {"dtau", "w0"}
     monkeypatch.setenv("PICASO_AMD_ALL_PLANES", "1")
     full = _case(og, jdi, False, True, "none", True).spectrum(opa, calculation="reflected+thermal")
     t_full = [t for t in opa.__dict__["_driver_tables"].values() if t is not t_lean][0]
@@ -101,7 +103,10 @@ def test_driver_lean_planes(monkeypatch):
     monkeypatch.delenv("PICASO_AMD_ALL_PLANES")
     _case(og, jdi, True, True, "none", True).spectrum(opa, calculation="reflected")
     t_cld = [t for t in opa.__dict__["_driver_tables"].values() if t is not t_lean and t is not t_full][0]
-    assert len(t_cld.want) == 11
+    assert set(t_cld.want) == set(resident.REFLECTED_PLANES) - {"tau", "tau_og", "gcos2"}
+    cloudy = _case(og, jdi, True, True, "none", True).spectrum(opa, calculation="reflected+thermal")
+    monkeypatch.setenv("PICASO_AMD_ALL_PLANES", "1")
+    _same(_case(og, jdi, True, True, "none", True).spectrum(opa, calculation="reflected+thermal"), cloudy)
 
 
 def test_driver_cloud_tables_on_their_own_grid(monkeypatch):

@@ -87,9 +87,13 @@ def test_lean_planes_not_used_with_clouds_or_test_mode(monkeypatch):
     monkeypatch.setattr(px, "compute_opacity_resident", lambda *a, **k: (wants.append(k.get("want")), real(*a, **k))[1])
     case = _case(jdi, og, "none", True, False)
     case.clouds(df={"opd": og["in/cld_opd"], "w0": og["in/cld_w0"], "g0": og["in/cld_g0"]})
-    case.spectrum(opa, calculation="reflected")
-    assert len(wants[-1]) == 11                                       # all eleven reflected-light planes
+    cloudy = case.spectrum(opa, calculation="reflected")
+    assert len(wants[-1]) == 8                   # the eleven reflected-light planes less tau, tau_og, gcos2 (re-derived)
+    monkeypatch.setenv("PICASO_AMD_ALL_PLANES", "1")
+    _same(case.spectrum(opa, calculation="reflected"), cloudy)
+    assert len(wants[-1]) == 11
+    monkeypatch.delenv("PICASO_AMD_ALL_PLANES")
     case = _case(jdi, og, "none", True, False)
     case.inputs["test_mode"] = "rayleigh"
     case.spectrum(opa, calculation="reflected")
-    assert len(wants[-1]) == 11
+    assert len(wants[-1]) == 11                  # a test mode: all eleven
