@@ -52,6 +52,8 @@ Node build(long start, long n, std::vector<int> &leaf, std::vector<std::vector<i
     return {id, level};
 }
 
+}  // namespace
+
 struct TrapzArgs {
     long n;                      // points; n - 1 summands
     const double *d, *y, *mult;
@@ -127,8 +129,6 @@ __global__ __launch_bounds__(1024) void k_pairwise_combine(const int *__restrict
     }
     if (threadIdx.x == 0) out[0] = vals[root];
 }
-
-}  // namespace
 
 void free_pairwise_plans(picaso_ctx *ctx)
 {
