@@ -1630,7 +1630,7 @@ def _picaso_driver(bundle, opa, subs, calculation):
     call enqueues gas stage -> ``compute_opacity`` -> reflected || thermal (+ fused disk sums) on every wavelength block
     of ``subs`` (``[(lo, hi, opacity object of the block)]``; the whole grid on one GPU is one block), a second and third
     copy the legs back.  Returns the output dictionary, or None when the call is outside what the driver covers
-    (correlated-k tables, SH, patchy clouds, level fluxes, full_output, transmission, Oklopcic Raman, cloud tables
+    (correlated-k tables, SH, patchy clouds, level fluxes, full_output, transmission, Oklopcic Raman or cloud tables
     on their own grid in a multi-block call, test modes) -- the caller then takes the call-by-call path, whose results these are bit for bit:
     the C function chains the same entry points in the same order."""
     from . import driver as drv
@@ -1647,8 +1647,8 @@ def _picaso_driver(bundle, opa, subs, calculation):
     common = inp["approx"]["rt_params"]["common"]
     toon = inp["approx"]["rt_params"]["toon"]
     raman = common["raman"]
-    if raman == 0:
-        return None
+    if raman == 0 and (len(subs) != 1 or os.environ.get("PICASO_AMD_RAMAN_PLANES")):
+        return None                # Oklopcic's factor: a plane formed per call on the block's device; one block for now
     wno, nwno = opa.wno, opa.nwno
     atm = _setup_atmosphere(inp, opa, wno)
     cld = atm.layer["cloud"]
@@ -1751,6 +1751,10 @@ def _picaso_driver(bundle, opa, subs, calculation):
         if raman == 1:
             row, _ = optics.raman_device(atm, sub, 1)
             k.raman = drv._dev(row)
+        elif raman == 0:           # (nlayer, nwno) plane from the layer temperatures (picaso_raman_oklopcic_dev), same stream
+            rplane, _ = optics.raman_device(atm, sub, 0)
+            hold.append(rplane)
+            k.raman = drv._dev(rplane)
         else:
             k.raman = None
         k.cld_tab_nin, k.cld_tab_xp, k.cld_tab_fp = 0, None, None

@@ -135,3 +135,20 @@ def test_driver_cloud_tables_on_their_own_grid(monkeypatch):
     _same(case.spectrum(opa, calculation="reflected+thermal"), got)
     monkeypatch.setenv("PICASO_AMD_HOST_REGRID", "1")
     _same(case.spectrum(opa, calculation="reflected+thermal"), got)
+
+
+@pytest.mark.parametrize("cloud", [False, True])
+@pytest.mark.parametrize("calc", ["reflected", "reflected+thermal"])
+def test_driver_oklopcic_raman(monkeypatch, cloud, calc):
+    """raman='oklopcic': the factor plane is formed on the device per call (layer temperatures) and handed to the driver's
+    opacity launch -- the bits of the call-by-call path."""
+    from picaso_amd import justdoit as jdi
+    og = np.load(os.path.join(GOLDEN, "optics.npz"))
+    opa = jdi.opannection(filename_db=DB, query_method="linear")
+    opa.raman_stellar_shifts = og["in/raman_shifts"]
+    opa.raman_db = {"c": og["in/raman_c"], "ji": og["in/raman_ji"], "deltanu": og["in/raman_deltanu"]}
+    got = [_case(og, jdi, cloud, True, "oklopcic", True, k).spectrum(opa, calculation=calc) for k in range(2)]
+    assert len(opa.__dict__["_driver_tables"]) == 1
+    monkeypatch.setenv("PICASO_AMD_NO_DRIVER", "1")
+    for k in range(2):
+        _same(_case(og, jdi, cloud, True, "oklopcic", True, k).spectrum(opa, calculation=calc), got[k])
