@@ -46,11 +46,50 @@ void *arena_take(picaso_ctx *ctx, size_t bytes)
     return p;
 }
 
+static int small_ring_reserve(picaso_ctx *ctx)
+{
+    if (ctx->small_h) return 0;
+    const size_t ring = picaso_ctx::SMALL_BYTES * picaso_ctx::NSMALL;
+    PZ_HIP(ctx, hipHostMalloc((void **)&ctx->small_h, ring, hipHostMallocDefault));
+    PZ_HIP(ctx, hipMalloc((void **)&ctx->small_d, ring));
+    for (int i = 0; i < picaso_ctx::NSMALL; ++i)
+        PZ_HIP(ctx, hipEventCreateWithFlags(&ctx->small_ev[i], hipEventDisableTiming));
+    return 0;
+}
+
+// device address the NEXT table_upload of `bytes` will return (tables that point into themselves are filled first)
+int table_next_dev(picaso_ctx *ctx, size_t bytes, const char **dev)
+{
+    if (bytes <= picaso_ctx::SMALL_BYTES) {
+        PZ_TRY(small_ring_reserve(ctx));
+        *dev = ctx->small_d + (size_t)ctx->small_next * picaso_ctx::SMALL_BYTES;
+    } else {
+        *dev = ctx->ring_d + (size_t)ctx->ring_next * picaso_ctx::SLOT_BYTES;
+    }
+    return 0;
+}
+
 int table_upload(picaso_ctx *ctx, const void *host, size_t bytes, const void **dev)
 {
     if (bytes > picaso_ctx::SLOT_BYTES)
         return fail(ctx, "geometry/profile table of %zu bytes exceeds the %zu-byte slot", bytes,
                     picaso_ctx::SLOT_BYTES);
+    if (bytes <= picaso_ctx::SMALL_BYTES) {
+        PZ_TRY(small_ring_reserve(ctx));
+        const int s = ctx->small_next;
+        ctx->small_next = (s + 1) % picaso_ctx::NSMALL;
+        if (ctx->small_pending[s]) {
+            PZ_HIP(ctx, hipEventSynchronize(ctx->small_ev[s]));
+            ctx->small_pending[s] = false;
+        }
+        char *h = ctx->small_h + (size_t)s * picaso_ctx::SMALL_BYTES, *d = ctx->small_d + (size_t)s * picaso_ctx::SMALL_BYTES;
+        memcpy(h, host, bytes);
+        PZ_HIP(ctx, hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, ctx->stream));
+        PZ_HIP(ctx, hipEventRecord(ctx->small_ev[s], ctx->stream));
+        ctx->small_pending[s] = true;
+        *dev = d;
+        return 0;
+    }
     const int s = ctx->ring_next;
     ctx->ring_next = (s + 1) % picaso_ctx::NSLOT;
     if (ctx->ring_pending[s]) {
@@ -208,6 +247,10 @@ void picaso_ctx_destroy(picaso_ctx *ctx)
     if (ctx->ck_scratch) (void)hipFree(ctx->ck_scratch);
     if (ctx->ring_d) (void)hipFree(ctx->ring_d);
     if (ctx->ring_h) (void)hipHostFree(ctx->ring_h);
+    if (ctx->small_d) (void)hipFree(ctx->small_d);
+    if (ctx->small_h) (void)hipHostFree(ctx->small_h);
+    for (int i = 0; i < picaso_ctx::NSMALL; ++i)
+        if (ctx->small_ev[i]) (void)hipEventDestroy(ctx->small_ev[i]);
     for (int i = 0; i < picaso_ctx::NSLOT; ++i)
         if (ctx->ring_ev[i]) (void)hipEventDestroy(ctx->ring_ev[i]);
     if (ctx->wait_ev) (void)hipEventDestroy(ctx->wait_ev);
@@ -984,7 +1027,8 @@ int picaso_get_reflected_3d_batch_dev(picaso_ctx *ctx, int nspec, int nlevel, in
     if (tab.size() > picaso_ctx::SLOT_BYTES) return fail(ctx, "get_reflected_3d_batch: too many spectra for one call");
     ReflBatchItem *items = (ReflBatchItem *)tab.data();
     double *geo = (double *)(tab.data() + head);
-    const char *dbase = ctx->ring_d + (size_t)ctx->ring_next * picaso_ctx::SLOT_BYTES;
+    const char *dbase = nullptr;
+    PZ_TRY(table_next_dev(ctx, tab.size(), &dbase));
     for (int s = 0; s < nspec; ++s) {
         ReflBatchItem &it = items[s];
         memset(&it, 0, sizeof(it));
@@ -1135,8 +1179,8 @@ static int thermal_1d_core(picaso_ctx *ctx, int nlevel, const double *wno, int n
         }
         const void *d = nullptr;
         // device addresses of the level tables are known only after the slot is chosen: fill, then upload once
-        const int slot = ctx->ring_next;
-        const char *dbase = ctx->ring_d + (size_t)slot * picaso_ctx::SLOT_BYTES;
+        const char *dbase = nullptr;
+        PZ_TRY(table_next_dev(ctx, btab.size(), &dbase));
         for (int s = 0; s < nspec; ++s) {
             ThermalBatchItem &it = items[s];
             it.dtau = bt->dtau[s]; it.w0 = bt->w0[s]; it.cosb = bt->cosb[s]; it.surf_reflect = bt->surf_reflect[s];
@@ -1486,7 +1530,8 @@ int picaso_get_thermal_3d_batch_dev(picaso_ctx *ctx, int nspec, int nlevel, cons
                     (picaso_ctx::SLOT_BYTES - 4096) / (sizeof(double) * per + sizeof(ThermalBatchItem)));
     ThermalBatchItem *items = (ThermalBatchItem *)tab.data();
     double *lv = (double *)(tab.data() + head);
-    const char *dbase = ctx->ring_d + (size_t)ctx->ring_next * picaso_ctx::SLOT_BYTES;
+    const char *dbase = nullptr;
+    PZ_TRY(table_next_dev(ctx, tab.size(), &dbase));
     for (int s = 0; s < nspec; ++s) {
         double *t_u1 = lv + per * s, *t_T = t_u1 + nfac, *t_P = t_T + (size_t)nlevel * nfac;
         for (int i = 0; i < nfac; ++i) t_u1[i] = ubar1[(size_t)s * nfac + i];

@@ -31,6 +31,15 @@ struct picaso_ctx {
     hipEvent_t ring_ev[NSLOT] = {};
     bool ring_pending[NSLOT] = {};
     int ring_next = 0;
+    // ... and a second ring of many small slots for the tables of 1-D spectra (rows / weights / coefficients of one
+    // spectrum: ~30 KB; level temperatures; batch items): a chunk of a retrieval uploads a dozen of them back to back, and
+    // with eight slots the host waited for the GPU to consume the chunk's first tables before it could enqueue its last
+    static constexpr int NSMALL = 64;
+    static constexpr size_t SMALL_BYTES = 64u << 10;
+    char *small_h = nullptr, *small_d = nullptr;
+    hipEvent_t small_ev[NSMALL] = {};
+    bool small_pending[NSMALL] = {};
+    int small_next = 0;
     // pinned bounce buffer (two halves) for host<->device copies of small and medium arrays, so the
     // caller's pageable memory is never pinned by the runtime (see picaso_memcpy_h2d)
     static constexpr size_t STAGE_BYTES = 8u << 20;

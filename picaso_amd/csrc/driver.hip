@@ -20,6 +20,52 @@
 
 using namespace pz;
 
+// The opacity stage of one block: cloud planes (device, host columns, or tables interpolated in the launch), gas stage +
+// mixing as one launch, the level planes as a second one that the thermal leg does not wait for (it reads layer planes
+// only: `thermal_waits_here` orders its stream in between).  PICASO_AMD_UNFUSED_OPACITY=1: the two launches with
+// TAUGAS / TAURAY in HBM (A/B).
+static int opacity_stage(const picaso_block &k, const picaso_spectrum_job &j, int b, picaso_ctx *thermal_waits_here)
+{
+    // cloud tables handed over as full-grid host planes: this block's columns, strided copy (the reference slices
+    // nothing: it has one grid; justdoit.py:4774 fans out whole spectra)
+    const double *cld[3] = {k.cld_opd, k.cld_w0, k.cld_g0};
+    if (k.cld_host_opd) {
+        const double *src[3] = {k.cld_host_opd, k.cld_host_w0, k.cld_host_g0};
+        double *dst[3] = {k.cld_work_opd, k.cld_work_w0, k.cld_work_g0};
+        for (int c = 0; c < 3; ++c) {
+            if (!src[c] || !dst[c]) return fail(k.ctx, "toon_spectrum_blocks: block %d: incomplete host cloud planes", b);
+            PZ_TRY(picaso_memcpy_h2d_2d(k.ctx, dst[c], sizeof(double) * (size_t)k.nwno, src[c] + k.col0,
+                                        sizeof(double) * (size_t)k.cld_host_pitch, sizeof(double) * (size_t)k.nwno,
+                                        (size_t)j.nlayer));
+            cld[c] = dst[c];
+        }
+    }
+    double *const *o = k.planes;
+    const bool fused = (!o[1] || o[0]) && (!o[8] || o[7]) && !getenv("PICASO_AMD_UNFUSED_OPACITY");
+    if (fused) {
+        PZ_TRY(picaso_gas_compute_opacity_dev(k.ctx, j.nlayer, k.nwno, j.mol_mode, j.nmol, k.mol_tabs, j.mol_rows,
+                                              j.mol_wts, j.mol_fac, j.cont_interp, j.ncont, k.cont_tabs, j.cont_rows,
+                                              j.cont_wts, j.cont_fac, j.nray, k.ray_tabs, j.ray_fac, cld[0], cld[1],
+                                              cld[2], k.raman, j.raman_rows, j.raman_const, j.test_mode,
+                                              j.delta_eddington, j.stream, o[0], o[1], o[2], o[3], o[4], o[5], o[6],
+                                              o[7], o[8], o[9], o[10], o[11], o[12], 0, k.cld_tab_nin, k.cld_tab_xp,
+                                              k.cld_tab_fp, k.cld_tab_nin ? k.wno : nullptr));
+        if (thermal_waits_here) PZ_TRY(picaso_ctx_wait(thermal_waits_here, k.ctx));
+        PZ_TRY(picaso_level_sums_dev(k.ctx, j.nlayer, k.nwno, o[0], o[1], o[7], o[8]));
+    } else {
+        if (k.cld_tab_nin) return fail(k.ctx, "toon_spectrum_blocks: cloud tables need the fused opacity launch");
+        PZ_TRY(picaso_opacity_gas_ck_dev(k.ctx, j.nlayer, k.nwno, 1, j.mol_mode, j.nmol, k.mol_tabs, j.mol_rows,
+                                         j.mol_wts, j.mol_fac, j.cont_interp, j.ncont, k.cont_tabs, j.cont_rows,
+                                         j.cont_wts, j.cont_fac, j.nray, k.ray_tabs, j.ray_fac, k.taugas, k.tauray));
+        PZ_TRY(picaso_compute_opacity_ck_dev(k.ctx, j.nlayer, k.nwno, 1, k.taugas, k.tauray, cld[0], cld[1], cld[2],
+                                             k.raman, j.raman_rows, j.raman_const, j.test_mode, j.delta_eddington,
+                                             j.stream, o[0], o[1], o[2], o[3], o[4], o[5], o[6], o[7], o[8], o[9], o[10],
+                                             o[11], o[12]));
+        if (thermal_waits_here) PZ_TRY(picaso_ctx_wait(thermal_waits_here, k.ctx));
+    }
+    return 0;
+}
+
 extern "C" int picaso_toon_spectrum_blocks(int nblocks, picaso_block *blocks, const picaso_spectrum_job *job)
 {
     if (nblocks < 1 || !blocks || !job) return fail(nullptr, "toon_spectrum_blocks: null argument");
@@ -32,45 +78,7 @@ extern "C" int picaso_toon_spectrum_blocks(int nblocks, picaso_block *blocks, co
         if (k.albedo_mark || k.thermal_mark)
             return fail(k.ctx, "toon_spectrum_blocks: block %d still has uncollected results", b);
         picaso_ctx *tctx = k.tctx ? k.tctx : k.ctx;
-        // cloud tables handed over as full-grid host planes: this block's columns, strided copy (the reference slices
-        // nothing: it has one grid; justdoit.py:4774 fans out whole spectra)
-        const double *cld[3] = {k.cld_opd, k.cld_w0, k.cld_g0};
-        if (k.cld_host_opd) {
-            const double *src[3] = {k.cld_host_opd, k.cld_host_w0, k.cld_host_g0};
-            double *dst[3] = {k.cld_work_opd, k.cld_work_w0, k.cld_work_g0};
-            for (int c = 0; c < 3; ++c) {
-                if (!src[c] || !dst[c]) return fail(k.ctx, "toon_spectrum_blocks: block %d: incomplete host cloud planes", b);
-                PZ_TRY(picaso_memcpy_h2d_2d(k.ctx, dst[c], sizeof(double) * (size_t)k.nwno, src[c] + k.col0,
-                                            sizeof(double) * (size_t)k.cld_host_pitch, sizeof(double) * (size_t)k.nwno,
-                                            (size_t)j.nlayer));
-                cld[c] = dst[c];
-            }
-        }
-        double *const *o = k.planes;
-        // gas stage + mixing as one launch, the level planes as a second one that the thermal leg does not wait for
-        // (it reads layer planes only); PICASO_AMD_UNFUSED_OPACITY=1: the two launches with TAUGAS / TAURAY in HBM (A/B)
-        const bool fused = (!o[1] || o[0]) && (!o[8] || o[7]) && !getenv("PICASO_AMD_UNFUSED_OPACITY");
-        if (fused) {
-            PZ_TRY(picaso_gas_compute_opacity_dev(k.ctx, j.nlayer, k.nwno, j.mol_mode, j.nmol, k.mol_tabs, j.mol_rows,
-                                                  j.mol_wts, j.mol_fac, j.cont_interp, j.ncont, k.cont_tabs, j.cont_rows,
-                                                  j.cont_wts, j.cont_fac, j.nray, k.ray_tabs, j.ray_fac, cld[0], cld[1],
-                                                  cld[2], k.raman, j.raman_rows, j.raman_const, j.test_mode,
-                                                  j.delta_eddington, j.stream, o[0], o[1], o[2], o[3], o[4], o[5], o[6],
-                                                  o[7], o[8], o[9], o[10], o[11], o[12], 0, k.cld_tab_nin, k.cld_tab_xp,
-                                                  k.cld_tab_fp, k.cld_tab_nin ? k.wno : nullptr));
-            if (tctx != k.ctx && j.do_thermal) PZ_TRY(picaso_ctx_wait(tctx, k.ctx));
-            PZ_TRY(picaso_level_sums_dev(k.ctx, j.nlayer, k.nwno, o[0], o[1], o[7], o[8]));
-        } else {
-            if (k.cld_tab_nin) return fail(k.ctx, "toon_spectrum_blocks: cloud tables need the fused opacity launch");
-            PZ_TRY(picaso_opacity_gas_ck_dev(k.ctx, j.nlayer, k.nwno, 1, j.mol_mode, j.nmol, k.mol_tabs, j.mol_rows,
-                                             j.mol_wts, j.mol_fac, j.cont_interp, j.ncont, k.cont_tabs, j.cont_rows,
-                                             j.cont_wts, j.cont_fac, j.nray, k.ray_tabs, j.ray_fac, k.taugas, k.tauray));
-            PZ_TRY(picaso_compute_opacity_ck_dev(k.ctx, j.nlayer, k.nwno, 1, k.taugas, k.tauray, cld[0], cld[1], cld[2],
-                                                 k.raman, j.raman_rows, j.raman_const, j.test_mode, j.delta_eddington,
-                                                 j.stream, o[0], o[1], o[2], o[3], o[4], o[5], o[6], o[7], o[8], o[9], o[10],
-                                                 o[11], o[12]));
-            if (tctx != k.ctx && j.do_thermal) PZ_TRY(picaso_ctx_wait(tctx, k.ctx));
-        }
+        PZ_TRY(opacity_stage(k, j, b, (tctx != k.ctx && j.do_thermal) ? tctx : nullptr));
         if (j.do_reflected) {
             const double *const *r = k.refl_planes;
             PZ_TRY(picaso_get_reflected_1d_dev(k.ctx, nlevel, k.nwno, k.nwno, j.numg, j.numt, r[0], r[1], r[2], r[3], r[4],

@@ -186,3 +186,4 @@ def collect(table, which):
 def abandon(table):
     """Drop result copies nobody will collect (an exception between ``enqueue`` and ``collect``)."""
     _lib.load().picaso_toon_spectrum_abandon(ctypes.c_int(table.n), table.blocks)
+

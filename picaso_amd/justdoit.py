@@ -1626,13 +1626,30 @@ def _fetch(prefetched, key, dev, returns=None, integral=None):
 
 
 def _picaso_driver(bundle, opa, subs, calculation):
+    """``_driver_prepare`` + the C call + ``_driver_finish``; None when the call is outside what the driver covers."""
+    from . import driver as drv
+    p = _driver_prepare(bundle, opa, subs, calculation)
+    if p is None:
+        return None
+    try:
+        drv.enqueue(p["table"], p["job"])
+        return _driver_finish(p)
+    except BaseException:
+        drv.abandon(p["table"])
+        raise
+
+
+def _driver_prepare(bundle, opa, subs, calculation, slot=None):
     """The 1-D Toon spectrum (reference justdoit.py:236-385, 552-599) through ``picaso_toon_spectrum_blocks``: ONE C
     call enqueues gas stage -> ``compute_opacity`` -> reflected || thermal (+ fused disk sums) on every wavelength block
     of ``subs`` (``[(lo, hi, opacity object of the block)]``; the whole grid on one GPU is one block), a second and third
     copy the legs back.  Returns the output dictionary, or None when the call is outside what the driver covers
     (correlated-k tables, SH, patchy clouds, level fluxes, full_output, transmission, Oklopcic Raman or cloud tables
     on their own grid in a multi-block call, test modes) -- the caller then takes the call-by-call path, whose results these are bit for bit:
-    the C function chains the same entry points in the same order."""
+    the C function chains the same entry points in the same order.
+    This half does everything up to the C call -- set-up, block table (``slot``: which of several tables of the same
+    signature, for spectra that are in flight together: ``spectrum_batch``), per-call pointers, job -- and returns what
+    the call and ``_driver_finish`` need."""
     from . import driver as drv
     if os.environ.get("PICASO_AMD_NO_DRIVER") or os.environ.get("PICASO_AMD_RAMAN_PLANES"):
         return None
@@ -1695,11 +1712,11 @@ def _picaso_driver(bundle, opa, subs, calculation):
         return tuple(id(mt[m]) for m in plan["molecules"]) + tuple(id(sub._cia[p]) for p in plan["cia_pairs"])
     key = (tuple((lo, hi, id(sub)) + table_ids(sub) for lo, hi, sub in subs), nlayer, ng, nt, tuple(plan["molecules"]),
            tuple(plan["cia_pairs"]), tuple(factors[2]), linear, tuple(sorted(want)), lean, not cloud_free and not tables, do_r, do_t,
-           derive)
+           derive, slot)
     cache = opa.__dict__.setdefault("_driver_tables", {})
     table = cache.get(key)
     if table is None:
-        if len(cache) > 8:
+        if len(cache) > (8 if slot is None else 40):
             cache.clear()
         table = cache[key] = drv.BlockTable(subs, nlayer, ng, nt, plan["molecules"], plan["cia_pairs"], factors[2], linear,
                                             want, lean, not cloud_free and not tables, do_r, do_t, _constant_planes, derive)
@@ -1748,6 +1765,7 @@ def _picaso_driver(bundle, opa, subs, calculation):
         rs = _resident_vector(sub, "surf_reflect", np.asarray(sr, dtype=float).reshape(nwno)[lo:hi] if sr_full else sr, nw)
         f0 = _resident_vector(sub, "F0PI", 1.0 if nostar else (F0PI if len(subs) == 1 else F0PI[lo:hi]), nw)
         k.surf_reflect, k.F0PI = drv._dev(rs), drv._dev(f0)
+        hold.append((rs, f0))            # the block holds raw addresses: the vectors live as long as the call is in flight
         if raman == 1:
             row, _ = optics.raman_device(atm, sub, 1)
             k.raman = drv._dev(row)
@@ -1792,6 +1810,7 @@ def _picaso_driver(bundle, opa, subs, calculation):
             d_w, d_wr = _trapz_resident(sub, wno)
             if do_r:
                 d_st = f0 if stellar is F0PI else _resident_vector(sub, "stellar", stellar, nw)
+                hold.append(d_st)
                 k.trapz_d, k.stellar = drv._dev(d_w), drv._dev(d_st)
                 denom = _bond_denominator(sub, wno, stellar, d_st)
             if do_t:
@@ -1802,20 +1821,16 @@ def _picaso_driver(bundle, opa, subs, calculation):
                              toon["toon_coefficients"], frac_a, frac_b, frac_c, common["TTHG_params"]["constant_back"],
                              common["TTHG_params"]["constant_forward"], 0.0, atm.level["temperature"], atm.level["pressure"],
                              atm.hard_surface)
-    try:
-        drv.enqueue(table, job)
-        return _driver_finish(table, do_r, do_t, full, nwno, integrals, denom if (integrals and do_r) else None, wno, stellar,
-                              inp, atm, opa)
-    except BaseException:
-        drv.abandon(table)
-        raise
-    finally:
-        del keep, hold
+    return dict(table=table, job=job, keep=(keep, hold), do_r=do_r, do_t=do_t, full=full, nwno=nwno, integrals=integrals,
+                denom=denom if (integrals and do_r) else None, wno=wno, stellar=stellar, inp=inp, atm=atm, opa=opa,
+                signature=key[1:-1])
 
 
-def _driver_finish(table, do_r, do_t, full, nwno, integrals, denom, wno, stellar, inp, atm, opa):
+def _driver_finish(p):
     """Second half of ``_picaso_driver``: the results as they arrive (their copies were enqueued with the launches)."""
     from . import driver as drv
+    table, do_r, do_t, full, nwno, integrals, denom = (p[k] for k in ("table", "do_r", "do_t", "full", "nwno", "integrals", "denom"))
+    wno, stellar, inp, atm, opa = (p[k] for k in ("wno", "stellar", "inp", "atm", "opa"))
     returns = {}
     out = {"wavenumber": wno}
     if do_r:
@@ -1930,15 +1945,17 @@ def spectrum_batch(cases, opacityclass, calculation="reflected", full_output=Fal
     cases = list(cases)
     outs = []
     in_flight = []                 # chunks whose launches and result copies are on the stream
-    for c0 in range(0, len(cases), max(1, int(batch_size))):
-        chunk = cases[c0:c0 + max(1, int(batch_size))]
-        batch = _SolveBatch()
-        fins = []
+    B = max(1, int(batch_size))
+    for c0 in range(0, len(cases), B):
+        chunk = cases[c0:c0 + B]
         for case in chunk:
             if case.inputs["atmosphere"].get("profile") is None:
                 raise Exception("Need to set atmosphere profile with the atmosphere() function")
             if case.inputs["planet"]["gravity"] is None:
                 raise Exception("Need to set gravity with the gravity() function")
+        batch = _SolveBatch()
+        fins = []
+        for case in chunk:
             fins.append(picaso(case, opacityclass, dimension="1d", calculation=calculation, full_output=full_output,
                                as_dict=as_dict, defer=True, _batch=batch))
         batch.flush()

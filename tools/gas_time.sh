@@ -1,10 +1,10 @@
 #!/bin/bash
 # average duration of the opacity kernels inside spectrum() (rocprofv3 kernel trace of tools/e2e_1d_time.py); used as
-# AB_CMD of tools/ab.sh
+# AB_CMD of tools/ab.sh (GAS_TOOL=tools/e2e_3d_time.py: the 3-D path's launches)
 export TMPDIR=/tmp
 R=$(cd "$(dirname "$0")/.." && pwd)
 D=$(mktemp -d /tmp/gas_XXXX)
-(cd /tmp && WARM=80 rocprofv3 --kernel-trace --stats --output-format csv -d $D -o g -- python $R/tools/e2e_1d_time.py > $D/out.txt 2>&1)
+(cd /tmp && WARM=80 rocprofv3 --kernel-trace --stats --output-format csv -d $D -o g -- python $R/${GAS_TOOL:-tools/e2e_1d_time.py} > $D/out.txt 2>&1)
 python - "$D" <<'PY'
 import csv, glob, sys
 rows = []
