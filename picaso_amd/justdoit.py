@@ -1254,7 +1254,14 @@ def picaso(bundle, opacityclass, dimension="1d", calculation="reflected", full_o
             atm_f = _setup_atmosphere(inp, opa, wno, prof_f, None)
             atm = _setup_atmosphere(inp, opa, wno, {k: (v if v.ndim == 1 else v[:, 0, 0]) for k, v in prof3.items()},
                                     None)                     # facet (0, 0): sizes, surface, full_output
-            planes3d = optics.compute_opacity_facets(atm_f, opa, ng, nt, **co3)
+            if clear3 and not full_output and not os.environ.get("PICASO_AMD_FACET_FASTEST"):
+                # no cloud: the two (three) planes in facet-major layout straight from ONE fused gas + mixing launch over
+                # all facets; the solvers take every facet as a spectrum of its own (resident.*_3d_fm_batch: same bits)
+                planes3d = optics.compute_opacity_facet_major(
+                    atm_f, opa, ng, nt, stream=common["stream"], delta_eddington=common["delta_eddington"],
+                    raman=common["raman"], exclude_mol=inp["atmosphere"]["exclude_mol"], want=want3)
+            else:
+                planes3d = optics.compute_opacity_facets(atm_f, opa, ng, nt, **co3)
             tlev3 = atm_f.level["temperature"].reshape(nlv, ng, nt)
             plev3 = np.ascontiguousarray(np.broadcast_to(atm_f.level["pressure"].reshape(nlv, 1, 1), (nlv, ng, nt)))
     elif _shared is not None:
@@ -1361,11 +1368,13 @@ def picaso(bundle, opacityclass, dimension="1d", calculation="reflected", full_o
             if dimension == "3d" and _batch is not None:          # phase_curve(): one launch for a chunk of phases
                 tt3 = (toon["single_phase"], toon["multi_phase"], frac_a, frac_b, frac_c, constant_back, constant_forward)
                 present = tuple(k for k in resident.REFLECTED_PLANES if planes3d.get(k) is not None)
+                present += ("facet-major",) if planes3d.get("_fm") else ()
                 _batch.add_reflected_3d((nlevel, nwno, ng, nt, tt3, present, tuple(gweight), tuple(tweight)),
                                         dict(ctx=ctx, planes=planes3d, rs=rs, ubar0=ubar0, ubar1=ubar1,
                                              cos_theta=cos_theta, F0PI=d_f0, xint=xint, albedo=alb))
             elif dimension == "3d":                               # justdoit.py:488-500
-                resident.reflected_3d(ctx, nlevel, nwno, ng, nt, planes3d, rs, ubar0, ubar1, cos_theta, d_f0,
+                (resident.reflected_3d if not planes3d.get("_fm") else _reflected_3d_fm)(
+                    ctx, nlevel, nwno, ng, nt, planes3d, rs, ubar0, ubar1, cos_theta, d_f0,
                                       toon["single_phase"], toon["multi_phase"], frac_a, frac_b, frac_c,
                                       constant_back, constant_forward, xint, gweight, tweight, alb)
             elif is_sh:                                           # justdoit.py:259-269
@@ -1436,12 +1445,18 @@ def picaso(bundle, opacityclass, dimension="1d", calculation="reflected", full_o
             disk_x = DeviceArray((nwno + 1,), tctx)       # [nwno]: the effective-temperature integral
             disk = disk_x.head(nwno)
             if dimension == "3d" and _batch is not None:
-                _batch.add_thermal_3d((nlevel, nwno, ng, nt, int(atm.hard_surface), d_wno.addr, th3[2] is not None,
-                                       tuple(gweight), tuple(tweight)),
+                _batch.add_thermal_3d((nlevel, nwno, ng, nt, int(atm.hard_surface), d_wno.addr,
+                                       (th3[2] is not None, bool(planes3d.get("_fm"))), tuple(gweight), tuple(tweight)),
                                       dict(ctx=ctx, wno=d_wno, tlevel=np.array(tlev3, dtype=float),
                                            plevel=np.array(plev3, dtype=float), dtau=planes3d[th3[0]],
                                            w0=planes3d[th3[1]], cosb=planes3d[th3[2]] if th3[2] else None,
                                            ubar1=ubar1, rs=rs, flux=flux, disk=disk, keep=planes3d))
+            elif dimension == "3d" and planes3d.get("_fm"):
+                resident.thermal_3d_fm_batch(ctx, nlevel, d_wno, nwno, ng, nt, np.asarray(tlev3, dtype=float)[None],
+                                             [planes3d[th3[0]]], [planes3d[th3[1]]], None,
+                                             np.asarray(plev3, dtype=float)[None],
+                                             np.asarray(ubar1, dtype=float).reshape(1, ng, nt), [rs], atm.hard_surface,
+                                             [flux], gweight, tweight, [disk])
             elif dimension == "3d":                               # justdoit.py:502-514
                 resident.thermal_3d(ctx, nlevel, d_wno, nwno, ng, nt, tlev3, planes3d[th3[0]],
                                     planes3d[th3[1]], planes3d[th3[2]] if th3[2] else None, plev3, ubar1, rs,
@@ -1609,6 +1624,15 @@ def picaso(bundle, opacityclass, dimension="1d", calculation="reflected", full_o
 # ------------------------------------------------------------------------------------------------
 # one C call per spectrum (csrc/driver.hip): the launch sequence of the 1-D Toon path for every wavelength block
 # ------------------------------------------------------------------------------------------------
+def _reflected_3d_fm(ctx, nlevel, nwno, ng, nt, planes, rs, ubar0, ubar1, cos_theta, F0PI, single_phase, multi_phase,
+                     frac_a, frac_b, frac_c, constant_back, constant_forward, xint, gweight, tweight, albedo):
+    """``resident.reflected_3d`` for facet-major planes (one spectrum through ``reflected_3d_fm_batch``)."""
+    resident.reflected_3d_fm_batch(ctx, nlevel, nwno, ng, nt, [planes], [rs], np.asarray(ubar0, dtype=float).reshape(1, ng, nt),
+                                   np.asarray(ubar1, dtype=float).reshape(1, ng, nt), np.array([cos_theta], dtype=float),
+                                   [F0PI], single_phase, multi_phase, frac_a, frac_b, frac_c, constant_back,
+                                   constant_forward, [xint], gweight, tweight, [albedo])
+
+
 def _fetch(prefetched, key, dev, returns=None, integral=None):
     """Host copy of the resident result ``dev``: the pinned block ``finish.prefetch`` put on the stream when there is
     one (wait for that copy only), a synchronous copy otherwise.  A prefetched block one longer than the result carries
@@ -1878,8 +1902,9 @@ class _SolveBatch:
 
     def flush(self):
         for key, items in self.refl3.items():
-            nlevel, nwno, ng, nt, tt, _, gw, tw = key
-            resident.reflected_3d_batch(items[0]["ctx"], nlevel, nwno, ng, nt, [it["planes"] for it in items],
+            nlevel, nwno, ng, nt, tt, present, gw, tw = key
+            fn = resident.reflected_3d_fm_batch if "facet-major" in present else resident.reflected_3d_batch
+            fn(items[0]["ctx"], nlevel, nwno, ng, nt, [it["planes"] for it in items],
                                         [it["rs"] for it in items],
                                         np.stack([np.asarray(it["ubar0"], dtype=float).reshape(ng, nt) for it in items]),
                                         np.stack([np.asarray(it["ubar1"], dtype=float).reshape(ng, nt) for it in items]),
@@ -1887,8 +1912,9 @@ class _SolveBatch:
                                         [it["F0PI"] for it in items], *tt, [it["xint"] for it in items], gweight=gw,
                                         tweight=tw, albedo=[it["albedo"] for it in items])
         for key, items in self.therm3.items():
-            nlevel, nwno, ng, nt, hard, _, has_g, gw, tw = key
-            resident.thermal_3d_batch(items[0]["ctx"], nlevel, items[0]["wno"], nwno, ng, nt,
+            nlevel, nwno, ng, nt, hard, _, (has_g, fm), gw, tw = key
+            fn = resident.thermal_3d_fm_batch if fm else resident.thermal_3d_batch
+            fn(items[0]["ctx"], nlevel, items[0]["wno"], nwno, ng, nt,
                                       np.stack([it["tlevel"] for it in items]), [it["dtau"] for it in items],
                                       [it["w0"] for it in items], [it["cosb"] for it in items] if has_g else None,
                                       np.stack([it["plevel"] for it in items]),

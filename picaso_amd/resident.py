@@ -420,6 +420,54 @@ def reflected_3d_batch(ctx, nlevel, nwno, numg, numt, planes, surf_reflect, ubar
         _cd(constant_forward), p_x, ptr(gw) if fuse else None, ptr(tw) if fuse else None, p_al), ctx)
 
 
+def reflected_3d_fm_batch(ctx, nlevel, nwno, numg, numt, planes, surf_reflect, ubar0, ubar1, cos_theta, F0PI,
+                          single_phase, multi_phase, frac_a, frac_b, frac_c, constant_back, constant_forward,
+                          xint_at_top, gweight, tweight, albedo):
+    """``reflected_3d_batch`` on FACET-MAJOR planes -- ``(nfacets, rows, nwno)``, what the fused gas + mixing launch
+    writes for the tall atmosphere of all facets (``optics.compute_opacity_facet_major``): every facet of every spectrum
+    goes into the batched launch as a spectrum of its own with one facet (its planes = one slab of the stack, its geometry
+    = that facet's ``ubar0 / ubar1``; a wave then holds 64 wavelengths of one facet instead of the 64 facets of one
+    wavelength), followed by the disk sum of each spectrum.  Same kernel body, same bits as the facet-fastest layout."""
+    nspec, nfac = len(planes), numg * numt
+    u0 = f64(ubar0, (nspec, numg, numt)).reshape(nspec * nfac, 1, 1)
+    u1 = f64(ubar1, (nspec, numg, numt)).reshape(nspec * nfac, 1, 1)
+    ct = np.repeat(f64(np.zeros(nspec) + np.asarray(cos_theta, dtype=np.float64), (nspec,)), nfac)
+    rs, f0 = _per_spectrum(surf_reflect, nspec), _per_spectrum(F0PI, nspec)
+    keys = [k for k in REFLECTED_PLANES if planes[0].get(k) is not None]
+    pseudo = []
+    for pl in planes:
+        stride = {k: (pl[k].nbytes // nfac) for k in keys}
+        pseudo += [{k: pl[k].addr + f * stride[k] for k in keys} for f in range(nfac)]
+    xs = [x.addr + 8 * nwno * f for x in xint_at_top for f in range(nfac)]
+    reflected_3d_batch(ctx, nlevel, nwno, 1, 1, pseudo, [r for r in rs for _ in range(nfac)], u0, u1, ct,
+                       [x for x in f0 for _ in range(nfac)], single_phase, multi_phase, frac_a, frac_b, frac_c,
+                       constant_back, constant_forward, xs)
+    if albedo is not None and gweight is not None and tweight is not None:
+        cts = np.zeros(nspec) + np.asarray(cos_theta, dtype=np.float64)
+        for s in range(nspec):
+            compress_disco(ctx, nwno, float(cts[s]), xint_at_top[s], gweight, tweight, f0[s], albedo[s])
+
+
+def thermal_3d_fm_batch(ctx, nlevel, wno, nwno, numg, numt, tlevel_3d, dtau, w0, cosb, plevel_3d, ubar1, surf_reflect,
+                        hard_surface, int_at_top, gweight, tweight, flux_disk):
+    """``thermal_3d_batch`` on facet-major planes (see ``reflected_3d_fm_batch``)."""
+    nspec, nfac = len(dtau), numg * numt
+    u1 = f64(ubar1, (nspec, numg, numt)).reshape(nspec * nfac, 1, 1)
+    tl = np.ascontiguousarray(np.moveaxis(f64(tlevel_3d, (nspec, nlevel, numg, numt)).reshape(nspec, nlevel, nfac), 2, 1))
+    pl = np.ascontiguousarray(np.moveaxis(f64(plevel_3d, (nspec, nlevel, numg, numt)).reshape(nspec, nlevel, nfac), 2, 1))
+    rs = _per_spectrum(surf_reflect, nspec)
+
+    def slabs(arrs):
+        return [a.addr + f * (a.nbytes // nfac) for a in arrs for f in range(nfac)]
+    thermal_3d_batch(ctx, nlevel, wno, nwno, 1, 1, tl.reshape(nspec * nfac, nlevel, 1, 1), slabs(dtau), slabs(w0),
+                     slabs(cosb) if cosb is not None else None, pl.reshape(nspec * nfac, nlevel, 1, 1), u1,
+                     [r for r in rs for _ in range(nfac)], hard_surface,
+                     [x.addr + 8 * nwno * f for x in int_at_top for f in range(nfac)])
+    if flux_disk is not None and gweight is not None and tweight is not None:
+        for s in range(nspec):
+            compress_thermal(ctx, nwno, int_at_top[s], gweight, tweight, flux_disk[s])
+
+
 def thermal_3d_batch(ctx, nlevel, wno, nwno, numg, numt, tlevel_3d, dtau_3d, w0_3d, cosb_3d, plevel_3d, ubar1,
                      surf_reflect, hard_surface, int_at_top, gweight=None, tweight=None, flux_disk=None):
     """``len(dtau_3d)`` 3-D thermal spectra in ONE launch (``picaso_get_thermal_3d_batch_dev``): ``tlevel_3d`` /

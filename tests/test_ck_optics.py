@@ -629,3 +629,49 @@ def test_gpu_raman_oklopcic_plane_is_compute_raman(og, nlayer):
     px.raman_oklopcic_device(opa, tlayer, out)
     want = np.minimum(px.compute_raman(opa.nwno, nlayer, opa.wno, shifts, tlayer, c * 2.0, ji, dnu + 1.0), 0.99999)
     assert np.array_equal(out.to_host(), want, equal_nan=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("raman", ["none", "oklopcic"])
+def test_gpu_3d_facet_major_planes_equal_facet_fastest(og, raman, monkeypatch):
+    """A 3-D spectrum without cloud: the default path (ONE fused gas + mixing launch over the tall atmosphere of all facets,
+    facet-major planes, every facet a spectrum of its own in the batched solver launches) against the facet-fastest
+    planes of ``compute_opacity_facets`` -- single spectrum and phase curve, per-facet temperatures AND abundances,
+    bit for bit."""
+    from picaso_amd import justdoit as jdi
+    opa = jdi.opannection(filename_db=DB, query_method="linear")
+    if raman == "oklopcic":
+        opa.raman_stellar_shifts = og["in/raman_shifts"]
+        opa.raman_db = {"c": og["in/raman_c"], "ji": og["in/raman_ji"], "deltanu": og["in/raman_deltanu"]}
+    ng, nt = 3, 2
+    rng = np.random.default_rng(4)
+
+    def profile(k):
+        pr = {"pressure": og["in/plevel_bar"],
+              "temperature": og["in/tlevel"][:, None, None] * (1.0 + 0.05 * k + 0.1 * rng.random((1, ng, nt)))}
+        for m in ("H2", "He", "H2O", "CH4"):
+            pr[m] = og["in/mix/" + m]
+        pr["H2O"] = og["in/mix/H2O"][:, None, None] * (1.0 + 0.5 * rng.random((1, ng, nt)))
+        return pr
+    profs = [profile(k) for k in range(3)]
+
+    def run():
+        one = jdi.inputs()
+        one.gravity(gravity=float(og["in/gravity"]))
+        one.approx(raman=raman)
+        one.phase_angle(0.7, num_gangle=ng, num_tangle=nt)
+        one.atmosphere_3d(profs[0])
+        a = one.spectrum(opa, calculation="reflected+thermal", dimension="3d")
+        pc = jdi.inputs()
+        pc.gravity(gravity=float(og["in/gravity"]))
+        pc.approx(raman=raman)
+        pc.phase_curve_geometry("reflected", [0.0, 1.1, 2.3], num_gangle=ng, num_tangle=nt)
+        pc.atmosphere_4d(profs)
+        return a, pc.phase_curve(opa)
+    a_fm, c_fm = run()
+    monkeypatch.setenv("PICASO_AMD_FACET_FASTEST", "1")
+    a_ff, c_ff = run()
+    for key in ("albedo", "thermal"):
+        assert np.array_equal(a_fm[key], a_ff[key]), key
+    for ph in c_ff:
+        assert np.array_equal(c_fm[ph]["albedo"], c_ff[ph]["albedo"]), ph
