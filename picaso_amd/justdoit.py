@@ -1343,11 +1343,11 @@ def picaso(bundle, opacityclass, dimension="1d", calculation="reflected", full_o
 
     rs = _resident_vector(opa, "surf_reflect", atm.surf_reflect, nwno)
     d_f0 = _resident_vector(opa, "F0PI", 1.0 if inp["star"]["database"] == "nostar" else F0PI, nwno)
-    # 1-D Toon spectra with both legs: the thermal kernels go to a second stream that waits for the
+    # 1-D spectra (Toon and SH) with both legs: the thermal kernels go to a second stream that waits for the
     # opacity planes only, so they run next to the reflected-light kernel (each of the two alone
     # leaves SIMDs idle through its tail) instead of behind it
     tctx = ctx
-    if (dimension == "1d" and not is_sh and "reflected" in calculation and "thermal" in calculation
+    if (dimension == "1d" and "reflected" in calculation and "thermal" in calculation
             and os.environ.get("PICASO_AMD_OVERLAP_LEGS", "1") != "0"):
         tctx = _lib.aux_context(_lib.device_of(ctx))     # one per process and device, shared by every caller
         _lib.ctx_wait(tctx, ctx)                         # (in a batch: every member's, so the last one covers the launch)
@@ -1462,7 +1462,7 @@ def picaso(bundle, opacityclass, dimension="1d", calculation="reflected", full_o
                                     planes3d[th3[1]], planes3d[th3[2]] if th3[2] else None, plev3, ubar1, rs,
                                     atm.hard_surface, flux, gweight, tweight, disk)
             elif is_sh:                                           # justdoit.py:364-370
-                _thermal_sh(ctx, nlevel, d_wno, nwno, ng, nt, atm.level["temperature"], planes,
+                _thermal_sh(tctx, nlevel, d_wno, nwno, ng, nt, atm.level["temperature"], planes,
                             atm.level["pressure"], ubar1, rs, common["stream"], atm.hard_surface,
                             common["delta_eddington"], flux, gweight, tweight, disk)
             else:
