@@ -1343,11 +1343,11 @@ def picaso(bundle, opacityclass, dimension="1d", calculation="reflected", full_o
 
     rs = _resident_vector(opa, "surf_reflect", atm.surf_reflect, nwno)
     d_f0 = _resident_vector(opa, "F0PI", 1.0 if inp["star"]["database"] == "nostar" else F0PI, nwno)
-    # 1-D spectra (Toon and SH) with both legs: the thermal kernels go to a second stream that waits for the
+    # Spectra (Toon, SH, 3-D) with both legs: the thermal kernels go to a second stream that waits for the
     # opacity planes only, so they run next to the reflected-light kernel (each of the two alone
     # leaves SIMDs idle through its tail) instead of behind it
     tctx = ctx
-    if (dimension == "1d" and "reflected" in calculation and "thermal" in calculation
+    if ("reflected" in calculation and "thermal" in calculation and (dimension == "1d" or _batch is None)
             and os.environ.get("PICASO_AMD_OVERLAP_LEGS", "1") != "0"):
         tctx = _lib.aux_context(_lib.device_of(ctx))     # one per process and device, shared by every caller
         _lib.ctx_wait(tctx, ctx)                         # (in a batch: every member's, so the last one covers the launch)
@@ -1452,13 +1452,13 @@ def picaso(bundle, opacityclass, dimension="1d", calculation="reflected", full_o
                                            w0=planes3d[th3[1]], cosb=planes3d[th3[2]] if th3[2] else None,
                                            ubar1=ubar1, rs=rs, flux=flux, disk=disk, keep=planes3d))
             elif dimension == "3d" and planes3d.get("_fm"):
-                resident.thermal_3d_fm_batch(ctx, nlevel, d_wno, nwno, ng, nt, np.asarray(tlev3, dtype=float)[None],
+                resident.thermal_3d_fm_batch(tctx, nlevel, d_wno, nwno, ng, nt, np.asarray(tlev3, dtype=float)[None],
                                              [planes3d[th3[0]]], [planes3d[th3[1]]], None,
                                              np.asarray(plev3, dtype=float)[None],
                                              np.asarray(ubar1, dtype=float).reshape(1, ng, nt), [rs], atm.hard_surface,
                                              [flux], gweight, tweight, [disk])
             elif dimension == "3d":                               # justdoit.py:502-514
-                resident.thermal_3d(ctx, nlevel, d_wno, nwno, ng, nt, tlev3, planes3d[th3[0]],
+                resident.thermal_3d(tctx, nlevel, d_wno, nwno, ng, nt, tlev3, planes3d[th3[0]],
                                     planes3d[th3[1]], planes3d[th3[2]] if th3[2] else None, plev3, ubar1, rs,
                                     atm.hard_surface, flux, gweight, tweight, disk)
             elif is_sh:                                           # justdoit.py:364-370
@@ -1560,7 +1560,7 @@ def picaso(bundle, opacityclass, dimension="1d", calculation="reflected", full_o
     # planes read from the second stream stay alive until the results are in; everything else returns to the
     # context's block cache as soon as its kernels are enqueued (reuse is ordered on the stream: the phases of a
     # phase curve recycle one set of plane blocks)
-    keep_alive = [planes, planes_clear] if tctx is not ctx else []
+    keep_alive = [planes, planes_clear, planes3d] if tctx is not ctx else []
 
     def finish():
         # Results are read back leg by leg (each copy waits for the stream that produced it) and a leg's spectrum-wide
