@@ -77,6 +77,9 @@ enum { S_T = 0, S_XU, S_EO, S_KAPPA, S_ZETA, S_D1, S_D2 };   // late-use variabl
 #ifndef PZ_REFL_FAST_NONZP
 #define PZ_REFL_FAST_NONZP 1
 #endif
+#ifndef PZ_REFL_CLEAR_VARIANT
+#define PZ_REFL_CLEAR_VARIANT 1
+#endif
 #ifndef PZ_REFL_CLOUD_BODY
 #define PZ_REFL_CLOUD_BODY 1
 #endif
@@ -351,7 +354,7 @@ __device__ __forceinline__ double disk_finish(double c1, double acc, double F, d
 // the branch-free load sequence (the conditional loads cost the HBM-bound facet kernel 7 %)
 // The kernel body.  `bx_in` = this workgroup's column group within its spectrum, `by_in` = its angle group,
 // `angp` = the angle table (the kernel argument's, or the batch entry's).
-template <int NA, bool IS3D, bool ZP, bool FAST, bool BIG, bool DRV, typename AnglePtr>
+template <int NA, bool IS3D, bool ZP, bool FAST, bool BIG, int DRV, typename AnglePtr>
 __device__ __forceinline__ void reflected_toa_body(const ReflectedArgs &a, const unsigned bx_in, const unsigned by_in,
                                                    AnglePtr angp)
 {
@@ -418,9 +421,12 @@ __device__ __forceinline__ void reflected_toa_body(const ReflectedArgs &a, const
     // all wave-uniform (kernel arguments).  The 1-D default-options launches take the same patterns (round 4: the product
     // leaves tau / tau_og / gcos2 -- and for a cloud-free atmosphere everything but dtau and w0 -- out of HBM; the caller
     // asks picaso_reflected_1d_can_derive first); every other 1-D launch is handed all eleven planes
-    const bool derive_tau = DRV && a.tau == nullptr, derive_tauo = DRV && a.tau_og == nullptr;
-    const bool derive_g2 = DRV && a.gcos2 == nullptr, clear = DRV && a.ftau_cld == nullptr;
-    const bool alias_og = DRV && a.dtau_og == nullptr;
+    // DRV = 2 (1-D default options): the launcher saw that ONLY dtau and w0 exist -- the pattern of an atmosphere without
+    // cloud -- and says so at compile time: no flag, no test and no second copy of the layer body survive in this variant
+    constexpr bool CLEAR = (DRV == 2);
+    const bool derive_tau = CLEAR || (DRV && a.tau == nullptr), derive_tauo = CLEAR || (DRV && a.tau_og == nullptr);
+    const bool derive_g2 = CLEAR || (DRV && a.gcos2 == nullptr), clear = CLEAR || (DRV && a.ftau_cld == nullptr);
+    const bool alias_og = CLEAR || (DRV && a.dtau_og == nullptr);
     double tau_i = derive_tau ? 0.0 : p_tau[0];
     double tauo_pred = 0.0;          // tau_og[i-1] + dtau_og[i-1] of the layer above
 #pragma unroll
@@ -450,6 +456,7 @@ __device__ __forceinline__ void reflected_toa_body(const ReflectedArgs &a, const
             const unsigned o = voff0 + (unsigned)i * pitch8;
             L.dt = ld(a.dtau, o);
             L.w0 = ld(a.w0, o);
+            if constexpr (CLEAR) return;
             if (!derive_tau) L.tau_n = ld(a.tau + pitch, o);
             if (!clear) {
                 L.g = ld(a.cosb, o);
@@ -510,6 +517,17 @@ __device__ __forceinline__ void reflected_toa_body(const ReflectedArgs &a, const
         L.cbo = p_cbo[o];
     };
     auto prep = [&](LayerIn &L) {
+        if constexpr (CLEAR) {
+            L.g = 0.0; L.fc = 0.0; L.fr = 1.0; L.gcos2 = 0.5; L.cbo = 0.0;
+            L.dto = L.dt; L.w0o = L.w0;
+            L.tau_n = tau_i + L.dt;
+            L.tauo = tauo_pred;
+            L.cum_tau = L.eo_ok = L.same_dt = L.nocld = L.allf = true;
+            L.af_cloud = false;
+            tau_i = L.tau_n;
+            tauo_pred = L.tauo + L.dto;
+            return;
+        }
         if constexpr (DRV) {
             if (clear) { L.g = 0.0; L.fc = 0.0; L.fr = 1.0; L.gcos2 = 0.5; L.cbo = 0.0; }
             else if (derive_g2) L.gcos2 = 0.5 * L.fr;
@@ -535,6 +553,7 @@ __device__ __forceinline__ void reflected_toa_body(const ReflectedArgs &a, const
             reflected_layer<NA, IS3D, ZP, FIRST_, LAST_, LDS, FAST, false, true, 2>(a, L_, S, g, K, F, clip, tc, b_top); \
         else                                                                                             \
             reflected_layer<NA, IS3D, ZP, FIRST_, LAST_, LDS, FAST>(a, L_, S, g, K, F, clip, tc, b_top); \
+        if constexpr (CLEAR) __builtin_amdgcn_sched_barrier(0);   /* straight-line code: keep the layers apart */ \
     } while (0)
 
     // Two register sets used alternately (no copy) for one or two angles per lane -- the HBM-bound 3-D facet
@@ -631,7 +650,7 @@ __device__ __forceinline__ void xcd_decode(unsigned b, unsigned nrep, unsigned n
     }
 }
 
-template <int NA, bool IS3D, bool ZP, bool FAST = false, bool BIG = false, bool DRV = false>
+template <int NA, bool IS3D, bool ZP, bool FAST = false, bool BIG = false, int DRV = 0>
 __global__ __launch_bounds__(PZ_REFL_BLOCK, (BIG ? 1 : NA <= 2 ? PZ_REFL_MINWAVES_FEW : PZ_REFL_MINWAVES)) void k_reflected_toa(const ReflectedArgs a)
 {
     // Angle groups as separate workgroups (ny > 1): every group re-reads the eleven planes of its columns.
@@ -652,7 +671,7 @@ __global__ __launch_bounds__(PZ_REFL_BLOCK, (BIG ? 1 : NA <= 2 ? PZ_REFL_MINWAVE
 // The same body for `nspec` spectra in one grid (picaso_get_reflected_1d_batch_dev): the workgroup finds its
 // spectrum's planes, outputs and angle table in the device table a.batch.  A separate instantiation so that the
 // single-spectrum kernels keep their register allocation; same operations, same bits.
-template <int NA, bool IS3D, bool ZP, bool FAST = false, bool BIG = false, bool DRV = false>
+template <int NA, bool IS3D, bool ZP, bool FAST = false, bool BIG = false, int DRV = 0>
 __global__ __launch_bounds__(PZ_REFL_BLOCK, (BIG ? 1 : NA <= 2 ? PZ_REFL_MINWAVES_FEW : PZ_REFL_MINWAVES)) void k_reflected_toa_batch(const ReflectedArgs a)
 {
     unsigned spec, bx, by = 0;
@@ -716,13 +735,17 @@ static int launch1d(picaso_ctx *ctx, const ReflectedArgs &a_in)
     const bool drv = !(a.tau && a.tau_og && a.gcos2 && a.ftau_cld && a.dtau_og);
     if (drv) {
         if (!fast) return fail(ctx, "reflected: planes may be left out only with the reference's default options");
+        // only dtau and w0: the compile-time form (five angles, symmetric geometry: the shape of a spectrum() call)
+        const bool only2 = !a.tau && !a.tau_og && !a.gcos2 && !a.ftau_cld && !a.dtau_og && PZ_REFL_CLEAR_VARIANT;
         if (a.batch) {
-            if (zp && big) { if constexpr (NA == 5) PZ_GO((k_reflected_toa_batch<NA, false, true, true, true, true>)); }
-            else if (zp) PZ_GO((k_reflected_toa_batch<NA, false, true, true, false, true>));
-            else PZ_GO((k_reflected_toa_batch<NA, false, false, true, false, true>));
-        } else if (zp && big) { if constexpr (NA == 5) PZ_GO((k_reflected_toa<NA, false, true, true, true, true>)); }
-        else if (zp) PZ_GO((k_reflected_toa<NA, false, true, true, false, true>));
-        else PZ_GO((k_reflected_toa<NA, false, false, true, false, true>));
+            if (zp && big) { if constexpr (NA == 5) PZ_GO((k_reflected_toa_batch<NA, false, true, true, true, 1>)); }
+            else if (zp && only2 && NA == 5) { if constexpr (NA == 5) PZ_GO((k_reflected_toa_batch<NA, false, true, true, false, 2>)); }
+            else if (zp) PZ_GO((k_reflected_toa_batch<NA, false, true, true, false, 1>));
+            else PZ_GO((k_reflected_toa_batch<NA, false, false, true, false, 1>));
+        } else if (zp && big) { if constexpr (NA == 5) PZ_GO((k_reflected_toa<NA, false, true, true, true, 1>)); }
+        else if (zp && only2 && NA == 5) { if constexpr (NA == 5) PZ_GO((k_reflected_toa<NA, false, true, true, false, 2>)); }
+        else if (zp) PZ_GO((k_reflected_toa<NA, false, true, true, false, 1>));
+        else PZ_GO((k_reflected_toa<NA, false, false, true, false, 1>));
         PZ_HIP(ctx, hipGetLastError());
         return 0;
     }
