@@ -123,7 +123,7 @@ def workload_reflected(ctx, args, lo, hi, seed, nwno_total, scene=None):
                 abytes=8 * n * (9 * nlayer + 2 * nlevel + 2 + ng + 1),
                 # launches of at most one 64-column block per CU (256 CUs) run the cooperative kernel (api.hip)
                 kernel=("k_reflected_coop<true>" if n <= 16384 and ng <= 5 and not os.environ.get("PICASO_AMD_REFL_NO_COOP")
-                        else "k_reflected_toa<%d, false, true, true, false, false>" % ng),
+                        else "k_reflected_toa<%d, false, true, true, false, 0>" % ng),
                 workload="BASELINE configs[2]: Toon two-stream reflected light (get_reflected_1d + "
                          "compress_disco), TTHG_ray, N=2, delta-Eddington, Rayleigh + cloud slab",
                 metric="spectra/sec (1e5 wave x 90 layer reflected)")
