@@ -77,6 +77,9 @@ enum { S_T = 0, S_XU, S_EO, S_KAPPA, S_ZETA, S_D1, S_D2 };   // late-use variabl
 #ifndef PZ_REFL_FAST_NONZP
 #define PZ_REFL_FAST_NONZP 1
 #endif
+#ifndef PZ_REFL_LEVELS_VARIANT
+#define PZ_REFL_LEVELS_VARIANT 1
+#endif
 #ifndef PZ_REFL_CLEAR_VARIANT
 #define PZ_REFL_CLEAR_VARIANT 1
 #endif
@@ -423,10 +426,16 @@ __device__ __forceinline__ void reflected_toa_body(const ReflectedArgs &a, const
     // asks picaso_reflected_1d_can_derive first); every other 1-D launch is handed all eleven planes
     // DRV = 2 (1-D default options): the launcher saw that ONLY dtau and w0 exist -- the pattern of an atmosphere without
     // cloud -- and says so at compile time: no flag, no test and no second copy of the layer body survive in this variant
-    constexpr bool CLEAR = (DRV == 2);
-    const bool derive_tau = CLEAR || (DRV && a.tau == nullptr), derive_tauo = CLEAR || (DRV && a.tau_og == nullptr);
-    const bool derive_g2 = CLEAR || (DRV && a.gcos2 == nullptr), clear = CLEAR || (DRV && a.ftau_cld == nullptr);
-    const bool alias_og = CLEAR || (DRV && a.dtau_og == nullptr);
+    // DRV = 3: the other pattern of the product (a cloudy atmosphere): tau, tau_og and gcos2 left out, the cloud planes
+    // present -- known at compile time, so the two tests of "the level depths are the running sums" (they are: they are
+    // formed here), the exec-mask tests and the branches behind them disappear from every layer (timing build of the
+    // eleven-plane kernel with those two tests compiled out: 0.223 -> 0.207 ms)
+    constexpr bool CLEAR = (DRV == 2), LEVELS = (DRV == 3);
+    const bool derive_tau = CLEAR || LEVELS || (DRV && a.tau == nullptr);
+    const bool derive_tauo = CLEAR || LEVELS || (DRV && a.tau_og == nullptr);
+    const bool derive_g2 = CLEAR || LEVELS || (DRV && a.gcos2 == nullptr);
+    const bool clear = CLEAR || (!LEVELS && DRV && a.ftau_cld == nullptr);
+    const bool alias_og = CLEAR || (!LEVELS && DRV && a.dtau_og == nullptr);
     double tau_i = derive_tau ? 0.0 : p_tau[0];
     double tauo_pred = 0.0;          // tau_og[i-1] + dtau_og[i-1] of the layer above
 #pragma unroll
@@ -457,6 +466,15 @@ __device__ __forceinline__ void reflected_toa_body(const ReflectedArgs &a, const
             L.dt = ld(a.dtau, o);
             L.w0 = ld(a.w0, o);
             if constexpr (CLEAR) return;
+            if constexpr (LEVELS) {
+                L.g = ld(a.cosb, o);
+                L.fc = ld(a.ftau_cld, o);
+                L.fr = ld(a.ftau_ray, o);
+                L.cbo = ld(a.cosb_og, o);
+                L.dto = ld(a.dtau_og, o);
+                L.w0o = ld(a.w0_og, o);
+                return;
+            }
             if (!derive_tau) L.tau_n = ld(a.tau + pitch, o);
             if (!clear) {
                 L.g = ld(a.cosb, o);
@@ -524,6 +542,19 @@ __device__ __forceinline__ void reflected_toa_body(const ReflectedArgs &a, const
             L.tauo = tauo_pred;
             L.cum_tau = L.eo_ok = L.same_dt = L.nocld = L.allf = true;
             L.af_cloud = false;
+            tau_i = L.tau_n;
+            tauo_pred = L.tauo + L.dto;
+            return;
+        }
+        if constexpr (LEVELS) {
+            L.gcos2 = 0.5 * L.fr;
+            L.tau_n = tau_i + L.dt;
+            L.tauo = tauo_pred;
+            L.cum_tau = L.eo_ok = true;
+            L.same_dt = __all(L.dto == L.dt);
+            L.nocld = __all(L.fc == 0.0);
+            L.allf = L.same_dt;
+            L.af_cloud = !L.same_dt && !L.nocld;
             tau_i = L.tau_n;
             tauo_pred = L.tauo + L.dto;
             return;
@@ -737,13 +768,16 @@ static int launch1d(picaso_ctx *ctx, const ReflectedArgs &a_in)
         if (!fast) return fail(ctx, "reflected: planes may be left out only with the reference's default options");
         // only dtau and w0: the compile-time form (five angles, symmetric geometry: the shape of a spectrum() call)
         const bool only2 = !a.tau && !a.tau_og && !a.gcos2 && !a.ftau_cld && !a.dtau_og && PZ_REFL_CLEAR_VARIANT;
+        const bool levels3 = !a.tau && !a.tau_og && !a.gcos2 && a.ftau_cld && a.dtau_og && PZ_REFL_LEVELS_VARIANT;
         if (a.batch) {
             if (zp && big) { if constexpr (NA == 5) PZ_GO((k_reflected_toa_batch<NA, false, true, true, true, 1>)); }
             else if (zp && only2 && NA == 5) { if constexpr (NA == 5) PZ_GO((k_reflected_toa_batch<NA, false, true, true, false, 2>)); }
+            else if (zp && levels3 && NA == 5) { if constexpr (NA == 5) PZ_GO((k_reflected_toa_batch<NA, false, true, true, false, 3>)); }
             else if (zp) PZ_GO((k_reflected_toa_batch<NA, false, true, true, false, 1>));
             else PZ_GO((k_reflected_toa_batch<NA, false, false, true, false, 1>));
         } else if (zp && big) { if constexpr (NA == 5) PZ_GO((k_reflected_toa<NA, false, true, true, true, 1>)); }
         else if (zp && only2 && NA == 5) { if constexpr (NA == 5) PZ_GO((k_reflected_toa<NA, false, true, true, false, 2>)); }
+        else if (zp && levels3 && NA == 5) { if constexpr (NA == 5) PZ_GO((k_reflected_toa<NA, false, true, true, false, 3>)); }
         else if (zp) PZ_GO((k_reflected_toa<NA, false, true, true, false, 1>));
         else PZ_GO((k_reflected_toa<NA, false, false, true, false, 1>));
         PZ_HIP(ctx, hipGetLastError());
