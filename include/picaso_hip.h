@@ -337,6 +337,19 @@ int picaso_get_reflected_SH(picaso_ctx *ctx, int nlevel, int nwno, int numg, int
                             double constant_back, double constant_forward, int stream, double b_top,
                             int flx, int single_form, int compound_f_deltaM, double *xint_at_top,
                             double *flux);
+/* Cloud-free columns: picaso_get_reflected_SH_dev accepts NULL for tau, cosb, ftau_cld, ftau_ray, f_deltaM, dtau_og,
+ * tau_og, w0_og and cosb_og TOGETHER (all of them or none; cosb is never read and may be NULL on its own) -- without
+ * cloud they are constants (ftau_cld = 0, ftau_ray = 1, cosb = f_deltaM = 0), copies (dtau_og = dtau, w0_og = w0) and
+ * running sums of dtau (tau = tau_og), what optics.compute_opacity writes for such an atmosphere (optics.py:303-431).
+ * The launch then reads dtau and w0 only and shares the angle-independent half of every layer (stream coefficients,
+ * modes, the matrix recursion of the sweep) between the disk angles of a lane (k_sh4_clear, csrc/sh.hip).  Built for
+ * stream = 4, the reference's default SH options (config.json) and flx = 0: this function returns 1 when a call with
+ * these options may leave the planes out, 0 when it needs all of them.  Results agree with the full-plane launch to
+ * <= 1e-9 relative (as both do with the reference), not bit for bit (the full-plane kernel takes angle-dependent and angle-independent reciprocals of a
+ * layer from one Newton iteration); a column's bits do not depend on the launch shape. */
+int picaso_reflected_SH_can_derive(int stream, int w_single_form, int w_multi_form, int psingle_form,
+                                   int w_single_rayleigh, int w_multi_rayleigh, int psingle_rayleigh, double frac_c,
+                                   int single_form, int flx);
 int picaso_get_reflected_SH_dev(picaso_ctx *ctx, int nlevel, int nwno, long plane_pitch, int numg,
                                 int numt, const double *dtau, const double *tau, const double *w0,
                                 const double *cosb, const double *ftau_cld, const double *ftau_ray,

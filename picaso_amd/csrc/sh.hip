@@ -1029,13 +1029,15 @@ __device__ __forceinline__ Blk<NB> subx(const Blk<NB> &A, const Blk<NB> &B)
 }
 
 // modes_sh4 / modes_sh2 with the arithmetic written out (fluxes.py:3388-3434, 3245-3251)
-struct ModesT4 { double lam[2], E[2], iE[2], R[2], Q[2], S[2]; Blk<2> Mn, Pl; };
+struct ModesT4 { double lam[2], E[2], iE[2], R[2], Q[2], S[2], beta, gama; Blk<2> Mn, Pl; };
 __device__ __forceinline__ void modes_sh4x(const double (&a)[4], double dt, ModesT4 &M, const Exp2Coef &K)
 {
     const double a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3];
     const double a01 = a0 * a1;
     const double beta = (a01 + div_const(4 * (a0 * a3), 9.0, R9)) + div_const(a2 * a3, 9.0, R9);
     const double gama = div_const((a01 * a2) * a3, 9.0, R9);
+    M.beta = beta;
+    M.gama = gama;
     const double disc = fsqrt(fma(beta, beta, -(4 * gama)));
     const double x1 = 0.5 * (beta + disc), x2 = 0.5 * (beta - disc);
     const double il1 = frsq(x1), il2 = frsq(x2);
@@ -1307,17 +1309,17 @@ static void launch_sht_na(picaso_ctx *ctx, const SHTArgs &a, int na, int nchunk)
 // counted from the source for SH4); one wave alone on its SIMD issues an fp64 instruction every ~5.5 cycles, two
 // or more share the 4 cycles of the pipe, and a launch whose waves are not a multiple of the 2 x SIMD slots pays
 // for the partly filled last round.
-static int sh_thermal_angles_per_lane(const picaso_ctx *ctx, long ncol, int nang)
+static int sh_angles_per_lane(const picaso_ctx *ctx, long ncol, int nang, double S, double A, const char *env,
+                              int max_per_lane = 5)
 {
-    if (const char *e = getenv("PICASO_AMD_SHT_ANGLES")) {
+    if (const char *e = getenv(env)) {
         const int m = atoi(e);
-        if (m >= 1 && m <= 5) return m;
+        if (m >= 1 && m <= max_per_lane) return m;
     }
-    const double S = 400.0, A = 110.0;
     const long simds = 4L * ctx->ncu, groups = (ncol + 63) / 64;
     int best = 1;
     double best_t = 1e300;
-    for (int m = 1; m <= 5; ++m) {
+    for (int m = 1; m <= max_per_lane; ++m) {
         const int nchunk = (nang + m - 1) / m;
         const long waves = groups * nchunk;
         const double per_wave = S + A * ((double)nang / nchunk);      // mean chunk
@@ -1332,7 +1334,7 @@ static int sh_thermal_angles_per_lane(const picaso_ctx *ctx, long ncol, int nang
 
 static int launch_sh_thermal(picaso_ctx *ctx, SHTArgs &a, int stream, int nang, const double *ubar1, double *xint)
 {
-    const int m = sh_thermal_angles_per_lane(ctx, a.nwno, nang);
+    const int m = sh_angles_per_lane(ctx, a.nwno, nang, 400.0, 110.0, "PICASO_AMD_SHT_ANGLES");
     const int nchunk = (nang + m - 1) / m;
     const int per_lane = (nang + nchunk - 1) / nchunk;                           // nearly equal chunks, last one short
     const int per_launch = (SH_MAX_ANG / per_lane) * per_lane;                   // whole chunks per launch
@@ -1354,6 +1356,296 @@ static int launch_sh_thermal(picaso_ctx *ctx, SHTArgs &a, int stream, int nang, 
         const int chunks = (na + per_lane - 1) / per_lane;
         if (stream == 4) launch_sht_na<2>(ctx, a, per_lane, chunks);
         else launch_sht_na<1>(ctx, a, per_lane, chunks);
+        PZ_HIP(ctx, hipGetLastError());
+    }
+    return 0;
+}
+
+static SHArgs::Angle make_sh_angle(double u0, double u1, bool thermal);
+
+// ---------------------------------------------------------------------------------------------------------------
+// Reflected light, SH4, cloud-free columns, the reference's default options: the angle-independent half of a layer
+// shared between the disk angles of a lane (review item: "measure the angle sharing instead of modelling it").
+//
+// Without cloud every l >= 1 moment of the phase function is multiplied by ftau_cld = 0 (w_*_rayleigh = 1), so the
+// Legendre weights are (1, 0, ftau_ray / 2, 0) with ftau_ray = 1, cosb = 0 makes the delta-scaling the identity
+// (f_deltaM = 0: dtau_og = dtau, w0_og = w0, tau_og = tau -- and the reference's in-place compounding of f_deltaM,
+// which gives every angle of a cloudy column its own matrices, multiplies a zero), and the level depths are the
+// running sums of dtau.  The stream coefficients a_l = (1 - w0, 3, 5 - w0 / 2, 7), the two modes, the blocks Mn / Pl
+// and the matrix half of the sweep (R, S, the two inverses) are then the same for every angle; what is left per
+// angle is the particular solution along 1/u0, the right-hand sides of the elimination, the source-function weights
+// along u1 and the update of its TOA functional: ~190 fp64 instructions per layer shared, ~275 per angle (from the
+// timings below) -- k_sh<2,false,false,true> spends ~590 per angle.  The launch reads dtau and w0 only (and F0PI,
+// surf_reflect): picaso_get_reflected_SH_dev with the nine other plane arguments NULL.
+//
+// Same formulas in the same order as sh_body (fluxes.py:2675-2976, 3336-3607) with the exact zeros dropped, written
+// out like k_sh_thermal (contraction off, explicit fma): a column's result depends neither on the launch shape nor on
+// how many angles share its lane.  It is NOT bit-identical to k_sh on the full plane set of the same column -- k_sh
+// takes six reciprocals of a layer, two of them along the angle, from one Newton core (modes_sh4_batched), so even
+// its angle-independent blocks carry the angle in their last bits; the two agree to <= 1e-9 like each does with the
+// oracle (observed 5e-10 over 1e5 columns; tests/test_sh_clear_gpu.py).
+// ---------------------------------------------------------------------------------------------------------------
+#pragma clang fp contract(off)
+
+struct SHCArgs {
+    int nlayer, nwno;
+    long pitch;
+    const double *dtau, *w0, *surf_reflect, *F0PI;
+    int na;                                         // angles of this launch: blockIdx.y = chunk of NA of them
+    struct Angle {
+        double u0, iu0, iu1, mus, imus, nl0, nl1, nlm;   // as SHArgs::Angle
+        double x2, x4;                              // (1/u0)^2, (1/u0)^4
+        double p2u0, hp2u1;                         // P_2(-u0); P_2(u1) / 2
+        int sym;                                    // u0 == u1
+    } ang[SH_MAX_ANG];
+    double psing;                                   // Rayleigh single scattering 0.75 (1 + cos_theta^2), :2846
+    double b_top;
+    double *xint;                                   // first angle of this launch, (na, nwno)
+};
+
+// Angles per lane: two.  Measured at 1e5 x 90 x 5 (tools/sh_clear_time.py; the full-plane kernel on the same cloud-free
+// scene: 1.009 ms): one angle per lane 0.804 ms (what dropping the cloud arithmetic and nine planes gives by itself), two
+// 0.667 (198 -> 256 VGPRs, 6 spilled, still two waves per SIMD), three 0.80 (100 VGPRs spilled to scratch), five 1.52 --
+// or 0.80 in 352 registers with one wave per SIMD (1 563 waves on 1 024 SIMDs: two rounds).  The per-angle sweep state in
+// LDS instead (11 doubles per angle, a plain loop over the angles in 232 VGPRs): 0.884 / 0.735 / 0.737 for one / two /
+// three angles per lane -- the LDS round trips cost more than the third angle's share of the common half saves.
+// From the two register timings: ~190 instructions per layer shared, ~275 per angle.
+constexpr int SHC_MAX_PER_LANE = 2;
+
+template <int NA>
+__global__ __launch_bounds__(256, 2) void k_sh4_clear(const SHCArgs a)
+{
+    constexpr int NB = 2;
+    const long w = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= a.nwno) return;
+    const int n = a.nlayer;
+    const long pitch = a.pitch;
+    const int k0 = blockIdx.y * NA;
+    const int na = min(NA, a.na - k0);
+    const SHCArgs::Angle *const ang = a.ang + k0;
+    Exp2Coef K;
+    K.load();
+    const double F = a.F0PI[w], rs = a.surf_reflect[w];
+    const double CLIP2 = -35.0 * LOG2E;
+    // per angle: transmission to the top T, TOA functional J = kappa + zeta . v, sweep right-hand side delta, the
+    // beam exponential at the layer top and the previous layer's particular solution at its bottom
+    double T[NA], kappa[NA], zeta[NA][NB], delta[NA][NB], e_top[NA], p_zmn_up[NA][NB], p_zpl_up[NA][NB];
+#pragma unroll
+    for (int k = 0; k < NA; ++k) {
+        T[k] = 1.0;
+        kappa[k] = 0.0;
+        e_top[k] = 1.0;                                                      // tau[0] = 0 (optics.py cumsum)
+#pragma unroll
+        for (int r = 0; r < NB; ++r) zeta[k][r] = delta[k][r] = p_zmn_up[k][r] = p_zpl_up[k][r] = 0.0;
+    }
+    Blk<NB> R, pMn, pPl, pME, pPE;
+    double tau_t = 0.0;
+
+    for (int i = 0; i < n; ++i) {
+        const long o = (long)i * pitch + w;
+        const double dt = a.dtau[o], w0 = a.w0[o];
+        const double tau_b = tau_t + dt;
+        // ---- stream coefficients and modes (:2858-2860, 3388-3434) ----
+        const double al[4] = {1.0 - w0, 3.0, fma(-w0, 0.5, 5.0), 7.0};
+        ModesT4 M;
+        modes_sh4x(al, dt, M, K);
+        const Blk<NB> ME = scale_cols(M.Mn, M.E), PE = scale_cols(M.Pl, M.E);
+        // beam source moments b_l = F w0 w_single_l P_l(-u0) / 4 pi: b_0 for all angles, b_2 = fw2 P_2(-u0) / 4 pi
+        const double b0 = (F * w0) * (0.25 / PI), fw2 = F * (w0 * 0.5);
+        const double sgl = div_const(w0 * F, FOURPI, R4PI) * a.psing;         // :2959-2965
+        const double a0 = al[0], a2 = al[2];
+        const double A_ = 3.0 * b0, a3b0 = 7.0 * b0;
+
+        // ---- elimination, matrix half (angle independent) ----
+        Blk<NB> Rn, Sm, A2i, G, Ki, Mni;
+        if (i == 0) {
+            Mni = invx(M.Mn);
+            Rn = mmx(Mni, PE);
+            Sm = Rn; A2i = Rn; G = Rn; Ki = Rn;                              // not used for i == 0
+        } else {
+            const Blk<NB> A1 = subx(pPl, mmx(pME, R)), A2 = subx(pMn, mmx(pPE, R));
+            A2i = invx(A2);
+            G = mmx(A1, A2i);
+            Ki = invx(subx(M.Mn, mmx(G, M.Pl)));
+            const Blk<NB> GM = subx(PE, mmx(G, ME));
+            Rn = mmx(Ki, GM);
+            Sm = mmx(A2i, subx(ME, mmx(M.Pl, Rn)));
+            Mni = Rn;                                                        // not used for i > 0
+        }
+
+        // ---- per angle ----
+#pragma unroll
+        for (int k = 0; k < NA; ++k) {
+            if (k >= na) break;
+            const SHCArgs::Angle &g = ang[k];
+            const double iu1 = g.iu1, x = g.iu0, x2 = g.x2;
+            const double edt = fexp2(dt * g.nl1, K);                         // exp(-dtau/u1)
+            // particular solution eta_l = Delta_l / Delta (:3397-3416) with b_1 = b_3 = 0
+            const double b2 = (fw2 * g.p2u0) * (0.25 / PI);
+            const double iDel = frcp(9 * ((g.x4 - M.beta * x2) + M.gama));
+            const double P = fma(a2, 7.0, -(9 * x2)), Q = fma(a0, 3.0, -x2);
+            const double a3b2 = 7.0 * b2, b0x = b0 * x;
+            const double B_ = a3b2 - 2 * a3b0, C_ = -b0x, E_ = -(3 * (b2 * x)), F_ = -(3 * b0x);
+            double eta[4];
+            eta[0] = fma(A_, P, 2 * (B_ * x2)) * iDel;
+            eta[1] = fma(C_, P, -((2 * a0) * (a3b2 * x))) * iDel;
+            eta[2] = fma(a3b2, Q, -(14.0 * (C_ * x))) * iDel;
+            eta[3] = fma(E_, Q, 2 * (F_ * x2)) * iDel;
+            const double h0 = 0.5 * eta[0], e58 = 0.625 * eta[2], m0 = -0.125 * eta[0];
+            const double zpl0 = ((h0 + eta[1]) + e58) * (2 * PI), zmn0 = ((h0 - eta[1]) + e58) * (2 * PI);
+            const double zpl1 = ((m0 + e58) + eta[3]) * (2 * PI), zmn1 = ((m0 + e58) - eta[3]) * (2 * PI);
+            const double ed = e_top[k];                                      // exp(-clip35(tau[i]/u0))
+            const double eu = fexp2_clip(tau_b * g.nl0, K);
+            e_top[k] = eu;
+            const double zmn_dn[NB] = {zmn0 * ed, zmn1 * ed}, zpl_dn[NB] = {zpl0 * ed, zpl1 * ed};
+            const double zmn_up[NB] = {zmn0 * eu, zmn1 * eu}, zpl_up[NB] = {zpl0 * eu, zpl1 * eu};
+
+            // source-function weights along u1 (:2898-2970, 3601-3605): the odd moments vanish
+            const double e01 = fma(g.hp2u1, M.Q[0], 1.0), e23 = fma(g.hp2u1, M.Q[1], 1.0);
+            const double cm[4] = {e01, e01, e23, e23};
+            const double Tk = T[k];
+            const double Ti = Tk * iu1, tw = Ti * w0;
+            const bool noclip_lane = (iu1 + M.lam[0]) * dt <= 35.0;          // per lane; the work is wave-uniform (k_sh)
+            const bool noclip = __all(noclip_lane);
+            double gd[NB], gv[NB];
+#pragma unroll
+            for (int r = 0; r < NB; ++r) {
+                const double alpha = iu1 + M.lam[r], beta = iu1 - M.lam[r];
+                const double rab = frcp(alpha * beta);
+                double ea = edt * M.E[r], eb = edt * M.iE[r];
+                if (!noclip) {
+                    const double ead = fexpk(-clip35(alpha * dt), K), ebd = fexpk(-clip35(beta * dt), K);
+                    ea = noclip_lane ? ea : ead;
+                    eb = noclip_lane ? eb : ebd;
+                }
+                const double ha = (1 - ea) * (rab * beta), hb = (1 - eb) * (rab * alpha);
+                gd[r] = (tw * cm[2 * r]) * ha;
+                gv[r] = ((tw * cm[2 * r + 1]) * hb) * M.E[r];
+            }
+            // (1 - exp(-clip35(mus dtau)))/mus (:2901-2905); mus = 2/u1 in the symmetric geometry
+            const bool sq_lane = g.sym && (g.mus * dt <= 35.0);
+            double e_mus = edt * edt;
+            if (!__all(sq_lane)) {
+                const double d = fexp2_clip(dt * g.nlm, K);
+                e_mus = sq_lane ? e_mus : d;
+            }
+            const double om = 1 - e_mus;
+            const double expon1 = (om * g.imus) * fmax(ed, EXP_M35);
+            const double Nsum = fma(g.hp2u1, eta[2], eta[0]) * expon1;      // :2919-2920, 2945-2948
+            // exp(-tau_og/u0) at the layer top, unclipped (:2962): the exponential at hand unless its clip bound
+            const double targ = tau_t * g.nl0;
+            double e_tauo = ed;
+            if (!__all(targ >= CLIP2)) {
+                const double d = fexp2(targ, K);
+                e_tauo = (targ >= CLIP2) ? ed : d;
+            }
+            const double single = ((sgl * om) * e_tauo) * g.imus;
+            double c = Ti * fma(w0, Nsum, single);
+            const double Tn = Tk * edt;
+            T[k] = Tn;
+            if (i == n - 1) {             // xint[n] = flux_bot/pi = (Pl E d + Mn v + zpl_up)[0]/pi  (:2891, :2967)
+                const double tp = Tn * (1.0 / PI);
+#pragma unroll
+                for (int r = 0; r < NB; ++r) {
+                    gd[r] = fma(tp, PE.m[0][r], gd[r]);
+                    gv[r] = fma(tp, M.Mn.m[0][r], gv[r]);
+                }
+                c = fma(tp, zpl_up[0], c);
+            }
+            // elimination, right-hand sides
+            double z2[NB], deltan[NB];
+            mtvx(Rn, gd, z2);
+            if (i == 0) {
+                const double bt[NB] = {a.b_top - zmn_dn[0], -a.b_top / 4 - zmn_dn[1]};    // :3479-3480
+                mvx(Mni, bt, deltan);
+                kappa[k] = c + dotx(gd, deltan);
+#pragma unroll
+                for (int r = 0; r < NB; ++r) zeta[k][r] = gv[r] - z2[r];
+            } else {
+                double cP[NB], cM[NB], t1[NB], t2[NB], rhs[NB], tv[NB], t[NB], z1[NB];
+                mvx(pPE, delta[k], t1);
+                mvx(pME, delta[k], t2);
+#pragma unroll
+                for (int r = 0; r < NB; ++r) {
+                    cP[r] = (zpl_dn[r] - p_zpl_up[k][r]) - t1[r];
+                    cM[r] = (t2[r] + p_zmn_up[k][r]) - zmn_dn[r];
+                }
+                mvx(G, cP, rhs);
+#pragma unroll
+                for (int r = 0; r < NB; ++r) rhs[r] += cM[r];
+                mvx(Ki, rhs, deltan);
+                mvx(M.Pl, deltan, tv);
+#pragma unroll
+                for (int r = 0; r < NB; ++r) tv[r] += cP[r];
+                mvx(A2i, tv, t);
+                kappa[k] = ((kappa[k] + dotx(zeta[k], t)) + dotx(gd, deltan)) + c;
+                mtvx(Sm, zeta[k], z1);
+#pragma unroll
+                for (int r = 0; r < NB; ++r) zeta[k][r] = (z1[r] + gv[r]) - z2[r];
+            }
+#pragma unroll
+            for (int r = 0; r < NB; ++r) {
+                delta[k][r] = deltan[r];
+                p_zmn_up[k][r] = zmn_up[r];
+                p_zpl_up[k][r] = zpl_up[r];
+            }
+        }
+        R = Rn;
+        pMn = M.Mn; pPl = M.Pl; pME = ME; pPE = PE;
+        tau_t = tau_b;
+    }
+    // ---- surface rows (:3484-3494) ----
+    Blk<NB> W, L;
+#pragma unroll
+    for (int r = 0; r < NB; ++r)
+#pragma unroll
+        for (int s_ = 0; s_ < NB; ++s_) {
+            W.m[r][s_] = fma(-rs, pME.m[r][s_], pPE.m[r][s_]);
+            L.m[r][s_] = fma(-rs, pPl.m[r][s_], pMn.m[r][s_]);
+        }
+    const Blk<NB> Li = invx(subx(L, mmx(W, R)));
+#pragma unroll
+    for (int k = 0; k < NA; ++k) {
+        if (k >= na) break;
+        const SHCArgs::Angle &g = ang[k];
+        const double bsf = (rs * g.u0) * F * fexpk(-(tau_t * g.iu0), K);     // :2863-2864
+        const double bs[NB] = {bsf, -bsf / 4};
+        double wd[NB], rhs[NB], v[NB];
+        mvx(W, delta[k], wd);
+#pragma unroll
+        for (int r = 0; r < NB; ++r) rhs[r] = ((bs[r] - p_zpl_up[k][r]) + rs * p_zmn_up[k][r]) - wd[r];
+        mvx(Li, rhs, v);
+        a.xint[(long)(k0 + k) * a.nwno + w] = kappa[k] + dotx(zeta[k], v);
+    }
+}
+#pragma clang fp contract(fast)
+
+static int launch_sh4_clear(picaso_ctx *ctx, SHCArgs &a, int nang, const double *ubar0, const double *ubar1, double *xint)
+{
+    const int m = sh_angles_per_lane(ctx, a.nwno, nang, 190.0, 275.0, "PICASO_AMD_SHC_ANGLES", SHC_MAX_PER_LANE);
+    const int nchunk = (nang + m - 1) / m;
+    const int per_lane = (nang + nchunk - 1) / nchunk;
+    const int per_launch = (SH_MAX_ANG / per_lane) * per_lane;
+    for (int done = 0; done < nang; done += per_launch) {
+        const int na = (nang - done < per_launch) ? nang - done : per_launch;
+        for (int k = 0; k < na; ++k) {
+#pragma clang fp contract(off)
+            const SHArgs::Angle s = make_sh_angle(ubar0[done + k], ubar1[done + k], false);
+            SHCArgs::Angle &g = a.ang[k];
+            g.u0 = s.u0; g.iu0 = s.iu0; g.iu1 = s.iu1; g.mus = s.mus; g.imus = s.imus;
+            g.nl0 = s.nl0; g.nl1 = s.nl1; g.nlm = s.nlm;
+            g.x2 = g.iu0 * g.iu0;
+            g.x4 = g.x2 * g.x2;
+            const double m0 = -s.u0, m1 = s.u1;                                  // legP (fluxes.py:3639-3646)
+            g.p2u0 = (3 * m0 * m0 - 1) / 2;
+            g.hp2u1 = 0.5 * ((3 * m1 * m1 - 1) / 2);
+            g.sym = (s.u0 == s.u1) ? 1 : 0;
+        }
+        a.na = na;
+        a.xint = xint + (size_t)done * a.nwno;
+        const dim3 grid((unsigned)((a.nwno + 255) / 256), (unsigned)((na + per_lane - 1) / per_lane));
+        if (per_lane == 1) hipLaunchKernelGGL(k_sh4_clear<1>, grid, dim3(256), 0, ctx->stream, a);
+        else hipLaunchKernelGGL(k_sh4_clear<2>, grid, dim3(256), 0, ctx->stream, a);
         PZ_HIP(ctx, hipGetLastError());
     }
     return 0;
@@ -1453,6 +1745,15 @@ using namespace pz;
 
 extern "C" {
 
+int picaso_reflected_SH_can_derive(int stream, int w_single_form, int w_multi_form, int psingle_form,
+                                   int w_single_rayleigh, int w_multi_rayleigh, int psingle_rayleigh, double frac_c,
+                                   int single_form, int flx)
+{
+    if (getenv("PICASO_AMD_SH_NO_CLEAR")) return 0;
+    return stream == 4 && !flx && w_single_form == 0 && w_multi_form == 0 && psingle_form == 0 && single_form == 0 &&
+           w_single_rayleigh == 1 && w_multi_rayleigh == 1 && psingle_rayleigh == 1 && frac_c == 2.0;
+}
+
 int picaso_get_reflected_SH_dev(picaso_ctx *ctx, int nlevel, int nwno, long plane_pitch, int numg, int numt,
                                 const double *dtau, const double *tau, const double *w0,
                                 const double *cosb, const double *ftau_cld, const double *ftau_ray,
@@ -1467,14 +1768,41 @@ int picaso_get_reflected_SH_dev(picaso_ctx *ctx, int nlevel, int nwno, long plan
                                 double *xint_at_top, double *flux, const double *gweight,
                                 const double *tweight, double *albedo)
 {
-    (void)cosb;
     if (!ctx) return fail(nullptr, "null context");
     if (nlevel < 2 || nwno < 1 || numg < 1 || numt < 1) return fail(ctx, "get_reflected_SH: bad sizes");
     if (stream != 2 && stream != 4) return fail(ctx, "get_reflected_SH: stream must be 2 or 4, got %d", stream);
     if (flx && !flux) return fail(ctx, "get_reflected_SH: flx=1 needs the flux output (numg,numt,stream*nlevel,nwno)");
     if (flx && plane_pitch != nwno) return fail(ctx, "get_reflected_SH: flx=1 needs contiguous planes");
     if (plane_pitch < nwno) return fail(ctx, "get_reflected_SH: plane_pitch < nwno");
+    if (!dtau || !w0) return fail(ctx, "get_reflected_SH: dtau and w0 are required");
     PZ_HIP(ctx, hipSetDevice(ctx->device));
+    (void)cosb;                                                           // never read (fluxes.py:2675-2976)
+    const double *const derivable[8] = {tau, ftau_cld, ftau_ray, f_deltaM, dtau_og, tau_og, w0_og, cosb_og};
+    int nnull = 0;
+    for (int j = 0; j < 8; ++j) nnull += derivable[j] ? 0 : 1;
+    if (nnull) {
+        // cloud-free form: dtau and w0 only, everything else known (k_sh4_clear)
+        if (nnull != 8)
+            return fail(ctx, "get_reflected_SH: leave out all of tau, cosb, ftau_cld, ftau_ray, f_deltaM, dtau_og, tau_og, "
+                             "w0_og, cosb_og (a cloud-free column: they are constants, copies and running sums) or none");
+        if (!picaso_reflected_SH_can_derive(stream, w_single_form, w_multi_form, psingle_form, w_single_rayleigh,
+                                            w_multi_rayleigh, psingle_rayleigh, frac_c, single_form, flx))
+            return fail(ctx, "get_reflected_SH: the cloud-free form (dtau and w0 only) is built for stream 4, the default "
+                             "phase-function options and flx = 0; pass all eleven planes");
+        if (!surf_reflect || !F0PI || !ubar0 || !ubar1 || !xint_at_top) return fail(ctx, "get_reflected_SH: null argument");
+        SHCArgs c{};
+        c.nlayer = nlevel - 1; c.nwno = nwno; c.pitch = plane_pitch;
+        c.dtau = dtau; c.w0 = w0; c.surf_reflect = surf_reflect; c.F0PI = F0PI;
+        {
+#pragma clang fp contract(off)
+            c.psing = 0.75 * (1 + cos_theta * cos_theta);
+        }
+        c.b_top = b_top;
+        PZ_TRY(launch_sh4_clear(ctx, c, numg * numt, ubar0, ubar1, xint_at_top));
+        if (albedo && gweight && tweight)
+            PZ_TRY(picaso_compress_disco_dev(ctx, nwno, cos_theta, xint_at_top, gweight, numg, tweight, numt, F0PI, albedo));
+        return 0;
+    }
     SHArgs a{};
     a.nlayer = nlevel - 1; a.nwno = nwno; a.stream = stream; a.pitch = plane_pitch;
     a.dtau = dtau; a.tau = tau; a.w0 = w0; a.ftau_cld = ftau_cld; a.ftau_ray = ftau_ray;
@@ -1592,7 +1920,10 @@ int picaso_get_reflected_SH(picaso_ctx *ctx, int nlevel, int nwno, int numg, int
     PZ_TRY(arena_reset(ctx, sizeof(double) * (9 * nl + 2 * nv + 2 * (size_t)nwno + nang * nwno + nflux) + 64 * 256));
     const double *d[10], *d_rs, *d_f0;
     const double *h[10] = {dtau, tau, w0, ftau_cld, ftau_ray, f_deltaM, dtau_og, tau_og, w0_og, cosb_og};
-    for (int j = 0; j < 10; ++j) PZ_TRY(arena_upload(ctx, h[j], (j == 1 || j == 7) ? nv : nl, &d[j]));
+    for (int j = 0; j < 10; ++j) {                    // planes left out (cloud-free form) stay NULL for the _dev entry
+        d[j] = nullptr;
+        if (h[j]) PZ_TRY(arena_upload(ctx, h[j], (j == 1 || j == 7) ? nv : nl, &d[j]));
+    }
     PZ_TRY(arena_upload(ctx, surf_reflect, (size_t)nwno, &d_rs));
     PZ_TRY(arena_upload(ctx, F0PI, (size_t)nwno, &d_f0));
     double *d_x = (double *)arena_take(ctx, sizeof(double) * nang * nwno);

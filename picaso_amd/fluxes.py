@@ -122,10 +122,14 @@ def get_reflected_SH(nlevel, nwno, numg, numt, dtau, tau, w0, cosb, ftau_cld, ft
     ``f_deltaM * fac**(k+1)`` and the caller's array is left multiplied by ``fac**(numg*numt)``
     (done here too when ``f_deltaM`` is a writable float64 array).  ``False`` gives the
     non-compounding variant (every angle sees ``f_deltaM * fac``; the caller's array is untouched).
+
+    Not in the reference: a cloud-free atmosphere may pass ``None`` for every plane but ``dtau`` and ``w0`` (stream 4,
+    default options, ``flx=0``; ``picaso_reflected_SH_can_derive``) -- the launch then shares the angle-independent
+    half of each layer between the disk angles.
     """
     ctx = context()
-    arrs = [f64(p) for p in (dtau, tau, w0, cosb, ftau_cld, ftau_ray, f_deltaM, dtau_og, tau_og,
-                             w0_og, cosb_og)]
+    arrs = [f64(p) if p is not None else None
+            for p in (dtau, tau, w0, cosb, ftau_cld, ftau_ray, f_deltaM, dtau_og, tau_og, w0_og, cosb_og)]
     rs, f0 = per_wave(surf_reflect, nwno), per_wave(F0PI, nwno)
     u0, u1 = f64(ubar0, (numg, numt)), f64(ubar1, (numg, numt))
     xint = np.zeros((numg, numt, nwno))

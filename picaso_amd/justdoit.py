@@ -1306,6 +1306,21 @@ def picaso(bundle, opacityclass, dimension="1d", calculation="reflected", full_o
         lean = (not is_sh and ngauss == 1 and getattr(atm, "cloud_free", False) and inp["test_mode"] is None
                 and not do_holes and len(getattr(atm, "rayleigh_molecules", [])) > 0
                 and not os.environ.get("PICASO_AMD_ALL_PLANES"))
+        # SH4 with the reference's default forms, same atmosphere: dtau and w0 are all the cloud-free SH launch reads
+        # (resident.reflected_SH_can_derive; the angle-independent half of a layer shared between the disk angles);
+        # the thermal SH solver reads dtau, w0 and cosb_og (= 0)
+        sh_lean = False
+        if is_sh:
+            sh_o = inp["approx"]["rt_params"]["SH"]
+            sh_lean = (ngauss == 1 and getattr(atm, "cloud_free", False) and inp["test_mode"] is None and not do_holes
+                       and not full_output and len(getattr(atm, "rayleigh_molecules", [])) > 0
+                       and not os.environ.get("PICASO_AMD_ALL_PLANES")
+                       and resident.reflected_SH_can_derive(
+                           common["stream"], sh_o["w_single_form"], sh_o["w_multi_form"], sh_o["psingle_form"],
+                           sh_o["w_single_rayleigh"], sh_o["w_multi_rayleigh"], sh_o["psingle_rayleigh"], frac_c,
+                           sh_o["single_form"], 1 if sh_o["calculate_fluxes"] else 0))
+            if sh_lean:
+                want = {"dtau", "w0"}
         th_w0 = "w0_no_raman"
         if lean:
             want = set()
@@ -1326,6 +1341,10 @@ def picaso(bundle, opacityclass, dimension="1d", calculation="reflected", full_o
             planes.update(dtau_og=planes["dtau"], cosb_og=zero)
             if th_w0 == "w0":
                 planes["w0_no_raman"] = planes["w0"]
+        elif sh_lean:
+            zero, _, _ = _constant_planes(opa, nlayer, nwno)
+            rplanes = {"dtau": planes["dtau"], "w0": planes["w0"]}
+            planes = dict(rplanes, cosb_og=zero)
         elif lean:
             zero, one, half = _constant_planes(opa, nlayer, nwno)
             planes.update(dtau_og=planes["dtau"], cosb=zero, cosb_og=zero, ftau_cld=zero, ftau_ray=one, gcos2=half)
@@ -1382,7 +1401,8 @@ def picaso(bundle, opacityclass, dimension="1d", calculation="reflected", full_o
                 sh_flux = None                                    # layer moment fluxes, flx = calculate_fluxes
                 if sh_opt["calculate_fluxes"]:
                     sh_flux = DeviceArray((ng, nt, common["stream"] * nlevel, nwno), ctx)
-                _reflected_sh(ctx, nlevel, nwno, ng, nt, planes, rs, ubar0, ubar1, cos_theta, d_f0,
+                _reflected_sh(ctx, nlevel, nwno, ng, nt, rplanes if rplanes is not None else planes, rs, ubar0, ubar1,
+                              cos_theta, d_f0,
                               sh_opt, frac_a, frac_b, frac_c, constant_back, constant_forward,
                               common["stream"], b_top, xint, gweight, tweight, alb, sh_flux)
                 if sh_flux is not None:
@@ -2381,7 +2401,8 @@ def _reflected_sh(ctx, nlevel, nwno, ng, nt, planes, rs, ubar0, ubar1, cos_theta
              "w0_og", "cosb_og")
     check(load().picaso_get_reflected_SH_dev(
         ctx, ci(nlevel), ci(nwno), ctypes.c_long(nwno), ci(ng), ci(nt),
-        *[ptr(planes[k].addr) for k in names], ptr(rs.addr), ptr(u0), ptr(u1), cd(cos_theta),
+        *[ptr(planes[k].addr) if planes.get(k) is not None else None for k in names], ptr(rs.addr), ptr(u0), ptr(u1),
+        cd(cos_theta),
         ptr(F0PI.addr), ci(sh["w_single_form"]), ci(sh["w_multi_form"]), ci(sh["psingle_form"]),
         ci(sh["w_single_rayleigh"]), ci(sh["w_multi_rayleigh"]), ci(sh["psingle_rayleigh"]),
         cd(frac_a), cd(frac_b), cd(frac_c), cd(constant_back), cd(constant_forward), ci(stream),
@@ -2406,6 +2427,7 @@ def _thermal_sh(ctx, nlevel, d_wno, nwno, ng, nt, tlevel, planes, plevel, ubar1,
     differs = 1 if delta_eddington else 0
     check(load().picaso_get_thermal_SH_dev(
         ctx, ci(nlevel), ptr(d_wno.addr), ci(nwno), ctypes.c_long(nwno), ci(ng), ci(nt), ptr(tl),
-        ptr(planes["dtau"].addr), ptr(planes["tau"].addr), ptr(planes["w0"].addr),
+        ptr(planes["dtau"].addr), ptr(planes["tau"].addr) if planes.get("tau") is not None else None,   # tau: never read
+        ptr(planes["w0"].addr),
         ptr(planes["cosb_og"].addr), ptr(pl), ptr(u1), ptr(rs.addr), ci(stream), ci(int(hard_surface)),
         ci(differs), ci(0), ptr(flux.addr), ptr(gw), ptr(tw), ptr(disk.addr)), ctx)

@@ -298,20 +298,32 @@ SH_PLANES = ("dtau", "tau", "w0", "cosb", "ftau_cld", "ftau_ray", "f_deltaM", "d
              "cosb_og")
 
 
+def reflected_SH_can_derive(stream, w_single_form=0, w_multi_form=0, psingle_form=0, w_single_rayleigh=1,
+                            w_multi_rayleigh=1, psingle_rayleigh=1, frac_c=2.0, single_form=0, flx=0):
+    """True when ``reflected_SH`` with these options takes a cloud-free atmosphere as ``dtau`` and ``w0`` only
+    (``picaso_reflected_SH_can_derive``)."""
+    lib = load()
+    lib.picaso_reflected_SH_can_derive.argtypes = [ctypes.c_int] * 7 + [ctypes.c_double] + [ctypes.c_int] * 2
+    return bool(lib.picaso_reflected_SH_can_derive(int(stream), int(w_single_form), int(w_multi_form), int(psingle_form),
+                                                   int(w_single_rayleigh), int(w_multi_rayleigh), int(psingle_rayleigh),
+                                                   float(frac_c), int(single_form), int(flx)))
+
+
 def reflected_SH(ctx, nlevel, nwno, numg, numt, planes, surf_reflect, ubar0, ubar1, cos_theta, F0PI,
                  w_single_form, w_multi_form, psingle_form, w_single_rayleigh, w_multi_rayleigh,
                  psingle_rayleigh, frac_a, frac_b, frac_c, constant_back, constant_forward, stream,
                  xint_at_top, b_top=0.0, single_form=0, compound_f_deltaM=True, gweight=None, tweight=None,
                  albedo=None, plane_pitch=None):
     """Asynchronous ``get_reflected_SH`` (``flx=0``) on resident planes (+ optional fused
-    ``compress_disco``); ``planes`` maps ``SH_PLANES`` to DeviceArrays."""
+    ``compress_disco``); ``planes`` maps ``SH_PLANES`` to DeviceArrays.  A cloud-free atmosphere may give ``dtau``
+    and ``w0`` only (``reflected_SH_can_derive``): the other planes are constants, copies and running sums."""
     u0, u1 = f64(ubar0, (numg, numt)), f64(ubar1, (numg, numt))
     gw = f64(gweight) if gweight is not None else None
     tw = f64(tweight) if tweight is not None else None
     pitch = nwno if plane_pitch is None else plane_pitch
     check(load().picaso_get_reflected_SH_dev(
         ctx, _ci(nlevel), _ci(nwno), ctypes.c_long(pitch), _ci(numg), _ci(numt),
-        *[_addr(planes[k]) for k in SH_PLANES], _addr(surf_reflect), ptr(u0), ptr(u1), _cd(cos_theta),
+        *[_addr(planes.get(k)) for k in SH_PLANES], _addr(surf_reflect), ptr(u0), ptr(u1), _cd(cos_theta),
         _addr(F0PI), _ci(int(w_single_form)), _ci(int(w_multi_form)), _ci(int(psingle_form)),
         _ci(int(w_single_rayleigh)), _ci(int(w_multi_rayleigh)), _ci(int(psingle_rayleigh)), _cd(frac_a),
         _cd(frac_b), _cd(frac_c), _cd(constant_back), _cd(constant_forward), _ci(int(stream)), _cd(b_top),

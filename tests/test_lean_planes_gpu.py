@@ -97,3 +97,46 @@ def test_lean_planes_not_used_with_clouds_or_test_mode(monkeypatch):
     case.inputs["test_mode"] = "rayleigh"
     case.spectrum(opa, calculation="reflected")
     assert len(wants[-1]) == 11                  # a test mode: all eleven
+
+
+@pytest.mark.parametrize("calc", ["reflected+thermal", "reflected", "thermal"])
+def test_sh4_cloud_free_writes_two_planes(monkeypatch, calc):
+    """rt_method='SH', stream 4, default forms, no cloud: dtau and w0 are written and the cloud-free SH launch
+    (k_sh4_clear) solves them; reflected light agrees with the full-plane launch to the oracle's tolerance (not bit for
+    bit: sh.hip), thermal emission -- the same kernel on the same two planes -- is bit-identical.  A cloud, other
+    forms, layer fluxes or full_output keep the thirteen planes."""
+    from picaso_amd import justdoit as jdi
+    from picaso_amd import optics as px
+    og = np.load(os.path.join(GOLDEN, "optics.npz"))
+    opa = jdi.opannection(filename_db=DB)
+    wants = []
+    real = px.compute_opacity_resident
+    monkeypatch.setattr(px, "compute_opacity_resident", lambda *a, **k: (wants.append(k.get("want")), real(*a, **k))[1])
+
+    def case(**sh):
+        c = _case(jdi, og, "none", True, False)
+        c.approx(raman="none", rt_method="SH", stream=4, **sh)
+        return c
+    monkeypatch.delenv("PICASO_AMD_ALL_PLANES", raising=False)
+    lean = case().spectrum(opa, calculation=calc)
+    assert wants[-1] == {"dtau", "w0"}
+    monkeypatch.setenv("PICASO_AMD_ALL_PLANES", "1")
+    full = case().spectrum(opa, calculation=calc)
+    assert wants[-1] is None
+    monkeypatch.delenv("PICASO_AMD_ALL_PLANES")
+    if "reflected" in calc:
+        assert np.max(np.abs(lean["albedo"] - full["albedo"]) / np.abs(full["albedo"])) < 1e-9
+        assert np.isfinite(lean["albedo"]).all() and (lean["albedo"] > 0).all()
+    if "thermal" in calc:
+        assert np.array_equal(lean["thermal"], full["thermal"])
+    if calc == "reflected":
+        c = case()
+        c.clouds(df={"opd": og["in/cld_opd"], "w0": og["in/cld_w0"], "g0": og["in/cld_g0"]})
+        c.spectrum(opa, calculation=calc)
+        assert wants[-1] is None
+        case(w_multi_form="OTHG").spectrum(opa, calculation=calc)
+        assert wants[-1] is None
+        case(calculate_fluxes="on").spectrum(opa, calculation=calc)
+        assert wants[-1] is None
+        case().spectrum(opa, calculation=calc, full_output=True)
+        assert wants[-1] is None

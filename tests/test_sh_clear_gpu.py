@@ -1,0 +1,119 @@
+"""get_reflected_SH (reference fluxes.py:2675-2976, 3336-3607) for cloud-free columns with the angle-independent half of
+each layer shared between the disk angles of a lane (`k_sh4_clear<NA>`, sh.hip): the call with `dtau` and `w0` only
+against the oracle on the full plane set, against the full-plane kernel (`k_sh`: to the oracle's tolerance, not bit for bit --
+see the kernel's header), and the same bits however many angles share a lane and however the wavelengths are cut."""
+import numpy as np
+import pytest
+
+from helpers import rel_err
+
+pytestmark = pytest.mark.gpu
+
+TTHG = (1.0, -1.0, 2.0, -0.5, 1.0)               # frac_a, frac_b, frac_c, constant_back, constant_forward
+OPTS = (0, 0, 0, 1, 1, 1)                        # the reference's default SH forms (config.json)
+PLANES = ("dtau", "tau", "w0", "cosb", "ftau_cld", "ftau_ray", "f_deltaM", "dtau_og", "tau_og", "w0_og", "cosb_og")
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from picaso_amd import _lib, disco, fluxes
+    assert _lib.device_count() > 0, "no MI355X visible"
+    _lib.context()
+
+    class H:
+        pass
+    h = H()
+    h.fluxes, h.disco = fluxes, disco
+    return h
+
+
+def _geom(hip, ng, nt, phase):
+    if nt == 1:
+        g, gw, t, tw = hip.disco.get_angles_1d(ng)
+    else:
+        g, gw, t, tw = hip.disco.get_angles_3d(ng, nt)
+    u0, u1, ct, _, _ = hip.disco.compute_disco(ng, nt, g, t, phase)
+    return u0, u1, ct
+
+
+def _scene(nlayer, nwno, seed, **kw):
+    from picaso_amd import synthetic as syn
+    sc = syn.make_scene(nlayer, nwno, seed=seed, stream=4, cloud=False, **kw)
+    # what the reference's compute_opacity leaves for a cloud-free atmosphere (optics.py:303-431)
+    assert not sc["ftau_cld"].any() and np.all(sc["ftau_ray"] == 1.0) and not sc["cosb_og"].any()
+    assert not sc["f_deltaM"].any() and np.array_equal(sc["dtau"], sc["dtau_og"]) and np.array_equal(sc["w0"], sc["w0_og"])
+    assert np.array_equal(sc["tau"], sc["tau_og"])
+    return sc
+
+
+def _call(fn, sc, nlayer, nwno, ng, nt, u0, u1, ct, rs, f0, lean, b_top=0.0, lo=None, hi=None):
+    cut = (lambda a: a) if lo is None else (lambda a: np.ascontiguousarray(a[..., lo:hi]))
+    planes = [cut(sc[k]) if (not lean or k in ("dtau", "w0")) else None for k in PLANES]
+    if not lean:
+        planes[6] = planes[6].copy()                                  # f_deltaM is compounded in place
+    n = nwno if lo is None else hi - lo
+    rs_, f0_ = (cut(np.zeros(nwno) + rs), cut(np.zeros(nwno) + f0))
+    x, _ = fn(nlayer + 1, n, ng, nt, *planes, rs_, u0, u1, ct, f0_, *OPTS, *TTHG, 4, b_top)
+    return x
+
+
+@pytest.mark.parametrize("ng,nt,phase", [(5, 1, 0.0), (8, 1, 0.0), (3, 2, 0.9), (4, 3, 2.1), (6, 1, 0.0)])
+def test_against_oracle_and_full_plane_kernel(hip, oracle, monkeypatch, ng, nt, phase):
+    nlayer, nwno = 31, 523
+    monkeypatch.delenv("PICASO_AMD_SHC_ANGLES", raising=False)
+    rng = np.random.default_rng(17 * ng + nt)
+    u0, u1, ct = _geom(hip, ng, nt, phase)
+    for trial in range(3):
+        sc = _scene(nlayer, nwno, 900 + 5 * trial + ng)
+        rs = 0.4 * rng.random(nwno) if trial else 0.0
+        f0 = 1.0 + rng.random(nwno) if trial == 2 else 1.0
+        b_top = 0.0 if trial < 2 else 0.3
+        got = _call(hip.fluxes.get_reflected_SH, sc, nlayer, nwno, ng, nt, u0, u1, ct, rs, f0, True, b_top)
+        want = _call(oracle.get_reflected_SH, sc, nlayer, nwno, ng, nt, u0, u1, ct, rs, f0, False, b_top)
+        assert rel_err(got, want) < 1e-9, (trial, "oracle")
+        full = _call(hip.fluxes.get_reflected_SH, sc, nlayer, nwno, ng, nt, u0, u1, ct, rs, f0, False, b_top)
+        assert rel_err(got, full) < 1e-9, (trial, "full-plane kernel")
+        for m in (1, 2):                                              # angles per lane: same bits
+            monkeypatch.setenv("PICASO_AMD_SHC_ANGLES", str(m))
+            alt = _call(hip.fluxes.get_reflected_SH, sc, nlayer, nwno, ng, nt, u0, u1, ct, rs, f0, True, b_top)
+            assert np.array_equal(alt, got), (trial, m)
+        monkeypatch.delenv("PICASO_AMD_SHC_ANGLES")
+        lo, hi = 130, 387                                             # a wavelength block alone: same bits
+        part = _call(hip.fluxes.get_reflected_SH, sc, nlayer, nwno, ng, nt, u0, u1, ct, rs, f0, True, b_top, lo, hi)
+        assert np.array_equal(part, got[..., lo:hi]), trial
+
+
+def test_thick_thin_conservative_and_single_layer(hip, oracle):
+    """Layers far beyond the 35-clips, nearly transparent columns, w0 -> 1 and nlayer = 1."""
+    u0, u1, ct = _geom(hip, 5, 1, 0.0)
+    for nlayer, nwno, kw in ((40, 301, dict(gas_scale=300.0, ray_scale=30.0)), (40, 301, dict(gas_scale=1e-4, ray_scale=1e-3)),
+                             (25, 200, dict(gas_scale=1e-7, ray_scale=5.0)), (1, 67, {}), (90, 129, dict(ray_scale=200.0))):
+        sc = _scene(nlayer, nwno, 31 + nlayer, **kw)
+        got = _call(hip.fluxes.get_reflected_SH, sc, nlayer, nwno, 5, 1, u0, u1, ct, 0.2, 1.0, True)
+        want = _call(oracle.get_reflected_SH, sc, nlayer, nwno, 5, 1, u0, u1, ct, 0.2, 1.0, False)
+        assert np.isfinite(got).all()
+        assert rel_err(got, want, floor=1e-30) < 1e-9, (nlayer, kw)
+
+
+def test_refusals(hip):
+    """Some of the planes left out, stream 2, non-default forms, flx = 1: clean errors, not a wrong kernel."""
+    from picaso_amd._lib import PicasoHipError
+    from picaso_amd import resident
+    nlayer, nwno = 9, 70
+    sc = _scene(nlayer, nwno, 5)
+    u0, u1, ct = _geom(hip, 5, 1, 0.0)
+    head = (nlayer + 1, nwno, 5, 1)
+    tail = (0.0, u0, u1, ct, 1.0)
+    lean = [sc[k] if k in ("dtau", "w0") else None for k in PLANES]
+    partial = list(lean)
+    partial[1] = sc["tau"]
+    with pytest.raises(PicasoHipError, match="all of"):
+        hip.fluxes.get_reflected_SH(*head, *partial, *tail, *OPTS, *TTHG, 4)
+    with pytest.raises(PicasoHipError, match="stream 4"):
+        hip.fluxes.get_reflected_SH(*head, *lean, *tail, *OPTS, *TTHG, 2)
+    with pytest.raises(PicasoHipError, match="stream 4"):
+        hip.fluxes.get_reflected_SH(*head, *lean, *tail, 1, 0, 0, 1, 1, 1, *TTHG, 4)
+    with pytest.raises(PicasoHipError, match="stream 4"):
+        hip.fluxes.get_reflected_SH(*head, *lean, *tail, *OPTS, *TTHG, 4, 0.0, 1)
+    assert resident.reflected_SH_can_derive(4) and not resident.reflected_SH_can_derive(2)
+    assert not resident.reflected_SH_can_derive(4, w_multi_form=1) and not resident.reflected_SH_can_derive(4, flx=1)
