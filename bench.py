@@ -192,8 +192,9 @@ def workload_thermal(ctx, args, lo, hi, seed, nwno_total, scene=None):
                 metric="spectra/sec (%d wave x %d layer thermal)" % (nwno_total, nlayer))
 
 
-def workload_sh4(ctx, args, lo, hi, seed, nwno_total, scene=None):
-    """configs[3]: get_reflected_SH, stream = 4, + compress_disco."""
+def workload_sh4(ctx, args, lo, hi, seed, nwno_total, scene=None, clear=False):
+    """configs[3]: get_reflected_SH, stream = 4, + compress_disco.  ``clear``: the scene has no cloud and the launch is
+    handed dtau and w0 only (picaso_reflected_SH_can_derive; the oracle still gets all eleven planes)."""
     nlayer, nlevel, ng = args.nlayer, args.nlayer + 1, args.ngauss
     n = hi - lo
     gang, gw, tang, tw = disco.get_angles_1d(ng)
@@ -206,8 +207,10 @@ def workload_sh4(ctx, args, lo, hi, seed, nwno_total, scene=None):
     xint = device.DeviceArray((ng, 1, n), ctx)
     opts = (0, 0, 0, 1, 1, 1)        # w_single_form, w_multi_form, psingle_form, *_rayleigh (config.json defaults)
 
+    planes = {"dtau": d["dtau"], "w0": d["w0"]} if clear else d
+
     def solve(albedo):
-        resident.reflected_SH(ctx, nlevel, n, ng, 1, d, d["surf_reflect"], ubar0, ubar1, 1.0, d["F0PI"], *opts,
+        resident.reflected_SH(ctx, nlevel, n, ng, 1, planes, d["surf_reflect"], ubar0, ubar1, 1.0, d["F0PI"], *opts,
                               *TTHG, 4, xint, gweight=gw, tweight=tw, albedo=albedo)
 
     def oracle(sl):
@@ -219,6 +222,12 @@ def workload_sh4(ctx, args, lo, hi, seed, nwno_total, scene=None):
                                      *opts, *TTHG, 4)
         return orc.compress_disco(ns, 1.0, xo, gw, tw, np.ones(ns))
 
+    if clear:
+        return dict(solve=solve, oracle=oracle, nloc=n, abytes=8 * n * (2 * nlayer + 2 + ng + 1), kernel="k_sh4_clear<2>",
+                    workload="configs[3] on a cloud-free atmosphere: SH4 reflected light from dtau and w0 only (the other "
+                             "nine planes are constants, copies and running sums), angle-independent half of each layer "
+                             "shared between two disk angles of a lane",
+                    metric="spectra/sec (%d wave x %d layer SH4 reflected, cloud-free)" % (nwno_total, nlayer))
     return dict(solve=solve, oracle=oracle, nloc=n,
                 abytes=8 * n * (9 * nlayer + 2 * nlevel + 2 + ng + 1),
                 kernel="k_sh<2, false, false, true>",
@@ -460,6 +469,19 @@ def companions(ctx, args, wl, res_single, nwno_total):
     sec["configs[3] 12500-column shard"] = entry(w3s, ms3s)
     sec["configs[3] 12500-column shard"]["bit_identical_to_unsharded"] = bool(np.array_equal(out3s.to_host(), out3.to_host()[:12500]))
     del w3, w3s, sc4
+    # the same atmosphere without its cloud: the cloud-free SH4 form against the full-plane kernel on the same planes
+    # (no cloud profile: opd = w0 = g0 = 0 in every layer, what ATMSETUP.get_clouds leaves, atmsetup.py:609-640 -- COSB is
+    # the cloud's g0 itself, optics.py:338, so a g0 without optical depth would still delta-scale the layer)
+    sc4c = syn.mix_planes(scene["taugas"], scene["tauray"], 0.0 * scene["taucld"], 0.0 * scene["w0_cld"],
+                          0.0 * scene["g0_cld"], stream=4)
+    sc4c["wno"] = scene["wno"]
+    w3c = workload_sh4(ctx, args, 0, nwno_total, 3, nwno_total, scene=sc4c, clear=True)
+    ms3c = steady_ms(ctx, lambda: w3c["solve"](out3), 40, prewarm_ms=100.0)
+    sec["configs[3] cloud-free"] = entry(w3c, ms3c, n_oracle=128, res=out3.to_host())
+    w3f = workload_sh4(ctx, args, 0, nwno_total, 3, nwno_total, scene=sc4c)
+    sec["configs[3] cloud-free"]["full_plane_kernel_ms"] = steady_ms(ctx, lambda: w3f["solve"](out3), 40, prewarm_ms=100.0)
+    sec["configs[3] cloud-free"]["frac_is"] = "of the HBM peak for the 1 480 B per wavelength this launch reads and writes; the kernel is fp64-issue bound"
+    del w3c, w3f, sc4c
     # configs[4]: 64 facets x 90 layers, the 12 500-wavelength block one of 8 GPUs holds
     w4 = workload_3d(ctx, args, 0, 12500, 3, 12500)
     out4 = device.DeviceArray((12500,), ctx)

@@ -341,6 +341,8 @@ int picaso_get_reflected_SH(picaso_ctx *ctx, int nlevel, int nwno, int numg, int
  * tau_og, w0_og and cosb_og TOGETHER (all of them or none; cosb is never read and may be NULL on its own) -- without
  * cloud they are constants (ftau_cld = 0, ftau_ray = 1, cosb = f_deltaM = 0), copies (dtau_og = dtau, w0_og = w0) and
  * running sums of dtau (tau = tau_og), what optics.compute_opacity writes for such an atmosphere (optics.py:303-431).
+ * "Cloud-free" means NO cloud profile -- opd = w0 = g0 = 0 in every layer (atmsetup.py get_clouds): COSB is the cloud's
+ * g0 itself (optics.py:338), so a layer with g0 != 0 and no optical depth is still delta-scaled and needs all planes.
  * The launch then reads dtau and w0 only and shares the angle-independent half of every layer (stream coefficients,
  * modes, the matrix recursion of the sweep) between the disk angles of a lane (k_sh4_clear, csrc/sh.hip).  Built for
  * stream = 4, the reference's default SH options (config.json) and flx = 0: this function returns 1 when a call with
