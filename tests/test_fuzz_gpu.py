@@ -169,6 +169,33 @@ def test_fuzz_spherical_harmonics(oracle, block):
         assert rel_err(xg, xo, 1e-4 * np.abs(xo).max()) < 1e-7, (block, it, nlayer, nwno, ng, nt, stream, opts, sform)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("block", range(4))
+def test_fuzz_sh4_cloud_free_form(oracle, block):
+    """get_reflected_SH handed dtau and w0 only (k_sh4_clear) against the oracle on all eleven planes of the same
+    cloud-free scene: random sizes, geometry, optical thickness, surface, stellar flux and top boundary."""
+    from picaso_amd import fluxes
+    from picaso_amd import synthetic as syn
+    rng = np.random.default_rng(3500 + block + 7919 * OFFSET)
+    for it in range(12):
+        nlayer = int(rng.choice([1, 2, 3, 7, 19, 40, 90]))
+        nwno = int(rng.choice([1, 5, 63, 64, 65, 130, 257, 300]))
+        sc = syn.make_scene(nlayer, nwno, seed=2600 + 50 * block + it, stream=4, cloud=False,
+                            gas_scale=float(10.0 ** rng.uniform(-4, 2.5)), ray_scale=float(10.0 ** rng.uniform(-2, 2)))
+        ng, nt, gw, tw, u0, u1, ct = _geometry(rng)
+        rs = rng.random(nwno) * float(rng.choice([0.0, 0.3, 1.0]))
+        f0 = 1.0 + rng.random(nwno) if rng.random() < 0.5 else np.ones(nwno)
+        b_top = float(rng.choice([0.0, 0.2]))
+        tail = (rs, u0, u1, ct, f0, 0, 0, 0, 1, 1, 1, *TTHG, 4, b_top)
+        full = [sc[k] for k in ("dtau", "tau", "w0", "cosb", "ftau_cld", "ftau_ray", "f_deltaM", "dtau_og", "tau_og", "w0_og",
+                                "cosb_og")]
+        lean = [sc["dtau"], None, sc["w0"]] + [None] * 8
+        xg, _ = fluxes.get_reflected_SH(nlayer + 1, nwno, ng, nt, *lean, *tail)
+        xo, _ = oracle.get_reflected_SH(nlayer + 1, nwno, ng, nt, *[np.array(a) for a in full], *tail)
+        assert np.isfinite(xg).all()
+        assert rel_err(xg, xo, 1e-4 * np.abs(xo).max()) < 1e-7, (block, it, nlayer, nwno, ng, nt, b_top)
+
+
 def _facet_planes(rng, nlayer, nwno, ng, nt, seed):
     """Per-facet planes (rows, nwno, ng, nt): every facet its own random scene."""
     from picaso_amd import synthetic as syn

@@ -57,7 +57,7 @@ def _call(fn, sc, nlayer, nwno, ng, nt, u0, u1, ct, rs, f0, lean, b_top=0.0, lo=
     return x
 
 
-@pytest.mark.parametrize("ng,nt,phase", [(5, 1, 0.0), (8, 1, 0.0), (3, 2, 0.9), (4, 3, 2.1), (6, 1, 0.0)])
+@pytest.mark.parametrize("ng,nt,phase", [(5, 1, 0.0), (8, 1, 0.0), (3, 2, 0.9), (4, 3, 2.1), (6, 1, 0.0), (7, 5, 1.2)])
 def test_against_oracle_and_full_plane_kernel(hip, oracle, monkeypatch, ng, nt, phase):
     nlayer, nwno = 31, 523
     monkeypatch.delenv("PICASO_AMD_SHC_ANGLES", raising=False)
