@@ -367,6 +367,33 @@ int picaso_get_reflected_SH_dev(picaso_ctx *ctx, int nlevel, int nwno, long plan
                                 double *flux, const double *gweight, const double *tweight,
                                 double *albedo);
 
+/* picaso_get_reflected_SH_dev with one more statement from the caller: the first `cloud_free_above` layers (0 ..
+ * cloud_free_above - 1, counted from the top) carry no cloud in ANY column -- their planes hold what
+ * optics.compute_opacity writes for a layer without a cloud profile entry (ftau_cld = cosb_og = f_deltaM = 0, ftau_ray = 1,
+ * dtau_og = dtau, w0_og = w0, tau = tau_og = the running sum of dtau).  A cloud deck sits below some pressure; above it
+ * the SH blocks are the same for every disk angle (fluxes.py:2823-2824 compounds an f_deltaM of zero), so those layers go
+ * through the cloud-free kernel (two angles per lane share the angle-independent half of a layer), which hands its sweep
+ * state to the full kernel at the first cloudy layer.  Taken for stream = 4, the default forms and flx = 0
+ * (picaso_reflected_SH_can_derive) from 4 layers on; otherwise, and with cloud_free_above = 0, this IS
+ * picaso_get_reflected_SH_dev.  Results agree with the unsplit launch to <= 1e-9 relative (not bit for bit); they do not
+ * depend on launch shape or wavelength block, but they do depend on cloud_free_above: every block of a sharded spectrum
+ * must be given the same value.  The statement is not verified (PICASO_AMD_SH_CHECK_TOP=1 in the environment checks it
+ * on the device and fails the call, synchronising -- a debugging aid). */
+int picaso_get_reflected_SH_top_dev(picaso_ctx *ctx, int nlevel, int nwno, long plane_pitch, int numg,
+                                    int numt, const double *dtau, const double *tau, const double *w0,
+                                    const double *cosb, const double *ftau_cld, const double *ftau_ray,
+                                    const double *f_deltaM, const double *dtau_og, const double *tau_og,
+                                    const double *w0_og, const double *cosb_og,
+                                    const double *surf_reflect, const double *ubar0,
+                                    const double *ubar1, double cos_theta, const double *F0PI,
+                                    int w_single_form, int w_multi_form, int psingle_form,
+                                    int w_single_rayleigh, int w_multi_rayleigh, int psingle_rayleigh,
+                                    double frac_a, double frac_b, double frac_c, double constant_back,
+                                    double constant_forward, int stream, double b_top, int flx,
+                                    int single_form, int compound_f_deltaM, int cloud_free_above,
+                                    double *xint_at_top, double *flux, const double *gweight,
+                                    const double *tweight, double *albedo);
+
 /* `nspec` SH spectra (flx = 0) of one shape and option set in one launch, see picaso_get_reflected_1d_batch_dev:
  * host arrays of nspec device pointers, ngeom = 1 or nspec geometries (at most 16 disk angles), bit-identical per
  * spectrum to picaso_get_reflected_SH_dev (fluxes.py:2675-2976).  Planes are read, never modified (the reference's

@@ -69,7 +69,12 @@ struct SHArgs {
     // batched launch (picaso_get_reflected_SH_batch_dev): blockIdx.y = spectrum, see ReflectedArgs::batch
     const struct SHBatchItem *batch;
     int nspec_;
+    // resume below a cloud-free top (picaso_get_reflected_SH_top_dev): the sweep state k_sh4_clear left at the top of
+    // layer `start_layer`, [slot][nwno] (SHC_SHARED shared slots, then SHC_STATE per angle of the call)
+    int start_layer;
+    const double *state;
 };
+constexpr int SHC_SHARED = 20, SHC_STATE = 11;
 struct SHBatchItem {
     const double *dtau, *tau, *w0, *ftau_cld, *ftau_ray, *f_deltaM, *dtau_og, *tau_og, *w0_og, *cosb_og;
     const double *surf_reflect, *F0PI;
@@ -378,7 +383,45 @@ __device__ __forceinline__ void sh_body(const SHArgs &a, AnglePtr angp)
 #pragma unroll
     for (int r = 0; r < NB; ++r) top_zmn[r] = top_zpl[r] = 0.0;
 
-    for (int i = 0; i < n; ++i) {
+    if (!THERMAL && !FLX && a.start_layer > 0) {
+        // the layers above start_layer were swept by k_sh4_clear (no cloud there): take its state over
+        const double *sp = a.state + w;
+        auto ld = [&](int sl) { return sp[(long)sl * a.nwno]; };
+        int sl = 0;
+#pragma unroll
+        for (int r = 0; r < NB; ++r)
+#pragma unroll
+            for (int c2 = 0; c2 < NB; ++c2) R.m[r][c2] = ld(sl++);
+#pragma unroll
+        for (int r = 0; r < NB; ++r)
+#pragma unroll
+            for (int c2 = 0; c2 < NB; ++c2) pMn.m[r][c2] = ld(sl++);
+#pragma unroll
+        for (int r = 0; r < NB; ++r)
+#pragma unroll
+            for (int c2 = 0; c2 < NB; ++c2) pPl.m[r][c2] = ld(sl++);
+#pragma unroll
+        for (int r = 0; r < NB; ++r)
+#pragma unroll
+            for (int c2 = 0; c2 < NB; ++c2) pME.m[r][c2] = ld(sl++);
+#pragma unroll
+        for (int r = 0; r < NB; ++r)
+#pragma unroll
+            for (int c2 = 0; c2 < NB; ++c2) pPE.m[r][c2] = ld(sl++);
+        sl = SHC_SHARED + SHC_STATE * (a.first_angle + ang);
+        T = ld(sl++);
+        kappa = ld(sl++);
+        e_top = ld(sl++);
+#pragma unroll
+        for (int r = 0; r < NB; ++r) zeta[r] = ld(sl++);
+#pragma unroll
+        for (int r = 0; r < NB; ++r) delta[r] = ld(sl++);
+#pragma unroll
+        for (int r = 0; r < NB; ++r) p_zmn_up[r] = ld(sl++);
+#pragma unroll
+        for (int r = 0; r < NB; ++r) p_zpl_up[r] = ld(sl++);
+    }
+    for (int i = (!THERMAL && !FLX) ? a.start_layer : 0; i < n; ++i) {
         const long o = (long)i * pitch + w;
         const double dt = a.dtau[o], w0 = a.w0[o], cbo = a.cosb_og[o];
         // ---- Legendre weights of the phase function ----
@@ -1401,6 +1444,10 @@ struct SHCArgs {
     double psing;                                   // Rayleigh single scattering 0.75 (1 + cos_theta^2), :2846
     double b_top;
     double *xint;                                   // first angle of this launch, (na, nwno)
+    // a cloud-free TOP only (picaso_get_reflected_SH_top_dev): sweep the first `nstop` layers and leave the state for
+    // k_sh (SHArgs::state) instead of closing the column with the surface rows
+    int nstop, first_angle;
+    double *state;
 };
 
 // Angles per lane: two.  Measured at 1e5 x 90 x 5 (tools/sh_clear_time.py; the full-plane kernel on the same cloud-free
@@ -1441,7 +1488,8 @@ __global__ __launch_bounds__(256, 2) void k_sh4_clear(const SHCArgs a)
     Blk<NB> R, pMn, pPl, pME, pPE;
     double tau_t = 0.0;
 
-    for (int i = 0; i < n; ++i) {
+    const int nsweep = a.state ? a.nstop : n;
+    for (int i = 0; i < nsweep; ++i) {
         const long o = (long)i * pitch + w;
         const double dt = a.dtau[o], w0 = a.w0[o];
         const double tau_b = tau_t + dt;
@@ -1594,6 +1642,39 @@ __global__ __launch_bounds__(256, 2) void k_sh4_clear(const SHCArgs a)
         pMn = M.Mn; pPl = M.Pl; pME = ME; pPE = PE;
         tau_t = tau_b;
     }
+    if (a.state) {
+        // hand the sweep over at the top of layer nstop: shared blocks (every angle chunk holds the same values; the
+        // first one writes them), then this lane's angles
+        double *sp = a.state + w;
+        auto st = [&](int sl, double v) { sp[(long)sl * a.nwno] = v; };
+        if (blockIdx.y == 0) {
+            int sl = 0;
+            const Blk<NB> *const blks[5] = {&R, &pMn, &pPl, &pME, &pPE};
+#pragma unroll
+            for (int b = 0; b < 5; ++b)
+#pragma unroll
+                for (int r = 0; r < NB; ++r)
+#pragma unroll
+                    for (int c2 = 0; c2 < NB; ++c2) st(sl++, blks[b]->m[r][c2]);
+        }
+#pragma unroll
+        for (int k = 0; k < NA; ++k) {
+            if (k >= na) break;
+            int sl = SHC_SHARED + SHC_STATE * (a.first_angle + k0 + k);
+            st(sl++, T[k]);
+            st(sl++, kappa[k]);
+            st(sl++, e_top[k]);
+#pragma unroll
+            for (int r = 0; r < NB; ++r) st(sl++, zeta[k][r]);
+#pragma unroll
+            for (int r = 0; r < NB; ++r) st(sl++, delta[k][r]);
+#pragma unroll
+            for (int r = 0; r < NB; ++r) st(sl++, p_zmn_up[k][r]);
+#pragma unroll
+            for (int r = 0; r < NB; ++r) st(sl++, p_zpl_up[k][r]);
+        }
+        return;
+    }
     // ---- surface rows (:3484-3494) ----
     Blk<NB> W, L;
 #pragma unroll
@@ -1642,12 +1723,49 @@ static int launch_sh4_clear(picaso_ctx *ctx, SHCArgs &a, int nang, const double 
             g.sym = (s.u0 == s.u1) ? 1 : 0;
         }
         a.na = na;
+        a.first_angle = done;
         a.xint = xint + (size_t)done * a.nwno;
         const dim3 grid((unsigned)((a.nwno + 255) / 256), (unsigned)((na + per_lane - 1) / per_lane));
         if (per_lane == 1) hipLaunchKernelGGL(k_sh4_clear<1>, grid, dim3(256), 0, ctx->stream, a);
         else hipLaunchKernelGGL(k_sh4_clear<2>, grid, dim3(256), 0, ctx->stream, a);
         PZ_HIP(ctx, hipGetLastError());
     }
+    return 0;
+}
+
+constexpr int SH_TOP_MIN = 4;     // cloud-free layers from which the split (two launches, a state hand-over) is taken
+
+// PICASO_AMD_SH_CHECK_TOP=1: count the elements of the first `top` layers that contradict the caller's statement
+// (picaso_get_reflected_SH_top_dev) -- a synchronising debug aid, the tests run with it.
+__global__ void k_sh_check_top(const SHArgs a, int top, unsigned long long *bad)
+{
+#pragma clang fp contract(off)
+    const long w = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= a.nwno) return;
+    unsigned n = 0;
+    for (int i = 0; i < top; ++i) {
+        const long o = (long)i * a.pitch + w;
+        const double dt = a.dtau[o];
+        n += (a.ftau_cld[o] != 0.0) + (a.cosb_og[o] != 0.0) + (a.f_deltaM[o] != 0.0) + (a.ftau_ray[o] != 1.0) +
+             (a.dtau_og[o] != dt) + (a.w0_og[o] != a.w0[o]) + (a.tau[o + a.pitch] != a.tau[o] + dt) +
+             (a.tau_og[o] != a.tau[o]) + (i == 0 && a.tau[o] != 0.0);
+    }
+    if (n) atomicAdd(bad, (unsigned long long)n);
+}
+
+static int sh_check_top(picaso_ctx *ctx, const SHArgs &a, int top)
+{
+    PZ_TRY(ck_scratch_reserve(ctx, 256));
+    unsigned long long *d = (unsigned long long *)ctx->ck_scratch, h = 0;
+    PZ_HIP(ctx, hipMemsetAsync(d, 0, sizeof(h), ctx->stream));
+    hipLaunchKernelGGL(k_sh_check_top, dim3((unsigned)((a.nwno + 255) / 256)), dim3(256), 0, ctx->stream, a, top, d);
+    PZ_HIP(ctx, hipGetLastError());
+    PZ_HIP(ctx, hipMemcpyAsync(&h, d, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+    PZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (h)
+        return fail(ctx, "get_reflected_SH: cloud_free_above = %d, but %llu plane elements of those layers are not what a "
+                         "cloud-free layer holds (ftau_cld = cosb_og = f_deltaM = 0, ftau_ray = 1, dtau_og = dtau, w0_og = w0, "
+                         "tau = tau_og = the running sum of dtau)", top, h);
     return 0;
 }
 
@@ -1768,6 +1886,28 @@ int picaso_get_reflected_SH_dev(picaso_ctx *ctx, int nlevel, int nwno, long plan
                                 double *xint_at_top, double *flux, const double *gweight,
                                 const double *tweight, double *albedo)
 {
+    return picaso_get_reflected_SH_top_dev(ctx, nlevel, nwno, plane_pitch, numg, numt, dtau, tau, w0, cosb, ftau_cld,
+                                           ftau_ray, f_deltaM, dtau_og, tau_og, w0_og, cosb_og, surf_reflect, ubar0, ubar1,
+                                           cos_theta, F0PI, w_single_form, w_multi_form, psingle_form, w_single_rayleigh,
+                                           w_multi_rayleigh, psingle_rayleigh, frac_a, frac_b, frac_c, constant_back,
+                                           constant_forward, stream, b_top, flx, single_form, compound_f_deltaM, 0,
+                                           xint_at_top, flux, gweight, tweight, albedo);
+}
+
+int picaso_get_reflected_SH_top_dev(picaso_ctx *ctx, int nlevel, int nwno, long plane_pitch, int numg, int numt,
+                                    const double *dtau, const double *tau, const double *w0,
+                                    const double *cosb, const double *ftau_cld, const double *ftau_ray,
+                                    const double *f_deltaM, const double *dtau_og, const double *tau_og,
+                                    const double *w0_og, const double *cosb_og, const double *surf_reflect,
+                                    const double *ubar0, const double *ubar1, double cos_theta,
+                                    const double *F0PI, int w_single_form, int w_multi_form,
+                                    int psingle_form, int w_single_rayleigh, int w_multi_rayleigh,
+                                    int psingle_rayleigh, double frac_a, double frac_b, double frac_c,
+                                    double constant_back, double constant_forward, int stream,
+                                    double b_top, int flx, int single_form, int compound_f_deltaM,
+                                    int cloud_free_above, double *xint_at_top, double *flux, const double *gweight,
+                                    const double *tweight, double *albedo)
+{
     if (!ctx) return fail(nullptr, "null context");
     if (nlevel < 2 || nwno < 1 || numg < 1 || numt < 1) return fail(ctx, "get_reflected_SH: bad sizes");
     if (stream != 2 && stream != 4) return fail(ctx, "get_reflected_SH: stream must be 2 or 4, got %d", stream);
@@ -1803,6 +1943,7 @@ int picaso_get_reflected_SH_dev(picaso_ctx *ctx, int nlevel, int nwno, long plan
             PZ_TRY(picaso_compress_disco_dev(ctx, nwno, cos_theta, xint_at_top, gweight, numg, tweight, numt, F0PI, albedo));
         return 0;
     }
+    if (cloud_free_above < 0) return fail(ctx, "get_reflected_SH: cloud_free_above must be >= 0, got %d", cloud_free_above);
     SHArgs a{};
     a.nlayer = nlevel - 1; a.nwno = nwno; a.stream = stream; a.pitch = plane_pitch;
     a.dtau = dtau; a.tau = tau; a.w0 = w0; a.ftau_cld = ftau_cld; a.ftau_ray = ftau_ray;
@@ -1814,7 +1955,37 @@ int picaso_get_reflected_SH_dev(picaso_ctx *ctx, int nlevel, int nwno, long plan
     a.frac_a = frac_a; a.frac_b = frac_b; a.frac_c = frac_c; a.constant_back = constant_back;
     a.constant_forward = constant_forward; a.b_top = b_top;
     a.compound = compound_f_deltaM ? 1 : 0;
-    PZ_TRY(launch_sh_angles(ctx, a, numg * numt, ubar0, ubar1, xint_at_top, flx ? flux : nullptr, false));
+    // A cloud-free top (the caller's statement: no cloud in layers 0 .. cloud_free_above - 1 of any column): those
+    // layers go through k_sh4_clear, two angles per lane sharing the angle-independent half, which leaves the sweep
+    // state at the top of the first cloudy layer for k_sh to continue from.  Worth a second launch from a few layers on.
+    const int nlayer = nlevel - 1;
+    const int top = cloud_free_above > nlayer ? nlayer : cloud_free_above;
+    if (top >= SH_TOP_MIN && !getenv("PICASO_AMD_SH_NO_TOP") &&
+        picaso_reflected_SH_can_derive(stream, w_single_form, w_multi_form, psingle_form, w_single_rayleigh,
+                                       w_multi_rayleigh, psingle_rayleigh, frac_c, single_form, flx)) {
+        if (!surf_reflect || !F0PI || !ubar0 || !ubar1 || !xint_at_top) return fail(ctx, "get_reflected_SH: null argument");
+        if (getenv("PICASO_AMD_SH_CHECK_TOP")) PZ_TRY(sh_check_top(ctx, a, top));
+        const int nang = numg * numt;
+        SHCArgs c{};
+        c.nlayer = nlayer; c.nwno = nwno; c.pitch = plane_pitch;
+        c.dtau = dtau; c.w0 = w0; c.surf_reflect = surf_reflect; c.F0PI = F0PI;
+        {
+#pragma clang fp contract(off)
+            c.psing = 0.75 * (1 + cos_theta * cos_theta);
+        }
+        c.b_top = b_top;
+        if (top < nlayer) {
+            PZ_TRY(ck_scratch_reserve(ctx, sizeof(double) * (size_t)(SHC_SHARED + SHC_STATE * nang) * nwno));
+            c.nstop = top;
+            c.state = ctx->ck_scratch;
+            a.start_layer = top;
+            a.state = ctx->ck_scratch;
+        }
+        PZ_TRY(launch_sh4_clear(ctx, c, nang, ubar0, ubar1, xint_at_top));
+        if (top < nlayer) PZ_TRY(launch_sh_angles(ctx, a, nang, ubar0, ubar1, xint_at_top, nullptr, false));
+    } else {
+        PZ_TRY(launch_sh_angles(ctx, a, numg * numt, ubar0, ubar1, xint_at_top, flx ? flux : nullptr, false));
+    }
     if (albedo && gweight && tweight)
         PZ_TRY(picaso_compress_disco_dev(ctx, nwno, cos_theta, xint_at_top, gweight, numg, tweight, numt, F0PI, albedo));
     return 0;

@@ -313,21 +313,24 @@ def reflected_SH(ctx, nlevel, nwno, numg, numt, planes, surf_reflect, ubar0, uba
                  w_single_form, w_multi_form, psingle_form, w_single_rayleigh, w_multi_rayleigh,
                  psingle_rayleigh, frac_a, frac_b, frac_c, constant_back, constant_forward, stream,
                  xint_at_top, b_top=0.0, single_form=0, compound_f_deltaM=True, gweight=None, tweight=None,
-                 albedo=None, plane_pitch=None):
+                 albedo=None, plane_pitch=None, cloud_free_above=0):
     """Asynchronous ``get_reflected_SH`` (``flx=0``) on resident planes (+ optional fused
     ``compress_disco``); ``planes`` maps ``SH_PLANES`` to DeviceArrays.  A cloud-free atmosphere may give ``dtau``
-    and ``w0`` only (``reflected_SH_can_derive``): the other planes are constants, copies and running sums."""
+    and ``w0`` only (``reflected_SH_can_derive``): the other planes are constants, copies and running sums.
+    ``cloud_free_above``: the caller's statement that the first that many layers carry no cloud in any column
+    (``picaso_get_reflected_SH_top_dev``)."""
     u0, u1 = f64(ubar0, (numg, numt)), f64(ubar1, (numg, numt))
     gw = f64(gweight) if gweight is not None else None
     tw = f64(tweight) if tweight is not None else None
     pitch = nwno if plane_pitch is None else plane_pitch
-    check(load().picaso_get_reflected_SH_dev(
+    check(load().picaso_get_reflected_SH_top_dev(
         ctx, _ci(nlevel), _ci(nwno), ctypes.c_long(pitch), _ci(numg), _ci(numt),
         *[_addr(planes.get(k)) for k in SH_PLANES], _addr(surf_reflect), ptr(u0), ptr(u1), _cd(cos_theta),
         _addr(F0PI), _ci(int(w_single_form)), _ci(int(w_multi_form)), _ci(int(psingle_form)),
         _ci(int(w_single_rayleigh)), _ci(int(w_multi_rayleigh)), _ci(int(psingle_rayleigh)), _cd(frac_a),
         _cd(frac_b), _cd(frac_c), _cd(constant_back), _cd(constant_forward), _ci(int(stream)), _cd(b_top),
-        _ci(0), _ci(int(single_form)), _ci(1 if compound_f_deltaM else 0), _addr(xint_at_top), None,
+        _ci(0), _ci(int(single_form)), _ci(1 if compound_f_deltaM else 0), _ci(int(cloud_free_above)),
+        _addr(xint_at_top), None,
         ptr(gw) if gw is not None else None, ptr(tw) if tw is not None else None, _addr(albedo)), ctx)
 
 

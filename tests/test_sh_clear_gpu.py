@@ -117,3 +117,74 @@ def test_refusals(hip):
         hip.fluxes.get_reflected_SH(*head, *lean, *tail, *OPTS, *TTHG, 4, 0.0, 1)
     assert resident.reflected_SH_can_derive(4) and not resident.reflected_SH_can_derive(2)
     assert not resident.reflected_SH_can_derive(4, w_multi_form=1) and not resident.reflected_SH_can_derive(4, flx=1)
+
+
+# ---- a cloud-free TOP above a cloud deck: picaso_get_reflected_SH_top_dev (cloud_free_above) ----
+
+def _resident_call(hip, sc, nlayer, nwno, ng, nt, u0, u1, ct, rs, f0, top, lo=None, hi=None):
+    from picaso_amd import _lib, device, resident
+    ctx = _lib.context()
+    scn = dict(sc)
+    scn["F0PI"] = np.zeros(nwno) + f0
+    scn["surf_reflect"] = np.zeros(nwno) + rs
+    d = resident.upload_scene(scn, resident.SH_PLANES + ("F0PI", "surf_reflect"), lo, hi, ctx=ctx)
+    n = nwno if lo is None else hi - lo
+    x = device.DeviceArray((ng, nt, n), ctx)
+    resident.reflected_SH(ctx, nlayer + 1, n, ng, nt, d, d["surf_reflect"], u0, u1, ct, d["F0PI"], *OPTS, *TTHG, 4, x,
+                          cloud_free_above=top)
+    return x.to_host()
+
+
+@pytest.mark.parametrize("ng,nt,phase", [(5, 1, 0.0), (4, 3, 1.4), (7, 3, 0.6)])
+def test_cloud_free_top_above_a_cloud_deck(hip, oracle, monkeypatch, ng, nt, phase):
+    """The layers above the cloud slab through k_sh4_clear, the rest through k_sh from the state it leaves: against the
+    oracle and the unsplit launch (1e-9), the same bits for a wavelength block alone and at either number of angles per
+    lane; cloud_free_above = 0 (and < 4) IS the unsplit launch."""
+    from picaso_amd import synthetic as syn
+    nlayer, nwno = 40, 389
+    monkeypatch.setenv("PICASO_AMD_SH_CHECK_TOP", "1")
+    u0, u1, ct = _geom(hip, ng, nt, phase)
+    rng = np.random.default_rng(5 + ng)
+    for trial in range(2):
+        sc = syn.make_scene(nlayer, nwno, seed=700 + trial + ng, stream=4)
+        deck = int(np.argmax(sc["ftau_cld"].any(axis=1)))             # first cloudy layer (0.55 nlayer = 22)
+        assert deck == 22 and not sc["cosb_og"][:deck].any()
+        rs = 0.3 * rng.random(nwno) if trial else 0.0
+        f0 = 1.0 + rng.random(nwno)
+        planes = [np.array(sc[k]) for k in PLANES]
+        want, _ = oracle.get_reflected_SH(nlayer + 1, nwno, ng, nt, *planes, np.zeros(nwno) + rs, u0, u1, ct, f0, *OPTS,
+                                          *TTHG, 4)
+        plain = _resident_call(hip, sc, nlayer, nwno, ng, nt, u0, u1, ct, rs, f0, 0)
+        assert rel_err(plain, want) < 1e-9
+        for top in (deck, 10, 4):
+            got = _resident_call(hip, sc, nlayer, nwno, ng, nt, u0, u1, ct, rs, f0, top)
+            assert rel_err(got, want) < 1e-9, (trial, top, "oracle")
+            assert rel_err(got, plain) < 1e-9 and not np.array_equal(got, plain), (trial, top)
+            part = _resident_call(hip, sc, nlayer, nwno, ng, nt, u0, u1, ct, rs, f0, top, 101, 300)
+            assert np.array_equal(part, got[..., 101:300]), (trial, top, "block")
+            for m in (1, 2):
+                monkeypatch.setenv("PICASO_AMD_SHC_ANGLES", str(m))
+                assert np.array_equal(_resident_call(hip, sc, nlayer, nwno, ng, nt, u0, u1, ct, rs, f0, top), got), (top, m)
+            monkeypatch.delenv("PICASO_AMD_SHC_ANGLES")
+        assert np.array_equal(_resident_call(hip, sc, nlayer, nwno, ng, nt, u0, u1, ct, rs, f0, 3), plain)
+        monkeypatch.setenv("PICASO_AMD_SH_NO_TOP", "1")
+        assert np.array_equal(_resident_call(hip, sc, nlayer, nwno, ng, nt, u0, u1, ct, rs, f0, deck), plain)
+        monkeypatch.delenv("PICASO_AMD_SH_NO_TOP")
+
+
+def test_cloud_free_top_statement_is_checked_on_request(hip, monkeypatch):
+    """A cloud_free_above that reaches into the cloud: PICASO_AMD_SH_CHECK_TOP=1 fails the call; the whole column
+    (cloud_free_above >= nlayer on a cloud-free scene) is the cloud-free form's bits."""
+    from picaso_amd import synthetic as syn
+    from picaso_amd._lib import PicasoHipError
+    nlayer, nwno = 20, 130
+    u0, u1, ct = _geom(hip, 5, 1, 0.0)
+    sc = syn.make_scene(nlayer, nwno, seed=11, stream=4)
+    monkeypatch.setenv("PICASO_AMD_SH_CHECK_TOP", "1")
+    with pytest.raises(PicasoHipError, match="cloud_free_above = 12"):
+        _resident_call(hip, sc, nlayer, nwno, 5, 1, u0, u1, ct, 0.0, 1.0, 12)           # the slab starts at layer 11
+    _resident_call(hip, sc, nlayer, nwno, 5, 1, u0, u1, ct, 0.0, 1.0, 11)
+    clear = _scene(nlayer, nwno, 12)
+    whole = _resident_call(hip, clear, nlayer, nwno, 5, 1, u0, u1, ct, 0.1, 1.0, nlayer + 5)
+    lean = _call(hip.fluxes.get_reflected_SH, clear, nlayer, nwno, 5, 1, u0, u1, ct, 0.1, 1.0, True)
+    assert np.array_equal(whole, lean)
