@@ -192,9 +192,11 @@ def workload_thermal(ctx, args, lo, hi, seed, nwno_total, scene=None):
                 metric="spectra/sec (%d wave x %d layer thermal)" % (nwno_total, nlayer))
 
 
-def workload_sh4(ctx, args, lo, hi, seed, nwno_total, scene=None, clear=False):
+def workload_sh4(ctx, args, lo, hi, seed, nwno_total, scene=None, clear=False, top=0):
     """configs[3]: get_reflected_SH, stream = 4, + compress_disco.  ``clear``: the scene has no cloud and the launch is
-    handed dtau and w0 only (picaso_reflected_SH_can_derive; the oracle still gets all eleven planes)."""
+    handed dtau and w0 only (picaso_reflected_SH_can_derive; the oracle still gets all eleven planes).  ``top``: the
+    caller's statement that the first ``top`` layers carry no cloud (picaso_get_reflected_SH_top_dev; what spectrum()
+    reads off the cloud profile)."""
     nlayer, nlevel, ng = args.nlayer, args.nlayer + 1, args.ngauss
     n = hi - lo
     gang, gw, tang, tw = disco.get_angles_1d(ng)
@@ -211,7 +213,7 @@ def workload_sh4(ctx, args, lo, hi, seed, nwno_total, scene=None, clear=False):
 
     def solve(albedo):
         resident.reflected_SH(ctx, nlevel, n, ng, 1, planes, d["surf_reflect"], ubar0, ubar1, 1.0, d["F0PI"], *opts,
-                              *TTHG, 4, xint, gweight=gw, tweight=tw, albedo=albedo)
+                              *TTHG, 4, xint, gweight=gw, tweight=tw, albedo=albedo, cloud_free_above=top)
 
     def oracle(sl):
         from oracle import oracle as orc
@@ -230,7 +232,7 @@ def workload_sh4(ctx, args, lo, hi, seed, nwno_total, scene=None, clear=False):
                     metric="spectra/sec (%d wave x %d layer SH4 reflected, cloud-free)" % (nwno_total, nlayer))
     return dict(solve=solve, oracle=oracle, nloc=n,
                 abytes=8 * n * (9 * nlayer + 2 * nlevel + 2 + ng + 1),
-                kernel="k_sh<2, false, false, true>",
+                kernel="k_sh<2, false, false, true>" if not top else "k_sh4_clear<2> (layers 0-%d) + k_sh<2, false, false, true>" % (top - 1),
                 workload="BASELINE configs[3]: spherical-harmonics SH4 reflected light (get_reflected_SH + "
                          "compress_disco), TTHG, delta-M, Rayleigh + cloud slab",
                 metric="spectra/sec (%d wave x %d layer SH4 reflected)" % (nwno_total, nlayer))
@@ -468,7 +470,14 @@ def companions(ctx, args, wl, res_single, nwno_total):
     ms3s = steady_ms(ctx, lambda: w3s["solve"](out3s), 150)
     sec["configs[3] 12500-column shard"] = entry(w3s, ms3s)
     sec["configs[3] 12500-column shard"]["bit_identical_to_unsharded"] = bool(np.array_equal(out3s.to_host(), out3.to_host()[:12500]))
-    del w3, w3s, sc4
+    # the same launch told where the cloud deck begins (what spectrum() reads off the cloud profile): the layers above it
+    # go through the cloud-free kernel, which hands its sweep state to k_sh
+    busy = scene["taucld"].any(axis=1) | scene["g0_cld"].any(axis=1)
+    deck = int(np.argmax(busy)) if busy.any() else args.nlayer
+    w3t = workload_sh4(ctx, args, 0, nwno_total, 3, nwno_total, scene=sc4, top=deck)
+    ms3t = steady_ms(ctx, lambda: w3t["solve"](out3), 40, prewarm_ms=100.0)
+    sec["configs[3] cloud_free_above=%d" % deck] = entry(w3t, ms3t, n_oracle=128, res=out3.to_host())
+    del w3, w3s, w3t, sc4
     # the same atmosphere without its cloud: the cloud-free SH4 form against the full-plane kernel on the same planes
     # (no cloud profile: opd = w0 = g0 = 0 in every layer, what ATMSETUP.get_clouds leaves, atmsetup.py:609-640 -- COSB is
     # the cloud's g0 itself, optics.py:338, so a g0 without optical depth would still delta-scale the layer)

@@ -1096,6 +1096,25 @@ def _ones(opa, nwno):
     return hit
 
 
+def _cloud_free_top(inp, nlayer):
+    """Number of layers above the cloud deck: the first layer whose cloud profile rows hold any optical depth or any
+    asymmetry (COSB is the cloud's g0 itself, optics.py:338, so a g0 without optical depth still delta-scales the layer).
+    Read off the profile AS GIVEN (linear regridding keeps a zero row zero); tables larger than 2e5 numbers are not
+    scanned (0: no statement) -- the scan would cost more than it saves."""
+    prof = inp["clouds"]["profile"]
+    if prof is None:
+        return nlayer
+    busy = np.zeros(nlayer, dtype=bool)
+    for k in ("opd", "g0"):
+        v = np.asarray(prof[k], dtype=np.float64)
+        if v.ndim == 0:
+            return 0 if v != 0 else nlayer
+        if v.size > 200000 or v.size % nlayer:
+            return 0
+        busy |= (v.reshape(nlayer, -1) != 0).any(axis=1)
+    return int(np.argmax(busy)) if busy.any() else nlayer
+
+
 def _constant_planes(opa, nlayer, nwno):
     """Resident ``(nlayer, nwno)`` planes of 0, 1 and 0.5, kept on the opacity object: what ``compute_opacity``
     writes into cosb / cosb_og / ftau_cld, ftau_ray and gcos2 for an atmosphere without cloud."""
@@ -1309,7 +1328,7 @@ def picaso(bundle, opacityclass, dimension="1d", calculation="reflected", full_o
         # SH4 with the reference's default forms, same atmosphere: dtau and w0 are all the cloud-free SH launch reads
         # (resident.reflected_SH_can_derive; the angle-independent half of a layer shared between the disk angles);
         # the thermal SH solver reads dtau, w0 and cosb_og (= 0)
-        sh_lean = False
+        sh_lean, sh_top = False, 0
         if is_sh:
             sh_o = inp["approx"]["rt_params"]["SH"]
             sh_lean = (ngauss == 1 and getattr(atm, "cloud_free", False) and inp["test_mode"] is None and not do_holes
@@ -1321,6 +1340,11 @@ def picaso(bundle, opacityclass, dimension="1d", calculation="reflected", full_o
                            sh_o["single_form"], 1 if sh_o["calculate_fluxes"] else 0))
             if sh_lean:
                 want = {"dtau", "w0"}
+            elif (ngauss == 1 and inp["test_mode"] is None and not do_holes and len(getattr(atm, "rayleigh_molecules", [])) > 0
+                  and not os.environ.get("PICASO_AMD_ALL_PLANES")):
+                # a cloud deck: the layers above it are swept by the cloud-free kernel (picaso_get_reflected_SH_top_dev;
+                # every wavelength block of a sharded spectrum reads the same profile, hence the same statement)
+                sh_top = _cloud_free_top(inp, nlayer)
         th_w0 = "w0_no_raman"
         if lean:
             want = set()
@@ -1404,7 +1428,7 @@ def picaso(bundle, opacityclass, dimension="1d", calculation="reflected", full_o
                 _reflected_sh(ctx, nlevel, nwno, ng, nt, rplanes if rplanes is not None else planes, rs, ubar0, ubar1,
                               cos_theta, d_f0,
                               sh_opt, frac_a, frac_b, frac_c, constant_back, constant_forward,
-                              common["stream"], b_top, xint, gweight, tweight, alb, sh_flux)
+                              common["stream"], b_top, xint, gweight, tweight, alb, sh_flux, cloud_free_above=sh_top)
                 if sh_flux is not None:
                     atm.flux_layers = sh_flux.to_host()
             else:
@@ -2391,7 +2415,7 @@ def _reflected(ctx, nlevel, nwno, ng, nt, planes, rs, ubar0, ubar1, cos_theta, F
 
 def _reflected_sh(ctx, nlevel, nwno, ng, nt, planes, rs, ubar0, ubar1, cos_theta, F0PI, sh, frac_a,
                   frac_b, frac_c, constant_back, constant_forward, stream, b_top, xint, gweight,
-                  tweight, albedo, flux=None):
+                  tweight, albedo, flux=None, cloud_free_above=0):
     import ctypes
     from ._lib import check, f64, load, ptr
     u0, u1 = f64(ubar0, (ng, nt)), f64(ubar1, (ng, nt))
@@ -2399,14 +2423,15 @@ def _reflected_sh(ctx, nlevel, nwno, ng, nt, planes, rs, ubar0, ubar1, cos_theta
     ci, cd = ctypes.c_int, ctypes.c_double
     names = ("dtau", "tau", "w0", "cosb", "ftau_cld", "ftau_ray", "f_deltaM", "dtau_og", "tau_og",
              "w0_og", "cosb_og")
-    check(load().picaso_get_reflected_SH_dev(
+    check(load().picaso_get_reflected_SH_top_dev(
         ctx, ci(nlevel), ci(nwno), ctypes.c_long(nwno), ci(ng), ci(nt),
         *[ptr(planes[k].addr) if planes.get(k) is not None else None for k in names], ptr(rs.addr), ptr(u0), ptr(u1),
         cd(cos_theta),
         ptr(F0PI.addr), ci(sh["w_single_form"]), ci(sh["w_multi_form"]), ci(sh["psingle_form"]),
         ci(sh["w_single_rayleigh"]), ci(sh["w_multi_rayleigh"]), ci(sh["psingle_rayleigh"]),
         cd(frac_a), cd(frac_b), cd(frac_c), cd(constant_back), cd(constant_forward), ci(stream),
-        cd(b_top), ci(1 if flux is not None else 0), ci(sh["single_form"]), ci(1), ptr(xint.addr),
+        cd(b_top), ci(1 if flux is not None else 0), ci(sh["single_form"]), ci(1), ci(int(cloud_free_above)),
+        ptr(xint.addr),
         ptr(flux.addr) if flux is not None else None, ptr(gw), ptr(tw),
         ptr(albedo.addr)), ctx)
 

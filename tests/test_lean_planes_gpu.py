@@ -140,3 +140,34 @@ def test_sh4_cloud_free_writes_two_planes(monkeypatch, calc):
         assert wants[-1] is None
         case().spectrum(opa, calculation=calc, full_output=True)
         assert wants[-1] is None
+
+
+def test_sh4_cloud_deck_uses_the_cloud_free_top(monkeypatch):
+    """rt_method='SH', stream 4 with a cloud below layer 12: spectrum() states the cloud-free top to the SH launch
+    (picaso_get_reflected_SH_top_dev; the statement is checked on the device here), the result agrees with the unsplit
+    launch to 1e-9 and wavelength blocks (devices=[0, 0, 0]) reproduce it bit for bit."""
+    from picaso_amd import justdoit as jdi
+    og = np.load(os.path.join(GOLDEN, "optics.npz"))
+    opa = jdi.opannection(filename_db=DB)
+    nlayer = og["in/cld_opd"].shape[0]
+    deck = 12
+    cld = {k: np.array(og["in/cld_" + k]) for k in ("opd", "w0", "g0")}
+    cld["opd"] = np.abs(cld["opd"]) + 0.05
+    for k in ("opd", "g0"):
+        cld[k][:deck] = 0.0
+
+    def case():
+        c = _case(jdi, og, "none", True, False)
+        c.approx(raman="none", rt_method="SH", stream=4)
+        c.clouds(df=cld)
+        return c
+    assert jdi._cloud_free_top(case().inputs, nlayer) == deck
+    monkeypatch.setenv("PICASO_AMD_SH_CHECK_TOP", "1")
+    split = case().spectrum(opa, calculation="reflected+thermal")
+    blocks = case().spectrum(opa, calculation="reflected+thermal", devices=[0, 0, 0])
+    monkeypatch.setenv("PICASO_AMD_SH_NO_TOP", "1")
+    plain = case().spectrum(opa, calculation="reflected+thermal")
+    assert np.array_equal(blocks["albedo"], split["albedo"]) and np.array_equal(blocks["thermal"], split["thermal"])
+    assert not np.array_equal(split["albedo"], plain["albedo"])          # the split path did run
+    assert np.max(np.abs(split["albedo"] - plain["albedo"]) / np.abs(plain["albedo"])) < 1e-9
+    assert np.array_equal(split["thermal"], plain["thermal"])
