@@ -558,6 +558,30 @@ def product_companion(ctx, nwno=100000, nlevel=91, ncalls=30, nbatch=32):
         tb.append(time.perf_counter() - t0)
     rl = [c.spectrum(opa, calculation=calc) for c in cases[:4]]
     same = all(np.array_equal(a[k], b[k]) for a, b in zip(rb[:4], rl) for k in a if isinstance(a[k], np.ndarray))
+
+    def timed(c, n=12):
+        for _ in range(4):
+            c.spectrum(opa, calculation=calc)
+        tt = []
+        for _ in range(n):
+            t0 = time.perf_counter()
+            out = c.spectrum(opa, calculation=calc)
+            tt.append(time.perf_counter() - t0)
+        return 1e3 * float(np.median(tt)), out
+    # the same call with the spherical-harmonics solver (SH4): without cloud (dtau and w0 only, angle-independent half
+    # of a layer shared between disk angles) and with a grey box cloud below layer 50 (the layers above the deck go
+    # through the cloud-free kernel: spectrum() states where the deck begins, justdoit._cloud_free_top)
+    sh = make(0)
+    sh.approx(raman="none", rt_method="SH", stream=4)
+    sh_ms, sh_out = timed(sh)
+    shc = make(0)
+    shc.approx(raman="none", rt_method="SH", stream=4)
+    nl = nlevel - 1
+    box = np.zeros((nl, 196))
+    box[50:60] = 0.3
+    shc.clouds(df={"opd": box, "w0": np.where(box > 0, 0.95, 0.0), "g0": np.where(box > 0, 0.6, 0.0)},
+               wavenumber=np.linspace(wno[0], wno[-1], 196))
+    shc_ms, shc_out = timed(shc)
     return {"product": {
         "workload": "inputs.spectrum(opa, 'reflected+thermal'), %d wavelengths x %d layers, 5 Gauss angles, cloud-free, "
                     "resident opacity tables (5 molecules, 2 CIA pairs, 2 Rayleigh species): set-up, opacity mixing, "
@@ -566,7 +590,9 @@ def product_companion(ctx, nwno=100000, nlevel=91, ncalls=30, nbatch=32):
         "spectrum_ms_after_300ms_idle": 1e3 * float(np.median(idle)),
         "spectrum_batch_ms_per_spectrum": 1e3 * min(tb) / nbatch, "batch_of": nbatch,
         "spectrum_batch_equals_single_calls": bool(same),
-        "finite": bool(np.all(np.isfinite(r["albedo"])) and np.all(np.isfinite(r["thermal"]))),
+        "sh4_spectrum_ms": sh_ms, "sh4_box_cloud_below_layer_50_spectrum_ms": shc_ms,
+        "finite": bool(np.all(np.isfinite(r["albedo"])) and np.all(np.isfinite(r["thermal"]))
+                       and all(np.all(np.isfinite(o[k])) for o in (sh_out, shc_out) for k in ("albedo", "thermal"))),
         "seconds": time.perf_counter() - t_all}}
 
 
