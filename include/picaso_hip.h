@@ -675,6 +675,14 @@ int picaso_broadcast_facets_dev(picaso_ctx *ctx, size_t nrows, int nwno, int nfa
 int picaso_regrid_rows_dev(picaso_ctx *ctx, int nrows, int nin, long nwno, const double *xp, const double *fp,
                            const double *x, const double *scale, double *out);
 
+/* The same for tables that differ from facet to facet (3-D path, clouds_3d on a grid of their own: the reference
+ * regrids facet by facet on the host, justdoit.py:437-449 -> atmsetup.py:609-622): fp (nlayer, nfacets, nin) -> out
+ * (nlayer, nwno, nfacets), facet index fastest -- the layout picaso_compute_opacity_facets_dev reads its cloud inputs in.
+ * numpy.interp's bits per (layer, facet) row. */
+int picaso_regrid_facets_dev(picaso_ctx *ctx, int nlayer, int nfacets, int nin, long nwno, const double *xp,
+                             const double *fp, const double *x, double *out);
+
+
 /* Oklopcic (2016) Raman factor plane, replaces optics.compute_raman (reference picaso/optics.py:434-494) as
  * compute_opacity calls it (optics.py:285-294): out (nlayer, nwno) = min((ray + w_shift)/(ray + wo_shift), cap).
  * Q, QS: device tables (ntrans, nwno) of c_i / wno**3 / (wno + deltanu_i) and of that times the stellar shift ratio

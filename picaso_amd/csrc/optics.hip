@@ -529,6 +529,37 @@ __global__ __launch_bounds__(256) void k_regrid_rows(const RegridArgs a)
     }
 }
 
+// The same for cloud tables that differ from facet to facet (the 3-D path: clouds_3d on the 196-point grid of virga,
+// justdoit.py:4515-4620 -- the reference regrids facet by facet on the host, atmsetup.py:609-622): fp is
+// (nlayer, nfacets, nin), out the (nlayer, nwno, nfacets) plane the facet mixing kernel and the 3-D solvers read, facet
+// index fastest.  One thread per (wavelength, facet) element, so that the writes are coalesced; the bracket search is
+// repeated per facet (a few LDS reads), the table rows come from L2.  Same arithmetic as k_regrid_rows.
+struct RegridFacetArgs {
+    int nlayer, nfac, nin;
+    long nwno;
+    const double *xp, *fp, *x;
+    double *out;
+};
+__global__ __launch_bounds__(256) void k_regrid_facets(const RegridFacetArgs a)
+{
+#pragma clang fp contract(off)
+    __shared__ double sxp[REGRID_LDS];
+    const bool in_lds = a.nin <= REGRID_LDS;
+    if (in_lds) {
+        for (int i = threadIdx.x; i < a.nin; i += blockDim.x) sxp[i] = a.xp[i];
+        __syncthreads();
+    }
+    const double *xp = in_lds ? sxp : a.xp;
+    const long e = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    const long ncol = a.nwno * a.nfac;
+    if (e >= ncol) return;
+    const long w = e / a.nfac;
+    const int f = (int)(e - w * a.nfac);
+    const RegridBracket b = regrid_bracket(xp, a.nin, a.x[w]);
+    for (int i = 0; i < a.nlayer; ++i)
+        a.out[(long)i * ncol + e] = regrid_value(a.fp + ((long)i * a.nfac + f) * a.nin, b);
+}
+
 // Oklopcic (2016) Raman factor plane, reference optics.compute_raman (optics.py:434-494): for every transition i of the
 // H2 table, Q_i(w) = c_i / w^3 / (w + dnu_i) and (dnu_i != 0) Q_i(w) * shift_i(w) depend on the wavelength only and
 // arrive as resident (ntrans, nwno) tables formed once with numpy's own pow and divisions; the layer enters through the
@@ -651,6 +682,22 @@ int picaso_regrid_rows_dev(picaso_ctx *ctx, int nrows, int nin, long nwno, const
     a.scale = scale ? *scale : 1.0;
     a.out = out;
     hipLaunchKernelGGL(k_regrid_rows, dim3((unsigned)((nwno + 255) / 256)), dim3(256), 0, ctx->stream, a);
+    PZ_HIP(ctx, hipGetLastError());
+    return 0;
+}
+
+int picaso_regrid_facets_dev(picaso_ctx *ctx, int nlayer, int nfacets, int nin, long nwno, const double *xp,
+                             const double *fp, const double *x, double *out)
+{
+    if (!ctx) return fail(nullptr, "null context");
+    if (nlayer < 1 || nfacets < 1 || nin < 2 || nwno < 1 || !xp || !fp || !x || !out)
+        return fail(ctx, "regrid_facets: bad arguments");
+    PZ_HIP(ctx, hipSetDevice(ctx->device));
+    RegridFacetArgs a{};
+    a.nlayer = nlayer; a.nfac = nfacets; a.nin = nin; a.nwno = nwno;
+    a.xp = xp; a.fp = fp; a.x = x; a.out = out;
+    const long total = nwno * nfacets;
+    hipLaunchKernelGGL(k_regrid_facets, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, a);
     PZ_HIP(ctx, hipGetLastError());
     return 0;
 }

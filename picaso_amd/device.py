@@ -196,6 +196,24 @@ def regrid_rows(xp, fp, d_x, ctx, scale=None):
     return out
 
 
+def regrid_facets(xp, fp, d_x, ctx):
+    """Per-facet tables ``fp`` ``(nlayer, nfacets, nin)`` (host) on the grid ``xp`` -> the ``(nlayer, nwno, nfacets)``
+    DeviceArray (facet index fastest) of ``numpy.interp`` along the last axis on the device grid ``d_x``
+    (``picaso_regrid_facets_dev``)."""
+    fp = np.ascontiguousarray(fp, dtype=np.float64)
+    nlayer, nfac, nin = fp.shape
+    nwno = int(d_x.shape[0])
+    d_xp = DeviceArray.from_host(np.ascontiguousarray(xp, dtype=np.float64).reshape(nin), ctx)
+    d_fp = DeviceArray.from_host(fp, ctx)
+    out = DeviceArray((nlayer, nwno, nfac), ctx)
+    _lib.check(_lib.load().picaso_regrid_facets_dev(ctx, ctypes.c_int(nlayer), ctypes.c_int(nfac), ctypes.c_int(nin),
+                                                    ctypes.c_long(nwno), ctypes.c_void_p(d_xp.addr),
+                                                    ctypes.c_void_p(d_fp.addr), ctypes.c_void_p(d_x.addr),
+                                                    ctypes.c_void_p(out.addr)), ctx)
+    out._inputs = (d_xp, d_fp)
+    return out
+
+
 def sync(ctx=None):
     ctx = ctx if ctx is not None else _lib.context()
     _lib.check(_lib.load().picaso_sync(ctx), ctx)

@@ -1220,11 +1220,13 @@ def picaso(bundle, opacityclass, dimension="1d", calculation="reflected", full_o
         prof3 = inp["atmosphere"]["profile_3d"]
         cld3 = inp["clouds"].get("profile_3d")
         if isinstance(cld3, dict) and cld3.get("wavenumber") is not None and not (
-                len(cld3["wavenumber"]) == len(wno) and np.array_equal(cld3["wavenumber"], wno)):
+                len(cld3["wavenumber"]) == len(wno) and np.array_equal(cld3["wavenumber"], wno)) and os.environ.get("PICASO_AMD_HOST_REGRID"):
             # a cloud dataset on its own wavenumber grid (clouds_3d(ds)): onto the opacity grid, linear in wavenumber
-            # like the reference's per-facet get_clouds -> wavelength.regrid (atmsetup.py:609-622)
+            # like the reference's per-facet get_clouds -> wavelength.regrid (atmsetup.py:609-622).  Normally on the
+            # device (compute_opacity_facets: numpy.interp's bits); here the host form of the same interpolation
             cld3 = dict(cld3, **{k: _interp_axis(wno, cld3["wavenumber"], np.asarray(cld3[k], dtype=float), 1)
                                  for k in ("opd", "w0", "g0")})
+            cld3.pop("wavenumber")
         # Only planes that cannot be re-derived exactly inside the solvers are written (each is nfacets x 9 MB
         # at 12 500 wavelengths x 90 layers): the level optical depths are running sums and gcos2 is
         # 0.5 ftau_ray, so the reflected kernel takes 8 planes instead of 11; without cloud (and outside the

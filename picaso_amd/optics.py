@@ -1010,11 +1010,35 @@ def compute_opacity_facets(atms, opacityclass, numg, numt, stream=2, delta_eddin
         d_rf, rf_rows = raman_device(atms[0][0] if isinstance(atms, list) else atm_f, opa, raman)
     d_c = [None, None, None]
     if clouds_3d is not None:
-        from .device import broadcast_facets
+        from .device import broadcast_facets, regrid_facets, regrid_rows
         d_c = []
+        in_wno = clouds_3d.get("wavenumber") if isinstance(clouds_3d, dict) else None
+        if in_wno is not None and len(in_wno) == nwno and np.array_equal(in_wno, opa.wno):
+            in_wno = None
+        if in_wno is not None:
+            # tables on a wavenumber grid of their own (virga's 196 points): regridded on the device with numpy.interp's
+            # bits -- the reference's per-facet get_clouds -> wavelength.regrid (atmsetup.py:609-622) -- instead of
+            # (nlayer, nwno, nfacets) host arrays: 3 x 576 MB and seconds of numpy at 1e5 wavelengths x 64 facets
+            in_wno = np.asarray(in_wno, dtype=np.float64)
+            nin = in_wno.size
+            order = np.argsort(in_wno, kind="stable") if np.any(np.diff(in_wno) < 0) else None
+            d_x = _wno_device(opa, opa.wno)
         for k in ("opd", "w0", "g0"):
             a = np.asarray(clouds_3d[k], dtype=float)
-            if a.size == nlayer * nwno:          # one table for the whole disk: tiled over the facets on the device
+            if in_wno is not None and nin >= 2:
+                if a.size == nlayer * nin:       # one table for the whole disk
+                    rows = a.reshape(nlayer, nin)
+                    rows = rows if order is None else rows[:, order]
+                    d_c.append(broadcast_facets(regrid_rows(in_wno if order is None else in_wno[order], rows, d_x, ctx), nfac))
+                else:                            # (nlayer, nin, numg, numt): rows per (layer, facet)
+                    rows = np.ascontiguousarray(np.moveaxis(a.reshape(nlayer, nin, nfac), 1, 2))
+                    rows = rows if order is None else np.ascontiguousarray(rows[:, :, order])
+                    d_c.append(regrid_facets(in_wno if order is None else in_wno[order], rows, d_x, ctx))
+            elif in_wno is not None:             # a single wavenumber: the value everywhere
+                a = np.repeat(a.reshape(nlayer, 1, -1), nwno, axis=1)
+                d_c.append(broadcast_facets(DeviceArray.from_host(np.ascontiguousarray(a[:, :, 0]), ctx), nfac) if a.shape[2] == 1
+                           else DeviceArray.from_host(np.ascontiguousarray(a), ctx))
+            elif a.size == nlayer * nwno:        # one table for the whole disk: tiled over the facets on the device
                 d_c.append(broadcast_facets(DeviceArray.from_host(a.reshape(nlayer, nwno), ctx), nfac))
             else:
                 d_c.append(DeviceArray.from_host(a.reshape(nlayer, nwno, nfac), ctx))

@@ -195,3 +195,53 @@ def test_gpu_new_entry_points_refuse_bad_arguments():
         check(load().picaso_compute_opacity_ck_dev(ctx, ci(2), ci(8), ci(1), vp(planes[0].addr), vp(planes[1].addr), None,
                                                    None, None, vp(d.addr), ci(7), ctypes.c_double(0.99999), ci(0), ci(1),
                                                    ci(2), *outs), ctx)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("per_facet", [False, True])
+def test_gpu_3d_cloud_tables_on_their_own_grid_regrid_on_the_device(monkeypatch, per_facet):
+    """spectrum(dimension='3d') with clouds_3d tables on a wavenumber grid of their own (decreasing, reaching past the
+    opacity grid on one side): regridded on the device (picaso_regrid_rows_dev / picaso_regrid_facets_dev) -- the same
+    bits as handing in the numpy.interp rows the reference forms facet by facet (atmsetup.py:609-622), and the host
+    form of the interpolation (PICASO_AMD_HOST_REGRID=1) to rounding."""
+    og = np.load(os.path.join(GOLDEN, "optics.npz"))
+    opa = jdi.opannection(filename_db=DB, query_method="linear")
+    ng, nt = 3, 2
+    nlayer, nin = len(og["in/tlevel"]) - 1, 9
+    rng = np.random.default_rng(3 + per_facet)
+    wn = np.linspace(opa.wno[-1] * 0.9, opa.wno[0] * 1.05, nin)[::-1].copy()          # decreasing
+    shape = (nlayer, nin, ng, nt) if per_facet else (nlayer, nin)
+    cld = {"opd": 0.3 * rng.random(shape), "w0": 0.5 + 0.49 * rng.random(shape), "g0": 0.8 * rng.random(shape)}
+    for k in ("opd", "g0"):
+        cld[k][:5] = 0.0
+
+    def case(tables):
+        c = jdi.inputs()
+        c.phase_angle(np.pi / 4, num_gangle=ng, num_tangle=nt)
+        c.gravity(gravity=float(og["in/gravity"]))
+        prof = {"pressure": og["in/plevel_bar"],
+                "temperature": og["in/tlevel"][:, None, None] * (1.0 + 0.02 * np.arange(ng * nt).reshape(1, ng, nt))}
+        for k in ("H2", "He", "H2O", "CH4"):
+            prof[k] = og["in/mix/" + k]
+        c.atmosphere_3d(prof)
+        c.clouds_3d(tables)
+        c.approx(raman="none")
+        return c
+    calc = "reflected+thermal"
+    monkeypatch.delenv("PICASO_AMD_HOST_REGRID", raising=False)
+    dev = case(dict(cld, wavenumber=wn)).spectrum(opa, calculation=calc, dimension="3d")
+    # numpy.interp rows on the opacity grid, handed in as arrays already on it
+    o = np.argsort(wn)
+    on_grid = {}
+    for k, v in cld.items():
+        rows = np.moveaxis(v.reshape(nlayer, nin, -1), 1, 2)[..., o]                 # (nlayer, nfac|1, nin)
+        r = np.stack([[np.interp(opa.wno, wn[o], row) for row in lay] for lay in rows])   # (nlayer, nfac|1, nwno)
+        r = np.moveaxis(r, 1, 2)
+        on_grid[k] = np.ascontiguousarray(r.reshape(nlayer, opa.nwno, ng, nt) if per_facet else r[:, :, 0])
+    ref = case(on_grid).spectrum(opa, calculation=calc, dimension="3d")
+    for key in ("albedo", "thermal"):
+        assert np.isfinite(dev[key]).all() and np.array_equal(dev[key], ref[key]), key
+    monkeypatch.setenv("PICASO_AMD_HOST_REGRID", "1")
+    host = case(dict(cld, wavenumber=wn)).spectrum(opa, calculation=calc, dimension="3d")
+    for key in ("albedo", "thermal"):
+        assert np.max(np.abs(host[key] - dev[key]) / np.abs(dev[key])) < 1e-11, key

@@ -41,6 +41,13 @@ c3.phase_angle(np.pi / 3, num_gangle=ng, num_tangle=nt)
 c3.gravity(gravity=2500.0)
 c3.atmosphere_3d(prof3)
 c3.approx(raman="none")
+if os.environ.get("CLOUD3D"):         # CLOUD3D=1: a grey cloud below layer 50 on every facet, tables on a 196-point grid of their own
+    box = np.zeros((nlevel - 1, 196))
+    box[50:60] = 0.3
+    if os.environ.get("CLOUD3D") == "2":   # ... differing from facet to facet: (nlayer, 196, ng, nt) tables
+        box = box[:, :, None, None] * (1.0 + 0.3 * np.cos(np.arange(64).reshape(1, 1, 8, 8)))
+    c3.clouds_3d(df={"opd": box, "w0": np.where(box > 0, 0.95, 0.0), "g0": np.where(box > 0, 0.6, 0.0),
+                     "wavenumber": np.linspace(wno[0], wno[-1], 196)})
 if os.environ.get("PROFILE_3D"):      # PROFILE_3D=1: cProfile + wall time of the batched call alone (for rocprofv3 too)
     import cProfile, pstats
     for _ in range(30):
@@ -75,6 +82,9 @@ for calc in ("reflected", "thermal"):
         c3.spectrum(opa, calculation=calc, dimension="3d")
         ts.append(time.perf_counter() - t0)
     out["spectrum_3d_%s_only_ms" % calc] = round(1e3 * min(ts), 3)
+if os.environ.get("CLOUD3D"):
+    print(json.dumps(out))
+    sys.exit(0)
 # phase curve: P phases of the same map
 P = 8
 phases = list(np.linspace(0.0, 2 * np.pi * (P - 1) / P, P))
