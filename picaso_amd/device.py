@@ -93,6 +93,16 @@ class DeviceArray:
         v._owner = self            # keeps the parent alive; views are never freed
         return v
 
+    def row_range(self, lo, hi):
+        """Non-owning view of ``self[lo:hi]`` (leading axis)."""
+        v = DeviceArray.__new__(DeviceArray)
+        v.ctx, v.shape = self.ctx, (int(hi) - int(lo),) + tuple(self.shape[1:])
+        v.size = int(np.prod(v.shape))
+        v.nbytes = v.size * 8
+        v.addr = self.addr + int(lo) * (self.nbytes // int(self.shape[0]))
+        v._owner = self
+        return v
+
     def head(self, n):
         """Non-owning view of the first ``n`` elements of a 1-D buffer (a result vector allocated with room for a
         spectrum-wide integral behind it)."""
