@@ -82,7 +82,19 @@ for calc in ("reflected", "thermal"):
         c3.spectrum(opa, calculation=calc, dimension="3d")
         ts.append(time.perf_counter() - t0)
     out["spectrum_3d_%s_only_ms" % calc] = round(1e3 * min(ts), 3)
-if os.environ.get("CLOUD3D"):
+if os.environ.get("CLOUD3D"):         # ... and an 8-phase reflected curve with that cloud map at every phase
+    P = 8
+    phases = list(np.linspace(0.0, 2 * np.pi * (P - 1) / P, P))
+    pc = jdi.inputs()
+    pc.phase_curve_geometry("reflected", phases, num_gangle=ng, num_tangle=nt)
+    pc.gravity(gravity=2500.0)
+    pc.atmosphere_4d([prof3 for _ in phases])
+    pc.approx(raman="none")
+    cmap = c3.inputs["clouds"]["profile_3d"]
+    pc.phase_curve(opa, clouds_by_phase=[cmap] * P)
+    t0 = time.perf_counter()
+    res = pc.phase_curve(opa, clouds_by_phase=[cmap] * P)
+    out["phase_curve_reflected_%d_phases_cloudy_ms" % P] = round(1e3 * (time.perf_counter() - t0), 3)
     print(json.dumps(out))
     sys.exit(0)
 # phase curve: P phases of the same map
