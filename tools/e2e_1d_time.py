@@ -28,7 +28,10 @@ prof = {"pressure": plev, "temperature": 150.0 + 1200.0 * ((np.log10(plev) + 6) 
         "He": np.full(nlevel, 0.155), "H2O": np.full(nlevel, 1e-3), "CH4": np.full(nlevel, 5e-4),
         "CO": np.full(nlevel, 1e-4), "NH3": np.full(nlevel, 1e-5)}
 case = jdi.inputs()
-case.phase_angle(0)
+if os.environ.get("PHASE"):            # PHASE=<radians>: a 6 x 6 disk grid at that phase angle instead of the symmetric 1-D one
+    case.phase_angle(float(os.environ["PHASE"]), num_gangle=6, num_tangle=6)
+else:
+    case.phase_angle(0)
 case.gravity(gravity=2500.0)
 case.atmosphere(df=prof)
 # RAMAN=none|pollack|oklopcic, RT=toon|SH, LVL=1 (level fluxes), STAR=1 (a stellar spectrum on the grid: fpfs and Raman need one)
@@ -63,7 +66,8 @@ if os.environ.get("CLOUD"):
         for i, w in enumerate(wn):
             fh.write("%4d %9.3f %9.2f %8.2f- %7.2f %9.3f %9.3f\n" % (i + 1, 1e4 / w, w, w - 1, w + 1, 2.0, w))
     os.environ["picaso_refdata"] = d
-    case.clouds(g0=[0.8], w0=[0.95], opd=[1.5], p=[0.0], dp=[1.5])
+    hk = dict(do_holes=True, fhole=0.3, fthin_cld=0.1) if os.environ.get("HOLES") else {}     # HOLES=1: patchy cloud
+    case.clouds(g0=[0.8], w0=[0.95], opd=[1.5], p=[0.0], dp=[1.5], **hk)
     if os.environ["CLOUD"] == "table":
         cl = case.inputs["clouds"]
         case.clouds(df={k: np.stack([np.interp(wno, cl["wavenumber"], row) for row in cl["profile"][k]])
