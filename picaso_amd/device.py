@@ -192,11 +192,15 @@ def regrid_rows(xp, fp, d_x, ctx, scale=None):
     """``numpy.interp(x, xp, row)`` for every row of the host table ``fp`` ``(nrows, nin)``, on the device grid
     ``d_x`` (a DeviceArray of ``nwno`` wavenumbers): a ``(nrows, nwno)`` DeviceArray, bit for bit what the
     reference's ``wavelength.regrid`` returns (``picaso_regrid_rows_dev``).  ``scale``: result times a scalar."""
-    fp = np.ascontiguousarray(fp, dtype=np.float64)
-    nrows, nin = fp.shape
+    if isinstance(fp, DeviceArray):          # tables already resident (kept by the caller between calls)
+        d_fp, d_xp = fp, xp
+        nrows, nin = fp.shape
+    else:
+        fp = np.ascontiguousarray(fp, dtype=np.float64)
+        nrows, nin = fp.shape
+        d_xp = DeviceArray.from_host(np.ascontiguousarray(xp, dtype=np.float64).reshape(nin), ctx)
+        d_fp = DeviceArray.from_host(fp, ctx)
     nwno = int(d_x.shape[0])
-    d_xp = DeviceArray.from_host(np.ascontiguousarray(xp, dtype=np.float64).reshape(nin), ctx)
-    d_fp = DeviceArray.from_host(fp, ctx)
     out = DeviceArray((nrows, nwno), ctx)
     sc = ctypes.byref(ctypes.c_double(float(scale))) if scale is not None else None
     _lib.check(_lib.load().picaso_regrid_rows_dev(ctx, ctypes.c_int(nrows), ctypes.c_int(nin), ctypes.c_long(nwno),
@@ -210,11 +214,15 @@ def regrid_facets(xp, fp, d_x, ctx):
     """Per-facet tables ``fp`` ``(nlayer, nfacets, nin)`` (host) on the grid ``xp`` -> the ``(nlayer, nwno, nfacets)``
     DeviceArray (facet index fastest) of ``numpy.interp`` along the last axis on the device grid ``d_x``
     (``picaso_regrid_facets_dev``)."""
-    fp = np.ascontiguousarray(fp, dtype=np.float64)
-    nlayer, nfac, nin = fp.shape
+    if isinstance(fp, DeviceArray):
+        d_fp, d_xp = fp, xp
+        nlayer, nfac, nin = fp.shape
+    else:
+        fp = np.ascontiguousarray(fp, dtype=np.float64)
+        nlayer, nfac, nin = fp.shape
+        d_xp = DeviceArray.from_host(np.ascontiguousarray(xp, dtype=np.float64).reshape(nin), ctx)
+        d_fp = DeviceArray.from_host(fp, ctx)
     nwno = int(d_x.shape[0])
-    d_xp = DeviceArray.from_host(np.ascontiguousarray(xp, dtype=np.float64).reshape(nin), ctx)
-    d_fp = DeviceArray.from_host(fp, ctx)
     out = DeviceArray((nlayer, nwno, nfac), ctx)
     _lib.check(_lib.load().picaso_regrid_facets_dev(ctx, ctypes.c_int(nlayer), ctypes.c_int(nfac), ctypes.c_int(nin),
                                                     ctypes.c_long(nwno), ctypes.c_void_p(d_xp.addr),

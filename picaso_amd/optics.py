@@ -1039,12 +1039,16 @@ def compute_opacity_facets(atms, opacityclass, numg, numt, stream=2, delta_eddin
                                            for t in tabs])
                     rows = np.ascontiguousarray(rows if order is None else rows[:, :, order])
                 memo = (arrs, clouds_3d["wavenumber"], shared, np.ascontiguousarray(rows),
-                        np.ascontiguousarray(in_wno if order is None else in_wno[order]))
+                        np.ascontiguousarray(in_wno if order is None else in_wno[order]), {})
                 try:
                     clouds_3d["_rows"] = memo
                 except TypeError:
                     pass
-            _, _, shared, rows, xp = memo
+            _, _, shared, rows, xp, resident_tabs = memo
+            key = (os.getpid(), getattr(ctx, "value", ctx))
+            if key not in resident_tabs:         # the compact tables stay in HBM with the dictionary (27 MB at 64 facets)
+                resident_tabs[key] = (DeviceArray.from_host(xp, ctx), DeviceArray.from_host(rows, ctx))
+            xp, rows = resident_tabs[key]
             if shared:
                 d_all = regrid_rows(xp, rows, d_x, ctx)                                  # (3 nlayer, nwno)
                 d_c = [broadcast_facets(d_all.row_range(j * nlayer, (j + 1) * nlayer), nfac) for j in range(3)]
