@@ -1275,12 +1275,17 @@ def picaso(bundle, opacityclass, dimension="1d", calculation="reflected", full_o
             atm_f = _setup_atmosphere(inp, opa, wno, prof_f, None)
             atm = _setup_atmosphere(inp, opa, wno, {k: (v if v.ndim == 1 else v[:, 0, 0]) for k, v in prof3.items()},
                                     None)                     # facet (0, 0): sizes, surface, full_output
-            if clear3 and not full_output and not os.environ.get("PICASO_AMD_FACET_FASTEST"):
-                # no cloud: the two (three) planes in facet-major layout straight from ONE fused gas + mixing launch over
-                # all facets; the solvers take every facet as a spectrum of its own (resident.*_3d_fm_batch: same bits)
+            tabs3 = None
+            if (not clear3 and lean3 and cld3 is not None and inp["test_mode"] is None and not full_output
+                    and not os.environ.get("PICASO_AMD_FACET_FASTEST") and not os.environ.get("PICASO_AMD_HOST_REGRID")):
+                tabs3 = optics._facet_major_cloud_tables(cld3, nlv - 1, nfac, ctx)   # tables on their own grid, else None
+            if (clear3 or tabs3 is not None) and not full_output and not os.environ.get("PICASO_AMD_FACET_FASTEST"):
+                # the planes in facet-major layout straight from ONE fused gas + mixing launch over all facets (no cloud:
+                # two or three of them; cloud tables on their own grid: interpolated inside that launch); the solvers take
+                # every facet as a spectrum of its own (resident.*_3d_fm_batch: same bits)
                 planes3d = optics.compute_opacity_facet_major(
                     atm_f, opa, ng, nt, stream=common["stream"], delta_eddington=common["delta_eddington"],
-                    raman=common["raman"], exclude_mol=inp["atmosphere"]["exclude_mol"], want=want3)
+                    raman=common["raman"], exclude_mol=inp["atmosphere"]["exclude_mol"], want=want3, cloud_tables=tabs3)
             else:
                 planes3d = optics.compute_opacity_facets(atm_f, opa, ng, nt, **co3)
             tlev3 = atm_f.level["temperature"].reshape(nlv, ng, nt)
@@ -1499,7 +1504,8 @@ def picaso(bundle, opacityclass, dimension="1d", calculation="reflected", full_o
                                            ubar1=ubar1, rs=rs, flux=flux, disk=disk, keep=planes3d))
             elif dimension == "3d" and planes3d.get("_fm"):
                 resident.thermal_3d_fm_batch(tctx, nlevel, d_wno, nwno, ng, nt, np.asarray(tlev3, dtype=float)[None],
-                                             [planes3d[th3[0]]], [planes3d[th3[1]]], None,
+                                             [planes3d[th3[0]]], [planes3d[th3[1]]],
+                                             [planes3d[th3[2]]] if th3[2] else None,
                                              np.asarray(plev3, dtype=float)[None],
                                              np.asarray(ubar1, dtype=float).reshape(1, ng, nt), [rs], atm.hard_surface,
                                              [flux], gweight, tweight, [disk])

@@ -1083,14 +1083,44 @@ def compute_opacity_facets(atms, opacityclass, numg, numt, stream=2, delta_eddin
     return {k: v for k, v in out.items() if v is not None}
 
 
+def _facet_major_cloud_tables(clouds_3d, nlayer, nfac, ctx):
+    """Cloud tables on their own increasing wavenumber grid as resident ``(3, nfacets * nlayer, nin)`` rows in
+    facet-major order (opd, w0, g0) with their grid, kept on the cloud dictionary while its arrays are the same
+    objects.  None when the tables are not of that kind."""
+    in_wno = clouds_3d.get("wavenumber") if isinstance(clouds_3d, dict) else None
+    if in_wno is None or np.size(in_wno) < 2:
+        return None
+    in_wno = np.asarray(in_wno, dtype=np.float64)
+    nin = in_wno.size
+    arrs = [clouds_3d[k] for k in ("opd", "w0", "g0")]
+    if any(np.size(a) not in (nlayer * nin, nlayer * nin * nfac) for a in arrs):
+        return None
+    memo = clouds_3d.get("_tall")
+    if memo is None or any(x is not y for x, y in zip(memo[0], arrs)) or memo[1] is not clouds_3d["wavenumber"]:
+        order = np.argsort(in_wno, kind="stable") if np.any(np.diff(in_wno) < 0) else slice(None)
+        tall = np.stack([np.moveaxis(np.broadcast_to(np.asarray(a, dtype=float).reshape(nlayer, nin, -1), (nlayer, nin, nfac)),
+                                     (0, 1, 2), (1, 2, 0))[:, :, order].reshape(nfac * nlayer, nin) for a in arrs])
+        memo = (arrs, clouds_3d["wavenumber"], np.ascontiguousarray(tall), np.ascontiguousarray(in_wno[order]), {})
+        try:
+            clouds_3d["_tall"] = memo
+        except TypeError:
+            pass
+    key = (os.getpid(), getattr(ctx, "value", ctx))
+    if key not in memo[4]:
+        memo[4][key] = (DeviceArray.from_host(memo[3], ctx), DeviceArray.from_host(memo[2], ctx))
+    return memo[4][key] + (memo[2], nin)
+
+
 def compute_opacity_facet_major(atm_f, opacityclass, numg, numt, stream=2, delta_eddington=True, raman=2, exclude_mol=1,
-                                want=("dtau", "w0")):
+                                want=("dtau", "w0"), cloud_tables=None):
     """The planes of a 3-D spectrum WITHOUT cloud in facet-major layout ``(nfacets, nlayer, nwno)``, from one fused
     gas + mixing launch over the tall atmosphere of all facets (``picaso_gas_compute_opacity_dev`` with
     ``nfacets * nlayer`` layers): no TAUGAS / TAURAY stack in HBM and no transposing mixing launch
     (``compute_opacity_facets``: 0.76 + 0.79 ms at 64 facets x 90 layers x 12 500 wavelengths; this: 0.9).  Only the
     planes a cloud-free column cannot re-derive exist (``want`` out of dtau, w0, w0_no_raman); the solvers take them
-    through ``resident.reflected_3d_fm_batch / thermal_3d_fm_batch``.  Same arithmetic per element: same bits."""
+    through ``resident.reflected_3d_fm_batch / thermal_3d_fm_batch``.  Same arithmetic per element: same bits.
+    ``cloud_tables`` (``_facet_major_cloud_tables``): cloud tables on their own wavenumber grid, interpolated inside the
+    launch like the 1-D path's (numpy.interp's bits) -- no TAUGAS / TAURAY stack, no regridded or tiled cloud planes."""
     opa = opacityclass
     ctx = opa.ctx
     nfac = numg * numt
@@ -1134,10 +1164,20 @@ def compute_opacity_facet_major(atm_f, opacityclass, numg, numt, stream=2, delta
         sl = slice(f0 * nlayer, f1 * nlayer)
         nl_c = (f1 - f0) * nlayer
         off = f0 * nlayer * nwno * 8
+        cld_tab, keep = (_ci(0), None, None, None), None
+        if cloud_tables is not None:
+            d_xp, d_tall, h_tall, nin = cloud_tables
+            if f0 == 0 and f1 == nfac:           # one launch: the resident (3 ntot, nin) rows as they are
+                d_fp = d_tall
+            else:                                # this chunk's opd / w0 / g0 rows, contiguous
+                d_fp = keep = DeviceArray.from_host(np.ascontiguousarray(h_tall[:, sl].reshape(3 * nl_c, nin)), ctx)
+            cld_tab = (_ci(nin), ptr(d_xp.addr), ptr(d_fp.addr), ptr(_wno_device(opa, opa.wno).addr))
         mix = (None, None, None,
                ptr(d_rf.addr + (off if rf_rows else 0)) if d_rf is not None else None, _ci(nl_c if (d_rf is not None and raman == 0) else 0),
                _cd(0.99999), _ci(0), _ci(1 if delta_eddington else 0), _ci(stream),
-               *[ptr(out[k].addr + off) if k in out else None for k in OUT_NAMES], _ci(0), _ci(0), None, None, None)
+               *[ptr(out[k].addr + off) if k in out else None for k in OUT_NAMES], _ci(0), *cld_tab)
+        if keep is not None:
+            out.setdefault("_cloud_chunks", []).append(keep)
         cont_rows = np.repeat(pl["cia_rows"][None, sl], len(cont_tabs), axis=0) if cont_tabs else None
         _gas_call(opa, nl_c, mol_tabs, pl["rows"][:, sl] if mol_tabs else None, pl["wts"][:, sl] if mol_tabs else None,
                   mol_fac[:, sl] if mol_tabs else None, cont_tabs, cont_rows, cont_fac[:, sl] if cont_tabs else None,
@@ -1145,6 +1185,8 @@ def compute_opacity_facet_major(atm_f, opacityclass, numg, numt, stream=2, delta
     out["_fm"] = True
     if d_rf is not None:
         out["_raman"] = d_rf              # the launch is asynchronous: its inputs live as long as its outputs
+    if cloud_tables is not None:
+        out["_cloud_tables"] = cloud_tables[:2]
     return out
 
 

@@ -241,6 +241,24 @@ def test_gpu_3d_cloud_tables_on_their_own_grid_regrid_on_the_device(monkeypatch,
     ref = case(on_grid).spectrum(opa, calculation=calc, dimension="3d")
     for key in ("albedo", "thermal"):
         assert np.isfinite(dev[key]).all() and np.array_equal(dev[key], ref[key]), key
+    # ... which took the facet-major planes of the fused gas + mixing launch (tables interpolated inside it); the
+    # facet-fastest planes of round 3's mixing launch (tables regridded and tiled first): the same bits
+    from picaso_amd import optics as px
+    calls = []
+    real = px.compute_opacity_facet_major
+    monkeypatch.setattr(px, "compute_opacity_facet_major", lambda *a, **k: (calls.append(k.get("cloud_tables") is not None),
+                                                                            real(*a, **k))[1])
+    again = case(dict(cld, wavenumber=wn)).spectrum(opa, calculation=calc, dimension="3d")
+    assert calls == [True]
+    monkeypatch.setenv("PICASO_AMD_FACET_FASTEST", "1")
+    ff = case(dict(cld, wavenumber=wn)).spectrum(opa, calculation=calc, dimension="3d")
+    assert calls == [True]
+    monkeypatch.delenv("PICASO_AMD_FACET_FASTEST")
+    for key in ("albedo", "thermal"):
+        assert np.array_equal(again[key], dev[key]) and np.array_equal(ff[key], dev[key]), key
+    for one in ("reflected", "thermal"):
+        a = case(dict(cld, wavenumber=wn)).spectrum(opa, calculation=one, dimension="3d")
+        assert np.array_equal(a["albedo" if one == "reflected" else "thermal"], dev["albedo" if one == "reflected" else "thermal"])
     monkeypatch.setenv("PICASO_AMD_HOST_REGRID", "1")
     host = case(dict(cld, wavenumber=wn)).spectrum(opa, calculation=calc, dimension="3d")
     for key in ("albedo", "thermal"):
