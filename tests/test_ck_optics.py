@@ -514,16 +514,31 @@ def test_gpu_gasesfly_spectrum_runs_through_picaso(ck, og):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("clouds", [None, "shared", "per_facet"])
 @pytest.mark.parametrize("calc", ["reflected", "thermal"])
-def test_gpu_phase_curve_equals_single_phase_runs(og, calc):
+def test_gpu_phase_curve_equals_single_phase_runs(og, calc, clouds):
     """phase_curve(): every phase of phase_curve_geometry with its own facet profiles, against the
     same phases run one at a time through phase_angle() + atmosphere_3d() + spectrum(dimension='3d')
-    (thermal phase curves integrate over the phase-0 geometry, justdoit.py:1648-1653)."""
+    (thermal phase curves integrate over the phase-0 geometry, justdoit.py:1648-1653).  ``clouds``: a cloud map per
+    phase (``clouds_by_phase``) as tables on a 7-point wavenumber grid of their own, one for the disk or one per facet
+    -- interpolated inside the fused opacity launch of each phase, solved in the batched launch of the chunk."""
     from picaso_amd import justdoit as jdi
     opa = jdi.opannection(filename_db=DB, query_method="linear")
     ng, nt = 3, 2
     phases = [0.0, 0.9, 2.0]
     nlevel = len(og["in/tlevel"])
+    rng = np.random.default_rng(8)
+    wn = np.linspace(opa.wno[0] * 0.98, opa.wno[-1] * 1.01, 7)
+
+    def cloud_map(k):
+        if clouds is None:
+            return None
+        shape = (nlevel - 1, 7) if clouds == "shared" else (nlevel - 1, 7, ng, nt)
+        c = {"opd": (0.1 + 0.05 * k) * rng.random(shape), "w0": 0.6 + 0.3 * rng.random(shape), "g0": 0.7 * rng.random(shape),
+             "wavenumber": wn}
+        c["opd"][:4] = 0.0
+        return c
+    maps = [cloud_map(k) for k in range(len(phases))]
 
     def profile(k):
         dT = 40.0 * k * np.cos(np.arange(ng))[None, :, None] * np.ones((1, 1, nt))
@@ -537,7 +552,7 @@ def test_gpu_phase_curve_equals_single_phase_runs(og, calc):
     case.approx(raman="none")
     case.phase_curve_geometry(calc, phases, num_gangle=ng, num_tangle=nt)
     case.atmosphere_4d([profile(k) for k in range(len(phases))])
-    curve = case.phase_curve(opa)
+    curve = case.phase_curve(opa, clouds_by_phase=maps if clouds else None)
     assert list(curve.keys()) == phases and case.inputs["phase_angle"] == phases
     key = "albedo" if calc == "reflected" else "thermal"
     for k, ph in enumerate(phases):
@@ -546,6 +561,8 @@ def test_gpu_phase_curve_equals_single_phase_runs(og, calc):
         one.approx(raman="none")
         one.phase_angle(ph if calc == "reflected" else 0.0, num_gangle=ng, num_tangle=nt)
         one.atmosphere_3d(profile(k))
+        if clouds:
+            one.clouds_3d({a: (b.copy() if a != "wavenumber" else b) for a, b in maps[k].items() if not a.startswith("_")})
         want = one.spectrum(opa, calculation=calc, dimension="3d")
         assert np.array_equal(curve[ph][key], want[key]), (calc, ph)
     assert not np.array_equal(curve[phases[0]][key], curve[phases[2]][key])
