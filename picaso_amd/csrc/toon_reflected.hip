@@ -808,30 +808,43 @@ static int launch1d(picaso_ctx *ctx, const ReflectedArgs &a_in)
 int launch_reflected_toa(picaso_ctx *ctx, const ReflectedArgs &a, bool is3d)
 {
     if (a.ncol <= 0 || a.nlayer < 1) return fail(ctx, "reflected: empty problem");
+    // 3-D: the reference's default options (TTHG_ray, N = 2, frac_c = 2; 3-D is quadrature-only anyway) fixed at compile
+    // time like the 1-D launches, and with them the two plane patterns of the product known at compile time as well --
+    // only dtau and w0 (a map without cloud), or everything but tau / tau_og / gcos2 (cloud tables): same bits as the
+    // generic instantiations (PICASO_AMD_REFL3D_GENERIC=1), which every other option set and plane pattern keeps
+    const bool all3 = a.tau && a.tau_og && a.gcos2 && a.ftau_cld && a.dtau_og;
+    const bool fast3 = is3d && a.single_phase == 3 && a.multi_phase == 0 && a.frac_c == 2.0 &&
+                       (double)a.pitch * (a.nlayer + 1) * 8.0 < 4294967296.0 && !getenv("PICASO_AMD_REFL3D_GENERIC");
+    const bool only2_3 = !a.tau && !a.tau_og && !a.gcos2 && !a.ftau_cld && !a.dtau_og;
+    const bool levels3_3 = !a.tau && !a.tau_og && !a.gcos2 && a.ftau_cld && a.dtau_og;
     if (is3d && a.batch) {                         // a.tau etc.: the presence pattern of EVERY spectrum's planes
         const int block = PZ_REFL_BLOCK;
         ReflectedArgs b = a;
         b.bps = (unsigned)((a.ncol + block - 1) / block);
         b.batch_interleave = 0;
         const dim3 grid(b.bps * (unsigned)a.nspec);
-        const bool all = a.tau && a.tau_og && a.gcos2 && a.ftau_cld && a.dtau_og;
-        if (all)
-            hipLaunchKernelGGL((k_reflected_toa_batch<1, true, false>), grid, dim3(block), 0, ctx->stream, b);
-        else
-            hipLaunchKernelGGL((k_reflected_toa_batch<1, true, false, false, false, true>), grid, dim3(block), 0,
-                               ctx->stream, b);
+#define PZ_GO3(KERNEL) hipLaunchKernelGGL(KERNEL, grid, dim3(block), 0, ctx->stream, b)
+        if (fast3 && all3) PZ_GO3((k_reflected_toa_batch<1, true, false, true, false, 0>));
+        else if (fast3 && only2_3) PZ_GO3((k_reflected_toa_batch<1, true, false, true, false, 2>));
+        else if (fast3 && levels3_3) PZ_GO3((k_reflected_toa_batch<1, true, false, true, false, 3>));
+        else if (fast3) PZ_GO3((k_reflected_toa_batch<1, true, false, true, false, 1>));
+        else if (all3) PZ_GO3((k_reflected_toa_batch<1, true, false>));
+        else PZ_GO3((k_reflected_toa_batch<1, true, false, false, false, 1>));
+#undef PZ_GO3
         PZ_HIP(ctx, hipGetLastError());
         return 0;
     }
     if (is3d) {
         const int block = PZ_REFL_BLOCK;
-        const long grid = (a.ncol + block - 1) / block;
-        const bool all = a.tau && a.tau_og && a.gcos2 && a.ftau_cld && a.dtau_og;
-        if (all)
-            hipLaunchKernelGGL((k_reflected_toa<1, true, false>), dim3((unsigned)grid), dim3(block), 0, ctx->stream, a);
-        else
-            hipLaunchKernelGGL((k_reflected_toa<1, true, false, false, false, true>), dim3((unsigned)grid), dim3(block),
-                               0, ctx->stream, a);
+        const dim3 grid((unsigned)((a.ncol + block - 1) / block));
+#define PZ_GO3(KERNEL) hipLaunchKernelGGL(KERNEL, grid, dim3(block), 0, ctx->stream, a)
+        if (fast3 && all3) PZ_GO3((k_reflected_toa<1, true, false, true, false, 0>));
+        else if (fast3 && only2_3) PZ_GO3((k_reflected_toa<1, true, false, true, false, 2>));
+        else if (fast3 && levels3_3) PZ_GO3((k_reflected_toa<1, true, false, true, false, 3>));
+        else if (fast3) PZ_GO3((k_reflected_toa<1, true, false, true, false, 1>));
+        else if (all3) PZ_GO3((k_reflected_toa<1, true, false>));
+        else PZ_GO3((k_reflected_toa<1, true, false, false, false, 1>));
+#undef PZ_GO3
         PZ_HIP(ctx, hipGetLastError());
         return 0;
     }
