@@ -281,7 +281,7 @@ def workload_3d(ctx, args, lo, hi, seed, nwno_total, scene=None):
 
     return dict(solve=solve, oracle=oracle, nloc=n, oracle_sample=256,
                 abytes=8 * n * (ng * nt * (9 * nlayer + 2 * nlevel + 1) + 2 + 1),
-                kernel="k_reflected_toa<1, true, false, false, false, false>",
+                kernel="k_reflected_toa<1, true, false, false, false, 0>",
                 workload="BASELINE configs[4]: 3-D reflected light, 8x8 facets at phase pi/3 (get_reflected_3d + "
                          "compress_disco), facet planes generated on the device",
                 metric="spectra/sec (%d wave x %d layer x 64 facet 3-D reflected)" % (nwno_total, nlayer))
