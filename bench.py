@@ -582,7 +582,62 @@ def product_companion(ctx, nwno=100000, nlevel=91, ncalls=30, nbatch=32):
     shc.clouds(df={"opd": box, "w0": np.where(box > 0, 0.95, 0.0), "g0": np.where(box > 0, 0.6, 0.0)},
                wavenumber=np.linspace(wno[0], wno[-1], 196))
     shc_ms, shc_out = timed(shc)
+    # the 3-D form of the same call (BASELINE configs[4]'s per-GPU shape: 8 x 8 facets x 12 500 wavelengths x 90 layers,
+    # per-facet temperatures): without cloud, with a per-facet cloud map on a 196-point wavenumber grid of its own
+    # (clouds_3d as virga hands it over), and an 8-phase reflected-light curve of the cloudy map
+    n3 = 12500
+    w3 = np.linspace(3000.0, 30000.0, n3)
+    mol3 = {m: {i: 10.0 ** (-24.0 + 2.0 * np.sin(w3 / 2500.0 + k) + 0.4 * np.log10(p) + 0.8 * np.log10(t / 300.0))
+                for (i, p, t) in pt} for k, m in enumerate(mols)}
+    con3 = {pr: {t: 10.0 ** (-7.0 + np.cos(w3 / 4000.0 + k) + 0.3 * np.log10(t / 300.0)) for t in cia_t}
+            for k, pr in enumerate(("H2H2", "H2He"))}
+    opa3 = px.RetrieveOpacities(w3, pt, mol3, con3, cia_t, rayleigh_opa={m: 1e-27 * (w3 / 1e4) ** 4 for m in ("H2", "He")},
+                                query_method="linear", ctx=ctx)
+    pert = 1.0 + 0.1 * np.cos(np.arange(64).reshape(8, 8))
+    prof3 = dict(prof, temperature=prof["temperature"][:, None, None] * pert[None])
+    box3 = np.zeros((nl, 196, 8, 8))
+    box3[50:60] = 0.3 * (1.0 + 0.3 * np.cos(np.arange(64).reshape(1, 1, 8, 8)))
+    cmap = {"opd": box3, "w0": np.where(box3 > 0, 0.95, 0.0), "g0": np.where(box3 > 0, 0.6, 0.0),
+            "wavenumber": np.linspace(w3[0], w3[-1], 196)}
+
+    def case3(cloudy):
+        c = jdi.inputs()
+        c.phase_angle(np.pi / 3, num_gangle=8, num_tangle=8)
+        c.gravity(gravity=2500.0)
+        c.atmosphere_3d(prof3)
+        c.approx(raman="none")
+        if cloudy:
+            c.clouds_3d(df=cmap)
+        return c
+
+    def timed3(c, n=8):
+        for _ in range(3):
+            c.spectrum(opa3, calculation=calc, dimension="3d")
+        tt = []
+        for _ in range(n):
+            t0 = time.perf_counter()
+            out = c.spectrum(opa3, calculation=calc, dimension="3d")
+            tt.append(time.perf_counter() - t0)
+        return 1e3 * float(np.median(tt)), out
+    s3_ms, s3_out = timed3(case3(False))
+    s3c_ms, s3c_out = timed3(case3(True))
+    phases = list(2 * np.pi * (np.arange(8) + 0.5) / 8)          # (not pi itself: the disk geometry divides by 1 + cos)
+    pc = jdi.inputs()
+    pc.phase_curve_geometry("reflected", phases, num_gangle=8, num_tangle=8)
+    pc.gravity(gravity=2500.0)
+    pc.atmosphere_4d([prof3 for _ in phases])
+    pc.approx(raman="none")
+    pc.phase_curve(opa3, clouds_by_phase=[cmap] * 8)
+    t0 = time.perf_counter()
+    curve = pc.phase_curve(opa3, clouds_by_phase=[cmap] * 8)
+    pc_ms = 1e3 * (time.perf_counter() - t0)
+    fin3 = all(np.all(np.isfinite(o[k])) for o in (s3_out, s3c_out) for k in ("albedo", "thermal")) and \
+        all(np.all(np.isfinite(v["albedo"])) for v in curve.values())
     return {"product": {
+        "spectrum_3d": {"workload": "spectrum(dimension='3d', 'reflected+thermal'): 8 x 8 facets x %d wavelengths x %d layers, "
+                                    "per-facet temperatures" % (n3, nl),
+                        "cloud_free_ms": s3_ms, "per_facet_cloud_map_on_196_point_grid_ms": s3c_ms,
+                        "phase_curve_reflected_8_phases_cloudy_ms": pc_ms, "finite": bool(fin3)},
         "workload": "inputs.spectrum(opa, 'reflected+thermal'), %d wavelengths x %d layers, 5 Gauss angles, cloud-free, "
                     "resident opacity tables (5 molecules, 2 CIA pairs, 2 Rayleigh species): set-up, opacity mixing, "
                     "both Toon solves, disk sums, integrals, results on the host" % (nwno, nlevel - 1),
