@@ -14,11 +14,13 @@ Here the ``ngauss`` loop is one launch over ``nwno*ngauss`` columns per solver
 """
 from collections import namedtuple
 
+import os
+
 import numpy as np
 
 from . import _lib, resident
 from ._lib import f64
-from .device import DeviceArray
+from .device import DeviceArray, PinnedArray
 
 # the reference's containers (climate.py:1962-1966)
 Atmosphere_Tuple = namedtuple("Atmosphere_Tuple", ["dtdp", "mmw_layer", "nlevel", "t_level", "p_level", "condensables",
@@ -89,6 +91,23 @@ def _planes(wed, noed, ctx, thermal_only=False):
     return pl
 
 
+_VEC_CACHE = {}
+
+
+def _resident_small(values, ctx):
+    """A per-wavelength host vector as a resident one, kept by content: the T(P) iteration calls get_fluxes thousands of
+    times with the same wavenumbers, bin widths, stellar flux and surface reflectivity (four 5 KB uploads per call,
+    0.06 ms each)."""
+    a = np.ascontiguousarray(values, dtype=np.float64)
+    key = (os.getpid(), getattr(ctx, "value", ctx), a.tobytes())
+    hit = _VEC_CACHE.get(key)
+    if hit is None:
+        if len(_VEC_CACHE) >= 64:
+            _VEC_CACHE.clear()
+        hit = _VEC_CACHE[key] = DeviceArray.from_host(a, ctx)
+    return hit
+
+
 def get_fluxes(Atmosphere, OpacityWEd, OpacityNoEd, ScatteringPhase, Disco, Opagrid, F0PI, reflected, thermal,
                do_holes=False, fhole=0.0, hole_OpacityWEd=None, hole_OpacityNoEd=None, ctx=None,
                copy_outputs=False):
@@ -117,20 +136,29 @@ def get_fluxes(Atmosphere, OpacityWEd, OpacityNoEd, ScatteringPhase, Disco, Opag
     flux_plus_ir = np.zeros((nlevel, nwno))
     flux_minus_ir = np.zeros((nlevel, nwno))
 
-    rs = DeviceArray.from_host(np.zeros(nwno) + f64(sp.surf_reflect), ctx)
+    rs = _resident_small(np.zeros(nwno) + f64(sp.surf_reflect), ctx)
+    if thermal:                                           # uploaded (first use) before the second stream is ordered behind this one
+        d_wno, d_dw = _resident_small(wno, ctx), _resident_small(dwni, ctx)
     sets = [_planes(OpacityWEd, OpacityNoEd, ctx, thermal_only=not reflected)]
     if do_holes:
         sets.append(_planes(hole_OpacityWEd, hole_OpacityNoEd, ctx, thermal_only=not reflected))
 
-    def blend(results):                                   # (1-fhole)*cloudy + fhole*clear, climate.py:1838-1842
+    def blend(results, c):                                # (1-fhole)*cloudy + fhole*clear, climate.py:1838-1842
         if len(results) == 1:
             return results[0]
         for a, b in zip(*results):
-            resident.axpby(ctx, 1.0 - fhole, a, fhole, b, a)
+            resident.axpby(c, 1.0 - fhole, a, fhole, b, a)
         return results[0]
 
+    # both legs are small launches (661 bins x 8 Gauss points = 83 waves on a 1 024-SIMD chip, one 90-layer chain each):
+    # the thermal leg goes to the process's second stream, behind the uploads above, and runs next to the reflected one
+    tctx = ctx
+    if reflected and thermal and os.environ.get("PICASO_AMD_OVERLAP_LEGS", "1") != "0":
+        tctx = _lib.aux_context(_lib.device_of(ctx))
+        _lib.ctx_wait(tctx, ctx)
+
     if reflected:                                         # climate.py:1796-1874
-        d_f0 = DeviceArray.from_host(np.zeros(nwno) + f64(F0PI), ctx)
+        d_f0 = _resident_small(np.zeros(nwno) + f64(F0PI), ctx)
         half = np.full((1, 1), 0.5)                       # ubar0_clima = ubar1_clima = 0.5, one angle
         xdummy = DeviceArray((1, 1, nwno), ctx)
         res = []
@@ -143,26 +171,27 @@ def get_fluxes(Atmosphere, OpacityWEd, OpacityNoEd, ScatteringPhase, Disco, Opag
                                      float(sp.constant_forward), gauss_wts, xdummy, get_toa_intensity=0,
                                      lvl_fluxes=lv)
             res.append(lv)
-        refl_stack = blend(res)[0]._owner                 # read back after the thermal leg is enqueued
+        refl_stack = blend(res, ctx)[0]._owner            # read back after the thermal leg is enqueued
+        refl_pin = refl_stack.to_host_async(PinnedArray(refl_stack.shape, ctx))     # the copy: behind the leg's last kernel
 
     if thermal:                                           # climate.py:1879-1941
-        d_wno, d_dw = DeviceArray.from_host(wno, ctx), DeviceArray.from_host(dwni, ctx)
-        xdummy = DeviceArray((ng, nt, nwno), ctx)
+        xdummy = DeviceArray((ng, nt, nwno), tctx)
         res = []
         for pl in sets:
-            lv = [DeviceArray((ng, nt, nlevel, nwno), ctx) for _ in range(4)]
-            resident.thermal_1d_ck(ctx, nlevel, d_wno, nwno, ngauss, ng, nt, temperature, pl["dtau_og"],
+            lv = [DeviceArray((ng, nt, nlevel, nwno), tctx) for _ in range(4)]
+            resident.thermal_1d_ck(tctx, nlevel, d_wno, nwno, ngauss, ng, nt, temperature, pl["dtau_og"],
                                    pl["w0_no_raman"], pl["cosb_og"], pressure, Disco.ubar1, rs, 0, gauss_wts,
                                    xdummy, dwno=d_dw, calc_type=1, lvl_fluxes=lv)
             res.append(lv)
-        disk = DeviceArray((4, nlevel, nwno), ctx)
-        for k, x in enumerate(blend(res)):                # compress_thermal over the disk angles (:1925-1928)
-            resident.compress_thermal(ctx, nlevel * nwno, x, Disco.gweight, Disco.tweight, disk.row_block(k))
-        therm_disk = disk
+        disk = DeviceArray((4, nlevel, nwno), tctx)
+        for k, x in enumerate(blend(res, tctx)):          # compress_thermal over the disk angles (:1925-1928)
+            resident.compress_thermal(tctx, nlevel * nwno, x, Disco.gweight, Disco.tweight, disk.row_block(k))
+        therm_pin = disk.to_host_async(PinnedArray(disk.shape, tctx))
 
     # both legs are on the stream before the first copy back (each copy is a synchronisation)
     if reflected:
-        fm, fp, fmm, fpm = refl_stack.to_host()           # Gauss-weighted (1,1,nlevel,nwno) each
+        fm, fp, fmm, fpm = refl_pin.wait().copy()         # Gauss-weighted (1,1,nlevel,nwno) each
+        refl_pin.free()
         flux_net_v_layer += np.sum(fpm, axis=3) - np.sum(fmm, axis=3)
         flux_net_v += np.sum(fp, axis=3) - np.sum(fm, axis=3)
         # the single two-stream angle stands for every disk angle (climate.py:1803-1805, :1868-1869)
@@ -171,11 +200,12 @@ def get_fluxes(Atmosphere, OpacityWEd, OpacityNoEd, ScatteringPhase, Disco, Opag
         if copy_outputs:
             flux_plus_v, flux_minus_v = flux_plus_v.copy(), flux_minus_v.copy()
     if thermal:
-        fm, fp, fmm, fpm = therm_disk.to_host()
+        fm, fp, fmm, fpm = therm_pin.wait()
         flux_net_ir_layer = ((fpm - fmm) * dwni).sum(axis=1)                  # (:1931-1936)
         flux_net_ir = ((fp - fm) * dwni).sum(axis=1)
         flux_plus_ir = fp * dwni
         flux_minus_ir = fm * dwni
+        therm_pin.free()
 
     if flux_plus_v is None:
         flux_plus_v, flux_minus_v = np.zeros((ng, nt, nlevel, nwno)), np.zeros((ng, nt, nlevel, nwno))
