@@ -633,7 +633,38 @@ def product_companion(ctx, nwno=100000, nlevel=91, ncalls=30, nbatch=32):
     pc_ms = 1e3 * (time.perf_counter() - t0)
     fin3 = all(np.all(np.isfinite(o[k])) for o in (s3_out, s3c_out) for k in ("albedo", "thermal")) and \
         all(np.all(np.isfinite(v["albedo"])) for v in curve.values())
+    # the climate solver's call between Jacobians: get_fluxes (reference climate.py:1687) at the climate tables' shape --
+    # 91 levels, 661 bins x 8 Gauss points, one two-stream angle for the visible and 5 disk angles for the infrared,
+    # level fluxes of both legs back on the host -- with the thirteen opacity planes resident (what calculate_atm hands over)
+    from picaso_amd import climate as pcl
+    from picaso_amd.device import DeviceArray
+    nlev_c, nw_c, ng_c = 91, 661, 8
+    scs = [syn.make_scene(nlev_c - 1, nw_c, seed=70 + ig, gas_scale=10.0 ** (0.5 * ig - 2)) for ig in range(ng_c)]
+    stc = {k: np.ascontiguousarray(np.stack([sc_[k] for sc_ in scs], axis=2)) for k in resident.REFLECTED_PLANES + ("w0_no_raman",)}
+    xg, wg = np.polynomial.legendre.leggauss(ng_c)
+    gang_c, gw_c, tang_c, tw_c = disco.get_angles_1d(5)
+    u0_c, u1_c, _, _, _ = disco.compute_disco(5, 1, gang_c, tang_c, 0.0)
+    wno_c = scs[0]["wno"]
+    atm_t = pcl.Atmosphere_Tuple(None, None, nlev_c, scs[0]["tlevel"], scs[0]["plevel"], None, None, None, None)
+    sp_t = pcl.ScatteringPhase_Tuple(np.zeros(nw_c), 3, 0, 1.0, -1.0, 2.0, -0.5, 1.0)
+    dis_t = pcl.Disco_Tuple(5, 1, gw_c, tw_c, u0_c, u1_c, 1.0)
+    og_t = pcl.Opagrid_Tuple(nw_c, np.abs(np.gradient(wno_c)), wno_c, ng_c, 0.5 * wg)
+    up = lambda a: DeviceArray.from_host(a, ctx)
+    wed = pcl.OpacityWEd_Tuple(*[up(stc[k]) for k in ("dtau", "tau", "w0", "cosb", "ftau_cld", "ftau_ray", "gcos2", "w0_no_raman")], None)
+    noed = pcl.OpacityNoEd_Tuple(*[up(stc[k]) for k in ("dtau_og", "tau_og", "w0_og", "cosb_og")])
+    f0c = np.ones(nw_c)
+    for _ in range(10):
+        fl = pcl.get_fluxes(atm_t, wed, noed, sp_t, dis_t, og_t, f0c, True, True, ctx=ctx)
+    tc_ = []
+    for _ in range(30):
+        t0 = time.perf_counter()
+        fl = pcl.get_fluxes(atm_t, wed, noed, sp_t, dis_t, og_t, f0c, True, True, ctx=ctx)
+        tc_.append(time.perf_counter() - t0)
+    clim_ms = 1e3 * float(np.median(tc_))
+    clim_ok = all(np.all(np.isfinite(a)) for a in fl)
     return {"product": {
+        "climate_get_fluxes": {"workload": "climate.get_fluxes(reflected, thermal): 91 levels, 661 bins x 8 Gauss points, level "
+                                           "fluxes of both legs, resident opacity planes", "ms": clim_ms, "finite": bool(clim_ok)},
         "spectrum_3d": {"workload": "spectrum(dimension='3d', 'reflected+thermal'): 8 x 8 facets x %d wavelengths x %d layers, "
                                     "per-facet temperatures" % (n3, nl),
                         "cloud_free_ms": s3_ms, "per_facet_cloud_map_on_196_point_grid_ms": s3c_ms,

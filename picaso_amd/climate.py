@@ -243,9 +243,9 @@ def get_fluxes_tbatch(temperatures, Atmosphere, OpacityWEd, OpacityNoEd, Scatter
     ng, nt = int(Disco.ng), int(Disco.nt)
     nwno, ngauss = int(Opagrid.nwno), int(Opagrid.ngauss)
     dwni, wno, gauss_wts = f64(Opagrid.delta_wno), f64(Opagrid.wno), f64(Opagrid.gauss_wts)
-    rs = DeviceArray.from_host(np.zeros(nwno) + f64(sp.surf_reflect), ctx)
+    rs = _resident_small(np.zeros(nwno) + f64(sp.surf_reflect), ctx)
     pl = _planes(OpacityWEd, OpacityNoEd, ctx, thermal_only=True)
-    d_wno, d_dw = DeviceArray.from_host(wno, ctx), DeviceArray.from_host(dwni, ctx)
+    d_wno, d_dw = _resident_small(wno, ctx), _resident_small(dwni, ctx)
     net_layer, net = np.empty((nitem, nlevel)), np.empty((nitem, nlevel))
     plus = minus = None
     if not nets_only:
