@@ -62,6 +62,22 @@ def test_driver_equals_call_by_call_path(monkeypatch, pollack_table, devices, ca
         _same(w, g)
 
 
+@pytest.mark.parametrize("cloud", [False, True])
+def test_driver_blocks_enqueued_from_threads(monkeypatch, cloud):
+    """Wavelength blocks on different devices are enqueued from a thread each (csrc/driver.hip); on this pool's single
+    GPU that form is forced here (PICASO_AMD_PARALLEL_BLOCKS=1) over five blocks, twenty times: the serial loop's bits."""
+    from picaso_amd import justdoit as jdi
+    og = np.load(os.path.join(GOLDEN, "optics.npz"))
+    opa = jdi.opannection(filename_db=DB, query_method="linear")
+    devs = [0, 0, 0, 0, 0]
+    monkeypatch.setenv("PICASO_AMD_PARALLEL_BLOCKS", "0")
+    want = _case(og, jdi, cloud, True, "none", True).spectrum(opa, calculation="reflected+thermal", devices=devs)
+    monkeypatch.setenv("PICASO_AMD_PARALLEL_BLOCKS", "1")
+    for _ in range(20):
+        _same(want, _case(og, jdi, cloud, True, "none", True).spectrum(opa, calculation="reflected+thermal", devices=devs))
+    _same(want, _case(og, jdi, cloud, True, "none", True).spectrum(opa, calculation="reflected+thermal"))
+
+
 def test_driver_nearest_query_and_falls_through_where_it_does_not_apply(monkeypatch):
     from picaso_amd import justdoit as jdi
     og = np.load(os.path.join(GOLDEN, "optics.npz"))
