@@ -1028,7 +1028,8 @@ def compute_opacity_facets(atms, opacityclass, numg, numt, stream=2, delta_eddin
             # while its arrays are the same objects (a spectrum() called again, the phases of a curve that share a map)
             arrs = [clouds_3d[k] for k in ("opd", "w0", "g0")]
             memo = clouds_3d.get("_rows")
-            if memo is None or any(x is not y for x, y in zip(memo[0], arrs)) or memo[1] is not clouds_3d["wavenumber"]:
+            stamp = _table_fingerprint(arrs, clouds_3d["wavenumber"])
+            if memo is None or memo[1] != stamp:
                 tabs = [np.asarray(x, dtype=float) for x in arrs]
                 shared = all(t.size == nlayer * nin for t in tabs)
                 if shared:
@@ -1038,7 +1039,7 @@ def compute_opacity_facets(atms, opacityclass, numg, numt, stream=2, delta_eddin
                     rows = np.concatenate([np.moveaxis(np.broadcast_to(t.reshape(nlayer, nin, -1), (nlayer, nin, nfac)), 1, 2)
                                            for t in tabs])
                     rows = np.ascontiguousarray(rows if order is None else rows[:, :, order])
-                memo = (arrs, clouds_3d["wavenumber"], shared, np.ascontiguousarray(rows),
+                memo = (arrs, stamp, shared, np.ascontiguousarray(rows),
                         np.ascontiguousarray(in_wno if order is None else in_wno[order]), {})
                 try:
                     clouds_3d["_rows"] = memo
@@ -1083,6 +1084,17 @@ def compute_opacity_facets(atms, opacityclass, numg, numt, stream=2, delta_eddin
     return {k: v for k, v in out.items() if v is not None}
 
 
+def _table_fingerprint(arrs, wavenumber):
+    """Identity of the table objects plus a strided sample of their contents: a memo kept with a cloud dictionary is
+    dropped when an array is replaced OR edited in place (scaled, a layer rewritten; a single-element edit between two
+    sample points is not seen -- declare the clouds again, ``clouds_3d`` starts the dictionary afresh)."""
+    out = []
+    for a in list(arrs) + [wavenumber]:
+        v = np.asarray(a).ravel()
+        out.append((id(a), v.size, float(v[::max(1, v.size // 4096)].sum())))
+    return tuple(out)
+
+
 def _facet_major_cloud_tables(clouds_3d, nlayer, nfac, ctx):
     """Cloud tables on their own increasing wavenumber grid as resident ``(3, nfacets * nlayer, nin)`` rows in
     facet-major order (opd, w0, g0) with their grid, kept on the cloud dictionary while its arrays are the same
@@ -1096,11 +1108,12 @@ def _facet_major_cloud_tables(clouds_3d, nlayer, nfac, ctx):
     if any(np.size(a) not in (nlayer * nin, nlayer * nin * nfac) for a in arrs):
         return None
     memo = clouds_3d.get("_tall")
-    if memo is None or any(x is not y for x, y in zip(memo[0], arrs)) or memo[1] is not clouds_3d["wavenumber"]:
+    stamp = _table_fingerprint(arrs, clouds_3d["wavenumber"])
+    if memo is None or memo[1] != stamp:
         order = np.argsort(in_wno, kind="stable") if np.any(np.diff(in_wno) < 0) else slice(None)
         tall = np.stack([np.moveaxis(np.broadcast_to(np.asarray(a, dtype=float).reshape(nlayer, nin, -1), (nlayer, nin, nfac)),
                                      (0, 1, 2), (1, 2, 0))[:, :, order].reshape(nfac * nlayer, nin) for a in arrs])
-        memo = (arrs, clouds_3d["wavenumber"], np.ascontiguousarray(tall), np.ascontiguousarray(in_wno[order]), {})
+        memo = (arrs, stamp, np.ascontiguousarray(tall), np.ascontiguousarray(in_wno[order]), {})
         try:
             clouds_3d["_tall"] = memo
         except TypeError:

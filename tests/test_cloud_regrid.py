@@ -263,3 +263,36 @@ def test_gpu_3d_cloud_tables_on_their_own_grid_regrid_on_the_device(monkeypatch,
     host = case(dict(cld, wavenumber=wn)).spectrum(opa, calculation=calc, dimension="3d")
     for key in ("albedo", "thermal"):
         assert np.max(np.abs(host[key] - dev[key]) / np.abs(dev[key])) < 1e-11, key
+
+
+@pytest.mark.gpu
+def test_gpu_3d_cloud_tables_edited_in_place_are_seen():
+    """The compact tables stay resident with the cloud dictionary between calls; scaling an array in place (same
+    object) must drop them: the second spectrum equals one from a fresh dictionary with the scaled values."""
+    og = np.load(os.path.join(GOLDEN, "optics.npz"))
+    opa = jdi.opannection(filename_db=DB, query_method="linear")
+    ng, nt = 2, 2
+    nlayer, nin = len(og["in/tlevel"]) - 1, 6
+    rng = np.random.default_rng(12)
+    wn = np.linspace(opa.wno[0], opa.wno[-1], nin)
+    cld = {"opd": 0.2 * rng.random((nlayer, nin, ng, nt)), "w0": 0.5 + 0.4 * rng.random((nlayer, nin, ng, nt)),
+           "g0": 0.6 * rng.random((nlayer, nin, ng, nt)), "wavenumber": wn}
+
+    def run(tables):
+        c = jdi.inputs()
+        c.phase_angle(0.5, num_gangle=ng, num_tangle=nt)
+        c.gravity(gravity=float(og["in/gravity"]))
+        prof = {"pressure": og["in/plevel_bar"], "temperature": og["in/tlevel"][:, None, None] * np.ones((1, ng, nt))}
+        for k in ("H2", "He", "H2O", "CH4"):
+            prof[k] = og["in/mix/" + k]
+        c.atmosphere_3d(prof)
+        c.approx(raman="none")
+        c.inputs["clouds"]["profile_3d"] = tables            # the dictionary itself, as phase_curve(clouds_by_phase=) hands it on
+        c.inputs["clouds"]["dims"] = "3d"
+        return c.spectrum(opa, calculation="reflected", dimension="3d")["albedo"]
+    first = run(cld)
+    assert "_tall" in cld
+    cld["opd"] *= 3.0
+    second = run(cld)
+    fresh = run({k: (v.copy() if k != "wavenumber" else v) for k, v in cld.items() if not k.startswith("_")})
+    assert np.array_equal(second, fresh) and not np.array_equal(second, first)
