@@ -93,6 +93,16 @@ class DeviceArray:
         v._owner = self            # keeps the parent alive; views are never freed
         return v
 
+    def __deepcopy__(self, memo):
+        """A DeviceArray inside a container that is deep-copied (``copy.deepcopy(case)``): the copy is a non-owning view
+        of the same allocation that keeps the original alive -- two owners of one device pointer would free it twice."""
+        v = DeviceArray.__new__(DeviceArray)
+        v.ctx, v.shape, v.size, v.nbytes, v.addr = self.ctx, self.shape, self.size, self.nbytes, self.addr
+        v._owner = self
+        return v
+
+    __copy__ = lambda self: self.__deepcopy__(None)
+
     def row_range(self, lo, hi):
         """Non-owning view of ``self[lo:hi]`` (leading axis)."""
         v = DeviceArray.__new__(DeviceArray)

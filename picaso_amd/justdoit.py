@@ -968,9 +968,6 @@ class inputs:
             ds = df
         if ds is None or (isinstance(ds, dict) and not hasattr(ds, "coords") and "lon" not in ds and "lat" not in ds) \
                 or not (isinstance(ds, dict) or hasattr(ds, "coords")):
-            if isinstance(ds, dict):                  # resident copies of an earlier declaration of this dictionary: afresh
-                ds.pop("_rows", None)
-                ds.pop("_tall", None)
             self.inputs["clouds"]["profile_3d"] = ds
             return
         coords, variables = _dataset_like(ds, extra_coords=("wno",))

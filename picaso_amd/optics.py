@@ -1027,7 +1027,7 @@ def compute_opacity_facets(atms, opacityclass, numg, numt, stream=2, delta_eddin
             # the three tables in ONE upload and ONE launch: (3 nlayer[, nfacets], nin) rows, kept on the cloud dictionary
             # while its arrays are the same objects (a spectrum() called again, the phases of a curve that share a map)
             arrs = [clouds_3d[k] for k in ("opd", "w0", "g0")]
-            memo = clouds_3d.get("_rows")
+            memo = _cloud_memo_get("rows", clouds_3d)
             stamp = _table_fingerprint(arrs, clouds_3d["wavenumber"])
             if memo is None or memo[1] != stamp:
                 tabs = [np.asarray(x, dtype=float) for x in arrs]
@@ -1041,10 +1041,7 @@ def compute_opacity_facets(atms, opacityclass, numg, numt, stream=2, delta_eddin
                     rows = np.ascontiguousarray(rows if order is None else rows[:, :, order])
                 memo = (arrs, stamp, shared, np.ascontiguousarray(rows),
                         np.ascontiguousarray(in_wno if order is None else in_wno[order]), {})
-                try:
-                    clouds_3d["_rows"] = memo
-                except TypeError:
-                    pass
+                _cloud_memo_put("rows", clouds_3d, memo)
             _, _, shared, rows, xp, resident_tabs = memo
             key = (os.getpid(), getattr(ctx, "value", ctx))
             if key not in resident_tabs:         # the compact tables stay in HBM with the dictionary (27 MB at 64 facets)
@@ -1084,10 +1081,25 @@ def compute_opacity_facets(atms, opacityclass, numg, numt, stream=2, delta_eddin
     return {k: v for k, v in out.items() if v is not None}
 
 
+_CLOUD_MEMO = {}      # (kind, id(cloud dictionary)) -> memo; the caller's dictionary is never written to (it may be deep-copied)
+
+
+def _cloud_memo_get(kind, clouds_3d):
+    return _CLOUD_MEMO.get((kind, id(clouds_3d)))
+
+
+def _cloud_memo_put(kind, clouds_3d, memo):
+    if len(_CLOUD_MEMO) >= 24:                  # a phase curve's maps; older ones go (their device tables with them)
+        for k in list(_CLOUD_MEMO)[:8]:
+            del _CLOUD_MEMO[k]
+    _CLOUD_MEMO[(kind, id(clouds_3d))] = memo
+
+
 def _table_fingerprint(arrs, wavenumber):
     """Identity of the table objects plus a strided sample of their contents: a memo kept with a cloud dictionary is
     dropped when an array is replaced OR edited in place (scaled, a layer rewritten; a single-element edit between two
-    sample points is not seen -- declare the clouds again, ``clouds_3d`` starts the dictionary afresh)."""
+    sample points is not seen -- hand over a new dictionary).  The ids also guard the memo against a dictionary id reused
+    after collection."""
     out = []
     for a in list(arrs) + [wavenumber]:
         v = np.asarray(a).ravel()
@@ -1107,17 +1119,14 @@ def _facet_major_cloud_tables(clouds_3d, nlayer, nfac, ctx):
     arrs = [clouds_3d[k] for k in ("opd", "w0", "g0")]
     if any(np.size(a) not in (nlayer * nin, nlayer * nin * nfac) for a in arrs):
         return None
-    memo = clouds_3d.get("_tall")
+    memo = _cloud_memo_get("tall", clouds_3d)
     stamp = _table_fingerprint(arrs, clouds_3d["wavenumber"])
     if memo is None or memo[1] != stamp:
         order = np.argsort(in_wno, kind="stable") if np.any(np.diff(in_wno) < 0) else slice(None)
         tall = np.stack([np.moveaxis(np.broadcast_to(np.asarray(a, dtype=float).reshape(nlayer, nin, -1), (nlayer, nin, nfac)),
                                      (0, 1, 2), (1, 2, 0))[:, :, order].reshape(nfac * nlayer, nin) for a in arrs])
         memo = (arrs, stamp, np.ascontiguousarray(tall), np.ascontiguousarray(in_wno[order]), {})
-        try:
-            clouds_3d["_tall"] = memo
-        except TypeError:
-            pass
+        _cloud_memo_put("tall", clouds_3d, memo)
     key = (os.getpid(), getattr(ctx, "value", ctx))
     if key not in memo[4]:
         memo[4][key] = (DeviceArray.from_host(memo[3], ctx), DeviceArray.from_host(memo[2], ctx))

@@ -291,7 +291,9 @@ def test_gpu_3d_cloud_tables_edited_in_place_are_seen():
         c.inputs["clouds"]["dims"] = "3d"
         return c.spectrum(opa, calculation="reflected", dimension="3d")["albedo"]
     first = run(cld)
-    assert "_tall" in cld
+    assert set(cld) == {"opd", "w0", "g0", "wavenumber"}          # the caller's dictionary is not written to
+    import copy
+    assert np.array_equal(run(copy.deepcopy(cld)), first)
     cld["opd"] *= 3.0
     second = run(cld)
     fresh = run({k: (v.copy() if k != "wavenumber" else v) for k, v in cld.items() if not k.startswith("_")})
