@@ -568,107 +568,125 @@ def product_companion(ctx, nwno=100000, nlevel=91, ncalls=30, nbatch=32):
             out = c.spectrum(opa, calculation=calc)
             tt.append(time.perf_counter() - t0)
         return 1e3 * float(np.median(tt)), out
-    # the same call with the spherical-harmonics solver (SH4): without cloud (dtau and w0 only, angle-independent half
-    # of a layer shared between disk angles) and with a grey box cloud below layer 50 (the layers above the deck go
-    # through the cloud-free kernel: spectrum() states where the deck begins, justdoit._cloud_free_top)
-    sh = make(0)
-    sh.approx(raman="none", rt_method="SH", stream=4)
-    sh_ms, sh_out = timed(sh)
-    shc = make(0)
-    shc.approx(raman="none", rt_method="SH", stream=4)
+    def guarded(fn):                      # a companion that fails reports its error instead of taking the others down
+        try:
+            return fn()
+        except Exception as exc:
+            return {"error": "%s: %s" % (type(exc).__name__, exc)}
+
     nl = nlevel - 1
-    box = np.zeros((nl, 196))
-    box[50:60] = 0.3
-    shc.clouds(df={"opd": box, "w0": np.where(box > 0, 0.95, 0.0), "g0": np.where(box > 0, 0.6, 0.0)},
-               wavenumber=np.linspace(wno[0], wno[-1], 196))
-    shc_ms, shc_out = timed(shc)
-    # the 3-D form of the same call (BASELINE configs[4]'s per-GPU shape: 8 x 8 facets x 12 500 wavelengths x 90 layers,
-    # per-facet temperatures): without cloud, with a per-facet cloud map on a 196-point wavenumber grid of its own
-    # (clouds_3d as virga hands it over), and an 8-phase reflected-light curve of the cloudy map
-    n3 = 12500
-    w3 = np.linspace(3000.0, 30000.0, n3)
-    mol3 = {m: {i: 10.0 ** (-24.0 + 2.0 * np.sin(w3 / 2500.0 + k) + 0.4 * np.log10(p) + 0.8 * np.log10(t / 300.0))
-                for (i, p, t) in pt} for k, m in enumerate(mols)}
-    con3 = {pr: {t: 10.0 ** (-7.0 + np.cos(w3 / 4000.0 + k) + 0.3 * np.log10(t / 300.0)) for t in cia_t}
-            for k, pr in enumerate(("H2H2", "H2He"))}
-    opa3 = px.RetrieveOpacities(w3, pt, mol3, con3, cia_t, rayleigh_opa={m: 1e-27 * (w3 / 1e4) ** 4 for m in ("H2", "He")},
-                                query_method="linear", ctx=ctx)
-    pert = 1.0 + 0.1 * np.cos(np.arange(64).reshape(8, 8))
-    prof3 = dict(prof, temperature=prof["temperature"][:, None, None] * pert[None])
-    box3 = np.zeros((nl, 196, 8, 8))
-    box3[50:60] = 0.3 * (1.0 + 0.3 * np.cos(np.arange(64).reshape(1, 1, 8, 8)))
-    cmap = {"opd": box3, "w0": np.where(box3 > 0, 0.95, 0.0), "g0": np.where(box3 > 0, 0.6, 0.0),
-            "wavenumber": np.linspace(w3[0], w3[-1], 196)}
 
-    def case3(cloudy):
-        c = jdi.inputs()
-        c.phase_angle(np.pi / 3, num_gangle=8, num_tangle=8)
-        c.gravity(gravity=2500.0)
-        c.atmosphere_3d(prof3)
-        c.approx(raman="none")
-        if cloudy:
-            c.clouds_3d(df=cmap)
-        return c
+    def part_sh4():
+        # the same call with the spherical-harmonics solver (SH4): without cloud (dtau and w0 only, angle-independent half
+        # of a layer shared between disk angles) and with a grey box cloud below layer 50 (the layers above the deck go
+        # through the cloud-free kernel: spectrum() states where the deck begins, justdoit._cloud_free_top)
+        sh = make(0)
+        sh.approx(raman="none", rt_method="SH", stream=4)
+        sh_ms, sh_out = timed(sh)
+        shc = make(0)
+        shc.approx(raman="none", rt_method="SH", stream=4)
+        box = np.zeros((nl, 196))
+        box[50:60] = 0.3
+        shc.clouds(df={"opd": box, "w0": np.where(box > 0, 0.95, 0.0), "g0": np.where(box > 0, 0.6, 0.0)},
+                   wavenumber=np.linspace(wno[0], wno[-1], 196))
+        shc_ms, shc_out = timed(shc)
+        return {"sh4_spectrum_ms": sh_ms, "sh4_box_cloud_below_layer_50_spectrum_ms": shc_ms,
+                "finite": bool(all(np.all(np.isfinite(o[k])) for o in (sh_out, shc_out) for k in ("albedo", "thermal")))}
 
-    def timed3(c, n=8):
-        for _ in range(3):
-            c.spectrum(opa3, calculation=calc, dimension="3d")
-        tt = []
-        for _ in range(n):
-            t0 = time.perf_counter()
-            out = c.spectrum(opa3, calculation=calc, dimension="3d")
-            tt.append(time.perf_counter() - t0)
-        return 1e3 * float(np.median(tt)), out
-    s3_ms, s3_out = timed3(case3(False))
-    s3c_ms, s3c_out = timed3(case3(True))
-    phases = list(2 * np.pi * (np.arange(8) + 0.5) / 8)          # (not pi itself: the disk geometry divides by 1 + cos)
-    pc = jdi.inputs()
-    pc.phase_curve_geometry("reflected", phases, num_gangle=8, num_tangle=8)
-    pc.gravity(gravity=2500.0)
-    pc.atmosphere_4d([prof3 for _ in phases])
-    pc.approx(raman="none")
-    pc.phase_curve(opa3, clouds_by_phase=[cmap] * 8)
-    t0 = time.perf_counter()
-    curve = pc.phase_curve(opa3, clouds_by_phase=[cmap] * 8)
-    pc_ms = 1e3 * (time.perf_counter() - t0)
-    fin3 = all(np.all(np.isfinite(o[k])) for o in (s3_out, s3c_out) for k in ("albedo", "thermal")) and \
-        all(np.all(np.isfinite(v["albedo"])) for v in curve.values())
-    # the climate solver's call between Jacobians: get_fluxes (reference climate.py:1687) at the climate tables' shape --
-    # 91 levels, 661 bins x 8 Gauss points, one two-stream angle for the visible and 5 disk angles for the infrared,
-    # level fluxes of both legs back on the host -- with the thirteen opacity planes resident (what calculate_atm hands over)
-    from picaso_amd import climate as pcl
-    from picaso_amd.device import DeviceArray
-    nlev_c, nw_c, ng_c = 91, 661, 8
-    scs = [syn.make_scene(nlev_c - 1, nw_c, seed=70 + ig, gas_scale=10.0 ** (0.5 * ig - 2)) for ig in range(ng_c)]
-    stc = {k: np.ascontiguousarray(np.stack([sc_[k] for sc_ in scs], axis=2)) for k in resident.REFLECTED_PLANES + ("w0_no_raman",)}
-    xg, wg = np.polynomial.legendre.leggauss(ng_c)
-    gang_c, gw_c, tang_c, tw_c = disco.get_angles_1d(5)
-    u0_c, u1_c, _, _, _ = disco.compute_disco(5, 1, gang_c, tang_c, 0.0)
-    wno_c = scs[0]["wno"]
-    atm_t = pcl.Atmosphere_Tuple(None, None, nlev_c, scs[0]["tlevel"], scs[0]["plevel"], None, None, None, None)
-    sp_t = pcl.ScatteringPhase_Tuple(np.zeros(nw_c), 3, 0, 1.0, -1.0, 2.0, -0.5, 1.0)
-    dis_t = pcl.Disco_Tuple(5, 1, gw_c, tw_c, u0_c, u1_c, 1.0)
-    og_t = pcl.Opagrid_Tuple(nw_c, np.abs(np.gradient(wno_c)), wno_c, ng_c, 0.5 * wg)
-    up = lambda a: DeviceArray.from_host(a, ctx)
-    wed = pcl.OpacityWEd_Tuple(*[up(stc[k]) for k in ("dtau", "tau", "w0", "cosb", "ftau_cld", "ftau_ray", "gcos2", "w0_no_raman")], None)
-    noed = pcl.OpacityNoEd_Tuple(*[up(stc[k]) for k in ("dtau_og", "tau_og", "w0_og", "cosb_og")])
-    f0c = np.ones(nw_c)
-    for _ in range(10):
-        fl = pcl.get_fluxes(atm_t, wed, noed, sp_t, dis_t, og_t, f0c, True, True, ctx=ctx)
-    tc_ = []
-    for _ in range(30):
+    def part_3d():
+        # the 3-D form of the same call (BASELINE configs[4]'s per-GPU shape: 8 x 8 facets x 12 500 wavelengths x 90 layers,
+        # per-facet temperatures): without cloud, with a per-facet cloud map on a 196-point wavenumber grid of its own
+        # (clouds_3d as virga hands it over), and an 8-phase reflected-light curve of the cloudy map
+        n3 = 12500
+        w3 = np.linspace(3000.0, 30000.0, n3)
+        mol3 = {m: {i: 10.0 ** (-24.0 + 2.0 * np.sin(w3 / 2500.0 + k) + 0.4 * np.log10(p) + 0.8 * np.log10(t / 300.0))
+                    for (i, p, t) in pt} for k, m in enumerate(mols)}
+        con3 = {pr: {t: 10.0 ** (-7.0 + np.cos(w3 / 4000.0 + k) + 0.3 * np.log10(t / 300.0)) for t in cia_t}
+                for k, pr in enumerate(("H2H2", "H2He"))}
+        opa3 = px.RetrieveOpacities(w3, pt, mol3, con3, cia_t, rayleigh_opa={m: 1e-27 * (w3 / 1e4) ** 4 for m in ("H2", "He")},
+                                    query_method="linear", ctx=ctx)
+        pert = 1.0 + 0.1 * np.cos(np.arange(64).reshape(8, 8))
+        prof3 = dict(prof, temperature=prof["temperature"][:, None, None] * pert[None])
+        box3 = np.zeros((nl, 196, 8, 8))
+        box3[50:60] = 0.3 * (1.0 + 0.3 * np.cos(np.arange(64).reshape(1, 1, 8, 8)))
+        cmap = {"opd": box3, "w0": np.where(box3 > 0, 0.95, 0.0), "g0": np.where(box3 > 0, 0.6, 0.0),
+                "wavenumber": np.linspace(w3[0], w3[-1], 196)}
+
+        def case3(cloudy):
+            c = jdi.inputs()
+            c.phase_angle(np.pi / 3, num_gangle=8, num_tangle=8)
+            c.gravity(gravity=2500.0)
+            c.atmosphere_3d(prof3)
+            c.approx(raman="none")
+            if cloudy:
+                c.clouds_3d(df=cmap)
+            return c
+
+        def timed3(c, n=8):
+            for _ in range(3):
+                c.spectrum(opa3, calculation=calc, dimension="3d")
+            tt = []
+            for _ in range(n):
+                t0 = time.perf_counter()
+                out = c.spectrum(opa3, calculation=calc, dimension="3d")
+                tt.append(time.perf_counter() - t0)
+            return 1e3 * float(np.median(tt)), out
+        s3_ms, s3_out = timed3(case3(False))
+        s3c_ms, s3c_out = timed3(case3(True))
+        phases = list(2 * np.pi * (np.arange(8) + 0.5) / 8)          # (not pi itself: the disk geometry divides by 1 + cos)
+        pc = jdi.inputs()
+        pc.phase_curve_geometry("reflected", phases, num_gangle=8, num_tangle=8)
+        pc.gravity(gravity=2500.0)
+        pc.atmosphere_4d([prof3 for _ in phases])
+        pc.approx(raman="none")
+        pc.phase_curve(opa3, clouds_by_phase=[cmap] * 8)
         t0 = time.perf_counter()
-        fl = pcl.get_fluxes(atm_t, wed, noed, sp_t, dis_t, og_t, f0c, True, True, ctx=ctx)
-        tc_.append(time.perf_counter() - t0)
-    clim_ms = 1e3 * float(np.median(tc_))
-    clim_ok = all(np.all(np.isfinite(a)) for a in fl)
+        curve = pc.phase_curve(opa3, clouds_by_phase=[cmap] * 8)
+        pc_ms = 1e3 * (time.perf_counter() - t0)
+        fin3 = all(np.all(np.isfinite(o[k])) for o in (s3_out, s3c_out) for k in ("albedo", "thermal")) and \
+            all(np.all(np.isfinite(v["albedo"])) for v in curve.values())
+        return {"workload": "spectrum(dimension='3d', 'reflected+thermal'): 8 x 8 facets x %d wavelengths x %d layers, "
+                            "per-facet temperatures" % (n3, nl),
+                "cloud_free_ms": s3_ms, "per_facet_cloud_map_on_196_point_grid_ms": s3c_ms,
+                "phase_curve_reflected_8_phases_cloudy_ms": pc_ms, "finite": bool(fin3)}
+
+    def part_climate():
+        # the climate solver's call between Jacobians: get_fluxes (reference climate.py:1687) at the climate tables' shape --
+        # 91 levels, 661 bins x 8 Gauss points, one two-stream angle for the visible and 5 disk angles for the infrared,
+        # level fluxes of both legs back on the host -- with the thirteen opacity planes resident (what calculate_atm hands over)
+        from picaso_amd import climate as pcl
+        from picaso_amd.device import DeviceArray
+        nlev_c, nw_c, ng_c = 91, 661, 8
+        scs = [syn.make_scene(nlev_c - 1, nw_c, seed=70 + ig, gas_scale=10.0 ** (0.5 * ig - 2)) for ig in range(ng_c)]
+        stc = {k: np.ascontiguousarray(np.stack([sc_[k] for sc_ in scs], axis=2)) for k in resident.REFLECTED_PLANES + ("w0_no_raman",)}
+        xg, wg = np.polynomial.legendre.leggauss(ng_c)
+        gang_c, gw_c, tang_c, tw_c = disco.get_angles_1d(5)
+        u0_c, u1_c, _, _, _ = disco.compute_disco(5, 1, gang_c, tang_c, 0.0)
+        wno_c = scs[0]["wno"]
+        atm_t = pcl.Atmosphere_Tuple(None, None, nlev_c, scs[0]["tlevel"], scs[0]["plevel"], None, None, None, None)
+        sp_t = pcl.ScatteringPhase_Tuple(np.zeros(nw_c), 3, 0, 1.0, -1.0, 2.0, -0.5, 1.0)
+        dis_t = pcl.Disco_Tuple(5, 1, gw_c, tw_c, u0_c, u1_c, 1.0)
+        og_t = pcl.Opagrid_Tuple(nw_c, np.abs(np.gradient(wno_c)), wno_c, ng_c, 0.5 * wg)
+        up = lambda a: DeviceArray.from_host(a, ctx)
+        wed = pcl.OpacityWEd_Tuple(*[up(stc[k]) for k in ("dtau", "tau", "w0", "cosb", "ftau_cld", "ftau_ray", "gcos2", "w0_no_raman")], None)
+        noed = pcl.OpacityNoEd_Tuple(*[up(stc[k]) for k in ("dtau_og", "tau_og", "w0_og", "cosb_og")])
+        f0c = np.ones(nw_c)
+        for _ in range(10):
+            fl = pcl.get_fluxes(atm_t, wed, noed, sp_t, dis_t, og_t, f0c, True, True, ctx=ctx)
+        tc_ = []
+        for _ in range(30):
+            t0 = time.perf_counter()
+            fl = pcl.get_fluxes(atm_t, wed, noed, sp_t, dis_t, og_t, f0c, True, True, ctx=ctx)
+            tc_.append(time.perf_counter() - t0)
+        clim_ms = 1e3 * float(np.median(tc_))
+        clim_ok = all(np.all(np.isfinite(a)) for a in fl)
+        return {"workload": "climate.get_fluxes(reflected, thermal): 91 levels, 661 bins x 8 Gauss points, level "
+                            "fluxes of both legs, resident opacity planes", "ms": clim_ms, "finite": bool(clim_ok)}
+
+    sh4 = guarded(part_sh4)
     return {"product": {
-        "climate_get_fluxes": {"workload": "climate.get_fluxes(reflected, thermal): 91 levels, 661 bins x 8 Gauss points, level "
-                                           "fluxes of both legs, resident opacity planes", "ms": clim_ms, "finite": bool(clim_ok)},
-        "spectrum_3d": {"workload": "spectrum(dimension='3d', 'reflected+thermal'): 8 x 8 facets x %d wavelengths x %d layers, "
-                                    "per-facet temperatures" % (n3, nl),
-                        "cloud_free_ms": s3_ms, "per_facet_cloud_map_on_196_point_grid_ms": s3c_ms,
-                        "phase_curve_reflected_8_phases_cloudy_ms": pc_ms, "finite": bool(fin3)},
+        "climate_get_fluxes": guarded(part_climate),
+        "spectrum_3d": guarded(part_3d),
         "workload": "inputs.spectrum(opa, 'reflected+thermal'), %d wavelengths x %d layers, 5 Gauss angles, cloud-free, "
                     "resident opacity tables (5 molecules, 2 CIA pairs, 2 Rayleigh species): set-up, opacity mixing, "
                     "both Toon solves, disk sums, integrals, results on the host" % (nwno, nlevel - 1),
@@ -676,9 +694,10 @@ def product_companion(ctx, nwno=100000, nlevel=91, ncalls=30, nbatch=32):
         "spectrum_ms_after_300ms_idle": 1e3 * float(np.median(idle)),
         "spectrum_batch_ms_per_spectrum": 1e3 * min(tb) / nbatch, "batch_of": nbatch,
         "spectrum_batch_equals_single_calls": bool(same),
-        "sh4_spectrum_ms": sh_ms, "sh4_box_cloud_below_layer_50_spectrum_ms": shc_ms,
-        "finite": bool(np.all(np.isfinite(r["albedo"])) and np.all(np.isfinite(r["thermal"]))
-                       and all(np.all(np.isfinite(o[k])) for o in (sh_out, shc_out) for k in ("albedo", "thermal"))),
+        "sh4_spectrum_ms": sh4.get("sh4_spectrum_ms"),
+        "sh4_box_cloud_below_layer_50_spectrum_ms": sh4.get("sh4_box_cloud_below_layer_50_spectrum_ms"),
+        **({"sh4_error": sh4["error"]} if "error" in sh4 else {}),
+        "finite": bool(np.all(np.isfinite(r["albedo"])) and np.all(np.isfinite(r["thermal"])) and sh4.get("finite", False)),
         "seconds": time.perf_counter() - t_all}}
 
 
