@@ -1457,6 +1457,10 @@ struct SHCArgs {
 // LDS instead (11 doubles per angle, a plain loop over the angles in 232 VGPRs): 0.884 / 0.735 / 0.737 for one / two /
 // three angles per lane -- the LDS round trips cost more than the third angle's share of the common half saves.
 // From the two register timings: ~190 instructions per layer shared, ~275 per angle.
+// The angle's three reciprocals from one Newton core (prefix products, as modes_sh4_batched): 0.629 ms at 1e5 columns but
+// 0.148 instead of 0.135 at 12 500, where one wave per SIMD waits out the longer dependency chain; not kept.
+// The beam exponential exp(-tau[i+1]/u0) as the product of the two at hand (symmetric geometry, no clip): 0.641 ms against
+// 0.629 with its own polynomial -- the wave-uniform test costs more than the exponential (as in k_sh, PZ_SH_OPT_EXP).
 constexpr int SHC_MAX_PER_LANE = 2;
 
 template <int NA>
