@@ -28,60 +28,82 @@ constexpr int TRANSIT_BLOCK = 64;
 #define PZ_TRANSIT_ROWS 2
 #endif
 constexpr int TRANSIT_ROWS = PZ_TRANSIT_ROWS;
+#ifndef PZ_TRANSIT_WAVES
+#define PZ_TRANSIT_WAVES 4
+#endif
+constexpr int TRANSIT_WAVES = PZ_TRANSIT_WAVES;
 
-__global__ __launch_bounds__(TRANSIT_BLOCK) void k_transit(const TransitArgs a)
+// TRANSIT_WAVES waves share one tile of 64 wavelengths: wave v sums the chords i = v, v + WAVES, ... (chord i has i terms:
+// round-robin keeps the waves level), leaves (1 - exp(-TAUALL_i)) z_i dz_i in the tile's place once every wave is done
+// with it, and wave 0 adds those terms in level order -- the reference's order, whoever formed them.  With one wave per
+// tile a CU held three waves (the tile is 46 KB) and the kernel waited on the latency of its dependent fp64 adds.
+__global__ __launch_bounds__(TRANSIT_BLOCK * TRANSIT_WAVES) void k_transit(const TransitArgs a)
 {
-    extern __shared__ double tau_lds[];                 // [nlayer][64]
-    const long w = blockIdx.x * (long)TRANSIT_BLOCK + threadIdx.x;
+    extern __shared__ double tau_lds[];                 // [nlevel][64]: nlayer rows of TAU, later nlevel rows of terms
+    const int lane = threadIdx.x % TRANSIT_BLOCK, wave = threadIdx.x / TRANSIT_BLOCK;
+    const long w = blockIdx.x * (long)TRANSIT_BLOCK + lane;
     const int n = a.nlevel, nl = n - 1;
     const double *dl = a.tab, *zdz = dl + (long)n * n, *colden = zdz + n, *mmw = colden + nl;
     const bool live = w < a.nwno;
-    for (int l = 0; l < nl; ++l) {                      // TAU = DTAU / colden * mmw   (fluxes.py:2648-2650)
+    for (int l = wave; l < nl; l += TRANSIT_WAVES) {    // TAU = DTAU / colden * mmw   (fluxes.py:2648-2650)
         const double d = live ? a.dtau[(long)l * a.pitch + w] : 0.0;
-        tau_lds[l * TRANSIT_BLOCK + threadIdx.x] = d / colden[l] * mmw[l];
+        tau_lds[l * TRANSIT_BLOCK + lane] = d / colden[l] * mmw[l];
     }
-    if (!live) return;
-    // A chord's sum is one dependent chain of fp64 adds in the reference's order (j ascending), and a block's LDS tile
-    // leaves a CU three waves: the kernel waits on latency, not on throughput.  TRANSIT_ROWS chords are therefore summed
-    // side by side -- independent chains, each still in its own order, so the same bits -- and the disk sum over the
-    // chords stays in level order.  spectrum('transmission') at 1e5 x 90: 0.83 ms with one chord at a time, 0.67 with two, 0.73 with
+    __syncthreads();
+    // A chord's sum is one dependent chain of fp64 adds in the reference's order (j ascending); TRANSIT_ROWS chords of a
+    // wave are summed side by side -- independent chains, each still in its own order, so the same bits.
+    // spectrum('transmission') at 1e5 x 90, one wave per tile: 0.83 ms with one chord at a time, 0.67 with two, 0.73 with
     // four, 0.75 with eight, 0.91 with sixteen (the chord geometry arrives through scalar loads, one per chord and shell).
-    double acc = 0.0;
-    const double *const tl = tau_lds + threadIdx.x;
-    for (int i0 = 0; i0 < n; i0 += TRANSIT_ROWS) {
+    // With TRANSIT_WAVES waves per tile (two chords side by side): 2 waves 0.57 ms, 4 waves 0.48, 8 waves 0.47.
+    const double *const tl = tau_lds + lane;
+    constexpr int STEP = TRANSIT_WAVES;
+    constexpr int MAXT = 64;                            // chords per wave the registers hold: nlevel <= MAXT * WAVES
+    double term[MAXT];
+    int nt = 0;
+    for (int i0 = wave; i0 < n; i0 += STEP * TRANSIT_ROWS) {
         double t[TRANSIT_ROWS];
 #pragma unroll
         for (int k = 0; k < TRANSIT_ROWS; ++k) t[k] = 0.0;
-        if (i0 + TRANSIT_ROWS <= n) {
+        if (i0 + STEP * (TRANSIT_ROWS - 1) < n) {
             for (int j = 0; j < i0; ++j) {              // every chord of the group crosses shell j
 #pragma unroll
                 for (int k = 0; k < TRANSIT_ROWS; ++k)  // two because of the sphere's symmetry (:2655-2656)
-                    t[k] = t[k] + (2.0 * tl[(i0 + k - j - 1) * TRANSIT_BLOCK]) * dl[(long)(i0 + k) * n + j];
+                    t[k] = t[k] + (2.0 * tl[(i0 + STEP * k - j - 1) * TRANSIT_BLOCK]) * dl[(long)(i0 + STEP * k) * n + j];
             }
 #pragma unroll
             for (int k = 1; k < TRANSIT_ROWS; ++k)      // the shells only the deeper chords of the group reach
-                for (int j = i0; j < i0 + k; ++j)
-                    t[k] = t[k] + (2.0 * tl[(i0 + k - j - 1) * TRANSIT_BLOCK]) * dl[(long)(i0 + k) * n + j];
+                for (int j = i0; j < i0 + STEP * k; ++j)
+                    t[k] = t[k] + (2.0 * tl[(i0 + STEP * k - j - 1) * TRANSIT_BLOCK]) * dl[(long)(i0 + STEP * k) * n + j];
         } else {                                        // the last, short group: one chord at a time
-            for (int k = 0; i0 + k < n; ++k)
-                for (int j = 0; j < i0 + k; ++j)
-                    t[k] = t[k] + (2.0 * tl[(i0 + k - j - 1) * TRANSIT_BLOCK]) * dl[(long)(i0 + k) * n + j];
+            for (int k = 0; i0 + STEP * k < n; ++k)
+                for (int j = 0; j < i0 + STEP * k; ++j)
+                    t[k] = t[k] + (2.0 * tl[(i0 + STEP * k - j - 1) * TRANSIT_BLOCK]) * dl[(long)(i0 + STEP * k) * n + j];
         }
 #pragma unroll
         for (int k = 0; k < TRANSIT_ROWS; ++k)
-            if (i0 + k < n) acc = acc + (1.0 - fexp(-t[k])) * zdz[i0 + k];   // (1 - transmitted) . (z dz)  (:2660-2661)
+            if (i0 + STEP * k < n && nt < MAXT) term[nt++] = (1.0 - fexp(-t[k])) * zdz[i0 + STEP * k];   // (:2660-2661)
     }
+    __syncthreads();                                    // every wave is done with TAU: the tile now takes the terms
+    {
+        int q = 0;
+        for (int i = wave; i < n; i += STEP) tau_lds[i * TRANSIT_BLOCK + lane] = term[q++];
+    }
+    __syncthreads();
+    if (wave != 0 || !live) return;
+    double acc = 0.0;
+    for (int i = 0; i < n; ++i) acc = acc + tl[i * TRANSIT_BLOCK];           // the disk sum in level order
     a.out[w] = a.zmin_term + a.two_over_rs2 * acc;
 }
 
 int launch_transit(picaso_ctx *ctx, const TransitArgs &a)
 {
-    const size_t lds = sizeof(double) * (size_t)(a.nlevel - 1) * TRANSIT_BLOCK;
-    if (lds > 160 * 1024) return fail(ctx, "get_transit_1d: %d levels exceed the LDS tile", a.nlevel);
+    const size_t lds = sizeof(double) * (size_t)a.nlevel * TRANSIT_BLOCK;
+    if (lds > 160 * 1024 || a.nlevel > 64 * TRANSIT_WAVES)
+        return fail(ctx, "get_transit_1d: %d levels exceed the LDS tile", a.nlevel);
     const long grid = (a.nwno + TRANSIT_BLOCK - 1) / TRANSIT_BLOCK;
     if (lds > 64 * 1024)
         PZ_HIP(ctx, hipFuncSetAttribute((const void *)k_transit, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_transit, dim3((unsigned)grid), dim3(TRANSIT_BLOCK), lds, ctx->stream, a);
+    hipLaunchKernelGGL(k_transit, dim3((unsigned)grid), dim3(TRANSIT_BLOCK * TRANSIT_WAVES), lds, ctx->stream, a);
     PZ_HIP(ctx, hipGetLastError());
     return 0;
 }
