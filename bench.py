@@ -683,9 +683,23 @@ def product_companion(ctx, nwno=100000, nlevel=91, ncalls=30, nbatch=32):
         return {"workload": "climate.get_fluxes(reflected, thermal): 91 levels, 661 bins x 8 Gauss points, level "
                             "fluxes of both legs, resident opacity planes", "ms": clim_ms, "finite": bool(clim_ok)}
 
+    def part_transmission():
+        c = make(0)
+        c.gravity(radius=7.1e9, mass=1.9e30)
+        c.star(relative_flux=1.0 + 0.2 * np.cos(wno / 900.0), radius=6.9e10, semi_major=7.5e12)
+        for _ in range(4):
+            c.spectrum(opa, calculation="transmission")
+        tt = []
+        for _ in range(12):
+            t0 = time.perf_counter()
+            o = c.spectrum(opa, calculation="transmission")
+            tt.append(time.perf_counter() - t0)
+        return {"ms": 1e3 * float(np.median(tt)), "finite": bool(np.all(np.isfinite(o["transit_depth"])))}
+
     sh4 = guarded(part_sh4)
     return {"product": {
         "climate_get_fluxes": guarded(part_climate),
+        "transmission_spectrum": guarded(part_transmission),
         "spectrum_3d": guarded(part_3d),
         "workload": "inputs.spectrum(opa, 'reflected+thermal'), %d wavelengths x %d layers, 5 Gauss angles, cloud-free, "
                     "resident opacity tables (5 molecules, 2 CIA pairs, 2 Rayleigh species): set-up, opacity mixing, "
