@@ -127,6 +127,27 @@ def aux_context(device=None, index=0):
     return _aux[key]
 
 
+_destroy_hooks = []
+
+
+def on_context_destroy(hook):
+    """Register ``hook(ctx_value)``: called by ``destroy_context`` so that module-level caches of DeviceArrays drop what
+    they hold for that context (a new context may be created at the same address later)."""
+    _destroy_hooks.append(hook)
+
+
+def destroy_context(ctx):
+    """Free a context made by ``new_context`` (``picaso_ctx_destroy``) after telling the caches that key device
+    memory by context.  The per-process contexts of ``context()`` / ``aux_context()`` live as long as the process."""
+    value = getattr(ctx, "value", ctx)
+    for hook in _destroy_hooks:
+        hook(value)
+    for table in (_ctx, _aux):
+        for k in [k for k, v in table.items() if getattr(v, "value", v) == value]:
+            del table[k]
+    load().picaso_ctx_destroy(ctx)
+
+
 def device_of(ctx):
     d = ctypes.c_int(0)
     check(load().picaso_ctx_device(ctx, ctypes.byref(d)), ctx)

@@ -91,7 +91,8 @@ def _planes(wed, noed, ctx, thermal_only=False):
     return pl
 
 
-_VEC_CACHE = {}
+_VEC_CACHE = {}          # (pid, context, bytes) -> DeviceArray; entries of a context go when it is destroyed
+_lib.on_context_destroy(lambda value: [_VEC_CACHE.pop(k) for k in [k for k in _VEC_CACHE if k[1] == value]])
 
 
 def _resident_small(values, ctx):
@@ -102,8 +103,8 @@ def _resident_small(values, ctx):
     key = (os.getpid(), getattr(ctx, "value", ctx), a.tobytes())
     hit = _VEC_CACHE.get(key)
     if hit is None:
-        if len(_VEC_CACHE) >= 64:
-            _VEC_CACHE.clear()
+        while len(_VEC_CACHE) >= 64:               # oldest first
+            del _VEC_CACHE[next(iter(_VEC_CACHE))]
         hit = _VEC_CACHE[key] = DeviceArray.from_host(a, ctx)
     return hit
 

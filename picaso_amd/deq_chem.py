@@ -3,33 +3,39 @@
 Drop-in for ``picaso.deq_chem.mix_all_gases_gasesfly`` (reference picaso/deq_chem.py:333-384): numpy
 arrays in, the ``(nlayer, nwno, ngauss, 4)`` array of ln(mixed k) out.  The per-gas tables are large
 (tens of MB each) and do not change between calls of a climate run, so their device copies are kept
-and reused while the host arrays are the same objects with the same content fingerprint.
+and reused for host arrays with the same content (keyed by a digest of every byte, not by address).
 ``picaso_amd.optics.RetrieveCKs(kappas=...)`` is the resident form ``picaso()`` uses.
 """
+import os
+
 import numpy as np
 
 from . import _lib, resident
 from ._lib import f64
 from .device import DeviceArray
 
-_tables = {}            # (address, shape) -> (fingerprint, DeviceArray)
+_tables = {}            # (pid, context, digest of the table) -> DeviceArray: content-addressed, oldest out first
+_TABLES_MAX = 64
+_lib.on_context_destroy(lambda value: [_tables.pop(k) for k in [k for k in _tables if k[1] == value]])
 
 
 def _fingerprint(a):
-    flat = a.reshape(-1)
-    step = max(1, flat.size // 4096)
-    return float(flat[::step].sum()), float(flat[0]), float(flat[-1])
+    """Digest of every byte of the table (``optics.content_digest``): an in-place edit of one coefficient is a new
+    table, as it is for the reference, which reads its arguments afresh on every call (deq_chem.py:334-384)."""
+    from .optics import content_digest
+    return content_digest(a)
 
 
 def _resident_table(a, ctx):
     a = f64(a)
-    key = (a.ctypes.data, a.shape)
-    fp = _fingerprint(a)
+    key = (os.getpid(), getattr(ctx, "value", ctx), _fingerprint(a))
     hit = _tables.get(key)
-    if hit is not None and hit[0] == fp:
-        return hit[1]
+    if hit is not None:
+        return hit
+    while len(_tables) >= _TABLES_MAX:
+        del _tables[next(iter(_tables))]
     d = DeviceArray.from_host(a, ctx)
-    _tables[key] = (fp, d)
+    _tables[key] = d
     return d
 
 

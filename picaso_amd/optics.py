@@ -634,13 +634,16 @@ _SHARD_SCALARS = ("raman_db", "query_method")
 
 def resync_shard(s, opa, lo, hi):
     """Bring a shard's copies of the parent's mutable host attributes up to date (called on every use of a cached
-    shard or replica: ``picaso(devices=...)``, ``phase_curve(devices=...)``).  Cheap when nothing changed: the
-    parent's attribute objects are compared by identity."""
+    shard or replica: ``picaso(devices=...)``, ``phase_curve(devices=...)``).  The parent's arrays are compared by a digest
+    of their whole content (``content_digest``; 0.1 ms for the 0.8 MB vectors of a 1e5-point grid), so ``star()`` called
+    again, an array replaced or one edited in place all reach the shard."""
     if s is opa:
         return s
-    stamp = tuple(id(getattr(opa, n, None)) for n in _SHARD_VECTORS) + tuple(
-        (id(v) if isinstance(v, np.ndarray) or not isinstance(v, (str, int, float, type(None))) else v)
-        for v in (getattr(opa, n, None) for n in _SHARD_SCALARS))
+    def mark(v):          # arrays by content (every byte: an in-place edit of the stellar spectrum counts), the rest by value
+        if isinstance(v, np.ndarray):
+            return content_digest(v)
+        return v if isinstance(v, (str, int, float, type(None))) else id(v)
+    stamp = tuple(mark(getattr(opa, n, None)) for n in _SHARD_VECTORS + _SHARD_SCALARS)
     if getattr(s, "_parent_stamp", None) == stamp:
         return s
     nwno = opa.nwno
@@ -1081,6 +1084,11 @@ def compute_opacity_facets(atms, opacityclass, numg, numt, stream=2, delta_eddin
     return {k: v for k, v in out.items() if v is not None}
 
 
+try:                                   # in the image; the fallback is hashlib (slower, same coverage)
+    from xxhash import xxh3_128 as _xxh3
+except ImportError:                    # pragma: no cover
+    _xxh3 = None
+
 _CLOUD_MEMO = {}      # (kind, id(cloud dictionary)) -> memo; the caller's dictionary is never written to (it may be deep-copied)
 
 
@@ -1095,16 +1103,29 @@ def _cloud_memo_put(kind, clouds_3d, memo):
     _CLOUD_MEMO[(kind, id(clouds_3d))] = memo
 
 
+def content_digest(a):
+    """128-bit digest of EVERY byte of ``a`` (plus shape and dtype): the key of the content caches.  The reference
+    re-reads its inputs on every call (justdoit.py:437-449, atmsetup.py:609-622, deq_chem.py:334-384), so a device copy
+    may be reused only while the host array is bit for bit the one it was made from; an edit of a single element in
+    place changes the digest.  xxh3 runs at memory speed (about 1 ms per 25 MB table); blake2b is the fallback."""
+    v = np.ascontiguousarray(a)
+    head = ("%s|%s|" % (v.dtype.str, v.shape)).encode()
+    buf = memoryview(v.reshape(-1).view(np.uint8)) if v.size else b""
+    if _xxh3 is not None:
+        h = _xxh3(head)
+        h.update(buf)
+        return h.digest()
+    import hashlib
+    h = hashlib.blake2b(head, digest_size=16)
+    h.update(buf)
+    return h.digest()
+
+
 def _table_fingerprint(arrs, wavenumber):
-    """Identity of the table objects plus a strided sample of their contents: a memo kept with a cloud dictionary is
-    dropped when an array is replaced OR edited in place (scaled, a layer rewritten; a single-element edit between two
-    sample points is not seen -- hand over a new dictionary).  The ids also guard the memo against a dictionary id reused
-    after collection."""
-    out = []
-    for a in list(arrs) + [wavenumber]:
-        v = np.asarray(a).ravel()
-        out.append((id(a), v.size, float(v[::max(1, v.size // 4096)].sum())))
-    return tuple(out)
+    """Identity of the table objects plus a digest of ALL their contents: a memo kept with a cloud dictionary is dropped
+    when an array is replaced OR edited in place anywhere (scaled, one (layer, facet) row rewritten, one element
+    changed).  The ids also guard the memo against a dictionary id reused after collection."""
+    return tuple((id(a), content_digest(a)) for a in list(arrs) + [wavenumber])
 
 
 def _facet_major_cloud_tables(clouds_3d, nlayer, nfac, ctx):

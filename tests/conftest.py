@@ -19,6 +19,17 @@ def oracle():
     return orc
 
 
+@pytest.fixture
+def h5py(monkeypatch):
+    """``import h5py`` works inside the test: the real package, or tests/helpers.py's stand-in registered under its name
+    (the product's readers import it lazily), so the HDF5 reader branch always executes."""
+    from helpers import h5py_module
+    mod, stub = h5py_module()
+    if stub:
+        monkeypatch.setitem(sys.modules, "h5py", mod)
+    return mod
+
+
 def pytest_collection_modifyitems(config, items):
     """gpu-marked tests are skipped (not failed) on a box without a HIP device or without the library."""
     try:

@@ -1,8 +1,9 @@
 """Correlated-k table FILES -> arrays -> HBM-resident tables (reference
 ``get_ck_tables`` opacity_factory.py:2221-2327, ``RetrieveCKs.__init__`` / ``get_h5_data`` optics.py:676-770,
 ``opannection`` justdoit.py:1296-1419).  The files are written here in the reference's layouts: per-gas
-``<gas>_1460.npy`` directories (axes from ``$picaso_refdata``), per-gas and premixed HDF5 (when h5py is
-installed), the sqlite continuum database."""
+``<gas>_1460.npy`` directories (axes from ``$picaso_refdata``), per-gas and premixed HDF5 (through h5py where it is
+installed, else through the stand-in of tests/helpers.py registered under that name: the reader branch always runs),
+the sqlite continuum database."""
 import os
 import sqlite3
 import io
@@ -97,7 +98,7 @@ def test_read_continuum_db():
 
 
 def _write_h5(path, wno, dw, kcoeffs, gauss, premixed):
-    import h5py
+    import h5py                       # the `h5py` fixture has registered the package or its stand-in
     rows = _grid_rows()
     with h5py.File(path, "w") as f:
         f["wno"], f["delta_wno"] = wno, dw
@@ -113,8 +114,7 @@ def _write_h5(path, wno, dw, kcoeffs, gauss, premixed):
             f["nc_p"] = NC_P
 
 
-def test_read_hdf5_premixed_and_per_gas(tmp_path):
-    pytest.importorskip("h5py")
+def test_read_hdf5_premixed_and_per_gas(tmp_path, h5py):
     from picaso_amd import optics as px
     wno = np.linspace(50.0, 30000.0, 17)
     dw = np.gradient(wno)
@@ -126,6 +126,8 @@ def test_read_hdf5_premixed_and_per_gas(tmp_path):
     assert np.array_equal(t["kappa"], tabs["H2O"]) and t["molecules"] == ["H2O", "CH4"]
     assert np.array_equal(t["nc_p"], NC_P) and np.array_equal(t["temps"], TEMPS)
     assert np.array_equal(t["pressures"], PRESS) and np.array_equal(t["gauss_wts"], gauss[1])
+    assert np.array_equal(t["wno"], wno) and np.array_equal(t["delta_wno"], dw)
+    assert t["abunds_map"] == ["H2O", "CH4"] and t["abunds"].shape == (NC_P.sum(), 2)
     d = tmp_path / "by_molecule"
     d.mkdir()
     for m in tabs:
@@ -133,6 +135,25 @@ def test_read_hdf5_premixed_and_per_gas(tmp_path):
     t = px.read_ck_tables(str(d), preload_gases="all")
     assert sorted(t["molecules"]) == ["CH4", "H2", "H2O"] and np.array_equal(t["kappas"]["CH4"], tabs["CH4"])
     assert np.array_equal(t["nc_p"], NC_P)
+    # the same tables through the .npy route (axes from $picaso_refdata): every array bit for bit
+    ref, _ = _refdata(tmp_path, wno)
+    dn = tmp_path / "by_molecule_npy"
+    dn.mkdir()
+    for m, a in tabs.items():
+        np.save(dn / ("%s_1460.npy" % m), a)
+    n = px.read_ck_tables(str(dn), preload_gases="all", refdata=ref)
+    assert sorted(n["molecules"]) == sorted(t["molecules"])
+    for m in tabs:
+        assert np.array_equal(n["kappas"][m], t["kappas"][m])
+    for k in ("pressures", "temps", "nc_p", "gauss_pts", "gauss_wts"):
+        assert np.array_equal(n[k], t[k]), k
+    assert np.allclose(n["wno"], wno, rtol=1e-15) and np.allclose(n["delta_wno"], dw, rtol=1e-15)     # through a text file
+    # a requested gas without a table: the reference says so and goes on (opacity_factory.py:2286-2290)
+    with pytest.warns(UserWarning, match="no k-table for NH3"):
+        t2 = px.read_ck_tables(str(d), preload_gases=["H2O", "NH3"])
+    assert t2["molecules"] == ["H2O"]
+    with pytest.raises(Exception, match="No molecules are left to mix"), pytest.warns(UserWarning):
+        px.read_ck_tables(str(d), preload_gases=["NH3"])
 
 
 def test_hdf5_without_h5py_is_a_clear_error(tmp_path, monkeypatch):
@@ -176,14 +197,12 @@ def _cont_db_on(path, wno):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("method", ["resortrebin", "preweighted"])
-def test_gpu_opannection_from_ck_files_equals_arrays(tmp_path, method):
+@pytest.mark.parametrize("method", ["resortrebin", "resortrebin_hdf5", "preweighted"])
+def test_gpu_opannection_from_ck_files_equals_arrays(tmp_path, method, h5py):
     """opannection(method=..., ck_db=<files>, filename_db=<continuum db>) builds the same resident tables as
     RetrieveCKs(<arrays>): a reflected + thermal spectrum through both is bit-identical."""
     from picaso_amd import justdoit as jdi
     from picaso_amd import optics as px
-    if method == "preweighted":
-        pytest.importorskip("h5py")
     og = np.load(os.path.join(GOLDEN, "optics.npz"))
     wno = np.sort(og["in/wno"])
     ref, dw = _refdata(tmp_path, wno)
@@ -203,6 +222,13 @@ def test_gpu_opannection_from_ck_files_equals_arrays(tmp_path, method):
         finally:
             del os.environ["picaso_refdata"]
         assert opa.on_fly and sorted(opa.preload_gases) == ["CH4", "H2", "H2O"]
+    elif method == "resortrebin_hdf5":            # per-gas HDF5 tables: axes from the files themselves
+        d = tmp_path / "by_molecule"
+        d.mkdir()
+        for m, a in tabs.items():
+            _write_h5(str(d / ("%s_1460.hdf5" % m)), wno, dw, a, gauss, False)
+        opa = jdi.opannection(method="resortrebin", ck_db=str(d), filename_db=cdb, rayleigh_opa=ray)
+        assert opa.on_fly and sorted(opa.preload_gases) == ["CH4", "H2", "H2O"]
     else:
         f = str(tmp_path / "pm.hdf5")
         _write_h5(f, wno, dw, tabs["H2O"], gauss, True)
@@ -211,7 +237,7 @@ def test_gpu_opannection_from_ck_files_equals_arrays(tmp_path, method):
     _, cont, ctemps = px.read_continuum_db(cdb)
     pressures = np.concatenate([PRESS[:n] for n in NC_P])
     temps_flat = np.concatenate([[t] * n for t, n in zip(TEMPS, NC_P)])
-    kw = dict(kappas=tabs, on_fly=True) if method == "resortrebin" else dict(ln_kappa=tabs["H2O"])
+    kw = dict(kappas=tabs, on_fly=True) if method.startswith("resortrebin") else dict(ln_kappa=tabs["H2O"])
     arr = px.RetrieveCKs(wno, gauss[1], pressures, temps_flat, NC_P, continuum=cont, cia_temps=ctemps,
                          rayleigh_opa=ray, gauss_pts=gauss[0], **kw)
 

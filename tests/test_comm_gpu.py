@@ -112,7 +112,7 @@ def test_product_sharded_over_contexts_bit_identical(world):
             v.free()
         xr.free()
     for c in ctxs[1:]:
-        _lib.load().picaso_ctx_destroy(c)
+        _lib.destroy_context(c)
     assert np.array_equal(got, want)
 
 
