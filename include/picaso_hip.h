@@ -524,6 +524,56 @@ int picaso_get_thermal_1d_ck_dev(picaso_ctx *ctx, int nlevel, const double *wno,
                                  double *flux_minus_mdpt, double *flux_plus_mdpt, const double *gweight,
                                  const double *tweight, double *flux_disk);
 
+/* The same Gauss-point loop around the spherical-harmonics solvers (reference picaso/justdoit.py:256-269 + :307 reflected,
+ * :364-370 + :380 thermal: get_reflected_SH / get_thermal_SH once per Gauss point on plane[:, :, ig], accumulated with
+ * gauss_wts[ig] in ig order).  Planes (nlayer|nlevel, nwno, ngauss) as compute_opacity returns them, Gauss index fastest;
+ * surf_reflect / F0PI / wno (nwno); output (numg,numt,nwno) (+ optional fused disk sum).  All nwno*ngauss columns go
+ * through ONE launch of the SH kernels, so every column carries the bits of the per-Gauss-point call
+ * picaso_get_reflected_SH_top_dev / picaso_get_thermal_SH_dev (arguments as there; flx = 0: the reference discards the
+ * layer fluxes of the loop, justdoit.py:259).  The reference's in-place f_deltaM compounding acts on each Gauss slice
+ * separately (a view per ig), i.e. per column as in the monochromatic call.  cloud_free_above as in _top_dev (0: none). */
+int picaso_get_reflected_SH_ck_dev(picaso_ctx *ctx, int nlevel, int nwno, int ngauss, int numg, int numt,
+                                   const double *dtau, const double *tau, const double *w0, const double *cosb,
+                                   const double *ftau_cld, const double *ftau_ray, const double *f_deltaM,
+                                   const double *dtau_og, const double *tau_og, const double *w0_og,
+                                   const double *cosb_og, const double *surf_reflect, const double *ubar0,
+                                   const double *ubar1, double cos_theta, const double *F0PI, int w_single_form,
+                                   int w_multi_form, int psingle_form, int w_single_rayleigh, int w_multi_rayleigh,
+                                   int psingle_rayleigh, double frac_a, double frac_b, double frac_c,
+                                   double constant_back, double constant_forward, int stream, double b_top,
+                                   int single_form, int compound_f_deltaM, int cloud_free_above, const double *gauss_wts,
+                                   double *xint_at_top, const double *gweight, const double *tweight, double *albedo);
+int picaso_get_thermal_SH_ck_dev(picaso_ctx *ctx, int nlevel, const double *wno, int nwno, int ngauss, int numg,
+                                 int numt, const double *tlevel, const double *dtau, const double *tau,
+                                 const double *w0, const double *cosb_og, const double *plevel, const double *ubar1,
+                                 const double *surf_reflect, int stream, int hard_surface,
+                                 int cosb_differs_from_cosb_og, const double *gauss_wts, double *xint_at_top,
+                                 const double *gweight, const double *tweight, double *flux_disk);
+
+/* ... and around the 3-D solvers (reference picaso/justdoit.py:488-500 reflected, :502-516 thermal: get_reflected_3d /
+ * get_thermal_3d once per Gauss point on DTAU_3d[:, :, :, :, ig]).  Planes are FACET-MAJOR: (numg*numt, nlayer|nlevel,
+ * nwno, ngauss), facet f = g*numt + t, Gauss index fastest -- what picaso_compute_opacity_facet_major_ck_dev writes; the
+ * reference's (nlayer, nwno, numg, numt, ngauss) arrays are this with the facet axes moved to the front.  Every facet is
+ * solved as a spectrum of nwno*ngauss columns by the batched 3-D launches (a wave = 64 columns of one facet, all loads
+ * coalesced), bit-identical per (facet, wavelength, Gauss point) to picaso_get_reflected_3d_dev / picaso_get_thermal_3d_dev
+ * on the slice.  Plane families that picaso_get_reflected_3d_dev accepts as NULL may be NULL here (tau / tau_og / gcos2
+ * re-derived, no cloud, no delta-scaling; cosb NULL in the thermal call = no cloud).  tlevel_3d / plevel_3d HOST
+ * (nlevel, numg, numt), ubar0 / ubar1 HOST (numg, numt); output (numg,numt,nwno) (+ optional fused disk sum). */
+int picaso_get_reflected_3d_ck_dev(picaso_ctx *ctx, int nlevel, int nwno, int ngauss, int numg, int numt,
+                                   const double *dtau, const double *tau, const double *w0, const double *cosb,
+                                   const double *gcos2, const double *ftau_cld, const double *ftau_ray,
+                                   const double *dtau_og, const double *tau_og, const double *w0_og,
+                                   const double *cosb_og, const double *surf_reflect, const double *ubar0,
+                                   const double *ubar1, double cos_theta, const double *F0PI, int single_phase,
+                                   int multi_phase, double frac_a, double frac_b, double frac_c, double constant_back,
+                                   double constant_forward, const double *gauss_wts, double *xint_at_top,
+                                   const double *gweight, const double *tweight, double *albedo);
+int picaso_get_thermal_3d_ck_dev(picaso_ctx *ctx, int nlevel, const double *wno, int nwno, int ngauss, int numg,
+                                 int numt, const double *tlevel_3d, const double *dtau, const double *w0,
+                                 const double *cosb, const double *plevel_3d, const double *ubar1,
+                                 const double *surf_reflect, int hard_surface, const double *gauss_wts,
+                                 double *int_at_top, const double *gweight, const double *tweight, double *flux_disk);
+
 /* The thermal leg of climate.get_fluxes (reference picaso/climate.py:1879-1941) for `nitem` level-temperature profiles
  * over ONE set of opacity planes in one launch sequence: the climate solver's Jacobian perturbs one level temperature at
  * a time and calls get_fluxes with unchanged opacities (climate.py:1105-1180), ~nlevel calls per Newton step.  Planes
@@ -660,6 +710,22 @@ int picaso_compute_opacity_facets_dev(picaso_ctx *ctx, int nlayer, int nwno, int
                                       double *ftau_cld, double *ftau_ray, double *gcos2, double *dtau_og,
                                       double *tau_og, double *w0_og, double *cosb_og, double *w0_no_raman,
                                       double *f_deltaM);
+
+/* The facet loop of the 3-D branch for correlated-k tables (reference picaso/justdoit.py:437-471: compute_opacity facet
+ * by facet, `DTAU_3d[:, :, g, t, :] = dtau`), facet-major: taugas (nfacets, nlayer, nwno, ngauss) and tauray (nfacets,
+ * nlayer, nwno) from picaso_opacity_gas_ck_dev on the tall atmosphere of all facets; the cloud planes (nlayer, nwno) one
+ * per facet `cloud_stride` elements apart (0: one set for the whole disk; NULL: no cloud); raman_factor with raman_rows =
+ * nlayer one (nlayer, nwno) plane per facet, facet-major, with raman_rows = 0 one row for everything.  The 13 outputs are
+ * (nfacets, nlayer|nlevel, nwno, ngauss), any of them NULL = not written; each facet's numbers are those of
+ * picaso_compute_opacity_ck_dev on that facet. */
+int picaso_compute_opacity_facet_major_ck_dev(picaso_ctx *ctx, int nfacets, int nlayer, int nwno, int ngauss,
+                                              const double *taugas, const double *tauray, const double *taucld,
+                                              const double *w0_cld, const double *g0_cld, long cloud_stride,
+                                              const double *raman_factor, int raman_rows, double raman_const,
+                                              int test_mode, int delta_eddington, int stream, double *dtau, double *tau,
+                                              double *w0, double *cosb, double *ftau_cld, double *ftau_ray, double *gcos2,
+                                              double *dtau_og, double *tau_og, double *w0_og, double *cosb_og,
+                                              double *w0_no_raman, double *f_deltaM);
 
 /* A (nrows, nwno) plane shared by all facets -> (nrows, nwno, nfacets), facet index fastest, optionally times
  * facet_scale[f] (host array of nfacets, or NULL): cloud tables that do not vary over the disk, and the synthetic

@@ -1008,9 +1008,9 @@ class inputs:
             raise Exception("rt_method must be 'toon' or 'SH'")
         if calculate_fluxes not in ("off", "on"):
             raise Exception("calculate_fluxes must be 'off' or 'on'")
-        for opt in (w_single_form, w_multi_form, psingle_form):
-            if opt == "isotropic":      # accepted but not handled by the reference
-                raise Exception("SH form 'isotropic' is not handled by the reference solver either")
+        # 'isotropic' (index 2) is accepted as in the reference (justdoit.py:4730-4732); its solver has no branch for it and
+        # falls through with the l >= 1 Legendre weights at their initial ones and p_single = 0 (fluxes.py:2805-2855),
+        # which the kernels reproduce (tests/golden/sh_extra_*.npz)
         a = self.inputs["approx"]
         a["get_lvl_flux"] = get_lvl_flux
         a["rt_method"] = rt_method

@@ -504,3 +504,75 @@ def thermal_3d_batch(ctx, nlevel, wno, nwno, numg, numt, tlevel_3d, dtau_3d, w0_
     check(load().picaso_get_thermal_3d_batch_dev(
         ctx, _ci(nspec), _ci(nlevel), _addr(wno), _ci(nwno), _ci(numg), _ci(numt), ptr(tl), p_dt, p_w0, p_cb, ptr(pl),
         ptr(u1), p_rs, _ci(int(hard_surface)), p_fx, ptr(gw) if fuse else None, ptr(tw) if fuse else None, p_fd), ctx)
+
+
+# ------------------------------------------------------------------------------------------------
+# the correlated-k Gauss-point loop around the SH and the 3-D solvers (csrc/ckloop.hip)
+# ------------------------------------------------------------------------------------------------
+def _opt(x):
+    return ptr(x) if x is not None else None
+
+
+def reflected_SH_ck(ctx, nlevel, nwno, ngauss, numg, numt, planes, surf_reflect, ubar0, ubar1, cos_theta, F0PI,
+                    w_single_form, w_multi_form, psingle_form, w_single_rayleigh, w_multi_rayleigh, psingle_rayleigh,
+                    frac_a, frac_b, frac_c, constant_back, constant_forward, stream, gauss_wts, xint_at_top, b_top=0.0,
+                    single_form=0, compound_f_deltaM=True, cloud_free_above=0, gweight=None, tweight=None, albedo=None):
+    """The reference's ``for ig in range(ngauss)`` loop around ``get_reflected_SH`` (justdoit.py:256-269, :307) as one
+    launch: ``planes`` maps ``SH_PLANES`` to ``(nlayer|nlevel, nwno, ngauss)`` DeviceArrays as ``compute_opacity`` lays
+    them out; ``xint_at_top`` the Gauss-weighted ``(numg, numt, nwno)`` result (``picaso_get_reflected_SH_ck_dev``)."""
+    u0, u1 = f64(ubar0, (numg, numt)), f64(ubar1, (numg, numt))
+    gw = f64(gweight) if gweight is not None else None
+    tw = f64(tweight) if tweight is not None else None
+    check(load().picaso_get_reflected_SH_ck_dev(
+        ctx, _ci(nlevel), _ci(nwno), _ci(ngauss), _ci(numg), _ci(numt), *[_addr(planes.get(k)) for k in SH_PLANES],
+        _addr(surf_reflect), ptr(u0), ptr(u1), _cd(cos_theta), _addr(F0PI), _ci(int(w_single_form)),
+        _ci(int(w_multi_form)), _ci(int(psingle_form)), _ci(int(w_single_rayleigh)), _ci(int(w_multi_rayleigh)),
+        _ci(int(psingle_rayleigh)), _cd(frac_a), _cd(frac_b), _cd(frac_c), _cd(constant_back), _cd(constant_forward),
+        _ci(int(stream)), _cd(b_top), _ci(int(single_form)), _ci(1 if compound_f_deltaM else 0),
+        _ci(int(cloud_free_above)), ptr(f64(gauss_wts, (ngauss,))), _addr(xint_at_top), _opt(gw), _opt(tw),
+        _addr(albedo)), ctx)
+
+
+def thermal_SH_ck(ctx, nlevel, wno, nwno, ngauss, numg, numt, tlevel, dtau, w0, cosb_og, plevel, ubar1, surf_reflect,
+                  stream, hard_surface, cosb_differs_from_cosb_og, gauss_wts, xint_at_top, tau=None, gweight=None,
+                  tweight=None, flux_disk=None):
+    """The ``ngauss`` loop around ``get_thermal_SH`` (justdoit.py:364-370, :380) as one launch
+    (``picaso_get_thermal_SH_ck_dev``): planes ``(nlayer, nwno, ngauss)``; ``cosb_differs_from_cosb_og`` is the
+    reference's ``np.array_equal(cosb, cosb_og)`` test (fluxes.py:3072-3075), evaluated by the caller."""
+    gw = f64(gweight) if gweight is not None else None
+    tw = f64(tweight) if tweight is not None else None
+    check(load().picaso_get_thermal_SH_ck_dev(
+        ctx, _ci(nlevel), _addr(wno), _ci(nwno), _ci(ngauss), _ci(numg), _ci(numt), ptr(f64(tlevel, (nlevel,))),
+        _addr(dtau), _addr(tau), _addr(w0), _addr(cosb_og), ptr(f64(plevel, (nlevel,))), ptr(f64(ubar1, (numg, numt))),
+        _addr(surf_reflect), _ci(int(stream)), _ci(int(hard_surface)), _ci(1 if cosb_differs_from_cosb_og else 0),
+        ptr(f64(gauss_wts, (ngauss,))), _addr(xint_at_top), _opt(gw), _opt(tw), _addr(flux_disk)), ctx)
+
+
+def reflected_3d_ck(ctx, nlevel, nwno, ngauss, numg, numt, planes, surf_reflect, ubar0, ubar1, cos_theta, F0PI,
+                    single_phase, multi_phase, frac_a, frac_b, frac_c, constant_back, constant_forward, gauss_wts,
+                    xint_at_top, gweight=None, tweight=None, albedo=None):
+    """The ``ngauss`` loop around ``get_reflected_3d`` (justdoit.py:488-500) as one launch on FACET-MAJOR planes
+    ``(numg*numt, nlayer|nlevel, nwno, ngauss)`` (``optics.compute_opacity_facet_major_ck``); planes missing from
+    ``planes`` are passed as NULL and re-derived (``picaso_get_reflected_3d_ck_dev``)."""
+    gw = f64(gweight) if gweight is not None else None
+    tw = f64(tweight) if tweight is not None else None
+    check(load().picaso_get_reflected_3d_ck_dev(
+        ctx, _ci(nlevel), _ci(nwno), _ci(ngauss), _ci(numg), _ci(numt), *[_addr(planes.get(k)) for k in REFLECTED_PLANES],
+        _addr(surf_reflect), ptr(f64(ubar0, (numg, numt))), ptr(f64(ubar1, (numg, numt))), _cd(cos_theta), _addr(F0PI),
+        _ci(single_phase), _ci(multi_phase), _cd(frac_a), _cd(frac_b), _cd(frac_c), _cd(constant_back),
+        _cd(constant_forward), ptr(f64(gauss_wts, (ngauss,))), _addr(xint_at_top), _opt(gw), _opt(tw), _addr(albedo)), ctx)
+
+
+def thermal_3d_ck(ctx, nlevel, wno, nwno, ngauss, numg, numt, tlevel_3d, dtau, w0, cosb, plevel_3d, ubar1, surf_reflect,
+                  hard_surface, gauss_wts, int_at_top, gweight=None, tweight=None, flux_disk=None):
+    """The ``ngauss`` loop around ``get_thermal_3d`` (justdoit.py:502-516) as one launch on facet-major planes
+    ``(numg*numt, nlayer, nwno, ngauss)``; ``tlevel_3d`` / ``plevel_3d`` host ``(nlevel, numg, numt)``
+    (``picaso_get_thermal_3d_ck_dev``)."""
+    gw = f64(gweight) if gweight is not None else None
+    tw = f64(tweight) if tweight is not None else None
+    check(load().picaso_get_thermal_3d_ck_dev(
+        ctx, _ci(nlevel), _addr(wno), _ci(nwno), _ci(ngauss), _ci(numg), _ci(numt),
+        ptr(f64(tlevel_3d, (nlevel, numg, numt))), _addr(dtau), _addr(w0), _addr(cosb),
+        ptr(f64(plevel_3d, (nlevel, numg, numt))), ptr(f64(ubar1, (numg, numt))), _addr(surf_reflect),
+        _ci(int(hard_surface)), ptr(f64(gauss_wts, (ngauss,))), _addr(int_at_top), _opt(gw), _opt(tw),
+        _addr(flux_disk)), ctx)

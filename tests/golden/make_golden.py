@@ -824,3 +824,235 @@ def make_climate_fluxes():
 
 if __name__ == "__main__" and (("climate" in sys.argv[1:]) or not sys.argv[1:]):
     make_climate_fluxes()
+
+
+# ------------------------------------------------------------------------------------------------
+# round 5: the remaining option corner of the SH solver and the correlated-k loop around SH / 3-D
+# ------------------------------------------------------------------------------------------------
+def _sh_reflected(sc, geo, rs, f0, fd, forms, stream, b_top=0.0, flx=0):
+    """One get_reflected_SH call of the reference on fresh copies (it writes into f_deltaM)."""
+    wsf, wmf, psf, wsr, wmr, psr, sf = forms
+    return fl.get_reflected_SH(
+        sc["nlevel"], sc["nwno"], geo["numg"], geo["numt"], sc["dtau"].copy(), sc["tau"].copy(), sc["w0"].copy(),
+        sc["cosb"].copy(), sc["ftau_cld"].copy(), sc["ftau_ray"].copy(), fd.copy(), sc["dtau_og"].copy(),
+        sc["tau_og"].copy(), sc["w0_og"].copy(), sc["cosb_og"].copy(), rs, geo["ubar0"], geo["ubar1"], geo["cos_theta"],
+        f0, wsf, wmf, psf, wsr, wmr, psr, TTHG["frac_a"], TTHG["frac_b"], TTHG["frac_c"], TTHG["constant_back"],
+        TTHG["constant_forward"], stream, b_top=b_top, flx=flx, single_form=sf)
+
+
+def make_sh_extra():
+    """SH option corner the round-4 fixtures left open: form index 2 ('isotropic', accepted by the reference's approx(),
+    justdoit.py:4730-4732; get_reflected_SH falls through with the `ones` weights, fluxes.py:2805-2855) on each of the
+    three form arguments, and a non-zero top boundary b_top.  Inputs are those of scene_sh_<name>.npz (not stored again)."""
+    sc_all = scenes_1d()
+    for name in ("cfg3like", "phase60"):
+        sc, geo, rs, f0 = sc_all[name]
+        store = {}
+        combos = [(2, 2, 2, 1, 1, 1, 0), (2, 0, 0, 1, 1, 1, 0), (0, 2, 0, 1, 1, 1, 0), (0, 0, 2, 1, 1, 1, 0),
+                  (2, 1, 2, 0, 0, 0, 1), (1, 2, 0, 1, 0, 1, 1), (2, 2, 2, 0, 1, 0, 0)]
+        for stream in (2, 4):
+            fd = sc["f_deltaM"].copy()
+            if stream == 4:
+                fd = sc["cosb_og"] ** 4 if np.any(sc["f_deltaM"]) else fd
+            for forms in combos:
+                xint, _ = _sh_reflected(sc, geo, rs, f0, fd, forms, stream)
+                store["reflsh/s%d_f%d%d%d_r%d%d%d_sf%d/xint" % ((stream,) + forms)] = xint
+            for forms, b_top in (((0, 0, 0, 1, 1, 1, 0), 0.3), ((1, 1, 1, 1, 1, 1, 0), 0.05), ((2, 2, 2, 1, 1, 1, 0), 1.0)):
+                xint, _ = _sh_reflected(sc, geo, rs, f0, fd, forms, stream, b_top=b_top)
+                key = "btop/s%d_f%d%d%d_r%d%d%d_sf%d" % ((stream,) + forms)
+                store[key + "/xint"] = xint
+                store[key + "/b_top"] = np.array(b_top)
+        path = os.path.join(HERE, "sh_extra_%s.npz" % name)
+        np.savez_compressed(path, **store)
+        print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024))
+
+
+def make_ck_rt():
+    """The correlated-k loop of the reference's picaso() around the SH solvers and around the 3-D solvers
+    (justdoit.py:256-307 / 364-380: get_reflected_SH / get_thermal_SH once per Gauss point, `xint_at_top +=
+    xint*gauss_wts[ig]`; :488-516: get_reflected_3d / get_thermal_3d per Gauss point on planes with a trailing ngauss
+    axis), run here with the reference's own functions.
+      sh/...   : the planes the reference's compute_opacity made from ck.npz's 4-Gauss table (ck.npz `de1_s2/*`,
+                 `de1_s4/*` -- read from there, not stored again), 5 disk angles at zero phase and 3 x 2 at phase 1.0
+      r3d/...  : solver level -- synthetic planes (nlayer|nlevel, nwno, 3, 3, 8) stored whole (small), outputs of the loop
+      p3d/...  : pipeline level -- an 8-Gauss premixed table + per-facet temperature / cloud columns through the
+                 reference's get_pre_mix_ck + get_continuum + compute_opacity facet by facet (justdoit.py:437-471), then
+                 the two loops; inputs and outputs stored (and a few planes of one facet as a spot check)."""
+    import types
+    import pandas as pd
+    optics = ref_shim.load("optics")
+    ck = np.load(os.path.join(HERE, "ck.npz"))
+    og = np.load(os.path.join(HERE, "optics.npz"))
+    wno = og["in/wno"]
+    nwno = wno.size
+    nlevel = og["in/tlevel"].size
+    nlayer = nlevel - 1
+    store = {}
+    names = ("dtau", "tau", "w0", "cosb", "ftau_cld", "ftau_ray", "gcos2", "dtau_og", "tau_og", "w0_og", "cosb_og",
+             "w0_no_raman", "f_deltaM")
+    gauss_wts = ck["in/gauss_wts"]
+    ngauss = gauss_wts.size
+    rs = np.linspace(0.05, 0.35, nwno)
+    f0 = np.linspace(0.7, 1.4, nwno)
+    tlevel = og["in/tlevel"]
+    plevel = og["in/plevel_bar"] * 1e6
+    store.update({"sh/surf_reflect": rs, "sh/F0PI": f0, "sh/tlevel": tlevel, "sh/plevel": plevel})
+    geos = {"g5": geometry_1d(5), "g3x2": geometry_3d(3, 2, 1.0)}
+    for gname, geo in geos.items():
+        for k, v in geo.items():
+            store["sh/%s/geo/%s" % (gname, k)] = np.asarray(v)
+    for stream in (2, 4):
+        pl = {nm: ck["de1_s%d/%s" % (stream, nm)] for nm in names}
+        for gname, geo in geos.items():
+            for forms in ((0, 0, 0, 1, 1, 1, 0), (1, 1, 1, 1, 1, 1, 0), (2, 0, 1, 1, 0, 1, 1)):
+                xint_at_top = 0
+                for ig in range(ngauss):                       # justdoit.py:256-307
+                    sc = {nm: np.ascontiguousarray(pl[nm][:, :, ig]) for nm in names}
+                    sc.update(nlevel=nlevel, nwno=nwno)
+                    xint, _ = _sh_reflected(sc, geo, rs, f0, sc["f_deltaM"], forms, stream)
+                    xint_at_top += xint * gauss_wts[ig]
+                key = "sh/%s/s%d_f%d%d%d_r%d%d%d_sf%d" % ((gname, stream) + forms)
+                store[key + "/xint_at_top"] = xint_at_top
+                store[key + "/albedo"] = di.compress_disco(nwno, geo["cos_theta"], xint_at_top, geo["gweight"],
+                                                           geo["tweight"], f0)
+            for hs in (0, 1):
+                flux_at_top = 0
+                for ig in range(ngauss):                       # justdoit.py:364-380
+                    s_ = {nm: np.ascontiguousarray(pl[nm][:, :, ig]) for nm in names}
+                    flux, _ = fl.get_thermal_SH(nlevel, wno, nwno, geo["numg"], geo["numt"], tlevel, s_["dtau"], s_["tau"],
+                                                s_["w0"], s_["cosb"], s_["dtau_og"], s_["tau_og"], s_["w0_og"],
+                                                s_["w0_no_raman"], s_["cosb_og"], plevel, geo["ubar1"], rs.copy(), stream, hs)
+                    flux_at_top += flux * gauss_wts[ig]
+                key = "sh/%s/thermal_s%d_hs%d" % (gname, stream, hs)
+                store[key + "/flux_at_top"] = flux_at_top
+                store[key + "/thermal"] = di.compress_thermal(nwno, flux_at_top, geo["gweight"], geo["tweight"])
+
+    # ---- r3d: the 3-D solvers inside the Gauss loop on stored synthetic planes ----
+    ng, nt, ng8 = 3, 3, 8
+    xg, wg = np.polynomial.legendre.leggauss(4)
+    wts8 = np.concatenate([0.95 * 0.5 * wg, 0.05 * 0.5 * wg])
+    geo3 = geometry_3d(ng, nt, np.pi / 3)
+    nl3, nw3 = 12, 10
+    rng = np.random.default_rng(2025)
+    scale = 10.0 ** np.linspace(-1.5, 1.2, ng8)
+    planes3 = {k: np.zeros(((nl3 + 1) if k in ("tau", "tau_og") else nl3, nw3, ng, nt, ng8))
+               for k in PLANES + ("w0_no_raman",)}
+    for g in range(ng):
+        for t in range(nt):
+            base = syn.make_scene(nl3, nw3, seed=500 + 10 * g + t, cloud_opd=float(rng.uniform(0.05, 3.0)))
+            for ig in range(ng8):
+                mixed = syn.mix_planes(base["taugas"] * scale[ig], base["tauray"], base["taucld"], base["w0_cld"],
+                                       base["g0_cld"])
+                for k in planes3:
+                    planes3[k][:, :, g, t, ig] = mixed[k]
+    p3, tl3 = syn.pressure_temperature(nl3 + 1)
+    t3 = np.stack([np.stack([tl3 * (1.0 + 0.1 * rng.uniform(-1, 1)) for _ in range(nt)], axis=1) for _ in range(ng)], axis=1)
+    pl3 = np.broadcast_to((p3 * 1e6)[:, None, None], (nl3 + 1, ng, nt)).copy()
+    wno3 = syn.wavenumber_grid(nw3)
+    f03, rs3 = np.linspace(0.8, 1.3, nw3), np.linspace(0.0, 0.4, nw3)
+    for k, v in planes3.items():
+        store["r3d/in/" + k] = v
+    store.update({"r3d/in/tlevel": t3, "r3d/in/plevel": pl3, "r3d/in/wno": wno3, "r3d/in/F0PI": f03,
+                  "r3d/in/surf_reflect": rs3, "r3d/in/gauss_wts": wts8})
+    for k, v in geo3.items():
+        store["r3d/geo/" + k] = np.asarray(v)
+
+    def loops_3d(pl, wno_, nw_, nlev_, t3_, p3_, rs_, f0_, wts_, key):
+        for sp, mp in ((3, 0), (0, 1), (1, 0)):
+            xint_at_top = 0
+            for ig in range(wts_.size):                       # justdoit.py:488-500
+                xint = fl.get_reflected_3d(nlev_, wno_, nw_, ng, nt, *[pl[k][:, :, :, :, ig].copy() for k in PLANES], rs_,
+                                           geo3["ubar0"], geo3["ubar1"], geo3["cos_theta"], f0_, sp, mp, TTHG["frac_a"],
+                                           TTHG["frac_b"], TTHG["frac_c"], TTHG["constant_back"], TTHG["constant_forward"])
+                xint_at_top += xint * wts_[ig]
+            store["%s/refl_sp%d_mp%d/xint_at_top" % (key, sp, mp)] = xint_at_top
+            store["%s/refl_sp%d_mp%d/albedo" % (key, sp, mp)] = di.compress_disco(
+                nw_, geo3["cos_theta"], xint_at_top, geo3["gweight"], geo3["tweight"], f0_)
+        for hs in (0, 1):
+            flux_at_top = 0
+            for ig in range(wts_.size):                       # justdoit.py:502-514
+                flux = fl.get_thermal_3d(nlev_, wno_, nw_, ng, nt, t3_, pl["dtau_og"][:, :, :, :, ig].copy(),
+                                         pl["w0_no_raman"][:, :, :, :, ig].copy(), pl["cosb_og"][:, :, :, :, ig].copy(),
+                                         p3_, geo3["ubar1"], rs_, hs)
+                flux_at_top += flux * wts_[ig]
+            store["%s/therm_hs%d/flux_at_top" % (key, hs)] = flux_at_top
+            store["%s/therm_hs%d/thermal" % (key, hs)] = di.compress_thermal(nw_, flux_at_top, geo3["gweight"],
+                                                                             geo3["tweight"])
+    loops_3d(planes3, wno3, nw3, nl3 + 1, t3, pl3, rs3, f03, wts8, "r3d")
+
+    # ---- p3d: table -> per-facet compute_opacity -> the two loops ----
+    temps = np.array([100.0, 250.0, 600.0, 1200.0, 2600.0])
+    press = np.array([1e-6, 1e-4, 1e-2, 1.0, 30.0, 300.0])
+    nc_p = np.array([6, 6, 6, 5, 4])
+    pressures = np.concatenate([press[:n] for n in nc_p])
+    temps_flat = np.concatenate([[t] * n for t, n in zip(temps, nc_p)])
+    rng = np.random.default_rng(888)
+    kappa = np.zeros((press.size, temps.size, nwno, ng8))
+    for ip, p_ in enumerate(press):
+        for it, t_ in enumerate(temps):
+            base = (-26.0 + 2.0 * np.sin(wno / 2500.0) + 0.5 * np.log10(p_) + 0.9 * np.log10(t_ / 300.0))
+            steps = np.cumsum(0.35 + 0.3 * rng.random((nwno, ng8)), axis=1)
+            kappa[ip, it] = np.log(10.0) * (base[:, None] - 1.0 + steps)
+    cia_temps = np.array([75.0, 200.0, 500.0, 1000.0, 2000.0, 4000.0])
+    mixkeys = ("H2", "He", "H2O", "CH4")
+    mix = {k: og["in/mix/" + k] for k in mixkeys}
+    gravity = float(og["in/gravity"])
+    weights = _ref_weights(mixkeys)
+    plevel_bar = og["in/plevel_bar"]
+    tfac = 1.0 + 0.12 * np.sin(1.0 + np.arange(ng * nt)).reshape(ng, nt)             # per-facet temperature scale
+    cfac = (0.2 + 1.6 * rng.random((ng, nt)))                                        # per-facet cloud optical-depth scale
+    t3p = og["in/tlevel"][:, None, None] * tfac[None]
+    db = os.path.join(HERE, "synthetic_opacities.db")
+
+    def make_atm(g, t):
+        atm = types.SimpleNamespace()
+        atm.c = types.SimpleNamespace(nlayer=nlayer, nlevel=nlevel, pconv=1e6, k_b=1.380649e-16,
+                                      amu=1.66053906660e-24, rgas=8.31446261815324)
+        atm.planet = types.SimpleNamespace(gravity=gravity)
+        p = plevel_bar * 1e6
+        tl = t3p[:, g, t]
+        atm.level = {"pressure": p, "temperature": tl}
+        lay_mix = pd.DataFrame({k: 0.5 * (v[1:] + v[:-1]) for k, v in mix.items()})
+        mmw_lvl = sum(mix[k] * weights[k] for k in mix)
+        atm.layer = {"pressure": np.sqrt(p[1:] * p[:-1]), "temperature": 0.5 * (tl[1:] + tl[:-1]),
+                     "mmw": 0.5 * (mmw_lvl[1:] + mmw_lvl[:-1]), "colden": _ref_colden(p, tl, mmw_lvl, gravity),
+                     "electrons": np.zeros(nlayer), "mixingratios": lay_mix,
+                     "cloud": {"opd": og["in/cld_opd"] * cfac[g, t], "w0": og["in/cld_w0"].copy(),
+                               "g0": og["in/cld_g0"].copy()}}
+        atm.molecules = np.array(["H2O", "CH4", "H2"])
+        atm.continuum_molecules = [["H2", "H2"], ["H2", "He"], ["H2", "CH4"]]
+        atm.rayleigh_molecules = ["H2", "He", "CH4", "H2O"]
+        return atm
+
+    opa = object.__new__(optics.RetrieveCKs)
+    opa.pressures, opa.temps, opa.nc_p, opa.kappa = pressures, temps_flat, nc_p, kappa
+    opa.continuum_db, opa.cia_temps = db, cia_temps
+    opa.wno, opa.nwno, opa.ngauss, opa.gauss_wts = wno, nwno, ng8, wts8
+    rayleigh = ref_shim.load("rayleigh")
+    ray = rayleigh.Rayleigh(wno)
+    opa.rayleigh_opa = {m: ray.compute_sigma(m) for m in ("H2", "He", "CH4", "H2O")}
+    pl3p = {k: np.zeros(((nlevel if k in ("tau", "tau_og") else nlayer), nwno, ng, nt, ng8)) for k in names}
+    for g in range(ng):
+        for t in range(nt):                                    # justdoit.py:437-471
+            atm = make_atm(g, t)
+            opa.get_pre_mix_ck(atm)
+            opa.get_continuum(atm)
+            out = optics.compute_opacity(atm, opa, ngauss=ng8, stream=2, delta_eddington=True, raman=2, test_mode=None)
+            for nm, arr in zip(names, out):
+                pl3p[nm][:, :, g, t, :] = arr
+    p3p = np.broadcast_to((plevel_bar * 1e6)[:, None, None], (nlevel, ng, nt)).copy()
+    store.update({"p3d/in/press": press, "p3d/in/temps": temps, "p3d/in/nc_p": nc_p, "p3d/in/kappa": kappa,
+                  "p3d/in/gauss_wts": wts8, "p3d/in/cia_temps": cia_temps, "p3d/in/tlevel": t3p,
+                  "p3d/in/cloud_scale": cfac, "p3d/in/surf_reflect": rs, "p3d/in/F0PI": f0})
+    for nm in ("dtau", "w0", "tau_og", "w0_no_raman", "cosb_og"):
+        store["p3d/facet_2_1/" + nm] = pl3p[nm][:, :, 2, 1, :]
+    loops_3d(pl3p, wno, nwno, nlevel, t3p, p3p, rs, f0, wts8, "p3d")
+    path = os.path.join(HERE, "ck_rt.npz")
+    np.savez_compressed(path, **store)
+    print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024))
+
+
+if __name__ == "__main__" and (("sh_extra" in sys.argv[1:]) or not sys.argv[1:]):
+    make_sh_extra()
+if __name__ == "__main__" and (("ck_rt" in sys.argv[1:]) or not sys.argv[1:]):
+    make_ck_rt()
