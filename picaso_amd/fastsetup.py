@@ -12,6 +12,8 @@ import os
 
 import numpy as np
 
+from .options import current as _options
+
 from . import _lib
 from .atmsetup import ATMSETUP, molecular_weight
 
@@ -129,7 +131,7 @@ class _PressureGrid:
 
 
 def setup(inp, opa, wno):
-    if os.environ.get("PICASO_AMD_PY_SETUP"):
+    if _options().py_setup:
         return None
     if (getattr(opa, "query_method", None) != "linear" or getattr(opa, "ngauss", 1) != 1 or not hasattr(opa, "_row_lut")
             or getattr(opa, "on_fly", False)):
@@ -231,7 +233,7 @@ def setup_facets(inp, opa, wno, prof_f):
     facet, ``(nlevel, 1)`` for what does not; the pressure grid is shared) from ``picaso_host_setup_facets``, with the tall
     plan and per-layer coefficients ``optics.gas_stage_facets`` would form (facet-major ``nfacets * nlayer`` layers) attached
     as ``atm._fast_tall``.  ``None`` outside the C function's scope."""
-    if os.environ.get("PICASO_AMD_PY_SETUP"):
+    if _options().py_setup:
         return None
     if (getattr(opa, "query_method", None) != "linear" or getattr(opa, "ngauss", 1) != 1 or not hasattr(opa, "_row_lut")
             or getattr(opa, "on_fly", False) or inp["atmosphere"].get("exclude_mol", 1) != 1):

@@ -20,8 +20,13 @@ import os
 import numpy as np
 
 from . import _lib, device, disco, fastsetup, optics, resident
+from . import options as _options
 from .atmsetup import ATMSETUP, CloudTables
 from .device import DeviceArray
+from .options import Options                                                        # noqa: F401  (jdi.Options)
+from .spectrum import (Spectrum, _atmosphere_block, _bond_denominator, _cloud_free_top, _constant_planes,   # noqa: F401
+                       _fetch, _interp_axis, _ones, _post_final, _post_reflected, _post_thermal, _postprocess,
+                       _reflected, _resident_vector, _setup_atmosphere, _trapz_resident)
 
 # option tables (reference justdoit.py:5512-5534, 5647-5658)
 def single_phase_options(printout=True):
@@ -254,24 +259,6 @@ def _dataset_like(ds, extra_coords=()):
     coords["pressure"] = coords["pressure"] * fac
     coords["pressure_unit_in"] = unit
     return coords, variables
-
-
-def _interp_axis(x_new, x_old, arr, axis):
-    """Linear interpolation of ``arr`` along ``axis`` from the increasing grid ``x_old`` to ``x_new`` (end values
-    held outside the grid)."""
-    x_old = np.asarray(x_old, dtype=float)
-    if x_old.size == 1:
-        return np.repeat(arr, len(x_new), axis=axis)
-    if np.any(np.diff(x_old) < 0):
-        order = np.argsort(x_old)
-        x_old, arr = x_old[order], np.take(arr, order, axis=axis)
-    x = np.clip(np.asarray(x_new, dtype=float), x_old[0], x_old[-1])
-    j = np.clip(np.searchsorted(x_old, x, side="right") - 1, 0, x_old.size - 2)
-    t = (x - x_old[j]) / (x_old[j + 1] - x_old[j])
-    shape = [1] * arr.ndim
-    shape[axis] = -1
-    t = t.reshape(shape)
-    return np.take(arr, j, axis=axis) * (1.0 - t) + np.take(arr, j + 1, axis=axis) * t
 
 
 def _regrid_lonlat(coords, variables, lon_new, lat_new):
@@ -886,7 +873,7 @@ class inputs:
         self.nlevel = len(order)
 
     def phase_curve(self, opacityclass, full_output=False, plot_opacity=False, n_cpu=1, verbose=False,
-                    clouds_by_phase=None, devices=None):
+                    clouds_by_phase=None, devices=None, options=None):
         """Spectrum at every phase of ``phase_curve_geometry`` (reference justdoit.py:4741-4777; its
         ``n_cpu`` joblib fan-out is a loop here: the phases share the resident opacity tables and one
         GPU).  ``devices=N`` (or a list of device indices) deals the phases out to N GPUs round-robin -- the
@@ -916,14 +903,15 @@ class inputs:
         # phase), and the copies back (each a stream synchronisation) come at the end.  The input planes
         # of a phase return to the context's block cache as soon as its kernels are enqueued (reuse is
         # ordered on the stream); at most `in_flight` phases keep their small result buffers pending.
-        in_flight = int(os.environ.get("PICASO_AMD_PHASES_IN_FLIGHT", "16"))
+        opt = _options.current(options)
+        in_flight = opt.phases_in_flight
         # One solver launch per leg for a CHUNK of phases (picaso_get_reflected_3d_batch_dev / _thermal_3d_batch_dev;
         # "all phases as one batched launch instead of joblib processes"): the phases' planes
         # stay resident until the chunk's launch, so the chunk is sized to ~48 GB of planes (PICASO_AMD_PHASE_CHUNK
         # overrides; 1 = one launch per phase, the round-3 form).  One batch per replica with devices=N.
         nfac_pc = all_geom[phases[0]]["num_gangle"] * all_geom[phases[0]]["num_tangle"]
         per_phase = 11 * 8.0 * max(self.nlevel - 1, 1) * opacityclass.nwno * nfac_pc
-        chunk = int(os.environ.get("PICASO_AMD_PHASE_CHUNK", str(max(1, min(in_flight, int(48e9 // max(per_phase, 1.0)))))))
+        chunk = opt.phase_chunk or max(1, min(in_flight, int(48e9 // max(per_phase, 1.0))))
         batches = [_SolveBatch() if chunk > 1 else None for _ in replicas]
         results, pending = {}, []
         try:
@@ -938,7 +926,7 @@ class inputs:
                 bt = batches[i % len(replicas)]
                 pending.append((ph, picaso(self, replicas[i % len(replicas)], dimension="3d",
                                            calculation=calculation, full_output=full_output,
-                                           plot_opacity=plot_opacity, defer=True, _batch=bt)))
+                                           plot_opacity=plot_opacity, defer=True, options=opt, _batch=bt)))
                 if bt is not None and bt.pending() >= chunk * (2 if "+" in calculation else 1):
                     bt.flush()
                 if len(pending) >= in_flight:
@@ -1043,7 +1031,7 @@ class inputs:
         t["single_phase"] = single_phase_options(False).index(single_phase)
 
     def spectrum(self, opacityclass, calculation="reflected", dimension="1d", full_output=False,
-                 plot_opacity=False, as_dict=True, devices=None, gather="host"):
+                 plot_opacity=False, as_dict=True, devices=None, gather="host", options=None):
         """Run the spectrum (reference justdoit.py:4779-4840).  ``devices=N`` (or a list of device indices):
         the wavelength grid is cut into N contiguous blocks, one per GPU (``picaso(devices=...)``)."""
         if dimension not in ("1d", "3d"):
@@ -1056,872 +1044,46 @@ class inputs:
             raise Exception("Need to set gravity with the gravity() function")
         return picaso(self, opacityclass, dimension=dimension, calculation=calculation,
                       full_output=full_output, plot_opacity=plot_opacity, as_dict=as_dict, devices=devices,
-                      gather=gather)
-
-
-def _resident_vector(opa, name, value, nwno):
-    """Per-wavelength vector (or a scalar broadcast to one) in HBM, kept on the opacity object while its
-    content does not change: a retrieval calls spectrum() with the same grid, stellar spectrum and
-    surface reflectivity thousands of times (3 x 0.8 MB of H2D per call at 1e5 wavelengths)."""
-    cache = opa.__dict__.setdefault("_resident_vectors", {})
-    hit = cache.get(name)
-    if np.ndim(value) == 0:                        # a scalar: compared as one (no 1e5-element array per call)
-        key = float(value)
-        # (the tag of an array entry is the ndarray itself: compare tuples only)
-        if hit is not None and isinstance(hit[2], tuple) and hit[2] == ("scalar", key, nwno):
-            return hit[1]
-        a = np.full(nwno, key)
-        tag = ("scalar", key, nwno)
-    else:
-        if name == "wno" and hit is not None and not isinstance(hit[2], tuple) and hit[2] is value:    # the opacity object's own grid: never edited
-            return hit[1]
-        a = np.ascontiguousarray(np.zeros(nwno) + np.asarray(value, dtype=float))
-        if hit is not None and hit[0] is not None and hit[0].shape == a.shape and np.array_equal(hit[0], a):
-            cache[name] = (hit[0], hit[1], value)
-            return hit[1]
-        tag = value
-    d = DeviceArray.from_host(a, opa.ctx)
-    cache[name] = (a.copy(), d, tag)
-    return d
-
-
-def _ones(opa, nwno):
-    """``np.zeros(nwno) + 1.0`` (the reference's F0PI without a star, justdoit.py:174-175), kept on the opacity object
-    and read-only: nothing on the path writes to F0PI."""
-    hit = opa.__dict__.get("_ones")
-    if hit is None or hit.shape != (nwno,):
-        hit = np.zeros(nwno) + 1.0
-        hit.flags.writeable = False
-        opa.__dict__["_ones"] = hit
-    return hit
-
-
-def _cloud_free_top(inp, nlayer):
-    """Number of layers above the cloud deck: the first layer whose cloud profile rows hold any optical depth or any
-    asymmetry (COSB is the cloud's g0 itself, optics.py:338, so a g0 without optical depth still delta-scales the layer).
-    Read off the profile AS GIVEN (linear regridding keeps a zero row zero); tables larger than 2e5 numbers are not
-    scanned (0: no statement) -- the scan would cost more than it saves."""
-    prof = inp["clouds"]["profile"]
-    if prof is None:
-        return nlayer
-    busy = np.zeros(nlayer, dtype=bool)
-    for k in ("opd", "g0"):
-        v = np.asarray(prof[k], dtype=np.float64)
-        if v.ndim == 0:
-            return 0 if v != 0 else nlayer
-        if v.size > 200000 or v.size % nlayer:
-            return 0
-        busy |= (v.reshape(nlayer, -1) != 0).any(axis=1)
-    return int(np.argmax(busy)) if busy.any() else nlayer
-
-
-def _constant_planes(opa, nlayer, nwno):
-    """Resident ``(nlayer, nwno)`` planes of 0, 1 and 0.5, kept on the opacity object: what ``compute_opacity``
-    writes into cosb / cosb_og / ftau_cld, ftau_ray and gcos2 for an atmosphere without cloud."""
-    cache = opa.__dict__.setdefault("_const_planes", {})
-    key = (nlayer, nwno)
-    if key not in cache:
-        cache[key] = (DeviceArray.zeros((nlayer, nwno), opa.ctx),
-                      DeviceArray.from_host(np.ones((nlayer, nwno)), opa.ctx),
-                      DeviceArray.from_host(np.full((nlayer, nwno), 0.5), opa.ctx))
-    return cache[key]
-
-
-def _setup_atmosphere(inp, opa, wno, profile=None, cloud_profile=None):
-    """ATMSETUP sequence of the reference's ``picaso()`` (justdoit.py:180-243) for the 1-D profile
-    or, in the 3-D path, for one facet's profile (``atm_1d.disect(g,t)``, justdoit.py:446-449)."""
-    if profile is None:                    # the whole set-up in one C call where it applies (fastsetup.py)
-        fast = fastsetup.setup(inp, opa, wno)
-        if fast is not None:
-            return fast
-    elif cloud_profile is None and all(getattr(v, "ndim", 0) == 2 for v in profile.values()):      # facet form (3-D path)
-        fast = fastsetup.setup_facets(inp, opa, wno, profile)
-        if fast is not None:
-            return fast
-    cfg = inp
-    if profile is not None:
-        cfg = dict(inp)
-        cfg["atmosphere"] = dict(inp["atmosphere"], profile=profile)
-        cfg["clouds"] = dict(inp["clouds"], profile=cloud_profile)
-    atm = ATMSETUP(cfg)
-    atm.surf_reflect = inp.get("surface_reflect", 0)
-    atm.hard_surface = inp.get("hard_surface", 0)
-    atm.wavenumber = wno
-    atm.planet.gravity = inp["planet"]["gravity"]
-    atm.planet.radius = inp["planet"]["radius"]
-    atm.planet.mass = inp["planet"]["mass"]
-    atm.get_lvl_flux = inp["approx"].get("get_lvl_flux", False)
-    atm.get_profile()
-    atm.get_mmw()
-    atm.get_density()
-    atm.get_altitude(p_reference=inp["approx"]["p_reference"])
-    atm.get_column_density()
-    atm.get_needed_continuum(opa.rayleigh_molecules, opa.avail_continuum)
-    atm.get_clouds(wno)
-    no_opa = [m for m in atm.molecules if m not in opa.molecules]
-    if no_opa:
-        atm.add_warnings("I found chemistry for these but I do not have computed individual line "
-                         "opacities (not including continuum) for: " + ",".join(no_opa))
-    atm.molecules = np.array([m for m in atm.molecules if m not in no_opa])
-    return atm
+                      gather=gather, options=options)
 
 
 def picaso(bundle, opacityclass, dimension="1d", calculation="reflected", full_output=False,
-           plot_opacity=False, as_dict=True, defer=False, devices=None, gather="host", _raw=False, _shared=None,
-           _batch=None):
-    """Spectrum driver (reference ``picaso()``, justdoit.py:65-621, 1-D Toon branch).
+           plot_opacity=False, as_dict=True, defer=False, devices=None, gather="host", options=None, _raw=False,
+           _shared=None, _batch=None):
+    """Spectrum driver (reference ``picaso()``, justdoit.py:65-621).
 
-    ``defer=True`` (used by ``phase_curve``): every kernel of the spectrum is enqueued and a function is
-    returned that copies the results back and finishes the output dictionary -- the caller can enqueue
-    the next spectrum while the GPU is still working on this one.
+    The work is ``spectrum.Spectrum``: plan (ATMSETUP, opacity planes) -> enqueue (every leg's solver launches) ->
+    finish (results back, integrals, the output dictionary), the same three stages for Toon / SH, 1-D / 3-D,
+    monochromatic / correlated-k tables, patchy clouds, level fluxes.  In front of it sit two shortcuts with the same
+    results bit for bit: the plain 1-D Toon spectrum goes through ONE C call (``_picaso_driver``, csrc/driver.hip), and
+    ``devices=N`` cuts the grid into N wavelength blocks, one per GPU (``_picaso_devices``).
 
-    ``devices=N`` (or a list of device indices): the wavelength grid of this ONE spectrum is cut into N
-    contiguous blocks, one per GPU, each with its opacity tables and planes resident on its own device; see
-    ``_picaso_devices``."""
+    ``defer=True`` (used by ``phase_curve`` / ``spectrum_batch`` / the block loop of ``devices=``): every kernel of the
+    spectrum is enqueued and the ``Spectrum`` is returned; calling it copies the results back and finishes the output
+    dictionary -- the caller can enqueue the next spectrum while the GPU is still working on this one.
+    ``options``: an ``options.Options`` (A/B and test switches; default: from the environment)."""
+    opt = _options.current(options)
     if devices is not None:
         return _picaso_devices(bundle, opacityclass, devices, gather, dimension=dimension, calculation=calculation,
-                               full_output=full_output, plot_opacity=plot_opacity, as_dict=as_dict, defer=defer)
+                               full_output=full_output, plot_opacity=plot_opacity, as_dict=as_dict, defer=defer, opt=opt)
     if dimension == "1d" and not (full_output or defer or _raw or plot_opacity) and _shared is None and _batch is None:
-        fast = _picaso_driver(bundle, opacityclass, [(0, opacityclass.nwno, opacityclass)], calculation)
+        fast = _picaso_driver(bundle, opacityclass, [(0, opacityclass.nwno, opacityclass)], calculation, opt)
         if fast is not None:
             return fast
-    inp = bundle.inputs
-    opa = opacityclass
-    ctx = opa.ctx
-    wno, nwno = opa.wno, opa.nwno
-    ngauss = opa.ngauss
-    common = inp["approx"]["rt_params"]["common"]
-    toon = inp["approx"]["rt_params"]["toon"]
-    frac_a, frac_b, frac_c = common["TTHG_params"]["fraction"]
-    constant_back = common["TTHG_params"]["constant_back"]
-    constant_forward = common["TTHG_params"]["constant_forward"]
-    geom = inp["disco"]
-    ng, nt = geom["num_gangle"], geom["num_tangle"]
-    gweight, tweight = geom["gweight"], geom["tweight"]
-    cos_theta, ubar0, ubar1 = geom["cos_theta"], geom["ubar0"], geom["ubar1"]
-    if inp["star"]["database"] == "nostar":
-        F0PI = np.zeros(nwno) + 1.0                           # justdoit.py:174-175
-    else:
-        F0PI = inp["star"]["relative_flux"]
-    stellar = getattr(opa, "unshifted_stellar_spec", None)
-    if stellar is None:
-        stellar = F0PI
-    b_top = 0.0
-    sa = inp["star"]["semi_major"]
-    radius_star = inp["star"]["radius"]
+    s = Spectrum(bundle, opacityclass, dimension=dimension, calculation=calculation, full_output=full_output,
+                 as_dict=as_dict, raw=_raw, shared=_shared, batch=_batch, options=opt)
+    s.plan().enqueue()
+    return s if defer else s.finish()
 
-    do_holes = bool(inp["clouds"].get("do_holes", False))
-    is_sh = inp["approx"]["rt_method"] == "SH"
-    planes3d = tlev3 = plev3 = None
-    if dimension == "3d":                                      # justdoit.py:407-471
-        if is_sh or ngauss > 1 or do_holes or inp["approx"].get("get_lvl_flux", False):
-            raise Exception("dimension='3d' is built for rt_method='toon', monochromatic opacities, "
-                            "no patchy clouds and no level fluxes")
-        prof3 = inp["atmosphere"]["profile_3d"]
-        cld3 = inp["clouds"].get("profile_3d")
-        if isinstance(cld3, dict) and cld3.get("wavenumber") is not None and not (
-                len(cld3["wavenumber"]) == len(wno) and np.array_equal(cld3["wavenumber"], wno)) and os.environ.get("PICASO_AMD_HOST_REGRID"):
-            # a cloud dataset on its own wavenumber grid (clouds_3d(ds)): onto the opacity grid, linear in wavenumber
-            # like the reference's per-facet get_clouds -> wavelength.regrid (atmsetup.py:609-622).  Normally on the
-            # device (compute_opacity_facets: numpy.interp's bits); here the host form of the same interpolation
-            cld3 = dict(cld3, **{k: _interp_axis(wno, cld3["wavenumber"], np.asarray(cld3[k], dtype=float), 1)
-                                 for k in ("opd", "w0", "g0")})
-            cld3.pop("wavenumber")
-        # Only planes that cannot be re-derived exactly inside the solvers are written (each is nfacets x 9 MB
-        # at 12 500 wavelengths x 90 layers): the level optical depths are running sums and gcos2 is
-        # 0.5 ftau_ray, so the reflected kernel takes 8 planes instead of 11; without cloud (and outside the
-        # test modes) cosb = cosb_og = ftau_cld = 0, ftau_ray = 1 and the delta-scaling is the identity, which
-        # leaves dtau and w0 -- and w0_no_raman equals w0 when the Raman factor is the constant 0.99999
-        # (raman='none').  PICASO_AMD_ALL_PLANES=1 writes and reads the full set (A/B, tests).
-        clear3 = cld3 is None and inp["test_mode"] is None and not os.environ.get("PICASO_AMD_ALL_PLANES")
-        lean3 = not os.environ.get("PICASO_AMD_ALL_PLANES")
-        want3 = set()
-        th3 = ("dtau_og", "w0_no_raman", "cosb_og")
-        if "reflected" in calculation:
-            if clear3:
-                want3 |= {"dtau", "w0"}
-            elif lean3:
-                want3 |= set(resident.REFLECTED_PLANES) - {"tau", "tau_og", "gcos2"}
-            else:
-                want3 |= set(resident.REFLECTED_PLANES)
-        if "thermal" in calculation:
-            if clear3:
-                th3 = ("dtau", "w0" if (common["raman"] == 2 and "reflected" in calculation) else "w0_no_raman", None)
-            want3 |= {k for k in th3 if k is not None}
-        co3 = dict(stream=common["stream"], delta_eddington=common["delta_eddington"], test_mode=inp["test_mode"],
-                   raman=common["raman"], clouds_3d=cld3, exclude_mol=inp["atmosphere"]["exclude_mol"], want=want3)
-        if os.environ.get("PICASO_AMD_FACET_LOOP"):           # A/B: one ATMSETUP + one gas launch per facet
-            atms = []
-            for g in range(ng):
-                row = []
-                for t in range(nt):
-                    prof = {k: (v if v.ndim == 1 else v[:, g, t]) for k, v in prof3.items()}
-                    row.append(_setup_atmosphere(inp, opa, wno, prof, None))
-                atms.append(row)
-            atm = atms[0][0]
-            planes3d = optics.compute_opacity_facets(atms, opa, ng, nt, **co3)
-            tlev3 = np.stack([np.stack([a_.level["temperature"] for a_ in row], axis=1) for row in atms], axis=1)
-            plev3 = np.stack([np.stack([a_.level["pressure"] for a_ in row], axis=1) for row in atms], axis=1)
-        else:
-            # all facets in ONE facet-form ATMSETUP ((nlevel, nfacets) columns; the reference builds one
-            # per facet, justdoit.py:437-449) and one batched gas stage
-            nfac, nlv = ng * nt, len(prof3["pressure"])
-            prof_f = {}
-            for k, v in prof3.items():
-                if k == "temperature":
-                    prof_f[k] = np.ascontiguousarray(np.broadcast_to(v.reshape(nlv, -1), (nlv, nfac)))
-                else:
-                    prof_f[k] = v.reshape(nlv, -1)            # (nlevel, 1) shared or (nlevel, nfacets)
-            atm_f = _setup_atmosphere(inp, opa, wno, prof_f, None)
-            atm = _setup_atmosphere(inp, opa, wno, {k: (v if v.ndim == 1 else v[:, 0, 0]) for k, v in prof3.items()},
-                                    None)                     # facet (0, 0): sizes, surface, full_output
-            tabs3 = None
-            if (not clear3 and lean3 and cld3 is not None and inp["test_mode"] is None and not full_output
-                    and not os.environ.get("PICASO_AMD_FACET_FASTEST") and not os.environ.get("PICASO_AMD_HOST_REGRID")):
-                tabs3 = optics._facet_major_cloud_tables(cld3, nlv - 1, nfac, ctx)   # tables on their own grid, else None
-            if (clear3 or tabs3 is not None) and not full_output and not os.environ.get("PICASO_AMD_FACET_FASTEST"):
-                # the planes in facet-major layout straight from ONE fused gas + mixing launch over all facets (no cloud:
-                # two or three of them; cloud tables on their own grid: interpolated inside that launch); the solvers take
-                # every facet as a spectrum of its own (resident.*_3d_fm_batch: same bits)
-                planes3d = optics.compute_opacity_facet_major(
-                    atm_f, opa, ng, nt, stream=common["stream"], delta_eddington=common["delta_eddington"],
-                    raman=common["raman"], exclude_mol=inp["atmosphere"]["exclude_mol"], want=want3, cloud_tables=tabs3)
-            else:
-                planes3d = optics.compute_opacity_facets(atm_f, opa, ng, nt, **co3)
-            tlev3 = atm_f.level["temperature"].reshape(nlv, ng, nt)
-            plev3 = np.ascontiguousarray(np.broadcast_to(atm_f.level["pressure"].reshape(nlv, 1, 1), (nlv, ng, nt)))
-    elif _shared is not None:
-        atm = _atmosphere_block(_shared["atm"], _shared["lo"], _shared["hi"], wno)
-    else:
-        atm = _setup_atmosphere(inp, opa, wno)
-    nlevel, nlayer = atm.c.nlevel, atm.c.nlayer
-
-    fhole = planes = planes_clear = rplanes = None
-    gauss_wts = np.asarray(opa.gauss_wts, dtype=float)
-    if dimension == "1d":
-        if _shared is not None and _shared.get("plan") is not None:
-            opa._plan = _shared["plan"]         # table rows / weights per layer: the same for every wavelength block
-        else:
-            opa.get_opacities(atm, exclude_mol=inp["atmosphere"]["exclude_mol"])
-        # only the planes the requested legs read are written (toon: 11 for reflected light, 3 for
-        # thermal emission, 1 for transmission; the SH solvers take the whole set)
-        want = None
-        # planes the reflected kernels re-derive exactly are not written at all where the launch can do so (default
-        # options; resident.reflected_can_derive): tau, tau_og (running sums), gcos2 (0.5 ftau_ray)
-        derive = (not is_sh and ngauss == 1 and "reflected" in calculation and not do_holes and inp["test_mode"] is None
-                  and not full_output and not os.environ.get("PICASO_AMD_ALL_PLANES")
-                  and resident.reflected_can_derive(nlevel, nwno, ng, nt, ubar0, ubar1, cos_theta, toon["single_phase"],
-                                                    toon["multi_phase"], frac_c, toon["toon_coefficients"],
-                                                    atm.get_lvl_flux))
-        if not is_sh:
-            want = set()
-            if "reflected" in calculation:
-                want |= set(resident.REFLECTED_PLANES)
-                if derive:
-                    want -= {"tau", "tau_og", "gcos2"}
-            if "thermal" in calculation:
-                want |= {"dtau_og", "w0_no_raman", "cosb_og"}
-            if "transmission" in calculation:
-                want |= {"dtau_og"}
-        # Cloud-free atmosphere (no cloud profile, no test mode): most of the 13 planes are exact copies of others or
-        # constants -- cosb = cosb_og = ftau_cld = 0, ftau_ray = 1, gcos2 = 0.5, and with cosb = 0 the delta-scaling is
-        # the identity (dtau_og = dtau, tau_og = tau, w0_og = w0) -- so only dtau, tau and w0 are written (0.26 ->
-        # 0.09 ms of mixing at 1e5 x 90) and the solvers get the same buffer under several names plus three
-        # constant planes kept on the opacity object: same values, hence the same bits, as the full set (the 3-D
-        # path does the equivalent inside its kernels; PICASO_AMD_ALL_PLANES=1 writes everything, tests).
-        lean = (not is_sh and ngauss == 1 and getattr(atm, "cloud_free", False) and inp["test_mode"] is None
-                and not do_holes and len(getattr(atm, "rayleigh_molecules", [])) > 0
-                and not os.environ.get("PICASO_AMD_ALL_PLANES"))
-        # SH4 with the reference's default forms, same atmosphere: dtau and w0 are all the cloud-free SH launch reads
-        # (resident.reflected_SH_can_derive; the angle-independent half of a layer shared between the disk angles);
-        # the thermal SH solver reads dtau, w0 and cosb_og (= 0)
-        sh_lean, sh_top = False, 0
-        if is_sh:
-            sh_o = inp["approx"]["rt_params"]["SH"]
-            sh_lean = (ngauss == 1 and getattr(atm, "cloud_free", False) and inp["test_mode"] is None and not do_holes
-                       and not full_output and len(getattr(atm, "rayleigh_molecules", [])) > 0
-                       and not os.environ.get("PICASO_AMD_ALL_PLANES")
-                       and resident.reflected_SH_can_derive(
-                           common["stream"], sh_o["w_single_form"], sh_o["w_multi_form"], sh_o["psingle_form"],
-                           sh_o["w_single_rayleigh"], sh_o["w_multi_rayleigh"], sh_o["psingle_rayleigh"], frac_c,
-                           sh_o["single_form"], 1 if sh_o["calculate_fluxes"] else 0))
-            if sh_lean:
-                want = {"dtau", "w0"}
-            elif (ngauss == 1 and inp["test_mode"] is None and not do_holes and len(getattr(atm, "rayleigh_molecules", [])) > 0
-                  and not os.environ.get("PICASO_AMD_ALL_PLANES")):
-                # a cloud deck: the layers above it are swept by the cloud-free kernel (picaso_get_reflected_SH_top_dev;
-                # every wavelength block of a sharded spectrum reads the same profile, hence the same statement)
-                sh_top = _cloud_free_top(inp, nlayer)
-        th_w0 = "w0_no_raman"
-        if lean:
-            want = set()
-            if "reflected" in calculation:
-                want |= {"dtau", "w0"} if derive else {"dtau", "tau", "w0"}
-            if "thermal" in calculation:
-                th_w0 = "w0" if (common["raman"] == 2 and "reflected" in calculation) else "w0_no_raman"
-                want |= {"dtau", th_w0}
-            if "transmission" in calculation:
-                want |= {"dtau"}
-        co_kw = dict(ngauss=ngauss, stream=common["stream"], delta_eddington=common["delta_eddington"],
-                     test_mode=inp["test_mode"], raman=common["raman"], full_output=full_output, want=want)
-        planes = optics.compute_opacity_resident(atm, opa, **co_kw)
-        if lean and derive:
-            # the reflected kernel gets dtau and w0 only (everything else re-derived); the thermal one its three names
-            zero, _, _ = _constant_planes(opa, nlayer, nwno)
-            rplanes = {"dtau": planes["dtau"], "w0": planes["w0"]}
-            planes.update(dtau_og=planes["dtau"], cosb_og=zero)
-            if th_w0 == "w0":
-                planes["w0_no_raman"] = planes["w0"]
-        elif sh_lean:
-            zero, _, _ = _constant_planes(opa, nlayer, nwno)
-            rplanes = {"dtau": planes["dtau"], "w0": planes["w0"]}
-            planes = dict(rplanes, cosb_og=zero)
-        elif lean:
-            zero, one, half = _constant_planes(opa, nlayer, nwno)
-            planes.update(dtau_og=planes["dtau"], cosb=zero, cosb_og=zero, ftau_cld=zero, ftau_ray=one, gcos2=half)
-            if "tau" in planes:
-                planes.update(tau_og=planes["tau"], w0_og=planes["w0"])
-            if th_w0 == "w0":
-                planes["w0_no_raman"] = planes["w0"]
-        # patchy clouds (justdoit.py:139-142, 248-252): a second, thinned-cloud column set
-        if do_holes:
-            fhole = float(inp["clouds"]["fhole"])
-            planes_clear = optics.compute_opacity_resident(atm, opa, fthin_cld=inp["clouds"]["fthin_cld"],
-                                                           do_holes=True, **co_kw)
-        if is_sh and (ngauss > 1 or do_holes):
-            raise Exception("rt_method='SH' with correlated-k tables or patchy clouds is not built; use 'toon'")
-
-    rs = _resident_vector(opa, "surf_reflect", atm.surf_reflect, nwno)
-    d_f0 = _resident_vector(opa, "F0PI", 1.0 if inp["star"]["database"] == "nostar" else F0PI, nwno)
-    # Spectra (Toon, SH, 3-D) with both legs: the thermal kernels go to a second stream that waits for the
-    # opacity planes only, so they run next to the reflected-light kernel (each of the two alone
-    # leaves SIMDs idle through its tail, DESIGN.md section 6) instead of behind it
-    tctx = ctx
-    if ("reflected" in calculation and "thermal" in calculation and (dimension == "1d" or _batch is None)
-            and os.environ.get("PICASO_AMD_OVERLAP_LEGS", "1") != "0"):
-        tctx = _lib.aux_context(_lib.device_of(ctx))     # one per process and device, shared by every caller
-        _lib.ctx_wait(tctx, ctx)                         # (in a batch: every member's, so the last one covers the launch)
-    returns = {"wavenumber": wno}
-    dev_results = {}          # per-wavelength results still in HBM (the multi-GPU form gathers them with RCCL)
-    prefetched = {}           # result copies already on the stream (finish.prefetch)
-    enqueued = False
-    try:
-        # every leg first enqueues its kernels; the copies back (each a stream synchronisation) and the
-        # host-side integrals run afterwards, so the GPU goes through reflected + thermal (+ transit)
-        # back to back while the host is still preparing the next launch
-        collect = []
-        if "reflected" in calculation:
-            xint = DeviceArray((ng, nt, nwno), ctx)
-            alb_x = DeviceArray((nwno + 1,), ctx)         # [nwno]: the Bond-albedo integral (finish.prefetch)
-            alb = alb_x.head(nwno)
-            lvl = None
-            if dimension == "3d" and _batch is not None:          # phase_curve(): one launch for a chunk of phases
-                tt3 = (toon["single_phase"], toon["multi_phase"], frac_a, frac_b, frac_c, constant_back, constant_forward)
-                present = tuple(k for k in resident.REFLECTED_PLANES if planes3d.get(k) is not None)
-                present += ("facet-major",) if planes3d.get("_fm") else ()
-                _batch.add_reflected_3d((nlevel, nwno, ng, nt, tt3, present, tuple(gweight), tuple(tweight)),
-                                        dict(ctx=ctx, planes=planes3d, rs=rs, ubar0=ubar0, ubar1=ubar1,
-                                             cos_theta=cos_theta, F0PI=d_f0, xint=xint, albedo=alb))
-            elif dimension == "3d":                               # justdoit.py:488-500
-                (resident.reflected_3d if not planes3d.get("_fm") else _reflected_3d_fm)(
-                    ctx, nlevel, nwno, ng, nt, planes3d, rs, ubar0, ubar1, cos_theta, d_f0,
-                                      toon["single_phase"], toon["multi_phase"], frac_a, frac_b, frac_c,
-                                      constant_back, constant_forward, xint, gweight, tweight, alb)
-            elif is_sh:                                           # justdoit.py:259-269
-                sh_opt = inp["approx"]["rt_params"]["SH"]
-                sh_flux = None                                    # layer moment fluxes, flx = calculate_fluxes
-                if sh_opt["calculate_fluxes"]:
-                    sh_flux = DeviceArray((ng, nt, common["stream"] * nlevel, nwno), ctx)
-                _reflected_sh(ctx, nlevel, nwno, ng, nt, rplanes if rplanes is not None else planes, rs, ubar0, ubar1,
-                              cos_theta, d_f0,
-                              sh_opt, frac_a, frac_b, frac_c, constant_back, constant_forward,
-                              common["stream"], b_top, xint, gweight, tweight, alb, sh_flux, cloud_free_above=sh_top)
-                if sh_flux is not None:
-                    atm.flux_layers = sh_flux.to_host()
-            else:
-                lvl = [DeviceArray((ng, nt, nlevel, nwno), ctx) for _ in range(4)] if atm.get_lvl_flux else None
-                tt = (toon["single_phase"], toon["multi_phase"], frac_a, frac_b, frac_c, constant_back,
-                      constant_forward)
-
-                def run(pl, x, lv, fuse):                         # the ngauss loop of justdoit.py:256-307
-                    if ngauss > 1:
-                        resident.reflected_1d_ck(ctx, nlevel, nwno, ngauss, ng, nt, pl, rs, ubar0, ubar1,
-                                                 cos_theta, d_f0, *tt, gauss_wts, x,
-                                                 toon_coefficients=toon["toon_coefficients"], b_top=b_top,
-                                                 gweight=gweight if fuse else None,
-                                                 tweight=tweight if fuse else None, albedo=alb if fuse else None,
-                                                 lvl_fluxes=lv)
-                    elif _batch is not None and lv is None and fuse:
-                        # spectrum_batch(): the launch is issued later, together with the other spectra's
-                        _batch.add_reflected(
-                            (nlevel, nwno, ng, nt, tt, toon["toon_coefficients"], b_top, tuple(gweight), tuple(tweight),
-                             tuple(k_ for k_ in resident.REFLECTED_PLANES if pl.get(k_) is not None)),
-                            dict(ctx=ctx, planes=pl, rs=rs, ubar0=ubar0, ubar1=ubar1, cos_theta=cos_theta, F0PI=d_f0,
-                                 xint=x, albedo=alb))
-                    else:
-                        _reflected(ctx, nlevel, nwno, ng, nt, pl, rs, ubar0, ubar1, cos_theta, d_f0, *tt,
-                                   toon["toon_coefficients"], b_top, x, lv, gweight, tweight,
-                                   alb if fuse else None)
-                if not do_holes:
-                    run(rplanes if rplanes is not None else planes, xint, lvl, True)
-                else:                                             # justdoit.py:287-305
-                    xc = DeviceArray((ng, nt, nwno), ctx)
-                    lvc = [DeviceArray((ng, nt, nlevel, nwno), ctx) for _ in range(4)] if lvl else None
-                    run(planes, xint, lvl, False)
-                    run(planes_clear, xc, lvc, False)
-                    resident.axpby(ctx, 1.0 - fhole, xint, fhole, xc, xint)
-                    for a_, b_ in zip(lvl or [], lvc or []):
-                        resident.axpby(ctx, 1.0 - fhole, a_, fhole, b_, a_)
-                    resident.compress_disco(ctx, nwno, cos_theta, xint, gweight, tweight, d_f0, alb)
-
-            dev_results["albedo"] = alb
-
-            def collect_reflected():          # read back after every leg has been enqueued (see `collect`)
-                albedo = _fetch(prefetched, "albedo", alb, returns, "bond_integral")
-                returns["albedo"] = albedo
-                if full_output:
-                    atm.xint_at_top = xint.to_host()
-                if lvl is not None:
-                    # justdoit.py:536-548: every level disk-integrated with compress_disco(..., F0PI = 1):
-                    # (nlevel, nwno) arrays; on the device over nlevel*nwno columns (F0PI = None means 1)
-                    atm.lvl_output_reflected = {}
-                    for key, a_ in zip(("flux_minus", "flux_plus", "flux_minus_mdpt", "flux_plus_mdpt"), lvl):
-                        dsum = DeviceArray((nlevel, nwno), ctx)
-                        resident.compress_disco(ctx, nlevel * nwno, cos_theta, a_, gweight, tweight, None, dsum)
-                        atm.lvl_output_reflected[key] = dsum.to_host()
-            collect.append(collect_reflected)
-        if "thermal" in calculation:
-            d_wno = _resident_vector(opa, "wno", wno, nwno)
-            flux = DeviceArray((ng, nt, nwno), tctx)
-            disk_x = DeviceArray((nwno + 1,), tctx)       # [nwno]: the effective-temperature integral
-            disk = disk_x.head(nwno)
-            if dimension == "3d" and _batch is not None:
-                _batch.add_thermal_3d((nlevel, nwno, ng, nt, int(atm.hard_surface), d_wno.addr,
-                                       (th3[2] is not None, bool(planes3d.get("_fm"))), tuple(gweight), tuple(tweight)),
-                                      dict(ctx=ctx, wno=d_wno, tlevel=np.array(tlev3, dtype=float),
-                                           plevel=np.array(plev3, dtype=float), dtau=planes3d[th3[0]],
-                                           w0=planes3d[th3[1]], cosb=planes3d[th3[2]] if th3[2] else None,
-                                           ubar1=ubar1, rs=rs, flux=flux, disk=disk, keep=planes3d))
-            elif dimension == "3d" and planes3d.get("_fm"):
-                resident.thermal_3d_fm_batch(tctx, nlevel, d_wno, nwno, ng, nt, np.asarray(tlev3, dtype=float)[None],
-                                             [planes3d[th3[0]]], [planes3d[th3[1]]],
-                                             [planes3d[th3[2]]] if th3[2] else None,
-                                             np.asarray(plev3, dtype=float)[None],
-                                             np.asarray(ubar1, dtype=float).reshape(1, ng, nt), [rs], atm.hard_surface,
-                                             [flux], gweight, tweight, [disk])
-            elif dimension == "3d":                               # justdoit.py:502-514
-                resident.thermal_3d(tctx, nlevel, d_wno, nwno, ng, nt, tlev3, planes3d[th3[0]],
-                                    planes3d[th3[1]], planes3d[th3[2]] if th3[2] else None, plev3, ubar1, rs,
-                                    atm.hard_surface, flux, gweight, tweight, disk)
-            elif is_sh:                                           # justdoit.py:364-370
-                _thermal_sh(tctx, nlevel, d_wno, nwno, ng, nt, atm.level["temperature"], planes,
-                            atm.level["pressure"], ubar1, rs, common["stream"], atm.hard_surface,
-                            common["delta_eddington"], flux, gweight, tweight, disk)
-            else:
-                # get_lvl_flux switches the thermal leg to calc_type = 1 with dwno = wno*0 (justdoit.py:322-327,
-                # :342): the bin-mean Planck function in wavenumber units, also for the top-of-atmosphere flux
-                tlvl = [DeviceArray((ng, nt, nlevel, nwno), tctx) for _ in range(4)] if atm.get_lvl_flux else None
-                tkw = {}
-                if tlvl is not None:
-                    tkw = dict(dwno=DeviceArray.zeros((nwno,), tctx), calc_type=1)
-
-                def runt(pl, fx, lv, fuse):                       # the ngauss loop of justdoit.py:328-380
-                    kw = dict(gweight=gweight, tweight=tweight, flux_disk=disk) if fuse else {}
-                    kw.update(tkw)
-                    if ngauss > 1:
-                        resident.thermal_1d_ck(tctx, nlevel, d_wno, nwno, ngauss, ng, nt, atm.level["temperature"],
-                                               pl["dtau_og"], pl["w0_no_raman"], pl["cosb_og"],
-                                               atm.level["pressure"], ubar1, rs, atm.hard_surface, gauss_wts,
-                                               fx, lvl_fluxes=lv, **kw)
-                    elif _batch is not None and lv is None and fuse and not tkw:
-                        _batch.add_thermal(
-                            (nlevel, nwno, ng, nt, int(atm.hard_surface), d_wno.addr, tuple(gweight), tuple(tweight)),
-                            dict(ctx=tctx, wno=d_wno, tlevel=np.array(atm.level["temperature"], dtype=float),
-                                 plevel=np.array(atm.level["pressure"], dtype=float), dtau=pl["dtau_og"],
-                                 w0=pl["w0_no_raman"], cosb=pl["cosb_og"], ubar1=ubar1, rs=rs, flux=fx, disk=disk))
-                    else:
-                        resident.thermal_1d(tctx, nlevel, d_wno, nwno, ng, nt, atm.level["temperature"],
-                                            pl["dtau_og"], pl["w0_no_raman"], pl["cosb_og"],
-                                            atm.level["pressure"], ubar1, rs, atm.hard_surface, fx, lvl_fluxes=lv, **kw)
-                if not do_holes:
-                    runt(planes, flux, tlvl, True)
-                else:                                             # justdoit.py:346-361
-                    fc = DeviceArray((ng, nt, nwno), tctx)
-                    tlvc = [DeviceArray((ng, nt, nlevel, nwno), tctx) for _ in range(4)] if tlvl else None
-                    runt(planes, flux, tlvl, False)
-                    runt(planes_clear, fc, tlvc, False)
-                    resident.axpby(tctx, 1.0 - fhole, flux, fhole, fc, flux)
-                    for a_, b_ in zip(tlvl or [], tlvc or []):
-                        resident.axpby(tctx, 1.0 - fhole, a_, fhole, b_, a_)
-                    resident.compress_thermal(tctx, nwno, flux, gweight, tweight, disk)
-                tlvl_disk = None
-                if tlvl is not None:                              # justdoit.py:575-580, disk sums on the device
-                    tlvl_disk = []
-                    for a_ in tlvl:
-                        dsum = DeviceArray((nlevel, nwno), tctx)
-                        resident.compress_thermal(tctx, nlevel * nwno, a_, gweight, tweight, dsum)
-                        tlvl_disk.append(dsum)
-
-            dev_results["thermal"] = disk
-
-            def collect_thermal():
-                returns["thermal"] = _fetch(prefetched, "thermal", disk, returns, "teff_integral")
-                if full_output:
-                    atm.flux_at_top = flux.to_host()
-                if dimension != "3d" and not is_sh and tlvl_disk is not None:
-                    # energy per wavenumber bin: disk-integrated level flux * delta_wno (justdoit.py:575-580)
-                    delta_wno = getattr(opa, "delta_wno", None)
-                    if delta_wno is None:
-                        delta_wno = np.concatenate((np.diff(wno), [np.diff(wno)[-1]]))
-                    atm.lvl_output_thermal = {
-                        key: a_.to_host() * delta_wno
-                        for key, a_ in zip(("flux_minus", "flux_plus", "flux_minus_mdpt", "flux_plus_mdpt"), tlvl_disk)}
-            collect.append(collect_thermal)
-        if "transmission" in calculation:                         # justdoit.py:388-405, :522-523
-            if dimension != "1d":
-                raise Exception("transmission is a 1-D calculation (the reference has no 3-D branch for it)")
-            if radius_star == "nostar" or np.isnan(radius_star) or np.isnan(atm.planet.radius):
-                raise Exception("transmission needs the stellar radius (star()) and the planet radius and "
-                                "mass (gravity())")
-            tr = DeviceArray((nwno,), ctx)
-
-            def runtr(pl, out):
-                resident.transit_1d_ck(ctx, atm.level["z"], atm.level["dz"], nlevel, nwno, ngauss, radius_star,
-                                       atm.layer["mmw"], atm.c.k_b, atm.c.amu, atm.level["pressure"],
-                                       atm.level["temperature"], atm.layer["colden"], pl["dtau_og"], gauss_wts, out)
-            runtr(planes, tr)
-            if do_holes:                                          # blend per Gauss point == blend of the sums
-                trc = DeviceArray((nwno,), ctx)
-                runtr(planes_clear, trc)
-                resident.axpby(ctx, 1.0 - fhole, tr, fhole, trc, tr)
-            dev_results["transit_depth"] = tr
-            collect.append(lambda: returns.__setitem__("transit_depth", tr.to_host()))
-        enqueued = True
-    finally:
-        # The thermal leg may run on a second stream (tctx) that reads the opacity planes of `ctx`.  The planes must
-        # not return to ctx's block cache while that stream may still read them: in the normal case the copies back
-        # (each a synchronisation of the stream that produced the result) have run by the time they are released --
-        # at the end of this call, or, with defer=True, when `finish` (which keeps them alive) is done.  Only an
-        # exception in between needs the explicit wait.  (A wait here on every call would also make the blocks of
-        # a multi-GPU spectrum, each enqueued with defer=True, take turns instead of running side by side.)
-        if tctx is not ctx and not enqueued:
-            try:
-                device.sync(tctx)
-            except Exception:
-                pass
-    # planes read from the second stream stay alive until the results are in; everything else returns to the
-    # context's block cache as soon as its kernels are enqueued (reuse is ordered on the stream: the phases of a
-    # phase curve recycle one set of plane blocks)
-    keep_alive = [planes, planes_clear, planes3d] if tctx is not ctx else []
-
-    def finish():
-        # Results are read back leg by leg (each copy waits for the stream that produced it) and a leg's spectrum-wide
-        # integrals run as soon as it has arrived: the Bond-albedo integral overlaps the thermal kernels still running
-        # on the second stream.  Same stages, same order of keys as _postprocess.
-        out = {"wavenumber": wno}
-        for fin in collect:
-            fin()
-            if _raw:
-                continue
-            if "albedo" in returns and "albedo" not in out:
-                _post_reflected(out, returns, wno, stellar, sa, atm.planet.radius, opa)
-            if "thermal" in returns and "thermal" not in out:
-                _post_thermal(out, returns, wno, stellar, radius_star, atm.planet.radius, opa)
-        del keep_alive[:]
-        if _raw:          # one wavelength block of a multi-GPU spectrum: the integrals need the whole grid
-            if full_output:
-                returns["full_output"] = atm.as_dict() if as_dict else atm
-            return returns
-        out = _post_final(out, returns)
-        if full_output:
-            out["full_output"] = atm.as_dict() if as_dict else atm
-        return out
-    def prefetch(post_ctx=None):
-        # spectrum_batch(): the copies of the per-wavelength results go on the stream NOW, behind this spectrum's solver
-        # launches, into pinned blocks; finish() then waits for these copies only, while the stream already holds the
-        # next spectra's launches.  ``post_ctx``: a context whose stream the caller has ordered behind the solvers
-        # (``ctx_wait``) -- the integrals (four launches that leave the chip empty) and the PCIe copies then run next to
-        # the following spectra's opacity kernels instead of in front of them
-        # ... preceded by the spectrum-wide integrals of the two results (numpy's bits: csrc/integrals.hip), each
-        # stored behind its vector so that one copy brings both
-        whole = not _raw and nwno > 1 and _shared is None and not os.environ.get("PICASO_AMD_HOST_INTEGRALS")
-        if "albedo" in dev_results and "albedo" not in prefetched:
-            src, denom = alb, None
-            if whole:
-                d_w, _ = _trapz_resident(opa, wno)
-                d_st = d_f0 if stellar is F0PI else _resident_vector(opa, "stellar", stellar, nwno)
-                denom = _bond_denominator(opa, wno, stellar, d_st)
-                resident.trapz(post_ctx or ctx, nwno, d_w, alb, alb_x.addr + 8 * nwno, mult=d_st)
-                src = alb_x
-            pc = post_ctx or src.ctx
-            prefetched["albedo"] = (src.to_host_async(device.PinnedArray(src.shape, pc), pc), denom)
-        if "thermal" in dev_results and "thermal" not in prefetched:
-            src = disk
-            if whole:
-                _, d_wr = _trapz_resident(opa, wno)
-                resident.trapz(post_ctx or tctx, nwno, d_wr, disk, disk_x.addr + 8 * nwno, reverse=True)
-                src = disk_x
-            pc = post_ctx or src.ctx
-            prefetched["thermal"] = (src.to_host_async(device.PinnedArray(src.shape, pc), pc), None)
-    finish.dev, finish.ctx, finish.tctx, finish.prefetch = dev_results, ctx, tctx, prefetch
-    if defer:
-        return finish
-    if not _raw and not os.environ.get("PICASO_AMD_SYNC_COPIES"):
-        # the call-by-call path (cloud tables on their own grid, Oklopcic Raman, SH, correlated-k, 3-D): integrals and
-        # result copies go on the streams behind each leg's kernels, as the C driver does for the plain Toon call
-        prefetch()
-    return finish()
 
 
 # ------------------------------------------------------------------------------------------------
 # one C call per spectrum (csrc/driver.hip): the launch sequence of the 1-D Toon path for every wavelength block
 # ------------------------------------------------------------------------------------------------
-def _reflected_3d_fm(ctx, nlevel, nwno, ng, nt, planes, rs, ubar0, ubar1, cos_theta, F0PI, single_phase, multi_phase,
-                     frac_a, frac_b, frac_c, constant_back, constant_forward, xint, gweight, tweight, albedo):
-    """``resident.reflected_3d`` for facet-major planes (one spectrum through ``reflected_3d_fm_batch``)."""
-    resident.reflected_3d_fm_batch(ctx, nlevel, nwno, ng, nt, [planes], [rs], np.asarray(ubar0, dtype=float).reshape(1, ng, nt),
-                                   np.asarray(ubar1, dtype=float).reshape(1, ng, nt), np.array([cos_theta], dtype=float),
-                                   [F0PI], single_phase, multi_phase, frac_a, frac_b, frac_c, constant_back,
-                                   constant_forward, [xint], gweight, tweight, [albedo])
-
-
-def _fetch(prefetched, key, dev, returns=None, integral=None):
-    """Host copy of the resident result ``dev``: the pinned block ``finish.prefetch`` put on the stream when there is
-    one (wait for that copy only), a synchronous copy otherwise.  A prefetched block one longer than the result carries
-    the result's spectrum-wide integral in its last element: stored as ``returns[integral]``."""
-    hit = prefetched.pop(key, None)
-    if hit is None:
-        return dev.to_host()
-    p, denom = hit
-    a = p.wait()
-    out = a[:dev.size].copy()
-    if a.size > dev.size:
-        returns[integral] = a[dev.size] if denom is None else (a[dev.size], denom)
-    p.free()
-    return out
-
-
-def _picaso_driver(bundle, opa, subs, calculation):
-    """``_driver_prepare`` + the C call + ``_driver_finish``; None when the call is outside what the driver covers."""
-    from . import driver as drv
-    p = _driver_prepare(bundle, opa, subs, calculation)
-    if p is None:
-        return None
-    try:
-        drv.enqueue(p["table"], p["job"])
-        return _driver_finish(p)
-    except BaseException:
-        drv.abandon(p["table"])
-        raise
-
-
-def _driver_prepare(bundle, opa, subs, calculation, slot=None):
-    """The 1-D Toon spectrum (reference justdoit.py:236-385, 552-599) through ``picaso_toon_spectrum_blocks``: ONE C
-    call enqueues gas stage -> ``compute_opacity`` -> reflected || thermal (+ fused disk sums) on every wavelength block
-    of ``subs`` (``[(lo, hi, opacity object of the block)]``; the whole grid on one GPU is one block), a second and third
-    copy the legs back.  Returns the output dictionary, or None when the call is outside what the driver covers
-    (correlated-k tables, SH, patchy clouds, level fluxes, full_output, transmission, Oklopcic Raman or cloud tables
-    on their own grid in a multi-block call, test modes) -- the caller then takes the call-by-call path, whose results these are bit for bit:
-    the C function chains the same entry points in the same order.
-    This half does everything up to the C call -- set-up, block table (``slot``: which of several tables of the same
-    signature, for spectra that are in flight together: ``spectrum_batch``), per-call pointers, job -- and returns what
-    the call and ``_driver_finish`` need."""
-    from . import driver as drv
-    if os.environ.get("PICASO_AMD_NO_DRIVER") or os.environ.get("PICASO_AMD_RAMAN_PLANES"):
-        return None
-    inp = bundle.inputs
-    legs = set(calculation.split("+"))
-    if not legs or not legs <= {"reflected", "thermal"}:
-        return None
-    if (inp["approx"]["rt_method"] == "SH" or opa.ngauss != 1 or getattr(opa, "on_fly", False)
-            or inp["clouds"].get("do_holes", False) or inp["approx"].get("get_lvl_flux", False)
-            or inp["test_mode"] is not None or not hasattr(opa, "_cia") or not hasattr(opa, "_ray")):
-        return None
-    common = inp["approx"]["rt_params"]["common"]
-    toon = inp["approx"]["rt_params"]["toon"]
-    raman = common["raman"]
-    if raman == 0 and (len(subs) != 1 or os.environ.get("PICASO_AMD_RAMAN_PLANES")):
-        return None                # Oklopcic's factor: a plane formed per call on the block's device; one block for now
-    wno, nwno = opa.wno, opa.nwno
-    atm = _setup_atmosphere(inp, opa, wno)
-    cld = atm.layer["cloud"]
-    cloud_free = bool(getattr(atm, "cloud_free", False))
-    # cloud tables on their own wavenumber grid (what virga and the box-cloud form of clouds() hand over): regridded on the
-    # device as in compute_opacity_resident, for ONE block over the grid
-    tables = not cloud_free and isinstance(cld, CloudTables)
-    if tables and (len(subs) != 1 or np.size(cld.wno) != nwno or os.environ.get("PICASO_AMD_HOST_REGRID")):
-        return None
-    nlevel, nlayer = atm.c.nlevel, atm.c.nlayer
-    opa.get_opacities(atm, exclude_mol=inp["atmosphere"]["exclude_mol"])
-    plan = opa._plan
-    if plan.get("premixed"):
-        return None
-    factors = optics._layer_factors(atm, opa)
-    plan["_factors"] = (atm.layer["mixingratios"], factors)
-    linear = opa.query_method == "linear"
-    do_r, do_t = "reflected" in legs, "thermal" in legs
-    geom = inp["disco"]
-    ng, nt = geom["num_gangle"], geom["num_tangle"]
-    frac_a, frac_b, frac_c = common["TTHG_params"]["fraction"]
-    # which planes compute_opacity writes: exactly picaso()'s choice (see there for the cloud-free form and for the
-    # planes the reflected kernels re-derive)
-    derive = (do_r and not os.environ.get("PICASO_AMD_ALL_PLANES")
-              and resident.reflected_can_derive(nlevel, nwno, ng, nt, geom["ubar0"], geom["ubar1"], geom["cos_theta"],
-                                                toon["single_phase"], toon["multi_phase"], frac_c,
-                                                toon["toon_coefficients"], False))
-    want = set()
-    if do_r:
-        want |= set(resident.REFLECTED_PLANES)
-        if derive:
-            want -= {"tau", "tau_og", "gcos2"}
-    if do_t:
-        want |= {"dtau_og", "w0_no_raman", "cosb_og"}
-    lean = (cloud_free and len(getattr(atm, "rayleigh_molecules", [])) > 0 and not os.environ.get("PICASO_AMD_ALL_PLANES"))
-    if lean:
-        want = set()
-        if do_r:
-            want |= {"dtau", "w0"} if derive else {"dtau", "tau", "w0"}
-        if do_t:
-            want |= {"dtau", "w0" if (raman == 2 and do_r) else "w0_no_raman"}
-    def table_ids(sub):          # a block table holds raw table addresses: replaced tables are a new signature
-        mt = sub._mol_log if linear else sub._mol_raw
-        return tuple(id(mt[m]) for m in plan["molecules"]) + tuple(id(sub._cia[p]) for p in plan["cia_pairs"])
-    key = (tuple((lo, hi, id(sub)) + table_ids(sub) for lo, hi, sub in subs), nlayer, ng, nt, tuple(plan["molecules"]),
-           tuple(plan["cia_pairs"]), tuple(factors[2]), linear, tuple(sorted(want)), lean, not cloud_free and not tables, do_r, do_t,
-           derive, slot)
-    cache = opa.__dict__.setdefault("_driver_tables", {})
-    table = cache.get(key)
-    if table is None:
-        if len(cache) > (8 if slot is None else 40):
-            cache.clear()
-        table = cache[key] = drv.BlockTable(subs, nlayer, ng, nt, plan["molecules"], plan["cia_pairs"], factors[2], linear,
-                                            want, lean, not cloud_free and not tables, do_r, do_t, _constant_planes, derive)
-    nostar = inp["star"]["database"] == "nostar"
-    F0PI = _ones(opa, nwno) if nostar else inp["star"]["relative_flux"]
-    stellar = getattr(opa, "unshifted_stellar_spec", None)
-    if stellar is None:
-        stellar = F0PI
-    sr = atm.surf_reflect
-    sr_full = np.ndim(sr) > 0 and np.size(sr) == nwno and nwno > 1
-    overlap = do_r and do_t and os.environ.get("PICASO_AMD_OVERLAP_LEGS", "1") != "0"
-    # one block over the grid: the spectrum-wide integrals are formed on the device behind each result vector and
-    # arrive with it (host arrays one element longer; the dictionary gets views of the first nwno)
-    integrals = len(subs) == 1 and nwno > 1 and not os.environ.get("PICASO_AMD_HOST_INTEGRALS")
-    returns, hold = {}, []
-    full = {}
-    if do_r:
-        full["albedo"] = np.empty(nwno + 1 if integrals else nwno)
-    if do_t:
-        full["thermal"] = np.empty(nwno + 1 if integrals else nwno)
-    dcld = dtab = None
-    if tables:
-        stack = cld.__dict__.get("_stack")
-        if stack is None:
-            stack = cld.__dict__["_stack"] = np.concatenate([cld.compact[k] for k in ("opd", "w0", "g0")])
-        if os.environ.get("PICASO_AMD_UNFUSED_OPACITY") or os.environ.get("PICASO_AMD_REGRID_PLANES"):
-            all3 = device.regrid_rows(cld.in_wno, stack, optics._wno_device(opa, cld.wno), opa.ctx).reshape((3, nlayer, nwno))
-            dcld = [all3.row_block(0), all3.row_block(1), all3.row_block(2)]
-            hold.append((all3, dcld))
-        else:           # interpolated inside the opacity launch: no regridded planes in HBM (same bits)
-            dtab = (int(np.size(cld.in_wno)),
-                    DeviceArray.from_host(np.ascontiguousarray(cld.in_wno, dtype=np.float64), opa.ctx),
-                    DeviceArray.from_host(np.ascontiguousarray(stack, dtype=np.float64), opa.ctx))
-            hold.append(dtab)
-    elif not cloud_free:
-        def plane(x):
-            a = np.asarray(x, dtype=float)
-            return a if (a.shape == (nlayer, nwno) and a.flags.c_contiguous) else \
-                np.ascontiguousarray(np.broadcast_to(a, (nlayer, nwno)))
-        hcld = [plane(cld[k]) for k in ("opd", "w0", "g0")]
-        hold.append(hcld)
-    seen_dev = {}
-    for b, (lo, hi, sub) in enumerate(subs):
-        k = table.blocks[b]
-        nw = hi - lo
-        rs = _resident_vector(sub, "surf_reflect", np.asarray(sr, dtype=float).reshape(nwno)[lo:hi] if sr_full else sr, nw)
-        f0 = _resident_vector(sub, "F0PI", 1.0 if nostar else (F0PI if len(subs) == 1 else F0PI[lo:hi]), nw)
-        k.surf_reflect, k.F0PI = drv._dev(rs), drv._dev(f0)
-        hold.append((rs, f0))            # the block holds raw addresses: the vectors live as long as the call is in flight
-        if raman == 1:
-            row, _ = optics.raman_device(atm, sub, 1)
-            k.raman = drv._dev(row)
-        elif raman == 0:           # (nlayer, nwno) plane from the layer temperatures (picaso_raman_oklopcic_dev), same stream
-            rplane, _ = optics.raman_device(atm, sub, 0)
-            hold.append(rplane)
-            k.raman = drv._dev(rplane)
-        else:
-            k.raman = None
-        k.cld_tab_nin, k.cld_tab_xp, k.cld_tab_fp = 0, None, None
-        if dtab is not None:
-            k.cld_opd = k.cld_w0 = k.cld_g0 = None
-            k.cld_host_opd = k.cld_host_w0 = k.cld_host_g0 = None
-            k.cld_tab_nin, k.cld_tab_xp, k.cld_tab_fp = dtab[0], drv._dev(dtab[1]), drv._dev(dtab[2])
-            k.wno = drv._dev(_resident_vector(sub, "wno", sub.wno, nw))
-        elif dcld is not None:
-            k.cld_opd, k.cld_w0, k.cld_g0 = (drv._dev(x) for x in dcld)
-            k.cld_host_opd = k.cld_host_w0 = k.cld_host_g0 = None
-        elif not cloud_free:
-            k.cld_opd = k.cld_w0 = k.cld_g0 = None
-            k.cld_host_opd, k.cld_host_w0, k.cld_host_g0 = (drv._host(h) for h in hcld)
-            k.cld_host_pitch = nwno
-        else:
-            k.cld_opd = k.cld_w0 = k.cld_g0 = None
-            k.cld_host_opd = k.cld_host_w0 = k.cld_host_g0 = None
-        tctx = sub.ctx
-        if do_t:
-            if overlap:
-                dev = _lib.device_of(sub.ctx)
-                tctx = _lib.aux_context(dev, seen_dev.get(dev, 0))       # blocks that share a device: a stream each
-                seen_dev[dev] = seen_dev.get(dev, 0) + 1
-            k.tctx = tctx.value if hasattr(tctx, "value") else tctx
-            fl, dk, pin = table.thermal_workspace(b, tctx, ng, nt)
-            k.flux, k.disk = drv._dev(fl), drv._dev(dk)
-            k.thermal_pin = ctypes.cast(ctypes.c_void_p(pin.addr), drv._dp)
-            k.wno = drv._dev(_resident_vector(sub, "wno", sub.wno, nw))
-            k.thermal_host = drv._host(full["thermal"])
-        if do_r:
-            k.albedo_host = drv._host(full["albedo"])
-        k.trapz_d = k.trapz_dr = k.stellar = None
-        if integrals:
-            d_w, d_wr = _trapz_resident(sub, wno)
-            if do_r:
-                d_st = f0 if stellar is F0PI else _resident_vector(sub, "stellar", stellar, nw)
-                hold.append(d_st)
-                k.trapz_d, k.stellar = drv._dev(d_w), drv._dev(d_st)
-                denom = _bond_denominator(sub, wno, stellar, d_st)
-            if do_t:
-                k.trapz_dr = drv._dev(d_wr)
-    job, keep = drv.make_job(nlayer, plan, factors, linear, 0 if raman == 1 else nlayer, common["stream"],
-                             common["delta_eddington"], do_r, do_t, ng, nt, geom["ubar0"], geom["ubar1"], geom["cos_theta"],
-                             geom["gweight"], geom["tweight"], toon["single_phase"], toon["multi_phase"],
-                             toon["toon_coefficients"], frac_a, frac_b, frac_c, common["TTHG_params"]["constant_back"],
-                             common["TTHG_params"]["constant_forward"], 0.0, atm.level["temperature"], atm.level["pressure"],
-                             atm.hard_surface)
-    return dict(table=table, job=job, keep=(keep, hold), do_r=do_r, do_t=do_t, full=full, nwno=nwno, integrals=integrals,
-                denom=denom if (integrals and do_r) else None, wno=wno, stellar=stellar, inp=inp, atm=atm, opa=opa,
-                signature=key[1:-1])
-
-
-def _driver_finish(p):
-    """Second half of ``_picaso_driver``: the results as they arrive (their copies were enqueued with the launches)."""
-    from . import driver as drv
-    table, do_r, do_t, full, nwno, integrals, denom = (p[k] for k in ("table", "do_r", "do_t", "full", "nwno", "integrals", "denom"))
-    wno, stellar, inp, atm, opa = (p[k] for k in ("wno", "stellar", "inp", "atm", "opa"))
-    returns = {}
-    out = {"wavenumber": wno}
-    if do_r:
-        drv.collect(table, 1)
-        returns["albedo"] = full["albedo"][:nwno]
-        if integrals:
-            returns["bond_integral"] = (full["albedo"][nwno], denom)
-        _post_reflected(out, returns, wno, stellar, inp["star"]["semi_major"], atm.planet.radius, opa)
-    if do_t:
-        drv.collect(table, 2)
-        returns["thermal"] = full["thermal"][:nwno]
-        if integrals:
-            returns["teff_integral"] = full["thermal"][nwno]
-        _post_thermal(out, returns, wno, stellar, inp["star"]["radius"], atm.planet.radius, opa)
-    return _post_final(out, returns)
+def _picaso_driver(bundle, opa, subs, calculation, opt=None):
+    """The plain 1-D Toon spectrum through ONE C call (``onecall.run``); None outside what the driver covers."""
+    from . import onecall
+    return onecall.run(bundle, opa, subs, calculation, _options.current(opt))
 
 
 # ------------------------------------------------------------------------------------------------
@@ -2010,7 +1172,8 @@ class _SolveBatch:
         self.refl, self.therm = {}, {}
 
 
-def spectrum_batch(cases, opacityclass, calculation="reflected", full_output=False, as_dict=True, batch_size=4):
+def spectrum_batch(cases, opacityclass, calculation="reflected", full_output=False, as_dict=True, batch_size=4,
+                   options=None):
     """``[case.spectrum(opacityclass, calculation) for case in cases]`` (1-D) with the solvers of up to
     ``batch_size`` spectra in ONE launch each: what a retrieval or a model grid asks of the reference one
     ``spectrum()`` call and one process at a time (driver.py:405-426).  ``cases``: ``inputs`` objects, each with its
@@ -2020,6 +1183,7 @@ def spectrum_batch(cases, opacityclass, calculation="reflected", full_output=Fal
     host sets up and enqueues chunk k + 1, and only then waits for k's result copies (``picaso_memcpy_d2h_async`` into
     pinned blocks, ``picaso_mark_wait``) and runs its integrals.  HBM: the planes of a chunk stay resident until its
     launch (0.8 GB per cloudy 1e5 x 90 spectrum, 0.2 GB per cloud-free one), two chunks at a time."""
+    opt = _options.current(options)
     cases = list(cases)
     outs = []
     in_flight = []                 # chunks whose launches and result copies are on the stream
@@ -2035,13 +1199,13 @@ def spectrum_batch(cases, opacityclass, calculation="reflected", full_output=Fal
         fins = []
         for case in chunk:
             fins.append(picaso(case, opacityclass, dimension="1d", calculation=calculation, full_output=full_output,
-                               as_dict=as_dict, defer=True, _batch=batch))
+                               as_dict=as_dict, defer=True, options=opt, _batch=batch))
         batch.flush()
         # integrals and result copies on a stream of their own, behind this chunk's solvers
         post = {}
         for fin in fins:
             key = getattr(fin.ctx, "value", fin.ctx)
-            if key not in post and not os.environ.get("PICASO_AMD_NO_POST_STREAM"):
+            if key not in post and not opt.no_post_stream:
                 pc = _lib.aux_context(_lib.device_of(fin.ctx), 1 << 20)
                 _lib.ctx_wait(pc, fin.ctx)
                 if fin.tctx is not fin.ctx:
@@ -2112,24 +1276,6 @@ def _opacity_shards(opa, devs):
     return cache[key]
 
 
-def _atmosphere_block(atm0, lo, hi, wno):
-    """One wavelength block's view of an ATMSETUP that was set up once for the whole grid: everything but the
-    cloud tables and the wavenumbers is per layer / level and shared; the cloud arrays are column slices (views)."""
-    atm = copy.copy(atm0)
-    atm.wavenumber = wno
-    atm.layer = dict(atm0.layer)
-    cld = atm0.layer["cloud"]
-    if isinstance(cld, CloudTables):          # tables on their own grid: the block regrids its own columns
-        atm.layer["cloud"] = cld.columns(lo, hi)
-        atm.layer["cloud"].wno = wno
-    else:
-        atm.layer["cloud"] = {k: v[:, lo:hi] for k, v in cld.items()}
-    sr = atm0.surf_reflect
-    if np.ndim(sr) > 0 and np.size(sr) == np.size(atm0.wavenumber):
-        atm.surf_reflect = np.ascontiguousarray(np.asarray(sr, dtype=float)[lo:hi])
-    return atm
-
-
 class _Bundle:
     def __init__(self, inputs_dict, nlevel):
         self.inputs, self.nlevel = inputs_dict, nlevel
@@ -2186,7 +1332,8 @@ def _merge_blocks(parts, key=None):
     return first
 
 
-def _picaso_devices(bundle, opa, devices, gather, dimension, calculation, full_output, plot_opacity, as_dict, defer):
+def _picaso_devices(bundle, opa, devices, gather, dimension, calculation, full_output, plot_opacity, as_dict, defer,
+                    opt=None):
     """``picaso(..., devices=N)``: ONE spectrum in N contiguous wavelength blocks (``sharding.shard_bounds``), one
     per GPU.  Each block's opacity tables live on its device (``optics.shard_opacity``, uploaded once per
     opacity object), its gas stage, ``compute_opacity`` and solvers run there, all blocks are enqueued before the
@@ -2207,7 +1354,7 @@ def _picaso_devices(bundle, opa, devices, gather, dimension, calculation, full_o
     shards = _opacity_shards(opa, devs)
     nwno = opa.nwno
     if dimension == "1d" and gather == "host" and not (full_output or defer or plot_opacity):
-        fast = _picaso_driver(bundle, opa, shards, calculation)       # every block in one C call (csrc/driver.hip)
+        fast = _picaso_driver(bundle, opa, shards, calculation, opt)  # every block in one C call (csrc/driver.hip)
         if fast is not None:
             return fast
     nlevel = getattr(bundle, "nlevel", None)
@@ -2228,7 +1375,7 @@ def _picaso_devices(bundle, opa, devices, gather, dimension, calculation, full_o
         b = _Bundle(_slice_inputs(inp, lo, hi, nwno, nlayer, clouds=shared is None), nlevel)
         sh = dict(shared, lo=lo, hi=hi) if shared is not None else None
         fins.append(picaso(b, sub, dimension=dimension, calculation=calculation, full_output=full_output,
-                           plot_opacity=plot_opacity, as_dict=True, defer=True, _raw=True, _shared=sh))
+                           plot_opacity=plot_opacity, as_dict=True, defer=True, options=opt, _raw=True, _shared=sh))
     gathered = {}
     if gather == "rccl" and len(devs) > 1:
         if len(set(devs)) != len(devs):
@@ -2272,195 +1419,3 @@ def _picaso_devices(bundle, opa, devices, gather, dimension, calculation, full_o
         return out
     return finish if defer else finish()
 
-
-def _trapz_weights(opa, wno):
-    """``diff(1/wno)`` and ``diff(1/wno[::-1])``: the abscissa differences ``np.trapezoid`` forms on every call, kept
-    on the opacity object (the grid does not change between the 1e4-1e6 spectra of a retrieval; at 1e5 wavelengths
-    the three integrals of a reflected + thermal spectrum were 0.4 ms of the 1.5 ms call)."""
-    hit = opa.__dict__.get("_trapz")
-    if hit is None or hit[0] is not wno:
-        inv = 1 / wno
-        hit = (wno, np.diff(inv), np.diff(inv[::-1]))
-        opa.__dict__["_trapz"] = hit
-    return hit[1], hit[2]
-
-
-def _trapz(d, y, buf=None):
-    """``np.trapezoid(y, x)`` with ``d = diff(x)`` given: numpy's own expression, so the same bits.  ``buf``: a scratch
-    array of ``d``'s shape for the intermediate results (three fresh 0.8 MB arrays per integral at 1e5 wavelengths
-    cost more than the arithmetic)."""
-    if buf is None or buf.shape != d.shape:
-        return (d * (y[1:] + y[:-1]) / 2.0).sum(-1)
-    np.add(y[1:], y[:-1], out=buf)
-    np.multiply(d, buf, out=buf)
-    np.divide(buf, 2.0, out=buf)
-    return buf.sum(-1)
-
-
-def _trapz_scratch(opa, n):
-    """Two scratch vectors kept on the opacity object for the spectrum-wide integrals."""
-    hit = opa.__dict__.get("_trapz_buf")
-    if hit is None or hit[0].shape != (n - 1,):
-        hit = (np.empty(n - 1), np.empty(n))
-        opa.__dict__["_trapz_buf"] = hit
-    return hit
-
-
-def _trapz_resident(opa, wno):
-    """``_trapz_weights`` in HBM (``picaso_trapz_dev``), uploaded once per grid."""
-    d, dr = _trapz_weights(opa, wno)
-    hit = opa.__dict__.get("_trapz_dev")
-    if hit is None or hit[0] is not d:
-        hit = (d, DeviceArray.from_host(d, opa.ctx), DeviceArray.from_host(dr, opa.ctx))
-        opa.__dict__["_trapz_dev"] = hit
-    return hit[1], hit[2]
-
-
-def _bond_denominator(opa, wno, stellar, d_stellar):
-    """``np.trapz(x=1/wno, y=stellar)``, kept while the resident copy of the stellar spectrum is the same object
-    (``_resident_vector`` replaces it when the content changes)."""
-    hit = opa.__dict__.get("_bond_denom")
-    if hit is None or hit[0] is not d_stellar or hit[1] is not wno:
-        d, _ = _trapz_weights(opa, wno)
-        hit = (d_stellar, wno, _trapz(d, np.zeros(len(wno)) + np.asarray(stellar, dtype=float)))
-        opa.__dict__["_bond_denom"] = hit
-    return hit[2]
-
-
-def _post_reflected(out, raw, wno, stellar, sa, planet_radius, opa=None):
-    """Bond albedo (Batalha+2019 eq. 18) and the reflected planet-to-star flux ratio (justdoit.py:552-566).
-    ``raw["bond_integral"]`` = (numerator integrated on the device, denominator) when the caller had them."""
-    albedo = raw["albedo"]
-    out["albedo"] = albedo
-    if raw.get("bond_integral") is not None:
-        num, denom = raw["bond_integral"]
-        out["bond_albedo"] = num / denom
-    elif opa is not None:
-        d, _ = _trapz_weights(opa, wno)
-        b1, b2 = _trapz_scratch(opa, len(wno))
-        # the denominator does not change while the stellar spectrum does not: kept with a copy it is compared against
-        # (one pass instead of the integral's four; a read-only array -- the no-star ones -- is known by identity)
-        hit = opa.__dict__.get("_bond_denom_host")
-        if (hit is not None and hit[0] is stellar and hit[1] is wno and isinstance(stellar, np.ndarray)
-                and (not stellar.flags.writeable or np.array_equal(stellar, hit[2]))):
-            denom = hit[3]
-        else:
-            denom = _trapz(d, stellar, b1)
-            if isinstance(stellar, np.ndarray):
-                opa.__dict__["_bond_denom_host"] = (stellar, wno, None if not stellar.flags.writeable else stellar.copy(),
-                                                    denom)
-        np.multiply(albedo, stellar, out=b2)
-        out["bond_albedo"] = _trapz(d, b2, b1) / denom
-    else:
-        out["bond_albedo"] = (np.trapezoid(x=1 / wno, y=albedo * stellar) / np.trapezoid(x=1 / wno, y=stellar))
-    if (not np.isnan(sa)) and (not np.isnan(planet_radius)):
-        out["fpfs_reflected"] = albedo * (planet_radius / sa) ** 2.0
-    else:
-        out["fpfs_reflected"] = []
-
-
-def _post_thermal(out, raw, wno, stellar, radius_star, planet_radius, opa=None):
-    """Effective temperature and the thermal planet-to-star flux ratio (justdoit.py:567-599)."""
-    thermal = raw["thermal"]
-    out["thermal"] = thermal
-    out["thermal_unit"] = "erg/s/(cm^2)/(cm)"
-    if raw.get("teff_integral") is not None:
-        out["effective_temperature"] = (raw["teff_integral"] / 5.67e-5) ** 0.25
-    elif opa is not None:
-        _, dr = _trapz_weights(opa, wno)
-        b1, _ = _trapz_scratch(opa, len(wno))
-        out["effective_temperature"] = (_trapz(dr, thermal[::-1], b1) / 5.67e-5) ** 0.25
-    else:
-        out["effective_temperature"] = (np.trapezoid(x=1 / wno[::-1], y=thermal[::-1]) / 5.67e-5) ** 0.25
-    if radius_star == "nostar":
-        out["fpfs_thermal"] = ["No star mode for Brown Dwarfs was used"]
-    elif (not np.isnan(planet_radius)) and (not np.isnan(radius_star)):
-        out["fpfs_thermal"] = thermal / stellar * (planet_radius / radius_star) ** 2.0
-    else:
-        out["fpfs_thermal"] = []
-
-
-def _post_final(out, raw):
-    if "transit_depth" in raw:
-        out["transit_depth"] = raw["transit_depth"]
-    if ("fpfs_reflected" in out) and ("fpfs_thermal" in out):
-        if (not isinstance(out["fpfs_reflected"], list)) and (not isinstance(out["fpfs_thermal"], list)):
-            out["fpfs_total"] = out["fpfs_thermal"] + out["fpfs_reflected"]
-    return out
-
-
-def _postprocess(raw, wno, stellar, sa, radius_star, planet_radius, opa=None):
-    """The spectrum-wide quantities of the reference's return dictionary (justdoit.py:552-599) from the
-    per-wavelength results: Bond albedo, planet-to-star flux ratios, effective temperature.  Separate from the
-    solve so that a spectrum computed in wavelength blocks on several GPUs goes through exactly the same arithmetic
-    on the gathered arrays as a single-GPU one (which runs the three stages as its results arrive, see ``picaso``)."""
-    out = {"wavenumber": wno}
-    if "albedo" in raw:
-        _post_reflected(out, raw, wno, stellar, sa, planet_radius, opa)
-    if "thermal" in raw:
-        _post_thermal(out, raw, wno, stellar, radius_star, planet_radius, opa)
-    return _post_final(out, raw)
-
-
-def _reflected(ctx, nlevel, nwno, ng, nt, planes, rs, ubar0, ubar1, cos_theta, F0PI, single_phase,
-               multi_phase, frac_a, frac_b, frac_c, constant_back, constant_forward,
-               toon_coefficients, b_top, xint, lvl, gweight, tweight, albedo):
-    import ctypes
-    from ._lib import check, f64, load, ptr
-    u0, u1 = f64(ubar0, (ng, nt)), f64(ubar1, (ng, nt))
-    gw, tw = f64(gweight), f64(tweight)
-    ci, cd = ctypes.c_int, ctypes.c_double
-    check(load().picaso_get_reflected_1d_dev(
-        ctx, ci(nlevel), ci(nwno), ctypes.c_long(nwno), ci(ng), ci(nt),
-        *[ptr(planes[k].addr) if planes.get(k) is not None else None for k in resident.REFLECTED_PLANES],
-        ptr(rs.addr), ptr(u0), ptr(u1),
-        cd(cos_theta), ptr(F0PI.addr), ci(single_phase), ci(multi_phase), cd(frac_a), cd(frac_b),
-        cd(frac_c), cd(constant_back), cd(constant_forward), ci(1), ci(1 if lvl else 0),
-        ci(toon_coefficients), cd(b_top), ptr(xint.addr),
-        *[ptr(l.addr) if lvl else None for l in (lvl or [None] * 4)], ptr(gw), ptr(tw),
-        ptr(albedo.addr) if albedo is not None else None), ctx)
-
-
-def _reflected_sh(ctx, nlevel, nwno, ng, nt, planes, rs, ubar0, ubar1, cos_theta, F0PI, sh, frac_a,
-                  frac_b, frac_c, constant_back, constant_forward, stream, b_top, xint, gweight,
-                  tweight, albedo, flux=None, cloud_free_above=0):
-    import ctypes
-    from ._lib import check, f64, load, ptr
-    u0, u1 = f64(ubar0, (ng, nt)), f64(ubar1, (ng, nt))
-    gw, tw = f64(gweight), f64(tweight)
-    ci, cd = ctypes.c_int, ctypes.c_double
-    names = ("dtau", "tau", "w0", "cosb", "ftau_cld", "ftau_ray", "f_deltaM", "dtau_og", "tau_og",
-             "w0_og", "cosb_og")
-    check(load().picaso_get_reflected_SH_top_dev(
-        ctx, ci(nlevel), ci(nwno), ctypes.c_long(nwno), ci(ng), ci(nt),
-        *[ptr(planes[k].addr) if planes.get(k) is not None else None for k in names], ptr(rs.addr), ptr(u0), ptr(u1),
-        cd(cos_theta),
-        ptr(F0PI.addr), ci(sh["w_single_form"]), ci(sh["w_multi_form"]), ci(sh["psingle_form"]),
-        ci(sh["w_single_rayleigh"]), ci(sh["w_multi_rayleigh"]), ci(sh["psingle_rayleigh"]),
-        cd(frac_a), cd(frac_b), cd(frac_c), cd(constant_back), cd(constant_forward), ci(stream),
-        cd(b_top), ci(1 if flux is not None else 0), ci(sh["single_form"]), ci(1), ci(int(cloud_free_above)),
-        ptr(xint.addr),
-        ptr(flux.addr) if flux is not None else None, ptr(gw), ptr(tw),
-        ptr(albedo.addr)), ctx)
-
-
-def _thermal_sh(ctx, nlevel, d_wno, nwno, ng, nt, tlevel, planes, plevel, ubar1, rs, stream,
-                hard_surface, delta_eddington, flux, gweight, tweight, disk):
-    import ctypes
-    from ._lib import check, f64, load, ptr
-    u1 = f64(ubar1, (ng, nt))
-    gw, tw = f64(gweight), f64(tweight)
-    tl, pl = f64(tlevel), f64(plevel)
-    ci = ctypes.c_int
-    # ff = 0 if np.array_equal(cosb, cosb_og) else cosb_og**stream (fluxes.py:3072-3075).  Without delta-Eddington
-    # scaling the two planes are the same array; with it they are equal only where cosb_og**stream vanishes against
-    # cosb_og, and there `cosb_og**stream` IS the reference's 0 (exactly for a cloud-free atmosphere, to < 1e-21 in the
-    # weights otherwise): the kernel forms it per element, and nothing is copied back to decide (a 72 MB read of
-    # f_deltaM per call used to sit here: 9.5 of the 11.7 ms of an SH4 spectrum at 1e5 wavelengths).
-    differs = 1 if delta_eddington else 0
-    check(load().picaso_get_thermal_SH_dev(
-        ctx, ci(nlevel), ptr(d_wno.addr), ci(nwno), ctypes.c_long(nwno), ci(ng), ci(nt), ptr(tl),
-        ptr(planes["dtau"].addr), ptr(planes["tau"].addr) if planes.get("tau") is not None else None,   # tau: never read
-        ptr(planes["w0"].addr),
-        ptr(planes["cosb_og"].addr), ptr(pl), ptr(u1), ptr(rs.addr), ci(stream), ci(int(hard_surface)),
-        ci(differs), ci(0), ptr(flux.addr), ptr(gw), ptr(tw), ptr(disk.addr)), ctx)

@@ -1,0 +1,260 @@
+"""One C call per spectrum (csrc/driver.hip): the launch sequence of the 1-D Toon path for every wavelength block.
+
+The plain 1-D Toon spectrum (reference justdoit.py:236-385, 552-599) through ``picaso_toon_spectrum_blocks``: ONE C call
+enqueues gas stage -> ``compute_opacity`` -> reflected || thermal (+ fused disk sums) on every wavelength block of ``subs``
+(``[(lo, hi, opacity object of the block)]``; the whole grid on one GPU is one block), a second and third copy the legs
+back.  Outside what the driver covers (correlated-k tables, SH, patchy clouds, level fluxes, full_output, transmission,
+Oklopcic Raman or cloud tables on their own grid in a multi-block call, test modes) ``prepare`` returns None and the caller
+takes ``spectrum.Spectrum``, whose results these are bit for bit: the C function chains the same entry points in the same
+order.  ``prepare`` does everything up to the C call -- set-up, block table, per-call pointers, job -- ``run`` is
+prepare + the call + ``finish``.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib, device, optics, resident
+from . import driver as drv
+from .atmsetup import CloudTables
+from .device import DeviceArray
+from .spectrum import (_bond_denominator, _constant_planes, _ones, _post_final, _post_reflected, _post_thermal,
+                       _resident_vector, _setup_atmosphere, _trapz_resident)
+
+
+def run(bundle, opa, subs, calculation, opt):
+    """``prepare`` + the C call + ``finish``; None when the call is outside what the driver covers."""
+    p = prepare(bundle, opa, subs, calculation, opt)
+    if p is None:
+        return None
+    try:
+        drv.enqueue(p["table"], p["job"])
+        return finish(p)
+    except BaseException:
+        drv.abandon(p["table"])
+        raise
+
+
+def _in_scope(inp, opa, legs, nblocks, opt):
+    """The calls the C driver covers: reflected and / or thermal, Toon, monochromatic resident tables, no patchy clouds,
+    no level fluxes, no test mode; Oklopcic's Raman plane (formed per call on the block's device) for one block only."""
+    if opt.no_driver or opt.raman_planes:
+        return False
+    if not legs or not legs <= {"reflected", "thermal"}:
+        return False
+    if (inp["approx"]["rt_method"] == "SH" or opa.ngauss != 1 or getattr(opa, "on_fly", False)
+            or inp["clouds"].get("do_holes", False) or inp["approx"].get("get_lvl_flux", False)
+            or inp["test_mode"] is not None or not hasattr(opa, "_cia") or not hasattr(opa, "_ray")):
+        return False
+    return not (inp["approx"]["rt_params"]["common"]["raman"] == 0 and nblocks != 1)
+
+
+def _plane_set(atm, geom, toon, frac_c, nwno, raman, do_r, do_t, opt):
+    """Which planes compute_opacity writes: exactly ``Spectrum._want_1d``'s choice (see there for the cloud-free form and
+    for the planes the reflected kernels re-derive).  Returns ``(want, lean, derive)``."""
+    ng, nt = geom["num_gangle"], geom["num_tangle"]
+    derive = (do_r and not opt.all_planes
+              and resident.reflected_can_derive(atm.c.nlevel, nwno, ng, nt, geom["ubar0"], geom["ubar1"], geom["cos_theta"],
+                                                toon["single_phase"], toon["multi_phase"], frac_c,
+                                                toon["toon_coefficients"], False))
+    lean = (bool(getattr(atm, "cloud_free", False)) and len(getattr(atm, "rayleigh_molecules", [])) > 0
+            and not opt.all_planes)
+    want = set()
+    if lean:
+        if do_r:
+            want |= {"dtau", "w0"} if derive else {"dtau", "tau", "w0"}
+        if do_t:
+            want |= {"dtau", "w0" if (raman == 2 and do_r) else "w0_no_raman"}
+        return want, lean, derive
+    if do_r:
+        want |= set(resident.REFLECTED_PLANES)
+        if derive:
+            want -= {"tau", "tau_og", "gcos2"}
+    if do_t:
+        want |= {"dtau_og", "w0_no_raman", "cosb_og"}
+    return want, lean, derive
+
+
+def _cloud_inputs(atm, opa, tables, nlayer, nwno, opt, hold):
+    """The cloud tables of the call as ``(device planes | None, device tables on their own grid | None, host planes |
+    None)``: tables on their own wavenumber grid (what virga and the box-cloud form of clouds() hand over) are regridded on
+    the device as in ``compute_opacity_resident`` -- interpolated inside the opacity launch, no regridded planes in HBM
+    (same bits) -- arrays already on the opacity grid travel as host planes, block by block."""
+    cld = atm.layer["cloud"]
+    if tables:
+        stack = cld.__dict__.get("_stack")
+        if stack is None:
+            stack = cld.__dict__["_stack"] = np.concatenate([cld.compact[k] for k in ("opd", "w0", "g0")])
+        if opt.unfused_opacity or opt.regrid_planes:
+            all3 = device.regrid_rows(cld.in_wno, stack, optics._wno_device(opa, cld.wno), opa.ctx).reshape((3, nlayer, nwno))
+            dcld = [all3.row_block(0), all3.row_block(1), all3.row_block(2)]
+            hold.append((all3, dcld))
+            return dcld, None, None
+        dtab = (int(np.size(cld.in_wno)),
+                DeviceArray.from_host(np.ascontiguousarray(cld.in_wno, dtype=np.float64), opa.ctx),
+                DeviceArray.from_host(np.ascontiguousarray(stack, dtype=np.float64), opa.ctx))
+        hold.append(dtab)
+        return None, dtab, None
+    if getattr(atm, "cloud_free", False):
+        return None, None, None
+
+    def plane(x):
+        a = np.asarray(x, dtype=float)
+        return a if (a.shape == (nlayer, nwno) and a.flags.c_contiguous) else \
+            np.ascontiguousarray(np.broadcast_to(a, (nlayer, nwno)))
+    hcld = [plane(cld[k]) for k in ("opd", "w0", "g0")]
+    hold.append(hcld)
+    return None, None, hcld
+
+
+def _fill_block(k, sub, lo, hi, c):
+    """The per-call pointers of one wavelength block ``k`` (a ``driver.Block``): resident per-wavelength vectors, the
+    Raman factor, the cloud inputs, the thermal workspace on the block's second stream, where the results go."""
+    nw, nwno, hold, atm = hi - lo, c["nwno"], c["hold"], c["atm"]
+    sr = atm.surf_reflect
+    sr_full = np.ndim(sr) > 0 and np.size(sr) == nwno and nwno > 1
+    rs = _resident_vector(sub, "surf_reflect", np.asarray(sr, dtype=float).reshape(nwno)[lo:hi] if sr_full else sr, nw)
+    f0 = _resident_vector(sub, "F0PI", 1.0 if c["nostar"] else (c["F0PI"] if c["nblocks"] == 1 else c["F0PI"][lo:hi]), nw)
+    k.surf_reflect, k.F0PI = drv._dev(rs), drv._dev(f0)
+    hold.append((rs, f0))            # the block holds raw addresses: the vectors live as long as the call is in flight
+    if c["raman"] == 1:
+        row, _ = optics.raman_device(atm, sub, 1)
+        k.raman = drv._dev(row)
+    elif c["raman"] == 0:           # (nlayer, nwno) plane from the layer temperatures (picaso_raman_oklopcic_dev), same stream
+        rplane, _ = optics.raman_device(atm, sub, 0)
+        hold.append(rplane)
+        k.raman = drv._dev(rplane)
+    else:
+        k.raman = None
+    dcld, dtab, hcld = c["clouds"]
+    k.cld_tab_nin, k.cld_tab_xp, k.cld_tab_fp = 0, None, None
+    k.cld_opd = k.cld_w0 = k.cld_g0 = None
+    k.cld_host_opd = k.cld_host_w0 = k.cld_host_g0 = None
+    if dtab is not None:
+        k.cld_tab_nin, k.cld_tab_xp, k.cld_tab_fp = dtab[0], drv._dev(dtab[1]), drv._dev(dtab[2])
+        k.wno = drv._dev(_resident_vector(sub, "wno", sub.wno, nw))
+    elif dcld is not None:
+        k.cld_opd, k.cld_w0, k.cld_g0 = (drv._dev(x) for x in dcld)
+    elif hcld is not None:
+        k.cld_host_opd, k.cld_host_w0, k.cld_host_g0 = (drv._host(h) for h in hcld)
+        k.cld_host_pitch = nwno
+    if c["do_t"]:
+        tctx = sub.ctx
+        if c["overlap"]:
+            dev = _lib.device_of(sub.ctx)
+            seen = c["seen_dev"]
+            tctx = _lib.aux_context(dev, seen.get(dev, 0))       # blocks that share a device: a stream each
+            seen[dev] = seen.get(dev, 0) + 1
+        k.tctx = tctx.value if hasattr(tctx, "value") else tctx
+        fl, dk, pin = c["table"].thermal_workspace(c["b"], tctx, c["ng"], c["nt"])
+        k.flux, k.disk = drv._dev(fl), drv._dev(dk)
+        k.thermal_pin = ctypes.cast(ctypes.c_void_p(pin.addr), drv._dp)
+        k.wno = drv._dev(_resident_vector(sub, "wno", sub.wno, nw))
+        k.thermal_host = drv._host(c["full"]["thermal"])
+    if c["do_r"]:
+        k.albedo_host = drv._host(c["full"]["albedo"])
+    k.trapz_d = k.trapz_dr = k.stellar = None
+    if c["integrals"]:
+        # one block over the grid: the spectrum-wide integrals are formed on the device behind each result vector and
+        # arrive with it (host arrays one element longer; the dictionary gets views of the first nwno)
+        d_w, d_wr = _trapz_resident(sub, c["wno"])
+        if c["do_r"]:
+            d_st = f0 if c["stellar"] is c["F0PI"] else _resident_vector(sub, "stellar", c["stellar"], nw)
+            hold.append(d_st)
+            k.trapz_d, k.stellar = drv._dev(d_w), drv._dev(d_st)
+            c["denom"] = _bond_denominator(sub, c["wno"], c["stellar"], d_st)
+        if c["do_t"]:
+            k.trapz_dr = drv._dev(d_wr)
+
+
+def prepare(bundle, opa, subs, calculation, opt, slot=None):
+    """Everything up to the C call: set-up, block table (``slot``: which of several tables of the same signature, for
+    spectra that are in flight together), per-call pointers, job.  None: outside the driver's scope."""
+    inp = bundle.inputs
+    legs = set(calculation.split("+"))
+    if not _in_scope(inp, opa, legs, len(subs), opt):
+        return None
+    common = inp["approx"]["rt_params"]["common"]
+    toon = inp["approx"]["rt_params"]["toon"]
+    raman = common["raman"]
+    wno, nwno = opa.wno, opa.nwno
+    atm = _setup_atmosphere(inp, opa, wno)
+    cld = atm.layer["cloud"]
+    cloud_free = bool(getattr(atm, "cloud_free", False))
+    tables = not cloud_free and isinstance(cld, CloudTables)
+    if tables and (len(subs) != 1 or np.size(cld.wno) != nwno or opt.host_regrid):
+        return None                 # tables on their own grid: regridded on the device for ONE block over the grid
+    nlevel, nlayer = atm.c.nlevel, atm.c.nlayer
+    opa.get_opacities(atm, exclude_mol=inp["atmosphere"]["exclude_mol"])
+    plan = opa._plan
+    if plan.get("premixed"):
+        return None
+    factors = optics._layer_factors(atm, opa)
+    plan["_factors"] = (atm.layer["mixingratios"], factors)
+    linear = opa.query_method == "linear"
+    do_r, do_t = "reflected" in legs, "thermal" in legs
+    geom = inp["disco"]
+    ng, nt = geom["num_gangle"], geom["num_tangle"]
+    frac_a, frac_b, frac_c = common["TTHG_params"]["fraction"]
+    want, lean, derive = _plane_set(atm, geom, toon, frac_c, nwno, raman, do_r, do_t, opt)
+
+    def table_ids(sub):          # a block table holds raw table addresses: replaced tables are a new signature
+        mt = sub._mol_log if linear else sub._mol_raw
+        return tuple(id(mt[m]) for m in plan["molecules"]) + tuple(id(sub._cia[p]) for p in plan["cia_pairs"])
+    key = (tuple((lo, hi, id(sub)) + table_ids(sub) for lo, hi, sub in subs), nlayer, ng, nt, tuple(plan["molecules"]),
+           tuple(plan["cia_pairs"]), tuple(factors[2]), linear, tuple(sorted(want)), lean, not cloud_free and not tables, do_r, do_t,
+           derive, slot)
+    cache = opa.__dict__.setdefault("_driver_tables", {})
+    table = cache.get(key)
+    if table is None:
+        if len(cache) > (8 if slot is None else 40):
+            cache.clear()
+        table = cache[key] = drv.BlockTable(subs, nlayer, ng, nt, plan["molecules"], plan["cia_pairs"], factors[2], linear,
+                                            want, lean, not cloud_free and not tables, do_r, do_t, _constant_planes, derive)
+    nostar = inp["star"]["database"] == "nostar"
+    F0PI = _ones(opa, nwno) if nostar else inp["star"]["relative_flux"]
+    stellar = getattr(opa, "unshifted_stellar_spec", None)
+    if stellar is None:
+        stellar = F0PI
+    integrals = len(subs) == 1 and nwno > 1 and not opt.host_integrals
+    hold, full = [], {}
+    if do_r:
+        full["albedo"] = np.empty(nwno + 1 if integrals else nwno)
+    if do_t:
+        full["thermal"] = np.empty(nwno + 1 if integrals else nwno)
+    c = dict(nwno=nwno, wno=wno, hold=hold, atm=atm, nostar=nostar, F0PI=F0PI, stellar=stellar, nblocks=len(subs),
+             raman=raman, clouds=_cloud_inputs(atm, opa, tables, nlayer, nwno, opt, hold), do_r=do_r, do_t=do_t,
+             overlap=do_r and do_t and opt.overlap_legs, seen_dev={}, table=table, ng=ng, nt=nt, full=full,
+             integrals=integrals, denom=None)
+    for b, (lo, hi, sub) in enumerate(subs):
+        c["b"] = b
+        _fill_block(table.blocks[b], sub, lo, hi, c)
+    job, keep = drv.make_job(nlayer, plan, factors, linear, 0 if raman == 1 else nlayer, common["stream"],
+                             common["delta_eddington"], do_r, do_t, ng, nt, geom["ubar0"], geom["ubar1"], geom["cos_theta"],
+                             geom["gweight"], geom["tweight"], toon["single_phase"], toon["multi_phase"],
+                             toon["toon_coefficients"], frac_a, frac_b, frac_c, common["TTHG_params"]["constant_back"],
+                             common["TTHG_params"]["constant_forward"], 0.0, atm.level["temperature"], atm.level["pressure"],
+                             atm.hard_surface)
+    return dict(table=table, job=job, keep=(keep, hold), do_r=do_r, do_t=do_t, full=full, nwno=nwno, integrals=integrals,
+                denom=c["denom"] if (integrals and do_r) else None, wno=wno, stellar=stellar, inp=inp, atm=atm, opa=opa,
+                signature=key[1:-1])
+
+
+def finish(p):
+    """Second half of ``run``: the results as they arrive (their copies were enqueued with the launches)."""
+    table, do_r, do_t, full, nwno, integrals, denom = (p[k] for k in ("table", "do_r", "do_t", "full", "nwno", "integrals", "denom"))
+    wno, stellar, inp, atm, opa = (p[k] for k in ("wno", "stellar", "inp", "atm", "opa"))
+    returns = {}
+    out = {"wavenumber": wno}
+    if do_r:
+        drv.collect(table, 1)
+        returns["albedo"] = full["albedo"][:nwno]
+        if integrals:
+            returns["bond_integral"] = (full["albedo"][nwno], denom)
+        _post_reflected(out, returns, wno, stellar, inp["star"]["semi_major"], atm.planet.radius, opa)
+    if do_t:
+        drv.collect(table, 2)
+        returns["thermal"] = full["thermal"][:nwno]
+        if integrals:
+            returns["teff_integral"] = full["thermal"][nwno]
+        _post_thermal(out, returns, wno, stellar, inp["star"]["radius"], atm.planet.radius, opa)
+    return _post_final(out, returns)

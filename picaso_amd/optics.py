@@ -27,6 +27,7 @@ from . import _lib
 from ._lib import check, f64, load, ptr
 from .atmsetup import CloudTables
 from .device import DeviceArray, regrid_rows
+from .options import current as _options
 
 _ci, _cd = ctypes.c_int, ctypes.c_double
 AVOGADRO = 6.02214086e+23
@@ -832,7 +833,7 @@ def raman_device(atm, opa, raman):
     (Oklopcic: depends on the layer temperatures, computed per call on the host) or one row of ``nwno`` values for
     every layer (Pollack: the table on the opacity grid, kept on the opacity object once formed)."""
     nlayer = atm.c.nlayer
-    if raman == 1 and not os.environ.get("PICASO_AMD_RAMAN_PLANES"):
+    if raman == 1 and not _options().raman_planes:
         ref = os.environ.get("picaso_refdata")
         path = os.path.join(ref, "opacities", "raman_fortran.txt") if ref is not None else None
         st = os.stat(path) if path is not None and os.path.isfile(path) else None
@@ -842,7 +843,7 @@ def raman_device(atm, opa, raman):
             row = np.minimum(raman_pollack(1, 1e4 / opa.wno)[0], 0.99999)
             hit = opa.__dict__["_raman_pollack"] = (key, DeviceArray.from_host(np.ascontiguousarray(row), opa.ctx))
         return hit[1], 0
-    if raman == 0 and not os.environ.get("PICASO_AMD_RAMAN_PLANES"):
+    if raman == 0 and not _options().raman_planes:
         out = DeviceArray((nlayer, opa.nwno), opa.ctx)
         raman_oklopcic_device(opa, np.asarray(atm.layer["temperature"], dtype=float), out)
         return out, nlayer
@@ -982,7 +983,7 @@ def compute_opacity_facets(atms, opacityclass, numg, numt, stream=2, delta_eddin
     if opa.ngauss != 1:
         raise Exception("compute_opacity_facets takes monochromatic opacities")
     tg3, tr3 = DeviceArray((nfac, nlayer, nwno), ctx), DeviceArray((nfac, nlayer, nwno), ctx)
-    on_dev = not os.environ.get("PICASO_AMD_RAMAN_PLANES")
+    on_dev = not _options().raman_planes
     row_mode = raman == 1 and on_dev
     rf3 = [] if raman in (0, 1) and not on_dev else None      # host planes, one per facet
     d_rf3 = DeviceArray((nfac, nlayer, nwno), ctx) if raman == 0 and on_dev else None   # Oklopcic: layer temperatures
@@ -1233,6 +1234,113 @@ def compute_opacity_facet_major(atm_f, opacityclass, numg, numt, stream=2, delta
     return out
 
 
+def _cloud_planes_facet_major(clouds_3d, opa, nlayer, nfac, ctx):
+    """The cloud tables of the 3-D path as resident facet-major planes ``(d_opd, d_w0, d_g0, stride)``, each
+    ``(nfacets | 1, nlayer, nwno)``; ``stride`` = elements between two facets (0: one set for the whole disk).  Tables on
+    a wavenumber grid of their own are regridded on the device with numpy.interp's bits -- the reference's per-facet
+    get_clouds -> wavelength.regrid (atmsetup.py:609-622) -- from the compact rows kept with the cloud dictionary
+    (``_facet_major_cloud_tables``: re-uploaded when any byte of the caller's arrays changes)."""
+    nwno = opa.nwno
+    in_wno = clouds_3d.get("wavenumber") if isinstance(clouds_3d, dict) else None
+    if in_wno is not None and np.size(in_wno) == nwno and np.array_equal(in_wno, opa.wno):
+        in_wno = None
+    if in_wno is not None and np.size(in_wno) >= 2:
+        tabs = _facet_major_cloud_tables(clouds_3d, nlayer, nfac, ctx)
+        if tabs is None:
+            raise Exception("clouds_3d: opd / w0 / g0 must hold nlayer x nwavenumber (x nfacets) numbers")
+        d_xp, d_tall, _, nin = tabs
+        rows = regrid_rows(d_xp, d_tall.reshape((3 * nfac * nlayer, nin)), _wno_device(opa, opa.wno), ctx)
+        rows._inputs = (d_xp, d_tall)
+        r3 = rows.reshape((3, nfac * nlayer, nwno))
+        return r3.row_block(0), r3.row_block(1), r3.row_block(2), nlayer * nwno, rows
+    out = []
+    shared = True
+    for k in ("opd", "w0", "g0"):
+        a = np.asarray(clouds_3d[k], dtype=float)
+        if in_wno is not None:                   # a single wavenumber: the value everywhere
+            a = np.repeat(a.reshape(nlayer, 1, -1), nwno, axis=1)
+        if a.size == nlayer * nwno:
+            out.append(a.reshape(1, nlayer, nwno))
+        else:
+            shared = False
+            out.append(np.moveaxis(a.reshape(nlayer, nwno, nfac), 2, 0))
+    if not shared:
+        out = [np.broadcast_to(a, (nfac, nlayer, nwno)) for a in out]
+    devs = [DeviceArray.from_host(np.ascontiguousarray(a), ctx) for a in out]
+    return devs[0], devs[1], devs[2], (0 if shared else nlayer * nwno), None
+
+
+def compute_opacity_facet_major_ck(atm_f, opacityclass, numg, numt, stream=2, delta_eddington=True, test_mode=None,
+                                   raman=2, clouds_3d=None, exclude_mol=1, want=None):
+    """The planes of a 3-D spectrum on CORRELATED-K tables (reference justdoit.py:437-471 with ``ngauss > 1``:
+    ``get_opacities`` + ``compute_opacity`` facet by facet, ``DTAU_3d[:, :, g, t, :] = dtau``) in facet-major layout
+    ``(nfacets, nlayer|nlevel, nwno, ngauss)``: ONE gas launch over the tall atmosphere of all facets
+    (``nfacets * nlayer`` layers; premixed table rows or, for on-the-fly mixing, one resort-rebin launch over all of
+    them), then ``picaso_compute_opacity_facet_major_ck_dev``.  Each facet's numbers are those of
+    ``compute_opacity_resident`` on that facet's atmosphere (tests/test_ck3d_gpu.py).  ``want``: the planes to write
+    (default all 13).  The solvers: ``resident.reflected_3d_ck`` / ``thermal_3d_ck``."""
+    import types
+    opa = opacityclass
+    ctx = opa.ctx
+    nfac = numg * numt
+    nlayer, nwno, ngauss = atm_f.c.nlayer, opa.nwno, opa.ngauss
+    ntot = nfac * nlayer
+
+    def flat(a):                      # (nlayer, nfacets | 1) -> facet-major (nfacets*nlayer,)
+        a = np.asarray(a, dtype=float)
+        return np.ascontiguousarray(np.broadcast_to(a.reshape(nlayer, -1), (nlayer, nfac)).T).ravel()
+    mix = atm_f.layer["mixingratios"]
+    tall = types.SimpleNamespace(
+        c=types.SimpleNamespace(nlayer=ntot, pconv=atm_f.c.pconv),
+        layer={"temperature": flat(atm_f.layer["temperature"]), "pressure": flat(atm_f.layer["pressure"]),
+               "mixingratios": {m: flat(mix[m].values if hasattr(mix[m], "values") else mix[m]) for m in atm_f.molecules}},
+        molecules=atm_f.molecules, continuum_molecules=atm_f.continuum_molecules)
+    opa.get_opacities(tall, exclude_mol=exclude_mol)
+    pl = opa._plan
+    mol_fac, cont_fac, ray_names, ray_fac = _layer_factors(atm_f, opa)
+    cont_tabs = [opa._cia[p] for p in pl["cia_pairs"]]
+    ray_tabs = [opa._ray[m] for m in ray_names]
+    mol_tabs = [pl.get("table", opa._kappa)]
+    taugas, tauray = DeviceArray((nfac, nlayer, nwno, ngauss), ctx), DeviceArray((nfac, nlayer, nwno), ctx)
+    per_layer = (16 + 32 + 8) + len(cont_tabs) * (8 + 16 + 8) + len(ray_tabs) * 8 + 8
+    fchunk = max(1, int((3600 * 1024) // (per_layer * nlayer)))         # per-layer tables of a launch: one 4 MB slot
+    for f0 in range(0, nfac, fchunk):
+        f1 = min(nfac, f0 + fchunk)
+        sl = slice(f0 * nlayer, f1 * nlayer)
+        cont_rows = np.repeat(pl["cia_rows"][None, sl], len(cont_tabs), axis=0) if cont_tabs else None
+        cont_wts = np.repeat(pl["cia_wts"][None, sl], len(cont_tabs), axis=0) if cont_tabs else None
+        _gas_call(opa, (f1 - f0) * nlayer, mol_tabs, pl["rows"][:, sl], pl["wts"][:, sl], mol_fac[:, sl], cont_tabs,
+                  cont_rows, cont_fac[:, sl] if cont_tabs else None, ray_tabs, ray_fac[:, sl] if ray_tabs else None,
+                  taugas.row_block(f0), tauray.row_block(f0), mol_mode=2, cont_wts=cont_wts, ngauss=ngauss)
+    # the Raman factor: none (the constant), Pollack's row for every layer and facet, or Oklopcic's plane per facet
+    d_rf, rf_rows = None, 0
+    if raman == 1:
+        d_rf, rf_rows = raman_device(atm_f, opa, 1)
+    elif raman == 0:
+        d_rf, rf_rows = DeviceArray((nfac, nlayer, nwno), ctx), nlayer
+        tl = np.broadcast_to(np.asarray(atm_f.layer["temperature"], dtype=float).reshape(nlayer, -1), (nlayer, nfac))
+        for f in range(nfac):
+            raman_oklopcic_device(opa, tl[:, f], d_rf.row_block(f))
+    d_cld = (None, None, None, 0, None)
+    if clouds_3d is not None:
+        d_cld = _cloud_planes_facet_major(clouds_3d, opa, nlayer, nfac, ctx)
+    tm = 0
+    if test_mode is not None:
+        tm = 1 if test_mode == "rayleigh" else 2
+    out = {k: (DeviceArray((nfac, (nlayer + 1 if k in ("tau", "tau_og") else nlayer), nwno, ngauss), ctx)
+               if (want is None or k in want) else None) for k in OUT_NAMES}
+    check(load().picaso_compute_opacity_facet_major_ck_dev(
+        ctx, _ci(nfac), _ci(nlayer), _ci(nwno), _ci(ngauss), ptr(taugas.addr), ptr(tauray.addr),
+        *[ptr(d.addr) if d is not None else None for d in d_cld[:3]], ctypes.c_long(d_cld[3]),
+        ptr(d_rf.addr) if d_rf is not None else None, _ci(rf_rows), _cd(0.99999), _ci(tm),
+        _ci(1 if delta_eddington else 0), _ci(stream),
+        *[ptr(out[k].addr) if out[k] is not None else None for k in OUT_NAMES]), ctx)
+    out = {k: v for k, v in out.items() if v is not None}
+    out["_fm"], out["_ck"] = True, True
+    out["_inputs"] = (taugas, tauray, d_rf, d_cld, pl.get("table"))     # asynchronous launch: inputs live with the outputs
+    return out
+
+
 def _wno_device(opa, wno):
     """The wavenumber grid as a device vector; the opacity object's own grid is uploaded once."""
     if wno is opa.wno:
@@ -1262,7 +1370,7 @@ def compute_opacity_resident(atmosphere, opacityclass, ngauss=1, stream=2, delta
     # Monochromatic tables: gas stage and mixing as ONE launch (picaso_gas_compute_opacity_dev; TAUGAS / TAURAY stay in
     # registers) unless the caller wants those two planes back (full_output) or a level plane without its layer plane.
     # PICASO_AMD_UNFUSED_OPACITY=1: the two launches (A/B, tests) -- same bits either way.
-    fused = (ngauss == 1 and not full_output and not os.environ.get("PICASO_AMD_UNFUSED_OPACITY")
+    fused = (ngauss == 1 and not full_output and not _options().unfused_opacity
              and (want is None or (("tau" not in want or "dtau" in want) and ("tau_og" not in want or "dtau_og" in want))))
     if not fused:
         taugas, tauray = DeviceArray((nlayer,) + gshape, ctx), DeviceArray((nlayer, nwno), ctx)
@@ -1277,12 +1385,12 @@ def compute_opacity_resident(atmosphere, opacityclass, ngauss=1, stream=2, delta
     def taucld_host():
         t = plane(cld["opd"])
         return fthin_cld * t if do_holes else t             # optics.py:314-315
-    on_device = isinstance(cld, CloudTables) and np.size(cld.wno) == nwno and not os.environ.get("PICASO_AMD_HOST_REGRID")
+    on_device = isinstance(cld, CloudTables) and np.size(cld.wno) == nwno and not _options().host_regrid
     cld_tab = (_ci(0), None, None, None)
     tab_keep = None
     if getattr(atm, "cloud_free", False) and not do_holes:  # no cloud profile: NULL planes read as zero
         d_cld = d_w0 = d_g0 = None
-    elif on_device and fused and not do_holes and not os.environ.get("PICASO_AMD_REGRID_PLANES"):
+    elif on_device and fused and not do_holes and not _options().regrid_planes:
         # tables on their own wavenumber grid, interpolated INSIDE the fused opacity launch (numpy.interp's bits, as
         # picaso_regrid_rows_dev): no regridded planes in HBM
         stack = cld.__dict__.get("_stack")

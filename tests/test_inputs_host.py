@@ -584,7 +584,8 @@ def test_resident_vector_alternating_arrays_and_scalars(monkeypatch):
     surf_reflect array then the default scalar 0: the cache must tell the two kinds apart (round-3 review: the
     array entry's tag IS the ndarray, and comparing it with a tuple raised)."""
     from picaso_amd import justdoit as jdi
-    monkeypatch.setattr(jdi, "DeviceArray", _FakeDev)
+    from picaso_amd import spectrum
+    monkeypatch.setattr(spectrum, "DeviceArray", _FakeDev)          # where _resident_vector lives (re-exported by justdoit)
 
     class Opa:
         ctx = None

@@ -36,7 +36,8 @@ wrap(jdi, "_resident_vector")
 wrap(jdi, "_picaso_driver")
 wrap(jdi, "picaso")
 wrap(jdi, "_opacity_shards")
-wrap(jdi, "_driver_finish")
+from picaso_amd import onecall
+wrap(onecall, "finish")
 devs = [int(x) for x in os.environ["DEVICES"].split(",")] if os.environ.get("DEVICES") else None
 
 # the scene of tools/e2e_1d_time.py
