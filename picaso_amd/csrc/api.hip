@@ -674,7 +674,7 @@ static int reflected_1d_core(picaso_ctx *ctx, int nlevel, int nwno, int ncolper,
         if (const char *e = getenv("PICASO_AMD_REFL_COOP_COLS")) coop_cols = atol(e);
         a.na = nang;
         a.ny = 1;
-        if (ncol <= coop_cols && !derived && reflected_coop_ok(a)) {
+        if (ncol <= coop_cols && reflected_coop_ok(a)) {       // (also with the product's two derived plane sets)
             for (int k = 0; k < nang; ++k)
                 a.ang[k] = make_refl_angle(ubar0[k], ubar1[k], fuse ? gweight[k / numt] : 0.0,
                                            fuse ? tweight[k % numt] : 0.0);

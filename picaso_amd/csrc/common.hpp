@@ -166,6 +166,7 @@ int launch_reflected_toa(picaso_ctx *ctx, const ReflectedArgs &a, bool is3d);
 // cooperative kernel for small 1-D launches (toon_reflected_coop.hip): one workgroup per 64 columns, a wave for the
 // angle-independent layer quantities and one wave per disk angle; a.ang[0 .. a.na) = ALL angles, a.ny = 1
 bool reflected_coop_ok(const ReflectedArgs &a);
+int reflected_coop_pattern(const ReflectedArgs &a);
 int launch_reflected_coop(picaso_ctx *ctx, const ReflectedArgs &a);
 // out[r][w] = sum_j wts[j] in[r][w*n + j]  (correlated-k Gauss-point sum, justdoit.py:307, 380)
 int launch_weighted_colsum(picaso_ctx *ctx, int nrows, long nwno, int n, const double *wts_host,

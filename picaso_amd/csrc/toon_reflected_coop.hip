@@ -413,11 +413,17 @@ __device__ __forceinline__ void rc_shared_plain_round(const double (*in)[RW_NV][
 #undef RC_FOR_J
 }
 
-// ZP: every angle has ubar0 == ubar1 (zero phase angle), as in k_reflected_toa
-template <bool ZP>
+// ZP: every angle has ubar0 == ubar1 (zero phase angle), as in k_reflected_toa.
+// DRV: which planes exist -- 0 all eleven; 2 only dtau and w0 (an atmosphere without cloud: the others are constants,
+// copies and running sums); 3 everything but tau, tau_og and gcos2 (running sums and 0.5 ftau_ray) -- the two patterns
+// picaso() / the C driver hand over when picaso_reflected_1d_can_derive says yes (k_reflected_toa's DRV = 2 / 3).  Wave L
+// forms the missing values from the ones it loaded with the operations compute_opacity uses (optics.py:342, 353-354,
+// 412-420), so the LDS ring holds the same eleven numbers per layer as with all planes in HBM: same bits downstream.
+template <bool ZP, int DRV>
 __global__ __launch_bounds__(64 * (RC_MAX_ANGLES / RC_APW + 2)) void k_reflected_coop(const ReflectedArgs a)
 {
 #pragma clang fp contract(off)      // operations as written: the same ones reflected_layer performs
+    constexpr bool CLEAR = (DRV == 2), LEVELS = (DRV == 3), NOSUMS = CLEAR || LEVELS;
     __shared__ double raw[3][RC_R][RW_NV][64];        // plane values, two rounds ahead of the angle waves
     __shared__ double ring[2][RC_R][RC_NV][64];       // wave S's results, one round ahead
     __shared__ int lflag[3][RC_R];                    // wave-uniform shortcut flags of a layer (wave L)
@@ -447,11 +453,25 @@ __global__ __launch_bounds__(64 * (RC_MAX_ANGLES / RC_APW + 2)) void k_reflected
         // wave L: HBM -> LDS, every plane value read exactly once, and the wave-uniform shortcut tests of
         // k_reflected_toa's `prep` (bit-exact comparisons, see reflected_layer) on the values it holds
         // ------------------------------------------------------------------------------------------------
-        const double *pl[RW_NV] = {a.dtau + col, a.tau + col + pitch, a.w0 + col, a.cosb + col, a.gcos2 + col,
-                                   a.ftau_cld + col, a.ftau_ray + col, a.dtau_og + col, a.tau_og + col,
-                                   a.w0_og + col, a.cosb_og + col};
-        double tau_i = a.tau[col];
+        // RW_DT, RW_TAUN, RW_W0, RW_G, RW_GCOS2, RW_FC, RW_FR, RW_DTO, RW_TAUO, RW_W0O, RW_CBO: which are in HBM
+        constexpr bool have[RW_NV] = {true, !NOSUMS, true, !CLEAR, !NOSUMS, !CLEAR, !CLEAR, !CLEAR, !NOSUMS, !CLEAR, !CLEAR};
+        const double *pl[RW_NV] = {a.dtau + col, have[RW_TAUN] ? a.tau + col + pitch : nullptr, a.w0 + col,
+                                   have[RW_G] ? a.cosb + col : nullptr, have[RW_GCOS2] ? a.gcos2 + col : nullptr,
+                                   have[RW_FC] ? a.ftau_cld + col : nullptr, have[RW_FR] ? a.ftau_ray + col : nullptr,
+                                   have[RW_DTO] ? a.dtau_og + col : nullptr, have[RW_TAUO] ? a.tau_og + col : nullptr,
+                                   have[RW_W0O] ? a.w0_og + col : nullptr, have[RW_CBO] ? a.cosb_og + col : nullptr};
+        double tau_i = NOSUMS ? 0.0 : a.tau[col];
         double tauo_pred = 0.0;                       // tau_og[i-1] + dtau_og[i-1] of the layer above
+        // the values of the planes that are not in HBM, from the ones that are (in layer order: the running sums)
+        auto derive = [&](double (&x)[RW_NV]) {
+            if (CLEAR) {
+                x[RW_G] = 0.0; x[RW_FC] = 0.0; x[RW_FR] = 1.0; x[RW_GCOS2] = 0.5; x[RW_CBO] = 0.0;
+                x[RW_DTO] = x[RW_DT]; x[RW_W0O] = x[RW_W0];
+            } else if (LEVELS) {
+                x[RW_GCOS2] = 0.5 * x[RW_FR];
+            }
+            if (NOSUMS) { x[RW_TAUN] = tau_i + x[RW_DT]; x[RW_TAUO] = tauo_pred; }
+        };
         // the loads of round q + 1 are issued BEFORE round q's values (loaded a step earlier) are written to LDS and
         // the step's barrier is reached: a round's loads stay in flight for a whole step instead of holding it up
         double v[2][RC_R][RW_NV];
@@ -462,7 +482,8 @@ __global__ __launch_bounds__(64 * (RC_MAX_ANGLES / RC_APW + 2)) void k_reflected
                 if (i < n) {
                     const long o = (long)i * pitch;
 #pragma unroll
-                    for (int p = 0; p < RW_NV; ++p) dst[j][p] = pl[p][o];
+                    for (int p = 0; p < RW_NV; ++p)
+                        if (have[p]) dst[j][p] = pl[p][o];
                 }
             }
         };
@@ -482,9 +503,13 @@ __global__ __launch_bounds__(64 * (RC_MAX_ANGLES / RC_APW + 2)) void k_reflected
             for (int j = 0; j < RC_R; ++j) {
                 const int i = q * RC_R + j;
                 if (i < n) {
+                    double x[RW_NV];
 #pragma unroll
-                    for (int p = 0; p < RW_NV; ++p) raw[q % 3][j][p][lane] = src[j][p];
-                    const int fl = layer_flags(src[j]);
+                    for (int p = 0; p < RW_NV; ++p) x[p] = have[p] ? src[j][p] : 0.0;
+                    derive(x);
+#pragma unroll
+                    for (int p = 0; p < RW_NV; ++p) raw[q % 3][j][p][lane] = x[p];
+                    const int fl = layer_flags(x);
                     if (lane == 0) lflag[q % 3][j] = fl;
                     all &= (i > 0 && i < n - 1) ? fl : 0;
                 } else {
@@ -501,16 +526,21 @@ __global__ __launch_bounds__(64 * (RC_MAX_ANGLES / RC_APW + 2)) void k_reflected
             for (int j = 0; j < RC_R; ++j) {
                 const long o = (long)(q * RC_R + j) * pitch;
 #pragma unroll
-                for (int p = 0; p < RW_NV; ++p) dst[j][p] = pl[p][o];
+                for (int p = 0; p < RW_NV; ++p)
+                    if (have[p]) dst[j][p] = pl[p][o];
             }
         };
         auto store_full = [&](int q, const double (&src)[RC_R][RW_NV]) {     // 0 < layers < n - 1
             int all = RCF_ALL;
 #pragma unroll
             for (int j = 0; j < RC_R; ++j) {
+                double x[RW_NV];
 #pragma unroll
-                for (int p = 0; p < RW_NV; ++p) raw[q % 3][j][p][lane] = src[j][p];
-                const int fl = layer_flags(src[j]);
+                for (int p = 0; p < RW_NV; ++p) x[p] = have[p] ? src[j][p] : 0.0;
+                derive(x);
+#pragma unroll
+                for (int p = 0; p < RW_NV; ++p) raw[q % 3][j][p][lane] = x[p];
+                const int fl = layer_flags(x);
                 if (lane == 0) lflag[q % 3][j] = fl;
                 all &= fl;
             }
@@ -607,7 +637,7 @@ __global__ __launch_bounds__(64 * (RC_MAX_ANGLES / RC_APW + 2)) void k_reflected
         for (int kk = 0; kk < NA; ++kk) {
             g[kk] = a.ang[k0 + kk];
             st[kk].T = 1.0;
-            st[kk].XU = fexp2(mul_unfused(a.tau[col], ZP ? g[kk].nl1 : g[kk].nl0), K);
+            st[kk].XU = fexp2(mul_unfused(NOSUMS ? 0.0 : a.tau[col], ZP ? g[kk].nl1 : g[kk].nl0), K);
             st[kk].EO = st[kk].KAPPA = st[kk].ZETA = st[kk].D1 = st[kk].D2 = 0.0;
             st[kk].l_gam = st[kk].l_EM = st[kk].l_rho = 0.0;
         }
@@ -664,8 +694,19 @@ __global__ __launch_bounds__(64 * (RC_MAX_ANGLES / RC_APW + 2)) void k_reflected
     else angle_wave(std::integral_constant<int, 1>{});
 }
 
+// 0: all eleven planes; 2: only dtau and w0; 3: all but tau, tau_og, gcos2; -1: another pattern (not for this kernel)
+int reflected_coop_pattern(const ReflectedArgs &a)
+{
+    const bool cloudset = a.cosb && a.cosb_og && a.ftau_cld && a.ftau_ray, og = a.dtau_og && a.w0_og;
+    if (a.tau && a.tau_og && a.gcos2 && cloudset && og) return 0;
+    if (!a.tau && !a.tau_og && !a.gcos2 && cloudset && og) return 3;
+    if (!a.tau && !a.tau_og && !a.gcos2 && !a.cosb && !a.cosb_og && !a.ftau_cld && !a.ftau_ray && !a.dtau_og && !a.w0_og) return 2;
+    return -1;
+}
+
 bool reflected_coop_ok(const ReflectedArgs &a)
 {
+    if (reflected_coop_pattern(a) < 0) return false;
     if (getenv("PICASO_AMD_REFL_NO_COOP")) return false;
     if (a.na < 1 || a.na > RC_MAX_ANGLES || a.ny > 1 || a.nlayer < 1) return false;
     // the reference's default options (what reflected_layer<.., FAST = true> fixes at compile time)
@@ -680,10 +721,12 @@ int launch_reflected_coop(picaso_ctx *ctx, const ReflectedArgs &a)
     for (int k = 0; k < a.na; ++k) zp = zp && (a.ang[k].u0 == a.ang[k].u1);
     if (zp && a.cos_theta != 1.0) zp = false;          // as fast_options: the ZP variant fixes cos_theta = 1
     const dim3 grid((unsigned)((a.ncol + 63) / 64)), block(64 * ((a.na + RC_APW - 1) / RC_APW + 2));
-    if (zp)
-        hipLaunchKernelGGL((k_reflected_coop<true>), grid, block, 0, ctx->stream, a);
-    else
-        hipLaunchKernelGGL((k_reflected_coop<false>), grid, block, 0, ctx->stream, a);
+    const int drv = reflected_coop_pattern(a);
+    if (drv < 0) return fail(ctx, "reflected (cooperative kernel): unsupported set of planes");
+#define PZ_GO(Z, D) hipLaunchKernelGGL((k_reflected_coop<Z, D>), grid, block, 0, ctx->stream, a)
+    if (zp) { if (drv == 0) PZ_GO(true, 0); else if (drv == 2) PZ_GO(true, 2); else PZ_GO(true, 3); }
+    else { if (drv == 0) PZ_GO(false, 0); else if (drv == 2) PZ_GO(false, 2); else PZ_GO(false, 3); }
+#undef PZ_GO
     PZ_HIP(ctx, hipGetLastError());
     return 0;
 }

@@ -118,3 +118,45 @@ def test_coop_is_the_kernel_that_ran(monkeypatch):
     xb, ab = run()
     assert np.array_equal(xa, xb) and np.array_equal(aa, ab)
     assert np.isfinite(aa).all() and aa.max() > 0
+
+
+@pytest.mark.parametrize("nwno", [64, 1000, 12500])
+@pytest.mark.parametrize("phase", [0.0, 0.8])
+def test_coop_with_the_products_derived_plane_sets(monkeypatch, nwno, phase):
+    """picaso() / the C driver leave out the planes the kernels re-derive (tau, tau_og, gcos2; for an atmosphere without
+    cloud everything but dtau and w0).  At shard sizes those launches take k_reflected_coop too (round 4 sent them to the
+    angle-group shapes: the product path differed from the measured one): same bits as the full plane set through the
+    cooperative kernel and as the same plane set through the generic kernels."""
+    from picaso_amd import _lib, device, disco, resident
+    from picaso_amd import synthetic as syn
+    ctx = _lib.context()
+    nlayer, ng = 37, 5
+    if phase == 0.0:
+        g, gw, t, tw = disco.get_angles_1d(ng)
+        nt, ct = 1, 1.0
+    else:
+        g, gw, t, tw = disco.get_angles_3d(3, 2)
+        nt = 2
+    u0, u1, cth, _, _ = disco.compute_disco(len(g), nt, g, t, phase)
+    ct = 1.0 if phase == 0.0 else float(cth)
+    for cloud in (True, False):
+        sc = syn.make_scene(nlayer, nwno, seed=11, cloud=cloud)
+        sc["F0PI"] = np.linspace(0.9, 1.1, nwno)
+        sc["surf_reflect"] = np.full(nwno, 0.15)
+        d = resident.upload_scene(sc, resident.REFLECTED_PLANES + ("F0PI", "surf_reflect"), ctx=ctx)
+        keep = [k for k in resident.REFLECTED_PLANES if k not in ("tau", "tau_og", "gcos2")] if cloud else ["dtau", "w0"]
+        lean = {k: d[k] for k in keep}
+        assert resident.reflected_can_derive(nlayer + 1, nwno, len(g), nt, u0, u1, ct, 3, 0, 2.0)
+
+        def run(planes):
+            x, alb = device.DeviceArray((len(g), nt, nwno), ctx), device.DeviceArray((nwno,), ctx)
+            resident.reflected_1d(ctx, nlayer + 1, nwno, len(g), nt, planes, d["surf_reflect"], u0, u1, ct, d["F0PI"], 3, 0,
+                                  *TTHG, x, gweight=gw, tweight=tw, albedo=alb)
+            return x.to_host(), alb.to_host()
+        monkeypatch.delenv("PICASO_AMD_REFL_NO_COOP", raising=False)
+        full_c, lean_c = run(d), run(lean)
+        monkeypatch.setenv("PICASO_AMD_REFL_NO_COOP", "1")
+        lean_g = run(lean)
+        for a, b in ((full_c, lean_c), (lean_c, lean_g)):
+            assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), (cloud, nwno, phase)
+        assert np.isfinite(lean_c[1]).all() and lean_c[1].max() > 0
