@@ -352,6 +352,18 @@ int picaso_get_reflected_SH(picaso_ctx *ctx, int nlevel, int nwno, int numg, int
 int picaso_reflected_SH_can_derive(int stream, int w_single_form, int w_multi_form, int psingle_form,
                                    int w_single_rayleigh, int w_multi_rayleigh, int psingle_rayleigh, double frac_c,
                                    int single_form, int flx);
+/* The level planes alone may be left out as well: tau and tau_og TOGETHER NULL, everything else given (a cloudy
+ * atmosphere, where the cloud-free form above does not apply).  compute_opacity forms them as running sums of dtau /
+ * dtau_og from 0 at the top (optics.py:353-354, 418-420), so the launch carries the beam exponentials exp(-tau/u0) and
+ * exp(-tau_og/u0) down the column as running products of the layers' exp(-dtau/u0) -- in the symmetric geometry (ubar0
+ * == ubar1) the factor exp(-dtau/ubar1) the layer forms anyway: two of a layer's five exponentials and three of its
+ * eleven loads less.  The reference's clipped exp(-clip35(tau/u0)) is max(., e^-35) of the running product.  Returns 1
+ * when a call with these arguments may do so (the default phase-function options, flx = 0, planes below 4 GB), 0 when it
+ * needs both planes.  Results agree with the plane-reading launch to the rounding of the product (<= nlayer ulp of the
+ * exponentials: ~1e-14 relative in the exponentials, <= 1e-11 in the intensities), not bit for bit; they do not depend on launch shape or wavelength block. */
+int picaso_reflected_SH_can_derive_levels(int nlevel, long plane_pitch, int stream, int w_single_form, int w_multi_form,
+                                          int psingle_form, int w_single_rayleigh, int w_multi_rayleigh,
+                                          int psingle_rayleigh, double frac_c, int single_form, int flx);
 int picaso_get_reflected_SH_dev(picaso_ctx *ctx, int nlevel, int nwno, long plane_pitch, int numg,
                                 int numt, const double *dtau, const double *tau, const double *w0,
                                 const double *cosb, const double *ftau_cld, const double *ftau_ray,

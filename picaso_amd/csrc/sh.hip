@@ -315,9 +315,17 @@ __device__ __forceinline__ void modes_sh2(const double (&a)[2], double dt, Modes
 #ifndef PZ_SH_MINWAVES
 #define PZ_SH_MINWAVES 2
 #endif
-template <int NB, bool THERMAL, bool FLX, bool FAST, typename AnglePtr>
+// DRVT (FAST reflected kernels): the level planes tau and tau_og are not in HBM (NULL).  compute_opacity forms them as
+// running sums of dtau / dtau_og from 0 at the top (optics.py:353-354, 418-420), so the beam exponentials of a level,
+// exp(-tau/u0) and exp(-tau_og/u0), are running PRODUCTS of the layers' exp(-dtau/u0): carried unclipped down the column,
+// one multiply per layer -- in the symmetric geometry (u0 == u1) by exp(-dtau/u1), which the layer needs anyway, so
+// two of its five exponentials (15 instructions each) and three of its eleven loads go; other geometries pay one
+// exponential for the two.  The reference's clipped form exp(-clip35(tau/u0)) (:3418-3421) is max(., e^-35) of the
+// unclipped one.  A column's value differs from the plane-reading kernel's by the rounding of the product (<= n ulp).
+template <int NB, bool THERMAL, bool FLX, bool FAST, bool DRVT, typename AnglePtr>
 __device__ __forceinline__ void sh_body(const SHArgs &a, AnglePtr angp)
 {
+    static_assert(!DRVT || (FAST && !THERMAL && !FLX), "derived level planes: the default-options reflected kernels");
     constexpr int NS = 2 * NB;      // stream
     // 1-D grid, XCD-aware order.  Consecutive workgroups go to consecutive XCDs (8 of them, each with
     // its own L2), and every angle re-reads the same 13 planes: block b = (chunk of 8 column groups,
@@ -341,6 +349,10 @@ __device__ __forceinline__ void sh_body(const SHArgs &a, AnglePtr angp)
     if (w >= a.nwno) return;
     const int n = a.nlayer;
     const long pitch = a.pitch;
+    // Plane element of a layer (`LD` in the layer body).  FAST kernels address the planes as SGPR base + 32-bit lane
+    // offset (launch_sh takes them only for planes smaller than 4 GB): one v_add_u32 per layer for all planes instead of a
+    // 64-bit v_lshl_add_u64 per load (eleven per layer; profiles/r05_isa_k_sh4_fast_before.json).
+    const unsigned voff0 = (unsigned)(w * 8), pitch8 = (unsigned)(pitch * 8);
     const int w_single_form = FAST ? 0 : a.w_single_form, w_multi_form = FAST ? 0 : a.w_multi_form;
     const int psingle_form = FAST ? 0 : a.psingle_form, single_form = FAST ? 0 : a.single_form;
     const int w_single_rayleigh = FAST ? 1 : a.w_single_rayleigh, w_multi_rayleigh = FAST ? 1 : a.w_multi_rayleigh;
@@ -367,6 +379,8 @@ __device__ __forceinline__ void sh_body(const SHArgs &a, AnglePtr angp)
 
     double T = 1.0, kappa = 0.0;
     double e_top = 0.0;              // exp(-tau/u0) at the top of the current layer (carried)
+    double p_og = 1.0;               // DRVT: exp(-tau_og/u0) at the top of the current layer, unclipped (e_top: exp(-tau/u0))
+    if (DRVT) e_top = 1.0;           // tau[0] = 0
     double zeta[NB], delta[NB];
     Blk<NB> R;
     // previous layer
@@ -411,7 +425,9 @@ __device__ __forceinline__ void sh_body(const SHArgs &a, AnglePtr angp)
         sl = SHC_SHARED + SHC_STATE * (a.first_angle + ang);
         T = ld(sl++);
         kappa = ld(sl++);
-        e_top = ld(sl++);
+        e_top = ld(sl++);            // unclipped exp(-tau/u0) at the top of start_layer (k_sh4_clear)
+        p_og = e_top;                // no cloud above: tau_og = tau
+        if (!DRVT && NB == 2) e_top = fmax(e_top, EXP_M35);
 #pragma unroll
         for (int r = 0; r < NB; ++r) zeta[r] = ld(sl++);
 #pragma unroll
@@ -421,9 +437,18 @@ __device__ __forceinline__ void sh_body(const SHArgs &a, AnglePtr angp)
 #pragma unroll
         for (int r = 0; r < NB; ++r) p_zpl_up[r] = ld(sl++);
     }
-    for (int i = (!THERMAL && !FLX) ? a.start_layer : 0; i < n; ++i) {
+    // One layer of the sweep.  Called twice per trip of the loop below: the sweep state of a layer (R, the previous layer's
+    // four blocks and particular solutions: 18 doubles) then alternates between two register sets instead of being copied
+    // back at the end of every layer (18 v_mov_b64 per layer in the single-body loop; the compiler does not unroll a loop
+    // around wave-uniform votes by itself).
+    auto layer = [&](const int i) {
         const long o = (long)i * pitch + w;
-        const double dt = a.dtau[o], w0 = a.w0[o], cbo = a.cosb_og[o];
+        const unsigned vo = voff0 + (unsigned)i * pitch8;
+        auto LD = [&](const double *base, int below = 0) -> double {      // below = 1: the level under the layer
+            if constexpr (FAST) return *(const double *)((const char *)base + (vo + (below ? pitch8 : 0u)));
+            else return base[o + (below ? pitch : 0)];
+        };
+        const double dt = LD(a.dtau), w0 = LD(a.w0), cbo = LD(a.cosb_og);
         // ---- Legendre weights of the phase function ----
         double wsg[NS], wmu[NS];
 #pragma unroll
@@ -431,12 +456,12 @@ __device__ __forceinline__ void sh_body(const SHArgs &a, AnglePtr angp)
         double psing = 0.0;
         bool nocld = false;          // reflected: no cloud in this layer anywhere in the wave (see below)
         if (!THERMAL) {
-            const double fc = a.ftau_cld[o], fr = a.ftau_ray[o];
+            const double fc = LD(a.ftau_cld), fr = LD(a.ftau_ray);
             // f_deltaM as angle k of the reference sees it: its TTHG branch multiplies the array in
             // place by `fac` once per angle (:2823-2824), so the OTHG branch of angle k reads
             // f_deltaM fac^k (the aliasing is live when one form is OTHG and the other TTHG) and
             // the TTHG branch f_deltaM fac^(k+1).
-            double fd_prev = a.f_deltaM[o], fd = fd_prev, f = 0.0, gf = 0.0, gb = 0.0;
+            double fd_prev = LD(a.f_deltaM), fd = fd_prev, f = 0.0, gf = 0.0, gb = 0.0;
             // No cloud in this layer anywhere in the wave and Rayleigh-weighted moments (w_*_rayleigh = 1):
             // every l >= 1 moment is multiplied by ftau_cld = 0, so the weights are (1, 0, ftau_ray/2, 0)
             // whatever the phase-function form and f_deltaM -- the TTHG / OTHG blocks (a pow, two
@@ -534,10 +559,14 @@ __device__ __forceinline__ void sh_body(const SHArgs &a, AnglePtr angp)
         // ---- particular solution at the layer top / bottom ----
         double eta[NS];
         double zmn_dn[NB], zpl_dn[NB], zmn_up[NB], zpl_up[NB];
-        double B0 = 0.0, b1 = 0.0, ed_layer = 0.0;
+        double B0 = 0.0, b1 = 0.0, ed_layer = 0.0, exp_dt_u0 = 0.0;
         if (!THERMAL) {
             double zpl[NB], zmn[NB];
-            const double tau_t = a.tau[o], tau_b = a.tau[o + pitch];
+            double tau_t = 0.0, tau_b = 0.0;
+            if constexpr (!DRVT) { tau_t = LD(a.tau); tau_b = LD(a.tau, 1); }
+            // DRVT: exp(-dtau/u0), the factor of the running products
+            const double fac0 = !DRVT ? 0.0 : (sym ? edt_layer : fexp2(dt * g.nl0, K));
+            exp_dt_u0 = fac0;
             double ed, eu;
             if constexpr (NB == 2) {                                         // :3397-3416, :3441-3450
                 const double x = iu0, x2 = x * x;
@@ -579,6 +608,11 @@ __device__ __forceinline__ void sh_body(const SHArgs &a, AnglePtr angp)
                     zpl[1] = ((m0 + e58) + eta[3]) * (2 * PI);
                     zmn[1] = ((m0 + e58) - eta[3]) * (2 * PI);
                 }
+                if constexpr (DRVT) {
+                    ed = fmax(e_top, EXP_M35);
+                    e_top = e_top * fac0;                                    // unclipped, carried
+                    eu = fmax(e_top, EXP_M35);
+                } else {
                 ed = (i == 0) ? fexp2_clip(tau_t * g.nl0, K) : e_top;    // = last layer's eu (same element)
                 // exp(-tau[i+1]/u0) = exp(-tau[i]/u0) exp(-dtau/u1) in the symmetric geometry when the level
                 // depths are the running sums of the layer depths (bit-exact, whole wave) and the 35-clip
@@ -587,6 +621,7 @@ __device__ __forceinline__ void sh_body(const SHArgs &a, AnglePtr angp)
                     eu = ed * edt_layer;
                 else
                     eu = fexp2_clip(tau_b * g.nl0, K);
+                }
             } else {                                                         // :3240-3265
                 const double x = iu0;
                 const double iDel = frcp(x * x - al[0] * al[1]);
@@ -594,10 +629,16 @@ __device__ __forceinline__ void sh_body(const SHArgs &a, AnglePtr angp)
                 eta[1] = (bl[0] * x - al[0] * bl[1]) * iDel;
                 zmn[0] = (0.5 * eta[0] - eta[1]) * 2 * PI;
                 zpl[0] = (0.5 * eta[0] + eta[1]) * 2 * PI;
-                ed = (i == 0) ? fexp2(tau_t * g.nl0, K) : e_top;
-                eu = fexp2(tau_b * g.nl0, K);
+                if constexpr (DRVT) {
+                    ed = e_top;
+                    e_top = e_top * fac0;
+                    eu = e_top;
+                } else {
+                    ed = (i == 0) ? fexp2(tau_t * g.nl0, K) : e_top;
+                    eu = fexp2(tau_b * g.nl0, K);
+                }
             }
-            e_top = eu;
+            if constexpr (!DRVT) e_top = eu;
             ed_layer = ed;
 #pragma unroll
             for (int r = 0; r < NB; ++r) {
@@ -700,18 +741,31 @@ __device__ __forceinline__ void sh_body(const SHArgs &a, AnglePtr angp)
                     }
                     Nsum = sN * expon1;
                 }
-                const double dto = a.dtau_og[o];
+                const double dto = LD(a.dtau_og);
                 double e_muso = e_mus;
+                double faco = 0.0;                                           // DRVT: exp(-dtau_og/u0)
+                if constexpr (DRVT) faco = exp_dt_u0;
                 if (!__all(dto == dt)) {
                     const double d = fexp2_clip(dto * g.nlm, K);
                     e_muso = (dto == dt) ? e_mus : d;
+                    if constexpr (DRVT) {
+                        const double d0 = fexp2(dto * g.nl0, K);
+                        faco = (dto == dt) ? faco : d0;
+                    }
                 }
-                // exp(-tau_og/u0) at the layer top: the (unclipped) exponential of tau already at hand when
-                // nothing above has been delta-scaled (tau_og == tau in the whole wave)
-                const double tauo = a.tau_og[o];
-                const double e_tauo = (PZ_SH_OPT_EXP && __all(tauo == a.tau[o]) && __all(tauo * g.nl0 >= -35.0 * LOG2E))
-                                          ? ed_layer : fexp2(tauo * g.nl0, K);
-                const double single = div_const(a.w0_og[o] * F, FOURPI, R4PI) * psing *
+                // exp(-tau_og/u0) at the layer top, unclipped (:2962)
+                double e_tauo;
+                if constexpr (DRVT) {
+                    e_tauo = p_og;
+                    p_og = p_og * faco;
+                } else {
+                // the exponential of tau already at hand when nothing above has been delta-scaled (tau_og == tau in
+                // the whole wave)
+                const double tauo = LD(a.tau_og);
+                e_tauo = (PZ_SH_OPT_EXP && __all(tauo == LD(a.tau)) && __all(tauo * g.nl0 >= -35.0 * LOG2E))
+                             ? ed_layer : fexp2(tauo * g.nl0, K);
+                }
+                const double single = div_const(LD(a.w0_og) * F, FOURPI, R4PI) * psing *
                                       (1 - e_muso) * e_tauo * imus;          // :2959-2965
                 c = T * iu1 * (w0 * Nsum + single);
             } else {
@@ -790,16 +844,37 @@ __device__ __forceinline__ void sh_body(const SHArgs &a, AnglePtr angp)
 #pragma unroll
             for (int r = 0; r < NB; ++r) rhs[r] += cM[r];
             mv(K, rhs, deltan);
+            double tv[NB];
+            mv(M.Pl, deltan, tv);
+#pragma unroll
+            for (int r = 0; r < NB; ++r) tv[r] += cP[r];
+            if constexpr (!FLX) {
+                // v_{i-1} = Sm v_i + t with Sm = A2i (ME - Pl Rn), t = A2i tv enters the TOA functional only through
+                // zeta.t and Sm^T zeta: with z = A2i^T zeta these are z.tv and ME^T z - Rn^T (Pl^T z), and the two
+                // NB x NB products that form Sm (and the matrix-vector product for t) are not needed -- 34 instead of
+                // 49 fp64 instructions per layer at NB = 2 (the flx = 1 kernels keep Sm and t: their second sweep reads them)
+                double z[NB], y[NB], z1[NB], z2[NB];
+                mtv(A2i, zeta, z);
+                kappa = kappa + dot(z, tv) + dot(gd, deltan) + c;
+                mtv(M.Pl, z, y);
+#pragma unroll
+                for (int r = 0; r < NB; ++r) y[r] += gd[r];
+                mtv(ME, z, z1);
+                mtv(Rn, y, z2);
+#pragma unroll
+                for (int r = 0; r < NB; ++r) {
+                    zeta[r] = z1[r] + gv[r] - z2[r];
+                    delta[r] = deltan[r];
+                }
+                R = Rn;
+            } else {
             Blk<NB> Sm = mm(M.Pl, Rn);
 #pragma unroll
             for (int r = 0; r < NB; ++r)
 #pragma unroll
                 for (int s = 0; s < NB; ++s) Sm.m[r][s] = ME.m[r][s] - Sm.m[r][s];
             Sm = mm(A2i, Sm);
-            double tv[NB], t[NB];
-            mv(M.Pl, deltan, tv);
-#pragma unroll
-            for (int r = 0; r < NB; ++r) tv[r] += cP[r];
+            double t[NB];
             mv(A2i, tv, t);
             if constexpr (FLX) {                       // v_{i-1} = Sm v_i + t
                 int sl = 3 * NB * NB + 4 * NB;
@@ -820,6 +895,7 @@ __device__ __forceinline__ void sh_body(const SHArgs &a, AnglePtr angp)
                 delta[r] = deltan[r];
             }
             R = Rn;
+            }
         }
         if constexpr (FLX) {
             int sl = 0;
@@ -852,11 +928,24 @@ __device__ __forceinline__ void sh_body(const SHArgs &a, AnglePtr angp)
 #pragma unroll
         for (int r = 0; r < NB; ++r) { p_zmn_up[r] = zmn_up[r]; p_zpl_up[r] = zpl_up[r]; }
         T = Tn;
+    };
+    if constexpr (FAST && !THERMAL && !FLX) {      // (the generic and flx = 1 bodies are larger: two copies would spill)
+        int i = a.start_layer;
+        for (; i + 1 < n; i += 2) {
+            layer(i);
+            layer(i + 1);
+        }
+        if (i < n) layer(i);
+    } else {
+        for (int i = (!THERMAL && !FLX) ? a.start_layer : 0; i < n; ++i) layer(i);
     }
     // ---- surface rows (:3484-3494 / :3287-3289) ----
     double bs[NB];
     if (!THERMAL) {
-        const double bsf = (0. + rs * u0 * F * fexpk(-a.tau[(long)n * pitch + w] / u0, K));   // :2863-2864
+        double e_bot;                                                        // exp(-tau[n]/u0), unclipped
+        if constexpr (DRVT) e_bot = e_top;
+        else e_bot = fexpk(-a.tau[(long)n * pitch + w] / u0, K);
+        const double bsf = (0. + rs * u0 * F * e_bot);                                          // :2863-2864
         bs[0] = bsf;
         if constexpr (NB == 2) bs[1] = -bsf / 4;
     } else {
@@ -953,25 +1042,35 @@ __device__ __forceinline__ void sh_body(const SHArgs &a, AnglePtr angp)
     }
 }
 
-template <int NB, bool THERMAL, bool FLX, bool FAST = false>
+template <int NB, bool THERMAL, bool FLX, bool FAST = false, bool DRVT = false>
 __global__ __launch_bounds__(256, PZ_SH_MINWAVES) void k_sh(const SHArgs a)
 {
-    sh_body<NB, THERMAL, FLX, FAST>(a, a.ang);
+    sh_body<NB, THERMAL, FLX, FAST, DRVT>(a, a.ang);
 }
 
-// `nspec` spectra of one shape and option set in one grid (picaso_get_reflected_SH_batch_dev): blockIdx.y = spectrum,
-// whose planes, output and angle table come from the device table a.batch, read through the constant address
-// space like kernel arguments (see k_reflected_toa_batch).  Same body, same bits.
-template <int NB, bool FAST>
-__global__ __launch_bounds__(256, PZ_SH_MINWAVES) void k_sh_batch(const SHArgs a)
+// Reflected light without layer fluxes: ONE kernel for a single spectrum and for `nspec` spectra of one shape and option
+// set in one grid (picaso_get_reflected_SH_batch_dev: blockIdx.y = spectrum, whose planes, output and angle table come
+// from the device table a.batch, read through the constant address space like kernel arguments).  A single launch is the
+// same machine code with a.batch = NULL -- its angle table is the kernel-argument segment itself -- so "spectrum s of a
+// batch is bit-identical to its own launch" does not rest on the compiler contracting two instantiations of the body
+// alike (round 5: it did not, once the layer body was inlined twice).
+template <int NB, bool FAST, bool DRVT = false>
+__global__ __launch_bounds__(256, PZ_SH_MINWAVES) void k_sh_refl(const SHArgs a)
 {
     typedef const __attribute__((address_space(4))) SHBatchItem *ItemPtr;
-    const auto &it = *((ItemPtr)(unsigned long)a.batch + blockIdx.y);
+    typedef const __attribute__((address_space(4))) SHArgs::Angle *AngPtr;
+    typedef const __attribute__((address_space(4))) char *ArgBytes;
     SHArgs b = a;
-    b.dtau = it.dtau; b.tau = it.tau; b.w0 = it.w0; b.ftau_cld = it.ftau_cld; b.ftau_ray = it.ftau_ray;
-    b.f_deltaM = it.f_deltaM; b.dtau_og = it.dtau_og; b.tau_og = it.tau_og; b.w0_og = it.w0_og; b.cosb_og = it.cosb_og;
-    b.surf_reflect = it.surf_reflect; b.F0PI = it.F0PI; b.xint = it.xint; b.cos_theta = it.cos_theta;
-    sh_body<NB, false, false, FAST>(b, it.ang);
+    AngPtr angp = (AngPtr)((ArgBytes)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(SHArgs, ang));
+    if (a.batch) {
+        const ItemPtr it = (ItemPtr)(unsigned long)a.batch + blockIdx.y;
+        b.dtau = it->dtau; b.tau = it->tau; b.w0 = it->w0; b.ftau_cld = it->ftau_cld; b.ftau_ray = it->ftau_ray;
+        b.f_deltaM = it->f_deltaM; b.dtau_og = it->dtau_og; b.tau_og = it->tau_og; b.w0_og = it->w0_og;
+        b.cosb_og = it->cosb_og; b.surf_reflect = it->surf_reflect; b.F0PI = it->F0PI; b.xint = it->xint;
+        b.cos_theta = it->cos_theta;
+        angp = it->ang;
+    }
+    sh_body<NB, false, false, FAST, DRVT>(b, angp);
 }
 
 
@@ -1477,7 +1576,6 @@ __global__ __launch_bounds__(256, 2) void k_sh4_clear(const SHCArgs a)
     Exp2Coef K;
     K.load();
     const double F = a.F0PI[w], rs = a.surf_reflect[w];
-    const double CLIP2 = -35.0 * LOG2E;
     // per angle: transmission to the top T, TOA functional J = kappa + zeta . v, sweep right-hand side delta, the
     // beam exponential at the layer top and the previous layer's particular solution at its bottom
     double T[NA], kappa[NA], zeta[NA][NB], delta[NA][NB], e_top[NA], p_zmn_up[NA][NB], p_zpl_up[NA][NB];
@@ -1546,9 +1644,14 @@ __global__ __launch_bounds__(256, 2) void k_sh4_clear(const SHCArgs a)
             const double h0 = 0.5 * eta[0], e58 = 0.625 * eta[2], m0 = -0.125 * eta[0];
             const double zpl0 = ((h0 + eta[1]) + e58) * (2 * PI), zmn0 = ((h0 - eta[1]) + e58) * (2 * PI);
             const double zpl1 = ((m0 + e58) + eta[3]) * (2 * PI), zmn1 = ((m0 + e58) - eta[3]) * (2 * PI);
-            const double ed = e_top[k];                                      // exp(-clip35(tau[i]/u0))
-            const double eu = fexp2_clip(tau_b * g.nl0, K);
-            e_top[k] = eu;
+            // exp(-tau/u0) at the layer top and bottom.  e_top carries the UNCLIPPED value: in the symmetric geometry
+            // (u0 == u1) the bottom one is the top one times exp(-dtau/u1), already at hand -- one multiply instead of a
+            // 15-instruction polynomial -- and the reference's exp(-clip35(tau/u0)) (:3418-3421) is max(., e^-35) of it
+            // (exp is monotonic).  Other geometries form the exponential of the running sum tau directly.
+            const double pt = e_top[k];
+            const double pb = g.sym ? pt * edt : fexp2(tau_b * g.nl0, K);
+            e_top[k] = pb;
+            const double ed = fmax(pt, EXP_M35), eu = fmax(pb, EXP_M35);
             const double zmn_dn[NB] = {zmn0 * ed, zmn1 * ed}, zpl_dn[NB] = {zpl0 * ed, zpl1 * ed};
             const double zmn_up[NB] = {zmn0 * eu, zmn1 * eu}, zpl_up[NB] = {zpl0 * eu, zpl1 * eu};
 
@@ -1582,15 +1685,10 @@ __global__ __launch_bounds__(256, 2) void k_sh4_clear(const SHCArgs a)
                 e_mus = sq_lane ? e_mus : d;
             }
             const double om = 1 - e_mus;
-            const double expon1 = (om * g.imus) * fmax(ed, EXP_M35);
+            const double expon1 = (om * g.imus) * ed;
             const double Nsum = fma(g.hp2u1, eta[2], eta[0]) * expon1;      // :2919-2920, 2945-2948
-            // exp(-tau_og/u0) at the layer top, unclipped (:2962): the exponential at hand unless its clip bound
-            const double targ = tau_t * g.nl0;
-            double e_tauo = ed;
-            if (!__all(targ >= CLIP2)) {
-                const double d = fexp2(targ, K);
-                e_tauo = (targ >= CLIP2) ? ed : d;
-            }
+            // exp(-tau_og/u0) at the layer top, unclipped (:2962): tau_og = tau without cloud
+            const double e_tauo = pt;
             const double single = ((sgl * om) * e_tauo) * g.imus;
             double c = Ti * fma(w0, Nsum, single);
             const double Tn = Tk * edt;
@@ -1751,8 +1849,9 @@ __global__ void k_sh_check_top(const SHArgs a, int top, unsigned long long *bad)
         const long o = (long)i * a.pitch + w;
         const double dt = a.dtau[o];
         n += (a.ftau_cld[o] != 0.0) + (a.cosb_og[o] != 0.0) + (a.f_deltaM[o] != 0.0) + (a.ftau_ray[o] != 1.0) +
-             (a.dtau_og[o] != dt) + (a.w0_og[o] != a.w0[o]) + (a.tau[o + a.pitch] != a.tau[o] + dt) +
-             (a.tau_og[o] != a.tau[o]) + (i == 0 && a.tau[o] != 0.0);
+             (a.dtau_og[o] != dt) + (a.w0_og[o] != a.w0[o]);
+        if (a.tau && a.tau_og)                  // (left out: re-derived as running sums in the kernels)
+            n += (a.tau[o + a.pitch] != a.tau[o] + dt) + (a.tau_og[o] != a.tau[o]) + (i == 0 && a.tau[o] != 0.0);
     }
     if (n) atomicAdd(bad, (unsigned long long)n);
 }
@@ -1785,29 +1884,34 @@ static int launch_sh(picaso_ctx *ctx, SHArgs &a, int nang, bool thermal)
     const bool flx = a.flux != nullptr;
     const bool fast = !thermal && !flx && !getenv("PICASO_AMD_SH_GENERIC") && a.w_single_form == 0 &&
                       a.w_multi_form == 0 && a.psingle_form == 0 && a.single_form == 0 && a.w_single_rayleigh == 1 &&
-                      a.w_multi_rayleigh == 1 && a.psingle_rayleigh == 1 && a.frac_c == 2.0;   // config.json defaults
-    if (a.batch) {
-        if (thermal || flx) return fail(ctx, "SH batch: reflected light without layer fluxes only");
+                      a.w_multi_rayleigh == 1 && a.psingle_rayleigh == 1 && a.frac_c == 2.0 &&   // config.json defaults
+                      (double)a.pitch * (a.nlayer + 1) * 8.0 < 4294967296.0;                   // 32-bit plane offsets
+    if (a.batch && (thermal || flx)) return fail(ctx, "SH batch: reflected light without layer fluxes only");
+    const bool drvt = !thermal && (!a.tau || !a.tau_og);   // level planes left out: picaso_reflected_SH_can_derive_levels
+    if (drvt && (!fast || a.tau || a.tau_og))
+        return fail(ctx, "get_reflected_SH: tau and tau_og may be left out (both) only with the reference's default "
+                         "options, flx = 0 and planes below 4 GB (picaso_reflected_SH_can_derive_levels)");
+    if (!thermal && !flx) {                         // single spectrum (a.batch = NULL) or a batch: the same kernel
+#define PZ_GO(KERNEL) hipLaunchKernelGGL(KERNEL, grid, dim3(block), 0, ctx->stream, a)
         if (a.stream == 4) {
-            if (fast) hipLaunchKernelGGL((k_sh_batch<2, true>), grid, dim3(block), 0, ctx->stream, a);
-            else hipLaunchKernelGGL((k_sh_batch<2, false>), grid, dim3(block), 0, ctx->stream, a);
+            if (drvt) PZ_GO((k_sh_refl<2, true, true>));
+            else if (fast) PZ_GO((k_sh_refl<2, true>));
+            else PZ_GO((k_sh_refl<2, false>));
         } else {
-            if (fast) hipLaunchKernelGGL((k_sh_batch<1, true>), grid, dim3(block), 0, ctx->stream, a);
-            else hipLaunchKernelGGL((k_sh_batch<1, false>), grid, dim3(block), 0, ctx->stream, a);
+            if (drvt) PZ_GO((k_sh_refl<1, true, true>));
+            else if (fast) PZ_GO((k_sh_refl<1, true>));
+            else PZ_GO((k_sh_refl<1, false>));
         }
+#undef PZ_GO
         PZ_HIP(ctx, hipGetLastError());
         return 0;
     }
     if (a.stream == 4) {
         if (thermal) hipLaunchKernelGGL((k_sh<2, true, false>), grid, dim3(block), 0, ctx->stream, a);
-        else if (flx) hipLaunchKernelGGL((k_sh<2, false, true>), grid, dim3(block), 0, ctx->stream, a);
-        else if (fast) hipLaunchKernelGGL((k_sh<2, false, false, true>), grid, dim3(block), 0, ctx->stream, a);
-        else hipLaunchKernelGGL((k_sh<2, false, false>), grid, dim3(block), 0, ctx->stream, a);
+        else hipLaunchKernelGGL((k_sh<2, false, true>), grid, dim3(block), 0, ctx->stream, a);
     } else {
         if (thermal) hipLaunchKernelGGL((k_sh<1, true, false>), grid, dim3(block), 0, ctx->stream, a);
-        else if (flx) hipLaunchKernelGGL((k_sh<1, false, true>), grid, dim3(block), 0, ctx->stream, a);
-        else if (fast) hipLaunchKernelGGL((k_sh<1, false, false, true>), grid, dim3(block), 0, ctx->stream, a);
-        else hipLaunchKernelGGL((k_sh<1, false, false>), grid, dim3(block), 0, ctx->stream, a);
+        else hipLaunchKernelGGL((k_sh<1, false, true>), grid, dim3(block), 0, ctx->stream, a);
     }
     PZ_HIP(ctx, hipGetLastError());
     return 0;
@@ -1876,6 +1980,16 @@ int picaso_reflected_SH_can_derive(int stream, int w_single_form, int w_multi_fo
            w_single_rayleigh == 1 && w_multi_rayleigh == 1 && psingle_rayleigh == 1 && frac_c == 2.0;
 }
 
+int picaso_reflected_SH_can_derive_levels(int nlevel, long plane_pitch, int stream, int w_single_form, int w_multi_form,
+                                          int psingle_form, int w_single_rayleigh, int w_multi_rayleigh,
+                                          int psingle_rayleigh, double frac_c, int single_form, int flx)
+{
+    if (getenv("PICASO_AMD_SH_GENERIC") || getenv("PICASO_AMD_SH_ALL_PLANES")) return 0;
+    return (stream == 2 || stream == 4) && !flx && w_single_form == 0 && w_multi_form == 0 && psingle_form == 0 &&
+           single_form == 0 && w_single_rayleigh == 1 && w_multi_rayleigh == 1 && psingle_rayleigh == 1 && frac_c == 2.0 &&
+           nlevel >= 2 && (double)plane_pitch * nlevel * 8.0 < 4294967296.0;
+}
+
 int picaso_get_reflected_SH_dev(picaso_ctx *ctx, int nlevel, int nwno, long plane_pitch, int numg, int numt,
                                 const double *dtau, const double *tau, const double *w0,
                                 const double *cosb, const double *ftau_cld, const double *ftau_ray,
@@ -1924,7 +2038,14 @@ int picaso_get_reflected_SH_top_dev(picaso_ctx *ctx, int nlevel, int nwno, long 
     const double *const derivable[8] = {tau, ftau_cld, ftau_ray, f_deltaM, dtau_og, tau_og, w0_og, cosb_og};
     int nnull = 0;
     for (int j = 0; j < 8; ++j) nnull += derivable[j] ? 0 : 1;
-    if (nnull) {
+    // only the two level planes left out: the running-product form of the beam exponentials (k_sh<.., DRVT>)
+    const bool levels_only = (nnull == 2 && !tau && !tau_og);
+    if (levels_only &&
+        !picaso_reflected_SH_can_derive_levels(nlevel, plane_pitch, stream, w_single_form, w_multi_form, psingle_form,
+                                               w_single_rayleigh, w_multi_rayleigh, psingle_rayleigh, frac_c, single_form, flx))
+        return fail(ctx, "get_reflected_SH: tau and tau_og may be left out only with the reference's default phase-function "
+                         "options, flx = 0 and planes below 4 GB (picaso_reflected_SH_can_derive_levels); pass them");
+    if (nnull && !levels_only) {
         // cloud-free form: dtau and w0 only, everything else known (k_sh4_clear)
         if (nnull != 8)
             return fail(ctx, "get_reflected_SH: leave out all of tau, cosb, ftau_cld, ftau_ray, f_deltaM, dtau_og, tau_og, "

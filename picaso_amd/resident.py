@@ -309,6 +309,20 @@ def reflected_SH_can_derive(stream, w_single_form=0, w_multi_form=0, psingle_for
                                                    float(frac_c), int(single_form), int(flx)))
 
 
+def reflected_SH_can_derive_levels(nlevel, plane_pitch, stream, w_single_form=0, w_multi_form=0, psingle_form=0,
+                                   w_single_rayleigh=1, w_multi_rayleigh=1, psingle_rayleigh=1, frac_c=2.0, single_form=0,
+                                   flx=0):
+    """True when ``reflected_SH`` / ``reflected_SH_ck`` with these options may be handed ``None`` for the level planes
+    ``tau`` and ``tau_og`` (both): the launch then carries the beam exponentials as running products of the layers'
+    (``picaso_reflected_SH_can_derive_levels``)."""
+    lib = load()
+    lib.picaso_reflected_SH_can_derive_levels.argtypes = ([ctypes.c_int, ctypes.c_long] + [ctypes.c_int] * 7
+                                                          + [ctypes.c_double] + [ctypes.c_int] * 2)
+    return bool(lib.picaso_reflected_SH_can_derive_levels(
+        int(nlevel), int(plane_pitch), int(stream), int(w_single_form), int(w_multi_form), int(psingle_form),
+        int(w_single_rayleigh), int(w_multi_rayleigh), int(psingle_rayleigh), float(frac_c), int(single_form), int(flx)))
+
+
 def reflected_SH(ctx, nlevel, nwno, numg, numt, planes, surf_reflect, ubar0, ubar1, cos_theta, F0PI,
                  w_single_form, w_multi_form, psingle_form, w_single_rayleigh, w_multi_rayleigh,
                  psingle_rayleigh, frac_a, frac_b, frac_c, constant_back, constant_forward, stream,

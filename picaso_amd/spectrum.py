@@ -372,7 +372,8 @@ class Spectrum:
         and w0 are written (0.26 -> 0.09 ms of mixing at 1e5 x 90) and the solvers get the same buffer under several
         names plus three constant planes kept on the opacity object: same values, hence the same bits, as the full set.
         ``sh_lean``: SH4 with the reference's default forms, same atmosphere: dtau and w0 are all the cloud-free SH launch
-        reads.  ``sh_top``: a cloud deck -- the layers above it go through the cloud-free SH kernel.  Correlated-k tables,
+        reads.  ``sh_top``: a cloud deck -- the layers above it go through the cloud-free SH kernel; a cloudy SH spectrum with
+        the default options leaves out the level planes (running products in the kernel).  Correlated-k tables (Toon),
         patchy clouds, test modes and ``all_planes`` take the full set."""
         inp, opt, calc, common, toon = self.inp, self.opt, self.calculation, self.common, self.toon
         plain = (self.ngauss == 1 and inp["test_mode"] is None and not self.do_holes and not opt.all_planes)
@@ -395,9 +396,17 @@ class Spectrum:
                                 sh_o["single_form"], 1 if sh_o["calculate_fluxes"] else 0))
             if self.sh_lean:
                 want = {"dtau", "w0"}
-            elif inp["test_mode"] is None and rayleigh and not opt.all_planes:
-                # (every wavelength block of a sharded spectrum reads the same profile, hence the same statement)
-                self.sh_top = _cloud_free_top(inp, atm.c.nlayer)
+            else:
+                if inp["test_mode"] is None and rayleigh and not opt.all_planes:
+                    # (every wavelength block of a sharded spectrum reads the same profile, hence the same statement)
+                    self.sh_top = _cloud_free_top(inp, atm.c.nlayer)
+                # the level planes tau / tau_og are running sums: the default-options launch carries the beam exponentials
+                # as running products instead of reading them, and cosb, gcos2, w0_no_raman are read by no SH solver
+                if (not opt.all_planes and not self.full_output and resident.reflected_SH_can_derive_levels(
+                        atm.c.nlevel, self.nwno * self.ngauss, common["stream"], sh_o["w_single_form"], sh_o["w_multi_form"],
+                        sh_o["psingle_form"], sh_o["w_single_rayleigh"], sh_o["w_multi_rayleigh"], sh_o["psingle_rayleigh"],
+                        self.frac[2], sh_o["single_form"], 1 if (sh_o["calculate_fluxes"] and self.ngauss == 1) else 0)):
+                    want = {"dtau", "w0", "cosb_og", "ftau_cld", "ftau_ray", "f_deltaM", "dtau_og", "w0_og"}
         elif self.lean:
             want = set()
             if "reflected" in calc:

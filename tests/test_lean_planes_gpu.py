@@ -103,8 +103,8 @@ def test_lean_planes_not_used_with_clouds_or_test_mode(monkeypatch):
 def test_sh4_cloud_free_writes_two_planes(monkeypatch, calc):
     """rt_method='SH', stream 4, default forms, no cloud: dtau and w0 are written and the cloud-free SH launch
     (k_sh4_clear) solves them; reflected light agrees with the full-plane launch to the oracle's tolerance (not bit for
-    bit: sh.hip), thermal emission -- the same kernel on the same two planes -- is bit-identical.  A cloud, other
-    forms, layer fluxes or full_output keep the thirteen planes."""
+    bit: sh.hip), thermal emission -- the same kernel on the same two planes -- is bit-identical.  Other
+    forms or layer fluxes keep the thirteen planes; a cloud with the default forms takes eight."""
     from picaso_amd import justdoit as jdi
     from picaso_amd import optics as px
     og = np.load(os.path.join(GOLDEN, "optics.npz"))
@@ -130,10 +130,18 @@ def test_sh4_cloud_free_writes_two_planes(monkeypatch, calc):
     if "thermal" in calc:
         assert np.array_equal(lean["thermal"], full["thermal"])
     if calc == "reflected":
+        # a cloud with the default forms: the eight planes the SH launch reads -- the level planes tau / tau_og are running
+        # sums (running products of the beam exponentials in the kernel, round 5), cosb / gcos2 / w0_no_raman are read by
+        # no SH solver -- within the rounding of the products of the full set's result
         c = case()
         c.clouds(df={"opd": og["in/cld_opd"], "w0": og["in/cld_w0"], "g0": og["in/cld_g0"]})
-        c.spectrum(opa, calculation=calc)
+        eight = c.spectrum(opa, calculation=calc)
+        assert wants[-1] == {"dtau", "w0", "cosb_og", "ftau_cld", "ftau_ray", "f_deltaM", "dtau_og", "w0_og"}
+        monkeypatch.setenv("PICASO_AMD_ALL_PLANES", "1")
+        thirteen = c.spectrum(opa, calculation=calc)
         assert wants[-1] is None
+        monkeypatch.delenv("PICASO_AMD_ALL_PLANES")
+        assert np.max(np.abs(eight["albedo"] - thirteen["albedo"]) / np.abs(thirteen["albedo"])) < 1e-11
         case(w_multi_form="OTHG").spectrum(opa, calculation=calc)
         assert wants[-1] is None
         case(calculate_fluxes="on").spectrum(opa, calculation=calc)

@@ -188,3 +188,63 @@ def test_cloud_free_top_statement_is_checked_on_request(hip, monkeypatch):
     whole = _resident_call(hip, clear, nlayer, nwno, 5, 1, u0, u1, ct, 0.1, 1.0, nlayer + 5)
     lean = _call(hip.fluxes.get_reflected_SH, clear, nlayer, nwno, 5, 1, u0, u1, ct, 0.1, 1.0, True)
     assert np.array_equal(whole, lean)
+
+
+@pytest.mark.parametrize("stream", [2, 4])
+@pytest.mark.parametrize("phase", [0.0, 1.1])
+def test_sh_level_planes_left_out_running_products(stream, phase):
+    """tau and tau_og left out (picaso_reflected_SH_can_derive_levels): the launch carries exp(-tau/u0) and
+    exp(-tau_og/u0) as running products of the layers' exp(-dtau/u0) (in the symmetric geometry the exp(-dtau/u1) at hand)
+    instead of reading the planes and forming two more exponentials per layer.  Against the plane-reading launch: the
+    rounding of the products times the conditioning of the layer systems (observed <= 5e-12, SH2 at the larger end), for
+    thin and for 35-clipped thick columns, with and without the cloud-free top split; a column's bits do not depend on the wavelength block it is launched in."""
+    from picaso_amd import _lib, device, disco, resident
+    from picaso_amd import synthetic as syn
+    ctx = _lib.context()
+    nlayer, nwno = 41, 777
+    if phase == 0.0:
+        g, gw, t, tw = disco.get_angles_1d(5)
+        nt = 1
+    else:
+        g, gw, t, tw = disco.get_angles_3d(3, 2)
+        nt = 2
+    u0, u1, cth, _, _ = disco.compute_disco(len(g), nt, g, t, phase)
+    ct = 1.0 if phase == 0.0 else float(cth)
+    ng = len(g)
+    opts = (0, 0, 0, 1, 1, 1, 1.0, -1.0, 2.0, -0.5, 1.0, stream)
+    assert resident.reflected_SH_can_derive_levels(nlayer + 1, nwno, stream)
+    assert not resident.reflected_SH_can_derive_levels(nlayer + 1, nwno, stream, w_single_form=1)
+    for seed, kw in ((3, {}), (4, dict(gas_scale=80.0, cloud_opd=30.0)), (5, dict(cloud=False))):
+        sc = syn.make_scene(nlayer, nwno, seed=seed, stream=stream, **kw)
+        sc["F0PI"] = np.linspace(0.8, 1.2, nwno)
+        sc["surf_reflect"] = np.full(nwno, 0.2)
+        d = resident.upload_scene(sc, resident.SH_PLANES + ("F0PI", "surf_reflect"), ctx=ctx)
+        lean = {k: v for k, v in d.items() if k not in ("tau", "tau_og")}
+
+        def run(planes, top=0, lo=0, hi=nwno):
+            n = hi - lo
+            pl = planes if (lo, hi) == (0, nwno) else {k: device.DeviceArray.from_host(
+                np.ascontiguousarray(sc[k][:, lo:hi]), ctx) for k in planes if k in resident.SH_PLANES}
+            rs = device.DeviceArray.from_host(sc["surf_reflect"][lo:hi], ctx)
+            f0 = device.DeviceArray.from_host(sc["F0PI"][lo:hi], ctx)
+            x = device.DeviceArray((ng, nt, n), ctx)
+            resident.reflected_SH(ctx, nlayer + 1, n, ng, nt, pl, rs, u0, u1, ct, f0, *opts, x, cloud_free_above=top)
+            return x.to_host()
+        full, drv = run(d), run(lean)
+        assert np.isfinite(drv).all()
+        assert np.max(np.abs(drv - full) / np.abs(full)) < 1e-10, (seed, stream, phase)
+        # launch-shape invariance of the derived form
+        part = run(lean, lo=100, hi=400)
+        assert np.array_equal(part, drv[:, :, 100:400])
+        if stream == 4 and seed == 3:
+            from picaso_amd import justdoit as jdi           # noqa: F401
+            top = int(np.argmax((sc["ftau_cld"] != 0).any(axis=1)))
+            if top >= 4:
+                a, b = run(d, top=top), run(lean, top=top)
+                assert np.max(np.abs(b - a) / np.abs(a)) < 1e-10
+                assert np.max(np.abs(b - full) / np.abs(full)) < 1e-9
+    # options outside the default set: the launch asks for the planes
+    with pytest.raises(Exception, match="tau and tau_og may be left out"):
+        x = device.DeviceArray((ng, nt, nwno), ctx)
+        resident.reflected_SH(ctx, nlayer + 1, nwno, ng, nt, lean, d["surf_reflect"], u0, u1, ct, d["F0PI"], 1, 1, 1, 1, 1, 1,
+                              1.0, -1.0, 2.0, -0.5, 1.0, stream, x)
