@@ -192,11 +192,12 @@ def workload_thermal(ctx, args, lo, hi, seed, nwno_total, scene=None):
                 metric="spectra/sec (%d wave x %d layer thermal)" % (nwno_total, nlayer))
 
 
-def workload_sh4(ctx, args, lo, hi, seed, nwno_total, scene=None, clear=False, top=0):
+def workload_sh4(ctx, args, lo, hi, seed, nwno_total, scene=None, clear=False, top=0, levels=True):
     """configs[3]: get_reflected_SH, stream = 4, + compress_disco.  ``clear``: the scene has no cloud and the launch is
     handed dtau and w0 only (picaso_reflected_SH_can_derive; the oracle still gets all eleven planes).  ``top``: the
     caller's statement that the first ``top`` layers carry no cloud (picaso_get_reflected_SH_top_dev; what spectrum()
-    reads off the cloud profile)."""
+    reads off the cloud profile).  ``levels=False``: the level planes tau / tau_og are left out
+    (picaso_reflected_SH_can_derive_levels: running products of the beam exponentials in the kernel; spectrum()'s plane set)."""
     nlayer, nlevel, ng = args.nlayer, args.nlayer + 1, args.ngauss
     n = hi - lo
     gang, gw, tang, tw = disco.get_angles_1d(ng)
@@ -210,6 +211,8 @@ def workload_sh4(ctx, args, lo, hi, seed, nwno_total, scene=None, clear=False, t
     opts = (0, 0, 0, 1, 1, 1)        # w_single_form, w_multi_form, psingle_form, *_rayleigh (config.json defaults)
 
     planes = {"dtau": d["dtau"], "w0": d["w0"]} if clear else d
+    if not levels and not clear:
+        planes = {k: v for k, v in d.items() if k not in ("tau", "tau_og")}
 
     def solve(albedo):
         resident.reflected_SH(ctx, nlevel, n, ng, 1, planes, d["surf_reflect"], ubar0, ubar1, 1.0, d["F0PI"], *opts,
@@ -232,7 +235,8 @@ def workload_sh4(ctx, args, lo, hi, seed, nwno_total, scene=None, clear=False, t
                     metric="spectra/sec (%d wave x %d layer SH4 reflected, cloud-free)" % (nwno_total, nlayer))
     return dict(solve=solve, oracle=oracle, nloc=n,
                 abytes=8 * n * (9 * nlayer + 2 * nlevel + 2 + ng + 1),
-                kernel="k_sh<2, false, false, true>" if not top else "k_sh4_clear<2> (layers 0-%d) + k_sh<2, false, false, true>" % (top - 1),
+                kernel=("k_sh_refl<2, true%s>" % ("" if levels else ", true")) if not top else
+                       "k_sh4_clear<2> (layers 0-%d) + k_sh_refl<2, true%s>" % (top - 1, "" if levels else ", true"),
                 workload="BASELINE configs[3]: spherical-harmonics SH4 reflected light (get_reflected_SH + "
                          "compress_disco), TTHG, delta-M, Rayleigh + cloud slab",
                 metric="spectra/sec (%d wave x %d layer SH4 reflected)" % (nwno_total, nlayer))
@@ -477,6 +481,17 @@ def companions(ctx, args, wl, res_single, nwno_total):
     w3t = workload_sh4(ctx, args, 0, nwno_total, 3, nwno_total, scene=sc4, top=deck)
     ms3t = steady_ms(ctx, lambda: w3t["solve"](out3), 40, prewarm_ms=100.0)
     sec["configs[3] cloud_free_above=%d" % deck] = entry(w3t, ms3t, n_oracle=128, res=out3.to_host())
+    # ... and without the level planes tau / tau_og (running sums: the kernel carries the beam exponentials as running
+    # products; the plane set spectrum() hands over): whole grid, shard, and with the cloud deck statement -- the product's
+    # launch.  Algorithmic bytes stay SURVEY 8(d)'s eleven planes.
+    for tag, n3, tp in (("configs[3] level planes left out", nwno_total, 0),
+                        ("configs[3] 12500-column shard, level planes left out", 12500, 0),
+                        ("configs[3] level planes left out, cloud_free_above=%d" % deck, nwno_total, deck)):
+        w3l = workload_sh4(ctx, args, 0, n3, 3, nwno_total, scene=sc4, top=tp, levels=False)
+        o3l = device.DeviceArray((n3,), ctx)
+        ms3l = steady_ms(ctx, lambda: w3l["solve"](o3l), 40 if n3 > 20000 else 150, prewarm_ms=100.0)
+        sec[tag] = entry(w3l, ms3l, n_oracle=128, res=o3l.to_host())
+        del w3l, o3l
     del w3, w3s, w3t, sc4
     # the same atmosphere without its cloud: the cloud-free SH4 form against the full-plane kernel on the same planes
     # (no cloud profile: opd = w0 = g0 = 0 in every layer, what ATMSETUP.get_clouds leaves, atmsetup.py:609-640 -- COSB is
@@ -696,8 +711,65 @@ def product_companion(ctx, nwno=100000, nlevel=91, ncalls=30, nbatch=32):
             tt.append(time.perf_counter() - t0)
         return {"ms": 1e3 * float(np.median(tt)), "finite": bool(np.all(np.isfinite(o["transit_depth"])))}
 
+    def part_ck():
+        # correlated-k tables at the climate grid's shape (661 bins x 8 Gauss points, premixed): the Gauss loop is the column
+        # axis of ONE launch per leg for every solver (csrc/ckloop.hip) -- SH4 in 1-D, and the 3-D branch on 8 x 8 facets
+        # with per-facet temperatures (reference justdoit.py:256-307, 488-516), plus an 8-phase thermal phase curve
+        nb, nk = 661, 8
+        wck = np.linspace(40.0, 28000.0, nb)
+        xg, wg = np.polynomial.legendre.leggauss(4)
+        gpts = np.concatenate([0.95 * 0.5 * (xg + 1), 0.95 + 0.05 * 0.5 * (xg + 1)])
+        gwts = np.concatenate([0.95 * 0.5 * wg, 0.05 * 0.5 * wg])
+        tk, pk = np.array(temps), np.array(press)
+        lnk = np.log(10.0) * (-26.0 + 2.0 * np.sin(wck / 2500.0)[None, None, :, None] + 0.5 * np.log10(pk)[:, None, None, None]
+                              + 0.9 * np.log10(tk / 300.0)[None, :, None, None] + 0.6 * np.arange(nk)[None, None, None, :])
+        cont = {pr: {t: 10.0 ** (-7.0 + np.cos(wck / 4000.0 + k) + 0.3 * np.log10(t / 300.0)) for t in cia_t}
+                for k, pr in enumerate(("H2H2", "H2He"))}
+        opk = px.RetrieveCKs(wck, gwts, np.tile(pk, tk.size), np.repeat(tk, pk.size), np.full(tk.size, pk.size), lnk,
+                             continuum=cont, cia_temps=cia_t, rayleigh_opa={m: 1e-27 * (wck / 1e4) ** 4 for m in ("H2", "He")},
+                             gauss_pts=gpts, ctx=ctx)
+
+        def timed_k(c, n=10, **kw):
+            for _ in range(3):
+                c.spectrum(opk, calculation=calc, **kw)
+            tt = []
+            for _ in range(n):
+                t0 = time.perf_counter()
+                out = c.spectrum(opk, calculation=calc, **kw)
+                tt.append(time.perf_counter() - t0)
+            return 1e3 * float(np.median(tt)), out
+        toon = make(0)
+        toon_ms, toon_out = timed_k(toon)
+        sh = make(0)
+        sh.approx(raman="none", rt_method="SH", stream=4)
+        sh_ms, sh_out = timed_k(sh)
+        pert = 1.0 + 0.1 * np.cos(np.arange(64).reshape(8, 8))
+        c3 = jdi.inputs()
+        c3.phase_angle(np.pi / 3, num_gangle=8, num_tangle=8)
+        c3.gravity(gravity=2500.0)
+        c3.atmosphere_3d(dict(prof, temperature=prof["temperature"][:, None, None] * pert[None]))
+        c3.approx(raman="none")
+        d3_ms, d3_out = timed_k(c3, n=6, dimension="3d")
+        phases = list(2 * np.pi * (np.arange(8) + 0.5) / 8)
+        pc = jdi.inputs()
+        pc.phase_curve_geometry("thermal", phases, num_gangle=8, num_tangle=8)
+        pc.gravity(gravity=2500.0)
+        pc.atmosphere_4d([dict(prof, temperature=prof["temperature"][:, None, None] * (pert[None] + 0.01 * k)) for k in range(8)])
+        pc.approx(raman="none")
+        pc.phase_curve(opk)
+        t0 = time.perf_counter()
+        curve = pc.phase_curve(opk)
+        pc_ms = 1e3 * (time.perf_counter() - t0)
+        fin = all(np.all(np.isfinite(o[k])) for o in (toon_out, sh_out, d3_out) for k in ("albedo", "thermal")) and \
+            all(np.all(np.isfinite(v["thermal"])) for v in curve.values())
+        return {"workload": "spectrum(opa = RetrieveCKs: %d bins x %d Gauss points, premixed, %d layers, 'reflected+thermal')"
+                            % (nb, nk, nl),
+                "toon_1d_ms": toon_ms, "sh4_1d_ms": sh_ms, "toon_3d_8x8_facets_ms": d3_ms,
+                "thermal_phase_curve_8_phases_8x8_facets_ms": pc_ms, "finite": bool(fin)}
+
     sh4 = guarded(part_sh4)
     return {"product": {
+        "correlated_k": guarded(part_ck),
         "climate_get_fluxes": guarded(part_climate),
         "transmission_spectrum": guarded(part_transmission),
         "spectrum_3d": guarded(part_3d),
