@@ -60,9 +60,21 @@ def test_sampled_columns_vs_oracle(full, oracle):
     planes = [np.ascontiguousarray(sc[k][:, idx]) for k in PLANES]
     xo, _ = oracle.get_reflected_1d(NLAYER + 1, sc["wno"][idx], idx.size, NG, 1, *planes, sc["surf_reflect"][idx],
                                     full["u0"], full["u1"], 1.0, sc["F0PI"][idx], 3, 0, *TTHG)
-    assert rel_err(full["x"][:, :, idx], xo) < 1e-8
+    # Observed (round 5, this sample): 3.2e-9 on xint, 1.1e-9 on the albedo -- from a handful of columns with a layer
+    # close to the direct-beam singularity lambda^2 = 1/ubar0^2 (fluxes.py:1155), where ANY fp64 evaluation, the
+    # reference's own included, carries ~eps / |lambda^2 - 1/ubar0^2| (tools/headline_error_x87.py,
+    # profiles/r05_headline_error_x87.json: 8 of 1e5 columns above 1e-10, the worst at |lambda^2 - 1/ubar0^2| = 3.6e-8,
+    # where the kernel sits 9e-11 from the x87 evaluation of the reference's expressions and the fp64 restatement 8e-10).
+    # Every column is held to 1e-9 plus that conditioning term; all but a few need no term at all.
+    w0, fcg = sc["w0"][:, idx], (sc["ftau_cld"] * sc["cosb"])[:, idx]
+    g1, g2 = (np.sqrt(3.0) * 0.5) * (2 - w0 * (1 + fcg)), (np.sqrt(3.0) * w0 * 0.5) * (1 - fcg)
+    dist = np.min(np.abs((g1 * g1 - g2 * g2)[:, :, None] - 1.0 / full["u0"].ravel()[None, None, :] ** 2), axis=(0, 2))
+    tol = 1e-9 + np.finfo(float).eps / dist
+    err = np.max(np.abs(full["x"][:, :, idx] - xo) / np.abs(xo), axis=(0, 1))
+    assert np.all(err < tol), (float(err.max()), int(np.argmax(err / tol)))
+    assert (err >= 1e-9).sum() <= 10 and (err >= 1e-10).sum() <= 40
     alb_o = oracle.compress_disco(idx.size, 1.0, xo, full["gw"], full["tw"], sc["F0PI"][idx])
-    assert rel_err(full["alb"][idx], alb_o) < 1e-8
+    assert np.all(np.abs(full["alb"][idx] - alb_o) / np.abs(alb_o) < tol)
 
 
 def test_eight_shards_as_on_an_8_gpu_node(full):
@@ -191,8 +203,8 @@ def test_thermal_fullsize(nwno, calc_type, oracle):
                                   np.ascontiguousarray(sc["w0_no_raman"][:, idx]),
                                   np.ascontiguousarray(sc["cosb_og"][:, idx]), sc["plevel"], u1, np.zeros(idx.size), 0,
                                   sc["dwno"][idx], calc_type)
-    assert rel_err(f[:, :, idx], fo) < 1e-8
-    assert rel_err(disk[idx], oracle.compress_thermal(idx.size, fo, gw, tw)) < 1e-8
+    assert rel_err(f[:, :, idx], fo) < 1e-9                     # observed 2.3e-11 / 8.4e-12 (round 5)
+    assert rel_err(disk[idx], oracle.compress_thermal(idx.size, fo, gw, tw)) < 1e-9
     for world in (3, 8):       # 8 shards of a 1e5 grid take the one-angle-per-wave launch, the whole grid the fused one
         parts = [run(lo, hi, calc_type) for lo, hi in shard_bounds(nwno, world)]
         assert np.array_equal(np.concatenate([p[0] for p in parts], axis=2), f)
@@ -232,8 +244,8 @@ def test_sh4_fullsize_eight_shards(oracle):
     planes = [np.ascontiguousarray(sc[k][:, idx]) for k in resident.SH_PLANES]
     xo, _ = oracle.get_reflected_SH(NLAYER + 1, idx.size, NG, 1, *planes, sc["surf_reflect"][idx], u0, u1, 1.0,
                                     sc["F0PI"][idx], *opts, *TTHG, 4)
-    assert rel_err(x[:, :, idx], xo) < 1e-8
-    assert rel_err(alb[idx], oracle.compress_disco(idx.size, 1.0, xo, gw, tw, sc["F0PI"][idx])) < 1e-8
+    assert rel_err(x[:, :, idx], xo) < 1e-9                     # observed 4.5e-11 / 1.4e-12 (round 5)
+    assert rel_err(alb[idx], oracle.compress_disco(idx.size, 1.0, xo, gw, tw, sc["F0PI"][idx])) < 1e-9
 
 
 def test_3d_64_facets_90_layers(oracle):
@@ -280,8 +292,8 @@ def test_3d_64_facets_90_layers(oracle):
     xo = oracle.get_reflected_3d(NLAYER + 1, base["wno"][idx], idx.size, ng, nt, *planes, rs[idx], u0, u1, float(ct),
                                  f0[idx], 0, 0, *TTHG)
     xo = xo[0] if isinstance(xo, tuple) else xo
-    assert rel_err(x[:, :, idx], xo) < 1e-8
-    assert rel_err(alb[idx], oracle.compress_disco(idx.size, float(ct), xo, gw, tw, f0[idx])) < 1e-8
+    assert rel_err(x[:, :, idx], xo) < 1e-9                     # observed 9.8e-13 / 5.8e-14 (round 5)
+    assert rel_err(alb[idx], oracle.compress_disco(idx.size, float(ct), xo, gw, tw, f0[idx])) < 1e-9
 
 
 def test_config4_full_size_on_one_gpu(oracle, monkeypatch):
@@ -335,8 +347,8 @@ def test_config4_full_size_on_one_gpu(oracle, monkeypatch):
         xo = oracle.get_reflected_3d(nlevel, opa.wno[lo:hi], n, ng, nt, *sub, np.full(n, 0.1), u0, u1, float(ct),
                                      np.ones(n), 3, 0, *TTHG)
         xo = xo[0] if isinstance(xo, tuple) else xo
-        assert rel_err(x[:, :, lo:hi], xo) < 1e-8, (lo, hi)
-        assert rel_err(out["albedo"][lo:hi], oracle.compress_disco(n, float(ct), xo, gw, tw, np.ones(n))) < 1e-8
+        assert rel_err(x[:, :, lo:hi], xo) < 1e-9, (lo, hi)     # observed 5.7e-15 / 8.0e-16 (round 5)
+        assert rel_err(out["albedo"][lo:hi], oracle.compress_disco(n, float(ct), xo, gw, tw, np.ones(n))) < 1e-9
     # the level planes are the running sums of the layer planes also beyond 4 GiB
     tail = kept["tau"].columns_to_host(nwno - 4, nwno)
     dt_tail = kept["dtau"].columns_to_host(nwno - 4, nwno)
@@ -371,8 +383,8 @@ def test_cold_levels_planck_overflow(calc_type, oracle):
     assert np.all(np.isfinite(fg)) and np.all(np.isfinite(fo))
     assert 1.4387769 * wno.max() / tlevel.min() > 709.8            # exp() of the top level really overflows
     scale = np.max(np.abs(fo))
-    assert np.max(np.abs(fg - fo)) <= 1e-8 * scale
+    assert np.max(np.abs(fg - fo)) <= 1e-9 * scale
     nz = np.abs(fo) > 1e-250
-    assert rel_err(fg[nz], fo[nz]) < 1e-8
+    assert rel_err(fg[nz], fo[nz]) < 1e-9                       # observed 2.2e-12 (round 5)
     for a, b in zip(lg, lo):
         assert np.all(np.isfinite(a))

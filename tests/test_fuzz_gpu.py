@@ -158,7 +158,7 @@ def test_fuzz_spherical_harmonics(oracle, block):
         from picaso_amd import synthetic as syn
         sc = syn.make_scene(nlayer, nwno, seed=1800 + 50 * block + it, stream=stream)
         ng, nt, gw, tw, u0, u1, ct = _geometry(rng)
-        opts = [int(rng.integers(0, 2)) for _ in range(3)] + [int(rng.integers(0, 2)) for _ in range(3)]
+        opts = [int(rng.integers(0, 3)) for _ in range(3)] + [int(rng.integers(0, 2)) for _ in range(3)]   # forms: TTHG / OTHG / isotropic
         sform = int(rng.integers(0, 2))
         rs = float(rng.choice([0.0, 0.3]))
         args = lambda fd: (nlayer + 1, nwno, ng, nt, sc["dtau"], sc["tau"], sc["w0"], sc["cosb"], sc["ftau_cld"],
@@ -166,7 +166,8 @@ def test_fuzz_spherical_harmonics(oracle, block):
                            ct, np.ones(nwno), *opts, *TTHG, stream)
         xg, _ = fluxes.get_reflected_SH(*args(sc["f_deltaM"].copy()), b_top=0.0, flx=0, single_form=sform)
         xo, _ = oracle.get_reflected_SH(*args(sc["f_deltaM"].copy()), b_top=0.0, flx=0, single_form=sform)
-        assert rel_err(xg, xo, 1e-4 * np.abs(xo).max()) < 1e-7, (block, it, nlayer, nwno, ng, nt, stream, opts, sform)
+        # observed max over the four blocks (round 5): 1.3e-12
+        assert rel_err(xg, xo, 1e-4 * np.abs(xo).max()) < 1e-9, (block, it, nlayer, nwno, ng, nt, stream, opts, sform)
 
 
 @pytest.mark.gpu
@@ -193,7 +194,8 @@ def test_fuzz_sh4_cloud_free_form(oracle, block):
         xg, _ = fluxes.get_reflected_SH(nlayer + 1, nwno, ng, nt, *lean, *tail)
         xo, _ = oracle.get_reflected_SH(nlayer + 1, nwno, ng, nt, *[np.array(a) for a in full], *tail)
         assert np.isfinite(xg).all()
-        assert rel_err(xg, xo, 1e-4 * np.abs(xo).max()) < 1e-7, (block, it, nlayer, nwno, ng, nt, b_top)
+        # observed max over the four blocks (round 5): 3.4e-11
+        assert rel_err(xg, xo, 1e-4 * np.abs(xo).max()) < 1e-9, (block, it, nlayer, nwno, ng, nt, b_top)
 
 
 def _facet_planes(rng, nlayer, nwno, ng, nt, seed):
