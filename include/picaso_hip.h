@@ -771,7 +771,7 @@ int picaso_raman_oklopcic_dev(picaso_ctx *ctx, int nlayer, long nwno, int ntrans
                               const int *j_initial, const int *is_rayleigh, const double *j_at_temp, double cap,
                               double *out);
 
-/* ---- one call per spectrum: every launch of picaso()'s 1-D Toon path, for every wavelength block -------------
+/* ---- one call per spectrum: every launch of picaso()'s 1-D path (Toon or SH), for every wavelength block ---------
  * (reference picaso/justdoit.py:236-385 is the per-spectrum sequence; its fan-out over processes :4774).  The
  * caller keeps one picaso_block per wavelength block (pointers into that block's resident tables and a workspace it
  * allocated once) and fills one picaso_spectrum_job per call with the per-layer tables all blocks share; the
@@ -833,6 +833,15 @@ typedef struct picaso_spectrum_job {
     double frac_a, frac_b, frac_c, constant_back, constant_forward, b_top;
     const double *tlevel, *plevel;         /* host (nlevel) */
     int hard_surface;
+    /* rt_method = 1: the spherical-harmonics solvers instead of the Toon ones (reference justdoit.py:259-269, 364-370):
+     * picaso_get_reflected_SH_top_dev / picaso_get_thermal_SH_dev with `stream` above (2 or 4), flx = 0 and the
+     * reference's per-angle f_deltaM compounding.  The block's refl_planes then hold the SH argument order -- dtau, tau,
+     * w0, cosb, ftau_cld, ftau_ray, f_deltaM, dtau_og, tau_og, w0_og, cosb_og (NULL where that entry point takes NULL) --
+     * and th_dtau / th_w0 / th_cosb what get_thermal_SH reads (dtau, w0, cosb_og).  0: Toon. */
+    int rt_method;
+    int sh_w_single_form, sh_w_multi_form, sh_psingle_form, sh_w_single_rayleigh, sh_w_multi_rayleigh,
+        sh_psingle_rayleigh, sh_single_form;
+    int sh_cloud_free_above;               /* as picaso_get_reflected_SH_top_dev (the same value for every block) */
 } picaso_spectrum_job;
 int picaso_toon_spectrum_blocks(int nblocks, picaso_block *blocks, const picaso_spectrum_job *job);
 /* copy one leg's results (which = 1: albedo, 2: thermal flux) of every block into albedo_host / thermal_host */

@@ -79,7 +79,16 @@ static int enqueue_block(int nblocks, picaso_block *blocks, const picaso_spectru
             return fail(k.ctx, "toon_spectrum_blocks: block %d still has uncollected results", b);
         picaso_ctx *tctx = k.tctx ? k.tctx : k.ctx;
         PZ_TRY(opacity_stage(k, j, b, (tctx != k.ctx && j.do_thermal) ? tctx : nullptr));
-        if (j.do_reflected) {
+        if (j.do_reflected && j.rt_method == 1) {
+            const double *const *r = k.refl_planes;             // SH argument order (picaso_spectrum_job::rt_method)
+            PZ_TRY(picaso_get_reflected_SH_top_dev(k.ctx, nlevel, k.nwno, k.nwno, j.numg, j.numt, r[0], r[1], r[2], r[3], r[4],
+                                                   r[5], r[6], r[7], r[8], r[9], r[10], k.surf_reflect, j.ubar0, j.ubar1,
+                                                   j.cos_theta, k.F0PI, j.sh_w_single_form, j.sh_w_multi_form,
+                                                   j.sh_psingle_form, j.sh_w_single_rayleigh, j.sh_w_multi_rayleigh,
+                                                   j.sh_psingle_rayleigh, j.frac_a, j.frac_b, j.frac_c, j.constant_back,
+                                                   j.constant_forward, j.stream, j.b_top, 0, j.sh_single_form, 1,
+                                                   j.sh_cloud_free_above, k.xint, nullptr, j.gweight, j.tweight, k.albedo));
+        } else if (j.do_reflected) {
             const double *const *r = k.refl_planes;
             PZ_TRY(picaso_get_reflected_1d_dev(k.ctx, nlevel, k.nwno, k.nwno, j.numg, j.numt, r[0], r[1], r[2], r[3], r[4],
                                                r[5], r[6], r[7], r[8], r[9], r[10], k.surf_reflect, j.ubar0, j.ubar1,
@@ -87,6 +96,8 @@ static int enqueue_block(int nblocks, picaso_block *blocks, const picaso_spectru
                                                j.frac_c, j.constant_back, j.constant_forward, 1, 0, j.toon_coefficients,
                                                j.b_top, k.xint, nullptr, nullptr, nullptr, nullptr, j.gweight, j.tweight,
                                                k.albedo));
+        }
+        if (j.do_reflected) {
             if (k.trapz_d) {
                 if (nblocks != 1) return fail(k.ctx, "toon_spectrum_blocks: device integrals need ONE block over the grid");
                 PZ_TRY(picaso_trapz_dev(k.ctx, k.nwno, k.trapz_d, k.albedo, k.stellar, 0, k.albedo + k.nwno));
@@ -96,6 +107,13 @@ static int enqueue_block(int nblocks, picaso_block *blocks, const picaso_spectru
                                                sizeof(double) * (size_t)(k.nwno + (k.trapz_d ? 1 : 0)), &k.albedo_mark));
         }
         if (j.do_thermal) {
+            if (j.rt_method == 1)
+                // ff = 0 if np.array_equal(cosb, cosb_og) else cosb_og**stream (fluxes.py:3072-3075): with delta-Eddington
+                // scaling the two planes differ wherever cosb_og**stream does not vanish (spectrum._thermal_sh)
+                PZ_TRY(picaso_get_thermal_SH_dev(tctx, nlevel, k.wno, k.nwno, k.nwno, j.numg, j.numt, j.tlevel, k.th_dtau,
+                                                 nullptr, k.th_w0, k.th_cosb, j.plevel, j.ubar1, k.surf_reflect, j.stream,
+                                                 j.hard_surface, j.delta_eddington, 0, k.flux, j.gweight, j.tweight, k.disk));
+            else
             PZ_TRY(picaso_get_thermal_1d_dev(tctx, nlevel, k.wno, k.nwno, k.nwno, j.numg, j.numt, j.tlevel, k.th_dtau,
                                              k.th_w0, k.th_cosb, j.plevel, j.ubar1, k.surf_reflect, j.hard_surface,
                                              nullptr, 0, k.flux, nullptr, nullptr, nullptr, nullptr, j.gweight, j.tweight,

@@ -21,6 +21,7 @@ _ip = ctypes.POINTER(ctypes.c_int)
 OUT_NAMES = ("dtau", "tau", "w0", "cosb", "ftau_cld", "ftau_ray", "gcos2", "dtau_og", "tau_og", "w0_og", "cosb_og",
              "w0_no_raman", "f_deltaM")                                 # order of picaso_compute_opacity_ck_dev
 REFL_NAMES = ("dtau", "tau", "w0", "cosb", "gcos2", "ftau_cld", "ftau_ray", "dtau_og", "tau_og", "w0_og", "cosb_og")
+SH_NAMES = ("dtau", "tau", "w0", "cosb", "ftau_cld", "ftau_ray", "f_deltaM", "dtau_og", "tau_og", "w0_og", "cosb_og")
 
 
 class Block(ctypes.Structure):
@@ -49,7 +50,11 @@ class Job(ctypes.Structure):
                 ("gweight", _dp), ("tweight", _dp), ("single_phase", ctypes.c_int), ("multi_phase", ctypes.c_int),
                 ("toon_coefficients", ctypes.c_int), ("frac_a", ctypes.c_double), ("frac_b", ctypes.c_double),
                 ("frac_c", ctypes.c_double), ("constant_back", ctypes.c_double), ("constant_forward", ctypes.c_double),
-                ("b_top", ctypes.c_double), ("tlevel", _dp), ("plevel", _dp), ("hard_surface", ctypes.c_int)]
+                ("b_top", ctypes.c_double), ("tlevel", _dp), ("plevel", _dp), ("hard_surface", ctypes.c_int),
+                ("rt_method", ctypes.c_int), ("sh_w_single_form", ctypes.c_int), ("sh_w_multi_form", ctypes.c_int),
+                ("sh_psingle_form", ctypes.c_int), ("sh_w_single_rayleigh", ctypes.c_int),
+                ("sh_w_multi_rayleigh", ctypes.c_int), ("sh_psingle_rayleigh", ctypes.c_int),
+                ("sh_single_form", ctypes.c_int), ("sh_cloud_free_above", ctypes.c_int)]
 
 
 def _dev(x):
@@ -77,7 +82,7 @@ class BlockTable:
     of the same signature: every access is ordered on the blocks' streams."""
 
     def __init__(self, subs, nlayer, ng, nt, mol_names, cia_pairs, ray_names, linear, want, lean, host_cloud,
-                 do_reflected, do_thermal, const_planes, derive=False):
+                 do_reflected, do_thermal, const_planes, derive=False, sh=False):
         self.subs, self.n = subs, len(subs)
         self.blocks = (Block * self.n)()
         self.keep = []                                   # DeviceArrays and pointer tables the structs point into
@@ -103,7 +108,13 @@ class BlockTable:
                     self.keep.append(pl[name])
                     k.planes[i] = _dev(pl[name])
             rpl = pl
-            if lean and derive:                          # the reflected kernel re-derives all but dtau and w0
+            if sh and lean:                              # SH, no cloud: the launch reads dtau and w0 (thermal: + cosb_og = 0)
+                zero, one, half = const_planes(sub, nlayer, nw)
+                rpl = {"dtau": pl["dtau"], "w0": pl["w0"]}
+                pl = dict(pl, cosb_og=zero)
+            elif sh:
+                pass                                     # the planes as written (level planes may be left out: derived)
+            elif lean and derive:                        # the reflected kernel re-derives all but dtau and w0
                 zero, one, half = const_planes(sub, nlayer, nw)
                 rpl = {"dtau": pl["dtau"], "w0": pl.get("w0")}
                 pl.update(dtau_og=pl["dtau"], cosb_og=zero)
@@ -117,13 +128,15 @@ class BlockTable:
                 if "w0_no_raman" not in pl and "w0" in pl:
                     pl["w0_no_raman"] = pl["w0"]
             if do_reflected:
-                for i, name in enumerate(REFL_NAMES):
+                for i, name in enumerate(SH_NAMES if sh else REFL_NAMES):
                     k.refl_planes[i] = _dev(rpl.get(name))       # None: left out, re-derived in the kernel
                 x, a = DeviceArray((ng, nt, nw), ctx), DeviceArray((nw + 1,), ctx)     # [nw]: the Bond-albedo integral
                 pin = PinnedArray((nw + 1,), ctx)           # the result copy is enqueued with the launches
                 self.keep += [x, a, pin]
                 k.xint, k.albedo, k.albedo_pin = _dev(x), _dev(a), ctypes.cast(ctypes.c_void_p(pin.addr), _dp)
-            if do_thermal:
+            if do_thermal and sh:                        # get_thermal_SH reads dtau, w0 and cosb_og (spectrum._thermal_sh)
+                k.th_dtau, k.th_w0, k.th_cosb = _dev(pl["dtau"]), _dev(pl["w0"]), _dev(pl["cosb_og"])
+            elif do_thermal:
                 k.th_dtau, k.th_w0, k.th_cosb = _dev(pl["dtau_og"]), _dev(pl["w0_no_raman"]), _dev(pl["cosb_og"])
             if host_cloud:
                 cw = [DeviceArray((nlayer, nw), ctx) for _ in range(3)]
@@ -144,7 +157,7 @@ class BlockTable:
 
 def make_job(nlayer, plan, factors, linear, raman_rows, stream, delta_eddington, do_reflected, do_thermal, ng, nt, ubar0,
              ubar1, cos_theta, gweight, tweight, single_phase, multi_phase, toon_coefficients, frac_a, frac_b, frac_c,
-             constant_back, constant_forward, b_top, tlevel, plevel, hard_surface):
+             constant_back, constant_forward, b_top, tlevel, plevel, hard_surface, sh=None, sh_top=0):
     """The per-call half: (Job, the numpy arrays it points into).  ``plan`` = ``opa._plan`` (table rows and weights per
     molecule and layer, CIA rows), ``factors`` = ``optics._layer_factors`` (per-layer coefficients of the sums)."""
     mol_fac, cont_fac, ray_names, ray_fac = factors
@@ -170,6 +183,13 @@ def make_job(nlayer, plan, factors, linear, raman_rows, stream, delta_eddington,
     j.frac_a, j.frac_b, j.frac_c = float(frac_a), float(frac_b), float(frac_c)
     j.constant_back, j.constant_forward, j.b_top = float(constant_back), float(constant_forward), float(b_top)
     j.tlevel, j.plevel, j.hard_surface = _host(keep["tl"]), _host(keep["pl"]), int(hard_surface)
+    j.rt_method = 0
+    if sh is not None:                     # inputs["approx"]["rt_params"]["SH"]: the spherical-harmonics solvers
+        j.rt_method = 1
+        j.sh_w_single_form, j.sh_w_multi_form, j.sh_psingle_form = (int(sh[k]) for k in ("w_single_form", "w_multi_form", "psingle_form"))
+        j.sh_w_single_rayleigh, j.sh_w_multi_rayleigh, j.sh_psingle_rayleigh = (
+            int(sh[k]) for k in ("w_single_rayleigh", "w_multi_rayleigh", "psingle_rayleigh"))
+        j.sh_single_form, j.sh_cloud_free_above = int(sh["single_form"]), int(sh_top)
     return j, keep
 
 

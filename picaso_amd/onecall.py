@@ -1,10 +1,10 @@
-"""One C call per spectrum (csrc/driver.hip): the launch sequence of the 1-D Toon path for every wavelength block.
+"""One C call per spectrum (csrc/driver.hip): the launch sequence of the 1-D path (Toon or SH) for every wavelength block.
 
-The plain 1-D Toon spectrum (reference justdoit.py:236-385, 552-599) through ``picaso_toon_spectrum_blocks``: ONE C call
+The plain 1-D spectrum (reference justdoit.py:236-385, 552-599) through ``picaso_toon_spectrum_blocks``: ONE C call
 enqueues gas stage -> ``compute_opacity`` -> reflected || thermal (+ fused disk sums) on every wavelength block of ``subs``
 (``[(lo, hi, opacity object of the block)]``; the whole grid on one GPU is one block), a second and third copy the legs
-back.  Outside what the driver covers (correlated-k tables, SH, patchy clouds, level fluxes, full_output, transmission,
-Oklopcic Raman or cloud tables on their own grid in a multi-block call, test modes) ``prepare`` returns None and the caller
+back.  Outside what the driver covers (correlated-k tables, SH layer fluxes, patchy clouds, level fluxes, full_output,
+transmission, Oklopcic Raman in a multi-block call, test modes) ``prepare`` returns None and the caller
 takes ``spectrum.Spectrum``, whose results these are bit for bit: the C function chains the same entry points in the same
 order.  ``prepare`` does everything up to the C call -- set-up, block table, per-call pointers, job -- ``run`` is
 prepare + the call + ``finish``.
@@ -35,17 +35,44 @@ def run(bundle, opa, subs, calculation, opt):
 
 
 def _in_scope(inp, opa, legs, nblocks, opt):
-    """The calls the C driver covers: reflected and / or thermal, Toon, monochromatic resident tables, no patchy clouds,
-    no level fluxes, no test mode; Oklopcic's Raman plane (formed per call on the block's device) for one block only."""
+    """The calls the C driver covers: reflected and / or thermal, Toon or SH (without layer fluxes), monochromatic
+    resident tables, no patchy clouds (SH ignores them, as the reference: ``Spectrum`` says so with a warning and is left to
+    say it), no level fluxes, no test mode; Oklopcic's Raman plane (formed per call on the block's device) for one block
+    only."""
     if opt.no_driver or opt.raman_planes:
         return False
     if not legs or not legs <= {"reflected", "thermal"}:
         return False
-    if (inp["approx"]["rt_method"] == "SH" or opa.ngauss != 1 or getattr(opa, "on_fly", False)
-            or inp["clouds"].get("do_holes", False) or inp["approx"].get("get_lvl_flux", False)
+    is_sh = inp["approx"]["rt_method"] == "SH"
+    if (opa.ngauss != 1 or getattr(opa, "on_fly", False) or inp["clouds"].get("do_holes", False)
+            or (inp["approx"].get("get_lvl_flux", False) and not is_sh)
             or inp["test_mode"] is not None or not hasattr(opa, "_cia") or not hasattr(opa, "_ray")):
         return False
+    if is_sh and inp["approx"]["rt_params"]["SH"]["calculate_fluxes"]:
+        return False                # the layer moment fluxes (flx = 1) are a per-call output of the call-by-call path
     return not (inp["approx"]["rt_params"]["common"]["raman"] == 0 and nblocks != 1)
+
+
+_SH_READS = ("dtau", "w0", "cosb_og", "ftau_cld", "ftau_ray", "f_deltaM", "dtau_og", "w0_og")
+
+
+def _plane_set_sh(inp, atm, nwno, common, frac_c, opt):
+    """``_plane_set`` for the SH solvers: ``(want, lean, sh_top)`` as ``Spectrum._want_1d`` chooses them -- dtau and w0
+    for a cloud-free atmosphere with the default options, the eight planes the launch reads when the level planes may be
+    derived, all thirteen otherwise; ``sh_top`` = the cloud-free layers above the deck."""
+    from .spectrum import _cloud_free_top
+    sh = inp["approx"]["rt_params"]["SH"]
+    forms = (sh["w_single_form"], sh["w_multi_form"], sh["psingle_form"], sh["w_single_rayleigh"], sh["w_multi_rayleigh"],
+             sh["psingle_rayleigh"], frac_c, sh["single_form"], 0)
+    rayleigh = len(getattr(atm, "rayleigh_molecules", [])) > 0
+    lean = (bool(getattr(atm, "cloud_free", False)) and rayleigh and not opt.all_planes
+            and resident.reflected_SH_can_derive(common["stream"], *forms))
+    if lean:
+        return {"dtau", "w0"}, True, 0
+    sh_top = _cloud_free_top(inp, atm.c.nlayer) if (rayleigh and not opt.all_planes) else 0
+    if not opt.all_planes and resident.reflected_SH_can_derive_levels(atm.c.nlevel, nwno, common["stream"], *forms):
+        return set(_SH_READS), False, sh_top
+    return set(drv.OUT_NAMES), False, sh_top
 
 
 def _plane_set(atm, geom, toon, frac_c, nwno, raman, do_r, do_t, opt):
@@ -89,10 +116,9 @@ def _cloud_inputs(atm, opa, tables, nlayer, nwno, opt, hold):
             dcld = [all3.row_block(0), all3.row_block(1), all3.row_block(2)]
             hold.append((all3, dcld))
             return dcld, None, None
-        dtab = (int(np.size(cld.in_wno)),
-                DeviceArray.from_host(np.ascontiguousarray(cld.in_wno, dtype=np.float64), opa.ctx),
-                DeviceArray.from_host(np.ascontiguousarray(stack, dtype=np.float64), opa.ctx))
-        hold.append(dtab)
+        # the compact tables go to every block's device (0.4 MB): each block interpolates them to its own wavenumbers
+        dtab = (int(np.size(cld.in_wno)), np.ascontiguousarray(cld.in_wno, dtype=np.float64),
+                np.ascontiguousarray(stack, dtype=np.float64))
         return None, dtab, None
     if getattr(atm, "cloud_free", False):
         return None, None, None
@@ -130,7 +156,9 @@ def _fill_block(k, sub, lo, hi, c):
     k.cld_opd = k.cld_w0 = k.cld_g0 = None
     k.cld_host_opd = k.cld_host_w0 = k.cld_host_g0 = None
     if dtab is not None:
-        k.cld_tab_nin, k.cld_tab_xp, k.cld_tab_fp = dtab[0], drv._dev(dtab[1]), drv._dev(dtab[2])
+        d_xp, d_fp = DeviceArray.from_host(dtab[1], sub.ctx), DeviceArray.from_host(dtab[2], sub.ctx)
+        hold.append((d_xp, d_fp))
+        k.cld_tab_nin, k.cld_tab_xp, k.cld_tab_fp = dtab[0], drv._dev(d_xp), drv._dev(d_fp)
         k.wno = drv._dev(_resident_vector(sub, "wno", sub.wno, nw))
     elif dcld is not None:
         k.cld_opd, k.cld_w0, k.cld_g0 = (drv._dev(x) for x in dcld)
@@ -181,8 +209,9 @@ def prepare(bundle, opa, subs, calculation, opt, slot=None):
     cld = atm.layer["cloud"]
     cloud_free = bool(getattr(atm, "cloud_free", False))
     tables = not cloud_free and isinstance(cld, CloudTables)
-    if tables and (len(subs) != 1 or np.size(cld.wno) != nwno or opt.host_regrid):
-        return None                 # tables on their own grid: regridded on the device for ONE block over the grid
+    if tables and (np.size(cld.wno) != nwno or opt.host_regrid or
+                   (len(subs) != 1 and (opt.unfused_opacity or opt.regrid_planes))):
+        return None                 # tables on their own grid: interpolated inside each block's fused opacity launch
     nlevel, nlayer = atm.c.nlevel, atm.c.nlayer
     opa.get_opacities(atm, exclude_mol=inp["atmosphere"]["exclude_mol"])
     plan = opa._plan
@@ -195,21 +224,28 @@ def prepare(bundle, opa, subs, calculation, opt, slot=None):
     geom = inp["disco"]
     ng, nt = geom["num_gangle"], geom["num_tangle"]
     frac_a, frac_b, frac_c = common["TTHG_params"]["fraction"]
-    want, lean, derive = _plane_set(atm, geom, toon, frac_c, nwno, raman, do_r, do_t, opt)
+    is_sh = inp["approx"]["rt_method"] == "SH"
+    sh_top = 0
+    if is_sh:
+        want, lean, sh_top = _plane_set_sh(inp, atm, nwno, common, frac_c, opt)
+        derive = False
+    else:
+        want, lean, derive = _plane_set(atm, geom, toon, frac_c, nwno, raman, do_r, do_t, opt)
 
     def table_ids(sub):          # a block table holds raw table addresses: replaced tables are a new signature
         mt = sub._mol_log if linear else sub._mol_raw
         return tuple(id(mt[m]) for m in plan["molecules"]) + tuple(id(sub._cia[p]) for p in plan["cia_pairs"])
     key = (tuple((lo, hi, id(sub)) + table_ids(sub) for lo, hi, sub in subs), nlayer, ng, nt, tuple(plan["molecules"]),
            tuple(plan["cia_pairs"]), tuple(factors[2]), linear, tuple(sorted(want)), lean, not cloud_free and not tables, do_r, do_t,
-           derive, slot)
+           derive, is_sh, slot)
     cache = opa.__dict__.setdefault("_driver_tables", {})
     table = cache.get(key)
     if table is None:
         if len(cache) > (8 if slot is None else 40):
             cache.clear()
         table = cache[key] = drv.BlockTable(subs, nlayer, ng, nt, plan["molecules"], plan["cia_pairs"], factors[2], linear,
-                                            want, lean, not cloud_free and not tables, do_r, do_t, _constant_planes, derive)
+                                            want, lean, not cloud_free and not tables, do_r, do_t, _constant_planes, derive,
+                                            sh=is_sh)
     nostar = inp["star"]["database"] == "nostar"
     F0PI = _ones(opa, nwno) if nostar else inp["star"]["relative_flux"]
     stellar = getattr(opa, "unshifted_stellar_spec", None)
@@ -233,7 +269,7 @@ def prepare(bundle, opa, subs, calculation, opt, slot=None):
                              geom["gweight"], geom["tweight"], toon["single_phase"], toon["multi_phase"],
                              toon["toon_coefficients"], frac_a, frac_b, frac_c, common["TTHG_params"]["constant_back"],
                              common["TTHG_params"]["constant_forward"], 0.0, atm.level["temperature"], atm.level["pressure"],
-                             atm.hard_surface)
+                             atm.hard_surface, sh=inp["approx"]["rt_params"]["SH"] if is_sh else None, sh_top=sh_top)
     return dict(table=table, job=job, keep=(keep, hold), do_r=do_r, do_t=do_t, full=full, nwno=nwno, integrals=integrals,
                 denom=c["denom"] if (integrals and do_r) else None, wno=wno, stellar=stellar, inp=inp, atm=atm, opa=opa,
                 signature=key[1:-1])

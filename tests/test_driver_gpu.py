@@ -1,5 +1,5 @@
 """picaso_toon_spectrum_blocks (csrc/driver.hip): one C call enqueues gas stage -> compute_opacity -> reflected ||
-thermal for every wavelength block of a 1-D Toon spectrum (reference sequence justdoit.py:236-385; fan-out
+thermal for every wavelength block of a 1-D Toon or SH spectrum (reference sequence justdoit.py:236-385; fan-out
 justdoit.py:4774).  It only chains the library's entry points, so every output must equal the call-by-call path of
 ``justdoit.picaso`` (``PICASO_AMD_NO_DRIVER=1``) bit for bit -- single GPU and wavelength blocks, cloud-free (three planes
 + aliases) and cloudy (host cloud planes cut per block inside the C call), Raman off / Pollack, one or both legs, with
@@ -88,11 +88,11 @@ def test_driver_nearest_query_and_falls_through_where_it_does_not_apply(monkeypa
     _same(_case(og, jdi, True, True, "none", True).spectrum(opa, calculation="reflected+thermal"), got)
     monkeypatch.delenv("PICASO_AMD_NO_DRIVER")
     n = len(opa.__dict__["_driver_tables"])
-    # outside the driver: full_output, transmission, SH, level fluxes -- the usual path, no new block table
+    # outside the driver: full_output, transmission, SH layer fluxes, level fluxes -- the usual path, no new block table
     _case(og, jdi, True, True, "none", True).spectrum(opa, calculation="reflected", full_output=True)
     _case(og, jdi, False, True, "none", False).spectrum(opa, calculation="reflected+transmission")
     sh = _case(og, jdi, True, True, "none", False)
-    sh.approx(raman="none", rt_method="SH", stream=4)
+    sh.approx(raman="none", rt_method="SH", stream=4, calculate_fluxes="on")
     sh.spectrum(opa, calculation="reflected")
     lv = _case(og, jdi, False, True, "none", False)
     lv.approx(raman="none", get_lvl_flux=True)
@@ -168,3 +168,39 @@ def test_driver_oklopcic_raman(monkeypatch, cloud, calc):
     monkeypatch.setenv("PICASO_AMD_NO_DRIVER", "1")
     for k in range(2):
         _same(_case(og, jdi, cloud, True, "oklopcic", True, k).spectrum(opa, calculation=calc), got[k])
+
+
+@pytest.mark.parametrize("devices", [None, [0, 0, 0]])
+@pytest.mark.parametrize("calc", ["reflected", "thermal", "reflected+thermal"])
+@pytest.mark.parametrize("cloud,stream,forms", [(False, 4, {}), (True, 4, {}), (True, 2, {}),
+                                                (True, 4, dict(w_single_form="OTHG", psingle_form="isotropic",
+                                                               single_form="legendre", w_multi_rayleigh="off"))])
+def test_driver_runs_the_sh_solvers(monkeypatch, devices, calc, cloud, stream, forms):
+    """rt_method='SH' through the C driver (round 5: it used to take the Python per-block loop, 0.2 ms of interpreter time
+    per wavelength block): cloud-free (dtau and w0 only), a cloud deck with the default forms (eight planes, level planes
+    derived, the layers above the deck through the cloud-free kernel) and other forms (all thirteen planes) -- whole grid
+    and wavelength blocks, every output equal to the call-by-call path bit for bit."""
+    from picaso_amd import justdoit as jdi
+    og = np.load(os.path.join(GOLDEN, "optics.npz"))
+    opa = jdi.opannection(filename_db=DB, query_method="linear")
+
+    def make(k):
+        c = _case(og, jdi, cloud, True, "none", True, k)
+        c.approx(raman="none", delta_eddington=True, rt_method="SH", stream=stream, **forms)
+        return c
+    monkeypatch.setenv("PICASO_AMD_NO_DRIVER", "1")
+    want = [make(k).spectrum(opa, calculation=calc, devices=devices) for k in range(2)]
+    assert "_driver_tables" not in opa.__dict__
+    monkeypatch.delenv("PICASO_AMD_NO_DRIVER")
+    got = [make(k).spectrum(opa, calculation=calc, devices=devices) for k in range(2)]
+    assert len(opa.__dict__["_driver_tables"]) == 1
+    (table,) = opa.__dict__["_driver_tables"].values()
+    if not cloud and stream == 4:
+        assert set(table.want) == {"dtau", "w0"}
+    elif not forms:
+        assert set(table.want) == {"dtau", "w0", "cosb_og", "ftau_cld", "ftau_ray", "f_deltaM", "dtau_og", "w0_og"}
+    else:
+        assert len(table.want) == 13
+    for w, g in zip(want, got):
+        _same(w, g)
+        assert all(np.isfinite(v).all() for v in g.values() if isinstance(v, np.ndarray))

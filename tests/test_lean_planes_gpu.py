@@ -112,6 +112,7 @@ def test_sh4_cloud_free_writes_two_planes(monkeypatch, calc):
     wants = []
     real = px.compute_opacity_resident
     monkeypatch.setattr(px, "compute_opacity_resident", lambda *a, **k: (wants.append(k.get("want")), real(*a, **k))[1])
+    monkeypatch.setenv("PICASO_AMD_NO_DRIVER", "1")       # the call-by-call path (the C driver's choice: tests/test_driver_gpu.py)
 
     def case(**sh):
         c = _case(jdi, og, "none", True, False)
