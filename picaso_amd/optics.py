@@ -594,6 +594,7 @@ def shard_opacity(opa, lo, hi, ctx):
     s.__dict__.pop("_trapz", None)
     s.__dict__.pop("_trapz_buf", None)
     s.__dict__.pop("_driver_tables", None)
+    s.__dict__.pop("_cloud_tables_dev", None)
     for k in ("_trapz_dev", "_bond_denom", "_bond_denom_host", "_ones", "_fast_setup"):
         s.__dict__.pop(k, None)
     s.molecular_opa, s.continuum_opa = ({} if isinstance(opa.molecular_opa, dict) else None), {}
