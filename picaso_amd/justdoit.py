@@ -24,7 +24,7 @@ from . import options as _options
 from .atmsetup import ATMSETUP, CloudTables
 from .device import DeviceArray
 from .options import Options                                                        # noqa: F401  (jdi.Options)
-from .spectrum import (Spectrum, _atmosphere_block, _bond_denominator, _cloud_free_top, _constant_planes,   # noqa: F401
+from .spectrum import (Spectrum, setup_facets_3d, _atmosphere_block, _bond_denominator, _cloud_free_top, _constant_planes,   # noqa: F401
                        _fetch, _interp_axis, _ones, _post_final, _post_reflected, _post_thermal, _postprocess,
                        _reflected, _resident_vector, _setup_atmosphere, _trapz_resident)
 
@@ -1370,6 +1370,13 @@ def _picaso_devices(bundle, opa, devices, gather, dimension, calculation, full_o
             opa.get_opacities(atm0, exclude_mol=inp["atmosphere"]["exclude_mol"])
             plan = opa._plan
         shared = dict(atm=atm0, plan=plan)
+    elif (dimension == "3d" and len(shards) > 1 and opa.ngauss == 1 and not _options.current(opt).facet_loop
+          and not inp["approx"].get("get_lvl_flux", False)):
+        # 3-D: the facet-form ATMSETUP and the tall plan (rows / weights / coefficients of every (facet, layer)) once
+        geom = inp["disco"]
+        atm_f, atm0, tlev3, plev3 = setup_facets_3d(inp, opa, opa.wno, geom["num_gangle"], geom["num_tangle"])
+        tall = getattr(atm_f, "_fast_tall", None)
+        shared = dict(atm_f=atm_f, atm=atm0, tlev3=tlev3, plev3=plev3, tall=tall[:2] if tall is not None else None)
     fins = []
     for lo, hi, sub in shards:
         b = _Bundle(_slice_inputs(inp, lo, hi, nwno, nlayer, clouds=shared is None), nlevel)

@@ -186,6 +186,25 @@ def _fetch(prefetched, key, dev, returns=None, integral=None):
 
 
 
+def setup_facets_3d(inp, opa, wno, ng, nt):
+    """All facets in ONE facet-form ATMSETUP ((nlevel, nfacets) columns; the reference builds one per facet,
+    justdoit.py:437-449), the atmosphere of facet (0, 0) (sizes, surface, full_output) and the level tables the thermal
+    solver takes: ``(atm_f, atm, tlev3, plev3)``."""
+    prof3 = inp["atmosphere"]["profile_3d"]
+    nfac, nlv = ng * nt, len(prof3["pressure"])
+    prof_f = {}
+    for k, v in prof3.items():
+        if k == "temperature":
+            prof_f[k] = np.ascontiguousarray(np.broadcast_to(v.reshape(nlv, -1), (nlv, nfac)))
+        else:
+            prof_f[k] = v.reshape(nlv, -1)            # (nlevel, 1) shared or (nlevel, nfacets)
+    atm_f = _setup_atmosphere(inp, opa, wno, prof_f, None)
+    atm = _setup_atmosphere(inp, opa, wno, {k: (v if v.ndim == 1 else v[:, 0, 0]) for k, v in prof3.items()}, None)
+    tlev3 = atm_f.level["temperature"].reshape(nlv, ng, nt)
+    plev3 = np.ascontiguousarray(np.broadcast_to(atm_f.level["pressure"].reshape(nlv, 1, 1), (nlv, ng, nt)))
+    return atm_f, atm, tlev3, plev3
+
+
 # ------------------------------------------------------------------------------------------------
 # one spectrum: plan -> enqueue -> finish
 # ------------------------------------------------------------------------------------------------
@@ -327,20 +346,18 @@ class Spectrum:
             self.tlev3 = np.stack([np.stack([a_.level["temperature"] for a_ in row], axis=1) for row in atms], axis=1)
             self.plev3 = np.stack([np.stack([a_.level["pressure"] for a_ in row], axis=1) for row in atms], axis=1)
             return
-        # all facets in ONE facet-form ATMSETUP ((nlevel, nfacets) columns; the reference builds one
-        # per facet, justdoit.py:437-449) and one batched gas stage
         nfac, nlv = ng * nt, len(prof3["pressure"])
-        prof_f = {}
-        for k, v in prof3.items():
-            if k == "temperature":
-                prof_f[k] = np.ascontiguousarray(np.broadcast_to(v.reshape(nlv, -1), (nlv, nfac)))
-            else:
-                prof_f[k] = v.reshape(nlv, -1)            # (nlevel, 1) shared or (nlevel, nfacets)
-        atm_f = _setup_atmosphere(inp, opa, wno, prof_f, None)
-        self.atm = _setup_atmosphere(inp, opa, wno, {k: (v if v.ndim == 1 else v[:, 0, 0]) for k, v in prof3.items()},
-                                     None)                # facet (0, 0): sizes, surface, full_output
-        self.tlev3 = atm_f.level["temperature"].reshape(nlv, ng, nt)
-        self.plev3 = np.ascontiguousarray(np.broadcast_to(atm_f.level["pressure"].reshape(nlv, 1, 1), (nlv, ng, nt)))
+        if self.shared is not None:
+            # one wavelength block of a multi-GPU spectrum: the facet set-up and the table rows / weights of every
+            # (facet, layer) do not depend on the block -- done once for the grid (setup_facets_3d in _picaso_devices)
+            sh = self.shared
+            atm_f = copy.copy(sh["atm_f"])
+            if sh.get("tall") is not None:
+                atm_f._fast_tall = sh["tall"] + (opa,)
+            self.atm = _atmosphere_block(sh["atm"], sh["lo"], sh["hi"], wno)
+            self.tlev3, self.plev3 = sh["tlev3"], sh["plev3"]
+        else:
+            atm_f, self.atm, self.tlev3, self.plev3 = setup_facets_3d(inp, opa, wno, ng, nt)
         if self.ngauss > 1:
             # correlated-k tables (justdoit.py:407-421: planes with a trailing ngauss axis): facet-major planes with the
             # Gauss index fastest; the legs solve all nwno*ngauss columns of a facet in one launch (resident.*_3d_ck)
