@@ -19,7 +19,9 @@ its own buffer and every gather has finished when the timed region ends).  `--sc
 instead.  Prints ONE JSON line (rank 0).
 
 --config selects the other BASELINE workloads (not the headline): 1 thermal emission 1e4 x 90,
-3 SH4 reflected 1e5 x 90, 4 3-D 8x8 facets x 90 x nwno (default 12 500 per GPU: 1e5 over 8 GPUs).
+3 SH4 reflected 1e5 x 90, 4 3-D 8x8 facets x 90 x nwno (default 12 500 per GPU: 1e5 over 8 GPUs).  With --gpus N they
+shard, gather and report exactly like the headline: `per_rank` (each rank's columns, solve ms, gather ms) and `checks`
+(gathered == local shard; gathered == the unsharded spectrum solved on rank 0, bit for bit).
 
 Clock ramp: an idle MI355X takes ~100 launches (30 ms) of this kernel to reach its steady clock
 state (tools/refl_time.py --ramp: 0.53, 0.35, 0.32, 0.30, 0.29 ... 0.25 ms per launch in groups of
@@ -848,7 +850,9 @@ def main():
         comm = sharding.Comm.from_launcher(ctx, group)     # RCCL inside the library
 
     build, nwno_cfg = WORKLOADS[args.config]
-    nwno = args.nwno or nwno_cfg
+    # configs[4] is stated as 1e5 wavelengths over 8 GPUs: 12 500 per GPU; with --gpus N and no --nwno the grid is
+    # N x 12 500 wavelengths, cut into N blocks like every other configuration
+    nwno = args.nwno or (nwno_cfg * world if args.config == 4 else nwno_cfg)
     if args.scaling == "strong":
         nwno_total = nwno
         lo, hi = sharding.shard_of(nwno_total, world, rank)
@@ -970,7 +974,9 @@ def main():
             # recorded in the JSON line (and on stderr when false) rather than asserted: a failed check must
             # not cost the run its measurement
             checks["gathered_contains_local_shard"] = bool(np.array_equal(res_full[lo:hi], res_local))
-            if args.scaling == "strong" and args.config != 4:
+            # configs[4]'s unsharded planes are 64 x the 1-D ones (51 GB at 1e5 wavelengths): solved next to this rank's
+            # shard only while both fit comfortably in HBM
+            if args.scaling == "strong" and (args.config != 4 or nwno_total * 64 * args.nlayer * 8 * 12 < 120e9):
                 wl1 = build(ctx, args, 0, nwno_total, seed, nwno_total)
                 one = device.DeviceArray((nwno_total,), ctx)
                 wl1["solve"](one)

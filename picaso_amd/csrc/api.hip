@@ -49,11 +49,24 @@ void *arena_take(picaso_ctx *ctx, size_t bytes)
 static int small_ring_reserve(picaso_ctx *ctx)
 {
     if (ctx->small_h) return 0;
+    // all or nothing: small_h doubles as the "reserved" flag, so it is published only when the device ring and every
+    // event exist; a failure half way frees what it got and the next call tries again from the start
     const size_t ring = picaso_ctx::SMALL_BYTES * picaso_ctx::NSMALL;
-    PZ_HIP(ctx, hipHostMalloc((void **)&ctx->small_h, ring, hipHostMallocDefault));
-    PZ_HIP(ctx, hipMalloc((void **)&ctx->small_d, ring));
-    for (int i = 0; i < picaso_ctx::NSMALL; ++i)
-        PZ_HIP(ctx, hipEventCreateWithFlags(&ctx->small_ev[i], hipEventDisableTiming));
+    char *h = nullptr, *d = nullptr;
+    hipEvent_t ev[picaso_ctx::NSMALL];
+    int nev = 0;
+    hipError_t e = hipHostMalloc((void **)&h, ring, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipMalloc((void **)&d, ring);
+    for (; e == hipSuccess && nev < picaso_ctx::NSMALL; ++nev) e = hipEventCreateWithFlags(&ev[nev], hipEventDisableTiming);
+    if (e != hipSuccess) {
+        for (int i = 0; i < nev - 1; ++i) (void)hipEventDestroy(ev[i]);      // ev[nev - 1] is the one that failed
+        if (d) (void)hipFree(d);
+        if (h) (void)hipHostFree(h);
+        return fail(ctx, "small table ring: %s", hipGetErrorString(e));
+    }
+    for (int i = 0; i < picaso_ctx::NSMALL; ++i) ctx->small_ev[i] = ev[i];
+    ctx->small_d = (decltype(ctx->small_d))d;
+    ctx->small_h = (decltype(ctx->small_h))h;
     return 0;
 }
 

@@ -17,6 +17,7 @@
 #include <cstddef>
 #include <cstdlib>
 #include <cstring>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -152,19 +153,36 @@ extern "C" int picaso_toon_spectrum_blocks(int nblocks, picaso_block *blocks, co
             else if (ca[0]->device == cb[0]->device) one_device = true;
         }
     if (one_device && !(force && force[0] == '1')) parallel = false;
+    // A failing block leaves its message on its own context and in the thread-local buffer of the thread that ran it.
+    // The caller asks picaso_last_error(blocks[0].ctx) or picaso_last_error(NULL) from ITS thread: the text is carried
+    // over to both.
     if (!parallel) {
-        for (int b = 0; b < nblocks; ++b) PZ_TRY(enqueue_block(nblocks, blocks, j, b));
+        for (int b = 0; b < nblocks; ++b)
+            if (int rc = enqueue_block(nblocks, blocks, j, b)) {
+                char msg[sizeof(g_err)];
+                snprintf(msg, sizeof(msg), "%s", g_err);
+                fail(blocks[0].ctx, "%s", msg);
+                return rc;
+            }
         return 0;
     }
     std::vector<int> rc((size_t)nblocks, 0);
+    std::vector<std::string> msgs((size_t)nblocks);
     std::vector<std::thread> workers;
     workers.reserve((size_t)nblocks - 1);
     for (int b = 1; b < nblocks; ++b)
-        workers.emplace_back([&, b] { rc[(size_t)b] = enqueue_block(nblocks, blocks, j, b); });
+        workers.emplace_back([&, b] {
+            rc[(size_t)b] = enqueue_block(nblocks, blocks, j, b);
+            if (rc[(size_t)b]) msgs[(size_t)b] = g_err;          // this worker's thread-local text
+        });
     rc[0] = enqueue_block(nblocks, blocks, j, 0);
+    if (rc[0]) msgs[0] = g_err;
     for (auto &t : workers) t.join();
     for (int b = 0; b < nblocks; ++b)
-        if (rc[(size_t)b]) return rc[(size_t)b];      // the message is on that block's context (picaso_last_error)
+        if (rc[(size_t)b]) {
+            fail(blocks[0].ctx, "%s", msgs[(size_t)b].c_str());
+            return rc[(size_t)b];
+        }
     return 0;
 }
 

@@ -759,12 +759,19 @@ static int launch1d(picaso_ctx *ctx, const ReflectedArgs &a_in)
     bool big = false;
     if constexpr (NA == 5)
         big = a.ny <= 1 && (long)nspec * ncg * (block / 64) <= 1024 && getenv("PICASO_AMD_REFL_NO_BIG") == nullptr;
-    const bool fast = fast_options(a, zp);
+    bool fast = fast_options(a, zp);
 #define PZ_GO(KERNEL) hipLaunchKernelGGL(KERNEL, grid, dim3(block), 0, ctx->stream, a)
     // planes left out (re-derived in the kernel): the default-options kernels only -- reflected_1d_can_derive() is the
     // caller's way to know
     const bool drv = !(a.tau && a.tau_og && a.gcos2 && a.ftau_cld && a.dtau_og);
     if (drv) {
+        // reflected_1d_can_derive() looked at ALL angles of the call; this launch may be a chunk of them whose angles
+        // all happen to have ubar0 == ubar1 at a phase angle other than zero: not the zero-phase variant's geometry
+        // (it fixes cos_theta = 1), but the general default-options kernel takes it -- same bits
+        if (!fast && zp && a.cos_theta != 1.0) {
+            zp = false;
+            fast = fast_options(a, zp);
+        }
         if (!fast) return fail(ctx, "reflected: planes may be left out only with the reference's default options");
         // only dtau and w0: the compile-time form (five angles, symmetric geometry: the shape of a spectrum() call)
         const bool only2 = !a.tau && !a.tau_og && !a.gcos2 && !a.ftau_cld && !a.dtau_og && PZ_REFL_CLEAR_VARIANT;

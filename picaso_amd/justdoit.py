@@ -267,8 +267,13 @@ def _regrid_lonlat(coords, variables, lon_new, lat_new):
     not compared): on a rectilinear lon / lat grid that is this interpolation up to ESMF's great-circle cell
     geometry."""
     out = {}
+    lon = np.asarray(coords["lon"], dtype=float)
+    # a longitude axis that goes around the planet is periodic: facets beyond its first / last column are interpolated
+    # across the +-180 seam; a regional map (less than a full circle with its own spacing) keeps its end values
+    ulon = np.unique(lon)
+    wraps = ulon.size > 2 and (ulon[-1] - ulon[0]) + 1.5 * np.max(np.diff(ulon)) >= 360.0
     for k, v in variables.items():
-        out[k] = _interp_axis(lat_new, coords["lat"], _interp_axis(lon_new, coords["lon"], v, 0), 1)
+        out[k] = _interp_axis(lat_new, coords["lat"], _interp_axis(lon_new, lon, v, 0, period=360.0 if wraps else None), 1)
     return out
 
 

@@ -16,15 +16,25 @@ from .atmsetup import ATMSETUP, CloudTables
 from .device import DeviceArray
 
 
-def _interp_axis(x_new, x_old, arr, axis):
-    """Linear interpolation of ``arr`` along ``axis`` from the increasing grid ``x_old`` to ``x_new`` (end values
-    held outside the grid)."""
+def _interp_axis(x_new, x_old, arr, axis, period=None):
+    """Linear interpolation of ``arr`` along ``axis`` from the grid ``x_old`` to ``x_new`` (end values held outside the
+    grid).  ``x_old`` is sorted here if need be; repeated abscissae (a longitude axis holding both -180 and 180) keep
+    their first entry.  ``period``: the axis is periodic (longitude, 360): points beyond either end are interpolated
+    across the seam instead of being clamped to the end value."""
     x_old = np.asarray(x_old, dtype=float)
+    arr = np.asarray(arr)
+    if np.any(np.diff(x_old) <= 0):
+        x_old, first = np.unique(x_old, return_index=True)          # sorted, duplicates dropped
+        arr = np.take(arr, first, axis=axis)
+    if period is not None and x_old.size > 1:
+        if x_old[-1] - x_old[0] >= period:                          # both ends of the seam present: one of them is the other
+            keep = x_old < x_old[0] + period
+            x_old, arr = x_old[keep], np.compress(keep, arr, axis=axis)
+        x_old = np.concatenate([[x_old[-1] - period], x_old, [x_old[0] + period]])
+        arr = np.concatenate([np.take(arr, [-1], axis=axis), arr, np.take(arr, [0], axis=axis)], axis=axis)
+        x_new = x_old[1] + np.mod(np.asarray(x_new, dtype=float) - x_old[1], period)
     if x_old.size == 1:
         return np.repeat(arr, len(x_new), axis=axis)
-    if np.any(np.diff(x_old) < 0):
-        order = np.argsort(x_old)
-        x_old, arr = x_old[order], np.take(arr, order, axis=axis)
     x = np.clip(np.asarray(x_new, dtype=float), x_old[0], x_old[-1])
     j = np.clip(np.searchsorted(x_old, x, side="right") - 1, 0, x_old.size - 2)
     t = (x - x_old[j]) / (x_old[j + 1] - x_old[j])

@@ -743,3 +743,26 @@ def test_3d_builders_take_the_reference_keywords_and_a_dataset():
         pc.atmosphere_4d({"lon": lon, "lat": lat, "pressure": pres_pa, "temperature": Tl}, zero_point="noon", verbose=False)
     pc.atmosphere_4d([{"pressure": np.sort(pres_pa) * 1e-5, "temperature": want}] * 2)       # per-phase facet profiles
     assert len(pc.inputs["atmosphere"]["profile_4d"]) == 2
+
+
+def test_lonlat_regrid_with_a_seam_and_repeated_longitudes():
+    """The bilinear lon / lat step of the 3-D builders (build_3d_input.py:12-62 hands it to xesmf): a longitude axis that
+    holds both -180 and 180 must not divide by zero, and facets beyond the first / last column of a global map are
+    interpolated across the seam, not clamped to the end column; a regional map keeps its end values."""
+    from picaso_amd import justdoit as jdi
+    lon = np.array([-180.0, -90.0, 0.0, 90.0, 180.0])
+    lat = np.array([-45.0, 45.0])
+    field = np.array([1.0, 2.0, 3.0, 4.0, 1.0])[:, None] * np.ones((1, 2))
+    out = jdi._regrid_lonlat({"lon": lon, "lat": lat}, {"t": field}, np.array([-180.0, -135.0, 170.0, 185.0]), np.array([0.0]))
+    assert np.all(np.isfinite(out["t"]))
+    assert np.allclose(out["t"][:, 0], [1.0, 1.5, 4.0 + (80.0 / 90.0) * (1.0 - 4.0), 1.0 + 5.0 / 90.0])
+    # cell-centred global axis (no point on the seam): -180 lies half way between the last and the first column
+    lon2 = np.array([-135.0, -45.0, 45.0, 135.0])
+    f2 = np.array([1.0, 2.0, 3.0, 5.0])[:, None] * np.ones((1, 2))
+    out2 = jdi._regrid_lonlat({"lon": lon2, "lat": lat}, {"t": f2}, np.array([-180.0, 180.0, 170.0]), np.array([0.0]))
+    assert np.allclose(out2["t"][:, 0], [3.0, 3.0, 5.0 + (35.0 / 90.0) * (1.0 - 5.0)])
+    # a regional map: end values held
+    lon3 = np.array([-20.0, 0.0, 20.0])
+    f3 = np.array([1.0, 2.0, 3.0])[:, None] * np.ones((1, 2))
+    out3 = jdi._regrid_lonlat({"lon": lon3, "lat": lat}, {"t": f3}, np.array([-60.0, 10.0, 90.0]), np.array([0.0]))
+    assert np.allclose(out3["t"][:, 0], [1.0, 2.5, 3.0])

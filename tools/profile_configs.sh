@@ -8,7 +8,7 @@ for C in 1 3 4 shard; do
   OUT=$ROOT/gpurun_out/prof_${TAG}_c$C
   mkdir -p $OUT
   ARGS="--config $C"
-  case $C in 1) K="k_thermal_";; 3) K="k_sh<";; 4) K="k_reflected_toa<1, true";;
+  case $C in 1) K="k_thermal_";; 3) K="k_sh_refl<";; 4) K="k_reflected_toa<1, true";;
              shard) K="k_reflected_coop"; ARGS="--config 2 --nwno 12500";; esac     # the 8-GPU wavelength shard
   cd /tmp
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- python $ROOT/bench.py $ARGS --steps 20 --warmup 5 --cpu-sample 0 > $OUT/trace.log 2>&1
