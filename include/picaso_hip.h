@@ -842,6 +842,15 @@ typedef struct picaso_spectrum_job {
     int sh_w_single_form, sh_w_multi_form, sh_psingle_form, sh_w_single_rayleigh, sh_w_multi_rayleigh,
         sh_psingle_rayleigh, sh_single_form;
     int sh_cloud_free_above;               /* as picaso_get_reflected_SH_top_dev (the same value for every block) */
+    /* nfacets > 0: a 3-D spectrum (reference justdoit.py:407-516: one atmosphere per (gangle, tangle) facet) on
+     * FACET-MAJOR planes.  nfacets = numg * numt; the per-layer tables above hold nfacets * nlayer rows (the tall
+     * atmosphere of all facets: facet f's layers at [f nlayer, (f + 1) nlayer)) and ONE picaso_gas_compute_opacity_dev
+     * launch over them writes the block's planes as (nfacets, nlayer, nwno); tlevel / plevel are host (nfacets, nlevel);
+     * cloud input: none, or tables on their own grid with 3 nfacets nlayer rows (cld_tab_*).  The solvers are
+     * picaso_get_reflected_3d_batch_dev / picaso_get_thermal_3d_batch_dev with every facet as a spectrum of one facet
+     * (its slab of the planes, its ubar0 / ubar1), then picaso_compress_disco_dev / picaso_compress_thermal_dev.  The level
+     * planes (planes[1], planes[8]: tau, tau_og) must be NULL -- the 3-D kernels form them as running sums.  Toon only. */
+    int nfacets;
 } picaso_spectrum_job;
 int picaso_toon_spectrum_blocks(int nblocks, picaso_block *blocks, const picaso_spectrum_job *job);
 /* copy one leg's results (which = 1: albedo, 2: thermal flux) of every block into albedo_host / thermal_host */

@@ -69,9 +69,106 @@ static int opacity_stage(const picaso_block &k, const picaso_spectrum_job &j, in
     return 0;
 }
 
+// behind a leg's disk sum: the spectrum-wide integral (one block over the grid) and the result copy on the leg's stream
+static int reflected_tail(int nblocks, picaso_block &k)
+{
+    if (k.trapz_d) {
+        if (nblocks != 1) return fail(k.ctx, "toon_spectrum_blocks: device integrals need ONE block over the grid");
+        PZ_TRY(picaso_trapz_dev(k.ctx, k.nwno, k.trapz_d, k.albedo, k.stellar, 0, k.albedo + k.nwno));
+    }
+    if (k.albedo_pin && k.albedo_host)
+        PZ_TRY(picaso_memcpy_d2h_async(k.ctx, k.albedo_pin, k.albedo,
+                                       sizeof(double) * (size_t)(k.nwno + (k.trapz_d ? 1 : 0)), &k.albedo_mark));
+    return 0;
+}
+
+static int thermal_tail(int nblocks, picaso_block &k, picaso_ctx *tctx)
+{
+    if (k.trapz_dr) {
+        if (nblocks != 1) return fail(k.ctx, "toon_spectrum_blocks: device integrals need ONE block over the grid");
+        PZ_TRY(picaso_trapz_dev(tctx, k.nwno, k.trapz_dr, k.disk, nullptr, 1, k.disk + k.nwno));
+    }
+    if (k.thermal_pin && k.thermal_host)
+        PZ_TRY(picaso_memcpy_d2h_async(tctx, k.thermal_pin, k.disk,
+                                       sizeof(double) * (size_t)(k.nwno + (k.trapz_dr ? 1 : 0)), &k.thermal_mark));
+    return 0;
+}
+
+// One block of a 3-D spectrum (picaso_spectrum_job::nfacets; reference justdoit.py:407-516): ONE fused gas + mixing launch
+// over the tall atmosphere of all facets writes facet-major planes, every facet goes into the batched 3-D solver launch as
+// a spectrum of its own with one facet (a wave holds 64 wavelengths of one facet), then the disk sums -- the sequence of
+// spectrum.Spectrum._plan_3d / _reflected_3d_fm / resident.thermal_3d_fm_batch, with the same entry points.
+static int enqueue_block_3d(int nblocks, picaso_block *blocks, const picaso_spectrum_job &j, int b)
+{
+    picaso_block &k = blocks[b];
+    const int nfac = j.nfacets, nlevel = j.nlayer + 1;
+    if (!k.ctx || k.nwno < 1) return fail(k.ctx, "toon_spectrum_blocks: block %d has no context or no columns", b);
+    if (k.albedo_mark || k.thermal_mark)
+        return fail(k.ctx, "toon_spectrum_blocks: block %d still has uncollected results", b);
+    if (nfac != j.numg * j.numt) return fail(k.ctx, "toon_spectrum_blocks: nfacets must be numg * numt");
+    if (j.rt_method != 0) return fail(k.ctx, "toon_spectrum_blocks: 3-D blocks are Toon only (the reference has no 3-D SH)");
+    if ((long)nfac * j.nlayer > 2147483647L / 4) return fail(k.ctx, "toon_spectrum_blocks: too many facet-layers");
+    double *const *o = k.planes;
+    if (o[1] || o[8])
+        return fail(k.ctx, "toon_spectrum_blocks: 3-D blocks leave tau / tau_og out (running sums down ONE facet's layers)");
+    if (k.cld_opd || k.cld_host_opd)
+        return fail(k.ctx, "toon_spectrum_blocks: 3-D blocks take cloud tables on their own grid (cld_tab_*) or none");
+    picaso_ctx *tctx = k.tctx ? k.tctx : k.ctx;
+    PZ_TRY(picaso_gas_compute_opacity_dev(k.ctx, nfac * j.nlayer, k.nwno, j.mol_mode, j.nmol, k.mol_tabs, j.mol_rows,
+                                          j.mol_wts, j.mol_fac, j.cont_interp, j.ncont, k.cont_tabs, j.cont_rows,
+                                          j.cont_wts, j.cont_fac, j.nray, k.ray_tabs, j.ray_fac, nullptr, nullptr, nullptr,
+                                          k.raman, j.raman_rows, j.raman_const, j.test_mode, j.delta_eddington, j.stream,
+                                          o[0], o[1], o[2], o[3], o[4], o[5], o[6], o[7], o[8], o[9], o[10], o[11], o[12], 0,
+                                          k.cld_tab_nin, k.cld_tab_xp, k.cld_tab_fp, k.cld_tab_nin ? k.wno : nullptr));
+    if (tctx != k.ctx && j.do_thermal) PZ_TRY(picaso_ctx_wait(tctx, k.ctx));
+    const size_t slab = (size_t)j.nlayer * (size_t)k.nwno;
+    auto slabs = [&](const double *base) {
+        std::vector<const double *> v((size_t)nfac);
+        for (int f = 0; f < nfac; ++f) v[(size_t)f] = base + (size_t)f * slab;
+        return v;
+    };
+    const std::vector<const double *> rs((size_t)nfac, k.surf_reflect);
+    if (j.do_reflected) {
+        std::vector<const double *> cols[11];
+        const double *const *colp[11];
+        for (int p = 0; p < 11; ++p) {
+            if (k.refl_planes[p] && (p == 1 || p == 8))
+                return fail(k.ctx, "toon_spectrum_blocks: 3-D blocks leave tau / tau_og out");
+            if (k.refl_planes[p]) cols[p] = slabs(k.refl_planes[p]);
+            colp[p] = k.refl_planes[p] ? cols[p].data() : nullptr;
+        }
+        const std::vector<const double *> f0((size_t)nfac, k.F0PI);
+        const std::vector<double> ct((size_t)nfac, j.cos_theta);
+        std::vector<double *> xs((size_t)nfac);
+        for (int f = 0; f < nfac; ++f) xs[(size_t)f] = k.xint + (size_t)f * (size_t)k.nwno;
+        PZ_TRY(picaso_get_reflected_3d_batch_dev(k.ctx, nfac, nlevel, k.nwno, 1, 1, colp[0], colp[1], colp[2], colp[3],
+                                                 colp[4], colp[5], colp[6], colp[7], colp[8], colp[9], colp[10], rs.data(),
+                                                 j.ubar0, j.ubar1, ct.data(), f0.data(), j.single_phase, j.multi_phase,
+                                                 j.frac_a, j.frac_b, j.frac_c, j.constant_back, j.constant_forward,
+                                                 xs.data(), nullptr, nullptr, nullptr));
+        PZ_TRY(picaso_compress_disco_dev(k.ctx, k.nwno, j.cos_theta, k.xint, j.gweight, j.numg, j.tweight, j.numt, k.F0PI,
+                                         k.albedo));
+        PZ_TRY(reflected_tail(nblocks, k));
+    }
+    if (j.do_thermal) {
+        const std::vector<const double *> dt = slabs(k.th_dtau), w0 = slabs(k.th_w0);
+        std::vector<const double *> cb;
+        if (k.th_cosb) cb = slabs(k.th_cosb);
+        std::vector<double *> fx((size_t)nfac);
+        for (int f = 0; f < nfac; ++f) fx[(size_t)f] = k.flux + (size_t)f * (size_t)k.nwno;
+        PZ_TRY(picaso_get_thermal_3d_batch_dev(tctx, nfac, nlevel, k.wno, k.nwno, 1, 1, j.tlevel, dt.data(), w0.data(),
+                                               k.th_cosb ? cb.data() : nullptr, j.plevel, j.ubar1, rs.data(),
+                                               j.hard_surface, fx.data(), nullptr, nullptr, nullptr));
+        PZ_TRY(picaso_compress_thermal_dev(tctx, (size_t)k.nwno, k.flux, j.gweight, j.numg, j.tweight, j.numt, k.disk));
+        PZ_TRY(thermal_tail(nblocks, k, tctx));
+    }
+    return 0;
+}
+
 // one block: opacity stage -> reflected || thermal (+ integrals, result copies) on the block's own context(s)
 static int enqueue_block(int nblocks, picaso_block *blocks, const picaso_spectrum_job &j, int b)
 {
+    if (j.nfacets > 0) return enqueue_block_3d(nblocks, blocks, j, b);
     const int nlevel = j.nlayer + 1;
     {
         picaso_block &k = blocks[b];
@@ -98,15 +195,7 @@ static int enqueue_block(int nblocks, picaso_block *blocks, const picaso_spectru
                                                j.b_top, k.xint, nullptr, nullptr, nullptr, nullptr, j.gweight, j.tweight,
                                                k.albedo));
         }
-        if (j.do_reflected) {
-            if (k.trapz_d) {
-                if (nblocks != 1) return fail(k.ctx, "toon_spectrum_blocks: device integrals need ONE block over the grid");
-                PZ_TRY(picaso_trapz_dev(k.ctx, k.nwno, k.trapz_d, k.albedo, k.stellar, 0, k.albedo + k.nwno));
-            }
-            if (k.albedo_pin && k.albedo_host)
-                PZ_TRY(picaso_memcpy_d2h_async(k.ctx, k.albedo_pin, k.albedo,
-                                               sizeof(double) * (size_t)(k.nwno + (k.trapz_d ? 1 : 0)), &k.albedo_mark));
-        }
+        if (j.do_reflected) PZ_TRY(reflected_tail(nblocks, k));
         if (j.do_thermal) {
             if (j.rt_method == 1)
                 // ff = 0 if np.array_equal(cosb, cosb_og) else cosb_og**stream (fluxes.py:3072-3075): with delta-Eddington
@@ -119,13 +208,7 @@ static int enqueue_block(int nblocks, picaso_block *blocks, const picaso_spectru
                                              k.th_w0, k.th_cosb, j.plevel, j.ubar1, k.surf_reflect, j.hard_surface,
                                              nullptr, 0, k.flux, nullptr, nullptr, nullptr, nullptr, j.gweight, j.tweight,
                                              k.disk));
-            if (k.trapz_dr) {
-                if (nblocks != 1) return fail(k.ctx, "toon_spectrum_blocks: device integrals need ONE block over the grid");
-                PZ_TRY(picaso_trapz_dev(tctx, k.nwno, k.trapz_dr, k.disk, nullptr, 1, k.disk + k.nwno));
-            }
-            if (k.thermal_pin && k.thermal_host)
-                PZ_TRY(picaso_memcpy_d2h_async(tctx, k.thermal_pin, k.disk,
-                                               sizeof(double) * (size_t)(k.nwno + (k.trapz_dr ? 1 : 0)), &k.thermal_mark));
+            PZ_TRY(thermal_tail(nblocks, k, tctx));
         }
     }
     return 0;

@@ -1,5 +1,5 @@
 """ctypes side of ``picaso_toon_spectrum_blocks`` (``csrc/driver.hip``): one C call enqueues every launch of a 1-D
-Toon spectrum -- gas stage, ``compute_opacity``, reflected and thermal solvers with their fused disk sums -- for
+(Toon or SH) or a 3-D spectrum -- gas stage, ``compute_opacity``, reflected and thermal solvers with their fused disk sums -- for
 every wavelength block of the spectrum (reference sequence: justdoit.py:236-385; its fan-out over worker
 processes: justdoit.py:4774).
 
@@ -54,7 +54,7 @@ class Job(ctypes.Structure):
                 ("rt_method", ctypes.c_int), ("sh_w_single_form", ctypes.c_int), ("sh_w_multi_form", ctypes.c_int),
                 ("sh_psingle_form", ctypes.c_int), ("sh_w_single_rayleigh", ctypes.c_int),
                 ("sh_w_multi_rayleigh", ctypes.c_int), ("sh_psingle_rayleigh", ctypes.c_int),
-                ("sh_single_form", ctypes.c_int), ("sh_cloud_free_above", ctypes.c_int)]
+                ("sh_single_form", ctypes.c_int), ("sh_cloud_free_above", ctypes.c_int), ("nfacets", ctypes.c_int)]
 
 
 def _dev(x):
@@ -82,7 +82,7 @@ class BlockTable:
     of the same signature: every access is ordered on the blocks' streams."""
 
     def __init__(self, subs, nlayer, ng, nt, mol_names, cia_pairs, ray_names, linear, want, lean, host_cloud,
-                 do_reflected, do_thermal, const_planes, derive=False, sh=False):
+                 do_reflected, do_thermal, const_planes, derive=False, sh=False, facets=0, th3=None):
         self.subs, self.n = subs, len(subs)
         self.blocks = (Block * self.n)()
         self.keep = []                                   # DeviceArrays and pointer tables the structs point into
@@ -98,6 +98,11 @@ class BlockTable:
             mt, ct, rt = _table_ptrs(tabs), _table_ptrs(ctabs), _table_ptrs(rtabs)
             self.keep += [mt, ct, rt, tabs, ctabs, rtabs]    # the tables themselves too: the structs hold raw addresses
             k.mol_tabs, k.cont_tabs, k.ray_tabs = ctypes.cast(mt, _dpp), ctypes.cast(ct, _dpp), ctypes.cast(rt, _dpp)
+            if facets:
+                # a 3-D block (Job.nfacets): facet-major planes (nfacets, nlayer, nw) from the fused launch over the tall
+                # atmosphere; no TAUGAS / TAURAY workspace (that launch keeps the sums in registers), no level planes
+                self._facet_block(k, ctx, nw, nlayer, ng, nt, facets, want, do_reflected, do_thermal, th3)
+                continue
             tg, tr = DeviceArray((nlayer, nw), ctx), DeviceArray((nlayer, nw), ctx)
             self.keep += [tg, tr]
             k.taugas, k.tauray = _dev(tg), _dev(tr)
@@ -144,6 +149,26 @@ class BlockTable:
                 k.cld_work_opd, k.cld_work_w0, k.cld_work_g0 = (_dev(c) for c in cw)
         self.thermal_ws = {}                              # thermal outputs live on the thermal leg's context
 
+    def _facet_block(self, k, ctx, nw, nlayer, ng, nt, facets, want, do_reflected, do_thermal, th3):
+        if {"tau", "tau_og"} & set(want):
+            raise ValueError("3-D blocks: the level planes are running sums inside the solvers")
+        pl = {}
+        for i, name in enumerate(OUT_NAMES):
+            if name in want:
+                pl[name] = DeviceArray((facets, nlayer, nw), ctx)
+                self.keep.append(pl[name])
+                k.planes[i] = _dev(pl[name])
+        if do_reflected:
+            for i, name in enumerate(REFL_NAMES):
+                k.refl_planes[i] = _dev(pl.get(name))
+            x, a = DeviceArray((ng, nt, nw), ctx), DeviceArray((nw + 1,), ctx)
+            pin = PinnedArray((nw + 1,), ctx)
+            self.keep += [x, a, pin]
+            k.xint, k.albedo, k.albedo_pin = _dev(x), _dev(a), ctypes.cast(ctypes.c_void_p(pin.addr), _dp)
+        if do_thermal:
+            k.th_dtau, k.th_w0 = _dev(pl[th3[0]]), _dev(pl[th3[1]])
+            k.th_cosb = _dev(pl[th3[2]]) if th3[2] else None
+
     def thermal_workspace(self, b, tctx, ng, nt):
         """flux / disk of block b on the context the thermal leg runs on (allocated once per context)."""
         key = (b, getattr(tctx, "value", tctx))
@@ -157,7 +182,7 @@ class BlockTable:
 
 def make_job(nlayer, plan, factors, linear, raman_rows, stream, delta_eddington, do_reflected, do_thermal, ng, nt, ubar0,
              ubar1, cos_theta, gweight, tweight, single_phase, multi_phase, toon_coefficients, frac_a, frac_b, frac_c,
-             constant_back, constant_forward, b_top, tlevel, plevel, hard_surface, sh=None, sh_top=0):
+             constant_back, constant_forward, b_top, tlevel, plevel, hard_surface, sh=None, sh_top=0, nfacets=0):
     """The per-call half: (Job, the numpy arrays it points into).  ``plan`` = ``opa._plan`` (table rows and weights per
     molecule and layer, CIA rows), ``factors`` = ``optics._layer_factors`` (per-layer coefficients of the sums)."""
     mol_fac, cont_fac, ray_names, ray_fac = factors
@@ -183,7 +208,7 @@ def make_job(nlayer, plan, factors, linear, raman_rows, stream, delta_eddington,
     j.frac_a, j.frac_b, j.frac_c = float(frac_a), float(frac_b), float(frac_c)
     j.constant_back, j.constant_forward, j.b_top = float(constant_back), float(constant_forward), float(b_top)
     j.tlevel, j.plevel, j.hard_surface = _host(keep["tl"]), _host(keep["pl"]), int(hard_surface)
-    j.rt_method = 0
+    j.rt_method, j.nfacets = 0, int(nfacets)    # nfacets > 0: plan / factors of the tall atmosphere, tlevel / plevel (nfacets, nlevel)
     if sh is not None:                     # inputs["approx"]["rt_params"]["SH"]: the spherical-harmonics solvers
         j.rt_method = 1
         j.sh_w_single_form, j.sh_w_multi_form, j.sh_psingle_form = (int(sh[k]) for k in ("w_single_form", "w_multi_form", "psingle_form"))

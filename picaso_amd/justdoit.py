@@ -1071,8 +1071,8 @@ def picaso(bundle, opacityclass, dimension="1d", calculation="reflected", full_o
     if devices is not None:
         return _picaso_devices(bundle, opacityclass, devices, gather, dimension=dimension, calculation=calculation,
                                full_output=full_output, plot_opacity=plot_opacity, as_dict=as_dict, defer=defer, opt=opt)
-    if dimension == "1d" and not (full_output or defer or _raw or plot_opacity) and _shared is None and _batch is None:
-        fast = _picaso_driver(bundle, opacityclass, [(0, opacityclass.nwno, opacityclass)], calculation, opt)
+    if dimension in ("1d", "3d") and not (full_output or defer or _raw or plot_opacity) and _shared is None and _batch is None:
+        fast = _picaso_driver(bundle, opacityclass, [(0, opacityclass.nwno, opacityclass)], calculation, opt, dimension)
         if fast is not None:
             return fast
     s = Spectrum(bundle, opacityclass, dimension=dimension, calculation=calculation, full_output=full_output,
@@ -1085,10 +1085,11 @@ def picaso(bundle, opacityclass, dimension="1d", calculation="reflected", full_o
 # ------------------------------------------------------------------------------------------------
 # one C call per spectrum (csrc/driver.hip): the launch sequence of the 1-D Toon path for every wavelength block
 # ------------------------------------------------------------------------------------------------
-def _picaso_driver(bundle, opa, subs, calculation, opt=None):
-    """The plain 1-D Toon spectrum through ONE C call (``onecall.run``); None outside what the driver covers."""
+def _picaso_driver(bundle, opa, subs, calculation, opt=None, dimension="1d"):
+    """The plain 1-D (Toon or SH) or 3-D spectrum through ONE C call (``onecall.run``); None outside what the driver
+    covers."""
     from . import onecall
-    return onecall.run(bundle, opa, subs, calculation, _options.current(opt))
+    return onecall.run(bundle, opa, subs, calculation, _options.current(opt), dimension)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -1358,8 +1359,8 @@ def _picaso_devices(bundle, opa, devices, gather, dimension, calculation, full_o
     devs = _device_list(devices)
     shards = _opacity_shards(opa, devs)
     nwno = opa.nwno
-    if dimension == "1d" and gather == "host" and not (full_output or defer or plot_opacity):
-        fast = _picaso_driver(bundle, opa, shards, calculation, opt)  # every block in one C call (csrc/driver.hip)
+    if dimension in ("1d", "3d") and gather == "host" and not (full_output or defer or plot_opacity):
+        fast = _picaso_driver(bundle, opa, shards, calculation, opt, dimension)  # every block in one C call (csrc/driver.hip)
         if fast is not None:
             return fast
     nlevel = getattr(bundle, "nlevel", None)

@@ -1,4 +1,5 @@
-"""One C call per spectrum (csrc/driver.hip): the launch sequence of the 1-D path (Toon or SH) for every wavelength block.
+"""One C call per spectrum (csrc/driver.hip): the launch sequence of the 1-D path (Toon or SH) or of the 3-D path for every
+wavelength block.
 
 The plain 1-D spectrum (reference justdoit.py:236-385, 552-599) through ``picaso_toon_spectrum_blocks``: ONE C call
 enqueues gas stage -> ``compute_opacity`` -> reflected || thermal (+ fused disk sums) on every wavelength block of ``subs``
@@ -21,9 +22,9 @@ from .spectrum import (_bond_denominator, _constant_planes, _ones, _post_final, 
                        _resident_vector, _setup_atmosphere, _trapz_resident)
 
 
-def run(bundle, opa, subs, calculation, opt):
+def run(bundle, opa, subs, calculation, opt, dimension="1d"):
     """``prepare`` + the C call + ``finish``; None when the call is outside what the driver covers."""
-    p = prepare(bundle, opa, subs, calculation, opt)
+    p = (prepare_3d if dimension == "3d" else prepare)(bundle, opa, subs, calculation, opt)
     if p is None:
         return None
     try:
@@ -279,6 +280,111 @@ def prepare(bundle, opa, subs, calculation, opt, slot=None):
     return dict(table=table, job=job, keep=(keep, hold), do_r=do_r, do_t=do_t, full=full, nwno=nwno, integrals=integrals,
                 denom=c["denom"] if (integrals and do_r) else None, wno=wno, stellar=stellar, inp=inp, atm=atm, opa=opa,
                 signature=key[1:-1])
+
+
+def _in_scope_3d(inp, opa, legs, opt):
+    """The 3-D calls the C driver covers: what ``Spectrum._plan_3d`` sends through ONE fused gas + mixing launch over all
+    facets (facet-major planes) -- reflected and / or thermal Toon, monochromatic resident tables, no cloud or cloud tables
+    on their own wavenumber grid, Raman off or Pollack -- without the A/B switches that choose another layout."""
+    if (opt.no_driver or opt.all_planes or opt.facet_loop or opt.facet_fastest or opt.host_regrid or opt.raman_planes
+            or opt.unfused_opacity or opt.regrid_planes):
+        return False
+    if not legs or not legs <= {"reflected", "thermal"}:
+        return False
+    if (opa.ngauss != 1 or getattr(opa, "on_fly", False) or inp["test_mode"] is not None or not hasattr(opa, "_cia")
+            or not hasattr(opa, "_ray") or inp["approx"].get("get_lvl_flux", False)
+            or inp["approx"]["rt_method"] == "SH" or inp["clouds"].get("do_holes", False)):
+        return False                # (SH / do_holes in 3-D: Spectrum warns and ignores them, as the reference -- left to it)
+    return inp["approx"]["rt_params"]["common"]["raman"] in (1, 2) and inp["atmosphere"]["exclude_mol"] == 1
+
+
+def prepare_3d(bundle, opa, subs, calculation, opt, slot=None):
+    """``prepare`` for ``dimension='3d'`` (reference justdoit.py:407-516): the facet-form set-up and the tall plan once
+    for all wavelength blocks, a block table with facet-major planes, a job with ``nfacets``."""
+    from .spectrum import setup_facets_3d
+    inp = bundle.inputs
+    legs = set(calculation.split("+"))
+    if not _in_scope_3d(inp, opa, legs, opt):
+        return None
+    common, toon, geom = inp["approx"]["rt_params"]["common"], inp["approx"]["rt_params"]["toon"], inp["disco"]
+    raman = common["raman"]
+    wno, nwno = opa.wno, opa.nwno
+    ng, nt = geom["num_gangle"], geom["num_tangle"]
+    nfac = ng * nt
+    cld3 = inp["clouds"].get("profile_3d")
+    atm_f, atm, tlev3, plev3 = setup_facets_3d(inp, opa, wno, ng, nt)
+    plan, factors = optics.tall_plan(atm_f, opa, nfac, 1)
+    if plan.get("premixed"):
+        return None
+    nlevel, nlayer = atm.c.nlevel, atm.c.nlayer
+    tabs_sig = None
+    if cld3 is not None:
+        first = optics._facet_major_cloud_tables(cld3, nlayer, nfac, subs[0][2].ctx)
+        if first is None:
+            return None             # cloud arrays on the opacity grid: the facet-fastest mixing launch (Spectrum)
+        tabs_sig = first[3]
+    nmol, ncont, nray = len(plan["molecules"]), len(plan["cia_pairs"]), len(factors[2])
+    if (nmol * 56 + ncont * 12 + nray * 8 + 8) * nfac * nlayer > 3600 * 1024:
+        return None                 # the per-layer tables of the tall atmosphere must fit ONE table slot (one launch)
+    do_r, do_t = "reflected" in legs, "thermal" in legs
+    linear = opa.query_method == "linear"
+    frac_a, frac_b, frac_c = common["TTHG_params"]["fraction"]
+    want, th3 = set(), ("dtau_og", "w0_no_raman", "cosb_og")
+    if cld3 is None:                # Spectrum._want_3d(clear3=True)
+        if do_r:
+            want |= {"dtau", "w0"}
+        if do_t:
+            th3 = ("dtau", "w0" if (raman == 2 and do_r) else "w0_no_raman", None)
+    elif do_r:
+        want |= set(resident.REFLECTED_PLANES) - {"tau", "tau_og", "gcos2"}
+    if do_t:
+        want |= {k for k in th3 if k is not None}
+
+    def table_ids(sub):
+        mt = sub._mol_log if linear else sub._mol_raw
+        return tuple(id(mt[m]) for m in plan["molecules"]) + tuple(id(sub._cia[p]) for p in plan["cia_pairs"])
+    key = ("3d", tuple((lo, hi, id(sub)) + table_ids(sub) for lo, hi, sub in subs), nlayer, ng, nt, tuple(plan["molecules"]),
+           tuple(plan["cia_pairs"]), tuple(factors[2]), linear, tuple(sorted(want)), th3, do_r, do_t, slot)
+    cache = opa.__dict__.setdefault("_driver_tables", {})
+    table = cache.get(key)
+    if table is None:
+        if len(cache) > (8 if slot is None else 40):
+            cache.clear()
+        table = cache[key] = drv.BlockTable(subs, nlayer, ng, nt, plan["molecules"], plan["cia_pairs"], factors[2], linear,
+                                            want, False, False, do_r, do_t, _constant_planes, facets=nfac, th3=th3)
+    nostar = inp["star"]["database"] == "nostar"
+    F0PI = _ones(opa, nwno) if nostar else inp["star"]["relative_flux"]
+    stellar = getattr(opa, "unshifted_stellar_spec", None)
+    if stellar is None:
+        stellar = F0PI
+    integrals = len(subs) == 1 and nwno > 1 and not opt.host_integrals
+    hold, full = [], {}
+    if do_r:
+        full["albedo"] = np.empty(nwno + 1 if integrals else nwno)
+    if do_t:
+        full["thermal"] = np.empty(nwno + 1 if integrals else nwno)
+    c = dict(nwno=nwno, wno=wno, hold=hold, atm=atm, nostar=nostar, F0PI=F0PI, stellar=stellar, nblocks=len(subs),
+             raman=raman, clouds=(None, None, None), do_r=do_r, do_t=do_t, overlap=do_r and do_t and opt.overlap_legs,
+             seen_dev={}, table=table, ng=ng, nt=nt, full=full, integrals=integrals, denom=None)
+    for b, (lo, hi, sub) in enumerate(subs):
+        c["b"] = b
+        k = table.blocks[b]
+        _fill_block(k, sub, lo, hi, c)
+        if cld3 is not None:        # the tall tables, resident per device (kept on the cloud dictionary by content)
+            d_xp, d_tall, _, nin = optics._facet_major_cloud_tables(cld3, nlayer, nfac, sub.ctx)
+            hold.append((d_xp, d_tall))
+            k.cld_tab_nin, k.cld_tab_xp, k.cld_tab_fp = nin, drv._dev(d_xp), drv._dev(d_tall)
+            k.wno = drv._dev(_resident_vector(sub, "wno", sub.wno, hi - lo))
+    tl = np.ascontiguousarray(np.asarray(tlev3, dtype=float).reshape(nlevel, nfac).T)
+    pv = np.ascontiguousarray(np.asarray(plev3, dtype=float).reshape(nlevel, nfac).T)
+    job, keep = drv.make_job(nlayer, plan, factors, linear, 0, common["stream"], common["delta_eddington"], do_r, do_t, ng, nt,
+                             geom["ubar0"], geom["ubar1"], geom["cos_theta"], geom["gweight"], geom["tweight"],
+                             toon["single_phase"], toon["multi_phase"], toon["toon_coefficients"], frac_a, frac_b, frac_c,
+                             common["TTHG_params"]["constant_back"], common["TTHG_params"]["constant_forward"], 0.0, tl, pv,
+                             atm.hard_surface, nfacets=nfac)
+    return dict(table=table, job=job, keep=(keep, hold, tabs_sig), do_r=do_r, do_t=do_t, full=full, nwno=nwno,
+                integrals=integrals, denom=c["denom"] if (integrals and do_r) else None, wno=wno, stellar=stellar, inp=inp,
+                atm=atm, opa=opa, signature=key[2:-1])
 
 
 def finish(p):

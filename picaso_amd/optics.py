@@ -1172,6 +1172,29 @@ def _facet_major_cloud_tables(clouds_3d, nlayer, nfac, ctx):
     return memo[4][key] + (memo[2], nin)
 
 
+def tall_plan(atm_f, opa, nfac, exclude_mol=1):
+    """Table rows / weights (``opa._plan``) and per-layer coefficients (``_layer_factors``) of the TALL atmosphere of a
+    3-D spectrum: the ``nfac * nlayer`` layers of all facets, facet-major.  From ``picaso_host_setup_facets`` when the
+    facet-form set-up went through it (``atm_f._fast_tall``), else with the mirror's table search on the flattened
+    layer temperatures and pressures."""
+    nlayer = atm_f.c.nlayer
+    fast = getattr(atm_f, "_fast_tall", None)
+    if fast is not None and fast[2] is opa and exclude_mol == 1:
+        opa._plan = fast[0]
+        opa.molecular_opa, opa.continuum_opa = _LazyPlanes(opa, "mol"), _LazyPlanes(opa, "cia")
+        return fast[0], fast[1]
+    import types
+
+    def flat(a):
+        return np.ascontiguousarray(np.broadcast_to(np.asarray(a, dtype=float), (nlayer, nfac)).T).ravel()
+    tall = types.SimpleNamespace(
+        c=types.SimpleNamespace(nlayer=nfac * nlayer, pconv=atm_f.c.pconv),
+        layer={"temperature": flat(atm_f.layer["temperature"]), "pressure": flat(atm_f.layer["pressure"])},
+        molecules=atm_f.molecules, continuum_molecules=atm_f.continuum_molecules)
+    opa.get_opacities(tall, exclude_mol=exclude_mol)
+    return opa._plan, _layer_factors(atm_f, opa)
+
+
 def compute_opacity_facet_major(atm_f, opacityclass, numg, numt, stream=2, delta_eddington=True, raman=2, exclude_mol=1,
                                 want=("dtau", "w0"), cloud_tables=None):
     """The planes of a 3-D spectrum WITHOUT cloud in facet-major layout ``(nfacets, nlayer, nwno)``, from one fused
@@ -1187,23 +1210,7 @@ def compute_opacity_facet_major(atm_f, opacityclass, numg, numt, stream=2, delta
     nfac = numg * numt
     nlayer, nwno = atm_f.c.nlayer, opa.nwno
     ntot = nfac * nlayer
-    fast = getattr(atm_f, "_fast_tall", None)
-    if fast is not None and fast[2] is opa and exclude_mol == 1:
-        opa._plan = pl = fast[0]
-        opa.molecular_opa, opa.continuum_opa = _LazyPlanes(opa, "mol"), _LazyPlanes(opa, "cia")
-        mol_fac, cont_fac, ray_names, ray_fac = fast[1]
-    else:
-        import types
-
-        def flat(a):
-            return np.ascontiguousarray(np.broadcast_to(np.asarray(a, dtype=float), (nlayer, nfac)).T).ravel()
-        tall = types.SimpleNamespace(
-            c=types.SimpleNamespace(nlayer=ntot, pconv=atm_f.c.pconv),
-            layer={"temperature": flat(atm_f.layer["temperature"]), "pressure": flat(atm_f.layer["pressure"])},
-            molecules=atm_f.molecules, continuum_molecules=atm_f.continuum_molecules)
-        opa.get_opacities(tall, exclude_mol=exclude_mol)
-        pl = opa._plan
-        mol_fac, cont_fac, ray_names, ray_fac = _layer_factors(atm_f, opa)
+    pl, (mol_fac, cont_fac, ray_names, ray_fac) = tall_plan(atm_f, opa, nfac, exclude_mol)
     mol_tabs = [(opa._mol_log if opa.query_method == "linear" else opa._mol_raw)[m] for m in pl["molecules"]]
     mol_mode = 1 if opa.query_method == "linear" else 0
     cont_tabs = [opa._cia[p] for p in pl["cia_pairs"]]

@@ -248,12 +248,14 @@ def test_gpu_3d_cloud_tables_on_their_own_grid_regrid_on_the_device(monkeypatch,
     real = px.compute_opacity_facet_major
     monkeypatch.setattr(px, "compute_opacity_facet_major", lambda *a, **k: (calls.append(k.get("cloud_tables") is not None),
                                                                             real(*a, **k))[1])
+    monkeypatch.setenv("PICASO_AMD_NO_DRIVER", "1")       # the call-by-call path (the C driver makes the same launches itself)
     again = case(dict(cld, wavenumber=wn)).spectrum(opa, calculation=calc, dimension="3d")
     assert calls == [True]
     monkeypatch.setenv("PICASO_AMD_FACET_FASTEST", "1")
     ff = case(dict(cld, wavenumber=wn)).spectrum(opa, calculation=calc, dimension="3d")
     assert calls == [True]
     monkeypatch.delenv("PICASO_AMD_FACET_FASTEST")
+    monkeypatch.delenv("PICASO_AMD_NO_DRIVER")
     for key in ("albedo", "thermal"):
         assert np.array_equal(again[key], dev[key]) and np.array_equal(ff[key], dev[key]), key
     for one in ("reflected", "thermal"):

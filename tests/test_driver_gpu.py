@@ -204,3 +204,55 @@ def test_driver_runs_the_sh_solvers(monkeypatch, devices, calc, cloud, stream, f
     for w, g in zip(want, got):
         _same(w, g)
         assert all(np.isfinite(v).all() for v in g.values() if isinstance(v, np.ndarray))
+
+
+@pytest.mark.parametrize("devices", [None, [0, 0, 0]])
+@pytest.mark.parametrize("calc", ["reflected", "thermal", "reflected+thermal"])
+@pytest.mark.parametrize("cloud,raman", [(None, "none"), (None, "pollack"), ("shared", "none"), ("per_facet", "none")])
+def test_driver_runs_the_3d_blocks(monkeypatch, pollack_table, devices, calc, cloud, raman):
+    """dimension='3d' through the C driver (round 5; it took the Python per-block loop, ~0.45 ms of interpreter time per
+    wavelength block): ONE fused gas + mixing launch over the tall atmosphere of all facets, the batched 3-D solvers with
+    every facet as a spectrum of its own, the disk sums -- cloud-free maps and cloud tables on their own wavenumber grid
+    (one table for the disk, one per facet), whole grid and wavelength blocks, every output equal to the call-by-call
+    path (spectrum.Spectrum) bit for bit."""
+    from picaso_amd import justdoit as jdi
+    og = np.load(os.path.join(GOLDEN, "optics.npz"))
+    opa = jdi.opannection(filename_db=DB, query_method="linear")
+    ng, nt = 3, 2
+    nlayer, nin = len(og["in/tlevel"]) - 1, 7
+    rng = np.random.default_rng(5)
+    wn = np.linspace(opa.wno[-1] * 0.95, opa.wno[0] * 1.02, nin)
+    shape = (nlayer, nin, ng, nt) if cloud == "per_facet" else (nlayer, nin)
+    cld = {"opd": 0.3 * rng.random(shape), "w0": 0.5 + 0.49 * rng.random(shape), "g0": 0.8 * rng.random(shape), "wavenumber": wn}
+    for k in ("opd", "g0"):
+        cld[k][:4] = 0.0
+
+    def make(k):
+        c = jdi.inputs()
+        c.phase_angle(0.6 + 0.2 * k, num_gangle=ng, num_tangle=nt)
+        c.gravity(gravity=float(og["in/gravity"]), radius=7.1e9, mass=1.9e30)
+        nwno = opa.nwno
+        c.star(relative_flux=1.0 + 0.3 * np.sin(np.arange(nwno) / 7.0), radius=6.9e10, semi_major=7.5e12)
+        c.surface_reflect(0.1 + 0.2 * np.cos(np.arange(nwno) / 11.0) ** 2)
+        prof = {"pressure": og["in/plevel_bar"],
+                "temperature": og["in/tlevel"][:, None, None] * (1.0 + 0.015 * (1 + k) * np.arange(ng * nt).reshape(1, ng, nt))}
+        for m in ("H2", "He", "H2O", "CH4"):
+            prof[m] = og["in/mix/" + m]
+        c.atmosphere_3d(prof)
+        if cloud:
+            c.clouds_3d(dict(cld))
+        c.approx(raman=raman)
+        return c
+    monkeypatch.setenv("PICASO_AMD_NO_DRIVER", "1")
+    want = [make(k).spectrum(opa, calculation=calc, dimension="3d", devices=devices) for k in range(2)]
+    assert "_driver_tables" not in opa.__dict__
+    monkeypatch.delenv("PICASO_AMD_NO_DRIVER")
+    got = [make(k).spectrum(opa, calculation=calc, dimension="3d", devices=devices) for k in range(2)]
+    assert len(opa.__dict__["_driver_tables"]) == 1          # the second spectrum reused the first one's blocks
+    (table,) = opa.__dict__["_driver_tables"].values()
+    if cloud is None and "reflected" in calc:
+        assert set(table.want) == {"dtau", "w0"} | ({"w0_no_raman"} if ("thermal" in calc and raman != "none") else set())
+    assert not ({"tau", "tau_og"} & set(table.want))
+    for w, g in zip(want, got):
+        _same(w, g)
+        assert all(np.isfinite(v).all() for v in g.values() if isinstance(v, np.ndarray))
