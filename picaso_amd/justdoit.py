@@ -1312,7 +1312,10 @@ def _slice_inputs(inp, lo, hi, nwno, nlayer, clouds=True):
             new[k] = v                 # other tables are regridded onto the block's own wavenumbers (get_clouds)
         cl["profile"] = new
     p3 = cl.get("profile_3d")
-    if p3 is not None:
+    if p3 is not None and p3.get("wavenumber") is None:
+        # arrays already on the opacity grid: this block's columns.  Tables on a wavenumber grid of their own go to every
+        # block as they are (the same dictionary: its resident copies are kept with it) and are interpolated onto the
+        # block's wavenumbers there
         cl["profile_3d"] = {k: np.ascontiguousarray(np.asarray(v, dtype=float).reshape((nlayer, nwno, -1))[:, lo:hi])
                             for k, v in p3.items()}
     out["clouds"] = cl
