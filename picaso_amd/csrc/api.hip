@@ -157,7 +157,7 @@ static bool spread_angles(long ncol, int nang, long limit = 1280L * 64)
 // 64-column block per CU with the reference's default options take k_reflected_coop instead, reflected_1d_core.)
 //
 // The choice is made from a two-constant model of a wave's time per layer, fitted to steady-state measurements on
-// the MI355X at 90 layers and 5 angles (PICASO_AMD_ANGLE_GROUP sweeps of round 2; DESIGN_HISTORY.md section 6):
+// the MI355X at 90 layers and 5 angles (PICASO_AMD_ANGLE_GROUP sweeps of round 2):
 //     a wave that carries g angles and has its SIMD to itself:   t1(g) = T_SHARED + g * T_ANGLE        per layer
 //     ... and shares the SIMD with a second wave of the launch:  t2(g) = PAIRED * t1(g)
 // (g = 1, 2, 3 alone: 0.050 / 0.063 / 0.084 ms at 90 layers -> 0.37 + 0.19 g us per layer; paired 0.085 / 0.110 /
@@ -1176,7 +1176,7 @@ static int thermal_1d_core(picaso_ctx *ctx, int nlevel, const double *wno, int n
     // Small launches: the cooperative kernel (helper waves compute the layer quantities into LDS, one
     // sweeper wave per 64 columns runs the recurrence for all angles; the level temperatures travel as
     // kernel arguments).  Step time of get_thermal_1d + compress_thermal at 1e4 x 90 x 5 (BASELINE
-    // configs[1]) and where it stops paying: DESIGN.md section 7 (DESIGN_HISTORY.md section 4).
+    // configs[1]) and where it stops paying: DESIGN.md section 7.
     // Batched launch: the table = nspec entries followed by every spectrum's level temperatures and pressures;
     // entry s carries the angles [first, first + count) of this launch chunk
     std::vector<char> btab;

@@ -131,6 +131,16 @@ __device__ __forceinline__ double frcp(double b)
     return y;
 }
 
+// 1/b to 2^-46 relative (1.4e-14): v_rcp_f64 + ONE Newton step, 3 instructions.  Only where the reciprocal enters as
+// a plain factor of a product (no difference is formed from the result): thermal emission's per-angle
+// 1/((lam mu - 1)(lam mu + 1)), whose error multiplies the angle's source terms and nothing else.
+__device__ __forceinline__ double frcp1(double b)
+{
+#pragma clang fp contract(off)
+    const double y = __builtin_amdgcn_rcp(b);
+    return fma(y, fma(-b, y, 1.0), y);
+}
+
 // sqrt(x), correctly rounded like the library call it replaces, for normal-range arguments: v_rsq_f64 seed,
 // two coupled Goldschmidt steps on g ~ sqrt(x), h ~ 1/(2 sqrt(x)) and one residual correction
 // g + (x - g g) h (exact residual in the fma); 12 instructions + the zero guard, against the compiler's

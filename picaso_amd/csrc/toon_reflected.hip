@@ -351,7 +351,7 @@ __device__ __forceinline__ double disk_finish(double c1, double acc, double F, d
 
 // BIG: one wave per SIMD (grids of up to 1 024 column-waves, five angles): the whole 512-entry register file
 // belongs to the wave, so the sweep state stays in registers instead of LDS -- 50 000 columns 0.1365 ms against
-// 0.1636 (round-2 sweep, DESIGN_HISTORY.md), same bits.  Of no use to the 1e5-column launch: its 1 563 waves need
+// 0.1636 (round-2 sweep), same bits.  Of no use to the 1e5-column launch: its 1 563 waves need
 // two per SIMD.
 // DRV (3-D only): some planes are NULL and re-derived in the kernel (see below); the full-plane 3-D launch keeps
 // the branch-free load sequence (the conditional loads cost the HBM-bound facet kernel 7 %)
@@ -693,7 +693,7 @@ __global__ __launch_bounds__(PZ_REFL_BLOCK, (BIG ? 1 : NA <= 2 ? PZ_REFL_MINWAVE
     // their chunk would put up to 8 x ny more workgroups on the first XCDs than on the others (12 500
     // columns, one angle per wave: 35 on XCD 0 of 32 CUs, 0.078 ms instead of 0.050).  A 2-D (x, y) grid
     // shares L2 only when the column-group count happens to be a multiple of 8 (12 250 columns 0.050 ms,
-    // 12 000 0.069, 12 500 0.072: round-2 sweep, DESIGN_HISTORY.md).
+    // 12 000 0.069, 12 500 0.072: round-2 sweep).
     unsigned bx = blockIdx.x, by = 0;
     if (!IS3D && a.ny > 1) xcd_decode(blockIdx.x, (unsigned)a.ny, (unsigned)a.ncg, by, bx);
     reflected_toa_body<NA, IS3D, ZP, FAST, BIG, DRV>(a, bx, by, a.ang);

@@ -27,7 +27,7 @@
 // so a spectrum does not depend on how many GPUs it was cut across (tests/test_parity_gpu.py,
 // test_fullsize_gpu.py, test_fuzz_gpu.py all run through this kernel at their sizes).
 //
-// What it buys, measured (the measurements behind it: DESIGN_HISTORY.md section 6): 0.047-0.048 ms for any launch up to 16 384 columns x 90 layers x 5
+// What it buys, measured (the measurements behind it: DESIGN.md appendix A.3): 0.047-0.048 ms for any launch up to 16 384 columns x 90 layers x 5
 // angles, against 0.048-0.050 (one angle per workgroup, <= 13 056 columns) and 0.061 (angle pairs, to 16 384) of the
 // grid.y shapes.  Why not more: a wave alone on its SIMD issues one fp64 instruction per ~7.5 cycles here (2.38 GHz
 // in these light launches), two waves sharing a SIMD one per ~5.8 between them, against the pipe's 4.2 -- the
@@ -64,7 +64,7 @@ enum { RCF_CUM_TAU = 1, RCF_EO_OK = 2, RCF_SAME_DT = 4, RCF_NOCLD = 8, RCF_ALL =
 #ifndef PZ_RCOOP_APW
 #define PZ_RCOOP_APW 1
 #endif
-constexpr int RC_APW = PZ_RCOOP_APW;                 // angles per angle wave (1 or 2; measured: 1, see DESIGN_HISTORY.md section 6)
+constexpr int RC_APW = PZ_RCOOP_APW;                 // angles per angle wave (1 or 2; measured: 1)
 constexpr int RC_MAX_ANGLES = 6 * RC_APW;            // at most 6 angle waves + S + L = 8 waves (two per SIMD)
 
 struct RcState {

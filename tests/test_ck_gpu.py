@@ -115,7 +115,7 @@ def test_ck_level_fluxes(oracle):
                            calc_type=1, lvl_fluxes=lvt_d)
     got = [a.to_host() for a in lvt_d]
     # vs the oracle: bounded by the reference formula's own conditioning in optically thick layers
-    # (b_surface - c_plus_down cancellation, see tests/helpers.py:lvl_excess and DESIGN_HISTORY.md section 3)
+    # (b_surface - c_plus_down cancellation, see tests/helpers.py:lvl_excess and DESIGN.md appendix A.1)
     assert lvl_err(got, lt) < 2e-4
     # the batch plumbing itself: identical to looping the ngauss = 1 entry point over the slices
     from picaso_amd import fluxes

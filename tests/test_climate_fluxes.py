@@ -44,7 +44,7 @@ def _check(out, g, c, tol, tol_ir_lvl=None):
     metric, |got - ref| over the per-wavenumber scale of the (plus, minus) pair -- entries that all
     but vanish are differences of nearly equal terms in the reference's formulation.  The thermal
     level fluxes of optically thick Gauss points carry the reference's own b_surface - c_plus_down
-    cancellation (DESIGN_HISTORY.md section 3, tests/test_ck_gpu.py): `tol_ir_lvl`."""
+    cancellation (tests/test_ck_gpu.py): `tol_ir_lvl`."""
     assert len(out) == 8
     got = dict(zip(OUT, out))
     for name in OUT:
@@ -125,7 +125,7 @@ def test_gpu_calculate_atm_feeds_get_fluxes(oracle):
     noed_h = pc.OpacityNoEd_Tuple(ref["dtau_og"], ref["tau_og"], ref["w0_og"], ref["cosb_og"])
     want = co.get_fluxes(atm_t, wed_h, noed_h, sp, dis, grid, np.ones(nwno), True, True)
     # visible nets tight; the thermal nets of this scene's optically thick Gauss points carry the
-    # reference formulation's own cancellation noise at the deep levels (tests/test_ck_gpu.py, DESIGN_HISTORY.md section 3)
+    # reference formulation's own cancellation noise at the deep levels (tests/test_ck_gpu.py)
     for name, a, b in zip(OUT, out, want):
         if name.startswith("flux_net"):
             assert rel_err(a, b, 1e-4 * np.abs(b).max()) < (1e-4 if name.endswith("_ir") or "ir_" in name else 1e-7), name

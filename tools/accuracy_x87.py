@@ -1,6 +1,6 @@
 """Accuracy of the single-sweep elimination vs the reference algorithm, both evaluated in x87 extended
 precision on a fresh scene (run on the GPU box): shows which of GPU / oracle is closer to the
-extended-precision result.  Development aid quoted in DESIGN_HISTORY.md section 3."""
+extended-precision result.  Development aid quoted in DESIGN.md appendix A.1."""
 import sys, os
 ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0,ROOT); sys.path.insert(0,os.path.join(ROOT,'tests')); sys.path.insert(0,os.path.join(ROOT,'tools'))

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Secondary measurements quoted in DESIGN.md / DESIGN_HISTORY.md (run on the GPU box): thermal (BASELINE configs[1]),
+"""Secondary measurements quoted in DESIGN.md (run on the GPU box): thermal (BASELINE configs[1]),
 3-D reflected facets, level-flux kernels, opacity pre-stage, and the PCIe-inclusive host-pointer
 call of the headline workload.  HIP-event timed on the library's stream, inputs resident in HBM
 unless stated."""
