@@ -11,6 +11,23 @@
 
 #include "../../include/picaso_hip.h"
 
+// Round 5: the layer body's arithmetic regrouped for fewer instructions (7 per angle-layer and 2 per layer of ~479 per
+// five-angle layer).  The VALUES are the same expressions; their rounding is not, so results differ from rounds 1-4 in the
+// last bits (observed <= 2e-13; every launch shape, shard and batch member still agrees bit for bit because every kernel
+// takes the same regrouped form, toon_reflected_coop.hip included).  0 = the round-4 operation order (A/B).
+//   (1) the beam terms at the bottom of a layer from those at its top (c-dn = c-up e0, c+dn = c+up e0) where the beam
+//       exponential is carried as a running product anyway;
+//   (2) the common factors of the two mode integrals multiplied once: T/(lu^2 - 1) w0/2pi (1 + Gamma) B0;
+//   (3) the layer source S0 = t2 (ssa eo + (w0/2pi A0) B0 fx) where the layer is not delta-scaled;
+//   (4) the per-angle reciprocal 1/(den (lu - 1)(lu + 1)) with ONE Newton step (2^-46): it is a common FACTOR of every
+//       beam term of the layer (and of the mode integrals), so its error scales the layer's particular solution and the
+//       homogeneous response to it alike -- the near-singular cancellation at lambda u0 -> 1 is untouched (checked
+//       against the x87 oracle on the headline scene's worst columns, tools/headline_error_x87.py);
+//   (5) 1/g2 and 1/EP from one reciprocal of their product.
+#ifndef PZ_REFL_DIET
+#define PZ_REFL_DIET 1
+#endif
+
 namespace pz { struct PairwisePlan; }        // integrals.hip: the summation tree of one array length
 
 struct picaso_ctx {

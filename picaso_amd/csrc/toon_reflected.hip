@@ -97,6 +97,7 @@ enum { S_T = 0, S_XU, S_EO, S_KAPPA, S_ZETA, S_D1, S_D2 };   // late-use variabl
 #ifndef PZ_REFL_BATCH_RCP
 #define PZ_REFL_BATCH_RCP 0
 #endif
+// PZ_REFL_DIET (common.hpp): the round-5 regrouping of this body's arithmetic; 0 = the round-4 operation order
 template <int NA, bool LDS>
 struct ReflState {
     static constexpr int NL = LDS ? PZ_REFL_NLDS : 0;      // variables [NSTATE-NL, NSTATE) in LDS
@@ -174,10 +175,18 @@ __device__ __forceinline__ void reflected_layer(const ReflectedArgs &a, const La
     double g1, g2, lam, lam2;
     if (NC) toon_gammas_nocld(tc, w0, g1, g2, lam, lam2);
     else toon_gammas(tc, w0, fcg, g1, g2, lam, lam2);
-    const double gam = (g1 - lam) * frcp(g2);
     const double E = fmin(lam * dt, clip);
     const double EP = fexp2(E * -NEG_LOG2E, K);
+#if PZ_REFL_DIET
+    // 1/g2 and 1/EP from one reciprocal (g2 of order w0 <= 1, EP <= e^35: the product stays in range; g2 = 0 -- a layer
+    // that does not scatter -- is NaN in Gamma here as in round 4 and in the reference's (g1 - lamda)/g2, fluxes.py:1141)
+    const double r_ge = frcp(g2 * EP);
+    const double ig2 = r_ge * EP, EM = r_ge * g2;
+    const double gam = (g1 - lam) * ig2;
+#else
+    const double gam = (g1 - lam) * frcp(g2);
     const double EM = frcp(EP);
+#endif
     // No cloud anywhere in this layer of the wave (ftau_cld == 0 in every lane, checked per wave):
     // TTHG_ray's p_single = ftau_cld tthg + ftau_ray 3/4 (1 + cos^2) is its Rayleigh part alone
     // (bit-identical: 0 * tthg + x = x), without the two Henyey-Greenstein terms.
@@ -203,6 +212,8 @@ __device__ __forceinline__ void reflected_layer(const ReflectedArgs &a, const La
     const double c15 = NC ? 0.0 : 1.5 * fcg;
     const double gp = 1.0 + gam;
     const double gmc = NC ? 0.0 : (1.0 - gam) * c15;
+    const double w2gp = w2pi * gp, w2gmc = NC ? 0.0 : w2pi * gmc;      // PZ_REFL_DIET (2)
+    const double w2A0 = w2pi * A0;                                    // PZ_REFL_DIET (3)
 
     // ---- elimination factors shared by all angles ----
     double a1i = 0.0, a2i = 0.0, ia = 0.0, rho_n = gam, sfac = 0.0;
@@ -249,7 +260,7 @@ __device__ __forceinline__ void reflected_layer(const ReflectedArgs &a, const La
         r3_[0] = R;
 #else
 #pragma unroll
-        for (int k = 0; k < NA; ++k) r3_[k] = frcp(q[k]);
+        for (int k = 0; k < NA; ++k) r3_[k] = PZ_REFL_DIET ? frcp1(q[k]) : frcp(q[k]);
 #endif
     }
 
@@ -269,19 +280,36 @@ __device__ __forceinline__ void reflected_layer(const ReflectedArgs &a, const La
         const double xu = S.get(S_XU, k), Tk = S.get(S_T, k);
         const double xd = (AF || L.cum_tau) ? xu * e0 : fexp2_cold(L.tau_n * nl0_k, K);
         const double fw = Fw0h * rden;
-        const double fx = fw * xu, fxd = fw * xd;
+        const double fx = fw * xu;
         const double cmu = am2 * fx, cpu = ap2 * fx;       // c-/c+ at the top of the layer
-        const double cmd = am2 * fxd, cpd = ap2 * fxd;     // ... and at the bottom
+        double cmd, cpd;                                   // ... and at the bottom
+        if (PZ_REFL_DIET && (AF || L.cum_tau)) {           // xd = xu e0: the bottom terms are the top ones times e0
+            cmd = cmu * e0;
+            cpd = cpu * e0;
+        } else {
+            const double fxd = fw * xd;
+            cmd = am2 * fxd;
+            cpd = ap2 * fxd;
+        }
         S.set(S_XU, k, xd);
         // source-function coefficients (fluxes.py:1275-1296, 1395-1406)
         const double B0 = fma(gcq, q2_k, 1.0);
         const double h15 = NC ? 0.0 : c15 * u1_k;
         const double Aqq = NC ? B0 * A0 : fma(B0, A0, -(h15 * hz));       // (mpl c+ + mmi c-) / (2 fx)
-        const double X = gp * B0, Y = NC ? 0.0 : gmc * u1_k;
-        const double Tw = Tk * w2pi, Trd = Tw * rd;
         const double ee = fma(EP, et, -1.0), ff = fma(-EM, et, 1.0);
-        double vp = (Trd * lp1) * ((NC ? X : X + Y) * ee);
-        double vn = (Trd * lm1) * ((NC ? X : X - Y) * ff);
+        double vp, vn;
+        if (PZ_REFL_DIET) {
+            // (x + 0 = x - 0 = x exactly: the cloud-free copy and the general body agree bit for bit on a layer without cloud)
+            const double Trd = Tk * rd, wX = w2gp * B0;
+            const double wY = NC ? 0.0 : w2gmc * u1_k;
+            vp = ((Trd * (NC ? wX : wX + wY)) * lp1) * ee;
+            vn = ((Trd * (NC ? wX : wX - wY)) * lm1) * ff;
+        } else {
+            const double X = gp * B0, Y = NC ? 0.0 : gmc * u1_k;
+            const double Tw = Tk * w2pi, Trd = Tw * rd;
+            vp = (Trd * lp1) * ((NC ? X : X + Y) * ee);
+            vn = (Trd * lm1) * ((NC ? X : X - Y) * ff);
+        }
         // exp(-tau_og[i]/u0): the running product of the layers above when tau_og really is the
         // running sum of dtau_og, else formed directly
         const double eo = (!FIRST && (AF || L.eo_ok)) ? S.get(S_EO, k) : fexp2_cold(L.tauo * nl0_k, K);
@@ -296,8 +324,14 @@ __device__ __forceinline__ void reflected_layer(const ReflectedArgs &a, const La
         }
         if (!LAST) S.set(S_EO, k, eo * e0o);
         // S0 = (ssa eo t1 + Aq t2) u0/(u0+u1) with Aq = 2 w2pi fx Aqq; wq2 = 2 u0/(u0+u1) (1 if ZP)
-        const double s1 = (ssa_h * wq2_k) * (eo * t1);
-        const double S0 = fma((w2pi * wq2_k) * fx, Aqq * t2, s1);
+        double S0;
+        if (PZ_REFL_DIET && ZP && (NC || L.nocld) && (AF ? (SDT != 2) : L.same_dt)) {
+            // t1 == t2 and Aqq = B0 A0 (no cloud: the general body's h15 hz is +0): S0 = t2 (ssa eo + (w0/2pi A0) (B0 fx))
+            S0 = fma(w2A0, B0 * fx, ssa_h * eo) * t2;
+        } else {
+            const double s1 = (ssa_h * wq2_k) * (eo * t1);
+            S0 = fma((w2pi * wq2_k) * fx, Aqq * t2, s1);
+        }
         double kap = fma(Tk, S0, S.get(S_KAPPA, k));
         const double Tn = Tk * et;
         if (LAST) {                                        // xint[n] = flux_zero/pi (fluxes.py:1266-1270)

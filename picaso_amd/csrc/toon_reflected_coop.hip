@@ -101,6 +101,16 @@ __device__ __forceinline__ void frcp_n(const double (&b)[NA], double (&y)[NA])
     RC_FOR_K e[kk] = fma(-b[kk], y[kk], 1.0);
     RC_FOR_K y[kk] = fma(y[kk], e[kk], y[kk]);
 }
+// frcp1 (one Newton step, 2^-46) over NA arguments: the per-angle 1/(den (lu - 1)(lu + 1)) of PZ_REFL_DIET
+template <int NA>
+__device__ __forceinline__ void frcp1_n(const double (&b)[NA], double (&y)[NA])
+{
+#pragma clang fp contract(off)
+    double e[NA], y0[NA];
+    RC_FOR_K y0[kk] = __builtin_amdgcn_rcp(b[kk]);
+    RC_FOR_K e[kk] = fma(-b[kk], y0[kk], 1.0);
+    RC_FOR_K y[kk] = fma(y0[kk], e[kk], y0[kk]);
+}
 
 // One layer of NA angles: NA iterations of reflected_layer's angle loop, every statement written over the NA angles
 // (see above).  `in`: the layer's plane values (wave L), `slot`: the angle-independent quantities (wave S), read
@@ -145,7 +155,8 @@ __device__ __forceinline__ void rc_angle(const double (*in)[64], const double (*
     RC_FOR_K lml[kk] = lm1[kk] * lp1[kk];
     RC_FOR_K q3[kk] = den[kk] * lml[kk];
     fexp2_n<NA>(targ, K, et);
-    frcp_n<NA>(q3, r3);
+    if (PZ_REFL_DIET) frcp1_n<NA>(q3, r3);
+    else frcp_n<NA>(q3, r3);
     if (ZP) {
         RC_FOR_K e0[kk] = et[kk];
     } else {
@@ -167,12 +178,17 @@ __device__ __forceinline__ void rc_angle(const double (*in)[64], const double (*
     }
     RC_FOR_K fw[kk] = Fw0h * rden[kk];
     RC_FOR_K fx[kk] = fw[kk] * st[kk].XU;
-    RC_FOR_K fxd[kk] = fw[kk] * xd[kk];
     double cmu[NA], cpu[NA], cmd[NA], cpd[NA], B0[NA], Aqq[NA], X[NA], Y[NA], Tw[NA], Trd[NA], ee[NA], ff[NA];
     RC_FOR_K cmu[kk] = am2[kk] * fx[kk];
     RC_FOR_K cpu[kk] = ap2[kk] * fx[kk];
-    RC_FOR_K cmd[kk] = am2[kk] * fxd[kk];
-    RC_FOR_K cpd[kk] = ap2[kk] * fxd[kk];
+    if (PZ_REFL_DIET && cum_tau) {                      // reflected_layer, PZ_REFL_DIET (1)
+        RC_FOR_K cmd[kk] = cmu[kk] * e0[kk];
+        RC_FOR_K cpd[kk] = cpu[kk] * e0[kk];
+    } else {
+        RC_FOR_K fxd[kk] = fw[kk] * xd[kk];
+        RC_FOR_K cmd[kk] = am2[kk] * fxd[kk];
+        RC_FOR_K cpd[kk] = ap2[kk] * fxd[kk];
+    }
     RC_FOR_K B0[kk] = fma(gcq, g[kk].q2, 1.0);
     if (PLAIN) {
         RC_FOR_K Aqq[kk] = B0[kk] * A0;
@@ -181,14 +197,24 @@ __device__ __forceinline__ void rc_angle(const double (*in)[64], const double (*
         RC_FOR_K Aqq[kk] = fma(B0[kk], A0, -((c15 * g[kk].u1) * hz[kk]));
         RC_FOR_K Y[kk] = gmc * g[kk].u1;
     }
-    RC_FOR_K X[kk] = gp * B0[kk];
-    RC_FOR_K Tw[kk] = st[kk].T * w2pi;
-    RC_FOR_K Trd[kk] = Tw[kk] * rd[kk];
     RC_FOR_K ee[kk] = fma(EP, et[kk], -1.0);
     RC_FOR_K ff[kk] = fma(-EM, et[kk], 1.0);
     double vp[NA], vn[NA], eo[NA], t2[NA], t1[NA], e0o[NA];
-    RC_FOR_K vp[kk] = (Trd[kk] * lp1[kk]) * ((PLAIN ? X[kk] : X[kk] + Y[kk]) * ee[kk]);
-    RC_FOR_K vn[kk] = (Trd[kk] * lm1[kk]) * ((PLAIN ? X[kk] : X[kk] - Y[kk]) * ff[kk]);
+    const double w2A0 = w2pi * A0;
+    if (PZ_REFL_DIET) {                                 // reflected_layer, PZ_REFL_DIET (2)
+        const double w2gp = w2pi * gp, w2gmc = PLAIN ? 0.0 : w2pi * gmc;
+        RC_FOR_K Trd[kk] = st[kk].T * rd[kk];
+        RC_FOR_K X[kk] = w2gp * B0[kk];
+        RC_FOR_K Y[kk] = PLAIN ? 0.0 : w2gmc * g[kk].u1;
+        RC_FOR_K vp[kk] = ((Trd[kk] * (PLAIN ? X[kk] : X[kk] + Y[kk])) * lp1[kk]) * ee[kk];
+        RC_FOR_K vn[kk] = ((Trd[kk] * (PLAIN ? X[kk] : X[kk] - Y[kk])) * lm1[kk]) * ff[kk];
+    } else {
+        RC_FOR_K X[kk] = gp * B0[kk];
+        RC_FOR_K Tw[kk] = st[kk].T * w2pi;
+        RC_FOR_K Trd[kk] = Tw[kk] * rd[kk];
+        RC_FOR_K vp[kk] = (Trd[kk] * lp1[kk]) * ((PLAIN ? X[kk] : X[kk] + Y[kk]) * ee[kk]);
+        RC_FOR_K vn[kk] = (Trd[kk] * lm1[kk]) * ((PLAIN ? X[kk] : X[kk] - Y[kk]) * ff[kk]);
+    }
     if (!first && eo_ok) {
         RC_FOR_K eo[kk] = st[kk].EO;
     } else {
@@ -207,8 +233,12 @@ __device__ __forceinline__ void rc_angle(const double (*in)[64], const double (*
     }
     if (!last) RC_FOR_K st[kk].EO = eo[kk] * e0o[kk];
     double s1[NA], S0[NA], kap[NA], Tn[NA], delta_n[NA];
-    RC_FOR_K s1[kk] = (ssa_h * (ZP ? 1.0 : g[kk].wq2)) * (eo[kk] * t1[kk]);
-    RC_FOR_K S0[kk] = fma((w2pi * (ZP ? 1.0 : g[kk].wq2)) * fx[kk], Aqq[kk] * t2[kk], s1[kk]);
+    if (PZ_REFL_DIET && ZP && nocld && same_dt) {       // reflected_layer, PZ_REFL_DIET (3)
+        RC_FOR_K S0[kk] = fma(w2A0, B0[kk] * fx[kk], ssa_h * eo[kk]) * t2[kk];
+    } else {
+        RC_FOR_K s1[kk] = (ssa_h * (ZP ? 1.0 : g[kk].wq2)) * (eo[kk] * t1[kk]);
+        RC_FOR_K S0[kk] = fma((w2pi * (ZP ? 1.0 : g[kk].wq2)) * fx[kk], Aqq[kk] * t2[kk], s1[kk]);
+    }
     RC_FOR_K kap[kk] = fma(st[kk].T, S0[kk], st[kk].KAPPA);
     RC_FOR_K Tn[kk] = st[kk].T * et[kk];
     if (last) {                                            // xint[n] = flux_zero/pi (fluxes.py:1266-1270)
@@ -275,10 +305,15 @@ __device__ __forceinline__ void rc_shared(const ReflectedArgs &a, const double (
             ps = p_single<false>(3, in[RW_CBO][lane], in[RW_GCOS2][lane], fc, fr, cos_theta, a.frac_a, a.frac_b, 2.0,
                                  a.constant_back, a.constant_forward);
     }
-    const double gam = (g1 - lam) * frcp(g2);
     const double E = fmin(lam * dt, clip);
     const double EP = fexp2(E * -NEG_LOG2E, K);
+#if PZ_REFL_DIET
+    const double r_ge = frcp(g2 * EP);                 // reflected_layer, PZ_REFL_DIET (5)
+    const double gam = (g1 - lam) * (r_ge * EP), EM = r_ge * g2;
+#else
+    const double gam = (g1 - lam) * frcp(g2);
     const double EM = frcp(EP);
+#endif
     const double ssa_h = (w0o * F * (0.125 / PI)) * ps;
     const double w2pi = w0 * (0.5 / PI);
     const double Fw0h = (0.5 * F) * w0;
@@ -367,12 +402,23 @@ __device__ __forceinline__ void rc_shared_plain_round(const double (*in)[RW_NV][
     RC_FOR_J bb[j] = g2[j] * g2[j];
     RC_FOR_J dd[j] = aa[j] - bb[j];
     fsqrt_n<NL>(dd, lam);
-    frcp_n<NL>(g2, ig2);
-    RC_FOR_J gam[j] = (g1[j] - lam[j]) * ig2[j];
     RC_FOR_J E[j] = fmin(lam[j] * dt[j], 35.0);                 // fluxes.py:1174
     RC_FOR_J targ[j] = E[j] * -NEG_LOG2E;
     fexp2_n<NL>(targ, K, EP);
+#if PZ_REFL_DIET
+    {                                                           // reflected_layer, PZ_REFL_DIET (5)
+        double pge[NL], rge[NL];
+        RC_FOR_J pge[j] = g2[j] * EP[j];
+        frcp_n<NL>(pge, rge);
+        RC_FOR_J ig2[j] = rge[j] * EP[j];
+        RC_FOR_J EM[j] = rge[j] * g2[j];
+    }
+    RC_FOR_J gam[j] = (g1[j] - lam[j]) * ig2[j];
+#else
+    frcp_n<NL>(g2, ig2);
+    RC_FOR_J gam[j] = (g1[j] - lam[j]) * ig2[j];
     frcp_n<NL>(EP, EM);
+#endif
     double ps[NL], ssa_h[NL], w2pi[NL], Fw0h[NL], A0[NL];
     RC_FOR_J ps[j] = fr[j] * (0.75 * fma(cos_theta, cos_theta, 1.0));
     RC_FOR_J ssa_h[j] = (w0o[j] * F * (0.125 / PI)) * ps[j];
