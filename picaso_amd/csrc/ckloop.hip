@@ -225,34 +225,4 @@ int picaso_get_thermal_3d_ck_dev(picaso_ctx *ctx, int nlevel, const double *wno,
     return 0;
 }
 
-int picaso_compute_opacity_facet_major_ck_dev(picaso_ctx *ctx, int nfacets, int nlayer, int nwno, int ngauss,
-                                              const double *taugas, const double *tauray, const double *taucld,
-                                              const double *w0_cld, const double *g0_cld, long cloud_stride,
-                                              const double *raman_factor, int raman_rows, double raman_const,
-                                              int test_mode, int delta_eddington, int stream, double *dtau, double *tau,
-                                              double *w0, double *cosb, double *ftau_cld, double *ftau_ray, double *gcos2,
-                                              double *dtau_og, double *tau_og, double *w0_og, double *cosb_og,
-                                              double *w0_no_raman, double *f_deltaM)
-{
-    if (!ctx) return fail(nullptr, "null context");
-    if (nfacets < 1 || nlayer < 1 || nwno < 1) return fail(ctx, "compute_opacity_facet_major_ck: bad sizes");
-    if (!taugas || !tauray) return fail(ctx, "compute_opacity_facet_major_ck: taugas and tauray are required");
-    if (cloud_stride < 0) return fail(ctx, "compute_opacity_facet_major_ck: cloud_stride must be >= 0");
-    const size_t lay = (size_t)nlayer * nwno * ngauss, lev = (size_t)(nlayer + 1) * nwno * ngauss;
-    const size_t ray = (size_t)nlayer * nwno;
-    auto at = [](double *p, size_t off) { return p ? p + off : nullptr; };
-    auto cat = [](const double *p, size_t off) { return p ? p + off : nullptr; };
-    for (int f = 0; f < nfacets; ++f) {                                   // justdoit.py:437-471, one facet's columns each
-        const size_t fl = lay * f, fv = lev * f, fc = (size_t)cloud_stride * f;
-        PZ_TRY(picaso_compute_opacity_ck_dev(ctx, nlayer, nwno, ngauss, taugas + fl, tauray + ray * f, cat(taucld, fc),
-                                             cat(w0_cld, fc), cat(g0_cld, fc),
-                                             raman_rows ? cat(raman_factor, ray * f) : raman_factor, raman_rows,
-                                             raman_const, test_mode, delta_eddington, stream, at(dtau, fl), at(tau, fv),
-                                             at(w0, fl), at(cosb, fl), at(ftau_cld, fl), at(ftau_ray, fl), at(gcos2, fl),
-                                             at(dtau_og, fl), at(tau_og, fv), at(w0_og, fl), at(cosb_og, fl),
-                                             at(w0_no_raman, fl), at(f_deltaM, fl)));
-    }
-    return 0;
-}
-
 }  // extern "C"
