@@ -998,8 +998,8 @@ def compute_opacity_facets(atms, opacityclass, numg, numt, stream=2, delta_eddin
                 rf3.append(raman_plane_host(one, opa, raman))
         if d_rf3 is not None:
             tl = np.broadcast_to(np.asarray(atm_f.layer["temperature"], dtype=float), (nlayer, nfac))
-            for f in range(nfac):
-                raman_oklopcic_device(opa, tl[:, f], d_rf3.row_block(f))
+            # all facets in one launch: the tall atmosphere's nfac * nlayer layer temperatures, facet-major
+            raman_oklopcic_device(opa, np.ascontiguousarray(tl.T).ravel(), d_rf3)
         atms = None
     for g in range(numg if atms is not None else 0):
         for t in range(numt):
@@ -1222,8 +1222,7 @@ def compute_opacity_facet_major(atm_f, opacityclass, numg, numt, stream=2, delta
     elif raman == 0:
         d_rf = DeviceArray((nfac, nlayer, nwno), ctx)
         tl = np.broadcast_to(np.asarray(atm_f.layer["temperature"], dtype=float), (nlayer, nfac))
-        for f in range(nfac):
-            raman_oklopcic_device(opa, tl[:, f], d_rf.row_block(f))
+        raman_oklopcic_device(opa, np.ascontiguousarray(tl.T).ravel(), d_rf)      # all facets in one launch
     out = {k: DeviceArray((nfac, nlayer, nwno), ctx) for k in OUT_NAMES if k in want}
     per_layer = len(mol_tabs) * (16 + 32 + 8) + len(cont_tabs) * (4 + 8) + len(ray_tabs) * 8 + 8
     fchunk = max(1, int((3600 * 1024) // (per_layer * nlayer)))         # per-layer tables of a launch: one 4 MB slot
@@ -1343,8 +1342,7 @@ def compute_opacity_facet_major_ck(atm_f, opacityclass, numg, numt, stream=2, de
     elif raman == 0:
         d_rf, rf_rows = DeviceArray((nfac, nlayer, nwno), ctx), nlayer
         tl = np.broadcast_to(np.asarray(atm_f.layer["temperature"], dtype=float).reshape(nlayer, -1), (nlayer, nfac))
-        for f in range(nfac):
-            raman_oklopcic_device(opa, tl[:, f], d_rf.row_block(f))
+        raman_oklopcic_device(opa, np.ascontiguousarray(tl.T).ravel(), d_rf)      # all facets in one launch
     d_cld = (None, None, None, 0, None)
     if clouds_3d is not None:
         d_cld = _cloud_planes_facet_major(clouds_3d, opa, nlayer, nfac, ctx)
