@@ -113,6 +113,11 @@ static int enqueue_block_3d(int nblocks, picaso_block *blocks, const picaso_spec
         return fail(k.ctx, "toon_spectrum_blocks: 3-D blocks leave tau / tau_og out (running sums down ONE facet's layers)");
     if (k.cld_opd || k.cld_host_opd)
         return fail(k.ctx, "toon_spectrum_blocks: 3-D blocks take cloud tables on their own grid (cld_tab_*) or none");
+    if (j.do_reflected && (!k.refl_planes[0] || !k.refl_planes[2] || !k.xint || !k.albedo || !k.surf_reflect || !k.F0PI))
+        return fail(k.ctx, "toon_spectrum_blocks: block %d: the reflected leg needs dtau, w0, xint, albedo, surf_reflect, F0PI", b);
+    if (j.do_thermal && (!k.th_dtau || !k.th_w0 || !k.flux || !k.disk || !k.wno || !k.surf_reflect || !j.tlevel || !j.plevel))
+        return fail(k.ctx, "toon_spectrum_blocks: block %d: the thermal leg needs dtau, w0, flux, disk, wno, surf_reflect and "
+                           "the level tables", b);
     picaso_ctx *tctx = k.tctx ? k.tctx : k.ctx;
     PZ_TRY(picaso_gas_compute_opacity_dev(k.ctx, nfac * j.nlayer, k.nwno, j.mol_mode, j.nmol, k.mol_tabs, j.mol_rows,
                                           j.mol_wts, j.mol_fac, j.cont_interp, j.ncont, k.cont_tabs, j.cont_rows,

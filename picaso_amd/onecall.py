@@ -133,6 +133,34 @@ def _cloud_inputs(atm, opa, tables, nlayer, nwno, opt, hold):
     return None, None, hcld
 
 
+def _call_state(inp, opa, subs, opt, atm, raman, do_r, do_t, table, ng, nt):
+    """What ``_fill_block`` needs of one call, for 1-D and 3-D alike: stellar inputs, the full-grid result arrays (one
+    element longer when the spectrum-wide integrals arrive with them), the list that keeps per-call device objects alive."""
+    nwno = opa.nwno
+    nostar = inp["star"]["database"] == "nostar"
+    F0PI = _ones(opa, nwno) if nostar else inp["star"]["relative_flux"]
+    stellar = getattr(opa, "unshifted_stellar_spec", None)
+    if stellar is None:
+        stellar = F0PI
+    integrals = len(subs) == 1 and nwno > 1 and not opt.host_integrals
+    full = {}
+    if do_r:
+        full["albedo"] = np.empty(nwno + 1 if integrals else nwno)
+    if do_t:
+        full["thermal"] = np.empty(nwno + 1 if integrals else nwno)
+    return dict(inp=inp, opa=opa, nwno=nwno, wno=opa.wno, hold=[], atm=atm, nostar=nostar, F0PI=F0PI, stellar=stellar,
+                nblocks=len(subs), raman=raman, clouds=(None, None, None), do_r=do_r, do_t=do_t,
+                overlap=do_r and do_t and opt.overlap_legs, seen_dev={}, table=table, ng=ng, nt=nt, full=full,
+                integrals=integrals, denom=None)
+
+
+def _prepared(c, job, keep, signature):
+    """The dictionary ``prepare`` / ``prepare_3d`` return (``finish`` reads it; ``keep`` holds what the job points into)."""
+    return dict(table=c["table"], job=job, keep=(keep, c["hold"]), do_r=c["do_r"], do_t=c["do_t"], full=c["full"],
+                nwno=c["nwno"], integrals=c["integrals"], denom=c["denom"] if (c["integrals"] and c["do_r"]) else None,
+                wno=c["wno"], stellar=c["stellar"], inp=c["inp"], atm=c["atm"], opa=c["opa"], signature=signature)
+
+
 def _fill_block(k, sub, lo, hi, c):
     """The per-call pointers of one wavelength block ``k`` (a ``driver.Block``): resident per-wavelength vectors, the
     Raman factor, the cloud inputs, the thermal workspace on the block's second stream, where the results go."""
@@ -253,21 +281,8 @@ def prepare(bundle, opa, subs, calculation, opt, slot=None):
         table = cache[key] = drv.BlockTable(subs, nlayer, ng, nt, plan["molecules"], plan["cia_pairs"], factors[2], linear,
                                             want, lean, not cloud_free and not tables, do_r, do_t, _constant_planes, derive,
                                             sh=is_sh)
-    nostar = inp["star"]["database"] == "nostar"
-    F0PI = _ones(opa, nwno) if nostar else inp["star"]["relative_flux"]
-    stellar = getattr(opa, "unshifted_stellar_spec", None)
-    if stellar is None:
-        stellar = F0PI
-    integrals = len(subs) == 1 and nwno > 1 and not opt.host_integrals
-    hold, full = [], {}
-    if do_r:
-        full["albedo"] = np.empty(nwno + 1 if integrals else nwno)
-    if do_t:
-        full["thermal"] = np.empty(nwno + 1 if integrals else nwno)
-    c = dict(nwno=nwno, wno=wno, hold=hold, atm=atm, nostar=nostar, F0PI=F0PI, stellar=stellar, nblocks=len(subs),
-             raman=raman, clouds=_cloud_inputs(atm, opa, tables, nlayer, nwno, opt, hold), do_r=do_r, do_t=do_t,
-             overlap=do_r and do_t and opt.overlap_legs, seen_dev={}, table=table, ng=ng, nt=nt, full=full,
-             integrals=integrals, denom=None)
+    c = _call_state(inp, opa, subs, opt, atm, raman, do_r, do_t, table, ng, nt)
+    c["clouds"] = _cloud_inputs(atm, opa, tables, nlayer, nwno, opt, c["hold"])
     for b, (lo, hi, sub) in enumerate(subs):
         c["b"] = b
         _fill_block(table.blocks[b], sub, lo, hi, c)
@@ -277,9 +292,7 @@ def prepare(bundle, opa, subs, calculation, opt, slot=None):
                              toon["toon_coefficients"], frac_a, frac_b, frac_c, common["TTHG_params"]["constant_back"],
                              common["TTHG_params"]["constant_forward"], 0.0, atm.level["temperature"], atm.level["pressure"],
                              atm.hard_surface, sh=inp["approx"]["rt_params"]["SH"] if is_sh else None, sh_top=sh_top)
-    return dict(table=table, job=job, keep=(keep, hold), do_r=do_r, do_t=do_t, full=full, nwno=nwno, integrals=integrals,
-                denom=c["denom"] if (integrals and do_r) else None, wno=wno, stellar=stellar, inp=inp, atm=atm, opa=opa,
-                signature=key[1:-1])
+    return _prepared(c, job, keep, key[1:-1])
 
 
 def _in_scope_3d(inp, opa, legs, opt):
@@ -352,20 +365,8 @@ def prepare_3d(bundle, opa, subs, calculation, opt, slot=None):
             cache.clear()
         table = cache[key] = drv.BlockTable(subs, nlayer, ng, nt, plan["molecules"], plan["cia_pairs"], factors[2], linear,
                                             want, False, False, do_r, do_t, _constant_planes, facets=nfac, th3=th3)
-    nostar = inp["star"]["database"] == "nostar"
-    F0PI = _ones(opa, nwno) if nostar else inp["star"]["relative_flux"]
-    stellar = getattr(opa, "unshifted_stellar_spec", None)
-    if stellar is None:
-        stellar = F0PI
-    integrals = len(subs) == 1 and nwno > 1 and not opt.host_integrals
-    hold, full = [], {}
-    if do_r:
-        full["albedo"] = np.empty(nwno + 1 if integrals else nwno)
-    if do_t:
-        full["thermal"] = np.empty(nwno + 1 if integrals else nwno)
-    c = dict(nwno=nwno, wno=wno, hold=hold, atm=atm, nostar=nostar, F0PI=F0PI, stellar=stellar, nblocks=len(subs),
-             raman=raman, clouds=(None, None, None), do_r=do_r, do_t=do_t, overlap=do_r and do_t and opt.overlap_legs,
-             seen_dev={}, table=table, ng=ng, nt=nt, full=full, integrals=integrals, denom=None)
+    c = _call_state(inp, opa, subs, opt, atm, raman, do_r, do_t, table, ng, nt)
+    hold = c["hold"]
     for b, (lo, hi, sub) in enumerate(subs):
         c["b"] = b
         k = table.blocks[b]
@@ -382,9 +383,7 @@ def prepare_3d(bundle, opa, subs, calculation, opt, slot=None):
                              toon["single_phase"], toon["multi_phase"], toon["toon_coefficients"], frac_a, frac_b, frac_c,
                              common["TTHG_params"]["constant_back"], common["TTHG_params"]["constant_forward"], 0.0, tl, pv,
                              atm.hard_surface, nfacets=nfac)
-    return dict(table=table, job=job, keep=(keep, hold, tabs_sig), do_r=do_r, do_t=do_t, full=full, nwno=nwno,
-                integrals=integrals, denom=c["denom"] if (integrals and do_r) else None, wno=wno, stellar=stellar, inp=inp,
-                atm=atm, opa=opa, signature=key[2:-1])
+    return _prepared(c, job, (keep, tabs_sig), key[2:-1])
 
 
 def finish(p):
