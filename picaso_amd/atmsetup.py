@@ -237,8 +237,10 @@ class ATMSETUP:
             if np.ndim(zi):
                 # facet form: libm pow() per element, which is what `z[i] ** 2` is for the numpy scalar of
                 # the 1-D path (and of the reference); numpy squares ARRAYS as x*x, one ulp off now and then
-                import math
-                return c.G * planet.mass / np.array([math.pow(v, 2.0) for v in zi])
+                # (as numpy scalars, not math.pow: a runaway profile overflows to inf with a warning, as in the 1-D path,
+                # instead of raising)
+                with np.errstate(over="ignore"):
+                    return c.G * planet.mass / np.array([np.float64(v) ** 2 for v in zi])
             return c.G * planet.mass / zi ** 2
 
         below = np.unique(np.where(plevel > p_reference)[0])

@@ -239,7 +239,7 @@ def setup_facets(inp, opa, wno, prof_f):
             or getattr(opa, "on_fly", False) or inp["atmosphere"].get("exclude_mol", 1) != 1):
         return None
     radius, mass = inp["planet"]["radius"], inp["planet"]["mass"]
-    if not isinstance(radius, float) or radius == radius:          # facet form with a planet radius: the mirror (pow per element)
+    if not isinstance(radius, float) or (radius == radius and not isinstance(mass, float)):
         return None
     cols = tuple(prof_f.keys())
     cache = opa.__dict__.setdefault("_fast_setup", {})
@@ -292,7 +292,9 @@ def setup_facets(inp, opa, wno, prof_f):
     a = SetupArgs.from_buffer_copy(lay.template)
     a.pressure_bar, a.temperature, a.mix = _addr(pbar), _addr(T), ctypes.addressof(mixp)
     a.gravity, a.radius, a.p_reference_bar = float(gravity), radius, float(inp["approx"]["p_reference"])
-    a.GM = 0.0
+    # a planet radius: gravity G M / z^2 level by level with libm's pow, facet by facet -- what the mirror's facet form does
+    # element by element (atmsetup.get_altitude: math.pow per facet) and the reference's per-facet ATMSETUP with its scalars
+    a.GM = c.G * mass if radius == radius else 0.0
     a.coef1_den = 1.01325 ** 2 * (gravity / 100.0)
     if pg.addr is None:
         pg.addr = (_addr(pg.log_pratio), _addr(pg.log10_player), _addr(pg.cube_hi), _addr(pg.cube_lo))

@@ -137,16 +137,18 @@ def test_setup_struct_layout():
     assert lib.picaso_host_setup_abi() == ctypes.sizeof(fastsetup.SetupArgs)
 
 
+@pytest.mark.parametrize("planet", [False, True])
 @pytest.mark.parametrize("seed", range(8))
-def test_fast_setup_facets_bits_of_the_mirror(opa, monkeypatch, seed):
+def test_fast_setup_facets_bits_of_the_mirror(opa, monkeypatch, seed, planet):
     """The facet form of the 3-D path: (nlevel, nfacets) temperature columns, mixing ratios shared or per facet -- the
-    facet-form ATMSETUP and the tall plan / coefficients of optics.gas_stage_facets, array by array."""
+    facet-form ATMSETUP and the tall plan / coefficients of optics.gas_stage_facets, array by array; with constant gravity
+    and (round 5) with a planet radius and mass, gravity G M / z^2 level by level in every facet."""
     import types
     rng = np.random.default_rng(300 + seed)
     wno = opa._wno_test
     nlevel, nfac = int(rng.choice([3, 10, 31])), int(rng.choice([1, 4, 9]))
     cols = ["H2", "He", "H2O", "CH4", "Na"][:int(rng.integers(3, 6))]
-    case = _case(rng, nlevel, float(rng.choice([1.0, 1e-9, 1e5, 0.03])), cols)
+    case = _case(rng, nlevel, float(rng.choice([1.0, 1e-9, 1e5, 0.03])), cols, planet=planet)
     inp = case.inputs
     base = inp["atmosphere"]["profile"]
     prof_f = {"pressure": np.asarray(base["pressure"]).reshape(nlevel, 1),
