@@ -31,14 +31,14 @@ def _host_stamp():
 def build(force=False):
     so = os.path.join(_HERE, "libpicaso_oracle.so")
     stamp = so + ".host"
-    srcs = [os.path.join(_HERE, f) for f in ("picaso_oracle.c", "sh_oracle.c", "mix_oracle.c", "Makefile")]
+    srcs = [os.path.join(_HERE, f) for f in ("picaso_oracle.c", "sh_oracle.c", "sh_oracle_x80.c", "mix_oracle.c", "Makefile")]
     here = _host_stamp()
     try:
         with open(stamp) as fh:
             built_on = fh.read().strip()
     except OSError:
         built_on = ""
-    if force or not os.path.exists(so) or built_on != here or \
+    if force or not os.path.exists(so) or not os.path.exists(os.path.join(_HERE, "libsh_oracle_x80.so")) or built_on != here or \
             os.path.getmtime(so) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "all"])
         with open(stamp, "w") as fh:
@@ -70,6 +70,18 @@ def lib_x80():
     return _LIB_X80
 
 
+_LIB_SH_X80 = None
+
+
+def lib_sh_x80():
+    """The spherical-harmonics restatement built with ``double = long double`` (sh_oracle_x80.c)."""
+    global _LIB_SH_X80
+    if _LIB_SH_X80 is None:
+        build()
+        _LIB_SH_X80 = ctypes.CDLL(os.path.join(_HERE, "libsh_oracle_x80.so"))
+    return _LIB_SH_X80
+
+
 class _Prec:
     """Array / scalar marshalling of one build of the restatement."""
 
@@ -98,6 +110,7 @@ class _Prec:
 
 _F64 = _Prec(np.float64, ctypes.c_double, lib)
 _X80 = _Prec(np.longdouble, ctypes.c_longdouble, lib_x80)
+_X80_SH = _Prec(np.longdouble, ctypes.c_longdouble, lib_sh_x80)
 
 
 def _a(x, shape=None):
@@ -230,27 +243,30 @@ def get_reflected_SH(nlevel, nwno, numg, numt, dtau, tau, w0, cosb, ftau_cld, ft
                      dtau_og, tau_og, w0_og, cosb_og, surf_reflect, ubar0, ubar1, cos_theta, F0PI,
                      w_single_form, w_multi_form, psingle_form, w_single_rayleigh, w_multi_rayleigh,
                      psingle_rayleigh, frac_a, frac_b, frac_c, constant_back, constant_forward,
-                     stream, b_top=0, flx=0, single_form=0):
+                     stream, b_top=0, flx=0, single_form=0, x80=False):
     """Signature of reference ``fluxes.get_reflected_SH`` (fluxes.py:2675-2679).  Like the
     reference, the TTHG branch multiplies ``f_deltaM`` IN PLACE once per angle (fluxes.py:2823-2824)
-    -- the caller's array is modified when it is a float64 C-contiguous array."""
-    keep = [_a(p) for p in (dtau, tau, w0, cosb, ftau_cld, ftau_ray)]
-    fd = f_deltaM if (isinstance(f_deltaM, np.ndarray) and f_deltaM.dtype == np.float64
-                      and f_deltaM.flags.c_contiguous) else _a(f_deltaM).copy()
-    og = [_a(p) for p in (dtau_og, tau_og, w0_og, cosb_og)]
-    sr, f0 = _per_wave(surf_reflect, nwno), _per_wave(F0PI, nwno)
-    u0, u1 = _a(ubar0), _a(ubar1)
-    xint = np.zeros((numg, numt, nwno))
-    flux = np.zeros((numg, numt, stream * nlevel, nwno))
-    ci, cd = ctypes.c_int, ctypes.c_double
-    rc = lib().orc_reflected_SH(
-        ci(nlevel), ci(nwno), ci(numg), ci(numt), *[_p(k) for k in keep], _p(fd), *[_p(k) for k in og],
-        _p(sr), _p(u0), _p(u1), cd(cos_theta), _p(f0), ci(w_single_form), ci(w_multi_form),
+    -- the caller's array is modified when it is a float64 C-contiguous array.  ``x80=True``: the same source in x87
+    extended precision (``sh_oracle_x80.c``; ``f_deltaM`` is then never written back): ``|fp64 - x80|`` is how far the
+    reference's own fp64 rounding moves an element."""
+    P = _X80_SH if x80 else _F64
+    keep = [P.a(p) for p in (dtau, tau, w0, cosb, ftau_cld, ftau_ray)]
+    fd = f_deltaM if (not x80 and isinstance(f_deltaM, np.ndarray) and f_deltaM.dtype == np.float64
+                      and f_deltaM.flags.c_contiguous) else P.a(f_deltaM).copy()
+    og = [P.a(p) for p in (dtau_og, tau_og, w0_og, cosb_og)]
+    sr, f0 = P.per_wave(surf_reflect, nwno), P.per_wave(F0PI, nwno)
+    u0, u1 = P.a(ubar0), P.a(ubar1)
+    xint = P.zeros((numg, numt, nwno))
+    flux = P.zeros((numg, numt, stream * nlevel, nwno))
+    ci, cd, p = ctypes.c_int, P.cs, P.p
+    rc = P.lib().orc_reflected_SH(
+        ci(nlevel), ci(nwno), ci(numg), ci(numt), *[p(k) for k in keep], p(fd), *[p(k) for k in og],
+        p(sr), p(u0), p(u1), cd(cos_theta), p(f0), ci(w_single_form), ci(w_multi_form),
         ci(psingle_form), ci(w_single_rayleigh), ci(w_multi_rayleigh), ci(psingle_rayleigh),
         cd(frac_a), cd(frac_b), cd(frac_c), cd(constant_back), cd(constant_forward), ci(stream),
-        cd(b_top), ci(single_form), _p(xint), _p(flux) if flx else None)
+        cd(b_top), ci(single_form), p(xint), p(flux) if flx else None)
     _check(rc, "reflected_SH")
-    return xint, flux
+    return P.out(xint), P.out(flux)
 
 
 def get_thermal_SH(nlevel, wno, nwno, numg, numt, tlevel, dtau, tau, w0, cosb, dtau_og, tau_og,

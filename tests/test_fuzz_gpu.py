@@ -166,8 +166,25 @@ def test_fuzz_spherical_harmonics(oracle, block):
                            ct, np.ones(nwno), *opts, *TTHG, stream)
         xg, _ = fluxes.get_reflected_SH(*args(sc["f_deltaM"].copy()), b_top=0.0, flx=0, single_form=sform)
         xo, _ = oracle.get_reflected_SH(*args(sc["f_deltaM"].copy()), b_top=0.0, flx=0, single_form=sform)
-        # observed max over the four blocks (round 5): 1.3e-12
-        assert rel_err(xg, xo, 1e-4 * np.abs(xo).max()) < 1e-9, (block, it, nlayer, nwno, ng, nt, stream, opts, sform)
+        # observed max over the four blocks (round 5): 1.3e-12; one draw of offsets 1-300 at 2.3e-8 (see _sh_close)
+        _sh_close(oracle, xg, xo, args(sc["f_deltaM"].copy()), dict(b_top=0.0, flx=0, single_form=sform),
+                  float(sc["w0"].max()), (block, it, nlayer, nwno, ng, nt, stream, opts, sform))
+
+
+def _sh_close(oracle, xg, xo, args, kwargs, w0max, tag, tol=1e-9, loose=1e-7):
+    """``xg`` (kernel) against ``xo`` (the fp64 oracle) at ``tol``.  Where that fails the column set must be one the
+    reference's own formulas are ill-conditioned on -- nearly conservative scattering, w0 > 0.999: the SH4 modes of
+    fluxes.py:3388-3434 lose digits, and the fp64 oracle itself sits up to 1.7e-8 from the x87 extended-precision evaluation
+    of the same restatement (oracle/sh_oracle_x80.c) -- and there the kernel is held to ``loose`` against the x87 value.
+    Seed offsets 0-300 (round 5): 17 of ~11 000 draws beyond 1e-9, all with max w0 > 0.9994; kernel vs x87 at most 2.5e-8
+    (1.5 - 22 x the fp64 oracle's own distance), well inside BASELINE's 1e-6."""
+    floor = 1e-4 * np.abs(xo).max()
+    if rel_err(xg, xo, floor) < tol:
+        return
+    xx, _ = oracle.get_reflected_SH(*args, **kwargs, x80=True)
+    e_ref, e_k = rel_err(xo, xx, floor), rel_err(xg, xx, floor)
+    assert w0max > 0.999 and e_k < loose, (tag, "max w0 %.6f, kernel vs x87 %.2e, fp64 oracle vs x87 %.2e"
+                                          % (w0max, e_k, e_ref))
 
 
 @pytest.mark.gpu
@@ -194,8 +211,9 @@ def test_fuzz_sh4_cloud_free_form(oracle, block):
         xg, _ = fluxes.get_reflected_SH(nlayer + 1, nwno, ng, nt, *lean, *tail)
         xo, _ = oracle.get_reflected_SH(nlayer + 1, nwno, ng, nt, *[np.array(a) for a in full], *tail)
         assert np.isfinite(xg).all()
-        # observed max over the four blocks (round 5): 3.4e-11
-        assert rel_err(xg, xo, 1e-4 * np.abs(xo).max()) < 1e-9, (block, it, nlayer, nwno, ng, nt, b_top)
+        # observed max over the four blocks (round 5): 3.4e-11; nearly conservative draws of the soak: see _sh_close
+        _sh_close(oracle, xg, xo, (nlayer + 1, nwno, ng, nt, *[np.array(a) for a in full], *tail), {},
+                  float(sc["w0"].max()), (block, it, nlayer, nwno, ng, nt, b_top))
 
 
 def _facet_planes(rng, nlayer, nwno, ng, nt, seed):
