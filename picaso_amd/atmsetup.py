@@ -214,20 +214,21 @@ class ATMSETUP:
         dz = np.zeros(shape)
         gravity = np.zeros(shape)
         n = len(plevel)
-        if constant_gravity and n > 1 and np.ndim(tlevel) == 1 and np.all(np.diff(plevel) > 0):
-            # same arithmetic as the level loops below, element-wise (gravity does not depend on z;
-            # the running sums are sequential like the loops): 64 facets x 91 levels per 3-D spectrum
+        if constant_gravity and n > 1 and np.all(np.diff(np.reshape(plevel, (n, -1))[:, 0]) > 0):
+            # same arithmetic as the level loops below, element-wise (gravity does not depend on z; the running sums
+            # are sequential like the loops: cumsum along the level axis).  1-D, or the facet form -- (nlevel, nfacets)
+            # temperatures over a shared (nlevel, 1) pressure column: 64 facets x 91 levels per 3-D spectrum
             g = planet.gravity
-            iref = int(np.argmax(plevel >= p_reference))
-            scale_h = c.k_b * tlevel / (mmw * g)
+            iref = int(np.argmax(np.reshape(plevel, (n, -1))[:, 0] >= p_reference))
+            scale_h = np.broadcast_to(c.k_b * tlevel / (mmw * g), shape)
             if iref < n - 1:                                  # inwards from the reference level
                 gravity[iref:n - 1] = g
                 dz[iref:n - 1] = scale_h[iref:n - 1] * np.log(plevel[iref + 1:] / plevel[iref:n - 1])
-                z[iref:] = np.cumsum(np.concatenate(([z[iref]], -dz[iref:n - 1])))
+                z[iref:] = np.cumsum(np.concatenate((z[iref][None], -dz[iref:n - 1]), axis=0), axis=0)
             if iref >= 1:                                     # outwards
                 gravity[1:iref + 1] = g
                 dz[1:iref + 1] = scale_h[1:iref + 1] * np.log(plevel[1:iref + 1] / plevel[0:iref])
-                z[iref::-1] = np.cumsum(np.concatenate(([z[iref]], dz[iref:0:-1])))
+                z[iref::-1] = np.cumsum(np.concatenate((z[iref][None], dz[iref:0:-1]), axis=0), axis=0)
             return self._finish_altitude(z, dz, gravity, lambda i: g, tlevel, mmw)
 
         def g_at(i):

@@ -366,12 +366,14 @@ class RetrieveCKs:
         p_log_grid = np.log10(self.pressures[self.pressures > 0])
         t_inv_grid = 1 / self.temps
 
-        def last_true(mask):        # last grid index satisfying the condition, 0 when none does
-            return np.where(mask, np.arange(mask.shape[1])[None, :], -1).max(axis=1).clip(min=0)
-        t_low = last_true(t_inv_grid[None, :] > t_inv[:, None])                  # optics.py:1101-1113
+        # last grid index satisfying the condition, 0 when none does (optics.py:1101-1113, 1124-1141).  Both grids are
+        # strictly monotonic (np.unique in __init__), so "the last index with grid > x" / "<= x" is a count: a binary
+        # search instead of an (nlayer, ngrid) mask -- nlayer is nfacets * nlayer for the tall atmosphere of a 3-D spectrum
+        asc = t_inv_grid[::-1]                                                   # 1/T of ascending temperatures: descending
+        t_low = (len(asc) - np.searchsorted(asc, t_inv, side="right") - 1).clip(min=0)      # last index with grid > 1/T
         t_low[t_low == (len(t_inv_grid) - 1)] = len(t_inv_grid) - 2
         t_hi = t_low + 1
-        p_low = last_true(p_log_grid[None, :] <= p_log[:, None])                 # optics.py:1124-1141
+        p_low = (np.searchsorted(p_log_grid, p_log, side="right") - 1).clip(min=0)          # last index with grid <= log10 P
         p_low = np.minimum(p_low, self.nc_p[t_hi] - 3)
         p_hi = p_low + 1
         t_i = (t_inv - t_inv_grid[t_low]) / (t_inv_grid[t_hi] - t_inv_grid[t_low])
@@ -419,7 +421,7 @@ class RetrieveCKs:
         cia_rows = np.zeros((nlayer, 2), dtype=np.int32)
         cia_wts = np.zeros((nlayer, 2))
         if cia_pairs:
-            lo = np.where(st[None, :] <= tlayer[:, None], np.arange(len(st))[None, :], -1).max(axis=1)
+            lo = np.searchsorted(st, tlayer, side="right") - 1      # last CIA temperature <= T_layer (st is sorted, unique)
             lo = np.clip(lo, 0, len(st) - 2)              # below the grid: first pair; at/above its top: last pair
             ti = (1 / tlayer - 1 / st[lo]) / (1 / st[lo + 1] - 1 / st[lo])
             cia_rows = np.stack([lo, lo + 1], axis=1).astype(np.int32)

@@ -48,3 +48,14 @@ if os.environ.get("PROFILE", "1") == "1":
         c3.spectrum(opk, calculation=calc, dimension="3d")
     pr.disable()
     pstats.Stats(pr).sort_stats("tottime").print_stats(28)
+if os.environ.get("PHASES"):
+    phases = list(2 * np.pi * (np.arange(8) + 0.5) / 8)
+    pc = jdi.inputs()
+    pc.phase_curve_geometry("thermal", phases, num_gangle=8, num_tangle=8)
+    pc.gravity(gravity=2500.0)
+    pc.atmosphere_4d([dict(prof, temperature=prof["temperature"][:, None, None] * (pert[None] + 0.01 * k)) for k in range(8)])
+    pc.approx(raman="none")
+    pc.phase_curve(opk)
+    t0 = time.perf_counter(); pc.phase_curve(opk); print("thermal CK phase curve ms", 1e3 * (time.perf_counter() - t0))
+    pr = cProfile.Profile(); pr.enable(); pc.phase_curve(opk); pr.disable()
+    pstats.Stats(pr).sort_stats("tottime").print_stats(30)
