@@ -78,6 +78,39 @@ def test_driver_blocks_enqueued_from_threads(monkeypatch, cloud):
     _same(want, _case(og, jdi, cloud, True, "none", True).spectrum(opa, calculation="reflected+thermal"))
 
 
+@pytest.mark.parametrize("kind", ["sh", "3d"])
+def test_driver_sh_and_3d_blocks_enqueued_from_threads(monkeypatch, kind):
+    """The threaded enqueue (blocks on different devices; forced here onto the one GPU) for the round-5 block kinds: SH4
+    blocks and 3-D blocks, four blocks, ten times each: the serial loop's bits."""
+    from picaso_amd import justdoit as jdi
+    og = np.load(os.path.join(GOLDEN, "optics.npz"))
+    opa = jdi.opannection(filename_db=DB, query_method="linear")
+    devs = [0, 0, 0, 0]
+
+    def run(devices):
+        if kind == "sh":
+            c = _case(og, jdi, True, True, "none", True)
+            c.approx(raman="none", delta_eddington=True, rt_method="SH", stream=4)
+            return c.spectrum(opa, calculation="reflected+thermal", devices=devices)
+        c = jdi.inputs()
+        c.phase_angle(0.7, num_gangle=3, num_tangle=2)
+        c.gravity(gravity=float(og["in/gravity"]))
+        prof = {"pressure": og["in/plevel_bar"],
+                "temperature": og["in/tlevel"][:, None, None] * (1.0 + 0.02 * np.arange(6).reshape(1, 3, 2))}
+        for m in ("H2", "He", "H2O", "CH4"):
+            prof[m] = og["in/mix/" + m]
+        c.atmosphere_3d(prof)
+        c.approx(raman="none")
+        return c.spectrum(opa, calculation="reflected+thermal", dimension="3d", devices=devices)
+    monkeypatch.setenv("PICASO_AMD_PARALLEL_BLOCKS", "0")
+    want = run(devs)
+    assert len(opa.__dict__["_driver_tables"]) == 1
+    monkeypatch.setenv("PICASO_AMD_PARALLEL_BLOCKS", "1")
+    for _ in range(10):
+        _same(want, run(devs))
+    _same(want, run(None))
+
+
 def test_driver_nearest_query_and_falls_through_where_it_does_not_apply(monkeypatch):
     from picaso_amd import justdoit as jdi
     og = np.load(os.path.join(GOLDEN, "optics.npz"))
