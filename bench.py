@@ -244,7 +244,7 @@ def workload_sh4(ctx, args, lo, hi, seed, nwno_total, scene=None, clear=False, t
                 metric="spectra/sec (%d wave x %d layer SH4 reflected)" % (nwno_total, nlayer))
 
 
-def workload_3d(ctx, args, lo, hi, seed, nwno_total, scene=None):
+def workload_3d(ctx, args, lo, hi, seed, nwno_total, scene=None, single_phase=0):
     """configs[4]: get_reflected_3d on 8x8 facets + compress_disco; facet index fastest in memory.  The 64 facet
     plane sets are generated ON THE DEVICE: every (nlayer, n) base plane is uploaded once and tiled
     over the facets by picaso_broadcast_facets_dev, the optical-depth planes times a per-facet factor -- at the
@@ -269,7 +269,9 @@ def workload_3d(ctx, args, lo, hi, seed, nwno_total, scene=None):
     xint = device.DeviceArray((ng, nt, n), ctx)
 
     def solve(albedo):
-        resident.reflected_3d(ctx, nlevel, n, ng, nt, d, rs, ubar0, ubar1, float(ct), f0, 0, 0, *TTHG, xint,
+        # single_phase = 0 ('cahoy'): the form get_reflected_3d has of its own (fluxes.py:604-615); 3 (TTHG_ray): the
+        # reference's default option, which the library's compile-time default-options 3-D kernel takes
+        resident.reflected_3d(ctx, nlevel, n, ng, nt, d, rs, ubar0, ubar1, float(ct), f0, single_phase, 0, *TTHG, xint,
                               gweight=gw, tweight=tw, albedo=albedo)
 
     def oracle(sl):
@@ -281,7 +283,7 @@ def workload_3d(ctx, args, lo, hi, seed, nwno_total, scene=None):
             a3 = a[:, :, None] * fac[None, None, :] if k in scaled else np.repeat(a[:, :, None], ng * nt, axis=2)
             planes.append(np.ascontiguousarray(a3).reshape(a.shape[0], ns, ng, nt))
         xo = orc.get_reflected_3d(nlevel, base["wno"][sl], ns, ng, nt, *planes, np.zeros(ns), ubar0, ubar1,
-                                  float(ct), np.ones(ns), 0, 0, *TTHG)
+                                  float(ct), np.ones(ns), single_phase, 0, *TTHG)
         xo = xo[0] if isinstance(xo, tuple) else xo
         return orc.compress_disco(ns, float(ct), xo, gw, tw, np.ones(ns))
 
@@ -514,6 +516,10 @@ def companions(ctx, args, wl, res_single, nwno_total):
     ms4 = steady_ms(ctx, lambda: w4["solve"](out4), 40, prewarm_ms=100.0)
     sec["configs[4] 12500-column shard"] = entry(w4, ms4, n_oracle=64, res=out4.to_host())
     del w4
+    w4d = workload_3d(ctx, args, 0, 12500, 3, 12500, single_phase=3)
+    ms4d = steady_ms(ctx, lambda: w4d["solve"](out4), 40, prewarm_ms=100.0)
+    sec["configs[4] 12500-column shard, default phase options (TTHG_ray)"] = entry(w4d, ms4d, n_oracle=64, res=out4.to_host())
+    del w4d
     extra["secondary"] = sec
     extra["secondary_seconds"] = time.perf_counter() - t_all
     return extra
