@@ -897,6 +897,16 @@ typedef struct picaso_setup_args {
     double *mol_fac, *cont_fac, *ray_fac;  /* (nopa | ncont | nray, nlayer) */
     int *pt_opa_index, *n_pt_opa_index;    /* (4 nlayer) sorted unique ptids used, and how many */
     double *scratch;                       /* (3 nlevel) */
+    /* premixed correlated-k tables (reference RetrieveCKs.get_pre_mix_ck / get_continuum, optics.py:1081-1161, 1398-1498):
+     * the table search above is theirs as well (get_mixing_indices, :1200-1278), with these differences, switched on here:
+     * premixed = 1: nopa = 1, rows = p * nt + t of the four neighbours (row_lut is not read, pt_opa_index not written),
+     * mol_fac[0] = colden / mmw (no mixing ratio, optics.py:256-262);
+     * cont_interp = 1: besides the nearest row, the BRACKETING continuum temperatures and the 1/T weight of every layer
+     * (:1411-1428, 1474-1478): cia_rows2 (nlayer, 2) = lo, lo + 1 and cia_wts2 (nlayer, 2) = 1 - ti, ti with lo the last
+     * temperature <= T_layer clipped to [0, ncia_t - 2], ti = (1/T - 1/t_lo) / (1/t_hi - 1/t_lo).  0 / NULL: as before. */
+    int premixed, cont_interp;
+    int *cia_rows2;
+    double *cia_wts2;
 } picaso_setup_args;
 int picaso_host_setup(const picaso_setup_args *args);
 /* the facets of a 3-D spectrum in one call: facet f reads temperature + f t_stride and mix[m] + f mix_stride[m] (0: one

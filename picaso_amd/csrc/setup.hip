@@ -154,6 +154,15 @@ extern "C" int picaso_host_setup(const picaso_setup_args *a)
         const double pi = (p_log - a->p_log_grid[p_lo]) / (a->p_log_grid[p_hi] - a->p_log_grid[p_lo]);
         const long r4[4] = {csum[t_lo] + p_lo, csum[t_hi] + p_lo, csum[t_hi] + p_hi, csum[t_lo] + p_hi};   // ll, hl, hh, lh
         const double w4[4] = {(1 - ti) * (1 - pi), ti * (1 - pi), ti * pi, (1 - ti) * pi};
+        if (a->premixed) {
+            // premixed k-table: row = p * ntemp + t whatever the raggedness of the grid (RetrieveCKs.get_opacities;
+            // reference optics.py:1153-1156), same four terms in the same order
+            const long t4[4] = {t_lo, t_hi, t_hi, t_lo}, p4[4] = {p_lo, p_lo, p_hi, p_hi};
+            for (int q = 0; q < 4; ++q) {
+                a->rows[(size_t)i * 4 + q] = (int)(p4[q] * a->nt + t4[q]);
+                a->wts[(size_t)i * 4 + q] = w4[q];
+            }
+        } else
         for (int q = 0; q < 4; ++q) {
             const long id = 1 + r4[q];
             if (id >= a->nlut || a->row_lut[id] < 0) return 4;                // no table row for this ptid: the mirror raises
@@ -171,6 +180,17 @@ extern "C" int picaso_host_setup(const picaso_setup_args *a)
             if (d < bd) { bd = d; best = j; }
         }
         for (int c = 0; c < std::max(a->ncont, 1); ++c) a->cia_rows[(size_t)c * nl + i] = best;
+        if (a->cont_interp) {
+            // the bracketing pair and its 1/T weight (RetrieveCKs._plan_continuum; reference optics.py:1411-1428, 1474-1478)
+            const double tl = a->layer_temperature[i];
+            long lo = last_le(a->cia_temps, a->ncia_t, tl);
+            lo = std::max(0L, std::min(lo, (long)a->ncia_t - 2));
+            const double ti = (1 / tl - 1 / a->cia_temps[lo]) / (1 / a->cia_temps[lo + 1] - 1 / a->cia_temps[lo]);
+            a->cia_rows2[(size_t)i * 2] = (int)lo;
+            a->cia_rows2[(size_t)i * 2 + 1] = (int)lo + 1;
+            a->cia_wts2[(size_t)i * 2] = 1 - ti;
+            a->cia_wts2[(size_t)i * 2 + 1] = ti;
+        }
     }
     std::sort(uniq, uniq + nuniq);
     *a->n_pt_opa_index = (int)(std::unique(uniq, uniq + nuniq) - uniq);
@@ -191,6 +211,9 @@ extern "C" int picaso_host_setup(const picaso_setup_args *a)
         for (int c = 0; c < a->ncont; ++c)
             a->cont_fac[(size_t)c * nl + i] = COEF1 * a->layer_mix[(size_t)a->cont_a[c] * nl + i] *
                                               a->layer_mix[(size_t)a->cont_b[c] * nl + i];
+        if (a->premixed)
+            a->mol_fac[i] = a->colden[i] / a->layer_mmw[i];                  // optics.py:256-262: no mixing ratio
+        else
         for (int m = 0; m < a->nopa; ++m)
             a->mol_fac[(size_t)m * nl + i] = 1.0 * (a->colden[i] * a->layer_mix[(size_t)a->opa_idx[m] * nl + i] / a->layer_mmw[i]);
         for (int r = 0; r < a->nray; ++r)
@@ -225,6 +248,7 @@ extern "C" int picaso_host_setup_facets(const picaso_setup_args *a, int nfac, lo
         b.cia_rows += F * nc1 * nl;
         b.mol_fac += F * nopa * nl; b.cont_fac += F * ncont * nl; b.ray_fac += F * nray * nl;
         b.pt_opa_index += F * 4 * nl; b.n_pt_opa_index += F;
+        if (a->cont_interp) { b.cia_rows2 += F * 2 * nl; b.cia_wts2 += F * 2 * nl; }
         const int rc = picaso_host_setup(&b);
         if (rc != 0) return rc;
     }

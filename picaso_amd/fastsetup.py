@@ -5,8 +5,9 @@ state of ``ATMSETUP`` (reference atmsetup.py:74-461), the table rows and weights
 ``setup(inp, opa, wno)`` returns an ``ATMSETUP`` filled exactly as ``justdoit._setup_atmosphere`` + ``opa.get_opacities``
 + ``optics._layer_factors`` would fill it (``tests/test_fast_setup.py``: every array ``np.array_equal``), or ``None`` when
 the call is outside the C function's scope -- an ``e-`` column, ``H-`` / ``H2-``
-continua, nearest-neighbour or correlated-k tables, ``exclude_mol``, facet-form profiles -- and the caller takes the numpy
-mirror.  ``PICASO_AMD_PY_SETUP=1`` forces the mirror (A/B)."""
+continua, nearest-neighbour tables, k-tables mixed on the fly, ``exclude_mol`` -- and the caller takes the numpy
+mirror.  Premixed correlated-k tables (``RetrieveCKs``) are in scope from round 5: the same ragged-grid search with the
+k-table's row numbering, the bracketing continuum temperatures with their 1/T weight, ``mol_fac = colden / mmw``.  ``PICASO_AMD_PY_SETUP=1`` forces the mirror (A/B)."""
 import ctypes
 import os
 
@@ -31,11 +32,24 @@ class SetupArgs(ctypes.Structure):
                 ("scale_height", _vp), ("layer_temperature", _vp), ("layer_pressure", _vp), ("layer_mmw", _vp),
                 ("layer_gravity", _vp), ("colden", _vp), ("layer_mix", _vp), ("rows", _vp), ("wts", _vp), ("cia_rows", _vp),
                 ("mol_fac", _vp), ("cont_fac", _vp), ("ray_fac", _vp), ("pt_opa_index", _vp), ("n_pt_opa_index", _vp),
-                ("scratch", _vp)]
+                ("scratch", _vp), ("premixed", _ci), ("cont_interp", _ci), ("cia_rows2", _vp), ("cia_wts2", _vp)]
 
 
 def _addr(a):
     return a.__array_interface__["data"][0]
+
+
+def _is_premixed(opa):
+    """A RetrieveCKs object with a premixed table loaded (not mixing on the fly)."""
+    return getattr(opa, "_kappa", None) is not None and not getattr(opa, "on_fly", False) and hasattr(opa, "temps")
+
+
+def _in_scope(opa):
+    """Opacity objects the C set-up covers: monochromatic tables with 'linear' interpolation, premixed k-tables."""
+    if _is_premixed(opa):
+        return True
+    return (getattr(opa, "query_method", None) == "linear" and getattr(opa, "ngauss", 1) == 1 and hasattr(opa, "_row_lut")
+            and not getattr(opa, "on_fly", False))
 
 
 class _Signature:
@@ -65,19 +79,32 @@ class _Signature:
         if ("H-" in molecules and "H-bf" in avail):
             return
         self.rayleigh_molecules = [m for m in molecules if m in opa.rayleigh_molecules]
+        # premixed correlated-k tables (RetrieveCKs with a table loaded, not mixing on the fly): no per-molecule line
+        # opacities -- ONE "molecule", the premixed table, whose rows are p * ntemp + t of the same ragged-grid search
+        self.premixed = _is_premixed(opa)
         opam = set(opa.molecules)
         self.no_opa = [m for m in molecules if m not in opam]
         self.molecules = [m for m in molecules if m in opam]
+        self.nopa = 1 if self.premixed else len(self.molecules)
         self.cia_pairs = [a + b for a, b in self.continuum_molecules]
         self.ray_names = [m for m in self.rayleigh_molecules if m in opa._ray]
         ix = {m: i for i, m in enumerate(molecules)}
         i32 = lambda xs: np.ascontiguousarray(xs, dtype=np.int32)
         self.opa_idx, self.ray_idx = i32([ix[m] for m in self.molecules]), i32([ix[m] for m in self.ray_names])
         self.cont_a, self.cont_b = i32([ix[a] for a, _ in self.continuum_molecules]), i32([ix[b] for _, b in self.continuum_molecules])
-        self.t_inv_grid = np.ascontiguousarray(opa.t_inv_grid, dtype=np.float64)
-        self.p_log_grid = np.ascontiguousarray(opa.p_log_grid, dtype=np.float64)
-        self.nc_p = np.ascontiguousarray(opa.nc_p, dtype=np.int64)
-        self.row_lut = np.ascontiguousarray(opa._row_lut, dtype=np.int64)
+        if self.premixed:
+            # get_mixing_indices' grids (optics.py:1200-1278)
+            self.t_inv_grid = np.ascontiguousarray(1 / np.asarray(opa.temps, dtype=np.float64))
+            self.p_log_grid = np.ascontiguousarray(np.log10(opa.pressures[opa.pressures > 0]), dtype=np.float64)
+            self.nc_p = np.ascontiguousarray(opa.nc_p, dtype=np.int64)
+            if self.nc_p.size != self.t_inv_grid.size:
+                return
+            self.row_lut = np.zeros(1, dtype=np.int64)         # not read: rows are p * ntemp + t
+        else:
+            self.t_inv_grid = np.ascontiguousarray(opa.t_inv_grid, dtype=np.float64)
+            self.p_log_grid = np.ascontiguousarray(opa.p_log_grid, dtype=np.float64)
+            self.nc_p = np.ascontiguousarray(opa.nc_p, dtype=np.int64)
+            self.row_lut = np.ascontiguousarray(opa._row_lut, dtype=np.int64)
         self.cia_temps = np.ascontiguousarray(np.unique(opa.cia_temps), dtype=np.float64)
         if self.cia_temps.size < 1 or self.t_inv_grid.size < 2:
             return
@@ -94,7 +121,7 @@ class _Layout:
     def __init__(self, sig, n, c):
         nl = n - 1
         nmol = len(sig.all_molecules)
-        self.nopa, self.ncont, self.nray = len(sig.molecules), len(sig.continuum_molecules), len(sig.ray_names)
+        self.nopa, self.ncont, self.nray = sig.nopa, len(sig.continuum_molecules), len(sig.ray_names)
         nopa, ncont, nray = self.nopa, self.ncont, self.nray
         self.sizes = [n] * 6 + [nl] * 5 + [nmol * nl, nopa * nl * 4, nopa * nl, ncont * nl, nray * nl, 3 * n]
         self.offs = np.concatenate(([0], np.cumsum(self.sizes)))[:-1].tolist()
@@ -114,6 +141,7 @@ class _Layout:
         a.nlut, a.ncia_t, a.cia_temps = sig.row_lut.size, sig.cia_temps.size, _addr(sig.cia_temps)
         a.nopa, a.ncont, a.nray = nopa, ncont, nray
         a.opa_idx, a.cont_a, a.cont_b, a.ray_idx = _addr(sig.opa_idx), _addr(sig.cont_a), _addr(sig.cont_b), _addr(sig.ray_idx)
+        a.premixed = a.cont_interp = 1 if sig.premixed else 0
         self.template = bytes(a)
 
 
@@ -133,8 +161,7 @@ class _PressureGrid:
 def setup(inp, opa, wno):
     if _options().py_setup:
         return None
-    if (getattr(opa, "query_method", None) != "linear" or getattr(opa, "ngauss", 1) != 1 or not hasattr(opa, "_row_lut")
-            or getattr(opa, "on_fly", False)):
+    if not _in_scope(opa):
         return None
     at = inp["atmosphere"]
     if at.get("exclude_mol", 1) != 1:
@@ -191,6 +218,10 @@ def setup(inp, opa, wno):
         setattr(a, name, fb + off)
     for name, off in lay.i_fields:
         setattr(a, name, ib + off)
+    rows2 = wts2 = None
+    if sig.premixed:
+        rows2, wts2 = np.empty((nl, 2), dtype=np.int32), np.empty((nl, 2))
+        a.cia_rows2, a.cia_wts2 = _addr(rows2), _addr(wts2)
     rc = _lib.load().picaso_host_setup(ctypes.byref(a))
     if rc != 0:
         return None
@@ -209,8 +240,9 @@ def setup(inp, opa, wno):
                      pressure=f(0, (n,)), mmw=f(1, (n,)), den=f(2, (n,)), z=f(3, (n,)), dz=f(4, (n,)), scale_height=f(5, (n,)))
     atm.layer.update(mixingratios={m: lmix[i] for i, m in enumerate(sig.all_molecules)}, temperature=f(6, (nl,)),
                      pressure=f(7, (nl,)), mmw=f(8, (nl,)), gravity=f(9, (nl,)), colden=f(10, (nl,)))
-    npt = int(ibuf[o_pt + 4 * nl])
-    atm.layer["pt_opa_index"] = ibuf[o_pt:o_pt + npt].astype(np.int64)
+    if not sig.premixed:
+        npt = int(ibuf[o_pt + 4 * nl])
+        atm.layer["pt_opa_index"] = ibuf[o_pt:o_pt + npt].astype(np.int64)
     c.nlevel, c.nlayer = n, nl
     atm.continuum_molecules = [list(p) for p in sig.continuum_molecules]
     atm.rayleigh_molecules = list(sig.rayleigh_molecules)
@@ -220,8 +252,12 @@ def setup(inp, opa, wno):
                          "opacities (not including continuum) for: " + ",".join(sig.no_opa))
     atm.molecules = np.array(sig.molecules)
     cia_rows = ibuf[o_cia:o_cia + nl]
-    plan = dict(molecules=list(sig.molecules), rows=ibuf[:nopa * nl * 4].reshape(nopa, nl, 4), wts=f(12, (nopa, nl, 4)),
-                fac=np.ones(nopa), cia_pairs=list(sig.cia_pairs), cia_rows=cia_rows, nlayer=nl)
+    if sig.premixed:                  # RetrieveCKs.get_opacities' plan (premixed table rows, bracketing continuum temperatures)
+        plan = dict(premixed=True, molecules=["premixed"], rows=ibuf[:nl * 4].reshape(1, nl, 4), wts=f(12, (1, nl, 4)),
+                    fac=np.ones(1), nlayer=nl, cia_pairs=list(sig.cia_pairs), cia_rows=rows2, cia_wts=wts2)
+    else:
+        plan = dict(molecules=list(sig.molecules), rows=ibuf[:nopa * nl * 4].reshape(nopa, nl, 4), wts=f(12, (nopa, nl, 4)),
+                    fac=np.ones(nopa), cia_pairs=list(sig.cia_pairs), cia_rows=cia_rows, nlayer=nl)
     factors = (f(13, (nopa, nl)), f(14, (ncont, nl)), list(sig.ray_names), f(15, (nray, nl)))
     plan["_factors"] = (atm.layer["mixingratios"], factors)
     atm._fast = (plan, factors, opa, (fbuf, ibuf, mixp))
@@ -235,8 +271,7 @@ def setup_facets(inp, opa, wno, prof_f):
     as ``atm._fast_tall``.  ``None`` outside the C function's scope."""
     if _options().py_setup:
         return None
-    if (getattr(opa, "query_method", None) != "linear" or getattr(opa, "ngauss", 1) != 1 or not hasattr(opa, "_row_lut")
-            or getattr(opa, "on_fly", False) or inp["atmosphere"].get("exclude_mol", 1) != 1):
+    if not _in_scope(opa) or inp["atmosphere"].get("exclude_mol", 1) != 1:
         return None
     radius, mass = inp["planet"]["radius"], inp["planet"]["mass"]
     if not isinstance(radius, float) or (radius == radius and not isinstance(mass, float)):
@@ -303,6 +338,10 @@ def setup_facets(inp, opa, wno, prof_f):
         setattr(a, name, fb + 8 * foff[k])
     for name, o in zip(("rows", "cia_rows", "pt_opa_index", "n_pt_opa_index"), ioff):
         setattr(a, name, ib + 4 * o)
+    rows2 = wts2 = None
+    if sig.premixed:
+        rows2, wts2 = np.empty((nfac * nl, 2), dtype=np.int32), np.empty((nfac * nl, 2))
+        a.cia_rows2, a.cia_wts2 = _addr(rows2), _addr(wts2)
     rc = _lib.load().picaso_host_setup_facets(ctypes.byref(a), _ci(nfac), ctypes.c_long(n), mstr)
     if rc != 0:
         return None
@@ -344,8 +383,12 @@ def setup_facets(inp, opa, wno, prof_f):
 
     def tall(k, nsp):
         return np.ascontiguousarray(f(k, (nsp, nl)).transpose(1, 0, 2)).reshape(nsp, ntot)
-    plan = dict(molecules=list(sig.molecules), rows=rows, wts=wts, fac=np.ones(nopa), cia_pairs=list(sig.cia_pairs),
-                cia_rows=cia_rows, nlayer=ntot)
+    if sig.premixed:
+        plan = dict(premixed=True, molecules=["premixed"], rows=rows, wts=wts, fac=np.ones(1), nlayer=ntot,
+                    cia_pairs=list(sig.cia_pairs), cia_rows=rows2, cia_wts=wts2)
+    else:
+        plan = dict(molecules=list(sig.molecules), rows=rows, wts=wts, fac=np.ones(nopa), cia_pairs=list(sig.cia_pairs),
+                    cia_rows=cia_rows, nlayer=ntot)
     factors = (tall(13, nopa), tall(14, ncont), list(sig.ray_names), tall(15, nray))
     atm._fast_tall = (plan, factors, opa)
     return atm

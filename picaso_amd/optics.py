@@ -342,6 +342,12 @@ class RetrieveCKs:
         ``get_pre_mix_ck``, reference optics.py:1500-1538)."""
         if exclude_mol != 1:
             raise Exception("premixed correlated-k tables cannot exclude molecules")
+        fast = getattr(atmosphere, "_fast", None)
+        if fast is not None and fast[2] is self and fast[0].get("premixed"):    # formed with the atmosphere (fastsetup.py)
+            self._plan = fast[0]
+            self.continuum_opa = _LazyPlanes(self, "cia")
+            self.molecular_opa = None
+            return
         nlayer = atmosphere.c.nlayer
         if self._kappa is None:
             raise Exception("no premixed table loaded: use get_opacities_deq_onfly")
@@ -1320,9 +1326,16 @@ def compute_opacity_facet_major_ck(atm_f, opacityclass, numg, numt, stream=2, de
         layer={"temperature": flat(atm_f.layer["temperature"]), "pressure": flat(atm_f.layer["pressure"]),
                "mixingratios": {m: flat(mix[m].values if hasattr(mix[m], "values") else mix[m]) for m in atm_f.molecules}},
         molecules=atm_f.molecules, continuum_molecules=atm_f.continuum_molecules)
-    opa.get_opacities(tall, exclude_mol=exclude_mol)
-    pl = opa._plan
-    mol_fac, cont_fac, ray_names, ray_fac = _layer_factors(atm_f, opa)
+    fast = getattr(atm_f, "_fast_tall", None)
+    if fast is not None and fast[2] is opa and fast[0].get("premixed") and exclude_mol == 1:
+        # the tall plan and coefficients came with the facet-form set-up (fastsetup.setup_facets)
+        opa._plan = pl = fast[0]
+        opa.continuum_opa, opa.molecular_opa = _LazyPlanes(opa, "cia"), None
+        mol_fac, cont_fac, ray_names, ray_fac = fast[1]
+    else:
+        opa.get_opacities(tall, exclude_mol=exclude_mol)
+        pl = opa._plan
+        mol_fac, cont_fac, ray_names, ray_fac = _layer_factors(atm_f, opa)
     cont_tabs = [opa._cia[p] for p in pl["cia_pairs"]]
     ray_tabs = [opa._ray[m] for m in ray_names]
     mol_tabs = [pl.get("table", opa._kappa)]

@@ -189,3 +189,101 @@ def test_fast_setup_facets_bits_of_the_mirror(opa, monkeypatch, seed, planet):
     assert ff[2] == fr[2]
     for i in (0, 1, 3):
         _same(ff[i], fr[i], ("factors", i))
+
+
+@pytest.fixture()
+def opk(monkeypatch):
+    """A premixed correlated-k opacity object (RetrieveCKs) on a ragged (P, T) grid, device tables as stand-ins."""
+    monkeypatch.setattr(px, "DeviceArray", _Dev)
+    nb, nk = 7, 4
+    wck = np.linspace(40.0, 28000.0, nb)
+    tk = np.array([100.0, 300.0, 700.0, 1500.0, 3000.0])
+    pk = np.array([1e-6, 1e-4, 1e-2, 1e-1, 1.0, 10.0, 100.0, 500.0])
+    nc_p = np.array([8, 8, 7, 6, 8])                                   # ragged: fewer pressures at some temperatures
+    lnk = np.zeros((pk.size, tk.size, nb, nk))
+    cia_t = [75.0, 200.0, 500.0, 1000.0, 2000.0, 4000.0]
+    cont = {pr: {t: np.ones(nb) for t in cia_t} for pr in ("H2H2", "H2He", "H2CH4")}
+    o = px.RetrieveCKs(wck, np.full(nk, 1.0 / nk), np.tile(pk, tk.size), np.repeat(tk, pk.size), nc_p, lnk, continuum=cont,
+                       cia_temps=cia_t, rayleigh_opa={m: np.ones(nb) for m in ("H2", "He")}, gauss_pts=np.linspace(0.1, 0.9, nk),
+                       ctx=object())
+    o._wno_test = wck
+    return o
+
+
+def _compare(f, r, pf, pr, ff, fr, facets=False):
+    for d in ("level", "layer"):
+        fd, rd = getattr(f, d), getattr(r, d)
+        assert set(fd) == set(rd), (d, set(fd) ^ set(rd))
+        for k in rd:
+            if k == "mixingratios":
+                for m in rd[k]:
+                    _same(fd[k][m], rd[k][m], (d, k, m))
+            elif k != "cloud":
+                _same(fd[k], rd[k], (d, k))
+    assert list(f.molecules) == list(r.molecules)
+    assert f.continuum_molecules == r.continuum_molecules and f.rayleigh_molecules == r.rayleigh_molecules
+    assert f.warnings == r.warnings
+    assert pf["premixed"] and pr["premixed"] and pf["molecules"] == pr["molecules"] and pf["cia_pairs"] == pr["cia_pairs"]
+    assert pf["nlayer"] == pr["nlayer"]
+    for k in ("rows", "wts", "fac", "cia_rows", "cia_wts"):
+        _same(pf[k], pr[k], ("plan", k))
+    assert ff[2] == fr[2]
+    for i in (0, 1, 3):
+        _same(ff[i], fr[i], ("factors", i))
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_fast_setup_premixed_k_tables_bits_of_the_mirror(opk, monkeypatch, seed):
+    """Round 5: premixed correlated-k tables through the C set-up -- the ragged-grid search of get_mixing_indices with the
+    k-table's row numbering, the bracketing continuum temperatures and their 1/T weights (RetrieveCKs._plan_continuum),
+    mol_fac = colden / mmw -- against the numpy mirror, array by array."""
+    rng = np.random.default_rng(700 + seed)
+    cols = ["H2", "He", "H2O", "CH4", "Na"][:int(rng.integers(3, 6))]
+    nlevel = int(rng.choice([2, 3, 10, 61, 91]))
+    case = _case(rng, nlevel, float(rng.choice([1.0, 1e-9, 1e5, 0.03])), cols, planet=seed % 2 == 1)
+    wno = opk._wno_test
+    fast = jdi._setup_atmosphere(case.inputs, opk, wno)
+    assert getattr(fast, "_fast", None) is not None, "the C set-up declined a k-table profile inside its scope"
+    opk.get_opacities(fast)
+    pf, ff = opk._plan, px._layer_factors(fast, opk)
+    assert pf is fast._fast[0]
+    monkeypatch.setenv("PICASO_AMD_PY_SETUP", "1")
+    ref = jdi._setup_atmosphere(case.inputs, opk, wno)
+    assert getattr(ref, "_fast", None) is None
+    opk.get_opacities(ref)
+    pr, fr = opk._plan, px._layer_factors(ref, opk)
+    monkeypatch.delenv("PICASO_AMD_PY_SETUP")
+    _compare(fast, ref, pf, pr, ff, fr)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_fast_setup_premixed_k_tables_facet_form(opk, monkeypatch, seed):
+    import types
+    rng = np.random.default_rng(900 + seed)
+    wno = opk._wno_test
+    nlevel, nfac = int(rng.choice([3, 10, 31])), int(rng.choice([1, 4, 9]))
+    cols = ["H2", "He", "H2O", "CH4"][:int(rng.integers(3, 5))]
+    case = _case(rng, nlevel, float(rng.choice([1.0, 1e-9, 0.03])), cols, planet=seed % 2 == 1)
+    inp = case.inputs
+    base = inp["atmosphere"]["profile"]
+    prof_f = {"pressure": np.asarray(base["pressure"]).reshape(nlevel, 1),
+              "temperature": np.ascontiguousarray(np.asarray(base["temperature"])[:, None] * (1.0 + 0.1 * rng.random((1, nfac))))}
+    for k in cols:
+        v = np.asarray(base[k]).reshape(nlevel, 1)
+        prof_f[k] = v * (1.0 + 0.2 * rng.random((1, nfac))) if (seed % 2 and k != "H2") else v
+    fast = jdi._setup_atmosphere(inp, opk, wno, prof_f, None)
+    assert getattr(fast, "_fast_tall", None) is not None
+    monkeypatch.setenv("PICASO_AMD_PY_SETUP", "1")
+    ref = jdi._setup_atmosphere(inp, opk, wno, prof_f, None)
+    assert getattr(ref, "_fast_tall", None) is None
+    nl = nlevel - 1
+
+    def flat(a):
+        return np.ascontiguousarray(np.broadcast_to(np.asarray(a, dtype=float), (nl, nfac)).T).ravel()
+    tall = types.SimpleNamespace(c=types.SimpleNamespace(nlayer=nfac * nl, pconv=ref.c.pconv),
+                                 layer={"temperature": flat(ref.layer["temperature"]), "pressure": flat(ref.layer["pressure"])},
+                                 molecules=ref.molecules, continuum_molecules=ref.continuum_molecules)
+    opk.get_opacities(tall)
+    pr, fr = opk._plan, px._layer_factors(ref, opk)
+    monkeypatch.delenv("PICASO_AMD_PY_SETUP")
+    _compare(fast, ref, fast._fast_tall[0], pr, fast._fast_tall[1], fr, facets=True)
