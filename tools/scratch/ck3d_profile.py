@@ -36,6 +36,19 @@ c3.gravity(gravity=2500.0)
 c3.atmosphere_3d(dict(prof, temperature=prof["temperature"][:, None, None] * pert[None]))
 c3.approx(raman="none")
 calc = os.environ.get("CALC", "reflected+thermal")
+if os.environ.get("DIM") == "1d":
+    c1 = jdi.inputs()
+    c1.phase_angle(0, num_gangle=5)
+    c1.gravity(gravity=2500.0)
+    c1.atmosphere(df=dict(prof))
+    c1.approx(raman="none")
+    for _ in range(5):
+        c1.spectrum(opk, calculation=calc)
+    tt = []
+    for _ in range(20):
+        t0 = time.perf_counter(); c1.spectrum(opk, calculation=calc); tt.append(time.perf_counter() - t0)
+    print("1-D CK spectrum ms", 1e3 * np.median(tt))
+    sys.exit(0)
 for _ in range(3):
     c3.spectrum(opk, calculation=calc, dimension="3d")
 tt = []
