@@ -851,6 +851,14 @@ typedef struct picaso_spectrum_job {
      * (its slab of the planes, its ubar0 / ubar1), then picaso_compress_disco_dev / picaso_compress_thermal_dev.  The level
      * planes (planes[1], planes[8]: tau, tau_og) must be NULL -- the 3-D kernels form them as running sums.  Toon only. */
     int nfacets;
+    /* ngauss > 1: premixed correlated-k tables (reference justdoit.py:256-313, 328-380: the Gauss-point loop around the Toon
+     * solvers).  The block's molecular table is ONE table of nwno * ngauss columns (mol_mode = 2, nmol = 1), continua are
+     * interpolated (cont_interp = 1, cont_rows / cont_wts [ncont][nlayer][2]), planes / taugas are (rows, nwno, ngauss) with
+     * the Gauss index fastest, tauray and the cloud planes (rows, nwno); the opacity stage is picaso_opacity_gas_ck_dev +
+     * picaso_compute_opacity_ck_dev, the legs picaso_get_reflected_1d_ck_dev / picaso_get_thermal_1d_ck_dev with
+     * gauss_wts (host, ngauss).  0 or 1: monochromatic.  Toon, 1-D only. */
+    int ngauss;
+    const double *gauss_wts;
 } picaso_spectrum_job;
 int picaso_toon_spectrum_blocks(int nblocks, picaso_block *blocks, const picaso_spectrum_job *job);
 /* copy one leg's results (which = 1: albedo, 2: thermal flux) of every block into albedo_host / thermal_host */

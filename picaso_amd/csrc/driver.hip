@@ -44,7 +44,8 @@ static int opacity_stage(const picaso_block &k, const picaso_spectrum_job &j, in
         }
     }
     double *const *o = k.planes;
-    const bool fused = (!o[1] || o[0]) && (!o[8] || o[7]) && !getenv("PICASO_AMD_UNFUSED_OPACITY");
+    const int ngs = j.ngauss > 1 ? j.ngauss : 1;          // correlated-k tables: the two launches, Gauss axis in the columns
+    const bool fused = ngs == 1 && (!o[1] || o[0]) && (!o[8] || o[7]) && !getenv("PICASO_AMD_UNFUSED_OPACITY");
     if (fused) {
         PZ_TRY(picaso_gas_compute_opacity_dev(k.ctx, j.nlayer, k.nwno, j.mol_mode, j.nmol, k.mol_tabs, j.mol_rows,
                                               j.mol_wts, j.mol_fac, j.cont_interp, j.ncont, k.cont_tabs, j.cont_rows,
@@ -57,10 +58,11 @@ static int opacity_stage(const picaso_block &k, const picaso_spectrum_job &j, in
         PZ_TRY(picaso_level_sums_dev(k.ctx, j.nlayer, k.nwno, o[0], o[1], o[7], o[8]));
     } else {
         if (k.cld_tab_nin) return fail(k.ctx, "toon_spectrum_blocks: cloud tables need the fused opacity launch");
-        PZ_TRY(picaso_opacity_gas_ck_dev(k.ctx, j.nlayer, k.nwno, 1, j.mol_mode, j.nmol, k.mol_tabs, j.mol_rows,
+        if (!k.taugas || !k.tauray) return fail(k.ctx, "toon_spectrum_blocks: block %d has no TAUGAS / TAURAY workspace", b);
+        PZ_TRY(picaso_opacity_gas_ck_dev(k.ctx, j.nlayer, k.nwno, ngs, j.mol_mode, j.nmol, k.mol_tabs, j.mol_rows,
                                          j.mol_wts, j.mol_fac, j.cont_interp, j.ncont, k.cont_tabs, j.cont_rows,
                                          j.cont_wts, j.cont_fac, j.nray, k.ray_tabs, j.ray_fac, k.taugas, k.tauray));
-        PZ_TRY(picaso_compute_opacity_ck_dev(k.ctx, j.nlayer, k.nwno, 1, k.taugas, k.tauray, cld[0], cld[1], cld[2],
+        PZ_TRY(picaso_compute_opacity_ck_dev(k.ctx, j.nlayer, k.nwno, ngs, k.taugas, k.tauray, cld[0], cld[1], cld[2],
                                              k.raman, j.raman_rows, j.raman_const, j.test_mode, j.delta_eddington,
                                              j.stream, o[0], o[1], o[2], o[3], o[4], o[5], o[6], o[7], o[8], o[9], o[10],
                                              o[11], o[12]));
@@ -107,6 +109,7 @@ static int enqueue_block_3d(int nblocks, picaso_block *blocks, const picaso_spec
         return fail(k.ctx, "toon_spectrum_blocks: block %d still has uncollected results", b);
     if (nfac != j.numg * j.numt) return fail(k.ctx, "toon_spectrum_blocks: nfacets must be numg * numt");
     if (j.rt_method != 0) return fail(k.ctx, "toon_spectrum_blocks: 3-D blocks are Toon only (the reference has no 3-D SH)");
+    if (j.ngauss > 1) return fail(k.ctx, "toon_spectrum_blocks: 3-D blocks take monochromatic tables");
     if ((long)nfac * j.nlayer > 2147483647L / 4) return fail(k.ctx, "toon_spectrum_blocks: too many facet-layers");
     double *const *o = k.planes;
     if (o[1] || o[8])
@@ -182,6 +185,8 @@ static int enqueue_block(int nblocks, picaso_block *blocks, const picaso_spectru
             return fail(k.ctx, "toon_spectrum_blocks: block %d still has uncollected results", b);
         picaso_ctx *tctx = k.tctx ? k.tctx : k.ctx;
         PZ_TRY(opacity_stage(k, j, b, (tctx != k.ctx && j.do_thermal) ? tctx : nullptr));
+        if (j.rt_method == 1 && j.ngauss > 1)
+            return fail(k.ctx, "toon_spectrum_blocks: correlated-k blocks are Toon only");
         if (j.do_reflected && j.rt_method == 1) {
             const double *const *r = k.refl_planes;             // SH argument order (picaso_spectrum_job::rt_method)
             PZ_TRY(picaso_get_reflected_SH_top_dev(k.ctx, nlevel, k.nwno, k.nwno, j.numg, j.numt, r[0], r[1], r[2], r[3], r[4],
@@ -191,6 +196,15 @@ static int enqueue_block(int nblocks, picaso_block *blocks, const picaso_spectru
                                                    j.sh_psingle_rayleigh, j.frac_a, j.frac_b, j.frac_c, j.constant_back,
                                                    j.constant_forward, j.stream, j.b_top, 0, j.sh_single_form, 1,
                                                    j.sh_cloud_free_above, k.xint, nullptr, j.gweight, j.tweight, k.albedo));
+        } else if (j.do_reflected && j.ngauss > 1) {
+            const double *const *r = k.refl_planes;             // (rows, nwno, ngauss): the Gauss loop inside the call
+            if (!j.gauss_wts) return fail(k.ctx, "toon_spectrum_blocks: ngauss > 1 without gauss_wts");
+            PZ_TRY(picaso_get_reflected_1d_ck_dev(k.ctx, nlevel, k.nwno, j.ngauss, j.numg, j.numt, r[0], r[1], r[2], r[3], r[4],
+                                                  r[5], r[6], r[7], r[8], r[9], r[10], k.surf_reflect, j.ubar0, j.ubar1,
+                                                  j.cos_theta, k.F0PI, j.single_phase, j.multi_phase, j.frac_a, j.frac_b,
+                                                  j.frac_c, j.constant_back, j.constant_forward, 1, 0, j.toon_coefficients,
+                                                  j.b_top, j.gauss_wts, k.xint, nullptr, nullptr, nullptr, nullptr, j.gweight,
+                                                  j.tweight, k.albedo));
         } else if (j.do_reflected) {
             const double *const *r = k.refl_planes;
             PZ_TRY(picaso_get_reflected_1d_dev(k.ctx, nlevel, k.nwno, k.nwno, j.numg, j.numt, r[0], r[1], r[2], r[3], r[4],
@@ -208,7 +222,13 @@ static int enqueue_block(int nblocks, picaso_block *blocks, const picaso_spectru
                 PZ_TRY(picaso_get_thermal_SH_dev(tctx, nlevel, k.wno, k.nwno, k.nwno, j.numg, j.numt, j.tlevel, k.th_dtau,
                                                  nullptr, k.th_w0, k.th_cosb, j.plevel, j.ubar1, k.surf_reflect, j.stream,
                                                  j.hard_surface, j.delta_eddington, 0, k.flux, j.gweight, j.tweight, k.disk));
-            else
+            else if (j.ngauss > 1) {
+                if (!j.gauss_wts) return fail(k.ctx, "toon_spectrum_blocks: ngauss > 1 without gauss_wts");
+                PZ_TRY(picaso_get_thermal_1d_ck_dev(tctx, nlevel, k.wno, k.nwno, j.ngauss, j.numg, j.numt, j.tlevel, k.th_dtau,
+                                                    k.th_w0, k.th_cosb, j.plevel, j.ubar1, k.surf_reflect, j.hard_surface,
+                                                    nullptr, 0, j.gauss_wts, k.flux, nullptr, nullptr, nullptr, nullptr,
+                                                    j.gweight, j.tweight, k.disk));
+            } else
             PZ_TRY(picaso_get_thermal_1d_dev(tctx, nlevel, k.wno, k.nwno, k.nwno, j.numg, j.numt, j.tlevel, k.th_dtau,
                                              k.th_w0, k.th_cosb, j.plevel, j.ubar1, k.surf_reflect, j.hard_surface,
                                              nullptr, 0, k.flux, nullptr, nullptr, nullptr, nullptr, j.gweight, j.tweight,

@@ -54,7 +54,8 @@ class Job(ctypes.Structure):
                 ("rt_method", ctypes.c_int), ("sh_w_single_form", ctypes.c_int), ("sh_w_multi_form", ctypes.c_int),
                 ("sh_psingle_form", ctypes.c_int), ("sh_w_single_rayleigh", ctypes.c_int),
                 ("sh_w_multi_rayleigh", ctypes.c_int), ("sh_psingle_rayleigh", ctypes.c_int),
-                ("sh_single_form", ctypes.c_int), ("sh_cloud_free_above", ctypes.c_int), ("nfacets", ctypes.c_int)]
+                ("sh_single_form", ctypes.c_int), ("sh_cloud_free_above", ctypes.c_int), ("nfacets", ctypes.c_int),
+                ("ngauss", ctypes.c_int), ("gauss_wts", _dp)]
 
 
 def _dev(x):
@@ -82,7 +83,7 @@ class BlockTable:
     of the same signature: every access is ordered on the blocks' streams."""
 
     def __init__(self, subs, nlayer, ng, nt, mol_names, cia_pairs, ray_names, linear, want, lean, host_cloud,
-                 do_reflected, do_thermal, const_planes, derive=False, sh=False, facets=0, th3=None):
+                 do_reflected, do_thermal, const_planes, derive=False, sh=False, facets=0, th3=None, ngauss=1):
         self.subs, self.n = subs, len(subs)
         self.blocks = (Block * self.n)()
         self.keep = []                                   # DeviceArrays and pointer tables the structs point into
@@ -93,7 +94,9 @@ class BlockTable:
             k.ctx = ctx.value if hasattr(ctx, "value") else ctx
             k.tctx = None
             k.nwno, k.col0 = nw, lo
-            tabs = [(sub._mol_log if linear else sub._mol_raw)[m] for m in mol_names]
+            # premixed k-tables (ngauss > 1): ONE table of nwno * ngauss columns; planes (rows, nwno, ngauss), Gauss index fastest
+            tabs = [sub._kappa] if ngauss > 1 else [(sub._mol_log if linear else sub._mol_raw)[m] for m in mol_names]
+            ncolg = nw * ngauss
             ctabs, rtabs = [sub._cia[p] for p in cia_pairs], [sub._ray[m] for m in ray_names]
             mt, ct, rt = _table_ptrs(tabs), _table_ptrs(ctabs), _table_ptrs(rtabs)
             self.keep += [mt, ct, rt, tabs, ctabs, rtabs]    # the tables themselves too: the structs hold raw addresses
@@ -103,13 +106,13 @@ class BlockTable:
                 # atmosphere; no TAUGAS / TAURAY workspace (that launch keeps the sums in registers), no level planes
                 self._facet_block(k, ctx, nw, nlayer, ng, nt, facets, want, do_reflected, do_thermal, th3)
                 continue
-            tg, tr = DeviceArray((nlayer, nw), ctx), DeviceArray((nlayer, nw), ctx)
+            tg, tr = DeviceArray((nlayer, ncolg), ctx), DeviceArray((nlayer, nw), ctx)
             self.keep += [tg, tr]
             k.taugas, k.tauray = _dev(tg), _dev(tr)
             pl = {}
             for i, name in enumerate(OUT_NAMES):
                 if name in want:
-                    pl[name] = DeviceArray((nlayer + 1 if name in ("tau", "tau_og") else nlayer, nw), ctx)
+                    pl[name] = DeviceArray((nlayer + 1 if name in ("tau", "tau_og") else nlayer, ncolg), ctx)
                     self.keep.append(pl[name])
                     k.planes[i] = _dev(pl[name])
             rpl = pl
@@ -182,22 +185,26 @@ class BlockTable:
 
 def make_job(nlayer, plan, factors, linear, raman_rows, stream, delta_eddington, do_reflected, do_thermal, ng, nt, ubar0,
              ubar1, cos_theta, gweight, tweight, single_phase, multi_phase, toon_coefficients, frac_a, frac_b, frac_c,
-             constant_back, constant_forward, b_top, tlevel, plevel, hard_surface, sh=None, sh_top=0, nfacets=0):
+             constant_back, constant_forward, b_top, tlevel, plevel, hard_surface, sh=None, sh_top=0, nfacets=0,
+             gauss_wts=None):
     """The per-call half: (Job, the numpy arrays it points into).  ``plan`` = ``opa._plan`` (table rows and weights per
     molecule and layer, CIA rows), ``factors`` = ``optics._layer_factors`` (per-layer coefficients of the sums)."""
     mol_fac, cont_fac, ray_names, ray_fac = factors
     nmol, ncont = len(plan["molecules"]), len(plan["cia_pairs"])
+    premixed = bool(plan.get("premixed"))         # k-tables: cia_rows / cia_wts (nlayer, 2), the bracketing temperatures
     keep = dict(
         rows=np.ascontiguousarray(plan["rows"], dtype=np.int32), wts=_lib.f64(plan["wts"]), mol_fac=_lib.f64(mol_fac),
         cont_rows=np.ascontiguousarray(np.repeat(plan["cia_rows"][None], max(ncont, 1), axis=0), dtype=np.int32),
+        cont_wts=_lib.f64(np.repeat(plan["cia_wts"][None], max(ncont, 1), axis=0)) if premixed else None,
         cont_fac=_lib.f64(cont_fac), ray_fac=_lib.f64(ray_fac), u0=_lib.f64(ubar0, (ng, nt)), u1=_lib.f64(ubar1, (ng, nt)),
         gw=_lib.f64(gweight), tw=_lib.f64(tweight), tl=_lib.f64(tlevel), pl=_lib.f64(plevel))
     j = Job()
-    j.nlayer, j.mol_mode, j.nmol, j.cont_interp, j.ncont, j.nray = nlayer, (1 if linear else 0), nmol, 0, ncont, len(ray_names)
+    j.nlayer, j.mol_mode, j.nmol, j.cont_interp, j.ncont, j.nray = (nlayer, (2 if premixed else (1 if linear else 0)), nmol,
+                                                                    (1 if premixed else 0), ncont, len(ray_names))
     j.mol_rows = keep["rows"].ctypes.data_as(_ip) if nmol else None
     j.mol_wts, j.mol_fac = (_host(keep["wts"]), _host(keep["mol_fac"])) if nmol else (None, None)
     j.cont_rows = keep["cont_rows"].ctypes.data_as(_ip) if ncont else None
-    j.cont_wts, j.cont_fac = None, (_host(keep["cont_fac"]) if ncont else None)
+    j.cont_wts, j.cont_fac = (_host(keep["cont_wts"]) if (premixed and ncont) else None), (_host(keep["cont_fac"]) if ncont else None)
     j.ray_fac = _host(keep["ray_fac"]) if len(ray_names) else None
     j.raman_rows, j.raman_const = raman_rows, 0.99999
     j.test_mode, j.delta_eddington, j.stream = 0, (1 if delta_eddington else 0), stream
@@ -209,6 +216,10 @@ def make_job(nlayer, plan, factors, linear, raman_rows, stream, delta_eddington,
     j.constant_back, j.constant_forward, j.b_top = float(constant_back), float(constant_forward), float(b_top)
     j.tlevel, j.plevel, j.hard_surface = _host(keep["tl"]), _host(keep["pl"]), int(hard_surface)
     j.rt_method, j.nfacets = 0, int(nfacets)    # nfacets > 0: plan / factors of the tall atmosphere, tlevel / plevel (nfacets, nlevel)
+    j.ngauss, j.gauss_wts = 1, None
+    if gauss_wts is not None and len(gauss_wts) > 1:      # premixed k-tables: the Gauss-point loop inside the solver calls
+        keep["gauss_wts"] = _lib.f64(gauss_wts)
+        j.ngauss, j.gauss_wts = int(len(gauss_wts)), _host(keep["gauss_wts"])
     if sh is not None:                     # inputs["approx"]["rt_params"]["SH"]: the spherical-harmonics solvers
         j.rt_method = 1
         j.sh_w_single_form, j.sh_w_multi_form, j.sh_psingle_form = (int(sh[k]) for k in ("w_single_form", "w_multi_form", "psingle_form"))

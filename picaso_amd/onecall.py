@@ -45,7 +45,10 @@ def _in_scope(inp, opa, legs, nblocks, opt):
     if not legs or not legs <= {"reflected", "thermal"}:
         return False
     is_sh = inp["approx"]["rt_method"] == "SH"
-    if (opa.ngauss != 1 or getattr(opa, "on_fly", False) or inp["clouds"].get("do_holes", False)
+    if opa.ngauss != 1 and (is_sh or getattr(opa, "_kappa", None) is None or inp["approx"].get("get_lvl_flux", False)
+                            or inp["approx"]["rt_params"]["common"]["raman"] == 0):
+        return False                # k-tables: premixed, Toon, TOA intensities (the SH / level-flux forms: Spectrum)
+    if (getattr(opa, "on_fly", False) or inp["clouds"].get("do_holes", False)
             or (inp["approx"].get("get_lvl_flux", False) and not is_sh)
             or inp["test_mode"] is not None or not hasattr(opa, "_cia") or not hasattr(opa, "_ray")):
         return False
@@ -244,14 +247,15 @@ def prepare(bundle, opa, subs, calculation, opt, slot=None):
     cld = atm.layer["cloud"]
     cloud_free = bool(getattr(atm, "cloud_free", False))
     tables = not cloud_free and isinstance(cld, CloudTables)
-    if tables and (np.size(cld.wno) != nwno or opt.host_regrid or
+    if tables and (np.size(cld.wno) != nwno or opt.host_regrid or opa.ngauss != 1 or
                    (len(subs) != 1 and (opt.unfused_opacity or opt.regrid_planes))):
         return None                 # tables on their own grid: interpolated inside each block's fused opacity launch
     nlevel, nlayer = atm.c.nlevel, atm.c.nlayer
     opa.get_opacities(atm, exclude_mol=inp["atmosphere"]["exclude_mol"])
     plan = opa._plan
-    if plan.get("premixed"):
-        return None
+    ck = bool(plan.get("premixed"))
+    if ck and ("table" in plan or opa.ngauss < 2):
+        return None                 # mixed on the fly: a per-call table (Spectrum)
     factors = optics._layer_factors(atm, opa)
     plan["_factors"] = (atm.layer["mixingratios"], factors)
     linear = opa.query_method == "linear"
@@ -264,15 +268,23 @@ def prepare(bundle, opa, subs, calculation, opt, slot=None):
     if is_sh:
         want, lean, sh_top = _plane_set_sh(inp, atm, nwno, common, frac_c, opt)
         derive = False
+    elif ck:                        # k-tables: the full set, as Spectrum._want_1d (no aliases, nothing derived)
+        want, lean, derive = set(), False, False
+        if do_r:
+            want |= set(resident.REFLECTED_PLANES)
+        if do_t:
+            want |= {"dtau_og", "w0_no_raman", "cosb_og"}
     else:
         want, lean, derive = _plane_set(atm, geom, toon, frac_c, nwno, raman, do_r, do_t, opt)
 
     def table_ids(sub):          # a block table holds raw table addresses: replaced tables are a new signature
+        if ck:
+            return (id(sub._kappa),) + tuple(id(sub._cia[p]) for p in plan["cia_pairs"])
         mt = sub._mol_log if linear else sub._mol_raw
         return tuple(id(mt[m]) for m in plan["molecules"]) + tuple(id(sub._cia[p]) for p in plan["cia_pairs"])
     key = (tuple((lo, hi, id(sub)) + table_ids(sub) for lo, hi, sub in subs), nlayer, ng, nt, tuple(plan["molecules"]),
            tuple(plan["cia_pairs"]), tuple(factors[2]), linear, tuple(sorted(want)), lean, not cloud_free and not tables, do_r, do_t,
-           derive, is_sh, slot)
+           derive, is_sh, opa.ngauss, slot)
     cache = opa.__dict__.setdefault("_driver_tables", {})
     table = cache.get(key)
     if table is None:
@@ -280,7 +292,7 @@ def prepare(bundle, opa, subs, calculation, opt, slot=None):
             cache.clear()
         table = cache[key] = drv.BlockTable(subs, nlayer, ng, nt, plan["molecules"], plan["cia_pairs"], factors[2], linear,
                                             want, lean, not cloud_free and not tables, do_r, do_t, _constant_planes, derive,
-                                            sh=is_sh)
+                                            sh=is_sh, ngauss=opa.ngauss)
     c = _call_state(inp, opa, subs, opt, atm, raman, do_r, do_t, table, ng, nt)
     c["clouds"] = _cloud_inputs(atm, opa, tables, nlayer, nwno, opt, c["hold"])
     for b, (lo, hi, sub) in enumerate(subs):
@@ -291,7 +303,8 @@ def prepare(bundle, opa, subs, calculation, opt, slot=None):
                              geom["gweight"], geom["tweight"], toon["single_phase"], toon["multi_phase"],
                              toon["toon_coefficients"], frac_a, frac_b, frac_c, common["TTHG_params"]["constant_back"],
                              common["TTHG_params"]["constant_forward"], 0.0, atm.level["temperature"], atm.level["pressure"],
-                             atm.hard_surface, sh=inp["approx"]["rt_params"]["SH"] if is_sh else None, sh_top=sh_top)
+                             atm.hard_surface, sh=inp["approx"]["rt_params"]["SH"] if is_sh else None, sh_top=sh_top,
+                             gauss_wts=opa.gauss_wts if ck else None)
     return _prepared(c, job, keep, key[1:-1])
 
 

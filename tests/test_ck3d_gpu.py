@@ -273,3 +273,46 @@ def test_3d_ck_on_the_fly_mixing_and_phase_curve(fx):
         one.atmosphere_3d(profile(k))
         want = one.spectrum(opa, calculation="thermal", dimension="3d")
         assert np.array_equal(res[ph]["thermal"], want["thermal"]), ph
+
+
+@pytest.mark.parametrize("devices", [None, [0, 0, 0]])
+@pytest.mark.parametrize("calc", ["reflected", "thermal", "reflected+thermal"])
+@pytest.mark.parametrize("cloud", [False, True])
+def test_driver_runs_toon_spectra_on_k_tables(monkeypatch, fx, devices, calc, cloud):
+    """A Toon spectrum on premixed k-tables through the C driver (picaso_spectrum_job.ngauss; round 5: it took the
+    call-by-call path, a dozen ctypes calls for 0.18 ms of GPU work): picaso_opacity_gas_ck_dev ->
+    picaso_compute_opacity_ck_dev -> picaso_get_reflected_1d_ck_dev || picaso_get_thermal_1d_ck_dev, whole grid and
+    wavelength blocks, every output equal to spectrum.Spectrum's bit for bit."""
+    from picaso_amd import justdoit as jdi
+    r, ck, og = fx
+    opa = _opa(og["in/wno"], ck["in/gauss_wts"], ck["in/press"], ck["in/temps"], ck["in/nc_p"], ck["in/kappa"],
+               ck["in/cia_temps"])
+    opa.relative_flux = None
+
+    def make(k):
+        case = jdi.inputs()
+        case.phase_angle(0, num_gangle=5)
+        case.gravity(gravity=float(og["in/gravity"]))
+        prof = {"pressure": og["in/plevel_bar"], "temperature": og["in/tlevel"] * (1.0 + 0.01 * k)}
+        for m in ("H2", "He", "H2O", "CH4"):
+            prof[m] = og["in/mix/" + m]
+        case.atmosphere(df=prof)
+        if cloud:
+            case.clouds(df={"opd": og["in/cld_opd"], "w0": og["in/cld_w0"], "g0": og["in/cld_g0"]})
+        case.surface_reflect(r["sh/surf_reflect"], og["in/wno"])
+        case.approx(raman="none", delta_eddington=True)
+        return case
+    monkeypatch.setenv("PICASO_AMD_NO_DRIVER", "1")
+    want = [make(k).spectrum(opa, calculation=calc, devices=devices) for k in range(2)]
+    assert "_driver_tables" not in opa.__dict__
+    monkeypatch.delenv("PICASO_AMD_NO_DRIVER")
+    got = [make(k).spectrum(opa, calculation=calc, devices=devices) for k in range(2)]
+    assert len(opa.__dict__["_driver_tables"]) == 1
+    for w, g in zip(want, got):
+        assert set(w) == set(g)
+        for key in w:
+            if isinstance(w[key], np.ndarray):
+                assert np.array_equal(w[key], g[key], equal_nan=True), key
+            else:
+                assert w[key] == g[key] or (w[key] != w[key] and g[key] != g[key]), key
+        assert all(np.isfinite(v).all() for v in g.values() if isinstance(v, np.ndarray))
