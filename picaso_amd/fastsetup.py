@@ -9,7 +9,6 @@ continua, nearest-neighbour tables, k-tables mixed on the fly, ``exclude_mol`` -
 mirror.  Premixed correlated-k tables (``RetrieveCKs``) are in scope from round 5: the same ragged-grid search with the
 k-table's row numbering, the bracketing continuum temperatures with their 1/T weight, ``mol_fac = colden / mmw``.  ``PICASO_AMD_PY_SETUP=1`` forces the mirror (A/B)."""
 import ctypes
-import os
 
 import numpy as np
 

@@ -13,15 +13,13 @@ Out of scope here: chemistry, virga clouds, stellar grids 
 relative flux vector), xarray I/O, climate, retrievals, phase curves, 3-D regridding.
 """
 import copy
-import ctypes
 
 import os
 
 import numpy as np
 
-from . import _lib, device, disco, fastsetup, optics, resident
+from . import _lib, disco, optics, resident
 from . import options as _options
-from .atmsetup import ATMSETUP, CloudTables
 from .device import DeviceArray
 from .options import Options                                                        # noqa: F401  (jdi.Options)
 from .spectrum import (Spectrum, setup_facets_3d, _atmosphere_block, _bond_denominator, _cloud_free_top, _constant_planes,   # noqa: F401
