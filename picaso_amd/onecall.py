@@ -343,11 +343,15 @@ def prepare_3d(bundle, opa, subs, calculation, opt, slot=None):
     if plan.get("premixed"):
         return None
     nlevel, nlayer = atm.c.nlevel, atm.c.nlayer
-    tabs_sig = None
+    tabs_sig = stamp3 = None
     if cld3 is not None:
-        first = optics._facet_major_cloud_tables(cld3, nlayer, nfac, subs[0][2].ctx)
-        if first is None:
+        if not isinstance(cld3, dict) or cld3.get("wavenumber") is None:
             return None             # cloud arrays on the opacity grid: the facet-fastest mixing launch (Spectrum)
+        # ONE digest of the tables per call (0.5 ms for 64 facets x 90 x 196 x 3), whatever the number of blocks
+        stamp3 = optics._table_fingerprint([cld3[k] for k in ("opd", "w0", "g0")], cld3["wavenumber"])
+        first = optics._facet_major_cloud_tables(cld3, nlayer, nfac, subs[0][2].ctx, stamp=stamp3)
+        if first is None:
+            return None
         tabs_sig = first[3]
     nmol, ncont, nray = len(plan["molecules"]), len(plan["cia_pairs"]), len(factors[2])
     if (nmol * 56 + ncont * 12 + nray * 8 + 8) * nfac * nlayer > 3600 * 1024:
@@ -385,7 +389,7 @@ def prepare_3d(bundle, opa, subs, calculation, opt, slot=None):
         k = table.blocks[b]
         _fill_block(k, sub, lo, hi, c)
         if cld3 is not None:        # the tall tables, resident per device (kept on the cloud dictionary by content)
-            d_xp, d_tall, _, nin = optics._facet_major_cloud_tables(cld3, nlayer, nfac, sub.ctx)
+            d_xp, d_tall, _, nin = optics._facet_major_cloud_tables(cld3, nlayer, nfac, sub.ctx, stamp=stamp3)
             hold.append((d_xp, d_tall))
             k.cld_tab_nin, k.cld_tab_xp, k.cld_tab_fp = nin, drv._dev(d_xp), drv._dev(d_tall)
             k.wno = drv._dev(_resident_vector(sub, "wno", sub.wno, hi - lo))

@@ -1154,7 +1154,7 @@ def _table_fingerprint(arrs, wavenumber):
     return tuple((id(a), content_digest(a)) for a in list(arrs) + [wavenumber])
 
 
-def _facet_major_cloud_tables(clouds_3d, nlayer, nfac, ctx):
+def _facet_major_cloud_tables(clouds_3d, nlayer, nfac, ctx, stamp=None):
     """Cloud tables on their own increasing wavenumber grid as resident ``(3, nfacets * nlayer, nin)`` rows in
     facet-major order (opd, w0, g0) with their grid, kept on the cloud dictionary while its arrays are the same
     objects.  None when the tables are not of that kind."""
@@ -1167,7 +1167,8 @@ def _facet_major_cloud_tables(clouds_3d, nlayer, nfac, ctx):
     if any(np.size(a) not in (nlayer * nin, nlayer * nin * nfac) for a in arrs):
         return None
     memo = _cloud_memo_get("tall", clouds_3d)
-    stamp = _table_fingerprint(arrs, clouds_3d["wavenumber"])
+    if stamp is None:               # (a caller that asks once per wavelength block digests the tables once and hands it in)
+        stamp = _table_fingerprint(arrs, clouds_3d["wavenumber"])
     if memo is None or memo[1] != stamp:
         order = np.argsort(in_wno, kind="stable") if np.any(np.diff(in_wno) < 0) else slice(None)
         tall = np.stack([np.moveaxis(np.broadcast_to(np.asarray(a, dtype=float).reshape(nlayer, nin, -1), (nlayer, nin, nfac)),

@@ -92,6 +92,13 @@ if os.environ.get("CLOUD3D"):         # ... and an 8-phase reflected curve with 
     pc.approx(raman="none")
     cmap = c3.inputs["clouds"]["profile_3d"]
     pc.phase_curve(opa, clouds_by_phase=[cmap] * P)
+    if os.environ.get("PROFILE_PC"):  # PROFILE_PC=1: cProfile of the cloudy curve
+        import cProfile, pstats
+        pr = cProfile.Profile()
+        pr.enable()
+        pc.phase_curve(opa, clouds_by_phase=[cmap] * P)
+        pr.disable()
+        pstats.Stats(pr).sort_stats("cumulative").print_stats(40)
     t0 = time.perf_counter()
     res = pc.phase_curve(opa, clouds_by_phase=[cmap] * P)
     out["phase_curve_reflected_%d_phases_cloudy_ms" % P] = round(1e3 * (time.perf_counter() - t0), 3)
