@@ -64,6 +64,53 @@ def kernel_source_hash():
     return h.hexdigest()[:16]
 
 
+def live_traffic(kernel_tag="k_reflected_toa<5", timeout_s=150.0):
+    """HBM bytes per launch of the headline kernel from the PMC counters, measured NOW: two short child runs of this
+    script under `rocprofv3 --pmc` (FETCH_SIZE and WRITE_SIZE in separate passes: both do not fit one TCC pass;
+    --kernel-trace only, no other trace domain), (2 * FETCH_SIZE + WRITE_SIZE) KB per dispatch -- FETCH_SIZE doubled per
+    the gfx950 correction of MI355X_MICROARCH.md (HBM / rocprofv3).  Returns (bytes, note) or (None, why not)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if any(k in os.environ for k in ("ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB", "ROCPROFILER_LIBRARY_CTOR",
+                                     "ROCPROF_OUTPUT_PATH")) or "rocprofiler" in os.environ.get("LD_PRELOAD", ""):
+        return None, "this process already runs under a profiler"
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if not exe:
+        return None, "rocprofv3 not found"
+    child = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--prewarm-ms", "0",
+             "--cpu-sample", "0", "--steady-steps", "0", "--secondary", "0", "--product", "0", "--traffic", "off"]
+    env = dict(os.environ, TMPDIR="/tmp")
+    means = {}
+    t0 = time.perf_counter()
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        out = tempfile.mkdtemp(prefix="picaso_pmc_", dir="/tmp")
+        try:
+            r = subprocess.run([exe, "--kernel-trace", "--output-format", "csv", "--pmc", ctr, "-d", out, "-o", "pmc",
+                                "--"] + child, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                               timeout=timeout_s)
+            n, tot = 0, 0.0
+            for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if row.get("Counter_Name") == ctr and kernel_tag in row.get("Kernel_Name", ""):
+                        n += 1
+                        tot += float(row.get("Counter_Value", 0))
+            if not n:
+                return None, "no %s rows for %s (rocprofv3 rc %d)" % (ctr, kernel_tag, r.returncode)
+            means[ctr] = (tot / n, n)
+        except Exception as e:       # a profiler that is missing a counter, hangs or dies must not take the bench line with it
+            return None, "%s pass failed: %s" % (ctr, str(e)[:200])
+        finally:
+            shutil.rmtree(out, ignore_errors=True)
+    nbytes = (2.0 * means["FETCH_SIZE"][0] + means["WRITE_SIZE"][0]) * 1024.0
+    return nbytes, ("measured in this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes of a child "
+                    "`bench.py --steps 3` (%d and %d dispatches of the kernel, %.0f s), (2 x FETCH_SIZE + WRITE_SIZE) KB per "
+                    "dispatch, FETCH_SIZE doubled per the gfx950 correction"
+                    % (means["FETCH_SIZE"][1], means["WRITE_SIZE"][1], time.perf_counter() - t0))
+
+
 # ---------------------------------------------------------------------------------------------
 # workloads: each returns a dict with solve(), the local result DeviceArray, algorithmic bytes of
 # the local launch, and how to check the result against the CPU oracle
@@ -820,6 +867,9 @@ def main():
     ap.add_argument("--batch", type=int, default=4, help="spectra per launch of the throughput_batched companion")
     ap.add_argument("--product", type=int, default=1,
                     help="with --secondary: also time inputs.spectrum() and spectrum_batch() end to end (product); 0 = skip")
+    ap.add_argument("--traffic", default="live", choices=("live", "committed", "off"),
+                    help="roofline.traffic: 'live' = two rocprofv3 --pmc passes of a short child run, now (falls back to the "
+                         "committed profiles/traffic.json when the profiler is not usable); 'committed' = that file only")
     ap.add_argument("--spawn", action="store_true",
                     help="start the ranks as subprocesses also for --gpus 1 (the N > 1 code path -- rendezvous, RCCL "
                          "communicator, gather in the timed region, checks -- with one rank, on a 1-GPU box)")
@@ -1002,14 +1052,25 @@ def main():
         traffic = valu = None
         tfile = os.path.join(ROOT, "profiles", "traffic.json")
         src_hash = kernel_source_hash()
+        traffic_source = traffic_committed = None
         if args.config == 2 and world == 1 and nwno == 100000 and args.nlayer == 90 and args.ngauss == 5 \
-                and os.path.exists(tfile):
+                and os.path.exists(tfile) and args.traffic != "off":
             try:
                 prof = json.load(open(tfile))
                 if prof.get("kernel_source_hash") == src_hash:     # counters of THESE kernel sources only
                     traffic, valu = prof.get("hbm_bytes_per_launch"), prof.get("valu_wave_insts_per_launch")
+                    traffic_committed = traffic
+                    traffic_source = ("profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of these "
+                                      "kernel sources, committed; not measured in this run)")
             except Exception:
                 traffic = valu = None
+            if args.traffic == "live":
+                device.sync(ctx)
+                live, note = live_traffic()
+                if live is not None:
+                    traffic, traffic_source = live, note
+                elif traffic_source:
+                    traffic_source += "; live pass not taken: " + note
         out = {
             "metric": wl["metric"] if args.config != 2 else "spectra/sec (1e5 wave x 90 layer reflected)",
             "value": value, "unit": "spectra/s", "n_gpus": world, "steps": args.steps,
@@ -1028,9 +1089,7 @@ def main():
             "wavelength_layer_updates_per_s": value * nwno_total / spectra_per_step * args.nlayer,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_source": ("profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
-                                            "these kernel sources, committed; not measured in this run)"
-                                            if traffic is not None else None),
+                         "traffic_source": traffic_source, "traffic_committed": traffic_committed,
                          "kernel": wl["kernel"], "kernel_ms": kernel_ms, "algorithmic_bytes": abytes,
                          "kernel_source_hash": src_hash},
         }
