@@ -443,6 +443,21 @@ int picaso_get_thermal_SH_dev(picaso_ctx *ctx, int nlevel, const double *wno, in
                               int cosb_differs_from_cosb_og, int flx, double *xint_at_top,
                               const double *gweight, const double *tweight, double *flux_disk);
 
+/* ---- Planck-function tables ------------------------------------------------------------------ */
+/* replaces fluxes.blackbody(t, w) (reference picaso/fluxes.py:1660-1680): Planck function per unit wavelength, cgs,
+ * `t` (ntemp) in K, `w_cm` (nwave) WAVELENGTH in cm; out (ntemp, nwave) C-order.  An exponential that overflows gives 0
+ * (numpy's 1/(inf - 1)).  The solvers evaluate the same device function level by level and never read such a table
+ * (fluxes.py:1752); the entry point is for callers that use blackbody() on its own (brightness temperatures). */
+int picaso_blackbody(picaso_ctx *ctx, int ntemp, const double *t, long nwave, const double *w_cm, double *out);
+int picaso_blackbody_dev(picaso_ctx *ctx, int ntemp, const double *t, long nwave, const double *w_cm, double *out);
+/* replaces fluxes.blackbody_integrated(T, wave, dwave) (reference picaso/fluxes.py:1609-1658): mean of the wavenumber
+ * Planck function at wave - dwave/2, wave, wave + dwave/2 (nbb = 1), what get_thermal_1d(calc_type=1) uses
+ * (fluxes.py:1754); `wave`, `dwave` (nwave) in cm^-1; out (ntemp, nwave). */
+int picaso_blackbody_integrated(picaso_ctx *ctx, int ntemp, const double *T, long nwave, const double *wave,
+                                const double *dwave, double *out);
+int picaso_blackbody_integrated_dev(picaso_ctx *ctx, int ntemp, const double *T, long nwave, const double *wave,
+                                    const double *dwave, double *out);
+
 /* ---- disk quadrature ----------------------------------------------------------------------- */
 /* replaces disco.compress_disco (reference picaso/disco.py:117-149) */
 int picaso_compress_disco(picaso_ctx *ctx, int nwno, double cos_theta, const double *xint_at_top,

@@ -313,3 +313,26 @@ def mix_all_gases_gasesfly(kappas, mixes, gauss_pts, gauss_wts, indices):
         ctypes.c_int(nk), _p(mx), _p(_a(gauss_pts)), _p(_a(gauss_wts)),
         idx.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), ctypes.c_int(nlayer), _p(out)), "mix_all_gases_gasesfly")
     return out
+
+
+def blackbody(t, w):
+    """Planck function per unit wavelength, cgs, (ntemp, nwave) -- restates fluxes.blackbody, reference
+    picaso/fluxes.py:1660-1680 (numpy: the reference's own expression under numba)."""
+    h, c, k = 6.62607004e-27, 2.99792458e+10, 1.38064852e-16
+    t, w = np.atleast_1d(np.asarray(t, float)), np.atleast_1d(np.asarray(w, float))
+    with np.errstate(over="ignore"):
+        return ((2.0 * h * c ** 2.0) / (w ** 5.0)) * (1.0 / (np.exp((h * c) / np.outer(t, w * k)) - 1.0))
+
+
+def blackbody_integrated(T, wave, dwave):
+    """Three-point bin mean of the wavenumber Planck function, (ntemp, nwave) -- restates fluxes.blackbody_integrated,
+    reference picaso/fluxes.py:1609-1658 (nbb = 1: wave - dwave/2, wave, wave + dwave/2, summed in that order)."""
+    h, c, k = 6.62607004e-27, 2.99792458e+10, 1.38064852e-16
+    c1, c2 = 2 * h * c ** 2, h * c / k
+    T, wave, dwave = (np.atleast_1d(np.asarray(x, float)) for x in (T, wave, dwave))
+    s = np.zeros((T.size, wave.size))
+    with np.errstate(over="ignore"):
+        for kk in (-1, 0, 1):
+            wn = wave + kk * dwave / 2.0
+            s += c1 * (wn ** 3) / (np.exp(c2 * wn[None, :] / T[:, None]) - 1)
+    return s / 3.0

@@ -182,3 +182,61 @@ def get_transit_1d(z, dz, nlevel, nwno, rstar, mmw, k_b, amu, player, tlayer, co
         ptr(f64(mmw, (nlevel - 1,))), _cd(k_b), _cd(amu), ptr(f64(player)), ptr(f64(tlayer)),
         ptr(f64(colden, (nlevel - 1,))), ptr(d), ptr(out)), ctx)
     return out
+
+
+def blackbody(t, w):
+    """Planck function per unit wavelength in cgs (reference ``fluxes.blackbody``, fluxes.py:1660-1680): ``t`` in K,
+    ``w`` WAVELENGTH in cm; returns ``(ntemp, nwave)``.  The same device function the thermal solvers evaluate level by
+    level (``get_thermal_1d`` forms ``blackbody(tlevel, 1/wno)``, fluxes.py:1752)."""
+    ctx = context()
+    t_ = np.ascontiguousarray(np.atleast_1d(t), dtype=np.float64).ravel()
+    w_ = np.ascontiguousarray(np.atleast_1d(w), dtype=np.float64).ravel()
+    out = np.zeros((t_.size, w_.size))
+    check(load().picaso_blackbody(ctx, _ci(t_.size), ptr(t_), ctypes.c_long(w_.size), ptr(w_), ptr(out)), ctx)
+    return out
+
+
+def blackbody_integrated(T, wave, dwave):
+    """Mean of the wavenumber Planck function over each bin (three points: centre and both edges), the climate
+    calculation's blackbody (reference ``fluxes.blackbody_integrated``, fluxes.py:1609-1658): ``T`` in K, ``wave`` and
+    ``dwave`` in cm^-1; returns ``(ntemp, nwave)``."""
+    ctx = context()
+    t_ = np.ascontiguousarray(np.atleast_1d(T), dtype=np.float64).ravel()
+    w_ = np.ascontiguousarray(np.atleast_1d(wave), dtype=np.float64).ravel()
+    d_ = f64(np.atleast_1d(dwave), (w_.size,))
+    out = np.zeros((t_.size, w_.size))
+    check(load().picaso_blackbody_integrated(ctx, _ci(t_.size), ptr(t_), ctypes.c_long(w_.size), ptr(w_), ptr(d_),
+                                             ptr(out)), ctx)
+    return out
+
+
+def chapman(pressure, pm, hratio):
+    """Chapman function of the tidal / energy-injection profile (reference ``fluxes.chapman``, fluxes.py:3731-3751).
+    Host arithmetic: ``nlevel`` numbers per climate run, nothing for a GPU."""
+    x = pressure / pm
+    return np.exp(1.0 + hratio * np.log(x) - x ** hratio)
+
+
+def tidal_flux(T_e, nlevel, pressure, col_den, InjectionBundle):
+    """Tidal (internal + injected) flux at every level (reference ``fluxes.tidal_flux``, fluxes.py:3671-3729):
+    ``-sigma T_e**4`` plus the running sum of the injected energy (a Chapman profile times the column density, or the
+    caller's ``beam_profile``), rescaled to the total ``wave_in`` / ``sum(beam_profile)``.  ``InjectionBundle`` carries
+    ``inject_beam, beam_profile, pm, hratio, wave_in`` as in the reference.  Host arithmetic (a recurrence over
+    ``nlevel`` numbers, in the reference's operation order); like the reference, levels 0 and 1 stay at zero before the
+    rescaling and a profile that injects nothing divides by zero."""
+    sigma_sb = 0.56687e-4
+    tide = -sigma_sb * (T_e ** 4)
+    T_tot = 0.0
+    tidal = np.zeros(nlevel)
+    if InjectionBundle.inject_beam == True:  # noqa: E712  (the reference's test: a numpy bool counts)
+        beam = InjectionBundle.beam_profile
+        for j in range(2, nlevel):
+            tidal[j] = tidal[j - 1] - beam[j]
+            T_tot += tidal[j] - tidal[j - 1]
+        total = np.sum(beam)
+    else:
+        for j in range(2, nlevel):
+            tidal[j] = tidal[j - 1] - chapman(pressure[j], InjectionBundle.pm, InjectionBundle.hratio) * col_den[j - 1]
+            T_tot += tidal[j] - tidal[j - 1]
+        total = InjectionBundle.wave_in
+    return (tidal * total / T_tot) + tide - (tidal[-1] * total / T_tot)

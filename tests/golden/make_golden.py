@@ -1056,3 +1056,34 @@ if __name__ == "__main__" and (("sh_extra" in sys.argv[1:]) or not sys.argv[1:])
     make_sh_extra()
 if __name__ == "__main__" and (("ck_rt" in sys.argv[1:]) or not sys.argv[1:]):
     make_ck_rt()
+
+
+def make_planck():
+    """fluxes.blackbody / blackbody_integrated / chapman / tidal_flux (fluxes.py:1609-1680, 3671-3751) on seeded
+    inputs that include an overflowing exponential (cold level, short wavelength)."""
+    import collections
+    rng = np.random.default_rng(77)
+    t = np.concatenate([[40.0, 68.0], np.sort(rng.uniform(75.0, 3200.0, 19))])
+    wno = np.sort(rng.uniform(30.0, 33000.0, 57))[::-1].copy()
+    dwno = np.abs(np.gradient(wno)) * rng.uniform(0.6, 1.4, wno.size)
+    store = dict(t=t, wno=wno, dwno=dwno, w_cm=1.0 / wno)
+    with np.errstate(over="ignore"):
+        store["blackbody"] = fl.blackbody(t, 1.0 / wno)
+        store["blackbody_integrated"] = fl.blackbody_integrated(t, wno, dwno)
+    nlevel = 31
+    pressure = np.logspace(-6, 2, nlevel)
+    col_den = rng.uniform(0.5, 2.0, nlevel - 1) * np.diff(pressure) * 1e3
+    store.update(pressure=pressure, col_den=col_den)
+    Bundle = collections.namedtuple("InjectionBundle", "inject_beam beam_profile pm hratio wave_in")
+    beam = rng.uniform(0.0, 5.0e3, nlevel)
+    store["beam_profile"] = beam
+    store["chapman"] = np.array([fl.chapman(p, 0.01, 1.7) for p in pressure])
+    store["tidal_chapman"] = fl.tidal_flux(450.0, nlevel, pressure, col_den, Bundle(False, None, 0.01, 1.7, 2.5e6))
+    store["tidal_beam"] = fl.tidal_flux(450.0, nlevel, pressure, col_den, Bundle(True, beam, 0.0, 0.0, 0.0))
+    path = os.path.join(HERE, "planck.npz")
+    np.savez_compressed(path, **store)
+    print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024))
+
+
+if __name__ == "__main__" and (("planck" in sys.argv[1:]) or not sys.argv[1:]):
+    make_planck()
