@@ -168,7 +168,40 @@ def workload_reflected(ctx, args, lo, hi, seed, nwno_total, scene=None):
                                         [x["F0PI"] for x in sets], 3, 0, *TTHG, xs, gweight=gw, tweight=tw, albedo=albs)
         return launch, albs
 
+    def solve_batch_distinct(B):
+        """B DIFFERENT atmospheres in one launch: what a retrieval's batch is.  Member 0 is the headline scene; the others
+        are drawn afresh (own gas field, own cloud) with the cloud slab moved up or down by 6 layers per member and every
+        third member cloud-free, so the per-wave shortcut flags of the layer body (cloud in this layer or not, delta-scaled
+        or not) differ between the members of one launch.  Returns (launch, albedo arrays, the same members one by one)."""
+        sets = [d]
+        for m in range(1, B):
+            comps = list(syn.tau_components(nlayer, n, syn.BASE_SEED + seed + 100 + m, cloud=(m % 3 != 2),
+                                            gas_scale=1.0 + 0.15 * m))
+            shift = 6 * ((m + 1) // 2) * (1 if m % 2 else -1)
+            comps[2:] = [np.roll(c, shift, axis=0) for c in comps[2:]]
+            sc = syn.mix_planes(*comps)
+            sc["F0PI"], sc["surf_reflect"] = scene["F0PI"][lo:hi], scene["surf_reflect"][lo:hi]
+            sets.append(resident.upload_scene(sc, keys, ctx=ctx))
+        xs = [device.DeviceArray((ng, 1, n), ctx) for _ in range(B)]
+        albs = [device.DeviceArray((n,), ctx) for _ in range(B)]
+
+        def launch():
+            resident.reflected_1d_batch(ctx, nlevel, n, ng, 1, sets, [x["surf_reflect"] for x in sets], ubar0, ubar1, 1.0,
+                                        [x["F0PI"] for x in sets], 3, 0, *TTHG, xs, gweight=gw, tweight=tw, albedo=albs)
+
+        def singles():
+            out = []
+            x1, a1 = device.DeviceArray((ng, 1, n), ctx), device.DeviceArray((n,), ctx)
+            for x in sets:
+                resident.reflected_1d(ctx, nlevel, n, ng, 1, x, x["surf_reflect"], ubar0, ubar1, 1.0, x["F0PI"], 3, 0,
+                                      *TTHG, x1, toon_coefficients=0, b_top=0.0, gweight=gw, tweight=tw, albedo=a1)
+                device.sync(ctx)
+                out.append(a1.to_host())
+            return out
+        return launch, albs, singles
+
     return dict(solve=solve, oracle=oracle, nloc=n, scene=scene, solve_batch=solve_batch,
+                solve_batch_distinct=solve_batch_distinct,
                 abytes=8 * n * (9 * nlayer + 2 * nlevel + 2 + ng + 1),
                 # launches of at most one 64-column block per CU (256 CUs) run the cooperative kernel (api.hip)
                 kernel=("k_reflected_coop<true>" if n <= 16384 and ng <= 5 and not os.environ.get("PICASO_AMD_REFL_NO_COOP")
@@ -477,6 +510,24 @@ def companions(ctx, args, wl, res_single, nwno_total):
         "roofline_frac": wl["abytes"] / (ms / B2 * 1e-3) / 1e9 / HBM_PEAK_GBS,
         "bit_identical_to_single_launch": all(bool(np.array_equal(a.to_host(), res_single)) for a in albs)}
     del launch, albs
+    # the same launch with B DIFFERENT atmospheres (own gas field, cloud slab at another height or none): the members'
+    # wave-uniform shortcut flags diverge inside one launch, as in a retrieval's batch
+    if "solve_batch_distinct" in wl:
+        launch, albs, singles = wl["solve_batch_distinct"](B)
+        ms = steady_ms(ctx, launch, max(10, 200 // B), prewarm_ms=100.0)
+        got = [a.to_host() for a in albs]
+        one = singles()
+        extra["throughput_batched"]["distinct_atmospheres"] = {
+            "value": 1e3 * B / ms, "batch": B, "ms_per_spectrum": ms / B,
+            "roofline_frac": wl["abytes"] / (ms / B * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "each_member_bit_identical_to_its_own_single_launch": all(bool(np.array_equal(g, o)) for g, o in zip(got, one)),
+            "finite": all(bool(np.all(np.isfinite(g))) for g in got),
+            "what": "B = %d different atmospheres in one launch: member 0 the headline scene, the others their own gas "
+                    "fields with the cloud slab 6 layers higher / lower per member, every third member cloud-free" % B}
+        if not extra["throughput_batched"]["distinct_atmospheres"]["each_member_bit_identical_to_its_own_single_launch"]:
+            print("bench.py: CHECK FAILED: a member of the distinct-atmosphere batch differs from its own launch",
+                  file=sys.stderr)
+        del launch, albs, singles
 
     def entry(w, ms_, n_oracle=256, res=None):
         e = {"ms": ms_, "kernel": w["kernel"], "algorithmic_bytes": w["abytes"],
