@@ -557,6 +557,20 @@ def companions(ctx, args, wl, res_single, nwno_total):
         "workload": "configs[1], 16 atmospheres per launch (picaso_get_thermal_1d_batch_dev): 16 plane sets in their own HBM "
                     "allocations, 16 level-temperature profiles; ms per spectrum"}
     del launch1, dk, w1
+    # BASELINE.md section 3 asks for the thermal workload at 1e5 and 1e6 wavelengths as well: the headline scene's own
+    # thermal planes, and ten copies of them side by side (a 1e6-column scene would take the host a minute to draw)
+    for nth, reps in ((nwno_total, 1), (10 * nwno_total, 10)):
+        if nwno_total != 100000:
+            break
+        sct = {k: (np.tile(scene[k], (1, reps)) if scene[k].ndim == 2 else np.tile(scene[k], reps))
+               for k in ("dtau_og", "w0_no_raman", "cosb_og", "wno")}
+        sct["tlevel"], sct["plevel"] = scene["tlevel"], scene["plevel"]
+        wt = workload_thermal(ctx, a1, 0, nth, 3, nth, scene=sct)
+        outt = device.DeviceArray((nth,), ctx)
+        mst = steady_ms(ctx, lambda: wt["solve"](outt), 100 if reps == 1 else 20, prewarm_ms=100.0)
+        sec["configs[1] at %d wavelengths" % nth] = entry(wt, mst, n_oracle=128, res=outt.to_host())
+        sec["configs[1] at %d wavelengths" % nth]["wavelength_layer_updates_per_s"] = nth * args.nlayer / (mst * 1e-3)
+        del wt, outt, sct
     # configs[2], the 12 500-column block one of 8 GPUs solves
     w2 = workload_reflected(ctx, args, 0, 12500, 3, nwno_total, scene=scene)
     out2 = device.DeviceArray((12500,), ctx)
