@@ -49,6 +49,10 @@ int picaso_dev_free(picaso_ctx *ctx, void *dptr);
 /* picaso_dev_free keeps blocks for reuse by later picaso_dev_malloc calls of the same size (reuse is
  * ordered on the context's stream); this returns all cached blocks to the driver. */
 int picaso_pool_trim(picaso_ctx *ctx);
+/* what the context holds right now: out[0..5] = bytes and blocks handed out by picaso_dev_malloc (live), bytes and blocks
+ * cached for reuse (free, capped at 64 GB; picaso_pool_trim returns them), bytes and blocks of pinned host memory
+ * (handed out + cached).  For a long-running caller (a retrieval) that wants to see a leak as a number. */
+int picaso_ctx_mem_stats(picaso_ctx *ctx, size_t *out6);
 int picaso_memcpy_h2d(picaso_ctx *ctx, void *dst, const void *src, size_t bytes);
 int picaso_memcpy_d2h(picaso_ctx *ctx, void *dst, const void *src, size_t bytes);
 int picaso_memcpy_d2d(picaso_ctx *ctx, void *dst, const void *src, size_t bytes);

@@ -326,6 +326,21 @@ int picaso_dev_free(picaso_ctx *ctx, void *dptr)
     ctx->pool_bytes += size;
     return 0;
 }
+int picaso_ctx_mem_stats(picaso_ctx *ctx, size_t *out6)
+{
+    if (!ctx || !out6) return fail(ctx, "picaso_ctx_mem_stats: null argument");
+    size_t live = 0, hbytes = 0;
+    for (const auto &kv : ctx->live) live += kv.second;
+    for (const auto &kv : ctx->host_live) hbytes += kv.second;
+    for (const auto &kv : ctx->host_pool) hbytes += kv.first;
+    out6[0] = live;
+    out6[1] = ctx->live.size();
+    out6[2] = ctx->pool_bytes;
+    out6[3] = ctx->pool.size();
+    out6[4] = hbytes;
+    out6[5] = ctx->host_live.size() + ctx->host_pool.size();
+    return 0;
+}
 int picaso_pool_trim(picaso_ctx *ctx)
 {
     if (!ctx) return fail(nullptr, "null context");

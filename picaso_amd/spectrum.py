@@ -786,6 +786,10 @@ class Spectrum:
             if "thermal" in returns and "thermal" not in out:
                 _post_thermal(out, returns, self.wno, self.stellar, self.radius_star, atm.planet.radius, self.opa)
         del self.keep_alive[:]
+        # the collectors are closures over `self`: dropping them breaks the reference cycle, so that this object -- and the
+        # device arrays it owns -- go when the caller lets go of it, not when Python's cycle collector next runs (a
+        # retrieval loop otherwise piles up hundreds of dead planes between two collections: tools/leak_check.py)
+        self.collect = []
         if self.raw:          # one wavelength block of a multi-GPU spectrum: the integrals need the whole grid
             if self.full_output:
                 returns["full_output"] = atm.as_dict() if self.as_dict else atm
