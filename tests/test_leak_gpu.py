@@ -1,5 +1,5 @@
 """A retrieval-shaped loop leaves nothing to Python's cycle collector: every device array of a finished spectrum() /
-spectrum_batch() / 3-D call goes when the caller lets go of the result (tools/leak_check.py: nine kinds of calls, every
+spectrum_batch() / 3-D call goes when the caller lets go of the result (tools/leak_check.py: thirteen kinds of calls, every
 call with new inputs).  Before round 5's fix a finished ``spectrum.Spectrum`` sat in a reference cycle with its own
 collectors, and hundreds of dead planes piled up between two collections (GBs at 1e5 wavelengths)."""
 import os
@@ -18,7 +18,7 @@ def test_no_device_arrays_wait_for_the_cycle_collector(capsys):
     gc.collect()
     gc.disable()                 # nothing may be hidden by a collection that happens to run inside the loop
     try:
-        rc = leak_check.main(["--calls", "90", "--nwno", "3000", "--cycles-only"])
+        rc = leak_check.main(["--calls", "91", "--nwno", "3000", "--cycles-only"])
     finally:
         if was:
             gc.enable()

@@ -63,6 +63,21 @@ def main(argv=None):
     opa = px.RetrieveOpacities(wno, pt, molecular, continuum, cia_t, rayleigh_opa=ray, query_method="linear", ctx=ctx)
     plev = np.logspace(-6, 2, nlevel)
     rng = np.random.default_rng(11)
+    # premixed correlated-k tables (661 bins x 8 Gauss points), as bench.py's product.correlated_k
+    nb, nk = 661, 8
+    wck = np.linspace(40.0, 28000.0, nb)
+    xg, wg = np.polynomial.legendre.leggauss(4)
+    gpts = np.concatenate([0.95 * 0.5 * (xg + 1), 0.95 + 0.05 * 0.5 * (xg + 1)])
+    gwts = np.concatenate([0.95 * 0.5 * wg, 0.05 * 0.5 * wg])
+    tk, pk = np.array(temps), np.array(press)
+    lnk = np.log(10.0) * (-26.0 + 2.0 * np.sin(wck / 2500.0)[None, None, :, None] + 0.5 * np.log10(pk)[:, None, None, None]
+                          + 0.9 * np.log10(tk / 300.0)[None, :, None, None] + 0.6 * np.arange(nk)[None, None, None, :])
+    cont = {pr: {t: 10.0 ** (-7.0 + np.cos(wck / 4000.0 + k) + 0.3 * np.log10(t / 300.0)) for t in cia_t}
+            for k, pr in enumerate(("H2H2", "H2He"))}
+    opk = px.RetrieveCKs(wck, gwts, np.tile(pk, tk.size), np.repeat(tk, pk.size), np.full(tk.size, pk.size), lnk,
+                         continuum=cont, cia_temps=cia_t, rayleigh_opa={m: 1e-27 * (wck / 1e4) ** 4 for m in ("H2", "He")},
+                         gauss_pts=gpts, ctx=ctx)
+    NKIND = 13
     kinds = {}
 
     def one(i):
@@ -73,7 +88,7 @@ def main(argv=None):
                 "H2O": np.full(nlevel, 1e-3 * (1 + rng.random())), "CH4": np.full(nlevel, 5e-4 * (1 + rng.random())),
                 "CO": np.full(nlevel, 1e-4), "NH3": np.full(nlevel, 1e-5)}
         case = jdi.inputs()
-        kind = i % 9
+        kind = i % NKIND
         if kind == 6:                # spectrum_batch: three atmospheres of a retrieval's batch
             cases = []
             for _ in range(3):
@@ -86,6 +101,26 @@ def main(argv=None):
             rb = jdi.spectrum_batch(cases, opa, calculation="reflected+thermal", batch_size=3)
             kinds[kind] = kinds.get(kind, 0) + 1
             return all(np.all(np.isfinite(r["albedo"])) and np.all(np.isfinite(r["thermal"])) for r in rb)
+        if kind in (9, 10):          # k-tables: Toon and SH4 inside the Gauss loop; 11: an 8-phase... a 2-phase thermal curve
+            c = jdi.inputs()
+            c.phase_angle(0)
+            c.gravity(gravity=2500.0)
+            c.atmosphere(df=prof)
+            c.approx(**({"raman": "none"} if kind == 9 else {"raman": "none", "rt_method": "SH", "stream": 4}))
+            r = c.spectrum(opk, calculation="reflected+thermal")
+            kinds[kind] = kinds.get(kind, 0) + 1
+            return bool(np.all(np.isfinite(r["albedo"])) and np.all(np.isfinite(r["thermal"])))
+        if kind == 11:
+            pert = 1.0 + 0.1 * np.cos(np.arange(16).reshape(4, 4) + rng.random())
+            pc = jdi.inputs()
+            pc.phase_curve_geometry("thermal", [0.4, 2.0], num_gangle=4, num_tangle=4)
+            pc.gravity(gravity=2500.0)
+            pc.atmosphere_4d([dict(prof, temperature=prof["temperature"][:, None, None] * (pert[None] + 0.01 * k))
+                              for k in range(2)])
+            pc.approx(raman="none")
+            curve = pc.phase_curve(opk)
+            kinds[kind] = kinds.get(kind, 0) + 1
+            return all(np.all(np.isfinite(v["thermal"])) for v in curve.values())
         if kind == 7:                # 3-D: 4 x 4 facets, per-facet temperatures, a cloud map on its own grid every other call
             pert = 1.0 + 0.1 * np.cos(np.arange(16).reshape(4, 4) + rng.random())
             c3 = jdi.inputs()
@@ -126,7 +161,7 @@ def main(argv=None):
                       semi_major=7.5e12)
             case.gravity(radius=7.1e9, mass=1.9e30)
             calc = "reflected+thermal+transmission"
-        r = case.spectrum(opa, calculation=calc)
+        r = case.spectrum(opa, calculation=calc, devices=[0, 0] if kind == 12 else None)   # 12: two wavelength blocks
         kinds[kind] = kinds.get(kind, 0) + 1
         ok = all(np.all(np.isfinite(v)) for v in r.values() if isinstance(v, np.ndarray) and v.dtype == np.float64)
         return ok
@@ -135,6 +170,7 @@ def main(argv=None):
     t0 = time.perf_counter()
     finite = True
     every = max(1, args.calls // 30)
+    assert args.calls >= NKIND
     for i in range(args.calls):
         finite = one(i) and finite
         if i % every == 0 or i == args.calls - 1:
