@@ -4,8 +4,10 @@ The HIP library is the product: if ``libpicaso_hip.so`` is missing, or no MI355X
 a compute entry point is called, this module raises -- there is no CPU fallback.
 """
 import ctypes
+import functools
 import os
 import re
+import threading
 
 import numpy as np
 
@@ -97,6 +99,24 @@ def context(device=None):
                                  % lib.picaso_last_error(None).decode())
         _ctx[key] = h
     return _ctx[key]
+
+
+# One product call at a time per process.  A spectrum is dozens of C calls that share the context's stream, staging
+# arena and block pool and the workspaces kept with the opacity object; two Python threads inside spectrum() at once
+# interleave them (ctypes releases the GIL during a C call) and read each other's planes -- measured: wrong spectra
+# and "block still has uncollected results" (tools/scratch/threads_probe.py).  The reference fans out with PROCESSES
+# (joblib, justdoit.py:4774); here threads are safe but serialised -- parallelism is the batch axis, devices=N, or one
+# process per GPU.  Re-entrant: the public functions call each other.
+CALL_LOCK = threading.RLock()
+
+
+def serialized(fn):
+    """Decorator of the public entry points: the call runs under ``CALL_LOCK``."""
+    @functools.wraps(fn)
+    def locked(*args, **kwargs):
+        with CALL_LOCK:
+            return fn(*args, **kwargs)
+    return locked
 
 
 def new_context(device=None):

@@ -34,6 +34,7 @@ Disco_Tuple = namedtuple("Disco_Tuple", ["ng", "nt", "gweight", "tweight", "ubar
 Opagrid_Tuple = namedtuple("Opagrid_Tuple", ["nwno", "delta_wno", "wno", "ngauss", "gauss_wts"])
 
 
+@_lib.serialized
 def calculate_atm(bundle, opacityclass, only_atmosphere=False):
     """Atmosphere set-up and opacities of one climate iteration (reference ``climate.calculate_atm``,
     climate.py:1969-2135): returns ``OpacityWEd, OpacityNoEd, ScatteringPhase, Disco, Atmosphere,
@@ -109,6 +110,7 @@ def _resident_small(values, ctx):
     return hit
 
 
+@_lib.serialized
 def get_fluxes(Atmosphere, OpacityWEd, OpacityNoEd, ScatteringPhase, Disco, Opagrid, F0PI, reflected, thermal,
                do_holes=False, fhole=0.0, hole_OpacityWEd=None, hole_OpacityNoEd=None, ctx=None,
                copy_outputs=False):
@@ -214,6 +216,7 @@ def get_fluxes(Atmosphere, OpacityWEd, OpacityNoEd, ScatteringPhase, Disco, Opag
             flux_plus_ir, flux_minus_ir)
 
 
+@_lib.serialized
 def get_fluxes_tbatch(temperatures, Atmosphere, OpacityWEd, OpacityNoEd, ScatteringPhase, Disco, Opagrid, ctx=None,
                       chunk=32, nets_only=False):
     """The IR half of ``get_fluxes`` (``reflected=False, thermal=True``) for every level-temperature profile in

@@ -44,6 +44,7 @@ def clear_table_cache():
     _tables.clear()
 
 
+@_lib.serialized
 def mix_all_gases_gasesfly(kappas, mixes, gauss_pts, gauss_wts, indices, ctx=None):
     """``kappas``: list of ``(npres, ntemp, nwno, ngauss)`` ln(kappa) arrays, ``mixes``: list of per-layer
     mixing ratios, ``indices`` = [p_low, p_hi, t_low, t_hi] per layer (``get_mixing_indices``).

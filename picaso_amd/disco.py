@@ -7,7 +7,7 @@ import ctypes
 
 import numpy as np
 
-from ._lib import check, context, f64, load, per_wave, ptr
+from ._lib import check, context, f64, load, per_wave, ptr, serialized
 
 # Half-sphere Gauss abscissae/weights, Abramowitz & Stegun Table 25.8 (k = 0), n = 5..8
 # (the same table the reference hard-codes, disco.py:67-84).
@@ -59,6 +59,7 @@ def compute_disco(ng, nt, gangle, tangle, phase_angle):
     return ubar0, ubar1, cos_theta, latitude, longitude
 
 
+@serialized
 def compress_disco(nwno, cos_theta, xint_at_top, gweight, tweight, F0PI):
     """Disk-integrated albedo (reference disco.py:117-149)."""
     ctx = context()
@@ -72,6 +73,7 @@ def compress_disco(nwno, cos_theta, xint_at_top, gweight, tweight, F0PI):
     return out
 
 
+@serialized
 def compress_thermal(nwno, flux_at_top, gweight, tweight):
     """Disk-integrated thermal flux; 3-D ``(ng,nt,nwno)`` or 4-D ``(ng,nt,nlevel,nwno)`` input
     (reference disco.py:151-181)."""

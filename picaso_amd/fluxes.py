@@ -10,11 +10,12 @@ import ctypes
 
 import numpy as np
 
-from ._lib import check, context, f64, load, per_wave, ptr
+from ._lib import check, context, f64, load, per_wave, ptr, serialized
 
 _ci, _cd = ctypes.c_int, ctypes.c_double
 
 
+@serialized
 def get_reflected_1d(nlevel, wno, nwno, numg, numt, dtau, tau, w0, cosb, gcos2, ftau_cld, ftau_ray,
                      dtau_og, tau_og, w0_og, cosb_og, surf_reflect, ubar0, ubar1, cos_theta, F0PI,
                      single_phase, multi_phase, frac_a, frac_b, frac_c, constant_back,
@@ -48,6 +49,7 @@ def get_reflected_1d(nlevel, wno, nwno, numg, numt, dtau, tau, w0, cosb, gcos2, 
     return xint, tuple(lvl)
 
 
+@serialized
 def get_reflected_3d(nlevel, wno, nwno, numg, numt, dtau_3d, tau_3d, w0_3d, cosb_3d, gcos2_3d,
                      ftau_cld_3d, ftau_ray_3d, dtau_og_3d, tau_og_3d, w0_og_3d, cosb_og_3d,
                      surf_reflect, ubar0, ubar1, cos_theta, F0PI, single_phase, multi_phase, frac_a,
@@ -68,6 +70,7 @@ def get_reflected_3d(nlevel, wno, nwno, numg, numt, dtau_3d, tau_3d, w0_3d, cosb
     return xint
 
 
+@serialized
 def get_thermal_1d(nlevel, wno, nwno, numg, numt, tlevel, dtau, w0, cosb, plevel, ubar1,
                    surf_reflect, hard_surface, dwno, calc_type, want_lvl=True):
     """Toon89 thermal emission, 1-D (reference ``fluxes.get_thermal_1d``, fluxes.py:1682-1912).
@@ -90,6 +93,7 @@ def get_thermal_1d(nlevel, wno, nwno, numg, numt, tlevel, dtau, w0, cosb, plevel
     return flux, tuple(lvl)
 
 
+@serialized
 def get_thermal_3d(nlevel, wno, nwno, numg, numt, tlevel_3d, dtau_3d, w0_3d, cosb_3d, plevel_3d,
                    ubar1, surf_reflect, hard_surface):
     """Toon89 thermal emission with per-facet profiles (reference ``fluxes.get_thermal_3d``,
@@ -107,6 +111,7 @@ def get_thermal_3d(nlevel, wno, nwno, numg, numt, tlevel_3d, dtau_3d, w0_3d, cos
     return out
 
 
+@serialized
 def get_reflected_SH(nlevel, nwno, numg, numt, dtau, tau, w0, cosb, ftau_cld, ftau_ray, f_deltaM,
                      dtau_og, tau_og, w0_og, cosb_og, surf_reflect, ubar0, ubar1, cos_theta, F0PI,
                      w_single_form, w_multi_form, psingle_form, w_single_rayleigh, w_multi_rayleigh,
@@ -149,6 +154,7 @@ def get_reflected_SH(nlevel, nwno, numg, numt, dtau, tau, w0, cosb, ftau_cld, ft
     return xint, flux
 
 
+@serialized
 def get_thermal_SH(nlevel, wno, nwno, numg, numt, tlevel, dtau, tau, w0, cosb, dtau_og, tau_og,
                    w0_og, w0_no_raman, cosb_og, plevel, ubar1, surf_reflect, stream, hard_surface,
                    flx=0):
@@ -169,6 +175,7 @@ def get_thermal_SH(nlevel, wno, nwno, numg, numt, tlevel, dtau, tau, w0, cosb, d
     return xint, np.zeros((numg, numt, stream * nlevel, nwno))
 
 
+@serialized
 def get_transit_1d(z, dz, nlevel, nwno, rstar, mmw, k_b, amu, player, tlayer, colden, DTAU):
     """Transmission spectrum ``(Rp/Rs)**2`` (reference ``fluxes.get_transit_1d``, fluxes.py:2581-2663).
     Same positional arguments; ``DTAU`` is ``(nlayer, nwno)``.  Returns ``(nwno,)``."""
@@ -184,6 +191,7 @@ def get_transit_1d(z, dz, nlevel, nwno, rstar, mmw, k_b, amu, player, tlayer, co
     return out
 
 
+@serialized
 def blackbody(t, w):
     """Planck function per unit wavelength in cgs (reference ``fluxes.blackbody``, fluxes.py:1660-1680): ``t`` in K,
     ``w`` WAVELENGTH in cm; returns ``(ntemp, nwave)``.  The same device function the thermal solvers evaluate level by
@@ -196,6 +204,7 @@ def blackbody(t, w):
     return out
 
 
+@serialized
 def blackbody_integrated(T, wave, dwave):
     """Mean of the wavenumber Planck function over each bin (three points: centre and both edges), the climate
     calculation's blackbody (reference ``fluxes.blackbody_integrated``, fluxes.py:1609-1658): ``T`` in K, ``wave`` and

@@ -875,6 +875,7 @@ class inputs:
         self.inputs["atmosphere"]["exclude_mol"] = exclude_mol
         self.nlevel = len(order)
 
+    @_lib.serialized
     def phase_curve(self, opacityclass, full_output=False, plot_opacity=False, n_cpu=1, verbose=False,
                     clouds_by_phase=None, devices=None, options=None):
         """Spectrum at every phase of ``phase_curve_geometry`` (reference justdoit.py:4741-4777; its
@@ -1050,6 +1051,7 @@ class inputs:
                       gather=gather, options=options)
 
 
+@_lib.serialized
 def picaso(bundle, opacityclass, dimension="1d", calculation="reflected", full_output=False,
            plot_opacity=False, as_dict=True, defer=False, devices=None, gather="host", options=None, _raw=False,
            _shared=None, _batch=None):
@@ -1176,6 +1178,7 @@ class _SolveBatch:
         self.refl, self.therm = {}, {}
 
 
+@_lib.serialized
 def spectrum_batch(cases, opacityclass, calculation="reflected", full_output=False, as_dict=True, batch_size=4,
                    options=None):
     """``[case.spectrum(opacityclass, calculation) for case in cases]`` (1-D) with the solvers of up to

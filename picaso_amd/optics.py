@@ -1389,6 +1389,7 @@ def _wno_device(opa, wno):
     return DeviceArray.from_host(np.ascontiguousarray(wno, dtype=np.float64), opa.ctx)
 
 
+@_lib.serialized
 def compute_opacity_resident(atmosphere, opacityclass, ngauss=1, stream=2, delta_eddington=True,
                              test_mode=None, raman=0, fthin_cld=None, do_holes=False,
                              full_output=False, want=None):
@@ -1486,6 +1487,7 @@ def compute_opacity_resident(atmosphere, opacityclass, ngauss=1, stream=2, delta
     return out
 
 
+@_lib.serialized
 def compute_opacity(atmosphere, opacityclass, ngauss=1, stream=2, delta_eddington=True,
                     test_mode=False, raman=0, plot_opacity=False, full_output=False,
                     return_mode=False, fthin_cld=None, do_holes=False):
