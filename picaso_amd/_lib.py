@@ -85,12 +85,36 @@ def device_count():
     return n.value if rc == 0 else 0
 
 
+# The HIP runtime does not survive fork(): a child of a process that has already created a context segfaults in its first
+# HIP call (measured: exit status 139 from the first kernel launch of a forked child) -- what multiprocessing's default
+# start method on Linux gives a retrieval that builds its opacity object before starting the pool.  Importing this
+# package before a fork is fine (nothing touches the GPU until a context exists); using the GPU on both sides is not,
+# and is a clean error here instead of a dead worker.
+_gpu_pid = None           # the process that created this module's first context
+
+
+def _check_not_forked():
+    if _gpu_pid is not None and os.getpid() != _gpu_pid:
+        raise PicasoHipError(
+            "picaso_amd: this process (pid %d) was forked from pid %d after that one had started using the GPU; the HIP "
+            "runtime does not survive fork().  Start the workers with multiprocessing.get_context('spawn') (or joblib's "
+            "default loky backend), or create the opacity object inside the worker." % (os.getpid(), _gpu_pid))
+
+
+def _mark_gpu_used():
+    global _gpu_pid
+    _check_not_forked()
+    if _gpu_pid is None:
+        _gpu_pid = os.getpid()
+
+
 def context(device=None):
     """Per-process, per-device context (lazy: safe to import before fork)."""
     if device is None:
         device = int(os.environ.get("PICASO_AMD_DEVICE", "0"))
     key = (os.getpid(), device)
     if key not in _ctx:
+        _mark_gpu_used()
         lib = load()
         h = ctypes.c_void_p()
         rc = lib.picaso_ctx_create(ctypes.c_int(device), ctypes.byref(h))
@@ -114,6 +138,7 @@ def serialized(fn):
     """Decorator of the public entry points: the call runs under ``CALL_LOCK``."""
     @functools.wraps(fn)
     def locked(*args, **kwargs):
+        _check_not_forked()
         with CALL_LOCK:
             return fn(*args, **kwargs)
     return locked
@@ -124,6 +149,7 @@ def new_context(device=None):
     two independent spectra in flight.  Device memory may be read from any context's stream."""
     if device is None:
         device = int(os.environ.get("PICASO_AMD_DEVICE", "0"))
+    _mark_gpu_used()
     h = ctypes.c_void_p()
     rc = load().picaso_ctx_create(ctypes.c_int(device), ctypes.byref(h))
     if rc != 0:

@@ -64,3 +64,44 @@ def test_concurrent_spectra_on_one_opacity_object_equal_the_serial_ones():
         t.join()
     assert err == [None] * nthreads, err
     assert bad == [0] * nthreads, bad
+
+
+@pytest.mark.gpu
+def test_forked_child_gets_a_clean_error_not_a_segfault():
+    """multiprocessing's default start method on Linux: the HIP runtime does not survive fork(), a child of a process that
+    has used the GPU died with SIGSEGV in its first launch.  Now the mirror says so (PicasoHipError naming the remedy)."""
+    import os
+    import time
+    from picaso_amd import _lib, disco, fluxes
+    from picaso_amd import synthetic as syn
+    sc = syn.make_scene(20, 200, seed=2)
+    g, gw, t, tw = disco.get_angles_1d(5)
+    _, u1, _, _, _ = disco.compute_disco(5, 1, g, t, 0.0)
+    targs = (21, sc["wno"], 200, 5, 1, sc["tlevel"], sc["dtau_og"], sc["w0_no_raman"], sc["cosb_og"], sc["plevel"], u1,
+             np.zeros(200), 0, sc["wno"] * 0, 0)
+    fluxes.get_thermal_1d(*targs, want_lvl=False)            # the parent has used the GPU
+    pid = os.fork()
+    if pid == 0:
+        code = 3
+        try:
+            fluxes.get_thermal_1d(*targs, want_lvl=False)
+        except _lib.PicasoHipError as e:
+            code = 7 if "fork" in str(e) and "spawn" in str(e) else 4
+        except BaseException:                                 # noqa: BLE001
+            code = 5
+        os._exit(code)
+    t0 = time.time()
+    status = None
+    while time.time() - t0 < 60:
+        r, st = os.waitpid(pid, os.WNOHANG)
+        if r:
+            status = st
+            break
+        time.sleep(0.05)
+    if status is None:
+        os.kill(pid, 9)
+        os.waitpid(pid, 0)
+        raise AssertionError("the forked child hung")
+    assert os.WIFEXITED(status) and os.WEXITSTATUS(status) == 7, "child status %r" % (status,)
+    # the parent is unharmed
+    fluxes.get_thermal_1d(*targs, want_lvl=False)
