@@ -453,6 +453,8 @@ class Spectrum:
                 want |= {"dtau_og", "w0_no_raman", "cosb_og"}
             if "transmission" in calc:
                 want |= {"dtau_og"}
+        if not want:            # a calculation string that names no leg (full_output of the set-up alone): one plane, no leg reads it
+            want = {"dtau"} if self.lean else {"dtau_og"}
         return want
 
     def _plan_1d(self):

@@ -766,3 +766,13 @@ def test_lonlat_regrid_with_a_seam_and_repeated_longitudes():
     f3 = np.array([1.0, 2.0, 3.0])[:, None] * np.ones((1, 2))
     out3 = jdi._regrid_lonlat({"lon": lon3, "lat": lat}, {"t": f3}, np.array([-60.0, 10.0, 90.0]), np.array([0.0]))
     assert np.allclose(out3["t"][:, 0], [1.0, 2.5, 3.0])
+
+
+def test_calculation_string_that_names_no_leg_returns_the_grid_alone():
+    """The reference only tests `'reflected' in calculation` / 'thermal' / 'transmission' (justdoit.py:254, 318, 388):
+    any other string runs the set-up and returns {'wavenumber': wno} (:517-621).  Same here (was a KeyError: 'dtau')."""
+    import types
+    from picaso_amd import justdoit as jdi
+    opa = types.SimpleNamespace(wno=np.linspace(1.0, 2.0, 7))
+    out = jdi.picaso({}, opa, calculation="emission")
+    assert list(out) == ["wavenumber"] and out["wavenumber"] is opa.wno
