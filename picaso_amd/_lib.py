@@ -12,7 +12,8 @@ import threading
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpicaso_hip.so")
+# PICASO_AMD_LIB: another build of the same sources (an A/B build kept beside the current one)
+LIB_PATH = os.environ.get("PICASO_AMD_LIB") or os.path.join(_HERE, "libpicaso_hip.so")
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "picaso_hip.h")
 
 c_double_p = ctypes.POINTER(ctypes.c_double)
