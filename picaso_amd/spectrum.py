@@ -453,7 +453,7 @@ class Spectrum:
                 want |= {"dtau_og", "w0_no_raman", "cosb_og"}
             if "transmission" in calc:
                 want |= {"dtau_og"}
-        if not want:            # a calculation string that names no leg (full_output of the set-up alone): one plane, no leg reads it
+        if want is not None and not want:            # (None = the whole set, SH) a calculation string that names no leg (full_output of the set-up alone): one plane, no leg reads it
             want = {"dtau"} if self.lean else {"dtau_og"}
         return want
 
