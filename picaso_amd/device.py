@@ -103,6 +103,14 @@ class DeviceArray:
 
     __copy__ = lambda self: self.__deepcopy__(None)
 
+    def __reduce__(self):
+        """Device memory does not travel between processes: an opacity object (or anything else holding resident
+        tables) handed to a ``multiprocessing`` / joblib worker fails HERE, with the remedy, not in ctypes."""
+        raise TypeError("picaso_amd: a DeviceArray (resident tables of an opacity object, device planes) cannot be "
+                        "pickled -- device memory belongs to the process that allocated it.  Create the opacity object "
+                        "inside the worker process (opannection(...) there), and send inputs / results, which are "
+                        "plain numpy.")
+
     def row_range(self, lo, hi):
         """Non-owning view of ``self[lo:hi]`` (leading axis)."""
         v = DeviceArray.__new__(DeviceArray)

@@ -776,3 +776,22 @@ def test_calculation_string_that_names_no_leg_returns_the_grid_alone():
     opa = types.SimpleNamespace(wno=np.linspace(1.0, 2.0, 7))
     out = jdi.picaso({}, opa, calculation="emission")
     assert list(out) == ["wavenumber"] and out["wavenumber"] is opa.wno
+
+
+def test_inputs_pickle_and_device_arrays_refuse_with_the_remedy():
+    """What a multiprocessing / joblib fan-out sends to its workers: the case (plain numpy: pickles) and, by mistake, the
+    opacity object (device memory: a clear TypeError naming the remedy, not a ctypes pointer error)."""
+    import pickle
+    from picaso_amd import device
+    from picaso_amd import justdoit as jdi
+    c = jdi.inputs()
+    c.phase_angle(0)
+    c.gravity(gravity=2500.0)
+    nlevel = 11
+    c.atmosphere(df={"pressure": np.logspace(-6, 2, nlevel), "temperature": np.linspace(200, 1500, nlevel),
+                     "H2": np.full(nlevel, 0.85), "He": np.full(nlevel, 0.15)})
+    c2 = pickle.loads(pickle.dumps(c))
+    assert np.array_equal(c2.inputs["atmosphere"]["profile"]["temperature"], c.inputs["atmosphere"]["profile"]["temperature"])
+    d = device.DeviceArray.__new__(device.DeviceArray)            # no GPU needed to ask the question
+    with pytest.raises(TypeError, match="inside the worker"):
+        pickle.dumps(d)
