@@ -913,6 +913,8 @@ int picaso_get_reflected_1d(picaso_ctx *ctx, int nlevel, const double *wno, int 
     if (!ctx) return fail(nullptr, "null context");
     if (nlevel < 2 || nwno < 1 || numg < 1 || numt < 1)
         return fail(ctx, "get_reflected_1d: bad sizes nlevel=%d nwno=%d numg=%d numt=%d", nlevel, nwno, numg, numt);
+    PZ_NEED(ctx, "get_reflected_1d", dtau, tau, w0, cosb, gcos2, ftau_cld, ftau_ray, dtau_og, tau_og, w0_og, cosb_og, surf_reflect,
+            ubar0, ubar1, F0PI, xint_at_top);
     PZ_HIP(ctx, hipSetDevice(ctx->device));
     const size_t nl = (size_t)(nlevel - 1) * nwno, nv = (size_t)nlevel * nwno;
     const size_t nang = (size_t)numg * numt;
@@ -1115,6 +1117,8 @@ int picaso_get_reflected_3d(picaso_ctx *ctx, int nlevel, const double *wno, int 
     if (!ctx) return fail(nullptr, "null context");
     if (nlevel < 2 || nwno < 1 || numg < 1 || numt < 1)
         return fail(ctx, "get_reflected_3d: bad sizes");
+    PZ_NEED(ctx, "get_reflected_3d", dtau_3d, tau_3d, w0_3d, cosb_3d, gcos2_3d, ftau_cld_3d, ftau_ray_3d, dtau_og_3d, tau_og_3d,
+            w0_og_3d, cosb_og_3d, surf_reflect, ubar0, ubar1, F0PI, xint_at_top);
     PZ_HIP(ctx, hipSetDevice(ctx->device));
     const size_t nfac = (size_t)numg * numt;
     const size_t nl = (size_t)(nlevel - 1) * nwno * nfac, nv = (size_t)nlevel * nwno * nfac;
@@ -1461,6 +1465,7 @@ int picaso_get_thermal_1d(picaso_ctx *ctx, int nlevel, const double *wno, int nw
 {
     if (!ctx) return fail(nullptr, "null context");
     if (nlevel < 2 || nwno < 1 || numg < 1 || numt < 1) return fail(ctx, "get_thermal_1d: bad sizes");
+    PZ_NEED(ctx, "get_thermal_1d", wno, tlevel, dtau, w0, cosb, plevel, ubar1, surf_reflect, flux_at_top);
     PZ_HIP(ctx, hipSetDevice(ctx->device));
     const size_t nl = (size_t)(nlevel - 1) * nwno, nv = (size_t)nlevel * nwno;
     const size_t nang = (size_t)numg * numt;
@@ -1501,6 +1506,7 @@ int picaso_get_thermal_3d_dev(picaso_ctx *ctx, int nlevel, const double *wno, in
 {
     if (!ctx) return fail(nullptr, "null context");
     if (nlevel < 2 || nwno < 1 || numg < 1 || numt < 1) return fail(ctx, "get_thermal_3d: bad sizes");
+    PZ_NEED(ctx, "get_thermal_3d", wno, tlevel_3d, plevel_3d, ubar1, surf_reflect, int_at_top);
     if (!dtau_3d || !w0_3d) return fail(ctx, "get_thermal_3d: dtau and w0 are required (cosb NULL = no cloud)");
     PZ_HIP(ctx, hipSetDevice(ctx->device));
     const int nfac = numg * numt;
@@ -1607,6 +1613,7 @@ int picaso_get_thermal_3d(picaso_ctx *ctx, int nlevel, const double *wno, int nw
 {
     if (!ctx) return fail(nullptr, "null context");
     if (nlevel < 2 || nwno < 1 || numg < 1 || numt < 1) return fail(ctx, "get_thermal_3d: bad sizes");
+    PZ_NEED(ctx, "get_thermal_3d", wno, tlevel_3d, dtau_3d, w0_3d, cosb_3d, plevel_3d, ubar1, surf_reflect, int_at_top);
     PZ_HIP(ctx, hipSetDevice(ctx->device));
     const size_t nfac = (size_t)numg * numt;
     const size_t nl = (size_t)(nlevel - 1) * nwno * nfac;
@@ -1664,6 +1671,8 @@ int picaso_compress_disco(picaso_ctx *ctx, int nwno, double cos_theta, const dou
                           const double *F0PI, double *albedo)
 {
     if (!ctx) return fail(nullptr, "null context");
+    if (nwno < 1 || ng < 1 || nt < 1) return fail(ctx, "compress_disco: bad sizes nwno=%d ng=%d nt=%d", nwno, ng, nt);
+    PZ_NEED(ctx, "compress_disco", xint_at_top, gweight, tweight, F0PI, albedo);
     PZ_HIP(ctx, hipSetDevice(ctx->device));
     const size_t nx = (size_t)ng * nt * nwno;
     PZ_TRY(arena_reset(ctx, sizeof(double) * (nx + 2 * (size_t)nwno) + 16 * 256));
@@ -1694,6 +1703,8 @@ int picaso_compress_thermal(picaso_ctx *ctx, size_t ninner, const double *flux_a
                             double *flux)
 {
     if (!ctx) return fail(nullptr, "null context");
+    if (ninner < 1 || ng < 1 || nt < 1) return fail(ctx, "compress_thermal: bad sizes");
+    PZ_NEED(ctx, "compress_thermal", flux_at_top, gweight, tweight, flux);
     PZ_HIP(ctx, hipSetDevice(ctx->device));
     const size_t nx = (size_t)ng * nt * ninner;
     PZ_TRY(arena_reset(ctx, sizeof(double) * (nx + ninner) + 16 * 256));

@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <initializer_list>
+
 #include <unordered_map>
 
 #include <cstdarg>
@@ -93,9 +95,25 @@ void free_pairwise_plans(picaso_ctx *ctx);
 #define PZ_HIP(ctx, expr)                                                                    \
     do {                                                                                     \
         hipError_t e__ = (expr);                                                             \
-        if (e__ != hipSuccess)                                                               \
+        if (e__ != hipSuccess) {                                                             \
+            /* the runtime keeps a failed call as its "last error": drop it, or the hipGetLastError() behind the NEXT  \
+             * call's kernel launch reports this failure again and one bad call poisons every later one */           \
+            (void)hipGetLastError();                                                         \
             return pz::fail(ctx, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__),     \
                             __FILE__, __LINE__);                                             \
+        }                                                                                    \
+    } while (0)
+
+// required pointer arguments of an entry point: PZ_NEED(ctx, "who", a, b, c) fails cleanly on the first NULL
+inline bool any_null(std::initializer_list<const void *> ps)
+{
+    for (const void *p : ps)
+        if (!p) return true;
+    return false;
+}
+#define PZ_NEED(ctx, who, ...)                                                                   \
+    do {                                                                                         \
+        if (pz::any_null({__VA_ARGS__})) return pz::fail(ctx, "%s: a required array argument is NULL (%s)", who, #__VA_ARGS__); \
     } while (0)
 
 #define PZ_TRY(expr)              \
@@ -111,6 +129,7 @@ void *arena_take(picaso_ctx *ctx, size_t bytes);
 template <typename T>
 inline int arena_upload(picaso_ctx *ctx, const T *host, size_t count, const T **dev)
 {
+    if (!host && count) return fail(ctx, "a required input array is NULL");
     T *d = static_cast<T *>(arena_take(ctx, count * sizeof(T)));
     if (!d) return fail(ctx, "arena exhausted");
     PZ_HIP(ctx, hipMemcpyAsync(d, host, count * sizeof(T), hipMemcpyHostToDevice, ctx->stream));

@@ -2030,6 +2030,7 @@ int picaso_get_reflected_SH_top_dev(picaso_ctx *ctx, int nlevel, int nwno, long 
     if (nlevel < 2 || nwno < 1 || numg < 1 || numt < 1) return fail(ctx, "get_reflected_SH: bad sizes");
     if (stream != 2 && stream != 4) return fail(ctx, "get_reflected_SH: stream must be 2 or 4, got %d", stream);
     if (flx && !flux) return fail(ctx, "get_reflected_SH: flx=1 needs the flux output (numg,numt,stream*nlevel,nwno)");
+    PZ_NEED(ctx, "get_reflected_SH", surf_reflect, ubar0, ubar1, F0PI, xint_at_top);
     if (flx && plane_pitch != nwno) return fail(ctx, "get_reflected_SH: flx=1 needs contiguous planes");
     if (plane_pitch < nwno) return fail(ctx, "get_reflected_SH: plane_pitch < nwno");
     if (!dtau || !w0) return fail(ctx, "get_reflected_SH: dtau and w0 are required");
@@ -2248,6 +2249,7 @@ int picaso_get_thermal_SH_dev(picaso_ctx *ctx, int nlevel, const double *wno, in
     (void)tau;
     if (!ctx) return fail(nullptr, "null context");
     if (nlevel < 2 || nwno < 1 || numg < 1 || numt < 1) return fail(ctx, "get_thermal_SH: bad sizes");
+    PZ_NEED(ctx, "get_thermal_SH", wno, tlevel, dtau, w0, cosb_og, plevel, ubar1, surf_reflect, xint_at_top);
     if (stream != 2 && stream != 4) return fail(ctx, "get_thermal_SH: stream must be 2 or 4, got %d", stream);
     if (flx) return fail(ctx, "get_thermal_SH: flx=1 is broken in the reference (fluxes.py:3102) and not built");
     PZ_HIP(ctx, hipSetDevice(ctx->device));

@@ -121,6 +121,7 @@ int picaso_get_transit_1d_dev(picaso_ctx *ctx, const double *z, const double *dz
 {
     if (!ctx) return fail(nullptr, "null context");
     if (nlevel < 2 || nwno < 1) return fail(ctx, "get_transit_1d: bad sizes nlevel=%d nwno=%d", nlevel, nwno);
+    PZ_NEED(ctx, "get_transit_1d", z, dz, mmw, player, tlayer, colden, dtau, rprs2);
     if (plane_pitch < nwno) return fail(ctx, "get_transit_1d: plane_pitch %ld < nwno %d", plane_pitch, nwno);
     PZ_HIP(ctx, hipSetDevice(ctx->device));
     const int n = nlevel, nl = nlevel - 1;
