@@ -51,7 +51,7 @@ def test_bad_arguments_fail_cleanly_and_do_not_poison_the_context():
         return lib.picaso_get_reflected_SH(
             ctx, ci(nl), ci(nw), ci(ng), ci(1), p(dt), p(lev), p(lay), p(lay), p(lay), p(lay), p(lay), p(lay), p(lev), p(lay),
             p(lay), p(vec), p(u), p(u), cd(1.0), p(vec), ci(0), ci(0), ci(0), ci(1), ci(1), ci(1), cd(1.0), cd(-1.0), cd(2.0),
-            cd(-0.5), cd(1.0), ci(stream), cd(0.0), ci(0), ci(0), p(x), None)
+            cd(-0.5), cd(1.0), ci(stream), cd(0.0), ci(0), ci(0), ci(0), p(x), None)
 
     for name, call in (("reflected", refl), ("thermal", therm), ("transit", transit), ("blackbody", bb), ("compress", dsc), ("SH", sh)):
         assert call() == 0, "%s: %s" % (name, (lib.picaso_last_error(ctx) or b"").decode())

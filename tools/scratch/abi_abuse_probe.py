@@ -38,7 +38,7 @@ def child(name):
     def sh(stream=4, dt=lay):
         return lib.picaso_get_reflected_SH(ctx, ci(nl), ci(nw), ci(ng), ci(1), p(dt), p(lev), p(lay), p(lay), p(lay), p(lay), p(lay), p(lay),
             p(lev), p(lay), p(lay), p(vec), p(u), p(u), cd(1.0), p(vec), ci(0), ci(0), ci(0), ci(1), ci(1), ci(1), cd(1.0), cd(-1.0), cd(2.0),
-            cd(-0.5), cd(1.0), ci(stream), cd(0.0), ci(0), ci(0), p(x), None)
+            cd(-0.5), cd(1.0), ci(stream), cd(0.0), ci(0), ci(0), ci(0), p(x), None)
     table = {"refl_nlevel1": lambda: refl(nlevel=1), "refl_nwno0": lambda: refl(nwno=0), "refl_numg0": lambda: refl(numg=0),
              "refl_null_dtau": lambda: refl(dtau=None), "refl_null_out": lambda: refl(out=None), "refl_bad_single_phase": lambda: refl(sp=9),
              "refl_numg_huge": lambda: refl(numg=100000), "therm_nlevel1": lambda: therm(nlevel=1), "therm_nwno_neg": lambda: therm(nwno=-5),
