@@ -584,6 +584,7 @@ static int reflected_1d_core(picaso_ctx *ctx, int nlevel, int nwno, int ncolper,
     // (running sums of dtau / dtau_og), gcos2 (0.5 ftau_ray), and -- a column without cloud -- cosb, cosb_og, ftau_cld,
     // ftau_ray (0, 0, 0, 1) with dtau_og, w0_og (no delta-scaling: dtau, w0).  The cloud set goes together.
     if (!dtau || !w0) return fail(ctx, "get_reflected_1d: dtau and w0 are required");
+    if (!bt) PZ_NEED(ctx, "get_reflected_1d", surf_reflect, ubar0, ubar1, F0PI, xint_at_top);   // a NULL device pointer would be a GPU fault
     const bool clear_set = !ftau_cld;
     if (clear_set ? (cosb || cosb_og || ftau_ray || gcos2) : (!cosb || !cosb_og || !ftau_ray))
         return fail(ctx, "get_reflected_1d: cosb, cosb_og, ftau_cld, ftau_ray are given together or all left out (gcos2 "
@@ -1167,6 +1168,7 @@ static int thermal_1d_core(picaso_ctx *ctx, int nlevel, const double *wno, int n
     if (nlevel < 2 || nwno < 1 || numg < 1 || numt < 1)
         return fail(ctx, "get_thermal_1d: bad sizes nlevel=%d nwno=%d numg=%d numt=%d", nlevel, nwno, numg, numt);
     if (!dtau || !w0 || !cosb) return fail(ctx, "get_thermal_1d: dtau, w0 and cosb are required");
+    if (!bt) PZ_NEED(ctx, "get_thermal_1d", wno, tlevel, plevel, ubar1, surf_reflect, flux_at_top);
     const int nspec = bt ? bt->nspec : 1;
     const long ncol = (long)nwno * ncolper;
     if (plane_pitch < ncol) return fail(ctx, "get_thermal_1d: plane_pitch %ld < %ld columns", plane_pitch, ncol);
