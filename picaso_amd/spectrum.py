@@ -483,7 +483,8 @@ class Spectrum:
         elif self.sh_lean:
             zero, _, _ = _constant_planes(opa, nlayer, nwno)
             self.rplanes = {"dtau": planes["dtau"], "w0": planes["w0"]}
-            self.planes = dict(self.rplanes, cosb_og=zero)
+            # (dtau_og: what the transmission leg reads -- without cloud nothing is delta-scaled, dtau_og IS dtau)
+            self.planes = dict(self.rplanes, cosb_og=zero, dtau_og=planes["dtau"])
         elif self.lean:
             zero, one, half = _constant_planes(opa, nlayer, nwno)
             planes.update(dtau_og=planes["dtau"], cosb=zero, cosb_og=zero, ftau_cld=zero, ftau_ray=one, gcos2=half)
