@@ -1149,10 +1149,10 @@ class _SolveBatch:
         for key, items in self.refl.items():
             nlevel, nwno, ng, nt, tt, tcoef, b_top, gw, tw, _ = key
             ctx = items[0]["ctx"]
-            if len(items) == 1:
-                it = items[0]
-                _reflected(ctx, nlevel, nwno, ng, nt, it["planes"], it["rs"], it["ubar0"], it["ubar1"],
-                           it["cos_theta"], it["F0PI"], *tt, tcoef, b_top, it["xint"], None, gw, tw, it["albedo"])
+            if len(items) == 1 or ng * nt > 8:       # the batched launch carries at most 8 disk angles: a 6 x 6 disk goes alone
+                for it in items:
+                    _reflected(ctx, nlevel, nwno, ng, nt, it["planes"], it["rs"], it["ubar0"], it["ubar1"],
+                               it["cos_theta"], it["F0PI"], *tt, tcoef, b_top, it["xint"], None, gw, tw, it["albedo"])
                 continue
             same = all(np.array_equal(it["ubar0"], items[0]["ubar0"]) and np.array_equal(it["ubar1"], items[0]["ubar1"])
                        and it["cos_theta"] == items[0]["cos_theta"] for it in items)
@@ -1166,11 +1166,11 @@ class _SolveBatch:
         for key, items in self.therm.items():
             nlevel, nwno, ng, nt, hard, _, gw, tw = key
             ctx = items[0]["ctx"]
-            if len(items) == 1:
-                it = items[0]
-                resident.thermal_1d(ctx, nlevel, it["wno"], nwno, ng, nt, it["tlevel"], it["dtau"], it["w0"], it["cosb"],
-                                    it["plevel"], it["ubar1"], it["rs"], hard, it["flux"], gweight=gw, tweight=tw,
-                                    flux_disk=it["disk"])
+            if len(items) == 1 or ng * nt > 8:
+                for it in items:
+                    resident.thermal_1d(ctx, nlevel, it["wno"], nwno, ng, nt, it["tlevel"], it["dtau"], it["w0"], it["cosb"],
+                                        it["plevel"], it["ubar1"], it["rs"], hard, it["flux"], gweight=gw, tweight=tw,
+                                        flux_disk=it["disk"])
                 continue
             same = all(np.array_equal(it["ubar1"], items[0]["ubar1"]) for it in items)
             u1 = items[0]["ubar1"] if same else np.stack([np.asarray(it["ubar1"], dtype=float).reshape(ng, nt) for it in items])
