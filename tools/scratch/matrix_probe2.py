@@ -28,7 +28,20 @@ def ck(nb=120, nk=8):
     cont = {pr: {t: 10.0 ** (-7.0 + np.cos(wck / 4000.0 + k) + 0.3 * np.log10(t / 300.0)) for t in cia_t} for k, pr in enumerate(("H2H2", "H2He"))}
     return px.RetrieveCKs(wck, gwts, np.tile(pk, tk.size), np.repeat(tk, pk.size), np.full(tk.size, pk.size), lnk, continuum=cont, cia_temps=cia_t,
                           rayleigh_opa={m: 1e-27 * (wck / 1e4) ** 4 for m in ("H2", "He")}, gauss_pts=gpts, ctx=ctx)
-OPAS = {"mono": mono(), "ck": ck()}
+def ck_fly(nb=120, nk=8):
+    """per-gas k-tables mixed on the fly (resort-rebin, deq_chem.py:334)"""
+    wck = np.linspace(40.0, 28000.0, nb)
+    xg, wg = np.polynomial.legendre.leggauss(4)
+    gpts = np.concatenate([0.95 * 0.5 * (xg + 1), 0.95 + 0.05 * 0.5 * (xg + 1)]); gwts = np.concatenate([0.95 * 0.5 * wg, 0.05 * 0.5 * wg])
+    tk, pk = np.array(temps), np.array(press)
+    def tab(j):
+        return np.log(10.0) * (-26.0 + 2.0 * np.sin(wck / 2500.0 + j)[None, None, :, None] + 0.5 * np.log10(pk)[:, None, None, None]
+                               + 0.9 * np.log10(tk / 300.0)[None, :, None, None] + 0.6 * np.arange(nk)[None, None, None, :])
+    cont = {pr: {t: 10.0 ** (-7.0 + np.cos(wck / 4000.0 + k) + 0.3 * np.log10(t / 300.0)) for t in cia_t} for k, pr in enumerate(("H2H2", "H2He"))}
+    return px.RetrieveCKs(wck, gwts, np.tile(pk, tk.size), np.repeat(tk, pk.size), np.full(tk.size, pk.size), None, continuum=cont, cia_temps=cia_t,
+                          rayleigh_opa={m: 1e-27 * (wck / 1e4) ** 4 for m in ("H2", "He")}, kappas={"H2O": tab(0), "CH4": tab(1), "H2": tab(2) - 8.0},
+                          gauss_pts=gpts, on_fly=True, ctx=ctx)
+OPAS = {"mono": mono(), "ck": ck(), "ck_fly": ck_fly()}
 d = tempfile.mkdtemp(); os.makedirs(os.path.join(d, "opacities"))
 wn = np.round(np.linspace(30.0, 34000.0, 196)[::-1], 2)
 with open(os.path.join(d, "opacities", "wave_EGP.dat"), "w") as fh:
@@ -42,7 +55,7 @@ prof = {"pressure": plev, "temperature": 150.0 + 1200.0 * ((np.log10(plev) + 6) 
 pert = 1.0 + 0.1 * np.cos(np.arange(16).reshape(4, 4))
 CALCS = ["reflected", "thermal", "reflected+thermal", "reflected+thermal+transmission", "transmission"]
 nbad = ntot = 0
-for oname, dim, sh, calc, cloud, de, full in itertools.product(("mono", "ck"), ("1d", "3d"), (False, True), CALCS, ("none", "own-grid"), (True, False), (False, True)):
+for oname, dim, sh, calc, cloud, de, full in itertools.product(("mono", "ck", "ck_fly"), ("1d", "3d"), (False, True), CALCS, ("none", "own-grid"), (True, False), (False, True)):
     opa = OPAS[oname]; wno = opa.wno; nwno = wno.size
     if dim == "3d" and "transmission" in calc:
         continue                                   # the reference has no 3-D transmission branch: a clean error here (checked below once)
