@@ -30,8 +30,43 @@ def h5py(monkeypatch):
     return mod
 
 
+# The order the GPU tests run in (the driver runs `pytest -x -q -m gpu` in ONE process: whatever fails first hides the rest).
+# Parity evidence first, in SURVEY.md section 8's order a1 -> f4; hygiene last, so that a failure of a bit-identity or
+# process-hygiene test can never leave a section-8 row or a BASELINE config without a result.
+#   class 0  reference-fixture tests: the HIP path against tests/golden/*.npz (arrays the reference itself produced)
+#   class 1  oracle tests: the HIP path against oracle/ (pinned by the same fixtures on the CPU side) at sizes no fixture has
+#   class 2  bit identity of one launch shape / call path against another, shape and option sweeps
+#   class 3  ABI abuse, processes, threads, caches, leaks
+_GPU_ORDER = [
+    # class 0 -- a1/a2/a3 optics, a7/a8/a10/a11/a12/a16 solvers, a9 Planck, a13 thermal SH + CK loops, f1 mixing/climate, f3 transit
+    "test_optics", "test_parity_gpu", "test_planck", "test_ck_loops_gpu", "test_ck3d_gpu", "test_ck_optics", "test_mixing",
+    "test_climate_fluxes", "test_transit", "test_dlugach",
+    # class 1
+    "test_fullsize_gpu", "test_fuzz_gpu", "test_sh_thermal_gpu", "test_sh_clear_gpu", "test_ck_gpu", "test_tiny_grids_gpu",
+    "test_cloud_regrid", "test_ck_readers",
+    # class 2
+    "test_refl_coop_gpu", "test_lean_planes_gpu", "test_integrals_gpu", "test_batch_gpu", "test_batch_hetero_gpu",
+    "test_driver_gpu", "test_devices_gpu", "test_comm_gpu",
+    # class 3
+    "test_content_caches", "test_abi_abuse_gpu", "test_threads_gpu", "test_processes_gpu", "test_leak_gpu",
+]
+
+
+def _gpu_rank(item):
+    mod = os.path.splitext(os.path.basename(str(item.fspath)))[0]
+    try:
+        return _GPU_ORDER.index(mod)
+    except ValueError:
+        return len(_GPU_ORDER) - 5          # an unlisted file: after the parity classes, before class 3
+
+
 def pytest_collection_modifyitems(config, items):
-    """gpu-marked tests are skipped (not failed) on a box without a HIP device or without the library."""
+    """GPU tests run parity-first (``_GPU_ORDER``; a stable sort, so a file's own order is kept and CPU tests stay
+    where they were); on a box without a HIP device or without the library they are skipped (not failed)."""
+    gpu_slots = [i for i, it in enumerate(items) if "gpu" in it.keywords]
+    ordered = sorted((items[i] for i in gpu_slots), key=_gpu_rank)
+    for slot, it in zip(gpu_slots, ordered):
+        items[slot] = it
     try:
         from picaso_amd import _lib
         have_gpu = _lib.device_count() > 0

@@ -22,5 +22,10 @@ def test_no_device_arrays_wait_for_the_cycle_collector(capsys):
     finally:
         if was:
             gc.enable()
+    import json
     out = capsys.readouterr().out
-    assert rc == 0, out[-2000:]
+    rec = json.loads(out.strip().splitlines()[-1])
+    # on failure: which shapes waited, and who held them (referrer chains inside the unreachable set) -- not the samples
+    assert rc == 0 and rec["finite"], json.dumps({k: rec[k] for k in (
+        "device_arrays_that_waited_for_the_cycle_collector", "held_by", "finite", "calls_by_kind")})
+    assert rec["device_arrays_that_waited_for_the_cycle_collector"] == {} and rec["held_by"] == {}

@@ -182,12 +182,51 @@ def main(argv=None):
     from picaso_amd import device
 
     def census():
+        """every live DeviceArray by shape -- the FULL counter: a top-N cut makes a shape that is tied at rank N appear to
+        vanish when gc.get_objects() changes its order (round 5's red GPUTEST: five resident (nwno,) vectors, nothing cyclic)"""
         c = collections.Counter()
         for o in gc.get_objects():
             if isinstance(o, device.DeviceArray):
                 c[str(tuple(o.shape))] += 1
-        return dict(c.most_common(12))
+        return dict(c)
+
+    def holders():
+        """Who keeps the arrays only a collection frees: collect with DEBUG_SAVEALL (nothing is freed, everything
+        unreachable lands in gc.garbage) and name, for each unreachable DeviceArray, its referrers two levels up."""
+        def name(o):
+            t = type(o).__name__
+            if isinstance(o, dict):
+                return "dict(keys=%s)" % sorted(map(str, o))[:8]
+            if t in ("function", "method"):
+                return "%s %s" % (t, getattr(o, "__qualname__", "?"))
+            if t == "frame":
+                return "frame %s:%d" % (o.f_code.co_qualname if hasattr(o.f_code, "co_qualname") else o.f_code.co_name, o.f_lineno)
+            if t == "cell":
+                return "cell"
+            if isinstance(o, (list, tuple)):
+                return "%s[%d]" % (t, len(o))
+            return t
+        gc.set_debug(gc.DEBUG_SAVEALL)
+        try:
+            gc.collect()
+            junk = list(gc.garbage)
+        finally:
+            gc.set_debug(0)
+            del gc.garbage[:]
+        ids = {id(o) for o in junk}
+        chains = collections.Counter()
+        for o in junk:
+            if not isinstance(o, device.DeviceArray):
+                continue
+            for r1 in gc.get_referrers(o):
+                if id(r1) not in ids:
+                    continue
+                ups = sorted({name(r2) for r2 in gc.get_referrers(r1) if id(r2) in ids})[:4]
+                chains["%s <- %s <- %s" % (tuple(o.shape), name(r1), " | ".join(ups))] += 1
+        del junk
+        return dict(chains.most_common(40))
     alive_before = census()
+    held_by = holders()          # (frees nothing: SAVEALL keeps the unreachable objects alive until the list is cleared)
     gc.collect()
     alive_after = census()
     # after the first third (pools, rings, code objects have reached their size) nothing may grow
@@ -200,6 +239,9 @@ def main(argv=None):
            "device_mb_growth_after_first_third": round(dev_growth, 1), "samples_call_rss_devfree_[liveMB,liveN,poolMB,poolN,pinnedMB,pinnedN]": samples}
     cyclic = {k: v - alive_after.get(k, 0) for k, v in alive_before.items() if v != alive_after.get(k, 0)}
     out["device_arrays_that_waited_for_the_cycle_collector"] = cyclic
+    out["held_by"] = held_by
+    if cyclic:                   # the one thing a reader of a failure needs comes last (the caller prints the tail)
+        print(json.dumps({"cyclic": cyclic, "held_by": held_by}), file=sys.stderr)
     print(json.dumps(out))
     return 0 if (finite and not cyclic and (args.cycles_only or dev_growth < 256.0)) else 1
 
