@@ -419,6 +419,40 @@ def spawn_ranks(ngpus):
     return rc if rc >= 0 else 1
 
 
+def gpu_clocks(local=0):
+    """Current sclk / mclk in MHz of the GPU this rank runs on, best effort: the amdgpu sysfs tables (the line marked
+    '*' is the level in use), else ``rocm-smi --showclocks --json``; None where neither can be read."""
+    import glob
+    import re
+    out = {}
+    cards = sorted(d for d in glob.glob("/sys/class/drm/card[0-9]*/device") if os.path.exists(os.path.join(d, "pp_dpm_sclk")))
+    if cards:
+        d = cards[min(local, len(cards) - 1)]
+        for key, fn in (("sclk_mhz", "pp_dpm_sclk"), ("mclk_mhz", "pp_dpm_mclk")):
+            try:
+                cur = [ln for ln in open(os.path.join(d, fn)).read().splitlines() if ln.rstrip().endswith("*")]
+                out[key] = int(re.search(r"(\d+)\s*[Mm][Hh]z", cur[0]).group(1)) if cur else None
+            except Exception:
+                out[key] = None
+        out["source"] = "sysfs " + os.path.join(d, "pp_dpm_*")
+        if out.get("sclk_mhz") is not None:
+            return out
+    try:
+        import subprocess
+        txt = subprocess.run(["rocm-smi", "--showclocks", "--json"], capture_output=True, text=True, timeout=15).stdout
+        card = sorted(json.loads(txt).items())[local][1]
+        for key, pat in (("sclk_mhz", "sclk"), ("mclk_mhz", "mclk")):
+            val = [v for k, v in card.items() if pat in k.lower() and "level" in k.lower()]
+            m_ = re.search(r"(\d+)\s*[Mm][Hh]z", val[0]) if val else None
+            out[key] = int(m_.group(1)) if m_ else None
+        out["source"] = "rocm-smi --showclocks --json"
+    except Exception as exc:
+        out.setdefault("sclk_mhz", None)
+        out.setdefault("mclk_mhz", None)
+        out["source"] = "unreadable (%s)" % type(exc).__name__
+    return out
+
+
 def orc_flags():
     try:
         from oracle import oracle as orc
@@ -926,6 +960,8 @@ def main():
                     help="wavelengths of the same workload timed on the CPU oracle (0 = skip)")
     ap.add_argument("--steady-steps", type=int, default=2000,
                     help="N = 1: steps of an extra untimed run after the timed region, reported as steady_state")
+    ap.add_argument("--repeats", type=int, default=9,
+                    help="further K-step blocks after the timed one (N = 1): their median / min / max go into the line")
     ap.add_argument("--secondary", type=int, default=1,
                     help="N = 1, default workload: after the timed region also time the batched launch of the same "
                          "workload (throughput_batched) and the other BASELINE configurations (secondary); 0 = skip")
@@ -1063,6 +1099,27 @@ def main():
     stream_ms = device.timer_stop(ctx) / args.steps       # HIP events on the kernel's stream (solve [+ last gathers])
     barrier()
     elapsed = time.perf_counter() - t0
+    # ---- untimed: the spread of the same K-step block on this box (nine more blocks, each bracketed like the timed
+    # one) and the clocks the GPU reports while a block is still on the stream -- what makes `value` comparable across
+    # boxes (the timed block above is the metric; these only say where it sits) ----
+    repeats = None
+    if not comm and args.repeats > 0:
+        blocks, clk = [], []
+        for _ in range(args.repeats):
+            device.sync(ctx)
+            device.timer_start(ctx)
+            for _ in range(args.steps):
+                step()
+            if len(clk) < 3:
+                clk.append(gpu_clocks(local_rank))          # read while the block runs (the launches above are asynchronous)
+            blocks.append(device.timer_stop(ctx) / args.steps)
+        repeats = {"n": len(blocks), "steps_per_block": args.steps, "median_ms": float(np.median(blocks)),
+                   "min_ms": float(min(blocks)), "max_ms": float(max(blocks)), "ms": [round(b, 5) for b in blocks],
+                   "timed_block_ms": stream_ms, "clocks_under_load": clk, "clocks_idle_after": None,
+                   "what": "HIP-event time per step of further %d-step blocks after the timed one (untimed by the driver)"
+                           % args.steps}
+        device.sync(ctx)
+        repeats["clocks_idle_after"] = gpu_clocks(local_rank)
     if comm:
         elapsed = comm.max(elapsed)
     last = (nstep[0] - 1) % (2 * G)
@@ -1151,6 +1208,7 @@ def main():
                        if comm else "none"},
             "prewarm": {"ms": args.prewarm_ms, "launches": nprewarm, "why": "GPU clock ramp, untimed"},
             "cold_ms_first_20": cold_ms,
+            "repeats": repeats,
             "wavelength_layer_updates_per_s": value * nwno_total / spectra_per_step * args.nlayer,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

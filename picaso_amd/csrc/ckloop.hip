@@ -62,6 +62,10 @@ static int check_ck(picaso_ctx *ctx, const char *who, int nlevel, int nwno, int 
     if (ngauss < 1 || ngauss > MAX_CK_GAUSS) return fail(ctx, "%s: ngauss must be 1..%d, got %d", who, MAX_CK_GAUSS, ngauss);
     if (!gauss_wts) return fail(ctx, "%s: gauss_wts is null", who);
     if (nlevel < 2 || nwno < 1 || numg < 1 || numt < 1) return fail(ctx, "%s: bad sizes", who);
+    // the inner solvers count columns in an int: nwno * ngauss (x facets in the 3-D forms) must fit
+    if ((long)nwno * ngauss * (long)numg * numt > 2147483647L)
+        return fail(ctx, "%s: nwno * ngauss * numg * numt = %ld columns exceed INT_MAX", who,
+                    (long)nwno * ngauss * (long)numg * numt);
     return 0;
 }
 

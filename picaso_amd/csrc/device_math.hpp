@@ -133,7 +133,11 @@ __device__ __forceinline__ double frcp(double b)
 
 // 1/b to 2^-46 relative (1.4e-14): v_rcp_f64 + ONE Newton step, 3 instructions.  Only where the reciprocal enters as
 // a plain factor of a product (no difference is formed from the result): thermal emission's per-angle
-// 1/((lam mu - 1)(lam mu + 1)), whose error multiplies the angle's source terms and nothing else.
+// 1/((lam mu - 1)(lam mu + 1)), whose error multiplies the angle's source terms and nothing else; and, under PZ_REFL_DIET
+// (round 5), the reflected solvers' per-angle 1/(den (lu - 1)(lu + 1)) (toon_reflected.hip, toon_reflected_coop.hip): a common
+// factor of the layer's direct-beam terms and mode integrals, so the near-singular cancellation at lambda u0 -> 1 sees the
+// same factor on both sides.  A deliberate 2^-46 against the reference's fp64 division there; -DPZ_REFL_DIET=0 restores the
+// 1-ulp frcp, and tests/test_refl_coop_gpu.py / tools/headline_error_x87.py bound the difference.
 __device__ __forceinline__ double frcp1(double b)
 {
 #pragma clang fp contract(off)

@@ -181,6 +181,7 @@ extern "C" int picaso_host_setup(const picaso_setup_args *a)
         }
         for (int c = 0; c < std::max(a->ncont, 1); ++c) a->cia_rows[(size_t)c * nl + i] = best;
         if (a->cont_interp) {
+            if (a->ncia_t < 2) return 5;     // one continuum temperature has no bracketing pair: the mirror's IndexError
             // the bracketing pair and its 1/T weight (RetrieveCKs._plan_continuum; reference optics.py:1411-1428, 1474-1478)
             const double tl = a->layer_temperature[i];
             long lo = last_le(a->cia_temps, a->ncia_t, tl);

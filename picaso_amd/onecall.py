@@ -40,8 +40,8 @@ def _in_scope(inp, opa, legs, nblocks, opt):
     resident tables, no patchy clouds (SH ignores them, as the reference: ``Spectrum`` says so with a warning and is left to
     say it), no level fluxes, no test mode; Oklopcic's Raman plane (formed per call on the block's device) for one block
     only."""
-    if opt.no_driver or opt.raman_planes:
-        return False
+    if opt.no_driver or opt.raman_planes or opt.unfused_opacity:
+        return False                # (unfused_opacity: the C driver always takes the fused launch; Spectrum honours the option)
     if not legs or not legs <= {"reflected", "thermal"}:
         return False
     is_sh = inp["approx"]["rt_method"] == "SH"

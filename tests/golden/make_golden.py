@@ -278,12 +278,13 @@ def _ref_weights(names):
     return {k: float(am.ATMSETUP.get_weights(object(), [k])[k]) for k in names}
 
 
-def make_optics(nwno=40, nlevel=31, tag="", full=True):
+def make_optics(nwno=40, nlevel=31, tag="", full=True, qms=None):
     """Synthetic monochromatic sqlite DB in the reference schema (committed next to the fixtures),
     driven through the reference's own RetrieveOpacities + compute_opacity with a duck-typed
     atmosphere (SURVEY.md Appendix B).  Defaults: the 40-point x 30-layer fixture of round 1;
     ``make_optics(196, 61, "_196x60", full=False)`` is BASELINE configs[0]'s shape (196-point opacity
-    grid, 60 layers) with the planes of the default options only."""
+    grid, 60 layers) with the planes of the default options only (``qms``: the query methods, default linear only;
+    round 6 adds "nearest" AFTER "linear", so the arrays of rounds 1-5 are reproduced unchanged)."""
     import sqlite3
     import types
     import pandas as pd
@@ -387,7 +388,7 @@ def make_optics(nwno=40, nlevel=31, tag="", full=True):
     names = ("dtau", "tau", "w0", "cosb", "ftau_cld", "ftau_ray", "gcos2", "dtau_og", "tau_og",
              "w0_og", "cosb_og", "w0_no_raman", "f_deltaM")
     raman_file = os.path.join(ref_shim.REF_ROOT, "reference", "opacities", "raman.txt")
-    for qm in (("nearest", "linear") if full else ("linear",)):
+    for qm in (qms or (("nearest", "linear") if full else ("linear",))):
         opa = optics.RetrieveOpacities(db, raman_file, query_method=qm)
         if shifts_n is None:
             shifts_n = 1.0 + 0.05 * rng.standard_normal((nwno, len(opa.raman_db)))
@@ -628,7 +629,7 @@ def make_sh():
 if __name__ == "__main__" and (("optics" in sys.argv[1:]) or not sys.argv[1:]):
     make_optics()
 if __name__ == "__main__" and (("optics196" in sys.argv[1:]) or not sys.argv[1:]):
-    make_optics(196, 61, "_196x60", full=False)
+    make_optics(196, 61, "_196x60", full=False, qms=("linear", "nearest"))
 if __name__ == "__main__" and (("ck" in sys.argv[1:]) or not sys.argv[1:]):
     make_ck()
 if __name__ == "__main__" and (("transit" in sys.argv[1:]) or not sys.argv[1:]):

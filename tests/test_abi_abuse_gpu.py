@@ -1,7 +1,7 @@
 """Bad arguments straight at the C ABI (the host-pointer forms a binding would call): every call comes back with rc != 0
 and a message naming the entry point, and the NEXT good call on the same context succeeds.  Before round 5's guards a NULL
 required array was a SIGSEGV (thermal / transit) or a failed hipMemcpyAsync whose sticky "last error" made every later
-launch of the context report it again (tools/scratch/abi_abuse_probe.py runs each case in a child process)."""
+launch of the context report it again."""
 import ctypes
 
 import numpy as np

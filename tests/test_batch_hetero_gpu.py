@@ -1,7 +1,6 @@
 """spectrum_batch over a HETEROGENEOUS list -- Toon and SH4, cloud tables / patchy clouds / none, the symmetric disk and a 6 x 6
 disk at phase 0.8 (36 angles: more than the batched launch carries; it used to raise "at most 8 disk angles"), level
-fluxes -- and spectrum(devices=[0, 0, 0]) for each case: every output equals the plain spectrum() call bit for bit
-(tools/scratch/matrix_probe3.py is the longer form)."""
+fluxes -- and spectrum(devices=[0, 0, 0]) for each case: every output equals the plain spectrum() call bit for bit."""
 import numpy as np
 import pytest
 

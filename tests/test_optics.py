@@ -405,7 +405,8 @@ def scale_err_rows(got, want):
 
 
 @pytest.mark.gpu
-def test_gpu_spectrum_config0_196_points_60_layers(oracle):
+@pytest.mark.parametrize("qm", ["linear", "nearest"])
+def test_gpu_spectrum_config0_196_points_60_layers(oracle, qm):
     """BASELINE configs[0] at its stated shape: reflected-light spectrum on a 196-point opacity grid x 60
     layers through inputs.spectrum() (sqlite DB -> HBM tables -> gas stage -> mixing -> Toon solver ->
     disk integration), against [the reference's own compute_opacity planes for this DB and profile
@@ -413,12 +414,12 @@ def test_gpu_spectrum_config0_196_points_60_layers(oracle):
     from picaso_amd import disco
     from picaso_amd import justdoit as jdi
     g196 = np.load(os.path.join(GOLDEN, "optics_196x60.npz"))
-    opa = jdi.opannection(filename_db=os.path.join(GOLDEN, "synthetic_opacities_196x60.db"), query_method="linear")
+    opa = jdi.opannection(filename_db=os.path.join(GOLDEN, "synthetic_opacities_196x60.db"), query_method=qm)
     assert opa.nwno == 196 and len(g196["in/tlevel"]) == 61
     case = _bundle(g196, jdi, None, True, 2, 2)
     case.surface_reflect(0.1)
     out = case.spectrum(opa, calculation="reflected+thermal", full_output=True)
-    key = "linear/de1_s2_r2_tmnone"
+    key = qm + "/de1_s2_r2_tmnone"          # get_opacities (linear) / get_opacities_nearest (optics.py:2310-2368)
     P = {nm: g196["%s/%s" % (key, nm)] for nm in NAMES}
     nlevel, nwno = P["tau"].shape
     assert (nlevel, nwno) == (61, 196)

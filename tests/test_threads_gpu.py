@@ -1,7 +1,7 @@
 """spectrum() from several Python threads on ONE opacity object returns the serial answers.  A spectrum is dozens of C
 calls sharing the context's stream, arena and pool and the opacity object's workspaces; ctypes releases the GIL during
 each, so unguarded threads interleave them -- measured before the guard: wrong spectra and "block still has uncollected
-results" (tools/scratch/threads_probe.py).  The public entry points run under one re-entrant lock (picaso_amd/_lib.py:
+results".  The public entry points run under one re-entrant lock (picaso_amd/_lib.py:
 CALL_LOCK); the reference itself fans out with processes (justdoit.py:4774)."""
 import threading
 

@@ -17,7 +17,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from picaso_amd import _lib, device, disco, resident  # noqa: E402
 from picaso_amd import synthetic as syn  # noqa: E402
