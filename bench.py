@@ -728,6 +728,24 @@ def product_companion(ctx, nwno=100000, nlevel=91, ncalls=30, nbatch=32):
     rl = [c.spectrum(opa, calculation=calc) for c in cases[:4]]
     same = all(np.array_equal(a[k], b[k]) for a, b in zip(rb[:4], rl) for k in a if isinstance(a[k], np.ndarray))
 
+    def pipelined():                   # a retrieval's loop: ask for sample i + 1, then read sample i (spectrum_async)
+        prev, outs_ = None, []
+        for c in cases:
+            h = c.spectrum_async(opa, calculation=calc)
+            if prev is not None:
+                outs_.append(prev.result())
+            prev = h
+        outs_.append(prev.result())
+        return outs_
+    for _ in range(2):
+        ra = pipelined()
+    ta = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        ra = pipelined()
+        ta.append(time.perf_counter() - t0)
+    same_async = all(np.array_equal(a[k], b[k]) for a, b in zip(ra[:4], rl) for k in a if isinstance(a[k], np.ndarray))
+
     def timed(c, n=12):
         for _ in range(4):
             c.spectrum(opa, calculation=calc)
@@ -934,6 +952,8 @@ def product_companion(ctx, nwno=100000, nlevel=91, ncalls=30, nbatch=32):
         "spectrum_ms_after_300ms_idle": 1e3 * float(np.median(idle)),
         "spectrum_batch_ms_per_spectrum": 1e3 * min(tb) / nbatch, "batch_of": nbatch,
         "spectrum_batch_equals_single_calls": bool(same),
+        "spectrum_async_pipelined_ms_per_spectrum": 1e3 * min(ta) / nbatch,
+        "spectrum_async_equals_single_calls": bool(same_async),
         "sh4_spectrum_ms": sh4.get("sh4_spectrum_ms"),
         "sh4_box_cloud_below_layer_50_spectrum_ms": sh4.get("sh4_box_cloud_below_layer_50_spectrum_ms"),
         **({"sh4_error": sh4["error"]} if "error" in sh4 else {}),

@@ -1050,6 +1050,24 @@ class inputs:
                       full_output=full_output, plot_opacity=plot_opacity, as_dict=as_dict, devices=devices,
                       gather=gather, options=options)
 
+    def spectrum_async(self, opacityclass, calculation="reflected", dimension="1d", full_output=False, as_dict=True,
+                       options=None):
+        """``spectrum()`` without the wait: set-up and every launch of this spectrum are enqueued (result copies
+        included) and a ``PendingSpectrum`` comes back at once; its ``result()`` is ``spectrum()``'s dictionary, bit for
+        bit.  A retrieval that asks for sample i + 1 before it reads sample i hides the host set-up of one call behind the
+        GPU time of the other (``picaso_async``).  No counterpart in the reference, whose callers fan out whole processes
+        (justdoit.py:4741-4777)."""
+        if dimension not in ("1d", "3d"):
+            raise Exception("dimension must be '1d' or '3d'")
+        have = self.inputs["atmosphere"].get("profile" if dimension == "1d" else "profile_3d")
+        if have is None:
+            raise Exception("Need to set atmosphere profile with the atmosphere%s() function"
+                            % ("" if dimension == "1d" else "_3d"))
+        if self.inputs["planet"]["gravity"] is None:
+            raise Exception("Need to set gravity with the gravity() function")
+        return picaso_async(self, opacityclass, dimension=dimension, calculation=calculation, full_output=full_output,
+                            as_dict=as_dict, options=options)
+
 
 @_lib.serialized
 def picaso(bundle, opacityclass, dimension="1d", calculation="reflected", full_output=False,
@@ -1094,6 +1112,89 @@ def _picaso_driver(bundle, opa, subs, calculation, opt=None, dimension="1d"):
     covers."""
     from . import onecall
     return onecall.run(bundle, opa, subs, calculation, _options.current(opt), dimension)
+
+
+# ------------------------------------------------------------------------------------------------
+# a spectrum whose result is read later: the host side of call i + 1 runs while the GPU works on call i
+# ------------------------------------------------------------------------------------------------
+ASYNC_DEPTH = 4        # spectra of one opacity object in flight through the C driver (a block table -- planes, pinned result
+#                        blocks -- per slot; a fifth call first finishes the oldest)
+
+
+class PendingSpectrum:
+    """Handle of ``picaso_async`` / ``inputs.spectrum_async``: ``result()`` (or calling it) waits for this spectrum's result
+    copies, forms the output dictionary -- ``spectrum()``'s, bit for bit -- and returns it (the same object every time)."""
+
+    def __init__(self, finish, abandon=None):
+        self._finish, self._abandon, self._out, self._err = finish, abandon, None, None
+
+    def done(self):
+        return self._finish is None
+
+    @_lib.serialized
+    def result(self):
+        if self._finish is not None:
+            fin, self._finish = self._finish, None
+            try:
+                self._out = fin()
+            except BaseException as exc:         # the launches are on the stream: drop their result copies, keep the error
+                self._err = exc
+                if self._abandon is not None:
+                    self._abandon()
+            self._abandon = None
+        if self._err is not None:
+            raise self._err
+        return self._out
+
+    __call__ = result
+
+
+@_lib.serialized
+def picaso_async(bundle, opacityclass, dimension="1d", calculation="reflected", full_output=False, as_dict=True,
+                 options=None):
+    """``picaso()`` up to and including the last launch; returns a ``PendingSpectrum``.
+
+    What the C driver covers (``onecall.prepare``: the plain 1-D Toon / SH and 3-D spectra) is enqueued through it on one of
+    ``ASYNC_DEPTH`` block tables of the opacity object -- each with its own planes and pinned result blocks, so the spectra
+    in flight do not touch each other's memory; the streams order them.  Everything else (k-tables mixed on the fly,
+    patchy clouds, level fluxes, ``full_output`` ...) is ``picaso(defer=True)`` with its result copies already on the
+    stream.  Either way the dictionary is the one ``picaso()`` returns for the same inputs.  The case must not be given a
+    new star before ``result()`` (the flux ratios are formed there); atmosphere, clouds and geometry may change at once."""
+    from . import onecall
+    from . import driver as drv
+    opt = _options.current(options)
+    legs = any(leg in calculation for leg in ("reflected", "thermal", "transmission"))
+    if not full_output and not legs:
+        out = {"wavenumber": opacityclass.wno}
+        return PendingSpectrum(lambda: out)
+    if not full_output:
+        st = opacityclass.__dict__.setdefault("_async_slots", {"n": 0, "live": {}})
+        slot = st["n"] % ASYNC_DEPTH
+        old = st["live"].pop(slot, None)
+        if old is not None and not old.done():
+            try:
+                old.result()                      # the slot's planes and pinned blocks are about to be reused
+            except BaseException:
+                pass                              # its owner gets the error from result()
+        subs = [(0, opacityclass.nwno, opacityclass)]
+        p = (onecall.prepare_3d if dimension == "3d" else onecall.prepare)(bundle, opacityclass, subs, calculation, opt,
+                                                                          slot=slot)
+        if p is not None:
+            p["inp"] = dict(p["inp"], star=dict(p["inp"]["star"]))      # what finish() reads of the case, as it is now
+            try:
+                drv.enqueue(p["table"], p["job"])
+            except BaseException:
+                drv.abandon(p["table"])
+                raise
+            h = PendingSpectrum(lambda: onecall.finish(p), lambda: drv.abandon(p["table"]))
+            st["live"][slot] = h
+            st["n"] += 1
+            return h
+    s = picaso(bundle, opacityclass, dimension=dimension, calculation=calculation, full_output=full_output, as_dict=as_dict,
+               defer=True, options=opt)
+    if not opt.sync_copies:
+        s.prefetch()
+    return PendingSpectrum(s)
 
 
 # ------------------------------------------------------------------------------------------------
