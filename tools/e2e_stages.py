@@ -38,6 +38,10 @@ wrap(jdi, "picaso")
 wrap(jdi, "_opacity_shards")
 from picaso_amd import onecall
 wrap(onecall, "finish")
+wrap(onecall, "prepare")
+for _n in ("_setup_atmosphere", "_call_state", "_cloud_inputs", "_fill_block", "_post_reflected", "_post_thermal",
+           "_post_final", "_plane_set", "_prepared", "_in_scope"):
+    wrap(onecall, _n, "onecall." + _n)
 devs = [int(x) for x in os.environ["DEVICES"].split(",")] if os.environ.get("DEVICES") else None
 
 # the scene of tools/e2e_1d_time.py
