@@ -880,6 +880,12 @@ typedef struct picaso_spectrum_job {
     const double *gauss_wts;
 } picaso_spectrum_job;
 int picaso_toon_spectrum_blocks(int nblocks, picaso_block *blocks, const picaso_spectrum_job *job);
+/* picaso_toon_spectrum_blocks in two calls (1-D blocks, enqueued one after the other): phase = 1 the opacity stage alone --
+ * it reads nlayer, ngauss, the mol_ / cont_ / ray_ fields, raman_rows / raman_const, test_mode, delta_eddington, stream,
+ * do_thermal and nfacets (= 0) of the job and ctx / tctx, the tables, planes, cloud inputs and raman of the blocks, nothing
+ * else -- phase = 2 the legs, integrals and result copies.  The caller fills the other half of job and blocks in between,
+ * while the gas kernel runs.  Same launches, same order, same streams as the one call: same bits. */
+int picaso_toon_spectrum_phase(int nblocks, picaso_block *blocks, const picaso_spectrum_job *job, int phase);
 /* copy one leg's results (which = 1: albedo, 2: thermal flux) of every block into albedo_host / thermal_host */
 int picaso_toon_spectrum_collect(int nblocks, picaso_block *blocks, int which);
 /* wait for and drop result copies that will not be collected (the caller failed in between) */

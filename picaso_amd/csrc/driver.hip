@@ -174,9 +174,14 @@ static int enqueue_block_3d(int nblocks, picaso_block *blocks, const picaso_spec
 }
 
 // one block: opacity stage -> reflected || thermal (+ integrals, result copies) on the block's own context(s)
-static int enqueue_block(int nblocks, picaso_block *blocks, const picaso_spectrum_job &j, int b)
+// phase 0: the whole block.  1: the opacity stage alone (picaso_toon_spectrum_phase: the caller has filled the opacity half
+// of the job and of the block and fills the rest while the gas kernel runs).  2: everything behind the opacity stage.
+static int enqueue_block(int nblocks, picaso_block *blocks, const picaso_spectrum_job &j, int b, int phase = 0)
 {
-    if (j.nfacets > 0) return enqueue_block_3d(nblocks, blocks, j, b);
+    if (j.nfacets > 0) {
+        if (phase) return fail(blocks[b].ctx, "toon_spectrum_phase: 3-D blocks are enqueued in one piece");
+        return enqueue_block_3d(nblocks, blocks, j, b);
+    }
     const int nlevel = j.nlayer + 1;
     {
         picaso_block &k = blocks[b];
@@ -184,7 +189,8 @@ static int enqueue_block(int nblocks, picaso_block *blocks, const picaso_spectru
         if (k.albedo_mark || k.thermal_mark)
             return fail(k.ctx, "toon_spectrum_blocks: block %d still has uncollected results", b);
         picaso_ctx *tctx = k.tctx ? k.tctx : k.ctx;
-        PZ_TRY(opacity_stage(k, j, b, (tctx != k.ctx && j.do_thermal) ? tctx : nullptr));
+        if (phase != 2) PZ_TRY(opacity_stage(k, j, b, (tctx != k.ctx && j.do_thermal) ? tctx : nullptr));
+        if (phase == 1) return 0;
         if (j.rt_method == 1 && j.ngauss > 1)
             return fail(k.ctx, "toon_spectrum_blocks: correlated-k blocks are Toon only");
         if (j.do_reflected && j.rt_method == 1) {
@@ -290,6 +296,27 @@ extern "C" int picaso_toon_spectrum_blocks(int nblocks, picaso_block *blocks, co
         if (rc[(size_t)b]) {
             fail(blocks[0].ctx, "%s", msgs[(size_t)b].c_str());
             return rc[(size_t)b];
+        }
+    return 0;
+}
+
+// The same sequence in two calls (1-D blocks): phase 1 enqueues the opacity stage of every block and returns -- it reads
+// the opacity half of the job (table rows / weights / coefficients, Raman, delta-Eddington, stream, do_thermal) and of the
+// blocks (tables, planes, cloud inputs, raman, ctx / tctx) and nothing else -- phase 2 the legs, integrals and result copies.
+// What the caller has to prepare for the legs (geometry, level tables, resident vectors, result buffers) is prepared
+// while the gas kernel runs instead of in front of it; same launches in the same order on the same streams, same bits.
+extern "C" int picaso_toon_spectrum_phase(int nblocks, picaso_block *blocks, const picaso_spectrum_job *job, int phase)
+{
+    if (nblocks < 1 || !blocks || !job) return fail(nullptr, "toon_spectrum_phase: null argument");
+    if (phase != 1 && phase != 2) return fail(blocks[0].ctx, "toon_spectrum_phase: phase must be 1 or 2, got %d", phase);
+    const picaso_spectrum_job &j = *job;
+    if (j.nlayer < 1 || (phase == 2 && (j.numg < 1 || j.numt < 1))) return fail(blocks[0].ctx, "toon_spectrum_phase: bad sizes");
+    for (int b = 0; b < nblocks; ++b)
+        if (int rc = enqueue_block(nblocks, blocks, j, b, phase)) {
+            char msg[sizeof(g_err)];
+            snprintf(msg, sizeof(msg), "%s", g_err);
+            fail(blocks[0].ctx, "%s", msg);
+            return rc;
         }
     return 0;
 }

@@ -186,18 +186,20 @@ class BlockTable:
 def make_job(nlayer, plan, factors, linear, raman_rows, stream, delta_eddington, do_reflected, do_thermal, ng, nt, ubar0,
              ubar1, cos_theta, gweight, tweight, single_phase, multi_phase, toon_coefficients, frac_a, frac_b, frac_c,
              constant_back, constant_forward, b_top, tlevel, plevel, hard_surface, sh=None, sh_top=0, nfacets=0,
-             gauss_wts=None):
+             gauss_wts=None, after_opacity=None):
     """The per-call half: (Job, the numpy arrays it points into).  ``plan`` = ``opa._plan`` (table rows and weights per
-    molecule and layer, CIA rows), ``factors`` = ``optics._layer_factors`` (per-layer coefficients of the sums)."""
+    molecule and layer, CIA rows), ``factors`` = ``optics._layer_factors`` (per-layer coefficients of the sums).
+    ``after_opacity``: called with the Job as soon as the fields the opacity stage reads are set (``enqueue(..., phase=1)``
+    from there puts the gas kernel on the stream while the other half of the job is still being filled)."""
     mol_fac, cont_fac, ray_names, ray_fac = factors
     nmol, ncont = len(plan["molecules"]), len(plan["cia_pairs"])
     premixed = bool(plan.get("premixed"))         # k-tables: cia_rows / cia_wts (nlayer, 2), the bracketing temperatures
+    # ---- the opacity stage's half ----
     keep = dict(
         rows=np.ascontiguousarray(plan["rows"], dtype=np.int32), wts=_lib.f64(plan["wts"]), mol_fac=_lib.f64(mol_fac),
         cont_rows=np.ascontiguousarray(np.repeat(plan["cia_rows"][None], max(ncont, 1), axis=0), dtype=np.int32),
         cont_wts=_lib.f64(np.repeat(plan["cia_wts"][None], max(ncont, 1), axis=0)) if premixed else None,
-        cont_fac=_lib.f64(cont_fac), ray_fac=_lib.f64(ray_fac), u0=_lib.f64(ubar0, (ng, nt)), u1=_lib.f64(ubar1, (ng, nt)),
-        gw=_lib.f64(gweight), tw=_lib.f64(tweight), tl=_lib.f64(tlevel), pl=_lib.f64(plevel))
+        cont_fac=_lib.f64(cont_fac), ray_fac=_lib.f64(ray_fac))
     j = Job()
     j.nlayer, j.mol_mode, j.nmol, j.cont_interp, j.ncont, j.nray = (nlayer, (2 if premixed else (1 if linear else 0)), nmol,
                                                                     (1 if premixed else 0), ncont, len(ray_names))
@@ -209,17 +211,22 @@ def make_job(nlayer, plan, factors, linear, raman_rows, stream, delta_eddington,
     j.raman_rows, j.raman_const = raman_rows, 0.99999
     j.test_mode, j.delta_eddington, j.stream = 0, (1 if delta_eddington else 0), stream
     j.do_reflected, j.do_thermal, j.numg, j.numt = int(do_reflected), int(do_thermal), ng, nt
+    j.rt_method, j.nfacets = 0, int(nfacets)    # nfacets > 0: plan / factors of the tall atmosphere, tlevel / plevel (nfacets, nlevel)
+    j.ngauss, j.gauss_wts = 1, None
+    if gauss_wts is not None and len(gauss_wts) > 1:      # premixed k-tables: the Gauss-point loop inside the solver calls
+        keep["gauss_wts"] = _lib.f64(gauss_wts)
+        j.ngauss, j.gauss_wts = int(len(gauss_wts)), _host(keep["gauss_wts"])
+    if after_opacity is not None:
+        after_opacity(j)
+    # ---- the legs' half ----
+    keep.update(u0=_lib.f64(ubar0, (ng, nt)), u1=_lib.f64(ubar1, (ng, nt)), gw=_lib.f64(gweight), tw=_lib.f64(tweight),
+                tl=_lib.f64(tlevel), pl=_lib.f64(plevel))
     j.ubar0, j.ubar1, j.cos_theta = _host(keep["u0"]), _host(keep["u1"]), float(cos_theta)
     j.gweight, j.tweight = _host(keep["gw"]), _host(keep["tw"])
     j.single_phase, j.multi_phase, j.toon_coefficients = int(single_phase), int(multi_phase), int(toon_coefficients)
     j.frac_a, j.frac_b, j.frac_c = float(frac_a), float(frac_b), float(frac_c)
     j.constant_back, j.constant_forward, j.b_top = float(constant_back), float(constant_forward), float(b_top)
     j.tlevel, j.plevel, j.hard_surface = _host(keep["tl"]), _host(keep["pl"]), int(hard_surface)
-    j.rt_method, j.nfacets = 0, int(nfacets)    # nfacets > 0: plan / factors of the tall atmosphere, tlevel / plevel (nfacets, nlevel)
-    j.ngauss, j.gauss_wts = 1, None
-    if gauss_wts is not None and len(gauss_wts) > 1:      # premixed k-tables: the Gauss-point loop inside the solver calls
-        keep["gauss_wts"] = _lib.f64(gauss_wts)
-        j.ngauss, j.gauss_wts = int(len(gauss_wts)), _host(keep["gauss_wts"])
     if sh is not None:                     # inputs["approx"]["rt_params"]["SH"]: the spherical-harmonics solvers
         j.rt_method = 1
         j.sh_w_single_form, j.sh_w_multi_form, j.sh_psingle_form = (int(sh[k]) for k in ("w_single_form", "w_multi_form", "psingle_form"))
@@ -229,9 +236,14 @@ def make_job(nlayer, plan, factors, linear, raman_rows, stream, delta_eddington,
     return j, keep
 
 
-def enqueue(table, job):
-    _lib.check(_lib.load().picaso_toon_spectrum_blocks(ctypes.c_int(table.n), table.blocks, ctypes.byref(job)),
-               table.subs[0][2].ctx)
+def enqueue(table, job, phase=0):
+    """``phase`` 0: the whole spectrum in one call; 1: the opacity stage alone, 2: everything behind it
+    (``picaso_toon_spectrum_phase``, 1-D blocks: what ``make_job(after_opacity=...)`` is for)."""
+    if phase:
+        rc = _lib.load().picaso_toon_spectrum_phase(ctypes.c_int(table.n), table.blocks, ctypes.byref(job), ctypes.c_int(phase))
+    else:
+        rc = _lib.load().picaso_toon_spectrum_blocks(ctypes.c_int(table.n), table.blocks, ctypes.byref(job))
+    _lib.check(rc, table.subs[0][2].ctx)
 
 
 def collect(table, which):

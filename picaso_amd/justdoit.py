@@ -1177,12 +1177,12 @@ def picaso_async(bundle, opacityclass, dimension="1d", calculation="reflected", 
             except BaseException:
                 pass                              # its owner gets the error from result()
         subs = [(0, opacityclass.nwno, opacityclass)]
-        p = (onecall.prepare_3d if dimension == "3d" else onecall.prepare)(bundle, opacityclass, subs, calculation, opt,
-                                                                          slot=slot)
+        p = onecall.prepare_3d(bundle, opacityclass, subs, calculation, opt, slot=slot) if dimension == "3d" else \
+            onecall.prepare(bundle, opacityclass, subs, calculation, opt, slot=slot, early=True)
         if p is not None:
             p["inp"] = dict(p["inp"], star=dict(p["inp"]["star"]))      # what finish() reads of the case, as it is now
             try:
-                drv.enqueue(p["table"], p["job"])
+                drv.enqueue(p["table"], p["job"], p.get("phase", 0))
             except BaseException:
                 drv.abandon(p["table"])
                 raise

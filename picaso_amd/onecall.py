@@ -24,11 +24,12 @@ from .spectrum import (_bond_denominator, _constant_planes, _ones, _post_final, 
 
 def run(bundle, opa, subs, calculation, opt, dimension="1d"):
     """``prepare`` + the C call + ``finish``; None when the call is outside what the driver covers."""
-    p = (prepare_3d if dimension == "3d" else prepare)(bundle, opa, subs, calculation, opt)
+    p = prepare_3d(bundle, opa, subs, calculation, opt) if dimension == "3d" else \
+        prepare(bundle, opa, subs, calculation, opt, early=True)
     if p is None:
         return None
     try:
-        drv.enqueue(p["table"], p["job"])
+        drv.enqueue(p["table"], p["job"], p.get("phase", 0))
         return finish(p)
     except BaseException:
         drv.abandon(p["table"])
@@ -165,15 +166,16 @@ def _prepared(c, job, keep, signature):
 
 
 def _fill_block(k, sub, lo, hi, c):
-    """The per-call pointers of one wavelength block ``k`` (a ``driver.Block``): resident per-wavelength vectors, the
-    Raman factor, the cloud inputs, the thermal workspace on the block's second stream, where the results go."""
+    """The per-call pointers of one wavelength block ``k`` (a ``driver.Block``): what the opacity stage reads
+    (``_fill_block_opacity``), then what the legs read (``_fill_block_legs``)."""
+    _fill_block_opacity(k, sub, lo, hi, c)
+    _fill_block_legs(k, sub, lo, hi, c)
+
+
+def _fill_block_opacity(k, sub, lo, hi, c):
+    """The opacity stage's half: the Raman factor, the cloud inputs, and the context of the thermal leg (the stage orders
+    that stream behind its gas launch)."""
     nw, nwno, hold, atm = hi - lo, c["nwno"], c["hold"], c["atm"]
-    sr = atm.surf_reflect
-    sr_full = np.ndim(sr) > 0 and np.size(sr) == nwno and nwno > 1
-    rs = _resident_vector(sub, "surf_reflect", np.asarray(sr, dtype=float).reshape(nwno)[lo:hi] if sr_full else sr, nw)
-    f0 = _resident_vector(sub, "F0PI", 1.0 if c["nostar"] else (c["F0PI"] if c["nblocks"] == 1 else c["F0PI"][lo:hi]), nw)
-    k.surf_reflect, k.F0PI = drv._dev(rs), drv._dev(f0)
-    hold.append((rs, f0))            # the block holds raw addresses: the vectors live as long as the call is in flight
     if c["raman"] == 1:
         row, _ = optics.raman_device(atm, sub, 1)
         k.raman = drv._dev(row)
@@ -211,6 +213,21 @@ def _fill_block(k, sub, lo, hi, c):
             tctx = _lib.aux_context(dev, seen.get(dev, 0))       # blocks that share a device: a stream each
             seen[dev] = seen.get(dev, 0) + 1
         k.tctx = tctx.value if hasattr(tctx, "value") else tctx
+        c.setdefault("tctx", {})[c["b"]] = tctx
+
+
+def _fill_block_legs(k, sub, lo, hi, c):
+    """The legs' half: resident per-wavelength vectors, the thermal workspace on the block's second stream, where the
+    results go, the spectrum-wide integrals."""
+    nw, nwno, hold, atm = hi - lo, c["nwno"], c["hold"], c["atm"]
+    sr = atm.surf_reflect
+    sr_full = np.ndim(sr) > 0 and np.size(sr) == nwno and nwno > 1
+    rs = _resident_vector(sub, "surf_reflect", np.asarray(sr, dtype=float).reshape(nwno)[lo:hi] if sr_full else sr, nw)
+    f0 = _resident_vector(sub, "F0PI", 1.0 if c["nostar"] else (c["F0PI"] if c["nblocks"] == 1 else c["F0PI"][lo:hi]), nw)
+    k.surf_reflect, k.F0PI = drv._dev(rs), drv._dev(f0)
+    hold.append((rs, f0))            # the block holds raw addresses: the vectors live as long as the call is in flight
+    if c["do_t"]:
+        tctx = c["tctx"][c["b"]]
         fl, dk, pin = c["table"].thermal_workspace(c["b"], tctx, c["ng"], c["nt"])
         k.flux, k.disk = drv._dev(fl), drv._dev(dk)
         k.thermal_pin = ctypes.cast(ctypes.c_void_p(pin.addr), drv._dp)
@@ -232,9 +249,12 @@ def _fill_block(k, sub, lo, hi, c):
             k.trapz_dr = drv._dev(d_wr)
 
 
-def prepare(bundle, opa, subs, calculation, opt, slot=None):
+def prepare(bundle, opa, subs, calculation, opt, slot=None, early=False):
     """Everything up to the C call: set-up, block table (``slot``: which of several tables of the same signature, for
-    spectra that are in flight together), per-call pointers, job.  None: outside the driver's scope."""
+    spectra that are in flight together), per-call pointers, job.  None: outside the driver's scope.  ``early=True`` (what
+    ``run`` and ``picaso_async`` pass): the opacity stage is ALREADY on the stream when this returns and the returned
+    dictionary says ``phase = 2`` -- the caller owes ``drv.enqueue(table, job, phase=2)``; with the default it says 0
+    and nothing has been enqueued."""
     inp = bundle.inputs
     legs = set(calculation.split("+"))
     if not _in_scope(inp, opa, legs, len(subs), opt):
@@ -295,17 +315,28 @@ def prepare(bundle, opa, subs, calculation, opt, slot=None):
                                             sh=is_sh, ngauss=opa.ngauss)
     c = _call_state(inp, opa, subs, opt, atm, raman, do_r, do_t, table, ng, nt)
     c["clouds"] = _cloud_inputs(atm, opa, tables, nlayer, nwno, opt, c["hold"])
+    # The opacity stage first (round 6): as soon as the table rows / weights / coefficients are in the job and the cloud
+    # inputs in the blocks, the gas kernel goes on the stream (drv.enqueue(phase=1)); geometry, level tables, resident
+    # vectors, result buffers -- what the legs read -- are filled while it runs, and ``run`` enqueues the legs (phase 2).
+    # The same launches in the same order: same bits (PICASO_AMD_ONE_PHASE=1 / Options(one_phase=True): one call, as before).
+    early = early and len(subs) == 1 and not opt.one_phase      # several blocks: the one call enqueues them from a thread each
     for b, (lo, hi, sub) in enumerate(subs):
         c["b"] = b
-        _fill_block(table.blocks[b], sub, lo, hi, c)
+        _fill_block_opacity(table.blocks[b], sub, lo, hi, c)
     job, keep = drv.make_job(nlayer, plan, factors, linear, 0 if raman == 1 else nlayer, common["stream"],
                              common["delta_eddington"], do_r, do_t, ng, nt, geom["ubar0"], geom["ubar1"], geom["cos_theta"],
                              geom["gweight"], geom["tweight"], toon["single_phase"], toon["multi_phase"],
                              toon["toon_coefficients"], frac_a, frac_b, frac_c, common["TTHG_params"]["constant_back"],
                              common["TTHG_params"]["constant_forward"], 0.0, atm.level["temperature"], atm.level["pressure"],
                              atm.hard_surface, sh=inp["approx"]["rt_params"]["SH"] if is_sh else None, sh_top=sh_top,
-                             gauss_wts=opa.gauss_wts if ck else None)
-    return _prepared(c, job, keep, key[1:-1])
+                             gauss_wts=opa.gauss_wts if ck else None,
+                             after_opacity=(lambda j: drv.enqueue(table, j, phase=1)) if early else None)
+    for b, (lo, hi, sub) in enumerate(subs):
+        c["b"] = b
+        _fill_block_legs(table.blocks[b], sub, lo, hi, c)
+    p = _prepared(c, job, keep, key[1:-1])
+    p["phase"] = 2 if early else 0
+    return p
 
 
 def _in_scope_3d(inp, opa, legs, opt):

@@ -30,6 +30,7 @@ _ENV = {
     "sync_copies":        "PICASO_AMD_SYNC_COPIES",        # result copies synchronously after the launches
     "no_post_stream":     "PICASO_AMD_NO_POST_STREAM",     # spectrum_batch: integrals on the solver stream
     "py_setup":           "PICASO_AMD_PY_SETUP",           # ATMSETUP through the Python mirror, not picaso_host_setup
+    "one_phase":          "PICASO_AMD_ONE_PHASE",          # the C driver in ONE call (opacity stage not enqueued ahead of the legs' set-up)
 }
 
 
@@ -47,6 +48,7 @@ class Options:
     sync_copies: bool = False
     no_post_stream: bool = False
     py_setup: bool = False
+    one_phase: bool = False
     phases_in_flight: int = 16           # PICASO_AMD_PHASES_IN_FLIGHT: phase_curve() phases enqueued before the first is read
     phase_chunk: int = 0                 # PICASO_AMD_PHASE_CHUNK: phases per batched launch (0: from the HBM budget)
     overlap_legs: bool = True            # PICASO_AMD_OVERLAP_LEGS=0: thermal leg behind the reflected one, same stream

@@ -110,3 +110,16 @@ def test_async_handle_that_is_dropped_and_errors_that_are_kept():
         bad.spectrum_async(opa)
     assert _same(c0.spectrum_async(opa, **kw0).result(), want)
     assert jdi.inputs.spectrum_async.__doc__ and jdi.picaso_async.__doc__
+
+
+@pytest.mark.gpu
+def test_opacity_stage_enqueued_ahead_equals_the_one_call():
+    """spectrum() enqueues the opacity stage before it fills the legs' half of the job (picaso_toon_spectrum_phase 1, then 2);
+    Options(one_phase=True) is the single C call of rounds 4-5: every case, every key, bit for bit -- and the async path too."""
+    jdi, opa, cases = _setup()
+    one = jdi.Options(one_phase=True)
+    for k, (c, kw) in enumerate(cases):
+        a = c.spectrum(opa, **kw)
+        b = c.spectrum(opa, options=one, **kw)
+        assert _same(a, b), k
+        assert _same(c.spectrum_async(opa, options=one, **kw).result(), a), k
