@@ -46,7 +46,7 @@ _GPU_ORDER = [
     "test_cloud_regrid", "test_ck_readers",
     # class 2
     "test_refl_coop_gpu", "test_lean_planes_gpu", "test_integrals_gpu", "test_batch_gpu", "test_batch_hetero_gpu",
-    "test_driver_gpu", "test_async_gpu", "test_devices_gpu", "test_comm_gpu",
+    "test_driver_gpu", "test_async_gpu", "test_paths_matrix_gpu", "test_devices_gpu", "test_comm_gpu",
     # class 3
     "test_content_caches", "test_abi_abuse_gpu", "test_threads_gpu", "test_processes_gpu", "test_leak_gpu",
 ]
