@@ -1,5 +1,5 @@
 """A retrieval-shaped loop leaves nothing to Python's cycle collector: every device array of a finished spectrum() /
-spectrum_batch() / 3-D call goes when the caller lets go of the result (tools/leak_check.py: thirteen kinds of calls, every
+spectrum_batch() / 3-D call goes when the caller lets go of the result (tools/leak_check.py: fourteen kinds of calls, every
 call with new inputs).  Before round 5's fix a finished ``spectrum.Spectrum`` sat in a reference cycle with its own
 collectors, and hundreds of dead planes piled up between two collections (GBs at 1e5 wavelengths)."""
 import os

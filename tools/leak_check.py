@@ -77,7 +77,7 @@ def main(argv=None):
     opk = px.RetrieveCKs(wck, gwts, np.tile(pk, tk.size), np.repeat(tk, pk.size), np.full(tk.size, pk.size), lnk,
                          continuum=cont, cia_temps=cia_t, rayleigh_opa={m: 1e-27 * (wck / 1e4) ** 4 for m in ("H2", "He")},
                          gauss_pts=gpts, ctx=ctx)
-    NKIND = 13
+    NKIND = 14
     kinds = {}
 
     def one(i):
@@ -101,6 +101,18 @@ def main(argv=None):
             rb = jdi.spectrum_batch(cases, opa, calculation="reflected+thermal", batch_size=3)
             kinds[kind] = kinds.get(kind, 0) + 1
             return all(np.all(np.isfinite(r["albedo"])) and np.all(np.isfinite(r["thermal"])) for r in rb)
+        if kind == 13:               # spectrum_async: three spectra in flight (the third is never read: its slot is finished on reuse)
+            hs = []
+            for _ in range(3):
+                c = jdi.inputs()
+                c.phase_angle(0)
+                c.gravity(gravity=2500.0)
+                c.atmosphere(df=dict(prof, temperature=prof["temperature"] * (1.0 + 0.05 * rng.random())))
+                c.approx(raman="none")
+                hs.append(c.spectrum_async(opa, calculation="reflected+thermal"))
+            ra = [h.result() for h in hs[:2]]
+            kinds[kind] = kinds.get(kind, 0) + 1
+            return all(np.all(np.isfinite(r["albedo"])) and np.all(np.isfinite(r["thermal"])) for r in ra)
         if kind in (9, 10):          # k-tables: Toon and SH4 inside the Gauss loop; 11: an 8-phase... a 2-phase thermal curve
             c = jdi.inputs()
             c.phase_angle(0)
