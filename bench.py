@@ -1106,6 +1106,7 @@ def main():
         for _ in range(20):
             step()
         nprewarm += 20
+    clocks_before = gpu_clocks(local_rank) if not comm else None      # behind the ramp, in front of the W warm-up steps
     for _ in range(args.warmup):
         step()
     barrier()
@@ -1135,7 +1136,8 @@ def main():
             blocks.append(device.timer_stop(ctx) / args.steps)
         repeats = {"n": len(blocks), "steps_per_block": args.steps, "median_ms": float(np.median(blocks)),
                    "min_ms": float(min(blocks)), "max_ms": float(max(blocks)), "ms": [round(b, 5) for b in blocks],
-                   "timed_block_ms": stream_ms, "clocks_under_load": clk, "clocks_idle_after": None,
+                   "timed_block_ms": stream_ms, "clocks_before_timed_block": clocks_before, "clocks_under_load": clk,
+                   "clocks_idle_after": None,
                    "what": "HIP-event time per step of further %d-step blocks after the timed one (untimed by the driver)"
                            % args.steps}
         device.sync(ctx)
